@@ -1,0 +1,243 @@
+"""Host-side callers of the hot path, restated for SAM-level inputs.
+
+* `tile_region`     -- window tiler, follows loadRefs (reference src/Lancet.cc:189-316):
+                       padding, clipping, 600 bp windows with stride 100, last window LEN = len-offset-1,
+                       uppercase + IUPAC->N, windows keyed/ordered by the "chr:start-end" string
+                       (std::map order, src/Microassembler.hh:148 / src/Microassembler.cc:779).
+* `extract_reads`   -- per-window read selection, follows Microassembler::extractReads
+                       (reference src/Microassembler.cc:436-655) on already-decoded SAM fields.
+* `build_batch`     -- packs the selected reads of many windows into the SoA `WindowBatch` that crosses the
+                       C-ABI (include/lancet_engine.h : lancet_window_batch).
+
+BAM/BGZF decoding itself is out of scope for this round; inputs here are `SamRead` records.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .synth import SamRead, cigar_ref_len
+
+TMR = 4   # reference src/Ref.hh:36
+NML = 5   # reference src/Ref.hh:37
+FWD = 1   # reference src/ReadInfo.hh:30
+REV = 2
+
+_AMBIG = set("MRWSYKVHDBXmrwsykvhdbx")  # reference src/util.cc:167-187 isAmbiguos
+
+
+@dataclasses.dataclass
+class Window:
+    hdr: str
+    chrom: str
+    start: int      # Ref_t::refstart (1-based)
+    end: int        # Ref_t::refend = start + LEN
+    seq: str
+
+
+def tile_region(contig_seq: str, chrom: str, region: str, contig_len: Optional[int] = None,
+                padding: int = 250, window_size: int = 600, delta: int = 100) -> List[Window]:
+    """reference src/Lancet.cc:189-316 (loadRefs).  `contig_seq` is the full contig (1-based coords)."""
+    contig_len = len(contig_seq) if contig_len is None else contig_len
+    x = region.find(":")
+    if x < 0:
+        sp, ep = 1, contig_len
+    else:
+        y = region.find("-", x)
+        sp = int(region[x + 1:y]) - padding
+        ep = int(region[y + 1:]) + padding
+        if sp < 1:
+            sp = 1
+        if ep > contig_len:
+            ep = contig_len
+    s = contig_seq[sp - 1:ep].upper()
+    s = "".join("N" if c in _AMBIG else c for c in s)
+    out: List[Window] = []
+    end = len(s)
+    offset = 0
+    while offset < end:
+        ln = window_size
+        if offset + window_size >= len(s):
+            ln = len(s) - offset - 1
+            end = offset
+        ss = s[offset:offset + ln] if ln > 0 else ""
+        start = sp + offset
+        out.append(Window(f"{chrom}:{start}-{start + ln}", chrom, start, start + ln, ss))
+        offset += delta
+    return out
+
+
+def windows_in_processing_order(windows: Sequence[Window]) -> List[Window]:
+    """std::map<string, Ref_t*> iteration order (reference src/Microassembler.cc:779)."""
+    return sorted(windows, key=lambda w: w.hdr.encode())
+
+
+@dataclasses.dataclass
+class ReadFilterParams:
+    min_map_qual: int = 15          # reference src/Lancet.hh:49
+    max_delta_as_xs: int = 5        # reference src/Lancet.hh:50
+    primary_alignment_only: bool = False
+    xa_filter: bool = False
+    max_avg_cov: int = 10000
+
+
+def extract_reads(reads: Sequence[SamRead], starts: np.ndarray, win: Window, code: int,
+                  p: ReadFilterParams) -> Tuple[List[Tuple[SamRead, int, int, bool]], bool]:
+    """reference src/Microassembler.cc:436-655.  `reads` must be in BAM (coordinate) order and
+    `starts` = their 0-based positions (for the region seek).  Returns ([(read, mate, strand, mapped)], skip)."""
+    out = []
+    mq = p.min_map_qual
+    min_delta = p.max_delta_as_xs
+    if code == NML:
+        mq = 0
+        min_delta = -1
+    totalbp = 0
+    rawlen = len(win.seq)
+    # BamTools region = overlap semantics; anything that can pass the containment test starts >= refstart
+    lo = int(np.searchsorted(starts, win.start, side="left"))
+    for i in range(lo, len(reads)):
+        r = reads[i]
+        alstart = r.pos - 1
+        if alstart > win.end:
+            break
+        if rawlen > 0 and (totalbp / rawlen) > p.max_avg_cov:       # :491-496
+            return out, True
+        alend = alstart + cigar_ref_len(r.cigar)                     # GetEndPosition: 0-based half-open
+        if alstart < win.start or alend > win.end:                   # :498-500 (1-based vs 0-based, kept)
+            continue
+        if p.primary_alignment_only and (r.flag & 0x100):
+            continue
+        if not (r.mapq >= mq and not (r.flag & 0x400)):              # :504
+            continue
+        mate = 1 if (r.flag & 0x40) else (2 if (r.flag & 0x80) else 0)
+        if (r.flag & 0x40) and (r.flag & 0x80):
+            mate = 2                                                 # :510-511 second assignment wins
+        strand = REV if (r.flag & 0x10) else FWD
+        a_s = float(r.tags["AS"]) if "AS" in r.tags else -1.0
+        x_s = float(r.tags["XS"]) if "XS" in r.tags else -1.0
+        if abs(a_s - x_s) <= min_delta and a_s != -1 and x_s != -1:   # :535
+            continue
+        xt = r.tags.get("XT", "")
+        if xt == "R" and code != NML:                                # :554-559
+            continue
+        xa = r.tags.get("XA", "")
+        if xa != "" and code != NML and p.xa_filter:                 # :573-579
+            continue
+        mapped = not (r.flag & 0x4)
+        out.append((r, mate, strand, mapped))
+        totalbp += len(r.seq)
+    return out, False
+
+
+@dataclasses.dataclass
+class WindowBatch:
+    """SoA batch that crosses the C-ABI (include/lancet_engine.h: lancet_window_batch)."""
+    n_windows: int
+    hdr: List[str]
+    chrom: List[str]
+    chr_id: np.ndarray        # int32[n]
+    ref_start: np.ndarray     # int32[n]
+    ref_off: np.ndarray       # uint32[n+1]
+    ref_bases: np.ndarray     # uint8[]
+    read_begin: np.ndarray    # uint32[n+1]
+    seq_off: np.ndarray       # uint32[R+1]
+    seq: np.ndarray           # uint8[]
+    qual: np.ndarray          # uint8[]
+    label: np.ndarray         # uint8[R]
+    strand: np.ndarray        # uint8[R]
+    mate: np.ndarray          # uint8[R]
+    mapped: np.ndarray        # uint8[R]
+    name_rank: np.ndarray     # uint32[R]
+
+    @property
+    def n_reads(self) -> int:
+        return int(self.read_begin[-1])
+
+
+def build_batch(windows: Sequence[Window], per_window_reads: Sequence[Sequence[Tuple[str, str, str, int, int, int, bool]]],
+                chrom_ids: Optional[Dict[str, int]] = None) -> WindowBatch:
+    """per_window_reads[w] = [(name, seq, qual, label, strand, mate, mapped)], tumor reads then normal reads
+    (the order Graph_t::readid2info gets filled, reference src/Microassembler.cc:833-834)."""
+    n = len(windows)
+    chrom_ids = chrom_ids if chrom_ids is not None else {}
+    ref_off = np.zeros(n + 1, dtype=np.uint32)
+    read_begin = np.zeros(n + 1, dtype=np.uint32)
+    refs = []
+    seqs: List[bytes] = []
+    quals: List[bytes] = []
+    seq_len: List[int] = []
+    label: List[int] = []
+    strand: List[int] = []
+    mate: List[int] = []
+    mapped: List[int] = []
+    ranks: List[int] = []
+    chr_id = np.zeros(n, dtype=np.int32)
+    ref_start = np.zeros(n, dtype=np.int32)
+    for w, win in enumerate(windows):
+        refs.append(win.seq.encode())
+        ref_off[w + 1] = ref_off[w] + len(win.seq)
+        chr_id[w] = chrom_ids.setdefault(win.chrom, len(chrom_ids))
+        ref_start[w] = win.start
+        rs = per_window_reads[w]
+        names = sorted({r[0].encode() for r in rs})
+        rank = {nm: i for i, nm in enumerate(names)}
+        for (name, s, q, lab, st, mt, mp) in rs:
+            seqs.append(s.encode())
+            quals.append(q.encode())
+            seq_len.append(len(s))
+            label.append(lab)
+            strand.append(st)
+            mate.append(mt)
+            mapped.append(1 if mp else 0)
+            ranks.append(rank[name.encode()])
+        read_begin[w + 1] = read_begin[w] + len(rs)
+    seq_off = np.zeros(len(seq_len) + 1, dtype=np.uint32)
+    if seq_len:
+        seq_off[1:] = np.cumsum(np.asarray(seq_len, dtype=np.uint64)).astype(np.uint32)
+    return WindowBatch(
+        n_windows=n, hdr=[w.hdr for w in windows], chrom=[w.chrom for w in windows],
+        chr_id=chr_id, ref_start=ref_start, ref_off=ref_off,
+        ref_bases=np.frombuffer(b"".join(refs), dtype=np.uint8).copy(),
+        read_begin=read_begin, seq_off=seq_off,
+        seq=np.frombuffer(b"".join(seqs), dtype=np.uint8).copy(),
+        qual=np.frombuffer(b"".join(quals), dtype=np.uint8).copy(),
+        label=np.asarray(label, dtype=np.uint8), strand=np.asarray(strand, dtype=np.uint8),
+        mate=np.asarray(mate, dtype=np.uint8), mapped=np.asarray(mapped, dtype=np.uint8),
+        name_rank=np.asarray(ranks, dtype=np.uint32))
+
+
+def batch_from_sam(windows: Sequence[Window], tumor: Sequence[SamRead], normal: Sequence[SamRead],
+                   p: Optional[ReadFilterParams] = None, max_k: int = 101):
+    """Runs the per-window part of processReads (reference src/Microassembler.cc:779-842) up to the
+    processGraph call: returns (batch, kept_windows) for windows that are not skipped.
+    Active-region prefilter is not applied here (== --active-region-off)."""
+    p = p or ReadFilterParams()
+    t_starts = np.asarray([r.pos - 1 for r in tumor], dtype=np.int64)
+    n_starts = np.asarray([r.pos - 1 for r in normal], dtype=np.int64)
+    kept: List[Window] = []
+    per: List[list] = []
+    for win in windows_in_processing_order(windows):
+        if _is_repeat(win.seq, max_k):                                  # :800
+            continue
+        tr, skip_t = extract_reads(tumor, t_starts, win, TMR, p)
+        nr, skip_n = extract_reads(normal, n_starts, win, NML, p)
+        if skip_t or skip_n:
+            continue
+        rs = [(r.qname, r.seq, r.qual, TMR, st, mt, mp) for (r, mt, st, mp) in tr]
+        rs += [(r.qname, r.seq, r.qual, NML, st, mt, mp) for (r, mt, st, mp) in nr]
+        kept.append(win)
+        per.append(rs)
+    return build_batch(kept, per), kept
+
+
+def _is_repeat(seq: str, k: int) -> bool:
+    """reference src/util.cc:295-315 (offsets [0, len-K))."""
+    seen = set()
+    for off in range(0, len(seq) - k):
+        s = seq[off:off + k]
+        if s in seen:
+            return True
+        seen.add(s)
+    return False

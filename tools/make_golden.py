@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/* by running the REFERENCE ITSELF in this container.
+
+What is run: the unmodified reference binary that the survey stage built from /root/reference with the
+recipe in SURVEY.md §8(c); it lives at /tmp/oracle/src/lancet (sources there are byte-identical to
+/root/reference/src -- this script checks that with `diff -rq` before trusting it).  SAM->BAM conversion and
+BAM indexing use the htslib `test_view` and `bamtools index` programs from the same build.  None of this
+travels to the GPU box; only the small data files written under tests/golden/ do:
+
+  <case>.reads.npz   the simulated reads (SAM fields) + contig sequence (inputs)
+  <case>.vcf         the reference's VCF (header without ##fileDate, + body)   (expected output)
+  <case>.trace.txt   digest of the reference's `-v` stderr: per-window k attempts, rejection reasons,
+                     anchors, per-stage node/edge counts, emitted transcripts    (expected stage outputs)
+  <case>.json        the command line / parameters of the case
+
+Usage:  python tools/make_golden.py [case ...]
+"""
+from __future__ import annotations
+
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lancet_amd import synth  # noqa: E402
+
+REF_BIN = "/tmp/oracle/src/lancet"
+TEST_VIEW = "/tmp/oracle/htslib-1.15.1/test/test_view"
+BAMTOOLS = "/tmp/oracle/bamtools-2.5.2/bin/bamtools"
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+CASES = {
+    # name: (synth kwargs, region, extra reference flags)
+    "cfg1_k25": (dict(ref_len=6000, cov_t=30, cov_n=30), "chr22:2200-2799",
+                 ["--padding", "0", "--min-k", "25", "--max-k", "25"]),
+    "tile30": (dict(ref_len=9000, cov_t=30, cov_n=30), "chr22:1500-6500", []),
+    "tile60": (dict(ref_len=6000, cov_t=60, cov_n=60, tumor_seed=111, normal_seed=212), "chr22:1500-3500", []),
+    "str100": (dict(ref_len=6000, cov_t=100, cov_n=40, str_fraction=0.30, lowcomplex_fraction=0.05,
+                    ref_seed=44, tumor_seed=141, normal_seed=242), "chr22:1500-3000", []),
+    "err_hi": (dict(ref_len=6000, cov_t=40, cov_n=30, error_rate=0.01, read_len=100, ref_seed=7,
+                    tumor_seed=17, normal_seed=27, somatic_every=700, germline_every=500),
+               "chr22:1000-4500", []),
+    "dups": (dict(ref_len=8000, cov_t=40, cov_n=40, ref_seed=5, tumor_seed=15, normal_seed=25, dup_prob=1.0,
+                  somatic_every=600, germline_every=500, read_len=100), "chr22:1000-6500", []),
+}
+
+
+def run(cmd, **kw):
+    return subprocess.run(cmd, check=True, **kw)
+
+
+def check_reference_is_unmodified():
+    r = subprocess.run(["diff", "-rq", "/tmp/oracle/src", "/root/reference/src"], capture_output=True, text=True)
+    extra = [l for l in r.stdout.splitlines() if not re.search(r"Only in /tmp/oracle/src: (lancet|lancet_pg)$", l)]
+    if extra:
+        raise SystemExit("reference build tree differs from /root/reference/src:\n" + "\n".join(extra))
+
+
+def digest_trace(stderr: str) -> str:
+    """Keeps the lines that pin stage results; drops alignments dumps and progress chatter."""
+    keep = []
+    pat = re.compile(
+        r"^(== Processing|Repeat in reference|Near-perfect repeat|reads: |  \d+: nodes:| nodes: |ref trim5|"
+        r"Ambiguous match|No match to reference|Cycle found|compressing graph|  removing |removing low coverage|"
+        r"remove tips round| removed|remove short links| Found |FINISHED|>p_| refcomp:| perfect:|"
+        r"searching from|Missing source|WARNING: DFS_LIMIT)")
+    for line in stderr.splitlines():
+        if pat.match(line):
+            keep.append(line.rstrip())
+    return "\n".join(keep) + "\n"
+
+
+def make_case(name: str):
+    kwargs, region, flags = CASES[name]
+    data = synth.make_tumor_normal(**kwargs)
+    ref, rname = data["ref"], data["rname"]
+    with tempfile.TemporaryDirectory(prefix="lancet_golden_") as td:
+        fa = os.path.join(td, "ref.fa")
+        synth.write_fasta(fa, rname, ref)
+        bams = {}
+        for sample, rg, pairs in (("TUMOR", "tumor", data["tumor"]), ("NORMAL", "normal", data["normal"])):
+            sam = os.path.join(td, f"{rg}.sam")
+            bam = os.path.join(td, f"{rg}.bam")
+            synth.write_sam(sam, rname, len(ref), sample, rg, pairs)
+            run([TEST_VIEW, "-b", "-p", bam, sam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            run([BAMTOOLS, "index", "-in", bam])
+            bams[rg] = bam
+        cmd = [REF_BIN, "--tumor", bams["tumor"], "--normal", bams["normal"], "--ref", fa, "--reg", region,
+               "--num-threads", "1", "--active-region-off", "-v"] + flags
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=td)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr[-3000:])
+            raise SystemExit(f"reference failed on case {name}")
+        vcf = "".join(l + "\n" for l in r.stdout.splitlines()
+                      if not l.startswith("##fileDate") and not l.startswith("##cmdline")
+                      and not l.startswith("##reference"))
+        # `ctime()` ends with '\n' and the header has no newline after it: "##fileDate=...\n##source"
+    os.makedirs(GOLDEN, exist_ok=True)
+    with open(os.path.join(GOLDEN, f"{name}.vcf"), "w") as f:
+        f.write(vcf)
+    with open(os.path.join(GOLDEN, f"{name}.trace.txt"), "w") as f:
+        f.write(digest_trace(r.stderr))
+    reads = {}
+    for rg in ("tumor", "normal"):
+        rs = synth.pairs_to_sorted_reads(data[rg])
+        reads[f"{rg}_qname"] = np.array([x.qname for x in rs])
+        reads[f"{rg}_flag"] = np.array([x.flag for x in rs], dtype=np.int32)
+        reads[f"{rg}_pos"] = np.array([x.pos for x in rs], dtype=np.int32)
+        reads[f"{rg}_mapq"] = np.array([x.mapq for x in rs], dtype=np.int32)
+        reads[f"{rg}_cigar"] = np.array([x.cigar for x in rs])
+        reads[f"{rg}_seq"] = np.array([x.seq for x in rs])
+        reads[f"{rg}_qual"] = np.array([x.qual for x in rs])
+        reads[f"{rg}_as"] = np.array([x.tags["AS"] for x in rs], dtype=np.int32)
+        reads[f"{rg}_xs"] = np.array([x.tags["XS"] for x in rs], dtype=np.int32)
+        reads[f"{rg}_md"] = np.array([x.tags["MD"] for x in rs])
+    np.savez_compressed(os.path.join(GOLDEN, f"{name}.reads.npz"), ref=np.array(ref), rname=np.array(rname), **reads)
+    with open(os.path.join(GOLDEN, f"{name}.json"), "w") as f:
+        json.dump({"synth": kwargs, "region": region, "flags": flags,
+                   "reference_cmd": " ".join(os.path.basename(c) if c.startswith("/tmp") else c for c in cmd),
+                   "n_vcf_records": sum(1 for l in vcf.splitlines() if not l.startswith("#"))}, f, indent=1)
+    print(f"{name}: {sum(1 for l in vcf.splitlines() if not l.startswith('#'))} VCF records, "
+          f"{len(reads['tumor_qname'])}+{len(reads['normal_qname'])} reads")
+
+
+if __name__ == "__main__":
+    check_reference_is_unmodified()
+    for c in (sys.argv[1:] or list(CASES)):
+        make_case(c)
