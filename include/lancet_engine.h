@@ -1,0 +1,180 @@
+/* lancet_engine.h -- C-ABI of the MI355X micro-assembly engine (drop-in for Lancet's per-window hot path).
+ *
+ * The reference has no plugin / FFI interface.  The seam this library sits behind is the
+ * C++ member call
+ *      numreads = processGraph(g, graphref, minK, maxK);          reference src/Microassembler.cc:837
+ *                                                        (declared reference src/Microassembler.hh:224)
+ * whose inputs are, at that point, fully materialised:
+ *      g.readid2info  -- reads filled by Graph_t::addAlignment     reference src/Graph.cc:487-501
+ *                        (fields: reference src/ReadInfo.hh:44-67)
+ *      Ref_t          -- window reference string + coordinates     reference src/Ref.hh:55-97
+ *      knobs          -- Graph_t setters                           reference src/Microassembler.cc:726-753
+ * and whose only output is the stream of
+ *      vDB->addVar(Variant_t(...))                                 reference src/Graph.cc:1184-1188
+ *                                                (ctor signature: reference src/Variant.hh:106-112)
+ *
+ * One `lancet_engine_run` == that call, for a whole batch of independent windows at once.
+ * Plain pointers and sizes only; no C++ / torch types.  Return 0 on success, <0 on error (never aborts).
+ * Outputs are owned by the engine and stay valid until the next upload/run/destroy on that engine.
+ * One engine per (host thread, GPU); an engine is not thread-safe.
+ */
+#ifndef LANCET_ENGINE_H
+#define LANCET_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* sample labels / strands as the reference encodes them */
+#define LANCET_TMR 4 /* reference src/Ref.hh:36 */
+#define LANCET_NML 5 /* reference src/Ref.hh:37 */
+#define LANCET_FWD 1 /* reference src/ReadInfo.hh:30 */
+#define LANCET_REV 2 /* reference src/ReadInfo.hh:31 */
+
+/* Knobs copied into Graph_t before processGraph (reference src/Microassembler.cc:726-753, defaults
+ * reference src/Lancet.hh:33-81).  lancet_params_default() fills the reference defaults. */
+typedef struct lancet_params {
+  int32_t min_k;             /* minK 11                      */
+  int32_t max_k;             /* maxK 101                     */
+  int32_t max_tip_len;       /* MAX_TIP_LEN 11               */
+  int32_t cov_threshold;     /* COV_THRESHOLD 5              */
+  int32_t low_cov_threshold; /* LOW_COV_THRESHOLD 1          */
+  int32_t dfs_limit;         /* DFS_LIMIT 1000000            */
+  int32_t max_indel_len;     /* MAX_INDEL_LEN 500            */
+  int32_t max_mismatch;      /* MAX_MISMATCH 2               */
+  int32_t min_qual_trim;     /* MIN_QV_TRIM 10 + '!'         */
+  int32_t min_qual_call;     /* MIN_QV_CALL 17 + '!'         */
+  int32_t max_unit_len;      /* MAX_UNIT_LEN 4   (STR)       */
+  int32_t min_report_units;  /* MIN_REPORT_UNITS 3           */
+  int32_t min_report_len;    /* MIN_REPORT_LEN 7             */
+  int32_t dist_from_str;     /* DIST_FROM_STR 1              */
+  int32_t lr_mode;           /* --linked-reads; must be 0 in this version (LANCET_E_UNSUPPORTED) */
+  int32_t reserved;
+  double  min_cov_ratio;     /* MIN_COV_RATIO 0.01           */
+} lancet_params;
+
+/* A batch of independent windows, SoA, caller-owned, read-only during the call.
+ * Reads of window w are read_begin[w] .. read_begin[w+1]-1, in the order Graph_t::readid2info is filled:
+ * tumor reads in BAM order, then normal reads in BAM order (reference src/Microassembler.cc:833-834).
+ * Bases / qualities are ASCII exactly as BamAlignment::QueryBases / Qualities hold them (phred+33). */
+typedef struct lancet_window_batch {
+  int32_t         n_windows;
+  const int32_t  *chr_id;      /* [n_windows] caller's chromosome id, echoed in lancet_variant        */
+  const int32_t  *ref_start;   /* [n_windows] Ref_t::refstart (1-based)                               */
+  const uint32_t *ref_off;     /* [n_windows+1] offsets into ref_bases                                 */
+  const char     *ref_bases;   /* Ref_t::rawseq of every window, upper-case ACGTN, concatenated        */
+  const uint32_t *read_begin;  /* [n_windows+1]                                                        */
+  const uint32_t *seq_off;     /* [n_reads+1] offsets into seq / qual                                  */
+  const char     *seq;         /* ReadInfo_t::seq_m                                                    */
+  const char     *qual;        /* ReadInfo_t::qv_m                                                     */
+  const uint8_t  *label;       /* [n_reads] LANCET_TMR | LANCET_NML   (ReadInfo_t::label_m)            */
+  const uint8_t  *strand;      /* [n_reads] LANCET_FWD | LANCET_REV   (ReadInfo_t::strand)             */
+  const uint8_t  *mate;        /* [n_reads] 0 | 1 | 2                 (ReadInfo_t::mate_order_m)       */
+  const uint8_t  *mapped;      /* [n_reads] 1 = CODE_MAPPED, 0 = CODE_BASTARD (ReadInfo_t::code_m)     */
+  const uint32_t *name_rank;   /* [n_reads] dense rank of ReadInfo_t::readname_m among the window's
+                                  read names under std::string operator< (equal names = equal rank)   */
+} lancet_window_batch;
+
+/* One addVar(Variant_t(...)) call, arguments as passed at reference src/Graph.cc:1184-1188. */
+typedef struct lancet_variant {
+  int32_t  window;          /* index of the window in the batch                                      */
+  int32_t  seq_in_window;   /* emission order within the window (0,1,2,...)                          */
+  int32_t  chr_id;
+  int32_t  pos;             /* transcript.pos - 1  (Variant_t ctor arg pos_)                          */
+  uint8_t  code;            /* 'x' snv, '^' ins, 'v' del, 'c' complex                                 */
+  uint8_t  prev_bp_ref;
+  uint8_t  prev_bp_alt;
+  uint8_t  reserved;
+  uint16_t kmer;            /* K                                                                      */
+  uint16_t cov[8];          /* RCN fwd,rev  RCT fwd,rev  ACN fwd,rev  ACT fwd,rev                     */
+  uint16_t reserved2;
+  uint32_t ref_off, ref_len;   /* transcript.ref  (may contain '-') in the blob                       */
+  uint32_t alt_off, alt_len;   /* transcript.qry  (may contain '-') in the blob                       */
+  uint32_t str_off, str_len;   /* STR annotation "<len><motif>" or empty                              */
+} lancet_variant;
+
+/* Per-window outcome. */
+typedef struct lancet_window_stats {
+  int32_t  status;        /* LANCET_W_* below                                                        */
+  int32_t  final_k;       /* k of the last graph build (0 if none)                                   */
+  int32_t  n_builds;      /* k-attempts that reached buildgraph                                       */
+  int32_t  n_variants;
+  uint64_t n_kmers;       /* sum over builds of the loadSequence trip count         */
+  uint32_t max_nodes;     /* largest node table over the builds                                       */
+  uint32_t reserved;
+} lancet_window_stats;
+
+#define LANCET_W_OK            0   /* processed (possibly with no variants)                          */
+#define LANCET_W_NO_READS      1   /* countMappedReads()<=0 -> returned early (Microassembler.cc:83)  */
+#define LANCET_W_K_EXHAUSTED   2   /* every k up to max_k was rejected                                */
+#define LANCET_W_OVERFLOW     -1   /* a device work-space limit was hit; results for this window are
+                                      NOT valid (reported loudly, never silently wrong)               */
+
+/* error codes */
+#define LANCET_OK              0
+#define LANCET_E_ARG          -1
+#define LANCET_E_NO_DEVICE    -2
+#define LANCET_E_HIP          -3
+#define LANCET_E_UNSUPPORTED  -4
+#define LANCET_E_OOM          -5
+#define LANCET_E_STATE        -6
+
+typedef struct lancet_engine lancet_engine;
+
+void lancet_params_default(lancet_params *p);
+
+/* device >= 0 : HIP device ordinal.  There is no CPU backend: creation fails with LANCET_E_NO_DEVICE
+ * when no gfx950-compatible device is present. */
+int  lancet_engine_create(const lancet_params *p, int device, lancet_engine **out);
+void lancet_engine_destroy(lancet_engine *e);
+const char *lancet_engine_last_error(const lancet_engine *e);
+
+/* Copies a batch to HBM (packs bases to 2 bit, sizes the per-window work space).  After this returns the
+ * batch is device-resident and the caller's buffers are no longer referenced. */
+int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b);
+
+/* Runs the whole hot path (self-tuning k loop included) for every uploaded window.  Blocking. */
+int lancet_engine_run(lancet_engine *e);
+
+/* upload + run in one call, the exact equivalent of the reference seam. */
+int lancet_engine_process(lancet_engine *e, const lancet_window_batch *b);
+
+/* Results of the last run: variants ordered by (window, seq_in_window) so that the caller can replay
+ * addVar in reference order. */
+int lancet_engine_results(lancet_engine *e, const lancet_variant **variants, uint32_t *n_variants,
+                          const char **blob, uint32_t *blob_len, const lancet_window_stats **stats);
+
+/* Timing of the last run as measured with HIP events on the engine's stream (milliseconds):
+ * out[0] = all kernels of the run, out[1] = the assembly kernel only. */
+int lancet_engine_last_timing(lancet_engine *e, float out[2]);
+
+/* ---- host side of the seam: Variant_t normalisation + VariantDB + VCF ----------
+ * reference src/Variant.hh:106-172 (ctor), src/VariantDB.cc:28-91 (addVar), :93-179 (VCF),
+ * src/Variant.cc:39-223 (printVCF). */
+typedef struct lancet_filters {     /* reference src/Variant.hh:42-56, defaults src/Lancet.cc:627-637 */
+  double  min_phred_fisher_str, min_phred_fisher, max_vaf_normal, min_vaf_tumor;
+  int32_t min_cov_normal, max_cov_normal, min_cov_tumor, max_cov_tumor;
+  int32_t min_alt_cnt_tumor, max_alt_cnt_normal, min_strand_bias, reserved;
+} lancet_filters;
+
+typedef struct lancet_vdb lancet_vdb;
+
+void lancet_filters_default(lancet_filters *f);
+lancet_vdb *lancet_vdb_create(const lancet_filters *f);
+void lancet_vdb_destroy(lancet_vdb *db);
+/* addVar for records [0,n) in the given order; chr_names[chr_id] gives the chromosome string. */
+int  lancet_vdb_add(lancet_vdb *db, const lancet_variant *v, uint32_t n, const char *blob,
+                    const char *const *chr_names, int32_t n_chr);
+uint32_t lancet_vdb_size(const lancet_vdb *db);
+/* Writes the VCF (header + sorted body) into a malloc'd string the caller frees with lancet_free.
+ * date_line: text after "##fileDate=" (ctime() format incl. trailing newline), may be NULL -> omitted. */
+char *lancet_vdb_vcf(lancet_vdb *db, const char *version, const char *cmdline, const char *reference,
+                     const char *date_line, const char *sample_normal, const char *sample_tumor);
+void lancet_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LANCET_ENGINE_H */

@@ -37,8 +37,8 @@ class SamRead:
     def sam_line(self, mate_pos: int, tlen: int) -> str:
         t = []
         for k, v in self.tags.items():
-            if isinstance(v, int):
-                t.append(f"{k}:i:{v}")
+            if isinstance(v, (int, np.integer)):
+                t.append(f"{k}:i:{int(v)}")
             else:
                 t.append(f"{k}:Z:{v}")
         return "\t".join([self.qname, str(self.flag), self.rname, str(self.pos), str(self.mapq), self.cigar,
@@ -205,7 +205,7 @@ def _cigar_md(ref_b: np.ndarray, seq: np.ndarray, rpos: np.ndarray):
     # MD must alternate number / token; collapse "x" "^..." adjacency is already number-separated
     mdstr = "".join(md)
     cigar = "".join(f"{l}{o}" for l, o in ops)
-    return int(rpos[lo]) + 1, cigar, mdstr, nm
+    return int(rpos[lo]) + 1, cigar, mdstr, int(nm)
 
 
 def simulate_sample(ref: str, rname: str, haps: List[Tuple[np.ndarray, np.ndarray]], hap_probs: List[float],

@@ -1,0 +1,1243 @@
+// lancet_oracle.cc -- TEST INFRASTRUCTURE ONLY.
+//
+// CPU restatement of Lancet's per-window hot path (Microassembler::processGraph and everything below it),
+// written to be read side by side with the reference: every function cites the reference file:line it
+// follows.  It deliberately keeps the reference's data-structure semantics (std::unordered_map<std::string,..>
+// iteration order, vector edge order, float coverage averaging, unsorted binary_search ...) because those are
+// observable in the VCF.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+// (lancet_amd/csrc) never links, includes or calls it.
+//
+// PINNING: this oracle is checked (tests/test_oracle_golden.py) against outputs of the reference itself:
+// tests/golden/*.vcf and *.trace.txt were produced by the unmodified reference binary (tools/make_golden.py).
+// Linked-read mode (BX/HP, reference src/Graph.cc:239-263) is not restated: parity for --linked-reads is
+// "unpinned / not implemented".
+//
+// Build: see oracle/Makefile (g++ -O2 -std=c++17, no -ffast-math; x86-64 SSE float semantics as the reference).
+
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <set>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../include/lancet_engine.h"
+
+namespace {
+
+typedef char Ori;
+const Ori F = 'F', R = 'R';
+enum Edgedir { FF, FR, RF, RR };                                  // reference src/Edge.hh:37
+const int REF_LABEL = 3;                                           // reference src/Graph.hh:58
+
+// ---- Edge_t static helpers, reference src/Edge.hh:71-111 -------------------------------------------------
+Ori edgedir_start(Edgedir d) { return (d == FF || d == FR) ? F : R; }
+Ori edgedir_dest(Edgedir d) { return (d == FF || d == RF) ? F : R; }
+Ori flipdir(Ori d) { return d == R ? F : R; }
+Edgedir flipme(Edgedir d) { switch (d) { case FF: return RF; case FR: return RR; case RF: return FF; default: return FR; } }
+Edgedir fliplink(Edgedir d) { switch (d) { case FF: return RR; case FR: return FR; case RF: return RF; default: return FF; } }
+bool isDir(Edgedir d, Ori dir) {                                   // reference src/Edge.cc:25-31
+  if (dir == F && (d == FF || d == FR)) return true;
+  if (dir == R && (d == RR || d == RF)) return true;
+  return false;
+}
+
+// ---- util, reference src/util.cc --------------------------------------------------------------------------
+char rrc(char b) {                                                 // :204-217
+  switch (b) {
+    case 'A': return 'T'; case 'a': return 't'; case 'C': return 'G'; case 'c': return 'g';
+    case 'G': return 'C'; case 'g': return 'c'; case 'T': return 'A'; case 't': return 'a';
+    case 'N': return 'N'; case 'n': return 'n';
+  }
+  return 0;
+}
+std::string rc_str(const std::string &s) {                         // :221-231
+  std::string r;
+  for (int i = (int)s.length() - 1; i >= 0; --i) r.push_back(rrc(s[i]));
+  return r;
+}
+bool isDNA(char b) { return b == 'A' || b == 'a' || b == 'C' || b == 'c' || b == 'G' || b == 'g' || b == 'T' || b == 't'; }  // :188-199
+
+int HammingDistance(const std::string &a, const std::string &b) {  // :278-289
+  if (a.length() != b.length()) return -1;
+  int d = 0;
+  for (size_t i = 0; i < a.length(); ++i) if (a[i] != b[i]) d++;
+  return d;
+}
+bool isRepeat(const std::string &seq, int K) {                     // :295-315
+  std::set<std::string> mers;
+  int end = (int)seq.length() - K;
+  for (int off = 0; off < end; ++off) {
+    std::string s = seq.substr(off, K);
+    if (mers.count(s) > 0) return true;
+    mers.insert(s);
+  }
+  return false;
+}
+bool kMismatch(size_t s, size_t e, const std::string &t, size_t start, int max) {   // :336-360
+  size_t i = start, L = e - s + 1;
+  while (i < (t.size() - L + 1)) {
+    bool flag = true;
+    int count = 0;
+    size_t j = 0;
+    while (j < L && i + j < t.size()) {
+      if (t[i + j] != t[s + j]) { ++count; if (count > max) { flag = false; break; } }
+      ++j;
+    }
+    if (flag && j == L) return true;
+    ++i;
+  }
+  return false;
+}
+bool isAlmostRepeat(const std::string &seq, int K, int max) {      // :317-334
+  int end = (int)seq.length() - K;
+  for (int off = 0; off < end; ++off)
+    if (kMismatch(off, off + K, seq, off + 1, max)) return true;
+  return false;
+}
+bool seqAboveQual(const std::string &qv, int Q) {                  // :406-412
+  for (char c : qv) if (c < Q) return false;
+  return true;
+}
+
+// findTandems, reference src/util.cc:574-758.  seq[offset-1] with offset==0 reads the byte before the string
+// data; with libstdc++ that byte is 0 for both SSO and heap strings, restated as '\0'.
+bool findTandems(const std::string &seq, int max_unit_len, int min_report_units, int min_report_len,
+                 int dist_from_str, int pos, int &len, std::string &motif) {
+  bool ans = false;
+  const int TS = 100;
+  unsigned MIN_REPORT_LEN = min_report_len, MIN_REPORT_UNITS = min_report_units, MAX_UNIT_LEN = max_unit_len;
+  int delta = dist_from_str;
+  static thread_local int offsets[TS][TS];
+  for (unsigned merlen = 1; merlen <= MAX_UNIT_LEN; ++merlen)
+    for (unsigned phase = 0; phase < merlen; ++phase) offsets[merlen][phase] = phase;
+  auto at = [&](long i) -> char { return (i < 0 || i >= (long)seq.length()) ? '\0' : seq[i]; };
+  for (unsigned i = 0; i < seq.length(); ++i) {
+    for (unsigned merlen = 1; merlen <= MAX_UNIT_LEN; ++merlen) {
+      int phase = i % merlen;
+      int offset = offsets[merlen][phase];
+      unsigned j = 0;
+      while ((j < merlen) && (i + j < seq.length()) && (seq[i + j] == seq[offset + j])) ++j;
+      if (j != merlen || (i + j + 1 == seq.length())) {
+        if (at((long)offset - 1) != at((long)offset + merlen - 1)) {
+          if (((i - offset) / merlen >= MIN_REPORT_UNITS) && (i - offset >= MIN_REPORT_LEN)) {
+            unsigned ml = 1;
+            while (ml < merlen) {
+              unsigned units = (i - offset + j) / ml;
+              int allmatch = 1;
+              for (unsigned index = 1; allmatch && (index < units); ++index)
+                for (unsigned m = 0; m < ml; ++m)
+                  if (seq[offset + m] != seq[offset + index * ml + m]) { allmatch = 0; break; }
+              if (!allmatch) ++ml; else break;
+            }
+            if (ml == merlen) {
+              int start = offset, end = i + j, L = i + j - offset;
+              if ((pos >= (start - delta)) && (pos <= (end + delta))) {
+                ans = true;
+                len = L;
+                for (unsigned z = 0; z < merlen; ++z) motif += seq[offset + z];
+              }
+            }
+          }
+        }
+        offsets[merlen][phase] = i;
+      }
+    }
+  }
+  return ans;
+}
+
+// ---- CanonicalMer_t, reference src/Mer.hh:44-71 ------------------------------------------------------------
+struct CMer {
+  std::string mer;
+  Ori ori;
+  void set(const std::string &m) {
+    std::string r = rc_str(m);          // rc2 == reverse complement (Mer.hh:103-118)
+    if (m < r) { mer = m; ori = F; } else { mer = r; ori = R; }
+  }
+};
+
+// ---- cov_t, reference src/Ref.hh:41-53 (hp* fields only matter in LR mode; omitted) -----------------------
+struct Cov { uint16_t fwd = 0, rev = 0, minqv_fwd = 0, minqv_rev = 0; };
+
+struct Edge { std::string to; Edgedir dir; int flag; };
+
+// ---- Node_t, reference src/Node.hh:45-217, src/Node.cc ------------------------------------------------------
+struct Node {
+  std::string id, str;
+  unsigned short K = 0;
+  float cov_tf = 0, cov_tr = 0, cov_nf = 0, cov_nr = 0;
+  bool isRef = false, isTumor = false, isNormal = false, isSource = false, isSink = false, dead = false;
+  int comp = 0;
+  bool touchRef = false;
+  int onRefPath = 0;
+  int color = 0, MIN_QUAL = 0, mincov = 0, mincovQV = 0;
+  std::vector<char> status;
+  std::vector<Cov> distT, distN;
+  std::vector<Edge> edges;
+  std::vector<uint32_t> mate1, mate2;     // read names as their lexicographic dense rank
+
+  explicit Node(const std::string &mer) : id(mer), str(mer) {
+    status.resize(str.size(), 'E'); distT.resize(str.size()); distN.resize(str.size());
+  }
+  bool isSpecial() const { return isSink || isSource || isRef; }
+  int strlen_() const { return isSpecial() ? 0 : (int)str.length(); }               // Node.cc:349-354
+  int getSize() const { return (int)str.size() - K + 1; }
+  float totTmr() const { return cov_tf + cov_tr; }
+  float totNml() const { return cov_nf + cov_nr; }
+  float totCov() const { return cov_tf + cov_tr + cov_nf + cov_nr; }
+  float getCov(int strand, int label) const {                                        // Node.cc:675-688
+    if (label == LANCET_TMR) { if (strand == LANCET_FWD) return cov_tf; if (strand == LANCET_REV) return cov_tr; }
+    if (label == LANCET_NML) { if (strand == LANCET_FWD) return cov_nf; if (strand == LANCET_REV) return cov_nr; }
+    return 0;
+  }
+  void incCov(int strand, int label) {                                               // Node.cc:692-703
+    if (label == LANCET_TMR) { if (strand == LANCET_FWD) cov_tf++; else if (strand == LANCET_REV) cov_tr++; }
+    if (label == LANCET_NML) { if (strand == LANCET_FWD) cov_nf++; else if (strand == LANCET_REV) cov_nr++; }
+  }
+  bool isTandem() const { for (auto &e : edges) if (e.to == id) return true; return false; }   // Node.cc:123-134
+  void addEdge(const std::string &to, Edgedir dir) {                                 // Node.cc:140-175
+    for (auto &e : edges) if (e.to == to && e.dir == dir) return;
+    edges.push_back(Edge{to, dir, 0});
+  }
+  bool updateEdge(const std::string &oldid, Edgedir olddir, const std::string &newid, Edgedir newdir) {  // :181-204
+    for (auto &e : edges) if (e.to == oldid && e.dir == olddir) { e.to = newid; e.dir = newdir; return true; }
+    return false;
+  }
+  bool removeEdge(const std::string &to, Edgedir dir) {                              // Node.cc:209-229
+    for (size_t i = 0; i < edges.size(); ++i)
+      if (edges[i].to == to && edges[i].dir == dir) { edges.erase(edges.begin() + i); return true; }
+    return false;
+  }
+  int getBuddy(Ori dir) const {                                                      // Node.cc:235-266
+    int retval = -1;
+    if (isSpecial()) return retval;
+    for (size_t i = 0; i < edges.size(); ++i)
+      if (isDir(edges[i].dir, dir)) { if (retval != -1) return -1; retval = (int)i; }
+    if (retval != -1 && edges[retval].to == id) return -1;
+    return retval;
+  }
+  void updateCovStatus(char c) {                                                     // Node.cc:445-465
+    for (auto &s : status) { if (s == 'E') s = c; else if (s != c) s = 'B'; else s = c; }
+  }
+  void updateCovDistr(int cov, const std::string &qv, int strand, int sample) {      // Node.cc:470-497
+    std::vector<Cov> *d = sample == LANCET_TMR ? &distT : (sample == LANCET_NML ? &distN : nullptr);
+    if (!d) return;
+    for (size_t i = 0; i < d->size(); ++i) {
+      if (strand == LANCET_FWD) { (*d)[i].fwd = (uint16_t)cov; if (qv[i] >= MIN_QUAL) ++(*d)[i].minqv_fwd; }
+      else if (strand == LANCET_REV) { (*d)[i].rev = (uint16_t)cov; if (qv[i] >= MIN_QUAL) ++(*d)[i].minqv_rev; }
+    }
+  }
+  void revCovDistr() {                                                               // Node.cc:562-572
+    int i = 0, j = (int)distT.size() - 1;
+    while (i < j) { std::swap(distT[i], distT[j]); std::swap(distN[i], distN[j]); ++i; --j; }
+  }
+  void computeMinCov() {                                                             // Node.cc:600-615
+    int mn = 10000000, mnQV = 10000000;
+    for (size_t i = 0; i < distT.size(); ++i) {
+      int tot = distT[i].fwd + distT[i].rev + distN[i].fwd + distN[i].rev;
+      int totQV = distT[i].minqv_fwd + distT[i].minqv_rev + distN[i].minqv_fwd + distN[i].minqv_rev;
+      if (tot < mn) mn = tot;
+      if (totQV < mnQV) mnQV = totQV;
+    }
+    mincov = mn; mincovQV = mnQV;
+  }
+  bool isStatusCnt(char c) const {                                                   // Node.cc:423-440
+    int cnt = 0; unsigned N = 0;
+    for (unsigned i = (K - 1); i < status.size(); ++i) { ++N; if (status[i] == c) ++cnt; }
+    double prcnt = double(cnt) / double(N);
+    return prcnt > 0.8;
+  }
+  // hasOverlappingMate / addMateName, reference src/Node.cc:638-671: std::binary_search on the (unsorted)
+  // vector of the other mate's names.
+  bool hasOverlappingMate(uint32_t name, int id) const {
+    if (id == 1) return std::binary_search(mate2.begin(), mate2.end(), name);
+    if (id == 2) return std::binary_search(mate1.begin(), mate1.end(), name);
+    return false;
+  }
+  void addMateName(uint32_t name, int id) { if (id == 1) mate1.push_back(name); if (id == 2) mate2.push_back(name); }
+};
+
+// ---- Ref_t, reference src/Ref.hh:55-136, src/Ref.cc -------------------------------------------------------
+struct RefInfo {
+  unsigned short K = 0;
+  std::string hdr, seq, rawseq, chr;
+  int refstart = 0, refend = 0;
+  unsigned short trim5 = 0, trim3 = 0;
+  std::unordered_map<std::string, Cov> merN, merT;
+  std::vector<Cov> covN, covT;
+  std::set<int> refcompids;
+  int refnodes = 0, refcomp = 0, allcomp = 0;
+  bool indexed = false;
+
+  void setK(int k) {                                                                 // Ref.hh:109, Ref.cc:28-38, :355-387
+    K = k; indexed = false;
+    merN.clear(); merT.clear();
+    covN.assign(rawseq.size(), Cov()); covT.assign(rawseq.size(), Cov());
+  }
+  void indexMers() {                                                                 // Ref.cc:40-64
+    if (indexed) return;
+    CMer c;
+    for (unsigned i = 0; (i + K) < seq.length(); ++i) {
+      c.set(seq.substr(i, K));
+      merN.insert({c.mer, Cov()}); merT.insert({c.mer, Cov()});
+    }
+    indexed = true;
+  }
+  bool hasMer(const std::string &m) { indexMers(); return merN.count(m); }           // Ref.cc:67-71
+  void updateCoverage(const std::string &m, int cov, int strand, int sample) {       // Ref.cc:128-149
+    indexMers();
+    auto *t = sample == LANCET_TMR ? &merT : (sample == LANCET_NML ? &merN : nullptr);
+    if (!t) return;
+    auto it = t->find(m);
+    if (it != t->end()) { if (strand == LANCET_FWD) it->second.fwd = (uint16_t)cov; else if (strand == LANCET_REV) it->second.rev = (uint16_t)cov; }
+  }
+  void computeCoverage(int sample) {                                                 // Ref.cc:173-250
+    auto *t = sample == LANCET_TMR ? &merT : &merN;
+    auto *cv = sample == LANCET_TMR ? &covT : &covN;
+    CMer c;
+    for (unsigned i = 0; (i + K) < rawseq.length(); ++i) {
+      c.set(rawseq.substr(i, K));
+      auto it = t->find(c.mer);
+      if (it != t->end()) {
+        if (i == 0) { for (int j = 0; j < K; ++j) { cv->at(j).fwd = it->second.fwd; cv->at(j).rev = it->second.rev; } }
+        else { cv->at(i + K - 1).fwd = it->second.fwd; cv->at(i + K - 1).rev = it->second.rev; }
+      } else {
+        if (i == 0) { for (int j = 0; j < K; ++j) { cv->at(j).fwd = 0; cv->at(j).rev = 0; } }
+        cv->at(i + K - 1).fwd = 0; cv->at(i + K - 1).rev = 0;
+      }
+    }
+  }
+  Cov getCovStructAt(unsigned pos, int sample) const {                               // Ref.cc:253-267
+    const auto *cv = sample == LANCET_NML ? &covN : &covT;
+    Cov c;
+    if (cv->size() > pos) c = (*cv)[pos];
+    return c;
+  }
+};
+
+struct ReadInfo {                                                                    // reference src/ReadInfo.hh:44-67
+  int label; std::string seq, qv; char code; unsigned short strand, mate_order; uint32_t name;
+  unsigned short trm5 = 0, trm3 = 0; bool isjunk = false;
+};
+
+// ---- Transcript_t, reference src/Transcript.hh:33-315 -----------------------------------------------------
+struct Transcript {
+  unsigned pos, ref_pos, start_pos; char code; unsigned end_pos, ref_end_pos;
+  std::string ref, qry; bool isSomatic;
+  Cov min_alt_N, min_alt_T, min_non0_alt_N, min_non0_alt_T, mean_alt_N, mean_alt_T, mean_non0_alt_N, mean_non0_alt_T;
+  Cov min_ref_N, min_ref_T, min_non0_ref_N, min_non0_ref_T, mean_ref_N, mean_ref_T, mean_non0_ref_N, mean_non0_ref_T;
+  std::vector<Cov> alt_N, alt_T, ref_N, ref_T;
+  char prev_bp_ref, prev_bp_alt;
+  Transcript(int pos_, int ref_pos_, int start_pos_, char code_, char r, char q, Cov an, Cov at, Cov rn, Cov rt,
+             char pbr, char pba, int end_pos_, int ref_end_pos_, bool flag)
+      : pos(pos_), ref_pos(ref_pos_), start_pos(start_pos_), code(code_), end_pos(end_pos_), ref_end_pos(ref_end_pos_) {
+    isSomatic = flag; ref = r; qry = q;
+    alt_N.push_back(an); alt_T.push_back(at); ref_N.push_back(rn); ref_T.push_back(rt);
+    min_alt_N = an; min_alt_T = at; min_non0_alt_N = an; min_non0_alt_T = at;
+    min_ref_N = rn; min_ref_T = rt; min_non0_ref_N = rn; min_non0_ref_T = rt;
+    prev_bp_ref = pbr; prev_bp_alt = pba;
+  }
+  static void computeStats(std::vector<Cov> &d, Cov &mn, Cov &mn0, Cov &mean, Cov &mean0) {   // :123-226
+    unsigned n = d.size();
+    Cov sum, sum0, n0;     // unsigned short accumulators: wrap like the reference
+    for (unsigned i = 0; i < n; ++i) {
+#define LANCET_ACC(f) \
+      sum.f += d[i].f; if (d[i].f != 0) { sum0.f += d[i].f; ++n0.f; } \
+      if (d[i].f < mn.f) mn.f = d[i].f; if (d[i].f < mn0.f && d[i].f != 0) mn0.f = d[i].f;
+      LANCET_ACC(fwd) LANCET_ACC(rev) LANCET_ACC(minqv_fwd) LANCET_ACC(minqv_rev)
+#undef LANCET_ACC
+    }
+#define LANCET_MEAN(f) \
+    if (n > 0) mean.f = (uint16_t)((float)sum.f / (float)n); else mean.f = 0; \
+    if (n0.f > 0) mean0.f = (uint16_t)std::ceil((float)sum0.f / (float)n0.f); else mean0.f = 0;
+    LANCET_MEAN(fwd) LANCET_MEAN(rev) LANCET_MEAN(minqv_fwd) LANCET_MEAN(minqv_rev)
+#undef LANCET_MEAN
+  }
+  void updateStats() {                                                               // :107-120
+    computeStats(alt_N, min_alt_N, min_non0_alt_N, mean_alt_N, mean_non0_alt_N);
+    computeStats(alt_T, min_alt_T, min_non0_alt_T, mean_alt_T, mean_non0_alt_T);
+    computeStats(ref_N, min_ref_N, min_non0_ref_N, mean_ref_N, mean_non0_ref_N);
+    computeStats(ref_T, min_ref_T, min_non0_ref_T, mean_ref_T, mean_non0_ref_T);
+  }
+  bool x() const { return code == 'x'; }
+  int getMinCovNfwd() const { return x() ? min_alt_N.minqv_fwd : min_alt_N.fwd; }   // :245-246
+  int getMinCovNrev() const { return x() ? min_alt_N.minqv_rev : min_alt_N.rev; }
+  int getMinCovTfwd() const { return x() ? min_alt_T.minqv_fwd : min_alt_T.fwd; }
+  int getMinCovTrev() const { return x() ? min_alt_T.minqv_rev : min_alt_T.rev; }
+  int getMinNon0CovNfwd() const { return x() ? min_non0_alt_N.minqv_fwd : min_non0_alt_N.fwd; }
+  int getMinNon0CovNrev() const { return x() ? min_non0_alt_N.minqv_rev : min_non0_alt_N.rev; }
+};
+
+// ---- Path_t, reference src/Path.hh:39-141, src/Path.cc ------------------------------------------------------
+struct Graph;
+struct Path {
+  std::vector<Node *> nodes;
+  std::vector<Edge *> edges;
+  std::vector<Edgedir> edgedir;
+  Ori dir = F; int len = 0, hasCycle = 0, match_bp = 0, snp_bp = 0, ins_bp = 0, del_bp = 0, K, score = 0, flag = 1;
+  explicit Path(int k) : K(k) {}
+  Node *curNode() const { return nodes.back(); }
+  std::string str() const {                                                          // Path.cc:69-105
+    std::string retval;
+    Ori d = edgedir_start(edgedir[0]);
+    for (size_t i = 0; i < nodes.size(); ++i) {
+      Node *n = nodes[i];
+      std::string nstr = n->str;
+      if (d == R) nstr = rc_str(nstr);
+      if (!n->isSpecial()) { if (retval.length() > 0) retval += nstr.substr(K - 1); else retval = nstr; }
+      if (i < edgedir.size()) d = edgedir_dest(edgedir[i]);
+    }
+    return retval;
+  }
+  std::vector<Cov> covDistr(char sample) const {                                     // Path.cc:110-175
+    std::vector<Cov> pc, nc;
+    Ori d = edgedir_start(edgedir[0]);
+    for (size_t i = 0; i < nodes.size(); ++i) {
+      nc.clear();
+      Node *n = nodes[i];
+      const std::vector<Cov> &C = sample == 'T' ? n->distT : n->distN;
+      if (d == R) { for (size_t j = C.size(); j > 0; --j) nc.push_back(C[j - 1]); }
+      else { for (size_t j = 0; j < C.size(); ++j) nc.push_back(C[j]); }
+      if (!n->isSpecial()) {
+        if (pc.size() == 0) { for (auto &c : nc) pc.push_back(c); }
+        else { for (size_t j = (K - 1); j < nc.size(); ++j) pc.push_back(nc[j]); }
+      }
+      if (i < edgedir.size()) d = edgedir_dest(edgedir[i]);
+    }
+    return pc;
+  }
+  Node *pathcontig(int pos) const {                                                  // Path.cc:291-314
+    int cur = 0;
+    for (Node *n : nodes) {
+      if (!n->isSpecial()) {
+        int span = n->str.length();
+        if (cur + span >= pos) return n;
+        cur += span - K + 1;
+      }
+    }
+    return nullptr;
+  }
+  int hasCycleWith(Node *node) {                                                     // Path.cc:319-333
+    if (hasCycle) return hasCycle;
+    for (Node *n : nodes) if (n == node) { hasCycle = 1; return 1; }
+    return 0;
+  }
+};
+
+// ---- global_align_aff, reference src/align.cc:235-364 (scores :28-31, tie rules :85-105) ------------------
+struct Cell { int score = 0; char tb = '*'; };
+void global_align_aff(const std::string &S, const std::string &T, std::string &S_aln, std::string &T_aln) {
+  const int MATCH = 2, MISMATCH = -4, GAP_OPEN = -8, GAP_EXTEND = -1;
+  S_aln.clear(); T_aln.clear();
+  int n = S.length(), m = T.length();
+  std::vector<std::vector<Cell>> M(n + 2, std::vector<Cell>(m + 2)), X(n + 2, std::vector<Cell>(m + 2)), Y(n + 2, std::vector<Cell>(m + 2));
+  for (int j = 0; j <= m; ++j) { X[0][j].score = GAP_OPEN + j * GAP_EXTEND; X[0][j].tb = '^'; M[0][j] = X[0][j]; }
+  for (int i = 0; i <= n; ++i) { Y[i][0].score = GAP_OPEN + i * GAP_EXTEND; Y[i][0].tb = '<'; M[i][0] = Y[i][0]; }
+  M[0][0].score = 0; M[0][0].tb = '*';
+  for (int j = 1; j <= m; ++j)
+    for (int i = 1; i <= n; ++i) {
+      { int a = X[i - 1][j].score + GAP_EXTEND, b = M[i - 1][j].score + GAP_OPEN;            // maxx
+        if (a > b) { X[i][j].score = a; X[i][j].tb = '-'; } else { X[i][j].score = b; X[i][j].tb = '<'; } }
+      { int a = Y[i][j - 1].score + GAP_EXTEND, b = M[i][j - 1].score + GAP_OPEN;            // maxy
+        if (a > b) { Y[i][j].score = a; Y[i][j].tb = '|'; } else { Y[i][j].score = b; Y[i][j].tb = '^'; } }
+      Cell r; r.score = M[i - 1][j - 1].score + (S[i - 1] == T[j - 1] ? MATCH : MISMATCH); r.tb = '\\';   // maxscorexy
+      if (X[i][j].score > r.score) { r.score = X[i][j].score; r.tb = '<'; }
+      if (Y[i][j].score > r.score) { r.score = Y[i][j].score; r.tb = '^'; }
+      M[i][j] = r;
+    }
+  std::string ts, tt;
+  int i = n, j = m;
+  bool forcey = false, forcex = false;
+  while (i > 0 || j > 0) {
+    char t = M[i][j].tb;
+    if (t == '*') break;
+    else if (forcex) { ts.push_back(S[i - 1]); tt.push_back('-'); if (X[i][j].tb == '<') forcex = false; --i; }
+    else if (t == '<') { ts.push_back(S[i - 1]); tt.push_back('-'); if (X[i][j].tb == '-') forcex = true; --i; }
+    else if (forcey) { ts.push_back('-'); tt.push_back(T[j - 1]); if (Y[i][j].tb == '^') forcey = false; --j; }
+    else if (t == '^') { ts.push_back('-'); tt.push_back(T[j - 1]); if (Y[i][j].tb == '|') forcey = true; --j; }
+    else if (t == '\\') { ts.push_back(S[i - 1]); tt.push_back(T[j - 1]); --i; --j; }
+    else break;
+  }
+  S_aln.assign(ts.rbegin(), ts.rend());
+  T_aln.assign(tt.rbegin(), tt.rend());
+}
+
+struct OutVariant {
+  int window, seq, chr_id, pos; char code, pbr, pba; uint16_t kmer; uint16_t cov[8];
+  std::string ref, alt, str;
+};
+
+// ---- Graph_t, reference src/Graph.hh / src/Graph.cc ------------------------------------------------------
+typedef std::unordered_map<std::string, Node *> MerTable;
+struct Graph {
+  const lancet_params *P;
+  bool verbose = false;
+  std::ostringstream *tr = nullptr;
+  int K = 0, MAX_LINK_LEN = 0;
+  MerTable nodes;
+  int totalreadbp = 0;
+  Node *source = nullptr, *sink = nullptr;
+  RefInfo *ref = nullptr;
+  bool is_ref_added = false;
+  std::vector<ReadInfo> reads;
+  std::vector<OutVariant> *out = nullptr;
+  int cur_window = 0, cur_chr = 0, emit_seq = 0;
+  uint64_t n_kmers = 0; uint32_t max_nodes = 0; int n_builds = 0;
+
+  void setK(int k) { K = k; MAX_LINK_LEN = (int)floor((double)K / 2.0); }              // Graph.hh:143
+  void clear(bool flag) {                                                            // Graph.cc:29-60
+    if (flag) { std::vector<ReadInfo>().swap(reads); is_ref_added = false; }
+    totalreadbp = 0;
+    for (auto &kv : nodes) delete kv.second;
+    nodes.clear();
+    MerTable().swap(nodes);
+    source = nullptr; sink = nullptr;
+    if (ref && flag) ref = nullptr;   // the RefInfo itself is owned by the caller here
+  }
+  Node *getNode(const std::string &id) { auto it = nodes.find(id); return it == nodes.end() ? nullptr : it->second; }
+
+  void trim(int rid) {                                                               // Graph.cc:355-384
+    ReadInfo &r = reads[rid];
+    const std::string &seq = r.seq, &qv = r.qv;
+    int trim3 = 0, trim5 = 0, len = seq.length();
+    auto S = [&](int i) -> char { return (i >= 0 && i < len) ? seq[i] : '\0'; };
+    auto Q = [&](int i) -> char { return (i >= 0 && i < len) ? qv[i] : '\0'; };
+    while ((!isDNA(S(trim5)) || (Q(trim5) < P->min_qual_trim)) && (trim5 < len)) ++trim5;
+    if (trim5 < len) {
+      while ((!isDNA(S(len - 1 - trim3)) || (Q(len - 1 - trim3) < P->min_qual_trim)) && (trim3 < len)) ++trim3;
+      r.isjunk = false;
+      for (int i = trim5; i < len - trim3; ++i) if (!isDNA(seq[i])) { r.isjunk = true; break; }
+    } else r.isjunk = true;
+    r.trm5 = trim5; r.trm3 = trim3;
+  }
+
+  void loadSequence(int readid, const std::string &seq, const std::string &qv, bool isRef, unsigned strand) {   // Graph.cc:119-349
+    if (!isRef) totalreadbp += seq.length();
+    CMer uc, vc; std::string uc_qv, vc_qv;
+    Node *unode = nullptr, *vnode = nullptr;
+    MerTable::iterator ui, vi;
+    int sample = reads[readid].label;
+    int end = (int)seq.length() - K;
+    for (int offset = 0; offset < end; ++offset) {
+      ++n_kmers;
+      if (offset == 0) {
+        uc.set(seq.substr(offset, K)); vc.set(seq.substr(offset + 1, K));
+        uc_qv = qv.substr(offset, K); vc_qv = qv.substr(offset + 1, K);
+        if (uc.ori == R) std::reverse(uc_qv.begin(), uc_qv.end());
+        if (vc.ori == R) std::reverse(vc_qv.begin(), vc_qv.end());
+      } else {
+        uc = vc; uc_qv = vc_qv;
+        vc.set(seq.substr(offset + 1, K)); vc_qv = qv.substr(offset + 1, K);
+        if (vc.ori == R) std::reverse(vc_qv.begin(), vc_qv.end());
+      }
+      if (offset == 0) { ui = nodes.find(uc.mer); vi = nodes.find(vc.mer); }
+      else { ui = vi; vi = nodes.find(vc.mer); }
+      bool uf = false, vf = false;
+      if (ui != nodes.end()) { uf = true; unode = ui->second; }
+      if (vi != nodes.end()) { vf = true; vnode = vi->second; }
+      if (!uf) { ui = nodes.insert({uc.mer, new Node(uc.mer)}).first; unode = ui->second; unode->MIN_QUAL = P->min_qual_call; unode->K = K; }
+      if (!vf) { vi = nodes.insert({vc.mer, new Node(vc.mer)}).first; vnode = vi->second; vnode->MIN_QUAL = P->min_qual_call; vnode->K = K; }
+      // NOTE: as in the reference, `ui` may dangle-by-rehash semantics do not matter (iterators stay valid
+      // across rehash for unordered_map) and unode==vnode is possible (homopolymers).
+      if (sample == LANCET_NML) { unode->isNormal = true; vnode->isNormal = true; unode->updateCovStatus('N'); vnode->updateCovStatus('N'); }
+      if (seqAboveQual(uc_qv, P->min_qual_call) && seqAboveQual(vc_qv, P->min_qual_call)) {
+        if (sample == LANCET_TMR) { unode->isTumor = true; vnode->isTumor = true; unode->updateCovStatus('T'); vnode->updateCovStatus('T'); }
+      }
+      unode->addMateName(reads[readid].name, reads[readid].mate_order);
+      vnode->addMateName(reads[readid].name, reads[readid].mate_order);
+      if (!isRef) {
+        if (offset == 0) {
+          bool ovl = unode->hasOverlappingMate(reads[readid].name, reads[readid].mate_order);
+          if (!ovl) {
+            unode->incCov(strand, sample);
+            unode->updateCovDistr((int)unode->getCov(strand, sample), uc_qv, strand, sample);
+            ref->updateCoverage(uc.mer, (int)unode->getCov(strand, sample), strand, sample);
+          }
+        }
+        bool ovl = vnode->hasOverlappingMate(reads[readid].name, reads[readid].mate_order);
+        if (!ovl) {
+          vnode->incCov(strand, sample);
+          vnode->updateCovDistr((int)vnode->getCov(strand, sample), vc_qv, strand, sample);
+          ref->updateCoverage(vc.mer, (int)vnode->getCov(strand, sample), strand, sample);
+        }
+      }
+      Edgedir fdir = FF, rdir = FF;
+      if (uc.ori == F && vc.ori == F) { fdir = FF; rdir = RR; }
+      else if (uc.ori == F && vc.ori == R) { fdir = FR; rdir = FR; }
+      else if (uc.ori == R && vc.ori == F) { fdir = RF; rdir = RF; }
+      else { fdir = RR; rdir = FF; }
+      unode->addEdge(vc.mer, fdir);
+      vnode->addEdge(uc.mer, rdir);
+    }
+  }
+
+  void buildgraph(RefInfo *refinfo) {                                                // Graph.cc:530-589
+    ref = refinfo;
+    if (!is_ref_added) {
+      ReadInfo r; r.label = REF_LABEL; r.seq = ref->rawseq; r.qv = std::string(ref->rawseq.size(), 'K');
+      r.code = 'R'; r.strand = LANCET_FWD; r.mate_order = 0; r.name = 0xffffffffu;
+      reads.push_back(r);
+      is_ref_added = true;
+    }
+    ++n_builds;
+    for (size_t i = 0; i < reads.size(); ++i) {
+      if (reads[i].isjunk) continue;
+      std::string seq, qv;
+      int len = reads[i].seq.length(), t5 = reads[i].trm5, t3 = reads[i].trm3;
+      if (t5 || t3) { seq = reads[i].seq.substr(t5, len - t5 - t3); qv = reads[i].qv.substr(t5, len - t5 - t3); }
+      else { seq = reads[i].seq; qv = reads[i].qv; }
+      loadSequence(i, seq, qv, reads[i].label == REF_LABEL, reads[i].strand);
+    }
+    for (auto &kv : nodes) kv.second->computeMinCov();
+    if (nodes.size() > max_nodes) max_nodes = nodes.size();
+    ref->computeCoverage(LANCET_TMR);
+    ref->computeCoverage(LANCET_NML);
+  }
+
+  void printStats(int compid) {                                                      // Graph.cc:3674-3691
+    int edgecnt = 0, span = 0;
+    for (auto &kv : nodes) if (kv.second->comp == compid) { edgecnt += kv.second->edges.size(); span += kv.second->strlen_(); }
+    *tr << "  " << compid << ": nodes: " << nodes.size() << " edges: " << edgecnt << " span: " << span << std::endl;
+  }
+
+  int markRef(Node *n) {                                                             // Node.cc:271-295
+    if (n->isSource || n->isSink) return 1;
+    CMer c;
+    n->touchRef = false;
+    for (unsigned i = 0; i < n->str.length() - K + 1; ++i) {
+      c.set(n->str.substr(i, K));
+      if (ref->hasMer(c.mer)) { n->touchRef = true; return 1; }
+    }
+    return 0;
+  }
+  void markRefNodes() {                                                              // Graph.cc:2233-2248
+    if (verbose) *tr << std::endl << "mark refnodes" << std::endl;
+    int n = 0, refnodes = 0;
+    for (auto &kv : nodes) { ++n; refnodes += markRef(kv.second); kv.second->comp = 0; }
+    if (verbose) *tr << " nodes: " << n << " refnodes: " << refnodes << std::endl;
+  }
+
+  void removeNode(Node *node) {                                                      // Graph.cc:2768-2784
+    node->dead = true;
+    for (size_t i = 0; i < node->edges.size(); ++i) {
+      Node *nn = getNode(node->edges[i].to);
+      if (nn && nn != node) nn->removeEdge(node->id, fliplink(node->edges[i].dir));
+    }
+  }
+  void cleanDead() {                                                                 // Graph.cc:2737-2762
+    std::set<std::string> deadnodes;
+    for (auto &kv : nodes) if (kv.second->dead) deadnodes.insert(kv.second->id);
+    if (verbose) *tr << "  removing " << deadnodes.size() << " dead nodes" << std::endl;
+    for (auto &d : deadnodes) { auto mi = nodes.find(d); delete mi->second; nodes.erase(mi); }
+  }
+
+  void compressNode(Node *node, Ori dir) {                                           // Graph.cc:2486-2706
+    while (true) {
+      int uniqueid = node->getBuddy(dir);
+      if (uniqueid == -1) return;
+      if (node->isTandem()) return;
+      Edgedir edir = node->edges[uniqueid].dir;
+      Ori bdir = F;
+      if (edir == FF || edir == RF) bdir = R;
+      Node *buddy = getNode(node->edges[uniqueid].to);
+      if (buddy->isTandem()) return;
+      int buniqueid = buddy->getBuddy(bdir);
+      if (buniqueid == -1) return;
+      std::string astr = node->str;
+      if (dir == R) { astr = rc_str(astr); node->revCovDistr(); }
+      std::string bstr = buddy->str;
+      if (edgedir_dest(edir) == R) { bstr = rc_str(bstr); buddy->revCovDistr(); }
+      std::string mstr = astr + bstr.substr(K - 1);
+      if (dir == R) mstr = rc_str(mstr);
+      node->str = mstr;
+      int amerlen = astr.length() - K + 1, bmerlen = bstr.length() - K + 1;
+      float ntf = node->cov_tf, nnf = node->cov_nf, ntr = node->cov_tr, nnr = node->cov_nr;
+      float ctf = buddy->cov_tf, cnf = buddy->cov_nf, ctr = buddy->cov_tr, cnr = buddy->cov_nr;
+      for (unsigned j = (K - 1); j < buddy->distT.size(); ++j) {
+        node->distT.push_back(buddy->distT[j]); node->distN.push_back(buddy->distN[j]); node->status.push_back(buddy->status[j]);
+      }
+      node->computeMinCov();
+      node->cov_tf = ((ntf * amerlen) + (ctf * bmerlen)) / (amerlen + bmerlen);
+      node->cov_nf = ((nnf * amerlen) + (cnf * bmerlen)) / (amerlen + bmerlen);
+      node->cov_tr = ((ntr * amerlen) + (ctr * bmerlen)) / (amerlen + bmerlen);
+      node->cov_nr = ((nnr * amerlen) + (cnr * bmerlen)) / (amerlen + bmerlen);
+      if (dir == R) node->revCovDistr();
+      buddy->dead = true;
+      if (buddy->isRef) node->isRef = true;
+      if (buddy->isNormal) node->isNormal = true;
+      if (buddy->isTumor) node->isTumor = true;
+      node->edges.erase(node->edges.begin() + uniqueid);
+      for (int i = 0; i < (int)buddy->edges.size(); ++i) {
+        if (i == buniqueid) continue;
+        Edge ne = buddy->edges[i];
+        if (edir == FR || edir == RF) ne.dir = flipme(ne.dir);
+        Node *other = getNode(ne.to);
+        if (other == buddy) { ne.to = node->id; node->edges.push_back(ne); }
+        else { node->edges.push_back(ne); other->updateEdge(buddy->id, fliplink(buddy->edges[i].dir), node->id, fliplink(ne.dir)); }
+      }
+    }
+  }
+  void compress(int compid) {                                                        // Graph.cc:2712-2732
+    if (verbose) *tr << "compressing graph:";
+    for (auto mi = nodes.begin(); mi != nodes.end(); ++mi) {
+      if (mi->second->comp == compid) {
+        if (mi->second->dead) continue;
+        if (mi->second->isSpecial()) continue;
+        compressNode(mi->second, F);
+        compressNode(mi->second, R);
+      }
+    }
+    cleanDead();
+  }
+  double avgcov() const { return ((double)totalreadbp) / ((double)ref->rawseq.length()); }
+  void removeLowCov(bool docompression, int compid) {                                // Graph.cc:2790-2827
+    if (verbose) *tr << std::endl << "removing low coverage:";
+    int low = 0;
+    double avg = avgcov();
+    for (auto mi = nodes.begin(); mi != nodes.end(); ++mi) {
+      if (mi->second->comp == compid) {
+        Node *node = mi->second;
+        if (node->isSpecial()) continue;
+        if ((node->mincovQV <= P->low_cov_threshold) || (node->mincovQV <= (P->min_cov_ratio * avg)) ||
+            (node->totTmr() == 1 && node->totNml() == 1)) { ++low; removeNode(node); }
+      }
+    }
+    if (verbose) *tr << " found " << low;
+    cleanDead();
+    if (docompression) compress(compid);
+    if (verbose) printStats(compid);
+  }
+  void removeShortLinks(int compid) {                                                // Graph.cc:2833-2880
+    int links = 0;
+    double avg = avgcov();
+    if (verbose) *tr << std::endl << "remove short links: ";
+    for (auto mi = nodes.begin(); mi != nodes.end(); ++mi) {
+      if (mi->second->comp == compid) {
+        Node *cur = mi->second;
+        if (cur->isSpecial()) continue;
+        int deg = cur->edges.size(), len = cur->getSize();
+        if ((deg >= 2) && (len < MAX_LINK_LEN) && (cur->mincov <= floor(sqrt(avg)))) {
+          int LEN = 0; std::string MOTIF = "";
+          findTandems(cur->str, P->max_unit_len, P->min_report_units, P->min_report_len, P->dist_from_str, K - 1, LEN, MOTIF);
+          if (LEN == 0) { removeNode(cur); ++links; }
+        }
+      }
+    }
+    if (verbose) *tr << " removed links: " << links << std::endl;
+    if (links) compress(compid);
+    if (verbose) printStats(compid);
+  }
+  void removeTips(int compid) {                                                      // Graph.cc:2885-2926
+    int tips = 0, round = 0;
+    do {
+      ++round; tips = 0;
+      if (verbose) *tr << std::endl << "remove tips round: " << round;
+      for (auto mi = nodes.begin(); mi != nodes.end(); ++mi) {
+        if (mi->second->comp == compid) {
+          Node *cur = mi->second;
+          if (cur->isSpecial()) continue;
+          int deg = cur->edges.size(), len = cur->strlen_() - K + 1;
+          if ((deg <= 1) && (len < P->max_tip_len)) { removeNode(cur); ++tips; }
+        }
+      }
+      if (verbose) *tr << " removed: " << tips << std::endl;
+      if (tips) compress(compid);
+    } while (tips);
+    if (verbose) printStats(compid);
+  }
+
+  int markConnectedComponents() {                                                    // Graph.cc:2252-2336
+    if (verbose) *tr << std::endl << "connected components" << std::endl;
+    int n = 0, refnodes = 0;
+    ref->refcompids.clear();
+    for (auto &kv : nodes) { ++n; kv.second->comp = 0; }
+    int comp = 0, refcomp = 0;
+    for (auto mi = nodes.begin(); mi != nodes.end(); ++mi) {
+      if (mi->second->comp != 0) continue;
+      ++comp;
+      std::deque<Node *> Q;
+      Q.push_back(mi->second);
+      int touches = 0;
+      while (!Q.empty()) {
+        Node *cur = Q.front(); Q.pop_front();
+        if (cur->comp == 0) {
+          cur->comp = comp;
+          if (cur->touchRef) ++touches;
+          for (auto &e : cur->edges) Q.push_back(getNode(e.to));
+        }
+      }
+      if (touches) { ++refcomp; ref->refcompids.insert(comp); }
+    }
+    ref->refnodes = refnodes; ref->refcomp = refcomp; ref->allcomp = comp;
+    if (verbose) {
+      *tr << " nodes: " << n << " refnodes: " << refnodes << " comp: " << comp << " refcomp: " << refcomp << " refcompids: ";
+      for (int c : ref->refcompids) *tr << " " << c;
+      *tr << std::endl;
+    }
+    return comp;
+  }
+
+  void markRefEnds(int compid) {                                                     // Graph.cc:2028-2228
+    CMer source_mer, sink_mer, tmp;
+    int source_offset = -1, sink_offset = -1, offset;
+    ref->trim5 = -1; ref->trim3 = -1;
+    source = nullptr; sink = nullptr;
+    bool ambiguous = false;
+    for (offset = 0; offset < (int)ref->rawseq.length(); ++offset) {
+      tmp.set(ref->rawseq.substr(offset, K));
+      Node *t = getNode(tmp.mer);
+      if (t && (t->totCov() >= P->cov_threshold) && (t->comp == compid)) {
+        if (source == nullptr) { source = t; source_mer = tmp; source_offset = offset; }
+        else if (source == t) { source = nullptr; ambiguous = true; break; }
+      }
+    }
+    if (ambiguous) { if (verbose) *tr << "Ambiguous match to reference for source" << std::endl; return; }
+    if (!source) { if (verbose) *tr << "No match to reference for source" << std::endl; return; }
+    ambiguous = false;
+    for (offset = (int)ref->rawseq.length() - K; offset >= 0; --offset) {
+      tmp.set(ref->rawseq.substr(offset, K));
+      Node *t = getNode(tmp.mer);
+      if (t && (t->totCov() >= P->cov_threshold) && (t->comp == compid)) {
+        if (sink == nullptr) { sink = t; sink_mer = tmp; sink_offset = offset; }
+        else if (sink == t) { sink = nullptr; ambiguous = true; break; }
+      }
+    }
+    if (ambiguous) { if (verbose) *tr << "Ambiguous match to reference for sink" << std::endl; return; }
+    if (!sink) { if (verbose) *tr << "No match to reference for sink" << std::endl; return; }
+    int ref_dist = sink_offset - source_offset + K;
+    sink_offset = ref->rawseq.length() - sink_offset - K;
+    ref->seq = ref->rawseq.substr(source_offset, ref_dist);
+    if (verbose) *tr << "ref trim5: " << source_offset << " trim3: " << sink_offset << " uncovered: " << source_offset + sink_offset
+                     << " ref_dist: " << ref_dist << std::endl;
+    ref->trim5 = source_offset; ref->trim3 = sink_offset;
+    std::ostringstream sid; sid << "source" << compid;
+    Node *ns = new Node(sid.str());
+    ns->comp = compid;
+    Edgedir sourcedir = FF;
+    if (source_mer.ori == R) sourcedir = FR;
+    for (int i = (int)source->edges.size() - 1; i >= 0; --i) {
+      if (edgedir_start(source->edges[i].dir) == flipdir(source_mer.ori)) {
+        Node *other = getNode(source->edges[i].to);
+        if (other != nullptr && other != source) {
+          other->removeEdge(source->id, fliplink(source->edges[i].dir));
+          source->edges.erase(source->edges.begin() + i);
+        }
+      }
+    }
+    ns->addEdge(source_mer.mer, sourcedir);
+    ns->isSource = true;
+    source->addEdge(ns->id, fliplink(sourcedir));
+    source = ns;
+    nodes.insert({ns->id, ns});
+    std::ostringstream kid; kid << "sink" << compid;
+    Node *nk = new Node(kid.str());
+    nk->comp = compid;
+    Edgedir sinkdir = RR;
+    if (sink_mer.ori == R) sinkdir = FF;
+    for (int i = (int)sink->edges.size() - 1; i >= 0; --i) {
+      if (edgedir_start(sink->edges[i].dir) == sink_mer.ori) {
+        Node *other = getNode(sink->edges[i].to);
+        if (other != nullptr && other != sink) {
+          other->removeEdge(sink->id, fliplink(sink->edges[i].dir));
+          sink->edges.erase(sink->edges.begin() + i);
+        }
+      }
+    }
+    nk->addEdge(sink_mer.mer, sinkdir);
+    nk->isSink = true;
+    sink->addEdge(nk->id, fliplink(sinkdir));
+    sink = nk;
+    nodes.insert({nk->id, nk});
+  }
+
+  void hasCycleRec(Node *node, Ori dir, bool *ans) {                                 // Graph.cc:651-681
+    if (node != nullptr && !(*ans)) {
+      node->color = 2;
+      for (size_t i = 0; i < node->edges.size(); ++i) {
+        Edge &e = node->edges[i];
+        if (isDir(e.dir, dir)) {
+          Node *other = getNode(e.to);
+          if (other->isSpecial()) continue;
+          if (other->color == 2) { *ans = true; break; }
+          if (other->color == 1) hasCycleRec(other, edgedir_dest(e.dir), ans);
+        }
+      }
+      node->color = 3;
+    }
+  }
+  bool hasCycle() {                                                                  // Graph.cc:593-625
+    bool a1 = false, a2 = false, ans = false;
+    if (source != nullptr && sink != nullptr) {
+      for (auto &kv : nodes) { if (kv.second->isSpecial()) continue; kv.second->color = 1; }
+      hasCycleRec(source, F, &a1);
+      hasCycleRec(source, R, &a2);
+      ans = a1 || a2;
+    }
+    if (ans && verbose) *tr << "Cycle found in the graph (kmer = " << K << ")!" << std::endl;
+    return ans;
+  }
+
+  Path *bfs(Node *src, Node *snk, Ori dir) {                                         // Graph.cc:1299-1425
+    int complete = 0, visit = 0;
+    int reflen = ref->seq.length();
+    std::deque<Path *> Q;
+    Path *path = new Path(K);
+    path->nodes.push_back(src); path->dir = dir; path->len = K;
+    Path *best = nullptr;
+    Q.push_back(path);
+    while (!Q.empty()) {
+      ++visit;
+      if (P->dfs_limit && visit > P->dfs_limit) { if (verbose) *tr << "WARNING: DFS_LIMIT (" << P->dfs_limit << ") exceeded" << std::endl; break; }
+      path = Q.front(); Q.pop_front();
+      Node *cur = path->curNode();
+      if (cur == snk && path->flag == 0) {
+        ++complete;
+        if (best == nullptr) best = new Path(*path);
+        else if (path->score > best->score) { delete best; best = new Path(*path); }
+      } else if (path->len > reflen + P->max_indel_len) {
+      } else {
+        for (size_t i = 0; i < cur->edges.size(); ++i) {
+          Edge *edge = &cur->edges[i];
+          if (isDir(edge->dir, path->dir)) {
+            Node *other = getNode(edge->to);
+            if (!path->hasCycle) path->hasCycleWith(other);
+            Path *np = new Path(*path);
+            np->nodes.push_back(other); np->edges.push_back(edge); np->edgedir.push_back(edge->dir);
+            np->dir = edgedir_dest(edge->dir);
+            np->len = path->len + other->strlen_() - K + 1;
+            np->flag = path->flag * edge->flag;
+            if (edge->flag == 0) np->score = path->score + 1;
+            Q.push_back(np);
+          }
+        }
+      }
+      delete path;
+    }
+    while (!Q.empty()) { delete Q.front(); Q.pop_front(); }
+    if (complete == 0) { if (best) delete best; best = nullptr; }
+    return best;
+  }
+
+  bool findRepeatsInGraphPaths() {                                                   // Graph.cc:686-730
+    if (verbose) *tr << std::endl << "looking for near-perfect repeats:" << std::endl;
+    if (source == nullptr || sink == nullptr) { if (verbose) *tr << "Missing source or sink" << std::endl; return false; }
+    if (verbose) *tr << std::endl << "searching from " << source->id << " to " << sink->id << " dir: " << F << std::endl;
+    bool answer = false;
+    std::vector<Edge *> edges;
+    while (true) {
+      Path *path = bfs(source, sink, F);
+      if (path == nullptr) break;
+      if (isAlmostRepeat(path->str(), K, P->max_mismatch)) {
+        answer = true;
+        if (verbose) *tr << "Near-perfect repeat in assembled sequence for kmer " << K << std::endl;
+        break;    // (the reference leaks `path` here)
+      }
+      for (Edge *e : path->edges) { e->flag = 1; edges.push_back(e); }
+      delete path;
+    }
+    for (Edge *e : edges) e->flag = 0;
+    return answer;
+  }
+
+  void processPath(Path *path, int &complete, int &perfect, int &withsnps, int &withindel, int &withmix) {   // Graph.cc:788-1220
+    std::string refseq = ref->seq;
+    const int HD_CUTOFF = 5;
+    path->match_bp = path->snp_bp = path->ins_bp = path->del_bp = 0;
+    std::string ref_aln, path_aln;
+    std::vector<Cov> covN = path->covDistr('N'), covT = path->covDistr('T');
+    std::string pathseq = path->str();
+    int hd = HammingDistance(refseq, pathseq);
+    if (hd == -1 || hd > HD_CUTOFF) global_align_aff(refseq, pathseq, ref_aln, path_aln);
+    else { ref_aln = refseq; path_aln = pathseq; }
+    if (verbose) {      // printVerticalAlignment side effects (Graph.cc:749-783): the bp counters
+      for (size_t i = 0; i < ref_aln.length(); ++i) {
+        if (ref_aln[i] == path_aln[i]) ++path->match_bp;
+        else if (ref_aln[i] == '-') ++path->ins_bp;
+        else if (path_aln[i] == '-') ++path->del_bp;
+        else ++path->snp_bp;
+      }
+    }
+    unsigned pos_in_ref = 0, refpos = 0, pathpos = 0;
+    Node *spanner;
+    char code = '?', prev_code = '?';
+    std::vector<Transcript> ts;
+    bool bail = false;
+    for (unsigned i = 0; i < ref_aln.length(); ++i) {
+      prev_code = code;
+      if (ref_aln[i] == '-') { code = '^'; pos_in_ref = refpos; ++pathpos; }
+      else if (path_aln[i] == '-') { code = 'v'; pos_in_ref = refpos; ++refpos; }
+      else { code = '='; if (ref_aln[i] != path_aln[i]) code = 'x'; pos_in_ref = refpos; ++refpos; ++pathpos; }
+      spanner = path->pathcontig(pathpos);
+      if (spanner == nullptr) { bail = true; break; }
+      bool within_tumor_node = spanner->isStatusCnt('T');
+      int Pp = pathpos - 1;
+      Cov COVn = covN[Pp], COVt = covT[Pp];
+      Cov REFn = ref->getCovStructAt(pos_in_ref + ref->trim5, LANCET_NML);
+      Cov REFt = ref->getCovStructAt(pos_in_ref + ref->trim5, LANCET_TMR);
+      if (code != '=') {
+        unsigned rrpos = pos_in_ref + ref->refstart + ref->trim5;
+        unsigned n = ts.size();
+        int pr = i - 1, pa = i - 1;
+        while (pr >= 0 && ref_aln[pr] != 'A' && ref_aln[pr] != 'C' && ref_aln[pr] != 'G' && ref_aln[pr] != 'T') --pr;
+        while (pa >= 0 && path_aln[pa] != 'A' && path_aln[pa] != 'C' && path_aln[pa] != 'G' && path_aln[pa] != 'T') --pa;
+        if (n > 0 && prev_code != '=') {
+          Transcript &t = ts[n - 1];
+          if (within_tumor_node) t.isSomatic = true;
+          t.ref += ref_aln[i]; t.qry += path_aln[i];
+          t.end_pos = Pp; t.ref_end_pos = pos_in_ref;
+          if (code == '^' && t.code == code && t.pos == rrpos) { t.alt_N.push_back(COVn); t.alt_T.push_back(COVt); }
+          else if (code == 'v' && t.code == code && (t.pos + t.ref.length()) == rrpos) { t.ref_N.push_back(REFn); t.ref_T.push_back(REFt); }
+          else if (code == 'x' || t.code != code) {
+            t.code = 'c';
+            t.alt_N.push_back(COVn); t.alt_T.push_back(COVt); t.ref_N.push_back(REFn); t.ref_T.push_back(REFt);
+          }
+        } else {
+          ts.push_back(Transcript(rrpos, pos_in_ref, Pp + 1, code, ref_aln[i], path_aln[i], COVn, COVt, REFn, REFt,
+                                  pr >= 0 ? ref_aln[pr] : '\0', pa >= 0 ? path_aln[pa] : '\0', Pp, pos_in_ref, within_tumor_node));
+        }
+      }
+    }
+    (void)bail;
+    if (verbose) {
+      *tr << ">p_" << ref->chr << ":" << ref->refstart << "-" << ref->refend << "_" << complete << " cycle: " << path->hasCycle
+          << " match: " << path->match_bp << " snp: " << path->snp_bp << " ins: " << path->ins_bp << " del: " << path->del_bp;
+    }
+    for (size_t ti = 0; ti < ts.size(); ++ti) {
+      Transcript &t = ts[ti];
+      if (t.code != 'x') {
+        for (int j = 0; j <= K; ++j) {
+          unsigned idx1 = t.end_pos + j;
+          if (idx1 < covN.size()) {
+            spanner = path->pathcontig(idx1);
+            if (spanner == nullptr) break;
+            if (spanner->isStatusCnt('T')) t.isSomatic = true;
+            t.alt_N.push_back(covN[idx1]); t.alt_T.push_back(covT[idx1]);
+          }
+          unsigned idx2 = t.ref_end_pos + ref->trim5 + j;
+          t.ref_N.push_back(ref->getCovStructAt(idx2, LANCET_NML));
+          t.ref_T.push_back(ref->getCovStructAt(idx2, LANCET_TMR));
+        }
+      }
+      t.updateStats();
+      unsigned short RCNF = t.min_ref_N.fwd, RCNR = t.min_ref_N.rev, RCTF = t.min_ref_T.fwd, RCTR = t.min_ref_T.rev;
+      unsigned short ACNF = t.getMinCovNfwd(), ACNR = t.getMinCovNrev();
+      if (t.code != 'x') { ACNF = t.getMinNon0CovNfwd(); ACNR = t.getMinNon0CovNrev(); }
+      unsigned short ACTF = t.getMinCovTfwd(), ACTR = t.getMinCovTrev();
+      if (t.isSomatic) {
+        RCNF = t.mean_ref_N.fwd; RCNR = t.mean_ref_N.rev; RCTF = t.mean_ref_T.fwd; RCTR = t.mean_ref_T.rev;
+        ACNF = 0; ACNR = 0;
+      }
+      if (verbose) {
+        *tr << " " << t.pos << ":" << t.ref << "|" << t.qry << "|R:(" << RCNF << "+," << RCNR << "-)n,(" << RCTF << "+," << RCTR
+            << "-)t|A:(" << ACNF << "+," << ACNR << "-)n,(" << ACTF << "+," << ACTR << "-)t|HPref(0,0,0)n,(0,0,0)t|HPalt(0,0,0)n,(0,0,0)t|"
+            << t.prev_bp_ref << "|" << t.prev_bp_alt;
+      }
+      if (ACNF > 0 || ACNR > 0 || ACTF > 0 || ACTR > 0) {
+        int LEN = 0; std::string MOTIF = ""; std::ostringstream STR;
+        bool ans = findTandems(pathseq, P->max_unit_len, P->min_report_units, P->min_report_len, P->dist_from_str, t.start_pos, LEN, MOTIF);
+        if (ans) STR << LEN << MOTIF;
+        OutVariant v;
+        v.window = cur_window; v.seq = emit_seq++; v.chr_id = cur_chr; v.pos = (int)t.pos - 1;
+        v.code = t.code; v.pbr = t.prev_bp_ref; v.pba = t.prev_bp_alt; v.kmer = K;
+        v.cov[0] = RCNF; v.cov[1] = RCNR; v.cov[2] = RCTF; v.cov[3] = RCTR; v.cov[4] = ACNF; v.cov[5] = ACNR; v.cov[6] = ACTF; v.cov[7] = ACTR;
+        v.ref = t.ref; v.alt = t.qry; v.str = STR.str();
+        out->push_back(v);
+      }
+    }
+    if (verbose) *tr << std::endl;
+    if ((path->snp_bp + path->ins_bp + path->del_bp) == 0) ++perfect;
+    else if (path->snp_bp == 0) ++withindel;
+    else if ((path->ins_bp + path->del_bp) == 0) ++withsnps;
+    else ++withmix;
+    for (Node *n : path->nodes) ++n->onRefPath;
+  }
+
+  void eka() {                                                                       // Graph.cc:1430-1501
+    if (verbose) *tr << std::endl << "searching from " << source->id << " to " << sink->id << " dir: " << F << std::endl;
+    int complete = 0, allcycles = 0, perfect = 0, withsnps = 0, withindel = 0, withmix = 0;
+    while (true) {
+      Path *path = bfs(source, sink, F);
+      if (path == nullptr) break;
+      if (path->hasCycle) ++allcycles;
+      ++complete;
+      processPath(path, complete, perfect, withsnps, withindel, withmix);
+      for (Edge *e : path->edges) e->flag = 1;
+      delete path;
+    }
+    if (verbose) {
+      *tr << " refcomp: " << ref->refcomp << " refnodes: " << ref->refnodes - 2 << " complete: " << complete << " allcycles: " << allcycles << std::endl;
+      *tr << " perfect: " << perfect << " withsnps: " << withsnps << " withindel: " << withindel << " withmix: " << withmix
+          << " withmixindel: " << withmix + withindel << std::endl;
+    }
+  }
+  void countRefPath() {                                                              // Graph.cc:2420-2445
+    if (source) {
+      if (source != nullptr && sink != nullptr) eka();
+      int n = 0;
+      for (auto &kv : nodes) if (kv.second->onRefPath) ++n;                          // alignRefNodes :2399-2415
+      if (verbose) *tr << " Found " << n << " on ref path" << std::endl;
+    }
+  }
+};
+
+// ---- Microassembler::processGraph, reference src/Microassembler.cc:73-249 ----------------------------------
+int processGraph(Graph &g, RefInfo *refinfo, int graphCnt, lancet_window_stats *st) {
+  const lancet_params *P = g.P;
+  std::ostringstream &tr = *g.tr;
+  int mapped = 0;
+  for (auto &r : g.reads) if (r.code == 'M') ++mapped;
+  if (mapped <= 0) { st->status = LANCET_W_NO_READS; g.clear(true); return 0; }   // (the reference returns without clear)
+  if (g.verbose) {
+    tr << "== Processing " << graphCnt << ": " << refinfo->hdr << " numsequences: " << g.reads.size() << " mapped: " << mapped
+       << " bastards: " << (int)(g.reads.size() - mapped) << std::endl;
+    tr << "=====================================================" << std::endl;
+  }
+  bool rptInRef = false, rptInQry = false, cycleInGraph = false;
+  bool processed = false;
+  for (int k = P->min_k; k <= P->max_k; k += 2) {
+    g.setK(k);
+    refinfo->setK(k);
+    rptInRef = rptInQry = cycleInGraph = false;
+    if (isRepeat(refinfo->rawseq, k)) { if (g.verbose) tr << "Repeat in reference sequence for kmer " << k << std::endl; rptInRef = true; continue; }
+    if (isAlmostRepeat(refinfo->rawseq, k, P->max_mismatch)) { if (g.verbose) tr << "Near-perfect repeat in reference sequence for kmer " << k << std::endl; rptInRef = true; continue; }
+    g.buildgraph(refinfo);
+    st->final_k = k;
+    double avgcov = ((double)g.totalreadbp) / ((double)refinfo->rawseq.length());
+    if (g.verbose) {
+      tr << "reads: " << g.reads.size() << " reflen: " << refinfo->rawseq.length() << " readlen: " << g.totalreadbp << " cov: " << avgcov << std::endl;
+      g.printStats(0);
+    }
+    g.markRefNodes();
+    g.removeLowCov(false, 0);
+    int numcomp = g.markConnectedComponents();
+    for (int c = 1; c <= numcomp; ++c) {
+      if (g.verbose) g.printStats(c);
+      g.markRefEnds(c);
+      if (g.hasCycle()) { g.clear(false); cycleInGraph = true; break; }
+      g.compress(c);
+      if (g.verbose) g.printStats(c);
+      g.removeLowCov(true, c);
+      g.removeTips(c);
+      g.removeShortLinks(c);
+      if (g.hasCycle()) { g.clear(false); cycleInGraph = true; break; }
+      if (g.findRepeatsInGraphPaths()) { g.clear(false); rptInQry = true; break; }
+      g.countRefPath();
+    }
+    if (rptInQry || cycleInGraph) continue;
+    processed = true;
+    break;
+  }
+  g.clear(true);
+  if (g.verbose) {
+    if (rptInRef) tr << " Found repeat in reference" << std::endl;
+    if (rptInQry) tr << " Found repeat in assembly" << std::endl;
+    if (cycleInGraph) tr << " Found cycle in assembly" << std::endl;
+    tr << "FINISHED" << std::endl;
+  }
+  st->status = processed ? LANCET_W_OK : LANCET_W_K_EXHAUSTED;
+  return 1;
+}
+
+struct OracleResult {
+  std::vector<lancet_variant> variants;
+  std::string blob;
+  std::vector<lancet_window_stats> stats;
+  std::string trace;
+};
+
+}  // namespace
+
+extern "C" {
+
+// Runs the restated hot path over a batch.  chr_names (optional) are only used for the trace text.
+// Returns an opaque handle; accessors below.  verbose!=0 fills the trace (reference `-v` stderr subset).
+void *lancet_oracle_run(const lancet_params *P, const lancet_window_batch *b, const char *const *chr_names,
+                        const char *const *hdrs, int verbose) {
+  auto *res = new OracleResult();
+  std::ostringstream tr;
+  tr.setf(std::ios::fixed, std::ios::floatfield);     // reference src/Lancet.cc:622-623
+  tr.precision(1);
+  std::vector<OutVariant> out;
+  Graph g;
+  g.P = P; g.verbose = verbose != 0; g.tr = &tr; g.out = &out;
+  res->stats.resize(b->n_windows);
+  int graphCnt = 0;
+  for (int w = 0; w < b->n_windows; ++w) {
+    lancet_window_stats &st = res->stats[w];
+    memset(&st, 0, sizeof(st));
+    RefInfo ref;
+    ref.rawseq.assign(b->ref_bases + b->ref_off[w], b->ref_bases + b->ref_off[w + 1]);
+    ref.seq = ref.rawseq;
+    ref.chr = chr_names ? chr_names[b->chr_id[w]] : std::to_string(b->chr_id[w]);
+    ref.refstart = b->ref_start[w];
+    ref.refend = ref.refstart + (int)ref.rawseq.length();
+    ref.hdr = hdrs ? hdrs[w] : (ref.chr + ":" + std::to_string(ref.refstart) + "-" + std::to_string(ref.refend));
+    g.cur_window = w; g.cur_chr = b->chr_id[w]; g.emit_seq = 0;
+    g.n_kmers = 0; g.max_nodes = 0; g.n_builds = 0;
+    for (uint32_t r = b->read_begin[w]; r < b->read_begin[w + 1]; ++r) {             // Graph_t::addAlignment, Graph.cc:487-501
+      ReadInfo ri;
+      ri.label = b->label[r];
+      ri.seq.assign(b->seq + b->seq_off[r], b->seq + b->seq_off[r + 1]);
+      ri.qv.assign(b->qual + b->seq_off[r], b->qual + b->seq_off[r + 1]);
+      ri.code = b->mapped[r] ? 'M' : 'B';
+      ri.strand = b->strand[r]; ri.mate_order = b->mate[r]; ri.name = b->name_rank[r];
+      g.reads.push_back(ri);
+      g.trim((int)g.reads.size() - 1);
+    }
+    ++graphCnt;
+    size_t before = out.size();
+    processGraph(g, &ref, graphCnt, &st);
+    st.n_variants = (int)(out.size() - before);
+    st.n_kmers = g.n_kmers; st.max_nodes = g.max_nodes; st.n_builds = g.n_builds;
+  }
+  for (auto &v : out) {
+    lancet_variant lv; memset(&lv, 0, sizeof(lv));
+    lv.window = v.window; lv.seq_in_window = v.seq; lv.chr_id = v.chr_id; lv.pos = v.pos; lv.code = v.code;
+    lv.prev_bp_ref = v.pbr; lv.prev_bp_alt = v.pba; lv.kmer = v.kmer;
+    memcpy(lv.cov, v.cov, sizeof(lv.cov));
+    lv.ref_off = res->blob.size(); lv.ref_len = v.ref.size(); res->blob += v.ref;
+    lv.alt_off = res->blob.size(); lv.alt_len = v.alt.size(); res->blob += v.alt;
+    lv.str_off = res->blob.size(); lv.str_len = v.str.size(); res->blob += v.str;
+    res->variants.push_back(lv);
+  }
+  res->trace = tr.str();
+  return res;
+}
+uint32_t lancet_oracle_n_variants(void *h) { return ((OracleResult *)h)->variants.size(); }
+const lancet_variant *lancet_oracle_variants(void *h) { return ((OracleResult *)h)->variants.data(); }
+const char *lancet_oracle_blob(void *h) { return ((OracleResult *)h)->blob.data(); }
+uint32_t lancet_oracle_blob_len(void *h) { return ((OracleResult *)h)->blob.size(); }
+const lancet_window_stats *lancet_oracle_stats(void *h) { return ((OracleResult *)h)->stats.data(); }
+const char *lancet_oracle_trace(void *h) { return ((OracleResult *)h)->trace.c_str(); }
+void lancet_oracle_free(void *h) { delete (OracleResult *)h; }
+
+// Stand-alone pieces, exported so tests can pin kernels individually.
+int lancet_oracle_align(const char *S, const char *T, char *S_aln, char *T_aln, int cap) {
+  std::string a, b;
+  global_align_aff(S, T, a, b);
+  if ((int)a.size() + 1 > cap) return -1;
+  memcpy(S_aln, a.c_str(), a.size() + 1); memcpy(T_aln, b.c_str(), b.size() + 1);
+  return (int)a.size();
+}
+int lancet_oracle_is_repeat(const char *s, int k) { return isRepeat(s, k); }
+int lancet_oracle_is_almost_repeat(const char *s, int k, int mm) { return isAlmostRepeat(s, k, mm); }
+int lancet_oracle_find_tandems(const char *s, int mul, int mru, int mrl, int dfs, int pos, int *len, char *motif, int cap) {
+  int L = 0; std::string m;
+  bool a = findTandems(s, mul, mru, mrl, dfs, pos, L, m);
+  *len = L;
+  snprintf(motif, cap, "%s", m.c_str());
+  return a;
+}
+uint64_t lancet_oracle_std_hash(const char *s) { return std::hash<std::string>()(std::string(s)); }
+
+}  // extern "C"

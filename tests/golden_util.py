@@ -1,0 +1,66 @@
+"""Helpers shared by the parity tests: load tests/golden fixtures and turn them into window batches."""
+from __future__ import annotations
+
+import json
+import os
+import re
+
+import numpy as np
+
+from lancet_amd import frontend
+from lancet_amd.synth import SamRead
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(f[:-5] for f in os.listdir(GOLDEN) if f.endswith(".json"))
+
+_DIGEST = re.compile(
+    r"^(== Processing|Repeat in reference|Near-perfect repeat|reads: |  \d+: nodes:| nodes: |ref trim5|"
+    r"Ambiguous match|No match to reference|Cycle found|compressing graph|  removing |removing low coverage|"
+    r"remove tips round| removed|remove short links| Found |FINISHED|>p_| refcomp:| perfect:|"
+    r"searching from|Missing source|WARNING: DFS_LIMIT)")
+
+
+def digest_trace(text: str) -> str:
+    return "\n".join(l.rstrip() for l in text.splitlines() if _DIGEST.match(l)) + "\n"
+
+
+def load_case(name: str):
+    meta = json.load(open(os.path.join(GOLDEN, f"{name}.json")))
+    z = np.load(os.path.join(GOLDEN, f"{name}.reads.npz"))
+    ref = str(z["ref"])
+    rname = str(z["rname"])
+    reads = {}
+    for rg in ("tumor", "normal"):
+        rs = []
+        for i in range(len(z[f"{rg}_qname"])):
+            rs.append(SamRead(str(z[f"{rg}_qname"][i]), int(z[f"{rg}_flag"][i]), rname, int(z[f"{rg}_pos"][i]),
+                              int(z[f"{rg}_mapq"][i]), str(z[f"{rg}_cigar"][i]), str(z[f"{rg}_seq"][i]),
+                              str(z[f"{rg}_qual"][i]),
+                              {"AS": int(z[f"{rg}_as"][i]), "XS": int(z[f"{rg}_xs"][i]), "MD": str(z[f"{rg}_md"][i])}))
+        reads[rg] = rs
+    return meta, ref, rname, reads
+
+
+def case_params(meta):
+    """reference CLI flags of the case -> (padding, min_k, max_k)."""
+    flags = meta["flags"]
+    opt = {"--padding": 250, "--min-k": 11, "--max-k": 101}
+    for i in range(0, len(flags), 2):
+        opt[flags[i]] = int(flags[i + 1])
+    return opt["--padding"], opt["--min-k"], opt["--max-k"]
+
+
+def case_batch(name: str):
+    meta, ref, rname, reads = load_case(name)
+    padding, min_k, max_k = case_params(meta)
+    windows = frontend.tile_region(ref, rname, meta["region"], padding=padding)
+    batch, kept = frontend.batch_from_sam(windows, reads["tumor"], reads["normal"], max_k=max_k)
+    return meta, batch, kept, (min_k, max_k)
+
+
+def golden_vcf(name: str) -> str:
+    return open(os.path.join(GOLDEN, f"{name}.vcf")).read()
+
+
+def golden_trace(name: str) -> str:
+    return open(os.path.join(GOLDEN, f"{name}.trace.txt")).read()
