@@ -1,6 +1,7 @@
 """Helpers shared by the parity tests: load tests/golden fixtures and turn them into window batches."""
 from __future__ import annotations
 
+import functools
 import json
 import os
 import re
@@ -31,13 +32,10 @@ def load_case(name: str):
     rname = str(z["rname"])
     reads = {}
     for rg in ("tumor", "normal"):
-        rs = []
-        for i in range(len(z[f"{rg}_qname"])):
-            rs.append(SamRead(str(z[f"{rg}_qname"][i]), int(z[f"{rg}_flag"][i]), rname, int(z[f"{rg}_pos"][i]),
-                              int(z[f"{rg}_mapq"][i]), str(z[f"{rg}_cigar"][i]), str(z[f"{rg}_seq"][i]),
-                              str(z[f"{rg}_qual"][i]),
-                              {"AS": int(z[f"{rg}_as"][i]), "XS": int(z[f"{rg}_xs"][i]), "MD": str(z[f"{rg}_md"][i])}))
-        reads[rg] = rs
+        a = {k: z[f"{rg}_{k}"].tolist() for k in ("qname", "flag", "pos", "mapq", "cigar", "seq", "qual", "as", "xs", "md")}
+        reads[rg] = [SamRead(a["qname"][i], a["flag"][i], rname, a["pos"][i], a["mapq"][i], a["cigar"][i], a["seq"][i],
+                             a["qual"][i], {"AS": a["as"][i], "XS": a["xs"][i], "MD": a["md"][i]})
+                     for i in range(len(a["qname"]))]
     return meta, ref, rname, reads
 
 
@@ -50,6 +48,7 @@ def case_params(meta):
     return opt["--padding"], opt["--min-k"], opt["--max-k"]
 
 
+@functools.lru_cache(maxsize=None)
 def case_batch(name: str):
     meta, ref, rname, reads = load_case(name)
     padding, min_k, max_k = case_params(meta)
