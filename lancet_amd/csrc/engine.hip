@@ -1,0 +1,306 @@
+// engine.hip -- C-ABI of the MI355X micro-assembly engine (include/lancet_engine.h) on top of the kernels.
+//
+// Host responsibilities only: device memory, the upload/prep step (reads are trimmed and packed to
+// 2 bit/base + 1 quality bit/base on the GPU), the persistent-kernel launch, result read-back.
+// There is no CPU path: without a HIP device lancet_engine_create fails with LANCET_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "host_common.h"
+
+#define HIPCHK(e, call)                                                                           \
+  do { hipError_t _r = (call); if (_r != hipSuccess) { (e)->err = std::string(#call) + ": " + hipGetErrorString(_r); return LANCET_E_HIP; } } while (0)
+
+__global__ void __launch_bounds__(LANCET_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) window_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT) {
+  __shared__ WinShared S;
+  window_kernel_body(P, B, C, works, OUT, &S, (int)blockIdx.x);
+}
+
+__global__ void prep_kernel(const lancet_params *P, int n_reads, const char *seq, const char *qual, const uint32_t *seq_off,
+                            const uint8_t *label, const uint8_t *strand, const uint8_t *mate, const uint8_t *mapped,
+                            uint32_t *rinfo, uint32_t *bases, const uint32_t *bw, uint32_t *good, const uint32_t *gw) {
+  int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (r >= n_reads) return;
+  prep_read(P, seq, qual, seq_off[r], (int)(seq_off[r + 1] - seq_off[r]), label[r], strand[r], mate[r], mapped[r], &rinfo[r], bases, bw[r], good, gw[r]);
+}
+__global__ void ref_code_kernel(const char *ref, uint8_t *codes, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) codes[i] = (uint8_t)base_code(ref[i]);
+}
+
+struct DevBuf {
+  void *p = nullptr; size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = n + n / 4 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
+    cap = want; return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct lancet_engine {
+  lancet_params params;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  // device buffers
+  DevBuf d_params, d_batch, d_caps, d_out, d_works;
+  DevBuf d_chr, d_refstart, d_refoff, d_refasc, d_refcodes, d_readbegin, d_seqoff, d_seq, d_qual, d_label, d_strand, d_mate, d_mapped,
+      d_rinfo, d_name, d_bw, d_gw, d_bases, d_good;
+  DevBuf d_variants, d_blob, d_counters, d_stats, d_evtlen, d_evt, d_workmem;
+  EngineCaps caps;
+  int n_windows = 0, n_reads = 0, n_slots = 0;
+  bool uploaded = false, ran = false;
+  uint32_t evt_cap = 0;
+  size_t mem_budget = (size_t)32 << 30;
+  int max_slots = 2048;
+  uint32_t max_nodes_limit = 65536;
+  // host results
+  std::vector<lancet_variant> variants;
+  std::vector<char> blob;
+  std::vector<lancet_window_stats> stats;
+  std::vector<uint32_t> evt_len, evt;
+  float ms_all = 0, ms_kernel = 0;
+};
+
+extern "C" {
+
+void lancet_params_default(lancet_params *p) {
+  memset(p, 0, sizeof(*p));
+  p->min_k = 11; p->max_k = 101; p->max_tip_len = 11; p->cov_threshold = 5; p->low_cov_threshold = 1; p->dfs_limit = 1000000;
+  p->max_indel_len = 500; p->max_mismatch = 2; p->min_qual_trim = 10 + 33; p->min_qual_call = 17 + 33; p->max_unit_len = 4;
+  p->min_report_units = 3; p->min_report_len = 7; p->dist_from_str = 1; p->lr_mode = 0; p->min_cov_ratio = 0.01;
+}
+
+int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out) {
+  if (!p || !out) return LANCET_E_ARG;
+  *out = nullptr;
+  if (p->lr_mode) return LANCET_E_UNSUPPORTED;
+  if (p->max_k > 127 || p->min_k < 3 || p->max_unit_len > 8) return LANCET_E_UNSUPPORTED;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return LANCET_E_NO_DEVICE;
+  lancet_engine *e = new lancet_engine();
+  e->params = *p; e->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&e->stream) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
+      hipEventCreate(&e->ev1) != hipSuccess) { delete e; return LANCET_E_HIP; }
+  if (const char *s = getenv("LANCET_TRACE_WORDS")) e->evt_cap = (uint32_t)atoi(s);
+  if (const char *s = getenv("LANCET_MAX_SLOTS")) e->max_slots = atoi(s);
+  if (const char *s = getenv("LANCET_MEM_GB")) e->mem_budget = (size_t)atoi(s) << 30;
+  if (const char *s = getenv("LANCET_MAX_NODES")) e->max_nodes_limit = (uint32_t)atoi(s);
+  *out = e;
+  return LANCET_OK;
+}
+
+void lancet_engine_destroy(lancet_engine *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  DevBuf *all[] = {&e->d_params, &e->d_batch, &e->d_caps, &e->d_out, &e->d_works, &e->d_chr, &e->d_refstart, &e->d_refoff, &e->d_refasc,
+                   &e->d_refcodes, &e->d_readbegin, &e->d_seqoff, &e->d_seq, &e->d_qual, &e->d_label, &e->d_strand, &e->d_mate, &e->d_mapped,
+                   &e->d_rinfo, &e->d_name, &e->d_bw, &e->d_gw, &e->d_bases, &e->d_good, &e->d_variants, &e->d_blob, &e->d_counters,
+                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem};
+  for (DevBuf *b : all) b->release();
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+const char *lancet_engine_last_error(const lancet_engine *e) { return e ? e->err.c_str() : "null engine"; }
+
+// debug knob used by the tests: number of 32-bit trace words kept per window (0 = off)
+int lancet_engine_set_trace(lancet_engine *e, uint32_t words_per_window) { if (!e) return LANCET_E_ARG; e->evt_cap = words_per_window; return LANCET_OK; }
+
+static int up(lancet_engine *e, DevBuf &b, const void *src, size_t bytes) {
+  if (b.ensure(bytes ? bytes : 1)) { e->err = "hipMalloc failed"; return LANCET_E_OOM; }
+  if (bytes) HIPCHK(e, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, e->stream));
+  return LANCET_OK;
+}
+#define UP(buf, src, bytes) do { int _rc = up(e, buf, src, bytes); if (_rc) return _rc; } while (0)
+#define ENS(buf, bytes) do { if ((buf).ensure((bytes) ? (bytes) : 1)) { e->err = "hipMalloc failed"; return LANCET_E_OOM; } } while (0)
+
+int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
+  if (!e || !b || b->n_windows < 0) return LANCET_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  e->uploaded = false; e->ran = false;
+  const int nw = b->n_windows;
+  const uint32_t R = nw ? b->read_begin[nw] : 0;
+  const uint32_t nbases = R ? b->seq_off[R] : 0;
+  const uint32_t nref = nw ? b->ref_off[nw] : 0;
+  e->n_windows = nw; e->n_reads = (int)R;
+  if (nw == 0) { e->uploaded = true; return LANCET_OK; }
+  for (int w = 0; w < nw; ++w) if (b->ref_off[w + 1] - b->ref_off[w] > LC_MAXW) { e->err = "window longer than LC_MAXW"; return LANCET_E_UNSUPPORTED; }
+  e->caps = lc_caps_for_batch(b, &e->params, e->evt_cap, e->max_nodes_limit);
+  // ---- inputs
+  UP(e->d_params, &e->params, sizeof(lancet_params));
+  UP(e->d_chr, b->chr_id, sizeof(int32_t) * nw);
+  UP(e->d_refstart, b->ref_start, sizeof(int32_t) * nw);
+  UP(e->d_refoff, b->ref_off, sizeof(uint32_t) * (nw + 1));
+  UP(e->d_refasc, b->ref_bases, nref);
+  UP(e->d_readbegin, b->read_begin, sizeof(uint32_t) * (nw + 1));
+  UP(e->d_seqoff, b->seq_off, sizeof(uint32_t) * (R + 1));
+  UP(e->d_seq, b->seq, nbases);
+  UP(e->d_qual, b->qual, nbases);
+  UP(e->d_label, b->label, R); UP(e->d_strand, b->strand, R); UP(e->d_mate, b->mate, R); UP(e->d_mapped, b->mapped, R);
+  UP(e->d_name, b->name_rank, sizeof(uint32_t) * R);
+  std::vector<uint32_t> bw(R + 1), gw(R + 1);
+  uint32_t bo = 0, go = 0;
+  for (uint32_t r = 0; r < R; ++r) { uint32_t len = b->seq_off[r + 1] - b->seq_off[r]; bw[r] = bo; gw[r] = go; bo += (len + 15) / 16; go += (len + 31) / 32; }
+  bw[R] = bo; gw[R] = go;
+  UP(e->d_bw, bw.data(), sizeof(uint32_t) * (R + 1));
+  UP(e->d_gw, gw.data(), sizeof(uint32_t) * (R + 1));
+  ENS(e->d_bases, sizeof(uint32_t) * (bo + 1)); ENS(e->d_good, sizeof(uint32_t) * (go + 1)); ENS(e->d_rinfo, sizeof(uint32_t) * (R + 1));
+  ENS(e->d_refcodes, nref + 1);
+  // ---- prep on the device: Graph_t::trim + packing, reference -> codes
+  if (R) hipLaunchKernelGGL(prep_kernel, dim3((R + 255) / 256), dim3(256), 0, e->stream, (const lancet_params *)e->d_params.p, (int)R,
+                            (const char *)e->d_seq.p, (const char *)e->d_qual.p, (const uint32_t *)e->d_seqoff.p, (const uint8_t *)e->d_label.p,
+                            (const uint8_t *)e->d_strand.p, (const uint8_t *)e->d_mate.p, (const uint8_t *)e->d_mapped.p, (uint32_t *)e->d_rinfo.p,
+                            (uint32_t *)e->d_bases.p, (const uint32_t *)e->d_bw.p, (uint32_t *)e->d_good.p, (const uint32_t *)e->d_gw.p);
+  hipLaunchKernelGGL(ref_code_kernel, dim3((nref + 255) / 256), dim3(256), 0, e->stream, (const char *)e->d_refasc.p, (uint8_t *)e->d_refcodes.p, nref);
+  HIPCHK(e, hipGetLastError());
+  DevBatch db;
+  db.n_windows = nw; db.chr_id = (const int32_t *)e->d_chr.p; db.ref_start = (const int32_t *)e->d_refstart.p;
+  db.ref_off = (const uint32_t *)e->d_refoff.p; db.ref_codes = (const uint8_t *)e->d_refcodes.p; db.read_begin = (const uint32_t *)e->d_readbegin.p;
+  db.rinfo = (const uint32_t *)e->d_rinfo.p; db.name_rank = (const uint32_t *)e->d_name.p; db.base_woff = (const uint32_t *)e->d_bw.p;
+  db.good_woff = (const uint32_t *)e->d_gw.p; db.bases = (const uint32_t *)e->d_bases.p; db.good = (const uint32_t *)e->d_good.p;
+  UP(e->d_batch, &db, sizeof(db));
+  UP(e->d_caps, &e->caps, sizeof(e->caps));
+  // ---- work space: as many slots as fit (and are useful)
+  size_t slot_bytes = lc_work_carve(nullptr, nullptr, e->caps);
+  int slots = e->max_slots;
+  if (slots > nw) slots = nw;
+  while (slots > 1 && (size_t)slots * slot_bytes > e->mem_budget) slots /= 2;
+  e->n_slots = slots;
+  ENS(e->d_workmem, (size_t)slots * slot_bytes);
+  std::vector<Work> works(slots);
+  for (int s = 0; s < slots; ++s) lc_work_carve(&works[s], (char *)e->d_workmem.p + (size_t)s * slot_bytes, e->caps);
+  UP(e->d_works, works.data(), sizeof(Work) * slots);
+  // ---- outputs
+  ENS(e->d_variants, sizeof(lancet_variant) * e->caps.var_cap);
+  ENS(e->d_blob, e->caps.blob_cap);
+  ENS(e->d_counters, 64);
+  ENS(e->d_stats, sizeof(lancet_window_stats) * nw);
+  ENS(e->d_evtlen, sizeof(uint32_t) * nw);
+  ENS(e->d_evt, sizeof(uint32_t) * (size_t)nw * (e->caps.evt_cap ? e->caps.evt_cap : 1));
+  DevOut o;
+  o.variants = (lancet_variant *)e->d_variants.p; o.blob = (char *)e->d_blob.p;
+  o.n_variants = (uint32_t *)e->d_counters.p; o.n_blob = (uint32_t *)e->d_counters.p + 1; o.queue_head = (uint32_t *)e->d_counters.p + 2;
+  o.stats = (lancet_window_stats *)e->d_stats.p; o.evt_len = (uint32_t *)e->d_evtlen.p; o.evt_out = (uint32_t *)e->d_evt.p;
+  UP(e->d_out, &o, sizeof(o));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->uploaded = true;
+  return LANCET_OK;
+}
+
+int lancet_engine_run(lancet_engine *e) {
+  if (!e) return LANCET_E_ARG;
+  if (!e->uploaded) { e->err = "run before upload"; return LANCET_E_STATE; }
+  HIPCHK(e, hipSetDevice(e->device));
+  e->variants.clear(); e->blob.clear(); e->stats.clear(); e->evt_len.clear(); e->evt.clear();
+  if (e->n_windows == 0) { e->ran = true; return LANCET_OK; }
+  HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, 64, e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_stats.p, 0, sizeof(lancet_window_stats) * e->n_windows, e->stream));
+  hipLaunchKernelGGL(window_kernel, dim3(e->n_slots), dim3(LANCET_WG), 0, e->stream, (const lancet_params *)e->d_params.p,
+                     (const DevBatch *)e->d_batch.p, (const EngineCaps *)e->d_caps.p, (Work *)e->d_works.p, (DevOut *)e->d_out.p);
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipEventElapsedTime(&e->ms_all, e->ev0, e->ev1));
+  e->ms_kernel = e->ms_all;
+  // ---- read back
+  uint32_t counters[3];
+  HIPCHK(e, hipMemcpy(counters, e->d_counters.p, sizeof(counters), hipMemcpyDeviceToHost));
+  e->stats.resize(e->n_windows);
+  HIPCHK(e, hipMemcpy(e->stats.data(), e->d_stats.p, sizeof(lancet_window_stats) * e->n_windows, hipMemcpyDeviceToHost));
+  bool global_overflow = counters[0] > e->caps.var_cap || counters[1] > e->caps.blob_cap;
+  uint32_t nv = std::min(counters[0], e->caps.var_cap), nb = std::min(counters[1], e->caps.blob_cap);
+  std::vector<lancet_variant> raw(nv);
+  std::vector<char> rawblob(nb);
+  if (nv) HIPCHK(e, hipMemcpy(raw.data(), e->d_variants.p, sizeof(lancet_variant) * nv, hipMemcpyDeviceToHost));
+  if (nb) HIPCHK(e, hipMemcpy(rawblob.data(), e->d_blob.p, nb, hipMemcpyDeviceToHost));
+  if (e->caps.evt_cap) {
+    e->evt_len.resize(e->n_windows); e->evt.resize((size_t)e->n_windows * e->caps.evt_cap);
+    HIPCHK(e, hipMemcpy(e->evt_len.data(), e->d_evtlen.p, sizeof(uint32_t) * e->n_windows, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(e->evt.data(), e->d_evt.p, sizeof(uint32_t) * e->evt.size(), hipMemcpyDeviceToHost));
+  }
+  // variants of windows that overflowed are dropped; order by (window, emission order)
+  std::vector<uint32_t> idx;
+  for (uint32_t i = 0; i < nv; ++i) {
+    const lancet_variant &v = raw[i];
+    if (v.window < 0 || v.window >= e->n_windows) continue;
+    if (e->stats[v.window].status < 0) continue;
+    if ((size_t)v.str_off + v.str_len > nb) continue;
+    idx.push_back(i);
+  }
+  std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+    if (raw[a].window != raw[b].window) return raw[a].window < raw[b].window;
+    return raw[a].seq_in_window < raw[b].seq_in_window;
+  });
+  for (uint32_t i : idx) {
+    lancet_variant v = raw[i];
+    uint32_t o = (uint32_t)e->blob.size();
+    e->blob.insert(e->blob.end(), rawblob.begin() + v.ref_off, rawblob.begin() + v.ref_off + v.ref_len);
+    e->blob.insert(e->blob.end(), rawblob.begin() + v.alt_off, rawblob.begin() + v.alt_off + v.alt_len);
+    e->blob.insert(e->blob.end(), rawblob.begin() + v.str_off, rawblob.begin() + v.str_off + v.str_len);
+    v.ref_off = o; v.alt_off = o + v.ref_len; v.str_off = o + v.ref_len + v.alt_len;
+    e->variants.push_back(v);
+  }
+  if (global_overflow) {   // some window could not write its records: mark every window that lost some
+    std::vector<int> got(e->n_windows, 0);
+    for (auto &v : e->variants) ++got[v.window];
+    for (int w = 0; w < e->n_windows; ++w) if (e->stats[w].status >= 0 && got[w] != e->stats[w].n_variants) e->stats[w].status = LANCET_W_OVERFLOW;
+    e->variants.erase(std::remove_if(e->variants.begin(), e->variants.end(), [&](const lancet_variant &v) { return e->stats[v.window].status < 0; }), e->variants.end());
+  }
+  e->ran = true;
+  return LANCET_OK;
+}
+
+int lancet_engine_process(lancet_engine *e, const lancet_window_batch *b) {
+  int rc = lancet_engine_upload(e, b);
+  if (rc) return rc;
+  return lancet_engine_run(e);
+}
+
+int lancet_engine_results(lancet_engine *e, const lancet_variant **variants, uint32_t *n_variants, const char **blob, uint32_t *blob_len,
+                          const lancet_window_stats **stats) {
+  if (!e) return LANCET_E_ARG;
+  if (!e->ran) { e->err = "results before run"; return LANCET_E_STATE; }
+  if (variants) *variants = e->variants.data();
+  if (n_variants) *n_variants = (uint32_t)e->variants.size();
+  if (blob) *blob = e->blob.data();
+  if (blob_len) *blob_len = (uint32_t)e->blob.size();
+  if (stats) *stats = e->stats.data();
+  return LANCET_OK;
+}
+
+int lancet_engine_last_timing(lancet_engine *e, float out[2]) {
+  if (!e || !e->ran) return LANCET_E_STATE;
+  out[0] = e->ms_all; out[1] = e->ms_kernel;
+  return LANCET_OK;
+}
+
+// debug: trace events of the last run (see lancet_amd/trace.py); *words_per_window = 0 when tracing is off
+int lancet_engine_trace(lancet_engine *e, const uint32_t **evt_len, const uint32_t **evt, uint32_t *words_per_window) {
+  if (!e || !e->ran) return LANCET_E_STATE;
+  *evt_len = e->evt_len.data(); *evt = e->evt.data(); *words_per_window = e->caps.evt_cap;
+  return LANCET_OK;
+}
+
+// introspection used by bench.py: slots in flight and bytes of work space per slot
+int lancet_engine_geometry(lancet_engine *e, int32_t *n_slots, uint64_t *slot_bytes) {
+  if (!e || !e->uploaded) return LANCET_E_STATE;
+  *n_slots = e->n_slots; *slot_bytes = lc_work_carve(nullptr, nullptr, e->caps);
+  return LANCET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+// host_common.h -- host-side sizing of the HBM work space (shared by engine.hip and the test-side emulator).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+#include "layout.h"
+#include "../../include/lancet_engine.h"
+
+static inline uint32_t lc_pow2_ge(uint32_t x) { uint32_t p = 1; while (p < x) p <<= 1; return p; }
+static inline uint32_t lc_bucket_cap_for(uint32_t nodes) {
+  const uint32_t chain[] = {13u, 29u, 59u, 127u, 257u, 541u, 1109u, 2357u, 5087u, 10273u, 20753u, 42043u,
+                            85229u, 172933u, 351061u, 712697u, 1447153u, 2938679u};
+  for (int i = 0; i < 18; ++i) if (chain[i] >= nodes + 2) return chain[i] + 1;
+  return 2938680u;
+}
+
+// Work-space caps for a batch: the largest window decides.
+static inline EngineCaps lc_caps_for_batch(const lancet_window_batch *b, const lancet_params *p, uint32_t evt_cap,
+                                           uint32_t max_nodes_limit) {
+  EngineCaps c; memset(&c, 0, sizeof(c));
+  uint32_t max_reads = 0; uint64_t max_bases = 0;
+  for (int w = 0; w < b->n_windows; ++w) {
+    uint32_t r0 = b->read_begin[w], r1 = b->read_begin[w + 1];
+    if (r1 - r0 > max_reads) max_reads = r1 - r0;
+    uint64_t bases = (uint64_t)(b->seq_off[r1] - b->seq_off[r0]) + (b->ref_off[w + 1] - b->ref_off[w]);
+    if (bases > max_bases) max_bases = bases;
+  }
+  c.reads_cap = max_reads + 2;
+  c.occ_cap = (uint32_t)max_bases + 64;           // every base starts at most one k-mer
+  uint32_t nodes = c.occ_cap;
+  if (nodes > max_nodes_limit) nodes = max_nodes_limit;
+  c.node_cap = nodes;
+  c.table_cap = lc_pow2_ge(2 * nodes);
+  c.bucket_cap = lc_bucket_cap_for(nodes);
+  c.special_cap = 64;
+  c.surv_cap = nodes < 4096 ? nodes : 4096;
+  uint32_t maxk = (uint32_t)(p->max_k > 0 ? p->max_k : 101);
+  c.max_k = maxk;
+  c.seq_cap = c.surv_cap * maxk + 8 * LC_MAXW * 8 + 65536;
+  c.queue_cap = 32768;
+  c.path_cap = LC_MAXW + (uint32_t)p->max_indel_len + 256;
+  c.evt_cap = evt_cap;
+  c.var_cap = (uint32_t)b->n_windows * 8 + 1024;
+  c.blob_cap = (uint32_t)b->n_windows * 512 + 65536;
+  return c;
+}
+
+struct LcCarver {
+  char *base; size_t off;
+  template <class T> T *take(size_t n) {
+    off = (off + 63) & ~(size_t)63;
+    T *p = base ? (T *)(base + off) : (T *)nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+// Lays one Work slot out at `base` (may be null to just measure).  Returns bytes used.
+static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
+  LcCarver k{base, 0};
+  const size_t nodes = (size_t)c.node_cap + c.special_cap;
+  Work t; memset(&t, 0, sizeof(t));
+  t.occ_base = k.take<uint32_t>(c.reads_cap + 1);
+  t.cand = k.take<uint8_t>(c.reads_cap);
+  t.occ = k.take<uint32_t>(c.occ_cap);
+  t.tags = k.take<unsigned long long>(c.table_cap);
+  t.slot_key = k.take<unsigned long long>((size_t)c.table_cap * LC_NWMAX);
+  t.slot_first = k.take<uint32_t>(c.table_cap);
+  t.slot_node = k.take<uint32_t>(c.table_cap);
+  t.bitmap = k.take<uint32_t>(c.occ_cap / 32 + 2);
+  t.bitpre = k.take<uint32_t>(c.occ_cap / 32 + 2);
+  t.csr = k.take<uint32_t>(c.occ_cap);
+  t.nkey = k.take<unsigned long long>(nodes * LC_NWMAX);
+  t.nhash = k.take<unsigned long long>(nodes);
+  t.ncnt = k.take<uint32_t>(nodes * 4);
+  t.nflags = k.take<uint32_t>(nodes);
+  t.efirst = k.take<uint32_t>(nodes * 8);
+  t.eto = k.take<uint32_t>(nodes * 8);
+  t.edges = k.take<uint32_t>(nodes * LC_EMAX);
+  t.necnt = k.take<uint32_t>(nodes);
+  t.ncov = k.take<float>(nodes * 4);
+  t.ncomp = k.take<int32_t>(nodes);
+  t.nmincov = k.take<int32_t>(nodes);
+  t.nmincovqv = k.take<int32_t>(nodes);
+  t.nocc = k.take<uint32_t>(nodes + 1);
+  t.nfill = k.take<uint32_t>(nodes);
+  t.nseq_lo = k.take<uint32_t>(nodes); t.nseq_hi = k.take<uint32_t>(nodes);
+  t.nseq_clo = k.take<uint32_t>(nodes); t.nseq_chi = k.take<uint32_t>(nodes);
+  t.nkm = k.take<uint32_t>(nodes); t.nkmT = k.take<uint32_t>(nodes);
+  t.nqv = k.take<uint32_t>(nodes);
+  t.ncolor = k.take<uint8_t>(nodes);
+  t.nonref = k.take<uint32_t>(nodes);
+  t.qv = k.take<uint16_t>((size_t)c.surv_cap * c.max_k * 4);
+  t.seq = k.take<uint32_t>(c.seq_cap);
+  t.ht_next = k.take<uint32_t>(nodes);
+  t.ht_bucket = k.take<uint32_t>(c.bucket_cap);
+  t.order = k.take<uint32_t>(nodes + 1);
+  t.scratch = k.take<uint32_t>(2 * nodes > c.occ_cap ? 2 * nodes : c.occ_cap);
+  t.refcov = k.take<uint16_t>(LC_MAXW * 4);
+  t.queue = k.take<BfsEntry>(c.queue_cap);
+  t.pnodes = k.take<uint32_t>(nodes); t.pedges = k.take<uint32_t>(nodes);
+  t.pdesc = k.take<uint32_t>(c.path_cap);
+  t.pseq = k.take<uint8_t>(c.path_cap);
+  t.tb = k.take<uint8_t>((size_t)(LC_MAXW + 2) * (c.path_cap + 2));
+  t.dp = k.take<int32_t>(7 * (LC_MAXW + 2));
+  t.aln = k.take<uint8_t>(2 * (size_t)(LC_MAXW + c.path_cap + 2));
+  t.evt = k.take<uint32_t>(c.evt_cap + 8);
+  if (w) *w = t;
+  return (k.off + 255) & ~(size_t)255;
+}

@@ -1,0 +1,260 @@
+// host_vdb.cc -- host side below the seam: Variant_t normalisation, VariantDB_t and the VCF writer
+// (SURVEY.md §8(f) N3).  Double-precision Fisher scores are computed with the C library's lgamma/exp/log10
+// exactly as the reference does, so that the printed 6-digit values agree.
+//
+//   Variant_t ctor        reference src/Variant.hh:106-172
+//   getSignature          reference src/Variant.cc:339-344
+//   VariantDB_t::addVar   reference src/VariantDB.cc:28-91   (std::map keyed by the sha256 hex of the signature)
+//   printHeader/printToVCF reference src/VariantDB.cc:93-179 ; byPos src/VariantDB.hh:37-54 (std::sort, unstable)
+//   Variant_t::printVCF   reference src/Variant.cc:39-223
+//   FET_t                 reference src/FET.hh:36-128 (Heng Li's kt_fisher_exact)
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/lancet_engine.h"
+
+namespace {
+
+// ---- SHA-256 (FIPS 180-4), hex digest: only its ordering matters (map iteration order of the final merge)
+struct Sha256 {
+  uint32_t h[8]; uint8_t buf[64]; uint64_t len; size_t fill;
+  static uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+  void init() {
+    static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    memcpy(h, iv, sizeof(h)); len = 0; fill = 0;
+  }
+  void block(const uint8_t *p) {
+    static const uint32_t k[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+        0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+        0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+        0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+        0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+        0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t w[64];
+    for (int i = 0; i < 16; ++i) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+    for (int i = 16; i < 64; ++i) {
+      uint32_t s0 = ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10);
+      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; ++i) {
+      uint32_t S1 = ror(e, 6) ^ ror(e, 11) ^ ror(e, 25), ch = (e & f) ^ (~e & g), t1 = hh + S1 + ch + k[i] + w[i];
+      uint32_t S0 = ror(a, 2) ^ ror(a, 13) ^ ror(a, 22), mj = (a & b) ^ (a & c) ^ (b & c), t2 = S0 + mj;
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+  void update(const uint8_t *p, size_t n) {
+    len += n;
+    while (n) { size_t t = std::min(n, 64 - fill); memcpy(buf + fill, p, t); fill += t; p += t; n -= t; if (fill == 64) { block(buf); fill = 0; } }
+  }
+  std::string hex() {
+    uint64_t bits = len * 8;
+    uint8_t pad = 0x80; update(&pad, 1);
+    uint8_t z = 0; while (fill != 56) update(&z, 1);
+    uint8_t l[8]; for (int i = 0; i < 8; ++i) l[i] = (uint8_t)(bits >> (56 - 8 * i));
+    update(l, 8);
+    static const char *hx = "0123456789abcdef";
+    std::string s;
+    for (int i = 0; i < 8; ++i) for (int j = 3; j >= 0; --j) { uint8_t b = (uint8_t)(h[i] >> (8 * j)); s.push_back(hx[b >> 4]); s.push_back(hx[b & 15]); }
+    return s;
+  }
+};
+std::string sha256_hex(const std::string &s) { Sha256 c; c.init(); c.update((const uint8_t *)s.data(), s.size()); return c.hex(); }
+
+// ---- FET_t
+double lbinom(int n, int k) { if (k == 0 || n == k) return 0; return lgamma(n + 1) - lgamma(k + 1) - lgamma(n - k + 1); }
+double hypergeo(int n11, int n1_, int n_1, int n) { return exp(lbinom(n1_, n11) + lbinom(n - n1_, n_1 - n11) - lbinom(n, n_1)); }
+// only q (the probability of the observed table) is consumed by the reference; the tails do not feed back into it
+double kt_fisher_exact_q(int n11, int n12, int n21, int n22) {
+  int n1_ = n11 + n12, n_1 = n11 + n21, n = n11 + n12 + n21 + n22;
+  int mx = (n_1 < n1_) ? n_1 : n1_;
+  int mn = n1_ + n_1 - n; if (mn < 0) mn = 0;
+  if (mn == mx) return 1.;
+  return hypergeo(n11, n1_, n_1, n);
+}
+
+std::string dtos(double d) { std::ostringstream s; s << d; return s.str(); }
+std::string itos(int i) { std::ostringstream s; s << i; return s.str(); }
+
+struct Variant {
+  unsigned short kmer = 0; std::string chr; int pos = 0; char type = '?'; unsigned short len = 0;
+  std::string ref, alt, str;
+  unsigned short rcn_f = 0, rcn_r = 0, rct_f = 0, rct_r = 0, acn_f = 0, acn_r = 0, act_f = 0, act_r = 0;
+
+  Variant(const std::string &chr_, const lancet_variant &v, const char *blob) {
+    kmer = v.kmer; chr = chr_; pos = v.pos;
+    std::string ref_(blob + v.ref_off, v.ref_len), alt_(blob + v.alt_off, v.alt_len);
+    str.assign(blob + v.str_off, v.str_len);
+    char code = (char)v.code;
+    if (code == '^') { type = 'I'; ref_ = ""; len = (unsigned short)alt_.length(); }
+    if (code == 'v') { type = 'D'; alt_ = ""; len = (unsigned short)ref_.length(); }
+    if (code == 'x') { type = 'S'; pos++; }
+    if (code == 'c') {
+      type = 'C';
+      ref_.erase(std::remove(ref_.begin(), ref_.end(), '-'), ref_.end());
+      alt_.erase(std::remove(alt_.begin(), alt_.end(), '-'), alt_.end());
+      unsigned short rl = (unsigned short)ref_.length(), al = (unsigned short)alt_.length();
+      if (rl == al) len = al; else if (rl > al) len = rl - al; else len = al - rl;
+    }
+    if (type != 'S') { ref = (char)v.prev_bp_alt + ref_; alt = (char)v.prev_bp_alt + alt_; }
+    else { alt = alt_; ref = ref_; len = 1; }
+    rcn_f = v.cov[0]; rcn_r = v.cov[1]; rct_f = v.cov[2]; rct_r = v.cov[3];
+    acn_f = v.cov[4]; acn_r = v.cov[5]; act_f = v.cov[6]; act_r = v.cov[7];
+  }
+  std::string signature() const { return chr + ":" + itos(pos) + ":" + type + ":" + itos(len) + ":" + ref + ":" + alt; }
+  int tot() const { return rcn_f + rcn_r + rct_f + rct_r + acn_f + acn_r + act_f + act_r; }
+  double fet_score() const {
+    double prob = kt_fisher_exact_q(rcn_f + rcn_r, rct_f + rct_r, acn_f + acn_r, act_f + act_r);
+    if (prob == 1.0) return 0.0;
+    if (prob == 0.0) return -10.0 * log10(1 / std::numeric_limits<double>::max());
+    return -10.0 * log10(prob);
+  }
+  double sb_score() const {
+    double prob = kt_fisher_exact_q(rct_f, rct_r, act_f, act_r);
+    if (prob == 1) return 0.0;
+    return -10.0 * log10(prob);
+  }
+  static std::string genotype(int R, int A) { if (R > 0 && A > 0) return "0/1"; if (R > 0 && A == 0) return "0/0"; if (R == 0 && A > 0) return "1/1"; return "."; }
+  std::string vcf(const lancet_filters &fs) const {
+    int tr_t = rct_f + rct_r, ta_t = act_f + act_r, tr_n = rcn_f + rcn_r, ta_n = acn_f + acn_r;
+    double fet = fet_score(), sb = sb_score();
+    std::string status;
+    if (ta_n > 0 && ta_t > 0) status = "SHARED"; else if (ta_n == 0 && ta_t > 0) status = "SOMATIC"; else if (ta_n > 0 && ta_t == 0) status = "NORMAL"; else return "";
+    std::string INFO = status + ";FETS=" + dtos(fet);
+    if (type == 'I') INFO += ";TYPE=ins";
+    if (type == 'D') INFO += ";TYPE=del";
+    if (type == 'S') INFO += ";TYPE=snv";
+    if (type == 'C') INFO += ";TYPE=complex";
+    INFO += ";LEN=" + itos(len) + ";KMERSIZE=" + itos(kmer) + ";SB=" + dtos(sb);
+    if (!str.empty()) INFO += ";MS=" + str;
+    int tumor_cov = tr_t + ta_t; double tumor_vaf = (tumor_cov == 0) ? 0 : ((double)ta_t / (double)tumor_cov);
+    int normal_cov = tr_n + ta_n; double normal_vaf = (normal_cov == 0) ? 0 : ((double)ta_n / (double)normal_cov);
+    std::string F;
+    auto add = [&](const char *s) { if (F.empty()) F = s; else { F += ";"; F += s; } };
+    if (!str.empty()) { if (fet < fs.min_phred_fisher_str) add("LowFisherSTR"); }
+    else if (fet < fs.min_phred_fisher) add("LowFisherScore");
+    if (normal_cov < fs.min_cov_normal) add("LowCovNormal");
+    if (normal_cov > fs.max_cov_normal) add("HighCovNormal");
+    if (tumor_cov < fs.min_cov_tumor) add("LowCovTumor");
+    if (tumor_cov > fs.max_cov_tumor) add("HighCovTumor");
+    if (tumor_vaf < fs.min_vaf_tumor) add("LowVafTumor");
+    if (normal_vaf > fs.max_vaf_normal) add("HighVafNormal");
+    if (ta_t < fs.min_alt_cnt_tumor) add("LowAltCntTumor");
+    if (ta_n > fs.max_alt_cnt_normal) add("HighAltCntNormal");
+    if ((act_f < fs.min_strand_bias) || (act_r < fs.min_strand_bias)) add("StrandBias");
+    if (F.empty()) F = "PASS";
+    std::string NORMAL = genotype(tr_n, ta_n) + ":" + itos(tr_n) + "," + itos(ta_n) + ":" + itos(rcn_f) + "," + itos(rcn_r) + ":" + itos(acn_f) + "," +
+                         itos(acn_r) + ":" + itos(tr_n + ta_n);
+    std::string TUMOR = genotype(tr_t, ta_t) + ":" + itos(tr_t) + "," + itos(ta_t) + ":" + itos(rct_f) + "," + itos(rct_r) + ":" + itos(act_f) + "," +
+                        itos(act_r) + ":" + itos(tr_t + ta_t);
+    std::ostringstream line;
+    line << chr << "\t" << pos << "\t.\t" << ref << "\t" << alt << "\t" << fet << "\t" << F << "\t" << INFO << "\tGT:AD:SR:SA:DP\t" << NORMAL << "\t" << TUMOR << std::endl;
+    return line.str();
+  }
+};
+
+struct byPos {   // reference src/VariantDB.hh:37-54 (arguments by value there; same ordering)
+  bool operator()(const std::pair<std::string, Variant> &a, const std::pair<std::string, Variant> &b) const {
+    int cmp = a.second.chr.compare(b.second.chr);
+    if (cmp == 0) return a.second.pos < b.second.pos;
+    return cmp < 0;
+  }
+};
+
+}  // namespace
+
+struct lancet_vdb {
+  lancet_filters fs;
+  std::map<std::string, Variant> db;
+};
+
+extern "C" {
+
+void lancet_filters_default(lancet_filters *f) {   // reference src/Lancet.cc:627-637
+  memset(f, 0, sizeof(*f));
+  f->min_phred_fisher_str = 25; f->min_phred_fisher = 5; f->min_cov_normal = 10; f->max_cov_normal = 1000000; f->min_cov_tumor = 4;
+  f->max_cov_tumor = 1000000; f->min_vaf_tumor = 0.04; f->max_vaf_normal = 0; f->min_alt_cnt_tumor = 3; f->max_alt_cnt_normal = 0; f->min_strand_bias = 1;
+}
+lancet_vdb *lancet_vdb_create(const lancet_filters *f) { lancet_vdb *d = new lancet_vdb(); if (f) d->fs = *f; else lancet_filters_default(&d->fs); return d; }
+void lancet_vdb_destroy(lancet_vdb *db) { delete db; }
+uint32_t lancet_vdb_size(const lancet_vdb *db) { return db ? (uint32_t)db->db.size() : 0; }
+
+int lancet_vdb_add(lancet_vdb *db, const lancet_variant *v, uint32_t n, const char *blob, const char *const *chr_names, int32_t n_chr) {
+  if (!db || (n && (!v || !blob))) return LANCET_E_ARG;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (v[i].chr_id < 0 || v[i].chr_id >= n_chr) return LANCET_E_ARG;
+    Variant nv(chr_names[v[i].chr_id], v[i], blob);
+    std::string key = sha256_hex(nv.signature());
+    auto it = db->db.find(key);
+    if (it != db->db.end()) {
+      if (it->second.tot() < nv.tot()) {            // keep the entry with the larger total coverage; first wins ties
+        Variant &o = it->second;
+        o.kmer = nv.kmer;
+        o.rcn_f = nv.rcn_f; o.rcn_r = nv.rcn_r; o.rct_f = nv.rct_f; o.rct_r = nv.rct_r;
+        o.acn_f = nv.acn_f; o.acn_r = nv.acn_r; o.act_f = nv.act_f; o.act_r = nv.act_r;
+      }
+    } else db->db.insert(std::make_pair(key, nv));
+  }
+  return LANCET_OK;
+}
+
+char *lancet_vdb_vcf(lancet_vdb *db, const char *version, const char *cmdline, const char *reference, const char *date_line,
+                     const char *sample_normal, const char *sample_tumor) {
+  if (!db) return nullptr;
+  const lancet_filters &fs = db->fs;
+  std::ostringstream hdr;
+  hdr << "##fileformat=VCFv4.2\n";
+  if (date_line) hdr << "##fileDate=" << date_line;
+  hdr << "##source=lancet " << (version ? version : "1.1.0, October 18 2019") << "\n";
+  if (cmdline) hdr << "##cmdline=" << cmdline << "\n";
+  if (reference) hdr << "##reference=" << reference << "\n";
+  hdr << "##INFO=<ID=FETS,Number=1,Type=Float,Description=\"Phred-scaled p-value of the Fisher's exact test for tumor-normal allele counts\">\n"
+         "##INFO=<ID=SOMATIC,Number=0,Type=Flag,Description=\"Somatic mutation\">\n"
+         "##INFO=<ID=SHARED,Number=0,Type=Flag,Description=\"Shared mutation betweem tumor and normal\">\n"
+         "##INFO=<ID=NORMAL,Number=0,Type=Flag,Description=\"Mutation present only in the normal\">\n"
+         "##INFO=<ID=NONE,Number=0,Type=Flag,Description=\"Mutation not supported by data\">\n"
+         "##INFO=<ID=KMERSIZE,Number=1,Type=Integer,Description=\"K-mer size used to assemble the locus\">\n"
+         "##INFO=<ID=SB,Number=1,Type=Float,Description=\"Strand bias score: phred-scaled p-value of the Fisher's exact test for the forward/reverse read counts in the tumor\">\n"
+         "##INFO=<ID=MS,Number=1,Type=String,Description=\"Microsatellite mutation (format: #LEN#MOTIF)\">\n"
+         "##INFO=<ID=LEN,Number=1,Type=Integer,Description=\"Variant size in base pairs\">\n"
+         "##INFO=<ID=TYPE,Number=1,Type=String,Description=\"Variant type (snv, del, ins, complex)\">\n";
+  hdr << "##FILTER=<ID=LowCovNormal,Description=\"Low coverage in the normal (<" << fs.min_cov_normal << ")\">\n"
+         "##FILTER=<ID=HighCovNormal,Description=\"High coverage in the normal (>" << fs.max_cov_normal << ")\">\n"
+         "##FILTER=<ID=LowCovTumor,Description=\"Low coverage in the tumor (<" << fs.min_cov_tumor << ")\">\n"
+         "##FILTER=<ID=HighCovTumor,Description=\"High coverage in the tumor (>" << fs.max_cov_tumor << ")\">\n"
+         "##FILTER=<ID=LowVafTumor,Description=\"Low variant allele frequency in the tumor (<" << fs.min_vaf_tumor << ")\">\n"
+         "##FILTER=<ID=HighVafNormal,Description=\"High variant allele frequency in the normal (>" << fs.max_vaf_normal << ")\">\n"
+         "##FILTER=<ID=LowAltCntTumor,Description=\"Low alternative allele count in the tumor (<" << fs.min_alt_cnt_tumor << ")\">\n"
+         "##FILTER=<ID=HighAltCntNormal,Description=\"High alternative allele count in the normal (>" << fs.max_alt_cnt_normal << ")\">\n"
+         "##FILTER=<ID=LowFisherScore,Description=\"Low Fisher's exact test score for tumor-normal allele counts (<" << fs.min_phred_fisher << ")\">\n"
+         "##FILTER=<ID=LowFisherSTR,Description=\"Low Fisher's exact test score for tumor-normal STR allele counts (<" << fs.min_phred_fisher_str << ")\">\n"
+         "##FILTER=<ID=StrandBias,Description=\"Strand bias: # of non-reference reads in either forward or reverse strand below threshold (<" << fs.min_strand_bias << ")\">\n"
+         "##FILTER=<ID=STR,Description=\"Microsatellite mutation\">\n";
+  hdr << "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n"
+         "##FORMAT=<ID=DP,Number=1,Type=Integer,Description=\"Depth\">\n"
+         "##FORMAT=<ID=AD,Number=.,Type=Integer,Description=\"Allele depth: # of supporting ref,alt reads at the site\">\n"
+         "##FORMAT=<ID=SR,Number=.,Type=Integer,Description=\"Strand counts for ref: # of supporting forward,reverse reads for reference allele\">\n"
+         "##FORMAT=<ID=SA,Number=.,Type=Integer,Description=\"Strand counts for alt: # of supporting forward,reverse reads for alterantive allele\">\n";
+  hdr << "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" << (sample_normal ? sample_normal : "NORMAL") << "\t" << (sample_tumor ? sample_tumor : "TUMOR") << "\n";
+  std::vector<std::pair<std::string, Variant>> vec(db->db.begin(), db->db.end());
+  std::sort(vec.begin(), vec.end(), byPos());
+  std::string out = hdr.str();
+  for (auto &kv : vec) out += kv.second.vcf(fs);
+  char *r = (char *)malloc(out.size() + 1);
+  if (!r) return nullptr;
+  memcpy(r, out.c_str(), out.size() + 1);
+  return r;
+}
+void lancet_free(void *p) { free(p); }
+
+}  // extern "C"

@@ -1,0 +1,1676 @@
+// kernels.h -- the per-window micro-assembly kernel for gfx950 (single source, see wave.h).
+//
+// One workgroup assembles one window at a time, start to finish: reference repeat scan, the self-tuning k
+// loop, node-table build, graph clean-up, path enumeration, alignment and variant extraction -- the path the
+// reference runs inside Microassembler::processGraph (reference src/Microassembler.cc:73-249).  Function
+// headers cite the reference code whose observable behaviour they reproduce; the implementation is not a
+// translation: k-mers are 2-bit packed integers, the node table is an open-addressing hash over HBM, nodes are
+// dense ids in first-insertion order, unitigs are descriptor deques in an arena, libstdc++'s unordered_map
+// iteration order (which the reference's results depend on) is computed explicitly.
+#pragma once
+#include "wave.h"
+#include "layout.h"
+#include "../../include/lancet_engine.h"
+
+#ifndef LANCET_WG
+#define LANCET_WG 64
+#endif
+
+// ---------------------------------------------------------------------------------------------------------
+// trace events (optional; host side turns them into the reference's `-v` text, tests compare with goldens)
+// ---------------------------------------------------------------------------------------------------------
+enum {
+  EV_PROCESS = 1, EV_REPEAT_REF, EV_NEAR_REF, EV_READS, EV_STATS, EV_MARKREF, EV_LOWCOV, EV_CLEANDEAD,
+  EV_COMPRESS, EV_CC, EV_CCID, EV_CCEND, EV_TRIM, EV_AMBIG_SRC, EV_NOMATCH_SRC, EV_AMBIG_SNK, EV_NOMATCH_SNK,
+  EV_CYCLE, EV_TIPS_ROUND, EV_TIPS_REMOVED, EV_LINKS, EV_LOOKREP, EV_MISSING, EV_SEARCH, EV_NEAR_QRY,
+  EV_DFSLIMIT, EV_PATH, EV_TS, EV_PATH_END, EV_EKA_END, EV_FOUND, EV_END
+};
+
+struct WinShared {
+  int w, K, NW, R, reflen;
+  uint32_t O, N, nspecial, M;          // occurrences, k-mer nodes, special nodes, live order length
+  int overflow;
+  int seq_t5, seq_len;                 // Ref_t::seq as a window of rawseq (carried across k)
+  int trim5, trim3;                    // Ref_t::trim5/trim3 (unsigned short in the reference)
+  int totalreadbp;
+  uint32_t ht_bc, ht_next_resize, ht_elt, ht_head;
+  uint32_t source, sink;
+  int numcomp, refcomp;
+  int repE, repM;
+  uint32_t seq_top, qv_top;
+  int emit_seq;
+  uint32_t evt_len;
+  unsigned long long n_kmers;
+  uint32_t max_nodes;
+  int n_builds, final_k, status;
+  int tmp0, tmp1, tmp2, tmp3;
+  uint32_t part[LANCET_WG + 1];
+};
+
+struct Ctx {
+  const lancet_params *P;
+  const DevBatch *B;
+  const EngineCaps *C;
+  Work *W;
+  DevOut *OUT;
+  WinShared *S;
+};
+
+#define OVF(c) do { (c).S->overflow = 1; } while (0)
+
+// Uniform read of a control word: barrier, everybody reads, barrier (so that the next writer cannot race a
+// slow reader).  Every branch that contains a WG_SYNC must be decided through this.
+DEV int wg_bcast(const int *p) { WG_SYNC(); int v = *p; WG_SYNC(); return v; }
+DEV uint32_t wg_bcastu(const uint32_t *p) { WG_SYNC(); uint32_t v = *p; WG_SYNC(); return v; }
+
+DEV void evt(Ctx &c, uint32_t code, uint32_t a = 0, uint32_t b = 0, uint32_t d = 0, uint32_t e = 0, uint32_t f = 0,
+             uint32_t g = 0, uint32_t h = 0) {
+  if (!c.C->evt_cap) return;
+  WinShared &S = *c.S;
+  if (S.evt_len + 8 > c.C->evt_cap) return;
+  uint32_t *p = c.W->evt + S.evt_len;
+  p[0] = code; p[1] = a; p[2] = b; p[3] = d; p[4] = e; p[5] = f; p[6] = g; p[7] = h;
+  S.evt_len += 8;
+}
+DEV void evt_bytes(Ctx &c, const uint8_t *s, uint32_t n) {   // raw bytes appended after an event, padded to 8 words
+  if (!c.C->evt_cap) return;
+  WinShared &S = *c.S;
+  uint32_t words = ((n + 3) / 4 + 7) / 8 * 8;
+  if (S.evt_len + words > c.C->evt_cap) return;
+  uint8_t *p = (uint8_t *)(c.W->evt + S.evt_len);
+  for (uint32_t i = 0; i < words * 4; ++i) p[i] = i < n ? s[i] : 0;
+  S.evt_len += words;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------------------
+DEV int rd_base(const uint32_t *bases, uint32_t woff, int i) { return (bases[woff + (i >> 4)] >> ((i & 15) * 2)) & 3; }
+DEV int rd_good(const uint32_t *good, uint32_t woff, int i) { return (good[woff + (i >> 5)] >> (i & 31)) & 1; }
+// number of quality-passing bases in [a, b)
+DEV int good_count(const uint32_t *good, uint32_t woff, int a, int b) {
+  int n = 0;
+  for (int i = a; i < b;) {
+    int w = i >> 5, lo = i & 31;
+    int take = 32 - lo; if (take > b - i) take = b - i;
+    uint32_t m = good[woff + w] >> lo;
+    if (take < 32) m &= ((1u << take) - 1u);
+    n += dev_popc(m);
+    i += take;
+  }
+  return n;
+}
+
+DEV bool is_dir(uint32_t edir, char dir) {                        // Edge_t::isDir, reference src/Edge.cc:25-31
+  return dir == 'F' ? (edir == 0 || edir == 1) : (edir == 3 || edir == 2);
+}
+DEV char dir_start(uint32_t d) { return (d == 0 || d == 1) ? 'F' : 'R'; }    // reference src/Edge.hh:71-75
+DEV char dir_dest(uint32_t d) { return (d == 0 || d == 2) ? 'F' : 'R'; }     // :77-81
+DEV uint32_t flipme(uint32_t d) { return d == 0 ? 2u : d == 1 ? 3u : d == 2 ? 0u : 1u; }   // :89-97
+DEV uint32_t fliplink(uint32_t d) { return d == 0 ? 3u : d == 3 ? 0u : d; }                 // :99-107
+
+// 64-bit finaliser used for the open-addressing table (not observable)
+DEV unsigned long long mix64(unsigned long long x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return x;
+}
+
+// libstdc++ std::hash<std::string> == _Hash_bytes(ptr, len, 0xc70f6907) (64-bit MurmurHash2 variant,
+// SURVEY.md Appendix A.1).  `get(i)` returns byte i of the string.
+template <class G>
+DEV unsigned long long std_hash_bytes(G get, int len) {
+  const unsigned long long mul = (0xc6a4a793ULL << 32) + 0x5bd1e995ULL;
+  unsigned long long hash = 0xc70f6907ULL ^ ((unsigned long long)len * mul);
+  int nblk = len & ~7;
+  for (int i = 0; i < nblk; i += 8) {
+    unsigned long long d = 0;
+    for (int j = 7; j >= 0; --j) d = (d << 8) | (unsigned long long)get(i + j);
+    d *= mul; d ^= d >> 47; d *= mul;
+    hash ^= d; hash *= mul;
+  }
+  if (len & 7) {
+    unsigned long long d = 0;
+    for (int j = (len & 7) - 1; j >= 0; --j) d = (d << 8) | (unsigned long long)get(nblk + j);
+    hash ^= d; hash *= mul;
+  }
+  hash ^= hash >> 47; hash *= mul; hash ^= hash >> 47;
+  return hash;
+}
+
+// k-mer keys: 2*K bits right-aligned in NW little-endian 64-bit words, first base in the most significant
+// position, A<C<G<T = 0..3, so integer order == std::string order (reference src/Mer.hh:57-71).
+DEV int key_base(const unsigned long long *k, int K, int j) {      // j-th character
+  int bit = 2 * (K - 1 - j);
+  return (int)((k[bit >> 6] >> (bit & 63)) & 3ULL);
+}
+DEV void key_push_fw(unsigned long long *k, int NW, int K, int b) { // k = (k << 2 | b) mod 4^K
+  for (int w = NW - 1; w > 0; --w) k[w] = (k[w] << 2) | (k[w - 1] >> 62);
+  k[0] = (k[0] << 2) | (unsigned long long)b;
+  int top = 2 * K - 64 * (NW - 1);
+  if (top < 64) k[NW - 1] &= ((1ULL << top) - 1ULL);
+}
+DEV void key_push_rc(unsigned long long *k, int NW, int K, int b) { // k = (k >> 2) | (3-b) << 2(K-1)
+  for (int w = 0; w < NW - 1; ++w) k[w] = (k[w] >> 2) | (k[w + 1] << 62);
+  k[NW - 1] >>= 2;
+  int bit = 2 * (K - 1);
+  k[bit >> 6] |= ((unsigned long long)(3 - b)) << (bit & 63);
+}
+DEV bool key_less(const unsigned long long *a, const unsigned long long *b, int NW) {
+  for (int w = NW - 1; w >= 0; --w) { if (a[w] != b[w]) return a[w] < b[w]; }
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K0: reference repeat scan.  isRepeat / isAlmostRepeat (reference src/util.cc:295-360) for every k at once:
+//   isRepeat(seq,k)          <=> E >= k      E = longest exact self-match between offsets a<b with b+k-1 <= len-2
+//   isAlmostRepeat(seq,k,mm) <=> Mm >= k+1   Mm = longest self-match window with <= mm mismatches, b+L-1 <= len-1
+// (the reference skips the last k-mer in both loops).  One shift d = b-a per lane.
+// ---------------------------------------------------------------------------------------------------------
+DEV void repeat_scan(const uint8_t *s, int len, int mm, int *outE, int *outM) {
+  WG_LANE0 { *outE = 0; *outM = 0; }
+  WG_SYNC();
+  WG_FOR(dd, len > 1 ? len - 1 : 0) {
+    int d = dd + 1;
+    int run = 0, bestE = 0;
+    int lenE = len - 1 - d;                         // positions p with p + d <= len-2
+    for (int p = 0; p < lenE; ++p) { if (s[p] == s[p + d]) { ++run; if (run > bestE) bestE = run; } else run = 0; }
+    int lenM = len - d, lo = 0, mis = 0, bestM = 0;  // positions p with p + d <= len-1
+    for (int p = 0; p < lenM; ++p) {
+      if (s[p] != s[p + d]) ++mis;
+      while (mis > mm) { if (s[lo] != s[lo + d]) --mis; ++lo; }
+      if (p - lo + 1 > bestM) bestM = p - lo + 1;
+    }
+    if (bestE > 0) dev_atomic_max((uint32_t *)outE, (uint32_t)bestE);
+    if (bestM > 0) dev_atomic_max((uint32_t *)outM, (uint32_t)bestM);
+  }
+  WG_SYNC();
+}
+
+// exclusive prefix sum of a[0..n) in place; returns total in S.part[LANCET_WG]
+DEV void wg_scan(uint32_t *a, int n, WinShared &S) {
+  int chunk = (n + LANCET_WG - 1) / LANCET_WG;
+  WG_FOR(l, LANCET_WG) {
+    uint32_t s = 0;
+    int lo = l * chunk, hi = lo + chunk; if (hi > n) hi = n;
+    for (int i = lo; i < hi; ++i) s += a[i];
+    S.part[l] = s;
+  }
+  WG_SYNC();
+  WG_LANE0 { uint32_t s = 0; for (int l = 0; l < LANCET_WG; ++l) { uint32_t t = S.part[l]; S.part[l] = s; s += t; } S.part[LANCET_WG] = s; }
+  WG_SYNC();
+  WG_FOR(l, LANCET_WG) {
+    uint32_t s = S.part[l];
+    int lo = l * chunk, hi = lo + chunk; if (hi > n) hi = n;
+    for (int i = lo; i < hi; ++i) { uint32_t t = a[i]; a[i] = s; s += t; }
+  }
+  WG_SYNC();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// node accessors
+// ---------------------------------------------------------------------------------------------------------
+DEV bool n_special(const Ctx &c, uint32_t n) { return (c.W->nflags[n] & NF_SPECIAL) != 0; }
+DEV bool n_dead(const Ctx &c, uint32_t n) { return (c.W->nflags[n] & NF_DEAD) != 0; }
+DEV int n_len(const Ctx &c, uint32_t n) { return (int)(c.W->nseq_hi[n] - c.W->nseq_lo[n]); }   // str_m.length()
+DEV int n_strlen(const Ctx &c, uint32_t n) { return n_special(c, n) ? 0 : n_len(c, n); }       // Node_t::strlen
+DEV float n_totcov(const Ctx &c, uint32_t n) { const float *f = c.W->ncov + 4 * n; return f[0] + f[1] + f[2] + f[3]; }
+
+DEV int get_buddy(const Ctx &c, uint32_t n, char dir) {             // Node_t::getBuddy, reference src/Node.cc:235-266
+  if (n_special(c, n)) return -1;
+  int ret = -1;
+  const uint32_t *e = c.W->edges + n * LC_EMAX;
+  int cnt = (int)c.W->necnt[n];
+  for (int i = 0; i < cnt; ++i) if (is_dir(ED_DIR(e[i]), dir)) { if (ret != -1) return -1; ret = i; }
+  if (ret != -1 && ED_TO(e[ret]) == n) return -1;
+  return ret;
+}
+DEV bool is_tandem(const Ctx &c, uint32_t n) {                      // reference src/Node.cc:123-134
+  const uint32_t *e = c.W->edges + n * LC_EMAX;
+  for (int i = 0; i < (int)c.W->necnt[n]; ++i) if (ED_TO(e[i]) == n) return true;
+  return false;
+}
+DEV void add_edge(Ctx &c, uint32_t n, uint32_t to, uint32_t dir) {  // reference src/Node.cc:140-175
+  uint32_t *e = c.W->edges + n * LC_EMAX;
+  int cnt = (int)c.W->necnt[n];
+  for (int i = 0; i < cnt; ++i) if (ED_TO(e[i]) == to && ED_DIR(e[i]) == dir) return;
+  if (cnt >= LC_EMAX) { OVF(c); return; }
+  e[cnt] = ED_MAKE(to, dir);
+  c.W->necnt[n] = cnt + 1;
+}
+DEV void erase_edge_at(Ctx &c, uint32_t n, int idx) {
+  uint32_t *e = c.W->edges + n * LC_EMAX;
+  int cnt = (int)c.W->necnt[n];
+  for (int i = idx; i + 1 < cnt; ++i) e[i] = e[i + 1];
+  c.W->necnt[n] = cnt - 1;
+}
+DEV void remove_edge(Ctx &c, uint32_t n, uint32_t to, uint32_t dir) {   // reference src/Node.cc:209-229
+  uint32_t *e = c.W->edges + n * LC_EMAX;
+  for (int i = 0; i < (int)c.W->necnt[n]; ++i)
+    if (ED_TO(e[i]) == to && ED_DIR(e[i]) == dir) { erase_edge_at(c, n, i); return; }
+}
+DEV void update_edge(Ctx &c, uint32_t n, uint32_t oldto, uint32_t olddir, uint32_t newto, uint32_t newdir) {   // :181-204
+  uint32_t *e = c.W->edges + n * LC_EMAX;
+  for (int i = 0; i < (int)c.W->necnt[n]; ++i)
+    if (ED_TO(e[i]) == oldto && ED_DIR(e[i]) == olddir) { e[i] = ED_MAKE(newto, newdir) | (e[i] & (1u << 30)); return; }
+}
+DEV void remove_node(Ctx &c, uint32_t n) {                          // Graph_t::removeNode, reference src/Graph.cc:2768-2784
+  c.W->nflags[n] |= NF_DEAD;
+  const uint32_t *e = c.W->edges + n * LC_EMAX;
+  for (int i = 0; i < (int)c.W->necnt[n]; ++i) {
+    uint32_t nn = ED_TO(e[i]);
+    if (nn != n) remove_edge(c, nn, n, fliplink(ED_DIR(e[i])));
+  }
+}
+
+// position data behind a sequence descriptor (cov_t of the reference, src/Ref.hh:41-53)
+DEV void desc_cov(const Ctx &c, uint32_t d, int sampleT, uint16_t *fwd, uint16_t *rev, uint16_t *qf, uint16_t *qr) {
+  uint32_t km = SD_KMER(d);
+  const uint32_t *cn = c.W->ncnt + 4 * km;
+  int o = sampleT ? 0 : 2;
+  *fwd = (uint16_t)cn[o]; *rev = (uint16_t)cn[o + 1];
+  uint32_t q = c.W->nqv[km];
+  if (q == LC_NIL) { *qf = 0; *qr = 0; return; }
+  const uint16_t *qq = c.W->qv + ((size_t)q * c.S->K + SD_OFF(d)) * 4;
+  *qf = qq[o]; *qr = qq[o + 1];
+}
+DEV void desc_tot(const Ctx &c, uint32_t d, int *tot, int *totqv) {  // operands of Node_t::computeMinCov
+  uint32_t km = SD_KMER(d);
+  const uint32_t *cn = c.W->ncnt + 4 * km;
+  *tot = (int)(uint16_t)cn[0] + (int)(uint16_t)cn[1] + (int)(uint16_t)cn[2] + (int)(uint16_t)cn[3];
+  uint32_t q = c.W->nqv[km];
+  if (q == LC_NIL) { *totqv = 0; return; }
+  const uint16_t *qq = c.W->qv + ((size_t)q * c.S->K + SD_OFF(d)) * 4;
+  *totqv = (int)qq[0] + (int)qq[1] + (int)qq[2] + (int)qq[3];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// libstdc++ unordered_map order: exact replay of _M_insert_bucket_begin / _M_rehash_aux / _Prime_rehash_policy
+// (hashtable.h:1888-1912, 2380-2420, hashtable_policy.h / hashtable_c++0x.cc).
+// The prime chain is the subset of __prime_list reachable by growth_factor 2 from the initial 13 buckets.
+// ---------------------------------------------------------------------------------------------------------
+DEV uint32_t ht_next_prime(uint32_t n) {   // _M_next_bkt(n) for the values that can occur (n = 2*bucket_count or <= 13)
+  const uint32_t chain[] = {13u, 29u, 59u, 127u, 257u, 541u, 1109u, 2357u, 5087u, 10273u, 20753u, 42043u,
+                            85229u, 172933u, 351061u, 712697u, 1447153u, 2938679u};
+  for (int i = 0; i < 18; ++i) if (chain[i] >= n) return chain[i];
+  return 0;
+}
+DEV void ht_reset(Ctx &c) { WinShared &S = *c.S; S.ht_bc = 1; S.ht_next_resize = 0; S.ht_elt = 0; S.ht_head = LC_NIL; c.W->ht_bucket[0] = LC_NIL; }
+DEV void ht_rehash(Ctx &c, uint32_t nb) {
+  WinShared &S = *c.S; Work &W = *c.W;
+  if (nb == 0 || nb > c.C->bucket_cap) { OVF(c); return; }
+  for (uint32_t i = 0; i < nb; ++i) W.ht_bucket[i] = LC_NIL;
+  uint32_t p = S.ht_head; S.ht_head = LC_NIL;
+  uint32_t bbegin = 0;
+  while (p != LC_NIL) {
+    uint32_t nxt = W.ht_next[p];
+    uint32_t b = (uint32_t)(W.nhash[p] % nb);
+    if (W.ht_bucket[b] == LC_NIL) {
+      W.ht_next[p] = S.ht_head; S.ht_head = p; W.ht_bucket[b] = LC_BB;
+      if (W.ht_next[p] != LC_NIL) W.ht_bucket[bbegin] = p;
+      bbegin = b;
+    } else {
+      uint32_t prev = W.ht_bucket[b];
+      if (prev == LC_BB) { W.ht_next[p] = S.ht_head; S.ht_head = p; }
+      else { W.ht_next[p] = W.ht_next[prev]; W.ht_next[prev] = p; }
+    }
+    p = nxt;
+  }
+  S.ht_bc = nb;
+}
+DEV void ht_insert(Ctx &c, uint32_t n) {
+  WinShared &S = *c.S; Work &W = *c.W;
+  if (S.ht_elt + 1 > S.ht_next_resize) {                      // _Prime_rehash_policy::_M_need_rehash
+    unsigned long long mn = S.ht_elt + 1;
+    if (S.ht_next_resize == 0 && mn < 11) mn = 11;
+    if (mn >= S.ht_bc) {
+      unsigned long long want = mn + 1; if (want < 2ULL * S.ht_bc) want = 2ULL * S.ht_bc;
+      uint32_t nb = ht_next_prime((uint32_t)want);
+      S.ht_next_resize = nb;
+      ht_rehash(c, nb);
+      if (S.overflow) return;
+    } else S.ht_next_resize = S.ht_bc;
+  }
+  uint32_t b = (uint32_t)(W.nhash[n] % S.ht_bc);
+  uint32_t prev = W.ht_bucket[b];
+  if (prev != LC_NIL) {
+    if (prev == LC_BB) { W.ht_next[n] = S.ht_head; S.ht_head = n; }
+    else { W.ht_next[n] = W.ht_next[prev]; W.ht_next[prev] = n; }
+  } else {
+    W.ht_next[n] = S.ht_head; S.ht_head = n;
+    if (W.ht_next[n] != LC_NIL) W.ht_bucket[(uint32_t)(W.nhash[W.ht_next[n]] % S.ht_bc)] = n;
+    W.ht_bucket[b] = LC_BB;
+  }
+  ++S.ht_elt;
+}
+// Insert into the (array form of the) live table: unordered_map::insert after erasures.  Erase never moves
+// other nodes and keeps each bucket's run contiguous, so "bucket empty" == no live node hashes to it.
+DEV void order_insert(Ctx &c, uint32_t n) {
+  WinShared &S = *c.S; Work &W = *c.W;
+  if (S.ht_elt + 1 > S.ht_next_resize) {
+    unsigned long long mn = S.ht_elt + 1;
+    if (S.ht_next_resize == 0 && mn < 11) mn = 11;
+    if (mn >= S.ht_bc) {   // rebuild the linked form from the array, rehash, and read the array back
+      unsigned long long want = mn + 1; if (want < 2ULL * S.ht_bc) want = 2ULL * S.ht_bc;
+      uint32_t nb = ht_next_prime((uint32_t)want);
+      S.ht_head = S.M ? W.order[0] : LC_NIL;
+      for (uint32_t i = 0; i < S.M; ++i) W.ht_next[W.order[i]] = (i + 1 < S.M) ? W.order[i + 1] : LC_NIL;
+      S.ht_next_resize = nb;
+      ht_rehash(c, nb);
+      if (S.overflow) return;
+      uint32_t m = 0;
+      for (uint32_t p = S.ht_head; p != LC_NIL; p = W.ht_next[p]) W.order[m++] = p;
+    } else S.ht_next_resize = S.ht_bc;
+  }
+  uint32_t b = (uint32_t)(W.nhash[n] % S.ht_bc);
+  uint32_t at = 0;
+  for (uint32_t i = 0; i < S.M; ++i) if ((uint32_t)(W.nhash[W.order[i]] % S.ht_bc) == b) { at = i; break; }
+  for (uint32_t i = S.M; i > at; --i) W.order[i] = W.order[i - 1];
+  W.order[at] = n;
+  ++S.M; ++S.ht_elt;
+}
+// cleanDead (reference src/Graph.cc:2737-2762): erase every dead node from the table
+DEV uint32_t clean_dead(Ctx &c) {
+  WinShared &S = *c.S; Work &W = *c.W;
+  uint32_t m = 0, dead = 0;
+  for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (W.nflags[n] & NF_DEAD) ++dead; else W.order[m++] = n; }
+  S.M = m; S.ht_elt -= dead;
+  evt(c, EV_CLEANDEAD, dead);
+  return dead;
+}
+DEV void print_stats(Ctx &c, int comp) {                            // Graph_t::printStats, reference src/Graph.cc:3674-3691
+  if (!c.C->evt_cap) return;
+  WinShared &S = *c.S; Work &W = *c.W;
+  int edgecnt = 0, span = 0;
+  for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (W.ncomp[n] == comp) { edgecnt += W.necnt[n]; span += n_strlen(c, n); } }
+  evt(c, EV_STATS, comp, S.M, edgecnt, span);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// sequence deques
+// ---------------------------------------------------------------------------------------------------------
+DEV bool seq_reserve(Ctx &c, uint32_t n, uint32_t front, uint32_t back) {   // room for `front` more before, `back` after
+  Work &W = *c.W; WinShared &S = *c.S;
+  uint32_t lo = W.nseq_lo[n], hi = W.nseq_hi[n];
+  if (lo - W.nseq_clo[n] >= front && W.nseq_chi[n] - hi >= back) return true;
+  uint32_t len = hi - lo;
+  uint32_t cap = 2 * (len + front + back) + 16;
+  if (S.seq_top + cap > c.C->seq_cap) { OVF(c); return false; }
+  uint32_t nclo = S.seq_top; S.seq_top += cap;
+  uint32_t nlo = nclo + (cap - len - front - back) / 2 + front;
+  for (uint32_t i = 0; i < len; ++i) W.seq[nlo + i] = W.seq[lo + i];
+  W.nseq_clo[n] = nclo; W.nseq_chi[n] = nclo + cap; W.nseq_lo[n] = nlo; W.nseq_hi[n] = nlo + len;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// buildgraph (reference src/Graph.cc:530-589 + loadSequence :119-349 + Node.cc / Ref.cc counters)
+// ---------------------------------------------------------------------------------------------------------
+DEV void read_geom(const Ctx &c, int r, uint32_t *rinfo, uint32_t *bw, uint32_t *gw, int *tlen, bool *isref) {
+  const DevBatch &B = *c.B; const WinShared &S = *c.S;
+  if (r == S.R - 1) { *isref = true; *tlen = S.reflen; *rinfo = 0; *bw = 0; *gw = 0; return; }
+  uint32_t g = B.read_begin[S.w] + (uint32_t)r;
+  *isref = false; *rinfo = B.rinfo[g]; *bw = B.base_woff[g]; *gw = B.good_woff[g]; *tlen = (int)RI_TLEN(*rinfo);
+}
+DEV int read_base(const Ctx &c, bool isref, uint32_t bw, int i) {
+  if (isref) return c.B->ref_codes[c.B->ref_off[c.S->w] + i];
+  return rd_base(c.B->bases, bw, i);
+}
+
+template <int NW>
+DEV void build_insert_pass(Ctx &c, bool verify) {
+  WinShared &S = *c.S; Work &W = *c.W;
+  const int K = S.K;
+  const uint32_t mask = c.C->table_cap - 1;
+  WG_FOR(r, S.R) {
+    uint32_t rinfo, bw, gw; int tlen; bool isref;
+    read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref);
+    if (tlen - K <= 0) continue;
+    unsigned long long fw[NW], rc[NW];
+    for (int w = 0; w < NW; ++w) { fw[w] = 0; rc[w] = 0; }
+    uint32_t o = W.occ_base[r];
+    for (int i = 0; i < tlen; ++i) {
+      int b = read_base(c, isref, bw, i);
+      key_push_fw(fw, NW, K, b);
+      key_push_rc(rc, NW, K, b);
+      if (i < K - 1) continue;
+      bool isF = key_less(fw, rc, NW);                          // CanonicalMer_t::set: mer < rmer -> F, tie -> R
+      const unsigned long long *ck = isF ? fw : rc;
+      if (!verify) {
+        unsigned long long h = 0;
+        for (int w = 0; w < NW; ++w) h = mix64(h ^ (ck[w] + 0x9e3779b97f4a7c15ULL * (unsigned long long)(w + 1)));
+        if (h == 0) h = 1;
+        uint32_t idx = (uint32_t)h & mask;
+        uint32_t probes = 0;
+        while (true) {
+          unsigned long long cur = W.tags[idx];
+          if (cur == h) break;
+          if (cur == 0) {
+            unsigned long long old = dev_atomic_cas64(&W.tags[idx], 0ULL, h);
+            if (old == 0) { for (int w = 0; w < NW; ++w) W.slot_key[(size_t)idx * LC_NWMAX + w] = ck[w]; break; }
+            if (old == h) break;
+          }
+          idx = (idx + 1) & mask;
+          if (++probes > mask) { OVF(c); break; }
+        }
+        dev_atomic_min(&W.slot_first[idx], o);
+        W.occ[o] = idx | (isF ? 0u : 0x80000000u);
+      } else {
+        uint32_t idx = W.occ[o] & 0x7FFFFFFFu;
+        for (int w = 0; w < NW; ++w) if (W.slot_key[(size_t)idx * LC_NWMAX + w] != ck[w]) OVF(c);   // 64-bit tag collision
+      }
+      ++o;
+    }
+  }
+  WG_SYNC();
+}
+
+// tumor flag condition of loadSequence (reference src/Graph.cc:209-217): step s of a read qualifies when all
+// K quals of u and of v pass, i.e. bases s..s+K are all >= MIN_QUAL_CALL.
+DEV bool step_all_good(const Ctx &c, bool isref, uint32_t gw, int s, int tlen, int K) {
+  if (s < 0 || s >= tlen - K) return false;
+  if (isref) return true;                                        // reference quality string is 'K' everywhere
+  return good_count(c.B->good, gw, s, s + K + 1) == K + 1;
+}
+
+DEV void build_graph(Ctx &c) {
+  WinShared &S = *c.S; Work &W = *c.W; const EngineCaps &C = *c.C;
+  const int K = S.K;
+  // ---- occurrence index space: read r owns [occ_base[r], occ_base[r+1]) = its k-mers p = 0..tlen-K
+  WG_LANE0 {
+    uint32_t o = 0; int bp = 0;
+    for (int r = 0; r < S.R; ++r) {
+      uint32_t rinfo, bw, gw; int tlen; bool isref;
+      read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref);
+      W.occ_base[r] = o;
+      if (tlen > 0 && !isref) bp += tlen;                        // totalreadbp_m (Graph.cc:121-124)
+      if (tlen - K > 0) { o += (uint32_t)(tlen - K + 1); S.n_kmers += (unsigned long long)(tlen - K); }
+    }
+    W.occ_base[S.R] = o;
+    S.O = o; S.totalreadbp = bp;
+    if (o > C.occ_cap) OVF(c);
+    ++S.n_builds;
+  }
+  if (wg_bcast(&S.overflow)) return;
+  WG_FOR(i, C.table_cap) { W.tags[i] = 0; W.slot_first[i] = LC_NIL; }
+  WG_FOR(i, (int)(S.O / 32 + 2)) { W.bitmap[i] = 0; }
+  WG_SYNC();
+  // ---- pass 1: canonical k-mers -> open-addressing slots
+  switch (S.NW) { case 1: build_insert_pass<1>(c, false); break; case 2: build_insert_pass<2>(c, false); break;
+                  case 3: build_insert_pass<3>(c, false); break; default: build_insert_pass<4>(c, false); break; }
+  switch (S.NW) { case 1: build_insert_pass<1>(c, true); break; case 2: build_insert_pass<2>(c, true); break;
+                  case 3: build_insert_pass<3>(c, true); break; default: build_insert_pass<4>(c, true); break; }
+  if (wg_bcast(&S.overflow)) return;
+  // ---- dense node ids in first-insertion order (= order of first occurrence, Graph.cc:163-197)
+  WG_FOR(i, C.table_cap) { if (W.tags[i] != 0) { uint32_t f = W.slot_first[i]; dev_atomic_or(&W.bitmap[f >> 5], 1u << (f & 31)); } }
+  WG_SYNC();
+  int nwords = (int)(S.O / 32 + 1);
+  WG_FOR(i, nwords) { W.bitpre[i] = (uint32_t)dev_popc(W.bitmap[i]); }
+  WG_SYNC();
+  wg_scan(W.bitpre, nwords, S);
+  WG_LANE0 { S.N = S.part[LANCET_WG]; if (S.N > C.node_cap) OVF(c); if (S.N > S.max_nodes) S.max_nodes = S.N; S.nspecial = 0; }
+  if (wg_bcast(&S.overflow)) return;
+  WG_FOR(i, C.table_cap) {
+    if (W.tags[i] != 0) {
+      uint32_t f = W.slot_first[i];
+      uint32_t id = W.bitpre[f >> 5] + (uint32_t)dev_popc(W.bitmap[f >> 5] & ((1u << (f & 31)) - 1u));
+      W.slot_node[i] = id;
+      for (int w = 0; w < S.NW; ++w) W.nkey[(size_t)id * LC_NWMAX + w] = W.slot_key[(size_t)i * LC_NWMAX + w];
+    }
+  }
+  WG_SYNC();
+  // ---- per node: std::hash of the ASCII k-mer, zeroed counters
+  WG_FOR(n, S.N) {
+    const unsigned long long *k = W.nkey + (size_t)n * LC_NWMAX;
+    W.nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGT"[key_base(k, K, j)]; }, K);
+    for (int j = 0; j < 4; ++j) W.ncnt[4 * n + j] = 0;
+    for (int j = 0; j < 8; ++j) { W.efirst[8 * n + j] = LC_NIL; W.eto[8 * n + j] = 0; }
+    W.nflags[n] = 0; W.necnt[n] = 0; W.ncomp[n] = 0; W.nocc[n] = 0; W.nfill[n] = 0; W.nqv[n] = LC_NIL; W.ncolor[n] = 0;
+    W.nonref[n] = 0; W.nkm[n] = 1; W.nkmT[n] = 0;
+  }
+  // reads whose opposite mate (same name) comes earlier in the window: only these can ever see
+  // hasOverlappingMate()==true (reference src/Node.cc:638-661); everything else is counted directly.
+  WG_FOR(r, S.R) {
+    uint8_t cd = 0;
+    if (r != S.R - 1) {
+      uint32_t g0 = c.B->read_begin[S.w];
+      uint32_t mi = RI_MATE(c.B->rinfo[g0 + r]);
+      if (mi == 1 || mi == 2) {
+        uint32_t nm = c.B->name_rank[g0 + r];
+        for (int q = 0; q < r; ++q) if (c.B->name_rank[g0 + q] == nm && RI_MATE(c.B->rinfo[g0 + q]) == 3 - mi) { cd = 1; break; }
+      }
+    }
+    W.cand[r] = cd;
+  }
+  WG_SYNC();
+  // ---- pass 2: colours, coverage counters, edges, per-node occurrence counts
+  WG_FOR(r, S.R) {
+    uint32_t rinfo, bw, gw; int tlen; bool isref;
+    read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref);
+    if (tlen - K <= 0) continue;
+    uint32_t o0 = W.occ_base[r];
+    int nk = tlen - K + 1;
+    int ctr = isref ? -1 : ((RI_NML(rinfo) ? 2 : 0) + (RI_REV(rinfo) ? 1 : 0));
+    bool cd = W.cand[r] != 0;
+    uint32_t prevnode = 0; uint32_t prevori = 0;
+    for (int p = 0; p < nk; ++p) {
+      uint32_t oc = W.occ[o0 + p];
+      uint32_t X = W.slot_node[oc & 0x7FFFFFFFu], ori = oc >> 31;
+      uint32_t fl = 0;
+      if (!isref) {
+        if (RI_NML(rinfo)) fl |= NF_NORMAL;
+        else if (step_all_good(c, isref, gw, p, tlen, K) || step_all_good(c, isref, gw, p - 1, tlen, K)) fl |= NF_TUMOR;
+      }
+      if (fl) dev_atomic_or(&W.nflags[X], fl);
+      if (ctr >= 0 && !cd) dev_atomic_add(&W.ncnt[4 * X + ctr], 1u);
+      dev_atomic_add(&W.nocc[X], 1u);
+      if (p > 0) {   // step (p-1): u = prev, v = X   (Graph.cc:320-347)
+        uint32_t fdir = (prevori == 0) ? (ori == 0 ? 0u : 1u) : (ori == 0 ? 2u : 3u);     // FF FR RF RR
+        uint32_t rdir = (prevori == 0) ? (ori == 0 ? 3u : 1u) : (ori == 0 ? 2u : 0u);     // RR FR RF FF
+        int bnew = read_base(c, isref, bw, p + K - 1);      // base that v adds after u
+        int bold = read_base(c, isref, bw, p - 1);          // base that u has before v
+        // slot = (side, extension base in the node's canonical orientation): F side = right extension
+        uint32_t su = (prevori == 0) ? (uint32_t)bnew : 4u + (uint32_t)(3 - bnew);
+        uint32_t sv = (ori == 0) ? 4u + (uint32_t)bold : (uint32_t)(3 - bold);
+        uint32_t stamp = 2u * (o0 + (uint32_t)p - 1u);
+        W.eto[8 * prevnode + su] = ED_MAKE(X, fdir);
+        dev_atomic_min(&W.efirst[8 * prevnode + su], stamp);
+        W.eto[8 * X + sv] = ED_MAKE(prevnode, rdir);
+        dev_atomic_min(&W.efirst[8 * X + sv], stamp + 1u);
+      }
+      W.occ[o0 + p] = X | (ori << 31);
+      prevnode = X; prevori = ori;
+    }
+  }
+  WG_SYNC();
+  // ---- csr of occurrences by node
+  WG_LANE0 { W.nocc[S.N] = 0; }
+  WG_SYNC();
+  wg_scan(W.nocc, (int)S.N + 1, S);
+  WG_FOR(r, S.R) {
+    uint32_t rinfo, bw, gw; int tlen; bool isref;
+    read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref);
+    if (tlen - K <= 0) continue;
+    uint32_t o0 = W.occ_base[r];
+    uint32_t st = isref ? 2u : (W.cand[r] ? 1u : 0u);     // the reference read never counts (Graph.cc:265)
+    for (int p = 0; p < tlen - K + 1; ++p) {
+      uint32_t oc = W.occ[o0 + p];
+      uint32_t X = oc & 0x7FFFFFFFu;
+      uint32_t at = W.nocc[X] + dev_atomic_add(&W.nfill[X], 1u);
+      W.csr[at] = CS_MAKE(r, p, oc >> 31, st);
+    }
+  }
+  WG_SYNC();
+  // ---- mate-overlap replay for candidate reads (sequential, rare): reproduces std::binary_search over the
+  //      unsorted vector of opposite-mate names pushed so far on the node.
+  WG_LANE0 {
+    uint32_t g0 = c.B->read_begin[S.w];
+    for (int r = 0; r < S.R - 1; ++r) {
+      if (!W.cand[r]) continue;
+      uint32_t rinfo = c.B->rinfo[g0 + r];
+      int tlen = (int)RI_TLEN(rinfo);
+      if (tlen - K <= 0) continue;
+      uint32_t mi = RI_MATE(rinfo), nm = c.B->name_rank[g0 + r];
+      int ctr = (RI_NML(rinfo) ? 2 : 0) + (RI_REV(rinfo) ? 1 : 0);
+      for (int p = 0; p < tlen - K + 1; ++p) {
+        uint32_t X = W.occ[W.occ_base[r] + p] & 0x7FFFFFFFu;
+        uint32_t lo = W.nocc[X], hi = W.nocc[X + 1];
+        // gather pushes of the other mate from earlier reads, ordered by (read, position)
+        uint32_t *buf = W.scratch; uint32_t m = 0; uint32_t self = LC_NIL;
+        for (uint32_t i = lo; i < hi; ++i) {
+          uint32_t e = W.csr[i];
+          int er = (int)CS_READ(e), ep = (int)CS_POS(e);
+          if (er == r && ep == p) self = i;
+          if (er >= r || er == S.R - 1) continue;
+          if (RI_MATE(c.B->rinfo[g0 + er]) != 3 - mi) continue;
+          buf[m++] = ((uint32_t)er << 10) | (uint32_t)ep;
+        }
+        for (uint32_t i = 1; i < m; ++i) { uint32_t v = buf[i]; uint32_t j = i; while (j > 0 && buf[j - 1] > v) { buf[j] = buf[j - 1]; --j; } buf[j] = v; }
+        // virtual vector: each entry contributes 1 push as v (pos >= 1) and 1 push as u (pos <= tlen'-K-1)
+        uint32_t total = 0;
+        for (uint32_t i = 0; i < m; ++i) {
+          int er = (int)(buf[i] >> 10), ep = (int)(buf[i] & 1023);
+          int etl = (int)RI_TLEN(c.B->rinfo[g0 + er]);
+          uint32_t pushes = (ep >= 1 ? 1u : 0u) + (ep <= etl - K - 1 ? 1u : 0u);
+          buf[i] = (c.B->name_rank[g0 + er] << 2) | pushes;     // name ranks < 2^30
+          total += pushes;
+        }
+        auto elem = [&](uint32_t t) -> uint32_t { for (uint32_t i = 0; i < m; ++i) { uint32_t pc = buf[i] & 3u; if (t < pc) return buf[i] >> 2; t -= pc; } return 0u; };
+        uint32_t first = 0, len = total;                          // std::lower_bound
+        while (len > 0) { uint32_t half = len >> 1; uint32_t mid = first + half; if (elem(mid) < nm) { first = mid + 1; len = len - half - 1; } else len = half; }
+        bool ovl = (first != total) && !(nm < elem(first));
+        uint32_t e = W.csr[self];
+        if (!ovl) { W.ncnt[4 * X + ctr] += 1; W.csr[self] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), 0u); }
+        else W.csr[self] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), 2u);
+      }
+    }
+    S.seq_top = 0; S.qv_top = 0;
+  }
+  WG_SYNC();
+  // ---- per node: edges in first-seen order, float coverages, minimum coverages; first removeLowCov predicate
+  //      (reference src/Graph.cc:2790-2827 with docompression=false, compid=0) evaluated in the same pass.
+  const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
+  WG_FOR(n, S.N) {
+    uint32_t stamp[8]; uint32_t tgt[8]; int ne = 0;
+    for (int j = 0; j < 8; ++j) if (W.efirst[8 * n + j] != LC_NIL) { stamp[ne] = W.efirst[8 * n + j]; tgt[ne] = W.eto[8 * n + j]; ++ne; }
+    for (int i = 1; i < ne; ++i) { uint32_t s = stamp[i], t = tgt[i]; int j = i; while (j > 0 && stamp[j - 1] > s) { stamp[j] = stamp[j - 1]; tgt[j] = tgt[j - 1]; --j; } stamp[j] = s; tgt[j] = t; }
+    for (int i = 0; i < ne; ++i) W.edges[n * LC_EMAX + i] = tgt[i];
+    W.necnt[n] = ne;
+    const uint32_t *cn = W.ncnt + 4 * n;
+    for (int j = 0; j < 4; ++j) W.ncov[4 * n + j] = (float)cn[j];
+    int tot = (int)(uint16_t)cn[0] + (int)(uint16_t)cn[1] + (int)(uint16_t)cn[2] + (int)(uint16_t)cn[3];
+    // min over the K positions of the number of counted reads whose base there passes MIN_QUAL_CALL
+    int minqv = 10000000;
+    uint32_t lo = W.nocc[n], hi = W.nocc[n + 1];
+    for (int i = 0; i < K; ++i) {
+      int s = 0;
+      for (uint32_t q = lo; q < hi; ++q) {
+        uint32_t e = W.csr[q];
+        if (CS_ST(e) != 0) continue;
+        uint32_t g = c.B->read_begin[S.w] + CS_READ(e);
+        int pos = (int)CS_POS(e) + (CS_ORI(e) ? (K - 1 - i) : i);
+        s += rd_good(c.B->good, c.B->good_woff[g], pos);
+      }
+      if (s < minqv) minqv = s;
+    }
+    W.nmincov[n] = tot; W.nmincovqv[n] = minqv;
+    float tt = W.ncov[4 * n] + W.ncov[4 * n + 1], tn = W.ncov[4 * n + 2] + W.ncov[4 * n + 3];
+    bool low = (minqv <= c.P->low_cov_threshold) || ((double)minqv <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
+    if (!low) dev_atomic_or(&W.nflags[n], NF_SURV);
+  }
+  WG_SYNC();
+  // ---- Ref_t::mertable membership (indexMers over the possibly trimmed seq, reference src/Ref.cc:40-64)
+  {
+    uint32_t ro = W.occ_base[S.R - 1];
+    int nrefk = S.reflen - K + 1;                          // k-mers of the reference pseudo-read
+    bool loaded = (S.reflen - K > 0);
+    WG_FOR(i, S.seq_len - K > 0 ? S.seq_len - K : 0) {     // i + K < seq.length()
+      int p = S.seq_t5 + i;
+      if (loaded && p < nrefk) dev_atomic_or(&W.nflags[W.occ[ro + p] & 0x7FFFFFFFu], NF_INMER);
+    }
+    WG_SYNC();
+    // ---- Ref_t::computeCoverage (reference src/Ref.cc:173-250): per rawseq position, Tf Tr Nf Nr
+    WG_FOR(j, S.reflen) { for (int q = 0; q < 4; ++q) W.refcov[4 * j + q] = 0; }
+    WG_SYNC();
+    WG_FOR(i, S.reflen - K > 0 ? S.reflen - K : 0) {       // i + K < rawseq.length()
+      uint32_t X = W.occ[ro + i] & 0x7FFFFFFFu;
+      uint16_t v[4] = {0, 0, 0, 0};
+      if (W.nflags[X] & NF_INMER) for (int q = 0; q < 4; ++q) v[q] = (uint16_t)W.ncnt[4 * X + q];
+      if (i == 0) { for (int j = 0; j < K; ++j) for (int q = 0; q < 4; ++q) W.refcov[4 * j + q] = v[q]; }
+      else { for (int q = 0; q < 4; ++q) W.refcov[4 * (i + K - 1) + q] = v[q]; }
+    }
+    WG_SYNC();
+  }
+}
+
+// per-position quality counts + sequence descriptors for the nodes that survive the first filter
+DEV void materialize_survivors(Ctx &c) {
+  WinShared &S = *c.S; Work &W = *c.W;
+  const int K = S.K;
+  WG_LANE0 {
+    uint32_t ns = 0;
+    for (uint32_t n = 0; n < S.N; ++n) if (W.nflags[n] & NF_SURV) { W.nqv[n] = ns++; }
+    if (ns > c.C->surv_cap || (size_t)ns * K > (size_t)c.C->seq_cap) OVF(c);
+    S.tmp0 = (int)ns;
+  }
+  if (wg_bcast(&S.overflow)) return;
+  WG_FOR(n, S.N) {
+    if (!(W.nflags[n] & NF_SURV)) continue;
+    uint32_t q = W.nqv[n];
+    uint32_t lo = W.nocc[n], hi = W.nocc[n + 1];
+    for (int i = 0; i < K; ++i) {
+      uint16_t s[4] = {0, 0, 0, 0};
+      for (uint32_t x = lo; x < hi; ++x) {
+        uint32_t e = W.csr[x];
+        if (CS_ST(e) != 0) continue;
+        uint32_t g = c.B->read_begin[S.w] + CS_READ(e);
+        uint32_t ri = c.B->rinfo[g];
+        int pos = (int)CS_POS(e) + (CS_ORI(e) ? (K - 1 - i) : i);
+        if (rd_good(c.B->good, c.B->good_woff[g], pos)) s[(RI_NML(ri) ? 2 : 0) + (RI_REV(ri) ? 1 : 0)]++;
+      }
+      uint16_t *qq = W.qv + ((size_t)q * K + i) * 4;
+      qq[0] = s[0]; qq[1] = s[1]; qq[2] = s[2]; qq[3] = s[3];
+    }
+    // descriptor deque: K entries, no slack yet (grown on first merge)
+    uint32_t base = q * (uint32_t)K;
+    const unsigned long long *k = W.nkey + (size_t)n * LC_NWMAX;
+    for (int i = 0; i < K; ++i) W.seq[base + i] = SD_MAKE(n, i, key_base(k, K, i));
+    W.nseq_clo[n] = base; W.nseq_lo[n] = base; W.nseq_hi[n] = base + K; W.nseq_chi[n] = base + K;
+    uint32_t fl = W.nflags[n];
+    W.nkmT[n] = ((fl & NF_TUMOR) && !(fl & NF_NORMAL)) ? 1u : 0u;      // cov_status == 'T'
+  }
+  WG_LANE0 { S.seq_top = (uint32_t)S.tmp0 * (uint32_t)K; }
+  WG_SYNC();
+}
+
+// first removeLowCov(false, 0) + cleanDead; markRefNodes counters for the trace
+DEV void first_lowcov(Ctx &c) {
+  WinShared &S = *c.S; Work &W = *c.W;
+  // the live table in libstdc++ iteration order
+  WG_LANE0 {
+    ht_reset(c);
+    for (uint32_t n = 0; n < S.N && !S.overflow; ++n) ht_insert(c, n);
+    uint32_t m = 0;
+    for (uint32_t p = S.ht_head; p != LC_NIL; p = W.ht_next[p]) W.order[m++] = p;
+    S.M = m;
+  }
+  WG_SYNC();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// graph passes (single lane; the graphs are small after the first filter)
+// ---------------------------------------------------------------------------------------------------------
+DEV void recompute_after_append(Ctx &c, uint32_t n, uint32_t from, uint32_t to) {
+  // Node_t::computeMinCov over the merged arrays == min(old minima, minima over the appended descriptors)
+  Work &W = *c.W;
+  int mn = W.nmincov[n], mq = W.nmincovqv[n];
+  for (uint32_t i = from; i < to; ++i) { int t, tq; desc_tot(c, W.seq[i], &t, &tq); if (t < mn) mn = t; if (tq < mq) mq = tq; }
+  W.nmincov[n] = mn; W.nmincovqv[n] = mq;
+}
+
+DEV void compress_node(Ctx &c, uint32_t node, char dir) {          // Graph_t::compressNode, reference src/Graph.cc:2486-2706
+  Work &W = *c.W; WinShared &S = *c.S;
+  const int K = S.K;
+  while (!S.overflow) {
+    int uid = get_buddy(c, node, dir);
+    if (uid == -1) return;
+    if (is_tandem(c, node)) return;
+    uint32_t ew = W.edges[node * LC_EMAX + uid];
+    uint32_t edir = ED_DIR(ew);
+    char bdir = (edir == 0 || edir == 2) ? 'R' : 'F';
+    uint32_t buddy = ED_TO(ew);
+    if (is_tandem(c, buddy)) return;
+    int buid = get_buddy(c, buddy, bdir);
+    if (buid == -1) return;
+    bool brev = dir_dest(edir) == 'R';
+    int alen = n_len(c, node), blen = n_len(c, buddy);
+    uint32_t tail = (uint32_t)(blen - (K - 1));
+    // merged = astr + bstr[K-1:]  (dir F: append ; dir R: prepend the reverse complement)
+    if (dir == 'F') {
+      if (!seq_reserve(c, node, 0, tail)) return;
+      uint32_t hi = W.nseq_hi[node], blo = W.nseq_lo[buddy], bhi = W.nseq_hi[buddy];
+      for (uint32_t t = 0; t < tail; ++t) {
+        uint32_t d = brev ? W.seq[bhi - 1 - ((uint32_t)(K - 1) + t)] : W.seq[blo + (uint32_t)(K - 1) + t];
+        if (brev) d ^= 3u;
+        W.seq[hi + t] = d;
+      }
+      W.nseq_hi[node] = hi + tail;
+      recompute_after_append(c, node, hi, hi + tail);
+    } else {
+      if (!seq_reserve(c, node, tail, 0)) return;
+      uint32_t lo = W.nseq_lo[node], blo = W.nseq_lo[buddy], bhi = W.nseq_hi[buddy];
+      // element t of B'[K-1:] lands at lo-1-t, complemented
+      for (uint32_t t = 0; t < tail; ++t) {
+        uint32_t d = brev ? W.seq[bhi - 1 - ((uint32_t)(K - 1) + t)] : W.seq[blo + (uint32_t)(K - 1) + t];
+        if (brev) d ^= 3u;
+        W.seq[lo - 1 - t] = d ^ 3u;
+      }
+      W.nseq_lo[node] = lo - tail;
+      recompute_after_append(c, node, lo - tail, lo);
+    }
+    W.nkm[node] += W.nkm[buddy]; W.nkmT[node] += W.nkmT[buddy];
+    int amer = alen - K + 1, bmer = blen - K + 1;
+    float *nc = W.ncov + 4 * node; const float *bc = W.ncov + 4 * buddy;
+    for (int q = 0; q < 4; ++q) nc[q] = ((nc[q] * amer) + (bc[q] * bmer)) / (amer + bmer);      // Graph.cc:2632-2636
+    W.nflags[buddy] |= NF_DEAD;
+    W.nflags[node] |= (W.nflags[buddy] & (NF_TUMOR | NF_NORMAL));
+    erase_edge_at(c, node, uid);
+    int bcnt = (int)W.necnt[buddy];
+    for (int i = 0; i < bcnt; ++i) {
+      if (i == buid) continue;
+      uint32_t be = W.edges[buddy * LC_EMAX + i];
+      uint32_t ndir = ED_DIR(be);
+      if (edir == 1 || edir == 2) ndir = flipme(ndir);
+      uint32_t other = ED_TO(be);
+      int cnt = (int)W.necnt[node];
+      if (cnt >= LC_EMAX) { OVF(c); return; }
+      if (other == buddy) { W.edges[node * LC_EMAX + cnt] = ED_MAKE(node, ndir) | (be & (1u << 30)); W.necnt[node] = cnt + 1; }
+      else {
+        W.edges[node * LC_EMAX + cnt] = ED_MAKE(other, ndir) | (be & (1u << 30)); W.necnt[node] = cnt + 1;
+        update_edge(c, other, buddy, fliplink(ED_DIR(be)), node, fliplink(ndir));
+      }
+    }
+  }
+}
+DEV void compress(Ctx &c, int comp) {                               // reference src/Graph.cc:2712-2732
+  WinShared &S = *c.S; Work &W = *c.W;
+  evt(c, EV_COMPRESS);
+  for (uint32_t i = 0; i < S.M && !S.overflow; ++i) {
+    uint32_t n = W.order[i];
+    if (W.ncomp[n] != comp) continue;
+    if (W.nflags[n] & NF_DEAD) continue;
+    if (W.nflags[n] & NF_SPECIAL) continue;
+    compress_node(c, n, 'F');
+    compress_node(c, n, 'R');
+  }
+  clean_dead(c);
+}
+DEV void remove_low_cov(Ctx &c, int comp) {                         // reference src/Graph.cc:2790-2827 (docompression=true)
+  WinShared &S = *c.S; Work &W = *c.W;
+  const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
+  uint32_t low = 0;
+  for (uint32_t i = 0; i < S.M; ++i) {
+    uint32_t n = W.order[i];
+    if (W.ncomp[n] != comp) continue;
+    if (W.nflags[n] & NF_SPECIAL) continue;
+    int mq = W.nmincovqv[n];
+    float tt = W.ncov[4 * n] + W.ncov[4 * n + 1], tn = W.ncov[4 * n + 2] + W.ncov[4 * n + 3];
+    if ((mq <= c.P->low_cov_threshold) || ((double)mq <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f)) { ++low; remove_node(c, n); }
+  }
+  evt(c, EV_LOWCOV, low);
+  clean_dead(c);
+  compress(c, comp);
+  print_stats(c, comp);
+}
+
+// findTandems (reference src/util.cc:574-758) on a code string (0..3); returns ans, len, motif (codes)
+DEV bool find_tandems(const Ctx &c, const uint8_t *seq, int n, int pos, int *len, uint8_t *motif, int *motif_len) {
+  const unsigned MAXU = (unsigned)c.P->max_unit_len, MRU = (unsigned)c.P->min_report_units, MRL = (unsigned)c.P->min_report_len;
+  const int delta = c.P->dist_from_str;
+  bool ans = false;
+  int offsets[9][8];
+  for (unsigned ml = 1; ml <= MAXU && ml <= 8; ++ml) for (unsigned ph = 0; ph < ml; ++ph) offsets[ml][ph] = (int)ph;
+  *motif_len = 0;
+  for (unsigned i = 0; i < (unsigned)n; ++i) {
+    for (unsigned merlen = 1; merlen <= MAXU && merlen <= 8; ++merlen) {
+      int phase = (int)(i % merlen);
+      int offset = offsets[merlen][phase];
+      unsigned j = 0;
+      while ((j < merlen) && (i + j < (unsigned)n) && (seq[i + j] == seq[offset + j])) ++j;
+      if (j != merlen || (i + j + 1 == (unsigned)n)) {
+        int a = offset - 1, b = offset + (int)merlen - 1;
+        int ca = (a < 0 || a >= n) ? 255 : seq[a], cb = (b < 0 || b >= n) ? 255 : seq[b];    // byte before the string is 0 in libstdc++
+        if (ca != cb) {
+          if (((i - (unsigned)offset) / merlen >= MRU) && (i - (unsigned)offset >= MRL)) {
+            unsigned ml = 1;
+            while (ml < merlen) {
+              unsigned units = (i - (unsigned)offset + j) / ml;
+              int allmatch = 1;
+              for (unsigned index = 1; allmatch && (index < units); ++index)
+                for (unsigned m = 0; m < ml; ++m) if (seq[offset + m] != seq[offset + index * ml + m]) { allmatch = 0; break; }
+              if (!allmatch) ++ml; else break;
+            }
+            if (ml == merlen) {
+              int start = offset, end = (int)(i + j), L = (int)(i + j) - offset;
+              if ((pos >= (start - delta)) && (pos <= (end + delta))) {
+                ans = true; *len = L;
+                for (unsigned z = 0; z < merlen; ++z) if (*motif_len < 60) motif[(*motif_len)++] = seq[offset + z];
+              }
+            }
+          }
+        }
+        offsets[merlen][phase] = (int)i;
+      }
+    }
+  }
+  return ans;
+}
+
+DEV void node_string(const Ctx &c, uint32_t n, uint8_t *out) {      // str_m as codes
+  const Work &W = *c.W;
+  uint32_t lo = W.nseq_lo[n], hi = W.nseq_hi[n];
+  for (uint32_t i = lo; i < hi; ++i) out[i - lo] = (uint8_t)SD_BASE(W.seq[i]);
+}
+
+DEV void remove_tips(Ctx &c, int comp) {                            // reference src/Graph.cc:2885-2926
+  WinShared &S = *c.S; Work &W = *c.W;
+  int tips = 0, round = 0;
+  do {
+    ++round; tips = 0;
+    evt(c, EV_TIPS_ROUND, round);
+    for (uint32_t i = 0; i < S.M; ++i) {
+      uint32_t n = W.order[i];
+      if (W.ncomp[n] != comp) continue;
+      if (W.nflags[n] & NF_SPECIAL) continue;
+      int deg = (int)W.necnt[n], len = n_strlen(c, n) - S.K + 1;
+      if (deg <= 1 && len < c.P->max_tip_len) { remove_node(c, n); ++tips; }
+    }
+    evt(c, EV_TIPS_REMOVED, tips);
+    if (tips) compress(c, comp);
+  } while (tips && !S.overflow);
+  print_stats(c, comp);
+}
+DEV void remove_short_links(Ctx &c, int comp) {                     // reference src/Graph.cc:2833-2880
+  WinShared &S = *c.S; Work &W = *c.W;
+  const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
+  const int max_link_len = S.K / 2;                                  // setK: floor(K/2.0)
+  const double thr = floor(sqrt(avgcov));
+  int links = 0;
+  for (uint32_t i = 0; i < S.M; ++i) {
+    uint32_t n = W.order[i];
+    if (W.ncomp[n] != comp) continue;
+    if (W.nflags[n] & NF_SPECIAL) continue;
+    int deg = (int)W.necnt[n], len = n_len(c, n) - S.K + 1;
+    if (deg >= 2 && len < max_link_len && (double)W.nmincov[n] <= thr) {
+      int L = 0, ml = 0; uint8_t motif[64];
+      int sl = n_len(c, n);
+      if (sl > (int)c.C->path_cap) { OVF(c); return; }
+      node_string(c, n, W.pseq);
+      find_tandems(c, W.pseq, sl, S.K - 1, &L, motif, &ml);
+      if (L == 0) { remove_node(c, n); ++links; }
+    }
+  }
+  evt(c, EV_LINKS, links);
+  if (links) compress(c, comp);
+  print_stats(c, comp);
+}
+
+DEV int mark_connected_components(Ctx &c) {                         // reference src/Graph.cc:2252-2336
+  WinShared &S = *c.S; Work &W = *c.W;
+  for (uint32_t i = 0; i < S.M; ++i) W.ncomp[W.order[i]] = 0;
+  int comp = 0, refcomp = 0;
+  uint32_t *Q = W.scratch;                                            // FIFO; every node enqueued <= deg+1 times
+  uint32_t qcap = 2 * (c.C->node_cap + c.C->special_cap);
+  evt(c, EV_CC, S.M);
+  for (uint32_t i = 0; i < S.M; ++i) {
+    uint32_t s = W.order[i];
+    if (W.ncomp[s] != 0) continue;
+    ++comp;
+    uint32_t qh = 0, qt = 0;
+    int touches = 0;
+    // breadth-first; a node is labelled when first reached (the reference labels on pop; same partition)
+    W.ncomp[s] = comp; Q[qt++] = s;
+    while (qh < qt) {
+      uint32_t cur = Q[qh++];
+      if (W.nflags[cur] & NF_INMER) ++touches;
+      for (int e = 0; e < (int)W.necnt[cur]; ++e) {
+        uint32_t nx = ED_TO(W.edges[cur * LC_EMAX + e]);
+        if (W.ncomp[nx] != 0) continue;
+        if (qt >= qcap) { OVF(c); return comp; }
+        W.ncomp[nx] = comp; Q[qt++] = nx;
+      }
+    }
+    if (touches) { ++refcomp; evt(c, EV_CCID, comp); }
+  }
+  S.refcomp = refcomp;
+  evt(c, EV_CCEND, comp, refcomp);
+  return comp;
+}
+
+// markRefEnds (reference src/Graph.cc:2028-2228).  The node of the reference k-mer at `offset` is the node
+// of the reference pseudo-read's occurrence at that offset (if it is still in the table).
+DEV uint32_t special_new(Ctx &c, bool issource, int comp) {
+  WinShared &S = *c.S; Work &W = *c.W;
+  if (S.nspecial >= c.C->special_cap) { OVF(c); return LC_NIL; }
+  uint32_t id = c.C->node_cap + S.nspecial++;
+  char name[24]; int L = 0;
+  const char *pre = issource ? "source" : "sink";
+  while (*pre) name[L++] = *pre++;
+  char digs[12]; int nd = 0; int v = comp; do { digs[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
+  while (nd) name[L++] = digs[--nd];
+  W.nhash[id] = std_hash_bytes([&](int j) -> int { return (int)(unsigned char)name[j]; }, L);
+  for (int q = 0; q < 4; ++q) { W.ncnt[4 * id + q] = 0; W.ncov[4 * id + q] = 0.0f; }
+  W.nflags[id] = issource ? NF_SOURCE : NF_SINK;
+  W.necnt[id] = 0; W.ncomp[id] = comp; W.nmincov[id] = 0; W.nmincovqv[id] = 0; W.nqv[id] = LC_NIL; W.ncolor[id] = 0;
+  W.nseq_lo[id] = W.nseq_hi[id] = W.nseq_clo[id] = W.nseq_chi[id] = 0; W.nkm[id] = 0; W.nkmT[id] = 0; W.nonref[id] = 0;
+  return id;
+}
+DEV void mark_ref_ends(Ctx &c, int comp) {
+  WinShared &S = *c.S; Work &W = *c.W;
+  const int K = S.K;
+  S.trim5 = 0xFFFF; S.trim3 = 0xFFFF;
+  S.source = LC_NIL; S.sink = LC_NIL;
+  uint32_t ro = W.occ_base[S.R - 1];
+  int nrefk = (S.reflen - K > 0) ? S.reflen - K + 1 : 0;
+  uint32_t src = LC_NIL, snk = LC_NIL; uint32_t src_ori = 0, snk_ori = 0; int src_off = -1, snk_off = -1;
+  bool amb = false;
+  for (int off = 0; off < nrefk; ++off) {
+    uint32_t oc = W.occ[ro + off]; uint32_t t = oc & 0x7FFFFFFFu;
+    if ((W.nflags[t] & NF_DEAD) || !(W.nflags[t] & NF_SURV)) continue;
+    if (n_totcov(c, t) >= (float)c.P->cov_threshold && W.ncomp[t] == comp) {
+      if (src == LC_NIL) { src = t; src_ori = oc >> 31; src_off = off; }
+      else if (src == t) { src = LC_NIL; amb = true; break; }
+    }
+  }
+  if (amb) { evt(c, EV_AMBIG_SRC); return; }
+  if (src == LC_NIL) { evt(c, EV_NOMATCH_SRC); return; }
+  for (int off = S.reflen - K; off >= 0; --off) {
+    if (off >= nrefk) continue;
+    uint32_t oc = W.occ[ro + off]; uint32_t t = oc & 0x7FFFFFFFu;
+    if ((W.nflags[t] & NF_DEAD) || !(W.nflags[t] & NF_SURV)) continue;
+    if (n_totcov(c, t) >= (float)c.P->cov_threshold && W.ncomp[t] == comp) {
+      if (snk == LC_NIL) { snk = t; snk_ori = oc >> 31; snk_off = off; }
+      else if (snk == t) { snk = LC_NIL; amb = true; break; }
+    }
+  }
+  if (amb) { evt(c, EV_AMBIG_SNK); return; }
+  if (snk == LC_NIL) { evt(c, EV_NOMATCH_SNK); return; }
+  int ref_dist = snk_off - src_off + K;
+  int t3 = S.reflen - snk_off - K;
+  S.seq_t5 = src_off; S.seq_len = ref_dist;                           // ref_m->seq = rawseq.substr(source_offset, ref_dist)
+  S.trim5 = src_off & 0xFFFF; S.trim3 = t3 & 0xFFFF;
+  evt(c, EV_TRIM, src_off, t3, ref_dist);
+  // fake source
+  uint32_t ns = special_new(c, true, comp); if (ns == LC_NIL) return;
+  uint32_t sourcedir = src_ori ? 1u : 0u;                              // FF, or FR when the k-mer is reversed
+  char flip = src_ori ? 'F' : 'R';                                     // Edge_t::flipdir(source_mer.ori_m)
+  for (int i = (int)W.necnt[src] - 1; i >= 0; --i) {
+    uint32_t e = W.edges[src * LC_EMAX + i];
+    if (dir_start(ED_DIR(e)) == flip) {
+      uint32_t other = ED_TO(e);
+      if (other != src) { remove_edge(c, other, src, fliplink(ED_DIR(e))); erase_edge_at(c, src, i); }
+    }
+  }
+  add_edge(c, ns, src, sourcedir);
+  add_edge(c, src, ns, fliplink(sourcedir));
+  S.source = ns;
+  order_insert(c, ns);
+  // fake sink
+  uint32_t nk = special_new(c, false, comp); if (nk == LC_NIL) return;
+  uint32_t sinkdir = snk_ori ? 0u : 3u;                                // RR, or FF when reversed
+  char same = snk_ori ? 'R' : 'F';
+  for (int i = (int)W.necnt[snk] - 1; i >= 0; --i) {
+    uint32_t e = W.edges[snk * LC_EMAX + i];
+    if (dir_start(ED_DIR(e)) == same) {
+      uint32_t other = ED_TO(e);
+      if (other != snk) { remove_edge(c, other, snk, fliplink(ED_DIR(e))); erase_edge_at(c, snk, i); }
+    }
+  }
+  add_edge(c, nk, snk, sinkdir);
+  add_edge(c, snk, nk, fliplink(sinkdir));
+  S.sink = nk;
+  order_insert(c, nk);
+}
+
+DEV bool has_cycle(Ctx &c) {                                         // reference src/Graph.cc:593-681
+  WinShared &S = *c.S; Work &W = *c.W;
+  if (S.source == LC_NIL || S.sink == LC_NIL) return false;
+  for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (!(W.nflags[n] & NF_SPECIAL)) W.ncolor[n] = 1; }
+  bool ans = false;
+  // explicit stack of (node, next edge index, dir)
+  uint32_t *st = W.scratch; uint32_t cap = (2 * (c.C->node_cap + c.C->special_cap)) / 3;
+  for (int pass = 0; pass < 2 && !ans; ++pass) {
+    uint32_t sp = 0;
+    st[0] = S.source; st[1] = 0; st[2] = (uint32_t)(pass == 0 ? 'F' : 'R'); sp = 1;
+    W.ncolor[S.source] = 2;
+    while (sp && !ans) {
+      uint32_t *fr = st + 3 * (sp - 1);
+      uint32_t node = fr[0]; char dir = (char)fr[2];
+      bool descended = false;
+      while (fr[1] < W.necnt[node]) {
+        uint32_t e = W.edges[node * LC_EMAX + fr[1]]; ++fr[1];
+        if (!is_dir(ED_DIR(e), dir)) continue;
+        uint32_t other = ED_TO(e);
+        if (W.nflags[other] & NF_SPECIAL) continue;
+        if (W.ncolor[other] == 2) { ans = true; break; }
+        if (W.ncolor[other] == 1) {
+          if (sp >= cap) { OVF(c); return false; }
+          W.ncolor[other] = 2;
+          uint32_t *nf = st + 3 * sp; nf[0] = other; nf[1] = 0; nf[2] = (uint32_t)dir_dest(ED_DIR(e)); ++sp;
+          descended = true; break;
+        }
+      }
+      if (ans) break;
+      if (!descended) { W.ncolor[node] = 3; --sp; }
+    }
+  }
+  if (ans) evt(c, EV_CYCLE, S.K);
+  return ans;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// path enumeration: Graph_t::bfs (reference src/Graph.cc:1299-1425), a FIFO over whole paths.  Paths are
+// queue entries with parent links; the winner is the first-dequeued path with the most unflagged edges.
+// Returns queue index of the best path or LC_NIL.
+// ---------------------------------------------------------------------------------------------------------
+DEV bool path_has_node(const Ctx &c, uint32_t idx, uint32_t node) {
+  const BfsEntry *Q = c.W->queue;
+  for (uint32_t i = idx; i != LC_NIL; i = Q[i].parent) if (Q[i].node == node) return true;
+  return false;
+}
+DEV uint32_t bfs(Ctx &c) {
+  WinShared &S = *c.S; Work &W = *c.W;
+  BfsEntry *Q = W.queue;
+  const uint32_t cap = c.C->queue_cap;
+  int reflen = S.seq_len;
+  uint32_t qh = 0, qt = 0;
+  Q[qt].parent = LC_NIL; Q[qt].node = S.source; Q[qt].edge = LC_NIL; Q[qt].len = S.K; Q[qt].score = 0; Q[qt].dir = 'F'; Q[qt].bits = 1; ++qt;
+  uint32_t best = LC_NIL; int complete = 0; int visit = 0;
+  while (qh < qt) {
+    ++visit;
+    if (c.P->dfs_limit && visit > c.P->dfs_limit) { evt(c, EV_DFSLIMIT); break; }
+    uint32_t idx = qh++;
+    BfsEntry cur = Q[idx];
+    if (cur.node == S.sink && (cur.bits & 1) == 0) {
+      ++complete;
+      if (best == LC_NIL) best = idx; else if (cur.score > Q[best].score) best = idx;
+    } else if (cur.len > reflen + c.P->max_indel_len) {
+    } else {
+      int cnt = (int)W.necnt[cur.node];
+      for (int i = 0; i < cnt; ++i) {
+        uint32_t e = W.edges[cur.node * LC_EMAX + i];
+        if (!is_dir(ED_DIR(e), (char)cur.dir)) continue;
+        uint32_t other = ED_TO(e);
+        if (!(Q[idx].bits & 2) && path_has_node(c, idx, other)) Q[idx].bits |= 2;     // Path_t::hasCycle (informational)
+        if (qt >= cap) { OVF(c); return LC_NIL; }
+        BfsEntry ne;
+        ne.parent = idx; ne.node = other; ne.edge = (cur.node << 4) | (uint32_t)i; ne.dir = (uint8_t)dir_dest(ED_DIR(e));
+        ne.len = cur.len + n_strlen(c, other) - S.K + 1;
+        uint32_t ef = ED_FLAG(e);
+        ne.bits = (uint8_t)(((cur.bits & 1) & ef) | (Q[idx].bits & 2));
+        ne.score = (uint16_t)(cur.score + (ef == 0 ? 1 : 0));
+        Q[qt++] = ne;
+      }
+    }
+  }
+  if (complete == 0) best = LC_NIL;
+  return best;
+}
+// unpack the best path into W.pnodes / W.pedges ; returns number of nodes
+DEV int path_unpack(Ctx &c, uint32_t best) {
+  Work &W = *c.W; const BfsEntry *Q = W.queue;
+  int n = 0;
+  for (uint32_t i = best; i != LC_NIL; i = Q[i].parent) ++n;
+  int k = n;
+  for (uint32_t i = best; i != LC_NIL; i = Q[i].parent) { --k; W.pnodes[k] = Q[i].node; W.pedges[k] = Q[i].edge; }
+  return n;   // pedges[j] (j>=1) is the edge leading into node j
+}
+DEV void path_flag_edges(Ctx &c, int n, uint32_t v) {
+  Work &W = *c.W;
+  for (int j = 1; j < n; ++j) {
+    uint32_t owner = W.pedges[j] >> 4, ei = W.pedges[j] & 15u;
+    uint32_t *e = &W.edges[owner * LC_EMAX + ei];
+    *e = (*e & ~(1u << 30)) | (v << 30);
+  }
+}
+// Path_t::str + covDistr (reference src/Path.cc:69-175): string codes + descriptor per base ; returns length
+DEV int path_string(Ctx &c, int n) {
+  Work &W = *c.W; WinShared &S = *c.S;
+  const int K = S.K;
+  int len = 0;
+  uint32_t e1 = W.edges[(W.pedges[1] >> 4) * LC_EMAX + (W.pedges[1] & 15u)];
+  char dir = dir_start(ED_DIR(e1));
+  for (int i = 0; i < n; ++i) {
+    uint32_t nd = W.pnodes[i];
+    if (!(W.nflags[nd] & NF_SPECIAL)) {
+      uint32_t lo = W.nseq_lo[nd], hi = W.nseq_hi[nd];
+      int L = (int)(hi - lo);
+      int from = len > 0 ? K - 1 : 0;
+      if (len + L - from > (int)c.C->path_cap) { OVF(c); return 0; }
+      for (int j = from; j < L; ++j) {
+        uint32_t d = (dir == 'R') ? (W.seq[hi - 1 - (uint32_t)j] ^ 3u) : W.seq[lo + (uint32_t)j];
+        W.pdesc[len] = d; W.pseq[len] = (uint8_t)SD_BASE(d); ++len;
+      }
+    }
+    if (i + 1 < n) {
+      uint32_t e = W.edges[(W.pedges[i + 1] >> 4) * LC_EMAX + (W.pedges[i + 1] & 15u)];
+      dir = dir_dest(ED_DIR(e));
+    }
+  }
+  return len;
+}
+DEV uint32_t path_contig(const Ctx &c, int n, int pos) {            // Path_t::pathcontig, reference src/Path.cc:291-314
+  const Work &W = *c.W;
+  int cur = 0;
+  for (int i = 0; i < n; ++i) {
+    uint32_t nd = W.pnodes[i];
+    if (W.nflags[nd] & NF_SPECIAL) continue;
+    int span = n_len(c, nd);
+    if (cur + span >= pos) return nd;
+    cur += span - c.S->K + 1;
+  }
+  return LC_NIL;
+}
+DEV bool status_cnt_T(const Ctx &c, uint32_t n) {                   // Node_t::isStatusCnt('T'), reference src/Node.cc:423-440
+  double pr = (double)c.W->nkmT[n] / (double)c.W->nkm[n];
+  return pr > 0.8;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// global_align_aff (reference src/align.cc:235-364): full Gotoh, MATCH 2 / MISMATCH -4 / OPEN -8 / EXTEND -1,
+// the reference's tie rules; anti-diagonal wavefront across the workgroup, traceback by lane 0.
+// tb byte: M.tb [1:0] (0 '\\', 1 '<', 2 '^', 3 '*') ; X.tb [3:2] (0 '<', 1 '-', 2 '*') ; Y.tb [5:4] (0 '^', 1 '|', 2 '*')
+// ---------------------------------------------------------------------------------------------------------
+DEV void align_fill(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) {
+  Work &W = *c.W;
+  const int stride = m + 1;
+  const int A = LC_MAXW + 2;
+  int32_t *Mb[3] = {W.dp, W.dp + A, W.dp + 2 * A};
+  int32_t *Xb[2] = {W.dp + 3 * A, W.dp + 4 * A};
+  int32_t *Yb[2] = {W.dp + 5 * A, W.dp + 6 * A};
+  // boundary rows/cols of the traceback
+  WG_FOR(j, m + 1) { W.tb[j] = (uint8_t)((j == 0 ? 3 : 2) | (0 << 2) | (2 << 4)); }       // M[0][j] '^' ; Y[0][j] '*'
+  WG_FOR(i, n + 1) { if (i > 0) W.tb[(size_t)i * stride] = (uint8_t)(1 | (2 << 2) | (0 << 4)); }   // M[i][0] '<' ; X[i][0] '*'
+  WG_LANE0 { Mb[0][0] = 0; Mb[1][0] = -9; Xb[1][0] = -9; Mb[1][1] = -9; Yb[1][1] = -9; }   // diagonals 0 and 1
+  WG_SYNC();
+  for (int d = 2; d <= n + m; ++d) {
+    int32_t *Mc = Mb[d % 3], *Mp = Mb[(d + 2) % 3], *Mpp = Mb[(d + 1) % 3];
+    int32_t *Xc = Xb[d & 1], *Xp = Xb[(d + 1) & 1], *Yc = Yb[d & 1], *Yp = Yb[(d + 1) & 1];
+    int ilo = d - m; if (ilo < 1) ilo = 1;
+    int ihi = d - 1; if (ihi > n) ihi = n;
+    WG_FOR(t, ihi - ilo + 1) {
+      int i = ilo + t, j = d - i;
+      int xa = Xp[i - 1] + (-1), xb = Mp[i - 1] + (-8);
+      int xs, xt; if (xa > xb) { xs = xa; xt = 1; } else { xs = xb; xt = 0; }
+      int ya = Yp[i] + (-1), yb = Mp[i] + (-8);
+      int ys, yt; if (ya > yb) { ys = ya; yt = 1; } else { ys = yb; yt = 0; }
+      int ms = Mpp[i - 1] + (Sx[i - 1] == Tx[j - 1] ? 2 : -4), mt = 0;
+      if (xs > ms) { ms = xs; mt = 1; }
+      if (ys > ms) { ms = ys; mt = 2; }
+      Mc[i] = ms; Xc[i] = xs; Yc[i] = ys;
+      W.tb[(size_t)i * stride + j] = (uint8_t)(mt | (xt << 2) | (yt << 4));
+    }
+    WG_LANE0 {
+      if (d <= m) { Mc[0] = -8 - d; Xc[0] = -8 - d; }      // (0, d)
+      if (d <= n) { Mc[d] = -8 - d; Yc[d] = -8 - d; }      // (d, 0)
+    }
+    WG_SYNC();
+  }
+}
+// traceback into W.aln: returns alignment length; ref_aln at aln[0..L), path_aln at aln[cap..cap+L) (ASCII)
+DEV int align_traceback(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) {
+  Work &W = *c.W;
+  const int stride = m + 1;
+  const int cap = LC_MAXW + (int)c.C->path_cap + 2;
+  uint8_t *ra = W.aln, *pa = W.aln + cap;
+  int i = n, j = m, L = 0;
+  bool forcex = false, forcey = false;
+  while (i > 0 || j > 0) {
+    if (i < 0 || j < 0 || L >= cap) { OVF(c); return 0; }          // the reference would read out of bounds here
+    uint8_t b = W.tb[(size_t)i * stride + j];
+    int t = b & 3, x = (b >> 2) & 3, y = (b >> 4) & 3;
+    if (t == 3) break;
+    else if (forcex) { if (i < 1) { OVF(c); return 0; } ra[L] = "ACGT"[Sx[i - 1]]; pa[L] = '-'; ++L; if (x == 0) forcex = false; --i; }
+    else if (t == 1) { ra[L] = "ACGT"[Sx[i - 1]]; pa[L] = '-'; ++L; if (x == 1) forcex = true; --i; }
+    else if (forcey) { if (j < 1) { OVF(c); return 0; } ra[L] = '-'; pa[L] = "ACGT"[Tx[j - 1]]; ++L; if (y == 0) forcey = false; --j; }
+    else if (t == 2) { ra[L] = '-'; pa[L] = "ACGT"[Tx[j - 1]]; ++L; if (y == 1) forcey = true; --j; }
+    else { ra[L] = "ACGT"[Sx[i - 1]]; pa[L] = "ACGT"[Tx[j - 1]]; ++L; --i; --j; }
+  }
+  for (int a = 0, b2 = L - 1; a < b2; ++a, --b2) { uint8_t t1 = ra[a]; ra[a] = ra[b2]; ra[b2] = t1; uint8_t t2 = pa[a]; pa[a] = pa[b2]; pa[b2] = t2; }
+  return L;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// processPath (reference src/Graph.cc:788-1220) + Transcript_t::computeStats (reference src/Transcript.hh:123-226)
+// ---------------------------------------------------------------------------------------------------------
+struct Acc {   // one cov_t field of one of the four coverage vectors of a transcript
+  uint16_t first, mn, mnz, sum, sumnz, nnz; uint32_t n;
+};
+DEV void acc_init(Acc &a, uint16_t v) { a.first = v; a.mn = v; a.mnz = v; a.sum = 0; a.sumnz = 0; a.nnz = 0; a.n = 0; a.sum = (uint16_t)(a.sum + v); if (v != 0) { a.sumnz = (uint16_t)(a.sumnz + v); ++a.nnz; } a.n = 1; }
+DEV void acc_push(Acc &a, uint16_t v) {
+  a.sum = (uint16_t)(a.sum + v); if (v != 0) { a.sumnz = (uint16_t)(a.sumnz + v); a.nnz = (uint16_t)(a.nnz + 1); }
+  if (v < a.mn) a.mn = v;
+  if (v < a.mnz && v != 0) a.mnz = v;
+  ++a.n;
+}
+DEV uint16_t acc_mean(const Acc &a) { return a.n > 0 ? (uint16_t)((float)a.sum / (float)a.n) : (uint16_t)0; }
+
+struct TS {
+  uint32_t pos, ref_pos, start_pos, end_pos, ref_end_pos;
+  int col0, col1;          // alignment columns [col0, col1] -> transcript.ref / .qry
+  char code, prev_bp_ref, prev_bp_alt; bool somatic;
+  Acc aN[4], aT[4], rN[2], rT[2];   // alt: fwd rev minqv_fwd minqv_rev ; ref: fwd rev
+};
+DEV void ts_add_alt(TS &t, const uint16_t *n4, const uint16_t *t4) { for (int q = 0; q < 4; ++q) { acc_push(t.aN[q], n4[q]); acc_push(t.aT[q], t4[q]); } }
+DEV void ts_add_ref(TS &t, const uint16_t *n2, const uint16_t *t2) { for (int q = 0; q < 2; ++q) { acc_push(t.rN[q], n2[q]); acc_push(t.rT[q], t2[q]); } }
+
+DEV void ref_cov_at(const Ctx &c, uint32_t pos, uint16_t *n2, uint16_t *t2) {   // Ref_t::getCovStructAt, reference src/Ref.cc:253-267
+  if ((int)pos < c.S->reflen) { const uint16_t *r = c.W->refcov + 4 * pos; t2[0] = r[0]; t2[1] = r[1]; n2[0] = r[2]; n2[1] = r[3]; }
+  else { n2[0] = n2[1] = t2[0] = t2[1] = 0; }
+}
+DEV void path_cov_at(const Ctx &c, int P, uint16_t *n4, uint16_t *t4) {         // coverageN[P], coverageT[P]
+  uint32_t d = c.W->pdesc[P];
+  desc_cov(c, d, 0, &n4[0], &n4[1], &n4[2], &n4[3]);
+  desc_cov(c, d, 1, &t4[0], &t4[1], &t4[2], &t4[3]);
+}
+
+DEV void emit_variant(Ctx &c, const TS &t, const uint16_t cov[8], int strLen, const uint8_t *motif, int motifLen, bool hasStr,
+                      const uint8_t *ra, const uint8_t *pa) {
+  WinShared &S = *c.S; DevOut &O = *c.OUT;
+  uint32_t vi = dev_atomic_add(O.n_variants, 1u);
+  int rl = t.col1 - t.col0 + 1;
+  char sbuf[80]; int sl = 0;
+  if (hasStr) {
+    char digs[12]; int nd = 0; int v = strLen; do { digs[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (nd) sbuf[sl++] = digs[--nd];
+    for (int i = 0; i < motifLen; ++i) sbuf[sl++] = "ACGT"[motif[i]];
+  }
+  uint32_t need = (uint32_t)(2 * rl + sl);
+  uint32_t bo = dev_atomic_add(O.n_blob, need);
+  if (vi >= c.C->var_cap || bo + need > c.C->blob_cap) { OVF(c); return; }
+  lancet_variant &v = O.variants[vi];
+  v.window = S.w; v.seq_in_window = S.emit_seq++; v.chr_id = c.B->chr_id[S.w]; v.pos = (int32_t)t.pos - 1;
+  v.code = (uint8_t)t.code; v.prev_bp_ref = (uint8_t)t.prev_bp_ref; v.prev_bp_alt = (uint8_t)t.prev_bp_alt; v.reserved = 0;
+  v.kmer = (uint16_t)S.K; for (int q = 0; q < 8; ++q) v.cov[q] = cov[q]; v.reserved2 = 0;
+  v.ref_off = bo; v.ref_len = (uint32_t)rl; v.alt_off = bo + (uint32_t)rl; v.alt_len = (uint32_t)rl; v.str_off = bo + 2u * (uint32_t)rl; v.str_len = (uint32_t)sl;
+  for (int i = 0; i < rl; ++i) { O.blob[bo + i] = (char)ra[t.col0 + i]; O.blob[bo + rl + i] = (char)pa[t.col0 + i]; }
+  for (int i = 0; i < sl; ++i) O.blob[bo + 2 * rl + i] = sbuf[i];
+}
+
+// lane 0.  `np` = nodes in path, `plen` = path string length, aligned strings in W.aln (length L).
+DEV void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
+  WinShared &S = *c.S; Work &W = *c.W;
+  const int K = S.K;
+  const int cap = LC_MAXW + (int)c.C->path_cap + 2;
+  const uint8_t *ra = W.aln, *pa = W.aln + cap;
+  const int refstart = c.B->ref_start[S.w];
+  TS *ts = (TS *)(void *)W.tb;                 // the traceback matrix is dead by now: reuse it for the transcripts
+  int nts = 0;
+  unsigned pos_in_ref = 0, refpos = 0, pathpos = 0;
+  char code = '?', prev_code = '?';
+  int match_bp = 0, snp_bp = 0, ins_bp = 0, del_bp = 0;
+  for (int i = 0; i < L; ++i) {
+    if (ra[i] == pa[i]) ++match_bp; else if (ra[i] == '-') ++ins_bp; else if (pa[i] == '-') ++del_bp; else ++snp_bp;
+  }
+  for (int i = 0; i < L; ++i) {
+    prev_code = code;
+    if (ra[i] == '-') { code = '^'; pos_in_ref = refpos; ++pathpos; }
+    else if (pa[i] == '-') { code = 'v'; pos_in_ref = refpos; ++refpos; }
+    else { code = '='; if (ra[i] != pa[i]) code = 'x'; pos_in_ref = refpos; ++refpos; ++pathpos; }
+    uint32_t spanner = path_contig(c, np, (int)pathpos);
+    if (spanner == LC_NIL) break;
+    bool within_tumor = status_cnt_T(c, spanner);
+    int P = (int)pathpos - 1;
+    if (P < 0 || P >= plen) { OVF(c); return; }      // the reference reads coverageN[-1] here (undefined)
+    if (code != '=') {
+      uint16_t cn4[4], ct4[4], rn2[2], rt2[2];
+      path_cov_at(c, P, cn4, ct4);
+      ref_cov_at(c, pos_in_ref + (uint32_t)S.trim5, rn2, rt2);
+      unsigned rrpos = pos_in_ref + (unsigned)refstart + (unsigned)S.trim5;
+      int pr = i - 1, pq = i - 1;
+      while (pr >= 0 && ra[pr] != 'A' && ra[pr] != 'C' && ra[pr] != 'G' && ra[pr] != 'T') --pr;
+      while (pq >= 0 && pa[pq] != 'A' && pa[pq] != 'C' && pa[pq] != 'G' && pa[pq] != 'T') --pq;
+      if (pr < 0 || pq < 0) { OVF(c); return; }        // reference: assert(pr >= 0)
+      if (nts > 0 && prev_code != '=') {
+        TS &t = ts[nts - 1];
+        if (within_tumor) t.somatic = true;
+        int reflen_before = t.col1 - t.col0 + 1;        // transcript.ref.length() before the append
+        t.col1 = i; t.end_pos = (uint32_t)P; t.ref_end_pos = pos_in_ref;
+        if (code == '^' && t.code == code && t.pos == rrpos) ts_add_alt(t, cn4, ct4);
+        else if (code == 'v' && t.code == code && (t.pos + (unsigned)(reflen_before + 1)) == rrpos) ts_add_ref(t, rn2, rt2);
+        else if (code == 'x' || t.code != code) { t.code = 'c'; ts_add_alt(t, cn4, ct4); ts_add_ref(t, rn2, rt2); }
+      } else {
+        if (nts >= LC_MAXTS) { OVF(c); return; }
+        TS &t = ts[nts++];
+        t.pos = rrpos; t.ref_pos = pos_in_ref; t.start_pos = (uint32_t)(P + 1); t.code = code; t.end_pos = (uint32_t)P; t.ref_end_pos = pos_in_ref;
+        t.col0 = i; t.col1 = i; t.somatic = within_tumor; t.prev_bp_ref = (char)ra[pr]; t.prev_bp_alt = (char)pa[pq];
+        for (int q = 0; q < 4; ++q) { acc_init(t.aN[q], cn4[q]); acc_init(t.aT[q], ct4[q]); }
+        for (int q = 0; q < 2; ++q) { acc_init(t.rN[q], rn2[q]); acc_init(t.rT[q], rt2[q]); }
+      }
+    }
+  }
+  // bit 1 of the BFS entry = Path_t::hasCycle_m
+  evt(c, EV_PATH, (uint32_t)complete, (uint32_t)S.tmp3, (uint32_t)match_bp, (uint32_t)snp_bp, (uint32_t)ins_bp, (uint32_t)del_bp);
+  for (int ti = 0; ti < nts; ++ti) {
+    TS &t = ts[ti];
+    if (t.code != 'x') {
+      for (int j = 0; j <= K; ++j) {
+        unsigned idx1 = t.end_pos + (unsigned)j;
+        if (idx1 < (unsigned)plen) {
+          uint32_t sp = path_contig(c, np, (int)idx1);
+          if (sp == LC_NIL) break;
+          if (status_cnt_T(c, sp)) t.somatic = true;
+          uint16_t cn4[4], ct4[4];
+          path_cov_at(c, (int)idx1, cn4, ct4);
+          ts_add_alt(t, cn4, ct4);
+        }
+        unsigned idx2 = t.ref_end_pos + (unsigned)S.trim5 + (unsigned)j;
+        uint16_t rn2[2], rt2[2];
+        ref_cov_at(c, idx2, rn2, rt2);
+        ts_add_ref(t, rn2, rt2);
+      }
+    }
+    bool x = t.code == 'x';
+    uint16_t RCNF = t.rN[0].mn, RCNR = t.rN[1].mn, RCTF = t.rT[0].mn, RCTR = t.rT[1].mn;
+    uint16_t ACNF = x ? t.aN[2].mn : t.aN[0].mn, ACNR = x ? t.aN[3].mn : t.aN[1].mn;
+    if (!x) { ACNF = t.aN[0].mnz; ACNR = t.aN[1].mnz; }     // getMinNon0Cov*: code != 'x' -> .fwd/.rev
+    uint16_t ACTF = x ? t.aT[2].mn : t.aT[0].mn, ACTR = x ? t.aT[3].mn : t.aT[1].mn;
+    if (t.somatic) { RCNF = acc_mean(t.rN[0]); RCNR = acc_mean(t.rN[1]); RCTF = acc_mean(t.rT[0]); RCTR = acc_mean(t.rT[1]); ACNF = 0; ACNR = 0; }
+    uint16_t cov[8] = {RCNF, RCNR, RCTF, RCTR, ACNF, ACNR, ACTF, ACTR};
+    if (c.C->evt_cap) {
+      evt(c, EV_TS, t.pos, (uint32_t)(t.col1 - t.col0 + 1), ((uint32_t)RCNF << 16) | RCNR, ((uint32_t)RCTF << 16) | RCTR,
+          ((uint32_t)ACNF << 16) | ACNR, ((uint32_t)ACTF << 16) | ACTR, ((uint32_t)(uint8_t)t.prev_bp_ref << 8) | (uint8_t)t.prev_bp_alt);
+      evt_bytes(c, ra + t.col0, (uint32_t)(t.col1 - t.col0 + 1));
+      evt_bytes(c, pa + t.col0, (uint32_t)(t.col1 - t.col0 + 1));
+    }
+    if (ACNF > 0 || ACNR > 0 || ACTF > 0 || ACTR > 0) {
+      int LEN = 0, ml = 0; uint8_t motif[64];
+      bool ans = find_tandems(c, W.pseq, plen, (int)t.start_pos, &LEN, motif, &ml);
+      emit_variant(c, t, cov, LEN, motif, ml, ans, ra, pa);
+    }
+  }
+  evt(c, EV_PATH_END);
+  for (int i = 0; i < np; ++i) ++W.nonref[W.pnodes[i]];
+  // counters of eka (perfect / withsnps / withindel / withmix) ride in tmp0..tmp2 + part[0]
+  if ((snp_bp + ins_bp + del_bp) == 0) ++S.tmp0; else if (snp_bp == 0) ++S.tmp1; else if ((ins_bp + del_bp) == 0) ++S.tmp2; else ++S.part[0];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-component driver pieces that need the whole workgroup (alignment, repeat scan of a path)
+// ---------------------------------------------------------------------------------------------------------
+// returns true when a near-perfect repeat is found in a source->sink path (Graph_t::findRepeatsInGraphPaths,
+// reference src/Graph.cc:686-730)
+DEV bool repeats_in_graph_paths(Ctx &c) {
+  WinShared &S = *c.S; Work &W = *c.W;
+  WG_LANE0 {
+    evt(c, EV_LOOKREP);
+    S.tmp0 = 0;                                  // 0 continue, 1 stop:false, 2 stop:true
+    if (S.source == LC_NIL || S.sink == LC_NIL) { evt(c, EV_MISSING); S.tmp0 = 1; }
+    else evt(c, EV_SEARCH, (uint32_t)W.ncomp[S.source]);
+    S.tmp1 = 0;                                  // number of flagged-edge records kept in scratch
+  }
+  while (wg_bcast(&S.tmp0) == 0) {
+    WG_LANE0 {
+      uint32_t best = bfs(c);
+      if (best == LC_NIL || S.overflow) S.tmp0 = 1;
+      else { S.tmp2 = path_unpack(c, best); S.tmp3 = path_string(c, S.tmp2); if (S.overflow) S.tmp0 = 1; }
+    }
+    if (wg_bcast(&S.tmp0) != 0) break;
+    repeat_scan(W.pseq, wg_bcast(&S.tmp3), c.P->max_mismatch, &S.repE, &S.repM);      // isAlmostRepeat(path->str(), K, MAX_MISMATCH)
+    WG_LANE0 {
+      // NB isAlmostRepeat only looks at windows that end before the last base: handled inside repeat_scan
+      if (S.tmp3 - S.K > 0 && S.repM >= S.K + 1) { evt(c, EV_NEAR_QRY, S.K); S.tmp0 = 2; }
+      else {
+        path_flag_edges(c, S.tmp2, 1u);
+        for (int j = 1; j < S.tmp2; ++j) { if ((uint32_t)S.tmp1 < c.C->node_cap) W.scratch[S.tmp1++] = W.pedges[j]; else { OVF(c); S.tmp0 = 1; } }
+      }
+    }
+  }
+  WG_LANE0 {
+    for (int j = 0; j < S.tmp1; ++j) { uint32_t owner = W.scratch[j] >> 4, ei = W.scratch[j] & 15u; W.edges[owner * LC_EMAX + ei] &= ~(1u << 30); }
+  }
+  return wg_bcast(&S.tmp0) == 2;
+}
+
+// eka (reference src/Graph.cc:1430-1501) via countRefPath (:2420-2445)
+DEV void count_ref_path(Ctx &c) {
+  WinShared &S = *c.S; Work &W = *c.W;
+  if (wg_bcastu(&S.source) == LC_NIL) return;
+  if (wg_bcastu(&S.sink) != LC_NIL) {
+    WG_LANE0 { evt(c, EV_SEARCH, (uint32_t)W.ncomp[S.source]); S.tmp0 = S.tmp1 = S.tmp2 = 0; S.part[0] = 0; S.part[1] = 0; S.part[2] = 0; S.part[3] = 0; }
+    // part[1] = complete, part[2] = allcycles, part[3] = loop state (0 run, 1 stop)
+    while (wg_bcastu(&S.part[3]) == 0) {
+      WG_LANE0 {
+        uint32_t best = bfs(c);
+        if (best == LC_NIL || S.overflow) S.part[3] = 1;
+        else {
+          S.tmp3 = (W.queue[best].bits & 2) ? 1 : 0;
+          if (S.tmp3) ++S.part[2];
+          ++S.part[1];
+          S.part[4] = (uint32_t)path_unpack(c, best);
+          S.part[5] = (uint32_t)path_string(c, (int)S.part[4]);
+          // Hamming short-cut (reference src/Graph.cc:818-826)
+          int n = S.seq_len, m = (int)S.part[5];
+          const uint8_t *rs = c.B->ref_codes + c.B->ref_off[S.w] + S.seq_t5;
+          int hd = -1;
+          if (n == m) { hd = 0; for (int i = 0; i < n; ++i) if (rs[i] != W.pseq[i]) ++hd; }
+          S.part[6] = (hd == -1 || hd > 5) ? 1u : 0u;
+          if (!S.part[6]) {
+            const int cap = LC_MAXW + (int)c.C->path_cap + 2;
+            for (int i = 0; i < n; ++i) { W.aln[i] = "ACGTN"[rs[i]]; W.aln[cap + i] = "ACGT"[W.pseq[i]]; }
+            S.part[7] = (uint32_t)n;
+          }
+          if (n > LC_MAXW || n < 1 || m < 1) OVF(c);
+          if (S.overflow) S.part[3] = 1;
+        }
+      }
+      if (wg_bcastu(&S.part[3]) != 0) break;
+      if (wg_bcastu(&S.part[6])) {
+        const uint8_t *rs = c.B->ref_codes + c.B->ref_off[S.w] + S.seq_t5;
+        const int pl = (int)wg_bcastu(&S.part[5]);
+        align_fill(c, rs, S.seq_len, W.pseq, pl);
+        WG_LANE0 { S.part[7] = (uint32_t)align_traceback(c, rs, S.seq_len, W.pseq, pl); }
+        WG_SYNC();
+      }
+      WG_LANE0 {
+        if (!S.overflow) {
+          process_path_walk(c, (int)S.part[4], (int)S.part[5], (int)S.part[7], (int)S.part[1]);
+          path_flag_edges(c, (int)S.part[4], 1u);
+        }
+        if (S.overflow) S.part[3] = 1;
+      }
+    }
+    WG_LANE0 { evt(c, EV_EKA_END, (uint32_t)S.refcomp, S.part[1], S.part[2], (uint32_t)S.tmp0, (uint32_t)S.tmp2, (uint32_t)S.tmp1, S.part[0]); }
+  }
+  WG_LANE0 {
+    if (c.C->evt_cap) { uint32_t n = 0; for (uint32_t i = 0; i < S.M; ++i) if (W.nonref[W.order[i]]) ++n; evt(c, EV_FOUND, n); }
+  }
+  WG_SYNC();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the window: Microassembler::processGraph (reference src/Microassembler.cc:73-249)
+// ---------------------------------------------------------------------------------------------------------
+DEV void process_window(Ctx &c, int w) {
+  WinShared &S = *c.S; Work &W = *c.W; const DevBatch &B = *c.B;
+  WG_LANE0 {
+    S.w = w; S.overflow = 0; S.evt_len = 0; S.emit_seq = 0; S.n_kmers = 0; S.max_nodes = 0; S.n_builds = 0; S.final_k = 0;
+    S.status = LANCET_W_OK;
+    S.reflen = (int)(B.ref_off[w + 1] - B.ref_off[w]);
+    int nr = (int)(B.read_begin[w + 1] - B.read_begin[w]);
+    S.R = nr + 1;                                   // + the reference pseudo-read, appended last (Graph.cc:535-540)
+    S.seq_t5 = 0; S.seq_len = S.reflen; S.trim5 = 0; S.trim3 = 0;
+    int mapped = 0;
+    for (int r = 0; r < nr; ++r) if (RI_MAPPED(B.rinfo[B.read_begin[w] + r])) ++mapped;
+    S.tmp0 = mapped;
+    if ((uint32_t)S.R > c.C->reads_cap || S.reflen > LC_MAXW || S.reflen < 1) S.overflow = 1;
+    for (int i = 0; i < S.reflen; ++i) if (B.ref_codes[B.ref_off[w] + i] > 3) S.overflow = 1;    // N in the window reference: not supported yet
+    if (mapped > 0) evt(c, EV_PROCESS, (uint32_t)nr, (uint32_t)mapped);
+  }
+  if (wg_bcast(&S.tmp0) <= 0) { WG_LANE0 { S.status = LANCET_W_NO_READS; } WG_SYNC(); return; }     // Microassembler.cc:83
+  if (wg_bcast(&S.overflow)) { WG_LANE0 { S.status = LANCET_W_OVERFLOW; } WG_SYNC(); return; }
+  const int reflen = wg_bcast(&S.reflen);
+  repeat_scan(B.ref_codes + B.ref_off[w], reflen, c.P->max_mismatch, &S.repE, &S.repM);
+  const int refE = wg_bcast(&S.repE), refM = wg_bcast(&S.repM);
+  int rptInRef = 0, rptInQry = 0, cycleInGraph = 0;
+  bool processed = false;
+  for (int k = c.P->min_k; k <= c.P->max_k; k += 2) {
+    rptInRef = rptInQry = cycleInGraph = 0;
+    // isRepeat / isAlmostRepeat on rawseq (Microassembler.cc:118-131)
+    if (reflen - k > 0 && refE >= k) { WG_LANE0 { evt(c, EV_REPEAT_REF, k); } rptInRef = 1; continue; }
+    if (reflen - k > 0 && refM >= k + 1) { WG_LANE0 { evt(c, EV_NEAR_REF, k); } rptInRef = 1; continue; }
+    WG_LANE0 { S.K = k; S.NW = (2 * k + 63) / 64; S.final_k = k; S.source = LC_NIL; S.sink = LC_NIL; if (k > 127 || S.NW > LC_NWMAX) S.overflow = 1; }
+    if (wg_bcast(&S.overflow)) break;
+    build_graph(c);
+    if (wg_bcast(&S.overflow)) break;
+    materialize_survivors(c);
+    if (wg_bcast(&S.overflow)) break;
+    first_lowcov(c);
+    if (wg_bcast(&S.overflow)) break;
+    // ---- everything below is the (small) cleaned graph
+    WG_LANE0 {
+      evt(c, EV_READS, (uint32_t)S.R, (uint32_t)S.reflen, (uint32_t)S.totalreadbp);
+      // trace: printStats(0) over the full table, markRefNodes, removeLowCov(false,0)
+      if (c.C->evt_cap) {
+        uint32_t edges = 0, refn = 0, low = 0;
+        for (uint32_t n = 0; n < S.N; ++n) { edges += W.necnt[n]; if (W.nflags[n] & NF_INMER) ++refn; if (!(W.nflags[n] & NF_SURV)) ++low; }
+        evt(c, EV_STATS, 0, S.N, edges, S.N * (uint32_t)S.K);
+        evt(c, EV_MARKREF, S.N, refn);
+        evt(c, EV_LOWCOV, low);
+      }
+      // removeNode for every non-survivor: drop the reciprocal edges, then erase from the table
+      for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (!(W.nflags[n] & NF_SURV)) W.nflags[n] |= NF_DEAD; }
+    }
+    WG_SYNC();
+    WG_FOR(n, S.N) {
+      if (W.nflags[n] & NF_DEAD) continue;
+      uint32_t *e = W.edges + n * LC_EMAX; int cnt = (int)W.necnt[n], m = 0;
+      for (int i = 0; i < cnt; ++i) if (!(W.nflags[ED_TO(e[i])] & NF_DEAD)) e[m++] = e[i];
+      W.necnt[n] = m;
+    }
+    WG_SYNC();
+    WG_LANE0 {
+      clean_dead(c);
+      print_stats(c, 0);
+      S.numcomp = mark_connected_components(c);
+    }
+    int numcomp = wg_bcast(&S.numcomp);
+    bool brk = false;
+    for (int comp = 1; comp <= numcomp; ++comp) {
+      WG_LANE0 {
+        print_stats(c, comp);
+        mark_ref_ends(c, comp);
+        S.tmp0 = 0;
+        if (!S.overflow && has_cycle(c)) S.tmp0 = 1;
+        if (!S.tmp0 && !S.overflow) {
+          compress(c, comp);
+          print_stats(c, comp);
+          remove_low_cov(c, comp);
+          remove_tips(c, comp);
+          remove_short_links(c, comp);
+          if (!S.overflow && has_cycle(c)) S.tmp0 = 1;
+        }
+      }
+      if (wg_bcast(&S.overflow)) break;
+      if (wg_bcast(&S.tmp0)) { cycleInGraph = 1; brk = true; break; }
+      if (repeats_in_graph_paths(c)) { rptInQry = 1; brk = true; break; }
+      if (wg_bcast(&S.overflow)) break;
+      count_ref_path(c);
+      if (wg_bcast(&S.overflow)) break;
+    }
+    if (wg_bcast(&S.overflow)) break;
+    if (brk) continue;
+    processed = true;
+    break;
+  }
+  WG_LANE0 {
+    evt(c, EV_END, (uint32_t)rptInRef, (uint32_t)rptInQry, (uint32_t)cycleInGraph);
+    S.status = S.overflow ? LANCET_W_OVERFLOW : (processed ? LANCET_W_OK : LANCET_W_K_EXHAUSTED);
+  }
+  WG_SYNC();
+}
+
+// entry: persistent workgroup pulling windows off the batch queue
+DEV void window_kernel_body(const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT, WinShared *S, int slot) {
+  Ctx c; c.P = P; c.B = B; c.C = C; c.W = works + slot; c.OUT = OUT; c.S = S;
+  while (true) {
+    WG_LANE0 { S->tmp3 = (int)dev_atomic_add(OUT->queue_head, 1u); }
+    int w = wg_bcast(&S->tmp3);
+    if (w >= B->n_windows) break;
+    process_window(c, w);
+    WG_LANE0 {
+      lancet_window_stats &st = OUT->stats[w];
+      st.status = S->status; st.final_k = S->final_k; st.n_builds = S->n_builds; st.n_variants = S->emit_seq;
+      st.n_kmers = S->n_kmers; st.max_nodes = S->max_nodes; st.reserved = 0;
+      if (C->evt_cap) { OUT->evt_len[w] = S->evt_len; for (uint32_t i = 0; i < S->evt_len; ++i) OUT->evt_out[(size_t)w * C->evt_cap + i] = c.W->evt[i]; }
+    }
+    WG_SYNC();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// prep: Graph_t::trim (reference src/Graph.cc:355-384) + 2-bit packing ; one read per lane
+// ---------------------------------------------------------------------------------------------------------
+DEV bool is_dna(char b) { return b == 'A' || b == 'a' || b == 'C' || b == 'c' || b == 'G' || b == 'g' || b == 'T' || b == 't'; }
+DEV int base_code(char b) { switch (b) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; } return 4; }
+DEV void prep_read(const lancet_params *P, const char *seq, const char *qual, uint32_t off, int len, uint8_t label, uint8_t strand, uint8_t mate,
+                   uint8_t mapped, uint32_t *rinfo, uint32_t *bases, uint32_t bw, uint32_t *good, uint32_t gw) {
+  int trim5 = 0, trim3 = 0; bool junk = false;
+  while (trim5 < len && (!is_dna(seq[off + trim5]) || (qual[off + trim5] < P->min_qual_trim))) ++trim5;
+  if (trim5 < len) {
+    while (trim3 < len && (!is_dna(seq[off + len - 1 - trim3]) || (qual[off + len - 1 - trim3] < P->min_qual_trim))) ++trim3;
+    for (int i = trim5; i < len - trim3; ++i) if (!is_dna(seq[off + i])) { junk = true; break; }
+  } else junk = true;
+  int tlen = junk ? 0 : len - trim5 - trim3;
+  if (tlen > 0xFFFF) tlen = 0xFFFF;
+  *rinfo = (uint32_t)tlen | ((label == LANCET_NML ? 1u : 0u) << 16) | ((strand == LANCET_REV ? 1u : 0u) << 17) | ((uint32_t)(mate & 3) << 18) | ((mapped ? 1u : 0u) << 20);
+  for (int wv = 0; wv < (tlen + 15) / 16; ++wv) {
+    uint32_t v = 0;
+    for (int j = 0; j < 16 && wv * 16 + j < tlen; ++j) v |= (uint32_t)(base_code(seq[off + trim5 + wv * 16 + j]) & 3) << (2 * j);
+    bases[bw + wv] = v;
+  }
+  for (int wv = 0; wv < (tlen + 31) / 32; ++wv) {
+    uint32_t v = 0;
+    for (int j = 0; j < 32 && wv * 32 + j < tlen; ++j) if (qual[off + trim5 + wv * 32 + j] >= P->min_qual_call) v |= 1u << j;
+    good[gw + wv] = v;
+  }
+}

@@ -1,0 +1,160 @@
+// layout.h -- HBM data layout shared by the host side (engine.hip) and the kernels (kernels.h).
+//
+// Everything a window needs while it is being assembled lives in one "slot" of work space in HBM; a
+// persistent workgroup owns one slot and pulls windows from a queue.  Sizes are fixed per engine (EngineCaps);
+// a window that does not fit is reported with status LANCET_W_OVERFLOW, never processed approximately.
+#pragma once
+#include <stdint.h>
+
+#define LC_NWMAX 4            /* 64-bit words per k-mer key: k <= 128 (reference max k = 101)            */
+#define LC_EMAX 12            /* edges per node (8 possible k-mer extensions + source/sink + slack)       */
+#define LC_NIL 0xFFFFFFFFu
+#define LC_BB 0xFFFFFFFEu     /* libstdc++ _M_before_begin sentinel in the bucket array                   */
+#define LC_MAXW 640           /* window length cap (reference WINDOW_SIZE = 600)                          */
+#define LC_MAXTS 64           /* transcripts per path                                                     */
+
+/* per-read info word (DevBatch::rinfo) */
+#define RI_TLEN(x) ((x) & 0xFFFFu)      /* trimmed length, 0 for junk reads (reference Graph_t::trim)     */
+#define RI_NML(x) (((x) >> 16) & 1u)    /* label == NML                                                   */
+#define RI_REV(x) (((x) >> 17) & 1u)    /* strand == REV                                                  */
+#define RI_MATE(x) (((x) >> 18) & 3u)   /* mate_order 0|1|2                                               */
+#define RI_MAPPED(x) (((x) >> 20) & 1u)
+
+/* node flag bits */
+#define NF_TUMOR 1u
+#define NF_NORMAL 2u
+#define NF_DEAD 4u
+#define NF_SOURCE 8u
+#define NF_SINK 16u
+#define NF_INMER 32u       /* canonical k-mer is in Ref_t::mertable (reference src/Ref.cc:40-64)          */
+#define NF_SURV 64u        /* survived the first removeLowCov: per-position quality counts are stored     */
+#define NF_SPECIAL (NF_SOURCE | NF_SINK)
+
+/* edge word: target node [27:0], dir [29:28] (FF=0 FR=1 RF=2 RR=3, reference src/Edge.hh:37), flag [30]  */
+#define ED_TO(e) ((e) & 0x0FFFFFFFu)
+#define ED_DIR(e) (((e) >> 28) & 3u)
+#define ED_FLAG(e) (((e) >> 30) & 1u)
+#define ED_MAKE(to, dir) (((uint32_t)(to)) | ((uint32_t)(dir) << 28))
+
+/* sequence descriptor: one per base of a (compressed) node string:
+ *   base [1:0], offset inside the owning k-mer [8:2], owning k-mer node id [31:9]                        */
+#define SD_BASE(d) ((d) & 3u)
+#define SD_OFF(d) (((d) >> 2) & 0x7Fu)
+#define SD_KMER(d) ((d) >> 9)
+#define SD_MAKE(kmer, off, base) (((uint32_t)(kmer) << 9) | ((uint32_t)(off) << 2) | (uint32_t)(base))
+
+/* csr entry: read [15:0], k-mer position in read [25:16], ori R [26], state [28:27]                      */
+#define CS_READ(c) ((c) & 0xFFFFu)
+#define CS_POS(c) (((c) >> 16) & 0x3FFu)
+#define CS_ORI(c) (((c) >> 26) & 1u)
+#define CS_ST(c) (((c) >> 27) & 3u)   /* 0 counted, 1 candidate (needs the mate-overlap replay), 2 suppressed */
+#define CS_MAKE(r, p, ori, st) ((uint32_t)(r) | ((uint32_t)(p) << 16) | ((uint32_t)(ori) << 26) | ((uint32_t)(st) << 27))
+
+struct EngineCaps {
+  uint32_t reads_cap;    /* reads per window (incl. the reference pseudo-read)            */
+  uint32_t occ_cap;      /* k-mer occurrences per (window, k)                              */
+  uint32_t node_cap;     /* distinct k-mers per (window, k)                                */
+  uint32_t table_cap;    /* open-addressing slots, power of two >= 2*node_cap              */
+  uint32_t bucket_cap;   /* libstdc++ bucket-array simulation                              */
+  uint32_t special_cap;  /* source/sink pseudo nodes                                       */
+  uint32_t surv_cap;     /* nodes surviving the first low-coverage filter                  */
+  uint32_t seq_cap;      /* sequence-descriptor arena (u32)                                */
+  uint32_t queue_cap;    /* path-BFS queue entries                                         */
+  uint32_t path_cap;     /* longest path string                                            */
+  uint32_t evt_cap;      /* trace events (u32 words) per window, 0 = tracing off           */
+  uint32_t var_cap;      /* variant records for the whole batch                            */
+  uint32_t blob_cap;     /* variant string bytes for the whole batch                       */
+  uint32_t max_k;        /* largest k the engine was created for                           */
+};
+
+/* device-resident batch (after upload + prep) */
+struct DevBatch {
+  int32_t n_windows;
+  const int32_t *chr_id, *ref_start;
+  const uint32_t *ref_off;      /* [n+1] */
+  const uint8_t *ref_codes;     /* A,C,G,T -> 0..3 ; anything else 4 */
+  const uint32_t *read_begin;   /* [n+1] */
+  const uint32_t *rinfo;        /* [R] */
+  const uint32_t *name_rank;    /* [R] */
+  const uint32_t *base_woff;    /* [R] word offset of the read's packed bases (16 bases / u32) */
+  const uint32_t *good_woff;    /* [R] word offset of the read's quality mask (32 bases / u32) */
+  const uint32_t *bases;        /* 2-bit packed, trimmed reads only */
+  const uint32_t *good;         /* bit = (qual >= MIN_QUAL_CALL) */
+};
+
+struct BfsEntry {
+  uint32_t parent;      /* queue index of the path this one extends, LC_NIL for the root   */
+  uint32_t node;        /* last node of the path                                            */
+  uint32_t edge;        /* (owner node << 4) | edge index : the Edge_t* of the reference    */
+  int32_t len;
+  uint16_t score;
+  uint8_t dir;          /* 'F' / 'R' travel direction at `node`                             */
+  uint8_t bits;         /* bit0 flag, bit1 hasCycle                                         */
+};
+
+/* One slot of work space.  All pointers are device pointers into one big allocation. */
+struct Work {
+  /* ---- build ---- */
+  uint32_t *occ_base;     /* [reads_cap+1] first occurrence index of each read                 */
+  uint8_t *cand;          /* [reads_cap]   read has an earlier opposite mate of the same name  */
+  uint32_t *occ;          /* [occ_cap]     slot (then node) | ori<<31                           */
+  unsigned long long *tags;     /* [table_cap]                                               */
+  unsigned long long *slot_key; /* [table_cap * LC_NWMAX]                                    */
+  uint32_t *slot_first;   /* [table_cap]                                                       */
+  uint32_t *slot_node;    /* [table_cap]                                                       */
+  uint32_t *bitmap;       /* [occ_cap/32 + 2]                                                  */
+  uint32_t *bitpre;       /* [occ_cap/32 + 2]                                                  */
+  uint32_t *csr;          /* [occ_cap]                                                         */
+  /* ---- nodes: index < node_cap are k-mers in first-insertion order; then special nodes ---- */
+  unsigned long long *nkey;     /* [nodes * LC_NWMAX] right-aligned 2-bit canonical k-mer     */
+  unsigned long long *nhash;    /* [nodes] libstdc++ std::hash<std::string> of the node id     */
+  uint32_t *ncnt;         /* [nodes*4] counted occurrences: Tf Tr Nf Nr                        */
+  uint32_t *nflags;       /* [nodes]                                                           */
+  uint32_t *efirst;       /* [nodes*8] first-seen stamp of each possible k-mer edge            */
+  uint32_t *eto;          /* [nodes*8] target|dir of each possible k-mer edge                  */
+  uint32_t *edges;        /* [nodes*LC_EMAX]                                                   */
+  uint32_t *necnt;        /* [nodes]                                                           */
+  float *ncov;            /* [nodes*4] Tf Tr Nf Nr (float, as the reference)                   */
+  int32_t *ncomp;         /* [nodes]                                                           */
+  int32_t *nmincov;       /* [nodes]                                                           */
+  int32_t *nmincovqv;     /* [nodes]                                                           */
+  uint32_t *nocc;         /* [nodes+1] csr offsets                                             */
+  uint32_t *nfill;        /* [nodes]                                                           */
+  uint32_t *nseq_lo, *nseq_hi, *nseq_clo, *nseq_chi;  /* [nodes] deque in the seq arena        */
+  uint32_t *nkm;          /* [nodes] number of constituent k-mers  (cov_status entries >= K-1) */
+  uint32_t *nkmT;         /* [nodes] ... of which status == 'T'                                */
+  uint32_t *nqv;          /* [nodes] index into qv (LC_NIL if not stored)                      */
+  uint8_t *ncolor;        /* [nodes]                                                           */
+  uint32_t *nonref;       /* [nodes] onRefPath counter                                         */
+  uint16_t *qv;           /* [surv_cap * K * 4] per-position min-quality counts Tf Tr Nf Nr    */
+  uint32_t *seq;          /* [seq_cap] descriptor arena                                        */
+  /* ---- libstdc++ node-table order ---- */
+  uint32_t *ht_next;      /* [nodes]                                                           */
+  uint32_t *ht_bucket;    /* [bucket_cap]                                                      */
+  uint32_t *order;        /* [nodes] iteration order of the live table                         */
+  uint32_t *scratch;      /* [nodes*2] stacks / queues of the graph passes                     */
+  /* ---- reference coverage ---- */
+  uint16_t *refcov;       /* [LC_MAXW*4] Tf Tr Nf Nr per rawseq position                       */
+  /* ---- paths ---- */
+  BfsEntry *queue;        /* [queue_cap]                                                       */
+  uint32_t *pnodes;       /* [nodes] nodes of the current path                                 */
+  uint32_t *pedges;       /* [nodes] edge refs of the current path                             */
+  uint32_t *pdesc;        /* [path_cap] descriptor per path base                               */
+  uint8_t *pseq;          /* [path_cap] path string (codes 0..3)                               */
+  uint8_t *tb;            /* [(LC_MAXW+2)*(path_cap+2)] traceback bits                         */
+  int32_t *dp;            /* [7*(LC_MAXW+2)] alignment diagonals                               */
+  uint8_t *aln;           /* [2*(LC_MAXW+path_cap+2)] aligned strings (ASCII)                  */
+  uint32_t *evt;          /* [evt_cap] trace events                                            */
+};
+
+/* batch-level outputs */
+struct DevOut {
+  struct lancet_variant *variants;
+  char *blob;
+  uint32_t *n_variants;   /* atomic */
+  uint32_t *n_blob;       /* atomic */
+  struct lancet_window_stats *stats;
+  uint32_t *queue_head;   /* atomic window queue */
+  uint32_t *evt_len;      /* [n_windows] words used in the window's trace (slot evt copied out)  */
+  uint32_t *evt_out;      /* [n_windows * evt_cap] */
+};

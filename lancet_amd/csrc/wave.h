@@ -1,0 +1,51 @@
+// wave.h -- execution-model shims for the window kernels.
+//
+// The kernels are written in a "phase" style: a workgroup owns one window; data-parallel phases are
+// WG_FOR loops (work item i handled by lane i % WG_SIZE), single-lane sections are WG_LANE0, and phases are
+// separated by WG_SYNC().  All control state that decides uniform branches lives in LDS (struct WinShared),
+// written by lane 0 and read by everyone after a WG_SYNC.
+//
+// On gfx950 these map to the obvious HIP constructs.  When LANCET_WAVE_EMU is defined (ONLY by the test-side
+// build tests/emu/Makefile; never by the product build) the same source compiles as plain C++ that runs the
+// lanes of a phase one after the other, which lets the graph logic be debugged against the oracle on a
+// GPU-less development box.  The emulation build is test infrastructure: the shipped library is the HIP one
+// and has no CPU path.
+#pragma once
+#include <stdint.h>
+
+#ifndef LANCET_WAVE_EMU
+#include <hip/hip_runtime.h>
+#define DEV __device__ __forceinline__
+#define DEVNI __device__ __noinline__
+#define WG_FOR(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += (int)blockDim.x)
+#define WG_SYNC() __syncthreads()
+#define WG_LANE0 if (threadIdx.x == 0)
+#define WG_SHARED __shared__
+DEV uint32_t dev_atomic_min(uint32_t *p, uint32_t v) { return atomicMin(p, v); }
+DEV uint32_t dev_atomic_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+DEV uint32_t dev_atomic_max(uint32_t *p, uint32_t v) { return atomicMax(p, v); }
+DEV uint32_t dev_atomic_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
+DEV unsigned long long dev_atomic_cas64(unsigned long long *p, unsigned long long cmp, unsigned long long v) {
+  return atomicCAS(p, cmp, v);
+}
+DEV int dev_popc(uint32_t x) { return __popc(x); }
+DEV int dev_popcll(unsigned long long x) { return __popcll(x); }
+#else
+#include <cstring>
+#include <cmath>
+#define DEV static inline
+#define DEVNI static
+#define WG_FOR(i, n) for (int i = 0; i < (int)(n); ++i)
+#define WG_SYNC() ((void)0)
+#define WG_LANE0 if (true)
+#define WG_SHARED static thread_local
+DEV uint32_t dev_atomic_min(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
+DEV uint32_t dev_atomic_add(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+DEV uint32_t dev_atomic_max(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
+DEV uint32_t dev_atomic_or(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+DEV unsigned long long dev_atomic_cas64(unsigned long long *p, unsigned long long cmp, unsigned long long v) {
+  unsigned long long o = *p; if (o == cmp) *p = v; return o;
+}
+DEV int dev_popc(uint32_t x) { return __builtin_popcount(x); }
+DEV int dev_popcll(unsigned long long x) { return __builtin_popcountll(x); }
+#endif

@@ -1,0 +1,198 @@
+"""Python binding of the C-ABI in include/lancet_engine.h (ctypes; plain pointers only).
+
+`Engine` is the drop-in for the reference seam `Microassembler::processGraph` (reference
+src/Microassembler.cc:837) applied to a whole batch of windows; `VariantDB` is the host side below it
+(reference src/VariantDB.cc).  There is no CPU fallback: a missing library or a missing GPU raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import abi, trace as _trace
+
+_LIBPATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblancet_engine.so")
+_LIB = None
+
+ERRORS = {0: "OK", -1: "bad argument", -2: "no HIP device", -3: "HIP error", -4: "unsupported", -5: "out of memory", -6: "bad state"}
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_LIBPATH):
+            raise EngineError(f"{_LIBPATH} is missing: build it with `python -m lancet_amd.build` (there is no CPU fallback)")
+        L = C.CDLL(_LIBPATH)
+        L.lancet_params_default.argtypes = [C.POINTER(abi.LancetParams)]
+        L.lancet_engine_create.argtypes = [C.POINTER(abi.LancetParams), C.c_int, C.POINTER(C.c_void_p)]
+        L.lancet_engine_destroy.argtypes = [C.c_void_p]
+        L.lancet_engine_last_error.restype = C.c_char_p
+        L.lancet_engine_last_error.argtypes = [C.c_void_p]
+        L.lancet_engine_upload.argtypes = [C.c_void_p, C.POINTER(abi.LancetWindowBatch)]
+        L.lancet_engine_run.argtypes = [C.c_void_p]
+        L.lancet_engine_process.argtypes = [C.c_void_p, C.POINTER(abi.LancetWindowBatch)]
+        L.lancet_engine_results.argtypes = [C.c_void_p, C.POINTER(C.POINTER(abi.LancetVariant)), C.POINTER(C.c_uint32),
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(abi.LancetWindowStats))]
+        L.lancet_engine_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float * 2)]
+        L.lancet_engine_set_trace.argtypes = [C.c_void_p, C.c_uint32]
+        L.lancet_engine_trace.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32)]
+        L.lancet_engine_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+        L.lancet_filters_default.argtypes = [C.POINTER(abi.LancetFilters)]
+        L.lancet_vdb_create.restype = C.c_void_p
+        L.lancet_vdb_create.argtypes = [C.POINTER(abi.LancetFilters)]
+        L.lancet_vdb_destroy.argtypes = [C.c_void_p]
+        L.lancet_vdb_add.argtypes = [C.c_void_p, C.POINTER(abi.LancetVariant), C.c_uint32, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32]
+        L.lancet_vdb_size.restype = C.c_uint32
+        L.lancet_vdb_size.argtypes = [C.c_void_p]
+        L.lancet_vdb_vcf.restype = C.c_void_p
+        L.lancet_vdb_vcf.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
+        L.lancet_free.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+class Engine:
+    def __init__(self, params: Optional[abi.LancetParams] = None, device: int = 0, trace_words: int = 0):
+        self.L = lib()
+        self.params = params or abi.default_params()
+        h = C.c_void_p()
+        rc = self.L.lancet_engine_create(C.byref(self.params), device, C.byref(h))
+        if rc != 0:
+            raise EngineError(f"lancet_engine_create failed: {ERRORS.get(rc, rc)}")
+        self.h = h
+        self._batch = None
+        if trace_words:
+            self.L.lancet_engine_set_trace(self.h, trace_words)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise EngineError(f"{ERRORS.get(rc, rc)}: {self.L.lancet_engine_last_error(self.h).decode()}")
+
+    def upload(self, batch) -> None:
+        self._batch = batch
+        cb = abi.batch_to_c(batch)
+        self._chk(self.L.lancet_engine_upload(self.h, C.byref(cb)))
+
+    def run(self) -> None:
+        self._chk(self.L.lancet_engine_run(self.h))
+
+    def process(self, batch):
+        self.upload(batch)
+        self.run()
+        return self.results()
+
+    def raw_results(self):
+        vp = C.POINTER(abi.LancetVariant)()
+        n = C.c_uint32()
+        blob = C.c_void_p()
+        bl = C.c_uint32()
+        sp = C.POINTER(abi.LancetWindowStats)()
+        self._chk(self.L.lancet_engine_results(self.h, C.byref(vp), C.byref(n), C.byref(blob), C.byref(bl), C.byref(sp)))
+        return vp, n.value, (C.string_at(blob, bl.value) if bl.value else b""), sp
+
+    def results(self):
+        vp, n, blob, sp = self.raw_results()
+        variants = abi.variants_to_py(vp, n, blob)
+        nw = self._batch.n_windows
+        stats = [dict(status=sp[i].status, final_k=sp[i].final_k, n_builds=sp[i].n_builds, n_variants=sp[i].n_variants,
+                      n_kmers=sp[i].n_kmers, max_nodes=sp[i].max_nodes) for i in range(nw)]
+        return variants, stats
+
+    def timing_ms(self):
+        t = (C.c_float * 2)()
+        self._chk(self.L.lancet_engine_last_timing(self.h, C.byref(t)))
+        return float(t[0]), float(t[1])
+
+    def geometry(self):
+        s = C.c_int32()
+        b = C.c_uint64()
+        self._chk(self.L.lancet_engine_geometry(self.h, C.byref(s), C.byref(b)))
+        return s.value, b.value
+
+    def trace_text(self) -> str:
+        lp = C.POINTER(C.c_uint32)()
+        ep = C.POINTER(C.c_uint32)()
+        wpw = C.c_uint32()
+        self._chk(self.L.lancet_engine_trace(self.h, C.byref(lp), C.byref(ep), C.byref(wpw)))
+        if not wpw.value:
+            return ""
+        b = self._batch
+        lens = np.ctypeslib.as_array(lp, shape=(b.n_windows,))
+        ev = np.ctypeslib.as_array(ep, shape=(b.n_windows * wpw.value,))
+        parts = []
+        for w in range(b.n_windows):
+            words = ev[w * wpw.value: w * wpw.value + int(lens[w])]
+            end = int(b.ref_start[w]) + int(b.ref_off[w + 1] - b.ref_off[w])
+            parts.append(_trace.format_window(words, w + 1, b.hdr[w], b.chrom[w], int(b.ref_start[w]), end))
+        return "".join(parts)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lancet_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class VariantDB:
+    """reference src/VariantDB.cc: addVar + printToVCF (host)."""
+
+    def __init__(self, filters: Optional[abi.LancetFilters] = None):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.lancet_vdb_create(C.byref(filters) if filters is not None else None))
+
+    def add_raw(self, vptr, n: int, blob: bytes, chr_names: Sequence[str]) -> None:
+        names = abi.c_string_array(list(chr_names))
+        rc = self.L.lancet_vdb_add(self.h, vptr, n, blob, names, len(chr_names))
+        if rc != 0:
+            raise EngineError(f"lancet_vdb_add: {ERRORS.get(rc, rc)}")
+
+    def add_records(self, records: List[dict], chr_names: Sequence[str]) -> None:
+        """records: dicts as produced by abi.variants_to_py (any source)."""
+        arr = (abi.LancetVariant * len(records))()
+        blob = bytearray()
+        for i, r in enumerate(records):
+            v = arr[i]
+            v.window, v.seq_in_window, v.chr_id, v.pos = r["window"], r["seq"], r["chr_id"], r["pos"]
+            v.code, v.prev_bp_ref, v.prev_bp_alt, v.kmer = ord(r["code"]), ord(r["prev_bp_ref"]), ord(r["prev_bp_alt"]), r["kmer"]
+            for q in range(8):
+                v.cov[q] = r["cov"][q]
+            v.ref_off, v.ref_len = len(blob), len(r["ref"]); blob += r["ref"].encode()
+            v.alt_off, v.alt_len = len(blob), len(r["alt"]); blob += r["alt"].encode()
+            v.str_off, v.str_len = len(blob), len(r["str"]); blob += r["str"].encode()
+        self.add_raw(arr, len(records), bytes(blob) + b"\0", chr_names)
+
+    def size(self) -> int:
+        return int(self.L.lancet_vdb_size(self.h))
+
+    def vcf(self, version: Optional[str] = None, cmdline: Optional[str] = None, reference: Optional[str] = None,
+            date_line: Optional[str] = None, sample_normal: str = "NORMAL", sample_tumor: str = "TUMOR") -> str:
+        enc = lambda s: s.encode() if s is not None else None
+        p = self.L.lancet_vdb_vcf(self.h, enc(version), enc(cmdline), enc(reference), enc(date_line), enc(sample_normal), enc(sample_tumor))
+        if not p:
+            raise EngineError("lancet_vdb_vcf failed")
+        try:
+            return C.string_at(p).decode()
+        finally:
+            self.L.lancet_free(p)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lancet_vdb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

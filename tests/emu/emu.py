@@ -1,0 +1,62 @@
+"""TEST INFRASTRUCTURE ONLY -- loader for tests/emu/libemu.so (host emulation build of the kernels)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from lancet_amd import abi, trace
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        subprocess.run(["make", "-s", "-C", _HERE], check=True)
+        L = C.CDLL(os.path.join(_HERE, "libemu.so"))
+        L.lancet_emu_run.restype = C.c_void_p
+        L.lancet_emu_run.argtypes = [C.POINTER(abi.LancetParams), C.POINTER(abi.LancetWindowBatch), C.c_uint32]
+        for n, rt in (("n_variants", C.c_uint32), ("variants", C.POINTER(abi.LancetVariant)), ("blob", C.c_void_p),
+                      ("blob_len", C.c_uint32), ("stats", C.POINTER(abi.LancetWindowStats)),
+                      ("evt_len", C.POINTER(C.c_uint32)), ("evt", C.POINTER(C.c_uint32))):
+            f = getattr(L, "lancet_emu_" + n)
+            f.restype = rt
+            f.argtypes = [C.c_void_p]
+        L.lancet_emu_free.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def run(batch, params=None, evt_cap: int = 0):
+    """Returns (variants sorted by (window, seq), stats, trace text)."""
+    L = lib()
+    p = params or abi.default_params()
+    cb = abi.batch_to_c(batch)
+    h = L.lancet_emu_run(C.byref(p), C.byref(cb), evt_cap)
+    try:
+        n = L.lancet_emu_n_variants(h)
+        bl = L.lancet_emu_blob_len(h)
+        blob = C.string_at(L.lancet_emu_blob(h), bl) if bl else b""
+        variants = abi.variants_to_py(L.lancet_emu_variants(h), n, blob)
+        sp = L.lancet_emu_stats(h)
+        stats = [dict(status=sp[i].status, final_k=sp[i].final_k, n_builds=sp[i].n_builds, n_variants=sp[i].n_variants,
+                      n_kmers=sp[i].n_kmers, max_nodes=sp[i].max_nodes) for i in range(batch.n_windows)]
+        text = ""
+        if evt_cap:
+            lens = np.ctypeslib.as_array(L.lancet_emu_evt_len(h), shape=(batch.n_windows,))
+            ev = np.ctypeslib.as_array(L.lancet_emu_evt(h), shape=(batch.n_windows * evt_cap,))
+            parts = []
+            for w in range(batch.n_windows):
+                words = ev[w * evt_cap: w * evt_cap + int(lens[w])]
+                end = int(batch.ref_start[w]) + int(batch.ref_off[w + 1] - batch.ref_off[w])
+                parts.append(trace.format_window(words, w + 1, batch.hdr[w], batch.chrom[w], int(batch.ref_start[w]), end))
+            text = "".join(parts)
+    finally:
+        L.lancet_emu_free(h)
+    ok = {w for w, s in enumerate(stats) if s["status"] >= 0}
+    variants = sorted((v for v in variants if v["window"] in ok), key=lambda v: (v["window"], v["seq"]))
+    return variants, stats, text

@@ -1,0 +1,62 @@
+// emu_engine.cc -- TEST INFRASTRUCTURE ONLY.
+//
+// Compiles lancet_amd/csrc/kernels.h with LANCET_WAVE_EMU (lanes of a phase run one after the other on the
+// host) so that the kernel logic can be exercised against the oracle on a machine without a GPU.  This is a
+// debugging aid for the authoring container; it is not a backend: the product library (liblancet_engine.so)
+// contains only the HIP build and refuses to run without a device.
+#define LANCET_WAVE_EMU 1
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../lancet_amd/csrc/kernels.h"
+#include "../../lancet_amd/csrc/host_common.h"
+
+struct EmuResult {
+  std::vector<lancet_variant> variants;
+  std::vector<char> blob;
+  std::vector<lancet_window_stats> stats;
+  std::vector<uint32_t> evt_len, evt;
+  uint32_t evt_cap;
+  uint32_t n_variants, n_blob;
+};
+
+extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batch *b, uint32_t evt_cap) {
+  EngineCaps C = lc_caps_for_batch(b, P, evt_cap, 65536);
+  const uint32_t R = b->read_begin[b->n_windows];
+  // ---- device batch (host memory here)
+  std::vector<uint8_t> ref_codes(b->ref_off[b->n_windows]);
+  for (size_t i = 0; i < ref_codes.size(); ++i) ref_codes[i] = (uint8_t)base_code(b->ref_bases[i]);
+  std::vector<uint32_t> rinfo(R), bw(R + 1), gw(R + 1);
+  uint32_t bo = 0, go = 0;
+  for (uint32_t r = 0; r < R; ++r) { uint32_t len = b->seq_off[r + 1] - b->seq_off[r]; bw[r] = bo; gw[r] = go; bo += (len + 15) / 16; go += (len + 31) / 32; }
+  std::vector<uint32_t> bases(bo + 1), good(go + 1);
+  for (uint32_t r = 0; r < R; ++r)
+    prep_read(P, b->seq, b->qual, b->seq_off[r], (int)(b->seq_off[r + 1] - b->seq_off[r]), b->label[r], b->strand[r], b->mate[r], b->mapped[r],
+              &rinfo[r], bases.data(), bw[r], good.data(), gw[r]);
+  DevBatch B;
+  B.n_windows = b->n_windows; B.chr_id = b->chr_id; B.ref_start = b->ref_start; B.ref_off = b->ref_off; B.ref_codes = ref_codes.data();
+  B.read_begin = b->read_begin; B.rinfo = rinfo.data(); B.name_rank = b->name_rank; B.base_woff = bw.data(); B.good_woff = gw.data();
+  B.bases = bases.data(); B.good = good.data();
+  // ---- one work slot
+  size_t wbytes = lc_work_carve(nullptr, nullptr, C);
+  std::vector<char> wmem(wbytes + 256);
+  Work work; lc_work_carve(&work, wmem.data(), C);
+  auto *res = new EmuResult();
+  res->variants.resize(C.var_cap); res->blob.resize(C.blob_cap); res->stats.resize(b->n_windows);
+  res->evt_len.assign(b->n_windows, 0); res->evt.assign((size_t)b->n_windows * (evt_cap ? evt_cap : 1), 0); res->evt_cap = evt_cap;
+  uint32_t nv = 0, nb = 0, qh = 0;
+  DevOut O; O.variants = res->variants.data(); O.blob = res->blob.data(); O.n_variants = &nv; O.n_blob = &nb; O.stats = res->stats.data();
+  O.queue_head = &qh; O.evt_len = res->evt_len.data(); O.evt_out = res->evt.data();
+  static thread_local WinShared S;
+  window_kernel_body(P, &B, &C, &work, &O, &S, 0);
+  res->n_variants = nv < C.var_cap ? nv : C.var_cap; res->n_blob = nb;
+  return res;
+}
+extern "C" uint32_t lancet_emu_n_variants(void *h) { return ((EmuResult *)h)->n_variants; }
+extern "C" const lancet_variant *lancet_emu_variants(void *h) { return ((EmuResult *)h)->variants.data(); }
+extern "C" const char *lancet_emu_blob(void *h) { return ((EmuResult *)h)->blob.data(); }
+extern "C" uint32_t lancet_emu_blob_len(void *h) { return ((EmuResult *)h)->n_blob; }
+extern "C" const lancet_window_stats *lancet_emu_stats(void *h) { return ((EmuResult *)h)->stats.data(); }
+extern "C" const uint32_t *lancet_emu_evt_len(void *h) { return ((EmuResult *)h)->evt_len.data(); }
+extern "C" const uint32_t *lancet_emu_evt(void *h) { return ((EmuResult *)h)->evt.data(); }
+extern "C" void lancet_emu_free(void *h) { delete (EmuResult *)h; }

@@ -1,0 +1,63 @@
+"""Parity tests proper: the HIP engine, called through the C-ABI, against (a) the oracle on the same inputs,
+(b) the committed reference goldens (VCF + `-v` stage trace).  Bit-exact: everything is integer/index work
+except four float coverages per node, which must round exactly like the reference (no tolerance)."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from lancet_amd import abi, engine
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _names(batch):
+    id2chr = {}
+    for c, i in zip(batch.chrom, batch.chr_id):
+        id2chr[int(i)] = c
+    return [id2chr[i] for i in range(len(id2chr))]
+
+
+@pytest.mark.parametrize("case", gu.CASES)
+def test_engine_matches_oracle_and_reference(case):
+    meta, batch, kept, (min_k, max_k) = gu.case_batch(case)
+    p = abi.default_params(min_k=min_k, max_k=max_k)
+    eng = engine.Engine(p, device=0, trace_words=1 << 17)
+    variants, stats = eng.process(batch)
+    ov, ostats, _ = oracle.run(batch, p)
+    assert all(s["status"] >= 0 for s in stats), [s for s in stats if s["status"] < 0][:3]
+    assert variants == ov
+    key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
+    assert [key(s) for s in stats] == [key(s) for s in ostats]
+    assert gu.digest_trace(eng.trace_text()) == gu.golden_trace(case)          # every stage == reference `-v`
+    db = engine.VariantDB()
+    vp, n, blob, _ = eng.raw_results()
+    db.add_raw(vp, n, blob + b"\0", _names(batch))
+    assert db.vcf() == gu.golden_vcf(case)                                      # byte-identical VCF
+    eng.close()
+
+
+def test_engine_is_deterministic_and_order_independent():
+    """Same windows in a different batch order / slot assignment give the same per-window records."""
+    meta, batch, kept, (min_k, max_k) = gu.case_batch("tile30")
+    p = abi.default_params(min_k=min_k, max_k=max_k)
+    eng = engine.Engine(p)
+    a, sa = eng.process(batch)
+    b, sb = eng.process(batch)
+    assert a == b and sa == sb
+    eng.close()
+
+
+def test_empty_and_readless_windows():
+    from lancet_amd import frontend
+    w = [frontend.Window("c:1-600", "c", 1, 601, "ACGT" * 150), frontend.Window("c:101-700", "c", 101, 701, "TTGCA" * 120)]
+    batch = frontend.build_batch(w, [[], []])
+    eng = engine.Engine()
+    v, st = eng.process(batch)
+    assert v == [] and [s["status"] for s in st] == [1, 1]       # LANCET_W_NO_READS (Microassembler.cc:83)
+    ov, ost, _ = oracle.run(batch)
+    assert [s["status"] for s in ost] == [1, 1]
+    empty = frontend.build_batch([], [])
+    v, st = eng.process(empty)
+    assert v == [] and st == []
+    eng.close()

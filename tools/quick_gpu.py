@@ -1,0 +1,33 @@
+"""Quick GPU sanity/timing: replicate a golden case N times into one batch and time the engine."""
+import sys, time, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import golden_util as gu
+from lancet_amd import abi, engine, frontend
+
+def replicate(batch, times):
+    import copy
+    b = batch
+    R = b.n_reads
+    def tile(a): return np.concatenate([a] * times)
+    ref_off = np.concatenate([[0], np.cumsum(np.tile(np.diff(b.ref_off.astype(np.int64)), times))]).astype(np.uint32)
+    read_begin = np.concatenate([[0], np.cumsum(np.tile(np.diff(b.read_begin.astype(np.int64)), times))]).astype(np.uint32)
+    seq_off = np.concatenate([[0], np.cumsum(np.tile(np.diff(b.seq_off.astype(np.int64)), times))]).astype(np.uint32)
+    return frontend.WindowBatch(n_windows=b.n_windows * times, hdr=b.hdr * times, chrom=b.chrom * times, chr_id=tile(b.chr_id),
+        ref_start=tile(b.ref_start), ref_off=ref_off, ref_bases=tile(b.ref_bases), read_begin=read_begin, seq_off=seq_off,
+        seq=tile(b.seq), qual=tile(b.qual), label=tile(b.label), strand=tile(b.strand), mate=tile(b.mate), mapped=tile(b.mapped),
+        name_rank=tile(b.name_rank))
+
+case = sys.argv[1] if len(sys.argv) > 1 else "tile30"
+times = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+meta, batch, kept, (mk, xk) = gu.case_batch(case)
+big = replicate(batch, times)
+p = abi.default_params(min_k=mk, max_k=xk)
+eng = engine.Engine(p)
+t = time.time(); eng.upload(big); print("upload s", time.time() - t, "windows", big.n_windows, "slots/bytes", eng.geometry())
+for it in range(3):
+    t = time.time(); eng.run(); dt = time.time() - t
+    v, st = eng.results()
+    nk = sum(s["n_kmers"] for s in st)
+    print(f"run {it}: wall {dt:.3f}s kernel {eng.timing_ms()[1]:.1f} ms  windows/s {big.n_windows / dt:.0f}  Mkmers/s {nk / dt / 1e6:.1f} variants {len(v)} bad {sum(1 for s in st if s['status'] < 0)}")
