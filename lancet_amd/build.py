@@ -23,15 +23,38 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -ffp-contract=off: float coverage averaging must round like the reference's SSE code
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wno-unused-result", "-x", "hip", "engine.hip", "-x", "c++", "host_vdb.cc", "-o", LIB]
-    r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
-    if r.returncode != 0:
-        sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building liblancet_engine.so")
-    if verbose:
-        sys.stderr.write(r.stderr)
+    steps = [
+        [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
+         "-c", "engine.hip", "-o", "engine.o"],
+        [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-c", "host_vdb.cc", "-o", "host_vdb.o"],
+        [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "engine.o", "host_vdb.o", "-o", LIB],
+    ]
+    for cmd in steps:
+        r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("build of liblancet_engine.so failed: " + " ".join(cmd))
+        if verbose:
+            sys.stderr.write(r.stderr)
+    _check_gfx950(LIB)
     return LIB
+
+
+def _check_gfx950(lib: str) -> None:
+    """The device code object must be gfx950 (a silently defaulted arch would only fail on the GPU box)."""
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "clang-offload-bundler")):
+        return
+    fb = lib + ".fatbin"
+    try:
+        subprocess.run([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", lib, fb], check=True)
+        out = subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--list", "--type=o", "--input=" + fb],
+                             capture_output=True, text=True).stdout
+    finally:
+        if os.path.exists(fb):
+            os.remove(fb)
+    if "gfx950" not in out:
+        raise RuntimeError(f"liblancet_engine.so has no gfx950 code object (found: {out.split()})")
 
 
 if __name__ == "__main__":

@@ -17,7 +17,10 @@
 #define HIPCHK(e, call)                                                                           \
   do { hipError_t _r = (call); if (_r != hipSuccess) { (e)->err = std::string(#call) + ": " + hipGetErrorString(_r); return LANCET_E_HIP; } } while (0)
 
-__global__ void __launch_bounds__(LANCET_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) window_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT) {
+// launch_bounds is deliberately 2x the launched size: with a provably single-wave workgroup the compiler turns
+// s_barrier into a no-op and then threads the lane-0 sections of consecutive phases together, which lets lane 0
+// run ahead of the other lanes (observed on gfx950: lanes 1..63 skipped whole phases).
+__global__ void __launch_bounds__(LANCET_WG * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) window_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT) {
   __shared__ WinShared S;
   window_kernel_body(P, B, C, works, OUT, &S, (int)blockIdx.x);
 }
@@ -29,6 +32,16 @@ __global__ void prep_kernel(const lancet_params *P, int n_reads, const char *seq
   if (r >= n_reads) return;
   prep_read(P, seq, qual, seq_off[r], (int)(seq_off[r + 1] - seq_off[r]), label[r], strand[r], mate[r], mapped[r], &rinfo[r], bases, bw[r], good, gw[r]);
 }
+// test hook: global_align_aff alone (align_fill + align_traceback) on one pair of strings
+__global__ void __launch_bounds__(LANCET_WG * 2) align_test_kernel(const EngineCaps *C, Work *work, const uint8_t *Sx, int n, const uint8_t *Tx, int m, int *out_len) {
+  __shared__ WinShared S;
+  Ctx c; c.P = nullptr; c.B = nullptr; c.C = C; c.W = work; c.OUT = nullptr; c.S = &S;
+  WG_LANE0 { S.overflow = 0; }
+  WG_SYNC();
+  align_fill(c, Sx, n, Tx, m);
+  WG_LANE0 { int L = align_traceback(c, Sx, n, Tx, m); *out_len = S.overflow ? -1 : L; }
+}
+
 __global__ void ref_code_kernel(const char *ref, uint8_t *codes, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) codes[i] = (uint8_t)base_code(ref[i]);
@@ -125,7 +138,8 @@ static int up(lancet_engine *e, DevBuf &b, const void *src, size_t bytes) {
   if (bytes) HIPCHK(e, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, e->stream));
   return LANCET_OK;
 }
-#define UP(buf, src, bytes) do { int _rc = up(e, buf, src, bytes); if (_rc) return _rc; } while (0)
+#define DBG(msg) do { if (getenv("LANCET_DEBUG")) { fprintf(stderr, "[lancet] %s:%d %s\n", __func__, __LINE__, msg); fflush(stderr); } } while (0)
+#define UP(buf, src, bytes) do { DBG(#buf); int _rc = up(e, buf, src, bytes); if (_rc) return _rc; } while (0)
 #define ENS(buf, bytes) do { if ((buf).ensure((bytes) ? (bytes) : 1)) { e->err = "hipMalloc failed"; return LANCET_E_OOM; } } while (0)
 
 int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
@@ -160,6 +174,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   UP(e->d_gw, gw.data(), sizeof(uint32_t) * (R + 1));
   ENS(e->d_bases, sizeof(uint32_t) * (bo + 1)); ENS(e->d_good, sizeof(uint32_t) * (go + 1)); ENS(e->d_rinfo, sizeof(uint32_t) * (R + 1));
   ENS(e->d_refcodes, nref + 1);
+  DBG("prep launch");
   // ---- prep on the device: Graph_t::trim + packing, reference -> codes
   if (R) hipLaunchKernelGGL(prep_kernel, dim3((R + 255) / 256), dim3(256), 0, e->stream, (const lancet_params *)e->d_params.p, (int)R,
                             (const char *)e->d_seq.p, (const char *)e->d_qual.p, (const uint32_t *)e->d_seqoff.p, (const uint8_t *)e->d_label.p,
@@ -167,6 +182,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
                             (uint32_t *)e->d_bases.p, (const uint32_t *)e->d_bw.p, (uint32_t *)e->d_good.p, (const uint32_t *)e->d_gw.p);
   hipLaunchKernelGGL(ref_code_kernel, dim3((nref + 255) / 256), dim3(256), 0, e->stream, (const char *)e->d_refasc.p, (uint8_t *)e->d_refcodes.p, nref);
   HIPCHK(e, hipGetLastError());
+  DBG("prep launched");
   DevBatch db;
   db.n_windows = nw; db.chr_id = (const int32_t *)e->d_chr.p; db.ref_start = (const int32_t *)e->d_refstart.p;
   db.ref_off = (const uint32_t *)e->d_refoff.p; db.ref_codes = (const uint8_t *)e->d_refcodes.p; db.read_begin = (const uint32_t *)e->d_readbegin.p;
@@ -176,6 +192,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   UP(e->d_caps, &e->caps, sizeof(e->caps));
   // ---- work space: as many slots as fit (and are useful)
   size_t slot_bytes = lc_work_carve(nullptr, nullptr, e->caps);
+  DBG("carve measured");
   int slots = e->max_slots;
   if (slots > nw) slots = nw;
   while (slots > 1 && (size_t)slots * slot_bytes > e->mem_budget) slots /= 2;
@@ -196,7 +213,9 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   o.n_variants = (uint32_t *)e->d_counters.p; o.n_blob = (uint32_t *)e->d_counters.p + 1; o.queue_head = (uint32_t *)e->d_counters.p + 2;
   o.stats = (lancet_window_stats *)e->d_stats.p; o.evt_len = (uint32_t *)e->d_evtlen.p; o.evt_out = (uint32_t *)e->d_evt.p;
   UP(e->d_out, &o, sizeof(o));
+  DBG("sync");
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  DBG("uploaded");
   e->uploaded = true;
   return LANCET_OK;
 }
@@ -294,6 +313,44 @@ int lancet_engine_trace(lancet_engine *e, const uint32_t **evt_len, const uint32
   if (!e || !e->ran) return LANCET_E_STATE;
   *evt_len = e->evt_len.data(); *evt = e->evt.data(); *words_per_window = e->caps.evt_cap;
   return LANCET_OK;
+}
+
+// test hook: runs the device alignment on (S, T) (ACGT strings, |S| <= LC_MAXW); writes the aligned strings.
+int lancet_debug_align(lancet_engine *e, const char *S, const char *T, char *S_aln, char *T_aln, int cap) {
+  if (!e || !S || !T) return LANCET_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  int n = (int)strlen(S), m = (int)strlen(T);
+  if (n < 1 || m < 1 || n > LC_MAXW) return LANCET_E_ARG;
+  EngineCaps caps; memset(&caps, 0, sizeof(caps));
+  caps.reads_cap = 4; caps.occ_cap = 64; caps.node_cap = 16; caps.table_cap = 32; caps.bucket_cap = 32; caps.special_cap = 4; caps.surv_cap = 4;
+  caps.seq_cap = 64; caps.queue_cap = 4; caps.path_cap = (uint32_t)m + 8; caps.max_k = 16;
+  size_t bytes = lc_work_carve(nullptr, nullptr, caps);
+  DevBuf mem, dcaps, dwork, ds, dt, dl;
+  std::vector<uint8_t> sc(n), tc(m);
+  auto code = [](char b) -> uint8_t { switch (b) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; } return 4; };
+  for (int i = 0; i < n; ++i) sc[i] = code(S[i]);
+  for (int i = 0; i < m; ++i) tc[i] = code(T[i]);
+  if (mem.ensure(bytes) || dcaps.ensure(sizeof(caps)) || dwork.ensure(sizeof(Work)) || ds.ensure(n) || dt.ensure(m) || dl.ensure(4)) return LANCET_E_OOM;
+  Work w; lc_work_carve(&w, (char *)mem.p, caps);
+  HIPCHK(e, hipMemcpy(dcaps.p, &caps, sizeof(caps), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(dwork.p, &w, sizeof(w), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(ds.p, sc.data(), n, hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(dt.p, tc.data(), m, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(align_test_kernel, dim3(1), dim3(LANCET_WG), 0, e->stream, (const EngineCaps *)dcaps.p, (Work *)dwork.p, (const uint8_t *)ds.p, n,
+                     (const uint8_t *)dt.p, m, (int *)dl.p);
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  int L = 0;
+  HIPCHK(e, hipMemcpy(&L, dl.p, 4, hipMemcpyDeviceToHost));
+  int rc = LANCET_OK;
+  if (L < 0 || L + 1 > cap) rc = LANCET_E_UNSUPPORTED;
+  else {
+    const int acap = LC_MAXW + (int)caps.path_cap + 2;
+    HIPCHK(e, hipMemcpy(S_aln, w.aln, L, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(T_aln, w.aln + acap, L, hipMemcpyDeviceToHost));
+    S_aln[L] = 0; T_aln[L] = 0;
+  }
+  mem.release(); dcaps.release(); dwork.release(); ds.release(); dt.release(); dl.release();
+  return rc;
 }
 
 // introspection used by bench.py: slots in flight and bytes of work space per slot

@@ -53,20 +53,42 @@ struct Ctx {
   const EngineCaps *C;
   Work *W;
   DevOut *OUT;
-  WinShared *S;
+  volatile WinShared *S;   // volatile: control words written by lane 0 and read by every lane after a barrier must be
+                           // real LDS accesses (the optimiser was observed to drop/sink such stores across the barrier)
 };
 
 #define OVF(c) do { (c).S->overflow = 1; } while (0)
 
 // Uniform read of a control word: barrier, everybody reads, barrier (so that the next writer cannot race a
 // slow reader).  Every branch that contains a WG_SYNC must be decided through this.
-DEV int wg_bcast(const int *p) { WG_SYNC(); int v = *p; WG_SYNC(); return v; }
-DEV uint32_t wg_bcastu(const uint32_t *p) { WG_SYNC(); uint32_t v = *p; WG_SYNC(); return v; }
+// The value is passed through readfirstlane so that the compiler sees a wave-uniform (scalar) branch condition:
+// with a lane-varying condition it builds EXEC-masked control flow around the phases and, on gfx950, was observed
+// to let lanes 1..63 evaluate a loop condition before lane 0 had executed the preceding lane-0 section.
+DEV int wg_uniform(int v) {
+#ifndef LANCET_WAVE_EMU
+  return __builtin_amdgcn_readfirstlane(v);
+#else
+  return v;
+#endif
+}
+// The pointer is laundered through an empty asm so that the optimiser cannot correlate the value with a store
+// made by the preceding lane-0 section (observed on gfx950/ROCm 7.2: the lane-0 path was threaded straight into
+// a following `while (wg_bcast(..))` loop, lanes 1..63 then evaluated the loop condition before lane 0's store).
+DEV int wg_bcast(const volatile int *p) {
+  WG_SYNC();
+#ifndef LANCET_WAVE_EMU
+  asm volatile("" : "+v"(p) : : "memory");
+#endif
+  int v = wg_uniform(*p);
+  WG_SYNC();
+  return v;
+}
+DEV uint32_t wg_bcastu(const volatile uint32_t *p) { return (uint32_t)wg_bcast((const volatile int *)p); }
 
 DEV void evt(Ctx &c, uint32_t code, uint32_t a = 0, uint32_t b = 0, uint32_t d = 0, uint32_t e = 0, uint32_t f = 0,
              uint32_t g = 0, uint32_t h = 0) {
   if (!c.C->evt_cap) return;
-  WinShared &S = *c.S;
+  volatile WinShared &S = *c.S;
   if (S.evt_len + 8 > c.C->evt_cap) return;
   uint32_t *p = c.W->evt + S.evt_len;
   p[0] = code; p[1] = a; p[2] = b; p[3] = d; p[4] = e; p[5] = f; p[6] = g; p[7] = h;
@@ -74,7 +96,7 @@ DEV void evt(Ctx &c, uint32_t code, uint32_t a = 0, uint32_t b = 0, uint32_t d =
 }
 DEV void evt_bytes(Ctx &c, const uint8_t *s, uint32_t n) {   // raw bytes appended after an event, padded to 8 words
   if (!c.C->evt_cap) return;
-  WinShared &S = *c.S;
+  volatile WinShared &S = *c.S;
   uint32_t words = ((n + 3) / 4 + 7) / 8 * 8;
   if (S.evt_len + words > c.C->evt_cap) return;
   uint8_t *p = (uint8_t *)(c.W->evt + S.evt_len);
@@ -166,7 +188,7 @@ DEV bool key_less(const unsigned long long *a, const unsigned long long *b, int 
 //   isAlmostRepeat(seq,k,mm) <=> Mm >= k+1   Mm = longest self-match window with <= mm mismatches, b+L-1 <= len-1
 // (the reference skips the last k-mer in both loops).  One shift d = b-a per lane.
 // ---------------------------------------------------------------------------------------------------------
-DEV void repeat_scan(const uint8_t *s, int len, int mm, int *outE, int *outM) {
+DEV void repeat_scan(const uint8_t *s, int len, int mm, volatile int *outE, volatile int *outM) {
   WG_LANE0 { *outE = 0; *outM = 0; }
   WG_SYNC();
   WG_FOR(dd, len > 1 ? len - 1 : 0) {
@@ -187,7 +209,7 @@ DEV void repeat_scan(const uint8_t *s, int len, int mm, int *outE, int *outM) {
 }
 
 // exclusive prefix sum of a[0..n) in place; returns total in S.part[LANCET_WG]
-DEV void wg_scan(uint32_t *a, int n, WinShared &S) {
+DEV void wg_scan(uint32_t *a, int n, volatile WinShared &S) {
   int chunk = (n + LANCET_WG - 1) / LANCET_WG;
   WG_FOR(l, LANCET_WG) {
     uint32_t s = 0;
@@ -294,9 +316,9 @@ DEV uint32_t ht_next_prime(uint32_t n) {   // _M_next_bkt(n) for the values that
   for (int i = 0; i < 18; ++i) if (chain[i] >= n) return chain[i];
   return 0;
 }
-DEV void ht_reset(Ctx &c) { WinShared &S = *c.S; S.ht_bc = 1; S.ht_next_resize = 0; S.ht_elt = 0; S.ht_head = LC_NIL; c.W->ht_bucket[0] = LC_NIL; }
-DEV void ht_rehash(Ctx &c, uint32_t nb) {
-  WinShared &S = *c.S; Work &W = *c.W;
+DEV void ht_reset(Ctx &c) { volatile WinShared &S = *c.S; S.ht_bc = 1; S.ht_next_resize = 0; S.ht_elt = 0; S.ht_head = LC_NIL; c.W->ht_bucket[0] = LC_NIL; }
+DEVNI void ht_rehash(Ctx &c, uint32_t nb) {
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   if (nb == 0 || nb > c.C->bucket_cap) { OVF(c); return; }
   for (uint32_t i = 0; i < nb; ++i) W.ht_bucket[i] = LC_NIL;
   uint32_t p = S.ht_head; S.ht_head = LC_NIL;
@@ -317,8 +339,8 @@ DEV void ht_rehash(Ctx &c, uint32_t nb) {
   }
   S.ht_bc = nb;
 }
-DEV void ht_insert(Ctx &c, uint32_t n) {
-  WinShared &S = *c.S; Work &W = *c.W;
+DEVNI void ht_insert(Ctx &c, uint32_t n) {
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   if (S.ht_elt + 1 > S.ht_next_resize) {                      // _Prime_rehash_policy::_M_need_rehash
     unsigned long long mn = S.ht_elt + 1;
     if (S.ht_next_resize == 0 && mn < 11) mn = 11;
@@ -344,8 +366,8 @@ DEV void ht_insert(Ctx &c, uint32_t n) {
 }
 // Insert into the (array form of the) live table: unordered_map::insert after erasures.  Erase never moves
 // other nodes and keeps each bucket's run contiguous, so "bucket empty" == no live node hashes to it.
-DEV void order_insert(Ctx &c, uint32_t n) {
-  WinShared &S = *c.S; Work &W = *c.W;
+DEVNI void order_insert(Ctx &c, uint32_t n) {
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   if (S.ht_elt + 1 > S.ht_next_resize) {
     unsigned long long mn = S.ht_elt + 1;
     if (S.ht_next_resize == 0 && mn < 11) mn = 11;
@@ -369,17 +391,17 @@ DEV void order_insert(Ctx &c, uint32_t n) {
   ++S.M; ++S.ht_elt;
 }
 // cleanDead (reference src/Graph.cc:2737-2762): erase every dead node from the table
-DEV uint32_t clean_dead(Ctx &c) {
-  WinShared &S = *c.S; Work &W = *c.W;
+DEVNI uint32_t clean_dead(Ctx &c) {
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   uint32_t m = 0, dead = 0;
   for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (W.nflags[n] & NF_DEAD) ++dead; else W.order[m++] = n; }
   S.M = m; S.ht_elt -= dead;
   evt(c, EV_CLEANDEAD, dead);
   return dead;
 }
-DEV void print_stats(Ctx &c, int comp) {                            // Graph_t::printStats, reference src/Graph.cc:3674-3691
+DEVNI void print_stats(Ctx &c, int comp) {                            // Graph_t::printStats, reference src/Graph.cc:3674-3691
   if (!c.C->evt_cap) return;
-  WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   int edgecnt = 0, span = 0;
   for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (W.ncomp[n] == comp) { edgecnt += W.necnt[n]; span += n_strlen(c, n); } }
   evt(c, EV_STATS, comp, S.M, edgecnt, span);
@@ -389,7 +411,7 @@ DEV void print_stats(Ctx &c, int comp) {                            // Graph_t::
 // sequence deques
 // ---------------------------------------------------------------------------------------------------------
 DEV bool seq_reserve(Ctx &c, uint32_t n, uint32_t front, uint32_t back) {   // room for `front` more before, `back` after
-  Work &W = *c.W; WinShared &S = *c.S;
+  Work &W = *c.W; volatile WinShared &S = *c.S;
   uint32_t lo = W.nseq_lo[n], hi = W.nseq_hi[n];
   if (lo - W.nseq_clo[n] >= front && W.nseq_chi[n] - hi >= back) return true;
   uint32_t len = hi - lo;
@@ -406,7 +428,7 @@ DEV bool seq_reserve(Ctx &c, uint32_t n, uint32_t front, uint32_t back) {   // r
 // buildgraph (reference src/Graph.cc:530-589 + loadSequence :119-349 + Node.cc / Ref.cc counters)
 // ---------------------------------------------------------------------------------------------------------
 DEV void read_geom(const Ctx &c, int r, uint32_t *rinfo, uint32_t *bw, uint32_t *gw, int *tlen, bool *isref) {
-  const DevBatch &B = *c.B; const WinShared &S = *c.S;
+  const DevBatch &B = *c.B; const volatile WinShared &S = *c.S;
   if (r == S.R - 1) { *isref = true; *tlen = S.reflen; *rinfo = 0; *bw = 0; *gw = 0; return; }
   uint32_t g = B.read_begin[S.w] + (uint32_t)r;
   *isref = false; *rinfo = B.rinfo[g]; *bw = B.base_woff[g]; *gw = B.good_woff[g]; *tlen = (int)RI_TLEN(*rinfo);
@@ -418,7 +440,7 @@ DEV int read_base(const Ctx &c, bool isref, uint32_t bw, int i) {
 
 template <int NW>
 DEV void build_insert_pass(Ctx &c, bool verify) {
-  WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   const int K = S.K;
   const uint32_t mask = c.C->table_cap - 1;
   WG_FOR(r, S.R) {
@@ -473,7 +495,7 @@ DEV bool step_all_good(const Ctx &c, bool isref, uint32_t gw, int s, int tlen, i
 }
 
 DEV void build_graph(Ctx &c) {
-  WinShared &S = *c.S; Work &W = *c.W; const EngineCaps &C = *c.C;
+  volatile WinShared &S = *c.S; Work &W = *c.W; const EngineCaps &C = *c.C;
   const int K = S.K;
   // ---- occurrence index space: read r owns [occ_base[r], occ_base[r+1]) = its k-mers p = 0..tlen-K
   WG_LANE0 {
@@ -704,7 +726,7 @@ DEV void build_graph(Ctx &c) {
 
 // per-position quality counts + sequence descriptors for the nodes that survive the first filter
 DEV void materialize_survivors(Ctx &c) {
-  WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   const int K = S.K;
   WG_LANE0 {
     uint32_t ns = 0;
@@ -744,7 +766,7 @@ DEV void materialize_survivors(Ctx &c) {
 
 // first removeLowCov(false, 0) + cleanDead; markRefNodes counters for the trace
 DEV void first_lowcov(Ctx &c) {
-  WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   // the live table in libstdc++ iteration order
   WG_LANE0 {
     ht_reset(c);
@@ -767,8 +789,8 @@ DEV void recompute_after_append(Ctx &c, uint32_t n, uint32_t from, uint32_t to) 
   W.nmincov[n] = mn; W.nmincovqv[n] = mq;
 }
 
-DEV void compress_node(Ctx &c, uint32_t node, char dir) {          // Graph_t::compressNode, reference src/Graph.cc:2486-2706
-  Work &W = *c.W; WinShared &S = *c.S;
+DEVNI void compress_node(Ctx &c, uint32_t node, char dir) {          // Graph_t::compressNode, reference src/Graph.cc:2486-2706
+  Work &W = *c.W; volatile WinShared &S = *c.S;
   const int K = S.K;
   while (!S.overflow) {
     int uid = get_buddy(c, node, dir);
@@ -831,8 +853,8 @@ DEV void compress_node(Ctx &c, uint32_t node, char dir) {          // Graph_t::c
     }
   }
 }
-DEV void compress(Ctx &c, int comp) {                               // reference src/Graph.cc:2712-2732
-  WinShared &S = *c.S; Work &W = *c.W;
+DEVNI void compress(Ctx &c, int comp) {                               // reference src/Graph.cc:2712-2732
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   evt(c, EV_COMPRESS);
   for (uint32_t i = 0; i < S.M && !S.overflow; ++i) {
     uint32_t n = W.order[i];
@@ -844,8 +866,8 @@ DEV void compress(Ctx &c, int comp) {                               // reference
   }
   clean_dead(c);
 }
-DEV void remove_low_cov(Ctx &c, int comp) {                         // reference src/Graph.cc:2790-2827 (docompression=true)
-  WinShared &S = *c.S; Work &W = *c.W;
+DEVNI void remove_low_cov(Ctx &c, int comp) {                         // reference src/Graph.cc:2790-2827 (docompression=true)
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
   uint32_t low = 0;
   for (uint32_t i = 0; i < S.M; ++i) {
@@ -863,7 +885,7 @@ DEV void remove_low_cov(Ctx &c, int comp) {                         // reference
 }
 
 // findTandems (reference src/util.cc:574-758) on a code string (0..3); returns ans, len, motif (codes)
-DEV bool find_tandems(const Ctx &c, const uint8_t *seq, int n, int pos, int *len, uint8_t *motif, int *motif_len) {
+DEVNI bool find_tandems(const Ctx &c, const uint8_t *seq, int n, int pos, int *len, uint8_t *motif, int *motif_len) {
   const unsigned MAXU = (unsigned)c.P->max_unit_len, MRU = (unsigned)c.P->min_report_units, MRL = (unsigned)c.P->min_report_len;
   const int delta = c.P->dist_from_str;
   bool ans = false;
@@ -911,8 +933,8 @@ DEV void node_string(const Ctx &c, uint32_t n, uint8_t *out) {      // str_m as 
   for (uint32_t i = lo; i < hi; ++i) out[i - lo] = (uint8_t)SD_BASE(W.seq[i]);
 }
 
-DEV void remove_tips(Ctx &c, int comp) {                            // reference src/Graph.cc:2885-2926
-  WinShared &S = *c.S; Work &W = *c.W;
+DEVNI void remove_tips(Ctx &c, int comp) {                            // reference src/Graph.cc:2885-2926
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   int tips = 0, round = 0;
   do {
     ++round; tips = 0;
@@ -929,8 +951,8 @@ DEV void remove_tips(Ctx &c, int comp) {                            // reference
   } while (tips && !S.overflow);
   print_stats(c, comp);
 }
-DEV void remove_short_links(Ctx &c, int comp) {                     // reference src/Graph.cc:2833-2880
-  WinShared &S = *c.S; Work &W = *c.W;
+DEVNI void remove_short_links(Ctx &c, int comp) {                     // reference src/Graph.cc:2833-2880
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
   const int max_link_len = S.K / 2;                                  // setK: floor(K/2.0)
   const double thr = floor(sqrt(avgcov));
@@ -954,8 +976,8 @@ DEV void remove_short_links(Ctx &c, int comp) {                     // reference
   print_stats(c, comp);
 }
 
-DEV int mark_connected_components(Ctx &c) {                         // reference src/Graph.cc:2252-2336
-  WinShared &S = *c.S; Work &W = *c.W;
+DEVNI int mark_connected_components(Ctx &c) {                         // reference src/Graph.cc:2252-2336
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   for (uint32_t i = 0; i < S.M; ++i) W.ncomp[W.order[i]] = 0;
   int comp = 0, refcomp = 0;
   uint32_t *Q = W.scratch;                                            // FIFO; every node enqueued <= deg+1 times
@@ -989,7 +1011,7 @@ DEV int mark_connected_components(Ctx &c) {                         // reference
 // markRefEnds (reference src/Graph.cc:2028-2228).  The node of the reference k-mer at `offset` is the node
 // of the reference pseudo-read's occurrence at that offset (if it is still in the table).
 DEV uint32_t special_new(Ctx &c, bool issource, int comp) {
-  WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   if (S.nspecial >= c.C->special_cap) { OVF(c); return LC_NIL; }
   uint32_t id = c.C->node_cap + S.nspecial++;
   char name[24]; int L = 0;
@@ -1004,8 +1026,8 @@ DEV uint32_t special_new(Ctx &c, bool issource, int comp) {
   W.nseq_lo[id] = W.nseq_hi[id] = W.nseq_clo[id] = W.nseq_chi[id] = 0; W.nkm[id] = 0; W.nkmT[id] = 0; W.nonref[id] = 0;
   return id;
 }
-DEV void mark_ref_ends(Ctx &c, int comp) {
-  WinShared &S = *c.S; Work &W = *c.W;
+DEVNI void mark_ref_ends(Ctx &c, int comp) {
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   const int K = S.K;
   S.trim5 = 0xFFFF; S.trim3 = 0xFFFF;
   S.source = LC_NIL; S.sink = LC_NIL;
@@ -1071,8 +1093,8 @@ DEV void mark_ref_ends(Ctx &c, int comp) {
   order_insert(c, nk);
 }
 
-DEV bool has_cycle(Ctx &c) {                                         // reference src/Graph.cc:593-681
-  WinShared &S = *c.S; Work &W = *c.W;
+DEVNI bool has_cycle(Ctx &c) {                                         // reference src/Graph.cc:593-681
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   if (S.source == LC_NIL || S.sink == LC_NIL) return false;
   for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (!(W.nflags[n] & NF_SPECIAL)) W.ncolor[n] = 1; }
   bool ans = false;
@@ -1117,8 +1139,8 @@ DEV bool path_has_node(const Ctx &c, uint32_t idx, uint32_t node) {
   for (uint32_t i = idx; i != LC_NIL; i = Q[i].parent) if (Q[i].node == node) return true;
   return false;
 }
-DEV uint32_t bfs(Ctx &c) {
-  WinShared &S = *c.S; Work &W = *c.W;
+DEVNI uint32_t bfs(Ctx &c) {
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   BfsEntry *Q = W.queue;
   const uint32_t cap = c.C->queue_cap;
   int reflen = S.seq_len;
@@ -1156,7 +1178,7 @@ DEV uint32_t bfs(Ctx &c) {
   return best;
 }
 // unpack the best path into W.pnodes / W.pedges ; returns number of nodes
-DEV int path_unpack(Ctx &c, uint32_t best) {
+DEVNI int path_unpack(Ctx &c, uint32_t best) {
   Work &W = *c.W; const BfsEntry *Q = W.queue;
   int n = 0;
   for (uint32_t i = best; i != LC_NIL; i = Q[i].parent) ++n;
@@ -1173,8 +1195,8 @@ DEV void path_flag_edges(Ctx &c, int n, uint32_t v) {
   }
 }
 // Path_t::str + covDistr (reference src/Path.cc:69-175): string codes + descriptor per base ; returns length
-DEV int path_string(Ctx &c, int n) {
-  Work &W = *c.W; WinShared &S = *c.S;
+DEVNI int path_string(Ctx &c, int n) {
+  Work &W = *c.W; volatile WinShared &S = *c.S;
   const int K = S.K;
   int len = 0;
   uint32_t e1 = W.edges[(W.pedges[1] >> 4) * LC_EMAX + (W.pedges[1] & 15u)];
@@ -1257,7 +1279,7 @@ DEV void align_fill(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) 
   }
 }
 // traceback into W.aln: returns alignment length; ref_aln at aln[0..L), path_aln at aln[cap..cap+L) (ASCII)
-DEV int align_traceback(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) {
+DEVNI int align_traceback(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) {
   Work &W = *c.W;
   const int stride = m + 1;
   const int cap = LC_MAXW + (int)c.C->path_cap + 2;
@@ -1313,9 +1335,9 @@ DEV void path_cov_at(const Ctx &c, int P, uint16_t *n4, uint16_t *t4) {         
   desc_cov(c, d, 1, &t4[0], &t4[1], &t4[2], &t4[3]);
 }
 
-DEV void emit_variant(Ctx &c, const TS &t, const uint16_t cov[8], int strLen, const uint8_t *motif, int motifLen, bool hasStr,
+DEVNI void emit_variant(Ctx &c, const TS &t, const uint16_t cov[8], int strLen, const uint8_t *motif, int motifLen, bool hasStr,
                       const uint8_t *ra, const uint8_t *pa) {
-  WinShared &S = *c.S; DevOut &O = *c.OUT;
+  volatile WinShared &S = *c.S; DevOut &O = *c.OUT;
   uint32_t vi = dev_atomic_add(O.n_variants, 1u);
   int rl = t.col1 - t.col0 + 1;
   char sbuf[80]; int sl = 0;
@@ -1337,8 +1359,8 @@ DEV void emit_variant(Ctx &c, const TS &t, const uint16_t cov[8], int strLen, co
 }
 
 // lane 0.  `np` = nodes in path, `plen` = path string length, aligned strings in W.aln (length L).
-DEV void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
-  WinShared &S = *c.S; Work &W = *c.W;
+DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   const int K = S.K;
   const int cap = LC_MAXW + (int)c.C->path_cap + 2;
   const uint8_t *ra = W.aln, *pa = W.aln + cap;
@@ -1440,7 +1462,7 @@ DEV void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
 // returns true when a near-perfect repeat is found in a source->sink path (Graph_t::findRepeatsInGraphPaths,
 // reference src/Graph.cc:686-730)
 DEV bool repeats_in_graph_paths(Ctx &c) {
-  WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   WG_LANE0 {
     evt(c, EV_LOOKREP);
     S.tmp0 = 0;                                  // 0 continue, 1 stop:false, 2 stop:true
@@ -1473,7 +1495,7 @@ DEV bool repeats_in_graph_paths(Ctx &c) {
 
 // eka (reference src/Graph.cc:1430-1501) via countRefPath (:2420-2445)
 DEV void count_ref_path(Ctx &c) {
-  WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = *c.S; Work &W = *c.W;
   if (wg_bcastu(&S.source) == LC_NIL) return;
   if (wg_bcastu(&S.sink) != LC_NIL) {
     WG_LANE0 { evt(c, EV_SEARCH, (uint32_t)W.ncomp[S.source]); S.tmp0 = S.tmp1 = S.tmp2 = 0; S.part[0] = 0; S.part[1] = 0; S.part[2] = 0; S.part[3] = 0; }
@@ -1531,7 +1553,7 @@ DEV void count_ref_path(Ctx &c) {
 // the window: Microassembler::processGraph (reference src/Microassembler.cc:73-249)
 // ---------------------------------------------------------------------------------------------------------
 DEV void process_window(Ctx &c, int w) {
-  WinShared &S = *c.S; Work &W = *c.W; const DevBatch &B = *c.B;
+  volatile WinShared &S = *c.S; Work &W = *c.W; const DevBatch &B = *c.B;
   WG_LANE0 {
     S.w = w; S.overflow = 0; S.evt_len = 0; S.emit_seq = 0; S.n_kmers = 0; S.max_nodes = 0; S.n_builds = 0; S.final_k = 0;
     S.status = LANCET_W_OK;
@@ -1630,7 +1652,7 @@ DEV void process_window(Ctx &c, int w) {
 }
 
 // entry: persistent workgroup pulling windows off the batch queue
-DEV void window_kernel_body(const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT, WinShared *S, int slot) {
+DEV void window_kernel_body(const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT, volatile WinShared *S, int slot) {
   Ctx c; c.P = P; c.B = B; c.C = C; c.W = works + slot; c.OUT = OUT; c.S = S;
   while (true) {
     WG_LANE0 { S->tmp3 = (int)dev_atomic_add(OUT->queue_head, 1u); }

@@ -18,8 +18,14 @@
 #define DEV __device__ __forceinline__
 #define DEVNI __device__ __noinline__
 #define WG_FOR(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += (int)blockDim.x)
-#define WG_SYNC() __syncthreads()
-#define WG_LANE0 if (threadIdx.x == 0)
+// Agent-scope fence before the barrier: the phases communicate through HBM with a mix of atomics (performed
+// at L2) and plain loads (which may hit the CU's vector L1), so the L1 has to be invalidated at phase boundaries.
+#define WG_SYNC() do { __threadfence(); __syncthreads(); } while (0)
+// lane-0 predicate, opaque to the optimiser (two consecutive lane-0 sections must not be merged or threaded)
+DEV bool wg_is_lane0() { uint32_t t = threadIdx.x; asm volatile("" : "+v"(t)); return t == 0; }
+DEV void wg_sync_fn() { __threadfence(); __syncthreads(); }
+// every lane-0 section is followed by a barrier executed by all lanes
+#define WG_LANE0 for (int _wg_once = 1; _wg_once; _wg_once = 0, wg_sync_fn()) if (wg_is_lane0())
 #define WG_SHARED __shared__
 DEV uint32_t dev_atomic_min(uint32_t *p, uint32_t v) { return atomicMin(p, v); }
 DEV uint32_t dev_atomic_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }

@@ -26,9 +26,10 @@ class EngineError(RuntimeError):
 def lib():
     global _LIB
     if _LIB is None:
-        if not os.path.exists(_LIBPATH):
+        path = os.environ.get("LANCET_ENGINE_LIB", _LIBPATH)      # (debug: try an alternative build of the same library)
+        if not os.path.exists(path):
             raise EngineError(f"{_LIBPATH} is missing: build it with `python -m lancet_amd.build` (there is no CPU fallback)")
-        L = C.CDLL(_LIBPATH)
+        L = C.CDLL(path)
         L.lancet_params_default.argtypes = [C.POINTER(abi.LancetParams)]
         L.lancet_engine_create.argtypes = [C.POINTER(abi.LancetParams), C.c_int, C.POINTER(C.c_void_p)]
         L.lancet_engine_destroy.argtypes = [C.c_void_p]
@@ -43,6 +44,7 @@ def lib():
         L.lancet_engine_set_trace.argtypes = [C.c_void_p, C.c_uint32]
         L.lancet_engine_trace.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32)]
         L.lancet_engine_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+        L.lancet_debug_align.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.lancet_filters_default.argtypes = [C.POINTER(abi.LancetFilters)]
         L.lancet_vdb_create.restype = C.c_void_p
         L.lancet_vdb_create.argtypes = [C.POINTER(abi.LancetFilters)]
@@ -131,6 +133,14 @@ class Engine:
             end = int(b.ref_start[w]) + int(b.ref_off[w + 1] - b.ref_off[w])
             parts.append(_trace.format_window(words, w + 1, b.hdr[w], b.chrom[w], int(b.ref_start[w]), end))
         return "".join(parts)
+
+    def debug_align(self, s: str, t: str):
+        """Test hook: the device global_align_aff on one pair of strings."""
+        cap = len(s) + len(t) + 8
+        a = C.create_string_buffer(cap)
+        b = C.create_string_buffer(cap)
+        self._chk(self.L.lancet_debug_align(self.h, s.encode(), t.encode(), a, b, cap))
+        return a.value.decode(), b.value.decode()
 
     def close(self):
         if getattr(self, "h", None):

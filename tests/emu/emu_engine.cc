@@ -40,6 +40,7 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   // ---- one work slot
   size_t wbytes = lc_work_carve(nullptr, nullptr, C);
   std::vector<char> wmem(wbytes + 256);
+  memset(wmem.data(), getenv("LANCET_EMU_POISON") ? atoi(getenv("LANCET_EMU_POISON")) : 0xCD, wmem.size());   // HBM is not zeroed: make stale-memory bugs show up here
   Work work; lc_work_carve(&work, wmem.data(), C);
   auto *res = new EmuResult();
   res->variants.resize(C.var_cap); res->blob.resize(C.blob_cap); res->stats.resize(b->n_windows);
@@ -48,6 +49,7 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   DevOut O; O.variants = res->variants.data(); O.blob = res->blob.data(); O.n_variants = &nv; O.n_blob = &nb; O.stats = res->stats.data();
   O.queue_head = &qh; O.evt_len = res->evt_len.data(); O.evt_out = res->evt.data();
   static thread_local WinShared S;
+  memset(&S, 0xCD, sizeof(S));
   window_kernel_body(P, &B, &C, &work, &O, &S, 0);
   res->n_variants = nv < C.var_cap ? nv : C.var_cap; res->n_blob = nb;
   return res;

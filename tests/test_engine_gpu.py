@@ -61,3 +61,30 @@ def test_empty_and_readless_windows():
     v, st = eng.process(empty)
     assert v == [] and st == []
     eng.close()
+
+
+def _rand_seq(rng, n):
+    return "".join("ACGT"[i] for i in rng.integers(0, 4, size=n))
+
+
+def test_device_alignment_equals_reference_align_cc():
+    """Device Gotoh (anti-diagonal wavefront + traceback) vs the oracle, which test_oracle_golden pins against
+    the reference's own align.cc (oracle/_ref)."""
+    rng = np.random.default_rng(11)
+    eng = engine.Engine()
+    for it in range(40):
+        n = int(rng.integers(30, 600))
+        s = _rand_seq(rng, n)
+        t = list(s)
+        for _ in range(int(rng.integers(0, 6))):
+            p = int(rng.integers(0, max(1, len(t))))
+            r = rng.random()
+            if r < 0.34 and t:
+                t[p] = "ACGT"[int(rng.integers(0, 4))]
+            elif r < 0.67:
+                t[p:p] = list(_rand_seq(rng, int(rng.integers(1, 60))))
+            elif t:
+                del t[p:p + int(rng.integers(1, 60))]
+        t = "".join(t) or "A"
+        assert eng.debug_align(s, t) == oracle.align(s, t), (s, t)
+    eng.close()
