@@ -75,7 +75,7 @@ struct lancet_engine {
   int n_windows = 0, n_reads = 0, n_slots = 0;
   bool uploaded = false, ran = false;
   uint32_t evt_cap = 0;
-  size_t mem_budget = (size_t)32 << 30;
+  size_t mem_budget = (size_t)96 << 30;
   int max_slots = 2048;
   uint32_t max_nodes_limit = 65536;
   // host results
