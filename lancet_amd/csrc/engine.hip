@@ -20,7 +20,7 @@
 // launch_bounds is deliberately 2x the launched size: with a provably single-wave workgroup the compiler turns
 // s_barrier into a no-op and then threads the lane-0 sections of consecutive phases together, which lets lane 0
 // run ahead of the other lanes (observed on gfx950: lanes 1..63 skipped whole phases).
-__global__ void __launch_bounds__(LANCET_WG * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) window_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT) {
+__global__ void __launch_bounds__(LANCET_WG * 2) __attribute__((amdgpu_waves_per_eu(4, 4))) window_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT) {
   __shared__ WinShared S;
   window_kernel_body(P, B, C, works, OUT, &S, (int)blockIdx.x);
 }
@@ -70,13 +70,14 @@ struct lancet_engine {
   DevBuf d_params, d_batch, d_caps, d_out, d_works;
   DevBuf d_chr, d_refstart, d_refoff, d_refasc, d_refcodes, d_readbegin, d_seqoff, d_seq, d_qual, d_label, d_strand, d_mate, d_mapped,
       d_rinfo, d_name, d_bw, d_gw, d_bases, d_good;
-  DevBuf d_variants, d_blob, d_counters, d_stats, d_evtlen, d_evt, d_workmem;
+  DevBuf d_variants, d_blob, d_counters, d_stats, d_evtlen, d_evt, d_workmem, d_phase;
+  std::vector<unsigned long long> phase;
   EngineCaps caps;
   int n_windows = 0, n_reads = 0, n_slots = 0;
   bool uploaded = false, ran = false;
   uint32_t evt_cap = 0;
   size_t mem_budget = (size_t)96 << 30;
-  int max_slots = 2048;
+  int max_slots = 4096;
   uint32_t max_nodes_limit = 65536;
   // host results
   std::vector<lancet_variant> variants;
@@ -120,7 +121,7 @@ void lancet_engine_destroy(lancet_engine *e) {
   DevBuf *all[] = {&e->d_params, &e->d_batch, &e->d_caps, &e->d_out, &e->d_works, &e->d_chr, &e->d_refstart, &e->d_refoff, &e->d_refasc,
                    &e->d_refcodes, &e->d_readbegin, &e->d_seqoff, &e->d_seq, &e->d_qual, &e->d_label, &e->d_strand, &e->d_mate, &e->d_mapped,
                    &e->d_rinfo, &e->d_name, &e->d_bw, &e->d_gw, &e->d_bases, &e->d_good, &e->d_variants, &e->d_blob, &e->d_counters,
-                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem};
+                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase};
   for (DevBuf *b : all) b->release();
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -207,11 +208,12 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   ENS(e->d_counters, 64);
   ENS(e->d_stats, sizeof(lancet_window_stats) * nw);
   ENS(e->d_evtlen, sizeof(uint32_t) * nw);
+  ENS(e->d_phase, sizeof(unsigned long long) * 16 * nw);
   ENS(e->d_evt, sizeof(uint32_t) * (size_t)nw * (e->caps.evt_cap ? e->caps.evt_cap : 1));
   DevOut o;
   o.variants = (lancet_variant *)e->d_variants.p; o.blob = (char *)e->d_blob.p;
   o.n_variants = (uint32_t *)e->d_counters.p; o.n_blob = (uint32_t *)e->d_counters.p + 1; o.queue_head = (uint32_t *)e->d_counters.p + 2;
-  o.stats = (lancet_window_stats *)e->d_stats.p; o.evt_len = (uint32_t *)e->d_evtlen.p; o.evt_out = (uint32_t *)e->d_evt.p;
+  o.stats = (lancet_window_stats *)e->d_stats.p; o.evt_len = (uint32_t *)e->d_evtlen.p; o.evt_out = (uint32_t *)e->d_evt.p; o.phase = (unsigned long long *)e->d_phase.p;
   UP(e->d_out, &o, sizeof(o));
   DBG("sync");
   HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -247,6 +249,8 @@ int lancet_engine_run(lancet_engine *e) {
   std::vector<char> rawblob(nb);
   if (nv) HIPCHK(e, hipMemcpy(raw.data(), e->d_variants.p, sizeof(lancet_variant) * nv, hipMemcpyDeviceToHost));
   if (nb) HIPCHK(e, hipMemcpy(rawblob.data(), e->d_blob.p, nb, hipMemcpyDeviceToHost));
+  e->phase.resize((size_t)e->n_windows * 16);
+  HIPCHK(e, hipMemcpy(e->phase.data(), e->d_phase.p, sizeof(unsigned long long) * e->phase.size(), hipMemcpyDeviceToHost));
   if (e->caps.evt_cap) {
     e->evt_len.resize(e->n_windows); e->evt.resize((size_t)e->n_windows * e->caps.evt_cap);
     HIPCHK(e, hipMemcpy(e->evt_len.data(), e->d_evtlen.p, sizeof(uint32_t) * e->n_windows, hipMemcpyDeviceToHost));
@@ -351,6 +355,13 @@ int lancet_debug_align(lancet_engine *e, const char *S, const char *T, char *S_a
   }
   mem.release(); dcaps.release(); dwork.release(); ds.release(); dt.release(); dl.release();
   return rc;
+}
+
+// profiling aid: per-window, per-phase time in 10 ns ticks (16 phases per window, see PHASE() in kernels.h)
+int lancet_engine_phase_times(lancet_engine *e, const unsigned long long **ticks) {
+  if (!e || !e->ran) return LANCET_E_STATE;
+  *ticks = e->phase.data();
+  return LANCET_OK;
 }
 
 // introspection used by bench.py: slots in flight and bytes of work space per slot

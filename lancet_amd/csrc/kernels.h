@@ -45,6 +45,8 @@ struct WinShared {
   int n_builds, final_k, status;
   int tmp0, tmp1, tmp2, tmp3;
   uint32_t part[LANCET_WG + 1];
+  unsigned long long t_last, phase_acc[16];
+  int phase_cur;
 };
 
 struct Ctx {
@@ -58,6 +60,13 @@ struct Ctx {
 };
 
 #define OVF(c) do { (c).S->overflow = 1; } while (0)
+
+// per-phase wall-clock accounting (lane 0; 100 MHz constant counter), read back through lancet_engine_phase_times
+#ifndef LANCET_WAVE_EMU
+#define PHASE(c, id) do { if (threadIdx.x == 0) { unsigned long long _t = wall_clock64(); (c).S->phase_acc[(c).S->phase_cur] += _t - (c).S->t_last; (c).S->t_last = _t; (c).S->phase_cur = (id); } } while (0)
+#else
+#define PHASE(c, id) ((void)0)
+#endif
 
 // Uniform read of a control word: barrier, everybody reads, barrier (so that the next writer cannot race a
 // slow reader).  Every branch that contains a WG_SYNC must be decided through this.
@@ -214,7 +223,7 @@ DEV void wg_scan(uint32_t *a, int n, volatile WinShared &S) {
   WG_FOR(l, LANCET_WG) {
     uint32_t s = 0;
     int lo = l * chunk, hi = lo + chunk; if (hi > n) hi = n;
-    for (int i = lo; i < hi; ++i) s += a[i];
+    for (int i = lo; i < hi; ++i) s += ld2(&a[i]);
     S.part[l] = s;
   }
   WG_SYNC();
@@ -223,7 +232,7 @@ DEV void wg_scan(uint32_t *a, int n, volatile WinShared &S) {
   WG_FOR(l, LANCET_WG) {
     uint32_t s = S.part[l];
     int lo = l * chunk, hi = lo + chunk; if (hi > n) hi = n;
-    for (int i = lo; i < hi; ++i) { uint32_t t = a[i]; a[i] = s; s += t; }
+    for (int i = lo; i < hi; ++i) { uint32_t t = ld2(&a[i]); a[i] = s; s += t; }
   }
   WG_SYNC();
 }
@@ -464,7 +473,7 @@ DEV void build_insert_pass(Ctx &c, bool verify) {
         uint32_t idx = (uint32_t)h & mask;
         uint32_t probes = 0;
         while (true) {
-          unsigned long long cur = W.tags[idx];
+          unsigned long long cur = ld2(&W.tags[idx]);
           if (cur == h) break;
           if (cur == 0) {
             unsigned long long old = dev_atomic_cas64(&W.tags[idx], 0ULL, h);
@@ -516,25 +525,27 @@ DEV void build_graph(Ctx &c) {
   WG_FOR(i, C.table_cap) { W.tags[i] = 0; W.slot_first[i] = LC_NIL; }
   WG_FOR(i, (int)(S.O / 32 + 2)) { W.bitmap[i] = 0; }
   WG_SYNC();
+  PHASE(c, 2);
   // ---- pass 1: canonical k-mers -> open-addressing slots
   switch (S.NW) { case 1: build_insert_pass<1>(c, false); break; case 2: build_insert_pass<2>(c, false); break;
                   case 3: build_insert_pass<3>(c, false); break; default: build_insert_pass<4>(c, false); break; }
   switch (S.NW) { case 1: build_insert_pass<1>(c, true); break; case 2: build_insert_pass<2>(c, true); break;
                   case 3: build_insert_pass<3>(c, true); break; default: build_insert_pass<4>(c, true); break; }
   if (wg_bcast(&S.overflow)) return;
+  PHASE(c, 3);
   // ---- dense node ids in first-insertion order (= order of first occurrence, Graph.cc:163-197)
-  WG_FOR(i, C.table_cap) { if (W.tags[i] != 0) { uint32_t f = W.slot_first[i]; dev_atomic_or(&W.bitmap[f >> 5], 1u << (f & 31)); } }
+  WG_FOR(i, C.table_cap) { if (ld2(&W.tags[i]) != 0) { uint32_t f = ld2(&W.slot_first[i]); dev_atomic_or(&W.bitmap[f >> 5], 1u << (f & 31)); } }
   WG_SYNC();
   int nwords = (int)(S.O / 32 + 1);
-  WG_FOR(i, nwords) { W.bitpre[i] = (uint32_t)dev_popc(W.bitmap[i]); }
+  WG_FOR(i, nwords) { W.bitpre[i] = (uint32_t)dev_popc(ld2(&W.bitmap[i])); }
   WG_SYNC();
   wg_scan(W.bitpre, nwords, S);
   WG_LANE0 { S.N = S.part[LANCET_WG]; if (S.N > C.node_cap) OVF(c); if (S.N > S.max_nodes) S.max_nodes = S.N; S.nspecial = 0; }
   if (wg_bcast(&S.overflow)) return;
   WG_FOR(i, C.table_cap) {
-    if (W.tags[i] != 0) {
-      uint32_t f = W.slot_first[i];
-      uint32_t id = W.bitpre[f >> 5] + (uint32_t)dev_popc(W.bitmap[f >> 5] & ((1u << (f & 31)) - 1u));
+    if (ld2(&W.tags[i]) != 0) {
+      uint32_t f = ld2(&W.slot_first[i]);
+      uint32_t id = W.bitpre[f >> 5] + (uint32_t)dev_popc(ld2(&W.bitmap[f >> 5]) & ((1u << (f & 31)) - 1u));
       W.slot_node[i] = id;
       for (int w = 0; w < S.NW; ++w) W.nkey[(size_t)id * LC_NWMAX + w] = W.slot_key[(size_t)i * LC_NWMAX + w];
     }
@@ -551,19 +562,22 @@ DEV void build_graph(Ctx &c) {
   }
   // reads whose opposite mate (same name) comes earlier in the window: only these can ever see
   // hasOverlappingMate()==true (reference src/Node.cc:638-661); everything else is counted directly.
+  // cand: 0 none, 1 exactly one such earlier read (its index in mate_of), 2 several (same name seen more than once)
   WG_FOR(r, S.R) {
-    uint8_t cd = 0;
+    uint8_t cd = 0; uint32_t mo = LC_NIL;
     if (r != S.R - 1) {
       uint32_t g0 = c.B->read_begin[S.w];
       uint32_t mi = RI_MATE(c.B->rinfo[g0 + r]);
       if (mi == 1 || mi == 2) {
         uint32_t nm = c.B->name_rank[g0 + r];
-        for (int q = 0; q < r; ++q) if (c.B->name_rank[g0 + q] == nm && RI_MATE(c.B->rinfo[g0 + q]) == 3 - mi) { cd = 1; break; }
+        for (int q = 0; q < r; ++q) if (c.B->name_rank[g0 + q] == nm && RI_MATE(c.B->rinfo[g0 + q]) == 3 - mi) { if (cd == 0) { cd = 1; mo = (uint32_t)q; } else { cd = 2; break; } }
       }
     }
-    W.cand[r] = cd;
+    W.cand[r] = cd; W.mate_of[r] = mo;
   }
+  WG_LANE0 { S.tmp1 = 0; }
   WG_SYNC();
+  PHASE(c, 4);
   // ---- pass 2: colours, coverage counters, edges, per-node occurrence counts
   WG_FOR(r, S.R) {
     uint32_t rinfo, bw, gw; int tlen; bool isref;
@@ -622,18 +636,44 @@ DEV void build_graph(Ctx &c) {
     }
   }
   WG_SYNC();
-  // ---- mate-overlap replay for candidate reads (sequential, rare): reproduces std::binary_search over the
-  //      unsorted vector of opposite-mate names pushed so far on the node.
+  // ---- mate-overlap filter (parallel): an occurrence of a candidate read can only be suppressed if the node also
+  //      holds an occurrence of its earlier opposite mate; everything else is counted here.  The few that remain go
+  //      to the exact replay below.  (slot_first is free by now and serves as the to-do list.)
+  WG_FOR(r, S.R - 1) {
+    if (!W.cand[r]) continue;
+    uint32_t g0 = c.B->read_begin[S.w];
+    uint32_t rinfo = c.B->rinfo[g0 + r];
+    int tlen = (int)RI_TLEN(rinfo);
+    if (tlen - K <= 0) continue;
+    uint32_t mi = RI_MATE(rinfo), nm = c.B->name_rank[g0 + r], mo = W.mate_of[r];
+    bool multi = W.cand[r] == 2;
+    int ctr = (RI_NML(rinfo) ? 2 : 0) + (RI_REV(rinfo) ? 1 : 0);
+    for (int p = 0; p < tlen - K + 1; ++p) {
+      uint32_t X = W.occ[W.occ_base[r] + p] & 0x7FFFFFFFu;
+      uint32_t lo = W.nocc[X], hi = W.nocc[X + 1], self = LC_NIL; bool hit = false;
+      for (uint32_t i = lo; i < hi; ++i) {
+        uint32_t e = W.csr[i];
+        uint32_t er = CS_READ(e);
+        if ((int)er == r) { if ((int)CS_POS(e) == p) self = i; continue; }
+        if (!multi) { if (er == mo) hit = true; }
+        else if ((int)er < r && (int)er != S.R - 1 && c.B->name_rank[g0 + er] == nm && RI_MATE(c.B->rinfo[g0 + er]) == 3 - mi) hit = true;
+      }
+      if (!hit) { dev_atomic_add(&W.ncnt[4 * X + ctr], 1u); uint32_t e = W.csr[self]; W.csr[self] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), 0u); }
+      else { uint32_t t = dev_atomic_add((uint32_t *)&S.tmp1, 1u); if (t < c.C->table_cap) W.slot_first[t] = ((uint32_t)r << 10) | (uint32_t)p; else OVF(c); }
+    }
+  }
+  WG_SYNC();
+  // ---- exact replay for what is left (sequential, rare): reproduces std::binary_search over the unsorted vector of
+  //      opposite-mate names pushed so far on the node.
   WG_LANE0 {
     uint32_t g0 = c.B->read_begin[S.w];
-    for (int r = 0; r < S.R - 1; ++r) {
-      if (!W.cand[r]) continue;
+    uint32_t ntodo = (uint32_t)S.tmp1; if (ntodo > c.C->table_cap) ntodo = c.C->table_cap;
+    for (uint32_t ti = 0; ti < ntodo; ++ti) {
+      int r = (int)(W.slot_first[ti] >> 10), p = (int)(W.slot_first[ti] & 1023u);
       uint32_t rinfo = c.B->rinfo[g0 + r];
-      int tlen = (int)RI_TLEN(rinfo);
-      if (tlen - K <= 0) continue;
       uint32_t mi = RI_MATE(rinfo), nm = c.B->name_rank[g0 + r];
       int ctr = (RI_NML(rinfo) ? 2 : 0) + (RI_REV(rinfo) ? 1 : 0);
-      for (int p = 0; p < tlen - K + 1; ++p) {
+      {
         uint32_t X = W.occ[W.occ_base[r] + p] & 0x7FFFFFFFu;
         uint32_t lo = W.nocc[X], hi = W.nocc[X + 1];
         // gather pushes of the other mate from earlier reads, ordered by (read, position)
@@ -661,24 +701,25 @@ DEV void build_graph(Ctx &c) {
         while (len > 0) { uint32_t half = len >> 1; uint32_t mid = first + half; if (elem(mid) < nm) { first = mid + 1; len = len - half - 1; } else len = half; }
         bool ovl = (first != total) && !(nm < elem(first));
         uint32_t e = W.csr[self];
-        if (!ovl) { W.ncnt[4 * X + ctr] += 1; W.csr[self] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), 0u); }
+        if (!ovl) { W.ncnt[4 * X + ctr] = ld2(&W.ncnt[4 * X + ctr]) + 1; W.csr[self] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), 0u); }
         else W.csr[self] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), 2u);
       }
     }
     S.seq_top = 0; S.qv_top = 0;
   }
   WG_SYNC();
+  PHASE(c, 5);
   // ---- per node: edges in first-seen order, float coverages, minimum coverages; first removeLowCov predicate
   //      (reference src/Graph.cc:2790-2827 with docompression=false, compid=0) evaluated in the same pass.
   const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
   WG_FOR(n, S.N) {
     uint32_t stamp[8]; uint32_t tgt[8]; int ne = 0;
-    for (int j = 0; j < 8; ++j) if (W.efirst[8 * n + j] != LC_NIL) { stamp[ne] = W.efirst[8 * n + j]; tgt[ne] = W.eto[8 * n + j]; ++ne; }
+    for (int j = 0; j < 8; ++j) { uint32_t ef = ld2(&W.efirst[8 * n + j]); if (ef != LC_NIL) { stamp[ne] = ef; tgt[ne] = W.eto[8 * n + j]; ++ne; } }
     for (int i = 1; i < ne; ++i) { uint32_t s = stamp[i], t = tgt[i]; int j = i; while (j > 0 && stamp[j - 1] > s) { stamp[j] = stamp[j - 1]; tgt[j] = tgt[j - 1]; --j; } stamp[j] = s; tgt[j] = t; }
     for (int i = 0; i < ne; ++i) W.edges[n * LC_EMAX + i] = tgt[i];
     W.necnt[n] = ne;
-    const uint32_t *cn = W.ncnt + 4 * n;
-    for (int j = 0; j < 4; ++j) W.ncov[4 * n + j] = (float)cn[j];
+    uint32_t cn[4];
+    for (int j = 0; j < 4; ++j) { cn[j] = ld2(&W.ncnt[4 * n + j]); W.ncov[4 * n + j] = (float)cn[j]; }
     int tot = (int)(uint16_t)cn[0] + (int)(uint16_t)cn[1] + (int)(uint16_t)cn[2] + (int)(uint16_t)cn[3];
     // min over the K positions of the number of counted reads whose base there passes MIN_QUAL_CALL
     int minqv = 10000000;
@@ -716,11 +757,11 @@ DEV void build_graph(Ctx &c) {
     WG_FOR(i, S.reflen - K > 0 ? S.reflen - K : 0) {       // i + K < rawseq.length()
       uint32_t X = W.occ[ro + i] & 0x7FFFFFFFu;
       uint16_t v[4] = {0, 0, 0, 0};
-      if (W.nflags[X] & NF_INMER) for (int q = 0; q < 4; ++q) v[q] = (uint16_t)W.ncnt[4 * X + q];
+      if (ld2(&W.nflags[X]) & NF_INMER) for (int q = 0; q < 4; ++q) v[q] = (uint16_t)ld2(&W.ncnt[4 * X + q]);
       if (i == 0) { for (int j = 0; j < K; ++j) for (int q = 0; q < 4; ++q) W.refcov[4 * j + q] = v[q]; }
       else { for (int q = 0; q < 4; ++q) W.refcov[4 * (i + K - 1) + q] = v[q]; }
     }
-    WG_SYNC();
+    WG_SYNC_FENCE();   // from here on the node arrays are only touched with plain loads/stores: one L1 invalidate
   }
 }
 
@@ -1571,7 +1612,9 @@ DEV void process_window(Ctx &c, int w) {
   if (wg_bcast(&S.tmp0) <= 0) { WG_LANE0 { S.status = LANCET_W_NO_READS; } WG_SYNC(); return; }     // Microassembler.cc:83
   if (wg_bcast(&S.overflow)) { WG_LANE0 { S.status = LANCET_W_OVERFLOW; } WG_SYNC(); return; }
   const int reflen = wg_bcast(&S.reflen);
+  PHASE(c, 1);
   repeat_scan(B.ref_codes + B.ref_off[w], reflen, c.P->max_mismatch, &S.repE, &S.repM);
+  PHASE(c, 0);
   const int refE = wg_bcast(&S.repE), refM = wg_bcast(&S.repM);
   int rptInRef = 0, rptInQry = 0, cycleInGraph = 0;
   bool processed = false;
@@ -1584,10 +1627,13 @@ DEV void process_window(Ctx &c, int w) {
     if (wg_bcast(&S.overflow)) break;
     build_graph(c);
     if (wg_bcast(&S.overflow)) break;
+    PHASE(c, 6);
     materialize_survivors(c);
     if (wg_bcast(&S.overflow)) break;
+    PHASE(c, 7);
     first_lowcov(c);
     if (wg_bcast(&S.overflow)) break;
+    PHASE(c, 8);
     // ---- everything below is the (small) cleaned graph
     WG_LANE0 {
       evt(c, EV_READS, (uint32_t)S.R, (uint32_t)S.reflen, (uint32_t)S.totalreadbp);
@@ -1617,6 +1663,7 @@ DEV void process_window(Ctx &c, int w) {
     }
     int numcomp = wg_bcast(&S.numcomp);
     bool brk = false;
+    PHASE(c, 9);
     for (int comp = 1; comp <= numcomp; ++comp) {
       WG_LANE0 {
         print_stats(c, comp);
@@ -1634,11 +1681,15 @@ DEV void process_window(Ctx &c, int w) {
       }
       if (wg_bcast(&S.overflow)) break;
       if (wg_bcast(&S.tmp0)) { cycleInGraph = 1; brk = true; break; }
+      PHASE(c, 10);
       if (repeats_in_graph_paths(c)) { rptInQry = 1; brk = true; break; }
+      PHASE(c, 11);
       if (wg_bcast(&S.overflow)) break;
       count_ref_path(c);
+      PHASE(c, 9);
       if (wg_bcast(&S.overflow)) break;
     }
+    PHASE(c, 0);
     if (wg_bcast(&S.overflow)) break;
     if (brk) continue;
     processed = true;
@@ -1658,11 +1709,16 @@ DEV void window_kernel_body(const lancet_params *P, const DevBatch *B, const Eng
     WG_LANE0 { S->tmp3 = (int)dev_atomic_add(OUT->queue_head, 1u); }
     int w = wg_bcast(&S->tmp3);
     if (w >= B->n_windows) break;
+#ifndef LANCET_WAVE_EMU
+    if (threadIdx.x == 0) { for (int i = 0; i < 16; ++i) S->phase_acc[i] = 0; S->phase_cur = 0; S->t_last = wall_clock64(); }
+#endif
     process_window(c, w);
+    PHASE(c, 0);
     WG_LANE0 {
       lancet_window_stats &st = OUT->stats[w];
       st.status = S->status; st.final_k = S->final_k; st.n_builds = S->n_builds; st.n_variants = S->emit_seq;
       st.n_kmers = S->n_kmers; st.max_nodes = S->max_nodes; st.reserved = 0;
+      if (OUT->phase) for (int i = 0; i < 16; ++i) OUT->phase[(size_t)w * 16 + i] = S->phase_acc[i];
       if (C->evt_cap) { OUT->evt_len[w] = S->evt_len; for (uint32_t i = 0; i < S->evt_len; ++i) OUT->evt_out[(size_t)w * C->evt_cap + i] = c.W->evt[i]; }
     }
     WG_SYNC();

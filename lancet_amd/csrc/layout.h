@@ -97,6 +97,7 @@ struct Work {
   /* ---- build ---- */
   uint32_t *occ_base;     /* [reads_cap+1] first occurrence index of each read                 */
   uint8_t *cand;          /* [reads_cap]   read has an earlier opposite mate of the same name  */
+  uint32_t *mate_of;      /* [reads_cap]   index of that earlier mate (when unique)            */
   uint32_t *occ;          /* [occ_cap]     slot (then node) | ori<<31                           */
   unsigned long long *tags;     /* [table_cap]                                               */
   unsigned long long *slot_key; /* [table_cap * LC_NWMAX]                                    */
@@ -157,4 +158,5 @@ struct DevOut {
   uint32_t *queue_head;   /* atomic window queue */
   uint32_t *evt_len;      /* [n_windows] words used in the window's trace (slot evt copied out)  */
   uint32_t *evt_out;      /* [n_windows * evt_cap] */
+  unsigned long long *phase; /* [n_windows * 16] per-phase time (100 MHz ticks), may be null */
 };

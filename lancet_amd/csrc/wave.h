@@ -20,10 +20,13 @@
 #define WG_FOR(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += (int)blockDim.x)
 // Agent-scope fence before the barrier: the phases communicate through HBM with a mix of atomics (performed
 // at L2) and plain loads (which may hit the CU's vector L1), so the L1 has to be invalidated at phase boundaries.
-#define WG_SYNC() do { __threadfence(); __syncthreads(); } while (0)
+#define WG_SYNC() __syncthreads()
+// Used at the phase boundaries of the table build, where atomics (executed at L2) are followed by plain loads of the
+// same words (which may hit the vector L1): agent-scope fence = L1 invalidate.
+#define WG_SYNC_FENCE() do { __threadfence(); __syncthreads(); } while (0)
 // lane-0 predicate, opaque to the optimiser (two consecutive lane-0 sections must not be merged or threaded)
 DEV bool wg_is_lane0() { uint32_t t = threadIdx.x; asm volatile("" : "+v"(t)); return t == 0; }
-DEV void wg_sync_fn() { __threadfence(); __syncthreads(); }
+DEV void wg_sync_fn() { __syncthreads(); }
 // every lane-0 section is followed by a barrier executed by all lanes
 #define WG_LANE0 for (int _wg_once = 1; _wg_once; _wg_once = 0, wg_sync_fn()) if (wg_is_lane0())
 #define WG_SHARED __shared__
@@ -34,6 +37,9 @@ DEV uint32_t dev_atomic_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 DEV unsigned long long dev_atomic_cas64(unsigned long long *p, unsigned long long cmp, unsigned long long v) {
   return atomicCAS(p, cmp, v);
 }
+// load that bypasses the CU's vector L1 (performed at L2): for words that other lanes updated with atomics
+DEV uint32_t ld2(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV unsigned long long ld2(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV int dev_popc(uint32_t x) { return __popc(x); }
 DEV int dev_popcll(unsigned long long x) { return __popcll(x); }
 #else
@@ -43,6 +49,7 @@ DEV int dev_popcll(unsigned long long x) { return __popcll(x); }
 #define DEVNI static
 #define WG_FOR(i, n) for (int i = 0; i < (int)(n); ++i)
 #define WG_SYNC() ((void)0)
+#define WG_SYNC_FENCE() ((void)0)
 #define WG_LANE0 if (true)
 #define WG_SHARED static thread_local
 DEV uint32_t dev_atomic_min(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
@@ -52,6 +59,8 @@ DEV uint32_t dev_atomic_or(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | 
 DEV unsigned long long dev_atomic_cas64(unsigned long long *p, unsigned long long cmp, unsigned long long v) {
   unsigned long long o = *p; if (o == cmp) *p = v; return o;
 }
+DEV uint32_t ld2(const uint32_t *p) { return *p; }
+DEV unsigned long long ld2(const unsigned long long *p) { return *p; }
 DEV int dev_popc(uint32_t x) { return __builtin_popcount(x); }
 DEV int dev_popcll(unsigned long long x) { return __builtin_popcountll(x); }
 #endif

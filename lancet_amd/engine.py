@@ -45,6 +45,7 @@ def lib():
         L.lancet_engine_trace.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32)]
         L.lancet_engine_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
         L.lancet_debug_align.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        L.lancet_engine_phase_times.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64))]
         L.lancet_filters_default.argtypes = [C.POINTER(abi.LancetFilters)]
         L.lancet_vdb_create.restype = C.c_void_p
         L.lancet_vdb_create.argtypes = [C.POINTER(abi.LancetFilters)]
@@ -133,6 +134,12 @@ class Engine:
             end = int(b.ref_start[w]) + int(b.ref_off[w + 1] - b.ref_off[w])
             parts.append(_trace.format_window(words, w + 1, b.hdr[w], b.chrom[w], int(b.ref_start[w]), end))
         return "".join(parts)
+
+    def phase_times(self):
+        """[n_windows, 16] array of per-phase times in seconds (profiling aid)."""
+        p = C.POINTER(C.c_uint64)()
+        self._chk(self.L.lancet_engine_phase_times(self.h, C.byref(p)))
+        return np.ctypeslib.as_array(p, shape=(self._batch.n_windows, 16)).astype(np.float64) * 1e-8
 
     def debug_align(self, s: str, t: str):
         """Test hook: the device global_align_aff on one pair of strings."""
