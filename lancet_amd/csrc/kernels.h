@@ -468,9 +468,13 @@ DEV void build_insert_pass(Ctx &c, bool verify) {
       const unsigned long long *ck = isF ? fw : rc;
       if (!verify) {
         unsigned long long h = 0;
-        for (int w = 0; w < NW; ++w) h = mix64(h ^ (ck[w] + 0x9e3779b97f4a7c15ULL * (unsigned long long)(w + 1)));
-        if (h == 0) h = 1;
-        uint32_t idx = (uint32_t)h & mask;
+        uint32_t idx;
+        if (NW == 1 && K <= 31) { h = ck[0] + 1ULL; idx = (uint32_t)mix64(h) & mask; }       // tag == key: exact, no verify pass
+        else {
+          for (int w = 0; w < NW; ++w) h = mix64(h ^ (ck[w] + 0x9e3779b97f4a7c15ULL * (unsigned long long)(w + 1)));
+          if (h == 0) h = 1;
+          idx = (uint32_t)h & mask;
+        }
         uint32_t probes = 0;
         while (true) {
           unsigned long long cur = ld2(&W.tags[idx]);
@@ -486,7 +490,7 @@ DEV void build_insert_pass(Ctx &c, bool verify) {
         dev_atomic_min(&W.slot_first[idx], o);
         W.occ[o] = idx | (isF ? 0u : 0x80000000u);
       } else {
-        uint32_t idx = W.occ[o] & 0x7FFFFFFFu;
+        uint32_t idx = W.occ[o] & 0x3FFFFFFFu;
         for (int w = 0; w < NW; ++w) if (W.slot_key[(size_t)idx * LC_NWMAX + w] != ck[w]) OVF(c);   // 64-bit tag collision
       }
       ++o;
@@ -529,8 +533,10 @@ DEV void build_graph(Ctx &c) {
   // ---- pass 1: canonical k-mers -> open-addressing slots
   switch (S.NW) { case 1: build_insert_pass<1>(c, false); break; case 2: build_insert_pass<2>(c, false); break;
                   case 3: build_insert_pass<3>(c, false); break; default: build_insert_pass<4>(c, false); break; }
-  switch (S.NW) { case 1: build_insert_pass<1>(c, true); break; case 2: build_insert_pass<2>(c, true); break;
-                  case 3: build_insert_pass<3>(c, true); break; default: build_insert_pass<4>(c, true); break; }
+  if (K > 31) {   // 64-bit tags of longer keys can collide: compare the full keys
+    switch (S.NW) { case 1: build_insert_pass<1>(c, true); break; case 2: build_insert_pass<2>(c, true); break;
+                    case 3: build_insert_pass<3>(c, true); break; default: build_insert_pass<4>(c, true); break; }
+  }
   if (wg_bcast(&S.overflow)) return;
   PHASE(c, 3);
   // ---- dense node ids in first-insertion order (= order of first occurrence, Graph.cc:163-197)
@@ -578,6 +584,46 @@ DEV void build_graph(Ctx &c) {
   WG_LANE0 { S.tmp1 = 0; }
   WG_SYNC();
   PHASE(c, 4);
+  // ---- mate-overlap prefilter: an occurrence of a candidate read can only be suppressed if the node also holds an
+  //      occurrence of its earlier opposite mate.  Node ids of the mate go into a small private open-addressing set;
+  //      own k-mers that hit it get bit 30 in occ[] and are decided by the exact replay after the csr is built.
+  WG_FOR(r, S.R - 1) {
+    if (!W.cand[r]) continue;
+    uint32_t g0 = c.B->read_begin[S.w];
+    int tlen = (int)RI_TLEN(c.B->rinfo[g0 + r]);
+    if (tlen - K <= 0) continue;
+    uint32_t o0 = W.occ_base[r];
+    int nk = tlen - K + 1;
+    bool all = W.cand[r] == 2;
+    uint32_t set[256];
+    if (!all) {
+      uint32_t mo = W.mate_of[r];
+      int mtl = (int)RI_TLEN(c.B->rinfo[g0 + mo]);
+      int mnk = mtl - K > 0 ? mtl - K + 1 : 0;
+      if (mnk > 150) all = true;
+      else {
+        for (int i = 0; i < 256; ++i) set[i] = 0;
+        uint32_t m0 = W.occ_base[mo];
+        for (int j = 0; j < mnk; ++j) {
+          uint32_t id = W.slot_node[W.occ[m0 + j] & 0x3FFFFFFFu] + 1u;
+          uint32_t h = (id * 2654435761u) >> 24;
+          while (set[h] != 0 && set[h] != id) h = (h + 1) & 255u;
+          set[h] = id;
+        }
+      }
+    }
+    for (int p = 0; p < nk; ++p) {
+      uint32_t oc = W.occ[o0 + p];
+      bool hit = all;
+      if (!all) {
+        uint32_t id = W.slot_node[oc & 0x3FFFFFFFu] + 1u;
+        uint32_t h = (id * 2654435761u) >> 24;
+        while (set[h] != 0) { if (set[h] == id) { hit = true; break; } h = (h + 1) & 255u; }
+      }
+      if (hit) W.occ[o0 + p] = oc | 0x40000000u;
+    }
+  }
+  WG_SYNC();
   // ---- pass 2: colours, coverage counters, edges, per-node occurrence counts
   WG_FOR(r, S.R) {
     uint32_t rinfo, bw, gw; int tlen; bool isref;
@@ -586,11 +632,11 @@ DEV void build_graph(Ctx &c) {
     uint32_t o0 = W.occ_base[r];
     int nk = tlen - K + 1;
     int ctr = isref ? -1 : ((RI_NML(rinfo) ? 2 : 0) + (RI_REV(rinfo) ? 1 : 0));
-    bool cd = W.cand[r] != 0;
     uint32_t prevnode = 0; uint32_t prevori = 0;
     for (int p = 0; p < nk; ++p) {
       uint32_t oc = W.occ[o0 + p];
-      uint32_t X = W.slot_node[oc & 0x7FFFFFFFu], ori = oc >> 31;
+      uint32_t X = W.slot_node[oc & 0x3FFFFFFFu], ori = oc >> 31;
+      bool cd = (oc & 0x40000000u) != 0;       // needs the exact mate-overlap replay
       uint32_t fl = 0;
       if (!isref) {
         if (RI_NML(rinfo)) fl |= NF_NORMAL;
@@ -598,6 +644,7 @@ DEV void build_graph(Ctx &c) {
       }
       if (fl) dev_atomic_or(&W.nflags[X], fl);
       if (ctr >= 0 && !cd) dev_atomic_add(&W.ncnt[4 * X + ctr], 1u);
+      if (cd) { uint32_t t = dev_atomic_add((uint32_t *)&S.tmp1, 1u); if (t < c.C->table_cap) W.slot_first[t] = ((uint32_t)r << 10) | (uint32_t)p; else OVF(c); }
       dev_atomic_add(&W.nocc[X], 1u);
       if (p > 0) {   // step (p-1): u = prev, v = X   (Graph.cc:320-347)
         uint32_t fdir = (prevori == 0) ? (ori == 0 ? 0u : 1u) : (ori == 0 ? 2u : 3u);     // FF FR RF RR
@@ -613,7 +660,7 @@ DEV void build_graph(Ctx &c) {
         W.eto[8 * X + sv] = ED_MAKE(prevnode, rdir);
         dev_atomic_min(&W.efirst[8 * X + sv], stamp + 1u);
       }
-      W.occ[o0 + p] = X | (ori << 31);
+      W.occ[o0 + p] = X | (ori << 31) | (cd ? 0x40000000u : 0u);
       prevnode = X; prevori = ori;
     }
   }
@@ -627,39 +674,12 @@ DEV void build_graph(Ctx &c) {
     read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref);
     if (tlen - K <= 0) continue;
     uint32_t o0 = W.occ_base[r];
-    uint32_t st = isref ? 2u : (W.cand[r] ? 1u : 0u);     // the reference read never counts (Graph.cc:265)
     for (int p = 0; p < tlen - K + 1; ++p) {
       uint32_t oc = W.occ[o0 + p];
-      uint32_t X = oc & 0x7FFFFFFFu;
+      uint32_t X = oc & 0x3FFFFFFFu;
+      uint32_t st = isref ? 2u : ((oc & 0x40000000u) ? 1u : 0u);     // the reference read never counts (Graph.cc:265)
       uint32_t at = W.nocc[X] + dev_atomic_add(&W.nfill[X], 1u);
       W.csr[at] = CS_MAKE(r, p, oc >> 31, st);
-    }
-  }
-  WG_SYNC();
-  // ---- mate-overlap filter (parallel): an occurrence of a candidate read can only be suppressed if the node also
-  //      holds an occurrence of its earlier opposite mate; everything else is counted here.  The few that remain go
-  //      to the exact replay below.  (slot_first is free by now and serves as the to-do list.)
-  WG_FOR(r, S.R - 1) {
-    if (!W.cand[r]) continue;
-    uint32_t g0 = c.B->read_begin[S.w];
-    uint32_t rinfo = c.B->rinfo[g0 + r];
-    int tlen = (int)RI_TLEN(rinfo);
-    if (tlen - K <= 0) continue;
-    uint32_t mi = RI_MATE(rinfo), nm = c.B->name_rank[g0 + r], mo = W.mate_of[r];
-    bool multi = W.cand[r] == 2;
-    int ctr = (RI_NML(rinfo) ? 2 : 0) + (RI_REV(rinfo) ? 1 : 0);
-    for (int p = 0; p < tlen - K + 1; ++p) {
-      uint32_t X = W.occ[W.occ_base[r] + p] & 0x7FFFFFFFu;
-      uint32_t lo = W.nocc[X], hi = W.nocc[X + 1], self = LC_NIL; bool hit = false;
-      for (uint32_t i = lo; i < hi; ++i) {
-        uint32_t e = W.csr[i];
-        uint32_t er = CS_READ(e);
-        if ((int)er == r) { if ((int)CS_POS(e) == p) self = i; continue; }
-        if (!multi) { if (er == mo) hit = true; }
-        else if ((int)er < r && (int)er != S.R - 1 && c.B->name_rank[g0 + er] == nm && RI_MATE(c.B->rinfo[g0 + er]) == 3 - mi) hit = true;
-      }
-      if (!hit) { dev_atomic_add(&W.ncnt[4 * X + ctr], 1u); uint32_t e = W.csr[self]; W.csr[self] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), 0u); }
-      else { uint32_t t = dev_atomic_add((uint32_t *)&S.tmp1, 1u); if (t < c.C->table_cap) W.slot_first[t] = ((uint32_t)r << 10) | (uint32_t)p; else OVF(c); }
     }
   }
   WG_SYNC();
@@ -674,7 +694,7 @@ DEV void build_graph(Ctx &c) {
       uint32_t mi = RI_MATE(rinfo), nm = c.B->name_rank[g0 + r];
       int ctr = (RI_NML(rinfo) ? 2 : 0) + (RI_REV(rinfo) ? 1 : 0);
       {
-        uint32_t X = W.occ[W.occ_base[r] + p] & 0x7FFFFFFFu;
+        uint32_t X = W.occ[W.occ_base[r] + p] & 0x3FFFFFFFu;
         uint32_t lo = W.nocc[X], hi = W.nocc[X + 1];
         // gather pushes of the other mate from earlier reads, ordered by (read, position)
         uint32_t *buf = W.scratch; uint32_t m = 0; uint32_t self = LC_NIL;
@@ -721,25 +741,59 @@ DEV void build_graph(Ctx &c) {
     uint32_t cn[4];
     for (int j = 0; j < 4; ++j) { cn[j] = ld2(&W.ncnt[4 * n + j]); W.ncov[4 * n + j] = (float)cn[j]; }
     int tot = (int)(uint16_t)cn[0] + (int)(uint16_t)cn[1] + (int)(uint16_t)cn[2] + (int)(uint16_t)cn[3];
-    // min over the K positions of the number of counted reads whose base there passes MIN_QUAL_CALL
-    int minqv = 10000000;
+    // per position of the k-mer: number of counted reads whose base there passes MIN_QUAL_CALL, per strand/sample
+    // (Node_t::updateCovDistr minqv_fwd/minqv_rev, reference src/Node.cc:470-497).  One pass over the node's
+    // occurrences; the K quality bits of an occurrence are pulled out of the read's bit mask 32 at a time.
+    uint16_t pc[4 * 128];
+    for (int i = 0; i < 4 * K; ++i) pc[i] = 0;
     uint32_t lo = W.nocc[n], hi = W.nocc[n + 1];
-    for (int i = 0; i < K; ++i) {
-      int s = 0;
-      for (uint32_t q = lo; q < hi; ++q) {
-        uint32_t e = W.csr[q];
-        if (CS_ST(e) != 0) continue;
-        uint32_t g = c.B->read_begin[S.w] + CS_READ(e);
-        int pos = (int)CS_POS(e) + (CS_ORI(e) ? (K - 1 - i) : i);
-        s += rd_good(c.B->good, c.B->good_woff[g], pos);
+    const uint32_t g0 = c.B->read_begin[S.w];
+    for (uint32_t q = lo; q < hi; ++q) {
+      uint32_t e = W.csr[q];
+      if (CS_ST(e) != 0) continue;
+      uint32_t g = g0 + CS_READ(e);
+      uint32_t ri = c.B->rinfo[g];
+      int cls = (RI_NML(ri) ? 2 : 0) + (RI_REV(ri) ? 1 : 0);
+      uint32_t gw = c.B->good_woff[g];
+      int p0 = (int)CS_POS(e); bool rev = CS_ORI(e) != 0;
+      for (int i0 = 0; i0 < K; i0 += 32) {
+        int take = K - i0 < 32 ? K - i0 : 32;
+        int st = p0 + i0, wv = st >> 5, sh = st & 31;
+        uint32_t bits = c.B->good[gw + wv] >> sh;
+        if (sh + take > 32) bits |= c.B->good[gw + wv + 1] << (32 - sh);
+        if (take < 32) bits &= (1u << take) - 1u;
+        while (bits) {
+          int bpos = __builtin_ctz(bits); bits &= bits - 1;
+          int pos = rev ? (K - 1 - (i0 + bpos)) : (i0 + bpos);
+          pc[cls * K + pos]++;
+        }
       }
-      if (s < minqv) minqv = s;
     }
+    int minqv = 10000000;
+    for (int i = 0; i < K; ++i) { int sq = (int)pc[i] + (int)pc[K + i] + (int)pc[2 * K + i] + (int)pc[3 * K + i]; if (sq < minqv) minqv = sq; }
     W.nmincov[n] = tot; W.nmincovqv[n] = minqv;
     float tt = W.ncov[4 * n] + W.ncov[4 * n + 1], tn = W.ncov[4 * n + 2] + W.ncov[4 * n + 3];
     bool low = (minqv <= c.P->low_cov_threshold) || ((double)minqv <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
-    if (!low) dev_atomic_or(&W.nflags[n], NF_SURV);
+    if (!low) {
+      // survivor of the first removeLowCov: keep the per-position counts and start its sequence-descriptor deque
+      uint32_t qi = dev_atomic_add((uint32_t *)&S.qv_top, 1u);
+      if (qi >= c.C->surv_cap || ((size_t)qi + 1) * (size_t)K > (size_t)c.C->seq_cap) { OVF(c); }
+      else {
+        uint16_t *qq = W.qv + (size_t)qi * K * 4;
+        for (int i = 0; i < K; ++i) { qq[4 * i] = pc[i]; qq[4 * i + 1] = pc[K + i]; qq[4 * i + 2] = pc[2 * K + i]; qq[4 * i + 3] = pc[3 * K + i]; }
+        uint32_t base = qi * (uint32_t)K;
+        const unsigned long long *kk = W.nkey + (size_t)n * LC_NWMAX;
+        for (int i = 0; i < K; ++i) W.seq[base + i] = SD_MAKE(n, i, key_base(kk, K, i));
+        W.nseq_clo[n] = base; W.nseq_lo[n] = base; W.nseq_hi[n] = base + K; W.nseq_chi[n] = base + K;
+        uint32_t fl = ld2(&W.nflags[n]);
+        W.nkmT[n] = ((fl & NF_TUMOR) && !(fl & NF_NORMAL)) ? 1u : 0u;      // cov_status == 'T'
+        W.nqv[n] = qi;
+        dev_atomic_or(&W.nflags[n], NF_SURV);
+      }
+    }
   }
+  WG_SYNC();
+  WG_LANE0 { S.seq_top = S.qv_top * (uint32_t)K; }
   WG_SYNC();
   // ---- Ref_t::mertable membership (indexMers over the possibly trimmed seq, reference src/Ref.cc:40-64)
   {
@@ -748,14 +802,14 @@ DEV void build_graph(Ctx &c) {
     bool loaded = (S.reflen - K > 0);
     WG_FOR(i, S.seq_len - K > 0 ? S.seq_len - K : 0) {     // i + K < seq.length()
       int p = S.seq_t5 + i;
-      if (loaded && p < nrefk) dev_atomic_or(&W.nflags[W.occ[ro + p] & 0x7FFFFFFFu], NF_INMER);
+      if (loaded && p < nrefk) dev_atomic_or(&W.nflags[W.occ[ro + p] & 0x3FFFFFFFu], NF_INMER);
     }
     WG_SYNC();
     // ---- Ref_t::computeCoverage (reference src/Ref.cc:173-250): per rawseq position, Tf Tr Nf Nr
     WG_FOR(j, S.reflen) { for (int q = 0; q < 4; ++q) W.refcov[4 * j + q] = 0; }
     WG_SYNC();
     WG_FOR(i, S.reflen - K > 0 ? S.reflen - K : 0) {       // i + K < rawseq.length()
-      uint32_t X = W.occ[ro + i] & 0x7FFFFFFFu;
+      uint32_t X = W.occ[ro + i] & 0x3FFFFFFFu;
       uint16_t v[4] = {0, 0, 0, 0};
       if (ld2(&W.nflags[X]) & NF_INMER) for (int q = 0; q < 4; ++q) v[q] = (uint16_t)ld2(&W.ncnt[4 * X + q]);
       if (i == 0) { for (int j = 0; j < K; ++j) for (int q = 0; q < 4; ++q) W.refcov[4 * j + q] = v[q]; }
@@ -763,46 +817,6 @@ DEV void build_graph(Ctx &c) {
     }
     WG_SYNC_FENCE();   // from here on the node arrays are only touched with plain loads/stores: one L1 invalidate
   }
-}
-
-// per-position quality counts + sequence descriptors for the nodes that survive the first filter
-DEV void materialize_survivors(Ctx &c) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
-  const int K = S.K;
-  WG_LANE0 {
-    uint32_t ns = 0;
-    for (uint32_t n = 0; n < S.N; ++n) if (W.nflags[n] & NF_SURV) { W.nqv[n] = ns++; }
-    if (ns > c.C->surv_cap || (size_t)ns * K > (size_t)c.C->seq_cap) OVF(c);
-    S.tmp0 = (int)ns;
-  }
-  if (wg_bcast(&S.overflow)) return;
-  WG_FOR(n, S.N) {
-    if (!(W.nflags[n] & NF_SURV)) continue;
-    uint32_t q = W.nqv[n];
-    uint32_t lo = W.nocc[n], hi = W.nocc[n + 1];
-    for (int i = 0; i < K; ++i) {
-      uint16_t s[4] = {0, 0, 0, 0};
-      for (uint32_t x = lo; x < hi; ++x) {
-        uint32_t e = W.csr[x];
-        if (CS_ST(e) != 0) continue;
-        uint32_t g = c.B->read_begin[S.w] + CS_READ(e);
-        uint32_t ri = c.B->rinfo[g];
-        int pos = (int)CS_POS(e) + (CS_ORI(e) ? (K - 1 - i) : i);
-        if (rd_good(c.B->good, c.B->good_woff[g], pos)) s[(RI_NML(ri) ? 2 : 0) + (RI_REV(ri) ? 1 : 0)]++;
-      }
-      uint16_t *qq = W.qv + ((size_t)q * K + i) * 4;
-      qq[0] = s[0]; qq[1] = s[1]; qq[2] = s[2]; qq[3] = s[3];
-    }
-    // descriptor deque: K entries, no slack yet (grown on first merge)
-    uint32_t base = q * (uint32_t)K;
-    const unsigned long long *k = W.nkey + (size_t)n * LC_NWMAX;
-    for (int i = 0; i < K; ++i) W.seq[base + i] = SD_MAKE(n, i, key_base(k, K, i));
-    W.nseq_clo[n] = base; W.nseq_lo[n] = base; W.nseq_hi[n] = base + K; W.nseq_chi[n] = base + K;
-    uint32_t fl = W.nflags[n];
-    W.nkmT[n] = ((fl & NF_TUMOR) && !(fl & NF_NORMAL)) ? 1u : 0u;      // cov_status == 'T'
-  }
-  WG_LANE0 { S.seq_top = (uint32_t)S.tmp0 * (uint32_t)K; }
-  WG_SYNC();
 }
 
 // first removeLowCov(false, 0) + cleanDead; markRefNodes counters for the trace
@@ -1077,7 +1091,7 @@ DEVNI void mark_ref_ends(Ctx &c, int comp) {
   uint32_t src = LC_NIL, snk = LC_NIL; uint32_t src_ori = 0, snk_ori = 0; int src_off = -1, snk_off = -1;
   bool amb = false;
   for (int off = 0; off < nrefk; ++off) {
-    uint32_t oc = W.occ[ro + off]; uint32_t t = oc & 0x7FFFFFFFu;
+    uint32_t oc = W.occ[ro + off]; uint32_t t = oc & 0x3FFFFFFFu;
     if ((W.nflags[t] & NF_DEAD) || !(W.nflags[t] & NF_SURV)) continue;
     if (n_totcov(c, t) >= (float)c.P->cov_threshold && W.ncomp[t] == comp) {
       if (src == LC_NIL) { src = t; src_ori = oc >> 31; src_off = off; }
@@ -1088,7 +1102,7 @@ DEVNI void mark_ref_ends(Ctx &c, int comp) {
   if (src == LC_NIL) { evt(c, EV_NOMATCH_SRC); return; }
   for (int off = S.reflen - K; off >= 0; --off) {
     if (off >= nrefk) continue;
-    uint32_t oc = W.occ[ro + off]; uint32_t t = oc & 0x7FFFFFFFu;
+    uint32_t oc = W.occ[ro + off]; uint32_t t = oc & 0x3FFFFFFFu;
     if ((W.nflags[t] & NF_DEAD) || !(W.nflags[t] & NF_SURV)) continue;
     if (n_totcov(c, t) >= (float)c.P->cov_threshold && W.ncomp[t] == comp) {
       if (snk == LC_NIL) { snk = t; snk_ori = oc >> 31; snk_off = off; }
@@ -1626,9 +1640,6 @@ DEV void process_window(Ctx &c, int w) {
     WG_LANE0 { S.K = k; S.NW = (2 * k + 63) / 64; S.final_k = k; S.source = LC_NIL; S.sink = LC_NIL; if (k > 127 || S.NW > LC_NWMAX) S.overflow = 1; }
     if (wg_bcast(&S.overflow)) break;
     build_graph(c);
-    if (wg_bcast(&S.overflow)) break;
-    PHASE(c, 6);
-    materialize_survivors(c);
     if (wg_bcast(&S.overflow)) break;
     PHASE(c, 7);
     first_lowcov(c);

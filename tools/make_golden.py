@@ -45,6 +45,9 @@ CASES = {
     "err_hi": (dict(ref_len=6000, cov_t=40, cov_n=30, error_rate=0.01, read_len=100, ref_seed=7,
                     tumor_seed=17, normal_seed=27, somatic_every=700, germline_every=500),
                "chr22:1000-4500", []),
+    # short inserts: the two mates of most fragments overlap -> exercises hasOverlappingMate / unsorted binary_search
+    "ovl": (dict(ref_len=6000, cov_t=40, cov_n=30, ref_seed=9, tumor_seed=19, normal_seed=29, insert_mean=210.0,
+                 insert_sd=35.0, somatic_every=900, germline_every=600), "chr22:1200-3800", []),
     "dups": (dict(ref_len=8000, cov_t=40, cov_n=40, ref_seed=5, tumor_seed=15, normal_seed=25, dup_prob=1.0,
                   somatic_every=600, germline_every=500, read_len=100), "chr22:1000-6500", []),
 }
