@@ -72,8 +72,13 @@ struct lancet_engine {
       d_rinfo, d_name, d_bw, d_gw, d_bases, d_good;
   DevBuf d_variants, d_blob, d_counters, d_stats, d_evtlen, d_evt, d_workmem, d_phase;
   std::vector<unsigned long long> phase;
-  EngineCaps caps;
+  EngineCaps caps;      // tier 1
+  EngineCaps caps2;     // tier 2 (re-run of overflowed windows)
+  DevBuf d_caps2, d_works2, d_workmem2, d_out2, d_winlist;
+  int n_slots2 = 0;
+  uint32_t node_cap1 = 8192;
   int n_windows = 0, n_reads = 0, n_slots = 0;
+  int n_rerun = 0;
   bool uploaded = false, ran = false;
   uint32_t evt_cap = 0;
   size_t mem_budget = (size_t)96 << 30;
@@ -111,6 +116,7 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (const char *s = getenv("LANCET_MAX_SLOTS")) e->max_slots = atoi(s);
   if (const char *s = getenv("LANCET_MEM_GB")) e->mem_budget = (size_t)atoi(s) << 30;
   if (const char *s = getenv("LANCET_MAX_NODES")) e->max_nodes_limit = (uint32_t)atoi(s);
+  if (const char *s = getenv("LANCET_NODE_CAP1")) e->node_cap1 = (uint32_t)atoi(s);
   *out = e;
   return LANCET_OK;
 }
@@ -121,7 +127,7 @@ void lancet_engine_destroy(lancet_engine *e) {
   DevBuf *all[] = {&e->d_params, &e->d_batch, &e->d_caps, &e->d_out, &e->d_works, &e->d_chr, &e->d_refstart, &e->d_refoff, &e->d_refasc,
                    &e->d_refcodes, &e->d_readbegin, &e->d_seqoff, &e->d_seq, &e->d_qual, &e->d_label, &e->d_strand, &e->d_mate, &e->d_mapped,
                    &e->d_rinfo, &e->d_name, &e->d_bw, &e->d_gw, &e->d_bases, &e->d_good, &e->d_variants, &e->d_blob, &e->d_counters,
-                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase};
+                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist};
   for (DevBuf *b : all) b->release();
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -154,7 +160,9 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   e->n_windows = nw; e->n_reads = (int)R;
   if (nw == 0) { e->uploaded = true; return LANCET_OK; }
   for (int w = 0; w < nw; ++w) if (b->ref_off[w + 1] - b->ref_off[w] > LC_MAXW) { e->err = "window longer than LC_MAXW"; return LANCET_E_UNSUPPORTED; }
-  e->caps = lc_caps_for_batch(b, &e->params, e->evt_cap, e->max_nodes_limit);
+  e->caps = lc_caps_for_batch(b, &e->params, e->evt_cap, e->node_cap1, 1);
+  e->caps2 = lc_caps_for_batch(b, &e->params, e->evt_cap, e->max_nodes_limit, 2);
+  e->caps2.var_cap = e->caps.var_cap; e->caps2.blob_cap = e->caps.blob_cap;
   // ---- inputs
   UP(e->d_params, &e->params, sizeof(lancet_params));
   UP(e->d_chr, b->chr_id, sizeof(int32_t) * nw);
@@ -191,6 +199,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   db.good_woff = (const uint32_t *)e->d_gw.p; db.bases = (const uint32_t *)e->d_bases.p; db.good = (const uint32_t *)e->d_good.p;
   UP(e->d_batch, &db, sizeof(db));
   UP(e->d_caps, &e->caps, sizeof(e->caps));
+  UP(e->d_caps2, &e->caps2, sizeof(e->caps2));
   // ---- work space: as many slots as fit (and are useful)
   size_t slot_bytes = lc_work_carve(nullptr, nullptr, e->caps);
   DBG("carve measured");
@@ -213,7 +222,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   DevOut o;
   o.variants = (lancet_variant *)e->d_variants.p; o.blob = (char *)e->d_blob.p;
   o.n_variants = (uint32_t *)e->d_counters.p; o.n_blob = (uint32_t *)e->d_counters.p + 1; o.queue_head = (uint32_t *)e->d_counters.p + 2;
-  o.stats = (lancet_window_stats *)e->d_stats.p; o.evt_len = (uint32_t *)e->d_evtlen.p; o.evt_out = (uint32_t *)e->d_evt.p; o.phase = (unsigned long long *)e->d_phase.p;
+  o.stats = (lancet_window_stats *)e->d_stats.p; o.evt_len = (uint32_t *)e->d_evtlen.p; o.evt_out = (uint32_t *)e->d_evt.p; o.phase = (unsigned long long *)e->d_phase.p; o.win_list = nullptr; o.n_list = 0;
   UP(e->d_out, &o, sizeof(o));
   DBG("sync");
   HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -238,10 +247,43 @@ int lancet_engine_run(lancet_engine *e) {
   HIPCHK(e, hipStreamSynchronize(e->stream));
   HIPCHK(e, hipEventElapsedTime(&e->ms_all, e->ev0, e->ev1));
   e->ms_kernel = e->ms_all;
+  // ---- tier 2: windows that did not fit the small work space are re-run with the worst-case one
+  e->stats.resize(e->n_windows);
+  HIPCHK(e, hipMemcpy(e->stats.data(), e->d_stats.p, sizeof(lancet_window_stats) * e->n_windows, hipMemcpyDeviceToHost));
+  uint32_t nv_tier1 = 0;
+  HIPCHK(e, hipMemcpy(&nv_tier1, e->d_counters.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  std::vector<uint32_t> rerun;
+  std::vector<char> ok1(e->n_windows, 1);
+  for (int w = 0; w < e->n_windows; ++w) if (e->stats[w].status == LANCET_W_OVERFLOW) { rerun.push_back((uint32_t)w); ok1[w] = 0; }
+  e->n_rerun = (int)rerun.size();
+  if (!rerun.empty()) {
+    size_t slot2 = lc_work_carve(nullptr, nullptr, e->caps2);
+    int slots2 = (int)std::min<size_t>(rerun.size(), 128);
+    while (slots2 > 1 && (size_t)slots2 * slot2 > ((size_t)16 << 30)) slots2 /= 2;
+    if (e->d_workmem2.ensure((size_t)slots2 * slot2) || e->d_works2.ensure(sizeof(Work) * slots2) || e->d_winlist.ensure(sizeof(uint32_t) * rerun.size()) ||
+        e->d_out2.ensure(sizeof(DevOut))) { e->err = "hipMalloc failed (tier 2)"; return LANCET_E_OOM; }
+    std::vector<Work> works2(slots2);
+    for (int s2 = 0; s2 < slots2; ++s2) lc_work_carve(&works2[s2], (char *)e->d_workmem2.p + (size_t)s2 * slot2, e->caps2);
+    HIPCHK(e, hipMemcpy(e->d_works2.p, works2.data(), sizeof(Work) * slots2, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->d_winlist.p, rerun.data(), sizeof(uint32_t) * rerun.size(), hipMemcpyHostToDevice));
+    DevOut o2;
+    HIPCHK(e, hipMemcpy(&o2, e->d_out.p, sizeof(o2), hipMemcpyDeviceToHost));
+    o2.win_list = (const uint32_t *)e->d_winlist.p; o2.n_list = (uint32_t)rerun.size();
+    HIPCHK(e, hipMemcpy(e->d_out2.p, &o2, sizeof(o2), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemsetAsync((uint32_t *)e->d_counters.p + 2, 0, sizeof(uint32_t), e->stream));      // queue head
+    HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+    hipLaunchKernelGGL(window_kernel, dim3(slots2), dim3(LANCET_WG), 0, e->stream, (const lancet_params *)e->d_params.p,
+                       (const DevBatch *)e->d_batch.p, (const EngineCaps *)e->d_caps2.p, (Work *)e->d_works2.p, (DevOut *)e->d_out2.p);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    float ms2 = 0;
+    HIPCHK(e, hipEventElapsedTime(&ms2, e->ev0, e->ev1));
+    e->ms_all += ms2; e->ms_kernel += ms2;
+  }
   // ---- read back
   uint32_t counters[3];
   HIPCHK(e, hipMemcpy(counters, e->d_counters.p, sizeof(counters), hipMemcpyDeviceToHost));
-  e->stats.resize(e->n_windows);
   HIPCHK(e, hipMemcpy(e->stats.data(), e->d_stats.p, sizeof(lancet_window_stats) * e->n_windows, hipMemcpyDeviceToHost));
   bool global_overflow = counters[0] > e->caps.var_cap || counters[1] > e->caps.blob_cap;
   uint32_t nv = std::min(counters[0], e->caps.var_cap), nb = std::min(counters[1], e->caps.blob_cap);
@@ -262,6 +304,7 @@ int lancet_engine_run(lancet_engine *e) {
     const lancet_variant &v = raw[i];
     if (v.window < 0 || v.window >= e->n_windows) continue;
     if (e->stats[v.window].status < 0) continue;
+    if (i < nv_tier1 && !ok1[v.window]) continue;           // partial output of a window that was re-run in tier 2
     if ((size_t)v.str_off + v.str_len > nb) continue;
     idx.push_back(i);
   }
@@ -327,7 +370,7 @@ int lancet_debug_align(lancet_engine *e, const char *S, const char *T, char *S_a
   if (n < 1 || m < 1 || n > LC_MAXW) return LANCET_E_ARG;
   EngineCaps caps; memset(&caps, 0, sizeof(caps));
   caps.reads_cap = 4; caps.occ_cap = 64; caps.node_cap = 16; caps.table_cap = 32; caps.bucket_cap = 32; caps.special_cap = 4; caps.surv_cap = 4;
-  caps.seq_cap = 64; caps.queue_cap = 4; caps.path_cap = (uint32_t)m + 8; caps.max_k = 16;
+  caps.seq_cap = 64; caps.queue_cap = 4; caps.path_cap = (uint32_t)m + 8; caps.max_k = 16; caps.qv_cap = 64;
   size_t bytes = lc_work_carve(nullptr, nullptr, caps);
   DevBuf mem, dcaps, dwork, ds, dt, dl;
   std::vector<uint8_t> sc(n), tc(m);
@@ -363,6 +406,9 @@ int lancet_engine_phase_times(lancet_engine *e, const unsigned long long **ticks
   *ticks = e->phase.data();
   return LANCET_OK;
 }
+
+// number of windows of the last run that needed the worst-case work space (tier 2)
+int lancet_engine_rerun_count(lancet_engine *e) { return e ? e->n_rerun : -1; }
 
 // introspection used by bench.py: slots in flight and bytes of work space per slot
 int lancet_engine_geometry(lancet_engine *e, int32_t *n_slots, uint64_t *slot_bytes) {

@@ -15,8 +15,10 @@ static inline uint32_t lc_bucket_cap_for(uint32_t nodes) {
 }
 
 // Work-space caps for a batch: the largest window decides.
+// tier 1 = the common case (small tables: cheap to clear, cache/TLB friendly); tier 2 = worst case for the window
+// shapes in the batch, used to re-run the windows that overflowed tier 1.
 static inline EngineCaps lc_caps_for_batch(const lancet_window_batch *b, const lancet_params *p, uint32_t evt_cap,
-                                           uint32_t max_nodes_limit) {
+                                           uint32_t max_nodes_limit, int tier = 2) {
   EngineCaps c; memset(&c, 0, sizeof(c));
   uint32_t max_reads = 0; uint64_t max_bases = 0;
   for (int w = 0; w < b->n_windows; ++w) {
@@ -33,11 +35,18 @@ static inline EngineCaps lc_caps_for_batch(const lancet_window_batch *b, const l
   c.table_cap = lc_pow2_ge(2 * nodes);
   c.bucket_cap = lc_bucket_cap_for(nodes);
   c.special_cap = 64;
-  c.surv_cap = nodes < 4096 ? nodes : 4096;
   uint32_t maxk = (uint32_t)(p->max_k > 0 ? p->max_k : 101);
   c.max_k = maxk;
-  c.seq_cap = c.surv_cap * maxk + 8 * LC_MAXW * 8 + 65536;
-  c.queue_cap = 32768;
+  if (tier == 1) {
+    c.surv_cap = nodes < 4096 ? nodes : 4096;
+    c.qv_cap = 4096u * 32u;                    // (survivor, position) entries: 4096 survivors at k<=32, 1297 at k=101
+    c.queue_cap = 8192;
+  } else {
+    c.surv_cap = nodes < 16384 ? nodes : 16384;
+    c.qv_cap = c.surv_cap * maxk;
+    c.queue_cap = 65536;
+  }
+  c.seq_cap = 3 * c.qv_cap + 65536;
   c.path_cap = LC_MAXW + (uint32_t)p->max_indel_len + 256;
   c.evt_cap = evt_cap;
   c.var_cap = (uint32_t)b->n_windows * 8 + 1024;
@@ -91,7 +100,7 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.nqv = k.take<uint32_t>(nodes);
   t.ncolor = k.take<uint8_t>(nodes);
   t.nonref = k.take<uint32_t>(nodes);
-  t.qv = k.take<uint16_t>((size_t)c.surv_cap * c.max_k * 4);
+  t.qv = k.take<uint16_t>((size_t)c.qv_cap * 4);
   t.seq = k.take<uint32_t>(c.seq_cap);
   t.ht_next = k.take<uint32_t>(nodes);
   t.ht_bucket = k.take<uint32_t>(c.bucket_cap);

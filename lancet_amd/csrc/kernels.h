@@ -777,7 +777,7 @@ DEV void build_graph(Ctx &c) {
     if (!low) {
       // survivor of the first removeLowCov: keep the per-position counts and start its sequence-descriptor deque
       uint32_t qi = dev_atomic_add((uint32_t *)&S.qv_top, 1u);
-      if (qi >= c.C->surv_cap || ((size_t)qi + 1) * (size_t)K > (size_t)c.C->seq_cap) { OVF(c); }
+      if (qi >= c.C->surv_cap || ((size_t)qi + 1) * (size_t)K > (size_t)c.C->qv_cap) { OVF(c); }
       else {
         uint16_t *qq = W.qv + (size_t)qi * K * 4;
         for (int i = 0; i < K; ++i) { qq[4 * i] = pc[i]; qq[4 * i + 1] = pc[K + i]; qq[4 * i + 2] = pc[2 * K + i]; qq[4 * i + 3] = pc[3 * K + i]; }
@@ -1719,7 +1719,8 @@ DEV void window_kernel_body(const lancet_params *P, const DevBatch *B, const Eng
   while (true) {
     WG_LANE0 { S->tmp3 = (int)dev_atomic_add(OUT->queue_head, 1u); }
     int w = wg_bcast(&S->tmp3);
-    if (w >= B->n_windows) break;
+    if (OUT->win_list) { if ((uint32_t)w >= OUT->n_list) break; w = (int)OUT->win_list[w]; }
+    else if (w >= B->n_windows) break;
 #ifndef LANCET_WAVE_EMU
     if (threadIdx.x == 0) { for (int i = 0; i < 16; ++i) S->phase_acc[i] = 0; S->phase_cur = 0; S->t_last = wall_clock64(); }
 #endif

@@ -65,6 +65,7 @@ struct EngineCaps {
   uint32_t var_cap;      /* variant records for the whole batch                            */
   uint32_t blob_cap;     /* variant string bytes for the whole batch                       */
   uint32_t max_k;        /* largest k the engine was created for                           */
+  uint32_t qv_cap;       /* (survivor, k-mer position) entries of per-position quality counts */
 };
 
 /* device-resident batch (after upload + prep) */
@@ -159,4 +160,6 @@ struct DevOut {
   uint32_t *evt_len;      /* [n_windows] words used in the window's trace (slot evt copied out)  */
   uint32_t *evt_out;      /* [n_windows * evt_cap] */
   unsigned long long *phase; /* [n_windows * 16] per-phase time (100 MHz ticks), may be null */
+  const uint32_t *win_list;  /* when non-null: the windows to process (re-run of overflowed windows)   */
+  uint32_t n_list;
 };

@@ -43,6 +43,7 @@ def lib():
         L.lancet_engine_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float * 2)]
         L.lancet_engine_set_trace.argtypes = [C.c_void_p, C.c_uint32]
         L.lancet_engine_trace.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32)]
+        L.lancet_engine_rerun_count.argtypes = [C.c_void_p]
         L.lancet_engine_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
         L.lancet_debug_align.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.lancet_engine_phase_times.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64))]
@@ -111,6 +112,9 @@ class Engine:
         t = (C.c_float * 2)()
         self._chk(self.L.lancet_engine_last_timing(self.h, C.byref(t)))
         return float(t[0]), float(t[1])
+
+    def rerun_count(self) -> int:
+        return int(self.L.lancet_engine_rerun_count(self.h))
 
     def geometry(self):
         s = C.c_int32()

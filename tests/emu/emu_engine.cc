@@ -47,7 +47,7 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   res->evt_len.assign(b->n_windows, 0); res->evt.assign((size_t)b->n_windows * (evt_cap ? evt_cap : 1), 0); res->evt_cap = evt_cap;
   uint32_t nv = 0, nb = 0, qh = 0;
   DevOut O; O.variants = res->variants.data(); O.blob = res->blob.data(); O.n_variants = &nv; O.n_blob = &nb; O.stats = res->stats.data();
-  O.queue_head = &qh; O.phase = nullptr; O.evt_len = res->evt_len.data(); O.evt_out = res->evt.data();
+  O.queue_head = &qh; O.phase = nullptr; O.win_list = nullptr; O.n_list = 0; O.evt_len = res->evt_len.data(); O.evt_out = res->evt.data();
   static thread_local WinShared S;
   memset(&S, 0xCD, sizeof(S));
   window_kernel_body(P, &B, &C, &work, &O, &S, 0);

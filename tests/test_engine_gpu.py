@@ -88,3 +88,18 @@ def test_device_alignment_equals_reference_align_cc():
         t = "".join(t) or "A"
         assert eng.debug_align(s, t) == oracle.align(s, t), (s, t)
     eng.close()
+
+
+def test_overflowed_windows_are_rerun_with_worst_case_workspace(monkeypatch):
+    """Tier 1 (small tables) overflows on purpose; the engine must re-run those windows with the worst-case work
+    space and still return exactly the oracle's records (never approximate, never silently drop)."""
+    monkeypatch.setenv("LANCET_NODE_CAP1", "1024")
+    meta, batch, kept, (min_k, max_k) = gu.case_batch("tile60")
+    p = abi.default_params(min_k=min_k, max_k=max_k)
+    eng = engine.Engine(p)
+    variants, stats = eng.process(batch)
+    assert eng.rerun_count() > 0
+    ov, ostats, _ = oracle.run(batch, p)
+    assert variants == ov
+    assert [s["status"] for s in stats] == [s["status"] for s in ostats]
+    eng.close()
