@@ -48,7 +48,9 @@ def main():
     batch = workload.make_scan_batch(args.windows, args.cov, args.cov, seed=22 + 1000 * rank)
     params = abi.default_params()
     eng = engine.Engine(params, device=local_rank)
+    t_up = time.perf_counter()
     eng.upload(batch)                      # host -> HBM + trim/pack: outside the timed region
+    upload_ms = 1000.0 * (time.perf_counter() - t_up)
     n_slots, slot_bytes = eng.geometry()
 
     def step():
@@ -103,7 +105,7 @@ def main():
             "config": {"workload": f"chr22-scan proxy: {args.windows} windows/GPU x 600 bp, stride 100, "
                                    f"{args.cov:g}x tumor / {args.cov:g}x normal, 2x150 bp, k=11..101, active-region-off",
                        "windows_per_gpu": args.windows, "coverage": [args.cov, args.cov], "reads_per_gpu": int(batch.n_reads),
-                       "variants_rank0": len(variants), "slots_in_flight": n_slots, "workspace_MB_per_slot": round(slot_bytes / 2 ** 20, 1)},
+                       "variants_rank0": len(variants), "slots_in_flight": n_slots, "upload_ms": round(upload_ms, 1), "windows_rerun_tier2": eng.rerun_count(), "workspace_MB_per_slot": round(slot_bytes / 2 ** 20, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": None,
                          "kernel": "window_kernel", "kernel_ms": round(ms_kernel, 3), "algorithmic_bytes_per_launch": alg_bytes},
