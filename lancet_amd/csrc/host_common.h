@@ -84,8 +84,8 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.nhash = k.take<unsigned long long>(nodes);
   t.ncnt = k.take<uint32_t>(nodes * 4);
   t.nflags = k.take<uint32_t>(nodes);
-  t.efirst = k.take<uint32_t>(nodes * 8);
-  t.eto = k.take<uint32_t>(nodes * 8);
+  t.efirst = k.take<uint32_t>(nodes * 10);
+  t.eto = k.take<uint32_t>(nodes * 10);
   t.edges = k.take<uint32_t>(nodes * LC_EMAX);
   t.necnt = k.take<uint32_t>(nodes);
   t.ncov = k.take<float>(nodes * 4);

@@ -43,7 +43,7 @@ struct WinShared {
   unsigned long long n_kmers;
   uint32_t max_nodes;
   int n_builds, final_k, status;
-  int tmp0, tmp1, tmp2, tmp3;
+  int tmp0, tmp1, tmp2, tmp3, hasN;
   uint32_t part[LANCET_WG + 1];
   unsigned long long t_last, phase_acc[16];
   int phase_cur;
@@ -447,6 +447,19 @@ DEV int read_base(const Ctx &c, bool isref, uint32_t bw, int i) {
   return rd_base(c.B->bases, bw, i);
 }
 
+// ---- reference k-mers that contain N.  Only the reference pseudo-read can have them; they become
+// nodes like any other (they shift the libstdc++ rehash points and bucket order) but never gain coverage.  Their
+// identity is the ASCII string, 'N' sorting between 'G' and 'T', rrc('N') == 'N' (reference src/util.cc:204-217).
+DEV int n_ord(int code) { return code == 3 ? 4 : (code == 4 ? 3 : code); }          // A C G N T
+DEV int n_comp(int code) { return code == 4 ? 4 : 3 - code; }
+DEV int nk_char(const uint8_t *ref, int p, int K, bool isR, int j) {                 // j-th char (code) of the canonical string
+  return isR ? n_comp(ref[p + K - 1 - j]) : ref[p + j];
+}
+DEV bool nk_is_forward(const uint8_t *ref, int p, int K) {                           // mer < rc(mer)
+  for (int j = 0; j < K; ++j) { int a = n_ord(ref[p + j]), b = n_ord(n_comp(ref[p + K - 1 - j])); if (a != b) return a < b; }
+  return false;
+}
+
 template <int NW>
 DEV void build_insert_pass(Ctx &c, bool verify) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
@@ -459,19 +472,29 @@ DEV void build_insert_pass(Ctx &c, bool verify) {
     unsigned long long fw[NW], rc[NW];
     for (int w = 0; w < NW; ++w) { fw[w] = 0; rc[w] = 0; }
     uint32_t o = W.occ_base[r];
+    const uint8_t *refc = c.B->ref_codes + c.B->ref_off[S.w];
+    int nN = 0;                                                  // N's among the last K bases (reference read only)
     for (int i = 0; i < tlen; ++i) {
       int b = read_base(c, isref, bw, i);
-      key_push_fw(fw, NW, K, b);
-      key_push_rc(rc, NW, K, b);
+      if (isref) { if (b > 3) ++nN; if (i >= K && refc[i - K] > 3) --nN; }
+      key_push_fw(fw, NW, K, b & 3);
+      key_push_rc(rc, NW, K, b & 3);
       if (i < K - 1) continue;
-      bool isF = key_less(fw, rc, NW);                          // CanonicalMer_t::set: mer < rmer -> F, tie -> R
+      const bool nk = nN > 0;                                    // this k-mer contains N
+      const int p = i - K + 1;
+      bool isF = nk ? nk_is_forward(refc, p, K) : key_less(fw, rc, NW);   // CanonicalMer_t::set: mer < rmer -> F, tie -> R
       const unsigned long long *ck = isF ? fw : rc;
       if (!verify) {
         unsigned long long h = 0;
         uint32_t idx;
-        if (NW == 1 && K <= 31) { h = ck[0] + 1ULL; idx = (uint32_t)mix64(h) & mask; }       // tag == key: exact, no verify pass
+        if (nk) {
+          for (int j = 0; j < K; ++j) h = mix64(h * 131ULL + (unsigned long long)(nk_char(refc, p, K, !isF, j) + 1));
+          h |= 1ULL << 63;                                       // tag space disjoint from ordinary k-mers
+          idx = (uint32_t)mix64(h) & mask;
+        } else if (NW == 1 && K <= 31) { h = ck[0] + 1ULL; idx = (uint32_t)mix64(h) & mask; }   // tag == key: exact, no verify pass
         else {
           for (int w = 0; w < NW; ++w) h = mix64(h ^ (ck[w] + 0x9e3779b97f4a7c15ULL * (unsigned long long)(w + 1)));
+          h &= ~(1ULL << 63);
           if (h == 0) h = 1;
           idx = (uint32_t)h & mask;
         }
@@ -481,7 +504,11 @@ DEV void build_insert_pass(Ctx &c, bool verify) {
           if (cur == h) break;
           if (cur == 0) {
             unsigned long long old = dev_atomic_cas64(&W.tags[idx], 0ULL, h);
-            if (old == 0) { for (int w = 0; w < NW; ++w) W.slot_key[(size_t)idx * LC_NWMAX + w] = ck[w]; break; }
+            if (old == 0) {
+              if (nk) W.slot_key[(size_t)idx * LC_NWMAX] = ((unsigned long long)p << 1) | (isF ? 0ULL : 1ULL);   // where the string lives
+              else for (int w = 0; w < NW; ++w) W.slot_key[(size_t)idx * LC_NWMAX + w] = ck[w];
+              break;
+            }
             if (old == h) break;
           }
           idx = (idx + 1) & mask;
@@ -491,7 +518,13 @@ DEV void build_insert_pass(Ctx &c, bool verify) {
         W.occ[o] = idx | (isF ? 0u : 0x80000000u);
       } else {
         uint32_t idx = W.occ[o] & 0x3FFFFFFFu;
-        for (int w = 0; w < NW; ++w) if (W.slot_key[(size_t)idx * LC_NWMAX + w] != ck[w]) OVF(c);   // 64-bit tag collision
+        if (nk) {
+          unsigned long long sk = W.slot_key[(size_t)idx * LC_NWMAX];
+          int p2 = (int)(sk >> 1); bool r2 = (sk & 1ULL) != 0;
+          for (int j = 0; j < K; ++j) if (nk_char(refc, p, K, !isF, j) != nk_char(refc, p2, K, r2, j)) { OVF(c); break; }
+        } else if (K > 31) {
+          for (int w = 0; w < NW; ++w) if (W.slot_key[(size_t)idx * LC_NWMAX + w] != ck[w]) OVF(c);   // 64-bit tag collision
+        }
       }
       ++o;
     }
@@ -533,7 +566,7 @@ DEV void build_graph(Ctx &c) {
   // ---- pass 1: canonical k-mers -> open-addressing slots
   switch (S.NW) { case 1: build_insert_pass<1>(c, false); break; case 2: build_insert_pass<2>(c, false); break;
                   case 3: build_insert_pass<3>(c, false); break; default: build_insert_pass<4>(c, false); break; }
-  if (K > 31) {   // 64-bit tags of longer keys can collide: compare the full keys
+  if (K > 31 || S.hasN) {   // 64-bit tags of longer keys / of N k-mers can collide: compare the full keys
     switch (S.NW) { case 1: build_insert_pass<1>(c, true); break; case 2: build_insert_pass<2>(c, true); break;
                     case 3: build_insert_pass<3>(c, true); break; default: build_insert_pass<4>(c, true); break; }
   }
@@ -554,16 +587,21 @@ DEV void build_graph(Ctx &c) {
       uint32_t id = W.bitpre[f >> 5] + (uint32_t)dev_popc(ld2(&W.bitmap[f >> 5]) & ((1u << (f & 31)) - 1u));
       W.slot_node[i] = id;
       for (int w = 0; w < S.NW; ++w) W.nkey[(size_t)id * LC_NWMAX + w] = W.slot_key[(size_t)i * LC_NWMAX + w];
+      W.nflags[id] = (ld2(&W.tags[i]) >> 63) ? NF_NKMER : 0u;
     }
   }
   WG_SYNC();
   // ---- per node: std::hash of the ASCII k-mer, zeroed counters
   WG_FOR(n, S.N) {
     const unsigned long long *k = W.nkey + (size_t)n * LC_NWMAX;
-    W.nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGT"[key_base(k, K, j)]; }, K);
+    if (W.nflags[n] & NF_NKMER) {
+      const uint8_t *refc = c.B->ref_codes + c.B->ref_off[S.w];
+      int p = (int)(k[0] >> 1); bool isR = (k[0] & 1ULL) != 0;
+      W.nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGTN"[nk_char(refc, p, K, isR, j)]; }, K);
+    } else W.nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGT"[key_base(k, K, j)]; }, K);
     for (int j = 0; j < 4; ++j) W.ncnt[4 * n + j] = 0;
-    for (int j = 0; j < 8; ++j) { W.efirst[8 * n + j] = LC_NIL; W.eto[8 * n + j] = 0; }
-    W.nflags[n] = 0; W.necnt[n] = 0; W.ncomp[n] = 0; W.nocc[n] = 0; W.nfill[n] = 0; W.nqv[n] = LC_NIL; W.ncolor[n] = 0;
+    for (int j = 0; j < 10; ++j) { W.efirst[10 * n + j] = LC_NIL; W.eto[10 * n + j] = 0; }
+    W.necnt[n] = 0; W.ncomp[n] = 0; W.nocc[n] = 0; W.nfill[n] = 0; W.nqv[n] = LC_NIL; W.ncolor[n] = 0;
     W.nonref[n] = 0; W.nkm[n] = 1; W.nkmT[n] = 0;
   }
   // reads whose opposite mate (same name) comes earlier in the window: only these can ever see
@@ -652,13 +690,13 @@ DEV void build_graph(Ctx &c) {
         int bnew = read_base(c, isref, bw, p + K - 1);      // base that v adds after u
         int bold = read_base(c, isref, bw, p - 1);          // base that u has before v
         // slot = (side, extension base in the node's canonical orientation): F side = right extension
-        uint32_t su = (prevori == 0) ? (uint32_t)bnew : 4u + (uint32_t)(3 - bnew);
-        uint32_t sv = (ori == 0) ? 4u + (uint32_t)bold : (uint32_t)(3 - bold);
+        uint32_t su = (prevori == 0) ? (uint32_t)bnew : 5u + (uint32_t)n_comp(bnew);
+        uint32_t sv = (ori == 0) ? 5u + (uint32_t)bold : (uint32_t)n_comp(bold);
         uint32_t stamp = 2u * (o0 + (uint32_t)p - 1u);
-        W.eto[8 * prevnode + su] = ED_MAKE(X, fdir);
-        dev_atomic_min(&W.efirst[8 * prevnode + su], stamp);
-        W.eto[8 * X + sv] = ED_MAKE(prevnode, rdir);
-        dev_atomic_min(&W.efirst[8 * X + sv], stamp + 1u);
+        W.eto[10 * prevnode + su] = ED_MAKE(X, fdir);
+        dev_atomic_min(&W.efirst[10 * prevnode + su], stamp);
+        W.eto[10 * X + sv] = ED_MAKE(prevnode, rdir);
+        dev_atomic_min(&W.efirst[10 * X + sv], stamp + 1u);
       }
       W.occ[o0 + p] = X | (ori << 31) | (cd ? 0x40000000u : 0u);
       prevnode = X; prevori = ori;
@@ -733,8 +771,8 @@ DEV void build_graph(Ctx &c) {
   //      (reference src/Graph.cc:2790-2827 with docompression=false, compid=0) evaluated in the same pass.
   const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
   WG_FOR(n, S.N) {
-    uint32_t stamp[8]; uint32_t tgt[8]; int ne = 0;
-    for (int j = 0; j < 8; ++j) { uint32_t ef = ld2(&W.efirst[8 * n + j]); if (ef != LC_NIL) { stamp[ne] = ef; tgt[ne] = W.eto[8 * n + j]; ++ne; } }
+    uint32_t stamp[10]; uint32_t tgt[10]; int ne = 0;
+    for (int j = 0; j < 10; ++j) { uint32_t ef = ld2(&W.efirst[10 * n + j]); if (ef != LC_NIL) { stamp[ne] = ef; tgt[ne] = W.eto[10 * n + j]; ++ne; } }
     for (int i = 1; i < ne; ++i) { uint32_t s = stamp[i], t = tgt[i]; int j = i; while (j > 0 && stamp[j - 1] > s) { stamp[j] = stamp[j - 1]; tgt[j] = tgt[j - 1]; --j; } stamp[j] = s; tgt[j] = t; }
     for (int i = 0; i < ne; ++i) W.edges[n * LC_EMAX + i] = tgt[i];
     W.necnt[n] = ne;
@@ -1346,11 +1384,11 @@ DEVNI int align_traceback(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, i
     uint8_t b = W.tb[(size_t)i * stride + j];
     int t = b & 3, x = (b >> 2) & 3, y = (b >> 4) & 3;
     if (t == 3) break;
-    else if (forcex) { if (i < 1) { OVF(c); return 0; } ra[L] = "ACGT"[Sx[i - 1]]; pa[L] = '-'; ++L; if (x == 0) forcex = false; --i; }
-    else if (t == 1) { ra[L] = "ACGT"[Sx[i - 1]]; pa[L] = '-'; ++L; if (x == 1) forcex = true; --i; }
+    else if (forcex) { if (i < 1) { OVF(c); return 0; } ra[L] = "ACGTN"[Sx[i - 1]]; pa[L] = '-'; ++L; if (x == 0) forcex = false; --i; }
+    else if (t == 1) { ra[L] = "ACGTN"[Sx[i - 1]]; pa[L] = '-'; ++L; if (x == 1) forcex = true; --i; }
     else if (forcey) { if (j < 1) { OVF(c); return 0; } ra[L] = '-'; pa[L] = "ACGT"[Tx[j - 1]]; ++L; if (y == 0) forcey = false; --j; }
     else if (t == 2) { ra[L] = '-'; pa[L] = "ACGT"[Tx[j - 1]]; ++L; if (y == 1) forcey = true; --j; }
-    else { ra[L] = "ACGT"[Sx[i - 1]]; pa[L] = "ACGT"[Tx[j - 1]]; ++L; --i; --j; }
+    else { ra[L] = "ACGTN"[Sx[i - 1]]; pa[L] = "ACGT"[Tx[j - 1]]; ++L; --i; --j; }
   }
   for (int a = 0, b2 = L - 1; a < b2; ++a, --b2) { uint8_t t1 = ra[a]; ra[a] = ra[b2]; ra[b2] = t1; uint8_t t2 = pa[a]; pa[a] = pa[b2]; pa[b2] = t2; }
   return L;
@@ -1620,7 +1658,8 @@ DEV void process_window(Ctx &c, int w) {
     for (int r = 0; r < nr; ++r) if (RI_MAPPED(B.rinfo[B.read_begin[w] + r])) ++mapped;
     S.tmp0 = mapped;
     if ((uint32_t)S.R > c.C->reads_cap || S.reflen > LC_MAXW || S.reflen < 1) S.overflow = 1;
-    for (int i = 0; i < S.reflen; ++i) if (B.ref_codes[B.ref_off[w] + i] > 3) S.overflow = 1;    // N in the window reference: not supported yet
+    S.hasN = 0;
+    for (int i = 0; i < S.reflen && !S.overflow; ++i) if (B.ref_codes[B.ref_off[w] + i] > 3) S.hasN = 1;
     if (mapped > 0) evt(c, EV_PROCESS, (uint32_t)nr, (uint32_t)mapped);
   }
   if (wg_bcast(&S.tmp0) <= 0) { WG_LANE0 { S.status = LANCET_W_NO_READS; } WG_SYNC(); return; }     // Microassembler.cc:83

@@ -28,6 +28,7 @@
 #define NF_SINK 16u
 #define NF_INMER 32u       /* canonical k-mer is in Ref_t::mertable (reference src/Ref.cc:40-64)          */
 #define NF_SURV 64u        /* survived the first removeLowCov: per-position quality counts are stored     */
+#define NF_NKMER 128u      /* reference k-mer containing N: identified by its string, not by a 2-bit key */
 #define NF_SPECIAL (NF_SOURCE | NF_SINK)
 
 /* edge word: target node [27:0], dir [29:28] (FF=0 FR=1 RF=2 RR=3, reference src/Edge.hh:37), flag [30]  */
@@ -112,8 +113,8 @@ struct Work {
   unsigned long long *nhash;    /* [nodes] libstdc++ std::hash<std::string> of the node id     */
   uint32_t *ncnt;         /* [nodes*4] counted occurrences: Tf Tr Nf Nr                        */
   uint32_t *nflags;       /* [nodes]                                                           */
-  uint32_t *efirst;       /* [nodes*8] first-seen stamp of each possible k-mer edge            */
-  uint32_t *eto;          /* [nodes*8] target|dir of each possible k-mer edge                  */
+  uint32_t *efirst;       /* [nodes*10] first-seen stamp of each possible k-mer edge (2 sides x ACGTN) */
+  uint32_t *eto;          /* [nodes*10] target|dir of each possible k-mer edge                 */
   uint32_t *edges;        /* [nodes*LC_EMAX]                                                   */
   uint32_t *necnt;        /* [nodes]                                                           */
   float *ncov;            /* [nodes*4] Tf Tr Nf Nr (float, as the reference)                   */

@@ -319,7 +319,7 @@ def make_tumor_normal(ref_len: int = 20000, cov_t: float = 30, cov_n: float = 30
                       read_len: int = 150, error_rate: float = 0.005,
                       somatic_every: int = 2000, germline_every: int = 1000,
                       region: Tuple[int, int] | None = None, dup_prob: float = 0.0,
-                      insert_mean: float = 400.0, insert_sd: float = 40.0):
+                      insert_mean: float = 400.0, insert_sd: float = 40.0, n_runs=()):
     """Returns dict(ref, variants, tumor_pairs, normal_pairs)."""
     ref = random_reference(ref_len, ref_seed, str_fraction, lowcomplex_fraction)
     variants = plant_variants(ref, ref_seed + 1, somatic_every, germline_every, dup_prob=dup_prob)
@@ -327,6 +327,11 @@ def make_tumor_normal(ref_len: int = 20000, cov_t: float = 30, cov_n: float = 30
     h0 = build_haplotype(ref, [])
     h1 = build_haplotype(ref, germ)
     h2 = build_haplotype(ref, variants)
+    if n_runs:   # reference gaps: the FASTA shows N, the sequenced genome has real bases there
+        rl = list(ref)
+        for pos, ln in n_runs:
+            rl[pos:pos + ln] = "N" * ln
+        ref = "".join(rl)
     tumor = simulate_sample(ref, rname, [h0, h1, h2], [0.5, 0.25, 0.25], cov_t, tumor_seed, "T", "tumor",
                             read_len=read_len, error_rate=error_rate, region=region, insert_mean=insert_mean,
                             insert_sd=insert_sd)

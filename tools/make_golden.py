@@ -48,6 +48,9 @@ CASES = {
     # short inserts: the two mates of most fragments overlap -> exercises hasOverlappingMate / unsorted binary_search
     "ovl": (dict(ref_len=6000, cov_t=40, cov_n=30, ref_seed=9, tumor_seed=19, normal_seed=29, insert_mean=210.0,
                  insert_sd=35.0, somatic_every=900, germline_every=600), "chr22:1200-3800", []),
+    # N in the window reference: single N, short runs, a run longer than the small k values
+    "nref": (dict(ref_len=6000, cov_t=30, cov_n=30, ref_seed=12, tumor_seed=112, normal_seed=212,
+                  n_runs=((1510, 1), (1933, 3), (2405, 17), (2950, 2), (3391, 1))), "chr22:1200-3700", []),
     "dups": (dict(ref_len=8000, cov_t=40, cov_n=40, ref_seed=5, tumor_seed=15, normal_seed=25, dup_prob=1.0,
                   somatic_every=600, germline_every=500, read_len=100), "chr22:1000-6500", []),
 }
