@@ -1335,7 +1335,7 @@ DEV bool status_cnt_T(const Ctx &c, uint32_t n) {                   // Node_t::i
 // the reference's tie rules; anti-diagonal wavefront across the workgroup, traceback by lane 0.
 // tb byte: M.tb [1:0] (0 '\\', 1 '<', 2 '^', 3 '*') ; X.tb [3:2] (0 '<', 1 '-', 2 '*') ; Y.tb [5:4] (0 '^', 1 '|', 2 '*')
 // ---------------------------------------------------------------------------------------------------------
-DEV void align_fill(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) {
+DEV void align_fill_arrays(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) {
   Work &W = *c.W;
   const int stride = m + 1;
   const int A = LC_MAXW + 2;
@@ -1371,6 +1371,59 @@ DEV void align_fill(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) 
     WG_SYNC();
   }
 }
+#ifndef LANCET_WAVE_EMU
+// GPU form: systolic over the wave.  Lane l owns rows l+1, l+65, ... (<= 10 rows for a 640-base window); cell (i,j)
+// is computed at step t = i + j, so everything a cell needs was produced one or two steps earlier by the lane above
+// (wave shuffles) or by the lane itself.  The score diagonals never touch memory; only the traceback bytes do.
+DEVNI void align_fill(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) {
+  static_assert(LANCET_WG == 64, "one wave per window");
+  Work &W = *c.W;
+  const int stride = m + 1;
+  const int lane = (int)threadIdx.x;
+  for (int j = lane; j < m + 1; j += 64) W.tb[j] = (uint8_t)((j == 0 ? 3 : 2) | (0 << 2) | (2 << 4));           // M[0][j] '^' ; Y[0][j] '*'
+  for (int i = lane + 1; i < n + 1; i += 64) W.tb[(size_t)i * stride] = (uint8_t)(1 | (2 << 2) | (0 << 4));     // M[i][0] '<' ; X[i][0] '*'
+  constexpr int GMAX = (LC_MAXW + 63) / 64;
+  const int G = (n + 63) / 64;
+  int mL[GMAX], xL[GMAX], yL[GMAX], upM2[GMAX], sg[GMAX];
+#pragma unroll
+  for (int g = 0; g < GMAX; ++g) {
+    int i = g * 64 + lane + 1;
+    mL[g] = -8 - i; yL[g] = -8 - i; xL[g] = 0;                      // M(i,0) = Y(i,0) = GAP_OPEN + i*GAP_EXTEND
+    upM2[g] = (i - 1 == 0) ? 0 : -8 - (i - 1);                       // M(i-1,0)
+    sg[g] = (i <= n) ? (int)Sx[i - 1] : 255;
+  }
+  for (int t = 2; t <= n + m; ++t) {
+    int pM[GMAX], pX[GMAX];
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) { pM[g] = mL[g]; pX[g] = xL[g]; }
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+      if (g < G) {
+      int i = g * 64 + lane + 1, j = t - i;
+      int nbM = __shfl_up(pM[g], 1), nbX = __shfl_up(pX[g], 1);
+      if (g > 0) { int eM = __shfl(pM[g > 0 ? g - 1 : 0], 63), eX = __shfl(pX[g > 0 ? g - 1 : 0], 63); if (lane == 0) { nbM = eM; nbX = eX; } }
+      else if (lane == 0) { nbM = -8 - j; nbX = -8 - j; }             // row 0: M(0,j) = X(0,j)
+      bool active = (i <= n) && (j >= 1) && (j <= m);
+      if (active) {
+        int xa = nbX - 1, xb = nbM - 8;
+        int xs, xt; if (xa > xb) { xs = xa; xt = 1; } else { xs = xb; xt = 0; }
+        int ya = yL[g] - 1, yb = pM[g] - 8;
+        int ys, yt; if (ya > yb) { ys = ya; yt = 1; } else { ys = yb; yt = 0; }
+        int ms = upM2[g] + (sg[g] == (int)Tx[j - 1] ? 2 : -4), mt = 0;
+        if (xs > ms) { ms = xs; mt = 1; }
+        if (ys > ms) { ms = ys; mt = 2; }
+        mL[g] = ms; xL[g] = xs; yL[g] = ys;
+        W.tb[(size_t)i * stride + j] = (uint8_t)(mt | (xt << 2) | (yt << 4));
+      }
+      if (j >= 1) upM2[g] = nbM;                                      // M(i-1,j) is next step's M(i-1,j-1)
+      }
+    }
+  }
+  WG_SYNC();
+}
+#else
+DEV void align_fill(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) { align_fill_arrays(c, Sx, n, Tx, m); }
+#endif
 // traceback into W.aln: returns alignment length; ref_aln at aln[0..L), path_aln at aln[cap..cap+L) (ASCII)
 DEVNI int align_traceback(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) {
   Work &W = *c.W;
