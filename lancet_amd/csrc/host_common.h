@@ -82,24 +82,9 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.csr = k.take<uint32_t>(c.occ_cap);
   t.nkey = k.take<unsigned long long>(nodes * LC_NWMAX);
   t.nhash = k.take<unsigned long long>(nodes);
-  t.ncnt = k.take<uint32_t>(nodes * 4);
-  t.nflags = k.take<uint32_t>(nodes);
-  t.efirst = k.take<uint32_t>(nodes * 10);
-  t.eto = k.take<uint32_t>(nodes * 10);
-  t.edges = k.take<uint32_t>(nodes * LC_EMAX);
-  t.necnt = k.take<uint32_t>(nodes);
-  t.ncov = k.take<float>(nodes * 4);
-  t.ncomp = k.take<int32_t>(nodes);
-  t.nmincov = k.take<int32_t>(nodes);
-  t.nmincovqv = k.take<int32_t>(nodes);
+  t.hot = k.take<NodeHot>(nodes);
+  t.gr = k.take<NodeGr>(nodes);
   t.nocc = k.take<uint32_t>(nodes + 1);
-  t.nfill = k.take<uint32_t>(nodes);
-  t.nseq_lo = k.take<uint32_t>(nodes); t.nseq_hi = k.take<uint32_t>(nodes);
-  t.nseq_clo = k.take<uint32_t>(nodes); t.nseq_chi = k.take<uint32_t>(nodes);
-  t.nkm = k.take<uint32_t>(nodes); t.nkmT = k.take<uint32_t>(nodes);
-  t.nqv = k.take<uint32_t>(nodes);
-  t.ncolor = k.take<uint8_t>(nodes);
-  t.nonref = k.take<uint32_t>(nodes);
   t.qv = k.take<uint16_t>((size_t)c.qv_cap * 4);
   t.seq = k.take<uint32_t>(c.seq_cap);
   t.ht_next = k.take<uint32_t>(nodes);

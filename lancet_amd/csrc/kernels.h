@@ -240,54 +240,54 @@ DEV void wg_scan(uint32_t *a, int n, volatile WinShared &S) {
 // ---------------------------------------------------------------------------------------------------------
 // node accessors
 // ---------------------------------------------------------------------------------------------------------
-DEV bool n_special(const Ctx &c, uint32_t n) { return (c.W->nflags[n] & NF_SPECIAL) != 0; }
-DEV bool n_dead(const Ctx &c, uint32_t n) { return (c.W->nflags[n] & NF_DEAD) != 0; }
-DEV int n_len(const Ctx &c, uint32_t n) { return (int)(c.W->nseq_hi[n] - c.W->nseq_lo[n]); }   // str_m.length()
+DEV bool n_special(const Ctx &c, uint32_t n) { return (c.W->gr[n].flags & NF_SPECIAL) != 0; }
+DEV bool n_dead(const Ctx &c, uint32_t n) { return (c.W->gr[n].flags & NF_DEAD) != 0; }
+DEV int n_len(const Ctx &c, uint32_t n) { return (int)(c.W->gr[n].seq_hi - c.W->gr[n].seq_lo); }   // str_m.length()
 DEV int n_strlen(const Ctx &c, uint32_t n) { return n_special(c, n) ? 0 : n_len(c, n); }       // Node_t::strlen
-DEV float n_totcov(const Ctx &c, uint32_t n) { const float *f = c.W->ncov + 4 * n; return f[0] + f[1] + f[2] + f[3]; }
+DEV float n_totcov(const Ctx &c, uint32_t n) { const float *f = c.W->gr[n].cov; return f[0] + f[1] + f[2] + f[3]; }
 
 DEV int get_buddy(const Ctx &c, uint32_t n, char dir) {             // Node_t::getBuddy, reference src/Node.cc:235-266
   if (n_special(c, n)) return -1;
   int ret = -1;
-  const uint32_t *e = c.W->edges + n * LC_EMAX;
-  int cnt = (int)c.W->necnt[n];
+  const uint32_t *e = c.W->gr[n].edges;
+  int cnt = (int)c.W->gr[n].necnt;
   for (int i = 0; i < cnt; ++i) if (is_dir(ED_DIR(e[i]), dir)) { if (ret != -1) return -1; ret = i; }
   if (ret != -1 && ED_TO(e[ret]) == n) return -1;
   return ret;
 }
 DEV bool is_tandem(const Ctx &c, uint32_t n) {                      // reference src/Node.cc:123-134
-  const uint32_t *e = c.W->edges + n * LC_EMAX;
-  for (int i = 0; i < (int)c.W->necnt[n]; ++i) if (ED_TO(e[i]) == n) return true;
+  const uint32_t *e = c.W->gr[n].edges;
+  for (int i = 0; i < (int)c.W->gr[n].necnt; ++i) if (ED_TO(e[i]) == n) return true;
   return false;
 }
 DEV void add_edge(Ctx &c, uint32_t n, uint32_t to, uint32_t dir) {  // reference src/Node.cc:140-175
-  uint32_t *e = c.W->edges + n * LC_EMAX;
-  int cnt = (int)c.W->necnt[n];
+  uint32_t *e = c.W->gr[n].edges;
+  int cnt = (int)c.W->gr[n].necnt;
   for (int i = 0; i < cnt; ++i) if (ED_TO(e[i]) == to && ED_DIR(e[i]) == dir) return;
   if (cnt >= LC_EMAX) { OVF(c); return; }
   e[cnt] = ED_MAKE(to, dir);
-  c.W->necnt[n] = cnt + 1;
+  c.W->gr[n].necnt = cnt + 1;
 }
 DEV void erase_edge_at(Ctx &c, uint32_t n, int idx) {
-  uint32_t *e = c.W->edges + n * LC_EMAX;
-  int cnt = (int)c.W->necnt[n];
+  uint32_t *e = c.W->gr[n].edges;
+  int cnt = (int)c.W->gr[n].necnt;
   for (int i = idx; i + 1 < cnt; ++i) e[i] = e[i + 1];
-  c.W->necnt[n] = cnt - 1;
+  c.W->gr[n].necnt = cnt - 1;
 }
 DEV void remove_edge(Ctx &c, uint32_t n, uint32_t to, uint32_t dir) {   // reference src/Node.cc:209-229
-  uint32_t *e = c.W->edges + n * LC_EMAX;
-  for (int i = 0; i < (int)c.W->necnt[n]; ++i)
+  uint32_t *e = c.W->gr[n].edges;
+  for (int i = 0; i < (int)c.W->gr[n].necnt; ++i)
     if (ED_TO(e[i]) == to && ED_DIR(e[i]) == dir) { erase_edge_at(c, n, i); return; }
 }
 DEV void update_edge(Ctx &c, uint32_t n, uint32_t oldto, uint32_t olddir, uint32_t newto, uint32_t newdir) {   // :181-204
-  uint32_t *e = c.W->edges + n * LC_EMAX;
-  for (int i = 0; i < (int)c.W->necnt[n]; ++i)
+  uint32_t *e = c.W->gr[n].edges;
+  for (int i = 0; i < (int)c.W->gr[n].necnt; ++i)
     if (ED_TO(e[i]) == oldto && ED_DIR(e[i]) == olddir) { e[i] = ED_MAKE(newto, newdir) | (e[i] & (1u << 30)); return; }
 }
 DEV void remove_node(Ctx &c, uint32_t n) {                          // Graph_t::removeNode, reference src/Graph.cc:2768-2784
-  c.W->nflags[n] |= NF_DEAD;
-  const uint32_t *e = c.W->edges + n * LC_EMAX;
-  for (int i = 0; i < (int)c.W->necnt[n]; ++i) {
+  c.W->gr[n].flags |= NF_DEAD;
+  const uint32_t *e = c.W->gr[n].edges;
+  for (int i = 0; i < (int)c.W->gr[n].necnt; ++i) {
     uint32_t nn = ED_TO(e[i]);
     if (nn != n) remove_edge(c, nn, n, fliplink(ED_DIR(e[i])));
   }
@@ -296,19 +296,19 @@ DEV void remove_node(Ctx &c, uint32_t n) {                          // Graph_t::
 // position data behind a sequence descriptor (cov_t of the reference, src/Ref.hh:41-53)
 DEV void desc_cov(const Ctx &c, uint32_t d, int sampleT, uint16_t *fwd, uint16_t *rev, uint16_t *qf, uint16_t *qr) {
   uint32_t km = SD_KMER(d);
-  const uint32_t *cn = c.W->ncnt + 4 * km;
+  const uint32_t *cn = c.W->hot[km].cnt;
   int o = sampleT ? 0 : 2;
   *fwd = (uint16_t)cn[o]; *rev = (uint16_t)cn[o + 1];
-  uint32_t q = c.W->nqv[km];
+  uint32_t q = c.W->gr[km].nqv;
   if (q == LC_NIL) { *qf = 0; *qr = 0; return; }
   const uint16_t *qq = c.W->qv + ((size_t)q * c.S->K + SD_OFF(d)) * 4;
   *qf = qq[o]; *qr = qq[o + 1];
 }
 DEV void desc_tot(const Ctx &c, uint32_t d, int *tot, int *totqv) {  // operands of Node_t::computeMinCov
   uint32_t km = SD_KMER(d);
-  const uint32_t *cn = c.W->ncnt + 4 * km;
+  const uint32_t *cn = c.W->hot[km].cnt;
   *tot = (int)(uint16_t)cn[0] + (int)(uint16_t)cn[1] + (int)(uint16_t)cn[2] + (int)(uint16_t)cn[3];
-  uint32_t q = c.W->nqv[km];
+  uint32_t q = c.W->gr[km].nqv;
   if (q == LC_NIL) { *totqv = 0; return; }
   const uint16_t *qq = c.W->qv + ((size_t)q * c.S->K + SD_OFF(d)) * 4;
   *totqv = (int)qq[0] + (int)qq[1] + (int)qq[2] + (int)qq[3];
@@ -403,7 +403,7 @@ DEVNI void order_insert(Ctx &c, uint32_t n) {
 DEVNI uint32_t clean_dead(Ctx &c) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   uint32_t m = 0, dead = 0;
-  for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (W.nflags[n] & NF_DEAD) ++dead; else W.order[m++] = n; }
+  for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (W.gr[n].flags & NF_DEAD) ++dead; else W.order[m++] = n; }
   S.M = m; S.ht_elt -= dead;
   evt(c, EV_CLEANDEAD, dead);
   return dead;
@@ -412,7 +412,7 @@ DEVNI void print_stats(Ctx &c, int comp) {                            // Graph_t
   if (!c.C->evt_cap) return;
   volatile WinShared &S = *c.S; Work &W = *c.W;
   int edgecnt = 0, span = 0;
-  for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (W.ncomp[n] == comp) { edgecnt += W.necnt[n]; span += n_strlen(c, n); } }
+  for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (W.gr[n].comp == comp) { edgecnt += W.gr[n].necnt; span += n_strlen(c, n); } }
   evt(c, EV_STATS, comp, S.M, edgecnt, span);
 }
 
@@ -421,15 +421,15 @@ DEVNI void print_stats(Ctx &c, int comp) {                            // Graph_t
 // ---------------------------------------------------------------------------------------------------------
 DEV bool seq_reserve(Ctx &c, uint32_t n, uint32_t front, uint32_t back) {   // room for `front` more before, `back` after
   Work &W = *c.W; volatile WinShared &S = *c.S;
-  uint32_t lo = W.nseq_lo[n], hi = W.nseq_hi[n];
-  if (lo - W.nseq_clo[n] >= front && W.nseq_chi[n] - hi >= back) return true;
+  uint32_t lo = W.gr[n].seq_lo, hi = W.gr[n].seq_hi;
+  if (lo - W.gr[n].seq_clo >= front && W.gr[n].seq_chi - hi >= back) return true;
   uint32_t len = hi - lo;
   uint32_t cap = 2 * (len + front + back) + 16;
   if (S.seq_top + cap > c.C->seq_cap) { OVF(c); return false; }
   uint32_t nclo = S.seq_top; S.seq_top += cap;
   uint32_t nlo = nclo + (cap - len - front - back) / 2 + front;
   for (uint32_t i = 0; i < len; ++i) W.seq[nlo + i] = W.seq[lo + i];
-  W.nseq_clo[n] = nclo; W.nseq_chi[n] = nclo + cap; W.nseq_lo[n] = nlo; W.nseq_hi[n] = nlo + len;
+  W.gr[n].seq_clo = nclo; W.gr[n].seq_chi = nclo + cap; W.gr[n].seq_lo = nlo; W.gr[n].seq_hi = nlo + len;
   return true;
 }
 
@@ -587,22 +587,22 @@ DEV void build_graph(Ctx &c) {
       uint32_t id = W.bitpre[f >> 5] + (uint32_t)dev_popc(ld2(&W.bitmap[f >> 5]) & ((1u << (f & 31)) - 1u));
       W.slot_node[i] = id;
       for (int w = 0; w < S.NW; ++w) W.nkey[(size_t)id * LC_NWMAX + w] = W.slot_key[(size_t)i * LC_NWMAX + w];
-      W.nflags[id] = (ld2(&W.tags[i]) >> 63) ? NF_NKMER : 0u;
+      W.hot[id].flags = (ld2(&W.tags[i]) >> 63) ? NF_NKMER : 0u;
     }
   }
   WG_SYNC();
   // ---- per node: std::hash of the ASCII k-mer, zeroed counters
   WG_FOR(n, S.N) {
     const unsigned long long *k = W.nkey + (size_t)n * LC_NWMAX;
-    if (W.nflags[n] & NF_NKMER) {
+    if (W.hot[n].flags & NF_NKMER) {
       const uint8_t *refc = c.B->ref_codes + c.B->ref_off[S.w];
       int p = (int)(k[0] >> 1); bool isR = (k[0] & 1ULL) != 0;
       W.nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGTN"[nk_char(refc, p, K, isR, j)]; }, K);
     } else W.nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGT"[key_base(k, K, j)]; }, K);
-    for (int j = 0; j < 4; ++j) W.ncnt[4 * n + j] = 0;
-    for (int j = 0; j < 10; ++j) { W.efirst[10 * n + j] = LC_NIL; W.eto[10 * n + j] = 0; }
-    W.necnt[n] = 0; W.ncomp[n] = 0; W.nocc[n] = 0; W.nfill[n] = 0; W.nqv[n] = LC_NIL; W.ncolor[n] = 0;
-    W.nonref[n] = 0; W.nkm[n] = 1; W.nkmT[n] = 0;
+    for (int j = 0; j < 4; ++j) W.hot[n].cnt[j] = 0;
+    for (int j = 0; j < 10; ++j) { W.hot[n].efirst[j] = LC_NIL; W.hot[n].eto[j] = 0; }
+    W.gr[n].necnt = 0; W.gr[n].comp = 0; W.hot[n].nocc = 0; W.hot[n].nfill = 0; W.gr[n].nqv = LC_NIL; W.gr[n].color = 0;
+    W.gr[n].onref = 0; W.gr[n].nkm = 1; W.gr[n].nkmT = 0;
   }
   // reads whose opposite mate (same name) comes earlier in the window: only these can ever see
   // hasOverlappingMate()==true (reference src/Node.cc:638-661); everything else is counted directly.
@@ -670,39 +670,54 @@ DEV void build_graph(Ctx &c) {
     uint32_t o0 = W.occ_base[r];
     int nk = tlen - K + 1;
     int ctr = isref ? -1 : ((RI_NML(rinfo) ? 2 : 0) + (RI_REV(rinfo) ? 1 : 0));
-    uint32_t prevnode = 0; uint32_t prevori = 0;
+    // every update of iteration p lands in the record of this k-mer's node (one or two cache lines):
+    // colour flags, counters, its edge to the next k-mer (as u of step p) and to the previous one (as v of step p-1)
+    uint32_t prevnode = 0, prevori = 0;
+    uint32_t oc = W.occ[o0];
+    uint32_t X = W.slot_node[oc & 0x3FFFFFFFu], ori = oc >> 31;
     for (int p = 0; p < nk; ++p) {
-      uint32_t oc = W.occ[o0 + p];
-      uint32_t X = W.slot_node[oc & 0x3FFFFFFFu], ori = oc >> 31;
       bool cd = (oc & 0x40000000u) != 0;       // needs the exact mate-overlap replay
+      uint32_t noc = 0, Y = 0, yori = 0;
+      if (p + 1 < nk) { noc = W.occ[o0 + p + 1]; Y = W.slot_node[noc & 0x3FFFFFFFu]; yori = noc >> 31; }
+      NodeHot &H = W.hot[X];
       uint32_t fl = 0;
       if (!isref) {
         if (RI_NML(rinfo)) fl |= NF_NORMAL;
         else if (step_all_good(c, isref, gw, p, tlen, K) || step_all_good(c, isref, gw, p - 1, tlen, K)) fl |= NF_TUMOR;
       }
-      if (fl) dev_atomic_or(&W.nflags[X], fl);
-      if (ctr >= 0 && !cd) dev_atomic_add(&W.ncnt[4 * X + ctr], 1u);
+      if (fl && (fl & ~ld2(&H.flags))) dev_atomic_or(&H.flags, fl);
+      if (ctr >= 0 && !cd) dev_atomic_add(&H.cnt[ctr], 1u);
       if (cd) { uint32_t t = dev_atomic_add((uint32_t *)&S.tmp1, 1u); if (t < c.C->table_cap) W.slot_first[t] = ((uint32_t)r << 10) | (uint32_t)p; else OVF(c); }
-      dev_atomic_add(&W.nocc[X], 1u);
-      if (p > 0) {   // step (p-1): u = prev, v = X   (Graph.cc:320-347)
-        uint32_t fdir = (prevori == 0) ? (ori == 0 ? 0u : 1u) : (ori == 0 ? 2u : 3u);     // FF FR RF RR
+      dev_atomic_add(&H.nocc, 1u);
+      // edge slots: (side, extension base in the node's canonical orientation); F side = right extension.
+      // index: ACGT -> side*4 + base, N -> 8 + side            (Graph.cc:320-347 for the directions)
+      if (p + 1 < nk) {            // step p: u = X, v = Y
+        uint32_t fdir = (ori == 0) ? (yori == 0 ? 0u : 1u) : (yori == 0 ? 2u : 3u);       // FF FR RF RR
+        int bnew = read_base(c, isref, bw, p + K);            // base that v adds after u
+        int eb = (ori == 0) ? bnew : n_comp(bnew);
+        uint32_t side = (ori == 0) ? 0u : 1u;
+        uint32_t sl = eb < 4 ? side * 4u + (uint32_t)eb : 8u + side;
+        uint32_t stamp = 2u * (o0 + (uint32_t)p);
+        uint32_t cur = ld2(&H.efirst[sl]);
+        if (cur > stamp) { uint32_t old = dev_atomic_min(&H.efirst[sl], stamp); if (old == LC_NIL) H.eto[sl] = ED_MAKE(Y, fdir); }
+      }
+      if (p > 0) {                 // step p-1: u = prev, v = X
         uint32_t rdir = (prevori == 0) ? (ori == 0 ? 3u : 1u) : (ori == 0 ? 2u : 0u);     // RR FR RF FF
-        int bnew = read_base(c, isref, bw, p + K - 1);      // base that v adds after u
-        int bold = read_base(c, isref, bw, p - 1);          // base that u has before v
-        // slot = (side, extension base in the node's canonical orientation): F side = right extension
-        uint32_t su = (prevori == 0) ? (uint32_t)bnew : 5u + (uint32_t)n_comp(bnew);
-        uint32_t sv = (ori == 0) ? 5u + (uint32_t)bold : (uint32_t)n_comp(bold);
-        uint32_t stamp = 2u * (o0 + (uint32_t)p - 1u);
-        W.eto[10 * prevnode + su] = ED_MAKE(X, fdir);
-        dev_atomic_min(&W.efirst[10 * prevnode + su], stamp);
-        W.eto[10 * X + sv] = ED_MAKE(prevnode, rdir);
-        dev_atomic_min(&W.efirst[10 * X + sv], stamp + 1u);
+        int bold = read_base(c, isref, bw, p - 1);           // base that u has before v
+        int eb = (ori == 0) ? bold : n_comp(bold);
+        uint32_t side = (ori == 0) ? 1u : 0u;
+        uint32_t sl = eb < 4 ? side * 4u + (uint32_t)eb : 8u + side;
+        uint32_t stamp = 2u * (o0 + (uint32_t)p - 1u) + 1u;
+        uint32_t cur = ld2(&H.efirst[sl]);
+        if (cur > stamp) { uint32_t old = dev_atomic_min(&H.efirst[sl], stamp); if (old == LC_NIL) H.eto[sl] = ED_MAKE(prevnode, rdir); }
       }
       W.occ[o0 + p] = X | (ori << 31) | (cd ? 0x40000000u : 0u);
       prevnode = X; prevori = ori;
+      oc = noc; X = Y; ori = yori;
     }
   }
   WG_SYNC();
+  WG_FOR(n, S.N) { W.nocc[n] = ld2(&W.hot[n].nocc); }
   // ---- csr of occurrences by node
   WG_LANE0 { W.nocc[S.N] = 0; }
   WG_SYNC();
@@ -716,7 +731,7 @@ DEV void build_graph(Ctx &c) {
       uint32_t oc = W.occ[o0 + p];
       uint32_t X = oc & 0x3FFFFFFFu;
       uint32_t st = isref ? 2u : ((oc & 0x40000000u) ? 1u : 0u);     // the reference read never counts (Graph.cc:265)
-      uint32_t at = W.nocc[X] + dev_atomic_add(&W.nfill[X], 1u);
+      uint32_t at = W.nocc[X] + dev_atomic_add(&W.hot[X].nfill, 1u);
       W.csr[at] = CS_MAKE(r, p, oc >> 31, st);
     }
   }
@@ -759,7 +774,7 @@ DEV void build_graph(Ctx &c) {
         while (len > 0) { uint32_t half = len >> 1; uint32_t mid = first + half; if (elem(mid) < nm) { first = mid + 1; len = len - half - 1; } else len = half; }
         bool ovl = (first != total) && !(nm < elem(first));
         uint32_t e = W.csr[self];
-        if (!ovl) { W.ncnt[4 * X + ctr] = ld2(&W.ncnt[4 * X + ctr]) + 1; W.csr[self] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), 0u); }
+        if (!ovl) { W.hot[X].cnt[ctr] = ld2(&W.hot[X].cnt[ctr]) + 1; W.csr[self] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), 0u); }
         else W.csr[self] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), 2u);
       }
     }
@@ -772,12 +787,12 @@ DEV void build_graph(Ctx &c) {
   const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
   WG_FOR(n, S.N) {
     uint32_t stamp[10]; uint32_t tgt[10]; int ne = 0;
-    for (int j = 0; j < 10; ++j) { uint32_t ef = ld2(&W.efirst[10 * n + j]); if (ef != LC_NIL) { stamp[ne] = ef; tgt[ne] = W.eto[10 * n + j]; ++ne; } }
+    for (int j = 0; j < 10; ++j) { uint32_t ef = ld2(&W.hot[n].efirst[j]); if (ef != LC_NIL) { stamp[ne] = ef; tgt[ne] = W.hot[n].eto[j]; ++ne; } }
     for (int i = 1; i < ne; ++i) { uint32_t s = stamp[i], t = tgt[i]; int j = i; while (j > 0 && stamp[j - 1] > s) { stamp[j] = stamp[j - 1]; tgt[j] = tgt[j - 1]; --j; } stamp[j] = s; tgt[j] = t; }
-    for (int i = 0; i < ne; ++i) W.edges[n * LC_EMAX + i] = tgt[i];
-    W.necnt[n] = ne;
+    for (int i = 0; i < ne; ++i) W.gr[n].edges[i] = tgt[i];
+    W.gr[n].necnt = ne;
     uint32_t cn[4];
-    for (int j = 0; j < 4; ++j) { cn[j] = ld2(&W.ncnt[4 * n + j]); W.ncov[4 * n + j] = (float)cn[j]; }
+    for (int j = 0; j < 4; ++j) { cn[j] = ld2(&W.hot[n].cnt[j]); W.gr[n].cov[j] = (float)cn[j]; }
     int tot = (int)(uint16_t)cn[0] + (int)(uint16_t)cn[1] + (int)(uint16_t)cn[2] + (int)(uint16_t)cn[3];
     // per position of the k-mer: number of counted reads whose base there passes MIN_QUAL_CALL, per strand/sample
     // (Node_t::updateCovDistr minqv_fwd/minqv_rev, reference src/Node.cc:470-497).  One pass over the node's
@@ -809,8 +824,8 @@ DEV void build_graph(Ctx &c) {
     }
     int minqv = 10000000;
     for (int i = 0; i < K; ++i) { int sq = (int)pc[i] + (int)pc[K + i] + (int)pc[2 * K + i] + (int)pc[3 * K + i]; if (sq < minqv) minqv = sq; }
-    W.nmincov[n] = tot; W.nmincovqv[n] = minqv;
-    float tt = W.ncov[4 * n] + W.ncov[4 * n + 1], tn = W.ncov[4 * n + 2] + W.ncov[4 * n + 3];
+    W.gr[n].mincov = tot; W.gr[n].mincovqv = minqv;
+    float tt = W.gr[n].cov[0] + W.gr[n].cov[1], tn = W.gr[n].cov[2] + W.gr[n].cov[3];
     bool low = (minqv <= c.P->low_cov_threshold) || ((double)minqv <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
     if (!low) {
       // survivor of the first removeLowCov: keep the per-position counts and start its sequence-descriptor deque
@@ -822,11 +837,11 @@ DEV void build_graph(Ctx &c) {
         uint32_t base = qi * (uint32_t)K;
         const unsigned long long *kk = W.nkey + (size_t)n * LC_NWMAX;
         for (int i = 0; i < K; ++i) W.seq[base + i] = SD_MAKE(n, i, key_base(kk, K, i));
-        W.nseq_clo[n] = base; W.nseq_lo[n] = base; W.nseq_hi[n] = base + K; W.nseq_chi[n] = base + K;
-        uint32_t fl = ld2(&W.nflags[n]);
-        W.nkmT[n] = ((fl & NF_TUMOR) && !(fl & NF_NORMAL)) ? 1u : 0u;      // cov_status == 'T'
-        W.nqv[n] = qi;
-        dev_atomic_or(&W.nflags[n], NF_SURV);
+        W.gr[n].seq_clo = base; W.gr[n].seq_lo = base; W.gr[n].seq_hi = base + K; W.gr[n].seq_chi = base + K;
+        uint32_t fl = ld2(&W.hot[n].flags);
+        W.gr[n].nkmT = ((fl & NF_TUMOR) && !(fl & NF_NORMAL)) ? 1u : 0u;      // cov_status == 'T'
+        W.gr[n].nqv = qi;
+        dev_atomic_or(&W.hot[n].flags, NF_SURV);
       }
     }
   }
@@ -840,7 +855,7 @@ DEV void build_graph(Ctx &c) {
     bool loaded = (S.reflen - K > 0);
     WG_FOR(i, S.seq_len - K > 0 ? S.seq_len - K : 0) {     // i + K < seq.length()
       int p = S.seq_t5 + i;
-      if (loaded && p < nrefk) dev_atomic_or(&W.nflags[W.occ[ro + p] & 0x3FFFFFFFu], NF_INMER);
+      if (loaded && p < nrefk) dev_atomic_or(&W.hot[W.occ[ro + p] & 0x3FFFFFFFu].flags, NF_INMER);
     }
     WG_SYNC();
     // ---- Ref_t::computeCoverage (reference src/Ref.cc:173-250): per rawseq position, Tf Tr Nf Nr
@@ -849,10 +864,11 @@ DEV void build_graph(Ctx &c) {
     WG_FOR(i, S.reflen - K > 0 ? S.reflen - K : 0) {       // i + K < rawseq.length()
       uint32_t X = W.occ[ro + i] & 0x3FFFFFFFu;
       uint16_t v[4] = {0, 0, 0, 0};
-      if (ld2(&W.nflags[X]) & NF_INMER) for (int q = 0; q < 4; ++q) v[q] = (uint16_t)ld2(&W.ncnt[4 * X + q]);
+      if (ld2(&W.hot[X].flags) & NF_INMER) for (int q = 0; q < 4; ++q) v[q] = (uint16_t)ld2(&W.hot[X].cnt[q]);
       if (i == 0) { for (int j = 0; j < K; ++j) for (int q = 0; q < 4; ++q) W.refcov[4 * j + q] = v[q]; }
       else { for (int q = 0; q < 4; ++q) W.refcov[4 * (i + K - 1) + q] = v[q]; }
     }
+    WG_FOR(n, S.N) { W.gr[n].flags = ld2(&W.hot[n].flags); }     // the graph passes work on NodeGr only
     WG_SYNC_FENCE();   // from here on the node arrays are only touched with plain loads/stores: one L1 invalidate
   }
 }
@@ -877,9 +893,9 @@ DEV void first_lowcov(Ctx &c) {
 DEV void recompute_after_append(Ctx &c, uint32_t n, uint32_t from, uint32_t to) {
   // Node_t::computeMinCov over the merged arrays == min(old minima, minima over the appended descriptors)
   Work &W = *c.W;
-  int mn = W.nmincov[n], mq = W.nmincovqv[n];
+  int mn = W.gr[n].mincov, mq = W.gr[n].mincovqv;
   for (uint32_t i = from; i < to; ++i) { int t, tq; desc_tot(c, W.seq[i], &t, &tq); if (t < mn) mn = t; if (tq < mq) mq = tq; }
-  W.nmincov[n] = mn; W.nmincovqv[n] = mq;
+  W.gr[n].mincov = mn; W.gr[n].mincovqv = mq;
 }
 
 DEVNI void compress_node(Ctx &c, uint32_t node, char dir) {          // Graph_t::compressNode, reference src/Graph.cc:2486-2706
@@ -889,7 +905,7 @@ DEVNI void compress_node(Ctx &c, uint32_t node, char dir) {          // Graph_t:
     int uid = get_buddy(c, node, dir);
     if (uid == -1) return;
     if (is_tandem(c, node)) return;
-    uint32_t ew = W.edges[node * LC_EMAX + uid];
+    uint32_t ew = W.gr[node].edges[uid];
     uint32_t edir = ED_DIR(ew);
     char bdir = (edir == 0 || edir == 2) ? 'R' : 'F';
     uint32_t buddy = ED_TO(ew);
@@ -902,45 +918,45 @@ DEVNI void compress_node(Ctx &c, uint32_t node, char dir) {          // Graph_t:
     // merged = astr + bstr[K-1:]  (dir F: append ; dir R: prepend the reverse complement)
     if (dir == 'F') {
       if (!seq_reserve(c, node, 0, tail)) return;
-      uint32_t hi = W.nseq_hi[node], blo = W.nseq_lo[buddy], bhi = W.nseq_hi[buddy];
+      uint32_t hi = W.gr[node].seq_hi, blo = W.gr[buddy].seq_lo, bhi = W.gr[buddy].seq_hi;
       for (uint32_t t = 0; t < tail; ++t) {
         uint32_t d = brev ? W.seq[bhi - 1 - ((uint32_t)(K - 1) + t)] : W.seq[blo + (uint32_t)(K - 1) + t];
         if (brev) d ^= 3u;
         W.seq[hi + t] = d;
       }
-      W.nseq_hi[node] = hi + tail;
+      W.gr[node].seq_hi = hi + tail;
       recompute_after_append(c, node, hi, hi + tail);
     } else {
       if (!seq_reserve(c, node, tail, 0)) return;
-      uint32_t lo = W.nseq_lo[node], blo = W.nseq_lo[buddy], bhi = W.nseq_hi[buddy];
+      uint32_t lo = W.gr[node].seq_lo, blo = W.gr[buddy].seq_lo, bhi = W.gr[buddy].seq_hi;
       // element t of B'[K-1:] lands at lo-1-t, complemented
       for (uint32_t t = 0; t < tail; ++t) {
         uint32_t d = brev ? W.seq[bhi - 1 - ((uint32_t)(K - 1) + t)] : W.seq[blo + (uint32_t)(K - 1) + t];
         if (brev) d ^= 3u;
         W.seq[lo - 1 - t] = d ^ 3u;
       }
-      W.nseq_lo[node] = lo - tail;
+      W.gr[node].seq_lo = lo - tail;
       recompute_after_append(c, node, lo - tail, lo);
     }
-    W.nkm[node] += W.nkm[buddy]; W.nkmT[node] += W.nkmT[buddy];
+    W.gr[node].nkm += W.gr[buddy].nkm; W.gr[node].nkmT += W.gr[buddy].nkmT;
     int amer = alen - K + 1, bmer = blen - K + 1;
-    float *nc = W.ncov + 4 * node; const float *bc = W.ncov + 4 * buddy;
+    float *nc = W.gr[node].cov; const float *bc = W.gr[buddy].cov;
     for (int q = 0; q < 4; ++q) nc[q] = ((nc[q] * amer) + (bc[q] * bmer)) / (amer + bmer);      // Graph.cc:2632-2636
-    W.nflags[buddy] |= NF_DEAD;
-    W.nflags[node] |= (W.nflags[buddy] & (NF_TUMOR | NF_NORMAL));
+    W.gr[buddy].flags |= NF_DEAD;
+    W.gr[node].flags |= (W.gr[buddy].flags & (NF_TUMOR | NF_NORMAL));
     erase_edge_at(c, node, uid);
-    int bcnt = (int)W.necnt[buddy];
+    int bcnt = (int)W.gr[buddy].necnt;
     for (int i = 0; i < bcnt; ++i) {
       if (i == buid) continue;
-      uint32_t be = W.edges[buddy * LC_EMAX + i];
+      uint32_t be = W.gr[buddy].edges[i];
       uint32_t ndir = ED_DIR(be);
       if (edir == 1 || edir == 2) ndir = flipme(ndir);
       uint32_t other = ED_TO(be);
-      int cnt = (int)W.necnt[node];
+      int cnt = (int)W.gr[node].necnt;
       if (cnt >= LC_EMAX) { OVF(c); return; }
-      if (other == buddy) { W.edges[node * LC_EMAX + cnt] = ED_MAKE(node, ndir) | (be & (1u << 30)); W.necnt[node] = cnt + 1; }
+      if (other == buddy) { W.gr[node].edges[cnt] = ED_MAKE(node, ndir) | (be & (1u << 30)); W.gr[node].necnt = cnt + 1; }
       else {
-        W.edges[node * LC_EMAX + cnt] = ED_MAKE(other, ndir) | (be & (1u << 30)); W.necnt[node] = cnt + 1;
+        W.gr[node].edges[cnt] = ED_MAKE(other, ndir) | (be & (1u << 30)); W.gr[node].necnt = cnt + 1;
         update_edge(c, other, buddy, fliplink(ED_DIR(be)), node, fliplink(ndir));
       }
     }
@@ -951,9 +967,9 @@ DEVNI void compress(Ctx &c, int comp) {                               // referen
   evt(c, EV_COMPRESS);
   for (uint32_t i = 0; i < S.M && !S.overflow; ++i) {
     uint32_t n = W.order[i];
-    if (W.ncomp[n] != comp) continue;
-    if (W.nflags[n] & NF_DEAD) continue;
-    if (W.nflags[n] & NF_SPECIAL) continue;
+    if (W.gr[n].comp != comp) continue;
+    if (W.gr[n].flags & NF_DEAD) continue;
+    if (W.gr[n].flags & NF_SPECIAL) continue;
     compress_node(c, n, 'F');
     compress_node(c, n, 'R');
   }
@@ -965,10 +981,10 @@ DEVNI void remove_low_cov(Ctx &c, int comp) {                         // referen
   uint32_t low = 0;
   for (uint32_t i = 0; i < S.M; ++i) {
     uint32_t n = W.order[i];
-    if (W.ncomp[n] != comp) continue;
-    if (W.nflags[n] & NF_SPECIAL) continue;
-    int mq = W.nmincovqv[n];
-    float tt = W.ncov[4 * n] + W.ncov[4 * n + 1], tn = W.ncov[4 * n + 2] + W.ncov[4 * n + 3];
+    if (W.gr[n].comp != comp) continue;
+    if (W.gr[n].flags & NF_SPECIAL) continue;
+    int mq = W.gr[n].mincovqv;
+    float tt = W.gr[n].cov[0] + W.gr[n].cov[1], tn = W.gr[n].cov[2] + W.gr[n].cov[3];
     if ((mq <= c.P->low_cov_threshold) || ((double)mq <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f)) { ++low; remove_node(c, n); }
   }
   evt(c, EV_LOWCOV, low);
@@ -1022,7 +1038,7 @@ DEVNI bool find_tandems(const Ctx &c, const uint8_t *seq, int n, int pos, int *l
 
 DEV void node_string(const Ctx &c, uint32_t n, uint8_t *out) {      // str_m as codes
   const Work &W = *c.W;
-  uint32_t lo = W.nseq_lo[n], hi = W.nseq_hi[n];
+  uint32_t lo = W.gr[n].seq_lo, hi = W.gr[n].seq_hi;
   for (uint32_t i = lo; i < hi; ++i) out[i - lo] = (uint8_t)SD_BASE(W.seq[i]);
 }
 
@@ -1034,9 +1050,9 @@ DEVNI void remove_tips(Ctx &c, int comp) {                            // referen
     evt(c, EV_TIPS_ROUND, round);
     for (uint32_t i = 0; i < S.M; ++i) {
       uint32_t n = W.order[i];
-      if (W.ncomp[n] != comp) continue;
-      if (W.nflags[n] & NF_SPECIAL) continue;
-      int deg = (int)W.necnt[n], len = n_strlen(c, n) - S.K + 1;
+      if (W.gr[n].comp != comp) continue;
+      if (W.gr[n].flags & NF_SPECIAL) continue;
+      int deg = (int)W.gr[n].necnt, len = n_strlen(c, n) - S.K + 1;
       if (deg <= 1 && len < c.P->max_tip_len) { remove_node(c, n); ++tips; }
     }
     evt(c, EV_TIPS_REMOVED, tips);
@@ -1052,10 +1068,10 @@ DEVNI void remove_short_links(Ctx &c, int comp) {                     // referen
   int links = 0;
   for (uint32_t i = 0; i < S.M; ++i) {
     uint32_t n = W.order[i];
-    if (W.ncomp[n] != comp) continue;
-    if (W.nflags[n] & NF_SPECIAL) continue;
-    int deg = (int)W.necnt[n], len = n_len(c, n) - S.K + 1;
-    if (deg >= 2 && len < max_link_len && (double)W.nmincov[n] <= thr) {
+    if (W.gr[n].comp != comp) continue;
+    if (W.gr[n].flags & NF_SPECIAL) continue;
+    int deg = (int)W.gr[n].necnt, len = n_len(c, n) - S.K + 1;
+    if (deg >= 2 && len < max_link_len && (double)W.gr[n].mincov <= thr) {
       int L = 0, ml = 0; uint8_t motif[64];
       int sl = n_len(c, n);
       if (sl > (int)c.C->path_cap) { OVF(c); return; }
@@ -1071,27 +1087,27 @@ DEVNI void remove_short_links(Ctx &c, int comp) {                     // referen
 
 DEVNI int mark_connected_components(Ctx &c) {                         // reference src/Graph.cc:2252-2336
   volatile WinShared &S = *c.S; Work &W = *c.W;
-  for (uint32_t i = 0; i < S.M; ++i) W.ncomp[W.order[i]] = 0;
+  for (uint32_t i = 0; i < S.M; ++i) W.gr[W.order[i]].comp = 0;
   int comp = 0, refcomp = 0;
   uint32_t *Q = W.scratch;                                            // FIFO; every node enqueued <= deg+1 times
   uint32_t qcap = 2 * (c.C->node_cap + c.C->special_cap);
   evt(c, EV_CC, S.M);
   for (uint32_t i = 0; i < S.M; ++i) {
     uint32_t s = W.order[i];
-    if (W.ncomp[s] != 0) continue;
+    if (W.gr[s].comp != 0) continue;
     ++comp;
     uint32_t qh = 0, qt = 0;
     int touches = 0;
     // breadth-first; a node is labelled when first reached (the reference labels on pop; same partition)
-    W.ncomp[s] = comp; Q[qt++] = s;
+    W.gr[s].comp = comp; Q[qt++] = s;
     while (qh < qt) {
       uint32_t cur = Q[qh++];
-      if (W.nflags[cur] & NF_INMER) ++touches;
-      for (int e = 0; e < (int)W.necnt[cur]; ++e) {
-        uint32_t nx = ED_TO(W.edges[cur * LC_EMAX + e]);
-        if (W.ncomp[nx] != 0) continue;
+      if (W.gr[cur].flags & NF_INMER) ++touches;
+      for (int e = 0; e < (int)W.gr[cur].necnt; ++e) {
+        uint32_t nx = ED_TO(W.gr[cur].edges[e]);
+        if (W.gr[nx].comp != 0) continue;
         if (qt >= qcap) { OVF(c); return comp; }
-        W.ncomp[nx] = comp; Q[qt++] = nx;
+        W.gr[nx].comp = comp; Q[qt++] = nx;
       }
     }
     if (touches) { ++refcomp; evt(c, EV_CCID, comp); }
@@ -1113,10 +1129,10 @@ DEV uint32_t special_new(Ctx &c, bool issource, int comp) {
   char digs[12]; int nd = 0; int v = comp; do { digs[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
   while (nd) name[L++] = digs[--nd];
   W.nhash[id] = std_hash_bytes([&](int j) -> int { return (int)(unsigned char)name[j]; }, L);
-  for (int q = 0; q < 4; ++q) { W.ncnt[4 * id + q] = 0; W.ncov[4 * id + q] = 0.0f; }
-  W.nflags[id] = issource ? NF_SOURCE : NF_SINK;
-  W.necnt[id] = 0; W.ncomp[id] = comp; W.nmincov[id] = 0; W.nmincovqv[id] = 0; W.nqv[id] = LC_NIL; W.ncolor[id] = 0;
-  W.nseq_lo[id] = W.nseq_hi[id] = W.nseq_clo[id] = W.nseq_chi[id] = 0; W.nkm[id] = 0; W.nkmT[id] = 0; W.nonref[id] = 0;
+  for (int q = 0; q < 4; ++q) { W.hot[id].cnt[q] = 0; W.gr[id].cov[q] = 0.0f; }
+  W.gr[id].flags = issource ? NF_SOURCE : NF_SINK;
+  W.gr[id].necnt = 0; W.gr[id].comp = comp; W.gr[id].mincov = 0; W.gr[id].mincovqv = 0; W.gr[id].nqv = LC_NIL; W.gr[id].color = 0;
+  W.gr[id].seq_lo = W.gr[id].seq_hi = W.gr[id].seq_clo = W.gr[id].seq_chi = 0; W.gr[id].nkm = 0; W.gr[id].nkmT = 0; W.gr[id].onref = 0;
   return id;
 }
 DEVNI void mark_ref_ends(Ctx &c, int comp) {
@@ -1130,8 +1146,8 @@ DEVNI void mark_ref_ends(Ctx &c, int comp) {
   bool amb = false;
   for (int off = 0; off < nrefk; ++off) {
     uint32_t oc = W.occ[ro + off]; uint32_t t = oc & 0x3FFFFFFFu;
-    if ((W.nflags[t] & NF_DEAD) || !(W.nflags[t] & NF_SURV)) continue;
-    if (n_totcov(c, t) >= (float)c.P->cov_threshold && W.ncomp[t] == comp) {
+    if ((W.gr[t].flags & NF_DEAD) || !(W.gr[t].flags & NF_SURV)) continue;
+    if (n_totcov(c, t) >= (float)c.P->cov_threshold && W.gr[t].comp == comp) {
       if (src == LC_NIL) { src = t; src_ori = oc >> 31; src_off = off; }
       else if (src == t) { src = LC_NIL; amb = true; break; }
     }
@@ -1141,8 +1157,8 @@ DEVNI void mark_ref_ends(Ctx &c, int comp) {
   for (int off = S.reflen - K; off >= 0; --off) {
     if (off >= nrefk) continue;
     uint32_t oc = W.occ[ro + off]; uint32_t t = oc & 0x3FFFFFFFu;
-    if ((W.nflags[t] & NF_DEAD) || !(W.nflags[t] & NF_SURV)) continue;
-    if (n_totcov(c, t) >= (float)c.P->cov_threshold && W.ncomp[t] == comp) {
+    if ((W.gr[t].flags & NF_DEAD) || !(W.gr[t].flags & NF_SURV)) continue;
+    if (n_totcov(c, t) >= (float)c.P->cov_threshold && W.gr[t].comp == comp) {
       if (snk == LC_NIL) { snk = t; snk_ori = oc >> 31; snk_off = off; }
       else if (snk == t) { snk = LC_NIL; amb = true; break; }
     }
@@ -1158,8 +1174,8 @@ DEVNI void mark_ref_ends(Ctx &c, int comp) {
   uint32_t ns = special_new(c, true, comp); if (ns == LC_NIL) return;
   uint32_t sourcedir = src_ori ? 1u : 0u;                              // FF, or FR when the k-mer is reversed
   char flip = src_ori ? 'F' : 'R';                                     // Edge_t::flipdir(source_mer.ori_m)
-  for (int i = (int)W.necnt[src] - 1; i >= 0; --i) {
-    uint32_t e = W.edges[src * LC_EMAX + i];
+  for (int i = (int)W.gr[src].necnt - 1; i >= 0; --i) {
+    uint32_t e = W.gr[src].edges[i];
     if (dir_start(ED_DIR(e)) == flip) {
       uint32_t other = ED_TO(e);
       if (other != src) { remove_edge(c, other, src, fliplink(ED_DIR(e))); erase_edge_at(c, src, i); }
@@ -1173,8 +1189,8 @@ DEVNI void mark_ref_ends(Ctx &c, int comp) {
   uint32_t nk = special_new(c, false, comp); if (nk == LC_NIL) return;
   uint32_t sinkdir = snk_ori ? 0u : 3u;                                // RR, or FF when reversed
   char same = snk_ori ? 'R' : 'F';
-  for (int i = (int)W.necnt[snk] - 1; i >= 0; --i) {
-    uint32_t e = W.edges[snk * LC_EMAX + i];
+  for (int i = (int)W.gr[snk].necnt - 1; i >= 0; --i) {
+    uint32_t e = W.gr[snk].edges[i];
     if (dir_start(ED_DIR(e)) == same) {
       uint32_t other = ED_TO(e);
       if (other != snk) { remove_edge(c, other, snk, fliplink(ED_DIR(e))); erase_edge_at(c, snk, i); }
@@ -1189,33 +1205,33 @@ DEVNI void mark_ref_ends(Ctx &c, int comp) {
 DEVNI bool has_cycle(Ctx &c) {                                         // reference src/Graph.cc:593-681
   volatile WinShared &S = *c.S; Work &W = *c.W;
   if (S.source == LC_NIL || S.sink == LC_NIL) return false;
-  for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (!(W.nflags[n] & NF_SPECIAL)) W.ncolor[n] = 1; }
+  for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (!(W.gr[n].flags & NF_SPECIAL)) W.gr[n].color = 1; }
   bool ans = false;
   // explicit stack of (node, next edge index, dir)
   uint32_t *st = W.scratch; uint32_t cap = (2 * (c.C->node_cap + c.C->special_cap)) / 3;
   for (int pass = 0; pass < 2 && !ans; ++pass) {
     uint32_t sp = 0;
     st[0] = S.source; st[1] = 0; st[2] = (uint32_t)(pass == 0 ? 'F' : 'R'); sp = 1;
-    W.ncolor[S.source] = 2;
+    W.gr[S.source].color = 2;
     while (sp && !ans) {
       uint32_t *fr = st + 3 * (sp - 1);
       uint32_t node = fr[0]; char dir = (char)fr[2];
       bool descended = false;
-      while (fr[1] < W.necnt[node]) {
-        uint32_t e = W.edges[node * LC_EMAX + fr[1]]; ++fr[1];
+      while (fr[1] < W.gr[node].necnt) {
+        uint32_t e = W.gr[node].edges[fr[1]]; ++fr[1];
         if (!is_dir(ED_DIR(e), dir)) continue;
         uint32_t other = ED_TO(e);
-        if (W.nflags[other] & NF_SPECIAL) continue;
-        if (W.ncolor[other] == 2) { ans = true; break; }
-        if (W.ncolor[other] == 1) {
+        if (W.gr[other].flags & NF_SPECIAL) continue;
+        if (W.gr[other].color == 2) { ans = true; break; }
+        if (W.gr[other].color == 1) {
           if (sp >= cap) { OVF(c); return false; }
-          W.ncolor[other] = 2;
+          W.gr[other].color = 2;
           uint32_t *nf = st + 3 * sp; nf[0] = other; nf[1] = 0; nf[2] = (uint32_t)dir_dest(ED_DIR(e)); ++sp;
           descended = true; break;
         }
       }
       if (ans) break;
-      if (!descended) { W.ncolor[node] = 3; --sp; }
+      if (!descended) { W.gr[node].color = 3; --sp; }
     }
   }
   if (ans) evt(c, EV_CYCLE, S.K);
@@ -1250,9 +1266,9 @@ DEVNI uint32_t bfs(Ctx &c) {
       if (best == LC_NIL) best = idx; else if (cur.score > Q[best].score) best = idx;
     } else if (cur.len > reflen + c.P->max_indel_len) {
     } else {
-      int cnt = (int)W.necnt[cur.node];
+      int cnt = (int)W.gr[cur.node].necnt;
       for (int i = 0; i < cnt; ++i) {
-        uint32_t e = W.edges[cur.node * LC_EMAX + i];
+        uint32_t e = W.gr[cur.node].edges[i];
         if (!is_dir(ED_DIR(e), (char)cur.dir)) continue;
         uint32_t other = ED_TO(e);
         if (!(Q[idx].bits & 2) && path_has_node(c, idx, other)) Q[idx].bits |= 2;     // Path_t::hasCycle (informational)
@@ -1283,7 +1299,7 @@ DEV void path_flag_edges(Ctx &c, int n, uint32_t v) {
   Work &W = *c.W;
   for (int j = 1; j < n; ++j) {
     uint32_t owner = W.pedges[j] >> 4, ei = W.pedges[j] & 15u;
-    uint32_t *e = &W.edges[owner * LC_EMAX + ei];
+    uint32_t *e = &W.gr[owner].edges[ei];
     *e = (*e & ~(1u << 30)) | (v << 30);
   }
 }
@@ -1292,12 +1308,12 @@ DEVNI int path_string(Ctx &c, int n) {
   Work &W = *c.W; volatile WinShared &S = *c.S;
   const int K = S.K;
   int len = 0;
-  uint32_t e1 = W.edges[(W.pedges[1] >> 4) * LC_EMAX + (W.pedges[1] & 15u)];
+  uint32_t e1 = W.gr[(W.pedges[1] >> 4)].edges[(W.pedges[1] & 15u)];
   char dir = dir_start(ED_DIR(e1));
   for (int i = 0; i < n; ++i) {
     uint32_t nd = W.pnodes[i];
-    if (!(W.nflags[nd] & NF_SPECIAL)) {
-      uint32_t lo = W.nseq_lo[nd], hi = W.nseq_hi[nd];
+    if (!(W.gr[nd].flags & NF_SPECIAL)) {
+      uint32_t lo = W.gr[nd].seq_lo, hi = W.gr[nd].seq_hi;
       int L = (int)(hi - lo);
       int from = len > 0 ? K - 1 : 0;
       if (len + L - from > (int)c.C->path_cap) { OVF(c); return 0; }
@@ -1307,7 +1323,7 @@ DEVNI int path_string(Ctx &c, int n) {
       }
     }
     if (i + 1 < n) {
-      uint32_t e = W.edges[(W.pedges[i + 1] >> 4) * LC_EMAX + (W.pedges[i + 1] & 15u)];
+      uint32_t e = W.gr[(W.pedges[i + 1] >> 4)].edges[(W.pedges[i + 1] & 15u)];
       dir = dir_dest(ED_DIR(e));
     }
   }
@@ -1318,7 +1334,7 @@ DEV uint32_t path_contig(const Ctx &c, int n, int pos) {            // Path_t::p
   int cur = 0;
   for (int i = 0; i < n; ++i) {
     uint32_t nd = W.pnodes[i];
-    if (W.nflags[nd] & NF_SPECIAL) continue;
+    if (W.gr[nd].flags & NF_SPECIAL) continue;
     int span = n_len(c, nd);
     if (cur + span >= pos) return nd;
     cur += span - c.S->K + 1;
@@ -1326,7 +1342,7 @@ DEV uint32_t path_contig(const Ctx &c, int n, int pos) {            // Path_t::p
   return LC_NIL;
 }
 DEV bool status_cnt_T(const Ctx &c, uint32_t n) {                   // Node_t::isStatusCnt('T'), reference src/Node.cc:423-440
-  double pr = (double)c.W->nkmT[n] / (double)c.W->nkm[n];
+  double pr = (double)c.W->gr[n].nkmT / (double)c.W->gr[n].nkm;
   return pr > 0.8;
 }
 
@@ -1384,38 +1400,46 @@ DEVNI void align_fill(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m
   for (int i = lane + 1; i < n + 1; i += 64) W.tb[(size_t)i * stride] = (uint8_t)(1 | (2 << 2) | (0 << 4));     // M[i][0] '<' ; X[i][0] '*'
   constexpr int GMAX = (LC_MAXW + 63) / 64;
   const int G = (n + 63) / 64;
-  int mL[GMAX], xL[GMAX], yL[GMAX], upM2[GMAX], sg[GMAX];
+  // per row: M, X (packed 16+16 in A) and Y, M(i-1,j-1) (packed in B); all scores fit 16 bits (|score| < 4*1280)
+  int A[GMAX], Bv[GMAX], sg[GMAX];
+  auto lo16 = [](int v) -> int { return (int)(short)(v & 0xFFFF); };
+  auto hi16 = [](int v) -> int { return v >> 16; };
+  auto pack = [](int lo, int hi) -> int { return (lo & 0xFFFF) | (hi << 16); };
 #pragma unroll
   for (int g = 0; g < GMAX; ++g) {
     int i = g * 64 + lane + 1;
-    mL[g] = -8 - i; yL[g] = -8 - i; xL[g] = 0;                      // M(i,0) = Y(i,0) = GAP_OPEN + i*GAP_EXTEND
-    upM2[g] = (i - 1 == 0) ? 0 : -8 - (i - 1);                       // M(i-1,0)
+    A[g] = pack(-8 - i, 0);                                          // M(i,0) = GAP_OPEN + i*GAP_EXTEND ; X(i,0) unused
+    Bv[g] = pack(-8 - i, (i - 1 == 0) ? 0 : -8 - (i - 1));           // Y(i,0) ; M(i-1,0)
     sg[g] = (i <= n) ? (int)Sx[i - 1] : 255;
   }
   for (int t = 2; t <= n + m; ++t) {
-    int pM[GMAX], pX[GMAX];
+    // groups are visited from the last row block to the first, so that the values of block g-1 (and of the lane
+    // above) are still those of step t-1 when block g needs them
 #pragma unroll
-    for (int g = 0; g < GMAX; ++g) { pM[g] = mL[g]; pX[g] = xL[g]; }
-#pragma unroll
-    for (int g = 0; g < GMAX; ++g) {
+    for (int gg = 0; gg < GMAX; ++gg) {
+      const int g = GMAX - 1 - gg;
       if (g < G) {
-      int i = g * 64 + lane + 1, j = t - i;
-      int nbM = __shfl_up(pM[g], 1), nbX = __shfl_up(pX[g], 1);
-      if (g > 0) { int eM = __shfl(pM[g > 0 ? g - 1 : 0], 63), eX = __shfl(pX[g > 0 ? g - 1 : 0], 63); if (lane == 0) { nbM = eM; nbX = eX; } }
-      else if (lane == 0) { nbM = -8 - j; nbX = -8 - j; }             // row 0: M(0,j) = X(0,j)
-      bool active = (i <= n) && (j >= 1) && (j <= m);
-      if (active) {
-        int xa = nbX - 1, xb = nbM - 8;
-        int xs, xt; if (xa > xb) { xs = xa; xt = 1; } else { xs = xb; xt = 0; }
-        int ya = yL[g] - 1, yb = pM[g] - 8;
-        int ys, yt; if (ya > yb) { ys = ya; yt = 1; } else { ys = yb; yt = 0; }
-        int ms = upM2[g] + (sg[g] == (int)Tx[j - 1] ? 2 : -4), mt = 0;
-        if (xs > ms) { ms = xs; mt = 1; }
-        if (ys > ms) { ms = ys; mt = 2; }
-        mL[g] = ms; xL[g] = xs; yL[g] = ys;
-        W.tb[(size_t)i * stride + j] = (uint8_t)(mt | (xt << 2) | (yt << 4));
-      }
-      if (j >= 1) upM2[g] = nbM;                                      // M(i-1,j) is next step's M(i-1,j-1)
+        int i = g * 64 + lane + 1, j = t - i;
+        int nb = __shfl_up(A[g], 1);
+        if (g > 0) { int e = __shfl(A[g > 0 ? g - 1 : 0], 63); if (lane == 0) nb = e; }
+        else if (lane == 0) nb = pack(-8 - j, -8 - j);                 // row 0: M(0,j) = X(0,j)
+        int nbM = lo16(nb), nbX = hi16(nb);
+        bool active = (i <= n) && (j >= 1) && (j <= m);
+        int bv = Bv[g];
+        if (active) {
+          int xa = nbX - 1, xb = nbM - 8;
+          int xs, xt; if (xa > xb) { xs = xa; xt = 1; } else { xs = xb; xt = 0; }
+          int ya = lo16(bv) - 1, yb = lo16(A[g]) - 8;
+          int ys, yt; if (ya > yb) { ys = ya; yt = 1; } else { ys = yb; yt = 0; }
+          int ms = hi16(bv) + (sg[g] == (int)Tx[j - 1] ? 2 : -4), mt = 0;
+          if (xs > ms) { ms = xs; mt = 1; }
+          if (ys > ms) { ms = ys; mt = 2; }
+          A[g] = pack(ms, xs);
+          bv = pack(ys, hi16(bv));
+          W.tb[(size_t)i * stride + j] = (uint8_t)(mt | (xt << 2) | (yt << 4));
+        }
+        if (j >= 1) bv = pack(lo16(bv), nbM);                            // M(i-1,j) is next step's M(i-1,j-1)
+        Bv[g] = bv;
       }
     }
   }
@@ -1597,7 +1621,7 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
     }
   }
   evt(c, EV_PATH_END);
-  for (int i = 0; i < np; ++i) ++W.nonref[W.pnodes[i]];
+  for (int i = 0; i < np; ++i) ++W.gr[W.pnodes[i]].onref;
   // counters of eka (perfect / withsnps / withindel / withmix) ride in tmp0..tmp2 + part[0]
   if ((snp_bp + ins_bp + del_bp) == 0) ++S.tmp0; else if (snp_bp == 0) ++S.tmp1; else if ((ins_bp + del_bp) == 0) ++S.tmp2; else ++S.part[0];
 }
@@ -1613,7 +1637,7 @@ DEV bool repeats_in_graph_paths(Ctx &c) {
     evt(c, EV_LOOKREP);
     S.tmp0 = 0;                                  // 0 continue, 1 stop:false, 2 stop:true
     if (S.source == LC_NIL || S.sink == LC_NIL) { evt(c, EV_MISSING); S.tmp0 = 1; }
-    else evt(c, EV_SEARCH, (uint32_t)W.ncomp[S.source]);
+    else evt(c, EV_SEARCH, (uint32_t)W.gr[S.source].comp);
     S.tmp1 = 0;                                  // number of flagged-edge records kept in scratch
   }
   while (wg_bcast(&S.tmp0) == 0) {
@@ -1634,7 +1658,7 @@ DEV bool repeats_in_graph_paths(Ctx &c) {
     }
   }
   WG_LANE0 {
-    for (int j = 0; j < S.tmp1; ++j) { uint32_t owner = W.scratch[j] >> 4, ei = W.scratch[j] & 15u; W.edges[owner * LC_EMAX + ei] &= ~(1u << 30); }
+    for (int j = 0; j < S.tmp1; ++j) { uint32_t owner = W.scratch[j] >> 4, ei = W.scratch[j] & 15u; W.gr[owner].edges[ei] &= ~(1u << 30); }
   }
   return wg_bcast(&S.tmp0) == 2;
 }
@@ -1644,7 +1668,7 @@ DEV void count_ref_path(Ctx &c) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   if (wg_bcastu(&S.source) == LC_NIL) return;
   if (wg_bcastu(&S.sink) != LC_NIL) {
-    WG_LANE0 { evt(c, EV_SEARCH, (uint32_t)W.ncomp[S.source]); S.tmp0 = S.tmp1 = S.tmp2 = 0; S.part[0] = 0; S.part[1] = 0; S.part[2] = 0; S.part[3] = 0; }
+    WG_LANE0 { evt(c, EV_SEARCH, (uint32_t)W.gr[S.source].comp); S.tmp0 = S.tmp1 = S.tmp2 = 0; S.part[0] = 0; S.part[1] = 0; S.part[2] = 0; S.part[3] = 0; }
     // part[1] = complete, part[2] = allcycles, part[3] = loop state (0 run, 1 stop)
     while (wg_bcastu(&S.part[3]) == 0) {
       WG_LANE0 {
@@ -1690,7 +1714,7 @@ DEV void count_ref_path(Ctx &c) {
     WG_LANE0 { evt(c, EV_EKA_END, (uint32_t)S.refcomp, S.part[1], S.part[2], (uint32_t)S.tmp0, (uint32_t)S.tmp2, (uint32_t)S.tmp1, S.part[0]); }
   }
   WG_LANE0 {
-    if (c.C->evt_cap) { uint32_t n = 0; for (uint32_t i = 0; i < S.M; ++i) if (W.nonref[W.order[i]]) ++n; evt(c, EV_FOUND, n); }
+    if (c.C->evt_cap) { uint32_t n = 0; for (uint32_t i = 0; i < S.M; ++i) if (W.gr[W.order[i]].onref) ++n; evt(c, EV_FOUND, n); }
   }
   WG_SYNC();
 }
@@ -1743,20 +1767,20 @@ DEV void process_window(Ctx &c, int w) {
       // trace: printStats(0) over the full table, markRefNodes, removeLowCov(false,0)
       if (c.C->evt_cap) {
         uint32_t edges = 0, refn = 0, low = 0;
-        for (uint32_t n = 0; n < S.N; ++n) { edges += W.necnt[n]; if (W.nflags[n] & NF_INMER) ++refn; if (!(W.nflags[n] & NF_SURV)) ++low; }
+        for (uint32_t n = 0; n < S.N; ++n) { edges += W.gr[n].necnt; if (W.gr[n].flags & NF_INMER) ++refn; if (!(W.gr[n].flags & NF_SURV)) ++low; }
         evt(c, EV_STATS, 0, S.N, edges, S.N * (uint32_t)S.K);
         evt(c, EV_MARKREF, S.N, refn);
         evt(c, EV_LOWCOV, low);
       }
       // removeNode for every non-survivor: drop the reciprocal edges, then erase from the table
-      for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (!(W.nflags[n] & NF_SURV)) W.nflags[n] |= NF_DEAD; }
+      for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (!(W.gr[n].flags & NF_SURV)) W.gr[n].flags |= NF_DEAD; }
     }
     WG_SYNC();
     WG_FOR(n, S.N) {
-      if (W.nflags[n] & NF_DEAD) continue;
-      uint32_t *e = W.edges + n * LC_EMAX; int cnt = (int)W.necnt[n], m = 0;
-      for (int i = 0; i < cnt; ++i) if (!(W.nflags[ED_TO(e[i])] & NF_DEAD)) e[m++] = e[i];
-      W.necnt[n] = m;
+      if (W.gr[n].flags & NF_DEAD) continue;
+      uint32_t *e = W.gr[n].edges; int cnt = (int)W.gr[n].necnt, m = 0;
+      for (int i = 0; i < cnt; ++i) if (!(W.gr[ED_TO(e[i])].flags & NF_DEAD)) e[m++] = e[i];
+      W.gr[n].necnt = m;
     }
     WG_SYNC();
     WG_LANE0 {

@@ -94,6 +94,32 @@ struct BfsEntry {
   uint8_t bits;         /* bit0 flag, bit1 hasCycle                                         */
 };
 
+/* Node state as two 128-byte records so that one visit touches one or two cache lines instead of a dozen arrays.
+ * NodeHot: what the parallel table build updates with atomics (one line per k-mer occurrence).
+ * NodeGr : what the graph passes walk (line 0 = flags, degree, component, colour, edges). */
+struct NodeHot {
+  uint32_t flags;          /* NF_* while the table is being built (copied to NodeGr::flags at the end of the build) */
+  uint32_t cnt[4];         /* counted occurrences: Tf Tr Nf Nr                                                    */
+  uint32_t nocc, nfill;    /* occurrences of the node, csr fill cursor                                              */
+  uint32_t pad0;
+  uint32_t efirst[10];     /* first-seen stamp per possible edge: [0..3] F side ACGT, [4..7] R side ACGT, [8] F/N, [9] R/N */
+  uint32_t eto[10];        /* target|dir of that edge                                                              */
+  uint32_t pad1[4];
+};
+struct NodeGr {
+  uint32_t flags, necnt;   /* NF_* , number of edges                                                               */
+  int32_t comp;
+  uint32_t color;
+  uint32_t edges[LC_EMAX]; /* ordered (first-seen order, then the reference's erase/push_back edits)               */
+  float cov[4];            /* Tf Tr Nf Nr (float, as the reference)                                                */
+  int32_t mincov, mincovqv;
+  uint32_t seq_lo, seq_hi, seq_clo, seq_chi;   /* descriptor deque in the seq arena                                */
+  uint32_t nkm, nkmT;      /* constituent k-mers (cov_status entries >= K-1) / of which status == 'T'              */
+  uint32_t nqv;            /* index into qv (LC_NIL if not stored)                                                 */
+  uint32_t onref;
+  uint32_t pad[2];
+};
+
 /* One slot of work space.  All pointers are device pointers into one big allocation. */
 struct Work {
   /* ---- build ---- */
@@ -111,24 +137,9 @@ struct Work {
   /* ---- nodes: index < node_cap are k-mers in first-insertion order; then special nodes ---- */
   unsigned long long *nkey;     /* [nodes * LC_NWMAX] right-aligned 2-bit canonical k-mer     */
   unsigned long long *nhash;    /* [nodes] libstdc++ std::hash<std::string> of the node id     */
-  uint32_t *ncnt;         /* [nodes*4] counted occurrences: Tf Tr Nf Nr                        */
-  uint32_t *nflags;       /* [nodes]                                                           */
-  uint32_t *efirst;       /* [nodes*10] first-seen stamp of each possible k-mer edge (2 sides x ACGTN) */
-  uint32_t *eto;          /* [nodes*10] target|dir of each possible k-mer edge                 */
-  uint32_t *edges;        /* [nodes*LC_EMAX]                                                   */
-  uint32_t *necnt;        /* [nodes]                                                           */
-  float *ncov;            /* [nodes*4] Tf Tr Nf Nr (float, as the reference)                   */
-  int32_t *ncomp;         /* [nodes]                                                           */
-  int32_t *nmincov;       /* [nodes]                                                           */
-  int32_t *nmincovqv;     /* [nodes]                                                           */
+  NodeHot *hot;           /* [nodes]                                                           */
+  NodeGr *gr;             /* [nodes]                                                           */
   uint32_t *nocc;         /* [nodes+1] csr offsets                                             */
-  uint32_t *nfill;        /* [nodes]                                                           */
-  uint32_t *nseq_lo, *nseq_hi, *nseq_clo, *nseq_chi;  /* [nodes] deque in the seq arena        */
-  uint32_t *nkm;          /* [nodes] number of constituent k-mers  (cov_status entries >= K-1) */
-  uint32_t *nkmT;         /* [nodes] ... of which status == 'T'                                */
-  uint32_t *nqv;          /* [nodes] index into qv (LC_NIL if not stored)                      */
-  uint8_t *ncolor;        /* [nodes]                                                           */
-  uint32_t *nonref;       /* [nodes] onRefPath counter                                         */
   uint16_t *qv;           /* [surv_cap * K * 4] per-position min-quality counts Tf Tr Nf Nr    */
   uint32_t *seq;          /* [seq_cap] descriptor arena                                        */
   /* ---- libstdc++ node-table order ---- */
