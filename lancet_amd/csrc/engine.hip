@@ -77,6 +77,7 @@ struct lancet_engine {
   DevBuf d_caps2, d_works2, d_workmem2, d_out2, d_winlist;
   int n_slots2 = 0;
   uint32_t node_cap1 = 8192;
+  uint32_t debug_stop = 0;   // LANCET_STOP_PHASE (profiling only)
   int n_windows = 0, n_reads = 0, n_slots = 0;
   int n_rerun = 0;
   bool uploaded = false, ran = false;
@@ -117,6 +118,7 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (const char *s = getenv("LANCET_MEM_GB")) e->mem_budget = (size_t)atoi(s) << 30;
   if (const char *s = getenv("LANCET_MAX_NODES")) e->max_nodes_limit = (uint32_t)atoi(s);
   if (const char *s = getenv("LANCET_NODE_CAP1")) e->node_cap1 = (uint32_t)atoi(s);
+  if (const char *s = getenv("LANCET_STOP_PHASE")) e->debug_stop = (uint32_t)atoi(s);
   *out = e;
   return LANCET_OK;
 }
@@ -163,6 +165,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   e->caps = lc_caps_for_batch(b, &e->params, e->evt_cap, e->node_cap1, 1);
   e->caps2 = lc_caps_for_batch(b, &e->params, e->evt_cap, e->max_nodes_limit, 2);
   e->caps2.var_cap = e->caps.var_cap; e->caps2.blob_cap = e->caps.blob_cap;
+  e->caps.debug_stop = e->debug_stop;
   // ---- inputs
   UP(e->d_params, &e->params, sizeof(lancet_params));
   UP(e->d_chr, b->chr_id, sizeof(int32_t) * nw);
@@ -256,7 +259,7 @@ int lancet_engine_run(lancet_engine *e) {
   std::vector<char> ok1(e->n_windows, 1);
   for (int w = 0; w < e->n_windows; ++w) if (e->stats[w].status == LANCET_W_OVERFLOW) { rerun.push_back((uint32_t)w); ok1[w] = 0; }
   e->n_rerun = (int)rerun.size();
-  if (!rerun.empty()) {
+  if (!rerun.empty() && !e->debug_stop) {
     size_t slot2 = lc_work_carve(nullptr, nullptr, e->caps2);
     int slots2 = (int)std::min<size_t>(rerun.size(), 128);
     while (slots2 > 1 && (size_t)slots2 * slot2 > ((size_t)16 << 30)) slots2 /= 2;

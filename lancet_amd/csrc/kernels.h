@@ -45,6 +45,8 @@ struct WinShared {
   int n_builds, final_k, status;
   int tmp0, tmp1, tmp2, tmp3, hasN;
   uint32_t part[LANCET_WG + 1];
+  uint32_t mk[LANCET_WG][4], mmeta[LANCET_WG];   // staged quality masks of up to one wave of occurrences
+  uint32_t acc[128][4];                          // per k-mer position running counts Tf Tr Nf Nr
   unsigned long long t_last, phase_acc[16];
   int phase_cur;
 };
@@ -60,6 +62,9 @@ struct Ctx {
 };
 
 #define OVF(c) do { (c).S->overflow = 1; } while (0)
+// profiling only (EngineCaps::debug_stop): abandon the window after a phase marker, as an overflow
+#define STOP_SET(c, id) do { if ((c).C->debug_stop == (uint32_t)(id)) { WG_LANE0 { OVF(c); } } } while (0)
+#define STOP_RET(c, id) do { if ((c).C->debug_stop == (uint32_t)(id)) { WG_LANE0 { OVF(c); } return; } } while (0)
 
 // per-phase wall-clock accounting (lane 0; 100 MHz constant counter), read back through lancet_engine_phase_times
 #ifndef LANCET_WAVE_EMU
@@ -296,7 +301,7 @@ DEV void remove_node(Ctx &c, uint32_t n) {                          // Graph_t::
 // position data behind a sequence descriptor (cov_t of the reference, src/Ref.hh:41-53)
 DEV void desc_cov(const Ctx &c, uint32_t d, int sampleT, uint16_t *fwd, uint16_t *rev, uint16_t *qf, uint16_t *qr) {
   uint32_t km = SD_KMER(d);
-  const uint32_t *cn = c.W->hot[km].cnt;
+  const uint32_t *cn = c.W->kcnt + 4 * (size_t)km;
   int o = sampleT ? 0 : 2;
   *fwd = (uint16_t)cn[o]; *rev = (uint16_t)cn[o + 1];
   uint32_t q = c.W->gr[km].nqv;
@@ -306,7 +311,7 @@ DEV void desc_cov(const Ctx &c, uint32_t d, int sampleT, uint16_t *fwd, uint16_t
 }
 DEV void desc_tot(const Ctx &c, uint32_t d, int *tot, int *totqv) {  // operands of Node_t::computeMinCov
   uint32_t km = SD_KMER(d);
-  const uint32_t *cn = c.W->hot[km].cnt;
+  const uint32_t *cn = c.W->kcnt + 4 * (size_t)km;
   *tot = (int)(uint16_t)cn[0] + (int)(uint16_t)cn[1] + (int)(uint16_t)cn[2] + (int)(uint16_t)cn[3];
   uint32_t q = c.W->gr[km].nqv;
   if (q == LC_NIL) { *totqv = 0; return; }
@@ -572,6 +577,7 @@ DEV void build_graph(Ctx &c) {
   }
   if (wg_bcast(&S.overflow)) return;
   PHASE(c, 3);
+  STOP_RET(c, 3);
   // ---- dense node ids in first-insertion order (= order of first occurrence, Graph.cc:163-197)
   WG_FOR(i, C.table_cap) { if (ld2(&W.tags[i]) != 0) { uint32_t f = ld2(&W.slot_first[i]); dev_atomic_or(&W.bitmap[f >> 5], 1u << (f & 31)); } }
   WG_SYNC();
@@ -587,22 +593,19 @@ DEV void build_graph(Ctx &c) {
       uint32_t id = W.bitpre[f >> 5] + (uint32_t)dev_popc(ld2(&W.bitmap[f >> 5]) & ((1u << (f & 31)) - 1u));
       W.slot_node[i] = id;
       for (int w = 0; w < S.NW; ++w) W.nkey[(size_t)id * LC_NWMAX + w] = W.slot_key[(size_t)i * LC_NWMAX + w];
-      W.hot[id].flags = (ld2(&W.tags[i]) >> 63) ? NF_NKMER : 0u;
+      W.gr[id].flags = (ld2(&W.tags[i]) >> 63) ? NF_NKMER : 0u;
     }
   }
   WG_SYNC();
-  // ---- per node: std::hash of the ASCII k-mer, zeroed counters
+  // ---- per node: std::hash of the ASCII k-mer, zeroed occurrence counters
   WG_FOR(n, S.N) {
     const unsigned long long *k = W.nkey + (size_t)n * LC_NWMAX;
-    if (W.hot[n].flags & NF_NKMER) {
+    if (W.gr[n].flags & NF_NKMER) {
       const uint8_t *refc = c.B->ref_codes + c.B->ref_off[S.w];
       int p = (int)(k[0] >> 1); bool isR = (k[0] & 1ULL) != 0;
       W.nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGTN"[nk_char(refc, p, K, isR, j)]; }, K);
     } else W.nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGT"[key_base(k, K, j)]; }, K);
-    for (int j = 0; j < 4; ++j) W.hot[n].cnt[j] = 0;
-    for (int j = 0; j < 10; ++j) { W.hot[n].efirst[j] = LC_NIL; W.hot[n].eto[j] = 0; }
-    W.gr[n].necnt = 0; W.gr[n].comp = 0; W.hot[n].nocc = 0; W.hot[n].nfill = 0; W.gr[n].nqv = LC_NIL; W.gr[n].color = 0;
-    W.gr[n].onref = 0; W.gr[n].nkm = 1; W.gr[n].nkmT = 0;
+    W.nocc[n] = 0; W.nfill[n] = 0;
   }
   // reads whose opposite mate (same name) comes earlier in the window: only these can ever see
   // hasOverlappingMate()==true (reference src/Node.cc:638-661); everything else is counted directly.
@@ -619,9 +622,24 @@ DEV void build_graph(Ctx &c) {
     }
     W.cand[r] = cd; W.mate_of[r] = mo;
   }
-  WG_LANE0 { S.tmp1 = 0; }
+  WG_LANE0 { S.tmp1 = 0; W.nocc[S.N] = 0; }
   WG_SYNC();
   PHASE(c, 4);
+  STOP_RET(c, 4);
+  // ---- pass 2a: occurrences slot -> node id; occurrences per node (the only per-occurrence atomic, on a compact array)
+  WG_FOR(r, S.R) {
+    uint32_t rinfo, bw, gw; int tlen; bool isref;
+    read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref);
+    if (tlen - K <= 0) continue;
+    uint32_t o0 = W.occ_base[r];
+    for (int p = 0; p < tlen - K + 1; ++p) {
+      uint32_t oc = W.occ[o0 + p];
+      uint32_t X = W.slot_node[oc & 0x3FFFFFFFu];
+      dev_atomic_add(&W.nocc[X], 1u);
+      W.occ[o0 + p] = X | (oc & 0x80000000u);
+    }
+  }
+  WG_SYNC();
   // ---- mate-overlap prefilter: an occurrence of a candidate read can only be suppressed if the node also holds an
   //      occurrence of its earlier opposite mate.  Node ids of the mate go into a small private open-addressing set;
   //      own k-mers that hit it get bit 30 in occ[] and are decided by the exact replay after the csr is built.
@@ -643,7 +661,7 @@ DEV void build_graph(Ctx &c) {
         for (int i = 0; i < 256; ++i) set[i] = 0;
         uint32_t m0 = W.occ_base[mo];
         for (int j = 0; j < mnk; ++j) {
-          uint32_t id = W.slot_node[W.occ[m0 + j] & 0x3FFFFFFFu] + 1u;
+          uint32_t id = (W.occ[m0 + j] & 0x3FFFFFFFu) + 1u;
           uint32_t h = (id * 2654435761u) >> 24;
           while (set[h] != 0 && set[h] != id) h = (h + 1) & 255u;
           set[h] = id;
@@ -654,73 +672,19 @@ DEV void build_graph(Ctx &c) {
       uint32_t oc = W.occ[o0 + p];
       bool hit = all;
       if (!all) {
-        uint32_t id = W.slot_node[oc & 0x3FFFFFFFu] + 1u;
+        uint32_t id = (oc & 0x3FFFFFFFu) + 1u;
         uint32_t h = (id * 2654435761u) >> 24;
         while (set[h] != 0) { if (set[h] == id) { hit = true; break; } h = (h + 1) & 255u; }
       }
-      if (hit) W.occ[o0 + p] = oc | 0x40000000u;
+      if (hit) {
+        W.occ[o0 + p] = oc | 0x40000000u;
+        uint32_t t = dev_atomic_add((uint32_t *)&S.tmp1, 1u);
+        if (t < c.C->table_cap) W.slot_first[t] = ((uint32_t)r << 10) | (uint32_t)p; else OVF(c);
+      }
     }
   }
   WG_SYNC();
-  // ---- pass 2: colours, coverage counters, edges, per-node occurrence counts
-  WG_FOR(r, S.R) {
-    uint32_t rinfo, bw, gw; int tlen; bool isref;
-    read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref);
-    if (tlen - K <= 0) continue;
-    uint32_t o0 = W.occ_base[r];
-    int nk = tlen - K + 1;
-    int ctr = isref ? -1 : ((RI_NML(rinfo) ? 2 : 0) + (RI_REV(rinfo) ? 1 : 0));
-    // every update of iteration p lands in the record of this k-mer's node (one or two cache lines):
-    // colour flags, counters, its edge to the next k-mer (as u of step p) and to the previous one (as v of step p-1)
-    uint32_t prevnode = 0, prevori = 0;
-    uint32_t oc = W.occ[o0];
-    uint32_t X = W.slot_node[oc & 0x3FFFFFFFu], ori = oc >> 31;
-    for (int p = 0; p < nk; ++p) {
-      bool cd = (oc & 0x40000000u) != 0;       // needs the exact mate-overlap replay
-      uint32_t noc = 0, Y = 0, yori = 0;
-      if (p + 1 < nk) { noc = W.occ[o0 + p + 1]; Y = W.slot_node[noc & 0x3FFFFFFFu]; yori = noc >> 31; }
-      NodeHot &H = W.hot[X];
-      uint32_t fl = 0;
-      if (!isref) {
-        if (RI_NML(rinfo)) fl |= NF_NORMAL;
-        else if (step_all_good(c, isref, gw, p, tlen, K) || step_all_good(c, isref, gw, p - 1, tlen, K)) fl |= NF_TUMOR;
-      }
-      if (fl && (fl & ~ld2(&H.flags))) dev_atomic_or(&H.flags, fl);
-      if (ctr >= 0 && !cd) dev_atomic_add(&H.cnt[ctr], 1u);
-      if (cd) { uint32_t t = dev_atomic_add((uint32_t *)&S.tmp1, 1u); if (t < c.C->table_cap) W.slot_first[t] = ((uint32_t)r << 10) | (uint32_t)p; else OVF(c); }
-      dev_atomic_add(&H.nocc, 1u);
-      // edge slots: (side, extension base in the node's canonical orientation); F side = right extension.
-      // index: ACGT -> side*4 + base, N -> 8 + side            (Graph.cc:320-347 for the directions)
-      if (p + 1 < nk) {            // step p: u = X, v = Y
-        uint32_t fdir = (ori == 0) ? (yori == 0 ? 0u : 1u) : (yori == 0 ? 2u : 3u);       // FF FR RF RR
-        int bnew = read_base(c, isref, bw, p + K);            // base that v adds after u
-        int eb = (ori == 0) ? bnew : n_comp(bnew);
-        uint32_t side = (ori == 0) ? 0u : 1u;
-        uint32_t sl = eb < 4 ? side * 4u + (uint32_t)eb : 8u + side;
-        uint32_t stamp = 2u * (o0 + (uint32_t)p);
-        uint32_t cur = ld2(&H.efirst[sl]);
-        if (cur > stamp) { uint32_t old = dev_atomic_min(&H.efirst[sl], stamp); if (old == LC_NIL) H.eto[sl] = ED_MAKE(Y, fdir); }
-      }
-      if (p > 0) {                 // step p-1: u = prev, v = X
-        uint32_t rdir = (prevori == 0) ? (ori == 0 ? 3u : 1u) : (ori == 0 ? 2u : 0u);     // RR FR RF FF
-        int bold = read_base(c, isref, bw, p - 1);           // base that u has before v
-        int eb = (ori == 0) ? bold : n_comp(bold);
-        uint32_t side = (ori == 0) ? 1u : 0u;
-        uint32_t sl = eb < 4 ? side * 4u + (uint32_t)eb : 8u + side;
-        uint32_t stamp = 2u * (o0 + (uint32_t)p - 1u) + 1u;
-        uint32_t cur = ld2(&H.efirst[sl]);
-        if (cur > stamp) { uint32_t old = dev_atomic_min(&H.efirst[sl], stamp); if (old == LC_NIL) H.eto[sl] = ED_MAKE(prevnode, rdir); }
-      }
-      W.occ[o0 + p] = X | (ori << 31) | (cd ? 0x40000000u : 0u);
-      prevnode = X; prevori = ori;
-      oc = noc; X = Y; ori = yori;
-    }
-  }
-  WG_SYNC();
-  WG_FOR(n, S.N) { W.nocc[n] = ld2(&W.hot[n].nocc); }
   // ---- csr of occurrences by node
-  WG_LANE0 { W.nocc[S.N] = 0; }
-  WG_SYNC();
   wg_scan(W.nocc, (int)S.N + 1, S);
   WG_FOR(r, S.R) {
     uint32_t rinfo, bw, gw; int tlen; bool isref;
@@ -731,7 +695,7 @@ DEV void build_graph(Ctx &c) {
       uint32_t oc = W.occ[o0 + p];
       uint32_t X = oc & 0x3FFFFFFFu;
       uint32_t st = isref ? 2u : ((oc & 0x40000000u) ? 1u : 0u);     // the reference read never counts (Graph.cc:265)
-      uint32_t at = W.nocc[X] + dev_atomic_add(&W.hot[X].nfill, 1u);
+      uint32_t at = W.nocc[X] + dev_atomic_add(&W.nfill[X], 1u);
       W.csr[at] = CS_MAKE(r, p, oc >> 31, st);
     }
   }
@@ -745,7 +709,6 @@ DEV void build_graph(Ctx &c) {
       int r = (int)(W.slot_first[ti] >> 10), p = (int)(W.slot_first[ti] & 1023u);
       uint32_t rinfo = c.B->rinfo[g0 + r];
       uint32_t mi = RI_MATE(rinfo), nm = c.B->name_rank[g0 + r];
-      int ctr = (RI_NML(rinfo) ? 2 : 0) + (RI_REV(rinfo) ? 1 : 0);
       {
         uint32_t X = W.occ[W.occ_base[r] + p] & 0x3FFFFFFFu;
         uint32_t lo = W.nocc[X], hi = W.nocc[X + 1];
@@ -774,78 +737,167 @@ DEV void build_graph(Ctx &c) {
         while (len > 0) { uint32_t half = len >> 1; uint32_t mid = first + half; if (elem(mid) < nm) { first = mid + 1; len = len - half - 1; } else len = half; }
         bool ovl = (first != total) && !(nm < elem(first));
         uint32_t e = W.csr[self];
-        if (!ovl) { W.hot[X].cnt[ctr] = ld2(&W.hot[X].cnt[ctr]) + 1; W.csr[self] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), 0u); }
-        else W.csr[self] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), 2u);
+        W.csr[self] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), ovl ? 2u : 0u);
       }
     }
     S.seq_top = 0; S.qv_top = 0;
   }
   WG_SYNC();
   PHASE(c, 5);
-  // ---- per node: edges in first-seen order, float coverages, minimum coverages; first removeLowCov predicate
-  //      (reference src/Graph.cc:2790-2827 with docompression=false, compid=0) evaluated in the same pass.
+  STOP_RET(c, 5);
+  // ---- per node, gathering over its occurrences (reference src/Graph.cc:163-349): colours, counted occurrences per
+  //      strand/sample, edges in first-seen order (stamp = 2*occurrence index of the step's u, +1 for the v side),
+  //      float coverages.  Everything lands in the node's own record: no scattered updates.
   const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
   WG_FOR(n, S.N) {
-    uint32_t stamp[10]; uint32_t tgt[10]; int ne = 0;
-    for (int j = 0; j < 10; ++j) { uint32_t ef = ld2(&W.hot[n].efirst[j]); if (ef != LC_NIL) { stamp[ne] = ef; tgt[ne] = W.hot[n].eto[j]; ++ne; } }
-    for (int i = 1; i < ne; ++i) { uint32_t s = stamp[i], t = tgt[i]; int j = i; while (j > 0 && stamp[j - 1] > s) { stamp[j] = stamp[j - 1]; tgt[j] = tgt[j - 1]; --j; } stamp[j] = s; tgt[j] = t; }
-    for (int i = 0; i < ne; ++i) W.gr[n].edges[i] = tgt[i];
-    W.gr[n].necnt = ne;
-    uint32_t cn[4];
-    for (int j = 0; j < 4; ++j) { cn[j] = ld2(&W.hot[n].cnt[j]); W.gr[n].cov[j] = (float)cn[j]; }
-    int tot = (int)(uint16_t)cn[0] + (int)(uint16_t)cn[1] + (int)(uint16_t)cn[2] + (int)(uint16_t)cn[3];
-    // per position of the k-mer: number of counted reads whose base there passes MIN_QUAL_CALL, per strand/sample
-    // (Node_t::updateCovDistr minqv_fwd/minqv_rev, reference src/Node.cc:470-497).  One pass over the node's
-    // occurrences; the K quality bits of an occurrence are pulled out of the read's bit mask 32 at a time.
-    uint16_t pc[4 * 128];
-    for (int i = 0; i < 4 * K; ++i) pc[i] = 0;
-    uint32_t lo = W.nocc[n], hi = W.nocc[n + 1];
-    const uint32_t g0 = c.B->read_begin[S.w];
+    uint32_t ef0 = LC_NIL, ef1 = LC_NIL, ef2 = LC_NIL, ef3 = LC_NIL, ef4 = LC_NIL, ef5 = LC_NIL, ef6 = LC_NIL, ef7 = LC_NIL, ef8 = LC_NIL, ef9 = LC_NIL;
+#define LC_EFMIN(sl, st) do { uint32_t _s = (sl), _v = (st); \
+      ef0 = (_s == 0 && _v < ef0) ? _v : ef0; ef1 = (_s == 1 && _v < ef1) ? _v : ef1; ef2 = (_s == 2 && _v < ef2) ? _v : ef2; \
+      ef3 = (_s == 3 && _v < ef3) ? _v : ef3; ef4 = (_s == 4 && _v < ef4) ? _v : ef4; ef5 = (_s == 5 && _v < ef5) ? _v : ef5; \
+      ef6 = (_s == 6 && _v < ef6) ? _v : ef6; ef7 = (_s == 7 && _v < ef7) ? _v : ef7; ef8 = (_s == 8 && _v < ef8) ? _v : ef8; \
+      ef9 = (_s == 9 && _v < ef9) ? _v : ef9; } while (0)
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, fl = 0;
+    const uint32_t lo = W.nocc[n], hi = W.nocc[n + 1];
     for (uint32_t q = lo; q < hi; ++q) {
-      uint32_t e = W.csr[q];
-      if (CS_ST(e) != 0) continue;
-      uint32_t g = g0 + CS_READ(e);
-      uint32_t ri = c.B->rinfo[g];
-      int cls = (RI_NML(ri) ? 2 : 0) + (RI_REV(ri) ? 1 : 0);
-      uint32_t gw = c.B->good_woff[g];
-      int p0 = (int)CS_POS(e); bool rev = CS_ORI(e) != 0;
-      for (int i0 = 0; i0 < K; i0 += 32) {
-        int take = K - i0 < 32 ? K - i0 : 32;
-        int st = p0 + i0, wv = st >> 5, sh = st & 31;
-        uint32_t bits = c.B->good[gw + wv] >> sh;
-        if (sh + take > 32) bits |= c.B->good[gw + wv + 1] << (32 - sh);
-        if (take < 32) bits &= (1u << take) - 1u;
-        while (bits) {
-          int bpos = __builtin_ctz(bits); bits &= bits - 1;
-          int pos = rev ? (K - 1 - (i0 + bpos)) : (i0 + bpos);
-          pc[cls * K + pos]++;
+      const uint32_t e = W.csr[q];
+      const int r = (int)CS_READ(e), p = (int)CS_POS(e);
+      const uint32_t ori = CS_ORI(e), st = CS_ST(e);
+      uint32_t rinfo, bw, gw; int tlen; bool isref;
+      read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref);
+      const int nk = tlen - K + 1;
+      const uint32_t o0 = W.occ_base[r];
+      if (!isref) {
+        if (RI_NML(rinfo)) fl |= NF_NORMAL;
+        else if (!(fl & NF_TUMOR) && (step_all_good(c, isref, gw, p, tlen, K) || step_all_good(c, isref, gw, p - 1, tlen, K))) fl |= NF_TUMOR;
+        if (st == 0) { const int ctr = (RI_NML(rinfo) ? 2 : 0) + (RI_REV(rinfo) ? 1 : 0); c0 += ctr == 0; c1 += ctr == 1; c2 += ctr == 2; c3 += ctr == 3; }
+      }
+      // edge slots: (side, extension base in the node's canonical orientation); F side = right extension.
+      // index: ACGT -> side*4 + base, N -> 8 + side            (Graph.cc:320-347 for the directions)
+      if (p + 1 < nk) {            // step p: this node is u, the next k-mer v
+        int bnew = read_base(c, isref, bw, p + K);            // base that v adds after u
+        int eb = (ori == 0) ? bnew : n_comp(bnew);
+        uint32_t side = (ori == 0) ? 0u : 1u;
+        LC_EFMIN(eb < 4 ? side * 4u + (uint32_t)eb : 8u + side, 2u * (o0 + (uint32_t)p));
+      }
+      if (p > 0) {                 // step p-1: the previous k-mer is u, this node v
+        int bold = read_base(c, isref, bw, p - 1);           // base that u has before v
+        int eb = (ori == 0) ? bold : n_comp(bold);
+        uint32_t side = (ori == 0) ? 1u : 0u;
+        LC_EFMIN(eb < 4 ? side * 4u + (uint32_t)eb : 8u + side, 2u * (o0 + (uint32_t)p - 1u) + 1u);
+      }
+    }
+#undef LC_EFMIN
+    uint32_t stamp[10]; int ne = 0;
+    { const uint32_t ef[10] = {ef0, ef1, ef2, ef3, ef4, ef5, ef6, ef7, ef8, ef9};
+      for (int j = 0; j < 10; ++j) if (ef[j] != LC_NIL) stamp[ne++] = ef[j]; }
+    for (int i = 1; i < ne; ++i) { uint32_t s = stamp[i]; int j = i; while (j > 0 && stamp[j - 1] > s) { stamp[j] = stamp[j - 1]; --j; } stamp[j] = s; }
+    NodeGr &G = W.gr[n];
+    for (int i = 0; i < ne; ++i) {
+      const uint32_t s = stamp[i] >> 1;
+      const uint32_t a = W.occ[s], b = W.occ[s + 1];           // u and v of that step
+      const uint32_t ua = a >> 31, ub = b >> 31;
+      if ((stamp[i] & 1u) == 0) G.edges[i] = ED_MAKE(b & 0x3FFFFFFFu, ua == 0 ? (ub == 0 ? 0u : 1u) : (ub == 0 ? 2u : 3u));   // FF FR RF RR
+      else G.edges[i] = ED_MAKE(a & 0x3FFFFFFFu, ua == 0 ? (ub == 0 ? 3u : 1u) : (ub == 0 ? 2u : 0u));                          // RR FR RF FF
+    }
+    G.necnt = (uint32_t)ne; G.comp = 0; G.color = 0; G.onref = 0; G.nkm = 1; G.nkmT = 0; G.nqv = LC_NIL;
+    G.flags = (G.flags & NF_NKMER) | fl;
+    uint32_t *kc = W.kcnt + 4 * (size_t)n;
+    kc[0] = c0; kc[1] = c1; kc[2] = c2; kc[3] = c3;
+    G.cov[0] = (float)c0; G.cov[1] = (float)c1; G.cov[2] = (float)c2; G.cov[3] = (float)c3;
+    G.mincov = (int)(uint16_t)c0 + (int)(uint16_t)c1 + (int)(uint16_t)c2 + (int)(uint16_t)c3;
+    G.mincovqv = 0;
+    // first removeLowCov predicate (reference src/Graph.cc:2790-2827, docompression=false, compid=0): minqv <= T.
+    // minqv cannot exceed the number of counted occurrences, so most nodes (sequencing-error k-mers) are decided here;
+    // the others get their per-position counts from the whole wave below.
+    const uint32_t counted = c0 + c1 + c2 + c3;
+    const float tt = G.cov[0] + G.cov[1], tn = G.cov[2] + G.cov[3];
+    const bool low = ((int)counted <= c.P->low_cov_threshold) || ((double)counted <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
+    W.order[n] = low ? 0u : 1u;
+  }
+  WG_LANE0 { W.order[S.N] = 0; }
+  WG_SYNC();
+  wg_scan(W.order, (int)S.N + 1, S);
+  WG_FOR(n, S.N) { if (W.order[n + 1] != W.order[n]) W.pnodes[W.order[n]] = (uint32_t)n; }
+  WG_SYNC();
+  PHASE(c, 6);
+  // ---- undecided nodes, one at a time: number of counted reads whose base passes MIN_QUAL_CALL, per k-mer position and
+  //      strand/sample (Node_t::updateCovDistr minqv_fwd/minqv_rev, reference src/Node.cc:470-497).
+  //      Step 1, lane = occurrence: the K quality bits of the occurrence go to LDS (64 independent load chains in flight).
+  //      Step 2, lane = k-mer position: count over the staged occurrences out of LDS.
+  const uint32_t ncand = wg_bcastu(&S.part[LANCET_WG]);
+  WG_LANE0 { S.tmp0 = 0x7FFFFFFF; }
+  for (uint32_t ci = 0; ci < ncand; ++ci) {
+    const uint32_t n = W.pnodes[ci];
+    const uint32_t lo = W.nocc[n], hi = W.nocc[n + 1];
+    const uint32_t g0 = c.B->read_begin[S.w];
+    const uint32_t qi = (uint32_t)wg_uniform((int)S.qv_top);
+    if (qi >= c.C->surv_cap || ((size_t)qi + 1) * (size_t)K > (size_t)c.C->qv_cap) { WG_LANE0 { OVF(c); } return; }
+    uint16_t *qq = W.qv + (size_t)qi * K * 4;
+    for (uint32_t q0 = lo; q0 < hi; q0 += LANCET_WG) {
+      const int cnt = (int)(hi - q0 < (uint32_t)LANCET_WG ? hi - q0 : (uint32_t)LANCET_WG);
+      WG_FOR(j, cnt) {
+        const uint32_t e = W.csr[q0 + j];
+        uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, meta = 0;
+        if (CS_ST(e) == 0) {
+          const uint32_t g = g0 + CS_READ(e);
+          const uint32_t ri = c.B->rinfo[g];
+          const uint32_t *gd = c.B->good + c.B->good_woff[g];
+          const int p0 = (int)CS_POS(e), sh = p0 & 31, wv = p0 >> 5;
+          // bits [p0, p0+K) of the read's mask, 32 at a time; the word after is only touched when it holds needed bits
+          #define LC_TAKE(t) ((32 * (t) < K) ? ((gd[wv + (t)] >> sh) | ((sh && 32 * (t) + 32 - sh < K) ? (gd[wv + (t) + 1] << (32 - sh)) : 0u)) : 0u)
+          m0 = LC_TAKE(0); m1 = LC_TAKE(1); m2 = LC_TAKE(2); m3 = LC_TAKE(3);
+          #undef LC_TAKE
+          meta = 1u | (((RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u)) << 1) | (CS_ORI(e) << 3);
+        }
+        S.mk[j][0] = m0; S.mk[j][1] = m1; S.mk[j][2] = m2; S.mk[j][3] = m3; S.mmeta[j] = meta;
+      }
+      WG_SYNC();
+      const bool first = (q0 == lo), last = (q0 + LANCET_WG >= hi);
+      WG_FOR(i, K) {
+        const uint32_t (*mk)[4] = (const uint32_t (*)[4])S.mk;       // plain LDS reads: staged before the barrier above
+        const uint32_t *mm = (const uint32_t *)S.mmeta;
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (!first) { a0 = S.acc[i][0]; a1 = S.acc[i][1]; a2 = S.acc[i][2]; a3 = S.acc[i][3]; }
+        for (int j = 0; j < cnt; ++j) {
+          const uint32_t meta = mm[j];
+          const int idx = (meta & 8u) ? (K - 1 - i) : i;
+          const uint32_t bit = (mk[j][idx >> 5] >> (idx & 31)) & meta & 1u;
+          const uint32_t cls = (meta >> 1) & 3u;
+          a0 += (cls == 0) ? bit : 0u; a1 += (cls == 1) ? bit : 0u; a2 += (cls == 2) ? bit : 0u; a3 += (cls == 3) ? bit : 0u;
+        }
+        if (!last) { S.acc[i][0] = a0; S.acc[i][1] = a1; S.acc[i][2] = a2; S.acc[i][3] = a3; }
+        else {
+          qq[4 * i] = (uint16_t)a0; qq[4 * i + 1] = (uint16_t)a1; qq[4 * i + 2] = (uint16_t)a2; qq[4 * i + 3] = (uint16_t)a3;
+          const int sq = (int)(uint16_t)a0 + (int)(uint16_t)a1 + (int)(uint16_t)a2 + (int)(uint16_t)a3;
+          dev_atomic_min((uint32_t *)&S.tmp0, (uint32_t)sq);
         }
       }
+      WG_SYNC();
     }
-    int minqv = 10000000;
-    for (int i = 0; i < K; ++i) { int sq = (int)pc[i] + (int)pc[K + i] + (int)pc[2 * K + i] + (int)pc[3 * K + i]; if (sq < minqv) minqv = sq; }
-    W.gr[n].mincov = tot; W.gr[n].mincovqv = minqv;
-    float tt = W.gr[n].cov[0] + W.gr[n].cov[1], tn = W.gr[n].cov[2] + W.gr[n].cov[3];
-    bool low = (minqv <= c.P->low_cov_threshold) || ((double)minqv <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
+    const int minqv = wg_uniform(S.tmp0);
+    const float tt = W.gr[n].cov[0] + W.gr[n].cov[1], tn = W.gr[n].cov[2] + W.gr[n].cov[3];
+    const bool low = (minqv <= c.P->low_cov_threshold) || ((double)minqv <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
     if (!low) {
       // survivor of the first removeLowCov: keep the per-position counts and start its sequence-descriptor deque
-      uint32_t qi = dev_atomic_add((uint32_t *)&S.qv_top, 1u);
-      if (qi >= c.C->surv_cap || ((size_t)qi + 1) * (size_t)K > (size_t)c.C->qv_cap) { OVF(c); }
-      else {
-        uint16_t *qq = W.qv + (size_t)qi * K * 4;
-        for (int i = 0; i < K; ++i) { qq[4 * i] = pc[i]; qq[4 * i + 1] = pc[K + i]; qq[4 * i + 2] = pc[2 * K + i]; qq[4 * i + 3] = pc[3 * K + i]; }
-        uint32_t base = qi * (uint32_t)K;
-        const unsigned long long *kk = W.nkey + (size_t)n * LC_NWMAX;
-        for (int i = 0; i < K; ++i) W.seq[base + i] = SD_MAKE(n, i, key_base(kk, K, i));
-        W.gr[n].seq_clo = base; W.gr[n].seq_lo = base; W.gr[n].seq_hi = base + K; W.gr[n].seq_chi = base + K;
-        uint32_t fl = ld2(&W.hot[n].flags);
-        W.gr[n].nkmT = ((fl & NF_TUMOR) && !(fl & NF_NORMAL)) ? 1u : 0u;      // cov_status == 'T'
-        W.gr[n].nqv = qi;
-        dev_atomic_or(&W.hot[n].flags, NF_SURV);
+      const uint32_t base = qi * (uint32_t)K;
+      const unsigned long long *kk = W.nkey + (size_t)n * LC_NWMAX;
+      WG_FOR(i, K) { W.seq[base + i] = SD_MAKE(n, i, key_base(kk, K, i)); }
+    }
+    WG_LANE0 {
+      NodeGr &G = W.gr[n];
+      G.mincovqv = minqv;
+      if (!low) {
+        const uint32_t base = qi * (uint32_t)K;
+        G.seq_clo = base; G.seq_lo = base; G.seq_hi = base + K; G.seq_chi = base + K;
+        const uint32_t f = G.flags;
+        G.nkmT = ((f & NF_TUMOR) && !(f & NF_NORMAL)) ? 1u : 0u;      // cov_status == 'T'
+        G.nqv = qi;
+        G.flags = f | NF_SURV;
+        S.qv_top = qi + 1;
       }
+      S.tmp0 = 0x7FFFFFFF;
     }
   }
-  WG_SYNC();
   WG_LANE0 { S.seq_top = S.qv_top * (uint32_t)K; }
   WG_SYNC();
   // ---- Ref_t::mertable membership (indexMers over the possibly trimmed seq, reference src/Ref.cc:40-64)
@@ -855,7 +907,7 @@ DEV void build_graph(Ctx &c) {
     bool loaded = (S.reflen - K > 0);
     WG_FOR(i, S.seq_len - K > 0 ? S.seq_len - K : 0) {     // i + K < seq.length()
       int p = S.seq_t5 + i;
-      if (loaded && p < nrefk) dev_atomic_or(&W.hot[W.occ[ro + p] & 0x3FFFFFFFu].flags, NF_INMER);
+      if (loaded && p < nrefk) dev_atomic_or(&W.gr[W.occ[ro + p] & 0x3FFFFFFFu].flags, NF_INMER);
     }
     WG_SYNC();
     // ---- Ref_t::computeCoverage (reference src/Ref.cc:173-250): per rawseq position, Tf Tr Nf Nr
@@ -864,13 +916,13 @@ DEV void build_graph(Ctx &c) {
     WG_FOR(i, S.reflen - K > 0 ? S.reflen - K : 0) {       // i + K < rawseq.length()
       uint32_t X = W.occ[ro + i] & 0x3FFFFFFFu;
       uint16_t v[4] = {0, 0, 0, 0};
-      if (ld2(&W.hot[X].flags) & NF_INMER) for (int q = 0; q < 4; ++q) v[q] = (uint16_t)ld2(&W.hot[X].cnt[q]);
+      if (ld2(&W.gr[X].flags) & NF_INMER) for (int q = 0; q < 4; ++q) v[q] = (uint16_t)W.kcnt[4 * (size_t)X + q];
       if (i == 0) { for (int j = 0; j < K; ++j) for (int q = 0; q < 4; ++q) W.refcov[4 * j + q] = v[q]; }
       else { for (int q = 0; q < 4; ++q) W.refcov[4 * (i + K - 1) + q] = v[q]; }
     }
-    WG_FOR(n, S.N) { W.gr[n].flags = ld2(&W.hot[n].flags); }     // the graph passes work on NodeGr only
     WG_SYNC_FENCE();   // from here on the node arrays are only touched with plain loads/stores: one L1 invalidate
   }
+  STOP_RET(c, 6);
 }
 
 // first removeLowCov(false, 0) + cleanDead; markRefNodes counters for the trace
@@ -1129,7 +1181,7 @@ DEV uint32_t special_new(Ctx &c, bool issource, int comp) {
   char digs[12]; int nd = 0; int v = comp; do { digs[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
   while (nd) name[L++] = digs[--nd];
   W.nhash[id] = std_hash_bytes([&](int j) -> int { return (int)(unsigned char)name[j]; }, L);
-  for (int q = 0; q < 4; ++q) { W.hot[id].cnt[q] = 0; W.gr[id].cov[q] = 0.0f; }
+  for (int q = 0; q < 4; ++q) { W.kcnt[4 * (size_t)id + q] = 0; W.gr[id].cov[q] = 0.0f; }
   W.gr[id].flags = issource ? NF_SOURCE : NF_SINK;
   W.gr[id].necnt = 0; W.gr[id].comp = comp; W.gr[id].mincov = 0; W.gr[id].mincovqv = 0; W.gr[id].nqv = LC_NIL; W.gr[id].color = 0;
   W.gr[id].seq_lo = W.gr[id].seq_hi = W.gr[id].seq_clo = W.gr[id].seq_chi = 0; W.gr[id].nkm = 0; W.gr[id].nkmT = 0; W.gr[id].onref = 0;
@@ -1759,6 +1811,7 @@ DEV void process_window(Ctx &c, int w) {
     if (wg_bcast(&S.overflow)) break;
     PHASE(c, 7);
     first_lowcov(c);
+    STOP_SET(c, 7);
     if (wg_bcast(&S.overflow)) break;
     PHASE(c, 8);
     // ---- everything below is the (small) cleaned graph
@@ -1791,6 +1844,8 @@ DEV void process_window(Ctx &c, int w) {
     int numcomp = wg_bcast(&S.numcomp);
     bool brk = false;
     PHASE(c, 9);
+    STOP_SET(c, 8);
+    if (wg_bcast(&S.overflow)) break;
     for (int comp = 1; comp <= numcomp; ++comp) {
       WG_LANE0 {
         print_stats(c, comp);

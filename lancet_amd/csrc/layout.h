@@ -67,6 +67,7 @@ struct EngineCaps {
   uint32_t blob_cap;     /* variant string bytes for the whole batch                       */
   uint32_t max_k;        /* largest k the engine was created for                           */
   uint32_t qv_cap;       /* (survivor, k-mer position) entries of per-position quality counts */
+  uint32_t debug_stop;   /* profiling only: abandon every window after this phase marker (0 = off)  */
 };
 
 /* device-resident batch (after upload + prep) */
@@ -94,18 +95,8 @@ struct BfsEntry {
   uint8_t bits;         /* bit0 flag, bit1 hasCycle                                         */
 };
 
-/* Node state as two 128-byte records so that one visit touches one or two cache lines instead of a dozen arrays.
- * NodeHot: what the parallel table build updates with atomics (one line per k-mer occurrence).
- * NodeGr : what the graph passes walk (line 0 = flags, degree, component, colour, edges). */
-struct NodeHot {
-  uint32_t flags;          /* NF_* while the table is being built (copied to NodeGr::flags at the end of the build) */
-  uint32_t cnt[4];         /* counted occurrences: Tf Tr Nf Nr                                                    */
-  uint32_t nocc, nfill;    /* occurrences of the node, csr fill cursor                                              */
-  uint32_t pad0;
-  uint32_t efirst[10];     /* first-seen stamp per possible edge: [0..3] F side ACGT, [4..7] R side ACGT, [8] F/N, [9] R/N */
-  uint32_t eto[10];        /* target|dir of that edge                                                              */
-  uint32_t pad1[4];
-};
+/* Node state the graph passes walk: one 128-byte record (line 0 = flags, degree, component, colour, edges).
+ * It is written once per build by the lane that gathers the node's occurrences (kernels.h build_graph). */
 struct NodeGr {
   uint32_t flags, necnt;   /* NF_* , number of edges                                                               */
   int32_t comp;
@@ -137,7 +128,8 @@ struct Work {
   /* ---- nodes: index < node_cap are k-mers in first-insertion order; then special nodes ---- */
   unsigned long long *nkey;     /* [nodes * LC_NWMAX] right-aligned 2-bit canonical k-mer     */
   unsigned long long *nhash;    /* [nodes] libstdc++ std::hash<std::string> of the node id     */
-  NodeHot *hot;           /* [nodes]                                                           */
+  uint32_t *kcnt;         /* [nodes*4] counted occurrences of the k-mer: Tf Tr Nf Nr          */
+  uint32_t *nfill;        /* [nodes+1] csr fill cursors                                        */
   NodeGr *gr;             /* [nodes]                                                           */
   uint32_t *nocc;         /* [nodes+1] csr offsets                                             */
   uint16_t *qv;           /* [surv_cap * K * 4] per-position min-quality counts Tf Tr Nf Nr    */
