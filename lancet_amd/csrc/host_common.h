@@ -90,6 +90,8 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.seq = k.take<uint32_t>(c.seq_cap);
   t.ht_next = k.take<uint32_t>(nodes);
   t.ht_bucket = k.take<uint32_t>(c.bucket_cap);
+  t.ht_cnt = k.take<uint32_t>(c.bucket_cap);
+  t.ht_start = k.take<uint32_t>(c.bucket_cap);
   t.order = k.take<uint32_t>(nodes + 1);
   t.scratch = k.take<uint32_t>(2 * nodes > c.occ_cap ? 2 * nodes : c.occ_cap);
   t.refcov = k.take<uint16_t>(LC_MAXW * 4);

@@ -47,6 +47,7 @@ struct WinShared {
   uint32_t part[LANCET_WG + 1];
   uint32_t mk[LANCET_WG][4], mmeta[LANCET_WG];   // staged quality masks of up to one wave of occurrences
   uint32_t acc[128][4];                          // per k-mer position running counts Tf Tr Nf Nr
+  unsigned long long rs[LC_RS_WORDS];            // repeat_scan: the string at 4 bits per base
   unsigned long long t_last, phase_acc[16];
   int phase_cur;
 };
@@ -202,7 +203,7 @@ DEV bool key_less(const unsigned long long *a, const unsigned long long *b, int 
 //   isAlmostRepeat(seq,k,mm) <=> Mm >= k+1   Mm = longest self-match window with <= mm mismatches, b+L-1 <= len-1
 // (the reference skips the last k-mer in both loops).  One shift d = b-a per lane.
 // ---------------------------------------------------------------------------------------------------------
-DEV void repeat_scan(const uint8_t *s, int len, int mm, volatile int *outE, volatile int *outM) {
+DEV void repeat_scan_bytes(const uint8_t *s, int len, int mm, volatile int *outE, volatile int *outM) {
   WG_LANE0 { *outE = 0; *outM = 0; }
   WG_SYNC();
   WG_FOR(dd, len > 1 ? len - 1 : 0) {
@@ -216,6 +217,49 @@ DEV void repeat_scan(const uint8_t *s, int len, int mm, volatile int *outE, vola
       while (mis > mm) { if (s[lo] != s[lo + d]) --mis; ++lo; }
       if (p - lo + 1 > bestM) bestM = p - lo + 1;
     }
+    if (bestE > 0) dev_atomic_max((uint32_t *)outE, (uint32_t)bestE);
+    if (bestM > 0) dev_atomic_max((uint32_t *)outM, (uint32_t)bestM);
+  }
+  WG_SYNC();
+}
+// Same result, bit-parallel: the string is staged in LDS at 4 bits per base; a lane owns a shift d and pulls the
+// mismatch flags of 16 positions out of two unaligned 64-bit words.  Only mismatch positions are visited:
+// with last[j] = position of the (j+1)-th most recent mismatch, the longest exact run ending before a mismatch q is
+// q-1-last[0] and the longest window with <= mm mismatches ending there is q-1-last[mm] (the two-pointer window).
+DEV void repeat_scan(volatile WinShared &S, const uint8_t *s, int len, int mm, volatile int *outE, volatile int *outM) {
+  if (mm > 7 || mm < 0 || len + 48 > 16 * LC_RS_WORDS) { repeat_scan_bytes(s, len, mm, outE, outM); return; }
+  WG_LANE0 { *outE = 0; *outM = 0; }
+  const int nwords = len / 16 + 3;
+  WG_FOR(w, nwords) {
+    unsigned long long v = 0;
+    for (int j = 0; j < 16; ++j) { int idx = 16 * w + j; if (idx < len) v |= (unsigned long long)(s[idx] & 15u) << (4 * j); }
+    S.rs[w] = v;
+  }
+  WG_SYNC();
+  const unsigned long long *rs = (const unsigned long long *)S.rs;
+  WG_FOR(dd, len > 1 ? len - 1 : 0) {
+    const int d = dd + 1;
+    const int lenE = len - 1 - d, lenM = len - d;
+    int l0 = -1, l1 = -1, l2 = -1, l3 = -1, l4 = -1, l5 = -1, l6 = -1, l7 = -1, lm = -1;
+    int bestE = 0, bestM = 0;
+    for (int p0 = 0; p0 < lenM; p0 += 16) {
+      const int wa = p0 >> 4, wb = (p0 + d) >> 4, sb = ((p0 + d) & 15) * 4;
+      const unsigned long long a = rs[wa];
+      const unsigned long long b = sb ? ((rs[wb] >> sb) | (rs[wb + 1] << (64 - sb))) : rs[wb];
+      unsigned long long x = a ^ b;
+      unsigned long long ne = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x1111111111111111ULL;
+      if (lenM - p0 < 16) ne &= (1ULL << (4 * (lenM - p0))) - 1ULL;
+      while (ne) {
+        const int q = p0 + (__builtin_ctzll(ne) >> 2);
+        ne &= ne - 1ULL;
+        const int cm = q - 1 - lm; if (cm > bestM) bestM = cm;
+        const int ce = (q < lenE ? q : lenE) - 1 - l0; if (ce > bestE) bestE = ce;
+        l7 = l6; l6 = l5; l5 = l4; l4 = l3; l3 = l2; l2 = l1; l1 = l0; l0 = q;
+        lm = mm == 0 ? l0 : mm == 1 ? l1 : mm == 2 ? l2 : mm == 3 ? l3 : mm == 4 ? l4 : mm == 5 ? l5 : mm == 6 ? l6 : l7;
+      }
+    }
+    { const int cm = lenM - 1 - lm; if (cm > bestM) bestM = cm;
+      const int ce = lenE - 1 - l0; if (ce > bestE) bestE = ce; }
     if (bestE > 0) dev_atomic_max((uint32_t *)outE, (uint32_t)bestE);
     if (bestM > 0) dev_atomic_max((uint32_t *)outM, (uint32_t)bestM);
   }
@@ -925,23 +969,96 @@ DEV void build_graph(Ctx &c) {
   STOP_RET(c, 6);
 }
 
-// first removeLowCov(false, 0) + cleanDead; markRefNodes counters for the trace
+// ---------------------------------------------------------------------------------------------------------
+// libstdc++ iteration order of the node table after the build (nodes were inserted in id order 0..N-1).
+// The sequential replay (ht_insert) costs ~3N dependent memory round trips; the same order has a closed form per
+// growth stage.  While the bucket count is B, every insertion AND every rehash step applies one rule to an element x
+// of a sequence Q: "bucket(x) empty -> x becomes the list head; else x goes to the front of its bucket's run".
+// Hence after processing Q the list is: runs ordered by the position of their first element in Q, latest first;
+// inside a run, latest first.  Q of a stage = (list of the previous stage, then the node ids inserted before the next
+// rehash).  Each stage is a counting sort by (first position of the bucket desc, position desc): all parallel.
+// The first 541 insertions (6 small stages) are replayed sequentially.
+// ---------------------------------------------------------------------------------------------------------
+DEV void order_stage(Ctx &c, const uint32_t *Q, uint32_t *Qn, int n, uint32_t B) {
+  volatile WinShared &S = *c.S; Work &W = *c.W;
+  uint32_t *bkt = W.scratch, *tmp = W.scratch + c.C->node_cap;
+  uint32_t *first = W.ht_bucket, *cnt = W.ht_cnt, *start = W.ht_start, *out = W.ht_next;
+  WG_FOR(b, (int)B) { cnt[b] = 0; first[b] = LC_NIL; }
+  WG_SYNC();
+  WG_FOR(i, n) {
+    uint32_t b = (uint32_t)(W.nhash[Q[i]] % B);
+    bkt[i] = b;
+    dev_atomic_add(&cnt[b], 1u);
+    dev_atomic_min(&first[b], (uint32_t)i);
+  }
+  WG_SYNC();
+  WG_FOR(i, n) { uint32_t b = bkt[i]; tmp[n - 1 - i] = (ld2(&first[b]) == (uint32_t)i) ? ld2(&cnt[b]) : 0u; }
+  WG_SYNC();
+  wg_scan(tmp, n, S);                                   // elements in front of the run that starts with position i
+  WG_FOR(i, n) { uint32_t b = bkt[i]; if (ld2(&first[b]) == (uint32_t)i) start[b] = tmp[n - 1 - i]; }
+  WG_SYNC();
+  WG_FOR(b, (int)B) { first[b] = 0; }                   // from here: fill cursor of the run
+  WG_SYNC();
+  WG_FOR(i, n) { uint32_t b = bkt[i]; uint32_t at = start[b] + dev_atomic_add(&first[b], 1u); out[at] = (uint32_t)i; }
+  WG_SYNC();
+  WG_FOR(b, (int)B) {
+    uint32_t m = ld2(&cnt[b]);
+    if (m > 1) {
+      uint32_t *o = out + start[b];
+      for (uint32_t i = 1; i < m; ++i) { uint32_t v = o[i]; uint32_t j = i; while (j > 0 && o[j - 1] < v) { o[j] = o[j - 1]; --j; } o[j] = v; }
+    }
+  }
+  WG_SYNC();
+  WG_FOR(j, n) { Qn[j] = Q[out[j]]; }
+  WG_SYNC();
+}
+
+// the live table in libstdc++ iteration order -> order[0..M)
 DEV void first_lowcov(Ctx &c) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
-  // the live table in libstdc++ iteration order
+  const uint32_t SEQ = 541u;                            // a value of the growth chain
   WG_LANE0 {
     ht_reset(c);
-    for (uint32_t n = 0; n < S.N && !S.overflow; ++n) ht_insert(c, n);
+    uint32_t lim = S.N < SEQ ? S.N : SEQ;
+    for (uint32_t n = 0; n < lim && !S.overflow; ++n) ht_insert(c, n);
     uint32_t m = 0;
     for (uint32_t p = S.ht_head; p != LC_NIL; p = W.ht_next[p]) W.order[m++] = p;
     S.M = m;
   }
-  WG_SYNC();
+  const uint32_t N = wg_bcastu(&S.N);
+  if (N <= SEQ) return;
+  uint32_t *Q = W.order, *Qn = W.pnodes;
+  uint32_t nprev = SEQ, B = SEQ;
+  while (true) {
+    B = ht_next_prime(2u * B);
+    if (B == 0 || B > c.C->bucket_cap) { WG_LANE0 { OVF(c); } return; }
+    const uint32_t n = N < B ? N : B;
+    WG_FOR(j, (int)(n - nprev)) { Q[nprev + j] = nprev + (uint32_t)j; }
+    WG_SYNC();
+    order_stage(c, Q, Qn, (int)n, B);
+    uint32_t *t = Q; Q = Qn; Qn = t;
+    if (N <= B) break;
+    nprev = B;
+  }
+  if (Q != W.order) { WG_FOR(j, (int)N) { W.order[j] = Q[j]; } WG_SYNC(); }
+  WG_LANE0 { S.M = N; S.ht_bc = B; S.ht_elt = N; S.ht_next_resize = B; S.ht_head = LC_NIL; }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// graph passes (single lane; the graphs are small after the first filter)
-// ---------------------------------------------------------------------------------------------------------
+// cleanDead over the whole table (reference src/Graph.cc:2737-2762), parallel: compaction of order[] keeping the order
+DEV void clean_dead_wg(Ctx &c) {
+  volatile WinShared &S = *c.S; Work &W = *c.W;
+  const int M = (int)wg_bcastu(&S.M);
+  uint32_t *keep = W.scratch;
+  WG_FOR(i, M) { keep[i] = (W.gr[W.order[i]].flags & NF_DEAD) ? 0u : 1u; }
+  WG_LANE0 { keep[M] = 0; }
+  wg_scan(keep, M + 1, S);
+  WG_FOR(i, M) { if (keep[i + 1] != keep[i]) W.pnodes[keep[i]] = W.order[i]; }
+  WG_SYNC();
+  const int live = (int)wg_bcastu(&S.part[LANCET_WG]);
+  WG_FOR(i, live) { W.order[i] = W.pnodes[i]; }
+  WG_LANE0 { S.M = (uint32_t)live; S.ht_elt -= (uint32_t)(M - live); evt(c, EV_CLEANDEAD, (uint32_t)(M - live)); }
+}
+
 DEV void recompute_after_append(Ctx &c, uint32_t n, uint32_t from, uint32_t to) {
   // Node_t::computeMinCov over the merged arrays == min(old minima, minima over the appended descriptors)
   Work &W = *c.W;
@@ -1699,7 +1816,7 @@ DEV bool repeats_in_graph_paths(Ctx &c) {
       else { S.tmp2 = path_unpack(c, best); S.tmp3 = path_string(c, S.tmp2); if (S.overflow) S.tmp0 = 1; }
     }
     if (wg_bcast(&S.tmp0) != 0) break;
-    repeat_scan(W.pseq, wg_bcast(&S.tmp3), c.P->max_mismatch, &S.repE, &S.repM);      // isAlmostRepeat(path->str(), K, MAX_MISMATCH)
+    repeat_scan(S, W.pseq, wg_bcast(&S.tmp3), c.P->max_mismatch, &S.repE, &S.repM);      // isAlmostRepeat(path->str(), K, MAX_MISMATCH)
     WG_LANE0 {
       // NB isAlmostRepeat only looks at windows that end before the last base: handled inside repeat_scan
       if (S.tmp3 - S.K > 0 && S.repM >= S.K + 1) { evt(c, EV_NEAR_QRY, S.K); S.tmp0 = 2; }
@@ -1795,7 +1912,7 @@ DEV void process_window(Ctx &c, int w) {
   if (wg_bcast(&S.overflow)) { WG_LANE0 { S.status = LANCET_W_OVERFLOW; } WG_SYNC(); return; }
   const int reflen = wg_bcast(&S.reflen);
   PHASE(c, 1);
-  repeat_scan(B.ref_codes + B.ref_off[w], reflen, c.P->max_mismatch, &S.repE, &S.repM);
+  repeat_scan(S, B.ref_codes + B.ref_off[w], reflen, c.P->max_mismatch, &S.repE, &S.repM);
   PHASE(c, 0);
   const int refE = wg_bcast(&S.repE), refM = wg_bcast(&S.repM);
   int rptInRef = 0, rptInQry = 0, cycleInGraph = 0;
@@ -1825,9 +1942,9 @@ DEV void process_window(Ctx &c, int w) {
         evt(c, EV_MARKREF, S.N, refn);
         evt(c, EV_LOWCOV, low);
       }
-      // removeNode for every non-survivor: drop the reciprocal edges, then erase from the table
-      for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (!(W.gr[n].flags & NF_SURV)) W.gr[n].flags |= NF_DEAD; }
     }
+    // removeNode for every non-survivor: drop the reciprocal edges, then erase from the table
+    WG_FOR(n, S.N) { if (!(W.gr[n].flags & NF_SURV)) W.gr[n].flags |= NF_DEAD; }
     WG_SYNC();
     WG_FOR(n, S.N) {
       if (W.gr[n].flags & NF_DEAD) continue;
@@ -1836,8 +1953,8 @@ DEV void process_window(Ctx &c, int w) {
       W.gr[n].necnt = m;
     }
     WG_SYNC();
+    clean_dead_wg(c);
     WG_LANE0 {
-      clean_dead(c);
       print_stats(c, 0);
       S.numcomp = mark_connected_components(c);
     }

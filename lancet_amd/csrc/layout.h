@@ -11,6 +11,7 @@
 #define LC_NIL 0xFFFFFFFFu
 #define LC_BB 0xFFFFFFFEu     /* libstdc++ _M_before_begin sentinel in the bucket array                   */
 #define LC_MAXW 640           /* window length cap (reference WINDOW_SIZE = 600)                          */
+#define LC_RS_WORDS 96        /* 64-bit words of the LDS copy of a string in repeat_scan (16 bases each) */
 #define LC_MAXTS 64           /* transcripts per path                                                     */
 
 /* per-read info word (DevBatch::rinfo) */
@@ -137,6 +138,8 @@ struct Work {
   /* ---- libstdc++ node-table order ---- */
   uint32_t *ht_next;      /* [nodes]                                                           */
   uint32_t *ht_bucket;    /* [bucket_cap]                                                      */
+  uint32_t *ht_cnt;       /* [bucket_cap] parallel order stages: elements per bucket           */
+  uint32_t *ht_start;     /* [bucket_cap] parallel order stages: first list position of the run */
   uint32_t *order;        /* [nodes] iteration order of the live table                         */
   uint32_t *scratch;      /* [nodes*2] stacks / queues of the graph passes                     */
   /* ---- reference coverage ---- */

@@ -62,3 +62,11 @@ extern "C" const lancet_window_stats *lancet_emu_stats(void *h) { return ((EmuRe
 extern "C" const uint32_t *lancet_emu_evt_len(void *h) { return ((EmuResult *)h)->evt_len.data(); }
 extern "C" const uint32_t *lancet_emu_evt(void *h) { return ((EmuResult *)h)->evt.data(); }
 extern "C" void lancet_emu_free(void *h) { delete (EmuResult *)h; }
+
+// repeat_scan both ways (bit-parallel LDS version vs the byte-wise restatement) for the unit test
+extern "C" void lancet_emu_repeat_scan(const uint8_t *s, int len, int mm, int bitparallel, int *outE, int *outM) {
+  static WinShared S;
+  volatile int e = 0, m = 0;
+  if (bitparallel) repeat_scan(S, s, len, mm, &e, &m); else repeat_scan_bytes(s, len, mm, &e, &m);
+  *outE = e; *outM = m;
+}

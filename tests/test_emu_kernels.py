@@ -24,3 +24,31 @@ def test_emulated_kernels_match_oracle_and_reference_trace(case):
     key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
     assert [key(s) for s in st] == [key(s) for s in ost]
     assert gu.digest_trace(tr) == gu.golden_trace(case)
+
+
+def test_repeat_scan_bitparallel_matches_bytewise():
+    """The LDS/bit-parallel repeat scan (isRepeat / isAlmostRepeat operands, reference src/util.cc:295-360) against
+    the byte-wise restatement on random, repetitive and N-containing strings, several mismatch budgets."""
+    import ctypes
+    import numpy as np
+    L = emu.lib()
+    f = L.lancet_emu_repeat_scan
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    f.restype = None
+    rng = np.random.default_rng(5)
+    cases = []
+    for n in (1, 2, 3, 15, 16, 17, 31, 33, 100, 600, 601, 1396):
+        cases.append(rng.integers(0, 4, size=n).astype(np.uint8))
+    unit = rng.integers(0, 4, size=7).astype(np.uint8)
+    cases.append(np.tile(unit, 60)[:400])
+    s = rng.integers(0, 4, size=600).astype(np.uint8); s[300:340] = s[100:140]; s[310] ^= 1; cases.append(s)
+    s = rng.integers(0, 4, size=600).astype(np.uint8); s[50:90] = 4; cases.append(s)          # run of N
+    s = np.zeros(640, dtype=np.uint8); cases.append(s)
+    for s in cases:
+        for mm in (0, 1, 2, 3, 7, 9):
+            out = []
+            for bp in (0, 1):
+                e, m = ctypes.c_int(-1), ctypes.c_int(-1)
+                f(s.ctypes.data, len(s), mm, bp, ctypes.byref(e), ctypes.byref(m))
+                out.append((e.value, m.value))
+            assert out[0] == out[1], (len(s), mm, out)
