@@ -72,6 +72,8 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.occ_base = k.take<uint32_t>(c.reads_cap + 1);
   t.cand = k.take<uint8_t>(c.reads_cap);
   t.mate_of = k.take<uint32_t>(c.reads_cap);
+  t.items = k.take<uint32_t>(2 * ((size_t)c.reads_cap + LC_MAXW / LC_SEG + 2));
+  t.chunk = k.take<uint32_t>(2 * (((size_t)c.reads_cap + LC_MAXW / LC_SEG + 2) / 64 + 2));
   t.occ = k.take<uint32_t>(c.occ_cap);
   t.tags = k.take<unsigned long long>(c.table_cap);
   t.slot_key = k.take<unsigned long long>((size_t)c.table_cap * LC_NWMAX);

@@ -44,6 +44,7 @@ struct WinShared {
   uint32_t max_nodes;
   int n_builds, final_k, status;
   int tmp0, tmp1, tmp2, tmp3, hasN;
+  int nitems;                          // work items of the per-occurrence passes (build_items)
   uint32_t part[LANCET_WG + 1];
   uint32_t mk[LANCET_WG][4], mmeta[LANCET_WG];   // staged quality masks of up to one wave of occurrences
   uint32_t acc[128][4];                          // per k-mer position running counts Tf Tr Nf Nr
@@ -509,34 +510,81 @@ DEV bool nk_is_forward(const uint8_t *ref, int p, int K) {                      
   return false;
 }
 
+// ---- work items of the per-occurrence passes: one per read, the (long) reference pseudo-read cut into segments of
+// LC_SEG k-mer starts so that no lane trails the wave.  items[2i] = read | first k-mer start << 16,
+// items[2i+1] = sweep offset | number of k-mer starts << 16.  chunk[2c], chunk[2c+1] = sweep origin / length of the
+// c-th group of LANCET_WG items.  The sweep offset lines the lanes of a group up on the same genome position
+// (reads arrive in coordinate order per sample, so rank * (W - len) / n is a fair estimate of a read's start): at a
+// given step the lanes then touch the same few table slots / nodes, which the L2 can coalesce.
+DEV void build_items(Ctx &c) {
+  volatile WinShared &S = *c.S; Work &W = *c.W;
+  WG_LANE0 {
+    const uint32_t g0 = c.B->read_begin[S.w];
+    const int nr = S.R - 1;
+    int n = 0;
+    for (int r = 0; r < nr; ++r) {
+      int tlen = (int)RI_TLEN(c.B->rinfo[g0 + r]);
+      if (tlen <= 0) continue;
+      W.items[2 * n] = (uint32_t)r; W.items[2 * n + 1] = ((uint32_t)tlen << 16); ++n;
+    }
+    for (int b0 = 0; b0 < S.reflen; b0 += LC_SEG) {
+      int len = S.reflen - b0 < LC_SEG ? S.reflen - b0 : LC_SEG;
+      W.items[2 * n] = (uint32_t)nr | ((uint32_t)b0 << 16); W.items[2 * n + 1] = ((uint32_t)len << 16); ++n;
+    }
+    S.nitems = n;
+    for (int cb = 0; cb < n; cb += LANCET_WG) {
+      uint32_t lo = 0xFFFFu, hi = 0;
+      for (int j = cb; j < n && j < cb + LANCET_WG; ++j) { uint32_t e = W.items[2 * j + 1] & 0xFFFFu, l = W.items[2 * j + 1] >> 16; if (e < lo) lo = e; if (e + l > hi) hi = e + l; }
+      W.chunk[2 * (cb / LANCET_WG)] = lo; W.chunk[2 * (cb / LANCET_WG) + 1] = hi - lo;
+    }
+  }
+}
+#define ITEMS_BEGIN(c, S, W) \
+  for (int _cb = 0, _ni = wg_uniform((S).nitems); _cb < _ni; _cb += LANCET_WG) { \
+    const int _tlo = (int)(W).chunk[2 * (_cb / LANCET_WG)], _span = (int)(W).chunk[2 * (_cb / LANCET_WG) + 1]; \
+    WG_FOR(_j, (_ni - _cb < LANCET_WG ? _ni - _cb : LANCET_WG)) { \
+      const uint32_t _i0 = (W).items[2 * (_cb + _j)], _i1 = (W).items[2 * (_cb + _j) + 1]; \
+      const int r = (int)(_i0 & 0xFFFFu), _b0 = (int)(_i0 >> 16), _e = (int)(_i1 & 0xFFFFu) - _tlo; \
+      uint32_t rinfo, bw, gw; int tlen; bool isref; \
+      read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref); \
+      const int nk = tlen - (S).K + 1; \
+      const int pbeg = _b0, pend = (_b0 + (int)(_i1 >> 16) < nk) ? _b0 + (int)(_i1 >> 16) : nk; \
+      if (pend <= pbeg) continue;
+#define ITEMS_SWEEP(p) for (int _t = 0; _t < _span; ++_t) { const int p = pbeg + _t - _e; if (p < pbeg || p >= pend) continue;
+#define ITEMS_END } } }
+
 template <int NW>
 DEV void build_insert_pass(Ctx &c, bool verify) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   const int K = S.K;
   const uint32_t mask = c.C->table_cap - 1;
-  WG_FOR(r, S.R) {
-    uint32_t rinfo, bw, gw; int tlen; bool isref;
-    read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref);
-    if (tlen - K <= 0) continue;
+  ITEMS_BEGIN(c, S, W)
     unsigned long long fw[NW], rc[NW];
     for (int w = 0; w < NW; ++w) { fw[w] = 0; rc[w] = 0; }
-    uint32_t o = W.occ_base[r];
+    const uint32_t obase = W.occ_base[r];
     const uint8_t *refc = c.B->ref_codes + c.B->ref_off[S.w];
     int nN = 0;                                                  // N's among the last K bases (reference read only)
-    for (int i = 0; i < tlen; ++i) {
+    for (int i = pbeg; i < pbeg + K - 1; ++i) {                  // the K-1 bases before the first k-mer's last one
       int b = read_base(c, isref, bw, i);
-      if (isref) { if (b > 3) ++nN; if (i >= K && refc[i - K] > 3) --nN; }
+      if (isref && b > 3) ++nN;
       key_push_fw(fw, NW, K, b & 3);
       key_push_rc(rc, NW, K, b & 3);
-      if (i < K - 1) continue;
-      const bool nk = nN > 0;                                    // this k-mer contains N
-      const int p = i - K + 1;
-      bool isF = nk ? nk_is_forward(refc, p, K) : key_less(fw, rc, NW);   // CanonicalMer_t::set: mer < rmer -> F, tie -> R
+    }
+    ITEMS_SWEEP(p)
+      {
+        int b = read_base(c, isref, bw, p + K - 1);
+        if (isref) { if (b > 3) ++nN; if (p > pbeg && refc[p - 1] > 3) --nN; }
+        key_push_fw(fw, NW, K, b & 3);
+        key_push_rc(rc, NW, K, b & 3);
+      }
+      const uint32_t o = obase + (uint32_t)p;
+      const bool nk_ = nN > 0;                                   // this k-mer contains N
+      bool isF = nk_ ? nk_is_forward(refc, p, K) : key_less(fw, rc, NW);   // CanonicalMer_t::set: mer < rmer -> F, tie -> R
       const unsigned long long *ck = isF ? fw : rc;
       if (!verify) {
         unsigned long long h = 0;
         uint32_t idx;
-        if (nk) {
+        if (nk_) {
           for (int j = 0; j < K; ++j) h = mix64(h * 131ULL + (unsigned long long)(nk_char(refc, p, K, !isF, j) + 1));
           h |= 1ULL << 63;                                       // tag space disjoint from ordinary k-mers
           idx = (uint32_t)mix64(h) & mask;
@@ -554,7 +602,7 @@ DEV void build_insert_pass(Ctx &c, bool verify) {
           if (cur == 0) {
             unsigned long long old = dev_atomic_cas64(&W.tags[idx], 0ULL, h);
             if (old == 0) {
-              if (nk) W.slot_key[(size_t)idx * LC_NWMAX] = ((unsigned long long)p << 1) | (isF ? 0ULL : 1ULL);   // where the string lives
+              if (nk_) W.slot_key[(size_t)idx * LC_NWMAX] = ((unsigned long long)p << 1) | (isF ? 0ULL : 1ULL);   // where the string lives
               else for (int w = 0; w < NW; ++w) W.slot_key[(size_t)idx * LC_NWMAX + w] = ck[w];
               break;
             }
@@ -567,7 +615,7 @@ DEV void build_insert_pass(Ctx &c, bool verify) {
         W.occ[o] = idx | (isF ? 0u : 0x80000000u);
       } else {
         uint32_t idx = W.occ[o] & 0x3FFFFFFFu;
-        if (nk) {
+        if (nk_) {
           unsigned long long sk = W.slot_key[(size_t)idx * LC_NWMAX];
           int p2 = (int)(sk >> 1); bool r2 = (sk & 1ULL) != 0;
           for (int j = 0; j < K; ++j) if (nk_char(refc, p, K, !isF, j) != nk_char(refc, p2, K, r2, j)) { OVF(c); break; }
@@ -575,9 +623,7 @@ DEV void build_insert_pass(Ctx &c, bool verify) {
           for (int w = 0; w < NW; ++w) if (W.slot_key[(size_t)idx * LC_NWMAX + w] != ck[w]) OVF(c);   // 64-bit tag collision
         }
       }
-      ++o;
-    }
-  }
+  ITEMS_END
   WG_SYNC();
 }
 
@@ -671,18 +717,14 @@ DEV void build_graph(Ctx &c) {
   PHASE(c, 4);
   STOP_RET(c, 4);
   // ---- pass 2a: occurrences slot -> node id; occurrences per node (the only per-occurrence atomic, on a compact array)
-  WG_FOR(r, S.R) {
-    uint32_t rinfo, bw, gw; int tlen; bool isref;
-    read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref);
-    if (tlen - K <= 0) continue;
-    uint32_t o0 = W.occ_base[r];
-    for (int p = 0; p < tlen - K + 1; ++p) {
+  ITEMS_BEGIN(c, S, W)
+    const uint32_t o0 = W.occ_base[r];
+    ITEMS_SWEEP(p)
       uint32_t oc = W.occ[o0 + p];
       uint32_t X = W.slot_node[oc & 0x3FFFFFFFu];
       dev_atomic_add(&W.nocc[X], 1u);
       W.occ[o0 + p] = X | (oc & 0x80000000u);
-    }
-  }
+  ITEMS_END
   WG_SYNC();
   // ---- mate-overlap prefilter: an occurrence of a candidate read can only be suppressed if the node also holds an
   //      occurrence of its earlier opposite mate.  Node ids of the mate go into a small private open-addressing set;
@@ -730,19 +772,15 @@ DEV void build_graph(Ctx &c) {
   WG_SYNC();
   // ---- csr of occurrences by node
   wg_scan(W.nocc, (int)S.N + 1, S);
-  WG_FOR(r, S.R) {
-    uint32_t rinfo, bw, gw; int tlen; bool isref;
-    read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref);
-    if (tlen - K <= 0) continue;
-    uint32_t o0 = W.occ_base[r];
-    for (int p = 0; p < tlen - K + 1; ++p) {
+  ITEMS_BEGIN(c, S, W)
+    const uint32_t o0 = W.occ_base[r];
+    ITEMS_SWEEP(p)
       uint32_t oc = W.occ[o0 + p];
       uint32_t X = oc & 0x3FFFFFFFu;
       uint32_t st = isref ? 2u : ((oc & 0x40000000u) ? 1u : 0u);     // the reference read never counts (Graph.cc:265)
       uint32_t at = W.nocc[X] + dev_atomic_add(&W.nfill[X], 1u);
       W.csr[at] = CS_MAKE(r, p, oc >> 31, st);
-    }
-  }
+  ITEMS_END
   WG_SYNC();
   // ---- exact replay for what is left (sequential, rare): reproduces std::binary_search over the unsorted vector of
   //      opposite-mate names pushed so far on the node.
@@ -1911,6 +1949,7 @@ DEV void process_window(Ctx &c, int w) {
   if (wg_bcast(&S.tmp0) <= 0) { WG_LANE0 { S.status = LANCET_W_NO_READS; } WG_SYNC(); return; }     // Microassembler.cc:83
   if (wg_bcast(&S.overflow)) { WG_LANE0 { S.status = LANCET_W_OVERFLOW; } WG_SYNC(); return; }
   const int reflen = wg_bcast(&S.reflen);
+  build_items(c);
   PHASE(c, 1);
   repeat_scan(S, B.ref_codes + B.ref_off[w], reflen, c.P->max_mismatch, &S.repE, &S.repM);
   PHASE(c, 0);

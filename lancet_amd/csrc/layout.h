@@ -12,6 +12,7 @@
 #define LC_BB 0xFFFFFFFEu     /* libstdc++ _M_before_begin sentinel in the bucket array                   */
 #define LC_MAXW 640           /* window length cap (reference WINDOW_SIZE = 600)                          */
 #define LC_RS_WORDS 96        /* 64-bit words of the LDS copy of a string in repeat_scan (16 bases each) */
+#define LC_SEG 128            /* k-mer starts per work item of the reference pseudo-read                    */
 #define LC_MAXTS 64           /* transcripts per path                                                     */
 
 /* per-read info word (DevBatch::rinfo) */
@@ -118,6 +119,8 @@ struct Work {
   uint32_t *occ_base;     /* [reads_cap+1] first occurrence index of each read                 */
   uint8_t *cand;          /* [reads_cap]   read has an earlier opposite mate of the same name  */
   uint32_t *mate_of;      /* [reads_cap]   index of that earlier mate (when unique)            */
+  uint32_t *items;        /* [2*(reads_cap + LC_MAXW/LC_SEG + 2)] work items of the per-occurrence passes */
+  uint32_t *chunk;        /* [2*((reads_cap + LC_MAXW/LC_SEG + 2)/64 + 2)] sweep origin/length per group of items */
   uint32_t *occ;          /* [occ_cap]     slot (then node) | ori<<31                           */
   unsigned long long *tags;     /* [table_cap]                                               */
   unsigned long long *slot_key; /* [table_cap * LC_NWMAX]                                    */
