@@ -24,9 +24,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--windows", type=int, default=8192, help="windows per GPU per step")
+    ap.add_argument("--windows", type=int, default=32768, help="windows per GPU per step")
     ap.add_argument("--cov", type=float, default=30.0, help="coverage per sample")
-    ap.add_argument("--cpu-sample", type=int, default=192, help="windows timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1536, help="windows timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
 
     import numpy as np
@@ -110,6 +110,16 @@ def main():
                          "frac": round(achieved / 8000.0, 6), "traffic": None,
                          "kernel": "window_kernel", "kernel_ms": round(ms_kernel, 3), "algorithmic_bytes_per_launch": alg_bytes},
         }
+        # HBM-side bytes per launch from the committed PMC passes (tools/pmc_total.sh -> profiles/r1_traffic.json):
+        # rocprofv3 cannot run inside this process, so the figure is looked up for the exact workload it was taken on
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as fh:
+                for rec in json.load(fh)["measurements"]:
+                    if rec["windows"] == args.windows and rec["coverage"] == args.cov and world == 1:
+                        out["roofline"]["traffic"] = int((rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024)
+                        out["roofline"]["traffic_note"] = rec["note"]
+        except (OSError, KeyError, ValueError):
+            pass
         if args.cpu_sample and world == 1:
             from oracle import oracle
             ns = min(args.cpu_sample, batch.n_windows)

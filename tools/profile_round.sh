@@ -1,0 +1,9 @@
+# Round profile set on the GPU box: bench line, rocprofv3 kernel-trace stats of the same command, PMC traffic passes.
+TAG=${1:-r1_b}
+cd /root/repo; mkdir -p gpurun_out/$TAG
+python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err; tail -1 gpurun_out/$TAG/bench.json | cut -c1-300
+cd /tmp && export TMPDIR=/tmp
+rm -rf /root/repo/gpurun_out/$TAG/kt
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/$TAG/kt -- python /root/repo/bench.py --cpu-sample 0 > /root/repo/gpurun_out/$TAG/kt.log 2>&1
+cat /root/repo/gpurun_out/$TAG/kt/*/*kernel_stats.csv | head -12
+bash /root/repo/tools/pmc_total.sh | tee /root/repo/gpurun_out/$TAG/pmc.txt
