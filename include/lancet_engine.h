@@ -50,7 +50,7 @@ typedef struct lancet_params {
   int32_t min_report_units;  /* MIN_REPORT_UNITS 3           */
   int32_t min_report_len;    /* MIN_REPORT_LEN 7             */
   int32_t dist_from_str;     /* DIST_FROM_STR 1              */
-  int32_t lr_mode;           /* --linked-reads; must be 0 in this version (LANCET_E_UNSUPPORTED) */
+  int32_t lr_mode;           /* --linked-reads (LR_MODE false): barcode/haplotype aware coverage   */
   int32_t reserved;
   double  min_cov_ratio;     /* MIN_COV_RATIO 0.01           */
 } lancet_params;
@@ -75,7 +75,13 @@ typedef struct lancet_window_batch {
   const uint8_t  *mapped;      /* [n_reads] 1 = CODE_MAPPED, 0 = CODE_BASTARD (ReadInfo_t::code_m)     */
   const uint32_t *name_rank;   /* [n_reads] dense rank of ReadInfo_t::readname_m among the window's
                                   read names under std::string operator< (equal names = equal rank)   */
+  /* --linked-reads only (lancet_params::lr_mode != 0); may be NULL otherwise.
+   * reference: ReadInfo_t::BX / HP (src/ReadInfo.hh:60-61), filled by extractReads (src/Microassembler.cc:581-593) */
+  const uint32_t *bx_rank;     /* [n_reads] dense rank of the BX:Z barcode among the batch's barcodes under
+                                  std::string operator< ; LANCET_NO_BX for a read without barcode ("null")   */
+  const uint8_t  *hp;          /* [n_reads] HP:i haplotype 0 (unassigned / absent) | 1 | 2                    */
 } lancet_window_batch;
+#define LANCET_NO_BX 0xFFFFFFFFu
 
 /* One addVar(Variant_t(...)) call, arguments as passed at reference src/Graph.cc:1184-1188. */
 typedef struct lancet_variant {
@@ -96,6 +102,16 @@ typedef struct lancet_variant {
 } lancet_variant;
 
 /* Per-window outcome. */
+/* Linked-read annotations of variant i (same index as the lancet_variant array); all zero / empty unless lr_mode.
+ * Replaces the HPRN/HPRT/HPAN/HPAT and bxset_* arguments of the Variant_t constructor (reference src/Graph.cc:1166-1188). */
+typedef struct lancet_variant_lr {
+  uint16_t hp[12];          /* HPRN, HPRT, HPAN, HPAT ; each {hp1, hp2, hp0}                                  */
+  uint32_t bx_off[4];       /* bxset_ref_N, bxset_ref_T, bxset_alt_N, bxset_alt_T : offset (in u32) into bx_blob */
+  uint32_t bx_len[4];       /* number of barcodes; they are bx_rank values in increasing order (== the ';'-joined
+                               std::set<string> order of the reference); len 0 prints as "."                   */
+  uint32_t reserved[2];
+} lancet_variant_lr;
+
 typedef struct lancet_window_stats {
   int32_t  status;        /* LANCET_W_* below                                                        */
   int32_t  final_k;       /* k of the last graph build (0 if none)                                   */
@@ -148,6 +164,8 @@ int lancet_engine_results(lancet_engine *e, const lancet_variant **variants, uin
 
 /* Timing of the last run as measured with HIP events on the engine's stream (milliseconds):
  * out[0] = all kernels of the run, out[1] = the assembly kernel only. */
+/* Linked-read annotations of the last run (lr_mode engines; otherwise *lr = NULL): lr[i] belongs to variants[i]. */
+int lancet_engine_results_lr(lancet_engine *e, const lancet_variant_lr **lr, const uint32_t **bx_blob, uint32_t *bx_blob_len);
 int lancet_engine_last_timing(lancet_engine *e, float out[2]);
 
 /* ---- host side of the seam: Variant_t normalisation + VariantDB + VCF ----------
@@ -167,6 +185,12 @@ void lancet_vdb_destroy(lancet_vdb *db);
 /* addVar for records [0,n) in the given order; chr_names[chr_id] gives the chromosome string. */
 int  lancet_vdb_add(lancet_vdb *db, const lancet_variant *v, uint32_t n, const char *blob,
                     const char *const *chr_names, int32_t n_chr);
+/* --linked-reads flavour of lancet_vdb_add (VariantDB_t(LR_MODE=true)): lr / bx_blob from lancet_engine_results_lr,
+ * bx_names[rank] = the barcode strings the batch's bx_rank values refer to.  A database is either fed with
+ * lancet_vdb_add only or with lancet_vdb_add_lr only. */
+int  lancet_vdb_add_lr(lancet_vdb *db, const lancet_variant *v, const lancet_variant_lr *lr, uint32_t n, const char *blob,
+                       const uint32_t *bx_blob, const char *const *bx_names, uint32_t n_bx,
+                       const char *const *chr_names, int32_t n_chr);
 uint32_t lancet_vdb_size(const lancet_vdb *db);
 /* Writes the VCF (header + sorted body) into a malloc'd string the caller frees with lancet_free.
  * date_line: text after "##fileDate=" (ctime() format incl. trailing newline), may be NULL -> omitted. */

@@ -34,7 +34,12 @@ class LancetWindowBatch(C.Structure):
         ("seq", C.c_char_p), ("qual", C.c_char_p),
         ("label", C.POINTER(C.c_uint8)), ("strand", C.POINTER(C.c_uint8)), ("mate", C.POINTER(C.c_uint8)),
         ("mapped", C.POINTER(C.c_uint8)), ("name_rank", C.POINTER(C.c_uint32)),
+        ("bx_rank", C.POINTER(C.c_uint32)), ("hp", C.POINTER(C.c_uint8)),
     ]
+
+
+class LancetVariantLR(C.Structure):
+    _fields_ = [("hp", C.c_uint16 * 12), ("bx_off", C.c_uint32 * 4), ("bx_len", C.c_uint32 * 4), ("reserved", C.c_uint32 * 2)]
 
 
 class LancetVariant(C.Structure):
@@ -81,6 +86,9 @@ def batch_to_c(b) -> LancetWindowBatch:
     cb.mate = _p(b.mate, C.c_uint8)
     cb.mapped = _p(b.mapped, C.c_uint8)
     cb.name_rank = _p(b.name_rank, C.c_uint32)
+    if getattr(b, "bx_rank", None) is not None:
+        cb.bx_rank = _p(b.bx_rank, C.c_uint32)
+        cb.hp = _p(b.hp, C.c_uint8)
     cb._keep = b
     return cb
 
@@ -94,6 +102,15 @@ def variants_to_py(vptr, n: int, blob: bytes) -> List[dict]:
             prev_bp_ref=chr(v.prev_bp_ref), prev_bp_alt=chr(v.prev_bp_alt), kmer=v.kmer, cov=tuple(v.cov),
             ref=blob[v.ref_off:v.ref_off + v.ref_len].decode(), alt=blob[v.alt_off:v.alt_off + v.alt_len].decode(),
             str=blob[v.str_off:v.str_off + v.str_len].decode()))
+    return out
+
+
+def variants_lr_to_py(out: List[dict], lrptr, bx_blob) -> List[dict]:
+    """Adds the linked-read annotations (hp: 12 counts, bx: 4 tuples of barcode ranks) to variants_to_py's dicts."""
+    for i, d in enumerate(out):
+        l = lrptr[i]
+        d["hp"] = tuple(l.hp)
+        d["bx"] = tuple(tuple(int(bx_blob[l.bx_off[q] + j]) for j in range(l.bx_len[q])) for q in range(4))
     return out
 
 

@@ -69,7 +69,7 @@ struct lancet_engine {
   // device buffers
   DevBuf d_params, d_batch, d_caps, d_out, d_works;
   DevBuf d_chr, d_refstart, d_refoff, d_refasc, d_refcodes, d_readbegin, d_seqoff, d_seq, d_qual, d_label, d_strand, d_mate, d_mapped,
-      d_rinfo, d_name, d_bw, d_gw, d_bases, d_good;
+      d_rinfo, d_name, d_bw, d_gw, d_bases, d_good, d_bx, d_hp, d_varlr, d_bxblob;
   DevBuf d_variants, d_blob, d_counters, d_stats, d_evtlen, d_evt, d_workmem, d_phase;
   std::vector<unsigned long long> phase;
   EngineCaps caps;      // tier 1
@@ -90,6 +90,8 @@ struct lancet_engine {
   std::vector<char> blob;
   std::vector<lancet_window_stats> stats;
   std::vector<uint32_t> evt_len, evt;
+  std::vector<lancet_variant_lr> variants_lr;   // lr_mode: parallel to variants
+  std::vector<uint32_t> bx_blob;
   float ms_all = 0, ms_kernel = 0;
 };
 
@@ -105,7 +107,6 @@ void lancet_params_default(lancet_params *p) {
 int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out) {
   if (!p || !out) return LANCET_E_ARG;
   *out = nullptr;
-  if (p->lr_mode) return LANCET_E_UNSUPPORTED;
   if (p->max_k > 127 || p->min_k < 3 || p->max_unit_len > 8) return LANCET_E_UNSUPPORTED;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return LANCET_E_NO_DEVICE;
@@ -129,7 +130,7 @@ void lancet_engine_destroy(lancet_engine *e) {
   DevBuf *all[] = {&e->d_params, &e->d_batch, &e->d_caps, &e->d_out, &e->d_works, &e->d_chr, &e->d_refstart, &e->d_refoff, &e->d_refasc,
                    &e->d_refcodes, &e->d_readbegin, &e->d_seqoff, &e->d_seq, &e->d_qual, &e->d_label, &e->d_strand, &e->d_mate, &e->d_mapped,
                    &e->d_rinfo, &e->d_name, &e->d_bw, &e->d_gw, &e->d_bases, &e->d_good, &e->d_variants, &e->d_blob, &e->d_counters,
-                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist};
+                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist, &e->d_bx, &e->d_hp, &e->d_varlr, &e->d_bxblob};
   for (DevBuf *b : all) b->release();
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -156,6 +157,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   HIPCHK(e, hipSetDevice(e->device));
   e->uploaded = false; e->ran = false;
   const int nw = b->n_windows;
+  if (e->params.lr_mode && nw > 0 && b->read_begin[nw] > 0 && (!b->bx_rank || !b->hp)) { e->err = "lr_mode needs bx_rank and hp"; return LANCET_E_ARG; }
   const uint32_t R = nw ? b->read_begin[nw] : 0;
   const uint32_t nbases = R ? b->seq_off[R] : 0;
   const uint32_t nref = nw ? b->ref_off[nw] : 0;
@@ -164,7 +166,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   for (int w = 0; w < nw; ++w) if (b->ref_off[w + 1] - b->ref_off[w] > LC_MAXW) { e->err = "window longer than LC_MAXW"; return LANCET_E_UNSUPPORTED; }
   e->caps = lc_caps_for_batch(b, &e->params, e->evt_cap, e->node_cap1, 1);
   e->caps2 = lc_caps_for_batch(b, &e->params, e->evt_cap, e->max_nodes_limit, 2);
-  e->caps2.var_cap = e->caps.var_cap; e->caps2.blob_cap = e->caps.blob_cap;
+  e->caps2.var_cap = e->caps.var_cap; e->caps2.blob_cap = e->caps.blob_cap; e->caps2.bx_cap = e->caps.bx_cap;
   e->caps.debug_stop = e->debug_stop;
   // ---- inputs
   UP(e->d_params, &e->params, sizeof(lancet_params));
@@ -178,6 +180,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   UP(e->d_qual, b->qual, nbases);
   UP(e->d_label, b->label, R); UP(e->d_strand, b->strand, R); UP(e->d_mate, b->mate, R); UP(e->d_mapped, b->mapped, R);
   UP(e->d_name, b->name_rank, sizeof(uint32_t) * R);
+  if (e->params.lr_mode && R) { UP(e->d_bx, b->bx_rank, sizeof(uint32_t) * R); UP(e->d_hp, b->hp, R); }
   std::vector<uint32_t> bw(R + 1), gw(R + 1);
   uint32_t bo = 0, go = 0;
   for (uint32_t r = 0; r < R; ++r) { uint32_t len = b->seq_off[r + 1] - b->seq_off[r]; bw[r] = bo; gw[r] = go; bo += (len + 15) / 16; go += (len + 31) / 32; }
@@ -200,6 +203,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   db.ref_off = (const uint32_t *)e->d_refoff.p; db.ref_codes = (const uint8_t *)e->d_refcodes.p; db.read_begin = (const uint32_t *)e->d_readbegin.p;
   db.rinfo = (const uint32_t *)e->d_rinfo.p; db.name_rank = (const uint32_t *)e->d_name.p; db.base_woff = (const uint32_t *)e->d_bw.p;
   db.good_woff = (const uint32_t *)e->d_gw.p; db.bases = (const uint32_t *)e->d_bases.p; db.good = (const uint32_t *)e->d_good.p;
+  db.bx_rank = e->params.lr_mode ? (const uint32_t *)e->d_bx.p : nullptr; db.hp = e->params.lr_mode ? (const uint8_t *)e->d_hp.p : nullptr;
   UP(e->d_batch, &db, sizeof(db));
   UP(e->d_caps, &e->caps, sizeof(e->caps));
   UP(e->d_caps2, &e->caps2, sizeof(e->caps2));
@@ -217,6 +221,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   // ---- outputs
   ENS(e->d_variants, sizeof(lancet_variant) * e->caps.var_cap);
   ENS(e->d_blob, e->caps.blob_cap);
+  if (e->caps.lr_mode) { ENS(e->d_varlr, sizeof(lancet_variant_lr) * e->caps.var_cap); ENS(e->d_bxblob, sizeof(uint32_t) * e->caps.bx_cap); }
   ENS(e->d_counters, 64);
   ENS(e->d_stats, sizeof(lancet_window_stats) * nw);
   ENS(e->d_evtlen, sizeof(uint32_t) * nw);
@@ -225,6 +230,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   DevOut o;
   o.variants = (lancet_variant *)e->d_variants.p; o.blob = (char *)e->d_blob.p;
   o.n_variants = (uint32_t *)e->d_counters.p; o.n_blob = (uint32_t *)e->d_counters.p + 1; o.queue_head = (uint32_t *)e->d_counters.p + 2;
+  o.n_bx = (uint32_t *)e->d_counters.p + 3; o.variants_lr = (lancet_variant_lr *)e->d_varlr.p; o.bx_blob = (uint32_t *)e->d_bxblob.p;
   o.stats = (lancet_window_stats *)e->d_stats.p; o.evt_len = (uint32_t *)e->d_evtlen.p; o.evt_out = (uint32_t *)e->d_evt.p; o.phase = (unsigned long long *)e->d_phase.p; o.win_list = nullptr; o.n_list = 0;
   UP(e->d_out, &o, sizeof(o));
   DBG("sync");
@@ -238,7 +244,7 @@ int lancet_engine_run(lancet_engine *e) {
   if (!e) return LANCET_E_ARG;
   if (!e->uploaded) { e->err = "run before upload"; return LANCET_E_STATE; }
   HIPCHK(e, hipSetDevice(e->device));
-  e->variants.clear(); e->blob.clear(); e->stats.clear(); e->evt_len.clear(); e->evt.clear();
+  e->variants.clear(); e->blob.clear(); e->stats.clear(); e->evt_len.clear(); e->evt.clear(); e->variants_lr.clear(); e->bx_blob.clear();
   if (e->n_windows == 0) { e->ran = true; return LANCET_OK; }
   HIPCHK(e, hipEventRecord(e->ev0, e->stream));
   HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, 64, e->stream));
@@ -285,15 +291,22 @@ int lancet_engine_run(lancet_engine *e) {
     e->ms_all += ms2; e->ms_kernel += ms2;
   }
   // ---- read back
-  uint32_t counters[3];
+  uint32_t counters[4];
   HIPCHK(e, hipMemcpy(counters, e->d_counters.p, sizeof(counters), hipMemcpyDeviceToHost));
   HIPCHK(e, hipMemcpy(e->stats.data(), e->d_stats.p, sizeof(lancet_window_stats) * e->n_windows, hipMemcpyDeviceToHost));
-  bool global_overflow = counters[0] > e->caps.var_cap || counters[1] > e->caps.blob_cap;
+  bool global_overflow = counters[0] > e->caps.var_cap || counters[1] > e->caps.blob_cap || (e->caps.lr_mode && counters[3] > e->caps.bx_cap);
   uint32_t nv = std::min(counters[0], e->caps.var_cap), nb = std::min(counters[1], e->caps.blob_cap);
   std::vector<lancet_variant> raw(nv);
   std::vector<char> rawblob(nb);
   if (nv) HIPCHK(e, hipMemcpy(raw.data(), e->d_variants.p, sizeof(lancet_variant) * nv, hipMemcpyDeviceToHost));
   if (nb) HIPCHK(e, hipMemcpy(rawblob.data(), e->d_blob.p, nb, hipMemcpyDeviceToHost));
+  std::vector<lancet_variant_lr> rawlr; std::vector<uint32_t> rawbx;
+  if (e->caps.lr_mode) {
+    uint32_t nx = std::min(counters[3], e->caps.bx_cap);
+    rawlr.resize(nv); rawbx.resize(nx);
+    if (nv) HIPCHK(e, hipMemcpy(rawlr.data(), e->d_varlr.p, sizeof(lancet_variant_lr) * nv, hipMemcpyDeviceToHost));
+    if (nx) HIPCHK(e, hipMemcpy(rawbx.data(), e->d_bxblob.p, sizeof(uint32_t) * nx, hipMemcpyDeviceToHost));
+  }
   e->phase.resize((size_t)e->n_windows * 16);
   HIPCHK(e, hipMemcpy(e->phase.data(), e->d_phase.p, sizeof(unsigned long long) * e->phase.size(), hipMemcpyDeviceToHost));
   if (e->caps.evt_cap) {
@@ -323,11 +336,26 @@ int lancet_engine_run(lancet_engine *e) {
     e->blob.insert(e->blob.end(), rawblob.begin() + v.str_off, rawblob.begin() + v.str_off + v.str_len);
     v.ref_off = o; v.alt_off = o + v.ref_len; v.str_off = o + v.ref_len + v.alt_len;
     e->variants.push_back(v);
+    if (e->caps.lr_mode) {
+      lancet_variant_lr l = rawlr[i];
+      for (int q = 0; q < 4; ++q) {
+        if ((size_t)l.bx_off[q] + l.bx_len[q] > rawbx.size()) { l.bx_len[q] = 0; l.bx_off[q] = 0; }
+        uint32_t no = (uint32_t)e->bx_blob.size();
+        e->bx_blob.insert(e->bx_blob.end(), rawbx.begin() + l.bx_off[q], rawbx.begin() + l.bx_off[q] + l.bx_len[q]);
+        l.bx_off[q] = no;
+      }
+      e->variants_lr.push_back(l);
+    }
   }
   if (global_overflow) {   // some window could not write its records: mark every window that lost some
     std::vector<int> got(e->n_windows, 0);
     for (auto &v : e->variants) ++got[v.window];
     for (int w = 0; w < e->n_windows; ++w) if (e->stats[w].status >= 0 && got[w] != e->stats[w].n_variants) e->stats[w].status = LANCET_W_OVERFLOW;
+    if (e->caps.lr_mode) {
+      std::vector<lancet_variant_lr> keep;
+      for (size_t i = 0; i < e->variants.size(); ++i) if (e->stats[e->variants[i].window].status >= 0) keep.push_back(e->variants_lr[i]);
+      e->variants_lr.swap(keep);
+    }
     e->variants.erase(std::remove_if(e->variants.begin(), e->variants.end(), [&](const lancet_variant &v) { return e->stats[v.window].status < 0; }), e->variants.end());
   }
   e->ran = true;
@@ -349,6 +377,15 @@ int lancet_engine_results(lancet_engine *e, const lancet_variant **variants, uin
   if (blob) *blob = e->blob.data();
   if (blob_len) *blob_len = (uint32_t)e->blob.size();
   if (stats) *stats = e->stats.data();
+  return LANCET_OK;
+}
+
+int lancet_engine_results_lr(lancet_engine *e, const lancet_variant_lr **lr, const uint32_t **bx_blob, uint32_t *bx_blob_len) {
+  if (!e) return LANCET_E_ARG;
+  if (!e->ran) { e->err = "results before run"; return LANCET_E_STATE; }
+  if (lr) *lr = e->params.lr_mode ? e->variants_lr.data() : nullptr;
+  if (bx_blob) *bx_blob = e->bx_blob.data();
+  if (bx_blob_len) *bx_blob_len = (uint32_t)e->bx_blob.size();
   return LANCET_OK;
 }
 

@@ -51,6 +51,8 @@ static inline EngineCaps lc_caps_for_batch(const lancet_window_batch *b, const l
   c.evt_cap = evt_cap;
   c.var_cap = (uint32_t)b->n_windows * 8 + 1024;
   c.blob_cap = (uint32_t)b->n_windows * 512 + 65536;
+  c.lr_mode = p->lr_mode ? 1u : 0u;
+  c.bx_cap = c.lr_mode ? (uint32_t)b->n_windows * 2048u + 65536u : 0u;
   return c;
 }
 
@@ -88,7 +90,10 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.nfill = k.take<uint32_t>(nodes + 1);
   t.gr = k.take<NodeGr>(nodes);
   t.nocc = k.take<uint32_t>(nodes + 1);
-  t.qv = k.take<uint16_t>((size_t)c.qv_cap * 4);
+  t.qv = k.take<uint16_t>((size_t)c.qv_cap * (c.lr_mode ? 10 : 4));
+  t.khp = k.take<uint16_t>(c.lr_mode ? nodes * 6 : 1);
+  t.refhp = k.take<uint16_t>(c.lr_mode ? LC_MAXW * 6 : 1);
+  t.bxbuf = k.take<uint32_t>(c.lr_mode ? c.reads_cap : 1);
   t.seq = k.take<uint32_t>(c.seq_cap);
   t.ht_next = k.take<uint32_t>(nodes);
   t.ht_bucket = k.take<uint32_t>(c.bucket_cap);

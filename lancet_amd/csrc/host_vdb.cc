@@ -111,6 +111,24 @@ struct Variant {
     rcn_f = v.cov[0]; rcn_r = v.cov[1]; rct_f = v.cov[2]; rct_r = v.cov[3];
     acn_f = v.cov[4]; acn_r = v.cov[5]; act_f = v.cov[6]; act_r = v.cov[7];
   }
+  // --linked-reads members (Variant.hh:72-104): HPRN HPRT HPAN HPAT as {hp1, hp2, hp0}, barcode sets as printed
+  bool lr = false;
+  unsigned short hp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  std::string bx[4];                                   // bxset_ref_N, bxset_ref_T, bxset_alt_N, bxset_alt_T
+  void set_lr(const lancet_variant_lr &l, const uint32_t *bx_blob, const char *const *bx_names, uint32_t n_bx) {
+    lr = true;
+    for (int i = 0; i < 12; ++i) hp[i] = l.hp[i];
+    for (int q = 0; q < 4; ++q) {                      // Graph_t::getBXsetAt / Ref_t::getBXsetAt: ';'-joined, "." when empty
+      std::string r;
+      for (uint32_t j = 0; j < l.bx_len[q]; ++j) { uint32_t id = bx_blob[l.bx_off[q] + j]; if (j) r += ";"; r += id < n_bx ? bx_names[id] : "?"; }
+      bx[q] = r.empty() ? "." : r;
+    }
+  }
+  static double hp_score(int hpr1, int hpr2, int hpa1, int hpa2) {     // Variant_t::compute_HP_score, src/Variant.cc:281-298
+    double prob = kt_fisher_exact_q(hpr1, hpr2, hpa1, hpa2);
+    if (prob == 1) return 0.0;
+    return -10.0 * log10(prob);
+  }
   std::string signature() const { return chr + ":" + itos(pos) + ":" + type + ":" + itos(len) + ":" + ref + ":" + alt; }
   int tot() const { return rcn_f + rcn_r + rct_f + rct_r + acn_f + acn_r + act_f + act_r; }
   double fet_score() const {
@@ -128,14 +146,21 @@ struct Variant {
   std::string vcf(const lancet_filters &fs) const {
     int tr_t = rct_f + rct_r, ta_t = act_f + act_r, tr_n = rcn_f + rcn_r, ta_n = acn_f + acn_r;
     double fet = fet_score(), sb = sb_score();
-    std::string status;
-    if (ta_n > 0 && ta_t > 0) status = "SHARED"; else if (ta_n == 0 && ta_t > 0) status = "SOMATIC"; else if (ta_n > 0 && ta_t == 0) status = "NORMAL"; else return "";
+    std::string status; bool somatic = false;
+    if (ta_n > 0 && ta_t > 0) status = "SHARED"; else if (ta_n == 0 && ta_t > 0) { status = "SOMATIC"; somatic = true; } else if (ta_n > 0 && ta_t == 0) status = "NORMAL"; else return "";
     std::string INFO = status + ";FETS=" + dtos(fet);
     if (type == 'I') INFO += ";TYPE=ins";
     if (type == 'D') INFO += ";TYPE=del";
     if (type == 'S') INFO += ";TYPE=snv";
     if (type == 'C') INFO += ";TYPE=complex";
     INFO += ";LEN=" + itos(len) + ";KMERSIZE=" + itos(kmer) + ";SB=" + dtos(sb);
+    const unsigned short *HPRN = hp, *HPRT = hp + 3, *HPAN = hp + 6, *HPAT = hp + 9;
+    if (lr) {                                            // src/Variant.cc:56-60, 78-80
+      double hpsn = hp_score(HPRN[0], HPRN[1], HPAN[0], HPAN[1]);
+      double hpst = hp_score(HPRT[0], HPRT[1], HPAT[0], HPAT[1]);
+      double hps = hp_score(HPRN[0] + HPAN[0], HPRN[1] + HPAN[1], HPRT[0] + HPAT[0], HPRT[1] + HPAT[1]);
+      INFO += ";HPS=" + dtos(hps) + ";HPSN=" + dtos(hpsn) + ";HPST=" + dtos(hpst);
+    }
     if (!str.empty()) INFO += ";MS=" + str;
     int tumor_cov = tr_t + ta_t; double tumor_vaf = (tumor_cov == 0) ? 0 : ((double)ta_t / (double)tumor_cov);
     int normal_cov = tr_n + ta_n; double normal_vaf = (normal_cov == 0) ? 0 : ((double)ta_n / (double)normal_cov);
@@ -152,13 +177,21 @@ struct Variant {
     if (ta_t < fs.min_alt_cnt_tumor) add("LowAltCntTumor");
     if (ta_n > fs.max_alt_cnt_normal) add("HighAltCntNormal");
     if ((act_f < fs.min_strand_bias) || (act_r < fs.min_strand_bias)) add("StrandBias");
+    if (lr && somatic && HPAT[0] > 0 && HPAT[1] > 0) add("MultiHP");   // src/Variant.cc:172-177
     if (F.empty()) F = "PASS";
     std::string NORMAL = genotype(tr_n, ta_n) + ":" + itos(tr_n) + "," + itos(ta_n) + ":" + itos(rcn_f) + "," + itos(rcn_r) + ":" + itos(acn_f) + "," +
                          itos(acn_r) + ":" + itos(tr_n + ta_n);
     std::string TUMOR = genotype(tr_t, ta_t) + ":" + itos(tr_t) + "," + itos(ta_t) + ":" + itos(rct_f) + "," + itos(rct_r) + ":" + itos(act_f) + "," +
                         itos(act_r) + ":" + itos(tr_t + ta_t);
+    std::string FORMAT = "GT:AD:SR:SA:DP";
+    if (lr) {                                            // src/Variant.cc:204-215
+      FORMAT += ":HPR:HPA:BX";
+      auto c3 = [](const unsigned short *h) { return itos(h[0]) + "," + itos(h[1]) + "," + itos(h[2]); };
+      NORMAL += ":" + c3(HPRN) + ":" + c3(HPAN) + ":" + bx[0] + "," + bx[2];
+      TUMOR += ":" + c3(HPRT) + ":" + c3(HPAT) + ":" + bx[1] + "," + bx[3];
+    }
     std::ostringstream line;
-    line << chr << "\t" << pos << "\t.\t" << ref << "\t" << alt << "\t" << fet << "\t" << F << "\t" << INFO << "\tGT:AD:SR:SA:DP\t" << NORMAL << "\t" << TUMOR << std::endl;
+    line << chr << "\t" << pos << "\t.\t" << ref << "\t" << alt << "\t" << fet << "\t" << F << "\t" << INFO << "\t" << FORMAT << "\t" << NORMAL << "\t" << TUMOR << std::endl;
     return line.str();
   }
 };
@@ -175,6 +208,7 @@ struct byPos {   // reference src/VariantDB.hh:37-54 (arguments by value there; 
 
 struct lancet_vdb {
   lancet_filters fs;
+  bool lr = false;             // VariantDB_t::LR_MODE
   std::map<std::string, Variant> db;
 };
 
@@ -189,11 +223,14 @@ lancet_vdb *lancet_vdb_create(const lancet_filters *f) { lancet_vdb *d = new lan
 void lancet_vdb_destroy(lancet_vdb *db) { delete db; }
 uint32_t lancet_vdb_size(const lancet_vdb *db) { return db ? (uint32_t)db->db.size() : 0; }
 
-int lancet_vdb_add(lancet_vdb *db, const lancet_variant *v, uint32_t n, const char *blob, const char *const *chr_names, int32_t n_chr) {
+static int vdb_add(lancet_vdb *db, const lancet_variant *v, const lancet_variant_lr *lr, uint32_t n, const char *blob, const uint32_t *bx_blob,
+                   const char *const *bx_names, uint32_t n_bx, const char *const *chr_names, int32_t n_chr) {
   if (!db || (n && (!v || !blob))) return LANCET_E_ARG;
+  if (lr) db->lr = true;
   for (uint32_t i = 0; i < n; ++i) {
     if (v[i].chr_id < 0 || v[i].chr_id >= n_chr) return LANCET_E_ARG;
     Variant nv(chr_names[v[i].chr_id], v[i], blob);
+    if (lr) nv.set_lr(lr[i], bx_blob, bx_names, n_bx);
     std::string key = sha256_hex(nv.signature());
     auto it = db->db.find(key);
     if (it != db->db.end()) {
@@ -202,10 +239,22 @@ int lancet_vdb_add(lancet_vdb *db, const lancet_variant *v, uint32_t n, const ch
         o.kmer = nv.kmer;
         o.rcn_f = nv.rcn_f; o.rcn_r = nv.rcn_r; o.rct_f = nv.rct_f; o.rct_r = nv.rct_r;
         o.acn_f = nv.acn_f; o.acn_r = nv.acn_r; o.act_f = nv.act_f; o.act_r = nv.act_r;
+        for (int q = 0; q < 12; ++q) o.hp[q] = nv.hp[q];                         // src/VariantDB.cc:73-76
+        if (db->lr) for (int q = 0; q < 4; ++q) o.bx[q] = nv.bx[q];              // :78-83
       }
     } else db->db.insert(std::make_pair(key, nv));
   }
   return LANCET_OK;
+}
+int lancet_vdb_add(lancet_vdb *db, const lancet_variant *v, uint32_t n, const char *blob, const char *const *chr_names, int32_t n_chr) {
+  return vdb_add(db, v, nullptr, n, blob, nullptr, nullptr, 0, chr_names, n_chr);
+}
+int lancet_vdb_add_lr(lancet_vdb *db, const lancet_variant *v, const lancet_variant_lr *lr, uint32_t n, const char *blob, const uint32_t *bx_blob,
+                      const char *const *bx_names, uint32_t n_bx, const char *const *chr_names, int32_t n_chr) {
+  if (n && !lr) return LANCET_E_ARG;
+  if (!db) return LANCET_E_ARG;
+  db->lr = true;
+  return vdb_add(db, v, lr, n, blob, bx_blob, bx_names, n_bx, chr_names, n_chr);
 }
 
 char *lancet_vdb_vcf(lancet_vdb *db, const char *version, const char *cmdline, const char *reference, const char *date_line,
@@ -228,6 +277,10 @@ char *lancet_vdb_vcf(lancet_vdb *db, const char *version, const char *cmdline, c
          "##INFO=<ID=MS,Number=1,Type=String,Description=\"Microsatellite mutation (format: #LEN#MOTIF)\">\n"
          "##INFO=<ID=LEN,Number=1,Type=Integer,Description=\"Variant size in base pairs\">\n"
          "##INFO=<ID=TYPE,Number=1,Type=String,Description=\"Variant type (snv, del, ins, complex)\">\n";
+  if (db->lr)
+    hdr << "##INFO=<ID=HPS,Number=1,Type=Float,Description=\"Haplotype score for the T/N pair: phred-scaled p-value of the Fisher's exact test of the total counts of the two haplotype in the tumor-normal pair\">\n"
+           "##INFO=<ID=HPSN,Number=1,Type=Float,Description=\"Normal haplotype score: phred-scaled p-value of the Fisher's exact test for ref/alt haplotype counts in the normal\">\n"
+           "##INFO=<ID=HPST,Number=1,Type=Float,Description=\"Tumor haplotype score: phred-scaled p-value of the Fisher's exact test for ref/alt haplotype counts in the tumor\">\n";
   hdr << "##FILTER=<ID=LowCovNormal,Description=\"Low coverage in the normal (<" << fs.min_cov_normal << ")\">\n"
          "##FILTER=<ID=HighCovNormal,Description=\"High coverage in the normal (>" << fs.max_cov_normal << ")\">\n"
          "##FILTER=<ID=LowCovTumor,Description=\"Low coverage in the tumor (<" << fs.min_cov_tumor << ")\">\n"
@@ -240,11 +293,16 @@ char *lancet_vdb_vcf(lancet_vdb *db, const char *version, const char *cmdline, c
          "##FILTER=<ID=LowFisherSTR,Description=\"Low Fisher's exact test score for tumor-normal STR allele counts (<" << fs.min_phred_fisher_str << ")\">\n"
          "##FILTER=<ID=StrandBias,Description=\"Strand bias: # of non-reference reads in either forward or reverse strand below threshold (<" << fs.min_strand_bias << ")\">\n"
          "##FILTER=<ID=STR,Description=\"Microsatellite mutation\">\n";
+  if (db->lr) hdr << "##FILTER=<ID=MultiHP,Description=\"Supporting reads from multiple haplotypes based on linked-reads analysis\">\n";
   hdr << "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n"
          "##FORMAT=<ID=DP,Number=1,Type=Integer,Description=\"Depth\">\n"
          "##FORMAT=<ID=AD,Number=.,Type=Integer,Description=\"Allele depth: # of supporting ref,alt reads at the site\">\n"
          "##FORMAT=<ID=SR,Number=.,Type=Integer,Description=\"Strand counts for ref: # of supporting forward,reverse reads for reference allele\">\n"
          "##FORMAT=<ID=SA,Number=.,Type=Integer,Description=\"Strand counts for alt: # of supporting forward,reverse reads for alterantive allele\">\n";
+  if (db->lr)
+    hdr << "##FORMAT=<ID=BX,Number=.,Type=String,Description=\"Barcodes supporting ref and alt alleles\">\n"
+           "##FORMAT=<ID=HPR,Number=.,Type=Integer,Description=\"Haplotype counts for ref: # of reads supporting reference allele in haplotype 1, 2, and 0 respectively (0 = unassigned)\">\n"
+           "##FORMAT=<ID=HPA,Number=.,Type=Integer,Description=\"Haplotype counts for alt: # of reads supporting alternative allele in haplotype 1, 2, and 0 respectively (0 = unassigned)\">\n";
   hdr << "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" << (sample_normal ? sample_normal : "NORMAL") << "\t" << (sample_tumor ? sample_tumor : "TUMOR") << "\n";
   std::vector<std::pair<std::string, Variant>> vec(db->db.begin(), db->db.end());
   std::sort(vec.begin(), vec.end(), byPos());

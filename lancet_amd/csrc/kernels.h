@@ -47,7 +47,8 @@ struct WinShared {
   int nitems;                          // work items of the per-occurrence passes (build_items)
   uint32_t part[LANCET_WG + 1];
   uint32_t mk[LANCET_WG][4], mmeta[LANCET_WG];   // staged quality masks of up to one wave of occurrences
-  uint32_t acc[128][4];                          // per k-mer position running counts Tf Tr Nf Nr
+  uint16_t acc[128][10];                         // per k-mer position running counts Tf Tr Nf Nr (+ lr_mode: T hp0-2, N hp0-2 minqv)
+  int QS, LR;                                    // counters per (survivor, position): 4, or 10 with --linked-reads ; lr_mode
   unsigned long long rs[LC_RS_WORDS];            // repeat_scan: the string at 4 bits per base
   unsigned long long t_last, phase_acc[16];
   int phase_cur;
@@ -351,8 +352,19 @@ DEV void desc_cov(const Ctx &c, uint32_t d, int sampleT, uint16_t *fwd, uint16_t
   *fwd = (uint16_t)cn[o]; *rev = (uint16_t)cn[o + 1];
   uint32_t q = c.W->gr[km].nqv;
   if (q == LC_NIL) { *qf = 0; *qr = 0; return; }
-  const uint16_t *qq = c.W->qv + ((size_t)q * c.S->K + SD_OFF(d)) * 4;
+  const uint16_t *qq = c.W->qv + ((size_t)q * c.S->K + SD_OFF(d)) * c.S->QS;
   *qf = qq[o]; *qr = qq[o + 1];
+}
+// lr_mode: hp0 hp1 hp2 and hp0/1/2_minqv behind a descriptor (cov_t::hp*, reference src/Ref.hh:47-52)
+DEV void desc_hp(const Ctx &c, uint32_t d, int sampleT, uint16_t *hp3, uint16_t *hpm3) {
+  uint32_t km = SD_KMER(d);
+  const int o = sampleT ? 0 : 3;
+  const uint16_t *h = c.W->khp + 6 * (size_t)km + o;
+  hp3[0] = h[0]; hp3[1] = h[1]; hp3[2] = h[2];
+  uint32_t q = c.W->gr[km].nqv;
+  if (q == LC_NIL) { hpm3[0] = hpm3[1] = hpm3[2] = 0; return; }
+  const uint16_t *qq = c.W->qv + ((size_t)q * c.S->K + SD_OFF(d)) * c.S->QS + 4 + o;
+  hpm3[0] = qq[0]; hpm3[1] = qq[1]; hpm3[2] = qq[2];
 }
 DEV void desc_tot(const Ctx &c, uint32_t d, int *tot, int *totqv) {  // operands of Node_t::computeMinCov
   uint32_t km = SD_KMER(d);
@@ -360,7 +372,7 @@ DEV void desc_tot(const Ctx &c, uint32_t d, int *tot, int *totqv) {  // operands
   *tot = (int)(uint16_t)cn[0] + (int)(uint16_t)cn[1] + (int)(uint16_t)cn[2] + (int)(uint16_t)cn[3];
   uint32_t q = c.W->gr[km].nqv;
   if (q == LC_NIL) { *totqv = 0; return; }
-  const uint16_t *qq = c.W->qv + ((size_t)q * c.S->K + SD_OFF(d)) * 4;
+  const uint16_t *qq = c.W->qv + ((size_t)q * c.S->K + SD_OFF(d)) * c.S->QS;
   *totqv = (int)qq[0] + (int)qq[1] + (int)qq[2] + (int)qq[3];
 }
 
@@ -635,6 +647,70 @@ DEV bool step_all_good(const Ctx &c, bool isref, uint32_t gw, int s, int tlen, i
   return good_count(c.B->good, gw, s, s + K + 1) == K + 1;
 }
 
+// --linked-reads: what loadSequence does to ONE node, replayed over the node's occurrences in the order the reference
+// visits them (read, then position; reference src/Graph.cc:239-317).  Every occurrence is one "LR event"
+// (Node_t::hasBX / addBX / addHP) and, when it is counted (not the reference read, not an overlapping mate), one
+// "coverage event" that writes the CURRENT barcode count of the read's strand and the current haplotype counts
+// (last writer wins) and bumps hpX_minqv where the stored count had grown.  Only at offset 0 two LR events precede
+// the coverage events (u at position 0 and v at position 1): that matters when both are this node.
+//   out[0..3] = cov_distr fwd/rev of tumor, normal (barcode counts) ; out[4..6] / out[7..9] = hp0 hp1 hp2 tumor / normal
+//   csr bits 29..31 of a counted occurrence = "hpX had grown" (feeds hpX_minqv in the per-position pass)
+#define LC_PK(x, i) ((uint32_t)(((x) >> (16 * (i))) & 0xFFFFULL))
+DEVNI void lr_node_replay(Ctx &c, uint32_t lo, uint32_t hi, uint32_t *out) {
+  Work &W = *c.W; const DevBatch &B = *c.B; volatile WinShared &S = *c.S;
+  const uint32_t g0 = B.read_begin[S.w];
+  const uint32_t refr = (uint32_t)(S.R - 1);
+  for (uint32_t i = lo + 1; i < hi; ++i) {                      // order of the visits
+    const uint32_t v = W.csr[i], kv = (CS_READ(v) << 10) | CS_POS(v);
+    uint32_t j = i;
+    while (j > lo) { const uint32_t u = W.csr[j - 1]; if (((CS_READ(u) << 10) | CS_POS(u)) <= kv) break; W.csr[j] = u; --j; }
+    W.csr[j] = v;
+  }
+  unsigned long long bxc = 0, covw = 0, hpcT = 0, hpcN = 0, hpwT = 0, hpwN = 0;      // 16-bit fields
+  auto lr_event = [&](uint32_t i) {
+    const uint32_t e = W.csr[i], g = g0 + CS_READ(e);
+    const uint32_t ri = B.rinfo[g];
+    const uint32_t s = RI_NML(ri), d = RI_REV(ri), bx = B.bx_rank[g];
+    uint32_t h = B.hp[g]; if (h > 2) h = 2;
+    bool seen = false;
+    if (bx != 0xFFFFFFFFu)
+      for (uint32_t j = lo; j < i; ++j) {
+        const uint32_t rj = CS_READ(W.csr[j]);
+        if (rj == refr) continue;
+        if (RI_NML(B.rinfo[g0 + rj]) == s && B.bx_rank[g0 + rj] == bx) { seen = true; break; }
+      }
+    if (!seen) {
+      if (bx != 0xFFFFFFFFu) bxc += 1ULL << (16 * (2 * s + d));
+      if (s) hpcN += 1ULL << (16 * h); else hpcT += 1ULL << (16 * h);
+    }
+  };
+  auto cov_event = [&](uint32_t i) {
+    const uint32_t e = W.csr[i];
+    if (CS_ST(e) != 0) return;
+    const uint32_t ri = B.rinfo[g0 + CS_READ(e)];
+    const uint32_t s = RI_NML(ri), d = RI_REV(ri);
+    const unsigned long long cur = s ? hpcN : hpcT, old = s ? hpwN : hpwT;
+    uint32_t grow = 0;
+    for (int j = 0; j < 3; ++j) if (LC_PK(old, j) < LC_PK(cur, j)) grow |= 1u << j;
+    const int f = (int)(2 * s + d);
+    covw = (covw & ~(0xFFFFULL << (16 * f))) | ((unsigned long long)LC_PK(bxc, f) << (16 * f));
+    if (s) hpwN = cur; else hpwT = cur;
+    W.csr[i] = e | (grow << 29);
+  };
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint32_t e = W.csr[i];
+    if (CS_READ(e) == refr) continue;                            // BX "null", label REF: no effect (Graph.cc:243-262)
+    bool pair = false;
+    if (CS_POS(e) == 0 && i + 1 < hi) { const uint32_t e2 = W.csr[i + 1]; pair = CS_READ(e2) == CS_READ(e) && CS_POS(e2) == 1; }
+    lr_event(i);
+    if (pair) lr_event(i + 1);
+    cov_event(i);
+    if (pair) { cov_event(i + 1); ++i; }
+  }
+  for (int q = 0; q < 4; ++q) out[q] = LC_PK(covw, q);
+  for (int j = 0; j < 3; ++j) { out[4 + j] = LC_PK(hpwT, j); out[7 + j] = LC_PK(hpwN, j); }
+}
+
 DEV void build_graph(Ctx &c) {
   volatile WinShared &S = *c.S; Work &W = *c.W; const EngineCaps &C = *c.C;
   const int K = S.K;
@@ -886,7 +962,13 @@ DEV void build_graph(Ctx &c) {
     uint32_t *kc = W.kcnt + 4 * (size_t)n;
     kc[0] = c0; kc[1] = c1; kc[2] = c2; kc[3] = c3;
     G.cov[0] = (float)c0; G.cov[1] = (float)c1; G.cov[2] = (float)c2; G.cov[3] = (float)c3;
-    G.mincov = (int)(uint16_t)c0 + (int)(uint16_t)c1 + (int)(uint16_t)c2 + (int)(uint16_t)c3;
+    if (S.LR) {        // cov_distr holds barcode counts instead of read counts; the float coverages stay read counts
+      uint32_t lrv[10];
+      lr_node_replay(c, lo, hi, lrv);
+      for (int q = 0; q < 4; ++q) kc[q] = lrv[q];
+      for (int q = 0; q < 6; ++q) W.khp[6 * (size_t)n + q] = (uint16_t)lrv[4 + q];
+    }
+    G.mincov = (int)(uint16_t)kc[0] + (int)(uint16_t)kc[1] + (int)(uint16_t)kc[2] + (int)(uint16_t)kc[3];
     G.mincovqv = 0;
     // first removeLowCov predicate (reference src/Graph.cc:2790-2827, docompression=false, compid=0): minqv <= T.
     // minqv cannot exceed the number of counted occurrences, so most nodes (sequencing-error k-mers) are decided here;
@@ -914,7 +996,8 @@ DEV void build_graph(Ctx &c) {
     const uint32_t g0 = c.B->read_begin[S.w];
     const uint32_t qi = (uint32_t)wg_uniform((int)S.qv_top);
     if (qi >= c.C->surv_cap || ((size_t)qi + 1) * (size_t)K > (size_t)c.C->qv_cap) { WG_LANE0 { OVF(c); } return; }
-    uint16_t *qq = W.qv + (size_t)qi * K * 4;
+    const int QS = S.QS; const bool LR = S.LR != 0;
+    uint16_t *qq = W.qv + (size_t)qi * K * QS;
     for (uint32_t q0 = lo; q0 < hi; q0 += LANCET_WG) {
       const int cnt = (int)(hi - q0 < (uint32_t)LANCET_WG ? hi - q0 : (uint32_t)LANCET_WG);
       WG_FOR(j, cnt) {
@@ -929,7 +1012,7 @@ DEV void build_graph(Ctx &c) {
           #define LC_TAKE(t) ((32 * (t) < K) ? ((gd[wv + (t)] >> sh) | ((sh && 32 * (t) + 32 - sh < K) ? (gd[wv + (t) + 1] << (32 - sh)) : 0u)) : 0u)
           m0 = LC_TAKE(0); m1 = LC_TAKE(1); m2 = LC_TAKE(2); m3 = LC_TAKE(3);
           #undef LC_TAKE
-          meta = 1u | (((RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u)) << 1) | (CS_ORI(e) << 3);
+          meta = 1u | (((RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u)) << 1) | (CS_ORI(e) << 3) | ((e >> 29) << 4);
         }
         S.mk[j][0] = m0; S.mk[j][1] = m1; S.mk[j][2] = m2; S.mk[j][3] = m3; S.mmeta[j] = meta;
       }
@@ -939,17 +1022,27 @@ DEV void build_graph(Ctx &c) {
         const uint32_t (*mk)[4] = (const uint32_t (*)[4])S.mk;       // plain LDS reads: staged before the barrier above
         const uint32_t *mm = (const uint32_t *)S.mmeta;
         uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0;       // lr_mode: hp0/1/2_minqv tumor, normal
         if (!first) { a0 = S.acc[i][0]; a1 = S.acc[i][1]; a2 = S.acc[i][2]; a3 = S.acc[i][3]; }
+        if (!first && LR) { h0 = S.acc[i][4]; h1 = S.acc[i][5]; h2 = S.acc[i][6]; h3 = S.acc[i][7]; h4 = S.acc[i][8]; h5 = S.acc[i][9]; }
         for (int j = 0; j < cnt; ++j) {
           const uint32_t meta = mm[j];
           const int idx = (meta & 8u) ? (K - 1 - i) : i;
           const uint32_t bit = (mk[j][idx >> 5] >> (idx & 31)) & meta & 1u;
           const uint32_t cls = (meta >> 1) & 3u;
           a0 += (cls == 0) ? bit : 0u; a1 += (cls == 1) ? bit : 0u; a2 += (cls == 2) ? bit : 0u; a3 += (cls == 3) ? bit : 0u;
+          if (LR) {                                 // Node_t::updateHPCovDistr: quality ok and the stored count had grown
+            const uint32_t gT = (cls < 2) ? bit : 0u, gN = (cls >= 2) ? bit : 0u, gr3 = meta >> 4;
+            h0 += gT & gr3; h1 += gT & (gr3 >> 1); h2 += gT & (gr3 >> 2);
+            h3 += gN & gr3; h4 += gN & (gr3 >> 1); h5 += gN & (gr3 >> 2);
+          }
         }
-        if (!last) { S.acc[i][0] = a0; S.acc[i][1] = a1; S.acc[i][2] = a2; S.acc[i][3] = a3; }
-        else {
-          qq[4 * i] = (uint16_t)a0; qq[4 * i + 1] = (uint16_t)a1; qq[4 * i + 2] = (uint16_t)a2; qq[4 * i + 3] = (uint16_t)a3;
+        if (!last) {
+          S.acc[i][0] = (uint16_t)a0; S.acc[i][1] = (uint16_t)a1; S.acc[i][2] = (uint16_t)a2; S.acc[i][3] = (uint16_t)a3;
+          if (LR) { S.acc[i][4] = (uint16_t)h0; S.acc[i][5] = (uint16_t)h1; S.acc[i][6] = (uint16_t)h2; S.acc[i][7] = (uint16_t)h3; S.acc[i][8] = (uint16_t)h4; S.acc[i][9] = (uint16_t)h5; }
+        } else {
+          qq[QS * i] = (uint16_t)a0; qq[QS * i + 1] = (uint16_t)a1; qq[QS * i + 2] = (uint16_t)a2; qq[QS * i + 3] = (uint16_t)a3;
+          if (LR) { uint16_t *qh = qq + QS * i + 4; qh[0] = (uint16_t)h0; qh[1] = (uint16_t)h1; qh[2] = (uint16_t)h2; qh[3] = (uint16_t)h3; qh[4] = (uint16_t)h4; qh[5] = (uint16_t)h5; }
           const int sq = (int)(uint16_t)a0 + (int)(uint16_t)a1 + (int)(uint16_t)a2 + (int)(uint16_t)a3;
           dev_atomic_min((uint32_t *)&S.tmp0, (uint32_t)sq);
         }
@@ -1001,6 +1094,17 @@ DEV void build_graph(Ctx &c) {
       if (ld2(&W.gr[X].flags) & NF_INMER) for (int q = 0; q < 4; ++q) v[q] = (uint16_t)W.kcnt[4 * (size_t)X + q];
       if (i == 0) { for (int j = 0; j < K; ++j) for (int q = 0; q < 4; ++q) W.refcov[4 * j + q] = v[q]; }
       else { for (int q = 0; q < 4; ++q) W.refcov[4 * (i + K - 1) + q] = v[q]; }
+    }
+    if (S.LR) {        // hp0 hp1 hp2 of Ref_t::computeCoverage (reference src/Ref.cc:192-196, 216-240): same pattern
+      WG_FOR(j, S.reflen) { for (int q = 0; q < 6; ++q) W.refhp[6 * j + q] = 0; }
+      WG_SYNC();
+      WG_FOR(i, S.reflen - K > 0 ? S.reflen - K : 0) {
+        uint32_t X = W.occ[ro + i] & 0x3FFFFFFFu;
+        uint16_t v[6] = {0, 0, 0, 0, 0, 0};
+        if (ld2(&W.gr[X].flags) & NF_INMER) for (int q = 0; q < 6; ++q) v[q] = W.khp[6 * (size_t)X + q];
+        if (i == 0) { for (int j = 0; j < K; ++j) for (int q = 0; q < 6; ++q) W.refhp[6 * j + q] = v[q]; }
+        else { for (int q = 0; q < 6; ++q) W.refhp[6 * (i + K - 1) + q] = v[q]; }
+      }
     }
     WG_SYNC_FENCE();   // from here on the node arrays are only touched with plain loads/stores: one L1 invalidate
   }
@@ -1698,7 +1802,44 @@ struct TS {
   int col0, col1;          // alignment columns [col0, col1] -> transcript.ref / .qry
   char code, prev_bp_ref, prev_bp_alt; bool somatic;
   Acc aN[4], aT[4], rN[2], rT[2];   // alt: fwd rev minqv_fwd minqv_rev ; ref: fwd rev
+  // lr_mode, hp0 hp1 hp2: ref minimum and (u16-wrapping) sum per sample ; alt minimum of hpX and of hpX_minqv
+  uint16_t hrmnN[3], hrmnT[3], hrsumN[3], hrsumT[3], hamnN[3], hamnT[3], haqN[3], haqT[3];
 };
+struct HPc { uint16_t nh[3], nq[3], th[3], tq[3]; };   // hp0-2 and hp0-2_minqv of one position, normal / tumor
+DEV void ts_hp_init(TS &t, const HPc &a, const HPc &r) {
+  for (int j = 0; j < 3; ++j) {
+    t.hrmnN[j] = r.nh[j]; t.hrmnT[j] = r.th[j]; t.hrsumN[j] = r.nh[j]; t.hrsumT[j] = r.th[j];
+    t.hamnN[j] = a.nh[j]; t.hamnT[j] = a.th[j]; t.haqN[j] = a.nq[j]; t.haqT[j] = a.tq[j];
+  }
+}
+DEV void ts_hp_add_alt(TS &t, const HPc &a) {
+  for (int j = 0; j < 3; ++j) {
+    if (a.nh[j] < t.hamnN[j]) t.hamnN[j] = a.nh[j];
+    if (a.th[j] < t.hamnT[j]) t.hamnT[j] = a.th[j];
+    if (a.nq[j] < t.haqN[j]) t.haqN[j] = a.nq[j];
+    if (a.tq[j] < t.haqT[j]) t.haqT[j] = a.tq[j];
+  }
+}
+DEV void ts_hp_add_ref(TS &t, const HPc &r) {
+  for (int j = 0; j < 3; ++j) {
+    if (r.nh[j] < t.hrmnN[j]) t.hrmnN[j] = r.nh[j];
+    if (r.th[j] < t.hrmnT[j]) t.hrmnT[j] = r.th[j];
+    t.hrsumN[j] = (uint16_t)(t.hrsumN[j] + r.nh[j]); t.hrsumT[j] = (uint16_t)(t.hrsumT[j] + r.th[j]);
+  }
+}
+DEV void ref_hp_at(const Ctx &c, uint32_t pos, HPc &r) {       // hp0-2 of Ref_t::getCovStructAt (the minqv fields of the reference stay 0)
+  for (int j = 0; j < 3; ++j) { r.nh[j] = r.th[j] = r.nq[j] = r.tq[j] = 0; }
+  if (!c.S->LR || (int)pos >= c.S->reflen) return;
+  const uint16_t *h = c.W->refhp + 6 * pos;
+  for (int j = 0; j < 3; ++j) { r.th[j] = h[j]; r.nh[j] = h[3 + j]; }
+}
+DEV void path_hp_at(const Ctx &c, int P, HPc &a) {
+  for (int j = 0; j < 3; ++j) { a.nh[j] = a.th[j] = a.nq[j] = a.tq[j] = 0; }
+  if (!c.S->LR) return;
+  uint32_t d = c.W->pdesc[P];
+  desc_hp(c, d, 0, a.nh, a.nq);
+  desc_hp(c, d, 1, a.th, a.tq);
+}
 DEV void ts_add_alt(TS &t, const uint16_t *n4, const uint16_t *t4) { for (int q = 0; q < 4; ++q) { acc_push(t.aN[q], n4[q]); acc_push(t.aT[q], t4[q]); } }
 DEV void ts_add_ref(TS &t, const uint16_t *n2, const uint16_t *t2) { for (int q = 0; q < 2; ++q) { acc_push(t.rN[q], n2[q]); acc_push(t.rT[q], t2[q]); } }
 
@@ -1712,8 +1853,87 @@ DEV void path_cov_at(const Ctx &c, int P, uint16_t *n4, uint16_t *t4) {         
   desc_cov(c, d, 1, &t4[0], &t4[1], &t4[2], &t4[3]);
 }
 
+// ---- --linked-reads: barcode sets of a variant (Graph_t::getBXsetAt / Ref_t::getBXsetAt, reference src/Graph.cc:83-114,
+// src/Ref.cc:96-125).  bx_table[mer] = barcodes of all reads of the sample that contain the k-mer = the node's csr list.
+DEV void bx_add_node(Ctx &c, uint32_t X, uint32_t nml, uint32_t *n) {
+  Work &W = *c.W; const DevBatch &B = *c.B; volatile WinShared &S = *c.S;
+  const uint32_t g0 = B.read_begin[S.w], refr = (uint32_t)(S.R - 1);
+  uint32_t *buf = W.bxbuf;
+  for (uint32_t i = W.nocc[X]; i < W.nocc[X + 1]; ++i) {
+    const uint32_t r = CS_READ(W.csr[i]);
+    if (r == refr) continue;
+    if (RI_NML(B.rinfo[g0 + r]) != nml) continue;
+    const uint32_t bx = B.bx_rank[g0 + r];
+    if (bx == 0xFFFFFFFFu) continue;
+    uint32_t lo = 0, hi = *n;                                    // sorted, distinct (std::set<string> order == rank order)
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (buf[mid] < bx) lo = mid + 1; else hi = mid; }
+    if (lo < *n && buf[lo] == bx) continue;
+    if (*n >= c.C->reads_cap) { OVF(c); return; }
+    for (uint32_t j = *n; j > lo; --j) buf[j] = buf[j - 1];
+    buf[lo] = bx; ++*n;
+  }
+}
+// node of the k-mer codes[0..K) (2-bit codes) or LC_NIL: the open-addressing table of the current build
+DEVNI uint32_t kmer_lookup(Ctx &c, const uint8_t *codes) {
+  Work &W = *c.W; volatile WinShared &S = *c.S;
+  const int K = S.K, NW = S.NW;
+  unsigned long long fw[LC_NWMAX], rc[LC_NWMAX];
+  for (int w = 0; w < LC_NWMAX; ++w) { fw[w] = 0; rc[w] = 0; }
+  for (int i = 0; i < K; ++i) { key_push_fw(fw, NW, K, codes[i] & 3); key_push_rc(rc, NW, K, codes[i] & 3); }
+  const unsigned long long *ck = key_less(fw, rc, NW) ? fw : rc;
+  const uint32_t mask = c.C->table_cap - 1;
+  unsigned long long h = 0; uint32_t idx;
+  if (NW == 1 && K <= 31) { h = ck[0] + 1ULL; idx = (uint32_t)mix64(h) & mask; }
+  else {
+    for (int w = 0; w < NW; ++w) h = mix64(h ^ (ck[w] + 0x9e3779b97f4a7c15ULL * (unsigned long long)(w + 1)));
+    h &= ~(1ULL << 63);
+    if (h == 0) h = 1;
+    idx = (uint32_t)h & mask;
+  }
+  for (uint32_t probes = 0; probes <= mask; ++probes) {
+    const unsigned long long cur = W.tags[idx];
+    if (cur == 0) return LC_NIL;
+    if (cur == h) {
+      bool same = true;
+      if (!(NW == 1 && K <= 31)) for (int w = 0; w < NW; ++w) if (W.slot_key[(size_t)idx * LC_NWMAX + w] != ck[w]) same = false;
+      if (same) return W.slot_node[idx];
+    }
+    idx = (idx + 1) & mask;
+  }
+  return LC_NIL;
+}
+DEVNI void emit_variant_lr(Ctx &c, uint32_t vi, const TS &t, const uint16_t hp12[12], int plen) {
+  volatile WinShared &S = *c.S; Work &W = *c.W; DevOut &O = *c.OUT;
+  lancet_variant_lr &l = O.variants_lr[vi];
+  for (int q = 0; q < 12; ++q) l.hp[q] = hp12[q];
+  l.reserved[0] = l.reserved[1] = 0;
+  const int K = S.K;
+  const uint32_t ro = W.occ_base[S.R - 1];
+  for (int q = 0; q < 4; ++q) {          // bxset_ref_N, bxset_ref_T, bxset_alt_N, bxset_alt_T  (Graph.cc:1177-1182)
+    const uint32_t nml = (q == 0 || q == 2) ? 1u : 0u;
+    uint32_t n = 0;
+    if (q < 2) {                           // k-mers of Ref_t::seq at [ref_pos-1, ref_end_pos-1] that are in the reference's mer table
+      for (int i = (int)t.ref_pos - 1; i <= (int)t.ref_end_pos - 1; ++i) {
+        if (i < 0 || i + K > S.seq_len) continue;            // shorter substr: not a key of the table
+        const uint32_t X = W.occ[ro + (uint32_t)(S.seq_t5 + i)] & 0x3FFFFFFFu;
+        if (W.gr[X].flags & NF_INMER) bx_add_node(c, X, nml, &n);
+      }
+    } else {                               // k-mers of the path string at [start_pos-2, end_pos-1]
+      for (int i = (int)t.start_pos - 2; i <= (int)t.end_pos - 1; ++i) {
+        if (i < 0 || i + K > plen) continue;
+        const uint32_t X = kmer_lookup(c, W.pseq + i);
+        if (X != LC_NIL) bx_add_node(c, X, nml, &n);
+      }
+    }
+    const uint32_t off = dev_atomic_add(O.n_bx, n);
+    if (off + n > c.C->bx_cap) { OVF(c); l.bx_off[q] = 0; l.bx_len[q] = 0; continue; }
+    l.bx_off[q] = off; l.bx_len[q] = n;
+    for (uint32_t j = 0; j < n; ++j) O.bx_blob[off + j] = W.bxbuf[j];
+  }
+}
+
 DEVNI void emit_variant(Ctx &c, const TS &t, const uint16_t cov[8], int strLen, const uint8_t *motif, int motifLen, bool hasStr,
-                      const uint8_t *ra, const uint8_t *pa) {
+                      const uint8_t *ra, const uint8_t *pa, const uint16_t hp12[12], int plen) {
   volatile WinShared &S = *c.S; DevOut &O = *c.OUT;
   uint32_t vi = dev_atomic_add(O.n_variants, 1u);
   int rl = t.col1 - t.col0 + 1;
@@ -1733,6 +1953,7 @@ DEVNI void emit_variant(Ctx &c, const TS &t, const uint16_t cov[8], int strLen, 
   v.ref_off = bo; v.ref_len = (uint32_t)rl; v.alt_off = bo + (uint32_t)rl; v.alt_len = (uint32_t)rl; v.str_off = bo + 2u * (uint32_t)rl; v.str_len = (uint32_t)sl;
   for (int i = 0; i < rl; ++i) { O.blob[bo + i] = (char)ra[t.col0 + i]; O.blob[bo + rl + i] = (char)pa[t.col0 + i]; }
   for (int i = 0; i < sl; ++i) O.blob[bo + 2 * rl + i] = sbuf[i];
+  if (S.LR) emit_variant_lr(c, vi, t, hp12, plen);
 }
 
 // lane 0.  `np` = nodes in path, `plen` = path string length, aligned strings in W.aln (length L).
@@ -1764,6 +1985,9 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
       uint16_t cn4[4], ct4[4], rn2[2], rt2[2];
       path_cov_at(c, P, cn4, ct4);
       ref_cov_at(c, pos_in_ref + (uint32_t)S.trim5, rn2, rt2);
+      HPc ha, hr;
+      path_hp_at(c, P, ha);
+      ref_hp_at(c, pos_in_ref + (uint32_t)S.trim5, hr);
       unsigned rrpos = pos_in_ref + (unsigned)refstart + (unsigned)S.trim5;
       int pr = i - 1, pq = i - 1;
       while (pr >= 0 && ra[pr] != 'A' && ra[pr] != 'C' && ra[pr] != 'G' && ra[pr] != 'T') --pr;
@@ -1774,9 +1998,9 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
         if (within_tumor) t.somatic = true;
         int reflen_before = t.col1 - t.col0 + 1;        // transcript.ref.length() before the append
         t.col1 = i; t.end_pos = (uint32_t)P; t.ref_end_pos = pos_in_ref;
-        if (code == '^' && t.code == code && t.pos == rrpos) ts_add_alt(t, cn4, ct4);
-        else if (code == 'v' && t.code == code && (t.pos + (unsigned)(reflen_before + 1)) == rrpos) ts_add_ref(t, rn2, rt2);
-        else if (code == 'x' || t.code != code) { t.code = 'c'; ts_add_alt(t, cn4, ct4); ts_add_ref(t, rn2, rt2); }
+        if (code == '^' && t.code == code && t.pos == rrpos) { ts_add_alt(t, cn4, ct4); ts_hp_add_alt(t, ha); }
+        else if (code == 'v' && t.code == code && (t.pos + (unsigned)(reflen_before + 1)) == rrpos) { ts_add_ref(t, rn2, rt2); ts_hp_add_ref(t, hr); }
+        else if (code == 'x' || t.code != code) { t.code = 'c'; ts_add_alt(t, cn4, ct4); ts_add_ref(t, rn2, rt2); ts_hp_add_alt(t, ha); ts_hp_add_ref(t, hr); }
       } else {
         if (nts >= LC_MAXTS) { OVF(c); return; }
         TS &t = ts[nts++];
@@ -1784,6 +2008,7 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
         t.col0 = i; t.col1 = i; t.somatic = within_tumor; t.prev_bp_ref = (char)ra[pr]; t.prev_bp_alt = (char)pa[pq];
         for (int q = 0; q < 4; ++q) { acc_init(t.aN[q], cn4[q]); acc_init(t.aT[q], ct4[q]); }
         for (int q = 0; q < 2; ++q) { acc_init(t.rN[q], rn2[q]); acc_init(t.rT[q], rt2[q]); }
+        ts_hp_init(t, ha, hr);
       }
     }
   }
@@ -1801,11 +2026,13 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
           uint16_t cn4[4], ct4[4];
           path_cov_at(c, (int)idx1, cn4, ct4);
           ts_add_alt(t, cn4, ct4);
+          if (S.LR) { HPc ha; path_hp_at(c, (int)idx1, ha); ts_hp_add_alt(t, ha); }
         }
         unsigned idx2 = t.ref_end_pos + (unsigned)S.trim5 + (unsigned)j;
         uint16_t rn2[2], rt2[2];
         ref_cov_at(c, idx2, rn2, rt2);
         ts_add_ref(t, rn2, rt2);
+        if (S.LR) { HPc hr; ref_hp_at(c, idx2, hr); ts_hp_add_ref(t, hr); }
       }
     }
     bool x = t.code == 'x';
@@ -1815,16 +2042,32 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
     uint16_t ACTF = x ? t.aT[2].mn : t.aT[0].mn, ACTR = x ? t.aT[3].mn : t.aT[1].mn;
     if (t.somatic) { RCNF = acc_mean(t.rN[0]); RCNR = acc_mean(t.rN[1]); RCTF = acc_mean(t.rT[0]); RCTR = acc_mean(t.rT[1]); ACNF = 0; ACNR = 0; }
     uint16_t cov[8] = {RCNF, RCNR, RCTF, RCTR, ACNF, ACNR, ACTF, ACTR};
+    // haplotype counts (Graph.cc:1091-1128): min of the ref / alt counts, means of the ref counts when somatic
+    uint16_t hp12[12];                                  // HPRN HPRT HPAN HPAT as {hp1, hp2, hp0} (Graph.cc:1166-1169)
+    {
+      const uint32_t nref = t.rN[0].n;
+      auto mean = [&](uint16_t sum) -> uint16_t { return nref > 0 ? (uint16_t)((float)sum / (float)nref) : (uint16_t)0; };
+      uint16_t RN[3], RT[3], AN[3], AT[3];
+      for (int j = 0; j < 3; ++j) {
+        RN[j] = t.hrmnN[j]; RT[j] = t.hrmnT[j];
+        AN[j] = x ? t.haqN[j] : t.hamnN[j]; AT[j] = x ? t.haqT[j] : t.hamnT[j];
+        if (t.somatic) { RT[j] = mean(t.hrsumT[j]); RN[j] = mean(t.hrsumN[j]); AN[j] = 0; }
+        if (!S.LR) { RN[j] = RT[j] = AN[j] = AT[j] = 0; }
+      }
+      const uint16_t v[12] = {RN[1], RN[2], RN[0], RT[1], RT[2], RT[0], AN[1], AN[2], AN[0], AT[1], AT[2], AT[0]};
+      for (int q = 0; q < 12; ++q) hp12[q] = v[q];
+    }
     if (c.C->evt_cap) {
       evt(c, EV_TS, t.pos, (uint32_t)(t.col1 - t.col0 + 1), ((uint32_t)RCNF << 16) | RCNR, ((uint32_t)RCTF << 16) | RCTR,
           ((uint32_t)ACNF << 16) | ACNR, ((uint32_t)ACTF << 16) | ACTR, ((uint32_t)(uint8_t)t.prev_bp_ref << 8) | (uint8_t)t.prev_bp_alt);
       evt_bytes(c, ra + t.col0, (uint32_t)(t.col1 - t.col0 + 1));
       evt_bytes(c, pa + t.col0, (uint32_t)(t.col1 - t.col0 + 1));
+      evt_bytes(c, (const uint8_t *)hp12, 24);
     }
     if (ACNF > 0 || ACNR > 0 || ACTF > 0 || ACTR > 0) {
       int LEN = 0, ml = 0; uint8_t motif[64];
       bool ans = find_tandems(c, W.pseq, plen, (int)t.start_pos, &LEN, motif, &ml);
-      emit_variant(c, t, cov, LEN, motif, ml, ans, ra, pa);
+      emit_variant(c, t, cov, LEN, motif, ml, ans, ra, pa, hp12, plen);
     }
   }
   evt(c, EV_PATH_END);
@@ -1934,6 +2177,7 @@ DEV void process_window(Ctx &c, int w) {
   WG_LANE0 {
     S.w = w; S.overflow = 0; S.evt_len = 0; S.emit_seq = 0; S.n_kmers = 0; S.max_nodes = 0; S.n_builds = 0; S.final_k = 0;
     S.status = LANCET_W_OK;
+    S.LR = c.C->lr_mode ? 1 : 0; S.QS = S.LR ? 10 : 4;
     S.reflen = (int)(B.ref_off[w + 1] - B.ref_off[w]);
     int nr = (int)(B.read_begin[w + 1] - B.read_begin[w]);
     S.R = nr + 1;                                   // + the reference pseudo-read, appended last (Graph.cc:535-540)

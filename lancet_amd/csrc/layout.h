@@ -70,6 +70,8 @@ struct EngineCaps {
   uint32_t max_k;        /* largest k the engine was created for                           */
   uint32_t qv_cap;       /* (survivor, k-mer position) entries of per-position quality counts */
   uint32_t debug_stop;   /* profiling only: abandon every window after this phase marker (0 = off)  */
+  uint32_t lr_mode;      /* --linked-reads: 10 instead of 4 counters per (survivor, position), barcode outputs */
+  uint32_t bx_cap;       /* barcode ids (u32) of the variants' barcode sets, whole batch (lr_mode)   */
 };
 
 /* device-resident batch (after upload + prep) */
@@ -85,6 +87,8 @@ struct DevBatch {
   const uint32_t *good_woff;    /* [R] word offset of the read's quality mask (32 bases / u32) */
   const uint32_t *bases;        /* 2-bit packed, trimmed reads only */
   const uint32_t *good;         /* bit = (qual >= MIN_QUAL_CALL) */
+  const uint32_t *bx_rank;      /* [R] barcode rank or LANCET_NO_BX (lr_mode only, else null) */
+  const uint8_t *hp;            /* [R] haplotype 0|1|2 (lr_mode only, else null) */
 };
 
 struct BfsEntry {
@@ -136,7 +140,11 @@ struct Work {
   uint32_t *nfill;        /* [nodes+1] csr fill cursors                                        */
   NodeGr *gr;             /* [nodes]                                                           */
   uint32_t *nocc;         /* [nodes+1] csr offsets                                             */
-  uint16_t *qv;           /* [surv_cap * K * 4] per-position min-quality counts Tf Tr Nf Nr    */
+  uint16_t *qv;           /* [qv_cap * QS] per-position min-quality counts Tf Tr Nf Nr (QS = 4), in lr_mode followed by
+                             hp0/hp1/hp2_minqv of the tumor and of the normal (QS = 10)        */
+  uint16_t *khp;          /* [nodes*6] lr_mode: last-written hp0 hp1 hp2 of the k-mer, tumor then normal */
+  uint16_t *refhp;        /* [LC_MAXW*6] lr_mode: the same per rawseq position (Ref_t coverage)  */
+  uint32_t *bxbuf;        /* [reads_cap] lr_mode: sorted distinct barcodes of the set being collected */
   uint32_t *seq;          /* [seq_cap] descriptor arena                                        */
   /* ---- libstdc++ node-table order ---- */
   uint32_t *ht_next;      /* [nodes]                                                           */
@@ -167,6 +175,9 @@ struct DevOut {
   uint32_t *n_blob;       /* atomic */
   struct lancet_window_stats *stats;
   uint32_t *queue_head;   /* atomic window queue */
+  struct lancet_variant_lr *variants_lr;   /* lr_mode: parallel to variants */
+  uint32_t *bx_blob;      /* lr_mode: barcode ids of the variants' barcode sets */
+  uint32_t *n_bx;         /* atomic */
   uint32_t *evt_len;      /* [n_windows] words used in the window's trace (slot evt copied out)  */
   uint32_t *evt_out;      /* [n_windows * evt_cap] */
   unsigned long long *phase; /* [n_windows * 16] per-phase time (100 MHz ticks), may be null */

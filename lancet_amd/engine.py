@@ -41,6 +41,7 @@ def lib():
         L.lancet_engine_results.argtypes = [C.c_void_p, C.POINTER(C.POINTER(abi.LancetVariant)), C.POINTER(C.c_uint32),
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(abi.LancetWindowStats))]
         L.lancet_engine_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float * 2)]
+        L.lancet_engine_results_lr.argtypes = [C.c_void_p, C.POINTER(C.POINTER(abi.LancetVariantLR)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32)]
         L.lancet_engine_set_trace.argtypes = [C.c_void_p, C.c_uint32]
         L.lancet_engine_trace.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32)]
         L.lancet_engine_rerun_count.argtypes = [C.c_void_p]
@@ -52,6 +53,8 @@ def lib():
         L.lancet_vdb_create.argtypes = [C.POINTER(abi.LancetFilters)]
         L.lancet_vdb_destroy.argtypes = [C.c_void_p]
         L.lancet_vdb_add.argtypes = [C.c_void_p, C.POINTER(abi.LancetVariant), C.c_uint32, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32]
+        L.lancet_vdb_add_lr.argtypes = [C.c_void_p, C.POINTER(abi.LancetVariant), C.POINTER(abi.LancetVariantLR), C.c_uint32, C.c_char_p,
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_int32]
         L.lancet_vdb_size.restype = C.c_uint32
         L.lancet_vdb_size.argtypes = [C.c_void_p]
         L.lancet_vdb_vcf.restype = C.c_void_p
@@ -100,9 +103,20 @@ class Engine:
         self._chk(self.L.lancet_engine_results(self.h, C.byref(vp), C.byref(n), C.byref(blob), C.byref(bl), C.byref(sp)))
         return vp, n.value, (C.string_at(blob, bl.value) if bl.value else b""), sp
 
+    def raw_results_lr(self):
+        """(lancet_variant_lr*, bx_blob*, bx_blob_len) of the last run; the first is NULL unless lr_mode."""
+        lp = C.POINTER(abi.LancetVariantLR)()
+        bp = C.POINTER(C.c_uint32)()
+        bl = C.c_uint32()
+        self._chk(self.L.lancet_engine_results_lr(self.h, C.byref(lp), C.byref(bp), C.byref(bl)))
+        return lp, bp, bl.value
+
     def results(self):
         vp, n, blob, sp = self.raw_results()
         variants = abi.variants_to_py(vp, n, blob)
+        if self.params.lr_mode:
+            lp, bp, _ = self.raw_results_lr()
+            abi.variants_lr_to_py(variants, lp, bp)
         nw = self._batch.n_windows
         stats = [dict(status=sp[i].status, final_k=sp[i].final_k, n_builds=sp[i].n_builds, n_variants=sp[i].n_variants,
                       n_kmers=sp[i].n_kmers, max_nodes=sp[i].max_nodes) for i in range(nw)]
@@ -178,10 +192,28 @@ class VariantDB:
         if rc != 0:
             raise EngineError(f"lancet_vdb_add: {ERRORS.get(rc, rc)}")
 
-    def add_records(self, records: List[dict], chr_names: Sequence[str]) -> None:
-        """records: dicts as produced by abi.variants_to_py (any source)."""
+    def add_raw_lr(self, vptr, lrptr, n: int, blob: bytes, bx_blob, bx_names: Sequence[str], chr_names: Sequence[str]) -> None:
+        names = abi.c_string_array(list(chr_names))
+        bxn = abi.c_string_array(list(bx_names))
+        rc = self.L.lancet_vdb_add_lr(self.h, vptr, lrptr, n, blob, bx_blob, bxn, len(bx_names), names, len(chr_names))
+        if rc != 0:
+            raise EngineError(f"lancet_vdb_add_lr: {ERRORS.get(rc, rc)}")
+
+    def add_records(self, records: List[dict], chr_names: Sequence[str], bx_names: Optional[Sequence[str]] = None) -> None:
+        """records: dicts as produced by abi.variants_to_py (any source); with bx_names: linked-read records
+        (abi.variants_lr_to_py) for a --linked-reads database."""
         arr = (abi.LancetVariant * len(records))()
         blob = bytearray()
+        if bx_names is not None:
+            lr = (abi.LancetVariantLR * max(1, len(records)))()
+            ids: List[int] = []
+            for i, r in enumerate(records):
+                for q in range(12):
+                    lr[i].hp[q] = r["hp"][q]
+                for q in range(4):
+                    lr[i].bx_off[q], lr[i].bx_len[q] = len(ids), len(r["bx"][q])
+                    ids += list(r["bx"][q])
+            bxb = (C.c_uint32 * max(1, len(ids)))(*ids)
         for i, r in enumerate(records):
             v = arr[i]
             v.window, v.seq_in_window, v.chr_id, v.pos = r["window"], r["seq"], r["chr_id"], r["pos"]
@@ -191,7 +223,10 @@ class VariantDB:
             v.ref_off, v.ref_len = len(blob), len(r["ref"]); blob += r["ref"].encode()
             v.alt_off, v.alt_len = len(blob), len(r["alt"]); blob += r["alt"].encode()
             v.str_off, v.str_len = len(blob), len(r["str"]); blob += r["str"].encode()
-        self.add_raw(arr, len(records), bytes(blob) + b"\0", chr_names)
+        if bx_names is not None:
+            self.add_raw_lr(arr, lr, len(records), bytes(blob) + b"\0", bxb, bx_names, chr_names)
+        else:
+            self.add_raw(arr, len(records), bytes(blob) + b"\0", chr_names)
 
     def size(self) -> int:
         return int(self.L.lancet_vdb_size(self.h))

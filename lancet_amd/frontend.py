@@ -150,14 +150,22 @@ class WindowBatch:
     mate: np.ndarray          # uint8[R]
     mapped: np.ndarray        # uint8[R]
     name_rank: np.ndarray     # uint32[R]
+    # --linked-reads only (None otherwise): ReadInfo_t::BX as the dense rank of the barcode among the batch's barcodes
+    # under std::string operator< (NO_BX = "null"), ReadInfo_t::HP (0 | 1 | 2), and the barcode strings by rank
+    bx_rank: Optional[np.ndarray] = None    # uint32[R]
+    hp: Optional[np.ndarray] = None         # uint8[R]
+    bx_names: Optional[List[str]] = None
 
     @property
     def n_reads(self) -> int:
         return int(self.read_begin[-1])
 
 
+NO_BX = 0xFFFFFFFF
+
+
 def build_batch(windows: Sequence[Window], per_window_reads: Sequence[Sequence[Tuple[str, str, str, int, int, int, bool]]],
-                chrom_ids: Optional[Dict[str, int]] = None) -> WindowBatch:
+                chrom_ids: Optional[Dict[str, int]] = None, linked: bool = False) -> WindowBatch:
     """per_window_reads[w] = [(name, seq, qual, label, strand, mate, mapped)], tumor reads then normal reads
     (the order Graph_t::readid2info gets filled, reference src/Microassembler.cc:833-834)."""
     n = len(windows)
@@ -175,6 +183,8 @@ def build_batch(windows: Sequence[Window], per_window_reads: Sequence[Sequence[T
     ranks: List[int] = []
     chr_id = np.zeros(n, dtype=np.int32)
     ref_start = np.zeros(n, dtype=np.int32)
+    bxs: List[str] = []
+    hps: List[int] = []
     for w, win in enumerate(windows):
         refs.append(win.seq.encode())
         ref_off[w + 1] = ref_off[w] + len(win.seq)
@@ -183,7 +193,10 @@ def build_batch(windows: Sequence[Window], per_window_reads: Sequence[Sequence[T
         rs = per_window_reads[w]
         names = sorted({r[0].encode() for r in rs})
         rank = {nm: i for i, nm in enumerate(names)}
-        for (name, s, q, lab, st, mt, mp) in rs:
+        for rec in rs:
+            (name, s, q, lab, st, mt, mp) = rec[:7]
+            if linked:
+                bxs.append(rec[7]); hps.append(rec[8])
             seqs.append(s.encode())
             quals.append(q.encode())
             seq_len.append(len(s))
@@ -196,7 +209,14 @@ def build_batch(windows: Sequence[Window], per_window_reads: Sequence[Sequence[T
     seq_off = np.zeros(len(seq_len) + 1, dtype=np.uint32)
     if seq_len:
         seq_off[1:] = np.cumsum(np.asarray(seq_len, dtype=np.uint64)).astype(np.uint32)
+    lr = {}
+    if linked:
+        names = sorted({b.encode() for b in bxs if b != "null"})
+        rk = {nm: i for i, nm in enumerate(names)}
+        lr = dict(bx_rank=np.asarray([rk[b.encode()] if b != "null" else NO_BX for b in bxs], dtype=np.uint32),
+                  hp=np.asarray(hps, dtype=np.uint8), bx_names=[nm.decode() for nm in names])
     return WindowBatch(
+        **lr,
         n_windows=n, hdr=[w.hdr for w in windows], chrom=[w.chrom for w in windows],
         chr_id=chr_id, ref_start=ref_start, ref_off=ref_off,
         ref_bases=np.frombuffer(b"".join(refs), dtype=np.uint8).copy(),
@@ -209,7 +229,7 @@ def build_batch(windows: Sequence[Window], per_window_reads: Sequence[Sequence[T
 
 
 def batch_from_sam(windows: Sequence[Window], tumor: Sequence[SamRead], normal: Sequence[SamRead],
-                   p: Optional[ReadFilterParams] = None, max_k: int = 101):
+                   p: Optional[ReadFilterParams] = None, max_k: int = 101, linked: bool = False):
     """Runs the per-window part of processReads (reference src/Microassembler.cc:779-842) up to the
     processGraph call: returns (batch, kept_windows) for windows that are not skipped.
     Active-region prefilter is not applied here (== --active-region-off)."""
@@ -225,11 +245,13 @@ def batch_from_sam(windows: Sequence[Window], tumor: Sequence[SamRead], normal: 
         nr, skip_n = extract_reads(normal, n_starts, win, NML, p)
         if skip_t or skip_n:
             continue
-        rs = [(r.qname, r.seq, r.qual, TMR, st, mt, mp) for (r, mt, st, mp) in tr]
-        rs += [(r.qname, r.seq, r.qual, NML, st, mt, mp) for (r, mt, st, mp) in nr]
+        # BX / HP as extractReads reads them (reference src/Microassembler.cc:581-593): missing BX -> "null", missing HP -> 0
+        lr = (lambda r: (r.tags.get("BX", "") or "null", max(0, int(r.tags.get("HP", 0))))) if linked else (lambda r: ())
+        rs = [(r.qname, r.seq, r.qual, TMR, st, mt, mp) + lr(r) for (r, mt, st, mp) in tr]
+        rs += [(r.qname, r.seq, r.qual, NML, st, mt, mp) + lr(r) for (r, mt, st, mp) in nr]
         kept.append(win)
         per.append(rs)
-    return build_batch(kept, per), kept
+    return build_batch(kept, per, linked=linked), kept
 
 
 def _is_repeat(seq: str, k: int) -> bool:

@@ -211,9 +211,12 @@ def _cigar_md(ref_b: np.ndarray, seq: np.ndarray, rpos: np.ndarray):
 def simulate_sample(ref: str, rname: str, haps: List[Tuple[np.ndarray, np.ndarray]], hap_probs: List[float],
                     coverage: float, seed: int, prefix: str, rg: str, read_len: int = 150,
                     insert_mean: float = 400.0, insert_sd: float = 40.0, error_rate: float = 0.005,
-                    region: Tuple[int, int] | None = None) -> List[Tuple[SamRead, SamRead]]:
-    """Simulates fragments; returns list of (read1, read2) with read1.pos <= read2.pos not guaranteed."""
+                    region: Tuple[int, int] | None = None, linked: bool = False) -> List[Tuple[SamRead, SamRead]]:
+    """Simulates fragments; returns list of (read1, read2) with read1.pos <= read2.pos not guaranteed.
+    linked=True adds 10x-style tags from a separate random stream (the reads themselves do not change): BX:Z barcode
+    shared by a few fragments (some fragments have none), HP:i haplotype 0 (unassigned) / 1 / 2."""
     rng = np.random.default_rng(seed)
+    rng_lr = np.random.default_rng(seed + 7777)
     ref_b = np.frombuffer(ref.encode(), dtype=np.uint8)
     lo, hi = (0, len(ref)) if region is None else region
     span = hi - lo
@@ -259,6 +262,20 @@ def simulate_sample(ref: str, rname: str, haps: List[Tuple[np.ndarray, np.ndarra
                                  seq.tobytes().decode(), (q + 33).tobytes().decode(),
                                  {"AS": read_len - 5 * nm, "XS": 0, "NM": nm, "MD": md, "RG": rg}))
         if len(reads) == 2:
+            if linked:
+                pool = max(4, n_frag // 3)
+                code = int(rng_lr.integers(0, pool))
+                bx = "".join("ACGT"[(code * 2654435761 >> (2 * j)) & 3] for j in range(16)) + "-1"
+                has_bx = rng_lr.random() >= 0.1
+                u = rng_lr.random()
+                hp = 0 if u < 0.3 else (1 if h == 0 else 2)
+                if rng_lr.random() < 0.03:
+                    hp = 3 - hp if hp else 1              # phasing error
+                for rd in reads:
+                    if has_bx:
+                        rd.tags["BX"] = bx
+                    if rng_lr.random() >= 0.05:           # HP tag occasionally missing on one mate
+                        rd.tags["HP"] = hp
             pairs.append((reads[0], reads[1]))
     return pairs
 
@@ -319,7 +336,7 @@ def make_tumor_normal(ref_len: int = 20000, cov_t: float = 30, cov_n: float = 30
                       read_len: int = 150, error_rate: float = 0.005,
                       somatic_every: int = 2000, germline_every: int = 1000,
                       region: Tuple[int, int] | None = None, dup_prob: float = 0.0,
-                      insert_mean: float = 400.0, insert_sd: float = 40.0, n_runs=()):
+                      insert_mean: float = 400.0, insert_sd: float = 40.0, n_runs=(), linked: bool = False):
     """Returns dict(ref, variants, tumor_pairs, normal_pairs)."""
     ref = random_reference(ref_len, ref_seed, str_fraction, lowcomplex_fraction)
     variants = plant_variants(ref, ref_seed + 1, somatic_every, germline_every, dup_prob=dup_prob)
@@ -334,8 +351,8 @@ def make_tumor_normal(ref_len: int = 20000, cov_t: float = 30, cov_n: float = 30
         ref = "".join(rl)
     tumor = simulate_sample(ref, rname, [h0, h1, h2], [0.5, 0.25, 0.25], cov_t, tumor_seed, "T", "tumor",
                             read_len=read_len, error_rate=error_rate, region=region, insert_mean=insert_mean,
-                            insert_sd=insert_sd)
+                            insert_sd=insert_sd, linked=linked)
     normal = simulate_sample(ref, rname, [h0, h1], [0.5, 0.5], cov_n, normal_seed, "N", "normal",
                              read_len=read_len, error_rate=error_rate, region=region, insert_mean=insert_mean,
-                             insert_sd=insert_sd)
+                             insert_sd=insert_sd, linked=linked)
     return {"ref": ref, "rname": rname, "variants": variants, "tumor": tumor, "normal": normal}

@@ -83,8 +83,12 @@ def format_window(words: Sequence[int], idx1: int, hdr: str, chrom: str, start: 
         elif code == EV_TS:
             ref, i = _bytes(words, i, b)
             qry, i = _bytes(words, i, b)
+            hw = [int(x) for x in words[i:i + 6]]            # 12 x u16: HPRN HPRT HPAN HPAT, each {hp1, hp2, hp0}
+            i += 8
+            h = [(hw[q // 2] >> (16 * (q % 2))) & 0xFFFF for q in range(12)]
+            hp = lambda o: f"{h[o + 2]},{h[o]},{h[o + 1]}"     # printed as hp0,hp1,hp2 (reference src/Graph.cc:1138-1141)
             out.append(f" {a}:{ref}|{qry}|R:({c >> 16}+,{c & 0xFFFF}-)n,({d >> 16}+,{d & 0xFFFF}-)t|A:({e >> 16}+,{e & 0xFFFF}-)n,"
-                       f"({f >> 16}+,{f & 0xFFFF}-)t|HPref(0,0,0)n,(0,0,0)t|HPalt(0,0,0)n,(0,0,0)t|{chr(g >> 8)}|{chr(g & 0xFF)}")
+                       f"({f >> 16}+,{f & 0xFFFF}-)t|HPref({hp(0)})n,({hp(3)})t|HPalt({hp(6)})n,({hp(9)})t|{chr(g >> 8)}|{chr(g & 0xFF)}")
         elif code == EV_PATH_END:
             out.append("\n")
         elif code == EV_EKA_END:

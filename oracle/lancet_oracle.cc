@@ -166,8 +166,9 @@ struct CMer {
   }
 };
 
-// ---- cov_t, reference src/Ref.hh:41-53 (hp* fields only matter in LR mode; omitted) -----------------------
-struct Cov { uint16_t fwd = 0, rev = 0, minqv_fwd = 0, minqv_rev = 0; };
+// ---- cov_t, reference src/Ref.hh:41-53 (the hp* fields stay 0 unless --linked-reads) -------------------------
+struct Cov { uint16_t fwd = 0, rev = 0, minqv_fwd = 0, minqv_rev = 0, hp0 = 0, hp1 = 0, hp2 = 0, hp0_minqv = 0, hp1_minqv = 0, hp2_minqv = 0; };
+static const uint32_t NO_BX = 0xFFFFFFFFu;   // ReadInfo_t::BX == "null"; barcodes are their dense std::string rank
 
 struct Edge { std::string to; Edgedir dir; int flag; };
 
@@ -185,6 +186,8 @@ struct Node {
   std::vector<Cov> distT, distN;
   std::vector<Edge> edges;
   std::vector<uint32_t> mate1, mate2;     // read names as their lexicographic dense rank
+  std::set<uint32_t> bx_tf, bx_tr, bx_nf, bx_nr;   // bxset_{tmr,nml}_{fwd,rev} (only membership and size are observable)
+  int hp_t[3] = {0, 0, 0}, hp_n[3] = {0, 0, 0};    // hpset_tmr / hpset_nml
 
   explicit Node(const std::string &mer) : id(mer), str(mer) {
     status.resize(str.size(), 'E'); distT.resize(str.size()); distN.resize(str.size());
@@ -237,6 +240,37 @@ struct Node {
       else if (strand == LANCET_REV) { (*d)[i].rev = (uint16_t)cov; if (qv[i] >= MIN_QUAL) ++(*d)[i].minqv_rev; }
     }
   }
+  // ---- linked reads, reference src/Node.cc:30-118, 502-520
+  bool addBX(uint32_t bx, int strand, int label) {
+    if (bx == NO_BX) return false;
+    if (label == LANCET_TMR) { if (strand == LANCET_FWD) return bx_tf.insert(bx).second; if (strand == LANCET_REV) return bx_tr.insert(bx).second; }
+    if (label == LANCET_NML) { if (strand == LANCET_FWD) return bx_nf.insert(bx).second; if (strand == LANCET_REV) return bx_nr.insert(bx).second; }
+    return false;
+  }
+  void addHP(int hp, int label) { if (label == LANCET_TMR) hp_t[hp] += 1; if (label == LANCET_NML) hp_n[hp] += 1; }
+  bool hasBX(uint32_t bx, int label) const {         // "null" is never stored, so it is never found
+    if (label == LANCET_TMR) return bx_tf.count(bx) || bx_tr.count(bx);
+    if (label == LANCET_NML) return bx_nf.count(bx) || bx_nr.count(bx);
+    return false;
+  }
+  int BXcnt(int strand, int label) const {
+    if (label == LANCET_TMR) { if (strand == LANCET_FWD) return (int)bx_tf.size(); if (strand == LANCET_REV) return (int)bx_tr.size(); }
+    if (label == LANCET_NML) { if (strand == LANCET_FWD) return (int)bx_nf.size(); if (strand == LANCET_REV) return (int)bx_nr.size(); }
+    return -1;
+  }
+  int HPcnt(int hp, int label) const { if (label == LANCET_TMR) return hp_t[hp]; if (label == LANCET_NML) return hp_n[hp]; return -1; }
+  void updateHPCovDistr(int h0, int h1, int h2, const std::string &qv, int sample) {
+    std::vector<Cov> *d = sample == LANCET_TMR ? &distT : (sample == LANCET_NML ? &distN : nullptr);
+    if (!d) return;
+    for (size_t i = 0; i < d->size(); ++i) {
+      if (qv[i] >= MIN_QUAL) {
+        if ((*d)[i].hp0 < h0) ++(*d)[i].hp0_minqv;
+        if ((*d)[i].hp1 < h1) ++(*d)[i].hp1_minqv;
+        if ((*d)[i].hp2 < h2) ++(*d)[i].hp2_minqv;
+      }
+      (*d)[i].hp0 = (uint16_t)h0; (*d)[i].hp1 = (uint16_t)h1; (*d)[i].hp2 = (uint16_t)h2;
+    }
+  }
   void revCovDistr() {                                                               // Node.cc:562-572
     int i = 0, j = (int)distT.size() - 1;
     while (i < j) { std::swap(distT[i], distT[j]); std::swap(distN[i], distN[j]); ++i; --j; }
@@ -274,6 +308,7 @@ struct RefInfo {
   int refstart = 0, refend = 0;
   unsigned short trim5 = 0, trim3 = 0;
   std::unordered_map<std::string, Cov> merN, merT;
+  std::unordered_map<std::string, std::set<uint32_t>> bxN, bxT;                       // bx_table_nml / bx_table_tmr
   std::vector<Cov> covN, covT;
   std::set<int> refcompids;
   int refnodes = 0, refcomp = 0, allcomp = 0;
@@ -281,7 +316,7 @@ struct RefInfo {
 
   void setK(int k) {                                                                 // Ref.hh:109, Ref.cc:28-38, :355-387
     K = k; indexed = false;
-    merN.clear(); merT.clear();
+    merN.clear(); merT.clear(); bxN.clear(); bxT.clear();
     covN.assign(rawseq.size(), Cov()); covT.assign(rawseq.size(), Cov());
   }
   void indexMers() {                                                                 // Ref.cc:40-64
@@ -301,6 +336,31 @@ struct RefInfo {
     auto it = t->find(m);
     if (it != t->end()) { if (strand == LANCET_FWD) it->second.fwd = (uint16_t)cov; else if (strand == LANCET_REV) it->second.rev = (uint16_t)cov; }
   }
+  void addBX(uint32_t bx, const std::string &m, int sample) {                         // Ref.cc:75-93
+    indexMers();
+    auto *t = sample == LANCET_TMR ? &merT : (sample == LANCET_NML ? &merN : nullptr);
+    if (!t) return;
+    if (t->find(m) != t->end()) (sample == LANCET_TMR ? bxT : bxN)[m].insert(bx);
+  }
+  std::vector<uint32_t> getBXsetAt(int start, int end, const std::string &rseq, int sample) const {   // Ref.cc:96-125
+    std::set<uint32_t> bs;
+    const auto &map = sample == LANCET_TMR ? bxT : bxN;
+    CMer c;
+    for (int i = start; i <= end; ++i) {
+      if (i < 0 || (size_t)i > rseq.size()) continue;     // (the reference would throw here)
+      c.set(rseq.substr(i, K));
+      auto it = map.find(c.mer);
+      if (it != map.end()) bs.insert(it->second.begin(), it->second.end());
+    }
+    return std::vector<uint32_t>(bs.begin(), bs.end());
+  }
+  void updateHPCoverage(const std::string &m, int h0, int h1, int h2, int sample) {   // Ref.cc:152-170
+    indexMers();
+    auto *t = sample == LANCET_TMR ? &merT : (sample == LANCET_NML ? &merN : nullptr);
+    if (!t) return;
+    auto it = t->find(m);
+    if (it != t->end()) { it->second.hp0 = (uint16_t)h0; it->second.hp1 = (uint16_t)h1; it->second.hp2 = (uint16_t)h2; }
+  }
   void computeCoverage(int sample) {                                                 // Ref.cc:173-250
     auto *t = sample == LANCET_TMR ? &merT : &merN;
     auto *cv = sample == LANCET_TMR ? &covT : &covN;
@@ -309,11 +369,12 @@ struct RefInfo {
       c.set(rawseq.substr(i, K));
       auto it = t->find(c.mer);
       if (it != t->end()) {
-        if (i == 0) { for (int j = 0; j < K; ++j) { cv->at(j).fwd = it->second.fwd; cv->at(j).rev = it->second.rev; } }
-        else { cv->at(i + K - 1).fwd = it->second.fwd; cv->at(i + K - 1).rev = it->second.rev; }
+        const Cov &m = it->second;
+        if (i == 0) { for (int j = 0; j < K; ++j) { Cov &x = cv->at(j); x.fwd = m.fwd; x.rev = m.rev; x.hp0 = m.hp0; x.hp1 = m.hp1; x.hp2 = m.hp2; } }
+        else { Cov &x = cv->at(i + K - 1); x.fwd = m.fwd; x.rev = m.rev; x.hp0 = m.hp0; x.hp1 = m.hp1; x.hp2 = m.hp2; }
       } else {
-        if (i == 0) { for (int j = 0; j < K; ++j) { cv->at(j).fwd = 0; cv->at(j).rev = 0; } }
-        cv->at(i + K - 1).fwd = 0; cv->at(i + K - 1).rev = 0;
+        if (i == 0) { for (int j = 0; j < K; ++j) { Cov &x = cv->at(j); x.fwd = 0; x.rev = 0; x.hp0 = 0; x.hp1 = 0; x.hp2 = 0; } }
+        { Cov &x = cv->at(i + K - 1); x.fwd = 0; x.rev = 0; x.hp0 = 0; x.hp1 = 0; x.hp2 = 0; }
       }
     }
   }
@@ -328,6 +389,7 @@ struct RefInfo {
 struct ReadInfo {                                                                    // reference src/ReadInfo.hh:44-67
   int label; std::string seq, qv; char code; unsigned short strand, mate_order; uint32_t name;
   unsigned short trm5 = 0, trm3 = 0; bool isjunk = false;
+  uint32_t bx = NO_BX; int hp = 0;                                                   // ReadInfo_t::BX ("null"), HP
 };
 
 // ---- Transcript_t, reference src/Transcript.hh:33-315 -----------------------------------------------------
@@ -355,12 +417,14 @@ struct Transcript {
       sum.f += d[i].f; if (d[i].f != 0) { sum0.f += d[i].f; ++n0.f; } \
       if (d[i].f < mn.f) mn.f = d[i].f; if (d[i].f < mn0.f && d[i].f != 0) mn0.f = d[i].f;
       LANCET_ACC(fwd) LANCET_ACC(rev) LANCET_ACC(minqv_fwd) LANCET_ACC(minqv_rev)
+      LANCET_ACC(hp0) LANCET_ACC(hp1) LANCET_ACC(hp2) LANCET_ACC(hp0_minqv) LANCET_ACC(hp1_minqv) LANCET_ACC(hp2_minqv)
 #undef LANCET_ACC
     }
 #define LANCET_MEAN(f) \
     if (n > 0) mean.f = (uint16_t)((float)sum.f / (float)n); else mean.f = 0; \
     if (n0.f > 0) mean0.f = (uint16_t)std::ceil((float)sum0.f / (float)n0.f); else mean0.f = 0;
     LANCET_MEAN(fwd) LANCET_MEAN(rev) LANCET_MEAN(minqv_fwd) LANCET_MEAN(minqv_rev)
+    LANCET_MEAN(hp0) LANCET_MEAN(hp1) LANCET_MEAN(hp2) LANCET_MEAN(hp0_minqv) LANCET_MEAN(hp1_minqv) LANCET_MEAN(hp2_minqv)
 #undef LANCET_MEAN
   }
   void updateStats() {                                                               // :107-120
@@ -475,6 +539,8 @@ void global_align_aff(const std::string &S, const std::string &T, std::string &S
 struct OutVariant {
   int window, seq, chr_id, pos; char code, pbr, pba; uint16_t kmer; uint16_t cov[8];
   std::string ref, alt, str;
+  uint16_t hp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // HPRN HPRT HPAN HPAT, each {hp1, hp2, hp0} (Graph.cc:1166-1169)
+  std::vector<uint32_t> bx[4];                                // bxset_ref_N, bxset_ref_T, bxset_alt_N, bxset_alt_T
 };
 
 // ---- Graph_t, reference src/Graph.hh / src/Graph.cc ------------------------------------------------------
@@ -493,6 +559,7 @@ struct Graph {
   std::vector<OutVariant> *out = nullptr;
   int cur_window = 0, cur_chr = 0, emit_seq = 0;
   uint64_t n_kmers = 0; uint32_t max_nodes = 0; int n_builds = 0;
+  std::unordered_map<std::string, std::set<uint32_t>> bxT, bxN;                       // Graph_t::bx_table_tmr / _nml
 
   void setK(int k) { K = k; MAX_LINK_LEN = (int)floor((double)K / 2.0); }              // Graph.hh:143
   void clear(bool flag) {                                                            // Graph.cc:29-60
@@ -501,8 +568,25 @@ struct Graph {
     for (auto &kv : nodes) delete kv.second;
     nodes.clear();
     MerTable().swap(nodes);
+    bxT.clear(); bxN.clear();                                                        // Graph.cc:48-49
     source = nullptr; sink = nullptr;
     if (ref && flag) ref = nullptr;   // the RefInfo itself is owned by the caller here
+  }
+  void addBX(uint32_t bx, const std::string &mer, int sample) {                       // Graph.cc:65-79
+    if (sample == LANCET_TMR) bxT[mer].insert(bx);
+    if (sample == LANCET_NML) bxN[mer].insert(bx);
+  }
+  std::vector<uint32_t> getBXsetAt(int start, int end, const std::string &seq, int sample) const {   // Graph.cc:83-114
+    std::set<uint32_t> bs;
+    const auto &map = sample == LANCET_TMR ? bxT : bxN;
+    CMer c;
+    for (int i = start; i <= end; ++i) {
+      if (i < 0 || (size_t)i > seq.size()) continue;      // (the reference would throw here)
+      c.set(seq.substr(i, K));
+      auto it = map.find(c.mer);
+      if (it != map.end()) bs.insert(it->second.begin(), it->second.end());
+    }
+    return std::vector<uint32_t>(bs.begin(), bs.end());
   }
   Node *getNode(const std::string &id) { auto it = nodes.find(id); return it == nodes.end() ? nullptr : it->second; }
 
@@ -555,21 +639,35 @@ struct Graph {
       }
       unode->addMateName(reads[readid].name, reads[readid].mate_order);
       vnode->addMateName(reads[readid].name, reads[readid].mate_order);
+      const bool LR = P->lr_mode != 0;
+      if (LR) {                                                                        // Graph.cc:239-263 (also for the reference read: BX "null", label REF -> no effect)
+        const uint32_t bx = reads[readid].bx; const int hp = reads[readid].hp;
+        if (offset == 0) {
+          if (bx != NO_BX) { addBX(bx, uc.mer, sample); ref->addBX(bx, uc.mer, sample); }
+          if (!unode->hasBX(bx, sample)) { unode->addBX(bx, strand, sample); unode->addHP(hp, sample); }
+        }
+        if (bx != NO_BX) { addBX(bx, vc.mer, sample); ref->addBX(bx, vc.mer, sample); }
+        if (!vnode->hasBX(bx, sample)) { vnode->addBX(bx, strand, sample); vnode->addHP(hp, sample); }
+      }
+      auto credit = [&](Node *n, const std::string &mer, const std::string &q) {       // Graph.cc:274-289 / :303-317
+        n->incCov(strand, sample);
+        if (LR) {
+          n->updateCovDistr(n->BXcnt(strand, sample), q, strand, sample);
+          n->updateHPCovDistr(n->HPcnt(0, sample), n->HPcnt(1, sample), n->HPcnt(2, sample), q, sample);
+          ref->updateCoverage(mer, n->BXcnt(strand, sample), strand, sample);
+          ref->updateHPCoverage(mer, n->HPcnt(0, sample), n->HPcnt(1, sample), n->HPcnt(2, sample), sample);
+        } else {
+          n->updateCovDistr((int)n->getCov(strand, sample), q, strand, sample);
+          ref->updateCoverage(mer, (int)n->getCov(strand, sample), strand, sample);
+        }
+      };
       if (!isRef) {
         if (offset == 0) {
           bool ovl = unode->hasOverlappingMate(reads[readid].name, reads[readid].mate_order);
-          if (!ovl) {
-            unode->incCov(strand, sample);
-            unode->updateCovDistr((int)unode->getCov(strand, sample), uc_qv, strand, sample);
-            ref->updateCoverage(uc.mer, (int)unode->getCov(strand, sample), strand, sample);
-          }
+          if (!ovl) credit(unode, uc.mer, uc_qv);
         }
         bool ovl = vnode->hasOverlappingMate(reads[readid].name, reads[readid].mate_order);
-        if (!ovl) {
-          vnode->incCov(strand, sample);
-          vnode->updateCovDistr((int)vnode->getCov(strand, sample), vc_qv, strand, sample);
-          ref->updateCoverage(vc.mer, (int)vnode->getCov(strand, sample), strand, sample);
-        }
+        if (!ovl) credit(vnode, vc.mer, vc_qv);
       }
       Edgedir fdir = FF, rdir = FF;
       if (uc.ori == F && vc.ori == F) { fdir = FF; rdir = RR; }
@@ -1037,9 +1135,22 @@ struct Graph {
         RCNF = t.mean_ref_N.fwd; RCNR = t.mean_ref_N.rev; RCTF = t.mean_ref_T.fwd; RCTR = t.mean_ref_T.rev;
         ACNF = 0; ACNR = 0;
       }
+      // haplotype counts, Graph.cc:1091-1128
+      const bool x = t.code == 'x';
+      unsigned short HP0RN = t.min_ref_N.hp0, HP1RN = t.min_ref_N.hp1, HP2RN = t.min_ref_N.hp2;
+      unsigned short HP0RT = t.min_ref_T.hp0, HP1RT = t.min_ref_T.hp1, HP2RT = t.min_ref_T.hp2;
+      unsigned short HP0AN = x ? t.min_alt_N.hp0_minqv : t.min_alt_N.hp0, HP1AN = x ? t.min_alt_N.hp1_minqv : t.min_alt_N.hp1, HP2AN = x ? t.min_alt_N.hp2_minqv : t.min_alt_N.hp2;
+      unsigned short HP0AT = x ? t.min_alt_T.hp0_minqv : t.min_alt_T.hp0, HP1AT = x ? t.min_alt_T.hp1_minqv : t.min_alt_T.hp1, HP2AT = x ? t.min_alt_T.hp2_minqv : t.min_alt_T.hp2;
+      if (t.isSomatic) {
+        HP0RT = t.mean_ref_T.hp0; HP1RT = t.mean_ref_T.hp1; HP2RT = t.mean_ref_T.hp2;
+        HP0RN = t.mean_ref_N.hp0; HP1RN = t.mean_ref_N.hp1; HP2RN = t.mean_ref_N.hp2;
+        HP0AN = 0; HP1AN = 0; HP2AN = 0;
+      }
       if (verbose) {
         *tr << " " << t.pos << ":" << t.ref << "|" << t.qry << "|R:(" << RCNF << "+," << RCNR << "-)n,(" << RCTF << "+," << RCTR
-            << "-)t|A:(" << ACNF << "+," << ACNR << "-)n,(" << ACTF << "+," << ACTR << "-)t|HPref(0,0,0)n,(0,0,0)t|HPalt(0,0,0)n,(0,0,0)t|"
+            << "-)t|A:(" << ACNF << "+," << ACNR << "-)n,(" << ACTF << "+," << ACTR << "-)t|HPref("
+            << HP0RN << "," << HP1RN << "," << HP2RN << ")n,(" << HP0RT << "," << HP1RT << "," << HP2RT << ")t|HPalt("
+            << HP0AN << "," << HP1AN << "," << HP2AN << ")n,(" << HP0AT << "," << HP1AT << "," << HP2AT << ")t|"
             << t.prev_bp_ref << "|" << t.prev_bp_alt;
       }
       if (ACNF > 0 || ACNR > 0 || ACTF > 0 || ACTR > 0) {
@@ -1051,6 +1162,14 @@ struct Graph {
         v.code = t.code; v.pbr = t.prev_bp_ref; v.pba = t.prev_bp_alt; v.kmer = K;
         v.cov[0] = RCNF; v.cov[1] = RCNR; v.cov[2] = RCTF; v.cov[3] = RCTR; v.cov[4] = ACNF; v.cov[5] = ACNR; v.cov[6] = ACTF; v.cov[7] = ACTR;
         v.ref = t.ref; v.alt = t.qry; v.str = STR.str();
+        const uint16_t hp[12] = {HP1RN, HP2RN, HP0RN, HP1RT, HP2RT, HP0RT, HP1AN, HP2AN, HP0AN, HP1AT, HP2AT, HP0AT};
+        memcpy(v.hp, hp, sizeof(hp));
+        if (P->lr_mode) {                                                              // Graph.cc:1177-1182
+          v.bx[0] = ref->getBXsetAt((int)t.ref_pos - 1, (int)t.ref_end_pos - 1, refseq, LANCET_NML);
+          v.bx[1] = ref->getBXsetAt((int)t.ref_pos - 1, (int)t.ref_end_pos - 1, refseq, LANCET_TMR);
+          v.bx[2] = getBXsetAt((int)t.start_pos - 2, (int)t.end_pos - 1, pathseq, LANCET_NML);
+          v.bx[3] = getBXsetAt((int)t.start_pos - 2, (int)t.end_pos - 1, pathseq, LANCET_TMR);
+        }
         out->push_back(v);
       }
     }
@@ -1150,6 +1269,8 @@ int processGraph(Graph &g, RefInfo *refinfo, int graphCnt, lancet_window_stats *
 
 struct OracleResult {
   std::vector<lancet_variant> variants;
+  std::vector<lancet_variant_lr> lr;
+  std::vector<uint32_t> bx_blob;
   std::string blob;
   std::vector<lancet_window_stats> stats;
   std::string trace;
@@ -1191,6 +1312,7 @@ void *lancet_oracle_run(const lancet_params *P, const lancet_window_batch *b, co
       ri.qv.assign(b->qual + b->seq_off[r], b->qual + b->seq_off[r + 1]);
       ri.code = b->mapped[r] ? 'M' : 'B';
       ri.strand = b->strand[r]; ri.mate_order = b->mate[r]; ri.name = b->name_rank[r];
+      if (P->lr_mode && b->bx_rank && b->hp) { ri.bx = b->bx_rank[r]; ri.hp = b->hp[r]; }
       g.reads.push_back(ri);
       g.trim((int)g.reads.size() - 1);
     }
@@ -1209,6 +1331,10 @@ void *lancet_oracle_run(const lancet_params *P, const lancet_window_batch *b, co
     lv.alt_off = res->blob.size(); lv.alt_len = v.alt.size(); res->blob += v.alt;
     lv.str_off = res->blob.size(); lv.str_len = v.str.size(); res->blob += v.str;
     res->variants.push_back(lv);
+    lancet_variant_lr l; memset(&l, 0, sizeof(l));
+    memcpy(l.hp, v.hp, sizeof(l.hp));
+    for (int q = 0; q < 4; ++q) { l.bx_off[q] = res->bx_blob.size(); l.bx_len[q] = v.bx[q].size(); res->bx_blob.insert(res->bx_blob.end(), v.bx[q].begin(), v.bx[q].end()); }
+    res->lr.push_back(l);
   }
   res->trace = tr.str();
   return res;
@@ -1216,6 +1342,9 @@ void *lancet_oracle_run(const lancet_params *P, const lancet_window_batch *b, co
 uint32_t lancet_oracle_n_variants(void *h) { return ((OracleResult *)h)->variants.size(); }
 const lancet_variant *lancet_oracle_variants(void *h) { return ((OracleResult *)h)->variants.data(); }
 const char *lancet_oracle_blob(void *h) { return ((OracleResult *)h)->blob.data(); }
+const lancet_variant_lr *lancet_oracle_variants_lr(void *h) { return ((OracleResult *)h)->lr.data(); }
+const uint32_t *lancet_oracle_bx_blob(void *h) { return ((OracleResult *)h)->bx_blob.data(); }
+uint32_t lancet_oracle_bx_blob_len(void *h) { return ((OracleResult *)h)->bx_blob.size(); }
 uint32_t lancet_oracle_blob_len(void *h) { return ((OracleResult *)h)->blob.size(); }
 const lancet_window_stats *lancet_oracle_stats(void *h) { return ((OracleResult *)h)->stats.data(); }
 const char *lancet_oracle_trace(void *h) { return ((OracleResult *)h)->trace.c_str(); }

@@ -37,6 +37,10 @@ def lib():
         L.lancet_oracle_blob.argtypes = [C.c_void_p]
         L.lancet_oracle_blob_len.restype = C.c_uint32
         L.lancet_oracle_blob_len.argtypes = [C.c_void_p]
+        L.lancet_oracle_variants_lr.restype = C.POINTER(abi.LancetVariantLR)
+        L.lancet_oracle_variants_lr.argtypes = [C.c_void_p]
+        L.lancet_oracle_bx_blob.restype = C.POINTER(C.c_uint32)
+        L.lancet_oracle_bx_blob.argtypes = [C.c_void_p]
         L.lancet_oracle_stats.restype = C.POINTER(abi.LancetWindowStats)
         L.lancet_oracle_stats.argtypes = [C.c_void_p]
         L.lancet_oracle_trace.restype = C.c_char_p
@@ -68,6 +72,8 @@ def run(batch, params=None, verbose: bool = False):
         n = L.lancet_oracle_n_variants(h)
         blob = C.string_at(L.lancet_oracle_blob(h), L.lancet_oracle_blob_len(h)) if L.lancet_oracle_blob_len(h) else b""
         variants = abi.variants_to_py(L.lancet_oracle_variants(h), n, blob)
+        if p.lr_mode:
+            abi.variants_lr_to_py(variants, L.lancet_oracle_variants_lr(h), L.lancet_oracle_bx_blob(h))
         sp = L.lancet_oracle_stats(h)
         stats = [dict(status=sp[i].status, final_k=sp[i].final_k, n_builds=sp[i].n_builds, n_variants=sp[i].n_variants,
                       n_kmers=sp[i].n_kmers, max_nodes=sp[i].max_nodes) for i in range(batch.n_windows)]

@@ -88,8 +88,13 @@ def kt_fisher_exact(n11, n12, n21, n22) -> float:
 
 # ---------------- Variant_t ---------------------------------------------------------------------------------
 class Variant:
-    def __init__(self, chrom: str, rec: dict):
-        """rec: one lancet_variant as dict (abi.variants_to_py)."""
+    def __init__(self, chrom: str, rec: dict, lr: bool = False, bx_names=None):
+        """rec: one lancet_variant as dict (abi.variants_to_py [+ variants_lr_to_py]).  lr = Variant_t::LR_MODE."""
+        self.lr = lr
+        self.hp = tuple(rec.get("hp", (0,) * 12))             # HPRN HPRT HPAN HPAT, each {hp1, hp2, hp0}
+        self.bx = ["", "", "", ""]                              # bxset_ref_N, bxset_ref_T, bxset_alt_N, bxset_alt_T
+        if lr:
+            self.bx = [";".join(bx_names[i] for i in ids) or "." for ids in rec["bx"]]
         self.kmer = rec["kmer"]
         self.str = rec["str"]
         self.chr = chrom
@@ -140,6 +145,13 @@ class Variant:
         return -10.0 * _libm.log10(prob) if prob > 0 else float("inf")
 
     @staticmethod
+    def hp_score(hpr1, hpr2, hpa1, hpa2) -> float:            # Variant_t::compute_HP_score, src/Variant.cc:281-298
+        prob = kt_fisher_exact(hpr1, hpr2, hpa1, hpa2)
+        if prob == 1:
+            return 0.0
+        return -10.0 * _libm.log10(prob) if prob > 0 else float("inf")
+
+    @staticmethod
     def genotype(R, A) -> str:
         if R > 0 and A > 0:
             return "0/1"
@@ -167,6 +179,12 @@ class Variant:
         info = status + ";FETS=" + _g(fet)
         info += {"I": ";TYPE=ins", "D": ";TYPE=del", "S": ";TYPE=snv", "C": ";TYPE=complex"}.get(self.type, "")
         info += f";LEN={self.len};KMERSIZE={self.kmer};SB=" + _g(sb)
+        hprn, hprt, hpan, hpat = self.hp[0:3], self.hp[3:6], self.hp[6:9], self.hp[9:12]
+        if self.lr:                                               # src/Variant.cc:56-60, 78-80
+            hpsn = self.hp_score(hprn[0], hprn[1], hpan[0], hpan[1])
+            hpst = self.hp_score(hprt[0], hprt[1], hpat[0], hpat[1])
+            hps = self.hp_score(hprn[0] + hpan[0], hprn[1] + hpan[1], hprt[0] + hpat[0], hprt[1] + hpat[1])
+            info += ";HPS=" + _g(hps) + ";HPSN=" + _g(hpsn) + ";HPST=" + _g(hpst)
         if self.str:
             info += ";MS=" + self.str
         tumor_cov = tr_t + ta_t
@@ -197,16 +215,24 @@ class Variant:
             F.append("HighAltCntNormal")
         if self.act_f < fs["minStrandBias"] or self.act_r < fs["minStrandBias"]:
             F.append("StrandBias")
+        if self.lr and flag == "T" and hpat[0] > 0 and hpat[1] > 0:   # src/Variant.cc:172-177
+            F.append("MultiHP")
         flt = ";".join(F) if F else "PASS"
         normal = f"{self.genotype(tr_n, ta_n)}:{tr_n},{ta_n}:{self.rcn_f},{self.rcn_r}:{self.acn_f},{self.acn_r}:{tr_n + ta_n}"
         tumor = f"{self.genotype(tr_t, ta_t)}:{tr_t},{ta_t}:{self.rct_f},{self.rct_r}:{self.act_f},{self.act_r}:{tr_t + ta_t}"
-        return "\t".join([self.chr, str(self.pos), ".", self.ref, self.alt, _g(fet), flt, info, "GT:AD:SR:SA:DP",
-                          normal, tumor]) + "\n"
+        fmt = "GT:AD:SR:SA:DP"
+        if self.lr:                                               # src/Variant.cc:204-215
+            fmt += ":HPR:HPA:BX"
+            c = lambda t: ",".join(str(x) for x in t)
+            normal += ":" + c(hprn) + ":" + c(hpan) + ":" + self.bx[0] + "," + self.bx[2]
+            tumor += ":" + c(hprt) + ":" + c(hpat) + ":" + self.bx[1] + "," + self.bx[3]
+        return "\t".join([self.chr, str(self.pos), ".", self.ref, self.alt, _g(fet), flt, info, fmt, normal, tumor]) + "\n"
 
 
 # ---------------- VariantDB_t -------------------------------------------------------------------------------
 class VariantDB:
-    def __init__(self, filters: dict | None = None):
+    def __init__(self, filters: dict | None = None, lr: bool = False):
+        self.lr = lr
         self.db: Dict[str, Variant] = {}
         self.filters = dict(DEFAULT_FILTERS, **(filters or {}))
 
@@ -218,6 +244,9 @@ class VariantDB:
                 old.kmer = v.kmer
                 (old.rcn_f, old.rcn_r, old.rct_f, old.rct_r, old.acn_f, old.acn_r, old.act_f, old.act_r) = (
                     v.rcn_f, v.rcn_r, v.rct_f, v.rct_r, v.acn_f, v.acn_r, v.act_f, v.act_r)
+                old.hp = v.hp
+                if self.lr:
+                    old.bx = list(v.bx)
         else:
             self.db[key] = v
 
@@ -235,6 +264,10 @@ class VariantDB:
              "##INFO=<ID=MS,Number=1,Type=String,Description=\"Microsatellite mutation (format: #LEN#MOTIF)\">\n"
              "##INFO=<ID=LEN,Number=1,Type=Integer,Description=\"Variant size in base pairs\">\n"
              "##INFO=<ID=TYPE,Number=1,Type=String,Description=\"Variant type (snv, del, ins, complex)\">\n")
+        if self.lr:
+            h += ("##INFO=<ID=HPS,Number=1,Type=Float,Description=\"Haplotype score for the T/N pair: phred-scaled p-value of the Fisher's exact test of the total counts of the two haplotype in the tumor-normal pair\">\n"
+                  "##INFO=<ID=HPSN,Number=1,Type=Float,Description=\"Normal haplotype score: phred-scaled p-value of the Fisher's exact test for ref/alt haplotype counts in the normal\">\n"
+                  "##INFO=<ID=HPST,Number=1,Type=Float,Description=\"Tumor haplotype score: phred-scaled p-value of the Fisher's exact test for ref/alt haplotype counts in the tumor\">\n")
         h += (f"##FILTER=<ID=LowCovNormal,Description=\"Low coverage in the normal (<{fs['minCovNormal']})\">\n"
               f"##FILTER=<ID=HighCovNormal,Description=\"High coverage in the normal (>{fs['maxCovNormal']})\">\n"
               f"##FILTER=<ID=LowCovTumor,Description=\"Low coverage in the tumor (<{fs['minCovTumor']})\">\n"
@@ -247,11 +280,17 @@ class VariantDB:
               f"##FILTER=<ID=LowFisherSTR,Description=\"Low Fisher's exact test score for tumor-normal STR allele counts (<{_g(fs['minPhredFisherSTR'])})\">\n"
               f"##FILTER=<ID=StrandBias,Description=\"Strand bias: # of non-reference reads in either forward or reverse strand below threshold (<{fs['minStrandBias']})\">\n"
               "##FILTER=<ID=STR,Description=\"Microsatellite mutation\">\n")
+        if self.lr:
+            h += "##FILTER=<ID=MultiHP,Description=\"Supporting reads from multiple haplotypes based on linked-reads analysis\">\n"
         h += ("##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n"
               "##FORMAT=<ID=DP,Number=1,Type=Integer,Description=\"Depth\">\n"
               "##FORMAT=<ID=AD,Number=.,Type=Integer,Description=\"Allele depth: # of supporting ref,alt reads at the site\">\n"
               "##FORMAT=<ID=SR,Number=.,Type=Integer,Description=\"Strand counts for ref: # of supporting forward,reverse reads for reference allele\">\n"
               "##FORMAT=<ID=SA,Number=.,Type=Integer,Description=\"Strand counts for alt: # of supporting forward,reverse reads for alterantive allele\">\n")
+        if self.lr:
+            h += ("##FORMAT=<ID=BX,Number=.,Type=String,Description=\"Barcodes supporting ref and alt alleles\">\n"
+                  "##FORMAT=<ID=HPR,Number=.,Type=Integer,Description=\"Haplotype counts for ref: # of reads supporting reference allele in haplotype 1, 2, and 0 respectively (0 = unassigned)\">\n"
+                  "##FORMAT=<ID=HPA,Number=.,Type=Integer,Description=\"Haplotype counts for alt: # of reads supporting alternative allele in haplotype 1, 2, and 0 respectively (0 = unassigned)\">\n")
         h += f"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t{sample_n}\t{sample_t}\n"
         return h
 

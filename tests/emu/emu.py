@@ -42,6 +42,10 @@ def run(batch, params=None, evt_cap: int = 0):
         bl = L.lancet_emu_blob_len(h)
         blob = C.string_at(L.lancet_emu_blob(h), bl) if bl else b""
         variants = abi.variants_to_py(L.lancet_emu_variants(h), n, blob)
+        if p.lr_mode:
+            L.lancet_emu_variants_lr.restype = C.POINTER(abi.LancetVariantLR); L.lancet_emu_variants_lr.argtypes = [C.c_void_p]
+            L.lancet_emu_bx_blob.restype = C.POINTER(C.c_uint32); L.lancet_emu_bx_blob.argtypes = [C.c_void_p]
+            abi.variants_lr_to_py(variants, L.lancet_emu_variants_lr(h), L.lancet_emu_bx_blob(h))
         sp = L.lancet_emu_stats(h)
         stats = [dict(status=sp[i].status, final_k=sp[i].final_k, n_builds=sp[i].n_builds, n_variants=sp[i].n_variants,
                       n_kmers=sp[i].n_kmers, max_nodes=sp[i].max_nodes) for i in range(batch.n_windows)]

@@ -13,6 +13,8 @@
 
 struct EmuResult {
   std::vector<lancet_variant> variants;
+  std::vector<lancet_variant_lr> lr;
+  std::vector<uint32_t> bx_blob;
   std::vector<char> blob;
   std::vector<lancet_window_stats> stats;
   std::vector<uint32_t> evt_len, evt;
@@ -37,6 +39,7 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   B.n_windows = b->n_windows; B.chr_id = b->chr_id; B.ref_start = b->ref_start; B.ref_off = b->ref_off; B.ref_codes = ref_codes.data();
   B.read_begin = b->read_begin; B.rinfo = rinfo.data(); B.name_rank = b->name_rank; B.base_woff = bw.data(); B.good_woff = gw.data();
   B.bases = bases.data(); B.good = good.data();
+  B.bx_rank = P->lr_mode ? b->bx_rank : nullptr; B.hp = P->lr_mode ? b->hp : nullptr;
   // ---- one work slot
   size_t wbytes = lc_work_carve(nullptr, nullptr, C);
   std::vector<char> wmem(wbytes + 256);
@@ -45,8 +48,10 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   auto *res = new EmuResult();
   res->variants.resize(C.var_cap); res->blob.resize(C.blob_cap); res->stats.resize(b->n_windows);
   res->evt_len.assign(b->n_windows, 0); res->evt.assign((size_t)b->n_windows * (evt_cap ? evt_cap : 1), 0); res->evt_cap = evt_cap;
-  uint32_t nv = 0, nb = 0, qh = 0;
+  uint32_t nv = 0, nb = 0, qh = 0, nx = 0;
+  res->lr.resize(C.var_cap); res->bx_blob.resize(C.bx_cap + 1);
   DevOut O; O.variants = res->variants.data(); O.blob = res->blob.data(); O.n_variants = &nv; O.n_blob = &nb; O.stats = res->stats.data();
+  O.variants_lr = res->lr.data(); O.bx_blob = res->bx_blob.data(); O.n_bx = &nx;
   O.queue_head = &qh; O.phase = nullptr; O.win_list = nullptr; O.n_list = 0; O.evt_len = res->evt_len.data(); O.evt_out = res->evt.data();
   static thread_local WinShared S;
   memset(&S, 0xCD, sizeof(S));
@@ -57,6 +62,8 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
 extern "C" uint32_t lancet_emu_n_variants(void *h) { return ((EmuResult *)h)->n_variants; }
 extern "C" const lancet_variant *lancet_emu_variants(void *h) { return ((EmuResult *)h)->variants.data(); }
 extern "C" const char *lancet_emu_blob(void *h) { return ((EmuResult *)h)->blob.data(); }
+extern "C" const lancet_variant_lr *lancet_emu_variants_lr(void *h) { return ((EmuResult *)h)->lr.data(); }
+extern "C" const uint32_t *lancet_emu_bx_blob(void *h) { return ((EmuResult *)h)->bx_blob.data(); }
 extern "C" uint32_t lancet_emu_blob_len(void *h) { return ((EmuResult *)h)->n_blob; }
 extern "C" const lancet_window_stats *lancet_emu_stats(void *h) { return ((EmuResult *)h)->stats.data(); }
 extern "C" const uint32_t *lancet_emu_evt_len(void *h) { return ((EmuResult *)h)->evt_len.data(); }

@@ -13,6 +13,7 @@ from lancet_amd.synth import SamRead
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = sorted(f[:-5] for f in os.listdir(GOLDEN) if f.endswith(".json"))
+LR_CASES = [c for c in CASES if "--linked-reads" in json.load(open(os.path.join(GOLDEN, c + ".json")))["flags"]]
 
 _DIGEST = re.compile(
     r"^(== Processing|Repeat in reference|Near-perfect repeat|reads: |  \d+: nodes:| nodes: |ref trim5|"
@@ -36,16 +37,27 @@ def load_case(name: str):
         reads[rg] = [SamRead(a["qname"][i], a["flag"][i], rname, a["pos"][i], a["mapq"][i], a["cigar"][i], a["seq"][i],
                              a["qual"][i], {"AS": a["as"][i], "XS": a["xs"][i], "MD": a["md"][i]})
                      for i in range(len(a["qname"]))]
+        if f"{rg}_bx" in z.files:
+            bx, hp = z[f"{rg}_bx"].tolist(), z[f"{rg}_hp"].tolist()
+            for i, r in enumerate(reads[rg]):
+                if bx[i] != "":
+                    r.tags["BX"] = bx[i]
+                if hp[i] >= 0:
+                    r.tags["HP"] = hp[i]
     return meta, ref, rname, reads
 
 
 def case_params(meta):
     """reference CLI flags of the case -> (padding, min_k, max_k)."""
-    flags = meta["flags"]
+    flags = [f for f in meta["flags"] if f != "--linked-reads"]
     opt = {"--padding": 250, "--min-k": 11, "--max-k": 101}
     for i in range(0, len(flags), 2):
         opt[flags[i]] = int(flags[i + 1])
     return opt["--padding"], opt["--min-k"], opt["--max-k"]
+
+
+def case_lr(meta) -> bool:
+    return "--linked-reads" in meta["flags"]
 
 
 @functools.lru_cache(maxsize=None)
@@ -53,7 +65,7 @@ def case_batch(name: str):
     meta, ref, rname, reads = load_case(name)
     padding, min_k, max_k = case_params(meta)
     windows = frontend.tile_region(ref, rname, meta["region"], padding=padding)
-    batch, kept = frontend.batch_from_sam(windows, reads["tumor"], reads["normal"], max_k=max_k)
+    batch, kept = frontend.batch_from_sam(windows, reads["tumor"], reads["normal"], max_k=max_k, linked=case_lr(meta))
     return meta, batch, kept, (min_k, max_k)
 
 

@@ -46,19 +46,22 @@ def test_no_cpu_fallback(lib):
     with pytest.raises(engine.EngineError, match="no HIP device"):
         engine.Engine()
     h = ctypes.c_void_p()
+    p = abi.default_params(max_k=200)
+    assert lib.lancet_engine_create(ctypes.byref(p), 0, ctypes.byref(h)) == -4      # LANCET_E_UNSUPPORTED (k > 127)
     p = abi.default_params(lr_mode=1)
-    assert lib.lancet_engine_create(ctypes.byref(p), 0, ctypes.byref(h)) == -4      # LANCET_E_UNSUPPORTED
+    assert lib.lancet_engine_create(ctypes.byref(p), 0, ctypes.byref(h)) == -2      # LANCET_E_NO_DEVICE: no CPU path in any mode
 
 
 @pytest.mark.parametrize("case", gu.CASES)
 def test_host_variantdb_and_vcf_writer_reproduce_reference_vcf(case, lib):
     meta, batch, kept, (min_k, max_k) = gu.case_batch(case)
-    records, _, _ = oracle.run(batch, abi.default_params(min_k=min_k, max_k=max_k))
+    lr = gu.case_lr(meta)
+    records, _, _ = oracle.run(batch, abi.default_params(min_k=min_k, max_k=max_k, lr_mode=int(lr)))
     id2chr = {}
     for c, i in zip(batch.chrom, batch.chr_id):
         id2chr[int(i)] = c
     db = engine.VariantDB()
-    db.add_records(records, [id2chr[i] for i in range(len(id2chr))])
+    db.add_records(records, [id2chr[i] for i in range(len(id2chr))], bx_names=batch.bx_names if lr else None)
     assert db.vcf() == gu.golden_vcf(case)
     full = db.vcf(cmdline="lancet --x", reference="ref.fa", date_line="Sun Sep 27 05:27:00 2026\n")
     assert "##fileDate=Sun Sep 27 05:27:00 2026\n##source=lancet 1.1.0" in full and "##cmdline=lancet --x\n##reference=ref.fa\n" in full

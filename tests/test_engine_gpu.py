@@ -21,7 +21,8 @@ def _names(batch):
 @pytest.mark.parametrize("case", gu.CASES)
 def test_engine_matches_oracle_and_reference(case):
     meta, batch, kept, (min_k, max_k) = gu.case_batch(case)
-    p = abi.default_params(min_k=min_k, max_k=max_k)
+    lr = gu.case_lr(meta)                                                     # --linked-reads goldens
+    p = abi.default_params(min_k=min_k, max_k=max_k, lr_mode=int(lr))
     eng = engine.Engine(p, device=0, trace_words=1 << 17)
     variants, stats = eng.process(batch)
     ov, ostats, _ = oracle.run(batch, p)
@@ -32,7 +33,11 @@ def test_engine_matches_oracle_and_reference(case):
     assert gu.digest_trace(eng.trace_text()) == gu.golden_trace(case)          # every stage == reference `-v`
     db = engine.VariantDB()
     vp, n, blob, _ = eng.raw_results()
-    db.add_raw(vp, n, blob + b"\0", _names(batch))
+    if lr:
+        lp, bp, _ = eng.raw_results_lr()
+        db.add_raw_lr(vp, lp, n, blob + b"\0", bp, batch.bx_names, _names(batch))
+    else:
+        db.add_raw(vp, n, blob + b"\0", _names(batch))
     assert db.vcf() == gu.golden_vcf(case)                                      # byte-identical VCF
     eng.close()
 

@@ -51,6 +51,13 @@ CASES = {
     # N in the window reference: single N, short runs, a run longer than the small k values
     "nref": (dict(ref_len=6000, cov_t=30, cov_n=30, ref_seed=12, tumor_seed=112, normal_seed=212,
                   n_runs=((1510, 1), (1933, 3), (2405, 17), (2950, 2), (3391, 1))), "chr22:1200-3700", []),
+    # --linked-reads: barcode sets per k-mer, haplotype counts; short inserts so mates overlap too
+    "lr30": (dict(ref_len=6000, cov_t=30, cov_n=30, ref_seed=31, tumor_seed=131, normal_seed=231, linked=True,
+                  insert_mean=260.0, insert_sd=40.0, somatic_every=800, germline_every=500), "chr22:1200-3600",
+             ["--linked-reads"]),
+    "lr_deep": (dict(ref_len=6000, cov_t=70, cov_n=45, ref_seed=33, tumor_seed=133, normal_seed=233, linked=True,
+                     insert_mean=230.0, insert_sd=45.0, somatic_every=500, germline_every=350, error_rate=0.008,
+                     str_fraction=0.15), "chr22:1000-4200", ["--linked-reads"]),
     "dups": (dict(ref_len=8000, cov_t=40, cov_n=40, ref_seed=5, tumor_seed=15, normal_seed=25, dup_prob=1.0,
                   somatic_every=600, germline_every=500, read_len=100), "chr22:1000-6500", []),
 }
@@ -124,6 +131,9 @@ def make_case(name: str):
         reads[f"{rg}_as"] = np.array([x.tags["AS"] for x in rs], dtype=np.int32)
         reads[f"{rg}_xs"] = np.array([x.tags["XS"] for x in rs], dtype=np.int32)
         reads[f"{rg}_md"] = np.array([x.tags["MD"] for x in rs])
+        if kwargs.get("linked"):
+            reads[f"{rg}_bx"] = np.array([x.tags.get("BX", "") for x in rs])
+            reads[f"{rg}_hp"] = np.array([x.tags.get("HP", -1) for x in rs], dtype=np.int32)
     np.savez_compressed(os.path.join(GOLDEN, f"{name}.reads.npz"), ref=np.array(ref), rname=np.array(rname), **reads)
     with open(os.path.join(GOLDEN, f"{name}.json"), "w") as f:
         json.dump({"synth": kwargs, "region": region, "flags": flags,
