@@ -48,6 +48,7 @@ struct WinShared {
   uint32_t part[LANCET_WG + 1];
   uint32_t mk[LANCET_WG][4], mmeta[LANCET_WG];   // staged quality masks of up to one wave of occurrences
   uint16_t acc[128][10];                         // per k-mer position running counts Tf Tr Nf Nr (+ lr_mode: T hp0-2, N hp0-2 minqv)
+  int mr_src, mr_snk, mr_ambs, mr_ambk;          // mark_ref_scan: first / last qualifying reference offset, ambiguity flags
   int QS, LR;                                    // counters per (survivor, position): 4, or 10 with --linked-reads ; lr_mode
   unsigned long long rs[LC_RS_WORDS];            // repeat_scan: the string at 4 bits per base
   unsigned long long t_last, phase_acc[16];
@@ -1446,6 +1447,35 @@ DEV uint32_t special_new(Ctx &c, bool issource, int comp) {
   W.gr[id].seq_lo = W.gr[id].seq_hi = W.gr[id].seq_clo = W.gr[id].seq_chi = 0; W.gr[id].nkm = 0; W.gr[id].nkmT = 0; W.gr[id].onref = 0;
   return id;
 }
+// The two scans of markRefEnds (reference src/Graph.cc:2060-2110) over all reference offsets, in parallel:
+// mr_src / mr_snk = first / last offset whose node is live, has getTotCov() >= COV_THRESHOLD and is in the component
+// (-1 if none); mr_ambs / mr_ambk = the same node qualifies again further on (the reference then gives up).
+DEV void mark_ref_scan(Ctx &c, int comp) {
+  volatile WinShared &S = *c.S; Work &W = *c.W;
+  const int K = S.K;
+  const uint32_t ro = W.occ_base[S.R - 1];
+  const int nrefk = (S.reflen - K > 0) ? S.reflen - K + 1 : 0;
+  WG_LANE0 { S.mr_src = 0x7FFFFFFF; S.mr_snk = 0; S.mr_ambs = 0; S.mr_ambk = 0; }
+  WG_FOR(off, nrefk) {
+    const uint32_t t = W.occ[ro + off] & 0x3FFFFFFFu;
+    const uint32_t f = W.gr[t].flags;
+    if ((f & NF_DEAD) || !(f & NF_SURV)) continue;
+    if (n_totcov(c, t) >= (float)c.P->cov_threshold && W.gr[t].comp == comp) {
+      dev_atomic_min((uint32_t *)&S.mr_src, (uint32_t)off);
+      dev_atomic_max((uint32_t *)&S.mr_snk, (uint32_t)(off + 1));
+    }
+  }
+  WG_SYNC();
+  const int so = wg_uniform(S.mr_src), ko = wg_uniform(S.mr_snk) - 1;
+  if (so == 0x7FFFFFFF) { WG_LANE0 { S.mr_src = -1; S.mr_snk = -1; } return; }
+  const uint32_t sn = W.occ[ro + so] & 0x3FFFFFFFu, kn = W.occ[ro + ko] & 0x3FFFFFFFu;
+  WG_FOR(off, nrefk) {
+    const uint32_t t = W.occ[ro + off] & 0x3FFFFFFFu;
+    if (off > so && t == sn) S.mr_ambs = 1;
+    if (off < ko && t == kn) S.mr_ambk = 1;
+  }
+  WG_LANE0 { S.mr_snk = ko; }
+}
 DEVNI void mark_ref_ends(Ctx &c, int comp) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   const int K = S.K;
@@ -1453,29 +1483,15 @@ DEVNI void mark_ref_ends(Ctx &c, int comp) {
   S.source = LC_NIL; S.sink = LC_NIL;
   uint32_t ro = W.occ_base[S.R - 1];
   int nrefk = (S.reflen - K > 0) ? S.reflen - K + 1 : 0;
-  uint32_t src = LC_NIL, snk = LC_NIL; uint32_t src_ori = 0, snk_ori = 0; int src_off = -1, snk_off = -1;
-  bool amb = false;
-  for (int off = 0; off < nrefk; ++off) {
-    uint32_t oc = W.occ[ro + off]; uint32_t t = oc & 0x3FFFFFFFu;
-    if ((W.gr[t].flags & NF_DEAD) || !(W.gr[t].flags & NF_SURV)) continue;
-    if (n_totcov(c, t) >= (float)c.P->cov_threshold && W.gr[t].comp == comp) {
-      if (src == LC_NIL) { src = t; src_ori = oc >> 31; src_off = off; }
-      else if (src == t) { src = LC_NIL; amb = true; break; }
-    }
-  }
-  if (amb) { evt(c, EV_AMBIG_SRC); return; }
-  if (src == LC_NIL) { evt(c, EV_NOMATCH_SRC); return; }
-  for (int off = S.reflen - K; off >= 0; --off) {
-    if (off >= nrefk) continue;
-    uint32_t oc = W.occ[ro + off]; uint32_t t = oc & 0x3FFFFFFFu;
-    if ((W.gr[t].flags & NF_DEAD) || !(W.gr[t].flags & NF_SURV)) continue;
-    if (n_totcov(c, t) >= (float)c.P->cov_threshold && W.gr[t].comp == comp) {
-      if (snk == LC_NIL) { snk = t; snk_ori = oc >> 31; snk_off = off; }
-      else if (snk == t) { snk = LC_NIL; amb = true; break; }
-    }
-  }
-  if (amb) { evt(c, EV_AMBIG_SNK); return; }
-  if (snk == LC_NIL) { evt(c, EV_NOMATCH_SNK); return; }
+  (void)nrefk;
+  // the scans over the reference offsets ran in mark_ref_scan (same predicates, same outcome order)
+  if (S.mr_src >= 0 && S.mr_ambs) { evt(c, EV_AMBIG_SRC); return; }
+  if (S.mr_src < 0) { evt(c, EV_NOMATCH_SRC); return; }
+  if (S.mr_ambk) { evt(c, EV_AMBIG_SNK); return; }
+  if (S.mr_snk < 0) { evt(c, EV_NOMATCH_SNK); return; }
+  const int src_off = S.mr_src, snk_off = S.mr_snk;
+  const uint32_t soc = W.occ[ro + src_off], koc = W.occ[ro + snk_off];
+  const uint32_t src = soc & 0x3FFFFFFFu, snk = koc & 0x3FFFFFFFu, src_ori = soc >> 31, snk_ori = koc >> 31;
   int ref_dist = snk_off - src_off + K;
   int t3 = S.reflen - snk_off - K;
   S.seq_t5 = src_off; S.seq_len = ref_dist;                           // ref_m->seq = rawseq.substr(source_offset, ref_dist)
@@ -1513,10 +1529,10 @@ DEVNI void mark_ref_ends(Ctx &c, int comp) {
   order_insert(c, nk);
 }
 
-DEVNI bool has_cycle(Ctx &c) {                                         // reference src/Graph.cc:593-681
+DEVNI bool has_cycle(Ctx &c, bool colored = false) {                                         // reference src/Graph.cc:593-681
   volatile WinShared &S = *c.S; Work &W = *c.W;
   if (S.source == LC_NIL || S.sink == LC_NIL) return false;
-  for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (!(W.gr[n].flags & NF_SPECIAL)) W.gr[n].color = 1; }
+  if (!colored) for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (!(W.gr[n].flags & NF_SPECIAL)) W.gr[n].color = 1; }
   bool ans = false;
   // explicit stack of (node, next edge index, dir)
   uint32_t *st = W.scratch; uint32_t cap = (2 * (c.C->node_cap + c.C->special_cap)) / 3;
@@ -1767,9 +1783,17 @@ DEVNI int align_traceback(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, i
   uint8_t *ra = W.aln, *pa = W.aln + cap;
   int i = n, j = m, L = 0;
   bool forcex = false, forcey = false;
+  unsigned long long pre = 0; int bi = -1, bj = -1, used = 8;
   while (i > 0 || j > 0) {
     if (i < 0 || j < 0 || L >= cap) { OVF(c); return 0; }          // the reference would read out of bounds here
-    uint8_t b = W.tb[(size_t)i * stride + j];
+    // the path mostly runs along a diagonal: fetch the next 8 cells of the current diagonal in one go (independent
+    // loads, one wait) and fall back to a new batch whenever a gap leaves the diagonal
+    if (used >= 8 || i != bi - used || j != bj - used) {
+      bi = i; bj = j; used = 0;
+      pre = 0;
+      for (int q = 0; q < 8; ++q) pre |= (unsigned long long)((i - q >= 0 && j - q >= 0) ? W.tb[(size_t)(i - q) * stride + (j - q)] : (uint8_t)0) << (8 * q);
+    }
+    uint8_t b = (uint8_t)(pre >> (8 * used)); ++used;
     int t = b & 3, x = (b >> 2) & 3, y = (b >> 4) & 3;
     if (t == 3) break;
     else if (forcex) { if (i < 1) { OVF(c); return 0; } ra[L] = "ACGTN"[Sx[i - 1]]; pa[L] = '-'; ++L; if (x == 0) forcex = false; --i; }
@@ -1971,12 +1995,21 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
   for (int i = 0; i < L; ++i) {
     if (ra[i] == pa[i]) ++match_bp; else if (ra[i] == '-') ++ins_bp; else if (pa[i] == '-') ++del_bp; else ++snp_bp;
   }
+  int pc_i = 0, pc_cur = 0;
   for (int i = 0; i < L; ++i) {
     prev_code = code;
     if (ra[i] == '-') { code = '^'; pos_in_ref = refpos; ++pathpos; }
     else if (pa[i] == '-') { code = 'v'; pos_in_ref = refpos; ++refpos; }
     else { code = '='; if (ra[i] != pa[i]) code = 'x'; pos_in_ref = refpos; ++refpos; ++pathpos; }
-    uint32_t spanner = path_contig(c, np, (int)pathpos);
+    // Path_t::pathcontig(pathpos): pathpos never decreases, so the scan over the path's nodes resumes where it stopped
+    uint32_t spanner = LC_NIL;
+    for (; pc_i < np; ++pc_i) {
+      const uint32_t nd = W.pnodes[pc_i];
+      if (W.gr[nd].flags & NF_SPECIAL) continue;
+      const int span = n_len(c, nd);
+      if (pc_cur + span >= (int)pathpos) { spanner = nd; break; }
+      pc_cur += span - K + 1;
+    }
     if (spanner == LC_NIL) break;
     bool within_tumor = status_cnt_T(c, spanner);
     int P = (int)pathpos - 1;
@@ -2247,11 +2280,14 @@ DEV void process_window(Ctx &c, int w) {
     STOP_SET(c, 8);
     if (wg_bcast(&S.overflow)) break;
     for (int comp = 1; comp <= numcomp; ++comp) {
+      mark_ref_scan(c, comp);
+      WG_FOR(i, S.M) { const uint32_t n = W.order[i]; if (!(W.gr[n].flags & NF_SPECIAL)) W.gr[n].color = 1; }   // WHITE for the first hasCycle
+      WG_SYNC();
       WG_LANE0 {
         print_stats(c, comp);
         mark_ref_ends(c, comp);
         S.tmp0 = 0;
-        if (!S.overflow && has_cycle(c)) S.tmp0 = 1;
+        if (!S.overflow && has_cycle(c, true)) S.tmp0 = 1;
         if (!S.tmp0 && !S.overflow) {
           compress(c, comp);
           print_stats(c, comp);
