@@ -991,9 +991,17 @@ DEV void build_graph(Ctx &c) {
   //      Step 2, lane = k-mer position: count over the staged occurrences out of LDS.
   const uint32_t ncand = wg_bcastu(&S.part[LANCET_WG]);
   WG_LANE0 { S.tmp0 = 0x7FFFFFFF; }
+  // (node, csr range, float coverages) of the next candidate are fetched one iteration ahead: they are uniform values
+  // whose loads would otherwise head the dependent chain of every iteration
+  uint32_t n_nx = ncand ? W.pnodes[0] : 0u, lo_nx = 0, hi_nx = 0; float tt_nx = 0.0f, tn_nx = 0.0f;
+  if (ncand) { lo_nx = W.nocc[n_nx]; hi_nx = W.nocc[n_nx + 1]; tt_nx = W.gr[n_nx].cov[0] + W.gr[n_nx].cov[1]; tn_nx = W.gr[n_nx].cov[2] + W.gr[n_nx].cov[3]; }
   for (uint32_t ci = 0; ci < ncand; ++ci) {
-    const uint32_t n = W.pnodes[ci];
-    const uint32_t lo = W.nocc[n], hi = W.nocc[n + 1];
+    const uint32_t n = n_nx, lo = lo_nx, hi = hi_nx;
+    const float tt = tt_nx, tn = tn_nx;
+    if (ci + 1 < ncand) {
+      n_nx = W.pnodes[ci + 1]; lo_nx = W.nocc[n_nx]; hi_nx = W.nocc[n_nx + 1];
+      tt_nx = W.gr[n_nx].cov[0] + W.gr[n_nx].cov[1]; tn_nx = W.gr[n_nx].cov[2] + W.gr[n_nx].cov[3];
+    }
     const uint32_t g0 = c.B->read_begin[S.w];
     const uint32_t qi = (uint32_t)wg_uniform((int)S.qv_top);
     if (qi >= c.C->surv_cap || ((size_t)qi + 1) * (size_t)K > (size_t)c.C->qv_cap) { WG_LANE0 { OVF(c); } return; }
@@ -1026,13 +1034,22 @@ DEV void build_graph(Ctx &c) {
         uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0;       // lr_mode: hp0/1/2_minqv tumor, normal
         if (!first) { a0 = S.acc[i][0]; a1 = S.acc[i][1]; a2 = S.acc[i][2]; a3 = S.acc[i][3]; }
         if (!first && LR) { h0 = S.acc[i][4]; h1 = S.acc[i][5]; h2 = S.acc[i][6]; h3 = S.acc[i][7]; h4 = S.acc[i][8]; h5 = S.acc[i][9]; }
-        for (int j = 0; j < cnt; ++j) {
-          const uint32_t meta = mm[j];
-          const int idx = (meta & 8u) ? (K - 1 - i) : i;
-          const uint32_t bit = (mk[j][idx >> 5] >> (idx & 31)) & meta & 1u;
-          const uint32_t cls = (meta >> 1) & 3u;
-          a0 += (cls == 0) ? bit : 0u; a1 += (cls == 1) ? bit : 0u; a2 += (cls == 2) ? bit : 0u; a3 += (cls == 3) ? bit : 0u;
-          if (LR) {                                 // Node_t::updateHPCovDistr: quality ok and the stored count had grown
+        if (!LR) {
+          for (int j = 0; j < cnt; ++j) {
+            const uint32_t meta = mm[j];
+            const int idx = (meta & 8u) ? (K - 1 - i) : i;
+            const uint32_t bit = (mk[j][idx >> 5] >> (idx & 31)) & meta & 1u;
+            const uint32_t cls = (meta >> 1) & 3u;
+            a0 += (cls == 0) ? bit : 0u; a1 += (cls == 1) ? bit : 0u; a2 += (cls == 2) ? bit : 0u; a3 += (cls == 3) ? bit : 0u;
+          }
+        } else {
+          for (int j = 0; j < cnt; ++j) {
+            const uint32_t meta = mm[j];
+            const int idx = (meta & 8u) ? (K - 1 - i) : i;
+            const uint32_t bit = (mk[j][idx >> 5] >> (idx & 31)) & meta & 1u;
+            const uint32_t cls = (meta >> 1) & 3u;
+            a0 += (cls == 0) ? bit : 0u; a1 += (cls == 1) ? bit : 0u; a2 += (cls == 2) ? bit : 0u; a3 += (cls == 3) ? bit : 0u;
+            // Node_t::updateHPCovDistr: quality ok and the stored count had grown
             const uint32_t gT = (cls < 2) ? bit : 0u, gN = (cls >= 2) ? bit : 0u, gr3 = meta >> 4;
             h0 += gT & gr3; h1 += gT & (gr3 >> 1); h2 += gT & (gr3 >> 2);
             h3 += gN & gr3; h4 += gN & (gr3 >> 1); h5 += gN & (gr3 >> 2);
@@ -1051,7 +1068,6 @@ DEV void build_graph(Ctx &c) {
       WG_SYNC();
     }
     const int minqv = wg_uniform(S.tmp0);
-    const float tt = W.gr[n].cov[0] + W.gr[n].cov[1], tn = W.gr[n].cov[2] + W.gr[n].cov[3];
     const bool low = (minqv <= c.P->low_cov_threshold) || ((double)minqv <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
     if (!low) {
       // survivor of the first removeLowCov: keep the per-position counts and start its sequence-descriptor deque

@@ -131,6 +131,109 @@ def extract_reads(reads: Sequence[SamRead], starts: np.ndarray, win: Window, cod
     return out, False
 
 
+_MD_VALID = set("acgtumrwsykvhdbxnACGTUMRWSYKVHDBXN^")
+
+
+def _parse_md(md: str, M: Dict[int, int], start: int, qual: str, min_qv: int) -> None:
+    """reference src/util.cc:428-483 (parseMD), including its quirks: the quality looked at is the one of the base AFTER
+    the mismatch in MD coordinates (rpos is incremented first; std::string::operator[] at size() is '\\0')."""
+    n = len(md)
+    p = next((i for i in range(n) if md[i] in _MD_VALID), -1)
+    p_old = -1
+    pos, rpos = start, 0
+    while p != -1:
+        num = md[p_old + 1:p]
+        step = _atoi(num)
+        pos += step; rpos += step
+        if md[p] == "^":
+            p2 = next((i for i in range(p + 1, n) if md[i] not in _MD_VALID), -1)
+            dele = md[p + 1:p2] if p2 != -1 else md[p + 1:]
+            pos += len(dele)
+            if p2 == -1:           # find_first_of(valid, npos) == npos ; p_old = npos - 1
+                p = -1
+                p_old = n          # md.substr(npos) would throw in the reference; not reachable with a valid MD
+                break
+            p = next((i for i in range(p2, n) if md[i] in _MD_VALID), -1)
+            p_old = p2 - 1
+        else:
+            pos += 1; rpos += 1
+            q = ord(qual[rpos]) if rpos < len(qual) else 0
+            if q >= min_qv:
+                M[pos] = M.get(pos, 0) + 1
+            p_old = p
+            p = next((i for i in range(p_old + 1, n) if md[i] in _MD_VALID), -1)
+
+
+def _atoi(s: str) -> int:
+    i, n, v = 0, len(s), 0
+    while i < n and s[i] in " \t\n\r\f\v":
+        i += 1
+    neg = False
+    if i < n and s[i] in "+-":
+        neg = s[i] == "-"; i += 1
+    while i < n and s[i].isdigit():
+        v = v * 10 + ord(s[i]) - 48; i += 1
+    return -v if neg else v
+
+
+_CIGAR_RE = None
+
+
+def _cigar_ops(cigar: str):
+    global _CIGAR_RE
+    if _CIGAR_RE is None:
+        import re
+        _CIGAR_RE = re.compile(r"(\d+)([MIDNSHP=X])")
+    return [(int(n), t) for n, t in _CIGAR_RE.findall(cigar)]
+
+
+def is_active_region(reads: Sequence[SamRead], starts: np.ndarray, win: Window, code: int, p: "ReadFilterParams",
+                     min_evidence: int = 3, min_qual_call: int = 17 + 33) -> bool:
+    """reference src/Microassembler.cc:253-432 (isActiveRegion): any locus with >= MIN_EVIDENCE (= filters.minAltCntTumor)
+    mismatches (MD, quality filtered), insertions, deletions or soft-clip starts among the reads contained in the
+    window (MQ >= MIN_MAP_QUAL in the tumor, every MQ in the normal; duplicates skipped)."""
+    mq = 0 if code == NML else p.min_map_qual
+    mapX: Dict[int, int] = {}
+    mapI: Dict[int, int] = {}
+    mapD: Dict[int, int] = {}
+    mapSC: Dict[int, int] = {}
+    lo = int(np.searchsorted(starts, win.start, side="left"))
+    for i in range(lo, len(reads)):
+        r = reads[i]
+        alstart = r.pos - 1
+        if alstart > win.end:
+            break
+        ops = _cigar_ops(r.cigar)
+        alend = alstart + sum(n for n, t in ops if t in "MDN=X")
+        if alstart < win.start or alend > win.end:
+            continue
+        if not (r.mapq >= mq and not (r.flag & 0x400)):
+            continue
+        if not r.seq or not r.qual or r.seq == "*" or r.qual == "*":
+            continue
+        md = r.tags.get("MD")
+        if md is not None:
+            _parse_md(str(md), mapX, alstart, r.qual, min_qual_call)
+        pos = alstart
+        for n, t in ops:
+            if t != "I":
+                pos += n
+            if t == "X":
+                mapX[pos] = mapX.get(pos, 0) + 1
+            if t == "I":
+                mapI[pos] = mapI.get(pos, 0) + 1
+            if t == "D":
+                mapD[pos] = mapD.get(pos, 0) + 1
+        # BamAlignment::GetSoftClips (bamtools 2.5.2, src/api/BamAlignment.cpp:536-606): genome position of every S op
+        refpos = alstart
+        for n, t in ops:
+            if t in "DMXN=":
+                refpos += n
+            elif t == "S":
+                mapSC[refpos] = mapSC.get(refpos, 0) + 1
+    return any(any(v >= min_evidence for v in m.values()) for m in (mapX, mapI, mapD, mapSC))
+
+
 @dataclasses.dataclass
 class WindowBatch:
     """SoA batch that crosses the C-ABI (include/lancet_engine.h: lancet_window_batch)."""
@@ -229,7 +332,8 @@ def build_batch(windows: Sequence[Window], per_window_reads: Sequence[Sequence[T
 
 
 def batch_from_sam(windows: Sequence[Window], tumor: Sequence[SamRead], normal: Sequence[SamRead],
-                   p: Optional[ReadFilterParams] = None, max_k: int = 101, linked: bool = False):
+                   p: Optional[ReadFilterParams] = None, max_k: int = 101, linked: bool = False,
+                   active_region: bool = False, min_evidence: int = 3, min_qual_call: int = 17 + 33):
     """Runs the per-window part of processReads (reference src/Microassembler.cc:779-842) up to the
     processGraph call: returns (batch, kept_windows) for windows that are not skipped.
     Active-region prefilter is not applied here (== --active-region-off)."""
@@ -240,6 +344,9 @@ def batch_from_sam(windows: Sequence[Window], tumor: Sequence[SamRead], normal: 
     per: List[list] = []
     for win in windows_in_processing_order(windows):
         if _is_repeat(win.seq, max_k):                                  # :800
+            continue
+        if active_region and not (is_active_region(tumor, t_starts, win, TMR, p, min_evidence, min_qual_call)        # :817-820
+                                  or is_active_region(normal, n_starts, win, NML, p, min_evidence, min_qual_call)):
             continue
         tr, skip_t = extract_reads(tumor, t_starts, win, TMR, p)
         nr, skip_n = extract_reads(normal, n_starts, win, NML, p)

@@ -49,7 +49,7 @@ def load_case(name: str):
 
 def case_params(meta):
     """reference CLI flags of the case -> (padding, min_k, max_k)."""
-    flags = [f for f in meta["flags"] if f != "--linked-reads"]
+    flags = [f for f in meta["flags"] if f not in ("--linked-reads", "--active-region-on")]
     opt = {"--padding": 250, "--min-k": 11, "--max-k": 101}
     for i in range(0, len(flags), 2):
         opt[flags[i]] = int(flags[i + 1])
@@ -60,12 +60,18 @@ def case_lr(meta) -> bool:
     return "--linked-reads" in meta["flags"]
 
 
+def case_active_region(meta) -> bool:
+    """goldens are reference runs with --active-region-off unless the case carries this marker"""
+    return "--active-region-on" in meta["flags"]
+
+
 @functools.lru_cache(maxsize=None)
 def case_batch(name: str):
     meta, ref, rname, reads = load_case(name)
     padding, min_k, max_k = case_params(meta)
     windows = frontend.tile_region(ref, rname, meta["region"], padding=padding)
-    batch, kept = frontend.batch_from_sam(windows, reads["tumor"], reads["normal"], max_k=max_k, linked=case_lr(meta))
+    batch, kept = frontend.batch_from_sam(windows, reads["tumor"], reads["normal"], max_k=max_k, linked=case_lr(meta),
+                                          active_region=case_active_region(meta))
     return meta, batch, kept, (min_k, max_k)
 
 

@@ -1,0 +1,66 @@
+"""the host side either side of the hot path -- BGZF/BAM/FASTA decode, active-region
+prefilter, and the command-line program -- against a fixture written by the reference's own toolchain:
+tests/golden/ar_small.{tumor,normal}.bam (htslib), ar_small.fa, and ar_small.vcf = the reference's output for
+`lancet --tumor .. --normal .. --ref .. --reg chr22:900-3000 --num-threads 1` (active regions ON, its default)."""
+import io
+import os
+
+import pytest
+
+import golden_util as gu
+from lancet_amd import bamio, cli, engine, frontend
+
+G = gu.GOLDEN
+
+
+def test_bam_reader_decodes_the_htslib_written_fixture():
+    meta, ref, rname, reads = gu.load_case("ar_small")
+    for rg, sample in (("tumor", "TUMOR"), ("normal", "NORMAL")):
+        hdr, got = bamio.read_bam(os.path.join(G, f"ar_small.{rg}.bam"))
+        assert hdr["refs"] == [(rname, len(ref))] and hdr["samples"] == [sample]
+        want = reads[rg]
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert (a.qname, a.flag, a.rname, a.pos, a.mapq, a.cigar, a.seq, a.qual) == (b.qname, b.flag, b.rname, b.pos, b.mapq, b.cigar, b.seq, b.qual)
+            assert a.tags["AS"] == b.tags["AS"] and a.tags["XS"] == b.tags["XS"] and a.tags["MD"] == b.tags["MD"] and a.tags["RG"] == rg
+    assert bamio.read_fasta(os.path.join(G, "ar_small.fa")) == {rname: ref}
+
+
+def test_active_region_prefilter_selects_the_windows_the_reference_assembled():
+    meta, batch, kept, _ = gu.case_batch("ar_small")
+    assembled = [l.split()[3] for l in gu.golden_trace("ar_small").splitlines() if l.startswith("== Processing")]
+    assert [w.hdr for w in kept] == assembled and len(assembled) == 20
+    _, ref, rname, reads = gu.load_case("ar_small")
+    all_windows = frontend.tile_region(ref, rname, meta["region"])
+    assert len(all_windows) > len(kept)                      # the prefilter really dropped windows
+
+
+def test_parse_md_quirks():
+    M = {}
+    frontend._parse_md("10A5^AC6T0", M, 100, "I" * 40, 50)   # mismatch after 10, deletion of 2, mismatch after 6
+    assert M == {111: 1, 125: 1}
+    M = {}
+    frontend._parse_md("3A0", M, 0, "IIII", 50)              # quality looked up one past the mismatch: '\0' at size()
+    assert M == {}
+
+
+def test_cli_has_no_cpu_path():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(engine.EngineError):
+        cli.run(["--tumor", os.path.join(G, "ar_small.tumor.bam"), "--normal", os.path.join(G, "ar_small.normal.bam"),
+                 "--ref", os.path.join(G, "ar_small.fa"), "--reg", "chr22:900-3000"], out=io.StringIO())
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_vcf_is_byte_identical_to_the_reference():
+    out = io.StringIO()
+    argv = ["--tumor", os.path.join(G, "ar_small.tumor.bam"), "--normal", os.path.join(G, "ar_small.normal.bam"),
+            "--ref", os.path.join(G, "ar_small.fa"), "--reg", "chr22:900-3000", "--num-threads", "1"]
+    assert cli.run(argv, out=out, date_line="Sun Sep 27 05:27:00 2026\n") == 0
+    text = out.getvalue()
+    assert "##fileDate=Sun Sep 27 05:27:00 2026\n##source=lancet 1.1.0" in text and "##cmdline=lancet --tumor" in text
+    body = "".join(l + "\n" for l in text.splitlines()
+                   if not l.startswith("##fileDate") and not l.startswith("##cmdline") and not l.startswith("##reference"))
+    assert body == gu.golden_vcf("ar_small")

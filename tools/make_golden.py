@@ -58,6 +58,11 @@ CASES = {
     "lr_deep": (dict(ref_len=6000, cov_t=70, cov_n=45, ref_seed=33, tumor_seed=133, normal_seed=233, linked=True,
                      insert_mean=230.0, insert_sd=45.0, somatic_every=500, germline_every=350, error_rate=0.008,
                      str_fraction=0.15), "chr22:1000-4200", ["--linked-reads"]),
+    # active-region prefilter ON (the reference's default; every other case runs with --active-region-off).
+    # "--active-region-on" is a marker for this script, not a reference flag.  The BAM/FASTA inputs of this case
+    # are committed too (tests/golden/ar_small.*): they are the fixture of the BAM reader and of the CLI test.
+    "ar_small": (dict(ref_len=4000, cov_t=28, cov_n=24, ref_seed=51, tumor_seed=151, normal_seed=251,
+                      somatic_every=900, germline_every=700), "chr22:900-3000", ["--active-region-on"]),
     "dups": (dict(ref_len=8000, cov_t=40, cov_n=40, ref_seed=5, tumor_seed=15, normal_seed=25, dup_prob=1.0,
                   somatic_every=600, germline_every=500, read_len=100), "chr22:1000-6500", []),
 }
@@ -103,12 +108,19 @@ def make_case(name: str):
             run([TEST_VIEW, "-b", "-p", bam, sam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             run([BAMTOOLS, "index", "-in", bam])
             bams[rg] = bam
+        ar_on = "--active-region-on" in flags
         cmd = [REF_BIN, "--tumor", bams["tumor"], "--normal", bams["normal"], "--ref", fa, "--reg", region,
-               "--num-threads", "1", "--active-region-off", "-v"] + flags
+               "--num-threads", "1"] + ([] if ar_on else ["--active-region-off"]) + ["-v"] + [f for f in flags if f != "--active-region-on"]
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=td)
         if r.returncode != 0:
             sys.stderr.write(r.stderr[-3000:])
             raise SystemExit(f"reference failed on case {name}")
+        if ar_on:      # keep the real inputs of this case as fixtures (data files, written by htslib's test_view)
+            import shutil
+            os.makedirs(GOLDEN, exist_ok=True)
+            for rg in ("tumor", "normal"):
+                shutil.copy(bams[rg], os.path.join(GOLDEN, f"{name}.{rg}.bam"))
+            shutil.copy(fa, os.path.join(GOLDEN, f"{name}.fa"))
         vcf = "".join(l + "\n" for l in r.stdout.splitlines()
                       if not l.startswith("##fileDate") and not l.startswith("##cmdline")
                       and not l.startswith("##reference"))
