@@ -89,6 +89,7 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.kcnt = k.take<uint32_t>(nodes * 4);
   t.nfill = k.take<uint32_t>(nodes + 1);
   t.gr = k.take<NodeGr>(nodes);
+  t.cmp = k.take<CmpRec>(nodes);
   t.nocc = k.take<uint32_t>(nodes + 1);
   t.qv = k.take<uint16_t>((size_t)c.qv_cap * (c.lr_mode ? 10 : 4));
   t.khp = k.take<uint16_t>(c.lr_mode ? nodes * 6 : 1);

@@ -48,6 +48,7 @@ struct WinShared {
   uint32_t part[LANCET_WG + 1];
   uint32_t mk[LANCET_WG][4], mmeta[LANCET_WG];   // staged quality masks of up to one wave of occurrences
   uint16_t acc[128][10];                         // per k-mer position running counts Tf Tr Nf Nr (+ lr_mode: T hp0-2, N hp0-2 minqv)
+  int cmp_ok;                                    // compress_prepare: the component qualifies for compress_fast
   int mr_src, mr_snk, mr_ambs, mr_ambk;          // mark_ref_scan: first / last qualifying reference offset, ambiguity flags
   int QS, LR;                                    // counters per (survivor, position): 4, or 10 with --linked-reads ; lr_mode
   unsigned long long rs[LC_RS_WORDS];            // repeat_scan: the string at 4 bits per base
@@ -1290,6 +1291,142 @@ DEVNI void compress_node(Ctx &c, uint32_t node, char dir) {          // Graph_t:
     }
   }
 }
+// ---------------------------------------------------------------------------------------------------------
+// First compress of a component (every node still is one k-mer): the same merges in the same order as
+// compress()/compress_node() above, but each merge costs ONE dependent memory access instead of a dozen.
+//   compress_prepare (all lanes): per live node a 64-byte record with everything a merge reads from the absorbed
+//     node -- its two mergeable links (the getBuddy / isTandem / reciprocal-getBuddy tests of compressNode are
+//     properties of the untouched graph), coverages, flags, the descriptor and the minima the appended base brings.
+//   compress_fast (lane 0): for each head in table order, walk the chain of records read-only into a list
+//     (a ring or anything irregular falls back to compress_node on the untouched state), then replay the list:
+//     descriptors, float averages in merge order, minima, flags; the last absorbed node's outward edges are
+//     attached exactly like compress_node does.
+// ---------------------------------------------------------------------------------------------------------
+#define CL_VALID 0x80000000u
+#define CL_TO(l) ((l) & 0x0FFFFFFFu)
+#define CL_DIR(l) (((l) >> 28) & 3u)
+DEV uint32_t cmp_link(const Ctx &c, uint32_t n, char dir, bool *irregular) {
+  int uid = get_buddy(c, n, dir);
+  if (uid == -1 || is_tandem(c, n)) return 0u;
+  const uint32_t ew = c.W->gr[n].edges[uid], edir = ED_DIR(ew), b = ED_TO(ew);
+  if (is_tandem(c, b)) return 0u;
+  const char bdir = (edir == 0 || edir == 2) ? 'R' : 'F';
+  const int buid = get_buddy(c, b, bdir);
+  if (buid == -1) return 0u;
+  if (ED_TO(c.W->gr[b].edges[buid]) != n) { *irregular = true; return 0u; }
+  return CL_VALID | (edir << 28) | b;
+}
+DEV void compress_prepare(Ctx &c, int comp) {
+  volatile WinShared &S = *c.S; Work &W = *c.W;
+  const int K = S.K;
+  WG_LANE0 { S.cmp_ok = 1; }
+  WG_FOR(i, S.M) {
+    const uint32_t n = W.order[i];
+    CmpRec &r = W.cmp[n];
+    const NodeGr &G = W.gr[n];
+    r.lnk[0] = 0; r.lnk[1] = 0;
+    if (G.comp != comp || (G.flags & (NF_DEAD | NF_SPECIAL))) continue;
+    bool irr = false;
+    if ((int)(G.seq_hi - G.seq_lo) != K || G.nkm != 1 || G.nqv == LC_NIL) irr = true;
+    else {
+      r.lnk[0] = cmp_link(c, n, 'F', &irr);
+      r.lnk[1] = cmp_link(c, n, 'R', &irr);
+      for (int q = 0; q < 4; ++q) r.cov[q] = G.cov[q];
+      r.flags = G.flags; r.nkmT = G.nkmT;
+      r.d0 = W.seq[G.seq_lo]; r.dK = W.seq[G.seq_lo + (uint32_t)(K - 1)];
+      int t, q0, qK;
+      desc_tot(c, r.d0, &t, &q0); desc_tot(c, r.dK, &t, &qK);
+      r.tot = t; r.tq0 = q0; r.tqK = qK;
+    }
+    if (irr) S.cmp_ok = 0;
+  }
+  WG_SYNC();
+}
+DEVNI void compress_fast(Ctx &c, int comp) {
+  volatile WinShared &S = *c.S; Work &W = *c.W;
+  const int K = S.K;
+  evt(c, EV_COMPRESS);
+  uint32_t *list = W.scratch;                                   // (absorbed node, edge dir it is entered by) per merge
+  const uint32_t lcap = c.C->node_cap;
+  for (uint32_t oi = 0; oi < S.M && !S.overflow; ++oi) {
+    const uint32_t H = W.order[oi];
+    if (W.gr[H].comp != comp) continue;
+    if (W.gr[H].flags & (NF_DEAD | NF_SPECIAL)) continue;
+    for (int pass = 0; pass < 2 && !S.overflow; ++pass) {
+      const char dir = pass == 0 ? 'F' : 'R';
+      // ---- read-only walk.  The head's own link comes from its record; after a merge the head's edge in `dir` is the
+      //      absorbed node's onward edge, its direction flipped when the entering edge was FR or RF (flipme).
+      uint32_t l = W.cmp[H].lnk[pass];
+      uint32_t cnt = 0; bool ring = false;
+      uint32_t edir = CL_DIR(l), B = CL_TO(l);
+      bool valid = (l & CL_VALID) != 0;
+      while (valid) {
+        if (B == H || cnt >= lcap) { ring = true; break; }
+        const CmpRec &rb = W.cmp[B];                               // the one dependent access of this merge
+        list[2 * cnt] = B; list[2 * cnt + 1] = edir; ++cnt;
+        const char bdir = (edir == 0 || edir == 2) ? 'R' : 'F';
+        const uint32_t on = rb.lnk[bdir == 'R' ? 0 : 1];          // the absorbed node's link away from the head
+        valid = (on & CL_VALID) != 0;
+        if (valid) { uint32_t nd = CL_DIR(on); if (edir == 1 || edir == 2) nd = flipme(nd); edir = nd; B = CL_TO(on); }
+      }
+      if (ring) { compress_node(c, H, dir); continue; }           // untouched so far: the literal replay handles it
+      if (cnt == 0) continue;
+      // ---- replay
+      NodeGr &G = W.gr[H];
+      {                                                            // the head's edge to the first absorbed node goes away
+        const int uid = get_buddy(c, H, dir);
+        if (uid == -1) { OVF(c); return; }
+        erase_edge_at(c, H, uid);
+      }
+      if (!seq_reserve(c, H, dir == 'F' ? 0u : cnt, dir == 'F' ? cnt : 0u)) return;
+      uint32_t lo = G.seq_lo, hi = G.seq_hi;
+      int mn = G.mincov, mq = G.mincovqv;
+      float nc0 = G.cov[0], nc1 = G.cov[1], nc2 = G.cov[2], nc3 = G.cov[3];
+      uint32_t fl = G.flags, nkm = G.nkm, nkmT = G.nkmT;
+      int alen = (int)(hi - lo);
+      for (uint32_t j = 0; j < cnt; ++j) {
+        const uint32_t Bj = list[2 * j], ed = list[2 * j + 1];
+        const CmpRec &rb = W.cmp[Bj];
+        const bool brev = dir_dest(ed) == 'R';
+        uint32_t d = brev ? (rb.d0 ^ 3u) : rb.dK;
+        if (dir == 'F') W.seq[hi++] = d; else W.seq[--lo] = d ^ 3u;
+        if (rb.tot < mn) mn = rb.tot;
+        { const int tq = brev ? rb.tq0 : rb.tqK; if (tq < mq) mq = tq; }
+        const int amer = alen - K + 1, bmer = 1;                  // Graph.cc:2632-2636, same expression, same order
+        nc0 = ((nc0 * amer) + (rb.cov[0] * bmer)) / (amer + bmer);
+        nc1 = ((nc1 * amer) + (rb.cov[1] * bmer)) / (amer + bmer);
+        nc2 = ((nc2 * amer) + (rb.cov[2] * bmer)) / (amer + bmer);
+        nc3 = ((nc3 * amer) + (rb.cov[3] * bmer)) / (amer + bmer);
+        ++alen; nkm += 1; nkmT += rb.nkmT;
+        fl |= rb.flags & (NF_TUMOR | NF_NORMAL);
+        W.gr[Bj].flags = rb.flags | NF_DEAD;
+      }
+      G.seq_lo = lo; G.seq_hi = hi; G.mincov = mn; G.mincovqv = mq;
+      G.cov[0] = nc0; G.cov[1] = nc1; G.cov[2] = nc2; G.cov[3] = nc3;
+      G.flags = fl; G.nkm = nkm; G.nkmT = nkmT;
+      // ---- the last absorbed node's other edges move to the head (compress_node's tail, unchanged)
+      const uint32_t buddy = list[2 * (cnt - 1)], ed = list[2 * (cnt - 1) + 1];
+      const char bdir = (ed == 0 || ed == 2) ? 'R' : 'F';
+      const int buid = get_buddy(c, buddy, bdir);
+      const int bcnt = (int)W.gr[buddy].necnt;
+      for (int i = 0; i < bcnt; ++i) {
+        if (i == buid) continue;
+        const uint32_t be = W.gr[buddy].edges[i];
+        uint32_t ndir = ED_DIR(be);
+        if (ed == 1 || ed == 2) ndir = flipme(ndir);
+        const uint32_t other = ED_TO(be);
+        const int ec = (int)G.necnt;
+        if (ec >= LC_EMAX) { OVF(c); return; }
+        if (other == buddy) { G.edges[ec] = ED_MAKE(H, ndir) | (be & (1u << 30)); G.necnt = ec + 1; }
+        else {
+          G.edges[ec] = ED_MAKE(other, ndir) | (be & (1u << 30)); G.necnt = ec + 1;
+          update_edge(c, other, buddy, fliplink(ED_DIR(be)), H, fliplink(ndir));
+        }
+      }
+    }
+  }
+  clean_dead(c);
+}
 DEVNI void compress(Ctx &c, int comp) {                               // reference src/Graph.cc:2712-2732
   volatile WinShared &S = *c.S; Work &W = *c.W;
   evt(c, EV_COMPRESS);
@@ -2198,10 +2335,13 @@ DEV void count_ref_path(Ctx &c) {
       if (wg_bcastu(&S.part[6])) {
         const uint8_t *rs = c.B->ref_codes + c.B->ref_off[S.w] + S.seq_t5;
         const int pl = (int)wg_bcastu(&S.part[5]);
+        PHASE(c, 12);
         align_fill(c, rs, S.seq_len, W.pseq, pl);
+        PHASE(c, 13);
         WG_LANE0 { S.part[7] = (uint32_t)align_traceback(c, rs, S.seq_len, W.pseq, pl); }
         WG_SYNC();
       }
+      PHASE(c, 14);
       WG_LANE0 {
         if (!S.overflow) {
           process_path_walk(c, (int)S.part[4], (int)S.part[5], (int)S.part[7], (int)S.part[1]);
@@ -2209,6 +2349,7 @@ DEV void count_ref_path(Ctx &c) {
         }
         if (S.overflow) S.part[3] = 1;
       }
+      PHASE(c, 11);
     }
     WG_LANE0 { evt(c, EV_EKA_END, (uint32_t)S.refcomp, S.part[1], S.part[2], (uint32_t)S.tmp0, (uint32_t)S.tmp2, (uint32_t)S.tmp1, S.part[0]); }
   }
@@ -2304,8 +2445,15 @@ DEV void process_window(Ctx &c, int w) {
         mark_ref_ends(c, comp);
         S.tmp0 = 0;
         if (!S.overflow && has_cycle(c, true)) S.tmp0 = 1;
-        if (!S.tmp0 && !S.overflow) {
-          compress(c, comp);
+      }
+      if (wg_bcast(&S.overflow)) break;
+      if (wg_bcast(&S.tmp0)) { cycleInGraph = 1; brk = true; break; }
+      PHASE(c, 15);
+      compress_prepare(c, comp);
+      WG_LANE0 {
+        {
+          if (S.cmp_ok) compress_fast(c, comp); else compress(c, comp);
+          PHASE(c, 9);
           print_stats(c, comp);
           remove_low_cov(c, comp);
           remove_tips(c, comp);

@@ -117,6 +117,16 @@ struct NodeGr {
   uint32_t pad[2];
 };
 
+/* compress_prepare -> compress_fast: what one merge reads from the absorbed (single k-mer) node, in one line */
+struct CmpRec {
+  uint32_t lnk[2];         /* mergeable link in direction F / R: valid [31], edge dir [29:28], neighbour [27:0]          */
+  float cov[4];
+  uint32_t flags, nkmT;
+  uint32_t d0, dK;         /* descriptors of the k-mer's first / last base                                            */
+  int32_t tot, tq0, tqK;   /* computeMinCov operands of those positions                                               */
+  uint32_t pad[3];
+};
+
 /* One slot of work space.  All pointers are device pointers into one big allocation. */
 struct Work {
   /* ---- build ---- */
@@ -139,6 +149,7 @@ struct Work {
   uint32_t *kcnt;         /* [nodes*4] counted occurrences of the k-mer: Tf Tr Nf Nr          */
   uint32_t *nfill;        /* [nodes+1] csr fill cursors                                        */
   NodeGr *gr;             /* [nodes]                                                           */
+  CmpRec *cmp;            /* [nodes] compress_prepare records                                   */
   uint32_t *nocc;         /* [nodes+1] csr offsets                                             */
   uint16_t *qv;           /* [qv_cap * QS] per-position min-quality counts Tf Tr Nf Nr (QS = 4), in lr_mode followed by
                              hp0/hp1/hp2_minqv of the tumor and of the normal (QS = 10)        */

@@ -32,7 +32,7 @@ for it in range(3):
     nk = sum(s["n_kmers"] for s in st)
     print(f"run {it}: wall {dt:.3f}s kernel {eng.timing_ms()[1]:.1f} ms  windows/s {big.n_windows / dt:.0f}  Mkmers/s {nk / dt / 1e6:.1f} variants {len(v)} bad {sum(1 for s in st if s['status'] < 0)}")
 
-names = ["other", "ref repeat scan", "build: k-mer insert+verify", "build: node ids/hash", "build: pass2+csr+mate replay", "build: per-node minqv/lowcov pred", "materialize survivors", "libstdc++ order replay", "first lowcov+cc", "per-comp graph passes", "repeats in paths", "bfs+align+walk"]
+names = ["other", "ref repeat scan", "build: k-mer insert+verify", "build: node ids/hash", "build: pass2+csr+mate replay", "build: per-node minqv/lowcov pred", "materialize survivors", "libstdc++ order replay", "first lowcov+cc", "per-comp graph passes", "repeats in paths", "bfs+path string+hamming", "align fill", "align traceback", "transcript walk", "first compress"]
 pt = eng.phase_times().sum(axis=0)
 tot = pt.sum()
 for i, n in enumerate(names):
