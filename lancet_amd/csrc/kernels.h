@@ -46,6 +46,9 @@ struct WinShared {
   int tmp0, tmp1, tmp2, tmp3, hasN;
   int nitems;                          // work items of the per-occurrence passes (build_items)
   uint32_t part[LANCET_WG + 1];
+  uint32_t part2[LANCET_WG + 1];                 // second scan scratch (part[0..7] carry the path loop's state)
+  int wk[4];                                     // walk_prepare: match / snp / ins / del columns
+  int wk_n;                                      // walk_prepare: number of non-match columns
   uint32_t mk[LANCET_WG][4], mmeta[LANCET_WG];   // staged quality masks of up to one wave of occurrences
   uint16_t acc[128][10];                         // per k-mer position running counts Tf Tr Nf Nr (+ lr_mode: T hp0-2, N hp0-2 minqv)
   int cmp_ok;                                    // compress_prepare: the component qualifies for compress_fast
@@ -271,19 +274,20 @@ DEV void repeat_scan(volatile WinShared &S, const uint8_t *s, int len, int mm, v
 }
 
 // exclusive prefix sum of a[0..n) in place; returns total in S.part[LANCET_WG]
-DEV void wg_scan(uint32_t *a, int n, volatile WinShared &S) {
+DEV void wg_scan(uint32_t *a, int n, volatile WinShared &S, volatile uint32_t *part = nullptr) {
+  if (!part) part = S.part;
   int chunk = (n + LANCET_WG - 1) / LANCET_WG;
   WG_FOR(l, LANCET_WG) {
     uint32_t s = 0;
     int lo = l * chunk, hi = lo + chunk; if (hi > n) hi = n;
     for (int i = lo; i < hi; ++i) s += ld2(&a[i]);
-    S.part[l] = s;
+    part[l] = s;
   }
   WG_SYNC();
-  WG_LANE0 { uint32_t s = 0; for (int l = 0; l < LANCET_WG; ++l) { uint32_t t = S.part[l]; S.part[l] = s; s += t; } S.part[LANCET_WG] = s; }
+  WG_LANE0 { uint32_t s = 0; for (int l = 0; l < LANCET_WG; ++l) { uint32_t t = part[l]; part[l] = s; s += t; } part[LANCET_WG] = s; }
   WG_SYNC();
   WG_FOR(l, LANCET_WG) {
-    uint32_t s = S.part[l];
+    uint32_t s = part[l];
     int lo = l * chunk, hi = lo + chunk; if (hi > n) hi = n;
     for (int i = lo; i < hi; ++i) { uint32_t t = ld2(&a[i]); a[i] = s; s += t; }
   }
@@ -2133,6 +2137,30 @@ DEVNI void emit_variant(Ctx &c, const TS &t, const uint16_t cov[8], int strLen, 
   if (S.LR) emit_variant_lr(c, vi, t, hp12, plen);
 }
 
+// All lanes, before the transcript walk: per alignment column the reference position before it and the path position
+// after it (prefix counts of non-gap characters), the list of the columns that are not matches, and the four
+// column-type counts.  The walk (lane 0) then visits only the non-match columns instead of all of them.
+//   scratch[0..L) = pos_in_ref, scratch[L+1..2L+1) = pathpos - (column consumes a path base), scratch[2L+2..] = column list
+DEV void walk_prepare(Ctx &c, int L) {
+  volatile WinShared &S = *c.S; Work &W = *c.W;
+  const int cap = LC_MAXW + (int)c.C->path_cap + 2;
+  const uint8_t *ra = W.aln, *pa = W.aln + cap;
+  uint32_t *E1 = W.scratch, *E2 = W.scratch + (L + 1), *F = W.scratch + 2 * (L + 1), *cols = W.scratch + 3 * (L + 1);
+  WG_LANE0 { S.wk[0] = S.wk[1] = S.wk[2] = S.wk[3] = 0; E1[L] = 0; E2[L] = 0; F[L] = 0; }
+  WG_FOR(i, L) {
+    const uint8_t r = ra[i], p = pa[i];
+    E1[i] = r != '-'; E2[i] = p != '-'; F[i] = r != p;
+    const int t = r == p ? 0 : (r == '-' ? 2 : (p == '-' ? 3 : 1));
+    dev_atomic_add((uint32_t *)&S.wk[t], 1u);
+  }
+  WG_SYNC();
+  wg_scan(E1, L + 1, S, S.part2);
+  wg_scan(E2, L + 1, S, S.part2);
+  wg_scan(F, L + 1, S, S.part2);
+  WG_FOR(i, L) { if (F[i + 1] != F[i]) cols[F[i]] = (uint32_t)i; }
+  WG_LANE0 { S.wk_n = (int)F[L]; }
+}
+
 // lane 0.  `np` = nodes in path, `plen` = path string length, aligned strings in W.aln (length L).
 DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
@@ -2142,18 +2170,19 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
   const int refstart = c.B->ref_start[S.w];
   TS *ts = (TS *)(void *)W.tb;                 // the traceback matrix is dead by now: reuse it for the transcripts
   int nts = 0;
-  unsigned pos_in_ref = 0, refpos = 0, pathpos = 0;
+  unsigned pos_in_ref = 0, pathpos = 0;
   char code = '?', prev_code = '?';
-  int match_bp = 0, snp_bp = 0, ins_bp = 0, del_bp = 0;
-  for (int i = 0; i < L; ++i) {
-    if (ra[i] == pa[i]) ++match_bp; else if (ra[i] == '-') ++ins_bp; else if (pa[i] == '-') ++del_bp; else ++snp_bp;
-  }
+  const int match_bp = S.wk[0], snp_bp = S.wk[1], ins_bp = S.wk[2], del_bp = S.wk[3];      // walk_prepare
+  const uint32_t *E1 = W.scratch, *E2 = W.scratch + (L + 1), *cols = W.scratch + 3 * (L + 1);
   int pc_i = 0, pc_cur = 0;
-  for (int i = 0; i < L; ++i) {
-    prev_code = code;
-    if (ra[i] == '-') { code = '^'; pos_in_ref = refpos; ++pathpos; }
-    else if (pa[i] == '-') { code = 'v'; pos_in_ref = refpos; ++refpos; }
-    else { code = '='; if (ra[i] != pa[i]) code = 'x'; pos_in_ref = refpos; ++refpos; ++pathpos; }
+  int last_col = -2;
+  for (int ci = 0; ci < S.wk_n; ++ci) {
+    const int i = (int)cols[ci];
+    prev_code = (last_col == i - 1) ? code : '=';       // the column before is a match unless it is the previous listed one
+    last_col = i;
+    if (ra[i] == '-') code = '^'; else if (pa[i] == '-') code = 'v'; else code = 'x';
+    pos_in_ref = E1[i];
+    pathpos = E2[i] + (pa[i] != '-' ? 1u : 0u);
     // Path_t::pathcontig(pathpos): pathpos never decreases, so the scan over the path's nodes resumes where it stopped
     uint32_t spanner = LC_NIL;
     for (; pc_i < np; ++pc_i) {
@@ -2167,7 +2196,7 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
     bool within_tumor = status_cnt_T(c, spanner);
     int P = (int)pathpos - 1;
     if (P < 0 || P >= plen) { OVF(c); return; }      // the reference reads coverageN[-1] here (undefined)
-    if (code != '=') {
+    {
       uint16_t cn4[4], ct4[4], rn2[2], rt2[2];
       path_cov_at(c, P, cn4, ct4);
       ref_cov_at(c, pos_in_ref + (uint32_t)S.trim5, rn2, rt2);
@@ -2342,6 +2371,7 @@ DEV void count_ref_path(Ctx &c) {
         WG_SYNC();
       }
       PHASE(c, 14);
+      walk_prepare(c, (int)wg_bcastu(&S.part[7]));
       WG_LANE0 {
         if (!S.overflow) {
           process_path_walk(c, (int)S.part[4], (int)S.part[5], (int)S.part[7], (int)S.part[1]);
