@@ -49,7 +49,8 @@ struct WinShared {
   uint32_t part2[LANCET_WG + 1];                 // second scan scratch (part[0..7] carry the path loop's state)
   int wk[4];                                     // walk_prepare: match / snp / ins / del columns
   int wk_n;                                      // walk_prepare: number of non-match columns
-  uint32_t mk[LANCET_WG][4], mmeta[LANCET_WG];   // staged quality masks of up to one wave of occurrences
+  uint32_t mk[LC_STAGE][4], mmeta[LC_STAGE];     // staged quality masks of up to LC_STAGE occurrences
+  uint32_t g_n[LC_PACK], g_lo[LC_PACK], g_cnt[LC_PACK], g_es[LC_PACK], g_min[LC_PACK], g_N;   // the candidates of the current group
   uint16_t acc[128][10];                         // per k-mer position running counts Tf Tr Nf Nr (+ lr_mode: T hp0-2, N hp0-2 minqv)
   int cmp_ok;                                    // compress_prepare: the component qualifies for compress_fast
   int mr_src, mr_snk, mr_ambs, mr_ambk;          // mark_ref_scan: first / last qualifying reference offset, ambiguity flags
@@ -990,49 +991,77 @@ DEV void build_graph(Ctx &c) {
   WG_FOR(n, S.N) { if (W.order[n + 1] != W.order[n]) W.pnodes[W.order[n]] = (uint32_t)n; }
   WG_SYNC();
   PHASE(c, 6);
-  // ---- undecided nodes, one at a time: number of counted reads whose base passes MIN_QUAL_CALL, per k-mer position and
-  //      strand/sample (Node_t::updateCovDistr minqv_fwd/minqv_rev, reference src/Node.cc:470-497).
-  //      Step 1, lane = occurrence: the K quality bits of the occurrence go to LDS (64 independent load chains in flight).
-  //      Step 2, lane = k-mer position: count over the staged occurrences out of LDS.
+  // ---- undecided nodes: number of counted reads whose base passes MIN_QUAL_CALL, per k-mer position and strand/sample
+  //      (Node_t::updateCovDistr minqv_fwd/minqv_rev, reference src/Node.cc:470-497).  Up to LC_PACK consecutive
+  //      candidates are handled together as long as their occurrences fit the LDS staging area (a bigger one goes alone,
+  //      in rounds): the dependent chain occurrence -> read info -> quality words is paid once per group.
+  //      Step 1, lane = occurrence (two per lane, loads issued together): K quality bits + class of the occurrence -> LDS.
+  //      Step 2, lane = (candidate, k-mer position): count over the candidate's staged occurrences out of LDS.
   const uint32_t ncand = wg_bcastu(&S.part[LANCET_WG]);
-  WG_LANE0 { S.tmp0 = 0x7FFFFFFF; }
-  // (node, csr range, float coverages) of the next candidate are fetched one iteration ahead: they are uniform values
-  // whose loads would otherwise head the dependent chain of every iteration
-  uint32_t n_nx = ncand ? W.pnodes[0] : 0u, lo_nx = 0, hi_nx = 0; float tt_nx = 0.0f, tn_nx = 0.0f;
-  if (ncand) { lo_nx = W.nocc[n_nx]; hi_nx = W.nocc[n_nx + 1]; tt_nx = W.gr[n_nx].cov[0] + W.gr[n_nx].cov[1]; tn_nx = W.gr[n_nx].cov[2] + W.gr[n_nx].cov[3]; }
-  for (uint32_t ci = 0; ci < ncand; ++ci) {
-    const uint32_t n = n_nx, lo = lo_nx, hi = hi_nx;
-    const float tt = tt_nx, tn = tn_nx;
-    if (ci + 1 < ncand) {
-      n_nx = W.pnodes[ci + 1]; lo_nx = W.nocc[n_nx]; hi_nx = W.nocc[n_nx + 1];
-      tt_nx = W.gr[n_nx].cov[0] + W.gr[n_nx].cov[1]; tn_nx = W.gr[n_nx].cov[2] + W.gr[n_nx].cov[3];
+  const int QS = S.QS; const bool LR = S.LR != 0;
+  const uint32_t g0 = c.B->read_begin[S.w];
+  uint32_t ci = 0;
+  while (ci < ncand) {
+    WG_LANE0 {                                   // group formation
+      uint32_t gN = 0, tot = 0;
+      for (uint32_t k = 0; k < LC_PACK && ci + k < ncand; ++k) {
+        const uint32_t n = W.pnodes[ci + k], lo = W.nocc[n], cnt = W.nocc[n + 1] - lo;
+        if (gN > 0 && tot + cnt > LC_STAGE) break;
+        S.g_n[gN] = n; S.g_lo[gN] = lo; S.g_cnt[gN] = cnt; S.g_es[gN] = tot; S.g_min[gN] = 0x7FFFFFFFu;
+        ++gN; tot += cnt;
+        if (tot >= LC_STAGE) break;
+      }
+      S.g_N = gN;
+      if (S.qv_top + gN > c.C->surv_cap || ((size_t)S.qv_top + gN) * (size_t)K > (size_t)c.C->qv_cap) OVF(c);
     }
-    const uint32_t g0 = c.B->read_begin[S.w];
-    const uint32_t qi = (uint32_t)wg_uniform((int)S.qv_top);
-    if (qi >= c.C->surv_cap || ((size_t)qi + 1) * (size_t)K > (size_t)c.C->qv_cap) { WG_LANE0 { OVF(c); } return; }
-    const int QS = S.QS; const bool LR = S.LR != 0;
-    uint16_t *qq = W.qv + (size_t)qi * K * QS;
-    for (uint32_t q0 = lo; q0 < hi; q0 += LANCET_WG) {
-      const int cnt = (int)(hi - q0 < (uint32_t)LANCET_WG ? hi - q0 : (uint32_t)LANCET_WG);
-      WG_FOR(j, cnt) {
-        const uint32_t e = W.csr[q0 + j];
-        uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, meta = 0;
-        if (CS_ST(e) == 0) {
-          const uint32_t g = g0 + CS_READ(e);
-          const uint32_t ri = c.B->rinfo[g];
-          const uint32_t *gd = c.B->good + c.B->good_woff[g];
-          const int p0 = (int)CS_POS(e), sh = p0 & 31, wv = p0 >> 5;
-          // bits [p0, p0+K) of the read's mask, 32 at a time; the word after is only touched when it holds needed bits
-          #define LC_TAKE(t) ((32 * (t) < K) ? ((gd[wv + (t)] >> sh) | ((sh && 32 * (t) + 32 - sh < K) ? (gd[wv + (t) + 1] << (32 - sh)) : 0u)) : 0u)
-          m0 = LC_TAKE(0); m1 = LC_TAKE(1); m2 = LC_TAKE(2); m3 = LC_TAKE(3);
-          #undef LC_TAKE
-          meta = 1u | (((RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u)) << 1) | (CS_ORI(e) << 3) | ((e >> 29) << 4);
+    if (wg_bcast(&S.overflow)) return;
+    const int gN = wg_uniform((int)S.g_N);
+    const uint32_t qi0 = (uint32_t)wg_uniform((int)S.qv_top);
+    const uint32_t cnt0 = (uint32_t)wg_uniform((int)S.g_cnt[0]);
+    const bool big = cnt0 > LC_STAGE;            // then gN == 1: rounds over its occurrences, counts carried in S.acc
+    const uint32_t total = big ? cnt0 : (uint32_t)wg_uniform((int)(S.g_es[gN - 1] + S.g_cnt[gN - 1]));
+    for (uint32_t r0 = 0; r0 < total; r0 += LC_STAGE) {
+      const int cnt = (int)(total - r0 < LC_STAGE ? total - r0 : LC_STAGE);
+      WG_FOR(ln, LANCET_WG) {   // ---- step 1: entries ln and ln+64 of the staging area
+        uint32_t e[2], m[2][4], meta[2]; bool act[2];
+        const uint32_t *gd[2]; uint32_t ri[2];
+        for (int u = 0; u < 2; ++u) {
+          const int j = ln + u * LANCET_WG;
+          act[u] = j < cnt;
+          e[u] = 0;
+          if (act[u]) {
+            uint32_t src;
+            if (big) src = S.g_lo[0] + r0 + (uint32_t)j;
+            else { int k = 0; while (k + 1 < gN && (uint32_t)j >= S.g_es[k + 1]) ++k; src = S.g_lo[k] + ((uint32_t)j - S.g_es[k]); }
+            e[u] = W.csr[src];
+          }
         }
-        S.mk[j][0] = m0; S.mk[j][1] = m1; S.mk[j][2] = m2; S.mk[j][3] = m3; S.mmeta[j] = meta;
+        for (int u = 0; u < 2; ++u) {
+          act[u] = act[u] && CS_ST(e[u]) == 0;
+          ri[u] = 0; gd[u] = c.B->good;
+          if (act[u]) { const uint32_t g = g0 + CS_READ(e[u]); ri[u] = c.B->rinfo[g]; gd[u] = c.B->good + c.B->good_woff[g]; }
+        }
+        for (int u = 0; u < 2; ++u) {
+          m[u][0] = m[u][1] = m[u][2] = m[u][3] = 0; meta[u] = 0;
+          if (act[u]) {
+            const int p0 = (int)CS_POS(e[u]), sh = p0 & 31, wv = p0 >> 5;
+            // bits [p0, p0+K) of the read's mask, 32 at a time; the word after is only touched when it holds needed bits
+            #define LC_TAKE(t) ((32 * (t) < K) ? ((gd[u][wv + (t)] >> sh) | ((sh && 32 * (t) + 32 - sh < K) ? (gd[u][wv + (t) + 1] << (32 - sh)) : 0u)) : 0u)
+            m[u][0] = LC_TAKE(0); m[u][1] = LC_TAKE(1); m[u][2] = LC_TAKE(2); m[u][3] = LC_TAKE(3);
+            #undef LC_TAKE
+            meta[u] = 1u | (((RI_NML(ri[u]) ? 2u : 0u) + (RI_REV(ri[u]) ? 1u : 0u)) << 1) | (CS_ORI(e[u]) << 3) | ((e[u] >> 29) << 4);
+          }
+        }
+        for (int u = 0; u < 2; ++u) {
+          const int j = ln + u * LANCET_WG;
+          if (j < cnt) { S.mk[j][0] = m[u][0]; S.mk[j][1] = m[u][1]; S.mk[j][2] = m[u][2]; S.mk[j][3] = m[u][3]; S.mmeta[j] = meta[u]; }
+        }
       }
       WG_SYNC();
-      const bool first = (q0 == lo), last = (q0 + LANCET_WG >= hi);
-      WG_FOR(i, K) {
+      const bool first = (r0 == 0), last = (r0 + LC_STAGE >= total);
+      WG_FOR(t, gN * K) {   // ---- step 2
+        const int k = big ? 0 : t / K, i = big ? t : t - k * K;
+        const int es = big ? 0 : (int)S.g_es[k], ee = big ? cnt : es + (int)S.g_cnt[k];
         const uint32_t (*mk)[4] = (const uint32_t (*)[4])S.mk;       // plain LDS reads: staged before the barrier above
         const uint32_t *mm = (const uint32_t *)S.mmeta;
         uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -1040,7 +1069,7 @@ DEV void build_graph(Ctx &c) {
         if (!first) { a0 = S.acc[i][0]; a1 = S.acc[i][1]; a2 = S.acc[i][2]; a3 = S.acc[i][3]; }
         if (!first && LR) { h0 = S.acc[i][4]; h1 = S.acc[i][5]; h2 = S.acc[i][6]; h3 = S.acc[i][7]; h4 = S.acc[i][8]; h5 = S.acc[i][9]; }
         if (!LR) {
-          for (int j = 0; j < cnt; ++j) {
+          for (int j = es; j < ee; ++j) {
             const uint32_t meta = mm[j];
             const int idx = (meta & 8u) ? (K - 1 - i) : i;
             const uint32_t bit = (mk[j][idx >> 5] >> (idx & 31)) & meta & 1u;
@@ -1048,52 +1077,65 @@ DEV void build_graph(Ctx &c) {
             a0 += (cls == 0) ? bit : 0u; a1 += (cls == 1) ? bit : 0u; a2 += (cls == 2) ? bit : 0u; a3 += (cls == 3) ? bit : 0u;
           }
         } else {
-          for (int j = 0; j < cnt; ++j) {
+          for (int j = es; j < ee; ++j) {
             const uint32_t meta = mm[j];
             const int idx = (meta & 8u) ? (K - 1 - i) : i;
             const uint32_t bit = (mk[j][idx >> 5] >> (idx & 31)) & meta & 1u;
             const uint32_t cls = (meta >> 1) & 3u;
             a0 += (cls == 0) ? bit : 0u; a1 += (cls == 1) ? bit : 0u; a2 += (cls == 2) ? bit : 0u; a3 += (cls == 3) ? bit : 0u;
             // Node_t::updateHPCovDistr: quality ok and the stored count had grown
-            const uint32_t gT = (cls < 2) ? bit : 0u, gN = (cls >= 2) ? bit : 0u, gr3 = meta >> 4;
+            const uint32_t gT = (cls < 2) ? bit : 0u, gNm = (cls >= 2) ? bit : 0u, gr3 = meta >> 4;
             h0 += gT & gr3; h1 += gT & (gr3 >> 1); h2 += gT & (gr3 >> 2);
-            h3 += gN & gr3; h4 += gN & (gr3 >> 1); h5 += gN & (gr3 >> 2);
+            h3 += gNm & gr3; h4 += gNm & (gr3 >> 1); h5 += gNm & (gr3 >> 2);
           }
         }
         if (!last) {
           S.acc[i][0] = (uint16_t)a0; S.acc[i][1] = (uint16_t)a1; S.acc[i][2] = (uint16_t)a2; S.acc[i][3] = (uint16_t)a3;
           if (LR) { S.acc[i][4] = (uint16_t)h0; S.acc[i][5] = (uint16_t)h1; S.acc[i][6] = (uint16_t)h2; S.acc[i][7] = (uint16_t)h3; S.acc[i][8] = (uint16_t)h4; S.acc[i][9] = (uint16_t)h5; }
         } else {
+          uint16_t *qq = W.qv + (size_t)(qi0 + (uint32_t)k) * K * QS;
           qq[QS * i] = (uint16_t)a0; qq[QS * i + 1] = (uint16_t)a1; qq[QS * i + 2] = (uint16_t)a2; qq[QS * i + 3] = (uint16_t)a3;
           if (LR) { uint16_t *qh = qq + QS * i + 4; qh[0] = (uint16_t)h0; qh[1] = (uint16_t)h1; qh[2] = (uint16_t)h2; qh[3] = (uint16_t)h3; qh[4] = (uint16_t)h4; qh[5] = (uint16_t)h5; }
           const int sq = (int)(uint16_t)a0 + (int)(uint16_t)a1 + (int)(uint16_t)a2 + (int)(uint16_t)a3;
-          dev_atomic_min((uint32_t *)&S.tmp0, (uint32_t)sq);
+          dev_atomic_min((uint32_t *)&S.g_min[k], (uint32_t)sq);
         }
       }
       WG_SYNC();
     }
-    const int minqv = wg_uniform(S.tmp0);
-    const bool low = (minqv <= c.P->low_cov_threshold) || ((double)minqv <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
-    if (!low) {
-      // survivor of the first removeLowCov: keep the per-position counts and start its sequence-descriptor deque
-      const uint32_t base = qi * (uint32_t)K;
-      const unsigned long long *kk = W.nkey + (size_t)n * LC_NWMAX;
-      WG_FOR(i, K) { W.seq[base + i] = SD_MAKE(n, i, key_base(kk, K, i)); }
+    // ---- the first removeLowCov predicate per candidate; survivors keep their counts (slot qi0 + k; a non-survivor
+    //      leaves its slot unused) and start their sequence-descriptor deque
+    WG_FOR(t, gN * K) {
+      const int k = t / K, i = t - k * K;
+      const uint32_t n = S.g_n[k];
+      const int minqv = (int)S.g_min[k];
+      const float tt = W.gr[n].cov[0] + W.gr[n].cov[1], tn = W.gr[n].cov[2] + W.gr[n].cov[3];
+      const bool low = (minqv <= c.P->low_cov_threshold) || ((double)minqv <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
+      if (!low) {
+        const uint32_t base = (qi0 + (uint32_t)k) * (uint32_t)K;
+        const unsigned long long *kk = W.nkey + (size_t)n * LC_NWMAX;
+        W.seq[base + i] = SD_MAKE(n, i, key_base(kk, K, i));
+      }
     }
     WG_LANE0 {
-      NodeGr &G = W.gr[n];
-      G.mincovqv = minqv;
-      if (!low) {
-        const uint32_t base = qi * (uint32_t)K;
-        G.seq_clo = base; G.seq_lo = base; G.seq_hi = base + K; G.seq_chi = base + K;
-        const uint32_t f = G.flags;
-        G.nkmT = ((f & NF_TUMOR) && !(f & NF_NORMAL)) ? 1u : 0u;      // cov_status == 'T'
-        G.nqv = qi;
-        G.flags = f | NF_SURV;
-        S.qv_top = qi + 1;
+      for (int k = 0; k < gN; ++k) {
+        const uint32_t n = S.g_n[k];
+        NodeGr &G = W.gr[n];
+        const int minqv = (int)S.g_min[k];
+        const float tt = G.cov[0] + G.cov[1], tn = G.cov[2] + G.cov[3];
+        const bool low = (minqv <= c.P->low_cov_threshold) || ((double)minqv <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
+        G.mincovqv = minqv;
+        if (!low) {
+          const uint32_t qi = qi0 + (uint32_t)k, base = qi * (uint32_t)K;
+          G.seq_clo = base; G.seq_lo = base; G.seq_hi = base + K; G.seq_chi = base + K;
+          const uint32_t f = G.flags;
+          G.nkmT = ((f & NF_TUMOR) && !(f & NF_NORMAL)) ? 1u : 0u;      // cov_status == 'T'
+          G.nqv = qi;
+          G.flags = f | NF_SURV;
+        }
       }
-      S.tmp0 = 0x7FFFFFFF;
+      S.qv_top = qi0 + (uint32_t)gN;
     }
+    ci += (uint32_t)gN;
   }
   WG_LANE0 { S.seq_top = S.qv_top * (uint32_t)K; }
   WG_SYNC();
