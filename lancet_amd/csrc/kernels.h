@@ -1022,10 +1022,11 @@ DEV void build_graph(Ctx &c) {
     const uint32_t total = big ? cnt0 : (uint32_t)wg_uniform((int)(S.g_es[gN - 1] + S.g_cnt[gN - 1]));
     for (uint32_t r0 = 0; r0 < total; r0 += LC_STAGE) {
       const int cnt = (int)(total - r0 < LC_STAGE ? total - r0 : LC_STAGE);
-      WG_FOR(ln, LANCET_WG) {   // ---- step 1: entries ln and ln+64 of the staging area
-        uint32_t e[2], m[2][4], meta[2]; bool act[2];
-        const uint32_t *gd[2]; uint32_t ri[2];
-        for (int u = 0; u < 2; ++u) {
+      WG_FOR(ln, LANCET_WG) {   // ---- step 1: entries ln, ln+64, ... of the staging area
+        constexpr int U = LC_STAGE / LANCET_WG;
+        uint32_t e[U], m[U][4], meta[U]; bool act[U];
+        const uint32_t *gd[U]; uint32_t ri[U];
+        for (int u = 0; u < U; ++u) {
           const int j = ln + u * LANCET_WG;
           act[u] = j < cnt;
           e[u] = 0;
@@ -1036,12 +1037,12 @@ DEV void build_graph(Ctx &c) {
             e[u] = W.csr[src];
           }
         }
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
           act[u] = act[u] && CS_ST(e[u]) == 0;
           ri[u] = 0; gd[u] = c.B->good;
           if (act[u]) { const uint32_t g = g0 + CS_READ(e[u]); ri[u] = c.B->rinfo[g]; gd[u] = c.B->good + c.B->good_woff[g]; }
         }
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
           m[u][0] = m[u][1] = m[u][2] = m[u][3] = 0; meta[u] = 0;
           if (act[u]) {
             const int p0 = (int)CS_POS(e[u]), sh = p0 & 31, wv = p0 >> 5;
@@ -1052,7 +1053,7 @@ DEV void build_graph(Ctx &c) {
             meta[u] = 1u | (((RI_NML(ri[u]) ? 2u : 0u) + (RI_REV(ri[u]) ? 1u : 0u)) << 1) | (CS_ORI(e[u]) << 3) | ((e[u] >> 29) << 4);
           }
         }
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
           const int j = ln + u * LANCET_WG;
           if (j < cnt) { S.mk[j][0] = m[u][0]; S.mk[j][1] = m[u][1]; S.mk[j][2] = m[u][2]; S.mk[j][3] = m[u][3]; S.mmeta[j] = meta[u]; }
         }
