@@ -568,9 +568,11 @@ DEV void build_items(Ctx &c) {
       read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref); \
       const int nk = tlen - (S).K + 1; \
       const int pbeg = _b0, pend = (_b0 + (int)(_i1 >> 16) < nk) ? _b0 + (int)(_i1 >> 16) : nk; \
+      (void)_e; (void)_span; \
       if (pend <= pbeg) continue;
 #define ITEMS_SWEEP(p) for (int _t = 0; _t < _span; ++_t) { const int p = pbeg + _t - _e; if (p < pbeg || p >= pend) continue;
 #define ITEMS_END } } }
+#define ITEMS_END_NOSWEEP } }
 
 template <int NW>
 DEV void build_insert_pass(Ctx &c, bool verify) {
@@ -800,14 +802,17 @@ DEV void build_graph(Ctx &c) {
   PHASE(c, 4);
   STOP_RET(c, 4);
   // ---- pass 2a: occurrences slot -> node id; occurrences per node (the only per-occurrence atomic, on a compact array)
+  //      four occurrences per step so that their (independent) table look-ups are in flight together
   ITEMS_BEGIN(c, S, W)
     const uint32_t o0 = W.occ_base[r];
-    ITEMS_SWEEP(p)
-      uint32_t oc = W.occ[o0 + p];
-      uint32_t X = W.slot_node[oc & 0x3FFFFFFFu];
-      dev_atomic_add(&W.nocc[X], 1u);
-      W.occ[o0 + p] = X | (oc & 0x80000000u);
-  ITEMS_END
+    for (int p = pbeg; p < pend; p += 4) {
+      const int nv = pend - p < 4 ? pend - p : 4;
+      uint32_t oc[4], X[4];
+      for (int u = 0; u < 4; ++u) oc[u] = u < nv ? W.occ[o0 + p + u] : 0u;
+      for (int u = 0; u < 4; ++u) X[u] = u < nv ? W.slot_node[oc[u] & 0x3FFFFFFFu] : 0u;
+      for (int u = 0; u < 4; ++u) if (u < nv) { dev_atomic_add(&W.nocc[X[u]], 1u); W.occ[o0 + p + u] = X[u] | (oc[u] & 0x80000000u); }
+    }
+  ITEMS_END_NOSWEEP
   WG_SYNC();
   // ---- mate-overlap prefilter: an occurrence of a candidate read can only be suppressed if the node also holds an
   //      occurrence of its earlier opposite mate.  Node ids of the mate go into a small private open-addressing set;
@@ -857,13 +862,18 @@ DEV void build_graph(Ctx &c) {
   wg_scan(W.nocc, (int)S.N + 1, S);
   ITEMS_BEGIN(c, S, W)
     const uint32_t o0 = W.occ_base[r];
-    ITEMS_SWEEP(p)
-      uint32_t oc = W.occ[o0 + p];
-      uint32_t X = oc & 0x3FFFFFFFu;
-      uint32_t st = isref ? 2u : ((oc & 0x40000000u) ? 1u : 0u);     // the reference read never counts (Graph.cc:265)
-      uint32_t at = W.nocc[X] + dev_atomic_add(&W.nfill[X], 1u);
-      W.csr[at] = CS_MAKE(r, p, oc >> 31, st);
-  ITEMS_END
+    for (int p = pbeg; p < pend; p += 4) {
+      const int nv = pend - p < 4 ? pend - p : 4;
+      uint32_t oc[4], at[4];
+      for (int u = 0; u < 4; ++u) oc[u] = u < nv ? W.occ[o0 + p + u] : 0u;
+      for (int u = 0; u < 4; ++u) at[u] = u < nv ? W.nocc[oc[u] & 0x3FFFFFFFu] : 0u;
+      for (int u = 0; u < 4; ++u) if (u < nv) at[u] += dev_atomic_add(&W.nfill[oc[u] & 0x3FFFFFFFu], 1u);
+      for (int u = 0; u < 4; ++u) if (u < nv) {
+        const uint32_t st = isref ? 2u : ((oc[u] & 0x40000000u) ? 1u : 0u);     // the reference read never counts (Graph.cc:265)
+        W.csr[at[u]] = CS_MAKE(r, p + u, oc[u] >> 31, st);
+      }
+    }
+  ITEMS_END_NOSWEEP
   WG_SYNC();
   // ---- exact replay for what is left (sequential, rare): reproduces std::binary_search over the unsorted vector of
   //      opposite-mate names pushed so far on the node.
