@@ -924,7 +924,24 @@ DEV void build_graph(Ctx &c) {
   //      strand/sample, edges in first-seen order (stamp = 2*occurrence index of the step's u, +1 for the v side),
   //      float coverages.  Everything lands in the node's own record: no scattered updates.
   const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
-  WG_FOR(n, S.N) {
+  // A lane walks all occurrences of its node, and a wave step lasts as long as its busiest lane: visit the nodes grouped
+  // by occurrence count (> 24, 3..24, <= 2) so that the ~85 % one-occurrence (sequencing error) k-mers do not wait for
+  // the high-coverage ones.  perm[] = node ids in that order (two exclusive scans).
+  {
+    uint32_t *fa = W.order, *fb = W.scratch, *perm = W.ht_next;
+    WG_FOR(n, S.N) { const uint32_t cn = W.nocc[n + 1] - W.nocc[n]; fa[n] = cn > 24u; fb[n] = (cn > 2u && cn <= 24u); }
+    WG_LANE0 { fa[S.N] = 0; fb[S.N] = 0; }
+    wg_scan(fa, (int)S.N + 1, S);
+    wg_scan(fb, (int)S.N + 1, S);
+    WG_FOR(n, S.N) {
+      const uint32_t a = fa[n], b = fb[n], ta = fa[S.N], tb = fb[S.N];
+      const bool ia = fa[n + 1] != a, ib = fb[n + 1] != b;
+      perm[ia ? a : (ib ? ta + b : ta + tb + ((uint32_t)n - a - b))] = (uint32_t)n;
+    }
+    WG_SYNC();
+  }
+  WG_FOR(pi, S.N) {
+    const int n = (int)W.ht_next[pi];
     uint32_t ef0 = LC_NIL, ef1 = LC_NIL, ef2 = LC_NIL, ef3 = LC_NIL, ef4 = LC_NIL, ef5 = LC_NIL, ef6 = LC_NIL, ef7 = LC_NIL, ef8 = LC_NIL, ef9 = LC_NIL;
 #define LC_EFMIN(sl, st) do { uint32_t _s = (sl), _v = (st); \
       ef0 = (_s == 0 && _v < ef0) ? _v : ef0; ef1 = (_s == 1 && _v < ef1) ? _v : ef1; ef2 = (_s == 2 && _v < ef2) ? _v : ef2; \
@@ -2458,7 +2475,7 @@ DEV void process_window(Ctx &c, int w) {
     int mapped = 0;
     for (int r = 0; r < nr; ++r) if (RI_MAPPED(B.rinfo[B.read_begin[w] + r])) ++mapped;
     S.tmp0 = mapped;
-    if ((uint32_t)S.R > c.C->reads_cap || S.reflen > LC_MAXW || S.reflen < 1) S.overflow = 1;
+    if ((uint32_t)S.R > c.C->reads_cap || S.R > 0xFFFF || S.reflen > LC_MAXW || S.reflen < 1) S.overflow = 1;   // csr / item words keep the read in 16 bits
     S.hasN = 0;
     for (int i = 0; i < S.reflen && !S.overflow; ++i) if (B.ref_codes[B.ref_off[w] + i] > 3) S.hasN = 1;
     if (mapped > 0) evt(c, EV_PROCESS, (uint32_t)nr, (uint32_t)mapped);

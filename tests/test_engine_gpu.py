@@ -108,3 +108,18 @@ def test_overflowed_windows_are_rerun_with_worst_case_workspace(monkeypatch):
     assert variants == ov
     assert [s["status"] for s in stats] == [s["status"] for s in ostats]
     eng.close()
+
+
+def test_linked_reads_tier2_rerun_and_determinism(monkeypatch):
+    """--linked-reads through the worst-case work space (tier 1 forced to overflow) gives the same records as the
+    oracle; twice the same batch gives the same answer."""
+    meta, batch, kept, (min_k, max_k) = gu.case_batch("lr30")
+    p = abi.default_params(min_k=min_k, max_k=max_k, lr_mode=1)
+    ov, ostats, _ = oracle.run(batch, p)
+    monkeypatch.setenv("LANCET_NODE_CAP1", "256")
+    eng = engine.Engine(p)
+    a, sa = eng.process(batch)
+    assert eng.rerun_count() > 0
+    b, sb = eng.process(batch)
+    eng.close()
+    assert a == ov and a == b and sa == sb
