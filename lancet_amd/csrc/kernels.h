@@ -48,6 +48,7 @@ struct WinShared {
   uint32_t part[LANCET_WG + 1];
   uint32_t part2[LANCET_WG + 1];                 // second scan scratch (part[0..7] carry the path loop's state)
   int wk[4];                                     // walk_prepare: match / snp / ins / del columns
+  int ps_first, ps_len, ps_hd;                   // path_string_wg: first real node, length ; Hamming distance to the reference
   int wk_n;                                      // walk_prepare: number of non-match columns
   uint32_t mk[LC_STAGE][4], mmeta[LC_STAGE];     // staged quality masks of up to LC_STAGE occurrences
   uint32_t g_n[LC_PACK], g_lo[LC_PACK], g_cnt[LC_PACK], g_es[LC_PACK], g_min[LC_PACK], g_N;   // the candidates of the current group
@@ -1211,7 +1212,7 @@ DEV void build_graph(Ctx &c) {
 // Hence after processing Q the list is: runs ordered by the position of their first element in Q, latest first;
 // inside a run, latest first.  Q of a stage = (list of the previous stage, then the node ids inserted before the next
 // rehash).  Each stage is a counting sort by (first position of the bucket desc, position desc): all parallel.
-// The first 541 insertions (6 small stages) are replayed sequentially.
+// The first 127 insertions (4 small stages) are replayed sequentially.
 // ---------------------------------------------------------------------------------------------------------
 DEV void order_stage(Ctx &c, const uint32_t *Q, uint32_t *Qn, int n, uint32_t B) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
@@ -1250,7 +1251,7 @@ DEV void order_stage(Ctx &c, const uint32_t *Q, uint32_t *Qn, int n, uint32_t B)
 // the live table in libstdc++ iteration order -> order[0..M)
 DEV void first_lowcov(Ctx &c) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
-  const uint32_t SEQ = 541u;                            // a value of the growth chain
+  const uint32_t SEQ = 127u;                            // a value of the growth chain
   WG_LANE0 {
     ht_reset(c);
     uint32_t lim = S.N < SEQ ? S.N : SEQ;
@@ -1883,6 +1884,46 @@ DEVNI int path_string(Ctx &c, int n) {
   }
   return len;
 }
+// The same string and descriptors with all lanes: contribution length of every path node (special nodes none, the first
+// real node whole, the others without the K-1 overlap), exclusive scan, then one lane per output base.
+DEV int path_string_wg(Ctx &c, int n) {
+  Work &W = *c.W; volatile WinShared &S = *c.S;
+  const int K = S.K;
+  const int dcap = 7 * (LC_MAXW + 2);
+  if (2 * (n + 1) > dcap || n < 2) { WG_LANE0 { S.ps_len = path_string(c, n); } return wg_bcast(&S.ps_len); }
+  uint32_t *off = (uint32_t *)W.dp, *pdir = off + (n + 1);
+  WG_LANE0 { S.ps_first = 0x7FFFFFFF; off[n] = 0; }
+  WG_FOR(i, n) {
+    const uint32_t nd = W.pnodes[i];
+    if (!(W.gr[nd].flags & NF_SPECIAL)) dev_atomic_min((uint32_t *)&S.ps_first, (uint32_t)i);
+    const uint32_t pe = W.pedges[i == 0 ? 1 : i];
+    const uint32_t e = W.gr[pe >> 4].edges[pe & 15u];
+    pdir[i] = (uint32_t)(i == 0 ? dir_start(ED_DIR(e)) : dir_dest(ED_DIR(e)));
+  }
+  WG_SYNC();
+  const int f = wg_uniform(S.ps_first);
+  WG_FOR(i, n) {
+    const uint32_t nd = W.pnodes[i];
+    const int L = n_len(c, nd);
+    off[i] = (W.gr[nd].flags & NF_SPECIAL) ? 0u : (uint32_t)(i == f ? L : L - (K - 1));
+  }
+  WG_SYNC();
+  wg_scan(off, n + 1, S, S.part2);
+  const int plen = (int)wg_uniform((int)S.part2[LANCET_WG]);
+  if (plen > (int)c.C->path_cap) { WG_LANE0 { OVF(c); } return 0; }
+  WG_FOR(x, plen) {
+    int lo = 0, hi = n - 1;                                    // last node whose offset is <= x and that contributes
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)off[mid] <= x) lo = mid; else hi = mid - 1; }
+    while (lo > 0 && off[lo + 1] == off[lo]) --lo;             // (special nodes and empty contributions share an offset)
+    const uint32_t nd = W.pnodes[lo];
+    const uint32_t slo = W.gr[nd].seq_lo, shi = W.gr[nd].seq_hi;
+    const uint32_t j = (uint32_t)(x - (int)off[lo]) + (lo == f ? 0u : (uint32_t)(K - 1));
+    const uint32_t d = (pdir[lo] == (uint32_t)'R') ? (W.seq[shi - 1 - j] ^ 3u) : W.seq[slo + j];
+    W.pdesc[x] = d; W.pseq[x] = (uint8_t)SD_BASE(d);
+  }
+  WG_SYNC();
+  return plen;
+}
 DEV uint32_t path_contig(const Ctx &c, int n, int pos) {            // Path_t::pathcontig, reference src/Path.cc:291-314
   const Work &W = *c.W;
   int cur = 0;
@@ -2379,8 +2420,10 @@ DEV bool repeats_in_graph_paths(Ctx &c) {
     WG_LANE0 {
       uint32_t best = bfs(c);
       if (best == LC_NIL || S.overflow) S.tmp0 = 1;
-      else { S.tmp2 = path_unpack(c, best); S.tmp3 = path_string(c, S.tmp2); if (S.overflow) S.tmp0 = 1; }
+      else S.tmp2 = path_unpack(c, best);
     }
+    if (wg_bcast(&S.tmp0) != 0) break;
+    { const int pl = path_string_wg(c, wg_bcast(&S.tmp2)); WG_LANE0 { S.tmp3 = pl; if (S.overflow) S.tmp0 = 1; } }
     if (wg_bcast(&S.tmp0) != 0) break;
     repeat_scan(S, W.pseq, wg_bcast(&S.tmp3), c.P->max_mismatch, &S.repE, &S.repM);      // isAlmostRepeat(path->str(), K, MAX_MISMATCH)
     WG_LANE0 {
@@ -2414,18 +2457,26 @@ DEV void count_ref_path(Ctx &c) {
           if (S.tmp3) ++S.part[2];
           ++S.part[1];
           S.part[4] = (uint32_t)path_unpack(c, best);
-          S.part[5] = (uint32_t)path_string(c, (int)S.part[4]);
-          // Hamming short-cut (reference src/Graph.cc:818-826)
-          int n = S.seq_len, m = (int)S.part[5];
-          const uint8_t *rs = c.B->ref_codes + c.B->ref_off[S.w] + S.seq_t5;
-          int hd = -1;
-          if (n == m) { hd = 0; for (int i = 0; i < n; ++i) if (rs[i] != W.pseq[i]) ++hd; }
-          S.part[6] = (hd == -1 || hd > 5) ? 1u : 0u;
-          if (!S.part[6]) {
-            const int cap = LC_MAXW + (int)c.C->path_cap + 2;
-            for (int i = 0; i < n; ++i) { W.aln[i] = "ACGTN"[rs[i]]; W.aln[cap + i] = "ACGT"[W.pseq[i]]; }
-            S.part[7] = (uint32_t)n;
-          }
+        }
+      }
+      if (wg_bcastu(&S.part[3]) != 0) break;
+      {
+        const int m = path_string_wg(c, (int)wg_bcastu(&S.part[4]));
+        // Hamming short-cut (reference src/Graph.cc:818-826)
+        const int n = wg_bcast(&S.seq_len);
+        const uint8_t *rs = c.B->ref_codes + c.B->ref_off[S.w] + S.seq_t5;
+        WG_LANE0 { S.ps_hd = 0; }
+        if (n == m) { WG_FOR(i, n) { if (rs[i] != W.pseq[i]) dev_atomic_add((uint32_t *)&S.ps_hd, 1u); } }
+        WG_SYNC();
+        const int hd = (n == m) ? wg_uniform(S.ps_hd) : -1;
+        const bool need_align = (hd == -1 || hd > 5);
+        if (!need_align) {
+          const int cap = LC_MAXW + (int)c.C->path_cap + 2;
+          WG_FOR(i, n) { W.aln[i] = "ACGTN"[rs[i]]; W.aln[cap + i] = "ACGT"[W.pseq[i]]; }
+        }
+        WG_LANE0 {
+          S.part[5] = (uint32_t)m; S.part[6] = need_align ? 1u : 0u;
+          if (!need_align) S.part[7] = (uint32_t)n;
           if (n > LC_MAXW || n < 1 || m < 1) OVF(c);
           if (S.overflow) S.part[3] = 1;
         }
