@@ -1212,7 +1212,7 @@ DEV void build_graph(Ctx &c) {
 // Hence after processing Q the list is: runs ordered by the position of their first element in Q, latest first;
 // inside a run, latest first.  Q of a stage = (list of the previous stage, then the node ids inserted before the next
 // rehash).  Each stage is a counting sort by (first position of the bucket desc, position desc): all parallel.
-// The first 127 insertions (4 small stages) are replayed sequentially.
+// The first 29 insertions (2 small stages) are replayed sequentially.
 // ---------------------------------------------------------------------------------------------------------
 DEV void order_stage(Ctx &c, const uint32_t *Q, uint32_t *Qn, int n, uint32_t B) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
@@ -1251,7 +1251,7 @@ DEV void order_stage(Ctx &c, const uint32_t *Q, uint32_t *Qn, int n, uint32_t B)
 // the live table in libstdc++ iteration order -> order[0..M)
 DEV void first_lowcov(Ctx &c) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
-  const uint32_t SEQ = 127u;                            // a value of the growth chain
+  const uint32_t SEQ = 29u;                             // a value of the growth chain
   WG_LANE0 {
     ht_reset(c);
     uint32_t lim = S.N < SEQ ? S.N : SEQ;

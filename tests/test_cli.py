@@ -64,3 +64,22 @@ def test_cli_end_to_end_vcf_is_byte_identical_to_the_reference():
     body = "".join(l + "\n" for l in text.splitlines()
                    if not l.startswith("##fileDate") and not l.startswith("##cmdline") and not l.startswith("##reference"))
     assert body == gu.golden_vcf("ar_small")
+
+
+def test_bam_reader_decodes_barcode_and_haplotype_tags():
+    meta, ref, rname, reads = gu.load_case("lr_small")
+    for rg in ("tumor", "normal"):
+        _, got = bamio.read_bam(os.path.join(G, f"lr_small.{rg}.bam"))
+        assert [(r.qname, r.flag, r.tags.get("BX"), r.tags.get("HP")) for r in got] == \
+               [(r.qname, r.flag, r.tags.get("BX"), r.tags.get("HP")) for r in reads[rg]]
+
+
+@pytest.mark.gpu
+def test_cli_linked_reads_end_to_end_vcf_is_byte_identical_to_the_reference():
+    out = io.StringIO()
+    argv = ["--tumor", os.path.join(G, "lr_small.tumor.bam"), "--normal", os.path.join(G, "lr_small.normal.bam"),
+            "--ref", os.path.join(G, "lr_small.fa"), "--reg", "chr22:800-2700", "--linked-reads"]
+    assert cli.run(argv, out=out, date_line="Sun Sep 27 05:27:00 2026\n") == 0
+    body = "".join(l + "\n" for l in out.getvalue().splitlines()
+                   if not l.startswith("##fileDate") and not l.startswith("##cmdline") and not l.startswith("##reference"))
+    assert body == gu.golden_vcf("lr_small")

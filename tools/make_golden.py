@@ -63,6 +63,10 @@ CASES = {
     # are committed too (tests/golden/ar_small.*): they are the fixture of the BAM reader and of the CLI test.
     "ar_small": (dict(ref_len=4000, cov_t=28, cov_n=24, ref_seed=51, tumor_seed=151, normal_seed=251,
                       somatic_every=900, germline_every=700), "chr22:900-3000", ["--active-region-on"]),
+    # linked reads through the whole command line (BX:Z / HP:i decoded from BAM), active regions on; inputs committed
+    "lr_small": (dict(ref_len=3600, cov_t=30, cov_n=26, ref_seed=61, tumor_seed=161, normal_seed=261, linked=True,
+                      insert_mean=300.0, insert_sd=40.0, somatic_every=700, germline_every=600), "chr22:800-2700",
+                 ["--linked-reads", "--active-region-on"]),
     "dups": (dict(ref_len=8000, cov_t=40, cov_n=40, ref_seed=5, tumor_seed=15, normal_seed=25, dup_prob=1.0,
                   somatic_every=600, germline_every=500, read_len=100), "chr22:1000-6500", []),
 }
