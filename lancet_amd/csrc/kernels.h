@@ -235,7 +235,7 @@ DEV void repeat_scan_bytes(const uint8_t *s, int len, int mm, volatile int *outE
 // mismatch flags of 16 positions out of two unaligned 64-bit words.  Only mismatch positions are visited:
 // with last[j] = position of the (j+1)-th most recent mismatch, the longest exact run ending before a mismatch q is
 // q-1-last[0] and the longest window with <= mm mismatches ending there is q-1-last[mm] (the two-pointer window).
-DEV void repeat_scan(volatile WinShared &S, const uint8_t *s, int len, int mm, volatile int *outE, volatile int *outM) {
+DEVNI void repeat_scan(volatile WinShared &S, const uint8_t *s, int len, int mm, volatile int *outE, volatile int *outM) {
   if (mm > 7 || mm < 0 || len + 48 > 16 * LC_RS_WORDS) { repeat_scan_bytes(s, len, mm, outE, outM); return; }
   WG_LANE0 { *outE = 0; *outM = 0; }
   const int nwords = len / 16 + 3;
@@ -536,7 +536,7 @@ DEV bool nk_is_forward(const uint8_t *ref, int p, int K) {                      
 // c-th group of LANCET_WG items.  The sweep offset lines the lanes of a group up on the same genome position
 // (reads arrive in coordinate order per sample, so rank * (W - len) / n is a fair estimate of a read's start): at a
 // given step the lanes then touch the same few table slots / nodes, which the L2 can coalesce.
-DEV void build_items(Ctx &c) {
+DEVNI void build_items(Ctx &c) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   WG_LANE0 {
     const uint32_t g0 = c.B->read_begin[S.w];
@@ -576,7 +576,7 @@ DEV void build_items(Ctx &c) {
 #define ITEMS_END_NOSWEEP } }
 
 template <int NW>
-DEV void build_insert_pass(Ctx &c, bool verify) {
+DEVNI void build_insert_pass(Ctx &c, bool verify) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   const int K = S.K;
   const uint32_t mask = c.C->table_cap - 1;
@@ -721,9 +721,12 @@ DEVNI void lr_node_replay(Ctx &c, uint32_t lo, uint32_t hi, uint32_t *out) {
   for (int j = 0; j < 3; ++j) { out[4 + j] = LC_PK(hpwT, j); out[7 + j] = LC_PK(hpwN, j); }
 }
 
-DEV void build_graph(Ctx &c) {
+// buildgraph is cut into separately compiled pieces (DEVNI): one register allocation per phase instead of one for the
+// whole window program, which kept values of later phases alive (and spilled) across the hot loops of earlier ones.
+DEVNI void build_tables(Ctx &c) {
   volatile WinShared &S = *c.S; Work &W = *c.W; const EngineCaps &C = *c.C;
   const int K = S.K;
+  (void)C; (void)K; (void)W;
   // ---- occurrence index space: read r owns [occ_base[r], occ_base[r+1]) = its k-mers p = 0..tlen-K
   WG_LANE0 {
     uint32_t o = 0; int bp = 0;
@@ -800,8 +803,11 @@ DEV void build_graph(Ctx &c) {
   }
   WG_LANE0 { S.tmp1 = 0; W.nocc[S.N] = 0; }
   WG_SYNC();
-  PHASE(c, 4);
-  STOP_RET(c, 4);
+}
+DEVNI void build_csr(Ctx &c) {
+  volatile WinShared &S = *c.S; Work &W = *c.W; const EngineCaps &C = *c.C;
+  const int K = S.K;
+  (void)C; (void)K; (void)W;
   // ---- pass 2a: occurrences slot -> node id; occurrences per node (the only per-occurrence atomic, on a compact array)
   //      four occurrences per step so that their (independent) table look-ups are in flight together
   ITEMS_BEGIN(c, S, W)
@@ -919,8 +925,11 @@ DEV void build_graph(Ctx &c) {
     S.seq_top = 0; S.qv_top = 0;
   }
   WG_SYNC();
-  PHASE(c, 5);
-  STOP_RET(c, 5);
+}
+DEVNI void build_gather(Ctx &c) {
+  volatile WinShared &S = *c.S; Work &W = *c.W; const EngineCaps &C = *c.C;
+  const int K = S.K;
+  (void)C; (void)K; (void)W;
   // ---- per node, gathering over its occurrences (reference src/Graph.cc:163-349): colours, counted occurrences per
   //      strand/sample, edges in first-seen order (stamp = 2*occurrence index of the step's u, +1 for the v side),
   //      float coverages.  Everything lands in the node's own record: no scattered updates.
@@ -1018,7 +1027,12 @@ DEV void build_graph(Ctx &c) {
   wg_scan(W.order, (int)S.N + 1, S);
   WG_FOR(n, S.N) { if (W.order[n + 1] != W.order[n]) W.pnodes[W.order[n]] = (uint32_t)n; }
   WG_SYNC();
-  PHASE(c, 6);
+}
+DEVNI void build_qcounts(Ctx &c) {
+  volatile WinShared &S = *c.S; Work &W = *c.W; const EngineCaps &C = *c.C;
+  const int K = S.K;
+  (void)C; (void)K; (void)W;
+  const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
   // ---- undecided nodes: number of counted reads whose base passes MIN_QUAL_CALL, per k-mer position and strand/sample
   //      (Node_t::updateCovDistr minqv_fwd/minqv_rev, reference src/Node.cc:470-497).  Up to LC_PACK consecutive
   //      candidates are handled together as long as their occurrences fit the LDS staging area (a bigger one goes alone,
@@ -1168,6 +1182,11 @@ DEV void build_graph(Ctx &c) {
   }
   WG_LANE0 { S.seq_top = S.qv_top * (uint32_t)K; }
   WG_SYNC();
+}
+DEVNI void build_refcov(Ctx &c) {
+  volatile WinShared &S = *c.S; Work &W = *c.W; const EngineCaps &C = *c.C;
+  const int K = S.K;
+  (void)C; (void)K; (void)W;
   // ---- Ref_t::mertable membership (indexMers over the possibly trimmed seq, reference src/Ref.cc:40-64)
   {
     uint32_t ro = W.occ_base[S.R - 1];
@@ -1201,6 +1220,22 @@ DEV void build_graph(Ctx &c) {
     }
     WG_SYNC_FENCE();   // from here on the node arrays are only touched with plain loads/stores: one L1 invalidate
   }
+}
+DEV void build_graph(Ctx &c) {
+  build_tables(c);
+  if (wg_bcast(&c.S->overflow)) return;
+  PHASE(c, 4);
+  STOP_RET(c, 4);
+  build_csr(c);
+  if (wg_bcast(&c.S->overflow)) return;
+  PHASE(c, 5);
+  STOP_RET(c, 5);
+  build_gather(c);
+  if (wg_bcast(&c.S->overflow)) return;
+  PHASE(c, 6);
+  build_qcounts(c);
+  if (wg_bcast(&c.S->overflow)) return;
+  build_refcov(c);
   STOP_RET(c, 6);
 }
 
@@ -1214,7 +1249,7 @@ DEV void build_graph(Ctx &c) {
 // rehash).  Each stage is a counting sort by (first position of the bucket desc, position desc): all parallel.
 // The first 29 insertions (2 small stages) are replayed sequentially.
 // ---------------------------------------------------------------------------------------------------------
-DEV void order_stage(Ctx &c, const uint32_t *Q, uint32_t *Qn, int n, uint32_t B) {
+DEVNI void order_stage(Ctx &c, const uint32_t *Q, uint32_t *Qn, int n, uint32_t B) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   uint32_t *bkt = W.scratch, *tmp = W.scratch + c.C->node_cap;
   uint32_t *first = W.ht_bucket, *cnt = W.ht_cnt, *start = W.ht_start, *out = W.ht_next;
@@ -1249,7 +1284,7 @@ DEV void order_stage(Ctx &c, const uint32_t *Q, uint32_t *Qn, int n, uint32_t B)
 }
 
 // the live table in libstdc++ iteration order -> order[0..M)
-DEV void first_lowcov(Ctx &c) {
+DEVNI void first_lowcov(Ctx &c) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   const uint32_t SEQ = 29u;                             // a value of the growth chain
   WG_LANE0 {
@@ -1280,7 +1315,7 @@ DEV void first_lowcov(Ctx &c) {
 }
 
 // cleanDead over the whole table (reference src/Graph.cc:2737-2762), parallel: compaction of order[] keeping the order
-DEV void clean_dead_wg(Ctx &c) {
+DEVNI void clean_dead_wg(Ctx &c) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   const int M = (int)wg_bcastu(&S.M);
   uint32_t *keep = W.scratch;
@@ -1391,7 +1426,7 @@ DEV uint32_t cmp_link(const Ctx &c, uint32_t n, char dir, bool *irregular) {
   if (ED_TO(c.W->gr[b].edges[buid]) != n) { *irregular = true; return 0u; }
   return CL_VALID | (edir << 28) | b;
 }
-DEV void compress_prepare(Ctx &c, int comp) {
+DEVNI void compress_prepare(Ctx &c, int comp) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   const int K = S.K;
   WG_LANE0 { S.cmp_ok = 1; }
@@ -1678,7 +1713,7 @@ DEV uint32_t special_new(Ctx &c, bool issource, int comp) {
 // The two scans of markRefEnds (reference src/Graph.cc:2060-2110) over all reference offsets, in parallel:
 // mr_src / mr_snk = first / last offset whose node is live, has getTotCov() >= COV_THRESHOLD and is in the component
 // (-1 if none); mr_ambs / mr_ambk = the same node qualifies again further on (the reference then gives up).
-DEV void mark_ref_scan(Ctx &c, int comp) {
+DEVNI void mark_ref_scan(Ctx &c, int comp) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   const int K = S.K;
   const uint32_t ro = W.occ_base[S.R - 1];
@@ -1886,7 +1921,7 @@ DEVNI int path_string(Ctx &c, int n) {
 }
 // The same string and descriptors with all lanes: contribution length of every path node (special nodes none, the first
 // real node whole, the others without the K-1 overlap), exclusive scan, then one lane per output base.
-DEV int path_string_wg(Ctx &c, int n) {
+DEVNI int path_string_wg(Ctx &c, int n) {
   Work &W = *c.W; volatile WinShared &S = *c.S;
   const int K = S.K;
   const int dcap = 7 * (LC_MAXW + 2);
@@ -2252,7 +2287,7 @@ DEVNI void emit_variant(Ctx &c, const TS &t, const uint16_t cov[8], int strLen, 
 // after it (prefix counts of non-gap characters), the list of the columns that are not matches, and the four
 // column-type counts.  The walk (lane 0) then visits only the non-match columns instead of all of them.
 //   scratch[0..L) = pos_in_ref, scratch[L+1..2L+1) = pathpos - (column consumes a path base), scratch[2L+2..] = column list
-DEV void walk_prepare(Ctx &c, int L) {
+DEVNI void walk_prepare(Ctx &c, int L) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   const int cap = LC_MAXW + (int)c.C->path_cap + 2;
   const uint8_t *ra = W.aln, *pa = W.aln + cap;
@@ -2407,7 +2442,7 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
 // ---------------------------------------------------------------------------------------------------------
 // returns true when a near-perfect repeat is found in a source->sink path (Graph_t::findRepeatsInGraphPaths,
 // reference src/Graph.cc:686-730)
-DEV bool repeats_in_graph_paths(Ctx &c) {
+DEVNI bool repeats_in_graph_paths(Ctx &c) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   WG_LANE0 {
     evt(c, EV_LOOKREP);
@@ -2442,7 +2477,7 @@ DEV bool repeats_in_graph_paths(Ctx &c) {
 }
 
 // eka (reference src/Graph.cc:1430-1501) via countRefPath (:2420-2445)
-DEV void count_ref_path(Ctx &c) {
+DEVNI void count_ref_path(Ctx &c) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   if (wg_bcastu(&S.source) == LC_NIL) return;
   if (wg_bcastu(&S.sink) != LC_NIL) {
