@@ -809,17 +809,13 @@ DEVNI void build_csr(Ctx &c) {
   const int K = S.K;
   (void)C; (void)K; (void)W;
   // ---- pass 2a: occurrences slot -> node id; occurrences per node (the only per-occurrence atomic, on a compact array)
-  //      four occurrences per step so that their (independent) table look-ups are in flight together
-  ITEMS_BEGIN(c, S, W)
-    const uint32_t o0 = W.occ_base[r];
-    for (int p = pbeg; p < pend; p += 4) {
-      const int nv = pend - p < 4 ? pend - p : 4;
-      uint32_t oc[4], X[4];
-      for (int u = 0; u < 4; ++u) oc[u] = u < nv ? W.occ[o0 + p + u] : 0u;
-      for (int u = 0; u < 4; ++u) X[u] = u < nv ? W.slot_node[oc[u] & 0x3FFFFFFFu] : 0u;
-      for (int u = 0; u < 4; ++u) if (u < nv) { dev_atomic_add(&W.nocc[X[u]], 1u); W.occ[o0 + p + u] = X[u] | (oc[u] & 0x80000000u); }
-    }
-  ITEMS_END_NOSWEEP
+  //      occurrence-major (lane = consecutive occurrence index): occ[] is read and rewritten in whole cache lines
+  WG_FOR(o, S.O) {
+    const uint32_t oc = W.occ[o];
+    const uint32_t X = W.slot_node[oc & 0x3FFFFFFFu];
+    dev_atomic_add(&W.nocc[X], 1u);
+    W.occ[o] = X | (oc & 0x80000000u);
+  }
   WG_SYNC();
   // ---- mate-overlap prefilter: an occurrence of a candidate read can only be suppressed if the node also holds an
   //      occurrence of its earlier opposite mate.  Node ids of the mate go into a small private open-addressing set;
@@ -867,20 +863,20 @@ DEVNI void build_csr(Ctx &c) {
   WG_SYNC();
   // ---- csr of occurrences by node
   wg_scan(W.nocc, (int)S.N + 1, S);
-  ITEMS_BEGIN(c, S, W)
-    const uint32_t o0 = W.occ_base[r];
-    for (int p = pbeg; p < pend; p += 4) {
-      const int nv = pend - p < 4 ? pend - p : 4;
-      uint32_t oc[4], at[4];
-      for (int u = 0; u < 4; ++u) oc[u] = u < nv ? W.occ[o0 + p + u] : 0u;
-      for (int u = 0; u < 4; ++u) at[u] = u < nv ? W.nocc[oc[u] & 0x3FFFFFFFu] : 0u;
-      for (int u = 0; u < 4; ++u) if (u < nv) at[u] += dev_atomic_add(&W.nfill[oc[u] & 0x3FFFFFFFu], 1u);
-      for (int u = 0; u < 4; ++u) if (u < nv) {
-        const uint32_t st = isref ? 2u : ((oc[u] & 0x40000000u) ? 1u : 0u);     // the reference read never counts (Graph.cc:265)
-        W.csr[at[u]] = CS_MAKE(r, p + u, oc[u] >> 31, st);
-      }
+  {
+    // occurrence-major again; the read of an occurrence index is found by walking occ_base[] forward (a lane's indices
+    // only grow), its position in the read is the offset from the read's first occurrence
+    uint32_t rcur = 0;
+    const uint32_t refr = (uint32_t)(S.R - 1);
+    WG_FOR(o, S.O) {
+      while (rcur < refr && (uint32_t)o >= W.occ_base[rcur + 1]) ++rcur;
+      const uint32_t oc = W.occ[o];
+      const uint32_t X = oc & 0x3FFFFFFFu;
+      const uint32_t st = rcur == refr ? 2u : ((oc & 0x40000000u) ? 1u : 0u);     // the reference read never counts (Graph.cc:265)
+      const uint32_t at = W.nocc[X] + dev_atomic_add(&W.nfill[X], 1u);
+      W.csr[at] = CS_MAKE(rcur, (uint32_t)o - W.occ_base[rcur], oc >> 31, st);
     }
-  ITEMS_END_NOSWEEP
+  }
   WG_SYNC();
   // ---- exact replay for what is left (sequential, rare): reproduces std::binary_search over the unsorted vector of
   //      opposite-mate names pushed so far on the node.
