@@ -118,6 +118,7 @@ def main():
                     if rec["windows"] == args.windows and rec["coverage"] == args.cov and world == 1:
                         out["roofline"]["traffic"] = int((rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024)
                         out["roofline"]["traffic_note"] = rec["note"]
+                        break
         except (OSError, KeyError, ValueError):
             pass
         if args.cpu_sample and world == 1:
