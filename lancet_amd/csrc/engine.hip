@@ -188,7 +188,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   bw[R] = bo; gw[R] = go;
   UP(e->d_bw, bw.data(), sizeof(uint32_t) * (R + 1));
   UP(e->d_gw, gw.data(), sizeof(uint32_t) * (R + 1));
-  ENS(e->d_bases, sizeof(uint32_t) * (bo + 1)); ENS(e->d_good, sizeof(uint32_t) * (go + 1)); ENS(e->d_rinfo, sizeof(uint32_t) * (R + 1));
+  ENS(e->d_bases, sizeof(uint32_t) * (bo + 4));   /* (the occurrence-major insert reads up to two words past a k-mer) */ ENS(e->d_good, sizeof(uint32_t) * (go + 1)); ENS(e->d_rinfo, sizeof(uint32_t) * (R + 1));
   ENS(e->d_refcodes, nref + 1);
   DBG("prep launch");
   // ---- prep on the device: Graph_t::trim + packing, reference -> codes

@@ -625,7 +625,7 @@ DEVNI void build_insert_pass(Ctx &c, bool verify) {
             unsigned long long old = dev_atomic_cas64(&W.tags[idx], 0ULL, h);
             if (old == 0) {
               if (nk_) W.slot_key[(size_t)idx * LC_NWMAX] = ((unsigned long long)p << 1) | (isF ? 0ULL : 1ULL);   // where the string lives
-              else for (int w = 0; w < NW; ++w) W.slot_key[(size_t)idx * LC_NWMAX + w] = ck[w];
+              else if (!(NW == 1 && K <= 31)) for (int w = 0; w < NW; ++w) W.slot_key[(size_t)idx * LC_NWMAX + w] = ck[w];   // (k <= 31: the tag is the key + 1)
               break;
             }
             if (old == h) break;
@@ -646,6 +646,56 @@ DEVNI void build_insert_pass(Ctx &c, bool verify) {
         }
       }
   ITEMS_END
+  WG_SYNC();
+}
+
+// The common case (k <= 31, no N in the window reference) occurrence-major: lane = consecutive occurrence index, the
+// k-mer is cut out of the read's packed bases instead of being rolled along the read, so that neighbouring lanes read
+// the same words and occ[] is written in whole cache lines.  Same table protocol as build_insert_pass (exact tags).
+//   packed bases are little-endian (base j of the k-mer at bits 2j): the reverse-complement key of key_push_rc is the
+//   complement of exactly that; the forward key of key_push_fw is the same bases with the 2-bit groups reversed.
+DEVNI void build_insert_occ_major(Ctx &c) {
+  volatile WinShared &S = *c.S; Work &W = *c.W;
+  const int K = S.K;
+  const uint32_t mask = c.C->table_cap - 1;
+  const unsigned long long kmask = (K == 32) ? ~0ULL : ((1ULL << (2 * K)) - 1ULL);
+  const uint32_t refr = (uint32_t)(S.R - 1);
+  const uint32_t g0 = c.B->read_begin[S.w];
+  const uint8_t *refc = c.B->ref_codes + c.B->ref_off[S.w];
+  uint32_t rcur = 0;
+  WG_FOR(o, S.O) {
+    while (rcur < refr && (uint32_t)o >= W.occ_base[rcur + 1]) ++rcur;
+    const int p = (int)((uint32_t)o - W.occ_base[rcur]);
+    unsigned long long v = 0;                                    // base j of the k-mer at bits 2j
+    if (rcur == refr) { for (int j = 0; j < K; ++j) v |= (unsigned long long)(refc[p + j] & 3) << (2 * j); }
+    else {
+      const uint32_t *bp = c.B->bases + c.B->base_woff[g0 + rcur] + (uint32_t)(p >> 4);
+      const int sh = (p & 15) * 2;
+      const unsigned long long lo = (unsigned long long)bp[0] | ((unsigned long long)bp[1] << 32);
+      v = sh ? ((lo >> sh) | ((unsigned long long)bp[2] << (64 - sh))) : lo;
+      v &= kmask;
+    }
+    const unsigned long long rc = (~v) & kmask;
+    unsigned long long fw = dev_brev64(v);
+    fw = ((fw >> 1) & 0x5555555555555555ULL) | ((fw & 0x5555555555555555ULL) << 1);
+    fw >>= (64 - 2 * K);
+    const bool isF = fw < rc;                                    // CanonicalMer_t::set: mer < rmer -> F, tie -> R
+    const unsigned long long h = (isF ? fw : rc) + 1ULL;         // tag == key + 1: exact
+    uint32_t idx = (uint32_t)mix64(h) & mask;
+    uint32_t probes = 0;
+    while (true) {
+      const unsigned long long cur = ld2(&W.tags[idx]);
+      if (cur == h) break;
+      if (cur == 0) {
+        const unsigned long long old = dev_atomic_cas64(&W.tags[idx], 0ULL, h);
+        if (old == 0 || old == h) break;
+      }
+      idx = (idx + 1) & mask;
+      if (++probes > mask) { OVF(c); break; }
+    }
+    dev_atomic_min(&W.slot_first[idx], (uint32_t)o);
+    W.occ[o] = idx | (isF ? 0u : 0x80000000u);
+  }
   WG_SYNC();
 }
 
@@ -748,8 +798,9 @@ DEVNI void build_tables(Ctx &c) {
   WG_SYNC();
   PHASE(c, 2);
   // ---- pass 1: canonical k-mers -> open-addressing slots
-  switch (S.NW) { case 1: build_insert_pass<1>(c, false); break; case 2: build_insert_pass<2>(c, false); break;
-                  case 3: build_insert_pass<3>(c, false); break; default: build_insert_pass<4>(c, false); break; }
+  if (K <= 31 && !S.hasN) build_insert_occ_major(c);
+  else switch (S.NW) { case 1: build_insert_pass<1>(c, false); break; case 2: build_insert_pass<2>(c, false); break;
+                       case 3: build_insert_pass<3>(c, false); break; default: build_insert_pass<4>(c, false); break; }
   if (K > 31 || S.hasN) {   // 64-bit tags of longer keys / of N k-mers can collide: compare the full keys
     switch (S.NW) { case 1: build_insert_pass<1>(c, true); break; case 2: build_insert_pass<2>(c, true); break;
                     case 3: build_insert_pass<3>(c, true); break; default: build_insert_pass<4>(c, true); break; }
@@ -771,7 +822,9 @@ DEVNI void build_tables(Ctx &c) {
       uint32_t f = ld2(&W.slot_first[i]);
       uint32_t id = W.bitpre[f >> 5] + (uint32_t)dev_popc(ld2(&W.bitmap[f >> 5]) & ((1u << (f & 31)) - 1u));
       W.slot_node[i] = id;
-      for (int w = 0; w < S.NW; ++w) W.nkey[(size_t)id * LC_NWMAX + w] = W.slot_key[(size_t)i * LC_NWMAX + w];
+      const unsigned long long tg = ld2(&W.tags[i]);
+      if (S.NW == 1 && K <= 31 && !(tg >> 63)) W.nkey[(size_t)id * LC_NWMAX] = tg - 1ULL;            // exact tag: key + 1
+      else for (int w = 0; w < S.NW; ++w) W.nkey[(size_t)id * LC_NWMAX + w] = W.slot_key[(size_t)i * LC_NWMAX + w];
       W.gr[id].flags = (ld2(&W.tags[i]) >> 63) ? NF_NKMER : 0u;
     }
   }

@@ -41,6 +41,7 @@ DEV unsigned long long dev_atomic_cas64(unsigned long long *p, unsigned long lon
 DEV uint32_t ld2(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV unsigned long long ld2(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV int dev_popc(uint32_t x) { return __popc(x); }
+DEV unsigned long long dev_brev64(unsigned long long x) { return __brevll(x); }
 DEV int dev_popcll(unsigned long long x) { return __popcll(x); }
 #else
 #include <cstring>
@@ -62,5 +63,11 @@ DEV unsigned long long dev_atomic_cas64(unsigned long long *p, unsigned long lon
 DEV uint32_t ld2(const uint32_t *p) { return *p; }
 DEV unsigned long long ld2(const unsigned long long *p) { return *p; }
 DEV int dev_popc(uint32_t x) { return __builtin_popcount(x); }
+DEV unsigned long long dev_brev64(unsigned long long x) {
+  x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+  x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+  return __builtin_bswap64(x);
+}
 DEV int dev_popcll(unsigned long long x) { return __builtin_popcountll(x); }
 #endif

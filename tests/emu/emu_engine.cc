@@ -31,7 +31,7 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   std::vector<uint32_t> rinfo(R), bw(R + 1), gw(R + 1);
   uint32_t bo = 0, go = 0;
   for (uint32_t r = 0; r < R; ++r) { uint32_t len = b->seq_off[r + 1] - b->seq_off[r]; bw[r] = bo; gw[r] = go; bo += (len + 15) / 16; go += (len + 31) / 32; }
-  std::vector<uint32_t> bases(bo + 1), good(go + 1);
+  std::vector<uint32_t> bases(bo + 4), good(go + 1);
   for (uint32_t r = 0; r < R; ++r)
     prep_read(P, b->seq, b->qual, b->seq_off[r], (int)(b->seq_off[r + 1] - b->seq_off[r]), b->label[r], b->strand[r], b->mate[r], b->mapped[r],
               &rinfo[r], bases.data(), bw[r], good.data(), gw[r]);
