@@ -1009,12 +1009,19 @@ DEVNI void build_gather(Ctx &c) {
       ef9 = (_s == 9 && _v < ef9) ? _v : ef9; } while (0)
     uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, fl = 0;
     const uint32_t lo = W.nocc[n], hi = W.nocc[n + 1];
+    const int Rref = S.R - 1, reflen_ = S.reflen; const uint32_t g0_ = c.B->read_begin[S.w];
+#ifndef LANCET_WAVE_EMU
+#pragma unroll 4
+#endif
     for (uint32_t q = lo; q < hi; ++q) {
       const uint32_t e = W.csr[q];
       const int r = (int)CS_READ(e), p = (int)CS_POS(e);
       const uint32_t ori = CS_ORI(e), st = CS_ST(e);
-      uint32_t rinfo, bw, gw; int tlen; bool isref;
-      read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref);
+      // (read_geom without its volatile LDS reads, so that the loads of the unrolled iterations can be issued together)
+      const bool isref = r == Rref;
+      const uint32_t g_ = g0_ + (uint32_t)(isref ? 0 : r);
+      const uint32_t rinfo = isref ? 0u : c.B->rinfo[g_], bw = isref ? 0u : c.B->base_woff[g_], gw = isref ? 0u : c.B->good_woff[g_];
+      const int tlen = isref ? reflen_ : (int)RI_TLEN(rinfo);
       const int nk = tlen - K + 1;
       const uint32_t o0 = W.occ_base[r];
       if (!isref) {
