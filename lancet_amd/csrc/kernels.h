@@ -825,14 +825,14 @@ DEVNI void build_tables(Ctx &c) {
       const unsigned long long tg = ld2(&W.tags[i]);
       if (S.NW == 1 && K <= 31 && !(tg >> 63)) W.nkey[(size_t)id * LC_NWMAX] = tg - 1ULL;            // exact tag: key + 1
       else for (int w = 0; w < S.NW; ++w) W.nkey[(size_t)id * LC_NWMAX + w] = W.slot_key[(size_t)i * LC_NWMAX + w];
-      W.gr[id].flags = (ld2(&W.tags[i]) >> 63) ? NF_NKMER : 0u;
+      if (S.hasN) W.gr[id].flags = (tg >> 63) ? NF_NKMER : 0u;        // (without N in the window the gather pass writes the flags whole)
     }
   }
   WG_SYNC();
   // ---- per node: std::hash of the ASCII k-mer, zeroed occurrence counters
   WG_FOR(n, S.N) {
     const unsigned long long *k = W.nkey + (size_t)n * LC_NWMAX;
-    if (W.gr[n].flags & NF_NKMER) {
+    if (S.hasN && (W.gr[n].flags & NF_NKMER)) {
       const uint8_t *refc = c.B->ref_codes + c.B->ref_off[S.w];
       int p = (int)(k[0] >> 1); bool isR = (k[0] & 1ULL) != 0;
       W.nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGTN"[nk_char(refc, p, K, isR, j)]; }, K);
@@ -1058,7 +1058,7 @@ DEVNI void build_gather(Ctx &c) {
       else G.edges[i] = ED_MAKE(a & 0x3FFFFFFFu, ua == 0 ? (ub == 0 ? 3u : 1u) : (ub == 0 ? 2u : 0u));                          // RR FR RF FF
     }
     G.necnt = (uint32_t)ne; G.comp = 0; G.color = 0; G.onref = 0; G.nkm = 1; G.nkmT = 0; G.nqv = LC_NIL;
-    G.flags = (G.flags & NF_NKMER) | fl;
+    G.flags = (S.hasN ? (G.flags & NF_NKMER) : 0u) | fl;
     uint32_t *kc = W.kcnt + 4 * (size_t)n;
     kc[0] = c0; kc[1] = c1; kc[2] = c2; kc[3] = c3;
     G.cov[0] = (float)c0; G.cov[1] = (float)c1; G.cov[2] = (float)c2; G.cov[3] = (float)c3;
