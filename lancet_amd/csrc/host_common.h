@@ -107,7 +107,7 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.pnodes = k.take<uint32_t>(nodes); t.pedges = k.take<uint32_t>(nodes);
   t.pdesc = k.take<uint32_t>(c.path_cap);
   t.pseq = k.take<uint8_t>(c.path_cap);
-  t.tb = k.take<uint8_t>((size_t)(LC_MAXW + 2) * (c.path_cap + 2));
+  t.tb = k.take<uint8_t>((size_t)(LC_MAXW + c.path_cap + 4) * (LC_MAXW + 2));   /* anti-diagonal-major: (n+m+1) diagonals of n+1 cells */
   t.dp = k.take<int32_t>(7 * (LC_MAXW + 2));
   t.aln = k.take<uint8_t>(2 * (size_t)(LC_MAXW + c.path_cap + 2));
   t.evt = k.take<uint32_t>(c.evt_cap + 8);

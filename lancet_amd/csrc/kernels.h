@@ -2035,18 +2035,21 @@ DEV bool status_cnt_T(const Ctx &c, uint32_t n) {                   // Node_t::i
 // ---------------------------------------------------------------------------------------------------------
 // global_align_aff (reference src/align.cc:235-364): full Gotoh, MATCH 2 / MISMATCH -4 / OPEN -8 / EXTEND -1,
 // the reference's tie rules; anti-diagonal wavefront across the workgroup, traceback by lane 0.
+// The traceback matrix is stored anti-diagonal-major: cell (i, j) at (i + j) * (n + 1) + i.  The systolic fill works on one
+// anti-diagonal per step with lane = row, so a wave writes 64 consecutive bytes (one request) instead of 64 bytes in 64
+// different lines -- these stores were more than half of the kernel's write requests.
+#define LC_TB(i, j, n) ((size_t)((i) + (j)) * (size_t)((n) + 1) + (size_t)(i))
 // tb byte: M.tb [1:0] (0 '\\', 1 '<', 2 '^', 3 '*') ; X.tb [3:2] (0 '<', 1 '-', 2 '*') ; Y.tb [5:4] (0 '^', 1 '|', 2 '*')
 // ---------------------------------------------------------------------------------------------------------
 DEV void align_fill_arrays(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) {
   Work &W = *c.W;
-  const int stride = m + 1;
   const int A = LC_MAXW + 2;
   int32_t *Mb[3] = {W.dp, W.dp + A, W.dp + 2 * A};
   int32_t *Xb[2] = {W.dp + 3 * A, W.dp + 4 * A};
   int32_t *Yb[2] = {W.dp + 5 * A, W.dp + 6 * A};
   // boundary rows/cols of the traceback
-  WG_FOR(j, m + 1) { W.tb[j] = (uint8_t)((j == 0 ? 3 : 2) | (0 << 2) | (2 << 4)); }       // M[0][j] '^' ; Y[0][j] '*'
-  WG_FOR(i, n + 1) { if (i > 0) W.tb[(size_t)i * stride] = (uint8_t)(1 | (2 << 2) | (0 << 4)); }   // M[i][0] '<' ; X[i][0] '*'
+  WG_FOR(j, m + 1) { W.tb[LC_TB(0, j, n)] = (uint8_t)((j == 0 ? 3 : 2) | (0 << 2) | (2 << 4)); }       // M[0][j] '^' ; Y[0][j] '*'
+  WG_FOR(i, n + 1) { if (i > 0) W.tb[LC_TB(i, 0, n)] = (uint8_t)(1 | (2 << 2) | (0 << 4)); }   // M[i][0] '<' ; X[i][0] '*'
   WG_LANE0 { Mb[0][0] = 0; Mb[1][0] = -9; Xb[1][0] = -9; Mb[1][1] = -9; Yb[1][1] = -9; }   // diagonals 0 and 1
   WG_SYNC();
   for (int d = 2; d <= n + m; ++d) {
@@ -2064,7 +2067,7 @@ DEV void align_fill_arrays(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, 
       if (xs > ms) { ms = xs; mt = 1; }
       if (ys > ms) { ms = ys; mt = 2; }
       Mc[i] = ms; Xc[i] = xs; Yc[i] = ys;
-      W.tb[(size_t)i * stride + j] = (uint8_t)(mt | (xt << 2) | (yt << 4));
+      W.tb[LC_TB(i, j, n)] = (uint8_t)(mt | (xt << 2) | (yt << 4));
     }
     WG_LANE0 {
       if (d <= m) { Mc[0] = -8 - d; Xc[0] = -8 - d; }      // (0, d)
@@ -2080,10 +2083,9 @@ DEV void align_fill_arrays(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, 
 DEVNI void align_fill(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) {
   static_assert(LANCET_WG == 64, "one wave per window");
   Work &W = *c.W;
-  const int stride = m + 1;
   const int lane = (int)threadIdx.x;
-  for (int j = lane; j < m + 1; j += 64) W.tb[j] = (uint8_t)((j == 0 ? 3 : 2) | (0 << 2) | (2 << 4));           // M[0][j] '^' ; Y[0][j] '*'
-  for (int i = lane + 1; i < n + 1; i += 64) W.tb[(size_t)i * stride] = (uint8_t)(1 | (2 << 2) | (0 << 4));     // M[i][0] '<' ; X[i][0] '*'
+  for (int j = lane; j < m + 1; j += 64) W.tb[LC_TB(0, j, n)] = (uint8_t)((j == 0 ? 3 : 2) | (0 << 2) | (2 << 4));           // M[0][j] '^' ; Y[0][j] '*'
+  for (int i = lane + 1; i < n + 1; i += 64) W.tb[LC_TB(i, 0, n)] = (uint8_t)(1 | (2 << 2) | (0 << 4));     // M[i][0] '<' ; X[i][0] '*'
   constexpr int GMAX = (LC_MAXW + 63) / 64;
   const int G = (n + 63) / 64;
   // per row: M, X (packed 16+16 in A) and Y, M(i-1,j-1) (packed in B); all scores fit 16 bits (|score| < 4*1280)
@@ -2122,7 +2124,7 @@ DEVNI void align_fill(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m
           if (ys > ms) { ms = ys; mt = 2; }
           A[g] = pack(ms, xs);
           bv = pack(ys, hi16(bv));
-          W.tb[(size_t)i * stride + j] = (uint8_t)(mt | (xt << 2) | (yt << 4));
+          W.tb[LC_TB(i, j, n)] = (uint8_t)(mt | (xt << 2) | (yt << 4));
         }
         if (j >= 1) bv = pack(lo16(bv), nbM);                            // M(i-1,j) is next step's M(i-1,j-1)
         Bv[g] = bv;
@@ -2137,7 +2139,6 @@ DEV void align_fill(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) 
 // traceback into W.aln: returns alignment length; ref_aln at aln[0..L), path_aln at aln[cap..cap+L) (ASCII)
 DEVNI int align_traceback(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) {
   Work &W = *c.W;
-  const int stride = m + 1;
   const int cap = LC_MAXW + (int)c.C->path_cap + 2;
   uint8_t *ra = W.aln, *pa = W.aln + cap;
   int i = n, j = m, L = 0;
@@ -2150,7 +2151,7 @@ DEVNI int align_traceback(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, i
     if (used >= 8 || i != bi - used || j != bj - used) {
       bi = i; bj = j; used = 0;
       pre = 0;
-      for (int q = 0; q < 8; ++q) pre |= (unsigned long long)((i - q >= 0 && j - q >= 0) ? W.tb[(size_t)(i - q) * stride + (j - q)] : (uint8_t)0) << (8 * q);
+      for (int q = 0; q < 8; ++q) pre |= (unsigned long long)((i - q >= 0 && j - q >= 0) ? W.tb[LC_TB(i - q, j - q, n)] : (uint8_t)0) << (8 * q);
     }
     uint8_t b = (uint8_t)(pre >> (8 * used)); ++used;
     int t = b & 3, x = (b >> 2) & 3, y = (b >> 4) & 3;
