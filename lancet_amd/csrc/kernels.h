@@ -1050,7 +1050,14 @@ DEVNI void build_gather(Ctx &c) {
       for (int j = 0; j < 10; ++j) if (ef[j] != LC_NIL) stamp[ne++] = ef[j]; }
     for (int i = 1; i < ne; ++i) { uint32_t s = stamp[i]; int j = i; while (j > 0 && stamp[j - 1] > s) { stamp[j] = stamp[j - 1]; --j; } stamp[j] = s; }
     NodeGr &G = W.gr[n];
-    for (int i = 0; i < ne; ++i) {
+    // first removeLowCov predicate (reference src/Graph.cc:2790-2827, docompression=false, compid=0): minqv <= T.
+    // minqv cannot exceed the number of counted occurrences, so most nodes (sequencing-error k-mers) are decided here;
+    // the others get their per-position counts from the whole wave below.  A node that is certain to go needs no edge
+    // targets (only the edge COUNT shows up, in the trace's graph statistics): skip the look-ups of its neighbours.
+    const uint32_t counted = c0 + c1 + c2 + c3;
+    const float tt = (float)c0 + (float)c1, tn = (float)c2 + (float)c3;
+    const bool low = ((int)counted <= c.P->low_cov_threshold) || ((double)counted <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
+    if (!low) for (int i = 0; i < ne; ++i) {
       const uint32_t s = stamp[i] >> 1;
       const uint32_t a = W.occ[s], b = W.occ[s + 1];           // u and v of that step
       const uint32_t ua = a >> 31, ub = b >> 31;
@@ -1070,12 +1077,6 @@ DEVNI void build_gather(Ctx &c) {
     }
     G.mincov = (int)(uint16_t)kc[0] + (int)(uint16_t)kc[1] + (int)(uint16_t)kc[2] + (int)(uint16_t)kc[3];
     G.mincovqv = 0;
-    // first removeLowCov predicate (reference src/Graph.cc:2790-2827, docompression=false, compid=0): minqv <= T.
-    // minqv cannot exceed the number of counted occurrences, so most nodes (sequencing-error k-mers) are decided here;
-    // the others get their per-position counts from the whole wave below.
-    const uint32_t counted = c0 + c1 + c2 + c3;
-    const float tt = G.cov[0] + G.cov[1], tn = G.cov[2] + G.cov[3];
-    const bool low = ((int)counted <= c.P->low_cov_threshold) || ((double)counted <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
     W.order[n] = low ? 0u : 1u;
   }
   WG_LANE0 { W.order[S.N] = 0; }
