@@ -470,12 +470,12 @@ DEVNI void order_insert(Ctx &c, uint32_t n) {
   ++S.M; ++S.ht_elt;
 }
 // cleanDead (reference src/Graph.cc:2737-2762): erase every dead node from the table
-DEVNI uint32_t clean_dead(Ctx &c) {
+DEVNI uint32_t clean_dead(Ctx &c, bool quiet = false) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   uint32_t m = 0, dead = 0;
   for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (W.gr[n].flags & NF_DEAD) ++dead; else W.order[m++] = n; }
   S.M = m; S.ht_elt -= dead;
-  evt(c, EV_CLEANDEAD, dead);
+  if (!quiet) evt(c, EV_CLEANDEAD, dead);
   return dead;
 }
 DEVNI void print_stats(Ctx &c, int comp) {                            // Graph_t::printStats, reference src/Graph.cc:3674-3691
@@ -1509,10 +1509,10 @@ DEVNI void compress_prepare(Ctx &c, int comp) {
   }
   WG_SYNC();
 }
-DEVNI void compress_fast(Ctx &c, int comp) {
+DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   const int K = S.K;
-  evt(c, EV_COMPRESS);
+  if (!quiet) evt(c, EV_COMPRESS);
   uint32_t *list = W.scratch;                                   // (absorbed node, edge dir it is entered by) per merge
   const uint32_t lcap = c.C->node_cap;
   for (uint32_t oi = 0; oi < S.M && !S.overflow; ++oi) {
@@ -1542,10 +1542,10 @@ DEVNI void compress_fast(Ctx &c, int comp) {
       NodeGr &G = W.gr[H];
       {                                                            // the head's edge to the first absorbed node goes away
         const int uid = get_buddy(c, H, dir);
-        if (uid == -1) { OVF(c); return; }
+        if (uid == -1) { OVF(c); return 0; }
         erase_edge_at(c, H, uid);
       }
-      if (!seq_reserve(c, H, dir == 'F' ? 0u : cnt, dir == 'F' ? cnt : 0u)) return;
+      if (!seq_reserve(c, H, dir == 'F' ? 0u : cnt, dir == 'F' ? cnt : 0u)) return 0;
       uint32_t lo = G.seq_lo, hi = G.seq_hi;
       int mn = G.mincov, mq = G.mincovqv;
       float nc0 = G.cov[0], nc1 = G.cov[1], nc2 = G.cov[2], nc3 = G.cov[3];
@@ -1583,7 +1583,7 @@ DEVNI void compress_fast(Ctx &c, int comp) {
         if (ed == 1 || ed == 2) ndir = flipme(ndir);
         const uint32_t other = ED_TO(be);
         const int ec = (int)G.necnt;
-        if (ec >= LC_EMAX) { OVF(c); return; }
+        if (ec >= LC_EMAX) { OVF(c); return 0; }
         if (other == buddy) { G.edges[ec] = ED_MAKE(H, ndir) | (be & (1u << 30)); G.necnt = ec + 1; }
         else {
           G.edges[ec] = ED_MAKE(other, ndir) | (be & (1u << 30)); G.necnt = ec + 1;
@@ -1592,11 +1592,11 @@ DEVNI void compress_fast(Ctx &c, int comp) {
       }
     }
   }
-  clean_dead(c);
+  return clean_dead(c, quiet);
 }
-DEVNI void compress(Ctx &c, int comp) {                               // reference src/Graph.cc:2712-2732
+DEVNI uint32_t compress(Ctx &c, int comp, bool quiet = false) {       // reference src/Graph.cc:2712-2732
   volatile WinShared &S = *c.S; Work &W = *c.W;
-  evt(c, EV_COMPRESS);
+  if (!quiet) evt(c, EV_COMPRESS);
   for (uint32_t i = 0; i < S.M && !S.overflow; ++i) {
     uint32_t n = W.order[i];
     if (W.gr[n].comp != comp) continue;
@@ -1605,7 +1605,7 @@ DEVNI void compress(Ctx &c, int comp) {                               // referen
     compress_node(c, n, 'F');
     compress_node(c, n, 'R');
   }
-  clean_dead(c);
+  return clean_dead(c, quiet);
 }
 DEVNI void remove_low_cov(Ctx &c, int comp) {                         // reference src/Graph.cc:2790-2827 (docompression=true)
   volatile WinShared &S = *c.S; Work &W = *c.W;
@@ -2682,22 +2682,25 @@ DEV void process_window(Ctx &c, int w) {
     if (wg_bcast(&S.overflow)) break;
     for (int comp = 1; comp <= numcomp; ++comp) {
       mark_ref_scan(c, comp);
-      WG_FOR(i, S.M) { const uint32_t n = W.order[i]; if (!(W.gr[n].flags & NF_SPECIAL)) W.gr[n].color = 1; }   // WHITE for the first hasCycle
-      WG_SYNC();
       WG_LANE0 {
         print_stats(c, comp);
         mark_ref_ends(c, comp);
-        S.tmp0 = 0;
-        if (!S.overflow && has_cycle(c, true)) S.tmp0 = 1;
       }
       if (wg_bcast(&S.overflow)) break;
-      if (wg_bcast(&S.tmp0)) { cycleInGraph = 1; brk = true; break; }
       PHASE(c, 15);
       compress_prepare(c, comp);
       WG_LANE0 {
-        {
-          if (S.cmp_ok) compress_fast(c, comp); else compress(c, comp);
-          PHASE(c, 9);
+        // The reference runs hasCycle on the k-mer graph and compresses only if there is none.  Unitig compaction merges
+        // nodes across links that are the only edge on both sides, which neither creates nor removes a walk that comes
+        // back to a node on the DFS stack, so the answer is the same on the compacted graph -- with ~30x fewer nodes to
+        // visit.  The graph of a rejected k is thrown away, so compacting first is unobservable; only the trace lines
+        // of the compaction are held back until the cycle check has passed.
+        const uint32_t dead = S.cmp_ok ? compress_fast(c, comp, true) : compress(c, comp, true);
+        PHASE(c, 9);
+        S.tmp0 = 0;
+        if (!S.overflow && has_cycle(c)) S.tmp0 = 1;
+        if (!S.tmp0 && !S.overflow) {
+          evt(c, EV_COMPRESS); evt(c, EV_CLEANDEAD, dead);
           print_stats(c, comp);
           remove_low_cov(c, comp);
           remove_tips(c, comp);
