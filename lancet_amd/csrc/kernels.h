@@ -871,46 +871,53 @@ DEVNI void build_csr(Ctx &c) {
   }
   WG_SYNC();
   // ---- mate-overlap prefilter: an occurrence of a candidate read can only be suppressed if the node also holds an
-  //      occurrence of its earlier opposite mate.  Node ids of the mate go into a small private open-addressing set;
-  //      own k-mers that hit it get bit 30 in occ[] and are decided by the exact replay after the csr is built.
-  WG_FOR(r, S.R - 1) {
-    if (!W.cand[r]) continue;
-    uint32_t g0 = c.B->read_begin[S.w];
-    int tlen = (int)RI_TLEN(c.B->rinfo[g0 + r]);
-    if (tlen - K <= 0) continue;
-    uint32_t o0 = W.occ_base[r];
-    int nk = tlen - K + 1;
-    bool all = W.cand[r] == 2;
-    uint32_t set[256];
-    if (!all) {
-      uint32_t mo = W.mate_of[r];
-      int mtl = (int)RI_TLEN(c.B->rinfo[g0 + mo]);
-      int mnk = mtl - K > 0 ? mtl - K + 1 : 0;
-      if (mnk > 150) all = true;
-      else {
-        for (int i = 0; i < 256; ++i) set[i] = 0;
-        uint32_t m0 = W.occ_base[mo];
-        for (int j = 0; j < mnk; ++j) {
-          uint32_t id = (W.occ[m0 + j] & 0x3FFFFFFFu) + 1u;
-          uint32_t h = (id * 2654435761u) >> 24;
-          while (set[h] != 0 && set[h] != id) h = (h + 1) & 255u;
-          set[h] = id;
+  //      occurrence of its earlier opposite mate.  One candidate read at a time, whole wave: the mate's slot ids go into
+  //      an open-addressing set in LDS (whole-line reads of its occurrence run), then the read's own occurrences are
+  //      probed against it; hits get bit 30 in occ[] and are decided by the exact replay after the csr is built.
+  {
+    uint32_t *set = (uint32_t *)S.mk;                       // 512 words of the (idle) staging area
+    const uint32_t g0 = c.B->read_begin[S.w];
+    const int nreads = S.R - 1;
+    for (int r = 0; r < nreads; ++r) {
+      const int cd = wg_uniform((int)W.cand[r]);
+      if (!cd) continue;
+      const int tlen = wg_uniform((int)RI_TLEN(c.B->rinfo[g0 + r]));
+      if (tlen - K <= 0) continue;
+      const uint32_t o0 = W.occ_base[r];
+      const int nk = tlen - K + 1;
+      bool all = cd == 2;
+      uint32_t m0 = 0; int mnk = 0;
+      if (!all) {
+        const uint32_t mo = (uint32_t)wg_uniform((int)W.mate_of[r]);
+        const int mtl = wg_uniform((int)RI_TLEN(c.B->rinfo[g0 + mo]));
+        mnk = mtl - K > 0 ? mtl - K + 1 : 0;
+        if (mnk > 150) all = true; else m0 = W.occ_base[mo];
+      }
+      if (!all) {
+        WG_FOR(i, 512) { set[i] = 0; }
+        WG_SYNC();
+        WG_FOR(j, mnk) {
+          const uint32_t id = (W.occ[m0 + j] & 0x3FFFFFFFu) + 1u;
+          uint32_t h = (id * 2654435761u) >> 23;
+          while (true) { const uint32_t old = dev_atomic_cas32(&set[h], 0u, id); if (old == 0u || old == id) break; h = (h + 1) & 511u; }
+        }
+        WG_SYNC();
+      }
+      WG_FOR(p, nk) {
+        const uint32_t oc = W.occ[o0 + p];
+        bool hit = all;
+        if (!all) {
+          const uint32_t id = (oc & 0x3FFFFFFFu) + 1u;
+          uint32_t h = (id * 2654435761u) >> 23;
+          while (true) { const uint32_t v = ((volatile uint32_t *)set)[h]; if (v == 0u) break; if (v == id) { hit = true; break; } h = (h + 1) & 511u; }
+        }
+        if (hit) {
+          W.occ[o0 + p] = oc | 0x40000000u;
+          uint32_t t = dev_atomic_add((uint32_t *)&S.tmp1, 1u);
+          if (t < c.C->table_cap) W.slot_first[t] = ((uint32_t)r << 10) | (uint32_t)p; else OVF(c);
         }
       }
-    }
-    for (int p = 0; p < nk; ++p) {
-      uint32_t oc = W.occ[o0 + p];
-      bool hit = all;
-      if (!all) {
-        uint32_t id = (oc & 0x3FFFFFFFu) + 1u;
-        uint32_t h = (id * 2654435761u) >> 24;
-        while (set[h] != 0) { if (set[h] == id) { hit = true; break; } h = (h + 1) & 255u; }
-      }
-      if (hit) {
-        W.occ[o0 + p] = oc | 0x40000000u;
-        uint32_t t = dev_atomic_add((uint32_t *)&S.tmp1, 1u);
-        if (t < c.C->table_cap) W.slot_first[t] = ((uint32_t)r << 10) | (uint32_t)p; else OVF(c);
-      }
+      WG_SYNC();
     }
   }
   WG_SYNC();

@@ -37,6 +37,7 @@ DEV uint32_t dev_atomic_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 DEV unsigned long long dev_atomic_cas64(unsigned long long *p, unsigned long long cmp, unsigned long long v) {
   return atomicCAS(p, cmp, v);
 }
+DEV uint32_t dev_atomic_cas32(uint32_t *p, uint32_t cmp, uint32_t v) { return atomicCAS(p, cmp, v); }
 // load that bypasses the CU's vector L1 (performed at L2): for words that other lanes updated with atomics
 DEV uint32_t ld2(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV unsigned long long ld2(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -60,6 +61,7 @@ DEV uint32_t dev_atomic_or(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | 
 DEV unsigned long long dev_atomic_cas64(unsigned long long *p, unsigned long long cmp, unsigned long long v) {
   unsigned long long o = *p; if (o == cmp) *p = v; return o;
 }
+DEV uint32_t dev_atomic_cas32(uint32_t *p, uint32_t cmp, uint32_t v) { uint32_t o = *p; if (o == cmp) *p = v; return o; }
 DEV uint32_t ld2(const uint32_t *p) { return *p; }
 DEV unsigned long long ld2(const unsigned long long *p) { return *p; }
 DEV int dev_popc(uint32_t x) { return __builtin_popcount(x); }
