@@ -857,6 +857,47 @@ DEVNI void build_tables(Ctx &c) {
   WG_LANE0 { S.tmp1 = 0; W.nocc[S.N] = 0; }
   WG_SYNC();
 }
+// One flagged occurrence of the mate-overlap replay (todo entry `ti` = read << 10 | position): is the read's name "found" by
+// std::binary_search in the node's vector of opposite-mate names pushed by earlier reads (reference src/Node.cc:638-661)?
+// Writes state 2 (suppressed) or 0 (counted) into the occurrence's own csr entry.  false = `buf` too small.
+DEV bool mate_replay_item(Ctx &c, uint32_t ti, uint32_t *buf, uint32_t bufcap) {
+  volatile WinShared &S = *c.S; Work &W = *c.W;
+  const int K = S.K;
+  const uint32_t g0 = c.B->read_begin[S.w];
+  const int r = (int)(W.slot_first[ti] >> 10), p = (int)(W.slot_first[ti] & 1023u);
+  const uint32_t rinfo = c.B->rinfo[g0 + r];
+  const uint32_t mi = RI_MATE(rinfo), nm = c.B->name_rank[g0 + r];
+  const uint32_t X = W.occ[W.occ_base[r] + p] & 0x3FFFFFFFu;
+  const uint32_t lo = W.nocc[X], hi = W.nocc[X + 1];
+  // gather pushes of the other mate from earlier reads, ordered by (read, position)
+  uint32_t m = 0; uint32_t self = LC_NIL;
+  for (uint32_t i = lo; i < hi; ++i) {
+    uint32_t e = W.csr[i];
+    int er = (int)CS_READ(e), ep = (int)CS_POS(e);
+    if (er == r && ep == p) self = i;
+    if (er >= r || er == S.R - 1) continue;
+    if (RI_MATE(c.B->rinfo[g0 + er]) != 3 - mi) continue;
+    if (m >= bufcap) return false;
+    buf[m++] = ((uint32_t)er << 10) | (uint32_t)ep;
+  }
+  for (uint32_t i = 1; i < m; ++i) { uint32_t v = buf[i]; uint32_t j = i; while (j > 0 && buf[j - 1] > v) { buf[j] = buf[j - 1]; --j; } buf[j] = v; }
+  // virtual vector: each entry contributes 1 push as v (pos >= 1) and 1 push as u (pos <= tlen'-K-1)
+  uint32_t total = 0;
+  for (uint32_t i = 0; i < m; ++i) {
+    int er = (int)(buf[i] >> 10), ep = (int)(buf[i] & 1023);
+    int etl = (int)RI_TLEN(c.B->rinfo[g0 + er]);
+    uint32_t pushes = (ep >= 1 ? 1u : 0u) + (ep <= etl - K - 1 ? 1u : 0u);
+    buf[i] = (c.B->name_rank[g0 + er] << 2) | pushes;     // name ranks < 2^30
+    total += pushes;
+  }
+  auto elem = [&](uint32_t t) -> uint32_t { for (uint32_t i = 0; i < m; ++i) { uint32_t pc = buf[i] & 3u; if (t < pc) return buf[i] >> 2; t -= pc; } return 0u; };
+  uint32_t first = 0, len = total;                          // std::lower_bound
+  while (len > 0) { uint32_t half = len >> 1; uint32_t mid = first + half; if (elem(mid) < nm) { first = mid + 1; len = len - half - 1; } else len = half; }
+  const bool ovl = (first != total) && !(nm < elem(first));
+  const uint32_t e = W.csr[self];
+  W.csr[self] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), ovl ? 2u : 0u);
+  return true;
+}
 DEVNI void build_csr(Ctx &c) {
   volatile WinShared &S = *c.S; Work &W = *c.W; const EngineCaps &C = *c.C;
   const int K = S.K;
@@ -938,47 +979,23 @@ DEVNI void build_csr(Ctx &c) {
     }
   }
   WG_SYNC();
-  // ---- exact replay for what is left (sequential, rare): reproduces std::binary_search over the unsorted vector of
-  //      opposite-mate names pushed so far on the node.
-  WG_LANE0 {
-    uint32_t g0 = c.B->read_begin[S.w];
-    uint32_t ntodo = (uint32_t)S.tmp1; if (ntodo > c.C->table_cap) ntodo = c.C->table_cap;
-    for (uint32_t ti = 0; ti < ntodo; ++ti) {
-      int r = (int)(W.slot_first[ti] >> 10), p = (int)(W.slot_first[ti] & 1023u);
-      uint32_t rinfo = c.B->rinfo[g0 + r];
-      uint32_t mi = RI_MATE(rinfo), nm = c.B->name_rank[g0 + r];
-      {
-        uint32_t X = W.occ[W.occ_base[r] + p] & 0x3FFFFFFFu;
-        uint32_t lo = W.nocc[X], hi = W.nocc[X + 1];
-        // gather pushes of the other mate from earlier reads, ordered by (read, position)
-        uint32_t *buf = W.scratch; uint32_t m = 0; uint32_t self = LC_NIL;
-        for (uint32_t i = lo; i < hi; ++i) {
-          uint32_t e = W.csr[i];
-          int er = (int)CS_READ(e), ep = (int)CS_POS(e);
-          if (er == r && ep == p) self = i;
-          if (er >= r || er == S.R - 1) continue;
-          if (RI_MATE(c.B->rinfo[g0 + er]) != 3 - mi) continue;
-          buf[m++] = ((uint32_t)er << 10) | (uint32_t)ep;
-        }
-        for (uint32_t i = 1; i < m; ++i) { uint32_t v = buf[i]; uint32_t j = i; while (j > 0 && buf[j - 1] > v) { buf[j] = buf[j - 1]; --j; } buf[j] = v; }
-        // virtual vector: each entry contributes 1 push as v (pos >= 1) and 1 push as u (pos <= tlen'-K-1)
-        uint32_t total = 0;
-        for (uint32_t i = 0; i < m; ++i) {
-          int er = (int)(buf[i] >> 10), ep = (int)(buf[i] & 1023);
-          int etl = (int)RI_TLEN(c.B->rinfo[g0 + er]);
-          uint32_t pushes = (ep >= 1 ? 1u : 0u) + (ep <= etl - K - 1 ? 1u : 0u);
-          buf[i] = (c.B->name_rank[g0 + er] << 2) | pushes;     // name ranks < 2^30
-          total += pushes;
-        }
-        auto elem = [&](uint32_t t) -> uint32_t { for (uint32_t i = 0; i < m; ++i) { uint32_t pc = buf[i] & 3u; if (t < pc) return buf[i] >> 2; t -= pc; } return 0u; };
-        uint32_t first = 0, len = total;                          // std::lower_bound
-        while (len > 0) { uint32_t half = len >> 1; uint32_t mid = first + half; if (elem(mid) < nm) { first = mid + 1; len = len - half - 1; } else len = half; }
-        bool ovl = (first != total) && !(nm < elem(first));
-        uint32_t e = W.csr[self];
-        W.csr[self] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), ovl ? 2u : 0u);
+  // ---- exact replay for what is left: reproduces std::binary_search over the unsorted vector of opposite-mate names
+  //      pushed so far on the node.  The flagged occurrences are independent of each other (each one only
+  //      rewrites the state bits of its own csr entry): one per lane, each lane with its own slice of the scratch area;
+  //      an occurrence whose node has more earlier mates than the slice holds is left to lane 0 with the whole area.
+  {
+    const uint32_t ntodo0 = (uint32_t)wg_bcast(&S.tmp1);
+    const uint32_t ntodo = ntodo0 > c.C->table_cap ? c.C->table_cap : ntodo0;
+    const uint32_t slice = (2u * (c.C->node_cap + c.C->special_cap)) / LANCET_WG;
+    WG_FOR(ti, ntodo) { if (!mate_replay_item(c, (uint32_t)ti, W.scratch + (size_t)((uint32_t)ti & (LANCET_WG - 1)) * slice, slice)) W.slot_first[ti] |= 0x80000000u; }
+    WG_SYNC();
+    WG_LANE0 {
+      for (uint32_t ti = 0; ti < ntodo; ++ti) if (W.slot_first[ti] & 0x80000000u) {
+        W.slot_first[ti] &= 0x7FFFFFFFu;
+        if (!mate_replay_item(c, ti, W.scratch, 2u * (c.C->node_cap + c.C->special_cap))) OVF(c);
       }
+      S.seq_top = 0; S.qv_top = 0;
     }
-    S.seq_top = 0; S.qv_top = 0;
   }
   WG_SYNC();
 }
