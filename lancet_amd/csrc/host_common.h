@@ -86,7 +86,6 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.csr = k.take<uint32_t>(c.occ_cap);
   t.nkey = k.take<unsigned long long>(nodes * LC_NWMAX);
   t.nhash = k.take<unsigned long long>(nodes);
-  t.kcnt = k.take<uint32_t>(nodes * 4);
   t.nfill = k.take<uint32_t>(nodes + 1);
   t.gr = k.take<NodeGr>(nodes);
   t.cmp = k.take<CmpRec>(nodes);

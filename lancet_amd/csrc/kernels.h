@@ -355,7 +355,7 @@ DEV void remove_node(Ctx &c, uint32_t n) {                          // Graph_t::
 // position data behind a sequence descriptor (cov_t of the reference, src/Ref.hh:41-53)
 DEV void desc_cov(const Ctx &c, uint32_t d, int sampleT, uint16_t *fwd, uint16_t *rev, uint16_t *qf, uint16_t *qr) {
   uint32_t km = SD_KMER(d);
-  const uint32_t *cn = c.W->kcnt + 4 * (size_t)km;
+  const uint16_t *cn = c.W->gr[km].kc;
   int o = sampleT ? 0 : 2;
   *fwd = (uint16_t)cn[o]; *rev = (uint16_t)cn[o + 1];
   uint32_t q = c.W->gr[km].nqv;
@@ -376,7 +376,7 @@ DEV void desc_hp(const Ctx &c, uint32_t d, int sampleT, uint16_t *hp3, uint16_t 
 }
 DEV void desc_tot(const Ctx &c, uint32_t d, int *tot, int *totqv) {  // operands of Node_t::computeMinCov
   uint32_t km = SD_KMER(d);
-  const uint32_t *cn = c.W->kcnt + 4 * (size_t)km;
+  const uint16_t *cn = c.W->gr[km].kc;
   *tot = (int)(uint16_t)cn[0] + (int)(uint16_t)cn[1] + (int)(uint16_t)cn[2] + (int)(uint16_t)cn[3];
   uint32_t q = c.W->gr[km].nqv;
   if (q == LC_NIL) { *totqv = 0; return; }
@@ -1090,13 +1090,13 @@ DEVNI void build_gather(Ctx &c) {
     }
     G.necnt = (uint32_t)ne; G.comp = 0; G.color = 0; G.onref = 0; G.nkm = 1; G.nkmT = 0; G.nqv = LC_NIL;
     G.flags = (S.hasN ? (G.flags & NF_NKMER) : 0u) | fl;
-    uint32_t *kc = W.kcnt + 4 * (size_t)n;
-    kc[0] = c0; kc[1] = c1; kc[2] = c2; kc[3] = c3;
+    uint16_t *kc = G.kc;                     // counts per strand/sample as the cov_t fields hold them (unsigned short)
+    kc[0] = (uint16_t)c0; kc[1] = (uint16_t)c1; kc[2] = (uint16_t)c2; kc[3] = (uint16_t)c3;
     G.cov[0] = (float)c0; G.cov[1] = (float)c1; G.cov[2] = (float)c2; G.cov[3] = (float)c3;
     if (S.LR) {        // cov_distr holds barcode counts instead of read counts; the float coverages stay read counts
       uint32_t lrv[10];
       lr_node_replay(c, lo, hi, lrv);
-      for (int q = 0; q < 4; ++q) kc[q] = lrv[q];
+      for (int q = 0; q < 4; ++q) kc[q] = (uint16_t)lrv[q];
       for (int q = 0; q < 6; ++q) W.khp[6 * (size_t)n + q] = (uint16_t)lrv[4 + q];
     }
     G.mincov = (int)(uint16_t)kc[0] + (int)(uint16_t)kc[1] + (int)(uint16_t)kc[2] + (int)(uint16_t)kc[3];
@@ -1284,7 +1284,7 @@ DEVNI void build_refcov(Ctx &c) {
     WG_FOR(i, S.reflen - K > 0 ? S.reflen - K : 0) {       // i + K < rawseq.length()
       uint32_t X = W.occ[ro + i] & 0x3FFFFFFFu;
       uint16_t v[4] = {0, 0, 0, 0};
-      if (ld2(&W.gr[X].flags) & NF_INMER) for (int q = 0; q < 4; ++q) v[q] = (uint16_t)W.kcnt[4 * (size_t)X + q];
+      if (ld2(&W.gr[X].flags) & NF_INMER) for (int q = 0; q < 4; ++q) v[q] = W.gr[X].kc[q];
       if (i == 0) { for (int j = 0; j < K; ++j) for (int q = 0; q < 4; ++q) W.refcov[4 * j + q] = v[q]; }
       else { for (int q = 0; q < 4; ++q) W.refcov[4 * (i + K - 1) + q] = v[q]; }
     }
@@ -1785,7 +1785,7 @@ DEV uint32_t special_new(Ctx &c, bool issource, int comp) {
   char digs[12]; int nd = 0; int v = comp; do { digs[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
   while (nd) name[L++] = digs[--nd];
   W.nhash[id] = std_hash_bytes([&](int j) -> int { return (int)(unsigned char)name[j]; }, L);
-  for (int q = 0; q < 4; ++q) { W.kcnt[4 * (size_t)id + q] = 0; W.gr[id].cov[q] = 0.0f; }
+  for (int q = 0; q < 4; ++q) { W.gr[id].kc[q] = 0; W.gr[id].cov[q] = 0.0f; }
   W.gr[id].flags = issource ? NF_SOURCE : NF_SINK;
   W.gr[id].necnt = 0; W.gr[id].comp = comp; W.gr[id].mincov = 0; W.gr[id].mincovqv = 0; W.gr[id].nqv = LC_NIL; W.gr[id].color = 0;
   W.gr[id].seq_lo = W.gr[id].seq_hi = W.gr[id].seq_clo = W.gr[id].seq_chi = 0; W.gr[id].nkm = 0; W.gr[id].nkmT = 0; W.gr[id].onref = 0;

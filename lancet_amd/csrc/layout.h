@@ -116,7 +116,7 @@ struct NodeGr {
   uint32_t nkm, nkmT;      /* constituent k-mers (cov_status entries >= K-1) / of which status == 'T'              */
   uint32_t nqv;            /* index into qv (LC_NIL if not stored)                                                 */
   uint32_t onref;
-  uint32_t pad[2];
+  uint16_t kc[4];          /* the k-mer's counted occurrences Tf Tr Nf Nr (cov_t::fwd/rev are unsigned short); never merged */
 };
 
 /* compress_prepare -> compress_fast: what one merge reads from the absorbed (single k-mer) node, in one line */
@@ -148,7 +148,6 @@ struct Work {
   /* ---- nodes: index < node_cap are k-mers in first-insertion order; then special nodes ---- */
   unsigned long long *nkey;     /* [nodes * LC_NWMAX] right-aligned 2-bit canonical k-mer     */
   unsigned long long *nhash;    /* [nodes] libstdc++ std::hash<std::string> of the node id     */
-  uint32_t *kcnt;         /* [nodes*4] counted occurrences of the k-mer: Tf Tr Nf Nr          */
   uint32_t *nfill;        /* [nodes+1] csr fill cursors                                        */
   NodeGr *gr;             /* [nodes]                                                           */
   CmpRec *cmp;            /* [nodes] compress_prepare records                                   */
