@@ -123,3 +123,25 @@ def test_linked_reads_tier2_rerun_and_determinism(monkeypatch):
     b, sb = eng.process(batch)
     eng.close()
     assert a == ov and a == b and sa == sb
+
+
+@pytest.mark.parametrize("seed", [0, 1, 3])
+def test_engine_matches_oracle_on_random_cycle_prone_windows(seed):
+    """The stress inputs of test_emu_kernels.py on the real engine: tandem duplications / STR-rich reference / dense
+    variants, k up to the 90s (multi-word keys, rolling-insert path), hundreds of hasCycle and near-repeat decisions."""
+    from lancet_amd import frontend, synth
+    data = synth.make_tumor_normal(ref_len=4200, cov_t=34, cov_n=28, ref_seed=70 + seed, tumor_seed=170 + seed, normal_seed=270 + seed,
+                                   dup_prob=1.0 if seed % 2 == 0 else 0.3, str_fraction=0.25 if seed >= 2 else 0.05,
+                                   lowcomplex_fraction=0.05, somatic_every=350, germline_every=260, read_len=100,
+                                   insert_mean=230.0, insert_sd=40.0)
+    windows = frontend.tile_region(data["ref"], data["rname"], "chr22:500-3600")
+    batch, kept = frontend.batch_from_sam(windows, synth.pairs_to_sorted_reads(data["tumor"]), synth.pairs_to_sorted_reads(data["normal"]))
+    p = abi.default_params()
+    eng = engine.Engine(p, device=0, trace_words=1 << 17)
+    v, st = eng.process(batch)
+    ov, ost, otr = oracle.run(batch, p, verbose=True)
+    assert v == ov
+    key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
+    assert [key(s) for s in st] == [key(s) for s in ost]
+    assert gu.digest_trace(eng.trace_text()) == gu.digest_trace(otr)
+    eng.close()
