@@ -72,6 +72,7 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   const size_t nodes = (size_t)c.node_cap + c.special_cap;
   Work t; memset(&t, 0, sizeof(t));
   t.occ_base = k.take<uint32_t>(c.reads_cap + 1);
+  t.rd = k.take<uint32_t>(4 * (size_t)c.reads_cap);
   t.cand = k.take<uint8_t>(c.reads_cap);
   t.mate_of = k.take<uint32_t>(c.reads_cap);
   t.items = k.take<uint32_t>(2 * ((size_t)c.reads_cap + LC_MAXW / LC_SEG + 2));

@@ -784,6 +784,7 @@ DEVNI void build_tables(Ctx &c) {
       uint32_t rinfo, bw, gw; int tlen; bool isref;
       read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref);
       W.occ_base[r] = o;
+      W.rd[4 * r] = rinfo; W.rd[4 * r + 1] = bw; W.rd[4 * r + 2] = gw; W.rd[4 * r + 3] = o;     // one 16-byte record per read for the per-occurrence passes
       if (tlen > 0 && !isref) bp += tlen;                        // totalreadbp_m (Graph.cc:121-124)
       if (tlen - K > 0) { o += (uint32_t)(tlen - K + 1); S.n_kmers += (unsigned long long)(tlen - K); }
     }
@@ -1033,7 +1034,7 @@ DEVNI void build_gather(Ctx &c) {
       ef9 = (_s == 9 && _v < ef9) ? _v : ef9; } while (0)
     uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, fl = 0;
     const uint32_t lo = W.nocc[n], hi = W.nocc[n + 1];
-    const int Rref = S.R - 1, reflen_ = S.reflen; const uint32_t g0_ = c.B->read_begin[S.w];
+    const int Rref = S.R - 1, reflen_ = S.reflen;
 #ifndef LANCET_WAVE_EMU
 #pragma unroll 4
 #endif
@@ -1043,11 +1044,11 @@ DEVNI void build_gather(Ctx &c) {
       const uint32_t ori = CS_ORI(e), st = CS_ST(e);
       // (read_geom without its volatile LDS reads, so that the loads of the unrolled iterations can be issued together)
       const bool isref = r == Rref;
-      const uint32_t g_ = g0_ + (uint32_t)(isref ? 0 : r);
-      const uint32_t rinfo = isref ? 0u : c.B->rinfo[g_], bw = isref ? 0u : c.B->base_woff[g_], gw = isref ? 0u : c.B->good_woff[g_];
+      const lc_u4 rdv = *(const lc_u4 *)(W.rd + 4 * (size_t)r);                 // rinfo, packed-base offset, quality-mask offset, first occurrence
+      const uint32_t rinfo = rdv.x, bw = rdv.y, gw = rdv.z;
       const int tlen = isref ? reflen_ : (int)RI_TLEN(rinfo);
       const int nk = tlen - K + 1;
-      const uint32_t o0 = W.occ_base[r];
+      const uint32_t o0 = rdv.w;
       if (!isref) {
         if (RI_NML(rinfo)) fl |= NF_NORMAL;
         else if (!(fl & NF_TUMOR) && (step_all_good(c, isref, gw, p, tlen, K) || step_all_good(c, isref, gw, p - 1, tlen, K))) fl |= NF_TUMOR;
@@ -1122,7 +1123,6 @@ DEVNI void build_qcounts(Ctx &c) {
   //      Step 2, lane = (candidate, k-mer position): count over the candidate's staged occurrences out of LDS.
   const uint32_t ncand = wg_bcastu(&S.part[LANCET_WG]);
   const int QS = S.QS; const bool LR = S.LR != 0;
-  const uint32_t g0 = c.B->read_begin[S.w];
   uint32_t ci = 0;
   while (ci < ncand) {
     WG_LANE0 {                                   // group formation
@@ -1163,7 +1163,7 @@ DEVNI void build_qcounts(Ctx &c) {
         for (int u = 0; u < U; ++u) {
           act[u] = act[u] && CS_ST(e[u]) == 0;
           ri[u] = 0; gd[u] = c.B->good;
-          if (act[u]) { const uint32_t g = g0 + CS_READ(e[u]); ri[u] = c.B->rinfo[g]; gd[u] = c.B->good + c.B->good_woff[g]; }
+          if (act[u]) { const lc_u4 rdv = *(const lc_u4 *)(W.rd + 4 * (size_t)CS_READ(e[u])); ri[u] = rdv.x; gd[u] = c.B->good + rdv.z; }
         }
         for (int u = 0; u < U; ++u) {
           m[u][0] = m[u][1] = m[u][2] = m[u][3] = 0; meta[u] = 0;

@@ -133,6 +133,7 @@ struct CmpRec {
 struct Work {
   /* ---- build ---- */
   uint32_t *occ_base;     /* [reads_cap+1] first occurrence index of each read                 */
+  uint32_t *rd;           /* [reads_cap*4] per read: info word, packed-base offset, quality-mask offset, first occurrence (one 16-byte load) */
   uint8_t *cand;          /* [reads_cap]   read has an earlier opposite mate of the same name  */
   uint32_t *mate_of;      /* [reads_cap]   index of that earlier mate (when unique)            */
   uint32_t *items;        /* [2*(reads_cap + LC_MAXW/LC_SEG + 2)] work items of the per-occurrence passes */

@@ -41,6 +41,7 @@ DEV uint32_t dev_atomic_cas32(uint32_t *p, uint32_t cmp, uint32_t v) { return at
 // load that bypasses the CU's vector L1 (performed at L2): for words that other lanes updated with atomics
 DEV uint32_t ld2(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV unsigned long long ld2(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+typedef uint4 lc_u4;
 DEV int dev_popc(uint32_t x) { return __popc(x); }
 DEV unsigned long long dev_brev64(unsigned long long x) { return __brevll(x); }
 DEV int dev_popcll(unsigned long long x) { return __popcll(x); }
@@ -64,6 +65,7 @@ DEV unsigned long long dev_atomic_cas64(unsigned long long *p, unsigned long lon
 DEV uint32_t dev_atomic_cas32(uint32_t *p, uint32_t cmp, uint32_t v) { uint32_t o = *p; if (o == cmp) *p = v; return o; }
 DEV uint32_t ld2(const uint32_t *p) { return *p; }
 DEV unsigned long long ld2(const unsigned long long *p) { return *p; }
+struct alignas(16) lc_u4 { uint32_t x, y, z, w; };
 DEV int dev_popc(uint32_t x) { return __builtin_popcount(x); }
 DEV unsigned long long dev_brev64(unsigned long long x) {
   x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
