@@ -1400,7 +1400,7 @@ DEVNI void clean_dead_wg(Ctx &c) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   const int M = (int)wg_bcastu(&S.M);
   uint32_t *keep = W.scratch;
-  WG_FOR(i, M) { keep[i] = (W.gr[W.order[i]].flags & NF_DEAD) ? 0u : 1u; }
+  WG_FOR(i, M) { const uint32_t f = W.gr[W.order[i]].flags; keep[i] = ((f & NF_SURV) && !(f & NF_DEAD)) ? 1u : 0u; }
   WG_LANE0 { keep[M] = 0; }
   wg_scan(keep, M + 1, S);
   WG_FOR(i, M) { if (keep[i + 1] != keep[i]) W.pnodes[keep[i]] = W.order[i]; }
@@ -2684,13 +2684,12 @@ DEV void process_window(Ctx &c, int w) {
         evt(c, EV_LOWCOV, low);
       }
     }
-    // removeNode for every non-survivor: drop the reciprocal edges, then erase from the table
-    WG_FOR(n, S.N) { if (!(W.gr[n].flags & NF_SURV)) W.gr[n].flags |= NF_DEAD; }
-    WG_SYNC();
+    // removeNode for every non-survivor: drop the reciprocal edges, then erase from the table.  A node without NF_SURV is
+    // gone from here on (it is in no edge list and not in order[]); it does not need a NF_DEAD mark of its own.
     WG_FOR(n, S.N) {
-      if (W.gr[n].flags & NF_DEAD) continue;
+      if (!(W.gr[n].flags & NF_SURV)) continue;
       uint32_t *e = W.gr[n].edges; int cnt = (int)W.gr[n].necnt, m = 0;
-      for (int i = 0; i < cnt; ++i) if (!(W.gr[ED_TO(e[i])].flags & NF_DEAD)) e[m++] = e[i];
+      for (int i = 0; i < cnt; ++i) if (W.gr[ED_TO(e[i])].flags & NF_SURV) e[m++] = e[i];
       W.gr[n].necnt = m;
     }
     WG_SYNC();
