@@ -82,7 +82,7 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.slot_key = k.take<unsigned long long>((size_t)c.table_cap * LC_NWMAX);
   t.slot_first = k.take<uint32_t>(c.table_cap);
   t.slot_node = k.take<uint32_t>(c.table_cap);
-  t.bitmap = k.take<uint32_t>(c.occ_cap / 32 + 2);
+  t.bitmap = k.take<uint32_t>((c.occ_cap + c.special_cap) / 32 + 4);   /* also the visited set of the component search (node ids) */
   t.bitpre = k.take<uint32_t>(c.occ_cap / 32 + 2);
   t.csr = k.take<uint32_t>(c.occ_cap);
   t.nkey = k.take<unsigned long long>(nodes * LC_NWMAX);

@@ -1743,26 +1743,32 @@ DEVNI void remove_short_links(Ctx &c, int comp) {                     // referen
 
 DEVNI int mark_connected_components(Ctx &c) {                         // reference src/Graph.cc:2252-2336
   volatile WinShared &S = *c.S; Work &W = *c.W;
-  for (uint32_t i = 0; i < S.M; ++i) W.gr[W.order[i]].comp = 0;
+  // "already labelled" lives in a bitmap over node ids (a few hundred bytes that stay in cache) instead of in the
+  // 128-byte node records: a visit costs one record load, not one per neighbour as well
+  uint32_t *seen = W.bitmap;
+  const uint32_t nw = (c.C->node_cap + c.C->special_cap) / 32 + 1;
+  for (uint32_t i = 0; i < nw; ++i) seen[i] = 0;
   int comp = 0, refcomp = 0;
   uint32_t *Q = W.scratch;                                            // FIFO; every node enqueued <= deg+1 times
   uint32_t qcap = 2 * (c.C->node_cap + c.C->special_cap);
   evt(c, EV_CC, S.M);
   for (uint32_t i = 0; i < S.M; ++i) {
     uint32_t s = W.order[i];
-    if (W.gr[s].comp != 0) continue;
+    if (seen[s >> 5] & (1u << (s & 31))) continue;
     ++comp;
     uint32_t qh = 0, qt = 0;
     int touches = 0;
     // breadth-first; a node is labelled when first reached (the reference labels on pop; same partition)
+    seen[s >> 5] |= 1u << (s & 31);
     W.gr[s].comp = comp; Q[qt++] = s;
     while (qh < qt) {
       uint32_t cur = Q[qh++];
       if (W.gr[cur].flags & NF_INMER) ++touches;
       for (int e = 0; e < (int)W.gr[cur].necnt; ++e) {
         uint32_t nx = ED_TO(W.gr[cur].edges[e]);
-        if (W.gr[nx].comp != 0) continue;
+        if (seen[nx >> 5] & (1u << (nx & 31))) continue;
         if (qt >= qcap) { OVF(c); return comp; }
+        seen[nx >> 5] |= 1u << (nx & 31);
         W.gr[nx].comp = comp; Q[qt++] = nx;
       }
     }
