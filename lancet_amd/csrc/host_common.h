@@ -78,10 +78,9 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.items = k.take<uint32_t>(2 * ((size_t)c.reads_cap + LC_MAXW / LC_SEG + 2));
   t.chunk = k.take<uint32_t>(2 * (((size_t)c.reads_cap + LC_MAXW / LC_SEG + 2) / 64 + 2));
   t.occ = k.take<uint32_t>(c.occ_cap);
-  t.tags = k.take<unsigned long long>(c.table_cap);
+  t.slots = k.take<uint32_t>(4 * (size_t)c.table_cap);
+  t.todo = k.take<uint32_t>(c.table_cap);
   t.slot_key = k.take<unsigned long long>((size_t)c.table_cap * LC_NWMAX);
-  t.slot_first = k.take<uint32_t>(c.table_cap);
-  t.slot_node = k.take<uint32_t>(c.table_cap);
   t.bitmap = k.take<uint32_t>((c.occ_cap + c.special_cap) / 32 + 4);   /* also the visited set of the component search (node ids) */
   t.bitpre = k.take<uint32_t>(c.occ_cap / 32 + 2);
   t.csr = k.take<uint32_t>(c.occ_cap);

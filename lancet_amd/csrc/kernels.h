@@ -530,6 +530,12 @@ DEV bool nk_is_forward(const uint8_t *ref, int p, int K) {                      
   return false;
 }
 
+// ---- the k-mer table: open addressing, one 16-byte slot per entry = tag (u64), first occurrence (u32), node id (u32), so that
+// a probe brings in everything the insert needs with one line access
+#define SL_TAG(W, i) (*(unsigned long long *)((W).slots + 4 * (size_t)(i)))
+#define SL_FIRST(W, i) ((W).slots[4 * (size_t)(i) + 2])
+#define SL_NODE(W, i) ((W).slots[4 * (size_t)(i) + 3])
+
 // ---- work items of the per-occurrence passes: one per read, the (long) reference pseudo-read cut into segments of
 // LC_SEG k-mer starts so that no lane trails the wave.  items[2i] = read | first k-mer start << 16,
 // items[2i+1] = sweep offset | number of k-mer starts << 16.  chunk[2c], chunk[2c+1] = sweep origin / length of the
@@ -619,10 +625,10 @@ DEVNI void build_insert_pass(Ctx &c, bool verify) {
         }
         uint32_t probes = 0;
         while (true) {
-          unsigned long long cur = ld2(&W.tags[idx]);
+          unsigned long long cur = ld2(&SL_TAG(W, idx));
           if (cur == h) break;
           if (cur == 0) {
-            unsigned long long old = dev_atomic_cas64(&W.tags[idx], 0ULL, h);
+            unsigned long long old = dev_atomic_cas64(&SL_TAG(W, idx), 0ULL, h);
             if (old == 0) {
               if (nk_) W.slot_key[(size_t)idx * LC_NWMAX] = ((unsigned long long)p << 1) | (isF ? 0ULL : 1ULL);   // where the string lives
               else if (!(NW == 1 && K <= 31)) for (int w = 0; w < NW; ++w) W.slot_key[(size_t)idx * LC_NWMAX + w] = ck[w];   // (k <= 31: the tag is the key + 1)
@@ -633,7 +639,7 @@ DEVNI void build_insert_pass(Ctx &c, bool verify) {
           idx = (idx + 1) & mask;
           if (++probes > mask) { OVF(c); break; }
         }
-        dev_atomic_min(&W.slot_first[idx], o);
+        dev_atomic_min(&SL_FIRST(W, idx), o);
         W.occ[o] = idx | (isF ? 0u : 0x80000000u);
       } else {
         uint32_t idx = W.occ[o] & 0x3FFFFFFFu;
@@ -683,17 +689,22 @@ DEVNI void build_insert_occ_major(Ctx &c) {
     const unsigned long long h = (isF ? fw : rc) + 1ULL;         // tag == key + 1: exact
     uint32_t idx = (uint32_t)mix64(h) & mask;
     uint32_t probes = 0;
+    uint32_t seen_first = LC_NIL;
     while (true) {
-      const unsigned long long cur = ld2(&W.tags[idx]);
-      if (cur == h) break;
+      // A plain (L1-cacheable) 16-byte load: what it returns may be older than the atomics of other lanes, never wrong --
+      // tags do not change once set (a stale 0 just sends us into the CAS, which answers with the real tag) and the
+      // first-occurrence field only ever decreases (a stale, larger value costs a superfluous atomicMin at worst).
+      const lc_u4 sv = *(const lc_u4 *)(W.slots + 4 * (size_t)idx);
+      const unsigned long long cur = (unsigned long long)sv.x | ((unsigned long long)sv.y << 32);
+      if (cur == h) { seen_first = sv.z; break; }
       if (cur == 0) {
-        const unsigned long long old = dev_atomic_cas64(&W.tags[idx], 0ULL, h);
+        const unsigned long long old = dev_atomic_cas64(&SL_TAG(W, idx), 0ULL, h);
         if (old == 0 || old == h) break;
       }
       idx = (idx + 1) & mask;
       if (++probes > mask) { OVF(c); break; }
     }
-    dev_atomic_min(&W.slot_first[idx], (uint32_t)o);
+    if ((uint32_t)o < seen_first) dev_atomic_min(&SL_FIRST(W, idx), (uint32_t)o);     // most occurrences are not the first one
     W.occ[o] = idx | (isF ? 0u : 0x80000000u);
   }
   WG_SYNC();
@@ -794,7 +805,7 @@ DEVNI void build_tables(Ctx &c) {
     ++S.n_builds;
   }
   if (wg_bcast(&S.overflow)) return;
-  WG_FOR(i, C.table_cap) { W.tags[i] = 0; W.slot_first[i] = LC_NIL; }
+  WG_FOR(i, C.table_cap) { lc_u4 z; z.x = 0; z.y = 0; z.z = LC_NIL; z.w = 0; *(lc_u4 *)(W.slots + 4 * (size_t)i) = z; }
   WG_FOR(i, (int)(S.O / 32 + 2)) { W.bitmap[i] = 0; }
   WG_SYNC();
   PHASE(c, 2);
@@ -810,7 +821,7 @@ DEVNI void build_tables(Ctx &c) {
   PHASE(c, 3);
   STOP_RET(c, 3);
   // ---- dense node ids in first-insertion order (= order of first occurrence, Graph.cc:163-197)
-  WG_FOR(i, C.table_cap) { if (ld2(&W.tags[i]) != 0) { uint32_t f = ld2(&W.slot_first[i]); dev_atomic_or(&W.bitmap[f >> 5], 1u << (f & 31)); } }
+  WG_FOR(i, C.table_cap) { if (ld2(&SL_TAG(W, i)) != 0) { uint32_t f = ld2(&SL_FIRST(W, i)); dev_atomic_or(&W.bitmap[f >> 5], 1u << (f & 31)); } }
   WG_SYNC();
   int nwords = (int)(S.O / 32 + 1);
   WG_FOR(i, nwords) { W.bitpre[i] = (uint32_t)dev_popc(ld2(&W.bitmap[i])); }
@@ -819,11 +830,11 @@ DEVNI void build_tables(Ctx &c) {
   WG_LANE0 { S.N = S.part[LANCET_WG]; if (S.N > C.node_cap) OVF(c); if (S.N > S.max_nodes) S.max_nodes = S.N; S.nspecial = 0; }
   if (wg_bcast(&S.overflow)) return;
   WG_FOR(i, C.table_cap) {
-    if (ld2(&W.tags[i]) != 0) {
-      uint32_t f = ld2(&W.slot_first[i]);
+    if (ld2(&SL_TAG(W, i)) != 0) {
+      uint32_t f = ld2(&SL_FIRST(W, i));
       uint32_t id = W.bitpre[f >> 5] + (uint32_t)dev_popc(ld2(&W.bitmap[f >> 5]) & ((1u << (f & 31)) - 1u));
-      W.slot_node[i] = id;
-      const unsigned long long tg = ld2(&W.tags[i]);
+      SL_NODE(W, i) = id;
+      const unsigned long long tg = ld2(&SL_TAG(W, i));
       if (S.NW == 1 && K <= 31 && !(tg >> 63)) W.nkey[(size_t)id * LC_NWMAX] = tg - 1ULL;            // exact tag: key + 1
       else for (int w = 0; w < S.NW; ++w) W.nkey[(size_t)id * LC_NWMAX + w] = W.slot_key[(size_t)i * LC_NWMAX + w];
       if (S.hasN) W.gr[id].flags = (tg >> 63) ? NF_NKMER : 0u;        // (without N in the window the gather pass writes the flags whole)
@@ -865,7 +876,7 @@ DEV bool mate_replay_item(Ctx &c, uint32_t ti, uint32_t *buf, uint32_t bufcap) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   const int K = S.K;
   const uint32_t g0 = c.B->read_begin[S.w];
-  const int r = (int)(W.slot_first[ti] >> 10), p = (int)(W.slot_first[ti] & 1023u);
+  const int r = (int)(W.todo[ti] >> 10), p = (int)(W.todo[ti] & 1023u);
   const uint32_t rinfo = c.B->rinfo[g0 + r];
   const uint32_t mi = RI_MATE(rinfo), nm = c.B->name_rank[g0 + r];
   const uint32_t X = W.occ[W.occ_base[r] + p] & 0x3FFFFFFFu;
@@ -907,7 +918,7 @@ DEVNI void build_csr(Ctx &c) {
   //      occurrence-major (lane = consecutive occurrence index): occ[] is read and rewritten in whole cache lines
   WG_FOR(o, S.O) {
     const uint32_t oc = W.occ[o];
-    const uint32_t X = W.slot_node[oc & 0x3FFFFFFFu];
+    const uint32_t X = SL_NODE(W, oc & 0x3FFFFFFFu);
     dev_atomic_add(&W.nocc[X], 1u);
     W.occ[o] = X | (oc & 0x80000000u);
   }
@@ -956,7 +967,7 @@ DEVNI void build_csr(Ctx &c) {
         if (hit) {
           W.occ[o0 + p] = oc | 0x40000000u;
           uint32_t t = dev_atomic_add((uint32_t *)&S.tmp1, 1u);
-          if (t < c.C->table_cap) W.slot_first[t] = ((uint32_t)r << 10) | (uint32_t)p; else OVF(c);
+          if (t < c.C->table_cap) W.todo[t] = ((uint32_t)r << 10) | (uint32_t)p; else OVF(c);
         }
       }
       WG_SYNC();
@@ -988,11 +999,11 @@ DEVNI void build_csr(Ctx &c) {
     const uint32_t ntodo0 = (uint32_t)wg_bcast(&S.tmp1);
     const uint32_t ntodo = ntodo0 > c.C->table_cap ? c.C->table_cap : ntodo0;
     const uint32_t slice = (2u * (c.C->node_cap + c.C->special_cap)) / LANCET_WG;
-    WG_FOR(ti, ntodo) { if (!mate_replay_item(c, (uint32_t)ti, W.scratch + (size_t)((uint32_t)ti & (LANCET_WG - 1)) * slice, slice)) W.slot_first[ti] |= 0x80000000u; }
+    WG_FOR(ti, ntodo) { if (!mate_replay_item(c, (uint32_t)ti, W.scratch + (size_t)((uint32_t)ti & (LANCET_WG - 1)) * slice, slice)) W.todo[ti] |= 0x80000000u; }
     WG_SYNC();
     WG_LANE0 {
-      for (uint32_t ti = 0; ti < ntodo; ++ti) if (W.slot_first[ti] & 0x80000000u) {
-        W.slot_first[ti] &= 0x7FFFFFFFu;
+      for (uint32_t ti = 0; ti < ntodo; ++ti) if (W.todo[ti] & 0x80000000u) {
+        W.todo[ti] &= 0x7FFFFFFFu;
         if (!mate_replay_item(c, ti, W.scratch, 2u * (c.C->node_cap + c.C->special_cap))) OVF(c);
       }
       S.seq_top = 0; S.qv_top = 0;
@@ -2306,12 +2317,12 @@ DEVNI uint32_t kmer_lookup(Ctx &c, const uint8_t *codes) {
     idx = (uint32_t)h & mask;
   }
   for (uint32_t probes = 0; probes <= mask; ++probes) {
-    const unsigned long long cur = W.tags[idx];
+    const unsigned long long cur = SL_TAG(W, idx);
     if (cur == 0) return LC_NIL;
     if (cur == h) {
       bool same = true;
       if (!(NW == 1 && K <= 31)) for (int w = 0; w < NW; ++w) if (W.slot_key[(size_t)idx * LC_NWMAX + w] != ck[w]) same = false;
-      if (same) return W.slot_node[idx];
+      if (same) return SL_NODE(W, idx);
     }
     idx = (idx + 1) & mask;
   }
