@@ -1118,7 +1118,8 @@ DEVNI void build_gather(Ctx &c) {
   WG_LANE0 { W.order[S.N] = 0; }
   WG_SYNC();
   wg_scan(W.order, (int)S.N + 1, S);
-  WG_FOR(n, S.N) { if (W.order[n + 1] != W.order[n]) W.pnodes[W.order[n]] = (uint32_t)n; }
+  // the candidates with their csr range next to them (compact arrays for the group formation of the per-position pass)
+  WG_FOR(n, S.N) { if (W.order[n + 1] != W.order[n]) { const uint32_t at = W.order[n]; W.pnodes[at] = (uint32_t)n; W.pedges[at] = W.nocc[n]; W.ht_bucket[at] = W.nocc[n + 1] - W.nocc[n]; } }
   WG_SYNC();
 }
 DEVNI void build_qcounts(Ctx &c) {
@@ -1139,7 +1140,7 @@ DEVNI void build_qcounts(Ctx &c) {
     WG_LANE0 {                                   // group formation
       uint32_t gN = 0, tot = 0;
       for (uint32_t k = 0; k < LC_PACK && ci + k < ncand; ++k) {
-        const uint32_t n = W.pnodes[ci + k], lo = W.nocc[n], cnt = W.nocc[n + 1] - lo;
+        const uint32_t n = W.pnodes[ci + k], lo = W.pedges[ci + k], cnt = W.ht_bucket[ci + k];
         if (gN > 0 && tot + cnt > LC_STAGE) break;
         S.g_n[gN] = n; S.g_lo[gN] = lo; S.g_cnt[gN] = cnt; S.g_es[gN] = tot; S.g_min[gN] = 0x7FFFFFFFu;
         ++gN; tot += cnt;
@@ -1251,8 +1252,8 @@ DEVNI void build_qcounts(Ctx &c) {
         W.seq[base + i] = SD_MAKE(n, i, key_base(kk, K, i));
       }
     }
-    WG_LANE0 {
-      for (int k = 0; k < gN; ++k) {
+    WG_FOR(k, gN) {                              // one lane per candidate of the group: their record loads overlap
+      {
         const uint32_t n = S.g_n[k];
         NodeGr &G = W.gr[n];
         const int minqv = (int)S.g_min[k];
@@ -1268,8 +1269,8 @@ DEVNI void build_qcounts(Ctx &c) {
           G.flags = f | NF_SURV;
         }
       }
-      S.qv_top = qi0 + (uint32_t)gN;
     }
+    WG_LANE0 { S.qv_top = qi0 + (uint32_t)gN; }
     ci += (uint32_t)gN;
   }
   WG_LANE0 { S.seq_top = S.qv_top * (uint32_t)K; }
