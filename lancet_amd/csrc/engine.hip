@@ -159,6 +159,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   const int nw = b->n_windows;
   if (e->params.lr_mode && nw > 0 && b->read_begin[nw] > 0 && (!b->bx_rank || !b->hp)) { e->err = "lr_mode needs bx_rank and hp"; return LANCET_E_ARG; }
   const uint32_t R = nw ? b->read_begin[nw] : 0;
+  for (uint32_t r = 0; r < R; ++r) if (b->name_rank[r] > 0xFFFFu) { e->err = "name_rank must be the dense per-window rank (< 65536)"; return LANCET_E_ARG; }
   if (e->params.lr_mode) for (uint32_t r = 0; r < R; ++r) if (b->hp[r] > 2) { e->err = "hp must be 0, 1 or 2"; return LANCET_E_ARG; }   // Node_t::addHP indexes a 3-array (src/Node.cc:54-57)
   const uint32_t nbases = R ? b->seq_off[R] : 0;
   const uint32_t nref = nw ? b->ref_off[nw] : 0;

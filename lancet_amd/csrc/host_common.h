@@ -80,6 +80,7 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.occ = k.take<uint32_t>(c.occ_cap);
   t.slots = k.take<uint32_t>(4 * (size_t)c.table_cap);
   t.todo = k.take<uint32_t>(c.table_cap);
+  t.mv = k.take<uint32_t>(4 * (size_t)c.occ_cap);
   t.slot_key = k.take<unsigned long long>((size_t)c.table_cap * LC_NWMAX);
   t.bitmap = k.take<uint32_t>((c.occ_cap + c.special_cap) / 32 + 4);   /* also the visited set of the component search (node ids) */
   t.bitpre = k.take<uint32_t>(c.occ_cap / 32 + 2);

@@ -869,47 +869,6 @@ DEVNI void build_tables(Ctx &c) {
   WG_LANE0 { S.tmp1 = 0; W.nocc[S.N] = 0; }
   WG_SYNC();
 }
-// One flagged occurrence of the mate-overlap replay (todo entry `ti` = read << 10 | position): is the read's name "found" by
-// std::binary_search in the node's vector of opposite-mate names pushed by earlier reads (reference src/Node.cc:638-661)?
-// Writes state 2 (suppressed) or 0 (counted) into the occurrence's own csr entry.  false = `buf` too small.
-DEV bool mate_replay_item(Ctx &c, uint32_t ti, uint32_t *buf, uint32_t bufcap) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
-  const int K = S.K;
-  const uint32_t g0 = c.B->read_begin[S.w];
-  const int r = (int)(W.todo[ti] >> 10), p = (int)(W.todo[ti] & 1023u);
-  const uint32_t rinfo = c.B->rinfo[g0 + r];
-  const uint32_t mi = RI_MATE(rinfo), nm = c.B->name_rank[g0 + r];
-  const uint32_t X = W.occ[W.occ_base[r] + p] & 0x3FFFFFFFu;
-  const uint32_t lo = W.nocc[X], hi = W.nocc[X + 1];
-  // gather pushes of the other mate from earlier reads, ordered by (read, position)
-  uint32_t m = 0; uint32_t self = LC_NIL;
-  for (uint32_t i = lo; i < hi; ++i) {
-    uint32_t e = W.csr[i];
-    int er = (int)CS_READ(e), ep = (int)CS_POS(e);
-    if (er == r && ep == p) self = i;
-    if (er >= r || er == S.R - 1) continue;
-    if (RI_MATE(c.B->rinfo[g0 + er]) != 3 - mi) continue;
-    if (m >= bufcap) return false;
-    buf[m++] = ((uint32_t)er << 10) | (uint32_t)ep;
-  }
-  for (uint32_t i = 1; i < m; ++i) { uint32_t v = buf[i]; uint32_t j = i; while (j > 0 && buf[j - 1] > v) { buf[j] = buf[j - 1]; --j; } buf[j] = v; }
-  // virtual vector: each entry contributes 1 push as v (pos >= 1) and 1 push as u (pos <= tlen'-K-1)
-  uint32_t total = 0;
-  for (uint32_t i = 0; i < m; ++i) {
-    int er = (int)(buf[i] >> 10), ep = (int)(buf[i] & 1023);
-    int etl = (int)RI_TLEN(c.B->rinfo[g0 + er]);
-    uint32_t pushes = (ep >= 1 ? 1u : 0u) + (ep <= etl - K - 1 ? 1u : 0u);
-    buf[i] = (c.B->name_rank[g0 + er] << 2) | pushes;     // name ranks < 2^30
-    total += pushes;
-  }
-  auto elem = [&](uint32_t t) -> uint32_t { for (uint32_t i = 0; i < m; ++i) { uint32_t pc = buf[i] & 3u; if (t < pc) return buf[i] >> 2; t -= pc; } return 0u; };
-  uint32_t first = 0, len = total;                          // std::lower_bound
-  while (len > 0) { uint32_t half = len >> 1; uint32_t mid = first + half; if (elem(mid) < nm) { first = mid + 1; len = len - half - 1; } else len = half; }
-  const bool ovl = (first != total) && !(nm < elem(first));
-  const uint32_t e = W.csr[self];
-  W.csr[self] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), ovl ? 2u : 0u);
-  return true;
-}
 DEVNI void build_csr(Ctx &c) {
   volatile WinShared &S = *c.S; Work &W = *c.W; const EngineCaps &C = *c.C;
   const int K = S.K;
@@ -992,22 +951,72 @@ DEVNI void build_csr(Ctx &c) {
   }
   WG_SYNC();
   // ---- exact replay for what is left: reproduces std::binary_search over the unsorted vector of opposite-mate names
-  //      pushed so far on the node.  The flagged occurrences are independent of each other (each one only
-  //      rewrites the state bits of its own csr entry): one per lane, each lane with its own slice of the scratch area;
-  //      an occurrence whose node has more earlier mates than the slice holds is left to lane 0 with the whole area.
+  //      pushed so far on the node (reference src/Node.cc:638-671).  Per node that holds a flagged
+  //      occurrence, once: its csr run sorted into visiting order (read, position) and its two name vectors written out
+  //      (mv[]: read << 16 | name rank per push; mate-1 pushes at 4*lo, mate-2 pushes at 4*lo + 2*len).  Per flagged
+  //      occurrence: the vector it sees is the prefix pushed by earlier reads (binary search on the read field), then the
+  //      reference's lower_bound over the names of that prefix.
   {
     const uint32_t ntodo0 = (uint32_t)wg_bcast(&S.tmp1);
     const uint32_t ntodo = ntodo0 > c.C->table_cap ? c.C->table_cap : ntodo0;
-    const uint32_t slice = (2u * (c.C->node_cap + c.C->special_cap)) / LANCET_WG;
-    WG_FOR(ti, ntodo) { if (!mate_replay_item(c, (uint32_t)ti, W.scratch + (size_t)((uint32_t)ti & (LANCET_WG - 1)) * slice, slice)) W.todo[ti] |= 0x80000000u; }
-    WG_SYNC();
-    WG_LANE0 {
-      for (uint32_t ti = 0; ti < ntodo; ++ti) if (W.todo[ti] & 0x80000000u) {
-        W.todo[ti] &= 0x7FFFFFFFu;
-        if (!mate_replay_item(c, ti, W.scratch, 2u * (c.C->node_cap + c.C->special_cap))) OVF(c);
+    if (ntodo) {
+      const uint32_t g0 = c.B->read_begin[S.w];
+      uint32_t *mark = W.bitmap;
+      WG_FOR(i, (int)(S.N / 32 + 1)) { mark[i] = 0; }
+      WG_SYNC();
+      WG_FOR(ti, ntodo) {
+        const uint32_t X = W.occ[W.occ_base[W.todo[ti] >> 10] + (W.todo[ti] & 1023u)] & 0x3FFFFFFFu;
+        dev_atomic_or(&mark[X >> 5], 1u << (X & 31));
       }
-      S.seq_top = 0; S.qv_top = 0;
+      WG_SYNC();
+      WG_LANE0 { S.tmp2 = 0; }
+      WG_FOR(n, S.N) { if (ld2(&mark[n >> 5]) & (1u << (n & 31))) W.pnodes[dev_atomic_add((uint32_t *)&S.tmp2, 1u)] = (uint32_t)n; }   // the marked nodes, densely
+      WG_SYNC();
+      const int nmarked = wg_bcast(&S.tmp2);
+      WG_FOR(li, nmarked) {
+        const uint32_t n = W.pnodes[li];
+        const uint32_t lo = W.nocc[n], hi = W.nocc[n + 1], len = hi - lo;
+        for (uint32_t i = lo + 1; i < hi; ++i) {                 // visiting order (the run is nearly sorted already)
+          const uint32_t v = W.csr[i], kv = (CS_READ(v) << 10) | CS_POS(v);
+          uint32_t j = i;
+          while (j > lo) { const uint32_t u = W.csr[j - 1]; if (((CS_READ(u) << 10) | CS_POS(u)) <= kv) break; W.csr[j] = u; --j; }
+          W.csr[j] = v;
+        }
+        uint32_t n1 = 0, n2 = 0;
+        uint32_t *v1 = W.mv + 4 * (size_t)lo, *v2 = v1 + 2 * (size_t)len;
+        for (uint32_t i = lo; i < hi; ++i) {
+          const uint32_t e = W.csr[i], er = CS_READ(e);
+          if ((int)er == S.R - 1) continue;
+          const uint32_t ri = c.B->rinfo[g0 + er], mt = RI_MATE(ri);
+          if (mt != 1 && mt != 2) continue;
+          const int ep = (int)CS_POS(e), etl = (int)RI_TLEN(ri);
+          const uint32_t rec = (er << 16) | (c.B->name_rank[g0 + er] & 0xFFFFu);      // ranks < number of reads < 2^16
+          const uint32_t pushes = (ep >= 1 ? 1u : 0u) + (ep <= etl - K - 1 ? 1u : 0u);   // as v of step p-1, as u of step p
+          for (uint32_t q = 0; q < pushes; ++q) { if (mt == 1) v1[n1++] = rec; else v2[n2++] = rec; }
+        }
+        W.nfill[n] = n1 | (n2 << 16);
+      }
+      WG_SYNC();
+      WG_FOR(ti, ntodo) {
+        const uint32_t r = W.todo[ti] >> 10, p = W.todo[ti] & 1023u;
+        const uint32_t mi = RI_MATE(c.B->rinfo[g0 + r]), nm = c.B->name_rank[g0 + r] & 0xFFFFu;
+        const uint32_t X = W.occ[W.occ_base[r] + p] & 0x3FFFFFFFu;
+        const uint32_t lo = W.nocc[X], len = W.nocc[X + 1] - lo;
+        const uint32_t *vec = W.mv + 4 * (size_t)lo + (mi == 1 ? 2 * (size_t)len : 0);   // the OTHER mate's pushes
+        const uint32_t nv = mi == 1 ? (W.nfill[X] >> 16) : (W.nfill[X] & 0xFFFFu);
+        uint32_t total = 0;                                       // pushes of reads before r
+        { uint32_t f = 0, l = nv; while (l > 0) { const uint32_t h = l >> 1; if ((vec[f + h] >> 16) < r) { f += h + 1; l -= h + 1; } else l = h; } total = f; }
+        uint32_t first = 0, l2 = total;                           // std::lower_bound over the names, as pushed
+        while (l2 > 0) { const uint32_t h = l2 >> 1, mid = first + h; if ((vec[mid] & 0xFFFFu) < nm) { first = mid + 1; l2 = l2 - h - 1; } else l2 = h; }
+        const bool ovl = (first != total) && !(nm < (vec[first] & 0xFFFFu));
+        uint32_t f = lo, l = len;                                 // the occurrence's own entry in the sorted run
+        const uint32_t key = (r << 10) | p;
+        while (l > 0) { const uint32_t h = l >> 1; const uint32_t u = W.csr[f + h]; if (((CS_READ(u) << 10) | CS_POS(u)) < key) { f += h + 1; l -= h + 1; } else l = h; }
+        const uint32_t e = W.csr[f];
+        W.csr[f] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), ovl ? 2u : 0u);
+      }
     }
+    WG_LANE0 { S.seq_top = 0; S.qv_top = 0; }
   }
   WG_SYNC();
 }

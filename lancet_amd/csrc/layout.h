@@ -140,6 +140,7 @@ struct Work {
   uint32_t *chunk;        /* [2*((reads_cap + LC_MAXW/LC_SEG + 2)/64 + 2)] sweep origin/length per group of items */
   uint32_t *occ;          /* [occ_cap]     slot (then node) | ori<<31                           */
   uint32_t *slots;        /* [4*table_cap] k-mer table, 16 bytes per slot: tag (u64), first occurrence, node id */
+  uint32_t *mv;           /* [4*occ_cap] mate-name vectors of the nodes with flagged occurrences (read << 16 | name rank) */
   uint32_t *todo;         /* [table_cap] occurrences flagged by the mate-overlap prefilter (read << 10 | position)  */
   unsigned long long *slot_key; /* [table_cap * LC_NWMAX]                                    */
   uint32_t *bitmap;       /* [occ_cap/32 + 2]                                                  */
