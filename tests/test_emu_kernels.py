@@ -73,3 +73,23 @@ def test_emulated_kernels_match_oracle_on_random_cycle_prone_windows(seed):
     key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
     assert [key(s) for s in st] == [key(s) for s in ost]
     assert gu.digest_trace(tr) == gu.digest_trace(otr)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_emulated_kernels_match_oracle_on_random_linked_read_windows(seed):
+    """--linked-reads stress (oracle-pinned): random barcodes / haplotypes, overlapping mates, dense variants; records
+    (haplotype counts, barcode sets), stats and the stage trace (HPref / HPalt per transcript) must agree."""
+    from lancet_amd import frontend, synth
+    data = synth.make_tumor_normal(ref_len=3600, cov_t=36, cov_n=30, ref_seed=90 + seed, tumor_seed=190 + seed, normal_seed=290 + seed,
+                                   linked=True, dup_prob=0.5 if seed == 1 else 0.0, str_fraction=0.1, somatic_every=400,
+                                   germline_every=300, read_len=120, insert_mean=200.0 + 40 * seed, insert_sd=40.0)
+    windows = frontend.tile_region(data["ref"], data["rname"], "chr22:500-3000")
+    batch, kept = frontend.batch_from_sam(windows, synth.pairs_to_sorted_reads(data["tumor"]), synth.pairs_to_sorted_reads(data["normal"]),
+                                          linked=True)
+    p = abi.default_params(lr_mode=1)
+    v, st, tr = emu.run(batch, p, evt_cap=1 << 17)
+    ov, ost, otr = oracle.run(batch, p, verbose=True)
+    assert batch.n_windows >= 5 and len(ov) > 0 and v == ov
+    key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
+    assert [key(s) for s in st] == [key(s) for s in ost]
+    assert gu.digest_trace(tr) == gu.digest_trace(otr)

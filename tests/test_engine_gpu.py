@@ -145,3 +145,25 @@ def test_engine_matches_oracle_on_random_cycle_prone_windows(seed):
     assert [key(s) for s in st] == [key(s) for s in ost]
     assert gu.digest_trace(eng.trace_text()) == gu.digest_trace(otr)
     eng.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_engine_matches_oracle_on_random_linked_read_windows(seed):
+    """--linked-reads stress on the real engine (same inputs as test_emu_kernels.py): haplotype counts, barcode sets,
+    stats and the -v trace against the oracle."""
+    from lancet_amd import frontend, synth
+    data = synth.make_tumor_normal(ref_len=3600, cov_t=36, cov_n=30, ref_seed=90 + seed, tumor_seed=190 + seed, normal_seed=290 + seed,
+                                   linked=True, dup_prob=0.5 if seed == 1 else 0.0, str_fraction=0.1, somatic_every=400,
+                                   germline_every=300, read_len=120, insert_mean=200.0 + 40 * seed, insert_sd=40.0)
+    windows = frontend.tile_region(data["ref"], data["rname"], "chr22:500-3000")
+    batch, kept = frontend.batch_from_sam(windows, synth.pairs_to_sorted_reads(data["tumor"]), synth.pairs_to_sorted_reads(data["normal"]),
+                                          linked=True)
+    p = abi.default_params(lr_mode=1)
+    eng = engine.Engine(p, device=0, trace_words=1 << 17)
+    v, st = eng.process(batch)
+    ov, ost, otr = oracle.run(batch, p, verbose=True)
+    assert len(ov) > 0 and v == ov
+    key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
+    assert [key(s) for s in st] == [key(s) for s in ost]
+    assert gu.digest_trace(eng.trace_text()) == gu.digest_trace(otr)
+    eng.close()
