@@ -78,6 +78,7 @@ struct lancet_engine {
   int n_slots2 = 0;
   uint32_t node_cap1 = 8192;
   uint32_t debug_stop = 0;   // LANCET_STOP_PHASE (profiling only)
+  uint32_t table_start = 0;  // LANCET_TABLE_START (testing only: exercises the table-doubling path)
   int n_windows = 0, n_reads = 0, n_slots = 0;
   int n_rerun = 0;
   bool uploaded = false, ran = false;
@@ -120,6 +121,7 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (const char *s = getenv("LANCET_MAX_NODES")) e->max_nodes_limit = (uint32_t)atoi(s);
   if (const char *s = getenv("LANCET_NODE_CAP1")) e->node_cap1 = (uint32_t)atoi(s);
   if (const char *s = getenv("LANCET_STOP_PHASE")) e->debug_stop = (uint32_t)atoi(s);
+  if (const char *s = getenv("LANCET_TABLE_START")) e->table_start = lc_pow2_ge((uint32_t)atoi(s));
   *out = e;
   return LANCET_OK;
 }
@@ -170,6 +172,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   e->caps2 = lc_caps_for_batch(b, &e->params, e->evt_cap, e->max_nodes_limit, 2);
   e->caps2.var_cap = e->caps.var_cap; e->caps2.blob_cap = e->caps.blob_cap; e->caps2.bx_cap = e->caps.bx_cap;
   e->caps.debug_stop = e->debug_stop;
+  e->caps.table_start = e->caps2.table_start = e->table_start;
   // ---- inputs
   UP(e->d_params, &e->params, sizeof(lancet_params));
   UP(e->d_chr, b->chr_id, sizeof(int32_t) * nw);

@@ -53,6 +53,7 @@ struct WinShared {
   uint32_t mk[LC_STAGE][4], mmeta[LC_STAGE];     // staged quality masks of up to LC_STAGE occurrences
   uint32_t g_n[LC_PACK], g_lo[LC_PACK], g_cnt[LC_PACK], g_es[LC_PACK], g_min[LC_PACK], g_N;   // the candidates of the current group
   uint16_t acc[128][10];                         // per k-mer position running counts Tf Tr Nf Nr (+ lr_mode: T hp0-2, N hp0-2 minqv)
+  uint32_t tmask, N_last; int tfull;                 // open-addressing table of this build: size - 1, filled up, nodes of the window's previous build
   int cmp_ok;                                    // compress_prepare: the component qualifies for compress_fast
   int mr_src, mr_snk, mr_ambs, mr_ambk;          // mark_ref_scan: first / last qualifying reference offset, ambiguity flags
   int QS, LR;                                    // counters per (survivor, position): 4, or 10 with --linked-reads ; lr_mode
@@ -585,7 +586,8 @@ template <int NW>
 DEVNI void build_insert_pass(Ctx &c, bool verify) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   const int K = S.K;
-  const uint32_t mask = c.C->table_cap - 1;
+  const uint32_t mask = S.tmask;
+  const uint32_t plimit = mask + 1 < c.C->table_cap ? 48u : mask;   // a growable table is doubled rather than probed at length
   ITEMS_BEGIN(c, S, W)
     unsigned long long fw[NW], rc[NW];
     for (int w = 0; w < NW; ++w) { fw[w] = 0; rc[w] = 0; }
@@ -637,7 +639,7 @@ DEVNI void build_insert_pass(Ctx &c, bool verify) {
             if (old == h) break;
           }
           idx = (idx + 1) & mask;
-          if (++probes > mask) { OVF(c); break; }
+          if (++probes > plimit) { if (plimit < mask) S.tfull = 1; else OVF(c); break; }
         }
         dev_atomic_min(&SL_FIRST(W, idx), o);
         W.occ[o] = idx | (isF ? 0u : 0x80000000u);
@@ -663,7 +665,8 @@ DEVNI void build_insert_pass(Ctx &c, bool verify) {
 DEVNI void build_insert_occ_major(Ctx &c) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
   const int K = S.K;
-  const uint32_t mask = c.C->table_cap - 1;
+  const uint32_t mask = S.tmask;
+  const uint32_t plimit = mask + 1 < c.C->table_cap ? 48u : mask;   // a growable table is doubled rather than probed at length
   const unsigned long long kmask = (K == 32) ? ~0ULL : ((1ULL << (2 * K)) - 1ULL);
   const uint32_t refr = (uint32_t)(S.R - 1);
   const uint32_t g0 = c.B->read_begin[S.w];
@@ -702,7 +705,7 @@ DEVNI void build_insert_occ_major(Ctx &c) {
         if (old == 0 || old == h) break;
       }
       idx = (idx + 1) & mask;
-      if (++probes > mask) { OVF(c); break; }
+      if (++probes > plimit) { if (plimit < mask) S.tfull = 1; else OVF(c); break; }
     }
     if ((uint32_t)o < seen_first) dev_atomic_min(&SL_FIRST(W, idx), (uint32_t)o);     // most occurrences are not the first one
     W.occ[o] = idx | (isF ? 0u : 0x80000000u);
@@ -803,9 +806,18 @@ DEVNI void build_tables(Ctx &c) {
     S.O = o; S.totalreadbp = bp;
     if (o > C.occ_cap) OVF(c);
     ++S.n_builds;
+    // table size of this build: every slot is cleared and swept twice per build, so it follows the expected number of
+    // distinct k-mers (previous build of the window + 25 %, else an eighth of the occurrences + the reference's) at a
+    // load <= 2/3 instead of the worst case; a table that fills up is doubled and the insert redone (below).
+    const uint32_t est = S.N_last ? S.N_last + S.N_last / 4 : o / 8 + (uint32_t)S.reflen;
+    uint32_t tcap = 1024;
+    while (tcap < est + est / 2 && tcap < C.table_cap) tcap <<= 1;
+    if (C.table_start) tcap = C.table_start < C.table_cap ? C.table_start : C.table_cap;
+    S.tmask = tcap - 1; S.tfull = 0;
   }
   if (wg_bcast(&S.overflow)) return;
-  WG_FOR(i, C.table_cap) { lc_u4 z; z.x = 0; z.y = 0; z.z = LC_NIL; z.w = 0; *(lc_u4 *)(W.slots + 4 * (size_t)i) = z; }
+ again:
+  WG_FOR(i, (int)(S.tmask + 1)) { lc_u4 z; z.x = 0; z.y = 0; z.z = LC_NIL; z.w = 0; *(lc_u4 *)(W.slots + 4 * (size_t)i) = z; }
   WG_FOR(i, (int)(S.O / 32 + 2)) { W.bitmap[i] = 0; }
   WG_SYNC();
   PHASE(c, 2);
@@ -813,6 +825,7 @@ DEVNI void build_tables(Ctx &c) {
   if (K <= 31 && !S.hasN) build_insert_occ_major(c);
   else switch (S.NW) { case 1: build_insert_pass<1>(c, false); break; case 2: build_insert_pass<2>(c, false); break;
                        case 3: build_insert_pass<3>(c, false); break; default: build_insert_pass<4>(c, false); break; }
+  if (wg_bcast(&S.tfull)) { WG_LANE0 { S.tmask = S.tmask * 2 + 1; S.tfull = 0; } goto again; }
   if (K > 31 || S.hasN) {   // 64-bit tags of longer keys / of N k-mers can collide: compare the full keys
     switch (S.NW) { case 1: build_insert_pass<1>(c, true); break; case 2: build_insert_pass<2>(c, true); break;
                     case 3: build_insert_pass<3>(c, true); break; default: build_insert_pass<4>(c, true); break; }
@@ -821,15 +834,15 @@ DEVNI void build_tables(Ctx &c) {
   PHASE(c, 3);
   STOP_RET(c, 3);
   // ---- dense node ids in first-insertion order (= order of first occurrence, Graph.cc:163-197)
-  WG_FOR(i, C.table_cap) { if (ld2(&SL_TAG(W, i)) != 0) { uint32_t f = ld2(&SL_FIRST(W, i)); dev_atomic_or(&W.bitmap[f >> 5], 1u << (f & 31)); } }
+  WG_FOR(i, (int)(S.tmask + 1)) { if (ld2(&SL_TAG(W, i)) != 0) { uint32_t f = ld2(&SL_FIRST(W, i)); dev_atomic_or(&W.bitmap[f >> 5], 1u << (f & 31)); } }
   WG_SYNC();
   int nwords = (int)(S.O / 32 + 1);
   WG_FOR(i, nwords) { W.bitpre[i] = (uint32_t)dev_popc(ld2(&W.bitmap[i])); }
   WG_SYNC();
   wg_scan(W.bitpre, nwords, S);
-  WG_LANE0 { S.N = S.part[LANCET_WG]; if (S.N > C.node_cap) OVF(c); if (S.N > S.max_nodes) S.max_nodes = S.N; S.nspecial = 0; }
+  WG_LANE0 { S.N = S.part[LANCET_WG]; S.N_last = (uint32_t)S.N; if (S.N > C.node_cap) OVF(c); if (S.N > S.max_nodes) S.max_nodes = S.N; S.nspecial = 0; }
   if (wg_bcast(&S.overflow)) return;
-  WG_FOR(i, C.table_cap) {
+  WG_FOR(i, (int)(S.tmask + 1)) {
     if (ld2(&SL_TAG(W, i)) != 0) {
       uint32_t f = ld2(&SL_FIRST(W, i));
       uint32_t id = W.bitpre[f >> 5] + (uint32_t)dev_popc(ld2(&W.bitmap[f >> 5]) & ((1u << (f & 31)) - 1u));
@@ -2317,7 +2330,7 @@ DEVNI uint32_t kmer_lookup(Ctx &c, const uint8_t *codes) {
   for (int w = 0; w < LC_NWMAX; ++w) { fw[w] = 0; rc[w] = 0; }
   for (int i = 0; i < K; ++i) { key_push_fw(fw, NW, K, codes[i] & 3); key_push_rc(rc, NW, K, codes[i] & 3); }
   const unsigned long long *ck = key_less(fw, rc, NW) ? fw : rc;
-  const uint32_t mask = c.C->table_cap - 1;
+  const uint32_t mask = S.tmask;
   unsigned long long h = 0; uint32_t idx;
   if (NW == 1 && K <= 31) { h = ck[0] + 1ULL; idx = (uint32_t)mix64(h) & mask; }
   else {
@@ -2660,7 +2673,7 @@ DEVNI void count_ref_path(Ctx &c) {
 DEV void process_window(Ctx &c, int w) {
   volatile WinShared &S = *c.S; Work &W = *c.W; const DevBatch &B = *c.B;
   WG_LANE0 {
-    S.w = w; S.overflow = 0; S.evt_len = 0; S.emit_seq = 0; S.n_kmers = 0; S.max_nodes = 0; S.n_builds = 0; S.final_k = 0;
+    S.w = w; S.overflow = 0; S.evt_len = 0; S.emit_seq = 0; S.n_kmers = 0; S.max_nodes = 0; S.n_builds = 0; S.N_last = 0; S.final_k = 0;
     S.status = LANCET_W_OK;
     S.LR = c.C->lr_mode ? 1 : 0; S.QS = S.LR ? 10 : 4;
     S.reflen = (int)(B.ref_off[w + 1] - B.ref_off[w]);

@@ -72,6 +72,7 @@ struct EngineCaps {
   uint32_t max_k;        /* largest k the engine was created for                           */
   uint32_t qv_cap;       /* (survivor, k-mer position) entries of per-position quality counts */
   uint32_t debug_stop;   /* profiling only: abandon every window after this phase marker (0 = off)  */
+  uint32_t table_start;  /* testing only: first table size of every build (power of two; 0 = estimated)       */
   uint32_t lr_mode;      /* --linked-reads: 10 instead of 4 counters per (survivor, position), barcode outputs */
   uint32_t bx_cap;       /* barcode ids (u32) of the variants' barcode sets, whole batch (lr_mode)   */
 };

@@ -93,3 +93,16 @@ def test_emulated_kernels_match_oracle_on_random_linked_read_windows(seed):
     key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
     assert [key(s) for s in st] == [key(s) for s in ost]
     assert gu.digest_trace(tr) == gu.digest_trace(otr)
+
+
+@pytest.mark.parametrize("name", ["dups", "nref"])
+def test_table_doubling_path_gives_the_same_graphs(name, monkeypatch):
+    """Each build sizes its k-mer table from an estimate and doubles it when it fills up; started at 64 slots, every
+    build of every window goes through several doublings and must end with the same records, stats and trace
+    (dups: k up to the 90s through the rolling-insert + verify passes; nref: N k-mers)."""
+    meta, batch, kept, (min_k, max_k) = gu.case_batch(name)
+    p = abi.default_params(min_k=min_k, max_k=max_k)
+    base = emu.run(batch, p, evt_cap=1 << 17)
+    monkeypatch.setenv("LANCET_TABLE_START", "64")
+    grown = emu.run(batch, p, evt_cap=1 << 17)
+    assert grown[0] == base[0] and grown[1] == base[1] and gu.digest_trace(grown[2]) == gu.digest_trace(base[2])
