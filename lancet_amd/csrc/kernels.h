@@ -834,7 +834,11 @@ DEVNI void build_tables(Ctx &c) {
   PHASE(c, 3);
   STOP_RET(c, 3);
   // ---- dense node ids in first-insertion order (= order of first occurrence, Graph.cc:163-197)
-  WG_FOR(i, (int)(S.tmask + 1)) { if (ld2(&SL_TAG(W, i)) != 0) { uint32_t f = ld2(&SL_FIRST(W, i)); dev_atomic_or(&W.bitmap[f >> 5], 1u << (f & 31)); } }
+  WG_SYNC_FENCE();   // the insert pass read slots through the L1 while atomics changed them at L2: drop those lines, then whole-slot plain loads
+  WG_FOR(i, (int)(S.tmask + 1)) {
+    const lc_u4 sv = *(const lc_u4 *)(W.slots + 4 * (size_t)i);
+    if ((sv.x | sv.y) != 0) dev_atomic_or(&W.bitmap[sv.z >> 5], 1u << (sv.z & 31));
+  }
   WG_SYNC();
   int nwords = (int)(S.O / 32 + 1);
   WG_FOR(i, nwords) { W.bitpre[i] = (uint32_t)dev_popc(ld2(&W.bitmap[i])); }
@@ -843,11 +847,13 @@ DEVNI void build_tables(Ctx &c) {
   WG_LANE0 { S.N = S.part[LANCET_WG]; S.N_last = (uint32_t)S.N; if (S.N > C.node_cap) OVF(c); if (S.N > S.max_nodes) S.max_nodes = S.N; S.nspecial = 0; }
   if (wg_bcast(&S.overflow)) return;
   WG_FOR(i, (int)(S.tmask + 1)) {
-    if (ld2(&SL_TAG(W, i)) != 0) {
-      uint32_t f = ld2(&SL_FIRST(W, i));
+    const lc_u4 sv = *(const lc_u4 *)(W.slots + 4 * (size_t)i);
+    if ((sv.x | sv.y) != 0) {
+      const uint32_t f = sv.z;
       uint32_t id = W.bitpre[f >> 5] + (uint32_t)dev_popc(ld2(&W.bitmap[f >> 5]) & ((1u << (f & 31)) - 1u));
       SL_NODE(W, i) = id;
-      const unsigned long long tg = ld2(&SL_TAG(W, i));
+      W.todo[i] = id;                                              // compact copy for the slot -> node pass (todo[] is idle until the mate prefilter)
+      const unsigned long long tg = (unsigned long long)sv.x | ((unsigned long long)sv.y << 32);
       if (S.NW == 1 && K <= 31 && !(tg >> 63)) W.nkey[(size_t)id * LC_NWMAX] = tg - 1ULL;            // exact tag: key + 1
       else for (int w = 0; w < S.NW; ++w) W.nkey[(size_t)id * LC_NWMAX + w] = W.slot_key[(size_t)i * LC_NWMAX + w];
       if (S.hasN) W.gr[id].flags = (tg >> 63) ? NF_NKMER : 0u;        // (without N in the window the gather pass writes the flags whole)
@@ -890,8 +896,8 @@ DEVNI void build_csr(Ctx &c) {
   //      occurrence-major (lane = consecutive occurrence index): occ[] is read and rewritten in whole cache lines
   WG_FOR(o, S.O) {
     const uint32_t oc = W.occ[o];
-    const uint32_t X = SL_NODE(W, oc & 0x3FFFFFFFu);
-    dev_atomic_add(&W.nocc[X], 1u);
+    const uint32_t X = W.todo[oc & 0x3FFFFFFFu];               // 4-byte copies of the node ids: a quarter of the slots' footprint, mostly L1 hits
+    W.mv[o] = dev_atomic_add(&W.nocc[X], 1u);                   // arrival rank on the node = place in its csr run (mv[] is idle until the replay)
     W.occ[o] = X | (oc & 0x80000000u);
   }
   WG_SYNC();
@@ -958,7 +964,7 @@ DEVNI void build_csr(Ctx &c) {
       const uint32_t oc = W.occ[o];
       const uint32_t X = oc & 0x3FFFFFFFu;
       const uint32_t st = rcur == refr ? 2u : ((oc & 0x40000000u) ? 1u : 0u);     // the reference read never counts (Graph.cc:265)
-      const uint32_t at = W.nocc[X] + dev_atomic_add(&W.nfill[X], 1u);
+      const uint32_t at = W.nocc[X] + W.mv[o];
       W.csr[at] = CS_MAKE(rcur, (uint32_t)o - W.occ_base[rcur], oc >> 31, st);
     }
   }
