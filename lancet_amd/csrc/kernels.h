@@ -52,6 +52,8 @@ struct WinShared {
   int wk_n;                                      // walk_prepare: number of non-match columns
   uint32_t mk[LC_STAGE][4], mmeta[LC_STAGE];     // staged quality masks of up to LC_STAGE occurrences
   uint32_t g_n[LC_PACK], g_lo[LC_PACK], g_cnt[LC_PACK], g_es[LC_PACK], g_min[LC_PACK], g_N;   // the candidates of the current group
+  uint32_t g_fl[LC_PACK]; float g_tt[LC_PACK], g_tn[LC_PACK];      // their flags and tumor / normal coverage (fetched while the occurrences are staged)
+  uint32_t cq_n[64], cq_lo[64], cq_cnt[64];                        // the next 64 candidates (node, csr start, occurrences), fetched together
   uint16_t acc[128][10];                         // per k-mer position running counts Tf Tr Nf Nr (+ lr_mode: T hp0-2, N hp0-2 minqv)
   uint32_t tmask, N_last; int tfull;                 // open-addressing table of this build: size - 1, filled up, nodes of the window's previous build
   int cmp_ok;                                    // compress_prepare: the component qualifies for compress_fast
@@ -1163,12 +1165,23 @@ DEVNI void build_qcounts(Ctx &c) {
   //      Step 2, lane = (candidate, k-mer position): count over the candidate's staged occurrences out of LDS.
   const uint32_t ncand = wg_bcastu(&S.part[LANCET_WG]);
   const int QS = S.QS; const bool LR = S.LR != 0;
-  uint32_t ci = 0;
+  uint32_t ci = 0, cqb = 0;
+  bool cq_valid = false;
   while (ci < ncand) {
+    if (!cq_valid || ci + LC_PACK > cqb + 64) {  // candidate list a line at a time into LDS: group formation is a lane-0 chain
+      WG_FOR(t, 64) {
+        const uint32_t x = ci + (uint32_t)t;
+        if (x < ncand) { S.cq_n[t] = W.pnodes[x]; S.cq_lo[t] = W.pedges[x]; S.cq_cnt[t] = W.ht_bucket[x]; }
+      }
+      WG_SYNC();
+      cqb = ci; cq_valid = true;
+    }
     WG_LANE0 {                                   // group formation
       uint32_t gN = 0, tot = 0;
       for (uint32_t k = 0; k < LC_PACK && ci + k < ncand; ++k) {
-        const uint32_t n = W.pnodes[ci + k], lo = W.pedges[ci + k], cnt = W.ht_bucket[ci + k];
+        const uint32_t q = ci - cqb + k;
+        const uint32_t n = S.cq_n[q], lo = S.cq_lo[q], cnt = S.cq_cnt[q];
+        if (cnt > 0xFFFFu) OVF(c);                                // the per-position counters are 16 bits wide
         if (gN > 0 && tot + cnt > LC_STAGE) break;
         S.g_n[gN] = n; S.g_lo[gN] = lo; S.g_cnt[gN] = cnt; S.g_es[gN] = tot; S.g_min[gN] = 0x7FFFFFFFu;
         ++gN; tot += cnt;
@@ -1187,6 +1200,9 @@ DEVNI void build_qcounts(Ctx &c) {
       const int cnt = (int)(total - r0 < LC_STAGE ? total - r0 : LC_STAGE);
       WG_FOR(ln, LANCET_WG) {   // ---- step 1: entries ln, ln+64, ... of the staging area
         constexpr int U = LC_STAGE / LANCET_WG;
+        float gcov[4] = {0.f, 0.f, 0.f, 0.f}; uint32_t gfl = 0;
+        const bool gfetch = r0 == 0 && ln < gN;                  // lane k: candidate k's record for the tail of this group
+        if (gfetch) { const NodeGr &G = W.gr[S.g_n[ln]]; gcov[0] = G.cov[0]; gcov[1] = G.cov[1]; gcov[2] = G.cov[2]; gcov[3] = G.cov[3]; gfl = G.flags; }
         uint32_t e[U], m[U][4], meta[U]; bool act[U];
         const uint32_t *gd[U]; uint32_t ri[U];
         for (int u = 0; u < U; ++u) {
@@ -1218,7 +1234,9 @@ DEVNI void build_qcounts(Ctx &c) {
         }
         for (int u = 0; u < U; ++u) {
           const int j = ln + u * LANCET_WG;
-          if (j < cnt) { S.mk[j][0] = m[u][0]; S.mk[j][1] = m[u][1]; S.mk[j][2] = m[u][2]; S.mk[j][3] = m[u][3]; S.mmeta[j] = meta[u]; }
+          // (k <= 96 leaves the fourth mask word free: the class word rides along, one 16-byte LDS read per entry in step 2)
+          if (u == 0 && gfetch) { S.g_tt[ln] = gcov[0] + gcov[1]; S.g_tn[ln] = gcov[2] + gcov[3]; S.g_fl[ln] = gfl; }
+          if (j < cnt) { S.mk[j][0] = m[u][0]; S.mk[j][1] = m[u][1]; S.mk[j][2] = m[u][2]; S.mk[j][3] = K <= 96 ? meta[u] : m[u][3]; S.mmeta[j] = meta[u]; }
         }
       }
       WG_SYNC();
@@ -1226,33 +1244,39 @@ DEVNI void build_qcounts(Ctx &c) {
       WG_FOR(t, gN * K) {   // ---- step 2
         const int k = big ? 0 : t / K, i = big ? t : t - k * K;
         const int es = big ? 0 : (int)S.g_es[k], ee = big ? cnt : es + (int)S.g_cnt[k];
-        const uint32_t (*mk)[4] = (const uint32_t (*)[4])S.mk;       // plain LDS reads: staged before the barrier above
         const uint32_t *mm = (const uint32_t *)S.mmeta;
-        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        unsigned long long a = 0;                                      // four 16-bit counters: class c at bits 16c
         uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0;       // lr_mode: hp0/1/2_minqv tumor, normal
-        if (!first) { a0 = S.acc[i][0]; a1 = S.acc[i][1]; a2 = S.acc[i][2]; a3 = S.acc[i][3]; }
+        if (!first) a = (unsigned long long)S.acc[i][0] | ((unsigned long long)S.acc[i][1] << 16) | ((unsigned long long)S.acc[i][2] << 32) | ((unsigned long long)S.acc[i][3] << 48);
         if (!first && LR) { h0 = S.acc[i][4]; h1 = S.acc[i][5]; h2 = S.acc[i][6]; h3 = S.acc[i][7]; h4 = S.acc[i][8]; h5 = S.acc[i][9]; }
-        if (!LR) {
-          for (int j = es; j < ee; ++j) {
-            const uint32_t meta = mm[j];
-            const int idx = (meta & 8u) ? (K - 1 - i) : i;
-            const uint32_t bit = (mk[j][idx >> 5] >> (idx & 31)) & meta & 1u;
-            const uint32_t cls = (meta >> 1) & 3u;
-            a0 += (cls == 0) ? bit : 0u; a1 += (cls == 1) ? bit : 0u; a2 += (cls == 2) ? bit : 0u; a3 += (cls == 3) ? bit : 0u;
-          }
-        } else {
-          for (int j = es; j < ee; ++j) {
-            const uint32_t meta = mm[j];
-            const int idx = (meta & 8u) ? (K - 1 - i) : i;
-            const uint32_t bit = (mk[j][idx >> 5] >> (idx & 31)) & meta & 1u;
-            const uint32_t cls = (meta >> 1) & 3u;
-            a0 += (cls == 0) ? bit : 0u; a1 += (cls == 1) ? bit : 0u; a2 += (cls == 2) ? bit : 0u; a3 += (cls == 3) ? bit : 0u;
-            // Node_t::updateHPCovDistr: quality ok and the stored count had grown
+        // bit of k-mer position i in an entry: position i of a forward occurrence, K-1-i of a reverse one
+        const int iR = K - 1 - i;
+        const int wF = i >> 5, sF = i & 31, wR = iR >> 5, sR = iR & 31;
+        auto add_entry = [&](const lc_u4 v, const uint32_t meta) {
+          const bool rev = (meta & 8u) != 0;
+          const int wsel = rev ? wR : wF, sh = rev ? sR : sF;
+          const uint32_t word = K <= 32 ? v.x : (wsel == 0 ? v.x : wsel == 1 ? v.y : wsel == 2 ? v.z : v.w);
+          const uint32_t bit = (word >> sh) & meta & 1u;
+          const uint32_t cls = (meta >> 1) & 3u;
+          a += (unsigned long long)bit << (16 * cls);
+          if (LR) {   // Node_t::updateHPCovDistr: quality ok and the stored count had grown
             const uint32_t gT = (cls < 2) ? bit : 0u, gNm = (cls >= 2) ? bit : 0u, gr3 = meta >> 4;
             h0 += gT & gr3; h1 += gT & (gr3 >> 1); h2 += gT & (gr3 >> 2);
             h3 += gNm & gr3; h4 += gNm & (gr3 >> 1); h5 += gNm & (gr3 >> 2);
           }
+        };
+        const lc_u4 *mk4 = (const lc_u4 *)S.mk;                       // plain LDS reads: staged before the barrier above
+        if (K <= 96) {   // the class word is the entry's fourth word; four entries in flight per trip (the loop is LDS-latency bound)
+          int j = es;
+          for (; j + 4 <= ee; j += 4) {
+            const lc_u4 v0 = mk4[j], v1 = mk4[j + 1], v2 = mk4[j + 2], v3 = mk4[j + 3];
+            add_entry(v0, v0.w); add_entry(v1, v1.w); add_entry(v2, v2.w); add_entry(v3, v3.w);
+          }
+          for (; j < ee; ++j) { const lc_u4 v = mk4[j]; add_entry(v, v.w); }
+        } else {
+          for (int j = es; j < ee; ++j) add_entry(mk4[j], mm[j]);
         }
+        const uint32_t a0 = (uint32_t)(a & 0xFFFFu), a1 = (uint32_t)((a >> 16) & 0xFFFFu), a2 = (uint32_t)((a >> 32) & 0xFFFFu), a3 = (uint32_t)(a >> 48);
         if (!last) {
           S.acc[i][0] = (uint16_t)a0; S.acc[i][1] = (uint16_t)a1; S.acc[i][2] = (uint16_t)a2; S.acc[i][3] = (uint16_t)a3;
           if (LR) { S.acc[i][4] = (uint16_t)h0; S.acc[i][5] = (uint16_t)h1; S.acc[i][6] = (uint16_t)h2; S.acc[i][7] = (uint16_t)h3; S.acc[i][8] = (uint16_t)h4; S.acc[i][9] = (uint16_t)h5; }
@@ -1272,7 +1296,7 @@ DEVNI void build_qcounts(Ctx &c) {
       const int k = t / K, i = t - k * K;
       const uint32_t n = S.g_n[k];
       const int minqv = (int)S.g_min[k];
-      const float tt = W.gr[n].cov[0] + W.gr[n].cov[1], tn = W.gr[n].cov[2] + W.gr[n].cov[3];
+      const float tt = S.g_tt[k], tn = S.g_tn[k];
       const bool low = (minqv <= c.P->low_cov_threshold) || ((double)minqv <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
       if (!low) {
         const uint32_t base = (qi0 + (uint32_t)k) * (uint32_t)K;
@@ -1280,18 +1304,18 @@ DEVNI void build_qcounts(Ctx &c) {
         W.seq[base + i] = SD_MAKE(n, i, key_base(kk, K, i));
       }
     }
-    WG_FOR(k, gN) {                              // one lane per candidate of the group: their record loads overlap
+    WG_FOR(k, gN) {                              // one lane per candidate of the group: stores only
       {
         const uint32_t n = S.g_n[k];
         NodeGr &G = W.gr[n];
         const int minqv = (int)S.g_min[k];
-        const float tt = G.cov[0] + G.cov[1], tn = G.cov[2] + G.cov[3];
+        const float tt = S.g_tt[k], tn = S.g_tn[k];
         const bool low = (minqv <= c.P->low_cov_threshold) || ((double)minqv <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
         G.mincovqv = minqv;
         if (!low) {
           const uint32_t qi = qi0 + (uint32_t)k, base = qi * (uint32_t)K;
           G.seq_clo = base; G.seq_lo = base; G.seq_hi = base + K; G.seq_chi = base + K;
-          const uint32_t f = G.flags;
+          const uint32_t f = S.g_fl[k];
           G.nkmT = ((f & NF_TUMOR) && !(f & NF_NORMAL)) ? 1u : 0u;      // cov_status == 'T'
           G.nqv = qi;
           G.flags = f | NF_SURV;

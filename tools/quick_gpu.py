@@ -21,8 +21,12 @@ def replicate(batch, times):
 
 case = sys.argv[1] if len(sys.argv) > 1 else "tile30"
 times = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-meta, batch, kept, (mk, xk) = gu.case_batch(case)
-big = replicate(batch, times)
+if case == "bench":                                   # the bench.py workload, `times` windows
+    from lancet_amd import workload
+    big, mk, xk = workload.make_scan_batch(times, 30, 30, seed=22), 11, 101
+else:
+    meta, batch, kept, (mk, xk) = gu.case_batch(case)
+    big = replicate(batch, times)
 p = abi.default_params(min_k=mk, max_k=xk)
 eng = engine.Engine(p)
 t = time.time(); eng.upload(big); print("upload s", time.time() - t, "windows", big.n_windows, "slots/bytes", eng.geometry())
