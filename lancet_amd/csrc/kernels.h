@@ -1805,42 +1805,84 @@ DEVNI void remove_short_links(Ctx &c, int comp) {                     // referen
   print_stats(c, comp);
 }
 
-DEVNI int mark_connected_components(Ctx &c) {                         // reference src/Graph.cc:2252-2336
+// markConnectedComponents (reference src/Graph.cc:2252-2336), whole wave.  Only the partition, the numbering of the
+// components (in order of their first node in table order) and which of them hold a reference k-mer are observable,
+// not the breadth-first order the reference finds them in, so the partition is computed by min-label hooking with
+// pointer jumping (O(log n) rounds, every lane busy) instead of a one-lane queue walk that pays a full memory round trip
+// per node.  parent[] (node ids; a node's label only ever decreases) is updated with atomics and read at L2.
+DEVNI void mark_connected_components_wg(Ctx &c) {
   volatile WinShared &S = *c.S; Work &W = *c.W;
-  // "already labelled" lives in a bitmap over node ids (a few hundred bytes that stay in cache) instead of in the
-  // 128-byte node records: a visit costs one record load, not one per neighbour as well
-  uint32_t *seen = W.bitmap;
-  const uint32_t nw = (c.C->node_cap + c.C->special_cap) / 32 + 1;
-  for (uint32_t i = 0; i < nw; ++i) seen[i] = 0;
-  int comp = 0, refcomp = 0;
-  uint32_t *Q = W.scratch;                                            // FIFO; every node enqueued <= deg+1 times
-  uint32_t qcap = 2 * (c.C->node_cap + c.C->special_cap);
-  evt(c, EV_CC, S.M);
-  for (uint32_t i = 0; i < S.M; ++i) {
-    uint32_t s = W.order[i];
-    if (seen[s >> 5] & (1u << (s & 31))) continue;
-    ++comp;
-    uint32_t qh = 0, qt = 0;
-    int touches = 0;
-    // breadth-first; a node is labelled when first reached (the reference labels on pop; same partition)
-    seen[s >> 5] |= 1u << (s & 31);
-    W.gr[s].comp = comp; Q[qt++] = s;
-    while (qh < qt) {
-      uint32_t cur = Q[qh++];
-      if (W.gr[cur].flags & NF_INMER) ++touches;
-      for (int e = 0; e < (int)W.gr[cur].necnt; ++e) {
-        uint32_t nx = ED_TO(W.gr[cur].edges[e]);
-        if (seen[nx >> 5] & (1u << (nx & 31))) continue;
-        if (qt >= qcap) { OVF(c); return comp; }
-        seen[nx >> 5] |= 1u << (nx & 31);
-        W.gr[nx].comp = comp; Q[qt++] = nx;
-      }
-    }
-    if (touches) { ++refcomp; evt(c, EV_CCID, comp); }
+  const int M = (int)wg_bcastu(&S.M);
+  const uint32_t nodes = c.C->node_cap + c.C->special_cap;
+  uint32_t *parent = W.scratch, *minpos = W.scratch + nodes, *touch = W.pnodes, *first = W.pedges, *cid = W.nfill;
+  WG_LANE0 { evt(c, EV_CC, S.M); }
+  // one pass over the 128-byte node records: neighbours as a 16-byte record per table position (degree, three ids; the
+  // rare node of higher degree keeps using its record), so that a hooking round reads whole lines
+  uint32_t *adj = W.mv;                                          // idle after the build
+  WG_FOR(i, M) {
+    const uint32_t n = W.order[i];
+    const NodeGr &G = W.gr[n];
+    const int ne = (int)G.necnt;
+    lc_u4 a; a.x = (uint32_t)ne; a.y = ne > 0 ? ED_TO(G.edges[0]) : n; a.z = ne > 1 ? ED_TO(G.edges[1]) : n; a.w = ne > 2 ? ED_TO(G.edges[2]) : n;
+    *(lc_u4 *)(adj + 4 * (size_t)i) = a;
+    parent[n] = n; minpos[n] = LC_NIL; touch[n] = (G.flags & NF_INMER) ? 2u : 0u;
   }
-  S.refcomp = refcomp;
-  evt(c, EV_CCEND, comp, refcomp);
-  return comp;
+  WG_SYNC_FENCE();
+  while (true) {
+    WG_LANE0 { S.tmp0 = 0; }
+    // hook: the smallest label around a node goes to the node and to its current parent
+    WG_FOR(i, M) {
+      const uint32_t u = W.order[i];
+      const lc_u4 a = *(const lc_u4 *)(adj + 4 * (size_t)i);
+      const uint32_t pu = ld2(&parent[u]);
+      const uint32_t p1 = ld2(&parent[a.y]), p2 = ld2(&parent[a.z]), p3 = ld2(&parent[a.w]);   // (absent neighbours stand in as the node itself)
+      uint32_t m = pu;
+      if (p1 < m) m = p1;
+      if (p2 < m) m = p2;
+      if (p3 < m) m = p3;
+      if (a.x > 3) { const NodeGr &G = W.gr[u]; for (int e = 3; e < (int)a.x; ++e) { const uint32_t pv = ld2(&parent[ED_TO(G.edges[e])]); if (pv < m) m = pv; } }
+      if (m < pu) { dev_atomic_min(&parent[pu], m); dev_atomic_min(&parent[u], m); S.tmp0 = 1; }
+    }
+    WG_SYNC();
+    // jump: every node to its root
+    while (true) {
+      WG_LANE0 { S.tmp1 = 0; }
+      WG_FOR(i, M) {
+        const uint32_t u = W.order[i];
+        const uint32_t pu = ld2(&parent[u]), gp = ld2(&parent[pu]);
+        if (gp != pu) { dev_atomic_min(&parent[u], gp); S.tmp1 = 1; }
+      }
+      WG_SYNC();
+      if (!wg_bcast(&S.tmp1)) break;
+    }
+    if (!wg_bcast(&S.tmp0)) break;
+  }
+  // numbering: a component's place is that of its first node in table order
+  WG_FOR(i, M) {
+    const uint32_t u = W.order[i], r = ld2(&parent[u]);
+    dev_atomic_min(&minpos[r], (uint32_t)i);
+    if (ld2(&touch[u]) & 2u) dev_atomic_or(&touch[r], 1u);
+  }
+  WG_SYNC();
+  WG_FOR(i, M) { const uint32_t r = ld2(&parent[W.order[i]]); first[i] = (ld2(&minpos[r]) == (uint32_t)i) ? 1u : 0u; }
+  WG_LANE0 { first[M] = 0; }
+  wg_scan(first, M + 1, S);
+  const int numcomp = (int)wg_bcastu(&S.part[LANCET_WG]);
+  WG_LANE0 { S.tmp1 = 0; }
+  WG_FOR(i, M) {
+    const uint32_t r = ld2(&parent[W.order[i]]);
+    if (ld2(&minpos[r]) == (uint32_t)i) { cid[r] = first[i] + 1u; if (ld2(&touch[r]) & 1u) dev_atomic_add((uint32_t *)&S.tmp1, 1u); }
+  }
+  WG_SYNC_FENCE();
+  WG_FOR(i, M) { const uint32_t u = W.order[i]; W.gr[u].comp = (int)cid[ld2(&parent[u])]; }
+  WG_SYNC();
+  WG_LANE0 {
+    S.refcomp = S.tmp1; S.numcomp = numcomp;
+    if (c.C->evt_cap) {
+      for (int i = 0; i < M; ++i) { const uint32_t r = ld2(&parent[W.order[i]]); if (ld2(&minpos[r]) == (uint32_t)i && (ld2(&touch[r]) & 1u)) evt(c, EV_CCID, cid[r]); }
+    }
+    evt(c, EV_CCEND, (uint32_t)numcomp, (uint32_t)S.refcomp);
+  }
 }
 
 // markRefEnds (reference src/Graph.cc:2028-2228).  The node of the reference k-mer at `offset` is the node
@@ -2764,10 +2806,8 @@ DEV void process_window(Ctx &c, int w) {
     }
     WG_SYNC();
     clean_dead_wg(c);
-    WG_LANE0 {
-      print_stats(c, 0);
-      S.numcomp = mark_connected_components(c);
-    }
+    WG_LANE0 { print_stats(c, 0); }
+    mark_connected_components_wg(c);
     int numcomp = wg_bcast(&S.numcomp);
     bool brk = false;
     PHASE(c, 9);
