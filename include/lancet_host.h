@@ -1,0 +1,72 @@
+/* lancet_host.h -- C-ABI of the native host side around the engine.
+ *
+ * What the reference does between its command line and the processGraph call, restated for the batch interface of
+ * lancet_engine.h:
+ *      input decoding      BamReader + faidx                    reference src/Microassembler.cc:436-655, src/Lancet.cc:189-316
+ *      window tiling       loadRefs                             reference src/Lancet.cc:189-316
+ *      window order        std::map<string, Ref_t*> iteration   reference src/Microassembler.cc:779
+ *      per-window filters  isRepeat on the window reference     reference src/Microassembler.cc:800, src/util.cc:295-315
+ *                          isActiveRegion                       reference src/Microassembler.cc:253-432
+ *                          extractReads                         reference src/Microassembler.cc:436-655
+ * The output is a `lancet_window_batch` (arrays owned by the host object, valid until the next lancet_host_batch or
+ * lancet_host_close) ready for lancet_engine_upload.  Pure CPU code: no device, no engine involved.
+ * The bamtools / htslib libraries the reference reads its inputs with are not part of /root/reference; the readers
+ * here follow the published BGZF / BAM (SAM specification v1 sections 4.1-4.2) and FASTA formats.
+ */
+#ifndef LANCET_HOST_H
+#define LANCET_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "lancet_engine.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* command-line knobs of the host side (defaults: reference src/Lancet.hh:33-81, src/Lancet.cc:627-637) */
+typedef struct lancet_host_opts {
+  int32_t padding;                 /* --padding 250                                    */
+  int32_t window_size;             /* --window-size 600                                */
+  int32_t min_map_qual;            /* --min-map-qual 15                                */
+  int32_t max_delta_as_xs;         /* --max-as-xs-diff 5                               */
+  int32_t primary_alignment_only;  /* --primary-alignment-only                         */
+  int32_t xa_filter;               /* --XA-tag-filter                                  */
+  int32_t max_avg_cov;             /* --max-avg-cov 10000                              */
+  int32_t max_k;                   /* --max-k 101 (window reference repeat test)       */
+  int32_t linked;                  /* --linked-reads: fill bx_rank / hp                */
+  int32_t active_region;           /* 1 unless --active-region-off                     */
+  int32_t min_evidence;            /* active regions: filters.minAltCntTumor (3)       */
+  int32_t min_qual_call;           /* active regions: MIN_QUAL_CALL, ASCII (17 + '!')  */
+} lancet_host_opts;
+
+typedef struct lancet_host lancet_host;
+
+void lancet_host_opts_default(lancet_host_opts *o);
+
+/* Decodes both BAMs (whole files, coordinate order assumed as the reference does) and loads the FASTA.
+ * NULL on failure with a message in err. */
+lancet_host *lancet_host_open(const char *tumor_bam, const char *normal_bam, const char *ref_fasta, char *err, size_t errlen);
+void lancet_host_close(lancet_host *h);
+const char *lancet_host_last_error(const lancet_host *h);
+
+/* SM of the first @RG line of the normal (which = 0) / tumor (which = 1) BAM, "NA" if there is none
+ * (Microassembler::retriveSampleName, reference src/Microassembler.cc:52-67). */
+const char *lancet_host_sample(const lancet_host *h, int which);
+
+/* Tiles "chr:start-end" (or "chr") into windows and puts them in processing order.  Returns their number, < 0 on error. */
+int lancet_host_tile(lancet_host *h, const char *region, const lancet_host_opts *o);
+const char *lancet_host_chrom(const lancet_host *h);
+const char *lancet_host_window_hdr(const lancet_host *h, int w);            /* "chr:start-end" of tiled window w */
+
+/* Windows [w_begin, w_end) of the tiling through the per-window filters and read selection.  `out` points into
+ * arrays owned by h; kept[i] = tiled index of batch window i (kept has room for w_end - w_begin entries). */
+int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o, lancet_window_batch *out,
+                      int32_t *kept, int32_t *n_kept);
+/* barcode strings of the last batch by bx_rank (linked reads) */
+const char *const *lancet_host_bx_names(const lancet_host *h, uint32_t *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LANCET_HOST_H */

@@ -1,4 +1,5 @@
-"""Builds lancet_amd/csrc/liblancet_engine.so (HIP kernels + C-ABI + host VariantDB) for gfx950, in-tree."""
+"""Builds lancet_amd/csrc/liblancet_engine.so (HIP kernels + C-ABI + host VariantDB + native host front end) for gfx950
+and the command-line program lancet_amd/bin/lancet_gpu, in-tree."""
 from __future__ import annotations
 
 import os
@@ -7,12 +8,14 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "liblancet_engine.so")
-SOURCES = ["engine.hip", "host_vdb.cc"]
-HEADERS = ["kernels.h", "wave.h", "layout.h", "host_common.h", os.path.join("..", "..", "include", "lancet_engine.h")]
+SOURCES = ["engine.hip", "host_vdb.cc", "host_frontend.cc", "lancet_main.cc"]
+BIN = os.path.join(os.path.dirname(CSRC), "bin", "lancet_gpu")
+HEADERS = ["kernels.h", "wave.h", "layout.h", "host_common.h", os.path.join("..", "..", "include", "lancet_engine.h"),
+           os.path.join("..", "..", "include", "lancet_host.h")]
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(BIN):
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
@@ -27,8 +30,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
         [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
          "-c", "engine.hip", "-o", "engine.o"],
         [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-c", "host_vdb.cc", "-o", "host_vdb.o"],
-        [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "engine.o", "host_vdb.o", "-o", LIB],
+        [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-pthread", "-c", "host_frontend.cc", "-o", "host_frontend.o"],
+        [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "engine.o", "host_vdb.o", "host_frontend.o", "-lz", "-lpthread", "-o", LIB],
+        # the reference's command line on the native host side; finds the library next to itself
+        [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "lancet_main.cc", "-o", BIN, "-L.", "-llancet_engine",
+         "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath-link,/opt/rocm/lib"],
     ]
+    os.makedirs(os.path.dirname(BIN), exist_ok=True)
     for cmd in steps:
         r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
         if r.returncode != 0:

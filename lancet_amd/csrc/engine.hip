@@ -76,7 +76,7 @@ struct lancet_engine {
   EngineCaps caps2;     // tier 2 (re-run of overflowed windows)
   DevBuf d_caps2, d_works2, d_workmem2, d_out2, d_winlist;
   int n_slots2 = 0;
-  uint32_t node_cap1 = 8192;
+  uint32_t node_cap1 = 16384;   // tier-1 node limit per window (tables are sized per build, so a generous limit costs memory only)
   uint32_t debug_stop = 0;   // LANCET_STOP_PHASE (profiling only)
   uint32_t table_start = 0;  // LANCET_TABLE_START (testing only: exercises the table-doubling path)
   int n_windows = 0, n_reads = 0, n_slots = 0;

@@ -1,0 +1,513 @@
+// host_frontend.cc -- native host side in front of the engine: BGZF/BAM + FASTA input, window tiling, the per-window
+// filters and read selection of Microassembler::processReads, SoA batch assembly (include/lancet_host.h).
+// Pure CPU code (std::thread over windows); nothing here computes what the engine computes.
+//
+// reference: src/Lancet.cc:189-316 (loadRefs), src/Microassembler.cc:253-432 (isActiveRegion), :436-655 (extractReads),
+//            :779-842 (processReads), src/util.cc:295-315 (isRepeat), :428-483 (parseMD), :167-187 (isAmbiguos).
+#include "../../include/lancet_host.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+namespace {
+
+struct Read {
+  int32_t pos0;               // 0-based leftmost position (BamAlignment::Position)
+  int32_t ref_len;            // reference bases covered (M D N = X): GetEndPosition() - Position
+  uint16_t flag;
+  uint8_t mapq;
+  uint8_t has_md, has_xa, xt_is_R, has_qual;
+  int32_t hp;                 // HP:i (0 when absent)
+  float as, xs;               // -1 when absent (extractReads initialises them so)
+  uint32_t cig_off, n_cig;    // into Sample::cigar (BAM encoding: len << 4 | op)
+  uint32_t seq_off, l_seq;    // into Sample::seq / qual (ASCII, phred+33)
+  uint32_t name_off;          // into Sample::text (NUL terminated)
+  uint32_t md_off, bx_off;    // into Sample::text (NUL terminated; bx "null" when absent)
+};
+
+struct Sample {
+  std::vector<Read> reads;
+  std::vector<int32_t> starts;      // pos0 per read (region seek)
+  std::vector<uint32_t> cigar;
+  std::string seq, qual, text;
+  std::string sample_name = "NA";
+  std::vector<std::pair<std::string, int32_t>> refs;
+  std::string path;
+};
+
+struct Window { std::string hdr; int32_t start, end; std::string seq; };
+
+}  // namespace
+
+struct lancet_host {
+  std::string err;
+  Sample smp[2];                    // 0 normal, 1 tumor
+  std::map<std::string, std::string> contigs;
+  std::vector<std::string> contig_order;
+  std::string chrom;
+  std::vector<Window> windows;      // processing order
+  // last batch
+  std::vector<int32_t> b_chr, b_refstart;
+  std::vector<uint32_t> b_refoff, b_readbegin, b_seqoff, b_namerank, b_bxrank;
+  std::string b_ref, b_seq, b_qual;
+  std::vector<uint8_t> b_label, b_strand, b_mate, b_mapped, b_hp;
+  std::vector<std::string> bx_names;
+  std::vector<const char *> bx_ptrs;
+};
+
+namespace {
+
+bool read_file(const std::string &path, std::string *out, std::string *err) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) { *err = "cannot open " + path; return false; }
+  std::string buf;
+  char tmp[1 << 16];
+  size_t n;
+  while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.append(tmp, n);
+  fclose(f);
+  out->swap(buf);
+  return true;
+}
+
+// BGZF: a series of gzip members, each with the BC extra subfield holding the block size (SAM spec 4.1)
+bool bgzf_decompress(const std::string &raw, std::string *out, std::string *err) {
+  size_t p = 0;
+  out->clear();
+  std::vector<unsigned char> buf(1 << 16);
+  while (p < raw.size()) {
+    if (p + 18 > raw.size() || (unsigned char)raw[p] != 31 || (unsigned char)raw[p + 1] != 139) { *err = "not a BGZF block"; return false; }
+    const unsigned char *h = (const unsigned char *)raw.data() + p;
+    const unsigned xlen = h[10] | (h[11] << 8);
+    unsigned bsize = 0; bool found = false;
+    for (unsigned q = 12; q + 4 <= 12 + xlen;) {
+      const unsigned slen = h[q + 2] | (h[q + 3] << 8);
+      if (h[q] == 'B' && h[q + 1] == 'C' && slen == 2) { bsize = (h[q + 4] | (h[q + 5] << 8)) + 1u; found = true; }
+      q += 4 + slen;
+    }
+    if (!found || p + bsize > raw.size()) { *err = "truncated BGZF block"; return false; }
+    const size_t cdata = p + 12 + xlen, clen = bsize - 12 - xlen - 8;
+    const unsigned isize = h[bsize - 4] | (h[bsize - 3] << 8) | (h[bsize - 2] << 16) | ((unsigned)h[bsize - 1] << 24);
+    if (isize > buf.size()) buf.resize(isize);
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) { *err = "zlib init failed"; return false; }
+    zs.next_in = (Bytef *)raw.data() + cdata; zs.avail_in = (uInt)clen;
+    zs.next_out = buf.data(); zs.avail_out = (uInt)buf.size();
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END || zs.total_out != isize) { *err = "corrupt BGZF block"; return false; }
+    out->append((const char *)buf.data(), isize);
+    p += bsize;
+  }
+  return true;
+}
+
+inline int32_t rd_i32(const unsigned char *p) { int32_t v; memcpy(&v, p, 4); return v; }
+inline uint32_t rd_u32(const unsigned char *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+inline uint16_t rd_u16(const unsigned char *p) { uint16_t v; memcpy(&v, p, 2); return v; }
+
+// Decodes the alignments of contig `chrom` that start in [lo0, hi0] (0-based) -- everything a window of the tiled
+// region can select -- in file order.
+bool load_bam(const std::string &path, const std::string &chrom, int32_t lo0, int32_t hi0, Sample *S, std::string *err) {
+  std::string raw, buf;
+  if (!read_file(path, &raw, err)) return false;
+  if (!bgzf_decompress(raw, &buf, err)) { *err = path + ": " + *err; return false; }
+  raw.clear(); raw.shrink_to_fit();
+  const unsigned char *b = (const unsigned char *)buf.data();
+  const size_t n = buf.size();
+  if (n < 12 || memcmp(b, "BAM\1", 4) != 0) { *err = path + ": not a BAM file"; return false; }
+  const int32_t l_text = rd_i32(b + 4);
+  std::string text((const char *)b + 8, strnlen((const char *)b + 8, (size_t)l_text));
+  size_t p = 8 + (size_t)l_text;
+  const int32_t n_ref = rd_i32(b + p); p += 4;
+  int32_t want = -1;
+  for (int32_t i = 0; i < n_ref; ++i) {
+    const int32_t ln = rd_i32(b + p); p += 4;
+    std::string name((const char *)b + p, (size_t)(ln > 0 ? ln - 1 : 0)); p += (size_t)ln;
+    const int32_t len = rd_i32(b + p); p += 4;
+    if (name == chrom) want = i;
+    S->refs.emplace_back(name, len);
+  }
+  {   // SM of the first @RG line
+    size_t q = 0;
+    bool got = false;
+    while (q < text.size() && !got) {
+      size_t e = text.find('\n', q); if (e == std::string::npos) e = text.size();
+      if (text.compare(q, 3, "@RG") == 0) {
+        size_t f = q;
+        while (f < e) {
+          size_t t = text.find('\t', f); if (t == std::string::npos || t > e) t = e;
+          if (t - f > 3 && text.compare(f, 3, "SM:") == 0) { S->sample_name = text.substr(f + 3, t - f - 3); got = true; break; }
+          f = t + 1;
+        }
+      }
+      q = e + 1;
+    }
+  }
+  static const char SEQ[] = "=ACMGRSVTWYHKDBN";
+  while (p + 4 <= n) {
+    const int32_t bs = rd_i32(b + p); p += 4;
+    const size_t end = p + (size_t)bs;
+    if (end > n || bs < 32) { *err = path + ": truncated alignment record"; return false; }
+    const int32_t ref_id = rd_i32(b + p), pos = rd_i32(b + p + 4);
+    const unsigned l_name = b[p + 8], mapq = b[p + 9];
+    const unsigned n_cig = rd_u16(b + p + 12), flag = rd_u16(b + p + 14);
+    const int32_t l_seq = rd_i32(b + p + 16);
+    if (ref_id != want || want < 0 || pos < lo0 || pos > hi0) { p = end; continue; }
+    Read r; memset(&r, 0, sizeof r);
+    r.pos0 = pos; r.flag = (uint16_t)flag; r.mapq = (uint8_t)mapq; r.as = -1.f; r.xs = -1.f;
+    size_t q = p + 32;
+    r.name_off = (uint32_t)S->text.size(); S->text.append((const char *)b + q, l_name ? l_name - 1 : 0); S->text.push_back('\0'); q += l_name;
+    r.cig_off = (uint32_t)S->cigar.size(); r.n_cig = n_cig;
+    int32_t rl = 0;
+    for (unsigned i = 0; i < n_cig; ++i) {
+      const uint32_t c = rd_u32(b + q + 4 * i); S->cigar.push_back(c);
+      const unsigned op = c & 15u;                      // MIDNSHP=X
+      if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += (int32_t)(c >> 4);
+    }
+    r.ref_len = rl; q += 4 * (size_t)n_cig;
+    r.seq_off = (uint32_t)S->seq.size(); r.l_seq = (uint32_t)l_seq;
+    for (int32_t i = 0; i < l_seq; ++i) { const unsigned v = b[q + (size_t)(i >> 1)]; S->seq.push_back(SEQ[(i & 1) ? (v & 15u) : (v >> 4)]); }
+    q += (size_t)((l_seq + 1) / 2);
+    r.has_qual = (l_seq > 0 && b[q] != 0xFF) ? 1 : 0;
+    for (int32_t i = 0; i < l_seq; ++i) S->qual.push_back(r.has_qual ? (char)(b[q + (size_t)i] + 33) : '!');
+    q += (size_t)l_seq;
+    r.md_off = 0; r.bx_off = 0;
+    std::string bx = "null";
+    while (q + 3 <= end) {                              // tags
+      const char k0 = (char)b[q], k1 = (char)b[q + 1], t = (char)b[q + 2];
+      q += 3;
+      double num = 0; bool isnum = false; std::string sval; bool isstr = false;
+      switch (t) {
+        case 'A': sval.assign(1, (char)b[q]); isstr = true; q += 1; break;
+        case 'c': num = (int8_t)b[q]; isnum = true; q += 1; break;
+        case 'C': num = b[q]; isnum = true; q += 1; break;
+        case 's': { int16_t v; memcpy(&v, b + q, 2); num = v; isnum = true; q += 2; break; }
+        case 'S': num = rd_u16(b + q); isnum = true; q += 2; break;
+        case 'i': num = rd_i32(b + q); isnum = true; q += 4; break;
+        case 'I': num = rd_u32(b + q); isnum = true; q += 4; break;
+        case 'f': { float v; memcpy(&v, b + q, 4); num = v; isnum = true; q += 4; break; }
+        case 'Z': case 'H': { const size_t l = strnlen((const char *)b + q, end - q); sval.assign((const char *)b + q, l); isstr = true; q += l + 1; break; }
+        case 'B': {
+          const char st = (char)b[q]; const int32_t cnt = rd_i32(b + q + 1);
+          const size_t sz = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+          q += 5 + sz * (size_t)cnt; break;
+        }
+        default: *err = path + ": unknown BAM tag type"; return false;
+      }
+      if (k0 == 'A' && k1 == 'S' && isnum) r.as = (float)num;
+      else if (k0 == 'X' && k1 == 'S' && isnum) r.xs = (float)num;
+      else if (k0 == 'X' && k1 == 'T' && isstr) r.xt_is_R = (sval == "R");
+      else if (k0 == 'X' && k1 == 'A' && isstr) r.has_xa = !sval.empty();
+      else if (k0 == 'M' && k1 == 'D' && isstr) { r.has_md = 1; r.md_off = (uint32_t)S->text.size(); S->text.append(sval); S->text.push_back('\0'); }
+      else if (k0 == 'B' && k1 == 'X' && isstr) { if (!sval.empty()) bx = sval; }
+      else if (k0 == 'H' && k1 == 'P' && isnum) r.hp = num > 0 ? (int32_t)num : 0;
+    }
+    r.bx_off = (uint32_t)S->text.size(); S->text.append(bx); S->text.push_back('\0');
+    S->reads.push_back(r);
+    S->starts.push_back(pos);
+    p = end;
+  }
+  S->path = path;
+  return true;
+}
+
+bool load_fasta(const std::string &path, lancet_host *h) {
+  std::string buf;
+  if (!read_file(path, &buf, &h->err)) return false;
+  std::string *cur = nullptr;
+  size_t p = 0;
+  while (p < buf.size()) {
+    size_t e = buf.find('\n', p); if (e == std::string::npos) e = buf.size();
+    size_t le = e; while (le > p && (buf[le - 1] == '\r' || buf[le - 1] == '\n')) --le;
+    if (le > p && buf[p] == '>') {
+      size_t w = p + 1; while (w < le && !isspace((unsigned char)buf[w])) ++w;
+      std::string name = buf.substr(p + 1, w - p - 1);
+      h->contig_order.push_back(name);
+      cur = &h->contigs[name]; cur->clear();
+    } else if (cur) cur->append(buf, p, le - p);
+    p = e + 1;
+  }
+  return true;
+}
+
+inline bool md_valid(char c) { return c != 0 && strchr("acgtumrwsykvhdbxnACGTUMRWSYKVHDBXN^", c) != nullptr; }
+
+// parseMD (reference src/util.cc:428-483) with its quirks: the quality looked at is that of the base after the mismatch
+// in MD coordinates (rpos is incremented first; std::string::operator[] at size() is '\0')
+void parse_md(const char *md, std::unordered_map<int, int> &M, int start, const char *qual, int lqual, int min_qv) {
+  const int n = (int)strlen(md);
+  auto ffo = [&](int from) { for (int i = from; i < n; ++i) if (md_valid(md[i])) return i; return -1; };
+  auto ffno = [&](int from) { for (int i = from; i < n; ++i) if (!md_valid(md[i])) return i; return -1; };
+  int p = ffo(0), p_old = -1, pos = start, rpos = 0;
+  while (p != -1) {
+    const std::string num(md + p_old + 1, (size_t)(p - p_old - 1));
+    const int step = atoi(num.c_str());
+    pos += step; rpos += step;
+    if (md[p] == '^') {
+      const int p2 = ffno(p + 1);
+      pos += (p2 != -1) ? p2 - (p + 1) : n - (p + 1);
+      if (p2 == -1) break;
+      p = ffo(p2); p_old = p2 - 1;
+    } else {
+      pos += 1; rpos += 1;
+      const int q = rpos < lqual ? (unsigned char)qual[rpos] : 0;
+      if (q >= min_qv) ++M[pos];
+      p_old = p; p = ffo(p_old + 1);
+    }
+  }
+}
+
+bool any_ge(const std::unordered_map<int, int> &m, int thr) { for (auto &kv : m) if (kv.second >= thr) return true; return false; }
+
+// isActiveRegion for one sample (label TMR / NML)
+bool is_active_region(const Sample &S, const Window &win, bool normal, const lancet_host_opts &o) {
+  const int mq = normal ? 0 : o.min_map_qual;
+  std::unordered_map<int, int> mapX, mapI, mapD, mapSC;
+  size_t lo = (size_t)(std::lower_bound(S.starts.begin(), S.starts.end(), win.start) - S.starts.begin());
+  for (size_t i = lo; i < S.reads.size(); ++i) {
+    const Read &r = S.reads[i];
+    const int alstart = r.pos0;
+    if (alstart > win.end) break;
+    const int alend = alstart + r.ref_len;
+    if (alstart < win.start || alend > win.end) continue;
+    if (!(r.mapq >= mq && !(r.flag & 0x400))) continue;
+    if (r.l_seq == 0 || !r.has_qual) continue;
+    if (r.has_md) parse_md(S.text.c_str() + r.md_off, mapX, alstart, S.qual.data() + r.seq_off, (int)r.l_seq, o.min_qual_call);
+    int pos = alstart, refpos = alstart;
+    for (uint32_t c = 0; c < r.n_cig; ++c) {
+      const uint32_t cg = S.cigar[r.cig_off + c]; const unsigned op = cg & 15u; const int len = (int)(cg >> 4);
+      if (op != 1) pos += len;
+      if (op == 8) ++mapX[pos];
+      if (op == 1) ++mapI[pos];
+      if (op == 2) ++mapD[pos];
+      // BamAlignment::GetSoftClips (bamtools 2.5.2 src/api/BamAlignment.cpp:536-606): genome position of every S op
+      if (op == 2 || op == 0 || op == 8 || op == 3 || op == 7) refpos += len;
+      else if (op == 4) ++mapSC[refpos];
+    }
+  }
+  return any_ge(mapX, o.min_evidence) || any_ge(mapI, o.min_evidence) || any_ge(mapD, o.min_evidence) || any_ge(mapSC, o.min_evidence);
+}
+
+struct Sel { uint32_t idx; uint8_t mate, strand, mapped; };
+
+// extractReads for one sample; returns false when the window is to be skipped (coverage above --max-avg-cov)
+bool extract_reads(const Sample &S, const Window &win, bool normal, const lancet_host_opts &o, std::vector<Sel> *out) {
+  int mq = o.min_map_qual; double min_delta = o.max_delta_as_xs;
+  if (normal) { mq = 0; min_delta = -1; }
+  long totalbp = 0;
+  const size_t rawlen = win.seq.size();
+  size_t lo = (size_t)(std::lower_bound(S.starts.begin(), S.starts.end(), win.start) - S.starts.begin());
+  for (size_t i = lo; i < S.reads.size(); ++i) {
+    const Read &r = S.reads[i];
+    const int alstart = r.pos0;
+    if (alstart > win.end) break;
+    if (rawlen > 0 && ((double)totalbp / (double)rawlen) > (double)o.max_avg_cov) return false;      // :491-496
+    const int alend = alstart + r.ref_len;
+    if (alstart < win.start || alend > win.end) continue;                                           // :498-500
+    if (o.primary_alignment_only && (r.flag & 0x100)) continue;
+    if (!(r.mapq >= mq && !(r.flag & 0x400))) continue;                                             // :504
+    uint8_t mate = (r.flag & 0x40) ? 1 : ((r.flag & 0x80) ? 2 : 0);
+    if ((r.flag & 0x40) && (r.flag & 0x80)) mate = 2;                                               // :510-511
+    const uint8_t strand = (r.flag & 0x10) ? LANCET_REV : LANCET_FWD;
+    if (std::fabs((double)r.as - (double)r.xs) <= min_delta && r.as != -1.f && r.xs != -1.f) continue;   // :535
+    if (r.xt_is_R && !normal) continue;                                                             // :554-559
+    if (r.has_xa && !normal && o.xa_filter) continue;                                               // :573-579
+    out->push_back(Sel{(uint32_t)i, mate, strand, (uint8_t)((r.flag & 0x4) ? 0 : 1)});
+    totalbp += (long)r.l_seq;
+  }
+  return true;
+}
+
+// isRepeat (reference src/util.cc:295-315): a k-mer seen twice among offsets [0, len-K)
+bool is_repeat(const std::string &s, int k) {
+  const int n = (int)s.size() - k;
+  if (n <= 1) return false;
+  std::vector<int> idx((size_t)n);
+  for (int i = 0; i < n; ++i) idx[(size_t)i] = i;
+  std::sort(idx.begin(), idx.end(), [&](int a, int b) { return s.compare((size_t)a, (size_t)k, s, (size_t)b, (size_t)k) < 0; });
+  for (int i = 1; i < n; ++i) if (s.compare((size_t)idx[(size_t)i - 1], (size_t)k, s, (size_t)idx[(size_t)i], (size_t)k) == 0) return true;
+  return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+void lancet_host_opts_default(lancet_host_opts *o) {
+  o->padding = 250; o->window_size = 600; o->min_map_qual = 15; o->max_delta_as_xs = 5; o->primary_alignment_only = 0;
+  o->xa_filter = 0; o->max_avg_cov = 10000; o->max_k = 101; o->linked = 0; o->active_region = 1; o->min_evidence = 3;
+  o->min_qual_call = 17 + 33;
+}
+
+lancet_host *lancet_host_open(const char *tumor_bam, const char *normal_bam, const char *ref_fasta, char *err, size_t errlen) {
+  lancet_host *h = new lancet_host();
+  h->smp[0].path = normal_bam ? normal_bam : ""; h->smp[1].path = tumor_bam ? tumor_bam : "";
+  bool ok = tumor_bam && normal_bam && ref_fasta && load_fasta(ref_fasta, h);
+  if (ok) for (int s = 0; s < 2 && ok; ++s) { FILE *f = fopen(h->smp[s].path.c_str(), "rb"); if (!f) { h->err = "cannot open " + h->smp[s].path; ok = false; } else fclose(f); }
+  if (!ok) {
+    if (h->err.empty()) h->err = "missing argument";
+    if (err && errlen) { strncpy(err, h->err.c_str(), errlen - 1); err[errlen - 1] = 0; }
+    delete h; return nullptr;
+  }
+  return h;
+}
+void lancet_host_close(lancet_host *h) { delete h; }
+const char *lancet_host_last_error(const lancet_host *h) { return h ? h->err.c_str() : "null host"; }
+const char *lancet_host_sample(const lancet_host *h, int which) { return h->smp[which ? 1 : 0].sample_name.c_str(); }
+const char *lancet_host_chrom(const lancet_host *h) { return h->chrom.c_str(); }
+const char *lancet_host_window_hdr(const lancet_host *h, int w) { return (w >= 0 && (size_t)w < h->windows.size()) ? h->windows[(size_t)w].hdr.c_str() : ""; }
+
+// loadRefs (reference src/Lancet.cc:189-316): padding, clipping, windows of window_size every 100 bp, last window
+// LEN = len - offset - 1, upper case + IUPAC -> N; then the std::map<string, Ref_t*> order of processReads.
+int lancet_host_tile(lancet_host *h, const char *region, const lancet_host_opts *o) {
+  const std::string reg = region ? region : "";
+  const size_t x = reg.find(':');
+  h->chrom = reg.substr(0, x);
+  auto it = h->contigs.find(h->chrom);
+  if (it == h->contigs.end()) { h->err = "contig '" + h->chrom + "' not in the reference"; return LANCET_E_ARG; }
+  const std::string &contig = it->second;
+  long sp = 1, ep = (long)contig.size();
+  if (x != std::string::npos) {
+    const size_t y = reg.find('-', x);
+    if (y == std::string::npos) { h->err = "region must be chr:start-end"; return LANCET_E_ARG; }
+    sp = atol(reg.substr(x + 1, y - x - 1).c_str()) - o->padding;
+    ep = atol(reg.substr(y + 1).c_str()) + o->padding;
+    if (sp < 1) sp = 1;
+    if (ep > (long)contig.size()) ep = (long)contig.size();
+  }
+  std::string s = ep >= sp ? contig.substr((size_t)(sp - 1), (size_t)(ep - sp + 1)) : std::string();
+  for (char &c : s) { c = (char)toupper((unsigned char)c); if (strchr("MRWSYKVHDBX", c)) c = 'N'; }
+  h->windows.clear();
+  const long delta = 100, wsz = o->window_size;
+  long end = (long)s.size(), offset = 0;
+  while (offset < end) {
+    long ln = wsz;
+    if (offset + wsz >= (long)s.size()) { ln = (long)s.size() - offset - 1; end = offset; }
+    Window w;
+    w.seq = ln > 0 ? s.substr((size_t)offset, (size_t)ln) : std::string();
+    w.start = (int32_t)(sp + offset); w.end = (int32_t)(sp + offset + ln);
+    w.hdr = h->chrom + ":" + std::to_string(w.start) + "-" + std::to_string(w.end);
+    h->windows.push_back(std::move(w));
+    offset += delta;
+  }
+  std::stable_sort(h->windows.begin(), h->windows.end(), [](const Window &a, const Window &b) { return a.hdr < b.hdr; });
+  // the alignments a window can select start inside [sp, ep] (1-based window coordinates compared with 0-based
+  // alignment starts, as the reference does): decode just those
+  for (int smp = 0; smp < 2; ++smp) {
+    Sample &S = h->smp[smp];
+    const std::string path = S.path;
+    S = Sample(); S.path = path;
+    if (!load_bam(path, h->chrom, (int32_t)sp - 1, (int32_t)ep + 1, &S, &h->err)) return LANCET_E_ARG;
+    if (!std::is_sorted(S.starts.begin(), S.starts.end())) { h->err = path + ": not coordinate sorted"; return LANCET_E_ARG; }
+  }
+  return (int)h->windows.size();
+}
+
+int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o, lancet_window_batch *out,
+                      int32_t *kept, int32_t *n_kept) {
+  if (!h || !o || !out || w_begin < 0 || w_end < w_begin || (size_t)w_end > h->windows.size()) { if (h) h->err = "bad window range"; return LANCET_E_ARG; }
+  const int nwin = w_end - w_begin;
+  std::vector<std::vector<Sel>> selT((size_t)nwin), selN((size_t)nwin);
+  std::vector<uint8_t> keep((size_t)nwin, 0);
+  {   // per-window filters and read selection: independent windows, one chunk of windows per host thread at a time
+    std::atomic<int> next(0);
+    auto work = [&]() {
+      for (;;) {
+        const int i = next.fetch_add(1);
+        if (i >= nwin) break;
+        const Window &win = h->windows[(size_t)(w_begin + i)];
+        if (is_repeat(win.seq, o->max_k)) continue;                                                   // :800
+        if (o->active_region && !(is_active_region(h->smp[1], win, false, *o) || is_active_region(h->smp[0], win, true, *o))) continue;   // :817-820
+        if (!extract_reads(h->smp[1], win, false, *o, &selT[(size_t)i])) continue;
+        if (!extract_reads(h->smp[0], win, true, *o, &selN[(size_t)i])) continue;
+        keep[(size_t)i] = 1;
+      }
+    };
+    unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 1; if (nt > 64) nt = 64; if ((int)nt > nwin) nt = (unsigned)(nwin > 0 ? nwin : 1);
+    if (const char *e = getenv("LANCET_HOST_THREADS")) { const int v = atoi(e); if (v > 0) nt = (unsigned)v; }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+  }
+  // ---- SoA assembly, windows in processing order; per window tumor reads then normal reads (:833-834)
+  h->b_chr.clear(); h->b_refstart.clear(); h->b_refoff.assign(1, 0); h->b_readbegin.assign(1, 0); h->b_seqoff.assign(1, 0);
+  h->b_namerank.clear(); h->b_bxrank.clear(); h->b_ref.clear(); h->b_seq.clear(); h->b_qual.clear();
+  h->b_label.clear(); h->b_strand.clear(); h->b_mate.clear(); h->b_mapped.clear(); h->b_hp.clear();
+  std::vector<const char *> bx_of;                    // per read (linked)
+  int nk = 0;
+  for (int i = 0; i < nwin; ++i) {
+    if (!keep[(size_t)i]) continue;
+    const Window &win = h->windows[(size_t)(w_begin + i)];
+    if (kept) kept[nk] = w_begin + i;
+    ++nk;
+    h->b_chr.push_back(0); h->b_refstart.push_back(win.start);
+    h->b_ref.append(win.seq); h->b_refoff.push_back((uint32_t)h->b_ref.size());
+    std::vector<const char *> names;
+    const size_t r0 = h->b_label.size();
+    for (int smp = 1; smp >= 0; --smp) {
+      const Sample &S = h->smp[smp];
+      for (const Sel &s : (smp ? selT : selN)[(size_t)i]) {
+        const Read &r = S.reads[s.idx];
+        h->b_seq.append(S.seq, r.seq_off, r.l_seq); h->b_qual.append(S.qual, r.seq_off, r.l_seq);
+        h->b_seqoff.push_back((uint32_t)h->b_seq.size());
+        h->b_label.push_back(smp ? LANCET_TMR : LANCET_NML); h->b_strand.push_back(s.strand); h->b_mate.push_back(s.mate); h->b_mapped.push_back(s.mapped);
+        names.push_back(S.text.c_str() + r.name_off);
+        if (o->linked) { bx_of.push_back(S.text.c_str() + r.bx_off); h->b_hp.push_back((uint8_t)(r.hp > 255 ? 255 : r.hp)); }
+      }
+    }
+    // dense rank of the read name among the window's names under std::string operator<
+    std::vector<uint32_t> ord(names.size());
+    for (size_t j = 0; j < ord.size(); ++j) ord[j] = (uint32_t)j;
+    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return strcmp(names[a], names[b]) < 0; });
+    h->b_namerank.resize(r0 + names.size());
+    uint32_t rank = 0;
+    for (size_t j = 0; j < ord.size(); ++j) {
+      if (j > 0 && strcmp(names[ord[j]], names[ord[j - 1]]) != 0) ++rank;
+      h->b_namerank[r0 + ord[j]] = rank;
+    }
+    h->b_readbegin.push_back((uint32_t)h->b_label.size());
+  }
+  h->bx_names.clear(); h->bx_ptrs.clear();
+  if (o->linked) {
+    std::vector<std::string> all;
+    for (const char *b : bx_of) if (strcmp(b, "null") != 0) all.emplace_back(b);
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    h->bx_names.swap(all);
+    std::unordered_map<std::string, uint32_t> rk;
+    for (size_t j = 0; j < h->bx_names.size(); ++j) rk.emplace(h->bx_names[j], (uint32_t)j);
+    h->b_bxrank.reserve(bx_of.size());
+    for (const char *b : bx_of) h->b_bxrank.push_back(strcmp(b, "null") != 0 ? rk[b] : LANCET_NO_BX);
+    for (auto &s : h->bx_names) h->bx_ptrs.push_back(s.c_str());
+  }
+  memset(out, 0, sizeof *out);
+  out->n_windows = nk;
+  out->chr_id = h->b_chr.data(); out->ref_start = h->b_refstart.data(); out->ref_off = h->b_refoff.data(); out->ref_bases = h->b_ref.data();
+  out->read_begin = h->b_readbegin.data(); out->seq_off = h->b_seqoff.data(); out->seq = h->b_seq.data(); out->qual = h->b_qual.data();
+  out->label = h->b_label.data(); out->strand = h->b_strand.data(); out->mate = h->b_mate.data(); out->mapped = h->b_mapped.data();
+  out->name_rank = h->b_namerank.data();
+  out->bx_rank = o->linked ? h->b_bxrank.data() : nullptr; out->hp = o->linked ? h->b_hp.data() : nullptr;
+  if (n_kept) *n_kept = nk;
+  return LANCET_OK;
+}
+
+const char *const *lancet_host_bx_names(const lancet_host *h, uint32_t *n) {
+  if (n) *n = (uint32_t)h->bx_ptrs.size();
+  return h->bx_ptrs.data();
+}
+
+}  // extern "C"

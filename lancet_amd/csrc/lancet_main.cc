@@ -1,0 +1,123 @@
+// lancet_main.cc -- `lancet_gpu`: the reference's command line (reference src/Lancet.cc:655-800) on the native host side
+// (include/lancet_host.h) and the MI355X engine (include/lancet_engine.h).
+//
+//     lancet_gpu --tumor T.bam --normal N.bam --ref ref.fa --reg chr22:1000-5000 > out.vcf
+//
+// There is no CPU path: without a gfx950 device engine creation fails and the program stops with an error.
+// Not offered: --bed, --rg-file, --kmer-recovery, --print-graph, --verbose (the stage trace is printed by the Python
+// front end, lancet_amd/cli.py); --num-threads is accepted and ignored (windows are batched on the GPU).
+#include "../../include/lancet_host.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+namespace {
+struct Opt { const char *lng; char shrt; int has_arg; };
+const Opt OPTS[] = {
+  {"tumor", 't', 1}, {"normal", 'n', 1}, {"ref", 'r', 1}, {"reg", 'p', 1}, {"min-k", 'k', 1}, {"max-k", 'K', 1},
+  {"trim-lowqual", 'q', 1}, {"min-base-qual", 'C', 1}, {"quality-range", 'Q', 1}, {"min-map-qual", 'b', 1},
+  {"max-as-xs-diff", 'Z', 1}, {"tip-len", 'l', 1}, {"cov-thr", 'c', 1}, {"cov-ratio", 'x', 1}, {"low-cov", 'd', 1},
+  {"max-avg-cov", 'u', 1}, {"window-size", 'w', 1}, {"padding", 'P', 1}, {"dfs-limit", 'F', 1}, {"max-indel-len", 'T', 1},
+  {"max-mismatch", 'M', 1}, {"num-threads", 'X', 1}, {"min-alt-count-tumor", 'a', 1}, {"max-alt-count-normal", 'm', 1},
+  {"min-vaf-tumor", 'e', 1}, {"max-vaf-normal", 'i', 1}, {"min-coverage-tumor", 'o', 1}, {"max-coverage-tumor", 'y', 1},
+  {"min-coverage-normal", 'z', 1}, {"max-coverage-normal", 'j', 1}, {"min-phred-fisher", 's', 1},
+  {"min-phred-fisher-str", 'E', 1}, {"min-strand-bias", 'f', 1}, {"max-unit-length", 'U', 1}, {"min-report-unit", 'N', 1},
+  {"min-report-len", 'Y', 1}, {"dist-from-str", 'D', 1}, {"linked-reads", 'J', 0}, {"primary-alignment-only", 'I', 0},
+  {"XA-tag-filter", 'O', 0}, {"active-region-off", 'W', 0}, {"device", 0, 1}, {"batch-windows", 0, 1}, {"date-line", 0, 1},
+};
+int die(const std::string &m) { fprintf(stderr, "lancet_gpu: %s\n", m.c_str()); return 1; }
+}  // namespace
+
+int main(int argc, char **argv) {
+  std::string tumor, normal, ref, reg, qrange = "!", date_line;
+  int min_k = 11, max_k = 101, trim_lowqual = 10, min_base_qual = 17, tip_len = 11, cov_thr = 5, low_cov = 1, dfs_limit = 1000000;
+  int max_indel_len = 500, max_mismatch = 2, max_unit_length = 4, min_report_unit = 3, min_report_len = 7, dist_from_str = 1;
+  int device = 0, batch_windows = 32768;
+  double cov_ratio = 0.01;
+  lancet_host_opts ho; lancet_host_opts_default(&ho);
+  lancet_filters flt; lancet_filters_default(&flt);
+  for (int i = 1; i < argc; ++i) {
+    const char *a = argv[i];
+    const Opt *o = nullptr;
+    if (a[0] == '-' && a[1] == '-') { for (const Opt &c : OPTS) if (strcmp(a + 2, c.lng) == 0) o = &c; }
+    else if (a[0] == '-' && a[1] && !a[2]) { for (const Opt &c : OPTS) if (c.shrt && c.shrt == a[1]) o = &c; }
+    if (!o) return die(std::string("unknown option ") + a);
+    const char *v = "";
+    if (o->has_arg) { if (i + 1 >= argc) return die(std::string("option ") + a + " needs a value"); v = argv[++i]; }
+    const std::string L = o->lng;
+    if (L == "tumor") tumor = v; else if (L == "normal") normal = v; else if (L == "ref") ref = v; else if (L == "reg") reg = v;
+    else if (L == "min-k") min_k = atoi(v); else if (L == "max-k") max_k = atoi(v); else if (L == "trim-lowqual") trim_lowqual = atoi(v);
+    else if (L == "min-base-qual") min_base_qual = atoi(v); else if (L == "quality-range") qrange = v; else if (L == "min-map-qual") ho.min_map_qual = atoi(v);
+    else if (L == "max-as-xs-diff") ho.max_delta_as_xs = atoi(v); else if (L == "tip-len") tip_len = atoi(v); else if (L == "cov-thr") cov_thr = atoi(v);
+    else if (L == "cov-ratio") cov_ratio = atof(v); else if (L == "low-cov") low_cov = atoi(v); else if (L == "max-avg-cov") ho.max_avg_cov = atoi(v);
+    else if (L == "window-size") ho.window_size = atoi(v); else if (L == "padding") ho.padding = atoi(v); else if (L == "dfs-limit") dfs_limit = atoi(v);
+    else if (L == "max-indel-len") max_indel_len = atoi(v); else if (L == "max-mismatch") max_mismatch = atoi(v); else if (L == "num-threads") {}
+    else if (L == "min-alt-count-tumor") flt.min_alt_cnt_tumor = atoi(v); else if (L == "max-alt-count-normal") flt.max_alt_cnt_normal = atoi(v);
+    else if (L == "min-vaf-tumor") flt.min_vaf_tumor = atof(v); else if (L == "max-vaf-normal") flt.max_vaf_normal = atof(v);
+    else if (L == "min-coverage-tumor") flt.min_cov_tumor = atoi(v); else if (L == "max-coverage-tumor") flt.max_cov_tumor = atoi(v);
+    else if (L == "min-coverage-normal") flt.min_cov_normal = atoi(v); else if (L == "max-coverage-normal") flt.max_cov_normal = atoi(v);
+    else if (L == "min-phred-fisher") flt.min_phred_fisher = atof(v); else if (L == "min-phred-fisher-str") flt.min_phred_fisher_str = atof(v);
+    else if (L == "min-strand-bias") flt.min_strand_bias = (int)atof(v); else if (L == "max-unit-length") max_unit_length = atoi(v);
+    else if (L == "min-report-unit") min_report_unit = atoi(v); else if (L == "min-report-len") min_report_len = atoi(v); else if (L == "dist-from-str") dist_from_str = atoi(v);
+    else if (L == "linked-reads") ho.linked = 1; else if (L == "primary-alignment-only") ho.primary_alignment_only = 1; else if (L == "XA-tag-filter") ho.xa_filter = 1;
+    else if (L == "active-region-off") ho.active_region = 0; else if (L == "device") device = atoi(v); else if (L == "batch-windows") batch_windows = atoi(v);
+    else if (L == "date-line") date_line = v;
+  }
+  if (tumor.empty() || normal.empty() || ref.empty() || reg.empty()) return die("--tumor, --normal, --ref and --reg are required");
+  const int qoff = qrange.empty() ? 33 : (unsigned char)qrange[0];
+  lancet_params P; lancet_params_default(&P);
+  P.min_k = min_k; P.max_k = max_k; P.max_tip_len = tip_len; P.cov_threshold = cov_thr; P.low_cov_threshold = low_cov; P.dfs_limit = dfs_limit;
+  P.max_indel_len = max_indel_len; P.max_mismatch = max_mismatch; P.min_qual_trim = trim_lowqual + qoff; P.min_qual_call = min_base_qual + qoff;
+  P.max_unit_len = max_unit_length; P.min_report_units = min_report_unit; P.min_report_len = min_report_len; P.dist_from_str = dist_from_str;
+  P.lr_mode = ho.linked; P.min_cov_ratio = cov_ratio;
+  ho.max_k = max_k; ho.min_evidence = flt.min_alt_cnt_tumor; ho.min_qual_call = min_base_qual + qoff;
+
+  lancet_engine *eng = nullptr;
+  const int rc = lancet_engine_create(&P, device, &eng);          // fails without a GPU: there is no CPU path
+  if (rc != LANCET_OK) return die(std::string("cannot create the MI355X engine (code ") + std::to_string(rc) + "): " + (eng ? lancet_engine_last_error(eng) : "no gfx950 device / HIP runtime"));
+  char err[512] = "";
+  lancet_host *H = lancet_host_open(tumor.c_str(), normal.c_str(), ref.c_str(), err, sizeof err);
+  if (!H) return die(err);
+  const int nwin = lancet_host_tile(H, reg.c_str(), &ho);
+  if (nwin < 0) return die(lancet_host_last_error(H));
+  lancet_vdb *db = lancet_vdb_create(&flt);
+  const char *chr_names[1] = {lancet_host_chrom(H)};
+  std::vector<int32_t> kept((size_t)(batch_windows > 0 ? batch_windows : 1));
+  long done = 0;
+  const int step = batch_windows > 0 ? batch_windows : 1;
+  for (int lo = 0; lo < nwin; lo += step) {
+    const int hi = lo + step < nwin ? lo + step : nwin;
+    lancet_window_batch B; int32_t nk = 0;
+    if (lancet_host_batch(H, lo, hi, &ho, &B, kept.data(), &nk) != LANCET_OK) return die(lancet_host_last_error(H));
+    if (nk == 0) continue;
+    if (lancet_engine_process(eng, &B) != LANCET_OK) return die(std::string("engine: ") + lancet_engine_last_error(eng));
+    const lancet_variant *v; uint32_t nv, blen; const char *blob; const lancet_window_stats *st;
+    if (lancet_engine_results(eng, &v, &nv, &blob, &blen, &st) != LANCET_OK) return die(std::string("engine: ") + lancet_engine_last_error(eng));
+    for (int w = 0; w < nk; ++w) if (st[w].status < 0)
+      return die(std::string("work-space overflow in window ") + lancet_host_window_hdr(H, kept[(size_t)w]) + ": results withheld (no approximate output)");
+    int arc;
+    if (ho.linked) {
+      const lancet_variant_lr *lr; const uint32_t *bxb; uint32_t bxl, nbx;
+      if (lancet_engine_results_lr(eng, &lr, &bxb, &bxl) != LANCET_OK) return die(std::string("engine: ") + lancet_engine_last_error(eng));
+      const char *const *bxn = lancet_host_bx_names(H, &nbx);
+      arc = lancet_vdb_add_lr(db, v, lr, nv, blob, bxb, bxn, nbx, chr_names, 1);
+    } else arc = lancet_vdb_add(db, v, nv, blob, chr_names, 1);
+    if (arc != LANCET_OK) return die("VariantDB rejected the records");
+    done += nk;
+  }
+  std::string cmdline = "lancet";
+  for (int i = 1; i < argc; ++i) { if (strcmp(argv[i], "--date-line") == 0) { ++i; continue; } cmdline += " "; cmdline += argv[i]; }
+  if (date_line.empty()) { time_t t = time(nullptr); date_line = ctime(&t); }
+  else if (date_line.back() != '\n') date_line += "\n";
+  char *vcf = lancet_vdb_vcf(db, nullptr, cmdline.c_str(), ref.c_str(), date_line.c_str(), lancet_host_sample(H, 0), lancet_host_sample(H, 1));
+  if (!vcf) return die("VCF rendering failed");
+  fputs(vcf, stdout);
+  fprintf(stderr, "[lancet_gpu] %d windows tiled, %ld assembled on GPU %d, %u variants\n", nwin, done, device, lancet_vdb_size(db));
+  lancet_free(vcf);
+  lancet_vdb_destroy(db); lancet_host_close(H); lancet_engine_destroy(eng);
+  return 0;
+}

@@ -69,11 +69,12 @@ def _simulate(haps, probs, coverage: float, span: Tuple[int, int], rng, read_len
 
 def make_scan_batch(n_windows: int, cov_t: float = 30.0, cov_n: float = 30.0, seed: int = 22, read_len: int = 150,
                     window: int = 600, stride: int = 100, error_rate: float = 0.005, somatic_every: int = 2000,
-                    germline_every: int = 1000, chrom: str = "chr22") -> WindowBatch:
+                    germline_every: int = 1000, chrom: str = "chr22", str_fraction: float = 0.0,
+                    lowcomplex_fraction: float = 0.0) -> WindowBatch:
     margin = 1000
     region_len = window + stride * (n_windows - 1)
     ref_len = region_len + 2 * margin
-    ref = synth.random_reference(ref_len, seed)
+    ref = synth.random_reference(ref_len, seed, str_fraction, lowcomplex_fraction)      # (0.30 / 0.05)
     variants = synth.plant_variants(ref, seed + 1, somatic_every, germline_every)
     germ = [v for v in variants if not v.somatic]
     h0 = synth.build_haplotype(ref, [])

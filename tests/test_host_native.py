@@ -1,0 +1,194 @@
+"""The native host side (include/lancet_host.h: BAM / FASTA input, tiling, window filters, read selection, batch
+assembly) against the Python front end it replaces (lancet_amd/frontend.py + bamio.py, themselves pinned on
+reference-made fixtures by test_cli.py / test_frontend*.py): identical batches array for array.  CPU only."""
+import io
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import bam_writer
+import golden_util as gu
+from lancet_amd import bamio, build, frontend, host, synth
+
+G = gu.GOLDEN
+FIELDS = ("chr_id", "ref_start", "ref_off", "ref_bases", "read_begin", "seq_off", "seq", "qual", "label", "strand", "mate", "mapped", "name_rank")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    build.build()
+
+
+def _python_batch(tumor_bam, normal_bam, fasta, region, o, fp=None):
+    _, tumor = bamio.read_bam(tumor_bam)
+    _, normal = bamio.read_bam(normal_bam)
+    chrom = region.split(":")[0]
+    tumor = [r for r in tumor if r.rname == chrom]
+    normal = [r for r in normal if r.rname == chrom]
+    contigs = bamio.read_fasta(fasta)
+    wins = frontend.tile_region(contigs[chrom], chrom, region, padding=o.padding, window_size=o.window_size)
+    fp = fp or frontend.ReadFilterParams(min_map_qual=o.min_map_qual, max_delta_as_xs=o.max_delta_as_xs,
+                                         primary_alignment_only=bool(o.primary_alignment_only), xa_filter=bool(o.xa_filter),
+                                         max_avg_cov=o.max_avg_cov)
+    pb, kept = frontend.batch_from_sam(wins, tumor, normal, fp, max_k=o.max_k, linked=bool(o.linked), active_region=bool(o.active_region),
+                                       min_evidence=o.min_evidence, min_qual_call=o.min_qual_call)
+    return [w.hdr for w in frontend.windows_in_processing_order(wins)], pb
+
+
+def _same(b, pb, linked):
+    assert b.n_windows == pb.n_windows and b.hdr == pb.hdr
+    for f in FIELDS:
+        assert np.array_equal(getattr(b, f), getattr(pb, f)), f
+    if linked:
+        assert np.array_equal(b.bx_rank, pb.bx_rank) and np.array_equal(b.hp, pb.hp) and b.bx_names == pb.bx_names
+
+
+@pytest.mark.parametrize("case,region,kw", [
+    ("ar_small", "chr22:900-3000", {}),
+    ("ar_small", "chr22:900-3000", {"active_region": 0}),
+    ("ar_small", "chr22:1200-1900", {"padding": 0, "window_size": 400, "max_k": 31}),
+    ("lr_small", "chr22:800-2700", {"linked": 1}),
+    ("lr_small", "chr22:800-2700", {"linked": 1, "active_region": 0, "padding": 100}),
+    ("lr_small", "chr22", {"active_region": 0}),
+])
+def test_native_host_batches_equal_the_python_front_end_on_reference_made_bams(case, region, kw):
+    paths = [os.path.join(G, f"{case}.tumor.bam"), os.path.join(G, f"{case}.normal.bam"), os.path.join(G, f"{case}.fa")]
+    o = host.default_opts(**kw)
+    H = host.NativeHost(*paths)
+    hdrs = H.tile(region, o)
+    want_hdrs, pb = _python_batch(*paths, region, o)
+    assert hdrs == want_hdrs
+    b, idx = H.batch(0, len(hdrs), o)
+    _same(b, pb, bool(o.linked))
+    assert [hdrs[i] for i in idx] == b.hdr
+    assert (H.sample(False), H.sample(True)) == ("NORMAL", "TUMOR")
+    # the same windows in two chunks (how lancet_gpu walks a region): the kept windows concatenate to the whole
+    mid = len(hdrs) // 2
+    b1, i1 = H.batch(0, mid, o)
+    b2, i2 = H.batch(mid, len(hdrs), o)
+    assert i1 + i2 == idx and b1.n_reads + b2.n_reads == b.n_reads
+    H.close()
+
+
+def _decorate(reads, rng, linked):
+    """Tag / flag / CIGAR variety the read filters look at (reference src/Microassembler.cc:498-579, :253-432)."""
+    out = []
+    for r in reads:
+        tags = dict(r.tags)
+        u = rng.random()
+        flag, mapq, cigar, seq, qual = r.flag, r.mapq, r.cigar, r.seq, r.qual
+        if u < 0.04:
+            tags["XT"] = ("A", "R")
+        elif u < 0.08:
+            tags["XT"] = ("A", "U")
+        elif u < 0.12:
+            tags["XA"] = "chr1,+100,100M,1;"
+        elif u < 0.16:
+            tags["XS"] = int(tags.get("AS", 90)) - int(rng.integers(0, 8))
+        elif u < 0.19:
+            flag |= 0x400
+        elif u < 0.22:
+            flag |= 0x100
+        elif u < 0.26:
+            mapq = int(rng.integers(0, 20))
+        elif u < 0.30 and cigar.endswith("M") and cigar[:-1].isdigit() and int(cigar[:-1]) > 20:     # soft clip the head or the tail
+            n, k = int(cigar[:-1]), int(rng.integers(3, 12))
+            cigar = f"{k}S{n - k}M" if rng.random() < 0.5 else f"{n - k}M{k}S"
+            if cigar[0].isdigit() and cigar.split("S")[0].isdigit() and cigar.index("S") < cigar.index("M"):
+                r_pos_shift = k
+            else:
+                r_pos_shift = 0
+            r = synth.SamRead(r.qname, flag, r.rname, r.pos + r_pos_shift, mapq, cigar, seq, qual, tags)
+            tags.pop("MD", None)
+        elif u < 0.32:
+            del tags["AS"]
+        elif u < 0.33:
+            flag |= 0x4
+        if linked and rng.random() < 0.9:
+            tags["BX"] = "ACGT"[int(rng.integers(0, 4))] * 4 + f"{int(rng.integers(0, 40)):04d}-1"
+            if rng.random() < 0.8:
+                tags["HP"] = int(rng.integers(1, 3))
+        out.append(synth.SamRead(r.qname, flag, r.rname, r.pos, mapq, cigar, seq, qual, tags))
+    return sorted(out, key=lambda x: x.pos)
+
+
+@pytest.mark.parametrize("seed,linked", [(0, False), (1, True), (2, False)])
+def test_native_host_on_randomized_bams_with_filtered_reads(tmp_path, seed, linked):
+    """Synthetic tumor/normal with XT/XA/XS tags, duplicates, secondary alignments, low MAPQ, soft clips and unmapped
+    flags sprinkled in, written as BAM by the test-side writer: every filter of extractReads / isActiveRegion is hit."""
+    rng = np.random.default_rng(400 + seed)
+    data = synth.make_tumor_normal(ref_len=6000, cov_t=25, cov_n=20, ref_seed=30 + seed, tumor_seed=130 + seed, normal_seed=230 + seed,
+                                   somatic_every=500, germline_every=400, str_fraction=0.05 if seed == 2 else 0.0)
+    tumor = _decorate(synth.pairs_to_sorted_reads(data["tumor"]), rng, linked)
+    normal = _decorate(synth.pairs_to_sorted_reads(data["normal"]), rng, linked)
+    refs = [("chrA", 1000), (data["rname"], len(data["ref"]))]
+    tb, nb, fa = str(tmp_path / "t.bam"), str(tmp_path / "n.bam"), str(tmp_path / "r.fa")
+    bam_writer.write_bam(tb, refs, tumor, sample="TT")
+    bam_writer.write_bam(nb, refs, normal, sample="NN")
+    synth.write_fasta(fa, "chrA", "ACGT" * 250)
+    with open(fa, "a") as fh:
+        fh.write(f">{data['rname']} some description\n")
+        s = data["ref"][:3000].lower() + "R" + data["ref"][3001:]          # soft-masked half + an IUPAC code
+        for i in range(0, len(s), 70):
+            fh.write(s[i:i + 70] + "\n")
+    # the writer and the Python reader agree (so the comparison below is about the native reader)
+    _, back = bamio.read_bam(tb)
+    assert [(r.qname, r.flag, r.pos, r.cigar, r.seq, r.qual) for r in back] == [(r.qname, r.flag, r.pos, r.cigar, r.seq, r.qual) for r in tumor]
+    for kw in ({"linked": int(linked)}, {"linked": int(linked), "active_region": 0, "primary_alignment_only": 1, "xa_filter": 1, "min_map_qual": 10},
+               {"linked": int(linked), "max_avg_cov": 20, "active_region": 0}):
+        o = host.default_opts(**kw)
+        region = f"{data['rname']}:700-5200"
+        H = host.NativeHost(tb, nb, fa)
+        hdrs = H.tile(region, o)
+        want_hdrs, pb = _python_batch(tb, nb, fa, region, o)
+        assert hdrs == want_hdrs and len(hdrs) > 30
+        b, idx = H.batch(0, len(hdrs), o)
+        _same(b, pb, linked)
+        assert (H.sample(False), H.sample(True)) == ("NN", "TT")
+        H.close()
+    assert 0 < pb.n_windows < len(hdrs)                     # (--max-avg-cov 20 skipped some windows, kept others)
+
+
+def test_native_host_reports_bad_inputs(tmp_path):
+    with pytest.raises(Exception):
+        host.NativeHost(str(tmp_path / "missing.bam"), str(tmp_path / "missing.bam"), os.path.join(G, "ar_small.fa"))
+    H = host.NativeHost(os.path.join(G, "ar_small.tumor.bam"), os.path.join(G, "ar_small.normal.bam"), os.path.join(G, "ar_small.fa"))
+    with pytest.raises(Exception):
+        H.tile("chrZ:1-100", host.default_opts())
+    notbam = tmp_path / "x.bam"
+    notbam.write_bytes(b"hello")
+    H2 = host.NativeHost(str(notbam), str(notbam), os.path.join(G, "ar_small.fa"))
+    with pytest.raises(Exception):
+        H2.tile("chr22:900-3000", host.default_opts())
+
+
+def test_lancet_gpu_binary_has_no_cpu_path():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([build.BIN, "--tumor", os.path.join(G, "ar_small.tumor.bam"), "--normal", os.path.join(G, "ar_small.normal.bam"),
+                        "--ref", os.path.join(G, "ar_small.fa"), "--reg", "chr22:900-3000"], capture_output=True, text=True)
+    assert r.returncode != 0 and r.stdout == "" and "cannot create the MI355X engine" in r.stderr
+
+
+def _body(text):
+    return "".join(l + "\n" for l in text.splitlines()
+                   if not l.startswith("##fileDate") and not l.startswith("##cmdline") and not l.startswith("##reference"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,region,extra", [("ar_small", "chr22:900-3000", ["--num-threads", "1"]),
+                                               ("lr_small", "chr22:800-2700", ["--linked-reads"]),
+                                               ("ar_small", "chr22:900-3000", ["--batch-windows", "7"])])
+def test_lancet_gpu_binary_vcf_is_byte_identical_to_the_reference(case, region, extra):
+    """The native command-line program end to end (BAM -> host front end -> engine -> VariantDB -> VCF) on the
+    reference-made fixtures, also with the region cut into several engine batches."""
+    r = subprocess.run([build.BIN, "--tumor", os.path.join(G, f"{case}.tumor.bam"), "--normal", os.path.join(G, f"{case}.normal.bam"),
+                        "--ref", os.path.join(G, f"{case}.fa"), "--reg", region, "--date-line", "Sun Sep 27 05:27:00 2026"] + extra,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "##fileDate=Sun Sep 27 05:27:00 2026\n##source=lancet 1.1.0" in r.stdout and "##cmdline=lancet --tumor" in r.stdout
+    assert "--date-line" not in r.stdout
+    assert _body(r.stdout) == gu.golden_vcf(case)
