@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cctype>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -82,35 +83,54 @@ bool read_file(const std::string &path, std::string *out, std::string *err) {
   return true;
 }
 
-// BGZF: a series of gzip members, each with the BC extra subfield holding the block size (SAM spec 4.1)
+unsigned host_threads(int items);
+
+// BGZF: a series of gzip members, each with the BC extra subfield holding the block size (SAM spec 4.1).  The block
+// table is read first; the blocks are independent deflate streams and are inflated on the host threads.
 bool bgzf_decompress(const std::string &raw, std::string *out, std::string *err) {
-  size_t p = 0;
-  out->clear();
-  std::vector<unsigned char> buf(1 << 16);
+  struct Blk { size_t cdata, clen, opos; unsigned isize; };
+  std::vector<Blk> blks;
+  size_t p = 0, total = 0;
   while (p < raw.size()) {
     if (p + 18 > raw.size() || (unsigned char)raw[p] != 31 || (unsigned char)raw[p + 1] != 139) { *err = "not a BGZF block"; return false; }
     const unsigned char *h = (const unsigned char *)raw.data() + p;
     const unsigned xlen = h[10] | (h[11] << 8);
     unsigned bsize = 0; bool found = false;
-    for (unsigned q = 12; q + 4 <= 12 + xlen;) {
+    for (unsigned q = 12; q + 4 <= 12 + xlen && p + q + 4 <= raw.size();) {
       const unsigned slen = h[q + 2] | (h[q + 3] << 8);
       if (h[q] == 'B' && h[q + 1] == 'C' && slen == 2) { bsize = (h[q + 4] | (h[q + 5] << 8)) + 1u; found = true; }
       q += 4 + slen;
     }
-    if (!found || p + bsize > raw.size()) { *err = "truncated BGZF block"; return false; }
-    const size_t cdata = p + 12 + xlen, clen = bsize - 12 - xlen - 8;
+    if (!found || p + bsize > raw.size() || bsize < 12 + xlen + 8) { *err = "truncated BGZF block"; return false; }
     const unsigned isize = h[bsize - 4] | (h[bsize - 3] << 8) | (h[bsize - 2] << 16) | ((unsigned)h[bsize - 1] << 24);
-    if (isize > buf.size()) buf.resize(isize);
-    z_stream zs; memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, -15) != Z_OK) { *err = "zlib init failed"; return false; }
-    zs.next_in = (Bytef *)raw.data() + cdata; zs.avail_in = (uInt)clen;
-    zs.next_out = buf.data(); zs.avail_out = (uInt)buf.size();
-    const int rc = inflate(&zs, Z_FINISH);
-    inflateEnd(&zs);
-    if (rc != Z_STREAM_END || zs.total_out != isize) { *err = "corrupt BGZF block"; return false; }
-    out->append((const char *)buf.data(), isize);
+    blks.push_back(Blk{p + 12 + xlen, (size_t)bsize - 12 - xlen - 8, total, isize});
+    total += isize;
     p += bsize;
   }
+  out->resize(total);
+  std::atomic<size_t> next(0);
+  std::atomic<int> bad(0);
+  auto work = [&]() {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= blks.size()) break;
+      const Blk &b = blks[i];
+      if (b.isize == 0) continue;
+      z_stream zs; memset(&zs, 0, sizeof zs);
+      if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; continue; }
+      zs.next_in = (Bytef *)raw.data() + b.cdata; zs.avail_in = (uInt)b.clen;
+      zs.next_out = (Bytef *)&(*out)[b.opos]; zs.avail_out = b.isize;
+      const int rc = inflate(&zs, Z_FINISH);
+      if (rc != Z_STREAM_END || zs.total_out != b.isize) bad = 1;
+      inflateEnd(&zs);
+    }
+  };
+  const unsigned nt = host_threads((int)(blks.size() / 8 + 1));
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+  work();
+  for (auto &t : th) t.join();
+  if (bad) { *err = "corrupt BGZF block"; return false; }
   return true;
 }
 
@@ -122,8 +142,13 @@ inline uint16_t rd_u16(const unsigned char *p) { uint16_t v; memcpy(&v, p, 2); r
 // region can select -- in file order.
 bool load_bam(const std::string &path, const std::string &chrom, int32_t lo0, int32_t hi0, Sample *S, std::string *err) {
   std::string raw, buf;
+  const bool timing = getenv("LANCET_HOST_TIMING") != nullptr;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   if (!read_file(path, &raw, err)) return false;
+  const double t1 = now();
   if (!bgzf_decompress(raw, &buf, err)) { *err = path + ": " + *err; return false; }
+  const double t2 = now();
   raw.clear(); raw.shrink_to_fit();
   const unsigned char *b = (const unsigned char *)buf.data();
   const size_t n = buf.size();
@@ -179,11 +204,18 @@ bool load_bam(const std::string &path, const std::string &chrom, int32_t lo0, in
     }
     r.ref_len = rl; q += 4 * (size_t)n_cig;
     r.seq_off = (uint32_t)S->seq.size(); r.l_seq = (uint32_t)l_seq;
-    for (int32_t i = 0; i < l_seq; ++i) { const unsigned v = b[q + (size_t)(i >> 1)]; S->seq.push_back(SEQ[(i & 1) ? (v & 15u) : (v >> 4)]); }
-    q += (size_t)((l_seq + 1) / 2);
-    r.has_qual = (l_seq > 0 && b[q] != 0xFF) ? 1 : 0;
-    for (int32_t i = 0; i < l_seq; ++i) S->qual.push_back(r.has_qual ? (char)(b[q + (size_t)i] + 33) : '!');
-    q += (size_t)l_seq;
+    {
+      const size_t o0 = S->seq.size();
+      S->seq.resize(o0 + (size_t)l_seq); S->qual.resize(o0 + (size_t)l_seq);
+      char *sp = &S->seq[0] + o0, *qp = &S->qual[0] + o0;
+      for (int32_t i = 0; i + 1 < l_seq; i += 2) { const unsigned v = b[q + (size_t)(i >> 1)]; sp[i] = SEQ[v >> 4]; sp[i + 1] = SEQ[v & 15u]; }
+      if (l_seq & 1) sp[l_seq - 1] = SEQ[b[q + (size_t)(l_seq >> 1)] >> 4];
+      q += (size_t)((l_seq + 1) / 2);
+      r.has_qual = (l_seq > 0 && b[q] != 0xFF) ? 1 : 0;
+      if (r.has_qual) for (int32_t i = 0; i < l_seq; ++i) qp[i] = (char)(b[q + (size_t)i] + 33);
+      else memset(qp, '!', (size_t)l_seq);
+      q += (size_t)l_seq;
+    }
     r.md_off = 0; r.bx_off = 0;
     std::string bx = "null";
     while (q + 3 <= end) {                              // tags
@@ -221,6 +253,7 @@ bool load_bam(const std::string &path, const std::string &chrom, int32_t lo0, in
     p = end;
   }
   S->path = path;
+  if (timing) fprintf(stderr, "[lancet_host] %s: read %.3f s, inflate %.3f s (%zu MB), records %.3f s (%zu kept)\n", path.c_str(), t1 - t0, t2 - t1, buf.size() >> 20, now() - t2, S->reads.size());
   return true;
 }
 
@@ -331,6 +364,13 @@ bool extract_reads(const Sample &S, const Window &win, bool normal, const lancet
   return true;
 }
 
+unsigned host_threads(int items) {
+  unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 1; if (nt > 64) nt = 64;
+  if (const char *e = getenv("LANCET_HOST_THREADS")) { const int v = atoi(e); if (v > 0) nt = (unsigned)v; }
+  if ((int)nt > items) nt = (unsigned)(items > 0 ? items : 1);
+  return nt;
+}
+
 // isRepeat (reference src/util.cc:295-315): a k-mer seen twice among offsets [0, len-K)
 bool is_repeat(const std::string &s, int k) {
   const int n = (int)s.size() - k;
@@ -406,12 +446,19 @@ int lancet_host_tile(lancet_host *h, const char *region, const lancet_host_opts 
   std::stable_sort(h->windows.begin(), h->windows.end(), [](const Window &a, const Window &b) { return a.hdr < b.hdr; });
   // the alignments a window can select start inside [sp, ep] (1-based window coordinates compared with 0-based
   // alignment starts, as the reference does): decode just those
-  for (int smp = 0; smp < 2; ++smp) {
-    Sample &S = h->smp[smp];
-    const std::string path = S.path;
-    S = Sample(); S.path = path;
-    if (!load_bam(path, h->chrom, (int32_t)sp - 1, (int32_t)ep + 1, &S, &h->err)) return LANCET_E_ARG;
-    if (!std::is_sorted(S.starts.begin(), S.starts.end())) { h->err = path + ": not coordinate sorted"; return LANCET_E_ARG; }
+  {
+    std::string errs[2]; bool ok[2] = {false, false};
+    auto load = [&](int smp) {
+      Sample &S = h->smp[smp];
+      const std::string path = S.path;
+      S = Sample(); S.path = path;
+      ok[smp] = load_bam(path, h->chrom, (int32_t)sp - 1, (int32_t)ep + 1, &S, &errs[smp]);
+      if (ok[smp] && !std::is_sorted(S.starts.begin(), S.starts.end())) { errs[smp] = path + ": not coordinate sorted"; ok[smp] = false; }
+    };
+    std::thread other(load, 0);                         // the two samples side by side
+    load(1);
+    other.join();
+    for (int smp = 0; smp < 2; ++smp) if (!ok[smp]) { h->err = errs[smp]; return LANCET_E_ARG; }
   }
   return (int)h->windows.size();
 }
@@ -420,6 +467,9 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
                       int32_t *kept, int32_t *n_kept) {
   if (!h || !o || !out || w_begin < 0 || w_end < w_begin || (size_t)w_end > h->windows.size()) { if (h) h->err = "bad window range"; return LANCET_E_ARG; }
   const int nwin = w_end - w_begin;
+  const bool timing = getenv("LANCET_HOST_TIMING") != nullptr;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   std::vector<std::vector<Sel>> selT((size_t)nwin), selN((size_t)nwin);
   std::vector<uint8_t> keep((size_t)nwin, 0);
   {   // per-window filters and read selection: independent windows, one chunk of windows per host thread at a time
@@ -436,64 +486,99 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
         keep[(size_t)i] = 1;
       }
     };
-    unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 1; if (nt > 64) nt = 64; if ((int)nt > nwin) nt = (unsigned)(nwin > 0 ? nwin : 1);
-    if (const char *e = getenv("LANCET_HOST_THREADS")) { const int v = atoi(e); if (v > 0) nt = (unsigned)v; }
+    unsigned nt = host_threads(nwin);
     std::vector<std::thread> th;
     for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
     work();
     for (auto &t : th) t.join();
   }
-  // ---- SoA assembly, windows in processing order; per window tumor reads then normal reads (:833-834)
-  h->b_chr.clear(); h->b_refstart.clear(); h->b_refoff.assign(1, 0); h->b_readbegin.assign(1, 0); h->b_seqoff.assign(1, 0);
-  h->b_namerank.clear(); h->b_bxrank.clear(); h->b_ref.clear(); h->b_seq.clear(); h->b_qual.clear();
-  h->b_label.clear(); h->b_strand.clear(); h->b_mate.clear(); h->b_mapped.clear(); h->b_hp.clear();
-  std::vector<const char *> bx_of;                    // per read (linked)
-  int nk = 0;
-  for (int i = 0; i < nwin; ++i) {
-    if (!keep[(size_t)i]) continue;
+  const double t1 = now();
+  // ---- SoA assembly, windows in processing order; per window tumor reads then normal reads (:833-834).
+  //      Sizes first (prefix sums), then every window fills its own slices on the host threads.
+  std::vector<int> kw;                                 // kept windows (index into [w_begin, w_end))
+  for (int i = 0; i < nwin; ++i) if (keep[(size_t)i]) kw.push_back(i);
+  const int nk = (int)kw.size();
+  h->b_chr.assign((size_t)nk, 0); h->b_refstart.resize((size_t)nk);
+  h->b_refoff.assign((size_t)nk + 1, 0); h->b_readbegin.assign((size_t)nk + 1, 0);
+  std::vector<uint64_t> base0((size_t)nk + 1, 0);
+  for (int k = 0; k < nk; ++k) {
+    const int i = kw[(size_t)k];
     const Window &win = h->windows[(size_t)(w_begin + i)];
-    if (kept) kept[nk] = w_begin + i;
-    ++nk;
-    h->b_chr.push_back(0); h->b_refstart.push_back(win.start);
-    h->b_ref.append(win.seq); h->b_refoff.push_back((uint32_t)h->b_ref.size());
-    std::vector<const char *> names;
-    const size_t r0 = h->b_label.size();
-    for (int smp = 1; smp >= 0; --smp) {
-      const Sample &S = h->smp[smp];
-      for (const Sel &s : (smp ? selT : selN)[(size_t)i]) {
-        const Read &r = S.reads[s.idx];
-        h->b_seq.append(S.seq, r.seq_off, r.l_seq); h->b_qual.append(S.qual, r.seq_off, r.l_seq);
-        h->b_seqoff.push_back((uint32_t)h->b_seq.size());
-        h->b_label.push_back(smp ? LANCET_TMR : LANCET_NML); h->b_strand.push_back(s.strand); h->b_mate.push_back(s.mate); h->b_mapped.push_back(s.mapped);
-        names.push_back(S.text.c_str() + r.name_off);
-        if (o->linked) { bx_of.push_back(S.text.c_str() + r.bx_off); h->b_hp.push_back((uint8_t)(r.hp > 255 ? 255 : r.hp)); }
-      }
-    }
-    // dense rank of the read name among the window's names under std::string operator<
-    std::vector<uint32_t> ord(names.size());
-    for (size_t j = 0; j < ord.size(); ++j) ord[j] = (uint32_t)j;
-    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return strcmp(names[a], names[b]) < 0; });
-    h->b_namerank.resize(r0 + names.size());
-    uint32_t rank = 0;
-    for (size_t j = 0; j < ord.size(); ++j) {
-      if (j > 0 && strcmp(names[ord[j]], names[ord[j - 1]]) != 0) ++rank;
-      h->b_namerank[r0 + ord[j]] = rank;
-    }
-    h->b_readbegin.push_back((uint32_t)h->b_label.size());
+    if (kept) kept[k] = w_begin + i;
+    uint64_t nb = 0;
+    for (const Sel &s : selT[(size_t)i]) nb += h->smp[1].reads[s.idx].l_seq;
+    for (const Sel &s : selN[(size_t)i]) nb += h->smp[0].reads[s.idx].l_seq;
+    base0[(size_t)k + 1] = base0[(size_t)k] + nb;
+    h->b_readbegin[(size_t)k + 1] = h->b_readbegin[(size_t)k] + (uint32_t)(selT[(size_t)i].size() + selN[(size_t)i].size());
+    h->b_refoff[(size_t)k + 1] = h->b_refoff[(size_t)k] + (uint32_t)win.seq.size();
   }
-  h->bx_names.clear(); h->bx_ptrs.clear();
+  if (base0[(size_t)nk] > 0xFFFFFFFFull) { h->err = "batch holds more than 4 Gi bases: use fewer windows per batch"; return LANCET_E_ARG; }
+  const size_t R = h->b_readbegin[(size_t)nk], NB = (size_t)base0[(size_t)nk];
+  h->b_ref.resize(h->b_refoff[(size_t)nk]);
+  h->b_seq.resize(NB); h->b_qual.resize(NB);
+  h->b_seqoff.resize(R + 1); h->b_seqoff[0] = 0;
+  h->b_label.resize(R); h->b_strand.resize(R); h->b_mate.resize(R); h->b_mapped.resize(R); h->b_namerank.resize(R);
+  h->b_hp.resize(o->linked ? R : 0);
+  std::vector<const char *> bx_of(o->linked ? R : 0);   // per read (linked)
+  const double t2 = now();
+  {
+    std::atomic<int> next(0);
+    auto fill = [&]() {
+      std::vector<const char *> names; std::vector<uint32_t> ord;
+      for (;;) {
+        const int k = next.fetch_add(1);
+        if (k >= nk) break;
+        const int i = kw[(size_t)k];
+        const Window &win = h->windows[(size_t)(w_begin + i)];
+        h->b_refstart[(size_t)k] = win.start;
+        memcpy(&h->b_ref[h->b_refoff[(size_t)k]], win.seq.data(), win.seq.size());
+        size_t r = h->b_readbegin[(size_t)k]; const size_t r0 = r; size_t bo = (size_t)base0[(size_t)k];
+        names.clear();
+        for (int smp = 1; smp >= 0; --smp) {
+          const Sample &S = h->smp[smp];
+          for (const Sel &s : (smp ? selT : selN)[(size_t)i]) {
+            const Read &rd = S.reads[s.idx];
+            memcpy(&h->b_seq[bo], S.seq.data() + rd.seq_off, rd.l_seq); memcpy(&h->b_qual[bo], S.qual.data() + rd.seq_off, rd.l_seq);
+            bo += rd.l_seq;
+            h->b_seqoff[r + 1] = (uint32_t)bo;
+            h->b_label[r] = smp ? LANCET_TMR : LANCET_NML; h->b_strand[r] = s.strand; h->b_mate[r] = s.mate; h->b_mapped[r] = s.mapped;
+            names.push_back(S.text.c_str() + rd.name_off);
+            if (o->linked) { bx_of[r] = S.text.c_str() + rd.bx_off; h->b_hp[r] = (uint8_t)(rd.hp > 255 ? 255 : rd.hp); }
+            ++r;
+          }
+        }
+        // dense rank of the read name among the window's names under std::string operator<
+        ord.resize(names.size());
+        for (size_t j = 0; j < ord.size(); ++j) ord[j] = (uint32_t)j;
+        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return strcmp(names[a], names[b]) < 0; });
+        uint32_t rank = 0;
+        for (size_t j = 0; j < ord.size(); ++j) {
+          if (j > 0 && strcmp(names[ord[j]], names[ord[j - 1]]) != 0) ++rank;
+          h->b_namerank[r0 + ord[j]] = rank;
+        }
+      }
+    };
+    unsigned nt = host_threads(nk);
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(fill);
+    fill();
+    for (auto &t : th) t.join();
+  }
+  const double t3 = now();
+  h->bx_names.clear(); h->bx_ptrs.clear(); h->b_bxrank.clear();
   if (o->linked) {
-    std::vector<std::string> all;
-    for (const char *b : bx_of) if (strcmp(b, "null") != 0) all.emplace_back(b);
+    std::unordered_set<std::string> uniq;
+    for (const char *b : bx_of) if (strcmp(b, "null") != 0) uniq.emplace(b);
+    std::vector<std::string> all(uniq.begin(), uniq.end());
     std::sort(all.begin(), all.end());
-    all.erase(std::unique(all.begin(), all.end()), all.end());
     h->bx_names.swap(all);
     std::unordered_map<std::string, uint32_t> rk;
     for (size_t j = 0; j < h->bx_names.size(); ++j) rk.emplace(h->bx_names[j], (uint32_t)j);
     h->b_bxrank.reserve(bx_of.size());
     for (const char *b : bx_of) h->b_bxrank.push_back(strcmp(b, "null") != 0 ? rk[b] : LANCET_NO_BX);
-    for (auto &s : h->bx_names) h->bx_ptrs.push_back(s.c_str());
+    for (auto &s2 : h->bx_names) h->bx_ptrs.push_back(s2.c_str());
   }
+  if (timing) fprintf(stderr, "[lancet_host] threads %u; %d windows: select %.3f s, size %.3f s, fill %.3f s, barcodes %.3f s\n", host_threads(nwin), nwin, t1 - t0, t2 - t1, t3 - t2, now() - t3);
   memset(out, 0, sizeof *out);
   out->n_windows = nk;
   out->chr_id = h->b_chr.data(); out->ref_start = h->b_refstart.data(); out->ref_off = h->b_refoff.data(); out->ref_bases = h->b_ref.data();
