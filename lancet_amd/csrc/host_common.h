@@ -27,6 +27,15 @@ static inline EngineCaps lc_caps_for_batch(const lancet_window_batch *b, const l
     uint64_t bases = (uint64_t)(b->seq_off[r1] - b->seq_off[r0]) + (b->ref_off[w + 1] - b->ref_off[w]);
     if (bases > max_bases) max_bases = bases;
   }
+  if (tier == 1 && b->n_windows > 0) {
+    // coverage pile-ups: a window far above the batch's typical size would size every slot's work space; tier 1 is laid
+    // out for windows up to 4x the mean (they overflow at once and run in tier 2, whose limits are the true maxima)
+    const uint32_t R = b->read_begin[b->n_windows];
+    const uint64_t mean_reads = R / (uint32_t)b->n_windows, mean_bases = ((uint64_t)b->seq_off[R] + b->ref_off[b->n_windows]) / (uint64_t)b->n_windows;
+    const uint64_t lim_reads = 4 * mean_reads + 256, lim_bases = 4 * mean_bases + 32768;
+    if (max_reads > lim_reads) max_reads = (uint32_t)lim_reads;
+    if (max_bases > lim_bases) max_bases = lim_bases;
+  }
   c.reads_cap = max_reads + 2;
   c.occ_cap = (uint32_t)max_bases + 64;           // every base starts at most one k-mer
   uint32_t nodes = c.occ_cap;

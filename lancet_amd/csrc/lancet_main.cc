@@ -8,6 +8,7 @@
 // front end, lancet_amd/cli.py); --num-threads is accepted and ignored (windows are batched on the GPU).
 #include "../../include/lancet_host.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -76,13 +77,19 @@ int main(int argc, char **argv) {
   P.lr_mode = ho.linked; P.min_cov_ratio = cov_ratio;
   ho.max_k = max_k; ho.min_evidence = flt.min_alt_cnt_tumor; ho.min_qual_call = min_base_qual + qoff;
 
+  const bool timing = getenv("LANCET_HOST_TIMING") != nullptr;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_batch = 0, t_engine = 0, t_vdb = 0; float t_kernel = 0;
+  const double t_start = now();
   lancet_engine *eng = nullptr;
   const int rc = lancet_engine_create(&P, device, &eng);          // fails without a GPU: there is no CPU path
   if (rc != LANCET_OK) return die(std::string("cannot create the MI355X engine (code ") + std::to_string(rc) + "): " + (eng ? lancet_engine_last_error(eng) : "no gfx950 device / HIP runtime"));
   char err[512] = "";
   lancet_host *H = lancet_host_open(tumor.c_str(), normal.c_str(), ref.c_str(), err, sizeof err);
   if (!H) return die(err);
+  const double t_tile0 = now();
   const int nwin = lancet_host_tile(H, reg.c_str(), &ho);
+  const double t_tile = now() - t_tile0;
   if (nwin < 0) return die(lancet_host_last_error(H));
   lancet_vdb *db = lancet_vdb_create(&flt);
   const char *chr_names[1] = {lancet_host_chrom(H)};
@@ -92,9 +99,15 @@ int main(int argc, char **argv) {
   for (int lo = 0; lo < nwin; lo += step) {
     const int hi = lo + step < nwin ? lo + step : nwin;
     lancet_window_batch B; int32_t nk = 0;
+    double t0 = now();
     if (lancet_host_batch(H, lo, hi, &ho, &B, kept.data(), &nk) != LANCET_OK) return die(lancet_host_last_error(H));
+    t_batch += now() - t0;
     if (nk == 0) continue;
+    t0 = now();
     if (lancet_engine_process(eng, &B) != LANCET_OK) return die(std::string("engine: ") + lancet_engine_last_error(eng));
+    t_engine += now() - t0;
+    { float tm[2] = {0, 0}; lancet_engine_last_timing(eng, tm); t_kernel += tm[0]; }
+    t0 = now();
     const lancet_variant *v; uint32_t nv, blen; const char *blob; const lancet_window_stats *st;
     if (lancet_engine_results(eng, &v, &nv, &blob, &blen, &st) != LANCET_OK) return die(std::string("engine: ") + lancet_engine_last_error(eng));
     for (int w = 0; w < nk; ++w) if (st[w].status < 0)
@@ -107,6 +120,7 @@ int main(int argc, char **argv) {
       arc = lancet_vdb_add_lr(db, v, lr, nv, blob, bxb, bxn, nbx, chr_names, 1);
     } else arc = lancet_vdb_add(db, v, nv, blob, chr_names, 1);
     if (arc != LANCET_OK) return die("VariantDB rejected the records");
+    t_vdb += now() - t0;
     done += nk;
   }
   std::string cmdline = "lancet";
@@ -117,6 +131,8 @@ int main(int argc, char **argv) {
   if (!vcf) return die("VCF rendering failed");
   fputs(vcf, stdout);
   fprintf(stderr, "[lancet_gpu] %d windows tiled, %ld assembled on GPU %d, %u variants\n", nwin, done, device, lancet_vdb_size(db));
+  if (timing) fprintf(stderr, "[lancet_gpu] wall %.3f s: input decode + tiling %.3f, window filters + batches %.3f, engine (upload + kernels + results) %.3f (kernels %.3f), VariantDB %.3f\n",
+                      now() - t_start, t_tile, t_batch, t_engine, t_kernel / 1000.0, t_vdb);
   lancet_free(vcf);
   lancet_vdb_destroy(db); lancet_host_close(H); lancet_engine_destroy(eng);
   return 0;

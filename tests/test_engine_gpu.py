@@ -167,3 +167,36 @@ def test_engine_matches_oracle_on_random_linked_read_windows(seed):
     assert [key(s) for s in st] == [key(s) for s in ost]
     assert gu.digest_trace(eng.trace_text()) == gu.digest_trace(otr)
     eng.close()
+
+
+def _concat(a, b):
+    """two WindowBatches one after the other (test helper)"""
+    from lancet_amd import frontend
+    cat = np.concatenate
+    off = lambda x, y: cat([x, (y[1:].astype(np.int64) + int(x[-1])).astype(np.uint32)])
+    return frontend.WindowBatch(
+        n_windows=a.n_windows + b.n_windows, hdr=a.hdr + b.hdr, chrom=a.chrom + b.chrom, chr_id=cat([a.chr_id, b.chr_id]),
+        ref_start=cat([a.ref_start, b.ref_start]), ref_off=off(a.ref_off, b.ref_off), ref_bases=cat([a.ref_bases, b.ref_bases]),
+        read_begin=off(a.read_begin, b.read_begin), seq_off=off(a.seq_off, b.seq_off), seq=cat([a.seq, b.seq]), qual=cat([a.qual, b.qual]),
+        label=cat([a.label, b.label]), strand=cat([a.strand, b.strand]), mate=cat([a.mate, b.mate]), mapped=cat([a.mapped, b.mapped]),
+        name_rank=cat([a.name_rank, b.name_rank]))
+
+
+def test_coverage_pile_up_window_does_not_size_the_whole_batch():
+    """One window at 25x the coverage of the others: the tier-1 work space is laid out for the typical window (the
+    pile-up overflows at once and is assembled in the worst-case tier), slot size stays that of the plain batch, and
+    every window still equals the oracle."""
+    from lancet_amd import workload
+    plain = workload.make_scan_batch(48, 20, 20, seed=5, read_len=100)
+    pile = workload.make_scan_batch(2, 500, 500, seed=6, read_len=100)
+    both = _concat(plain, pile)
+    p = abi.default_params()
+    eng = engine.Engine(p)
+    eng.upload(plain); _, bytes_plain = eng.geometry()
+    v, st = eng.process(both)
+    _, bytes_both = eng.geometry()
+    assert eng.rerun_count() == 2 and all(s["status"] >= 0 for s in st)
+    assert bytes_both < 3 * bytes_plain
+    ov, ost, _ = oracle.run(both, p)
+    assert v == ov and [s["final_k"] for s in st] == [s["final_k"] for s in ost]
+    eng.close()
