@@ -21,8 +21,7 @@
 // s_barrier into a no-op and then threads the lane-0 sections of consecutive phases together, which lets lane 0
 // run ahead of the other lanes (observed on gfx950: lanes 1..63 skipped whole phases).
 __global__ void __launch_bounds__(LANCET_WG * 2) __attribute__((amdgpu_waves_per_eu(4, 4))) window_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT) {
-  __shared__ WinShared S;
-  window_kernel_body(P, B, C, works, OUT, &S, (int)blockIdx.x);
+  window_kernel_body(P, B, C, works, OUT, (volatile WinShared *)&lc_shared, (int)blockIdx.x);
 }
 
 __global__ void prep_kernel(const lancet_params *P, int n_reads, const char *seq, const char *qual, const uint32_t *seq_off,
@@ -34,7 +33,7 @@ __global__ void prep_kernel(const lancet_params *P, int n_reads, const char *seq
 }
 // test hook: global_align_aff alone (align_fill + align_traceback) on one pair of strings
 __global__ void __launch_bounds__(LANCET_WG * 2) align_test_kernel(const EngineCaps *C, Work *work, const uint8_t *Sx, int n, const uint8_t *Tx, int m, int *out_len) {
-  __shared__ WinShared S;
+  volatile WinShared &S = *(volatile WinShared *)&lc_shared;
   Ctx c; c.P = nullptr; c.B = nullptr; c.C = C; c.W = work; c.OUT = nullptr; c.S = &S;
   WG_LANE0 { S.overflow = 0; }
   WG_SYNC();

@@ -64,6 +64,15 @@ struct WinShared {
   int phase_cur;
 };
 
+// The one WinShared of the workgroup.  Functions reach it by name rather than through the pointer in Ctx: a pointer
+// loaded from a structure is generic to the compiler (FLAT instructions for every control word), the variable is LDS.
+#ifndef LANCET_WAVE_EMU
+static __shared__ WinShared lc_shared;
+#define LC_SREF(c) (*(volatile WinShared *)&lc_shared)
+#else
+#define LC_SREF(c) (*(c).S)
+#endif
+
 struct Ctx {
   const lancet_params *P;
   const DevBatch *B;
@@ -74,7 +83,7 @@ struct Ctx {
                            // real LDS accesses (the optimiser was observed to drop/sink such stores across the barrier)
 };
 
-#define OVF(c) do { (c).S->overflow = 1; } while (0)
+#define OVF(c) do { LC_SREF(c).overflow = 1; } while (0)
 // profiling only (EngineCaps::debug_stop): abandon the window after a phase marker, as an overflow
 #define STOP_SET(c, id) do { if ((c).C->debug_stop == (uint32_t)(id)) { WG_LANE0 { OVF(c); } } } while (0)
 #define STOP_RET(c, id) do { if ((c).C->debug_stop == (uint32_t)(id)) { WG_LANE0 { OVF(c); } return; } } while (0)
@@ -115,7 +124,7 @@ DEV uint32_t wg_bcastu(const volatile uint32_t *p) { return (uint32_t)wg_bcast((
 DEV void evt(Ctx &c, uint32_t code, uint32_t a = 0, uint32_t b = 0, uint32_t d = 0, uint32_t e = 0, uint32_t f = 0,
              uint32_t g = 0, uint32_t h = 0) {
   if (!c.C->evt_cap) return;
-  volatile WinShared &S = *c.S;
+  volatile WinShared &S = LC_SREF(c);
   if (S.evt_len + 8 > c.C->evt_cap) return;
   uint32_t *p = c.W->evt + S.evt_len;
   p[0] = code; p[1] = a; p[2] = b; p[3] = d; p[4] = e; p[5] = f; p[6] = g; p[7] = h;
@@ -123,7 +132,7 @@ DEV void evt(Ctx &c, uint32_t code, uint32_t a = 0, uint32_t b = 0, uint32_t d =
 }
 DEV void evt_bytes(Ctx &c, const uint8_t *s, uint32_t n) {   // raw bytes appended after an event, padded to 8 words
   if (!c.C->evt_cap) return;
-  volatile WinShared &S = *c.S;
+  volatile WinShared &S = LC_SREF(c);
   uint32_t words = ((n + 3) / 4 + 7) / 8 * 8;
   if (S.evt_len + words > c.C->evt_cap) return;
   uint8_t *p = (uint8_t *)(c.W->evt + S.evt_len);
@@ -363,7 +372,7 @@ DEV void desc_cov(const Ctx &c, uint32_t d, int sampleT, uint16_t *fwd, uint16_t
   *fwd = (uint16_t)cn[o]; *rev = (uint16_t)cn[o + 1];
   uint32_t q = c.W->gr[km].nqv;
   if (q == LC_NIL) { *qf = 0; *qr = 0; return; }
-  const uint16_t *qq = c.W->qv + ((size_t)q * c.S->K + SD_OFF(d)) * c.S->QS;
+  const uint16_t *qq = c.W->qv + ((size_t)q * LC_SREF(c).K + SD_OFF(d)) * LC_SREF(c).QS;
   *qf = qq[o]; *qr = qq[o + 1];
 }
 // lr_mode: hp0 hp1 hp2 and hp0/1/2_minqv behind a descriptor (cov_t::hp*, reference src/Ref.hh:47-52)
@@ -374,7 +383,7 @@ DEV void desc_hp(const Ctx &c, uint32_t d, int sampleT, uint16_t *hp3, uint16_t 
   hp3[0] = h[0]; hp3[1] = h[1]; hp3[2] = h[2];
   uint32_t q = c.W->gr[km].nqv;
   if (q == LC_NIL) { hpm3[0] = hpm3[1] = hpm3[2] = 0; return; }
-  const uint16_t *qq = c.W->qv + ((size_t)q * c.S->K + SD_OFF(d)) * c.S->QS + 4 + o;
+  const uint16_t *qq = c.W->qv + ((size_t)q * LC_SREF(c).K + SD_OFF(d)) * LC_SREF(c).QS + 4 + o;
   hpm3[0] = qq[0]; hpm3[1] = qq[1]; hpm3[2] = qq[2];
 }
 DEV void desc_tot(const Ctx &c, uint32_t d, int *tot, int *totqv) {  // operands of Node_t::computeMinCov
@@ -383,7 +392,7 @@ DEV void desc_tot(const Ctx &c, uint32_t d, int *tot, int *totqv) {  // operands
   *tot = (int)(uint16_t)cn[0] + (int)(uint16_t)cn[1] + (int)(uint16_t)cn[2] + (int)(uint16_t)cn[3];
   uint32_t q = c.W->gr[km].nqv;
   if (q == LC_NIL) { *totqv = 0; return; }
-  const uint16_t *qq = c.W->qv + ((size_t)q * c.S->K + SD_OFF(d)) * c.S->QS;
+  const uint16_t *qq = c.W->qv + ((size_t)q * LC_SREF(c).K + SD_OFF(d)) * LC_SREF(c).QS;
   *totqv = (int)qq[0] + (int)qq[1] + (int)qq[2] + (int)qq[3];
 }
 
@@ -398,9 +407,9 @@ DEV uint32_t ht_next_prime(uint32_t n) {   // _M_next_bkt(n) for the values that
   for (int i = 0; i < 18; ++i) if (chain[i] >= n) return chain[i];
   return 0;
 }
-DEV void ht_reset(Ctx &c) { volatile WinShared &S = *c.S; S.ht_bc = 1; S.ht_next_resize = 0; S.ht_elt = 0; S.ht_head = LC_NIL; c.W->ht_bucket[0] = LC_NIL; }
+DEV void ht_reset(Ctx &c) { volatile WinShared &S = LC_SREF(c); S.ht_bc = 1; S.ht_next_resize = 0; S.ht_elt = 0; S.ht_head = LC_NIL; c.W->ht_bucket[0] = LC_NIL; }
 DEVNI void ht_rehash(Ctx &c, uint32_t nb) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   if (nb == 0 || nb > c.C->bucket_cap) { OVF(c); return; }
   for (uint32_t i = 0; i < nb; ++i) W.ht_bucket[i] = LC_NIL;
   uint32_t p = S.ht_head; S.ht_head = LC_NIL;
@@ -422,7 +431,7 @@ DEVNI void ht_rehash(Ctx &c, uint32_t nb) {
   S.ht_bc = nb;
 }
 DEVNI void ht_insert(Ctx &c, uint32_t n) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   if (S.ht_elt + 1 > S.ht_next_resize) {                      // _Prime_rehash_policy::_M_need_rehash
     unsigned long long mn = S.ht_elt + 1;
     if (S.ht_next_resize == 0 && mn < 11) mn = 11;
@@ -449,7 +458,7 @@ DEVNI void ht_insert(Ctx &c, uint32_t n) {
 // Insert into the (array form of the) live table: unordered_map::insert after erasures.  Erase never moves
 // other nodes and keeps each bucket's run contiguous, so "bucket empty" == no live node hashes to it.
 DEVNI void order_insert(Ctx &c, uint32_t n) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   if (S.ht_elt + 1 > S.ht_next_resize) {
     unsigned long long mn = S.ht_elt + 1;
     if (S.ht_next_resize == 0 && mn < 11) mn = 11;
@@ -474,7 +483,7 @@ DEVNI void order_insert(Ctx &c, uint32_t n) {
 }
 // cleanDead (reference src/Graph.cc:2737-2762): erase every dead node from the table
 DEVNI uint32_t clean_dead(Ctx &c, bool quiet = false) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   uint32_t m = 0, dead = 0;
   for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (W.gr[n].flags & NF_DEAD) ++dead; else W.order[m++] = n; }
   S.M = m; S.ht_elt -= dead;
@@ -483,7 +492,7 @@ DEVNI uint32_t clean_dead(Ctx &c, bool quiet = false) {
 }
 DEVNI void print_stats(Ctx &c, int comp) {                            // Graph_t::printStats, reference src/Graph.cc:3674-3691
   if (!c.C->evt_cap) return;
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   int edgecnt = 0, span = 0;
   for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (W.gr[n].comp == comp) { edgecnt += W.gr[n].necnt; span += n_strlen(c, n); } }
   evt(c, EV_STATS, comp, S.M, edgecnt, span);
@@ -493,7 +502,7 @@ DEVNI void print_stats(Ctx &c, int comp) {                            // Graph_t
 // sequence deques
 // ---------------------------------------------------------------------------------------------------------
 DEV bool seq_reserve(Ctx &c, uint32_t n, uint32_t front, uint32_t back) {   // room for `front` more before, `back` after
-  Work &W = *c.W; volatile WinShared &S = *c.S;
+  Work &W = *c.W; volatile WinShared &S = LC_SREF(c);
   uint32_t lo = W.gr[n].seq_lo, hi = W.gr[n].seq_hi;
   if (lo - W.gr[n].seq_clo >= front && W.gr[n].seq_chi - hi >= back) return true;
   uint32_t len = hi - lo;
@@ -510,13 +519,13 @@ DEV bool seq_reserve(Ctx &c, uint32_t n, uint32_t front, uint32_t back) {   // r
 // buildgraph (reference src/Graph.cc:530-589 + loadSequence :119-349 + Node.cc / Ref.cc counters)
 // ---------------------------------------------------------------------------------------------------------
 DEV void read_geom(const Ctx &c, int r, uint32_t *rinfo, uint32_t *bw, uint32_t *gw, int *tlen, bool *isref) {
-  const DevBatch &B = *c.B; const volatile WinShared &S = *c.S;
+  const DevBatch &B = *c.B; const volatile WinShared &S = LC_SREF(c);
   if (r == S.R - 1) { *isref = true; *tlen = S.reflen; *rinfo = 0; *bw = 0; *gw = 0; return; }
   uint32_t g = B.read_begin[S.w] + (uint32_t)r;
   *isref = false; *rinfo = B.rinfo[g]; *bw = B.base_woff[g]; *gw = B.good_woff[g]; *tlen = (int)RI_TLEN(*rinfo);
 }
 DEV int read_base(const Ctx &c, bool isref, uint32_t bw, int i) {
-  if (isref) return c.B->ref_codes[c.B->ref_off[c.S->w] + i];
+  if (isref) return c.B->ref_codes[c.B->ref_off[LC_SREF(c).w] + i];
   return rd_base(c.B->bases, bw, i);
 }
 
@@ -546,7 +555,7 @@ DEV bool nk_is_forward(const uint8_t *ref, int p, int K) {                      
 // (reads arrive in coordinate order per sample, so rank * (W - len) / n is a fair estimate of a read's start): at a
 // given step the lanes then touch the same few table slots / nodes, which the L2 can coalesce.
 DEVNI void build_items(Ctx &c) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   WG_LANE0 {
     const uint32_t g0 = c.B->read_begin[S.w];
     const int nr = S.R - 1;
@@ -586,7 +595,7 @@ DEVNI void build_items(Ctx &c) {
 
 template <int NW>
 DEVNI void build_insert_pass(Ctx &c, bool verify) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   const int K = S.K;
   const uint32_t mask = S.tmask;
   const uint32_t plimit = mask + 1 < c.C->table_cap ? 48u : mask;   // a growable table is doubled rather than probed at length
@@ -665,22 +674,24 @@ DEVNI void build_insert_pass(Ctx &c, bool verify) {
 //   packed bases are little-endian (base j of the k-mer at bits 2j): the reverse-complement key of key_push_rc is the
 //   complement of exactly that; the forward key of key_push_fw is the same bases with the 2-bit groups reversed.
 DEVNI void build_insert_occ_major(Ctx &c) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   const int K = S.K;
   const uint32_t mask = S.tmask;
   const uint32_t plimit = mask + 1 < c.C->table_cap ? 48u : mask;   // a growable table is doubled rather than probed at length
   const unsigned long long kmask = (K == 32) ? ~0ULL : ((1ULL << (2 * K)) - 1ULL);
   const uint32_t refr = (uint32_t)(S.R - 1);
   const uint32_t g0 = c.B->read_begin[S.w];
-  const uint8_t *refc = c.B->ref_codes + c.B->ref_off[S.w];
+  LC_GLOBAL const uint8_t *refc = gptr((const uint8_t *)c.B->ref_codes) + c.B->ref_off[S.w];
+  LC_GLOBAL const uint32_t *occ_base = gptr((const uint32_t *)W.occ_base), *bases = gptr((const uint32_t *)c.B->bases), *base_woff = gptr((const uint32_t *)c.B->base_woff) + g0;
+  LC_GLOBAL uint32_t *slots = gptr((uint32_t *)W.slots), *occ = gptr((uint32_t *)W.occ);
   uint32_t rcur = 0;
   WG_FOR(o, S.O) {
-    while (rcur < refr && (uint32_t)o >= W.occ_base[rcur + 1]) ++rcur;
-    const int p = (int)((uint32_t)o - W.occ_base[rcur]);
+    while (rcur < refr && (uint32_t)o >= occ_base[rcur + 1]) ++rcur;
+    const int p = (int)((uint32_t)o - occ_base[rcur]);
     unsigned long long v = 0;                                    // base j of the k-mer at bits 2j
     if (rcur == refr) { for (int j = 0; j < K; ++j) v |= (unsigned long long)(refc[p + j] & 3) << (2 * j); }
     else {
-      const uint32_t *bp = c.B->bases + c.B->base_woff[g0 + rcur] + (uint32_t)(p >> 4);
+      LC_GLOBAL const uint32_t *bp = bases + base_woff[rcur] + (uint32_t)(p >> 4);
       const int sh = (p & 15) * 2;
       const unsigned long long lo = (unsigned long long)bp[0] | ((unsigned long long)bp[1] << 32);
       v = sh ? ((lo >> sh) | ((unsigned long long)bp[2] << (64 - sh))) : lo;
@@ -699,18 +710,18 @@ DEVNI void build_insert_occ_major(Ctx &c) {
       // A plain (L1-cacheable) 16-byte load: what it returns may be older than the atomics of other lanes, never wrong --
       // tags do not change once set (a stale 0 just sends us into the CAS, which answers with the real tag) and the
       // first-occurrence field only ever decreases (a stale, larger value costs a superfluous atomicMin at worst).
-      const lc_u4 sv = *(const lc_u4 *)(W.slots + 4 * (size_t)idx);
+      const lc_u4 sv = ldg4(slots + 4 * (size_t)idx);
       const unsigned long long cur = (unsigned long long)sv.x | ((unsigned long long)sv.y << 32);
       if (cur == h) { seen_first = sv.z; break; }
       if (cur == 0) {
-        const unsigned long long old = dev_atomic_cas64(&SL_TAG(W, idx), 0ULL, h);
+        const unsigned long long old = dev_atomic_cas64((LC_GLOBAL unsigned long long *)(slots + 4 * (size_t)idx), 0ULL, h);
         if (old == 0 || old == h) break;
       }
       idx = (idx + 1) & mask;
       if (++probes > plimit) { if (plimit < mask) S.tfull = 1; else OVF(c); break; }
     }
-    if ((uint32_t)o < seen_first) dev_atomic_min(&SL_FIRST(W, idx), (uint32_t)o);     // most occurrences are not the first one
-    W.occ[o] = idx | (isF ? 0u : 0x80000000u);
+    if ((uint32_t)o < seen_first) dev_atomic_min(slots + 4 * (size_t)idx + 2, (uint32_t)o);     // most occurrences are not the first one
+    occ[o] = idx | (isF ? 0u : 0x80000000u);
   }
   WG_SYNC();
 }
@@ -733,7 +744,7 @@ DEV bool step_all_good(const Ctx &c, bool isref, uint32_t gw, int s, int tlen, i
 //   csr bits 29..31 of a counted occurrence = "hpX had grown" (feeds hpX_minqv in the per-position pass)
 #define LC_PK(x, i) ((uint32_t)(((x) >> (16 * (i))) & 0xFFFFULL))
 DEVNI void lr_node_replay(Ctx &c, uint32_t lo, uint32_t hi, uint32_t *out) {
-  Work &W = *c.W; const DevBatch &B = *c.B; volatile WinShared &S = *c.S;
+  Work &W = *c.W; const DevBatch &B = *c.B; volatile WinShared &S = LC_SREF(c);
   const uint32_t g0 = B.read_begin[S.w];
   const uint32_t refr = (uint32_t)(S.R - 1);
   for (uint32_t i = lo + 1; i < hi; ++i) {                      // order of the visits
@@ -790,7 +801,7 @@ DEVNI void lr_node_replay(Ctx &c, uint32_t lo, uint32_t hi, uint32_t *out) {
 // buildgraph is cut into separately compiled pieces (DEVNI): one register allocation per phase instead of one for the
 // whole window program, which kept values of later phases alive (and spilled) across the hot loops of earlier ones.
 DEVNI void build_tables(Ctx &c) {
-  volatile WinShared &S = *c.S; Work &W = *c.W; const EngineCaps &C = *c.C;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W; const EngineCaps &C = *c.C;
   const int K = S.K;
   (void)C; (void)K; (void)W;
   // ---- occurrence index space: read r owns [occ_base[r], occ_base[r+1]) = its k-mers p = 0..tlen-K
@@ -891,7 +902,7 @@ DEVNI void build_tables(Ctx &c) {
   WG_SYNC();
 }
 DEVNI void build_csr(Ctx &c) {
-  volatile WinShared &S = *c.S; Work &W = *c.W; const EngineCaps &C = *c.C;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W; const EngineCaps &C = *c.C;
   const int K = S.K;
   (void)C; (void)K; (void)W;
   // ---- pass 2a: occurrences slot -> node id; occurrences per node (the only per-occurrence atomic, on a compact array)
@@ -1042,7 +1053,7 @@ DEVNI void build_csr(Ctx &c) {
   WG_SYNC();
 }
 DEVNI void build_gather(Ctx &c) {
-  volatile WinShared &S = *c.S; Work &W = *c.W; const EngineCaps &C = *c.C;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W; const EngineCaps &C = *c.C;
   const int K = S.K;
   (void)C; (void)K; (void)W;
   // ---- per node, gathering over its occurrences (reference src/Graph.cc:163-349): colours, counted occurrences per
@@ -1153,7 +1164,7 @@ DEVNI void build_gather(Ctx &c) {
   WG_SYNC();
 }
 DEVNI void build_qcounts(Ctx &c) {
-  volatile WinShared &S = *c.S; Work &W = *c.W; const EngineCaps &C = *c.C;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W; const EngineCaps &C = *c.C;
   const int K = S.K;
   (void)C; (void)K; (void)W;
   const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
@@ -1329,7 +1340,7 @@ DEVNI void build_qcounts(Ctx &c) {
   WG_SYNC();
 }
 DEVNI void build_refcov(Ctx &c) {
-  volatile WinShared &S = *c.S; Work &W = *c.W; const EngineCaps &C = *c.C;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W; const EngineCaps &C = *c.C;
   const int K = S.K;
   (void)C; (void)K; (void)W;
   // ---- Ref_t::mertable membership (indexMers over the possibly trimmed seq, reference src/Ref.cc:40-64)
@@ -1368,18 +1379,18 @@ DEVNI void build_refcov(Ctx &c) {
 }
 DEV void build_graph(Ctx &c) {
   build_tables(c);
-  if (wg_bcast(&c.S->overflow)) return;
+  if (wg_bcast(&LC_SREF(c).overflow)) return;
   PHASE(c, 4);
   STOP_RET(c, 4);
   build_csr(c);
-  if (wg_bcast(&c.S->overflow)) return;
+  if (wg_bcast(&LC_SREF(c).overflow)) return;
   PHASE(c, 5);
   STOP_RET(c, 5);
   build_gather(c);
-  if (wg_bcast(&c.S->overflow)) return;
+  if (wg_bcast(&LC_SREF(c).overflow)) return;
   PHASE(c, 6);
   build_qcounts(c);
-  if (wg_bcast(&c.S->overflow)) return;
+  if (wg_bcast(&LC_SREF(c).overflow)) return;
   build_refcov(c);
   STOP_RET(c, 6);
 }
@@ -1395,7 +1406,7 @@ DEV void build_graph(Ctx &c) {
 // The first 29 insertions (2 small stages) are replayed sequentially.
 // ---------------------------------------------------------------------------------------------------------
 DEVNI void order_stage(Ctx &c, const uint32_t *Q, uint32_t *Qn, int n, uint32_t B) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   uint32_t *bkt = W.scratch, *tmp = W.scratch + c.C->node_cap;
   uint32_t *first = W.ht_bucket, *cnt = W.ht_cnt, *start = W.ht_start, *out = W.ht_next;
   WG_FOR(b, (int)B) { cnt[b] = 0; first[b] = LC_NIL; }
@@ -1430,7 +1441,7 @@ DEVNI void order_stage(Ctx &c, const uint32_t *Q, uint32_t *Qn, int n, uint32_t 
 
 // the live table in libstdc++ iteration order -> order[0..M)
 DEVNI void first_lowcov(Ctx &c) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   const uint32_t SEQ = 29u;                             // a value of the growth chain
   WG_LANE0 {
     ht_reset(c);
@@ -1461,7 +1472,7 @@ DEVNI void first_lowcov(Ctx &c) {
 
 // cleanDead over the whole table (reference src/Graph.cc:2737-2762), parallel: compaction of order[] keeping the order
 DEVNI void clean_dead_wg(Ctx &c) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   const int M = (int)wg_bcastu(&S.M);
   uint32_t *keep = W.scratch;
   WG_FOR(i, M) { const uint32_t f = W.gr[W.order[i]].flags; keep[i] = ((f & NF_SURV) && !(f & NF_DEAD)) ? 1u : 0u; }
@@ -1483,7 +1494,7 @@ DEV void recompute_after_append(Ctx &c, uint32_t n, uint32_t from, uint32_t to) 
 }
 
 DEVNI void compress_node(Ctx &c, uint32_t node, char dir) {          // Graph_t::compressNode, reference src/Graph.cc:2486-2706
-  Work &W = *c.W; volatile WinShared &S = *c.S;
+  Work &W = *c.W; volatile WinShared &S = LC_SREF(c);
   const int K = S.K;
   while (!S.overflow) {
     int uid = get_buddy(c, node, dir);
@@ -1572,7 +1583,7 @@ DEV uint32_t cmp_link(const Ctx &c, uint32_t n, char dir, bool *irregular) {
   return CL_VALID | (edir << 28) | b;
 }
 DEVNI void compress_prepare(Ctx &c, int comp) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   const int K = S.K;
   WG_LANE0 { S.cmp_ok = 1; }
   WG_FOR(i, S.M) {
@@ -1598,7 +1609,7 @@ DEVNI void compress_prepare(Ctx &c, int comp) {
   WG_SYNC();
 }
 DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   const int K = S.K;
   if (!quiet) evt(c, EV_COMPRESS);
   uint32_t *list = W.scratch;                                   // (absorbed node, edge dir it is entered by) per merge
@@ -1683,7 +1694,7 @@ DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
   return clean_dead(c, quiet);
 }
 DEVNI uint32_t compress(Ctx &c, int comp, bool quiet = false) {       // reference src/Graph.cc:2712-2732
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   if (!quiet) evt(c, EV_COMPRESS);
   for (uint32_t i = 0; i < S.M && !S.overflow; ++i) {
     uint32_t n = W.order[i];
@@ -1696,7 +1707,7 @@ DEVNI uint32_t compress(Ctx &c, int comp, bool quiet = false) {       // referen
   return clean_dead(c, quiet);
 }
 DEVNI void remove_low_cov(Ctx &c, int comp) {                         // reference src/Graph.cc:2790-2827 (docompression=true)
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
   uint32_t low = 0;
   for (uint32_t i = 0; i < S.M; ++i) {
@@ -1763,7 +1774,7 @@ DEV void node_string(const Ctx &c, uint32_t n, uint8_t *out) {      // str_m as 
 }
 
 DEVNI void remove_tips(Ctx &c, int comp) {                            // reference src/Graph.cc:2885-2926
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   int tips = 0, round = 0;
   do {
     ++round; tips = 0;
@@ -1781,7 +1792,7 @@ DEVNI void remove_tips(Ctx &c, int comp) {                            // referen
   print_stats(c, comp);
 }
 DEVNI void remove_short_links(Ctx &c, int comp) {                     // reference src/Graph.cc:2833-2880
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
   const int max_link_len = S.K / 2;                                  // setK: floor(K/2.0)
   const double thr = floor(sqrt(avgcov));
@@ -1811,7 +1822,7 @@ DEVNI void remove_short_links(Ctx &c, int comp) {                     // referen
 // pointer jumping (O(log n) rounds, every lane busy) instead of a one-lane queue walk that pays a full memory round trip
 // per node.  parent[] (node ids; a node's label only ever decreases) is updated with atomics and read at L2.
 DEVNI void mark_connected_components_wg(Ctx &c) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   const int M = (int)wg_bcastu(&S.M);
   const uint32_t nodes = c.C->node_cap + c.C->special_cap;
   uint32_t *parent = W.scratch, *minpos = W.scratch + nodes, *touch = W.pnodes, *first = W.pedges, *cid = W.nfill;
@@ -1888,7 +1899,7 @@ DEVNI void mark_connected_components_wg(Ctx &c) {
 // markRefEnds (reference src/Graph.cc:2028-2228).  The node of the reference k-mer at `offset` is the node
 // of the reference pseudo-read's occurrence at that offset (if it is still in the table).
 DEV uint32_t special_new(Ctx &c, bool issource, int comp) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   if (S.nspecial >= c.C->special_cap) { OVF(c); return LC_NIL; }
   uint32_t id = c.C->node_cap + S.nspecial++;
   char name[24]; int L = 0;
@@ -1907,7 +1918,7 @@ DEV uint32_t special_new(Ctx &c, bool issource, int comp) {
 // mr_src / mr_snk = first / last offset whose node is live, has getTotCov() >= COV_THRESHOLD and is in the component
 // (-1 if none); mr_ambs / mr_ambk = the same node qualifies again further on (the reference then gives up).
 DEVNI void mark_ref_scan(Ctx &c, int comp) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   const int K = S.K;
   const uint32_t ro = W.occ_base[S.R - 1];
   const int nrefk = (S.reflen - K > 0) ? S.reflen - K + 1 : 0;
@@ -1933,7 +1944,7 @@ DEVNI void mark_ref_scan(Ctx &c, int comp) {
   WG_LANE0 { S.mr_snk = ko; }
 }
 DEVNI void mark_ref_ends(Ctx &c, int comp) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   const int K = S.K;
   S.trim5 = 0xFFFF; S.trim3 = 0xFFFF;
   S.source = LC_NIL; S.sink = LC_NIL;
@@ -1986,7 +1997,7 @@ DEVNI void mark_ref_ends(Ctx &c, int comp) {
 }
 
 DEVNI bool has_cycle(Ctx &c, bool colored = false) {                                         // reference src/Graph.cc:593-681
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   if (S.source == LC_NIL || S.sink == LC_NIL) return false;
   if (!colored) for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (!(W.gr[n].flags & NF_SPECIAL)) W.gr[n].color = 1; }
   bool ans = false;
@@ -2032,7 +2043,7 @@ DEV bool path_has_node(const Ctx &c, uint32_t idx, uint32_t node) {
   return false;
 }
 DEVNI uint32_t bfs(Ctx &c) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   BfsEntry *Q = W.queue;
   const uint32_t cap = c.C->queue_cap;
   int reflen = S.seq_len;
@@ -2088,7 +2099,7 @@ DEV void path_flag_edges(Ctx &c, int n, uint32_t v) {
 }
 // Path_t::str + covDistr (reference src/Path.cc:69-175): string codes + descriptor per base ; returns length
 DEVNI int path_string(Ctx &c, int n) {
-  Work &W = *c.W; volatile WinShared &S = *c.S;
+  Work &W = *c.W; volatile WinShared &S = LC_SREF(c);
   const int K = S.K;
   int len = 0;
   uint32_t e1 = W.gr[(W.pedges[1] >> 4)].edges[(W.pedges[1] & 15u)];
@@ -2115,7 +2126,7 @@ DEVNI int path_string(Ctx &c, int n) {
 // The same string and descriptors with all lanes: contribution length of every path node (special nodes none, the first
 // real node whole, the others without the K-1 overlap), exclusive scan, then one lane per output base.
 DEVNI int path_string_wg(Ctx &c, int n) {
-  Work &W = *c.W; volatile WinShared &S = *c.S;
+  Work &W = *c.W; volatile WinShared &S = LC_SREF(c);
   const int K = S.K;
   const int dcap = 7 * (LC_MAXW + 2);
   if (2 * (n + 1) > dcap || n < 2) { WG_LANE0 { S.ps_len = path_string(c, n); } return wg_bcast(&S.ps_len); }
@@ -2160,7 +2171,7 @@ DEV uint32_t path_contig(const Ctx &c, int n, int pos) {            // Path_t::p
     if (W.gr[nd].flags & NF_SPECIAL) continue;
     int span = n_len(c, nd);
     if (cur + span >= pos) return nd;
-    cur += span - c.S->K + 1;
+    cur += span - LC_SREF(c).K + 1;
   }
   return LC_NIL;
 }
@@ -2350,13 +2361,13 @@ DEV void ts_hp_add_ref(TS &t, const HPc &r) {
 }
 DEV void ref_hp_at(const Ctx &c, uint32_t pos, HPc &r) {       // hp0-2 of Ref_t::getCovStructAt (the minqv fields of the reference stay 0)
   for (int j = 0; j < 3; ++j) { r.nh[j] = r.th[j] = r.nq[j] = r.tq[j] = 0; }
-  if (!c.S->LR || (int)pos >= c.S->reflen) return;
+  if (!LC_SREF(c).LR || (int)pos >= LC_SREF(c).reflen) return;
   const uint16_t *h = c.W->refhp + 6 * pos;
   for (int j = 0; j < 3; ++j) { r.th[j] = h[j]; r.nh[j] = h[3 + j]; }
 }
 DEV void path_hp_at(const Ctx &c, int P, HPc &a) {
   for (int j = 0; j < 3; ++j) { a.nh[j] = a.th[j] = a.nq[j] = a.tq[j] = 0; }
-  if (!c.S->LR) return;
+  if (!LC_SREF(c).LR) return;
   uint32_t d = c.W->pdesc[P];
   desc_hp(c, d, 0, a.nh, a.nq);
   desc_hp(c, d, 1, a.th, a.tq);
@@ -2365,7 +2376,7 @@ DEV void ts_add_alt(TS &t, const uint16_t *n4, const uint16_t *t4) { for (int q 
 DEV void ts_add_ref(TS &t, const uint16_t *n2, const uint16_t *t2) { for (int q = 0; q < 2; ++q) { acc_push(t.rN[q], n2[q]); acc_push(t.rT[q], t2[q]); } }
 
 DEV void ref_cov_at(const Ctx &c, uint32_t pos, uint16_t *n2, uint16_t *t2) {   // Ref_t::getCovStructAt, reference src/Ref.cc:253-267
-  if ((int)pos < c.S->reflen) { const uint16_t *r = c.W->refcov + 4 * pos; t2[0] = r[0]; t2[1] = r[1]; n2[0] = r[2]; n2[1] = r[3]; }
+  if ((int)pos < LC_SREF(c).reflen) { const uint16_t *r = c.W->refcov + 4 * pos; t2[0] = r[0]; t2[1] = r[1]; n2[0] = r[2]; n2[1] = r[3]; }
   else { n2[0] = n2[1] = t2[0] = t2[1] = 0; }
 }
 DEV void path_cov_at(const Ctx &c, int P, uint16_t *n4, uint16_t *t4) {         // coverageN[P], coverageT[P]
@@ -2377,7 +2388,7 @@ DEV void path_cov_at(const Ctx &c, int P, uint16_t *n4, uint16_t *t4) {         
 // ---- --linked-reads: barcode sets of a variant (Graph_t::getBXsetAt / Ref_t::getBXsetAt, reference src/Graph.cc:83-114,
 // src/Ref.cc:96-125).  bx_table[mer] = barcodes of all reads of the sample that contain the k-mer = the node's csr list.
 DEV void bx_add_node(Ctx &c, uint32_t X, uint32_t nml, uint32_t *n) {
-  Work &W = *c.W; const DevBatch &B = *c.B; volatile WinShared &S = *c.S;
+  Work &W = *c.W; const DevBatch &B = *c.B; volatile WinShared &S = LC_SREF(c);
   const uint32_t g0 = B.read_begin[S.w], refr = (uint32_t)(S.R - 1);
   uint32_t *buf = W.bxbuf;
   for (uint32_t i = W.nocc[X]; i < W.nocc[X + 1]; ++i) {
@@ -2396,7 +2407,7 @@ DEV void bx_add_node(Ctx &c, uint32_t X, uint32_t nml, uint32_t *n) {
 }
 // node of the k-mer codes[0..K) (2-bit codes) or LC_NIL: the open-addressing table of the current build
 DEVNI uint32_t kmer_lookup(Ctx &c, const uint8_t *codes) {
-  Work &W = *c.W; volatile WinShared &S = *c.S;
+  Work &W = *c.W; volatile WinShared &S = LC_SREF(c);
   const int K = S.K, NW = S.NW;
   unsigned long long fw[LC_NWMAX], rc[LC_NWMAX];
   for (int w = 0; w < LC_NWMAX; ++w) { fw[w] = 0; rc[w] = 0; }
@@ -2424,7 +2435,7 @@ DEVNI uint32_t kmer_lookup(Ctx &c, const uint8_t *codes) {
   return LC_NIL;
 }
 DEVNI void emit_variant_lr(Ctx &c, uint32_t vi, const TS &t, const uint16_t hp12[12], int plen) {
-  volatile WinShared &S = *c.S; Work &W = *c.W; DevOut &O = *c.OUT;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W; DevOut &O = *c.OUT;
   lancet_variant_lr &l = O.variants_lr[vi];
   for (int q = 0; q < 12; ++q) l.hp[q] = hp12[q];
   l.reserved[0] = l.reserved[1] = 0;
@@ -2455,7 +2466,7 @@ DEVNI void emit_variant_lr(Ctx &c, uint32_t vi, const TS &t, const uint16_t hp12
 
 DEVNI void emit_variant(Ctx &c, const TS &t, const uint16_t cov[8], int strLen, const uint8_t *motif, int motifLen, bool hasStr,
                       const uint8_t *ra, const uint8_t *pa, const uint16_t hp12[12], int plen) {
-  volatile WinShared &S = *c.S; DevOut &O = *c.OUT;
+  volatile WinShared &S = LC_SREF(c); DevOut &O = *c.OUT;
   uint32_t vi = dev_atomic_add(O.n_variants, 1u);
   int rl = t.col1 - t.col0 + 1;
   char sbuf[80]; int sl = 0;
@@ -2482,7 +2493,7 @@ DEVNI void emit_variant(Ctx &c, const TS &t, const uint16_t cov[8], int strLen, 
 // column-type counts.  The walk (lane 0) then visits only the non-match columns instead of all of them.
 //   scratch[0..L) = pos_in_ref, scratch[L+1..2L+1) = pathpos - (column consumes a path base), scratch[2L+2..] = column list
 DEVNI void walk_prepare(Ctx &c, int L) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   const int cap = LC_MAXW + (int)c.C->path_cap + 2;
   const uint8_t *ra = W.aln, *pa = W.aln + cap;
   uint32_t *E1 = W.scratch, *E2 = W.scratch + (L + 1), *F = W.scratch + 2 * (L + 1), *cols = W.scratch + 3 * (L + 1);
@@ -2503,7 +2514,7 @@ DEVNI void walk_prepare(Ctx &c, int L) {
 
 // lane 0.  `np` = nodes in path, `plen` = path string length, aligned strings in W.aln (length L).
 DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   const int K = S.K;
   const int cap = LC_MAXW + (int)c.C->path_cap + 2;
   const uint8_t *ra = W.aln, *pa = W.aln + cap;
@@ -2637,7 +2648,7 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
 // returns true when a near-perfect repeat is found in a source->sink path (Graph_t::findRepeatsInGraphPaths,
 // reference src/Graph.cc:686-730)
 DEVNI bool repeats_in_graph_paths(Ctx &c) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   WG_LANE0 {
     evt(c, EV_LOOKREP);
     S.tmp0 = 0;                                  // 0 continue, 1 stop:false, 2 stop:true
@@ -2672,7 +2683,7 @@ DEVNI bool repeats_in_graph_paths(Ctx &c) {
 
 // eka (reference src/Graph.cc:1430-1501) via countRefPath (:2420-2445)
 DEVNI void count_ref_path(Ctx &c) {
-  volatile WinShared &S = *c.S; Work &W = *c.W;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
   if (wg_bcastu(&S.source) == LC_NIL) return;
   if (wg_bcastu(&S.sink) != LC_NIL) {
     WG_LANE0 { evt(c, EV_SEARCH, (uint32_t)W.gr[S.source].comp); S.tmp0 = S.tmp1 = S.tmp2 = 0; S.part[0] = 0; S.part[1] = 0; S.part[2] = 0; S.part[3] = 0; }
@@ -2743,7 +2754,7 @@ DEVNI void count_ref_path(Ctx &c) {
 // the window: Microassembler::processGraph (reference src/Microassembler.cc:73-249)
 // ---------------------------------------------------------------------------------------------------------
 DEV void process_window(Ctx &c, int w) {
-  volatile WinShared &S = *c.S; Work &W = *c.W; const DevBatch &B = *c.B;
+  volatile WinShared &S = LC_SREF(c); Work &W = *c.W; const DevBatch &B = *c.B;
   WG_LANE0 {
     S.w = w; S.overflow = 0; S.evt_len = 0; S.emit_seq = 0; S.n_kmers = 0; S.max_nodes = 0; S.n_builds = 0; S.N_last = 0; S.final_k = 0;
     S.status = LANCET_W_OK;

@@ -42,6 +42,25 @@ DEV uint32_t dev_atomic_cas32(uint32_t *p, uint32_t cmp, uint32_t v) { return at
 DEV uint32_t ld2(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV unsigned long long ld2(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 typedef uint4 lc_u4;
+// Pointers that come out of a structure in memory are generic to the compiler and get FLAT instructions, whose
+// completion is tracked by the LDS counter as well: every wait for an LDS read then also waits for all memory loads in
+// flight.  The hot loops therefore take global-address-space copies of their array pointers (GLOBAL instructions,
+// vmcnt only).
+#define LC_GLOBAL __attribute__((address_space(1)))
+template <class T> DEV LC_GLOBAL T *gptr(T *p) { return (LC_GLOBAL T *)p; }
+DEV lc_u4 ldg4(LC_GLOBAL const uint32_t *p) {
+  typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+  const v4 t = *(LC_GLOBAL const v4 *)p;
+  lc_u4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w; return r;
+}
+DEV uint32_t dev_atomic_min(LC_GLOBAL uint32_t *p, uint32_t v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV uint32_t dev_atomic_add(LC_GLOBAL uint32_t *p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV uint32_t dev_atomic_or(LC_GLOBAL uint32_t *p, uint32_t v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV unsigned long long dev_atomic_cas64(LC_GLOBAL unsigned long long *p, unsigned long long cmp, unsigned long long v) {
+  __hip_atomic_compare_exchange_strong(p, &cmp, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return cmp;
+}
+DEV uint32_t ld2(LC_GLOBAL const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV int dev_popc(uint32_t x) { return __popc(x); }
 DEV unsigned long long dev_brev64(unsigned long long x) { return __brevll(x); }
 DEV int dev_popcll(unsigned long long x) { return __popcll(x); }
@@ -66,6 +85,9 @@ DEV uint32_t dev_atomic_cas32(uint32_t *p, uint32_t cmp, uint32_t v) { uint32_t 
 DEV uint32_t ld2(const uint32_t *p) { return *p; }
 DEV unsigned long long ld2(const unsigned long long *p) { return *p; }
 struct alignas(16) lc_u4 { uint32_t x, y, z, w; };
+#define LC_GLOBAL
+template <class T> DEV T *gptr(T *p) { return p; }
+DEV lc_u4 ldg4(const uint32_t *p) { return *(const lc_u4 *)p; }
 DEV int dev_popc(uint32_t x) { return __builtin_popcount(x); }
 DEV unsigned long long dev_brev64(unsigned long long x) {
   x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
