@@ -21,7 +21,7 @@
 // s_barrier into a no-op and then threads the lane-0 sections of consecutive phases together, which lets lane 0
 // run ahead of the other lanes (observed on gfx950: lanes 1..63 skipped whole phases).
 __global__ void __launch_bounds__(LANCET_WG * 2) __attribute__((amdgpu_waves_per_eu(4, 4))) window_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT) {
-  window_kernel_body(P, B, C, works, OUT, (volatile WinShared *)&lc_shared, (int)blockIdx.x);
+  window_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL Work *)works, (LC_GLOBAL DevOut *)OUT, (LC_WS *)&lc_shared, (int)blockIdx.x);
 }
 
 __global__ void prep_kernel(const lancet_params *P, int n_reads, const char *seq, const char *qual, const uint32_t *seq_off,
@@ -33,8 +33,8 @@ __global__ void prep_kernel(const lancet_params *P, int n_reads, const char *seq
 }
 // test hook: global_align_aff alone (align_fill + align_traceback) on one pair of strings
 __global__ void __launch_bounds__(LANCET_WG * 2) align_test_kernel(const EngineCaps *C, Work *work, const uint8_t *Sx, int n, const uint8_t *Tx, int m, int *out_len) {
-  volatile WinShared &S = *(volatile WinShared *)&lc_shared;
-  Ctx c; c.P = nullptr; c.B = nullptr; c.C = C; c.W = work; c.OUT = nullptr; c.S = &S;
+  LC_WS &S = *(LC_WS *)&lc_shared;
+  Ctx c; c.P = nullptr; c.B = nullptr; c.C = (LC_GLOBAL const EngineCaps *)C; c.W = (LC_GLOBAL Work *)work; c.OUT = nullptr; c.S = &S;
   WG_LANE0 { S.overflow = 0; }
   WG_SYNC();
   align_fill(c, Sx, n, Tx, m);
@@ -203,11 +203,11 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   HIPCHK(e, hipGetLastError());
   DBG("prep launched");
   DevBatch db;
-  db.n_windows = nw; db.chr_id = (const int32_t *)e->d_chr.p; db.ref_start = (const int32_t *)e->d_refstart.p;
-  db.ref_off = (const uint32_t *)e->d_refoff.p; db.ref_codes = (const uint8_t *)e->d_refcodes.p; db.read_begin = (const uint32_t *)e->d_readbegin.p;
-  db.rinfo = (const uint32_t *)e->d_rinfo.p; db.name_rank = (const uint32_t *)e->d_name.p; db.base_woff = (const uint32_t *)e->d_bw.p;
-  db.good_woff = (const uint32_t *)e->d_gw.p; db.bases = (const uint32_t *)e->d_bases.p; db.good = (const uint32_t *)e->d_good.p;
-  db.bx_rank = e->params.lr_mode ? (const uint32_t *)e->d_bx.p : nullptr; db.hp = e->params.lr_mode ? (const uint8_t *)e->d_hp.p : nullptr;
+  db.n_windows = nw; db.chr_id = (LC_GLOBAL const int32_t *)e->d_chr.p; db.ref_start = (LC_GLOBAL const int32_t *)e->d_refstart.p;
+  db.ref_off = (LC_GLOBAL const uint32_t *)e->d_refoff.p; db.ref_codes = (LC_GLOBAL const uint8_t *)e->d_refcodes.p; db.read_begin = (LC_GLOBAL const uint32_t *)e->d_readbegin.p;
+  db.rinfo = (LC_GLOBAL const uint32_t *)e->d_rinfo.p; db.name_rank = (LC_GLOBAL const uint32_t *)e->d_name.p; db.base_woff = (LC_GLOBAL const uint32_t *)e->d_bw.p;
+  db.good_woff = (LC_GLOBAL const uint32_t *)e->d_gw.p; db.bases = (LC_GLOBAL const uint32_t *)e->d_bases.p; db.good = (LC_GLOBAL const uint32_t *)e->d_good.p;
+  db.bx_rank = e->params.lr_mode ? (LC_GLOBAL const uint32_t *)e->d_bx.p : nullptr; db.hp = e->params.lr_mode ? (LC_GLOBAL const uint8_t *)e->d_hp.p : nullptr;
   UP(e->d_batch, &db, sizeof(db));
   UP(e->d_caps, &e->caps, sizeof(e->caps));
   UP(e->d_caps2, &e->caps2, sizeof(e->caps2));
@@ -232,10 +232,10 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   ENS(e->d_phase, sizeof(unsigned long long) * 16 * nw);
   ENS(e->d_evt, sizeof(uint32_t) * (size_t)nw * (e->caps.evt_cap ? e->caps.evt_cap : 1));
   DevOut o;
-  o.variants = (lancet_variant *)e->d_variants.p; o.blob = (char *)e->d_blob.p;
-  o.n_variants = (uint32_t *)e->d_counters.p; o.n_blob = (uint32_t *)e->d_counters.p + 1; o.queue_head = (uint32_t *)e->d_counters.p + 2;
-  o.n_bx = (uint32_t *)e->d_counters.p + 3; o.variants_lr = (lancet_variant_lr *)e->d_varlr.p; o.bx_blob = (uint32_t *)e->d_bxblob.p;
-  o.stats = (lancet_window_stats *)e->d_stats.p; o.evt_len = (uint32_t *)e->d_evtlen.p; o.evt_out = (uint32_t *)e->d_evt.p; o.phase = (unsigned long long *)e->d_phase.p; o.win_list = nullptr; o.n_list = 0;
+  o.variants = (LC_GLOBAL lancet_variant *)e->d_variants.p; o.blob = (LC_GLOBAL char *)e->d_blob.p;
+  o.n_variants = (LC_GLOBAL uint32_t *)e->d_counters.p; o.n_blob = (LC_GLOBAL uint32_t *)e->d_counters.p + 1; o.queue_head = (LC_GLOBAL uint32_t *)e->d_counters.p + 2;
+  o.n_bx = (LC_GLOBAL uint32_t *)e->d_counters.p + 3; o.variants_lr = (LC_GLOBAL lancet_variant_lr *)e->d_varlr.p; o.bx_blob = (LC_GLOBAL uint32_t *)e->d_bxblob.p;
+  o.stats = (LC_GLOBAL lancet_window_stats *)e->d_stats.p; o.evt_len = (LC_GLOBAL uint32_t *)e->d_evtlen.p; o.evt_out = (LC_GLOBAL uint32_t *)e->d_evt.p; o.phase = (LC_GLOBAL unsigned long long *)e->d_phase.p; o.win_list = nullptr; o.n_list = 0;
   UP(e->d_out, &o, sizeof(o));
   DBG("sync");
   HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -281,7 +281,7 @@ int lancet_engine_run(lancet_engine *e) {
     HIPCHK(e, hipMemcpy(e->d_winlist.p, rerun.data(), sizeof(uint32_t) * rerun.size(), hipMemcpyHostToDevice));
     DevOut o2;
     HIPCHK(e, hipMemcpy(&o2, e->d_out.p, sizeof(o2), hipMemcpyDeviceToHost));
-    o2.win_list = (const uint32_t *)e->d_winlist.p; o2.n_list = (uint32_t)rerun.size();
+    o2.win_list = (LC_GLOBAL const uint32_t *)e->d_winlist.p; o2.n_list = (uint32_t)rerun.size();
     HIPCHK(e, hipMemcpy(e->d_out2.p, &o2, sizeof(o2), hipMemcpyHostToDevice));
     HIPCHK(e, hipMemsetAsync((uint32_t *)e->d_counters.p + 2, 0, sizeof(uint32_t), e->stream));      // queue head
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));

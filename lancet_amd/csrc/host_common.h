@@ -67,9 +67,9 @@ static inline EngineCaps lc_caps_for_batch(const lancet_window_batch *b, const l
 
 struct LcCarver {
   char *base; size_t off;
-  template <class T> T *take(size_t n) {
+  template <class T> LC_GLOBAL T *take(size_t n) {
     off = (off + 63) & ~(size_t)63;
-    T *p = base ? (T *)(base + off) : (T *)nullptr;
+    LC_GLOBAL T *p = base ? (LC_GLOBAL T *)(base + off) : (LC_GLOBAL T *)nullptr;
     off += n * sizeof(T);
     return p;
   }

@@ -66,20 +66,21 @@ struct WinShared {
 
 // The one WinShared of the workgroup.  Functions reach it by name rather than through the pointer in Ctx: a pointer
 // loaded from a structure is generic to the compiler (FLAT instructions for every control word), the variable is LDS.
+typedef volatile LC_LDS WinShared LC_WS;
 #ifndef LANCET_WAVE_EMU
 static __shared__ WinShared lc_shared;
-#define LC_SREF(c) (*(volatile WinShared *)&lc_shared)
+#define LC_SREF(c) (*(LC_WS *)&lc_shared)
 #else
 #define LC_SREF(c) (*(c).S)
 #endif
 
 struct Ctx {
-  const lancet_params *P;
-  const DevBatch *B;
-  const EngineCaps *C;
-  Work *W;
-  DevOut *OUT;
-  volatile WinShared *S;   // volatile: control words written by lane 0 and read by every lane after a barrier must be
+  LC_GLOBAL const lancet_params *P;
+  LC_GLOBAL const DevBatch *B;
+  LC_GLOBAL const EngineCaps *C;
+  LC_GLOBAL Work *W;
+  LC_GLOBAL DevOut *OUT;
+  LC_WS *S;                // volatile: control words written by lane 0 and read by every lane after a barrier must be
                            // real LDS accesses (the optimiser was observed to drop/sink such stores across the barrier)
 };
 
@@ -110,21 +111,21 @@ DEV int wg_uniform(int v) {
 // The pointer is laundered through an empty asm so that the optimiser cannot correlate the value with a store
 // made by the preceding lane-0 section (observed on gfx950/ROCm 7.2: the lane-0 path was threaded straight into
 // a following `while (wg_bcast(..))` loop, lanes 1..63 then evaluated the loop condition before lane 0's store).
-DEV int wg_bcast(const volatile int *p) {
+template <class P> DEV int wg_bcast(P p) {
   WG_SYNC();
 #ifndef LANCET_WAVE_EMU
   asm volatile("" : "+v"(p) : : "memory");
 #endif
-  int v = wg_uniform(*p);
+  int v = wg_uniform((int)*p);
   WG_SYNC();
   return v;
 }
-DEV uint32_t wg_bcastu(const volatile uint32_t *p) { return (uint32_t)wg_bcast((const volatile int *)p); }
+template <class P> DEV uint32_t wg_bcastu(P p) { return (uint32_t)wg_bcast(p); }
 
 DEV void evt(Ctx &c, uint32_t code, uint32_t a = 0, uint32_t b = 0, uint32_t d = 0, uint32_t e = 0, uint32_t f = 0,
              uint32_t g = 0, uint32_t h = 0) {
   if (!c.C->evt_cap) return;
-  volatile WinShared &S = LC_SREF(c);
+  LC_WS &S = LC_SREF(c);
   if (S.evt_len + 8 > c.C->evt_cap) return;
   uint32_t *p = c.W->evt + S.evt_len;
   p[0] = code; p[1] = a; p[2] = b; p[3] = d; p[4] = e; p[5] = f; p[6] = g; p[7] = h;
@@ -132,7 +133,7 @@ DEV void evt(Ctx &c, uint32_t code, uint32_t a = 0, uint32_t b = 0, uint32_t d =
 }
 DEV void evt_bytes(Ctx &c, const uint8_t *s, uint32_t n) {   // raw bytes appended after an event, padded to 8 words
   if (!c.C->evt_cap) return;
-  volatile WinShared &S = LC_SREF(c);
+  LC_WS &S = LC_SREF(c);
   uint32_t words = ((n + 3) / 4 + 7) / 8 * 8;
   if (S.evt_len + words > c.C->evt_cap) return;
   uint8_t *p = (uint8_t *)(c.W->evt + S.evt_len);
@@ -247,7 +248,7 @@ DEV void repeat_scan_bytes(const uint8_t *s, int len, int mm, volatile int *outE
 // mismatch flags of 16 positions out of two unaligned 64-bit words.  Only mismatch positions are visited:
 // with last[j] = position of the (j+1)-th most recent mismatch, the longest exact run ending before a mismatch q is
 // q-1-last[0] and the longest window with <= mm mismatches ending there is q-1-last[mm] (the two-pointer window).
-DEVNI void repeat_scan(volatile WinShared &S, const uint8_t *s, int len, int mm, volatile int *outE, volatile int *outM) {
+DEVNI void repeat_scan(LC_WS &S, const uint8_t *s, int len, int mm, volatile int *outE, volatile int *outM) {
   if (mm > 7 || mm < 0 || len + 48 > 16 * LC_RS_WORDS) { repeat_scan_bytes(s, len, mm, outE, outM); return; }
   WG_LANE0 { *outE = 0; *outM = 0; }
   const int nwords = len / 16 + 3;
@@ -288,7 +289,7 @@ DEVNI void repeat_scan(volatile WinShared &S, const uint8_t *s, int len, int mm,
 }
 
 // exclusive prefix sum of a[0..n) in place; returns total in S.part[LANCET_WG]
-DEV void wg_scan(uint32_t *a, int n, volatile WinShared &S, volatile uint32_t *part = nullptr) {
+DEV void wg_scan(uint32_t *a, int n, LC_WS &S, volatile uint32_t *part = nullptr) {
   if (!part) part = S.part;
   int chunk = (n + LANCET_WG - 1) / LANCET_WG;
   WG_FOR(l, LANCET_WG) {
@@ -407,9 +408,9 @@ DEV uint32_t ht_next_prime(uint32_t n) {   // _M_next_bkt(n) for the values that
   for (int i = 0; i < 18; ++i) if (chain[i] >= n) return chain[i];
   return 0;
 }
-DEV void ht_reset(Ctx &c) { volatile WinShared &S = LC_SREF(c); S.ht_bc = 1; S.ht_next_resize = 0; S.ht_elt = 0; S.ht_head = LC_NIL; c.W->ht_bucket[0] = LC_NIL; }
+DEV void ht_reset(Ctx &c) { LC_WS &S = LC_SREF(c); S.ht_bc = 1; S.ht_next_resize = 0; S.ht_elt = 0; S.ht_head = LC_NIL; c.W->ht_bucket[0] = LC_NIL; }
 DEVNI void ht_rehash(Ctx &c, uint32_t nb) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   if (nb == 0 || nb > c.C->bucket_cap) { OVF(c); return; }
   for (uint32_t i = 0; i < nb; ++i) W.ht_bucket[i] = LC_NIL;
   uint32_t p = S.ht_head; S.ht_head = LC_NIL;
@@ -431,7 +432,7 @@ DEVNI void ht_rehash(Ctx &c, uint32_t nb) {
   S.ht_bc = nb;
 }
 DEVNI void ht_insert(Ctx &c, uint32_t n) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   if (S.ht_elt + 1 > S.ht_next_resize) {                      // _Prime_rehash_policy::_M_need_rehash
     unsigned long long mn = S.ht_elt + 1;
     if (S.ht_next_resize == 0 && mn < 11) mn = 11;
@@ -458,7 +459,7 @@ DEVNI void ht_insert(Ctx &c, uint32_t n) {
 // Insert into the (array form of the) live table: unordered_map::insert after erasures.  Erase never moves
 // other nodes and keeps each bucket's run contiguous, so "bucket empty" == no live node hashes to it.
 DEVNI void order_insert(Ctx &c, uint32_t n) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   if (S.ht_elt + 1 > S.ht_next_resize) {
     unsigned long long mn = S.ht_elt + 1;
     if (S.ht_next_resize == 0 && mn < 11) mn = 11;
@@ -483,7 +484,7 @@ DEVNI void order_insert(Ctx &c, uint32_t n) {
 }
 // cleanDead (reference src/Graph.cc:2737-2762): erase every dead node from the table
 DEVNI uint32_t clean_dead(Ctx &c, bool quiet = false) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   uint32_t m = 0, dead = 0;
   for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (W.gr[n].flags & NF_DEAD) ++dead; else W.order[m++] = n; }
   S.M = m; S.ht_elt -= dead;
@@ -492,7 +493,7 @@ DEVNI uint32_t clean_dead(Ctx &c, bool quiet = false) {
 }
 DEVNI void print_stats(Ctx &c, int comp) {                            // Graph_t::printStats, reference src/Graph.cc:3674-3691
   if (!c.C->evt_cap) return;
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   int edgecnt = 0, span = 0;
   for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (W.gr[n].comp == comp) { edgecnt += W.gr[n].necnt; span += n_strlen(c, n); } }
   evt(c, EV_STATS, comp, S.M, edgecnt, span);
@@ -502,7 +503,7 @@ DEVNI void print_stats(Ctx &c, int comp) {                            // Graph_t
 // sequence deques
 // ---------------------------------------------------------------------------------------------------------
 DEV bool seq_reserve(Ctx &c, uint32_t n, uint32_t front, uint32_t back) {   // room for `front` more before, `back` after
-  Work &W = *c.W; volatile WinShared &S = LC_SREF(c);
+  LC_GLOBAL Work &W = *c.W; LC_WS &S = LC_SREF(c);
   uint32_t lo = W.gr[n].seq_lo, hi = W.gr[n].seq_hi;
   if (lo - W.gr[n].seq_clo >= front && W.gr[n].seq_chi - hi >= back) return true;
   uint32_t len = hi - lo;
@@ -519,7 +520,7 @@ DEV bool seq_reserve(Ctx &c, uint32_t n, uint32_t front, uint32_t back) {   // r
 // buildgraph (reference src/Graph.cc:530-589 + loadSequence :119-349 + Node.cc / Ref.cc counters)
 // ---------------------------------------------------------------------------------------------------------
 DEV void read_geom(const Ctx &c, int r, uint32_t *rinfo, uint32_t *bw, uint32_t *gw, int *tlen, bool *isref) {
-  const DevBatch &B = *c.B; const volatile WinShared &S = LC_SREF(c);
+  LC_GLOBAL const DevBatch &B = *c.B; const LC_WS &S = LC_SREF(c);
   if (r == S.R - 1) { *isref = true; *tlen = S.reflen; *rinfo = 0; *bw = 0; *gw = 0; return; }
   uint32_t g = B.read_begin[S.w] + (uint32_t)r;
   *isref = false; *rinfo = B.rinfo[g]; *bw = B.base_woff[g]; *gw = B.good_woff[g]; *tlen = (int)RI_TLEN(*rinfo);
@@ -555,7 +556,7 @@ DEV bool nk_is_forward(const uint8_t *ref, int p, int K) {                      
 // (reads arrive in coordinate order per sample, so rank * (W - len) / n is a fair estimate of a read's start): at a
 // given step the lanes then touch the same few table slots / nodes, which the L2 can coalesce.
 DEVNI void build_items(Ctx &c) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   WG_LANE0 {
     const uint32_t g0 = c.B->read_begin[S.w];
     const int nr = S.R - 1;
@@ -595,7 +596,7 @@ DEVNI void build_items(Ctx &c) {
 
 template <int NW>
 DEVNI void build_insert_pass(Ctx &c, bool verify) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   const int K = S.K;
   const uint32_t mask = S.tmask;
   const uint32_t plimit = mask + 1 < c.C->table_cap ? 48u : mask;   // a growable table is doubled rather than probed at length
@@ -674,16 +675,16 @@ DEVNI void build_insert_pass(Ctx &c, bool verify) {
 //   packed bases are little-endian (base j of the k-mer at bits 2j): the reverse-complement key of key_push_rc is the
 //   complement of exactly that; the forward key of key_push_fw is the same bases with the 2-bit groups reversed.
 DEVNI void build_insert_occ_major(Ctx &c) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   const int K = S.K;
   const uint32_t mask = S.tmask;
   const uint32_t plimit = mask + 1 < c.C->table_cap ? 48u : mask;   // a growable table is doubled rather than probed at length
   const unsigned long long kmask = (K == 32) ? ~0ULL : ((1ULL << (2 * K)) - 1ULL);
   const uint32_t refr = (uint32_t)(S.R - 1);
   const uint32_t g0 = c.B->read_begin[S.w];
-  LC_GLOBAL const uint8_t *refc = gptr((const uint8_t *)c.B->ref_codes) + c.B->ref_off[S.w];
-  LC_GLOBAL const uint32_t *occ_base = gptr((const uint32_t *)W.occ_base), *bases = gptr((const uint32_t *)c.B->bases), *base_woff = gptr((const uint32_t *)c.B->base_woff) + g0;
-  LC_GLOBAL uint32_t *slots = gptr((uint32_t *)W.slots), *occ = gptr((uint32_t *)W.occ);
+  LC_GLOBAL const uint8_t *refc = c.B->ref_codes + c.B->ref_off[S.w];
+  LC_GLOBAL const uint32_t *occ_base = W.occ_base, *bases = c.B->bases, *base_woff = c.B->base_woff + g0;
+  LC_GLOBAL uint32_t *slots = W.slots, *occ = W.occ;
   uint32_t rcur = 0;
   WG_FOR(o, S.O) {
     while (rcur < refr && (uint32_t)o >= occ_base[rcur + 1]) ++rcur;
@@ -744,7 +745,7 @@ DEV bool step_all_good(const Ctx &c, bool isref, uint32_t gw, int s, int tlen, i
 //   csr bits 29..31 of a counted occurrence = "hpX had grown" (feeds hpX_minqv in the per-position pass)
 #define LC_PK(x, i) ((uint32_t)(((x) >> (16 * (i))) & 0xFFFFULL))
 DEVNI void lr_node_replay(Ctx &c, uint32_t lo, uint32_t hi, uint32_t *out) {
-  Work &W = *c.W; const DevBatch &B = *c.B; volatile WinShared &S = LC_SREF(c);
+  LC_GLOBAL Work &W = *c.W; LC_GLOBAL const DevBatch &B = *c.B; LC_WS &S = LC_SREF(c);
   const uint32_t g0 = B.read_begin[S.w];
   const uint32_t refr = (uint32_t)(S.R - 1);
   for (uint32_t i = lo + 1; i < hi; ++i) {                      // order of the visits
@@ -801,7 +802,7 @@ DEVNI void lr_node_replay(Ctx &c, uint32_t lo, uint32_t hi, uint32_t *out) {
 // buildgraph is cut into separately compiled pieces (DEVNI): one register allocation per phase instead of one for the
 // whole window program, which kept values of later phases alive (and spilled) across the hot loops of earlier ones.
 DEVNI void build_tables(Ctx &c) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W; const EngineCaps &C = *c.C;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W; LC_GLOBAL const EngineCaps &C = *c.C;
   const int K = S.K;
   (void)C; (void)K; (void)W;
   // ---- occurrence index space: read r owns [occ_base[r], occ_base[r+1]) = its k-mers p = 0..tlen-K
@@ -902,7 +903,7 @@ DEVNI void build_tables(Ctx &c) {
   WG_SYNC();
 }
 DEVNI void build_csr(Ctx &c) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W; const EngineCaps &C = *c.C;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W; LC_GLOBAL const EngineCaps &C = *c.C;
   const int K = S.K;
   (void)C; (void)K; (void)W;
   // ---- pass 2a: occurrences slot -> node id; occurrences per node (the only per-occurrence atomic, on a compact array)
@@ -1053,7 +1054,7 @@ DEVNI void build_csr(Ctx &c) {
   WG_SYNC();
 }
 DEVNI void build_gather(Ctx &c) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W; const EngineCaps &C = *c.C;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W; LC_GLOBAL const EngineCaps &C = *c.C;
   const int K = S.K;
   (void)C; (void)K; (void)W;
   // ---- per node, gathering over its occurrences (reference src/Graph.cc:163-349): colours, counted occurrences per
@@ -1126,7 +1127,7 @@ DEVNI void build_gather(Ctx &c) {
     { const uint32_t ef[10] = {ef0, ef1, ef2, ef3, ef4, ef5, ef6, ef7, ef8, ef9};
       for (int j = 0; j < 10; ++j) if (ef[j] != LC_NIL) stamp[ne++] = ef[j]; }
     for (int i = 1; i < ne; ++i) { uint32_t s = stamp[i]; int j = i; while (j > 0 && stamp[j - 1] > s) { stamp[j] = stamp[j - 1]; --j; } stamp[j] = s; }
-    NodeGr &G = W.gr[n];
+    LC_GLOBAL NodeGr &G = W.gr[n];
     // first removeLowCov predicate (reference src/Graph.cc:2790-2827, docompression=false, compid=0): minqv <= T.
     // minqv cannot exceed the number of counted occurrences, so most nodes (sequencing-error k-mers) are decided here;
     // the others get their per-position counts from the whole wave below.  A node that is certain to go needs no edge
@@ -1164,7 +1165,7 @@ DEVNI void build_gather(Ctx &c) {
   WG_SYNC();
 }
 DEVNI void build_qcounts(Ctx &c) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W; const EngineCaps &C = *c.C;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W; LC_GLOBAL const EngineCaps &C = *c.C;
   const int K = S.K;
   (void)C; (void)K; (void)W;
   const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
@@ -1213,7 +1214,7 @@ DEVNI void build_qcounts(Ctx &c) {
         constexpr int U = LC_STAGE / LANCET_WG;
         float gcov[4] = {0.f, 0.f, 0.f, 0.f}; uint32_t gfl = 0;
         const bool gfetch = r0 == 0 && ln < gN;                  // lane k: candidate k's record for the tail of this group
-        if (gfetch) { const NodeGr &G = W.gr[S.g_n[ln]]; gcov[0] = G.cov[0]; gcov[1] = G.cov[1]; gcov[2] = G.cov[2]; gcov[3] = G.cov[3]; gfl = G.flags; }
+        if (gfetch) { LC_GLOBAL const NodeGr &G = W.gr[S.g_n[ln]]; gcov[0] = G.cov[0]; gcov[1] = G.cov[1]; gcov[2] = G.cov[2]; gcov[3] = G.cov[3]; gfl = G.flags; }
         uint32_t e[U], m[U][4], meta[U]; bool act[U];
         const uint32_t *gd[U]; uint32_t ri[U];
         for (int u = 0; u < U; ++u) {
@@ -1318,7 +1319,7 @@ DEVNI void build_qcounts(Ctx &c) {
     WG_FOR(k, gN) {                              // one lane per candidate of the group: stores only
       {
         const uint32_t n = S.g_n[k];
-        NodeGr &G = W.gr[n];
+        LC_GLOBAL NodeGr &G = W.gr[n];
         const int minqv = (int)S.g_min[k];
         const float tt = S.g_tt[k], tn = S.g_tn[k];
         const bool low = (minqv <= c.P->low_cov_threshold) || ((double)minqv <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
@@ -1340,7 +1341,7 @@ DEVNI void build_qcounts(Ctx &c) {
   WG_SYNC();
 }
 DEVNI void build_refcov(Ctx &c) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W; const EngineCaps &C = *c.C;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W; LC_GLOBAL const EngineCaps &C = *c.C;
   const int K = S.K;
   (void)C; (void)K; (void)W;
   // ---- Ref_t::mertable membership (indexMers over the possibly trimmed seq, reference src/Ref.cc:40-64)
@@ -1406,7 +1407,7 @@ DEV void build_graph(Ctx &c) {
 // The first 29 insertions (2 small stages) are replayed sequentially.
 // ---------------------------------------------------------------------------------------------------------
 DEVNI void order_stage(Ctx &c, const uint32_t *Q, uint32_t *Qn, int n, uint32_t B) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   uint32_t *bkt = W.scratch, *tmp = W.scratch + c.C->node_cap;
   uint32_t *first = W.ht_bucket, *cnt = W.ht_cnt, *start = W.ht_start, *out = W.ht_next;
   WG_FOR(b, (int)B) { cnt[b] = 0; first[b] = LC_NIL; }
@@ -1441,7 +1442,7 @@ DEVNI void order_stage(Ctx &c, const uint32_t *Q, uint32_t *Qn, int n, uint32_t 
 
 // the live table in libstdc++ iteration order -> order[0..M)
 DEVNI void first_lowcov(Ctx &c) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   const uint32_t SEQ = 29u;                             // a value of the growth chain
   WG_LANE0 {
     ht_reset(c);
@@ -1472,7 +1473,7 @@ DEVNI void first_lowcov(Ctx &c) {
 
 // cleanDead over the whole table (reference src/Graph.cc:2737-2762), parallel: compaction of order[] keeping the order
 DEVNI void clean_dead_wg(Ctx &c) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   const int M = (int)wg_bcastu(&S.M);
   uint32_t *keep = W.scratch;
   WG_FOR(i, M) { const uint32_t f = W.gr[W.order[i]].flags; keep[i] = ((f & NF_SURV) && !(f & NF_DEAD)) ? 1u : 0u; }
@@ -1487,14 +1488,14 @@ DEVNI void clean_dead_wg(Ctx &c) {
 
 DEV void recompute_after_append(Ctx &c, uint32_t n, uint32_t from, uint32_t to) {
   // Node_t::computeMinCov over the merged arrays == min(old minima, minima over the appended descriptors)
-  Work &W = *c.W;
+  LC_GLOBAL Work &W = *c.W;
   int mn = W.gr[n].mincov, mq = W.gr[n].mincovqv;
   for (uint32_t i = from; i < to; ++i) { int t, tq; desc_tot(c, W.seq[i], &t, &tq); if (t < mn) mn = t; if (tq < mq) mq = tq; }
   W.gr[n].mincov = mn; W.gr[n].mincovqv = mq;
 }
 
 DEVNI void compress_node(Ctx &c, uint32_t node, char dir) {          // Graph_t::compressNode, reference src/Graph.cc:2486-2706
-  Work &W = *c.W; volatile WinShared &S = LC_SREF(c);
+  LC_GLOBAL Work &W = *c.W; LC_WS &S = LC_SREF(c);
   const int K = S.K;
   while (!S.overflow) {
     int uid = get_buddy(c, node, dir);
@@ -1583,13 +1584,13 @@ DEV uint32_t cmp_link(const Ctx &c, uint32_t n, char dir, bool *irregular) {
   return CL_VALID | (edir << 28) | b;
 }
 DEVNI void compress_prepare(Ctx &c, int comp) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   const int K = S.K;
   WG_LANE0 { S.cmp_ok = 1; }
   WG_FOR(i, S.M) {
     const uint32_t n = W.order[i];
-    CmpRec &r = W.cmp[n];
-    const NodeGr &G = W.gr[n];
+    LC_GLOBAL CmpRec &r = W.cmp[n];
+    LC_GLOBAL const NodeGr &G = W.gr[n];
     r.lnk[0] = 0; r.lnk[1] = 0;
     if (G.comp != comp || (G.flags & (NF_DEAD | NF_SPECIAL))) continue;
     bool irr = false;
@@ -1609,7 +1610,7 @@ DEVNI void compress_prepare(Ctx &c, int comp) {
   WG_SYNC();
 }
 DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   const int K = S.K;
   if (!quiet) evt(c, EV_COMPRESS);
   uint32_t *list = W.scratch;                                   // (absorbed node, edge dir it is entered by) per merge
@@ -1628,7 +1629,7 @@ DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
       bool valid = (l & CL_VALID) != 0;
       while (valid) {
         if (B == H || cnt >= lcap) { ring = true; break; }
-        const CmpRec &rb = W.cmp[B];                               // the one dependent access of this merge
+        LC_GLOBAL const CmpRec &rb = W.cmp[B];                               // the one dependent access of this merge
         list[2 * cnt] = B; list[2 * cnt + 1] = edir; ++cnt;
         const char bdir = (edir == 0 || edir == 2) ? 'R' : 'F';
         const uint32_t on = rb.lnk[bdir == 'R' ? 0 : 1];          // the absorbed node's link away from the head
@@ -1638,7 +1639,7 @@ DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
       if (ring) { compress_node(c, H, dir); continue; }           // untouched so far: the literal replay handles it
       if (cnt == 0) continue;
       // ---- replay
-      NodeGr &G = W.gr[H];
+      LC_GLOBAL NodeGr &G = W.gr[H];
       {                                                            // the head's edge to the first absorbed node goes away
         const int uid = get_buddy(c, H, dir);
         if (uid == -1) { OVF(c); return 0; }
@@ -1652,7 +1653,7 @@ DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
       int alen = (int)(hi - lo);
       for (uint32_t j = 0; j < cnt; ++j) {
         const uint32_t Bj = list[2 * j], ed = list[2 * j + 1];
-        const CmpRec &rb = W.cmp[Bj];
+        LC_GLOBAL const CmpRec &rb = W.cmp[Bj];
         const bool brev = dir_dest(ed) == 'R';
         uint32_t d = brev ? (rb.d0 ^ 3u) : rb.dK;
         if (dir == 'F') W.seq[hi++] = d; else W.seq[--lo] = d ^ 3u;
@@ -1694,7 +1695,7 @@ DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
   return clean_dead(c, quiet);
 }
 DEVNI uint32_t compress(Ctx &c, int comp, bool quiet = false) {       // reference src/Graph.cc:2712-2732
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   if (!quiet) evt(c, EV_COMPRESS);
   for (uint32_t i = 0; i < S.M && !S.overflow; ++i) {
     uint32_t n = W.order[i];
@@ -1707,7 +1708,7 @@ DEVNI uint32_t compress(Ctx &c, int comp, bool quiet = false) {       // referen
   return clean_dead(c, quiet);
 }
 DEVNI void remove_low_cov(Ctx &c, int comp) {                         // reference src/Graph.cc:2790-2827 (docompression=true)
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
   uint32_t low = 0;
   for (uint32_t i = 0; i < S.M; ++i) {
@@ -1768,13 +1769,13 @@ DEVNI bool find_tandems(const Ctx &c, const uint8_t *seq, int n, int pos, int *l
 }
 
 DEV void node_string(const Ctx &c, uint32_t n, uint8_t *out) {      // str_m as codes
-  const Work &W = *c.W;
+  const LC_GLOBAL Work &W = *c.W;
   uint32_t lo = W.gr[n].seq_lo, hi = W.gr[n].seq_hi;
   for (uint32_t i = lo; i < hi; ++i) out[i - lo] = (uint8_t)SD_BASE(W.seq[i]);
 }
 
 DEVNI void remove_tips(Ctx &c, int comp) {                            // reference src/Graph.cc:2885-2926
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   int tips = 0, round = 0;
   do {
     ++round; tips = 0;
@@ -1792,7 +1793,7 @@ DEVNI void remove_tips(Ctx &c, int comp) {                            // referen
   print_stats(c, comp);
 }
 DEVNI void remove_short_links(Ctx &c, int comp) {                     // reference src/Graph.cc:2833-2880
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
   const int max_link_len = S.K / 2;                                  // setK: floor(K/2.0)
   const double thr = floor(sqrt(avgcov));
@@ -1822,7 +1823,7 @@ DEVNI void remove_short_links(Ctx &c, int comp) {                     // referen
 // pointer jumping (O(log n) rounds, every lane busy) instead of a one-lane queue walk that pays a full memory round trip
 // per node.  parent[] (node ids; a node's label only ever decreases) is updated with atomics and read at L2.
 DEVNI void mark_connected_components_wg(Ctx &c) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   const int M = (int)wg_bcastu(&S.M);
   const uint32_t nodes = c.C->node_cap + c.C->special_cap;
   uint32_t *parent = W.scratch, *minpos = W.scratch + nodes, *touch = W.pnodes, *first = W.pedges, *cid = W.nfill;
@@ -1832,7 +1833,7 @@ DEVNI void mark_connected_components_wg(Ctx &c) {
   uint32_t *adj = W.mv;                                          // idle after the build
   WG_FOR(i, M) {
     const uint32_t n = W.order[i];
-    const NodeGr &G = W.gr[n];
+    LC_GLOBAL const NodeGr &G = W.gr[n];
     const int ne = (int)G.necnt;
     lc_u4 a; a.x = (uint32_t)ne; a.y = ne > 0 ? ED_TO(G.edges[0]) : n; a.z = ne > 1 ? ED_TO(G.edges[1]) : n; a.w = ne > 2 ? ED_TO(G.edges[2]) : n;
     *(lc_u4 *)(adj + 4 * (size_t)i) = a;
@@ -1851,7 +1852,7 @@ DEVNI void mark_connected_components_wg(Ctx &c) {
       if (p1 < m) m = p1;
       if (p2 < m) m = p2;
       if (p3 < m) m = p3;
-      if (a.x > 3) { const NodeGr &G = W.gr[u]; for (int e = 3; e < (int)a.x; ++e) { const uint32_t pv = ld2(&parent[ED_TO(G.edges[e])]); if (pv < m) m = pv; } }
+      if (a.x > 3) { LC_GLOBAL const NodeGr &G = W.gr[u]; for (int e = 3; e < (int)a.x; ++e) { const uint32_t pv = ld2(&parent[ED_TO(G.edges[e])]); if (pv < m) m = pv; } }
       if (m < pu) { dev_atomic_min(&parent[pu], m); dev_atomic_min(&parent[u], m); S.tmp0 = 1; }
     }
     WG_SYNC();
@@ -1899,7 +1900,7 @@ DEVNI void mark_connected_components_wg(Ctx &c) {
 // markRefEnds (reference src/Graph.cc:2028-2228).  The node of the reference k-mer at `offset` is the node
 // of the reference pseudo-read's occurrence at that offset (if it is still in the table).
 DEV uint32_t special_new(Ctx &c, bool issource, int comp) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   if (S.nspecial >= c.C->special_cap) { OVF(c); return LC_NIL; }
   uint32_t id = c.C->node_cap + S.nspecial++;
   char name[24]; int L = 0;
@@ -1918,7 +1919,7 @@ DEV uint32_t special_new(Ctx &c, bool issource, int comp) {
 // mr_src / mr_snk = first / last offset whose node is live, has getTotCov() >= COV_THRESHOLD and is in the component
 // (-1 if none); mr_ambs / mr_ambk = the same node qualifies again further on (the reference then gives up).
 DEVNI void mark_ref_scan(Ctx &c, int comp) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   const int K = S.K;
   const uint32_t ro = W.occ_base[S.R - 1];
   const int nrefk = (S.reflen - K > 0) ? S.reflen - K + 1 : 0;
@@ -1944,7 +1945,7 @@ DEVNI void mark_ref_scan(Ctx &c, int comp) {
   WG_LANE0 { S.mr_snk = ko; }
 }
 DEVNI void mark_ref_ends(Ctx &c, int comp) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   const int K = S.K;
   S.trim5 = 0xFFFF; S.trim3 = 0xFFFF;
   S.source = LC_NIL; S.sink = LC_NIL;
@@ -1997,7 +1998,7 @@ DEVNI void mark_ref_ends(Ctx &c, int comp) {
 }
 
 DEVNI bool has_cycle(Ctx &c, bool colored = false) {                                         // reference src/Graph.cc:593-681
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   if (S.source == LC_NIL || S.sink == LC_NIL) return false;
   if (!colored) for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (!(W.gr[n].flags & NF_SPECIAL)) W.gr[n].color = 1; }
   bool ans = false;
@@ -2043,7 +2044,7 @@ DEV bool path_has_node(const Ctx &c, uint32_t idx, uint32_t node) {
   return false;
 }
 DEVNI uint32_t bfs(Ctx &c) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   BfsEntry *Q = W.queue;
   const uint32_t cap = c.C->queue_cap;
   int reflen = S.seq_len;
@@ -2082,7 +2083,7 @@ DEVNI uint32_t bfs(Ctx &c) {
 }
 // unpack the best path into W.pnodes / W.pedges ; returns number of nodes
 DEVNI int path_unpack(Ctx &c, uint32_t best) {
-  Work &W = *c.W; const BfsEntry *Q = W.queue;
+  LC_GLOBAL Work &W = *c.W; const BfsEntry *Q = W.queue;
   int n = 0;
   for (uint32_t i = best; i != LC_NIL; i = Q[i].parent) ++n;
   int k = n;
@@ -2090,7 +2091,7 @@ DEVNI int path_unpack(Ctx &c, uint32_t best) {
   return n;   // pedges[j] (j>=1) is the edge leading into node j
 }
 DEV void path_flag_edges(Ctx &c, int n, uint32_t v) {
-  Work &W = *c.W;
+  LC_GLOBAL Work &W = *c.W;
   for (int j = 1; j < n; ++j) {
     uint32_t owner = W.pedges[j] >> 4, ei = W.pedges[j] & 15u;
     uint32_t *e = &W.gr[owner].edges[ei];
@@ -2099,7 +2100,7 @@ DEV void path_flag_edges(Ctx &c, int n, uint32_t v) {
 }
 // Path_t::str + covDistr (reference src/Path.cc:69-175): string codes + descriptor per base ; returns length
 DEVNI int path_string(Ctx &c, int n) {
-  Work &W = *c.W; volatile WinShared &S = LC_SREF(c);
+  LC_GLOBAL Work &W = *c.W; LC_WS &S = LC_SREF(c);
   const int K = S.K;
   int len = 0;
   uint32_t e1 = W.gr[(W.pedges[1] >> 4)].edges[(W.pedges[1] & 15u)];
@@ -2126,7 +2127,7 @@ DEVNI int path_string(Ctx &c, int n) {
 // The same string and descriptors with all lanes: contribution length of every path node (special nodes none, the first
 // real node whole, the others without the K-1 overlap), exclusive scan, then one lane per output base.
 DEVNI int path_string_wg(Ctx &c, int n) {
-  Work &W = *c.W; volatile WinShared &S = LC_SREF(c);
+  LC_GLOBAL Work &W = *c.W; LC_WS &S = LC_SREF(c);
   const int K = S.K;
   const int dcap = 7 * (LC_MAXW + 2);
   if (2 * (n + 1) > dcap || n < 2) { WG_LANE0 { S.ps_len = path_string(c, n); } return wg_bcast(&S.ps_len); }
@@ -2164,7 +2165,7 @@ DEVNI int path_string_wg(Ctx &c, int n) {
   return plen;
 }
 DEV uint32_t path_contig(const Ctx &c, int n, int pos) {            // Path_t::pathcontig, reference src/Path.cc:291-314
-  const Work &W = *c.W;
+  const LC_GLOBAL Work &W = *c.W;
   int cur = 0;
   for (int i = 0; i < n; ++i) {
     uint32_t nd = W.pnodes[i];
@@ -2190,7 +2191,7 @@ DEV bool status_cnt_T(const Ctx &c, uint32_t n) {                   // Node_t::i
 // tb byte: M.tb [1:0] (0 '\\', 1 '<', 2 '^', 3 '*') ; X.tb [3:2] (0 '<', 1 '-', 2 '*') ; Y.tb [5:4] (0 '^', 1 '|', 2 '*')
 // ---------------------------------------------------------------------------------------------------------
 DEV void align_fill_arrays(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) {
-  Work &W = *c.W;
+  LC_GLOBAL Work &W = *c.W;
   const int A = LC_MAXW + 2;
   int32_t *Mb[3] = {W.dp, W.dp + A, W.dp + 2 * A};
   int32_t *Xb[2] = {W.dp + 3 * A, W.dp + 4 * A};
@@ -2230,7 +2231,7 @@ DEV void align_fill_arrays(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, 
 // (wave shuffles) or by the lane itself.  The score diagonals never touch memory; only the traceback bytes do.
 DEVNI void align_fill(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) {
   static_assert(LANCET_WG == 64, "one wave per window");
-  Work &W = *c.W;
+  LC_GLOBAL Work &W = *c.W;
   const int lane = (int)threadIdx.x;
   for (int j = lane; j < m + 1; j += 64) W.tb[LC_TB(0, j, n)] = (uint8_t)((j == 0 ? 3 : 2) | (0 << 2) | (2 << 4));           // M[0][j] '^' ; Y[0][j] '*'
   for (int i = lane + 1; i < n + 1; i += 64) W.tb[LC_TB(i, 0, n)] = (uint8_t)(1 | (2 << 2) | (0 << 4));     // M[i][0] '<' ; X[i][0] '*'
@@ -2286,7 +2287,7 @@ DEV void align_fill(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) 
 #endif
 // traceback into W.aln: returns alignment length; ref_aln at aln[0..L), path_aln at aln[cap..cap+L) (ASCII)
 DEVNI int align_traceback(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) {
-  Work &W = *c.W;
+  LC_GLOBAL Work &W = *c.W;
   const int cap = LC_MAXW + (int)c.C->path_cap + 2;
   uint8_t *ra = W.aln, *pa = W.aln + cap;
   int i = n, j = m, L = 0;
@@ -2388,7 +2389,7 @@ DEV void path_cov_at(const Ctx &c, int P, uint16_t *n4, uint16_t *t4) {         
 // ---- --linked-reads: barcode sets of a variant (Graph_t::getBXsetAt / Ref_t::getBXsetAt, reference src/Graph.cc:83-114,
 // src/Ref.cc:96-125).  bx_table[mer] = barcodes of all reads of the sample that contain the k-mer = the node's csr list.
 DEV void bx_add_node(Ctx &c, uint32_t X, uint32_t nml, uint32_t *n) {
-  Work &W = *c.W; const DevBatch &B = *c.B; volatile WinShared &S = LC_SREF(c);
+  LC_GLOBAL Work &W = *c.W; LC_GLOBAL const DevBatch &B = *c.B; LC_WS &S = LC_SREF(c);
   const uint32_t g0 = B.read_begin[S.w], refr = (uint32_t)(S.R - 1);
   uint32_t *buf = W.bxbuf;
   for (uint32_t i = W.nocc[X]; i < W.nocc[X + 1]; ++i) {
@@ -2407,7 +2408,7 @@ DEV void bx_add_node(Ctx &c, uint32_t X, uint32_t nml, uint32_t *n) {
 }
 // node of the k-mer codes[0..K) (2-bit codes) or LC_NIL: the open-addressing table of the current build
 DEVNI uint32_t kmer_lookup(Ctx &c, const uint8_t *codes) {
-  Work &W = *c.W; volatile WinShared &S = LC_SREF(c);
+  LC_GLOBAL Work &W = *c.W; LC_WS &S = LC_SREF(c);
   const int K = S.K, NW = S.NW;
   unsigned long long fw[LC_NWMAX], rc[LC_NWMAX];
   for (int w = 0; w < LC_NWMAX; ++w) { fw[w] = 0; rc[w] = 0; }
@@ -2435,7 +2436,7 @@ DEVNI uint32_t kmer_lookup(Ctx &c, const uint8_t *codes) {
   return LC_NIL;
 }
 DEVNI void emit_variant_lr(Ctx &c, uint32_t vi, const TS &t, const uint16_t hp12[12], int plen) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W; DevOut &O = *c.OUT;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W; DevOut &O = *c.OUT;
   lancet_variant_lr &l = O.variants_lr[vi];
   for (int q = 0; q < 12; ++q) l.hp[q] = hp12[q];
   l.reserved[0] = l.reserved[1] = 0;
@@ -2466,7 +2467,7 @@ DEVNI void emit_variant_lr(Ctx &c, uint32_t vi, const TS &t, const uint16_t hp12
 
 DEVNI void emit_variant(Ctx &c, const TS &t, const uint16_t cov[8], int strLen, const uint8_t *motif, int motifLen, bool hasStr,
                       const uint8_t *ra, const uint8_t *pa, const uint16_t hp12[12], int plen) {
-  volatile WinShared &S = LC_SREF(c); DevOut &O = *c.OUT;
+  LC_WS &S = LC_SREF(c); DevOut &O = *c.OUT;
   uint32_t vi = dev_atomic_add(O.n_variants, 1u);
   int rl = t.col1 - t.col0 + 1;
   char sbuf[80]; int sl = 0;
@@ -2493,7 +2494,7 @@ DEVNI void emit_variant(Ctx &c, const TS &t, const uint16_t cov[8], int strLen, 
 // column-type counts.  The walk (lane 0) then visits only the non-match columns instead of all of them.
 //   scratch[0..L) = pos_in_ref, scratch[L+1..2L+1) = pathpos - (column consumes a path base), scratch[2L+2..] = column list
 DEVNI void walk_prepare(Ctx &c, int L) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   const int cap = LC_MAXW + (int)c.C->path_cap + 2;
   const uint8_t *ra = W.aln, *pa = W.aln + cap;
   uint32_t *E1 = W.scratch, *E2 = W.scratch + (L + 1), *F = W.scratch + 2 * (L + 1), *cols = W.scratch + 3 * (L + 1);
@@ -2514,7 +2515,7 @@ DEVNI void walk_prepare(Ctx &c, int L) {
 
 // lane 0.  `np` = nodes in path, `plen` = path string length, aligned strings in W.aln (length L).
 DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   const int K = S.K;
   const int cap = LC_MAXW + (int)c.C->path_cap + 2;
   const uint8_t *ra = W.aln, *pa = W.aln + cap;
@@ -2648,7 +2649,7 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
 // returns true when a near-perfect repeat is found in a source->sink path (Graph_t::findRepeatsInGraphPaths,
 // reference src/Graph.cc:686-730)
 DEVNI bool repeats_in_graph_paths(Ctx &c) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   WG_LANE0 {
     evt(c, EV_LOOKREP);
     S.tmp0 = 0;                                  // 0 continue, 1 stop:false, 2 stop:true
@@ -2683,7 +2684,7 @@ DEVNI bool repeats_in_graph_paths(Ctx &c) {
 
 // eka (reference src/Graph.cc:1430-1501) via countRefPath (:2420-2445)
 DEVNI void count_ref_path(Ctx &c) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
   if (wg_bcastu(&S.source) == LC_NIL) return;
   if (wg_bcastu(&S.sink) != LC_NIL) {
     WG_LANE0 { evt(c, EV_SEARCH, (uint32_t)W.gr[S.source].comp); S.tmp0 = S.tmp1 = S.tmp2 = 0; S.part[0] = 0; S.part[1] = 0; S.part[2] = 0; S.part[3] = 0; }
@@ -2754,7 +2755,7 @@ DEVNI void count_ref_path(Ctx &c) {
 // the window: Microassembler::processGraph (reference src/Microassembler.cc:73-249)
 // ---------------------------------------------------------------------------------------------------------
 DEV void process_window(Ctx &c, int w) {
-  volatile WinShared &S = LC_SREF(c); Work &W = *c.W; const DevBatch &B = *c.B;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W; LC_GLOBAL const DevBatch &B = *c.B;
   WG_LANE0 {
     S.w = w; S.overflow = 0; S.evt_len = 0; S.emit_seq = 0; S.n_kmers = 0; S.max_nodes = 0; S.n_builds = 0; S.N_last = 0; S.final_k = 0;
     S.status = LANCET_W_OK;
@@ -2876,7 +2877,7 @@ DEV void process_window(Ctx &c, int w) {
 }
 
 // entry: persistent workgroup pulling windows off the batch queue
-DEV void window_kernel_body(const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT, volatile WinShared *S, int slot) {
+DEV void window_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *B, LC_GLOBAL const EngineCaps *C, LC_GLOBAL Work *works, LC_GLOBAL DevOut *OUT, LC_WS *S, int slot) {
   Ctx c; c.P = P; c.B = B; c.C = C; c.W = works + slot; c.OUT = OUT; c.S = S;
   while (true) {
     WG_LANE0 { S->tmp3 = (int)dev_atomic_add(OUT->queue_head, 1u); }

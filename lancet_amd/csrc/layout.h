@@ -6,6 +6,19 @@
 #pragma once
 #include <stdint.h>
 
+/* Address spaces of the device pointers.  A pointer that comes out of a structure in memory is generic to the compiler
+ * and gets FLAT instructions, whose completion is tracked by the LDS counter as well (every wait for an LDS read then
+ * also waits for all memory loads in flight, and LDS control words reached through a generic pointer are FLAT too).
+ * Typed pointers give GLOBAL / DS instructions.  Device pass only: empty in hipcc's host pass (where named address
+ * spaces do not convert to generic) and for the host-compiler builds (wave emulator). */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LANCET_WAVE_EMU)
+#define LC_GLOBAL __attribute__((address_space(1)))
+#define LC_LDS __attribute__((address_space(3)))
+#else
+#define LC_GLOBAL
+#define LC_LDS
+#endif
+
 #define LC_NWMAX 4            /* 64-bit words per k-mer key: k <= 128 (reference max k = 101)            */
 #define LC_EMAX 12            /* edges per node (8 possible k-mer extensions + source/sink + slack)       */
 #define LC_NIL 0xFFFFFFFFu
@@ -80,18 +93,18 @@ struct EngineCaps {
 /* device-resident batch (after upload + prep) */
 struct DevBatch {
   int32_t n_windows;
-  const int32_t *chr_id, *ref_start;
-  const uint32_t *ref_off;      /* [n+1] */
-  const uint8_t *ref_codes;     /* A,C,G,T -> 0..3 ; anything else 4 */
-  const uint32_t *read_begin;   /* [n+1] */
-  const uint32_t *rinfo;        /* [R] */
-  const uint32_t *name_rank;    /* [R] */
-  const uint32_t *base_woff;    /* [R] word offset of the read's packed bases (16 bases / u32) */
-  const uint32_t *good_woff;    /* [R] word offset of the read's quality mask (32 bases / u32) */
-  const uint32_t *bases;        /* 2-bit packed, trimmed reads only */
-  const uint32_t *good;         /* bit = (qual >= MIN_QUAL_CALL) */
-  const uint32_t *bx_rank;      /* [R] barcode rank or LANCET_NO_BX (lr_mode only, else null) */
-  const uint8_t *hp;            /* [R] haplotype 0|1|2 (lr_mode only, else null) */
+  LC_GLOBAL const int32_t *chr_id, *ref_start;
+  LC_GLOBAL const uint32_t *ref_off;      /* [n+1] */
+  LC_GLOBAL const uint8_t *ref_codes;     /* A,C,G,T -> 0..3 ; anything else 4 */
+  LC_GLOBAL const uint32_t *read_begin;   /* [n+1] */
+  LC_GLOBAL const uint32_t *rinfo;        /* [R] */
+  LC_GLOBAL const uint32_t *name_rank;    /* [R] */
+  LC_GLOBAL const uint32_t *base_woff;    /* [R] word offset of the read's packed bases (16 bases / u32) */
+  LC_GLOBAL const uint32_t *good_woff;    /* [R] word offset of the read's quality mask (32 bases / u32) */
+  LC_GLOBAL const uint32_t *bases;        /* 2-bit packed, trimmed reads only */
+  LC_GLOBAL const uint32_t *good;         /* bit = (qual >= MIN_QUAL_CALL) */
+  LC_GLOBAL const uint32_t *bx_rank;      /* [R] barcode rank or LANCET_NO_BX (lr_mode only, else null) */
+  LC_GLOBAL const uint8_t *hp;            /* [R] haplotype 0|1|2 (lr_mode only, else null) */
 };
 
 struct BfsEntry {
@@ -133,68 +146,68 @@ struct CmpRec {
 /* One slot of work space.  All pointers are device pointers into one big allocation. */
 struct Work {
   /* ---- build ---- */
-  uint32_t *occ_base;     /* [reads_cap+1] first occurrence index of each read                 */
-  uint32_t *rd;           /* [reads_cap*4] per read: info word, packed-base offset, quality-mask offset, first occurrence (one 16-byte load) */
-  uint8_t *cand;          /* [reads_cap]   read has an earlier opposite mate of the same name  */
-  uint32_t *mate_of;      /* [reads_cap]   index of that earlier mate (when unique)            */
-  uint32_t *items;        /* [2*(reads_cap + LC_MAXW/LC_SEG + 2)] work items of the per-occurrence passes */
-  uint32_t *chunk;        /* [2*((reads_cap + LC_MAXW/LC_SEG + 2)/64 + 2)] sweep origin/length per group of items */
-  uint32_t *occ;          /* [occ_cap]     slot (then node) | ori<<31                           */
-  uint32_t *slots;        /* [4*table_cap] k-mer table, 16 bytes per slot: tag (u64), first occurrence, node id */
-  uint32_t *mv;           /* [4*occ_cap] mate-name vectors of the nodes with flagged occurrences (read << 16 | name rank) */
-  uint32_t *todo;         /* [table_cap] occurrences flagged by the mate-overlap prefilter (read << 10 | position)  */
-  unsigned long long *slot_key; /* [table_cap * LC_NWMAX]                                    */
-  uint32_t *bitmap;       /* [occ_cap/32 + 2]                                                  */
-  uint32_t *bitpre;       /* [occ_cap/32 + 2]                                                  */
-  uint32_t *csr;          /* [occ_cap]                                                         */
+  LC_GLOBAL uint32_t *occ_base;     /* [reads_cap+1] first occurrence index of each read                 */
+  LC_GLOBAL uint32_t *rd;           /* [reads_cap*4] per read: info word, packed-base offset, quality-mask offset, first occurrence (one 16-byte load) */
+  LC_GLOBAL uint8_t *cand;          /* [reads_cap]   read has an earlier opposite mate of the same name  */
+  LC_GLOBAL uint32_t *mate_of;      /* [reads_cap]   index of that earlier mate (when unique)            */
+  LC_GLOBAL uint32_t *items;        /* [2*(reads_cap + LC_MAXW/LC_SEG + 2)] work items of the per-occurrence passes */
+  LC_GLOBAL uint32_t *chunk;        /* [2*((reads_cap + LC_MAXW/LC_SEG + 2)/64 + 2)] sweep origin/length per group of items */
+  LC_GLOBAL uint32_t *occ;          /* [occ_cap]     slot (then node) | ori<<31                           */
+  LC_GLOBAL uint32_t *slots;        /* [4*table_cap] k-mer table, 16 bytes per slot: tag (u64), first occurrence, node id */
+  LC_GLOBAL uint32_t *mv;           /* [4*occ_cap] mate-name vectors of the nodes with flagged occurrences (read << 16 | name rank) */
+  LC_GLOBAL uint32_t *todo;         /* [table_cap] occurrences flagged by the mate-overlap prefilter (read << 10 | position)  */
+  LC_GLOBAL unsigned long long *slot_key; /* [table_cap * LC_NWMAX]                                    */
+  LC_GLOBAL uint32_t *bitmap;       /* [occ_cap/32 + 2]                                                  */
+  LC_GLOBAL uint32_t *bitpre;       /* [occ_cap/32 + 2]                                                  */
+  LC_GLOBAL uint32_t *csr;          /* [occ_cap]                                                         */
   /* ---- nodes: index < node_cap are k-mers in first-insertion order; then special nodes ---- */
-  unsigned long long *nkey;     /* [nodes * LC_NWMAX] right-aligned 2-bit canonical k-mer     */
-  unsigned long long *nhash;    /* [nodes] libstdc++ std::hash<std::string> of the node id     */
-  uint32_t *nfill;        /* [nodes+1] csr fill cursors                                        */
-  NodeGr *gr;             /* [nodes]                                                           */
-  CmpRec *cmp;            /* [nodes] compress_prepare records                                   */
-  uint32_t *nocc;         /* [nodes+1] csr offsets                                             */
-  uint16_t *qv;           /* [qv_cap * QS] per-position min-quality counts Tf Tr Nf Nr (QS = 4), in lr_mode followed by
+  LC_GLOBAL unsigned long long *nkey;     /* [nodes * LC_NWMAX] right-aligned 2-bit canonical k-mer     */
+  LC_GLOBAL unsigned long long *nhash;    /* [nodes] libstdc++ std::hash<std::string> of the node id     */
+  LC_GLOBAL uint32_t *nfill;        /* [nodes+1] csr fill cursors                                        */
+  LC_GLOBAL NodeGr *gr;             /* [nodes]                                                           */
+  LC_GLOBAL CmpRec *cmp;            /* [nodes] compress_prepare records                                   */
+  LC_GLOBAL uint32_t *nocc;         /* [nodes+1] csr offsets                                             */
+  LC_GLOBAL uint16_t *qv;           /* [qv_cap * QS] per-position min-quality counts Tf Tr Nf Nr (QS = 4), in lr_mode followed by
                              hp0/hp1/hp2_minqv of the tumor and of the normal (QS = 10)        */
-  uint16_t *khp;          /* [nodes*6] lr_mode: last-written hp0 hp1 hp2 of the k-mer, tumor then normal */
-  uint16_t *refhp;        /* [LC_MAXW*6] lr_mode: the same per rawseq position (Ref_t coverage)  */
-  uint32_t *bxbuf;        /* [reads_cap] lr_mode: sorted distinct barcodes of the set being collected */
-  uint32_t *seq;          /* [seq_cap] descriptor arena                                        */
+  LC_GLOBAL uint16_t *khp;          /* [nodes*6] lr_mode: last-written hp0 hp1 hp2 of the k-mer, tumor then normal */
+  LC_GLOBAL uint16_t *refhp;        /* [LC_MAXW*6] lr_mode: the same per rawseq position (Ref_t coverage)  */
+  LC_GLOBAL uint32_t *bxbuf;        /* [reads_cap] lr_mode: sorted distinct barcodes of the set being collected */
+  LC_GLOBAL uint32_t *seq;          /* [seq_cap] descriptor arena                                        */
   /* ---- libstdc++ node-table order ---- */
-  uint32_t *ht_next;      /* [nodes]                                                           */
-  uint32_t *ht_bucket;    /* [bucket_cap]                                                      */
-  uint32_t *ht_cnt;       /* [bucket_cap] parallel order stages: elements per bucket           */
-  uint32_t *ht_start;     /* [bucket_cap] parallel order stages: first list position of the run */
-  uint32_t *order;        /* [nodes] iteration order of the live table                         */
-  uint32_t *scratch;      /* [nodes*2] stacks / queues of the graph passes                     */
+  LC_GLOBAL uint32_t *ht_next;      /* [nodes]                                                           */
+  LC_GLOBAL uint32_t *ht_bucket;    /* [bucket_cap]                                                      */
+  LC_GLOBAL uint32_t *ht_cnt;       /* [bucket_cap] parallel order stages: elements per bucket           */
+  LC_GLOBAL uint32_t *ht_start;     /* [bucket_cap] parallel order stages: first list position of the run */
+  LC_GLOBAL uint32_t *order;        /* [nodes] iteration order of the live table                         */
+  LC_GLOBAL uint32_t *scratch;      /* [nodes*2] stacks / queues of the graph passes                     */
   /* ---- reference coverage ---- */
-  uint16_t *refcov;       /* [LC_MAXW*4] Tf Tr Nf Nr per rawseq position                       */
+  LC_GLOBAL uint16_t *refcov;       /* [LC_MAXW*4] Tf Tr Nf Nr per rawseq position                       */
   /* ---- paths ---- */
-  BfsEntry *queue;        /* [queue_cap]                                                       */
-  uint32_t *pnodes;       /* [nodes] nodes of the current path                                 */
-  uint32_t *pedges;       /* [nodes] edge refs of the current path                             */
-  uint32_t *pdesc;        /* [path_cap] descriptor per path base                               */
-  uint8_t *pseq;          /* [path_cap] path string (codes 0..3)                               */
-  uint8_t *tb;            /* [(LC_MAXW+2)*(path_cap+2)] traceback bits                         */
-  int32_t *dp;            /* [7*(LC_MAXW+2)] alignment diagonals                               */
-  uint8_t *aln;           /* [2*(LC_MAXW+path_cap+2)] aligned strings (ASCII)                  */
-  uint32_t *evt;          /* [evt_cap] trace events                                            */
+  LC_GLOBAL BfsEntry *queue;        /* [queue_cap]                                                       */
+  LC_GLOBAL uint32_t *pnodes;       /* [nodes] nodes of the current path                                 */
+  LC_GLOBAL uint32_t *pedges;       /* [nodes] edge refs of the current path                             */
+  LC_GLOBAL uint32_t *pdesc;        /* [path_cap] descriptor per path base                               */
+  LC_GLOBAL uint8_t *pseq;          /* [path_cap] path string (codes 0..3)                               */
+  LC_GLOBAL uint8_t *tb;            /* [(LC_MAXW+2)*(path_cap+2)] traceback bits                         */
+  LC_GLOBAL int32_t *dp;            /* [7*(LC_MAXW+2)] alignment diagonals                               */
+  LC_GLOBAL uint8_t *aln;           /* [2*(LC_MAXW+path_cap+2)] aligned strings (ASCII)                  */
+  LC_GLOBAL uint32_t *evt;          /* [evt_cap] trace events                                            */
 };
 
 /* batch-level outputs */
 struct DevOut {
-  struct lancet_variant *variants;
-  char *blob;
-  uint32_t *n_variants;   /* atomic */
-  uint32_t *n_blob;       /* atomic */
-  struct lancet_window_stats *stats;
-  uint32_t *queue_head;   /* atomic window queue */
-  struct lancet_variant_lr *variants_lr;   /* lr_mode: parallel to variants */
-  uint32_t *bx_blob;      /* lr_mode: barcode ids of the variants' barcode sets */
-  uint32_t *n_bx;         /* atomic */
-  uint32_t *evt_len;      /* [n_windows] words used in the window's trace (slot evt copied out)  */
-  uint32_t *evt_out;      /* [n_windows * evt_cap] */
-  unsigned long long *phase; /* [n_windows * 16] per-phase time (100 MHz ticks), may be null */
-  const uint32_t *win_list;  /* when non-null: the windows to process (re-run of overflowed windows)   */
+  LC_GLOBAL struct lancet_variant *variants;
+  LC_GLOBAL char *blob;
+  LC_GLOBAL uint32_t *n_variants;   /* atomic */
+  LC_GLOBAL uint32_t *n_blob;       /* atomic */
+  LC_GLOBAL struct lancet_window_stats *stats;
+  LC_GLOBAL uint32_t *queue_head;   /* atomic window queue */
+  LC_GLOBAL struct lancet_variant_lr *variants_lr;   /* lr_mode: parallel to variants */
+  LC_GLOBAL uint32_t *bx_blob;      /* lr_mode: barcode ids of the variants' barcode sets */
+  LC_GLOBAL uint32_t *n_bx;         /* atomic */
+  LC_GLOBAL uint32_t *evt_len;      /* [n_windows] words used in the window's trace (slot evt copied out)  */
+  LC_GLOBAL uint32_t *evt_out;      /* [n_windows * evt_cap] */
+  LC_GLOBAL unsigned long long *phase; /* [n_windows * 16] per-phase time (100 MHz ticks), may be null */
+  LC_GLOBAL const uint32_t *win_list;  /* when non-null: the windows to process (re-run of overflowed windows)   */
   uint32_t n_list;
 };

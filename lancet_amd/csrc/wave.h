@@ -12,6 +12,7 @@
 // and has no CPU path.
 #pragma once
 #include <stdint.h>
+#include "layout.h"
 
 #ifndef LANCET_WAVE_EMU
 #include <hip/hip_runtime.h>
@@ -30,37 +31,26 @@ DEV void wg_sync_fn() { __syncthreads(); }
 // every lane-0 section is followed by a barrier executed by all lanes
 #define WG_LANE0 for (int _wg_once = 1; _wg_once; _wg_once = 0, wg_sync_fn()) if (wg_is_lane0())
 #define WG_SHARED __shared__
-DEV uint32_t dev_atomic_min(uint32_t *p, uint32_t v) { return atomicMin(p, v); }
-DEV uint32_t dev_atomic_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
-DEV uint32_t dev_atomic_max(uint32_t *p, uint32_t v) { return atomicMax(p, v); }
-DEV uint32_t dev_atomic_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
-DEV unsigned long long dev_atomic_cas64(unsigned long long *p, unsigned long long cmp, unsigned long long v) {
-  return atomicCAS(p, cmp, v);
-}
-DEV uint32_t dev_atomic_cas32(uint32_t *p, uint32_t cmp, uint32_t v) { return atomicCAS(p, cmp, v); }
-// load that bypasses the CU's vector L1 (performed at L2): for words that other lanes updated with atomics
-DEV uint32_t ld2(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEV unsigned long long ld2(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-typedef uint4 lc_u4;
-// Pointers that come out of a structure in memory are generic to the compiler and get FLAT instructions, whose
-// completion is tracked by the LDS counter as well: every wait for an LDS read then also waits for all memory loads in
-// flight.  The hot loops therefore take global-address-space copies of their array pointers (GLOBAL instructions,
-// vmcnt only).
-#define LC_GLOBAL __attribute__((address_space(1)))
-template <class T> DEV LC_GLOBAL T *gptr(T *p) { return (LC_GLOBAL T *)p; }
-DEV lc_u4 ldg4(LC_GLOBAL const uint32_t *p) {
-  typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-  const v4 t = *(LC_GLOBAL const v4 *)p;
-  lc_u4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w; return r;
-}
-DEV uint32_t dev_atomic_min(LC_GLOBAL uint32_t *p, uint32_t v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEV uint32_t dev_atomic_add(LC_GLOBAL uint32_t *p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEV uint32_t dev_atomic_or(LC_GLOBAL uint32_t *p, uint32_t v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEV unsigned long long dev_atomic_cas64(LC_GLOBAL unsigned long long *p, unsigned long long cmp, unsigned long long v) {
+// atomics / L2 loads on pointers of any address space (generic, LC_GLOBAL, LC_LDS)
+template <class P> DEV uint32_t dev_atomic_min(P p, uint32_t v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class P> DEV uint32_t dev_atomic_add(P p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class P> DEV uint32_t dev_atomic_max(P p, uint32_t v) { return __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class P> DEV uint32_t dev_atomic_or(P p, uint32_t v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class P> DEV unsigned long long dev_atomic_cas64(P p, unsigned long long cmp, unsigned long long v) {
   __hip_atomic_compare_exchange_strong(p, &cmp, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return cmp;
 }
-DEV uint32_t ld2(LC_GLOBAL const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class P> DEV uint32_t dev_atomic_cas32(P p, uint32_t cmp, uint32_t v) {
+  __hip_atomic_compare_exchange_strong(p, &cmp, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return cmp;
+}
+// load that bypasses the CU's vector L1 (performed at L2): for words that other lanes updated with atomics
+template <class P> DEV auto ld2(P p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+typedef uint4 lc_u4;
+typedef uint32_t lc_v4 __attribute__((ext_vector_type(4)));
+// 16-byte load / store through a global pointer (HIP's uint4 has no copy from an address-space reference)
+DEV lc_u4 ldg4(LC_GLOBAL const uint32_t *p) { const lc_v4 t = *(LC_GLOBAL const lc_v4 *)p; lc_u4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w; return r; }
+DEV void stg4(LC_GLOBAL uint32_t *p, const lc_u4 v) { lc_v4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(LC_GLOBAL lc_v4 *)p = t; }
 DEV int dev_popc(uint32_t x) { return __popc(x); }
 DEV unsigned long long dev_brev64(unsigned long long x) { return __brevll(x); }
 DEV int dev_popcll(unsigned long long x) { return __popcll(x); }
@@ -85,9 +75,8 @@ DEV uint32_t dev_atomic_cas32(uint32_t *p, uint32_t cmp, uint32_t v) { uint32_t 
 DEV uint32_t ld2(const uint32_t *p) { return *p; }
 DEV unsigned long long ld2(const unsigned long long *p) { return *p; }
 struct alignas(16) lc_u4 { uint32_t x, y, z, w; };
-#define LC_GLOBAL
-template <class T> DEV T *gptr(T *p) { return p; }
 DEV lc_u4 ldg4(const uint32_t *p) { return *(const lc_u4 *)p; }
+DEV void stg4(uint32_t *p, const lc_u4 v) { *(lc_u4 *)p = v; }
 DEV int dev_popc(uint32_t x) { return __builtin_popcount(x); }
 DEV unsigned long long dev_brev64(unsigned long long x) {
   x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
