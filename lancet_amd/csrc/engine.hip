@@ -35,10 +35,11 @@ __global__ void prep_kernel(const lancet_params *P, int n_reads, const char *seq
 __global__ void __launch_bounds__(LANCET_WG * 2) align_test_kernel(const EngineCaps *C, Work *work, const uint8_t *Sx, int n, const uint8_t *Tx, int m, int *out_len) {
   LC_WS &S = *(LC_WS *)&lc_shared;
   Ctx c; c.P = nullptr; c.B = nullptr; c.C = (LC_GLOBAL const EngineCaps *)C; c.W = (LC_GLOBAL Work *)work; c.OUT = nullptr; c.S = &S;
+  LC_CTX_PUBLISH(c);
   WG_LANE0 { S.overflow = 0; }
   WG_SYNC();
-  align_fill(c, Sx, n, Tx, m);
-  WG_LANE0 { int L = align_traceback(c, Sx, n, Tx, m); *out_len = S.overflow ? -1 : L; }
+  align_fill(c, (LC_GLOBAL const uint8_t *)Sx, n, (LC_GLOBAL const uint8_t *)Tx, m);
+  WG_LANE0 { int L = align_traceback(c, (LC_GLOBAL const uint8_t *)Sx, n, (LC_GLOBAL const uint8_t *)Tx, m); *out_len = S.overflow ? -1 : L; }
 }
 
 __global__ void ref_code_kernel(const char *ref, uint8_t *codes, uint32_t n) {

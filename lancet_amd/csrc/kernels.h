@@ -83,11 +83,23 @@ struct Ctx {
   LC_WS *S;                // volatile: control words written by lane 0 and read by every lane after a barrier must be
                            // real LDS accesses (the optimiser was observed to drop/sink such stores across the barrier)
 };
+// The context pointers are read in every function; Ctx itself travels by reference through the separately compiled
+// phase functions, i.e. it lives in the kernel's private memory and each `c.W` there is a FLAT load from scratch.  The
+// workgroup keeps one copy in LDS, reached by name (DS loads, no aliasing with the global stores).
+#ifndef LANCET_WAVE_EMU
+static __shared__ Ctx lc_ctx;
+#define LC_CTX(c) (*(LC_LDS Ctx *)&lc_ctx)
+#define LC_CTX_PUBLISH(c) do { if (threadIdx.x == 0) { LC_CTX(c).P = (c).P; LC_CTX(c).B = (c).B; LC_CTX(c).C = (c).C; LC_CTX(c).W = (c).W; LC_CTX(c).OUT = (c).OUT; } __syncthreads(); } while (0)
+#else
+#define LC_CTX(c) (c)
+#define LC_CTX_PUBLISH(c) ((void)0)
+#endif
+
 
 #define OVF(c) do { LC_SREF(c).overflow = 1; } while (0)
 // profiling only (EngineCaps::debug_stop): abandon the window after a phase marker, as an overflow
-#define STOP_SET(c, id) do { if ((c).C->debug_stop == (uint32_t)(id)) { WG_LANE0 { OVF(c); } } } while (0)
-#define STOP_RET(c, id) do { if ((c).C->debug_stop == (uint32_t)(id)) { WG_LANE0 { OVF(c); } return; } } while (0)
+#define STOP_SET(c, id) do { if (LC_CTX(c).C->debug_stop == (uint32_t)(id)) { WG_LANE0 { OVF(c); } } } while (0)
+#define STOP_RET(c, id) do { if (LC_CTX(c).C->debug_stop == (uint32_t)(id)) { WG_LANE0 { OVF(c); } return; } } while (0)
 
 // per-phase wall-clock accounting (lane 0; 100 MHz constant counter), read back through lancet_engine_phase_times
 #ifndef LANCET_WAVE_EMU
@@ -124,19 +136,19 @@ template <class P> DEV uint32_t wg_bcastu(P p) { return (uint32_t)wg_bcast(p); }
 
 DEV void evt(Ctx &c, uint32_t code, uint32_t a = 0, uint32_t b = 0, uint32_t d = 0, uint32_t e = 0, uint32_t f = 0,
              uint32_t g = 0, uint32_t h = 0) {
-  if (!c.C->evt_cap) return;
+  if (!LC_CTX(c).C->evt_cap) return;
   LC_WS &S = LC_SREF(c);
-  if (S.evt_len + 8 > c.C->evt_cap) return;
-  uint32_t *p = c.W->evt + S.evt_len;
+  if (S.evt_len + 8 > LC_CTX(c).C->evt_cap) return;
+  uint32_t *p = LC_CTX(c).W->evt + S.evt_len;
   p[0] = code; p[1] = a; p[2] = b; p[3] = d; p[4] = e; p[5] = f; p[6] = g; p[7] = h;
   S.evt_len += 8;
 }
 DEV void evt_bytes(Ctx &c, const uint8_t *s, uint32_t n) {   // raw bytes appended after an event, padded to 8 words
-  if (!c.C->evt_cap) return;
+  if (!LC_CTX(c).C->evt_cap) return;
   LC_WS &S = LC_SREF(c);
   uint32_t words = ((n + 3) / 4 + 7) / 8 * 8;
-  if (S.evt_len + words > c.C->evt_cap) return;
-  uint8_t *p = (uint8_t *)(c.W->evt + S.evt_len);
+  if (S.evt_len + words > LC_CTX(c).C->evt_cap) return;
+  uint8_t *p = (uint8_t *)(LC_CTX(c).W->evt + S.evt_len);
   for (uint32_t i = 0; i < words * 4; ++i) p[i] = i < n ? s[i] : 0;
   S.evt_len += words;
 }
@@ -225,7 +237,7 @@ DEV bool key_less(const unsigned long long *a, const unsigned long long *b, int 
 //   isAlmostRepeat(seq,k,mm) <=> Mm >= k+1   Mm = longest self-match window with <= mm mismatches, b+L-1 <= len-1
 // (the reference skips the last k-mer in both loops).  One shift d = b-a per lane.
 // ---------------------------------------------------------------------------------------------------------
-DEV void repeat_scan_bytes(const uint8_t *s, int len, int mm, volatile int *outE, volatile int *outM) {
+DEV void repeat_scan_bytes(LC_GLOBAL const uint8_t *s, int len, int mm, volatile LC_LDS int *outE, volatile LC_LDS int *outM) {
   WG_LANE0 { *outE = 0; *outM = 0; }
   WG_SYNC();
   WG_FOR(dd, len > 1 ? len - 1 : 0) {
@@ -248,7 +260,7 @@ DEV void repeat_scan_bytes(const uint8_t *s, int len, int mm, volatile int *outE
 // mismatch flags of 16 positions out of two unaligned 64-bit words.  Only mismatch positions are visited:
 // with last[j] = position of the (j+1)-th most recent mismatch, the longest exact run ending before a mismatch q is
 // q-1-last[0] and the longest window with <= mm mismatches ending there is q-1-last[mm] (the two-pointer window).
-DEVNI void repeat_scan(LC_WS &S, const uint8_t *s, int len, int mm, volatile int *outE, volatile int *outM) {
+DEVNI void repeat_scan(LC_WS &S, LC_GLOBAL const uint8_t *s, int len, int mm, volatile LC_LDS int *outE, volatile LC_LDS int *outM) {
   if (mm > 7 || mm < 0 || len + 48 > 16 * LC_RS_WORDS) { repeat_scan_bytes(s, len, mm, outE, outM); return; }
   WG_LANE0 { *outE = 0; *outM = 0; }
   const int nwords = len / 16 + 3;
@@ -288,10 +300,27 @@ DEVNI void repeat_scan(LC_WS &S, const uint8_t *s, int len, int mm, volatile int
   WG_SYNC();
 }
 
-// exclusive prefix sum of a[0..n) in place; returns total in S.part[LANCET_WG]
-DEV void wg_scan(uint32_t *a, int n, LC_WS &S, volatile uint32_t *part = nullptr) {
+// exclusive prefix sum of a[0..n) in place; returns total in part[LANCET_WG] (default: S.part)
+DEV void wg_scan(LC_GLOBAL uint32_t *a, int n, LC_WS &S, volatile LC_LDS uint32_t *part = nullptr) {
   if (!part) part = S.part;
   int chunk = (n + LANCET_WG - 1) / LANCET_WG;
+#ifndef LANCET_WAVE_EMU
+  // one wave: each lane sums its chunk, the 64 partial sums are scanned with wave shuffles (no LDS round trips)
+  WG_SYNC();
+  {
+    const int l = (int)threadIdx.x;
+    int lo = l * chunk, hi = lo + chunk; if (hi > n) hi = n;
+    uint32_t s = 0;
+    for (int i = lo; i < hi; ++i) s += ld2(&a[i]);
+    uint32_t inc = s;
+    for (int d = 1; d < LANCET_WG; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, d, LANCET_WG); if (l >= d) inc += t; }
+    const uint32_t total = (uint32_t)__shfl((int)inc, LANCET_WG - 1, LANCET_WG);
+    uint32_t run = inc - s;
+    for (int i = lo; i < hi; ++i) { const uint32_t t = ld2(&a[i]); a[i] = run; run += t; }
+    if (l == 0) part[LANCET_WG] = total;
+  }
+  WG_SYNC();
+#else
   WG_FOR(l, LANCET_WG) {
     uint32_t s = 0;
     int lo = l * chunk, hi = lo + chunk; if (hi > n) hi = n;
@@ -307,59 +336,60 @@ DEV void wg_scan(uint32_t *a, int n, LC_WS &S, volatile uint32_t *part = nullptr
     for (int i = lo; i < hi; ++i) { uint32_t t = ld2(&a[i]); a[i] = s; s += t; }
   }
   WG_SYNC();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // node accessors
 // ---------------------------------------------------------------------------------------------------------
-DEV bool n_special(const Ctx &c, uint32_t n) { return (c.W->gr[n].flags & NF_SPECIAL) != 0; }
-DEV bool n_dead(const Ctx &c, uint32_t n) { return (c.W->gr[n].flags & NF_DEAD) != 0; }
-DEV int n_len(const Ctx &c, uint32_t n) { return (int)(c.W->gr[n].seq_hi - c.W->gr[n].seq_lo); }   // str_m.length()
+DEV bool n_special(const Ctx &c, uint32_t n) { return (LC_CTX(c).W->gr[n].flags & NF_SPECIAL) != 0; }
+DEV bool n_dead(const Ctx &c, uint32_t n) { return (LC_CTX(c).W->gr[n].flags & NF_DEAD) != 0; }
+DEV int n_len(const Ctx &c, uint32_t n) { return (int)(LC_CTX(c).W->gr[n].seq_hi - LC_CTX(c).W->gr[n].seq_lo); }   // str_m.length()
 DEV int n_strlen(const Ctx &c, uint32_t n) { return n_special(c, n) ? 0 : n_len(c, n); }       // Node_t::strlen
-DEV float n_totcov(const Ctx &c, uint32_t n) { const float *f = c.W->gr[n].cov; return f[0] + f[1] + f[2] + f[3]; }
+DEV float n_totcov(const Ctx &c, uint32_t n) { const float *f = LC_CTX(c).W->gr[n].cov; return f[0] + f[1] + f[2] + f[3]; }
 
 DEV int get_buddy(const Ctx &c, uint32_t n, char dir) {             // Node_t::getBuddy, reference src/Node.cc:235-266
   if (n_special(c, n)) return -1;
   int ret = -1;
-  const uint32_t *e = c.W->gr[n].edges;
-  int cnt = (int)c.W->gr[n].necnt;
+  const uint32_t *e = LC_CTX(c).W->gr[n].edges;
+  int cnt = (int)LC_CTX(c).W->gr[n].necnt;
   for (int i = 0; i < cnt; ++i) if (is_dir(ED_DIR(e[i]), dir)) { if (ret != -1) return -1; ret = i; }
   if (ret != -1 && ED_TO(e[ret]) == n) return -1;
   return ret;
 }
 DEV bool is_tandem(const Ctx &c, uint32_t n) {                      // reference src/Node.cc:123-134
-  const uint32_t *e = c.W->gr[n].edges;
-  for (int i = 0; i < (int)c.W->gr[n].necnt; ++i) if (ED_TO(e[i]) == n) return true;
+  const uint32_t *e = LC_CTX(c).W->gr[n].edges;
+  for (int i = 0; i < (int)LC_CTX(c).W->gr[n].necnt; ++i) if (ED_TO(e[i]) == n) return true;
   return false;
 }
 DEV void add_edge(Ctx &c, uint32_t n, uint32_t to, uint32_t dir) {  // reference src/Node.cc:140-175
-  uint32_t *e = c.W->gr[n].edges;
-  int cnt = (int)c.W->gr[n].necnt;
+  uint32_t *e = LC_CTX(c).W->gr[n].edges;
+  int cnt = (int)LC_CTX(c).W->gr[n].necnt;
   for (int i = 0; i < cnt; ++i) if (ED_TO(e[i]) == to && ED_DIR(e[i]) == dir) return;
   if (cnt >= LC_EMAX) { OVF(c); return; }
   e[cnt] = ED_MAKE(to, dir);
-  c.W->gr[n].necnt = cnt + 1;
+  LC_CTX(c).W->gr[n].necnt = cnt + 1;
 }
 DEV void erase_edge_at(Ctx &c, uint32_t n, int idx) {
-  uint32_t *e = c.W->gr[n].edges;
-  int cnt = (int)c.W->gr[n].necnt;
+  uint32_t *e = LC_CTX(c).W->gr[n].edges;
+  int cnt = (int)LC_CTX(c).W->gr[n].necnt;
   for (int i = idx; i + 1 < cnt; ++i) e[i] = e[i + 1];
-  c.W->gr[n].necnt = cnt - 1;
+  LC_CTX(c).W->gr[n].necnt = cnt - 1;
 }
 DEV void remove_edge(Ctx &c, uint32_t n, uint32_t to, uint32_t dir) {   // reference src/Node.cc:209-229
-  uint32_t *e = c.W->gr[n].edges;
-  for (int i = 0; i < (int)c.W->gr[n].necnt; ++i)
+  uint32_t *e = LC_CTX(c).W->gr[n].edges;
+  for (int i = 0; i < (int)LC_CTX(c).W->gr[n].necnt; ++i)
     if (ED_TO(e[i]) == to && ED_DIR(e[i]) == dir) { erase_edge_at(c, n, i); return; }
 }
 DEV void update_edge(Ctx &c, uint32_t n, uint32_t oldto, uint32_t olddir, uint32_t newto, uint32_t newdir) {   // :181-204
-  uint32_t *e = c.W->gr[n].edges;
-  for (int i = 0; i < (int)c.W->gr[n].necnt; ++i)
+  uint32_t *e = LC_CTX(c).W->gr[n].edges;
+  for (int i = 0; i < (int)LC_CTX(c).W->gr[n].necnt; ++i)
     if (ED_TO(e[i]) == oldto && ED_DIR(e[i]) == olddir) { e[i] = ED_MAKE(newto, newdir) | (e[i] & (1u << 30)); return; }
 }
 DEV void remove_node(Ctx &c, uint32_t n) {                          // Graph_t::removeNode, reference src/Graph.cc:2768-2784
-  c.W->gr[n].flags |= NF_DEAD;
-  const uint32_t *e = c.W->gr[n].edges;
-  for (int i = 0; i < (int)c.W->gr[n].necnt; ++i) {
+  LC_CTX(c).W->gr[n].flags |= NF_DEAD;
+  const uint32_t *e = LC_CTX(c).W->gr[n].edges;
+  for (int i = 0; i < (int)LC_CTX(c).W->gr[n].necnt; ++i) {
     uint32_t nn = ED_TO(e[i]);
     if (nn != n) remove_edge(c, nn, n, fliplink(ED_DIR(e[i])));
   }
@@ -368,32 +398,32 @@ DEV void remove_node(Ctx &c, uint32_t n) {                          // Graph_t::
 // position data behind a sequence descriptor (cov_t of the reference, src/Ref.hh:41-53)
 DEV void desc_cov(const Ctx &c, uint32_t d, int sampleT, uint16_t *fwd, uint16_t *rev, uint16_t *qf, uint16_t *qr) {
   uint32_t km = SD_KMER(d);
-  const uint16_t *cn = c.W->gr[km].kc;
+  const uint16_t *cn = LC_CTX(c).W->gr[km].kc;
   int o = sampleT ? 0 : 2;
   *fwd = (uint16_t)cn[o]; *rev = (uint16_t)cn[o + 1];
-  uint32_t q = c.W->gr[km].nqv;
+  uint32_t q = LC_CTX(c).W->gr[km].nqv;
   if (q == LC_NIL) { *qf = 0; *qr = 0; return; }
-  const uint16_t *qq = c.W->qv + ((size_t)q * LC_SREF(c).K + SD_OFF(d)) * LC_SREF(c).QS;
+  const uint16_t *qq = LC_CTX(c).W->qv + ((size_t)q * LC_SREF(c).K + SD_OFF(d)) * LC_SREF(c).QS;
   *qf = qq[o]; *qr = qq[o + 1];
 }
 // lr_mode: hp0 hp1 hp2 and hp0/1/2_minqv behind a descriptor (cov_t::hp*, reference src/Ref.hh:47-52)
 DEV void desc_hp(const Ctx &c, uint32_t d, int sampleT, uint16_t *hp3, uint16_t *hpm3) {
   uint32_t km = SD_KMER(d);
   const int o = sampleT ? 0 : 3;
-  const uint16_t *h = c.W->khp + 6 * (size_t)km + o;
+  const uint16_t *h = LC_CTX(c).W->khp + 6 * (size_t)km + o;
   hp3[0] = h[0]; hp3[1] = h[1]; hp3[2] = h[2];
-  uint32_t q = c.W->gr[km].nqv;
+  uint32_t q = LC_CTX(c).W->gr[km].nqv;
   if (q == LC_NIL) { hpm3[0] = hpm3[1] = hpm3[2] = 0; return; }
-  const uint16_t *qq = c.W->qv + ((size_t)q * LC_SREF(c).K + SD_OFF(d)) * LC_SREF(c).QS + 4 + o;
+  const uint16_t *qq = LC_CTX(c).W->qv + ((size_t)q * LC_SREF(c).K + SD_OFF(d)) * LC_SREF(c).QS + 4 + o;
   hpm3[0] = qq[0]; hpm3[1] = qq[1]; hpm3[2] = qq[2];
 }
 DEV void desc_tot(const Ctx &c, uint32_t d, int *tot, int *totqv) {  // operands of Node_t::computeMinCov
   uint32_t km = SD_KMER(d);
-  const uint16_t *cn = c.W->gr[km].kc;
+  const uint16_t *cn = LC_CTX(c).W->gr[km].kc;
   *tot = (int)(uint16_t)cn[0] + (int)(uint16_t)cn[1] + (int)(uint16_t)cn[2] + (int)(uint16_t)cn[3];
-  uint32_t q = c.W->gr[km].nqv;
+  uint32_t q = LC_CTX(c).W->gr[km].nqv;
   if (q == LC_NIL) { *totqv = 0; return; }
-  const uint16_t *qq = c.W->qv + ((size_t)q * LC_SREF(c).K + SD_OFF(d)) * LC_SREF(c).QS;
+  const uint16_t *qq = LC_CTX(c).W->qv + ((size_t)q * LC_SREF(c).K + SD_OFF(d)) * LC_SREF(c).QS;
   *totqv = (int)qq[0] + (int)qq[1] + (int)qq[2] + (int)qq[3];
 }
 
@@ -408,10 +438,10 @@ DEV uint32_t ht_next_prime(uint32_t n) {   // _M_next_bkt(n) for the values that
   for (int i = 0; i < 18; ++i) if (chain[i] >= n) return chain[i];
   return 0;
 }
-DEV void ht_reset(Ctx &c) { LC_WS &S = LC_SREF(c); S.ht_bc = 1; S.ht_next_resize = 0; S.ht_elt = 0; S.ht_head = LC_NIL; c.W->ht_bucket[0] = LC_NIL; }
+DEV void ht_reset(Ctx &c) { LC_WS &S = LC_SREF(c); S.ht_bc = 1; S.ht_next_resize = 0; S.ht_elt = 0; S.ht_head = LC_NIL; LC_CTX(c).W->ht_bucket[0] = LC_NIL; }
 DEVNI void ht_rehash(Ctx &c, uint32_t nb) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
-  if (nb == 0 || nb > c.C->bucket_cap) { OVF(c); return; }
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  if (nb == 0 || nb > LC_CTX(c).C->bucket_cap) { OVF(c); return; }
   for (uint32_t i = 0; i < nb; ++i) W.ht_bucket[i] = LC_NIL;
   uint32_t p = S.ht_head; S.ht_head = LC_NIL;
   uint32_t bbegin = 0;
@@ -432,7 +462,7 @@ DEVNI void ht_rehash(Ctx &c, uint32_t nb) {
   S.ht_bc = nb;
 }
 DEVNI void ht_insert(Ctx &c, uint32_t n) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   if (S.ht_elt + 1 > S.ht_next_resize) {                      // _Prime_rehash_policy::_M_need_rehash
     unsigned long long mn = S.ht_elt + 1;
     if (S.ht_next_resize == 0 && mn < 11) mn = 11;
@@ -459,7 +489,7 @@ DEVNI void ht_insert(Ctx &c, uint32_t n) {
 // Insert into the (array form of the) live table: unordered_map::insert after erasures.  Erase never moves
 // other nodes and keeps each bucket's run contiguous, so "bucket empty" == no live node hashes to it.
 DEVNI void order_insert(Ctx &c, uint32_t n) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   if (S.ht_elt + 1 > S.ht_next_resize) {
     unsigned long long mn = S.ht_elt + 1;
     if (S.ht_next_resize == 0 && mn < 11) mn = 11;
@@ -484,7 +514,7 @@ DEVNI void order_insert(Ctx &c, uint32_t n) {
 }
 // cleanDead (reference src/Graph.cc:2737-2762): erase every dead node from the table
 DEVNI uint32_t clean_dead(Ctx &c, bool quiet = false) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   uint32_t m = 0, dead = 0;
   for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (W.gr[n].flags & NF_DEAD) ++dead; else W.order[m++] = n; }
   S.M = m; S.ht_elt -= dead;
@@ -492,8 +522,8 @@ DEVNI uint32_t clean_dead(Ctx &c, bool quiet = false) {
   return dead;
 }
 DEVNI void print_stats(Ctx &c, int comp) {                            // Graph_t::printStats, reference src/Graph.cc:3674-3691
-  if (!c.C->evt_cap) return;
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  if (!LC_CTX(c).C->evt_cap) return;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   int edgecnt = 0, span = 0;
   for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (W.gr[n].comp == comp) { edgecnt += W.gr[n].necnt; span += n_strlen(c, n); } }
   evt(c, EV_STATS, comp, S.M, edgecnt, span);
@@ -503,12 +533,12 @@ DEVNI void print_stats(Ctx &c, int comp) {                            // Graph_t
 // sequence deques
 // ---------------------------------------------------------------------------------------------------------
 DEV bool seq_reserve(Ctx &c, uint32_t n, uint32_t front, uint32_t back) {   // room for `front` more before, `back` after
-  LC_GLOBAL Work &W = *c.W; LC_WS &S = LC_SREF(c);
+  LC_GLOBAL Work &W = *LC_CTX(c).W; LC_WS &S = LC_SREF(c);
   uint32_t lo = W.gr[n].seq_lo, hi = W.gr[n].seq_hi;
   if (lo - W.gr[n].seq_clo >= front && W.gr[n].seq_chi - hi >= back) return true;
   uint32_t len = hi - lo;
   uint32_t cap = 2 * (len + front + back) + 16;
-  if (S.seq_top + cap > c.C->seq_cap) { OVF(c); return false; }
+  if (S.seq_top + cap > LC_CTX(c).C->seq_cap) { OVF(c); return false; }
   uint32_t nclo = S.seq_top; S.seq_top += cap;
   uint32_t nlo = nclo + (cap - len - front - back) / 2 + front;
   for (uint32_t i = 0; i < len; ++i) W.seq[nlo + i] = W.seq[lo + i];
@@ -520,14 +550,14 @@ DEV bool seq_reserve(Ctx &c, uint32_t n, uint32_t front, uint32_t back) {   // r
 // buildgraph (reference src/Graph.cc:530-589 + loadSequence :119-349 + Node.cc / Ref.cc counters)
 // ---------------------------------------------------------------------------------------------------------
 DEV void read_geom(const Ctx &c, int r, uint32_t *rinfo, uint32_t *bw, uint32_t *gw, int *tlen, bool *isref) {
-  LC_GLOBAL const DevBatch &B = *c.B; const LC_WS &S = LC_SREF(c);
+  LC_GLOBAL const DevBatch &B = *LC_CTX(c).B; const LC_WS &S = LC_SREF(c);
   if (r == S.R - 1) { *isref = true; *tlen = S.reflen; *rinfo = 0; *bw = 0; *gw = 0; return; }
   uint32_t g = B.read_begin[S.w] + (uint32_t)r;
   *isref = false; *rinfo = B.rinfo[g]; *bw = B.base_woff[g]; *gw = B.good_woff[g]; *tlen = (int)RI_TLEN(*rinfo);
 }
 DEV int read_base(const Ctx &c, bool isref, uint32_t bw, int i) {
-  if (isref) return c.B->ref_codes[c.B->ref_off[LC_SREF(c).w] + i];
-  return rd_base(c.B->bases, bw, i);
+  if (isref) return LC_CTX(c).B->ref_codes[LC_CTX(c).B->ref_off[LC_SREF(c).w] + i];
+  return rd_base(LC_CTX(c).B->bases, bw, i);
 }
 
 // ---- reference k-mers that contain N.  Only the reference pseudo-read can have them; they become
@@ -556,13 +586,13 @@ DEV bool nk_is_forward(const uint8_t *ref, int p, int K) {                      
 // (reads arrive in coordinate order per sample, so rank * (W - len) / n is a fair estimate of a read's start): at a
 // given step the lanes then touch the same few table slots / nodes, which the L2 can coalesce.
 DEVNI void build_items(Ctx &c) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   WG_LANE0 {
-    const uint32_t g0 = c.B->read_begin[S.w];
+    const uint32_t g0 = LC_CTX(c).B->read_begin[S.w];
     const int nr = S.R - 1;
     int n = 0;
     for (int r = 0; r < nr; ++r) {
-      int tlen = (int)RI_TLEN(c.B->rinfo[g0 + r]);
+      int tlen = (int)RI_TLEN(LC_CTX(c).B->rinfo[g0 + r]);
       if (tlen <= 0) continue;
       W.items[2 * n] = (uint32_t)r; W.items[2 * n + 1] = ((uint32_t)tlen << 16); ++n;
     }
@@ -596,15 +626,15 @@ DEVNI void build_items(Ctx &c) {
 
 template <int NW>
 DEVNI void build_insert_pass(Ctx &c, bool verify) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int K = S.K;
   const uint32_t mask = S.tmask;
-  const uint32_t plimit = mask + 1 < c.C->table_cap ? 48u : mask;   // a growable table is doubled rather than probed at length
+  const uint32_t plimit = mask + 1 < LC_CTX(c).C->table_cap ? 48u : mask;   // a growable table is doubled rather than probed at length
   ITEMS_BEGIN(c, S, W)
     unsigned long long fw[NW], rc[NW];
     for (int w = 0; w < NW; ++w) { fw[w] = 0; rc[w] = 0; }
     const uint32_t obase = W.occ_base[r];
-    const uint8_t *refc = c.B->ref_codes + c.B->ref_off[S.w];
+    LC_GLOBAL const uint8_t *refc = LC_CTX(c).B->ref_codes + LC_CTX(c).B->ref_off[S.w];
     int nN = 0;                                                  // N's among the last K bases (reference read only)
     for (int i = pbeg; i < pbeg + K - 1; ++i) {                  // the K-1 bases before the first k-mer's last one
       int b = read_base(c, isref, bw, i);
@@ -675,15 +705,15 @@ DEVNI void build_insert_pass(Ctx &c, bool verify) {
 //   packed bases are little-endian (base j of the k-mer at bits 2j): the reverse-complement key of key_push_rc is the
 //   complement of exactly that; the forward key of key_push_fw is the same bases with the 2-bit groups reversed.
 DEVNI void build_insert_occ_major(Ctx &c) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int K = S.K;
   const uint32_t mask = S.tmask;
-  const uint32_t plimit = mask + 1 < c.C->table_cap ? 48u : mask;   // a growable table is doubled rather than probed at length
+  const uint32_t plimit = mask + 1 < LC_CTX(c).C->table_cap ? 48u : mask;   // a growable table is doubled rather than probed at length
   const unsigned long long kmask = (K == 32) ? ~0ULL : ((1ULL << (2 * K)) - 1ULL);
   const uint32_t refr = (uint32_t)(S.R - 1);
-  const uint32_t g0 = c.B->read_begin[S.w];
-  LC_GLOBAL const uint8_t *refc = c.B->ref_codes + c.B->ref_off[S.w];
-  LC_GLOBAL const uint32_t *occ_base = W.occ_base, *bases = c.B->bases, *base_woff = c.B->base_woff + g0;
+  const uint32_t g0 = LC_CTX(c).B->read_begin[S.w];
+  LC_GLOBAL const uint8_t *refc = LC_CTX(c).B->ref_codes + LC_CTX(c).B->ref_off[S.w];
+  LC_GLOBAL const uint32_t *occ_base = W.occ_base, *bases = LC_CTX(c).B->bases, *base_woff = LC_CTX(c).B->base_woff + g0;
   LC_GLOBAL uint32_t *slots = W.slots, *occ = W.occ;
   uint32_t rcur = 0;
   WG_FOR(o, S.O) {
@@ -732,7 +762,7 @@ DEVNI void build_insert_occ_major(Ctx &c) {
 DEV bool step_all_good(const Ctx &c, bool isref, uint32_t gw, int s, int tlen, int K) {
   if (s < 0 || s >= tlen - K) return false;
   if (isref) return true;                                        // reference quality string is 'K' everywhere
-  return good_count(c.B->good, gw, s, s + K + 1) == K + 1;
+  return good_count(LC_CTX(c).B->good, gw, s, s + K + 1) == K + 1;
 }
 
 // --linked-reads: what loadSequence does to ONE node, replayed over the node's occurrences in the order the reference
@@ -745,7 +775,7 @@ DEV bool step_all_good(const Ctx &c, bool isref, uint32_t gw, int s, int tlen, i
 //   csr bits 29..31 of a counted occurrence = "hpX had grown" (feeds hpX_minqv in the per-position pass)
 #define LC_PK(x, i) ((uint32_t)(((x) >> (16 * (i))) & 0xFFFFULL))
 DEVNI void lr_node_replay(Ctx &c, uint32_t lo, uint32_t hi, uint32_t *out) {
-  LC_GLOBAL Work &W = *c.W; LC_GLOBAL const DevBatch &B = *c.B; LC_WS &S = LC_SREF(c);
+  LC_GLOBAL Work &W = *LC_CTX(c).W; LC_GLOBAL const DevBatch &B = *LC_CTX(c).B; LC_WS &S = LC_SREF(c);
   const uint32_t g0 = B.read_begin[S.w];
   const uint32_t refr = (uint32_t)(S.R - 1);
   for (uint32_t i = lo + 1; i < hi; ++i) {                      // order of the visits
@@ -802,7 +832,7 @@ DEVNI void lr_node_replay(Ctx &c, uint32_t lo, uint32_t hi, uint32_t *out) {
 // buildgraph is cut into separately compiled pieces (DEVNI): one register allocation per phase instead of one for the
 // whole window program, which kept values of later phases alive (and spilled) across the hot loops of earlier ones.
 DEVNI void build_tables(Ctx &c) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W; LC_GLOBAL const EngineCaps &C = *c.C;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W; LC_GLOBAL const EngineCaps &C = *LC_CTX(c).C;
   const int K = S.K;
   (void)C; (void)K; (void)W;
   // ---- occurrence index space: read r owns [occ_base[r], occ_base[r+1]) = its k-mers p = 0..tlen-K
@@ -876,9 +906,9 @@ DEVNI void build_tables(Ctx &c) {
   WG_SYNC();
   // ---- per node: std::hash of the ASCII k-mer, zeroed occurrence counters
   WG_FOR(n, S.N) {
-    const unsigned long long *k = W.nkey + (size_t)n * LC_NWMAX;
+    LC_GLOBAL const unsigned long long *k = W.nkey + (size_t)n * LC_NWMAX;
     if (S.hasN && (W.gr[n].flags & NF_NKMER)) {
-      const uint8_t *refc = c.B->ref_codes + c.B->ref_off[S.w];
+      LC_GLOBAL const uint8_t *refc = LC_CTX(c).B->ref_codes + LC_CTX(c).B->ref_off[S.w];
       int p = (int)(k[0] >> 1); bool isR = (k[0] & 1ULL) != 0;
       W.nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGTN"[nk_char(refc, p, K, isR, j)]; }, K);
     } else W.nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGT"[key_base(k, K, j)]; }, K);
@@ -890,11 +920,11 @@ DEVNI void build_tables(Ctx &c) {
   WG_FOR(r, S.R) {
     uint8_t cd = 0; uint32_t mo = LC_NIL;
     if (r != S.R - 1) {
-      uint32_t g0 = c.B->read_begin[S.w];
-      uint32_t mi = RI_MATE(c.B->rinfo[g0 + r]);
+      uint32_t g0 = LC_CTX(c).B->read_begin[S.w];
+      uint32_t mi = RI_MATE(LC_CTX(c).B->rinfo[g0 + r]);
       if (mi == 1 || mi == 2) {
-        uint32_t nm = c.B->name_rank[g0 + r];
-        for (int q = 0; q < r; ++q) if (c.B->name_rank[g0 + q] == nm && RI_MATE(c.B->rinfo[g0 + q]) == 3 - mi) { if (cd == 0) { cd = 1; mo = (uint32_t)q; } else { cd = 2; break; } }
+        uint32_t nm = LC_CTX(c).B->name_rank[g0 + r];
+        for (int q = 0; q < r; ++q) if (LC_CTX(c).B->name_rank[g0 + q] == nm && RI_MATE(LC_CTX(c).B->rinfo[g0 + q]) == 3 - mi) { if (cd == 0) { cd = 1; mo = (uint32_t)q; } else { cd = 2; break; } }
       }
     }
     W.cand[r] = cd; W.mate_of[r] = mo;
@@ -903,7 +933,7 @@ DEVNI void build_tables(Ctx &c) {
   WG_SYNC();
 }
 DEVNI void build_csr(Ctx &c) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W; LC_GLOBAL const EngineCaps &C = *c.C;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W; LC_GLOBAL const EngineCaps &C = *LC_CTX(c).C;
   const int K = S.K;
   (void)C; (void)K; (void)W;
   // ---- pass 2a: occurrences slot -> node id; occurrences per node (the only per-occurrence atomic, on a compact array)
@@ -921,12 +951,12 @@ DEVNI void build_csr(Ctx &c) {
   //      probed against it; hits get bit 30 in occ[] and are decided by the exact replay after the csr is built.
   {
     uint32_t *set = (uint32_t *)S.mk;                       // 512 words of the (idle) staging area
-    const uint32_t g0 = c.B->read_begin[S.w];
+    const uint32_t g0 = LC_CTX(c).B->read_begin[S.w];
     const int nreads = S.R - 1;
     for (int r = 0; r < nreads; ++r) {
       const int cd = wg_uniform((int)W.cand[r]);
       if (!cd) continue;
-      const int tlen = wg_uniform((int)RI_TLEN(c.B->rinfo[g0 + r]));
+      const int tlen = wg_uniform((int)RI_TLEN(LC_CTX(c).B->rinfo[g0 + r]));
       if (tlen - K <= 0) continue;
       const uint32_t o0 = W.occ_base[r];
       const int nk = tlen - K + 1;
@@ -934,7 +964,7 @@ DEVNI void build_csr(Ctx &c) {
       uint32_t m0 = 0; int mnk = 0;
       if (!all) {
         const uint32_t mo = (uint32_t)wg_uniform((int)W.mate_of[r]);
-        const int mtl = wg_uniform((int)RI_TLEN(c.B->rinfo[g0 + mo]));
+        const int mtl = wg_uniform((int)RI_TLEN(LC_CTX(c).B->rinfo[g0 + mo]));
         mnk = mtl - K > 0 ? mtl - K + 1 : 0;
         if (mnk > 150) all = true; else m0 = W.occ_base[mo];
       }
@@ -959,7 +989,7 @@ DEVNI void build_csr(Ctx &c) {
         if (hit) {
           W.occ[o0 + p] = oc | 0x40000000u;
           uint32_t t = dev_atomic_add((uint32_t *)&S.tmp1, 1u);
-          if (t < c.C->table_cap) W.todo[t] = ((uint32_t)r << 10) | (uint32_t)p; else OVF(c);
+          if (t < LC_CTX(c).C->table_cap) W.todo[t] = ((uint32_t)r << 10) | (uint32_t)p; else OVF(c);
         }
       }
       WG_SYNC();
@@ -991,10 +1021,10 @@ DEVNI void build_csr(Ctx &c) {
   //      reference's lower_bound over the names of that prefix.
   {
     const uint32_t ntodo0 = (uint32_t)wg_bcast(&S.tmp1);
-    const uint32_t ntodo = ntodo0 > c.C->table_cap ? c.C->table_cap : ntodo0;
+    const uint32_t ntodo = ntodo0 > LC_CTX(c).C->table_cap ? LC_CTX(c).C->table_cap : ntodo0;
     if (ntodo) {
-      const uint32_t g0 = c.B->read_begin[S.w];
-      uint32_t *mark = W.bitmap;
+      const uint32_t g0 = LC_CTX(c).B->read_begin[S.w];
+      LC_GLOBAL uint32_t *mark = W.bitmap;
       WG_FOR(i, (int)(S.N / 32 + 1)) { mark[i] = 0; }
       WG_SYNC();
       WG_FOR(ti, ntodo) {
@@ -1016,14 +1046,14 @@ DEVNI void build_csr(Ctx &c) {
           W.csr[j] = v;
         }
         uint32_t n1 = 0, n2 = 0;
-        uint32_t *v1 = W.mv + 4 * (size_t)lo, *v2 = v1 + 2 * (size_t)len;
+        LC_GLOBAL uint32_t *v1 = W.mv + 4 * (size_t)lo, *v2 = v1 + 2 * (size_t)len;
         for (uint32_t i = lo; i < hi; ++i) {
           const uint32_t e = W.csr[i], er = CS_READ(e);
           if ((int)er == S.R - 1) continue;
-          const uint32_t ri = c.B->rinfo[g0 + er], mt = RI_MATE(ri);
+          const uint32_t ri = LC_CTX(c).B->rinfo[g0 + er], mt = RI_MATE(ri);
           if (mt != 1 && mt != 2) continue;
           const int ep = (int)CS_POS(e), etl = (int)RI_TLEN(ri);
-          const uint32_t rec = (er << 16) | (c.B->name_rank[g0 + er] & 0xFFFFu);      // ranks < number of reads < 2^16
+          const uint32_t rec = (er << 16) | (LC_CTX(c).B->name_rank[g0 + er] & 0xFFFFu);      // ranks < number of reads < 2^16
           const uint32_t pushes = (ep >= 1 ? 1u : 0u) + (ep <= etl - K - 1 ? 1u : 0u);   // as v of step p-1, as u of step p
           for (uint32_t q = 0; q < pushes; ++q) { if (mt == 1) v1[n1++] = rec; else v2[n2++] = rec; }
         }
@@ -1032,10 +1062,10 @@ DEVNI void build_csr(Ctx &c) {
       WG_SYNC();
       WG_FOR(ti, ntodo) {
         const uint32_t r = W.todo[ti] >> 10, p = W.todo[ti] & 1023u;
-        const uint32_t mi = RI_MATE(c.B->rinfo[g0 + r]), nm = c.B->name_rank[g0 + r] & 0xFFFFu;
+        const uint32_t mi = RI_MATE(LC_CTX(c).B->rinfo[g0 + r]), nm = LC_CTX(c).B->name_rank[g0 + r] & 0xFFFFu;
         const uint32_t X = W.occ[W.occ_base[r] + p] & 0x3FFFFFFFu;
         const uint32_t lo = W.nocc[X], len = W.nocc[X + 1] - lo;
-        const uint32_t *vec = W.mv + 4 * (size_t)lo + (mi == 1 ? 2 * (size_t)len : 0);   // the OTHER mate's pushes
+        LC_GLOBAL const uint32_t *vec = W.mv + 4 * (size_t)lo + (mi == 1 ? 2 * (size_t)len : 0);   // the OTHER mate's pushes
         const uint32_t nv = mi == 1 ? (W.nfill[X] >> 16) : (W.nfill[X] & 0xFFFFu);
         uint32_t total = 0;                                       // pushes of reads before r
         { uint32_t f = 0, l = nv; while (l > 0) { const uint32_t h = l >> 1; if ((vec[f + h] >> 16) < r) { f += h + 1; l -= h + 1; } else l = h; } total = f; }
@@ -1054,7 +1084,7 @@ DEVNI void build_csr(Ctx &c) {
   WG_SYNC();
 }
 DEVNI void build_gather(Ctx &c) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W; LC_GLOBAL const EngineCaps &C = *c.C;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W; LC_GLOBAL const EngineCaps &C = *LC_CTX(c).C;
   const int K = S.K;
   (void)C; (void)K; (void)W;
   // ---- per node, gathering over its occurrences (reference src/Graph.cc:163-349): colours, counted occurrences per
@@ -1065,7 +1095,7 @@ DEVNI void build_gather(Ctx &c) {
   // by occurrence count (> 24, 3..24, <= 2) so that the ~85 % one-occurrence (sequencing error) k-mers do not wait for
   // the high-coverage ones.  perm[] = node ids in that order (two exclusive scans).
   {
-    uint32_t *fa = W.order, *fb = W.scratch, *perm = W.ht_next;
+    LC_GLOBAL uint32_t *fa = W.order, *fb = W.scratch, *perm = W.ht_next;
     WG_FOR(n, S.N) { const uint32_t cn = W.nocc[n + 1] - W.nocc[n]; fa[n] = cn > 24u; fb[n] = (cn > 2u && cn <= 24u); }
     WG_LANE0 { fa[S.N] = 0; fb[S.N] = 0; }
     wg_scan(fa, (int)S.N + 1, S);
@@ -1134,7 +1164,7 @@ DEVNI void build_gather(Ctx &c) {
     // targets (only the edge COUNT shows up, in the trace's graph statistics): skip the look-ups of its neighbours.
     const uint32_t counted = c0 + c1 + c2 + c3;
     const float tt = (float)c0 + (float)c1, tn = (float)c2 + (float)c3;
-    const bool low = ((int)counted <= c.P->low_cov_threshold) || ((double)counted <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
+    const bool low = ((int)counted <= LC_CTX(c).P->low_cov_threshold) || ((double)counted <= (LC_CTX(c).P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
     if (!low) for (int i = 0; i < ne; ++i) {
       const uint32_t s = stamp[i] >> 1;
       const uint32_t a = W.occ[s], b = W.occ[s + 1];           // u and v of that step
@@ -1165,7 +1195,7 @@ DEVNI void build_gather(Ctx &c) {
   WG_SYNC();
 }
 DEVNI void build_qcounts(Ctx &c) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W; LC_GLOBAL const EngineCaps &C = *c.C;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W; LC_GLOBAL const EngineCaps &C = *LC_CTX(c).C;
   const int K = S.K;
   (void)C; (void)K; (void)W;
   const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
@@ -1200,7 +1230,7 @@ DEVNI void build_qcounts(Ctx &c) {
         if (tot >= LC_STAGE) break;
       }
       S.g_N = gN;
-      if (S.qv_top + gN > c.C->surv_cap || ((size_t)S.qv_top + gN) * (size_t)K > (size_t)c.C->qv_cap) OVF(c);
+      if (S.qv_top + gN > LC_CTX(c).C->surv_cap || ((size_t)S.qv_top + gN) * (size_t)K > (size_t)LC_CTX(c).C->qv_cap) OVF(c);
     }
     if (wg_bcast(&S.overflow)) return;
     const int gN = wg_uniform((int)S.g_N);
@@ -1230,8 +1260,8 @@ DEVNI void build_qcounts(Ctx &c) {
         }
         for (int u = 0; u < U; ++u) {
           act[u] = act[u] && CS_ST(e[u]) == 0;
-          ri[u] = 0; gd[u] = c.B->good;
-          if (act[u]) { const lc_u4 rdv = *(const lc_u4 *)(W.rd + 4 * (size_t)CS_READ(e[u])); ri[u] = rdv.x; gd[u] = c.B->good + rdv.z; }
+          ri[u] = 0; gd[u] = LC_CTX(c).B->good;
+          if (act[u]) { const lc_u4 rdv = *(const lc_u4 *)(W.rd + 4 * (size_t)CS_READ(e[u])); ri[u] = rdv.x; gd[u] = LC_CTX(c).B->good + rdv.z; }
         }
         for (int u = 0; u < U; ++u) {
           m[u][0] = m[u][1] = m[u][2] = m[u][3] = 0; meta[u] = 0;
@@ -1293,7 +1323,7 @@ DEVNI void build_qcounts(Ctx &c) {
           S.acc[i][0] = (uint16_t)a0; S.acc[i][1] = (uint16_t)a1; S.acc[i][2] = (uint16_t)a2; S.acc[i][3] = (uint16_t)a3;
           if (LR) { S.acc[i][4] = (uint16_t)h0; S.acc[i][5] = (uint16_t)h1; S.acc[i][6] = (uint16_t)h2; S.acc[i][7] = (uint16_t)h3; S.acc[i][8] = (uint16_t)h4; S.acc[i][9] = (uint16_t)h5; }
         } else {
-          uint16_t *qq = W.qv + (size_t)(qi0 + (uint32_t)k) * K * QS;
+          LC_GLOBAL uint16_t *qq = W.qv + (size_t)(qi0 + (uint32_t)k) * K * QS;
           qq[QS * i] = (uint16_t)a0; qq[QS * i + 1] = (uint16_t)a1; qq[QS * i + 2] = (uint16_t)a2; qq[QS * i + 3] = (uint16_t)a3;
           if (LR) { uint16_t *qh = qq + QS * i + 4; qh[0] = (uint16_t)h0; qh[1] = (uint16_t)h1; qh[2] = (uint16_t)h2; qh[3] = (uint16_t)h3; qh[4] = (uint16_t)h4; qh[5] = (uint16_t)h5; }
           const int sq = (int)(uint16_t)a0 + (int)(uint16_t)a1 + (int)(uint16_t)a2 + (int)(uint16_t)a3;
@@ -1309,10 +1339,10 @@ DEVNI void build_qcounts(Ctx &c) {
       const uint32_t n = S.g_n[k];
       const int minqv = (int)S.g_min[k];
       const float tt = S.g_tt[k], tn = S.g_tn[k];
-      const bool low = (minqv <= c.P->low_cov_threshold) || ((double)minqv <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
+      const bool low = (minqv <= LC_CTX(c).P->low_cov_threshold) || ((double)minqv <= (LC_CTX(c).P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
       if (!low) {
         const uint32_t base = (qi0 + (uint32_t)k) * (uint32_t)K;
-        const unsigned long long *kk = W.nkey + (size_t)n * LC_NWMAX;
+        LC_GLOBAL const unsigned long long *kk = W.nkey + (size_t)n * LC_NWMAX;
         W.seq[base + i] = SD_MAKE(n, i, key_base(kk, K, i));
       }
     }
@@ -1322,7 +1352,7 @@ DEVNI void build_qcounts(Ctx &c) {
         LC_GLOBAL NodeGr &G = W.gr[n];
         const int minqv = (int)S.g_min[k];
         const float tt = S.g_tt[k], tn = S.g_tn[k];
-        const bool low = (minqv <= c.P->low_cov_threshold) || ((double)minqv <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
+        const bool low = (minqv <= LC_CTX(c).P->low_cov_threshold) || ((double)minqv <= (LC_CTX(c).P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
         G.mincovqv = minqv;
         if (!low) {
           const uint32_t qi = qi0 + (uint32_t)k, base = qi * (uint32_t)K;
@@ -1341,7 +1371,7 @@ DEVNI void build_qcounts(Ctx &c) {
   WG_SYNC();
 }
 DEVNI void build_refcov(Ctx &c) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W; LC_GLOBAL const EngineCaps &C = *c.C;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W; LC_GLOBAL const EngineCaps &C = *LC_CTX(c).C;
   const int K = S.K;
   (void)C; (void)K; (void)W;
   // ---- Ref_t::mertable membership (indexMers over the possibly trimmed seq, reference src/Ref.cc:40-64)
@@ -1406,10 +1436,10 @@ DEV void build_graph(Ctx &c) {
 // rehash).  Each stage is a counting sort by (first position of the bucket desc, position desc): all parallel.
 // The first 29 insertions (2 small stages) are replayed sequentially.
 // ---------------------------------------------------------------------------------------------------------
-DEVNI void order_stage(Ctx &c, const uint32_t *Q, uint32_t *Qn, int n, uint32_t B) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
-  uint32_t *bkt = W.scratch, *tmp = W.scratch + c.C->node_cap;
-  uint32_t *first = W.ht_bucket, *cnt = W.ht_cnt, *start = W.ht_start, *out = W.ht_next;
+DEVNI void order_stage(Ctx &c, LC_GLOBAL const uint32_t *Q, LC_GLOBAL uint32_t *Qn, int n, uint32_t B) {
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  LC_GLOBAL uint32_t *bkt = W.scratch, *tmp = W.scratch + LC_CTX(c).C->node_cap;
+  LC_GLOBAL uint32_t *first = W.ht_bucket, *cnt = W.ht_cnt, *start = W.ht_start, *out = W.ht_next;
   WG_FOR(b, (int)B) { cnt[b] = 0; first[b] = LC_NIL; }
   WG_SYNC();
   WG_FOR(i, n) {
@@ -1442,7 +1472,7 @@ DEVNI void order_stage(Ctx &c, const uint32_t *Q, uint32_t *Qn, int n, uint32_t 
 
 // the live table in libstdc++ iteration order -> order[0..M)
 DEVNI void first_lowcov(Ctx &c) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const uint32_t SEQ = 29u;                             // a value of the growth chain
   WG_LANE0 {
     ht_reset(c);
@@ -1454,16 +1484,16 @@ DEVNI void first_lowcov(Ctx &c) {
   }
   const uint32_t N = wg_bcastu(&S.N);
   if (N <= SEQ) return;
-  uint32_t *Q = W.order, *Qn = W.pnodes;
+  LC_GLOBAL uint32_t *Q = W.order, *Qn = W.pnodes;
   uint32_t nprev = SEQ, B = SEQ;
   while (true) {
     B = ht_next_prime(2u * B);
-    if (B == 0 || B > c.C->bucket_cap) { WG_LANE0 { OVF(c); } return; }
+    if (B == 0 || B > LC_CTX(c).C->bucket_cap) { WG_LANE0 { OVF(c); } return; }
     const uint32_t n = N < B ? N : B;
     WG_FOR(j, (int)(n - nprev)) { Q[nprev + j] = nprev + (uint32_t)j; }
     WG_SYNC();
     order_stage(c, Q, Qn, (int)n, B);
-    uint32_t *t = Q; Q = Qn; Qn = t;
+    LC_GLOBAL uint32_t *t = Q; Q = Qn; Qn = t;
     if (N <= B) break;
     nprev = B;
   }
@@ -1473,9 +1503,9 @@ DEVNI void first_lowcov(Ctx &c) {
 
 // cleanDead over the whole table (reference src/Graph.cc:2737-2762), parallel: compaction of order[] keeping the order
 DEVNI void clean_dead_wg(Ctx &c) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int M = (int)wg_bcastu(&S.M);
-  uint32_t *keep = W.scratch;
+  LC_GLOBAL uint32_t *keep = W.scratch;
   WG_FOR(i, M) { const uint32_t f = W.gr[W.order[i]].flags; keep[i] = ((f & NF_SURV) && !(f & NF_DEAD)) ? 1u : 0u; }
   WG_LANE0 { keep[M] = 0; }
   wg_scan(keep, M + 1, S);
@@ -1488,14 +1518,14 @@ DEVNI void clean_dead_wg(Ctx &c) {
 
 DEV void recompute_after_append(Ctx &c, uint32_t n, uint32_t from, uint32_t to) {
   // Node_t::computeMinCov over the merged arrays == min(old minima, minima over the appended descriptors)
-  LC_GLOBAL Work &W = *c.W;
+  LC_GLOBAL Work &W = *LC_CTX(c).W;
   int mn = W.gr[n].mincov, mq = W.gr[n].mincovqv;
   for (uint32_t i = from; i < to; ++i) { int t, tq; desc_tot(c, W.seq[i], &t, &tq); if (t < mn) mn = t; if (tq < mq) mq = tq; }
   W.gr[n].mincov = mn; W.gr[n].mincovqv = mq;
 }
 
 DEVNI void compress_node(Ctx &c, uint32_t node, char dir) {          // Graph_t::compressNode, reference src/Graph.cc:2486-2706
-  LC_GLOBAL Work &W = *c.W; LC_WS &S = LC_SREF(c);
+  LC_GLOBAL Work &W = *LC_CTX(c).W; LC_WS &S = LC_SREF(c);
   const int K = S.K;
   while (!S.overflow) {
     int uid = get_buddy(c, node, dir);
@@ -1575,16 +1605,16 @@ DEVNI void compress_node(Ctx &c, uint32_t node, char dir) {          // Graph_t:
 DEV uint32_t cmp_link(const Ctx &c, uint32_t n, char dir, bool *irregular) {
   int uid = get_buddy(c, n, dir);
   if (uid == -1 || is_tandem(c, n)) return 0u;
-  const uint32_t ew = c.W->gr[n].edges[uid], edir = ED_DIR(ew), b = ED_TO(ew);
+  const uint32_t ew = LC_CTX(c).W->gr[n].edges[uid], edir = ED_DIR(ew), b = ED_TO(ew);
   if (is_tandem(c, b)) return 0u;
   const char bdir = (edir == 0 || edir == 2) ? 'R' : 'F';
   const int buid = get_buddy(c, b, bdir);
   if (buid == -1) return 0u;
-  if (ED_TO(c.W->gr[b].edges[buid]) != n) { *irregular = true; return 0u; }
+  if (ED_TO(LC_CTX(c).W->gr[b].edges[buid]) != n) { *irregular = true; return 0u; }
   return CL_VALID | (edir << 28) | b;
 }
 DEVNI void compress_prepare(Ctx &c, int comp) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int K = S.K;
   WG_LANE0 { S.cmp_ok = 1; }
   WG_FOR(i, S.M) {
@@ -1610,11 +1640,11 @@ DEVNI void compress_prepare(Ctx &c, int comp) {
   WG_SYNC();
 }
 DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int K = S.K;
   if (!quiet) evt(c, EV_COMPRESS);
-  uint32_t *list = W.scratch;                                   // (absorbed node, edge dir it is entered by) per merge
-  const uint32_t lcap = c.C->node_cap;
+  LC_GLOBAL uint32_t *list = W.scratch;                                   // (absorbed node, edge dir it is entered by) per merge
+  const uint32_t lcap = LC_CTX(c).C->node_cap;
   for (uint32_t oi = 0; oi < S.M && !S.overflow; ++oi) {
     const uint32_t H = W.order[oi];
     if (W.gr[H].comp != comp) continue;
@@ -1695,7 +1725,7 @@ DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
   return clean_dead(c, quiet);
 }
 DEVNI uint32_t compress(Ctx &c, int comp, bool quiet = false) {       // reference src/Graph.cc:2712-2732
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   if (!quiet) evt(c, EV_COMPRESS);
   for (uint32_t i = 0; i < S.M && !S.overflow; ++i) {
     uint32_t n = W.order[i];
@@ -1708,7 +1738,7 @@ DEVNI uint32_t compress(Ctx &c, int comp, bool quiet = false) {       // referen
   return clean_dead(c, quiet);
 }
 DEVNI void remove_low_cov(Ctx &c, int comp) {                         // reference src/Graph.cc:2790-2827 (docompression=true)
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
   uint32_t low = 0;
   for (uint32_t i = 0; i < S.M; ++i) {
@@ -1717,7 +1747,7 @@ DEVNI void remove_low_cov(Ctx &c, int comp) {                         // referen
     if (W.gr[n].flags & NF_SPECIAL) continue;
     int mq = W.gr[n].mincovqv;
     float tt = W.gr[n].cov[0] + W.gr[n].cov[1], tn = W.gr[n].cov[2] + W.gr[n].cov[3];
-    if ((mq <= c.P->low_cov_threshold) || ((double)mq <= (c.P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f)) { ++low; remove_node(c, n); }
+    if ((mq <= LC_CTX(c).P->low_cov_threshold) || ((double)mq <= (LC_CTX(c).P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f)) { ++low; remove_node(c, n); }
   }
   evt(c, EV_LOWCOV, low);
   clean_dead(c);
@@ -1726,9 +1756,9 @@ DEVNI void remove_low_cov(Ctx &c, int comp) {                         // referen
 }
 
 // findTandems (reference src/util.cc:574-758) on a code string (0..3); returns ans, len, motif (codes)
-DEVNI bool find_tandems(const Ctx &c, const uint8_t *seq, int n, int pos, int *len, uint8_t *motif, int *motif_len) {
-  const unsigned MAXU = (unsigned)c.P->max_unit_len, MRU = (unsigned)c.P->min_report_units, MRL = (unsigned)c.P->min_report_len;
-  const int delta = c.P->dist_from_str;
+DEVNI bool find_tandems(const Ctx &c, LC_GLOBAL const uint8_t *seq, int n, int pos, int *len, uint8_t *motif, int *motif_len) {
+  const unsigned MAXU = (unsigned)LC_CTX(c).P->max_unit_len, MRU = (unsigned)LC_CTX(c).P->min_report_units, MRL = (unsigned)LC_CTX(c).P->min_report_len;
+  const int delta = LC_CTX(c).P->dist_from_str;
   bool ans = false;
   int offsets[9][8];
   for (unsigned ml = 1; ml <= MAXU && ml <= 8; ++ml) for (unsigned ph = 0; ph < ml; ++ph) offsets[ml][ph] = (int)ph;
@@ -1768,14 +1798,14 @@ DEVNI bool find_tandems(const Ctx &c, const uint8_t *seq, int n, int pos, int *l
   return ans;
 }
 
-DEV void node_string(const Ctx &c, uint32_t n, uint8_t *out) {      // str_m as codes
-  const LC_GLOBAL Work &W = *c.W;
+DEV void node_string(const Ctx &c, uint32_t n, LC_GLOBAL uint8_t *out) {      // str_m as codes
+  const LC_GLOBAL Work &W = *LC_CTX(c).W;
   uint32_t lo = W.gr[n].seq_lo, hi = W.gr[n].seq_hi;
   for (uint32_t i = lo; i < hi; ++i) out[i - lo] = (uint8_t)SD_BASE(W.seq[i]);
 }
 
 DEVNI void remove_tips(Ctx &c, int comp) {                            // reference src/Graph.cc:2885-2926
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   int tips = 0, round = 0;
   do {
     ++round; tips = 0;
@@ -1785,7 +1815,7 @@ DEVNI void remove_tips(Ctx &c, int comp) {                            // referen
       if (W.gr[n].comp != comp) continue;
       if (W.gr[n].flags & NF_SPECIAL) continue;
       int deg = (int)W.gr[n].necnt, len = n_strlen(c, n) - S.K + 1;
-      if (deg <= 1 && len < c.P->max_tip_len) { remove_node(c, n); ++tips; }
+      if (deg <= 1 && len < LC_CTX(c).P->max_tip_len) { remove_node(c, n); ++tips; }
     }
     evt(c, EV_TIPS_REMOVED, tips);
     if (tips) compress(c, comp);
@@ -1793,7 +1823,7 @@ DEVNI void remove_tips(Ctx &c, int comp) {                            // referen
   print_stats(c, comp);
 }
 DEVNI void remove_short_links(Ctx &c, int comp) {                     // reference src/Graph.cc:2833-2880
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
   const int max_link_len = S.K / 2;                                  // setK: floor(K/2.0)
   const double thr = floor(sqrt(avgcov));
@@ -1806,7 +1836,7 @@ DEVNI void remove_short_links(Ctx &c, int comp) {                     // referen
     if (deg >= 2 && len < max_link_len && (double)W.gr[n].mincov <= thr) {
       int L = 0, ml = 0; uint8_t motif[64];
       int sl = n_len(c, n);
-      if (sl > (int)c.C->path_cap) { OVF(c); return; }
+      if (sl > (int)LC_CTX(c).C->path_cap) { OVF(c); return; }
       node_string(c, n, W.pseq);
       find_tandems(c, W.pseq, sl, S.K - 1, &L, motif, &ml);
       if (L == 0) { remove_node(c, n); ++links; }
@@ -1823,14 +1853,14 @@ DEVNI void remove_short_links(Ctx &c, int comp) {                     // referen
 // pointer jumping (O(log n) rounds, every lane busy) instead of a one-lane queue walk that pays a full memory round trip
 // per node.  parent[] (node ids; a node's label only ever decreases) is updated with atomics and read at L2.
 DEVNI void mark_connected_components_wg(Ctx &c) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int M = (int)wg_bcastu(&S.M);
-  const uint32_t nodes = c.C->node_cap + c.C->special_cap;
-  uint32_t *parent = W.scratch, *minpos = W.scratch + nodes, *touch = W.pnodes, *first = W.pedges, *cid = W.nfill;
+  const uint32_t nodes = LC_CTX(c).C->node_cap + LC_CTX(c).C->special_cap;
+  LC_GLOBAL uint32_t *parent = W.scratch, *minpos = W.scratch + nodes, *touch = W.pnodes, *first = W.pedges, *cid = W.nfill;
   WG_LANE0 { evt(c, EV_CC, S.M); }
   // one pass over the 128-byte node records: neighbours as a 16-byte record per table position (degree, three ids; the
   // rare node of higher degree keeps using its record), so that a hooking round reads whole lines
-  uint32_t *adj = W.mv;                                          // idle after the build
+  LC_GLOBAL uint32_t *adj = W.mv;                                          // idle after the build
   WG_FOR(i, M) {
     const uint32_t n = W.order[i];
     LC_GLOBAL const NodeGr &G = W.gr[n];
@@ -1890,7 +1920,7 @@ DEVNI void mark_connected_components_wg(Ctx &c) {
   WG_SYNC();
   WG_LANE0 {
     S.refcomp = S.tmp1; S.numcomp = numcomp;
-    if (c.C->evt_cap) {
+    if (LC_CTX(c).C->evt_cap) {
       for (int i = 0; i < M; ++i) { const uint32_t r = ld2(&parent[W.order[i]]); if (ld2(&minpos[r]) == (uint32_t)i && (ld2(&touch[r]) & 1u)) evt(c, EV_CCID, cid[r]); }
     }
     evt(c, EV_CCEND, (uint32_t)numcomp, (uint32_t)S.refcomp);
@@ -1900,9 +1930,9 @@ DEVNI void mark_connected_components_wg(Ctx &c) {
 // markRefEnds (reference src/Graph.cc:2028-2228).  The node of the reference k-mer at `offset` is the node
 // of the reference pseudo-read's occurrence at that offset (if it is still in the table).
 DEV uint32_t special_new(Ctx &c, bool issource, int comp) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
-  if (S.nspecial >= c.C->special_cap) { OVF(c); return LC_NIL; }
-  uint32_t id = c.C->node_cap + S.nspecial++;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  if (S.nspecial >= LC_CTX(c).C->special_cap) { OVF(c); return LC_NIL; }
+  uint32_t id = LC_CTX(c).C->node_cap + S.nspecial++;
   char name[24]; int L = 0;
   const char *pre = issource ? "source" : "sink";
   while (*pre) name[L++] = *pre++;
@@ -1919,7 +1949,7 @@ DEV uint32_t special_new(Ctx &c, bool issource, int comp) {
 // mr_src / mr_snk = first / last offset whose node is live, has getTotCov() >= COV_THRESHOLD and is in the component
 // (-1 if none); mr_ambs / mr_ambk = the same node qualifies again further on (the reference then gives up).
 DEVNI void mark_ref_scan(Ctx &c, int comp) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int K = S.K;
   const uint32_t ro = W.occ_base[S.R - 1];
   const int nrefk = (S.reflen - K > 0) ? S.reflen - K + 1 : 0;
@@ -1928,7 +1958,7 @@ DEVNI void mark_ref_scan(Ctx &c, int comp) {
     const uint32_t t = W.occ[ro + off] & 0x3FFFFFFFu;
     const uint32_t f = W.gr[t].flags;
     if ((f & NF_DEAD) || !(f & NF_SURV)) continue;
-    if (n_totcov(c, t) >= (float)c.P->cov_threshold && W.gr[t].comp == comp) {
+    if (n_totcov(c, t) >= (float)LC_CTX(c).P->cov_threshold && W.gr[t].comp == comp) {
       dev_atomic_min((uint32_t *)&S.mr_src, (uint32_t)off);
       dev_atomic_max((uint32_t *)&S.mr_snk, (uint32_t)(off + 1));
     }
@@ -1945,7 +1975,7 @@ DEVNI void mark_ref_scan(Ctx &c, int comp) {
   WG_LANE0 { S.mr_snk = ko; }
 }
 DEVNI void mark_ref_ends(Ctx &c, int comp) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int K = S.K;
   S.trim5 = 0xFFFF; S.trim3 = 0xFFFF;
   S.source = LC_NIL; S.sink = LC_NIL;
@@ -1998,12 +2028,12 @@ DEVNI void mark_ref_ends(Ctx &c, int comp) {
 }
 
 DEVNI bool has_cycle(Ctx &c, bool colored = false) {                                         // reference src/Graph.cc:593-681
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   if (S.source == LC_NIL || S.sink == LC_NIL) return false;
   if (!colored) for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (!(W.gr[n].flags & NF_SPECIAL)) W.gr[n].color = 1; }
   bool ans = false;
   // explicit stack of (node, next edge index, dir)
-  uint32_t *st = W.scratch; uint32_t cap = (2 * (c.C->node_cap + c.C->special_cap)) / 3;
+  LC_GLOBAL uint32_t *st = W.scratch; uint32_t cap = (2 * (LC_CTX(c).C->node_cap + LC_CTX(c).C->special_cap)) / 3;
   for (int pass = 0; pass < 2 && !ans; ++pass) {
     uint32_t sp = 0;
     st[0] = S.source; st[1] = 0; st[2] = (uint32_t)(pass == 0 ? 'F' : 'R'); sp = 1;
@@ -2039,27 +2069,27 @@ DEVNI bool has_cycle(Ctx &c, bool colored = false) {                            
 // Returns queue index of the best path or LC_NIL.
 // ---------------------------------------------------------------------------------------------------------
 DEV bool path_has_node(const Ctx &c, uint32_t idx, uint32_t node) {
-  const BfsEntry *Q = c.W->queue;
+  const BfsEntry *Q = LC_CTX(c).W->queue;
   for (uint32_t i = idx; i != LC_NIL; i = Q[i].parent) if (Q[i].node == node) return true;
   return false;
 }
 DEVNI uint32_t bfs(Ctx &c) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
-  BfsEntry *Q = W.queue;
-  const uint32_t cap = c.C->queue_cap;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  LC_GLOBAL BfsEntry *Q = W.queue;
+  const uint32_t cap = LC_CTX(c).C->queue_cap;
   int reflen = S.seq_len;
   uint32_t qh = 0, qt = 0;
   Q[qt].parent = LC_NIL; Q[qt].node = S.source; Q[qt].edge = LC_NIL; Q[qt].len = S.K; Q[qt].score = 0; Q[qt].dir = 'F'; Q[qt].bits = 1; ++qt;
   uint32_t best = LC_NIL; int complete = 0; int visit = 0;
   while (qh < qt) {
     ++visit;
-    if (c.P->dfs_limit && visit > c.P->dfs_limit) { evt(c, EV_DFSLIMIT); break; }
+    if (LC_CTX(c).P->dfs_limit && visit > LC_CTX(c).P->dfs_limit) { evt(c, EV_DFSLIMIT); break; }
     uint32_t idx = qh++;
     BfsEntry cur = Q[idx];
     if (cur.node == S.sink && (cur.bits & 1) == 0) {
       ++complete;
       if (best == LC_NIL) best = idx; else if (cur.score > Q[best].score) best = idx;
-    } else if (cur.len > reflen + c.P->max_indel_len) {
+    } else if (cur.len > reflen + LC_CTX(c).P->max_indel_len) {
     } else {
       int cnt = (int)W.gr[cur.node].necnt;
       for (int i = 0; i < cnt; ++i) {
@@ -2083,7 +2113,7 @@ DEVNI uint32_t bfs(Ctx &c) {
 }
 // unpack the best path into W.pnodes / W.pedges ; returns number of nodes
 DEVNI int path_unpack(Ctx &c, uint32_t best) {
-  LC_GLOBAL Work &W = *c.W; const BfsEntry *Q = W.queue;
+  LC_GLOBAL Work &W = *LC_CTX(c).W; const BfsEntry *Q = W.queue;
   int n = 0;
   for (uint32_t i = best; i != LC_NIL; i = Q[i].parent) ++n;
   int k = n;
@@ -2091,16 +2121,16 @@ DEVNI int path_unpack(Ctx &c, uint32_t best) {
   return n;   // pedges[j] (j>=1) is the edge leading into node j
 }
 DEV void path_flag_edges(Ctx &c, int n, uint32_t v) {
-  LC_GLOBAL Work &W = *c.W;
+  LC_GLOBAL Work &W = *LC_CTX(c).W;
   for (int j = 1; j < n; ++j) {
     uint32_t owner = W.pedges[j] >> 4, ei = W.pedges[j] & 15u;
-    uint32_t *e = &W.gr[owner].edges[ei];
+    LC_GLOBAL uint32_t *e = &W.gr[owner].edges[ei];
     *e = (*e & ~(1u << 30)) | (v << 30);
   }
 }
 // Path_t::str + covDistr (reference src/Path.cc:69-175): string codes + descriptor per base ; returns length
 DEVNI int path_string(Ctx &c, int n) {
-  LC_GLOBAL Work &W = *c.W; LC_WS &S = LC_SREF(c);
+  LC_GLOBAL Work &W = *LC_CTX(c).W; LC_WS &S = LC_SREF(c);
   const int K = S.K;
   int len = 0;
   uint32_t e1 = W.gr[(W.pedges[1] >> 4)].edges[(W.pedges[1] & 15u)];
@@ -2111,7 +2141,7 @@ DEVNI int path_string(Ctx &c, int n) {
       uint32_t lo = W.gr[nd].seq_lo, hi = W.gr[nd].seq_hi;
       int L = (int)(hi - lo);
       int from = len > 0 ? K - 1 : 0;
-      if (len + L - from > (int)c.C->path_cap) { OVF(c); return 0; }
+      if (len + L - from > (int)LC_CTX(c).C->path_cap) { OVF(c); return 0; }
       for (int j = from; j < L; ++j) {
         uint32_t d = (dir == 'R') ? (W.seq[hi - 1 - (uint32_t)j] ^ 3u) : W.seq[lo + (uint32_t)j];
         W.pdesc[len] = d; W.pseq[len] = (uint8_t)SD_BASE(d); ++len;
@@ -2127,11 +2157,11 @@ DEVNI int path_string(Ctx &c, int n) {
 // The same string and descriptors with all lanes: contribution length of every path node (special nodes none, the first
 // real node whole, the others without the K-1 overlap), exclusive scan, then one lane per output base.
 DEVNI int path_string_wg(Ctx &c, int n) {
-  LC_GLOBAL Work &W = *c.W; LC_WS &S = LC_SREF(c);
+  LC_GLOBAL Work &W = *LC_CTX(c).W; LC_WS &S = LC_SREF(c);
   const int K = S.K;
   const int dcap = 7 * (LC_MAXW + 2);
   if (2 * (n + 1) > dcap || n < 2) { WG_LANE0 { S.ps_len = path_string(c, n); } return wg_bcast(&S.ps_len); }
-  uint32_t *off = (uint32_t *)W.dp, *pdir = off + (n + 1);
+  LC_GLOBAL uint32_t *off = (LC_GLOBAL uint32_t *)W.dp, *pdir = off + (n + 1);
   WG_LANE0 { S.ps_first = 0x7FFFFFFF; off[n] = 0; }
   WG_FOR(i, n) {
     const uint32_t nd = W.pnodes[i];
@@ -2150,7 +2180,7 @@ DEVNI int path_string_wg(Ctx &c, int n) {
   WG_SYNC();
   wg_scan(off, n + 1, S, S.part2);
   const int plen = (int)wg_uniform((int)S.part2[LANCET_WG]);
-  if (plen > (int)c.C->path_cap) { WG_LANE0 { OVF(c); } return 0; }
+  if (plen > (int)LC_CTX(c).C->path_cap) { WG_LANE0 { OVF(c); } return 0; }
   WG_FOR(x, plen) {
     int lo = 0, hi = n - 1;                                    // last node whose offset is <= x and that contributes
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)off[mid] <= x) lo = mid; else hi = mid - 1; }
@@ -2165,7 +2195,7 @@ DEVNI int path_string_wg(Ctx &c, int n) {
   return plen;
 }
 DEV uint32_t path_contig(const Ctx &c, int n, int pos) {            // Path_t::pathcontig, reference src/Path.cc:291-314
-  const LC_GLOBAL Work &W = *c.W;
+  const LC_GLOBAL Work &W = *LC_CTX(c).W;
   int cur = 0;
   for (int i = 0; i < n; ++i) {
     uint32_t nd = W.pnodes[i];
@@ -2177,7 +2207,7 @@ DEV uint32_t path_contig(const Ctx &c, int n, int pos) {            // Path_t::p
   return LC_NIL;
 }
 DEV bool status_cnt_T(const Ctx &c, uint32_t n) {                   // Node_t::isStatusCnt('T'), reference src/Node.cc:423-440
-  double pr = (double)c.W->gr[n].nkmT / (double)c.W->gr[n].nkm;
+  double pr = (double)LC_CTX(c).W->gr[n].nkmT / (double)LC_CTX(c).W->gr[n].nkm;
   return pr > 0.8;
 }
 
@@ -2190,8 +2220,8 @@ DEV bool status_cnt_T(const Ctx &c, uint32_t n) {                   // Node_t::i
 #define LC_TB(i, j, n) ((size_t)((i) + (j)) * (size_t)((n) + 1) + (size_t)(i))
 // tb byte: M.tb [1:0] (0 '\\', 1 '<', 2 '^', 3 '*') ; X.tb [3:2] (0 '<', 1 '-', 2 '*') ; Y.tb [5:4] (0 '^', 1 '|', 2 '*')
 // ---------------------------------------------------------------------------------------------------------
-DEV void align_fill_arrays(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) {
-  LC_GLOBAL Work &W = *c.W;
+DEV void align_fill_arrays(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const uint8_t *Tx, int m) {
+  LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int A = LC_MAXW + 2;
   int32_t *Mb[3] = {W.dp, W.dp + A, W.dp + 2 * A};
   int32_t *Xb[2] = {W.dp + 3 * A, W.dp + 4 * A};
@@ -2229,9 +2259,9 @@ DEV void align_fill_arrays(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, 
 // GPU form: systolic over the wave.  Lane l owns rows l+1, l+65, ... (<= 10 rows for a 640-base window); cell (i,j)
 // is computed at step t = i + j, so everything a cell needs was produced one or two steps earlier by the lane above
 // (wave shuffles) or by the lane itself.  The score diagonals never touch memory; only the traceback bytes do.
-DEVNI void align_fill(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) {
+DEVNI void align_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const uint8_t *Tx, int m) {
   static_assert(LANCET_WG == 64, "one wave per window");
-  LC_GLOBAL Work &W = *c.W;
+  LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int lane = (int)threadIdx.x;
   for (int j = lane; j < m + 1; j += 64) W.tb[LC_TB(0, j, n)] = (uint8_t)((j == 0 ? 3 : 2) | (0 << 2) | (2 << 4));           // M[0][j] '^' ; Y[0][j] '*'
   for (int i = lane + 1; i < n + 1; i += 64) W.tb[LC_TB(i, 0, n)] = (uint8_t)(1 | (2 << 2) | (0 << 4));     // M[i][0] '<' ; X[i][0] '*'
@@ -2283,13 +2313,13 @@ DEVNI void align_fill(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m
   WG_SYNC();
 }
 #else
-DEV void align_fill(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) { align_fill_arrays(c, Sx, n, Tx, m); }
+DEV void align_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const uint8_t *Tx, int m) { align_fill_arrays(c, Sx, n, Tx, m); }
 #endif
 // traceback into W.aln: returns alignment length; ref_aln at aln[0..L), path_aln at aln[cap..cap+L) (ASCII)
-DEVNI int align_traceback(Ctx &c, const uint8_t *Sx, int n, const uint8_t *Tx, int m) {
-  LC_GLOBAL Work &W = *c.W;
-  const int cap = LC_MAXW + (int)c.C->path_cap + 2;
-  uint8_t *ra = W.aln, *pa = W.aln + cap;
+DEVNI int align_traceback(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const uint8_t *Tx, int m) {
+  LC_GLOBAL Work &W = *LC_CTX(c).W;
+  const int cap = LC_MAXW + (int)LC_CTX(c).C->path_cap + 2;
+  LC_GLOBAL uint8_t *ra = W.aln, *pa = W.aln + cap;
   int i = n, j = m, L = 0;
   bool forcex = false, forcey = false;
   unsigned long long pre = 0; int bi = -1, bj = -1, used = 8;
@@ -2363,13 +2393,13 @@ DEV void ts_hp_add_ref(TS &t, const HPc &r) {
 DEV void ref_hp_at(const Ctx &c, uint32_t pos, HPc &r) {       // hp0-2 of Ref_t::getCovStructAt (the minqv fields of the reference stay 0)
   for (int j = 0; j < 3; ++j) { r.nh[j] = r.th[j] = r.nq[j] = r.tq[j] = 0; }
   if (!LC_SREF(c).LR || (int)pos >= LC_SREF(c).reflen) return;
-  const uint16_t *h = c.W->refhp + 6 * pos;
+  const uint16_t *h = LC_CTX(c).W->refhp + 6 * pos;
   for (int j = 0; j < 3; ++j) { r.th[j] = h[j]; r.nh[j] = h[3 + j]; }
 }
 DEV void path_hp_at(const Ctx &c, int P, HPc &a) {
   for (int j = 0; j < 3; ++j) { a.nh[j] = a.th[j] = a.nq[j] = a.tq[j] = 0; }
   if (!LC_SREF(c).LR) return;
-  uint32_t d = c.W->pdesc[P];
+  uint32_t d = LC_CTX(c).W->pdesc[P];
   desc_hp(c, d, 0, a.nh, a.nq);
   desc_hp(c, d, 1, a.th, a.tq);
 }
@@ -2377,11 +2407,11 @@ DEV void ts_add_alt(TS &t, const uint16_t *n4, const uint16_t *t4) { for (int q 
 DEV void ts_add_ref(TS &t, const uint16_t *n2, const uint16_t *t2) { for (int q = 0; q < 2; ++q) { acc_push(t.rN[q], n2[q]); acc_push(t.rT[q], t2[q]); } }
 
 DEV void ref_cov_at(const Ctx &c, uint32_t pos, uint16_t *n2, uint16_t *t2) {   // Ref_t::getCovStructAt, reference src/Ref.cc:253-267
-  if ((int)pos < LC_SREF(c).reflen) { const uint16_t *r = c.W->refcov + 4 * pos; t2[0] = r[0]; t2[1] = r[1]; n2[0] = r[2]; n2[1] = r[3]; }
+  if ((int)pos < LC_SREF(c).reflen) { const uint16_t *r = LC_CTX(c).W->refcov + 4 * pos; t2[0] = r[0]; t2[1] = r[1]; n2[0] = r[2]; n2[1] = r[3]; }
   else { n2[0] = n2[1] = t2[0] = t2[1] = 0; }
 }
 DEV void path_cov_at(const Ctx &c, int P, uint16_t *n4, uint16_t *t4) {         // coverageN[P], coverageT[P]
-  uint32_t d = c.W->pdesc[P];
+  uint32_t d = LC_CTX(c).W->pdesc[P];
   desc_cov(c, d, 0, &n4[0], &n4[1], &n4[2], &n4[3]);
   desc_cov(c, d, 1, &t4[0], &t4[1], &t4[2], &t4[3]);
 }
@@ -2389,9 +2419,9 @@ DEV void path_cov_at(const Ctx &c, int P, uint16_t *n4, uint16_t *t4) {         
 // ---- --linked-reads: barcode sets of a variant (Graph_t::getBXsetAt / Ref_t::getBXsetAt, reference src/Graph.cc:83-114,
 // src/Ref.cc:96-125).  bx_table[mer] = barcodes of all reads of the sample that contain the k-mer = the node's csr list.
 DEV void bx_add_node(Ctx &c, uint32_t X, uint32_t nml, uint32_t *n) {
-  LC_GLOBAL Work &W = *c.W; LC_GLOBAL const DevBatch &B = *c.B; LC_WS &S = LC_SREF(c);
+  LC_GLOBAL Work &W = *LC_CTX(c).W; LC_GLOBAL const DevBatch &B = *LC_CTX(c).B; LC_WS &S = LC_SREF(c);
   const uint32_t g0 = B.read_begin[S.w], refr = (uint32_t)(S.R - 1);
-  uint32_t *buf = W.bxbuf;
+  LC_GLOBAL uint32_t *buf = W.bxbuf;
   for (uint32_t i = W.nocc[X]; i < W.nocc[X + 1]; ++i) {
     const uint32_t r = CS_READ(W.csr[i]);
     if (r == refr) continue;
@@ -2401,14 +2431,14 @@ DEV void bx_add_node(Ctx &c, uint32_t X, uint32_t nml, uint32_t *n) {
     uint32_t lo = 0, hi = *n;                                    // sorted, distinct (std::set<string> order == rank order)
     while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (buf[mid] < bx) lo = mid + 1; else hi = mid; }
     if (lo < *n && buf[lo] == bx) continue;
-    if (*n >= c.C->reads_cap) { OVF(c); return; }
+    if (*n >= LC_CTX(c).C->reads_cap) { OVF(c); return; }
     for (uint32_t j = *n; j > lo; --j) buf[j] = buf[j - 1];
     buf[lo] = bx; ++*n;
   }
 }
 // node of the k-mer codes[0..K) (2-bit codes) or LC_NIL: the open-addressing table of the current build
 DEVNI uint32_t kmer_lookup(Ctx &c, const uint8_t *codes) {
-  LC_GLOBAL Work &W = *c.W; LC_WS &S = LC_SREF(c);
+  LC_GLOBAL Work &W = *LC_CTX(c).W; LC_WS &S = LC_SREF(c);
   const int K = S.K, NW = S.NW;
   unsigned long long fw[LC_NWMAX], rc[LC_NWMAX];
   for (int w = 0; w < LC_NWMAX; ++w) { fw[w] = 0; rc[w] = 0; }
@@ -2436,7 +2466,7 @@ DEVNI uint32_t kmer_lookup(Ctx &c, const uint8_t *codes) {
   return LC_NIL;
 }
 DEVNI void emit_variant_lr(Ctx &c, uint32_t vi, const TS &t, const uint16_t hp12[12], int plen) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W; DevOut &O = *c.OUT;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W; DevOut &O = *LC_CTX(c).OUT;
   lancet_variant_lr &l = O.variants_lr[vi];
   for (int q = 0; q < 12; ++q) l.hp[q] = hp12[q];
   l.reserved[0] = l.reserved[1] = 0;
@@ -2459,7 +2489,7 @@ DEVNI void emit_variant_lr(Ctx &c, uint32_t vi, const TS &t, const uint16_t hp12
       }
     }
     const uint32_t off = dev_atomic_add(O.n_bx, n);
-    if (off + n > c.C->bx_cap) { OVF(c); l.bx_off[q] = 0; l.bx_len[q] = 0; continue; }
+    if (off + n > LC_CTX(c).C->bx_cap) { OVF(c); l.bx_off[q] = 0; l.bx_len[q] = 0; continue; }
     l.bx_off[q] = off; l.bx_len[q] = n;
     for (uint32_t j = 0; j < n; ++j) O.bx_blob[off + j] = W.bxbuf[j];
   }
@@ -2467,7 +2497,7 @@ DEVNI void emit_variant_lr(Ctx &c, uint32_t vi, const TS &t, const uint16_t hp12
 
 DEVNI void emit_variant(Ctx &c, const TS &t, const uint16_t cov[8], int strLen, const uint8_t *motif, int motifLen, bool hasStr,
                       const uint8_t *ra, const uint8_t *pa, const uint16_t hp12[12], int plen) {
-  LC_WS &S = LC_SREF(c); DevOut &O = *c.OUT;
+  LC_WS &S = LC_SREF(c); DevOut &O = *LC_CTX(c).OUT;
   uint32_t vi = dev_atomic_add(O.n_variants, 1u);
   int rl = t.col1 - t.col0 + 1;
   char sbuf[80]; int sl = 0;
@@ -2478,9 +2508,9 @@ DEVNI void emit_variant(Ctx &c, const TS &t, const uint16_t cov[8], int strLen, 
   }
   uint32_t need = (uint32_t)(2 * rl + sl);
   uint32_t bo = dev_atomic_add(O.n_blob, need);
-  if (vi >= c.C->var_cap || bo + need > c.C->blob_cap) { OVF(c); return; }
+  if (vi >= LC_CTX(c).C->var_cap || bo + need > LC_CTX(c).C->blob_cap) { OVF(c); return; }
   lancet_variant &v = O.variants[vi];
-  v.window = S.w; v.seq_in_window = S.emit_seq++; v.chr_id = c.B->chr_id[S.w]; v.pos = (int32_t)t.pos - 1;
+  v.window = S.w; v.seq_in_window = S.emit_seq++; v.chr_id = LC_CTX(c).B->chr_id[S.w]; v.pos = (int32_t)t.pos - 1;
   v.code = (uint8_t)t.code; v.prev_bp_ref = (uint8_t)t.prev_bp_ref; v.prev_bp_alt = (uint8_t)t.prev_bp_alt; v.reserved = 0;
   v.kmer = (uint16_t)S.K; for (int q = 0; q < 8; ++q) v.cov[q] = cov[q]; v.reserved2 = 0;
   v.ref_off = bo; v.ref_len = (uint32_t)rl; v.alt_off = bo + (uint32_t)rl; v.alt_len = (uint32_t)rl; v.str_off = bo + 2u * (uint32_t)rl; v.str_len = (uint32_t)sl;
@@ -2494,10 +2524,10 @@ DEVNI void emit_variant(Ctx &c, const TS &t, const uint16_t cov[8], int strLen, 
 // column-type counts.  The walk (lane 0) then visits only the non-match columns instead of all of them.
 //   scratch[0..L) = pos_in_ref, scratch[L+1..2L+1) = pathpos - (column consumes a path base), scratch[2L+2..] = column list
 DEVNI void walk_prepare(Ctx &c, int L) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
-  const int cap = LC_MAXW + (int)c.C->path_cap + 2;
-  const uint8_t *ra = W.aln, *pa = W.aln + cap;
-  uint32_t *E1 = W.scratch, *E2 = W.scratch + (L + 1), *F = W.scratch + 2 * (L + 1), *cols = W.scratch + 3 * (L + 1);
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  const int cap = LC_MAXW + (int)LC_CTX(c).C->path_cap + 2;
+  LC_GLOBAL const uint8_t *ra = W.aln, *pa = W.aln + cap;
+  LC_GLOBAL uint32_t *E1 = W.scratch, *E2 = W.scratch + (L + 1), *F = W.scratch + 2 * (L + 1), *cols = W.scratch + 3 * (L + 1);
   WG_LANE0 { S.wk[0] = S.wk[1] = S.wk[2] = S.wk[3] = 0; E1[L] = 0; E2[L] = 0; F[L] = 0; }
   WG_FOR(i, L) {
     const uint8_t r = ra[i], p = pa[i];
@@ -2515,17 +2545,17 @@ DEVNI void walk_prepare(Ctx &c, int L) {
 
 // lane 0.  `np` = nodes in path, `plen` = path string length, aligned strings in W.aln (length L).
 DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int K = S.K;
-  const int cap = LC_MAXW + (int)c.C->path_cap + 2;
-  const uint8_t *ra = W.aln, *pa = W.aln + cap;
-  const int refstart = c.B->ref_start[S.w];
+  const int cap = LC_MAXW + (int)LC_CTX(c).C->path_cap + 2;
+  LC_GLOBAL const uint8_t *ra = W.aln, *pa = W.aln + cap;
+  const int refstart = LC_CTX(c).B->ref_start[S.w];
   TS *ts = (TS *)(void *)W.tb;                 // the traceback matrix is dead by now: reuse it for the transcripts
   int nts = 0;
   unsigned pos_in_ref = 0, pathpos = 0;
   char code = '?', prev_code = '?';
   const int match_bp = S.wk[0], snp_bp = S.wk[1], ins_bp = S.wk[2], del_bp = S.wk[3];      // walk_prepare
-  const uint32_t *E1 = W.scratch, *E2 = W.scratch + (L + 1), *cols = W.scratch + 3 * (L + 1);
+  LC_GLOBAL const uint32_t *E1 = W.scratch, *E2 = W.scratch + (L + 1), *cols = W.scratch + 3 * (L + 1);
   int pc_i = 0, pc_cur = 0;
   int last_col = -2;
   for (int ci = 0; ci < S.wk_n; ++ci) {
@@ -2624,7 +2654,7 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
       const uint16_t v[12] = {RN[1], RN[2], RN[0], RT[1], RT[2], RT[0], AN[1], AN[2], AN[0], AT[1], AT[2], AT[0]};
       for (int q = 0; q < 12; ++q) hp12[q] = v[q];
     }
-    if (c.C->evt_cap) {
+    if (LC_CTX(c).C->evt_cap) {
       evt(c, EV_TS, t.pos, (uint32_t)(t.col1 - t.col0 + 1), ((uint32_t)RCNF << 16) | RCNR, ((uint32_t)RCTF << 16) | RCTR,
           ((uint32_t)ACNF << 16) | ACNR, ((uint32_t)ACTF << 16) | ACTR, ((uint32_t)(uint8_t)t.prev_bp_ref << 8) | (uint8_t)t.prev_bp_alt);
       evt_bytes(c, ra + t.col0, (uint32_t)(t.col1 - t.col0 + 1));
@@ -2649,7 +2679,7 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
 // returns true when a near-perfect repeat is found in a source->sink path (Graph_t::findRepeatsInGraphPaths,
 // reference src/Graph.cc:686-730)
 DEVNI bool repeats_in_graph_paths(Ctx &c) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   WG_LANE0 {
     evt(c, EV_LOOKREP);
     S.tmp0 = 0;                                  // 0 continue, 1 stop:false, 2 stop:true
@@ -2666,13 +2696,13 @@ DEVNI bool repeats_in_graph_paths(Ctx &c) {
     if (wg_bcast(&S.tmp0) != 0) break;
     { const int pl = path_string_wg(c, wg_bcast(&S.tmp2)); WG_LANE0 { S.tmp3 = pl; if (S.overflow) S.tmp0 = 1; } }
     if (wg_bcast(&S.tmp0) != 0) break;
-    repeat_scan(S, W.pseq, wg_bcast(&S.tmp3), c.P->max_mismatch, &S.repE, &S.repM);      // isAlmostRepeat(path->str(), K, MAX_MISMATCH)
+    repeat_scan(S, W.pseq, wg_bcast(&S.tmp3), LC_CTX(c).P->max_mismatch, &S.repE, &S.repM);      // isAlmostRepeat(path->str(), K, MAX_MISMATCH)
     WG_LANE0 {
       // NB isAlmostRepeat only looks at windows that end before the last base: handled inside repeat_scan
       if (S.tmp3 - S.K > 0 && S.repM >= S.K + 1) { evt(c, EV_NEAR_QRY, S.K); S.tmp0 = 2; }
       else {
         path_flag_edges(c, S.tmp2, 1u);
-        for (int j = 1; j < S.tmp2; ++j) { if ((uint32_t)S.tmp1 < c.C->node_cap) W.scratch[S.tmp1++] = W.pedges[j]; else { OVF(c); S.tmp0 = 1; } }
+        for (int j = 1; j < S.tmp2; ++j) { if ((uint32_t)S.tmp1 < LC_CTX(c).C->node_cap) W.scratch[S.tmp1++] = W.pedges[j]; else { OVF(c); S.tmp0 = 1; } }
       }
     }
   }
@@ -2684,7 +2714,7 @@ DEVNI bool repeats_in_graph_paths(Ctx &c) {
 
 // eka (reference src/Graph.cc:1430-1501) via countRefPath (:2420-2445)
 DEVNI void count_ref_path(Ctx &c) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   if (wg_bcastu(&S.source) == LC_NIL) return;
   if (wg_bcastu(&S.sink) != LC_NIL) {
     WG_LANE0 { evt(c, EV_SEARCH, (uint32_t)W.gr[S.source].comp); S.tmp0 = S.tmp1 = S.tmp2 = 0; S.part[0] = 0; S.part[1] = 0; S.part[2] = 0; S.part[3] = 0; }
@@ -2705,14 +2735,14 @@ DEVNI void count_ref_path(Ctx &c) {
         const int m = path_string_wg(c, (int)wg_bcastu(&S.part[4]));
         // Hamming short-cut (reference src/Graph.cc:818-826)
         const int n = wg_bcast(&S.seq_len);
-        const uint8_t *rs = c.B->ref_codes + c.B->ref_off[S.w] + S.seq_t5;
+        LC_GLOBAL const uint8_t *rs = LC_CTX(c).B->ref_codes + LC_CTX(c).B->ref_off[S.w] + S.seq_t5;
         WG_LANE0 { S.ps_hd = 0; }
         if (n == m) { WG_FOR(i, n) { if (rs[i] != W.pseq[i]) dev_atomic_add((uint32_t *)&S.ps_hd, 1u); } }
         WG_SYNC();
         const int hd = (n == m) ? wg_uniform(S.ps_hd) : -1;
         const bool need_align = (hd == -1 || hd > 5);
         if (!need_align) {
-          const int cap = LC_MAXW + (int)c.C->path_cap + 2;
+          const int cap = LC_MAXW + (int)LC_CTX(c).C->path_cap + 2;
           WG_FOR(i, n) { W.aln[i] = "ACGTN"[rs[i]]; W.aln[cap + i] = "ACGT"[W.pseq[i]]; }
         }
         WG_LANE0 {
@@ -2724,7 +2754,7 @@ DEVNI void count_ref_path(Ctx &c) {
       }
       if (wg_bcastu(&S.part[3]) != 0) break;
       if (wg_bcastu(&S.part[6])) {
-        const uint8_t *rs = c.B->ref_codes + c.B->ref_off[S.w] + S.seq_t5;
+        LC_GLOBAL const uint8_t *rs = LC_CTX(c).B->ref_codes + LC_CTX(c).B->ref_off[S.w] + S.seq_t5;
         const int pl = (int)wg_bcastu(&S.part[5]);
         PHASE(c, 12);
         align_fill(c, rs, S.seq_len, W.pseq, pl);
@@ -2746,7 +2776,7 @@ DEVNI void count_ref_path(Ctx &c) {
     WG_LANE0 { evt(c, EV_EKA_END, (uint32_t)S.refcomp, S.part[1], S.part[2], (uint32_t)S.tmp0, (uint32_t)S.tmp2, (uint32_t)S.tmp1, S.part[0]); }
   }
   WG_LANE0 {
-    if (c.C->evt_cap) { uint32_t n = 0; for (uint32_t i = 0; i < S.M; ++i) if (W.gr[W.order[i]].onref) ++n; evt(c, EV_FOUND, n); }
+    if (LC_CTX(c).C->evt_cap) { uint32_t n = 0; for (uint32_t i = 0; i < S.M; ++i) if (W.gr[W.order[i]].onref) ++n; evt(c, EV_FOUND, n); }
   }
   WG_SYNC();
 }
@@ -2755,11 +2785,11 @@ DEVNI void count_ref_path(Ctx &c) {
 // the window: Microassembler::processGraph (reference src/Microassembler.cc:73-249)
 // ---------------------------------------------------------------------------------------------------------
 DEV void process_window(Ctx &c, int w) {
-  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *c.W; LC_GLOBAL const DevBatch &B = *c.B;
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W; LC_GLOBAL const DevBatch &B = *LC_CTX(c).B;
   WG_LANE0 {
     S.w = w; S.overflow = 0; S.evt_len = 0; S.emit_seq = 0; S.n_kmers = 0; S.max_nodes = 0; S.n_builds = 0; S.N_last = 0; S.final_k = 0;
     S.status = LANCET_W_OK;
-    S.LR = c.C->lr_mode ? 1 : 0; S.QS = S.LR ? 10 : 4;
+    S.LR = LC_CTX(c).C->lr_mode ? 1 : 0; S.QS = S.LR ? 10 : 4;
     S.reflen = (int)(B.ref_off[w + 1] - B.ref_off[w]);
     int nr = (int)(B.read_begin[w + 1] - B.read_begin[w]);
     S.R = nr + 1;                                   // + the reference pseudo-read, appended last (Graph.cc:535-540)
@@ -2767,7 +2797,7 @@ DEV void process_window(Ctx &c, int w) {
     int mapped = 0;
     for (int r = 0; r < nr; ++r) if (RI_MAPPED(B.rinfo[B.read_begin[w] + r])) ++mapped;
     S.tmp0 = mapped;
-    if ((uint32_t)S.R > c.C->reads_cap || S.R > 0xFFFF || S.reflen > LC_MAXW || S.reflen < 1) S.overflow = 1;   // csr / item words keep the read in 16 bits
+    if ((uint32_t)S.R > LC_CTX(c).C->reads_cap || S.R > 0xFFFF || S.reflen > LC_MAXW || S.reflen < 1) S.overflow = 1;   // csr / item words keep the read in 16 bits
     S.hasN = 0;
     for (int i = 0; i < S.reflen && !S.overflow; ++i) if (B.ref_codes[B.ref_off[w] + i] > 3) S.hasN = 1;
     if (mapped > 0) evt(c, EV_PROCESS, (uint32_t)nr, (uint32_t)mapped);
@@ -2777,12 +2807,12 @@ DEV void process_window(Ctx &c, int w) {
   const int reflen = wg_bcast(&S.reflen);
   build_items(c);
   PHASE(c, 1);
-  repeat_scan(S, B.ref_codes + B.ref_off[w], reflen, c.P->max_mismatch, &S.repE, &S.repM);
+  repeat_scan(S, B.ref_codes + B.ref_off[w], reflen, LC_CTX(c).P->max_mismatch, &S.repE, &S.repM);
   PHASE(c, 0);
   const int refE = wg_bcast(&S.repE), refM = wg_bcast(&S.repM);
   int rptInRef = 0, rptInQry = 0, cycleInGraph = 0;
   bool processed = false;
-  for (int k = c.P->min_k; k <= c.P->max_k; k += 2) {
+  for (int k = LC_CTX(c).P->min_k; k <= LC_CTX(c).P->max_k; k += 2) {
     rptInRef = rptInQry = cycleInGraph = 0;
     // isRepeat / isAlmostRepeat on rawseq (Microassembler.cc:118-131)
     if (reflen - k > 0 && refE >= k) { WG_LANE0 { evt(c, EV_REPEAT_REF, k); } rptInRef = 1; continue; }
@@ -2800,7 +2830,7 @@ DEV void process_window(Ctx &c, int w) {
     WG_LANE0 {
       evt(c, EV_READS, (uint32_t)S.R, (uint32_t)S.reflen, (uint32_t)S.totalreadbp);
       // trace: printStats(0) over the full table, markRefNodes, removeLowCov(false,0)
-      if (c.C->evt_cap) {
+      if (LC_CTX(c).C->evt_cap) {
         uint32_t edges = 0, refn = 0, low = 0;
         for (uint32_t n = 0; n < S.N; ++n) { edges += W.gr[n].necnt; if (W.gr[n].flags & NF_INMER) ++refn; if (!(W.gr[n].flags & NF_SURV)) ++low; }
         evt(c, EV_STATS, 0, S.N, edges, S.N * (uint32_t)S.K);
@@ -2812,7 +2842,7 @@ DEV void process_window(Ctx &c, int w) {
     // gone from here on (it is in no edge list and not in order[]); it does not need a NF_DEAD mark of its own.
     WG_FOR(n, S.N) {
       if (!(W.gr[n].flags & NF_SURV)) continue;
-      uint32_t *e = W.gr[n].edges; int cnt = (int)W.gr[n].necnt, m = 0;
+      LC_GLOBAL uint32_t *e = W.gr[n].edges; int cnt = (int)W.gr[n].necnt, m = 0;
       for (int i = 0; i < cnt; ++i) if (W.gr[ED_TO(e[i])].flags & NF_SURV) e[m++] = e[i];
       W.gr[n].necnt = m;
     }
@@ -2879,6 +2909,7 @@ DEV void process_window(Ctx &c, int w) {
 // entry: persistent workgroup pulling windows off the batch queue
 DEV void window_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *B, LC_GLOBAL const EngineCaps *C, LC_GLOBAL Work *works, LC_GLOBAL DevOut *OUT, LC_WS *S, int slot) {
   Ctx c; c.P = P; c.B = B; c.C = C; c.W = works + slot; c.OUT = OUT; c.S = S;
+  LC_CTX_PUBLISH(c);
   while (true) {
     WG_LANE0 { S->tmp3 = (int)dev_atomic_add(OUT->queue_head, 1u); }
     int w = wg_bcast(&S->tmp3);
@@ -2894,7 +2925,7 @@ DEV void window_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const De
       st.status = S->status; st.final_k = S->final_k; st.n_builds = S->n_builds; st.n_variants = S->emit_seq;
       st.n_kmers = S->n_kmers; st.max_nodes = S->max_nodes; st.reserved = 0;
       if (OUT->phase) for (int i = 0; i < 16; ++i) OUT->phase[(size_t)w * 16 + i] = S->phase_acc[i];
-      if (C->evt_cap) { OUT->evt_len[w] = S->evt_len; for (uint32_t i = 0; i < S->evt_len; ++i) OUT->evt_out[(size_t)w * C->evt_cap + i] = c.W->evt[i]; }
+      if (C->evt_cap) { OUT->evt_len[w] = S->evt_len; for (uint32_t i = 0; i < S->evt_len; ++i) OUT->evt_out[(size_t)w * C->evt_cap + i] = LC_CTX(c).W->evt[i]; }
     }
     WG_SYNC();
   }
