@@ -20,7 +20,7 @@
 // launch_bounds is deliberately 2x the launched size: with a provably single-wave workgroup the compiler turns
 // s_barrier into a no-op and then threads the lane-0 sections of consecutive phases together, which lets lane 0
 // run ahead of the other lanes (observed on gfx950: lanes 1..63 skipped whole phases).
-__global__ void __launch_bounds__(LANCET_WG * 2) __attribute__((amdgpu_waves_per_eu(4, 4))) window_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT) {
+__global__ void __launch_bounds__(LANCET_WG * 2) __attribute__((amdgpu_waves_per_eu(5, 5))) window_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT) {
   window_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL Work *)works, (LC_GLOBAL DevOut *)OUT, (LC_WS *)&lc_shared, (int)blockIdx.x);
 }
 
@@ -84,7 +84,7 @@ struct lancet_engine {
   bool uploaded = false, ran = false;
   uint32_t evt_cap = 0;
   size_t mem_budget = (size_t)96 << 30;
-  int max_slots = 4096;
+  int max_slots = 5120;      // work-space slots = resident single-wave workgroups: 5 per SIMD (96 VGPRs, < 8 KB LDS each) x 4 SIMDs x CUs
   uint32_t max_nodes_limit = 65536;
   // host results
   std::vector<lancet_variant> variants;
@@ -116,6 +116,7 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&e->stream) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
       hipEventCreate(&e->ev1) != hipSuccess) { delete e; return LANCET_E_HIP; }
   if (const char *s = getenv("LANCET_TRACE_WORDS")) e->evt_cap = (uint32_t)atoi(s);
+  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->max_slots = cus * 20; }
   if (const char *s = getenv("LANCET_MAX_SLOTS")) e->max_slots = atoi(s);
   if (const char *s = getenv("LANCET_MEM_GB")) e->mem_budget = (size_t)atoi(s) << 30;
   if (const char *s = getenv("LANCET_MAX_NODES")) e->max_nodes_limit = (uint32_t)atoi(s);

@@ -50,16 +50,24 @@ struct WinShared {
   int wk[4];                                     // walk_prepare: match / snp / ins / del columns
   int ps_first, ps_len, ps_hd;                   // path_string_wg: first real node, length ; Hamming distance to the reference
   int wk_n;                                      // walk_prepare: number of non-match columns
-  uint32_t mk[LC_STAGE][4], mmeta[LC_STAGE];     // staged quality masks of up to LC_STAGE occurrences
+  // (8 KB of LDS per workgroup = 20 single-wave workgroups per CU, the fifth wave per SIMD: two pairs of buffers that are
+  //  never live together share their space)
+  union {
+    uint32_t mk[LC_STAGE][4];                    // staged quality masks of up to LC_STAGE occurrences
+    unsigned long long rs[LC_RS_WORDS];          // repeat_scan (window start): the string at 4 bits per base
+  };
+  uint32_t mmeta[LC_STAGE];
   uint32_t g_n[LC_PACK], g_lo[LC_PACK], g_cnt[LC_PACK], g_es[LC_PACK], g_min[LC_PACK], g_N;   // the candidates of the current group
   uint32_t g_fl[LC_PACK]; float g_tt[LC_PACK], g_tn[LC_PACK];      // their flags and tumor / normal coverage (fetched while the occurrences are staged)
-  uint32_t cq_n[64], cq_lo[64], cq_cnt[64];                        // the next 64 candidates (node, csr start, occurrences), fetched together
-  uint16_t acc[128][10];                         // per k-mer position running counts Tf Tr Nf Nr (+ lr_mode: T hp0-2, N hp0-2 minqv)
+  union {
+    struct { uint32_t cq_n[64], cq_lo[64], cq_cnt[64]; };          // the next 64 candidates (node, csr start, occurrences), fetched together
+    uint16_t acc[128][10];                       // a candidate with more occurrences than the staging area, between its rounds: per k-mer
+                                                 // position running counts Tf Tr Nf Nr (+ lr_mode: T hp0-2, N hp0-2 minqv); the candidate list is re-fetched after it
+  };
   uint32_t tmask, N_last; int tfull;                 // open-addressing table of this build: size - 1, filled up, nodes of the window's previous build
   int cmp_ok;                                    // compress_prepare: the component qualifies for compress_fast
   int mr_src, mr_snk, mr_ambs, mr_ambk;          // mark_ref_scan: first / last qualifying reference offset, ambiguity flags
   int QS, LR;                                    // counters per (survivor, position): 4, or 10 with --linked-reads ; lr_mode
-  unsigned long long rs[LC_RS_WORDS];            // repeat_scan: the string at 4 bits per base
   unsigned long long t_last, phase_acc[16];
   int phase_cur;
 };
@@ -1366,6 +1374,7 @@ DEVNI void build_qcounts(Ctx &c) {
     }
     WG_LANE0 { S.qv_top = qi0 + (uint32_t)gN; }
     ci += (uint32_t)gN;
+    if (big) cq_valid = false;                   // its running counts lived where the candidate list does
   }
   WG_LANE0 { S.seq_top = S.qv_top * (uint32_t)K; }
   WG_SYNC();

@@ -106,3 +106,14 @@ def test_table_doubling_path_gives_the_same_graphs(name, monkeypatch):
     monkeypatch.setenv("LANCET_TABLE_START", "64")
     grown = emu.run(batch, p, evt_cap=1 << 17)
     assert grown[0] == base[0] and grown[1] == base[1] and gu.digest_trace(grown[2]) == gu.digest_trace(base[2])
+
+
+def test_emulated_kernels_on_a_coverage_pile_up():
+    """Nodes with more occurrences than the LDS staging area of the per-position pass (rounds with carried counts, whose
+    buffer shares its space with the candidate-list cache)."""
+    from lancet_amd import workload
+    pile = workload.make_scan_batch(2, 300, 300, seed=6, read_len=100)
+    p = abi.default_params()
+    v, st, _ = emu.run(pile, p)
+    ov, ost, _ = oracle.run(pile, p)
+    assert v == ov and [s["final_k"] for s in st] == [s["final_k"] for s in ost] and len(ov) > 0
