@@ -1654,10 +1654,28 @@ DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
   if (!quiet) evt(c, EV_COMPRESS);
   LC_GLOBAL uint32_t *list = W.scratch;                                   // (absorbed node, edge dir it is entered by) per merge
   const uint32_t lcap = LC_CTX(c).C->node_cap;
-  for (uint32_t oi = 0; oi < S.M && !S.overflow; ++oi) {
-    const uint32_t H = W.order[oi];
-    if (W.gr[H].comp != comp) continue;
-    if (W.gr[H].flags & (NF_DEAD | NF_SPECIAL)) continue;
+  // Which nodes are still heads is read off the merge records (both links of a node outside the component, of a special
+  // node and of every node absorbed so far are 0), one 8-byte load per table position, fetched one position ahead; the
+  // absorbed nodes are also noted in a bitmap for the compaction at the end.  After a ring (literal replay, which marks
+  // its merges in the node records only) both fall back to the node records.
+  const uint32_t M = S.M;
+  LC_GLOBAL uint32_t *gone = W.bitmap;
+  { const uint32_t nw = (LC_CTX(c).C->node_cap + LC_CTX(c).C->special_cap) / 32 + 1; for (uint32_t i = 0; i < nw; ++i) gone[i] = 0; }   // (special nodes sit above node_cap)
+  bool ringed = false;
+  uint32_t nabs = 0;
+  uint32_t Hn = M ? W.order[0] : 0;
+  uint32_t ln0 = M ? W.cmp[Hn].lnk[0] : 0u, ln1 = M ? W.cmp[Hn].lnk[1] : 0u;
+  for (uint32_t oi = 0; oi < M && !S.overflow; ++oi) {
+    const uint32_t H = Hn;
+    const uint32_t lh = ln0 | ln1;
+    if (oi + 1 < M) { Hn = W.order[oi + 1]; ln0 = W.cmp[Hn].lnk[0]; ln1 = W.cmp[Hn].lnk[1]; }
+    if (!ringed) {
+      if (!(lh & CL_VALID)) continue;                                         // nothing to merge here (or not a head)
+      if (!((W.cmp[H].lnk[0] | W.cmp[H].lnk[1]) & CL_VALID)) continue;        // (the early fetch may predate its absorption)
+    } else {
+      if (W.gr[H].comp != comp) continue;
+      if (W.gr[H].flags & (NF_DEAD | NF_SPECIAL)) continue;
+    }
     for (int pass = 0; pass < 2 && !S.overflow; ++pass) {
       const char dir = pass == 0 ? 'F' : 'R';
       // ---- read-only walk.  The head's own link comes from its record; after a merge the head's edge in `dir` is the
@@ -1675,7 +1693,7 @@ DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
         valid = (on & CL_VALID) != 0;
         if (valid) { uint32_t nd = CL_DIR(on); if (edir == 1 || edir == 2) nd = flipme(nd); edir = nd; B = CL_TO(on); }
       }
-      if (ring) { compress_node(c, H, dir); continue; }           // untouched so far: the literal replay handles it
+      if (ring) { ringed = true; compress_node(c, H, dir); continue; }           // untouched so far: the literal replay handles it
       if (cnt == 0) continue;
       // ---- replay
       LC_GLOBAL NodeGr &G = W.gr[H];
@@ -1706,6 +1724,7 @@ DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
         ++alen; nkm += 1; nkmT += rb.nkmT;
         fl |= rb.flags & (NF_TUMOR | NF_NORMAL);
         W.gr[Bj].flags = rb.flags | NF_DEAD;
+        W.cmp[Bj].lnk[0] = 0; W.cmp[Bj].lnk[1] = 0; gone[Bj >> 5] |= 1u << (Bj & 31); ++nabs;
       }
       G.seq_lo = lo; G.seq_hi = hi; G.mincov = mn; G.mincovqv = mq;
       G.cov[0] = nc0; G.cov[1] = nc1; G.cov[2] = nc2; G.cov[3] = nc3;
@@ -1731,7 +1750,12 @@ DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
       }
     }
   }
-  return clean_dead(c, quiet);
+  if (ringed || S.overflow) return clean_dead(c, quiet);
+  uint32_t m = 0;                                                 // cleanDead off the bitmap: no node record is touched
+  for (uint32_t i = 0; i < M; ++i) { const uint32_t n = W.order[i]; if (!(gone[n >> 5] & (1u << (n & 31)))) W.order[m++] = n; }
+  S.M = m; S.ht_elt -= nabs;
+  if (!quiet) evt(c, EV_CLEANDEAD, nabs);
+  return nabs;
 }
 DEVNI uint32_t compress(Ctx &c, int comp, bool quiet = false) {       // reference src/Graph.cc:2712-2732
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
