@@ -723,44 +723,64 @@ DEVNI void build_insert_occ_major(Ctx &c) {
   LC_GLOBAL const uint8_t *refc = LC_CTX(c).B->ref_codes + LC_CTX(c).B->ref_off[S.w];
   LC_GLOBAL const uint32_t *occ_base = W.occ_base, *bases = LC_CTX(c).B->bases, *base_woff = LC_CTX(c).B->base_woff + g0;
   LC_GLOBAL uint32_t *slots = W.slots, *occ = W.occ;
-  uint32_t rcur = 0;
-  WG_FOR(o, S.O) {
-    while (rcur < refr && (uint32_t)o >= occ_base[rcur + 1]) ++rcur;
-    const int p = (int)((uint32_t)o - occ_base[rcur]);
-    unsigned long long v = 0;                                    // base j of the k-mer at bits 2j
-    if (rcur == refr) { for (int j = 0; j < K; ++j) v |= (unsigned long long)(refc[p + j] & 3) << (2 * j); }
-    else {
-      LC_GLOBAL const uint32_t *bp = bases + base_woff[rcur] + (uint32_t)(p >> 4);
-      const int sh = (p & 15) * 2;
-      const unsigned long long lo = (unsigned long long)bp[0] | ((unsigned long long)bp[1] << 32);
-      v = sh ? ((lo >> sh) | ((unsigned long long)bp[2] << (64 - sh))) : lo;
-      v &= kmask;
-    }
-    const unsigned long long rc = (~v) & kmask;
-    unsigned long long fw = dev_brev64(v);
-    fw = ((fw >> 1) & 0x5555555555555555ULL) | ((fw & 0x5555555555555555ULL) << 1);
-    fw >>= (64 - 2 * K);
-    const bool isF = fw < rc;                                    // CanonicalMer_t::set: mer < rmer -> F, tie -> R
-    const unsigned long long h = (isF ? fw : rc) + 1ULL;         // tag == key + 1: exact
-    uint32_t idx = (uint32_t)mix64(h) & mask;
-    uint32_t probes = 0;
-    uint32_t seen_first = LC_NIL;
-    while (true) {
+  // LC_INS occurrences per lane and trip: keys first, then the first probe of each (one 16-byte load) issued together, then
+  // the rest of each probe sequence (the loads of different occurrences overlap; one occurrence is a dependent chain)
+  constexpr int LC_INS = 4;
+  WG_FOR(l, LANCET_WG) {
+    const int O = (int)S.O;
+    uint32_t rcur = 0;
+    for (int o0 = l; o0 < O; o0 += LC_INS * LANCET_WG) {
+      unsigned long long hh[LC_INS]; uint32_t ix[LC_INS]; bool fF[LC_INS]; lc_u4 sv0[LC_INS];
+      for (int u = 0; u < LC_INS; ++u) {
+        const int o = o0 + u * LANCET_WG;
+        hh[u] = 0; ix[u] = 0; fF[u] = false;
+        if (o >= O) continue;
+        while (rcur < refr && (uint32_t)o >= occ_base[rcur + 1]) ++rcur;
+        const int p = (int)((uint32_t)o - occ_base[rcur]);
+        unsigned long long v = 0;                                    // base j of the k-mer at bits 2j
+        if (rcur == refr) { for (int j = 0; j < K; ++j) v |= (unsigned long long)(refc[p + j] & 3) << (2 * j); }
+        else {
+          LC_GLOBAL const uint32_t *bp = bases + base_woff[rcur] + (uint32_t)(p >> 4);
+          const int sh = (p & 15) * 2;
+          const unsigned long long lo = (unsigned long long)bp[0] | ((unsigned long long)bp[1] << 32);
+          v = sh ? ((lo >> sh) | ((unsigned long long)bp[2] << (64 - sh))) : lo;
+          v &= kmask;
+        }
+        const unsigned long long rc = (~v) & kmask;
+        unsigned long long fw = dev_brev64(v);
+        fw = ((fw >> 1) & 0x5555555555555555ULL) | ((fw & 0x5555555555555555ULL) << 1);
+        fw >>= (64 - 2 * K);
+        fF[u] = fw < rc;                                             // CanonicalMer_t::set: mer < rmer -> F, tie -> R
+        hh[u] = (fF[u] ? fw : rc) + 1ULL;                            // tag == key + 1: exact
+        ix[u] = (uint32_t)mix64(hh[u]) & mask;
+      }
       // A plain (L1-cacheable) 16-byte load: what it returns may be older than the atomics of other lanes, never wrong --
       // tags do not change once set (a stale 0 just sends us into the CAS, which answers with the real tag) and the
       // first-occurrence field only ever decreases (a stale, larger value costs a superfluous atomicMin at worst).
-      const lc_u4 sv = ldg4(slots + 4 * (size_t)idx);
-      const unsigned long long cur = (unsigned long long)sv.x | ((unsigned long long)sv.y << 32);
-      if (cur == h) { seen_first = sv.z; break; }
-      if (cur == 0) {
-        const unsigned long long old = dev_atomic_cas64((LC_GLOBAL unsigned long long *)(slots + 4 * (size_t)idx), 0ULL, h);
-        if (old == 0 || old == h) break;
+      for (int u = 0; u < LC_INS; ++u) sv0[u] = ldg4(slots + 4 * (size_t)ix[u]);
+      for (int u = 0; u < LC_INS; ++u) {
+        const int o = o0 + u * LANCET_WG;
+        if (o >= O) continue;
+        const unsigned long long h = hh[u];
+        uint32_t idx = ix[u];
+        uint32_t probes = 0;
+        uint32_t seen_first = LC_NIL;
+        lc_u4 sv = sv0[u];
+        while (true) {
+          const unsigned long long cur = (unsigned long long)sv.x | ((unsigned long long)sv.y << 32);
+          if (cur == h) { seen_first = sv.z; break; }
+          if (cur == 0) {
+            const unsigned long long old = dev_atomic_cas64((LC_GLOBAL unsigned long long *)(slots + 4 * (size_t)idx), 0ULL, h);
+            if (old == 0 || old == h) break;
+          }
+          idx = (idx + 1) & mask;
+          if (++probes > plimit) { if (plimit < mask) S.tfull = 1; else OVF(c); break; }
+          sv = ldg4(slots + 4 * (size_t)idx);
+        }
+        if ((uint32_t)o < seen_first) dev_atomic_min(slots + 4 * (size_t)idx + 2, (uint32_t)o);     // most occurrences are not the first one
+        occ[o] = idx | (fF[u] ? 0u : 0x80000000u);
       }
-      idx = (idx + 1) & mask;
-      if (++probes > plimit) { if (plimit < mask) S.tfull = 1; else OVF(c); break; }
     }
-    if ((uint32_t)o < seen_first) dev_atomic_min(slots + 4 * (size_t)idx + 2, (uint32_t)o);     // most occurrences are not the first one
-    occ[o] = idx | (isF ? 0u : 0x80000000u);
   }
   WG_SYNC();
 }
@@ -946,11 +966,17 @@ DEVNI void build_csr(Ctx &c) {
   (void)C; (void)K; (void)W;
   // ---- pass 2a: occurrences slot -> node id; occurrences per node (the only per-occurrence atomic, on a compact array)
   //      occurrence-major (lane = consecutive occurrence index): occ[] is read and rewritten in whole cache lines
-  WG_FOR(o, S.O) {
-    const uint32_t oc = W.occ[o];
-    const uint32_t X = W.todo[oc & 0x3FFFFFFFu];               // 4-byte copies of the node ids: a quarter of the slots' footprint, mostly L1 hits
-    W.mv[o] = dev_atomic_add(&W.nocc[X], 1u);                   // arrival rank on the node = place in its csr run (mv[] is idle until the replay)
-    W.occ[o] = X | (oc & 0x80000000u);
+  //      four occurrences per lane and trip, each step issued for all four before the next (the steps of one occurrence
+  //      are a chain of dependent round trips; GLOBAL loads of different occurrences overlap)
+  WG_FOR(l, LANCET_WG) {
+    const int O = (int)S.O;
+    for (int o0 = l; o0 < O; o0 += 4 * LANCET_WG) {
+      uint32_t oc[4], X[4], rk[4];
+      for (int u = 0; u < 4; ++u) { const int o = o0 + u * LANCET_WG; oc[u] = o < O ? W.occ[o] : 0u; }
+      for (int u = 0; u < 4; ++u) { const int o = o0 + u * LANCET_WG; X[u] = o < O ? W.todo[oc[u] & 0x3FFFFFFFu] : 0u; }   // 4-byte copies of the node ids: a quarter of the slots' footprint
+      for (int u = 0; u < 4; ++u) { const int o = o0 + u * LANCET_WG; rk[u] = o < O ? dev_atomic_add(&W.nocc[X[u]], 1u) : 0u; }   // arrival rank on the node = place in its csr run
+      for (int u = 0; u < 4; ++u) { const int o = o0 + u * LANCET_WG; if (o < O) { W.mv[o] = rk[u]; W.occ[o] = X[u] | (oc[u] & 0x80000000u); } }   // (mv[] is idle until the replay)
+    }
   }
   WG_SYNC();
   // ---- mate-overlap prefilter: an occurrence of a candidate read can only be suppressed if the node also holds an
@@ -1009,15 +1035,26 @@ DEVNI void build_csr(Ctx &c) {
   {
     // occurrence-major again; the read of an occurrence index is found by walking occ_base[] forward (a lane's indices
     // only grow), its position in the read is the offset from the read's first occurrence
-    uint32_t rcur = 0;
     const uint32_t refr = (uint32_t)(S.R - 1);
-    WG_FOR(o, S.O) {
-      while (rcur < refr && (uint32_t)o >= W.occ_base[rcur + 1]) ++rcur;
-      const uint32_t oc = W.occ[o];
-      const uint32_t X = oc & 0x3FFFFFFFu;
-      const uint32_t st = rcur == refr ? 2u : ((oc & 0x40000000u) ? 1u : 0u);     // the reference read never counts (Graph.cc:265)
-      const uint32_t at = W.nocc[X] + W.mv[o];
-      W.csr[at] = CS_MAKE(rcur, (uint32_t)o - W.occ_base[rcur], oc >> 31, st);
+    WG_FOR(l, LANCET_WG) {
+      const int O = (int)S.O;
+      uint32_t rcur = 0;
+      for (int o0 = l; o0 < O; o0 += 4 * LANCET_WG) {        // four occurrences per lane and trip, as above
+        uint32_t oc[4], rk[4], at[4], rr[4], pp[4];
+        for (int u = 0; u < 4; ++u) { const int o = o0 + u * LANCET_WG; oc[u] = o < O ? W.occ[o] : 0u; rk[u] = o < O ? W.mv[o] : 0u; }
+        for (int u = 0; u < 4; ++u) {
+          const int o = o0 + u * LANCET_WG;
+          if (o < O) { while (rcur < refr && (uint32_t)o >= W.occ_base[rcur + 1]) ++rcur; rr[u] = rcur; pp[u] = (uint32_t)o - W.occ_base[rcur]; } else { rr[u] = 0; pp[u] = 0; }
+          at[u] = o < O ? W.nocc[oc[u] & 0x3FFFFFFFu] : 0u;
+        }
+        for (int u = 0; u < 4; ++u) {
+          const int o = o0 + u * LANCET_WG;
+          if (o < O) {
+            const uint32_t st = rr[u] == refr ? 2u : ((oc[u] & 0x40000000u) ? 1u : 0u);     // the reference read never counts (Graph.cc:265)
+            W.csr[at[u] + rk[u]] = CS_MAKE(rr[u], pp[u], oc[u] >> 31, st);
+          }
+        }
+      }
     }
   }
   WG_SYNC();
