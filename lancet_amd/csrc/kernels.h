@@ -907,9 +907,13 @@ DEVNI void build_tables(Ctx &c) {
   STOP_RET(c, 3);
   // ---- dense node ids in first-insertion order (= order of first occurrence, Graph.cc:163-197)
   WG_SYNC_FENCE();   // the insert pass read slots through the L1 while atomics changed them at L2: drop those lines, then whole-slot plain loads
-  WG_FOR(i, (int)(S.tmask + 1)) {
-    const lc_u4 sv = *(const lc_u4 *)(W.slots + 4 * (size_t)i);
-    if ((sv.x | sv.y) != 0) dev_atomic_or(&W.bitmap[sv.z >> 5], 1u << (sv.z & 31));
+  WG_FOR(l, LANCET_WG) {                     // four slots per lane and trip, loads together
+    const int T = (int)(S.tmask + 1);
+    for (int i0 = l; i0 < T; i0 += 4 * LANCET_WG) {
+      lc_u4 sv[4];
+      for (int u = 0; u < 4; ++u) { const int i = i0 + u * LANCET_WG; if (i < T) sv[u] = ldg4(W.slots + 4 * (size_t)i); else { sv[u].x = 0; sv[u].y = 0; sv[u].z = 0; sv[u].w = 0; } }
+      for (int u = 0; u < 4; ++u) if ((sv[u].x | sv[u].y) != 0) dev_atomic_or(&W.bitmap[sv[u].z >> 5], 1u << (sv[u].z & 31));
+    }
   }
   WG_SYNC();
   int nwords = (int)(S.O / 32 + 1);
@@ -918,17 +922,24 @@ DEVNI void build_tables(Ctx &c) {
   wg_scan(W.bitpre, nwords, S);
   WG_LANE0 { S.N = S.part[LANCET_WG]; S.N_last = (uint32_t)S.N; if (S.N > C.node_cap) OVF(c); if (S.N > S.max_nodes) S.max_nodes = S.N; S.nspecial = 0; }
   if (wg_bcast(&S.overflow)) return;
-  WG_FOR(i, (int)(S.tmask + 1)) {
-    const lc_u4 sv = *(const lc_u4 *)(W.slots + 4 * (size_t)i);
-    if ((sv.x | sv.y) != 0) {
-      const uint32_t f = sv.z;
-      uint32_t id = W.bitpre[f >> 5] + (uint32_t)dev_popc(ld2(&W.bitmap[f >> 5]) & ((1u << (f & 31)) - 1u));
-      SL_NODE(W, i) = id;
-      W.todo[i] = id;                                              // compact copy for the slot -> node pass (todo[] is idle until the mate prefilter)
-      const unsigned long long tg = (unsigned long long)sv.x | ((unsigned long long)sv.y << 32);
-      if (S.NW == 1 && K <= 31 && !(tg >> 63)) W.nkey[(size_t)id * LC_NWMAX] = tg - 1ULL;            // exact tag: key + 1
-      else for (int w = 0; w < S.NW; ++w) W.nkey[(size_t)id * LC_NWMAX + w] = W.slot_key[(size_t)i * LC_NWMAX + w];
-      if (S.hasN) W.gr[id].flags = (tg >> 63) ? NF_NKMER : 0u;        // (without N in the window the gather pass writes the flags whole)
+  WG_FOR(l, LANCET_WG) {
+    const int T = (int)(S.tmask + 1), NW = S.NW; const bool hasN = S.hasN != 0;
+    for (int i0 = l; i0 < T; i0 += 4 * LANCET_WG) {
+      lc_u4 sv[4]; uint32_t bp[4], bm[4];
+      for (int u = 0; u < 4; ++u) { const int i = i0 + u * LANCET_WG; if (i < T) sv[u] = ldg4(W.slots + 4 * (size_t)i); else { sv[u].x = 0; sv[u].y = 0; sv[u].z = 0; sv[u].w = 0; } }
+      for (int u = 0; u < 4; ++u) { const bool occd = (sv[u].x | sv[u].y) != 0; const uint32_t f = occd ? sv[u].z : 0u; bp[u] = W.bitpre[f >> 5]; bm[u] = ld2(&W.bitmap[f >> 5]); }
+      for (int u = 0; u < 4; ++u) {
+        if ((sv[u].x | sv[u].y) == 0) continue;
+        const int i = i0 + u * LANCET_WG;
+        const uint32_t f = sv[u].z;
+        const uint32_t id = bp[u] + (uint32_t)dev_popc(bm[u] & ((1u << (f & 31)) - 1u));
+        SL_NODE(W, i) = id;
+        W.todo[i] = id;                                              // compact copy for the slot -> node pass (todo[] is idle until the mate prefilter)
+        const unsigned long long tg = (unsigned long long)sv[u].x | ((unsigned long long)sv[u].y << 32);
+        if (NW == 1 && K <= 31 && !(tg >> 63)) W.nkey[(size_t)id * LC_NWMAX] = tg - 1ULL;            // exact tag: key + 1
+        else for (int w = 0; w < NW; ++w) W.nkey[(size_t)id * LC_NWMAX + w] = W.slot_key[(size_t)i * LC_NWMAX + w];
+        if (hasN) W.gr[id].flags = (tg >> 63) ? NF_NKMER : 0u;        // (without N in the window the gather pass writes the flags whole)
+      }
     }
   }
   WG_SYNC();
