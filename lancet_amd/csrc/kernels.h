@@ -259,8 +259,8 @@ DEV void repeat_scan_bytes(LC_GLOBAL const uint8_t *s, int len, int mm, volatile
       while (mis > mm) { if (s[lo] != s[lo + d]) --mis; ++lo; }
       if (p - lo + 1 > bestM) bestM = p - lo + 1;
     }
-    if (bestE > 0) dev_atomic_max((uint32_t *)outE, (uint32_t)bestE);
-    if (bestM > 0) dev_atomic_max((uint32_t *)outM, (uint32_t)bestM);
+    if (bestE > 0) dev_atomic_max((LC_LDS uint32_t *)outE, (uint32_t)bestE);
+    if (bestM > 0) dev_atomic_max((LC_LDS uint32_t *)outM, (uint32_t)bestM);
   }
   WG_SYNC();
 }
@@ -302,8 +302,8 @@ DEVNI void repeat_scan(LC_WS &S, LC_GLOBAL const uint8_t *s, int len, int mm, vo
     }
     { const int cm = lenM - 1 - lm; if (cm > bestM) bestM = cm;
       const int ce = lenE - 1 - l0; if (ce > bestE) bestE = ce; }
-    if (bestE > 0) dev_atomic_max((uint32_t *)outE, (uint32_t)bestE);
-    if (bestM > 0) dev_atomic_max((uint32_t *)outM, (uint32_t)bestM);
+    if (bestE > 0) dev_atomic_max((LC_LDS uint32_t *)outE, (uint32_t)bestE);
+    if (bestM > 0) dev_atomic_max((LC_LDS uint32_t *)outM, (uint32_t)bestM);
   }
   WG_SYNC();
 }
@@ -496,29 +496,39 @@ DEVNI void ht_insert(Ctx &c, uint32_t n) {
 }
 // Insert into the (array form of the) live table: unordered_map::insert after erasures.  Erase never moves
 // other nodes and keeps each bucket's run contiguous, so "bucket empty" == no live node hashes to it.
+// unordered_map::insert of a node that the table order has to show (the two special nodes per component), whole wave:
+// the place is in front of the first element of the same bucket (else at the head); finding it is a scan of the whole
+// order with a 64-bit modulo per element -- one lane took ~1 ms for it.  Call with all lanes; n is uniform.
 DEVNI void order_insert(Ctx &c, uint32_t n) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
-  if (S.ht_elt + 1 > S.ht_next_resize) {
-    unsigned long long mn = S.ht_elt + 1;
-    if (S.ht_next_resize == 0 && mn < 11) mn = 11;
-    if (mn >= S.ht_bc) {   // rebuild the linked form from the array, rehash, and read the array back
-      unsigned long long want = mn + 1; if (want < 2ULL * S.ht_bc) want = 2ULL * S.ht_bc;
-      uint32_t nb = ht_next_prime((uint32_t)want);
-      S.ht_head = S.M ? W.order[0] : LC_NIL;
-      for (uint32_t i = 0; i < S.M; ++i) W.ht_next[W.order[i]] = (i + 1 < S.M) ? W.order[i + 1] : LC_NIL;
-      S.ht_next_resize = nb;
-      ht_rehash(c, nb);
-      if (S.overflow) return;
-      uint32_t m = 0;
-      for (uint32_t p = S.ht_head; p != LC_NIL; p = W.ht_next[p]) W.order[m++] = p;
-    } else S.ht_next_resize = S.ht_bc;
+  WG_LANE0 {
+    if (S.ht_elt + 1 > S.ht_next_resize) {
+      unsigned long long mn = S.ht_elt + 1;
+      if (S.ht_next_resize == 0 && mn < 11) mn = 11;
+      if (mn >= S.ht_bc) {   // rebuild the linked form from the array, rehash, and read the array back
+        unsigned long long want = mn + 1; if (want < 2ULL * S.ht_bc) want = 2ULL * S.ht_bc;
+        uint32_t nb = ht_next_prime((uint32_t)want);
+        S.ht_head = S.M ? W.order[0] : LC_NIL;
+        for (uint32_t i = 0; i < S.M; ++i) W.ht_next[W.order[i]] = (i + 1 < S.M) ? W.order[i + 1] : LC_NIL;
+        S.ht_next_resize = nb;
+        ht_rehash(c, nb);
+        if (!S.overflow) { uint32_t m = 0; for (uint32_t p = S.ht_head; p != LC_NIL; p = W.ht_next[p]) W.order[m++] = p; }
+      } else S.ht_next_resize = S.ht_bc;
+    }
+    S.tmp3 = 0x7FFFFFFF;
   }
-  uint32_t b = (uint32_t)(W.nhash[n] % S.ht_bc);
-  uint32_t at = 0;
-  for (uint32_t i = 0; i < S.M; ++i) if ((uint32_t)(W.nhash[W.order[i]] % S.ht_bc) == b) { at = i; break; }
-  for (uint32_t i = S.M; i > at; --i) W.order[i] = W.order[i - 1];
-  W.order[at] = n;
-  ++S.M; ++S.ht_elt;
+  if (wg_bcast(&S.overflow)) return;
+  const uint32_t bc = wg_bcastu(&S.ht_bc), M = wg_bcastu(&S.M);
+  const uint32_t b = (uint32_t)(W.nhash[n] % bc);
+  WG_FOR(i, M) { if ((uint32_t)(W.nhash[W.order[i]] % bc) == b) dev_atomic_min((LC_LDS uint32_t *)&S.tmp3, (uint32_t)i); }
+  WG_SYNC();
+  uint32_t at = (uint32_t)wg_bcast(&S.tmp3);
+  if (at == 0x7FFFFFFFu) at = 0;
+  LC_GLOBAL uint32_t *tmp = W.scratch;                     // order[at..M) moves up by one: out, barrier, back
+  WG_FOR(i, M - at) { tmp[i] = W.order[at + (uint32_t)i]; }
+  WG_SYNC();
+  WG_FOR(i, M - at) { W.order[at + 1 + (uint32_t)i] = tmp[i]; }
+  WG_LANE0 { W.order[at] = n; ++S.M; ++S.ht_elt; }
 }
 // cleanDead (reference src/Graph.cc:2737-2762): erase every dead node from the table
 DEVNI uint32_t clean_dead(Ctx &c, bool quiet = false) {
@@ -995,7 +1005,7 @@ DEVNI void build_csr(Ctx &c) {
   //      an open-addressing set in LDS (whole-line reads of its occurrence run), then the read's own occurrences are
   //      probed against it; hits get bit 30 in occ[] and are decided by the exact replay after the csr is built.
   {
-    uint32_t *set = (uint32_t *)S.mk;                       // 512 words of the (idle) staging area
+    LC_LDS uint32_t *set = (LC_LDS uint32_t *)S.mk;                       // 512 words of the (idle) staging area
     const uint32_t g0 = LC_CTX(c).B->read_begin[S.w];
     const int nreads = S.R - 1;
     for (int r = 0; r < nreads; ++r) {
@@ -1029,11 +1039,11 @@ DEVNI void build_csr(Ctx &c) {
         if (!all) {
           const uint32_t id = (oc & 0x3FFFFFFFu) + 1u;
           uint32_t h = (id * 2654435761u) >> 23;
-          while (true) { const uint32_t v = ((volatile uint32_t *)set)[h]; if (v == 0u) break; if (v == id) { hit = true; break; } h = (h + 1) & 511u; }
+          while (true) { const uint32_t v = ((volatile LC_LDS uint32_t *)set)[h]; if (v == 0u) break; if (v == id) { hit = true; break; } h = (h + 1) & 511u; }
         }
         if (hit) {
           W.occ[o0 + p] = oc | 0x40000000u;
-          uint32_t t = dev_atomic_add((uint32_t *)&S.tmp1, 1u);
+          uint32_t t = dev_atomic_add((LC_LDS uint32_t *)&S.tmp1, 1u);
           if (t < LC_CTX(c).C->table_cap) W.todo[t] = ((uint32_t)r << 10) | (uint32_t)p; else OVF(c);
         }
       }
@@ -1089,7 +1099,7 @@ DEVNI void build_csr(Ctx &c) {
       }
       WG_SYNC();
       WG_LANE0 { S.tmp2 = 0; }
-      WG_FOR(n, S.N) { if (ld2(&mark[n >> 5]) & (1u << (n & 31))) W.pnodes[dev_atomic_add((uint32_t *)&S.tmp2, 1u)] = (uint32_t)n; }   // the marked nodes, densely
+      WG_FOR(n, S.N) { if (ld2(&mark[n >> 5]) & (1u << (n & 31))) W.pnodes[dev_atomic_add((LC_LDS uint32_t *)&S.tmp2, 1u)] = (uint32_t)n; }   // the marked nodes, densely
       WG_SYNC();
       const int nmarked = wg_bcast(&S.tmp2);
       WG_FOR(li, nmarked) {
@@ -1383,7 +1393,7 @@ DEVNI void build_qcounts(Ctx &c) {
           qq[QS * i] = (uint16_t)a0; qq[QS * i + 1] = (uint16_t)a1; qq[QS * i + 2] = (uint16_t)a2; qq[QS * i + 3] = (uint16_t)a3;
           if (LR) { uint16_t *qh = qq + QS * i + 4; qh[0] = (uint16_t)h0; qh[1] = (uint16_t)h1; qh[2] = (uint16_t)h2; qh[3] = (uint16_t)h3; qh[4] = (uint16_t)h4; qh[5] = (uint16_t)h5; }
           const int sq = (int)(uint16_t)a0 + (int)(uint16_t)a1 + (int)(uint16_t)a2 + (int)(uint16_t)a3;
-          dev_atomic_min((uint32_t *)&S.g_min[k], (uint32_t)sq);
+          dev_atomic_min((LC_LDS uint32_t *)&S.g_min[k], (uint32_t)sq);
         }
       }
       WG_SYNC();
@@ -1994,7 +2004,7 @@ DEVNI void mark_connected_components_wg(Ctx &c) {
   WG_LANE0 { S.tmp1 = 0; }
   WG_FOR(i, M) {
     const uint32_t r = ld2(&parent[W.order[i]]);
-    if (ld2(&minpos[r]) == (uint32_t)i) { cid[r] = first[i] + 1u; if (ld2(&touch[r]) & 1u) dev_atomic_add((uint32_t *)&S.tmp1, 1u); }
+    if (ld2(&minpos[r]) == (uint32_t)i) { cid[r] = first[i] + 1u; if (ld2(&touch[r]) & 1u) dev_atomic_add((LC_LDS uint32_t *)&S.tmp1, 1u); }
   }
   WG_SYNC_FENCE();
   WG_FOR(i, M) { const uint32_t u = W.order[i]; W.gr[u].comp = (int)cid[ld2(&parent[u])]; }
@@ -2035,13 +2045,21 @@ DEVNI void mark_ref_scan(Ctx &c, int comp) {
   const uint32_t ro = W.occ_base[S.R - 1];
   const int nrefk = (S.reflen - K > 0) ? S.reflen - K + 1 : 0;
   WG_LANE0 { S.mr_src = 0x7FFFFFFF; S.mr_snk = 0; S.mr_ambs = 0; S.mr_ambk = 0; }
-  WG_FOR(off, nrefk) {
-    const uint32_t t = W.occ[ro + off] & 0x3FFFFFFFu;
-    const uint32_t f = W.gr[t].flags;
-    if ((f & NF_DEAD) || !(f & NF_SURV)) continue;
-    if (n_totcov(c, t) >= (float)LC_CTX(c).P->cov_threshold && W.gr[t].comp == comp) {
-      dev_atomic_min((uint32_t *)&S.mr_src, (uint32_t)off);
-      dev_atomic_max((uint32_t *)&S.mr_snk, (uint32_t)(off + 1));
+  {
+    uint32_t lmin = 0x7FFFFFFFu, lmax = 0;                    // per lane; one pair of LDS atomics per lane at the end
+    const float thr = (float)LC_CTX(c).P->cov_threshold;
+    WG_FOR(off, nrefk) {
+      const uint32_t t = W.occ[ro + off] & 0x3FFFFFFFu;
+      LC_GLOBAL const NodeGr &G = W.gr[t];
+      const uint32_t f = G.flags;
+      if ((f & NF_DEAD) || !(f & NF_SURV)) continue;
+      if (G.cov[0] + G.cov[1] + G.cov[2] + G.cov[3] >= thr && G.comp == comp) {
+        if ((uint32_t)off < lmin) lmin = (uint32_t)off;
+        if ((uint32_t)(off + 1) > lmax) lmax = (uint32_t)(off + 1);
+      }
+    }
+    WG_FOR(l, LANCET_WG) {
+      if (lmax) { dev_atomic_min((LC_LDS uint32_t *)&S.mr_src, lmin); dev_atomic_max((LC_LDS uint32_t *)&S.mr_snk, lmax); }
     }
   }
   WG_SYNC();
@@ -2055,57 +2073,78 @@ DEVNI void mark_ref_scan(Ctx &c, int comp) {
   }
   WG_LANE0 { S.mr_snk = ko; }
 }
+// markRefEnds (reference src/Graph.cc): source / sink creation by lane 0, their insertion into the table order by the wave.
 DEVNI void mark_ref_ends(Ctx &c, int comp) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int K = S.K;
-  S.trim5 = 0xFFFF; S.trim3 = 0xFFFF;
-  S.source = LC_NIL; S.sink = LC_NIL;
-  uint32_t ro = W.occ_base[S.R - 1];
-  int nrefk = (S.reflen - K > 0) ? S.reflen - K + 1 : 0;
-  (void)nrefk;
-  // the scans over the reference offsets ran in mark_ref_scan (same predicates, same outcome order)
-  if (S.mr_src >= 0 && S.mr_ambs) { evt(c, EV_AMBIG_SRC); return; }
-  if (S.mr_src < 0) { evt(c, EV_NOMATCH_SRC); return; }
-  if (S.mr_ambk) { evt(c, EV_AMBIG_SNK); return; }
-  if (S.mr_snk < 0) { evt(c, EV_NOMATCH_SNK); return; }
-  const int src_off = S.mr_src, snk_off = S.mr_snk;
-  const uint32_t soc = W.occ[ro + src_off], koc = W.occ[ro + snk_off];
-  const uint32_t src = soc & 0x3FFFFFFFu, snk = koc & 0x3FFFFFFFu, src_ori = soc >> 31, snk_ori = koc >> 31;
-  int ref_dist = snk_off - src_off + K;
-  int t3 = S.reflen - snk_off - K;
-  S.seq_t5 = src_off; S.seq_len = ref_dist;                           // ref_m->seq = rawseq.substr(source_offset, ref_dist)
-  S.trim5 = src_off & 0xFFFF; S.trim3 = t3 & 0xFFFF;
-  evt(c, EV_TRIM, src_off, t3, ref_dist);
-  // fake source
-  uint32_t ns = special_new(c, true, comp); if (ns == LC_NIL) return;
-  uint32_t sourcedir = src_ori ? 1u : 0u;                              // FF, or FR when the k-mer is reversed
-  char flip = src_ori ? 'F' : 'R';                                     // Edge_t::flipdir(source_mer.ori_m)
-  for (int i = (int)W.gr[src].necnt - 1; i >= 0; --i) {
-    uint32_t e = W.gr[src].edges[i];
-    if (dir_start(ED_DIR(e)) == flip) {
-      uint32_t other = ED_TO(e);
-      if (other != src) { remove_edge(c, other, src, fliplink(ED_DIR(e))); erase_edge_at(c, src, i); }
+  WG_LANE0 {
+    S.tmp2 = (int)LC_NIL;                                      // node to insert next (LC_NIL: stop)
+    S.trim5 = 0xFFFF; S.trim3 = 0xFFFF;
+    S.source = LC_NIL; S.sink = LC_NIL;
+    // the scans over the reference offsets ran in mark_ref_scan (same predicates, same outcome order)
+    if (S.mr_src >= 0 && S.mr_ambs) evt(c, EV_AMBIG_SRC);
+    else if (S.mr_src < 0) evt(c, EV_NOMATCH_SRC);
+    else if (S.mr_ambk) evt(c, EV_AMBIG_SNK);
+    else if (S.mr_snk < 0) evt(c, EV_NOMATCH_SNK);
+    else {
+      const uint32_t ro = W.occ_base[S.R - 1];
+      const int src_off = S.mr_src, snk_off = S.mr_snk;
+      const uint32_t soc = W.occ[ro + src_off];
+      const uint32_t src = soc & 0x3FFFFFFFu, src_ori = soc >> 31;
+      int ref_dist = snk_off - src_off + K;
+      int t3 = S.reflen - snk_off - K;
+      S.seq_t5 = src_off; S.seq_len = ref_dist;                           // ref_m->seq = rawseq.substr(source_offset, ref_dist)
+      S.trim5 = src_off & 0xFFFF; S.trim3 = t3 & 0xFFFF;
+      evt(c, EV_TRIM, src_off, t3, ref_dist);
+      // fake source
+      uint32_t ns = special_new(c, true, comp);
+      if (ns != LC_NIL) {
+        uint32_t sourcedir = src_ori ? 1u : 0u;                              // FF, or FR when the k-mer is reversed
+        char flip = src_ori ? 'F' : 'R';                                     // Edge_t::flipdir(source_mer.ori_m)
+        for (int i = (int)W.gr[src].necnt - 1; i >= 0; --i) {
+          uint32_t e = W.gr[src].edges[i];
+          if (dir_start(ED_DIR(e)) == flip) {
+            uint32_t other = ED_TO(e);
+            if (other != src) { remove_edge(c, other, src, fliplink(ED_DIR(e))); erase_edge_at(c, src, i); }
+          }
+        }
+        add_edge(c, ns, src, sourcedir);
+        add_edge(c, src, ns, fliplink(sourcedir));
+        S.source = ns;
+        S.tmp2 = (int)ns;
+      }
     }
   }
-  add_edge(c, ns, src, sourcedir);
-  add_edge(c, src, ns, fliplink(sourcedir));
-  S.source = ns;
-  order_insert(c, ns);
-  // fake sink
-  uint32_t nk = special_new(c, false, comp); if (nk == LC_NIL) return;
-  uint32_t sinkdir = snk_ori ? 0u : 3u;                                // RR, or FF when reversed
-  char same = snk_ori ? 'R' : 'F';
-  for (int i = (int)W.gr[snk].necnt - 1; i >= 0; --i) {
-    uint32_t e = W.gr[snk].edges[i];
-    if (dir_start(ED_DIR(e)) == same) {
-      uint32_t other = ED_TO(e);
-      if (other != snk) { remove_edge(c, other, snk, fliplink(ED_DIR(e))); erase_edge_at(c, snk, i); }
+  uint32_t ins = (uint32_t)wg_bcast(&S.tmp2);
+  if (ins == LC_NIL) return;
+  order_insert(c, ins);
+  if (wg_bcast(&S.overflow)) return;
+  WG_LANE0 {
+    S.tmp2 = (int)LC_NIL;
+    const uint32_t ro = W.occ_base[S.R - 1];
+    const uint32_t koc = W.occ[ro + S.mr_snk];
+    const uint32_t snk = koc & 0x3FFFFFFFu, snk_ori = koc >> 31;
+    // fake sink
+    uint32_t nk = special_new(c, false, comp);
+    if (nk != LC_NIL) {
+      uint32_t sinkdir = snk_ori ? 0u : 3u;                                // RR, or FF when reversed
+      char same = snk_ori ? 'R' : 'F';
+      for (int i = (int)W.gr[snk].necnt - 1; i >= 0; --i) {
+        uint32_t e = W.gr[snk].edges[i];
+        if (dir_start(ED_DIR(e)) == same) {
+          uint32_t other = ED_TO(e);
+          if (other != snk) { remove_edge(c, other, snk, fliplink(ED_DIR(e))); erase_edge_at(c, snk, i); }
+        }
+      }
+      add_edge(c, nk, snk, sinkdir);
+      add_edge(c, snk, nk, fliplink(sinkdir));
+      S.sink = nk;
+      S.tmp2 = (int)nk;
     }
   }
-  add_edge(c, nk, snk, sinkdir);
-  add_edge(c, snk, nk, fliplink(sinkdir));
-  S.sink = nk;
-  order_insert(c, nk);
+  ins = (uint32_t)wg_bcast(&S.tmp2);
+  if (ins == LC_NIL) return;
+  order_insert(c, ins);
 }
 
 DEVNI bool has_cycle(Ctx &c, bool colored = false) {                                         // reference src/Graph.cc:593-681
@@ -2246,7 +2285,7 @@ DEVNI int path_string_wg(Ctx &c, int n) {
   WG_LANE0 { S.ps_first = 0x7FFFFFFF; off[n] = 0; }
   WG_FOR(i, n) {
     const uint32_t nd = W.pnodes[i];
-    if (!(W.gr[nd].flags & NF_SPECIAL)) dev_atomic_min((uint32_t *)&S.ps_first, (uint32_t)i);
+    if (!(W.gr[nd].flags & NF_SPECIAL)) dev_atomic_min((LC_LDS uint32_t *)&S.ps_first, (uint32_t)i);
     const uint32_t pe = W.pedges[i == 0 ? 1 : i];
     const uint32_t e = W.gr[pe >> 4].edges[pe & 15u];
     pdir[i] = (uint32_t)(i == 0 ? dir_start(ED_DIR(e)) : dir_dest(ED_DIR(e)));
@@ -2614,7 +2653,7 @@ DEVNI void walk_prepare(Ctx &c, int L) {
     const uint8_t r = ra[i], p = pa[i];
     E1[i] = r != '-'; E2[i] = p != '-'; F[i] = r != p;
     const int t = r == p ? 0 : (r == '-' ? 2 : (p == '-' ? 3 : 1));
-    dev_atomic_add((uint32_t *)&S.wk[t], 1u);
+    dev_atomic_add((LC_LDS uint32_t *)&S.wk[t], 1u);
   }
   WG_SYNC();
   wg_scan(E1, L + 1, S, S.part2);
@@ -2818,7 +2857,7 @@ DEVNI void count_ref_path(Ctx &c) {
         const int n = wg_bcast(&S.seq_len);
         LC_GLOBAL const uint8_t *rs = LC_CTX(c).B->ref_codes + LC_CTX(c).B->ref_off[S.w] + S.seq_t5;
         WG_LANE0 { S.ps_hd = 0; }
-        if (n == m) { WG_FOR(i, n) { if (rs[i] != W.pseq[i]) dev_atomic_add((uint32_t *)&S.ps_hd, 1u); } }
+        if (n == m) { WG_FOR(i, n) { if (rs[i] != W.pseq[i]) dev_atomic_add((LC_LDS uint32_t *)&S.ps_hd, 1u); } }
         WG_SYNC();
         const int hd = (n == m) ? wg_uniform(S.ps_hd) : -1;
         const bool need_align = (hd == -1 || hd > 5);
@@ -2938,10 +2977,8 @@ DEV void process_window(Ctx &c, int w) {
     if (wg_bcast(&S.overflow)) break;
     for (int comp = 1; comp <= numcomp; ++comp) {
       mark_ref_scan(c, comp);
-      WG_LANE0 {
-        print_stats(c, comp);
-        mark_ref_ends(c, comp);
-      }
+      WG_LANE0 { print_stats(c, comp); }
+      mark_ref_ends(c, comp);
       if (wg_bcast(&S.overflow)) break;
       PHASE(c, 15);
       compress_prepare(c, comp);
