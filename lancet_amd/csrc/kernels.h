@@ -1689,6 +1689,7 @@ DEVNI void compress_prepare(Ctx &c, int comp) {
     LC_GLOBAL CmpRec &r = W.cmp[n];
     LC_GLOBAL const NodeGr &G = W.gr[n];
     r.lnk[0] = 0; r.lnk[1] = 0;
+    W.todo[n] = 0;                                               // "absorbed" mark of compress_fast (todo[] is idle after the build)
     if (G.comp != comp || (G.flags & (NF_DEAD | NF_SPECIAL))) continue;
     bool irr = false;
     if ((int)(G.seq_hi - G.seq_lo) != K || G.nkm != 1 || G.nqv == LC_NIL) irr = true;
@@ -1714,11 +1715,10 @@ DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
   const uint32_t lcap = LC_CTX(c).C->node_cap;
   // Which nodes are still heads is read off the merge records (both links of a node outside the component, of a special
   // node and of every node absorbed so far are 0), one 8-byte load per table position, fetched one position ahead; the
-  // absorbed nodes are also noted in a bitmap for the compaction at the end.  After a ring (literal replay, which marks
-  // its merges in the node records only) both fall back to the node records.
+  // absorbed nodes are also marked in todo[] for the compaction of the table order, which the whole wave does afterwards
+  // (compact_absorbed_wg; S.tmp2 says whether it is due).  After a ring (literal replay, which marks its merges in the
+  // node records only) both fall back to the node records.
   const uint32_t M = S.M;
-  LC_GLOBAL uint32_t *gone = W.bitmap;
-  { const uint32_t nw = (LC_CTX(c).C->node_cap + LC_CTX(c).C->special_cap) / 32 + 1; for (uint32_t i = 0; i < nw; ++i) gone[i] = 0; }   // (special nodes sit above node_cap)
   bool ringed = false;
   uint32_t nabs = 0;
   uint32_t Hn = M ? W.order[0] : 0;
@@ -1766,9 +1766,14 @@ DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
       float nc0 = G.cov[0], nc1 = G.cov[1], nc2 = G.cov[2], nc3 = G.cov[3];
       uint32_t fl = G.flags, nkm = G.nkm, nkmT = G.nkmT;
       int alen = (int)(hi - lo);
+      // one merge per trip; the record of the next absorbed node is fetched before this trip's stores (a store orders
+      // every later load behind it for the compiler, and each record fetch is a full memory round trip)
+      uint32_t Bn = list[0], en = list[1];
+      CmpRec rn = W.cmp[Bn];
       for (uint32_t j = 0; j < cnt; ++j) {
-        const uint32_t Bj = list[2 * j], ed = list[2 * j + 1];
-        LC_GLOBAL const CmpRec &rb = W.cmp[Bj];
+        const uint32_t Bj = Bn, ed = en;
+        const CmpRec rb = rn;
+        if (j + 1 < cnt) { Bn = list[2 * j + 2]; en = list[2 * j + 3]; rn = W.cmp[Bn]; }
         const bool brev = dir_dest(ed) == 'R';
         uint32_t d = brev ? (rb.d0 ^ 3u) : rb.dK;
         if (dir == 'F') W.seq[hi++] = d; else W.seq[--lo] = d ^ 3u;
@@ -1782,7 +1787,7 @@ DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
         ++alen; nkm += 1; nkmT += rb.nkmT;
         fl |= rb.flags & (NF_TUMOR | NF_NORMAL);
         W.gr[Bj].flags = rb.flags | NF_DEAD;
-        W.cmp[Bj].lnk[0] = 0; W.cmp[Bj].lnk[1] = 0; gone[Bj >> 5] |= 1u << (Bj & 31); ++nabs;
+        W.cmp[Bj].lnk[0] = 0; W.cmp[Bj].lnk[1] = 0; W.todo[Bj] = 1; ++nabs;
       }
       G.seq_lo = lo; G.seq_hi = hi; G.mincov = mn; G.mincovqv = mq;
       G.cov[0] = nc0; G.cov[1] = nc1; G.cov[2] = nc2; G.cov[3] = nc3;
@@ -1808,15 +1813,28 @@ DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
       }
     }
   }
-  if (ringed || S.overflow) return clean_dead(c, quiet);
-  uint32_t m = 0;                                                 // cleanDead off the bitmap: no node record is touched
-  for (uint32_t i = 0; i < M; ++i) { const uint32_t n = W.order[i]; if (!(gone[n >> 5] & (1u << (n & 31)))) W.order[m++] = n; }
-  S.M = m; S.ht_elt -= nabs;
+  if (ringed || S.overflow) { S.tmp2 = 0; return clean_dead(c, quiet); }
+  S.tmp2 = 1;                                                     // cleanDead is due: compact_absorbed_wg, by the whole wave
   if (!quiet) evt(c, EV_CLEANDEAD, nabs);
   return nabs;
 }
+// cleanDead after compress_fast: the table order without the nodes marked in todo[] (scan-compaction, no node record touched)
+DEVNI void compact_absorbed_wg(Ctx &c) {
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  const int M = (int)wg_bcastu(&S.M);
+  LC_GLOBAL uint32_t *keep = W.scratch;
+  WG_FOR(i, M) { keep[i] = W.todo[W.order[i]] ? 0u : 1u; }
+  WG_LANE0 { keep[M] = 0; }
+  wg_scan(keep, M + 1, S);
+  WG_FOR(i, M) { if (keep[i + 1] != keep[i]) W.pnodes[keep[i]] = W.order[i]; }
+  WG_SYNC();
+  const int live = (int)wg_bcastu(&S.part[LANCET_WG]);
+  WG_FOR(i, live) { W.order[i] = W.pnodes[i]; }
+  WG_LANE0 { S.M = (uint32_t)live; S.ht_elt -= (uint32_t)(M - live); }
+}
 DEVNI uint32_t compress(Ctx &c, int comp, bool quiet = false) {       // reference src/Graph.cc:2712-2732
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  S.tmp2 = 0;                                                    // (no compaction pending, see compress_fast)
   if (!quiet) evt(c, EV_COMPRESS);
   for (uint32_t i = 0; i < S.M && !S.overflow; ++i) {
     uint32_t n = W.order[i];
@@ -2988,7 +3006,11 @@ DEV void process_window(Ctx &c, int w) {
         // back to a node on the DFS stack, so the answer is the same on the compacted graph -- with ~30x fewer nodes to
         // visit.  The graph of a rejected k is thrown away, so compacting first is unobservable; only the trace lines
         // of the compaction are held back until the cycle check has passed.
-        const uint32_t dead = S.cmp_ok ? compress_fast(c, comp, true) : compress(c, comp, true);
+        S.tmp1 = (int)(S.cmp_ok ? compress_fast(c, comp, true) : compress(c, comp, true));
+      }
+      if (wg_bcast(&S.tmp2)) compact_absorbed_wg(c);
+      WG_LANE0 {
+        const uint32_t dead = (uint32_t)S.tmp1;
         PHASE(c, 9);
         S.tmp0 = 0;
         if (!S.overflow && has_cycle(c)) S.tmp0 = 1;
