@@ -1869,18 +1869,34 @@ DEVNI bool find_tandems(const Ctx &c, LC_GLOBAL const uint8_t *seq, int n, int p
   const unsigned MAXU = (unsigned)LC_CTX(c).P->max_unit_len, MRU = (unsigned)LC_CTX(c).P->min_report_units, MRL = (unsigned)LC_CTX(c).P->min_report_len;
   const int delta = LC_CTX(c).P->dist_from_str;
   bool ans = false;
-  int offsets[9][8];
-  for (unsigned ml = 1; ml <= MAXU && ml <= 8; ++ml) for (unsigned ph = 0; ph < ml; ++ph) offsets[ml][ph] = (int)ph;
+  // The scan compares bytes of the string at data-dependent places, one dependent load after the other (~10 k of them for
+  // a 600-base path), and keeps a small table indexed at run time: both live in LDS for the duration (the staging area of
+  // the per-position pass is idle in the graph phases); a string that does not fit is scanned where it lies.
+  LC_WS &S = LC_SREF(c);
+  LC_LDS uint8_t *ls = (LC_LDS uint8_t *)S.mk;
+  const bool staged = n + 8 <= 2048;
+  if (staged) {
+    LC_GLOBAL const uint32_t *src = (LC_GLOBAL const uint32_t *)seq; LC_LDS uint32_t *dst = (LC_LDS uint32_t *)ls;
+    const int nwords = (n + 3) / 4;
+#ifndef LANCET_WAVE_EMU
+#pragma unroll 8
+#endif
+    for (int w = 0; w < nwords; ++w) dst[w] = src[w];
+  }
+#define LC_SEQ(i) (staged ? (int)ls[(i)] : (int)seq[(i)])
+  int offsets_local[9][8];
+  LC_LDS int *offs_lds = (LC_LDS int *)(ls + 2048);
+  for (unsigned ml = 1; ml <= MAXU && ml <= 8; ++ml) for (unsigned ph = 0; ph < ml; ++ph) { if (staged) offs_lds[ml * 8 + ph] = (int)ph; else offsets_local[ml][ph] = (int)ph; }
   *motif_len = 0;
   for (unsigned i = 0; i < (unsigned)n; ++i) {
     for (unsigned merlen = 1; merlen <= MAXU && merlen <= 8; ++merlen) {
       int phase = (int)(i % merlen);
-      int offset = offsets[merlen][phase];
+      int offset = staged ? offs_lds[merlen * 8 + (unsigned)phase] : offsets_local[merlen][phase];
       unsigned j = 0;
-      while ((j < merlen) && (i + j < (unsigned)n) && (seq[i + j] == seq[offset + j])) ++j;
+      while ((j < merlen) && (i + j < (unsigned)n) && (LC_SEQ(i + j) == LC_SEQ(offset + j))) ++j;
       if (j != merlen || (i + j + 1 == (unsigned)n)) {
         int a = offset - 1, b = offset + (int)merlen - 1;
-        int ca = (a < 0 || a >= n) ? 255 : seq[a], cb = (b < 0 || b >= n) ? 255 : seq[b];    // byte before the string is 0 in libstdc++
+        int ca = (a < 0 || a >= n) ? 255 : LC_SEQ(a), cb = (b < 0 || b >= n) ? 255 : LC_SEQ(b);    // byte before the string is 0 in libstdc++
         if (ca != cb) {
           if (((i - (unsigned)offset) / merlen >= MRU) && (i - (unsigned)offset >= MRL)) {
             unsigned ml = 1;
@@ -1888,23 +1904,24 @@ DEVNI bool find_tandems(const Ctx &c, LC_GLOBAL const uint8_t *seq, int n, int p
               unsigned units = (i - (unsigned)offset + j) / ml;
               int allmatch = 1;
               for (unsigned index = 1; allmatch && (index < units); ++index)
-                for (unsigned m = 0; m < ml; ++m) if (seq[offset + m] != seq[offset + index * ml + m]) { allmatch = 0; break; }
+                for (unsigned m = 0; m < ml; ++m) if (LC_SEQ(offset + m) != LC_SEQ(offset + index * ml + m)) { allmatch = 0; break; }
               if (!allmatch) ++ml; else break;
             }
             if (ml == merlen) {
               int start = offset, end = (int)(i + j), L = (int)(i + j) - offset;
               if ((pos >= (start - delta)) && (pos <= (end + delta))) {
                 ans = true; *len = L;
-                for (unsigned z = 0; z < merlen; ++z) if (*motif_len < 60) motif[(*motif_len)++] = seq[offset + z];
+                for (unsigned z = 0; z < merlen; ++z) if (*motif_len < 60) motif[(*motif_len)++] = (uint8_t)LC_SEQ(offset + z);
               }
             }
           }
         }
-        offsets[merlen][phase] = (int)i;
+        if (staged) offs_lds[merlen * 8 + (unsigned)phase] = (int)i; else offsets_local[merlen][phase] = (int)i;
       }
     }
   }
   return ans;
+#undef LC_SEQ
 }
 
 DEV void node_string(const Ctx &c, uint32_t n, LC_GLOBAL uint8_t *out) {      // str_m as codes
