@@ -181,7 +181,8 @@ def _body(text):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,region,extra", [("ar_small", "chr22:900-3000", ["--num-threads", "1"]),
                                                ("lr_small", "chr22:800-2700", ["--linked-reads"]),
-                                               ("ar_small", "chr22:900-3000", ["--batch-windows", "7"])])
+                                               ("ar_small", "chr22:900-3000", ["--batch-windows", "7"]),
+                                               ("lr_small", "chr22:800-2700", ["--linked-reads", "--batch-windows", "5"])])
 def test_lancet_gpu_binary_vcf_is_byte_identical_to_the_reference(case, region, extra):
     """The native command-line program end to end (BAM -> host front end -> engine -> VariantDB -> VCF) on the
     reference-made fixtures, also with the region cut into several engine batches."""
@@ -192,3 +193,34 @@ def test_lancet_gpu_binary_vcf_is_byte_identical_to_the_reference(case, region, 
     assert "##fileDate=Sun Sep 27 05:27:00 2026\n##source=lancet 1.1.0" in r.stdout and "##cmdline=lancet --tumor" in r.stdout
     assert "--date-line" not in r.stdout
     assert _body(r.stdout) == gu.golden_vcf(case)
+
+
+def test_native_host_multi_contig_inputs_and_whole_contig_region(tmp_path):
+    """Two contigs in BAM and FASTA (reads of the other contig must not leak into the windows), region given as a bare
+    contig name (loadRefs takes the whole contig, no padding), reads touching the contig's first and last bases."""
+    rng = np.random.default_rng(77)
+    a = synth.make_tumor_normal(ref_len=2600, cov_t=18, cov_n=14, ref_seed=41, tumor_seed=141, normal_seed=241, somatic_every=600, germline_every=500)
+    b = synth.make_tumor_normal(ref_len=2200, cov_t=18, cov_n=14, ref_seed=42, tumor_seed=142, normal_seed=242, somatic_every=500, germline_every=400)
+    def rename(reads, name):
+        return [synth.SamRead(r.qname, r.flag, name, r.pos, r.mapq, r.cigar, r.seq, r.qual, r.tags) for r in reads]
+    refs = [("chrA", len(a["ref"])), ("chrB", len(b["ref"]))]
+    tum = rename(synth.pairs_to_sorted_reads(a["tumor"]), "chrA") + rename(synth.pairs_to_sorted_reads(b["tumor"]), "chrB")
+    nor = rename(synth.pairs_to_sorted_reads(a["normal"]), "chrA") + rename(synth.pairs_to_sorted_reads(b["normal"]), "chrB")
+    tb, nb, fa = str(tmp_path / "t.bam"), str(tmp_path / "n.bam"), str(tmp_path / "r.fa")
+    bam_writer.write_bam(tb, refs, tum, sample="T2")
+    bam_writer.write_bam(nb, refs, nor, sample="N2")
+    with open(fa, "w") as fh:
+        for name, seq in (("chrA", a["ref"]), ("chrB", b["ref"])):
+            fh.write(f">{name}\n")
+            for i in range(0, len(seq), 61):
+                fh.write(seq[i:i + 61] + "\n")
+    for region in ("chrB", "chrA:1-2600", "chrB:300-1900"):
+        o = host.default_opts(active_region=0)
+        H = host.NativeHost(tb, nb, fa)
+        hdrs = H.tile(region, o)
+        want_hdrs, pb = _python_batch(tb, nb, fa, region, o)
+        assert hdrs == want_hdrs
+        bt, idx = H.batch(0, len(hdrs), o)
+        _same(bt, pb, False)
+        assert bt.n_reads > 100 and all(h.startswith(region.split(":")[0] + ":") for h in bt.hdr)
+        H.close()
