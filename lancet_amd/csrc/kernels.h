@@ -874,17 +874,22 @@ DEVNI void build_tables(Ctx &c) {
   const int K = S.K;
   (void)C; (void)K; (void)W;
   // ---- occurrence index space: read r owns [occ_base[r], occ_base[r+1]) = its k-mers p = 0..tlen-K
+  //      (k-mers per read by all lanes, exclusive scan, one 16-byte record per read for the per-occurrence passes)
+  WG_LANE0 { S.tmp1 = 0; S.tmp2 = 0; }
+  WG_FOR(r, S.R) {
+    uint32_t rinfo, bw, gw; int tlen; bool isref;
+    read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref);
+    W.rd[4 * r] = rinfo; W.rd[4 * r + 1] = bw; W.rd[4 * r + 2] = gw;
+    W.occ_base[r] = tlen - K > 0 ? (uint32_t)(tlen - K + 1) : 0u;
+    if (tlen > 0 && !isref) dev_atomic_add((LC_LDS uint32_t *)&S.tmp1, (uint32_t)tlen);          // totalreadbp_m (Graph.cc:121-124)
+    if (tlen - K > 0) dev_atomic_add((LC_LDS uint32_t *)&S.tmp2, (uint32_t)(tlen - K));
+  }
+  WG_LANE0 { W.occ_base[S.R] = 0; }
+  wg_scan(W.occ_base, S.R + 1, S);
+  WG_FOR(r, S.R) { W.rd[4 * r + 3] = W.occ_base[r]; }
   WG_LANE0 {
-    uint32_t o = 0; int bp = 0;
-    for (int r = 0; r < S.R; ++r) {
-      uint32_t rinfo, bw, gw; int tlen; bool isref;
-      read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref);
-      W.occ_base[r] = o;
-      W.rd[4 * r] = rinfo; W.rd[4 * r + 1] = bw; W.rd[4 * r + 2] = gw; W.rd[4 * r + 3] = o;     // one 16-byte record per read for the per-occurrence passes
-      if (tlen > 0 && !isref) bp += tlen;                        // totalreadbp_m (Graph.cc:121-124)
-      if (tlen - K > 0) { o += (uint32_t)(tlen - K + 1); S.n_kmers += (unsigned long long)(tlen - K); }
-    }
-    W.occ_base[S.R] = o;
+    const uint32_t o = S.part[LANCET_WG]; const int bp = S.tmp1;
+    S.n_kmers += (unsigned long long)(uint32_t)S.tmp2;
     S.O = o; S.totalreadbp = bp;
     if (o > C.occ_cap) OVF(c);
     ++S.n_builds;
@@ -2949,14 +2954,21 @@ DEV void process_window(Ctx &c, int w) {
     int nr = (int)(B.read_begin[w + 1] - B.read_begin[w]);
     S.R = nr + 1;                                   // + the reference pseudo-read, appended last (Graph.cc:535-540)
     S.seq_t5 = 0; S.seq_len = S.reflen; S.trim5 = 0; S.trim3 = 0;
-    int mapped = 0;
-    for (int r = 0; r < nr; ++r) if (RI_MAPPED(B.rinfo[B.read_begin[w] + r])) ++mapped;
-    S.tmp0 = mapped;
+    S.tmp0 = 0;
     if ((uint32_t)S.R > LC_CTX(c).C->reads_cap || S.R > 0xFFFF || S.reflen > LC_MAXW || S.reflen < 1) S.overflow = 1;   // csr / item words keep the read in 16 bits
     S.hasN = 0;
-    for (int i = 0; i < S.reflen && !S.overflow; ++i) if (B.ref_codes[B.ref_off[w] + i] > 3) S.hasN = 1;
-    if (mapped > 0) evt(c, EV_PROCESS, (uint32_t)nr, (uint32_t)mapped);
   }
+  {                                                             // mapped reads, N in the window reference: all lanes
+    WG_SYNC();
+    const uint32_t r0 = B.read_begin[w]; const int nr = S.R - 1, rl = S.reflen;
+    uint32_t mine = 0;
+    WG_FOR(r, nr) { if (RI_MAPPED(B.rinfo[r0 + (uint32_t)r])) ++mine; }
+    WG_FOR(l, LANCET_WG) { if (mine) dev_atomic_add((LC_LDS uint32_t *)&S.tmp0, mine); mine = 0; }
+    const uint32_t f0 = B.ref_off[w];
+    WG_FOR(i, rl) { if (B.ref_codes[f0 + (uint32_t)i] > 3) S.hasN = 1; }
+    WG_SYNC();
+  }
+  WG_LANE0 { if (S.tmp0 > 0) evt(c, EV_PROCESS, (uint32_t)(S.R - 1), (uint32_t)S.tmp0); }
   if (wg_bcast(&S.tmp0) <= 0) { WG_LANE0 { S.status = LANCET_W_NO_READS; } WG_SYNC(); return; }     // Microassembler.cc:83
   if (wg_bcast(&S.overflow)) { WG_LANE0 { S.status = LANCET_W_OVERFLOW; } WG_SYNC(); return; }
   const int reflen = wg_bcast(&S.reflen);
