@@ -33,7 +33,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-pthread", "-c", "host_frontend.cc", "-o", "host_frontend.o"],
         [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "engine.o", "host_vdb.o", "host_frontend.o", "-lz", "-lpthread", "-o", LIB],
         # the reference's command line on the native host side; finds the library next to itself
-        [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "lancet_main.cc", "-o", BIN, "-L.", "-llancet_engine",
+        [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-pthread", "lancet_main.cc", "-o", BIN, "-L.", "-llancet_engine",
          "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath-link,/opt/rocm/lib"],
     ]
     os.makedirs(os.path.dirname(BIN), exist_ok=True)

@@ -4,6 +4,9 @@
 //     lancet_gpu --tumor T.bam --normal N.bam --ref ref.fa --reg chr22:1000-5000 > out.vcf
 //
 // There is no CPU path: without a gfx950 device engine creation fails and the program stops with an error.
+// Beyond the reference's options: --device N | --devices a,b,... (one engine per entry; batches of --batch-windows windows
+// go to the engines in turn while the host prepares the next one; records reach the VariantDB in window order whatever
+// the number of engines).
 // Not offered: --bed, --rg-file, --kmer-recovery, --print-graph, --verbose (the stage trace is printed by the Python
 // front end, lancet_amd/cli.py); --num-threads is accepted and ignored (windows are batched on the GPU).
 #include "../../include/lancet_host.h"
@@ -13,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <future>
 #include <string>
 #include <vector>
 
@@ -28,13 +32,13 @@ const Opt OPTS[] = {
   {"min-coverage-normal", 'z', 1}, {"max-coverage-normal", 'j', 1}, {"min-phred-fisher", 's', 1},
   {"min-phred-fisher-str", 'E', 1}, {"min-strand-bias", 'f', 1}, {"max-unit-length", 'U', 1}, {"min-report-unit", 'N', 1},
   {"min-report-len", 'Y', 1}, {"dist-from-str", 'D', 1}, {"linked-reads", 'J', 0}, {"primary-alignment-only", 'I', 0},
-  {"XA-tag-filter", 'O', 0}, {"active-region-off", 'W', 0}, {"device", 0, 1}, {"batch-windows", 0, 1}, {"date-line", 0, 1},
+  {"XA-tag-filter", 'O', 0}, {"active-region-off", 'W', 0}, {"device", 0, 1}, {"devices", 0, 1}, {"batch-windows", 0, 1}, {"date-line", 0, 1},
 };
 int die(const std::string &m) { fprintf(stderr, "lancet_gpu: %s\n", m.c_str()); return 1; }
 }  // namespace
 
 int main(int argc, char **argv) {
-  std::string tumor, normal, ref, reg, qrange = "!", date_line;
+  std::string tumor, normal, ref, reg, qrange = "!", date_line, devices;
   int min_k = 11, max_k = 101, trim_lowqual = 10, min_base_qual = 17, tip_len = 11, cov_thr = 5, low_cov = 1, dfs_limit = 1000000;
   int max_indel_len = 500, max_mismatch = 2, max_unit_length = 4, min_report_unit = 3, min_report_len = 7, dist_from_str = 1;
   int device = 0, batch_windows = 32768;
@@ -65,7 +69,7 @@ int main(int argc, char **argv) {
     else if (L == "min-strand-bias") flt.min_strand_bias = (int)atof(v); else if (L == "max-unit-length") max_unit_length = atoi(v);
     else if (L == "min-report-unit") min_report_unit = atoi(v); else if (L == "min-report-len") min_report_len = atoi(v); else if (L == "dist-from-str") dist_from_str = atoi(v);
     else if (L == "linked-reads") ho.linked = 1; else if (L == "primary-alignment-only") ho.primary_alignment_only = 1; else if (L == "XA-tag-filter") ho.xa_filter = 1;
-    else if (L == "active-region-off") ho.active_region = 0; else if (L == "device") device = atoi(v); else if (L == "batch-windows") batch_windows = atoi(v);
+    else if (L == "active-region-off") ho.active_region = 0; else if (L == "device") device = atoi(v); else if (L == "devices") devices = v; else if (L == "batch-windows") batch_windows = atoi(v);
     else if (L == "date-line") date_line = v;
   }
   if (tumor.empty() || normal.empty() || ref.empty() || reg.empty()) return die("--tumor, --normal, --ref and --reg are required");
@@ -81,9 +85,20 @@ int main(int argc, char **argv) {
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_batch = 0, t_engine = 0, t_vdb = 0; float t_kernel = 0;
   const double t_start = now();
-  lancet_engine *eng = nullptr;
-  const int rc = lancet_engine_create(&P, device, &eng);          // fails without a GPU: there is no CPU path
-  if (rc != LANCET_OK) return die(std::string("cannot create the MI355X engine (code ") + std::to_string(rc) + "): " + (eng ? lancet_engine_last_error(eng) : "no gfx950 device / HIP runtime"));
+  // one engine per entry of --devices (default: --device); an entry may repeat a device (two engines on one GPU overlap the
+  // upload of a batch with the kernels of the previous one).  Batches go to the engines in turn; there is no CPU path:
+  // without a GPU engine creation fails.
+  std::vector<int> devs;
+  if (devices.empty()) devs.push_back(device);
+  else { size_t p0 = 0; while (p0 <= devices.size()) { size_t q = devices.find(',', p0); if (q == std::string::npos) q = devices.size(); if (q > p0) devs.push_back(atoi(devices.substr(p0, q - p0).c_str())); p0 = q + 1; } }
+  if (devs.empty()) return die("--devices is empty");
+  std::vector<lancet_engine *> engs;
+  for (int d : devs) {
+    lancet_engine *e = nullptr;
+    const int rc = lancet_engine_create(&P, d, &e);
+    if (rc != LANCET_OK) return die(std::string("cannot create the MI355X engine on device ") + std::to_string(d) + " (code " + std::to_string(rc) + "): " + (e ? lancet_engine_last_error(e) : "no gfx950 device / HIP runtime"));
+    engs.push_back(e);
+  }
   char err[512] = "";
   lancet_host *H = lancet_host_open(tumor.c_str(), normal.c_str(), ref.c_str(), err, sizeof err);
   if (!H) return die(err);
@@ -93,36 +108,76 @@ int main(int argc, char **argv) {
   if (nwin < 0) return die(lancet_host_last_error(H));
   lancet_vdb *db = lancet_vdb_create(&flt);
   const char *chr_names[1] = {lancet_host_chrom(H)};
-  std::vector<int32_t> kept((size_t)(batch_windows > 0 ? batch_windows : 1));
-  long done = 0;
   const int step = batch_windows > 0 ? batch_windows : 1;
-  for (int lo = 0; lo < nwin; lo += step) {
-    const int hi = lo + step < nwin ? lo + step : nwin;
+  const int nchunks = (nwin + step - 1) / step;
+  struct Job { bool have = false; std::vector<lancet_variant> v; std::string blob; std::vector<lancet_variant_lr> lr; std::vector<uint32_t> bx; std::vector<std::string> bxn; };
+  struct Slot { lancet_engine *e = nullptr; std::future<int> fut; int chunk = -1; int nk = 0; std::vector<int32_t> kept; std::vector<std::string> bxn; };
+  std::vector<Job> jobs((size_t)nchunks);
+  std::vector<Slot> slots(engs.size());
+  for (size_t k = 0; k < engs.size(); ++k) { slots[k].e = engs[k]; slots[k].kept.resize((size_t)step); }
+  long done = 0;
+  int next_add = 0;
+  std::string fail;
+  // results of a finished run are copied out (the engine's buffers live until its next upload) and added to the
+  // VariantDB strictly in chunk order: addVar order is window order
+  auto finish = [&](Slot &sl) -> bool {
+    const double t0 = now();
+    const int rc = sl.fut.get();
+    t_engine += now() - t0;
+    if (rc != LANCET_OK) { fail = std::string("engine: ") + lancet_engine_last_error(sl.e); return false; }
+    { float tm[2] = {0, 0}; lancet_engine_last_timing(sl.e, tm); t_kernel += tm[0]; }
+    const lancet_variant *v; uint32_t nv, blen; const char *blob; const lancet_window_stats *st;
+    if (lancet_engine_results(sl.e, &v, &nv, &blob, &blen, &st) != LANCET_OK) { fail = std::string("engine: ") + lancet_engine_last_error(sl.e); return false; }
+    for (int w = 0; w < sl.nk; ++w) if (st[w].status < 0) {
+      fail = std::string("work-space overflow in window ") + lancet_host_window_hdr(H, sl.kept[(size_t)w]) + ": results withheld (no approximate output)"; return false; }
+    Job &j = jobs[(size_t)sl.chunk];
+    j.v.assign(v, v + nv); j.blob.assign(blob, blen);
+    if (ho.linked) {
+      const lancet_variant_lr *lr; const uint32_t *bxb; uint32_t bxl;
+      if (lancet_engine_results_lr(sl.e, &lr, &bxb, &bxl) != LANCET_OK) { fail = std::string("engine: ") + lancet_engine_last_error(sl.e); return false; }
+      j.lr.assign(lr, lr + nv); j.bx.assign(bxb, bxb + bxl); j.bxn.swap(sl.bxn);
+    }
+    j.have = true; done += sl.nk; sl.chunk = -1;
+    return true;
+  };
+  auto flush = [&]() -> bool {
+    const double t0 = now();
+    while (next_add < nchunks && jobs[(size_t)next_add].have) {
+      Job &j = jobs[(size_t)next_add];
+      int arc = LANCET_OK;
+      if (!j.v.empty()) {
+        if (ho.linked) {
+          std::vector<const char *> names; for (auto &n : j.bxn) names.push_back(n.c_str());
+          arc = lancet_vdb_add_lr(db, j.v.data(), j.lr.data(), (uint32_t)j.v.size(), j.blob.c_str(), j.bx.data(), names.data(), (uint32_t)names.size(), chr_names, 1);
+        } else arc = lancet_vdb_add(db, j.v.data(), (uint32_t)j.v.size(), j.blob.c_str(), chr_names, 1);
+      }
+      if (arc != LANCET_OK) { fail = "VariantDB rejected the records"; return false; }
+      j = Job(); j.have = true;
+      ++next_add;
+    }
+    t_vdb += now() - t0;
+    return true;
+  };
+  for (int c = 0; c < nchunks; ++c) {
+    const int lo = c * step, hi = lo + step < nwin ? lo + step : nwin;
+    Slot &sl = slots[(size_t)c % slots.size()];
     lancet_window_batch B; int32_t nk = 0;
     double t0 = now();
-    if (lancet_host_batch(H, lo, hi, &ho, &B, kept.data(), &nk) != LANCET_OK) return die(lancet_host_last_error(H));
+    if (sl.fut.valid() && !finish(sl)) return die(fail);          // its kept[] / engine must be free before they are reused
+    if (lancet_host_batch(H, lo, hi, &ho, &B, sl.kept.data(), &nk) != LANCET_OK) return die(lancet_host_last_error(H));   // (overlaps the other engines' kernels)
     t_batch += now() - t0;
-    if (nk == 0) continue;
+    if (nk == 0) { jobs[(size_t)c].have = true; if (!flush()) return die(fail); continue; }
     t0 = now();
-    if (lancet_engine_process(eng, &B) != LANCET_OK) return die(std::string("engine: ") + lancet_engine_last_error(eng));
+    if (lancet_engine_upload(sl.e, &B) != LANCET_OK) return die(std::string("engine: ") + lancet_engine_last_error(sl.e));
     t_engine += now() - t0;
-    { float tm[2] = {0, 0}; lancet_engine_last_timing(eng, tm); t_kernel += tm[0]; }
-    t0 = now();
-    const lancet_variant *v; uint32_t nv, blen; const char *blob; const lancet_window_stats *st;
-    if (lancet_engine_results(eng, &v, &nv, &blob, &blen, &st) != LANCET_OK) return die(std::string("engine: ") + lancet_engine_last_error(eng));
-    for (int w = 0; w < nk; ++w) if (st[w].status < 0)
-      return die(std::string("work-space overflow in window ") + lancet_host_window_hdr(H, kept[(size_t)w]) + ": results withheld (no approximate output)");
-    int arc;
-    if (ho.linked) {
-      const lancet_variant_lr *lr; const uint32_t *bxb; uint32_t bxl, nbx;
-      if (lancet_engine_results_lr(eng, &lr, &bxb, &bxl) != LANCET_OK) return die(std::string("engine: ") + lancet_engine_last_error(eng));
-      const char *const *bxn = lancet_host_bx_names(H, &nbx);
-      arc = lancet_vdb_add_lr(db, v, lr, nv, blob, bxb, bxn, nbx, chr_names, 1);
-    } else arc = lancet_vdb_add(db, v, nv, blob, chr_names, 1);
-    if (arc != LANCET_OK) return die("VariantDB rejected the records");
-    t_vdb += now() - t0;
-    done += nk;
+    sl.chunk = c; sl.nk = nk; sl.bxn.clear();
+    if (ho.linked) { uint32_t nbx = 0; const char *const *bxn = lancet_host_bx_names(H, &nbx); for (uint32_t i = 0; i < nbx; ++i) sl.bxn.emplace_back(bxn[i]); }
+    lancet_engine *e = sl.e;
+    sl.fut = std::async(std::launch::async, [e]() { return lancet_engine_run(e); });
+    if (!flush()) return die(fail);
   }
+  for (Slot &sl : slots) if (sl.fut.valid() && !finish(sl)) return die(fail);
+  if (!flush()) return die(fail);
   std::string cmdline = "lancet";
   for (int i = 1; i < argc; ++i) { if (strcmp(argv[i], "--date-line") == 0) { ++i; continue; } cmdline += " "; cmdline += argv[i]; }
   if (date_line.empty()) { time_t t = time(nullptr); date_line = ctime(&t); }
@@ -130,10 +185,10 @@ int main(int argc, char **argv) {
   char *vcf = lancet_vdb_vcf(db, nullptr, cmdline.c_str(), ref.c_str(), date_line.c_str(), lancet_host_sample(H, 0), lancet_host_sample(H, 1));
   if (!vcf) return die("VCF rendering failed");
   fputs(vcf, stdout);
-  fprintf(stderr, "[lancet_gpu] %d windows tiled, %ld assembled on GPU %d, %u variants\n", nwin, done, device, lancet_vdb_size(db));
+  fprintf(stderr, "[lancet_gpu] %d windows tiled, %ld assembled on %zu engine(s), first GPU %d, %u variants\n", nwin, done, engs.size(), devs[0], lancet_vdb_size(db));
   if (timing) fprintf(stderr, "[lancet_gpu] wall %.3f s: input decode + tiling %.3f, window filters + batches %.3f, engine (upload + kernels + results) %.3f (kernels %.3f), VariantDB %.3f\n",
                       now() - t_start, t_tile, t_batch, t_engine, t_kernel / 1000.0, t_vdb);
   lancet_free(vcf);
-  lancet_vdb_destroy(db); lancet_host_close(H); lancet_engine_destroy(eng);
+  lancet_vdb_destroy(db); lancet_host_close(H); for (lancet_engine *e : engs) lancet_engine_destroy(e);
   return 0;
 }

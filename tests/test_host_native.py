@@ -182,10 +182,13 @@ def _body(text):
 @pytest.mark.parametrize("case,region,extra", [("ar_small", "chr22:900-3000", ["--num-threads", "1"]),
                                                ("lr_small", "chr22:800-2700", ["--linked-reads"]),
                                                ("ar_small", "chr22:900-3000", ["--batch-windows", "7"]),
-                                               ("lr_small", "chr22:800-2700", ["--linked-reads", "--batch-windows", "5"])])
+                                               ("lr_small", "chr22:800-2700", ["--linked-reads", "--batch-windows", "5"]),
+                                               ("ar_small", "chr22:900-3000", ["--batch-windows", "3", "--devices", "0,0"]),
+                                               ("lr_small", "chr22:800-2700", ["--linked-reads", "--batch-windows", "4", "--devices", "0,0,0"])])
 def test_lancet_gpu_binary_vcf_is_byte_identical_to_the_reference(case, region, extra):
     """The native command-line program end to end (BAM -> host front end -> engine -> VariantDB -> VCF) on the
-    reference-made fixtures, also with the region cut into several engine batches."""
+    reference-made fixtures, also with the region cut into several engine batches and with the batches going round several
+    engines (here: on the same GPU)."""
     r = subprocess.run([build.BIN, "--tumor", os.path.join(G, f"{case}.tumor.bam"), "--normal", os.path.join(G, f"{case}.normal.bam"),
                         "--ref", os.path.join(G, f"{case}.fa"), "--reg", region, "--date-line", "Sun Sep 27 05:27:00 2026"] + extra,
                        capture_output=True, text=True)
