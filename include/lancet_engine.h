@@ -168,6 +168,16 @@ int lancet_engine_results(lancet_engine *e, const lancet_variant **variants, uin
 int lancet_engine_results_lr(lancet_engine *e, const lancet_variant_lr **lr, const uint32_t **bx_blob, uint32_t *bx_blob_len);
 int lancet_engine_last_timing(lancet_engine *e, float out[2]);
 
+/* ---- the reference's -v stage trace (reference src/Microassembler.cc:87-246, Graph.cc verbose blocks) ----
+ * lancet_engine_set_trace: before an upload, reserve words_per_window 32-bit words of trace events per window (0 = off).
+ * lancet_engine_trace: after a run, evt_len[w] words of window w's events start at evt[w * words_per_window].
+ * lancet_trace_format: those events as the text the reference prints (malloc'd, free with lancet_free); idx1 = the running
+ * number of the window ("== Processing N:"), hdr / chrom / start / end = the window's name and coordinates. */
+int lancet_engine_set_trace(lancet_engine *e, uint32_t words_per_window);
+int lancet_engine_trace(lancet_engine *e, const uint32_t **evt_len, const uint32_t **evt, uint32_t *words_per_window);
+char *lancet_trace_format(const uint32_t *words, uint32_t n_words, int32_t idx1, const char *hdr, const char *chrom,
+                          int32_t start, int32_t end, int32_t dfs_limit);
+
 /* ---- host side of the seam: Variant_t normalisation + VariantDB + VCF ----------
  * reference src/Variant.hh:106-172 (ctor), src/VariantDB.cc:28-91 (addVar), :93-179 (VCF),
  * src/Variant.cc:39-223 (printVCF). */

@@ -7,8 +7,8 @@
 // Beyond the reference's options: --device N | --devices a,b,... (one engine per entry; batches of --batch-windows windows
 // go to the engines in turn while the host prepares the next one; records reach the VariantDB in window order whatever
 // the number of engines).
-// Not offered: --bed, --rg-file, --kmer-recovery, --print-graph, --verbose (the stage trace is printed by the Python
-// front end, lancet_amd/cli.py); --num-threads is accepted and ignored (windows are batched on the GPU).
+// Not offered: --bed, --rg-file, --kmer-recovery, --print-graph; --num-threads is accepted and ignored (windows are
+// batched on the GPU); -v prints the reference's per-window stage trace to stderr.
 #include "../../include/lancet_host.h"
 
 #include <chrono>
@@ -32,7 +32,7 @@ const Opt OPTS[] = {
   {"min-coverage-normal", 'z', 1}, {"max-coverage-normal", 'j', 1}, {"min-phred-fisher", 's', 1},
   {"min-phred-fisher-str", 'E', 1}, {"min-strand-bias", 'f', 1}, {"max-unit-length", 'U', 1}, {"min-report-unit", 'N', 1},
   {"min-report-len", 'Y', 1}, {"dist-from-str", 'D', 1}, {"linked-reads", 'J', 0}, {"primary-alignment-only", 'I', 0},
-  {"XA-tag-filter", 'O', 0}, {"active-region-off", 'W', 0}, {"device", 0, 1}, {"devices", 0, 1}, {"batch-windows", 0, 1}, {"date-line", 0, 1},
+  {"XA-tag-filter", 'O', 0}, {"active-region-off", 'W', 0}, {"verbose", 'v', 0}, {"device", 0, 1}, {"devices", 0, 1}, {"batch-windows", 0, 1}, {"date-line", 0, 1},
 };
 int die(const std::string &m) { fprintf(stderr, "lancet_gpu: %s\n", m.c_str()); return 1; }
 }  // namespace
@@ -41,7 +41,7 @@ int main(int argc, char **argv) {
   std::string tumor, normal, ref, reg, qrange = "!", date_line, devices;
   int min_k = 11, max_k = 101, trim_lowqual = 10, min_base_qual = 17, tip_len = 11, cov_thr = 5, low_cov = 1, dfs_limit = 1000000;
   int max_indel_len = 500, max_mismatch = 2, max_unit_length = 4, min_report_unit = 3, min_report_len = 7, dist_from_str = 1;
-  int device = 0, batch_windows = 32768;
+  int device = 0, batch_windows = 32768, verbose = 0;
   double cov_ratio = 0.01;
   lancet_host_opts ho; lancet_host_opts_default(&ho);
   lancet_filters flt; lancet_filters_default(&flt);
@@ -69,7 +69,7 @@ int main(int argc, char **argv) {
     else if (L == "min-strand-bias") flt.min_strand_bias = (int)atof(v); else if (L == "max-unit-length") max_unit_length = atoi(v);
     else if (L == "min-report-unit") min_report_unit = atoi(v); else if (L == "min-report-len") min_report_len = atoi(v); else if (L == "dist-from-str") dist_from_str = atoi(v);
     else if (L == "linked-reads") ho.linked = 1; else if (L == "primary-alignment-only") ho.primary_alignment_only = 1; else if (L == "XA-tag-filter") ho.xa_filter = 1;
-    else if (L == "active-region-off") ho.active_region = 0; else if (L == "device") device = atoi(v); else if (L == "devices") devices = v; else if (L == "batch-windows") batch_windows = atoi(v);
+    else if (L == "active-region-off") ho.active_region = 0; else if (L == "verbose") verbose = 1; else if (L == "device") device = atoi(v); else if (L == "devices") devices = v; else if (L == "batch-windows") batch_windows = atoi(v);
     else if (L == "date-line") date_line = v;
   }
   if (tumor.empty() || normal.empty() || ref.empty() || reg.empty()) return die("--tumor, --normal, --ref and --reg are required");
@@ -97,6 +97,7 @@ int main(int argc, char **argv) {
     lancet_engine *e = nullptr;
     const int rc = lancet_engine_create(&P, d, &e);
     if (rc != LANCET_OK) return die(std::string("cannot create the MI355X engine on device ") + std::to_string(d) + " (code " + std::to_string(rc) + "): " + (e ? lancet_engine_last_error(e) : "no gfx950 device / HIP runtime"));
+    if (verbose) lancet_engine_set_trace(e, 1u << 17);            // -v: the reference's per-window stage trace, to stderr
     engs.push_back(e);
   }
   char err[512] = "";
@@ -110,8 +111,8 @@ int main(int argc, char **argv) {
   const char *chr_names[1] = {lancet_host_chrom(H)};
   const int step = batch_windows > 0 ? batch_windows : 1;
   const int nchunks = (nwin + step - 1) / step;
-  struct Job { bool have = false; std::vector<lancet_variant> v; std::string blob; std::vector<lancet_variant_lr> lr; std::vector<uint32_t> bx; std::vector<std::string> bxn; };
-  struct Slot { lancet_engine *e = nullptr; std::future<int> fut; int chunk = -1; int nk = 0; std::vector<int32_t> kept; std::vector<std::string> bxn; };
+  struct Job { bool have = false; std::string trace; std::vector<lancet_variant> v; std::string blob; std::vector<lancet_variant_lr> lr; std::vector<uint32_t> bx; std::vector<std::string> bxn; };
+  struct Slot { lancet_engine *e = nullptr; std::future<int> fut; int chunk = -1; int nk = 0; long base = 0; std::vector<int32_t> kept; std::vector<std::string> bxn; };
   std::vector<Job> jobs((size_t)nchunks);
   std::vector<Slot> slots(engs.size());
   for (size_t k = 0; k < engs.size(); ++k) { slots[k].e = engs[k]; slots[k].kept.resize((size_t)step); }
@@ -137,13 +138,24 @@ int main(int argc, char **argv) {
       if (lancet_engine_results_lr(sl.e, &lr, &bxb, &bxl) != LANCET_OK) { fail = std::string("engine: ") + lancet_engine_last_error(sl.e); return false; }
       j.lr.assign(lr, lr + nv); j.bx.assign(bxb, bxb + bxl); j.bxn.swap(sl.bxn);
     }
-    j.have = true; done += sl.nk; sl.chunk = -1;
+    if (verbose) {
+      const uint32_t *elen, *evt; uint32_t wpw = 0;
+      if (lancet_engine_trace(sl.e, &elen, &evt, &wpw) == LANCET_OK && wpw) for (int w = 0; w < sl.nk; ++w) {
+        const char *hdr = lancet_host_window_hdr(H, sl.kept[(size_t)w]);
+        const char *col = strrchr(hdr, ':'); const char *dash = col ? strchr(col, '-') : nullptr;
+        const int start = col ? atoi(col + 1) : 0, end = dash ? atoi(dash + 1) : 0;
+        char *t = lancet_trace_format(evt + (size_t)w * wpw, elen[w], (int32_t)(sl.base + w + 1), hdr, lancet_host_chrom(H), start, end, dfs_limit);
+        if (t) { j.trace += t; lancet_free(t); }
+      }
+    }
+    j.have = true; sl.chunk = -1;
     return true;
   };
   auto flush = [&]() -> bool {
     const double t0 = now();
     while (next_add < nchunks && jobs[(size_t)next_add].have) {
       Job &j = jobs[(size_t)next_add];
+      if (!j.trace.empty()) fputs(j.trace.c_str(), stderr);
       int arc = LANCET_OK;
       if (!j.v.empty()) {
         if (ho.linked) {
@@ -170,7 +182,7 @@ int main(int argc, char **argv) {
     t0 = now();
     if (lancet_engine_upload(sl.e, &B) != LANCET_OK) return die(std::string("engine: ") + lancet_engine_last_error(sl.e));
     t_engine += now() - t0;
-    sl.chunk = c; sl.nk = nk; sl.bxn.clear();
+    sl.chunk = c; sl.nk = nk; sl.base = done; done += nk; sl.bxn.clear();
     if (ho.linked) { uint32_t nbx = 0; const char *const *bxn = lancet_host_bx_names(H, &nbx); for (uint32_t i = 0; i < nbx; ++i) sl.bxn.emplace_back(bxn[i]); }
     lancet_engine *e = sl.e;
     sl.fut = std::async(std::launch::async, [e]() { return lancet_engine_run(e); });

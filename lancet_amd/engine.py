@@ -60,6 +60,8 @@ def lib():
         L.lancet_vdb_vcf.restype = C.c_void_p
         L.lancet_vdb_vcf.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
         L.lancet_free.argtypes = [C.c_void_p]
+        L.lancet_trace_format.restype = C.c_void_p
+        L.lancet_trace_format.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_int32, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32]
         _LIB = L
     return _LIB
 

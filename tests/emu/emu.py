@@ -31,6 +31,9 @@ def lib():
     return _LIB
 
 
+LAST_EVENTS = []
+
+
 def run(batch, params=None, evt_cap: int = 0):
     """Returns (variants sorted by (window, seq), stats, trace text)."""
     L = lib()
@@ -54,8 +57,10 @@ def run(batch, params=None, evt_cap: int = 0):
             lens = np.ctypeslib.as_array(L.lancet_emu_evt_len(h), shape=(batch.n_windows,))
             ev = np.ctypeslib.as_array(L.lancet_emu_evt(h), shape=(batch.n_windows * evt_cap,))
             parts = []
+            LAST_EVENTS.clear()
             for w in range(batch.n_windows):
                 words = ev[w * evt_cap: w * evt_cap + int(lens[w])]
+                LAST_EVENTS.append(words.copy())                       # raw event words per window (for the formatter tests)
                 end = int(batch.ref_start[w]) + int(batch.ref_off[w + 1] - batch.ref_off[w])
                 parts.append(trace.format_window(words, w + 1, batch.hdr[w], batch.chrom[w], int(batch.ref_start[w]), end))
             text = "".join(parts)

@@ -65,3 +65,27 @@ def test_host_variantdb_and_vcf_writer_reproduce_reference_vcf(case, lib):
     assert db.vcf() == gu.golden_vcf(case)
     full = db.vcf(cmdline="lancet --x", reference="ref.fa", date_line="Sun Sep 27 05:27:00 2026\n")
     assert "##fileDate=Sun Sep 27 05:27:00 2026\n##source=lancet 1.1.0" in full and "##cmdline=lancet --x\n##reference=ref.fa\n" in full
+
+
+@pytest.mark.parametrize("name", ["tile30", "lr30", "dups"])
+def test_native_trace_formatter_matches_the_python_one(lib, name):
+    """lancet_trace_format (host C++, what `lancet_gpu -v` prints) against lancet_amd/trace.py -- itself pinned on the
+    reference's -v output by the golden traces -- on the event streams of the emulated kernels: every window, byte for byte."""
+    import numpy as np
+    import golden_util as gu
+    from emu import emu
+    from lancet_amd import trace
+    meta, batch, kept, (min_k, max_k) = gu.case_batch(name)
+    p = abi.default_params(min_k=min_k, max_k=max_k, lr_mode=int(gu.case_lr(meta)))
+    _, _, text = emu.run(batch, p, evt_cap=1 << 17)
+    assert len(emu.LAST_EVENTS) == batch.n_windows and len(text) > 1000
+    got = []
+    for w, words in enumerate(emu.LAST_EVENTS):
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        end = int(batch.ref_start[w]) + int(batch.ref_off[w + 1] - batch.ref_off[w])
+        ptr = lib.lancet_trace_format(words.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), len(words), w + 1, batch.hdr[w].encode(),
+                                      batch.chrom[w].encode(), int(batch.ref_start[w]), end, 1000000)
+        assert ptr
+        got.append(ctypes.string_at(ptr).decode())
+        lib.lancet_free(ptr)
+    assert "".join(got) == text

@@ -227,3 +227,16 @@ def test_native_host_multi_contig_inputs_and_whole_contig_region(tmp_path):
         _same(bt, pb, False)
         assert bt.n_reads > 100 and all(h.startswith(region.split(":")[0] + ":") for h in bt.hdr)
         H.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,region,extra", [("ar_small", "chr22:900-3000", ["--batch-windows", "7"]),
+                                               ("lr_small", "chr22:800-2700", ["--linked-reads", "--devices", "0,0", "--batch-windows", "6"])])
+def test_lancet_gpu_verbose_trace_equals_the_reference_trace(case, region, extra):
+    """`lancet_gpu -v`: the per-window stage trace on stderr (native formatter, windows numbered across engine batches)
+    against the trace of the reference's own -v run on the same BAMs."""
+    r = subprocess.run([build.BIN, "--tumor", os.path.join(G, f"{case}.tumor.bam"), "--normal", os.path.join(G, f"{case}.normal.bam"),
+                        "--ref", os.path.join(G, f"{case}.fa"), "--reg", region, "-v"] + extra, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert gu.digest_trace(r.stderr) == gu.digest_trace(gu.golden_trace(case))
+    assert _body(r.stdout) == gu.golden_vcf(case)
