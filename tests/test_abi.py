@@ -73,7 +73,9 @@ def test_native_trace_formatter_matches_the_python_one(lib, name):
     reference's -v output by the golden traces -- on the event streams of the emulated kernels: every window, byte for byte."""
     import numpy as np
     import golden_util as gu
-    from emu import emu
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import emu
     from lancet_amd import trace
     meta, batch, kept, (min_k, max_k) = gu.case_batch(name)
     p = abi.default_params(min_k=min_k, max_k=max_k, lr_mode=int(gu.case_lr(meta)))
