@@ -218,7 +218,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   DBG("carve measured");
   int slots = e->max_slots;
   if (slots > nw) slots = nw;
-  while (slots > 1 && (size_t)slots * slot_bytes > e->mem_budget) slots /= 2;
+  if ((size_t)slots * slot_bytes > e->mem_budget) slots = (int)std::max<size_t>(1, e->mem_budget / slot_bytes);   // as many as the budget holds
   e->n_slots = slots;
   ENS(e->d_workmem, (size_t)slots * slot_bytes);
   std::vector<Work> works(slots);
