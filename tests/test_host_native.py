@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import bam_writer
+import read_variety
 import golden_util as gu
 from lancet_amd import bamio, build, frontend, host, synth
 
@@ -72,46 +73,7 @@ def test_native_host_batches_equal_the_python_front_end_on_reference_made_bams(c
     H.close()
 
 
-def _decorate(reads, rng, linked):
-    """Tag / flag / CIGAR variety the read filters look at (reference src/Microassembler.cc:498-579, :253-432)."""
-    out = []
-    for r in reads:
-        tags = dict(r.tags)
-        u = rng.random()
-        flag, mapq, cigar, seq, qual = r.flag, r.mapq, r.cigar, r.seq, r.qual
-        if u < 0.04:
-            tags["XT"] = ("A", "R")
-        elif u < 0.08:
-            tags["XT"] = ("A", "U")
-        elif u < 0.12:
-            tags["XA"] = "chr1,+100,100M,1;"
-        elif u < 0.16:
-            tags["XS"] = int(tags.get("AS", 90)) - int(rng.integers(0, 8))
-        elif u < 0.19:
-            flag |= 0x400
-        elif u < 0.22:
-            flag |= 0x100
-        elif u < 0.26:
-            mapq = int(rng.integers(0, 20))
-        elif u < 0.30 and cigar.endswith("M") and cigar[:-1].isdigit() and int(cigar[:-1]) > 20:     # soft clip the head or the tail
-            n, k = int(cigar[:-1]), int(rng.integers(3, 12))
-            cigar = f"{k}S{n - k}M" if rng.random() < 0.5 else f"{n - k}M{k}S"
-            if cigar[0].isdigit() and cigar.split("S")[0].isdigit() and cigar.index("S") < cigar.index("M"):
-                r_pos_shift = k
-            else:
-                r_pos_shift = 0
-            r = synth.SamRead(r.qname, flag, r.rname, r.pos + r_pos_shift, mapq, cigar, seq, qual, tags)
-            tags.pop("MD", None)
-        elif u < 0.32:
-            del tags["AS"]
-        elif u < 0.33:
-            flag |= 0x4
-        if linked and rng.random() < 0.9:
-            tags["BX"] = "ACGT"[int(rng.integers(0, 4))] * 4 + f"{int(rng.integers(0, 40)):04d}-1"
-            if rng.random() < 0.8:
-                tags["HP"] = int(rng.integers(1, 3))
-        out.append(synth.SamRead(r.qname, flag, r.rname, r.pos, mapq, cigar, seq, qual, tags))
-    return sorted(out, key=lambda x: x.pos)
+_decorate = read_variety.decorate
 
 
 @pytest.mark.parametrize("seed,linked", [(0, False), (1, True), (2, False)])
@@ -240,3 +202,53 @@ def test_lancet_gpu_verbose_trace_equals_the_reference_trace(case, region, extra
     assert r.returncode == 0, r.stderr[-2000:]
     assert gu.digest_trace(r.stderr) == gu.digest_trace(gu.golden_trace(case))
     assert _body(r.stdout) == gu.golden_vcf(case)
+
+
+FLT_OPTS = dict(xa_filter=1, primary_alignment_only=1, min_map_qual=20)
+FLT_ARGS = ["--XA-tag-filter", "--primary-alignment-only", "--min-map-qual", "20"]
+
+
+def test_read_filters_against_a_reference_run_with_every_filter_engaged():
+    """`flt_small` (tools/make_filter_golden.py): the reference itself on reads with XT:A:R / XA tags, AS-XS ties, duplicates,
+    secondary alignments, low MAPQ, soft clips and unmapped flags, run with --XA-tag-filter --primary-alignment-only
+    --min-map-qual 20 and active regions on.  The native host side must assemble exactly the reference's windows with
+    exactly its read counts (the reference's -v prints both per window); the oracle on that batch must reproduce the
+    reference's VCF and stage trace."""
+    import re
+    from oracle import oracle
+    from lancet_amd import abi, engine
+    o = host.default_opts(**FLT_OPTS)
+    H = host.NativeHost(os.path.join(G, "flt_small.tumor.bam"), os.path.join(G, "flt_small.normal.bam"), os.path.join(G, "flt_small.fa"))
+    hdrs = H.tile("chr22:900-3300", o)
+    b, idx = H.batch(0, len(hdrs), o)
+    ref_trace = gu.golden_trace("flt_small")
+    want = [(m.group(1), int(m.group(2)), int(m.group(3))) for m in re.finditer(r"== Processing \d+: (\S+) numsequences: (\d+) mapped: (\d+)", ref_trace)]
+    nr = np.diff(b.read_begin.astype(np.int64))
+    got = [(b.hdr[w], int(nr[w]), int(b.mapped[b.read_begin[w]:b.read_begin[w + 1]].sum())) for w in range(b.n_windows)]
+    assert len(want) == 24 and got == want and len(hdrs) == 25
+    assert any(m < n for _, n, m in want)                       # (unmapped-flagged reads are loaded and counted as such)
+    want_hdrs, pb = _python_batch(os.path.join(G, "flt_small.tumor.bam"), os.path.join(G, "flt_small.normal.bam"), os.path.join(G, "flt_small.fa"),
+                                  "chr22:900-3300", o)
+    _same(b, pb, False)
+    p = abi.default_params()
+    ov, ost, otr = oracle.run(b, p, verbose=True)
+    db = engine.VariantDB()
+    db.add_records(ov, ["chr22"])
+    assert db.vcf(sample_normal="NORMAL", sample_tumor="TUMOR") == gu.golden_vcf("flt_small")
+    assert gu.digest_trace(otr) == gu.digest_trace(ref_trace)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    import emu                                                   # the kernel source under the wave emulator, same batch
+    ev, est, etr = emu.run(b, p, evt_cap=1 << 17)
+    assert ev == ov and gu.digest_trace(etr) == gu.digest_trace(ref_trace)
+    H.close()
+
+
+@pytest.mark.gpu
+def test_lancet_gpu_with_every_read_filter_engaged_equals_the_reference():
+    r = subprocess.run([build.BIN, "--tumor", os.path.join(G, "flt_small.tumor.bam"), "--normal", os.path.join(G, "flt_small.normal.bam"),
+                        "--ref", os.path.join(G, "flt_small.fa"), "--reg", "chr22:900-3300", "-v", "--batch-windows", "9"] + FLT_ARGS,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _body(r.stdout) == gu.golden_vcf("flt_small")
+    assert gu.digest_trace(r.stderr) == gu.digest_trace(gu.golden_trace("flt_small"))

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Golden case `flt_small`: the REFERENCE ITSELF (same binary and recipe as tools/make_golden.py) on reads that exercise
+every read filter of extractReads / isActiveRegion -- XT:A:R, XA, AS/XS ties, duplicates, secondary alignments, low MAPQ,
+soft clips, unmapped flags -- with `--XA-tag-filter --primary-alignment-only --min-map-qual 20`, active regions on.
+
+Written to tests/golden/: flt_small.{tumor,normal}.bam + .fa (inputs, made by htslib's test_view), .vcf (expected output),
+.trace.txt (digest of the reference's -v: which windows were assembled, with how many reads, and every stage result),
+.case.txt (the command line, JSON).  Nothing of the reference travels; only these data files do."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import read_variety  # noqa: E402
+from lancet_amd import synth  # noqa: E402
+import make_golden as mg  # noqa: E402
+
+NAME = "flt_small"
+FLAGS = ["--XA-tag-filter", "--primary-alignment-only", "--min-map-qual", "20"]
+REGION = "chr22:900-3300"
+
+if __name__ == "__main__":
+    mg.check_reference_is_unmodified()
+    data = synth.make_tumor_normal(ref_len=4200, cov_t=34, cov_n=28, ref_seed=71, tumor_seed=171, normal_seed=271,
+                                   somatic_every=800, germline_every=600)
+    rng = np.random.default_rng(71)
+    reads = {"tumor": read_variety.decorate(synth.pairs_to_sorted_reads(data["tumor"]), rng),
+             "normal": read_variety.decorate(synth.pairs_to_sorted_reads(data["normal"]), rng)}
+    rname, ref = data["rname"], data["ref"]
+    with tempfile.TemporaryDirectory(prefix="lancet_golden_") as td:
+        fa = os.path.join(td, "ref.fa")
+        synth.write_fasta(fa, rname, ref)
+        bams = {}
+        for sample, rg in (("TUMOR", "tumor"), ("NORMAL", "normal")):
+            sam, bam = os.path.join(td, f"{rg}.sam"), os.path.join(td, f"{rg}.bam")
+            with open(sam, "w") as f:
+                f.write("\n".join(["@HD\tVN:1.6\tSO:coordinate", f"@SQ\tSN:{rname}\tLN:{len(ref)}", f"@RG\tID:{rg}\tSM:{sample}\tPL:ILLUMINA"]
+                                  + [read_variety.sam_line(r) for r in reads[rg]]) + "\n")
+            mg.run([mg.TEST_VIEW, "-b", "-p", bam, sam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            mg.run([mg.BAMTOOLS, "index", "-in", bam])
+            bams[rg] = bam
+        cmd = [mg.REF_BIN, "--tumor", bams["tumor"], "--normal", bams["normal"], "--ref", fa, "--reg", REGION, "--num-threads", "1", "-v"] + FLAGS
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=td)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr[-3000:])
+            raise SystemExit("reference failed")
+        for rg in ("tumor", "normal"):
+            shutil.copy(bams[rg], os.path.join(mg.GOLDEN, f"{NAME}.{rg}.bam"))
+        shutil.copy(fa, os.path.join(mg.GOLDEN, f"{NAME}.fa"))
+    vcf = "".join(l + "\n" for l in r.stdout.splitlines()
+                  if not l.startswith("##fileDate") and not l.startswith("##cmdline") and not l.startswith("##reference"))
+    open(os.path.join(mg.GOLDEN, f"{NAME}.vcf"), "w").write(vcf)
+    open(os.path.join(mg.GOLDEN, f"{NAME}.trace.txt"), "w").write(mg.digest_trace(r.stderr))
+    json.dump({"region": REGION, "flags": FLAGS + ["--active-region-on"],
+               "reference_cmd": " ".join(os.path.basename(c) if c.startswith("/tmp") else c for c in cmd),
+               "n_vcf_records": sum(1 for l in vcf.splitlines() if not l.startswith("#"))},
+              open(os.path.join(mg.GOLDEN, f"{NAME}.case.txt"), "w"), indent=1)
+    print(NAME, sum(1 for l in vcf.splitlines() if not l.startswith("#")), "VCF records;", len(reads["tumor"]), "+", len(reads["normal"]), "reads;",
+          mg.digest_trace(r.stderr).count("== Processing"), "windows assembled")
