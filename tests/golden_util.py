@@ -47,13 +47,37 @@ def load_case(name: str):
     return meta, ref, rname, reads
 
 
+_ENGINE_FLAGS = {   # reference command-line flag -> lancet_params field (reference src/Lancet.cc:655-800, src/Microassembler.cc:726-753)
+    "--min-k": "min_k", "--max-k": "max_k", "--tip-len": "max_tip_len", "--cov-thr": "cov_threshold", "--cov-ratio": "min_cov_ratio",
+    "--low-cov": "low_cov_threshold", "--dfs-limit": "dfs_limit", "--max-indel-len": "max_indel_len", "--max-mismatch": "max_mismatch",
+    "--max-unit-length": "max_unit_len", "--min-report-unit": "min_report_units", "--min-report-len": "min_report_len",
+    "--dist-from-str": "dist_from_str", "--trim-lowqual": "min_qual_trim", "--min-base-qual": "min_qual_call"}
+
+
+def _flag_values(meta):
+    flags = [f for f in meta["flags"] if f not in ("--linked-reads", "--active-region-on")]
+    return {flags[i]: flags[i + 1] for i in range(0, len(flags), 2)}
+
+
 def case_params(meta):
     """reference CLI flags of the case -> (padding, min_k, max_k)."""
-    flags = [f for f in meta["flags"] if f not in ("--linked-reads", "--active-region-on")]
     opt = {"--padding": 250, "--min-k": 11, "--max-k": 101}
-    for i in range(0, len(flags), 2):
-        opt[flags[i]] = int(flags[i + 1])
-    return opt["--padding"], opt["--min-k"], opt["--max-k"]
+    opt.update(_flag_values(meta))
+    return int(opt["--padding"]), int(opt["--min-k"]), int(opt["--max-k"])
+
+
+def params(meta, **over):
+    """lancet_params of the case: reference defaults, the case's graph / STR / quality flags, lr_mode."""
+    from lancet_amd import abi
+    kw = {}
+    for flag, val in _flag_values(meta).items():
+        if flag not in _ENGINE_FLAGS:
+            continue
+        field = _ENGINE_FLAGS[flag]
+        kw[field] = float(val) if field == "min_cov_ratio" else int(val) + (33 if field in ("min_qual_trim", "min_qual_call") else 0)
+    kw["lr_mode"] = int(case_lr(meta))
+    kw.update(over)
+    return abi.default_params(**kw)
 
 
 def case_lr(meta) -> bool:

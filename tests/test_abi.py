@@ -56,7 +56,7 @@ def test_no_cpu_fallback(lib):
 def test_host_variantdb_and_vcf_writer_reproduce_reference_vcf(case, lib):
     meta, batch, kept, (min_k, max_k) = gu.case_batch(case)
     lr = gu.case_lr(meta)
-    records, _, _ = oracle.run(batch, abi.default_params(min_k=min_k, max_k=max_k, lr_mode=int(lr)))
+    records, _, _ = oracle.run(batch, gu.params(meta))
     id2chr = {}
     for c, i in zip(batch.chrom, batch.chr_id):
         id2chr[int(i)] = c

@@ -17,7 +17,7 @@ import emu  # noqa: E402
 @pytest.mark.parametrize("case", gu.CASES)
 def test_emulated_kernels_match_oracle_and_reference_trace(case):
     meta, batch, kept, (min_k, max_k) = gu.case_batch(case)
-    p = abi.default_params(min_k=min_k, max_k=max_k, lr_mode=int(gu.case_lr(meta)))
+    p = gu.params(meta)
     v, st, tr = emu.run(batch, p, evt_cap=1 << 17)
     ov, ost, _ = oracle.run(batch, p)
     assert v == ov

@@ -22,7 +22,7 @@ def _names(batch):
 def test_engine_matches_oracle_and_reference(case):
     meta, batch, kept, (min_k, max_k) = gu.case_batch(case)
     lr = gu.case_lr(meta)                                                     # --linked-reads goldens
-    p = abi.default_params(min_k=min_k, max_k=max_k, lr_mode=int(lr))
+    p = gu.params(meta)
     eng = engine.Engine(p, device=0, trace_words=1 << 17)
     variants, stats = eng.process(batch)
     ov, ostats, _ = oracle.run(batch, p)

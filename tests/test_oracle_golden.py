@@ -18,7 +18,7 @@ from oracle import oracle, vcf_oracle
 def test_oracle_reproduces_reference_vcf_and_trace(case):
     meta, batch, kept, (min_k, max_k) = gu.case_batch(case)
     lr = gu.case_lr(meta)                     # --linked-reads case
-    variants, stats, trace = oracle.run(batch, abi.default_params(min_k=min_k, max_k=max_k, lr_mode=int(lr)), verbose=True)
+    variants, stats, trace = oracle.run(batch, gu.params(meta), verbose=True)
     db = vcf_oracle.VariantDB(lr=lr)
     for rec in variants:                      # replay addVar in window-processing order
         db.add(vcf_oracle.Variant(batch.chrom[rec["window"]], rec, lr=lr, bx_names=batch.bx_names))

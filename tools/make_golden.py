@@ -67,6 +67,12 @@ CASES = {
     "lr_small": (dict(ref_len=3600, cov_t=30, cov_n=26, ref_seed=61, tumor_seed=161, normal_seed=261, linked=True,
                       insert_mean=300.0, insert_sd=40.0, somatic_every=700, germline_every=600), "chr22:800-2700",
                  ["--linked-reads", "--active-region-on"]),
+    # every graph / STR / quality knob of the command line away from its default (they all travel in lancet_params)
+    "knobs": (dict(ref_len=7000, cov_t=45, cov_n=35, ref_seed=81, tumor_seed=181, normal_seed=281, error_rate=0.008, str_fraction=0.12,
+                   somatic_every=600, germline_every=450, read_len=125, insert_mean=330.0, insert_sd=45.0), "chr22:1000-5600",
+              ["--min-k", "13", "--max-k", "75", "--tip-len", "7", "--cov-thr", "8", "--cov-ratio", "0.03", "--low-cov", "2",
+               "--max-indel-len", "120", "--max-mismatch", "1", "--max-unit-length", "3", "--min-report-unit", "2",
+               "--min-report-len", "5", "--dist-from-str", "2", "--trim-lowqual", "12", "--min-base-qual", "20"]),
     "dups": (dict(ref_len=8000, cov_t=40, cov_n=40, ref_seed=5, tumor_seed=15, normal_seed=25, dup_prob=1.0,
                   somatic_every=600, germline_every=500, read_len=100), "chr22:1000-6500", []),
 }
