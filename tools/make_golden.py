@@ -73,6 +73,9 @@ CASES = {
               ["--min-k", "13", "--max-k", "75", "--tip-len", "7", "--cov-thr", "8", "--cov-ratio", "0.03", "--low-cov", "2",
                "--max-indel-len", "120", "--max-mismatch", "1", "--max-unit-length", "3", "--min-report-unit", "2",
                "--min-report-len", "5", "--dist-from-str", "2", "--trim-lowqual", "12", "--min-base-qual", "20"]),
+    # deep coverage: k-mers with far more occurrences than the engine's LDS staging area holds (per-position counts in rounds)
+    "deep200": (dict(ref_len=3400, cov_t=220, cov_n=180, ref_seed=91, tumor_seed=191, normal_seed=291, error_rate=0.006,
+                     somatic_every=500, germline_every=400), "chr22:1200-2100", []),
     "dups": (dict(ref_len=8000, cov_t=40, cov_n=40, ref_seed=5, tumor_seed=15, normal_seed=25, dup_prob=1.0,
                   somatic_every=600, germline_every=500, read_len=100), "chr22:1000-6500", []),
 }
