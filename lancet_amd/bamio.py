@@ -39,7 +39,12 @@ def _tags(buf: bytes, p: int, end: int) -> dict:
         t = chr(buf[p + 2])
         p += 3
         if t == "A":
-            tags[key] = chr(buf[p]); p += 1
+            # What BamAlignment::GetTag(tag, std::string&) of bamtools 2.5.2 hands the reference for a one-character tag
+            # (src/api/BamAlignment.cpp: strlen over the raw tag block): the character AND every byte after it up to the
+            # next NUL -- i.e. the bare character only when the tag is the record's last one.  extractReads compares that
+            # string with "R" (XT:A:R, src/Microassembler.cc:549-559), so the repeat filter fires only then.
+            q = buf.find(b"\0", p, end)
+            tags[key] = buf[p:(q if q >= 0 else end)].decode("latin-1"); p += 1
         elif t in "cCsSiI":
             fmt, n = {"c": ("<b", 1), "C": ("<B", 1), "s": ("<h", 2), "S": ("<H", 2), "i": ("<i", 4), "I": ("<I", 4)}[t]
             tags[key] = struct.unpack_from(fmt, buf, p)[0]; p += n

@@ -223,7 +223,10 @@ bool load_bam(const std::string &path, const std::string &chrom, int32_t lo0, in
       q += 3;
       double num = 0; bool isnum = false; std::string sval; bool isstr = false;
       switch (t) {
-        case 'A': sval.assign(1, (char)b[q]); isstr = true; q += 1; break;
+        case 'A':   // bamtools' GetTag(tag, std::string&) on a one-character tag: strlen over the raw tag block, i.e. the character
+                    // and every byte after it up to the next NUL -- the bare character only when it is the record's last tag
+                    // (src/api/BamAlignment.cpp); extractReads compares that string with "R" (src/Microassembler.cc:549-559)
+          sval.assign((const char *)b + q, strnlen((const char *)b + q, end - q)); isstr = true; q += 1; break;
         case 'c': num = (int8_t)b[q]; isnum = true; q += 1; break;
         case 'C': num = b[q]; isnum = true; q += 1; break;
         case 's': { int16_t v; memcpy(&v, b + q, 2); num = v; isnum = true; q += 2; break; }

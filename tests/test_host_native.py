@@ -204,39 +204,44 @@ def test_lancet_gpu_verbose_trace_equals_the_reference_trace(case, region, extra
     assert _body(r.stdout) == gu.golden_vcf(case)
 
 
-FLT_OPTS = dict(xa_filter=1, primary_alignment_only=1, min_map_qual=20)
-FLT_ARGS = ["--XA-tag-filter", "--primary-alignment-only", "--min-map-qual", "20"]
+FLT_CASES = {   # name: (region, host options, reference flags, linked)
+    "flt_small": ("chr22:900-3300", dict(xa_filter=1, primary_alignment_only=1, min_map_qual=20),
+                  ["--XA-tag-filter", "--primary-alignment-only", "--min-map-qual", "20"], False),
+    "lrflt_small": ("chr22:800-2900", dict(primary_alignment_only=1, linked=1), ["--linked-reads", "--primary-alignment-only"], True),
+}
 
 
-def test_read_filters_against_a_reference_run_with_every_filter_engaged():
-    """`flt_small` (tools/make_filter_golden.py): the reference itself on reads with XT:A:R / XA tags, AS-XS ties, duplicates,
-    secondary alignments, low MAPQ, soft clips and unmapped flags, run with --XA-tag-filter --primary-alignment-only
-    --min-map-qual 20 and active regions on.  The native host side must assemble exactly the reference's windows with
-    exactly its read counts (the reference's -v prints both per window); the oracle on that batch must reproduce the
-    reference's VCF and stage trace."""
+@pytest.mark.parametrize("case", sorted(FLT_CASES))
+def test_read_filters_against_a_reference_run_with_the_filters_engaged(case):
+    """`flt_small` / `lrflt_small` (tools/make_filter_golden.py): the reference itself on reads with XT:A:R / XA tags, AS-XS
+    ties, duplicates, secondary alignments, low MAPQ, soft clips and unmapped flags (and, linked, BX / HP tags on most but
+    not all reads), run with its read-filter options and active regions on.  The native host side must assemble exactly
+    the reference's windows with exactly its read counts (the reference's -v prints both per window); the oracle and the
+    emulated kernels on that batch must reproduce the reference's VCF and stage trace."""
     import re
+    import sys
     from oracle import oracle
     from lancet_amd import abi, engine
-    o = host.default_opts(**FLT_OPTS)
-    H = host.NativeHost(os.path.join(G, "flt_small.tumor.bam"), os.path.join(G, "flt_small.normal.bam"), os.path.join(G, "flt_small.fa"))
-    hdrs = H.tile("chr22:900-3300", o)
+    region, opts, _, linked = FLT_CASES[case]
+    paths = [os.path.join(G, f"{case}.tumor.bam"), os.path.join(G, f"{case}.normal.bam"), os.path.join(G, f"{case}.fa")]
+    o = host.default_opts(**opts)
+    H = host.NativeHost(*paths)
+    hdrs = H.tile(region, o)
     b, idx = H.batch(0, len(hdrs), o)
-    ref_trace = gu.golden_trace("flt_small")
+    ref_trace = gu.golden_trace(case)
     want = [(m.group(1), int(m.group(2)), int(m.group(3))) for m in re.finditer(r"== Processing \d+: (\S+) numsequences: (\d+) mapped: (\d+)", ref_trace)]
     nr = np.diff(b.read_begin.astype(np.int64))
     got = [(b.hdr[w], int(nr[w]), int(b.mapped[b.read_begin[w]:b.read_begin[w + 1]].sum())) for w in range(b.n_windows)]
-    assert len(want) == 24 and got == want and len(hdrs) == 25
+    assert len(want) > 15 and got == want and len(hdrs) >= len(want)
     assert any(m < n for _, n, m in want)                       # (unmapped-flagged reads are loaded and counted as such)
-    want_hdrs, pb = _python_batch(os.path.join(G, "flt_small.tumor.bam"), os.path.join(G, "flt_small.normal.bam"), os.path.join(G, "flt_small.fa"),
-                                  "chr22:900-3300", o)
-    _same(b, pb, False)
-    p = abi.default_params()
+    want_hdrs, pb = _python_batch(*paths, region, o)
+    _same(b, pb, linked)
+    p = abi.default_params(lr_mode=int(linked))
     ov, ost, otr = oracle.run(b, p, verbose=True)
     db = engine.VariantDB()
-    db.add_records(ov, ["chr22"])
-    assert db.vcf(sample_normal="NORMAL", sample_tumor="TUMOR") == gu.golden_vcf("flt_small")
+    db.add_records(ov, ["chr22"], bx_names=b.bx_names if linked else None)
+    assert db.vcf(sample_normal="NORMAL", sample_tumor="TUMOR") == gu.golden_vcf(case)
     assert gu.digest_trace(otr) == gu.digest_trace(ref_trace)
-    import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
     import emu                                                   # the kernel source under the wave emulator, same batch
     ev, est, etr = emu.run(b, p, evt_cap=1 << 17)
@@ -245,10 +250,12 @@ def test_read_filters_against_a_reference_run_with_every_filter_engaged():
 
 
 @pytest.mark.gpu
-def test_lancet_gpu_with_every_read_filter_engaged_equals_the_reference():
-    r = subprocess.run([build.BIN, "--tumor", os.path.join(G, "flt_small.tumor.bam"), "--normal", os.path.join(G, "flt_small.normal.bam"),
-                        "--ref", os.path.join(G, "flt_small.fa"), "--reg", "chr22:900-3300", "-v", "--batch-windows", "9"] + FLT_ARGS,
+@pytest.mark.parametrize("case", sorted(FLT_CASES))
+def test_lancet_gpu_with_the_read_filters_engaged_equals_the_reference(case):
+    region, _, args, _ = FLT_CASES[case]
+    r = subprocess.run([build.BIN, "--tumor", os.path.join(G, f"{case}.tumor.bam"), "--normal", os.path.join(G, f"{case}.normal.bam"),
+                        "--ref", os.path.join(G, f"{case}.fa"), "--reg", region, "-v", "--batch-windows", "9"] + args,
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert _body(r.stdout) == gu.golden_vcf("flt_small")
-    assert gu.digest_trace(r.stderr) == gu.digest_trace(gu.golden_trace("flt_small"))
+    assert _body(r.stdout) == gu.golden_vcf(case)
+    assert gu.digest_trace(r.stderr) == gu.digest_trace(gu.golden_trace(case))

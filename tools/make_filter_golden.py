@@ -21,17 +21,22 @@ import read_variety  # noqa: E402
 from lancet_amd import synth  # noqa: E402
 import make_golden as mg  # noqa: E402
 
-NAME = "flt_small"
-FLAGS = ["--XA-tag-filter", "--primary-alignment-only", "--min-map-qual", "20"]
-REGION = "chr22:900-3300"
+CASES = {
+    "flt_small": (dict(ref_len=4200, cov_t=34, cov_n=28, ref_seed=71, tumor_seed=171, normal_seed=271, somatic_every=800, germline_every=600),
+                  False, ["--XA-tag-filter", "--primary-alignment-only", "--min-map-qual", "20"], "chr22:900-3300"),
+    # --linked-reads --primary-alignment-only on BX/HP-tagged reads (some without barcode / haplotype)
+    "lrflt_small": (dict(ref_len=3800, cov_t=32, cov_n=28, ref_seed=73, tumor_seed=173, normal_seed=273, somatic_every=700, germline_every=500,
+                         insert_mean=280.0, insert_sd=40.0), True, ["--linked-reads", "--primary-alignment-only"], "chr22:800-2900"),
+}
 
 if __name__ == "__main__":
-    mg.check_reference_is_unmodified()
-    data = synth.make_tumor_normal(ref_len=4200, cov_t=34, cov_n=28, ref_seed=71, tumor_seed=171, normal_seed=271,
-                                   somatic_every=800, germline_every=600)
+  mg.check_reference_is_unmodified()
+  for NAME in (sys.argv[1:] or list(CASES)):
+    kwargs, linked, FLAGS, REGION = CASES[NAME]
+    data = synth.make_tumor_normal(**kwargs)
     rng = np.random.default_rng(71)
-    reads = {"tumor": read_variety.decorate(synth.pairs_to_sorted_reads(data["tumor"]), rng),
-             "normal": read_variety.decorate(synth.pairs_to_sorted_reads(data["normal"]), rng)}
+    reads = {"tumor": read_variety.decorate(synth.pairs_to_sorted_reads(data["tumor"]), rng, linked),
+             "normal": read_variety.decorate(synth.pairs_to_sorted_reads(data["normal"]), rng, linked)}
     rname, ref = data["rname"], data["ref"]
     with tempfile.TemporaryDirectory(prefix="lancet_golden_") as td:
         fa = os.path.join(td, "ref.fa")
