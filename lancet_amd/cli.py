@@ -90,7 +90,9 @@ def run(argv: Optional[List[str]] = None, out=None, date_line: Optional[str] = N
     tumor = [r for r in tumor if r.rname == chrom]
     normal = [r for r in normal if r.rname == chrom]
     windows = frontend.tile_region(contigs[chrom], chrom, args.reg, padding=args.padding, window_size=args.window_size)
-    fp = frontend.ReadFilterParams(min_map_qual=args.min_map_qual, max_delta_as_xs=args.max_as_xs_diff,
+    # --max-as-xs-diff is accepted and without effect, as in the reference: its main() parses -Z but never hands the value to the
+    # assemblers (src/Lancet.cc:865-918 lacks the MAX_DELTA_AS_XS line of :496); the AS/XS filter always uses the default 5
+    fp = frontend.ReadFilterParams(min_map_qual=args.min_map_qual, max_delta_as_xs=5,
                                    primary_alignment_only=args.primary_alignment_only, xa_filter=args.xa_filter,
                                    max_avg_cov=args.max_avg_cov)
 

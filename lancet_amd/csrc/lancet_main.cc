@@ -57,7 +57,8 @@ int main(int argc, char **argv) {
     if (L == "tumor") tumor = v; else if (L == "normal") normal = v; else if (L == "ref") ref = v; else if (L == "reg") reg = v;
     else if (L == "min-k") min_k = atoi(v); else if (L == "max-k") max_k = atoi(v); else if (L == "trim-lowqual") trim_lowqual = atoi(v);
     else if (L == "min-base-qual") min_base_qual = atoi(v); else if (L == "quality-range") qrange = v; else if (L == "min-map-qual") ho.min_map_qual = atoi(v);
-    else if (L == "max-as-xs-diff") ho.max_delta_as_xs = atoi(v); else if (L == "tip-len") tip_len = atoi(v); else if (L == "cov-thr") cov_thr = atoi(v);
+    else if (L == "max-as-xs-diff") { /* accepted and without effect, as in the reference: its main() parses -Z but never hands it to the
+                                         assemblers (src/Lancet.cc:865-918 lacks the MAX_DELTA_AS_XS line of :496), so the filter always uses 5 */ } else if (L == "tip-len") tip_len = atoi(v); else if (L == "cov-thr") cov_thr = atoi(v);
     else if (L == "cov-ratio") cov_ratio = atof(v); else if (L == "low-cov") low_cov = atoi(v); else if (L == "max-avg-cov") ho.max_avg_cov = atoi(v);
     else if (L == "window-size") ho.window_size = atoi(v); else if (L == "padding") ho.padding = atoi(v); else if (L == "dfs-limit") dfs_limit = atoi(v);
     else if (L == "max-indel-len") max_indel_len = atoi(v); else if (L == "max-mismatch") max_mismatch = atoi(v); else if (L == "num-threads") {}

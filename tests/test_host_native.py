@@ -259,3 +259,43 @@ def test_lancet_gpu_with_the_read_filters_engaged_equals_the_reference(case):
     assert r.returncode == 0, r.stderr[-2000:]
     assert _body(r.stdout) == gu.golden_vcf(case)
     assert gu.digest_trace(r.stderr) == gu.digest_trace(gu.golden_trace(case))
+
+
+# reference option -> lancet_host_opts field as the command-line programs map them (lancet_main.cc / cli.py); --max-as-xs-diff
+# maps to nothing: the reference's main() parses it and never hands it to the assemblers (src/Lancet.cc:865-918 vs :496)
+_OPT_MAP = {"--max-avg-cov": ("max_avg_cov", int), "--min-map-qual": ("min_map_qual", int), "--window-size": ("window_size", int),
+            "--padding": ("padding", int), "--min-alt-count-tumor": ("min_evidence", int), "--min-base-qual": ("min_qual_call", lambda v: int(v) + 33),
+            "--max-as-xs-diff": (None, int), "--quality-range": (None, str)}
+_OPT_FLAGS = {"--active-region-off": ("active_region", 0), "--XA-tag-filter": ("xa_filter", 1), "--primary-alignment-only": ("primary_alignment_only", 1)}
+
+
+def test_window_and_read_selection_under_the_reference_s_options():
+    """tests/golden/flt_small.options.txt (tools/make_option_goldens.py): for fifteen option sets, the windows the reference
+    assembled and its read counts per window, from its own -v.  The native host side, given the same options, must select
+    the same windows with the same reads -- tiling (--window-size, --padding), coverage cut-off, MAPQ, active-region
+    thresholds (--min-alt-count-tumor, --min-base-qual), XA / primary-alignment filters; and --max-as-xs-diff changes
+    nothing, as in the reference."""
+    import json
+    spec = json.load(open(os.path.join(G, "flt_small.options.txt")))
+    paths = [os.path.join(G, "flt_small.tumor.bam"), os.path.join(G, "flt_small.normal.bam"), os.path.join(G, "flt_small.fa")]
+    assert len(spec["option_sets"]) >= 15
+    for optstr, want in spec["option_sets"].items():
+        toks, kw, i = optstr.split(), {}, 0
+        while i < len(toks):
+            if toks[i] in _OPT_FLAGS:
+                kw[_OPT_FLAGS[toks[i]][0]] = _OPT_FLAGS[toks[i]][1]; i += 1
+            else:
+                field, conv = _OPT_MAP[toks[i]]
+                if field:
+                    kw[field] = conv(toks[i + 1])
+                i += 2
+        o = host.default_opts(**kw)
+        H = host.NativeHost(*paths)
+        hdrs = H.tile(spec["region"], o)
+        b, idx = H.batch(0, len(hdrs), o)
+        nr = np.diff(b.read_begin.astype(np.int64))
+        got = [f"{b.hdr[w]} {int(nr[w])} {int(b.mapped[b.read_begin[w]:b.read_begin[w + 1]].sum())}" for w in range(b.n_windows)]
+        assert got == want, optstr
+        H.close()
+    sets = spec["option_sets"]
+    assert sets["--max-as-xs-diff 2"] == sets[""] == sets["--max-as-xs-diff 9"] and sets["--min-map-qual 5"] != sets[""]
