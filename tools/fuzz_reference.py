@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Differential run against the REFERENCE ITSELF on random synthetic cases (this container only; the binary of
+tools/make_golden.py): for each seed a random configuration (coverages, error rate, read length, insert size, STR / low
+complexity content, variant density, duplications, k range, linked reads) goes through the reference and through the
+oracle and the emulated kernels; VCF and -v digest must agree.  A case that does not is kept under /tmp for a golden.
+
+    python tools/fuzz_reference.py [first_seed] [n]"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+import make_golden as mg  # noqa: E402
+import golden_util as gu  # noqa: E402
+import emu  # noqa: E402
+from oracle import oracle, vcf_oracle  # noqa: E402
+
+
+def random_case(seed):
+    rng = np.random.default_rng(seed)
+    linked = rng.random() < 0.25
+    kw = dict(ref_len=int(rng.integers(3200, 5200)), cov_t=float(rng.choice([18, 30, 45, 70, 110])), cov_n=float(rng.choice([15, 28, 40, 60])),
+              ref_seed=1000 + seed, tumor_seed=2000 + seed, normal_seed=3000 + seed, error_rate=float(rng.choice([0.0, 0.003, 0.008, 0.015])),
+              read_len=int(rng.choice([76, 100, 125, 150])), insert_mean=float(rng.choice([190, 260, 330, 420])), insert_sd=float(rng.choice([20, 40, 60])),
+              somatic_every=int(rng.choice([300, 600, 1200])), germline_every=int(rng.choice([250, 500, 900])),
+              str_fraction=float(rng.choice([0.0, 0.0, 0.1, 0.3])), lowcomplex_fraction=float(rng.choice([0.0, 0.0, 0.05])),
+              dup_prob=float(rng.choice([0.0, 0.0, 0.5, 1.0])))
+    if linked:
+        kw["linked"] = True
+    flags = ["--linked-reads"] if linked else []
+    if rng.random() < 0.4:
+        lo = int(rng.choice([11, 13, 17, 21])); hi = int(rng.choice([35, 61, 85, 101]))
+        flags += ["--min-k", str(lo), "--max-k", str(hi)]
+    if rng.random() < 0.3:
+        flags += ["--max-mismatch", str(int(rng.integers(0, 4)))]
+    if rng.random() < 0.3:
+        flags += ["--cov-thr", str(int(rng.integers(2, 12))), "--low-cov", str(int(rng.integers(0, 4)))]
+    if rng.random() < 0.3:
+        flags += ["--tip-len", str(int(rng.integers(3, 20)))]
+    if rng.random() < 0.2:
+        flags += ["--max-indel-len", str(int(rng.integers(20, 300)))]
+    a = int(rng.integers(700, 1200)); b = a + int(rng.integers(900, 2200))
+    return kw, f"chr22:{a}-{min(b, kw['ref_len'] - 400)}", flags
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    mg.check_reference_is_unmodified()
+    bad = []
+    for seed in range(first, first + n):
+        kw, region, flags = random_case(seed)
+        name = f"fz{seed}"
+        td = tempfile.mkdtemp(prefix=f"lancet_fuzz_{seed}_")
+        mg.GOLDEN = td; mg.CASES[name] = (kw, region, flags)
+        try:
+            mg.make_case(name)
+        except SystemExit as e:
+            print(name, "reference failed:", e); continue
+        gu.GOLDEN = td; gu.case_batch.cache_clear()
+        meta, batch, kept, _ = gu.case_batch(name)
+        if batch.n_windows == 0:
+            print(name, 'no window left after the reference-repeat test; skipped'); continue
+        p = gu.params(meta)
+        lr = gu.case_lr(meta)
+        ov, ost, otr = oracle.run(batch, p, verbose=True)
+        db = vcf_oracle.VariantDB(lr=lr)
+        for rec in ov:
+            db.add(vcf_oracle.Variant(batch.chrom[rec["window"]], rec, lr=lr, bx_names=batch.bx_names))
+        ok_vcf = db.vcf() == gu.golden_vcf(name)
+        ok_tr = gu.digest_trace(otr) == gu.golden_trace(name)
+        ev, est, etr = emu.run(batch, p, evt_cap=1 << 18)
+        ok_emu = ev == ov and gu.digest_trace(etr) == gu.digest_trace(otr) and all(s["status"] >= 0 for s in est)
+        status = "ok" if (ok_vcf and ok_tr and ok_emu) else f"MISMATCH vcf={ok_vcf} trace={ok_tr} emu={ok_emu}"
+        print(f"{name}: {batch.n_windows} windows, {len(ov)} records, flags {flags} cov {kw['cov_t']}/{kw['cov_n']} err {kw['error_rate']} L {kw['read_len']}: {status}  [{td}]")
+        sys.stdout.flush()
+        if status != "ok":
+            bad.append((name, td))
+    print("mismatches:", bad)
+
+
+if __name__ == "__main__":
+    main()
