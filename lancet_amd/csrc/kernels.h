@@ -104,7 +104,11 @@ static __shared__ Ctx lc_ctx;
 #endif
 
 
+#ifdef LANCET_WAVE_EMU   /* (emulator build: LANCET_OVF_DEBUG=1 names the limit that was hit) */
+#define OVF(c) do { LC_SREF(c).overflow = 1; if (getenv("LANCET_OVF_DEBUG")) fprintf(stderr, "[emu] work-space limit hit at kernels.h:%d\n", __LINE__); } while (0)
+#else
 #define OVF(c) do { LC_SREF(c).overflow = 1; } while (0)
+#endif
 // profiling only (EngineCaps::debug_stop): abandon the window after a phase marker, as an overflow
 #define STOP_SET(c, id) do { if (LC_CTX(c).C->debug_stop == (uint32_t)(id)) { WG_LANE0 { OVF(c); } } } while (0)
 #define STOP_RET(c, id) do { if (LC_CTX(c).C->debug_stop == (uint32_t)(id)) { WG_LANE0 { OVF(c); } return; } } while (0)
@@ -634,7 +638,7 @@ DEVNI void build_items(Ctx &c) {
       const int r = (int)(_i0 & 0xFFFFu), _b0 = (int)(_i0 >> 16), _e = (int)(_i1 & 0xFFFFu) - _tlo; \
       uint32_t rinfo, bw, gw; int tlen; bool isref; \
       read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref); \
-      const int nk = tlen - (S).K + 1; \
+      const int nk = tlen - (S).K > 0 ? tlen - (S).K + 1 : 0;   /* a read of exactly K bases has no k-mer: loadSequence needs len > K (Graph.cc:121-124), and occ_base[] allots it no occurrence */ \
       const int pbeg = _b0, pend = (_b0 + (int)(_i1 >> 16) < nk) ? _b0 + (int)(_i1 >> 16) : nk; \
       (void)_e; (void)_span; \
       if (pend <= pbeg) continue;

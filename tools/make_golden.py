@@ -76,6 +76,11 @@ CASES = {
     # deep coverage: k-mers with far more occurrences than the engine's LDS staging area holds (per-position counts in rounds)
     "deep200": (dict(ref_len=3400, cov_t=220, cov_n=180, ref_seed=91, tumor_seed=191, normal_seed=291, error_rate=0.006,
                      somatic_every=500, germline_every=400), "chr22:1200-2100", []),
+    # found by tools/fuzz_reference.py (seed 32): k climbs to 99 on 100-base reads, some of which are trimmed to exactly k bases
+    # (a read needs more than k bases to contribute a k-mer); linked reads, duplications, STR-rich
+    "len_eq_k": (dict(ref_len=4918, cov_t=45.0, cov_n=28.0, ref_seed=1032, tumor_seed=2032, normal_seed=3032, error_rate=0.003, read_len=100,
+                      insert_mean=260.0, insert_sd=40.0, somatic_every=1200, germline_every=500, str_fraction=0.3, lowcomplex_fraction=0.05,
+                      dup_prob=1.0, linked=True), "chr22:969-2650", ["--linked-reads"]),
     "dups": (dict(ref_len=8000, cov_t=40, cov_n=40, ref_seed=5, tumor_seed=15, normal_seed=25, dup_prob=1.0,
                   somatic_every=600, germline_every=500, read_len=100), "chr22:1000-6500", []),
 }
