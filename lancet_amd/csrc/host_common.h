@@ -53,7 +53,10 @@ static inline EngineCaps lc_caps_for_batch(const lancet_window_batch *b, const l
   } else {
     c.surv_cap = nodes < 16384 ? nodes : 16384;
     c.qv_cap = c.surv_cap * maxk;
-    c.queue_cap = 65536;
+    // Graph_t::bfs keeps whole partial paths in its FIFO until DFS_LIMIT dequeues (reference src/Graph.cc:1299-1425); every
+    // dequeue enqueues at most the node's out-degree (a few after compaction).  The worst-case tier holds 4 entries per
+    // permitted dequeue, capped at 4 Mi entries (96 MB per slot); beyond that the window reports an overflow.
+    { uint64_t q = 4ull * (uint64_t)(p->dfs_limit > 0 ? p->dfs_limit : 1000000) + 4096; if (q < 65536) q = 65536; if (q > (4ull << 20)) q = 4ull << 20; c.queue_cap = (uint32_t)q; }
   }
   c.seq_cap = 3 * c.qv_cap + 65536;
   c.path_cap = LC_MAXW + (uint32_t)p->max_indel_len + 256;
