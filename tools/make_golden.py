@@ -81,6 +81,11 @@ CASES = {
     "len_eq_k": (dict(ref_len=4918, cov_t=45.0, cov_n=28.0, ref_seed=1032, tumor_seed=2032, normal_seed=3032, error_rate=0.003, read_len=100,
                       insert_mean=260.0, insert_sd=40.0, somatic_every=1200, germline_every=500, str_fraction=0.3, lowcomplex_fraction=0.05,
                       dup_prob=1.0, linked=True), "chr22:969-2650", ["--linked-reads"]),
+    # found by tools/fuzz_reference.py (seed 102): --low-cov 0 keeps every sequencing-error k-mer, the path search enumerates tens
+    # of thousands of partial paths per window (the worst-case tier's FIFO is sized from --dfs-limit); linked reads
+    "bushy": (dict(ref_len=4284, cov_t=45.0, cov_n=15.0, ref_seed=1102, tumor_seed=2102, normal_seed=3102, error_rate=0.015, read_len=100,
+                   insert_mean=260.0, insert_sd=20.0, somatic_every=1200, germline_every=500, dup_prob=1.0, linked=True), "chr22:1190-2791",
+              ["--linked-reads", "--cov-thr", "3", "--low-cov", "0"]),
     "dups": (dict(ref_len=8000, cov_t=40, cov_n=40, ref_seed=5, tumor_seed=15, normal_seed=25, dup_prob=1.0,
                   somatic_every=600, germline_every=500, read_len=100), "chr22:1000-6500", []),
 }
