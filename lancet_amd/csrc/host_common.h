@@ -43,7 +43,7 @@ static inline EngineCaps lc_caps_for_batch(const lancet_window_batch *b, const l
   c.node_cap = nodes;
   c.table_cap = lc_pow2_ge(2 * nodes);
   c.bucket_cap = lc_bucket_cap_for(nodes);
-  c.special_cap = 64;
+  c.special_cap = tier == 1 ? 64u : 4096u;     /* source + sink per component that touches the reference, per build */
   uint32_t maxk = (uint32_t)(p->max_k > 0 ? p->max_k : 101);
   c.max_k = maxk;
   if (tier == 1) {

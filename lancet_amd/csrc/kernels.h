@@ -2128,8 +2128,12 @@ DEVNI void mark_ref_ends(Ctx &c, int comp) {
     // the scans over the reference offsets ran in mark_ref_scan (same predicates, same outcome order)
     if (S.mr_src >= 0 && S.mr_ambs) evt(c, EV_AMBIG_SRC);
     else if (S.mr_src < 0) evt(c, EV_NOMATCH_SRC);
-    else if (S.mr_ambk) evt(c, EV_AMBIG_SNK);
-    else if (S.mr_snk < 0) evt(c, EV_NOMATCH_SNK);
+    else if (S.mr_ambk || S.mr_snk < 0) {
+      // the reference has its source_m pointing at the matching k-mer by now and leaves it there (src/Graph.cc:2060-2138):
+      // nothing is searched without a sink, but countRefPath still reports (" Found 0 on ref path")
+      evt(c, S.mr_ambk ? EV_AMBIG_SNK : EV_NOMATCH_SNK);
+      S.source = W.occ[W.occ_base[S.R - 1] + (uint32_t)S.mr_src] & 0x3FFFFFFFu;
+    }
     else {
       const uint32_t ro = W.occ_base[S.R - 1];
       const int src_off = S.mr_src, snk_off = S.mr_snk;
