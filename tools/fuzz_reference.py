@@ -42,6 +42,11 @@ def random_case(seed):
         flags += ["--tip-len", str(int(rng.integers(3, 20)))]
     if rng.random() < 0.2:
         flags += ["--max-indel-len", str(int(rng.integers(20, 300)))]
+    if seed >= 1000:        # (second generation of cases: N runs in the contig, even k, short reads against large k)
+        if rng.random() < 0.3:
+            kw["n_runs"] = tuple((int(rng.integers(900, kw["ref_len"] - 900)), int(rng.choice([1, 2, 5, 20, 60]))) for _ in range(int(rng.integers(1, 5))))
+        if rng.random() < 0.25:
+            lo = int(rng.choice([10, 12, 16, 20])); flags = [f for f in flags]; flags += ["--min-k", str(lo)] if "--min-k" not in flags else []
     a = int(rng.integers(700, 1200)); b = a + int(rng.integers(900, 2200))
     return kw, f"chr22:{a}-{min(b, kw['ref_len'] - 400)}", flags
 
