@@ -50,6 +50,8 @@ def test_no_cpu_fallback(lib):
     assert lib.lancet_engine_create(ctypes.byref(p), 0, ctypes.byref(h)) == -4      # LANCET_E_UNSUPPORTED (k > 127)
     p = abi.default_params(lr_mode=1)
     assert lib.lancet_engine_create(ctypes.byref(p), 0, ctypes.byref(h)) == -2      # LANCET_E_NO_DEVICE: no CPU path in any mode
+    p = abi.default_params(min_k=12)
+    assert lib.lancet_engine_create(ctypes.byref(p), 0, ctypes.byref(h)) == -4      # even k (palindromic k-mers) is refused, not approximated
 
 
 @pytest.mark.parametrize("case", gu.CASES)

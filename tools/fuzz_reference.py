@@ -42,7 +42,7 @@ def random_case(seed):
         flags += ["--tip-len", str(int(rng.integers(3, 20)))]
     if rng.random() < 0.2:
         flags += ["--max-indel-len", str(int(rng.integers(20, 300)))]
-    if seed >= 1000:        # (second generation of cases: N runs in the contig, even k, short reads against large k)
+    if seed >= 1000:        # (second generation of cases: N runs in the contig; even k -- known not to be bit-exact and refused by the engine)
         if rng.random() < 0.3:
             kw["n_runs"] = tuple((int(rng.integers(900, kw["ref_len"] - 900)), int(rng.choice([1, 2, 5, 20, 60]))) for _ in range(int(rng.integers(1, 5))))
         if rng.random() < 0.25:
