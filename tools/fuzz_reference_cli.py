@@ -48,6 +48,21 @@ def main():
         if rng.random() < 0.4: opts.append("--primary-alignment-only"); kw["primary_alignment_only"] = 1
         if rng.random() < 0.3: opts.append("--active-region-off"); kw["active_region"] = 0
         if rng.random() < 0.2: opts.extend(["--max-as-xs-diff", str(int(rng.integers(0, 12)))])        # (inert in the reference's main())
+        # VariantDB / VCF filter thresholds (reference src/Variant.hh:42-56; they only shape the FILTER column and the header)
+        flt = {}
+        def addf(flag, field, val):
+            opts.extend([flag, str(val)]); flt[field] = val
+        if "min_evidence" in kw: flt["min_alt_cnt_tumor"] = kw["min_evidence"]
+        if rng.random() < 0.3: addf("--max-alt-count-normal", "max_alt_cnt_normal", int(rng.integers(0, 4)))
+        if rng.random() < 0.3: addf("--min-vaf-tumor", "min_vaf_tumor", round(float(rng.choice([0.01, 0.1, 0.25])), 2))
+        if rng.random() < 0.3: addf("--max-vaf-normal", "max_vaf_normal", round(float(rng.choice([0.0, 0.05, 0.2])), 2))
+        if rng.random() < 0.3: addf("--min-coverage-tumor", "min_cov_tumor", int(rng.integers(2, 30)))
+        if rng.random() < 0.3: addf("--min-coverage-normal", "min_cov_normal", int(rng.integers(2, 30)))
+        if rng.random() < 0.2: addf("--max-coverage-tumor", "max_cov_tumor", int(rng.integers(20, 200)))
+        if rng.random() < 0.2: addf("--max-coverage-normal", "max_cov_normal", int(rng.integers(20, 200)))
+        if rng.random() < 0.3: addf("--min-phred-fisher", "min_phred_fisher", round(float(rng.choice([1.0, 5.0, 12.5])), 1))
+        if rng.random() < 0.3: addf("--min-phred-fisher-str", "min_phred_fisher_str", round(float(rng.choice([10.0, 25.0, 40.0])), 1))
+        if rng.random() < 0.3: addf("--min-strand-bias", "min_strand_bias", int(rng.integers(0, 4)))
         L = len(data["ref"]); a = int(rng.integers(500, 1000)); region = f"{data['rname']}:{a}-{min(L - 300, a + int(rng.integers(800, 2500)))}"
         if rng.random() < 0.1: region = data["rname"]
         with tempfile.TemporaryDirectory(prefix=f"lancet_fzcli_{seed}_") as td:
@@ -71,9 +86,23 @@ def main():
             b, idx = H.batch(0, len(hdrs), o)
             nr = np.diff(b.read_begin.astype(np.int64))
             got = [f"{b.hdr[w]} {int(nr[w])} {int(b.mapped[b.read_begin[w]:b.read_begin[w + 1]].sum())}" for w in range(b.n_windows)]
-            H.close()
             ok = got == want
-            print(f"cli{seed}: {region} {' '.join(opts)}: reference {len(want)} windows, native {len(got)}: {'ok' if ok else 'MISMATCH'}")
+            vcf_ok = True
+            if ok and b.n_windows and seed % 2 == 0:          # every other case: the whole host path below the seam as well
+                import ctypes as C
+                from oracle import oracle
+                from lancet_amd import abi, engine
+                p = abi.default_params(lr_mode=int(linked), max_k=kw.get("max_k", 101), min_qual_call=kw.get("min_qual_call", 17 + 33))
+                ov, _, _ = oracle.run(b, p)
+                f = abi.LancetFilters(); engine.lib().lancet_filters_default(C.byref(f))
+                for field, val in flt.items(): setattr(f, field, val)
+                db = engine.VariantDB(f)
+                db.add_records(ov, [data["rname"]], bx_names=b.bx_names if linked else None)
+                body = lambda t: "".join(l + "\n" for l in t.splitlines() if not l.startswith(("##fileDate", "##cmdline", "##reference")))
+                vcf_ok = body(db.vcf(sample_normal="NORMAL", sample_tumor="TUMOR")) == body(r.stdout)
+            H.close()
+            ok = ok and vcf_ok
+            print(f"cli{seed}: {region} {' '.join(opts)}: reference {len(want)} windows, native {len(got)}, vcf {'same' if vcf_ok else 'DIFFERENT'}: {'ok' if ok else 'MISMATCH'}")
             if not ok:
                 sw, sg = set(want), set(got)
                 print("    only reference:", sorted(sw - sg)[:3], "only native:", sorted(sg - sw)[:3])
