@@ -47,7 +47,15 @@ def random_case(seed):
             kw["n_runs"] = tuple((int(rng.integers(900, kw["ref_len"] - 900)), int(rng.choice([1, 2, 5, 20, 60]))) for _ in range(int(rng.integers(1, 5))))
         if rng.random() < 0.25:
             lo = int(rng.choice([10, 12, 16, 20])); flags = [f for f in flags]; flags += ["--min-k", str(lo)] if "--min-k" not in flags else []
-    a = int(rng.integers(700, 1200)); b = a + int(rng.integers(900, 2200))
+    if seed >= 2000:        # (third generation: quality thresholds, STR reporting options, coverage ratio, DFS limit)
+        if rng.random() < 0.4: flags += ["--trim-lowqual", str(int(rng.integers(2, 25)))]
+        if rng.random() < 0.4: flags += ["--min-base-qual", str(int(rng.integers(5, 38)))]
+        if rng.random() < 0.3: flags += ["--max-unit-length", str(int(rng.integers(1, 7)))]
+        if rng.random() < 0.3: flags += ["--min-report-unit", str(int(rng.integers(1, 6)))]
+        if rng.random() < 0.3: flags += ["--min-report-len", str(int(rng.integers(2, 14)))]
+        if rng.random() < 0.3: flags += ["--dist-from-str", str(int(rng.integers(0, 5)))]
+        if rng.random() < 0.3: flags += ["--cov-ratio", str(round(float(rng.choice([0.0, 0.02, 0.08, 0.2])), 2))]
+        if rng.random() < 0.15: flags += ["--dfs-limit", str(int(rng.choice([50, 500, 20000])))]
     return kw, f"chr22:{a}-{min(b, kw['ref_len'] - 400)}", flags
 
 
