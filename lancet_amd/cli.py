@@ -111,11 +111,12 @@ def run(argv: Optional[List[str]] = None, out=None, date_line: Optional[str] = N
     ordered = frontend.windows_in_processing_order(windows)
     step = max(1, args.batch_windows)
     n_done = 0
+    leak: list = []                       # reads a window without mapped reads leaves in the reference's graph (frontend.batch_from_sam)
     for lo in range(0, len(ordered), step):
         chunk = ordered[lo:lo + step]
         batch, kept = frontend.batch_from_sam(chunk, tumor, normal, fp, max_k=args.max_k, linked=args.linked_reads,
                                               active_region=not args.active_region_off, min_evidence=args.min_alt_count_tumor,
-                                              min_qual_call=args.min_base_qual + qoff)
+                                              min_qual_call=args.min_base_qual + qoff, leak=leak)
         if batch.n_windows == 0:
             continue
         _, stats = eng.process(batch)

@@ -50,6 +50,8 @@ struct Sample {
 };
 
 struct Window { std::string hdr; int32_t start, end; std::string seq; };
+struct Sel { uint32_t idx; uint8_t mate, strand, mapped; };
+struct RSel { uint8_t smp; Sel s; };   // a selected read: sample (1 tumor, 0 normal) + its per-window attributes
 
 }  // namespace
 
@@ -60,6 +62,8 @@ struct lancet_host {
   std::vector<std::string> contig_order;
   std::string chrom;
   std::vector<Window> windows;      // processing order
+  std::vector<RSel> leak;           // reads of a window without a mapped read: the reference's processGraph returns before g.clear()
+                                    // (src/Microassembler.cc:83), so they are still in the graph when the next window is loaded
   // last batch
   std::vector<int32_t> b_chr, b_refstart;
   std::vector<uint32_t> b_refoff, b_readbegin, b_seqoff, b_namerank, b_bxrank;
@@ -337,8 +341,6 @@ bool is_active_region(const Sample &S, const Window &win, bool normal, const lan
   return any_ge(mapX, o.min_evidence) || any_ge(mapI, o.min_evidence) || any_ge(mapD, o.min_evidence) || any_ge(mapSC, o.min_evidence);
 }
 
-struct Sel { uint32_t idx; uint8_t mate, strand, mapped; };
-
 // extractReads for one sample; returns false when the window is to be skipped (coverage above --max-avg-cov)
 bool extract_reads(const Sample &S, const Window &win, bool normal, const lancet_host_opts &o, std::vector<Sel> *out) {
   int mq = o.min_map_qual; double min_delta = o.max_delta_as_xs;
@@ -433,7 +435,7 @@ int lancet_host_tile(lancet_host *h, const char *region, const lancet_host_opts 
   }
   std::string s = ep >= sp ? contig.substr((size_t)(sp - 1), (size_t)(ep - sp + 1)) : std::string();
   for (char &c : s) { c = (char)toupper((unsigned char)c); if (strchr("MRWSYKVHDBX", c)) c = 'N'; }
-  h->windows.clear();
+  h->windows.clear(); h->leak.clear();
   const long delta = 100, wsz = o->window_size;
   long end = (long)s.size(), offset = 0;
   while (offset < end) {
@@ -482,11 +484,12 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
         const int i = next.fetch_add(1);
         if (i >= nwin) break;
         const Window &win = h->windows[(size_t)(w_begin + i)];
+        if (!win.seq.empty() && win.seq.find_first_not_of('N') == std::string::npos) continue;        // isNseq, :799
         if (is_repeat(win.seq, o->max_k)) continue;                                                   // :800
         if (o->active_region && !(is_active_region(h->smp[1], win, false, *o) || is_active_region(h->smp[0], win, true, *o))) continue;   // :817-820
-        if (!extract_reads(h->smp[1], win, false, *o, &selT[(size_t)i])) continue;
-        if (!extract_reads(h->smp[0], win, true, *o, &selN[(size_t)i])) continue;
-        keep[(size_t)i] = 1;
+        const bool okT = extract_reads(h->smp[1], win, false, *o, &selT[(size_t)i]);
+        const bool okN = extract_reads(h->smp[0], win, true, *o, &selN[(size_t)i]);      // (both samples are read before the skip test, :833-836)
+        keep[(size_t)i] = (okT && okN) ? 1 : 2;                                        // 2: skipped for coverage -> g.clear(true)
       }
     };
     unsigned nt = host_threads(nwin);
@@ -499,7 +502,18 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
   // ---- SoA assembly, windows in processing order; per window tumor reads then normal reads (:833-834).
   //      Sizes first (prefix sums), then every window fills its own slices on the host threads.
   std::vector<int> kw;                                 // kept windows (index into [w_begin, w_end))
-  for (int i = 0; i < nwin; ++i) if (keep[(size_t)i]) kw.push_back(i);
+  std::vector<std::vector<RSel>> lists;                // their reads: what an earlier window left in the graph, tumor, normal
+  for (int i = 0; i < nwin; ++i) {
+    if (keep[(size_t)i] == 2) { h->leak.clear(); continue; }
+    if (keep[(size_t)i] != 1) continue;
+    std::vector<RSel> l = h->leak;
+    for (const Sel &s : selT[(size_t)i]) l.push_back(RSel{1, s});
+    for (const Sel &s : selN[(size_t)i]) l.push_back(RSel{0, s});
+    bool mapped = false;
+    for (const RSel &r : l) mapped = mapped || r.s.mapped;
+    if (mapped) h->leak.clear(); else h->leak = l;       // countMappedReads() <= 0: processGraph returns, nothing is cleared
+    kw.push_back(i); lists.push_back(std::move(l));
+  }
   const int nk = (int)kw.size();
   h->b_chr.assign((size_t)nk, 0); h->b_refstart.resize((size_t)nk);
   h->b_refoff.assign((size_t)nk + 1, 0); h->b_readbegin.assign((size_t)nk + 1, 0);
@@ -509,10 +523,9 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
     const Window &win = h->windows[(size_t)(w_begin + i)];
     if (kept) kept[k] = w_begin + i;
     uint64_t nb = 0;
-    for (const Sel &s : selT[(size_t)i]) nb += h->smp[1].reads[s.idx].l_seq;
-    for (const Sel &s : selN[(size_t)i]) nb += h->smp[0].reads[s.idx].l_seq;
+    for (const RSel &r : lists[(size_t)k]) nb += h->smp[r.smp].reads[r.s.idx].l_seq;
     base0[(size_t)k + 1] = base0[(size_t)k] + nb;
-    h->b_readbegin[(size_t)k + 1] = h->b_readbegin[(size_t)k] + (uint32_t)(selT[(size_t)i].size() + selN[(size_t)i].size());
+    h->b_readbegin[(size_t)k + 1] = h->b_readbegin[(size_t)k] + (uint32_t)lists[(size_t)k].size();
     h->b_refoff[(size_t)k + 1] = h->b_refoff[(size_t)k] + (uint32_t)win.seq.size();
   }
   if (base0[(size_t)nk] > 0xFFFFFFFFull) { h->err = "batch holds more than 4 Gi bases: use fewer windows per batch"; return LANCET_E_ARG; }
@@ -537,9 +550,10 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
         memcpy(&h->b_ref[h->b_refoff[(size_t)k]], win.seq.data(), win.seq.size());
         size_t r = h->b_readbegin[(size_t)k]; const size_t r0 = r; size_t bo = (size_t)base0[(size_t)k];
         names.clear();
-        for (int smp = 1; smp >= 0; --smp) {
-          const Sample &S = h->smp[smp];
-          for (const Sel &s : (smp ? selT : selN)[(size_t)i]) {
+        {
+          for (const RSel &rs : lists[(size_t)k]) {
+            const int smp = rs.smp; const Sel &s = rs.s;
+            const Sample &S = h->smp[smp];
             const Read &rd = S.reads[s.idx];
             memcpy(&h->b_seq[bo], S.seq.data() + rd.seq_off, rd.l_seq); memcpy(&h->b_qual[bo], S.qual.data() + rd.seq_off, rd.l_seq);
             bo += rd.l_seq;

@@ -333,7 +333,8 @@ def build_batch(windows: Sequence[Window], per_window_reads: Sequence[Sequence[T
 
 def batch_from_sam(windows: Sequence[Window], tumor: Sequence[SamRead], normal: Sequence[SamRead],
                    p: Optional[ReadFilterParams] = None, max_k: int = 101, linked: bool = False,
-                   active_region: bool = False, min_evidence: int = 3, min_qual_call: int = 17 + 33):
+                   active_region: bool = False, min_evidence: int = 3, min_qual_call: int = 17 + 33,
+                   leak: Optional[list] = None):
     """Runs the per-window part of processReads (reference src/Microassembler.cc:779-842) up to the
     processGraph call: returns (batch, kept_windows) for windows that are not skipped.
     Active-region prefilter is not applied here (== --active-region-off)."""
@@ -342,7 +343,13 @@ def batch_from_sam(windows: Sequence[Window], tumor: Sequence[SamRead], normal: 
     n_starts = np.asarray([r.pos - 1 for r in normal], dtype=np.int64)
     kept: List[Window] = []
     per: List[list] = []
+    # `leak`: reads of a window without a mapped read.  processGraph returns there before g.clear() (reference
+    # src/Microassembler.cc:83), so they are still in the graph when the next window is loaded; pass the same list object
+    # again to carry them across calls (chunks of one scan).
+    leak = leak if leak is not None else []
     for win in windows_in_processing_order(windows):
+        if win.seq and all(c == "N" for c in win.seq):                  # isNseq, :799
+            continue
         if _is_repeat(win.seq, max_k):                                  # :800
             continue
         if active_region and not (is_active_region(tumor, t_starts, win, TMR, p, min_evidence, min_qual_call)        # :817-820
@@ -351,13 +358,19 @@ def batch_from_sam(windows: Sequence[Window], tumor: Sequence[SamRead], normal: 
         tr, skip_t = extract_reads(tumor, t_starts, win, TMR, p)
         nr, skip_n = extract_reads(normal, n_starts, win, NML, p)
         if skip_t or skip_n:
+            leak.clear()                                                # g.clear(true), :841
             continue
         # BX / HP as extractReads reads them (reference src/Microassembler.cc:581-593): missing BX -> "null", missing HP -> 0
         lr = (lambda r: (r.tags.get("BX", "") or "null", max(0, int(r.tags.get("HP", 0))))) if linked else (lambda r: ())
-        rs = [(r.qname, r.seq, r.qual, TMR, st, mt, mp) + lr(r) for (r, mt, st, mp) in tr]
+        rs = list(leak)
+        rs += [(r.qname, r.seq, r.qual, TMR, st, mt, mp) + lr(r) for (r, mt, st, mp) in tr]
         rs += [(r.qname, r.seq, r.qual, NML, st, mt, mp) + lr(r) for (r, mt, st, mp) in nr]
         kept.append(win)
         per.append(rs)
+        if any(rec[6] for rec in rs):
+            leak.clear()
+        else:
+            leak[:] = rs                                                # countMappedReads() <= 0: nothing is cleared
     return build_batch(kept, per, linked=linked), kept
 
 

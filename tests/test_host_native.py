@@ -299,3 +299,53 @@ def test_window_and_read_selection_under_the_reference_s_options():
         H.close()
     sets = spec["option_sets"]
     assert sets["--max-as-xs-diff 2"] == sets[""] == sets["--max-as-xs-diff 9"] and sets["--min-map-qual 5"] != sets[""]
+
+
+def test_reads_of_a_window_without_mapped_reads_stay_in_the_graph_as_in_the_reference():
+    """`leak_small` (tools/make_filter_golden.py): every read starting in [1500, 2250) carries the unmapped flag, so three
+    consecutive windows hold no mapped read.  The reference's processGraph returns there before g.clear()
+    (src/Microassembler.cc:83): the windows print nothing but use up a number, and their reads are still in
+    the graph when the next window is loaded (631 reads in `chr22:1850-2450`).  Both host sides reproduce it; oracle and
+    emulated kernels on that batch give the reference's VCF and trace."""
+    import re
+    import sys
+    from oracle import oracle
+    from lancet_amd import abi, engine
+    paths = [os.path.join(G, "leak_small.tumor.bam"), os.path.join(G, "leak_small.normal.bam"), os.path.join(G, "leak_small.fa")]
+    o = host.default_opts(active_region=0)
+    H = host.NativeHost(*paths)
+    hdrs = H.tile("chr22:1000-3000", o)
+    b, idx = H.batch(0, len(hdrs), o)
+    ref_trace = gu.golden_trace("leak_small")
+    want = [(int(m.group(1)), m.group(2), int(m.group(3)), int(m.group(4))) for m in
+            re.finditer(r"== Processing (\d+): (\S+) numsequences: (\d+) mapped: (\d+)", ref_trace)]
+    nr = np.diff(b.read_begin.astype(np.int64))
+    got = [(w + 1, b.hdr[w], int(nr[w]), int(b.mapped[b.read_begin[w]:b.read_begin[w + 1]].sum())) for w in range(b.n_windows)]
+    assert [g for g in got if g[3] > 0] == want and len(got) == len(want) + 3
+    assert [g[0] for g in got if g[3] == 0] == [6, 7, 8] and (9, "chr22:1850-2450", 631, 20) in want
+    # the same scan in chunks of four windows: the reads are carried from one call to the next
+    parts = [H.batch(lo, min(lo + 4, len(hdrs)), o)[0] for lo in range(0, len(hdrs), 4)]
+    assert sum(x.n_reads for x in parts) == b.n_reads and [int(n) for x in parts for n in np.diff(x.read_begin.astype(np.int64))] == [g[2] for g in got]
+    want_hdrs, pb = _python_batch(*paths, "chr22:1000-3000", o)
+    _same(b, pb, False)
+    p = abi.default_params()
+    ov, ost, otr = oracle.run(b, p, verbose=True)
+    db = engine.VariantDB()
+    db.add_records(ov, ["chr22"])
+    assert db.vcf(sample_normal="NORMAL", sample_tumor="TUMOR") == gu.golden_vcf("leak_small")
+    assert gu.digest_trace(otr) == gu.digest_trace(ref_trace)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    import emu
+    ev, est, etr = emu.run(b, p, evt_cap=1 << 18)
+    assert ev == ov and gu.digest_trace(etr) == gu.digest_trace(ref_trace) and [s["status"] for s in est][5:8] == [1, 1, 1]
+    H.close()
+
+
+@pytest.mark.gpu
+def test_lancet_gpu_reproduces_the_reference_s_read_leak():
+    r = subprocess.run([build.BIN, "--tumor", os.path.join(G, "leak_small.tumor.bam"), "--normal", os.path.join(G, "leak_small.normal.bam"),
+                        "--ref", os.path.join(G, "leak_small.fa"), "--reg", "chr22:1000-3000", "--active-region-off", "-v", "--batch-windows", "4"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _body(r.stdout) == gu.golden_vcf("leak_small")
+    assert gu.digest_trace(r.stderr) == gu.digest_trace(gu.golden_trace("leak_small"))

@@ -27,6 +27,11 @@ CASES = {
     # --linked-reads --primary-alignment-only on BX/HP-tagged reads (some without barcode / haplotype)
     "lrflt_small": (dict(ref_len=3800, cov_t=32, cov_n=28, ref_seed=73, tumor_seed=173, normal_seed=273, somatic_every=700, germline_every=500,
                          insert_mean=280.0, insert_sd=40.0), True, ["--linked-reads", "--primary-alignment-only"], "chr22:800-2900"),
+    # every read that starts in [1500, 2250) carries the unmapped flag: the window chr22:1550-2150 holds no mapped read, the
+    # reference's processGraph returns before g.clear() (src/Microassembler.cc:83) and its reads are still in the graph when
+    # the next window is loaded
+    "leak_small": (dict(ref_len=4000, cov_t=30, cov_n=26, ref_seed=75, tumor_seed=175, normal_seed=275, somatic_every=500, germline_every=400),
+                   False, ["--active-region-off"], "chr22:1000-3000"),
 }
 
 if __name__ == "__main__":
@@ -35,8 +40,12 @@ if __name__ == "__main__":
     kwargs, linked, FLAGS, REGION = CASES[NAME]
     data = synth.make_tumor_normal(**kwargs)
     rng = np.random.default_rng(71)
-    reads = {"tumor": read_variety.decorate(synth.pairs_to_sorted_reads(data["tumor"]), rng, linked),
-             "normal": read_variety.decorate(synth.pairs_to_sorted_reads(data["normal"]), rng, linked)}
+    if NAME == "leak_small":
+        unmap = lambda rs: [synth.SamRead(r.qname, r.flag | (0x4 if 1500 <= r.pos - 1 < 2250 else 0), r.rname, r.pos, r.mapq, r.cigar, r.seq, r.qual, r.tags) for r in rs]
+        reads = {"tumor": unmap(synth.pairs_to_sorted_reads(data["tumor"])), "normal": unmap(synth.pairs_to_sorted_reads(data["normal"]))}
+    else:
+        reads = {"tumor": read_variety.decorate(synth.pairs_to_sorted_reads(data["tumor"]), rng, linked),
+                 "normal": read_variety.decorate(synth.pairs_to_sorted_reads(data["normal"]), rng, linked)}
     rname, ref = data["rname"], data["ref"]
     with tempfile.TemporaryDirectory(prefix="lancet_golden_") as td:
         fa = os.path.join(td, "ref.fa")
@@ -62,7 +71,7 @@ if __name__ == "__main__":
                   if not l.startswith("##fileDate") and not l.startswith("##cmdline") and not l.startswith("##reference"))
     open(os.path.join(mg.GOLDEN, f"{NAME}.vcf"), "w").write(vcf)
     open(os.path.join(mg.GOLDEN, f"{NAME}.trace.txt"), "w").write(mg.digest_trace(r.stderr))
-    json.dump({"region": REGION, "flags": FLAGS + ["--active-region-on"],
+    json.dump({"region": REGION, "flags": FLAGS + ([] if "--active-region-off" in FLAGS else ["--active-region-on"]),
                "reference_cmd": " ".join(os.path.basename(c) if c.startswith("/tmp") else c for c in cmd),
                "n_vcf_records": sum(1 for l in vcf.splitlines() if not l.startswith("#"))},
               open(os.path.join(mg.GOLDEN, f"{NAME}.case.txt"), "w"), indent=1)
