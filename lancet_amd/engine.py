@@ -152,7 +152,7 @@ class Engine:
         for w in range(b.n_windows):
             words = ev[w * wpw.value: w * wpw.value + int(lens[w])]
             end = int(b.ref_start[w]) + int(b.ref_off[w + 1] - b.ref_off[w])
-            parts.append(_trace.format_window(words, w + 1, b.hdr[w], b.chrom[w], int(b.ref_start[w]), end))
+            parts.append(_trace.format_window(words, w + 1, b.hdr[w], b.chrom[w], int(b.ref_start[w]), end, dfs_limit=int(self.params.dfs_limit)))
         return "".join(parts)
 
     def phase_times(self):

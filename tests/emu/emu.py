@@ -62,7 +62,7 @@ def run(batch, params=None, evt_cap: int = 0):
                 words = ev[w * evt_cap: w * evt_cap + int(lens[w])]
                 LAST_EVENTS.append(words.copy())                       # raw event words per window (for the formatter tests)
                 end = int(batch.ref_start[w]) + int(batch.ref_off[w + 1] - batch.ref_off[w])
-                parts.append(trace.format_window(words, w + 1, batch.hdr[w], batch.chrom[w], int(batch.ref_start[w]), end))
+                parts.append(trace.format_window(words, w + 1, batch.hdr[w], batch.chrom[w], int(batch.ref_start[w]), end, dfs_limit=int(p.dfs_limit)))
             text = "".join(parts)
     finally:
         L.lancet_emu_free(h)
