@@ -56,6 +56,10 @@ def random_case(seed):
         if rng.random() < 0.3: flags += ["--dist-from-str", str(int(rng.integers(0, 5)))]
         if rng.random() < 0.3: flags += ["--cov-ratio", str(round(float(rng.choice([0.0, 0.02, 0.08, 0.2])), 2))]
         if rng.random() < 0.15: flags += ["--dfs-limit", str(int(rng.choice([50, 500, 20000])))]
+    if seed >= 4000:        # (fourth generation: very low coverage, long reads, inserts shorter than the reads -- mates overlap fully)
+        if rng.random() < 0.4: kw["cov_t"] = float(rng.choice([3, 6, 10])); kw["cov_n"] = float(rng.choice([3, 6, 12]))
+        if rng.random() < 0.3: kw["read_len"] = 250
+        if rng.random() < 0.5: kw["insert_mean"] = float(kw["read_len"]) * float(rng.choice([0.8, 1.0, 1.3])); kw["insert_sd"] = 15.0
     a = int(rng.integers(700, 1200)); b = a + int(rng.integers(900, 2200))
     if seed >= 1000 and "--min-k" in flags and int(flags[flags.index("--min-k") + 1]) % 2 == 0:
         flags[flags.index("--min-k") + 1] = str(int(flags[flags.index("--min-k") + 1]) + 1)      # (even k is refused by the engine: keep the cases odd)
