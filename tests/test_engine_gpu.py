@@ -18,7 +18,13 @@ def _names(batch):
     return [id2chr[i] for i in range(len(id2chr))]
 
 
-@pytest.mark.parametrize("case", gu.CASES)
+# `bushy` (--low-cov 0: one path search of 600 k partial paths on a single lane) was added after this round's GPU time was
+# spent; it is pinned on the CPU side (oracle and emulated kernels vs the reference) and joins this list once its run time
+# on the device has been measured.
+GPU_CASES = [c for c in gu.CASES if c != "bushy"]
+
+
+@pytest.mark.parametrize("case", GPU_CASES)
 def test_engine_matches_oracle_and_reference(case):
     meta, batch, kept, (min_k, max_k) = gu.case_batch(case)
     lr = gu.case_lr(meta)                                                     # --linked-reads goldens
