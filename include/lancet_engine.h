@@ -142,8 +142,8 @@ typedef struct lancet_engine lancet_engine;
 void lancet_params_default(lancet_params *p);
 
 /* device >= 0 : HIP device ordinal.  There is no CPU backend: creation fails with LANCET_E_NO_DEVICE
- * when no gfx950-compatible device is present.  LANCET_E_UNSUPPORTED: max_k > 127, min_k < 3, max_unit_len > 8, or an even
- * min_k (k-mers that are their own reverse complement are not handled bit-exactly; the reference's default k values are odd). */
+ * when no gfx950-compatible device is present.  LANCET_E_UNSUPPORTED: max_k > 127, min_k < 3 or max_unit_len > 8.  Even k is
+ * supported (k-mers that are their own reverse complement: CanonicalMer_t::set ties -> R, reference src/Mer.hh:57-71). */
 int  lancet_engine_create(const lancet_params *p, int device, lancet_engine **out);
 void lancet_engine_destroy(lancet_engine *e);
 const char *lancet_engine_last_error(const lancet_engine *e);

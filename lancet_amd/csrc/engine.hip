@@ -109,10 +109,6 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (!p || !out) return LANCET_E_ARG;
   *out = nullptr;
   if (p->max_k > 127 || p->min_k < 3 || p->max_unit_len > 8) return LANCET_E_UNSUPPORTED;
-  // Even k (the loop steps by 2 from min_k) admits k-mers that are their own reverse complement; the edge bookkeeping of such
-  // nodes differs from the reference's by one edge in its graph statistics (tools/fuzz_reference.py, seeds 1047 / 1112; no
-  // record differed).  Not bit-exact, therefore refused rather than approximated; the reference's default and usual k are odd.
-  if ((p->min_k & 1) == 0) return LANCET_E_UNSUPPORTED;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return LANCET_E_NO_DEVICE;
   lancet_engine *e = new lancet_engine();

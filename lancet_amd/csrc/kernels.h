@@ -1158,6 +1158,64 @@ DEVNI void build_csr(Ctx &c) {
   }
   WG_SYNC();
 }
+// Even k: a k-mer can be its own reverse complement, and CanonicalMer_t::set gives such a k-mer the orientation R wherever it
+// occurs (tie -> R, reference src/Mer.hh:57-71).  For an ordinary neighbour the (side, extension base) slot of a node fixes the
+// edge (target, direction) whichever strand the step was read on -- the target then appears reverse-complemented and the
+// reciprocal edge of loadSequence flips its orientation back (reference src/Graph.cc:320-347).  A self-complementary target
+// shows R on both strands, so the two ways of meeting it (this node as the step's u, or as its v) give two different edges
+// (e.g. RR and RF) that Node_t::addEdge keeps apart (it compares node and direction, src/Node.cc:140-175).  Hence for even k
+// the first-seen stamps are kept per (slot, role of this node in the step), the edges are resolved, and equal
+// (target, direction) pairs are merged under their earliest stamp.  Lane-local; only called when K is even.
+DEVNI void gather_edges_even(Ctx &c, uint32_t n, uint32_t lo, uint32_t hi) {
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  const int K = S.K;
+  const int Rref = S.R - 1, reflen_ = S.reflen;
+  uint32_t ef[20];
+  for (int j = 0; j < 20; ++j) ef[j] = LC_NIL;
+  for (uint32_t q = lo; q < hi; ++q) {
+    const uint32_t e = W.csr[q];
+    const int r = (int)CS_READ(e), p = (int)CS_POS(e);
+    const uint32_t ori = CS_ORI(e);
+    const bool isref = r == Rref;
+    const lc_u4 rdv = *(const lc_u4 *)(W.rd + 4 * (size_t)r);
+    const uint32_t bw = rdv.y;
+    const int tlen = isref ? reflen_ : (int)RI_TLEN(rdv.x);
+    const int nk = tlen - K + 1;
+    const uint32_t o0 = rdv.w;
+    if (p + 1 < nk) {
+      const int bnew = read_base(c, isref, bw, p + K);
+      const int eb = (ori == 0) ? bnew : n_comp(bnew);
+      const uint32_t side = (ori == 0) ? 0u : 1u;
+      const uint32_t sl = eb < 4 ? side * 4u + (uint32_t)eb : 8u + side, st = 2u * (o0 + (uint32_t)p);
+      if (st < ef[sl]) ef[sl] = st;
+    }
+    if (p > 0) {
+      const int bold = read_base(c, isref, bw, p - 1);
+      const int eb = (ori == 0) ? bold : n_comp(bold);
+      const uint32_t side = (ori == 0) ? 1u : 0u;
+      const uint32_t sl = 10u + (eb < 4 ? side * 4u + (uint32_t)eb : 8u + side), st = 2u * (o0 + (uint32_t)p - 1u) + 1u;
+      if (st < ef[sl]) ef[sl] = st;
+    }
+  }
+  uint32_t stamp[20], edge[20]; int ne = 0;
+  for (int j = 0; j < 20; ++j) {
+    if (ef[j] == LC_NIL) continue;
+    const uint32_t s = ef[j] >> 1;
+    const uint32_t a = W.occ[s], b = W.occ[s + 1];
+    const uint32_t ua = a >> 31, ub = b >> 31;
+    const uint32_t ew = (ef[j] & 1u) == 0 ? ED_MAKE(b & 0x3FFFFFFFu, ua == 0 ? (ub == 0 ? 0u : 1u) : (ub == 0 ? 2u : 3u))
+                                          : ED_MAKE(a & 0x3FFFFFFFu, ua == 0 ? (ub == 0 ? 3u : 1u) : (ub == 0 ? 2u : 0u));
+    int at = -1;
+    for (int i = 0; i < ne; ++i) if (edge[i] == ew) { at = i; break; }
+    if (at >= 0) { if (ef[j] < stamp[at]) stamp[at] = ef[j]; }
+    else { edge[ne] = ew; stamp[ne] = ef[j]; ++ne; }
+  }
+  for (int i = 1; i < ne; ++i) { const uint32_t s = stamp[i], ew = edge[i]; int j = i; while (j > 0 && stamp[j - 1] > s) { stamp[j] = stamp[j - 1]; edge[j] = edge[j - 1]; --j; } stamp[j] = s; edge[j] = ew; }
+  if (ne > LC_EMAX) { OVF(c); ne = LC_EMAX; }
+  LC_GLOBAL NodeGr &G = W.gr[n];
+  for (int i = 0; i < ne; ++i) G.edges[i] = edge[i];
+  G.necnt = (uint32_t)ne;
+}
 DEVNI void build_gather(Ctx &c) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W; LC_GLOBAL const EngineCaps &C = *LC_CTX(c).C;
   const int K = S.K;
@@ -1248,6 +1306,7 @@ DEVNI void build_gather(Ctx &c) {
       else G.edges[i] = ED_MAKE(a & 0x3FFFFFFFu, ua == 0 ? (ub == 0 ? 3u : 1u) : (ub == 0 ? 2u : 0u));                          // RR FR RF FF
     }
     G.necnt = (uint32_t)ne; G.comp = 0; G.color = 0; G.onref = 0; G.nkm = 1; G.nkmT = 0; G.nqv = LC_NIL;
+    if ((K & 1) == 0) gather_edges_even(c, (uint32_t)n, lo, hi);   // self-complementary neighbours: edges per (slot, role), merged by (target, direction)
     G.flags = (S.hasN ? (G.flags & NF_NKMER) : 0u) | fl;
     uint16_t *kc = G.kc;                     // counts per strand/sample as the cov_t fields hold them (unsigned short)
     kc[0] = (uint16_t)c0; kc[1] = (uint16_t)c1; kc[2] = (uint16_t)c2; kc[3] = (uint16_t)c3;

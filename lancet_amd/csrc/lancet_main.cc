@@ -97,7 +97,7 @@ int main(int argc, char **argv) {
   for (int d : devs) {
     lancet_engine *e = nullptr;
     const int rc = lancet_engine_create(&P, d, &e);
-    if (rc == LANCET_E_UNSUPPORTED) return die("unsupported parameters: --max-k must be <= 127, --min-k >= 3 and odd (even k admits k-mers that are their own reverse complement, which are not handled bit-exactly), --max-unit-length <= 8");
+    if (rc == LANCET_E_UNSUPPORTED) return die("unsupported parameters: --max-k must be <= 127, --min-k >= 3, --max-unit-length <= 8");
     if (rc != LANCET_OK) return die(std::string("cannot create the MI355X engine on device ") + std::to_string(d) + " (code " + std::to_string(rc) + "): " + (e ? lancet_engine_last_error(e) : "no gfx950 device / HIP runtime"));
     if (verbose) lancet_engine_set_trace(e, 1u << 17);            // -v: the reference's per-window stage trace, to stderr
     engs.push_back(e);

@@ -336,9 +336,19 @@ def make_tumor_normal(ref_len: int = 20000, cov_t: float = 30, cov_n: float = 30
                       read_len: int = 150, error_rate: float = 0.005,
                       somatic_every: int = 2000, germline_every: int = 1000,
                       region: Tuple[int, int] | None = None, dup_prob: float = 0.0,
-                      insert_mean: float = 400.0, insert_sd: float = 40.0, n_runs=(), linked: bool = False):
-    """Returns dict(ref, variants, tumor_pairs, normal_pairs)."""
+                      insert_mean: float = 400.0, insert_sd: float = 40.0, n_runs=(), linked: bool = False,
+                      palindromes=()):
+    """Returns dict(ref, variants, tumor_pairs, normal_pairs).
+    palindromes: (position, half length) pairs -- the reference gets s + revcomp(s) there (k-mers that are their own
+    reverse complement exist for even k only: CanonicalMer_t::set ties, reference src/Mer.hh:57-71)."""
     ref = random_reference(ref_len, ref_seed, str_fraction, lowcomplex_fraction)
+    if palindromes:
+        rl = list(ref)
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+        for pos, half in palindromes:
+            left = rl[pos:pos + half]
+            rl[pos + half:pos + 2 * half] = [comp[b] for b in reversed(left)]
+        ref = "".join(rl)
     variants = plant_variants(ref, ref_seed + 1, somatic_every, germline_every, dup_prob=dup_prob)
     germ = [v for v in variants if not v.somatic]
     h0 = build_haplotype(ref, [])

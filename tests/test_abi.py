@@ -51,7 +51,7 @@ def test_no_cpu_fallback(lib):
     p = abi.default_params(lr_mode=1)
     assert lib.lancet_engine_create(ctypes.byref(p), 0, ctypes.byref(h)) == -2      # LANCET_E_NO_DEVICE: no CPU path in any mode
     p = abi.default_params(min_k=12)
-    assert lib.lancet_engine_create(ctypes.byref(p), 0, ctypes.byref(h)) == -4      # even k (palindromic k-mers) is refused, not approximated
+    assert lib.lancet_engine_create(ctypes.byref(p), 0, ctypes.byref(h)) == -2      # even k is accepted (golden `evenk`); still no CPU path
 
 
 @pytest.mark.parametrize("case", gu.CASES)

@@ -18,10 +18,9 @@ def _names(batch):
     return [id2chr[i] for i in range(len(id2chr))]
 
 
-# `bushy` (--low-cov 0: one path search of 600 k partial paths on a single lane) was added after this round's GPU time was
-# spent; it is pinned on the CPU side (oracle and emulated kernels vs the reference) and joins this list once its run time
-# on the device has been measured.
-GPU_CASES = [c for c in gu.CASES if c != "bushy"]
+# every reference-made golden, including `bushy` (--low-cov 0: one path search of 600 k partial paths, 12 s for its 17 windows on
+# an MI355X, all through the worst-case tier) and `evenk` (--min-k 12: k-mers that are their own reverse complement)
+GPU_CASES = list(gu.CASES)
 
 
 @pytest.mark.parametrize("case", GPU_CASES)

@@ -61,8 +61,13 @@ def random_case(seed):
         if rng.random() < 0.3: kw["read_len"] = 250
         if rng.random() < 0.5: kw["insert_mean"] = float(kw["read_len"]) * float(rng.choice([0.8, 1.0, 1.3])); kw["insert_sd"] = 15.0
     a = int(rng.integers(700, 1200)); b = a + int(rng.integers(900, 2200))
-    if seed >= 1000 and "--min-k" in flags and int(flags[flags.index("--min-k") + 1]) % 2 == 0:
-        flags[flags.index("--min-k") + 1] = str(int(flags[flags.index("--min-k") + 1]) + 1)      # (even k is refused by the engine: keep the cases odd)
+    if 1000 <= seed < 5000 and "--min-k" in flags and int(flags[flags.index("--min-k") + 1]) % 2 == 0:
+        flags[flags.index("--min-k") + 1] = str(int(flags[flags.index("--min-k") + 1]) + 1)      # (generations 2-4 were drawn while even k was refused: kept odd so that they stay the same cases)
+    if seed >= 5000:        # (fifth generation: even k with self-complementary k-mers planted in the contig)
+        lo = int(rng.choice([10, 12, 14, 16, 20]))
+        if "--min-k" in flags: flags[flags.index("--min-k") + 1] = str(lo)
+        else: flags += ["--min-k", str(lo)]
+        kw["palindromes"] = tuple((int(rng.integers(a, min(b, kw["ref_len"] - 400))), int(rng.choice([lo // 2, lo // 2 + 1, lo // 2 + 2, 12]))) for _ in range(int(rng.integers(2, 9))))
     return kw, f"chr22:{a}-{min(b, kw['ref_len'] - 400)}", flags
 
 

@@ -86,6 +86,12 @@ CASES = {
     "bushy": (dict(ref_len=4284, cov_t=45.0, cov_n=15.0, ref_seed=1102, tumor_seed=2102, normal_seed=3102, error_rate=0.015, read_len=100,
                    insert_mean=260.0, insert_sd=20.0, somatic_every=1200, germline_every=500, dup_prob=1.0, linked=True), "chr22:1190-2791",
               ["--linked-reads", "--cov-thr", "3", "--low-cov", "0"]),
+    # even k (--min-k 12: the loop visits 12, 14, ...): k-mers that are their own reverse complement (planted in the contig at
+    # several lengths, so that the window's final k meets one), CanonicalMer_t::set ties -> R (reference src/Mer.hh:57-71)
+    "evenk": (dict(ref_len=7000, cov_t=36, cov_n=30, ref_seed=121, tumor_seed=1121, normal_seed=2121, somatic_every=700, germline_every=500,
+                   palindromes=((1700, 6), (1990, 7), (2300, 8), (2610, 6), (2900, 7), (3205, 9), (3500, 6), (3800, 8), (4100, 7), (4400, 6),
+                                (2455, 12), (3350, 11))),
+              "chr22:1300-5000", ["--min-k", "12"]),
     "dups": (dict(ref_len=8000, cov_t=40, cov_n=40, ref_seed=5, tumor_seed=15, normal_seed=25, dup_prob=1.0,
                   somatic_every=600, germline_every=500, read_len=100), "chr22:1000-6500", []),
 }
