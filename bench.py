@@ -5,11 +5,15 @@ Workload (BASELINE.json configs[1] proxy): synthetic "chr22 sc
 stride 100, paired 2x150 bp reads at 30x tumor / 30x normal, 0.5 % substitution errors, planted germline +
 somatic variants, self-tuning k = 11..101, every window assembled (== --active-region-off).
 A step = one pass of the hot path (lancet_engine_run) over one batch of windows already resident in HBM.
-N GPUs: each rank assembles its own batch (weak scaling) and the variant records are gathered to rank 0
-over RCCL inside the timed step.
+
+N GPUs (`--gpus N`; without WORLD_SIZE in the environment the script re-launches itself under torch.distributed.run with
+N ranks): rank r assembles its own synthetic contig (weak scaling); inside the timed step the variant records of every
+rank are sent to rank 0 over RCCL (sizes by all_gather, payloads point to point) and rank 0 replays them in window order
+into a VariantDB.
 
 Prints ONE JSON line on rank 0."""
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -19,6 +23,82 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def maybe_spawn(argv, gpus: int) -> None:
+    """`python bench.py --gpus N` alone: become N ranks (one process per GPU) under torch.distributed.run."""
+    if gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    port = 29400 + (os.getpid() % 500)
+    os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+                               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv))
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(batch, params, variants, n1: int, nall: int):
+    """The oracle (CPU restatement of the reference path, oracle/liblancet_oracle.so) on a bounded sample of the same
+    windows: one thread, then one thread per host core over chunks of windows (windows are independent, as the
+    reference's own --num-threads fan-out, src/Lancet.cc:910-928)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from lancet_amd import workload
+    from oracle import oracle
+    oracle.lib()
+    n1 = min(n1, batch.n_windows)
+    sample = workload.sub_batch(batch, 0, n1)
+    t = time.perf_counter()
+    ov, ostats, _ = oracle.run(sample, params)
+    dt1 = time.perf_counter() - t
+    same = ov == [v for v in variants if v["window"] < n1]
+    cores = os.cpu_count() or 1
+    nall = min(nall, batch.n_windows)
+    per = max(8, nall // (cores * 4))
+    chunks = [workload.sub_batch(batch, a, min(nall, a + per)) for a in range(0, nall, per)]
+    t = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:            # ctypes releases the GIL inside the library call
+        res = list(ex.map(lambda b: oracle.run(b, params)[1], chunks))
+    dta = time.perf_counter() - t
+    km1 = sum(s["n_kmers"] for s in ostats)
+    kma = sum(s["n_kmers"] for r in res for s in r)
+    return {"value": round(nall / dta, 2), "unit": "windows/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"oracle/liblancet_oracle.so on the first {nall} windows of the same batch, {cores} threads over chunks of {per} windows, {dta:.1f} s",
+            "mkmers_per_s": round(kma / dta / 1e6, 3),
+            "one_thread": {"value": round(n1 / dt1, 2), "mkmers_per_s": round(km1 / dt1 / 1e6, 3),
+                           "sample": f"first {n1} windows, 1 thread, {dt1:.1f} s"},
+            "gpu_results_identical_on_sample": bool(same),
+            "note": "the reference binary cannot travel to this box; in the authoring container it runs the golden cases at 13-23 windows/s/thread, this port at ~45 (DESIGN.md §7)"}
+
+
+def side_config(eng_cls, params, name, windows, cov_t, cov_n, steps, **kw):
+    """One more BASELINE.md configuration on this GPU (smaller batch, reported beside the headline)."""
+    import numpy as np
+    from lancet_amd import workload
+    b = workload.make_scan_batch(windows, cov_t, cov_n, seed=22, **kw)
+    eng = eng_cls(params, device=0)
+    eng.upload(b)
+    eng.run()
+    t = time.perf_counter()
+    for _ in range(steps):
+        eng.run()
+    dt = (time.perf_counter() - t) / steps
+    _, stats = eng.results()
+    ks, cnt = np.unique([s["final_k"] for s in stats if s["status"] == 0], return_counts=True)
+    out = {"name": name, "windows": windows, "coverage": [cov_t, cov_n], "windows_per_s": round(windows / dt, 1),
+           "mkmers_per_s": round(sum(s["n_kmers"] for s in stats) / dt / 1e6, 1), "reads_per_window": round(b.n_reads / windows, 1),
+           "builds_per_window": round(sum(s["n_builds"] for s in stats) / windows, 3),
+           "final_k_histogram": {int(k): int(c) for k, c in zip(ks, cnt)},
+           "k_exhausted": sum(1 for s in stats if s["status"] == 2), "overflowed": sum(1 for s in stats if s["status"] < 0),
+           "windows_rerun_general_path": eng.rerun_count()}
+    eng.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -26,8 +106,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--windows", type=int, default=32768, help="windows per GPU per step")
     ap.add_argument("--cov", type=float, default=30.0, help="coverage per sample")
-    ap.add_argument("--cpu-sample", type=int, default=1536, help="windows timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="windows timed on one thread of the CPU oracle (0 = skip the CPU legs)")
+    ap.add_argument("--cpu-sample-all", type=int, default=16384, help="windows timed on all host cores")
+    ap.add_argument("--no-configs", action="store_true", help="skip the side configurations (60x/60x, 100x/40x STR)")
     args = ap.parse_args()
+    maybe_spawn(sys.argv[1:], args.gpus)
 
     import numpy as np
     import torch
@@ -45,19 +128,26 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    batch = workload.make_scan_batch(args.windows, args.cov, args.cov, seed=22 + 1000 * rank)
+    chrom = f"chr{22 + rank}" if rank else "chr22"           # one synthetic contig per rank
+    batch = workload.make_scan_batch(args.windows, args.cov, args.cov, seed=22 + 1000 * rank, chrom=chrom)
     params = abi.default_params()
     eng = engine.Engine(params, device=local_rank)
     t_up = time.perf_counter()
     eng.upload(batch)                      # host -> HBM + trim/pack: outside the timed region
-    upload_ms = 1000.0 * (time.perf_counter() - t_up)
+    upload_first_ms = 1000.0 * (time.perf_counter() - t_up)       # includes the one-off work-space allocation
     n_slots, slot_bytes = eng.geometry()
+    windex = rank * args.windows + np.arange(args.windows, dtype=np.int64)
+    last = {}
 
     def step():
         eng.run()
         if world > 1:
             vp, n, blob, _ = eng.raw_results()
-            ldist.gather_bytes(ldist.pack_records(vp, n, blob), device)
+            parts = ldist.gather_bytes(ldist.pack_records(vp, n, blob, chr_names=[chrom], window_index=windex), device)
+            if rank == 0:
+                db = engine.VariantDB()
+                last["n"] = ldist.merge_into_vdb(parts, db)
+                last["db"] = db
 
     for _ in range(args.warmup):
         step()
@@ -68,7 +158,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kernel_ms.append(eng.timing_ms()[1])
+        kernel_ms.append(eng.kernel_times())
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -89,9 +179,22 @@ def main():
     else:
         n_kmers_all, n_bad_all = n_kmers, n_bad
 
+    # PCIe-inclusive rate (never `value`): the same batch handed over as host buffers each step (upload + trim/pack + kernels)
+    t1 = time.perf_counter()
+    eng.upload(batch)
+    up_ms = 1000.0 * (time.perf_counter() - t1)
+    eng.run()
+    e2e_s = time.perf_counter() - t1
+
     if rank == 0:
-        ms_kernel = float(np.mean(kernel_ms))
-        achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9
+        names = eng.kernel_names()
+        per_kernel = {nm: round(float(np.mean([k[i] for k in kernel_ms])), 3) for i, nm in enumerate(names)}
+        ms_all = float(sum(per_kernel.values()))
+        achieved = alg_bytes / (ms_all * 1e-3) / 1e9
+        own = [v for v in variants]
+        h = hashlib.sha256()
+        for v in own:
+            h.update(repr((v["window"], v["seq"], v["pos"], v["code"], v["ref"], v["alt"], v["cov"], v["kmer"], v["str"])).encode())
         out = {
             "metric": "assembled windows/sec (whole node), 600bp windows, self-tuning k, synthetic T/N",
             "value": round(world * args.windows * args.steps / dt, 2),
@@ -102,18 +205,30 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "mkmers_per_s": round(n_kmers_all * args.steps / dt / 1e6, 2),
             "overflowed_windows": n_bad_all,
+            "value_e2e": round(args.windows / e2e_s, 2),
+            "value_e2e_note": f"PCIe-inclusive, 1 GPU: host buffers -> upload + trim/pack ({up_ms:.0f} ms) + kernels, not overlapped; never `value`",
             "config": {"workload": f"chr22-scan proxy: {args.windows} windows/GPU x 600 bp, stride 100, "
                                    f"{args.cov:g}x tumor / {args.cov:g}x normal, 2x150 bp, k=11..101, active-region-off",
                        "windows_per_gpu": args.windows, "coverage": [args.cov, args.cov], "reads_per_gpu": int(batch.n_reads),
-                       "variants_rank0": len(variants), "slots_in_flight": n_slots, "upload_ms": round(upload_ms, 1), "windows_rerun_tier2": eng.rerun_count(), "workspace_MB_per_slot": round(slot_bytes / 2 ** 20, 1)},
+                       "records_rank0_contig": len(variants), "records_sha256_rank0_contig": h.hexdigest()[:16],
+                       "slots_in_flight": n_slots, "upload_first_ms": round(upload_first_ms, 1), "upload_ms": round(up_ms, 1),
+                       "windows_rerun_general_path": eng.rerun_count(), "workspace_MB_per_slot": round(slot_bytes / 2 ** 20, 1),
+                       "kernel_ms": per_kernel},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": None,
-                         "kernel": "window_kernel", "kernel_ms": round(ms_kernel, 3), "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel": "+".join(names), "kernel_ms": round(ms_all, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "per_kernel_ms": per_kernel,
+                         "note": "one pass over the batch = the listed kernels back to back on one stream; achieved = algorithmic bytes of the batch / the sum of their HIP-event durations",
+                         "peak_measured_copy": 6290.0, "frac_of_measured_copy": round(achieved / 6290.0, 6)},
         }
-        # HBM-side bytes per launch from the committed PMC passes (tools/pmc_total.sh -> profiles/r1_traffic.json):
+        if world > 1:
+            out["config"]["merged_records_vdb"] = last.get("n", 0)
+            out["config"]["vdb_variants"] = last["db"].size() if "db" in last else 0
+            out["config"]["gather"] = "sizes all_gather + send/recv to rank 0 (RCCL), replay in window order into lancet_vdb inside the step"
+        # HBM-side bytes per launch from the committed PMC passes (tools/pmc_total.sh -> profiles/r2_traffic.json):
         # rocprofv3 cannot run inside this process, so the figure is looked up for the exact workload it was taken on
         try:
-            with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as fh:
                 for rec in json.load(fh)["measurements"]:
                     if rec["windows"] == args.windows and rec["coverage"] == args.cov and world == 1:
                         out["roofline"]["traffic"] = int((rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024)
@@ -122,17 +237,14 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         if args.cpu_sample and world == 1:
-            from oracle import oracle
-            ns = min(args.cpu_sample, batch.n_windows)
-            sample = workload.sub_batch(batch, 0, ns)
-            t1 = time.perf_counter()
-            ov, ostats, _ = oracle.run(sample, params)
-            cdt = time.perf_counter() - t1
-            same = ov == [v for v in variants if v["window"] < ns]
-            out["cpu_baseline"] = {"value": round(ns / cdt, 2), "unit": "windows/s", "cores": 1, "kind": "port",
-                                   "sample": f"first {ns} windows of the same batch, oracle/liblancet_oracle.so, 1 thread, {cdt:.1f} s",
-                                   "mkmers_per_s": round(sum(s["n_kmers"] for s in ostats) / cdt / 1e6, 3),
-                                   "gpu_results_identical_on_sample": bool(same)}
+            out["cpu_baseline"] = cpu_baseline(batch, params, variants, args.cpu_sample, args.cpu_sample_all)
+        eng.close()
+        if world == 1 and not args.no_configs:
+            out["configs"] = [
+                side_config(engine.Engine, params, "config 2 at 60x/60x", 8192, 60.0, 60.0, 2),
+                side_config(engine.Engine, params, "config 4: 100x tumor / 40x normal, 30 % STR + 5 % low complexity", 4096, 100.0, 40.0, 2,
+                            str_fraction=0.30, lowcomplex_fraction=0.05),
+            ]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -168,6 +168,10 @@ int lancet_engine_results(lancet_engine *e, const lancet_variant **variants, uin
 /* Linked-read annotations of the last run (lr_mode engines; otherwise *lr = NULL): lr[i] belongs to variants[i]. */
 int lancet_engine_results_lr(lancet_engine *e, const lancet_variant_lr **lr, const uint32_t **bx_blob, uint32_t *bx_blob_len);
 int lancet_engine_last_timing(lancet_engine *e, float out[2]);
+/* The kernels one run launches, back to back on the engine's stream: lancet_engine_kernel_name(i) for i = 0, 1, ... (NULL past
+ * the last) and the HIP-event duration of each in the last run (milliseconds; returns how many were written, <= cap). */
+const char *lancet_engine_kernel_name(int i);
+int lancet_engine_kernel_times(lancet_engine *e, float *ms, int cap);
 
 /* ---- the reference's -v stage trace (reference src/Microassembler.cc:87-246, Graph.cc verbose blocks) ----
  * lancet_engine_set_trace: before an upload, reserve words_per_window 32-bit words of trace events per window (0 = off).

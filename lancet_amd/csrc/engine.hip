@@ -453,6 +453,16 @@ int lancet_engine_phase_times(lancet_engine *e, const unsigned long long **ticks
   return LANCET_OK;
 }
 
+// HIP-event durations (ms) of the kernels of the last run, in the order of lancet_engine_kernel_name(0..); returns how many
+static const char *const lc_kernel_names[] = {"window_kernel"};
+const char *lancet_engine_kernel_name(int i) { return (i >= 0 && i < (int)(sizeof(lc_kernel_names) / sizeof(lc_kernel_names[0]))) ? lc_kernel_names[i] : nullptr; }
+int lancet_engine_kernel_times(lancet_engine *e, float *ms, int cap) {
+  if (!e || !e->ran) return LANCET_E_STATE;
+  if (cap < 1 || !ms) return LANCET_E_ARG;
+  ms[0] = e->ms_kernel;
+  return 1;
+}
+
 // number of windows of the last run that needed the worst-case work space (tier 2)
 int lancet_engine_rerun_count(lancet_engine *e) { return e ? e->n_rerun : -1; }
 

@@ -1,11 +1,18 @@
-"""Multi-GPU: windows are sharded across ranks (no data-path collective); the only exchange is the gather of
-variant records into the VariantDB on rank 0: sizes via all_gather, payload via padded
-all_gather of one uint8 tensor per rank (NCCL == RCCL on ROCm; gloo on CPU for the tests).  Records are tiny
-(tens of bytes per variant), so this is latency- not bandwidth-bound on xGMI."""
+"""Multi-GPU: windows are sharded across ranks (independent units, no data-path collective); the only exchange is the
+gather of the variant records into the VariantDB on rank 0.
+
+  sizes    one all_gather of 8 bytes per rank
+  payload  point-to-point send / recv to rank 0 only (RCCL over xGMI on the GPUs, gloo in the CPU tests): a gatherv
+
+A payload carries everything `Variant_t`'s constructor gets (reference src/Graph.cc:1166-1188): the packed
+`lancet_variant` records, their string blob and -- with --linked-reads -- the `lancet_variant_lr` records, the barcode ids
+of their four barcode sets and the names of the barcodes used (ids are ranks inside ONE batch, so they travel as names).
+Rank 0 replays the union in (global window index, emission order): `addVar` keeps the first record on ties
+(src/VariantDB.cc:51), so the VCF must not depend on how the windows were dealt out."""
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Tuple
+from typing import List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -13,39 +20,126 @@ import torch.distributed as dist
 
 from . import abi
 
+_VDT = np.dtype(abi.LancetVariant)
+_LDT = np.dtype(abi.LancetVariantLR)
+_HDR = 8          # u64 words
+
 
 def shard_windows(n_windows: int, rank: int, world: int, chunk: int = 4096) -> List[int]:
     """Window i -> rank (i // chunk) % world : contiguous chunks keep a rank's reads sequential (SURVEY.md §8(e))."""
     return [i for i in range(n_windows) if (i // chunk) % world == rank]
 
 
-def pack_records(vptr, n: int, blob: bytes) -> bytes:
-    raw = C.string_at(vptr, n * C.sizeof(abi.LancetVariant)) if n else b""
-    hdr = np.array([n, len(blob)], dtype=np.uint64).tobytes()
-    return hdr + raw + blob
+def pack_records(vptr, n: int, blob: bytes, lrptr=None, bx_blob=None, bx_names: Optional[Sequence[str]] = None,
+                 chr_names: Sequence[str] = ("chr22",), window_index: Optional[np.ndarray] = None) -> bytes:
+    """One rank's records as bytes.  window_index[w] = global index of the rank's window w (default: identity)."""
+    recs = np.frombuffer(C.string_at(vptr, n * _VDT.itemsize), dtype=_VDT).copy() if n else np.zeros(0, dtype=_VDT)
+    if window_index is not None and n:
+        recs["window"] = np.asarray(window_index, dtype=np.int64)[recs["window"]]
+    lr = b""; ids = np.zeros(0, dtype=np.uint32); names = b""
+    has_lr = lrptr is not None and bool(lrptr)
+    if has_lr:
+        l = np.frombuffer(C.string_at(lrptr, n * _LDT.itemsize), dtype=_LDT).copy() if n else np.zeros(0, dtype=_LDT)
+        nbx = int((l["bx_off"] + l["bx_len"]).max()) if n else 0
+        raw = np.ctypeslib.as_array(bx_blob, shape=(nbx,)).astype(np.uint32) if nbx else np.zeros(0, dtype=np.uint32)
+        used, inv = np.unique(raw, return_inverse=True)                       # only the barcodes that occur travel
+        ids = inv.astype(np.uint32)
+        names = "\0".join(bx_names[int(u)] for u in used).encode()
+        lr = l.tobytes()
+    chrs = "\0".join(chr_names).encode()
+    hdr = np.array([n, len(blob), 1 if has_lr else 0, len(ids), len(names), len(chrs), 0, 0], dtype=np.uint64)
+    return hdr.tobytes() + recs.tobytes() + blob + lr + ids.tobytes() + names + chrs
 
 
-def unpack_records(buf: bytes):
-    n, bl = (int(x) for x in np.frombuffer(buf[:16], dtype=np.uint64))
-    sz = C.sizeof(abi.LancetVariant)
-    arr = (abi.LancetVariant * n).from_buffer_copy(buf[16:16 + n * sz]) if n else (abi.LancetVariant * 0)()
-    blob = buf[16 + n * sz:16 + n * sz + bl]
-    return arr, n, blob
+def unpack_records(buf: bytes) -> dict:
+    n, bl, has_lr, nbx, nl, cl, _, _ = (int(x) for x in np.frombuffer(buf[:8 * _HDR], dtype=np.uint64))
+    o = 8 * _HDR
+    recs = np.frombuffer(buf[o:o + n * _VDT.itemsize], dtype=_VDT).copy(); o += n * _VDT.itemsize
+    blob = buf[o:o + bl]; o += bl
+    lr = None; ids = None; names: List[str] = []
+    if has_lr:
+        lr = np.frombuffer(buf[o:o + n * _LDT.itemsize], dtype=_LDT).copy(); o += n * _LDT.itemsize
+        ids = np.frombuffer(buf[o:o + 4 * nbx], dtype=np.uint32).copy(); o += 4 * nbx
+        names = buf[o:o + nl].decode().split("\0") if nl else []; o += nl
+    chrs = buf[o:o + cl].decode().split("\0") if cl else []
+    return dict(n=n, recs=recs, blob=blob, lr=lr, bx_ids=ids, bx_names=names, chr_names=chrs)
 
 
 def gather_bytes(payload: bytes, device: torch.device, dst: int = 0) -> List[bytes]:
-    """Variable-size gather to `dst` (returns [] on other ranks)."""
+    """Variable-size gather to `dst`: sizes by all_gather, payloads by send / recv to `dst` only.  Returns [] elsewhere."""
     world = dist.get_world_size()
     rank = dist.get_rank()
     size = torch.tensor([len(payload)], dtype=torch.int64, device=device)
     sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(sizes, size)
-    mx = int(max(int(s.item()) for s in sizes))
-    buf = torch.zeros(max(mx, 1), dtype=torch.uint8, device=device)
-    if payload:
-        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
-    outs = [torch.zeros(max(mx, 1), dtype=torch.uint8, device=device) for _ in range(world)]
-    dist.all_gather(outs, buf)
+    sizes = [int(s.item()) for s in sizes]
     if rank != dst:
+        if len(payload):
+            dist.send(torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device), dst=dst)
         return []
-    return [bytes(o[:int(s.item())].cpu().numpy().tobytes()) for o, s in zip(outs, sizes)]
+    bufs = [None] * world
+    reqs = []
+    for r in range(world):
+        if r == dst or sizes[r] == 0:
+            continue
+        bufs[r] = torch.empty(sizes[r], dtype=torch.uint8, device=device)
+        reqs.append(dist.irecv(bufs[r], src=r))
+    for q in reqs:
+        q.wait()
+    return [payload if r == dst else (bytes(bufs[r].cpu().numpy().tobytes()) if bufs[r] is not None else b"") for r in range(world)]
+
+
+def merge_into_vdb(parts: Sequence[bytes], db) -> int:
+    """Rank 0: replays the records of every rank into `db` (lancet_amd.engine.VariantDB) in (global window, emission)
+    order -- the order a single process would have produced them in.  Returns the number of records added."""
+    ps = [unpack_records(b) for b in parts if b]
+    ps = [p for p in ps if p["n"]]
+    if not ps:
+        return 0
+    chr_names: List[str] = []
+    bx_names: List[str] = []
+    bx_index = {}
+    recs_all, lr_all, ids_all, blobs = [], [], [], []
+    blob_base = 0; id_base = 0
+    lr_mode = any(p["lr"] is not None for p in ps)
+    for p in ps:
+        r = p["recs"]
+        cmap = np.zeros(max(1, len(p["chr_names"])), dtype=np.int32)
+        for i, c in enumerate(p["chr_names"]):
+            if c not in chr_names:
+                chr_names.append(c)
+            cmap[i] = chr_names.index(c)
+        r["chr_id"] = cmap[r["chr_id"]]
+        for f in ("ref_off", "alt_off", "str_off"):
+            r[f] += blob_base
+        blob_base += len(p["blob"]); blobs.append(p["blob"])
+        recs_all.append(r)
+        if lr_mode:
+            l = p["lr"]
+            gmap = np.zeros(max(1, len(p["bx_names"])), dtype=np.uint32)
+            for i, nm in enumerate(p["bx_names"]):
+                if nm not in bx_index:
+                    bx_index[nm] = len(bx_names); bx_names.append(nm)
+                gmap[i] = bx_index[nm]
+            l["bx_off"] += id_base
+            id_base += len(p["bx_ids"])
+            ids_all.append(gmap[p["bx_ids"]] if len(p["bx_ids"]) else np.zeros(0, dtype=np.uint32))
+            lr_all.append(l)
+    recs = np.concatenate(recs_all)
+    order = np.lexsort((recs["seq_in_window"], recs["window"]))
+    recs = np.ascontiguousarray(recs[order])
+    blob = b"".join(blobs) + b"\0"
+    vptr = recs.ctypes.data_as(C.POINTER(abi.LancetVariant))
+    if lr_mode:
+        # ids become ranks in the union's name order: a set stays sorted by name (std::set<string>) because every rank's ids
+        # were ranks by name already
+        rank_of = np.argsort(np.argsort(np.array(bx_names, dtype=object))) if bx_names else np.zeros(0, dtype=np.int64)
+        sorted_names = sorted(bx_names)
+        lr = np.ascontiguousarray(np.concatenate(lr_all)[order])
+        ids = rank_of[np.concatenate(ids_all)].astype(np.uint32) if id_base else np.zeros(1, dtype=np.uint32)
+        ids = np.ascontiguousarray(ids)
+        db.add_raw_lr(vptr, lr.ctypes.data_as(C.POINTER(abi.LancetVariantLR)), len(recs), blob,
+                      ids.ctypes.data_as(C.POINTER(C.c_uint32)), sorted_names, chr_names)
+    else:
+        db.add_raw(vptr, len(recs), blob, chr_names)
+    return len(recs)

@@ -45,6 +45,9 @@ def lib():
         L.lancet_engine_set_trace.argtypes = [C.c_void_p, C.c_uint32]
         L.lancet_engine_trace.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32)]
         L.lancet_engine_rerun_count.argtypes = [C.c_void_p]
+        L.lancet_engine_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+        L.lancet_engine_kernel_name.restype = C.c_char_p
+        L.lancet_engine_kernel_name.argtypes = [C.c_int]
         L.lancet_engine_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
         L.lancet_debug_align.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.lancet_engine_phase_times.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64))]
@@ -128,6 +131,23 @@ class Engine:
         t = (C.c_float * 2)()
         self._chk(self.L.lancet_engine_last_timing(self.h, C.byref(t)))
         return float(t[0]), float(t[1])
+
+    def kernel_names(self):
+        out = []
+        i = 0
+        while True:
+            n = self.L.lancet_engine_kernel_name(i)
+            if not n:
+                return out
+            out.append(n.decode()); i += 1
+
+    def kernel_times(self):
+        """HIP-event duration (ms) of every kernel of the last run, in kernel_names() order."""
+        buf = (C.c_float * 8)()
+        n = self.L.lancet_engine_kernel_times(self.h, buf, 8)
+        if n < 0:
+            self._chk(n)
+        return [float(buf[i]) for i in range(n)]
 
     def rerun_count(self) -> int:
         return int(self.L.lancet_engine_rerun_count(self.h))

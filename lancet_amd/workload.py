@@ -136,7 +136,9 @@ def sub_batch(b: WindowBatch, w0: int, w1: int) -> WindowBatch:
         ref_bases=b.ref_bases[f0:f1].copy(), read_begin=(b.read_begin[w0:w1 + 1] - r0).astype(np.uint32),
         seq_off=(b.seq_off[r0:r1 + 1] - s0).astype(np.uint32), seq=b.seq[s0:s1].copy(), qual=b.qual[s0:s1].copy(),
         label=b.label[r0:r1].copy(), strand=b.strand[r0:r1].copy(), mate=b.mate[r0:r1].copy(),
-        mapped=b.mapped[r0:r1].copy(), name_rank=b.name_rank[r0:r1].copy())
+        mapped=b.mapped[r0:r1].copy(), name_rank=b.name_rank[r0:r1].copy(),
+        bx_rank=None if b.bx_rank is None else b.bx_rank[r0:r1].copy(), hp=None if b.hp is None else b.hp[r0:r1].copy(),
+        bx_names=b.bx_names)      # (barcode ranks stay ranks among the parent batch's barcodes)
 
 
 def algorithmic_bytes(b: WindowBatch, stats, n_variants: int) -> int:

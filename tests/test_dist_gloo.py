@@ -1,5 +1,6 @@
-"""N>1 path on CPU: two gloo ranks shard windows, pack their variant records and gather them to rank 0, where the
-VariantDB/VCF of the union must equal the single-process result."""
+"""N>1 path on CPU: two gloo ranks shard the windows of a reference golden, pack their variant records (with the linked-read
+annotations when the case has them) and send them to rank 0, which replays the union in window order into the VariantDB:
+the VCF must equal the reference's single-process VCF."""
 import os
 import sys
 
@@ -13,27 +14,14 @@ import golden_util as gu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, case, q):
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def records_to_c(recs, lr):
+    """dict records (abi.variants_to_py / variants_lr_to_py) -> the arrays the engine hands out"""
     import ctypes as C
-    from lancet_amd import abi, dist as ldist, engine, workload
-    from oracle import oracle
-    meta, batch, kept, (min_k, max_k) = gu.case_batch(case)
-    mine = ldist.shard_windows(batch.n_windows, rank, world, chunk=7)
-    # contiguous runs of windows -> sub batches; records produced here by the oracle (no GPU in this test)
-    recs = []
-    for w in mine:
-        sub = workload.sub_batch(batch, w, w + 1)
-        v, _, _ = oracle.run(sub, abi.default_params(min_k=min_k, max_k=max_k))
-        for r in v:
-            r["window"] = w
-            recs.append(r)
-    arr = (abi.LancetVariant * len(recs))()
+    from lancet_amd import abi
+    arr = (abi.LancetVariant * max(1, len(recs)))()
     blob = bytearray()
+    lra = (abi.LancetVariantLR * max(1, len(recs)))() if lr else None
+    ids = []
     for i, r in enumerate(recs):
         x = arr[i]
         x.window, x.seq_in_window, x.chr_id, x.pos = r["window"], r["seq"], r["chr_id"], r["pos"]
@@ -43,21 +31,49 @@ def _worker(rank, world, port, case, q):
         x.ref_off, x.ref_len = len(blob), len(r["ref"]); blob += r["ref"].encode()
         x.alt_off, x.alt_len = len(blob), len(r["alt"]); blob += r["alt"].encode()
         x.str_off, x.str_len = len(blob), len(r["str"]); blob += r["str"].encode()
-    payload = ldist.pack_records(arr, len(recs), bytes(blob))
+        if lr:
+            for q in range(12):
+                lra[i].hp[q] = r["hp"][q]
+            for q in range(4):
+                lra[i].bx_off[q], lra[i].bx_len[q] = len(ids), len(r["bx"][q])
+                ids += list(r["bx"][q])
+    bxb = (C.c_uint32 * max(1, len(ids)))(*ids) if lr else None
+    return arr, bytes(blob), lra, bxb
+
+
+def _worker(rank, world, port, case, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lancet_amd import dist as ldist, engine, workload
+    from oracle import oracle
+    meta, batch, kept, (min_k, max_k) = gu.case_batch(case)
+    lr = gu.case_lr(meta)
+    p = gu.params(meta)
+    mine = ldist.shard_windows(batch.n_windows, rank, world, chunk=3)
+    # this rank's windows as ONE batch of its own (local window indices 0..len(mine)-1); records by the oracle (no GPU here)
+    recs = []
+    for li, w in enumerate(mine):
+        sub = workload.sub_batch(batch, w, w + 1)
+        v, _, _ = oracle.run(sub, p)
+        for r in v:
+            r["window"] = li
+            recs.append(r)
+    arr, blob, lra, bxb = records_to_c(recs, lr)
+    payload = ldist.pack_records(arr, len(recs), blob, lra, bxb, batch.bx_names, ["chr22"], window_index=mine)
     parts = ldist.gather_bytes(payload, torch.device("cpu"))
     if rank == 0:
-        allrecs = []
-        for buf in parts:
-            a, n, b = ldist.unpack_records(buf)
-            allrecs += abi.variants_to_py(a, n, b)
-        allrecs.sort(key=lambda r: (r["window"], r["seq"]))      # replay in window order, whatever the rank count
         db = engine.VariantDB()
-        db.add_records(allrecs, ["chr22"])
-        q.put(db.vcf())
+        n = ldist.merge_into_vdb(parts, db)
+        q.put((n, db.vcf()))
+    else:
+        assert parts == []
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["tile30"])
+@pytest.mark.parametrize("case", ["tile30", "lr30"])
 def test_two_rank_gather_reproduces_single_process_vcf(case):
     from lancet_amd import build
     build.build()
@@ -67,10 +83,11 @@ def test_two_rank_gather_reproduces_single_process_vcf(case):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
     for p in procs:
         p.start()
-    vcf = q.get(timeout=300)
+    n, vcf = q.get(timeout=300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    assert n > 0
     assert vcf == gu.golden_vcf(case)
 
 
@@ -79,3 +96,20 @@ def test_shard_windows_partitions_everything():
     for world in (1, 2, 4, 8):
         seen = sorted(w for r in range(world) for w in ldist.shard_windows(1000, r, world, chunk=64))
         assert seen == list(range(1000))
+
+
+def test_bench_spawns_its_ranks(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE must re-launch itself under torch.distributed.run with N ranks."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    seen = {}
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(os, "execvp", lambda prog, argv: seen.setdefault("argv", argv))
+    bench.maybe_spawn(["--gpus", "4", "--steps", "2"], 4)
+    a = seen["argv"]
+    assert "torch.distributed.run" in a and "--nproc-per-node=4" in a and a[-4:] == ["--gpus", "4", "--steps", "2"]
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    seen.clear()
+    bench.maybe_spawn(["--gpus", "4"], 4)
+    assert not seen
