@@ -1,0 +1,761 @@
+// build_lds.h -- the first graph of every window, assembled in LDS (one 256-lane workgroup per window).
+//
+// What buildgraph / loadSequence (reference src/Graph.cc:119-349, 530-589) and the first removeLowCov(false, 0)
+// (src/Graph.cc:2790-2827) leave behind, computed with the window's working set in LDS instead of HBM:
+//   * the window's trimmed reads + the reference pseudo-read, 2 bit / base, and their quality masks: copied into LDS once;
+//   * the k-mer table: 8192 open-addressing slots of 4 bytes = 16-bit fingerprint | offset (in the LDS copy of the reads) of
+//     the k-mer's first occurrence.  A fingerprint match is confirmed by cutting that earlier k-mer out of the LDS reads, so the
+//     table needs no key storage and atomicMin on the word keeps the FIRST occurrence (= first-insertion order of
+//     std::unordered_map, which fixes the node ids);
+//   * per node: occurrence count, then -- only for the nodes whose count leaves the first low-coverage test open ("tracked") --
+//     the four strand/sample counts, colours and mate-pair signatures with LDS atomics (no csr, no per-occurrence HBM traffic);
+//   * per-position quality counts of the candidates as "counted - bases below MIN_QUAL_CALL" (about one LDS atomic per
+//     occurrence instead of k), in groups of candidates that fit LDS;
+//   * first-seen edge stamps of the survivors (atomicMin per (node, side, base) slot), resolved to edges in first-seen order.
+// HBM sees the packed reads once (coalesced), a 2-byte node id per occurrence (written once, streamed by the later passes) and
+// the hand-off area of the window (layout.h: PreHdr ...), which holds only what the graph phases of kernels.h read.
+//
+// The kernel builds the graph for the smallest k that passes the reference-repeat tests (Microassembler.cc:118-131) -- the
+// first buildgraph of the self-tuning-k loop; later k attempts of a window (8 % of the windows of a 30x/30x scan) and every
+// window outside the limits below run the general build phases of kernels.h.  Nothing is approximated: a window either gets
+// the identical node table here or is marked PB_NOT_BUILT.
+//
+// Not handled here (-> PB_NOT_BUILT, general path): --linked-reads, N in the window reference, even k or k > 31, windows
+// above the LDS limits, windows with an occurrence the mate-overlap prefilter flags (hasOverlappingMate needs the replay of
+// build_csr), reads whose name occurs more than once with the same mate number.
+#pragma once
+#include "kernels.h"
+
+#define BL_WG 256
+#define BL_BASES 40960            /* bases in LDS (reads padded to 16, + the reference)                       */
+#define BL_RMAX 512               /* reads per window                                                          */
+#define BL_SLOTS 8192
+#define BL_TCAP 2048              /* tracked nodes                                                             */
+#define BL_BIG 32768              /* bytes of the phase-dependent LDS area                                     */
+#define BL_EMPTY 0xFFFFFFFFu
+
+enum { BLW_NONE = 0, BLW_NOREADS, BLW_SIZE, BLW_HASN, BLW_K, BLW_TABLE, BLW_NODES, BLW_TRACKED, BLW_CAND, BLW_QV, BLW_SURV, BLW_MATE, BLW_NAMES, BLW_PAIRS };
+
+struct BlShared {
+  uint32_t bases[BL_BASES / 16 + 4];
+  uint32_t goodm[BL_BASES / 32 + 4];
+  uint16_t rdo[BL_RMAX + 4];        /* first 16-base word of read r                                             */
+  uint16_t gwo[BL_RMAX + 4];        /* first quality-mask word of read r                                        */
+  uint16_t obase[BL_RMAX + 4];      /* first occurrence index of read r; [R] = O                                */
+  uint32_t rinfo[BL_RMAX + 4];
+  uint8_t pidx[BL_RMAX + 4];        /* mate-pair signature bit of the read (0xFF none)                          */
+  uint8_t prole[BL_RMAX + 4];       /* 1 = earlier mate of a pair, 2 = the later one                            */
+  uint16_t idoff[PB_NCAP];          /* node id -> LDS offset of its first occurrence                            */
+  uint16_t cidx[PB_NCAP];           /* node id -> tracked index, later survivor index (0xFFFF none)             */
+  uint16_t t2c[BL_TCAP];            /* tracked index -> candidate index (0xFFFF none)                           */
+  uint32_t big[BL_BIG / 4];
+  uint32_t wsum[BL_WG / 64 + 1];
+  uint32_t scan_total;
+  int w, R, reflen, K, hasN, mapped;
+  uint32_t O, N, T, ncand, nsurv, nbw, ngw;
+  uint32_t totalreadbp, n_kmers;
+  int repE, repM;
+  int why;
+  uint32_t npairs, flagged, edges_total, refn;
+  uint32_t g0, g1;                  /* group bounds of the current pass                                          */
+};
+
+/* per-workgroup scratch in HBM (streamed, never shared between windows in flight) */
+struct BlScratch {
+  LC_GLOBAL uint16_t *occn;         /* [BL_BASES] slot, then node id | ori << 15, per k-mer start offset         */
+  LC_GLOBAL unsigned long long *tcc;/* [BL_TCAP] counted occurrences Tf Tr Nf Nr (4 x 16 bit)                    */
+  LC_GLOBAL uint32_t *tfl;          /* [BL_TCAP] NF_TUMOR | NF_NORMAL                                            */
+  LC_GLOBAL uint32_t *c_id;         /* [PB_CCAP] node of candidate ci                                            */
+  LC_GLOBAL uint32_t *c_ti;         /* [PB_CCAP] its tracked index                                               */
+  LC_GLOBAL uint32_t *c_minqv;      /* [PB_CCAP]                                                                 */
+  LC_GLOBAL uint32_t *s_ci;         /* [PB_SCAP] candidate of survivor si                                        */
+  LC_GLOBAL uint32_t *s_edges;      /* [PB_SCAP * 9] resolved edges + count                                      */
+};
+#define BL_SCRATCH_BYTES (2u * BL_BASES + 64u + 8u * BL_TCAP + 4u * BL_TCAP + 12u * PB_CCAP + 4u * PB_SCAP + 36u * PB_SCAP + 512u)
+DEV void bl_scratch_carve(BlScratch *s, char *base) {
+  size_t o = 0;
+  auto take = [&](size_t bytes) { char *p = base + o; o = (o + bytes + 63) & ~(size_t)63; return p; };
+  s->occn = (LC_GLOBAL uint16_t *)take(2u * BL_BASES + 64u);
+  s->tcc = (LC_GLOBAL unsigned long long *)take(8u * BL_TCAP);
+  s->tfl = (LC_GLOBAL uint32_t *)take(4u * BL_TCAP);
+  s->c_id = (LC_GLOBAL uint32_t *)take(4u * PB_CCAP);
+  s->c_ti = (LC_GLOBAL uint32_t *)take(4u * PB_CCAP);
+  s->c_minqv = (LC_GLOBAL uint32_t *)take(4u * PB_CCAP);
+  s->s_ci = (LC_GLOBAL uint32_t *)take(4u * PB_SCAP);
+  s->s_edges = (LC_GLOBAL uint32_t *)take(36u * PB_SCAP);
+}
+
+typedef LC_LDS BlShared BL_S;
+#ifndef LANCET_WAVE_EMU
+static __shared__ BlShared bl_shared;
+template <class P> DEV unsigned long long dev_atomic_add64(P p, unsigned long long v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <class P> DEV unsigned long long dev_atomic_or64(P p, unsigned long long v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#else
+DEV unsigned long long dev_atomic_add64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
+DEV unsigned long long dev_atomic_or64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o | v; return o; }
+#endif
+
+// uniform read of a control word: barrier, read, barrier (kernels.h wg_bcast)
+#define bl_bcast(p) wg_bcastu(p)
+
+// exclusive prefix sum of an LDS array in place, whole workgroup; the total lands in S.scan_total
+DEV void bl_scan32(LC_LDS uint32_t *a, int n, BL_S &S) {
+  WG_SYNC();
+#ifndef LANCET_WAVE_EMU
+  const int t = (int)threadIdx.x, chunk = (n + BL_WG - 1) / BL_WG;
+  int lo = t * chunk, hi = lo + chunk; if (lo > n) lo = n; if (hi > n) hi = n;
+  uint32_t s = 0;
+  for (int i = lo; i < hi; ++i) s += a[i];
+  uint32_t inc = s; const int lane = t & 63;
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += x; }
+  if (lane == 63) S.wsum[t >> 6] = inc;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int i = 0; i < (t >> 6); ++i) woff += S.wsum[i];
+  uint32_t run = woff + inc - s;
+  for (int i = lo; i < hi; ++i) { const uint32_t x = a[i]; a[i] = run; run += x; }
+  if (t == BL_WG - 1) S.scan_total = run;
+  __syncthreads();
+#else
+  uint32_t run = 0;
+  for (int i = 0; i < n; ++i) { const uint32_t x = a[i]; a[i] = run; run += x; }
+  S.scan_total = run;
+#endif
+}
+
+// the k-mer that starts at LDS offset `boff`: base j at bits 2j (k <= 31)
+DEV unsigned long long bl_kmer(const LC_LDS uint32_t *bases, uint32_t boff, unsigned long long kmask) {
+  const uint32_t w = boff >> 4, sh = (boff & 15u) * 2u;
+  const unsigned long long lo = (unsigned long long)bases[w] | ((unsigned long long)bases[w + 1] << 32);
+  const unsigned long long v = sh ? ((lo >> sh) | ((unsigned long long)bases[w + 2] << (64u - sh))) : lo;
+  return v & kmask;
+}
+// canonical form as kernels.h holds it (first base most significant; CanonicalMer_t::set, reference src/Mer.hh:57-71: tie -> R)
+DEV unsigned long long bl_canon(unsigned long long v, int K, unsigned long long kmask, bool *isF) {
+  const unsigned long long rc = (~v) & kmask;
+  unsigned long long fw = dev_brev64(v);
+  fw = ((fw >> 1) & 0x5555555555555555ULL) | ((fw & 0x5555555555555555ULL) << 1);
+  fw >>= (64 - 2 * K);
+  *isF = fw < rc;
+  return *isF ? fw : rc;
+}
+DEV int bl_base(const LC_LDS uint32_t *bases, uint32_t boff) { return (int)((bases[boff >> 4] >> ((boff & 15u) * 2u)) & 3u); }
+// quality-mask bits [a, b) of a read whose mask starts at word gw: all set?
+DEV bool bl_all_good(const LC_LDS uint32_t *goodm, uint32_t gw, int a, int b) {
+  for (int i = a; i < b;) {
+    const int w = i >> 5, lo = i & 31;
+    int take = 32 - lo; if (take > b - i) take = b - i;
+    uint32_t m = goodm[gw + w] >> lo;
+    const uint32_t full = take < 32 ? ((1u << take) - 1u) : 0xFFFFFFFFu;
+    if ((m & full) != full) return false;
+    i += take;
+  }
+  return true;
+}
+
+// every occurrence o of the window: read r, k-mer start p in the read, LDS offset boff of the k-mer (lane-strided)
+#define BL_OCC_BEGIN(S) WG_FOR(_t, BL_WG) { uint32_t _r = 0; const int _O = (int)(S).O, _R = (S).R; \
+  for (int o = _t; o < _O; o += BL_WG) { while ((int)_r + 1 < _R && (uint32_t)o >= (S).obase[_r + 1]) ++_r; \
+    const int r = (int)_r; const int p = o - (int)(S).obase[r]; const uint32_t boff = 16u * (S).rdo[r] + (uint32_t)p; (void)p; (void)boff; (void)r;
+#define BL_OCC_END } }
+
+#define BL_FAIL(S, code) do { (S).why = (code); } while (0)
+
+// One window.  Returns with the hand-off area of the window written (PB_BUILT) or marked PB_NOT_BUILT.
+DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *Bp, LC_GLOBAL const EngineCaps *C, BL_S &S, BlScratch &X,
+                           LC_GLOBAL uint8_t *area, int w) {
+  LC_GLOBAL const DevBatch &B = *Bp;
+  LC_GLOBAL PreHdr *H = (LC_GLOBAL PreHdr *)(area + PRE_OFF_HDR);
+  const uint32_t g0 = B.read_begin[w];
+  const int nr = (int)(B.read_begin[w + 1] - g0);
+  const int reflen = (int)(B.ref_off[w + 1] - B.ref_off[w]);
+  LC_GLOBAL const uint8_t *refc = B.ref_codes + B.ref_off[w];
+  WG_LANE0 { S.w = w; S.why = BLW_NONE; S.R = nr + 1; S.reflen = reflen; S.hasN = 0; S.mapped = 0; S.flagged = 0; S.npairs = 0; S.edges_total = 0; S.refn = 0;
+             H->status = PB_NOT_BUILT; H->why = 0;
+             if (nr > BL_RMAX || reflen > LC_MAXW || reflen < 1) S.why = BLW_SIZE; }
+  if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
+  // ---- mapped reads, N in the window reference, per-read geometry
+  LC_LDS uint32_t *tmpA = S.big, *tmpB = S.big + (BL_RMAX + 8), *tmpC = S.big + 2 * (BL_RMAX + 8);
+  WG_FOR(r, nr + 1) {
+    uint32_t ri = 0; int tlen = reflen;
+    if (r < nr) { ri = B.rinfo[g0 + (uint32_t)r]; tlen = (int)RI_TLEN(ri); if (RI_MAPPED(ri)) dev_atomic_add((LC_LDS uint32_t *)&S.mapped, 1u); }
+    S.rinfo[r] = ri;
+    tmpA[r] = (uint32_t)((tlen + 15) / 16); tmpB[r] = (uint32_t)((tlen + 31) / 32);
+  }
+  WG_FOR(i, reflen) { if (refc[i] > 3) S.hasN = 1; }
+  WG_LANE0 { tmpA[nr + 1] = 0; tmpB[nr + 1] = 0; }
+  bl_scan32(tmpA, nr + 2, S);
+  const uint32_t nbw = bl_bcast(&S.scan_total);
+  bl_scan32(tmpB, nr + 2, S);
+  const uint32_t ngw = bl_bcast(&S.scan_total);
+  WG_LANE0 {
+    S.nbw = nbw; S.ngw = ngw;
+    if (S.mapped <= 0) S.why = BLW_NOREADS;                    // the window kernel reports LANCET_W_NO_READS itself
+    else if (S.hasN) S.why = BLW_HASN;
+    else if (nbw > BL_BASES / 16 || ngw > BL_BASES / 32) S.why = BLW_SIZE;
+  }
+  if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
+  WG_FOR(r, nr + 2) { S.rdo[r] = (uint16_t)tmpA[r]; S.gwo[r] = (uint16_t)tmpB[r]; }
+  WG_SYNC();
+  // ---- the window's packed reads and quality masks into LDS (whole words; a read starts on a word)
+  WG_FOR(r, nr) {
+    const uint32_t ri = S.rinfo[r]; const int tlen = (int)RI_TLEN(ri);
+    LC_GLOBAL const uint32_t *bsrc = B.bases + B.base_woff[g0 + (uint32_t)r], *gsrc = B.good + B.good_woff[g0 + (uint32_t)r];
+    const int nb = (tlen + 15) / 16, ng = (tlen + 31) / 32;
+    for (int i = 0; i < nb; ++i) S.bases[S.rdo[r] + i] = bsrc[i];
+    for (int i = 0; i < ng; ++i) S.goodm[S.gwo[r] + i] = gsrc[i];
+  }
+  WG_FOR(wd, (reflen + 15) / 16) {
+    uint32_t v = 0;
+    for (int j = 0; j < 16 && wd * 16 + j < reflen; ++j) v |= (uint32_t)(refc[wd * 16 + j] & 3u) << (2 * j);
+    S.bases[S.rdo[nr] + wd] = v;
+  }
+  WG_FOR(i, 4) { S.bases[nbw + (uint32_t)i] = 0; }
+  WG_SYNC();
+  // ---- reference repeat scan -> the first k of the loop that reaches buildgraph (Microassembler.cc:118-131)
+  repeat_scan((volatile LC_LDS unsigned long long *)(S.big + 4 * (BL_RMAX + 8)), refc, reflen, P->max_mismatch, (volatile LC_LDS int *)&S.repE, (volatile LC_LDS int *)&S.repM);
+  WG_LANE0 {
+    int K = 0;
+    for (int k = P->min_k; k <= P->max_k; k += 2) {
+      if (reflen - k > 0 && S.repE >= k) continue;
+      if (reflen - k > 0 && S.repM >= k + 1) continue;
+      K = k; break;
+    }
+    S.K = K;
+    if (K == 0 || K > 31 || (K & 1) == 0) S.why = BLW_K;
+  }
+  if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
+  const int K = (int)bl_bcast(&S.K);
+  const unsigned long long kmask = (1ULL << (2 * K)) - 1ULL;
+  const int R = nr + 1;
+  // ---- occurrence index space (read r owns its k-mers p = 0..tlen-K; a read of exactly K bases has none, Graph.cc:142-143)
+  WG_LANE0 { S.totalreadbp = 0; S.n_kmers = 0; }
+  WG_SYNC();
+  WG_FOR(r, R) {
+    const int tlen = r < nr ? (int)RI_TLEN(S.rinfo[r]) : reflen;
+    tmpC[r] = tlen - K > 0 ? (uint32_t)(tlen - K + 1) : 0u;
+    if (tlen > 0 && r < nr) dev_atomic_add((LC_LDS uint32_t *)&S.totalreadbp, (uint32_t)tlen);
+    if (tlen - K > 0) dev_atomic_add((LC_LDS uint32_t *)&S.n_kmers, (uint32_t)(tlen - K));
+  }
+  WG_LANE0 { tmpC[R] = 0; }
+  bl_scan32(tmpC, R + 1, S);
+  WG_FOR(r, R + 1) { S.obase[r] = (uint16_t)tmpC[r]; }
+  WG_LANE0 { S.O = S.scan_total; }
+  WG_SYNC();
+  // ---- mate pairs: a read with exactly one earlier read of the same name and the opposite mate number is the later mate of
+  //      a pair (kernels.h build_tables: cand / mate_of); several such reads -> general path
+  {
+    LC_LDS uint32_t *first = S.big;                              // [2 * (BL_RMAX + 1)] smallest read index per (name, mate)
+    LC_LDS uint32_t *cnt = S.big + 2 * (BL_RMAX + 1);
+    WG_FOR(i, 4 * (BL_RMAX + 1)) { S.big[i] = i < 2 * (BL_RMAX + 1) ? 0xFFFFFFFFu : 0u; }
+    WG_FOR(r, R) { S.pidx[r] = 0xFF; S.prole[r] = 0; }
+    WG_SYNC();
+    WG_FOR(r, nr) {
+      const uint32_t mi = RI_MATE(S.rinfo[r]);
+      if (mi == 1 || mi == 2) {
+        const uint32_t nm = B.name_rank[g0 + (uint32_t)r];
+        if (nm > BL_RMAX) S.why = BLW_NAMES;
+        else { dev_atomic_min(&first[2 * nm + (mi - 1)], (uint32_t)r); dev_atomic_add(&cnt[2 * nm + (mi - 1)], 1u); }
+      }
+    }
+    WG_SYNC();
+    LC_LDS uint32_t *isl = S.big + 4 * (BL_RMAX + 1);          // later-mate flag per read -> pair index by scan
+    WG_FOR(r, nr + 1) {
+      uint32_t later = 0;
+      if (r < nr && !S.why) {
+        const uint32_t mi = RI_MATE(S.rinfo[r]);
+        if (mi == 1 || mi == 2) {
+          const uint32_t nm = B.name_rank[g0 + (uint32_t)r];
+          const uint32_t oc = cnt[2 * nm + (2 - mi)], of = first[2 * nm + (2 - mi)];
+          if (oc == 1 && of < (uint32_t)r) { later = 1; if (cnt[2 * nm + (mi - 1)] > 1) S.why = BLW_NAMES; }   // (two reads of this name and mate number would share the earlier mate)
+          else if (oc > 1 && of < (uint32_t)r) S.why = BLW_NAMES;   // (several earlier mates: the general path sorts it out)
+        }
+      }
+      isl[r] = later;
+    }
+    bl_scan32(isl, nr + 1, S);
+    WG_LANE0 { S.npairs = S.scan_total; if (S.scan_total > 254u) S.why = BLW_PAIRS; }
+    WG_SYNC();
+    WG_FOR(r, nr) {
+      if (!S.why && isl[r + 1] != isl[r]) {
+        const uint32_t mi = RI_MATE(S.rinfo[r]), nm = B.name_rank[g0 + (uint32_t)r];
+        const uint32_t q = first[2 * nm + (2 - mi)];
+        S.pidx[r] = (uint8_t)isl[r]; S.prole[r] = 2;
+        S.pidx[q] = (uint8_t)isl[r]; S.prole[q] = 1;               // (q is the earlier mate of exactly this read: its name has one read per mate number before r)
+      }
+    }
+  }
+  if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
+  // ---- pass 1: every k-mer into the table (first occurrence kept), slot per occurrence to HBM
+  LC_LDS uint32_t *tab = S.big;
+  WG_FOR(i, BL_SLOTS) { tab[i] = BL_EMPTY; }
+  WG_SYNC();
+  BL_OCC_BEGIN(S)
+    bool isF;
+    const unsigned long long ck = bl_canon(bl_kmer(S.bases, boff, kmask), K, kmask, &isF);
+    const unsigned long long h = mix64(ck + 1ULL);
+    uint32_t idx = (uint32_t)h & (BL_SLOTS - 1);
+    uint32_t fp = (uint32_t)(h >> 40) & 0xFFFFu; if (fp == 0xFFFFu) fp = 0xFFFEu;
+    const uint32_t mine = (fp << 16) | boff;
+    uint32_t probes = 0;
+    while (true) {
+      uint32_t cur = ld2(&tab[idx]);
+      if (cur == BL_EMPTY) { cur = dev_atomic_cas32(&tab[idx], BL_EMPTY, mine); if (cur == BL_EMPTY) break; }
+      if ((cur >> 16) == fp) {
+        bool f2;
+        if (bl_canon(bl_kmer(S.bases, cur & 0xFFFFu, kmask), K, kmask, &f2) == ck) { if (mine < cur) dev_atomic_min(&tab[idx], mine); break; }
+      }
+      idx = (idx + 1) & (BL_SLOTS - 1);
+      if (++probes > 256u) { S.why = BLW_TABLE; break; }
+    }
+    X.occn[boff] = (uint16_t)(idx | (isF ? 0u : 0x8000u));
+  BL_OCC_END
+  if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
+  // ---- node ids in first-insertion order: rank of the slot's first-occurrence offset among the occupied slots
+  {
+    LC_LDS uint32_t *bm = (LC_LDS uint32_t *)S.cidx;           // 1024 words of bitmap + 1024 words of prefix (cidx is idle: 12 KB)
+    LC_LDS uint32_t *pre = bm + BL_BASES / 32;
+    WG_FOR(i, BL_BASES / 32) { bm[i] = 0; }
+    WG_SYNC();
+    WG_FOR(i, BL_SLOTS) { const uint32_t e = tab[i]; if (e != BL_EMPTY) dev_atomic_or(&bm[(e & 0xFFFFu) >> 5], 1u << (e & 31u)); }
+    WG_SYNC();
+    WG_FOR(i, BL_BASES / 32) { pre[i] = (uint32_t)dev_popc(bm[i]); }
+    bl_scan32(pre, BL_BASES / 32, S);
+    WG_LANE0 { S.N = S.scan_total; if (S.scan_total > PB_NCAP) S.why = BLW_NODES; }
+    if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
+    WG_FOR(i, BL_SLOTS) {
+      const uint32_t e = tab[i];
+      if (e != BL_EMPTY) {
+        const uint32_t off = e & 0xFFFFu;
+        const uint32_t id = pre[off >> 5] + (uint32_t)dev_popc(bm[off >> 5] & ((1u << (off & 31u)) - 1u));
+        tab[i] = id;                                             // slot -> node id, occurrence count in the upper half (below)
+        S.idoff[id] = (uint16_t)off;
+      }
+    }
+    WG_SYNC();
+  }
+  const uint32_t N = bl_bcast(&S.N);
+  // ---- pass 2: slot -> node id per occurrence (HBM, streamed), occurrences per node
+  BL_OCC_BEGIN(S)
+    const uint32_t e = X.occn[boff];
+    const uint32_t old = dev_atomic_add(&tab[e & (BL_SLOTS - 1)], 1u << 16);
+    X.occn[boff] = (uint16_t)((old & 0xFFFFu) | (e & 0x8000u));
+  BL_OCC_END
+  WG_SYNC();
+  // ---- std::hash of every node's k-mer (libstdc++ table order), survivor bytes cleared
+  {
+    LC_GLOBAL unsigned long long *nhash = (LC_GLOBAL unsigned long long *)(area + PRE_OFF_NHASH);
+    LC_GLOBAL uint8_t *surv = (LC_GLOBAL uint8_t *)(area + PRE_OFF_SURV);
+    WG_FOR(n, N) {
+      bool f; const unsigned long long ck = bl_canon(bl_kmer(S.bases, S.idoff[n], kmask), K, kmask, &f);
+      nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGT"[key_base(&ck, K, j)]; }, K);
+      surv[n] = 0;
+    }
+  }
+  // ---- tracked nodes: those whose occurrence count leaves the first removeLowCov test open, and every node with a read AND
+  //      a reference occurrence (their counts feed Ref_t::computeCoverage).  A node with one occurrence is decided: its
+  //      counted occurrences are <= 1 (removeLowCov: mincovQV <= max(LOW_COV_THRESHOLD, MIN_COV_RATIO * avgcov)).
+  const double avgcov = ((double)S.totalreadbp) / ((double)reflen);
+  int tmin = 1;
+  while ((tmin <= P->low_cov_threshold) || ((double)tmin <= (P->min_cov_ratio * avgcov))) ++tmin;
+  const uint32_t tthr = tmin < 2 ? (uint32_t)tmin : 2u;
+  WG_FOR(i, BL_SLOTS) { const uint32_t e = tab[i]; if (e != BL_EMPTY) S.cidx[e & 0xFFFFu] = (uint16_t)(e >> 16); }     // count by node id
+  WG_SYNC();
+  {
+    LC_LDS uint32_t *fl = S.big;                                 // (the table is no longer needed: occn holds node ids)
+    WG_FOR(n, N + 1) { fl[n] = (n < (int)N && S.cidx[n] >= tthr) ? 1u : 0u; }
+    bl_scan32(fl, (int)N + 1, S);
+    WG_LANE0 { S.T = S.scan_total; if (S.scan_total > BL_TCAP) S.why = BLW_TRACKED; }
+    if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
+    WG_FOR(n, N) { S.cidx[n] = (fl[n + 1] != fl[n]) ? (uint16_t)fl[n] : (uint16_t)0xFFFFu; }
+    WG_SYNC();
+  }
+  const uint32_t T = bl_bcast(&S.T);
+  // ---- pass 3 (tracked nodes): counted occurrences per strand / sample, colours (Graph.cc:200-217), pair signatures
+  //      S.big: cc[T] (u64) | sig[T * SW] (u64, earlier mates present, one bit per pair) ... todo[1024] | mk[64] at the end
+  {
+    const uint32_t npairs = bl_bcast(&S.npairs);
+    const uint32_t SW = (npairs + 63u) / 64u;
+    LC_LDS unsigned long long *cc = (LC_LDS unsigned long long *)S.big;
+    LC_LDS unsigned long long *sig = cc + T;
+    LC_LDS uint32_t *mk = S.big + BL_BIG / 4 - 64;                 // marked tracked nodes (hold a flagged occurrence)
+    LC_LDS uint32_t *todo = mk - 1024;                             // flagged occurrences: read << 10 | position
+    WG_LANE0 { S.flagged = 0; if (2u * T * (1u + SW) > (uint32_t)(BL_BIG / 4 - 64 - 1024)) S.why = BLW_PAIRS; }
+    if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
+    WG_FOR(t, T) { cc[t] = 0; S.t2c[t] = 0; }
+    WG_FOR(t, T * SW) { sig[t] = 0; }
+    WG_FOR(i, 64) { mk[i] = 0; }
+    WG_SYNC();
+    BL_OCC_BEGIN(S)
+      if (r == nr) continue;                                       // the reference read: no colour, never counted (Graph.cc:265)
+      const uint32_t e = X.occn[boff];
+      const uint32_t ti = S.cidx[e & 0x1FFFu];
+      if (ti == 0xFFFFu) continue;
+      const uint32_t ri = S.rinfo[r];
+      const uint32_t cls = (RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u);
+      dev_atomic_add64(&cc[ti], 1ULL << (16 * cls));
+      if (RI_NML(ri)) { if (!(S.t2c[ti] & 2u)) dev_atomic_or((LC_LDS uint32_t *)&S.t2c[ti & ~1u], (ti & 1u) ? (2u << 16) : 2u); }
+      else if (!(S.t2c[ti] & 1u)) {
+        const int tlen = (int)RI_TLEN(ri);
+        const uint32_t gw = S.gwo[r];
+        // the step's u and v both pass MIN_QUAL_CALL at every base: bases s..s+K of the read, for step s = p or p - 1
+        const bool ok = (p < tlen - K && bl_all_good(S.goodm, gw, p, p + K + 1)) || (p - 1 >= 0 && p - 1 < tlen - K && bl_all_good(S.goodm, gw, p - 1, p + K));
+        if (ok) dev_atomic_or((LC_LDS uint32_t *)&S.t2c[ti & ~1u], (ti & 1u) ? (1u << 16) : 1u);
+      }
+      if (S.prole[r] == 1) dev_atomic_or64(&sig[ti * SW + (S.pidx[r] >> 6)], 1ULL << (S.pidx[r] & 63u));
+    BL_OCC_END
+    WG_SYNC();
+    // the later mates: an occurrence on a node that also holds one of the earlier mate can be an "overlapping mate"
+    // (Node_t::hasOverlappingMate, src/Node.cc:638-661: a hit needs the name to BE in the other mate's vector); these are replayed
+    BL_OCC_BEGIN(S)
+      if (S.prole[r] != 2) continue;
+      const uint32_t ti = S.cidx[X.occn[boff] & 0x1FFFu];
+      if (ti != 0xFFFFu && ((sig[ti * SW + (S.pidx[r] >> 6)] >> (S.pidx[r] & 63u)) & 1ULL)) {
+        const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.flagged, 1u);
+        if (at < 1024u) todo[at] = ((uint32_t)r << 10) | (uint32_t)p;
+        dev_atomic_or(&mk[ti >> 5], 1u << (ti & 31u));
+      }
+    BL_OCC_END
+    WG_LANE0 { if (S.flagged > 1024u) S.why = BLW_MATE; }
+    if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
+    const uint32_t nflag = bl_bcast(&S.flagged);
+    if (nflag) {
+      // ---- exact replay (kernels.h build_csr): std::binary_search over the names the OTHER mate number pushed on the node before
+      //      this read, in push order (unsorted: SURVEY.md H3).  The occurrences of the marked nodes are listed as
+      //      node << 20 | read << 10 | position and sorted, which is the order loadSequence visited them in.
+      LC_LDS uint32_t *list = S.big + 2 * T;                       // (sig is done with)
+      const uint32_t lcap0 = (uint32_t)(BL_BIG / 4 - 64 - 1024) - 2u * T;
+      uint32_t lcap = 1; while (lcap * 2u <= lcap0 && lcap < 4096u) lcap *= 2u;
+      WG_LANE0 { S.g0 = 0; }
+      WG_FOR(i, lcap) { list[i] = 0xFFFFFFFFu; }
+      WG_SYNC();
+      BL_OCC_BEGIN(S)
+        if (r == nr) continue;
+        const uint32_t ti = S.cidx[X.occn[boff] & 0x1FFFu];
+        if (ti == 0xFFFFu || !((mk[ti >> 5] >> (ti & 31u)) & 1u)) continue;
+        const uint32_t mt = RI_MATE(S.rinfo[r]);
+        if (mt != 1 && mt != 2) continue;
+        const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.g0, 1u);
+        if (at < lcap) list[at] = (ti << 20) | ((uint32_t)r << 10) | (uint32_t)p;
+      BL_OCC_END
+      WG_LANE0 { if (S.g0 > lcap) S.why = BLW_MATE; }
+      if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
+      const uint32_t nl = bl_bcast(&S.g0);
+      uint32_t n2 = 1; while (n2 < nl) n2 *= 2u;
+      for (uint32_t kk = 2; kk <= n2; kk <<= 1)                    // bitonic sort, ascending (the padding sorts last)
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+          WG_FOR(i, n2) {
+            const uint32_t l = (uint32_t)i ^ j;
+            if (l > (uint32_t)i) {
+              const uint32_t a = list[i], b2 = list[l];
+              const bool up = (((uint32_t)i & kk) == 0);
+              if ((a > b2) == up) { list[i] = b2; list[l] = a; }
+            }
+          }
+          WG_SYNC();
+        }
+      WG_FOR(fi, nflag) {
+        const uint32_t r = todo[fi] >> 10, p = todo[fi] & 1023u;
+        const uint32_t boff = 16u * S.rdo[r] + p;
+        const uint32_t e = X.occn[boff];
+        const uint32_t ti = S.cidx[e & 0x1FFFu];
+        const uint32_t ri = S.rinfo[r];
+        const uint32_t mi = RI_MATE(ri), nm = B.name_rank[g0 + r] & 0xFFFFu;
+        uint32_t lo = 0, len = nl;                                   // start of the node's run
+        while (len > 0) { const uint32_t h = len >> 1; if ((list[lo + h] >> 20) < ti) { lo += h + 1; len -= h + 1; } else len = h; }
+        // the other mate's pushes of reads before r, in order: one per step the occurrence takes part in (as v of step p-1, as u of step p)
+        auto pushes_of = [&](uint32_t ent) -> uint32_t {
+          const uint32_t er = (ent >> 10) & 1023u, ep = ent & 1023u;
+          const uint32_t eri = S.rinfo[er];
+          if (RI_MATE(eri) != 3u - mi) return 0u;
+          const int etl = (int)RI_TLEN(eri);
+          return (ep >= 1u ? 1u : 0u) + ((int)ep <= etl - K - 1 ? 1u : 0u);
+        };
+        uint32_t total = 0;
+        for (uint32_t i = lo; i < nl && (list[i] >> 20) == ti && ((list[i] >> 10) & 1023u) < r; ++i) total += pushes_of(list[i]);
+        auto name_at = [&](uint32_t idx) -> uint32_t {               // name rank of push number idx of that vector
+          uint32_t acc = 0;
+          for (uint32_t i = lo; i < nl; ++i) { const uint32_t pc = pushes_of(list[i]); if (idx < acc + pc) return B.name_rank[g0 + ((list[i] >> 10) & 1023u)] & 0xFFFFu; acc += pc; }
+          return 0xFFFFFFFFu;
+        };
+        uint32_t first = 0, l2 = total;                              // std::lower_bound over the names, as pushed
+        while (l2 > 0) { const uint32_t h = l2 >> 1, mid = first + h; if (name_at(mid) < nm) { first = mid + 1; l2 = l2 - h - 1; } else l2 = h; }
+        const bool ovl = (first != total) && !(nm < name_at(first));
+        if (ovl) {                                                   // do not update coverage for overlapping mates (Graph.cc:267-271)
+          const uint32_t cls = (RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u);
+          dev_atomic_add64(&cc[ti], 0ULL - (1ULL << (16 * cls)));
+          X.occn[boff] = (uint16_t)(e | 0x4000u);
+        }
+      }
+      WG_SYNC();
+    }
+    WG_FOR(t, T) { X.tcc[t] = cc[t]; X.tfl[t] = ((S.t2c[t] & 1u) ? NF_TUMOR : 0u) | ((S.t2c[t] & 2u) ? NF_NORMAL : 0u); }
+    WG_SYNC();
+  }
+  // ---- candidates: tracked nodes the count-based predicate leaves undecided (kernels.h build_gather: `low`), in node order
+  {
+    LC_LDS uint32_t *fl = S.big + 2 * BL_TCAP;                   // (cc still in the first 2 T words of S.big)
+    LC_LDS const unsigned long long *cc = (LC_LDS const unsigned long long *)S.big;
+    WG_FOR(t, T + 1) {
+      uint32_t cand = 0;
+      if (t < (int)T) {
+        const unsigned long long c4 = cc[t];
+        const uint32_t c0 = (uint32_t)(c4 & 0xFFFFu), c1 = (uint32_t)((c4 >> 16) & 0xFFFFu), c2 = (uint32_t)((c4 >> 32) & 0xFFFFu), c3 = (uint32_t)(c4 >> 48);
+        const uint32_t counted = c0 + c1 + c2 + c3;
+        const float tt = (float)c0 + (float)c1, tn = (float)c2 + (float)c3;
+        const bool low = ((int)counted <= P->low_cov_threshold) || ((double)counted <= (P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
+        cand = low ? 0u : 1u;
+      }
+      fl[t] = cand;
+    }
+    bl_scan32(fl, (int)T + 1, S);
+    WG_LANE0 { S.ncand = S.scan_total; if (S.scan_total > PB_CCAP) S.why = BLW_CAND; else if ((size_t)S.scan_total * (size_t)K > PB_QVCAP) S.why = BLW_QV; }
+    if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
+    WG_FOR(t, T) { S.t2c[t] = (fl[t + 1] != fl[t]) ? (uint16_t)fl[t] : (uint16_t)0xFFFFu; }
+    WG_SYNC();
+    WG_FOR(n, N) { const uint32_t ti = S.cidx[n]; if (ti != 0xFFFFu) { const uint32_t ci = S.t2c[ti]; if (ci != 0xFFFFu) { X.c_id[ci] = (uint32_t)n; X.c_ti[ci] = ti; } } }
+    WG_SYNC();
+  }
+  const uint32_t ncand = bl_bcast(&S.ncand);
+  // ---- per-position quality counts of the candidates (Node_t::updateCovDistr minqv_fwd / minqv_rev, src/Node.cc:470-497) as
+  //      counted - (occurrences whose base at that k-mer position is below MIN_QUAL_CALL); groups of candidates that fit LDS
+  {
+    LC_GLOBAL uint16_t *qv = (LC_GLOBAL uint16_t *)(area + PRE_OFF_QV);
+    LC_LDS unsigned long long *bad = (LC_LDS unsigned long long *)S.big;        // [group][K] four 16-bit counters
+    const uint32_t gmax = (BL_BIG / 8u) / (uint32_t)K;
+    for (uint32_t c0 = 0; c0 < ncand; c0 += gmax) {
+      const uint32_t c1 = c0 + gmax < ncand ? c0 + gmax : ncand;
+      WG_FOR(i, (c1 - c0) * (uint32_t)K) { bad[i] = 0; }
+      WG_SYNC();
+      BL_OCC_BEGIN(S)
+        if (r == nr) continue;
+        const uint32_t e = X.occn[boff];
+        if (e & 0x4000u) continue;                                   // an overlapping mate's occurrence: not counted
+        const uint32_t ti = S.cidx[e & 0x1FFFu];
+        if (ti == 0xFFFFu) continue;
+        const uint32_t ci = S.t2c[ti];
+        if (ci < c0 || ci >= c1) continue;                           // (0xFFFF: not a candidate)
+        const uint32_t ri = S.rinfo[r];
+        const uint32_t cls = (RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u);
+        const uint32_t gw = S.gwo[r];
+        const bool rev = (e & 0x8000u) != 0;
+        // bits p .. p+K-1 of the read's mask; a clear bit at read position p + j is k-mer position j (forward) or K-1-j (reverse)
+        for (int j0 = 0; j0 < K;) {
+          const int pos = p + j0, wv = pos >> 5, lo = pos & 31;
+          int take = 32 - lo; if (take > K - j0) take = K - j0;
+          uint32_t m = ~(S.goodm[gw + wv] >> lo);
+          if (take < 32) m &= (1u << take) - 1u;
+          while (m) {
+            const int j = j0 + (int)__builtin_ctz(m); m &= m - 1u;
+            const int i = rev ? K - 1 - j : j;
+            dev_atomic_add64(&bad[(ci - c0) * (uint32_t)K + (uint32_t)i], 1ULL << (16 * cls));
+          }
+          j0 += take;
+        }
+      BL_OCC_END
+      WG_SYNC();
+      WG_FOR(t, (c1 - c0) * (uint32_t)K) {
+        const uint32_t ci = c0 + (uint32_t)t / (uint32_t)K;
+        const unsigned long long c4 = X.tcc[X.c_ti[ci]], b4 = bad[t];
+        LC_GLOBAL uint16_t *q = qv + ((size_t)ci * K + ((uint32_t)t % (uint32_t)K)) * 4;
+        for (int cl = 0; cl < 4; ++cl) q[cl] = (uint16_t)(((c4 >> (16 * cl)) & 0xFFFFu) - ((b4 >> (16 * cl)) & 0xFFFFu));
+      }
+      WG_FOR(cc_, c1 - c0) {                                          // mincovQV of the candidate
+        const uint32_t ci = c0 + (uint32_t)cc_;
+        const unsigned long long c4 = X.tcc[X.c_ti[ci]];
+        uint32_t mn = 0x7FFFFFFFu;
+        for (int i = 0; i < K; ++i) {
+          const unsigned long long b4 = bad[(uint32_t)cc_ * (uint32_t)K + (uint32_t)i];
+          uint32_t sq = 0;
+          for (int cl = 0; cl < 4; ++cl) sq += (uint32_t)(((c4 >> (16 * cl)) & 0xFFFFu) - ((b4 >> (16 * cl)) & 0xFFFFu));
+          if (sq < mn) mn = sq;
+        }
+        X.c_minqv[ci] = mn;
+      }
+      WG_SYNC();
+    }
+  }
+  // ---- survivors of the first removeLowCov (the predicate on mincovQV), dense in node order
+  {
+    LC_LDS uint32_t *fl = S.big;
+    WG_FOR(ci, ncand + 1) {
+      uint32_t sv = 0;
+      if (ci < (int)ncand) {
+        const unsigned long long c4 = X.tcc[X.c_ti[ci]];
+        const float tt = (float)(uint32_t)(c4 & 0xFFFFu) + (float)(uint32_t)((c4 >> 16) & 0xFFFFu), tn = (float)(uint32_t)((c4 >> 32) & 0xFFFFu) + (float)(uint32_t)(c4 >> 48);
+        const int minqv = (int)X.c_minqv[ci];
+        const bool low = (minqv <= P->low_cov_threshold) || ((double)minqv <= (P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
+        sv = low ? 0u : 1u;
+      }
+      fl[ci] = sv;
+    }
+    bl_scan32(fl, (int)ncand + 1, S);
+    WG_LANE0 { S.nsurv = S.scan_total; if (S.scan_total > PB_SCAP) S.why = BLW_SURV; }
+    if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
+    LC_GLOBAL uint32_t *snode = (LC_GLOBAL uint32_t *)(area + PRE_OFF_SNODE);
+    LC_GLOBAL unsigned long long *skey = (LC_GLOBAL unsigned long long *)(area + PRE_OFF_SKEY);
+    LC_GLOBAL uint32_t *sid = (LC_GLOBAL uint32_t *)(area + PRE_OFF_SID);
+    LC_GLOBAL uint8_t *surv = (LC_GLOBAL uint8_t *)(area + PRE_OFF_SURV);
+    WG_FOR(ci, ncand) {
+      const bool sv = fl[ci + 1] != fl[ci];
+      const uint32_t n = X.c_id[ci];
+      snode[ci] = sv ? n : LC_NIL;
+      if (sv) {
+        const uint32_t si = fl[ci];
+        bool f; skey[ci] = bl_canon(bl_kmer(S.bases, S.idoff[n], kmask), K, kmask, &f);
+        sid[si] = n; surv[n] = 1; X.s_ci[si] = (uint32_t)ci;
+      }
+    }
+    WG_SYNC();
+  }
+  const uint32_t nsurv = bl_bcast(&S.nsurv);
+  // ---- Ref_t::mertable membership, Ref_t::computeCoverage (src/Ref.cc:40-64, 173-250) from the counts of the tracked nodes, the
+  //      reference pseudo-read's node per offset.  First build of the window: Ref_t::seq is still the whole rawseq.
+  {
+    LC_GLOBAL uint32_t *occ_ref = (LC_GLOBAL uint32_t *)(area + PRE_OFF_OCCREF);
+    LC_GLOBAL uint16_t *refcov = (LC_GLOBAL uint16_t *)(area + PRE_OFF_REFCOV);
+    LC_LDS uint32_t *inmer = S.big;                                // bitmap over node ids
+    WG_FOR(i, PB_NCAP / 32) { inmer[i] = 0; }
+    WG_FOR(j, reflen) { for (int q = 0; q < 4; ++q) refcov[4 * j + q] = 0; }
+    WG_SYNC();
+    const int nrefk = reflen - K > 0 ? reflen - K + 1 : 0;
+    const uint32_t rb = 16u * S.rdo[nr];
+    WG_FOR(i, reflen - K > 0 ? reflen - K : 0) {                   // i + K < seq.length()
+      const uint32_t n = X.occn[rb + (uint32_t)i] & 0x1FFFu;
+      dev_atomic_or(&inmer[n >> 5], 1u << (n & 31u));
+    }
+    WG_SYNC();
+    WG_FOR(i, reflen - K > 0 ? reflen - K : 0) {                   // i + K < rawseq.length(): every one of them is in the table here
+      const uint32_t n = X.occn[rb + (uint32_t)i] & 0x1FFFu;
+      const uint32_t ti = S.cidx[n];
+      unsigned long long c4 = 0;
+      if (ti != 0xFFFFu) c4 = X.tcc[ti];
+      uint16_t v[4]; for (int q = 0; q < 4; ++q) v[q] = (uint16_t)((c4 >> (16 * q)) & 0xFFFFu);
+      if (i == 0) { for (int j = 0; j < K; ++j) for (int q = 0; q < 4; ++q) refcov[4 * j + q] = v[q]; }
+      else { for (int q = 0; q < 4; ++q) refcov[4 * (i + K - 1) + q] = v[q]; }
+    }
+    WG_LANE0 { S.refn = 0; }
+    WG_SYNC();
+    WG_FOR(i, PB_NCAP / 32) { const uint32_t m = inmer[i]; if (m) dev_atomic_add((LC_LDS uint32_t *)&S.refn, (uint32_t)dev_popc(m)); }
+    // survivor index per node from here on (the tracked index is in c_ti for every candidate)
+    WG_SYNC();
+    LC_LDS uint32_t *inm2 = S.big + PB_NCAP / 32;                  // INMER per survivor: keep a copy of the bitmap while cidx changes meaning
+    (void)inm2;
+    WG_FOR(n, N) { S.cidx[n] = 0xFFFFu; }
+    WG_SYNC();
+    WG_FOR(si, nsurv) { S.cidx[X.c_id[X.s_ci[si]]] = (uint16_t)si; }
+    WG_SYNC();
+    WG_FOR(i, nrefk) {
+      const uint32_t e = X.occn[rb + (uint32_t)i];
+      const uint32_t n = e & 0x1FFFu;
+      occ_ref[i] = (S.cidx[n] != 0xFFFFu ? n : PB_NOSURV) | ((e & 0x8000u) ? 0x80000000u : 0u);
+    }
+  }
+  // ---- trace only: edge count of every node before the filter (printStats over the whole table): distinct (side, base) slots
+  if (C->evt_cap) {
+    LC_LDS uint32_t *msk = S.big + PB_NCAP / 32;                   // one byte per node, four nodes per word
+    WG_FOR(i, PB_NCAP / 4) { msk[i] = 0; }
+    WG_LANE0 { S.edges_total = 0; }
+    WG_SYNC();
+    BL_OCC_BEGIN(S)
+      const uint32_t e = X.occn[boff];
+      const uint32_t n = e & 0x1FFFu, ori = e >> 15;
+      const int tlen = r < nr ? (int)RI_TLEN(S.rinfo[r]) : reflen;
+      const int nk = tlen - K + 1;
+      uint32_t m = 0;
+      if (p + 1 < nk) { const int b = bl_base(S.bases, boff + (uint32_t)K); m |= 1u << ((ori == 0 ? 0 : 4) + (ori == 0 ? b : 3 - b)); }
+      if (p > 0) { const int b = bl_base(S.bases, boff - 1u); m |= 1u << ((ori == 0 ? 4 : 0) + (ori == 0 ? b : 3 - b)); }
+      if (m) dev_atomic_or(&msk[n >> 2], m << (8u * (n & 3u)));
+    BL_OCC_END
+    WG_SYNC();
+    WG_FOR(i, (N + 3) / 4) { const uint32_t m = msk[i]; if (m) dev_atomic_add((LC_LDS uint32_t *)&S.edges_total, (uint32_t)dev_popc(m)); }
+    WG_SYNC();
+  }
+  // ---- edges of the survivors in first-seen order (Node_t::addEdge order over the reads, Graph.cc:320-347): earliest step per
+  //      (side, extension base) slot with LDS atomicMin, groups of survivors that fit; stamp = 2 * offset of the step's u (+1 for
+  //      the v side), offsets grow with (read, position) like the occurrence index of kernels.h
+  {
+    LC_LDS uint32_t *inmer = S.big;                                // (kept: PB_NCAP / 32 words)
+    LC_LDS uint32_t *E = S.big + PB_NCAP / 32 + PB_NCAP / 4;       // [group][8]
+    const uint32_t gmax = (BL_BIG / 4u - PB_NCAP / 32u - PB_NCAP / 4u) / 8u;
+    LC_GLOBAL NodeGr *pgr = (LC_GLOBAL NodeGr *)(area + PRE_OFF_PGR);
+    for (uint32_t s0 = 0; s0 < nsurv; s0 += gmax) {
+      const uint32_t s1 = s0 + gmax < nsurv ? s0 + gmax : nsurv;
+      WG_FOR(i, (s1 - s0) * 8u) { E[i] = LC_NIL; }
+      WG_SYNC();
+      BL_OCC_BEGIN(S)
+        const uint32_t e = X.occn[boff];
+        const uint32_t si = S.cidx[e & 0x1FFFu];
+        if (si < s0 || si >= s1) continue;
+        const uint32_t ori = e >> 15;
+        const int tlen = r < nr ? (int)RI_TLEN(S.rinfo[r]) : reflen;
+        const int nk = tlen - K + 1;
+        if (p + 1 < nk) {                                            // step p: this node is u
+          const int b = bl_base(S.bases, boff + (uint32_t)K);
+          const uint32_t sl = (ori == 0 ? 0u : 4u) + (uint32_t)(ori == 0 ? b : 3 - b);
+          dev_atomic_min(&E[(si - s0) * 8u + sl], 2u * boff);
+        }
+        if (p > 0) {                                                 // step p-1: this node is v
+          const int b = bl_base(S.bases, boff - 1u);
+          const uint32_t sl = (ori == 0 ? 4u : 0u) + (uint32_t)(ori == 0 ? b : 3 - b);
+          dev_atomic_min(&E[(si - s0) * 8u + sl], 2u * (boff - 1u) + 1u);
+        }
+      BL_OCC_END
+      WG_SYNC();
+      WG_FOR(sg, s1 - s0) {                                          // one lane per survivor: its record
+        const uint32_t si = s0 + (uint32_t)sg, ci = X.s_ci[si], n = X.c_id[ci], ti = X.c_ti[ci];
+        uint32_t stamp[8]; int ne = 0;
+        for (int j = 0; j < 8; ++j) { const uint32_t v = E[(uint32_t)sg * 8u + (uint32_t)j]; if (v != LC_NIL) stamp[ne++] = v; }
+        for (int i = 1; i < ne; ++i) { const uint32_t s = stamp[i]; int j = i; while (j > 0 && stamp[j - 1] > s) { stamp[j] = stamp[j - 1]; --j; } stamp[j] = s; }
+        LC_GLOBAL NodeGr &G = pgr[si];
+        int m = 0;
+        for (int i = 0; i < ne; ++i) {
+          const uint32_t s = stamp[i] >> 1;
+          const uint32_t a = X.occn[s], b = X.occn[s + 1];           // u and v of that step
+          const uint32_t ua = a >> 15, ub = b >> 15;
+          uint32_t to, dir;
+          if ((stamp[i] & 1u) == 0) { to = b & 0x1FFFu; dir = ua == 0 ? (ub == 0 ? 0u : 1u) : (ub == 0 ? 2u : 3u); }   // FF FR RF RR
+          else { to = a & 0x1FFFu; dir = ua == 0 ? (ub == 0 ? 3u : 1u) : (ub == 0 ? 2u : 0u); }                         // RR FR RF FF
+          if (S.cidx[to] == 0xFFFFu) continue;                       // removeNode of a non-survivor took the edge with it
+          G.edges[m++] = ED_MAKE(to, dir);
+        }
+        for (int i = m; i < LC_EMAX; ++i) G.edges[i] = 0;
+        const unsigned long long c4 = X.tcc[ti];
+        const uint32_t c0 = (uint32_t)(c4 & 0xFFFFu), c1 = (uint32_t)((c4 >> 16) & 0xFFFFu), c2 = (uint32_t)((c4 >> 32) & 0xFFFFu), c3 = (uint32_t)(c4 >> 48);
+        const uint32_t f = X.tfl[ti];
+        G.flags = f | NF_SURV | ((inmer[n >> 5] >> (n & 31u)) & 1u ? NF_INMER : 0u);
+        G.necnt = (uint32_t)m; G.comp = 0; G.color = 0; G.onref = 0; G.nkm = 1;
+        G.nkmT = ((f & NF_TUMOR) && !(f & NF_NORMAL)) ? 1u : 0u;
+        G.cov[0] = (float)c0; G.cov[1] = (float)c1; G.cov[2] = (float)c2; G.cov[3] = (float)c3;
+        G.kc[0] = (uint16_t)c0; G.kc[1] = (uint16_t)c1; G.kc[2] = (uint16_t)c2; G.kc[3] = (uint16_t)c3;
+        G.mincov = (int)(c0 + c1 + c2 + c3); G.mincovqv = (int)X.c_minqv[ci];
+        const uint32_t base = ci * (uint32_t)K;
+        G.seq_clo = base; G.seq_lo = base; G.seq_hi = base + (uint32_t)K; G.seq_chi = base + (uint32_t)K;
+        G.nqv = ci;
+      }
+      WG_SYNC();
+    }
+  }
+  WG_LANE0 {
+    H->K = K; H->refE = S.repE; H->refM = S.repM; H->N = S.N; H->O = S.O; H->totalreadbp = S.totalreadbp; H->n_kmers = S.n_kmers;
+    H->ncand = S.ncand; H->nsurv = S.nsurv; H->edges_total = S.edges_total; H->refn = S.refn; H->why = 0;
+    H->status = PB_BUILT;
+  }
+  WG_SYNC();
+}
+
+// entry: persistent workgroups pull windows off the batch queue (`queue` is a counter of its own)
+// (queue[0] = next window, queue[1] = windows built)
+DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *B, LC_GLOBAL const EngineCaps *C, LC_GLOBAL uint8_t *pre,
+                           LC_GLOBAL uint8_t *scratch, LC_GLOBAL uint32_t *queue, BL_S &S, int slot) {
+  BlScratch X;
+  bl_scratch_carve(&X, (char *)(scratch + (size_t)slot * BL_SCRATCH_BYTES));
+  while (true) {
+    WG_LANE0 { S.w = (int)dev_atomic_add(queue, 1u); }
+    const int w = (int)bl_bcast(&S.w);
+    if (w >= B->n_windows) break;
+    bl_build_window(P, B, C, S, X, pre + (size_t)w * PRE_STRIDE, w);
+    WG_LANE0 { if (((LC_GLOBAL const PreHdr *)(pre + (size_t)w * PRE_STRIDE))->status == PB_BUILT) dev_atomic_add(queue + 1, 1u); }
+    WG_SYNC();
+  }
+}

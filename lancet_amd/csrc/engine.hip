@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "build_lds.h"
 #include "host_common.h"
 
 #define HIPCHK(e, call)                                                                           \
@@ -22,6 +23,12 @@
 // run ahead of the other lanes (observed on gfx950: lanes 1..63 skipped whole phases).
 __global__ void __launch_bounds__(LANCET_WG * 2) __attribute__((amdgpu_waves_per_eu(5, 5))) window_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT) {
   window_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL Work *)works, (LC_GLOBAL DevOut *)OUT, (LC_WS *)&lc_shared, (int)blockIdx.x);
+}
+
+// The first graph of every window in LDS (build_lds.h): 256 lanes per window, 2 workgroups per CU (80 KB of LDS each)
+__global__ void __launch_bounds__(BL_WG) build_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue) {
+  build_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL uint8_t *)pre, (LC_GLOBAL uint8_t *)scratch,
+                    (LC_GLOBAL uint32_t *)queue, *(BL_S *)&bl_shared, (int)blockIdx.x);
 }
 
 __global__ void prep_kernel(const lancet_params *P, int n_reads, const char *seq, const char *qual, const uint32_t *seq_off,
@@ -81,6 +88,12 @@ struct lancet_engine {
   uint32_t table_start = 0;  // LANCET_TABLE_START (testing only: exercises the table-doubling path)
   int n_windows = 0, n_reads = 0, n_slots = 0;
   int n_rerun = 0;
+  // LDS build kernel: hand-off areas (one per window), per-workgroup scratch
+  DevBuf d_pre, d_blscratch;
+  int n_bslots = 0, n_prebuilt = 0;
+  bool prebuild = true;       // LANCET_NO_PREBUILD=1: every window through the general build phases (comparison / debugging)
+  hipEvent_t evb0 = nullptr, evb1 = nullptr;
+  float ms_build = 0, ms_window = 0;
   bool uploaded = false, ran = false;
   uint32_t evt_cap = 0;
   size_t mem_budget = (size_t)96 << 30;
@@ -114,7 +127,9 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   lancet_engine *e = new lancet_engine();
   e->params = *p; e->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&e->stream) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
-      hipEventCreate(&e->ev1) != hipSuccess) { delete e; return LANCET_E_HIP; }
+      hipEventCreate(&e->ev1) != hipSuccess || hipEventCreate(&e->evb0) != hipSuccess || hipEventCreate(&e->evb1) != hipSuccess) { delete e; return LANCET_E_HIP; }
+  if (getenv("LANCET_NO_PREBUILD")) e->prebuild = false;
+  if (p->lr_mode) e->prebuild = false;                         // --linked-reads: barcode / haplotype bookkeeping lives in the general build only
   if (const char *s = getenv("LANCET_TRACE_WORDS")) e->evt_cap = (uint32_t)atoi(s);
   { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->max_slots = cus * 20; }
   if (const char *s = getenv("LANCET_MAX_SLOTS")) e->max_slots = atoi(s);
@@ -133,8 +148,10 @@ void lancet_engine_destroy(lancet_engine *e) {
   DevBuf *all[] = {&e->d_params, &e->d_batch, &e->d_caps, &e->d_out, &e->d_works, &e->d_chr, &e->d_refstart, &e->d_refoff, &e->d_refasc,
                    &e->d_refcodes, &e->d_readbegin, &e->d_seqoff, &e->d_seq, &e->d_qual, &e->d_label, &e->d_strand, &e->d_mate, &e->d_mapped,
                    &e->d_rinfo, &e->d_name, &e->d_bw, &e->d_gw, &e->d_bases, &e->d_good, &e->d_variants, &e->d_blob, &e->d_counters,
-                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist, &e->d_bx, &e->d_hp, &e->d_varlr, &e->d_bxblob};
+                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist, &e->d_bx, &e->d_hp, &e->d_varlr, &e->d_bxblob, &e->d_pre, &e->d_blscratch};
   for (DevBuf *b : all) b->release();
+  if (e->evb0) (void)hipEventDestroy(e->evb0);
+  if (e->evb1) (void)hipEventDestroy(e->evb1);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -238,6 +255,15 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   o.n_variants = (LC_GLOBAL uint32_t *)e->d_counters.p; o.n_blob = (LC_GLOBAL uint32_t *)e->d_counters.p + 1; o.queue_head = (LC_GLOBAL uint32_t *)e->d_counters.p + 2;
   o.n_bx = (LC_GLOBAL uint32_t *)e->d_counters.p + 3; o.variants_lr = (LC_GLOBAL lancet_variant_lr *)e->d_varlr.p; o.bx_blob = (LC_GLOBAL uint32_t *)e->d_bxblob.p;
   o.stats = (LC_GLOBAL lancet_window_stats *)e->d_stats.p; o.evt_len = (LC_GLOBAL uint32_t *)e->d_evtlen.p; o.evt_out = (LC_GLOBAL uint32_t *)e->d_evt.p; o.phase = (LC_GLOBAL unsigned long long *)e->d_phase.p; o.win_list = nullptr; o.n_list = 0;
+  o.pre = nullptr;
+  if (e->prebuild) {
+    int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
+    e->n_bslots = std::min(nw, cus * 2);
+    if (const char *s = getenv("LANCET_BUILD_SLOTS")) e->n_bslots = std::max(1, std::min(nw, atoi(s)));
+    ENS(e->d_pre, (size_t)nw * PRE_STRIDE);
+    ENS(e->d_blscratch, (size_t)e->n_bslots * BL_SCRATCH_BYTES);
+    o.pre = (LC_GLOBAL const uint8_t *)e->d_pre.p;
+  }
   UP(e->d_out, &o, sizeof(o));
   DBG("sync");
   HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -252,15 +278,30 @@ int lancet_engine_run(lancet_engine *e) {
   HIPCHK(e, hipSetDevice(e->device));
   e->variants.clear(); e->blob.clear(); e->stats.clear(); e->evt_len.clear(); e->evt.clear(); e->variants_lr.clear(); e->bx_blob.clear();
   if (e->n_windows == 0) { e->ran = true; return LANCET_OK; }
-  HIPCHK(e, hipEventRecord(e->ev0, e->stream));
   HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, 64, e->stream));
   HIPCHK(e, hipMemsetAsync(e->d_stats.p, 0, sizeof(lancet_window_stats) * e->n_windows, e->stream));
+  e->ms_build = 0; e->n_prebuilt = 0;
+  if (e->prebuild) {
+    HIPCHK(e, hipEventRecord(e->evb0, e->stream));
+    hipLaunchKernelGGL(build_kernel, dim3(e->n_bslots), dim3(BL_WG), 0, e->stream, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
+                       (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_blscratch.p, (uint32_t *)e->d_counters.p + 8);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipEventRecord(e->evb1, e->stream));
+  }
+  HIPCHK(e, hipEventRecord(e->ev0, e->stream));
   hipLaunchKernelGGL(window_kernel, dim3(e->n_slots), dim3(LANCET_WG), 0, e->stream, (const lancet_params *)e->d_params.p,
                      (const DevBatch *)e->d_batch.p, (const EngineCaps *)e->d_caps.p, (Work *)e->d_works.p, (DevOut *)e->d_out.p);
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipEventRecord(e->ev1, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
-  HIPCHK(e, hipEventElapsedTime(&e->ms_all, e->ev0, e->ev1));
+  HIPCHK(e, hipEventElapsedTime(&e->ms_window, e->ev0, e->ev1));
+  if (e->prebuild) {
+    HIPCHK(e, hipEventElapsedTime(&e->ms_build, e->evb0, e->evb1));
+    uint32_t bq[2] = {0, 0};
+    HIPCHK(e, hipMemcpy(bq, (uint32_t *)e->d_counters.p + 8, sizeof(bq), hipMemcpyDeviceToHost));
+    e->n_prebuilt = (int)bq[1];
+  }
+  e->ms_all = e->ms_window + e->ms_build;
   e->ms_kernel = e->ms_all;
   // ---- tier 2: windows that did not fit the small work space are re-run with the worst-case one
   e->stats.resize(e->n_windows);
@@ -294,7 +335,7 @@ int lancet_engine_run(lancet_engine *e) {
     HIPCHK(e, hipStreamSynchronize(e->stream));
     float ms2 = 0;
     HIPCHK(e, hipEventElapsedTime(&ms2, e->ev0, e->ev1));
-    e->ms_all += ms2; e->ms_kernel += ms2;
+    e->ms_all += ms2; e->ms_kernel += ms2; e->ms_window += ms2;
   }
   // ---- read back
   uint32_t counters[4];
@@ -454,14 +495,16 @@ int lancet_engine_phase_times(lancet_engine *e, const unsigned long long **ticks
 }
 
 // HIP-event durations (ms) of the kernels of the last run, in the order of lancet_engine_kernel_name(0..); returns how many
-static const char *const lc_kernel_names[] = {"window_kernel"};
+static const char *const lc_kernel_names[] = {"build_kernel", "window_kernel"};
 const char *lancet_engine_kernel_name(int i) { return (i >= 0 && i < (int)(sizeof(lc_kernel_names) / sizeof(lc_kernel_names[0]))) ? lc_kernel_names[i] : nullptr; }
 int lancet_engine_kernel_times(lancet_engine *e, float *ms, int cap) {
   if (!e || !e->ran) return LANCET_E_STATE;
-  if (cap < 1 || !ms) return LANCET_E_ARG;
-  ms[0] = e->ms_kernel;
-  return 1;
+  if (cap < 2 || !ms) return LANCET_E_ARG;
+  ms[0] = e->ms_build; ms[1] = e->ms_window;
+  return 2;
 }
+// windows of the last run whose first graph came from the LDS build kernel
+int lancet_engine_prebuilt_count(lancet_engine *e) { return e ? e->n_prebuilt : -1; }
 
 // number of windows of the last run that needed the worst-case work space (tier 2)
 int lancet_engine_rerun_count(lancet_engine *e) { return e ? e->n_rerun : -1; }

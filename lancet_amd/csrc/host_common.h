@@ -100,7 +100,7 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.nkey = k.take<unsigned long long>(nodes * LC_NWMAX);
   t.nhash = k.take<unsigned long long>(nodes);
   t.nfill = k.take<uint32_t>(nodes + 1);
-  t.gr = k.take<NodeGr>(nodes);
+  t.gr = k.take<NodeGr>(nodes + 1);          /* + the stand-in record of reference k-mers whose node is gone (prebuilt windows) */
   t.cmp = k.take<CmpRec>(nodes);
   t.nocc = k.take<uint32_t>(nodes + 1);
   t.qv = k.take<uint16_t>((size_t)c.qv_cap * (c.lr_mode ? 10 : 4));
@@ -123,6 +123,7 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.dp = k.take<int32_t>(7 * (LC_MAXW + 2));
   t.aln = k.take<uint8_t>(2 * (size_t)(LC_MAXW + c.path_cap + 2));
   t.evt = k.take<uint32_t>(c.evt_cap + 8);
+  t.survb = k.take<uint8_t>(nodes + 1);
   if (w) *w = t;
   return (k.off + 255) & ~(size_t)255;
 }

@@ -70,6 +70,8 @@ struct WinShared {
   int QS, LR;                                    // counters per (survivor, position): 4, or 10 with --linked-reads ; lr_mode
   unsigned long long t_last, phase_acc[16];
   int phase_cur;
+  int prebuilt;                                  // this build came from the LDS build kernel (build_lds.h): survb[] instead of the stale node records
+  uint32_t pre_edges, pre_refn;                  // its trace aggregates
 };
 
 // The one WinShared of the workgroup.  Functions reach it by name rather than through the pointer in Ctx: a pointer
@@ -272,17 +274,17 @@ DEV void repeat_scan_bytes(LC_GLOBAL const uint8_t *s, int len, int mm, volatile
 // mismatch flags of 16 positions out of two unaligned 64-bit words.  Only mismatch positions are visited:
 // with last[j] = position of the (j+1)-th most recent mismatch, the longest exact run ending before a mismatch q is
 // q-1-last[0] and the longest window with <= mm mismatches ending there is q-1-last[mm] (the two-pointer window).
-DEVNI void repeat_scan(LC_WS &S, LC_GLOBAL const uint8_t *s, int len, int mm, volatile LC_LDS int *outE, volatile LC_LDS int *outM) {
+DEVNI void repeat_scan(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL const uint8_t *s, int len, int mm, volatile LC_LDS int *outE, volatile LC_LDS int *outM) {
   if (mm > 7 || mm < 0 || len + 48 > 16 * LC_RS_WORDS) { repeat_scan_bytes(s, len, mm, outE, outM); return; }
   WG_LANE0 { *outE = 0; *outM = 0; }
   const int nwords = len / 16 + 3;
   WG_FOR(w, nwords) {
     unsigned long long v = 0;
     for (int j = 0; j < 16; ++j) { int idx = 16 * w + j; if (idx < len) v |= (unsigned long long)(s[idx] & 15u) << (4 * j); }
-    S.rs[w] = v;
+    rsbuf[w] = v;
   }
   WG_SYNC();
-  const unsigned long long *rs = (const unsigned long long *)S.rs;
+  const LC_LDS unsigned long long *rs = (const LC_LDS unsigned long long *)rsbuf;
   WG_FOR(dd, len > 1 ? len - 1 : 0) {
     const int d = dd + 1;
     const int lenE = len - 1 - d, lenM = len - d;
@@ -1641,7 +1643,8 @@ DEVNI void clean_dead_wg(Ctx &c) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int M = (int)wg_bcastu(&S.M);
   LC_GLOBAL uint32_t *keep = W.scratch;
-  WG_FOR(i, M) { const uint32_t f = W.gr[W.order[i]].flags; keep[i] = ((f & NF_SURV) && !(f & NF_DEAD)) ? 1u : 0u; }
+  if (wg_uniform(S.prebuilt)) { WG_FOR(i, M) { keep[i] = W.survb[W.order[i]] ? 1u : 0u; } }     // (no node is dead yet; the records of the non-survivors were never written)
+  else { WG_FOR(i, M) { const uint32_t f = W.gr[W.order[i]].flags; keep[i] = ((f & NF_SURV) && !(f & NF_DEAD)) ? 1u : 0u; } }
   WG_LANE0 { keep[M] = 0; }
   wg_scan(keep, M + 1, S);
   WG_FOR(i, M) { if (keep[i + 1] != keep[i]) W.pnodes[keep[i]] = W.order[i]; }
@@ -2923,7 +2926,7 @@ DEVNI bool repeats_in_graph_paths(Ctx &c) {
     if (wg_bcast(&S.tmp0) != 0) break;
     { const int pl = path_string_wg(c, wg_bcast(&S.tmp2)); WG_LANE0 { S.tmp3 = pl; if (S.overflow) S.tmp0 = 1; } }
     if (wg_bcast(&S.tmp0) != 0) break;
-    repeat_scan(S, W.pseq, wg_bcast(&S.tmp3), LC_CTX(c).P->max_mismatch, &S.repE, &S.repM);      // isAlmostRepeat(path->str(), K, MAX_MISMATCH)
+    repeat_scan(S.rs, W.pseq, wg_bcast(&S.tmp3), LC_CTX(c).P->max_mismatch, &S.repE, &S.repM);      // isAlmostRepeat(path->str(), K, MAX_MISMATCH)
     WG_LANE0 {
       // NB isAlmostRepeat only looks at windows that end before the last base: handled inside repeat_scan
       if (S.tmp3 - S.K > 0 && S.repM >= S.K + 1) { evt(c, EV_NEAR_QRY, S.K); S.tmp0 = 2; }
@@ -3009,6 +3012,55 @@ DEVNI void count_ref_path(Ctx &c) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The window's first graph as the LDS build kernel left it (build_lds.h, layout.h PreHdr ...): the slot's arrays are
+// brought to the state build_graph() leaves them in, as far as the graph phases read them -- std::hash of every node,
+// survivor flags, the survivors' records / per-position counts / sequence descriptors, the reference pseudo-read's
+// nodes, the reference coverage.  Whole wave, coalesced copies.  Returns false when the window has no such graph for k.
+// ---------------------------------------------------------------------------------------------------------
+DEVNI bool load_prebuilt(Ctx &c, int k) {
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  LC_GLOBAL const uint8_t *pre = LC_CTX(c).OUT->pre;
+  if (!pre) return false;
+  LC_GLOBAL const uint8_t *area = pre + (size_t)S.w * PRE_STRIDE;
+  LC_GLOBAL const PreHdr *H = (LC_GLOBAL const PreHdr *)(area + PRE_OFF_HDR);
+  WG_LANE0 { S.tmp1 = (H->status == PB_BUILT && H->K == k && S.n_builds == 0 && H->N <= LC_CTX(c).C->node_cap && (size_t)H->ncand * (size_t)k <= (size_t)LC_CTX(c).C->qv_cap &&
+                       H->ncand <= LC_CTX(c).C->surv_cap && (size_t)H->ncand * (size_t)k <= (size_t)LC_CTX(c).C->seq_cap) ? 1 : 0; }
+  if (!wg_bcast(&S.tmp1)) return false;
+  const uint32_t N = H->N, ncand = H->ncand, nsurv = H->nsurv;
+  const int K = k;
+  WG_LANE0 {
+    S.N = N; S.N_last = N; S.O = H->O; S.totalreadbp = (int)H->totalreadbp; S.n_kmers += (unsigned long long)H->n_kmers; ++S.n_builds;
+    if (N > S.max_nodes) S.max_nodes = N;
+    S.nspecial = 0; S.qv_top = ncand; S.seq_top = ncand * (uint32_t)K; S.tmask = 0; S.tfull = 0; S.prebuilt = 1;
+    S.pre_edges = H->edges_total; S.pre_refn = H->refn;
+    W.occ_base[S.R - 1] = 0;                                     // the reference pseudo-read's occurrences are the only ones the graph phases visit
+  }
+  LC_GLOBAL const unsigned long long *nhash = (LC_GLOBAL const unsigned long long *)(area + PRE_OFF_NHASH);
+  LC_GLOBAL const uint8_t *surv = (LC_GLOBAL const uint8_t *)(area + PRE_OFF_SURV);
+  LC_GLOBAL const uint32_t *snode = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_SNODE), *sid = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_SID);
+  LC_GLOBAL const unsigned long long *skey = (LC_GLOBAL const unsigned long long *)(area + PRE_OFF_SKEY);
+  LC_GLOBAL const uint32_t *occ_ref = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_OCCREF);
+  LC_GLOBAL const lc_v4 *pgr = (LC_GLOBAL const lc_v4 *)(area + PRE_OFF_PGR);
+  LC_GLOBAL const lc_v4 *qsrc = (LC_GLOBAL const lc_v4 *)(area + PRE_OFF_QV);
+  const uint32_t dummy = LC_CTX(c).C->node_cap + LC_CTX(c).C->special_cap;       // stand-in for reference k-mers whose node is gone
+  WG_FOR(n, N) { W.nhash[n] = nhash[n]; }
+  WG_FOR(i, (N + 3) / 4) { ((LC_GLOBAL uint32_t *)W.survb)[i] = ((LC_GLOBAL const uint32_t *)surv)[i]; }
+  WG_FOR(i, (int)(((size_t)ncand * K * 8 + 15) / 16)) { ((LC_GLOBAL lc_v4 *)W.qv)[i] = qsrc[i]; }
+  WG_FOR(i, nsurv * 8u) { const uint32_t si = (uint32_t)i >> 3, part = (uint32_t)i & 7u; ((LC_GLOBAL lc_v4 *)&W.gr[sid[si]])[part] = pgr[(size_t)si * 8 + part]; }
+  WG_FOR(t, ncand * (uint32_t)K) {
+    const uint32_t ci = (uint32_t)t / (uint32_t)K; const int i = (int)((uint32_t)t % (uint32_t)K);
+    const uint32_t n = snode[ci];
+    if (n != LC_NIL) { const unsigned long long kk = skey[ci]; W.seq[t] = SD_MAKE(n, i, key_base(&kk, K, i)); }
+  }
+  const int nrefk = S.reflen - K > 0 ? S.reflen - K + 1 : 0;
+  WG_FOR(i, nrefk) { const uint32_t e = occ_ref[i]; W.occ[i] = ((e & 0x3FFFFFFFu) == PB_NOSURV) ? (dummy | (e & 0x80000000u)) : e; }
+  WG_FOR(i, S.reflen * 2) { ((LC_GLOBAL uint32_t *)W.refcov)[i] = ((LC_GLOBAL const uint32_t *)(area + PRE_OFF_REFCOV))[i]; }
+  WG_LANE0 { W.gr[dummy].flags = 0; }
+  WG_SYNC_FENCE();
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // the window: Microassembler::processGraph (reference src/Microassembler.cc:73-249)
 // ---------------------------------------------------------------------------------------------------------
 DEV void process_window(Ctx &c, int w) {
@@ -3041,7 +3093,7 @@ DEV void process_window(Ctx &c, int w) {
   const int reflen = wg_bcast(&S.reflen);
   build_items(c);
   PHASE(c, 1);
-  repeat_scan(S, B.ref_codes + B.ref_off[w], reflen, LC_CTX(c).P->max_mismatch, &S.repE, &S.repM);
+  repeat_scan(S.rs, B.ref_codes + B.ref_off[w], reflen, LC_CTX(c).P->max_mismatch, &S.repE, &S.repM);
   PHASE(c, 0);
   const int refE = wg_bcast(&S.repE), refM = wg_bcast(&S.repM);
   int rptInRef = 0, rptInQry = 0, cycleInGraph = 0;
@@ -3053,7 +3105,8 @@ DEV void process_window(Ctx &c, int w) {
     if (reflen - k > 0 && refM >= k + 1) { WG_LANE0 { evt(c, EV_NEAR_REF, k); } rptInRef = 1; continue; }
     WG_LANE0 { S.K = k; S.NW = (2 * k + 63) / 64; S.final_k = k; S.source = LC_NIL; S.sink = LC_NIL; if (k > 127 || S.NW > LC_NWMAX) S.overflow = 1; }
     if (wg_bcast(&S.overflow)) break;
-    build_graph(c);
+    WG_LANE0 { S.prebuilt = 0; }
+    if (!load_prebuilt(c, k)) build_graph(c);
     if (wg_bcast(&S.overflow)) break;
     PHASE(c, 7);
     first_lowcov(c);
@@ -3066,7 +3119,8 @@ DEV void process_window(Ctx &c, int w) {
       // trace: printStats(0) over the full table, markRefNodes, removeLowCov(false,0)
       if (LC_CTX(c).C->evt_cap) {
         uint32_t edges = 0, refn = 0, low = 0;
-        for (uint32_t n = 0; n < S.N; ++n) { edges += W.gr[n].necnt; if (W.gr[n].flags & NF_INMER) ++refn; if (!(W.gr[n].flags & NF_SURV)) ++low; }
+        if (S.prebuilt) { edges = S.pre_edges; refn = S.pre_refn; for (uint32_t n = 0; n < S.N; ++n) if (!W.survb[n]) ++low; }
+        else for (uint32_t n = 0; n < S.N; ++n) { edges += W.gr[n].necnt; if (W.gr[n].flags & NF_INMER) ++refn; if (!(W.gr[n].flags & NF_SURV)) ++low; }
         evt(c, EV_STATS, 0, S.N, edges, S.N * (uint32_t)S.K);
         evt(c, EV_MARKREF, S.N, refn);
         evt(c, EV_LOWCOV, low);
@@ -3074,11 +3128,13 @@ DEV void process_window(Ctx &c, int w) {
     }
     // removeNode for every non-survivor: drop the reciprocal edges, then erase from the table.  A node without NF_SURV is
     // gone from here on (it is in no edge list and not in order[]); it does not need a NF_DEAD mark of its own.
-    WG_FOR(n, S.N) {
-      if (!(W.gr[n].flags & NF_SURV)) continue;
-      LC_GLOBAL uint32_t *e = W.gr[n].edges; int cnt = (int)W.gr[n].necnt, m = 0;
-      for (int i = 0; i < cnt; ++i) if (W.gr[ED_TO(e[i])].flags & NF_SURV) e[m++] = e[i];
-      W.gr[n].necnt = m;
+    if (!wg_uniform(S.prebuilt)) {                          // (a prebuilt graph arrives with the edges filtered)
+      WG_FOR(n, S.N) {
+        if (!(W.gr[n].flags & NF_SURV)) continue;
+        LC_GLOBAL uint32_t *e = W.gr[n].edges; int cnt = (int)W.gr[n].necnt, m = 0;
+        for (int i = 0; i < cnt; ++i) if (W.gr[ED_TO(e[i])].flags & NF_SURV) e[m++] = e[i];
+        W.gr[n].necnt = m;
+      }
     }
     WG_SYNC();
     clean_dead_wg(c);

@@ -143,6 +143,41 @@ struct CmpRec {
   uint32_t pad[3];
 };
 
+
+/* ---- hand-off of the LDS build kernel (build_lds.h) to the window kernel: one area per window of the batch ----
+ * The build kernel assembles the FIRST graph of a window (the smallest k that passes the reference-repeat tests) in LDS and
+ * leaves here exactly what the graph phases read: the node table in first-insertion order reduced to what is observable
+ * (std::hash of every k-mer for the libstdc++ iteration order, survivor flags), dense records of the nodes that survive the
+ * first removeLowCov, their per-position quality counts, the reference pseudo-read's node per offset and the reference
+ * coverage.  A window the LDS limits do not hold (or that needs the mate-overlap replay, N handling, even k, k > 31) is marked
+ * PB_NOT_BUILT and takes the general path (build phases of kernels.h in HBM). */
+#define PB_NCAP 5632          /* distinct k-mers per window (LDS table of 8192 slots)                          */
+#define PB_CCAP 2048          /* candidates: nodes not decided by their occurrence count alone                 */
+#define PB_SCAP 2048          /* survivors of the first removeLowCov                                          */
+#define PB_QVCAP 32768        /* (candidate, k-mer position) entries of per-position quality counts            */
+#define PB_NOSURV 0x3FFFFFFFu /* occ_ref entry of a reference k-mer whose node did not survive                 */
+#define PB_NOT_BUILT 0u
+#define PB_BUILT 1u
+struct PreHdr {
+  uint32_t status;            /* PB_BUILT / PB_NOT_BUILT                                                        */
+  uint32_t why;               /* PB_NOT_BUILT: which limit (diagnostic)                                        */
+  int32_t K, refE, refM;
+  uint32_t N, O, totalreadbp, n_kmers, ncand, nsurv;
+  uint32_t edges_total, refn; /* trace only: sum of the edge counts of all N nodes, nodes that hold a reference k-mer */
+  uint32_t pad[19];
+};
+#define PRE_OFF_HDR 0u
+#define PRE_OFF_OCCREF 128u                                   /* u32[LC_MAXW]   node | ori << 31 per reference offset   */
+#define PRE_OFF_REFCOV (PRE_OFF_OCCREF + 4u * LC_MAXW)        /* u16[LC_MAXW*4]                                         */
+#define PRE_OFF_NHASH (PRE_OFF_REFCOV + 8u * LC_MAXW)         /* u64[PB_NCAP]   std::hash of every node, by node id     */
+#define PRE_OFF_SURV (PRE_OFF_NHASH + 8u * PB_NCAP)           /* u8[PB_NCAP]    1 = survivor                            */
+#define PRE_OFF_SNODE (PRE_OFF_SURV + PB_NCAP)                /* u32[PB_CCAP]   node of candidate ci (LC_NIL: not a survivor) */
+#define PRE_OFF_SKEY (PRE_OFF_SNODE + 4u * PB_CCAP)           /* u64[PB_CCAP]   its canonical k-mer                     */
+#define PRE_OFF_SID (PRE_OFF_SKEY + 8u * PB_CCAP)             /* u32[PB_SCAP]   node of survivor si                     */
+#define PRE_OFF_PGR (PRE_OFF_SID + 4u * PB_SCAP)              /* NodeGr[PB_SCAP] records of the survivors, dense        */
+#define PRE_OFF_QV (PRE_OFF_PGR + 128u * PB_SCAP)             /* u16[PB_QVCAP*4] rows of K positions per candidate      */
+#define PRE_STRIDE ((PRE_OFF_QV + 8u * PB_QVCAP + 255u) & ~255u)
+
 /* One slot of work space.  All pointers are device pointers into one big allocation. */
 struct Work {
   /* ---- build ---- */
@@ -192,6 +227,7 @@ struct Work {
   LC_GLOBAL int32_t *dp;            /* [7*(LC_MAXW+2)] alignment diagonals                               */
   LC_GLOBAL uint8_t *aln;           /* [2*(LC_MAXW+path_cap+2)] aligned strings (ASCII)                  */
   LC_GLOBAL uint32_t *evt;          /* [evt_cap] trace events                                            */
+  LC_GLOBAL uint8_t *survb;         /* [nodes] prebuilt window: survivor flag per node (stands in for the stale node records) */
 };
 
 /* batch-level outputs */
@@ -210,4 +246,5 @@ struct DevOut {
   LC_GLOBAL unsigned long long *phase; /* [n_windows * 16] per-phase time (100 MHz ticks), may be null */
   LC_GLOBAL const uint32_t *win_list;  /* when non-null: the windows to process (re-run of overflowed windows)   */
   uint32_t n_list;
+  LC_GLOBAL const uint8_t *pre;        /* hand-off areas of the LDS build kernel (PRE_STRIDE bytes per window), or null */
 };

@@ -75,6 +75,7 @@ DEV uint32_t dev_atomic_cas32(uint32_t *p, uint32_t cmp, uint32_t v) { uint32_t 
 DEV uint32_t ld2(const uint32_t *p) { return *p; }
 DEV unsigned long long ld2(const unsigned long long *p) { return *p; }
 struct alignas(16) lc_u4 { uint32_t x, y, z, w; };
+typedef lc_u4 lc_v4;
 DEV lc_u4 ldg4(const uint32_t *p) { return *(const lc_u4 *)p; }
 DEV void stg4(uint32_t *p, const lc_u4 v) { *(lc_u4 *)p = v; }
 DEV int dev_popc(uint32_t x) { return __builtin_popcount(x); }

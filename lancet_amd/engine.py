@@ -45,6 +45,7 @@ def lib():
         L.lancet_engine_set_trace.argtypes = [C.c_void_p, C.c_uint32]
         L.lancet_engine_trace.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32)]
         L.lancet_engine_rerun_count.argtypes = [C.c_void_p]
+        L.lancet_engine_prebuilt_count.argtypes = [C.c_void_p]
         L.lancet_engine_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
         L.lancet_engine_kernel_name.restype = C.c_char_p
         L.lancet_engine_kernel_name.argtypes = [C.c_int]
@@ -148,6 +149,9 @@ class Engine:
         if n < 0:
             self._chk(n)
         return [float(buf[i]) for i in range(n)]
+
+    def prebuilt_count(self) -> int:
+        return int(self.L.lancet_engine_prebuilt_count(self.h))
 
     def rerun_count(self) -> int:
         return int(self.L.lancet_engine_rerun_count(self.h))

@@ -27,11 +27,14 @@ def lib():
             f.restype = rt
             f.argtypes = [C.c_void_p]
         L.lancet_emu_free.argtypes = [C.c_void_p]
+        L.lancet_emu_n_prebuilt.restype = C.c_uint32
+        L.lancet_emu_n_prebuilt.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
 
 LAST_EVENTS = []
+LAST_PREBUILT = [0]          # windows of the last run whose first graph came from the LDS build kernel
 
 
 def run(batch, params=None, evt_cap: int = 0):
@@ -42,6 +45,7 @@ def run(batch, params=None, evt_cap: int = 0):
     h = L.lancet_emu_run(C.byref(p), C.byref(cb), evt_cap)
     try:
         n = L.lancet_emu_n_variants(h)
+        LAST_PREBUILT[0] = int(L.lancet_emu_n_prebuilt(h))
         bl = L.lancet_emu_blob_len(h)
         blob = C.string_at(L.lancet_emu_blob(h), bl) if bl else b""
         variants = abi.variants_to_py(L.lancet_emu_variants(h), n, blob)

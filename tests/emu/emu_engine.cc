@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <vector>
 #include "../../lancet_amd/csrc/kernels.h"
+#include "../../lancet_amd/csrc/build_lds.h"
 #include "../../lancet_amd/csrc/host_common.h"
 
 struct EmuResult {
@@ -20,6 +21,7 @@ struct EmuResult {
   std::vector<uint32_t> evt_len, evt;
   uint32_t evt_cap;
   uint32_t n_variants, n_blob;
+  uint32_t n_prebuilt;
 };
 
 extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batch *b, uint32_t evt_cap) {
@@ -54,6 +56,20 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   DevOut O; O.variants = res->variants.data(); O.blob = res->blob.data(); O.n_variants = &nv; O.n_blob = &nb; O.stats = res->stats.data();
   O.variants_lr = res->lr.data(); O.bx_blob = res->bx_blob.data(); O.n_bx = &nx;
   O.queue_head = &qh; O.phase = nullptr; O.win_list = nullptr; O.n_list = 0; O.evt_len = res->evt_len.data(); O.evt_out = res->evt.data();
+  // ---- the LDS build kernel first (one emulated workgroup), unless switched off: LANCET_NO_PREBUILD=1 runs the general build for every window
+  std::vector<uint8_t> pre, blscr;
+  O.pre = nullptr;
+  res->n_prebuilt = 0;
+  if (!P->lr_mode && !getenv("LANCET_NO_PREBUILD") && b->n_windows > 0) {
+    pre.assign((size_t)b->n_windows * PRE_STRIDE, 0xCD); blscr.assign(BL_SCRATCH_BYTES + 256, 0xCD);
+    static thread_local BlShared BS;
+    memset(&BS, 0xCD, sizeof(BS));
+    uint32_t bq[2] = {0, 0};
+    build_kernel_body(P, &B, &C, pre.data(), blscr.data(), bq, BS, 0);
+    O.pre = pre.data();
+    res->n_prebuilt = bq[1];
+    if (getenv("LANCET_EMU_WHY")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); if (H->status != PB_BUILT) fprintf(stderr, "[emu] window %d not prebuilt: why %u\n", w, H->why); }
+  }
   static thread_local WinShared S;
   memset(&S, 0xCD, sizeof(S));
   window_kernel_body(P, &B, &C, &work, &O, &S, 0);
@@ -69,12 +85,13 @@ extern "C" uint32_t lancet_emu_blob_len(void *h) { return ((EmuResult *)h)->n_bl
 extern "C" const lancet_window_stats *lancet_emu_stats(void *h) { return ((EmuResult *)h)->stats.data(); }
 extern "C" const uint32_t *lancet_emu_evt_len(void *h) { return ((EmuResult *)h)->evt_len.data(); }
 extern "C" const uint32_t *lancet_emu_evt(void *h) { return ((EmuResult *)h)->evt.data(); }
+extern "C" uint32_t lancet_emu_n_prebuilt(void *h) { return ((EmuResult *)h)->n_prebuilt; }
 extern "C" void lancet_emu_free(void *h) { delete (EmuResult *)h; }
 
 // repeat_scan both ways (bit-parallel LDS version vs the byte-wise restatement) for the unit test
 extern "C" void lancet_emu_repeat_scan(const uint8_t *s, int len, int mm, int bitparallel, int *outE, int *outM) {
   static WinShared S;
   volatile int e = 0, m = 0;
-  if (bitparallel) repeat_scan(S, s, len, mm, &e, &m); else repeat_scan_bytes(s, len, mm, &e, &m);
+  if (bitparallel) repeat_scan(S.rs, s, len, mm, &e, &m); else repeat_scan_bytes(s, len, mm, &e, &m);
   *outE = e; *outM = m;
 }
