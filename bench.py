@@ -94,7 +94,7 @@ def side_config(eng_cls, params, name, windows, cov_t, cov_n, steps, **kw):
            "builds_per_window": round(sum(s["n_builds"] for s in stats) / windows, 3),
            "final_k_histogram": {int(k): int(c) for k, c in zip(ks, cnt)},
            "k_exhausted": sum(1 for s in stats if s["status"] == 2), "overflowed": sum(1 for s in stats if s["status"] < 0),
-           "windows_rerun_general_path": eng.rerun_count()}
+           "windows_first_graph_in_lds": eng.prebuilt_count(), "windows_rerun_worst_case_tier": eng.rerun_count()}
     eng.close()
     return out
 
@@ -212,7 +212,7 @@ def main():
                        "windows_per_gpu": args.windows, "coverage": [args.cov, args.cov], "reads_per_gpu": int(batch.n_reads),
                        "records_rank0_contig": len(variants), "records_sha256_rank0_contig": h.hexdigest()[:16],
                        "slots_in_flight": n_slots, "upload_first_ms": round(upload_first_ms, 1), "upload_ms": round(up_ms, 1),
-                       "windows_rerun_general_path": eng.rerun_count(), "workspace_MB_per_slot": round(slot_bytes / 2 ** 20, 1),
+                       "windows_first_graph_in_lds": eng.prebuilt_count(), "windows_rerun_worst_case_tier": eng.rerun_count(), "workspace_MB_per_slot": round(slot_bytes / 2 ** 20, 1),
                        "kernel_ms": per_kernel},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": None,

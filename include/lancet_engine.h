@@ -174,6 +174,8 @@ const char *lancet_engine_kernel_name(int i);
 int lancet_engine_kernel_times(lancet_engine *e, float *ms, int cap);
 /* Windows of the last run whose first graph was assembled by the LDS build kernel (the others took the general build phases). */
 int lancet_engine_prebuilt_count(lancet_engine *e);
+/* Profiling aid: wall-clock ticks (10 ns) the LDS build kernel's workgroups spent per phase in the last run (16 values). */
+int lancet_engine_build_phase_times(lancet_engine *e, const unsigned long long **ticks);
 
 /* ---- the reference's -v stage trace (reference src/Microassembler.cc:87-246, Graph.cc verbose blocks) ----
  * lancet_engine_set_trace: before an upload, reserve words_per_window 32-bit words of trace events per window (0 = off).

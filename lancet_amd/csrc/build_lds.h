@@ -26,7 +26,7 @@
 #pragma once
 #include "kernels.h"
 
-#define BL_WG 256
+#define BL_WG 512
 #define BL_BASES 40960            /* bases in LDS (reads padded to 16, + the reference)                       */
 #define BL_RMAX 512               /* reads per window                                                          */
 #define BL_SLOTS 8192
@@ -42,13 +42,14 @@ struct BlShared {
   uint16_t rdo[BL_RMAX + 4];        /* first 16-base word of read r                                             */
   uint16_t gwo[BL_RMAX + 4];        /* first quality-mask word of read r                                        */
   uint16_t obase[BL_RMAX + 4];      /* first occurrence index of read r; [R] = O                                */
+  uint16_t o2r[BL_BASES / 128 + 2]; /* read that holds occurrence 128 * j                                       */
   uint32_t rinfo[BL_RMAX + 4];
   uint8_t pidx[BL_RMAX + 4];        /* mate-pair signature bit of the read (0xFF none)                          */
   uint8_t prole[BL_RMAX + 4];       /* 1 = earlier mate of a pair, 2 = the later one                            */
   uint16_t idoff[PB_NCAP];          /* node id -> LDS offset of its first occurrence                            */
   uint16_t cidx[PB_NCAP];           /* node id -> tracked index, later survivor index (0xFFFF none)             */
   uint16_t t2c[BL_TCAP];            /* tracked index -> candidate index (0xFFFF none)                           */
-  uint32_t big[BL_BIG / 4];
+  alignas(16) uint32_t big[BL_BIG / 4];   /* (64-bit LDS atomics on it: must be 8-byte aligned) */
   uint32_t wsum[BL_WG / 64 + 1];
   uint32_t scan_total;
   int w, R, reflen, K, hasN, mapped;
@@ -58,6 +59,7 @@ struct BlShared {
   int why;
   uint32_t npairs, flagged, edges_total, refn;
   uint32_t g0, g1;                  /* group bounds of the current pass                                          */
+  unsigned long long t_last, ph_acc[16]; int ph_cur;   /* profiling: wall-clock ticks per phase (lane 0)                 */
 };
 
 /* per-workgroup scratch in HBM (streamed, never shared between windows in flight) */
@@ -72,9 +74,9 @@ struct BlScratch {
   LC_GLOBAL uint32_t *s_edges;      /* [PB_SCAP * 9] resolved edges + count                                      */
 };
 #define BL_SCRATCH_BYTES (2u * BL_BASES + 64u + 8u * BL_TCAP + 4u * BL_TCAP + 12u * PB_CCAP + 4u * PB_SCAP + 36u * PB_SCAP + 512u)
-DEV void bl_scratch_carve(BlScratch *s, char *base) {
+DEV void bl_scratch_carve(BlScratch *s, LC_GLOBAL uint8_t *base) {
   size_t o = 0;
-  auto take = [&](size_t bytes) { char *p = base + o; o = (o + bytes + 63) & ~(size_t)63; return p; };
+  auto take = [&](size_t bytes) { LC_GLOBAL uint8_t *p = base + o; o = (o + bytes + 63) & ~(size_t)63; return p; };
   s->occn = (LC_GLOBAL uint16_t *)take(2u * BL_BASES + 64u);
   s->tcc = (LC_GLOBAL unsigned long long *)take(8u * BL_TCAP);
   s->tfl = (LC_GLOBAL uint32_t *)take(4u * BL_TCAP);
@@ -95,6 +97,11 @@ DEV unsigned long long dev_atomic_add64(unsigned long long *p, unsigned long lon
 DEV unsigned long long dev_atomic_or64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o | v; return o; }
 #endif
 
+#ifndef LANCET_WAVE_EMU
+#define BLP(S, id) do { if (threadIdx.x == 0) { const unsigned long long _t = wall_clock64(); (S).ph_acc[(S).ph_cur] += _t - (S).t_last; (S).t_last = _t; (S).ph_cur = (id); } } while (0)
+#else
+#define BLP(S, id) ((void)0)
+#endif
 // uniform read of a control word: barrier, read, barrier (kernels.h wg_bcast)
 #define bl_bcast(p) wg_bcastu(p)
 
@@ -154,24 +161,47 @@ DEV bool bl_all_good(const LC_LDS uint32_t *goodm, uint32_t gw, int a, int b) {
 }
 
 // every occurrence o of the window: read r, k-mer start p in the read, LDS offset boff of the k-mer (lane-strided)
-#define BL_OCC_BEGIN(S) WG_FOR(_t, BL_WG) { uint32_t _r = 0; const int _O = (int)(S).O, _R = (S).R; \
-  for (int o = _t; o < _O; o += BL_WG) { while ((int)_r + 1 < _R && (uint32_t)o >= (S).obase[_r + 1]) ++_r; \
+#define BL_OCC_BEGIN(S) WG_FOR(_t, BL_WG) { const int _O = (int)(S).O; \
+  for (int o = _t; o < _O; o += BL_WG) { uint32_t _r = (S).o2r[o >> 7]; while ((uint32_t)o >= (S).obase[_r + 1]) ++_r; \
     const int r = (int)_r; const int p = o - (int)(S).obase[r]; const uint32_t boff = 16u * (S).rdo[r] + (uint32_t)p; (void)p; (void)boff; (void)r;
 #define BL_OCC_END } }
 
-#define BL_FAIL(S, code) do { (S).why = (code); } while (0)
+// The same walk with the occurrence's 2-byte HBM word fetched four occurrences ahead: a pass is a chain of (HBM word -> LDS
+// look-ups -> LDS atomics) per occurrence, and with two workgroups per CU nothing else hides the memory round trip.
+template <class F> DEV void bl_for_occ(BL_S &S, LC_GLOBAL const uint16_t *occn, F body) {
+  WG_FOR(_t, BL_WG) {
+    const int O_ = (int)S.O;
+    for (int o0 = _t; o0 < O_; o0 += 4 * BL_WG) {
+      int rr[4], pp[4]; uint32_t bo[4], ee[4];
+      for (int u = 0; u < 4; ++u) {
+        const int o = o0 + u * BL_WG;
+        const int oc = o < O_ ? o : O_ - 1;                          // (clamped: the loads below stay unconditional, four in flight)
+        uint32_t rc = S.o2r[oc >> 7];
+        while ((uint32_t)oc >= S.obase[rc + 1]) ++rc;
+        rr[u] = o < O_ ? (int)rc : -1; pp[u] = oc - (int)S.obase[rc]; bo[u] = 16u * S.rdo[rc] + (uint32_t)pp[u];
+      }
+#ifdef BL_DBG_COND
+      for (int u = 0; u < 4; ++u) ee[u] = rr[u] >= 0 ? (uint32_t)occn[bo[u]] : 0u;
+#else
+      for (int u = 0; u < 4; ++u) ee[u] = (uint32_t)occn[bo[u]];
+#endif
+      for (int u = 0; u < 4; ++u) if (rr[u] >= 0) body(rr[u], pp[u], bo[u], ee[u]);
+    }
+  }
+}
 
 // One window.  Returns with the hand-off area of the window written (PB_BUILT) or marked PB_NOT_BUILT.
-DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *Bp, LC_GLOBAL const EngineCaps *C, BL_S &S, BlScratch &X,
+DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *Bp, LC_GLOBAL const EngineCaps *C, BL_S &S, LC_GLOBAL uint8_t *xbase,
                            LC_GLOBAL uint8_t *area, int w) {
   LC_GLOBAL const DevBatch &B = *Bp;
+  BlScratch X; bl_scratch_carve(&X, xbase);                       // (a local of this function: its pointers live in registers)
   LC_GLOBAL PreHdr *H = (LC_GLOBAL PreHdr *)(area + PRE_OFF_HDR);
   const uint32_t g0 = B.read_begin[w];
   const int nr = (int)(B.read_begin[w + 1] - g0);
   const int reflen = (int)(B.ref_off[w + 1] - B.ref_off[w]);
   LC_GLOBAL const uint8_t *refc = B.ref_codes + B.ref_off[w];
   WG_LANE0 { S.w = w; S.why = BLW_NONE; S.R = nr + 1; S.reflen = reflen; S.hasN = 0; S.mapped = 0; S.flagged = 0; S.npairs = 0; S.edges_total = 0; S.refn = 0;
-             H->status = PB_NOT_BUILT; H->why = 0;
+             H->status = PB_NOT_BUILT; H->why = 0; H->have_rep = 0;
              if (nr > BL_RMAX || reflen > LC_MAXW || reflen < 1) S.why = BLW_SIZE; }
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
   // ---- mapped reads, N in the window reference, per-read geometry
@@ -197,6 +227,8 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
   WG_FOR(r, nr + 2) { S.rdo[r] = (uint16_t)tmpA[r]; S.gwo[r] = (uint16_t)tmpB[r]; }
   WG_SYNC();
+  BLP(S, 1);
+  if (C->debug_stop == 101u) { WG_LANE0 { H->why = 99; } return; }
   // ---- the window's packed reads and quality masks into LDS (whole words; a read starts on a word)
   WG_FOR(r, nr) {
     const uint32_t ri = S.rinfo[r]; const int tlen = (int)RI_TLEN(ri);
@@ -212,6 +244,8 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   }
   WG_FOR(i, 4) { S.bases[nbw + (uint32_t)i] = 0; }
   WG_SYNC();
+  BLP(S, 2);
+  if (C->debug_stop == 102u) { WG_LANE0 { H->why = 99; } return; }
   // ---- reference repeat scan -> the first k of the loop that reaches buildgraph (Microassembler.cc:118-131)
   repeat_scan((volatile LC_LDS unsigned long long *)(S.big + 4 * (BL_RMAX + 8)), refc, reflen, P->max_mismatch, (volatile LC_LDS int *)&S.repE, (volatile LC_LDS int *)&S.repM);
   WG_LANE0 {
@@ -222,12 +256,15 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       K = k; break;
     }
     S.K = K;
+    H->refE = S.repE; H->refM = S.repM; H->have_rep = 1;          // (the window kernel does not repeat the scan)
     if (K == 0 || K > 31 || (K & 1) == 0) S.why = BLW_K;
   }
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
   const int K = (int)bl_bcast(&S.K);
   const unsigned long long kmask = (1ULL << (2 * K)) - 1ULL;
   const int R = nr + 1;
+  BLP(S, 3);
+  if (C->debug_stop == 103u) { WG_LANE0 { H->why = 99; } return; }
   // ---- occurrence index space (read r owns its k-mers p = 0..tlen-K; a read of exactly K bases has none, Graph.cc:142-143)
   WG_LANE0 { S.totalreadbp = 0; S.n_kmers = 0; }
   WG_SYNC();
@@ -240,7 +277,12 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   WG_LANE0 { tmpC[R] = 0; }
   bl_scan32(tmpC, R + 1, S);
   WG_FOR(r, R + 1) { S.obase[r] = (uint16_t)tmpC[r]; }
-  WG_LANE0 { S.O = S.scan_total; }
+  WG_LANE0 { S.O = S.scan_total; S.obase[R + 1] = 0xFFFFu; }
+  WG_SYNC();
+  WG_FOR(r, R) {                                                 // read r holds the occurrences [obase[r], obase[r+1]): the multiples of 128 among them
+    const uint32_t a = S.obase[r], b = S.obase[r + 1];
+    for (uint32_t j = (a + 127u) >> 7; (j << 7) < b; ++j) S.o2r[j] = (uint16_t)r;
+  }
   WG_SYNC();
   // ---- mate pairs: a read with exactly one earlier read of the same name and the opposite mate number is the later mate of
   //      a pair (kernels.h build_tables: cand / mate_of); several such reads -> general path
@@ -286,6 +328,8 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     }
   }
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
+  BLP(S, 4);
+  if (C->debug_stop == 104u) { WG_LANE0 { H->why = 99; } return; }
   // ---- pass 1: every k-mer into the table (first occurrence kept), slot per occurrence to HBM
   LC_LDS uint32_t *tab = S.big;
   WG_FOR(i, BL_SLOTS) { tab[i] = BL_EMPTY; }
@@ -311,6 +355,8 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     X.occn[boff] = (uint16_t)(idx | (isF ? 0u : 0x8000u));
   BL_OCC_END
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
+  BLP(S, 5);
+  if (C->debug_stop == 105u) { WG_LANE0 { H->why = 99; } return; }
   // ---- node ids in first-insertion order: rank of the slot's first-occurrence offset among the occupied slots
   {
     LC_LDS uint32_t *bm = (LC_LDS uint32_t *)S.cidx;           // 1024 words of bitmap + 1024 words of prefix (cidx is idle: 12 KB)
@@ -335,13 +381,17 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_SYNC();
   }
   const uint32_t N = bl_bcast(&S.N);
+  BLP(S, 6);
+  if (C->debug_stop == 106u) { WG_LANE0 { H->why = 99; } return; }
   // ---- pass 2: slot -> node id per occurrence (HBM, streamed), occurrences per node
-  BL_OCC_BEGIN(S)
-    const uint32_t e = X.occn[boff];
+  bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
+    (void)r; (void)p;
     const uint32_t old = dev_atomic_add(&tab[e & (BL_SLOTS - 1)], 1u << 16);
     X.occn[boff] = (uint16_t)((old & 0xFFFFu) | (e & 0x8000u));
-  BL_OCC_END
+  });
   WG_SYNC();
+  BLP(S, 7);
+  if (C->debug_stop == 107u) { WG_LANE0 { H->why = 99; } return; }
   // ---- std::hash of every node's k-mer (libstdc++ table order), survivor bytes cleared
   {
     LC_GLOBAL unsigned long long *nhash = (LC_GLOBAL unsigned long long *)(area + PRE_OFF_NHASH);
@@ -371,6 +421,8 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_SYNC();
   }
   const uint32_t T = bl_bcast(&S.T);
+  BLP(S, 8);
+  if (C->debug_stop == 108u) { WG_LANE0 { H->why = 99; } return; }
   // ---- pass 3 (tracked nodes): counted occurrences per strand / sample, colours (Graph.cc:200-217), pair signatures
   //      S.big: cc[T] (u64) | sig[T * SW] (u64, earlier mates present, one bit per pair) ... todo[1024] | mk[64] at the end
   {
@@ -386,11 +438,11 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_FOR(t, T * SW) { sig[t] = 0; }
     WG_FOR(i, 64) { mk[i] = 0; }
     WG_SYNC();
-    BL_OCC_BEGIN(S)
-      if (r == nr) continue;                                       // the reference read: no colour, never counted (Graph.cc:265)
-      const uint32_t e = X.occn[boff];
+    bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
+      (void)boff;
+      if (r == nr) return;                                         // the reference read: no colour, never counted (Graph.cc:265)
       const uint32_t ti = S.cidx[e & 0x1FFFu];
-      if (ti == 0xFFFFu) continue;
+      if (ti == 0xFFFFu) return;
       const uint32_t ri = S.rinfo[r];
       const uint32_t cls = (RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u);
       dev_atomic_add64(&cc[ti], 1ULL << (16 * cls));
@@ -403,19 +455,22 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
         if (ok) dev_atomic_or((LC_LDS uint32_t *)&S.t2c[ti & ~1u], (ti & 1u) ? (1u << 16) : 1u);
       }
       if (S.prole[r] == 1) dev_atomic_or64(&sig[ti * SW + (S.pidx[r] >> 6)], 1ULL << (S.pidx[r] & 63u));
-    BL_OCC_END
+    });
     WG_SYNC();
+    if (C->debug_stop == 120u) { WG_LANE0 { H->why = 99; } return; }
     // the later mates: an occurrence on a node that also holds one of the earlier mate can be an "overlapping mate"
     // (Node_t::hasOverlappingMate, src/Node.cc:638-661: a hit needs the name to BE in the other mate's vector); these are replayed
-    BL_OCC_BEGIN(S)
-      if (S.prole[r] != 2) continue;
-      const uint32_t ti = S.cidx[X.occn[boff] & 0x1FFFu];
+    if (npairs) bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
+      (void)boff;
+      if (S.prole[r] != 2) return;
+      const uint32_t ti = S.cidx[e & 0x1FFFu];
       if (ti != 0xFFFFu && ((sig[ti * SW + (S.pidx[r] >> 6)] >> (S.pidx[r] & 63u)) & 1ULL)) {
         const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.flagged, 1u);
         if (at < 1024u) todo[at] = ((uint32_t)r << 10) | (uint32_t)p;
         dev_atomic_or(&mk[ti >> 5], 1u << (ti & 31u));
       }
-    BL_OCC_END
+    });
+    if (C->debug_stop == 121u) { WG_LANE0 { H->why = 99; } return; }
     WG_LANE0 { if (S.flagged > 1024u) S.why = BLW_MATE; }
     if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
     const uint32_t nflag = bl_bcast(&S.flagged);
@@ -429,15 +484,16 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       WG_LANE0 { S.g0 = 0; }
       WG_FOR(i, lcap) { list[i] = 0xFFFFFFFFu; }
       WG_SYNC();
-      BL_OCC_BEGIN(S)
-        if (r == nr) continue;
-        const uint32_t ti = S.cidx[X.occn[boff] & 0x1FFFu];
-        if (ti == 0xFFFFu || !((mk[ti >> 5] >> (ti & 31u)) & 1u)) continue;
+      bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
+        (void)boff;
+        if (r == nr) return;
+        const uint32_t ti = S.cidx[e & 0x1FFFu];
+        if (ti == 0xFFFFu || !((mk[ti >> 5] >> (ti & 31u)) & 1u)) return;
         const uint32_t mt = RI_MATE(S.rinfo[r]);
-        if (mt != 1 && mt != 2) continue;
+        if (mt != 1 && mt != 2) return;
         const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.g0, 1u);
         if (at < lcap) list[at] = (ti << 20) | ((uint32_t)r << 10) | (uint32_t)p;
-      BL_OCC_END
+      });
       WG_LANE0 { if (S.g0 > lcap) S.why = BLW_MATE; }
       if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
       const uint32_t nl = bl_bcast(&S.g0);
@@ -489,9 +545,12 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       }
       WG_SYNC();
     }
+    if (C->debug_stop == 122u) { WG_LANE0 { H->why = 99; } return; }
     WG_FOR(t, T) { X.tcc[t] = cc[t]; X.tfl[t] = ((S.t2c[t] & 1u) ? NF_TUMOR : 0u) | ((S.t2c[t] & 2u) ? NF_NORMAL : 0u); }
     WG_SYNC();
   }
+  BLP(S, 9);
+  if (C->debug_stop == 109u) { WG_LANE0 { H->why = 99; } return; }
   // ---- candidates: tracked nodes the count-based predicate leaves undecided (kernels.h build_gather: `low`), in node order
   {
     LC_LDS uint32_t *fl = S.big + 2 * BL_TCAP;                   // (cc still in the first 2 T words of S.big)
@@ -517,24 +576,28 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_SYNC();
   }
   const uint32_t ncand = bl_bcast(&S.ncand);
+  BLP(S, 10);
+  if (C->debug_stop == 110u) { WG_LANE0 { H->why = 99; } return; }
   // ---- per-position quality counts of the candidates (Node_t::updateCovDistr minqv_fwd / minqv_rev, src/Node.cc:470-497) as
   //      counted - (occurrences whose base at that k-mer position is below MIN_QUAL_CALL); groups of candidates that fit LDS
   {
     LC_GLOBAL uint16_t *qv = (LC_GLOBAL uint16_t *)(area + PRE_OFF_QV);
     LC_LDS unsigned long long *bad = (LC_LDS unsigned long long *)S.big;        // [group][K] four 16-bit counters
-    const uint32_t gmax = (BL_BIG / 8u) / (uint32_t)K;
+    const uint32_t gmax = (BL_BIG / 8u) / (uint32_t)(K + 1);
+    LC_LDS unsigned long long *gcc = bad + (size_t)gmax * K;                    // [group] the candidates' counted occurrences
     for (uint32_t c0 = 0; c0 < ncand; c0 += gmax) {
       const uint32_t c1 = c0 + gmax < ncand ? c0 + gmax : ncand;
       WG_FOR(i, (c1 - c0) * (uint32_t)K) { bad[i] = 0; }
+      WG_FOR(i, c1 - c0) { gcc[i] = X.tcc[X.c_ti[c0 + (uint32_t)i]]; }
       WG_SYNC();
-      BL_OCC_BEGIN(S)
-        if (r == nr) continue;
-        const uint32_t e = X.occn[boff];
-        if (e & 0x4000u) continue;                                   // an overlapping mate's occurrence: not counted
+      bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
+        (void)boff;
+        if (r == nr) return;
+        if (e & 0x4000u) return;                                     // an overlapping mate's occurrence: not counted
         const uint32_t ti = S.cidx[e & 0x1FFFu];
-        if (ti == 0xFFFFu) continue;
+        if (ti == 0xFFFFu) return;
         const uint32_t ci = S.t2c[ti];
-        if (ci < c0 || ci >= c1) continue;                           // (0xFFFF: not a candidate)
+        if (ci < c0 || ci >= c1) return;                             // (0xFFFF: not a candidate)
         const uint32_t ri = S.rinfo[r];
         const uint32_t cls = (RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u);
         const uint32_t gw = S.gwo[r];
@@ -552,17 +615,17 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
           }
           j0 += take;
         }
-      BL_OCC_END
+      });
       WG_SYNC();
       WG_FOR(t, (c1 - c0) * (uint32_t)K) {
         const uint32_t ci = c0 + (uint32_t)t / (uint32_t)K;
-        const unsigned long long c4 = X.tcc[X.c_ti[ci]], b4 = bad[t];
+        const unsigned long long c4 = gcc[(uint32_t)t / (uint32_t)K], b4 = bad[t];
         LC_GLOBAL uint16_t *q = qv + ((size_t)ci * K + ((uint32_t)t % (uint32_t)K)) * 4;
         for (int cl = 0; cl < 4; ++cl) q[cl] = (uint16_t)(((c4 >> (16 * cl)) & 0xFFFFu) - ((b4 >> (16 * cl)) & 0xFFFFu));
       }
       WG_FOR(cc_, c1 - c0) {                                          // mincovQV of the candidate
         const uint32_t ci = c0 + (uint32_t)cc_;
-        const unsigned long long c4 = X.tcc[X.c_ti[ci]];
+        const unsigned long long c4 = gcc[cc_];
         uint32_t mn = 0x7FFFFFFFu;
         for (int i = 0; i < K; ++i) {
           const unsigned long long b4 = bad[(uint32_t)cc_ * (uint32_t)K + (uint32_t)i];
@@ -575,6 +638,8 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       WG_SYNC();
     }
   }
+  BLP(S, 11);
+  if (C->debug_stop == 111u) { WG_LANE0 { H->why = 99; } return; }
   // ---- survivors of the first removeLowCov (the predicate on mincovQV), dense in node order
   {
     LC_LDS uint32_t *fl = S.big;
@@ -609,6 +674,8 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_SYNC();
   }
   const uint32_t nsurv = bl_bcast(&S.nsurv);
+  BLP(S, 12);
+  if (C->debug_stop == 112u) { WG_LANE0 { H->why = 99; } return; }
   // ---- Ref_t::mertable membership, Ref_t::computeCoverage (src/Ref.cc:40-64, 173-250) from the counts of the tracked nodes, the
   //      reference pseudo-read's node per offset.  First build of the window: Ref_t::seq is still the whole rawseq.
   {
@@ -651,14 +718,15 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       occ_ref[i] = (S.cidx[n] != 0xFFFFu ? n : PB_NOSURV) | ((e & 0x8000u) ? 0x80000000u : 0u);
     }
   }
+  BLP(S, 13);
+  if (C->debug_stop == 113u) { WG_LANE0 { H->why = 99; } return; }
   // ---- trace only: edge count of every node before the filter (printStats over the whole table): distinct (side, base) slots
   if (C->evt_cap) {
     LC_LDS uint32_t *msk = S.big + PB_NCAP / 32;                   // one byte per node, four nodes per word
     WG_FOR(i, PB_NCAP / 4) { msk[i] = 0; }
     WG_LANE0 { S.edges_total = 0; }
     WG_SYNC();
-    BL_OCC_BEGIN(S)
-      const uint32_t e = X.occn[boff];
+    bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
       const uint32_t n = e & 0x1FFFu, ori = e >> 15;
       const int tlen = r < nr ? (int)RI_TLEN(S.rinfo[r]) : reflen;
       const int nk = tlen - K + 1;
@@ -666,11 +734,13 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       if (p + 1 < nk) { const int b = bl_base(S.bases, boff + (uint32_t)K); m |= 1u << ((ori == 0 ? 0 : 4) + (ori == 0 ? b : 3 - b)); }
       if (p > 0) { const int b = bl_base(S.bases, boff - 1u); m |= 1u << ((ori == 0 ? 4 : 0) + (ori == 0 ? b : 3 - b)); }
       if (m) dev_atomic_or(&msk[n >> 2], m << (8u * (n & 3u)));
-    BL_OCC_END
+    });
     WG_SYNC();
     WG_FOR(i, (N + 3) / 4) { const uint32_t m = msk[i]; if (m) dev_atomic_add((LC_LDS uint32_t *)&S.edges_total, (uint32_t)dev_popc(m)); }
     WG_SYNC();
   }
+  BLP(S, 14);
+  if (C->debug_stop == 114u) { WG_LANE0 { H->why = 99; } return; }
   // ---- edges of the survivors in first-seen order (Node_t::addEdge order over the reads, Graph.cc:320-347): earliest step per
   //      (side, extension base) slot with LDS atomicMin, groups of survivors that fit; stamp = 2 * offset of the step's u (+1 for
   //      the v side), offsets grow with (read, position) like the occurrence index of kernels.h
@@ -683,10 +753,9 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       const uint32_t s1 = s0 + gmax < nsurv ? s0 + gmax : nsurv;
       WG_FOR(i, (s1 - s0) * 8u) { E[i] = LC_NIL; }
       WG_SYNC();
-      BL_OCC_BEGIN(S)
-        const uint32_t e = X.occn[boff];
+      bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
         const uint32_t si = S.cidx[e & 0x1FFFu];
-        if (si < s0 || si >= s1) continue;
+        if (si < s0 || si >= s1) return;
         const uint32_t ori = e >> 15;
         const int tlen = r < nr ? (int)RI_TLEN(S.rinfo[r]) : reflen;
         const int nk = tlen - K + 1;
@@ -700,7 +769,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
           const uint32_t sl = (ori == 0 ? 4u : 0u) + (uint32_t)(ori == 0 ? b : 3 - b);
           dev_atomic_min(&E[(si - s0) * 8u + sl], 2u * (boff - 1u) + 1u);
         }
-      BL_OCC_END
+      });
       WG_SYNC();
       WG_FOR(sg, s1 - s0) {                                          // one lane per survivor: its record
         const uint32_t si = s0 + (uint32_t)sg, ci = X.s_ci[si], n = X.c_id[ci], ti = X.c_ti[ci];
@@ -747,14 +816,20 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
 // entry: persistent workgroups pull windows off the batch queue (`queue` is a counter of its own)
 // (queue[0] = next window, queue[1] = windows built)
 DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *B, LC_GLOBAL const EngineCaps *C, LC_GLOBAL uint8_t *pre,
-                           LC_GLOBAL uint8_t *scratch, LC_GLOBAL uint32_t *queue, BL_S &S, int slot) {
-  BlScratch X;
-  bl_scratch_carve(&X, (char *)(scratch + (size_t)slot * BL_SCRATCH_BYTES));
+                           LC_GLOBAL uint8_t *scratch, LC_GLOBAL uint32_t *queue, BL_S &S, int slot, LC_GLOBAL unsigned long long *phase = nullptr) {
+  LC_GLOBAL uint8_t *xbase = scratch + (size_t)slot * BL_SCRATCH_BYTES;
   while (true) {
     WG_LANE0 { S.w = (int)dev_atomic_add(queue, 1u); }
     const int w = (int)bl_bcast(&S.w);
     if (w >= B->n_windows) break;
-    bl_build_window(P, B, C, S, X, pre + (size_t)w * PRE_STRIDE, w);
+#ifndef LANCET_WAVE_EMU
+    if (threadIdx.x == 0) { for (int i = 0; i < 16; ++i) S.ph_acc[i] = 0; S.ph_cur = 0; S.t_last = wall_clock64(); }
+#endif
+    bl_build_window(P, B, C, S, xbase, pre + (size_t)w * PRE_STRIDE, w);
+    BLP(S, 15);
+#ifndef LANCET_WAVE_EMU
+    if (threadIdx.x == 0 && phase) for (int i = 0; i < 16; ++i) if (S.ph_acc[i]) atomicAdd((unsigned long long *)&phase[i], S.ph_acc[i]);
+#endif
     WG_LANE0 { if (((LC_GLOBAL const PreHdr *)(pre + (size_t)w * PRE_STRIDE))->status == PB_BUILT) dev_atomic_add(queue + 1, 1u); }
     WG_SYNC();
   }

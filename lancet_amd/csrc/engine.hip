@@ -26,9 +26,10 @@ __global__ void __launch_bounds__(LANCET_WG * 2) __attribute__((amdgpu_waves_per
 }
 
 // The first graph of every window in LDS (build_lds.h): 256 lanes per window, 2 workgroups per CU (80 KB of LDS each)
-__global__ void __launch_bounds__(BL_WG) build_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue) {
+__global__ void __launch_bounds__(BL_WG) build_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue,
+                                                      unsigned long long *phase) {
   build_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL uint8_t *)pre, (LC_GLOBAL uint8_t *)scratch,
-                    (LC_GLOBAL uint32_t *)queue, *(BL_S *)&bl_shared, (int)blockIdx.x);
+                    (LC_GLOBAL uint32_t *)queue, *(BL_S *)&bl_shared, (int)blockIdx.x, (LC_GLOBAL unsigned long long *)phase);
 }
 
 __global__ void prep_kernel(const lancet_params *P, int n_reads, const char *seq, const char *qual, const uint32_t *seq_off,
@@ -89,7 +90,8 @@ struct lancet_engine {
   int n_windows = 0, n_reads = 0, n_slots = 0;
   int n_rerun = 0;
   // LDS build kernel: hand-off areas (one per window), per-workgroup scratch
-  DevBuf d_pre, d_blscratch;
+  DevBuf d_pre, d_blscratch, d_blphase;
+  unsigned long long blphase[16] = {0};
   int n_bslots = 0, n_prebuilt = 0;
   bool prebuild = true;       // LANCET_NO_PREBUILD=1: every window through the general build phases (comparison / debugging)
   hipEvent_t evb0 = nullptr, evb1 = nullptr;
@@ -148,7 +150,7 @@ void lancet_engine_destroy(lancet_engine *e) {
   DevBuf *all[] = {&e->d_params, &e->d_batch, &e->d_caps, &e->d_out, &e->d_works, &e->d_chr, &e->d_refstart, &e->d_refoff, &e->d_refasc,
                    &e->d_refcodes, &e->d_readbegin, &e->d_seqoff, &e->d_seq, &e->d_qual, &e->d_label, &e->d_strand, &e->d_mate, &e->d_mapped,
                    &e->d_rinfo, &e->d_name, &e->d_bw, &e->d_gw, &e->d_bases, &e->d_good, &e->d_variants, &e->d_blob, &e->d_counters,
-                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist, &e->d_bx, &e->d_hp, &e->d_varlr, &e->d_bxblob, &e->d_pre, &e->d_blscratch};
+                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist, &e->d_bx, &e->d_hp, &e->d_varlr, &e->d_bxblob, &e->d_pre, &e->d_blscratch, &e->d_blphase};
   for (DevBuf *b : all) b->release();
   if (e->evb0) (void)hipEventDestroy(e->evb0);
   if (e->evb1) (void)hipEventDestroy(e->evb1);
@@ -262,6 +264,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     if (const char *s = getenv("LANCET_BUILD_SLOTS")) e->n_bslots = std::max(1, std::min(nw, atoi(s)));
     ENS(e->d_pre, (size_t)nw * PRE_STRIDE);
     ENS(e->d_blscratch, (size_t)e->n_bslots * BL_SCRATCH_BYTES);
+    ENS(e->d_blphase, 16 * sizeof(unsigned long long));
     o.pre = (LC_GLOBAL const uint8_t *)e->d_pre.p;
   }
   UP(e->d_out, &o, sizeof(o));
@@ -282,9 +285,11 @@ int lancet_engine_run(lancet_engine *e) {
   HIPCHK(e, hipMemsetAsync(e->d_stats.p, 0, sizeof(lancet_window_stats) * e->n_windows, e->stream));
   e->ms_build = 0; e->n_prebuilt = 0;
   if (e->prebuild) {
+    HIPCHK(e, hipMemsetAsync(e->d_blphase.p, 0, 16 * sizeof(unsigned long long), e->stream));
     HIPCHK(e, hipEventRecord(e->evb0, e->stream));
     hipLaunchKernelGGL(build_kernel, dim3(e->n_bslots), dim3(BL_WG), 0, e->stream, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
-                       (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_blscratch.p, (uint32_t *)e->d_counters.p + 8);
+                       (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_blscratch.p, (uint32_t *)e->d_counters.p + 8,
+                       (unsigned long long *)e->d_blphase.p);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipEventRecord(e->evb1, e->stream));
   }
@@ -300,6 +305,7 @@ int lancet_engine_run(lancet_engine *e) {
     uint32_t bq[2] = {0, 0};
     HIPCHK(e, hipMemcpy(bq, (uint32_t *)e->d_counters.p + 8, sizeof(bq), hipMemcpyDeviceToHost));
     e->n_prebuilt = (int)bq[1];
+    HIPCHK(e, hipMemcpy(e->blphase, e->d_blphase.p, sizeof(e->blphase), hipMemcpyDeviceToHost));
   }
   e->ms_all = e->ms_window + e->ms_build;
   e->ms_kernel = e->ms_all;
@@ -502,6 +508,12 @@ int lancet_engine_kernel_times(lancet_engine *e, float *ms, int cap) {
   if (cap < 2 || !ms) return LANCET_E_ARG;
   ms[0] = e->ms_build; ms[1] = e->ms_window;
   return 2;
+}
+// profiling aid: workgroup-seconds of the LDS build kernel per phase (16 values, 10 ns ticks; BLP() markers of build_lds.h)
+int lancet_engine_build_phase_times(lancet_engine *e, const unsigned long long **ticks) {
+  if (!e || !e->ran) return LANCET_E_STATE;
+  *ticks = e->blphase;
+  return LANCET_OK;
 }
 // windows of the last run whose first graph came from the LDS build kernel
 int lancet_engine_prebuilt_count(lancet_engine *e) { return e ? e->n_prebuilt : -1; }

@@ -3093,7 +3093,17 @@ DEV void process_window(Ctx &c, int w) {
   const int reflen = wg_bcast(&S.reflen);
   build_items(c);
   PHASE(c, 1);
-  repeat_scan(S.rs, B.ref_codes + B.ref_off[w], reflen, LC_CTX(c).P->max_mismatch, &S.repE, &S.repM);
+  {
+    // isRepeat / isAlmostRepeat operands of the window reference: taken from the LDS build kernel when it scanned this window
+    LC_GLOBAL const uint8_t *pre = LC_CTX(c).OUT->pre;
+    LC_GLOBAL const PreHdr *H = pre ? (LC_GLOBAL const PreHdr *)(pre + (size_t)w * PRE_STRIDE + PRE_OFF_HDR) : nullptr;
+#ifdef BL_DBG_NOREP
+    WG_LANE0 { S.tmp1 = 0; (void)H; }
+#else
+    WG_LANE0 { S.tmp1 = (H && H->have_rep == 1u) ? 1 : 0; if (S.tmp1) { S.repE = H->refE; S.repM = H->refM; } }
+#endif
+    if (!wg_bcast(&S.tmp1)) repeat_scan(S.rs, B.ref_codes + B.ref_off[w], reflen, LC_CTX(c).P->max_mismatch, &S.repE, &S.repM);
+  }
   PHASE(c, 0);
   const int refE = wg_bcast(&S.repE), refM = wg_bcast(&S.repM);
   int rptInRef = 0, rptInQry = 0, cycleInGraph = 0;

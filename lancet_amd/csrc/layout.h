@@ -164,7 +164,8 @@ struct PreHdr {
   int32_t K, refE, refM;
   uint32_t N, O, totalreadbp, n_kmers, ncand, nsurv;
   uint32_t edges_total, refn; /* trace only: sum of the edge counts of all N nodes, nodes that hold a reference k-mer */
-  uint32_t pad[19];
+  uint32_t have_rep;          /* refE / refM are valid (also when the graph was not built)                      */
+  uint32_t pad[18];
 };
 #define PRE_OFF_HDR 0u
 #define PRE_OFF_OCCREF 128u                                   /* u32[LC_MAXW]   node | ori << 31 per reference offset   */

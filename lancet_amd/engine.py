@@ -46,6 +46,7 @@ def lib():
         L.lancet_engine_trace.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32)]
         L.lancet_engine_rerun_count.argtypes = [C.c_void_p]
         L.lancet_engine_prebuilt_count.argtypes = [C.c_void_p]
+        L.lancet_engine_build_phase_times.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64))]
         L.lancet_engine_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
         L.lancet_engine_kernel_name.restype = C.c_char_p
         L.lancet_engine_kernel_name.argtypes = [C.c_int]
@@ -149,6 +150,12 @@ class Engine:
         if n < 0:
             self._chk(n)
         return [float(buf[i]) for i in range(n)]
+
+    def build_phase_times(self):
+        """Workgroup-seconds of the LDS build kernel per phase (profiling aid)."""
+        p = C.POINTER(C.c_uint64)()
+        self._chk(self.L.lancet_engine_build_phase_times(self.h, C.byref(p)))
+        return [p[i] * 1e-8 for i in range(16)]
 
     def prebuilt_count(self) -> int:
         return int(self.L.lancet_engine_prebuilt_count(self.h))

@@ -65,7 +65,7 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
     static thread_local BlShared BS;
     memset(&BS, 0xCD, sizeof(BS));
     uint32_t bq[2] = {0, 0};
-    build_kernel_body(P, &B, &C, pre.data(), blscr.data(), bq, BS, 0);
+    build_kernel_body(P, &B, &C, pre.data(), blscr.data(), bq, BS, 0, nullptr);
     O.pre = pre.data();
     res->n_prebuilt = bq[1];
     if (getenv("LANCET_EMU_WHY")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); if (H->status != PB_BUILT) fprintf(stderr, "[emu] window %d not prebuilt: why %u\n", w, H->why); }
