@@ -247,7 +247,8 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   BLP(S, 2);
   if (C->debug_stop == 102u) { WG_LANE0 { H->why = 99; } return; }
   // ---- reference repeat scan -> the first k of the loop that reaches buildgraph (Microassembler.cc:118-131)
-  repeat_scan((volatile LC_LDS unsigned long long *)(S.big + 4 * (BL_RMAX + 8)), refc, reflen, P->max_mismatch, (volatile LC_LDS int *)&S.repE, (volatile LC_LDS int *)&S.repM);
+  repeat_scan_min((volatile LC_LDS unsigned long long *)(S.big + 4 * (BL_RMAX + 8)), refc, reflen, P->max_mismatch, P->min_k, P->min_k + 1, (volatile LC_LDS int *)&S.repE, (volatile LC_LDS int *)&S.repM,
+                  (const LC_LDS uint32_t *)&S.bases[S.rdo[nr]]);     // (the reference is in LDS already, 2 bits per base: no N here)
   WG_LANE0 {
     int K = 0;
     for (int k = P->min_k; k <= P->max_k; k += 2) {

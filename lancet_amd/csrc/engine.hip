@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(LANCET_WG * 2) __attribute__((amdgpu_waves_per
 }
 
 // The first graph of every window in LDS (build_lds.h): 256 lanes per window, 2 workgroups per CU (80 KB of LDS each)
-__global__ void __launch_bounds__(BL_WG) build_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue,
+__global__ void __launch_bounds__(BL_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) build_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue,
                                                       unsigned long long *phase) {
   build_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL uint8_t *)pre, (LC_GLOBAL uint8_t *)scratch,
                     (LC_GLOBAL uint32_t *)queue, *(BL_S *)&bl_shared, (int)blockIdx.x, (LC_GLOBAL unsigned long long *)phase);

@@ -95,3 +95,10 @@ extern "C" void lancet_emu_repeat_scan(const uint8_t *s, int len, int mm, int bi
   if (bitparallel) repeat_scan(S.rs, s, len, mm, &e, &m); else repeat_scan_bytes(s, len, mm, &e, &m);
   *outE = e; *outM = m;
 }
+// the long-matches-only scan: results below lminE / lminM may be reported smaller
+extern "C" void lancet_emu_repeat_scan_min(const uint8_t *s, int len, int mm, int lminE, int lminM, int *outE, int *outM) {
+  static WinShared S;
+  volatile int e = 0, m = 0;
+  repeat_scan_min(S.rs, s, len, mm, lminE, lminM, &e, &m);
+  *outE = e; *outM = m;
+}

@@ -54,6 +54,46 @@ def test_repeat_scan_bitparallel_matches_bytewise():
             assert out[0] == out[1], (len(s), mm, out)
 
 
+def test_repeat_scan_long_matches_only_decides_like_the_full_scan():
+    """repeat_scan_min looks only at match runs long enough to matter for `E >= k` (k >= lminE) and `M >= k + 1` (k + 1 >= lminM):
+    every such decision must equal the byte-wise restatement's (reference src/util.cc:295-360)."""
+    import ctypes
+    import numpy as np
+    L = emu.lib()
+    f = L.lancet_emu_repeat_scan
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    f.restype = None
+    g = L.lancet_emu_repeat_scan_min
+    g.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    g.restype = None
+    rng = np.random.default_rng(9)
+    cases = []
+    for n in (2, 17, 31, 32, 33, 48, 64, 100, 599, 600, 640, 1200):
+        for _ in range(3):
+            cases.append(rng.integers(0, 4, size=n).astype(np.uint8))
+    for n in (96, 600):
+        for per in (1, 2, 3, 5, 11, 37):
+            s = np.tile(rng.integers(0, 4, size=per).astype(np.uint8), n // per + 1)[:n].copy()
+            for _ in range(int(rng.integers(0, 6))):
+                s[int(rng.integers(0, n))] ^= 1
+            cases.append(s)
+    s = rng.integers(0, 4, size=600).astype(np.uint8); s[300:364] = s[100:164]; s[310] ^= 1; s[340] ^= 2; cases.append(s)
+    s = rng.integers(0, 4, size=600).astype(np.uint8); s[568:600] = s[10:42]; cases.append(s)                 # match up to the last base
+    s = rng.integers(0, 4, size=592).astype(np.uint8); s[560:592] = s[0:32]; cases.append(s)
+    s = rng.integers(0, 4, size=600).astype(np.uint8); s[50:90] = 4; cases.append(s)
+    for s in cases:
+        for mm in (0, 1, 2, 3, 7):
+            e0, m0 = ctypes.c_int(-1), ctypes.c_int(-1)
+            f(s.ctypes.data, len(s), mm, 0, ctypes.byref(e0), ctypes.byref(m0))
+            for k0 in (3, 7, 11, 12, 13, 25, 61):
+                e, m = ctypes.c_int(-1), ctypes.c_int(-1)
+                g(s.ctypes.data, len(s), mm, k0, k0 + 1, ctypes.byref(e), ctypes.byref(m))
+                assert max(e.value, k0 - 1) == max(e0.value, k0 - 1), (len(s), mm, k0, e.value, e0.value)
+                assert max(m.value, k0) == max(m0.value, k0), (len(s), mm, k0, m.value, m0.value)
+                g(s.ctypes.data, len(s), mm, 0x7FFF, k0 + 1, ctypes.byref(e), ctypes.byref(m))     # the path scan: only M is asked
+                assert max(m.value, k0) == max(m0.value, k0), (len(s), mm, k0, m.value, m0.value)
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
 def test_emulated_kernels_match_oracle_on_random_cycle_prone_windows(seed):
     """Not reference goldens but oracle-pinned stress: tandem duplications, STR-rich reference, dense variants -- many
