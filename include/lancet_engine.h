@@ -158,6 +158,12 @@ int lancet_engine_run(lancet_engine *e);
 /* upload + run in one call, the exact equivalent of the reference seam. */
 int lancet_engine_process(lancet_engine *e, const lancet_window_batch *b);
 
+/* lancet_engine_run in two halves: submit launches the kernels of the uploaded batch on the engine's stream and returns at once,
+ * wait blocks until they are done (and re-runs what overflowed the small work space) and reads the results back.  One batch in
+ * flight per engine; two engines on the same device, submitted in turn, overlap the tail of one batch with the bulk of the next. */
+int lancet_engine_submit(lancet_engine *e);
+int lancet_engine_wait(lancet_engine *e);
+
 /* Results of the last run: variants ordered by (window, seq_in_window) so that the caller can replay
  * addVar in reference order. */
 int lancet_engine_results(lancet_engine *e, const lancet_variant **variants, uint32_t *n_variants,

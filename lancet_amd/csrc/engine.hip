@@ -32,12 +32,42 @@ __global__ void __launch_bounds__(BL_WG) __attribute__((amdgpu_waves_per_eu(4, 4
                     (LC_GLOBAL uint32_t *)queue, *(BL_S *)&bl_shared, (int)blockIdx.x, (LC_GLOBAL unsigned long long *)phase);
 }
 
-__global__ void prep_kernel(const lancet_params *P, int n_reads, const char *seq, const char *qual, const uint32_t *seq_off,
+// Graph_t::trim (reference src/Graph.cc:355-384) + 2-bit packing + quality mask, one wave per read: the lanes look at consecutive
+// bases (a wave instruction reads 64 consecutive bytes), first / last base that is DNA with quality >= MIN_QUAL_TRIM by wave
+// reduction, junk test (a non-ACGT base inside the kept part) by ballot, then one output word per lane.
+__global__ void __launch_bounds__(256) prep_kernel(const lancet_params *P, int n_reads, const char *seq, const char *qual, const uint32_t *seq_off,
                             const uint8_t *label, const uint8_t *strand, const uint8_t *mate, const uint8_t *mapped,
                             uint32_t *rinfo, uint32_t *bases, const uint32_t *bw, uint32_t *good, const uint32_t *gw) {
-  int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int r = (int)((blockIdx.x * 256u + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63u);
   if (r >= n_reads) return;
-  prep_read(P, seq, qual, seq_off[r], (int)(seq_off[r + 1] - seq_off[r]), label[r], strand[r], mate[r], mapped[r], &rinfo[r], bases, bw[r], good, gw[r]);
+  const uint32_t off = seq_off[r];
+  const int len = (int)(seq_off[r + 1] - off);
+  const char *sq = seq + off, *ql = qual + off;
+  const int qtrim = P->min_qual_trim, qcall = P->min_qual_call;
+  int fg = 0x7FFFFFFF, lg = -1;
+  for (int p = lane; p < len; p += 64) { if (is_dna(sq[p]) && !(ql[p] < qtrim)) { if (p < fg) fg = p; if (p > lg) lg = p; } }
+  for (int d = 32; d > 0; d >>= 1) { const int a = __shfl_xor(fg, d, 64), b = __shfl_xor(lg, d, 64); if (a < fg) fg = a; if (b > lg) lg = b; }
+  bool junk = lg < 0;
+  if (!junk) {
+    bool bad = false;
+    for (int p = fg + lane; p <= lg; p += 64) if (!is_dna(sq[p])) bad = true;
+    junk = __ballot(bad) != 0;
+  }
+  const int trim5 = junk ? 0 : fg;
+  int tlen = junk ? 0 : lg - fg + 1;
+  if (tlen > 0xFFFF) tlen = 0xFFFF;
+  if (lane == 0) rinfo[r] = (uint32_t)tlen | ((label[r] == LANCET_NML ? 1u : 0u) << 16) | ((strand[r] == LANCET_REV ? 1u : 0u) << 17) | ((uint32_t)(mate[r] & 3) << 18) | ((mapped[r] ? 1u : 0u) << 20);
+  const uint32_t b0 = bw[r], g0 = gw[r];
+  for (int wv = lane; wv < (tlen + 15) / 16; wv += 64) {
+    uint32_t v = 0;
+    for (int j = 0; j < 16 && wv * 16 + j < tlen; ++j) v |= (uint32_t)(base_code(sq[trim5 + wv * 16 + j]) & 3) << (2 * j);
+    bases[b0 + wv] = v;
+  }
+  for (int wv = lane; wv < (tlen + 31) / 32; wv += 64) {
+    uint32_t v = 0;
+    for (int j = 0; j < 32 && wv * 32 + j < tlen; ++j) if (ql[trim5 + wv * 32 + j] >= qcall) v |= 1u << j;
+    good[g0 + wv] = v;
+  }
 }
 // test hook: global_align_aff alone (align_fill + align_traceback) on one pair of strings
 __global__ void __launch_bounds__(LANCET_WG * 2) align_test_kernel(const EngineCaps *C, Work *work, const uint8_t *Sx, int n, const uint8_t *Tx, int m, int *out_len) {
@@ -96,7 +126,7 @@ struct lancet_engine {
   bool prebuild = true;       // LANCET_NO_PREBUILD=1: every window through the general build phases (comparison / debugging)
   hipEvent_t evb0 = nullptr, evb1 = nullptr;
   float ms_build = 0, ms_window = 0;
-  bool uploaded = false, ran = false;
+  bool uploaded = false, ran = false, submitted = false;
   uint32_t evt_cap = 0;
   size_t mem_budget = (size_t)96 << 30;
   int max_slots = 5120;      // work-space slots = resident single-wave workgroups: 5 per SIMD (96 VGPRs, < 8 KB LDS each) x 4 SIMDs x CUs
@@ -176,6 +206,7 @@ static int up(lancet_engine *e, DevBuf &b, const void *src, size_t bytes) {
 
 int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   if (!e || !b || b->n_windows < 0) return LANCET_E_ARG;
+  if (e->submitted) { e->err = "upload while a batch is in flight"; return LANCET_E_STATE; }
   HIPCHK(e, hipSetDevice(e->device));
   e->uploaded = false; e->ran = false;
   const int nw = b->n_windows;
@@ -216,7 +247,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   ENS(e->d_refcodes, nref + 1);
   DBG("prep launch");
   // ---- prep on the device: Graph_t::trim + packing, reference -> codes
-  if (R) hipLaunchKernelGGL(prep_kernel, dim3((R + 255) / 256), dim3(256), 0, e->stream, (const lancet_params *)e->d_params.p, (int)R,
+  if (R) hipLaunchKernelGGL(prep_kernel, dim3((R + 3) / 4), dim3(256), 0, e->stream, (const lancet_params *)e->d_params.p, (int)R,
                             (const char *)e->d_seq.p, (const char *)e->d_qual.p, (const uint32_t *)e->d_seqoff.p, (const uint8_t *)e->d_label.p,
                             (const uint8_t *)e->d_strand.p, (const uint8_t *)e->d_mate.p, (const uint8_t *)e->d_mapped.p, (uint32_t *)e->d_rinfo.p,
                             (uint32_t *)e->d_bases.p, (const uint32_t *)e->d_bw.p, (uint32_t *)e->d_good.p, (const uint32_t *)e->d_gw.p);
@@ -275,12 +306,18 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   return LANCET_OK;
 }
 
-int lancet_engine_run(lancet_engine *e) {
+// lancet_engine_run = lancet_engine_submit (launches the kernels of the uploaded batch on the engine's stream, returns at once) +
+// lancet_engine_wait (waits for them, re-runs what overflowed the small work space, reads the results back).  Two engines on one
+// GPU, submitted in turn, overlap the tail of one batch (a few multi-build windows) with the bulk of the next.
+int lancet_engine_submit(lancet_engine *e) {
   if (!e) return LANCET_E_ARG;
   if (!e->uploaded) { e->err = "run before upload"; return LANCET_E_STATE; }
+  if (e->submitted) { e->err = "submit while a batch is in flight"; return LANCET_E_STATE; }
   HIPCHK(e, hipSetDevice(e->device));
+  e->ran = false;
   e->variants.clear(); e->blob.clear(); e->stats.clear(); e->evt_len.clear(); e->evt.clear(); e->variants_lr.clear(); e->bx_blob.clear();
-  if (e->n_windows == 0) { e->ran = true; return LANCET_OK; }
+  e->submitted = true;
+  if (e->n_windows == 0) return LANCET_OK;
   HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, 64, e->stream));
   HIPCHK(e, hipMemsetAsync(e->d_stats.p, 0, sizeof(lancet_window_stats) * e->n_windows, e->stream));
   e->ms_build = 0; e->n_prebuilt = 0;
@@ -298,6 +335,15 @@ int lancet_engine_run(lancet_engine *e) {
                      (const DevBatch *)e->d_batch.p, (const EngineCaps *)e->d_caps.p, (Work *)e->d_works.p, (DevOut *)e->d_out.p);
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+  return LANCET_OK;
+}
+
+int lancet_engine_wait(lancet_engine *e) {
+  if (!e) return LANCET_E_ARG;
+  if (!e->submitted) { e->err = "wait without submit"; return LANCET_E_STATE; }
+  HIPCHK(e, hipSetDevice(e->device));
+  e->submitted = false;
+  if (e->n_windows == 0) { e->ran = true; return LANCET_OK; }
   HIPCHK(e, hipStreamSynchronize(e->stream));
   HIPCHK(e, hipEventElapsedTime(&e->ms_window, e->ev0, e->ev1));
   if (e->prebuild) {
@@ -413,6 +459,12 @@ int lancet_engine_run(lancet_engine *e) {
   }
   e->ran = true;
   return LANCET_OK;
+}
+
+int lancet_engine_run(lancet_engine *e) {
+  int rc = lancet_engine_submit(e);
+  if (rc) return rc;
+  return lancet_engine_wait(e);
 }
 
 int lancet_engine_process(lancet_engine *e, const lancet_window_batch *b) {

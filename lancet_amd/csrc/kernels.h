@@ -2014,6 +2014,222 @@ DEVNI uint32_t compress_fast(Ctx &c, int comp, bool quiet = false) {
   if (!quiet) evt(c, EV_CLEANDEAD, nabs);
   return nabs;
 }
+// ---------------------------------------------------------------------------------------------------------
+// The first compress of a component by the whole wave (same result as compress_fast, which pays one dependent memory round
+// trip per merge on one lane -- a clean 600-bp window is ONE chain of ~590 merges).
+//   * The mergeable links of compress_prepare make every chain a path; a node has two "ports" (leave it through its F or
+//     its R side), and following the links from a port is a linked list over ports.  Pointer jumping over the ports
+//     (log2 rounds, one 16-byte record per port and round) gives every port: how many nodes lie beyond it, the smallest
+//     table position among them (the chain's head is the member the reference's loop over the table reaches first:
+//     Graph.cc:2712-2732), the port the list ends in, and the parity of orientation-changing links (FR / RF) along it.
+//   * From those every absorbed node knows its head, the side of the head it hangs on, its place j in the merge order
+//     and the direction it is entered by (compressNode's dir bookkeeping, Graph.cc:2486-2706), and writes its
+//     descriptor into the head's new deque and its merge operands into the head's slice of a list in merge order.
+//   * One lane per head replays the float averaging (Graph.cc:2632-2636) over its slice -- the only sequential part, on
+//     contiguous memory -- and builds the head's edge list: its own edges without the two merged links, then the outward
+//     edges of the F-side end, then those of the R-side end (the erase / push_back order of compressNode).
+//   * All live nodes redirect edges that point at an absorbed node to its head (Node_t::updateEdge keeps the position).
+// A ring (no end to start from) or an asymmetric link leaves everything untouched and returns false: compress_fast runs.
+// ---------------------------------------------------------------------------------------------------------
+// port record of compress_rank in 8 bytes: next port [12:0] (8191 = none) | nodes beyond [25:13] | smallest table position [38:26] |
+// last port [51:39] | parity [52]   <->   x = next (LC_NIL none), y = nodes beyond | parity << 31, z = smallest position, w = last port
+DEV lc_u4 pr_unpack(unsigned long long v) {
+  lc_u4 r; const uint32_t nx = (uint32_t)(v & 0x1FFFu);
+  r.x = nx == 0x1FFFu ? LC_NIL : nx; r.y = (uint32_t)((v >> 13) & 0x1FFFu) | ((uint32_t)((v >> 52) & 1u) << 31); r.z = (uint32_t)((v >> 26) & 0x1FFFu); r.w = (uint32_t)((v >> 39) & 0x1FFFu);
+  return r;
+}
+DEV unsigned long long pr_pack(const lc_u4 r) {
+  return (unsigned long long)(r.x == LC_NIL ? 0x1FFFu : r.x) | ((unsigned long long)(r.y & 0x1FFFu) << 13) | ((unsigned long long)(r.z & 0x1FFFu) << 26) | ((unsigned long long)(r.w & 0x1FFFu) << 39) | ((unsigned long long)(r.y >> 31) << 52);
+}
+DEVNI bool compress_rank(Ctx &c, int comp) {
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  const int K = S.K;
+  const uint32_t M = wg_bcastu(&S.M);
+  if (M == 0 || 2 * M > 8190u || (size_t)44 * M + 64 > (size_t)4 * LC_CTX(c).C->occ_cap) return false;
+  LC_GLOBAL uint32_t *pos = W.pnodes;                                       // node -> table position
+  // port records, 8 bytes: next port [12:0] (8191 = none) | nodes beyond [25:13] | smallest table position [38:26] | last port [51:39] | parity [52]
+  LC_GLOBAL unsigned long long *PA = (LC_GLOBAL unsigned long long *)W.mv, *PB = PA + 2 * (size_t)M;      // ping-pong
+  LC_GLOBAL uint32_t *ord = W.mv + 16 * (size_t)M;                         // merge operands in merge order: 8 words per absorbed node
+  LC_GLOBAL uint32_t *hs = W.mv + 24 * (size_t)M;                          // [M+1] absorbed nodes per head -> slice start
+  LC_GLOBAL uint32_t *al = hs + (M + 1);                                   // [M+1] deque length per head -> arena offset
+  LC_GLOBAL uint32_t *ne = al + (M + 1);                                   // [M * 13] new edge lists of the heads (count + 12)
+  WG_FOR(i, M) { pos[W.order[i]] = (uint32_t)i; }
+  WG_LANE0 { S.tmp0 = 0; S.tmp3 = 0; }
+  WG_SYNC();
+  WG_FOR(i, M) {
+    const uint32_t n = W.order[i];
+    for (uint32_t sd = 0; sd < 2; ++sd) {
+      const uint32_t l = W.cmp[n].lnk[sd];
+      lc_u4 r; r.x = LC_NIL; r.y = 0; r.z = (uint32_t)i; r.w = 2u * (uint32_t)i + sd;
+      if (l & CL_VALID) {
+        const uint32_t B = CL_TO(l), ed = CL_DIR(l);
+        const uint32_t sb = (ed == 0 || ed == 2) ? 1u : 0u;                 // the side of B the link arrives at ('R' -> 1)
+        const uint32_t back = W.cmp[B].lnk[sb];
+        if (!(back & CL_VALID) || CL_TO(back) != n || CL_DIR(back) != fliplink(ed)) S.tmp3 = 1;      // not the mirror image: leave it to the literal replay
+        r.x = 2u * pos[B] + (1u - sb); r.y = 1u | (((ed == 1 || ed == 2) ? 1u : 0u) << 31);
+      }
+      PA[2u * (uint32_t)i + sd] = pr_pack(r);
+    }
+  }
+  if (wg_bcast(&S.tmp3)) return false;
+  // ---- pointer jumping
+  LC_GLOBAL unsigned long long *P = PA, *Q = PB;
+  for (int round = 0; round < 15; ++round) {
+    WG_LANE0 { S.tmp0 = 0; }
+    WG_FOR(l, LANCET_WG) {                                                  // four ports per lane and trip: the records first, then what they point at
+      const int NP = (int)(2 * M);
+      for (int p0 = l; p0 < NP; p0 += 4 * LANCET_WG) {
+        lc_u4 r[4], q[4];
+        for (int u = 0; u < 4; ++u) { const int p = p0 + u * LANCET_WG; r[u] = pr_unpack(P[p < NP ? p : l]); }
+        for (int u = 0; u < 4; ++u) q[u] = pr_unpack(P[r[u].x != LC_NIL ? r[u].x : (uint32_t)l]);
+        for (int u = 0; u < 4; ++u) {
+          const int p = p0 + u * LANCET_WG;
+          if (p >= NP) continue;
+          if (r[u].x != LC_NIL) {
+            r[u].y = (((r[u].y & 0x7FFFFFFFu) + (q[u].y & 0x7FFFFFFFu)) & 0x7FFFFFFFu) | ((r[u].y ^ q[u].y) & 0x80000000u);
+            if (q[u].z < r[u].z) r[u].z = q[u].z;
+            r[u].w = q[u].w; r[u].x = q[u].x;
+            if (r[u].x != LC_NIL) S.tmp0 = 1;
+          }
+          Q[p] = pr_pack(r[u]);
+        }
+      }
+    }
+    WG_SYNC();
+    { LC_GLOBAL unsigned long long *t = P; P = Q; Q = t; }
+    if (!wg_bcast(&S.tmp0)) break;
+    if (round == 14) return false;                                        // a ring: no port ever reaches an end
+  }
+  // ---- heads, slices, arena space
+  WG_FOR(i, M) {
+    const lc_u4 a = pr_unpack(P[2 * (size_t)i]), b = pr_unpack(P[2 * (size_t)i + 1]);
+    const uint32_t mF = a.y & 0x7FFFFFFFu, mR = b.y & 0x7FFFFFFFu;
+    const uint32_t cmin = a.z < b.z ? a.z : b.z;
+    const bool head = (mF + mR > 0) && cmin == (uint32_t)i;
+    hs[i] = head ? mF + mR : 0u; al[i] = head ? (uint32_t)K + mF + mR : 0u;
+  }
+  WG_LANE0 { hs[M] = 0; al[M] = 0; }
+  wg_scan(hs, (int)M + 1, S);
+  const uint32_t nabs = wg_bcastu(&S.part[LANCET_WG]);
+  wg_scan(al, (int)M + 1, S);
+  const uint32_t need = wg_bcastu(&S.part[LANCET_WG]);
+  const uint32_t top = wg_bcastu(&S.seq_top);
+  if (top + need > LC_CTX(c).C->seq_cap) { WG_LANE0 { OVF(c); S.tmp1 = 0; S.tmp2 = 0; } return true; }
+  // ---- every absorbed node: head, side, place, entering direction; descriptor into the head's deque, operands into its slice
+  WG_FOR(i, M) {
+    const lc_u4 a = pr_unpack(P[2 * (size_t)i]), b = pr_unpack(P[2 * (size_t)i + 1]);
+    const uint32_t mF = a.y & 0x7FFFFFFFu, mR = b.y & 0x7FFFFFFFu;
+    if (mF + mR == 0) continue;
+    const uint32_t cmin = a.z < b.z ? a.z : b.z;
+    const uint32_t n = W.order[i];
+    if (cmin == (uint32_t)i) { W.cmp[n].pad[0] = n; W.cmp[n].pad[1] = 0; continue; }       // a head
+    const uint32_t sH = (a.z == cmin) ? 0u : 1u;                            // the head lies beyond this side
+    const lc_u4 away = sH ? a : b;                                          // the port that leads away from the head
+    const lc_u4 hF = pr_unpack(P[2 * (size_t)cmin]), hR = pr_unpack(P[2 * (size_t)cmin + 1]);
+    const bool onF = away.w == hF.w && (hF.y & 0x7FFFFFFFu) > 0;
+    const lc_u4 hp = onF ? hF : hR;
+    const uint32_t mdir = hp.y & 0x7FFFFFFFu, hmF = hF.y & 0x7FFFFFFFu, hmR = hR.y & 0x7FFFFFFFu;
+    const uint32_t j = mdir - (away.y & 0x7FFFFFFFu);                       // 1 .. mdir
+    const uint32_t st_j = ((hp.y ^ away.y) >> 31) & 1u;
+    LC_GLOBAL const CmpRec &r = W.cmp[n];
+    const uint32_t raw = fliplink(CL_DIR(r.lnk[sH]));                      // the link that enters this node, in its predecessor's frame
+    const uint32_t st_p = st_j ^ ((raw == 1 || raw == 2) ? 1u : 0u);
+    const uint32_t edir = st_p ? flipme(raw) : raw;
+    const bool brev = (edir == 1 || edir == 3);
+    const uint32_t H = W.order[cmin];
+    const uint32_t nb = top + al[cmin];                                     // the head's new deque: [nb, nb + K + hmF + hmR), its own k-mer at nb + hmR
+    const uint32_t d = brev ? (r.d0 ^ 3u) : r.dK;
+    if (onF) W.seq[nb + hmR + (uint32_t)K + (j - 1u)] = d; else W.seq[nb + hmR - j] = d ^ 3u;
+    const uint32_t t = hs[cmin] + (onF ? j - 1u : hmF + j - 1u);
+    lc_u4 o0, o1;
+    o0.x = __builtin_bit_cast(uint32_t, r.cov[0]); o0.y = __builtin_bit_cast(uint32_t, r.cov[1]); o0.z = __builtin_bit_cast(uint32_t, r.cov[2]); o0.w = __builtin_bit_cast(uint32_t, r.cov[3]);
+    o1.x = (uint32_t)r.tot; o1.y = (uint32_t)(brev ? r.tq0 : r.tqK); o1.z = r.flags; o1.w = r.nkmT;
+    stg4(ord + 8 * (size_t)t, o0); stg4(ord + 8 * (size_t)t + 4, o1);
+    W.cmp[n].pad[0] = H; W.cmp[n].pad[1] = 1u | (st_j << 1) | (edir << 2);
+    W.gr[n].flags = r.flags | NF_DEAD; W.todo[n] = 1;
+  }
+  WG_SYNC_FENCE();
+  // ---- one lane per head: the merges' arithmetic in merge order, the new deque, the new edge list
+  WG_FOR(i, M) {
+    const uint32_t cnt = hs[i + 1] - hs[i];
+    if (cnt == 0) continue;
+    const uint32_t H = W.order[i];
+    LC_GLOBAL NodeGr &G = W.gr[H];
+    const lc_u4 a = pr_unpack(P[2 * (size_t)i]), b = pr_unpack(P[2 * (size_t)i + 1]);
+    const uint32_t mF = a.y & 0x7FFFFFFFu, mR = b.y & 0x7FFFFFFFu;
+    const uint32_t nb = top + al[i], olo = G.seq_lo;
+    for (int t = 0; t < K; ++t) W.seq[nb + mR + (uint32_t)t] = W.seq[olo + (uint32_t)t];
+    int mn = G.mincov, mq = G.mincovqv;
+    float nc0 = G.cov[0], nc1 = G.cov[1], nc2 = G.cov[2], nc3 = G.cov[3];
+    uint32_t fl = G.flags, nkmT = G.nkmT;
+    LC_GLOBAL const uint32_t *sl = ord + 8 * (size_t)hs[i];
+    lc_u4 o0 = ldg4(sl), o1 = ldg4(sl + 4);
+    for (uint32_t t = 0; t < cnt; ++t) {
+      const lc_u4 c0 = o0, c1 = o1;
+      if (t + 1 < cnt) { o0 = ldg4(sl + 8 * (size_t)(t + 1)); o1 = ldg4(sl + 8 * (size_t)(t + 1) + 4); }
+      const int amer = (int)t + 1, bmer = 1;                                // Graph.cc:2632-2636, same expression, same order
+      nc0 = ((nc0 * amer) + (__builtin_bit_cast(float, c0.x) * bmer)) / (amer + bmer);
+      nc1 = ((nc1 * amer) + (__builtin_bit_cast(float, c0.y) * bmer)) / (amer + bmer);
+      nc2 = ((nc2 * amer) + (__builtin_bit_cast(float, c0.z) * bmer)) / (amer + bmer);
+      nc3 = ((nc3 * amer) + (__builtin_bit_cast(float, c0.w) * bmer)) / (amer + bmer);
+      if ((int)c1.x < mn) mn = (int)c1.x;
+      if ((int)c1.y < mq) mq = (int)c1.y;
+      fl |= c1.z & (NF_TUMOR | NF_NORMAL); nkmT += c1.w;
+    }
+    // edges: own ones without the merged links, then the outward edges of the F-side end, then of the R-side end
+    uint32_t el[LC_EMAX + 1]; int m = 0; bool bad = false;
+    const int uF = mF ? get_buddy(c, H, 'F') : -1, uR = mR ? get_buddy(c, H, 'R') : -1;
+    if ((mF && uF < 0) || (mR && uR < 0)) bad = true;
+    for (int e = 0; e < (int)G.necnt; ++e) { if (e == uF || e == uR) continue; el[m++] = G.edges[e]; }
+    for (int side = 0; side < 2 && !bad; ++side) {
+      if (!(side == 0 ? mF : mR)) continue;
+      const uint32_t E = W.order[(side == 0 ? a.w : b.w) >> 1];            // the end of the list in that direction
+      const uint32_t info = W.cmp[E].pad[1], ed = (info >> 2) & 3u, st = (info >> 1) & 1u;
+      const char bdir = (ed == 0 || ed == 2) ? 'R' : 'F';
+      const int buid = get_buddy(c, E, bdir);
+      const int bcnt = (int)W.gr[E].necnt;
+      for (int e = 0; e < bcnt; ++e) {
+        if (e == buid) continue;
+        const uint32_t be = W.gr[E].edges[e];
+        uint32_t ndir = ED_DIR(be);
+        if (st) ndir = flipme(ndir);
+        const uint32_t other = ED_TO(be);
+        if (m >= LC_EMAX) { bad = true; break; }
+        el[m++] = ED_MAKE(other == E ? H : other, ndir) | (be & (1u << 30));
+      }
+    }
+    if (bad) { OVF(c); continue; }
+    ne[13 * (size_t)i] = (uint32_t)m;
+    for (int e = 0; e < m; ++e) ne[13 * (size_t)i + 1 + e] = el[e];
+    G.seq_clo = nb; G.seq_lo = nb; G.seq_hi = nb + (uint32_t)K + mF + mR; G.seq_chi = G.seq_hi;
+    G.mincov = mn; G.mincovqv = mq; G.cov[0] = nc0; G.cov[1] = nc1; G.cov[2] = nc2; G.cov[3] = nc3;
+    G.flags = fl; G.nkm += cnt; G.nkmT = nkmT;
+  }
+  WG_SYNC_FENCE();
+  // ---- every live node of the component: the head's new list / its own one, edges into an absorbed node redirected to its head
+  //      (the orientation the edge arrives in flips when the absorbed node's frame was flipped against the head's: updateEdge)
+  WG_FOR(i, M) {
+    const uint32_t n = W.order[i];
+    LC_GLOBAL NodeGr &G = W.gr[n];
+    if (G.comp != comp || (G.flags & NF_DEAD)) continue;
+    const bool head = hs[i + 1] != hs[i];
+    const int cnt = head ? (int)ne[13 * (size_t)i] : (int)G.necnt;
+    for (int e = 0; e < cnt; ++e) {
+      uint32_t ew = head ? ne[13 * (size_t)i + 1 + e] : G.edges[e];
+      const uint32_t to = ED_TO(ew);
+      if (!(W.gr[to].flags & NF_SPECIAL) && W.todo[to]) {
+        const uint32_t info = W.cmp[to].pad[1];
+        ew = ED_MAKE(W.cmp[to].pad[0], ED_DIR(ew) ^ ((info >> 1) & 1u)) | (ew & (1u << 30));
+      }
+      G.edges[e] = ew;
+    }
+    G.necnt = (uint32_t)cnt;
+  }
+  WG_LANE0 { S.seq_top = top + need; S.tmp1 = (int)nabs; S.tmp2 = 1; }
+  WG_SYNC_FENCE();
+  return true;
+}
+
 // cleanDead after compress_fast: the table order without the nodes marked in todo[] (scan-compaction, no node record touched)
 DEVNI void compact_absorbed_wg(Ctx &c) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
@@ -3287,7 +3503,8 @@ DEV void process_window(Ctx &c, int w) {
       if (wg_bcast(&S.overflow)) break;
       PHASE(c, 15);
       compress_prepare(c, comp);
-      WG_LANE0 {
+      const bool ranked = wg_bcast(&S.cmp_ok) && compress_rank(c, comp);     // (whole wave; false: a ring or an irregular link, nothing touched)
+      if (!ranked) WG_LANE0 {
         // The reference runs hasCycle on the k-mer graph and compresses only if there is none.  Unitig compaction merges
         // nodes across links that are the only edge on both sides, which neither creates nor removes a walk that comes
         // back to a node on the DFS stack, so the answer is the same on the compacted graph -- with ~30x fewer nodes to

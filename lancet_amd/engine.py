@@ -37,6 +37,8 @@ def lib():
         L.lancet_engine_last_error.argtypes = [C.c_void_p]
         L.lancet_engine_upload.argtypes = [C.c_void_p, C.POINTER(abi.LancetWindowBatch)]
         L.lancet_engine_run.argtypes = [C.c_void_p]
+        L.lancet_engine_submit.argtypes = [C.c_void_p]
+        L.lancet_engine_wait.argtypes = [C.c_void_p]
         L.lancet_engine_process.argtypes = [C.c_void_p, C.POINTER(abi.LancetWindowBatch)]
         L.lancet_engine_results.argtypes = [C.c_void_p, C.POINTER(C.POINTER(abi.LancetVariant)), C.POINTER(C.c_uint32),
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(abi.LancetWindowStats))]
@@ -95,6 +97,13 @@ class Engine:
 
     def run(self) -> None:
         self._chk(self.L.lancet_engine_run(self.h))
+
+    def submit(self) -> None:
+        """Launch the kernels of the uploaded batch and return at once (collect with wait())."""
+        self._chk(self.L.lancet_engine_submit(self.h))
+
+    def wait(self) -> None:
+        self._chk(self.L.lancet_engine_wait(self.h))
 
     def process(self, batch):
         self.upload(batch)

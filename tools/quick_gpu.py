@@ -49,3 +49,8 @@ print("LDS build kernel: prebuilt", eng.prebuilt_count(), "of", big.n_windows, "
 for i, n in enumerate(bn):
     print(f"  build phase {i:2d} {n:32s} {bp[i]:9.3f} s  {100 * bp[i] / max(bt, 1e-12):5.1f} %")
 print("  total workgroup-seconds", bt, "per window us", 1e6 * bt / max(1, big.n_windows))
+ptw = eng.phase_times().sum(axis=1)
+import numpy as _np
+order_ = _np.argsort(-ptw)
+print("slowest windows (ms, builds, final_k):", [(round(1000 * float(ptw[i]), 2), st[i]["n_builds"], st[i]["final_k"]) for i in order_[:12]])
+print("window time percentiles ms: p50 %.2f p90 %.2f p99 %.2f max %.2f ; windows with > 1 build: %d" % (1000 * _np.percentile(ptw, 50), 1000 * _np.percentile(ptw, 90), 1000 * _np.percentile(ptw, 99), 1000 * ptw.max(), sum(1 for s_ in st if s_["n_builds"] > 1)))
