@@ -24,6 +24,7 @@
 // above the LDS limits, windows with an occurrence the mate-overlap prefilter flags (hasOverlappingMate needs the replay of
 // build_csr), reads whose name occurs more than once with the same mate number.
 #pragma once
+#include <stddef.h>
 #include "kernels.h"
 
 #define BL_WG 512
@@ -787,8 +788,11 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
           if ((stamp[i] & 1u) == 0) { to = b & 0x1FFFu; dir = ua == 0 ? (ub == 0 ? 0u : 1u) : (ub == 0 ? 2u : 3u); }   // FF FR RF RR
           else { to = a & 0x1FFFu; dir = ua == 0 ? (ub == 0 ? 3u : 1u) : (ub == 0 ? 2u : 0u); }                         // RR FR RF FF
           if (S.cidx[to] == 0xFFFFu) continue;                       // removeNode of a non-survivor took the edge with it
+          X.s_edges[9 * (size_t)si + (uint32_t)m] = S.cidx[to];     // (neighbour by survivor index: the component search below)
           G.edges[m++] = ED_MAKE(to, dir);
         }
+        for (int i = m; i < 8; ++i) X.s_edges[9 * (size_t)si + (uint32_t)i] = 0xFFFFu;
+        X.s_edges[9 * (size_t)si + 8] = ((inmer[n >> 5] >> (n & 31u)) & 1u);
         for (int i = m; i < LC_EMAX; ++i) G.edges[i] = 0;
         const unsigned long long c4 = X.tcc[ti];
         const uint32_t c0 = (uint32_t)(c4 & 0xFFFFu), c1 = (uint32_t)((c4 >> 16) & 0xFFFFu), c2 = (uint32_t)((c4 >> 32) & 0xFFFFu), c3 = (uint32_t)(c4 >> 48);
@@ -805,6 +809,134 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       }
       WG_SYNC();
     }
+  }
+  BLP(S, 15);
+  // ---- libstdc++ iteration order of the node table after the N inserts (kernels.h first_lowcov / order_stage),
+  //      reduced to the survivors (cleanDead), and markConnectedComponents over them -- all in LDS: the reads are done with, the
+  //      whole arena from S.bases to the end of S.big is laid out anew.  Tables of more than 4096 nodes leave this to the window kernel.
+  WG_LANE0 { H->have_order = 0; }
+  if (N <= 4096u && nsurv > 0) {
+    LC_LDS uint8_t *arena = (LC_LDS uint8_t *)&S.bases[0];
+    LC_LDS uint32_t *first = (LC_LDS uint32_t *)arena;                       // [5120] smallest position of a bucket's elements
+    LC_LDS uint32_t *tmp = first + 5120;                                     // [4104] run sizes -> run starts -> fill cursors
+    LC_LDS uint16_t *Qa = (LC_LDS uint16_t *)(tmp + 4104), *Qb = Qa + 4096, *bkt = Qb + 4096, *out = bkt + 4096;
+    LC_LDS unsigned long long *nh = (LC_LDS unsigned long long *)(out + 4096);   // [32] hashes of the first inserts
+    LC_LDS uint32_t *nx = (LC_LDS uint32_t *)(nh + 32), *bk = nx + 32;           // [32] list links, [64] buckets of the sequential prefix
+    LC_LDS uint16_t *pos2si = (LC_LDS uint16_t *)(bk + 64);                      // [PB_SCAP] survivor index of the node at a position
+    static_assert(5120 * 4 + 4104 * 4 + 4 * 4096 * 2 + 32 * 8 + 32 * 4 + 64 * 4 + PB_SCAP * 2 <= offsetof(BlShared, big) + BL_BIG, "order arena");
+    LC_GLOBAL const unsigned long long *nhash = (LC_GLOBAL const unsigned long long *)(area + PRE_OFF_NHASH);
+    const uint32_t SEQ = 29u;
+    const uint32_t n0 = N < SEQ ? N : SEQ;
+    WG_SYNC();
+    WG_FOR(i, n0) { nh[i] = nhash[i]; }
+    WG_LANE0 {                                                               // the first inserts literally (_M_insert_bucket_begin / _M_rehash_aux)
+      uint32_t bc = 1, next_resize = 0, elt = 0, head = LC_NIL;
+      bk[0] = LC_NIL;
+      for (uint32_t n = 0; n < n0; ++n) {
+        if (elt + 1 > next_resize) {
+          unsigned long long mn = elt + 1;
+          if (next_resize == 0 && mn < 11) mn = 11;
+          if (mn >= bc) {
+            unsigned long long want = mn + 1; if (want < 2ULL * bc) want = 2ULL * bc;
+            const uint32_t nb = ht_next_prime((uint32_t)want);
+            next_resize = nb;
+            for (uint32_t i = 0; i < nb; ++i) bk[i] = LC_NIL;
+            uint32_t pp = head; head = LC_NIL; uint32_t bbegin = 0;
+            while (pp != LC_NIL) {
+              const uint32_t nxt = nx[pp], b = (uint32_t)(nh[pp] % nb);
+              if (bk[b] == LC_NIL) { nx[pp] = head; head = pp; bk[b] = LC_BB; if (nx[pp] != LC_NIL) bk[bbegin] = pp; bbegin = b; }
+              else { const uint32_t prev = bk[b]; if (prev == LC_BB) { nx[pp] = head; head = pp; } else { nx[pp] = nx[prev]; nx[prev] = pp; } }
+              pp = nxt;
+            }
+            bc = nb;
+          } else next_resize = bc;
+        }
+        const uint32_t b = (uint32_t)(nh[n] % bc), prev = bk[b];
+        if (prev != LC_NIL) { if (prev == LC_BB) { nx[n] = head; head = n; } else { nx[n] = nx[prev]; nx[prev] = n; } }
+        else { nx[n] = head; head = n; if (nx[n] != LC_NIL) bk[(uint32_t)(nh[nx[n]] % bc)] = n; bk[b] = LC_BB; }
+        ++elt;
+      }
+      uint32_t m = 0;
+      for (uint32_t pp = head; pp != LC_NIL; pp = nx[pp]) Qa[m++] = (uint16_t)pp;
+      S.g0 = bc; S.g1 = next_resize;
+    }
+    LC_LDS uint16_t *Q = Qa, *Qn = Qb;
+    uint32_t nprev = SEQ, B = SEQ;
+    if (N > SEQ) while (true) {
+      B = ht_next_prime(2u * B);
+      const uint32_t n = N < B ? N : B;
+      WG_FOR(j, n - nprev) { Q[nprev + (uint32_t)j] = (uint16_t)(nprev + (uint32_t)j); }
+      WG_FOR(b, B) { first[b] = LC_NIL; }
+      WG_FOR(i, n + 1) { tmp[i] = 0; }
+      WG_SYNC();
+      WG_FOR(i, n) { const uint32_t b = (uint32_t)(nhash[Q[i]] % B); bkt[i] = (uint16_t)b; dev_atomic_min(&first[b], (uint32_t)i); }
+      WG_SYNC();
+      WG_FOR(i, n) { dev_atomic_add(&tmp[n - 1 - first[bkt[i]]], 1u); }      // elements per run, runs indexed by their first position, latest first
+      bl_scan32(tmp, (int)n, S);
+      WG_FOR(i, n) { const uint32_t at = dev_atomic_add(&tmp[n - 1 - first[bkt[i]]], 1u); out[at] = (uint16_t)i; }
+      WG_SYNC();
+      WG_FOR(x, n) {                                                          // inside a run: latest first
+        if (x > 0 && bkt[out[x - 1]] == bkt[out[x]]) continue;
+        const uint32_t b = bkt[out[x]];
+        uint32_t e = (uint32_t)x + 1; while (e < n && bkt[out[e]] == b) ++e;
+        for (uint32_t i = (uint32_t)x + 1; i < e; ++i) { const uint16_t v = out[i]; uint32_t j = i; while (j > (uint32_t)x && out[j - 1] < v) { out[j] = out[j - 1]; --j; } out[j] = v; }
+      }
+      WG_SYNC();
+      WG_FOR(j, n) { Qn[j] = Q[out[j]]; }
+      WG_SYNC();
+      { LC_LDS uint16_t *t = Q; Q = Qn; Qn = t; }
+      if (N <= B) break;
+      nprev = B;
+    }
+    if (N > SEQ) { WG_LANE0 { S.g0 = B; S.g1 = B; } }
+    // ---- cleanDead: the survivors in that order; position of every survivor
+    LC_GLOBAL const uint8_t *surv = (LC_GLOBAL const uint8_t *)(area + PRE_OFF_SURV);
+    LC_GLOBAL uint32_t *order_s = (LC_GLOBAL uint32_t *)(area + PRE_OFF_ORDER);
+    LC_GLOBAL const uint32_t *sidv = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_SID);
+    WG_FOR(j, N + 1) { tmp[j] = (j < (int)N && surv[Q[j]]) ? 1u : 0u; }
+    bl_scan32(tmp, (int)N + 1, S);
+    WG_FOR(j, N) { if (tmp[j + 1] != tmp[j]) { order_s[tmp[j]] = Q[j]; first[Q[j]] = tmp[j]; } }    // first[]: node -> position among the survivors (N <= 4096 < 5120)
+    WG_SYNC();
+    // ---- markConnectedComponents (Graph.cc:2252-2336): min-label hooking + pointer jumping over the survivors' positions; the label of a
+    //      component is the position of its first node in table order, which is also what numbers the components
+    LC_LDS uint32_t *parent = tmp;                                           // [nsurv]
+    LC_LDS uint32_t *touch = tmp + 2052;                                     // [nsurv] bit 0: component holds a reference k-mer ; later: component number
+    LC_LDS uint16_t *adj = Qa;                                               // [nsurv * 8] neighbours as positions (Qa .. out: 32 KB)
+    WG_FOR(si, nsurv) {
+      const uint32_t ppos = first[sidv[si]];
+      for (int e = 0; e < 8; ++e) { const uint32_t t = X.s_edges[9 * (size_t)si + (uint32_t)e]; adj[8 * ppos + (uint32_t)e] = t == 0xFFFFu ? (uint16_t)ppos : (uint16_t)first[sidv[t]]; }
+      parent[ppos] = ppos; touch[ppos] = X.s_edges[9 * (size_t)si + 8]; pos2si[ppos] = (uint16_t)si;
+    }
+    WG_SYNC();
+    while (true) {
+      WG_LANE0 { S.flagged = 0; }
+      WG_FOR(u, nsurv) {
+        const uint32_t pu = ld2(&parent[u]);
+        uint32_t m = pu;
+        for (int e = 0; e < 8; ++e) { const uint32_t pv = ld2(&parent[adj[8 * (uint32_t)u + (uint32_t)e]]); if (pv < m) m = pv; }
+        if (m < pu) { dev_atomic_min(&parent[pu], m); dev_atomic_min(&parent[u], m); S.flagged = 1; }
+      }
+      WG_SYNC();
+      while (true) {
+        WG_LANE0 { S.npairs = 0; }
+        WG_FOR(u, nsurv) { const uint32_t pu = ld2(&parent[u]), gp = ld2(&parent[pu]); if (gp != pu) { dev_atomic_min(&parent[u], gp); S.npairs = 1; } }
+        WG_SYNC();
+        if (!bl_bcast(&S.npairs)) break;
+      }
+      if (!bl_bcast(&S.flagged)) break;
+    }
+    WG_FOR(u, nsurv) { if (touch[u] & 1u) dev_atomic_or(&touch[parent[u]], 2u); }
+    WG_SYNC();
+    LC_LDS uint32_t *num = first;                                            // (positions are no longer looked up by node)
+    WG_FOR(u, nsurv + 1) { num[u] = (u < (int)nsurv && parent[u] == (uint32_t)u) ? 1u : 0u; }
+    bl_scan32(num, (int)nsurv + 1, S);
+    WG_LANE0 { S.nbw = S.scan_total; S.ngw = 0; }                            // (nbw / ngw are free by now: components, components on the reference)
+    WG_SYNC();
+    WG_FOR(u, nsurv) { if (parent[u] == (uint32_t)u && (touch[u] & 2u)) dev_atomic_add((LC_LDS uint32_t *)&S.ngw, 1u); }
+    LC_GLOBAL NodeGr *pgr2 = (LC_GLOBAL NodeGr *)(area + PRE_OFF_PGR);
+    WG_FOR(u, nsurv) { pgr2[pos2si[u]].comp = (int)(num[parent[u]] + 1u); }   // numbered by the position of the component's first node
+    WG_LANE0 { H->have_order = 1; H->ht_bc = S.g0; H->ht_next_resize = S.g1; H->numcomp = S.nbw; H->refcomp = S.ngw; }
+    WG_SYNC();
   }
   WG_LANE0 {
     H->K = K; H->refE = S.repE; H->refM = S.repM; H->N = S.N; H->O = S.O; H->totalreadbp = S.totalreadbp; H->n_kmers = S.n_kmers;

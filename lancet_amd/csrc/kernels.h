@@ -72,6 +72,7 @@ struct WinShared {
   int phase_cur;
   int prebuilt;                                  // this build came from the LDS build kernel (build_lds.h): survb[] instead of the stale node records
   uint32_t pre_edges, pre_refn;                  // its trace aggregates
+  int pre_order;                                 // ... and it came with the survivors' table order and the components
 };
 
 // The one WinShared of the workgroup.  Functions reach it by name rather than through the pointer in Ctx: a pointer
@@ -670,11 +671,11 @@ DEVNI uint32_t clean_dead(Ctx &c, bool quiet = false) {
   if (!quiet) evt(c, EV_CLEANDEAD, dead);
   return dead;
 }
-DEVNI void print_stats(Ctx &c, int comp) {                            // Graph_t::printStats, reference src/Graph.cc:3674-3691
-  if (!LC_CTX(c).C->evt_cap) return;
+DEVNI void print_stats(Ctx &c, int comp, bool every = false) {        // Graph_t::printStats, reference src/Graph.cc:3674-3691
+  if (!LC_CTX(c).C->evt_cap) return;                                   // (every: before the components are numbered every node carries 0)
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   int edgecnt = 0, span = 0;
-  for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (W.gr[n].comp == comp) { edgecnt += W.gr[n].necnt; span += n_strlen(c, n); } }
+  for (uint32_t i = 0; i < S.M; ++i) { uint32_t n = W.order[i]; if (every || W.gr[n].comp == comp) { edgecnt += W.gr[n].necnt; span += n_strlen(c, n); } }
   evt(c, EV_STATS, comp, S.M, edgecnt, span);
 }
 
@@ -3375,7 +3376,13 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
     S.nspecial = 0; S.qv_top = ncand; S.seq_top = ncand * (uint32_t)K; S.tmask = 0; S.tfull = 0; S.prebuilt = 1;
     S.pre_edges = H->edges_total; S.pre_refn = H->refn;
     W.occ_base[S.R - 1] = 0;                                     // the reference pseudo-read's occurrences are the only ones the graph phases visit
+    S.pre_order = H->have_order == 1u ? 1 : 0;
+    if (S.pre_order) {                                           // first_lowcov + cleanDead + markConnectedComponents came along
+      S.M = nsurv; S.ht_bc = H->ht_bc; S.ht_elt = nsurv; S.ht_next_resize = H->ht_next_resize; S.ht_head = LC_NIL;
+      S.numcomp = (int)H->numcomp; S.refcomp = (int)H->refcomp;
+    }
   }
+  const bool pre_order = H->have_order == 1u;
   LC_GLOBAL const unsigned long long *nhash = (LC_GLOBAL const unsigned long long *)(area + PRE_OFF_NHASH);
   LC_GLOBAL const uint8_t *surv = (LC_GLOBAL const uint8_t *)(area + PRE_OFF_SURV);
   LC_GLOBAL const uint32_t *snode = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_SNODE), *sid = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_SID);
@@ -3384,7 +3391,10 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
   LC_GLOBAL const lc_v4 *pgr = (LC_GLOBAL const lc_v4 *)(area + PRE_OFF_PGR);
   LC_GLOBAL const lc_v4 *qsrc = (LC_GLOBAL const lc_v4 *)(area + PRE_OFF_QV);
   const uint32_t dummy = LC_CTX(c).C->node_cap + LC_CTX(c).C->special_cap;       // stand-in for reference k-mers whose node is gone
-  WG_FOR(n, N) { W.nhash[n] = nhash[n]; }
+  if (pre_order) {                                               // only the survivors' hashes are looked at again (unordered_map::insert of the special nodes)
+    LC_GLOBAL const uint32_t *ord = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_ORDER);
+    WG_FOR(i, nsurv) { const uint32_t n = ord[i]; W.order[i] = n; W.nhash[n] = nhash[n]; }
+  } else { WG_FOR(n, N) { W.nhash[n] = nhash[n]; } }
   WG_FOR(i, (N + 3) / 4) { ((LC_GLOBAL uint32_t *)W.survb)[i] = ((LC_GLOBAL const uint32_t *)surv)[i]; }
   WG_FOR(i, (int)(((size_t)ncand * K * 8 + 15) / 16)) { ((LC_GLOBAL lc_v4 *)W.qv)[i] = qsrc[i]; }
   WG_FOR(i, nsurv * 8u) { const uint32_t si = (uint32_t)i >> 3, part = (uint32_t)i & 7u; ((LC_GLOBAL lc_v4 *)&W.gr[sid[si]])[part] = pgr[(size_t)si * 8 + part]; }
@@ -3456,11 +3466,12 @@ DEV void process_window(Ctx &c, int w) {
     if (reflen - k > 0 && refM >= k + 1) { WG_LANE0 { evt(c, EV_NEAR_REF, k); } rptInRef = 1; continue; }
     WG_LANE0 { S.K = k; S.NW = (2 * k + 63) / 64; S.final_k = k; S.source = LC_NIL; S.sink = LC_NIL; if (k > 127 || S.NW > LC_NWMAX) S.overflow = 1; }
     if (wg_bcast(&S.overflow)) break;
-    WG_LANE0 { S.prebuilt = 0; }
+    WG_LANE0 { S.prebuilt = 0; S.pre_order = 0; }
     if (!load_prebuilt(c, k)) build_graph(c);
     if (wg_bcast(&S.overflow)) break;
     PHASE(c, 7);
-    first_lowcov(c);
+    const bool pre_order = wg_bcast(&S.pre_order) != 0;
+    if (!pre_order) first_lowcov(c);
     STOP_SET(c, 7);
     if (wg_bcast(&S.overflow)) break;
     PHASE(c, 8);
@@ -3488,9 +3499,24 @@ DEV void process_window(Ctx &c, int w) {
       }
     }
     WG_SYNC();
-    clean_dead_wg(c);
-    WG_LANE0 { print_stats(c, 0); }
-    mark_connected_components_wg(c);
+    if (pre_order) {
+      WG_LANE0 {
+        evt(c, EV_CLEANDEAD, S.N - S.M);
+        print_stats(c, 0, true);
+        if (LC_CTX(c).C->evt_cap) {                             // markConnectedComponents' trace lines from the numbering that came along
+          evt(c, EV_CC, S.M);
+          LC_GLOBAL uint32_t *tc = W.scratch;
+          for (int q = 0; q <= S.numcomp; ++q) tc[q] = 0;
+          for (uint32_t i = 0; i < S.M; ++i) { const uint32_t n = W.order[i]; if (W.gr[n].flags & NF_INMER) tc[W.gr[n].comp] = 1; }
+          for (int q = 1; q <= S.numcomp; ++q) if (tc[q]) evt(c, EV_CCID, (uint32_t)q);
+          evt(c, EV_CCEND, (uint32_t)S.numcomp, (uint32_t)S.refcomp);
+        }
+      }
+    } else {
+      clean_dead_wg(c);
+      WG_LANE0 { print_stats(c, 0); }
+      mark_connected_components_wg(c);
+    }
     int numcomp = wg_bcast(&S.numcomp);
     bool brk = false;
     PHASE(c, 9);

@@ -165,7 +165,10 @@ struct PreHdr {
   uint32_t N, O, totalreadbp, n_kmers, ncand, nsurv;
   uint32_t edges_total, refn; /* trace only: sum of the edge counts of all N nodes, nodes that hold a reference k-mer */
   uint32_t have_rep;          /* refE / refM are valid (also when the graph was not built)                      */
-  uint32_t pad[18];
+  uint32_t have_order;        /* the survivors' table order, the hashtable state and the components are here too */
+  uint32_t ht_bc, ht_next_resize;   /* libstdc++ bucket count / next rehash threshold after the N inserts        */
+  uint32_t numcomp, refcomp;  /* markConnectedComponents: components, components that hold a reference k-mer     */
+  uint32_t pad[13];
 };
 #define PRE_OFF_HDR 0u
 #define PRE_OFF_OCCREF 128u                                   /* u32[LC_MAXW]   node | ori << 31 per reference offset   */
@@ -176,7 +179,8 @@ struct PreHdr {
 #define PRE_OFF_SKEY (PRE_OFF_SNODE + 4u * PB_CCAP)           /* u64[PB_CCAP]   its canonical k-mer                     */
 #define PRE_OFF_SID (PRE_OFF_SKEY + 8u * PB_CCAP)             /* u32[PB_SCAP]   node of survivor si                     */
 #define PRE_OFF_PGR (PRE_OFF_SID + 4u * PB_SCAP)              /* NodeGr[PB_SCAP] records of the survivors, dense        */
-#define PRE_OFF_QV (PRE_OFF_PGR + 128u * PB_SCAP)             /* u16[PB_QVCAP*4] rows of K positions per candidate      */
+#define PRE_OFF_ORDER (PRE_OFF_PGR + 128u * PB_SCAP)          /* u32[PB_SCAP]   the survivors in libstdc++ table order  */
+#define PRE_OFF_QV (PRE_OFF_ORDER + 4u * PB_SCAP)             /* u16[PB_QVCAP*4] rows of K positions per candidate      */
 #define PRE_STRIDE ((PRE_OFF_QV + 8u * PB_QVCAP + 255u) & ~255u)
 
 /* One slot of work space.  All pointers are device pointers into one big allocation. */
