@@ -141,6 +141,17 @@ struct lancet_engine {
   float ms_all = 0, ms_kernel = 0;
 };
 
+
+// Copies of an engine go through ITS stream and wait for that stream only: hipMemcpy on the legacy default stream would also wait
+// for the kernels of every other engine on the device (two engines take turns on one GPU).
+static hipError_t lc_copy(lancet_engine *e, void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
+
+static hipError_t lc_copy(lancet_engine *e, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+  hipError_t r = hipMemcpyAsync(dst, src, bytes, kind, e->stream);
+  if (r != hipSuccess) return r;
+  return hipStreamSynchronize(e->stream);
+}
+
 extern "C" {
 
 void lancet_params_default(lancet_params *p) {
@@ -158,7 +169,7 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return LANCET_E_NO_DEVICE;
   lancet_engine *e = new lancet_engine();
   e->params = *p; e->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&e->stream) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
       hipEventCreate(&e->ev1) != hipSuccess || hipEventCreate(&e->evb0) != hipSuccess || hipEventCreate(&e->evb1) != hipSuccess) { delete e; return LANCET_E_HIP; }
   if (getenv("LANCET_NO_PREBUILD")) e->prebuild = false;
   if (p->lr_mode) e->prebuild = false;                         // --linked-reads: barcode / haplotype bookkeeping lives in the general build only
@@ -349,17 +360,17 @@ int lancet_engine_wait(lancet_engine *e) {
   if (e->prebuild) {
     HIPCHK(e, hipEventElapsedTime(&e->ms_build, e->evb0, e->evb1));
     uint32_t bq[2] = {0, 0};
-    HIPCHK(e, hipMemcpy(bq, (uint32_t *)e->d_counters.p + 8, sizeof(bq), hipMemcpyDeviceToHost));
+    HIPCHK(e, lc_copy(e, bq, (uint32_t *)e->d_counters.p + 8, sizeof(bq), hipMemcpyDeviceToHost));
     e->n_prebuilt = (int)bq[1];
-    HIPCHK(e, hipMemcpy(e->blphase, e->d_blphase.p, sizeof(e->blphase), hipMemcpyDeviceToHost));
+    HIPCHK(e, lc_copy(e, e->blphase, e->d_blphase.p, sizeof(e->blphase), hipMemcpyDeviceToHost));
   }
   e->ms_all = e->ms_window + e->ms_build;
   e->ms_kernel = e->ms_all;
   // ---- tier 2: windows that did not fit the small work space are re-run with the worst-case one
   e->stats.resize(e->n_windows);
-  HIPCHK(e, hipMemcpy(e->stats.data(), e->d_stats.p, sizeof(lancet_window_stats) * e->n_windows, hipMemcpyDeviceToHost));
+  HIPCHK(e, lc_copy(e, e->stats.data(), e->d_stats.p, sizeof(lancet_window_stats) * e->n_windows, hipMemcpyDeviceToHost));
   uint32_t nv_tier1 = 0;
-  HIPCHK(e, hipMemcpy(&nv_tier1, e->d_counters.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIPCHK(e, lc_copy(e, &nv_tier1, e->d_counters.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
   std::vector<uint32_t> rerun;
   std::vector<char> ok1(e->n_windows, 1);
   for (int w = 0; w < e->n_windows; ++w) if (e->stats[w].status == LANCET_W_OVERFLOW) { rerun.push_back((uint32_t)w); ok1[w] = 0; }
@@ -372,12 +383,12 @@ int lancet_engine_wait(lancet_engine *e) {
         e->d_out2.ensure(sizeof(DevOut))) { e->err = "hipMalloc failed (tier 2)"; return LANCET_E_OOM; }
     std::vector<Work> works2(slots2);
     for (int s2 = 0; s2 < slots2; ++s2) lc_work_carve(&works2[s2], (char *)e->d_workmem2.p + (size_t)s2 * slot2, e->caps2);
-    HIPCHK(e, hipMemcpy(e->d_works2.p, works2.data(), sizeof(Work) * slots2, hipMemcpyHostToDevice));
-    HIPCHK(e, hipMemcpy(e->d_winlist.p, rerun.data(), sizeof(uint32_t) * rerun.size(), hipMemcpyHostToDevice));
+    HIPCHK(e, lc_copy(e, e->d_works2.p, works2.data(), sizeof(Work) * slots2, hipMemcpyHostToDevice));
+    HIPCHK(e, lc_copy(e, e->d_winlist.p, rerun.data(), sizeof(uint32_t) * rerun.size(), hipMemcpyHostToDevice));
     DevOut o2;
-    HIPCHK(e, hipMemcpy(&o2, e->d_out.p, sizeof(o2), hipMemcpyDeviceToHost));
+    HIPCHK(e, lc_copy(e, &o2, e->d_out.p, sizeof(o2), hipMemcpyDeviceToHost));
     o2.win_list = (LC_GLOBAL const uint32_t *)e->d_winlist.p; o2.n_list = (uint32_t)rerun.size();
-    HIPCHK(e, hipMemcpy(e->d_out2.p, &o2, sizeof(o2), hipMemcpyHostToDevice));
+    HIPCHK(e, lc_copy(e, e->d_out2.p, &o2, sizeof(o2), hipMemcpyHostToDevice));
     HIPCHK(e, hipMemsetAsync((uint32_t *)e->d_counters.p + 2, 0, sizeof(uint32_t), e->stream));      // queue head
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
     hipLaunchKernelGGL(window_kernel, dim3(slots2), dim3(LANCET_WG), 0, e->stream, (const lancet_params *)e->d_params.p,
@@ -391,27 +402,27 @@ int lancet_engine_wait(lancet_engine *e) {
   }
   // ---- read back
   uint32_t counters[4];
-  HIPCHK(e, hipMemcpy(counters, e->d_counters.p, sizeof(counters), hipMemcpyDeviceToHost));
-  HIPCHK(e, hipMemcpy(e->stats.data(), e->d_stats.p, sizeof(lancet_window_stats) * e->n_windows, hipMemcpyDeviceToHost));
+  HIPCHK(e, lc_copy(e, counters, e->d_counters.p, sizeof(counters), hipMemcpyDeviceToHost));
+  HIPCHK(e, lc_copy(e, e->stats.data(), e->d_stats.p, sizeof(lancet_window_stats) * e->n_windows, hipMemcpyDeviceToHost));
   bool global_overflow = counters[0] > e->caps.var_cap || counters[1] > e->caps.blob_cap || (e->caps.lr_mode && counters[3] > e->caps.bx_cap);
   uint32_t nv = std::min(counters[0], e->caps.var_cap), nb = std::min(counters[1], e->caps.blob_cap);
   std::vector<lancet_variant> raw(nv);
   std::vector<char> rawblob(nb);
-  if (nv) HIPCHK(e, hipMemcpy(raw.data(), e->d_variants.p, sizeof(lancet_variant) * nv, hipMemcpyDeviceToHost));
-  if (nb) HIPCHK(e, hipMemcpy(rawblob.data(), e->d_blob.p, nb, hipMemcpyDeviceToHost));
+  if (nv) HIPCHK(e, lc_copy(e, raw.data(), e->d_variants.p, sizeof(lancet_variant) * nv, hipMemcpyDeviceToHost));
+  if (nb) HIPCHK(e, lc_copy(e, rawblob.data(), e->d_blob.p, nb, hipMemcpyDeviceToHost));
   std::vector<lancet_variant_lr> rawlr; std::vector<uint32_t> rawbx;
   if (e->caps.lr_mode) {
     uint32_t nx = std::min(counters[3], e->caps.bx_cap);
     rawlr.resize(nv); rawbx.resize(nx);
-    if (nv) HIPCHK(e, hipMemcpy(rawlr.data(), e->d_varlr.p, sizeof(lancet_variant_lr) * nv, hipMemcpyDeviceToHost));
-    if (nx) HIPCHK(e, hipMemcpy(rawbx.data(), e->d_bxblob.p, sizeof(uint32_t) * nx, hipMemcpyDeviceToHost));
+    if (nv) HIPCHK(e, lc_copy(e, rawlr.data(), e->d_varlr.p, sizeof(lancet_variant_lr) * nv, hipMemcpyDeviceToHost));
+    if (nx) HIPCHK(e, lc_copy(e, rawbx.data(), e->d_bxblob.p, sizeof(uint32_t) * nx, hipMemcpyDeviceToHost));
   }
   e->phase.resize((size_t)e->n_windows * 16);
-  HIPCHK(e, hipMemcpy(e->phase.data(), e->d_phase.p, sizeof(unsigned long long) * e->phase.size(), hipMemcpyDeviceToHost));
+  HIPCHK(e, lc_copy(e, e->phase.data(), e->d_phase.p, sizeof(unsigned long long) * e->phase.size(), hipMemcpyDeviceToHost));
   if (e->caps.evt_cap) {
     e->evt_len.resize(e->n_windows); e->evt.resize((size_t)e->n_windows * e->caps.evt_cap);
-    HIPCHK(e, hipMemcpy(e->evt_len.data(), e->d_evtlen.p, sizeof(uint32_t) * e->n_windows, hipMemcpyDeviceToHost));
-    HIPCHK(e, hipMemcpy(e->evt.data(), e->d_evt.p, sizeof(uint32_t) * e->evt.size(), hipMemcpyDeviceToHost));
+    HIPCHK(e, lc_copy(e, e->evt_len.data(), e->d_evtlen.p, sizeof(uint32_t) * e->n_windows, hipMemcpyDeviceToHost));
+    HIPCHK(e, lc_copy(e, e->evt.data(), e->d_evt.p, sizeof(uint32_t) * e->evt.size(), hipMemcpyDeviceToHost));
   }
   // variants of windows that overflowed are dropped; order by (window, emission order)
   std::vector<uint32_t> idx;
@@ -524,21 +535,21 @@ int lancet_debug_align(lancet_engine *e, const char *S, const char *T, char *S_a
   for (int i = 0; i < m; ++i) tc[i] = code(T[i]);
   if (mem.ensure(bytes) || dcaps.ensure(sizeof(caps)) || dwork.ensure(sizeof(Work)) || ds.ensure(n) || dt.ensure(m) || dl.ensure(4)) return LANCET_E_OOM;
   Work w; lc_work_carve(&w, (char *)mem.p, caps);
-  HIPCHK(e, hipMemcpy(dcaps.p, &caps, sizeof(caps), hipMemcpyHostToDevice));
-  HIPCHK(e, hipMemcpy(dwork.p, &w, sizeof(w), hipMemcpyHostToDevice));
-  HIPCHK(e, hipMemcpy(ds.p, sc.data(), n, hipMemcpyHostToDevice));
-  HIPCHK(e, hipMemcpy(dt.p, tc.data(), m, hipMemcpyHostToDevice));
+  HIPCHK(e, lc_copy(e, dcaps.p, &caps, sizeof(caps), hipMemcpyHostToDevice));
+  HIPCHK(e, lc_copy(e, dwork.p, &w, sizeof(w), hipMemcpyHostToDevice));
+  HIPCHK(e, lc_copy(e, ds.p, sc.data(), n, hipMemcpyHostToDevice));
+  HIPCHK(e, lc_copy(e, dt.p, tc.data(), m, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(align_test_kernel, dim3(1), dim3(LANCET_WG), 0, e->stream, (const EngineCaps *)dcaps.p, (Work *)dwork.p, (const uint8_t *)ds.p, n,
                      (const uint8_t *)dt.p, m, (int *)dl.p);
   HIPCHK(e, hipStreamSynchronize(e->stream));
   int L = 0;
-  HIPCHK(e, hipMemcpy(&L, dl.p, 4, hipMemcpyDeviceToHost));
+  HIPCHK(e, lc_copy(e, &L, dl.p, 4, hipMemcpyDeviceToHost));
   int rc = LANCET_OK;
   if (L < 0 || L + 1 > cap) rc = LANCET_E_UNSUPPORTED;
   else {
     const int acap = LC_MAXW + (int)caps.path_cap + 2;
-    HIPCHK(e, hipMemcpy(S_aln, w.aln, L, hipMemcpyDeviceToHost));
-    HIPCHK(e, hipMemcpy(T_aln, w.aln + acap, L, hipMemcpyDeviceToHost));
+    HIPCHK(e, lc_copy(e, S_aln, w.aln, L, hipMemcpyDeviceToHost));
+    HIPCHK(e, lc_copy(e, T_aln, w.aln + acap, L, hipMemcpyDeviceToHost));
     S_aln[L] = 0; T_aln[L] = 0;
   }
   mem.release(); dcaps.release(); dwork.release(); ds.release(); dt.release(); dl.release();

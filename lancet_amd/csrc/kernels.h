@@ -2164,18 +2164,22 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
     float nc0 = G.cov[0], nc1 = G.cov[1], nc2 = G.cov[2], nc3 = G.cov[3];
     uint32_t fl = G.flags, nkmT = G.nkmT;
     LC_GLOBAL const uint32_t *sl = ord + 8 * (size_t)hs[i];
-    lc_u4 o0 = ldg4(sl), o1 = ldg4(sl + 4);
-    for (uint32_t t = 0; t < cnt; ++t) {
-      const lc_u4 c0 = o0, c1 = o1;
-      if (t + 1 < cnt) { o0 = ldg4(sl + 8 * (size_t)(t + 1)); o1 = ldg4(sl + 8 * (size_t)(t + 1) + 4); }
-      const int amer = (int)t + 1, bmer = 1;                                // Graph.cc:2632-2636, same expression, same order
-      nc0 = ((nc0 * amer) + (__builtin_bit_cast(float, c0.x) * bmer)) / (amer + bmer);
-      nc1 = ((nc1 * amer) + (__builtin_bit_cast(float, c0.y) * bmer)) / (amer + bmer);
-      nc2 = ((nc2 * amer) + (__builtin_bit_cast(float, c0.z) * bmer)) / (amer + bmer);
-      nc3 = ((nc3 * amer) + (__builtin_bit_cast(float, c0.w) * bmer)) / (amer + bmer);
-      if ((int)c1.x < mn) mn = (int)c1.x;
-      if ((int)c1.y < mq) mq = (int)c1.y;
-      fl |= c1.z & (NF_TUMOR | NF_NORMAL); nkmT += c1.w;
+    for (uint32_t t0 = 0; t0 < cnt; t0 += 4) {                              // four merges per trip: their operands are fetched together
+      lc_u4 oa[4], ob[4];
+      for (uint32_t u = 0; u < 4; ++u) { const uint32_t ix = t0 + u < cnt ? t0 + u : cnt - 1; oa[u] = ldg4(sl + 8 * (size_t)ix); ob[u] = ldg4(sl + 8 * (size_t)ix + 4); }
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t t = t0 + u;
+        if (t >= cnt) break;
+        const lc_u4 c0 = oa[u], c1 = ob[u];
+        const int amer = (int)t + 1, bmer = 1;                              // Graph.cc:2632-2636, same expression, same order
+        nc0 = ((nc0 * amer) + (__builtin_bit_cast(float, c0.x) * bmer)) / (amer + bmer);
+        nc1 = ((nc1 * amer) + (__builtin_bit_cast(float, c0.y) * bmer)) / (amer + bmer);
+        nc2 = ((nc2 * amer) + (__builtin_bit_cast(float, c0.z) * bmer)) / (amer + bmer);
+        nc3 = ((nc3 * amer) + (__builtin_bit_cast(float, c0.w) * bmer)) / (amer + bmer);
+        if ((int)c1.x < mn) mn = (int)c1.x;
+        if ((int)c1.y < mq) mq = (int)c1.y;
+        fl |= c1.z & (NF_TUMOR | NF_NORMAL); nkmT += c1.w;
+      }
     }
     // edges: own ones without the merged links, then the outward edges of the F-side end, then of the R-side end
     uint32_t el[LC_EMAX + 1]; int m = 0; bool bad = false;
@@ -2332,6 +2336,77 @@ DEVNI bool find_tandems(const Ctx &c, LC_GLOBAL const uint8_t *seq, int n, int p
         if (staged) offs_lds[merlen * 8 + (unsigned)phase] = (int)i; else offsets_local[merlen][phase] = (int)i;
       }
     }
+  }
+  return ans;
+#undef LC_SEQ
+}
+
+// The same answer from the neighbourhood of `pos` alone.  findTandems keeps, per unit length and phase, the start of the current
+// stretch of equal consecutive units, and reports a stretch when it ends (at position i, having matched j more characters) if
+// pos lies within delta of [start, i + j].  A stretch that ends at i < pos - delta - MAXU cannot reach pos, so the literal loop
+// is entered at i0 = pos - delta - MAXU with the per-(unit, phase) stretch starts found by walking back over equal units (before
+// i0 every unit is a whole one and the end-of-string rule of the reference cannot fire), and left as soon as every stretch in
+// progress starts right of pos + delta.  ~200 character comparisons instead of ~10 000 for a 600-base path; same order of the
+// reports (the reference appends every reported motif and keeps the last length).
+DEVNI bool find_tandems_local(const Ctx &c, LC_GLOBAL const uint8_t *seq, int n, int pos, int *len, uint8_t *motif, int *motif_len) {
+  const unsigned MAXU = (unsigned)LC_CTX(c).P->max_unit_len, MRU = (unsigned)LC_CTX(c).P->min_report_units, MRL = (unsigned)LC_CTX(c).P->min_report_len;
+  const int delta = LC_CTX(c).P->dist_from_str;
+  bool ans = false;
+  *motif_len = 0;
+  const unsigned MU = MAXU < 8 ? MAXU : 8;
+  int i0 = pos - delta - (int)MU; if (i0 < 0) i0 = 0;
+  if (i0 > n) i0 = n;
+#define LC_SEQ(i) ((int)seq[(i)])
+  int offs[9][8];
+  for (unsigned ml = 1; ml <= MU; ++ml) for (unsigned ph = 0; ph < ml; ++ph) {
+    int t = (int)ph;
+    if (i0 > (int)ph) {
+      int u = i0 - 1 - (int)(((unsigned)(i0 - 1) - ph) % ml);            // last position < i0 of this phase
+      // the stretch that holds u: back over equal neighbouring units
+      t = u;
+      while (t - (int)ml >= (int)ph) {
+        bool eq = true;
+        for (unsigned m = 0; m < ml; ++m) if (LC_SEQ(t - (int)ml + (int)m) != LC_SEQ(t + (int)m)) { eq = false; break; }
+        if (!eq) break;
+        t -= (int)ml;
+      }
+    }
+    offs[ml][ph] = t;
+  }
+  for (unsigned i = (unsigned)i0; i < (unsigned)n; ++i) {
+    bool live = false;                                           // a stretch in progress that still starts at or left of pos + delta
+    for (unsigned merlen = 1; merlen <= MU; ++merlen) {
+      const int phase = (int)(i % merlen);
+      const int offset = offs[merlen][phase];
+      unsigned j = 0;
+      while ((j < merlen) && (i + j < (unsigned)n) && (LC_SEQ(i + j) == LC_SEQ(offset + j))) ++j;
+      if (j != merlen || (i + j + 1 == (unsigned)n)) {
+        int a = offset - 1, b = offset + (int)merlen - 1;
+        int ca = (a < 0 || a >= n) ? 255 : LC_SEQ(a), cb = (b < 0 || b >= n) ? 255 : LC_SEQ(b);
+        if (ca != cb) {
+          if (((i - (unsigned)offset) / merlen >= MRU) && (i - (unsigned)offset >= MRL)) {
+            unsigned ml = 1;
+            while (ml < merlen) {
+              unsigned units = (i - (unsigned)offset + j) / ml;
+              int allmatch = 1;
+              for (unsigned index = 1; allmatch && (index < units); ++index)
+                for (unsigned m = 0; m < ml; ++m) if (LC_SEQ(offset + m) != LC_SEQ(offset + index * ml + m)) { allmatch = 0; break; }
+              if (!allmatch) ++ml; else break;
+            }
+            if (ml == merlen) {
+              int start = offset, end = (int)(i + j), L = (int)(i + j) - offset;
+              if ((pos >= (start - delta)) && (pos <= (end + delta))) {
+                ans = true; *len = L;
+                for (unsigned z = 0; z < merlen; ++z) if (*motif_len < 60) motif[(*motif_len)++] = (uint8_t)LC_SEQ(offset + z);
+              }
+            }
+          }
+        }
+        offs[merlen][phase] = (int)i;
+      }
+    }
+    for (unsigned ml = 1; ml <= MU && !live; ++ml) for (unsigned ph = 0; ph < ml; ++ph) if (offs[ml][ph] - delta <= pos) { live = true; break; }
+    if (!live) break;
   }
   return ans;
 #undef LC_SEQ
@@ -3235,7 +3310,7 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
     }
     if (ACNF > 0 || ACNR > 0 || ACTF > 0 || ACTR > 0) {
       int LEN = 0, ml = 0; uint8_t motif[64];
-      bool ans = find_tandems(c, W.pseq, plen, (int)t.start_pos, &LEN, motif, &ml);
+      bool ans = find_tandems_local(c, W.pseq, plen, (int)t.start_pos, &LEN, motif, &ml);
       emit_variant(c, t, cov, LEN, motif, ml, ans, ra, pa, hp12, plen);
     }
   }

@@ -102,3 +102,15 @@ extern "C" void lancet_emu_repeat_scan_min(const uint8_t *s, int len, int mm, in
   repeat_scan_min(S.rs, s, len, mm, lminE, lminM, &e, &m);
   *outE = e; *outM = m;
 }
+
+// find_tandems: the whole-string scan and the local one (test hook; both must equal the oracle's restatement of src/util.cc:574-758)
+extern "C" int lancet_emu_find_tandems(const uint8_t *codes, int n, int pos, int max_unit_len, int min_report_units, int min_report_len, int dist_from_str,
+                                       int local, int *len, uint8_t *motif, int *motif_len) {
+  lancet_params P; memset(&P, 0, sizeof(P));
+  P.max_unit_len = max_unit_len; P.min_report_units = min_report_units; P.min_report_len = min_report_len; P.dist_from_str = dist_from_str;
+  static WinShared S;
+  Ctx c; c.P = &P; c.B = nullptr; c.C = nullptr; c.W = nullptr; c.OUT = nullptr; c.S = &S;
+  *len = 0;
+  bool a = local ? find_tandems_local(c, codes, n, pos, len, motif, motif_len) : find_tandems(c, codes, n, pos, len, motif, motif_len);
+  return a ? 1 : 0;
+}

@@ -157,3 +157,57 @@ def test_emulated_kernels_on_a_coverage_pile_up():
     v, st, _ = emu.run(pile, p)
     ov, ost, _ = oracle.run(pile, p)
     assert v == ov and [s["final_k"] for s in st] == [s["final_k"] for s in ost] and len(ov) > 0
+
+
+def test_find_tandems_local_equals_whole_string_scan_and_oracle():
+    """findTandems (reference src/util.cc:574-758) evaluated from the neighbourhood of the position only must report what the
+    whole-string scan reports: answer, length (last report wins) and the concatenated motifs, on random, STR-rich and periodic strings,
+    at every kind of position (string ends included) and under several option sets."""
+    import ctypes
+    import numpy as np
+    L = emu.lib()
+    f = L.lancet_emu_find_tandems
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                  ctypes.POINTER(ctypes.c_int), ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    f.restype = ctypes.c_int
+    rng = np.random.default_rng(17)
+
+    def run(codes, pos, opt, local):
+        ln, ml = ctypes.c_int(0), ctypes.c_int(0)
+        motif = np.zeros(64, dtype=np.uint8)
+        a = f(codes.ctypes.data, len(codes), pos, opt[0], opt[1], opt[2], opt[3], local, ctypes.byref(ln), motif.ctypes.data, ctypes.byref(ml))
+        return bool(a), ln.value, "".join("ACGT"[x] for x in motif[:ml.value])
+
+    strings = []
+    for n in (1, 2, 5, 9, 30, 120, 600):
+        strings.append(rng.integers(0, 4, size=n).astype(np.uint8))
+    for _ in range(12):                                   # STR blocks of unit 1..5 in random sequence, some interrupted
+        parts = []
+        while sum(len(p) for p in parts) < 300:
+            if rng.random() < 0.5:
+                parts.append(rng.integers(0, 4, size=int(rng.integers(1, 25))).astype(np.uint8))
+            else:
+                u = rng.integers(0, 4, size=int(rng.integers(1, 6))).astype(np.uint8)
+                blk = np.tile(u, int(rng.integers(2, 15)))
+                if rng.random() < 0.3 and len(blk) > 4:
+                    blk[int(rng.integers(0, len(blk)))] ^= 1
+                parts.append(blk)
+        strings.append(np.concatenate(parts))
+    strings.append(np.tile(np.array([0, 1], dtype=np.uint8), 60))
+    strings.append(np.zeros(80, dtype=np.uint8))
+    opts = [(4, 3, 7, 1), (3, 2, 5, 2), (6, 1, 2, 0), (1, 3, 7, 4), (8, 2, 4, 1)]
+    checked = 0
+    for s in strings:
+        n = len(s)
+        text = "".join("ACGT"[x] for x in s)
+        positions = sorted(set([0, 1, n - 1, n, n // 2] + [int(x) for x in rng.integers(0, n + 1, size=min(n + 1, 40))]))
+        for opt in opts:
+            for pos in positions:
+                full = run(s, pos, opt, 0)
+                loc = run(s, pos, opt, 1)
+                assert loc == full, (text, pos, opt, loc, full)
+                a, ln, mo = oracle.find_tandems(text, pos, *opt)
+                if opt[0] <= 4 or True:
+                    assert (a, ln if a else 0, mo[:60]) == (full[0], full[1] if full[0] else 0, full[2]), (text, pos, opt, (a, ln, mo), full)
+                checked += 1
+    assert checked > 2000
