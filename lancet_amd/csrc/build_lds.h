@@ -60,6 +60,7 @@ struct BlShared {
   int why;
   uint32_t npairs, flagged, edges_total, refn;
   uint32_t g0, g1;                  /* group bounds of the current pass                                          */
+  uint32_t hint;                    /* a read with a repeated k-mer was seen (scheduling hint)                    */
   unsigned long long t_last, ph_acc[16]; int ph_cur;   /* profiling: wall-clock ticks per phase (lane 0)                 */
 };
 
@@ -201,8 +202,8 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   const int nr = (int)(B.read_begin[w + 1] - g0);
   const int reflen = (int)(B.ref_off[w + 1] - B.ref_off[w]);
   LC_GLOBAL const uint8_t *refc = B.ref_codes + B.ref_off[w];
-  WG_LANE0 { S.w = w; S.why = BLW_NONE; S.R = nr + 1; S.reflen = reflen; S.hasN = 0; S.mapped = 0; S.flagged = 0; S.npairs = 0; S.edges_total = 0; S.refn = 0;
-             H->status = PB_NOT_BUILT; H->why = 0; H->have_rep = 0;
+  WG_LANE0 { S.hint = 0; S.w = w; S.why = BLW_NONE; S.R = nr + 1; S.reflen = reflen; S.hasN = 0; S.mapped = 0; S.flagged = 0; S.npairs = 0; S.edges_total = 0; S.refn = 0;
+             H->status = PB_NOT_BUILT; H->why = 0; H->have_rep = 0; H->heavy = 0;
              if (nr > BL_RMAX || reflen > LC_MAXW || reflen < 1) S.why = BLW_SIZE; }
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
   // ---- mapped reads, N in the window reference, per-read geometry
@@ -258,7 +259,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       K = k; break;
     }
     S.K = K;
-    H->refE = S.repE; H->refM = S.repM; H->have_rep = 1;          // (the window kernel does not repeat the scan)
+    H->refE = S.repE; H->refM = S.repM; H->mapped = (uint32_t)S.mapped; H->have_rep = 1;          // (the window kernel does not repeat the scan)
     if (K == 0 || K > 31 || (K & 1) == 0) S.why = BLW_K;
   }
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
@@ -349,13 +350,18 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       if (cur == BL_EMPTY) { cur = dev_atomic_cas32(&tab[idx], BL_EMPTY, mine); if (cur == BL_EMPTY) break; }
       if ((cur >> 16) == fp) {
         bool f2;
-        if (bl_canon(bl_kmer(S.bases, cur & 0xFFFFu, kmask), K, kmask, &f2) == ck) { if (mine < cur) dev_atomic_min(&tab[idx], mine); break; }
+        if (bl_canon(bl_kmer(S.bases, cur & 0xFFFFu, kmask), K, kmask, &f2) == ck) {
+          if (mine < cur) dev_atomic_min(&tab[idx], mine);
+          if (r < nr && (cur & 0xFFFFu) - 16u * S.rdo[r] < (uint32_t)RI_TLEN(S.rinfo[r]) && cur != mine) S.hint = 1;      // the same k-mer twice in one read
+          break;
+        }
       }
       idx = (idx + 1) & (BL_SLOTS - 1);
       if (++probes > 256u) { S.why = BLW_TABLE; break; }
     }
     X.occn[boff] = (uint16_t)(idx | (isF ? 0u : 0x8000u));
   BL_OCC_END
+  WG_LANE0 { H->heavy = S.hint; }
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
   BLP(S, 5);
   if (C->debug_stop == 105u) { WG_LANE0 { H->why = 99; } return; }

@@ -35,6 +35,18 @@ __global__ void __launch_bounds__(BL_WG) __attribute__((amdgpu_waves_per_eu(4, 4
 // Graph_t::trim (reference src/Graph.cc:355-384) + 2-bit packing + quality mask, one wave per read: the lanes look at consecutive
 // bases (a wave instruction reads 64 consecutive bytes), first / last base that is DNA with quality >= MIN_QUAL_TRIM by wave
 // reduction, junk test (a non-ACGT base inside the kept part) by ballot, then one output word per lane.
+// Processing order of the window kernel: the windows the build kernel could not take (general build phases: slow) and those
+// with a read that repeats a k-mer (a tandem duplication: k will climb over several builds) first, so that the few long-running
+// windows do not end up as the tail of the launch.  Only the order changes; results are sorted by (window, emission) afterwards.
+__global__ void order_kernel(const uint8_t *pre, int n_windows, uint32_t *list, uint32_t *cnt) {
+  const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (w >= n_windows) return;
+  const PreHdr *H = (const PreHdr *)(pre + (size_t)w * PRE_STRIDE + PRE_OFF_HDR);
+  const bool first = H->status != PB_BUILT ? (H->why != BLW_NOREADS) : (H->heavy != 0);
+  if (first) list[atomicAdd(&cnt[0], 1u)] = (uint32_t)w;
+  else list[(uint32_t)n_windows - 1u - atomicAdd(&cnt[1], 1u)] = (uint32_t)w;
+}
+
 __global__ void __launch_bounds__(256) prep_kernel(const lancet_params *P, int n_reads, const char *seq, const char *qual, const uint32_t *seq_off,
                             const uint8_t *label, const uint8_t *strand, const uint8_t *mate, const uint8_t *mapped,
                             uint32_t *rinfo, uint32_t *bases, const uint32_t *bw, uint32_t *good, const uint32_t *gw) {
@@ -120,7 +132,8 @@ struct lancet_engine {
   int n_windows = 0, n_reads = 0, n_slots = 0;
   int n_rerun = 0;
   // LDS build kernel: hand-off areas (one per window), per-workgroup scratch
-  DevBuf d_pre, d_blscratch, d_blphase;
+  DevBuf d_pre, d_blscratch, d_blphase, d_order;
+  bool heavy_first = true;    // LANCET_NO_HEAVY_FIRST=1: windows in batch order
   unsigned long long blphase[16] = {0};
   int n_bslots = 0, n_prebuilt = 0;
   bool prebuild = true;       // LANCET_NO_PREBUILD=1: every window through the general build phases (comparison / debugging)
@@ -191,7 +204,7 @@ void lancet_engine_destroy(lancet_engine *e) {
   DevBuf *all[] = {&e->d_params, &e->d_batch, &e->d_caps, &e->d_out, &e->d_works, &e->d_chr, &e->d_refstart, &e->d_refoff, &e->d_refasc,
                    &e->d_refcodes, &e->d_readbegin, &e->d_seqoff, &e->d_seq, &e->d_qual, &e->d_label, &e->d_strand, &e->d_mate, &e->d_mapped,
                    &e->d_rinfo, &e->d_name, &e->d_bw, &e->d_gw, &e->d_bases, &e->d_good, &e->d_variants, &e->d_blob, &e->d_counters,
-                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist, &e->d_bx, &e->d_hp, &e->d_varlr, &e->d_bxblob, &e->d_pre, &e->d_blscratch, &e->d_blphase};
+                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist, &e->d_bx, &e->d_hp, &e->d_varlr, &e->d_bxblob, &e->d_pre, &e->d_blscratch, &e->d_blphase, &e->d_order};
   for (DevBuf *b : all) b->release();
   if (e->evb0) (void)hipEventDestroy(e->evb0);
   if (e->evb1) (void)hipEventDestroy(e->evb1);
@@ -307,6 +320,8 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     ENS(e->d_pre, (size_t)nw * PRE_STRIDE);
     ENS(e->d_blscratch, (size_t)e->n_bslots * BL_SCRATCH_BYTES);
     ENS(e->d_blphase, 16 * sizeof(unsigned long long));
+    e->heavy_first = getenv("LANCET_NO_HEAVY_FIRST") == nullptr;
+    if (e->heavy_first) { ENS(e->d_order, sizeof(uint32_t) * (size_t)nw); o.win_list = (LC_GLOBAL const uint32_t *)e->d_order.p; o.n_list = (uint32_t)nw; }
     o.pre = (LC_GLOBAL const uint8_t *)e->d_pre.p;
   }
   UP(e->d_out, &o, sizeof(o));
@@ -339,6 +354,11 @@ int lancet_engine_submit(lancet_engine *e) {
                        (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_blscratch.p, (uint32_t *)e->d_counters.p + 8,
                        (unsigned long long *)e->d_blphase.p);
     HIPCHK(e, hipGetLastError());
+    if (e->heavy_first) {
+      hipLaunchKernelGGL(order_kernel, dim3((e->n_windows + 255) / 256), dim3(256), 0, e->stream, (const uint8_t *)e->d_pre.p, e->n_windows, (uint32_t *)e->d_order.p,
+                         (uint32_t *)e->d_counters.p + 12);
+      HIPCHK(e, hipGetLastError());
+    }
     HIPCHK(e, hipEventRecord(e->evb1, e->stream));
   }
   HIPCHK(e, hipEventRecord(e->ev0, e->stream));

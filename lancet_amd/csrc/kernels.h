@@ -73,6 +73,7 @@ struct WinShared {
   int prebuilt;                                  // this build came from the LDS build kernel (build_lds.h): survb[] instead of the stale node records
   uint32_t pre_edges, pre_refn;                  // its trace aggregates
   int pre_order;                                 // ... and it came with the survivors' table order and the components
+  int items_ready;                               // build_items ran for this window
 };
 
 // The one WinShared of the workgroup.  Functions reach it by name rather than through the pointer in Ctx: a pointer
@@ -1672,6 +1673,7 @@ DEVNI void build_refcov(Ctx &c) {
   }
 }
 DEV void build_graph(Ctx &c) {
+  if (!wg_bcast(&LC_SREF(c).items_ready)) { build_items(c); WG_LANE0 { LC_SREF(c).items_ready = 1; } }     // (a window whose graphs all come from the LDS build kernel never needs them)
   build_tables(c);
   if (wg_bcast(&LC_SREF(c).overflow)) return;
   PHASE(c, 4);
@@ -2050,7 +2052,8 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
   LC_GLOBAL uint32_t *pos = W.pnodes;                                       // node -> table position
   // port records, 8 bytes: next port [12:0] (8191 = none) | nodes beyond [25:13] | smallest table position [38:26] | last port [51:39] | parity [52]
   LC_GLOBAL unsigned long long *PA = (LC_GLOBAL unsigned long long *)W.mv, *PB = PA + 2 * (size_t)M;      // ping-pong
-  LC_GLOBAL uint32_t *ord = W.mv + 16 * (size_t)M;                         // merge operands in merge order: 8 words per absorbed node
+  LC_GLOBAL uint32_t *ord = W.mv + 16 * (size_t)M;                         // the absorbed nodes' coverages in merge order (4 floats each)
+  LC_GLOBAL uint32_t *hacc = W.mv + 20 * (size_t)M;                        // [heads * 4] min tot, min totqv, colour bits, tumor-only k-mers of the absorbed nodes
   LC_GLOBAL uint32_t *hs = W.mv + 24 * (size_t)M;                          // [M+1] absorbed nodes per head -> slice start
   LC_GLOBAL uint32_t *al = hs + (M + 1);                                   // [M+1] deque length per head -> arena offset
   LC_GLOBAL uint32_t *ne = al + (M + 1);                                   // [M * 13] new edge lists of the heads (count + 12)
@@ -2108,6 +2111,7 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
     const uint32_t cmin = a.z < b.z ? a.z : b.z;
     const bool head = (mF + mR > 0) && cmin == (uint32_t)i;
     hs[i] = head ? mF + mR : 0u; al[i] = head ? (uint32_t)K + mF + mR : 0u;
+    if (head) { lc_u4 z; z.x = 0x7FFFFFFFu; z.y = 0x7FFFFFFFu; z.z = 0; z.w = 0; stg4(hacc + 4 * (size_t)i, z); }
   }
   WG_LANE0 { hs[M] = 0; al[M] = 0; }
   wg_scan(hs, (int)M + 1, S);
@@ -2142,10 +2146,15 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
     const uint32_t d = brev ? (r.d0 ^ 3u) : r.dK;
     if (onF) W.seq[nb + hmR + (uint32_t)K + (j - 1u)] = d; else W.seq[nb + hmR - j] = d ^ 3u;
     const uint32_t t = hs[cmin] + (onF ? j - 1u : hmF + j - 1u);
-    lc_u4 o0, o1;
+    lc_u4 o0;
     o0.x = __builtin_bit_cast(uint32_t, r.cov[0]); o0.y = __builtin_bit_cast(uint32_t, r.cov[1]); o0.z = __builtin_bit_cast(uint32_t, r.cov[2]); o0.w = __builtin_bit_cast(uint32_t, r.cov[3]);
-    o1.x = (uint32_t)r.tot; o1.y = (uint32_t)(brev ? r.tq0 : r.tqK); o1.z = r.flags; o1.w = r.nkmT;
-    stg4(ord + 8 * (size_t)t, o0); stg4(ord + 8 * (size_t)t + 4, o1);
+    stg4(ord + 4 * (size_t)t, o0);
+    {                                                                       // what does not depend on the merge order goes straight to the head
+      LC_GLOBAL uint32_t *ha = hacc + 4 * (size_t)cmin;
+      dev_atomic_min(&ha[0], (uint32_t)r.tot); dev_atomic_min(&ha[1], (uint32_t)(brev ? r.tq0 : r.tqK));
+      if (r.flags & (NF_TUMOR | NF_NORMAL)) dev_atomic_or(&ha[2], r.flags & (NF_TUMOR | NF_NORMAL));
+      if (r.nkmT) dev_atomic_add(&ha[3], r.nkmT);
+    }
     W.cmp[n].pad[0] = H; W.cmp[n].pad[1] = 1u | (st_j << 1) | (edir << 2);
     W.gr[n].flags = r.flags | NF_DEAD; W.todo[n] = 1;
   }
@@ -2163,24 +2172,27 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
     int mn = G.mincov, mq = G.mincovqv;
     float nc0 = G.cov[0], nc1 = G.cov[1], nc2 = G.cov[2], nc3 = G.cov[3];
     uint32_t fl = G.flags, nkmT = G.nkmT;
-    LC_GLOBAL const uint32_t *sl = ord + 8 * (size_t)hs[i];
-    for (uint32_t t0 = 0; t0 < cnt; t0 += 4) {                              // four merges per trip: their operands are fetched together
-      lc_u4 oa[4], ob[4];
-      for (uint32_t u = 0; u < 4; ++u) { const uint32_t ix = t0 + u < cnt ? t0 + u : cnt - 1; oa[u] = ldg4(sl + 8 * (size_t)ix); ob[u] = ldg4(sl + 8 * (size_t)ix + 4); }
-      for (uint32_t u = 0; u < 4; ++u) {
-        const uint32_t t = t0 + u;
-        if (t >= cnt) break;
-        const lc_u4 c0 = oa[u], c1 = ob[u];
-        const int amer = (int)t + 1, bmer = 1;                              // Graph.cc:2632-2636, same expression, same order
-        nc0 = ((nc0 * amer) + (__builtin_bit_cast(float, c0.x) * bmer)) / (amer + bmer);
-        nc1 = ((nc1 * amer) + (__builtin_bit_cast(float, c0.y) * bmer)) / (amer + bmer);
-        nc2 = ((nc2 * amer) + (__builtin_bit_cast(float, c0.z) * bmer)) / (amer + bmer);
-        nc3 = ((nc3 * amer) + (__builtin_bit_cast(float, c0.w) * bmer)) / (amer + bmer);
-        if ((int)c1.x < mn) mn = (int)c1.x;
-        if ((int)c1.y < mq) mq = (int)c1.y;
-        fl |= c1.z & (NF_TUMOR | NF_NORMAL); nkmT += c1.w;
-      }
+    LC_GLOBAL const uint32_t *sl = ord + 4 * (size_t)hs[i];
+    {
+      const lc_u4 ha = ldg4(hacc + 4 * (size_t)i);
+      if ((int)ha.x < mn) mn = (int)ha.x;
+      if ((int)ha.y < mq) mq = (int)ha.y;
+      fl |= ha.z; nkmT += ha.w;
     }
+    // four merges per trip, the next four coverages already on their way (named registers: an indexed local array lives in scratch
+    // memory, and waiting for it waits for the loads in flight as well)
+#define LC_MERGE_STEP(cv, t) do { if ((t) < cnt) { const int amer = (int)(t) + 1, bmer = 1;   /* Graph.cc:2632-2636, same expression, same order */ \
+      nc0 = ((nc0 * amer) + (__builtin_bit_cast(float, (cv).x) * bmer)) / (amer + bmer); nc1 = ((nc1 * amer) + (__builtin_bit_cast(float, (cv).y) * bmer)) / (amer + bmer); \
+      nc2 = ((nc2 * amer) + (__builtin_bit_cast(float, (cv).z) * bmer)) / (amer + bmer); nc3 = ((nc3 * amer) + (__builtin_bit_cast(float, (cv).w) * bmer)) / (amer + bmer); } } while (0)
+#define LC_MERGE_LOAD(u, t0) ldg4(sl + 4 * (size_t)((t0) + (u) < cnt ? (t0) + (u) : cnt - 1))
+    lc_u4 n0 = LC_MERGE_LOAD(0u, 0u), n1 = LC_MERGE_LOAD(1u, 0u), n2 = LC_MERGE_LOAD(2u, 0u), n3 = LC_MERGE_LOAD(3u, 0u);
+    for (uint32_t t0 = 0; t0 < cnt; t0 += 4) {
+      const lc_u4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+      if (t0 + 4 < cnt) { n0 = LC_MERGE_LOAD(0u, t0 + 4); n1 = LC_MERGE_LOAD(1u, t0 + 4); n2 = LC_MERGE_LOAD(2u, t0 + 4); n3 = LC_MERGE_LOAD(3u, t0 + 4); }
+      LC_MERGE_STEP(c0, t0); LC_MERGE_STEP(c1, t0 + 1); LC_MERGE_STEP(c2, t0 + 2); LC_MERGE_STEP(c3, t0 + 3);
+    }
+#undef LC_MERGE_STEP
+#undef LC_MERGE_LOAD
     // edges: own ones without the merged links, then the outward edges of the F-side end, then of the R-side end
     uint32_t el[LC_EMAX + 1]; int m = 0; bool bad = false;
     const int uF = mF ? get_buddy(c, H, 'F') : -1, uR = mR ? get_buddy(c, H, 'R') : -1;
@@ -2357,7 +2369,13 @@ DEVNI bool find_tandems_local(const Ctx &c, LC_GLOBAL const uint8_t *seq, int n,
   int i0 = pos - delta - (int)MU; if (i0 < 0) i0 = 0;
   if (i0 > n) i0 = n;
 #define LC_SEQ(i) ((int)seq[(i)])
+  // (the stretch starts are indexed at run time: in LDS -- the staging area of the per-position pass is idle in the graph phases -- an
+  //  indexed local array would live in scratch memory)
+#ifndef LANCET_WAVE_EMU
+  LC_LDS int (*offs)[8] = (LC_LDS int (*)[8])((LC_LDS uint8_t *)LC_SREF(c).mk + 2048);
+#else
   int offs[9][8];
+#endif
   for (unsigned ml = 1; ml <= MU; ++ml) for (unsigned ph = 0; ph < ml; ++ph) {
     int t = (int)ph;
     if (i0 > (int)ph) {
@@ -3343,7 +3361,18 @@ DEVNI bool repeats_in_graph_paths(Ctx &c) {
     if (wg_bcast(&S.tmp0) != 0) break;
     { const int pl = path_string_wg(c, wg_bcast(&S.tmp2)); WG_LANE0 { S.tmp3 = pl; if (S.overflow) S.tmp0 = 1; } }
     if (wg_bcast(&S.tmp0) != 0) break;
-    repeat_scan_min(S.rs, W.pseq, wg_bcast(&S.tmp3), LC_CTX(c).P->max_mismatch, 0x7FFF, wg_uniform(S.K) + 1, &S.repE, &S.repM);      // isAlmostRepeat(path->str(), K, MAX_MISMATCH): only M >= K + 1 is asked
+    {
+      // isAlmostRepeat(path->str(), K, MAX_MISMATCH): only M >= K + 1 is asked.  A path that spells the reference between the anchors
+      // needs no scan: its longest near-repeat cannot exceed that of the whole window reference, which passed this very test for
+      // this k before the graph was built (Microassembler.cc:124-131; the test is only made when reflen > k).
+      const int pl = wg_bcast(&S.tmp3);
+      LC_GLOBAL const uint8_t *rs = LC_CTX(c).B->ref_codes + LC_CTX(c).B->ref_off[S.w] + S.seq_t5;
+      WG_LANE0 { S.ps_hd = (pl == S.seq_len && S.reflen - S.K > 0) ? 0 : 1; }
+      WG_SYNC();
+      if (pl == S.seq_len) { WG_FOR(i, pl) { if (rs[i] != W.pseq[i]) S.ps_hd = 1; } }
+      if (wg_bcast(&S.ps_hd)) repeat_scan_min(S.rs, W.pseq, pl, LC_CTX(c).P->max_mismatch, 0x7FFF, wg_uniform(S.K) + 1, &S.repE, &S.repM);
+      else { WG_LANE0 { S.repE = 0; S.repM = 0; } }
+    }
     WG_LANE0 {
       // NB isAlmostRepeat only looks at windows that end before the last base: handled inside repeat_scan
       if (S.tmp3 - S.K > 0 && S.repM >= S.K + 1) { evt(c, EV_NEAR_QRY, S.K); S.tmp0 = 2; }
@@ -3492,6 +3521,7 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
 DEV void process_window(Ctx &c, int w) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W; LC_GLOBAL const DevBatch &B = *LC_CTX(c).B;
   WG_LANE0 {
+    S.items_ready = 0;
     S.w = w; S.overflow = 0; S.evt_len = 0; S.emit_seq = 0; S.n_kmers = 0; S.max_nodes = 0; S.n_builds = 0; S.N_last = 0; S.final_k = 0;
     S.status = LANCET_W_OK;
     S.LR = LC_CTX(c).C->lr_mode ? 1 : 0; S.QS = S.LR ? 10 : 4;
@@ -3503,7 +3533,9 @@ DEV void process_window(Ctx &c, int w) {
     if ((uint32_t)S.R > LC_CTX(c).C->reads_cap || S.R > 0xFFFF || S.reflen > LC_MAXW || S.reflen < 1) S.overflow = 1;   // csr / item words keep the read in 16 bits
     S.hasN = 0;
   }
-  {                                                             // mapped reads, N in the window reference: all lanes
+  LC_GLOBAL const PreHdr *H0 = LC_CTX(c).OUT->pre ? (LC_GLOBAL const PreHdr *)(LC_CTX(c).OUT->pre + (size_t)w * PRE_STRIDE + PRE_OFF_HDR) : nullptr;
+  WG_LANE0 { S.tmp1 = (H0 && H0->have_rep == 1u) ? 1 : 0; if (S.tmp1) { S.tmp0 = (int)H0->mapped; S.hasN = 0; } }     // (the build kernel counted them; it scans no window with N)
+  if (!wg_bcast(&S.tmp1)) {                                     // mapped reads, N in the window reference: all lanes
     WG_SYNC();
     const uint32_t r0 = B.read_begin[w]; const int nr = S.R - 1, rl = S.reflen;
     uint32_t mine = 0;
@@ -3517,7 +3549,6 @@ DEV void process_window(Ctx &c, int w) {
   if (wg_bcast(&S.tmp0) <= 0) { WG_LANE0 { S.status = LANCET_W_NO_READS; } WG_SYNC(); return; }     // Microassembler.cc:83
   if (wg_bcast(&S.overflow)) { WG_LANE0 { S.status = LANCET_W_OVERFLOW; } WG_SYNC(); return; }
   const int reflen = wg_bcast(&S.reflen);
-  build_items(c);
   PHASE(c, 1);
   {
     // isRepeat / isAlmostRepeat operands of the window reference: taken from the LDS build kernel when it scanned this window

@@ -168,7 +168,9 @@ struct PreHdr {
   uint32_t have_order;        /* the survivors' table order, the hashtable state and the components are here too */
   uint32_t ht_bc, ht_next_resize;   /* libstdc++ bucket count / next rehash threshold after the N inserts        */
   uint32_t numcomp, refcomp;  /* markConnectedComponents: components, components that hold a reference k-mer     */
-  uint32_t pad[13];
+  uint32_t heavy;             /* scheduling hint only: a read holds the same k-mer twice (tandem duplication: the graph will have a cycle and k will climb) */
+  uint32_t mapped;            /* countMappedReads of the window (valid with have_rep)                            */
+  uint32_t pad[11];
 };
 #define PRE_OFF_HDR 0u
 #define PRE_OFF_OCCREF 128u                                   /* u32[LC_MAXW]   node | ori << 31 per reference offset   */
