@@ -82,13 +82,16 @@ __global__ void __launch_bounds__(256) prep_kernel(const lancet_params *P, int n
   }
 }
 // test hook: global_align_aff alone (align_fill + align_traceback) on one pair of strings
-__global__ void __launch_bounds__(LANCET_WG * 2) align_test_kernel(const EngineCaps *C, Work *work, const uint8_t *Sx, int n, const uint8_t *Tx, int m, int *out_len) {
+__global__ void __launch_bounds__(LANCET_WG * 2) align_test_kernel(const EngineCaps *C, Work *work, const uint8_t *Sx, int n, const uint8_t *Tx, int m, int *out_len, int mode) {
   LC_WS &S = *(LC_WS *)&lc_shared;
   Ctx c; c.P = nullptr; c.B = nullptr; c.C = (LC_GLOBAL const EngineCaps *)C; c.W = (LC_GLOBAL Work *)work; c.OUT = nullptr; c.S = &S;
   LC_CTX_PUBLISH(c);
   WG_LANE0 { S.overflow = 0; }
   WG_SYNC();
-  align_fill(c, (LC_GLOBAL const uint8_t *)Sx, n, (LC_GLOBAL const uint8_t *)Tx, m);
+  if (mode == 1 || !align_fill_band(c, (LC_GLOBAL const uint8_t *)Sx, n, (LC_GLOBAL const uint8_t *)Tx, m)) {     // mode 1: the full matrix only
+    if (mode == 2) { WG_LANE0 { *out_len = -2; } return; }                                                          // mode 2: the band only (-2: not certified)
+    align_fill(c, (LC_GLOBAL const uint8_t *)Sx, n, (LC_GLOBAL const uint8_t *)Tx, m);
+  }
   WG_LANE0 { int L = align_traceback(c, (LC_GLOBAL const uint8_t *)Sx, n, (LC_GLOBAL const uint8_t *)Tx, m); *out_len = S.overflow ? -1 : L; }
 }
 
@@ -539,7 +542,11 @@ int lancet_engine_trace(lancet_engine *e, const uint32_t **evt_len, const uint32
 }
 
 // test hook: runs the device alignment on (S, T) (ACGT strings, |S| <= LC_MAXW); writes the aligned strings.
-int lancet_debug_align(lancet_engine *e, const char *S, const char *T, char *S_aln, char *T_aln, int cap) {
+// mode 0: band first, full matrix when the band is not certified (what the window kernel does); 1: full matrix only; 2: band only
+// (LANCET_E_STATE when the band could not be certified)
+int lancet_debug_align_mode(lancet_engine *e, const char *S, const char *T, char *S_aln, char *T_aln, int cap, int mode);
+int lancet_debug_align(lancet_engine *e, const char *S, const char *T, char *S_aln, char *T_aln, int cap) { return lancet_debug_align_mode(e, S, T, S_aln, T_aln, cap, 0); }
+int lancet_debug_align_mode(lancet_engine *e, const char *S, const char *T, char *S_aln, char *T_aln, int cap, int mode) {
   if (!e || !S || !T) return LANCET_E_ARG;
   HIPCHK(e, hipSetDevice(e->device));
   int n = (int)strlen(S), m = (int)strlen(T);
@@ -560,12 +567,13 @@ int lancet_debug_align(lancet_engine *e, const char *S, const char *T, char *S_a
   HIPCHK(e, lc_copy(e, ds.p, sc.data(), n, hipMemcpyHostToDevice));
   HIPCHK(e, lc_copy(e, dt.p, tc.data(), m, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(align_test_kernel, dim3(1), dim3(LANCET_WG), 0, e->stream, (const EngineCaps *)dcaps.p, (Work *)dwork.p, (const uint8_t *)ds.p, n,
-                     (const uint8_t *)dt.p, m, (int *)dl.p);
+                     (const uint8_t *)dt.p, m, (int *)dl.p, mode);
   HIPCHK(e, hipStreamSynchronize(e->stream));
   int L = 0;
   HIPCHK(e, lc_copy(e, &L, dl.p, 4, hipMemcpyDeviceToHost));
   int rc = LANCET_OK;
-  if (L < 0 || L + 1 > cap) rc = LANCET_E_UNSUPPORTED;
+  if (L == -2) rc = LANCET_E_STATE;
+  else if (L < 0 || L + 1 > cap) rc = LANCET_E_UNSUPPORTED;
   else {
     const int acap = LC_MAXW + (int)caps.path_cap + 2;
     HIPCHK(e, lc_copy(e, S_aln, w.aln, L, hipMemcpyDeviceToHost));

@@ -74,6 +74,7 @@ struct WinShared {
   uint32_t pre_edges, pre_refn;                  // its trace aggregates
   int pre_order;                                 // ... and it came with the survivors' table order and the components
   int items_ready;                               // build_items ran for this window
+  int al_band, al_lo, al_score;                  // alignment: traceback bytes in band layout (offsets j - i from al_lo, two per lane), score at (n, m)
 };
 
 // The one WinShared of the workgroup.  Functions reach it by name rather than through the pointer in Ctx: a pointer
@@ -2927,6 +2928,7 @@ DEV void align_fill_arrays(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL
 DEVNI void align_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const uint8_t *Tx, int m) {
   static_assert(LANCET_WG == 64, "one wave per window");
   LC_GLOBAL Work &W = *LC_CTX(c).W;
+  if (threadIdx.x == 0) LC_SREF(c).al_band = 0;
   const int lane = (int)threadIdx.x;
   for (int j = lane; j < m + 1; j += 64) W.tb[LC_TB(0, j, n)] = (uint8_t)((j == 0 ? 3 : 2) | (0 << 2) | (2 << 4));           // M[0][j] '^' ; Y[0][j] '*'
   for (int i = lane + 1; i < n + 1; i += 64) W.tb[LC_TB(i, 0, n)] = (uint8_t)(1 | (2 << 2) | (0 << 4));     // M[i][0] '<' ; X[i][0] '*'
@@ -2978,8 +2980,111 @@ DEVNI void align_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL cons
   WG_SYNC();
 }
 #else
-DEV void align_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const uint8_t *Tx, int m) { align_fill_arrays(c, Sx, n, Tx, m); }
+DEV void align_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const uint8_t *Tx, int m) { LC_SREF(c).al_band = 0; align_fill_arrays(c, Sx, n, Tx, m); }
 #endif
+// ---------------------------------------------------------------------------------------------------------
+// The same dynamic programme restricted to a band of 128 diagonals (offsets j - i in [lo, lo + 127]) around the two corners:
+// an anti-diagonal t = i + j meets 64 cells of the band (the offsets of t's parity), one per lane; the cell's three
+// neighbours were computed one or two steps earlier by the lane itself or by the lane next to it.  65 bytes of traceback per
+// anti-diagonal instead of n + 1, ~10x fewer cell updates for a 600 x 600 problem.
+// The result is the full matrix's whenever the best alignment stays inside the band, and that is CERTIFIED: an alignment
+// that leaves the band needs gaps of at least hi + 1 in one direction and hi + 1 - d back (resp. 1 - lo and 1 - lo + d),
+// which bounds its score; if the score found in the band is strictly above that bound, no alignment outside can equal it, so
+// every cell on an optimal path -- and every tie the reference's rules break -- has the same value in both programmes.
+// Returns false (nothing usable) when the band cannot be certified or does not hold both corners: align_fill then runs.
+// ---------------------------------------------------------------------------------------------------------
+#define LC_BNEG (-(1 << 24))
+DEV void band_cell(int i, int j, int sch, int tch, int dM, int uM, int uX, int lM, int lY, int *oM, int *oX, int *oY, uint8_t *otb) {
+  const int xa = uX - 1, xb = uM - 8;
+  int xs, xt; if (xa > xb) { xs = xa; xt = 1; } else { xs = xb; xt = 0; }
+  const int ya = lY - 1, yb = lM - 8;
+  int ys, yt; if (ya > yb) { ys = ya; yt = 1; } else { ys = yb; yt = 0; }
+  int ms = dM + (sch == tch ? 2 : -4), mt = 0;
+  if (xs > ms) { ms = xs; mt = 1; }
+  if (ys > ms) { ms = ys; mt = 2; }
+  (void)i; (void)j;
+  *oM = ms; *oX = xs; *oY = ys; *otb = (uint8_t)(mt | (xt << 2) | (yt << 4));
+}
+DEVNI bool align_fill_band(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const uint8_t *Tx, int m) {
+  LC_GLOBAL Work &W = *LC_CTX(c).W; LC_WS &S = LC_SREF(c);
+  const int d = m - n;
+  const int w = (127 - (d < 0 ? -d : d)) / 2;
+  if (w < 8 || n < 1 || m < 1) return false;
+  const int lo = (d < 0 ? d : 0) - w, hi = lo + 127;
+  if ((size_t)(n + m + 2) * 64 > (size_t)(LC_MAXW + LC_CTX(c).C->path_cap + 4) * (LC_MAXW + 2)) return false;
+  WG_LANE0 { S.al_band = 1; S.al_lo = lo; S.al_score = LC_BNEG; }
+#ifndef LANCET_WAVE_EMU
+  {
+    const int lane = (int)threadIdx.x;
+    int M1 = LC_BNEG, X1 = LC_BNEG, Y1 = LC_BNEG, M2 = LC_BNEG;     // own cell of the previous step (M, X, Y) and M of the one before
+    int fin = LC_BNEG;
+    for (int t = 2; t <= n + m; ++t) {
+      const int pt = (t - lo) & 1;
+      const int o = lo + 2 * lane + pt;
+      const int i = (t - o) >> 1, j = t - i;
+      const bool valid = o <= hi && i >= 1 && i <= n && j >= 1 && j <= m;
+      // the neighbour lane's previous cell: lane + 1 holds offset o + 1 when pt == 1, lane - 1 holds o - 1 when pt == 0
+      int nM = pt ? __shfl_down(M1, 1, 64) : __shfl_up(M1, 1, 64);
+      int nXY = pt ? __shfl_down(X1, 1, 64) : __shfl_up(Y1, 1, 64);
+      if (pt ? lane == 63 : lane == 0) { nM = LC_BNEG; nXY = LC_BNEG; }
+      int uM = pt ? nM : M1, uX = pt ? nXY : X1;                       // (i-1, j): offset o + 1
+      int lM = pt ? M1 : nM, lY = pt ? Y1 : nXY;                       // (i, j-1): offset o - 1
+      int dM = M2;                                                     // (i-1, j-1): offset o, two steps ago
+      if (i == 1) { uM = -8 - j; uX = -8 - j; dM = (j == 1) ? 0 : -8 - (j - 1); }
+      if (j == 1) { lM = -8 - i; lY = -8 - i; if (i != 1) dM = -8 - (i - 1); }
+      int cM = LC_BNEG, cX = LC_BNEG, cY = LC_BNEG; uint8_t tb = 0;
+      if (valid) {
+        band_cell(i, j, (int)Sx[i - 1], (int)Tx[j - 1], dM, uM, uX, lM, lY, &cM, &cX, &cY, &tb);
+        W.tb[(size_t)t * 64 + (size_t)lane] = tb;
+        if (i == n && j == m) fin = cM;
+      }
+      M2 = M1; M1 = cM; X1 = cX; Y1 = cY;
+    }
+    if (fin != LC_BNEG) S.al_score = fin;                              // (exactly one lane holds the corner)
+  }
+#else
+  {
+    int M1[64], X1[64], Y1[64], M2[64];
+    for (int l = 0; l < 64; ++l) { M1[l] = X1[l] = Y1[l] = M2[l] = LC_BNEG; }
+    for (int t = 2; t <= n + m; ++t) {
+      const int pt = (t - lo) & 1;
+      int nM_[64], nX_[64], nY_[64];
+      for (int lane = 0; lane < 64; ++lane) {
+        const int o = lo + 2 * lane + pt;
+        const int i = (t - o) >> 1, j = t - i;
+        const bool valid = o <= hi && i >= 1 && i <= n && j >= 1 && j <= m;
+        const int nl = pt ? lane + 1 : lane - 1;
+        int nM = (nl < 0 || nl > 63) ? LC_BNEG : M1[nl];
+        int nXY = (nl < 0 || nl > 63) ? LC_BNEG : (pt ? X1[nl] : Y1[nl]);
+        int uM = pt ? nM : M1[lane], uX = pt ? nXY : X1[lane];
+        int lM = pt ? M1[lane] : nM, lY = pt ? Y1[lane] : nXY;
+        int dM = M2[lane];
+        if (i == 1) { uM = -8 - j; uX = -8 - j; dM = (j == 1) ? 0 : -8 - (j - 1); }
+        if (j == 1) { lM = -8 - i; lY = -8 - i; if (i != 1) dM = -8 - (i - 1); }
+        int cM = LC_BNEG, cX = LC_BNEG, cY = LC_BNEG; uint8_t tb = 0;
+        if (valid) {
+          band_cell(i, j, (int)Sx[i - 1], (int)Tx[j - 1], dM, uM, uX, lM, lY, &cM, &cX, &cY, &tb);
+          W.tb[(size_t)t * 64 + (size_t)lane] = tb;
+          if (i == n && j == m) S.al_score = cM;
+        }
+        nM_[lane] = cM; nX_[lane] = cX; nY_[lane] = cY;
+      }
+      for (int l = 0; l < 64; ++l) { M2[l] = M1[l]; M1[l] = nM_[l]; X1[l] = nX_[l]; Y1[l] = nY_[l]; }
+    }
+  }
+#endif
+  WG_SYNC();
+  // ---- is the band enough?
+  const int score = wg_bcast(&S.al_score);
+  const int gh = hi + 1, gv_h = hi + 1 - d;                            // leave through the upper edge: >= gh columns skipped, >= gv_h rows to come back
+  const int gv = 1 - lo, gh_l = 1 - lo + d;                            // through the lower edge
+  const int out_hi = 2 * (m - gh) - (7 + gh) - (7 + gv_h);
+  const int out_lo = 2 * (n - gv) - (7 + gv) - (7 + gh_l);
+  const int bound = out_hi > out_lo ? out_hi : out_lo;
+  if (score == LC_BNEG || score <= bound) { WG_LANE0 { S.al_band = 0; } return false; }
+  return true;
+}
+
 // traceback into W.aln: returns alignment length; ref_aln at aln[0..L), path_aln at aln[cap..cap+L) (ASCII)
 DEVNI int align_traceback(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const uint8_t *Tx, int m) {
   LC_GLOBAL Work &W = *LC_CTX(c).W;
@@ -2995,7 +3100,20 @@ DEVNI int align_traceback(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL 
     if (used >= 8 || i != bi - used || j != bj - used) {
       bi = i; bj = j; used = 0;
       pre = 0;
-      for (int q = 0; q < 8; ++q) pre |= (unsigned long long)((i - q >= 0 && j - q >= 0) ? W.tb[LC_TB(i - q, j - q, n)] : (uint8_t)0) << (8 * q);
+      if (!LC_SREF(c).al_band) { for (int q = 0; q < 8; ++q) pre |= (unsigned long long)((i - q >= 0 && j - q >= 0) ? W.tb[LC_TB(i - q, j - q, n)] : (uint8_t)0) << (8 * q); }
+      else {
+        const int blo = LC_SREF(c).al_lo;
+        for (int q = 0; q < 8; ++q) {
+          const int ii = i - q, jj = j - q;
+          uint8_t bb = 0;
+          if (ii >= 0 && jj >= 0) {
+            if (ii == 0) bb = (uint8_t)((jj == 0 ? 3 : 2) | (0 << 2) | (2 << 4));        // the borders are not stored in the band layout
+            else if (jj == 0) bb = (uint8_t)(1 | (2 << 2) | (0 << 4));
+            else { const int tt = ii + jj, oo = jj - ii; bb = W.tb[(size_t)tt * 64 + (size_t)((oo - blo - ((tt - blo) & 1)) >> 1)]; }
+          }
+          pre |= (unsigned long long)bb << (8 * q);
+        }
+      }
     }
     uint8_t b = (uint8_t)(pre >> (8 * used)); ++used;
     int t = b & 3, x = (b >> 2) & 3, y = (b >> 4) & 3;
@@ -3433,7 +3551,7 @@ DEVNI void count_ref_path(Ctx &c) {
         LC_GLOBAL const uint8_t *rs = LC_CTX(c).B->ref_codes + LC_CTX(c).B->ref_off[S.w] + S.seq_t5;
         const int pl = (int)wg_bcastu(&S.part[5]);
         PHASE(c, 12);
-        align_fill(c, rs, S.seq_len, W.pseq, pl);
+        if (!align_fill_band(c, rs, S.seq_len, W.pseq, pl)) align_fill(c, rs, S.seq_len, W.pseq, pl);
         PHASE(c, 13);
         WG_LANE0 { S.part[7] = (uint32_t)align_traceback(c, rs, S.seq_len, W.pseq, pl); }
         WG_SYNC();

@@ -54,6 +54,7 @@ def lib():
         L.lancet_engine_kernel_name.argtypes = [C.c_int]
         L.lancet_engine_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
         L.lancet_debug_align.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        L.lancet_debug_align_mode.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
         L.lancet_engine_phase_times.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64))]
         L.lancet_filters_default.argtypes = [C.POINTER(abi.LancetFilters)]
         L.lancet_vdb_create.restype = C.c_void_p
@@ -201,12 +202,16 @@ class Engine:
         self._chk(self.L.lancet_engine_phase_times(self.h, C.byref(p)))
         return np.ctypeslib.as_array(p, shape=(self._batch.n_windows, 16)).astype(np.float64) * 1e-8
 
-    def debug_align(self, s: str, t: str):
-        """Test hook: the device global_align_aff on one pair of strings."""
+    def debug_align(self, s: str, t: str, mode: int = 0):
+        """Test hook: the device global_align_aff on one pair of strings.  mode 0: banded matrix with the full one as fall-back (what
+        the window kernel runs), 1: full matrix only, 2: band only -- returns None when the band could not be certified."""
         cap = len(s) + len(t) + 8
         a = C.create_string_buffer(cap)
         b = C.create_string_buffer(cap)
-        self._chk(self.L.lancet_debug_align(self.h, s.encode(), t.encode(), a, b, cap))
+        rc = self.L.lancet_debug_align_mode(self.h, s.encode(), t.encode(), a, b, cap, mode)
+        if rc == -6 and mode == 2:
+            return None
+        self._chk(rc)
         return a.value.decode(), b.value.decode()
 
     def close(self):

@@ -114,3 +114,27 @@ extern "C" int lancet_emu_find_tandems(const uint8_t *codes, int n, int pos, int
   bool a = local ? find_tandems_local(c, codes, n, pos, len, motif, motif_len) : find_tandems(c, codes, n, pos, len, motif, motif_len);
   return a ? 1 : 0;
 }
+
+// global_align_aff through the emulated kernels: mode 0 band with fall-back, 1 full matrix, 2 band only (returns -2 when not certified)
+extern "C" int lancet_emu_align(const char *Sa, const char *Ta, char *S_aln, char *T_aln, int cap, int mode) {
+  int n = (int)strlen(Sa), m = (int)strlen(Ta);
+  if (n < 1 || m < 1 || n > LC_MAXW) return -1;
+  EngineCaps caps; memset(&caps, 0, sizeof(caps));
+  caps.reads_cap = 4; caps.occ_cap = 64; caps.node_cap = 16; caps.table_cap = 32; caps.bucket_cap = 32; caps.special_cap = 4; caps.surv_cap = 4;
+  caps.seq_cap = 64; caps.queue_cap = 4; caps.path_cap = (uint32_t)m + 8; caps.max_k = 16; caps.qv_cap = 64;
+  size_t bytes = lc_work_carve(nullptr, nullptr, caps);
+  std::vector<char> mem(bytes + 256, 0);
+  Work w; lc_work_carve(&w, mem.data(), caps);
+  auto code = [](char b) -> uint8_t { switch (b) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; } return 4; };
+  std::vector<uint8_t> sc(n), tc(m);
+  for (int i = 0; i < n; ++i) sc[i] = code(Sa[i]);
+  for (int i = 0; i < m; ++i) tc[i] = code(Ta[i]);
+  static WinShared S; memset(&S, 0, sizeof(S));
+  Ctx c; c.P = nullptr; c.B = nullptr; c.C = &caps; c.W = &w; c.OUT = nullptr; c.S = &S;
+  if (mode == 1 || !align_fill_band(c, sc.data(), n, tc.data(), m)) { if (mode == 2) return -2; align_fill(c, sc.data(), n, tc.data(), m); }
+  int L = align_traceback(c, sc.data(), n, tc.data(), m);
+  if (S.overflow || L + 1 > cap) return -1;
+  const int acap = LC_MAXW + (int)caps.path_cap + 2;
+  memcpy(S_aln, w.aln, L); memcpy(T_aln, w.aln + acap, L); S_aln[L] = 0; T_aln[L] = 0;
+  return L;
+}

@@ -211,3 +211,59 @@ def test_find_tandems_local_equals_whole_string_scan_and_oracle():
                     assert (a, ln if a else 0, mo[:60]) == (full[0], full[1] if full[0] else 0, full[2]), (text, pos, opt, (a, ln, mo), full)
                 checked += 1
     assert checked > 2000
+
+
+def test_banded_alignment_equals_full_matrix_and_oracle():
+    """global_align_aff (reference src/align.cc:235-364) over a band of 128 diagonals, when the band certifies itself, must give the
+    aligned strings of the full matrix (and of the oracle, which test_oracle_golden pins on the reference's own align.cc); pairs the
+    band cannot hold must be refused (the full matrix then runs)."""
+    import ctypes
+    import numpy as np
+    L = emu.lib()
+    f = L.lancet_emu_align
+    f.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    f.restype = ctypes.c_int
+    rng = np.random.default_rng(23)
+
+    def rs(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, size=n))
+
+    def run(s, t, mode):
+        cap = len(s) + len(t) + 8
+        a, b = ctypes.create_string_buffer(cap), ctypes.create_string_buffer(cap)
+        r = f(s.encode(), t.encode(), a, b, cap, mode)
+        if r == -1:
+            return "undefined"          # the traceback left the matrix: undefined behaviour in the reference (reported as an overflow by the engine)
+        return None if r == -2 else (a.value.decode(), b.value.decode())
+
+    n_band = n_refused = 0
+    for it in range(160):
+        n = int(rng.integers(2, 640))
+        s = rs(n)
+        t = list(s)
+        for _ in range(int(rng.integers(0, 7))):
+            p = int(rng.integers(0, max(1, len(t))))
+            r = rng.random()
+            if r < 0.3 and t:
+                t[p] = "ACGT"[int(rng.integers(0, 4))]
+            elif r < 0.6:
+                t[p:p] = list(rs(int(rng.integers(1, 90))))
+            elif r < 0.9 and t:
+                del t[p:p + int(rng.integers(1, 90))]
+            elif t:                                           # tandem duplication / STR: many equally good alignments
+                u = t[max(0, p - 6):p] or ["A"]
+                t[p:p] = u * int(rng.integers(1, 6))
+        t = "".join(t) or "A"
+        if it % 9 == 0:
+            t = rs(int(rng.integers(2, 640)))                  # unrelated strings: the band must not certify a wrong answer
+        full = run(s, t, 1)
+        band = run(s, t, 2)
+        if full != "undefined":
+            assert full == oracle.align(s, t), (s, t)
+        if band is None:
+            n_refused += 1
+        else:
+            n_band += 1
+            assert band == full, (s, t, band, full)
+        assert run(s, t, 0) == full
+    assert n_band > 60 and n_refused > 5, (n_band, n_refused)

@@ -82,6 +82,7 @@ def test_device_alignment_equals_reference_align_cc():
     the reference's own align.cc (oracle/_ref)."""
     rng = np.random.default_rng(11)
     eng = engine.Engine()
+    n_band = 0
     for it in range(40):
         n = int(rng.integers(30, 600))
         s = _rand_seq(rng, n)
@@ -96,7 +97,13 @@ def test_device_alignment_equals_reference_align_cc():
             elif t:
                 del t[p:p + int(rng.integers(1, 60))]
         t = "".join(t) or "A"
-        assert eng.debug_align(s, t) == oracle.align(s, t), (s, t)
+        want = oracle.align(s, t)
+        assert eng.debug_align(s, t) == want, (s, t)                     # band of 128 diagonals, full matrix when it cannot certify itself
+        assert eng.debug_align(s, t, mode=1) == want, (s, t)             # the full matrix alone
+        band = eng.debug_align(s, t, mode=2)                             # the band alone: either refuses or is right
+        assert band is None or band == want, (s, t)
+        n_band += band is not None
+    assert n_band >= 20
     eng.close()
 
 
