@@ -92,7 +92,8 @@ __global__ void __launch_bounds__(LANCET_WG * 2) align_test_kernel(const EngineC
     if (mode == 2) { WG_LANE0 { *out_len = -2; } return; }                                                          // mode 2: the band only (-2: not certified)
     align_fill(c, (LC_GLOBAL const uint8_t *)Sx, n, (LC_GLOBAL const uint8_t *)Tx, m);
   }
-  WG_LANE0 { int L = align_traceback(c, (LC_GLOBAL const uint8_t *)Sx, n, (LC_GLOBAL const uint8_t *)Tx, m); *out_len = S.overflow ? -1 : L; }
+  WG_LANE0 { int L = align_traceback(c, (LC_GLOBAL const uint8_t *)Sx, n, (LC_GLOBAL const uint8_t *)Tx, m); S.tmp0 = L; *out_len = S.overflow ? -1 : L; }
+  align_traceback_fill(c, (LC_GLOBAL const uint8_t *)Sx, (LC_GLOBAL const uint8_t *)Tx, wg_bcast(&S.tmp0));
 }
 
 __global__ void ref_code_kernel(const char *ref, uint8_t *codes, uint32_t n) {

@@ -3086,10 +3086,14 @@ DEVNI bool align_fill_band(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL
 }
 
 // traceback into W.aln: returns alignment length; ref_aln at aln[0..L), path_aln at aln[cap..cap+L) (ASCII)
+// Lane 0 follows the traceback bytes and only NOTES every column (i << 16 | j << 2 | kind: 0 both characters, 1 reference character
+// against '-', 2 '-' against path character) in W.scratch; align_traceback_fill (all lanes) writes the two aligned strings from the
+// notes -- the walk itself then has no loads but the traceback bytes, eight cells of a diagonal at a time.
 DEVNI int align_traceback(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const uint8_t *Tx, int m) {
   LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int cap = LC_MAXW + (int)LC_CTX(c).C->path_cap + 2;
-  LC_GLOBAL uint8_t *ra = W.aln, *pa = W.aln + cap;
+  LC_GLOBAL uint32_t *cols = W.scratch;
+  (void)Sx; (void)Tx;
   int i = n, j = m, L = 0;
   bool forcex = false, forcey = false;
   unsigned long long pre = 0; int bi = -1, bj = -1, used = 8;
@@ -3118,14 +3122,27 @@ DEVNI int align_traceback(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL 
     uint8_t b = (uint8_t)(pre >> (8 * used)); ++used;
     int t = b & 3, x = (b >> 2) & 3, y = (b >> 4) & 3;
     if (t == 3) break;
-    else if (forcex) { if (i < 1) { OVF(c); return 0; } ra[L] = "ACGTN"[Sx[i - 1]]; pa[L] = '-'; ++L; if (x == 0) forcex = false; --i; }
-    else if (t == 1) { ra[L] = "ACGTN"[Sx[i - 1]]; pa[L] = '-'; ++L; if (x == 1) forcex = true; --i; }
-    else if (forcey) { if (j < 1) { OVF(c); return 0; } ra[L] = '-'; pa[L] = "ACGT"[Tx[j - 1]]; ++L; if (y == 0) forcey = false; --j; }
-    else if (t == 2) { ra[L] = '-'; pa[L] = "ACGT"[Tx[j - 1]]; ++L; if (y == 1) forcey = true; --j; }
-    else { ra[L] = "ACGTN"[Sx[i - 1]]; pa[L] = "ACGT"[Tx[j - 1]]; ++L; --i; --j; }
+    else if (forcex) { if (i < 1) { OVF(c); return 0; } cols[L++] = ((uint32_t)i << 16) | ((uint32_t)j << 2) | 1u; if (x == 0) forcex = false; --i; }
+    else if (t == 1) { cols[L++] = ((uint32_t)i << 16) | ((uint32_t)j << 2) | 1u; if (x == 1) forcex = true; --i; }
+    else if (forcey) { if (j < 1) { OVF(c); return 0; } cols[L++] = ((uint32_t)i << 16) | ((uint32_t)j << 2) | 2u; if (y == 0) forcey = false; --j; }
+    else if (t == 2) { cols[L++] = ((uint32_t)i << 16) | ((uint32_t)j << 2) | 2u; if (y == 1) forcey = true; --j; }
+    else { cols[L++] = ((uint32_t)i << 16) | ((uint32_t)j << 2); --i; --j; }
   }
-  for (int a = 0, b2 = L - 1; a < b2; ++a, --b2) { uint8_t t1 = ra[a]; ra[a] = ra[b2]; ra[b2] = t1; uint8_t t2 = pa[a]; pa[a] = pa[b2]; pa[b2] = t2; }
   return L;
+}
+// all lanes: the aligned strings from the noted columns (noted from the end of the alignment backwards)
+DEVNI void align_traceback_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, LC_GLOBAL const uint8_t *Tx, int L) {
+  LC_GLOBAL Work &W = *LC_CTX(c).W;
+  const int cap = LC_MAXW + (int)LC_CTX(c).C->path_cap + 2;
+  LC_GLOBAL uint8_t *ra = W.aln, *pa = W.aln + cap;
+  LC_GLOBAL const uint32_t *cols = W.scratch;
+  WG_FOR(x, L) {
+    const uint32_t v = cols[L - 1 - x];
+    const int i = (int)(v >> 16), j = (int)((v >> 2) & 0x3FFFu), kind = (int)(v & 3u);
+    ra[x] = kind == 2 ? (uint8_t)'-' : (uint8_t)"ACGTN"[Sx[i - 1]];
+    pa[x] = kind == 1 ? (uint8_t)'-' : (uint8_t)"ACGT"[Tx[j - 1]];
+  }
+  WG_SYNC();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -3555,6 +3572,7 @@ DEVNI void count_ref_path(Ctx &c) {
         PHASE(c, 13);
         WG_LANE0 { S.part[7] = (uint32_t)align_traceback(c, rs, S.seq_len, W.pseq, pl); }
         WG_SYNC();
+        align_traceback_fill(c, rs, W.pseq, (int)wg_bcastu(&S.part[7]));
       }
       PHASE(c, 14);
       walk_prepare(c, (int)wg_bcastu(&S.part[7]));

@@ -134,6 +134,7 @@ extern "C" int lancet_emu_align(const char *Sa, const char *Ta, char *S_aln, cha
   if (mode == 1 || !align_fill_band(c, sc.data(), n, tc.data(), m)) { if (mode == 2) return -2; align_fill(c, sc.data(), n, tc.data(), m); }
   int L = align_traceback(c, sc.data(), n, tc.data(), m);
   if (S.overflow || L + 1 > cap) return -1;
+  align_traceback_fill(c, sc.data(), tc.data(), L);
   const int acap = LC_MAXW + (int)caps.path_cap + 2;
   memcpy(S_aln, w.aln, L); memcpy(T_aln, w.aln + acap, L); S_aln[L] = 0; T_aln[L] = 0;
   return L;
