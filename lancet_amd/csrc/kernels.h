@@ -1880,29 +1880,83 @@ DEV uint32_t cmp_link(const Ctx &c, uint32_t n, char dir, bool *irregular) {
   if (ED_TO(LC_CTX(c).W->gr[b].edges[buid]) != n) { *irregular = true; return 0u; }
   return CL_VALID | (edir << 28) | b;
 }
+// First half of a node record (flags, degree, component, colour, the 12 edge words) in registers: the link tests of compress_prepare
+// look at a node's and its neighbours' edges a dozen times each; field by field that was ~100 dependent (L1-hit) loads per node.
+// The loops run over all 12 slots with a predicate, so that the edge words stay in registers (an array indexed at run time would
+// live in scratch memory).
+struct GrLine0 { uint32_t flags, necnt; int comp; uint32_t color; uint32_t e0, e1, e2, e3, e4, e5, e6, e7, e8, e9, e10, e11; };
+DEV GrLine0 gr_line0(LC_GLOBAL const NodeGr *g) {
+  LC_GLOBAL const uint32_t *p = (LC_GLOBAL const uint32_t *)g;
+  const lc_u4 a = ldg4(p), b = ldg4(p + 4), c = ldg4(p + 8), d = ldg4(p + 12);
+  GrLine0 r; r.flags = a.x; r.necnt = a.y; r.comp = (int)a.z; r.color = a.w;
+  r.e0 = b.x; r.e1 = b.y; r.e2 = b.z; r.e3 = b.w; r.e4 = c.x; r.e5 = c.y; r.e6 = c.z; r.e7 = c.w; r.e8 = d.x; r.e9 = d.y; r.e10 = d.z; r.e11 = d.w;
+  return r;
+}
+#define LC_L0_EACH(g, X) do { X(0, (g).e0); X(1, (g).e1); X(2, (g).e2); X(3, (g).e3); X(4, (g).e4); X(5, (g).e5); X(6, (g).e6); X(7, (g).e7); X(8, (g).e8); X(9, (g).e9); X(10, (g).e10); X(11, (g).e11); } while (0)
+// Node_t::getBuddy on the registers: the one edge in direction dir (LC_NIL: none, several, a special node, or a self loop)
+DEV uint32_t l0_buddy(const GrLine0 &g, uint32_t self, char dir) {
+  if (g.flags & NF_SPECIAL) return LC_NIL;
+  uint32_t ew = LC_NIL; int cnt = 0;
+#define LC_X(i, e) do { if ((uint32_t)(i) < g.necnt && is_dir(ED_DIR(e), dir)) { ew = (e); ++cnt; } } while (0)
+  LC_L0_EACH(g, LC_X);
+#undef LC_X
+  if (cnt != 1 || ED_TO(ew) == self) return LC_NIL;
+  return ew;
+}
+DEV bool l0_tandem(const GrLine0 &g, uint32_t self) {
+  bool t = false;
+#define LC_X(i, e) do { if ((uint32_t)(i) < g.necnt && ED_TO(e) == self) t = true; } while (0)
+  LC_L0_EACH(g, LC_X);
+#undef LC_X
+  return t;
+}
 DEVNI void compress_prepare(Ctx &c, int comp) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
-  const int K = S.K;
+  const int K = S.K, QS = S.QS;
+  LC_GLOBAL NodeGr *gr = W.gr; LC_GLOBAL CmpRec *cmp = W.cmp; LC_GLOBAL uint32_t *todo = W.todo; LC_GLOBAL const uint32_t *seq = W.seq; LC_GLOBAL const uint16_t *qv = W.qv;
   WG_LANE0 { S.cmp_ok = 1; }
   WG_FOR(i, S.M) {
     const uint32_t n = W.order[i];
-    LC_GLOBAL CmpRec &r = W.cmp[n];
-    LC_GLOBAL const NodeGr &G = W.gr[n];
-    r.lnk[0] = 0; r.lnk[1] = 0;
-    W.todo[n] = 0;                                               // "absorbed" mark of compress_fast (todo[] is idle after the build)
-    if (G.comp != comp || (G.flags & (NF_DEAD | NF_SPECIAL))) continue;
+    // round trip 1: the node's own record
+    const GrLine0 G = gr_line0(&gr[n]);
+    LC_GLOBAL const uint32_t *g1 = (LC_GLOBAL const uint32_t *)&gr[n] + 16;
+    const lc_u4 h0 = ldg4(g1), h1 = ldg4(g1 + 4), h2 = ldg4(g1 + 8), h3 = ldg4(g1 + 12);      // cov[4] | mincov mincovqv seq_lo seq_hi | seq_clo seq_chi nkm nkmT | nqv onref kc[4]
+    lc_u4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
+    todo[n] = 0;                                                 // "absorbed" mark of compress_fast / compress_rank (todo[] is idle after the build)
+    if (G.comp != comp || (G.flags & (NF_DEAD | NF_SPECIAL))) { cmp[n].lnk[0] = 0; cmp[n].lnk[1] = 0; continue; }
+    const uint32_t seq_lo = h1.z, seq_hi = h1.w, nkm = h2.z, nkmT = h2.w, nqv = h3.x;
+    if ((int)(seq_hi - seq_lo) != K || nkm != 1 || nqv == LC_NIL) { cmp[n].lnk[0] = 0; cmp[n].lnk[1] = 0; S.cmp_ok = 0; continue; }
+    const bool tand = l0_tandem(G, n);
+    const uint32_t ewF = tand ? LC_NIL : l0_buddy(G, n, 'F'), ewR = tand ? LC_NIL : l0_buddy(G, n, 'R');
+    // round trip 2: the two neighbours' records, the first / last descriptor, their per-position quality counts
+    const uint32_t bF = ewF != LC_NIL ? ED_TO(ewF) : n, bR = ewR != LC_NIL ? ED_TO(ewR) : n;
+    const GrLine0 BF = gr_line0(&gr[bF]), BR = gr_line0(&gr[bR]);
+    const uint32_t d0 = seq[seq_lo], dK = seq[seq_lo + (uint32_t)(K - 1)];
+    LC_GLOBAL const uint16_t *q0p = qv + ((size_t)nqv * K + 0) * QS, *qKp = qv + ((size_t)nqv * K + (size_t)(K - 1)) * QS;
+    const int tq0 = (int)q0p[0] + (int)q0p[1] + (int)q0p[2] + (int)q0p[3], tqK = (int)qKp[0] + (int)qKp[1] + (int)qKp[2] + (int)qKp[3];
     bool irr = false;
-    if ((int)(G.seq_hi - G.seq_lo) != K || G.nkm != 1 || G.nqv == LC_NIL) irr = true;
-    else {
-      r.lnk[0] = cmp_link(c, n, 'F', &irr);
-      r.lnk[1] = cmp_link(c, n, 'R', &irr);
-      for (int q = 0; q < 4; ++q) r.cov[q] = G.cov[q];
-      r.flags = G.flags; r.nkmT = G.nkmT;
-      r.d0 = W.seq[G.seq_lo]; r.dK = W.seq[G.seq_lo + (uint32_t)(K - 1)];
-      int t, q0, qK;
-      desc_tot(c, r.d0, &t, &q0); desc_tot(c, r.dK, &t, &qK);
-      r.tot = t; r.tq0 = q0; r.tqK = qK;
+    uint32_t lnk[2] = {0u, 0u};
+    for (int sd = 0; sd < 2; ++sd) {
+      const uint32_t ew = sd == 0 ? ewF : ewR;
+      if (ew == LC_NIL) continue;
+      const uint32_t edir = ED_DIR(ew), bn = ED_TO(ew);
+      const GrLine0 &Bq = sd == 0 ? BF : BR;
+      if (l0_tandem(Bq, bn)) continue;
+      const char bdir = (edir == 0 || edir == 2) ? 'R' : 'F';
+      const uint32_t bew = l0_buddy(Bq, bn, bdir);
+      if (bew == LC_NIL) continue;
+      if (ED_TO(bew) != n) { irr = true; continue; }
+      lnk[sd] = CL_VALID | (edir << 28) | bn;
     }
+    // (the descriptors of a single k-mer node belong to the node itself: desc_tot's `tot` is the sum of its own four counts)
+    const int tot = (int)(h3.z & 0xFFFFu) + (int)(h3.z >> 16) + (int)(h3.w & 0xFFFFu) + (int)(h3.w >> 16);
+    lc_u4 r0, r1, r2;
+    r0.x = lnk[0]; r0.y = lnk[1]; r0.z = h0.x; r0.w = h0.y;                          // lnk[2], cov[0..1]
+    r1.x = h0.z; r1.y = h0.w; r1.z = G.flags; r1.w = nkmT;                           // cov[2..3], flags, nkmT
+    r2.x = d0; r2.y = dK; r2.z = (uint32_t)tot; r2.w = (uint32_t)tq0;                // d0 dK tot tq0
+    LC_GLOBAL uint32_t *rp = (LC_GLOBAL uint32_t *)&cmp[n];
+    stg4(rp, r0); stg4(rp + 4, r1); stg4(rp + 8, r2); rp[12] = (uint32_t)tqK;
+    (void)z; (void)h2;
     if (irr) S.cmp_ok = 0;
   }
   WG_SYNC();
@@ -2290,7 +2344,10 @@ DEVNI void remove_low_cov(Ctx &c, int comp) {                         // referen
   }
   evt(c, EV_LOWCOV, low);
   clean_dead(c);
-  compress(c, comp);
+  // Nothing removed: the component was compressed to the end just before (compress is idempotent, hasCycle in between changes
+  // nothing), so the reference's unconditional compress() has nothing to merge -- only its trace lines are owed.
+  if (low == 0) { evt(c, EV_COMPRESS); evt(c, EV_CLEANDEAD, 0); S.tmp2 = 0; }
+  else compress(c, comp);
   print_stats(c, comp);
 }
 
