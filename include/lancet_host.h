@@ -44,20 +44,35 @@ typedef struct lancet_host lancet_host;
 
 void lancet_host_opts_default(lancet_host_opts *o);
 
-/* Decodes both BAMs (whole files, coordinate order assumed as the reference does) and loads the FASTA.
- * NULL on failure with a message in err. */
+/* Opens the inputs: the FASTA (through its .fai when there is one, so only tiled stretches are read) and the two BAMs
+ * (existence only; their alignments are decoded by the tile calls).  NULL on failure with a message in err. */
 lancet_host *lancet_host_open(const char *tumor_bam, const char *normal_bam, const char *ref_fasta, char *err, size_t errlen);
 void lancet_host_close(lancet_host *h);
 const char *lancet_host_last_error(const lancet_host *h);
 
 /* SM of the first @RG line of the normal (which = 0) / tumor (which = 1) BAM, "NA" if there is none
- * (Microassembler::retriveSampleName, reference src/Microassembler.cc:52-67). */
+ * (Microassembler::retriveSampleName, reference src/Microassembler.cc:52-67).  Valid after a tile call. */
 const char *lancet_host_sample(const lancet_host *h, int which);
+/* checkPresenceOfMDtag (reference src/util.cc:416-427): 1 when the first alignment of the BAM carries MD (or the BAM has
+ * no alignment), else 0.  main() turns the active-region module off when neither BAM has it (src/Lancet.cc:817-825).
+ * Valid after a tile call. */
+int lancet_host_first_has_md(const lancet_host *h, int which);
 
-/* Tiles "chr:start-end" (or "chr") into windows and puts them in processing order.  Returns their number, < 0 on error. */
+/* Tiles "chr:start-end" (or "chr") into windows (loadRefs, reference src/Lancet.cc:189-316), puts them in processing
+ * order and decodes the alignments of both BAMs the windows can select: through the .bai linear index when
+ * <bam>.bai / <stem>.bai exists (one seek per tiled stretch), else by streaming the BGZF blocks once and stopping
+ * after the last stretch.  Memory: the kept alignments + one slab of blocks, never the whole file.
+ * Returns the number of windows, < 0 on error. */
 int lancet_host_tile(lancet_host *h, const char *region, const lancet_host_opts *o);
-const char *lancet_host_chrom(const lancet_host *h);
+/* The same for a BED file (--bed; loadBed, reference src/Lancet.cc:319-351 -- its intervals are padded twice, as there)
+ * and/or several regions; contigs may differ.  All windows go into ONE table ordered by header string, as in the
+ * reference's main() (src/Lancet.cc:852-857); chr_id of the batches indexes lancet_host_chroms(). */
+int lancet_host_tile_regions(lancet_host *h, const char *bed_path, const char *const *regions, int n_regions, const lancet_host_opts *o);
+const char *lancet_host_chrom(const lancet_host *h);                        /* first contig of the tiling */
+const char *const *lancet_host_chroms(const lancet_host *h, int *n);        /* all of them, indexed by chr_id */
 const char *lancet_host_window_hdr(const lancet_host *h, int w);            /* "chr:start-end" of tiled window w */
+int lancet_host_window_chrom(const lancet_host *h, int w);                  /* its chr_id */
+int lancet_host_window_span(const lancet_host *h, int w, int32_t *start, int32_t *end);
 
 /* Windows [w_begin, w_end) of the tiling through the per-window filters and read selection.  `out` points into
  * arrays owned by h; kept[i] = tiled index of batch window i (kept has room for w_end - w_begin entries). */

@@ -98,7 +98,8 @@ def read_bam(path: str) -> Tuple[dict, List[SamRead]]:
         sb = buf[q:q + nb]; q += nb
         seq = "".join(_SEQ2[b] for b in sb)[:l_seq]
         qb = buf[q:q + l_seq]; q += l_seq
-        qual = "*" if (l_seq and qb[0] == 0xFF) else bytes(c + 33 for c in qb).decode()
+        # unstored qualities (0xFF): bamtools fills (char)0xFF, a negative char below every threshold; NUL bytes here
+        qual = "\0" * l_seq if (l_seq and qb[0] == 0xFF) else bytes(c + 33 for c in qb).decode()
         tags = _tags(buf, q, end)
         reads.append(SamRead(qname, flag, refs[ref_id][0] if ref_id >= 0 else "*", pos + 1, mapq, cigar, seq, qual, tags))
         p = end

@@ -66,6 +66,8 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--verbose", "-v", action="store_true", help="print the reference's per-window stage trace to stderr")
     ap.add_argument("--device", type=int, default=0, help="GPU index (not a reference option)")
     ap.add_argument("--batch-windows", type=int, default=32768, help="windows per engine batch (not a reference option)")
+    ap.add_argument("--strict", action="store_true", help="write no VCF when a window exceeded the engine's work space (default: finish, "
+                    "list those windows on stderr, exit code 3; not a reference option)")
     return ap
 
 
@@ -111,6 +113,7 @@ def run(argv: Optional[List[str]] = None, out=None, date_line: Optional[str] = N
     ordered = frontend.windows_in_processing_order(windows)
     step = max(1, args.batch_windows)
     n_done = 0
+    overflowed: List[str] = []
     leak: list = []                       # reads a window without mapped reads leaves in the reference's graph (frontend.batch_from_sam)
     for lo in range(0, len(ordered), step):
         chunk = ordered[lo:lo + step]
@@ -121,8 +124,9 @@ def run(argv: Optional[List[str]] = None, out=None, date_line: Optional[str] = N
             continue
         _, stats = eng.process(batch)
         bad = [kept[w].hdr for w in range(batch.n_windows) if stats[w]["status"] < 0]
-        if bad:
-            raise SystemExit(f"work-space overflow in {len(bad)} window(s), e.g. {bad[0]}: results withheld (no approximate output)")
+        if bad and args.strict:
+            raise SystemExit(f"work-space overflow in {len(bad)} window(s), e.g. {bad[0]}: results withheld (--strict)")
+        overflowed += bad               # such a window contributes nothing (the engine drops its records); the run goes on
         vp, n, blob, _ = eng.raw_results()
         if args.linked_reads:
             lp, bp, _ = eng.raw_results_lr()
@@ -139,6 +143,10 @@ def run(argv: Optional[List[str]] = None, out=None, date_line: Optional[str] = N
                      sample_normal=sample_n, sample_tumor=sample_t))
     sys.stderr.write(f"[lancet_amd] {len(windows)} windows tiled, {n_done} assembled on GPU {args.device}, {db.size()} variants\n")
     eng.close()
+    if overflowed:
+        sys.stderr.write(f"[lancet_amd] {len(overflowed)} window(s) exceeded the engine's work space and contributed NO variants:\n"
+                         + "".join(f"[lancet_amd]   {h}\n" for h in overflowed))
+        return 3
     return 0
 
 

@@ -6,6 +6,7 @@
 //            :779-842 (processReads), src/util.cc:295-315 (isRepeat), :428-483 (parseMD), :167-187 (isAmbiguos).
 #include "../../include/lancet_host.h"
 
+#include <sys/types.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -37,6 +38,7 @@ struct Read {
   uint32_t seq_off, l_seq;    // into Sample::seq / qual (ASCII, phred+33)
   uint32_t name_off;          // into Sample::text (NUL terminated)
   uint32_t md_off, bx_off;    // into Sample::text (NUL terminated; bx "null" when absent)
+  int32_t chr;                // index into lancet_host::chroms
 };
 
 struct Sample {
@@ -47,33 +49,13 @@ struct Sample {
   std::string sample_name = "NA";
   std::vector<std::pair<std::string, int32_t>> refs;
   std::string path;
+  int first_has_md = 1;             // MD on the first alignment of the file
+  std::vector<std::pair<size_t, size_t>> span;   // per contig of the tiling: its reads [first, last) (file order = coordinate order)
 };
 
-struct Window { std::string hdr; int32_t start, end; std::string seq; };
+struct Window { std::string hdr; int32_t start, end; std::string seq; int chr; };
 struct Sel { uint32_t idx; uint8_t mate, strand, mapped; };
 struct RSel { uint8_t smp; Sel s; };   // a selected read: sample (1 tumor, 0 normal) + its per-window attributes
-
-}  // namespace
-
-struct lancet_host {
-  std::string err;
-  Sample smp[2];                    // 0 normal, 1 tumor
-  std::map<std::string, std::string> contigs;
-  std::vector<std::string> contig_order;
-  std::string chrom;
-  std::vector<Window> windows;      // processing order
-  std::vector<RSel> leak;           // reads of a window without a mapped read: the reference's processGraph returns before g.clear()
-                                    // (src/Microassembler.cc:83), so they are still in the graph when the next window is loaded
-  // last batch
-  std::vector<int32_t> b_chr, b_refstart;
-  std::vector<uint32_t> b_refoff, b_readbegin, b_seqoff, b_namerank, b_bxrank;
-  std::string b_ref, b_seq, b_qual;
-  std::vector<uint8_t> b_label, b_strand, b_mate, b_mapped, b_hp;
-  std::vector<std::string> bx_names;
-  std::vector<const char *> bx_ptrs;
-};
-
-namespace {
 
 bool read_file(const std::string &path, std::string *out, std::string *err) {
   FILE *f = fopen(path.c_str(), "rb");
@@ -89,84 +71,301 @@ bool read_file(const std::string &path, std::string *out, std::string *err) {
 
 unsigned host_threads(int items);
 
-// BGZF: a series of gzip members, each with the BC extra subfield holding the block size (SAM spec 4.1).  The block
-// table is read first; the blocks are independent deflate streams and are inflated on the host threads.
-bool bgzf_decompress(const std::string &raw, std::string *out, std::string *err) {
-  struct Blk { size_t cdata, clen, opos; unsigned isize; };
-  std::vector<Blk> blks;
-  size_t p = 0, total = 0;
-  while (p < raw.size()) {
-    if (p + 18 > raw.size() || (unsigned char)raw[p] != 31 || (unsigned char)raw[p + 1] != 139) { *err = "not a BGZF block"; return false; }
-    const unsigned char *h = (const unsigned char *)raw.data() + p;
-    const unsigned xlen = h[10] | (h[11] << 8);
-    unsigned bsize = 0; bool found = false;
-    for (unsigned q = 12; q + 4 <= 12 + xlen && p + q + 4 <= raw.size();) {
-      const unsigned slen = h[q + 2] | (h[q + 3] << 8);
-      if (h[q] == 'B' && h[q + 1] == 'C' && slen == 2) { bsize = (h[q + 4] | (h[q + 5] << 8)) + 1u; found = true; }
-      q += 4 + slen;
-    }
-    if (!found || p + bsize > raw.size() || bsize < 12 + xlen + 8) { *err = "truncated BGZF block"; return false; }
-    const unsigned isize = h[bsize - 4] | (h[bsize - 3] << 8) | (h[bsize - 2] << 16) | ((unsigned)h[bsize - 1] << 24);
-    blks.push_back(Blk{p + 12 + xlen, (size_t)bsize - 12 - xlen - 8, total, isize});
-    total += isize;
-    p += bsize;
-  }
-  out->resize(total);
-  std::atomic<size_t> next(0);
-  std::atomic<int> bad(0);
-  auto work = [&]() {
-    for (;;) {
-      const size_t i = next.fetch_add(1);
-      if (i >= blks.size()) break;
-      const Blk &b = blks[i];
-      if (b.isize == 0) continue;
-      z_stream zs; memset(&zs, 0, sizeof zs);
-      if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; continue; }
-      zs.next_in = (Bytef *)raw.data() + b.cdata; zs.avail_in = (uInt)b.clen;
-      zs.next_out = (Bytef *)&(*out)[b.opos]; zs.avail_out = b.isize;
-      const int rc = inflate(&zs, Z_FINISH);
-      if (rc != Z_STREAM_END || zs.total_out != b.isize) bad = 1;
-      inflateEnd(&zs);
-    }
-  };
-  const unsigned nt = host_threads((int)(blks.size() / 8 + 1));
-  std::vector<std::thread> th;
-  for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
-  work();
-  for (auto &t : th) t.join();
-  if (bad) { *err = "corrupt BGZF block"; return false; }
-  return true;
-}
-
 inline int32_t rd_i32(const unsigned char *p) { int32_t v; memcpy(&v, p, 4); return v; }
 inline uint32_t rd_u32(const unsigned char *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 inline uint16_t rd_u16(const unsigned char *p) { uint16_t v; memcpy(&v, p, 2); return v; }
+inline uint64_t rd_u64(const unsigned char *p) { uint64_t v; memcpy(&v, p, 8); return v; }
 
-// Decodes the alignments of contig `chrom` that start in [lo0, hi0] (0-based) -- everything a window of the tiled
-// region can select -- in file order.
-bool load_bam(const std::string &path, const std::string &chrom, int32_t lo0, int32_t hi0, Sample *S, std::string *err) {
-  std::string raw, buf;
+// BGZF (SAM spec 4.1): a series of gzip members, each with the BC extra subfield holding the block size.  The file is
+// read in slabs of whole blocks from a compressed offset onwards; the blocks of a slab are independent deflate streams
+// and are inflated on the host threads.  Memory in flight is one slab, whatever the size of the file.
+class BgzfReader {
+ public:
+  ~BgzfReader() { if (f_) fclose(f_); }
+  bool open(const std::string &path, std::string *err) {
+    f_ = fopen(path.c_str(), "rb");
+    if (!f_) { *err = "cannot open " + path; return false; }
+    return true;
+  }
+  // continue at a BAM virtual offset (compressed offset << 16 | offset inside the inflated block)
+  bool seek(uint64_t voff, std::string *err) {
+    coff_ = voff >> 16; ubuf_.clear(); upos_ = 0; eof_ = false; slab_ = slab_max() < (1u << 20) ? slab_max() : (1u << 20);
+    const size_t in_block = (size_t)(voff & 0xFFFFu);
+    if (in_block == 0) return true;
+    if (!fill(err)) { if (err->empty()) *err = "index points past the end of the file"; return false; }
+    if (in_block > ubuf_.size()) { *err = "index points outside a BGZF block"; return false; }
+    upos_ = in_block;
+    return true;
+  }
+  // at least n bytes at the cursor; false at the end of the file (err stays empty) or on an error (err set)
+  bool need(size_t n, std::string *err) {
+    while (ubuf_.size() - upos_ < n) if (!fill(err)) return false;
+    return true;
+  }
+  const unsigned char *cur() const { return (const unsigned char *)ubuf_.data() + upos_; }
+  void advance(size_t n) { upos_ += n; }
+  uint64_t compressed_pos() const { return coff_; }
+  uint64_t inflated_total() const { return inflated_; }
+
+ private:
+  bool fill(std::string *err) {
+    if (eof_) return false;
+    if (upos_ > 0) { ubuf_.erase(0, upos_); upos_ = 0; }
+    cbuf_.resize(slab_);
+    if (fseeko(f_, (off_t)coff_, SEEK_SET) != 0) { *err = "seek failed"; return false; }
+    const size_t got = fread(&cbuf_[0], 1, slab_, f_);
+    if (got == 0) { eof_ = true; return false; }
+    struct Blk { size_t cdata, clen, opos; unsigned isize; };
+    std::vector<Blk> blks;
+    size_t p = 0, total = 0;
+    const unsigned char *raw = (const unsigned char *)cbuf_.data();
+    while (p + 18 <= got) {
+      const unsigned char *h = raw + p;
+      if (h[0] != 31 || h[1] != 139) { *err = "not a BGZF block"; return false; }
+      const unsigned xlen = h[10] | (h[11] << 8);
+      unsigned bsize = 0; bool found = false;
+      for (unsigned q = 12; q + 4 <= 12 + xlen && p + q + 6 <= got;) {
+        const unsigned slen = h[q + 2] | (h[q + 3] << 8);
+        if (h[q] == 'B' && h[q + 1] == 'C' && slen == 2) { bsize = (h[q + 4] | (h[q + 5] << 8)) + 1u; found = true; }
+        q += 4 + slen;
+      }
+      if (!found) { if (p + 12 + xlen > got) break; *err = "not a BGZF block"; return false; }
+      if (bsize < 12 + xlen + 8) { *err = "truncated BGZF block"; return false; }
+      if (p + bsize > got) break;                       // the rest of this block is in the next slab
+      const unsigned isize = h[bsize - 4] | (h[bsize - 3] << 8) | (h[bsize - 2] << 16) | ((unsigned)h[bsize - 1] << 24);
+      if (isize > 65536u) { *err = "corrupt BGZF block"; return false; }
+      blks.push_back(Blk{p + 12 + xlen, (size_t)bsize - 12 - xlen - 8, total, isize});
+      total += isize;
+      p += bsize;
+    }
+    if (blks.empty()) { *err = "truncated BGZF block"; return false; }   // fewer bytes than one block: the file ends inside a block
+    const size_t base = ubuf_.size();
+    ubuf_.resize(base + total);
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    auto work = [&]() {
+      for (;;) {
+        const size_t i = next.fetch_add(1);
+        if (i >= blks.size()) break;
+        const Blk &b = blks[i];
+        if (b.isize == 0) continue;
+        z_stream zs; memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; continue; }
+        zs.next_in = (Bytef *)raw + b.cdata; zs.avail_in = (uInt)b.clen;
+        zs.next_out = (Bytef *)&ubuf_[base + b.opos]; zs.avail_out = b.isize;
+        const int rc = inflate(&zs, Z_FINISH);
+        if (rc != Z_STREAM_END || zs.total_out != b.isize) bad = 1;
+        inflateEnd(&zs);
+      }
+    };
+    const unsigned nt = host_threads((int)(blks.size() / 8 + 1));
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (bad) { *err = "corrupt BGZF block"; return false; }
+    coff_ += p; inflated_ += total;
+    if (slab_ < slab_max()) slab_ *= 4;
+    return true;
+  }
+  // compressed bytes per read: grows from 256 KB to 16 MB; LANCET_HOST_SLAB_KB caps it (tests use it to make a small file span many slabs)
+  static size_t slab_max() { if (const char *e = getenv("LANCET_HOST_SLAB_KB")) { const long v = atol(e); if (v >= 64) return (size_t)v << 10; } return 16u << 20; }
+  FILE *f_ = nullptr;
+  uint64_t coff_ = 0, inflated_ = 0;
+  std::string cbuf_, ubuf_;
+  size_t upos_ = 0, slab_ = slab_max() < (1u << 18) ? slab_max() : (1u << 18);
+  bool eof_ = false;
+};
+
+// A .bai (SAM spec 5.2), reduced to what finding "the alignments that START at or after a position" needs.  Per reference
+// sequence: the linear index (for every 16 kb stretch the smallest virtual offset of an alignment overlapping it) when the
+// indexer wrote one (samtools does; `bamtools index` leaves it empty), the first chunk of every 16 kb leaf bin
+// (4681 + stretch: alignments that lie inside that stretch), and the first chunk of all.  Each gives a lower bound on the
+// file position of the first alignment starting at or after `lo`; the reader streams from there and skips what starts
+// before `lo`.  The bins' chunk lists are not needed because only alignment starts inside a range are wanted.
+struct RefIndex {
+  std::vector<uint64_t> linear;
+  std::unordered_map<uint32_t, uint64_t> leaf_first;
+  uint64_t first = 0;                                   // 0: no alignment on this reference sequence
+  uint64_t start_for(int32_t lo) const {
+    const size_t w = (size_t)(lo > 0 ? lo : 0) >> 14;
+    if (!linear.empty()) { for (size_t i = w; i < linear.size(); ++i) if (linear[i]) return linear[i]; return 0; }
+    for (size_t i = w; i-- > 0;) { auto it = leaf_first.find(4681u + (uint32_t)i); if (it != leaf_first.end()) return it->second; }   // a leaf before lo's: its alignments start earlier
+    return first;
+  }
+};
+bool load_bai(const std::string &bam, std::vector<RefIndex> *idx) {
+  std::string raw, err;
+  std::string cand[2] = {bam + ".bai", std::string()};
+  if (bam.size() > 4 && bam.compare(bam.size() - 4, 4, ".bam") == 0) cand[1] = bam.substr(0, bam.size() - 4) + ".bai";
+  bool got = false;
+  for (const std::string &c : cand) if (!got && !c.empty()) { FILE *f = fopen(c.c_str(), "rb"); if (f) { fclose(f); got = read_file(c, &raw, &err); } }
+  if (!got || raw.size() < 8 || memcmp(raw.data(), "BAI\1", 4) != 0) return false;
+  const unsigned char *b = (const unsigned char *)raw.data();
+  const size_t n = raw.size();
+  size_t p = 4;
+  const int32_t n_ref = rd_i32(b + p); p += 4;
+  if (n_ref < 0 || (size_t)n_ref > n) return false;
+  idx->assign((size_t)n_ref, RefIndex());
+  for (int32_t r = 0; r < n_ref; ++r) {
+    RefIndex &R = (*idx)[(size_t)r];
+    if (p + 4 > n) return false;
+    const int32_t n_bin = rd_i32(b + p); p += 4;
+    for (int32_t i = 0; i < n_bin; ++i) {
+      if (p + 8 > n) return false;
+      const uint32_t bin = rd_u32(b + p);
+      const int32_t n_chunk = rd_i32(b + p + 4); p += 8;
+      if (n_chunk < 0 || p + 16 * (size_t)n_chunk > n) return false;
+      if (bin < 37450u) for (int32_t c = 0; c < n_chunk; ++c) {          // (37450: samtools' metadata pseudo-bin)
+        const uint64_t beg = rd_u64(b + p + 16 * (size_t)c);
+        if (R.first == 0 || beg < R.first) R.first = beg;
+        if (bin >= 4681u) { auto it = R.leaf_first.find(bin); if (it == R.leaf_first.end()) R.leaf_first.emplace(bin, beg); else if (beg < it->second) it->second = beg; }
+      }
+      p += 16 * (size_t)n_chunk;
+    }
+    if (p + 4 > n) return false;
+    const int32_t n_intv = rd_i32(b + p); p += 4;
+    if (n_intv < 0 || p + 8 * (size_t)n_intv > n) return false;
+    R.linear.resize((size_t)n_intv);
+    for (int32_t i = 0; i < n_intv; ++i) R.linear[(size_t)i] = rd_u64(b + p + 8 * (size_t)i);
+    p += 8 * (size_t)n_intv;
+  }
+  return true;
+}
+
+// One alignment record (the block after block_size; SAM spec 4.2) -> Sample arrays.  Every length in the record is
+// checked against the record's end before it is used.
+bool decode_record(const unsigned char *b, size_t bs, int chr, Sample *S, std::string *err) {
+  static const char SEQ[] = "=ACMGRSVTWYHKDBN";
+  const size_t end = bs;
+  const int32_t pos = rd_i32(b + 4);
+  const unsigned l_name = b[8], mapq = b[9];
+  const unsigned n_cig = rd_u16(b + 12), flag = rd_u16(b + 14);
+  const int32_t l_seq = rd_i32(b + 16);
+  if (l_seq < 0 || 32 + (size_t)l_name + 4 * (size_t)n_cig + (size_t)((l_seq + 1) / 2) + (size_t)l_seq > end) { *err = "alignment record with fields past its end"; return false; }
+  Read r; memset(&r, 0, sizeof r);
+  r.pos0 = pos; r.flag = (uint16_t)flag; r.mapq = (uint8_t)mapq; r.as = -1.f; r.xs = -1.f; r.chr = chr;
+  size_t q = 32;
+  r.name_off = (uint32_t)S->text.size(); S->text.append((const char *)b + q, l_name ? strnlen((const char *)b + q, l_name - 1) : 0); S->text.push_back('\0'); q += l_name;
+  r.cig_off = (uint32_t)S->cigar.size(); r.n_cig = n_cig;
+  int32_t rl = 0;
+  for (unsigned i = 0; i < n_cig; ++i) {
+    const uint32_t c = rd_u32(b + q + 4 * i); S->cigar.push_back(c);
+    const unsigned op = c & 15u;                      // MIDNSHP=X
+    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += (int32_t)(c >> 4);
+  }
+  r.ref_len = rl; q += 4 * (size_t)n_cig;
+  r.seq_off = (uint32_t)S->seq.size(); r.l_seq = (uint32_t)l_seq;
+  {
+    const size_t o0 = S->seq.size();
+    S->seq.resize(o0 + (size_t)l_seq); S->qual.resize(o0 + (size_t)l_seq);
+    char *sp = &S->seq[0] + o0, *qp = &S->qual[0] + o0;
+    for (int32_t i = 0; i + 1 < l_seq; i += 2) { const unsigned v = b[q + (size_t)(i >> 1)]; sp[i] = SEQ[v >> 4]; sp[i + 1] = SEQ[v & 15u]; }
+    if (l_seq & 1) sp[l_seq - 1] = SEQ[b[q + (size_t)(l_seq >> 1)] >> 4];
+    q += (size_t)((l_seq + 1) / 2);
+    r.has_qual = (l_seq > 0 && b[q] != 0xFF) ? 1 : 0;
+    if (r.has_qual) for (int32_t i = 0; i < l_seq; ++i) qp[i] = (char)(b[q + (size_t)i] + 33);
+    else memset(qp, 0, (size_t)l_seq);       // unstored: bamtools fills (char)0xFF, negative = below every quality threshold; byte 0 is that for unsigned compares
+    q += (size_t)l_seq;
+  }
+  r.md_off = 0; r.bx_off = 0;
+  std::string bx = "null";
+  while (q + 3 <= end) {                              // tags
+    const char k0 = (char)b[q], k1 = (char)b[q + 1], t = (char)b[q + 2];
+    q += 3;
+    double num = 0; bool isnum = false; std::string sval; bool isstr = false;
+    size_t sz = 0;
+    switch (t) {
+      case 'A':   // bamtools' GetTag(tag, std::string&) on a one-character tag: strlen over the raw tag block, i.e. the character
+                  // and every byte after it up to the next NUL -- the bare character only when it is the record's last tag
+                  // (src/api/BamAlignment.cpp); extractReads compares that string with "R" (src/Microassembler.cc:549-559)
+        sval.assign((const char *)b + q, strnlen((const char *)b + q, end - q)); isstr = true; sz = 1; break;
+      case 'c': sz = 1; if (q + sz <= end) { num = (int8_t)b[q]; isnum = true; } break;
+      case 'C': sz = 1; if (q + sz <= end) { num = b[q]; isnum = true; } break;
+      case 's': sz = 2; if (q + sz <= end) { int16_t v; memcpy(&v, b + q, 2); num = v; isnum = true; } break;
+      case 'S': sz = 2; if (q + sz <= end) { num = rd_u16(b + q); isnum = true; } break;
+      case 'i': sz = 4; if (q + sz <= end) { num = rd_i32(b + q); isnum = true; } break;
+      case 'I': sz = 4; if (q + sz <= end) { num = rd_u32(b + q); isnum = true; } break;
+      case 'f': sz = 4; if (q + sz <= end) { float v; memcpy(&v, b + q, 4); num = v; isnum = true; } break;
+      case 'Z': case 'H': { const size_t l = strnlen((const char *)b + q, end - q); sval.assign((const char *)b + q, l); isstr = true; sz = l + 1; break; }
+      case 'B': {
+        if (q + 5 > end) { sz = 5; break; }
+        const char st = (char)b[q]; const int32_t cnt = rd_i32(b + q + 1);
+        const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+        if (cnt < 0) { *err = "BAM array tag with a negative count"; return false; }
+        sz = 5 + es * (size_t)cnt; break;
+      }
+      default: *err = "unknown BAM tag type"; return false;
+    }
+    if (q + sz > end && !(t == 'Z' || t == 'H')) { *err = "BAM tag past the end of its record"; return false; }
+    q += sz;
+    if (k0 == 'A' && k1 == 'S' && isnum) r.as = (float)num;
+    else if (k0 == 'X' && k1 == 'S' && isnum) r.xs = (float)num;
+    else if (k0 == 'X' && k1 == 'T' && isstr) r.xt_is_R = (sval == "R");
+    else if (k0 == 'X' && k1 == 'A' && isstr) r.has_xa = !sval.empty();
+    else if (k0 == 'M' && k1 == 'D' && isstr) { r.has_md = 1; r.md_off = (uint32_t)S->text.size(); S->text.append(sval); S->text.push_back('\0'); }
+    else if (k0 == 'B' && k1 == 'X' && isstr) { if (!sval.empty()) bx = sval; }
+    else if (k0 == 'H' && k1 == 'P' && isnum) r.hp = num > 0 ? (int32_t)num : 0;
+  }
+  r.bx_off = (uint32_t)S->text.size(); S->text.append(bx); S->text.push_back('\0');
+  S->reads.push_back(r);
+  S->starts.push_back(pos);
+  return true;
+}
+
+// true when the record carries an MD tag (checkPresenceOfMDtag, reference src/util.cc:416-427, looks at the first alignment)
+bool record_has_md(const unsigned char *b, size_t bs) {
+  const unsigned l_name = b[8]; const unsigned n_cig = rd_u16(b + 12); const int32_t l_seq = rd_i32(b + 16);
+  if (l_seq < 0) return false;
+  size_t q = 32 + (size_t)l_name + 4 * (size_t)n_cig + (size_t)((l_seq + 1) / 2) + (size_t)l_seq;
+  while (q + 3 <= bs) {
+    const char k0 = (char)b[q], k1 = (char)b[q + 1], t = (char)b[q + 2];
+    q += 3;
+    if (k0 == 'M' && k1 == 'D') return true;
+    size_t sz;
+    switch (t) {
+      case 'A': case 'c': case 'C': sz = 1; break;
+      case 's': case 'S': sz = 2; break;
+      case 'i': case 'I': case 'f': sz = 4; break;
+      case 'Z': case 'H': sz = strnlen((const char *)b + q, bs - q) + 1; break;
+      case 'B': { if (q + 5 > bs) return false; const char st = (char)b[q]; const int32_t cnt = rd_i32(b + q + 1); if (cnt < 0) return false;
+                  sz = 5 + ((st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4) * (size_t)cnt; break; }
+      default: return false;
+    }
+    q += sz;
+  }
+  return false;
+}
+
+// What the windows of a tiling can select from one contig: alignments that START in [lo, hi] (0-based), ranges sorted and disjoint.
+struct Want { std::string chrom; int chr; std::vector<std::pair<int32_t, int32_t>> iv; };
+
+// Decodes, in file order, the alignments the tiling can select.  With a .bai next to the BAM the reader jumps to each
+// range through the linear index; without one it streams the file once and stops after the last range.
+bool load_bam(const std::string &path, std::vector<Want> wants, Sample *S, std::string *err) {
   const bool timing = getenv("LANCET_HOST_TIMING") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
-  if (!read_file(path, &raw, err)) return false;
-  const double t1 = now();
-  if (!bgzf_decompress(raw, &buf, err)) { *err = path + ": " + *err; return false; }
-  const double t2 = now();
-  raw.clear(); raw.shrink_to_fit();
-  const unsigned char *b = (const unsigned char *)buf.data();
-  const size_t n = buf.size();
-  if (n < 12 || memcmp(b, "BAM\1", 4) != 0) { *err = path + ": not a BAM file"; return false; }
-  const int32_t l_text = rd_i32(b + 4);
-  std::string text((const char *)b + 8, strnlen((const char *)b + 8, (size_t)l_text));
-  size_t p = 8 + (size_t)l_text;
-  const int32_t n_ref = rd_i32(b + p); p += 4;
-  int32_t want = -1;
+  BgzfReader in;
+  if (!in.open(path, err)) return false;
+  auto fail = [&](const std::string &m) { *err = path + ": " + (err->empty() ? m : *err); return false; };
+  if (!in.need(12, err)) return fail("not a BAM file");
+  if (memcmp(in.cur(), "BAM\1", 4) != 0) { err->clear(); return fail("not a BAM file"); }
+  const int32_t l_text = rd_i32(in.cur() + 4);
+  if (l_text < 0 || !in.need(12 + (size_t)l_text, err)) { return fail("truncated BAM header"); }
+  std::string text((const char *)in.cur() + 8, strnlen((const char *)in.cur() + 8, (size_t)l_text));
+  const int32_t n_ref = rd_i32(in.cur() + 8 + (size_t)l_text);
+  in.advance(12 + (size_t)l_text);
+  if (n_ref < 0) return fail("truncated BAM header");
+  std::unordered_map<std::string, int32_t> tid_of;
   for (int32_t i = 0; i < n_ref; ++i) {
-    const int32_t ln = rd_i32(b + p); p += 4;
-    std::string name((const char *)b + p, (size_t)(ln > 0 ? ln - 1 : 0)); p += (size_t)ln;
-    const int32_t len = rd_i32(b + p); p += 4;
-    if (name == chrom) want = i;
+    if (!in.need(4, err)) return fail("truncated BAM header");
+    const int32_t ln = rd_i32(in.cur());
+    if (ln < 1 || ln > (1 << 20) || !in.need(8 + (size_t)ln, err)) return fail("truncated BAM header");
+    std::string name((const char *)in.cur() + 4, strnlen((const char *)in.cur() + 4, (size_t)ln - 1));
+    const int32_t len = rd_i32(in.cur() + 4 + (size_t)ln);
+    in.advance(8 + (size_t)ln);
+    tid_of.emplace(name, i);
     S->refs.emplace_back(name, len);
   }
   {   // SM of the first @RG line
@@ -185,103 +384,161 @@ bool load_bam(const std::string &path, const std::string &chrom, int32_t lo0, in
       q = e + 1;
     }
   }
-  static const char SEQ[] = "=ACMGRSVTWYHKDBN";
-  while (p + 4 <= n) {
-    const int32_t bs = rd_i32(b + p); p += 4;
-    const size_t end = p + (size_t)bs;
-    if (end > n || bs < 32) { *err = path + ": truncated alignment record"; return false; }
-    const int32_t ref_id = rd_i32(b + p), pos = rd_i32(b + p + 4);
-    const unsigned l_name = b[p + 8], mapq = b[p + 9];
-    const unsigned n_cig = rd_u16(b + p + 12), flag = rd_u16(b + p + 14);
-    const int32_t l_seq = rd_i32(b + p + 16);
-    if (ref_id != want || want < 0 || pos < lo0 || pos > hi0) { p = end; continue; }
-    Read r; memset(&r, 0, sizeof r);
-    r.pos0 = pos; r.flag = (uint16_t)flag; r.mapq = (uint8_t)mapq; r.as = -1.f; r.xs = -1.f;
-    size_t q = p + 32;
-    r.name_off = (uint32_t)S->text.size(); S->text.append((const char *)b + q, l_name ? l_name - 1 : 0); S->text.push_back('\0'); q += l_name;
-    r.cig_off = (uint32_t)S->cigar.size(); r.n_cig = n_cig;
-    int32_t rl = 0;
-    for (unsigned i = 0; i < n_cig; ++i) {
-      const uint32_t c = rd_u32(b + q + 4 * i); S->cigar.push_back(c);
-      const unsigned op = c & 15u;                      // MIDNSHP=X
-      if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += (int32_t)(c >> 4);
+  // the first alignment of the file: does it carry MD?  (no alignment at all counts as yes, as in the reference)
+  S->first_has_md = 1;
+  if (in.need(4, err)) {
+    const int32_t bs = rd_i32(in.cur());
+    if (bs < 32 || !in.need(4 + (size_t)bs, err)) return fail("truncated alignment record");
+    S->first_has_md = record_has_md(in.cur() + 4, (size_t)bs) ? 1 : 0;
+  } else if (!err->empty()) return fail("");
+  // ranges in file order: by reference id, then position
+  struct Rng { int32_t tid; int chr; int32_t lo, hi; };
+  std::vector<Rng> rngs;
+  size_t max_chr = 0;
+  for (const Want &w : wants) {
+    if ((size_t)w.chr + 1 > max_chr) max_chr = (size_t)w.chr + 1;
+    auto it = tid_of.find(w.chrom);
+    if (it == tid_of.end()) continue;                   // contig absent from this BAM: no reads (bamtools' SetRegion fails, the windows stay empty)
+    for (auto &iv : w.iv) rngs.push_back(Rng{it->second, w.chr, iv.first, iv.second});
+  }
+  std::sort(rngs.begin(), rngs.end(), [](const Rng &a, const Rng &b) { return a.tid != b.tid ? a.tid < b.tid : a.lo < b.lo; });
+  S->span.assign(max_chr, std::pair<size_t, size_t>(0, 0));
+  std::vector<RefIndex> index;
+  const bool indexed = load_bai(path, &index);
+  uint64_t seeks = 0;
+  int32_t prev_tid = 0, prev_pos = -1; bool have_prev = false;
+  bool at_end = false;
+  for (size_t ri = 0; ri < rngs.size() && !at_end; ++ri) {
+    const Rng &g = rngs[ri];
+    if (indexed && (size_t)g.tid < index.size()) {
+      const uint64_t voff = index[(size_t)g.tid].start_for(g.lo);
+      if (voff == 0) continue;                          // no alignment on this contig from lo onwards
+      if ((voff >> 16) > in.compressed_pos()) { if (!in.seek(voff, err)) return fail(""); ++seeks; have_prev = false; }
     }
-    r.ref_len = rl; q += 4 * (size_t)n_cig;
-    r.seq_off = (uint32_t)S->seq.size(); r.l_seq = (uint32_t)l_seq;
-    {
-      const size_t o0 = S->seq.size();
-      S->seq.resize(o0 + (size_t)l_seq); S->qual.resize(o0 + (size_t)l_seq);
-      char *sp = &S->seq[0] + o0, *qp = &S->qual[0] + o0;
-      for (int32_t i = 0; i + 1 < l_seq; i += 2) { const unsigned v = b[q + (size_t)(i >> 1)]; sp[i] = SEQ[v >> 4]; sp[i + 1] = SEQ[v & 15u]; }
-      if (l_seq & 1) sp[l_seq - 1] = SEQ[b[q + (size_t)(l_seq >> 1)] >> 4];
-      q += (size_t)((l_seq + 1) / 2);
-      r.has_qual = (l_seq > 0 && b[q] != 0xFF) ? 1 : 0;
-      if (r.has_qual) for (int32_t i = 0; i < l_seq; ++i) qp[i] = (char)(b[q + (size_t)i] + 33);
-      else memset(qp, '!', (size_t)l_seq);
-      q += (size_t)l_seq;
-    }
-    r.md_off = 0; r.bx_off = 0;
-    std::string bx = "null";
-    while (q + 3 <= end) {                              // tags
-      const char k0 = (char)b[q], k1 = (char)b[q + 1], t = (char)b[q + 2];
-      q += 3;
-      double num = 0; bool isnum = false; std::string sval; bool isstr = false;
-      switch (t) {
-        case 'A':   // bamtools' GetTag(tag, std::string&) on a one-character tag: strlen over the raw tag block, i.e. the character
-                    // and every byte after it up to the next NUL -- the bare character only when it is the record's last tag
-                    // (src/api/BamAlignment.cpp); extractReads compares that string with "R" (src/Microassembler.cc:549-559)
-          sval.assign((const char *)b + q, strnlen((const char *)b + q, end - q)); isstr = true; q += 1; break;
-        case 'c': num = (int8_t)b[q]; isnum = true; q += 1; break;
-        case 'C': num = b[q]; isnum = true; q += 1; break;
-        case 's': { int16_t v; memcpy(&v, b + q, 2); num = v; isnum = true; q += 2; break; }
-        case 'S': num = rd_u16(b + q); isnum = true; q += 2; break;
-        case 'i': num = rd_i32(b + q); isnum = true; q += 4; break;
-        case 'I': num = rd_u32(b + q); isnum = true; q += 4; break;
-        case 'f': { float v; memcpy(&v, b + q, 4); num = v; isnum = true; q += 4; break; }
-        case 'Z': case 'H': { const size_t l = strnlen((const char *)b + q, end - q); sval.assign((const char *)b + q, l); isstr = true; q += l + 1; break; }
-        case 'B': {
-          const char st = (char)b[q]; const int32_t cnt = rd_i32(b + q + 1);
-          const size_t sz = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
-          q += 5 + sz * (size_t)cnt; break;
-        }
-        default: *err = path + ": unknown BAM tag type"; return false;
+    const size_t first = S->reads.size();
+    for (;;) {
+      if (!in.need(4, err)) { if (!err->empty()) return fail(""); at_end = true; break; }
+      const int32_t bs = rd_i32(in.cur());
+      if (bs < 32) return fail("truncated alignment record");
+      if (!in.need(4 + (size_t)bs, err)) return fail("truncated alignment record");
+      const unsigned char *rec = in.cur() + 4;
+      const int32_t tid = rd_i32(rec), pos = rd_i32(rec + 4);
+      if (tid >= 0) {
+        if (have_prev && (tid < prev_tid || (tid == prev_tid && pos < prev_pos))) { err->clear(); return fail("not coordinate sorted"); }
+        prev_tid = tid; prev_pos = pos; have_prev = true;
       }
-      if (k0 == 'A' && k1 == 'S' && isnum) r.as = (float)num;
-      else if (k0 == 'X' && k1 == 'S' && isnum) r.xs = (float)num;
-      else if (k0 == 'X' && k1 == 'T' && isstr) r.xt_is_R = (sval == "R");
-      else if (k0 == 'X' && k1 == 'A' && isstr) r.has_xa = !sval.empty();
-      else if (k0 == 'M' && k1 == 'D' && isstr) { r.has_md = 1; r.md_off = (uint32_t)S->text.size(); S->text.append(sval); S->text.push_back('\0'); }
-      else if (k0 == 'B' && k1 == 'X' && isstr) { if (!sval.empty()) bx = sval; }
-      else if (k0 == 'H' && k1 == 'P' && isnum) r.hp = num > 0 ? (int32_t)num : 0;
+      if (tid < 0 || tid > g.tid || (tid == g.tid && pos > g.hi)) { if (tid < 0) at_end = true; break; }   // left for the next range
+      if (tid == g.tid && pos >= g.lo) { if (!decode_record(rec, (size_t)bs, g.chr, S, err)) return fail(""); }
+      in.advance(4 + (size_t)bs);
     }
-    r.bx_off = (uint32_t)S->text.size(); S->text.append(bx); S->text.push_back('\0');
-    S->reads.push_back(r);
-    S->starts.push_back(pos);
-    p = end;
+    std::pair<size_t, size_t> &sp = S->span[(size_t)g.chr];
+    if (S->reads.size() > first) { if (sp.second == sp.first) sp.first = first; sp.second = S->reads.size(); }
   }
   S->path = path;
-  if (timing) fprintf(stderr, "[lancet_host] %s: read %.3f s, inflate %.3f s (%zu MB), records %.3f s (%zu kept)\n", path.c_str(), t1 - t0, t2 - t1, buf.size() >> 20, now() - t2, S->reads.size());
+  if (timing) fprintf(stderr, "[lancet_host] %s: %s, %zu ranges, %llu seeks, %llu MB inflated, %zu alignments kept, %.3f s\n", path.c_str(),
+                      indexed ? "indexed (.bai)" : "no .bai: streamed from the start", rngs.size(), (unsigned long long)seeks,
+                      (unsigned long long)(in.inflated_total() >> 20), S->reads.size(), now() - t0);
   return true;
 }
 
-bool load_fasta(const std::string &path, lancet_host *h) {
-  std::string buf;
-  if (!read_file(path, &buf, &h->err)) return false;
-  std::string *cur = nullptr;
-  size_t p = 0;
-  while (p < buf.size()) {
-    size_t e = buf.find('\n', p); if (e == std::string::npos) e = buf.size();
-    size_t le = e; while (le > p && (buf[le - 1] == '\r' || buf[le - 1] == '\n')) --le;
-    if (le > p && buf[p] == '>') {
-      size_t w = p + 1; while (w < le && !isspace((unsigned char)buf[w])) ++w;
-      std::string name = buf.substr(p + 1, w - p - 1);
-      h->contig_order.push_back(name);
-      cur = &h->contigs[name]; cur->clear();
-    } else if (cur) cur->append(buf, p, le - p);
-    p = e + 1;
+// FASTA: through the .fai when there is one (only the tiled stretches are read), else the whole file once.
+struct FaiEnt { long len, off, linebases, linewidth; };
+struct Fasta {
+  std::string path;
+  bool have_fai = false, whole_loaded = false;
+  std::map<std::string, FaiEnt> fai;
+  std::map<std::string, std::string> whole;
+  bool open(const std::string &p, std::string *err) {
+    path = p;
+    std::string idx;
+    { FILE *f = fopen((p + ".fai").c_str(), "rb"); if (f) { fclose(f); std::string e2; have_fai = read_file(p + ".fai", &idx, &e2); } }
+    if (have_fai) {
+      size_t q = 0;
+      while (q < idx.size()) {
+        size_t e = idx.find('\n', q); if (e == std::string::npos) e = idx.size();
+        const std::string line = idx.substr(q, e - q);
+        q = e + 1;
+        if (line.empty()) continue;
+        std::vector<std::string> t; size_t a = 0;
+        while (a <= line.size()) { size_t b = line.find('\t', a); if (b == std::string::npos) b = line.size(); t.push_back(line.substr(a, b - a)); a = b + 1; }
+        if (t.size() < 5) { have_fai = false; fai.clear(); break; }
+        FaiEnt en{atol(t[1].c_str()), atol(t[2].c_str()), atol(t[3].c_str()), atol(t[4].c_str())};
+        if (en.linebases <= 0 || en.linewidth < en.linebases) { have_fai = false; fai.clear(); break; }
+        fai.emplace(t[0], en);
+      }
+      FILE *f = fopen(p.c_str(), "rb"); if (!f) { *err = "cannot open " + p; return false; } fclose(f);
+    }
+    if (!have_fai) return load_whole(err);
+    return true;
   }
-  return true;
-}
+  // the whole file, once: no .fai, or a contig the .fai does not list (an index older than the file)
+  bool load_whole(std::string *err) {
+    if (whole_loaded) return true;
+    {
+      std::string buf;
+      if (!read_file(path, &buf, err)) return false;
+      std::string *cur = nullptr;
+      size_t q = 0;
+      while (q < buf.size()) {
+        size_t e = buf.find('\n', q); if (e == std::string::npos) e = buf.size();
+        size_t le = e; while (le > q && (buf[le - 1] == '\r' || buf[le - 1] == '\n')) --le;
+        if (le > q && buf[q] == '>') {
+          size_t w = q + 1; while (w < le && !isspace((unsigned char)buf[w])) ++w;
+          cur = &whole[buf.substr(q + 1, w - q - 1)]; cur->clear();
+        } else if (cur) cur->append(buf, q, le - q);
+        q = e + 1;
+      }
+    }
+    whole_loaded = true;
+    return true;
+  }
+  long length(const std::string &name) {
+    if (have_fai) { auto it = fai.find(name); if (it != fai.end()) return it->second.len; std::string e; if (!load_whole(&e)) return -1; }
+    auto it = whole.find(name); return it == whole.end() ? -1 : (long)it->second.size();
+  }
+  // bases [sp, ep] (1-based, inclusive, already clipped to the contig)
+  bool fetch(const std::string &name, long sp, long ep, std::string *out, std::string *err) const {
+    out->clear();
+    if (ep < sp) return true;
+    if (!have_fai || fai.find(name) == fai.end()) { *out = whole.at(name).substr((size_t)(sp - 1), (size_t)(ep - sp + 1)); return true; }
+    const FaiEnt &en = fai.at(name);
+    const long p0 = sp - 1, p1 = ep - 1;
+    const long o0 = en.off + (p0 / en.linebases) * en.linewidth + p0 % en.linebases;
+    const long o1 = en.off + (p1 / en.linebases) * en.linewidth + p1 % en.linebases;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { *err = "cannot open " + path; return false; }
+    std::string raw((size_t)(o1 - o0 + 1), '\0');
+    const bool ok = fseeko(f, (off_t)o0, SEEK_SET) == 0 && fread(&raw[0], 1, raw.size(), f) == raw.size();
+    fclose(f);
+    if (!ok) { *err = path + ": short read (stale .fai?)"; return false; }
+    out->reserve((size_t)(ep - sp + 1));
+    for (char c : raw) if (c != '\n' && c != '\r') out->push_back(c);
+    if ((long)out->size() != ep - sp + 1) { *err = path + ": .fai does not match the file"; return false; }
+    return true;
+  }
+};
+
+}  // namespace
+
+struct lancet_host {
+  std::string err;
+  Sample smp[2];                    // 0 normal, 1 tumor
+  Fasta fa;
+  std::vector<std::string> chroms;     // contigs of the tiling, in order of first appearance (chr_id of the batches)
+  std::vector<const char *> chrom_ptrs;
+  std::vector<Window> windows;      // processing order
+  std::vector<RSel> leak;           // reads of a window without a mapped read: the reference's processGraph returns before g.clear()
+                                    // (src/Microassembler.cc:83), so they are still in the graph when the next window is loaded
+  // last batch
+  std::vector<int32_t> b_chr, b_refstart;
+  std::vector<uint32_t> b_refoff, b_readbegin, b_seqoff, b_namerank, b_bxrank;
+  std::string b_ref, b_seq, b_qual;
+  std::vector<uint8_t> b_label, b_strand, b_mate, b_mapped, b_hp;
+  std::vector<std::string> bx_names;
+  std::vector<const char *> bx_ptrs;
+};
+
+namespace {
 
 inline bool md_valid(char c) { return c != 0 && strchr("acgtumrwsykvhdbxnACGTUMRWSYKVHDBXN^", c) != nullptr; }
 
@@ -316,15 +573,17 @@ bool any_ge(const std::unordered_map<int, int> &m, int thr) { for (auto &kv : m)
 bool is_active_region(const Sample &S, const Window &win, bool normal, const lancet_host_opts &o) {
   const int mq = normal ? 0 : o.min_map_qual;
   std::unordered_map<int, int> mapX, mapI, mapD, mapSC;
-  size_t lo = (size_t)(std::lower_bound(S.starts.begin(), S.starts.end(), win.start) - S.starts.begin());
-  for (size_t i = lo; i < S.reads.size(); ++i) {
+  const std::pair<size_t, size_t> sp = (size_t)win.chr < S.span.size() ? S.span[(size_t)win.chr] : std::pair<size_t, size_t>(0, 0);
+  size_t lo = (size_t)(std::lower_bound(S.starts.begin() + (long)sp.first, S.starts.begin() + (long)sp.second, win.start) - S.starts.begin());
+  for (size_t i = lo; i < sp.second; ++i) {
     const Read &r = S.reads[i];
     const int alstart = r.pos0;
     if (alstart > win.end) break;
     const int alend = alstart + r.ref_len;
     if (alstart < win.start || alend > win.end) continue;
     if (!(r.mapq >= mq && !(r.flag & 0x400))) continue;
-    if (r.l_seq == 0 || !r.has_qual) continue;
+    if (r.l_seq == 0) continue;        // QueryBases / Qualities empty (:293); unstored qualities (0xFF) are NOT empty in bamtools:
+                                       // such reads still count with their CIGAR evidence, their MD mismatches never pass the quality test
     if (r.has_md) parse_md(S.text.c_str() + r.md_off, mapX, alstart, S.qual.data() + r.seq_off, (int)r.l_seq, o.min_qual_call);
     int pos = alstart, refpos = alstart;
     for (uint32_t c = 0; c < r.n_cig; ++c) {
@@ -347,8 +606,9 @@ bool extract_reads(const Sample &S, const Window &win, bool normal, const lancet
   if (normal) { mq = 0; min_delta = -1; }
   long totalbp = 0;
   const size_t rawlen = win.seq.size();
-  size_t lo = (size_t)(std::lower_bound(S.starts.begin(), S.starts.end(), win.start) - S.starts.begin());
-  for (size_t i = lo; i < S.reads.size(); ++i) {
+  const std::pair<size_t, size_t> sp = (size_t)win.chr < S.span.size() ? S.span[(size_t)win.chr] : std::pair<size_t, size_t>(0, 0);
+  size_t lo = (size_t)(std::lower_bound(S.starts.begin() + (long)sp.first, S.starts.begin() + (long)sp.second, win.start) - S.starts.begin());
+  for (size_t i = lo; i < sp.second; ++i) {
     const Read &r = S.reads[i];
     const int alstart = r.pos0;
     if (alstart > win.end) break;
@@ -400,7 +660,7 @@ void lancet_host_opts_default(lancet_host_opts *o) {
 lancet_host *lancet_host_open(const char *tumor_bam, const char *normal_bam, const char *ref_fasta, char *err, size_t errlen) {
   lancet_host *h = new lancet_host();
   h->smp[0].path = normal_bam ? normal_bam : ""; h->smp[1].path = tumor_bam ? tumor_bam : "";
-  bool ok = tumor_bam && normal_bam && ref_fasta && load_fasta(ref_fasta, h);
+  bool ok = tumor_bam && normal_bam && ref_fasta && h->fa.open(ref_fasta, &h->err);
   if (ok) for (int s = 0; s < 2 && ok; ++s) { FILE *f = fopen(h->smp[s].path.c_str(), "rb"); if (!f) { h->err = "cannot open " + h->smp[s].path; ok = false; } else fclose(f); }
   if (!ok) {
     if (h->err.empty()) h->err = "missing argument";
@@ -412,30 +672,45 @@ lancet_host *lancet_host_open(const char *tumor_bam, const char *normal_bam, con
 void lancet_host_close(lancet_host *h) { delete h; }
 const char *lancet_host_last_error(const lancet_host *h) { return h ? h->err.c_str() : "null host"; }
 const char *lancet_host_sample(const lancet_host *h, int which) { return h->smp[which ? 1 : 0].sample_name.c_str(); }
-const char *lancet_host_chrom(const lancet_host *h) { return h->chrom.c_str(); }
+const char *lancet_host_chrom(const lancet_host *h) { return h->chroms.empty() ? "" : h->chroms[0].c_str(); }
+const char *const *lancet_host_chroms(const lancet_host *h, int *n) { if (n) *n = (int)h->chrom_ptrs.size(); return h->chrom_ptrs.data(); }
+int lancet_host_first_has_md(const lancet_host *h, int which) { return h->smp[which ? 1 : 0].first_has_md; }
 const char *lancet_host_window_hdr(const lancet_host *h, int w) { return (w >= 0 && (size_t)w < h->windows.size()) ? h->windows[(size_t)w].hdr.c_str() : ""; }
+int lancet_host_window_chrom(const lancet_host *h, int w) { return (w >= 0 && (size_t)w < h->windows.size()) ? h->windows[(size_t)w].chr : -1; }
+int lancet_host_window_span(const lancet_host *h, int w, int32_t *start, int32_t *end) {
+  if (w < 0 || (size_t)w >= h->windows.size()) return LANCET_E_ARG;
+  if (start) *start = h->windows[(size_t)w].start;
+  if (end) *end = h->windows[(size_t)w].end;
+  return LANCET_OK;
+}
 
-// loadRefs (reference src/Lancet.cc:189-316): padding, clipping, windows of window_size every 100 bp, last window
-// LEN = len - offset - 1, upper case + IUPAC -> N; then the std::map<string, Ref_t*> order of processReads.
-int lancet_host_tile(lancet_host *h, const char *region, const lancet_host_opts *o) {
-  const std::string reg = region ? region : "";
+}  // extern "C"
+
+namespace {
+
+// loadRefs for one region (reference src/Lancet.cc:189-316): padding, clipping, windows of window_size every 100 bp, last
+// window LEN = len - offset - 1, upper case + IUPAC -> N.  Appends to h->windows and notes which alignment starts the
+// windows can select.
+int tile_one(lancet_host *h, const std::string &reg, const lancet_host_opts *o, std::map<std::string, std::vector<std::pair<int32_t, int32_t>>> *want) {
   const size_t x = reg.find(':');
-  h->chrom = reg.substr(0, x);
-  auto it = h->contigs.find(h->chrom);
-  if (it == h->contigs.end()) { h->err = "contig '" + h->chrom + "' not in the reference"; return LANCET_E_ARG; }
-  const std::string &contig = it->second;
-  long sp = 1, ep = (long)contig.size();
+  const std::string chrom = reg.substr(0, x);
+  const long clen = h->fa.length(chrom);
+  if (clen < 0) { h->err = "contig '" + chrom + "' not in the reference"; return LANCET_E_ARG; }
+  long sp = 1, ep = clen;
   if (x != std::string::npos) {
     const size_t y = reg.find('-', x);
     if (y == std::string::npos) { h->err = "region must be chr:start-end"; return LANCET_E_ARG; }
     sp = atol(reg.substr(x + 1, y - x - 1).c_str()) - o->padding;
     ep = atol(reg.substr(y + 1).c_str()) + o->padding;
     if (sp < 1) sp = 1;
-    if (ep > (long)contig.size()) ep = (long)contig.size();
+    if (ep > clen) ep = clen;
   }
-  std::string s = ep >= sp ? contig.substr((size_t)(sp - 1), (size_t)(ep - sp + 1)) : std::string();
+  std::string s;
+  if (!h->fa.fetch(chrom, sp, ep, &s, &h->err)) return LANCET_E_ARG;
   for (char &c : s) { c = (char)toupper((unsigned char)c); if (strchr("MRWSYKVHDBX", c)) c = 'N'; }
-  h->windows.clear(); h->leak.clear();
+  int chr = -1;
+  for (size_t i = 0; i < h->chroms.size(); ++i) if (h->chroms[i] == chrom) chr = (int)i;
+  if (chr < 0) { chr = (int)h->chroms.size(); h->chroms.push_back(chrom); }
   const long delta = 100, wsz = o->window_size;
   long end = (long)s.size(), offset = 0;
   while (offset < end) {
@@ -443,29 +718,89 @@ int lancet_host_tile(lancet_host *h, const char *region, const lancet_host_opts 
     if (offset + wsz >= (long)s.size()) { ln = (long)s.size() - offset - 1; end = offset; }
     Window w;
     w.seq = ln > 0 ? s.substr((size_t)offset, (size_t)ln) : std::string();
-    w.start = (int32_t)(sp + offset); w.end = (int32_t)(sp + offset + ln);
-    w.hdr = h->chrom + ":" + std::to_string(w.start) + "-" + std::to_string(w.end);
+    w.start = (int32_t)(sp + offset); w.end = (int32_t)(sp + offset + ln); w.chr = chr;
+    w.hdr = chrom + ":" + std::to_string(w.start) + "-" + std::to_string(w.end);
     h->windows.push_back(std::move(w));
     offset += delta;
   }
-  std::stable_sort(h->windows.begin(), h->windows.end(), [](const Window &a, const Window &b) { return a.hdr < b.hdr; });
   // the alignments a window can select start inside [sp, ep] (1-based window coordinates compared with 0-based
-  // alignment starts, as the reference does): decode just those
-  {
-    std::string errs[2]; bool ok[2] = {false, false};
-    auto load = [&](int smp) {
-      Sample &S = h->smp[smp];
-      const std::string path = S.path;
-      S = Sample(); S.path = path;
-      ok[smp] = load_bam(path, h->chrom, (int32_t)sp - 1, (int32_t)ep + 1, &S, &errs[smp]);
-      if (ok[smp] && !std::is_sorted(S.starts.begin(), S.starts.end())) { errs[smp] = path + ": not coordinate sorted"; ok[smp] = false; }
-    };
-    std::thread other(load, 0);                         // the two samples side by side
-    load(1);
-    other.join();
-    for (int smp = 0; smp < 2; ++smp) if (!ok[smp]) { h->err = errs[smp]; return LANCET_E_ARG; }
+  // alignment starts, as the reference does)
+  if (ep >= sp) (*want)[chrom].emplace_back((int32_t)sp - 1, (int32_t)ep + 1);
+  return LANCET_OK;
+}
+
+// processing order = iteration order of the reference's std::map<string, Ref_t*> keyed by the window header
+// (src/Microassembler.cc:779); a header tiled twice (overlapping BED lines) is kept once, like map::insert.  Then the
+// alignments of both samples are decoded for the union of the tiled stretches.
+int finish_tiling(lancet_host *h, std::map<std::string, std::vector<std::pair<int32_t, int32_t>>> &want) {
+  std::stable_sort(h->windows.begin(), h->windows.end(), [](const Window &a, const Window &b) { return a.hdr < b.hdr; });
+  h->windows.erase(std::unique(h->windows.begin(), h->windows.end(), [](const Window &a, const Window &b) { return a.hdr == b.hdr; }), h->windows.end());
+  h->chrom_ptrs.clear();
+  for (auto &c : h->chroms) h->chrom_ptrs.push_back(c.c_str());
+  std::vector<Want> wants;
+  for (auto &kv : want) {
+    Want w; w.chrom = kv.first; w.chr = 0;
+    for (size_t i = 0; i < h->chroms.size(); ++i) if (h->chroms[i] == kv.first) w.chr = (int)i;
+    std::sort(kv.second.begin(), kv.second.end());
+    for (auto &iv : kv.second) {
+      if (!w.iv.empty() && iv.first <= w.iv.back().second + 1) { if (iv.second > w.iv.back().second) w.iv.back().second = iv.second; }
+      else w.iv.push_back(iv);
+    }
+    wants.push_back(std::move(w));
   }
+  std::string errs[2]; bool ok[2] = {false, false};
+  auto load = [&](int smp) {
+    Sample &S = h->smp[smp];
+    const std::string path = S.path;
+    S = Sample(); S.path = path;
+    ok[smp] = load_bam(path, wants, &S, &errs[smp]);
+  };
+  std::thread other(load, 0);                         // the two samples side by side
+  load(1);
+  other.join();
+  for (int smp = 0; smp < 2; ++smp) if (!ok[smp]) { h->err = errs[smp]; return LANCET_E_ARG; }
   return (int)h->windows.size();
+}
+
+}  // namespace
+
+extern "C" {
+
+int lancet_host_tile(lancet_host *h, const char *region, const lancet_host_opts *o) {
+  const char *regs[1] = {region ? region : ""};
+  return lancet_host_tile_regions(h, nullptr, regs, 1, o);
+}
+
+// main() of the reference: loadBed first, then loadRefs on --reg, into one table (src/Lancet.cc:852-857).  loadBed hands
+// "chr:(start-PADDING)-(end+PADDING)" to loadRefs, which pads again (src/Lancet.cc:319-351, :233-249): a BED interval is
+// padded twice.  Lines starting with '#' are skipped; columns are tab separated.
+int lancet_host_tile_regions(lancet_host *h, const char *bed_path, const char *const *regions, int n_regions, const lancet_host_opts *o) {
+  if (!h || !o) return LANCET_E_ARG;
+  h->windows.clear(); h->leak.clear(); h->chroms.clear();
+  std::map<std::string, std::vector<std::pair<int32_t, int32_t>>> want;
+  if (bed_path && *bed_path) {
+    std::string bed;
+    if (!read_file(bed_path, &bed, &h->err)) return LANCET_E_ARG;
+    size_t q = 0; int line_no = 0;
+    while (q < bed.size()) {
+      size_t e = bed.find('\n', q); if (e == std::string::npos) e = bed.size();
+      std::string line = bed.substr(q, e - q);
+      q = e + 1; ++line_no;
+      if (!line.empty() && line.back() == '\r') line.pop_back();
+      if (!line.empty() && line[0] == '#') continue;
+      std::vector<std::string> t; size_t a = 0;
+      while (a <= line.size()) { size_t b = line.find('\t', a); if (b == std::string::npos) b = line.size(); t.push_back(line.substr(a, b - a)); a = b + 1; }
+      if (t.size() < 3 || t[1].empty() || t[2].empty() || !isdigit((unsigned char)t[1][0]) || !isdigit((unsigned char)t[2][0])) {
+        h->err = std::string(bed_path) + ": line " + std::to_string(line_no) + " is not chrom<TAB>start<TAB>end"; return LANCET_E_ARG; }   // (the reference's stoi throws here)
+      long sp = atol(t[1].c_str()) - o->padding, ep = atol(t[2].c_str()) + o->padding;
+      if (sp < 1) sp = 1;
+      const int rc = tile_one(h, t[0] + ":" + std::to_string(sp) + "-" + std::to_string(ep), o, &want);
+      if (rc != LANCET_OK) return rc;
+    }
+  }
+  for (int i = 0; i < n_regions; ++i) if (regions && regions[i] && *regions[i]) { const int rc = tile_one(h, regions[i], o, &want); if (rc != LANCET_OK) return rc; }
+  if (h->chroms.empty() && h->windows.empty() && !(bed_path && *bed_path)) { h->err = "no region given"; return LANCET_E_ARG; }
+  return finish_tiling(h, want);
 }
 
 int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o, lancet_window_batch *out,
@@ -484,7 +819,7 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
         const int i = next.fetch_add(1);
         if (i >= nwin) break;
         const Window &win = h->windows[(size_t)(w_begin + i)];
-        if (!win.seq.empty() && win.seq.find_first_not_of('N') == std::string::npos) continue;        // isNseq, :799
+        if (win.seq.empty()) continue;          // isNseq (:799, src/util.cc:259-273): its test `!= 'N' || != 'n'` holds for every character, so only an EMPTY window is "all N"
         if (is_repeat(win.seq, o->max_k)) continue;                                                   // :800
         if (o->active_region && !(is_active_region(h->smp[1], win, false, *o) || is_active_region(h->smp[0], win, true, *o))) continue;   // :817-820
         const bool okT = extract_reads(h->smp[1], win, false, *o, &selT[(size_t)i]);
@@ -546,7 +881,7 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
         if (k >= nk) break;
         const int i = kw[(size_t)k];
         const Window &win = h->windows[(size_t)(w_begin + i)];
-        h->b_refstart[(size_t)k] = win.start;
+        h->b_refstart[(size_t)k] = win.start; h->b_chr[(size_t)k] = win.chr;
         memcpy(&h->b_ref[h->b_refoff[(size_t)k]], win.seq.data(), win.seq.size());
         size_t r = h->b_readbegin[(size_t)k]; const size_t r0 = r; size_t bo = (size_t)base0[(size_t)k];
         names.clear();

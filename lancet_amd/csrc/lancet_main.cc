@@ -6,8 +6,9 @@
 // There is no CPU path: without a gfx950 device engine creation fails and the program stops with an error.
 // Beyond the reference's options: --device N | --devices a,b,... (one engine per entry; batches of --batch-windows windows
 // go to the engines in turn while the host prepares the next one; records reach the VariantDB in window order whatever
-// the number of engines).
-// Not offered: --bed, --rg-file, --kmer-recovery, --print-graph; --num-threads is accepted and ignored (windows are
+// the number of engines), --strict (no VCF at all when a window exceeded the engine's work space; by default the run
+// finishes, the windows are listed on stderr and the exit code is 3).
+// Not offered: --rg-file, --kmer-recovery, --print-graph; --num-threads is accepted and ignored (windows are
 // batched on the GPU); -v prints the reference's per-window stage trace to stderr.
 #include "../../include/lancet_host.h"
 
@@ -23,7 +24,7 @@
 namespace {
 struct Opt { const char *lng; char shrt; int has_arg; };
 const Opt OPTS[] = {
-  {"tumor", 't', 1}, {"normal", 'n', 1}, {"ref", 'r', 1}, {"reg", 'p', 1}, {"min-k", 'k', 1}, {"max-k", 'K', 1},
+  {"tumor", 't', 1}, {"normal", 'n', 1}, {"ref", 'r', 1}, {"reg", 'p', 1}, {"bed", 'B', 1}, {"min-k", 'k', 1}, {"max-k", 'K', 1},
   {"trim-lowqual", 'q', 1}, {"min-base-qual", 'C', 1}, {"quality-range", 'Q', 1}, {"min-map-qual", 'b', 1},
   {"max-as-xs-diff", 'Z', 1}, {"tip-len", 'l', 1}, {"cov-thr", 'c', 1}, {"cov-ratio", 'x', 1}, {"low-cov", 'd', 1},
   {"max-avg-cov", 'u', 1}, {"window-size", 'w', 1}, {"padding", 'P', 1}, {"dfs-limit", 'F', 1}, {"max-indel-len", 'T', 1},
@@ -32,16 +33,32 @@ const Opt OPTS[] = {
   {"min-coverage-normal", 'z', 1}, {"max-coverage-normal", 'j', 1}, {"min-phred-fisher", 's', 1},
   {"min-phred-fisher-str", 'E', 1}, {"min-strand-bias", 'f', 1}, {"max-unit-length", 'U', 1}, {"min-report-unit", 'N', 1},
   {"min-report-len", 'Y', 1}, {"dist-from-str", 'D', 1}, {"linked-reads", 'J', 0}, {"primary-alignment-only", 'I', 0},
-  {"XA-tag-filter", 'O', 0}, {"active-region-off", 'W', 0}, {"verbose", 'v', 0}, {"device", 0, 1}, {"devices", 0, 1}, {"batch-windows", 0, 1}, {"date-line", 0, 1},
+  {"XA-tag-filter", 'O', 0}, {"active-region-off", 'W', 0}, {"verbose", 'v', 0}, {"device", 0, 1}, {"devices", 0, 1}, {"batch-windows", 0, 1}, {"date-line", 0, 1}, {"strict", 0, 0}, {"help", 'h', 0},
 };
 int die(const std::string &m) { fprintf(stderr, "lancet_gpu: %s\n", m.c_str()); return 1; }
+void usage() {
+  fputs("Usage: lancet_gpu --tumor T.bam --normal N.bam --ref ref.fa (--reg chr:start-end | --bed regions.bed) [options] > out.vcf\n"
+        "The reference's options with the reference's defaults (lancet --help), except:\n"
+        "   --window-size, -w  <int>   : at most 640 bp (the engine's per-window tables; the reference default is 600)\n"
+        "   --max-k, -K        <int>   : at most 127; --min-k at least 3; --max-unit-length at most 8\n"
+        "   --num-threads, -X  <int>   : accepted and ignored (windows are batched on the GPU)\n"
+        "   --rg-file, --kmer-recovery, --print-graph, --node-str-len, --more-verbose, --print-config-file: not offered\n"
+        "Additional options:\n"
+        "   --device <n> | --devices a,b,...  : GPU(s) to use; an entry may repeat (two engines on one GPU overlap the upload of a\n"
+        "                                       batch with the kernels of the previous one)\n"
+        "   --batch-windows <n>               : windows per engine batch [32768]\n"
+        "   --strict                          : write no VCF when a window exceeded the engine's work space (default: finish,\n"
+        "                                       list those windows on stderr, exit code 3)\n"
+        "BAM input: <bam>.bai / <stem>.bai is used when present (one seek per tiled stretch); otherwise the BAM is streamed once.\n"
+        "There is no CPU path: a gfx950 device is required.\n", stderr);
+}
 }  // namespace
 
 int main(int argc, char **argv) {
-  std::string tumor, normal, ref, reg, qrange = "!", date_line, devices;
+  std::string tumor, normal, ref, reg, bed, qrange = "!", date_line, devices;
   int min_k = 11, max_k = 101, trim_lowqual = 10, min_base_qual = 17, tip_len = 11, cov_thr = 5, low_cov = 1, dfs_limit = 1000000;
   int max_indel_len = 500, max_mismatch = 2, max_unit_length = 4, min_report_unit = 3, min_report_len = 7, dist_from_str = 1;
-  int device = 0, batch_windows = 32768, verbose = 0;
+  int device = 0, batch_windows = 32768, verbose = 0, strict = 0;
   double cov_ratio = 0.01;
   lancet_host_opts ho; lancet_host_opts_default(&ho);
   lancet_filters flt; lancet_filters_default(&flt);
@@ -71,9 +88,10 @@ int main(int argc, char **argv) {
     else if (L == "min-report-unit") min_report_unit = atoi(v); else if (L == "min-report-len") min_report_len = atoi(v); else if (L == "dist-from-str") dist_from_str = atoi(v);
     else if (L == "linked-reads") ho.linked = 1; else if (L == "primary-alignment-only") ho.primary_alignment_only = 1; else if (L == "XA-tag-filter") ho.xa_filter = 1;
     else if (L == "active-region-off") ho.active_region = 0; else if (L == "verbose") verbose = 1; else if (L == "device") device = atoi(v); else if (L == "devices") devices = v; else if (L == "batch-windows") batch_windows = atoi(v);
-    else if (L == "date-line") date_line = v;
+    else if (L == "date-line") date_line = v; else if (L == "bed") bed = v; else if (L == "strict") strict = 1;
+    else if (L == "help") { usage(); return 0; }
   }
-  if (tumor.empty() || normal.empty() || ref.empty() || reg.empty()) return die("--tumor, --normal, --ref and --reg are required");
+  if (tumor.empty() || normal.empty() || ref.empty() || (reg.empty() && bed.empty())) { usage(); return die("--tumor, --normal, --ref and a region (--reg) or BED file (--bed) are required"); }
   const int qoff = qrange.empty() ? 33 : (unsigned char)qrange[0];
   lancet_params P; lancet_params_default(&P);
   P.min_k = min_k; P.max_k = max_k; P.max_tip_len = tip_len; P.cov_threshold = cov_thr; P.low_cov_threshold = low_cov; P.dfs_limit = dfs_limit;
@@ -106,11 +124,18 @@ int main(int argc, char **argv) {
   lancet_host *H = lancet_host_open(tumor.c_str(), normal.c_str(), ref.c_str(), err, sizeof err);
   if (!H) return die(err);
   const double t_tile0 = now();
-  const int nwin = lancet_host_tile(H, reg.c_str(), &ho);
+  const char *regs[1] = {reg.c_str()};
+  const int nwin = lancet_host_tile_regions(H, bed.empty() ? nullptr : bed.c_str(), regs, reg.empty() ? 0 : 1, &ho);
   const double t_tile = now() - t_tile0;
   if (nwin < 0) return die(lancet_host_last_error(H));
+  if (ho.active_region && !lancet_host_first_has_md(H, 1) && !lancet_host_first_has_md(H, 0)) {      // reference src/Lancet.cc:817-825
+    fputs("\n--------WARNING--------\nThe MD tag is required to select the active regions, but is missing from the alignments in the BAM(s) file(s).\n"
+          "To avoid unpredictable behavior, the active region module has been automatically turned off (--active-region-off)\n-----------------------\n\n", stderr);
+    ho.active_region = 0;
+  }
   lancet_vdb *db = lancet_vdb_create(&flt);
-  const char *chr_names[1] = {lancet_host_chrom(H)};
+  int n_chr = 0;
+  const char *const *chr_names = lancet_host_chroms(H, &n_chr);
   const int step = batch_windows > 0 ? batch_windows : 1;
   const int nchunks = (nwin + step - 1) / step;
   struct Job { bool have = false; std::string trace; std::vector<lancet_variant> v; std::string blob; std::vector<lancet_variant_lr> lr; std::vector<uint32_t> bx; std::vector<std::string> bxn; };
@@ -121,6 +146,7 @@ int main(int argc, char **argv) {
   long done = 0;
   int next_add = 0;
   std::string fail;
+  std::vector<std::string> overflowed;
   // results of a finished run are copied out (the engine's buffers live until its next upload) and added to the
   // VariantDB strictly in chunk order: addVar order is window order
   auto finish = [&](Slot &sl) -> bool {
@@ -132,7 +158,9 @@ int main(int argc, char **argv) {
     const lancet_variant *v; uint32_t nv, blen; const char *blob; const lancet_window_stats *st;
     if (lancet_engine_results(sl.e, &v, &nv, &blob, &blen, &st) != LANCET_OK) { fail = std::string("engine: ") + lancet_engine_last_error(sl.e); return false; }
     for (int w = 0; w < sl.nk; ++w) if (st[w].status < 0) {
-      fail = std::string("work-space overflow in window ") + lancet_host_window_hdr(H, sl.kept[(size_t)w]) + ": results withheld (no approximate output)"; return false; }
+      if (strict) { fail = std::string("work-space overflow in window ") + lancet_host_window_hdr(H, sl.kept[(size_t)w]) + ": results withheld (--strict)"; return false; }
+      overflowed.push_back(lancet_host_window_hdr(H, sl.kept[(size_t)w]));      // the window emitted nothing (the engine drops a window's records when it overflows)
+    }
     Job &j = jobs[(size_t)sl.chunk];
     j.v.assign(v, v + nv); j.blob.assign(blob, blen);
     if (ho.linked) {
@@ -143,10 +171,10 @@ int main(int argc, char **argv) {
     if (verbose) {
       const uint32_t *elen, *evt; uint32_t wpw = 0;
       if (lancet_engine_trace(sl.e, &elen, &evt, &wpw) == LANCET_OK && wpw) for (int w = 0; w < sl.nk; ++w) {
-        const char *hdr = lancet_host_window_hdr(H, sl.kept[(size_t)w]);
-        const char *col = strrchr(hdr, ':'); const char *dash = col ? strchr(col, '-') : nullptr;
-        const int start = col ? atoi(col + 1) : 0, end = dash ? atoi(dash + 1) : 0;
-        char *t = lancet_trace_format(evt + (size_t)w * wpw, elen[w], (int32_t)(sl.base + w + 1), hdr, lancet_host_chrom(H), start, end, dfs_limit);
+        const int tw = sl.kept[(size_t)w];
+        const char *hdr = lancet_host_window_hdr(H, tw);
+        int32_t start = 0, end = 0; lancet_host_window_span(H, tw, &start, &end);
+        char *t = lancet_trace_format(evt + (size_t)w * wpw, elen[w], (int32_t)(sl.base + w + 1), hdr, chr_names[lancet_host_window_chrom(H, tw)], start, end, dfs_limit);
         if (t) { j.trace += t; lancet_free(t); }
       }
     }
@@ -162,8 +190,8 @@ int main(int argc, char **argv) {
       if (!j.v.empty()) {
         if (ho.linked) {
           std::vector<const char *> names; for (auto &n : j.bxn) names.push_back(n.c_str());
-          arc = lancet_vdb_add_lr(db, j.v.data(), j.lr.data(), (uint32_t)j.v.size(), j.blob.c_str(), j.bx.data(), names.data(), (uint32_t)names.size(), chr_names, 1);
-        } else arc = lancet_vdb_add(db, j.v.data(), (uint32_t)j.v.size(), j.blob.c_str(), chr_names, 1);
+          arc = lancet_vdb_add_lr(db, j.v.data(), j.lr.data(), (uint32_t)j.v.size(), j.blob.c_str(), j.bx.data(), names.data(), (uint32_t)names.size(), chr_names, (uint32_t)n_chr);
+        } else arc = lancet_vdb_add(db, j.v.data(), (uint32_t)j.v.size(), j.blob.c_str(), chr_names, (uint32_t)n_chr);
       }
       if (arc != LANCET_OK) { fail = "VariantDB rejected the records"; return false; }
       j = Job(); j.have = true;
@@ -204,5 +232,10 @@ int main(int argc, char **argv) {
                       now() - t_start, t_tile, t_batch, t_engine, t_kernel / 1000.0, t_vdb);
   lancet_free(vcf);
   lancet_vdb_destroy(db); lancet_host_close(H); for (lancet_engine *e : engs) lancet_engine_destroy(e);
+  if (!overflowed.empty()) {
+    fprintf(stderr, "lancet_gpu: %zu window(s) exceeded the engine's work space (tier-2 limits, DESIGN.md section 4) and contributed NO variants:\n", overflowed.size());
+    for (const std::string &w : overflowed) fprintf(stderr, "lancet_gpu:   %s\n", w.c_str());
+    return 3;
+  }
   return 0;
 }

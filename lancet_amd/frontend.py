@@ -339,8 +339,17 @@ def batch_from_sam(windows: Sequence[Window], tumor: Sequence[SamRead], normal: 
     processGraph call: returns (batch, kept_windows) for windows that are not skipped.
     Active-region prefilter is not applied here (== --active-region-off)."""
     p = p or ReadFilterParams()
-    t_starts = np.asarray([r.pos - 1 for r in tumor], dtype=np.int64)
-    n_starts = np.asarray([r.pos - 1 for r in normal], dtype=np.int64)
+    # several contigs (--bed): tumor / normal may be {contig: reads}; the windows of all contigs share one processing order
+    by_chrom = isinstance(tumor, dict)
+    tumor_by = tumor if by_chrom else None
+    normal_by = normal if by_chrom else None
+    starts_of = lambda reads: np.asarray([r.pos - 1 for r in reads], dtype=np.int64)
+    if by_chrom:
+        t_starts_by = {c: starts_of(v) for c, v in tumor_by.items()}
+        n_starts_by = {c: starts_of(v) for c, v in normal_by.items()}
+    else:
+        t_starts = starts_of(tumor)
+        n_starts = starts_of(normal)
     kept: List[Window] = []
     per: List[list] = []
     # `leak`: reads of a window without a mapped read.  processGraph returns there before g.clear() (reference
@@ -348,8 +357,11 @@ def batch_from_sam(windows: Sequence[Window], tumor: Sequence[SamRead], normal: 
     # again to carry them across calls (chunks of one scan).
     leak = leak if leak is not None else []
     for win in windows_in_processing_order(windows):
-        if win.seq and all(c == "N" for c in win.seq):                  # isNseq, :799
-            continue
+        if by_chrom:
+            tumor, normal = tumor_by.get(win.chrom, []), normal_by.get(win.chrom, [])
+            t_starts, n_starts = t_starts_by.get(win.chrom, starts_of([])), n_starts_by.get(win.chrom, starts_of([]))
+        if not win.seq:                 # isNseq (:799, src/util.cc:259-273): `!= 'N' || != 'n'` holds for every character,
+            continue                    # so only an EMPTY window counts as all-N (long all-N windows fall to isRepeat)
         if _is_repeat(win.seq, max_k):                                  # :800
             continue
         if active_region and not (is_active_region(tumor, t_starts, win, TMR, p, min_evidence, min_qual_call)        # :817-820

@@ -35,8 +35,14 @@ def _lib():
         L.lancet_host_sample.restype = C.c_char_p
         L.lancet_host_sample.argtypes = [C.c_void_p, C.c_int]
         L.lancet_host_tile.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(LancetHostOpts)]
+        L.lancet_host_tile_regions.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(LancetHostOpts)]
         L.lancet_host_chrom.restype = C.c_char_p
         L.lancet_host_chrom.argtypes = [C.c_void_p]
+        L.lancet_host_chroms.restype = C.POINTER(C.c_char_p)
+        L.lancet_host_chroms.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.lancet_host_first_has_md.argtypes = [C.c_void_p, C.c_int]
+        L.lancet_host_window_chrom.argtypes = [C.c_void_p, C.c_int]
+        L.lancet_host_window_span.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.lancet_host_window_hdr.restype = C.c_char_p
         L.lancet_host_window_hdr.argtypes = [C.c_void_p, C.c_int]
         L.lancet_host_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(LancetHostOpts), C.POINTER(abi.LancetWindowBatch),
@@ -82,6 +88,23 @@ class NativeHost:
         self.n_windows = n
         return [self.L.lancet_host_window_hdr(self.h, w).decode() for w in range(n)]
 
+    def tile_regions(self, regions: List[str], opts: LancetHostOpts, bed: Optional[str] = None) -> List[str]:
+        """--bed and/or several regions into one table of windows (processing order = header order, across contigs)."""
+        arr = (C.c_char_p * max(1, len(regions)))(*[r.encode() for r in regions])
+        n = self.L.lancet_host_tile_regions(self.h, bed.encode() if bed else None, arr, len(regions), C.byref(opts))
+        if n < 0:
+            raise engine.EngineError(self.L.lancet_host_last_error(self.h).decode())
+        self.n_windows = n
+        return [self.L.lancet_host_window_hdr(self.h, w).decode() for w in range(n)]
+
+    def chroms(self) -> List[str]:
+        n = C.c_int()
+        p = self.L.lancet_host_chroms(self.h, C.byref(n))
+        return [p[i].decode() for i in range(n.value)]
+
+    def first_has_md(self, tumor: bool) -> bool:
+        return bool(self.L.lancet_host_first_has_md(self.h, 1 if tumor else 0))
+
     def batch(self, w_begin: int, w_end: int, opts: LancetHostOpts) -> Tuple[frontend.WindowBatch, List[int]]:
         """Windows [w_begin, w_end) of the tiling -> (batch, tiled indices of the windows kept).  Arrays are copied out."""
         cb = abi.LancetWindowBatch()
@@ -103,14 +126,15 @@ class NativeHost:
         nb = int(seq_off[-1])
         idx = [int(kept[i]) for i in range(nk.value)]
         hdr = [self.L.lancet_host_window_hdr(self.h, w).decode() for w in idx]
-        chrom = self.L.lancet_host_chrom(self.h).decode()
+        names = self.chroms()
+        chrom = [names[self.L.lancet_host_window_chrom(self.h, w)] for w in idx]
         lr = {}
         if opts.linked:
             nbx = C.c_uint32()
             names = self.L.lancet_host_bx_names(self.h, C.byref(nbx))
             lr = dict(bx_rank=arr(cb.bx_rank, R, np.uint32), hp=arr(cb.hp, R, np.uint8), bx_names=[names[i].decode() for i in range(nbx.value)])
         b = frontend.WindowBatch(
-            n_windows=n, hdr=hdr, chrom=[chrom] * n, chr_id=arr(cb.chr_id, n, np.int32), ref_start=arr(cb.ref_start, n, np.int32),
+            n_windows=n, hdr=hdr, chrom=chrom, chr_id=arr(cb.chr_id, n, np.int32), ref_start=arr(cb.ref_start, n, np.int32),
             ref_off=ref_off, ref_bases=arr(cb.ref_bases, int(ref_off[-1]), np.uint8), read_begin=read_begin, seq_off=seq_off,
             seq=arr(cb.seq, nb, np.uint8), qual=arr(cb.qual, nb, np.uint8), label=arr(cb.label, R, np.uint8),
             strand=arr(cb.strand, R, np.uint8), mate=arr(cb.mate, R, np.uint8), mapped=arr(cb.mapped, R, np.uint8),

@@ -349,3 +349,228 @@ def test_lancet_gpu_reproduces_the_reference_s_read_leak():
     assert r.returncode == 0, r.stderr[-2000:]
     assert _body(r.stdout) == gu.golden_vcf("leak_small")
     assert gu.digest_trace(r.stderr) == gu.digest_trace(gu.golden_trace("leak_small"))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# input at scale: .bai / streaming region reads, several contigs, --bed
+
+def _bed2_paths():
+    return [os.path.join(G, "bed2.tumor.bam"), os.path.join(G, "bed2.normal.bam"), os.path.join(G, "bed2.fa")]
+
+
+def _trace_windows(case):
+    import re
+    out = []
+    for line in open(os.path.join(G, f"{case}.trace.txt")):
+        m = re.match(r"== Processing (\d+): (\S+) numsequences: (\d+) mapped: (\d+)", line)
+        if m:
+            out.append((m.group(2), int(m.group(3))))
+    return out
+
+
+def _batches_equal(a, b, linked=False):
+    assert a.n_windows == b.n_windows and a.hdr == b.hdr and a.chrom == b.chrom
+    for f in FIELDS:
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+
+
+def test_bed_plus_region_tiling_and_selection_equal_the_reference_run(tmp_path, capfd):
+    """tests/golden/bed2.*: the reference itself on a BED file (three lines on two contigs, two of them overlapping once padded)
+    together with --reg.  Its -v trace names every window it assembled, in its processing order, with the number of reads:
+    the native host must tile (double padding of BED intervals, one table ordered by header, duplicates once), filter (active
+    regions on) and select the same.  Read through the bamtools-made .bai (no linear index), through a .bai with a linear
+    index, and streamed without an index: identical batches; and equal to the Python front end."""
+    paths = _bed2_paths()
+    case = __import__("json").load(open(os.path.join(G, "bed2.case.txt")))
+    bed = os.path.join(G, "bed2.bed")
+    want = _trace_windows("bed2")
+    assert len(want) == 32 and {h.split(":")[0] for h, _ in want} == {"chr21", "chr22"}
+    o = host.default_opts()
+    os.environ["LANCET_HOST_TIMING"] = "1"
+    try:
+        H = host.NativeHost(*paths)
+        hdrs = H.tile_regions([case["region"]], o, bed=bed)
+        err = capfd.readouterr().err
+        assert err.count("indexed (.bai)") == 2
+        assert H.chroms() == ["chr22", "chr21"] and (H.first_has_md(True), H.first_has_md(False)) == (True, True)
+        assert hdrs == sorted(set(hdrs)) and len(hdrs) >= len(want)
+        b, idx = H.batch(0, len(hdrs), o)
+        H.close()
+        assert [(h, int(b.read_begin[i + 1] - b.read_begin[i])) for i, h in enumerate(b.hdr)] == want
+        assert [b.chrom[i] for i in range(b.n_windows)] == [h.split(":")[0] for h in b.hdr]
+        assert [H2 for H2 in np.asarray(b.chr_id)] == [["chr22", "chr21"].index(c) for c in b.chrom]
+        # no index: streamed
+        import shutil
+        for f in ("bed2.tumor.bam", "bed2.normal.bam", "bed2.fa"):
+            shutil.copy(os.path.join(G, f), tmp_path / f)
+        sp = [str(tmp_path / "bed2.tumor.bam"), str(tmp_path / "bed2.normal.bam"), str(tmp_path / "bed2.fa")]
+        H = host.NativeHost(*sp)
+        assert H.tile_regions([case["region"]], o, bed=bed) == hdrs
+        assert capfd.readouterr().err.count("no .bai: streamed") == 2
+        b2, _ = H.batch(0, len(hdrs), o)
+        H.close()
+        _batches_equal(b, b2)
+        # the same BAM content rewritten by the test-side writer with a samtools-style .bai (linear index present)
+        for smp in ("tumor", "normal"):
+            _, reads = bamio.read_bam(os.path.join(G, f"bed2.{smp}.bam"))
+            bam_writer.write_bam(str(tmp_path / f"lin.{smp}.bam"), [("chr21", 3600), ("chr22", 4000)], reads, sample=smp.upper(), index=True, block=9000)
+        H = host.NativeHost(str(tmp_path / "lin.tumor.bam"), str(tmp_path / "lin.normal.bam"), sp[2])
+        assert H.tile_regions([case["region"]], o, bed=bed) == hdrs
+        assert capfd.readouterr().err.count("indexed (.bai)") == 2
+        b3, _ = H.batch(0, len(hdrs), o)
+        H.close()
+        _batches_equal(b, b3)
+    finally:
+        del os.environ["LANCET_HOST_TIMING"]
+    # Python front end on the same inputs, contigs side by side
+    contigs = bamio.read_fasta(paths[2])
+    by = {}
+    for smp, pth in (("tumor", paths[0]), ("normal", paths[1])):
+        _, reads = bamio.read_bam(pth)
+        by[smp] = {c: [r for r in reads if r.rname == c] for c in ("chr21", "chr22")}
+    wins = []
+    for line in open(bed):
+        if line.startswith("#"):
+            continue
+        c, s, e = line.rstrip("\n").split("\t")[:3]
+        reg = f"{c}:{max(1, int(s) - o.padding)}-{int(e) + o.padding}"
+        wins += frontend.tile_region(contigs[c], c, reg, padding=o.padding, window_size=o.window_size)
+    c = case["region"].split(":")[0]
+    wins += frontend.tile_region(contigs[c], c, case["region"], padding=o.padding, window_size=o.window_size)
+    seen, uniq = set(), []
+    for w in wins:
+        if w.hdr not in seen:
+            seen.add(w.hdr); uniq.append(w)
+    fp = frontend.ReadFilterParams(min_map_qual=o.min_map_qual, max_delta_as_xs=o.max_delta_as_xs, max_avg_cov=o.max_avg_cov)
+    pb, _ = frontend.batch_from_sam(uniq, by["tumor"], by["normal"], fp, max_k=o.max_k, active_region=True, min_evidence=o.min_evidence,
+                                    min_qual_call=o.min_qual_call)
+    assert pb.hdr == b.hdr
+    for f in FIELDS:
+        if f != "chr_id":                                   # (the two number the contigs in their own order of first appearance)
+            assert np.array_equal(getattr(b, f), getattr(pb, f)), f
+
+
+def test_indexed_reads_of_far_apart_stretches_seek_instead_of_streaming(tmp_path, capfd):
+    """Two contigs of 60 kb at low coverage, three small stretches far apart (one on the second contig): with a .bai the reader
+    seeks to each stretch and inflates a fraction of the file; the batches equal those of the streamed read."""
+    rng = np.random.default_rng(5)
+    datas = [synth.make_tumor_normal(ref_len=60000, cov_t=5, cov_n=4, ref_seed=501 + i, tumor_seed=1501 + i, normal_seed=2501 + i,
+                                     somatic_every=900, germline_every=700) for i in range(2)]
+    names = ["ctgA", "ctgB"]
+    ren = lambda rs, name: [synth.SamRead(r.qname + name, r.flag, name, r.pos, r.mapq, r.cigar, r.seq, r.qual, r.tags) for r in rs]
+    refs = [(n, len(d["ref"])) for n, d in zip(names, datas)]
+    fa = str(tmp_path / "r.fa")
+    with open(fa, "w") as fh:
+        for n, d in zip(names, datas):
+            fh.write(f">{n}\n")
+            for i in range(0, len(d["ref"]), 80):
+                fh.write(d["ref"][i:i + 80] + "\n")
+    for smp in ("tumor", "normal"):
+        reads = sum((ren(synth.pairs_to_sorted_reads(d[smp]), n) for n, d in zip(names, datas)), [])
+        for tag, kw in (("idx", dict(index=True)), ("lin0", dict(index=True, linear=False)), ("raw", dict())):
+            bam_writer.write_bam(str(tmp_path / f"{tag}.{smp}.bam"), refs, reads, sample=smp, block=20000, **kw)
+    regions = ["ctgA:20100-21000", "ctgA:52000-52900", "ctgB:40500-41400"]
+    o = host.default_opts(active_region=0)
+    os.environ["LANCET_HOST_TIMING"] = "1"
+    os.environ["LANCET_HOST_SLAB_KB"] = "64"            # (so that this small file spans many slabs)
+    try:
+        got = {}
+        for tag in ("idx", "lin0", "raw"):
+            H = host.NativeHost(str(tmp_path / f"{tag}.tumor.bam"), str(tmp_path / f"{tag}.normal.bam"), fa)
+            hdrs = H.tile_regions(regions, o)
+            err = capfd.readouterr().err
+            import re
+            mb = [int(x) for x in re.findall(r"(\d+) MB inflated", err)]
+            seeks = [int(x) for x in re.findall(r"(\d+) seeks", err)]
+            b, _ = H.batch(0, len(hdrs), o)
+            got[tag] = (b, seeks, mb)
+            H.close()
+    finally:
+        del os.environ["LANCET_HOST_TIMING"], os.environ["LANCET_HOST_SLAB_KB"]
+    _batches_equal(got["idx"][0], got["raw"][0]); _batches_equal(got["lin0"][0], got["raw"][0])
+    assert got["raw"][0].n_reads > 100 and got["raw"][0].n_windows >= 20
+    assert all(s >= 2 for s in got["idx"][1]) and all(s >= 2 for s in got["lin0"][1]) and got["raw"][1] == [0, 0]
+
+
+def test_native_bam_reader_rejects_damaged_files_instead_of_reading_past_them(tmp_path):
+    """Truncated file, a header length pointing past the end, a record with field lengths past its end, unsorted records:
+    an error message, not a crash (every length is checked against what is there)."""
+    import struct
+    import zlib
+    fa = os.path.join(G, "ar_small.fa")
+    good = open(os.path.join(G, "ar_small.tumor.bam"), "rb").read()
+    o = host.default_opts()
+
+    def tile_fails(raw, what):
+        p = tmp_path / "x.bam"
+        p.write_bytes(raw)
+        H = host.NativeHost(str(p), str(p), fa)
+        with pytest.raises(Exception) as ei:
+            H.tile("chr22:900-3000", o)
+        assert what in str(ei.value), str(ei.value)
+        H.close()
+    tile_fails(good[:len(good) // 2], "BGZF")                                        # cut inside a block
+    inflated = bamio.bgzf_decompress(good)
+    blocks = lambda body: b"".join(bam_writer._bgzf_block(body[i:i + 60000]) for i in range(0, len(body), 60000)) + bam_writer._bgzf_block(b"")
+    tile_fails(blocks(inflated[:len(inflated) // 2 + 7]), "truncated alignment record")   # cut inside a record
+    bad = bytearray(inflated); bad[4:8] = struct.pack("<i", 0x7FFFFF00)
+    tile_fails(blocks(bytes(bad)), "truncated BAM header")
+    # first record: l_seq far larger than the record
+    l_text = struct.unpack_from("<i", inflated, 4)[0]
+    p = 8 + l_text
+    n_ref = struct.unpack_from("<i", inflated, p)[0]; p += 4
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<i", inflated, p)[0]; p += 8 + ln
+    bad = bytearray(inflated); bad[p + 4 + 16:p + 4 + 20] = struct.pack("<i", 1 << 24)
+    # (the damaged record must be one the region selects: move it into the region)
+    bad[p + 4 + 4:p + 4 + 8] = struct.pack("<i", 1000)
+    tile_fails(blocks(bytes(bad)), "fields past its end")
+    # records out of coordinate order
+    _, reads = bamio.read_bam(os.path.join(G, "ar_small.tumor.bam"))
+    sw = list(reads); sw[40], sw[300] = sw[300], sw[40]
+    bam_writer.write_bam(str(tmp_path / "u.bam"), [("chr22", 4000)], sw)
+    tile_fails(open(tmp_path / "u.bam", "rb").read(), "not coordinate sorted")
+
+
+def test_first_alignment_without_md_is_reported_for_the_active_region_switch(tmp_path):
+    """checkPresenceOfMDtag looks at the first alignment of each BAM; main() turns the active-region module off when neither
+    has MD (reference src/Lancet.cc:817-825, src/util.cc:416-427)."""
+    _, reads = bamio.read_bam(os.path.join(G, "ar_small.tumor.bam"))
+    strip = [synth.SamRead(r.qname, r.flag, r.rname, r.pos, r.mapq, r.cigar, r.seq, r.qual, {k: v for k, v in r.tags.items() if k != "MD"}) for r in reads]
+    bam_writer.write_bam(str(tmp_path / "nomd.bam"), [("chr22", 4000)], strip)
+    H = host.NativeHost(str(tmp_path / "nomd.bam"), os.path.join(G, "ar_small.normal.bam"), os.path.join(G, "ar_small.fa"))
+    H.tile("chr22:900-3000", host.default_opts())
+    assert (H.first_has_md(True), H.first_has_md(False)) == (False, True)
+    H.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("indexed", [True, False])
+def test_lancet_gpu_bed_and_region_on_two_contigs_is_byte_identical_to_the_reference(tmp_path, indexed):
+    """`lancet_gpu --bed regions.bed --reg chr21:...` on the two-contig fixture (through the .bai, and streamed without one)
+    against the VCF of the reference's own run with the same BED file and region."""
+    import shutil
+    case = __import__("json").load(open(os.path.join(G, "bed2.case.txt")))
+    src = {f: os.path.join(G, f) for f in ("bed2.tumor.bam", "bed2.normal.bam", "bed2.fa", "bed2.bed")}
+    if not indexed:
+        for f in list(src):
+            shutil.copy(src[f], tmp_path / f); src[f] = str(tmp_path / f)
+    r = subprocess.run([build.BIN, "--tumor", src["bed2.tumor.bam"], "--normal", src["bed2.normal.bam"], "--ref", src["bed2.fa"],
+                        "--bed", src["bed2.bed"], "--reg", case["region"], "--batch-windows", "9", "--devices", "0,0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert _body(r.stdout) == gu.golden_vcf("bed2")
+    assert "chr21\t" in r.stdout and "chr22\t" in r.stdout
+
+
+@pytest.mark.gpu
+def test_lancet_gpu_finishes_and_lists_windows_that_exceeded_the_work_space(tmp_path):
+    """A window that overflows the engine's tables contributes nothing and is named on stderr; the run finishes with the
+    other windows' variants and exit code 3.  --strict: no VCF at all."""
+    args = [build.BIN, "--tumor", os.path.join(G, "ar_small.tumor.bam"), "--normal", os.path.join(G, "ar_small.normal.bam"),
+            "--ref", os.path.join(G, "ar_small.fa"), "--reg", "chr22:900-3000"]
+    env = dict(os.environ, LANCET_MAX_NODES="1500")          # node tables far below what a 600-bp window at k = 11 needs
+    r = subprocess.run(args, capture_output=True, text=True, env=env)
+    assert r.returncode == 3 and "exceeded the engine's work space" in r.stderr and "lancet_gpu:   chr22:" in r.stderr
+    assert r.stdout.startswith("##fileformat=VCF")
+    r = subprocess.run(args + ["--strict"], capture_output=True, text=True, env=env)
+    assert r.returncode == 1 and r.stdout == "" and "--strict" in r.stderr
