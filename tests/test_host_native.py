@@ -545,10 +545,10 @@ def test_first_alignment_without_md_is_reported_for_the_active_region_switch(tmp
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("indexed", [True, False])
-def test_lancet_gpu_bed_and_region_on_two_contigs_is_byte_identical_to_the_reference(tmp_path, indexed):
-    """`lancet_gpu --bed regions.bed --reg chr21:...` on the two-contig fixture (through the .bai, and streamed without one)
-    against the VCF of the reference's own run with the same BED file and region."""
+@pytest.mark.parametrize("indexed,with_reg", [(True, True), (False, True), (True, False)])
+def test_lancet_gpu_bed_and_region_on_two_contigs_is_byte_identical_to_the_reference(tmp_path, indexed, with_reg):
+    """`lancet_gpu --bed regions.bed [--reg chr21:...]` on the two-contig fixture (through the .bai, and streamed without one;
+    with the BED file alone, i.e. without --reg) against the VCF of the reference's own run with the same arguments."""
     import shutil
     case = __import__("json").load(open(os.path.join(G, "bed2.case.txt")))
     src = {f: os.path.join(G, f) for f in ("bed2.tumor.bam", "bed2.normal.bam", "bed2.fa", "bed2.bed")}
@@ -556,9 +556,10 @@ def test_lancet_gpu_bed_and_region_on_two_contigs_is_byte_identical_to_the_refer
         for f in list(src):
             shutil.copy(src[f], tmp_path / f); src[f] = str(tmp_path / f)
     r = subprocess.run([build.BIN, "--tumor", src["bed2.tumor.bam"], "--normal", src["bed2.normal.bam"], "--ref", src["bed2.fa"],
-                        "--bed", src["bed2.bed"], "--reg", case["region"], "--batch-windows", "9", "--devices", "0,0"], capture_output=True, text=True)
+                        "--bed", src["bed2.bed"], "--batch-windows", "9", "--devices", "0,0"] + (["--reg", case["region"]] if with_reg else []),
+                       capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert _body(r.stdout) == gu.golden_vcf("bed2")
+    assert _body(r.stdout) == gu.golden_vcf("bed2" if with_reg else "bed2_bedonly")
     assert "chr21\t" in r.stdout and "chr22\t" in r.stdout
 
 
@@ -568,7 +569,7 @@ def test_lancet_gpu_finishes_and_lists_windows_that_exceeded_the_work_space(tmp_
     other windows' variants and exit code 3.  --strict: no VCF at all."""
     args = [build.BIN, "--tumor", os.path.join(G, "ar_small.tumor.bam"), "--normal", os.path.join(G, "ar_small.normal.bam"),
             "--ref", os.path.join(G, "ar_small.fa"), "--reg", "chr22:900-3000"]
-    env = dict(os.environ, LANCET_MAX_NODES="1500")          # node tables far below what a 600-bp window at k = 11 needs
+    env = dict(os.environ, LANCET_NODE_CAP1="1500", LANCET_MAX_NODES="1500")   # node tables (both tiers) below what a 600-bp window at k = 11 needs
     r = subprocess.run(args, capture_output=True, text=True, env=env)
     assert r.returncode == 3 and "exceeded the engine's work space" in r.stderr and "lancet_gpu:   chr22:" in r.stderr
     assert r.stdout.startswith("##fileformat=VCF")

@@ -5,7 +5,7 @@ padded twice (:343-349 then :233-249), overlapping BED lines tiling the same win
 one header-ordered processing sequence, active regions on.
 
 Written to tests/golden/: bed2.{tumor,normal}.bam + .bam.bai (made by htslib's test_view / `bamtools index`), bed2.fa (+ .fai
-as htslib's faidx wrote it), bed2.bed (inputs); bed2.vcf (expected output), bed2.trace.txt (digest of the reference's -v),
+as htslib's faidx wrote it), bed2.bed (inputs); bed2.vcf (expected output; bed2_bedonly.vcf: the same run without --reg), bed2.trace.txt (digest of the reference's -v),
 bed2.case.txt (the command line, JSON).  Nothing of the reference travels; only these data files do."""
 import json
 import os
@@ -53,6 +53,10 @@ if __name__ == "__main__":
         if r.returncode != 0:
             sys.stderr.write(r.stderr[-3000:])
             raise SystemExit("reference failed")
+        # the BED file alone (no --reg)
+        r2 = subprocess.run([c for c in cmd if c not in ("--reg", REGION, "-v")], capture_output=True, text=True, cwd=td)
+        if r2.returncode != 0:
+            raise SystemExit("reference failed (BED only)")
         for rg in ("tumor", "normal"):
             shutil.copy(bams[rg], os.path.join(mg.GOLDEN, f"{NAME}.{rg}.bam"))
             shutil.copy(bams[rg] + ".bai", os.path.join(mg.GOLDEN, f"{NAME}.{rg}.bam.bai"))
@@ -62,6 +66,9 @@ if __name__ == "__main__":
     vcf = "".join(l + "\n" for l in r.stdout.splitlines()
                   if not l.startswith("##fileDate") and not l.startswith("##cmdline") and not l.startswith("##reference"))
     open(os.path.join(mg.GOLDEN, f"{NAME}.vcf"), "w").write(vcf)
+    vcf2 = "".join(l + "\n" for l in r2.stdout.splitlines()
+                   if not l.startswith("##fileDate") and not l.startswith("##cmdline") and not l.startswith("##reference"))
+    open(os.path.join(mg.GOLDEN, f"{NAME}_bedonly.vcf"), "w").write(vcf2)
     open(os.path.join(mg.GOLDEN, f"{NAME}.trace.txt"), "w").write(mg.digest_trace(r.stderr))
     json.dump({"region": REGION, "bed": BED, "flags": ["--active-region-on"],
                "reference_cmd": " ".join(os.path.basename(c) if c.startswith("/tmp") else c for c in cmd),
