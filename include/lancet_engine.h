@@ -180,6 +180,10 @@ const char *lancet_engine_kernel_name(int i);
 int lancet_engine_kernel_times(lancet_engine *e, float *ms, int cap);
 /* Windows of the last run whose first graph was assembled by the LDS build kernel (the others took the general build phases). */
 int lancet_engine_prebuilt_count(lancet_engine *e);
+/* Graphs the build kernel built AHEAD in the last run -- the next k of a window whose graph at the current k holds a k-mer twice
+ * in one read and will be rejected (reference src/Microassembler.cc:198-206: cycle -> next k) -- and how many of them the window
+ * kernel took instead of building that graph itself.  Scheduling only: results never depend on what was built ahead. */
+int lancet_engine_ahead_counts(lancet_engine *e, int32_t *built, int32_t *used);
 /* Profiling aid: wall-clock ticks (10 ns) the LDS build kernel's workgroups spent per phase in the last run (16 values). */
 int lancet_engine_build_phase_times(lancet_engine *e, const unsigned long long **ticks);
 

@@ -60,7 +60,8 @@ struct BlShared {
   int why;
   uint32_t npairs, flagged, edges_total, refn;
   uint32_t g0, g1;                  /* group bounds of the current pass                                          */
-  uint32_t hint;                    /* a read with a repeated k-mer was seen (scheduling hint)                    */
+  uint32_t hint;                    /* the graph will very likely have a cycle at this k (scheduling hint, see the insert pass) */
+  uint32_t ndup;                    /* occurrences noted in BlScratch::dupo                                        */
   unsigned long long t_last, ph_acc[16]; int ph_cur;   /* profiling: wall-clock ticks per phase (lane 0)                 */
 };
 
@@ -74,8 +75,10 @@ struct BlScratch {
   LC_GLOBAL uint32_t *c_minqv;      /* [PB_CCAP]                                                                 */
   LC_GLOBAL uint32_t *s_ci;         /* [PB_SCAP] candidate of survivor si                                        */
   LC_GLOBAL uint32_t *s_edges;      /* [PB_SCAP * 9] resolved edges + count                                      */
+  LC_GLOBAL uint16_t *dupo;         /* [BL_DUPCAP] occurrences that met their k-mer in the other orientation, or twice in one read */
 };
-#define BL_SCRATCH_BYTES (2u * BL_BASES + 64u + 8u * BL_TCAP + 4u * BL_TCAP + 12u * PB_CCAP + 4u * PB_SCAP + 36u * PB_SCAP + 512u)
+#define BL_DUPCAP 1024u
+#define BL_SCRATCH_BYTES (2u * BL_BASES + 64u + 8u * BL_TCAP + 4u * BL_TCAP + 12u * PB_CCAP + 4u * PB_SCAP + 36u * PB_SCAP + 2u * BL_DUPCAP + 640u)
 DEV void bl_scratch_carve(BlScratch *s, LC_GLOBAL uint8_t *base) {
   size_t o = 0;
   auto take = [&](size_t bytes) { LC_GLOBAL uint8_t *p = base + o; o = (o + bytes + 63) & ~(size_t)63; return p; };
@@ -87,8 +90,10 @@ DEV void bl_scratch_carve(BlScratch *s, LC_GLOBAL uint8_t *base) {
   s->c_minqv = (LC_GLOBAL uint32_t *)take(4u * PB_CCAP);
   s->s_ci = (LC_GLOBAL uint32_t *)take(4u * PB_SCAP);
   s->s_edges = (LC_GLOBAL uint32_t *)take(36u * PB_SCAP);
+  s->dupo = (LC_GLOBAL uint16_t *)take(2u * BL_DUPCAP);
 }
 
+static_assert(sizeof(BlShared) <= 80u * 1024u, "two workgroups of the build kernel per CU: 80 KB of LDS each");
 typedef LC_LDS BlShared BL_S;
 #ifndef LANCET_WAVE_EMU
 static __shared__ BlShared bl_shared;
@@ -193,8 +198,10 @@ template <class F> DEV void bl_for_occ(BL_S &S, LC_GLOBAL const uint16_t *occn, 
 }
 
 // One window.  Returns with the hand-off area of the window written (PB_BUILT) or marked PB_NOT_BUILT.
+// kmin: the loop over k starts there (min_k for the window's first graph; the k after a rejected one for a graph built ahead).
+// rep: the window's isRepeat / isAlmostRepeat operands when an earlier call scanned the reference already, else null.
 DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *Bp, LC_GLOBAL const EngineCaps *C, BL_S &S, LC_GLOBAL uint8_t *xbase,
-                           LC_GLOBAL uint8_t *area, int w) {
+                           LC_GLOBAL uint8_t *area, int w, int kmin, LC_GLOBAL const PreHdr *rep) {
   LC_GLOBAL const DevBatch &B = *Bp;
   BlScratch X; bl_scratch_carve(&X, xbase);                       // (a local of this function: its pointers live in registers)
   LC_GLOBAL PreHdr *H = (LC_GLOBAL PreHdr *)(area + PRE_OFF_HDR);
@@ -202,8 +209,8 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   const int nr = (int)(B.read_begin[w + 1] - g0);
   const int reflen = (int)(B.ref_off[w + 1] - B.ref_off[w]);
   LC_GLOBAL const uint8_t *refc = B.ref_codes + B.ref_off[w];
-  WG_LANE0 { S.hint = 0; S.w = w; S.why = BLW_NONE; S.R = nr + 1; S.reflen = reflen; S.hasN = 0; S.mapped = 0; S.flagged = 0; S.npairs = 0; S.edges_total = 0; S.refn = 0;
-             H->status = PB_NOT_BUILT; H->why = 0; H->have_rep = 0; H->heavy = 0;
+  WG_LANE0 { S.hint = 0; S.ndup = 0; S.w = w; S.why = BLW_NONE; S.R = nr + 1; S.reflen = reflen; S.hasN = 0; S.mapped = 0; S.flagged = 0; S.npairs = 0; S.edges_total = 0; S.refn = 0;
+             H->status = PB_NOT_BUILT; H->why = 0; H->have_rep = 0; H->heavy = 0; H->next = 0;
              if (nr > BL_RMAX || reflen > LC_MAXW || reflen < 1) S.why = BLW_SIZE; }
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
   // ---- mapped reads, N in the window reference, per-read geometry
@@ -249,11 +256,12 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   BLP(S, 2);
   if (C->debug_stop == 102u) { WG_LANE0 { H->why = 99; } return; }
   // ---- reference repeat scan -> the first k of the loop that reaches buildgraph (Microassembler.cc:118-131)
-  repeat_scan_min((volatile LC_LDS unsigned long long *)(S.big + 4 * (BL_RMAX + 8)), refc, reflen, P->max_mismatch, P->min_k, P->min_k + 1, (volatile LC_LDS int *)&S.repE, (volatile LC_LDS int *)&S.repM,
+  if (rep) { WG_LANE0 { S.repE = rep->refE; S.repM = rep->refM; } WG_SYNC(); }
+  else repeat_scan_min((volatile LC_LDS unsigned long long *)(S.big + 4 * (BL_RMAX + 8)), refc, reflen, P->max_mismatch, P->min_k, P->min_k + 1, (volatile LC_LDS int *)&S.repE, (volatile LC_LDS int *)&S.repM,
                   (const LC_LDS uint32_t *)&S.bases[S.rdo[nr]]);     // (the reference is in LDS already, 2 bits per base: no N here)
   WG_LANE0 {
     int K = 0;
-    for (int k = P->min_k; k <= P->max_k; k += 2) {
+    for (int k = kmin; k <= P->max_k; k += 2) {
       if (reflen - k > 0 && S.repE >= k) continue;
       if (reflen - k > 0 && S.repM >= k + 1) continue;
       K = k; break;
@@ -352,7 +360,16 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
         bool f2;
         if (bl_canon(bl_kmer(S.bases, cur & 0xFFFFu, kmask), K, kmask, &f2) == ck) {
           if (mine < cur) dev_atomic_min(&tab[idx], mine);
-          if (r < nr && (cur & 0xFFFFu) - 16u * S.rdo[r] < (uint32_t)RI_TLEN(S.rinfo[r]) && cur != mine) S.hint = 1;      // the same k-mer twice in one read
+          // Scheduling hint (PreHdr::heavy).  All reads are in reference orientation and the loop over k only builds at a k
+          // above the window reference's longest repeat, so a node normally meets its k-mer once per read and always in the
+          // same orientation.  The same k-mer twice in one read (a duplication in the sample), or in both orientations (an
+          // inverted repeat, which isRepeat does not look for), means a walk comes back to the node: if that node survives
+          // removeLowCov the graph has a cycle and this k is rejected (Microassembler.cc:198-206).  The occurrence is noted
+          // here and looked at again once the survivors are known.
+          if (cur != mine && ((f2 != isF) || (r < nr && (cur & 0xFFFFu) - 16u * S.rdo[r] < (uint32_t)RI_TLEN(S.rinfo[r])))) {
+            const uint32_t di = dev_atomic_add((LC_LDS uint32_t *)&S.ndup, 1u);
+            if (di < BL_DUPCAP) X.dupo[di] = (uint16_t)boff;
+          }
           break;
         }
       }
@@ -361,7 +378,6 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     }
     X.occn[boff] = (uint16_t)(idx | (isF ? 0u : 0x8000u));
   BL_OCC_END
-  WG_LANE0 { H->heavy = S.hint; }
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
   BLP(S, 5);
   if (C->debug_stop == 105u) { WG_LANE0 { H->why = 99; } return; }
@@ -419,6 +435,12 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   const uint32_t tthr = tmin < 2 ? (uint32_t)tmin : 2u;
   WG_FOR(i, BL_SLOTS) { const uint32_t e = tab[i]; if (e != BL_EMPTY) S.cidx[e & 0xFFFFu] = (uint16_t)(e >> 16); }     // count by node id
   WG_SYNC();
+  {   // the hint's occurrences: only nodes with real coverage matter (a hairpin in one erroneous read survives removeLowCov
+      // with coverage 2 and is trimmed as a tip later: k is not rejected for it)
+    const uint32_t nd = S.ndup < BL_DUPCAP ? S.ndup : BL_DUPCAP;
+    const uint32_t cthr = (uint32_t)(avgcov / 4.0) > 4u ? (uint32_t)(avgcov / 4.0) : 4u;
+    WG_FOR(i, nd) { if ((uint32_t)S.cidx[X.occn[X.dupo[i]] & 0x1FFFu] < cthr) X.dupo[i] = (uint16_t)0xFFFFu; }
+  }
   {
     LC_LDS uint32_t *fl = S.big;                                 // (the table is no longer needed: occn holds node ids)
     WG_FOR(n, N + 1) { fl[n] = (n < (int)N && S.cidx[n] >= tthr) ? 1u : 0u; }
@@ -720,10 +742,16 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_SYNC();
     WG_FOR(si, nsurv) { S.cidx[X.c_id[X.s_ci[si]]] = (uint16_t)si; }
     WG_SYNC();
+    {   // the hint: does a node that was met twice in a read / in both orientations survive?
+      const uint32_t nd = S.ndup < BL_DUPCAP ? S.ndup : BL_DUPCAP;
+      WG_FOR(i, nd) { const uint32_t o = X.dupo[i]; if (o != 0xFFFFu && S.cidx[X.occn[o] & 0x1FFFu] != 0xFFFFu) S.hint = 1; }
+      WG_LANE0 { if (S.ndup > BL_DUPCAP) S.hint = 1; }
+    }
+    WG_SYNC();
     WG_FOR(i, nrefk) {
       const uint32_t e = X.occn[rb + (uint32_t)i];
       const uint32_t n = e & 0x1FFFu;
-      occ_ref[i] = (S.cidx[n] != 0xFFFFu ? n : PB_NOSURV) | ((e & 0x8000u) ? 0x80000000u : 0u);
+      occ_ref[i] = n | (S.cidx[n] != 0xFFFFu ? 0u : PB_GONE) | ((e & 0x8000u) ? 0x80000000u : 0u);
     }
   }
   BLP(S, 13);
@@ -946,16 +974,23 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   }
   WG_LANE0 {
     H->K = K; H->refE = S.repE; H->refM = S.repM; H->N = S.N; H->O = S.O; H->totalreadbp = S.totalreadbp; H->n_kmers = S.n_kmers;
-    H->ncand = S.ncand; H->nsurv = S.nsurv; H->edges_total = S.edges_total; H->refn = S.refn; H->why = 0;
+    H->ncand = S.ncand; H->nsurv = S.nsurv; H->edges_total = S.edges_total; H->refn = S.refn; H->why = 0; H->heavy = S.hint;
     H->status = PB_BUILT;
   }
   WG_SYNC();
 }
 
-// entry: persistent workgroups pull windows off the batch queue (`queue` is a counter of its own)
-// (queue[0] = next window, queue[1] = windows built)
+// entry: persistent workgroups pull windows off the batch queue (`queue` is a counter block of its own)
+// Building ahead: a window whose graph holds the same k-mer twice in one read (PreHdr::heavy) will almost always be rejected at
+// this k (the duplication is a cycle), and the window kernel would then build the next graph with its general, HBM-resident
+// phases on one wave -- ~30x the latency of this kernel, and the few windows that climb through several k are the critical
+// path of the whole launch.  So the workgroup goes on to the next k of the window's loop right away (up to `depth` graphs
+// ahead), into an area of `pool` (pool_cap areas, handed out by queue[2]); PreHdr::next links them.  A graph built ahead that
+// the window kernel does not ask for is wasted work, nothing else: results never depend on what was built ahead.
+// (queue[0] = next window, queue[1] = windows built, queue[2] = pool areas handed out, queue[3] = graphs built ahead)
 DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *B, LC_GLOBAL const EngineCaps *C, LC_GLOBAL uint8_t *pre,
-                           LC_GLOBAL uint8_t *scratch, LC_GLOBAL uint32_t *queue, BL_S &S, int slot, LC_GLOBAL unsigned long long *phase = nullptr) {
+                           LC_GLOBAL uint8_t *scratch, LC_GLOBAL uint32_t *queue, BL_S &S, int slot, LC_GLOBAL unsigned long long *phase = nullptr,
+                           LC_GLOBAL uint8_t *pool = nullptr, uint32_t pool_cap = 0, int depth = 0) {
   LC_GLOBAL uint8_t *xbase = scratch + (size_t)slot * BL_SCRATCH_BYTES;
   while (true) {
     WG_LANE0 { S.w = (int)dev_atomic_add(queue, 1u); }
@@ -964,7 +999,25 @@ DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
 #ifndef LANCET_WAVE_EMU
     if (threadIdx.x == 0) { for (int i = 0; i < 16; ++i) S.ph_acc[i] = 0; S.ph_cur = 0; S.t_last = wall_clock64(); }
 #endif
-    bl_build_window(P, B, C, S, xbase, pre + (size_t)w * PRE_STRIDE, w);
+    bl_build_window(P, B, C, S, xbase, pre + (size_t)w * PRE_STRIDE, w, P->min_k, nullptr);
+    {
+      LC_GLOBAL PreHdr *H0 = (LC_GLOBAL PreHdr *)(pre + (size_t)w * PRE_STRIDE), *cur = H0;
+      for (int lvl = 0; pool && lvl < depth; ++lvl) {
+        WG_SYNC();
+        WG_LANE0 {
+          S.scan_total = 0xFFFFFFFFu;
+          if (cur->status == PB_BUILT && cur->heavy && cur->K + 2 <= P->max_k) { const uint32_t a = dev_atomic_add(queue + 2, 1u); if (a < pool_cap) S.scan_total = a; }
+        }
+        const uint32_t a = bl_bcast(&S.scan_total);
+        if (a == 0xFFFFFFFFu) break;
+        LC_GLOBAL uint8_t *nx = pool + (size_t)a * PRE_STRIDE;
+        bl_build_window(P, B, C, S, xbase, nx, w, cur->K + 2, H0);
+        WG_SYNC();
+        WG_LANE0 { if (((LC_GLOBAL PreHdr *)nx)->status == PB_BUILT) { cur->next = a + 1u; dev_atomic_add(queue + 3, 1u); } }
+        if (((LC_GLOBAL PreHdr *)nx)->status != PB_BUILT) break;
+        cur = (LC_GLOBAL PreHdr *)nx;
+      }
+    }
     BLP(S, 15);
 #ifndef LANCET_WAVE_EMU
     if (threadIdx.x == 0 && phase) for (int i = 0; i < 16; ++i) if (S.ph_acc[i]) atomicAdd((unsigned long long *)&phase[i], S.ph_acc[i]);

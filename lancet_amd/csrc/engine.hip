@@ -27,9 +27,9 @@ __global__ void __launch_bounds__(LANCET_WG * 2) __attribute__((amdgpu_waves_per
 
 // The first graph of every window in LDS (build_lds.h): 256 lanes per window, 2 workgroups per CU (80 KB of LDS each)
 __global__ void __launch_bounds__(BL_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) build_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue,
-                                                      unsigned long long *phase) {
+                                                      unsigned long long *phase, uint8_t *pool, uint32_t pool_cap, int depth) {
   build_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL uint8_t *)pre, (LC_GLOBAL uint8_t *)scratch,
-                    (LC_GLOBAL uint32_t *)queue, *(BL_S *)&bl_shared, (int)blockIdx.x, (LC_GLOBAL unsigned long long *)phase);
+                    (LC_GLOBAL uint32_t *)queue, *(BL_S *)&bl_shared, (int)blockIdx.x, (LC_GLOBAL unsigned long long *)phase, (LC_GLOBAL uint8_t *)pool, pool_cap, depth);
 }
 
 // Graph_t::trim (reference src/Graph.cc:355-384) + 2-bit packing + quality mask, one wave per read: the lanes look at consecutive
@@ -136,7 +136,9 @@ struct lancet_engine {
   int n_windows = 0, n_reads = 0, n_slots = 0;
   int n_rerun = 0;
   // LDS build kernel: hand-off areas (one per window), per-workgroup scratch
-  DevBuf d_pre, d_blscratch, d_blphase, d_order;
+  DevBuf d_pre, d_blscratch, d_blphase, d_order, d_prepool;
+  uint32_t pool_cap = 0; int ahead_depth = 3;      // graphs built ahead for windows whose k will climb (build_lds.h, build_kernel_body)
+  int n_ahead_built = 0, n_ahead_used = 0;
   bool heavy_first = true;    // LANCET_NO_HEAVY_FIRST=1: windows in batch order
   unsigned long long blphase[16] = {0};
   int n_bslots = 0, n_prebuilt = 0;
@@ -208,7 +210,7 @@ void lancet_engine_destroy(lancet_engine *e) {
   DevBuf *all[] = {&e->d_params, &e->d_batch, &e->d_caps, &e->d_out, &e->d_works, &e->d_chr, &e->d_refstart, &e->d_refoff, &e->d_refasc,
                    &e->d_refcodes, &e->d_readbegin, &e->d_seqoff, &e->d_seq, &e->d_qual, &e->d_label, &e->d_strand, &e->d_mate, &e->d_mapped,
                    &e->d_rinfo, &e->d_name, &e->d_bw, &e->d_gw, &e->d_bases, &e->d_good, &e->d_variants, &e->d_blob, &e->d_counters,
-                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist, &e->d_bx, &e->d_hp, &e->d_varlr, &e->d_bxblob, &e->d_pre, &e->d_blscratch, &e->d_blphase, &e->d_order};
+                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist, &e->d_bx, &e->d_hp, &e->d_varlr, &e->d_bxblob, &e->d_pre, &e->d_blscratch, &e->d_blphase, &e->d_order, &e->d_prepool};
   for (DevBuf *b : all) b->release();
   if (e->evb0) (void)hipEventDestroy(e->evb0);
   if (e->evb1) (void)hipEventDestroy(e->evb1);
@@ -316,7 +318,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   o.n_variants = (LC_GLOBAL uint32_t *)e->d_counters.p; o.n_blob = (LC_GLOBAL uint32_t *)e->d_counters.p + 1; o.queue_head = (LC_GLOBAL uint32_t *)e->d_counters.p + 2;
   o.n_bx = (LC_GLOBAL uint32_t *)e->d_counters.p + 3; o.variants_lr = (LC_GLOBAL lancet_variant_lr *)e->d_varlr.p; o.bx_blob = (LC_GLOBAL uint32_t *)e->d_bxblob.p;
   o.stats = (LC_GLOBAL lancet_window_stats *)e->d_stats.p; o.evt_len = (LC_GLOBAL uint32_t *)e->d_evtlen.p; o.evt_out = (LC_GLOBAL uint32_t *)e->d_evt.p; o.phase = (LC_GLOBAL unsigned long long *)e->d_phase.p; o.win_list = nullptr; o.n_list = 0;
-  o.pre = nullptr;
+  o.pre = nullptr; o.pre_pool = nullptr; o.n_ahead_used = nullptr;
   if (e->prebuild) {
     int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
     e->n_bslots = std::min(nw, cus * 2);
@@ -327,6 +329,10 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     e->heavy_first = getenv("LANCET_NO_HEAVY_FIRST") == nullptr;
     if (e->heavy_first) { ENS(e->d_order, sizeof(uint32_t) * (size_t)nw); o.win_list = (LC_GLOBAL const uint32_t *)e->d_order.p; o.n_list = (uint32_t)nw; }
     o.pre = (LC_GLOBAL const uint8_t *)e->d_pre.p;
+    e->ahead_depth = 3;
+    if (const char *s = getenv("LANCET_AHEAD_DEPTH")) e->ahead_depth = std::max(0, std::min(16, atoi(s)));
+    e->pool_cap = e->ahead_depth > 0 ? (uint32_t)std::max(64, nw / 4) : 0u;
+    if (e->pool_cap) { ENS(e->d_prepool, (size_t)e->pool_cap * PRE_STRIDE); o.pre_pool = (LC_GLOBAL const uint8_t *)e->d_prepool.p; o.n_ahead_used = (LC_GLOBAL uint32_t *)e->d_counters.p + 14; }
   }
   UP(e->d_out, &o, sizeof(o));
   DBG("sync");
@@ -356,7 +362,7 @@ int lancet_engine_submit(lancet_engine *e) {
     HIPCHK(e, hipEventRecord(e->evb0, e->stream));
     hipLaunchKernelGGL(build_kernel, dim3(e->n_bslots), dim3(BL_WG), 0, e->stream, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
                        (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_blscratch.p, (uint32_t *)e->d_counters.p + 8,
-                       (unsigned long long *)e->d_blphase.p);
+                       (unsigned long long *)e->d_blphase.p, (uint8_t *)(e->pool_cap ? e->d_prepool.p : nullptr), e->pool_cap, e->ahead_depth);
     HIPCHK(e, hipGetLastError());
     if (e->heavy_first) {
       hipLaunchKernelGGL(order_kernel, dim3((e->n_windows + 255) / 256), dim3(256), 0, e->stream, (const uint8_t *)e->d_pre.p, e->n_windows, (uint32_t *)e->d_order.p,
@@ -383,9 +389,9 @@ int lancet_engine_wait(lancet_engine *e) {
   HIPCHK(e, hipEventElapsedTime(&e->ms_window, e->ev0, e->ev1));
   if (e->prebuild) {
     HIPCHK(e, hipEventElapsedTime(&e->ms_build, e->evb0, e->evb1));
-    uint32_t bq[2] = {0, 0};
+    uint32_t bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(e, lc_copy(e, bq, (uint32_t *)e->d_counters.p + 8, sizeof(bq), hipMemcpyDeviceToHost));
-    e->n_prebuilt = (int)bq[1];
+    e->n_prebuilt = (int)bq[1]; e->n_ahead_built = (int)bq[3]; e->n_ahead_used = (int)bq[6];
     HIPCHK(e, lc_copy(e, e->blphase, e->d_blphase.p, sizeof(e->blphase), hipMemcpyDeviceToHost));
   }
   e->ms_all = e->ms_window + e->ms_build;
@@ -609,6 +615,26 @@ int lancet_engine_build_phase_times(lancet_engine *e, const unsigned long long *
 }
 // windows of the last run whose first graph came from the LDS build kernel
 int lancet_engine_prebuilt_count(lancet_engine *e) { return e ? e->n_prebuilt : -1; }
+
+// test/tuning hook: the hand-off headers of the last run (status, K, heavy, N per window)
+int lancet_debug_pre_headers(lancet_engine *e, uint32_t *out) {
+  if (!e || !e->uploaded || !e->d_pre.p) return LANCET_E_STATE;
+  std::vector<PreHdr> h(1);
+  for (int w = 0; w < e->n_windows; ++w) {
+    if (hipMemcpy(h.data(), (const uint8_t *)e->d_pre.p + (size_t)w * PRE_STRIDE + PRE_OFF_HDR, sizeof(PreHdr), hipMemcpyDeviceToHost) != hipSuccess) return LANCET_E_STATE;
+    out[4 * w] = h[0].status; out[4 * w + 1] = h[0].K; out[4 * w + 2] = h[0].heavy; out[4 * w + 3] = h[0].N;
+  }
+  return LANCET_OK;
+}
+
+// graphs the build kernel built ahead (a later k of a window whose first k was going to be rejected) / how many of them the
+// window kernel took
+int lancet_engine_ahead_counts(lancet_engine *e, int32_t *built, int32_t *used) {
+  if (!e) return LANCET_E_ARG;
+  if (built) *built = e->n_ahead_built;
+  if (used) *used = e->n_ahead_used;
+  return LANCET_OK;
+}
 
 // number of windows of the last run that needed the worst-case work space (tier 2)
 int lancet_engine_rerun_count(lancet_engine *e) { return e ? e->n_rerun : -1; }

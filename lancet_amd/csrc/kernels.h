@@ -3662,12 +3662,18 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
   if (!pre) return false;
   LC_GLOBAL const uint8_t *area = pre + (size_t)S.w * PRE_STRIDE;
   LC_GLOBAL const PreHdr *H = (LC_GLOBAL const PreHdr *)(area + PRE_OFF_HDR);
-  WG_LANE0 { S.tmp1 = (H->status == PB_BUILT && H->K == k && S.n_builds == 0 && H->N <= LC_CTX(c).C->node_cap && (size_t)H->ncand * (size_t)k <= (size_t)LC_CTX(c).C->qv_cap &&
+  // the window's first graph, or one the build kernel built ahead for a later k of this loop (PreHdr::next)
+  for (int hop = 0; hop < 16 && H->status == PB_BUILT && H->K < k && H->next != 0u && LC_CTX(c).OUT->pre_pool; ++hop) {
+    area = LC_CTX(c).OUT->pre_pool + (size_t)(H->next - 1u) * PRE_STRIDE;
+    H = (LC_GLOBAL const PreHdr *)(area + PRE_OFF_HDR);
+  }
+  WG_LANE0 { S.tmp1 = (H->status == PB_BUILT && H->K == k && H->N <= LC_CTX(c).C->node_cap && (size_t)H->ncand * (size_t)k <= (size_t)LC_CTX(c).C->qv_cap &&
                        H->ncand <= LC_CTX(c).C->surv_cap && (size_t)H->ncand * (size_t)k <= (size_t)LC_CTX(c).C->seq_cap) ? 1 : 0; }
   if (!wg_bcast(&S.tmp1)) return false;
   const uint32_t N = H->N, ncand = H->ncand, nsurv = H->nsurv;
   const int K = k;
   WG_LANE0 {
+    if (S.n_builds > 0 && LC_CTX(c).OUT->n_ahead_used) dev_atomic_add(LC_CTX(c).OUT->n_ahead_used, 1u);
     S.N = N; S.N_last = N; S.O = H->O; S.totalreadbp = (int)H->totalreadbp; S.n_kmers += (unsigned long long)H->n_kmers; ++S.n_builds;
     if (N > S.max_nodes) S.max_nodes = N;
     S.nspecial = 0; S.qv_top = ncand; S.seq_top = ncand * (uint32_t)K; S.tmask = 0; S.tfull = 0; S.prebuilt = 1;
@@ -3701,9 +3707,39 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
     if (n != LC_NIL) { const unsigned long long kk = skey[ci]; W.seq[t] = SD_MAKE(n, i, key_base(&kk, K, i)); }
   }
   const int nrefk = S.reflen - K > 0 ? S.reflen - K + 1 : 0;
-  WG_FOR(i, nrefk) { const uint32_t e = occ_ref[i]; W.occ[i] = ((e & 0x3FFFFFFFu) == PB_NOSURV) ? (dummy | (e & 0x80000000u)) : e; }
+  WG_FOR(i, nrefk) { const uint32_t e = occ_ref[i]; W.occ[i] = (e & PB_GONE) ? (dummy | (e & 0x80000000u)) : e; }
   WG_FOR(i, S.reflen * 2) { ((LC_GLOBAL uint32_t *)W.refcov)[i] = ((LC_GLOBAL const uint32_t *)(area + PRE_OFF_REFCOV))[i]; }
   WG_LANE0 { W.gr[dummy].flags = 0; }
+  // A graph built ahead was built as if it were the window's first: Ref_t::mertable indexed over the whole rawseq.  By now an
+  // earlier k of this window may have trimmed Ref_t::seq to its anchors (markRefEnds, reference src/Graph.cc:2200-2228) before it
+  // was rejected, and indexMers (src/Ref.cc:40-64) runs over that shorter seq at every k: the k-mers outside it
+  // are not in the table, their nodes are not reference nodes (unless another k-mer inside is the same node) and
+  // computeCoverage (src/Ref.cc:173-250) reads 0 for them.  Same rule as build_refcov, applied to what came along.
+  WG_LANE0 { S.tmp1 = (S.seq_t5 != 0 || S.seq_len != S.reflen) ? 1 : 0; }
+  if (wg_bcast(&S.tmp1)) {
+    const int t5 = wg_bcast(&S.seq_t5), L = wg_bcast(&S.seq_len);
+    WG_FOR(i, (N + 31u) / 32u) { W.bitmap[i] = 0; }
+    WG_SYNC_FENCE();
+    WG_FOR(i, L - K > 0 ? L - K : 0) {
+      const int p = t5 + i;
+      if (p < nrefk) { const uint32_t n = occ_ref[p] & 0x3FFFFFFFu; dev_atomic_or(&W.bitmap[n >> 5], 1u << (n & 31u)); }
+    }
+    WG_SYNC_FENCE();
+    WG_FOR(si, nsurv) {
+      const uint32_t n = sid[si]; const uint32_t f = W.gr[n].flags;
+      W.gr[n].flags = ((W.bitmap[n >> 5] >> (n & 31u)) & 1u) ? (f | NF_INMER) : (f & ~(uint32_t)NF_INMER);
+    }
+    WG_FOR(i, S.reflen - K > 0 ? S.reflen - K : 0) {
+      const uint32_t n = occ_ref[i] & 0x3FFFFFFFu;
+      if (!((W.bitmap[n >> 5] >> (n & 31u)) & 1u)) {
+        if (i == 0) { for (int j = 0; j < K; ++j) for (int q = 0; q < 4; ++q) W.refcov[4 * j + q] = 0; }
+        else { for (int q = 0; q < 4; ++q) W.refcov[4 * (i + K - 1) + q] = 0; }
+      }
+    }
+    if (LC_CTX(c).C->evt_cap) {                                   // trace only: nodes that hold a reference k-mer (markRefNodes' count)
+      WG_LANE0 { uint32_t cnt = 0; for (uint32_t i = 0; i < (N + 31u) / 32u; ++i) cnt += (uint32_t)dev_popc(W.bitmap[i]); S.pre_refn = cnt; }
+    }
+  }
   WG_SYNC_FENCE();
   return true;
 }
@@ -3807,7 +3843,9 @@ DEV void process_window(Ctx &c, int w) {
           LC_GLOBAL uint32_t *tc = W.scratch;
           for (int q = 0; q <= S.numcomp; ++q) tc[q] = 0;
           for (uint32_t i = 0; i < S.M; ++i) { const uint32_t n = W.order[i]; if (W.gr[n].flags & NF_INMER) tc[W.gr[n].comp] = 1; }
-          for (int q = 1; q <= S.numcomp; ++q) if (tc[q]) evt(c, EV_CCID, (uint32_t)q);
+          int rc = 0;
+          for (int q = 1; q <= S.numcomp; ++q) if (tc[q]) { evt(c, EV_CCID, (uint32_t)q); ++rc; }
+          S.refcomp = rc;                                       // (= the count that came along, unless Ref_t::seq has been trimmed since)
           evt(c, EV_CCEND, (uint32_t)S.numcomp, (uint32_t)S.refcomp);
         }
       }

@@ -155,7 +155,7 @@ struct CmpRec {
 #define PB_CCAP 2048          /* candidates: nodes not decided by their occurrence count alone                 */
 #define PB_SCAP 2048          /* survivors of the first removeLowCov                                          */
 #define PB_QVCAP 32768        /* (candidate, k-mer position) entries of per-position quality counts            */
-#define PB_NOSURV 0x3FFFFFFFu /* occ_ref entry of a reference k-mer whose node did not survive                 */
+#define PB_GONE 0x40000000u   /* occ_ref: the node of this reference k-mer did not survive the first removeLowCov (its id is still in the low bits) */
 #define PB_NOT_BUILT 0u
 #define PB_BUILT 1u
 struct PreHdr {
@@ -170,7 +170,9 @@ struct PreHdr {
   uint32_t numcomp, refcomp;  /* markConnectedComponents: components, components that hold a reference k-mer     */
   uint32_t heavy;             /* scheduling hint only: a read holds the same k-mer twice (tandem duplication: the graph will have a cycle and k will climb) */
   uint32_t mapped;            /* countMappedReads of the window (valid with have_rep)                            */
-  uint32_t pad[11];
+  uint32_t next;              /* 1 + index of the pool area that holds this window's graph at the next k of its loop (built ahead
+                                 because `heavy` says this k will be rejected), 0: none                          */
+  uint32_t pad[10];
 };
 #define PRE_OFF_HDR 0u
 #define PRE_OFF_OCCREF 128u                                   /* u32[LC_MAXW]   node | ori << 31 per reference offset   */
@@ -254,4 +256,6 @@ struct DevOut {
   LC_GLOBAL const uint32_t *win_list;  /* when non-null: the windows to process (re-run of overflowed windows)   */
   uint32_t n_list;
   LC_GLOBAL const uint8_t *pre;        /* hand-off areas of the LDS build kernel (PRE_STRIDE bytes per window), or null */
+  LC_GLOBAL const uint8_t *pre_pool;   /* areas of graphs built ahead at later k (PreHdr::next chains into it), or null */
+  LC_GLOBAL uint32_t *n_ahead_used;    /* atomic: window builds that took a graph built ahead                           */
 };

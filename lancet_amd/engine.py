@@ -48,6 +48,7 @@ def lib():
         L.lancet_engine_trace.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32)]
         L.lancet_engine_rerun_count.argtypes = [C.c_void_p]
         L.lancet_engine_prebuilt_count.argtypes = [C.c_void_p]
+        L.lancet_engine_ahead_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.lancet_engine_build_phase_times.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64))]
         L.lancet_engine_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
         L.lancet_engine_kernel_name.restype = C.c_char_p
@@ -169,6 +170,12 @@ class Engine:
 
     def prebuilt_count(self) -> int:
         return int(self.L.lancet_engine_prebuilt_count(self.h))
+
+    def ahead_counts(self):
+        """(graphs the build kernel built ahead at a later k, how many the window kernel took)"""
+        b, u = C.c_int32(), C.c_int32()
+        self._chk(self.L.lancet_engine_ahead_counts(self.h, C.byref(b), C.byref(u)))
+        return b.value, u.value
 
     def rerun_count(self) -> int:
         return int(self.L.lancet_engine_rerun_count(self.h))

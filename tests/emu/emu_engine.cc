@@ -21,7 +21,7 @@ struct EmuResult {
   std::vector<uint32_t> evt_len, evt;
   uint32_t evt_cap;
   uint32_t n_variants, n_blob;
-  uint32_t n_prebuilt;
+  uint32_t n_prebuilt, n_ahead_built, n_ahead_used;
 };
 
 extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batch *b, uint32_t evt_cap) {
@@ -57,17 +57,21 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   O.variants_lr = res->lr.data(); O.bx_blob = res->bx_blob.data(); O.n_bx = &nx;
   O.queue_head = &qh; O.phase = nullptr; O.win_list = nullptr; O.n_list = 0; O.evt_len = res->evt_len.data(); O.evt_out = res->evt.data();
   // ---- the LDS build kernel first (one emulated workgroup), unless switched off: LANCET_NO_PREBUILD=1 runs the general build for every window
-  std::vector<uint8_t> pre, blscr;
-  O.pre = nullptr;
-  res->n_prebuilt = 0;
+  std::vector<uint8_t> pre, blscr, pool;
+  O.pre = nullptr; O.pre_pool = nullptr; O.n_ahead_used = &res->n_ahead_used;
+  res->n_prebuilt = 0; res->n_ahead_built = 0; res->n_ahead_used = 0;
   if (!P->lr_mode && !getenv("LANCET_NO_PREBUILD") && b->n_windows > 0) {
     pre.assign((size_t)b->n_windows * PRE_STRIDE, 0xCD); blscr.assign(BL_SCRATCH_BYTES + 256, 0xCD);
     static thread_local BlShared BS;
     memset(&BS, 0xCD, sizeof(BS));
-    uint32_t bq[2] = {0, 0};
-    build_kernel_body(P, &B, &C, pre.data(), blscr.data(), bq, BS, 0, nullptr);
-    O.pre = pre.data();
-    res->n_prebuilt = bq[1];
+    uint32_t bq[4] = {0, 0, 0, 0};
+    const int depth = getenv("LANCET_AHEAD_DEPTH") ? atoi(getenv("LANCET_AHEAD_DEPTH")) : 3;
+    const uint32_t pool_cap = depth > 0 ? (uint32_t)(b->n_windows / 4 + 8) : 0u;
+    if (pool_cap) pool.assign((size_t)pool_cap * PRE_STRIDE, 0xCD);
+    build_kernel_body(P, &B, &C, pre.data(), blscr.data(), bq, BS, 0, nullptr, pool_cap ? pool.data() : nullptr, pool_cap, depth);
+    O.pre = pre.data(); O.pre_pool = pool_cap ? pool.data() : nullptr;
+    res->n_prebuilt = bq[1]; res->n_ahead_built = bq[3];
+    if (getenv("LANCET_EMU_HEAVY")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); if (H->status == PB_BUILT && H->heavy) fprintf(stderr, "[emu] heavy %d K %d\n", w, H->K); }
     if (getenv("LANCET_EMU_WHY")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); if (H->status != PB_BUILT) fprintf(stderr, "[emu] window %d not prebuilt: why %u\n", w, H->why); }
   }
   static thread_local WinShared S;
@@ -86,6 +90,8 @@ extern "C" const lancet_window_stats *lancet_emu_stats(void *h) { return ((EmuRe
 extern "C" const uint32_t *lancet_emu_evt_len(void *h) { return ((EmuResult *)h)->evt_len.data(); }
 extern "C" const uint32_t *lancet_emu_evt(void *h) { return ((EmuResult *)h)->evt.data(); }
 extern "C" uint32_t lancet_emu_n_prebuilt(void *h) { return ((EmuResult *)h)->n_prebuilt; }
+extern "C" uint32_t lancet_emu_n_ahead_built(void *h) { return ((EmuResult *)h)->n_ahead_built; }
+extern "C" uint32_t lancet_emu_n_ahead_used(void *h) { return ((EmuResult *)h)->n_ahead_used; }
 extern "C" void lancet_emu_free(void *h) { delete (EmuResult *)h; }
 
 // repeat_scan both ways (bit-parallel LDS version vs the byte-wise restatement) for the unit test

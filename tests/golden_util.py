@@ -105,3 +105,17 @@ def golden_vcf(name: str) -> str:
 
 def golden_trace(name: str) -> str:
     return open(os.path.join(GOLDEN, f"{name}.trace.txt")).read()
+
+
+def load_batches_npz(name: str):
+    """Window batches stored as arrays (tools/make_ahead_fixture.py): [WindowBatch, ...]"""
+    from lancet_amd import frontend
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    fields = ("chr_id", "ref_start", "ref_off", "ref_bases", "read_begin", "seq_off", "seq", "qual", "label", "strand", "mate", "mapped", "name_rank")
+    out, i = [], 0
+    while f"p{i}_hdr" in z:
+        kw = {f: z[f"p{i}_{f}"] for f in fields}
+        hdr = [str(x) for x in z[f"p{i}_hdr"]]
+        out.append(frontend.WindowBatch(n_windows=len(hdr), hdr=hdr, chrom=[str(x) for x in z[f"p{i}_chrom"]], **kw))
+        i += 1
+    return out

@@ -267,3 +267,51 @@ def test_banded_alignment_equals_full_matrix_and_oracle():
             assert band == full, (s, t, band, full)
         assert run(s, t, 0) == full
     assert n_band > 60 and n_refused > 5, (n_band, n_refused)
+
+
+def _same_as_oracle(batch, p, trace=True):
+    v, st, tr = emu.run(batch, p, evt_cap=1 << 17)
+    ov, ost, otr = oracle.run(batch, p, verbose=True)
+    key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
+    assert v == ov
+    assert [key(s) for s in st] == [key(s) for s in ost]
+    if trace:
+        assert gu.digest_trace(tr) == gu.digest_trace(otr)
+    return st
+
+
+def test_lds_build_kernel_and_graphs_built_ahead_on_the_bench_workload(monkeypatch):
+    """The two-kernel path on the kind of windows bench.py measures (30x/30x scan): every window's first graph comes from the
+    LDS build kernel, the windows whose k is going to be rejected get the next graphs built ahead and the window kernel takes
+    them; records, stats and the stage trace equal the oracle's.  Then the same windows with nothing built ahead
+    (LANCET_AHEAD_DEPTH=0) and with no LDS build at all (LANCET_NO_PREBUILD): same results -- what is built where is
+    scheduling only."""
+    from lancet_amd import workload
+    b = workload.make_scan_batch(400, 30, 30, seed=5)
+    p = abi.default_params()
+    st = _same_as_oracle(b, p)
+    extra = sum(s["n_builds"] - 1 for s in st)
+    assert emu.LAST_PREBUILT[0] == 400
+    assert extra >= 10 and emu.LAST_AHEAD[1] >= extra // 2 and emu.LAST_AHEAD[0] <= 3 * extra, (extra, emu.LAST_AHEAD)
+    base = emu.run(b, p, evt_cap=1 << 17)
+    monkeypatch.setenv("LANCET_AHEAD_DEPTH", "0")
+    plain = emu.run(b, p, evt_cap=1 << 17)
+    assert emu.LAST_AHEAD == [0, 0] and emu.LAST_PREBUILT[0] == 400
+    monkeypatch.setenv("LANCET_NO_PREBUILD", "1")
+    general = emu.run(b, p, evt_cap=1 << 17)
+    assert emu.LAST_PREBUILT[0] == 0
+    for other in (plain, general):
+        assert other[0] == base[0] and other[1] == base[1] and gu.digest_trace(other[2]) == gu.digest_trace(base[2])
+
+
+def test_graph_built_ahead_is_adjusted_to_the_trimmed_reference_table():
+    """tests/golden/ahead_trim.npz (tools/make_ahead_fixture.py): windows where a graph built ahead is taken after the rejected
+    k had trimmed Ref_t::seq; the table of reference k-mers is re-indexed over the trimmed seq at every k (reference
+    src/Ref.cc:40-64), which changes which nodes are reference nodes and the coverage computeCoverage reads for the
+    variants at the window's edges."""
+    p = abi.default_params()
+    used = 0
+    for b in gu.load_batches_npz("ahead_trim.npz"):
+        _same_as_oracle(b, p)
+        used += emu.LAST_AHEAD[1]
+    assert used >= 4

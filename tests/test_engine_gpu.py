@@ -47,6 +47,23 @@ def test_engine_matches_oracle_and_reference(case):
     eng.close()
 
 
+def test_graphs_built_ahead_after_the_reference_table_was_trimmed():
+    """tests/golden/ahead_trim.npz: windows of the bench workload where the window kernel takes a graph the LDS build kernel built
+    ahead, after the rejected k had trimmed Ref_t::seq (SURVEY.md H6): records, stats and trace equal the oracle's."""
+    p = abi.default_params()
+    used = 0
+    for batch in gu.load_batches_npz("ahead_trim.npz"):
+        eng = engine.Engine(p, device=0, trace_words=1 << 17)
+        variants, stats = eng.process(batch)
+        ov, ostats, otr = oracle.run(batch, p, verbose=True)
+        key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
+        assert variants == ov and [key(s) for s in stats] == [key(s) for s in ostats]
+        assert gu.digest_trace(eng.trace_text()) == gu.digest_trace(otr)
+        used += eng.ahead_counts()[1]
+        eng.close()
+    assert used >= 4
+
+
 def test_engine_is_deterministic_and_order_independent():
     """Same windows in a different batch order / slot assignment give the same per-window records."""
     meta, batch, kept, (min_k, max_k) = gu.case_batch("tile30")

@@ -92,6 +92,10 @@ CASES = {
                    palindromes=((1700, 6), (1990, 7), (2300, 8), (2610, 6), (2900, 7), (3205, 9), (3500, 6), (3800, 8), (4100, 7), (4400, 6),
                                 (2455, 12), (3350, 11))),
               "chr22:1300-5000", ["--min-k", "12"]),
+    # duplications at a coverage whose windows fit the LDS build kernel (<= 512 reads): k climbs through several graphs per window,
+    # most of them built ahead (build_lds.h, build_kernel_body) after Ref_t::seq was trimmed by the rejected k
+    "dups20": (dict(ref_len=8000, cov_t=22, cov_n=18, ref_seed=205, tumor_seed=215, normal_seed=225, dup_prob=1.0,
+                    somatic_every=600, germline_every=500, read_len=100), "chr22:1000-6500", []),
     "dups": (dict(ref_len=8000, cov_t=40, cov_n=40, ref_seed=5, tumor_seed=15, normal_seed=25, dup_prob=1.0,
                   somatic_every=600, germline_every=500, read_len=100), "chr22:1000-6500", []),
 }

@@ -54,3 +54,17 @@ import numpy as _np
 order_ = _np.argsort(-ptw)
 print("slowest windows (ms, builds, final_k):", [(round(1000 * float(ptw[i]), 2), st[i]["n_builds"], st[i]["final_k"]) for i in order_[:12]])
 print("window time percentiles ms: p50 %.2f p90 %.2f p99 %.2f max %.2f ; windows with > 1 build: %d" % (1000 * _np.percentile(ptw, 50), 1000 * _np.percentile(ptw, 90), 1000 * _np.percentile(ptw, 99), 1000 * ptw.max(), sum(1 for s_ in st if s_["n_builds"] > 1)))
+if os.environ.get("QUICK_SLOW"):
+    ns = int(os.environ["QUICK_SLOW"])
+    ph = eng.phase_times()
+    sl = ph[order_[:ns]].sum(axis=0)
+    print(f"phase split of the {ns} slowest windows (total {sl.sum():.3f} s):")
+    for i, n in enumerate(names):
+        print(f"  slow phase {i:2d} {n:36s} {sl[i]:9.3f} s  {100 * sl[i] / sl.sum():5.1f} %")
+    multi = [i for i, s_ in enumerate(st) if s_["n_builds"] > 1]
+    ml = ph[multi].sum(axis=0)
+    print(f"phase split of the {len(multi)} windows with > 1 build (total {ml.sum():.3f} s, {100 * ml.sum() / tot:.1f} % of all slot time):")
+    for i, n in enumerate(names):
+        print(f"  multi phase {i:2d} {n:36s} {ml[i]:9.3f} s  {100 * ml[i] / ml.sum():5.1f} %")
+    import collections
+    print("builds histogram:", sorted(collections.Counter(s_["n_builds"] for s_ in st).items()))
