@@ -245,7 +245,8 @@ def main():
                        "windows_per_gpu": args.windows, "coverage": [args.cov, args.cov], "reads_per_gpu": int(batch.n_reads),
                        "records_rank0_contig": len(variants), "records_sha256_rank0_contig": h.hexdigest()[:16],
                        "slots_in_flight": n_slots, "batches_in_flight": nfl, "upload_first_ms": round(upload_first_ms, 1), "upload_ms": round(up_ms, 1),
-                       "windows_first_graph_in_lds": eng.prebuilt_count(), "windows_rerun_worst_case_tier": eng.rerun_count(), "workspace_MB_per_slot": round(slot_bytes / 2 ** 20, 1),
+                       "windows_first_graph_in_lds": eng.prebuilt_count(), "graphs_built_ahead": eng.ahead_counts()[0], "graphs_built_ahead_used": eng.ahead_counts()[1],
+                       "windows_rerun_worst_case_tier": eng.rerun_count(), "workspace_MB_per_slot": round(slot_bytes / 2 ** 20, 1),
                        "kernel_ms": per_kernel},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": None,
