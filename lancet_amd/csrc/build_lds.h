@@ -258,7 +258,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   // ---- reference repeat scan -> the first k of the loop that reaches buildgraph (Microassembler.cc:118-131)
   if (rep) { WG_LANE0 { S.repE = rep->refE; S.repM = rep->refM; } WG_SYNC(); }
   else repeat_scan_min((volatile LC_LDS unsigned long long *)(S.big + 4 * (BL_RMAX + 8)), refc, reflen, P->max_mismatch, P->min_k, P->min_k + 1, (volatile LC_LDS int *)&S.repE, (volatile LC_LDS int *)&S.repM,
-                  (const LC_LDS uint32_t *)&S.bases[S.rdo[nr]]);     // (the reference is in LDS already, 2 bits per base: no N here)
+                  (const LC_LDS uint32_t *)&S.bases[S.rdo[nr]], (volatile LC_LDS int *)&S.flagged);     // (the reference is in LDS already, 2 bits per base: no N here)
   WG_LANE0 {
     int K = 0;
     for (int k = kmin; k <= P->max_k; k += 2) {

@@ -44,6 +44,7 @@ struct WinShared {
   uint32_t max_nodes;
   int n_builds, final_k, status;
   int tmp0, tmp1, tmp2, tmp3, hasN;
+  int rs_bad;                          // repeat_scan_min: the 2-bit staging met a code above 3
   int nitems;                          // work items of the per-occurrence passes (build_items)
   uint32_t part[LANCET_WG + 1];
   uint32_t part2[LANCET_WG + 1];                 // second scan scratch (part[0..7] carry the path loop's state)
@@ -325,71 +326,92 @@ DEVNI void repeat_scan(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL cons
 //   windows with i mismatches left of the run and mm - i right of it: (prev_i, next_{mm-i}) exclusive, i = 0..mm.
 // 20 ALU operations per word instead of 15 per mismatch position (12 of 16 positions mismatch on random sequence).
 // `packed2`: when non-null the string is taken from there (2 bits per base, 16 bases per word, no N) instead of from s.
-DEVNI void repeat_scan_min(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL const uint8_t *s, int len, int mm, int lminE, int lminM,
-                           volatile LC_LDS int *outE, volatile LC_LDS int *outM, const LC_LDS uint32_t *packed2 = nullptr) {
-  int rmin = lminE;
-  { const int rm = (lminM - mm + mm) / (mm + 1); if (rm < rmin) rmin = rm; }       // ceil((lminM - mm) / (mm + 1))
-  if (mm > 7 || mm < 0 || len + 48 > 16 * LC_RS_WORDS || rmin < 3) { repeat_scan(rsbuf, s, len, mm, outE, outM); return; }
-  WG_LANE0 { *outE = 0; *outM = 0; }
-  const int nwords = len / 16 + 3;
+// B = bits per base in the staged copy: 4 (any code, 16 positions per 64-bit word) or 2 (codes 0..3 only, 32 positions per word:
+// half the words to walk).  The 2-bit form is used whenever the string holds no N; `bad2` (LDS) is raised by the staging pass
+// of the 2-bit form when it meets a code above 3, and the caller then runs the 4-bit form.
+template <int B>
+DEV void repeat_scan_min_t(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL const uint8_t *s, int len, int mm, int rmin,
+                           volatile LC_LDS int *outE, volatile LC_LDS int *outM, const LC_LDS uint32_t *packed2, volatile LC_LDS int *bad2) {
+  constexpr int PW = 64 / B, SH = B == 4 ? 4 : 5, LB = B == 4 ? 2 : 1;
+  constexpr unsigned long long M1 = B == 4 ? 0x1111111111111111ULL : 0x5555555555555555ULL;
+  const int nwords = len / PW + 3;
   const bool al4 = (((size_t)s) & 3u) == 0;
   WG_FOR(w, nwords) {
     unsigned long long v = 0;
-    if (packed2) {                                                 // 2-bit groups spread to nibbles
-      unsigned long long x = 16 * w < len ? (unsigned long long)packed2[w] : 0ULL;
-      x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL; x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
-      x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL; x = (x | (x << 2)) & 0x3333333333333333ULL;
-      if (len - 16 * w < 16 && len - 16 * w > 0) x &= (1ULL << (4 * (len - 16 * w))) - 1ULL;
-      v = x;
-    } else if (al4 && 16 * w + 16 <= len) {                        // four aligned 4-byte loads, issued together
-      LC_GLOBAL const uint32_t *q = (LC_GLOBAL const uint32_t *)(s + 16 * w);
-      const uint32_t a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
-      const uint32_t aa[4] = {a0, a1, a2, a3};
-      for (int t = 0; t < 4; ++t) for (int j = 0; j < 4; ++j) v |= (unsigned long long)((aa[t] >> (8 * j)) & 15u) << (4 * (4 * t + j));
+    if (B == 2) {
+      if (packed2) {
+        const int nw32 = (len + 15) >> 4;
+        const unsigned long long lo = 2 * w < nw32 ? (unsigned long long)packed2[2 * w] : 0ULL, hi = 2 * w + 1 < nw32 ? (unsigned long long)packed2[2 * w + 1] : 0ULL;
+        v = lo | (hi << 32);
+        if (len - PW * w < PW) v &= len - PW * w > 0 ? (1ULL << (2 * (len - PW * w))) - 1ULL : 0ULL;
+      } else if (al4 && PW * w + PW <= len) {                      // eight aligned 4-byte loads, issued together
+        LC_GLOBAL const uint32_t *q = (LC_GLOBAL const uint32_t *)(s + PW * w);
+        const uint32_t a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5], a6 = q[6], a7 = q[7];
+        const uint32_t aa[8] = {a0, a1, a2, a3, a4, a5, a6, a7};
+        uint32_t any = 0;
+        for (int t = 0; t < 8; ++t) { any |= aa[t]; for (int j = 0; j < 4; ++j) v |= (unsigned long long)((aa[t] >> (8 * j)) & 3u) << (2 * (4 * t + j)); }
+        if (any & 0xFCFCFCFCu) *bad2 = 1;
+      } else {
+        for (int j = 0; j < PW; ++j) { const int idx = PW * w + j; if (idx < len) { const uint32_t cde = s[idx]; if (cde > 3u) *bad2 = 1; v |= (unsigned long long)(cde & 3u) << (2 * j); } }
+      }
     } else {
-      for (int j = 0; j < 16; ++j) { int idx = 16 * w + j; if (idx < len) v |= (unsigned long long)(s[idx] & 15u) << (4 * j); }
+      if (packed2) {                                               // 2-bit groups spread to nibbles
+        unsigned long long x = 16 * w < len ? (unsigned long long)packed2[w] : 0ULL;
+        x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL; x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+        x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL; x = (x | (x << 2)) & 0x3333333333333333ULL;
+        if (len - 16 * w < 16 && len - 16 * w > 0) x &= (1ULL << (4 * (len - 16 * w))) - 1ULL;
+        v = x;
+      } else if (al4 && 16 * w + 16 <= len) {                      // four aligned 4-byte loads, issued together
+        LC_GLOBAL const uint32_t *q = (LC_GLOBAL const uint32_t *)(s + 16 * w);
+        const uint32_t a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+        const uint32_t aa[4] = {a0, a1, a2, a3};
+        for (int t = 0; t < 4; ++t) for (int j = 0; j < 4; ++j) v |= (unsigned long long)((aa[t] >> (8 * j)) & 15u) << (4 * (4 * t + j));
+      } else {
+        for (int j = 0; j < 16; ++j) { int idx = 16 * w + j; if (idx < len) v |= (unsigned long long)(s[idx] & 15u) << (4 * j); }
+      }
     }
     rsbuf[w] = v;
   }
   WG_SYNC();
+  if (B == 2 && wg_bcast(bad2)) return;                           // a code above 3: the caller runs the 4-bit form
   const LC_LDS unsigned long long *rs = (const LC_LDS unsigned long long *)rsbuf;
   const int nsh = len > 1 ? len - 1 : 0;
   // shift d = item + 1: a lane that gets a second item gets a short one (the longest shifts are the first items)
   WG_FOR(it, nsh) {
     const int d = it + 1;
     const int lenE = len - 1 - d, lenM = len - d;
-    // mismatch mask of word w of this shift: bit 4j set <=> position 16 w + j mismatches (positions >= lenM read as mismatches)
+    // mismatch mask of word w of this shift: bit B j set <=> position PW w + j mismatches (positions >= lenM read as mismatches)
     auto NE = [&](int w) -> unsigned long long {
-      const int p0 = w << 4;
-      const int wb = (p0 + d) >> 4, sb = ((p0 + d) & 15) * 4;
+      const int p0 = w << SH;
+      const int wb = (p0 + d) >> SH, sb = ((p0 + d) & (PW - 1)) * B;
       const unsigned long long a = rs[w];
       const unsigned long long b = sb ? ((rs[wb] >> sb) | (rs[wb + 1] << (64 - sb))) : rs[wb];
       const unsigned long long x = a ^ b;
-      unsigned long long ne = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x1111111111111111ULL;
-      if (lenM - p0 < 16) ne |= (lenM - p0 <= 0) ? 0x1111111111111111ULL : (0x1111111111111111ULL << (4 * (lenM - p0)));
+      unsigned long long ne = B == 4 ? ((x | (x >> 1) | (x >> 2) | (x >> 3)) & M1) : ((x | (x >> 1)) & M1);
+      if (lenM - p0 < PW) ne |= (lenM - p0 <= 0) ? M1 : (M1 << (B * (lenM - p0)));
       return ne;
     };
     auto prev_mis = [&](int pos) -> int {                        // largest mismatch position < pos, or -1
-      int w = (pos - 1) >> 4;
+      int w = (pos - 1) >> SH;
       if (pos <= 0) return -1;
       unsigned long long m = NE(w);
-      const int hi = pos - (w << 4);                             // positions [0, hi) of the word
-      if (hi < 16) m &= (1ULL << (4 * hi)) - 1ULL;
+      const int hi = pos - (w << SH);                            // positions [0, hi) of the word
+      if (hi < PW) m &= (1ULL << (B * hi)) - 1ULL;
       while (true) {
-        if (m) return (w << 4) + ((63 - __builtin_clzll(m)) >> 2);
+        if (m) return (w << SH) + ((63 - __builtin_clzll(m)) >> LB);
         if (--w < 0) return -1;
         m = NE(w);
       }
     };
     auto next_mis = [&](int pos) -> int {                        // smallest mismatch position > pos, or lenM
-      int w = (pos + 1) >> 4;
+      int w = (pos + 1) >> SH;
       if (pos + 1 >= lenM) return lenM;
       unsigned long long m = NE(w);
-      const int lo = pos + 1 - (w << 4);
-      if (lo > 0) m &= ~((1ULL << (4 * lo)) - 1ULL);
+      const int lo = pos + 1 - (w << SH);
+      if (lo > 0) m &= ~((1ULL << (B * lo)) - 1ULL);
       while (true) {
-        if (m) { const int q = (w << 4) + (__builtin_ctzll(m) >> 2); return q < lenM ? q : lenM; }
-        if ((++w << 4) >= lenM) return lenM;
+        if (m) { const int q = (w << SH) + (__builtin_ctzll(m) >> LB); return q < lenM ? q : lenM; }
+        if ((++w << SH) >= lenM) return lenM;
         m = NE(w);
       }
     };
@@ -411,28 +433,28 @@ DEVNI void repeat_scan_min(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL 
       ++nc;
     };
     int run = 0;                                                   // matches ending just before the current word
-    const int nw = (lenM + 15) >> 4;
+    const int nw = (lenM + PW - 1) >> SH;
     for (int w = 0; w < nw; ++w) {
       const unsigned long long ne = NE(w);
-      const int p0 = w << 4;
-      if (ne == 0) { run += 16; continue; }
-      const int q1 = __builtin_ctzll(ne) >> 2, ql = (63 - __builtin_clzll(ne)) >> 2;
+      const int p0 = w << SH;
+      if (ne == 0) { run += PW; continue; }
+      const int q1 = __builtin_ctzll(ne) >> LB, ql = (63 - __builtin_clzll(ne)) >> LB;
       if (run + q1 >= rmin) note(p0 - run, p0 + q1);
-      if (rmin <= 14 && ql - q1 > rmin) {                          // a run of >= rmin matches between two mismatches of this word?
-        const unsigned long long mt = (~ne) & 0x1111111111111111ULL;
+      if (rmin <= PW - 2 && ql - q1 > rmin) {                      // a run of >= rmin matches between two mismatches of this word?
+        const unsigned long long mt = (~ne) & M1;
         unsigned long long t = mt;
-        for (int i = 1; i < rmin; ++i) t &= (mt >> (4 * i));
-        t &= ~((2ULL << (4 * q1)) - 1ULL);                         // starts after the first mismatch ...
-        t &= (1ULL << (4 * ql)) - 1ULL;                            // ... and before the last one
+        for (int i = 1; i < rmin; ++i) t &= (mt >> (B * i));
+        t &= ~((2ULL << (B * q1)) - 1ULL);                         // starts after the first mismatch ...
+        t &= (1ULL << (B * ql)) - 1ULL;                            // ... and before the last one
         if (t) {
           unsigned long long m = ne & (ne - 1ULL);
           int prevq = q1;
-          while (m) { const int q = __builtin_ctzll(m) >> 2; m &= m - 1ULL; if (q - prevq - 1 >= rmin) note(p0 + prevq + 1, p0 + q); prevq = q; }
+          while (m) { const int q = __builtin_ctzll(m) >> LB; m &= m - 1ULL; if (q - prevq - 1 >= rmin) note(p0 + prevq + 1, p0 + q); prevq = q; }
         }
       }
-      run = 15 - ql;
+      run = PW - 1 - ql;
     }
-    if (run >= rmin) note(lenM - run, lenM);                       // (a last word without a mismatch: lenM a multiple of 16)
+    if (run >= rmin) note(lenM - run, lenM);                       // (a last word without a mismatch: lenM a multiple of PW)
     for (int j = 0; j < 6; ++j) {
       if (j < nc) { const uint32_t v = j == 0 ? c0 : j == 1 ? c1 : j == 2 ? c2 : j == 3 ? c3 : j == 4 ? c4 : c5; run_end((int)(v >> 16), (int)(v & 0xFFFFu)); }
     }
@@ -440,6 +462,22 @@ DEVNI void repeat_scan_min(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL 
     if (bestM > 0) dev_atomic_max((LC_LDS uint32_t *)outM, (uint32_t)bestM);
   }
   WG_SYNC();
+}
+// `bits2`: LDS word the 2-bit form may use as its "met an N" flag; null: 4-bit form at once (a string known to hold N)
+DEVNI void repeat_scan_min(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL const uint8_t *s, int len, int mm, int lminE, int lminM,
+                           volatile LC_LDS int *outE, volatile LC_LDS int *outM, const LC_LDS uint32_t *packed2 = nullptr, volatile LC_LDS int *bits2 = nullptr) {
+  int rmin = lminE;
+  { const int rm = (lminM - mm + mm) / (mm + 1); if (rm < rmin) rmin = rm; }       // ceil((lminM - mm) / (mm + 1))
+  if (mm > 7 || mm < 0 || len + 48 > 16 * LC_RS_WORDS || rmin < 3) { repeat_scan(rsbuf, s, len, mm, outE, outM); return; }
+  WG_LANE0 { *outE = 0; *outM = 0; if (bits2) *bits2 = 0; }
+  WG_SYNC();
+  if (bits2) {
+    repeat_scan_min_t<2>(rsbuf, s, len, mm, rmin, outE, outM, packed2, bits2);
+    if (!wg_bcast(bits2)) return;
+    WG_LANE0 { *outE = 0; *outM = 0; }
+    WG_SYNC();
+  }
+  repeat_scan_min_t<4>(rsbuf, s, len, mm, rmin, outE, outM, packed2, nullptr);
 }
 
 // exclusive prefix sum of a[0..n) in place; returns total in part[LANCET_WG] (default: S.part)
@@ -2213,7 +2251,10 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
     W.cmp[n].pad[0] = H; W.cmp[n].pad[1] = 1u | (st_j << 1) | (edir << 2);
     W.gr[n].flags = r.flags | NF_DEAD; W.todo[n] = 1;
   }
-  WG_SYNC_FENCE();
+  // (Barriers, not agent-scope fences, between these passes: plain stores and loads of ONE wave through its CU's L1 stay ordered;
+  //  only words updated by atomics -- performed at L2 -- must then be read past the L1 (ld2).  A __threadfence() writes back /
+  //  invalidates across the XCDs' L2s and was measured at ~4 % of the kernel per fence and window.)
+  WG_SYNC();
   // ---- one lane per head: the merges' arithmetic in merge order, the new deque, the new edge list
   WG_FOR(i, M) {
     const uint32_t cnt = hs[i + 1] - hs[i];
@@ -2229,7 +2270,7 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
     uint32_t fl = G.flags, nkmT = G.nkmT;
     LC_GLOBAL const uint32_t *sl = ord + 4 * (size_t)hs[i];
     {
-      const lc_u4 ha = ldg4(hacc + 4 * (size_t)i);
+      lc_u4 ha; ha.x = ld2(&hacc[4 * (size_t)i]); ha.y = ld2(&hacc[4 * (size_t)i + 1]); ha.z = ld2(&hacc[4 * (size_t)i + 2]); ha.w = ld2(&hacc[4 * (size_t)i + 3]);
       if ((int)ha.x < mn) mn = (int)ha.x;
       if ((int)ha.y < mq) mq = (int)ha.y;
       fl |= ha.z; nkmT += ha.w;
@@ -2277,7 +2318,7 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
     G.mincov = mn; G.mincovqv = mq; G.cov[0] = nc0; G.cov[1] = nc1; G.cov[2] = nc2; G.cov[3] = nc3;
     G.flags = fl; G.nkm += cnt; G.nkmT = nkmT;
   }
-  WG_SYNC_FENCE();
+  WG_SYNC();
   // ---- every live node of the component: the head's new list / its own one, edges into an absorbed node redirected to its head
   //      (the orientation the edge arrives in flips when the absorbed node's frame was flipped against the head's: updateEdge)
   WG_FOR(i, M) {
@@ -2298,7 +2339,7 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
     G.necnt = (uint32_t)cnt;
   }
   WG_LANE0 { S.seq_top = top + need; S.tmp1 = (int)nabs; S.tmp2 = 1; }
-  WG_SYNC_FENCE();
+  WG_SYNC();
   return true;
 }
 
@@ -2537,6 +2578,148 @@ DEVNI void remove_short_links(Ctx &c, int comp) {                     // referen
   print_stats(c, comp);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// removeLowCov / removeTips / removeShortLinks / compress of the cleaned component with the whole wave doing the looking.
+// The reference walks the whole table per pass and removes / merges as it goes, so what a pass does to a node can depend
+// on what it did earlier in the same walk (a removal lowers the neighbours' degrees).  The part of each pass's test that
+// CANNOT change during the walk (component, special node, string length, coverage minima -- and for compress: which
+// links are mergeable, because a merge only redirects edges and never makes another link mergeable) is evaluated by all
+// lanes, the nodes that pass are compacted in table order, and lane 0 then walks only those with the live part of the test
+// (the degree; compress_node's own checks).  A table walk is ~2 dependent round trips per node; the lists are a few
+// nodes long.  cleanDead after each pass is a scan-compaction by the wave.
+// ---------------------------------------------------------------------------------------------------------
+enum { GP_LOWCOV = 0, GP_TIPS = 1, GP_LINKS = 2, GP_MERGE = 3 };
+DEVNI int pass_candidates_wg(Ctx &c, int comp, int pass) {            // list -> W.pedges (idle outside the path phases), count returned
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  const int M = (int)wg_bcastu(&S.M);
+  const int K = wg_bcast(&S.K);
+  LC_GLOBAL uint32_t *fl = W.scratch;
+  const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
+  const double thr = floor(sqrt(avgcov));
+  const int max_link_len = K / 2, max_tip_len = LC_CTX(c).P->max_tip_len;
+  LC_GLOBAL const NodeGr *gr = W.gr;
+  WG_FOR(i, M) {
+    const uint32_t n = W.order[i];
+    const GrLine0 G = gr_line0(&gr[n]);
+    LC_GLOBAL const uint32_t *g1 = (LC_GLOBAL const uint32_t *)&gr[n] + 16;
+    const lc_u4 h0 = ldg4(g1), h1 = ldg4(g1 + 4);                  // cov[4] | mincov mincovqv seq_lo seq_hi
+    bool ok = G.comp == comp && !(G.flags & (NF_SPECIAL | NF_DEAD));
+    if (ok) {
+      const int len = (int)(h1.w - h1.z);
+      if (pass == GP_LOWCOV) {
+        const int mq = (int)h1.y;
+        const float tt = __builtin_bit_cast(float, h0.x) + __builtin_bit_cast(float, h0.y), tn = __builtin_bit_cast(float, h0.z) + __builtin_bit_cast(float, h0.w);
+        ok = (mq <= LC_CTX(c).P->low_cov_threshold) || ((double)mq <= (LC_CTX(c).P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
+      } else if (pass == GP_TIPS) ok = (len - K + 1) < max_tip_len;
+      else if (pass == GP_LINKS) ok = (len - K + 1) < max_link_len && (double)(int)h1.x <= thr;
+      else {                                                       // a mergeable link on either side (compress_node's conditions)
+        ok = false;
+        if (!l0_tandem(G, n)) {
+          const uint32_t ewF = l0_buddy(G, n, 'F'), ewR = l0_buddy(G, n, 'R');
+          const uint32_t bF = ewF != LC_NIL ? ED_TO(ewF) : n, bR = ewR != LC_NIL ? ED_TO(ewR) : n;
+          const GrLine0 BF = gr_line0(&gr[bF]), BR = gr_line0(&gr[bR]);
+          for (int sd = 0; sd < 2; ++sd) {
+            const uint32_t ew = sd == 0 ? ewF : ewR;
+            if (ew == LC_NIL) continue;
+            const uint32_t edir = ED_DIR(ew), bn = ED_TO(ew);
+            const GrLine0 &Bq = sd == 0 ? BF : BR;
+            if (l0_tandem(Bq, bn)) continue;
+            if (l0_buddy(Bq, bn, (edir == 0 || edir == 2) ? 'R' : 'F') != LC_NIL) ok = true;
+          }
+        }
+      }
+    }
+    fl[i] = ok ? 1u : 0u;
+  }
+  WG_LANE0 { fl[M] = 0; }
+  wg_scan(fl, M + 1, S);
+  WG_FOR(i, M) { if (fl[i + 1] != fl[i]) W.pedges[fl[i]] = W.order[i]; }
+  WG_SYNC();
+  return (int)wg_bcastu(&S.part[LANCET_WG]);
+}
+// cleanDead (reference src/Graph.cc:2737-2763) by the wave: the table order without the nodes marked dead
+DEVNI void clean_dead_flags_wg(Ctx &c, bool quiet) {
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  const int M = (int)wg_bcastu(&S.M);
+  LC_GLOBAL uint32_t *keep = W.scratch;
+  WG_SYNC();                                                       // (lane 0 has just set the flags; plain stores and loads of ONE wave through its CU's L1 stay ordered: no cache maintenance -- an agent-scope fence per pass cost 25 % of the kernel)
+  WG_FOR(i, M) { keep[i] = (W.gr[W.order[i]].flags & NF_DEAD) ? 0u : 1u; }
+  WG_LANE0 { keep[M] = 0; }
+  wg_scan(keep, M + 1, S);
+  WG_FOR(i, M) { if (keep[i + 1] != keep[i]) W.pnodes[keep[i]] = W.order[i]; }
+  WG_SYNC();
+  const int live = (int)wg_bcastu(&S.part[LANCET_WG]);
+  WG_FOR(i, live) { W.order[i] = W.pnodes[i]; }
+  WG_LANE0 { S.M = (uint32_t)live; S.ht_elt -= (uint32_t)(M - live); if (!quiet) evt(c, EV_CLEANDEAD, (uint32_t)(M - live)); }
+  WG_SYNC();
+}
+DEVNI void compress_wg(Ctx &c, int comp) {                            // Graph_t::compress, reference src/Graph.cc:2712-2732
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  const int nc = pass_candidates_wg(c, comp, GP_MERGE);
+  WG_LANE0 {
+    S.tmp2 = 0;
+    evt(c, EV_COMPRESS);
+    for (int j = 0; j < nc && !S.overflow; ++j) {
+      const uint32_t n = W.pedges[j];
+      if (W.gr[n].flags & NF_DEAD) continue;
+      compress_node(c, n, 'F');
+      compress_node(c, n, 'R');
+    }
+  }
+  clean_dead_flags_wg(c, false);
+}
+DEVNI void remove_low_cov_wg(Ctx &c, int comp) {                      // reference src/Graph.cc:2790-2827 (docompression=true)
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  const int nc = pass_candidates_wg(c, comp, GP_LOWCOV);
+  WG_LANE0 { for (int j = 0; j < nc; ++j) remove_node(c, W.pedges[j]); evt(c, EV_LOWCOV, (uint32_t)nc); }
+  if (nc) clean_dead_flags_wg(c, false); else { WG_LANE0 { evt(c, EV_CLEANDEAD, 0); } }
+  // Nothing removed: the component was compressed to the end just before (compress is idempotent, hasCycle in between changes
+  // nothing), so the reference's unconditional compress() has nothing to merge -- only its trace lines are owed.
+  if (nc == 0) { WG_LANE0 { evt(c, EV_COMPRESS); evt(c, EV_CLEANDEAD, 0); S.tmp2 = 0; } }
+  else compress_wg(c, comp);
+  WG_LANE0 { print_stats(c, comp); }
+}
+DEVNI void remove_tips_wg(Ctx &c, int comp) {                         // reference src/Graph.cc:2885-2926
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  int round = 0;
+  while (true) {
+    ++round;
+    const int nc = pass_candidates_wg(c, comp, GP_TIPS);
+    WG_LANE0 {
+      int tips = 0;
+      evt(c, EV_TIPS_ROUND, round);
+      for (int j = 0; j < nc; ++j) { const uint32_t n = W.pedges[j]; if ((int)W.gr[n].necnt <= 1) { remove_node(c, n); ++tips; } }
+      evt(c, EV_TIPS_REMOVED, tips);
+      S.tmp3 = tips;
+    }
+    if (wg_bcast(&S.tmp3) == 0) break;
+    compress_wg(c, comp);
+    if (wg_bcast(&S.overflow)) break;
+  }
+  WG_LANE0 { print_stats(c, comp); }
+}
+DEVNI void remove_short_links_wg(Ctx &c, int comp) {                  // reference src/Graph.cc:2833-2880
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  const int nc = pass_candidates_wg(c, comp, GP_LINKS);
+  WG_LANE0 {
+    int links = 0;
+    for (int j = 0; j < nc && !S.overflow; ++j) {
+      const uint32_t n = W.pedges[j];
+      if ((int)W.gr[n].necnt < 2) continue;
+      int L = 0, ml = 0; uint8_t motif[64];
+      const int sl = n_len(c, n);
+      if (sl > (int)LC_CTX(c).C->path_cap) { OVF(c); break; }
+      node_string(c, n, W.pseq);
+      find_tandems(c, W.pseq, sl, S.K - 1, &L, motif, &ml);
+      if (L == 0) { remove_node(c, n); ++links; }
+    }
+    evt(c, EV_LINKS, links);
+    S.tmp3 = links;
+  }
+  if (wg_bcast(&S.tmp3) && !wg_bcast(&S.overflow)) compress_wg(c, comp);
+  WG_LANE0 { print_stats(c, comp); }
+}
+
 // markConnectedComponents (reference src/Graph.cc:2252-2336), whole wave.  Only the partition, the numbering of the
 // components (in order of their first node in table order) and which of them hold a reference k-mer are observable,
 // not the breadth-first order the reference finds them in, so the partition is computed by min-label hooking with
@@ -2559,7 +2742,7 @@ DEVNI void mark_connected_components_wg(Ctx &c) {
     *(lc_u4 *)(adj + 4 * (size_t)i) = a;
     parent[n] = n; minpos[n] = LC_NIL; touch[n] = (G.flags & NF_INMER) ? 2u : 0u;
   }
-  WG_SYNC_FENCE();
+  WG_SYNC();
   while (true) {
     WG_LANE0 { S.tmp0 = 0; }
     // hook: the smallest label around a node goes to the node and to its current parent
@@ -2605,7 +2788,7 @@ DEVNI void mark_connected_components_wg(Ctx &c) {
     const uint32_t r = ld2(&parent[W.order[i]]);
     if (ld2(&minpos[r]) == (uint32_t)i) { cid[r] = first[i] + 1u; if (ld2(&touch[r]) & 1u) dev_atomic_add((LC_LDS uint32_t *)&S.tmp1, 1u); }
   }
-  WG_SYNC_FENCE();
+  WG_SYNC();
   WG_FOR(i, M) { const uint32_t u = W.order[i]; W.gr[u].comp = (int)cid[ld2(&parent[u])]; }
   WG_SYNC();
   WG_LANE0 {
@@ -3562,7 +3745,7 @@ DEVNI bool repeats_in_graph_paths(Ctx &c) {
       WG_LANE0 { S.ps_hd = (pl == S.seq_len && S.reflen - S.K > 0) ? 0 : 1; }
       WG_SYNC();
       if (pl == S.seq_len) { WG_FOR(i, pl) { if (rs[i] != W.pseq[i]) S.ps_hd = 1; } }
-      if (wg_bcast(&S.ps_hd)) repeat_scan_min(S.rs, W.pseq, pl, LC_CTX(c).P->max_mismatch, 0x7FFF, wg_uniform(S.K) + 1, &S.repE, &S.repM);
+      if (wg_bcast(&S.ps_hd)) repeat_scan_min(S.rs, W.pseq, pl, LC_CTX(c).P->max_mismatch, 0x7FFF, wg_uniform(S.K) + 1, &S.repE, &S.repM, nullptr, &S.rs_bad);
       else { WG_LANE0 { S.repE = 0; S.repM = 0; } }
     }
     WG_LANE0 {
@@ -3719,28 +3902,28 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
   if (wg_bcast(&S.tmp1)) {
     const int t5 = wg_bcast(&S.seq_t5), L = wg_bcast(&S.seq_len);
     WG_FOR(i, (N + 31u) / 32u) { W.bitmap[i] = 0; }
-    WG_SYNC_FENCE();
+    WG_SYNC();
     WG_FOR(i, L - K > 0 ? L - K : 0) {
       const int p = t5 + i;
       if (p < nrefk) { const uint32_t n = occ_ref[p] & 0x3FFFFFFFu; dev_atomic_or(&W.bitmap[n >> 5], 1u << (n & 31u)); }
     }
-    WG_SYNC_FENCE();
+    WG_SYNC();                                                     // (the bitmap is read past the L1 below: ld2)
     WG_FOR(si, nsurv) {
       const uint32_t n = sid[si]; const uint32_t f = W.gr[n].flags;
-      W.gr[n].flags = ((W.bitmap[n >> 5] >> (n & 31u)) & 1u) ? (f | NF_INMER) : (f & ~(uint32_t)NF_INMER);
+      W.gr[n].flags = ((ld2(&W.bitmap[n >> 5]) >> (n & 31u)) & 1u) ? (f | NF_INMER) : (f & ~(uint32_t)NF_INMER);
     }
     WG_FOR(i, S.reflen - K > 0 ? S.reflen - K : 0) {
       const uint32_t n = occ_ref[i] & 0x3FFFFFFFu;
-      if (!((W.bitmap[n >> 5] >> (n & 31u)) & 1u)) {
+      if (!((ld2(&W.bitmap[n >> 5]) >> (n & 31u)) & 1u)) {
         if (i == 0) { for (int j = 0; j < K; ++j) for (int q = 0; q < 4; ++q) W.refcov[4 * j + q] = 0; }
         else { for (int q = 0; q < 4; ++q) W.refcov[4 * (i + K - 1) + q] = 0; }
       }
     }
     if (LC_CTX(c).C->evt_cap) {                                   // trace only: nodes that hold a reference k-mer (markRefNodes' count)
-      WG_LANE0 { uint32_t cnt = 0; for (uint32_t i = 0; i < (N + 31u) / 32u; ++i) cnt += (uint32_t)dev_popc(W.bitmap[i]); S.pre_refn = cnt; }
+      WG_LANE0 { uint32_t cnt = 0; for (uint32_t i = 0; i < (N + 31u) / 32u; ++i) cnt += (uint32_t)dev_popc(ld2(&W.bitmap[i])); S.pre_refn = cnt; }
     }
   }
-  WG_SYNC_FENCE();
+  WG_SYNC();
   return true;
 }
 
@@ -3788,7 +3971,7 @@ DEV void process_window(Ctx &c, int w) {
 #else
     WG_LANE0 { S.tmp1 = (H && H->have_rep == 1u) ? 1 : 0; if (S.tmp1) { S.repE = H->refE; S.repM = H->refM; } }
 #endif
-    if (!wg_bcast(&S.tmp1)) repeat_scan_min(S.rs, B.ref_codes + B.ref_off[w], reflen, LC_CTX(c).P->max_mismatch, LC_CTX(c).P->min_k, LC_CTX(c).P->min_k + 1, &S.repE, &S.repM);
+    if (!wg_bcast(&S.tmp1)) repeat_scan_min(S.rs, B.ref_codes + B.ref_off[w], reflen, LC_CTX(c).P->max_mismatch, LC_CTX(c).P->min_k, LC_CTX(c).P->min_k + 1, &S.repE, &S.repM, nullptr, &S.rs_bad);
   }
   PHASE(c, 0);
   const int refE = wg_bcast(&S.repE), refM = wg_bcast(&S.repM);
@@ -3884,11 +4067,14 @@ DEV void process_window(Ctx &c, int w) {
         if (!S.tmp0 && !S.overflow) {
           evt(c, EV_COMPRESS); evt(c, EV_CLEANDEAD, dead);
           print_stats(c, comp);
-          remove_low_cov(c, comp);
-          remove_tips(c, comp);
-          remove_short_links(c, comp);
-          if (!S.overflow && has_cycle(c)) S.tmp0 = 1;
         }
+        S.tmp3 = (!S.tmp0 && !S.overflow) ? 1 : 0;
+      }
+      if (wg_bcast(&S.tmp3)) {
+        remove_low_cov_wg(c, comp);
+        if (!wg_bcast(&S.overflow)) remove_tips_wg(c, comp);
+        if (!wg_bcast(&S.overflow)) remove_short_links_wg(c, comp);
+        WG_LANE0 { if (!S.overflow && has_cycle(c)) S.tmp0 = 1; }
       }
       if (wg_bcast(&S.overflow)) break;
       if (wg_bcast(&S.tmp0)) { cycleInGraph = 1; brk = true; break; }

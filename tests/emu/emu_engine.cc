@@ -102,10 +102,19 @@ extern "C" void lancet_emu_repeat_scan(const uint8_t *s, int len, int mm, int bi
   *outE = e; *outM = m;
 }
 // the long-matches-only scan: results below lminE / lminM may be reported smaller
-extern "C" void lancet_emu_repeat_scan_min(const uint8_t *s, int len, int mm, int lminE, int lminM, int *outE, int *outM) {
+// form 0: 4 bits per base; 1: 2 bits per base staged from the bytes (falls back to 4 when it meets an N); 2: 2 bits per base from
+// a packed copy of the string (the LDS build kernel's call; no N allowed)
+extern "C" void lancet_emu_repeat_scan_min(const uint8_t *s, int len, int mm, int lminE, int lminM, int *outE, int *outM, int form) {
   static WinShared S;
-  volatile int e = 0, m = 0;
-  repeat_scan_min(S.rs, s, len, mm, lminE, lminM, &e, &m);
+  volatile int e = 0, m = 0, bad = 0;
+  if (form == 0) repeat_scan_min(S.rs, s, len, mm, lminE, lminM, &e, &m);
+  else if (form == 1) repeat_scan_min(S.rs, s, len, mm, lminE, lminM, &e, &m, nullptr, &bad);
+  else {
+    static uint32_t packed[LC_MAXW / 16 + 64];
+    memset(packed, 0, sizeof packed);
+    for (int i = 0; i < len; ++i) packed[i >> 4] |= (uint32_t)(s[i] & 3u) << (2 * (i & 15));
+    repeat_scan_min(S.rs, s, len, mm, lminE, lminM, &e, &m, packed, &bad);
+  }
   *outE = e; *outM = m;
 }
 
