@@ -859,7 +859,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     LC_LDS uint16_t *pos2si = (LC_LDS uint16_t *)(bk + 64);                      // [PB_SCAP] survivor index of the node at a position
     static_assert(5120 * 4 + 4104 * 4 + 4 * 4096 * 2 + 32 * 8 + 32 * 4 + 64 * 4 + PB_SCAP * 2 <= offsetof(BlShared, big) + BL_BIG, "order arena");
     LC_GLOBAL const unsigned long long *nhash = (LC_GLOBAL const unsigned long long *)(area + PRE_OFF_NHASH);
-    const uint32_t SEQ = 29u;
+    const uint32_t SEQ = 13u;
     const uint32_t n0 = N < SEQ ? N : SEQ;
     WG_SYNC();
     WG_FOR(i, n0) { nh[i] = nhash[i]; }
@@ -942,8 +942,12 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       parent[ppos] = ppos; touch[ppos] = X.s_edges[9 * (size_t)si + 8]; pos2si[ppos] = (uint16_t)si;
     }
     WG_SYNC();
+    // (a round = one hooking pass + three pointer-jumping passes, one barrier each, then ONE look at the change flag: testing
+    //  for convergence after every pass cost two more barriers of the 512-lane workgroup per pass, and these passes do little
+    //  else than wait at barriers.  A round that changed nothing leaves every parent a root with no smaller neighbour label.)
+    WG_LANE0 { S.flagged = 0; }
+    WG_SYNC();
     while (true) {
-      WG_LANE0 { S.flagged = 0; }
       WG_FOR(u, nsurv) {
         const uint32_t pu = ld2(&parent[u]);
         uint32_t m = pu;
@@ -951,13 +955,15 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
         if (m < pu) { dev_atomic_min(&parent[pu], m); dev_atomic_min(&parent[u], m); S.flagged = 1; }
       }
       WG_SYNC();
-      while (true) {
-        WG_LANE0 { S.npairs = 0; }
-        WG_FOR(u, nsurv) { const uint32_t pu = ld2(&parent[u]), gp = ld2(&parent[pu]); if (gp != pu) { dev_atomic_min(&parent[u], gp); S.npairs = 1; } }
+      for (int jp = 0; jp < 3; ++jp) {
+        WG_FOR(u, nsurv) { const uint32_t pu = ld2(&parent[u]), gp = ld2(&parent[pu]); if (gp != pu) { dev_atomic_min(&parent[u], gp); S.flagged = 1; } }
         WG_SYNC();
-        if (!bl_bcast(&S.npairs)) break;
       }
-      if (!bl_bcast(&S.flagged)) break;
+      const uint32_t changed = S.flagged;                                   // (every lane reads it, then a barrier, then lane 0 clears it)
+      WG_SYNC();
+      if (!changed) break;
+      WG_LANE0 { S.flagged = 0; }
+      WG_SYNC();
     }
     WG_FOR(u, nsurv) { if (touch[u] & 1u) dev_atomic_or(&touch[parent[u]], 2u); }
     WG_SYNC();
