@@ -27,82 +27,9 @@
 #include <stddef.h>
 #include "kernels.h"
 
-#define BL_WG 512
-#define BL_BASES 40960            /* bases in LDS (reads padded to 16, + the reference)                       */
-#define BL_RMAX 512               /* reads per window                                                          */
-#define BL_SLOTS 8192
-#define BL_TCAP 2048              /* tracked nodes                                                             */
-#define BL_BIG 32768              /* bytes of the phase-dependent LDS area                                     */
 #define BL_EMPTY 0xFFFFFFFFu
-
-enum { BLW_NONE = 0, BLW_NOREADS, BLW_SIZE, BLW_HASN, BLW_K, BLW_TABLE, BLW_NODES, BLW_TRACKED, BLW_CAND, BLW_QV, BLW_SURV, BLW_MATE, BLW_NAMES, BLW_PAIRS };
-
-struct BlShared {
-  uint32_t bases[BL_BASES / 16 + 4];
-  uint32_t goodm[BL_BASES / 32 + 4];
-  uint16_t rdo[BL_RMAX + 4];        /* first 16-base word of read r                                             */
-  uint16_t gwo[BL_RMAX + 4];        /* first quality-mask word of read r                                        */
-  uint16_t obase[BL_RMAX + 4];      /* first occurrence index of read r; [R] = O                                */
-  uint16_t o2r[BL_BASES / 128 + 2]; /* read that holds occurrence 128 * j                                       */
-  uint32_t rinfo[BL_RMAX + 4];
-  uint8_t pidx[BL_RMAX + 4];        /* mate-pair signature bit of the read (0xFF none)                          */
-  uint8_t prole[BL_RMAX + 4];       /* 1 = earlier mate of a pair, 2 = the later one                            */
-  uint16_t idoff[PB_NCAP];          /* node id -> LDS offset of its first occurrence                            */
-  uint16_t cidx[PB_NCAP];           /* node id -> tracked index, later survivor index (0xFFFF none)             */
-  uint16_t t2c[BL_TCAP];            /* tracked index -> candidate index (0xFFFF none)                           */
-  alignas(16) uint32_t big[BL_BIG / 4];   /* (64-bit LDS atomics on it: must be 8-byte aligned) */
-  uint32_t wsum[BL_WG / 64 + 1];
-  uint32_t scan_total;
-  int w, R, reflen, K, hasN, mapped;
-  uint32_t O, N, T, ncand, nsurv, nbw, ngw;
-  uint32_t totalreadbp, n_kmers;
-  int repE, repM;
-  int why;
-  uint32_t npairs, flagged, edges_total, refn;
-  uint32_t g0, g1;                  /* group bounds of the current pass                                          */
-  uint32_t hint;                    /* the graph will very likely have a cycle at this k (scheduling hint, see the insert pass) */
-  uint32_t ndup;                    /* occurrences noted in BlScratch::dupo                                        */
-  unsigned long long t_last, ph_acc[16]; int ph_cur;   /* profiling: wall-clock ticks per phase (lane 0)                 */
-};
-
-/* per-workgroup scratch in HBM (streamed, never shared between windows in flight) */
-struct BlScratch {
-  LC_GLOBAL uint16_t *occn;         /* [BL_BASES] slot, then node id | ori << 15, per k-mer start offset         */
-  LC_GLOBAL unsigned long long *tcc;/* [BL_TCAP] counted occurrences Tf Tr Nf Nr (4 x 16 bit)                    */
-  LC_GLOBAL uint32_t *tfl;          /* [BL_TCAP] NF_TUMOR | NF_NORMAL                                            */
-  LC_GLOBAL uint32_t *c_id;         /* [PB_CCAP] node of candidate ci                                            */
-  LC_GLOBAL uint32_t *c_ti;         /* [PB_CCAP] its tracked index                                               */
-  LC_GLOBAL uint32_t *c_minqv;      /* [PB_CCAP]                                                                 */
-  LC_GLOBAL uint32_t *s_ci;         /* [PB_SCAP] candidate of survivor si                                        */
-  LC_GLOBAL uint32_t *s_edges;      /* [PB_SCAP * 9] resolved edges + count                                      */
-  LC_GLOBAL uint16_t *dupo;         /* [BL_DUPCAP] occurrences that met their k-mer in the other orientation, or twice in one read */
-};
 #define BL_DUPCAP 1024u
-#define BL_SCRATCH_BYTES (2u * BL_BASES + 64u + 8u * BL_TCAP + 4u * BL_TCAP + 12u * PB_CCAP + 4u * PB_SCAP + 36u * PB_SCAP + 2u * BL_DUPCAP + 640u)
-DEV void bl_scratch_carve(BlScratch *s, LC_GLOBAL uint8_t *base) {
-  size_t o = 0;
-  auto take = [&](size_t bytes) { LC_GLOBAL uint8_t *p = base + o; o = (o + bytes + 63) & ~(size_t)63; return p; };
-  s->occn = (LC_GLOBAL uint16_t *)take(2u * BL_BASES + 64u);
-  s->tcc = (LC_GLOBAL unsigned long long *)take(8u * BL_TCAP);
-  s->tfl = (LC_GLOBAL uint32_t *)take(4u * BL_TCAP);
-  s->c_id = (LC_GLOBAL uint32_t *)take(4u * PB_CCAP);
-  s->c_ti = (LC_GLOBAL uint32_t *)take(4u * PB_CCAP);
-  s->c_minqv = (LC_GLOBAL uint32_t *)take(4u * PB_CCAP);
-  s->s_ci = (LC_GLOBAL uint32_t *)take(4u * PB_SCAP);
-  s->s_edges = (LC_GLOBAL uint32_t *)take(36u * PB_SCAP);
-  s->dupo = (LC_GLOBAL uint16_t *)take(2u * BL_DUPCAP);
-}
-
-static_assert(sizeof(BlShared) <= 80u * 1024u, "two workgroups of the build kernel per CU: 80 KB of LDS each");
-typedef LC_LDS BlShared BL_S;
-#ifndef LANCET_WAVE_EMU
-static __shared__ BlShared bl_shared;
-template <class P> DEV unsigned long long dev_atomic_add64(P p, unsigned long long v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-template <class P> DEV unsigned long long dev_atomic_or64(P p, unsigned long long v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-#else
-DEV unsigned long long dev_atomic_add64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
-DEV unsigned long long dev_atomic_or64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o | v; return o; }
-#endif
+enum { BLW_NONE = 0, BLW_NOREADS, BLW_SIZE, BLW_HASN, BLW_K, BLW_TABLE, BLW_NODES, BLW_TRACKED, BLW_CAND, BLW_QV, BLW_SURV, BLW_MATE, BLW_NAMES, BLW_PAIRS };
 
 #ifndef LANCET_WAVE_EMU
 #define BLP(S, id) do { if (threadIdx.x == 0) { const unsigned long long _t = wall_clock64(); (S).ph_acc[(S).ph_cur] += _t - (S).t_last; (S).t_last = _t; (S).ph_cur = (id); } } while (0)
@@ -110,925 +37,37 @@ DEV unsigned long long dev_atomic_or64(unsigned long long *p, unsigned long long
 #define BLP(S, id) ((void)0)
 #endif
 // uniform read of a control word: barrier, read, barrier (kernels.h wg_bcast)
-#define bl_bcast(p) wg_bcastu(p)
 
-// exclusive prefix sum of an LDS array in place, whole workgroup; the total lands in S.scan_total
-DEV void bl_scan32(LC_LDS uint32_t *a, int n, BL_S &S) {
-  WG_SYNC();
-#ifndef LANCET_WAVE_EMU
-  const int t = (int)threadIdx.x, chunk = (n + BL_WG - 1) / BL_WG;
-  int lo = t * chunk, hi = lo + chunk; if (lo > n) lo = n; if (hi > n) hi = n;
-  uint32_t s = 0;
-  for (int i = lo; i < hi; ++i) s += a[i];
-  uint32_t inc = s; const int lane = t & 63;
-  for (int d = 1; d < 64; d <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += x; }
-  if (lane == 63) S.wsum[t >> 6] = inc;
-  __syncthreads();
-  uint32_t woff = 0;
-  for (int i = 0; i < (t >> 6); ++i) woff += S.wsum[i];
-  uint32_t run = woff + inc - s;
-  for (int i = lo; i < hi; ++i) { const uint32_t x = a[i]; a[i] = run; run += x; }
-  if (t == BL_WG - 1) S.scan_total = run;
-  __syncthreads();
-#else
-  uint32_t run = 0;
-  for (int i = 0; i < n; ++i) { const uint32_t x = a[i]; a[i] = run; run += x; }
-  S.scan_total = run;
-#endif
-}
-
-// the k-mer that starts at LDS offset `boff`: base j at bits 2j (k <= 31)
-DEV unsigned long long bl_kmer(const LC_LDS uint32_t *bases, uint32_t boff, unsigned long long kmask) {
-  const uint32_t w = boff >> 4, sh = (boff & 15u) * 2u;
-  const unsigned long long lo = (unsigned long long)bases[w] | ((unsigned long long)bases[w + 1] << 32);
-  const unsigned long long v = sh ? ((lo >> sh) | ((unsigned long long)bases[w + 2] << (64u - sh))) : lo;
-  return v & kmask;
-}
-// canonical form as kernels.h holds it (first base most significant; CanonicalMer_t::set, reference src/Mer.hh:57-71: tie -> R)
-DEV unsigned long long bl_canon(unsigned long long v, int K, unsigned long long kmask, bool *isF) {
-  const unsigned long long rc = (~v) & kmask;
-  unsigned long long fw = dev_brev64(v);
-  fw = ((fw >> 1) & 0x5555555555555555ULL) | ((fw & 0x5555555555555555ULL) << 1);
-  fw >>= (64 - 2 * K);
-  *isF = fw < rc;
-  return *isF ? fw : rc;
-}
-DEV int bl_base(const LC_LDS uint32_t *bases, uint32_t boff) { return (int)((bases[boff >> 4] >> ((boff & 15u) * 2u)) & 3u); }
-// quality-mask bits [a, b) of a read whose mask starts at word gw: all set?
-DEV bool bl_all_good(const LC_LDS uint32_t *goodm, uint32_t gw, int a, int b) {
-  for (int i = a; i < b;) {
-    const int w = i >> 5, lo = i & 31;
-    int take = 32 - lo; if (take > b - i) take = b - i;
-    uint32_t m = goodm[gw + w] >> lo;
-    const uint32_t full = take < 32 ? ((1u << take) - 1u) : 0xFFFFFFFFu;
-    if ((m & full) != full) return false;
-    i += take;
-  }
-  return true;
-}
-
-// every occurrence o of the window: read r, k-mer start p in the read, LDS offset boff of the k-mer (lane-strided)
-#define BL_OCC_BEGIN(S) WG_FOR(_t, BL_WG) { const int _O = (int)(S).O; \
-  for (int o = _t; o < _O; o += BL_WG) { uint32_t _r = (S).o2r[o >> 7]; while ((uint32_t)o >= (S).obase[_r + 1]) ++_r; \
-    const int r = (int)_r; const int p = o - (int)(S).obase[r]; const uint32_t boff = 16u * (S).rdo[r] + (uint32_t)p; (void)p; (void)boff; (void)r;
-#define BL_OCC_END } }
-
-// The same walk with the occurrence's 2-byte HBM word fetched four occurrences ahead: a pass is a chain of (HBM word -> LDS
-// look-ups -> LDS atomics) per occurrence, and with two workgroups per CU nothing else hides the memory round trip.
-template <class F> DEV void bl_for_occ(BL_S &S, LC_GLOBAL const uint16_t *occn, F body) {
-  WG_FOR(_t, BL_WG) {
-    const int O_ = (int)S.O;
-    for (int o0 = _t; o0 < O_; o0 += 4 * BL_WG) {
-      int rr[4], pp[4]; uint32_t bo[4], ee[4];
-      for (int u = 0; u < 4; ++u) {
-        const int o = o0 + u * BL_WG;
-        const int oc = o < O_ ? o : O_ - 1;                          // (clamped: the loads below stay unconditional, four in flight)
-        uint32_t rc = S.o2r[oc >> 7];
-        while ((uint32_t)oc >= S.obase[rc + 1]) ++rc;
-        rr[u] = o < O_ ? (int)rc : -1; pp[u] = oc - (int)S.obase[rc]; bo[u] = 16u * S.rdo[rc] + (uint32_t)pp[u];
-      }
-#ifdef BL_DBG_COND
-      for (int u = 0; u < 4; ++u) ee[u] = rr[u] >= 0 ? (uint32_t)occn[bo[u]] : 0u;
-#else
-      for (int u = 0; u < 4; ++u) ee[u] = (uint32_t)occn[bo[u]];
-#endif
-      for (int u = 0; u < 4; ++u) if (rr[u] >= 0) body(rr[u], pp[u], bo[u], ee[u]);
-    }
-  }
-}
-
-// One window.  Returns with the hand-off area of the window written (PB_BUILT) or marked PB_NOT_BUILT.
-// kmin: the loop over k starts there (min_k for the window's first graph; the k after a rejected one for a graph built ahead).
-// rep: the window's isRepeat / isAlmostRepeat operands when an earlier call scanned the reference already, else null.
-DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *Bp, LC_GLOBAL const EngineCaps *C, BL_S &S, LC_GLOBAL uint8_t *xbase,
-                           LC_GLOBAL uint8_t *area, int w, int kmin, LC_GLOBAL const PreHdr *rep) {
-  LC_GLOBAL const DevBatch &B = *Bp;
-  BlScratch X; bl_scratch_carve(&X, xbase);                       // (a local of this function: its pointers live in registers)
-  LC_GLOBAL PreHdr *H = (LC_GLOBAL PreHdr *)(area + PRE_OFF_HDR);
-  const uint32_t g0 = B.read_begin[w];
-  const int nr = (int)(B.read_begin[w + 1] - g0);
-  const int reflen = (int)(B.ref_off[w + 1] - B.ref_off[w]);
-  LC_GLOBAL const uint8_t *refc = B.ref_codes + B.ref_off[w];
-  WG_LANE0 { S.hint = 0; S.ndup = 0; S.w = w; S.why = BLW_NONE; S.R = nr + 1; S.reflen = reflen; S.hasN = 0; S.mapped = 0; S.flagged = 0; S.npairs = 0; S.edges_total = 0; S.refn = 0;
-             H->status = PB_NOT_BUILT; H->why = 0; H->have_rep = 0; H->heavy = 0; H->next = 0;
-             if (nr > BL_RMAX || reflen > LC_MAXW || reflen < 1) S.why = BLW_SIZE; }
-  if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
-  // ---- mapped reads, N in the window reference, per-read geometry
-  LC_LDS uint32_t *tmpA = S.big, *tmpB = S.big + (BL_RMAX + 8), *tmpC = S.big + 2 * (BL_RMAX + 8);
-  WG_FOR(r, nr + 1) {
-    uint32_t ri = 0; int tlen = reflen;
-    if (r < nr) { ri = B.rinfo[g0 + (uint32_t)r]; tlen = (int)RI_TLEN(ri); if (RI_MAPPED(ri)) dev_atomic_add((LC_LDS uint32_t *)&S.mapped, 1u); }
-    S.rinfo[r] = ri;
-    tmpA[r] = (uint32_t)((tlen + 15) / 16); tmpB[r] = (uint32_t)((tlen + 31) / 32);
-  }
-  WG_FOR(i, reflen) { if (refc[i] > 3) S.hasN = 1; }
-  WG_LANE0 { tmpA[nr + 1] = 0; tmpB[nr + 1] = 0; }
-  bl_scan32(tmpA, nr + 2, S);
-  const uint32_t nbw = bl_bcast(&S.scan_total);
-  bl_scan32(tmpB, nr + 2, S);
-  const uint32_t ngw = bl_bcast(&S.scan_total);
-  WG_LANE0 {
-    S.nbw = nbw; S.ngw = ngw;
-    if (S.mapped <= 0) S.why = BLW_NOREADS;                    // the window kernel reports LANCET_W_NO_READS itself
-    else if (S.hasN) S.why = BLW_HASN;
-    else if (nbw > BL_BASES / 16 || ngw > BL_BASES / 32) S.why = BLW_SIZE;
-  }
-  if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
-  WG_FOR(r, nr + 2) { S.rdo[r] = (uint16_t)tmpA[r]; S.gwo[r] = (uint16_t)tmpB[r]; }
-  WG_SYNC();
-  BLP(S, 1);
-  if (C->debug_stop == 101u) { WG_LANE0 { H->why = 99; } return; }
-  // ---- the window's packed reads and quality masks into LDS (whole words; a read starts on a word)
-  WG_FOR(r, nr) {
-    const uint32_t ri = S.rinfo[r]; const int tlen = (int)RI_TLEN(ri);
-    LC_GLOBAL const uint32_t *bsrc = B.bases + B.base_woff[g0 + (uint32_t)r], *gsrc = B.good + B.good_woff[g0 + (uint32_t)r];
-    const int nb = (tlen + 15) / 16, ng = (tlen + 31) / 32;
-    for (int i = 0; i < nb; ++i) S.bases[S.rdo[r] + i] = bsrc[i];
-    for (int i = 0; i < ng; ++i) S.goodm[S.gwo[r] + i] = gsrc[i];
-  }
-  WG_FOR(wd, (reflen + 15) / 16) {
-    uint32_t v = 0;
-    for (int j = 0; j < 16 && wd * 16 + j < reflen; ++j) v |= (uint32_t)(refc[wd * 16 + j] & 3u) << (2 * j);
-    S.bases[S.rdo[nr] + wd] = v;
-  }
-  WG_FOR(i, 4) { S.bases[nbw + (uint32_t)i] = 0; }
-  WG_SYNC();
-  BLP(S, 2);
-  if (C->debug_stop == 102u) { WG_LANE0 { H->why = 99; } return; }
-  // ---- reference repeat scan -> the first k of the loop that reaches buildgraph (Microassembler.cc:118-131)
-  if (rep) { WG_LANE0 { S.repE = rep->refE; S.repM = rep->refM; } WG_SYNC(); }
-  else repeat_scan_min((volatile LC_LDS unsigned long long *)(S.big + 4 * (BL_RMAX + 8)), refc, reflen, P->max_mismatch, P->min_k, P->min_k + 1, (volatile LC_LDS int *)&S.repE, (volatile LC_LDS int *)&S.repM,
-                  (const LC_LDS uint32_t *)&S.bases[S.rdo[nr]], (volatile LC_LDS int *)&S.flagged);     // (the reference is in LDS already, 2 bits per base: no N here)
-  WG_LANE0 {
-    int K = 0;
-    for (int k = kmin; k <= P->max_k; k += 2) {
-      if (reflen - k > 0 && S.repE >= k) continue;
-      if (reflen - k > 0 && S.repM >= k + 1) continue;
-      K = k; break;
-    }
-    S.K = K;
-    H->refE = S.repE; H->refM = S.repM; H->mapped = (uint32_t)S.mapped; H->have_rep = 1;          // (the window kernel does not repeat the scan)
-    if (K == 0 || K > 31 || (K & 1) == 0) S.why = BLW_K;
-  }
-  if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
-  const int K = (int)bl_bcast(&S.K);
-  const unsigned long long kmask = (1ULL << (2 * K)) - 1ULL;
-  const int R = nr + 1;
-  BLP(S, 3);
-  if (C->debug_stop == 103u) { WG_LANE0 { H->why = 99; } return; }
-  // ---- occurrence index space (read r owns its k-mers p = 0..tlen-K; a read of exactly K bases has none, Graph.cc:142-143)
-  WG_LANE0 { S.totalreadbp = 0; S.n_kmers = 0; }
-  WG_SYNC();
-  WG_FOR(r, R) {
-    const int tlen = r < nr ? (int)RI_TLEN(S.rinfo[r]) : reflen;
-    tmpC[r] = tlen - K > 0 ? (uint32_t)(tlen - K + 1) : 0u;
-    if (tlen > 0 && r < nr) dev_atomic_add((LC_LDS uint32_t *)&S.totalreadbp, (uint32_t)tlen);
-    if (tlen - K > 0) dev_atomic_add((LC_LDS uint32_t *)&S.n_kmers, (uint32_t)(tlen - K));
-  }
-  WG_LANE0 { tmpC[R] = 0; }
-  bl_scan32(tmpC, R + 1, S);
-  WG_FOR(r, R + 1) { S.obase[r] = (uint16_t)tmpC[r]; }
-  WG_LANE0 { S.O = S.scan_total; S.obase[R + 1] = 0xFFFFu; }
-  WG_SYNC();
-  WG_FOR(r, R) {                                                 // read r holds the occurrences [obase[r], obase[r+1]): the multiples of 128 among them
-    const uint32_t a = S.obase[r], b = S.obase[r + 1];
-    for (uint32_t j = (a + 127u) >> 7; (j << 7) < b; ++j) S.o2r[j] = (uint16_t)r;
-  }
-  WG_SYNC();
-  // ---- mate pairs: a read with exactly one earlier read of the same name and the opposite mate number is the later mate of
-  //      a pair (kernels.h build_tables: cand / mate_of); several such reads -> general path
-  {
-    LC_LDS uint32_t *first = S.big;                              // [2 * (BL_RMAX + 1)] smallest read index per (name, mate)
-    LC_LDS uint32_t *cnt = S.big + 2 * (BL_RMAX + 1);
-    WG_FOR(i, 4 * (BL_RMAX + 1)) { S.big[i] = i < 2 * (BL_RMAX + 1) ? 0xFFFFFFFFu : 0u; }
-    WG_FOR(r, R) { S.pidx[r] = 0xFF; S.prole[r] = 0; }
-    WG_SYNC();
-    WG_FOR(r, nr) {
-      const uint32_t mi = RI_MATE(S.rinfo[r]);
-      if (mi == 1 || mi == 2) {
-        const uint32_t nm = B.name_rank[g0 + (uint32_t)r];
-        if (nm > BL_RMAX) S.why = BLW_NAMES;
-        else { dev_atomic_min(&first[2 * nm + (mi - 1)], (uint32_t)r); dev_atomic_add(&cnt[2 * nm + (mi - 1)], 1u); }
-      }
-    }
-    WG_SYNC();
-    LC_LDS uint32_t *isl = S.big + 4 * (BL_RMAX + 1);          // later-mate flag per read -> pair index by scan
-    WG_FOR(r, nr + 1) {
-      uint32_t later = 0;
-      if (r < nr && !S.why) {
-        const uint32_t mi = RI_MATE(S.rinfo[r]);
-        if (mi == 1 || mi == 2) {
-          const uint32_t nm = B.name_rank[g0 + (uint32_t)r];
-          const uint32_t oc = cnt[2 * nm + (2 - mi)], of = first[2 * nm + (2 - mi)];
-          if (oc == 1 && of < (uint32_t)r) { later = 1; if (cnt[2 * nm + (mi - 1)] > 1) S.why = BLW_NAMES; }   // (two reads of this name and mate number would share the earlier mate)
-          else if (oc > 1 && of < (uint32_t)r) S.why = BLW_NAMES;   // (several earlier mates: the general path sorts it out)
-        }
-      }
-      isl[r] = later;
-    }
-    bl_scan32(isl, nr + 1, S);
-    WG_LANE0 { S.npairs = S.scan_total; if (S.scan_total > 254u) S.why = BLW_PAIRS; }
-    WG_SYNC();
-    WG_FOR(r, nr) {
-      if (!S.why && isl[r + 1] != isl[r]) {
-        const uint32_t mi = RI_MATE(S.rinfo[r]), nm = B.name_rank[g0 + (uint32_t)r];
-        const uint32_t q = first[2 * nm + (2 - mi)];
-        S.pidx[r] = (uint8_t)isl[r]; S.prole[r] = 2;
-        S.pidx[q] = (uint8_t)isl[r]; S.prole[q] = 1;               // (q is the earlier mate of exactly this read: its name has one read per mate number before r)
-      }
-    }
-  }
-  if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
-  BLP(S, 4);
-  if (C->debug_stop == 104u) { WG_LANE0 { H->why = 99; } return; }
-  // ---- pass 1: every k-mer into the table (first occurrence kept), slot per occurrence to HBM
-  LC_LDS uint32_t *tab = S.big;
-  WG_FOR(i, BL_SLOTS) { tab[i] = BL_EMPTY; }
-  WG_SYNC();
-  BL_OCC_BEGIN(S)
-    bool isF;
-    const unsigned long long ck = bl_canon(bl_kmer(S.bases, boff, kmask), K, kmask, &isF);
-    const unsigned long long h = mix64(ck + 1ULL);
-    uint32_t idx = (uint32_t)h & (BL_SLOTS - 1);
-    uint32_t fp = (uint32_t)(h >> 40) & 0xFFFFu; if (fp == 0xFFFFu) fp = 0xFFFEu;
-    const uint32_t mine = (fp << 16) | boff;
-    uint32_t probes = 0;
-    while (true) {
-      uint32_t cur = ld2(&tab[idx]);
-      if (cur == BL_EMPTY) { cur = dev_atomic_cas32(&tab[idx], BL_EMPTY, mine); if (cur == BL_EMPTY) break; }
-      if ((cur >> 16) == fp) {
-        bool f2;
-        if (bl_canon(bl_kmer(S.bases, cur & 0xFFFFu, kmask), K, kmask, &f2) == ck) {
-          if (mine < cur) dev_atomic_min(&tab[idx], mine);
-          // Scheduling hint (PreHdr::heavy).  All reads are in reference orientation and the loop over k only builds at a k
-          // above the window reference's longest repeat, so a node normally meets its k-mer once per read and always in the
-          // same orientation.  The same k-mer twice in one read (a duplication in the sample), or in both orientations (an
-          // inverted repeat, which isRepeat does not look for), means a walk comes back to the node: if that node survives
-          // removeLowCov the graph has a cycle and this k is rejected (Microassembler.cc:198-206).  The occurrence is noted
-          // here and looked at again once the survivors are known.
-          if (cur != mine && ((f2 != isF) || (r < nr && (cur & 0xFFFFu) - 16u * S.rdo[r] < (uint32_t)RI_TLEN(S.rinfo[r])))) {
-            const uint32_t di = dev_atomic_add((LC_LDS uint32_t *)&S.ndup, 1u);
-            if (di < BL_DUPCAP) X.dupo[di] = (uint16_t)boff;
-          }
-          break;
-        }
-      }
-      idx = (idx + 1) & (BL_SLOTS - 1);
-      if (++probes > 256u) { S.why = BLW_TABLE; break; }
-    }
-    X.occn[boff] = (uint16_t)(idx | (isF ? 0u : 0x8000u));
-  BL_OCC_END
-  if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
-  BLP(S, 5);
-  if (C->debug_stop == 105u) { WG_LANE0 { H->why = 99; } return; }
-  // ---- node ids in first-insertion order: rank of the slot's first-occurrence offset among the occupied slots
-  {
-    LC_LDS uint32_t *bm = (LC_LDS uint32_t *)S.cidx;           // 1024 words of bitmap + 1024 words of prefix (cidx is idle: 12 KB)
-    LC_LDS uint32_t *pre = bm + BL_BASES / 32;
-    WG_FOR(i, BL_BASES / 32) { bm[i] = 0; }
-    WG_SYNC();
-    WG_FOR(i, BL_SLOTS) { const uint32_t e = tab[i]; if (e != BL_EMPTY) dev_atomic_or(&bm[(e & 0xFFFFu) >> 5], 1u << (e & 31u)); }
-    WG_SYNC();
-    WG_FOR(i, BL_BASES / 32) { pre[i] = (uint32_t)dev_popc(bm[i]); }
-    bl_scan32(pre, BL_BASES / 32, S);
-    WG_LANE0 { S.N = S.scan_total; if (S.scan_total > PB_NCAP) S.why = BLW_NODES; }
-    if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
-    WG_FOR(i, BL_SLOTS) {
-      const uint32_t e = tab[i];
-      if (e != BL_EMPTY) {
-        const uint32_t off = e & 0xFFFFu;
-        const uint32_t id = pre[off >> 5] + (uint32_t)dev_popc(bm[off >> 5] & ((1u << (off & 31u)) - 1u));
-        tab[i] = id;                                             // slot -> node id, occurrence count in the upper half (below)
-        S.idoff[id] = (uint16_t)off;
-      }
-    }
-    WG_SYNC();
-  }
-  const uint32_t N = bl_bcast(&S.N);
-  BLP(S, 6);
-  if (C->debug_stop == 106u) { WG_LANE0 { H->why = 99; } return; }
-  // ---- pass 2: slot -> node id per occurrence (HBM, streamed), occurrences per node
-  bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
-    (void)r; (void)p;
-    const uint32_t old = dev_atomic_add(&tab[e & (BL_SLOTS - 1)], 1u << 16);
-    X.occn[boff] = (uint16_t)((old & 0xFFFFu) | (e & 0x8000u));
-  });
-  WG_SYNC();
-  BLP(S, 7);
-  if (C->debug_stop == 107u) { WG_LANE0 { H->why = 99; } return; }
-  // ---- std::hash of every node's k-mer (libstdc++ table order), survivor bytes cleared
-  {
-    LC_GLOBAL unsigned long long *nhash = (LC_GLOBAL unsigned long long *)(area + PRE_OFF_NHASH);
-    LC_GLOBAL uint8_t *surv = (LC_GLOBAL uint8_t *)(area + PRE_OFF_SURV);
-    WG_FOR(n, N) {
-      bool f; const unsigned long long ck = bl_canon(bl_kmer(S.bases, S.idoff[n], kmask), K, kmask, &f);
-      nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGT"[key_base(&ck, K, j)]; }, K);
-      surv[n] = 0;
-    }
-  }
-  // ---- tracked nodes: those whose occurrence count leaves the first removeLowCov test open, and every node with a read AND
-  //      a reference occurrence (their counts feed Ref_t::computeCoverage).  A node with one occurrence is decided: its
-  //      counted occurrences are <= 1 (removeLowCov: mincovQV <= max(LOW_COV_THRESHOLD, MIN_COV_RATIO * avgcov)).
-  const double avgcov = ((double)S.totalreadbp) / ((double)reflen);
-  int tmin = 1;
-  while ((tmin <= P->low_cov_threshold) || ((double)tmin <= (P->min_cov_ratio * avgcov))) ++tmin;
-  const uint32_t tthr = tmin < 2 ? (uint32_t)tmin : 2u;
-  WG_FOR(i, BL_SLOTS) { const uint32_t e = tab[i]; if (e != BL_EMPTY) S.cidx[e & 0xFFFFu] = (uint16_t)(e >> 16); }     // count by node id
-  WG_SYNC();
-  {   // the hint's occurrences: only nodes with real coverage matter (a hairpin in one erroneous read survives removeLowCov
-      // with coverage 2 and is trimmed as a tip later: k is not rejected for it)
-    const uint32_t nd = S.ndup < BL_DUPCAP ? S.ndup : BL_DUPCAP;
-    const uint32_t cthr = (uint32_t)(avgcov / 4.0) > 4u ? (uint32_t)(avgcov / 4.0) : 4u;
-    WG_FOR(i, nd) { if ((uint32_t)S.cidx[X.occn[X.dupo[i]] & 0x1FFFu] < cthr) X.dupo[i] = (uint16_t)0xFFFFu; }
-  }
-  {
-    LC_LDS uint32_t *fl = S.big;                                 // (the table is no longer needed: occn holds node ids)
-    WG_FOR(n, N + 1) { fl[n] = (n < (int)N && S.cidx[n] >= tthr) ? 1u : 0u; }
-    bl_scan32(fl, (int)N + 1, S);
-    WG_LANE0 { S.T = S.scan_total; if (S.scan_total > BL_TCAP) S.why = BLW_TRACKED; }
-    if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
-    WG_FOR(n, N) { S.cidx[n] = (fl[n + 1] != fl[n]) ? (uint16_t)fl[n] : (uint16_t)0xFFFFu; }
-    WG_SYNC();
-  }
-  const uint32_t T = bl_bcast(&S.T);
-  BLP(S, 8);
-  if (C->debug_stop == 108u) { WG_LANE0 { H->why = 99; } return; }
-  // ---- pass 3 (tracked nodes): counted occurrences per strand / sample, colours (Graph.cc:200-217), pair signatures
-  //      S.big: cc[T] (u64) | sig[T * SW] (u64, earlier mates present, one bit per pair) ... todo[1024] | mk[64] at the end
-  {
-    const uint32_t npairs = bl_bcast(&S.npairs);
-    const uint32_t SW = (npairs + 63u) / 64u;
-    LC_LDS unsigned long long *cc = (LC_LDS unsigned long long *)S.big;
-    LC_LDS unsigned long long *sig = cc + T;
-    LC_LDS uint32_t *mk = S.big + BL_BIG / 4 - 64;                 // marked tracked nodes (hold a flagged occurrence)
-    LC_LDS uint32_t *todo = mk - 1024;                             // flagged occurrences: read << 10 | position
-    WG_LANE0 { S.flagged = 0; if (2u * T * (1u + SW) > (uint32_t)(BL_BIG / 4 - 64 - 1024)) S.why = BLW_PAIRS; }
-    if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
-    WG_FOR(t, T) { cc[t] = 0; S.t2c[t] = 0; }
-    WG_FOR(t, T * SW) { sig[t] = 0; }
-    WG_FOR(i, 64) { mk[i] = 0; }
-    WG_SYNC();
-    bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
-      (void)boff;
-      if (r == nr) return;                                         // the reference read: no colour, never counted (Graph.cc:265)
-      const uint32_t ti = S.cidx[e & 0x1FFFu];
-      if (ti == 0xFFFFu) return;
-      const uint32_t ri = S.rinfo[r];
-      const uint32_t cls = (RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u);
-      dev_atomic_add64(&cc[ti], 1ULL << (16 * cls));
-      if (RI_NML(ri)) { if (!(S.t2c[ti] & 2u)) dev_atomic_or((LC_LDS uint32_t *)&S.t2c[ti & ~1u], (ti & 1u) ? (2u << 16) : 2u); }
-      else if (!(S.t2c[ti] & 1u)) {
-        const int tlen = (int)RI_TLEN(ri);
-        const uint32_t gw = S.gwo[r];
-        // the step's u and v both pass MIN_QUAL_CALL at every base: bases s..s+K of the read, for step s = p or p - 1
-        const bool ok = (p < tlen - K && bl_all_good(S.goodm, gw, p, p + K + 1)) || (p - 1 >= 0 && p - 1 < tlen - K && bl_all_good(S.goodm, gw, p - 1, p + K));
-        if (ok) dev_atomic_or((LC_LDS uint32_t *)&S.t2c[ti & ~1u], (ti & 1u) ? (1u << 16) : 1u);
-      }
-      if (S.prole[r] == 1) dev_atomic_or64(&sig[ti * SW + (S.pidx[r] >> 6)], 1ULL << (S.pidx[r] & 63u));
-    });
-    WG_SYNC();
-    if (C->debug_stop == 120u) { WG_LANE0 { H->why = 99; } return; }
-    // the later mates: an occurrence on a node that also holds one of the earlier mate can be an "overlapping mate"
-    // (Node_t::hasOverlappingMate, src/Node.cc:638-661: a hit needs the name to BE in the other mate's vector); these are replayed
-    if (npairs) bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
-      (void)boff;
-      if (S.prole[r] != 2) return;
-      const uint32_t ti = S.cidx[e & 0x1FFFu];
-      if (ti != 0xFFFFu && ((sig[ti * SW + (S.pidx[r] >> 6)] >> (S.pidx[r] & 63u)) & 1ULL)) {
-        const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.flagged, 1u);
-        if (at < 1024u) todo[at] = ((uint32_t)r << 10) | (uint32_t)p;
-        dev_atomic_or(&mk[ti >> 5], 1u << (ti & 31u));
-      }
-    });
-    if (C->debug_stop == 121u) { WG_LANE0 { H->why = 99; } return; }
-    WG_LANE0 { if (S.flagged > 1024u) S.why = BLW_MATE; }
-    if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
-    const uint32_t nflag = bl_bcast(&S.flagged);
-    if (nflag) {
-      // ---- exact replay (kernels.h build_csr): std::binary_search over the names the OTHER mate number pushed on the node before
-      //      this read, in push order (unsorted: SURVEY.md H3).  The occurrences of the marked nodes are listed as
-      //      node << 20 | read << 10 | position and sorted, which is the order loadSequence visited them in.
-      LC_LDS uint32_t *list = S.big + 2 * T;                       // (sig is done with)
-      const uint32_t lcap0 = (uint32_t)(BL_BIG / 4 - 64 - 1024) - 2u * T;
-      uint32_t lcap = 1; while (lcap * 2u <= lcap0 && lcap < 4096u) lcap *= 2u;
-      WG_LANE0 { S.g0 = 0; }
-      WG_FOR(i, lcap) { list[i] = 0xFFFFFFFFu; }
-      WG_SYNC();
-      bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
-        (void)boff;
-        if (r == nr) return;
-        const uint32_t ti = S.cidx[e & 0x1FFFu];
-        if (ti == 0xFFFFu || !((mk[ti >> 5] >> (ti & 31u)) & 1u)) return;
-        const uint32_t mt = RI_MATE(S.rinfo[r]);
-        if (mt != 1 && mt != 2) return;
-        const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.g0, 1u);
-        if (at < lcap) list[at] = (ti << 20) | ((uint32_t)r << 10) | (uint32_t)p;
-      });
-      WG_LANE0 { if (S.g0 > lcap) S.why = BLW_MATE; }
-      if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
-      const uint32_t nl = bl_bcast(&S.g0);
-      uint32_t n2 = 1; while (n2 < nl) n2 *= 2u;
-      for (uint32_t kk = 2; kk <= n2; kk <<= 1)                    // bitonic sort, ascending (the padding sorts last)
-        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-          WG_FOR(i, n2) {
-            const uint32_t l = (uint32_t)i ^ j;
-            if (l > (uint32_t)i) {
-              const uint32_t a = list[i], b2 = list[l];
-              const bool up = (((uint32_t)i & kk) == 0);
-              if ((a > b2) == up) { list[i] = b2; list[l] = a; }
-            }
-          }
-          WG_SYNC();
-        }
-      WG_FOR(fi, nflag) {
-        const uint32_t r = todo[fi] >> 10, p = todo[fi] & 1023u;
-        const uint32_t boff = 16u * S.rdo[r] + p;
-        const uint32_t e = X.occn[boff];
-        const uint32_t ti = S.cidx[e & 0x1FFFu];
-        const uint32_t ri = S.rinfo[r];
-        const uint32_t mi = RI_MATE(ri), nm = B.name_rank[g0 + r] & 0xFFFFu;
-        uint32_t lo = 0, len = nl;                                   // start of the node's run
-        while (len > 0) { const uint32_t h = len >> 1; if ((list[lo + h] >> 20) < ti) { lo += h + 1; len -= h + 1; } else len = h; }
-        // the other mate's pushes of reads before r, in order: one per step the occurrence takes part in (as v of step p-1, as u of step p)
-        auto pushes_of = [&](uint32_t ent) -> uint32_t {
-          const uint32_t er = (ent >> 10) & 1023u, ep = ent & 1023u;
-          const uint32_t eri = S.rinfo[er];
-          if (RI_MATE(eri) != 3u - mi) return 0u;
-          const int etl = (int)RI_TLEN(eri);
-          return (ep >= 1u ? 1u : 0u) + ((int)ep <= etl - K - 1 ? 1u : 0u);
-        };
-        uint32_t total = 0;
-        for (uint32_t i = lo; i < nl && (list[i] >> 20) == ti && ((list[i] >> 10) & 1023u) < r; ++i) total += pushes_of(list[i]);
-        auto name_at = [&](uint32_t idx) -> uint32_t {               // name rank of push number idx of that vector
-          uint32_t acc = 0;
-          for (uint32_t i = lo; i < nl; ++i) { const uint32_t pc = pushes_of(list[i]); if (idx < acc + pc) return B.name_rank[g0 + ((list[i] >> 10) & 1023u)] & 0xFFFFu; acc += pc; }
-          return 0xFFFFFFFFu;
-        };
-        uint32_t first = 0, l2 = total;                              // std::lower_bound over the names, as pushed
-        while (l2 > 0) { const uint32_t h = l2 >> 1, mid = first + h; if (name_at(mid) < nm) { first = mid + 1; l2 = l2 - h - 1; } else l2 = h; }
-        const bool ovl = (first != total) && !(nm < name_at(first));
-        if (ovl) {                                                   // do not update coverage for overlapping mates (Graph.cc:267-271)
-          const uint32_t cls = (RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u);
-          dev_atomic_add64(&cc[ti], 0ULL - (1ULL << (16 * cls)));
-          X.occn[boff] = (uint16_t)(e | 0x4000u);
-        }
-      }
-      WG_SYNC();
-    }
-    if (C->debug_stop == 122u) { WG_LANE0 { H->why = 99; } return; }
-    WG_FOR(t, T) { X.tcc[t] = cc[t]; X.tfl[t] = ((S.t2c[t] & 1u) ? NF_TUMOR : 0u) | ((S.t2c[t] & 2u) ? NF_NORMAL : 0u); }
-    WG_SYNC();
-  }
-  BLP(S, 9);
-  if (C->debug_stop == 109u) { WG_LANE0 { H->why = 99; } return; }
-  // ---- candidates: tracked nodes the count-based predicate leaves undecided (kernels.h build_gather: `low`), in node order
-  {
-    LC_LDS uint32_t *fl = S.big + 2 * BL_TCAP;                   // (cc still in the first 2 T words of S.big)
-    LC_LDS const unsigned long long *cc = (LC_LDS const unsigned long long *)S.big;
-    WG_FOR(t, T + 1) {
-      uint32_t cand = 0;
-      if (t < (int)T) {
-        const unsigned long long c4 = cc[t];
-        const uint32_t c0 = (uint32_t)(c4 & 0xFFFFu), c1 = (uint32_t)((c4 >> 16) & 0xFFFFu), c2 = (uint32_t)((c4 >> 32) & 0xFFFFu), c3 = (uint32_t)(c4 >> 48);
-        const uint32_t counted = c0 + c1 + c2 + c3;
-        const float tt = (float)c0 + (float)c1, tn = (float)c2 + (float)c3;
-        const bool low = ((int)counted <= P->low_cov_threshold) || ((double)counted <= (P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
-        cand = low ? 0u : 1u;
-      }
-      fl[t] = cand;
-    }
-    bl_scan32(fl, (int)T + 1, S);
-    WG_LANE0 { S.ncand = S.scan_total; if (S.scan_total > PB_CCAP) S.why = BLW_CAND; else if ((size_t)S.scan_total * (size_t)K > PB_QVCAP) S.why = BLW_QV; }
-    if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
-    WG_FOR(t, T) { S.t2c[t] = (fl[t + 1] != fl[t]) ? (uint16_t)fl[t] : (uint16_t)0xFFFFu; }
-    WG_SYNC();
-    WG_FOR(n, N) { const uint32_t ti = S.cidx[n]; if (ti != 0xFFFFu) { const uint32_t ci = S.t2c[ti]; if (ci != 0xFFFFu) { X.c_id[ci] = (uint32_t)n; X.c_ti[ci] = ti; } } }
-    WG_SYNC();
-  }
-  const uint32_t ncand = bl_bcast(&S.ncand);
-  BLP(S, 10);
-  if (C->debug_stop == 110u) { WG_LANE0 { H->why = 99; } return; }
-  // ---- per-position quality counts of the candidates (Node_t::updateCovDistr minqv_fwd / minqv_rev, src/Node.cc:470-497) as
-  //      counted - (occurrences whose base at that k-mer position is below MIN_QUAL_CALL); groups of candidates that fit LDS
-  {
-    LC_GLOBAL uint16_t *qv = (LC_GLOBAL uint16_t *)(area + PRE_OFF_QV);
-    LC_LDS unsigned long long *bad = (LC_LDS unsigned long long *)S.big;        // [group][K] four 16-bit counters
-    const uint32_t gmax = (BL_BIG / 8u) / (uint32_t)(K + 1);
-    LC_LDS unsigned long long *gcc = bad + (size_t)gmax * K;                    // [group] the candidates' counted occurrences
-    for (uint32_t c0 = 0; c0 < ncand; c0 += gmax) {
-      const uint32_t c1 = c0 + gmax < ncand ? c0 + gmax : ncand;
-      WG_FOR(i, (c1 - c0) * (uint32_t)K) { bad[i] = 0; }
-      WG_FOR(i, c1 - c0) { gcc[i] = X.tcc[X.c_ti[c0 + (uint32_t)i]]; }
-      WG_SYNC();
-      bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
-        (void)boff;
-        if (r == nr) return;
-        if (e & 0x4000u) return;                                     // an overlapping mate's occurrence: not counted
-        const uint32_t ti = S.cidx[e & 0x1FFFu];
-        if (ti == 0xFFFFu) return;
-        const uint32_t ci = S.t2c[ti];
-        if (ci < c0 || ci >= c1) return;                             // (0xFFFF: not a candidate)
-        const uint32_t ri = S.rinfo[r];
-        const uint32_t cls = (RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u);
-        const uint32_t gw = S.gwo[r];
-        const bool rev = (e & 0x8000u) != 0;
-        // bits p .. p+K-1 of the read's mask; a clear bit at read position p + j is k-mer position j (forward) or K-1-j (reverse)
-        for (int j0 = 0; j0 < K;) {
-          const int pos = p + j0, wv = pos >> 5, lo = pos & 31;
-          int take = 32 - lo; if (take > K - j0) take = K - j0;
-          uint32_t m = ~(S.goodm[gw + wv] >> lo);
-          if (take < 32) m &= (1u << take) - 1u;
-          while (m) {
-            const int j = j0 + (int)__builtin_ctz(m); m &= m - 1u;
-            const int i = rev ? K - 1 - j : j;
-            dev_atomic_add64(&bad[(ci - c0) * (uint32_t)K + (uint32_t)i], 1ULL << (16 * cls));
-          }
-          j0 += take;
-        }
-      });
-      WG_SYNC();
-      WG_FOR(t, (c1 - c0) * (uint32_t)K) {
-        const uint32_t ci = c0 + (uint32_t)t / (uint32_t)K;
-        const unsigned long long c4 = gcc[(uint32_t)t / (uint32_t)K], b4 = bad[t];
-        LC_GLOBAL uint16_t *q = qv + ((size_t)ci * K + ((uint32_t)t % (uint32_t)K)) * 4;
-        for (int cl = 0; cl < 4; ++cl) q[cl] = (uint16_t)(((c4 >> (16 * cl)) & 0xFFFFu) - ((b4 >> (16 * cl)) & 0xFFFFu));
-      }
-      WG_FOR(cc_, c1 - c0) {                                          // mincovQV of the candidate
-        const uint32_t ci = c0 + (uint32_t)cc_;
-        const unsigned long long c4 = gcc[cc_];
-        uint32_t mn = 0x7FFFFFFFu;
-        for (int i = 0; i < K; ++i) {
-          const unsigned long long b4 = bad[(uint32_t)cc_ * (uint32_t)K + (uint32_t)i];
-          uint32_t sq = 0;
-          for (int cl = 0; cl < 4; ++cl) sq += (uint32_t)(((c4 >> (16 * cl)) & 0xFFFFu) - ((b4 >> (16 * cl)) & 0xFFFFu));
-          if (sq < mn) mn = sq;
-        }
-        X.c_minqv[ci] = mn;
-      }
-      WG_SYNC();
-    }
-  }
-  BLP(S, 11);
-  if (C->debug_stop == 111u) { WG_LANE0 { H->why = 99; } return; }
-  // ---- survivors of the first removeLowCov (the predicate on mincovQV), dense in node order
-  {
-    LC_LDS uint32_t *fl = S.big;
-    WG_FOR(ci, ncand + 1) {
-      uint32_t sv = 0;
-      if (ci < (int)ncand) {
-        const unsigned long long c4 = X.tcc[X.c_ti[ci]];
-        const float tt = (float)(uint32_t)(c4 & 0xFFFFu) + (float)(uint32_t)((c4 >> 16) & 0xFFFFu), tn = (float)(uint32_t)((c4 >> 32) & 0xFFFFu) + (float)(uint32_t)(c4 >> 48);
-        const int minqv = (int)X.c_minqv[ci];
-        const bool low = (minqv <= P->low_cov_threshold) || ((double)minqv <= (P->min_cov_ratio * avgcov)) || (tt == 1.0f && tn == 1.0f);
-        sv = low ? 0u : 1u;
-      }
-      fl[ci] = sv;
-    }
-    bl_scan32(fl, (int)ncand + 1, S);
-    WG_LANE0 { S.nsurv = S.scan_total; if (S.scan_total > PB_SCAP) S.why = BLW_SURV; }
-    if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
-    LC_GLOBAL uint32_t *snode = (LC_GLOBAL uint32_t *)(area + PRE_OFF_SNODE);
-    LC_GLOBAL unsigned long long *skey = (LC_GLOBAL unsigned long long *)(area + PRE_OFF_SKEY);
-    LC_GLOBAL uint32_t *sid = (LC_GLOBAL uint32_t *)(area + PRE_OFF_SID);
-    LC_GLOBAL uint8_t *surv = (LC_GLOBAL uint8_t *)(area + PRE_OFF_SURV);
-    WG_FOR(ci, ncand) {
-      const bool sv = fl[ci + 1] != fl[ci];
-      const uint32_t n = X.c_id[ci];
-      snode[ci] = sv ? n : LC_NIL;
-      if (sv) {
-        const uint32_t si = fl[ci];
-        bool f; skey[ci] = bl_canon(bl_kmer(S.bases, S.idoff[n], kmask), K, kmask, &f);
-        sid[si] = n; surv[n] = 1; X.s_ci[si] = (uint32_t)ci;
-      }
-    }
-    WG_SYNC();
-  }
-  const uint32_t nsurv = bl_bcast(&S.nsurv);
-  BLP(S, 12);
-  if (C->debug_stop == 112u) { WG_LANE0 { H->why = 99; } return; }
-  // ---- Ref_t::mertable membership, Ref_t::computeCoverage (src/Ref.cc:40-64, 173-250) from the counts of the tracked nodes, the
-  //      reference pseudo-read's node per offset.  First build of the window: Ref_t::seq is still the whole rawseq.
-  {
-    LC_GLOBAL uint32_t *occ_ref = (LC_GLOBAL uint32_t *)(area + PRE_OFF_OCCREF);
-    LC_GLOBAL uint16_t *refcov = (LC_GLOBAL uint16_t *)(area + PRE_OFF_REFCOV);
-    LC_LDS uint32_t *inmer = S.big;                                // bitmap over node ids
-    WG_FOR(i, PB_NCAP / 32) { inmer[i] = 0; }
-    WG_FOR(j, reflen) { for (int q = 0; q < 4; ++q) refcov[4 * j + q] = 0; }
-    WG_SYNC();
-    const int nrefk = reflen - K > 0 ? reflen - K + 1 : 0;
-    const uint32_t rb = 16u * S.rdo[nr];
-    WG_FOR(i, reflen - K > 0 ? reflen - K : 0) {                   // i + K < seq.length()
-      const uint32_t n = X.occn[rb + (uint32_t)i] & 0x1FFFu;
-      dev_atomic_or(&inmer[n >> 5], 1u << (n & 31u));
-    }
-    WG_SYNC();
-    WG_FOR(i, reflen - K > 0 ? reflen - K : 0) {                   // i + K < rawseq.length(): every one of them is in the table here
-      const uint32_t n = X.occn[rb + (uint32_t)i] & 0x1FFFu;
-      const uint32_t ti = S.cidx[n];
-      unsigned long long c4 = 0;
-      if (ti != 0xFFFFu) c4 = X.tcc[ti];
-      uint16_t v[4]; for (int q = 0; q < 4; ++q) v[q] = (uint16_t)((c4 >> (16 * q)) & 0xFFFFu);
-      if (i == 0) { for (int j = 0; j < K; ++j) for (int q = 0; q < 4; ++q) refcov[4 * j + q] = v[q]; }
-      else { for (int q = 0; q < 4; ++q) refcov[4 * (i + K - 1) + q] = v[q]; }
-    }
-    WG_LANE0 { S.refn = 0; }
-    WG_SYNC();
-    WG_FOR(i, PB_NCAP / 32) { const uint32_t m = inmer[i]; if (m) dev_atomic_add((LC_LDS uint32_t *)&S.refn, (uint32_t)dev_popc(m)); }
-    // survivor index per node from here on (the tracked index is in c_ti for every candidate)
-    WG_SYNC();
-    LC_LDS uint32_t *inm2 = S.big + PB_NCAP / 32;                  // INMER per survivor: keep a copy of the bitmap while cidx changes meaning
-    (void)inm2;
-    WG_FOR(n, N) { S.cidx[n] = 0xFFFFu; }
-    WG_SYNC();
-    WG_FOR(si, nsurv) { S.cidx[X.c_id[X.s_ci[si]]] = (uint16_t)si; }
-    WG_SYNC();
-    {   // the hint: does a node that was met twice in a read / in both orientations survive?
-      const uint32_t nd = S.ndup < BL_DUPCAP ? S.ndup : BL_DUPCAP;
-      WG_FOR(i, nd) { const uint32_t o = X.dupo[i]; if (o != 0xFFFFu && S.cidx[X.occn[o] & 0x1FFFu] != 0xFFFFu) S.hint = 1; }
-      WG_LANE0 { if (S.ndup > BL_DUPCAP) S.hint = 1; }
-    }
-    WG_SYNC();
-    WG_FOR(i, nrefk) {
-      const uint32_t e = X.occn[rb + (uint32_t)i];
-      const uint32_t n = e & 0x1FFFu;
-      occ_ref[i] = n | (S.cidx[n] != 0xFFFFu ? 0u : PB_GONE) | ((e & 0x8000u) ? 0x80000000u : 0u);
-    }
-  }
-  BLP(S, 13);
-  if (C->debug_stop == 113u) { WG_LANE0 { H->why = 99; } return; }
-  // ---- trace only: edge count of every node before the filter (printStats over the whole table): distinct (side, base) slots
-  if (C->evt_cap) {
-    LC_LDS uint32_t *msk = S.big + PB_NCAP / 32;                   // one byte per node, four nodes per word
-    WG_FOR(i, PB_NCAP / 4) { msk[i] = 0; }
-    WG_LANE0 { S.edges_total = 0; }
-    WG_SYNC();
-    bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
-      const uint32_t n = e & 0x1FFFu, ori = e >> 15;
-      const int tlen = r < nr ? (int)RI_TLEN(S.rinfo[r]) : reflen;
-      const int nk = tlen - K + 1;
-      uint32_t m = 0;
-      if (p + 1 < nk) { const int b = bl_base(S.bases, boff + (uint32_t)K); m |= 1u << ((ori == 0 ? 0 : 4) + (ori == 0 ? b : 3 - b)); }
-      if (p > 0) { const int b = bl_base(S.bases, boff - 1u); m |= 1u << ((ori == 0 ? 4 : 0) + (ori == 0 ? b : 3 - b)); }
-      if (m) dev_atomic_or(&msk[n >> 2], m << (8u * (n & 3u)));
-    });
-    WG_SYNC();
-    WG_FOR(i, (N + 3) / 4) { const uint32_t m = msk[i]; if (m) dev_atomic_add((LC_LDS uint32_t *)&S.edges_total, (uint32_t)dev_popc(m)); }
-    WG_SYNC();
-  }
-  BLP(S, 14);
-  if (C->debug_stop == 114u) { WG_LANE0 { H->why = 99; } return; }
-  // ---- edges of the survivors in first-seen order (Node_t::addEdge order over the reads, Graph.cc:320-347): earliest step per
-  //      (side, extension base) slot with LDS atomicMin, groups of survivors that fit; stamp = 2 * offset of the step's u (+1 for
-  //      the v side), offsets grow with (read, position) like the occurrence index of kernels.h
-  {
-    LC_LDS uint32_t *inmer = S.big;                                // (kept: PB_NCAP / 32 words)
-    LC_LDS uint32_t *E = S.big + PB_NCAP / 32 + PB_NCAP / 4;       // [group][8]
-    const uint32_t gmax = (BL_BIG / 4u - PB_NCAP / 32u - PB_NCAP / 4u) / 8u;
-    LC_GLOBAL NodeGr *pgr = (LC_GLOBAL NodeGr *)(area + PRE_OFF_PGR);
-    for (uint32_t s0 = 0; s0 < nsurv; s0 += gmax) {
-      const uint32_t s1 = s0 + gmax < nsurv ? s0 + gmax : nsurv;
-      WG_FOR(i, (s1 - s0) * 8u) { E[i] = LC_NIL; }
-      WG_SYNC();
-      bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
-        const uint32_t si = S.cidx[e & 0x1FFFu];
-        if (si < s0 || si >= s1) return;
-        const uint32_t ori = e >> 15;
-        const int tlen = r < nr ? (int)RI_TLEN(S.rinfo[r]) : reflen;
-        const int nk = tlen - K + 1;
-        if (p + 1 < nk) {                                            // step p: this node is u
-          const int b = bl_base(S.bases, boff + (uint32_t)K);
-          const uint32_t sl = (ori == 0 ? 0u : 4u) + (uint32_t)(ori == 0 ? b : 3 - b);
-          dev_atomic_min(&E[(si - s0) * 8u + sl], 2u * boff);
-        }
-        if (p > 0) {                                                 // step p-1: this node is v
-          const int b = bl_base(S.bases, boff - 1u);
-          const uint32_t sl = (ori == 0 ? 4u : 0u) + (uint32_t)(ori == 0 ? b : 3 - b);
-          dev_atomic_min(&E[(si - s0) * 8u + sl], 2u * (boff - 1u) + 1u);
-        }
-      });
-      WG_SYNC();
-      WG_FOR(sg, s1 - s0) {                                          // one lane per survivor: its record
-        const uint32_t si = s0 + (uint32_t)sg, ci = X.s_ci[si], n = X.c_id[ci], ti = X.c_ti[ci];
-        uint32_t stamp[8]; int ne = 0;
-        for (int j = 0; j < 8; ++j) { const uint32_t v = E[(uint32_t)sg * 8u + (uint32_t)j]; if (v != LC_NIL) stamp[ne++] = v; }
-        for (int i = 1; i < ne; ++i) { const uint32_t s = stamp[i]; int j = i; while (j > 0 && stamp[j - 1] > s) { stamp[j] = stamp[j - 1]; --j; } stamp[j] = s; }
-        LC_GLOBAL NodeGr &G = pgr[si];
-        int m = 0;
-        for (int i = 0; i < ne; ++i) {
-          const uint32_t s = stamp[i] >> 1;
-          const uint32_t a = X.occn[s], b = X.occn[s + 1];           // u and v of that step
-          const uint32_t ua = a >> 15, ub = b >> 15;
-          uint32_t to, dir;
-          if ((stamp[i] & 1u) == 0) { to = b & 0x1FFFu; dir = ua == 0 ? (ub == 0 ? 0u : 1u) : (ub == 0 ? 2u : 3u); }   // FF FR RF RR
-          else { to = a & 0x1FFFu; dir = ua == 0 ? (ub == 0 ? 3u : 1u) : (ub == 0 ? 2u : 0u); }                         // RR FR RF FF
-          if (S.cidx[to] == 0xFFFFu) continue;                       // removeNode of a non-survivor took the edge with it
-          X.s_edges[9 * (size_t)si + (uint32_t)m] = S.cidx[to];     // (neighbour by survivor index: the component search below)
-          G.edges[m++] = ED_MAKE(to, dir);
-        }
-        for (int i = m; i < 8; ++i) X.s_edges[9 * (size_t)si + (uint32_t)i] = 0xFFFFu;
-        X.s_edges[9 * (size_t)si + 8] = ((inmer[n >> 5] >> (n & 31u)) & 1u);
-        for (int i = m; i < LC_EMAX; ++i) G.edges[i] = 0;
-        const unsigned long long c4 = X.tcc[ti];
-        const uint32_t c0 = (uint32_t)(c4 & 0xFFFFu), c1 = (uint32_t)((c4 >> 16) & 0xFFFFu), c2 = (uint32_t)((c4 >> 32) & 0xFFFFu), c3 = (uint32_t)(c4 >> 48);
-        const uint32_t f = X.tfl[ti];
-        G.flags = f | NF_SURV | ((inmer[n >> 5] >> (n & 31u)) & 1u ? NF_INMER : 0u);
-        G.necnt = (uint32_t)m; G.comp = 0; G.color = 0; G.onref = 0; G.nkm = 1;
-        G.nkmT = ((f & NF_TUMOR) && !(f & NF_NORMAL)) ? 1u : 0u;
-        G.cov[0] = (float)c0; G.cov[1] = (float)c1; G.cov[2] = (float)c2; G.cov[3] = (float)c3;
-        G.kc[0] = (uint16_t)c0; G.kc[1] = (uint16_t)c1; G.kc[2] = (uint16_t)c2; G.kc[3] = (uint16_t)c3;
-        G.mincov = (int)(c0 + c1 + c2 + c3); G.mincovqv = (int)X.c_minqv[ci];
-        const uint32_t base = ci * (uint32_t)K;
-        G.seq_clo = base; G.seq_lo = base; G.seq_hi = base + (uint32_t)K; G.seq_chi = base + (uint32_t)K;
-        G.nqv = ci;
-      }
-      WG_SYNC();
-    }
-  }
-  BLP(S, 15);
-  // ---- libstdc++ iteration order of the node table after the N inserts (kernels.h first_lowcov / order_stage),
-  //      reduced to the survivors (cleanDead), and markConnectedComponents over them -- all in LDS: the reads are done with, the
-  //      whole arena from S.bases to the end of S.big is laid out anew.  Tables of more than 4096 nodes leave this to the window kernel.
-  WG_LANE0 { H->have_order = 0; }
-  if (N <= 4096u && nsurv > 0) {
-    LC_LDS uint8_t *arena = (LC_LDS uint8_t *)&S.bases[0];
-    LC_LDS uint32_t *first = (LC_LDS uint32_t *)arena;                       // [5120] smallest position of a bucket's elements
-    LC_LDS uint32_t *tmp = first + 5120;                                     // [4104] run sizes -> run starts -> fill cursors
-    LC_LDS uint16_t *Qa = (LC_LDS uint16_t *)(tmp + 4104), *Qb = Qa + 4096, *bkt = Qb + 4096, *out = bkt + 4096;
-    LC_LDS unsigned long long *nh = (LC_LDS unsigned long long *)(out + 4096);   // [32] hashes of the first inserts
-    LC_LDS uint32_t *nx = (LC_LDS uint32_t *)(nh + 32), *bk = nx + 32;           // [32] list links, [64] buckets of the sequential prefix
-    LC_LDS uint16_t *pos2si = (LC_LDS uint16_t *)(bk + 64);                      // [PB_SCAP] survivor index of the node at a position
-    static_assert(5120 * 4 + 4104 * 4 + 4 * 4096 * 2 + 32 * 8 + 32 * 4 + 64 * 4 + PB_SCAP * 2 <= offsetof(BlShared, big) + BL_BIG, "order arena");
-    LC_GLOBAL const unsigned long long *nhash = (LC_GLOBAL const unsigned long long *)(area + PRE_OFF_NHASH);
-    const uint32_t SEQ = 13u;
-    const uint32_t n0 = N < SEQ ? N : SEQ;
-    WG_SYNC();
-    WG_FOR(i, n0) { nh[i] = nhash[i]; }
-    WG_LANE0 {                                                               // the first inserts literally (_M_insert_bucket_begin / _M_rehash_aux)
-      uint32_t bc = 1, next_resize = 0, elt = 0, head = LC_NIL;
-      bk[0] = LC_NIL;
-      for (uint32_t n = 0; n < n0; ++n) {
-        if (elt + 1 > next_resize) {
-          unsigned long long mn = elt + 1;
-          if (next_resize == 0 && mn < 11) mn = 11;
-          if (mn >= bc) {
-            unsigned long long want = mn + 1; if (want < 2ULL * bc) want = 2ULL * bc;
-            const uint32_t nb = ht_next_prime((uint32_t)want);
-            next_resize = nb;
-            for (uint32_t i = 0; i < nb; ++i) bk[i] = LC_NIL;
-            uint32_t pp = head; head = LC_NIL; uint32_t bbegin = 0;
-            while (pp != LC_NIL) {
-              const uint32_t nxt = nx[pp], b = (uint32_t)(nh[pp] % nb);
-              if (bk[b] == LC_NIL) { nx[pp] = head; head = pp; bk[b] = LC_BB; if (nx[pp] != LC_NIL) bk[bbegin] = pp; bbegin = b; }
-              else { const uint32_t prev = bk[b]; if (prev == LC_BB) { nx[pp] = head; head = pp; } else { nx[pp] = nx[prev]; nx[prev] = pp; } }
-              pp = nxt;
-            }
-            bc = nb;
-          } else next_resize = bc;
-        }
-        const uint32_t b = (uint32_t)(nh[n] % bc), prev = bk[b];
-        if (prev != LC_NIL) { if (prev == LC_BB) { nx[n] = head; head = n; } else { nx[n] = nx[prev]; nx[prev] = n; } }
-        else { nx[n] = head; head = n; if (nx[n] != LC_NIL) bk[(uint32_t)(nh[nx[n]] % bc)] = n; bk[b] = LC_BB; }
-        ++elt;
-      }
-      uint32_t m = 0;
-      for (uint32_t pp = head; pp != LC_NIL; pp = nx[pp]) Qa[m++] = (uint16_t)pp;
-      S.g0 = bc; S.g1 = next_resize;
-    }
-    LC_LDS uint16_t *Q = Qa, *Qn = Qb;
-    uint32_t nprev = SEQ, B = SEQ;
-    if (N > SEQ) while (true) {
-      B = ht_next_prime(2u * B);
-      const uint32_t n = N < B ? N : B;
-      WG_FOR(j, n - nprev) { Q[nprev + (uint32_t)j] = (uint16_t)(nprev + (uint32_t)j); }
-      WG_FOR(b, B) { first[b] = LC_NIL; }
-      WG_FOR(i, n + 1) { tmp[i] = 0; }
-      WG_SYNC();
-      WG_FOR(i, n) { const uint32_t b = (uint32_t)(nhash[Q[i]] % B); bkt[i] = (uint16_t)b; dev_atomic_min(&first[b], (uint32_t)i); }
-      WG_SYNC();
-      WG_FOR(i, n) { dev_atomic_add(&tmp[n - 1 - first[bkt[i]]], 1u); }      // elements per run, runs indexed by their first position, latest first
-      bl_scan32(tmp, (int)n, S);
-      WG_FOR(i, n) { const uint32_t at = dev_atomic_add(&tmp[n - 1 - first[bkt[i]]], 1u); out[at] = (uint16_t)i; }
-      WG_SYNC();
-      WG_FOR(x, n) {                                                          // inside a run: latest first
-        if (x > 0 && bkt[out[x - 1]] == bkt[out[x]]) continue;
-        const uint32_t b = bkt[out[x]];
-        uint32_t e = (uint32_t)x + 1; while (e < n && bkt[out[e]] == b) ++e;
-        for (uint32_t i = (uint32_t)x + 1; i < e; ++i) { const uint16_t v = out[i]; uint32_t j = i; while (j > (uint32_t)x && out[j - 1] < v) { out[j] = out[j - 1]; --j; } out[j] = v; }
-      }
-      WG_SYNC();
-      WG_FOR(j, n) { Qn[j] = Q[out[j]]; }
-      WG_SYNC();
-      { LC_LDS uint16_t *t = Q; Q = Qn; Qn = t; }
-      if (N <= B) break;
-      nprev = B;
-    }
-    if (N > SEQ) { WG_LANE0 { S.g0 = B; S.g1 = B; } }
-    // ---- cleanDead: the survivors in that order; position of every survivor
-    LC_GLOBAL const uint8_t *surv = (LC_GLOBAL const uint8_t *)(area + PRE_OFF_SURV);
-    LC_GLOBAL uint32_t *order_s = (LC_GLOBAL uint32_t *)(area + PRE_OFF_ORDER);
-    LC_GLOBAL const uint32_t *sidv = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_SID);
-    WG_FOR(j, N + 1) { tmp[j] = (j < (int)N && surv[Q[j]]) ? 1u : 0u; }
-    bl_scan32(tmp, (int)N + 1, S);
-    WG_FOR(j, N) { if (tmp[j + 1] != tmp[j]) { order_s[tmp[j]] = Q[j]; first[Q[j]] = tmp[j]; } }    // first[]: node -> position among the survivors (N <= 4096 < 5120)
-    WG_SYNC();
-    // ---- markConnectedComponents (Graph.cc:2252-2336): min-label hooking + pointer jumping over the survivors' positions; the label of a
-    //      component is the position of its first node in table order, which is also what numbers the components
-    LC_LDS uint32_t *parent = tmp;                                           // [nsurv]
-    LC_LDS uint32_t *touch = tmp + 2052;                                     // [nsurv] bit 0: component holds a reference k-mer ; later: component number
-    LC_LDS uint16_t *adj = Qa;                                               // [nsurv * 8] neighbours as positions (Qa .. out: 32 KB)
-    WG_FOR(si, nsurv) {
-      const uint32_t ppos = first[sidv[si]];
-      for (int e = 0; e < 8; ++e) { const uint32_t t = X.s_edges[9 * (size_t)si + (uint32_t)e]; adj[8 * ppos + (uint32_t)e] = t == 0xFFFFu ? (uint16_t)ppos : (uint16_t)first[sidv[t]]; }
-      parent[ppos] = ppos; touch[ppos] = X.s_edges[9 * (size_t)si + 8]; pos2si[ppos] = (uint16_t)si;
-    }
-    WG_SYNC();
-    // (a round = one hooking pass + three pointer-jumping passes, one barrier each, then ONE look at the change flag: testing
-    //  for convergence after every pass cost two more barriers of the 512-lane workgroup per pass, and these passes do little
-    //  else than wait at barriers.  A round that changed nothing leaves every parent a root with no smaller neighbour label.)
-    WG_LANE0 { S.flagged = 0; }
-    WG_SYNC();
-    while (true) {
-      WG_FOR(u, nsurv) {
-        const uint32_t pu = ld2(&parent[u]);
-        uint32_t m = pu;
-        for (int e = 0; e < 8; ++e) { const uint32_t pv = ld2(&parent[adj[8 * (uint32_t)u + (uint32_t)e]]); if (pv < m) m = pv; }
-        if (m < pu) { dev_atomic_min(&parent[pu], m); dev_atomic_min(&parent[u], m); S.flagged = 1; }
-      }
-      WG_SYNC();
-      for (int jp = 0; jp < 3; ++jp) {
-        WG_FOR(u, nsurv) { const uint32_t pu = ld2(&parent[u]), gp = ld2(&parent[pu]); if (gp != pu) { dev_atomic_min(&parent[u], gp); S.flagged = 1; } }
-        WG_SYNC();
-      }
-      const uint32_t changed = S.flagged;                                   // (every lane reads it, then a barrier, then lane 0 clears it)
-      WG_SYNC();
-      if (!changed) break;
-      WG_LANE0 { S.flagged = 0; }
-      WG_SYNC();
-    }
-    WG_FOR(u, nsurv) { if (touch[u] & 1u) dev_atomic_or(&touch[parent[u]], 2u); }
-    WG_SYNC();
-    LC_LDS uint32_t *num = first;                                            // (positions are no longer looked up by node)
-    WG_FOR(u, nsurv + 1) { num[u] = (u < (int)nsurv && parent[u] == (uint32_t)u) ? 1u : 0u; }
-    bl_scan32(num, (int)nsurv + 1, S);
-    WG_LANE0 { S.nbw = S.scan_total; S.ngw = 0; }                            // (nbw / ngw are free by now: components, components on the reference)
-    WG_SYNC();
-    WG_FOR(u, nsurv) { if (parent[u] == (uint32_t)u && (touch[u] & 2u)) dev_atomic_add((LC_LDS uint32_t *)&S.ngw, 1u); }
-    LC_GLOBAL NodeGr *pgr2 = (LC_GLOBAL NodeGr *)(area + PRE_OFF_PGR);
-    WG_FOR(u, nsurv) { pgr2[pos2si[u]].comp = (int)(num[parent[u]] + 1u); }   // numbered by the position of the component's first node
-    WG_LANE0 { H->have_order = 1; H->ht_bc = S.g0; H->ht_next_resize = S.g1; H->numcomp = S.nbw; H->refcomp = S.ngw; }
-    WG_SYNC();
-  }
-  WG_LANE0 {
-    H->K = K; H->refE = S.repE; H->refM = S.repM; H->N = S.N; H->O = S.O; H->totalreadbp = S.totalreadbp; H->n_kmers = S.n_kmers;
-    H->ncand = S.ncand; H->nsurv = S.nsurv; H->edges_total = S.edges_total; H->refn = S.refn; H->why = 0; H->heavy = S.hint;
-    H->status = PB_BUILT;
-  }
-  WG_SYNC();
-}
-
-// entry: persistent workgroups pull windows off the batch queue (`queue` is a counter block of its own)
-// Building ahead: a window whose graph holds the same k-mer twice in one read (PreHdr::heavy) will almost always be rejected at
-// this k (the duplication is a cycle), and the window kernel would then build the next graph with its general, HBM-resident
-// phases on one wave -- ~30x the latency of this kernel, and the few windows that climb through several k are the critical
-// path of the whole launch.  So the workgroup goes on to the next k of the window's loop right away (up to `depth` graphs
-// ahead), into an area of `pool` (pool_cap areas, handed out by queue[2]); PreHdr::next links them.  A graph built ahead that
-// the window kernel does not ask for is wasted work, nothing else: results never depend on what was built ahead.
-// (queue[0] = next window, queue[1] = windows built, queue[2] = pool areas handed out, queue[3] = graphs built ahead)
-DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *B, LC_GLOBAL const EngineCaps *C, LC_GLOBAL uint8_t *pre,
-                           LC_GLOBAL uint8_t *scratch, LC_GLOBAL uint32_t *queue, BL_S &S, int slot, LC_GLOBAL unsigned long long *phase = nullptr,
-                           LC_GLOBAL uint8_t *pool = nullptr, uint32_t pool_cap = 0, int depth = 0) {
-  LC_GLOBAL uint8_t *xbase = scratch + (size_t)slot * BL_SCRATCH_BYTES;
-  while (true) {
-    WG_LANE0 { S.w = (int)dev_atomic_add(queue, 1u); }
-    const int w = (int)bl_bcast(&S.w);
-    if (w >= B->n_windows) break;
-#ifndef LANCET_WAVE_EMU
-    if (threadIdx.x == 0) { for (int i = 0; i < 16; ++i) S.ph_acc[i] = 0; S.ph_cur = 0; S.t_last = wall_clock64(); }
-#endif
-    bl_build_window(P, B, C, S, xbase, pre + (size_t)w * PRE_STRIDE, w, P->min_k, nullptr);
-    {
-      LC_GLOBAL PreHdr *H0 = (LC_GLOBAL PreHdr *)(pre + (size_t)w * PRE_STRIDE), *cur = H0;
-      for (int lvl = 0; pool && lvl < depth; ++lvl) {
-        WG_SYNC();
-        WG_LANE0 {
-          S.scan_total = 0xFFFFFFFFu;
-          if (cur->status == PB_BUILT && cur->heavy && cur->K + 2 <= P->max_k) { const uint32_t a = dev_atomic_add(queue + 2, 1u); if (a < pool_cap) S.scan_total = a; }
-        }
-        const uint32_t a = bl_bcast(&S.scan_total);
-        if (a == 0xFFFFFFFFu) break;
-        LC_GLOBAL uint8_t *nx = pool + (size_t)a * PRE_STRIDE;
-        bl_build_window(P, B, C, S, xbase, nx, w, cur->K + 2, H0);
-        WG_SYNC();
-        WG_LANE0 { if (((LC_GLOBAL PreHdr *)nx)->status == PB_BUILT) { cur->next = a + 1u; dev_atomic_add(queue + 3, 1u); } }
-        if (((LC_GLOBAL PreHdr *)nx)->status != PB_BUILT) break;
-        cur = (LC_GLOBAL PreHdr *)nx;
-      }
-    }
-    BLP(S, 15);
-#ifndef LANCET_WAVE_EMU
-    if (threadIdx.x == 0 && phase) for (int i = 0; i < 16; ++i) if (S.ph_acc[i]) atomicAdd((unsigned long long *)&phase[i], S.ph_acc[i]);
-#endif
-    WG_LANE0 { if (((LC_GLOBAL const PreHdr *)(pre + (size_t)w * PRE_STRIDE))->status == PB_BUILT) dev_atomic_add(queue + 1, 1u); }
-    WG_SYNC();
-  }
-}
+// Two size configurations of the same code:
+//   bl_small  512 lanes, 40 960 bases, 512 reads, 80 KB of LDS: two workgroups per CU -- the 30x/30x windows;
+//   bl_large 1024 lanes, 65 520 bases (16-bit offsets), 1024 reads, ~100 KB of LDS: one workgroup per CU -- windows the small
+//            one turns away for their size (60x/60x: ~360 reads, 58 k bases), taken off the list the small kernel leaves.
+// Same limits on what leaves the workgroup (PB_NCAP nodes, PB_CCAP candidates, PB_SCAP survivors: layout.h).
+#define BL_NS bl_small
+#define BL_WG 512
+#define BL_BASES 40960            /* bases in LDS (reads padded to 16, + the reference)                       */
+#define BL_RMAX 512               /* reads per window                                                          */
+#define BL_SLOTS 8192
+#define BL_TCAP 2048              /* tracked nodes                                                             */
+#define BL_BIG 32768              /* bytes of the phase-dependent LDS area                                     */
+#define BL_LDS_LIMIT (80u * 1024u)
+#include "build_lds_impl.h"
+#undef BL_NS
+#undef BL_WG
+#undef BL_BASES
+#undef BL_RMAX
+#undef BL_LDS_LIMIT
+#define BL_NS bl_large
+#define BL_WG 1024
+#define BL_BASES 65520
+#define BL_RMAX 1024
+#define BL_LDS_LIMIT (160u * 1024u)
+#include "build_lds_impl.h"
+#undef BL_NS
+#undef BL_WG
+#undef BL_BASES
+#undef BL_RMAX
+#undef BL_SLOTS
+#undef BL_TCAP
+#undef BL_BIG
+#undef BL_LDS_LIMIT

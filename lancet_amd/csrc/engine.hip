@@ -26,10 +26,19 @@ __global__ void __launch_bounds__(LANCET_WG * 2) __attribute__((amdgpu_waves_per
 }
 
 // The first graph of every window in LDS (build_lds.h): 256 lanes per window, 2 workgroups per CU (80 KB of LDS each)
-__global__ void __launch_bounds__(BL_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) build_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue,
-                                                      unsigned long long *phase, uint8_t *pool, uint32_t pool_cap, int depth) {
-  build_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL uint8_t *)pre, (LC_GLOBAL uint8_t *)scratch,
-                    (LC_GLOBAL uint32_t *)queue, *(BL_S *)&bl_shared, (int)blockIdx.x, (LC_GLOBAL unsigned long long *)phase, (LC_GLOBAL uint8_t *)pool, pool_cap, depth);
+__global__ void __launch_bounds__(bl_small::WG) __attribute__((amdgpu_waves_per_eu(4, 4))) build_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue,
+                                                      unsigned long long *phase, uint8_t *pool, uint32_t pool_cap, int depth, uint32_t *biglist) {
+  bl_small::build_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL uint8_t *)pre, (LC_GLOBAL uint8_t *)scratch,
+                    (LC_GLOBAL uint32_t *)queue, *(bl_small::BL_S *)&bl_small::bl_shared, (int)blockIdx.x, (LC_GLOBAL unsigned long long *)phase, (LC_GLOBAL uint8_t *)pool, pool_cap, depth,
+                    (LC_GLOBAL uint32_t *)biglist, false);
+}
+// The same for the windows the 512-lane configuration turned away for their size (60x/60x: ~360 reads, 58 k bases): 1024 lanes,
+// one workgroup per CU (~100 KB of LDS), off the list the first kernel left.
+__global__ void __launch_bounds__(bl_large::WG) __attribute__((amdgpu_waves_per_eu(4, 4))) build_kernel_large(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue,
+                                                      unsigned long long *phase, uint8_t *pool, uint32_t pool_cap, int depth, uint32_t *biglist) {
+  bl_large::build_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL uint8_t *)pre, (LC_GLOBAL uint8_t *)scratch,
+                    (LC_GLOBAL uint32_t *)queue, *(bl_large::BL_S *)&bl_large::bl_shared, (int)blockIdx.x, (LC_GLOBAL unsigned long long *)phase, (LC_GLOBAL uint8_t *)pool, pool_cap, depth,
+                    (LC_GLOBAL uint32_t *)biglist, true);
 }
 
 // Graph_t::trim (reference src/Graph.cc:355-384) + 2-bit packing + quality mask, one wave per read: the lanes look at consecutive
@@ -136,7 +145,8 @@ struct lancet_engine {
   int n_windows = 0, n_reads = 0, n_slots = 0;
   int n_rerun = 0;
   // LDS build kernel: hand-off areas (one per window), per-workgroup scratch
-  DevBuf d_pre, d_blscratch, d_blphase, d_order, d_prepool;
+  DevBuf d_pre, d_blscratch, d_blphase, d_order, d_prepool, d_blscratch_large, d_biglist;
+  int n_bslots_large = 0, n_biglist = 0;
   uint32_t pool_cap = 0; int ahead_depth = 3;      // graphs built ahead for windows whose k will climb (build_lds.h, build_kernel_body)
   int n_ahead_built = 0, n_ahead_used = 0;
   bool heavy_first = true;    // LANCET_NO_HEAVY_FIRST=1: windows in batch order
@@ -210,7 +220,7 @@ void lancet_engine_destroy(lancet_engine *e) {
   DevBuf *all[] = {&e->d_params, &e->d_batch, &e->d_caps, &e->d_out, &e->d_works, &e->d_chr, &e->d_refstart, &e->d_refoff, &e->d_refasc,
                    &e->d_refcodes, &e->d_readbegin, &e->d_seqoff, &e->d_seq, &e->d_qual, &e->d_label, &e->d_strand, &e->d_mate, &e->d_mapped,
                    &e->d_rinfo, &e->d_name, &e->d_bw, &e->d_gw, &e->d_bases, &e->d_good, &e->d_variants, &e->d_blob, &e->d_counters,
-                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist, &e->d_bx, &e->d_hp, &e->d_varlr, &e->d_bxblob, &e->d_pre, &e->d_blscratch, &e->d_blphase, &e->d_order, &e->d_prepool};
+                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist, &e->d_bx, &e->d_hp, &e->d_varlr, &e->d_bxblob, &e->d_pre, &e->d_blscratch, &e->d_blphase, &e->d_order, &e->d_prepool, &e->d_blscratch_large, &e->d_biglist};
   for (DevBuf *b : all) b->release();
   if (e->evb0) (void)hipEventDestroy(e->evb0);
   if (e->evb1) (void)hipEventDestroy(e->evb1);
@@ -308,7 +318,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   ENS(e->d_variants, sizeof(lancet_variant) * e->caps.var_cap);
   ENS(e->d_blob, e->caps.blob_cap);
   if (e->caps.lr_mode) { ENS(e->d_varlr, sizeof(lancet_variant_lr) * e->caps.var_cap); ENS(e->d_bxblob, sizeof(uint32_t) * e->caps.bx_cap); }
-  ENS(e->d_counters, 64);
+  ENS(e->d_counters, 128);
   ENS(e->d_stats, sizeof(lancet_window_stats) * nw);
   ENS(e->d_evtlen, sizeof(uint32_t) * nw);
   ENS(e->d_phase, sizeof(unsigned long long) * 16 * nw);
@@ -324,7 +334,9 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     e->n_bslots = std::min(nw, cus * 2);
     if (const char *s = getenv("LANCET_BUILD_SLOTS")) e->n_bslots = std::max(1, std::min(nw, atoi(s)));
     ENS(e->d_pre, (size_t)nw * PRE_STRIDE);
-    ENS(e->d_blscratch, (size_t)e->n_bslots * BL_SCRATCH_BYTES);
+    ENS(e->d_blscratch, (size_t)e->n_bslots * bl_small::SCRATCH_BYTES);
+    e->n_bslots_large = getenv("LANCET_NO_LARGE_BUILD") ? 0 : std::min(nw, cus);
+    if (e->n_bslots_large) { ENS(e->d_blscratch_large, (size_t)e->n_bslots_large * bl_large::SCRATCH_BYTES); ENS(e->d_biglist, sizeof(uint32_t) * (size_t)nw); }
     ENS(e->d_blphase, 16 * sizeof(unsigned long long));
     e->heavy_first = getenv("LANCET_NO_HEAVY_FIRST") == nullptr;
     if (e->heavy_first) { ENS(e->d_order, sizeof(uint32_t) * (size_t)nw); o.win_list = (LC_GLOBAL const uint32_t *)e->d_order.p; o.n_list = (uint32_t)nw; }
@@ -354,19 +366,28 @@ int lancet_engine_submit(lancet_engine *e) {
   e->variants.clear(); e->blob.clear(); e->stats.clear(); e->evt_len.clear(); e->evt.clear(); e->variants_lr.clear(); e->bx_blob.clear();
   e->submitted = true;
   if (e->n_windows == 0) return LANCET_OK;
-  HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, 64, e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, 128, e->stream));
   HIPCHK(e, hipMemsetAsync(e->d_stats.p, 0, sizeof(lancet_window_stats) * e->n_windows, e->stream));
   e->ms_build = 0; e->n_prebuilt = 0;
   if (e->prebuild) {
     HIPCHK(e, hipMemsetAsync(e->d_blphase.p, 0, 16 * sizeof(unsigned long long), e->stream));
     HIPCHK(e, hipEventRecord(e->evb0, e->stream));
-    hipLaunchKernelGGL(build_kernel, dim3(e->n_bslots), dim3(BL_WG), 0, e->stream, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
+    hipLaunchKernelGGL(build_kernel, dim3(e->n_bslots), dim3(bl_small::WG), 0, e->stream, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
                        (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_blscratch.p, (uint32_t *)e->d_counters.p + 8,
-                       (unsigned long long *)e->d_blphase.p, (uint8_t *)(e->pool_cap ? e->d_prepool.p : nullptr), e->pool_cap, e->ahead_depth);
+                       (unsigned long long *)e->d_blphase.p, (uint8_t *)(e->pool_cap ? e->d_prepool.p : nullptr), e->pool_cap, e->ahead_depth,
+                       (uint32_t *)(e->n_bslots_large ? e->d_biglist.p : nullptr));
     HIPCHK(e, hipGetLastError());
+    if (getenv("LANCET_DEBUG")) { HIPCHK(e, hipStreamSynchronize(e->stream)); DBG("build_kernel done"); }
+    if (e->n_bslots_large) {
+      hipLaunchKernelGGL(build_kernel_large, dim3(e->n_bslots_large), dim3(bl_large::WG), 0, e->stream, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
+                         (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_blscratch_large.p, (uint32_t *)e->d_counters.p + 8,
+                         (unsigned long long *)e->d_blphase.p, (uint8_t *)(e->pool_cap ? e->d_prepool.p : nullptr), e->pool_cap, e->ahead_depth, (uint32_t *)e->d_biglist.p);
+      HIPCHK(e, hipGetLastError());
+      if (getenv("LANCET_DEBUG")) { HIPCHK(e, hipStreamSynchronize(e->stream)); DBG("build_kernel_large done"); }
+    }
     if (e->heavy_first) {
       hipLaunchKernelGGL(order_kernel, dim3((e->n_windows + 255) / 256), dim3(256), 0, e->stream, (const uint8_t *)e->d_pre.p, e->n_windows, (uint32_t *)e->d_order.p,
-                         (uint32_t *)e->d_counters.p + 12);
+                         (uint32_t *)e->d_counters.p + 16);
       HIPCHK(e, hipGetLastError());
     }
     HIPCHK(e, hipEventRecord(e->evb1, e->stream));
@@ -375,6 +396,7 @@ int lancet_engine_submit(lancet_engine *e) {
   hipLaunchKernelGGL(window_kernel, dim3(e->n_slots), dim3(LANCET_WG), 0, e->stream, (const lancet_params *)e->d_params.p,
                      (const DevBatch *)e->d_batch.p, (const EngineCaps *)e->d_caps.p, (Work *)e->d_works.p, (DevOut *)e->d_out.p);
   HIPCHK(e, hipGetLastError());
+  if (getenv("LANCET_DEBUG")) { HIPCHK(e, hipStreamSynchronize(e->stream)); DBG("window_kernel done"); }
   HIPCHK(e, hipEventRecord(e->ev1, e->stream));
   return LANCET_OK;
 }
@@ -391,7 +413,7 @@ int lancet_engine_wait(lancet_engine *e) {
     HIPCHK(e, hipEventElapsedTime(&e->ms_build, e->evb0, e->evb1));
     uint32_t bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(e, lc_copy(e, bq, (uint32_t *)e->d_counters.p + 8, sizeof(bq), hipMemcpyDeviceToHost));
-    e->n_prebuilt = (int)bq[1]; e->n_ahead_built = (int)bq[3]; e->n_ahead_used = (int)bq[6];
+    e->n_prebuilt = (int)bq[1]; e->n_ahead_built = (int)bq[3]; e->n_ahead_used = (int)bq[6]; e->n_biglist = (int)bq[4];
     HIPCHK(e, lc_copy(e, e->blphase, e->d_blphase.p, sizeof(e->blphase), hipMemcpyDeviceToHost));
   }
   e->ms_all = e->ms_window + e->ms_build;

@@ -21,7 +21,7 @@ struct EmuResult {
   std::vector<uint32_t> evt_len, evt;
   uint32_t evt_cap;
   uint32_t n_variants, n_blob;
-  uint32_t n_prebuilt, n_ahead_built, n_ahead_used;
+  uint32_t n_prebuilt, n_ahead_built, n_ahead_used, n_biglist;
 };
 
 extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batch *b, uint32_t evt_cap) {
@@ -59,16 +59,25 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   // ---- the LDS build kernel first (one emulated workgroup), unless switched off: LANCET_NO_PREBUILD=1 runs the general build for every window
   std::vector<uint8_t> pre, blscr, pool;
   O.pre = nullptr; O.pre_pool = nullptr; O.n_ahead_used = &res->n_ahead_used;
-  res->n_prebuilt = 0; res->n_ahead_built = 0; res->n_ahead_used = 0;
+  res->n_prebuilt = 0; res->n_ahead_built = 0; res->n_ahead_used = 0; res->n_biglist = 0;
   if (!P->lr_mode && !getenv("LANCET_NO_PREBUILD") && b->n_windows > 0) {
-    pre.assign((size_t)b->n_windows * PRE_STRIDE, 0xCD); blscr.assign(BL_SCRATCH_BYTES + 256, 0xCD);
-    static thread_local BlShared BS;
-    memset(&BS, 0xCD, sizeof(BS));
-    uint32_t bq[4] = {0, 0, 0, 0};
+    pre.assign((size_t)b->n_windows * PRE_STRIDE, 0xCD); blscr.assign(bl_large::SCRATCH_BYTES + 256, 0xCD);
+    static thread_local bl_small::BlShared BS;
+    static thread_local bl_large::BlShared BSL;
+    memset(&BS, 0xCD, sizeof(BS)); memset(&BSL, 0xCD, sizeof(BSL));
+    uint32_t bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<uint32_t> biglist((size_t)b->n_windows + 1, 0);
+    const bool large = getenv("LANCET_NO_LARGE_BUILD") == nullptr;
     const int depth = getenv("LANCET_AHEAD_DEPTH") ? atoi(getenv("LANCET_AHEAD_DEPTH")) : 3;
     const uint32_t pool_cap = depth > 0 ? (uint32_t)(b->n_windows / 4 + 8) : 0u;
     if (pool_cap) pool.assign((size_t)pool_cap * PRE_STRIDE, 0xCD);
-    build_kernel_body(P, &B, &C, pre.data(), blscr.data(), bq, BS, 0, nullptr, pool_cap ? pool.data() : nullptr, pool_cap, depth);
+    if (getenv("LANCET_EMU_FORCE_LARGE")) {                     // (test hook: every window through the 1024-lane configuration)
+      for (int w = 0; w < b->n_windows; ++w) { biglist[(size_t)w] = (uint32_t)w; PreHdr *H = (PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); H->status = PB_NOT_BUILT; H->why = 0; H->have_rep = 0; H->heavy = 0; H->next = 0; }
+      bq[4] = (uint32_t)b->n_windows;
+    } else
+    bl_small::build_kernel_body(P, &B, &C, pre.data(), blscr.data(), bq, BS, 0, nullptr, pool_cap ? pool.data() : nullptr, pool_cap, depth, large ? biglist.data() : nullptr, false);
+    if (large) bl_large::build_kernel_body(P, &B, &C, pre.data(), blscr.data(), bq, BSL, 0, nullptr, pool_cap ? pool.data() : nullptr, pool_cap, depth, biglist.data(), true);
+    res->n_biglist = bq[4];
     O.pre = pre.data(); O.pre_pool = pool_cap ? pool.data() : nullptr;
     res->n_prebuilt = bq[1]; res->n_ahead_built = bq[3];
     if (getenv("LANCET_EMU_HEAVY")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); if (H->status == PB_BUILT && H->heavy) fprintf(stderr, "[emu] heavy %d K %d\n", w, H->K); }
@@ -90,6 +99,7 @@ extern "C" const lancet_window_stats *lancet_emu_stats(void *h) { return ((EmuRe
 extern "C" const uint32_t *lancet_emu_evt_len(void *h) { return ((EmuResult *)h)->evt_len.data(); }
 extern "C" const uint32_t *lancet_emu_evt(void *h) { return ((EmuResult *)h)->evt.data(); }
 extern "C" uint32_t lancet_emu_n_prebuilt(void *h) { return ((EmuResult *)h)->n_prebuilt; }
+extern "C" uint32_t lancet_emu_n_biglist(void *h) { return ((EmuResult *)h)->n_biglist; }
 extern "C" uint32_t lancet_emu_n_ahead_built(void *h) { return ((EmuResult *)h)->n_ahead_built; }
 extern "C" uint32_t lancet_emu_n_ahead_used(void *h) { return ((EmuResult *)h)->n_ahead_used; }
 extern "C" void lancet_emu_free(void *h) { delete (EmuResult *)h; }

@@ -319,3 +319,18 @@ def test_graph_built_ahead_is_adjusted_to_the_trimmed_reference_table():
         _same_as_oracle(b, p)
         used += emu.LAST_AHEAD[1]
     assert used >= 4
+
+
+def test_deep_windows_through_the_1024_lane_build_configuration(monkeypatch):
+    """60x/60x windows are above the 512-lane configuration's limits (40 960 bases in LDS): the first build kernel lists them and
+    the 1024-lane configuration (65 520 bases, one workgroup per CU) builds them, graphs built ahead included.  Then 30x/30x
+    windows forced through the 1024-lane configuration (every size-dependent piece of it on inputs the other one also takes)."""
+    from lancet_amd import workload
+    p = abi.default_params()
+    b = workload.make_scan_batch(100, 60, 60, seed=22)
+    _same_as_oracle(b, p)
+    assert emu.LAST_BIGLIST[0] == 100 and emu.LAST_PREBUILT[0] >= 80
+    monkeypatch.setenv("LANCET_EMU_FORCE_LARGE", "1")
+    b30 = workload.make_scan_batch(60, 30, 30, seed=4)
+    _same_as_oracle(b30, p)
+    assert emu.LAST_PREBUILT[0] == 60

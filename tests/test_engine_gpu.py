@@ -64,6 +64,30 @@ def test_graphs_built_ahead_after_the_reference_table_was_trimmed():
     assert used >= 4
 
 
+def test_deep_windows_through_the_1024_lane_build_configuration():
+    """60x/60x windows (~360 reads, ~58 k bases: above the 512-lane configuration's LDS limits) are taken off the list the first
+    build kernel leaves and built by the 1024-lane one; records and stats equal the oracle's, also with that kernel switched
+    off (LANCET_NO_LARGE_BUILD: general path)."""
+    import os
+    from lancet_amd import workload
+    batch = workload.make_scan_batch(160, 60, 60, seed=22)
+    p = abi.default_params()
+    ov, ostats, _ = oracle.run(batch, p)
+    key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
+    for off in (False, True):
+        if off:
+            os.environ["LANCET_NO_LARGE_BUILD"] = "1"
+        try:
+            eng = engine.Engine(p, device=0)
+            variants, stats = eng.process(batch)
+            built = eng.prebuilt_count()
+            eng.close()
+        finally:
+            os.environ.pop("LANCET_NO_LARGE_BUILD", None)
+        assert variants == ov and [key(s) for s in stats] == [key(s) for s in ostats]
+        assert (built == 0) if off else (built >= 120), built
+
+
 def test_engine_is_deterministic_and_order_independent():
     """Same windows in a different batch order / slot assignment give the same per-window records."""
     meta, batch, kept, (min_k, max_k) = gu.case_batch("tile30")

@@ -21,9 +21,10 @@ def replicate(batch, times):
 
 case = sys.argv[1] if len(sys.argv) > 1 else "tile30"
 times = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-if case == "bench":                                   # the bench.py workload, `times` windows
+if case in ("bench", "bench60"):                      # the bench.py workload (bench60: at 60x/60x), `times` windows
     from lancet_amd import workload
-    big, mk, xk = workload.make_scan_batch(times, 30, 30, seed=22), 11, 101
+    cov = 60 if case == "bench60" else 30
+    big, mk, xk = workload.make_scan_batch(times, cov, cov, seed=22), 11, 101
 else:
     meta, batch, kept, (mk, xk) = gu.case_batch(case)
     big = replicate(batch, times)
