@@ -104,6 +104,7 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.cmp = k.take<CmpRec>(nodes);
   t.nocc = k.take<uint32_t>(nodes + 1);
   t.qv = k.take<uint16_t>((size_t)c.qv_cap * (c.lr_mode ? 10 : 4));
+  t.qv_own = t.qv;
   t.khp = k.take<uint16_t>(c.lr_mode ? nodes * 6 : 1);
   t.refhp = k.take<uint16_t>(c.lr_mode ? LC_MAXW * 6 : 1);
   t.bxbuf = k.take<uint32_t>(c.lr_mode ? c.reads_cap : 1);

@@ -1712,6 +1712,7 @@ DEVNI void build_refcov(Ctx &c) {
   }
 }
 DEV void build_graph(Ctx &c) {
+  WG_LANE0 { LC_CTX(c).W->qv = LC_CTX(c).W->qv_own; }
   if (!wg_bcast(&LC_SREF(c).items_ready)) { build_items(c); WG_LANE0 { LC_SREF(c).items_ready = 1; } }     // (a window whose graphs all come from the LDS build kernel never needs them)
   build_tables(c);
   if (wg_bcast(&LC_SREF(c).overflow)) return;
@@ -3882,8 +3883,16 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
     WG_FOR(i, nsurv) { const uint32_t n = ord[i]; W.order[i] = n; W.nhash[n] = nhash[n]; }
   } else { WG_FOR(n, N) { W.nhash[n] = nhash[n]; } }
   WG_FOR(i, (N + 3) / 4) { ((LC_GLOBAL uint32_t *)W.survb)[i] = ((LC_GLOBAL const uint32_t *)surv)[i]; }
-  WG_FOR(i, (int)(((size_t)ncand * K * 8 + 15) / 16)) { ((LC_GLOBAL lc_v4 *)W.qv)[i] = qsrc[i]; }
-  WG_FOR(i, nsurv * 8u) { const uint32_t si = (uint32_t)i >> 3, part = (uint32_t)i & 7u; ((LC_GLOBAL lc_v4 *)&W.gr[sid[si]])[part] = pgr[(size_t)si * 8 + part]; }
+  WG_LANE0 { W.qv = (LC_GLOBAL uint16_t *)(area + PRE_OFF_QV); }  // (read in place: 73 KB per window not copied; build_graph points qv back at the slot's array)
+  (void)qsrc;
+  WG_FOR(l, LANCET_WG) {                                          // four 16-byte pieces in flight per lane (the loads first, then the stores)
+    const int total = (int)(nsurv * 8u);
+    for (int i0 = l; i0 < total; i0 += 4 * LANCET_WG) {
+      lc_v4 v[4]; uint32_t dn[4];
+      for (int u = 0; u < 4; ++u) { const int i = i0 + u * LANCET_WG; const int ic = i < total ? i : total - 1; v[u] = pgr[(size_t)ic]; dn[u] = sid[(uint32_t)ic >> 3]; }
+      for (int u = 0; u < 4; ++u) { const int i = i0 + u * LANCET_WG; if (i < total) ((LC_GLOBAL lc_v4 *)&W.gr[dn[u]])[(uint32_t)i & 7u] = v[u]; }
+    }
+  }
   WG_FOR(t, ncand * (uint32_t)K) {
     const uint32_t ci = (uint32_t)t / (uint32_t)K; const int i = (int)((uint32_t)t % (uint32_t)K);
     const uint32_t n = snode[ci];

@@ -138,6 +138,12 @@ int main(int argc, char **argv) {
   const char *const *chr_names = lancet_host_chroms(H, &n_chr);
   const int step = batch_windows > 0 ? batch_windows : 1;
   const int nchunks = (nwin + step - 1) / step;
+  // a scan of several batches on one GPU: a second engine on the same device, so that the upload / trim of batch i+1 and the tail
+  // of its kernels overlap with batch i (what `--devices 0,0` asks for explicitly; bench.py --in-flight 2 measures it)
+  if (devices.empty() && nchunks > 1 && engs.size() == 1) {
+    lancet_engine *e2 = nullptr;
+    if (lancet_engine_create(&P, device, &e2) == LANCET_OK) { if (verbose) lancet_engine_set_trace(e2, 1u << 17); engs.push_back(e2); }
+  }
   struct Job { bool have = false; std::string trace; std::vector<lancet_variant> v; std::string blob; std::vector<lancet_variant_lr> lr; std::vector<uint32_t> bx; std::vector<std::string> bxn; };
   struct Slot { lancet_engine *e = nullptr; std::future<int> fut; int chunk = -1; int nk = 0; long base = 0; std::vector<int32_t> kept; std::vector<std::string> bxn; };
   std::vector<Job> jobs((size_t)nchunks);

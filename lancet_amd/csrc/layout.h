@@ -211,6 +211,8 @@ struct Work {
   LC_GLOBAL NodeGr *gr;             /* [nodes]                                                           */
   LC_GLOBAL CmpRec *cmp;            /* [nodes] compress_prepare records                                   */
   LC_GLOBAL uint32_t *nocc;         /* [nodes+1] csr offsets                                             */
+  LC_GLOBAL uint16_t *qv_own;       /* the slot's own array; `qv` below points at it, or -- for a graph the LDS build kernel made -- straight
+                             at the rows in the window's hand-off area (they are only read after the build)                */
   LC_GLOBAL uint16_t *qv;           /* [qv_cap * QS] per-position min-quality counts Tf Tr Nf Nr (QS = 4), in lr_mode followed by
                              hp0/hp1/hp2_minqv of the tumor and of the normal (QS = 10)        */
   LC_GLOBAL uint16_t *khp;          /* [nodes*6] lr_mode: last-written hp0 hp1 hp2 of the k-mer, tumor then normal */
