@@ -969,6 +969,7 @@ DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
                            LC_GLOBAL uint8_t *scratch, LC_GLOBAL uint32_t *queue, BL_S &S, int slot, LC_GLOBAL unsigned long long *phase = nullptr,
                            LC_GLOBAL uint8_t *pool = nullptr, uint32_t pool_cap = 0, int depth = 0, LC_GLOBAL uint32_t *biglist = nullptr, bool from_list = false) {
   LC_GLOBAL uint8_t *xbase = scratch + (size_t)slot * SCRATCH_BYTES;
+  if (from_list && queue[4] == 0u) return;                       // (nothing was turned away for its size: the usual case at 30x)
   while (true) {
     WG_LANE0 { S.w = (int)dev_atomic_add(queue + (from_list ? 5 : 0), 1u); }
     int w = (int)bl_bcast(&S.w);

@@ -81,6 +81,7 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
     O.pre = pre.data(); O.pre_pool = pool_cap ? pool.data() : nullptr;
     res->n_prebuilt = bq[1]; res->n_ahead_built = bq[3];
     if (getenv("LANCET_EMU_HEAVY")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); if (H->status == PB_BUILT && H->heavy) fprintf(stderr, "[emu] heavy %d K %d\n", w, H->K); }
+    if (getenv("LANCET_EMU_HDR")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); fprintf(stderr, "[emu] hdr %d status %u K %d refE %d refM %d heavy %u next %u\n", w, H->status, H->K, H->refE, H->refM, H->heavy, H->next); }
     if (getenv("LANCET_EMU_WHY")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); if (H->status != PB_BUILT) fprintf(stderr, "[emu] window %d not prebuilt: why %u\n", w, H->why); }
   }
   static thread_local WinShared S;
