@@ -45,6 +45,9 @@ struct WinShared {
   int n_builds, final_k, status;
   int tmp0, tmp1, tmp2, tmp3, hasN;
   int rs_bad;                          // repeat_scan_min: the 2-bit staging met a code above 3
+  // the paths findRepeatsInGraphPaths enumerated, kept for eka (W.mv): see pcache_store
+  int pc_ok, pc_n, pc_i, pc_bits, pc_dfs, pc_end_dfs, bfs_dfs;
+  uint32_t pc_top, pc_rd, pc_base;
   int nitems;                          // work items of the per-occurrence passes (build_items)
   uint32_t part[LANCET_WG + 1];
   uint32_t part2[LANCET_WG + 1];                 // second scan scratch (part[0..7] carry the path loop's state)
@@ -2986,11 +2989,12 @@ DEVNI uint32_t bfs(Ctx &c) {
   const uint32_t cap = LC_CTX(c).C->queue_cap;
   int reflen = S.seq_len;
   uint32_t qh = 0, qt = 0;
+  S.bfs_dfs = 0;
   Q[qt].parent = LC_NIL; Q[qt].node = S.source; Q[qt].edge = LC_NIL; Q[qt].len = S.K; Q[qt].score = 0; Q[qt].dir = 'F'; Q[qt].bits = 1; ++qt;
   uint32_t best = LC_NIL; int complete = 0; int visit = 0;
   while (qh < qt) {
     ++visit;
-    if (LC_CTX(c).P->dfs_limit && visit > LC_CTX(c).P->dfs_limit) { evt(c, EV_DFSLIMIT); break; }
+    if (LC_CTX(c).P->dfs_limit && visit > LC_CTX(c).P->dfs_limit) { evt(c, EV_DFSLIMIT); S.bfs_dfs = 1; break; }
     uint32_t idx = qh++;
     BfsEntry cur = Q[idx];
     if (cur.node == S.sink && (cur.bits & 1) == 0) {
@@ -3719,6 +3723,40 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
 // ---------------------------------------------------------------------------------------------------------
 // returns true when a near-perfect repeat is found in a source->sink path (Graph_t::findRepeatsInGraphPaths,
 // reference src/Graph.cc:686-730)
+// findRepeatsInGraphPaths (reference src/Graph.cc:1218-1296) and eka (:1430-1501) enumerate the same paths: both start from
+// cleared edge flags on the same graph, take the best path of a breadth-first search over whole partial paths, flag its edges
+// and search again.  The search is the longest one-lane stretch left in the window kernel, so the first enumeration keeps what
+// the second needs of every path -- nodes, edges, string, per-base descriptors, the has-cycle bit, whether DFS_LIMIT cut the
+// search short -- in W.mv (idle in the graph phases) and eka replays them instead of searching again.  Only a first search
+// that ran to its natural end (no near-repeat found, nothing overflowed, everything fitted) is replayed.
+DEVNI void pcache_store(Ctx &c) {
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  LC_GLOBAL uint32_t *pc = W.mv;
+  const uint32_t capw = 4u * LC_CTX(c).C->occ_cap;
+  WG_LANE0 {
+    const uint32_t n = (uint32_t)S.tmp2, pl = (uint32_t)S.tmp3, need = 4u + 2u * n + pl + (pl + 3u) / 4u;
+    if (S.pc_top + need > capw) S.pc_ok = 0;
+    else { pc[S.pc_top] = n; pc[S.pc_top + 1] = pl; pc[S.pc_top + 2] = (uint32_t)S.pc_bits; pc[S.pc_top + 3] = (uint32_t)S.pc_dfs; S.pc_base = S.pc_top; S.pc_top += need; ++S.pc_n; }
+  }
+  if (!wg_bcast(&S.pc_ok)) return;
+  const uint32_t base = wg_bcastu(&S.pc_base), n = (uint32_t)wg_bcast(&S.tmp2), pl = (uint32_t)wg_bcast(&S.tmp3);
+  WG_FOR(i, n) { pc[base + 4u + (uint32_t)i] = W.pnodes[i]; pc[base + 4u + n + (uint32_t)i] = W.pedges[i]; }
+  WG_FOR(i, pl) { pc[base + 4u + 2u * n + (uint32_t)i] = W.pdesc[i]; }
+  WG_FOR(i, (pl + 3u) / 4u) { pc[base + 4u + 2u * n + pl + (uint32_t)i] = ((LC_GLOBAL const uint32_t *)W.pseq)[i]; }
+  WG_SYNC();
+}
+// the next path of the replay into W.pnodes / W.pedges / W.pdesc / W.pseq; returns its string length
+DEVNI int pcache_load(Ctx &c) {
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  LC_GLOBAL const uint32_t *pc = W.mv;
+  const uint32_t base = wg_bcastu(&S.pc_base);
+  const uint32_t n = pc[base], pl = pc[base + 1];
+  WG_FOR(i, n) { W.pnodes[i] = pc[base + 4u + (uint32_t)i]; W.pedges[i] = pc[base + 4u + n + (uint32_t)i]; }
+  WG_FOR(i, pl) { W.pdesc[i] = pc[base + 4u + 2u * n + (uint32_t)i]; }
+  WG_FOR(i, (pl + 3u) / 4u) { ((LC_GLOBAL uint32_t *)W.pseq)[i] = pc[base + 4u + 2u * n + pl + (uint32_t)i]; }
+  WG_SYNC();
+  return (int)pl;
+}
 DEVNI bool repeats_in_graph_paths(Ctx &c) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   WG_LANE0 {
@@ -3727,12 +3765,13 @@ DEVNI bool repeats_in_graph_paths(Ctx &c) {
     if (S.source == LC_NIL || S.sink == LC_NIL) { evt(c, EV_MISSING); S.tmp0 = 1; }
     else evt(c, EV_SEARCH, (uint32_t)W.gr[S.source].comp);
     S.tmp1 = 0;                                  // number of flagged-edge records kept in scratch
+    S.pc_ok = 1; S.pc_n = 0; S.pc_top = 0; S.pc_end_dfs = 0;
   }
   while (wg_bcast(&S.tmp0) == 0) {
     WG_LANE0 {
       uint32_t best = bfs(c);
-      if (best == LC_NIL || S.overflow) S.tmp0 = 1;
-      else S.tmp2 = path_unpack(c, best);
+      if (best == LC_NIL || S.overflow) { S.tmp0 = 1; S.pc_end_dfs = S.bfs_dfs; }
+      else { S.tmp2 = path_unpack(c, best); S.pc_bits = (W.queue[best].bits & 2) ? 1 : 0; S.pc_dfs = S.bfs_dfs; }
     }
     if (wg_bcast(&S.tmp0) != 0) break;
     { const int pl = path_string_wg(c, wg_bcast(&S.tmp2)); WG_LANE0 { S.tmp3 = pl; if (S.overflow) S.tmp0 = 1; } }
@@ -3757,9 +3796,11 @@ DEVNI bool repeats_in_graph_paths(Ctx &c) {
         for (int j = 1; j < S.tmp2; ++j) { if ((uint32_t)S.tmp1 < LC_CTX(c).C->node_cap) W.scratch[S.tmp1++] = W.pedges[j]; else { OVF(c); S.tmp0 = 1; } }
       }
     }
+    if (wg_bcast(&S.tmp0) == 0 && wg_bcast(&S.pc_ok)) pcache_store(c);
   }
   WG_LANE0 {
     for (int j = 0; j < S.tmp1; ++j) { uint32_t owner = W.scratch[j] >> 4, ei = W.scratch[j] & 15u; W.gr[owner].edges[ei] &= ~(1u << 30); }
+    if (S.tmp0 != 1 || S.overflow) S.pc_ok = 0;          // (only a search that ran to its natural end is replayed by eka)
   }
   return wg_bcast(&S.tmp0) == 2;
 }
@@ -3769,22 +3810,36 @@ DEVNI void count_ref_path(Ctx &c) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   if (wg_bcastu(&S.source) == LC_NIL) return;
   if (wg_bcastu(&S.sink) != LC_NIL) {
-    WG_LANE0 { evt(c, EV_SEARCH, (uint32_t)W.gr[S.source].comp); S.tmp0 = S.tmp1 = S.tmp2 = 0; S.part[0] = 0; S.part[1] = 0; S.part[2] = 0; S.part[3] = 0; }
+    WG_LANE0 { evt(c, EV_SEARCH, (uint32_t)W.gr[S.source].comp); S.tmp0 = S.tmp1 = S.tmp2 = 0; S.part[0] = 0; S.part[1] = 0; S.part[2] = 0; S.part[3] = 0; S.pc_i = 0; S.pc_rd = 0; }
+    const bool replay = wg_bcast(&S.pc_ok) != 0;             // the paths are the ones findRepeatsInGraphPaths found (pcache_store)
     // part[1] = complete, part[2] = allcycles, part[3] = loop state (0 run, 1 stop)
     while (wg_bcastu(&S.part[3]) == 0) {
       WG_LANE0 {
-        uint32_t best = bfs(c);
-        if (best == LC_NIL || S.overflow) S.part[3] = 1;
-        else {
-          S.tmp3 = (W.queue[best].bits & 2) ? 1 : 0;
-          if (S.tmp3) ++S.part[2];
-          ++S.part[1];
-          S.part[4] = (uint32_t)path_unpack(c, best);
+        if (replay) {
+          if (S.pc_i < S.pc_n) {
+            LC_GLOBAL const uint32_t *pc = W.mv + S.pc_rd;
+            const uint32_t n = pc[0], pl = pc[1];
+            if (pc[3]) evt(c, EV_DFSLIMIT);
+            S.tmp3 = (int)pc[2];
+            if (S.tmp3) ++S.part[2];
+            ++S.part[1];
+            S.part[4] = n;
+            S.pc_base = S.pc_rd; S.pc_rd += 4u + 2u * n + pl + (pl + 3u) / 4u; ++S.pc_i;
+          } else { if (S.pc_end_dfs) evt(c, EV_DFSLIMIT); S.part[3] = 1; }
+        } else {
+          uint32_t best = bfs(c);
+          if (best == LC_NIL || S.overflow) S.part[3] = 1;
+          else {
+            S.tmp3 = (W.queue[best].bits & 2) ? 1 : 0;
+            if (S.tmp3) ++S.part[2];
+            ++S.part[1];
+            S.part[4] = (uint32_t)path_unpack(c, best);
+          }
         }
       }
       if (wg_bcastu(&S.part[3]) != 0) break;
       {
-        const int m = path_string_wg(c, (int)wg_bcastu(&S.part[4]));
+        const int m = replay ? pcache_load(c) : path_string_wg(c, (int)wg_bcastu(&S.part[4]));
         // Hamming short-cut (reference src/Graph.cc:818-826)
         const int n = wg_bcast(&S.seq_len);
         LC_GLOBAL const uint8_t *rs = LC_CTX(c).B->ref_codes + LC_CTX(c).B->ref_off[S.w] + S.seq_t5;
