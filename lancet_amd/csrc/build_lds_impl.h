@@ -112,6 +112,15 @@ DEV unsigned long long bl_canon(unsigned long long v, int K, unsigned long long 
   *isF = fw < rc;
   return *isF ? fw : rc;
 }
+DEV unsigned long long bl_canon2(unsigned long long v, int K, unsigned long long kmask, bool *isF, unsigned long long *fwd) {
+  const unsigned long long rc = (~v) & kmask;
+  unsigned long long fw = dev_brev64(v);
+  fw = ((fw >> 1) & 0x5555555555555555ULL) | ((fw & 0x5555555555555555ULL) << 1);
+  fw >>= (64 - 2 * K);
+  *fwd = fw;
+  *isF = fw < rc;
+  return *isF ? fw : rc;
+}
 DEV int bl_base(const LC_LDS uint32_t *bases, uint32_t boff) { return (int)((bases[boff >> 4] >> ((boff & 15u) * 2u)) & 3u); }
 // quality-mask bits [a, b) of a read whose mask starts at word gw: all set?
 DEV bool bl_all_good(const LC_LDS uint32_t *goodm, uint32_t gw, int a, int b) {
@@ -306,18 +315,28 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   WG_SYNC();
   BL_OCC_BEGIN(S)
     bool isF;
-    const unsigned long long ck = bl_canon(bl_kmer(S.bases, boff, kmask), K, kmask, &isF);
-    const unsigned long long h = mix64(ck + 1ULL);
-    uint32_t idx = (uint32_t)h & (BL_SLOTS - 1);
-    uint32_t fp = (uint32_t)(h >> 40) & 0xFFFFu; if (fp == 0xFFFFu) fp = 0xFFFEu;
+    const unsigned long long v1 = bl_kmer(S.bases, boff, kmask);
+    unsigned long long fw1;
+    const unsigned long long ck = bl_canon2(v1, K, kmask, &isF, &fw1);
+    // An earlier occurrence v2 (as it lies in LDS: first base in the low bits) is the same node iff it is this k-mer or its
+    // reverse complement.  Read first-base-high, v2's reverse complement is ~v2 & mask (bl_canon); that equals this k-mer's
+    // forward form fw1 iff v2 == ~fw1 & mask.  So a fingerprint hit is confirmed with one k-mer cut out of LDS and two
+    // compares, without canonicalising the earlier occurrence (k is odd here: no k-mer is its own reverse complement).
+    const unsigned long long alt = (~fw1) & kmask;
+    // table hash on 32-bit words (the table is private to this pass: node ids come from first-occurrence offsets, not slots)
+    uint32_t hh = (uint32_t)ck * 0x9E3779B1u ^ (((uint32_t)(ck >> 32)) ^ ((uint32_t)ck >> 15)) * 0x85EBCA77u;
+    hh ^= hh >> 15; hh *= 0x2C1B3C6Du; hh ^= hh >> 12;
+    uint32_t idx = hh & (BL_SLOTS - 1);
+    uint32_t fp = hh >> 16; if (fp == 0xFFFFu) fp = 0xFFFEu;
     const uint32_t mine = (fp << 16) | boff;
     uint32_t probes = 0;
     while (true) {
       uint32_t cur = ld2(&tab[idx]);
       if (cur == BL_EMPTY) { cur = dev_atomic_cas32(&tab[idx], BL_EMPTY, mine); if (cur == BL_EMPTY) break; }
       if ((cur >> 16) == fp) {
-        bool f2;
-        if (bl_canon(bl_kmer(S.bases, cur & 0xFFFFu, kmask), K, kmask, &f2) == ck) {
+        const unsigned long long v2 = bl_kmer(S.bases, cur & 0xFFFFu, kmask);
+        if (v2 == v1 || v2 == alt) {
+          const bool f2 = (v2 == v1) ? isF : !isF;
           if (mine < cur) dev_atomic_min(&tab[idx], mine);
           // Scheduling hint (PreHdr::heavy).  All reads are in reference orientation and the loop over k only builds at a k
           // above the window reference's longest repeat, so a node normally meets its k-mer once per read and always in the

@@ -449,10 +449,15 @@ DEV void repeat_scan_min_t(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL 
         for (int i = 1; i < rmin; ++i) t &= (mt >> (B * i));
         t &= ~((2ULL << (B * q1)) - 1ULL);                         // starts after the first mismatch ...
         t &= (1ULL << (B * ql)) - 1ULL;                            // ... and before the last one
-        if (t) {
-          unsigned long long m = ne & (ne - 1ULL);
-          int prevq = q1;
-          while (m) { const int q = __builtin_ctzll(m) >> LB; m &= m - 1ULL; if (q - prevq - 1 >= rmin) note(p0 + prevq + 1, p0 + q); prevq = q; }
+        // every set bit of t starts rmin matching positions; the lowest one of a group is where a long run begins, the next
+        // mismatch above it is where it ends.  One trip per LONG run (walking all the word's mismatches instead made every
+        // lane of the wave wait ~24 trips whenever one lane had a long run in its word -- which is nearly always).
+        while (t) {
+          const int sb = __builtin_ctzll(t) >> LB;                          // run [sb, e)
+          const unsigned long long above = ne >> (B * sb);                 // (the word's last mismatch is above sb: not zero)
+          const int e = sb + (__builtin_ctzll(above) >> LB);
+          note(p0 + sb, p0 + e);
+          t = e >= PW ? 0ULL : (t & ~((1ULL << (B * e)) - 1ULL));
         }
       }
       run = PW - 1 - ql;
@@ -2989,6 +2994,7 @@ DEVNI uint32_t bfs(Ctx &c) {
   const uint32_t cap = LC_CTX(c).C->queue_cap;
   int reflen = S.seq_len;
   uint32_t qh = 0, qt = 0;
+  const bool tracing = LC_CTX(c).C->evt_cap != 0;
   S.bfs_dfs = 0;
   Q[qt].parent = LC_NIL; Q[qt].node = S.source; Q[qt].edge = LC_NIL; Q[qt].len = S.K; Q[qt].score = 0; Q[qt].dir = 'F'; Q[qt].bits = 1; ++qt;
   uint32_t best = LC_NIL; int complete = 0; int visit = 0;
@@ -3007,7 +3013,9 @@ DEVNI uint32_t bfs(Ctx &c) {
         uint32_t e = W.gr[cur.node].edges[i];
         if (!is_dir(ED_DIR(e), (char)cur.dir)) continue;
         uint32_t other = ED_TO(e);
-        if (!(Q[idx].bits & 2) && path_has_node(c, idx, other)) Q[idx].bits |= 2;     // Path_t::hasCycle (informational)
+        // Path_t::hasCycle: only ever printed (the -v trace: per path and in the search summary) -- a walk up the whole partial
+        // path per expansion, i.e. quadratic in the path's nodes, so it is evaluated only when the trace is being recorded
+        if (tracing && !(Q[idx].bits & 2) && path_has_node(c, idx, other)) Q[idx].bits |= 2;
         if (qt >= cap) { OVF(c); return LC_NIL; }
         BfsEntry ne;
         ne.parent = idx; ne.node = other; ne.edge = (cur.node << 4) | (uint32_t)i; ne.dir = (uint8_t)dir_dest(ED_DIR(e));
