@@ -599,12 +599,24 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   //      counted - (occurrences whose base at that k-mer position is below MIN_QUAL_CALL); groups of candidates that fit LDS
   {
     LC_GLOBAL uint16_t *qv = (LC_GLOBAL uint16_t *)(area + PRE_OFF_QV);
-    LC_LDS unsigned long long *bad = (LC_LDS unsigned long long *)S.big;        // [group][K] four 16-bit counters
-    const uint32_t gmax = (BL_BIG / 8u) / (uint32_t)(K + 1);
-    LC_LDS unsigned long long *gcc = bad + (size_t)gmax * K;                    // [group] the candidates' counted occurrences
+    // Counters per (candidate, k-mer position): four classes.  When no candidate has more than 255 counted occurrences in a class
+    // (the usual case below ~100x) they are bytes of one 32-bit word -- twice as many candidates per group, i.e. fewer passes
+    // over the window's occurrences, and 32-bit LDS atomics -- else 16-bit fields of a 64-bit word.
+    WG_LANE0 { S.g0 = 0; }
+    WG_SYNC();
+    WG_FOR(ci, ncand) {
+      const unsigned long long c4 = X.tcc[X.c_ti[ci]];
+      if ((c4 & 0xFF00FF00FF00FF00ULL) != 0ULL) S.g0 = 1;
+    }
+    const bool wide = bl_bcast(&S.g0) != 0 || C->debug_stop == 130u;      // (130: test knob, the 16-bit form on any window)
+    const uint32_t esz = wide ? 8u : 4u;
+    const uint32_t gmax = ((uint32_t)BL_BIG - 8u) / ((uint32_t)K * esz + 8u);
+    LC_LDS unsigned long long *bad64 = (LC_LDS unsigned long long *)S.big;      // wide: [group][K] four 16-bit counters
+    LC_LDS uint32_t *bad32 = (LC_LDS uint32_t *)S.big;                          // else: [group][K] four 8-bit counters
+    LC_LDS unsigned long long *gcc = (LC_LDS unsigned long long *)S.big + ((size_t)gmax * K * esz + 7u) / 8u;   // [group] the candidates' counted occurrences
     for (uint32_t c0 = 0; c0 < ncand; c0 += gmax) {
       const uint32_t c1 = c0 + gmax < ncand ? c0 + gmax : ncand;
-      WG_FOR(i, (c1 - c0) * (uint32_t)K) { bad[i] = 0; }
+      if (wide) { WG_FOR(i, (c1 - c0) * (uint32_t)K) { bad64[i] = 0; } } else { WG_FOR(i, (c1 - c0) * (uint32_t)K) { bad32[i] = 0; } }
       WG_FOR(i, c1 - c0) { gcc[i] = X.tcc[X.c_ti[c0 + (uint32_t)i]]; }
       WG_SYNC();
       bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
@@ -628,26 +640,27 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
           while (m) {
             const int j = j0 + (int)__builtin_ctz(m); m &= m - 1u;
             const int i = rev ? K - 1 - j : j;
-            dev_atomic_add64(&bad[(ci - c0) * (uint32_t)K + (uint32_t)i], 1ULL << (16 * cls));
+            if (wide) dev_atomic_add64(&bad64[(ci - c0) * (uint32_t)K + (uint32_t)i], 1ULL << (16 * cls));
+            else dev_atomic_add(&bad32[(ci - c0) * (uint32_t)K + (uint32_t)i], 1u << (8 * cls));
           }
           j0 += take;
         }
       });
       WG_SYNC();
+      auto bad_of = [&](uint32_t t, int cl) -> uint32_t { return wide ? (uint32_t)((bad64[t] >> (16 * cl)) & 0xFFFFu) : ((bad32[t] >> (8 * cl)) & 0xFFu); };
       WG_FOR(t, (c1 - c0) * (uint32_t)K) {
         const uint32_t ci = c0 + (uint32_t)t / (uint32_t)K;
-        const unsigned long long c4 = gcc[(uint32_t)t / (uint32_t)K], b4 = bad[t];
+        const unsigned long long c4 = gcc[(uint32_t)t / (uint32_t)K];
         LC_GLOBAL uint16_t *q = qv + ((size_t)ci * K + ((uint32_t)t % (uint32_t)K)) * 4;
-        for (int cl = 0; cl < 4; ++cl) q[cl] = (uint16_t)(((c4 >> (16 * cl)) & 0xFFFFu) - ((b4 >> (16 * cl)) & 0xFFFFu));
+        for (int cl = 0; cl < 4; ++cl) q[cl] = (uint16_t)(((c4 >> (16 * cl)) & 0xFFFFu) - bad_of((uint32_t)t, cl));
       }
       WG_FOR(cc_, c1 - c0) {                                          // mincovQV of the candidate
         const uint32_t ci = c0 + (uint32_t)cc_;
         const unsigned long long c4 = gcc[cc_];
         uint32_t mn = 0x7FFFFFFFu;
         for (int i = 0; i < K; ++i) {
-          const unsigned long long b4 = bad[(uint32_t)cc_ * (uint32_t)K + (uint32_t)i];
           uint32_t sq = 0;
-          for (int cl = 0; cl < 4; ++cl) sq += (uint32_t)(((c4 >> (16 * cl)) & 0xFFFFu) - ((b4 >> (16 * cl)) & 0xFFFFu));
+          for (int cl = 0; cl < 4; ++cl) sq += (uint32_t)((c4 >> (16 * cl)) & 0xFFFFu) - bad_of((uint32_t)cc_ * (uint32_t)K + (uint32_t)i, cl);
           if (sq < mn) mn = sq;
         }
         X.c_minqv[ci] = mn;

@@ -146,7 +146,7 @@ struct lancet_engine {
   int n_rerun = 0;
   // LDS build kernel: hand-off areas (one per window), per-workgroup scratch
   DevBuf d_pre, d_blscratch, d_blphase, d_order, d_prepool, d_blscratch_large, d_biglist;
-  int n_bslots_large = 0, n_biglist = 0;
+  int n_bslots_large = 0, n_biglist = -1;          // n_biglist: windows the last batch handed to the 1024-lane configuration (-1: no batch yet)
   uint32_t pool_cap = 0; int ahead_depth = 3;      // graphs built ahead for windows whose k will climb (build_lds.h, build_kernel_body)
   int n_ahead_built = 0, n_ahead_used = 0;
   bool heavy_first = true;    // LANCET_NO_HEAVY_FIRST=1: windows in batch order
@@ -379,7 +379,10 @@ int lancet_engine_submit(lancet_engine *e) {
     HIPCHK(e, hipGetLastError());
     if (getenv("LANCET_DEBUG")) { HIPCHK(e, hipStreamSynchronize(e->stream)); DBG("build_kernel done"); }
     if (e->n_bslots_large) {
-      hipLaunchKernelGGL(build_kernel_large, dim3(e->n_bslots_large), dim3(bl_large::WG), 0, e->stream, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
+      // (grid sized from what the previous batch left on the list -- batches of one scan are alike; the kernel works any list
+      //  off whatever its grid, and a full grid of idle 1024-lane workgroups costs 0.4 ms per batch)
+      const int glarge = e->n_biglist < 0 ? e->n_bslots_large : std::max(8, std::min(e->n_bslots_large, e->n_biglist));
+      hipLaunchKernelGGL(build_kernel_large, dim3(glarge), dim3(bl_large::WG), 0, e->stream, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
                          (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_blscratch_large.p, (uint32_t *)e->d_counters.p + 8,
                          (unsigned long long *)e->d_blphase.p, (uint8_t *)(e->pool_cap ? e->d_prepool.p : nullptr), e->pool_cap, e->ahead_depth, (uint32_t *)e->d_biglist.p);
       HIPCHK(e, hipGetLastError());

@@ -27,6 +27,7 @@ struct EmuResult {
 extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batch *b, uint32_t evt_cap) {
   EngineCaps C = lc_caps_for_batch(b, P, evt_cap, 65536);
   if (const char *ts = getenv("LANCET_TABLE_START")) C.table_start = lc_pow2_ge((uint32_t)atoi(ts));
+  if (const char *st = getenv("LANCET_STOP_PHASE")) C.debug_stop = (uint32_t)atoi(st);
   const uint32_t R = b->read_begin[b->n_windows];
   // ---- device batch (host memory here)
   std::vector<uint8_t> ref_codes(b->ref_off[b->n_windows]);

@@ -298,6 +298,10 @@ def test_lds_build_kernel_and_graphs_built_ahead_on_the_bench_workload(monkeypat
     assert emu.LAST_PREBUILT[0] == 400
     assert extra >= 10 and emu.LAST_AHEAD[1] >= extra // 2 and emu.LAST_AHEAD[0] <= 3 * extra, (extra, emu.LAST_AHEAD)
     base = emu.run(b, p, evt_cap=1 << 17)
+    monkeypatch.setenv("LANCET_STOP_PHASE", "130")          # (knob: 16-bit instead of 8-bit per-position counters in the build kernel)
+    wide = emu.run(b, p, evt_cap=1 << 17)
+    monkeypatch.delenv("LANCET_STOP_PHASE")
+    assert wide[0] == base[0] and wide[1] == base[1] and gu.digest_trace(wide[2]) == gu.digest_trace(base[2])
     monkeypatch.setenv("LANCET_AHEAD_DEPTH", "0")
     plain = emu.run(b, p, evt_cap=1 << 17)
     assert emu.LAST_AHEAD == [0, 0] and emu.LAST_PREBUILT[0] == 400
