@@ -877,7 +877,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
             for (uint32_t i = 0; i < nb; ++i) bk[i] = LC_NIL;
             uint32_t pp = head; head = LC_NIL; uint32_t bbegin = 0;
             while (pp != LC_NIL) {
-              const uint32_t nxt = nx[pp], b = (uint32_t)(nh[pp] % nb);
+              const uint32_t nxt = nx[pp], b = ht_mod(nh[pp], nb);
               if (bk[b] == LC_NIL) { nx[pp] = head; head = pp; bk[b] = LC_BB; if (nx[pp] != LC_NIL) bk[bbegin] = pp; bbegin = b; }
               else { const uint32_t prev = bk[b]; if (prev == LC_BB) { nx[pp] = head; head = pp; } else { nx[pp] = nx[prev]; nx[prev] = pp; } }
               pp = nxt;
@@ -885,9 +885,9 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
             bc = nb;
           } else next_resize = bc;
         }
-        const uint32_t b = (uint32_t)(nh[n] % bc), prev = bk[b];
+        const uint32_t b = ht_mod(nh[n], bc), prev = bk[b];
         if (prev != LC_NIL) { if (prev == LC_BB) { nx[n] = head; head = n; } else { nx[n] = nx[prev]; nx[prev] = n; } }
-        else { nx[n] = head; head = n; if (nx[n] != LC_NIL) bk[(uint32_t)(nh[nx[n]] % bc)] = n; bk[b] = LC_BB; }
+        else { nx[n] = head; head = n; if (nx[n] != LC_NIL) bk[ht_mod(nh[nx[n]], bc)] = n; bk[b] = LC_BB; }
         ++elt;
       }
       uint32_t m = 0;
@@ -903,7 +903,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       WG_FOR(b, B) { first[b] = LC_NIL; }
       WG_FOR(i, n + 1) { tmp[i] = 0; }
       WG_SYNC();
-      WG_FOR(i, n) { const uint32_t b = (uint32_t)(nhash[Q[i]] % B); bkt[i] = (uint16_t)b; dev_atomic_min(&first[b], (uint32_t)i); }
+      WG_FOR(i, n) { const uint32_t b = ht_mod(nhash[Q[i]], B); bkt[i] = (uint16_t)b; dev_atomic_min(&first[b], (uint32_t)i); }
       WG_SYNC();
       WG_FOR(i, n) { dev_atomic_add(&tmp[n - 1 - first[bkt[i]]], 1u); }      // elements per run, runs indexed by their first position, latest first
       bl_scan32(tmp, (int)n, S);

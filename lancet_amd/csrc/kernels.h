@@ -626,6 +626,17 @@ DEV uint32_t ht_next_prime(uint32_t n) {   // _M_next_bkt(n) for the values that
   for (int i = 0; i < 18; ++i) if (chain[i] >= n) return chain[i];
   return 0;
 }
+// hash % bucket_count for the bucket counts of that chain: a 64-bit remainder by a run-time divisor is a ~100-instruction loop
+// on this hardware, by a compile-time constant a few multiplies -- and the replay takes one per node and growth stage.
+DEV uint32_t ht_mod(unsigned long long h, uint32_t bc) {
+  switch (bc) {
+    case 13u: return (uint32_t)(h % 13u);       case 29u: return (uint32_t)(h % 29u);       case 59u: return (uint32_t)(h % 59u);
+    case 127u: return (uint32_t)(h % 127u);     case 257u: return (uint32_t)(h % 257u);     case 541u: return (uint32_t)(h % 541u);
+    case 1109u: return (uint32_t)(h % 1109u);   case 2357u: return (uint32_t)(h % 2357u);   case 5087u: return (uint32_t)(h % 5087u);
+    case 10273u: return (uint32_t)(h % 10273u); case 20753u: return (uint32_t)(h % 20753u); case 42043u: return (uint32_t)(h % 42043u);
+    default: return (uint32_t)(h % bc);
+  }
+}
 DEV void ht_reset(Ctx &c) { LC_WS &S = LC_SREF(c); S.ht_bc = 1; S.ht_next_resize = 0; S.ht_elt = 0; S.ht_head = LC_NIL; LC_CTX(c).W->ht_bucket[0] = LC_NIL; }
 DEVNI void ht_rehash(Ctx &c, uint32_t nb) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
@@ -635,7 +646,7 @@ DEVNI void ht_rehash(Ctx &c, uint32_t nb) {
   uint32_t bbegin = 0;
   while (p != LC_NIL) {
     uint32_t nxt = W.ht_next[p];
-    uint32_t b = (uint32_t)(W.nhash[p] % nb);
+    uint32_t b = ht_mod(W.nhash[p], nb);
     if (W.ht_bucket[b] == LC_NIL) {
       W.ht_next[p] = S.ht_head; S.ht_head = p; W.ht_bucket[b] = LC_BB;
       if (W.ht_next[p] != LC_NIL) W.ht_bucket[bbegin] = p;
@@ -699,8 +710,8 @@ DEVNI void order_insert(Ctx &c, uint32_t n) {
   }
   if (wg_bcast(&S.overflow)) return;
   const uint32_t bc = wg_bcastu(&S.ht_bc), M = wg_bcastu(&S.M);
-  const uint32_t b = (uint32_t)(W.nhash[n] % bc);
-  WG_FOR(i, M) { if ((uint32_t)(W.nhash[W.order[i]] % bc) == b) dev_atomic_min((LC_LDS uint32_t *)&S.tmp3, (uint32_t)i); }
+  const uint32_t b = ht_mod(W.nhash[n], bc);
+  WG_FOR(i, M) { if (ht_mod(W.nhash[W.order[i]], bc) == b) dev_atomic_min((LC_LDS uint32_t *)&S.tmp3, (uint32_t)i); }
   WG_SYNC();
   uint32_t at = (uint32_t)wg_bcast(&S.tmp3);
   if (at == 0x7FFFFFFFu) at = 0;
@@ -1756,7 +1767,7 @@ DEVNI void order_stage(Ctx &c, LC_GLOBAL const uint32_t *Q, LC_GLOBAL uint32_t *
   WG_FOR(b, (int)B) { cnt[b] = 0; first[b] = LC_NIL; }
   WG_SYNC();
   WG_FOR(i, n) {
-    uint32_t b = (uint32_t)(W.nhash[Q[i]] % B);
+    uint32_t b = ht_mod(W.nhash[Q[i]], B);
     bkt[i] = b;
     dev_atomic_add(&cnt[b], 1u);
     dev_atomic_min(&first[b], (uint32_t)i);
