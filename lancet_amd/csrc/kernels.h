@@ -3675,13 +3675,28 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
   }
   // bit 1 of the BFS entry = Path_t::hasCycle_m
   evt(c, EV_PATH, (uint32_t)complete, (uint32_t)S.tmp3, (uint32_t)match_bp, (uint32_t)snp_bp, (uint32_t)ins_bp, (uint32_t)del_bp);
+  // Path_t::pathcontig over positions that mostly increase: the scan over the path's nodes resumes where the last one stopped
+  // (from the start again when a position lies before the last one) instead of walking the path from its first node per position
+  int ct_i = 0, ct_cur = 0, ct_last = -1;
+  auto contig_at = [&](int pos) -> uint32_t {
+    if (pos < ct_last) { ct_i = 0; ct_cur = 0; }
+    ct_last = pos;
+    for (; ct_i < np; ++ct_i) {
+      const uint32_t nd = W.pnodes[ct_i];
+      if (W.gr[nd].flags & NF_SPECIAL) continue;
+      const int span = n_len(c, nd);
+      if (ct_cur + span >= pos) return nd;
+      ct_cur += span - K + 1;
+    }
+    return LC_NIL;
+  };
   for (int ti = 0; ti < nts; ++ti) {
     TS &t = ts[ti];
     if (t.code != 'x') {
       for (int j = 0; j <= K; ++j) {
         unsigned idx1 = t.end_pos + (unsigned)j;
         if (idx1 < (unsigned)plen) {
-          uint32_t sp = path_contig(c, np, (int)idx1);
+          uint32_t sp = contig_at((int)idx1);
           if (sp == LC_NIL) break;
           if (status_cnt_T(c, sp)) t.somatic = true;
           uint16_t cn4[4], ct4[4];
