@@ -335,7 +335,16 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     if (const char *s = getenv("LANCET_BUILD_SLOTS")) e->n_bslots = std::max(1, std::min(nw, atoi(s)));
     ENS(e->d_pre, (size_t)nw * PRE_STRIDE);
     ENS(e->d_blscratch, (size_t)e->n_bslots * bl_small::SCRATCH_BYTES);
-    e->n_bslots_large = getenv("LANCET_NO_LARGE_BUILD") ? 0 : std::min(nw, cus);
+    // Can any window be too big for the 512-lane configuration?  Trimming only shortens reads, so the untrimmed lengths bound the
+    // LDS footprint (reads padded to 16 bases + the reference); when none can, the 1024-lane kernel is not launched at all.
+    bool may_need_large = false;
+    for (int w = 0; w < nw && !may_need_large; ++w) {
+      const uint32_t r0 = b->read_begin[w], r1 = b->read_begin[w + 1];
+      if (r1 - r0 > 512u) { may_need_large = true; break; }
+      const uint64_t raw = (uint64_t)(b->seq_off[r1] - b->seq_off[r0]) + 15ull * (r1 - r0) + (b->ref_off[w + 1] - b->ref_off[w]) + 16u;
+      if (raw > 40960ull) may_need_large = true;
+    }
+    e->n_bslots_large = (getenv("LANCET_NO_LARGE_BUILD") || !may_need_large) ? 0 : std::min(nw, cus);
     if (e->n_bslots_large) { ENS(e->d_blscratch_large, (size_t)e->n_bslots_large * bl_large::SCRATCH_BYTES); ENS(e->d_biglist, sizeof(uint32_t) * (size_t)nw); }
     ENS(e->d_blphase, 16 * sizeof(unsigned long long));
     e->heavy_first = getenv("LANCET_NO_HEAVY_FIRST") == nullptr;
