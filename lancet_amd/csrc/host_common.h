@@ -61,10 +61,13 @@ static inline EngineCaps lc_caps_for_batch(const lancet_window_batch *b, const l
   c.seq_cap = 3 * c.qv_cap + 65536;
   c.path_cap = LC_MAXW + (uint32_t)p->max_indel_len + 256;
   c.evt_cap = evt_cap;
-  c.var_cap = (uint32_t)b->n_windows * 8 + 1024;
-  c.blob_cap = (uint32_t)b->n_windows * 512 + 65536;
+  // Records of the whole batch.  A scan emits ~0.7 per window; permissive settings (--low-cov 0 on noisy reads) reach several
+  // hundred per window (fuzz case 7122: 355), and a small batch has no other windows to average that out: 64 per window and
+  // a floor of 64 Ki records (lancet_variant is 64 bytes: 140 MB for a 32768-window batch).
+  c.var_cap = (uint32_t)b->n_windows * 64u + 65536u;
+  c.blob_cap = (uint32_t)b->n_windows * 4096u + (4u << 20);
   c.lr_mode = p->lr_mode ? 1u : 0u;
-  c.bx_cap = c.lr_mode ? (uint32_t)b->n_windows * 2048u + 65536u : 0u;
+  c.bx_cap = c.lr_mode ? (uint32_t)b->n_windows * 8192u + (1u << 20) : 0u;
   return c;
 }
 
