@@ -811,7 +811,8 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   std::vector<std::vector<Sel>> selT((size_t)nwin), selN((size_t)nwin);
-  std::vector<uint8_t> keep((size_t)nwin, 0);
+  std::vector<uint8_t> keep((size_t)nwin, 0), wmapped((size_t)nwin, 0);
+  std::vector<uint64_t> wbases((size_t)nwin, 0);
   {   // per-window filters and read selection: independent windows, one chunk of windows per host thread at a time
     std::atomic<int> next(0);
     auto work = [&]() {
@@ -825,6 +826,10 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
         const bool okT = extract_reads(h->smp[1], win, false, *o, &selT[(size_t)i]);
         const bool okN = extract_reads(h->smp[0], win, true, *o, &selN[(size_t)i]);      // (both samples are read before the skip test, :833-836)
         keep[(size_t)i] = (okT && okN) ? 1 : 2;                                        // 2: skipped for coverage -> g.clear(true)
+        uint64_t nb = 0; uint8_t mp = 0;
+        for (const Sel &s : selT[(size_t)i]) { nb += h->smp[1].reads[s.idx].l_seq; mp |= s.mapped; }
+        for (const Sel &s : selN[(size_t)i]) { nb += h->smp[0].reads[s.idx].l_seq; mp |= s.mapped; }
+        wbases[(size_t)i] = nb; wmapped[(size_t)i] = mp;
       }
     };
     unsigned nt = host_threads(nwin);
@@ -837,17 +842,17 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
   // ---- SoA assembly, windows in processing order; per window tumor reads then normal reads (:833-834).
   //      Sizes first (prefix sums), then every window fills its own slices on the host threads.
   std::vector<int> kw;                                 // kept windows (index into [w_begin, w_end))
-  std::vector<std::vector<RSel>> lists;                // their reads: what an earlier window left in the graph, tumor, normal
+  std::vector<std::vector<RSel>> pre;                  // per kept window: what an earlier window left in the graph (nearly always empty);
+                                                       // its own reads follow: selT then selN -- no per-window copies
   for (int i = 0; i < nwin; ++i) {
     if (keep[(size_t)i] == 2) { h->leak.clear(); continue; }
     if (keep[(size_t)i] != 1) continue;
-    std::vector<RSel> l = h->leak;
-    for (const Sel &s : selT[(size_t)i]) l.push_back(RSel{1, s});
-    for (const Sel &s : selN[(size_t)i]) l.push_back(RSel{0, s});
-    bool mapped = false;
-    for (const RSel &r : l) mapped = mapped || r.s.mapped;
-    if (mapped) h->leak.clear(); else h->leak = l;       // countMappedReads() <= 0: processGraph returns, nothing is cleared
-    kw.push_back(i); lists.push_back(std::move(l));
+    kw.push_back(i); pre.push_back(h->leak);
+    if (wmapped[(size_t)i]) h->leak.clear();           // (left-over reads are unmapped by construction: the window's own reads decide)
+    else {                                             // countMappedReads() <= 0: processGraph returns, nothing is cleared
+      for (const Sel &s2 : selT[(size_t)i]) h->leak.push_back(RSel{1, s2});
+      for (const Sel &s2 : selN[(size_t)i]) h->leak.push_back(RSel{0, s2});
+    }
   }
   const int nk = (int)kw.size();
   h->b_chr.assign((size_t)nk, 0); h->b_refstart.resize((size_t)nk);
@@ -857,10 +862,10 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
     const int i = kw[(size_t)k];
     const Window &win = h->windows[(size_t)(w_begin + i)];
     if (kept) kept[k] = w_begin + i;
-    uint64_t nb = 0;
-    for (const RSel &r : lists[(size_t)k]) nb += h->smp[r.smp].reads[r.s.idx].l_seq;
+    uint64_t nb = wbases[(size_t)i];
+    for (const RSel &r : pre[(size_t)k]) nb += h->smp[r.smp].reads[r.s.idx].l_seq;
     base0[(size_t)k + 1] = base0[(size_t)k] + nb;
-    h->b_readbegin[(size_t)k + 1] = h->b_readbegin[(size_t)k] + (uint32_t)lists[(size_t)k].size();
+    h->b_readbegin[(size_t)k + 1] = h->b_readbegin[(size_t)k] + (uint32_t)(pre[(size_t)k].size() + selT[(size_t)i].size() + selN[(size_t)i].size());
     h->b_refoff[(size_t)k + 1] = h->b_refoff[(size_t)k] + (uint32_t)win.seq.size();
   }
   if (base0[(size_t)nk] > 0xFFFFFFFFull) { h->err = "batch holds more than 4 Gi bases: use fewer windows per batch"; return LANCET_E_ARG; }
@@ -886,8 +891,7 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
         size_t r = h->b_readbegin[(size_t)k]; const size_t r0 = r; size_t bo = (size_t)base0[(size_t)k];
         names.clear();
         {
-          for (const RSel &rs : lists[(size_t)k]) {
-            const int smp = rs.smp; const Sel &s = rs.s;
+          auto one = [&](int smp, const Sel &s) {
             const Sample &S = h->smp[smp];
             const Read &rd = S.reads[s.idx];
             memcpy(&h->b_seq[bo], S.seq.data() + rd.seq_off, rd.l_seq); memcpy(&h->b_qual[bo], S.qual.data() + rd.seq_off, rd.l_seq);
@@ -897,7 +901,10 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
             names.push_back(S.text.c_str() + rd.name_off);
             if (o->linked) { bx_of[r] = S.text.c_str() + rd.bx_off; h->b_hp[r] = (uint8_t)(rd.hp > 255 ? 255 : rd.hp); }
             ++r;
-          }
+          };
+          for (const RSel &rs : pre[(size_t)k]) one(rs.smp, rs.s);
+          for (const Sel &s2 : selT[(size_t)i]) one(1, s2);
+          for (const Sel &s2 : selN[(size_t)i]) one(0, s2);
         }
         // dense rank of the read name among the window's names under std::string operator<
         ord.resize(names.size());
