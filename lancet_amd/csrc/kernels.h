@@ -1162,17 +1162,36 @@ DEVNI void build_tables(Ctx &c) {
   // reads whose opposite mate (same name) comes earlier in the window: only these can ever see
   // hasOverlappingMate()==true (reference src/Node.cc:638-661); everything else is counted directly.
   // cand: 0 none, 1 exactly one such earlier read (its index in mate_of), 2 several (same name seen more than once)
-  WG_FOR(r, S.R) {
-    uint8_t cd = 0; uint32_t mo = LC_NIL;
-    if (r != S.R - 1) {
-      uint32_t g0 = LC_CTX(c).B->read_begin[S.w];
-      uint32_t mi = RI_MATE(LC_CTX(c).B->rinfo[g0 + r]);
-      if (mi == 1 || mi == 2) {
-        uint32_t nm = LC_CTX(c).B->name_rank[g0 + r];
-        for (int q = 0; q < r; ++q) if (LC_CTX(c).B->name_rank[g0 + q] == nm && RI_MATE(LC_CTX(c).B->rinfo[g0 + q]) == 3 - mi) { if (cd == 0) { cd = 1; mo = (uint32_t)q; } else { cd = 2; break; } }
-      }
+  // (the smallest and second smallest read index per (name, mate number), by atomicMin over the name ranks -- a scan over the
+  //  earlier reads per read is quadratic in the window's reads: 120 ms for a 12 000-read pile-up)
+  {
+    const int R1 = S.R - 1;
+    const uint32_t g0 = LC_CTX(c).B->read_begin[S.w];
+    LC_GLOBAL uint32_t *f1 = W.mv, *f2 = W.mv + 2 * (size_t)S.R;        // (mv[] is idle until build_csr; name ranks are < R)
+    WG_FOR(i, 4 * S.R) { W.mv[i] = LC_NIL; }
+    WG_SYNC();
+    WG_FOR(r, R1) {
+      const uint32_t mi = RI_MATE(LC_CTX(c).B->rinfo[g0 + r]);
+      if (mi == 1 || mi == 2) dev_atomic_min(&f1[2 * (size_t)LC_CTX(c).B->name_rank[g0 + r] + (mi - 1u)], (uint32_t)r);
     }
-    W.cand[r] = cd; W.mate_of[r] = mo;
+    WG_SYNC();
+    WG_FOR(r, R1) {
+      const uint32_t mi = RI_MATE(LC_CTX(c).B->rinfo[g0 + r]);
+      if (mi == 1 || mi == 2) { const size_t sl = 2 * (size_t)LC_CTX(c).B->name_rank[g0 + r] + (mi - 1u); if (ld2(&f1[sl]) != (uint32_t)r) dev_atomic_min(&f2[sl], (uint32_t)r); }
+    }
+    WG_SYNC();
+    WG_FOR(r, S.R) {
+      uint8_t cd = 0; uint32_t mo = LC_NIL;
+      if (r != R1) {
+        const uint32_t mi = RI_MATE(LC_CTX(c).B->rinfo[g0 + r]);
+        if (mi == 1 || mi == 2) {
+          const size_t sl = 2 * (size_t)LC_CTX(c).B->name_rank[g0 + r] + (2u - mi);    // the opposite mate number's entry
+          const uint32_t a1 = ld2(&f1[sl]), a2 = ld2(&f2[sl]);
+          if (a1 < (uint32_t)r) { cd = 1; mo = a1; if (a2 < (uint32_t)r) cd = 2; }
+        }
+      }
+      W.cand[r] = cd; W.mate_of[r] = mo;
+    }
   }
   WG_LANE0 { S.tmp1 = 0; W.nocc[S.N] = 0; }
   WG_SYNC();
