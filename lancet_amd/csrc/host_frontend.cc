@@ -532,7 +532,15 @@ struct lancet_host {
   // last batch
   std::vector<int32_t> b_chr, b_refstart;
   std::vector<uint32_t> b_refoff, b_readbegin, b_seqoff, b_namerank, b_bxrank;
-  std::string b_ref, b_seq, b_qual;
+  std::string b_ref;
+  // bases / qualities of the batch: grow-only raw buffers (a std::string would zero-fill ~270 MB per batch on one thread before the
+  // host threads overwrite every byte of it; here the pages are first touched by the threads that fill them)
+  struct RawBuf {
+    char *p = nullptr; size_t cap = 0;
+    ~RawBuf() { free(p); }
+    void need(size_t n) { if (n > cap) { free(p); cap = n + n / 8 + 4096; p = (char *)malloc(cap); } }
+    char *data() { return p; }
+  } b_seq, b_qual;
   std::vector<uint8_t> b_label, b_strand, b_mate, b_mapped, b_hp;
   std::vector<std::string> bx_names;
   std::vector<const char *> bx_ptrs;
@@ -871,7 +879,8 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
   if (base0[(size_t)nk] > 0xFFFFFFFFull) { h->err = "batch holds more than 4 Gi bases: use fewer windows per batch"; return LANCET_E_ARG; }
   const size_t R = h->b_readbegin[(size_t)nk], NB = (size_t)base0[(size_t)nk];
   h->b_ref.resize(h->b_refoff[(size_t)nk]);
-  h->b_seq.resize(NB); h->b_qual.resize(NB);
+  h->b_seq.need(NB + 1); h->b_qual.need(NB + 1);
+  if (!h->b_seq.p || !h->b_qual.p) { h->err = "out of memory for the batch"; return LANCET_E_ARG; }
   h->b_seqoff.resize(R + 1); h->b_seqoff[0] = 0;
   h->b_label.resize(R); h->b_strand.resize(R); h->b_mate.resize(R); h->b_mapped.resize(R); h->b_namerank.resize(R);
   h->b_hp.resize(o->linked ? R : 0);
@@ -894,7 +903,7 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
           auto one = [&](int smp, const Sel &s) {
             const Sample &S = h->smp[smp];
             const Read &rd = S.reads[s.idx];
-            memcpy(&h->b_seq[bo], S.seq.data() + rd.seq_off, rd.l_seq); memcpy(&h->b_qual[bo], S.qual.data() + rd.seq_off, rd.l_seq);
+            memcpy(h->b_seq.p + bo, S.seq.data() + rd.seq_off, rd.l_seq); memcpy(h->b_qual.p + bo, S.qual.data() + rd.seq_off, rd.l_seq);
             bo += rd.l_seq;
             h->b_seqoff[r + 1] = (uint32_t)bo;
             h->b_label[r] = smp ? LANCET_TMR : LANCET_NML; h->b_strand[r] = s.strand; h->b_mate[r] = s.mate; h->b_mapped[r] = s.mapped;
