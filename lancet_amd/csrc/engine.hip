@@ -147,7 +147,7 @@ struct lancet_engine {
   // LDS build kernel: hand-off areas (one per window), per-workgroup scratch
   DevBuf d_pre, d_blscratch, d_blphase, d_order, d_prepool, d_blscratch_large, d_biglist;
   int n_bslots_large = 0, n_biglist = -1;          // n_biglist: windows the last batch handed to the 1024-lane configuration (-1: no batch yet)
-  uint32_t pool_cap = 0; int ahead_depth = 3;      // graphs built ahead for windows whose k will climb (build_lds.h, build_kernel_body)
+  uint32_t pool_cap = 0; int ahead_depth = 6;      // graphs built ahead for windows whose k will climb (build_lds.h, build_kernel_body)
   int n_ahead_built = 0, n_ahead_used = 0;
   bool heavy_first = true;    // LANCET_NO_HEAVY_FIRST=1: windows in batch order
   unsigned long long blphase[16] = {0};
@@ -350,7 +350,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     e->heavy_first = getenv("LANCET_NO_HEAVY_FIRST") == nullptr;
     if (e->heavy_first) { ENS(e->d_order, sizeof(uint32_t) * (size_t)nw); o.win_list = (LC_GLOBAL const uint32_t *)e->d_order.p; o.n_list = (uint32_t)nw; }
     o.pre = (LC_GLOBAL const uint8_t *)e->d_pre.p;
-    e->ahead_depth = 3;
+    e->ahead_depth = 6;
     if (const char *s = getenv("LANCET_AHEAD_DEPTH")) e->ahead_depth = std::max(0, std::min(16, atoi(s)));
     e->pool_cap = e->ahead_depth > 0 ? (uint32_t)std::max(64, nw / 4) : 0u;
     if (e->pool_cap) { ENS(e->d_prepool, (size_t)e->pool_cap * PRE_STRIDE); o.pre_pool = (LC_GLOBAL const uint8_t *)e->d_prepool.p; o.n_ahead_used = (LC_GLOBAL uint32_t *)e->d_counters.p + 14; }

@@ -69,7 +69,7 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
     uint32_t bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<uint32_t> biglist((size_t)b->n_windows + 1, 0);
     const bool large = getenv("LANCET_NO_LARGE_BUILD") == nullptr;
-    const int depth = getenv("LANCET_AHEAD_DEPTH") ? atoi(getenv("LANCET_AHEAD_DEPTH")) : 3;
+    const int depth = getenv("LANCET_AHEAD_DEPTH") ? atoi(getenv("LANCET_AHEAD_DEPTH")) : 6;
     const uint32_t pool_cap = depth > 0 ? (uint32_t)(b->n_windows / 4 + 8) : 0u;
     if (pool_cap) pool.assign((size_t)pool_cap * PRE_STRIDE, 0xCD);
     if (getenv("LANCET_EMU_FORCE_LARGE")) {                     // (test hook: every window through the 1024-lane configuration)
