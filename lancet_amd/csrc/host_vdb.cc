@@ -9,21 +9,71 @@
 //   Variant_t::printVCF   reference src/Variant.cc:39-223
 //   FET_t                 reference src/FET.hh:36-128 (Heng Li's kt_fisher_exact)
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <cpuid.h>
+#include <immintrin.h>
 
 #include "../../include/lancet_engine.h"
 
 namespace {
 
 // ---- SHA-256 (FIPS 180-4), hex digest: only its ordering matters (map iteration order of the final merge)
+static const uint32_t SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+// One 64-byte block with the x86 SHA extensions (sha256rnds2 / sha256msg1 / sha256msg2), used when the host CPU has them:
+// rank 0 hashes every record of every rank when it replays them, and the scalar rounds were its largest single cost.
+__attribute__((target("sha,sse4.1,ssse3"))) void sha256_block_ni(uint32_t st[8], const uint8_t *p) {
+  const __m128i bswap = _mm_set_epi64x(0x0c0d0e0f08090a0bLL, 0x0405060700010203LL);
+  __m128i t = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i *)&st[0]), 0xB1);   // CDAB
+  __m128i s1 = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i *)&st[4]), 0x1B);  // EFGH
+  __m128i s0 = _mm_alignr_epi8(t, s1, 8);                                          // ABEF
+  s1 = _mm_blend_epi16(s1, t, 0xF0);                                               // CDGH
+  const __m128i s0_in = s0, s1_in = s1;
+  __m128i m[4];
+  for (int r = 0; r < 4; ++r) m[r] = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(p + 16 * r)), bswap);
+  for (int r = 0; r < 16; ++r) {                                                   // four rounds per turn
+    if (r >= 4) {
+      __m128i w = _mm_sha256msg1_epu32(m[r & 3], m[(r + 1) & 3]);
+      w = _mm_add_epi32(w, _mm_alignr_epi8(m[(r + 3) & 3], m[(r + 2) & 3], 4));
+      m[r & 3] = _mm_sha256msg2_epu32(w, m[(r + 3) & 3]);
+    }
+    __m128i x = _mm_add_epi32(m[r & 3], _mm_loadu_si128((const __m128i *)&SHA_K[4 * r]));
+    s1 = _mm_sha256rnds2_epu32(s1, s0, x);
+    s0 = _mm_sha256rnds2_epu32(s0, s1, _mm_shuffle_epi32(x, 0x0E));
+  }
+  s0 = _mm_add_epi32(s0, s0_in); s1 = _mm_add_epi32(s1, s1_in);
+  t = _mm_shuffle_epi32(s0, 0x1B);                                                 // FEBA
+  s1 = _mm_shuffle_epi32(s1, 0xB1);                                                // DCHG
+  _mm_storeu_si128((__m128i *)&st[0], _mm_blend_epi16(t, s1, 0xF0));               // DCBA
+  _mm_storeu_si128((__m128i *)&st[4], _mm_alignr_epi8(s1, t, 8));                  // HGFE
+}
+bool sha_ni_detect() {
+  unsigned a, b, c, d;
+  if (getenv("LANCET_NO_SHA_NI")) return false;
+  if (!__get_cpuid_count(7, 0, &a, &b, &c, &d)) return false;
+  bool sha = (b >> 29) & 1;
+  if (!__get_cpuid(1, &a, &b, &c, &d)) return false;
+  return sha && ((c >> 19) & 1) && ((c >> 9) & 1);                                 // + sse4.1, ssse3
+}
+const bool SHA_NI = sha_ni_detect();
 struct Sha256 {
   uint32_t h[8]; uint8_t buf[64]; uint64_t len; size_t fill;
   static uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
@@ -32,13 +82,8 @@ struct Sha256 {
     memcpy(h, iv, sizeof(h)); len = 0; fill = 0;
   }
   void block(const uint8_t *p) {
-    static const uint32_t k[64] = {
-        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
-        0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
-        0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
-        0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
-        0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
-        0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    if (SHA_NI) { sha256_block_ni(h, p); return; }
+    const uint32_t *k = SHA_K;
     uint32_t w[64];
     for (int i = 0; i < 16; ++i) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
     for (int i = 16; i < 64; ++i) {
@@ -57,19 +102,23 @@ struct Sha256 {
     len += n;
     while (n) { size_t t = std::min(n, 64 - fill); memcpy(buf + fill, p, t); fill += t; p += t; n -= t; if (fill == 64) { block(buf); fill = 0; } }
   }
-  std::string hex() {
+  void digest(uint8_t out[32]) {
     uint64_t bits = len * 8;
-    uint8_t pad = 0x80; update(&pad, 1);
-    uint8_t z = 0; while (fill != 56) update(&z, 1);
+    uint8_t tail[72]; size_t nt = (fill < 56 ? 56 : 120) - fill;
+    memset(tail, 0, sizeof(tail)); tail[0] = 0x80;
+    update(tail, nt);
     uint8_t l[8]; for (int i = 0; i < 8; ++i) l[i] = (uint8_t)(bits >> (56 - 8 * i));
     update(l, 8);
-    static const char *hx = "0123456789abcdef";
-    std::string s;
-    for (int i = 0; i < 8; ++i) for (int j = 3; j >= 0; --j) { uint8_t b = (uint8_t)(h[i] >> (8 * j)); s.push_back(hx[b >> 4]); s.push_back(hx[b & 15]); }
-    return s;
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) out[4 * i + j] = (uint8_t)(h[i] >> (24 - 8 * j));
   }
 };
-std::string sha256_hex(const std::string &s) { Sha256 c; c.init(); c.update((const uint8_t *)s.data(), s.size()); return c.hex(); }
+// The map key.  The reference keys its std::map by the 64-character hex digest; hex encoding keeps byte order
+// ('0'..'9' < 'a'..'f'), so ordering the 32 raw bytes with memcmp IS the reference's iteration order.
+struct Dig {
+  uint8_t b[32];
+  bool operator<(const Dig &o) const { return memcmp(b, o.b, 32) < 0; }
+};
+void sha256_bin(const char *p, size_t n, Dig &d) { Sha256 c; c.init(); c.update((const uint8_t *)p, n); c.digest(d.b); }
 
 // ---- FET_t
 double lbinom(int n, int k) { if (k == 0 || n == k) return 0; return lgamma(n + 1) - lgamma(k + 1) - lgamma(n - k + 1); }
@@ -84,32 +133,44 @@ double kt_fisher_exact_q(int n11, int n12, int n21, int n22) {
 }
 
 std::string dtos(double d) { std::ostringstream s; s << d; return s.str(); }
-std::string itos(int i) { std::ostringstream s; s << i; return s.str(); }
+std::string itos(int i) { return std::to_string(i); }
 
 struct Variant {
   unsigned short kmer = 0; std::string chr; int pos = 0; char type = '?'; unsigned short len = 0;
   std::string ref, alt, str;
   unsigned short rcn_f = 0, rcn_r = 0, rct_f = 0, rct_r = 0, acn_f = 0, acn_r = 0, act_f = 0, act_r = 0;
 
-  Variant(const std::string &chr_, const lancet_variant &v, const char *blob) {
-    kmer = v.kmer; chr = chr_; pos = v.pos;
-    std::string ref_(blob + v.ref_off, v.ref_len), alt_(blob + v.alt_off, v.alt_len);
-    str.assign(blob + v.str_off, v.str_len);
+  // Variant_t's constructor normalisation (src/Variant.hh:106-172) on caller-owned strings, so that the replay can
+  // reuse two per-thread buffers for the records it only needs the signature of.
+  static void normalise(const lancet_variant &v, const char *blob, std::string &ref, std::string &alt, int &pos, char &type, unsigned short &len) {
+    ref.assign(blob + v.ref_off, v.ref_len); alt.assign(blob + v.alt_off, v.alt_len);
+    pos = v.pos; type = '?'; len = 0;
     char code = (char)v.code;
-    if (code == '^') { type = 'I'; ref_ = ""; len = (unsigned short)alt_.length(); }
-    if (code == 'v') { type = 'D'; alt_ = ""; len = (unsigned short)ref_.length(); }
+    if (code == '^') { type = 'I'; ref.clear(); len = (unsigned short)alt.length(); }
+    if (code == 'v') { type = 'D'; alt.clear(); len = (unsigned short)ref.length(); }
     if (code == 'x') { type = 'S'; pos++; }
     if (code == 'c') {
       type = 'C';
-      ref_.erase(std::remove(ref_.begin(), ref_.end(), '-'), ref_.end());
-      alt_.erase(std::remove(alt_.begin(), alt_.end(), '-'), alt_.end());
-      unsigned short rl = (unsigned short)ref_.length(), al = (unsigned short)alt_.length();
+      ref.erase(std::remove(ref.begin(), ref.end(), '-'), ref.end());
+      alt.erase(std::remove(alt.begin(), alt.end(), '-'), alt.end());
+      unsigned short rl = (unsigned short)ref.length(), al = (unsigned short)alt.length();
       if (rl == al) len = al; else if (rl > al) len = rl - al; else len = al - rl;
     }
-    if (type != 'S') { ref = (char)v.prev_bp_alt + ref_; alt = (char)v.prev_bp_alt + alt_; }
-    else { alt = alt_; ref = ref_; len = 1; }
+    if (type != 'S') { ref.insert(ref.begin(), (char)v.prev_bp_alt); alt.insert(alt.begin(), (char)v.prev_bp_alt); }
+    else len = 1;
+  }
+  Variant() {}
+  Variant(const std::string &chr_, const lancet_variant &v, const char *blob) {
+    kmer = v.kmer; chr = chr_;
+    str.assign(blob + v.str_off, v.str_len);
+    normalise(v, blob, ref, alt, pos, type, len);
     rcn_f = v.cov[0]; rcn_r = v.cov[1]; rct_f = v.cov[2]; rct_r = v.cov[3];
     acn_f = v.cov[4]; acn_r = v.cov[5]; act_f = v.cov[6]; act_r = v.cov[7];
+  }
+  static int tot_of(const lancet_variant &v) {
+    int t = 0;
+    for (int q = 0; q < 8; ++q) t += (unsigned short)v.cov[q];
+    return t;
   }
   // --linked-reads members (Variant.hh:72-104): HPRN HPRT HPAN HPAT as {hp1, hp2, hp0}, barcode sets as printed
   bool lr = false;
@@ -129,7 +190,20 @@ struct Variant {
     if (prob == 1) return 0.0;
     return -10.0 * log10(prob);
   }
-  std::string signature() const { return chr + ":" + itos(pos) + ":" + type + ":" + itos(len) + ":" + ref + ":" + alt; }
+  // getSignature (src/Variant.cc:339-344): chr:pos:type:len:ref:alt
+  static void signature_into(std::string &out, const char *chr, int pos, char type, unsigned short len, const std::string &ref, const std::string &alt) {
+    auto dec = [&out](int x) {                            // "%d"
+      char num[12]; int k = 12; unsigned u = x < 0 ? 0u - (unsigned)x : (unsigned)x;
+      do { num[--k] = (char)('0' + u % 10); u /= 10; } while (u);
+      if (x < 0) num[--k] = '-';
+      out.append(num + k, (size_t)(12 - k));
+    };
+    out.assign(chr); out += ':';
+    dec(pos); out += ':';
+    out += type; out += ':';
+    dec((int)len); out += ':';
+    out += ref; out += ':'; out += alt;
+  }
   int tot() const { return rcn_f + rcn_r + rct_f + rct_r + acn_f + acn_r + act_f + act_r; }
   double fet_score() const {
     double prob = kt_fisher_exact_q(rcn_f + rcn_r, rct_f + rct_r, acn_f + acn_r, act_f + act_r);
@@ -196,21 +270,35 @@ struct Variant {
   }
 };
 
-struct byPos {   // reference src/VariantDB.hh:37-54 (arguments by value there; same ordering)
-  bool operator()(const std::pair<std::string, Variant> &a, const std::pair<std::string, Variant> &b) const {
-    int cmp = a.second.chr.compare(b.second.chr);
-    if (cmp == 0) return a.second.pos < b.second.pos;
+struct byPos {   // reference src/VariantDB.hh:37-54 (pairs by value there; same ordering)
+  bool operator()(const std::pair<const Dig, Variant> *a, const std::pair<const Dig, Variant> *b) const {
+    int cmp = a->second.chr.compare(b->second.chr);
+    if (cmp == 0) return a->second.pos < b->second.pos;
     return cmp < 0;
   }
 };
 
 }  // namespace
 
+// The reference keeps one std::map.  Here it is cut into 16 by the first hex digit of the key (the top four bits of the
+// digest), so walking shard 0..15 in turn IS the single map's iteration order, and a batch of records replayed on rank 0
+// is hashed by all host threads and inserted one shard per thread.  Each shard sees its records in arrival order:
+// addVar's "larger total coverage replaces, first wins ties" is decided per key, and a key lives in exactly one shard.
+static const int VDB_SHARDS = 16;
 struct lancet_vdb {
   lancet_filters fs;
   bool lr = false;             // VariantDB_t::LR_MODE
-  std::map<std::string, Variant> db;
+  std::map<Dig, Variant> db[VDB_SHARDS];
+  size_t size() const { size_t n = 0; for (int s = 0; s < VDB_SHARDS; ++s) n += db[s].size(); return n; }
 };
+static int vdb_threads() {
+  static const int n = [] {
+    const char *e = getenv("LANCET_VDB_THREADS");
+    int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    return t < 1 ? 1 : (t > (e ? VDB_SHARDS : 4) ? (e ? VDB_SHARDS : 4) : t);   // 4 unless asked: a record costs ~0.2 us, waking more threads costs more
+  }();
+  return n;
+}
 
 extern "C" {
 
@@ -221,29 +309,63 @@ void lancet_filters_default(lancet_filters *f) {   // reference src/Lancet.cc:62
 }
 lancet_vdb *lancet_vdb_create(const lancet_filters *f) { lancet_vdb *d = new lancet_vdb(); if (f) d->fs = *f; else lancet_filters_default(&d->fs); return d; }
 void lancet_vdb_destroy(lancet_vdb *db) { delete db; }
-uint32_t lancet_vdb_size(const lancet_vdb *db) { return db ? (uint32_t)db->db.size() : 0; }
+uint32_t lancet_vdb_size(const lancet_vdb *db) { return db ? (uint32_t)db->size() : 0; }
 
 static int vdb_add(lancet_vdb *db, const lancet_variant *v, const lancet_variant_lr *lr, uint32_t n, const char *blob, const uint32_t *bx_blob,
                    const char *const *bx_names, uint32_t n_bx, const char *const *chr_names, int32_t n_chr) {
   if (!db || (n && (!v || !blob))) return LANCET_E_ARG;
   if (lr) db->lr = true;
-  for (uint32_t i = 0; i < n; ++i) {
-    if (v[i].chr_id < 0 || v[i].chr_id >= n_chr) return LANCET_E_ARG;
-    Variant nv(chr_names[v[i].chr_id], v[i], blob);
-    if (lr) nv.set_lr(lr[i], bx_blob, bx_names, n_bx);
-    std::string key = sha256_hex(nv.signature());
-    auto it = db->db.find(key);
-    if (it != db->db.end()) {
-      if (it->second.tot() < nv.tot()) {            // keep the entry with the larger total coverage; first wins ties
-        Variant &o = it->second;
-        o.kmer = nv.kmer;
-        o.rcn_f = nv.rcn_f; o.rcn_r = nv.rcn_r; o.rct_f = nv.rct_f; o.rct_r = nv.rct_r;
-        o.acn_f = nv.acn_f; o.acn_r = nv.acn_r; o.act_f = nv.act_f; o.act_r = nv.act_r;
-        for (int q = 0; q < 12; ++q) o.hp[q] = nv.hp[q];                         // src/VariantDB.cc:73-76
-        if (db->lr) for (int q = 0; q < 4; ++q) o.bx[q] = nv.bx[q];              // :78-83
+  for (uint32_t i = 0; i < n; ++i) if (v[i].chr_id < 0 || v[i].chr_id >= n_chr) return LANCET_E_ARG;
+  const int T = n >= 32768 ? vdb_threads() : 1;
+  auto run = [&](auto &&fn) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(fn, t);
+    fn(0);
+    for (auto &x : th) x.join();
+  };
+  // 1. the key of every record: normalise into per-thread buffers, sha256 of the signature (no allocation per record)
+  static const bool timing = getenv("LANCET_VDB_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto t0 = now();
+  std::vector<Dig> key(n);
+  run([&](int t) {
+    std::string ref, alt, sig; int pos; char type; unsigned short len;
+    for (uint32_t i = (uint32_t)((uint64_t)n * t / T), hi = (uint32_t)((uint64_t)n * (t + 1) / T); i < hi; ++i) {
+      Variant::normalise(v[i], blob, ref, alt, pos, type, len);
+      Variant::signature_into(sig, chr_names[v[i].chr_id], pos, type, len, ref, alt);
+      sha256_bin(sig.data(), sig.size(), key[i]);
+    }
+  });
+  auto t1 = now();
+  // 2. addVar (src/VariantDB.cc:28-91), shard s on thread s mod T, records in arrival order
+  run([&](int t) {
+    for (uint32_t i = 0; i < n; ++i) {
+      int sh = key[i].b[0] >> 4;
+      if (sh % T != t) continue;
+      auto &m = db->db[sh];
+      auto it = m.lower_bound(key[i]);
+      if (it != m.end() && !(key[i] < it->first)) {
+        if (it->second.tot() < Variant::tot_of(v[i])) {          // keep the entry with the larger total coverage; first wins ties
+          Variant &o = it->second;
+          o.kmer = v[i].kmer;
+          o.rcn_f = v[i].cov[0]; o.rcn_r = v[i].cov[1]; o.rct_f = v[i].cov[2]; o.rct_r = v[i].cov[3];
+          o.acn_f = v[i].cov[4]; o.acn_r = v[i].cov[5]; o.act_f = v[i].cov[6]; o.act_r = v[i].cov[7];
+          if (lr) {
+            Variant nv; nv.set_lr(lr[i], bx_blob, bx_names, n_bx);
+            for (int q = 0; q < 12; ++q) o.hp[q] = nv.hp[q];                       // src/VariantDB.cc:73-76
+            for (int q = 0; q < 4; ++q) o.bx[q] = nv.bx[q];                        // :78-83
+          } else {
+            for (int q = 0; q < 12; ++q) o.hp[q] = 0;
+            if (db->lr) for (int q = 0; q < 4; ++q) o.bx[q].clear();
+          }
+        }
+      } else {
+        auto ins = m.emplace_hint(it, std::piecewise_construct, std::forward_as_tuple(key[i]), std::forward_as_tuple(chr_names[v[i].chr_id], v[i], blob));
+        if (lr) ins->second.set_lr(lr[i], bx_blob, bx_names, n_bx);
       }
-    } else db->db.insert(std::make_pair(key, nv));
-  }
+    }
+  });
+  if (timing) fprintf(stderr, "lancet_vdb_add: %u records, %d threads: keys %.2f ms, insert %.2f ms\n", n, T, std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(now() - t1).count());
   return LANCET_OK;
 }
 int lancet_vdb_add(lancet_vdb *db, const lancet_variant *v, uint32_t n, const char *blob, const char *const *chr_names, int32_t n_chr) {
@@ -304,10 +426,14 @@ char *lancet_vdb_vcf(lancet_vdb *db, const char *version, const char *cmdline, c
            "##FORMAT=<ID=HPR,Number=.,Type=Integer,Description=\"Haplotype counts for ref: # of reads supporting reference allele in haplotype 1, 2, and 0 respectively (0 = unassigned)\">\n"
            "##FORMAT=<ID=HPA,Number=.,Type=Integer,Description=\"Haplotype counts for alt: # of reads supporting alternative allele in haplotype 1, 2, and 0 respectively (0 = unassigned)\">\n";
   hdr << "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" << (sample_normal ? sample_normal : "NORMAL") << "\t" << (sample_tumor ? sample_tumor : "TUMOR") << "\n";
-  std::vector<std::pair<std::string, Variant>> vec(db->db.begin(), db->db.end());
+  // printToVCF copies the map into a vector in key order and std::sorts it by (chr, pos) -- an unstable sort, so the
+  // order of equal positions depends on that starting order: shard 0..15 in turn reproduces it.
+  std::vector<const std::pair<const Dig, Variant> *> vec;
+  vec.reserve(db->size());
+  for (int s = 0; s < VDB_SHARDS; ++s) for (auto &kv : db->db[s]) vec.push_back(&kv);
   std::sort(vec.begin(), vec.end(), byPos());
   std::string out = hdr.str();
-  for (auto &kv : vec) out += kv.second.vcf(fs);
+  for (auto *kv : vec) out += kv->second.vcf(fs);
   char *r = (char *)malloc(out.size() + 1);
   if (!r) return nullptr;
   memcpy(r, out.c_str(), out.size() + 1);

@@ -51,15 +51,17 @@ def pack_records(vptr, n: int, blob: bytes, lrptr=None, bx_blob=None, bx_names: 
     return hdr.tobytes() + recs.tobytes() + blob + lr + ids.tobytes() + names + chrs
 
 
-def unpack_records(buf: bytes) -> dict:
+def unpack_records(buf: bytes, copy: bool = True) -> dict:
+    """copy=False returns read-only views into `buf` for the record arrays (merge_into_vdb copies them once, into place)."""
     n, bl, has_lr, nbx, nl, cl, _, _ = (int(x) for x in np.frombuffer(buf[:8 * _HDR], dtype=np.uint64))
     o = 8 * _HDR
-    recs = np.frombuffer(buf[o:o + n * _VDT.itemsize], dtype=_VDT).copy(); o += n * _VDT.itemsize
+    own = (lambda a: a.copy()) if copy else (lambda a: a)
+    recs = own(np.frombuffer(buf, dtype=_VDT, count=n, offset=o)); o += n * _VDT.itemsize
     blob = buf[o:o + bl]; o += bl
     lr = None; ids = None; names: List[str] = []
     if has_lr:
-        lr = np.frombuffer(buf[o:o + n * _LDT.itemsize], dtype=_LDT).copy(); o += n * _LDT.itemsize
-        ids = np.frombuffer(buf[o:o + 4 * nbx], dtype=np.uint32).copy(); o += 4 * nbx
+        lr = own(np.frombuffer(buf, dtype=_LDT, count=n, offset=o)); o += n * _LDT.itemsize
+        ids = own(np.frombuffer(buf, dtype=np.uint32, count=nbx, offset=o)); o += 4 * nbx
         names = buf[o:o + nl].decode().split("\0") if nl else []; o += nl
     chrs = buf[o:o + cl].decode().split("\0") if cl else []
     return dict(n=n, recs=recs, blob=blob, lr=lr, bx_ids=ids, bx_names=names, chr_names=chrs)
@@ -92,18 +94,22 @@ def gather_bytes(payload: bytes, device: torch.device, dst: int = 0) -> List[byt
 def merge_into_vdb(parts: Sequence[bytes], db) -> int:
     """Rank 0: replays the records of every rank into `db` (lancet_amd.engine.VariantDB) in (global window, emission)
     order -- the order a single process would have produced them in.  Returns the number of records added."""
-    ps = [unpack_records(b) for b in parts if b]
+    ps = [unpack_records(b, copy=False) for b in parts if b]
     ps = [p for p in ps if p["n"]]
     if not ps:
         return 0
     chr_names: List[str] = []
     bx_names: List[str] = []
     bx_index = {}
-    recs_all, lr_all, ids_all, blobs = [], [], [], []
-    blob_base = 0; id_base = 0
+    ids_all, blobs = [], []
+    blob_base = 0; id_base = 0; o = 0
     lr_mode = any(p["lr"] is not None for p in ps)
+    total = sum(p["n"] for p in ps)
+    recs = np.empty(total, dtype=_VDT)                        # every part is copied once, straight into its place
+    lr = np.empty(total, dtype=_LDT) if lr_mode else None
     for p in ps:
-        r = p["recs"]
+        r = recs[o:o + p["n"]]
+        r[:] = p["recs"]
         cmap = np.zeros(max(1, len(p["chr_names"])), dtype=np.int32)
         for i, c in enumerate(p["chr_names"]):
             if c not in chr_names:
@@ -113,9 +119,9 @@ def merge_into_vdb(parts: Sequence[bytes], db) -> int:
         for f in ("ref_off", "alt_off", "str_off"):
             r[f] += blob_base
         blob_base += len(p["blob"]); blobs.append(p["blob"])
-        recs_all.append(r)
         if lr_mode:
-            l = p["lr"]
+            l = lr[o:o + p["n"]]
+            l[:] = p["lr"]
             gmap = np.zeros(max(1, len(p["bx_names"])), dtype=np.uint32)
             for i, nm in enumerate(p["bx_names"]):
                 if nm not in bx_index:
@@ -124,10 +130,14 @@ def merge_into_vdb(parts: Sequence[bytes], db) -> int:
             l["bx_off"] += id_base
             id_base += len(p["bx_ids"])
             ids_all.append(gmap[p["bx_ids"]] if len(p["bx_ids"]) else np.zeros(0, dtype=np.uint32))
-            lr_all.append(l)
-    recs = np.concatenate(recs_all)
-    order = np.lexsort((recs["seq_in_window"], recs["window"]))
-    recs = np.ascontiguousarray(recs[order])
+        o += p["n"]
+    # ranks that hold contiguous runs of windows arrive already in (window, emission) order: check before sorting
+    w, q = recs["window"], recs["seq_in_window"]
+    if total > 1 and not bool(np.all((w[1:] > w[:-1]) | ((w[1:] == w[:-1]) & (q[1:] >= q[:-1])))):
+        order = np.lexsort((q, w))
+        recs = np.ascontiguousarray(recs[order])
+        if lr_mode:
+            lr = np.ascontiguousarray(lr[order])
     blob = b"".join(blobs) + b"\0"
     vptr = recs.ctypes.data_as(C.POINTER(abi.LancetVariant))
     if lr_mode:
@@ -135,7 +145,6 @@ def merge_into_vdb(parts: Sequence[bytes], db) -> int:
         # were ranks by name already
         rank_of = np.argsort(np.argsort(np.array(bx_names, dtype=object))) if bx_names else np.zeros(0, dtype=np.int64)
         sorted_names = sorted(bx_names)
-        lr = np.ascontiguousarray(np.concatenate(lr_all)[order])
         ids = rank_of[np.concatenate(ids_all)].astype(np.uint32) if id_base else np.zeros(1, dtype=np.uint32)
         ids = np.ascontiguousarray(ids)
         db.add_raw_lr(vptr, lr.ctypes.data_as(C.POINTER(abi.LancetVariantLR)), len(recs), blob,
