@@ -16,6 +16,8 @@ import argparse
 import hashlib
 import json
 import os
+import queue
+import threading
 import sys
 import time
 
@@ -153,11 +155,36 @@ def main():
             vp, n, blob, _ = e.raw_results()
             parts = ldist.gather_bytes(ldist.pack_records(vp, n, blob, chr_names=[chrom], window_index=windex), device)
             if rank == 0:
+                merge_q.put(parts)
+
+    # rank 0 replays the gathered records on a second host thread (the C side releases the GIL), so that the replay of step i
+    # overlaps the gather of step i+1; run_steps() returns only when every step it submitted has been replayed.
+    merge_q = queue.Queue()
+
+    def merger():
+        while True:
+            parts = merge_q.get()
+            try:
+                if parts is None:
+                    return
                 db = engine.VariantDB()
                 last["n"] = ldist.merge_into_vdb(parts, db)
                 last["db"] = db
+            except BaseException as ex:          # surfaced by run_steps
+                last["error"] = ex
+            finally:
+                merge_q.task_done()
+
+    if world > 1 and rank == 0:
+        threading.Thread(target=merger, daemon=True).start()
 
     def run_steps(k):
+        _run_steps(k)
+        merge_q.join()
+        if "error" in last:
+            raise last["error"]
+
+    def _run_steps(k):
         pend = []
         for i in range(k):
             e = engs[i % nfl]
