@@ -124,12 +124,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # LANCET_BENCH_ONE_GPU=1 (a check of the N-rank path on a box with one GPU, never a measurement): every rank on device 0,
+    # the record gather over gloo through host memory instead of RCCL.  The JSON line says so ("comm").
+    one_gpu = world > 1 and os.environ.get("LANCET_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    comm_device = torch.device("cpu") if one_gpu else device
 
     chrom = f"chr{22 + rank}" if rank else "chr22"           # one synthetic contig per rank
     batch = workload.make_scan_batch(args.windows, args.cov, args.cov, seed=22 + 1000 * rank, chrom=chrom)
@@ -153,7 +162,7 @@ def main():
         e.wait()
         if world > 1:
             vp, n, blob, _ = e.raw_results()
-            parts = ldist.gather_bytes(ldist.pack_records(vp, n, blob, chr_names=[chrom], window_index=windex), device)
+            parts = ldist.gather_bytes(ldist.pack_records(vp, n, blob, chr_names=[chrom], window_index=windex), comm_device)
             if rank == 0:
                 merge_q.put(parts)
 
@@ -206,7 +215,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # kernel durations for the roofline: launches that have the GPU to themselves (with two batches in flight the HIP events of a
@@ -221,7 +230,7 @@ def main():
     n_bad = sum(1 for s in stats if s["status"] < 0)
     alg_bytes = workload.algorithmic_bytes(batch, stats, len(variants))
     if world > 1:
-        t = torch.tensor([n_kmers, n_bad], dtype=torch.int64, device=device)
+        t = torch.tensor([n_kmers, n_bad], dtype=torch.int64, device=comm_device)
         dist.all_reduce(t)
         n_kmers_all, n_bad_all = int(t[0].item()), int(t[1].item())
     else:
@@ -286,7 +295,9 @@ def main():
         if world > 1:
             out["config"]["merged_records_vdb"] = last.get("n", 0)
             out["config"]["vdb_variants"] = last["db"].size() if "db" in last else 0
-            out["config"]["gather"] = "sizes all_gather + send/recv to rank 0 (RCCL), replay in window order into lancet_vdb inside the step"
+            out["config"]["gather"] = "sizes all_gather + send/recv to rank 0 (RCCL), replay in window order into lancet_vdb inside the step (second host thread on rank 0)"
+            if one_gpu:
+                out["config"]["comm"] = "LANCET_BENCH_ONE_GPU=1: all ranks on device 0, gather over gloo -- a check of the N-rank path, not a measurement"
         # HBM-side bytes per launch from the committed PMC passes (tools/pmc_total.sh -> profiles/r2_traffic.json):
         # rocprofv3 cannot run inside this process, so the figure is looked up for the exact workload it was taken on
         try:
