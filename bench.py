@@ -129,6 +129,7 @@ def main():
     one_gpu = world > 1 and os.environ.get("LANCET_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local_rank = 0
+        os.environ.setdefault("LANCET_MEM_GB", str(max(8, 160 // (world * max(1, args.in_flight)))))   # the ranks share one device's HBM
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
