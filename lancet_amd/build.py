@@ -8,7 +8,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "liblancet_engine.so")
-SOURCES = ["engine.hip", "host_vdb.cc", "host_frontend.cc", "host_trace.cc", "lancet_main.cc"]
+SOURCES = ["engine.hip", "window_fat.hip", "host_vdb.cc", "host_frontend.cc", "host_trace.cc", "lancet_main.cc"]
 BIN = os.path.join(os.path.dirname(CSRC), "bin", "lancet_gpu")
 HEADERS = ["kernels.h", "build_lds.h", "build_lds_impl.h", "wave.h", "layout.h", "host_common.h", os.path.join("..", "..", "include", "lancet_engine.h"),
            os.path.join("..", "..", "include", "lancet_host.h")]
@@ -29,10 +29,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     steps = [
         [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
          "-c", "engine.hip", "-o", "engine.o"],
+        [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
+         "-c", "window_fat.hip", "-o", "window_fat.o"],
         [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-c", "host_vdb.cc", "-o", "host_vdb.o"],
         [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-pthread", "-c", "host_frontend.cc", "-o", "host_frontend.o"],
         [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-c", "host_trace.cc", "-o", "host_trace.o"],
-        [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "engine.o", "host_vdb.o", "host_frontend.o", "host_trace.o", "-lz", "-lpthread", "-o", LIB],
+        [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "engine.o", "window_fat.o", "host_vdb.o", "host_frontend.o", "host_trace.o", "-lz", "-lpthread", "-o", LIB],
         # the reference's command line on the native host side; finds the library next to itself
         [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-pthread", "lancet_main.cc", "-o", BIN, "-L.", "-llancet_engine",
          "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath-link,/opt/rocm/lib"],

@@ -15,6 +15,9 @@
 #include "build_lds.h"
 #include "host_common.h"
 
+// window_fat.hip
+int lc_launch_window_fat(int slots, hipStream_t stream, const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT);
+
 #define HIPCHK(e, call)                                                                           \
   do { hipError_t _r = (call); if (_r != hipSuccess) { (e)->err = std::string(#call) + ": " + hipGetErrorString(_r); return LANCET_E_HIP; } } while (0)
 
@@ -455,9 +458,14 @@ int lancet_engine_wait(lancet_engine *e) {
     HIPCHK(e, lc_copy(e, e->d_out2.p, &o2, sizeof(o2), hipMemcpyHostToDevice));
     HIPCHK(e, hipMemsetAsync((uint32_t *)e->d_counters.p + 2, 0, sizeof(uint32_t), e->stream));      // queue head
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-    hipLaunchKernelGGL(window_kernel, dim3(slots2), dim3(LANCET_WG), 0, e->stream, (const lancet_params *)e->d_params.p,
-                       (const DevBatch *)e->d_batch.p, (const EngineCaps *)e->d_caps2.p, (Work *)e->d_works2.p, (DevOut *)e->d_out2.p);
-    HIPCHK(e, hipGetLastError());
+    if (getenv("LANCET_NO_FAT")) {
+      hipLaunchKernelGGL(window_kernel, dim3(slots2), dim3(LANCET_WG), 0, e->stream, (const lancet_params *)e->d_params.p,
+                         (const DevBatch *)e->d_batch.p, (const EngineCaps *)e->d_caps2.p, (Work *)e->d_works2.p, (DevOut *)e->d_out2.p);
+      HIPCHK(e, hipGetLastError());
+    } else {      // several waves per window (window_fat.hip)
+      HIPCHK(e, (hipError_t)lc_launch_window_fat(slots2, e->stream, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
+                                                 (const EngineCaps *)e->d_caps2.p, (Work *)e->d_works2.p, (DevOut *)e->d_out2.p));
+    }
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     float ms2 = 0;

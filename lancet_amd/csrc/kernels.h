@@ -3213,6 +3213,7 @@ DEVNI void align_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL cons
   LC_GLOBAL Work &W = *LC_CTX(c).W;
   if (threadIdx.x == 0) LC_SREF(c).al_band = 0;
   const int lane = (int)threadIdx.x;
+  if (lane < 64) {                                                   // (helper waves of the fat form only wait at the barrier below)
   for (int j = lane; j < m + 1; j += 64) W.tb[LC_TB(0, j, n)] = (uint8_t)((j == 0 ? 3 : 2) | (0 << 2) | (2 << 4));           // M[0][j] '^' ; Y[0][j] '*'
   for (int i = lane + 1; i < n + 1; i += 64) W.tb[LC_TB(i, 0, n)] = (uint8_t)(1 | (2 << 2) | (0 << 4));     // M[i][0] '<' ; X[i][0] '*'
   constexpr int GMAX = (LC_MAXW + 63) / 64;
@@ -3260,6 +3261,7 @@ DEVNI void align_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL cons
       }
     }
   }
+  }
   WG_SYNC();
 }
 #else
@@ -3301,6 +3303,7 @@ DEVNI bool align_fill_band(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL
     const int lane = (int)threadIdx.x;
     int M1 = LC_BNEG, X1 = LC_BNEG, Y1 = LC_BNEG, M2 = LC_BNEG;     // own cell of the previous step (M, X, Y) and M of the one before
     int fin = LC_BNEG;
+    if (lane < 64)                                                   // (not the helper waves of the fat form)
     for (int t = 2; t <= n + m; ++t) {
       const int pt = (t - lo) & 1;
       const int o = lo + 2 * lane + pt;

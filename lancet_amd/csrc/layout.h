@@ -27,6 +27,7 @@
 #define LC_RS_WORDS 96        /* 64-bit words of the LDS copy of a string in repeat_scan (16 bases each) */
 #define LC_STAGE 192          /* occurrences staged in LDS per round of the per-position quality counts     */
 #define LC_PACK 8             /* candidates handled together in that pass                                   */
+#define LC_FAT_LANES 256     /* lanes per window of the re-run tier's kernel (window_fat.hip)                  */
 #define LC_SEG 128            /* k-mer starts per work item of the reference pseudo-read                    */
 #define LC_MAXTS 64           /* transcripts per path                                                     */
 

@@ -18,7 +18,20 @@
 #include <hip/hip_runtime.h>
 #define DEV __device__ __forceinline__
 #define DEVNI __device__ __noinline__
+#ifndef LANCET_FAT
 #define WG_FOR(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += (int)blockDim.x)
+#define XG_FOR(i, n) WG_FOR(i, n)
+#define XG_LANES 64
+#else
+// The fat form of the window kernel (window_fat.hip; the re-run tier, where a coverage pile-up is one window's build over
+// a million k-mer occurrences): the same source on a workgroup of several waves.  Wave 0 runs every phase as before;
+// the other waves ("helpers") start every WG_FOR past its bound, take part in every barrier, and share the loops marked
+// XG_FOR -- the streaming passes of the general build, whose iterations are independent.
+DEV int wg_thin_lane() { const int t = (int)threadIdx.x; return t < 64 ? t : 0x3FFFFF00; }
+#define WG_FOR(i, n) for (int i = wg_thin_lane(); i < (int)(n); i += 64)
+#define XG_FOR(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += (int)blockDim.x)
+#define XG_LANES ((int)blockDim.x)
+#endif
 // Agent-scope fence before the barrier: the phases communicate through HBM with a mix of atomics (performed
 // at L2) and plain loads (which may hit the CU's vector L1), so the L1 has to be invalidated at phase boundaries.
 #define WG_SYNC() __syncthreads()
@@ -60,6 +73,8 @@ DEV int dev_popcll(unsigned long long x) { return __popcll(x); }
 #define DEV static inline
 #define DEVNI static
 #define WG_FOR(i, n) for (int i = 0; i < (int)(n); ++i)
+#define XG_FOR(i, n) WG_FOR(i, n)
+#define XG_LANES 64
 #define WG_SYNC() ((void)0)
 #define WG_SYNC_FENCE() ((void)0)
 #define WG_LANE0 if (true)
