@@ -15,6 +15,14 @@
 #ifndef LANCET_WG
 #define LANCET_WG 64
 #endif
+// the per-position quality counts stage LC_QSTAGE occurrences per round, three per lane: all the lanes of the fat form
+#ifdef LANCET_FAT
+#define LC_QLANES LC_FAT_LANES
+#define LC_QSTAGE (3 * LC_FAT_LANES)
+#else
+#define LC_QLANES LANCET_WG
+#define LC_QSTAGE LC_STAGE
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // trace events (optional; host side turns them into the reference's `-v` text, tests compare with goldens)
@@ -57,10 +65,10 @@ struct WinShared {
   // (8 KB of LDS per workgroup = 20 single-wave workgroups per CU, the fifth wave per SIMD: two pairs of buffers that are
   //  never live together share their space)
   union {
-    uint32_t mk[LC_STAGE][4];                    // staged quality masks of up to LC_STAGE occurrences
+    uint32_t mk[LC_QSTAGE][4];                   // staged quality masks of up to LC_QSTAGE occurrences
     unsigned long long rs[LC_RS_WORDS];          // repeat_scan (window start): the string at 4 bits per base
   };
-  uint32_t mmeta[LC_STAGE];
+  uint32_t mmeta[LC_QSTAGE];
   uint32_t g_n[LC_PACK], g_lo[LC_PACK], g_cnt[LC_PACK], g_es[LC_PACK], g_min[LC_PACK], g_N;   // the candidates of the current group
   uint32_t g_fl[LC_PACK]; float g_tt[LC_PACK], g_tn[LC_PACK];      // their flags and tumor / normal coverage (fetched while the occurrences are staged)
   union {
@@ -927,13 +935,13 @@ DEVNI void build_insert_occ_major(Ctx &c) {
   // LC_INS occurrences per lane and trip: keys first, then the first probe of each (one 16-byte load) issued together, then
   // the rest of each probe sequence (the loads of different occurrences overlap; one occurrence is a dependent chain)
   constexpr int LC_INS = 4;
-  WG_FOR(l, LANCET_WG) {
+  XG_FOR(l, XG_LANES) {
     const int O = (int)S.O;
     uint32_t rcur = 0;
-    for (int o0 = l; o0 < O; o0 += LC_INS * LANCET_WG) {
+    for (int o0 = l; o0 < O; o0 += LC_INS * XG_LANES) {
       unsigned long long hh[LC_INS]; uint32_t ix[LC_INS]; bool fF[LC_INS]; lc_u4 sv0[LC_INS];
       for (int u = 0; u < LC_INS; ++u) {
-        const int o = o0 + u * LANCET_WG;
+        const int o = o0 + u * XG_LANES;
         hh[u] = 0; ix[u] = 0; fF[u] = false;
         if (o >= O) continue;
         while (rcur < refr && (uint32_t)o >= occ_base[rcur + 1]) ++rcur;
@@ -960,7 +968,7 @@ DEVNI void build_insert_occ_major(Ctx &c) {
       // first-occurrence field only ever decreases (a stale, larger value costs a superfluous atomicMin at worst).
       for (int u = 0; u < LC_INS; ++u) sv0[u] = ldg4(slots + 4 * (size_t)ix[u]);
       for (int u = 0; u < LC_INS; ++u) {
-        const int o = o0 + u * LANCET_WG;
+        const int o = o0 + u * XG_LANES;
         if (o >= O) continue;
         const unsigned long long h = hh[u];
         uint32_t idx = ix[u];
@@ -1095,8 +1103,8 @@ DEVNI void build_tables(Ctx &c) {
   }
   if (wg_bcast(&S.overflow)) return;
  again:
-  WG_FOR(i, (int)(S.tmask + 1)) { lc_u4 z; z.x = 0; z.y = 0; z.z = LC_NIL; z.w = 0; *(lc_u4 *)(W.slots + 4 * (size_t)i) = z; }
-  WG_FOR(i, (int)(S.O / 32 + 2)) { W.bitmap[i] = 0; }
+  XG_FOR(i, (int)(S.tmask + 1)) { lc_u4 z; z.x = 0; z.y = 0; z.z = LC_NIL; z.w = 0; *(lc_u4 *)(W.slots + 4 * (size_t)i) = z; }
+  XG_FOR(i, (int)(S.O / 32 + 2)) { W.bitmap[i] = 0; }
   WG_SYNC();
   PHASE(c, 2);
   // ---- pass 1: canonical k-mers -> open-addressing slots
@@ -1113,30 +1121,30 @@ DEVNI void build_tables(Ctx &c) {
   STOP_RET(c, 3);
   // ---- dense node ids in first-insertion order (= order of first occurrence, Graph.cc:163-197)
   WG_SYNC_FENCE();   // the insert pass read slots through the L1 while atomics changed them at L2: drop those lines, then whole-slot plain loads
-  WG_FOR(l, LANCET_WG) {                     // four slots per lane and trip, loads together
+  XG_FOR(l, XG_LANES) {                      // four slots per lane and trip, loads together
     const int T = (int)(S.tmask + 1);
-    for (int i0 = l; i0 < T; i0 += 4 * LANCET_WG) {
+    for (int i0 = l; i0 < T; i0 += 4 * XG_LANES) {
       lc_u4 sv[4];
-      for (int u = 0; u < 4; ++u) { const int i = i0 + u * LANCET_WG; if (i < T) sv[u] = ldg4(W.slots + 4 * (size_t)i); else { sv[u].x = 0; sv[u].y = 0; sv[u].z = 0; sv[u].w = 0; } }
+      for (int u = 0; u < 4; ++u) { const int i = i0 + u * XG_LANES; if (i < T) sv[u] = ldg4(W.slots + 4 * (size_t)i); else { sv[u].x = 0; sv[u].y = 0; sv[u].z = 0; sv[u].w = 0; } }
       for (int u = 0; u < 4; ++u) if ((sv[u].x | sv[u].y) != 0) dev_atomic_or(&W.bitmap[sv[u].z >> 5], 1u << (sv[u].z & 31));
     }
   }
   WG_SYNC();
   int nwords = (int)(S.O / 32 + 1);
-  WG_FOR(i, nwords) { W.bitpre[i] = (uint32_t)dev_popc(ld2(&W.bitmap[i])); }
+  XG_FOR(i, nwords) { W.bitpre[i] = (uint32_t)dev_popc(ld2(&W.bitmap[i])); }
   WG_SYNC();
   wg_scan(W.bitpre, nwords, S);
   WG_LANE0 { S.N = S.part[LANCET_WG]; S.N_last = (uint32_t)S.N; if (S.N > C.node_cap) OVF(c); if (S.N > S.max_nodes) S.max_nodes = S.N; S.nspecial = 0; }
   if (wg_bcast(&S.overflow)) return;
-  WG_FOR(l, LANCET_WG) {
+  XG_FOR(l, XG_LANES) {
     const int T = (int)(S.tmask + 1), NW = S.NW; const bool hasN = S.hasN != 0;
-    for (int i0 = l; i0 < T; i0 += 4 * LANCET_WG) {
+    for (int i0 = l; i0 < T; i0 += 4 * XG_LANES) {
       lc_u4 sv[4]; uint32_t bp[4], bm[4];
-      for (int u = 0; u < 4; ++u) { const int i = i0 + u * LANCET_WG; if (i < T) sv[u] = ldg4(W.slots + 4 * (size_t)i); else { sv[u].x = 0; sv[u].y = 0; sv[u].z = 0; sv[u].w = 0; } }
+      for (int u = 0; u < 4; ++u) { const int i = i0 + u * XG_LANES; if (i < T) sv[u] = ldg4(W.slots + 4 * (size_t)i); else { sv[u].x = 0; sv[u].y = 0; sv[u].z = 0; sv[u].w = 0; } }
       for (int u = 0; u < 4; ++u) { const bool occd = (sv[u].x | sv[u].y) != 0; const uint32_t f = occd ? sv[u].z : 0u; bp[u] = W.bitpre[f >> 5]; bm[u] = ld2(&W.bitmap[f >> 5]); }
       for (int u = 0; u < 4; ++u) {
         if ((sv[u].x | sv[u].y) == 0) continue;
-        const int i = i0 + u * LANCET_WG;
+        const int i = i0 + u * XG_LANES;
         const uint32_t f = sv[u].z;
         const uint32_t id = bp[u] + (uint32_t)dev_popc(bm[u] & ((1u << (f & 31)) - 1u));
         SL_NODE(W, i) = id;
@@ -1150,7 +1158,7 @@ DEVNI void build_tables(Ctx &c) {
   }
   WG_SYNC();
   // ---- per node: std::hash of the ASCII k-mer, zeroed occurrence counters
-  WG_FOR(n, S.N) {
+  XG_FOR(n, S.N) {
     LC_GLOBAL const unsigned long long *k = W.nkey + (size_t)n * LC_NWMAX;
     if (S.hasN && (W.gr[n].flags & NF_NKMER)) {
       LC_GLOBAL const uint8_t *refc = LC_CTX(c).B->ref_codes + LC_CTX(c).B->ref_off[S.w];
@@ -1204,14 +1212,14 @@ DEVNI void build_csr(Ctx &c) {
   //      occurrence-major (lane = consecutive occurrence index): occ[] is read and rewritten in whole cache lines
   //      four occurrences per lane and trip, each step issued for all four before the next (the steps of one occurrence
   //      are a chain of dependent round trips; GLOBAL loads of different occurrences overlap)
-  WG_FOR(l, LANCET_WG) {
+  XG_FOR(l, XG_LANES) {
     const int O = (int)S.O;
-    for (int o0 = l; o0 < O; o0 += 4 * LANCET_WG) {
+    for (int o0 = l; o0 < O; o0 += 4 * XG_LANES) {
       uint32_t oc[4], X[4], rk[4];
-      for (int u = 0; u < 4; ++u) { const int o = o0 + u * LANCET_WG; oc[u] = o < O ? W.occ[o] : 0u; }
-      for (int u = 0; u < 4; ++u) { const int o = o0 + u * LANCET_WG; X[u] = o < O ? W.todo[oc[u] & 0x3FFFFFFFu] : 0u; }   // 4-byte copies of the node ids: a quarter of the slots' footprint
-      for (int u = 0; u < 4; ++u) { const int o = o0 + u * LANCET_WG; rk[u] = o < O ? dev_atomic_add(&W.nocc[X[u]], 1u) : 0u; }   // arrival rank on the node = place in its csr run
-      for (int u = 0; u < 4; ++u) { const int o = o0 + u * LANCET_WG; if (o < O) { W.mv[o] = rk[u]; W.occ[o] = X[u] | (oc[u] & 0x80000000u); } }   // (mv[] is idle until the replay)
+      for (int u = 0; u < 4; ++u) { const int o = o0 + u * XG_LANES; oc[u] = o < O ? W.occ[o] : 0u; }
+      for (int u = 0; u < 4; ++u) { const int o = o0 + u * XG_LANES; X[u] = o < O ? W.todo[oc[u] & 0x3FFFFFFFu] : 0u; }   // 4-byte copies of the node ids: a quarter of the slots' footprint
+      for (int u = 0; u < 4; ++u) { const int o = o0 + u * XG_LANES; rk[u] = o < O ? dev_atomic_add(&W.nocc[X[u]], 1u) : 0u; }   // arrival rank on the node = place in its csr run
+      for (int u = 0; u < 4; ++u) { const int o = o0 + u * XG_LANES; if (o < O) { W.mv[o] = rk[u]; W.occ[o] = X[u] | (oc[u] & 0x80000000u); } }   // (mv[] is idle until the replay)
     }
   }
   WG_SYNC();
@@ -1272,19 +1280,19 @@ DEVNI void build_csr(Ctx &c) {
     // occurrence-major again; the read of an occurrence index is found by walking occ_base[] forward (a lane's indices
     // only grow), its position in the read is the offset from the read's first occurrence
     const uint32_t refr = (uint32_t)(S.R - 1);
-    WG_FOR(l, LANCET_WG) {
+    XG_FOR(l, XG_LANES) {
       const int O = (int)S.O;
       uint32_t rcur = 0;
-      for (int o0 = l; o0 < O; o0 += 4 * LANCET_WG) {        // four occurrences per lane and trip, as above
+      for (int o0 = l; o0 < O; o0 += 4 * XG_LANES) {        // four occurrences per lane and trip, as above
         uint32_t oc[4], rk[4], at[4], rr[4], pp[4];
-        for (int u = 0; u < 4; ++u) { const int o = o0 + u * LANCET_WG; oc[u] = o < O ? W.occ[o] : 0u; rk[u] = o < O ? W.mv[o] : 0u; }
+        for (int u = 0; u < 4; ++u) { const int o = o0 + u * XG_LANES; oc[u] = o < O ? W.occ[o] : 0u; rk[u] = o < O ? W.mv[o] : 0u; }
         for (int u = 0; u < 4; ++u) {
-          const int o = o0 + u * LANCET_WG;
+          const int o = o0 + u * XG_LANES;
           if (o < O) { while (rcur < refr && (uint32_t)o >= W.occ_base[rcur + 1]) ++rcur; rr[u] = rcur; pp[u] = (uint32_t)o - W.occ_base[rcur]; } else { rr[u] = 0; pp[u] = 0; }
           at[u] = o < O ? W.nocc[oc[u] & 0x3FFFFFFFu] : 0u;
         }
         for (int u = 0; u < 4; ++u) {
-          const int o = o0 + u * LANCET_WG;
+          const int o = o0 + u * XG_LANES;
           if (o < O) {
             const uint32_t st = rr[u] == refr ? 2u : ((oc[u] & 0x40000000u) ? 1u : 0u);     // the reference read never counts (Graph.cc:265)
             W.csr[at[u] + rk[u]] = CS_MAKE(rr[u], pp[u], oc[u] >> 31, st);
@@ -1306,18 +1314,18 @@ DEVNI void build_csr(Ctx &c) {
     if (ntodo) {
       const uint32_t g0 = LC_CTX(c).B->read_begin[S.w];
       LC_GLOBAL uint32_t *mark = W.bitmap;
-      WG_FOR(i, (int)(S.N / 32 + 1)) { mark[i] = 0; }
+      XG_FOR(i, (int)(S.N / 32 + 1)) { mark[i] = 0; }
       WG_SYNC();
-      WG_FOR(ti, ntodo) {
+      XG_FOR(ti, ntodo) {
         const uint32_t X = W.occ[W.occ_base[W.todo[ti] >> 10] + (W.todo[ti] & 1023u)] & 0x3FFFFFFFu;
         dev_atomic_or(&mark[X >> 5], 1u << (X & 31));
       }
       WG_SYNC();
       WG_LANE0 { S.tmp2 = 0; }
-      WG_FOR(n, S.N) { if (ld2(&mark[n >> 5]) & (1u << (n & 31))) W.pnodes[dev_atomic_add((LC_LDS uint32_t *)&S.tmp2, 1u)] = (uint32_t)n; }   // the marked nodes, densely
+      XG_FOR(n, S.N) { if (ld2(&mark[n >> 5]) & (1u << (n & 31))) W.pnodes[dev_atomic_add((LC_LDS uint32_t *)&S.tmp2, 1u)] = (uint32_t)n; }   // the marked nodes, densely
       WG_SYNC();
       const int nmarked = wg_bcast(&S.tmp2);
-      WG_FOR(li, nmarked) {
+      XG_FOR(li, nmarked) {
         const uint32_t n = W.pnodes[li];
         const uint32_t lo = W.nocc[n], hi = W.nocc[n + 1], len = hi - lo;
         for (uint32_t i = lo + 1; i < hi; ++i) {                 // visiting order (the run is nearly sorted already)
@@ -1341,7 +1349,7 @@ DEVNI void build_csr(Ctx &c) {
         W.nfill[n] = n1 | (n2 << 16);
       }
       WG_SYNC();
-      WG_FOR(ti, ntodo) {
+      XG_FOR(ti, ntodo) {
         const uint32_t r = W.todo[ti] >> 10, p = W.todo[ti] & 1023u;
         const uint32_t mi = RI_MATE(LC_CTX(c).B->rinfo[g0 + r]), nm = LC_CTX(c).B->name_rank[g0 + r] & 0xFFFFu;
         const uint32_t X = W.occ[W.occ_base[r] + p] & 0x3FFFFFFFu;
@@ -1435,18 +1443,18 @@ DEVNI void build_gather(Ctx &c) {
   // the high-coverage ones.  perm[] = node ids in that order (two exclusive scans).
   {
     LC_GLOBAL uint32_t *fa = W.order, *fb = W.scratch, *perm = W.ht_next;
-    WG_FOR(n, S.N) { const uint32_t cn = W.nocc[n + 1] - W.nocc[n]; fa[n] = cn > 24u; fb[n] = (cn > 2u && cn <= 24u); }
+    XG_FOR(n, S.N) { const uint32_t cn = W.nocc[n + 1] - W.nocc[n]; fa[n] = cn > 24u; fb[n] = (cn > 2u && cn <= 24u); }
     WG_LANE0 { fa[S.N] = 0; fb[S.N] = 0; }
     wg_scan(fa, (int)S.N + 1, S);
     wg_scan(fb, (int)S.N + 1, S);
-    WG_FOR(n, S.N) {
+    XG_FOR(n, S.N) {
       const uint32_t a = fa[n], b = fb[n], ta = fa[S.N], tb = fb[S.N];
       const bool ia = fa[n + 1] != a, ib = fb[n + 1] != b;
       perm[ia ? a : (ib ? ta + b : ta + tb + ((uint32_t)n - a - b))] = (uint32_t)n;
     }
     WG_SYNC();
   }
-  WG_FOR(pi, S.N) {
+  XG_FOR(pi, S.N) {
     const int n = (int)W.ht_next[pi];
     uint32_t ef0 = LC_NIL, ef1 = LC_NIL, ef2 = LC_NIL, ef3 = LC_NIL, ef4 = LC_NIL, ef5 = LC_NIL, ef6 = LC_NIL, ef7 = LC_NIL, ef8 = LC_NIL, ef9 = LC_NIL;
 #define LC_EFMIN(sl, st) do { uint32_t _s = (sl), _v = (st); \
@@ -1531,7 +1539,7 @@ DEVNI void build_gather(Ctx &c) {
   WG_SYNC();
   wg_scan(W.order, (int)S.N + 1, S);
   // the candidates with their csr range next to them (compact arrays for the group formation of the per-position pass)
-  WG_FOR(n, S.N) { if (W.order[n + 1] != W.order[n]) { const uint32_t at = W.order[n]; W.pnodes[at] = (uint32_t)n; W.pedges[at] = W.nocc[n]; W.ht_bucket[at] = W.nocc[n + 1] - W.nocc[n]; } }
+  XG_FOR(n, S.N) { if (W.order[n + 1] != W.order[n]) { const uint32_t at = W.order[n]; W.pnodes[at] = (uint32_t)n; W.pedges[at] = W.nocc[n]; W.ht_bucket[at] = W.nocc[n + 1] - W.nocc[n]; } }
   WG_SYNC();
 }
 DEVNI void build_qcounts(Ctx &c) {
@@ -1564,10 +1572,10 @@ DEVNI void build_qcounts(Ctx &c) {
         const uint32_t q = ci - cqb + k;
         const uint32_t n = S.cq_n[q], lo = S.cq_lo[q], cnt = S.cq_cnt[q];
         if (cnt > 0xFFFFu) OVF(c);                                // the per-position counters are 16 bits wide
-        if (gN > 0 && tot + cnt > LC_STAGE) break;
+        if (gN > 0 && tot + cnt > LC_QSTAGE) break;
         S.g_n[gN] = n; S.g_lo[gN] = lo; S.g_cnt[gN] = cnt; S.g_es[gN] = tot; S.g_min[gN] = 0x7FFFFFFFu;
         ++gN; tot += cnt;
-        if (tot >= LC_STAGE) break;
+        if (tot >= LC_QSTAGE) break;
       }
       S.g_N = gN;
       if (S.qv_top + gN > LC_CTX(c).C->surv_cap || ((size_t)S.qv_top + gN) * (size_t)K > (size_t)LC_CTX(c).C->qv_cap) OVF(c);
@@ -1576,19 +1584,19 @@ DEVNI void build_qcounts(Ctx &c) {
     const int gN = wg_uniform((int)S.g_N);
     const uint32_t qi0 = (uint32_t)wg_uniform((int)S.qv_top);
     const uint32_t cnt0 = (uint32_t)wg_uniform((int)S.g_cnt[0]);
-    const bool big = cnt0 > LC_STAGE;            // then gN == 1: rounds over its occurrences, counts carried in S.acc
+    const bool big = cnt0 > LC_QSTAGE;            // then gN == 1: rounds over its occurrences, counts carried in S.acc
     const uint32_t total = big ? cnt0 : (uint32_t)wg_uniform((int)(S.g_es[gN - 1] + S.g_cnt[gN - 1]));
-    for (uint32_t r0 = 0; r0 < total; r0 += LC_STAGE) {
-      const int cnt = (int)(total - r0 < LC_STAGE ? total - r0 : LC_STAGE);
-      WG_FOR(ln, LANCET_WG) {   // ---- step 1: entries ln, ln+64, ... of the staging area
-        constexpr int U = LC_STAGE / LANCET_WG;
+    for (uint32_t r0 = 0; r0 < total; r0 += LC_QSTAGE) {
+      const int cnt = (int)(total - r0 < LC_QSTAGE ? total - r0 : LC_QSTAGE);
+      XG_FOR(ln, LC_QLANES) {   // ---- step 1: entries ln, ln + lanes, ... of the staging area
+        constexpr int U = LC_QSTAGE / LC_QLANES;
         float gcov[4] = {0.f, 0.f, 0.f, 0.f}; uint32_t gfl = 0;
         const bool gfetch = r0 == 0 && ln < gN;                  // lane k: candidate k's record for the tail of this group
         if (gfetch) { LC_GLOBAL const NodeGr &G = W.gr[S.g_n[ln]]; gcov[0] = G.cov[0]; gcov[1] = G.cov[1]; gcov[2] = G.cov[2]; gcov[3] = G.cov[3]; gfl = G.flags; }
         uint32_t e[U], m[U][4], meta[U]; bool act[U];
         const uint32_t *gd[U]; uint32_t ri[U];
         for (int u = 0; u < U; ++u) {
-          const int j = ln + u * LANCET_WG;
+          const int j = ln + u * LC_QLANES;
           act[u] = j < cnt;
           e[u] = 0;
           if (act[u]) {
@@ -1615,15 +1623,15 @@ DEVNI void build_qcounts(Ctx &c) {
           }
         }
         for (int u = 0; u < U; ++u) {
-          const int j = ln + u * LANCET_WG;
+          const int j = ln + u * LC_QLANES;
           // (k <= 96 leaves the fourth mask word free: the class word rides along, one 16-byte LDS read per entry in step 2)
           if (u == 0 && gfetch) { S.g_tt[ln] = gcov[0] + gcov[1]; S.g_tn[ln] = gcov[2] + gcov[3]; S.g_fl[ln] = gfl; }
           if (j < cnt) { S.mk[j][0] = m[u][0]; S.mk[j][1] = m[u][1]; S.mk[j][2] = m[u][2]; S.mk[j][3] = K <= 96 ? meta[u] : m[u][3]; S.mmeta[j] = meta[u]; }
         }
       }
       WG_SYNC();
-      const bool first = (r0 == 0), last = (r0 + LC_STAGE >= total);
-      WG_FOR(t, gN * K) {   // ---- step 2
+      const bool first = (r0 == 0), last = (r0 + LC_QSTAGE >= total);
+      XG_FOR(t, gN * K) {   // ---- step 2
         const int k = big ? 0 : t / K, i = big ? t : t - k * K;
         const int es = big ? 0 : (int)S.g_es[k], ee = big ? cnt : es + (int)S.g_cnt[k];
         const uint32_t *mm = (const uint32_t *)S.mmeta;

@@ -30,7 +30,7 @@
 DEV int wg_thin_lane() { const int t = (int)threadIdx.x; return t < 64 ? t : 0x3FFFFF00; }
 #define WG_FOR(i, n) for (int i = wg_thin_lane(); i < (int)(n); i += 64)
 #define XG_FOR(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += (int)blockDim.x)
-#define XG_LANES ((int)blockDim.x)
+#define XG_LANES LC_FAT_LANES
 #endif
 // Agent-scope fence before the barrier: the phases communicate through HBM with a mix of atomics (performed
 // at L2) and plain loads (which may hit the CU's vector L1), so the L1 has to be invalidated at phase boundaries.
