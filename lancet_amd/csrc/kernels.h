@@ -69,6 +69,9 @@ struct WinShared {
     unsigned long long rs[LC_RS_WORDS];          // repeat_scan (window start): the string at 4 bits per base
   };
   uint32_t mmeta[LC_QSTAGE];
+#ifdef LANCET_FAT
+  uint32_t pacc[(LC_FAT_LANES / 2) * 10];        // step 2 split over lane groups: running counts per (candidate, position), 4 classes + 6 lr
+#endif
   uint32_t g_n[LC_PACK], g_lo[LC_PACK], g_cnt[LC_PACK], g_es[LC_PACK], g_min[LC_PACK], g_N;   // the candidates of the current group
   uint32_t g_fl[LC_PACK]; float g_tt[LC_PACK], g_tn[LC_PACK];      // their flags and tumor / normal coverage (fetched while the occurrences are staged)
   union {
@@ -1629,9 +1632,69 @@ DEVNI void build_qcounts(Ctx &c) {
           if (j < cnt) { S.mk[j][0] = m[u][0]; S.mk[j][1] = m[u][1]; S.mk[j][2] = m[u][2]; S.mk[j][3] = K <= 96 ? meta[u] : m[u][3]; S.mmeta[j] = meta[u]; }
         }
       }
-      WG_SYNC();
       const bool first = (r0 == 0), last = (r0 + LC_QSTAGE >= total);
-      XG_FOR(t, gN * K) {   // ---- step 2
+      const int T = gN * K;
+#ifdef LANCET_FAT
+      // few (candidate, position) pairs -- a pile-up's candidates have thousands of occurrences each, so a group is one or two
+      // of them: P lane groups take a slice of the staged entries each and add their counts up in LDS
+      const int P = (2 * T <= LC_QLANES) ? LC_QLANES / T : 1;
+      if (P > 1 && first) { XG_FOR(x, T * 10) { S.pacc[x] = 0; } }
+#else
+      constexpr int P = 1; (void)P;
+#endif
+      WG_SYNC();
+#ifdef LANCET_FAT
+      if (P > 1) {
+        XG_FOR(x, T * P) {
+          const int part = x / T, t = x - part * T;
+          const int k = big ? 0 : t / K, i = big ? t : t - k * K;
+          const int es = big ? 0 : (int)S.g_es[k], ee = big ? cnt : es + (int)S.g_cnt[k];
+          const int chunk = (ee - es + P - 1) / P;
+          const int js = es + part * chunk, je = js + chunk < ee ? js + chunk : ee;
+          unsigned long long a = 0;
+          uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0;
+          const int iR = K - 1 - i;
+          const int wF = i >> 5, sF = i & 31, wR = iR >> 5, sR = iR & 31;
+          const lc_u4 *mk4 = (const lc_u4 *)S.mk;
+          const uint32_t *mm = (const uint32_t *)S.mmeta;
+          for (int j = js; j < je; ++j) {
+            const lc_u4 v = mk4[j]; const uint32_t meta = mm[j];
+            const bool rev = (meta & 8u) != 0;
+            const int wsel = rev ? wR : wF, sh = rev ? sR : sF;
+            const uint32_t word = K <= 32 ? v.x : (wsel == 0 ? v.x : wsel == 1 ? v.y : wsel == 2 ? v.z : v.w);
+            const uint32_t bit = (word >> sh) & meta & 1u;
+            const uint32_t cls = (meta >> 1) & 3u;
+            a += (unsigned long long)bit << (16 * cls);
+            if (LR) {
+              const uint32_t gT = (cls < 2) ? bit : 0u, gNm = (cls >= 2) ? bit : 0u, gr3 = meta >> 4;
+              h0 += gT & gr3; h1 += gT & (gr3 >> 1); h2 += gT & (gr3 >> 2);
+              h3 += gNm & gr3; h4 += gNm & (gr3 >> 1); h5 += gNm & (gr3 >> 2);
+            }
+          }
+          LC_LDS uint32_t *pa = (LC_LDS uint32_t *)&S.pacc[10 * t];
+          if (js < je) {
+            for (int q = 0; q < 4; ++q) { const uint32_t aq = (uint32_t)((a >> (16 * q)) & 0xFFFFu); if (aq) dev_atomic_add(pa + q, aq); }
+            if (LR) { if (h0) dev_atomic_add(pa + 4, h0); if (h1) dev_atomic_add(pa + 5, h1); if (h2) dev_atomic_add(pa + 6, h2);
+                      if (h3) dev_atomic_add(pa + 7, h3); if (h4) dev_atomic_add(pa + 8, h4); if (h5) dev_atomic_add(pa + 9, h5); }
+          }
+        }
+        WG_SYNC();
+        if (last) {
+          XG_FOR(t, T) {
+            const int k = big ? 0 : t / K, i = big ? t : t - k * K;
+            const uint32_t a0 = S.pacc[10 * t], a1 = S.pacc[10 * t + 1], a2 = S.pacc[10 * t + 2], a3 = S.pacc[10 * t + 3];
+            LC_GLOBAL uint16_t *qq = W.qv + (size_t)(qi0 + (uint32_t)k) * K * QS;
+            qq[QS * i] = (uint16_t)a0; qq[QS * i + 1] = (uint16_t)a1; qq[QS * i + 2] = (uint16_t)a2; qq[QS * i + 3] = (uint16_t)a3;
+            if (LR) { uint16_t *qh = qq + QS * i + 4; for (int q = 0; q < 6; ++q) qh[q] = (uint16_t)S.pacc[10 * t + 4 + q]; }
+            const int sq = (int)(uint16_t)a0 + (int)(uint16_t)a1 + (int)(uint16_t)a2 + (int)(uint16_t)a3;
+            dev_atomic_min((LC_LDS uint32_t *)&S.g_min[k], (uint32_t)sq);
+          }
+          WG_SYNC();
+        }
+        continue;
+      }
+#endif
+      XG_FOR(t, T) {   // ---- step 2
         const int k = big ? 0 : t / K, i = big ? t : t - k * K;
         const int es = big ? 0 : (int)S.g_es[k], ee = big ? cnt : es + (int)S.g_cnt[k];
         const uint32_t *mm = (const uint32_t *)S.mmeta;
