@@ -18,6 +18,7 @@
 // the per-position quality counts stage LC_QSTAGE occurrences per round, three per lane: all the lanes of the fat form
 #ifdef LANCET_FAT
 #define LC_QLANES LC_FAT_LANES
+#define LC_PF_G 6                       /* 512-word sets in the staging area */
 #define LC_QSTAGE (3 * LC_FAT_LANES)
 #else
 #define LC_QLANES LANCET_WG
@@ -71,6 +72,7 @@ struct WinShared {
   uint32_t mmeta[LC_QSTAGE];
 #ifdef LANCET_FAT
   uint32_t pacc[(LC_FAT_LANES / 2) * 10];        // step 2 split over lane groups: running counts per (candidate, position), 4 classes + 6 lr
+  uint32_t pf_o0[LC_PF_G], pf_nk[LC_PF_G], pf_m0[LC_PF_G], pf_mnk[LC_PF_G], pf_r[LC_PF_G], pf_all[LC_PF_G];   // mate-overlap prefilter: LC_PF_G candidate reads per trip
 #endif
   uint32_t g_n[LC_PACK], g_lo[LC_PACK], g_cnt[LC_PACK], g_es[LC_PACK], g_min[LC_PACK], g_N;   // the candidates of the current group
   uint32_t g_fl[LC_PACK]; float g_tt[LC_PACK], g_tn[LC_PACK];      // their flags and tumor / normal coverage (fetched while the occurrences are staged)
@@ -1230,6 +1232,73 @@ DEVNI void build_csr(Ctx &c) {
   //      occurrence of its earlier opposite mate.  One candidate read at a time, whole wave: the mate's slot ids go into
   //      an open-addressing set in LDS (whole-line reads of its occurrence run), then the read's own occurrences are
   //      probed against it; hits get bit 30 in occ[] and are decided by the exact replay after the csr is built.
+#ifdef LANCET_FAT
+  // several waves: the candidate reads are listed first (any order: the hits are a set), then LC_PF_G of them share every
+  // trip -- one set each in the staging area -- so that a pile-up's ~6000 candidate reads cost ~1000 barrier rounds, not 18000
+  {
+    LC_LDS uint32_t *set = (LC_LDS uint32_t *)S.mk;
+    static_assert(LC_PF_G * 512 <= LC_QSTAGE * 4, "sets live in the staging area");
+    const uint32_t g0 = LC_CTX(c).B->read_begin[S.w];
+    const int nreads = S.R - 1;
+    LC_GLOBAL uint32_t *clist = W.pnodes;                                  // (idle until the replay below)
+    WG_LANE0 { S.tmp2 = 0; }
+    XG_FOR(r, nreads) {
+      if (W.cand[r] && (int)RI_TLEN(LC_CTX(c).B->rinfo[g0 + r]) - K > 0) {
+        const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.tmp2, 1u);
+        if (at < C.node_cap) clist[at] = (uint32_t)r; else OVF(c);
+      }
+    }
+    if (wg_bcast(&S.overflow)) return;
+    const int ncl = wg_bcast(&S.tmp2);
+    for (int c0 = 0; c0 < ncl; c0 += LC_PF_G) {
+      const int ng = ncl - c0 < LC_PF_G ? ncl - c0 : LC_PF_G;
+      WG_FOR(g, ng) {
+        const uint32_t r = clist[c0 + g];
+        const int tlen = (int)RI_TLEN(LC_CTX(c).B->rinfo[g0 + r]);
+        bool all = W.cand[r] == 2;
+        uint32_t m0 = 0; int mnk = 0;
+        if (!all) {
+          const uint32_t mo = W.mate_of[r];
+          const int mtl = (int)RI_TLEN(LC_CTX(c).B->rinfo[g0 + mo]);
+          mnk = mtl - K > 0 ? mtl - K + 1 : 0;
+          if (mnk > 150) { all = true; mnk = 0; } else m0 = W.occ_base[mo];
+        }
+        S.pf_r[g] = r; S.pf_o0[g] = W.occ_base[r]; S.pf_nk[g] = (uint32_t)(tlen - K + 1); S.pf_m0[g] = m0; S.pf_mnk[g] = (uint32_t)mnk; S.pf_all[g] = all ? 1u : 0u;
+      }
+      XG_FOR(i, LC_PF_G * 512) { set[i] = 0; }
+      WG_SYNC();
+      XG_FOR(x, ng * 160) {
+        const int g = x / 160, j = x - g * 160;
+        if ((uint32_t)j < S.pf_mnk[g]) {
+          LC_LDS uint32_t *sg = set + 512 * g;
+          const uint32_t id = (W.occ[S.pf_m0[g] + (uint32_t)j] & 0x3FFFFFFFu) + 1u;
+          uint32_t h = (id * 2654435761u) >> 23;
+          while (true) { const uint32_t old = dev_atomic_cas32(&sg[h], 0u, id); if (old == 0u || old == id) break; h = (h + 1) & 511u; }
+        }
+      }
+      WG_SYNC();
+      for (int g = 0; g < ng; ++g) {
+        const uint32_t r = S.pf_r[g], o0 = S.pf_o0[g]; const int nk = (int)S.pf_nk[g]; const bool all = S.pf_all[g] != 0;
+        volatile LC_LDS uint32_t *sg = (volatile LC_LDS uint32_t *)(set + 512 * g);
+        XG_FOR(p, nk) {
+          const uint32_t oc = W.occ[o0 + p];
+          bool hit = all;
+          if (!all) {
+            const uint32_t id = (oc & 0x3FFFFFFFu) + 1u;
+            uint32_t h = (id * 2654435761u) >> 23;
+            while (true) { const uint32_t v = sg[h]; if (v == 0u) break; if (v == id) { hit = true; break; } h = (h + 1) & 511u; }
+          }
+          if (hit) {
+            W.occ[o0 + p] = oc | 0x40000000u;
+            uint32_t t = dev_atomic_add((LC_LDS uint32_t *)&S.tmp1, 1u);
+            if (t < LC_CTX(c).C->table_cap) W.todo[t] = (r << 10) | (uint32_t)p; else OVF(c);
+          }
+        }
+      }
+      WG_SYNC();
+    }
+  }
+#else
   {
     LC_LDS uint32_t *set = (LC_LDS uint32_t *)S.mk;                       // 512 words of the (idle) staging area
     const uint32_t g0 = LC_CTX(c).B->read_begin[S.w];
@@ -1276,6 +1345,7 @@ DEVNI void build_csr(Ctx &c) {
       WG_SYNC();
     }
   }
+#endif
   WG_SYNC();
   // ---- csr of occurrences by node
   wg_scan(W.nocc, (int)S.N + 1, S);
