@@ -140,13 +140,21 @@ struct lancet_engine {
   std::vector<unsigned long long> phase;
   EngineCaps caps;      // tier 1
   EngineCaps caps2;     // tier 2 (re-run of overflowed windows)
-  DevBuf d_caps2, d_works2, d_workmem2, d_out2, d_winlist;
+  DevBuf d_caps2, d_works2, d_workmem2, d_out2, d_winlist, d_skip;
   int n_slots2 = 0;
   uint32_t node_cap1 = 16384;   // tier-1 node limit per window (tables are sized per build, so a generous limit costs memory only)
   uint32_t debug_stop = 0;   // LANCET_STOP_PHASE (profiling only)
   uint32_t table_start = 0;  // LANCET_TABLE_START (testing only: exercises the table-doubling path)
   int n_windows = 0, n_reads = 0, n_slots = 0;
   int n_rerun = 0;
+  // windows the host can tell will not fit tier 1 (more reads than its slots hold: coverage pile-ups) go to the re-run tier at
+  // once, on a second stream, while tier 1 works through the rest
+  std::vector<uint32_t> pred;
+  std::vector<uint8_t> is_pred;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t evf0 = nullptr, evf1 = nullptr, ev_ready = nullptr;
+  bool fat_inflight = false;
+  float ms_fat = 0;
   // LDS build kernel: hand-off areas (one per window), per-workgroup scratch
   DevBuf d_pre, d_blscratch, d_blphase, d_order, d_prepool, d_blscratch_large, d_biglist;
   int n_bslots_large = 0, n_biglist = -1;          // n_biglist: windows the last batch handed to the 1024-lane configuration (-1: no batch yet)
@@ -223,12 +231,16 @@ void lancet_engine_destroy(lancet_engine *e) {
   DevBuf *all[] = {&e->d_params, &e->d_batch, &e->d_caps, &e->d_out, &e->d_works, &e->d_chr, &e->d_refstart, &e->d_refoff, &e->d_refasc,
                    &e->d_refcodes, &e->d_readbegin, &e->d_seqoff, &e->d_seq, &e->d_qual, &e->d_label, &e->d_strand, &e->d_mate, &e->d_mapped,
                    &e->d_rinfo, &e->d_name, &e->d_bw, &e->d_gw, &e->d_bases, &e->d_good, &e->d_variants, &e->d_blob, &e->d_counters,
-                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist, &e->d_bx, &e->d_hp, &e->d_varlr, &e->d_bxblob, &e->d_pre, &e->d_blscratch, &e->d_blphase, &e->d_order, &e->d_prepool, &e->d_blscratch_large, &e->d_biglist};
+                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist, &e->d_skip, &e->d_bx, &e->d_hp, &e->d_varlr, &e->d_bxblob, &e->d_pre, &e->d_blscratch, &e->d_blphase, &e->d_order, &e->d_prepool, &e->d_blscratch_large, &e->d_biglist};
   for (DevBuf *b : all) b->release();
   if (e->evb0) (void)hipEventDestroy(e->evb0);
   if (e->evb1) (void)hipEventDestroy(e->evb1);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->evf0) (void)hipEventDestroy(e->evf0);
+  if (e->evf1) (void)hipEventDestroy(e->evf1);
+  if (e->ev_ready) (void)hipEventDestroy(e->ev_ready);
+  if (e->stream2) (void)hipStreamDestroy(e->stream2);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -331,7 +343,19 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   o.n_variants = (LC_GLOBAL uint32_t *)e->d_counters.p; o.n_blob = (LC_GLOBAL uint32_t *)e->d_counters.p + 1; o.queue_head = (LC_GLOBAL uint32_t *)e->d_counters.p + 2;
   o.n_bx = (LC_GLOBAL uint32_t *)e->d_counters.p + 3; o.variants_lr = (LC_GLOBAL lancet_variant_lr *)e->d_varlr.p; o.bx_blob = (LC_GLOBAL uint32_t *)e->d_bxblob.p;
   o.stats = (LC_GLOBAL lancet_window_stats *)e->d_stats.p; o.evt_len = (LC_GLOBAL uint32_t *)e->d_evtlen.p; o.evt_out = (LC_GLOBAL uint32_t *)e->d_evt.p; o.phase = (LC_GLOBAL unsigned long long *)e->d_phase.p; o.win_list = nullptr; o.n_list = 0;
-  o.pre = nullptr; o.pre_pool = nullptr; o.n_ahead_used = nullptr;
+  o.pre = nullptr; o.pre_pool = nullptr; o.n_ahead_used = nullptr; o.skip = nullptr;
+  e->pred.clear(); e->is_pred.assign(nw, 0);
+  if (!e->debug_stop && !getenv("LANCET_NO_FAT") && !getenv("LANCET_NO_EARLY_RERUN")) {
+    for (int w = 0; w < nw; ++w)                         // process_window's first test: more reads than a tier-1 slot holds
+      if (b->read_begin[w + 1] - b->read_begin[w] + 1 > e->caps.reads_cap) { e->pred.push_back((uint32_t)w); e->is_pred[w] = 1; }
+    if (e->pred.size() > 4096) { e->pred.clear(); e->is_pred.assign(nw, 0); }
+  }
+  if (!e->pred.empty()) {
+    UP(e->d_skip, e->is_pred.data(), (size_t)nw);
+    o.skip = (LC_GLOBAL const uint8_t *)e->d_skip.p;
+    if (!e->stream2 && (hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e->evf0) != hipSuccess ||
+                        hipEventCreate(&e->evf1) != hipSuccess || hipEventCreate(&e->ev_ready) != hipSuccess)) { e->err = "second stream"; return LANCET_E_HIP; }
+  }
   if (e->prebuild) {
     int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
     e->n_bslots = std::min(nw, cus * 2);
@@ -366,6 +390,37 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   return LANCET_OK;
 }
 
+// The re-run tier for a list of windows: worst-case work space, window_fat.hip (or the one-wave kernel with LANCET_NO_FAT),
+// queue head in counters[qword].  Launched on `st`; the caller brackets it with events.
+static int lc_launch_rerun(lancet_engine *e, const std::vector<uint32_t> &list, hipStream_t st, int qword) {
+  size_t slot2 = lc_work_carve(nullptr, nullptr, e->caps2);
+  int slots2 = (int)std::min<size_t>(list.size(), 128);
+  while (slots2 > 1 && (size_t)slots2 * slot2 > ((size_t)16 << 30)) slots2 /= 2;
+  if (e->d_workmem2.ensure((size_t)slots2 * slot2) || e->d_works2.ensure(sizeof(Work) * slots2) || e->d_winlist.ensure(sizeof(uint32_t) * list.size()) ||
+      e->d_out2.ensure(sizeof(DevOut))) { e->err = "hipMalloc failed (tier 2)"; return LANCET_E_OOM; }
+  std::vector<Work> works2(slots2);
+  for (int s2 = 0; s2 < slots2; ++s2) lc_work_carve(&works2[s2], (char *)e->d_workmem2.p + (size_t)s2 * slot2, e->caps2);
+  HIPCHK(e, lc_copy(e, e->d_works2.p, works2.data(), sizeof(Work) * slots2, hipMemcpyHostToDevice));
+  HIPCHK(e, lc_copy(e, e->d_winlist.p, list.data(), sizeof(uint32_t) * list.size(), hipMemcpyHostToDevice));
+  DevOut o2;
+  HIPCHK(e, lc_copy(e, &o2, e->d_out.p, sizeof(o2), hipMemcpyDeviceToHost));
+  o2.win_list = (LC_GLOBAL const uint32_t *)e->d_winlist.p; o2.n_list = (uint32_t)list.size(); o2.skip = nullptr;
+  o2.queue_head = (LC_GLOBAL uint32_t *)e->d_counters.p + qword;
+  HIPCHK(e, lc_copy(e, e->d_out2.p, &o2, sizeof(o2), hipMemcpyHostToDevice));
+  return slots2;
+}
+static int lc_launch_rerun_kernel(lancet_engine *e, int slots2, hipStream_t st) {
+  if (getenv("LANCET_NO_FAT")) {
+    hipLaunchKernelGGL(window_kernel, dim3(slots2), dim3(LANCET_WG), 0, st, (const lancet_params *)e->d_params.p,
+                       (const DevBatch *)e->d_batch.p, (const EngineCaps *)e->d_caps2.p, (Work *)e->d_works2.p, (DevOut *)e->d_out2.p);
+    HIPCHK(e, hipGetLastError());
+  } else {      // several waves per window (window_fat.hip)
+    HIPCHK(e, (hipError_t)lc_launch_window_fat(slots2, st, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
+                                               (const EngineCaps *)e->d_caps2.p, (Work *)e->d_works2.p, (DevOut *)e->d_out2.p));
+  }
+  return LANCET_OK;
+}
+
 // lancet_engine_run = lancet_engine_submit (launches the kernels of the uploaded batch on the engine's stream, returns at once) +
 // lancet_engine_wait (waits for them, re-runs what overflowed the small work space, reads the results back).  Two engines on one
 // GPU, submitted in turn, overlap the tail of one batch (a few multi-build windows) with the bulk of the next.
@@ -381,6 +436,18 @@ int lancet_engine_submit(lancet_engine *e) {
   HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, 128, e->stream));
   HIPCHK(e, hipMemsetAsync(e->d_stats.p, 0, sizeof(lancet_window_stats) * e->n_windows, e->stream));
   e->ms_build = 0; e->n_prebuilt = 0;
+  e->fat_inflight = false; e->ms_fat = 0;
+  if (!e->pred.empty()) {          // the pile-ups start now, next to everything else
+    int slots2 = lc_launch_rerun(e, e->pred, e->stream2, 4);
+    if (slots2 < 0) return slots2;
+    HIPCHK(e, hipEventRecord(e->ev_ready, e->stream));            // counters and statistics are cleared
+    HIPCHK(e, hipStreamWaitEvent(e->stream2, e->ev_ready, 0));
+    HIPCHK(e, hipEventRecord(e->evf0, e->stream2));
+    int rc = lc_launch_rerun_kernel(e, slots2, e->stream2);
+    if (rc) return rc;
+    HIPCHK(e, hipEventRecord(e->evf1, e->stream2));
+    e->fat_inflight = true;
+  }
   if (e->prebuild) {
     HIPCHK(e, hipMemsetAsync(e->d_blphase.p, 0, 16 * sizeof(unsigned long long), e->stream));
     HIPCHK(e, hipEventRecord(e->evb0, e->stream));
@@ -424,6 +491,11 @@ int lancet_engine_wait(lancet_engine *e) {
   if (e->n_windows == 0) { e->ran = true; return LANCET_OK; }
   HIPCHK(e, hipStreamSynchronize(e->stream));
   HIPCHK(e, hipEventElapsedTime(&e->ms_window, e->ev0, e->ev1));
+  if (e->fat_inflight) {
+    HIPCHK(e, hipStreamSynchronize(e->stream2));
+    HIPCHK(e, hipEventElapsedTime(&e->ms_fat, e->evf0, e->evf1));
+    e->fat_inflight = false;
+  }
   if (e->prebuild) {
     HIPCHK(e, hipEventElapsedTime(&e->ms_build, e->evb0, e->evb1));
     uint32_t bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -431,6 +503,7 @@ int lancet_engine_wait(lancet_engine *e) {
     e->n_prebuilt = (int)bq[1]; e->n_ahead_built = (int)bq[3]; e->n_ahead_used = (int)bq[6]; e->n_biglist = (int)bq[4];
     HIPCHK(e, lc_copy(e, e->blphase, e->d_blphase.p, sizeof(e->blphase), hipMemcpyDeviceToHost));
   }
+  if (e->ms_fat > e->ms_window + e->ms_build) e->ms_window = e->ms_fat - e->ms_build;    // both started together: the window kernels' time is the longer of the two
   e->ms_all = e->ms_window + e->ms_build;
   e->ms_kernel = e->ms_all;
   // ---- tier 2: windows that did not fit the small work space are re-run with the worst-case one
@@ -440,32 +513,14 @@ int lancet_engine_wait(lancet_engine *e) {
   HIPCHK(e, lc_copy(e, &nv_tier1, e->d_counters.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
   std::vector<uint32_t> rerun;
   std::vector<char> ok1(e->n_windows, 1);
-  for (int w = 0; w < e->n_windows; ++w) if (e->stats[w].status == LANCET_W_OVERFLOW) { rerun.push_back((uint32_t)w); ok1[w] = 0; }
-  e->n_rerun = (int)rerun.size();
+  for (int w = 0; w < e->n_windows; ++w) if (e->stats[w].status == LANCET_W_OVERFLOW && !e->is_pred[w]) { rerun.push_back((uint32_t)w); ok1[w] = 0; }
+  e->n_rerun = (int)(rerun.size() + e->pred.size());
   if (!rerun.empty() && !e->debug_stop) {
-    size_t slot2 = lc_work_carve(nullptr, nullptr, e->caps2);
-    int slots2 = (int)std::min<size_t>(rerun.size(), 128);
-    while (slots2 > 1 && (size_t)slots2 * slot2 > ((size_t)16 << 30)) slots2 /= 2;
-    if (e->d_workmem2.ensure((size_t)slots2 * slot2) || e->d_works2.ensure(sizeof(Work) * slots2) || e->d_winlist.ensure(sizeof(uint32_t) * rerun.size()) ||
-        e->d_out2.ensure(sizeof(DevOut))) { e->err = "hipMalloc failed (tier 2)"; return LANCET_E_OOM; }
-    std::vector<Work> works2(slots2);
-    for (int s2 = 0; s2 < slots2; ++s2) lc_work_carve(&works2[s2], (char *)e->d_workmem2.p + (size_t)s2 * slot2, e->caps2);
-    HIPCHK(e, lc_copy(e, e->d_works2.p, works2.data(), sizeof(Work) * slots2, hipMemcpyHostToDevice));
-    HIPCHK(e, lc_copy(e, e->d_winlist.p, rerun.data(), sizeof(uint32_t) * rerun.size(), hipMemcpyHostToDevice));
-    DevOut o2;
-    HIPCHK(e, lc_copy(e, &o2, e->d_out.p, sizeof(o2), hipMemcpyDeviceToHost));
-    o2.win_list = (LC_GLOBAL const uint32_t *)e->d_winlist.p; o2.n_list = (uint32_t)rerun.size();
-    HIPCHK(e, lc_copy(e, e->d_out2.p, &o2, sizeof(o2), hipMemcpyHostToDevice));
+    int slots2 = lc_launch_rerun(e, rerun, e->stream, 2);
+    if (slots2 < 0) return slots2;
     HIPCHK(e, hipMemsetAsync((uint32_t *)e->d_counters.p + 2, 0, sizeof(uint32_t), e->stream));      // queue head
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-    if (getenv("LANCET_NO_FAT")) {
-      hipLaunchKernelGGL(window_kernel, dim3(slots2), dim3(LANCET_WG), 0, e->stream, (const lancet_params *)e->d_params.p,
-                         (const DevBatch *)e->d_batch.p, (const EngineCaps *)e->d_caps2.p, (Work *)e->d_works2.p, (DevOut *)e->d_out2.p);
-      HIPCHK(e, hipGetLastError());
-    } else {      // several waves per window (window_fat.hip)
-      HIPCHK(e, (hipError_t)lc_launch_window_fat(slots2, e->stream, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
-                                                 (const EngineCaps *)e->d_caps2.p, (Work *)e->d_works2.p, (DevOut *)e->d_out2.p));
-    }
+    { int rc = lc_launch_rerun_kernel(e, slots2, e->stream); if (rc) return rc; }
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     float ms2 = 0;

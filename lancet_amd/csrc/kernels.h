@@ -4369,6 +4369,7 @@ DEV void window_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const De
     int w = wg_bcast(&S->tmp3);
     if (OUT->win_list) { if ((uint32_t)w >= OUT->n_list) break; w = (int)OUT->win_list[w]; }
     else if (w >= B->n_windows) break;
+    if (OUT->skip && OUT->skip[w]) continue;      // a coverage pile-up the host sent straight to the re-run tier (engine.hip)
 #ifndef LANCET_WAVE_EMU
     if (threadIdx.x == 0) { for (int i = 0; i < 16; ++i) S->phase_acc[i] = 0; S->phase_cur = 0; S->t_last = wall_clock64(); }
 #endif

@@ -27,7 +27,7 @@
 #define LC_RS_WORDS 96        /* 64-bit words of the LDS copy of a string in repeat_scan (16 bases each) */
 #define LC_STAGE 192          /* occurrences staged in LDS per round of the per-position quality counts     */
 #define LC_PACK 8             /* candidates handled together in that pass                                   */
-#define LC_FAT_LANES 256     /* lanes per window of the re-run tier's kernel (window_fat.hip)                  */
+#define LC_FAT_LANES 512     /* lanes per window of the re-run tier's kernel (window_fat.hip)                  */
 #define LC_SEG 128            /* k-mer starts per work item of the reference pseudo-read                    */
 #define LC_MAXTS 64           /* transcripts per path                                                     */
 
@@ -261,4 +261,5 @@ struct DevOut {
   LC_GLOBAL const uint8_t *pre;        /* hand-off areas of the LDS build kernel (PRE_STRIDE bytes per window), or null */
   LC_GLOBAL const uint8_t *pre_pool;   /* areas of graphs built ahead at later k (PreHdr::next chains into it), or null */
   LC_GLOBAL uint32_t *n_ahead_used;    /* atomic: window builds that took a graph built ahead                           */
+  LC_GLOBAL const uint8_t *skip;       /* [n_windows] or null; non-zero: not this launch's window (a concurrent launch of the re-run tier has it) */
 };

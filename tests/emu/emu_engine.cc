@@ -54,7 +54,7 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   res->evt_len.assign(b->n_windows, 0); res->evt.assign((size_t)b->n_windows * (evt_cap ? evt_cap : 1), 0); res->evt_cap = evt_cap;
   uint32_t nv = 0, nb = 0, qh = 0, nx = 0;
   res->lr.resize(C.var_cap); res->bx_blob.resize(C.bx_cap + 1);
-  DevOut O; O.variants = res->variants.data(); O.blob = res->blob.data(); O.n_variants = &nv; O.n_blob = &nb; O.stats = res->stats.data();
+  DevOut O; memset(&O, 0, sizeof(O)); O.variants = res->variants.data(); O.blob = res->blob.data(); O.n_variants = &nv; O.n_blob = &nb; O.stats = res->stats.data();
   O.variants_lr = res->lr.data(); O.bx_blob = res->bx_blob.data(); O.n_bx = &nx;
   O.queue_head = &qh; O.phase = nullptr; O.win_list = nullptr; O.n_list = 0; O.evt_len = res->evt_len.data(); O.evt_out = res->evt.data();
   // ---- the LDS build kernel first (one emulated workgroup), unless switched off: LANCET_NO_PREBUILD=1 runs the general build for every window
