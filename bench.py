@@ -104,8 +104,8 @@ def side_config(eng_cls, params, name, windows, cov_t, cov_n, steps, **kw):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--windows", type=int, default=32768, help="windows per GPU per step")
     ap.add_argument("--cov", type=float, default=30.0, help="coverage per sample")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="windows timed on one thread of the CPU oracle (0 = skip the CPU legs)")
