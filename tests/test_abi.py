@@ -29,6 +29,15 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, n), n
 
 
+def test_library_carries_every_gfx950_kernel(lib):
+    """The device code of both translation units is in the shipped library: the LDS build kernel in its two sizes, the
+    window kernel on one wave and on several (the re-run tier), ordering and read preparation."""
+    blob = open(build.LIB, "rb").read()
+    for k in (b"build_kernel", b"build_kernel_large", b"order_kernel", b"prep_kernel", b"window_kernel", b"window_kernel_fat"):
+        assert re.search(rb"_Z\d+" + k + rb"P", blob), k
+    assert b"gfx950" in blob
+
+
 def test_struct_layouts_match_header(lib):
     assert ctypes.sizeof(abi.LancetParams) == 72
     assert ctypes.sizeof(abi.LancetVariant) == 64
