@@ -1744,8 +1744,10 @@ DEVNI void build_qcounts(Ctx &c) {
           LC_LDS uint32_t *pa = (LC_LDS uint32_t *)&S.pacc[10 * t];
           if (js < je) {
             for (int q = 0; q < 4; ++q) { const uint32_t aq = (uint32_t)((a >> (16 * q)) & 0xFFFFu); if (aq) dev_atomic_add(pa + q, aq); }
-            if (LR) { if (h0) dev_atomic_add(pa + 4, h0); if (h1) dev_atomic_add(pa + 5, h1); if (h2) dev_atomic_add(pa + 6, h2);
-                      if (h3) dev_atomic_add(pa + 7, h3); if (h4) dev_atomic_add(pa + 8, h4); if (h5) dev_atomic_add(pa + 9, h5); }
+            if (LR) {
+              const uint32_t hh[6] = {h0, h1, h2, h3, h4, h5};
+              for (int q = 0; q < 6; ++q) if (hh[q]) dev_atomic_add(pa + 4 + q, hh[q]);
+            }
           }
         }
         WG_SYNC();

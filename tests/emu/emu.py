@@ -11,13 +11,16 @@ from lancet_amd import abi, trace
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIBS = {}
+FAT = [False]                # True: the build with LANCET_FAT (the re-run tier's source, lanes still one after the other)
 
 
 def lib():
     global _LIB
+    _LIB = _LIBS.get(FAT[0])
     if _LIB is None:
-        subprocess.run(["make", "-s", "-C", _HERE], check=True)
-        L = C.CDLL(os.path.join(_HERE, "libemu.so"))
+        subprocess.run(["make", "-s", "-C", _HERE, "all"], check=True)
+        L = C.CDLL(os.path.join(_HERE, "libemu_fat.so" if FAT[0] else "libemu.so"))
         L.lancet_emu_run.restype = C.c_void_p
         L.lancet_emu_run.argtypes = [C.POINTER(abi.LancetParams), C.POINTER(abi.LancetWindowBatch), C.c_uint32]
         for n, rt in (("n_variants", C.c_uint32), ("variants", C.POINTER(abi.LancetVariant)), ("blob", C.c_void_p),
@@ -33,6 +36,7 @@ def lib():
             getattr(L, f).restype = C.c_uint32
             getattr(L, f).argtypes = [C.c_void_p]
         _LIB = L
+        _LIBS[FAT[0]] = L
     return _LIB
 
 

@@ -338,3 +338,46 @@ def test_deep_windows_through_the_1024_lane_build_configuration(monkeypatch):
     b30 = workload.make_scan_batch(60, 30, 30, seed=4)
     _same_as_oracle(b30, p)
     assert emu.LAST_PREBUILT[0] == 60
+
+
+# ---- the source of the several-wave re-run tier (window_fat.hip = kernels.h with LANCET_FAT): its own code paths -- per-position
+#      counts split over lane groups, the mate-overlap prefilter six reads at a time, the larger staging area -- emulated lane after
+#      lane with every graph built by the general build (LANCET_NO_PREBUILD).  The races a real workgroup could add are the GPU
+#      suite's business (tests/test_engine_gpu*.py under LANCET_NODE_CAP1=64); this pins the logic.
+@pytest.fixture
+def fat_emu(monkeypatch):
+    monkeypatch.setenv("LANCET_NO_PREBUILD", "1")
+    emu.FAT[0] = True
+    yield emu
+    emu.FAT[0] = False
+
+
+_KEY = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
+
+
+@pytest.mark.parametrize("case", gu.CASES)
+def test_fat_source_matches_oracle_and_reference_trace(case, fat_emu):
+    meta, batch, kept, (min_k, max_k) = gu.case_batch(case)
+    p = gu.params(meta)
+    v, st, tr = fat_emu.run(batch, p, evt_cap=1 << 17)
+    ov, ost, _ = oracle.run(batch, p)
+    assert v == ov
+    assert [_KEY(s) for s in st] == [_KEY(s) for s in ost]
+    assert gu.digest_trace(tr) == gu.golden_trace(case)
+
+
+def test_fat_source_on_coverage_pile_ups(fat_emu):
+    """Candidates with more occurrences than even the larger staging area (1536): rounds with the counts carried in LDS across
+    them, groups of one or two candidates split over lane groups; overlapping mates by the hundred for the grouped prefilter."""
+    from lancet_amd import workload
+    p = abi.default_params()
+    for pile in (workload.make_scan_batch(1, 1300, 1300, seed=6, read_len=100), workload.make_scan_batch(2, 300, 300, seed=6, read_len=100),
+                 workload.make_scan_batch(3, 150, 90, seed=9, read_len=250)):
+        v, st, _ = fat_emu.run(pile, p)
+        ov, ost, _ = oracle.run(pile, p)
+        assert v == ov and [_KEY(s) for s in st] == [_KEY(s) for s in ost]
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_fat_source_on_random_linked_read_windows(seed, fat_emu):
+    test_emulated_kernels_match_oracle_on_random_linked_read_windows(seed)
