@@ -12,7 +12,7 @@ from lancet_amd import abi, trace
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 _LIBS = {}
-FAT = [False]                # True: the build with LANCET_FAT (the re-run tier's source, lanes still one after the other)
+FAT = [os.environ.get("LANCET_EMU_FAT") == "1"]                # True: the build with LANCET_FAT (the re-run tier's source, lanes still one after the other)
 
 
 def lib():
