@@ -391,8 +391,9 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
 }
 
 // The re-run tier for a list of windows: worst-case work space, window_fat.hip (or the one-wave kernel with LANCET_NO_FAT),
-// queue head in counters[qword].  Launched on `st`; the caller brackets it with events.
-static int lc_launch_rerun(lancet_engine *e, const std::vector<uint32_t> &list, hipStream_t st, int qword) {
+// queue head in counters[qword].  lc_prepare_rerun lays out the work space and the list (returns the number of slots),
+// lc_launch_rerun_kernel launches on `st`; the caller brackets it with events.
+static int lc_prepare_rerun(lancet_engine *e, const std::vector<uint32_t> &list, int qword) {
   size_t slot2 = lc_work_carve(nullptr, nullptr, e->caps2);
   int slots2 = (int)std::min<size_t>(list.size(), 128);
   while (slots2 > 1 && (size_t)slots2 * slot2 > ((size_t)16 << 30)) slots2 /= 2;
@@ -438,7 +439,7 @@ int lancet_engine_submit(lancet_engine *e) {
   e->ms_build = 0; e->n_prebuilt = 0;
   e->fat_inflight = false; e->ms_fat = 0;
   if (!e->pred.empty()) {          // the pile-ups start now, next to everything else
-    int slots2 = lc_launch_rerun(e, e->pred, e->stream2, 4);
+    int slots2 = lc_prepare_rerun(e, e->pred, 4);
     if (slots2 < 0) return slots2;
     HIPCHK(e, hipEventRecord(e->ev_ready, e->stream));            // counters and statistics are cleared
     HIPCHK(e, hipStreamWaitEvent(e->stream2, e->ev_ready, 0));
@@ -516,7 +517,7 @@ int lancet_engine_wait(lancet_engine *e) {
   for (int w = 0; w < e->n_windows; ++w) if (e->stats[w].status == LANCET_W_OVERFLOW && !e->is_pred[w]) { rerun.push_back((uint32_t)w); ok1[w] = 0; }
   e->n_rerun = (int)(rerun.size() + e->pred.size());
   if (!rerun.empty() && !e->debug_stop) {
-    int slots2 = lc_launch_rerun(e, rerun, e->stream, 2);
+    int slots2 = lc_prepare_rerun(e, rerun, 2);
     if (slots2 < 0) return slots2;
     HIPCHK(e, hipMemsetAsync((uint32_t *)e->d_counters.p + 2, 0, sizeof(uint32_t), e->stream));      // queue head
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
