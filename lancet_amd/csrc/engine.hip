@@ -120,7 +120,10 @@ struct DevBuf {
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
     size_t want = n + n / 4 + 256;
-    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
+    if (hipMalloc(&p, want) != hipSuccess) {             // no room for the slack: the exact size
+      (void)hipGetLastError(); want = n;
+      if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return -1; }
+    }
     cap = want; return 0;
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -324,8 +327,12 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   int slots = e->max_slots;
   if (slots > nw) slots = nw;
   if ((size_t)slots * slot_bytes > e->mem_budget) slots = (int)std::max<size_t>(1, e->mem_budget / slot_bytes);   // as many as the budget holds
+  // a GPU that is shared (or a second engine on it): fewer windows in flight rather than no run
+  while (e->d_workmem.ensure((size_t)slots * slot_bytes)) {
+    if (slots <= 64) { e->err = "hipMalloc failed (work space)"; return LANCET_E_OOM; }
+    slots = slots * 3 / 4;
+  }
   e->n_slots = slots;
-  ENS(e->d_workmem, (size_t)slots * slot_bytes);
   std::vector<Work> works(slots);
   for (int s = 0; s < slots; ++s) lc_work_carve(&works[s], (char *)e->d_workmem.p + (size_t)s * slot_bytes, e->caps);
   UP(e->d_works, works.data(), sizeof(Work) * slots);
