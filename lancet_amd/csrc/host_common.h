@@ -51,7 +51,7 @@ static inline EngineCaps lc_caps_for_batch(const lancet_window_batch *b, const l
     c.qv_cap = 4096u * 32u;                    // (survivor, position) entries: 4096 survivors at k<=32, 1297 at k=101
     c.queue_cap = 8192;
   } else {
-    c.surv_cap = nodes < 16384 ? nodes : 16384;
+    c.surv_cap = nodes;                        // every node may survive (--low-cov 0 on noisy reads: fuzz case 10083, 17 k survivors of 17.4 k nodes)
     c.qv_cap = c.surv_cap * maxk;
     // Graph_t::bfs keeps whole partial paths in its FIFO until DFS_LIMIT dequeues (reference src/Graph.cc:1299-1425); every
     // dequeue enqueues at most the node's out-degree (a few after compaction).  The worst-case tier holds 4 entries per

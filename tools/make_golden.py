@@ -86,6 +86,11 @@ CASES = {
     "bushy": (dict(ref_len=4284, cov_t=45.0, cov_n=15.0, ref_seed=1102, tumor_seed=2102, normal_seed=3102, error_rate=0.015, read_len=100,
                    insert_mean=260.0, insert_sd=20.0, somatic_every=1200, germline_every=500, dup_prob=1.0, linked=True), "chr22:1190-2791",
               ["--linked-reads", "--cov-thr", "3", "--low-cov", "0"]),
+    # found by tools/fuzz_reference.py (seed 10083): --low-cov 0 on 250-base reads at 1.5 % errors, k climbing to 100 -- four windows
+    # keep ~17 k of their 17.4 k nodes past the first low-coverage filter (the worst-case tier's survivor arrays were capped at 16 Ki)
+    "allsurvive": (dict(ref_len=3863, cov_t=70.0, cov_n=15.0, ref_seed=11083, tumor_seed=12083, normal_seed=13083, error_rate=0.015, read_len=250,
+                        insert_mean=190.0, insert_sd=20.0, somatic_every=300, germline_every=500, str_fraction=0.3, lowcomplex_fraction=0.0,
+                        dup_prob=0.0, palindromes=((2113, 11), (1607, 12))), "chr22:750-2901", ["--cov-thr", "5", "--low-cov", "0", "--min-k", "20"]),
     # even k (--min-k 12: the loop visits 12, 14, ...): k-mers that are their own reverse complement (planted in the contig at
     # several lengths, so that the window's final k meets one), CanonicalMer_t::set ties -> R (reference src/Mer.hh:57-71)
     "evenk": (dict(ref_len=7000, cov_t=36, cov_n=30, ref_seed=121, tumor_seed=1121, normal_seed=2121, somatic_every=700, germline_every=500,
