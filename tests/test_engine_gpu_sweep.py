@@ -84,3 +84,23 @@ def test_random_options_and_workloads_match_the_oracle(seed):
     variants2, _ = eng.process(batch)                       # and again on the same engine: same records
     assert variants2 == variants
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_draws_through_the_rerun_tier(seed, monkeypatch):
+    """The same draws with a tier-1 node table of 64 entries: practically every window overflows tier 1 and is assembled by the
+    several-wave kernel of the re-run tier (window_fat.hip) -- its helper waves, split quality counts and grouped mate prefilter
+    against the oracle, on ordinary windows rather than the rare pile-up."""
+    monkeypatch.setenv("LANCET_NODE_CAP1", "64")
+    over, wl = draw(seed)
+    p = abi.default_params(**over)
+    batch = workload.make_scan_batch(256, seed=700 + seed, **wl)
+    eng = engine.Engine(p, device=0)
+    variants, stats = eng.process(batch)
+    assert eng.rerun_count() > 0
+    ov, ostats = oracle_parallel(batch, p)
+    key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
+    assert all(s["status"] >= 0 for s in stats), (over, wl)
+    assert [key(s) for s in stats] == [key(s) for s in ostats], (over, wl)
+    assert variants == ov, (over, wl)
+    eng.close()
