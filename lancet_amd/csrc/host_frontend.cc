@@ -10,6 +10,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <atomic>
 #include <cctype>
 #include <chrono>
@@ -798,9 +799,12 @@ int lancet_host_tile_regions(lancet_host *h, const char *bed_path, const char *c
       if (!line.empty() && line[0] == '#') continue;
       std::vector<std::string> t; size_t a = 0;
       while (a <= line.size()) { size_t b = line.find('\t', a); if (b == std::string::npos) b = line.size(); t.push_back(line.substr(a, b - a)); a = b + 1; }
-      if (t.size() < 3 || t[1].empty() || t[2].empty() || !isdigit((unsigned char)t[1][0]) || !isdigit((unsigned char)t[2][0])) {
+      // std::stoi as the reference uses it (src/Lancet.cc:343-344): leading blanks, a sign, then digits; anything after them is ignored
+      auto stoi_like = [](const std::string &x, long *v) { char *end = nullptr; errno = 0; *v = strtol(x.c_str(), &end, 10); return end != x.c_str() && errno == 0 && *v >= INT32_MIN && *v <= INT32_MAX; };
+      long b0 = 0, b1 = 0;
+      if (t.size() < 3 || !stoi_like(t[1], &b0) || !stoi_like(t[2], &b1)) {
         h->err = std::string(bed_path) + ": line " + std::to_string(line_no) + " is not chrom<TAB>start<TAB>end"; return LANCET_E_ARG; }   // (the reference's stoi throws here)
-      long sp = atol(t[1].c_str()) - o->padding, ep = atol(t[2].c_str()) + o->padding;
+      long sp = b0 - o->padding, ep = b1 + o->padding;
       if (sp < 1) sp = 1;
       const int rc = tile_one(h, t[0] + ":" + std::to_string(sp) + "-" + std::to_string(ep), o, &want);
       if (rc != LANCET_OK) return rc;

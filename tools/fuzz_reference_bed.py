@@ -42,7 +42,14 @@ def random_bed(rng):
             a, b = 0, L                                                                        # the whole contig
         else:
             a = int(rng.integers(200, L - 800)); b = a + int(rng.integers(100, 1500))
-        lines.append(f"{c}\t{a}\t{min(b, L)}" + ("\tname%d\t0\t+" % len(lines) if rng.random() < 0.2 else ""))
+        sa, sb = str(a), str(min(b, L))
+        v = rng.random()                       # what std::stoi lets through (reference src/Lancet.cc:343-344)
+        if v < 0.06: sa = " " + sa
+        elif v < 0.12: sa = "+" + sa
+        elif v < 0.18: sb = sb + "abc"
+        elif v < 0.24 and a < 400: sa = str(a - 600)          # negative start: clamped to 1 after the padding
+        line = f"{c}\t{sa}\t{sb}" + ("\tname%d\t0\t+" % len(lines) if rng.random() < 0.2 else "")
+        lines.append(line + ("\r" if rng.random() < 0.05 and line.count("\t") > 2 else ""))
     return "\n".join(lines) + "\n"
 
 
