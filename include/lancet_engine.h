@@ -184,6 +184,11 @@ int lancet_engine_prebuilt_count(lancet_engine *e);
  * in one read and will be rejected (reference src/Microassembler.cc:198-206: cycle -> next k) -- and how many of them the window
  * kernel took instead of building that graph itself.  Scheduling only: results never depend on what was built ahead. */
 int lancet_engine_ahead_counts(lancet_engine *e, int32_t *built, int32_t *used);
+/* Build service of the last run.  A window whose k was rejected and whose next graph was not built ahead is suspended; a few
+ * resident workgroups of the LDS build kernel build that graph while the window kernel goes on with other windows, then the window
+ * resumes.  out = requests posted, served, not buildable in LDS, taken back by the window kernel (general build).  Scheduling
+ * only: results never depend on who built a graph. */
+int lancet_engine_svc_counts(lancet_engine *e, uint32_t out[4]);
 /* Profiling aid: wall-clock ticks (10 ns) the LDS build kernel's workgroups spent per phase in the last run (16 values). */
 int lancet_engine_build_phase_times(lancet_engine *e, const unsigned long long **ticks);
 

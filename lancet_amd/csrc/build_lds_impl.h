@@ -981,6 +981,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   WG_LANE0 {
     H->K = K; H->refE = S.repE; H->refM = S.repM; H->N = S.N; H->O = S.O; H->totalreadbp = S.totalreadbp; H->n_kmers = S.n_kmers;
     H->ncand = S.ncand; H->nsurv = S.nsurv; H->edges_total = S.edges_total; H->refn = S.refn; H->why = 0; H->heavy = S.hint;
+    H->big = BL_WG > 512 ? 1u : 0u;
     H->status = PB_BUILT;
   }
   WG_SYNC();
@@ -1040,6 +1041,78 @@ DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     }
     WG_SYNC();
   }
+}
+
+// Build service (layout.h SvcCtl): resident workgroups that build, on request of the window kernel, the graph of a window at a
+// later k of its loop -- the window was suspended when its k was rejected and nobody had built the next graph ahead.  A
+// workgroup takes a ticket, waits for that request to be posted (or for `done`), builds into a pool area (and on into the
+// following k while the hint says that one will be rejected too), chains the area to the window's hand-off and puts the
+// request on the ready list.  Host emulation: one call serves what is posted and returns.
+DEV void svc_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *B, LC_GLOBAL const EngineCaps *C, LC_GLOBAL uint8_t *pre,
+                         LC_GLOBAL uint8_t *scratch, LC_GLOBAL uint32_t *queue, BL_S &S, int slot, LC_GLOBAL uint8_t *pool, uint32_t pool_cap, int depth,
+                         LC_GLOBAL SvcCtl *sv) {
+  LC_GLOBAL uint8_t *xbase = scratch + (size_t)slot * SCRATCH_BYTES;
+#ifndef LANCET_WAVE_EMU
+  WG_LANE0 { dev_atomic_add(&sv->alive, 1u); }
+#endif
+  while (true) {
+    WG_LANE0 { S.w = (int)dev_atomic_add(&sv->ticket, 1u); }
+    const uint32_t t = bl_bcast(&S.w);
+    if (t >= sv->cap) break;
+    WG_LANE0 {
+      uint32_t st;
+      while (true) {
+        st = ld_acq(&sv->req[t].state);
+        if (st != SV_EMPTY) break;
+#ifdef LANCET_WAVE_EMU
+        sv->ticket = t; st = 0xFFFFFFFFu; break;                 // (nothing more is posted: hand the ticket back)
+#else
+        if (ld2(&sv->done)) { st = 0xFFFFFFFFu; break; }
+        dev_sleep();
+#endif
+      }
+      if (st == SV_POSTED) st = dev_atomic_cas32(&sv->req[t].state, SV_POSTED, SV_CLAIMED) == SV_POSTED ? SV_CLAIMED : SV_STOLEN;
+      S.g0 = st;
+    }
+    const uint32_t st = bl_bcast(&S.g0);
+    if (st == 0xFFFFFFFFu) break;
+    if (st != SV_CLAIMED) continue;                                 // a window slot took it back
+    const int w = (int)sv->req[t].w, k = sv->req[t].k;
+#ifndef LANCET_WAVE_EMU
+    if (threadIdx.x == 0) { for (int i = 0; i < 16; ++i) S.ph_acc[i] = 0; S.ph_cur = 0; S.t_last = wall_clock64(); }
+#endif
+    LC_GLOBAL PreHdr *H0 = (LC_GLOBAL PreHdr *)(pre + (size_t)w * PRE_STRIDE), *cur = H0;
+    for (int hop = 0; hop < 64 && cur->next != 0u; ++hop) cur = (LC_GLOBAL PreHdr *)(pool + (size_t)(cur->next - 1u) * PRE_STRIDE);
+    bool any = false;
+    if (cur->status == PB_BUILT && cur->K < k) {
+      for (int lvl = 0; lvl <= depth; ++lvl) {
+        WG_SYNC();
+        WG_LANE0 {
+          S.scan_total = 0xFFFFFFFFu;
+          if (lvl == 0 || (cur->heavy && cur->K + 2 <= P->max_k)) { const uint32_t a = dev_atomic_add(queue + 2, 1u); if (a < pool_cap) S.scan_total = a; }
+        }
+        const uint32_t a = bl_bcast(&S.scan_total);
+        if (a == 0xFFFFFFFFu) break;
+        LC_GLOBAL uint8_t *nx = pool + (size_t)a * PRE_STRIDE;
+        bl_build_window(P, B, C, S, xbase, nx, w, lvl == 0 ? k : cur->K + 2, H0);
+        WG_SYNC();
+        if (((LC_GLOBAL PreHdr *)nx)->status != PB_BUILT) break;
+        WG_LANE0 { cur->next = a + 1u; dev_atomic_add(queue + 3, 1u); }
+        any = true;
+        cur = (LC_GLOBAL PreHdr *)nx;
+      }
+    }
+    WG_SYNC();
+    WG_LANE0 {
+      dev_atomic_add(any ? &sv->n_built : &sv->n_failed, 1u);
+      sv->req[t].state = SV_DONE;
+      const uint32_t r = dev_atomic_add(&sv->rdy_alloc, 1u);
+      st_rel(&sv->rdy[r], t + 1u);
+    }
+  }
+#ifndef LANCET_WAVE_EMU
+  WG_LANE0 { dev_atomic_add(&sv->alive, 0xFFFFFFFFu); }
+#endif
 }
 
 }  // namespace BL_NS

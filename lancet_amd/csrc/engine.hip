@@ -44,6 +44,16 @@ __global__ void __launch_bounds__(bl_large::WG) __attribute__((amdgpu_waves_per_
                     (LC_GLOBAL uint32_t *)biglist, true);
 }
 
+// Build service (build_lds_impl.h svc_kernel_body): a few resident 512-lane workgroups that build, while the window kernel runs, the
+// graphs of later k attempts it asks for.  Launched on its own stream before the batch's kernels, leaves when svc_done_kernel
+// (enqueued behind the window kernel) has set SvcCtl::done.
+__global__ void __launch_bounds__(bl_small::WG) __attribute__((amdgpu_waves_per_eu(4, 4))) svc_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue,
+                                                      uint8_t *pool, uint32_t pool_cap, int depth, SvcCtl *sv) {
+  bl_small::svc_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL uint8_t *)pre, (LC_GLOBAL uint8_t *)scratch,
+                    (LC_GLOBAL uint32_t *)queue, *(bl_small::BL_S *)&bl_small::bl_shared, (int)blockIdx.x, (LC_GLOBAL uint8_t *)pool, pool_cap, depth, (LC_GLOBAL SvcCtl *)sv);
+}
+__global__ void svc_done_kernel(SvcCtl *sv) { __hip_atomic_store(&sv->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
 // Graph_t::trim (reference src/Graph.cc:355-384) + 2-bit packing + quality mask, one wave per read: the lanes look at consecutive
 // bases (a wave instruction reads 64 consecutive bytes), first / last base that is DNA with quality >= MIN_QUAL_TRIM by wave
 // reduction, junk test (a non-ACGT base inside the kept part) by ballot, then one output word per lane.
@@ -104,7 +114,7 @@ __global__ void __launch_bounds__(LANCET_WG * 2) align_test_kernel(const EngineC
     if (mode == 2) { WG_LANE0 { *out_len = -2; } return; }                                                          // mode 2: the band only (-2: not certified)
     align_fill(c, (LC_GLOBAL const uint8_t *)Sx, n, (LC_GLOBAL const uint8_t *)Tx, m);
   }
-  WG_LANE0 { int L = align_traceback(c, (LC_GLOBAL const uint8_t *)Sx, n, (LC_GLOBAL const uint8_t *)Tx, m); S.tmp0 = L; *out_len = S.overflow ? -1 : L; }
+  { const int L = align_traceback_wg(c, (LC_GLOBAL const uint8_t *)Sx, n, (LC_GLOBAL const uint8_t *)Tx, m); WG_LANE0 { S.tmp0 = L; *out_len = S.overflow ? -1 : L; } }
   align_traceback_fill(c, (LC_GLOBAL const uint8_t *)Sx, (LC_GLOBAL const uint8_t *)Tx, wg_bcast(&S.tmp0));
 }
 
@@ -168,8 +178,17 @@ struct lancet_engine {
   int n_bslots = 0, n_prebuilt = 0;
   bool prebuild = true;       // LANCET_NO_PREBUILD=1: every window through the general build phases (comparison / debugging)
   hipEvent_t evb0 = nullptr, evb1 = nullptr;
+  // build service (svc_kernel): control block + request / ready / continuation arrays in one buffer, scratch of its workgroups
+  DevBuf d_svc, d_svcscratch;
+  hipStream_t stream3 = nullptr; hipEvent_t ev_svc = nullptr;
+  bool svc = true, svc_running = false;      // LANCET_NO_SVC=1 (at create): every later graph of a window by the general build
+  int n_svc_wgs = 16; uint32_t svc_cap = 0; int svc_depth = 6;
+  SvcCtl svc_host;
+  uint32_t svc_counts[4] = {0, 0, 0, 0};     // posted, built, failed, stolen of the last run
   float ms_build = 0, ms_window = 0;
   bool uploaded = false, ran = false, submitted = false;
+  bool dbg = false, no_fat = false, no_early_rerun = false, no_large_build = false;     // LANCET_DEBUG / LANCET_NO_FAT / ... read once, at create
+  int build_slots_env = 0, ahead_depth_env = -1;
   uint32_t evt_cap = 0;
   size_t mem_budget = (size_t)96 << 30;
   int max_slots = 5120;      // work-space slots = resident single-wave workgroups: 5 per SIMD (96 VGPRs, < 8 KB LDS each) x 4 SIMDs x CUs
@@ -215,6 +234,13 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
       hipEventCreate(&e->ev1) != hipSuccess || hipEventCreate(&e->evb0) != hipSuccess || hipEventCreate(&e->evb1) != hipSuccess) { delete e; return LANCET_E_HIP; }
   if (getenv("LANCET_NO_PREBUILD")) e->prebuild = false;
+  if (getenv("LANCET_NO_SVC")) e->svc = false;
+  e->dbg = getenv("LANCET_DEBUG") != nullptr; e->no_fat = getenv("LANCET_NO_FAT") != nullptr; e->no_early_rerun = getenv("LANCET_NO_EARLY_RERUN") != nullptr;
+  e->no_large_build = getenv("LANCET_NO_LARGE_BUILD") != nullptr; e->heavy_first = getenv("LANCET_NO_HEAVY_FIRST") == nullptr;
+  if (const char *s = getenv("LANCET_BUILD_SLOTS")) e->build_slots_env = std::max(1, atoi(s));
+  if (const char *s = getenv("LANCET_AHEAD_DEPTH")) e->ahead_depth_env = std::max(0, std::min(16, atoi(s)));
+  if (const char *s = getenv("LANCET_SVC_WGS")) e->n_svc_wgs = std::max(0, std::min(256, atoi(s)));
+  if (const char *s = getenv("LANCET_SVC_DEPTH")) e->svc_depth = std::max(0, std::min(16, atoi(s)));
   if (p->lr_mode) e->prebuild = false;                         // --linked-reads: barcode / haplotype bookkeeping lives in the general build only
   if (const char *s = getenv("LANCET_TRACE_WORDS")) e->evt_cap = (uint32_t)atoi(s);
   { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->max_slots = cus * 20; }
@@ -234,7 +260,7 @@ void lancet_engine_destroy(lancet_engine *e) {
   DevBuf *all[] = {&e->d_params, &e->d_batch, &e->d_caps, &e->d_out, &e->d_works, &e->d_chr, &e->d_refstart, &e->d_refoff, &e->d_refasc,
                    &e->d_refcodes, &e->d_readbegin, &e->d_seqoff, &e->d_seq, &e->d_qual, &e->d_label, &e->d_strand, &e->d_mate, &e->d_mapped,
                    &e->d_rinfo, &e->d_name, &e->d_bw, &e->d_gw, &e->d_bases, &e->d_good, &e->d_variants, &e->d_blob, &e->d_counters,
-                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist, &e->d_skip, &e->d_bx, &e->d_hp, &e->d_varlr, &e->d_bxblob, &e->d_pre, &e->d_blscratch, &e->d_blphase, &e->d_order, &e->d_prepool, &e->d_blscratch_large, &e->d_biglist};
+                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist, &e->d_skip, &e->d_bx, &e->d_hp, &e->d_varlr, &e->d_bxblob, &e->d_pre, &e->d_blscratch, &e->d_blphase, &e->d_order, &e->d_prepool, &e->d_blscratch_large, &e->d_biglist, &e->d_svc, &e->d_svcscratch};
   for (DevBuf *b : all) b->release();
   if (e->evb0) (void)hipEventDestroy(e->evb0);
   if (e->evb1) (void)hipEventDestroy(e->evb1);
@@ -243,6 +269,8 @@ void lancet_engine_destroy(lancet_engine *e) {
   if (e->evf0) (void)hipEventDestroy(e->evf0);
   if (e->evf1) (void)hipEventDestroy(e->evf1);
   if (e->ev_ready) (void)hipEventDestroy(e->ev_ready);
+  if (e->ev_svc) (void)hipEventDestroy(e->ev_svc);
+  if (e->stream3) (void)hipStreamDestroy(e->stream3);
   if (e->stream2) (void)hipStreamDestroy(e->stream2);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -258,7 +286,7 @@ static int up(lancet_engine *e, DevBuf &b, const void *src, size_t bytes) {
   if (bytes) HIPCHK(e, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, e->stream));
   return LANCET_OK;
 }
-#define DBG(msg) do { if (getenv("LANCET_DEBUG")) { fprintf(stderr, "[lancet] %s:%d %s\n", __func__, __LINE__, msg); fflush(stderr); } } while (0)
+#define DBG(msg) do { if (e->dbg) { fprintf(stderr, "[lancet] %s:%d %s\n", __func__, __LINE__, msg); fflush(stderr); } } while (0)
 #define UP(buf, src, bytes) do { DBG(#buf); int _rc = up(e, buf, src, bytes); if (_rc) return _rc; } while (0)
 #define ENS(buf, bytes) do { if ((buf).ensure((bytes) ? (bytes) : 1)) { e->err = "hipMalloc failed"; return LANCET_E_OOM; } } while (0)
 
@@ -350,9 +378,10 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   o.n_variants = (LC_GLOBAL uint32_t *)e->d_counters.p; o.n_blob = (LC_GLOBAL uint32_t *)e->d_counters.p + 1; o.queue_head = (LC_GLOBAL uint32_t *)e->d_counters.p + 2;
   o.n_bx = (LC_GLOBAL uint32_t *)e->d_counters.p + 3; o.variants_lr = (LC_GLOBAL lancet_variant_lr *)e->d_varlr.p; o.bx_blob = (LC_GLOBAL uint32_t *)e->d_bxblob.p;
   o.stats = (LC_GLOBAL lancet_window_stats *)e->d_stats.p; o.evt_len = (LC_GLOBAL uint32_t *)e->d_evtlen.p; o.evt_out = (LC_GLOBAL uint32_t *)e->d_evt.p; o.phase = (LC_GLOBAL unsigned long long *)e->d_phase.p; o.win_list = nullptr; o.n_list = 0;
-  o.pre = nullptr; o.pre_pool = nullptr; o.n_ahead_used = nullptr; o.skip = nullptr;
+  o.pre = nullptr; o.pre_pool = nullptr; o.n_ahead_used = nullptr; o.skip = nullptr; o.svc = nullptr;
+  e->svc_cap = 0;
   e->pred.clear(); e->is_pred.assign(nw, 0);
-  if (!e->debug_stop && !getenv("LANCET_NO_FAT") && !getenv("LANCET_NO_EARLY_RERUN")) {
+  if (!e->debug_stop && !e->no_fat && !e->no_early_rerun) {
     for (int w = 0; w < nw; ++w)                         // process_window's first test: more reads than a tier-1 slot holds
       if (b->read_begin[w + 1] - b->read_begin[w] + 1 > e->caps.reads_cap) { e->pred.push_back((uint32_t)w); e->is_pred[w] = 1; }
     if (e->pred.size() > 4096) { e->pred.clear(); e->is_pred.assign(nw, 0); }
@@ -366,7 +395,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   if (e->prebuild) {
     int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
     e->n_bslots = std::min(nw, cus * 2);
-    if (const char *s = getenv("LANCET_BUILD_SLOTS")) e->n_bslots = std::max(1, std::min(nw, atoi(s)));
+    if (e->build_slots_env) e->n_bslots = std::min(nw, e->build_slots_env);
     ENS(e->d_pre, (size_t)nw * PRE_STRIDE);
     ENS(e->d_blscratch, (size_t)e->n_bslots * bl_small::SCRATCH_BYTES);
     // Can any window be too big for the 512-lane configuration?  Trimming only shortens reads, so the untrimmed lengths bound the
@@ -378,15 +407,27 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
       const uint64_t raw = (uint64_t)(b->seq_off[r1] - b->seq_off[r0]) + 15ull * (r1 - r0) + (b->ref_off[w + 1] - b->ref_off[w]) + 16u;
       if (raw > 40960ull) may_need_large = true;
     }
-    e->n_bslots_large = (getenv("LANCET_NO_LARGE_BUILD") || !may_need_large) ? 0 : std::min(nw, cus);
+    e->n_bslots_large = (e->no_large_build || !may_need_large) ? 0 : std::min(nw, cus);
     if (e->n_bslots_large) { ENS(e->d_blscratch_large, (size_t)e->n_bslots_large * bl_large::SCRATCH_BYTES); ENS(e->d_biglist, sizeof(uint32_t) * (size_t)nw); }
     ENS(e->d_blphase, 16 * sizeof(unsigned long long));
-    e->heavy_first = getenv("LANCET_NO_HEAVY_FIRST") == nullptr;
     if (e->heavy_first) { ENS(e->d_order, sizeof(uint32_t) * (size_t)nw); o.win_list = (LC_GLOBAL const uint32_t *)e->d_order.p; o.n_list = (uint32_t)nw; }
     o.pre = (LC_GLOBAL const uint8_t *)e->d_pre.p;
-    e->ahead_depth = 6;
-    if (const char *s = getenv("LANCET_AHEAD_DEPTH")) e->ahead_depth = std::max(0, std::min(16, atoi(s)));
+    e->ahead_depth = e->ahead_depth_env >= 0 ? e->ahead_depth_env : 6;
     e->pool_cap = e->ahead_depth > 0 ? (uint32_t)std::max(64, nw / 4) : 0u;
+    const bool use_svc = e->svc && e->n_svc_wgs > 0 && !e->debug_stop;
+    if (use_svc) e->pool_cap += (uint32_t)std::max(64, nw / 8);
+    if (use_svc) {
+      if (!e->stream3 && (hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e->ev_svc) != hipSuccess)) { e->err = "service stream"; return LANCET_E_HIP; }
+      e->svc_cap = 2u * (uint32_t)nw + 1024u;
+      const size_t off_req = 256, off_rdy = off_req + sizeof(SvcReq) * (size_t)e->svc_cap, off_cont = (off_rdy + 4u * (size_t)e->svc_cap + 63) & ~(size_t)63;
+      ENS(e->d_svc, off_cont + sizeof(SvcCont) * (size_t)e->svc_cap);
+      ENS(e->d_svcscratch, (size_t)e->n_svc_wgs * bl_small::SCRATCH_BYTES);
+      memset(&e->svc_host, 0, sizeof(SvcCtl));
+      e->svc_host.cap = e->svc_cap;
+      e->svc_host.req = (LC_GLOBAL SvcReq *)((char *)e->d_svc.p + off_req); e->svc_host.rdy = (LC_GLOBAL uint32_t *)((char *)e->d_svc.p + off_rdy);
+      e->svc_host.cont = (LC_GLOBAL SvcCont *)((char *)e->d_svc.p + off_cont);
+      o.svc = (LC_GLOBAL SvcCtl *)e->d_svc.p;
+    }
     if (e->pool_cap) { ENS(e->d_prepool, (size_t)e->pool_cap * PRE_STRIDE); o.pre_pool = (LC_GLOBAL const uint8_t *)e->d_prepool.p; o.n_ahead_used = (LC_GLOBAL uint32_t *)e->d_counters.p + 14; }
   }
   UP(e->d_out, &o, sizeof(o));
@@ -400,7 +441,9 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
 // The re-run tier for a list of windows: worst-case work space, window_fat.hip (or the one-wave kernel with LANCET_NO_FAT),
 // queue head in counters[qword].  lc_prepare_rerun lays out the work space and the list (returns the number of slots),
 // lc_launch_rerun_kernel launches on `st`; the caller brackets it with events.
-static int lc_prepare_rerun(lancet_engine *e, const std::vector<uint32_t> &list, int qword) {
+// early: the launch runs next to build_kernel of the same batch -- the hand-off areas are being written (or still hold the previous
+// batch's graphs), so it must not look at them: every graph by the general build.
+static int lc_prepare_rerun(lancet_engine *e, const std::vector<uint32_t> &list, int qword, bool early) {
   size_t slot2 = lc_work_carve(nullptr, nullptr, e->caps2);
   int slots2 = (int)std::min<size_t>(list.size(), 128);
   while (slots2 > 1 && (size_t)slots2 * slot2 > ((size_t)16 << 30)) slots2 /= 2;
@@ -412,13 +455,14 @@ static int lc_prepare_rerun(lancet_engine *e, const std::vector<uint32_t> &list,
   HIPCHK(e, lc_copy(e, e->d_winlist.p, list.data(), sizeof(uint32_t) * list.size(), hipMemcpyHostToDevice));
   DevOut o2;
   HIPCHK(e, lc_copy(e, &o2, e->d_out.p, sizeof(o2), hipMemcpyDeviceToHost));
-  o2.win_list = (LC_GLOBAL const uint32_t *)e->d_winlist.p; o2.n_list = (uint32_t)list.size(); o2.skip = nullptr;
+  o2.win_list = (LC_GLOBAL const uint32_t *)e->d_winlist.p; o2.n_list = (uint32_t)list.size(); o2.skip = nullptr; o2.svc = nullptr;
+  if (early) { o2.pre = nullptr; o2.pre_pool = nullptr; o2.n_ahead_used = nullptr; }
   o2.queue_head = (LC_GLOBAL uint32_t *)e->d_counters.p + qword;
   HIPCHK(e, lc_copy(e, e->d_out2.p, &o2, sizeof(o2), hipMemcpyHostToDevice));
   return slots2;
 }
 static int lc_launch_rerun_kernel(lancet_engine *e, int slots2, hipStream_t st) {
-  if (getenv("LANCET_NO_FAT")) {
+  if (e->no_fat) {
     hipLaunchKernelGGL(window_kernel, dim3(slots2), dim3(LANCET_WG), 0, st, (const lancet_params *)e->d_params.p,
                        (const DevBatch *)e->d_batch.p, (const EngineCaps *)e->d_caps2.p, (Work *)e->d_works2.p, (DevOut *)e->d_out2.p);
     HIPCHK(e, hipGetLastError());
@@ -432,21 +476,11 @@ static int lc_launch_rerun_kernel(lancet_engine *e, int slots2, hipStream_t st) 
 // lancet_engine_run = lancet_engine_submit (launches the kernels of the uploaded batch on the engine's stream, returns at once) +
 // lancet_engine_wait (waits for them, re-runs what overflowed the small work space, reads the results back).  Two engines on one
 // GPU, submitted in turn, overlap the tail of one batch (a few multi-build windows) with the bulk of the next.
-int lancet_engine_submit(lancet_engine *e) {
-  if (!e) return LANCET_E_ARG;
-  if (!e->uploaded) { e->err = "run before upload"; return LANCET_E_STATE; }
-  if (e->submitted) { e->err = "submit while a batch is in flight"; return LANCET_E_STATE; }
-  HIPCHK(e, hipSetDevice(e->device));
-  e->ran = false;
-  e->variants.clear(); e->blob.clear(); e->stats.clear(); e->evt_len.clear(); e->evt.clear(); e->variants_lr.clear(); e->bx_blob.clear();
-  e->submitted = true;
-  if (e->n_windows == 0) return LANCET_OK;
-  HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, 128, e->stream));
-  HIPCHK(e, hipMemsetAsync(e->d_stats.p, 0, sizeof(lancet_window_stats) * e->n_windows, e->stream));
-  e->ms_build = 0; e->n_prebuilt = 0;
-  e->fat_inflight = false; e->ms_fat = 0;
+// Everything after the launch of the build service goes through lc_submit_body: whatever it returns, svc_done_kernel is enqueued
+// behind it, so that the service's workgroups never outlive a submit that failed half way.
+static int lc_submit_body(lancet_engine *e) {
   if (!e->pred.empty()) {          // the pile-ups start now, next to everything else
-    int slots2 = lc_prepare_rerun(e, e->pred, 4);
+    int slots2 = lc_prepare_rerun(e, e->pred, 4, true);
     if (slots2 < 0) return slots2;
     HIPCHK(e, hipEventRecord(e->ev_ready, e->stream));            // counters and statistics are cleared
     HIPCHK(e, hipStreamWaitEvent(e->stream2, e->ev_ready, 0));
@@ -464,7 +498,7 @@ int lancet_engine_submit(lancet_engine *e) {
                        (unsigned long long *)e->d_blphase.p, (uint8_t *)(e->pool_cap ? e->d_prepool.p : nullptr), e->pool_cap, e->ahead_depth,
                        (uint32_t *)(e->n_bslots_large ? e->d_biglist.p : nullptr));
     HIPCHK(e, hipGetLastError());
-    if (getenv("LANCET_DEBUG")) { HIPCHK(e, hipStreamSynchronize(e->stream)); DBG("build_kernel done"); }
+    if (e->dbg) { HIPCHK(e, hipStreamSynchronize(e->stream)); DBG("build_kernel done"); }
     if (e->n_bslots_large) {
       // (grid sized from what the previous batch left on the list -- batches of one scan are alike; the kernel works any list
       //  off whatever its grid, and a full grid of idle 1024-lane workgroups costs 0.4 ms per batch)
@@ -473,7 +507,7 @@ int lancet_engine_submit(lancet_engine *e) {
                          (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_blscratch_large.p, (uint32_t *)e->d_counters.p + 8,
                          (unsigned long long *)e->d_blphase.p, (uint8_t *)(e->pool_cap ? e->d_prepool.p : nullptr), e->pool_cap, e->ahead_depth, (uint32_t *)e->d_biglist.p);
       HIPCHK(e, hipGetLastError());
-      if (getenv("LANCET_DEBUG")) { HIPCHK(e, hipStreamSynchronize(e->stream)); DBG("build_kernel_large done"); }
+      if (e->dbg) { HIPCHK(e, hipStreamSynchronize(e->stream)); DBG("build_kernel_large done"); }
     }
     if (e->heavy_first) {
       hipLaunchKernelGGL(order_kernel, dim3((e->n_windows + 255) / 256), dim3(256), 0, e->stream, (const uint8_t *)e->d_pre.p, e->n_windows, (uint32_t *)e->d_order.p,
@@ -486,8 +520,49 @@ int lancet_engine_submit(lancet_engine *e) {
   hipLaunchKernelGGL(window_kernel, dim3(e->n_slots), dim3(LANCET_WG), 0, e->stream, (const lancet_params *)e->d_params.p,
                      (const DevBatch *)e->d_batch.p, (const EngineCaps *)e->d_caps.p, (Work *)e->d_works.p, (DevOut *)e->d_out.p);
   HIPCHK(e, hipGetLastError());
-  if (getenv("LANCET_DEBUG")) { HIPCHK(e, hipStreamSynchronize(e->stream)); DBG("window_kernel done"); }
+  if (e->dbg && !e->svc_running) { HIPCHK(e, hipStreamSynchronize(e->stream)); DBG("window_kernel done"); }
   HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+  return LANCET_OK;
+}
+
+int lancet_engine_submit(lancet_engine *e) {
+  if (!e) return LANCET_E_ARG;
+  if (!e->uploaded) { e->err = "run before upload"; return LANCET_E_STATE; }
+  if (e->submitted) { e->err = "submit while a batch is in flight"; return LANCET_E_STATE; }
+  HIPCHK(e, hipSetDevice(e->device));
+  e->ran = false;
+  e->variants.clear(); e->blob.clear(); e->stats.clear(); e->evt_len.clear(); e->evt.clear(); e->variants_lr.clear(); e->bx_blob.clear();
+  if (e->n_windows == 0) { e->submitted = true; return LANCET_OK; }
+  HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, 128, e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_stats.p, 0, sizeof(lancet_window_stats) * e->n_windows, e->stream));
+  e->ms_build = 0; e->n_prebuilt = 0;
+  e->fat_inflight = false; e->ms_fat = 0;
+  e->svc_running = false;
+  if (e->svc_cap) {                // the build service takes its place on the GPU before the batch's kernels
+    HIPCHK(e, hipMemsetAsync(e->d_svc.p, 0, 256 + (sizeof(SvcReq) + 4u) * (size_t)e->svc_cap, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->d_svc.p, &e->svc_host, sizeof(SvcCtl), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipEventRecord(e->ev_svc, e->stream));
+    HIPCHK(e, hipStreamWaitEvent(e->stream3, e->ev_svc, 0));
+    hipLaunchKernelGGL(svc_kernel, dim3(e->n_svc_wgs), dim3(bl_small::WG), 0, e->stream3, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
+                       (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_svcscratch.p, (uint32_t *)e->d_counters.p + 8,
+                       (uint8_t *)e->d_prepool.p, e->pool_cap, e->svc_depth, (SvcCtl *)e->d_svc.p);
+    HIPCHK(e, hipGetLastError());
+    e->svc_running = true;
+  }
+  const int rc = lc_submit_body(e);
+  if (e->svc_running) {
+    hipLaunchKernelGGL(svc_done_kernel, dim3(1), dim3(1), 0, e->stream, (SvcCtl *)e->d_svc.p);
+    if (hipGetLastError() != hipSuccess || rc) {               // make sure the service leaves before the error is reported
+      (void)hipStreamSynchronize(e->stream);
+      const unsigned one = 1;
+      (void)hipMemcpy((char *)e->d_svc.p + offsetof(SvcCtl, done), &one, sizeof(one), hipMemcpyHostToDevice);
+      (void)hipStreamSynchronize(e->stream3);
+      e->svc_running = false;
+      if (!rc) { e->err = "svc_done_kernel launch"; return LANCET_E_HIP; }
+    }
+  }
+  if (rc) { (void)hipStreamSynchronize(e->stream); if (e->stream2) (void)hipStreamSynchronize(e->stream2); e->fat_inflight = false; return rc; }
+  e->submitted = true;
   return LANCET_OK;
 }
 
@@ -498,6 +573,13 @@ int lancet_engine_wait(lancet_engine *e) {
   e->submitted = false;
   if (e->n_windows == 0) { e->ran = true; return LANCET_OK; }
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (e->svc_running) {
+    HIPCHK(e, hipStreamSynchronize(e->stream3));
+    e->svc_running = false;
+    SvcCtl ct;
+    HIPCHK(e, lc_copy(e, &ct, e->d_svc.p, sizeof(ct), hipMemcpyDeviceToHost));
+    e->svc_counts[0] = std::min(ct.req_alloc, ct.cap); e->svc_counts[1] = ct.n_built; e->svc_counts[2] = ct.n_failed; e->svc_counts[3] = ct.n_stolen;
+  }
   HIPCHK(e, hipEventElapsedTime(&e->ms_window, e->ev0, e->ev1));
   if (e->fat_inflight) {
     HIPCHK(e, hipStreamSynchronize(e->stream2));
@@ -524,7 +606,7 @@ int lancet_engine_wait(lancet_engine *e) {
   for (int w = 0; w < e->n_windows; ++w) if (e->stats[w].status == LANCET_W_OVERFLOW && !e->is_pred[w]) { rerun.push_back((uint32_t)w); ok1[w] = 0; }
   e->n_rerun = (int)(rerun.size() + e->pred.size());
   if (!rerun.empty() && !e->debug_stop) {
-    int slots2 = lc_prepare_rerun(e, rerun, 2);
+    int slots2 = lc_prepare_rerun(e, rerun, 2, false);
     if (slots2 < 0) return slots2;
     HIPCHK(e, hipMemsetAsync((uint32_t *)e->d_counters.p + 2, 0, sizeof(uint32_t), e->stream));      // queue head
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
@@ -739,6 +821,13 @@ int lancet_engine_ahead_counts(lancet_engine *e, int32_t *built, int32_t *used) 
   if (!e) return LANCET_E_ARG;
   if (built) *built = e->n_ahead_built;
   if (used) *used = e->n_ahead_used;
+  return LANCET_OK;
+}
+
+// build service of the last run: requests posted by the window kernel, served (graph built in LDS), not buildable there, taken back
+int lancet_engine_svc_counts(lancet_engine *e, uint32_t out[4]) {
+  if (!e || !out) return LANCET_E_ARG;
+  for (int i = 0; i < 4; ++i) out[i] = e->svc_counts[i];
   return LANCET_OK;
 }
 

@@ -68,6 +68,7 @@ struct WinShared {
   union {
     uint32_t mk[LC_QSTAGE][4];                   // staged quality masks of up to LC_QSTAGE occurrences
     unsigned long long rs[LC_RS_WORDS];          // repeat_scan (window start): the string at 4 bits per base
+    uint8_t lbytes[LC_QSTAGE * 16];              // alignment: the two strings (band fill) ; transcript walk: the transcripts (LC_TS_LDS of them)
   };
   uint32_t mmeta[LC_QSTAGE];
 #ifdef LANCET_FAT
@@ -92,6 +93,10 @@ struct WinShared {
   int pre_order;                                 // ... and it came with the survivors' table order and the components
   int items_ready;                               // build_items ran for this window
   int al_band, al_lo, al_score;                  // alignment: traceback bytes in band layout (offsets j - i from al_lo, two per lane), score at (n, m)
+  int al_L;                                      // align_traceback_wg: alignment length
+  int nosusp_k;                                  // build service: the k this window was resumed for (no second request for it)
+  uint32_t svc_i;                                // ... the request just posted
+  int act, act_arg;                              // what the slot does next (window_kernel_body)
 };
 
 // The one WinShared of the workgroup.  Functions reach it by name rather than through the pointer in Ctx: a pointer
@@ -2653,7 +2658,8 @@ DEVNI bool find_tandems_local(const Ctx &c, LC_GLOBAL const uint8_t *seq, int n,
   // (the stretch starts are indexed at run time: in LDS -- the staging area of the per-position pass is idle in the graph phases -- an
   //  indexed local array would live in scratch memory)
 #ifndef LANCET_WAVE_EMU
-  LC_LDS int (*offs)[8] = (LC_LDS int (*)[8])((LC_LDS uint8_t *)LC_SREF(c).mk + 2048);
+  static_assert(sizeof(LC_SREF(c).mmeta) >= 9 * 8 * sizeof(int), "stretch starts of find_tandems_local");
+  LC_LDS int (*offs)[8] = (LC_LDS int (*)[8])((LC_LDS uint32_t *)LC_SREF(c).mmeta);      // (not the staging area itself: the transcripts of the walk live there)
 #else
   int offs[9][8];
 #endif
@@ -3444,8 +3450,15 @@ DEVNI bool align_fill_band(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL
 #ifndef LANCET_WAVE_EMU
   {
     const int lane = (int)threadIdx.x;
+    LC_GLOBAL uint8_t *tbp = W.tb;
     int M1 = LC_BNEG, X1 = LC_BNEG, Y1 = LC_BNEG, M2 = LC_BNEG;     // own cell of the previous step (M, X, Y) and M of the one before
     int fin = LC_BNEG;
+    // The two strings in LDS: every step of every lane reads one character of each, and a global load there (~1 us under load)
+    // was the whole cost of a step (1200 steps for a 600 x 600 problem).
+    LC_LDS uint8_t *ls = (LC_LDS uint8_t *)&S.lbytes[0];
+    const bool staged = (size_t)(n + m) <= sizeof(S.lbytes);
+    if (staged) { WG_FOR(x, n) { ls[x] = Sx[x]; } WG_FOR(x, m) { ls[n + x] = Tx[x]; } }
+    WG_SYNC();
     if (lane < 64)                                                   // (not the helper waves of the fat form)
     for (int t = 2; t <= n + m; ++t) {
       const int pt = (t - lo) & 1;
@@ -3463,8 +3476,8 @@ DEVNI bool align_fill_band(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL
       if (j == 1) { lM = -8 - i; lY = -8 - i; if (i != 1) dM = -8 - (i - 1); }
       int cM = LC_BNEG, cX = LC_BNEG, cY = LC_BNEG; uint8_t tb = 0;
       if (valid) {
-        band_cell(i, j, (int)Sx[i - 1], (int)Tx[j - 1], dM, uM, uX, lM, lY, &cM, &cX, &cY, &tb);
-        W.tb[(size_t)t * 64 + (size_t)lane] = tb;
+        band_cell(i, j, staged ? (int)ls[i - 1] : (int)Sx[i - 1], staged ? (int)ls[n + j - 1] : (int)Tx[j - 1], dM, uM, uX, lM, lY, &cM, &cX, &cY, &tb);
+        tbp[(size_t)t * 64 + (size_t)lane] = tb;
         if (i == n && j == m) fin = cM;
       }
       M2 = M1; M1 = cM; X1 = cX; Y1 = cY;
@@ -3558,6 +3571,69 @@ DEVNI int align_traceback(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL 
     else { cols[L++] = ((uint32_t)i << 16) | ((uint32_t)j << 2); --i; --j; }
   }
   return L;
+}
+// The same walk by the whole wave (all lanes: returns the length, uniform).  Host emulation: the one-lane walk above.
+// GPU: every lane follows the walk redundantly (the state is wave-uniform); the traceback bytes are fetched 64 at a time, one per
+// lane, along the line the walk is on -- the diagonal, or the column / row while a gap is being extended -- and handed around with a
+// wave shuffle, so the walk pays one memory round trip per 64 cells (or per turn) instead of one per 8; the notes are kept one per
+// lane and stored 64 at a time.
+DEVNI int align_traceback_wg(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const uint8_t *Tx, int m) {
+  LC_WS &S = LC_SREF(c);
+#ifdef LANCET_WAVE_EMU
+  WG_LANE0 { S.al_L = align_traceback(c, Sx, n, Tx, m); }
+  return wg_bcast(&S.al_L);
+#else
+  LC_GLOBAL Work &W = *LC_CTX(c).W;
+  (void)Sx; (void)Tx;
+  if (threadIdx.x < 64) {
+    const int lane = (int)threadIdx.x;
+    const int cap = LC_MAXW + (int)LC_CTX(c).C->path_cap + 2;
+    LC_GLOBAL uint32_t *cols = W.scratch;
+    LC_GLOBAL const uint8_t *tbp = W.tb;
+    const int band = S.al_band, blo = S.al_lo;
+    int i = n, j = m, L = 0;
+    bool forcex = false, forcey = false, bad = false;
+    int ci = 0, cj = 0, cdir = -1;
+    uint32_t mine = 0, note = 0;
+    while (i > 0 || j > 0) {
+      if (i < 0 || j < 0 || L >= cap) { bad = true; break; }              // the reference would read out of bounds here
+      const int want = forcex ? 1 : (forcey ? 2 : 0);
+      int q = -1;
+      if (cdir == want) {
+        if (want == 0) { if (ci - i == cj - j) q = ci - i; }
+        else if (want == 1) { if (cj == j) q = ci - i; }
+        else { if (ci == i) q = cj - j; }
+      }
+      if (q < 0 || q > 63) {
+        cdir = want; ci = i; cj = j; q = 0;
+        const int ii = want == 2 ? i : i - lane, jj = want == 1 ? j : j - lane;
+        uint32_t bb = 0;
+        if (ii >= 0 && jj >= 0) {
+          if (!band) bb = tbp[LC_TB(ii, jj, n)];
+          else if (ii == 0) bb = (uint32_t)((jj == 0 ? 3 : 2) | (0 << 2) | (2 << 4));        // the borders are not stored in the band layout
+          else if (jj == 0) bb = (uint32_t)(1 | (2 << 2) | (0 << 4));
+          else { const int tt = ii + jj, oo = jj - ii; const int li = (oo - blo - ((tt - blo) & 1)) >> 1; bb = (li >= 0 && li < 64) ? tbp[(size_t)tt * 64 + (size_t)li] : 0u; }
+        }
+        mine = bb;
+      }
+      const uint32_t b = (uint32_t)__shfl((int)mine, q, 64);
+      const int t = (int)(b & 3u), x = (int)((b >> 2) & 3u), y = (int)((b >> 4) & 3u);
+      uint32_t v;
+      if (t == 3) break;
+      else if (forcex) { if (i < 1) { bad = true; break; } v = ((uint32_t)i << 16) | ((uint32_t)j << 2) | 1u; if (x == 0) forcex = false; --i; }
+      else if (t == 1) { v = ((uint32_t)i << 16) | ((uint32_t)j << 2) | 1u; if (x == 1) forcex = true; --i; }
+      else if (forcey) { if (j < 1) { bad = true; break; } v = ((uint32_t)i << 16) | ((uint32_t)j << 2) | 2u; if (y == 0) forcey = false; --j; }
+      else if (t == 2) { v = ((uint32_t)i << 16) | ((uint32_t)j << 2) | 2u; if (y == 1) forcey = true; --j; }
+      else { v = ((uint32_t)i << 16) | ((uint32_t)j << 2); --i; --j; }
+      if (lane == (L & 63)) note = v;
+      ++L;
+      if ((L & 63) == 0) cols[L - 64 + lane] = note;
+    }
+    if (!bad && lane < (L & 63)) cols[(L & ~63) + lane] = note;
+    if (lane == 0) { if (bad) { OVF(c); L = 0; } S.al_L = L; }
+  }
+  return wg_bcast(&S.al_L);
+#endif
 }
 // all lanes: the aligned strings from the noted columns (noted from the end of the alignment backwards)
 DEVNI void align_traceback_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, LC_GLOBAL const uint8_t *Tx, int L) {
@@ -3779,7 +3855,17 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
   const int cap = LC_MAXW + (int)LC_CTX(c).C->path_cap + 2;
   LC_GLOBAL const uint8_t *ra = W.aln, *pa = W.aln + cap;
   const int refstart = LC_CTX(c).B->ref_start[S.w];
-  TS *ts = (TS *)(void *)W.tb;                 // the traceback matrix is dead by now: reuse it for the transcripts
+  // The transcripts: the first LC_TS_LDS of a path in LDS (the staging area of the build phases, idle here), further ones in the
+  // traceback matrix, which is dead by now.  Every column of an indel updates a dozen running minima / sums of its transcript:
+  // in HBM that was ~100 dependent accesses per column and the longest phase of the windows that define the launch's tail.
+  TS *ts_far = (TS *)(void *)W.tb;
+#ifndef LANCET_WAVE_EMU
+  TS *ts_near = (TS *)(LC_LDS TS *)&lc_shared.lbytes[0];
+#else
+  TS *ts_near = (TS *)(void *)&S.lbytes[0];
+#endif
+  constexpr int LC_TS_LDS = (int)(sizeof(S.lbytes) / sizeof(TS));
+  auto ts_at = [&](int idx) -> TS & { return idx < LC_TS_LDS ? ts_near[idx] : ts_far[idx]; };
   int nts = 0;
   unsigned pos_in_ref = 0, pathpos = 0;
   char code = '?', prev_code = '?';
@@ -3820,7 +3906,7 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
       while (pq >= 0 && pa[pq] != 'A' && pa[pq] != 'C' && pa[pq] != 'G' && pa[pq] != 'T') --pq;
       if (pr < 0 || pq < 0) { OVF(c); return; }        // reference: assert(pr >= 0)
       if (nts > 0 && prev_code != '=') {
-        TS &t = ts[nts - 1];
+        TS &t = ts_at(nts - 1);
         if (within_tumor) t.somatic = true;
         int reflen_before = t.col1 - t.col0 + 1;        // transcript.ref.length() before the append
         t.col1 = i; t.end_pos = (uint32_t)P; t.ref_end_pos = pos_in_ref;
@@ -3829,7 +3915,7 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
         else if (code == 'x' || t.code != code) { t.code = 'c'; ts_add_alt(t, cn4, ct4); ts_add_ref(t, rn2, rt2); ts_hp_add_alt(t, ha); ts_hp_add_ref(t, hr); }
       } else {
         if (nts >= LC_MAXTS) { OVF(c); return; }
-        TS &t = ts[nts++];
+        TS &t = ts_at(nts++);
         t.pos = rrpos; t.ref_pos = pos_in_ref; t.start_pos = (uint32_t)(P + 1); t.code = code; t.end_pos = (uint32_t)P; t.ref_end_pos = pos_in_ref;
         t.col0 = i; t.col1 = i; t.somatic = within_tumor; t.prev_bp_ref = (char)ra[pr]; t.prev_bp_alt = (char)pa[pq];
         for (int q = 0; q < 4; ++q) { acc_init(t.aN[q], cn4[q]); acc_init(t.aT[q], ct4[q]); }
@@ -3856,7 +3942,7 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
     return LC_NIL;
   };
   for (int ti = 0; ti < nts; ++ti) {
-    TS &t = ts[ti];
+    TS &t = ts_at(ti);
     if (t.code != 'x') {
       for (int j = 0; j <= K; ++j) {
         unsigned idx1 = t.end_pos + (unsigned)j;
@@ -4065,7 +4151,7 @@ DEVNI void count_ref_path(Ctx &c) {
         PHASE(c, 12);
         if (!align_fill_band(c, rs, S.seq_len, W.pseq, pl)) align_fill(c, rs, S.seq_len, W.pseq, pl);
         PHASE(c, 13);
-        WG_LANE0 { S.part[7] = (uint32_t)align_traceback(c, rs, S.seq_len, W.pseq, pl); }
+        { const int aL = align_traceback_wg(c, rs, S.seq_len, W.pseq, pl); WG_LANE0 { S.part[7] = (uint32_t)aL; } }
         WG_SYNC();
         align_traceback_fill(c, rs, W.pseq, (int)wg_bcastu(&S.part[7]));
       }
@@ -4191,9 +4277,49 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// the window: Microassembler::processGraph (reference src/Microassembler.cc:73-249)
+// Build service (layout.h SvcCtl): the loop needs a graph at k that nobody built in LDS.  If the window is one the LDS build
+// kernel can take (its first graph came from the 512-lane configuration) the state the reference carries from one k to the
+// next (Ref_t::seq / trim of the last markRefEnds, the variants emitted so far) goes into a continuation record,
+// a request is posted and the slot is free for another window.  Returns true when the window was suspended.
 // ---------------------------------------------------------------------------------------------------------
-DEV void process_window(Ctx &c, int w) {
+#define LANCET_W_SUSPENDED 0x5355
+DEVNI bool try_suspend(Ctx &c, int k) {
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  LC_GLOBAL SvcCtl *sv = LC_CTX(c).OUT->svc;
+  if (!sv) return false;
+  const int w = wg_uniform(S.w);
+  WG_LANE0 {
+    S.tmp1 = 0;
+    LC_GLOBAL const PreHdr *H0 = (LC_GLOBAL const PreHdr *)(LC_CTX(c).OUT->pre + (size_t)w * PRE_STRIDE + PRE_OFF_HDR);
+    if (k != S.nosusp_k && (k & 1) && k <= 31 && !S.overflow && LC_CTX(c).OUT->pre_pool && H0->status == PB_BUILT && !H0->big) {
+      const uint32_t i = dev_atomic_add(&sv->req_alloc, 1u);
+      if (i < sv->cap) { S.tmp1 = 1; S.svc_i = i; }
+    }
+  }
+  if (!wg_bcast(&S.tmp1)) return false;
+  const uint32_t i = wg_bcastu(&S.svc_i);
+  const uint32_t ecap = LC_CTX(c).C->evt_cap;
+  if (ecap) { WG_FOR(j, S.evt_len) { LC_CTX(c).OUT->evt_out[(size_t)w * ecap + (uint32_t)j] = W.evt[j]; } }
+  PHASE(c, 0);
+  WG_LANE0 {
+    LC_GLOBAL SvcCont &ct = sv->cont[i];
+    ct.k = k; ct.seq_t5 = S.seq_t5; ct.seq_len = S.seq_len; ct.trim5 = S.trim5; ct.trim3 = S.trim3; ct.emit_seq = S.emit_seq;
+    ct.n_builds = S.n_builds; ct.final_k = S.final_k; ct.max_nodes = S.max_nodes; ct.evt_len = S.evt_len; ct.N_last = S.N_last; ct.pad = 0;
+    ct.n_kmers = S.n_kmers;
+    sv->req[i].w = (uint32_t)w; sv->req[i].k = k;
+    if (LC_CTX(c).OUT->phase) for (int q = 0; q < 16; ++q) LC_CTX(c).OUT->phase[(size_t)w * 16 + q] = S.phase_acc[q];
+    S.status = LANCET_W_SUSPENDED;
+  }
+  WG_SYNC();
+  WG_LANE0 { st_rel(&sv->req[i].state, SV_POSTED); }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the window: Microassembler::processGraph (reference src/Microassembler.cc:73-249)
+// rq: -1, or the request (SvcCtl::req) whose graph is ready -- the window resumes at that k
+// ---------------------------------------------------------------------------------------------------------
+DEV void process_window(Ctx &c, int w, int rq = -1) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W; LC_GLOBAL const DevBatch &B = *LC_CTX(c).B;
   WG_LANE0 {
     S.items_ready = 0;
@@ -4207,6 +4333,18 @@ DEV void process_window(Ctx &c, int w) {
     S.tmp0 = 0;
     if ((uint32_t)S.R > LC_CTX(c).C->reads_cap || S.R > 0xFFFF || S.reflen > LC_MAXW || S.reflen < 1) S.overflow = 1;   // csr / item words keep the read in 16 bits
     S.hasN = 0;
+    S.nosusp_k = -1;
+    if (rq >= 0) {                                  // what the window carried when it was suspended
+      LC_GLOBAL const SvcCont &ct = LC_CTX(c).OUT->svc->cont[rq];
+      S.seq_t5 = ct.seq_t5; S.seq_len = ct.seq_len; S.trim5 = ct.trim5; S.trim3 = ct.trim3; S.emit_seq = ct.emit_seq;
+      S.n_builds = ct.n_builds; S.final_k = ct.final_k; S.max_nodes = ct.max_nodes; S.evt_len = ct.evt_len; S.N_last = ct.N_last;
+      S.n_kmers = ct.n_kmers; S.nosusp_k = ct.k;
+    }
+  }
+  if (rq >= 0 && LC_CTX(c).C->evt_cap) {
+    const uint32_t ecap = LC_CTX(c).C->evt_cap, el = wg_bcastu(&S.evt_len);
+    WG_FOR(j, el) { W.evt[j] = LC_CTX(c).OUT->evt_out[(size_t)w * ecap + (uint32_t)j]; }
+    WG_SYNC();
   }
   LC_GLOBAL const PreHdr *H0 = LC_CTX(c).OUT->pre ? (LC_GLOBAL const PreHdr *)(LC_CTX(c).OUT->pre + (size_t)w * PRE_STRIDE + PRE_OFF_HDR) : nullptr;
   WG_LANE0 { S.tmp1 = (H0 && H0->have_rep == 1u) ? 1 : 0; if (S.tmp1) { S.tmp0 = (int)H0->mapped; S.hasN = 0; } }     // (the build kernel counted them; it scans no window with N)
@@ -4220,7 +4358,7 @@ DEV void process_window(Ctx &c, int w) {
     WG_FOR(i, rl) { if (B.ref_codes[f0 + (uint32_t)i] > 3) S.hasN = 1; }
     WG_SYNC();
   }
-  WG_LANE0 { if (S.tmp0 > 0) evt(c, EV_PROCESS, (uint32_t)(S.R - 1), (uint32_t)S.tmp0); }
+  WG_LANE0 { if (S.tmp0 > 0 && rq < 0) evt(c, EV_PROCESS, (uint32_t)(S.R - 1), (uint32_t)S.tmp0); }
   if (wg_bcast(&S.tmp0) <= 0) { WG_LANE0 { S.status = LANCET_W_NO_READS; } WG_SYNC(); return; }     // Microassembler.cc:83
   if (wg_bcast(&S.overflow)) { WG_LANE0 { S.status = LANCET_W_OVERFLOW; } WG_SYNC(); return; }
   const int reflen = wg_bcast(&S.reflen);
@@ -4240,7 +4378,8 @@ DEV void process_window(Ctx &c, int w) {
   const int refE = wg_bcast(&S.repE), refM = wg_bcast(&S.repM);
   int rptInRef = 0, rptInQry = 0, cycleInGraph = 0;
   bool processed = false;
-  for (int k = LC_CTX(c).P->min_k; k <= LC_CTX(c).P->max_k; k += 2) {
+  const int k_first = rq >= 0 ? wg_uniform(LC_CTX(c).OUT->svc->cont[rq].k) : LC_CTX(c).P->min_k;
+  for (int k = k_first; k <= LC_CTX(c).P->max_k; k += 2) {
     rptInRef = rptInQry = cycleInGraph = 0;
     // isRepeat / isAlmostRepeat on rawseq (Microassembler.cc:118-131)
     if (reflen - k > 0 && refE >= k) { WG_LANE0 { evt(c, EV_REPEAT_REF, k); } rptInRef = 1; continue; }
@@ -4248,7 +4387,10 @@ DEV void process_window(Ctx &c, int w) {
     WG_LANE0 { S.K = k; S.NW = (2 * k + 63) / 64; S.final_k = k; S.source = LC_NIL; S.sink = LC_NIL; if (k > 127 || S.NW > LC_NWMAX) S.overflow = 1; }
     if (wg_bcast(&S.overflow)) break;
     WG_LANE0 { S.prebuilt = 0; S.pre_order = 0; }
-    if (!load_prebuilt(c, k)) build_graph(c);
+    if (!load_prebuilt(c, k)) {
+      if (try_suspend(c, k)) return;
+      build_graph(c);
+    }
     if (wg_bcast(&S.overflow)) break;
     PHASE(c, 7);
     const bool pre_order = wg_bcast(&S.pre_order) != 0;
@@ -4362,20 +4504,65 @@ DEV void process_window(Ctx &c, int w) {
   WG_SYNC();
 }
 
-// entry: persistent workgroup pulling windows off the batch queue
-DEV void window_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *B, LC_GLOBAL const EngineCaps *C, LC_GLOBAL Work *works, LC_GLOBAL DevOut *OUT, LC_WS *S, int slot) {
+// entry: persistent workgroup pulling windows off the batch queue -- and, with the build service, suspended windows whose graph
+// is ready off the ready list.  Returns 1 only in the host emulation: nothing to do until the service has run.
+DEV int window_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *B, LC_GLOBAL const EngineCaps *C, LC_GLOBAL Work *works, LC_GLOBAL DevOut *OUT, LC_WS *S, int slot) {
   Ctx c; c.P = P; c.B = B; c.C = C; c.W = works + slot; c.OUT = OUT; c.S = S;
   LC_CTX_PUBLISH(c);
+  LC_GLOBAL SvcCtl *sv = OUT->svc;
+  int idle = 0;                                             // consecutive waits (a slot that has waited ~50 ms takes a request back whatever the service does)
   while (true) {
-    WG_LANE0 { S->tmp3 = (int)dev_atomic_add(OUT->queue_head, 1u); }
-    int w = wg_bcast(&S->tmp3);
-    if (OUT->win_list) { if ((uint32_t)w >= OUT->n_list) break; w = (int)OUT->win_list[w]; }
-    else if (w >= B->n_windows) break;
-    if (OUT->skip && OUT->skip[w]) continue;      // a coverage pile-up the host sent straight to the re-run tier (engine.hip)
-#ifndef LANCET_WAVE_EMU
-    if (threadIdx.x == 0) { for (int i = 0; i < 16; ++i) S->phase_acc[i] = 0; S->phase_cur = 0; S->t_last = wall_clock64(); }
+    WG_LANE0 {
+      int a = 3, g = 0; bool got = false;                  // 0 new window, 1 resume (graph ready), 2 resume (request taken back), 3 leave, 4 wait
+      if (sv) {
+        const uint32_t h = ld2(&sv->rdy_head);
+        if (h < sv->cap) {
+          const uint32_t v = ld_acq(&sv->rdy[h]);
+          if (v != 0u && dev_atomic_cas32(&sv->rdy_head, h, h + 1u) == h) { a = 1; g = (int)(v - 1u); got = true; dev_atomic_add(&sv->n_resumed, 1u); }
+        }
+      }
+      if (!got) {
+        const uint32_t limit = OUT->win_list ? OUT->n_list : (uint32_t)B->n_windows;
+        if (ld2(OUT->queue_head) < limit) { const uint32_t q = dev_atomic_add(OUT->queue_head, 1u); if (q < limit) { a = 0; g = (int)q; got = true; } }
+      }
+      if (!got && sv) {
+        uint32_t posted = ld2(&sv->req_alloc); if (posted > sv->cap) posted = sv->cap;
+        if (ld2(&sv->n_resumed) < posted) {
+          a = 4;
+          if (ld2(&sv->alive) == 0u || idle > 20000) {      // no service workgroup runs: the general build after all
+            for (uint32_t i = 0; i < posted; ++i)
+              if (ld2(&sv->req[i].state) == SV_POSTED && dev_atomic_cas32(&sv->req[i].state, SV_POSTED, SV_STOLEN) == SV_POSTED) {
+                (void)ld_acq(&sv->req[i].state);
+                a = 2; g = (int)i; dev_atomic_add(&sv->n_resumed, 1u); dev_atomic_add(&sv->n_stolen, 1u); break;
+              }
+          }
+        }
+      }
+      S->act = a; S->act_arg = g;
+    }
+    const int act = wg_bcast(&S->act), arg = wg_bcast(&S->act_arg);
+    if (act == 3) break;
+    if (act == 4) {
+#ifdef LANCET_WAVE_EMU
+      return 1;
+#else
+      dev_sleep(); ++idle; continue;
 #endif
-    process_window(c, w);
+    }
+    idle = 0;
+    int w = arg, rq = -1;
+    if (act == 0) {
+      if (OUT->win_list) w = (int)OUT->win_list[w];
+      if (OUT->skip && OUT->skip[w]) continue;      // a coverage pile-up the host sent straight to the re-run tier (engine.hip)
+    } else { rq = arg; w = (int)sv->req[rq].w; }
+#ifndef LANCET_WAVE_EMU
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < 16; ++i) S->phase_acc[i] = (rq >= 0 && OUT->phase) ? OUT->phase[(size_t)w * 16 + i] : 0ull;
+      S->phase_cur = 0; S->t_last = wall_clock64();
+    }
+#endif
+    process_window(c, w, rq);
+    if (wg_bcast(&S->status) == LANCET_W_SUSPENDED) continue;
     PHASE(c, 0);
     WG_LANE0 {
       lancet_window_stats &st = OUT->stats[w];
@@ -4386,6 +4573,7 @@ DEV void window_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const De
     }
     WG_SYNC();
   }
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------

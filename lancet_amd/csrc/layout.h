@@ -172,8 +172,9 @@ struct PreHdr {
   uint32_t heavy;             /* scheduling hint only: a read holds the same k-mer twice (tandem duplication: the graph will have a cycle and k will climb) */
   uint32_t mapped;            /* countMappedReads of the window (valid with have_rep)                            */
   uint32_t next;              /* 1 + index of the pool area that holds this window's graph at the next k of its loop (built ahead
-                                 because `heavy` says this k will be rejected), 0: none                          */
-  uint32_t pad[10];
+                                 because `heavy` says this k will be rejected, or on request of the window kernel), 0: none */
+  uint32_t big;               /* built by the 1024-lane configuration (the build service runs the 512-lane one)   */
+  uint32_t pad[9];
 };
 #define PRE_OFF_HDR 0u
 #define PRE_OFF_OCCREF 128u                                   /* u32[LC_MAXW]   node | ori << 31 per reference offset   */
@@ -242,6 +243,39 @@ struct Work {
   LC_GLOBAL uint8_t *survb;         /* [nodes] prebuilt window: survivor flag per node (stands in for the stale node records) */
 };
 
+/* ---- build service (engine.hip svc_kernel): graphs of later k attempts built in LDS on request ----
+ * A window whose k was rejected and whose next graph nobody built ahead used to build it with the general (HBM) phases on its one
+ * wave: ~9 ms, the critical path of the launch.  Instead the window is SUSPENDED: its carried state (SvcCont) and a request
+ * (SvcReq) are posted, the slot goes on with another window; a few resident workgroups of the LDS build kernel serve the
+ * requests into pool areas (chained by PreHdr::next like graphs built ahead) and put them on a ready list, from which any slot
+ * resumes the window.  Scheduling only: the records never depend on who built a graph. */
+#define SV_EMPTY 0u
+#define SV_POSTED 1u
+#define SV_CLAIMED 2u   /* a service workgroup is building it                      */
+#define SV_DONE 3u      /* on the ready list                                       */
+#define SV_STOLEN 4u    /* taken back by a window slot (general build)             */
+struct SvcReq { uint32_t w; int32_t k; uint32_t state; uint32_t pad; };
+struct SvcCont {          /* WinShared fields that live across the k attempts of a window */
+  int32_t k, seq_t5, seq_len, trim5, trim3, emit_seq, n_builds, final_k;
+  uint32_t max_nodes, evt_len, N_last, pad;
+  unsigned long long n_kmers;
+};
+struct SvcCtl {
+  uint32_t req_alloc;     /* requests posted (may run past `cap`: those were not posted)      */
+  uint32_t ticket;        /* next request a service workgroup waits for                       */
+  uint32_t rdy_alloc, rdy_head;
+  uint32_t n_resumed;     /* requests taken off the ready list or stolen                      */
+  uint32_t alive;         /* service workgroups running                                       */
+  uint32_t done;          /* set after the window kernel: the service workgroups leave        */
+  uint32_t n_built, n_stolen, n_failed;
+  uint32_t cap;
+  uint32_t steal_cursor;
+  uint32_t pad[4];
+  LC_GLOBAL SvcReq *req;          /* [cap] */
+  LC_GLOBAL uint32_t *rdy;        /* [cap] request index + 1 */
+  LC_GLOBAL SvcCont *cont;        /* [cap] */
+};
+
 /* batch-level outputs */
 struct DevOut {
   LC_GLOBAL struct lancet_variant *variants;
@@ -262,4 +296,5 @@ struct DevOut {
   LC_GLOBAL const uint8_t *pre_pool;   /* areas of graphs built ahead at later k (PreHdr::next chains into it), or null */
   LC_GLOBAL uint32_t *n_ahead_used;    /* atomic: window builds that took a graph built ahead                           */
   LC_GLOBAL const uint8_t *skip;       /* [n_windows] or null; non-zero: not this launch's window (a concurrent launch of the re-run tier has it) */
+  LC_GLOBAL SvcCtl *svc;               /* build service of this launch, or null                                          */
 };

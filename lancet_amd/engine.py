@@ -26,7 +26,7 @@ class EngineError(RuntimeError):
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.environ.get("LANCET_ENGINE_LIB", _LIBPATH)      # (debug: try an alternative build of the same library)
+        path = _LIBPATH
         if not os.path.exists(path):
             raise EngineError(f"{_LIBPATH} is missing: build it with `python -m lancet_amd.build` (there is no CPU fallback)")
         L = C.CDLL(path)
@@ -49,6 +49,7 @@ def lib():
         L.lancet_engine_rerun_count.argtypes = [C.c_void_p]
         L.lancet_engine_prebuilt_count.argtypes = [C.c_void_p]
         L.lancet_engine_ahead_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.lancet_engine_svc_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 4)]
         L.lancet_engine_build_phase_times.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64))]
         L.lancet_engine_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
         L.lancet_engine_kernel_name.restype = C.c_char_p
@@ -176,6 +177,12 @@ class Engine:
         b, u = C.c_int32(), C.c_int32()
         self._chk(self.L.lancet_engine_ahead_counts(self.h, C.byref(b), C.byref(u)))
         return b.value, u.value
+
+    def svc_counts(self):
+        """Build service of the last run: (requests posted, served in LDS, not buildable there, taken back by the window kernel)"""
+        a = (C.c_uint32 * 4)()
+        self._chk(self.L.lancet_engine_svc_counts(self.h, C.byref(a)))
+        return tuple(int(x) for x in a)
 
     def rerun_count(self) -> int:
         return int(self.L.lancet_engine_rerun_count(self.h))

@@ -22,6 +22,7 @@ struct EmuResult {
   uint32_t evt_cap;
   uint32_t n_variants, n_blob;
   uint32_t n_prebuilt, n_ahead_built, n_ahead_used, n_biglist;
+  uint32_t n_svc_built, n_svc_stolen, n_svc_posted;
 };
 
 extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batch *b, uint32_t evt_cap) {
@@ -59,18 +60,19 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   O.queue_head = &qh; O.phase = nullptr; O.win_list = nullptr; O.n_list = 0; O.evt_len = res->evt_len.data(); O.evt_out = res->evt.data();
   // ---- the LDS build kernel first (one emulated workgroup), unless switched off: LANCET_NO_PREBUILD=1 runs the general build for every window
   std::vector<uint8_t> pre, blscr, pool;
+  static thread_local bl_small::BlShared BS;
+  uint32_t bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t pool_cap = 0; int depth = 0;
   O.pre = nullptr; O.pre_pool = nullptr; O.n_ahead_used = &res->n_ahead_used;
   res->n_prebuilt = 0; res->n_ahead_built = 0; res->n_ahead_used = 0; res->n_biglist = 0;
   if (!P->lr_mode && !getenv("LANCET_NO_PREBUILD") && b->n_windows > 0) {
     pre.assign((size_t)b->n_windows * PRE_STRIDE, 0xCD); blscr.assign(bl_large::SCRATCH_BYTES + 256, 0xCD);
-    static thread_local bl_small::BlShared BS;
     static thread_local bl_large::BlShared BSL;
     memset(&BS, 0xCD, sizeof(BS)); memset(&BSL, 0xCD, sizeof(BSL));
-    uint32_t bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<uint32_t> biglist((size_t)b->n_windows + 1, 0);
     const bool large = getenv("LANCET_NO_LARGE_BUILD") == nullptr;
-    const int depth = getenv("LANCET_AHEAD_DEPTH") ? atoi(getenv("LANCET_AHEAD_DEPTH")) : 6;
-    const uint32_t pool_cap = depth > 0 ? (uint32_t)(b->n_windows / 4 + 8) : 0u;
+    depth = getenv("LANCET_AHEAD_DEPTH") ? atoi(getenv("LANCET_AHEAD_DEPTH")) : 6;
+    pool_cap = (uint32_t)(b->n_windows / 4 + (depth > 0 ? 8 : 0) + (getenv("LANCET_NO_SVC") ? 0 : 24));
     if (pool_cap) pool.assign((size_t)pool_cap * PRE_STRIDE, 0xCD);
     if (getenv("LANCET_EMU_FORCE_LARGE")) {                     // (test hook: every window through the 1024-lane configuration)
       for (int w = 0; w < b->n_windows; ++w) { biglist[(size_t)w] = (uint32_t)w; PreHdr *H = (PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); H->status = PB_NOT_BUILT; H->why = 0; H->have_rep = 0; H->heavy = 0; H->next = 0; }
@@ -87,7 +89,20 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   }
   static thread_local WinShared S;
   memset(&S, 0xCD, sizeof(S));
-  window_kernel_body(P, &B, &C, &work, &O, &S, 0);
+  // ---- the build service (engine.hip svc_kernel): LANCET_NO_SVC=1 off, LANCET_SVC_DEAD=1 nobody serves (the slots take their requests back)
+  SvcCtl sv; memset(&sv, 0, sizeof(sv));
+  std::vector<SvcReq> sreq; std::vector<uint32_t> srdy; std::vector<SvcCont> scont;
+  if (O.pre && O.pre_pool && !getenv("LANCET_NO_SVC")) {
+    sv.cap = (uint32_t)b->n_windows * 4u + 16u;
+    sreq.assign(sv.cap, SvcReq{0, 0, SV_EMPTY, 0}); srdy.assign(sv.cap, 0u); scont.resize(sv.cap);
+    sv.req = sreq.data(); sv.rdy = srdy.data(); sv.cont = scont.data();
+    sv.alive = getenv("LANCET_SVC_DEAD") ? 0u : 1u;
+    O.svc = &sv;
+  }
+  while (window_kernel_body(P, &B, &C, &work, &O, &S, 0) != 0)
+    bl_small::svc_kernel_body(P, &B, &C, pre.data(), blscr.data(), bq, BS, 0, pool.data(), pool_cap, getenv("LANCET_SVC_DEPTH") ? atoi(getenv("LANCET_SVC_DEPTH")) : depth, &sv);
+  res->n_svc_built = sv.n_built; res->n_svc_stolen = sv.n_stolen; res->n_svc_posted = sv.req_alloc < sv.cap ? sv.req_alloc : sv.cap;
+  if (getenv("LANCET_EMU_SVC")) fprintf(stderr, "[emu] svc posted %u built %u failed %u stolen %u\n", sv.req_alloc, sv.n_built, sv.n_failed, sv.n_stolen);
   res->n_variants = nv < C.var_cap ? nv : C.var_cap; res->n_blob = nb;
   return res;
 }
@@ -104,6 +119,9 @@ extern "C" uint32_t lancet_emu_n_prebuilt(void *h) { return ((EmuResult *)h)->n_
 extern "C" uint32_t lancet_emu_n_biglist(void *h) { return ((EmuResult *)h)->n_biglist; }
 extern "C" uint32_t lancet_emu_n_ahead_built(void *h) { return ((EmuResult *)h)->n_ahead_built; }
 extern "C" uint32_t lancet_emu_n_ahead_used(void *h) { return ((EmuResult *)h)->n_ahead_used; }
+extern "C" uint32_t lancet_emu_n_svc_posted(void *h) { return ((EmuResult *)h)->n_svc_posted; }
+extern "C" uint32_t lancet_emu_n_svc_built(void *h) { return ((EmuResult *)h)->n_svc_built; }
+extern "C" uint32_t lancet_emu_n_svc_stolen(void *h) { return ((EmuResult *)h)->n_svc_stolen; }
 extern "C" void lancet_emu_free(void *h) { delete (EmuResult *)h; }
 
 // repeat_scan both ways (bit-parallel LDS version vs the byte-wise restatement) for the unit test

@@ -46,6 +46,7 @@ print("  total slot-seconds", tot, "per window ms", 1000 * tot / big.n_windows)
 
 bn = ["setup", "reads -> LDS", "repeat scan + k", "occurrence space + pairs", "insert", "node ids", "slot -> id + counts", "std::hash", "class counts + mate replay", "candidates", "per-position counts", "survivors", "ref coverage", "trace masks", "edges + records", "tail"]
 bp = eng.build_phase_times(); bt = sum(bp)
+print("build service (posted, served, not buildable, taken back):", eng.svc_counts(), "graphs built ahead / taken from the pool:", eng.ahead_counts())
 print("LDS build kernel: prebuilt", eng.prebuilt_count(), "of", big.n_windows, "kernel ms", eng.kernel_times())
 for i, n in enumerate(bn):
     print(f"  build phase {i:2d} {n:32s} {bp[i]:9.3f} s  {100 * bp[i] / max(bt, 1e-12):5.1f} %")

@@ -1,0 +1,20 @@
+"""Per-window slot time of the window kernel against what the build kernel knows about the window (tuning aid for order_kernel)."""
+import sys, os, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from lancet_amd import abi, engine, workload
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+big = workload.make_scan_batch(n, 30, 30, seed=22)
+eng = engine.Engine(abi.default_params(min_k=11, max_k=101))
+eng.upload(big)
+for _ in range(2): eng.run()
+v, st = eng.results()
+ph = eng.phase_times()
+hd = np.zeros(8 * n, dtype=np.uint32)
+eng.L.lancet_debug_pre_headers.argtypes = [C.c_void_p, C.c_void_p]
+eng.L.lancet_debug_pre_headers(eng.h, hd.ctypes.data)
+hd = hd.reshape(n, 8)
+np.savez_compressed(os.path.join(ROOT, "gpurun_out", "tail_probe.npz"), phase=ph, hdr=hd, builds=np.array([s["n_builds"] for s in st]), nvar=np.array([s["n_variants"] for s in st]),
+                    reads=np.diff(big.read_begin), kernel=np.array(eng.kernel_times()))
+print("kernel ms", eng.kernel_times(), "svc", eng.svc_counts())
