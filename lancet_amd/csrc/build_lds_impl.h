@@ -1048,12 +1048,17 @@ DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
 // workgroup takes a ticket, waits for that request to be posted (or for `done`), builds into a pool area (and on into the
 // following k while the hint says that one will be rejected too), chains the area to the window's hand-off and puts the
 // request on the ready list.  Host emulation: one call serves what is posted and returns.
+// A waiting workgroup also leaves when NOTHING on the device has made progress for ~60 ms (the build kernel's and the window
+// kernel's queue heads, the slots' heartbeat, the request counter): under a profiler that serialises kernels (rocprofv3 --pmc) the
+// service would otherwise wait for a window kernel that cannot start before it has left.  The slots then find no service
+// (SvcCtl::alive == 0) and build those graphs themselves.
 DEV void svc_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *B, LC_GLOBAL const EngineCaps *C, LC_GLOBAL uint8_t *pre,
                          LC_GLOBAL uint8_t *scratch, LC_GLOBAL uint32_t *queue, BL_S &S, int slot, LC_GLOBAL uint8_t *pool, uint32_t pool_cap, int depth,
-                         LC_GLOBAL SvcCtl *sv) {
+                         LC_GLOBAL SvcCtl *sv, LC_GLOBAL const uint32_t *wqueue = nullptr) {
   LC_GLOBAL uint8_t *xbase = scratch + (size_t)slot * SCRATCH_BYTES;
 #ifndef LANCET_WAVE_EMU
   WG_LANE0 { dev_atomic_add(&sv->alive, 1u); }
+  unsigned long long t_prog = wall_clock64(); uint32_t last_sum = 0xFFFFFFFFu;      // (lane 0's)
 #endif
   while (true) {
     WG_LANE0 { S.w = (int)dev_atomic_add(&sv->ticket, 1u); }
@@ -1068,6 +1073,12 @@ DEV void svc_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBa
         sv->ticket = t; st = 0xFFFFFFFFu; break;                 // (nothing more is posted: hand the ticket back)
 #else
         if (ld2(&sv->done)) { st = 0xFFFFFFFFu; break; }
+        {
+          const uint32_t sum = ld2(queue) + ld2(&sv->beat) + ld2(&sv->req_alloc) + (wqueue ? ld2(wqueue) : 0u);
+          const unsigned long long now = wall_clock64();
+          if (sum != last_sum) { last_sum = sum; t_prog = now; }
+          else if (now - t_prog > 6000000ull) { dev_atomic_add(&sv->n_gaveup, 1u); st = 0xFFFFFFFFu; break; }      // 60 ms at 100 MHz
+        }
         dev_sleep();
 #endif
       }

@@ -48,9 +48,10 @@ __global__ void __launch_bounds__(bl_large::WG) __attribute__((amdgpu_waves_per_
 // graphs of later k attempts it asks for.  Launched on its own stream before the batch's kernels, leaves when svc_done_kernel
 // (enqueued behind the window kernel) has set SvcCtl::done.
 __global__ void __launch_bounds__(bl_small::WG) __attribute__((amdgpu_waves_per_eu(4, 4))) svc_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue,
-                                                      uint8_t *pool, uint32_t pool_cap, int depth, SvcCtl *sv) {
+                                                      uint8_t *pool, uint32_t pool_cap, int depth, SvcCtl *sv, const uint32_t *wqueue) {
   bl_small::svc_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL uint8_t *)pre, (LC_GLOBAL uint8_t *)scratch,
-                    (LC_GLOBAL uint32_t *)queue, *(bl_small::BL_S *)&bl_small::bl_shared, (int)blockIdx.x, (LC_GLOBAL uint8_t *)pool, pool_cap, depth, (LC_GLOBAL SvcCtl *)sv);
+                    (LC_GLOBAL uint32_t *)queue, *(bl_small::BL_S *)&bl_small::bl_shared, (int)blockIdx.x, (LC_GLOBAL uint8_t *)pool, pool_cap, depth, (LC_GLOBAL SvcCtl *)sv,
+                    (LC_GLOBAL const uint32_t *)wqueue);
 }
 __global__ void svc_done_kernel(SvcCtl *sv) { __hip_atomic_store(&sv->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -545,7 +546,7 @@ int lancet_engine_submit(lancet_engine *e) {
     HIPCHK(e, hipStreamWaitEvent(e->stream3, e->ev_svc, 0));
     hipLaunchKernelGGL(svc_kernel, dim3(e->n_svc_wgs), dim3(bl_small::WG), 0, e->stream3, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
                        (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_svcscratch.p, (uint32_t *)e->d_counters.p + 8,
-                       (uint8_t *)e->d_prepool.p, e->pool_cap, e->svc_depth, (SvcCtl *)e->d_svc.p);
+                       (uint8_t *)e->d_prepool.p, e->pool_cap, e->svc_depth, (SvcCtl *)e->d_svc.p, (const uint32_t *)e->d_counters.p + 2);
     HIPCHK(e, hipGetLastError());
     e->svc_running = true;
   }

@@ -63,6 +63,7 @@ struct WinShared {
   int wk[4];                                     // walk_prepare: match / snp / ins / del columns
   int ps_first, ps_len, ps_hd;                   // path_string_wg: first real node, length ; Hamming distance to the reference
   int wk_n;                                      // walk_prepare: number of non-match columns
+  int wk_stop, wk_nts, wk_last, wk_code, wk_tend, wk_tref;   // process_path_walk_wg: lane 0's state between the chunks of columns
   // (8 KB of LDS per workgroup = 20 single-wave workgroups per CU, the fifth wave per SIMD: two pairs of buffers that are
   //  never live together share their space)
   union {
@@ -84,6 +85,9 @@ struct WinShared {
   };
   uint32_t tmask, N_last; int tfull;                 // open-addressing table of this build: size - 1, filled up, nodes of the window's previous build
   int cmp_ok;                                    // compress_prepare: the component qualifies for compress_fast
+  uint32_t cmp_nh;                               // compress_rank: heads found
+  int seq_lazy;                                  // graph from the LDS build kernel: the k-mer nodes' descriptors are not written yet (seq_materialize)
+  unsigned long long lz_area;                    // ... its hand-off area (candidate keys)
   int mr_src, mr_snk, mr_ambs, mr_ambk;          // mark_ref_scan: first / last qualifying reference offset, ambiguity flags
   int QS, LR;                                    // counters per (survivor, position): 4, or 10 with --linked-reads ; lr_mode
   unsigned long long t_last, phase_acc[16];
@@ -145,6 +149,13 @@ static __shared__ Ctx lc_ctx;
 #define PHASE(c, id) do { if (threadIdx.x == 0) { unsigned long long _t = wall_clock64(); (c).S->phase_acc[(c).S->phase_cur] += _t - (c).S->t_last; (c).S->t_last = _t; (c).S->phase_cur = (id); } } while (0)
 #else
 #define PHASE(c, id) ((void)0)
+#endif
+// profiling builds only (tools/subphase.sh: -DLANCET_PROF=<group>): the steps inside ONE of the coarse phases, accounted in the slots of
+// the general build's phases (2..7, idle on windows whose graphs all come from the LDS build kernel); SUBEND returns to the coarse phase
+#ifdef LANCET_PROF
+#define SUBPHASE(c, group, id) do { if (LANCET_PROF == (group)) PHASE(c, id); } while (0)
+#else
+#define SUBPHASE(c, group, id) ((void)0)
 #endif
 
 // Uniform read of a control word: barrier, everybody reads, barrier (so that the next writer cannot race a
@@ -2135,11 +2146,36 @@ DEV bool l0_tandem(const GrLine0 &g, uint32_t self) {
 #undef LC_X
   return t;
 }
+// descriptor i of candidate ci's k-mer while the descriptors are not materialised (load_prebuilt)
+DEV uint32_t seq_desc_lazy(const LC_WS &S, uint32_t node, uint32_t ci, int K, int i) {
+  LC_GLOBAL const unsigned long long *skey = (LC_GLOBAL const unsigned long long *)((LC_GLOBAL const uint8_t *)(uintptr_t)S.lz_area + PRE_OFF_SKEY);
+  const unsigned long long kk = skey[ci];
+  return SD_MAKE(node, i, key_base(&kk, K, i));
+}
+// all lanes: write every survivor's descriptors (what load_prebuilt used to do), for the routes that read W.seq of k-mer nodes directly
+DEVNI void seq_materialize_all(Ctx &c) {
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  if (!wg_bcast(&S.seq_lazy)) return;
+  LC_GLOBAL const uint8_t *area = (LC_GLOBAL const uint8_t *)(uintptr_t)S.lz_area;
+  LC_GLOBAL const PreHdr *H = (LC_GLOBAL const PreHdr *)(area + PRE_OFF_HDR);
+  LC_GLOBAL const uint32_t *snode = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_SNODE);
+  LC_GLOBAL const unsigned long long *skey = (LC_GLOBAL const unsigned long long *)(area + PRE_OFF_SKEY);
+  const int K = wg_uniform(S.K);
+  const uint32_t ncand = H->ncand;
+  WG_FOR(t, ncand * (uint32_t)K) {
+    const uint32_t ci = (uint32_t)t / (uint32_t)K; const int i = (int)((uint32_t)t % (uint32_t)K);
+    const uint32_t n = snode[ci];
+    if (n != LC_NIL) { const unsigned long long kk = skey[ci]; W.seq[t] = SD_MAKE(n, i, key_base(&kk, K, i)); }
+  }
+  WG_LANE0 { S.seq_lazy = 0; }
+  WG_SYNC();
+}
 DEVNI void compress_prepare(Ctx &c, int comp) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int K = S.K, QS = S.QS;
   LC_GLOBAL NodeGr *gr = W.gr; LC_GLOBAL CmpRec *cmp = W.cmp; LC_GLOBAL uint32_t *todo = W.todo; LC_GLOBAL const uint32_t *seq = W.seq; LC_GLOBAL const uint16_t *qv = W.qv;
   WG_LANE0 { S.cmp_ok = 1; }
+  const bool lazy = wg_bcast(&S.seq_lazy) != 0;
   WG_FOR(i, S.M) {
     const uint32_t n = W.order[i];
     // round trip 1: the node's own record
@@ -2156,7 +2192,12 @@ DEVNI void compress_prepare(Ctx &c, int comp) {
     // round trip 2: the two neighbours' records, the first / last descriptor, their per-position quality counts
     const uint32_t bF = ewF != LC_NIL ? ED_TO(ewF) : n, bR = ewR != LC_NIL ? ED_TO(ewR) : n;
     const GrLine0 BF = gr_line0(&gr[bF]), BR = gr_line0(&gr[bR]);
-    const uint32_t d0 = seq[seq_lo], dK = seq[seq_lo + (uint32_t)(K - 1)];
+    uint32_t d0, dK;
+    if (lazy && seq_lo == nqv * (uint32_t)K) {                  // (a k-mer node of a graph from the LDS build kernel: its descriptors follow from its key)
+      LC_GLOBAL const unsigned long long *skey = (LC_GLOBAL const unsigned long long *)((LC_GLOBAL const uint8_t *)(uintptr_t)S.lz_area + PRE_OFF_SKEY);
+      const unsigned long long kk = skey[nqv];
+      d0 = SD_MAKE(n, 0, key_base(&kk, K, 0)); dK = SD_MAKE(n, K - 1, key_base(&kk, K, K - 1));
+    } else { d0 = seq[seq_lo]; dK = seq[seq_lo + (uint32_t)(K - 1)]; }
     LC_GLOBAL const uint16_t *q0p = qv + ((size_t)nqv * K + 0) * QS, *qKp = qv + ((size_t)nqv * K + (size_t)(K - 1)) * QS;
     const int tq0 = (int)q0p[0] + (int)q0p[1] + (int)q0p[2] + (int)q0p[3], tqK = (int)qKp[0] + (int)qKp[1] + (int)qKp[2] + (int)qKp[3];
     bool irr = false;
@@ -2327,6 +2368,7 @@ DEV unsigned long long pr_pack(const lc_u4 r) {
 DEVNI bool compress_rank(Ctx &c, int comp) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int K = S.K;
+  SUBPHASE(c, 1, 2);
   const uint32_t M = wg_bcastu(&S.M);
   if (M == 0 || 2 * M > 8190u || (size_t)44 * M + 64 > (size_t)4 * LC_CTX(c).C->occ_cap) return false;
   LC_GLOBAL uint32_t *pos = W.pnodes;                                       // node -> table position
@@ -2337,8 +2379,9 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
   LC_GLOBAL uint32_t *hs = W.mv + 24 * (size_t)M;                          // [M+1] absorbed nodes per head -> slice start
   LC_GLOBAL uint32_t *al = hs + (M + 1);                                   // [M+1] deque length per head -> arena offset
   LC_GLOBAL uint32_t *ne = al + (M + 1);                                   // [M * 13] new edge lists of the heads (count + 12)
+  LC_GLOBAL uint32_t *hl = ne + 13 * (size_t)M;                            // [M] table positions of the heads (any order)
   WG_FOR(i, M) { pos[W.order[i]] = (uint32_t)i; }
-  WG_LANE0 { S.tmp0 = 0; S.tmp3 = 0; }
+  WG_LANE0 { S.tmp0 = 0; S.tmp3 = 0; S.cmp_nh = 0; }
   WG_SYNC();
   WG_FOR(i, M) {
     const uint32_t n = W.order[i];
@@ -2356,6 +2399,7 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
     }
   }
   if (wg_bcast(&S.tmp3)) return false;
+  SUBPHASE(c, 1, 3);
   // ---- pointer jumping
   LC_GLOBAL unsigned long long *P = PA, *Q = PB;
   for (int round = 0; round < 15; ++round) {
@@ -2385,13 +2429,14 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
     if (round == 14) return false;                                        // a ring: no port ever reaches an end
   }
   // ---- heads, slices, arena space
+  SUBPHASE(c, 1, 4);
   WG_FOR(i, M) {
     const lc_u4 a = pr_unpack(P[2 * (size_t)i]), b = pr_unpack(P[2 * (size_t)i + 1]);
     const uint32_t mF = a.y & 0x7FFFFFFFu, mR = b.y & 0x7FFFFFFFu;
     const uint32_t cmin = a.z < b.z ? a.z : b.z;
     const bool head = (mF + mR > 0) && cmin == (uint32_t)i;
     hs[i] = head ? mF + mR : 0u; al[i] = head ? (uint32_t)K + mF + mR : 0u;
-    if (head) { lc_u4 z; z.x = 0x7FFFFFFFu; z.y = 0x7FFFFFFFu; z.z = 0; z.w = 0; stg4(hacc + 4 * (size_t)i, z); }
+    if (head) { lc_u4 z; z.x = 0x7FFFFFFFu; z.y = 0x7FFFFFFFu; z.z = 0; z.w = 0; stg4(hacc + 4 * (size_t)i, z); hl[dev_atomic_add((LC_LDS uint32_t *)&S.cmp_nh, 1u)] = (uint32_t)i; }
   }
   WG_LANE0 { hs[M] = 0; al[M] = 0; }
   wg_scan(hs, (int)M + 1, S);
@@ -2401,6 +2446,7 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
   const uint32_t top = wg_bcastu(&S.seq_top);
   if (top + need > LC_CTX(c).C->seq_cap) { WG_LANE0 { OVF(c); S.tmp1 = 0; S.tmp2 = 0; } return true; }
   // ---- every absorbed node: head, side, place, entering direction; descriptor into the head's deque, operands into its slice
+  SUBPHASE(c, 1, 5);
   WG_FOR(i, M) {
     const lc_u4 a = pr_unpack(P[2 * (size_t)i]), b = pr_unpack(P[2 * (size_t)i + 1]);
     const uint32_t mF = a.y & 0x7FFFFFFFu, mR = b.y & 0x7FFFFFFFu;
@@ -2442,8 +2488,12 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
   //  only words updated by atomics -- performed at L2 -- must then be read past the L1 (ld2).  A __threadfence() writes back /
   //  invalidates across the XCDs' L2s and was measured at ~4 % of the kernel per fence and window.)
   WG_SYNC();
-  // ---- one lane per head: the merges' arithmetic in merge order, the new deque, the new edge list
-  WG_FOR(i, M) {
+  // ---- one lane per head: the new deque, the new edge list  (the heads are few: a list of them instead of a look at every position)
+  SUBPHASE(c, 1, 6);
+  const uint32_t nheads = wg_bcastu(&S.cmp_nh);
+  const bool lazy = wg_bcast(&S.seq_lazy) != 0;
+  WG_FOR(hx, nheads) {
+    const uint32_t i = hl[hx];
     const uint32_t cnt = hs[i + 1] - hs[i];
     if (cnt == 0) continue;
     const uint32_t H = W.order[i];
@@ -2451,31 +2501,16 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
     const lc_u4 a = pr_unpack(P[2 * (size_t)i]), b = pr_unpack(P[2 * (size_t)i + 1]);
     const uint32_t mF = a.y & 0x7FFFFFFFu, mR = b.y & 0x7FFFFFFFu;
     const uint32_t nb = top + al[i], olo = G.seq_lo;
-    for (int t = 0; t < K; ++t) W.seq[nb + mR + (uint32_t)t] = W.seq[olo + (uint32_t)t];
+    if (lazy && olo == G.nqv * (uint32_t)K) { for (int t = 0; t < K; ++t) W.seq[nb + mR + (uint32_t)t] = seq_desc_lazy(S, H, G.nqv, K, t); }
+    else for (int t = 0; t < K; ++t) W.seq[nb + mR + (uint32_t)t] = W.seq[olo + (uint32_t)t];
     int mn = G.mincov, mq = G.mincovqv;
-    float nc0 = G.cov[0], nc1 = G.cov[1], nc2 = G.cov[2], nc3 = G.cov[3];
     uint32_t fl = G.flags, nkmT = G.nkmT;
-    LC_GLOBAL const uint32_t *sl = ord + 4 * (size_t)hs[i];
     {
       lc_u4 ha; ha.x = ld2(&hacc[4 * (size_t)i]); ha.y = ld2(&hacc[4 * (size_t)i + 1]); ha.z = ld2(&hacc[4 * (size_t)i + 2]); ha.w = ld2(&hacc[4 * (size_t)i + 3]);
       if ((int)ha.x < mn) mn = (int)ha.x;
       if ((int)ha.y < mq) mq = (int)ha.y;
       fl |= ha.z; nkmT += ha.w;
     }
-    // four merges per trip, the next four coverages already on their way (named registers: an indexed local array lives in scratch
-    // memory, and waiting for it waits for the loads in flight as well)
-#define LC_MERGE_STEP(cv, t) do { if ((t) < cnt) { const int amer = (int)(t) + 1, bmer = 1;   /* Graph.cc:2632-2636, same expression, same order */ \
-      nc0 = ((nc0 * amer) + (__builtin_bit_cast(float, (cv).x) * bmer)) / (amer + bmer); nc1 = ((nc1 * amer) + (__builtin_bit_cast(float, (cv).y) * bmer)) / (amer + bmer); \
-      nc2 = ((nc2 * amer) + (__builtin_bit_cast(float, (cv).z) * bmer)) / (amer + bmer); nc3 = ((nc3 * amer) + (__builtin_bit_cast(float, (cv).w) * bmer)) / (amer + bmer); } } while (0)
-#define LC_MERGE_LOAD(u, t0) ldg4(sl + 4 * (size_t)((t0) + (u) < cnt ? (t0) + (u) : cnt - 1))
-    lc_u4 n0 = LC_MERGE_LOAD(0u, 0u), n1 = LC_MERGE_LOAD(1u, 0u), n2 = LC_MERGE_LOAD(2u, 0u), n3 = LC_MERGE_LOAD(3u, 0u);
-    for (uint32_t t0 = 0; t0 < cnt; t0 += 4) {
-      const lc_u4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
-      if (t0 + 4 < cnt) { n0 = LC_MERGE_LOAD(0u, t0 + 4); n1 = LC_MERGE_LOAD(1u, t0 + 4); n2 = LC_MERGE_LOAD(2u, t0 + 4); n3 = LC_MERGE_LOAD(3u, t0 + 4); }
-      LC_MERGE_STEP(c0, t0); LC_MERGE_STEP(c1, t0 + 1); LC_MERGE_STEP(c2, t0 + 2); LC_MERGE_STEP(c3, t0 + 3);
-    }
-#undef LC_MERGE_STEP
-#undef LC_MERGE_LOAD
     // edges: own ones without the merged links, then the outward edges of the F-side end, then of the R-side end
     uint32_t el[LC_EMAX + 1]; int m = 0; bool bad = false;
     const int uF = mF ? get_buddy(c, H, 'F') : -1, uR = mR ? get_buddy(c, H, 'R') : -1;
@@ -2502,10 +2537,34 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
     ne[13 * (size_t)i] = (uint32_t)m;
     for (int e = 0; e < m; ++e) ne[13 * (size_t)i + 1 + e] = el[e];
     G.seq_clo = nb; G.seq_lo = nb; G.seq_hi = nb + (uint32_t)K + mF + mR; G.seq_chi = G.seq_hi;
-    G.mincov = mn; G.mincovqv = mq; G.cov[0] = nc0; G.cov[1] = nc1; G.cov[2] = nc2; G.cov[3] = nc3;
+    G.mincov = mn; G.mincovqv = mq;
     G.flags = fl; G.nkm += cnt; G.nkmT = nkmT;
   }
+  // ---- the float averaging of the merges (Graph.cc:2632-2636), in merge order: the one strictly sequential piece -- a clean window is
+  //      ONE chain of ~590 merges, four IEEE divisions each.  The four coverages are independent recurrences: one lane per (head,
+  //      coverage) instead of one per head, the next four operands already on their way.
+  WG_FOR(x, 4 * nheads) {
+    const uint32_t i = hl[(uint32_t)x >> 2], q = (uint32_t)x & 3u;
+    const uint32_t cnt = hs[i + 1] - hs[i];
+    if (cnt == 0) continue;
+    LC_GLOBAL NodeGr &G = W.gr[W.order[i]];
+    float nc = G.cov[q];
+    LC_GLOBAL const uint32_t *sl = ord + 4 * (size_t)hs[i] + q;
+#define LC_MERGE_STEP(cv, t) do { if ((t) < cnt) { const int amer = (int)(t) + 1, bmer = 1;   /* Graph.cc:2632-2636, same expression, same order */ \
+      nc = ((nc * amer) + (__builtin_bit_cast(float, (cv)) * bmer)) / (amer + bmer); } } while (0)
+#define LC_MERGE_LOAD(u, t0) sl[4 * (size_t)((t0) + (u) < cnt ? (t0) + (u) : cnt - 1)]
+    uint32_t n0 = LC_MERGE_LOAD(0u, 0u), n1 = LC_MERGE_LOAD(1u, 0u), n2 = LC_MERGE_LOAD(2u, 0u), n3 = LC_MERGE_LOAD(3u, 0u);
+    for (uint32_t t0 = 0; t0 < cnt; t0 += 4) {
+      const uint32_t c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+      if (t0 + 4 < cnt) { n0 = LC_MERGE_LOAD(0u, t0 + 4); n1 = LC_MERGE_LOAD(1u, t0 + 4); n2 = LC_MERGE_LOAD(2u, t0 + 4); n3 = LC_MERGE_LOAD(3u, t0 + 4); }
+      LC_MERGE_STEP(c0, t0); LC_MERGE_STEP(c1, t0 + 1); LC_MERGE_STEP(c2, t0 + 2); LC_MERGE_STEP(c3, t0 + 3);
+    }
+#undef LC_MERGE_STEP
+#undef LC_MERGE_LOAD
+    G.cov[q] = nc;
+  }
   WG_SYNC();
+  SUBPHASE(c, 1, 7);
   // ---- every live node of the component: the head's new list / its own one, edges into an absorbed node redirected to its head
   //      (the orientation the edge arrives in flips when the absorbed node's frame was flipped against the head's: updateEdge)
   WG_FOR(i, M) {
@@ -2513,6 +2572,10 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
     LC_GLOBAL NodeGr &G = W.gr[n];
     if (G.comp != comp || (G.flags & NF_DEAD)) continue;
     const bool head = hs[i + 1] != hs[i];
+    if (lazy && !head && !(G.flags & NF_SPECIAL) && G.nqv != LC_NIL && G.seq_lo == G.nqv * (uint32_t)K && G.seq_hi == G.seq_lo + (uint32_t)K) {
+      const uint32_t b0 = G.seq_lo, q = G.nqv;                  // a k-mer node that stays on its own: its descriptors are due now
+      for (int t = 0; t < K; ++t) W.seq[b0 + (uint32_t)t] = seq_desc_lazy(S, n, q, K, t);
+    }
     const int cnt = head ? (int)ne[13 * (size_t)i] : (int)G.necnt;
     for (int e = 0; e < cnt; ++e) {
       uint32_t ew = head ? ne[13 * (size_t)i + 1 + e] : G.edges[e];
@@ -3428,6 +3491,7 @@ DEV void align_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const 
 // Returns false (nothing usable) when the band cannot be certified or does not hold both corners: align_fill then runs.
 // ---------------------------------------------------------------------------------------------------------
 #define LC_BNEG (-(1 << 24))
+template <bool B> struct LcBool { static constexpr bool value = B; };
 DEV void band_cell(int i, int j, int sch, int tch, int dM, int uM, int uX, int lM, int lY, int *oM, int *oX, int *oY, uint8_t *otb) {
   const int xa = uX - 1, xb = uM - 8;
   int xs, xt; if (xa > xb) { xs = xa; xt = 1; } else { xs = xb; xt = 0; }
@@ -3451,7 +3515,11 @@ DEVNI bool align_fill_band(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL
   {
     const int lane = (int)threadIdx.x;
     LC_GLOBAL uint8_t *tbp = W.tb;
-    int M1 = LC_BNEG, X1 = LC_BNEG, Y1 = LC_BNEG, M2 = LC_BNEG;     // own cell of the previous step (M, X, Y) and M of the one before
+    // A lane owns two neighbouring offsets, E = lo + 2 * lane (met on the steps of one parity) and O = E + 1 (the other parity), and
+    // keeps the last cell of each in registers: the cell above a new E cell is the lane's own O cell, the one to its left the O cell
+    // of the lane below (one DPP wave shift, no LDS round trip); for an O cell it is the other way round; the diagonal predecessor is
+    // the previous cell of the same offset.  Two steps per trip, so the parity is a compile-time constant.
+    int ME = LC_BNEG, XE = LC_BNEG, YE = LC_BNEG, MO = LC_BNEG, XO = LC_BNEG, YO = LC_BNEG;
     int fin = LC_BNEG;
     // The two strings in LDS: every step of every lane reads one character of each, and a global load there (~1 us under load)
     // was the whole cost of a step (1200 steps for a 600 x 600 problem).
@@ -3459,29 +3527,53 @@ DEVNI bool align_fill_band(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL
     const bool staged = (size_t)(n + m) <= sizeof(S.lbytes);
     if (staged) { WG_FOR(x, n) { ls[x] = Sx[x]; } WG_FOR(x, m) { ls[n + x] = Tx[x]; } }
     WG_SYNC();
-    if (lane < 64)                                                   // (not the helper waves of the fat form)
-    for (int t = 2; t <= n + m; ++t) {
-      const int pt = (t - lo) & 1;
-      const int o = lo + 2 * lane + pt;
-      const int i = (t - o) >> 1, j = t - i;
-      const bool valid = o <= hi && i >= 1 && i <= n && j >= 1 && j <= m;
-      // the neighbour lane's previous cell: lane + 1 holds offset o + 1 when pt == 1, lane - 1 holds o - 1 when pt == 0
-      int nM = pt ? __shfl_down(M1, 1, 64) : __shfl_up(M1, 1, 64);
-      int nXY = pt ? __shfl_down(X1, 1, 64) : __shfl_up(Y1, 1, 64);
-      if (pt ? lane == 63 : lane == 0) { nM = LC_BNEG; nXY = LC_BNEG; }
-      int uM = pt ? nM : M1, uX = pt ? nXY : X1;                       // (i-1, j): offset o + 1
-      int lM = pt ? M1 : nM, lY = pt ? Y1 : nXY;                       // (i, j-1): offset o - 1
-      int dM = M2;                                                     // (i-1, j-1): offset o, two steps ago
-      if (i == 1) { uM = -8 - j; uX = -8 - j; dM = (j == 1) ? 0 : -8 - (j - 1); }
-      if (j == 1) { lM = -8 - i; lY = -8 - i; if (i != 1) dM = -8 - (i - 1); }
-      int cM = LC_BNEG, cX = LC_BNEG, cY = LC_BNEG; uint8_t tb = 0;
-      if (valid) {
-        band_cell(i, j, staged ? (int)ls[i - 1] : (int)Sx[i - 1], staged ? (int)ls[n + j - 1] : (int)Tx[j - 1], dM, uM, uX, lM, lY, &cM, &cX, &cY, &tb);
-        tbp[(size_t)t * 64 + (size_t)lane] = tb;
-        if (i == n && j == m) fin = cM;
-      }
-      M2 = M1; M1 = cM; X1 = cX; Y1 = cY;
-    }
+    // (two instances of the loop: with a global load anywhere in it, every step's wait for that load would also wait for the
+    //  previous step's traceback store -- a full memory round trip per step; the LDS instance leaves the stores in flight)
+    auto run = [&](auto STG) {
+      constexpr bool stg = decltype(STG)::value;
+      const int oE = lo + 2 * lane, oO = oE + 1;
+      const bool okE = oE <= hi, okO = oO <= hi;
+      auto cell = [&](const int t, const int o, const bool ok, const int dM0, const int uM0, const int uX0, const int lM0, const int lY0, int &oM, int &oX, int &oY) {
+        const int i = (t - o) >> 1, j = t - i;
+        const bool valid = ok && i >= 1 && i <= n && j >= 1 && j <= m;
+        int dM = dM0, uM = uM0, uX = uX0, lM = lM0, lY = lY0;
+        if (i == 1) { uM = -8 - j; uX = -8 - j; dM = (j == 1) ? 0 : -8 - (j - 1); }
+        if (j == 1) { lM = -8 - i; lY = -8 - i; if (i != 1) dM = -8 - (i - 1); }
+        const int ic = valid ? i - 1 : 0, jc = valid ? j - 1 : 0;
+        int sch, tch;
+        if constexpr (stg) { sch = (int)ls[ic]; tch = (int)ls[n + jc]; } else { sch = (int)Sx[ic]; tch = (int)Tx[jc]; }
+        const int xa = uX - 1, xb = uM - 8;
+        const int xs = xa > xb ? xa : xb, xt = xa > xb ? 1 : 0;
+        const int ya = lY - 1, yb = lM - 8;
+        const int ys = ya > yb ? ya : yb, yt = ya > yb ? 1 : 0;
+        int ms = dM + (sch == tch ? 2 : -4), mt = 0;
+        if (xs > ms) { ms = xs; mt = 1; }
+        if (ys > ms) { ms = ys; mt = 2; }
+        if (valid) {
+          tbp[(size_t)t * 64 + (size_t)lane] = (uint8_t)(mt | (xt << 2) | (yt << 4));
+          if (i == n && j == m) fin = ms;
+        }
+        oM = valid ? ms : LC_BNEG; oX = valid ? xs : LC_BNEG; oY = valid ? ys : LC_BNEG;
+      };
+      // wave_shr:1 -- lane l reads lane l - 1 (lane 0 keeps `old`); wave_shl:1 -- lane l reads lane l + 1 (lane 63 keeps `old`)
+      auto stepE = [&](const int t) {      // new cell at offset E: above = own O, left = O of lane - 1
+        const int lM = __builtin_amdgcn_update_dpp(LC_BNEG, MO, 0x138, 0xf, 0xf, false);
+        const int lY = __builtin_amdgcn_update_dpp(LC_BNEG, YO, 0x138, 0xf, 0xf, false);
+        int cM, cX, cY; cell(t, oE, okE, ME, MO, XO, lM, lY, cM, cX, cY);
+        ME = cM; XE = cX; YE = cY;
+      };
+      auto stepO = [&](const int t) {      // new cell at offset O: above = E of lane + 1, left = own E
+        const int uM = __builtin_amdgcn_update_dpp(LC_BNEG, ME, 0x130, 0xf, 0xf, false);
+        const int uX = __builtin_amdgcn_update_dpp(LC_BNEG, XE, 0x130, 0xf, 0xf, false);
+        int cM, cX, cY; cell(t, oO, okO, MO, uM, uX, ME, YE, cM, cX, cY);
+        MO = cM; XO = cX; YO = cY;
+      };
+      int t = 2;
+      if (((t - lo) & 1) != 0) { stepO(t); ++t; }
+      for (; t + 1 <= n + m; t += 2) { stepE(t); stepO(t + 1); }
+      if (t <= n + m) stepE(t);
+    };
+    if (lane < 64) { if (staged) run(LcBool<true>{}); else run(LcBool<false>{}); }          // (not the helper waves of the fat form)
     if (fin != LC_BNEG) S.al_score = fin;                              // (exactly one lane holds the corner)
   }
 #else
@@ -3656,14 +3748,14 @@ DEVNI void align_traceback_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, LC_GLOBAL c
 struct Acc {   // one cov_t field of one of the four coverage vectors of a transcript
   uint16_t first, mn, mnz, sum, sumnz, nnz; uint32_t n;
 };
-DEV void acc_init(Acc &a, uint16_t v) { a.first = v; a.mn = v; a.mnz = v; a.sum = 0; a.sumnz = 0; a.nnz = 0; a.n = 0; a.sum = (uint16_t)(a.sum + v); if (v != 0) { a.sumnz = (uint16_t)(a.sumnz + v); ++a.nnz; } a.n = 1; }
-DEV void acc_push(Acc &a, uint16_t v) {
+template <class A> DEV void acc_init(A &a, uint16_t v) { a.first = v; a.mn = v; a.mnz = v; a.sum = 0; a.sumnz = 0; a.nnz = 0; a.n = 0; a.sum = (uint16_t)(a.sum + v); if (v != 0) { a.sumnz = (uint16_t)(a.sumnz + v); ++a.nnz; } a.n = 1; }
+template <class A> DEV void acc_push(A &a, uint16_t v) {
   a.sum = (uint16_t)(a.sum + v); if (v != 0) { a.sumnz = (uint16_t)(a.sumnz + v); a.nnz = (uint16_t)(a.nnz + 1); }
   if (v < a.mn) a.mn = v;
   if (v < a.mnz && v != 0) a.mnz = v;
   ++a.n;
 }
-DEV uint16_t acc_mean(const Acc &a) { return a.n > 0 ? (uint16_t)((float)a.sum / (float)a.n) : (uint16_t)0; }
+template <class A> DEV uint16_t acc_mean(const A &a) { return a.n > 0 ? (uint16_t)((float)a.sum / (float)a.n) : (uint16_t)0; }
 
 struct TS {
   uint32_t pos, ref_pos, start_pos, end_pos, ref_end_pos;
@@ -3674,13 +3766,13 @@ struct TS {
   uint16_t hrmnN[3], hrmnT[3], hrsumN[3], hrsumT[3], hamnN[3], hamnT[3], haqN[3], haqT[3];
 };
 struct HPc { uint16_t nh[3], nq[3], th[3], tq[3]; };   // hp0-2 and hp0-2_minqv of one position, normal / tumor
-DEV void ts_hp_init(TS &t, const HPc &a, const HPc &r) {
+template <class T> DEV void ts_hp_init(T &t, const HPc &a, const HPc &r) {
   for (int j = 0; j < 3; ++j) {
     t.hrmnN[j] = r.nh[j]; t.hrmnT[j] = r.th[j]; t.hrsumN[j] = r.nh[j]; t.hrsumT[j] = r.th[j];
     t.hamnN[j] = a.nh[j]; t.hamnT[j] = a.th[j]; t.haqN[j] = a.nq[j]; t.haqT[j] = a.tq[j];
   }
 }
-DEV void ts_hp_add_alt(TS &t, const HPc &a) {
+template <class T> DEV void ts_hp_add_alt(T &t, const HPc &a) {
   for (int j = 0; j < 3; ++j) {
     if (a.nh[j] < t.hamnN[j]) t.hamnN[j] = a.nh[j];
     if (a.th[j] < t.hamnT[j]) t.hamnT[j] = a.th[j];
@@ -3688,7 +3780,7 @@ DEV void ts_hp_add_alt(TS &t, const HPc &a) {
     if (a.tq[j] < t.haqT[j]) t.haqT[j] = a.tq[j];
   }
 }
-DEV void ts_hp_add_ref(TS &t, const HPc &r) {
+template <class T> DEV void ts_hp_add_ref(T &t, const HPc &r) {
   for (int j = 0; j < 3; ++j) {
     if (r.nh[j] < t.hrmnN[j]) t.hrmnN[j] = r.nh[j];
     if (r.th[j] < t.hrmnT[j]) t.hrmnT[j] = r.th[j];
@@ -3708,8 +3800,8 @@ DEV void path_hp_at(const Ctx &c, int P, HPc &a) {
   desc_hp(c, d, 0, a.nh, a.nq);
   desc_hp(c, d, 1, a.th, a.tq);
 }
-DEV void ts_add_alt(TS &t, const uint16_t *n4, const uint16_t *t4) { for (int q = 0; q < 4; ++q) { acc_push(t.aN[q], n4[q]); acc_push(t.aT[q], t4[q]); } }
-DEV void ts_add_ref(TS &t, const uint16_t *n2, const uint16_t *t2) { for (int q = 0; q < 2; ++q) { acc_push(t.rN[q], n2[q]); acc_push(t.rT[q], t2[q]); } }
+template <class T> DEV void ts_add_alt(T &t, const uint16_t *n4, const uint16_t *t4) { for (int q = 0; q < 4; ++q) { acc_push(t.aN[q], n4[q]); acc_push(t.aT[q], t4[q]); } }
+template <class T> DEV void ts_add_ref(T &t, const uint16_t *n2, const uint16_t *t2) { for (int q = 0; q < 2; ++q) { acc_push(t.rN[q], n2[q]); acc_push(t.rT[q], t2[q]); } }
 
 DEV void ref_cov_at(const Ctx &c, uint32_t pos, uint16_t *n2, uint16_t *t2) {   // Ref_t::getCovStructAt, reference src/Ref.cc:253-267
   if ((int)pos < LC_SREF(c).reflen) { const uint16_t *r = LC_CTX(c).W->refcov + 4 * pos; t2[0] = r[0]; t2[1] = r[1]; n2[0] = r[2]; n2[1] = r[3]; }
@@ -3855,17 +3947,8 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
   const int cap = LC_MAXW + (int)LC_CTX(c).C->path_cap + 2;
   LC_GLOBAL const uint8_t *ra = W.aln, *pa = W.aln + cap;
   const int refstart = LC_CTX(c).B->ref_start[S.w];
-  // The transcripts: the first LC_TS_LDS of a path in LDS (the staging area of the build phases, idle here), further ones in the
-  // traceback matrix, which is dead by now.  Every column of an indel updates a dozen running minima / sums of its transcript:
-  // in HBM that was ~100 dependent accesses per column and the longest phase of the windows that define the launch's tail.
-  TS *ts_far = (TS *)(void *)W.tb;
-#ifndef LANCET_WAVE_EMU
-  TS *ts_near = (TS *)(LC_LDS TS *)&lc_shared.lbytes[0];
-#else
-  TS *ts_near = (TS *)(void *)&S.lbytes[0];
-#endif
-  constexpr int LC_TS_LDS = (int)(sizeof(S.lbytes) / sizeof(TS));
-  auto ts_at = [&](int idx) -> TS & { return idx < LC_TS_LDS ? ts_near[idx] : ts_far[idx]; };
+  TS *ts = (TS *)(void *)W.tb;                 // the traceback matrix is dead by now: reuse it for the transcripts
+  auto ts_at = [&](int idx) -> TS & { return ts[idx]; };
   int nts = 0;
   unsigned pos_in_ref = 0, pathpos = 0;
   char code = '?', prev_code = '?';
@@ -4003,6 +4086,203 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
   if ((snp_bp + ins_bp + del_bp) == 0) ++S.tmp0; else if (snp_bp == 0) ++S.tmp1; else if ((ins_bp + del_bp) == 0) ++S.tmp2; else ++S.part[0];
 }
 
+// The same walk with the looking-up done by all lanes (short reads; --linked-reads keeps the one-lane form above).
+// What a column contributes -- the path's and the reference's coverage at its position, the node that spans it -- does not
+// depend on the columns before it, and in HBM it is a chain of ~15 dependent loads per column (and per position of the K+1
+// positions every indel is extended by), which made this the longest phase of the windows that align.  So: the lanes gather
+// 64 columns at a time into LDS records (the `acc` area of the build phases, idle here), lane 0 then runs the reference's
+// sequential rules (which transcript a column opens / extends / turns complex) over LDS.  Path_t::pathcontig becomes a
+// binary search over the path's node ends (they grow along the path).
+//   record (10 words): alt N fwd|rev, N qf|qr, alt T fwd|rev, T qf|qr, ref N fwd|rev, ref T fwd|rev, column / position j, P, pos_in_ref,
+//                      flags (1 spanner within tumor, 2 no spanner, 4 P outside the path) | column code << 8
+DEV void walk_gather(Ctx &c, volatile LC_LDS uint32_t *rec, int pathpos, int P, uint32_t refpos, int plen, int np, LC_GLOBAL const uint32_t *pend, uint32_t w6, uint32_t w8, uint32_t code) {
+  LC_GLOBAL Work &W = *LC_CTX(c).W;
+  uint32_t fl = 0;
+  // first node whose end reaches pathpos (special nodes carry the running position: never the answer unless nothing else is)
+  int lo = 0, hi = np;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)(pend[2 * mid] & 0x7FFFFFFFu) >= pathpos) hi = mid; else lo = mid + 1; }
+  while (lo < np && (pend[2 * lo] & 0x80000000u)) ++lo;
+  if (lo >= np) fl |= 2u; else if (pend[2 * lo + 1] & 1u) fl |= 1u;
+  uint16_t cn4[4] = {0, 0, 0, 0}, ct4[4] = {0, 0, 0, 0}, rn2[2], rt2[2];
+  if (P < 0 || P >= plen) fl |= 4u; else path_cov_at(c, P, cn4, ct4);
+  ref_cov_at(c, refpos, rn2, rt2);
+  rec[0] = (uint32_t)cn4[0] | ((uint32_t)cn4[1] << 16); rec[1] = (uint32_t)cn4[2] | ((uint32_t)cn4[3] << 16);
+  rec[2] = (uint32_t)ct4[0] | ((uint32_t)ct4[1] << 16); rec[3] = (uint32_t)ct4[2] | ((uint32_t)ct4[3] << 16);
+  rec[4] = (uint32_t)rn2[0] | ((uint32_t)rn2[1] << 16); rec[5] = (uint32_t)rt2[0] | ((uint32_t)rt2[1] << 16);
+  rec[6] = w6; rec[7] = (uint32_t)P; rec[8] = w8; rec[9] = fl | (code << 8);
+  (void)W;
+}
+DEVNI void process_path_walk_wg(Ctx &c, int np, int plen, int L, int complete) {
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  const int K = wg_uniform(S.K);
+  const int cap = LC_MAXW + (int)LC_CTX(c).C->path_cap + 2;
+  LC_GLOBAL const uint8_t *ra = W.aln, *pa = W.aln + cap;
+  const int refstart = LC_CTX(c).B->ref_start[S.w];
+  const int trim5 = wg_uniform(S.trim5);
+  // the transcripts of the path in LDS (the staging area of the build phases); a path with more of them than fit there takes the one-lane form
+#ifndef LANCET_WAVE_EMU
+  LC_LDS TS *ts = (LC_LDS TS *)&lc_shared.lbytes[0];
+#else
+  TS *ts = (TS *)(void *)&S.lbytes[0];
+#endif
+  constexpr int LC_TS_LDS = (int)(sizeof(S.lbytes) / sizeof(TS));
+  volatile LC_LDS uint32_t *recs = (volatile LC_LDS uint32_t *)&S.acc[0][0];
+  static_assert(sizeof(S.acc) >= 64 * 10 * sizeof(uint32_t), "64 column records");
+  LC_GLOBAL const uint32_t *E1 = W.scratch, *E2 = W.scratch + (L + 1), *cols = W.scratch + 3 * (L + 1);
+  // ---- the path's nodes: end position (Path_t::pathcontig's cur + span) | special << 31, isStatusCnt('T')  (W.cmp is idle after the first compress)
+  LC_GLOBAL uint32_t *pend = (LC_GLOBAL uint32_t *)W.cmp;
+  LC_GLOBAL uint32_t *pstep = W.pdesc + plen;                     // [np + 1] span - K + 1 per node (behind the path's descriptors) -> running position
+  const bool fits = (size_t)plen + (size_t)np + 2 <= (size_t)LC_CTX(c).C->path_cap && (size_t)np * 8 <= (size_t)(LC_CTX(c).C->node_cap + LC_CTX(c).C->special_cap) * sizeof(CmpRec);
+  if (!fits) { WG_LANE0 { process_path_walk(c, np, plen, L, complete); } return; }
+  SUBPHASE(c, 4, 3);
+  WG_FOR(i, np) {
+    const uint32_t nd = W.pnodes[i];
+    pstep[i] = (W.gr[nd].flags & NF_SPECIAL) ? 0u : (uint32_t)(n_len(c, nd) - K + 1);
+  }
+  WG_LANE0 { pstep[np] = 0; }
+  wg_scan(pstep, np + 1, S, S.part2);
+  WG_FOR(i, np) {
+    const uint32_t nd = W.pnodes[i];
+    const bool sp = (W.gr[nd].flags & NF_SPECIAL) != 0;
+    pend[2 * i] = sp ? (pstep[i] | 0x80000000u) : (pstep[i] + (uint32_t)n_len(c, nd));
+    pend[2 * i + 1] = (!sp && status_cnt_T(c, nd)) ? 1u : 0u;
+  }
+  WG_LANE0 { S.wk_stop = 0; S.wk_nts = 0; S.wk_last = -2; S.wk_code = '?'; }
+  WG_SYNC();
+  const int ncols = wg_bcast(&S.wk_n);
+  // ---- the non-match columns
+  SUBPHASE(c, 4, 4);
+  for (int c0 = 0; c0 < ncols; c0 += 64) {
+    WG_FOR(l, LANCET_WG) {
+      const int ci = c0 + l;
+      if (ci < ncols) {
+        const int i = (int)cols[ci];
+        const uint8_t r = ra[i], p = pa[i];
+        const uint32_t code = r == '-' ? (uint32_t)'^' : (p == '-' ? (uint32_t)'v' : (uint32_t)'x');
+        const uint32_t pos_in_ref = E1[i];
+        const int pathpos = (int)(E2[i] + (p != '-' ? 1u : 0u));
+        walk_gather(c, recs + 10 * l, pathpos, pathpos - 1, pos_in_ref + (uint32_t)trim5, plen, np, pend, (uint32_t)i, pos_in_ref, code);
+      }
+    }
+    WG_SYNC();
+    WG_LANE0 {
+      const int cnt = ncols - c0 < 64 ? ncols - c0 : 64;
+      int nts = S.wk_nts, last_col = S.wk_last; char code = (char)S.wk_code, prev_code;
+      for (int l = 0; l < cnt && !S.wk_stop; ++l) {
+        volatile LC_LDS uint32_t *rc = recs + 10 * l;
+        const int i = (int)rc[6], P = (int)rc[7]; const uint32_t pos_in_ref = rc[8], fl = rc[9] & 0xFFu;
+        prev_code = (last_col == i - 1) ? code : '=';
+        last_col = i; code = (char)(rc[9] >> 8);
+        if (fl & 2u) { S.wk_stop = 1; break; }                           // no node spans the position: the reference's loop ends here
+        if (fl & 4u) { OVF(c); S.wk_stop = 2; break; }                   // the reference reads coverageN[-1] here (undefined)
+        const bool within_tumor = (fl & 1u) != 0;
+        uint16_t cn4[4] = {(uint16_t)rc[0], (uint16_t)(rc[0] >> 16), (uint16_t)rc[1], (uint16_t)(rc[1] >> 16)};
+        uint16_t ct4[4] = {(uint16_t)rc[2], (uint16_t)(rc[2] >> 16), (uint16_t)rc[3], (uint16_t)(rc[3] >> 16)};
+        uint16_t rn2[2] = {(uint16_t)rc[4], (uint16_t)(rc[4] >> 16)}, rt2[2] = {(uint16_t)rc[5], (uint16_t)(rc[5] >> 16)};
+        const unsigned rrpos = pos_in_ref + (unsigned)refstart + (unsigned)trim5;
+        if (nts > 0 && prev_code != '=') {
+          auto &t = ts[nts - 1];
+          if (within_tumor) t.somatic = true;
+          const int reflen_before = t.col1 - t.col0 + 1;
+          t.col1 = i; t.end_pos = (uint32_t)P; t.ref_end_pos = pos_in_ref;
+          if (code == '^' && t.code == code && t.pos == rrpos) { ts_add_alt(t, cn4, ct4); }
+          else if (code == 'v' && t.code == code && (t.pos + (unsigned)(reflen_before + 1)) == rrpos) { ts_add_ref(t, rn2, rt2); }
+          else if (code == 'x' || t.code != code) { t.code = 'c'; ts_add_alt(t, cn4, ct4); ts_add_ref(t, rn2, rt2); }
+        } else {
+          int pr = i - 1, pq = i - 1;
+          while (pr >= 0 && ra[pr] != 'A' && ra[pr] != 'C' && ra[pr] != 'G' && ra[pr] != 'T') --pr;
+          while (pq >= 0 && pa[pq] != 'A' && pa[pq] != 'C' && pa[pq] != 'G' && pa[pq] != 'T') --pq;
+          if (pr < 0 || pq < 0) { OVF(c); S.wk_stop = 2; break; }        // reference: assert(pr >= 0)
+          if (nts >= LC_MAXTS) { OVF(c); S.wk_stop = 2; break; }
+          if (nts >= LC_TS_LDS) { S.wk_stop = 3; break; }                 // more transcripts than LDS holds: the one-lane form, from the start
+          auto &t = ts[nts++];
+          t.pos = rrpos; t.ref_pos = pos_in_ref; t.start_pos = (uint32_t)(P + 1); t.code = code; t.end_pos = (uint32_t)P; t.ref_end_pos = pos_in_ref;
+          t.col0 = i; t.col1 = i; t.somatic = within_tumor; t.prev_bp_ref = (char)ra[pr]; t.prev_bp_alt = (char)pa[pq];
+          for (int q = 0; q < 4; ++q) { acc_init(t.aN[q], cn4[q]); acc_init(t.aT[q], ct4[q]); }
+          for (int q = 0; q < 2; ++q) { acc_init(t.rN[q], rn2[q]); acc_init(t.rT[q], rt2[q]); }
+          HPc z; for (int j = 0; j < 3; ++j) { z.nh[j] = z.th[j] = z.nq[j] = z.tq[j] = 0; }
+          ts_hp_init(t, z, z);
+        }
+      }
+      S.wk_nts = nts; S.wk_last = last_col; S.wk_code = (int)code;
+    }
+    if (wg_bcast(&S.wk_stop)) break;
+  }
+  if (wg_bcast(&S.wk_stop) == 2) return;                                  // work-space limit / undefined read: the window is given up
+  if (wg_bcast(&S.wk_stop) == 3) { WG_LANE0 { process_path_walk(c, np, plen, L, complete); } return; }
+  WG_LANE0 { evt(c, EV_PATH, (uint32_t)complete, (uint32_t)S.tmp3, (uint32_t)S.wk[0], (uint32_t)S.wk[1], (uint32_t)S.wk[2], (uint32_t)S.wk[3]); }
+  // ---- the transcripts: K + 1 positions past the end of every indel / complex one, then the record
+  const int nts = wg_bcast(&S.wk_nts);
+  SUBPHASE(c, 4, 5);
+  for (int ti = 0; ti < nts; ++ti) {
+    WG_LANE0 { const auto &t = ts[ti]; S.wk_code = (int)t.code; S.wk_tend = (int)t.end_pos; S.wk_tref = (int)t.ref_end_pos; S.wk_stop = 0; }
+    if ((char)wg_bcast(&S.wk_code) != 'x') {
+      const int tend = wg_bcast(&S.wk_tend), tref = wg_bcast(&S.wk_tref);
+      for (int j0 = 0; j0 <= K; j0 += 64) {
+        WG_FOR(l, LANCET_WG) {
+          const int j = j0 + l;
+          if (j <= K) {
+            const unsigned idx1 = (unsigned)tend + (unsigned)j;
+            // (idx1 >= plen: the path contributes nothing at this position, the reference still does)
+            // contig_at(idx1) and coverage[idx1]: the node search is made for idx1 itself here (not idx1 + 1 as in the column walk)
+            walk_gather(c, recs + 10 * l, (int)idx1, idx1 < (unsigned)plen ? (int)idx1 : -1, (uint32_t)tref + (uint32_t)trim5 + (uint32_t)j, plen, np, pend, (uint32_t)j, idx1 < (unsigned)plen ? 1u : 0u, 0u);
+          }
+        }
+        WG_SYNC();
+        WG_LANE0 {
+          auto &t = ts[ti];
+          const int cnt = K + 1 - j0 < 64 ? K + 1 - j0 : 64;
+          for (int l = 0; l < cnt; ++l) {
+            volatile LC_LDS uint32_t *rc = recs + 10 * l;
+            if (rc[8]) {                                                   // idx1 < plen
+              if (rc[9] & 2u) { S.wk_stop = 1; break; }                    // contig_at == NIL: the reference leaves the loop over j
+              if (rc[9] & 1u) t.somatic = true;
+              uint16_t cn4[4] = {(uint16_t)rc[0], (uint16_t)(rc[0] >> 16), (uint16_t)rc[1], (uint16_t)(rc[1] >> 16)};
+              uint16_t ct4[4] = {(uint16_t)rc[2], (uint16_t)(rc[2] >> 16), (uint16_t)rc[3], (uint16_t)(rc[3] >> 16)};
+              ts_add_alt(t, cn4, ct4);
+            }
+            uint16_t rn2[2] = {(uint16_t)rc[4], (uint16_t)(rc[4] >> 16)}, rt2[2] = {(uint16_t)rc[5], (uint16_t)(rc[5] >> 16)};
+            ts_add_ref(t, rn2, rt2);
+          }
+        }
+        if (wg_bcast(&S.wk_stop)) break;
+      }
+    }
+    SUBPHASE(c, 4, 6);
+    WG_LANE0 {
+      auto &t = ts[ti];
+      const bool x = t.code == 'x';
+      uint16_t RCNF = t.rN[0].mn, RCNR = t.rN[1].mn, RCTF = t.rT[0].mn, RCTR = t.rT[1].mn;
+      uint16_t ACNF = x ? t.aN[2].mn : t.aN[0].mn, ACNR = x ? t.aN[3].mn : t.aN[1].mn;
+      if (!x) { ACNF = t.aN[0].mnz; ACNR = t.aN[1].mnz; }     // getMinNon0Cov*: code != 'x' -> .fwd/.rev
+      uint16_t ACTF = x ? t.aT[2].mn : t.aT[0].mn, ACTR = x ? t.aT[3].mn : t.aT[1].mn;
+      if (t.somatic) { RCNF = acc_mean(t.rN[0]); RCNR = acc_mean(t.rN[1]); RCTF = acc_mean(t.rT[0]); RCTR = acc_mean(t.rT[1]); ACNF = 0; ACNR = 0; }
+      uint16_t cov[8] = {RCNF, RCNR, RCTF, RCTR, ACNF, ACNR, ACTF, ACTR};
+      uint16_t hp12[12]; for (int q = 0; q < 12; ++q) hp12[q] = 0;
+      if (LC_CTX(c).C->evt_cap) {
+        evt(c, EV_TS, t.pos, (uint32_t)(t.col1 - t.col0 + 1), ((uint32_t)RCNF << 16) | RCNR, ((uint32_t)RCTF << 16) | RCTR,
+            ((uint32_t)ACNF << 16) | ACNR, ((uint32_t)ACTF << 16) | ACTR, ((uint32_t)(uint8_t)t.prev_bp_ref << 8) | (uint8_t)t.prev_bp_alt);
+        evt_bytes(c, ra + t.col0, (uint32_t)(t.col1 - t.col0 + 1));
+        evt_bytes(c, pa + t.col0, (uint32_t)(t.col1 - t.col0 + 1));
+        evt_bytes(c, (const uint8_t *)hp12, 24);
+      }
+      if (ACNF > 0 || ACNR > 0 || ACTF > 0 || ACTR > 0) {
+        int LEN = 0, ml = 0; uint8_t motif[64];
+        bool ans = find_tandems_local(c, W.pseq, plen, (int)t.start_pos, &LEN, motif, &ml);
+        TS tc; tc.pos = t.pos; tc.ref_pos = t.ref_pos; tc.start_pos = t.start_pos; tc.end_pos = t.end_pos; tc.ref_end_pos = t.ref_end_pos; tc.col0 = t.col0; tc.col1 = t.col1;
+        tc.code = t.code; tc.prev_bp_ref = t.prev_bp_ref; tc.prev_bp_alt = t.prev_bp_alt; tc.somatic = t.somatic;      // (what emit_variant reads; short reads: no haplotype fields)
+        emit_variant(c, tc, cov, LEN, motif, ml, ans, ra, pa, hp12, plen);
+      }
+    }
+    SUBPHASE(c, 4, 5);
+  }
+  SUBPHASE(c, 4, 7);
+  WG_LANE0 { evt(c, EV_PATH_END); }
+  WG_FOR(i, np) { dev_atomic_add(&W.gr[W.pnodes[i]].onref, 1u); }
+  // counters of eka (perfect / withsnps / withindel / withmix) ride in tmp0..tmp2 + part[0]
+  WG_LANE0 { const int snp_bp = S.wk[1], ins_bp = S.wk[2], del_bp = S.wk[3]; if ((snp_bp + ins_bp + del_bp) == 0) ++S.tmp0; else if (snp_bp == 0) ++S.tmp1; else if ((ins_bp + del_bp) == 0) ++S.tmp2; else ++S.part[0]; }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // per-component driver pieces that need the whole workgroup (alignment, repeat scan of a path)
 // ---------------------------------------------------------------------------------------------------------
@@ -4053,13 +4333,16 @@ DEVNI bool repeats_in_graph_paths(Ctx &c) {
     S.pc_ok = 1; S.pc_n = 0; S.pc_top = 0; S.pc_end_dfs = 0;
   }
   while (wg_bcast(&S.tmp0) == 0) {
+    SUBPHASE(c, 3, 2);
     WG_LANE0 {
       uint32_t best = bfs(c);
       if (best == LC_NIL || S.overflow) { S.tmp0 = 1; S.pc_end_dfs = S.bfs_dfs; }
       else { S.tmp2 = path_unpack(c, best); S.pc_bits = (W.queue[best].bits & 2) ? 1 : 0; S.pc_dfs = S.bfs_dfs; }
     }
     if (wg_bcast(&S.tmp0) != 0) break;
+    SUBPHASE(c, 3, 3);
     { const int pl = path_string_wg(c, wg_bcast(&S.tmp2)); WG_LANE0 { S.tmp3 = pl; if (S.overflow) S.tmp0 = 1; } }
+    SUBPHASE(c, 3, 4);
     if (wg_bcast(&S.tmp0) != 0) break;
     {
       // isAlmostRepeat(path->str(), K, MAX_MISMATCH): only M >= K + 1 is asked.  A path that spells the reference between the anchors
@@ -4073,6 +4356,7 @@ DEVNI bool repeats_in_graph_paths(Ctx &c) {
       if (wg_bcast(&S.ps_hd)) repeat_scan_min(S.rs, W.pseq, pl, LC_CTX(c).P->max_mismatch, 0x7FFF, wg_uniform(S.K) + 1, &S.repE, &S.repM, nullptr, &S.rs_bad);
       else { WG_LANE0 { S.repE = 0; S.repM = 0; } }
     }
+    SUBPHASE(c, 3, 5);
     WG_LANE0 {
       // NB isAlmostRepeat only looks at windows that end before the last base: handled inside repeat_scan
       if (S.tmp3 - S.K > 0 && S.repM >= S.K + 1) { evt(c, EV_NEAR_QRY, S.K); S.tmp0 = 2; }
@@ -4081,8 +4365,10 @@ DEVNI bool repeats_in_graph_paths(Ctx &c) {
         for (int j = 1; j < S.tmp2; ++j) { if ((uint32_t)S.tmp1 < LC_CTX(c).C->node_cap) W.scratch[S.tmp1++] = W.pedges[j]; else { OVF(c); S.tmp0 = 1; } }
       }
     }
+    SUBPHASE(c, 3, 6);
     if (wg_bcast(&S.tmp0) == 0 && wg_bcast(&S.pc_ok)) pcache_store(c);
   }
+  SUBPHASE(c, 3, 10);
   WG_LANE0 {
     for (int j = 0; j < S.tmp1; ++j) { uint32_t owner = W.scratch[j] >> 4, ei = W.scratch[j] & 15u; W.gr[owner].edges[ei] &= ~(1u << 30); }
     if (S.tmp0 != 1 || S.overflow) S.pc_ok = 0;          // (only a search that ran to its natural end is replayed by eka)
@@ -4156,12 +4442,16 @@ DEVNI void count_ref_path(Ctx &c) {
         align_traceback_fill(c, rs, W.pseq, (int)wg_bcastu(&S.part[7]));
       }
       PHASE(c, 14);
+      SUBPHASE(c, 4, 2);
       walk_prepare(c, (int)wg_bcastu(&S.part[7]));
+      SUBPHASE(c, 4, 14);
+      if (wg_uniform(S.LR)) {
+        WG_LANE0 { if (!S.overflow) process_path_walk(c, (int)S.part[4], (int)S.part[5], (int)S.part[7], (int)S.part[1]); }
+      } else if (!wg_bcast(&S.overflow)) {
+        process_path_walk_wg(c, (int)wg_bcastu(&S.part[4]), (int)wg_bcastu(&S.part[5]), (int)wg_bcastu(&S.part[7]), (int)wg_bcastu(&S.part[1]));
+      }
       WG_LANE0 {
-        if (!S.overflow) {
-          process_path_walk(c, (int)S.part[4], (int)S.part[5], (int)S.part[7], (int)S.part[1]);
-          path_flag_edges(c, (int)S.part[4], 1u);
-        }
+        if (!S.overflow) path_flag_edges(c, (int)S.part[4], 1u);
         if (S.overflow) S.part[3] = 1;
       }
       PHASE(c, 11);
@@ -4233,11 +4523,12 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
       for (int u = 0; u < 4; ++u) { const int i = i0 + u * LANCET_WG; if (i < total) ((LC_GLOBAL lc_v4 *)&W.gr[dn[u]])[(uint32_t)i & 7u] = v[u]; }
     }
   }
-  WG_FOR(t, ncand * (uint32_t)K) {
-    const uint32_t ci = (uint32_t)t / (uint32_t)K; const int i = (int)((uint32_t)t % (uint32_t)K);
-    const uint32_t n = snode[ci];
-    if (n != LC_NIL) { const unsigned long long kk = skey[ci]; W.seq[t] = SD_MAKE(n, i, key_base(&kk, K, i)); }
-  }
+  // The survivors' sequence descriptors (K words each: 32 KB per window) are NOT written here: almost every k-mer node is merged
+  // into a unitig by the first compress, which needs only the first and the last descriptor of a node -- both follow from its
+  // key.  compress_prepare / compress_rank derive what they need (seq_desc_lazy) and write out the K descriptors of the few
+  // nodes that stay on their own; any other route into the graph phases calls seq_materialize_all first.
+  WG_LANE0 { S.seq_lazy = 1; S.lz_area = (unsigned long long)(uintptr_t)area; }
+  (void)snode; (void)skey;
   const int nrefk = S.reflen - K > 0 ? S.reflen - K + 1 : 0;
   WG_FOR(i, nrefk) { const uint32_t e = occ_ref[i]; W.occ[i] = (e & PB_GONE) ? (dummy | (e & 0x80000000u)) : e; }
   WG_FOR(i, S.reflen * 2) { ((LC_GLOBAL uint32_t *)W.refcov)[i] = ((LC_GLOBAL const uint32_t *)(area + PRE_OFF_REFCOV))[i]; }
@@ -4386,7 +4677,7 @@ DEV void process_window(Ctx &c, int w, int rq = -1) {
     if (reflen - k > 0 && refM >= k + 1) { WG_LANE0 { evt(c, EV_NEAR_REF, k); } rptInRef = 1; continue; }
     WG_LANE0 { S.K = k; S.NW = (2 * k + 63) / 64; S.final_k = k; S.source = LC_NIL; S.sink = LC_NIL; if (k > 127 || S.NW > LC_NWMAX) S.overflow = 1; }
     if (wg_bcast(&S.overflow)) break;
-    WG_LANE0 { S.prebuilt = 0; S.pre_order = 0; }
+    WG_LANE0 { S.prebuilt = 0; S.pre_order = 0; S.seq_lazy = 0; if (LC_CTX(c).OUT->svc) dev_atomic_add(&LC_CTX(c).OUT->svc->beat, 1u); }
     if (!load_prebuilt(c, k)) {
       if (try_suspend(c, k)) return;
       build_graph(c);
@@ -4448,13 +4739,17 @@ DEV void process_window(Ctx &c, int w, int rq = -1) {
     STOP_SET(c, 8);
     if (wg_bcast(&S.overflow)) break;
     for (int comp = 1; comp <= numcomp; ++comp) {
+      SUBPHASE(c, 2, 2);
       mark_ref_scan(c, comp);
       WG_LANE0 { print_stats(c, comp); }
+      SUBPHASE(c, 2, 3);
       mark_ref_ends(c, comp);
+      SUBPHASE(c, 2, 9);
       if (wg_bcast(&S.overflow)) break;
       PHASE(c, 15);
       compress_prepare(c, comp);
       const bool ranked = wg_bcast(&S.cmp_ok) && compress_rank(c, comp);     // (whole wave; false: a ring or an irregular link, nothing touched)
+      if (!ranked) seq_materialize_all(c);
       if (!ranked) WG_LANE0 {
         // The reference runs hasCycle on the k-mer graph and compresses only if there is none.  Unitig compaction merges
         // nodes across links that are the only edge on both sides, which neither creates nor removes a walk that comes
@@ -4463,10 +4758,12 @@ DEV void process_window(Ctx &c, int w, int rq = -1) {
         // of the compaction are held back until the cycle check has passed.
         S.tmp1 = (int)(S.cmp_ok ? compress_fast(c, comp, true) : compress(c, comp, true));
       }
+      SUBPHASE(c, 1, 15);
       if (wg_bcast(&S.tmp2)) compact_absorbed_wg(c);
       WG_LANE0 {
         const uint32_t dead = (uint32_t)S.tmp1;
         PHASE(c, 9);
+        SUBPHASE(c, 2, 4);
         S.tmp0 = 0;
         if (!S.overflow && has_cycle(c)) S.tmp0 = 1;
         if (!S.tmp0 && !S.overflow) {
@@ -4476,10 +4773,15 @@ DEV void process_window(Ctx &c, int w, int rq = -1) {
         S.tmp3 = (!S.tmp0 && !S.overflow) ? 1 : 0;
       }
       if (wg_bcast(&S.tmp3)) {
+        SUBPHASE(c, 2, 5);
         remove_low_cov_wg(c, comp);
+        SUBPHASE(c, 2, 6);
         if (!wg_bcast(&S.overflow)) remove_tips_wg(c, comp);
+        SUBPHASE(c, 2, 7);
         if (!wg_bcast(&S.overflow)) remove_short_links_wg(c, comp);
+        SUBPHASE(c, 2, 4);
         WG_LANE0 { if (!S.overflow && has_cycle(c)) S.tmp0 = 1; }
+        SUBPHASE(c, 2, 9);
       }
       if (wg_bcast(&S.overflow)) break;
       if (wg_bcast(&S.tmp0)) { cycleInGraph = 1; brk = true; break; }
@@ -4517,7 +4819,8 @@ DEV int window_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       if (sv) {
         const uint32_t h = ld2(&sv->rdy_head);
         if (h < sv->cap) {
-          const uint32_t v = ld_acq(&sv->rdy[h]);
+          uint32_t v = ld2(&sv->rdy[h]);
+          if (v != 0u) v = ld_acq(&sv->rdy[h]);                  // (the acquire -- an L1 / L2 invalidate -- only when there is something to take)
           if (v != 0u && dev_atomic_cas32(&sv->rdy_head, h, h + 1u) == h) { a = 1; g = (int)(v - 1u); got = true; dev_atomic_add(&sv->n_resumed, 1u); }
         }
       }
@@ -4550,6 +4853,7 @@ DEV int window_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
 #endif
     }
     idle = 0;
+    WG_LANE0 { if (sv) dev_atomic_add(&sv->beat, 1u); }
     int w = arg, rq = -1;
     if (act == 0) {
       if (OUT->win_list) w = (int)OUT->win_list[w];

@@ -269,8 +269,9 @@ struct SvcCtl {
   uint32_t done;          /* set after the window kernel: the service workgroups leave        */
   uint32_t n_built, n_stolen, n_failed;
   uint32_t cap;
-  uint32_t steal_cursor;
-  uint32_t pad[4];
+  uint32_t beat;          /* bumped by the window slots at every window / k attempt: the service's sign that somebody else runs */
+  uint32_t n_gaveup;      /* service workgroups that left because nothing else made progress (kernels serialised by a profiler)  */
+  uint32_t pad[3];
   LC_GLOBAL SvcReq *req;          /* [cap] */
   LC_GLOBAL uint32_t *rdy;        /* [cap] request index + 1 */
   LC_GLOBAL SvcCont *cont;        /* [cap] */

@@ -72,7 +72,7 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
     std::vector<uint32_t> biglist((size_t)b->n_windows + 1, 0);
     const bool large = getenv("LANCET_NO_LARGE_BUILD") == nullptr;
     depth = getenv("LANCET_AHEAD_DEPTH") ? atoi(getenv("LANCET_AHEAD_DEPTH")) : 6;
-    pool_cap = (uint32_t)(b->n_windows / 4 + (depth > 0 ? 8 : 0) + (getenv("LANCET_NO_SVC") ? 0 : 24));
+    pool_cap = (uint32_t)(b->n_windows / 4 + (depth > 0 ? 8 : 0) + (getenv("LANCET_NO_SVC") ? 0 : (b->n_windows < 128 ? 4 * b->n_windows + 24 : 536)));
     if (pool_cap) pool.assign((size_t)pool_cap * PRE_STRIDE, 0xCD);
     if (getenv("LANCET_EMU_FORCE_LARGE")) {                     // (test hook: every window through the 1024-lane configuration)
       for (int w = 0; w < b->n_windows; ++w) { biglist[(size_t)w] = (uint32_t)w; PreHdr *H = (PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); H->status = PB_NOT_BUILT; H->why = 0; H->have_rep = 0; H->heavy = 0; H->next = 0; }

@@ -287,9 +287,10 @@ def _same_as_oracle(batch, p, trace=True):
 def test_lds_build_kernel_and_graphs_built_ahead_on_the_bench_workload(monkeypatch):
     """The two-kernel path on the kind of windows bench.py measures (30x/30x scan): every window's first graph comes from the
     LDS build kernel, the windows whose k is going to be rejected get the next graphs built ahead and the window kernel takes
-    them; records, stats and the stage trace equal the oracle's.  Then the same windows with nothing built ahead
-    (LANCET_AHEAD_DEPTH=0) and with no LDS build at all (LANCET_NO_PREBUILD): same results -- what is built where is
-    scheduling only."""
+    them; a window whose next graph nobody built ahead is suspended and gets it from the build service.  Records, stats and the
+    stage trace equal the oracle's.  Then the same windows with nothing built ahead (LANCET_AHEAD_DEPTH=0: every later graph on
+    request), with a service nobody runs (the slots take their requests back: general build), without the service, and with no
+    LDS build at all (LANCET_NO_PREBUILD): same results -- what is built where is scheduling only."""
     from lancet_amd import workload
     b = workload.make_scan_batch(400, 30, 30, seed=5)
     p = abi.default_params()
@@ -302,13 +303,22 @@ def test_lds_build_kernel_and_graphs_built_ahead_on_the_bench_workload(monkeypat
     wide = emu.run(b, p, evt_cap=1 << 17)
     monkeypatch.delenv("LANCET_STOP_PHASE")
     assert wide[0] == base[0] and wide[1] == base[1] and gu.digest_trace(wide[2]) == gu.digest_trace(base[2])
+    assert emu.LAST_SVC[0] >= 1 and emu.LAST_SVC[1] == emu.LAST_SVC[0] and emu.LAST_SVC[2] == 0, emu.LAST_SVC
     monkeypatch.setenv("LANCET_AHEAD_DEPTH", "0")
+    monkeypatch.setenv("LANCET_SVC_DEPTH", "0")
+    on_request = emu.run(b, p, evt_cap=1 << 17)
+    assert emu.LAST_SVC[0] == extra and emu.LAST_SVC[1] == extra and emu.LAST_AHEAD == [0, extra], (extra, emu.LAST_SVC, emu.LAST_AHEAD)
+    monkeypatch.setenv("LANCET_SVC_DEAD", "1")
+    taken_back = emu.run(b, p, evt_cap=1 << 17)
+    assert emu.LAST_SVC[0] == extra and emu.LAST_SVC[1] == 0 and emu.LAST_SVC[2] == extra, (extra, emu.LAST_SVC)
+    monkeypatch.delenv("LANCET_SVC_DEAD")
+    monkeypatch.setenv("LANCET_NO_SVC", "1")
     plain = emu.run(b, p, evt_cap=1 << 17)
-    assert emu.LAST_AHEAD == [0, 0] and emu.LAST_PREBUILT[0] == 400
+    assert emu.LAST_AHEAD == [0, 0] and emu.LAST_SVC == [0, 0, 0] and emu.LAST_PREBUILT[0] == 400
     monkeypatch.setenv("LANCET_NO_PREBUILD", "1")
     general = emu.run(b, p, evt_cap=1 << 17)
     assert emu.LAST_PREBUILT[0] == 0
-    for other in (plain, general):
+    for other in (on_request, taken_back, plain, general):
         assert other[0] == base[0] and other[1] == base[1] and gu.digest_trace(other[2]) == gu.digest_trace(base[2])
 
 
