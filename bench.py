@@ -46,11 +46,10 @@ def cpu_model() -> str:
 
 def cpu_baseline(batch, params, variants, n1: int, nall: int):
     """The oracle (CPU restatement of the reference path, oracle/liblancet_oracle.so) on a bounded sample of the same
-    windows: one thread, then one thread per host core over chunks of windows (windows are independent, as the
-    reference's own --num-threads fan-out, src/Lancet.cc:910-928)."""
-    from concurrent.futures import ThreadPoolExecutor
+    windows: one thread, then one worker PROCESS per hardware thread over chunks of windows (windows are independent, as
+    the reference's own --num-threads fan-out, src/Lancet.cc:910-928; processes, not threads of one process: oracle/cpu_fanout.py)."""
     from lancet_amd import workload
-    from oracle import oracle
+    from oracle import cpu_fanout, oracle
     oracle.lib()
     n1 = min(n1, batch.n_windows)
     sample = workload.sub_batch(batch, 0, n1)
@@ -58,45 +57,54 @@ def cpu_baseline(batch, params, variants, n1: int, nall: int):
     ov, ostats, _ = oracle.run(sample, params)
     dt1 = time.perf_counter() - t
     same = ov == [v for v in variants if v["window"] < n1]
-    cores = os.cpu_count() or 1
+    threads = os.cpu_count() or 1
+    phys = cpu_fanout.physical_cores()
     nall = min(nall, batch.n_windows)
-    per = max(8, nall // (cores * 4))
-    chunks = [workload.sub_batch(batch, a, min(nall, a + per)) for a in range(0, nall, per)]
-    t = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=cores) as ex:            # ctypes releases the GIL inside the library call
-        res = list(ex.map(lambda b: oracle.run(b, params)[1], chunks))
-    dta = time.perf_counter() - t
+    per = max(4, nall // (threads * 6))
+    dta, kma, done = cpu_fanout.run(batch, {}, nall, threads, per)
     km1 = sum(s["n_kmers"] for s in ostats)
-    kma = sum(s["n_kmers"] for r in res for s in r)
-    return {"value": round(nall / dta, 2), "unit": "windows/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-            "sample": f"oracle/liblancet_oracle.so on the first {nall} windows of the same batch, {cores} threads over chunks of {per} windows, {dta:.1f} s",
+    return {"value": round(done / dta, 2), "unit": "windows/s", "cores": threads, "physical_cores": phys, "hardware_threads": threads,
+            "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"oracle/liblancet_oracle.so on the first {nall} windows of the same batch, {threads} worker processes (one per hardware thread; {phys} physical cores) over chunks of {per} windows, {dta:.1f} s",
             "mkmers_per_s": round(kma / dta / 1e6, 3),
             "one_thread": {"value": round(n1 / dt1, 2), "mkmers_per_s": round(km1 / dt1 / 1e6, 3),
                            "sample": f"first {n1} windows, 1 thread, {dt1:.1f} s"},
+            "scaling_over_one_thread": round((done / dta) / (n1 / dt1), 1),
             "gpu_results_identical_on_sample": bool(same),
             "note": "the reference binary cannot travel to this box; in the authoring container it runs the golden cases at 13-23 windows/s/thread, this port at ~45 (DESIGN.md §7)"}
 
 
 def side_config(eng_cls, params, name, windows, cov_t, cov_n, steps, **kw):
-    """One more BASELINE.md configuration on this GPU (smaller batch, reported beside the headline)."""
+    """One more BASELINE.md configuration on this GPU (smaller batch, reported beside the headline), with its own roofline:
+    algorithmic bytes of the batch / HIP-event durations of its kernels."""
     import numpy as np
     from lancet_amd import workload
     b = workload.make_scan_batch(windows, cov_t, cov_n, seed=22, **kw)
     eng = eng_cls(params, device=0)
     eng.upload(b)
     eng.run()
+    kms = []
     t = time.perf_counter()
     for _ in range(steps):
         eng.run()
+        kms.append(eng.kernel_times())
     dt = (time.perf_counter() - t) / steps
-    _, stats = eng.results()
+    variants, stats = eng.results()
     ks, cnt = np.unique([s["final_k"] for s in stats if s["status"] == 0], return_counts=True)
-    out = {"name": name, "windows": windows, "coverage": [cov_t, cov_n], "windows_per_s": round(windows / dt, 1),
+    names = eng.kernel_names()
+    per_kernel = {nm: round(float(np.mean([k[i] for k in kms])), 3) for i, nm in enumerate(names)}
+    ms_all = float(sum(per_kernel.values()))
+    alg = workload.algorithmic_bytes(b, stats, len(variants))
+    out = {"name": name, "windows": windows, "steps": steps, "coverage": [cov_t, cov_n], "windows_per_s": round(windows / dt, 1),
            "mkmers_per_s": round(sum(s["n_kmers"] for s in stats) / dt / 1e6, 1), "reads_per_window": round(b.n_reads / windows, 1),
            "builds_per_window": round(sum(s["n_builds"] for s in stats) / windows, 3),
            "final_k_histogram": {int(k): int(c) for k, c in zip(ks, cnt)},
            "k_exhausted": sum(1 for s in stats if s["status"] == 2), "overflowed": sum(1 for s in stats if s["status"] < 0),
-           "windows_first_graph_in_lds": eng.prebuilt_count(), "windows_rerun_worst_case_tier": eng.rerun_count()}
+           "windows_first_graph_in_lds": eng.prebuilt_count(), "windows_rerun_worst_case_tier": eng.rerun_count(),
+           "build_service": dict(zip(("posted", "served", "not_buildable", "taken_back"), eng.svc_counts())),
+           "roofline": {"bound": "hbm", "achieved": round(alg / (ms_all * 1e-3) / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(alg / (ms_all * 1e-3) / 1e9 / 8000.0, 6), "algorithmic_bytes_per_launch": int(alg),
+                        "kernel_ms": round(ms_all, 3), "per_kernel_ms": per_kernel}}
     eng.close()
     return out
 
@@ -112,6 +120,8 @@ def main():
     ap.add_argument("--cpu-sample-all", type=int, default=16384, help="windows timed on all host cores")
     ap.add_argument("--no-configs", action="store_true", help="skip the side configurations (60x/60x, 100x/40x STR)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight per GPU (engines submitted in turn); 1 = every step alone on the GPU")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank assembles its own contig of --windows windows; strong: ONE contig of --windows windows dealt out over the ranks in chunks (dist.shard_windows)")
     args = ap.parse_args()
     maybe_spawn(sys.argv[1:], args.gpus)
 
@@ -141,8 +151,22 @@ def main():
     torch.cuda.set_device(device)
     comm_device = torch.device("cpu") if one_gpu else device
 
-    chrom = f"chr{22 + rank}" if rank else "chr22"           # one synthetic contig per rank
-    batch = workload.make_scan_batch(args.windows, args.cov, args.cov, seed=22 + 1000 * rank, chrom=chrom)
+    rccl_ranks = dist.get_world_size() if world > 1 else 1     # what the process group reports, not what was asked for
+    strong = args.scaling == "strong" and world > 1
+    if strong:
+        # one contig, its windows dealt out in chunks of 1024 (dist.shard_windows): every rank holds interleaved runs of windows, so the
+        # records reach rank 0 out of window order and the replay has to restore it
+        chrom = "chr22"
+        full = workload.make_scan_batch(args.windows, args.cov, args.cov, seed=22, chrom=chrom)
+        mine = np.array(ldist.shard_windows(args.windows, rank, world, chunk=1024), dtype=np.int64)
+        runs = np.split(mine, np.where(np.diff(mine) != 1)[0] + 1) if len(mine) else []
+        batch = workload.concat_batches([workload.sub_batch(full, int(r[0]), int(r[-1]) + 1) for r in runs])
+        windex = mine
+    else:
+        chrom = f"chr{22 + rank}" if rank else "chr22"           # one synthetic contig per rank
+        batch = workload.make_scan_batch(args.windows, args.cov, args.cov, seed=22 + 1000 * rank, chrom=chrom)
+        windex = rank * args.windows + np.arange(args.windows, dtype=np.int64)
+    n_local = batch.n_windows
     params = abi.default_params()
     # `--in-flight 2` (default): two engines on the GPU, each with the batch resident, submitted in turn -- the kernels of step
     # i+1 are queued while step i drains, so the tail of a batch (a few windows that need several k attempts) overlaps the bulk of
@@ -156,14 +180,16 @@ def main():
     for e2 in engs[1:]:
         e2.upload(batch)
     n_slots, slot_bytes = eng.geometry()
-    windex = rank * args.windows + np.arange(args.windows, dtype=np.int64)
     last = {}
+    tm = {"gather": 0.0, "replay": 0.0, "steps": 0}
 
     def complete(e):
         e.wait()
         if world > 1:
             vp, n, blob, _ = e.raw_results()
+            tg = time.perf_counter()
             parts = ldist.gather_bytes(ldist.pack_records(vp, n, blob, chr_names=[chrom], window_index=windex), comm_device)
+            tm["gather"] += time.perf_counter() - tg; tm["steps"] += 1
             if rank == 0:
                 merge_q.put(parts)
 
@@ -178,7 +204,9 @@ def main():
                 if parts is None:
                     return
                 db = engine.VariantDB()
+                tr = time.perf_counter()
                 last["n"] = ldist.merge_into_vdb(parts, db)
+                tm["replay"] += time.perf_counter() - tr
                 last["db"] = db
             except BaseException as ex:          # surfaced by run_steps
                 last["error"] = ex
@@ -209,6 +237,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    tm["gather"] = tm["replay"] = 0.0; tm["steps"] = 0
     t0 = time.perf_counter()
     run_steps(args.steps)
     if world > 1:
@@ -219,6 +248,10 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        g = torch.tensor([1000.0 * tm["gather"] / max(1, tm["steps"])], dtype=torch.float64, device=comm_device)
+        gl = [torch.zeros(1, dtype=torch.float64, device=comm_device) for _ in range(world)]
+        dist.all_gather(gl, g)
+        gather_ms = [round(float(x.item()), 3) for x in gl]
     # kernel durations for the roofline: launches that have the GPU to themselves (with two batches in flight the HIP events of a
     # kernel also cover the time it shares the device with the other batch's kernels)
     kernel_ms = []
@@ -267,22 +300,23 @@ def main():
             h.update(repr((v["window"], v["seq"], v["pos"], v["code"], v["ref"], v["alt"], v["cov"], v["kmer"], v["str"])).encode())
         out = {
             "metric": "assembled windows/sec (whole node), 600bp windows, self-tuning k, synthetic T/N",
-            "value": round(world * args.windows * args.steps / dt, 2),
+            "value": round((args.windows if strong else world * args.windows) * args.steps / dt, 2),
             "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "mkmers_per_s": round(n_kmers_all * args.steps / dt / 1e6, 2),
             "overflowed_windows": n_bad_all,
-            "value_e2e": round(args.windows / e2e_s, 2),
+            "value_e2e": round(n_local / e2e_s, 2),
             "value_e2e_note": f"PCIe-inclusive, per GPU: host buffers -> upload + trim/pack ({up_ms:.0f} ms per batch) + kernels, {nfl} batch(es) in flight; never `value`",
             "config": {"workload": f"chr22-scan proxy: {args.windows} windows/GPU x 600 bp, stride 100, "
                                    f"{args.cov:g}x tumor / {args.cov:g}x normal, 2x150 bp, k=11..101, active-region-off",
                        "windows_per_gpu": args.windows, "coverage": [args.cov, args.cov], "reads_per_gpu": int(batch.n_reads),
                        "records_rank0_contig": len(variants), "records_sha256_rank0_contig": h.hexdigest()[:16],
                        "slots_in_flight": n_slots, "batches_in_flight": nfl, "upload_first_ms": round(upload_first_ms, 1), "upload_ms": round(up_ms, 1),
-                       "windows_first_graph_in_lds": eng.prebuilt_count(), "graphs_built_ahead": eng.ahead_counts()[0], "graphs_built_ahead_used": eng.ahead_counts()[1],
+                       "windows_first_graph_in_lds": eng.prebuilt_count(), "graphs_built_ahead": eng.ahead_counts()[0], "graphs_taken_from_pool": eng.ahead_counts()[1],
+                       "build_service": dict(zip(("posted", "served", "not_buildable", "taken_back"), eng.svc_counts())),
                        "windows_rerun_worst_case_tier": eng.rerun_count(), "workspace_MB_per_slot": round(slot_bytes / 2 ** 20, 1),
                        "kernel_ms": per_kernel},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
@@ -297,6 +331,11 @@ def main():
             out["config"]["merged_records_vdb"] = last.get("n", 0)
             out["config"]["vdb_variants"] = last["db"].size() if "db" in last else 0
             out["config"]["gather"] = "sizes all_gather + send/recv to rank 0 (RCCL), replay in window order into lancet_vdb inside the step (second host thread on rank 0)"
+            out["rccl_ranks"] = rccl_ranks                     # dist.get_world_size() after init_process_group("nccl")
+            out["comm_backend"] = dist.get_backend()
+            out["gather_ms_per_step_by_rank"] = gather_ms      # sizes all_gather + payload send / recv, as each rank saw it
+            out["replay_ms_per_step_rank0"] = round(1000.0 * tm["replay"] / max(1, args.steps), 3)
+            out["windows_per_rank"] = n_local
             if one_gpu:
                 out["config"]["comm"] = "LANCET_BENCH_ONE_GPU=1: all ranks on device 0, gather over gloo -- a check of the N-rank path, not a measurement"
         # HBM-side bytes per launch from the committed PMC passes (tools/pmc_total.sh -> profiles/r2_traffic.json):
@@ -316,8 +355,8 @@ def main():
             e2.close()
         if world == 1 and not args.no_configs:
             out["configs"] = [
-                side_config(engine.Engine, params, "config 2 at 60x/60x", 8192, 60.0, 60.0, 2),
-                side_config(engine.Engine, params, "config 4: 100x tumor / 40x normal, 30 % STR + 5 % low complexity", 4096, 100.0, 40.0, 2,
+                side_config(engine.Engine, params, "config 2 at 60x/60x", 8192, 60.0, 60.0, 8),
+                side_config(engine.Engine, params, "config 4: 100x tumor / 40x normal, 30 % STR + 5 % low complexity", 4096, 100.0, 40.0, 8,
                             str_fraction=0.30, lowcomplex_fraction=0.05),
             ]
         print(json.dumps(out))

@@ -43,9 +43,16 @@ enum { BLW_NONE = 0, BLW_NOREADS, BLW_SIZE, BLW_HASN, BLW_K, BLW_TABLE, BLW_NODE
 //   bl_large 1024 lanes, 65 520 bases (16-bit offsets), 1024 reads, ~100 KB of LDS: one workgroup per CU -- windows the small
 //            one turns away for their size (60x/60x: ~360 reads, 58 k bases), taken off the list the small kernel leaves.
 // Same limits on what leaves the workgroup (PB_NCAP nodes, PB_CCAP candidates, PB_SCAP survivors: layout.h).
+#ifndef BL_SMALL_WG
+#define BL_SMALL_WG 512           /* lanes of the small configuration (tuning builds: tools/variant.sh)          */
+#define BL_SMALL_EU 4             /* waves per SIMD it is compiled for: 2 workgroups per CU                      */
+#endif
+#ifndef BL_SMALL_BASES
+#define BL_SMALL_BASES 40960
+#endif
 #define BL_NS bl_small
-#define BL_WG 512
-#define BL_BASES 40960            /* bases in LDS (reads padded to 16, + the reference)                       */
+#define BL_WG BL_SMALL_WG
+#define BL_BASES BL_SMALL_BASES   /* bases in LDS (reads padded to 16, + the reference)                       */
 #define BL_RMAX 512               /* reads per window                                                          */
 #define BL_SLOTS 8192
 #define BL_TCAP 2048              /* tracked nodes                                                             */

@@ -5,10 +5,12 @@
 // There is no CPU path: without a HIP device lancet_engine_create fails with LANCET_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -29,7 +31,7 @@ __global__ void __launch_bounds__(LANCET_WG * 2) __attribute__((amdgpu_waves_per
 }
 
 // The first graph of every window in LDS (build_lds.h): 256 lanes per window, 2 workgroups per CU (80 KB of LDS each)
-__global__ void __launch_bounds__(bl_small::WG) __attribute__((amdgpu_waves_per_eu(4, 4))) build_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue,
+__global__ void __launch_bounds__(bl_small::WG) __attribute__((amdgpu_waves_per_eu(BL_SMALL_EU, BL_SMALL_EU))) build_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue,
                                                       unsigned long long *phase, uint8_t *pool, uint32_t pool_cap, int depth, uint32_t *biglist) {
   bl_small::build_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL uint8_t *)pre, (LC_GLOBAL uint8_t *)scratch,
                     (LC_GLOBAL uint32_t *)queue, *(bl_small::BL_S *)&bl_small::bl_shared, (int)blockIdx.x, (LC_GLOBAL unsigned long long *)phase, (LC_GLOBAL uint8_t *)pool, pool_cap, depth,
@@ -47,7 +49,7 @@ __global__ void __launch_bounds__(bl_large::WG) __attribute__((amdgpu_waves_per_
 // Build service (build_lds_impl.h svc_kernel_body): a few resident 512-lane workgroups that build, while the window kernel runs, the
 // graphs of later k attempts it asks for.  Launched on its own stream before the batch's kernels, leaves when svc_done_kernel
 // (enqueued behind the window kernel) has set SvcCtl::done.
-__global__ void __launch_bounds__(bl_small::WG) __attribute__((amdgpu_waves_per_eu(4, 4))) svc_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue,
+__global__ void __launch_bounds__(bl_small::WG) __attribute__((amdgpu_waves_per_eu(BL_SMALL_EU, BL_SMALL_EU))) svc_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue,
                                                       uint8_t *pool, uint32_t pool_cap, int depth, SvcCtl *sv, const uint32_t *wqueue) {
   bl_small::svc_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL uint8_t *)pre, (LC_GLOBAL uint8_t *)scratch,
                     (LC_GLOBAL uint32_t *)queue, *(bl_small::BL_S *)&bl_small::bl_shared, (int)blockIdx.x, (LC_GLOBAL uint8_t *)pool, pool_cap, depth, (LC_GLOBAL SvcCtl *)sv,
@@ -188,6 +190,11 @@ struct lancet_engine {
   uint32_t svc_counts[4] = {0, 0, 0, 0};     // posted, built, failed, stolen of the last run
   float ms_build = 0, ms_window = 0;
   bool uploaded = false, ran = false, submitted = false;
+  // upload: reads are trimmed and packed by host threads into a pinned staging buffer that mirrors one device buffer (one DMA);
+  // LANCET_PREP=device keeps the round-2 path (ASCII bases + qualities to the device, prep_kernel there)
+  void *h_stage = nullptr; size_t h_stage_cap = 0; DevBuf d_stage;
+  bool host_prep = true; int prep_threads = 0;
+  float ms_pack = 0;
   bool dbg = false, no_fat = false, no_early_rerun = false, no_large_build = false;     // LANCET_DEBUG / LANCET_NO_FAT / ... read once, at create
   int build_slots_env = 0, ahead_depth_env = -1;
   uint32_t evt_cap = 0;
@@ -215,6 +222,38 @@ static hipError_t lc_copy(lancet_engine *e, void *dst, const void *src, size_t b
   return hipStreamSynchronize(e->stream);
 }
 
+// Graph_t::trim (reference src/Graph.cc:355-384) + 2-bit packing + quality mask on the host: the scalar twin of prep_kernel, one read
+static inline bool lc_is_dna(char b) { return b == 'A' || b == 'a' || b == 'C' || b == 'c' || b == 'G' || b == 'g' || b == 'T' || b == 't'; }
+static inline uint32_t lc_code(char b) { switch (b) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; } return 4; }
+static void lc_prep_read_host(const lancet_params &P, const char *sq, const char *ql, int len, uint8_t label, uint8_t strand, uint8_t mate, uint8_t mapped,
+                              uint32_t *rinfo, uint32_t *bases, uint32_t *good) {
+  int fg = 0; while (fg < len && !(lc_is_dna(sq[fg]) && !(ql[fg] < P.min_qual_trim))) ++fg;
+  int lg = len - 1; while (lg >= fg && !(lc_is_dna(sq[lg]) && !(ql[lg] < P.min_qual_trim))) --lg;
+  bool junk = fg >= len || lg < fg;
+  if (!junk) for (int p = fg; p <= lg; ++p) if (!lc_is_dna(sq[p])) { junk = true; break; }
+  const int trim5 = junk ? 0 : fg;
+  int tlen = junk ? 0 : lg - fg + 1;
+  if (tlen > 0xFFFF) tlen = 0xFFFF;
+  *rinfo = (uint32_t)tlen | ((label == LANCET_NML ? 1u : 0u) << 16) | ((strand == LANCET_REV ? 1u : 0u) << 17) | ((uint32_t)(mate & 3) << 18) | ((mapped ? 1u : 0u) << 20);
+  const char *s = sq + trim5, *q = ql + trim5;
+  for (int wv = 0; wv < (tlen + 15) / 16; ++wv) {
+    uint32_t v = 0; const int n = std::min(16, tlen - wv * 16);
+    for (int j = 0; j < n; ++j) v |= (lc_code(s[wv * 16 + j]) & 3u) << (2 * j);
+    bases[wv] = v;
+  }
+  for (int wv = 0; wv < (tlen + 31) / 32; ++wv) {
+    uint32_t v = 0; const int n = std::min(32, tlen - wv * 32);
+    for (int j = 0; j < n; ++j) if (q[wv * 32 + j] >= P.min_qual_call) v |= 1u << j;
+    good[wv] = v;
+  }
+}
+template <class F> static void lc_parallel(int threads, size_t n, F body) {       // body(lo, hi, t) over a static split of [0, n)
+  if (threads <= 1 || n < 4096) { body((size_t)0, n, 0); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < threads; ++t) th.emplace_back([=] { body(n * (size_t)t / threads, n * (size_t)(t + 1) / threads, t); });
+  for (auto &x : th) x.join();
+}
+
 extern "C" {
 
 void lancet_params_default(lancet_params *p) {
@@ -236,6 +275,8 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
       hipEventCreate(&e->ev1) != hipSuccess || hipEventCreate(&e->evb0) != hipSuccess || hipEventCreate(&e->evb1) != hipSuccess) { delete e; return LANCET_E_HIP; }
   if (getenv("LANCET_NO_PREBUILD")) e->prebuild = false;
   if (getenv("LANCET_NO_SVC")) e->svc = false;
+  if (const char *s = getenv("LANCET_PREP")) e->host_prep = strcmp(s, "device") != 0;
+  if (const char *s = getenv("LANCET_PREP_THREADS")) e->prep_threads = std::max(1, atoi(s));
   e->dbg = getenv("LANCET_DEBUG") != nullptr; e->no_fat = getenv("LANCET_NO_FAT") != nullptr; e->no_early_rerun = getenv("LANCET_NO_EARLY_RERUN") != nullptr;
   e->no_large_build = getenv("LANCET_NO_LARGE_BUILD") != nullptr; e->heavy_first = getenv("LANCET_NO_HEAVY_FIRST") == nullptr;
   if (const char *s = getenv("LANCET_BUILD_SLOTS")) e->build_slots_env = std::max(1, atoi(s));
@@ -261,8 +302,9 @@ void lancet_engine_destroy(lancet_engine *e) {
   DevBuf *all[] = {&e->d_params, &e->d_batch, &e->d_caps, &e->d_out, &e->d_works, &e->d_chr, &e->d_refstart, &e->d_refoff, &e->d_refasc,
                    &e->d_refcodes, &e->d_readbegin, &e->d_seqoff, &e->d_seq, &e->d_qual, &e->d_label, &e->d_strand, &e->d_mate, &e->d_mapped,
                    &e->d_rinfo, &e->d_name, &e->d_bw, &e->d_gw, &e->d_bases, &e->d_good, &e->d_variants, &e->d_blob, &e->d_counters,
-                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist, &e->d_skip, &e->d_bx, &e->d_hp, &e->d_varlr, &e->d_bxblob, &e->d_pre, &e->d_blscratch, &e->d_blphase, &e->d_order, &e->d_prepool, &e->d_blscratch_large, &e->d_biglist, &e->d_svc, &e->d_svcscratch};
+                   &e->d_stats, &e->d_evtlen, &e->d_evt, &e->d_workmem, &e->d_phase, &e->d_caps2, &e->d_works2, &e->d_workmem2, &e->d_out2, &e->d_winlist, &e->d_skip, &e->d_bx, &e->d_hp, &e->d_varlr, &e->d_bxblob, &e->d_pre, &e->d_blscratch, &e->d_blphase, &e->d_order, &e->d_prepool, &e->d_blscratch_large, &e->d_biglist, &e->d_svc, &e->d_svcscratch, &e->d_stage};
   for (DevBuf *b : all) b->release();
+  if (e->h_stage) (void)hipHostFree(e->h_stage);
   if (e->evb0) (void)hipEventDestroy(e->evb0);
   if (e->evb1) (void)hipEventDestroy(e->evb1);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -299,8 +341,6 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   const int nw = b->n_windows;
   if (e->params.lr_mode && nw > 0 && b->read_begin[nw] > 0 && (!b->bx_rank || !b->hp)) { e->err = "lr_mode needs bx_rank and hp"; return LANCET_E_ARG; }
   const uint32_t R = nw ? b->read_begin[nw] : 0;
-  for (uint32_t r = 0; r < R; ++r) if (b->name_rank[r] > 0xFFFFu) { e->err = "name_rank must be the dense per-window rank (< 65536)"; return LANCET_E_ARG; }
-  if (e->params.lr_mode) for (uint32_t r = 0; r < R; ++r) if (b->hp[r] > 2) { e->err = "hp must be 0, 1 or 2"; return LANCET_E_ARG; }   // Node_t::addHP indexes a 3-array (src/Node.cc:54-57)
   const uint32_t nbases = R ? b->seq_off[R] : 0;
   const uint32_t nref = nw ? b->ref_off[nw] : 0;
   e->n_windows = nw; e->n_reads = (int)R;
@@ -313,6 +353,82 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   e->caps.table_start = e->caps2.table_start = e->table_start;
   // ---- inputs
   UP(e->d_params, &e->params, sizeof(lancet_params));
+  DevBatch db;
+  db.n_windows = nw;
+  if (e->host_prep) {
+    // One staging buffer, same layout on both sides: window arrays, per-read words, packed bases / quality masks, reference codes.
+    const int T = e->prep_threads > 0 ? e->prep_threads : (int)std::max(1u, std::min(48u, std::thread::hardware_concurrency()));
+    const auto t_pack0 = std::chrono::steady_clock::now();
+    std::vector<uint64_t> tb((size_t)T + 1, 0), tg((size_t)T + 1, 0);
+    std::vector<char> bad((size_t)T, 0);
+    lc_parallel(T, (size_t)R, [&](size_t lo, size_t hi, int t) {
+      uint64_t bo = 0, go = 0; char bd = 0;
+      for (size_t r = lo; r < hi; ++r) {
+        const uint32_t len = b->seq_off[r + 1] - b->seq_off[r]; bo += (len + 15) / 16; go += (len + 31) / 32;
+        if (b->name_rank[r] > 0xFFFFu) bd = 1;
+        if (e->params.lr_mode && b->hp[r] > 2) bd = 2;
+      }
+      tb[(size_t)t + 1] = bo; tg[(size_t)t + 1] = go; bad[(size_t)t] = bd;
+    });
+    for (int t = 0; t < T; ++t) {
+      if (bad[(size_t)t] == 1) { e->err = "name_rank must be the dense per-window rank (< 65536)"; return LANCET_E_ARG; }
+      if (bad[(size_t)t] == 2) { e->err = "hp must be 0, 1 or 2"; return LANCET_E_ARG; }      // Node_t::addHP indexes a 3-array (src/Node.cc:54-57)
+      tb[(size_t)t + 1] += tb[(size_t)t]; tg[(size_t)t + 1] += tg[(size_t)t];
+    }
+    const uint64_t bo_all = tb[(size_t)T], go_all = tg[(size_t)T];
+    if (bo_all + 4 > 0xFFFFFFFFull) { e->err = "batch too large"; return LANCET_E_ARG; }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_chr = take(4 * (size_t)nw), o_rs = take(4 * (size_t)nw), o_ro = take(4 * ((size_t)nw + 1)), o_rb = take(4 * ((size_t)nw + 1));
+    const size_t o_ri = take(4 * ((size_t)R + 1)), o_nm = take(4 * (size_t)R), o_bw = take(4 * ((size_t)R + 1)), o_gw = take(4 * ((size_t)R + 1));
+    const size_t o_ba = take(4 * ((size_t)bo_all + 4)), o_go = take(4 * ((size_t)go_all + 1)), o_rc = take((size_t)nref + 1);
+    const size_t o_bx = e->params.lr_mode ? take(4 * (size_t)R) : 0, o_hp = e->params.lr_mode ? take((size_t)R) : 0;
+    const size_t total = off;
+    if (total > e->h_stage_cap) {
+      if (e->h_stage) (void)hipHostFree(e->h_stage);
+      e->h_stage = nullptr; e->h_stage_cap = 0;
+      const size_t want = total + total / 8;
+      if (hipHostMalloc(&e->h_stage, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); e->err = "hipHostMalloc failed (staging)"; return LANCET_E_OOM; }
+      e->h_stage_cap = want;
+    }
+    ENS(e->d_stage, total);
+    char *H = (char *)e->h_stage;
+    memcpy(H + o_chr, b->chr_id, 4 * (size_t)nw); memcpy(H + o_rs, b->ref_start, 4 * (size_t)nw);
+    memcpy(H + o_ro, b->ref_off, 4 * ((size_t)nw + 1)); memcpy(H + o_rb, b->read_begin, 4 * ((size_t)nw + 1));
+    uint32_t *h_ri = (uint32_t *)(H + o_ri), *h_nm = (uint32_t *)(H + o_nm), *h_bw = (uint32_t *)(H + o_bw), *h_gw = (uint32_t *)(H + o_gw);
+    uint32_t *h_ba = (uint32_t *)(H + o_ba), *h_go = (uint32_t *)(H + o_go);
+    const lancet_params P = e->params;
+    lc_parallel(T, (size_t)R, [&](size_t lo, size_t hi, int t) {
+      uint64_t bo = tb[(size_t)t], go = tg[(size_t)t];
+      for (size_t r = lo; r < hi; ++r) {
+        const uint32_t o = b->seq_off[r], len = b->seq_off[r + 1] - o;
+        h_bw[r] = (uint32_t)bo; h_gw[r] = (uint32_t)go; h_nm[r] = b->name_rank[r];
+        lc_prep_read_host(P, b->seq + o, b->qual + o, (int)len, b->label[r], b->strand[r], b->mate[r], b->mapped[r], &h_ri[r], h_ba + bo, h_go + go);
+        // (the words a trimmed read does not fill stay unread: every consumer goes by the trimmed length; zero them anyway so that the staging buffer is deterministic)
+        const uint32_t tl = RI_TLEN(h_ri[r]);
+        for (uint32_t wv = (tl + 15) / 16; wv < (len + 15) / 16; ++wv) h_ba[bo + wv] = 0;
+        for (uint32_t wv = (tl + 31) / 32; wv < (len + 31) / 32; ++wv) h_go[go + wv] = 0;
+        bo += (len + 15) / 16; go += (len + 31) / 32;
+      }
+    });
+    h_ri[R] = 0; h_bw[R] = (uint32_t)bo_all; h_gw[R] = (uint32_t)go_all;
+    for (int i = 0; i < 4; ++i) h_ba[bo_all + (uint64_t)i] = 0;
+    h_go[go_all] = 0;
+    uint8_t *h_rc = (uint8_t *)(H + o_rc);
+    lc_parallel(T, (size_t)nref, [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; ++i) h_rc[i] = (uint8_t)lc_code(b->ref_bases[i]); });
+    h_rc[nref] = 0;
+    if (e->params.lr_mode && R) { memcpy(H + o_bx, b->bx_rank, 4 * (size_t)R); memcpy(H + o_hp, b->hp, (size_t)R); }
+    e->ms_pack = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_pack0).count();
+    HIPCHK(e, hipMemcpyAsync(e->d_stage.p, e->h_stage, total, hipMemcpyHostToDevice, e->stream));
+    char *D = (char *)e->d_stage.p;
+    db.chr_id = (LC_GLOBAL const int32_t *)(D + o_chr); db.ref_start = (LC_GLOBAL const int32_t *)(D + o_rs);
+    db.ref_off = (LC_GLOBAL const uint32_t *)(D + o_ro); db.ref_codes = (LC_GLOBAL const uint8_t *)(D + o_rc); db.read_begin = (LC_GLOBAL const uint32_t *)(D + o_rb);
+    db.rinfo = (LC_GLOBAL const uint32_t *)(D + o_ri); db.name_rank = (LC_GLOBAL const uint32_t *)(D + o_nm); db.base_woff = (LC_GLOBAL const uint32_t *)(D + o_bw);
+    db.good_woff = (LC_GLOBAL const uint32_t *)(D + o_gw); db.bases = (LC_GLOBAL const uint32_t *)(D + o_ba); db.good = (LC_GLOBAL const uint32_t *)(D + o_go);
+    db.bx_rank = e->params.lr_mode ? (LC_GLOBAL const uint32_t *)(D + o_bx) : nullptr; db.hp = e->params.lr_mode ? (LC_GLOBAL const uint8_t *)(D + o_hp) : nullptr;
+  } else {
+  for (uint32_t r = 0; r < R; ++r) if (b->name_rank[r] > 0xFFFFu) { e->err = "name_rank must be the dense per-window rank (< 65536)"; return LANCET_E_ARG; }
+  if (e->params.lr_mode) for (uint32_t r = 0; r < R; ++r) if (b->hp[r] > 2) { e->err = "hp must be 0, 1 or 2"; return LANCET_E_ARG; }   // Node_t::addHP indexes a 3-array (src/Node.cc:54-57)
   UP(e->d_chr, b->chr_id, sizeof(int32_t) * nw);
   UP(e->d_refstart, b->ref_start, sizeof(int32_t) * nw);
   UP(e->d_refoff, b->ref_off, sizeof(uint32_t) * (nw + 1));
@@ -341,12 +457,12 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   hipLaunchKernelGGL(ref_code_kernel, dim3((nref + 255) / 256), dim3(256), 0, e->stream, (const char *)e->d_refasc.p, (uint8_t *)e->d_refcodes.p, nref);
   HIPCHK(e, hipGetLastError());
   DBG("prep launched");
-  DevBatch db;
-  db.n_windows = nw; db.chr_id = (LC_GLOBAL const int32_t *)e->d_chr.p; db.ref_start = (LC_GLOBAL const int32_t *)e->d_refstart.p;
+  db.chr_id = (LC_GLOBAL const int32_t *)e->d_chr.p; db.ref_start = (LC_GLOBAL const int32_t *)e->d_refstart.p;
   db.ref_off = (LC_GLOBAL const uint32_t *)e->d_refoff.p; db.ref_codes = (LC_GLOBAL const uint8_t *)e->d_refcodes.p; db.read_begin = (LC_GLOBAL const uint32_t *)e->d_readbegin.p;
   db.rinfo = (LC_GLOBAL const uint32_t *)e->d_rinfo.p; db.name_rank = (LC_GLOBAL const uint32_t *)e->d_name.p; db.base_woff = (LC_GLOBAL const uint32_t *)e->d_bw.p;
   db.good_woff = (LC_GLOBAL const uint32_t *)e->d_gw.p; db.bases = (LC_GLOBAL const uint32_t *)e->d_bases.p; db.good = (LC_GLOBAL const uint32_t *)e->d_good.p;
   db.bx_rank = e->params.lr_mode ? (LC_GLOBAL const uint32_t *)e->d_bx.p : nullptr; db.hp = e->params.lr_mode ? (LC_GLOBAL const uint8_t *)e->d_hp.p : nullptr;
+  }
   UP(e->d_batch, &db, sizeof(db));
   UP(e->d_caps, &e->caps, sizeof(e->caps));
   UP(e->d_caps2, &e->caps2, sizeof(e->caps2));

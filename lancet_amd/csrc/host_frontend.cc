@@ -389,7 +389,7 @@ bool load_bam(const std::string &path, std::vector<Want> wants, Sample *S, std::
   S->first_has_md = 1;
   if (in.need(4, err)) {
     const int32_t bs = rd_i32(in.cur());
-    if (bs < 32 || !in.need(4 + (size_t)bs, err)) return fail("truncated alignment record");
+    if (bs < 32 || bs > (256 << 20) || !in.need(4 + (size_t)bs, err)) return fail("truncated alignment record");
     S->first_has_md = record_has_md(in.cur() + 4, (size_t)bs) ? 1 : 0;
   } else if (!err->empty()) return fail("");
   // ranges in file order: by reference id, then position
@@ -421,6 +421,7 @@ bool load_bam(const std::string &path, std::vector<Want> wants, Sample *S, std::
       if (!in.need(4, err)) { if (!err->empty()) return fail(""); at_end = true; break; }
       const int32_t bs = rd_i32(in.cur());
       if (bs < 32) return fail("truncated alignment record");
+      if (bs > (256 << 20)) return fail("alignment record of more than 256 MB (damaged block_size?)");     // (need() would buffer the rest of the file first)
       if (!in.need(4 + (size_t)bs, err)) return fail("truncated alignment record");
       const unsigned char *rec = in.cur() + 4;
       const int32_t tid = rd_i32(rec), pos = rd_i32(rec + 4);
@@ -698,7 +699,9 @@ int lancet_host_window_span(const lancet_host *h, int w, int32_t *start, int32_t
 namespace {
 
 // loadRefs for one region (reference src/Lancet.cc:189-316): padding, clipping, windows of window_size every 100 bp, last
-// window LEN = len - offset - 1, upper case + IUPAC -> N.  Appends to h->windows and notes which alignment starts the
+// window LEN = len - offset - 1, upper case + IUPAC -> N.
+// Known divergence: the padded end is clipped to the contig length of the FASTA index; the reference clips to the tumor BAM header's
+// RefLength (src/Lancet.cc:233-249).  The two agree whenever the BAM was aligned to this FASTA (the only supported use).  Appends to h->windows and notes which alignment starts the
 // windows can select.
 int tile_one(lancet_host *h, const std::string &reg, const lancet_host_opts *o, std::map<std::string, std::vector<std::pair<int32_t, int32_t>>> *want) {
   const size_t x = reg.find(':');

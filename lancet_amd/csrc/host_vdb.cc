@@ -22,8 +22,11 @@
 #include <thread>
 #include <vector>
 
+#if defined(__x86_64__) || defined(__i386__)
+#define LANCET_X86_SHA 1
 #include <cpuid.h>
 #include <immintrin.h>
+#endif
 
 #include "../../include/lancet_engine.h"
 
@@ -38,6 +41,7 @@ static const uint32_t SHA_K[64] = {
     0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
     0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 
+#ifdef LANCET_X86_SHA
 // One 64-byte block with the x86 SHA extensions (sha256rnds2 / sha256msg1 / sha256msg2), used when the host CPU has them:
 // rank 0 hashes every record of every rank when it replays them, and the scalar rounds were its largest single cost.
 __attribute__((target("sha,sse4.1,ssse3"))) void sha256_block_ni(uint32_t st[8], const uint8_t *p) {
@@ -73,7 +77,7 @@ bool sha_ni_detect() {
   if (!__get_cpuid(1, &a, &b, &c, &d)) return false;
   return sha && ((c >> 19) & 1) && ((c >> 9) & 1);                                 // + sse4.1, ssse3
 }
-const bool SHA_NI = sha_ni_detect();
+#endif
 struct Sha256 {
   uint32_t h[8]; uint8_t buf[64]; uint64_t len; size_t fill;
   static uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
@@ -81,8 +85,8 @@ struct Sha256 {
     static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
     memcpy(h, iv, sizeof(h)); len = 0; fill = 0;
   }
-  void block(const uint8_t *p) {
-    if (SHA_NI) { sha256_block_ni(h, p); return; }
+  static bool use_ni();
+  void block_scalar(const uint8_t *p) {
     const uint32_t *k = SHA_K;
     uint32_t w[64];
     for (int i = 0; i < 16; ++i) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
@@ -98,6 +102,12 @@ struct Sha256 {
     }
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
   }
+  void block(const uint8_t *p) {
+#ifdef LANCET_X86_SHA
+    if (use_ni()) { sha256_block_ni(h, p); return; }
+#endif
+    block_scalar(p);
+  }
   void update(const uint8_t *p, size_t n) {
     len += n;
     while (n) { size_t t = std::min(n, 64 - fill); memcpy(buf + fill, p, t); fill += t; p += t; n -= t; if (fill == 64) { block(buf); fill = 0; } }
@@ -112,6 +122,21 @@ struct Sha256 {
     for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) out[4 * i + j] = (uint8_t)(h[i] >> (24 - 8 * j));
   }
 };
+// The SHA-NI rounds are used only when the CPU has them AND they reproduce the scalar rounds on one block (checked once, at first use).
+bool Sha256::use_ni() {
+#ifdef LANCET_X86_SHA
+  static const bool ok = [] {
+    if (!sha_ni_detect()) return false;
+    uint8_t blk[64]; for (int i = 0; i < 64; ++i) blk[i] = (uint8_t)(37 * i + 11);
+    Sha256 a, b; a.init(); b.init();
+    sha256_block_ni(a.h, blk); b.block_scalar(blk);
+    return memcmp(a.h, b.h, sizeof(a.h)) == 0;
+  }();
+  return ok;
+#else
+  return false;
+#endif
+}
 // The map key.  The reference keys its std::map by the 64-character hex digest; hex encoding keeps byte order
 // ('0'..'9' < 'a'..'f'), so ordering the 32 raw bytes with memcmp IS the reference's iteration order.
 struct Dig {

@@ -4144,7 +4144,9 @@ DEVNI void process_path_walk_wg(Ctx &c, int np, int plen, int L, int complete) {
   WG_FOR(i, np) {
     const uint32_t nd = W.pnodes[i];
     const bool sp = (W.gr[nd].flags & NF_SPECIAL) != 0;
-    pend[2 * i] = sp ? (pstep[i] | 0x80000000u) : (pstep[i] + (uint32_t)n_len(c, nd));
+    // (a special node -- source first, sink last -- carries the end of the real node before it, so that the ends never decrease
+    //  along the path and the binary search of walk_gather is sound: running position + K - 1 is exactly that end)
+    pend[2 * i] = sp ? ((pstep[i] + (uint32_t)(K - 1)) | 0x80000000u) : (pstep[i] + (uint32_t)n_len(c, nd));
     pend[2 * i + 1] = (!sp && status_cnt_T(c, nd)) ? 1u : 0u;
   }
   WG_LANE0 { S.wk_stop = 0; S.wk_nts = 0; S.wk_last = -2; S.wk_code = '?'; }
@@ -4445,7 +4447,12 @@ DEVNI void count_ref_path(Ctx &c) {
       SUBPHASE(c, 4, 2);
       walk_prepare(c, (int)wg_bcastu(&S.part[7]));
       SUBPHASE(c, 4, 14);
-      if (wg_uniform(S.LR)) {
+#ifdef LANCET_WAVE_EMU
+      const bool old_walk = getenv("LANCET_OLD_WALK") != nullptr;      // (emulator only: the one-lane form on every window, to compare the two)
+#else
+      const bool old_walk = false;
+#endif
+      if (wg_uniform(S.LR) || old_walk) {
         WG_LANE0 { if (!S.overflow) process_path_walk(c, (int)S.part[4], (int)S.part[5], (int)S.part[7], (int)S.part[1]); }
       } else if (!wg_bcast(&S.overflow)) {
         process_path_walk_wg(c, (int)wg_bcastu(&S.part[4]), (int)wg_bcastu(&S.part[5]), (int)wg_bcastu(&S.part[7]), (int)wg_bcastu(&S.part[1]));

@@ -30,9 +30,12 @@ def shard_windows(n_windows: int, rank: int, world: int, chunk: int = 4096) -> L
     return [i for i in range(n_windows) if (i // chunk) % world == rank]
 
 
-def pack_records(vptr, n: int, blob: bytes, lrptr=None, bx_blob=None, bx_names: Optional[Sequence[str]] = None,
-                 chr_names: Sequence[str] = ("chr22",), window_index: Optional[np.ndarray] = None) -> bytes:
-    """One rank's records as bytes.  window_index[w] = global index of the rank's window w (default: identity)."""
+def pack_records(vptr, n: int, blob: bytes, lrptr=None, bx_blob=None, bx_names: Optional[Sequence[str]] = None, *,
+                 chr_names: Sequence[str], window_index: Optional[np.ndarray] = None) -> bytes:
+    """One rank's records as bytes.  chr_names[chr_id] = the contig names of the rank's batch (required: records carry ids);
+    window_index[w] = global index of the rank's window w (default: identity)."""
+    if not chr_names:
+        raise ValueError("pack_records: chr_names is required")
     recs = np.frombuffer(C.string_at(vptr, n * _VDT.itemsize), dtype=_VDT).copy() if n else np.zeros(0, dtype=_VDT)
     if window_index is not None and n:
         recs["window"] = np.asarray(window_index, dtype=np.int64)[recs["window"]]
@@ -104,6 +107,8 @@ def merge_into_vdb(parts: Sequence[bytes], db) -> int:
     ids_all, blobs = [], []
     blob_base = 0; id_base = 0; o = 0
     lr_mode = any(p["lr"] is not None for p in ps)
+    if lr_mode and not all(p["lr"] is not None for p in ps):
+        raise ValueError("merge_into_vdb: some ranks sent linked-read records and some did not (one run is either --linked-reads or not)")
     total = sum(p["n"] for p in ps)
     recs = np.empty(total, dtype=_VDT)                        # every part is copied once, straight into its place
     lr = np.empty(total, dtype=_LDT) if lr_mode else None

@@ -141,6 +141,25 @@ def sub_batch(b: WindowBatch, w0: int, w1: int) -> WindowBatch:
         bx_names=b.bx_names)      # (barcode ranks stay ranks among the parent batch's barcodes)
 
 
+def concat_batches(parts) -> WindowBatch:
+    """Several batches (short reads, same contig table) as one: the windows of parts[0], then parts[1], ..."""
+    parts = list(parts)
+    if len(parts) == 1:
+        return parts[0]
+    def offs(name, base_of):
+        out, base = [np.zeros(1, dtype=np.int64)], 0
+        for p in parts:
+            a = getattr(p, name).astype(np.int64)
+            out.append(a[1:] + base); base += int(a[-1])
+        return np.concatenate(out).astype(np.uint32)
+    cat = lambda name: np.concatenate([getattr(p, name) for p in parts])
+    return WindowBatch(
+        n_windows=sum(p.n_windows for p in parts), hdr=[h for p in parts for h in p.hdr], chrom=[c for p in parts for c in p.chrom],
+        chr_id=cat("chr_id"), ref_start=cat("ref_start"), ref_off=offs("ref_off", None), ref_bases=cat("ref_bases"),
+        read_begin=offs("read_begin", None), seq_off=offs("seq_off", None), seq=cat("seq"), qual=cat("qual"), label=cat("label"),
+        strand=cat("strand"), mate=cat("mate"), mapped=cat("mapped"), name_rank=cat("name_rank"))
+
+
 def algorithmic_bytes(b: WindowBatch, stats, n_variants: int) -> int:
     """per (window, k-attempt that reaches buildgraph)
          sum_reads(ceil(len/4) + len) + ceil(W/4) + W/8 + 16*kmers + 40*nodes      (+128 B per emitted variant)."""

@@ -1,0 +1,110 @@
+"""TEST / MEASUREMENT INFRASTRUCTURE ONLY -- the oracle (oracle/liblancet_oracle.so) fanned out over worker PROCESSES, for
+bench.py's `cpu_baseline` leg: windows are independent, as the reference's own --num-threads fan-out (reference
+src/Lancet.cc:910-928), and one process per hardware thread keeps the workers off each other's allocator and page tables
+(256 threads inside one process measured 9x one thread on a 2 x 64-core host; that was contention, not the path).
+
+The sample batch is written once as .npy files (in /dev/shm when there is one); every worker maps them, cuts its own chunks
+(chunk j goes to worker j mod N) and reports when it is ready; the clock runs from the common "go" to the last worker's end,
+so no start-up and no window data between processes is inside the timed region."""
+from __future__ import annotations
+
+import os
+import pickle
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+_ARRAYS = ("chr_id", "ref_start", "ref_off", "ref_bases", "read_begin", "seq_off", "seq", "qual", "label", "strand", "mate", "mapped", "name_rank")
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def physical_cores() -> int:
+    """Distinct (package, core) pairs of /proc/cpuinfo; os.cpu_count() counts hardware threads."""
+    seen, phys, core = set(), None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return len(seen) or (os.cpu_count() or 1)
+
+
+def _worker(d: str, idx: int, n: int) -> None:
+    sys.path[:] = [q for q in sys.path if os.path.abspath(q or ".") != os.path.dirname(os.path.abspath(__file__))]   # (`oracle` must be the package)
+    sys.path.insert(0, _ROOT)
+    from lancet_amd import abi, frontend, workload
+    from oracle import oracle
+    oracle.lib()
+    meta = pickle.load(open(os.path.join(d, "meta.pkl"), "rb"))
+    arrs = {k: np.load(os.path.join(d, k + ".npy"), mmap_mode="r") for k in _ARRAYS}
+    batch = frontend.WindowBatch(n_windows=meta["n_windows"], hdr=meta["hdr"], chrom=meta["chrom"], **arrs)
+    p = abi.default_params(**meta["params"])
+    print("ready", flush=True)
+    if sys.stdin.readline().strip() != "go":
+        return
+    t = time.perf_counter()
+    km = nw = 0
+    for j, (a, b) in enumerate(meta["ranges"]):
+        if j % n == idx:
+            _, st, _ = oracle.run(workload.sub_batch(batch, a, b), p)
+            km += sum(s["n_kmers"] for s in st)
+            nw += b - a
+    print("done", km, nw, time.perf_counter() - t, flush=True)
+
+
+def run(batch, params_kw: dict, n_windows: int, workers: int, chunk: int, timeout_s: float = 300.0):
+    """Oracle over windows [0, n_windows) of `batch` on `workers` processes.  Returns (seconds, k-mers, windows done)."""
+    sys.path.insert(0, _ROOT)
+    from lancet_amd import workload
+    sample = workload.sub_batch(batch, 0, n_windows)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="lancet_cpu_", dir=base)
+    procs = []
+    try:
+        for k in _ARRAYS:
+            np.save(os.path.join(d, k + ".npy"), np.ascontiguousarray(getattr(sample, k)))
+        ranges = [(a, min(n_windows, a + chunk)) for a in range(0, n_windows, chunk)]
+        pickle.dump({"n_windows": sample.n_windows, "hdr": sample.hdr, "chrom": sample.chrom, "params": params_kw, "ranges": ranges},
+                    open(os.path.join(d, "meta.pkl"), "wb"))
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        for i in range(workers):
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "worker", d, str(i), str(workers)],
+                                          stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env))
+        deadline = time.time() + timeout_s
+        for p in procs:
+            line = p.stdout.readline()
+            if line.strip() != "ready" or time.time() > deadline:
+                raise RuntimeError("cpu_fanout: a worker did not come up")
+        t = time.perf_counter()
+        for p in procs:
+            p.stdin.write("go\n"); p.stdin.flush()
+        km = nw = 0
+        for p in procs:
+            f = p.stdout.readline().split()
+            if len(f) != 4 or f[0] != "done":
+                raise RuntimeError("cpu_fanout: a worker failed")
+            km += int(f[1]); nw += int(f[2])
+        dt = time.perf_counter() - t
+        return dt, km, nw
+    finally:
+        for p in procs:
+            try:
+                p.kill()
+            except OSError:
+                pass
+        shutil.rmtree(d, ignore_errors=True)
+
+
+if __name__ == "__main__" and len(sys.argv) == 5 and sys.argv[1] == "worker":
+    _worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))

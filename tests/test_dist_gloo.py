@@ -62,7 +62,7 @@ def _worker(rank, world, port, case, q):
             r["window"] = li
             recs.append(r)
     arr, blob, lra, bxb = records_to_c(recs, lr)
-    payload = ldist.pack_records(arr, len(recs), blob, lra, bxb, batch.bx_names, ["chr22"], window_index=mine)
+    payload = ldist.pack_records(arr, len(recs), blob, lra, bxb, batch.bx_names, chr_names=["chr22"], window_index=mine)
     parts = ldist.gather_bytes(payload, torch.device("cpu"))
     if rank == 0:
         db = engine.VariantDB()

@@ -253,3 +253,84 @@ def test_coverage_pile_up_window_does_not_size_the_whole_batch():
     ov, ost, _ = oracle.run(both, p)
     assert v == ov and [s["final_k"] for s in st] == [s["final_k"] for s in ost]
     eng.close()
+
+
+def test_pile_up_started_early_does_not_read_the_previous_batch_hand_off():
+    """Two different batches through ONE engine; in the second a coverage pile-up sits at a window index whose hand-off area
+    still holds a graph of the first batch (PB_BUILT, a k that also suits the pile-up's window).  The pile-up is launched in the
+    re-run tier next to the build kernel, i.e. before its own hand-off area is rewritten: it must not look at it (every graph
+    by the general build).  Both batches equal the oracle, also when run twice more in alternation."""
+    from lancet_amd import workload
+    p = abi.default_params()
+    first = workload.make_scan_batch(50, 20, 20, seed=5, read_len=100)
+    plain = workload.make_scan_batch(48, 20, 20, seed=15, read_len=100)
+    pile = workload.make_scan_batch(2, 500, 500, seed=6, read_len=100)
+    second = _concat(_concat(workload.sub_batch(plain, 0, 20), pile), workload.sub_batch(plain, 20, 48))     # pile-ups at indices 20, 21
+    o1, s1, _ = oracle.run(first, p)
+    o2, s2, _ = oracle.run(second, p)
+    eng = engine.Engine(p)
+    for rnd in range(3):
+        v, st = eng.process(first)
+        assert v == o1 and [s["final_k"] for s in st] == [s["final_k"] for s in s1], rnd
+        v, st = eng.process(second)
+        assert eng.rerun_count() == 2 and all(s["status"] >= 0 for s in st)
+        assert v == o2 and [(s["final_k"], s["n_builds"]) for s in st] == [(s["final_k"], s["n_builds"]) for s in s2], rnd
+    eng.close()
+
+
+def test_build_service_is_scheduling_only(monkeypatch):
+    """Cycle-prone windows (tandem duplications: k climbs) with the build service on, with more service workgroups, with nothing
+    built ahead (every later graph on request), and with the service off: identical records and per-window statistics, equal
+    to the oracle's; the service did serve requests."""
+    from lancet_amd import workload
+    p = abi.default_params()
+    b = workload.make_scan_batch(600, 30, 30, seed=11)
+    ov, ost, _ = oracle.run(b, p)
+    key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
+    served = []
+    for env in ({}, {"LANCET_SVC_WGS": "64"}, {"LANCET_AHEAD_DEPTH": "0", "LANCET_SVC_DEPTH": "0"}, {"LANCET_NO_SVC": "1"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        eng = engine.Engine(p)
+        for _ in range(2):
+            v, st = eng.process(b)
+            assert v == ov and [key(s) for s in st] == [key(s) for s in ost], env
+        served.append(eng.svc_counts())
+        eng.close()
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    assert served[0][0] >= 1 and served[0][1] + served[0][3] == served[0][0] and served[3] == (0, 0, 0, 0), served
+    extra = sum(s["n_builds"] - 1 for s in ost)
+    assert served[2][0] == extra, (served, extra)
+
+
+def test_host_and_device_trim_and_pack_agree(monkeypatch):
+    """Graph_t::trim + packing runs on host threads at upload (pinned staging, one DMA); LANCET_PREP=device keeps the device kernel
+    (prep_kernel).  Same records either way, on reads with low-quality ends, N bases and junk reads (golden `filters`-like
+    batch: tests/read_variety) and on a scan batch."""
+    from lancet_amd import workload
+    p = abi.default_params(min_qual_trim=33 + 12, min_qual_call=33 + 20)
+    odd = workload.make_scan_batch(64, 25, 25, seed=4, error_rate=0.01)
+    rng = np.random.default_rng(8)
+    for r in range(odd.n_reads):                                            # low-quality ends, N / IUPAC inside, whole reads of junk
+        a, e = int(odd.seq_off[r]), int(odd.seq_off[r + 1])
+        u = rng.random()
+        if u < 0.15: odd.qual[a:a + int(rng.integers(1, 12))] = 33 + 2
+        elif u < 0.30: odd.qual[e - int(rng.integers(1, 12)):e] = 33 + 5
+        elif u < 0.35: odd.seq[a + int(rng.integers(0, e - a))] = ord("N")
+        elif u < 0.40: odd.seq[a + int(rng.integers(0, e - a))] = ord("R")          # (an IUPAC code: junk like N)
+        elif u < 0.43: odd.qual[a:e] = 33
+        elif u < 0.46: odd.seq[a] = ord("N"); odd.seq[e - 1] = ord("N")
+        elif u < 0.60: odd.qual[a + int(rng.integers(0, e - a))] = 33 + 15     # between the two thresholds: kept, not counted
+    batches = [workload.make_scan_batch(96, 25, 25, seed=3, error_rate=0.01), odd]
+    for b in batches:
+        out = []
+        for mode in ("host", "device"):
+            monkeypatch.setenv("LANCET_PREP", mode)
+            eng = engine.Engine(p)
+            v, st = eng.process(b)
+            out.append((v, [(s["status"], s["final_k"], s["n_kmers"], s["max_nodes"]) for s in st]))
+            eng.close()
+        assert out[0] == out[1]
+        ov, ost, _ = oracle.run(b, p)
+        assert out[0][0] == ov
