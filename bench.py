@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--cpu-sample-all", type=int, default=16384, help="windows timed on all host cores")
     ap.add_argument("--no-configs", action="store_true", help="skip the side configurations (60x/60x, 100x/40x STR)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight per GPU (engines submitted in turn); 1 = every step alone on the GPU")
+    ap.add_argument("--chain", type=int, default=1, help="1: a batch's kernels start when those of the batch before it (other engine) are through -- back to back, no host gap; 0: as soon as submitted")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: every rank assembles its own contig of --windows windows; strong: ONE contig of --windows windows dealt out over the ranks in chunks (dist.shard_windows)")
     args = ap.parse_args()
@@ -226,7 +227,7 @@ def main():
         pend = []
         for i in range(k):
             e = engs[i % nfl]
-            e.submit()
+            e.submit(after=pend[-1] if pend and args.chain else None)
             pend.append(e)
             if len(pend) >= nfl:
                 complete(pend.pop(0))
@@ -274,11 +275,11 @@ def main():
     # the kernels of the previous one when two engines take turns
     t1 = time.perf_counter()
     pend = []
-    ne2e = 4
+    ne2e = 6
     for i in range(ne2e):
         e = engs[i % nfl]
         e.upload(batch)
-        e.submit()
+        e.submit(after=pend[-1] if pend and args.chain else None)
         pend.append(e)
         if len(pend) >= nfl:
             pend.pop(0).wait()

@@ -163,6 +163,10 @@ int lancet_engine_process(lancet_engine *e, const lancet_window_batch *b);
  * flight per engine; two engines on the same device, submitted in turn, overlap the tail of one batch with the bulk of the next. */
 int lancet_engine_submit(lancet_engine *e);
 int lancet_engine_wait(lancet_engine *e);
+/* submit for the second of two engines that take turns on one device: e's kernels start when `prev`'s kernels are through (a batch's
+ * kernels are sized for the whole device; side by side with another batch's they only slow each other down), while the host side of
+ * the two batches -- upload, launch, read-back -- overlaps the other's kernels.  prev == NULL: lancet_engine_submit. */
+int lancet_engine_submit_after(lancet_engine *e, lancet_engine *prev);
 
 /* Results of the last run: variants ordered by (window, seq_in_window) so that the caller can replay
  * addVar in reference order. */

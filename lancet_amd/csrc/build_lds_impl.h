@@ -1048,7 +1048,7 @@ DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
 // workgroup takes a ticket, waits for that request to be posted (or for `done`), builds into a pool area (and on into the
 // following k while the hint says that one will be rejected too), chains the area to the window's hand-off and puts the
 // request on the ready list.  Host emulation: one call serves what is posted and returns.
-// A waiting workgroup also leaves when NOTHING on the device has made progress for ~60 ms (the build kernel's and the window
+// A waiting workgroup also leaves when NOTHING of its batch has made progress for ~300 ms (another engine's batch may hold the device for tens of ms first) (the build kernel's and the window
 // kernel's queue heads, the slots' heartbeat, the request counter): under a profiler that serialises kernels (rocprofv3 --pmc) the
 // service would otherwise wait for a window kernel that cannot start before it has left.  The slots then find no service
 // (SvcCtl::alive == 0) and build those graphs themselves.
@@ -1077,7 +1077,7 @@ DEV void svc_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBa
           const uint32_t sum = ld2(queue) + ld2(&sv->beat) + ld2(&sv->req_alloc) + (wqueue ? ld2(wqueue) : 0u);
           const unsigned long long now = wall_clock64();
           if (sum != last_sum) { last_sum = sum; t_prog = now; }
-          else if (now - t_prog > 6000000ull) { dev_atomic_add(&sv->n_gaveup, 1u); st = 0xFFFFFFFFu; break; }      // 60 ms at 100 MHz
+          else if (now - t_prog > 30000000ull) { dev_atomic_add(&sv->n_gaveup, 1u); st = 0xFFFFFFFFu; break; }      // 300 ms at 100 MHz
         }
         dev_sleep();
 #endif

@@ -18,6 +18,7 @@
 #include "host_common.h"
 
 // window_fat.hip
+extern "C" int lancet_engine_submit(lancet_engine *e);
 int lc_launch_window_fat(int slots, hipStream_t stream, const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT);
 
 #define HIPCHK(e, call)                                                                           \
@@ -55,6 +56,9 @@ __global__ void __launch_bounds__(bl_small::WG) __attribute__((amdgpu_waves_per_
                     (LC_GLOBAL uint32_t *)queue, *(bl_small::BL_S *)&bl_small::bl_shared, (int)blockIdx.x, (LC_GLOBAL uint8_t *)pool, pool_cap, depth, (LC_GLOBAL SvcCtl *)sv,
                     (LC_GLOBAL const uint32_t *)wqueue);
 }
+// (the control block is set up by a kernel, not by a copy: an asynchronous copy from pageable host memory blocks the caller until the
+//  stream has caught up, and with another engine's persistent kernels on the device that is the rest of their batch)
+__global__ void svc_init_kernel(SvcCtl *sv, SvcCtl v) { *sv = v; }
 __global__ void svc_done_kernel(SvcCtl *sv) { __hip_atomic_store(&sv->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Graph_t::trim (reference src/Graph.cc:355-384) + 2-bit packing + quality mask, one wave per read: the lanes look at consecutive
@@ -186,8 +190,10 @@ struct lancet_engine {
   hipStream_t stream3 = nullptr; hipEvent_t ev_svc = nullptr;
   bool svc = true, svc_running = false;      // LANCET_NO_SVC=1 (at create): every later graph of a window by the general build
   int n_svc_wgs = 16; uint32_t svc_cap = 0; int svc_depth = 6;
+  int svc_cus = 8, n_cus = 256;                // CUs set aside for the service (CU masks on the two streams): its workgroups must be resident
+                                             // whatever the batch's kernels -- or another engine's -- occupy; 0 = no masks
   SvcCtl svc_host;
-  uint32_t svc_counts[4] = {0, 0, 0, 0};     // posted, built, failed, stolen of the last run
+  uint32_t svc_counts[5] = {0, 0, 0, 0, 0};  // posted, built, failed, stolen of the last run ; service workgroups that gave up waiting
   float ms_build = 0, ms_window = 0;
   bool uploaded = false, ran = false, submitted = false;
   // upload: reads are trimmed and packed by host threads into a pinned staging buffer that mirrors one device buffer (one DMA);
@@ -223,29 +229,36 @@ static hipError_t lc_copy(lancet_engine *e, void *dst, const void *src, size_t b
 }
 
 // Graph_t::trim (reference src/Graph.cc:355-384) + 2-bit packing + quality mask on the host: the scalar twin of prep_kernel, one read
-static inline bool lc_is_dna(char b) { return b == 'A' || b == 'a' || b == 'C' || b == 'c' || b == 'G' || b == 'g' || b == 'T' || b == 't'; }
-static inline uint32_t lc_code(char b) { switch (b) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; } return 4; }
+struct LcCodeTab { uint8_t c[256]; LcCodeTab() { for (int i = 0; i < 256; ++i) c[i] = 4; c['A'] = c['a'] = 0; c['C'] = c['c'] = 1; c['G'] = c['g'] = 2; c['T'] = c['t'] = 3; } };
+static const LcCodeTab lc_tab;
+static inline uint32_t lc_code(char b) { return lc_tab.c[(uint8_t)b]; }
 static void lc_prep_read_host(const lancet_params &P, const char *sq, const char *ql, int len, uint8_t label, uint8_t strand, uint8_t mate, uint8_t mapped,
                               uint32_t *rinfo, uint32_t *bases, uint32_t *good) {
-  int fg = 0; while (fg < len && !(lc_is_dna(sq[fg]) && !(ql[fg] < P.min_qual_trim))) ++fg;
-  int lg = len - 1; while (lg >= fg && !(lc_is_dna(sq[lg]) && !(ql[lg] < P.min_qual_trim))) --lg;
+  const uint8_t *tab = lc_tab.c;
+  const int qtrim = P.min_qual_trim, qcall = P.min_qual_call;
+  int fg = 0; while (fg < len && !(tab[(uint8_t)sq[fg]] < 4 && !(ql[fg] < qtrim))) ++fg;
+  int lg = len - 1; while (lg >= fg && !(tab[(uint8_t)sq[lg]] < 4 && !(ql[lg] < qtrim))) --lg;
   bool junk = fg >= len || lg < fg;
-  if (!junk) for (int p = fg; p <= lg; ++p) if (!lc_is_dna(sq[p])) { junk = true; break; }
+  if (!junk) { uint32_t any = 0; for (int p = fg; p <= lg; ++p) any |= tab[(uint8_t)sq[p]]; junk = (any & 4u) != 0; }
   const int trim5 = junk ? 0 : fg;
   int tlen = junk ? 0 : lg - fg + 1;
   if (tlen > 0xFFFF) tlen = 0xFFFF;
   *rinfo = (uint32_t)tlen | ((label == LANCET_NML ? 1u : 0u) << 16) | ((strand == LANCET_REV ? 1u : 0u) << 17) | ((uint32_t)(mate & 3) << 18) | ((mapped ? 1u : 0u) << 20);
-  const char *s = sq + trim5, *q = ql + trim5;
-  for (int wv = 0; wv < (tlen + 15) / 16; ++wv) {
-    uint32_t v = 0; const int n = std::min(16, tlen - wv * 16);
-    for (int j = 0; j < n; ++j) v |= (lc_code(s[wv * 16 + j]) & 3u) << (2 * j);
+  const uint8_t *s = (const uint8_t *)sq + trim5; const char *q = ql + trim5;
+  const int nfull = tlen / 16;
+  for (int wv = 0; wv < nfull; ++wv) {
+    const uint8_t *x = s + wv * 16; uint32_t v = 0;
+    for (int j = 0; j < 16; ++j) v |= (uint32_t)(tab[x[j]] & 3u) << (2 * j);
     bases[wv] = v;
   }
-  for (int wv = 0; wv < (tlen + 31) / 32; ++wv) {
-    uint32_t v = 0; const int n = std::min(32, tlen - wv * 32);
-    for (int j = 0; j < n; ++j) if (q[wv * 32 + j] >= P.min_qual_call) v |= 1u << j;
+  if (tlen & 15) { uint32_t v = 0; for (int j = 0; j < (tlen & 15); ++j) v |= (uint32_t)(tab[s[nfull * 16 + j]] & 3u) << (2 * j); bases[nfull] = v; }
+  const int gfull = tlen / 32;
+  for (int wv = 0; wv < gfull; ++wv) {
+    const char *x = q + wv * 32; uint32_t v = 0;
+    for (int j = 0; j < 32; ++j) v |= (uint32_t)(x[j] >= qcall) << j;
     good[wv] = v;
   }
+  if (tlen & 31) { uint32_t v = 0; for (int j = 0; j < (tlen & 31); ++j) v |= (uint32_t)(q[gfull * 32 + j] >= qcall) << j; good[gfull] = v; }
 }
 template <class F> static void lc_parallel(int threads, size_t n, F body) {       // body(lo, hi, t) over a static split of [0, n)
   if (threads <= 1 || n < 4096) { body((size_t)0, n, 0); return; }
@@ -271,10 +284,27 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return LANCET_E_NO_DEVICE;
   lancet_engine *e = new lancet_engine();
   e->params = *p; e->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
+  if (hipSetDevice(device) != hipSuccess) { delete e; return LANCET_E_HIP; }
+  if (getenv("LANCET_NO_SVC") || p->lr_mode || getenv("LANCET_NO_PREBUILD")) e->svc = false;
+  if (const char *s = getenv("LANCET_SVC_CUS")) e->svc_cus = std::max(0, std::min(64, atoi(s)));
+  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->n_cus = cus; }
+  if (!e->svc || e->svc_cus * 4 > e->n_cus) e->svc_cus = 0;
+  if (e->svc_cus) {
+    // Build service on its own CUs (spread over the device: every n_cus / svc_cus-th one); the batch's kernels on the others.
+    const uint32_t words = (uint32_t)((e->n_cus + 31) / 32);
+    std::vector<uint32_t> m_main(words, 0), m_svc(words, 0);
+    const int step = e->n_cus / e->svc_cus;
+    for (int c = 0; c < e->n_cus; ++c) { const bool sv = (c % step) == step / 2 && c / step < e->svc_cus; (sv ? m_svc : m_main)[(size_t)c >> 5] |= 1u << (c & 31); }
+    if (hipExtStreamCreateWithCUMask(&e->stream, words, m_main.data()) != hipSuccess || hipExtStreamCreateWithCUMask(&e->stream3, words, m_svc.data()) != hipSuccess) {
+      (void)hipGetLastError();
+      if (e->stream) { (void)hipStreamDestroy(e->stream); e->stream = nullptr; }
+      if (e->stream3) { (void)hipStreamDestroy(e->stream3); e->stream3 = nullptr; }
+      e->svc_cus = 0;
+    }
+  }
+  if ((!e->stream && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) || hipEventCreate(&e->ev0) != hipSuccess ||
       hipEventCreate(&e->ev1) != hipSuccess || hipEventCreate(&e->evb0) != hipSuccess || hipEventCreate(&e->evb1) != hipSuccess) { delete e; return LANCET_E_HIP; }
   if (getenv("LANCET_NO_PREBUILD")) e->prebuild = false;
-  if (getenv("LANCET_NO_SVC")) e->svc = false;
   if (const char *s = getenv("LANCET_PREP")) e->host_prep = strcmp(s, "device") != 0;
   if (const char *s = getenv("LANCET_PREP_THREADS")) e->prep_threads = std::max(1, atoi(s));
   e->dbg = getenv("LANCET_DEBUG") != nullptr; e->no_fat = getenv("LANCET_NO_FAT") != nullptr; e->no_early_rerun = getenv("LANCET_NO_EARLY_RERUN") != nullptr;
@@ -285,7 +315,8 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (const char *s = getenv("LANCET_SVC_DEPTH")) e->svc_depth = std::max(0, std::min(16, atoi(s)));
   if (p->lr_mode) e->prebuild = false;                         // --linked-reads: barcode / haplotype bookkeeping lives in the general build only
   if (const char *s = getenv("LANCET_TRACE_WORDS")) e->evt_cap = (uint32_t)atoi(s);
-  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->max_slots = cus * 20; }
+  e->max_slots = (e->n_cus - e->svc_cus) * 20;
+  if (e->svc_cus) e->n_svc_wgs = 2 * e->svc_cus;
   if (const char *s = getenv("LANCET_MAX_SLOTS")) e->max_slots = atoi(s);
   if (const char *s = getenv("LANCET_MEM_GB")) e->mem_budget = (size_t)atoi(s) << 30;
   if (const char *s = getenv("LANCET_MAX_NODES")) e->max_nodes_limit = (uint32_t)atoi(s);
@@ -357,7 +388,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   db.n_windows = nw;
   if (e->host_prep) {
     // One staging buffer, same layout on both sides: window arrays, per-read words, packed bases / quality masks, reference codes.
-    const int T = e->prep_threads > 0 ? e->prep_threads : (int)std::max(1u, std::min(48u, std::thread::hardware_concurrency()));
+    const int T = e->prep_threads > 0 ? e->prep_threads : (int)std::max(1u, std::min(96u, std::thread::hardware_concurrency()));
     const auto t_pack0 = std::chrono::steady_clock::now();
     std::vector<uint64_t> tb((size_t)T + 1, 0), tg((size_t)T + 1, 0);
     std::vector<char> bad((size_t)T, 0);
@@ -419,6 +450,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     h_rc[nref] = 0;
     if (e->params.lr_mode && R) { memcpy(H + o_bx, b->bx_rank, 4 * (size_t)R); memcpy(H + o_hp, b->hp, (size_t)R); }
     e->ms_pack = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_pack0).count();
+    if (e->dbg) fprintf(stderr, "[lancet] trim + pack on %d host threads: %.1f ms, %.1f MB to the device\n", T, e->ms_pack, total / 1048576.0);
     HIPCHK(e, hipMemcpyAsync(e->d_stage.p, e->h_stage, total, hipMemcpyHostToDevice, e->stream));
     char *D = (char *)e->d_stage.p;
     db.chr_id = (LC_GLOBAL const int32_t *)(D + o_chr); db.ref_start = (LC_GLOBAL const int32_t *)(D + o_rs);
@@ -510,7 +542,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
                         hipEventCreate(&e->evf1) != hipSuccess || hipEventCreate(&e->ev_ready) != hipSuccess)) { e->err = "second stream"; return LANCET_E_HIP; }
   }
   if (e->prebuild) {
-    int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
+    const int cus = e->n_cus - e->svc_cus;
     e->n_bslots = std::min(nw, cus * 2);
     if (e->build_slots_env) e->n_bslots = std::min(nw, e->build_slots_env);
     ENS(e->d_pre, (size_t)nw * PRE_STRIDE);
@@ -534,7 +566,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     const bool use_svc = e->svc && e->n_svc_wgs > 0 && !e->debug_stop;
     if (use_svc) e->pool_cap += (uint32_t)std::max(64, nw / 8);
     if (use_svc) {
-      if (!e->stream3 && (hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e->ev_svc) != hipSuccess)) { e->err = "service stream"; return LANCET_E_HIP; }
+      if ((!e->stream3 && hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess) || (!e->ev_svc && hipEventCreate(&e->ev_svc) != hipSuccess)) { e->err = "service stream"; return LANCET_E_HIP; }
       e->svc_cap = 2u * (uint32_t)nw + 1024u;
       const size_t off_req = 256, off_rdy = off_req + sizeof(SvcReq) * (size_t)e->svc_cap, off_cont = (off_rdy + 4u * (size_t)e->svc_cap + 63) & ~(size_t)63;
       ENS(e->d_svc, off_cont + sizeof(SvcCont) * (size_t)e->svc_cap);
@@ -642,6 +674,19 @@ static int lc_submit_body(lancet_engine *e) {
   return LANCET_OK;
 }
 
+// Two engines on one device, submitted in turn: the kernels of `e` start only when `prev`'s kernels are through.  Both of a batch's
+// kernels are persistent and sized for the whole device (LDS of every CU); side by side with the other batch's they only slow each other
+// down (measured: 61-68 ms per step overlapped, 57 one batch at a time, 54-55 back to back like this).  What the second engine buys is
+// that upload, launch and read-back of one batch run while the other's kernels do.
+int lancet_engine_submit_after(lancet_engine *e, lancet_engine *prev) {
+  if (!e) return LANCET_E_ARG;
+  if (prev && prev != e && prev->device == e->device && prev->submitted && prev->n_windows > 0) {
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamWaitEvent(e->stream, prev->ev1, 0));
+  }
+  return lancet_engine_submit(e);
+}
+
 int lancet_engine_submit(lancet_engine *e) {
   if (!e) return LANCET_E_ARG;
   if (!e->uploaded) { e->err = "run before upload"; return LANCET_E_STATE; }
@@ -657,7 +702,8 @@ int lancet_engine_submit(lancet_engine *e) {
   e->svc_running = false;
   if (e->svc_cap) {                // the build service takes its place on the GPU before the batch's kernels
     HIPCHK(e, hipMemsetAsync(e->d_svc.p, 0, 256 + (sizeof(SvcReq) + 4u) * (size_t)e->svc_cap, e->stream));
-    HIPCHK(e, hipMemcpyAsync(e->d_svc.p, &e->svc_host, sizeof(SvcCtl), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(svc_init_kernel, dim3(1), dim3(1), 0, e->stream, (SvcCtl *)e->d_svc.p, e->svc_host);
+    HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipEventRecord(e->ev_svc, e->stream));
     HIPCHK(e, hipStreamWaitEvent(e->stream3, e->ev_svc, 0));
     hipLaunchKernelGGL(svc_kernel, dim3(e->n_svc_wgs), dim3(bl_small::WG), 0, e->stream3, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
@@ -695,7 +741,7 @@ int lancet_engine_wait(lancet_engine *e) {
     e->svc_running = false;
     SvcCtl ct;
     HIPCHK(e, lc_copy(e, &ct, e->d_svc.p, sizeof(ct), hipMemcpyDeviceToHost));
-    e->svc_counts[0] = std::min(ct.req_alloc, ct.cap); e->svc_counts[1] = ct.n_built; e->svc_counts[2] = ct.n_failed; e->svc_counts[3] = ct.n_stolen;
+    e->svc_counts[0] = std::min(ct.req_alloc, ct.cap); e->svc_counts[1] = ct.n_built; e->svc_counts[2] = ct.n_failed; e->svc_counts[3] = ct.n_stolen; e->svc_counts[4] = ct.n_gaveup;
   }
   HIPCHK(e, hipEventElapsedTime(&e->ms_window, e->ev0, e->ev1));
   if (e->fat_inflight) {
@@ -751,8 +797,7 @@ int lancet_engine_wait(lancet_engine *e) {
     if (nv) HIPCHK(e, lc_copy(e, rawlr.data(), e->d_varlr.p, sizeof(lancet_variant_lr) * nv, hipMemcpyDeviceToHost));
     if (nx) HIPCHK(e, lc_copy(e, rawbx.data(), e->d_bxblob.p, sizeof(uint32_t) * nx, hipMemcpyDeviceToHost));
   }
-  e->phase.resize((size_t)e->n_windows * 16);
-  HIPCHK(e, lc_copy(e, e->phase.data(), e->d_phase.p, sizeof(unsigned long long) * e->phase.size(), hipMemcpyDeviceToHost));
+  e->phase.clear();                                   // (profiling data: fetched when lancet_engine_phase_times asks for it)
   if (e->caps.evt_cap) {
     e->evt_len.resize(e->n_windows); e->evt.resize((size_t)e->n_windows * e->caps.evt_cap);
     HIPCHK(e, lc_copy(e, e->evt_len.data(), e->d_evtlen.p, sizeof(uint32_t) * e->n_windows, hipMemcpyDeviceToHost));
@@ -898,6 +943,12 @@ int lancet_debug_align_mode(lancet_engine *e, const char *S, const char *T, char
 // profiling aid: per-window, per-phase time in 10 ns ticks (16 phases per window, see PHASE() in kernels.h)
 int lancet_engine_phase_times(lancet_engine *e, const unsigned long long **ticks) {
   if (!e || !e->ran) return LANCET_E_STATE;
+  if (e->phase.empty() && e->n_windows > 0) {
+    if (e->submitted) { e->err = "phase times while a batch is in flight"; return LANCET_E_STATE; }
+    HIPCHK(e, hipSetDevice(e->device));
+    e->phase.resize((size_t)e->n_windows * 16);
+    HIPCHK(e, lc_copy(e, e->phase.data(), e->d_phase.p, sizeof(unsigned long long) * e->phase.size(), hipMemcpyDeviceToHost));
+  }
   *ticks = e->phase.data();
   return LANCET_OK;
 }
@@ -944,6 +995,7 @@ int lancet_engine_ahead_counts(lancet_engine *e, int32_t *built, int32_t *used) 
 // build service of the last run: requests posted by the window kernel, served (graph built in LDS), not buildable there, taken back
 int lancet_engine_svc_counts(lancet_engine *e, uint32_t out[4]) {
   if (!e || !out) return LANCET_E_ARG;
+  if (e->dbg && e->svc_counts[4]) fprintf(stderr, "[lancet] %u service workgroups gave up waiting\n", e->svc_counts[4]);
   for (int i = 0; i < 4; ++i) out[i] = e->svc_counts[i];
   return LANCET_OK;
 }

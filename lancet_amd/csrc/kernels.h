@@ -4820,9 +4820,10 @@ DEV int window_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   LC_CTX_PUBLISH(c);
   LC_GLOBAL SvcCtl *sv = OUT->svc;
   int idle = 0;                                             // consecutive waits (a slot that has waited ~50 ms takes a request back whatever the service does)
+  bool waiting = false;                                     // this slot is counted in SvcCtl::n_waiting (uniform)
   while (true) {
     WG_LANE0 {
-      int a = 3, g = 0; bool got = false;                  // 0 new window, 1 resume (graph ready), 2 resume (request taken back), 3 leave, 4 wait
+      int a = 3, g = 0; bool got = false, just_registered = false;   // 0 new window, 1 resume (graph ready), 2 resume (request taken back), 3 leave, 4 wait, 5 wait (newly counted)
       if (sv) {
         const uint32_t h = ld2(&sv->rdy_head);
         if (h < sv->cap) {
@@ -4837,9 +4838,13 @@ DEV int window_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       }
       if (!got && sv) {
         uint32_t posted = ld2(&sv->req_alloc); if (posted > sv->cap) posted = sv->cap;
-        if (ld2(&sv->n_resumed) < posted) {
+        const uint32_t resumed = ld2(&sv->n_resumed);
+        if (resumed < posted) {
           a = 4;
-          if (ld2(&sv->alive) == 0u || idle > 20000) {      // no service workgroup runs: the general build after all
+          // Only as many slots wait as there are requests out: the rest leave, so that their share of the CU (LDS, wave slots) is
+          // free for the next batch's kernels while the last few windows of this one finish.
+          if (!waiting) { const uint32_t wv = dev_atomic_add(&sv->n_waiting, 1u); if (wv >= posted - resumed) { dev_atomic_add(&sv->n_waiting, 0xFFFFFFFFu); a = 3; } else { a = 5; just_registered = true; } }
+          if (a != 3 && (ld2(&sv->alive) == 0u || idle > 20000)) {      // no service workgroup runs: the general build after all
             for (uint32_t i = 0; i < posted; ++i)
               if (ld2(&sv->req[i].state) == SV_POSTED && dev_atomic_cas32(&sv->req[i].state, SV_POSTED, SV_STOLEN) == SV_POSTED) {
                 (void)ld_acq(&sv->req[i].state);
@@ -4848,12 +4853,15 @@ DEV int window_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
           }
         }
       }
+      if (sv && ((waiting && a != 4) || (!waiting && a == 2 && just_registered))) dev_atomic_add(&sv->n_waiting, 0xFFFFFFFFu);   // (got work, or leaves)
       S->act = a; S->act_arg = g;
     }
-    const int act = wg_bcast(&S->act), arg = wg_bcast(&S->act_arg);
+    int act = wg_bcast(&S->act); const int arg = wg_bcast(&S->act_arg);
+    if (act == 5) { waiting = true; act = 4; } else if (act != 4) waiting = false;
     if (act == 3) break;
     if (act == 4) {
 #ifdef LANCET_WAVE_EMU
+      if (waiting) sv->n_waiting -= 1u;                      // (the emulated slot comes back after the service has run)
       return 1;
 #else
       dev_sleep(); ++idle; continue;

@@ -271,7 +271,8 @@ struct SvcCtl {
   uint32_t cap;
   uint32_t beat;          /* bumped by the window slots at every window / k attempt: the service's sign that somebody else runs */
   uint32_t n_gaveup;      /* service workgroups that left because nothing else made progress (kernels serialised by a profiler)  */
-  uint32_t pad[3];
+  uint32_t n_waiting;     /* window slots that wait for a graph: never more than there are requests out (the others leave and free their CU) */
+  uint32_t pad[2];
   LC_GLOBAL SvcReq *req;          /* [cap] */
   LC_GLOBAL uint32_t *rdy;        /* [cap] request index + 1 */
   LC_GLOBAL SvcCont *cont;        /* [cap] */

@@ -38,6 +38,7 @@ def lib():
         L.lancet_engine_upload.argtypes = [C.c_void_p, C.POINTER(abi.LancetWindowBatch)]
         L.lancet_engine_run.argtypes = [C.c_void_p]
         L.lancet_engine_submit.argtypes = [C.c_void_p]
+        L.lancet_engine_submit_after.argtypes = [C.c_void_p, C.c_void_p]
         L.lancet_engine_wait.argtypes = [C.c_void_p]
         L.lancet_engine_process.argtypes = [C.c_void_p, C.POINTER(abi.LancetWindowBatch)]
         L.lancet_engine_results.argtypes = [C.c_void_p, C.POINTER(C.POINTER(abi.LancetVariant)), C.POINTER(C.c_uint32),
@@ -101,9 +102,13 @@ class Engine:
     def run(self) -> None:
         self._chk(self.L.lancet_engine_run(self.h))
 
-    def submit(self) -> None:
-        """Launch the kernels of the uploaded batch and return at once (collect with wait())."""
-        self._chk(self.L.lancet_engine_submit(self.h))
+    def submit(self, after: "Engine | None" = None) -> None:
+        """Launch the kernels of the uploaded batch and return at once (collect with wait()).  `after`: another engine on the same
+        device whose batch is in flight -- this batch's kernels then start when that one's build kernel is through."""
+        if after is not None and after is not self:
+            self._chk(self.L.lancet_engine_submit_after(self.h, after.h))
+        else:
+            self._chk(self.L.lancet_engine_submit(self.h))
 
     def wait(self) -> None:
         self._chk(self.L.lancet_engine_wait(self.h))
