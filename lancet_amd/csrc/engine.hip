@@ -190,7 +190,7 @@ struct lancet_engine {
   hipStream_t stream3 = nullptr; hipEvent_t ev_svc = nullptr;
   bool svc = true, svc_running = false;      // LANCET_NO_SVC=1 (at create): every later graph of a window by the general build
   int n_svc_wgs = 16; uint32_t svc_cap = 0; int svc_depth = 6;
-  int svc_cus = 8, n_cus = 256;                // CUs set aside for the service (CU masks on the two streams): its workgroups must be resident
+  int svc_cus = 0, n_cus = 256;                // LANCET_SVC_CUS=n: CUs set aside for the service (CU masks on the two streams), so that its workgroups are resident
                                              // whatever the batch's kernels -- or another engine's -- occupy; 0 = no masks
   SvcCtl svc_host;
   uint32_t svc_counts[5] = {0, 0, 0, 0, 0};  // posted, built, failed, stolen of the last run ; service workgroups that gave up waiting
@@ -531,9 +531,19 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   e->svc_cap = 0;
   e->pred.clear(); e->is_pred.assign(nw, 0);
   if (!e->debug_stop && !e->no_fat && !e->no_early_rerun) {
-    for (int w = 0; w < nw; ++w)                         // process_window's first test: more reads than a tier-1 slot holds
-      if (b->read_begin[w + 1] - b->read_begin[w] + 1 > e->caps.reads_cap) { e->pred.push_back((uint32_t)w); e->is_pred[w] = 1; }
-    if (e->pred.size() > 4096) { e->pred.clear(); e->is_pred.assign(nw, 0); }
+    for (int w = 0; w < nw; ++w) {
+      const uint32_t r0 = b->read_begin[w], r1 = b->read_begin[w + 1];
+      bool big = r1 - r0 + 1 > e->caps.reads_cap;        // process_window's first test: more reads than a tier-1 slot holds
+      // ... or more than the larger configuration of the LDS build kernel takes (65 520 bases with every read padded to 16, 1024 reads):
+      // its graphs would all come from the general build on ONE wave (tens of ms: the tail of the launch); the several-wave kernel of the
+      // re-run tier builds them in a few ms, next to everything else
+      if (!big && e->prebuild && !e->no_large_build) {
+        const uint64_t raw = (uint64_t)(b->seq_off[r1] - b->seq_off[r0]) + 8ull * (r1 - r0) + (b->ref_off[w + 1] - b->ref_off[w]) + 16u;    // (8: the mean padding)
+        big = raw > 65520ull || r1 - r0 > 1024u;
+      }
+      if (big) { e->pred.push_back((uint32_t)w); e->is_pred[w] = 1; }
+    }
+    if (e->pred.size() > 4096 || e->pred.size() * 4 > (size_t)nw) { e->pred.clear(); e->is_pred.assign(nw, 0); }     // (a batch of nothing but such windows: tier 1 keeps them)
   }
   if (!e->pred.empty()) {
     UP(e->d_skip, e->is_pred.data(), (size_t)nw);
@@ -680,7 +690,7 @@ static int lc_submit_body(lancet_engine *e) {
 // that upload, launch and read-back of one batch run while the other's kernels do.
 int lancet_engine_submit_after(lancet_engine *e, lancet_engine *prev) {
   if (!e) return LANCET_E_ARG;
-  if (prev && prev != e && prev->device == e->device && prev->submitted && prev->n_windows > 0) {
+  if (prev && prev != e && prev->device == e->device) {          // (an event never recorded, or long since reached, does not hold anything up)
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamWaitEvent(e->stream, prev->ev1, 0));
   }
@@ -977,7 +987,7 @@ int lancet_debug_pre_headers(lancet_engine *e, uint32_t *out) {
   std::vector<PreHdr> h(1);
   for (int w = 0; w < e->n_windows; ++w) {
     if (hipMemcpy(h.data(), (const uint8_t *)e->d_pre.p + (size_t)w * PRE_STRIDE + PRE_OFF_HDR, sizeof(PreHdr), hipMemcpyDeviceToHost) != hipSuccess) return LANCET_E_STATE;
-    out[8 * w] = h[0].status; out[8 * w + 1] = h[0].K; out[8 * w + 2] = h[0].heavy; out[8 * w + 3] = h[0].N;
+    out[8 * w] = h[0].status | (h[0].why << 8); out[8 * w + 1] = h[0].K; out[8 * w + 2] = h[0].heavy; out[8 * w + 3] = h[0].N;
     out[8 * w + 4] = h[0].nsurv; out[8 * w + 5] = h[0].numcomp; out[8 * w + 6] = h[0].ncand; out[8 * w + 7] = h[0].next;
   }
   return LANCET_OK;

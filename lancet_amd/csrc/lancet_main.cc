@@ -221,7 +221,9 @@ int main(int argc, char **argv) {
     sl.chunk = c; sl.nk = nk; sl.base = done; done += nk; sl.bxn.clear();
     if (ho.linked) { uint32_t nbx = 0; const char *const *bxn = lancet_host_bx_names(H, &nbx); for (uint32_t i = 0; i < nbx; ++i) sl.bxn.emplace_back(bxn[i]); }
     lancet_engine *e = sl.e;
-    sl.fut = std::async(std::launch::async, [e]() { return lancet_engine_run(e); });
+    // (the engine that took the chunk before this one: on the same GPU the two batches' kernels run back to back, not side by side)
+    lancet_engine *prev = (c > 0 && slots.size() > 1) ? slots[(size_t)(c - 1) % slots.size()].e : nullptr;
+    sl.fut = std::async(std::launch::async, [e, prev]() { const int rc = lancet_engine_submit_after(e, prev); return rc ? rc : lancet_engine_wait(e); });
     if (!flush()) return die(fail);
   }
   for (Slot &sl : slots) if (sl.fut.valid() && !finish(sl)) return die(fail);
