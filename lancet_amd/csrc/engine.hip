@@ -27,7 +27,10 @@ int lc_launch_window_fat(int slots, hipStream_t stream, const lancet_params *P, 
 // launch_bounds is deliberately 2x the launched size: with a provably single-wave workgroup the compiler turns
 // s_barrier into a no-op and then threads the lane-0 sections of consecutive phases together, which lets lane 0
 // run ahead of the other lanes (observed on gfx950: lanes 1..63 skipped whole phases).
-__global__ void __launch_bounds__(LANCET_WG * 2) __attribute__((amdgpu_waves_per_eu(5, 5))) window_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT) {
+#ifndef LC_W_EU
+#define LC_W_EU 4               /* waves per SIMD the window kernel is compiled for: 128 VGPRs, 16 slots per CU (5: 96 VGPRs and 2.4x the spills for the same kernel time; tools/variant.sh) */
+#endif
+__global__ void __launch_bounds__(LANCET_WG * 2) __attribute__((amdgpu_waves_per_eu(LC_W_EU, LC_W_EU))) window_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, Work *works, DevOut *OUT) {
   window_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL Work *)works, (LC_GLOBAL DevOut *)OUT, (LC_WS *)&lc_shared, (int)blockIdx.x);
 }
 
@@ -315,7 +318,7 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (const char *s = getenv("LANCET_SVC_DEPTH")) e->svc_depth = std::max(0, std::min(16, atoi(s)));
   if (p->lr_mode) e->prebuild = false;                         // --linked-reads: barcode / haplotype bookkeeping lives in the general build only
   if (const char *s = getenv("LANCET_TRACE_WORDS")) e->evt_cap = (uint32_t)atoi(s);
-  e->max_slots = (e->n_cus - e->svc_cus) * 20;
+  e->max_slots = (e->n_cus - e->svc_cus) * 4 * LC_W_EU;
   if (e->svc_cus) e->n_svc_wgs = 2 * e->svc_cus;
   if (const char *s = getenv("LANCET_MAX_SLOTS")) e->max_slots = atoi(s);
   if (const char *s = getenv("LANCET_MEM_GB")) e->mem_budget = (size_t)atoi(s) << 30;
