@@ -50,6 +50,11 @@ lancet_host *lancet_host_open(const char *tumor_bam, const char *normal_bam, con
 void lancet_host_close(lancet_host *h);
 const char *lancet_host_last_error(const lancet_host *h);
 
+/* --rg-file (Microassembler::loadRG, reference src/Microassembler.cc:29-48; applied at :302 and :616): only alignments whose RG tag is
+ * one of the whitespace-separated names in the file are used ("null" stands for an alignment without RG; an empty file keeps all).
+ * NULL / "": keep everything (the default).  Call before lancet_host_batch. */
+int lancet_host_set_rg_file(lancet_host *h, const char *path);
+
 /* SM of the first @RG line of the normal (which = 0) / tumor (which = 1) BAM, "NA" if there is none
  * (Microassembler::retriveSampleName, reference src/Microassembler.cc:52-67).  Valid after a tile call. */
 const char *lancet_host_sample(const lancet_host *h, int which);

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -39,6 +40,7 @@ struct Read {
   uint32_t seq_off, l_seq;    // into Sample::seq / qual (ASCII, phred+33)
   uint32_t name_off;          // into Sample::text (NUL terminated)
   uint32_t md_off, bx_off;    // into Sample::text (NUL terminated; bx "null" when absent)
+  uint32_t rg_off;            // RG:Z value in Sample::text, 0xFFFFFFFF when the alignment has no RG tag
   int32_t chr;                // index into lancet_host::chroms
 };
 
@@ -269,7 +271,7 @@ bool decode_record(const unsigned char *b, size_t bs, int chr, Sample *S, std::s
     else memset(qp, 0, (size_t)l_seq);       // unstored: bamtools fills (char)0xFF, negative = below every quality threshold; byte 0 is that for unsigned compares
     q += (size_t)l_seq;
   }
-  r.md_off = 0; r.bx_off = 0;
+  r.md_off = 0; r.bx_off = 0; r.rg_off = 0xFFFFFFFFu;
   std::string bx = "null";
   while (q + 3 <= end) {                              // tags
     const char k0 = (char)b[q], k1 = (char)b[q + 1], t = (char)b[q + 2];
@@ -306,6 +308,7 @@ bool decode_record(const unsigned char *b, size_t bs, int chr, Sample *S, std::s
     else if (k0 == 'X' && k1 == 'A' && isstr) r.has_xa = !sval.empty();
     else if (k0 == 'M' && k1 == 'D' && isstr) { r.has_md = 1; r.md_off = (uint32_t)S->text.size(); S->text.append(sval); S->text.push_back('\0'); }
     else if (k0 == 'B' && k1 == 'X' && isstr) { if (!sval.empty()) bx = sval; }
+    else if (k0 == 'R' && k1 == 'G' && isstr) { r.rg_off = (uint32_t)S->text.size(); S->text.append(sval); S->text.push_back('\0'); }
     else if (k0 == 'H' && k1 == 'P' && isnum) r.hp = num > 0 ? (int32_t)num : 0;
   }
   r.bx_off = (uint32_t)S->text.size(); S->text.append(bx); S->text.push_back('\0');
@@ -546,6 +549,8 @@ struct lancet_host {
   std::vector<uint8_t> b_label, b_strand, b_mate, b_mapped, b_hp;
   std::vector<std::string> bx_names;
   std::vector<const char *> bx_ptrs;
+  // --rg-file (Microassembler::loadRG, reference src/Microassembler.cc:29-48): the read groups to keep; {"null"} keeps everything (:716-721)
+  std::set<std::string> readgroups{"null"};
 };
 
 namespace {
@@ -580,8 +585,10 @@ void parse_md(const char *md, std::unordered_map<int, int> &M, int start, const 
 bool any_ge(const std::unordered_map<int, int> &m, int thr) { for (auto &kv : m) if (kv.second >= thr) return true; return false; }
 
 // isActiveRegion for one sample (label TMR / NML)
-bool is_active_region(const Sample &S, const Window &win, bool normal, const lancet_host_opts &o) {
+bool is_active_region(const Sample &S, const Window &win, bool normal, const lancet_host_opts &o, const std::set<std::string> &rgs) {
   const int mq = normal ? 0 : o.min_map_qual;
+  const bool rg_all = rgs.count("null") != 0;
+  std::string rg;                       // NOT cleared per alignment in the reference (:296): an alignment without RG keeps the previous one's
   std::unordered_map<int, int> mapX, mapI, mapD, mapSC;
   const std::pair<size_t, size_t> sp = (size_t)win.chr < S.span.size() ? S.span[(size_t)win.chr] : std::pair<size_t, size_t>(0, 0);
   size_t lo = (size_t)(std::lower_bound(S.starts.begin() + (long)sp.first, S.starts.begin() + (long)sp.second, win.start) - S.starts.begin());
@@ -594,6 +601,9 @@ bool is_active_region(const Sample &S, const Window &win, bool normal, const lan
     if (!(r.mapq >= mq && !(r.flag & 0x400))) continue;
     if (r.l_seq == 0) continue;        // QueryBases / Qualities empty (:293); unstored qualities (0xFF) are NOT empty in bamtools:
                                        // such reads still count with their CIGAR evidence, their MD mismatches never pass the quality test
+    if (r.rg_off != 0xFFFFFFFFu) rg = S.text.c_str() + r.rg_off;       // al.GetTag("RG", rg); if (rg.empty()) rg = "null";  (:296-297)
+    if (rg.empty()) rg = "null";
+    if (!(rg_all || rgs.count(rg))) continue;                            // :302 (everything below is inside that branch)
     if (r.has_md) parse_md(S.text.c_str() + r.md_off, mapX, alstart, S.qual.data() + r.seq_off, (int)r.l_seq, o.min_qual_call);
     int pos = alstart, refpos = alstart;
     for (uint32_t c = 0; c < r.n_cig; ++c) {
@@ -611,7 +621,8 @@ bool is_active_region(const Sample &S, const Window &win, bool normal, const lan
 }
 
 // extractReads for one sample; returns false when the window is to be skipped (coverage above --max-avg-cov)
-bool extract_reads(const Sample &S, const Window &win, bool normal, const lancet_host_opts &o, std::vector<Sel> *out) {
+bool extract_reads(const Sample &S, const Window &win, bool normal, const lancet_host_opts &o, const std::set<std::string> &rgs, std::vector<Sel> *out) {
+  const bool rg_all = rgs.count("null") != 0;
   int mq = o.min_map_qual; double min_delta = o.max_delta_as_xs;
   if (normal) { mq = 0; min_delta = -1; }
   long totalbp = 0;
@@ -633,6 +644,10 @@ bool extract_reads(const Sample &S, const Window &win, bool normal, const lancet
     if (std::fabs((double)r.as - (double)r.xs) <= min_delta && r.as != -1.f && r.xs != -1.f) continue;   // :535
     if (r.xt_is_R && !normal) continue;                                                             // :554-559
     if (r.has_xa && !normal && o.xa_filter) continue;                                               // :573-579
+    if (!rg_all) {                                                                                  // :611-616 (rg = ""; GetTag; empty -> "null")
+      const char *rg = r.rg_off != 0xFFFFFFFFu ? S.text.c_str() + r.rg_off : "";
+      if (!rgs.count(*rg ? rg : "null")) continue;
+    }
     out->push_back(Sel{(uint32_t)i, mate, strand, (uint8_t)((r.flag & 0x4) ? 0 : 1)});
     totalbp += (long)r.l_seq;
   }
@@ -684,6 +699,21 @@ const char *lancet_host_last_error(const lancet_host *h) { return h ? h->err.c_s
 const char *lancet_host_sample(const lancet_host *h, int which) { return h->smp[which ? 1 : 0].sample_name.c_str(); }
 const char *lancet_host_chrom(const lancet_host *h) { return h->chroms.empty() ? "" : h->chroms[0].c_str(); }
 const char *const *lancet_host_chroms(const lancet_host *h, int *n) { if (n) *n = (int)h->chrom_ptrs.size(); return h->chrom_ptrs.data(); }
+// --rg-file: Microassembler::loadRG (reference src/Microassembler.cc:29-48) -- whitespace-separated read-group names; an empty file
+// keeps everything ("null").  Call before the windows are batched.
+int lancet_host_set_rg_file(lancet_host *h, const char *path) {
+  if (!h) return LANCET_E_ARG;
+  h->readgroups.clear();
+  if (path && *path) {
+    FILE *fp = fopen(path, "r");
+    if (!fp) { h->err = std::string("cannot open read-group file '") + path + "'"; h->readgroups.insert("null"); return LANCET_E_ARG; }
+    char buf[4096];
+    while (fscanf(fp, "%4095s", buf) == 1) h->readgroups.insert(buf);
+    fclose(fp);
+  }
+  if (h->readgroups.empty()) h->readgroups.insert("null");
+  return LANCET_OK;
+}
 int lancet_host_first_has_md(const lancet_host *h, int which) { return h->smp[which ? 1 : 0].first_has_md; }
 const char *lancet_host_window_hdr(const lancet_host *h, int w) { return (w >= 0 && (size_t)w < h->windows.size()) ? h->windows[(size_t)w].hdr.c_str() : ""; }
 int lancet_host_window_chrom(const lancet_host *h, int w) { return (w >= 0 && (size_t)w < h->windows.size()) ? h->windows[(size_t)w].chr : -1; }
@@ -837,9 +867,9 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
         const Window &win = h->windows[(size_t)(w_begin + i)];
         if (win.seq.empty()) continue;          // isNseq (:799, src/util.cc:259-273): its test `!= 'N' || != 'n'` holds for every character, so only an EMPTY window is "all N"
         if (is_repeat(win.seq, o->max_k)) continue;                                                   // :800
-        if (o->active_region && !(is_active_region(h->smp[1], win, false, *o) || is_active_region(h->smp[0], win, true, *o))) continue;   // :817-820
-        const bool okT = extract_reads(h->smp[1], win, false, *o, &selT[(size_t)i]);
-        const bool okN = extract_reads(h->smp[0], win, true, *o, &selN[(size_t)i]);      // (both samples are read before the skip test, :833-836)
+        if (o->active_region && !(is_active_region(h->smp[1], win, false, *o, h->readgroups) || is_active_region(h->smp[0], win, true, *o, h->readgroups))) continue;   // :817-820
+        const bool okT = extract_reads(h->smp[1], win, false, *o, h->readgroups, &selT[(size_t)i]);
+        const bool okN = extract_reads(h->smp[0], win, true, *o, h->readgroups, &selN[(size_t)i]);      // (both samples are read before the skip test, :833-836)
         keep[(size_t)i] = (okT && okN) ? 1 : 2;                                        // 2: skipped for coverage -> g.clear(true)
         uint64_t nb = 0; uint8_t mp = 0;
         for (const Sel &s : selT[(size_t)i]) { nb += h->smp[1].reads[s.idx].l_seq; mp |= s.mapped; }

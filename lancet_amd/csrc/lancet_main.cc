@@ -8,7 +8,7 @@
 // go to the engines in turn while the host prepares the next one; records reach the VariantDB in window order whatever
 // the number of engines), --strict (no VCF at all when a window exceeded the engine's work space; by default the run
 // finishes, the windows are listed on stderr and the exit code is 3).
-// Not offered: --rg-file, --kmer-recovery, --print-graph; --num-threads is accepted and ignored (windows are
+// Not offered: --kmer-recovery, --print-graph; --num-threads is accepted and ignored (windows are
 // batched on the GPU); -v prints the reference's per-window stage trace to stderr.
 #include "../../include/lancet_host.h"
 
@@ -24,7 +24,7 @@
 namespace {
 struct Opt { const char *lng; char shrt; int has_arg; };
 const Opt OPTS[] = {
-  {"tumor", 't', 1}, {"normal", 'n', 1}, {"ref", 'r', 1}, {"reg", 'p', 1}, {"bed", 'B', 1}, {"min-k", 'k', 1}, {"max-k", 'K', 1},
+  {"tumor", 't', 1}, {"normal", 'n', 1}, {"ref", 'r', 1}, {"reg", 'p', 1}, {"bed", 'B', 1}, {"rg-file", 'g', 1}, {"min-k", 'k', 1}, {"max-k", 'K', 1},
   {"trim-lowqual", 'q', 1}, {"min-base-qual", 'C', 1}, {"quality-range", 'Q', 1}, {"min-map-qual", 'b', 1},
   {"max-as-xs-diff", 'Z', 1}, {"tip-len", 'l', 1}, {"cov-thr", 'c', 1}, {"cov-ratio", 'x', 1}, {"low-cov", 'd', 1},
   {"max-avg-cov", 'u', 1}, {"window-size", 'w', 1}, {"padding", 'P', 1}, {"dfs-limit", 'F', 1}, {"max-indel-len", 'T', 1},
@@ -42,7 +42,7 @@ void usage() {
         "   --window-size, -w  <int>   : at most 640 bp (the engine's per-window tables; the reference default is 600)\n"
         "   --max-k, -K        <int>   : at most 127; --min-k at least 3; --max-unit-length at most 8\n"
         "   --num-threads, -X  <int>   : accepted and ignored (windows are batched on the GPU)\n"
-        "   --rg-file, --kmer-recovery, --print-graph, --node-str-len, --more-verbose, --print-config-file: not offered\n"
+        "   --kmer-recovery, --print-graph, --node-str-len, --more-verbose, --print-config-file: not offered\n"
         "Additional options:\n"
         "   --device <n> | --devices a,b,...  : GPU(s) to use; an entry may repeat (two engines on one GPU overlap the upload of a\n"
         "                                       batch with the kernels of the previous one)\n"
@@ -55,7 +55,7 @@ void usage() {
 }  // namespace
 
 int main(int argc, char **argv) {
-  std::string tumor, normal, ref, reg, bed, qrange = "!", date_line, devices;
+  std::string tumor, normal, ref, reg, bed, qrange = "!", date_line, devices, rg_file;
   int min_k = 11, max_k = 101, trim_lowqual = 10, min_base_qual = 17, tip_len = 11, cov_thr = 5, low_cov = 1, dfs_limit = 1000000;
   int max_indel_len = 500, max_mismatch = 2, max_unit_length = 4, min_report_unit = 3, min_report_len = 7, dist_from_str = 1;
   int device = 0, batch_windows = 32768, verbose = 0, strict = 0;
@@ -88,7 +88,7 @@ int main(int argc, char **argv) {
     else if (L == "min-report-unit") min_report_unit = atoi(v); else if (L == "min-report-len") min_report_len = atoi(v); else if (L == "dist-from-str") dist_from_str = atoi(v);
     else if (L == "linked-reads") ho.linked = 1; else if (L == "primary-alignment-only") ho.primary_alignment_only = 1; else if (L == "XA-tag-filter") ho.xa_filter = 1;
     else if (L == "active-region-off") ho.active_region = 0; else if (L == "verbose") verbose = 1; else if (L == "device") device = atoi(v); else if (L == "devices") devices = v; else if (L == "batch-windows") batch_windows = atoi(v);
-    else if (L == "date-line") date_line = v; else if (L == "bed") bed = v; else if (L == "strict") strict = 1;
+    else if (L == "date-line") date_line = v; else if (L == "bed") bed = v; else if (L == "rg-file") rg_file = v; else if (L == "strict") strict = 1;
     else if (L == "help") { usage(); return 0; }
   }
   if (tumor.empty() || normal.empty() || ref.empty() || (reg.empty() && bed.empty())) { usage(); return die("--tumor, --normal, --ref and a region (--reg) or BED file (--bed) are required"); }
@@ -122,6 +122,7 @@ int main(int argc, char **argv) {
   }
   char err[512] = "";
   lancet_host *H = lancet_host_open(tumor.c_str(), normal.c_str(), ref.c_str(), err, sizeof err);
+  if (H && !rg_file.empty() && lancet_host_set_rg_file(H, rg_file.c_str()) != LANCET_OK) return die(lancet_host_last_error(H));
   if (!H) return die(err);
   const double t_tile0 = now();
   const char *regs[1] = {reg.c_str()};

@@ -41,6 +41,7 @@ def _lib():
         L.lancet_host_chroms.restype = C.POINTER(C.c_char_p)
         L.lancet_host_chroms.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.lancet_host_first_has_md.argtypes = [C.c_void_p, C.c_int]
+        L.lancet_host_set_rg_file.argtypes = [C.c_void_p, C.c_char_p]
         L.lancet_host_window_chrom.argtypes = [C.c_void_p, C.c_int]
         L.lancet_host_window_span.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.lancet_host_window_hdr.restype = C.c_char_p
@@ -80,6 +81,11 @@ class NativeHost:
 
     def sample(self, tumor: bool) -> str:
         return self.L.lancet_host_sample(self.h, 1 if tumor else 0).decode()
+
+    def set_rg_file(self, path: Optional[str]) -> None:
+        """--rg-file: keep only the alignments of the read groups named in the file (None: all)."""
+        if self.L.lancet_host_set_rg_file(self.h, path.encode() if path else None) != 0:
+            raise engine.EngineError(self.L.lancet_host_last_error(self.h).decode())
 
     def tile(self, region: str, opts: LancetHostOpts) -> List[str]:
         n = self.L.lancet_host_tile(self.h, region.encode(), C.byref(opts))

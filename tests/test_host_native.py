@@ -249,6 +249,50 @@ def test_read_filters_against_a_reference_run_with_the_filters_engaged(case):
     H.close()
 
 
+def test_read_group_filter_against_a_reference_run_with_rg_file():
+    """`rg_small` (tools/make_filter_golden.py): the reference with --rg-file naming two of three read groups, on reads that carry
+    RG:Z:rgA / rgB / rgC or no RG tag, active regions on (loadRG and its two uses, reference src/Microassembler.cc:29-48, :296-302,
+    :611-616).  The native host side selects exactly the reference's windows and read counts; the oracle on that batch reproduces
+    the reference's VCF and stage trace; without the file the selection differs (the filter is not a no-op on this input)."""
+    import re
+    from oracle import oracle
+    from lancet_amd import abi, engine
+    case, region = "rg_small", "chr22:900-3100"
+    paths = [os.path.join(G, f"{case}.tumor.bam"), os.path.join(G, f"{case}.normal.bam"), os.path.join(G, f"{case}.fa")]
+    o = host.default_opts()
+    ref_trace = gu.golden_trace(case)
+    want = [(m.group(1), int(m.group(2)), int(m.group(3))) for m in re.finditer(r"== Processing \d+: (\S+) numsequences: (\d+) mapped: (\d+)", ref_trace)]
+    got = {}
+    for rg in (os.path.join(G, f"{case}.rg.txt"), None):
+        H = host.NativeHost(*paths)
+        H.set_rg_file(rg)
+        hdrs = H.tile(region, o)
+        b, idx = H.batch(0, len(hdrs), o)
+        nr = np.diff(b.read_begin.astype(np.int64))
+        got[rg] = [(b.hdr[w], int(nr[w]), int(b.mapped[b.read_begin[w]:b.read_begin[w + 1]].sum())) for w in range(b.n_windows)]
+        if rg:
+            assert len(want) > 15 and got[rg] == want
+            p = abi.default_params()
+            ov, ost, otr = oracle.run(b, p, verbose=True)
+            db = engine.VariantDB()
+            db.add_records(ov, ["chr22"])
+            assert db.vcf(sample_normal="NORMAL", sample_tumor="TUMOR") == gu.golden_vcf(case)
+            assert gu.digest_trace(otr) == gu.digest_trace(ref_trace)
+        H.close()
+    assert got[None] != want and sum(n for _, n, _ in got[None]) > 1.3 * sum(n for _, n, _ in want)
+
+
+@pytest.mark.gpu
+def test_lancet_gpu_with_rg_file_equals_the_reference():
+    case = "rg_small"
+    r = subprocess.run([build.BIN, "--tumor", os.path.join(G, f"{case}.tumor.bam"), "--normal", os.path.join(G, f"{case}.normal.bam"),
+                        "--ref", os.path.join(G, f"{case}.fa"), "--reg", "chr22:900-3100", "-v", "--rg-file", os.path.join(G, f"{case}.rg.txt")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _body(r.stdout) == gu.golden_vcf(case)
+    assert gu.digest_trace(r.stderr) == gu.digest_trace(gu.golden_trace(case))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", sorted(FLT_CASES))
 def test_lancet_gpu_with_the_read_filters_engaged_equals_the_reference(case):

@@ -30,6 +30,10 @@ CASES = {
     # every read that starts in [1500, 2250) carries the unmapped flag: the window chr22:1550-2150 holds no mapped read, the
     # reference's processGraph returns before g.clear() (src/Microassembler.cc:83) and its reads are still in the graph when
     # the next window is loaded
+    # --rg-file (reference src/Microassembler.cc:29-48, 296-302, 611-616): reads carry RG:Z:rgA / rgB / rgC or no RG at all, the file
+    # names rgA and rgC; active regions on (isActiveRegion reads the tag without clearing the previous read's value)
+    "rg_small": (dict(ref_len=4000, cov_t=44, cov_n=36, ref_seed=77, tumor_seed=177, normal_seed=277, somatic_every=600, germline_every=500),
+                 False, ["--rg-file", "RGFILE"], "chr22:900-3100"),
     "leak_small": (dict(ref_len=4000, cov_t=30, cov_n=26, ref_seed=75, tumor_seed=175, normal_seed=275, somatic_every=500, germline_every=400),
                    False, ["--active-region-off"], "chr22:1000-3000"),
 }
@@ -43,6 +47,17 @@ if __name__ == "__main__":
     if NAME == "leak_small":
         unmap = lambda rs: [synth.SamRead(r.qname, r.flag | (0x4 if 1500 <= r.pos - 1 < 2250 else 0), r.rname, r.pos, r.mapq, r.cigar, r.seq, r.qual, r.tags) for r in rs]
         reads = {"tumor": unmap(synth.pairs_to_sorted_reads(data["tumor"])), "normal": unmap(synth.pairs_to_sorted_reads(data["normal"]))}
+    elif NAME == "rg_small":
+        def tag_rg(rs):
+            out = []
+            for r in rs:
+                tags = dict(r.tags); u = rng.random()
+                if u < 0.45: tags["RG"] = "rgA"
+                elif u < 0.70: tags["RG"] = "rgB"
+                elif u < 0.85: tags["RG"] = "rgC"
+                out.append(synth.SamRead(r.qname, r.flag, r.rname, r.pos, r.mapq, r.cigar, r.seq, r.qual, tags))
+            return out
+        reads = {"tumor": tag_rg(synth.pairs_to_sorted_reads(data["tumor"])), "normal": tag_rg(synth.pairs_to_sorted_reads(data["normal"]))}
     else:
         reads = {"tumor": read_variety.decorate(synth.pairs_to_sorted_reads(data["tumor"]), rng, linked),
                  "normal": read_variety.decorate(synth.pairs_to_sorted_reads(data["normal"]), rng, linked)}
@@ -54,12 +69,15 @@ if __name__ == "__main__":
         for sample, rg in (("TUMOR", "tumor"), ("NORMAL", "normal")):
             sam, bam = os.path.join(td, f"{rg}.sam"), os.path.join(td, f"{rg}.bam")
             with open(sam, "w") as f:
-                f.write("\n".join(["@HD\tVN:1.6\tSO:coordinate", f"@SQ\tSN:{rname}\tLN:{len(ref)}", f"@RG\tID:{rg}\tSM:{sample}\tPL:ILLUMINA"]
+                extra_rg = [f"@RG\tID:{x}\tSM:{sample}\tPL:ILLUMINA" for x in ("rgA", "rgB", "rgC")] if NAME == "rg_small" else []
+                f.write("\n".join(["@HD\tVN:1.6\tSO:coordinate", f"@SQ\tSN:{rname}\tLN:{len(ref)}", f"@RG\tID:{rg}\tSM:{sample}\tPL:ILLUMINA"] + extra_rg
                                   + [read_variety.sam_line(r) for r in reads[rg]]) + "\n")
             mg.run([mg.TEST_VIEW, "-b", "-p", bam, sam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             mg.run([mg.BAMTOOLS, "index", "-in", bam])
             bams[rg] = bam
-        cmd = [mg.REF_BIN, "--tumor", bams["tumor"], "--normal", bams["normal"], "--ref", fa, "--reg", REGION, "--num-threads", "1", "-v"] + FLAGS
+        rgfile = os.path.join(td, "rg.txt")
+        open(rgfile, "w").write("rgA\nrgC\n")
+        cmd = [mg.REF_BIN, "--tumor", bams["tumor"], "--normal", bams["normal"], "--ref", fa, "--reg", REGION, "--num-threads", "1", "-v"] + [rgfile if x == "RGFILE" else x for x in FLAGS]
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=td)
         if r.returncode != 0:
             sys.stderr.write(r.stderr[-3000:])
@@ -67,6 +85,8 @@ if __name__ == "__main__":
         for rg in ("tumor", "normal"):
             shutil.copy(bams[rg], os.path.join(mg.GOLDEN, f"{NAME}.{rg}.bam"))
         shutil.copy(fa, os.path.join(mg.GOLDEN, f"{NAME}.fa"))
+        if NAME == "rg_small":
+            shutil.copy(rgfile, os.path.join(mg.GOLDEN, f"{NAME}.rg.txt"))
     vcf = "".join(l + "\n" for l in r.stdout.splitlines()
                   if not l.startswith("##fileDate") and not l.startswith("##cmdline") and not l.startswith("##reference"))
     open(os.path.join(mg.GOLDEN, f"{NAME}.vcf"), "w").write(vcf)
