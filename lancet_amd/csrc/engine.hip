@@ -379,7 +379,8 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   const uint32_t nref = nw ? b->ref_off[nw] : 0;
   e->n_windows = nw; e->n_reads = (int)R;
   if (nw == 0) { e->uploaded = true; return LANCET_OK; }
-  for (int w = 0; w < nw; ++w) if (b->ref_off[w + 1] - b->ref_off[w] > LC_MAXW) { e->err = "window longer than LC_MAXW"; return LANCET_E_UNSUPPORTED; }
+  // (a window longer than LC_MAXW, or with more than 65 535 reads, does not fail the batch: process_window reports it LANCET_W_OVERFLOW
+  //  on its own and every other window is assembled)
   e->caps = lc_caps_for_batch(b, &e->params, e->evt_cap, e->node_cap1, 1);
   e->caps2 = lc_caps_for_batch(b, &e->params, e->evt_cap, e->max_nodes_limit, 2);
   e->caps2.var_cap = e->caps.var_cap; e->caps2.blob_cap = e->caps.blob_cap; e->caps2.bx_cap = e->caps.bx_cap;
@@ -399,7 +400,11 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
       uint64_t bo = 0, go = 0; char bd = 0;
       for (size_t r = lo; r < hi; ++r) {
         const uint32_t len = b->seq_off[r + 1] - b->seq_off[r]; bo += (len + 15) / 16; go += (len + 31) / 32;
-        if (b->name_rank[r] > 0xFFFFu) bd = 1;
+        if (b->name_rank[r] > 0xFFFFu) {              // fine in a window of more than 65 535 reads (reported as an overflow of that window), else not a dense rank
+          const uint32_t *ub = std::upper_bound(b->read_begin, b->read_begin + nw + 1, (uint32_t)r);
+          const size_t w = (size_t)(ub - b->read_begin) - 1;
+          if (b->read_begin[w + 1] - b->read_begin[w] <= 0xFFFFu) bd = 1;
+        }
         if (e->params.lr_mode && b->hp[r] > 2) bd = 2;
       }
       tb[(size_t)t + 1] = bo; tg[(size_t)t + 1] = go; bad[(size_t)t] = bd;
@@ -462,7 +467,11 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     db.good_woff = (LC_GLOBAL const uint32_t *)(D + o_gw); db.bases = (LC_GLOBAL const uint32_t *)(D + o_ba); db.good = (LC_GLOBAL const uint32_t *)(D + o_go);
     db.bx_rank = e->params.lr_mode ? (LC_GLOBAL const uint32_t *)(D + o_bx) : nullptr; db.hp = e->params.lr_mode ? (LC_GLOBAL const uint8_t *)(D + o_hp) : nullptr;
   } else {
-  for (uint32_t r = 0; r < R; ++r) if (b->name_rank[r] > 0xFFFFu) { e->err = "name_rank must be the dense per-window rank (< 65536)"; return LANCET_E_ARG; }
+  for (uint32_t r = 0; r < R; ++r) if (b->name_rank[r] > 0xFFFFu) {
+    const uint32_t *ub = std::upper_bound(b->read_begin, b->read_begin + nw + 1, r);
+    const size_t w = (size_t)(ub - b->read_begin) - 1;
+    if (b->read_begin[w + 1] - b->read_begin[w] <= 0xFFFFu) { e->err = "name_rank must be the dense per-window rank (< 65536)"; return LANCET_E_ARG; }
+  }
   if (e->params.lr_mode) for (uint32_t r = 0; r < R; ++r) if (b->hp[r] > 2) { e->err = "hp must be 0, 1 or 2"; return LANCET_E_ARG; }   // Node_t::addHP indexes a 3-array (src/Node.cc:54-57)
   UP(e->d_chr, b->chr_id, sizeof(int32_t) * nw);
   UP(e->d_refstart, b->ref_start, sizeof(int32_t) * nw);

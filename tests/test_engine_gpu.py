@@ -334,3 +334,38 @@ def test_host_and_device_trim_and_pack_agree(monkeypatch):
         assert out[0] == out[1]
         ov, ost, _ = oracle.run(b, p)
         assert out[0][0] == ov
+
+
+def test_a_window_beyond_the_engine_limits_fails_alone():
+    """One window of 700 bp (LC_MAXW is 640) and one with 70 000 reads (read ids are 16 bit) inside an ordinary batch: they are reported
+    LANCET_W_OVERFLOW on their own; the batch is not refused and every other window equals the oracle."""
+    from lancet_amd import frontend, workload
+    p = abi.default_params()
+    b = workload.make_scan_batch(24, 20, 20, seed=9, read_len=100)
+    # window 5: 100 more reference bases
+    ref = bytearray(b.ref_bases.tobytes()); cut = int(b.ref_off[6])
+    ref[cut:cut] = (b"ACGT" * 25)
+    ref_off = b.ref_off.astype(np.int64).copy(); ref_off[6:] += 100
+    # window 11: its reads 400 times over (70 k reads, names ranked densely)
+    r0, r1 = int(b.read_begin[11]), int(b.read_begin[12]); n = r1 - r0; times = 70000 // n + 1
+    lens = np.diff(b.seq_off.astype(np.int64))
+    def rep(a, per_read=True):
+        mid = np.tile(a[r0:r1], times)
+        return np.concatenate([a[:r0], mid, a[r1:]])
+    s0, s1 = int(b.seq_off[r0]), int(b.seq_off[r1])
+    seq = np.concatenate([b.seq[:s0], np.tile(b.seq[s0:s1], times), b.seq[s1:]]); qual = np.concatenate([b.qual[:s0], np.tile(b.qual[s0:s1], times), b.qual[s1:]])
+    lens2 = np.concatenate([lens[:r0], np.tile(lens[r0:r1], times), lens[r1:]])
+    seq_off = np.concatenate([[0], np.cumsum(lens2)]).astype(np.uint32)
+    name = np.concatenate([b.name_rank[:r0], (np.arange(n * times) // 1).astype(np.uint32), b.name_rank[r1:]])
+    read_begin = b.read_begin.astype(np.int64).copy(); read_begin[12:] += n * (times - 1)
+    big = frontend.WindowBatch(n_windows=b.n_windows, hdr=b.hdr, chrom=b.chrom, chr_id=b.chr_id, ref_start=b.ref_start, ref_off=ref_off.astype(np.uint32),
+                               ref_bases=np.frombuffer(bytes(ref), dtype=np.uint8), read_begin=read_begin.astype(np.uint32), seq_off=seq_off, seq=seq, qual=qual,
+                               label=rep(b.label), strand=rep(b.strand), mate=rep(b.mate), mapped=rep(b.mapped), name_rank=name)
+    eng = engine.Engine(p)
+    v, st = eng.process(big)
+    assert st[5]["status"] < 0 and st[11]["status"] < 0
+    ov, ost, _ = oracle.run(b, p)
+    keep = [w for w in range(b.n_windows) if w not in (5, 11)]
+    assert all(st[w]["status"] >= 0 for w in keep)
+    assert [x for x in v if x["window"] in keep] == [x for x in ov if x["window"] in keep]
+    eng.close()
