@@ -41,8 +41,9 @@ struct BlScratch {
   LC_GLOBAL uint32_t *s_ci;         /* [PB_SCAP] candidate of survivor si                                        */
   LC_GLOBAL uint32_t *s_edges;      /* [PB_SCAP * 9] resolved edges + count                                      */
   LC_GLOBAL uint16_t *dupo;         /* [BL_DUPCAP] occurrences that met their k-mer in the other orientation, or twice in one read */
+  LC_GLOBAL uint32_t *ord;          /* [4 * PB_CMAX] bl_compress_first: the merged k-mers' coverages in merge order (4 floats each) */
 };
-static constexpr uint32_t SCRATCH_BYTES = (2u * BL_BASES + 64u + 8u * BL_TCAP + 4u * BL_TCAP + 12u * PB_CCAP + 4u * PB_SCAP + 36u * PB_SCAP + 2u * BL_DUPCAP + 640u);
+static constexpr uint32_t SCRATCH_BYTES = (2u * BL_BASES + 64u + 8u * BL_TCAP + 4u * BL_TCAP + 12u * PB_CCAP + 4u * PB_SCAP + 36u * PB_SCAP + 2u * BL_DUPCAP + 16u * PB_CMAX + 704u);
 static constexpr int WG = BL_WG;
 DEV void bl_scratch_carve(BlScratch *s, LC_GLOBAL uint8_t *base) {
   size_t o = 0;
@@ -56,6 +57,7 @@ DEV void bl_scratch_carve(BlScratch *s, LC_GLOBAL uint8_t *base) {
   s->s_ci = (LC_GLOBAL uint32_t *)take(4u * PB_SCAP);
   s->s_edges = (LC_GLOBAL uint32_t *)take(36u * PB_SCAP);
   s->dupo = (LC_GLOBAL uint16_t *)take(2u * BL_DUPCAP);
+  s->ord = (LC_GLOBAL uint32_t *)take(16u * PB_CMAX);
 }
 
 static_assert(sizeof(BlShared) <= BL_LDS_LIMIT, "LDS of the build kernel: 2 x 80 KB (512 lanes) or 1 x 160 KB (1024 lanes) per CU");
@@ -165,6 +167,401 @@ template <class F> DEV void bl_for_occ(BL_S &S, LC_GLOBAL const uint16_t *occn, 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// markRefEnds (reference src/Graph.cc:2028-2228) and the first Graph_t::compress (:2486-2732) of a single-component first graph,
+// in LDS by the whole workgroup -- what the window kernel otherwise does on one wave over HBM (kernels.h mark_ref_scan /
+// mark_ref_ends / compress_prepare / compress_rank, whose results this reproduces field for field).  Nodes are addressed by their
+// position in the table order after cleanDead (0 .. nsurv-1; the source is nsurv, the sink nsurv + 1); an edge is 16 bits:
+// neighbour position [9:0], direction [11:10].  Returns with PreCmp::done = 1 and
+//   * the records of the live nodes rewritten in the hand-off area (unitig heads: coverage by the reference's float recurrence in merge
+//     order, minima, flags, new edge list, new descriptor deque in CSEQ; the others: edges redirected to the heads; the two special nodes),
+//   * CLIVE = the table order after the two insertions and cleanDead,
+// or with done = 0 and nothing touched (no unambiguous source / sink, a ring, an irregular link, more than 8 edges on a node, a
+// table that would be rehashed by the insertions, too many heads / descriptors): the window kernel then does all of it itself.
+// ---------------------------------------------------------------------------------------------------------
+#define BLC_TO(e) ((uint32_t)(e) & 0x3FFu)
+#define BLC_DIR(e) (((uint32_t)(e) >> 10) & 3u)
+#define BLC_MAKE(to, dir) ((uint16_t)((to) | ((dir) << 10)))
+DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const EngineCaps *C, BL_S &S, BlScratch &X, LC_GLOBAL uint8_t *area, const int K,
+                             const uint32_t N, const uint32_t nsurv, const uint32_t ncand, const int reflen, const uint32_t ht_bc) {
+  LC_GLOBAL PreCmp *CH = (LC_GLOBAL PreCmp *)(area + PRE_OFF_CHDR);
+  LC_GLOBAL const uint32_t *occ_ref = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_OCCREF);
+  LC_GLOBAL const unsigned long long *nhash = (LC_GLOBAL const unsigned long long *)(area + PRE_OFF_NHASH);
+  LC_GLOBAL const unsigned long long *skey = (LC_GLOBAL const unsigned long long *)(area + PRE_OFF_SKEY);
+  LC_GLOBAL const uint32_t *sidv = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_SID);
+  LC_GLOBAL NodeGr *pgr = (LC_GLOBAL NodeGr *)(area + PRE_OFF_PGR);
+  LC_GLOBAL const uint16_t *qv = (LC_GLOBAL const uint16_t *)(area + PRE_OFF_QV);
+  LC_GLOBAL uint32_t *clive = (LC_GLOBAL uint32_t *)(area + PRE_OFF_CLIVE);
+  LC_GLOBAL uint32_t *cseq = (LC_GLOBAL uint32_t *)(area + PRE_OFF_CSEQ);
+  const uint32_t Pn = nsurv + 2u, SRC = nsurv, SNK = nsurv + 1u;
+  // ---- LDS arena (the reads are done with; pos2si of the component search stays where it is, at byte 70304)
+  LC_LDS uint8_t *arena = (LC_LDS uint8_t *)&S.bases[0];
+  LC_LDS uint16_t *pos2si = (LC_LDS uint16_t *)(arena + 70304);
+  LC_LDS uint16_t *E = (LC_LDS uint16_t *)arena;                               // [Pn][8]
+  LC_LDS uint8_t *NE = arena + 13376;                                          // [Pn]
+  LC_LDS uint8_t *FL = arena + 14272;                                          // [Pn] 1 tumor, 2 normal, 4 source, 8 sink, 16 absorbed
+  LC_LDS uint16_t *SI2POS = (LC_LDS uint16_t *)(arena + 15168);                // [nsurv]
+  LC_LDS uint32_t *LNK = (LC_LDS uint32_t *)(arena + 16896);                   // [Pn][2]
+  LC_LDS unsigned long long *PT = (LC_LDS unsigned long long *)(arena + 23616);   // [2 Pn] port records (kernels.h pr_pack)
+  LC_LDS uint32_t *HS = (LC_LDS uint32_t *)(arena + 36992);                    // [Pn + 1]
+  LC_LDS uint32_t *AL = (LC_LDS uint32_t *)(arena + 40384);                    // [Pn + 1]
+  LC_LDS uint16_t *HEADOF = (LC_LDS uint16_t *)(arena + 43776);                // [Pn] head (position) of an absorbed node
+  LC_LDS uint8_t *INFO = arena + 45504;                                        // [Pn] 1 | frame flipped << 1 | entering direction << 2
+  LC_LDS uint16_t *HX = (LC_LDS uint16_t *)(arena + 46400);                    // [Pn] index of a head in the head list
+  LC_LDS uint16_t *HL = (LC_LDS uint16_t *)(arena + 48128);                    // [PB_CHEADS]
+  LC_LDS uint32_t *HACC = (LC_LDS uint32_t *)(arena + 48640);                  // [PB_CHEADS][4]
+  LC_LDS uint16_t *NEWE = (LC_LDS uint16_t *)(arena + 52736);                  // [PB_CHEADS][13]
+  LC_LDS uint16_t *NPOS = (LC_LDS uint16_t *)(arena + 59392);                  // [N <= 4096] node id -> position (0xFFFF: not a survivor)
+  static_assert(13376 >= (PB_CMAX + 2) * 16 && 14272 - 13376 >= PB_CMAX + 2 && 16896 - 15168 >= 2 * PB_CMAX && 23616 - 16896 >= 8 * (PB_CMAX + 2) &&
+                36992 - 23616 >= 16 * (PB_CMAX + 2) && 40384 - 36992 >= 4 * (PB_CMAX + 3) && 45504 - 43776 >= 2 * (PB_CMAX + 2) && 48128 - 46400 >= 2 * (PB_CMAX + 2) &&
+                52736 - 48640 >= 16 * PB_CHEADS && 59392 - 52736 >= 26 * PB_CHEADS && 59392 + 2 * 4096 <= 70304, "compress arena");
+  WG_LANE0 { CH->done = 0; S.why = 0; S.flagged = 0; S.g0 = 0x7FFFFFFFu; S.g1 = 0; S.ndup = 0; }
+  WG_FOR(n, N) { NPOS[n] = (uint16_t)0xFFFFu; }
+  WG_SYNC();
+  WG_FOR(u, nsurv) { const uint32_t si = pos2si[u]; SI2POS[si] = (uint16_t)u; NPOS[sidv[si]] = (uint16_t)u; }
+  WG_SYNC();
+  WG_FOR(u, Pn) {
+    uint32_t ne = 0, fl = 0;
+    if ((uint32_t)u < nsurv) {
+      const uint32_t si = pos2si[u];
+      LC_GLOBAL const NodeGr &G = pgr[si];
+      ne = G.necnt; fl = G.flags & 3u;
+      if (ne > 8u) { S.why = 1; ne = 8; }
+      for (uint32_t e = 0; e < ne; ++e) E[8 * (uint32_t)u + e] = BLC_MAKE((uint32_t)SI2POS[X.s_edges[9 * (size_t)si + e]], ED_DIR(G.edges[e]));
+      dev_atomic_add((LC_LDS uint32_t *)&S.ndup, ne);                         // (trace: edges before markRefEnds)
+    } else fl = (uint32_t)u == SRC ? 4u : 8u;
+    NE[u] = (uint8_t)ne; FL[u] = (uint8_t)fl;
+  }
+  // ---- markRefEnds' two scans (kernels.h mark_ref_scan): first / last reference offset whose node survives with getTotCov() >= COV_THRESHOLD
+  const int nrefk = reflen - K > 0 ? reflen - K + 1 : 0;
+  WG_FOR(off, nrefk) {
+    const uint32_t e = occ_ref[off];
+    if (e & PB_GONE) continue;
+    const uint32_t u = NPOS[e & 0x1FFFu];
+    const unsigned long long c4 = X.tcc[X.c_ti[X.s_ci[pos2si[u]]]];
+    const uint32_t tot = (uint32_t)(c4 & 0xFFFFu) + (uint32_t)((c4 >> 16) & 0xFFFFu) + (uint32_t)((c4 >> 32) & 0xFFFFu) + (uint32_t)(c4 >> 48);
+    if ((float)tot >= (float)P->cov_threshold) { dev_atomic_min((LC_LDS uint32_t *)&S.g0, (uint32_t)off); dev_atomic_max((LC_LDS uint32_t *)&S.g1, (uint32_t)off + 1u); }
+  }
+  WG_SYNC();
+  if (bl_bcast(&S.why) || bl_bcast(&S.g0) == 0x7FFFFFFFu) return;
+  const int so = (int)bl_bcast(&S.g0), ko = (int)bl_bcast(&S.g1) - 1;
+  const uint32_t sn = occ_ref[so] & 0x1FFFu, kn = occ_ref[ko] & 0x1FFFu;
+  WG_FOR(off, nrefk) {
+    const uint32_t e = occ_ref[off];
+    if (e & PB_GONE) continue;                                              // (a node that is gone is not "the same node again")
+    const uint32_t t = e & 0x1FFFu;
+    if ((off > so && t == sn) || (off < ko && t == kn)) S.why = 2;             // ambiguous source / sink: no anchors
+  }
+  if (bl_bcast(&S.why)) return;
+  // ---- markRefEnds proper (kernels.h mark_ref_ends), lane 0: cut the edges that leave the source k-mer backwards / the sink k-mer forwards, hang the special nodes on
+  WG_LANE0 {
+    auto erase_at = [&](uint32_t u, int idx) { const int cnt = (int)NE[u]; for (int i = idx; i + 1 < cnt; ++i) E[8 * u + i] = E[8 * u + i + 1]; NE[u] = (uint8_t)(cnt - 1); };
+    auto remove_edge_l = [&](uint32_t u, uint32_t to, uint32_t dir) { for (int i = 0; i < (int)NE[u]; ++i) if (BLC_TO(E[8 * u + i]) == to && BLC_DIR(E[8 * u + i]) == dir) { erase_at(u, i); return; } };
+    auto add_edge_l = [&](uint32_t u, uint32_t to, uint32_t dir) {
+      const int cnt = (int)NE[u];
+      for (int i = 0; i < cnt; ++i) if (BLC_TO(E[8 * u + i]) == to && BLC_DIR(E[8 * u + i]) == dir) return;
+      if (cnt >= 8) { S.why = 3; return; }
+      E[8 * u + cnt] = BLC_MAKE(to, dir); NE[u] = (uint8_t)(cnt + 1);
+    };
+    for (int which = 0; which < 2; ++which) {
+      const uint32_t oc = occ_ref[which == 0 ? so : ko];
+      const uint32_t x = NPOS[oc & 0x1FFFu], ori = oc >> 31;
+      const uint32_t sdir = which == 0 ? (ori ? 1u : 0u) : (ori ? 0u : 3u);     // source: FF, or FR when the k-mer is reversed ; sink: RR, or FF
+      const char cut = which == 0 ? (ori ? 'F' : 'R') : (ori ? 'R' : 'F');       // the edges that start in this direction go
+      for (int i = (int)NE[x] - 1; i >= 0; --i) {
+        const uint32_t e = E[8 * x + i];
+        if (dir_start(BLC_DIR(e)) == cut) { const uint32_t other = BLC_TO(e); if (other != x) { remove_edge_l(other, x, fliplink(BLC_DIR(e))); erase_at(x, i); } }
+      }
+      const uint32_t sp = which == 0 ? SRC : SNK;
+      add_edge_l(sp, x, sdir);
+      add_edge_l(x, sp, fliplink(sdir));
+    }
+  }
+  if (bl_bcast(&S.why)) return;
+  // ---- where unordered_map::insert puts the two special nodes (kernels.h order_insert; no rehash: the caller checked): in front of the first
+  //      element of the same bucket, else at the head.  S.g0 / S.g1 = position of the source / the sink in the table after both insertions.
+  unsigned long long hsrc, hsnk;
+  {
+    const char ns[] = "source1", nk[] = "sink1";
+    hsrc = std_hash_bytes([&](int j) -> int { return (int)(unsigned char)ns[j]; }, 7);
+    hsnk = std_hash_bytes([&](int j) -> int { return (int)(unsigned char)nk[j]; }, 5);
+  }
+  const uint32_t bsrc = ht_mod(hsrc, ht_bc), bsnk = ht_mod(hsnk, ht_bc);
+  WG_LANE0 { S.g0 = 0x7FFFFFFFu; S.g1 = 0x7FFFFFFFu; }
+  WG_SYNC();
+  WG_FOR(u, nsurv) {
+    const uint32_t b = ht_mod(nhash[sidv[pos2si[u]]], ht_bc);
+    if (b == bsrc) dev_atomic_min((LC_LDS uint32_t *)&S.g0, (uint32_t)u);
+    if (b == bsnk) dev_atomic_min((LC_LDS uint32_t *)&S.g1, (uint32_t)u);
+  }
+  WG_SYNC();
+  uint32_t at_s = bl_bcast(&S.g0), at_k = bl_bcast(&S.g1);
+  if (at_s == 0x7FFFFFFFu) at_s = 0;
+  // (the sink is inserted into the order that holds the source already)
+  if (at_k != 0x7FFFFFFFu) at_k = at_k >= at_s ? at_k + 1u : at_k;
+  if (bsnk == bsrc && (at_k == 0x7FFFFFFFu || at_s < at_k)) at_k = at_s;
+  if (at_k == 0x7FFFFFFFu) at_k = 0;
+  if (at_k <= at_s) at_s += 1u;                                                // final index of the source once the sink is in
+  // final table index of position u (before cleanDead): real nodes shift by the insertions in front of them
+  auto final_index = [&](uint32_t u) -> uint32_t {
+    if (u == SRC) return at_s; if (u == SNK) return at_k;
+    uint32_t i = u; const uint32_t s0 = at_k <= at_s ? at_s - 1u : at_s;      // source's index before the sink went in
+    if (i >= s0) ++i;
+    if (i >= at_k) ++i;
+    return i;
+  };
+  // ---- compress_prepare: the mergeable link of every node in either direction
+  auto buddy = [&](uint32_t u, char dir) -> int {                               // Node_t::getBuddy
+    if (FL[u] & 12u) return -1;
+    int ret = -1; const int cnt = (int)NE[u];
+    for (int i = 0; i < cnt; ++i) if (is_dir(BLC_DIR(E[8 * u + i]), dir)) { if (ret != -1) return -1; ret = i; }
+    if (ret != -1 && BLC_TO(E[8 * u + ret]) == u) return -1;
+    return ret;
+  };
+  auto tandem = [&](uint32_t u) -> bool { const int cnt = (int)NE[u]; for (int i = 0; i < cnt; ++i) if (BLC_TO(E[8 * u + i]) == u) return true; return false; };
+  WG_FOR(u, Pn) {
+    uint32_t l0 = 0, l1 = 0;
+    if (!(FL[u] & 12u) && !tandem((uint32_t)u)) {
+      for (int sd = 0; sd < 2; ++sd) {
+        const int uid = buddy((uint32_t)u, sd == 0 ? 'F' : 'R');
+        if (uid < 0) continue;
+        const uint32_t ew = E[8 * (uint32_t)u + (uint32_t)uid], edir = BLC_DIR(ew), b = BLC_TO(ew);
+        if ((FL[b] & 12u) || tandem(b)) continue;
+        const int buid = buddy(b, (edir == 0 || edir == 2) ? 'R' : 'F');
+        if (buid < 0) continue;
+        if (BLC_TO(E[8 * b + (uint32_t)buid]) != (uint32_t)u) { S.why = 4; continue; }      // an irregular link: the literal replay's business
+        (sd == 0 ? l0 : l1) = CL_VALID | (edir << 28) | b;
+      }
+    }
+    LNK[2 * u] = l0; LNK[2 * u + 1] = l1;
+  }
+  if (bl_bcast(&S.why)) return;
+  // ---- compress_rank: ports, pointer jumping
+  WG_FOR(u, Pn) {
+    for (uint32_t sd = 0; sd < 2; ++sd) {
+      const uint32_t l = LNK[2 * u + sd];
+      lc_u4 r; r.x = LC_NIL; r.y = 0; r.z = (uint32_t)u; r.w = 2u * (uint32_t)u + sd;
+      if (l & CL_VALID) {
+        const uint32_t B = CL_TO(l), ed = CL_DIR(l);
+        const uint32_t sb = (ed == 0 || ed == 2) ? 1u : 0u;
+        const uint32_t back = LNK[2 * B + sb];
+        if (!(back & CL_VALID) || CL_TO(back) != (uint32_t)u || CL_DIR(back) != fliplink(ed)) S.why = 5;
+        r.x = 2u * B + (1u - sb); r.y = 1u | (((ed == 1 || ed == 2) ? 1u : 0u) << 31);
+      }
+      PT[2u * (uint32_t)u + sd] = pr_pack(r);
+    }
+  }
+  if (bl_bcast(&S.why)) return;
+  {
+    const int NP = (int)(2u * Pn);
+    for (int round = 0; ; ++round) {
+      if (round == 15) { return; }                                             // a ring: no port ever reaches an end
+      WG_LANE0 { S.flagged = 0; }
+      WG_SYNC();
+      lc_u4 r[4]; bool have[4], chg = false;
+#ifndef LANCET_WAVE_EMU
+      const int l = (int)threadIdx.x;
+      for (int q = 0; q < 4; ++q) {
+        const int p = l + q * BL_WG; have[q] = p < NP;
+        if (have[q]) { r[q] = pr_unpack(PT[p]); if (r[q].x != LC_NIL) { const lc_u4 t = pr_unpack(PT[r[q].x]);
+          r[q].y = (((r[q].y & 0x7FFFFFFFu) + (t.y & 0x7FFFFFFFu)) & 0x7FFFFFFFu) | ((r[q].y ^ t.y) & 0x80000000u);
+          if (t.z < r[q].z) r[q].z = t.z;
+          r[q].w = t.w; r[q].x = t.x; if (r[q].x != LC_NIL) chg = true; } }
+      }
+      __syncthreads();
+      for (int q = 0; q < 4; ++q) if (have[q]) PT[l + q * BL_WG] = pr_pack(r[q]);
+      if (chg) S.flagged = 1;
+#else
+      {                                                                       // (lanes one after the other: all reads of a round see the round's start)
+        std::vector<unsigned long long> nxt((size_t)NP);
+        for (int p = 0; p < NP; ++p) {
+          lc_u4 a = pr_unpack(PT[p]);
+          if (a.x != LC_NIL) { const lc_u4 t = pr_unpack(PT[a.x]);
+            a.y = (((a.y & 0x7FFFFFFFu) + (t.y & 0x7FFFFFFFu)) & 0x7FFFFFFFu) | ((a.y ^ t.y) & 0x80000000u);
+            if (t.z < a.z) a.z = t.z;
+            a.w = t.w; a.x = t.x; if (a.x != LC_NIL) chg = true; }
+          nxt[(size_t)p] = pr_pack(a);
+        }
+        for (int p = 0; p < NP; ++p) PT[p] = nxt[(size_t)p];
+        if (chg) S.flagged = 1;
+        (void)r; (void)have;
+      }
+#endif
+      static_assert(4 * BL_WG >= 2 * (PB_CMAX + 2), "ports per lane");
+      if (!bl_bcast(&S.flagged)) break;
+    }
+  }
+  // ---- heads, slices of the merge-order list, arena space of the new deques
+  WG_LANE0 { S.flagged = 0; }
+  WG_SYNC();
+  WG_FOR(u, Pn + 1) {
+    uint32_t hs = 0, al = 0;
+    if ((uint32_t)u < Pn) {
+      const lc_u4 a = pr_unpack(PT[2 * (size_t)u]), b = pr_unpack(PT[2 * (size_t)u + 1]);
+      const uint32_t mF = a.y & 0x7FFFFFFFu, mR = b.y & 0x7FFFFFFFu, cmin = a.z < b.z ? a.z : b.z;
+      if (mF + mR > 0 && cmin == (uint32_t)u) {
+        hs = mF + mR; al = (uint32_t)K + mF + mR;
+        const uint32_t hx = dev_atomic_add((LC_LDS uint32_t *)&S.flagged, 1u);
+        if (hx < PB_CHEADS) { HL[hx] = (uint16_t)u; HX[u] = (uint16_t)hx; HACC[4 * hx] = 0x7FFFFFFFu; HACC[4 * hx + 1] = 0x7FFFFFFFu; HACC[4 * hx + 2] = 0; HACC[4 * hx + 3] = 0; }
+      }
+    }
+    HS[u] = hs; AL[u] = al;
+  }
+  bl_scan32(HS, (int)Pn + 1, S);
+  const uint32_t nabs = bl_bcast(&S.scan_total);
+  bl_scan32(AL, (int)Pn + 1, S);
+  const uint32_t need = bl_bcast(&S.scan_total);
+  const uint32_t nheads = bl_bcast(&S.flagged);
+  if (nheads > PB_CHEADS || need > PB_CSEQ || nabs > PB_CMAX) return;
+  // per node: its k-mer's figures (what compress_prepare keeps in a CmpRec)
+  auto node_key = [&](uint32_t u, uint32_t *ci_out) -> unsigned long long { const uint32_t ci = X.s_ci[pos2si[u]]; *ci_out = ci; return skey[ci]; };
+  const uint32_t top = ncand * (uint32_t)K;                                     // the window kernel's arena top for a graph from here
+  // ---- every merged k-mer: its head, side, place in the merge order; descriptor into the head's deque, coverage into its slice
+  WG_FOR(u, Pn) {
+    const lc_u4 a = pr_unpack(PT[2 * (size_t)u]), b = pr_unpack(PT[2 * (size_t)u + 1]);
+    const uint32_t mF = a.y & 0x7FFFFFFFu, mR = b.y & 0x7FFFFFFFu;
+    if (mF + mR == 0) continue;
+    const uint32_t cmin = a.z < b.z ? a.z : b.z;
+    if (cmin == (uint32_t)u) continue;                                         // a head
+    const uint32_t sH = (a.z == cmin) ? 0u : 1u;
+    const lc_u4 away = sH ? a : b;
+    const lc_u4 hF = pr_unpack(PT[2 * (size_t)cmin]), hR = pr_unpack(PT[2 * (size_t)cmin + 1]);
+    const bool onF = away.w == hF.w && (hF.y & 0x7FFFFFFFu) > 0;
+    const lc_u4 hp = onF ? hF : hR;
+    const uint32_t mdir = hp.y & 0x7FFFFFFFu, hmF = hF.y & 0x7FFFFFFFu, hmR = hR.y & 0x7FFFFFFFu;
+    const uint32_t j = mdir - (away.y & 0x7FFFFFFFu);
+    const uint32_t st_j = ((hp.y ^ away.y) >> 31) & 1u;
+    const uint32_t raw = fliplink(CL_DIR(LNK[2 * u + sH]));
+    const uint32_t st_p = st_j ^ ((raw == 1 || raw == 2) ? 1u : 0u);
+    const uint32_t edir = st_p ? flipme(raw) : raw;
+    const bool brev = (edir == 1 || edir == 3);
+    uint32_t ci; const unsigned long long kk = node_key((uint32_t)u, &ci);
+    const uint32_t n = sidv[pos2si[u]];
+    const uint32_t d0 = SD_MAKE(n, 0, key_base(&kk, K, 0)), dK = SD_MAKE(n, K - 1, key_base(&kk, K, K - 1));
+    const uint32_t nb = AL[cmin];
+    const uint32_t d = brev ? (d0 ^ 3u) : dK;
+    if (onF) cseq[nb + hmR + (uint32_t)K + (j - 1u)] = d; else cseq[nb + hmR - j] = d ^ 3u;
+    const uint32_t t = HS[cmin] + (onF ? j - 1u : hmF + j - 1u);
+    const unsigned long long c4 = X.tcc[X.c_ti[ci]];
+    const uint32_t c0 = (uint32_t)(c4 & 0xFFFFu), c1 = (uint32_t)((c4 >> 16) & 0xFFFFu), c2 = (uint32_t)((c4 >> 32) & 0xFFFFu), c3 = (uint32_t)(c4 >> 48);
+    lc_u4 o0; o0.x = __builtin_bit_cast(uint32_t, (float)c0); o0.y = __builtin_bit_cast(uint32_t, (float)c1); o0.z = __builtin_bit_cast(uint32_t, (float)c2); o0.w = __builtin_bit_cast(uint32_t, (float)c3);
+    stg4(X.ord + 4 * (size_t)t, o0);
+    LC_GLOBAL const uint16_t *q0p = qv + ((size_t)ci * K + 0) * 4, *qKp = qv + ((size_t)ci * K + (size_t)(K - 1)) * 4;
+    const uint32_t tq0 = (uint32_t)q0p[0] + q0p[1] + q0p[2] + q0p[3], tqK = (uint32_t)qKp[0] + qKp[1] + qKp[2] + qKp[3];
+    const uint32_t fl = FL[u] & 3u, hx = HX[cmin];
+    dev_atomic_min(&HACC[4 * hx], c0 + c1 + c2 + c3); dev_atomic_min(&HACC[4 * hx + 1], brev ? tq0 : tqK);
+    if (fl) dev_atomic_or(&HACC[4 * hx + 2], fl);
+    if (fl == 1u) dev_atomic_add(&HACC[4 * hx + 3], 1u);
+    HEADOF[u] = (uint16_t)cmin; INFO[u] = (uint8_t)(1u | (st_j << 1) | (edir << 2));
+    FL[u] = (uint8_t)(FL[u] | 16u);
+  }
+  WG_SYNC();
+  // ---- the heads: own k-mer's descriptors, minima / flags, the new edge list (own edges without the merged links, then the outward
+  //      edges of the F-side end, then of the R-side end: the erase / push_back order of compressNode)
+  WG_FOR(hx, nheads) {
+    const uint32_t u = HL[hx];
+    const lc_u4 a = pr_unpack(PT[2 * (size_t)u]), b = pr_unpack(PT[2 * (size_t)u + 1]);
+    const uint32_t mF = a.y & 0x7FFFFFFFu, mR = b.y & 0x7FFFFFFFu, cnt = mF + mR;
+    uint32_t ci; const unsigned long long kk = node_key(u, &ci);
+    const uint32_t si = pos2si[u], n = sidv[si];
+    const uint32_t nb = AL[u];
+    for (int t = 0; t < K; ++t) cseq[nb + mR + (uint32_t)t] = SD_MAKE(n, t, key_base(&kk, K, t));
+    uint16_t el[13]; int m = 0; bool bad = false;
+    const int uF = mF ? buddy(u, 'F') : -1, uR = mR ? buddy(u, 'R') : -1;
+    if ((mF && uF < 0) || (mR && uR < 0)) bad = true;
+    for (int e = 0; e < (int)NE[u]; ++e) { if (e == uF || e == uR) continue; el[m++] = E[8 * u + (uint32_t)e]; }
+    for (int side = 0; side < 2 && !bad; ++side) {
+      if (!(side == 0 ? mF : mR)) continue;
+      const uint32_t En = ((side == 0 ? a.w : b.w) >> 1);                     // the end of the list in that direction
+      const uint32_t info = INFO[En], ed = (info >> 2) & 3u, st = (info >> 1) & 1u;
+      const int buid = buddy(En, (ed == 0 || ed == 2) ? 'R' : 'F');
+      for (int e = 0; e < (int)NE[En]; ++e) {
+        if (e == buid) continue;
+        const uint32_t be = E[8 * En + (uint32_t)e];
+        uint32_t ndir = BLC_DIR(be); if (st) ndir = flipme(ndir);
+        const uint32_t other = BLC_TO(be);
+        if (m >= 12) { bad = true; break; }
+        el[m++] = BLC_MAKE(other == En ? u : other, ndir);
+      }
+    }
+    if (bad) { S.why = 6; continue; }
+    NEWE[13 * (size_t)hx] = (uint16_t)m;
+    for (int e = 0; e < m; ++e) NEWE[13 * (size_t)hx + 1 + (size_t)e] = el[e];
+  }
+  if (bl_bcast(&S.why)) return;                                                // (nothing in the hand-off records has been touched so far)
+  // ---- from here on the records change: no way back
+  WG_FOR(hx, nheads) {                                                         // record fields that do not depend on the merge order
+    const uint32_t u = HL[hx];
+    const uint32_t cnt = HS[u + 1] - HS[u];
+    uint32_t ci; (void)node_key(u, &ci);
+    const uint32_t si = pos2si[u];
+    const uint32_t nb = AL[u];
+    LC_GLOBAL NodeGr &G = pgr[si];
+    const unsigned long long c4 = X.tcc[X.c_ti[ci]];
+    const uint32_t own = (uint32_t)(c4 & 0xFFFFu) + (uint32_t)((c4 >> 16) & 0xFFFFu) + (uint32_t)((c4 >> 32) & 0xFFFFu) + (uint32_t)(c4 >> 48);
+    int mn = (int)own, mq = (int)X.c_minqv[ci];
+    if ((int)HACC[4 * hx] < mn) mn = (int)HACC[4 * hx];
+    if ((int)HACC[4 * hx + 1] < mq) mq = (int)HACC[4 * hx + 1];
+    const uint32_t f0 = FL[u] & 3u;
+    G.flags = (G.flags | HACC[4 * hx + 2]);
+    G.nkm = 1u + cnt; G.nkmT = (f0 == 1u ? 1u : 0u) + HACC[4 * hx + 3];
+    G.mincov = mn; G.mincovqv = mq;
+    G.seq_clo = top + nb; G.seq_lo = top + nb; G.seq_hi = top + nb + (uint32_t)K + cnt; G.seq_chi = G.seq_hi;
+  }
+  // ---- the float averaging of the merges (Graph.cc:2632-2636) in merge order: one lane per (head, coverage)
+  WG_FOR(x, 4 * nheads) {
+    const uint32_t hx = (uint32_t)x >> 2, q = (uint32_t)x & 3u;
+    const uint32_t u = HL[hx];
+    const uint32_t cnt = HS[u + 1] - HS[u];
+    uint32_t ci; (void)node_key(u, &ci);
+    const unsigned long long c4 = X.tcc[X.c_ti[ci]];
+    float nc = (float)(uint32_t)((c4 >> (16 * q)) & 0xFFFFu);
+    LC_GLOBAL const uint32_t *sl = X.ord + 4 * (size_t)HS[u] + q;
+    for (uint32_t t = 0; t < cnt; ++t) { const int amer = (int)t + 1, bmer = 1; nc = ((nc * amer) + (__builtin_bit_cast(float, sl[4 * (size_t)t]) * bmer)) / (amer + bmer); }
+    pgr[pos2si[u]].cov[q] = nc;
+  }
+  // ---- every live node: edges into a merged k-mer go to its head (frame flipped with it); the records' edge lists; dead flags
+  WG_FOR(u, Pn) {
+    if (FL[u] & 16u) { if ((uint32_t)u < nsurv) pgr[pos2si[u]].flags |= NF_DEAD; continue; }
+    const bool head = HS[u + 1] != HS[u];
+    const uint32_t hx = head ? (uint32_t)HX[u] : 0u;
+    const int cnt = head ? (int)NEWE[13 * (size_t)hx] : (int)NE[u];
+    LC_GLOBAL NodeGr &G = pgr[(uint32_t)u < nsurv ? (uint32_t)pos2si[u] : nsurv + ((uint32_t)u - nsurv)];
+    if ((uint32_t)u >= nsurv) {                                                // a special node: the record special_new makes
+      G.flags = (uint32_t)u == SRC ? NF_SOURCE : NF_SINK; G.comp = 1; G.color = 0; G.mincov = 0; G.mincovqv = 0; G.nqv = LC_NIL;
+      G.seq_lo = G.seq_hi = G.seq_clo = G.seq_chi = 0; G.nkm = 0; G.nkmT = 0; G.onref = 0;
+      for (int q = 0; q < 4; ++q) { G.kc[q] = 0; G.cov[q] = 0.0f; }
+    }
+    for (int e = 0; e < cnt; ++e) {
+      uint32_t ew = head ? NEWE[13 * (size_t)hx + 1 + (size_t)e] : E[8 * (uint32_t)u + (uint32_t)e];
+      uint32_t to = BLC_TO(ew), dir = BLC_DIR(ew);
+      if (FL[to] & 16u) { dir ^= (INFO[to] >> 1) & 1u; to = HEADOF[to]; }
+      G.edges[e] = ED_MAKE(to < nsurv ? sidv[pos2si[to]] : PB_SPECIAL + (to - nsurv), dir);
+    }
+    for (int e = cnt; e < LC_EMAX; ++e) G.edges[e] = 0;
+    G.necnt = (uint32_t)cnt;
+  }
+  // ---- cleanDead: the table order without the merged k-mers, the two special nodes in their places
+  WG_SYNC();
+  WG_FOR(u, Pn + 1) { AL[u] = ((uint32_t)u < Pn && !(FL[u] & 16u)) ? 1u : 0u; }   // (AL is done with: keep flags by FINAL index)
+  WG_SYNC();
+  {
+    LC_LDS uint32_t *keep = HS;                                                 // (HS is done with too) keep[final index]
+    WG_FOR(i, Pn + 1) { keep[i] = 0; }
+    WG_SYNC();
+    WG_FOR(u, Pn) { if (AL[u]) keep[final_index((uint32_t)u)] = 1u; }
+    bl_scan32(keep, (int)Pn + 1, S);
+    WG_FOR(u, Pn) { if (AL[u]) clive[keep[final_index((uint32_t)u)]] = (uint32_t)u < nsurv ? (uint32_t)pos2si[u] : (0x80000000u | ((uint32_t)u - nsurv)); }
+  }
+  WG_LANE0 {
+    CH->m_live = Pn - nabs; CH->dead = nabs; CH->seqn = need; CH->src_off = so; CH->snk_off = ko; CH->edges0 = S.ndup; CH->pad0 = 0;
+    CH->spec_hash[0] = hsrc; CH->spec_hash[1] = hsnk;
+    CH->done = 1;
+  }
+  WG_SYNC();
+}
+
 // One window.  Returns with the hand-off area of the window written (PB_BUILT) or marked PB_NOT_BUILT.
 // kmin: the loop over k starts there (min_k for the window's first graph; the k after a rejected one for a graph built ahead).
 // rep: the window's isRepeat / isAlmostRepeat operands when an earlier call scanned the reference already, else null.
@@ -179,6 +576,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   LC_GLOBAL const uint8_t *refc = B.ref_codes + B.ref_off[w];
   WG_LANE0 { S.hint = 0; S.ndup = 0; S.w = w; S.why = BLW_NONE; S.R = nr + 1; S.reflen = reflen; S.hasN = 0; S.mapped = 0; S.flagged = 0; S.npairs = 0; S.edges_total = 0; S.refn = 0;
              H->status = PB_NOT_BUILT; H->why = 0; H->have_rep = 0; H->heavy = 0; H->next = 0;
+             ((LC_GLOBAL PreCmp *)(area + PRE_OFF_CHDR))->done = 0;
              if (nr > BL_RMAX || reflen > LC_MAXW || reflen < 1) S.why = BLW_SIZE; }
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
   // ---- mapped reads, N in the window reference, per-read geometry
@@ -977,6 +1375,12 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_FOR(u, nsurv) { pgr2[pos2si[u]].comp = (int)(num[parent[u]] + 1u); }   // numbered by the position of the component's first node
     WG_LANE0 { H->have_order = 1; H->ht_bc = S.g0; H->ht_next_resize = S.g1; H->numcomp = S.nbw; H->refcomp = S.ngw; }
     WG_SYNC();
+    // ---- the window's first graph with a single component: markRefEnds and the first compress here too (bl_compress_first)
+    {
+      const uint32_t hbc = bl_bcast(&S.g0), hnr = bl_bcast(&S.g1), ncomp = bl_bcast(&S.nbw);
+      if (!rep && ncomp == 1u && nsurv <= PB_CMAX && nsurv + 2u <= hnr && C->debug_stop != 140u)
+        bl_compress_first(P, C, S, X, area, K, N, nsurv, ncand, reflen, hbc);
+    }
   }
   WG_LANE0 {
     H->K = K; H->refE = S.repE; H->refM = S.repM; H->N = S.N; H->O = S.O; H->totalreadbp = S.totalreadbp; H->n_kmers = S.n_kmers;

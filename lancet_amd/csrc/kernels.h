@@ -86,6 +86,8 @@ struct WinShared {
   uint32_t tmask, N_last; int tfull;                 // open-addressing table of this build: size - 1, filled up, nodes of the window's previous build
   int cmp_ok;                                    // compress_prepare: the component qualifies for compress_fast
   uint32_t cmp_nh;                               // compress_rank: heads found
+  int cmp_done;                                  // the graph came with markRefEnds and the first compress done (build_lds_impl.h bl_compress_first)
+  uint32_t cmp_dead, cmp_edges0, cmp_nsurv;      // ... its cleanDead count, the survivors' edge total before markRefEnds (trace), the survivors
   int seq_lazy;                                  // graph from the LDS build kernel: the k-mer nodes' descriptors are not written yet (seq_materialize)
   unsigned long long lz_area;                    // ... its hand-off area (candidate keys)
   int mr_src, mr_snk, mr_ambs, mr_ambk;          // mark_ref_scan: first / last qualifying reference offset, ambiguity flags
@@ -4515,13 +4517,63 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
   LC_GLOBAL const lc_v4 *pgr = (LC_GLOBAL const lc_v4 *)(area + PRE_OFF_PGR);
   LC_GLOBAL const lc_v4 *qsrc = (LC_GLOBAL const lc_v4 *)(area + PRE_OFF_QV);
   const uint32_t dummy = LC_CTX(c).C->node_cap + LC_CTX(c).C->special_cap;       // stand-in for reference k-mers whose node is gone
+  // markRefEnds and the first compress came along too (a single-component first graph): only the ~20 unitigs are loaded, the window
+  // kernel goes on at hasCycle (process_window).  The special nodes get this slot's ids (PB_SPECIAL + k in the hand-off).
+  LC_GLOBAL const PreCmp *CH = (LC_GLOBAL const PreCmp *)(area + PRE_OFF_CHDR);
+  WG_LANE0 { S.tmp1 = (S.seq_t5 != 0 || S.seq_len != S.reflen) ? 1 : 0; }       // Ref_t::seq trimmed by an earlier k of this window (see below)
+  const bool trimmed_before = wg_bcast(&S.tmp1) != 0;
+  const bool cdone = pre_order && !trimmed_before && CH->done == 1u && LC_CTX(c).C->special_cap >= 2u && CH->m_live <= LC_CTX(c).C->node_cap &&
+                     (size_t)ncand * (size_t)K + CH->seqn <= (size_t)LC_CTX(c).C->seq_cap;
+  WG_LANE0 { S.cmp_done = cdone ? 1 : 0; }
+  if (cdone) {
+    const uint32_t mlive = CH->m_live, seqn = CH->seqn, ncap = LC_CTX(c).C->node_cap;
+    LC_GLOBAL const uint32_t *clive = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_CLIVE);
+    LC_GLOBAL const uint32_t *cseq = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_CSEQ);
+    WG_LANE0 {
+      const int so = CH->src_off, ko = CH->snk_off;
+      S.M = mlive; S.ht_elt = mlive; S.nspecial = 2; S.source = ncap; S.sink = ncap + 1u;
+      S.seq_t5 = so; S.seq_len = ko - so + K; S.trim5 = so & 0xFFFF; S.trim3 = (S.reflen - ko - K) & 0xFFFF;
+      S.seq_top = ncand * (uint32_t)K + seqn; S.cmp_dead = CH->dead; S.cmp_edges0 = CH->edges0; S.cmp_nsurv = nsurv;
+    }
+    // what the descriptors of merged k-mers still point at: the k-mer's counts and its quality-count row (first and last 16 bytes of a record)
+    WG_FOR(si, nsurv) {
+      const uint32_t n = sid[si];
+      LC_GLOBAL lc_v4 *dst = (LC_GLOBAL lc_v4 *)&W.gr[n];
+      const lc_v4 a = pgr[8 * (size_t)si], z = pgr[8 * (size_t)si + 7];
+      dst[0] = a; dst[7] = z;
+    }
+    WG_SYNC();
+    WG_FOR(i, mlive) {                                              // the live nodes: whole records, in table order
+      const uint32_t idx = clive[i];
+      const bool sp = (idx & 0x80000000u) != 0;
+      const uint32_t ri = sp ? nsurv + (idx & 0xFFu) : idx;
+      const uint32_t id = sp ? ncap + (idx & 0xFFu) : sid[ri];
+      W.order[i] = id;
+      W.nhash[id] = sp ? CH->spec_hash[idx & 0xFFu] : nhash[id];
+      lc_v4 r[8];
+      for (int q = 0; q < 8; ++q) r[q] = pgr[8 * (size_t)ri + q];
+      for (int q = 1; q < 4; ++q) {                                 // edges[12]: the special nodes' ids
+        if (ED_TO(r[q].x) >= PB_SPECIAL) r[q].x = (r[q].x & 0xF0000000u) | (ncap + (ED_TO(r[q].x) - PB_SPECIAL));
+        if (ED_TO(r[q].y) >= PB_SPECIAL) r[q].y = (r[q].y & 0xF0000000u) | (ncap + (ED_TO(r[q].y) - PB_SPECIAL));
+        if (ED_TO(r[q].z) >= PB_SPECIAL) r[q].z = (r[q].z & 0xF0000000u) | (ncap + (ED_TO(r[q].z) - PB_SPECIAL));
+        if (ED_TO(r[q].w) >= PB_SPECIAL) r[q].w = (r[q].w & 0xF0000000u) | (ncap + (ED_TO(r[q].w) - PB_SPECIAL));
+      }
+      LC_GLOBAL lc_v4 *dst = (LC_GLOBAL lc_v4 *)&W.gr[id];
+      for (int q = 0; q < 8; ++q) dst[q] = r[q];
+      // a k-mer node that stayed on its own: its K descriptors (the merged ones are in the heads' deques, the heads' own k-mers too)
+      const uint32_t nqv = r[7].x, slo = r[5].z, shi = r[5].w;
+      if (!sp && nqv != LC_NIL && slo == nqv * (uint32_t)K && shi == slo + (uint32_t)K) {
+        const unsigned long long kk = skey[nqv];
+        for (int t = 0; t < K; ++t) W.seq[slo + (uint32_t)t] = SD_MAKE(id, t, key_base(&kk, K, t));
+      }
+    }
+    { const uint32_t base = ncand * (uint32_t)K; WG_FOR(i, seqn) { W.seq[base + (uint32_t)i] = cseq[i]; } }
+    WG_LANE0 { S.seq_lazy = 0; }
+  } else {
   if (pre_order) {                                               // only the survivors' hashes are looked at again (unordered_map::insert of the special nodes)
     LC_GLOBAL const uint32_t *ord = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_ORDER);
     WG_FOR(i, nsurv) { const uint32_t n = ord[i]; W.order[i] = n; W.nhash[n] = nhash[n]; }
   } else { WG_FOR(n, N) { W.nhash[n] = nhash[n]; } }
-  WG_FOR(i, (N + 3) / 4) { ((LC_GLOBAL uint32_t *)W.survb)[i] = ((LC_GLOBAL const uint32_t *)surv)[i]; }
-  WG_LANE0 { W.qv = (LC_GLOBAL uint16_t *)(area + PRE_OFF_QV); }  // (read in place: 73 KB per window not copied; build_graph points qv back at the slot's array)
-  (void)qsrc;
   WG_FOR(l, LANCET_WG) {                                          // four 16-byte pieces in flight per lane (the loads first, then the stores)
     const int total = (int)(nsurv * 8u);
     for (int i0 = l; i0 < total; i0 += 4 * LANCET_WG) {
@@ -4536,6 +4588,10 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
   // nodes that stay on their own; any other route into the graph phases calls seq_materialize_all first.
   WG_LANE0 { S.seq_lazy = 1; S.lz_area = (unsigned long long)(uintptr_t)area; }
   (void)snode; (void)skey;
+  }
+  WG_FOR(i, (N + 3) / 4) { ((LC_GLOBAL uint32_t *)W.survb)[i] = ((LC_GLOBAL const uint32_t *)surv)[i]; }
+  WG_LANE0 { W.qv = (LC_GLOBAL uint16_t *)(area + PRE_OFF_QV); }  // (read in place: 73 KB per window not copied; build_graph points qv back at the slot's array)
+  (void)qsrc;
   const int nrefk = S.reflen - K > 0 ? S.reflen - K + 1 : 0;
   WG_FOR(i, nrefk) { const uint32_t e = occ_ref[i]; W.occ[i] = (e & PB_GONE) ? (dummy | (e & 0x80000000u)) : e; }
   WG_FOR(i, S.reflen * 2) { ((LC_GLOBAL uint32_t *)W.refcov)[i] = ((LC_GLOBAL const uint32_t *)(area + PRE_OFF_REFCOV))[i]; }
@@ -4545,8 +4601,7 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
   // was rejected, and indexMers (src/Ref.cc:40-64) runs over that shorter seq at every k: the k-mers outside it
   // are not in the table, their nodes are not reference nodes (unless another k-mer inside is the same node) and
   // computeCoverage (src/Ref.cc:173-250) reads 0 for them.  Same rule as build_refcov, applied to what came along.
-  WG_LANE0 { S.tmp1 = (S.seq_t5 != 0 || S.seq_len != S.reflen) ? 1 : 0; }
-  if (wg_bcast(&S.tmp1)) {
+  if (trimmed_before) {
     const int t5 = wg_bcast(&S.seq_t5), L = wg_bcast(&S.seq_len);
     WG_FOR(i, (N + 31u) / 32u) { W.bitmap[i] = 0; }
     WG_SYNC();
@@ -4720,7 +4775,18 @@ DEV void process_window(Ctx &c, int w, int rq = -1) {
       }
     }
     WG_SYNC();
-    if (pre_order) {
+    const bool cdone = pre_order && wg_bcast(&S.cmp_done) != 0;    // markRefEnds and the first compress came along too: the trace lines of the stages before them from the counts
+    if (cdone) {
+      WG_LANE0 {
+        if (LC_CTX(c).C->evt_cap) {
+          evt(c, EV_CLEANDEAD, S.N - S.cmp_nsurv);
+          evt(c, EV_STATS, 0, S.cmp_nsurv, S.cmp_edges0, S.cmp_nsurv * (uint32_t)S.K);
+          evt(c, EV_CC, S.cmp_nsurv);
+          if (S.refcomp) evt(c, EV_CCID, 1u);
+          evt(c, EV_CCEND, (uint32_t)S.numcomp, (uint32_t)S.refcomp);
+        }
+      }
+    } else if (pre_order) {
       WG_LANE0 {
         evt(c, EV_CLEANDEAD, S.N - S.M);
         print_stats(c, 0, true);
@@ -4746,6 +4812,15 @@ DEV void process_window(Ctx &c, int w, int rq = -1) {
     STOP_SET(c, 8);
     if (wg_bcast(&S.overflow)) break;
     for (int comp = 1; comp <= numcomp; ++comp) {
+      if (cdone) {
+        WG_LANE0 {
+          if (LC_CTX(c).C->evt_cap) {
+            evt(c, EV_STATS, 1u, S.cmp_nsurv, S.cmp_edges0, S.cmp_nsurv * (uint32_t)S.K);
+            evt(c, EV_TRIM, (uint32_t)S.seq_t5, (uint32_t)(S.reflen - (S.seq_t5 + S.seq_len)), (uint32_t)S.seq_len);
+          }
+          S.tmp1 = (int)S.cmp_dead; S.tmp2 = 0;
+        }
+      } else {
       SUBPHASE(c, 2, 2);
       mark_ref_scan(c, comp);
       WG_LANE0 { print_stats(c, comp); }
@@ -4755,7 +4830,8 @@ DEV void process_window(Ctx &c, int w, int rq = -1) {
       if (wg_bcast(&S.overflow)) break;
       PHASE(c, 15);
       compress_prepare(c, comp);
-      const bool ranked = wg_bcast(&S.cmp_ok) && compress_rank(c, comp);     // (whole wave; false: a ring or an irregular link, nothing touched)
+      }
+      const bool ranked = cdone || (wg_bcast(&S.cmp_ok) && compress_rank(c, comp));     // (whole wave; false: a ring or an irregular link, nothing touched)
       if (!ranked) seq_materialize_all(c);
       if (!ranked) WG_LANE0 {
         // The reference runs hasCycle on the k-mer graph and compresses only if there is none.  Unitig compaction merges

@@ -187,7 +187,28 @@ struct PreHdr {
 #define PRE_OFF_PGR (PRE_OFF_SID + 4u * PB_SCAP)              /* NodeGr[PB_SCAP] records of the survivors, dense        */
 #define PRE_OFF_ORDER (PRE_OFF_PGR + 128u * PB_SCAP)          /* u32[PB_SCAP]   the survivors in libstdc++ table order  */
 #define PRE_OFF_QV (PRE_OFF_ORDER + 4u * PB_SCAP)             /* u16[PB_QVCAP*4] rows of K positions per candidate      */
-#define PRE_STRIDE ((PRE_OFF_QV + 8u * PB_QVCAP + 255u) & ~255u)
+/* ---- first compress done by the build kernel (build_lds_impl.h bl_compress_first): single-component first graphs ----
+ * markRefEnds + the first Graph_t::compress of the component in LDS; the window kernel then loads the ~20 unitigs instead of ~600
+ * k-mer nodes and starts at hasCycle.  PreCmp::done == 0: nothing here, the window kernel does both itself. */
+#define PB_CMAX 832u          /* survivors a graph may have for this                                                  */
+#define PB_CHEADS 256u        /* unitigs with merged k-mers                                                           */
+#define PB_CSEQ 12288u        /* descriptor words of their new deques                                                 */
+#define PB_SPECIAL 0x0FFFFFF0u /* edge target: special node k of the component is PB_SPECIAL + k (the window kernel knows its node ids) */
+struct PreCmp {
+  uint32_t done;
+  uint32_t m_live;            /* nodes in the table after cleanDead (two special nodes included), in CLIVE             */
+  uint32_t dead;              /* k-mer nodes merged away (the cleanDead count of the trace)                            */
+  uint32_t seqn;              /* words used in CSEQ: the window kernel's arena top moves by this                       */
+  int32_t src_off, snk_off;   /* markRefEnds: offsets of the source / sink k-mer in the window reference              */
+  uint32_t edges0;            /* trace only: edges of the survivors before markRefEnds                                 */
+  uint32_t pad0;
+  unsigned long long spec_hash[2];   /* std::hash of "source1" / "sink1"                                               */
+  uint32_t pad[4];
+};
+#define PRE_OFF_CHDR ((PRE_OFF_QV + 8u * PB_QVCAP + 63u) & ~63u)
+#define PRE_OFF_CLIVE (PRE_OFF_CHDR + 64u)                    /* u32[PB_CMAX + 2]  record index (survivor index, or nsurv + k for special k) per table position */
+#define PRE_OFF_CSEQ ((PRE_OFF_CLIVE + 4u * (PB_CMAX + 2u) + 63u) & ~63u)   /* u32[PB_CSEQ]                                  */
+#define PRE_STRIDE ((PRE_OFF_CSEQ + 4u * PB_CSEQ + 255u) & ~255u)
 
 /* One slot of work space.  All pointers are device pointers into one big allocation. */
 struct Work {

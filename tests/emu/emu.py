@@ -32,7 +32,7 @@ def lib():
         L.lancet_emu_free.argtypes = [C.c_void_p]
         L.lancet_emu_n_prebuilt.restype = C.c_uint32
         L.lancet_emu_n_prebuilt.argtypes = [C.c_void_p]
-        for f in ("lancet_emu_n_ahead_built", "lancet_emu_n_ahead_used", "lancet_emu_n_biglist", "lancet_emu_n_svc_posted", "lancet_emu_n_svc_built", "lancet_emu_n_svc_stolen"):
+        for f in ("lancet_emu_n_ahead_built", "lancet_emu_n_ahead_used", "lancet_emu_n_biglist", "lancet_emu_n_svc_posted", "lancet_emu_n_svc_built", "lancet_emu_n_svc_stolen", "lancet_emu_n_cmp_done"):
             getattr(L, f).restype = C.c_uint32
             getattr(L, f).argtypes = [C.c_void_p]
         _LIB = L
@@ -44,6 +44,7 @@ LAST_EVENTS = []
 LAST_BIGLIST = [0]           # windows handed to the 1024-lane configuration of the LDS build kernel, last run
 LAST_AHEAD = [0, 0]          # graphs built ahead at a later k / taken by the window kernel, last run
 LAST_PREBUILT = [0]          # windows of the last run whose first graph came from the LDS build kernel
+LAST_CMP = [0]               # windows of the last run whose first compress (and markRefEnds) the build kernel did
 LAST_SVC = [0, 0, 0]         # build service, last run: requests posted by suspended windows / served in LDS / taken back (general build)
 
 
@@ -58,6 +59,7 @@ def run(batch, params=None, evt_cap: int = 0):
         LAST_PREBUILT[0] = int(L.lancet_emu_n_prebuilt(h))
         LAST_BIGLIST[0] = int(L.lancet_emu_n_biglist(h))
         LAST_AHEAD[0], LAST_AHEAD[1] = int(L.lancet_emu_n_ahead_built(h)), int(L.lancet_emu_n_ahead_used(h))
+        LAST_CMP[0] = int(L.lancet_emu_n_cmp_done(h))
         LAST_SVC[0], LAST_SVC[1], LAST_SVC[2] = int(L.lancet_emu_n_svc_posted(h)), int(L.lancet_emu_n_svc_built(h)), int(L.lancet_emu_n_svc_stolen(h))
         bl = L.lancet_emu_blob_len(h)
         blob = C.string_at(L.lancet_emu_blob(h), bl) if bl else b""

@@ -23,6 +23,7 @@ struct EmuResult {
   uint32_t n_variants, n_blob;
   uint32_t n_prebuilt, n_ahead_built, n_ahead_used, n_biglist;
   uint32_t n_svc_built, n_svc_stolen, n_svc_posted;
+  uint32_t n_cmp_done = 0;
 };
 
 extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batch *b, uint32_t evt_cap) {
@@ -83,6 +84,9 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
     res->n_biglist = bq[4];
     O.pre = pre.data(); O.pre_pool = pool_cap ? pool.data() : nullptr;
     res->n_prebuilt = bq[1]; res->n_ahead_built = bq[3];
+    res->n_cmp_done = 0;
+    for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); const PreCmp *CH = (const PreCmp *)(pre.data() + (size_t)w * PRE_STRIDE + PRE_OFF_CHDR); if (H->status == PB_BUILT && CH->done == 1u) ++res->n_cmp_done; }
+    if (getenv("LANCET_EMU_CMP")) fprintf(stderr, "[emu] first compress done by the build kernel: %u of %u built windows\n", res->n_cmp_done, bq[1]);
     if (getenv("LANCET_EMU_HEAVY")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); if (H->status == PB_BUILT && H->heavy) fprintf(stderr, "[emu] heavy %d K %d\n", w, H->K); }
     if (getenv("LANCET_EMU_HDR")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); fprintf(stderr, "[emu] hdr %d status %u K %d refE %d refM %d heavy %u next %u\n", w, H->status, H->K, H->refE, H->refM, H->heavy, H->next); }
     if (getenv("LANCET_EMU_WHY")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); if (H->status != PB_BUILT) fprintf(stderr, "[emu] window %d not prebuilt: why %u\n", w, H->why); }
@@ -119,6 +123,7 @@ extern "C" uint32_t lancet_emu_n_prebuilt(void *h) { return ((EmuResult *)h)->n_
 extern "C" uint32_t lancet_emu_n_biglist(void *h) { return ((EmuResult *)h)->n_biglist; }
 extern "C" uint32_t lancet_emu_n_ahead_built(void *h) { return ((EmuResult *)h)->n_ahead_built; }
 extern "C" uint32_t lancet_emu_n_ahead_used(void *h) { return ((EmuResult *)h)->n_ahead_used; }
+extern "C" uint32_t lancet_emu_n_cmp_done(void *h) { return ((EmuResult *)h)->n_cmp_done; }
 extern "C" uint32_t lancet_emu_n_svc_posted(void *h) { return ((EmuResult *)h)->n_svc_posted; }
 extern "C" uint32_t lancet_emu_n_svc_built(void *h) { return ((EmuResult *)h)->n_svc_built; }
 extern "C" uint32_t lancet_emu_n_svc_stolen(void *h) { return ((EmuResult *)h)->n_svc_stolen; }
