@@ -180,6 +180,12 @@ template <class F> DEV void bl_for_occ(BL_S &S, LC_GLOBAL const uint16_t *occn, 
 // or with done = 0 and nothing touched (no unambiguous source / sink, a ring, an irregular link, more than 8 edges on a node, a
 // table that would be rehashed by the insertions, too many heads / descriptors): the window kernel then does all of it itself.
 // ---------------------------------------------------------------------------------------------------------
+// profiling builds only (-DLANCET_PROF_A): the steps of bl_compress_first accounted in the build kernel's phase slots 1..13
+#ifdef LANCET_PROF_A
+#define BLPA(S, id) BLP(S, id)
+#else
+#define BLPA(S, id) ((void)0)
+#endif
 #define BLC_TO(e) ((uint32_t)(e) & 0x3FFu)
 #define BLC_DIR(e) (((uint32_t)(e) >> 10) & 3u)
 #define BLC_MAKE(to, dir) ((uint16_t)((to) | ((dir) << 10)))
@@ -213,13 +219,21 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
   LC_LDS uint32_t *HACC = (LC_LDS uint32_t *)(arena + 48640);                  // [PB_CHEADS][4]
   LC_LDS uint16_t *NEWE = (LC_LDS uint16_t *)(arena + 52736);                  // [PB_CHEADS][13]
   LC_LDS uint16_t *NPOS = (LC_LDS uint16_t *)(arena + 59392);                  // [N <= 4096] node id -> position (0xFFFF: not a survivor)
+  LC_LDS unsigned long long *ORD = (LC_LDS unsigned long long *)(arena + 59392);  // [merged k-mers] their counted occurrences (4 x 16 bit) in merge order -- over NPOS, once markRefEnds is through
+  LC_LDS unsigned long long *TCC = (LC_LDS unsigned long long *)(arena + 74400);  // [nsurv] counted occurrences Tf Tr Nf Nr of the k-mer at a position (behind pos2si)
+  LC_LDS uint16_t *CI = (LC_LDS uint16_t *)(arena + 67584);                      // [nsurv] its candidate index (between NPOS and pos2si)
+  static_assert(74400 + 8 * PB_CMAX <= offsetof(BlShared, big) + BL_BIG && 8 * PB_CMAX <= 2 * 4096 && 67584 + 2 * PB_CMAX <= 70304, "compress arena (2)");
   static_assert(13376 >= (PB_CMAX + 2) * 16 && 14272 - 13376 >= PB_CMAX + 2 && 16896 - 15168 >= 2 * PB_CMAX && 23616 - 16896 >= 8 * (PB_CMAX + 2) &&
                 36992 - 23616 >= 16 * (PB_CMAX + 2) && 40384 - 36992 >= 4 * (PB_CMAX + 3) && 45504 - 43776 >= 2 * (PB_CMAX + 2) && 48128 - 46400 >= 2 * (PB_CMAX + 2) &&
                 52736 - 48640 >= 16 * PB_CHEADS && 59392 - 52736 >= 26 * PB_CHEADS && 59392 + 2 * 4096 <= 70304, "compress arena");
   WG_LANE0 { CH->done = 0; S.why = 0; S.flagged = 0; S.g0 = 0x7FFFFFFFu; S.g1 = 0; S.ndup = 0; }
+  BLPA(S, 1);
   WG_FOR(n, N) { NPOS[n] = (uint16_t)0xFFFFu; }
   WG_SYNC();
-  WG_FOR(u, nsurv) { const uint32_t si = pos2si[u]; SI2POS[si] = (uint16_t)u; NPOS[sidv[si]] = (uint16_t)u; }
+  WG_FOR(u, nsurv) {
+    const uint32_t si = pos2si[u]; SI2POS[si] = (uint16_t)u; NPOS[sidv[si]] = (uint16_t)u;
+    const uint32_t ci = X.s_ci[si]; CI[u] = (uint16_t)ci; TCC[u] = X.tcc[X.c_ti[ci]];
+  }
   WG_SYNC();
   WG_FOR(u, Pn) {
     uint32_t ne = 0, fl = 0;
@@ -233,18 +247,20 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     } else fl = (uint32_t)u == SRC ? 4u : 8u;
     NE[u] = (uint8_t)ne; FL[u] = (uint8_t)fl;
   }
+  BLPA(S, 2);
   // ---- markRefEnds' two scans (kernels.h mark_ref_scan): first / last reference offset whose node survives with getTotCov() >= COV_THRESHOLD
   const int nrefk = reflen - K > 0 ? reflen - K + 1 : 0;
   WG_FOR(off, nrefk) {
     const uint32_t e = occ_ref[off];
     if (e & PB_GONE) continue;
     const uint32_t u = NPOS[e & 0x1FFFu];
-    const unsigned long long c4 = X.tcc[X.c_ti[X.s_ci[pos2si[u]]]];
+    const unsigned long long c4 = TCC[u];
     const uint32_t tot = (uint32_t)(c4 & 0xFFFFu) + (uint32_t)((c4 >> 16) & 0xFFFFu) + (uint32_t)((c4 >> 32) & 0xFFFFu) + (uint32_t)(c4 >> 48);
     if ((float)tot >= (float)P->cov_threshold) { dev_atomic_min((LC_LDS uint32_t *)&S.g0, (uint32_t)off); dev_atomic_max((LC_LDS uint32_t *)&S.g1, (uint32_t)off + 1u); }
   }
   WG_SYNC();
   if (bl_bcast(&S.why) || bl_bcast(&S.g0) == 0x7FFFFFFFu) return;
+  const uint32_t edges0 = bl_bcast(&S.ndup);                                   // (S.ndup serves as a flag further down)
   const int so = (int)bl_bcast(&S.g0), ko = (int)bl_bcast(&S.g1) - 1;
   const uint32_t sn = occ_ref[so] & 0x1FFFu, kn = occ_ref[ko] & 0x1FFFu;
   WG_FOR(off, nrefk) {
@@ -254,6 +270,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     if ((off > so && t == sn) || (off < ko && t == kn)) S.why = 2;             // ambiguous source / sink: no anchors
   }
   if (bl_bcast(&S.why)) return;
+  BLPA(S, 3);
   // ---- markRefEnds proper (kernels.h mark_ref_ends), lane 0: cut the edges that leave the source k-mer backwards / the sink k-mer forwards, hang the special nodes on
   WG_LANE0 {
     auto erase_at = [&](uint32_t u, int idx) { const int cnt = (int)NE[u]; for (int i = idx; i + 1 < cnt; ++i) E[8 * u + i] = E[8 * u + i + 1]; NE[u] = (uint8_t)(cnt - 1); };
@@ -279,6 +296,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     }
   }
   if (bl_bcast(&S.why)) return;
+  BLPA(S, 4);
   // ---- where unordered_map::insert puts the two special nodes (kernels.h order_insert; no rehash: the caller checked): in front of the first
   //      element of the same bucket, else at the head.  S.g0 / S.g1 = position of the source / the sink in the table after both insertions.
   unsigned long long hsrc, hsnk;
@@ -305,12 +323,14 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
   if (at_k <= at_s) at_s += 1u;                                                // final index of the source once the sink is in
   // final table index of position u (before cleanDead): real nodes shift by the insertions in front of them
   auto final_index = [&](uint32_t u) -> uint32_t {
-    if (u == SRC) return at_s; if (u == SNK) return at_k;
+    if (u == SRC) return at_s;
+    if (u == SNK) return at_k;
     uint32_t i = u; const uint32_t s0 = at_k <= at_s ? at_s - 1u : at_s;      // source's index before the sink went in
     if (i >= s0) ++i;
     if (i >= at_k) ++i;
     return i;
   };
+  BLPA(S, 5);
   // ---- compress_prepare: the mergeable link of every node in either direction
   auto buddy = [&](uint32_t u, char dir) -> int {                               // Node_t::getBuddy
     if (FL[u] & 12u) return -1;
@@ -337,6 +357,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     LNK[2 * u] = l0; LNK[2 * u + 1] = l1;
   }
   if (bl_bcast(&S.why)) return;
+  BLPA(S, 6);
   // ---- compress_rank: ports, pointer jumping
   WG_FOR(u, Pn) {
     for (uint32_t sd = 0; sd < 2; ++sd) {
@@ -355,10 +376,13 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
   if (bl_bcast(&S.why)) return;
   {
     const int NP = (int)(2u * Pn);
+    // (two change flags taken in turn -- S.flagged / S.ndup -- so that a round is two barriers: read, barrier, write + flag, barrier, look)
+    WG_LANE0 { S.flagged = 0; S.ndup = 0; }
+    WG_SYNC();
     for (int round = 0; ; ++round) {
       if (round == 15) { return; }                                             // a ring: no port ever reaches an end
-      WG_LANE0 { S.flagged = 0; }
-      WG_SYNC();
+      LC_LDS uint32_t *flag = (round & 1) ? (LC_LDS uint32_t *)&S.ndup : (LC_LDS uint32_t *)&S.flagged;
+      LC_LDS uint32_t *other = (round & 1) ? (LC_LDS uint32_t *)&S.flagged : (LC_LDS uint32_t *)&S.ndup;
       lc_u4 r[4]; bool have[4], chg = false;
 #ifndef LANCET_WAVE_EMU
       const int l = (int)threadIdx.x;
@@ -371,7 +395,10 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
       }
       __syncthreads();
       for (int q = 0; q < 4; ++q) if (have[q]) PT[l + q * BL_WG] = pr_pack(r[q]);
-      if (chg) S.flagged = 1;
+      if (chg) *flag = 1;
+      if (l == 0) *other = 0;
+      __syncthreads();
+      if (!*flag) break;
 #else
       {                                                                       // (lanes one after the other: all reads of a round see the round's start)
         std::vector<unsigned long long> nxt((size_t)NP);
@@ -384,14 +411,16 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
           nxt[(size_t)p] = pr_pack(a);
         }
         for (int p = 0; p < NP; ++p) PT[p] = nxt[(size_t)p];
-        if (chg) S.flagged = 1;
+        *flag = chg ? 1u : 0u; *other = 0;
         (void)r; (void)have;
+        if (!*flag) break;
       }
 #endif
-      static_assert(4 * BL_WG >= 2 * (PB_CMAX + 2), "ports per lane");
-      if (!bl_bcast(&S.flagged)) break;
     }
+    static_assert(4 * BL_WG >= 2 * (PB_CMAX + 2), "ports per lane");
   }
+  WG_SYNC();
+  BLPA(S, 7);
   // ---- heads, slices of the merge-order list, arena space of the new deques
   WG_LANE0 { S.flagged = 0; }
   WG_SYNC();
@@ -415,8 +444,9 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
   const uint32_t nheads = bl_bcast(&S.flagged);
   if (nheads > PB_CHEADS || need > PB_CSEQ || nabs > PB_CMAX) return;
   // per node: its k-mer's figures (what compress_prepare keeps in a CmpRec)
-  auto node_key = [&](uint32_t u, uint32_t *ci_out) -> unsigned long long { const uint32_t ci = X.s_ci[pos2si[u]]; *ci_out = ci; return skey[ci]; };
+  auto node_key = [&](uint32_t u, uint32_t *ci_out) -> unsigned long long { const uint32_t ci = CI[u]; *ci_out = ci; return skey[ci]; };
   const uint32_t top = ncand * (uint32_t)K;                                     // the window kernel's arena top for a graph from here
+  BLPA(S, 8);
   // ---- every merged k-mer: its head, side, place in the merge order; descriptor into the head's deque, coverage into its slice
   WG_FOR(u, Pn) {
     const lc_u4 a = pr_unpack(PT[2 * (size_t)u]), b = pr_unpack(PT[2 * (size_t)u + 1]);
@@ -443,10 +473,9 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     const uint32_t d = brev ? (d0 ^ 3u) : dK;
     if (onF) cseq[nb + hmR + (uint32_t)K + (j - 1u)] = d; else cseq[nb + hmR - j] = d ^ 3u;
     const uint32_t t = HS[cmin] + (onF ? j - 1u : hmF + j - 1u);
-    const unsigned long long c4 = X.tcc[X.c_ti[ci]];
+    const unsigned long long c4 = TCC[u];
     const uint32_t c0 = (uint32_t)(c4 & 0xFFFFu), c1 = (uint32_t)((c4 >> 16) & 0xFFFFu), c2 = (uint32_t)((c4 >> 32) & 0xFFFFu), c3 = (uint32_t)(c4 >> 48);
-    lc_u4 o0; o0.x = __builtin_bit_cast(uint32_t, (float)c0); o0.y = __builtin_bit_cast(uint32_t, (float)c1); o0.z = __builtin_bit_cast(uint32_t, (float)c2); o0.w = __builtin_bit_cast(uint32_t, (float)c3);
-    stg4(X.ord + 4 * (size_t)t, o0);
+    ORD[t] = c4;
     LC_GLOBAL const uint16_t *q0p = qv + ((size_t)ci * K + 0) * 4, *qKp = qv + ((size_t)ci * K + (size_t)(K - 1)) * 4;
     const uint32_t tq0 = (uint32_t)q0p[0] + q0p[1] + q0p[2] + q0p[3], tqK = (uint32_t)qKp[0] + qKp[1] + qKp[2] + qKp[3];
     const uint32_t fl = FL[u] & 3u, hx = HX[cmin];
@@ -457,6 +486,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     FL[u] = (uint8_t)(FL[u] | 16u);
   }
   WG_SYNC();
+  BLPA(S, 9);
   // ---- the heads: own k-mer's descriptors, minima / flags, the new edge list (own edges without the merged links, then the outward
   //      edges of the F-side end, then of the R-side end: the erase / push_back order of compressNode)
   WG_FOR(hx, nheads) {
@@ -490,6 +520,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     for (int e = 0; e < m; ++e) NEWE[13 * (size_t)hx + 1 + (size_t)e] = el[e];
   }
   if (bl_bcast(&S.why)) return;                                                // (nothing in the hand-off records has been touched so far)
+  BLPA(S, 10);
   // ---- from here on the records change: no way back
   WG_FOR(hx, nheads) {                                                         // record fields that do not depend on the merge order
     const uint32_t u = HL[hx];
@@ -498,7 +529,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     const uint32_t si = pos2si[u];
     const uint32_t nb = AL[u];
     LC_GLOBAL NodeGr &G = pgr[si];
-    const unsigned long long c4 = X.tcc[X.c_ti[ci]];
+    const unsigned long long c4 = TCC[u];
     const uint32_t own = (uint32_t)(c4 & 0xFFFFu) + (uint32_t)((c4 >> 16) & 0xFFFFu) + (uint32_t)((c4 >> 32) & 0xFFFFu) + (uint32_t)(c4 >> 48);
     int mn = (int)own, mq = (int)X.c_minqv[ci];
     if ((int)HACC[4 * hx] < mn) mn = (int)HACC[4 * hx];
@@ -509,18 +540,27 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     G.mincov = mn; G.mincovqv = mq;
     G.seq_clo = top + nb; G.seq_lo = top + nb; G.seq_hi = top + nb + (uint32_t)K + cnt; G.seq_chi = G.seq_hi;
   }
+  BLPA(S, 11);
   // ---- the float averaging of the merges (Graph.cc:2632-2636) in merge order: one lane per (head, coverage)
   WG_FOR(x, 4 * nheads) {
     const uint32_t hx = (uint32_t)x >> 2, q = (uint32_t)x & 3u;
     const uint32_t u = HL[hx];
     const uint32_t cnt = HS[u + 1] - HS[u];
-    uint32_t ci; (void)node_key(u, &ci);
-    const unsigned long long c4 = X.tcc[X.c_ti[ci]];
-    float nc = (float)(uint32_t)((c4 >> (16 * q)) & 0xFFFFu);
-    LC_GLOBAL const uint32_t *sl = X.ord + 4 * (size_t)HS[u] + q;
-    for (uint32_t t = 0; t < cnt; ++t) { const int amer = (int)t + 1, bmer = 1; nc = ((nc * amer) + (__builtin_bit_cast(float, sl[4 * (size_t)t]) * bmer)) / (amer + bmer); }
+    float nc = (float)(uint32_t)((TCC[u] >> (16 * q)) & 0xFFFFu);
+    LC_LDS const unsigned long long *sl = ORD + HS[u];
+    // (the operands of the next four merges are on their way while these four divide)
+    auto opnd = [&](uint32_t t) -> float { return (float)(uint32_t)((sl[t < cnt ? t : cnt - 1] >> (16 * q)) & 0xFFFFu); };
+    float n0 = opnd(0), n1 = opnd(1), n2 = opnd(2), n3 = opnd(3);
+    for (uint32_t t0 = 0; t0 < cnt; t0 += 4) {
+      const float c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+      if (t0 + 4 < cnt) { n0 = opnd(t0 + 4); n1 = opnd(t0 + 5); n2 = opnd(t0 + 6); n3 = opnd(t0 + 7); }
+#define BLC_STEP(cv, t) do { if ((t) < cnt) { const int amer = (int)(t) + 1, bmer = 1; nc = ((nc * amer) + ((cv) * bmer)) / (amer + bmer); } } while (0)   /* Graph.cc:2632-2636, same expression, same order */
+      BLC_STEP(c0, t0); BLC_STEP(c1, t0 + 1); BLC_STEP(c2, t0 + 2); BLC_STEP(c3, t0 + 3);
+#undef BLC_STEP
+    }
     pgr[pos2si[u]].cov[q] = nc;
   }
+  BLPA(S, 12);
   // ---- every live node: edges into a merged k-mer go to its head (frame flipped with it); the records' edge lists; dead flags
   WG_FOR(u, Pn) {
     if (FL[u] & 16u) { if ((uint32_t)u < nsurv) pgr[pos2si[u]].flags |= NF_DEAD; continue; }
@@ -542,6 +582,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     for (int e = cnt; e < LC_EMAX; ++e) G.edges[e] = 0;
     G.necnt = (uint32_t)cnt;
   }
+  BLPA(S, 13);
   // ---- cleanDead: the table order without the merged k-mers, the two special nodes in their places
   WG_SYNC();
   WG_FOR(u, Pn + 1) { AL[u] = ((uint32_t)u < Pn && !(FL[u] & 16u)) ? 1u : 0u; }   // (AL is done with: keep flags by FINAL index)
@@ -555,7 +596,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     WG_FOR(u, Pn) { if (AL[u]) clive[keep[final_index((uint32_t)u)]] = (uint32_t)u < nsurv ? (uint32_t)pos2si[u] : (0x80000000u | ((uint32_t)u - nsurv)); }
   }
   WG_LANE0 {
-    CH->m_live = Pn - nabs; CH->dead = nabs; CH->seqn = need; CH->src_off = so; CH->snk_off = ko; CH->edges0 = S.ndup; CH->pad0 = 0;
+    CH->m_live = Pn - nabs; CH->dead = nabs; CH->seqn = need; CH->src_off = so; CH->snk_off = ko; CH->edges0 = edges0; CH->pad0 = 0;
     CH->spec_hash[0] = hsrc; CH->spec_hash[1] = hsnk;
     CH->done = 1;
   }
