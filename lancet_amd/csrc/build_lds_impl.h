@@ -41,9 +41,11 @@ struct BlScratch {
   LC_GLOBAL uint32_t *s_ci;         /* [PB_SCAP] candidate of survivor si                                        */
   LC_GLOBAL uint32_t *s_edges;      /* [PB_SCAP * 9] resolved edges + count                                      */
   LC_GLOBAL uint16_t *dupo;         /* [BL_DUPCAP] occurrences that met their k-mer in the other orientation, or twice in one read */
-  LC_GLOBAL uint32_t *ord;          /* [4 * PB_CMAX] bl_compress_first: the merged k-mers' coverages in merge order (4 floats each) */
+  LC_GLOBAL uint32_t *ord;          /* [4 * PB_CMAX] (spare) */
+  LC_GLOBAL uint32_t *pq;           /* [BL_PQCAP] per-position counts: the occurrences of the candidates beyond the first LDS group (read | position << 10 | candidate << 20 | reversed << 31) */
 };
-static constexpr uint32_t SCRATCH_BYTES = (2u * BL_BASES + 64u + 8u * BL_TCAP + 4u * BL_TCAP + 12u * PB_CCAP + 4u * PB_SCAP + 36u * PB_SCAP + 2u * BL_DUPCAP + 16u * PB_CMAX + 704u);
+static constexpr uint32_t BL_PQCAP = 16384u;
+static constexpr uint32_t SCRATCH_BYTES = (2u * BL_BASES + 64u + 8u * BL_TCAP + 4u * BL_TCAP + 12u * PB_CCAP + 4u * PB_SCAP + 36u * PB_SCAP + 2u * BL_DUPCAP + 16u * PB_CMAX + 4u * 16384u + 768u);
 static constexpr int WG = BL_WG;
 DEV void bl_scratch_carve(BlScratch *s, LC_GLOBAL uint8_t *base) {
   size_t o = 0;
@@ -58,6 +60,7 @@ DEV void bl_scratch_carve(BlScratch *s, LC_GLOBAL uint8_t *base) {
   s->s_edges = (LC_GLOBAL uint32_t *)take(36u * PB_SCAP);
   s->dupo = (LC_GLOBAL uint16_t *)take(2u * BL_DUPCAP);
   s->ord = (LC_GLOBAL uint32_t *)take(16u * PB_CMAX);
+  s->pq = (LC_GLOBAL uint32_t *)take(4u * BL_PQCAP);
 }
 
 static_assert(sizeof(BlShared) <= BL_LDS_LIMIT, "LDS of the build kernel: 2 x 80 KB (512 lanes) or 1 x 160 KB (1024 lanes) per CU");
@@ -259,9 +262,10 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     if ((float)tot >= (float)P->cov_threshold) { dev_atomic_min((LC_LDS uint32_t *)&S.g0, (uint32_t)off); dev_atomic_max((LC_LDS uint32_t *)&S.g1, (uint32_t)off + 1u); }
   }
   WG_SYNC();
-  if (bl_bcast(&S.why) || bl_bcast(&S.g0) == 0x7FFFFFFFu) return;
-  const uint32_t edges0 = bl_bcast(&S.ndup);                                   // (S.ndup serves as a flag further down)
-  const int so = (int)bl_bcast(&S.g0), ko = (int)bl_bcast(&S.g1) - 1;
+  const uint32_t why_a = S.why, g0_a = S.g0, g1_a = S.g1, edges0 = S.ndup;     // (one pair of barriers for the four words; S.ndup serves as a flag further down)
+  WG_SYNC();
+  if (why_a || g0_a == 0x7FFFFFFFu) return;
+  const int so = (int)g0_a, ko = (int)g1_a - 1;
   const uint32_t sn = occ_ref[so] & 0x1FFFu, kn = occ_ref[ko] & 0x1FFFu;
   WG_FOR(off, nrefk) {
     const uint32_t e = occ_ref[off];
@@ -314,7 +318,8 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     if (b == bsnk) dev_atomic_min((LC_LDS uint32_t *)&S.g1, (uint32_t)u);
   }
   WG_SYNC();
-  uint32_t at_s = bl_bcast(&S.g0), at_k = bl_bcast(&S.g1);
+  uint32_t at_s = S.g0, at_k = S.g1;
+  WG_SYNC();
   if (at_s == 0x7FFFFFFFu) at_s = 0;
   // (the sink is inserted into the order that holds the source already)
   if (at_k != 0x7FFFFFFFu) at_k = at_k >= at_s ? at_k + 1u : at_k;
@@ -437,11 +442,11 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     }
     HS[u] = hs; AL[u] = al;
   }
-  bl_scan32(HS, (int)Pn + 1, S);
-  const uint32_t nabs = bl_bcast(&S.scan_total);
+  bl_scan32(HS, (int)Pn + 1, S);                                              // (ends in a barrier: scan_total is readable)
+  const uint32_t nabs = S.scan_total;
   bl_scan32(AL, (int)Pn + 1, S);
-  const uint32_t need = bl_bcast(&S.scan_total);
-  const uint32_t nheads = bl_bcast(&S.flagged);
+  const uint32_t need = S.scan_total, nheads = S.flagged;
+  WG_SYNC();
   if (nheads > PB_CHEADS || need > PB_CSEQ || nabs > PB_CMAX) return;
   // per node: its k-mer's figures (what compress_prepare keeps in a CmpRec)
   auto node_key = [&](uint32_t u, uint32_t *ci_out) -> unsigned long long { const uint32_t ci = CI[u]; *ci_out = ci; return skey[ci]; };
@@ -563,7 +568,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
   BLPA(S, 12);
   // ---- every live node: edges into a merged k-mer go to its head (frame flipped with it); the records' edge lists; dead flags
   WG_FOR(u, Pn) {
-    if (FL[u] & 16u) { if ((uint32_t)u < nsurv) pgr[pos2si[u]].flags |= NF_DEAD; continue; }
+    if (FL[u] & 16u) continue;                     // (a merged k-mer: the window kernel marks it dead itself -- its record is not touched again here)
     const bool head = HS[u + 1] != HS[u];
     const uint32_t hx = head ? (uint32_t)HX[u] : 0u;
     const int cnt = head ? (int)NEWE[13 * (size_t)hx] : (int)NE[u];
@@ -1058,18 +1063,11 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       if (wide) { WG_FOR(i, (c1 - c0) * (uint32_t)K) { bad64[i] = 0; } } else { WG_FOR(i, (c1 - c0) * (uint32_t)K) { bad32[i] = 0; } }
       WG_FOR(i, c1 - c0) { gcc[i] = X.tcc[X.c_ti[c0 + (uint32_t)i]]; }
       WG_SYNC();
-      bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
-        (void)boff;
-        if (r == nr) return;
-        if (e & 0x4000u) return;                                     // an overlapping mate's occurrence: not counted
-        const uint32_t ti = S.cidx[e & 0x1FFFu];
-        if (ti == 0xFFFFu) return;
-        const uint32_t ci = S.t2c[ti];
-        if (ci < c0 || ci >= c1) return;                             // (0xFFFF: not a candidate)
+      // one occurrence of candidate ci: the bases of its k-mer below MIN_QUAL_CALL
+      auto count_occ = [&](int r, int p, uint32_t ci, bool rev) {
         const uint32_t ri = S.rinfo[r];
         const uint32_t cls = (RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u);
         const uint32_t gw = S.gwo[r];
-        const bool rev = (e & 0x8000u) != 0;
         // bits p .. p+K-1 of the read's mask; a clear bit at read position p + j is k-mer position j (forward) or K-1-j (reverse)
         for (int j0 = 0; j0 < K;) {
           const int pos = p + j0, wv = pos >> 5, lo = pos & 31;
@@ -1084,6 +1082,34 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
           }
           j0 += take;
         }
+      };
+      // The first group walks every occurrence of the window and notes those of the candidates that did not fit (usually a few dozen
+      // of ~600); the later groups work that list off instead of walking all occurrences again.
+      const bool listed = c0 > 0 && bl_bcast(&S.g1) <= BL_PQCAP;
+      if (c0 == 0) { WG_LANE0 { S.g1 = 0; } WG_SYNC(); }
+      if (listed) {
+        const uint32_t nq = S.g1;
+        WG_FOR(i, nq) {
+          const uint32_t v = X.pq[i], ci = (v >> 20) & 0x7FFu;
+          if (ci >= c0 && ci < c1) count_occ((int)(v & 0x3FFu), (int)((v >> 10) & 0x3FFu), ci, (v >> 31) != 0);
+        }
+      } else
+      bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
+        (void)boff;
+        if (r == nr) return;
+        if (e & 0x4000u) return;                                     // an overlapping mate's occurrence: not counted
+        const uint32_t ti = S.cidx[e & 0x1FFFu];
+        if (ti == 0xFFFFu) return;
+        const uint32_t ci = S.t2c[ti];
+        if (ci == 0xFFFFu) return;                                   // not a candidate
+        if (ci >= c1 && c0 == 0) {                                   // a later group's: note it
+          if (p > 1023 || r > 1023) { S.g1 = BL_PQCAP + 1u; return; }     // (does not fit an entry: the later groups walk everything)
+          const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.g1, 1u);
+          if (at < BL_PQCAP) X.pq[at] = (uint32_t)r | ((uint32_t)p << 10) | (ci << 20) | ((e & 0x8000u) ? 0x80000000u : 0u);
+          return;
+        }
+        if (ci < c0 || ci >= c1) return;
+        count_occ(r, p, ci, (e & 0x8000u) != 0);
       });
       WG_SYNC();
       auto bad_of = [&](uint32_t t, int cl) -> uint32_t { return wide ? (uint32_t)((bad64[t] >> (16 * cl)) & 0xFFFFu) : ((bad32[t] >> (8 * cl)) & 0xFFu); };

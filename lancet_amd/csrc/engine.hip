@@ -203,6 +203,7 @@ struct lancet_engine {
   // LANCET_PREP=device keeps the round-2 path (ASCII bases + qualities to the device, prep_kernel there)
   void *h_stage = nullptr; size_t h_stage_cap = 0; DevBuf d_stage;
   bool host_prep = true; int prep_threads = 0;
+  int exact_need_large = -1;       // host trim: does any window exceed the 512-lane build configuration (exact: from the trimmed lengths)?  -1 unknown
   float ms_pack = 0;
   bool dbg = false, no_fat = false, no_early_rerun = false, no_large_build = false;     // LANCET_DEBUG / LANCET_NO_FAT / ... read once, at create
   int build_slots_env = 0, ahead_depth_env = -1;
@@ -457,6 +458,19 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     lc_parallel(T, (size_t)nref, [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; ++i) h_rc[i] = (uint8_t)lc_code(b->ref_bases[i]); });
     h_rc[nref] = 0;
     if (e->params.lr_mode && R) { memcpy(H + o_bx, b->bx_rank, 4 * (size_t)R); memcpy(H + o_hp, b->hp, (size_t)R); }
+    {   // the 512-lane build configuration's size test (build_lds_impl.h: nbw / ngw against BL_BASES), window by window on the trimmed lengths
+      std::vector<char> need((size_t)T, 0);
+      lc_parallel(T, (size_t)nw, [&](size_t lo, size_t hi, int t) {
+        for (size_t w = lo; w < hi && !need[(size_t)t]; ++w) {
+          const uint32_t r0 = b->read_begin[w], r1 = b->read_begin[w + 1], rl = b->ref_off[w + 1] - b->ref_off[w];
+          uint64_t wb = (rl + 15) / 16, wg = (rl + 31) / 32;
+          for (uint32_t r = r0; r < r1; ++r) { const uint32_t tl = RI_TLEN(h_ri[r]); wb += (tl + 15) / 16; wg += (tl + 31) / 32; }
+          if (r1 - r0 > 512u || wb > BL_SMALL_BASES / 16u || wg > BL_SMALL_BASES / 32u) need[(size_t)t] = 1;
+        }
+      });
+      e->exact_need_large = 0;
+      for (int t = 0; t < T; ++t) if (need[(size_t)t]) e->exact_need_large = 1;
+    }
     e->ms_pack = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_pack0).count();
     if (e->dbg) fprintf(stderr, "[lancet] trim + pack on %d host threads: %.1f ms, %.1f MB to the device\n", T, e->ms_pack, total / 1048576.0);
     HIPCHK(e, hipMemcpyAsync(e->d_stage.p, e->h_stage, total, hipMemcpyHostToDevice, e->stream));
@@ -572,6 +586,8 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     // Can any window be too big for the 512-lane configuration?  Trimming only shortens reads, so the untrimmed lengths bound the
     // LDS footprint (reads padded to 16 bases + the reference); when none can, the 1024-lane kernel is not launched at all.
     bool may_need_large = false;
+    if (e->host_prep && e->exact_need_large >= 0) may_need_large = e->exact_need_large != 0;
+    else
     for (int w = 0; w < nw && !may_need_large; ++w) {
       const uint32_t r0 = b->read_begin[w], r1 = b->read_begin[w + 1];
       if (r1 - r0 > 512u) { may_need_large = true; break; }

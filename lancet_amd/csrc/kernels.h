@@ -4539,7 +4539,8 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
     WG_FOR(si, nsurv) {
       const uint32_t n = sid[si];
       LC_GLOBAL lc_v4 *dst = (LC_GLOBAL lc_v4 *)&W.gr[n];
-      const lc_v4 a = pgr[8 * (size_t)si], z = pgr[8 * (size_t)si + 7];
+      lc_v4 a = pgr[8 * (size_t)si]; const lc_v4 z = pgr[8 * (size_t)si + 7];
+      a.x |= NF_DEAD;                                                // (merged into a unitig -- unless it is in the list of live nodes, whose records follow)
       dst[0] = a; dst[7] = z;
     }
     WG_SYNC();
