@@ -44,6 +44,34 @@ def cpu_model() -> str:
     return "unknown"
 
 
+def cpu_limits() -> dict:
+    """What this process may actually use of the host: affinity mask, cgroup CPU quota (a container with a quota of N CPUs scales
+    to N whatever os.cpu_count() says)."""
+    out = {}
+    try:
+        out["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                out["cgroup_cpu_max"] = " ".join(txt)
+                if txt and txt[0] != "max" and len(txt) > 1:
+                    out["cgroup_cpus"] = round(int(txt[0]) / int(txt[1]), 2)
+            else:
+                q = int(txt[0]); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                out["cgroup_cpus"] = round(q / per, 2) if q > 0 else None
+            break
+        except (OSError, ValueError):
+            continue
+    try:
+        out["loadavg"] = [float(x) for x in open("/proc/loadavg").read().split()[:3]]
+    except OSError:
+        pass
+    return out
+
+
 def cpu_baseline(batch, params, variants, n1: int, nall: int):
     """The oracle (CPU restatement of the reference path, oracle/liblancet_oracle.so) on a bounded sample of the same
     windows: one thread, then one worker PROCESS per hardware thread over chunks of windows (windows are independent, as
@@ -58,6 +86,10 @@ def cpu_baseline(batch, params, variants, n1: int, nall: int):
     dt1 = time.perf_counter() - t
     same = ov == [v for v in variants if v["window"] < n1]
     threads = os.cpu_count() or 1
+    try:
+        threads = min(threads, len(os.sched_getaffinity(0)))      # (what this process may run on)
+    except (AttributeError, OSError):
+        pass
     phys = cpu_fanout.physical_cores()
     nall = min(nall, batch.n_windows)
     per = max(4, nall // (threads * 6))
@@ -69,7 +101,7 @@ def cpu_baseline(batch, params, variants, n1: int, nall: int):
             "mkmers_per_s": round(kma / dta / 1e6, 3),
             "one_thread": {"value": round(n1 / dt1, 2), "mkmers_per_s": round(km1 / dt1 / 1e6, 3),
                            "sample": f"first {n1} windows, 1 thread, {dt1:.1f} s"},
-            "scaling_over_one_thread": round((done / dta) / (n1 / dt1), 1),
+            "scaling_over_one_thread": round((done / dta) / (n1 / dt1), 1), "host_limits": cpu_limits(),
             "gpu_results_identical_on_sample": bool(same),
             "note": "the reference binary cannot travel to this box; in the authoring container it runs the golden cases at 13-23 windows/s/thread, this port at ~45 (DESIGN.md §7)"}
 
@@ -339,13 +371,14 @@ def main():
             out["windows_per_rank"] = n_local
             if one_gpu:
                 out["config"]["comm"] = "LANCET_BENCH_ONE_GPU=1: all ranks on device 0, gather over gloo -- a check of the N-rank path, not a measurement"
-        # HBM-side bytes per launch from the committed PMC passes (tools/pmc_total.sh -> profiles/r2_traffic.json):
+        # HBM-side bytes per launch from the committed PMC passes (tools/pmc_total.sh -> profiles/r3_traffic.json):
         # rocprofv3 cannot run inside this process, so the figure is looked up for the exact workload it was taken on
         try:
-            with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r3_traffic.json")) as fh:
                 for rec in json.load(fh)["measurements"]:
                     if rec["windows"] == args.windows and rec["coverage"] == args.cov and world == 1:
                         out["roofline"]["traffic"] = int((rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024)
+                        out["roofline"]["traffic_fetch_write"] = [int(rec["FETCH_SIZE_KB"] * 1024), int(rec["WRITE_SIZE_KB"] * 1024)]
                         out["roofline"]["traffic_note"] = rec["note"]
                         break
         except (OSError, KeyError, ValueError):
