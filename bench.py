@@ -305,19 +305,33 @@ def main():
 
     # PCIe-inclusive rate (never `value`): the batch handed over as host buffers every step; upload + trim/pack of one batch overlap
     # the kernels of the previous one when two engines take turns
-    t1 = time.perf_counter()
+    # (steady state: the clock runs from the completion of the second step to that of the last -- the first upload has no kernels to hide
+    #  behind and the last kernels no upload to hide)
     pend = []
-    ne2e = 6
+    ne2e = 10
+    done_at = []
+    tl = []
     for i in range(ne2e):
         e = engs[i % nfl]
+        ta = time.perf_counter()
         e.upload(batch)
+        tb = time.perf_counter()
         e.submit(after=pend[-1] if pend and args.chain else None)
+        tc = time.perf_counter()
         pend.append(e)
         if len(pend) >= nfl:
             pend.pop(0).wait()
+            done_at.append(time.perf_counter())
+        tl.append((ta, tb, tc, time.perf_counter()))
     while pend:
         pend.pop(0).wait()
-    e2e_s = (time.perf_counter() - t1) / ne2e
+        done_at.append(time.perf_counter())
+    e2e_s = (done_at[-1] - done_at[1]) / (ne2e - 2)
+    if os.environ.get("LANCET_BENCH_TIMELINE"):
+        z = tl[0][0]
+        for i, (ta, tb, tc, td) in enumerate(tl):
+            print(f"[e2e] step {i}: upload {1e3 * (ta - z):7.1f} .. {1e3 * (tb - z):7.1f}  submit .. {1e3 * (tc - z):7.1f}  wait .. {1e3 * (td - z):7.1f}", file=sys.stderr)
+        print("[e2e] completions", [round(1e3 * (x - z), 1) for x in done_at], file=sys.stderr)
     t1 = time.perf_counter()
     eng.upload(batch)
     up_ms = 1000.0 * (time.perf_counter() - t1)

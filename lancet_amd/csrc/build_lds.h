@@ -31,17 +31,24 @@
 #define BL_DUPCAP 1024u
 enum { BLW_NONE = 0, BLW_NOREADS, BLW_SIZE, BLW_HASN, BLW_K, BLW_TABLE, BLW_NODES, BLW_TRACKED, BLW_CAND, BLW_QV, BLW_SURV, BLW_MATE, BLW_NAMES, BLW_PAIRS };
 
+#ifdef LANCET_WAVE_EMU
+#define BL_DBG(...) do { if (getenv("LANCET_EMU_WHY")) fprintf(stderr, __VA_ARGS__); } while (0)
+#else
+#define BL_DBG(...) ((void)0)
+#endif
 #ifndef LANCET_WAVE_EMU
 #define BLP(S, id) do { if (threadIdx.x == 0) { const unsigned long long _t = wall_clock64(); (S).ph_acc[(S).ph_cur] += _t - (S).t_last; (S).t_last = _t; (S).ph_cur = (id); } } while (0)
 #else
-#define BLP(S, id) ((void)0)
+static thread_local unsigned long bl_emu_sync_acc[17], bl_emu_sync_last = 0; static thread_local int bl_emu_sync_cur = 16;   /* barriers per phase (tuning aid) */
+#define BLP(S, id) do { bl_emu_sync_acc[bl_emu_sync_cur] += lc_emu_syncs - bl_emu_sync_last; bl_emu_sync_last = lc_emu_syncs; bl_emu_sync_cur = (id); } while (0)
 #endif
 // uniform read of a control word: barrier, read, barrier (kernels.h wg_bcast)
 
 // Two size configurations of the same code:
 //   bl_small  512 lanes, 40 960 bases, 512 reads, 80 KB of LDS: two workgroups per CU -- the 30x/30x windows;
-//   bl_large 1024 lanes, 65 520 bases (16-bit offsets), 1024 reads, ~100 KB of LDS: one workgroup per CU -- windows the small
-//            one turns away for their size (60x/60x: ~360 reads, 58 k bases), taken off the list the small kernel leaves.
+//   bl_large 1024 lanes, 131 040 bases (17-bit offsets under a 15-bit fingerprint), 1024 reads, a 64 KB phase area (room for the
+//            mate-overlap replay of 8192 occurrences), ~158 KB of LDS: one workgroup per CU -- windows the small one turns away
+//            for their size (60x/60x: ~360 reads, 58 k bases), taken off the list the small kernel leaves.
 // Same limits on what leaves the workgroup (PB_NCAP nodes, PB_CCAP candidates, PB_SCAP survivors: layout.h).
 #ifndef BL_SMALL_WG
 #define BL_SMALL_WG 512           /* lanes of the small configuration (tuning builds: tools/variant.sh)          */
@@ -57,17 +64,25 @@ enum { BLW_NONE = 0, BLW_NOREADS, BLW_SIZE, BLW_HASN, BLW_K, BLW_TABLE, BLW_NODE
 #define BL_SLOTS 8192
 #define BL_TCAP 2048              /* tracked nodes                                                             */
 #define BL_BIG 32768              /* bytes of the phase-dependent LDS area                                     */
+#define BL_OFFBITS 16             /* bits of an LDS base offset                                                */
+#define BL_FLAGCAP 1024u          /* occurrences the mate-overlap prefilter may flag                           */
 #define BL_LDS_LIMIT (80u * 1024u)
 #include "build_lds_impl.h"
 #undef BL_NS
 #undef BL_WG
 #undef BL_BASES
 #undef BL_RMAX
+#undef BL_BIG
+#undef BL_OFFBITS
+#undef BL_FLAGCAP
 #undef BL_LDS_LIMIT
 #define BL_NS bl_large
 #define BL_WG 1024
-#define BL_BASES 65520
+#define BL_BASES 131040
 #define BL_RMAX 1024
+#define BL_BIG 65536
+#define BL_OFFBITS 17
+#define BL_FLAGCAP 2048u
 #define BL_LDS_LIMIT (160u * 1024u)
 #include "build_lds_impl.h"
 #undef BL_NS
@@ -77,4 +92,6 @@ enum { BLW_NONE = 0, BLW_NOREADS, BLW_SIZE, BLW_HASN, BLW_K, BLW_TABLE, BLW_NODE
 #undef BL_SLOTS
 #undef BL_TCAP
 #undef BL_BIG
+#undef BL_OFFBITS
+#undef BL_FLAGCAP
 #undef BL_LDS_LIMIT

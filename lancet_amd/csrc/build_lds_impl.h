@@ -1,18 +1,31 @@
 // build_lds_impl.h -- body of the LDS build kernel, included by build_lds.h once per size configuration (BL_NS, BL_WG, BL_BASES,
-// BL_RMAX, BL_SLOTS, BL_TCAP, BL_BIG, BL_LDS_LIMIT).  No include guard on purpose.
+// BL_RMAX, BL_SLOTS, BL_TCAP, BL_BIG, BL_OFFBITS, BL_FLAGCAP, BL_LDS_LIMIT).  No include guard on purpose.
 namespace BL_NS {
+
+// An LDS offset (a base of the packed reads) has BL_OFFBITS bits; the k-mer table keeps it under a fingerprint of the remaining bits.
+#if BL_OFFBITS > 16
+typedef uint32_t bl_occ_t;          /* an occurrence index (the window may hold more than 65 535 k-mer starts) */
+#else
+typedef uint16_t bl_occ_t;
+#endif
+static constexpr uint32_t BL_OFFMASK = (1u << BL_OFFBITS) - 1u;
+static constexpr uint32_t LDS_BASES = BL_BASES, LDS_READS = BL_RMAX;       /* this configuration's limits, for the host */
+static_assert(BL_BASES < (1u << BL_OFFBITS) && BL_BASES / 16 + 4 < 65536, "offsets of the packed reads");
 
 struct BlShared {
   uint32_t bases[BL_BASES / 16 + 4];
   uint32_t goodm[BL_BASES / 32 + 4];
   uint16_t rdo[BL_RMAX + 4];        /* first 16-base word of read r                                             */
   uint16_t gwo[BL_RMAX + 4];        /* first quality-mask word of read r                                        */
-  uint16_t obase[BL_RMAX + 4];      /* first occurrence index of read r; [R] = O                                */
+  bl_occ_t obase[BL_RMAX + 4];      /* first occurrence index of read r; [R] = O                                */
   uint16_t o2r[BL_BASES / 128 + 2]; /* read that holds occurrence 128 * j                                       */
   uint32_t rinfo[BL_RMAX + 4];
   uint8_t pidx[BL_RMAX + 4];        /* mate-pair signature bit of the read (0xFF none)                          */
   uint8_t prole[BL_RMAX + 4];       /* 1 = earlier mate of a pair, 2 = the later one                            */
-  uint16_t idoff[PB_NCAP];          /* node id -> LDS offset of its first occurrence                            */
+  uint16_t idoff[PB_NCAP];          /* node id -> LDS offset of its first occurrence (its low 16 bits)          */
+#if BL_OFFBITS > 16
+  uint32_t idhi[PB_NCAP / 32 + 1];  /* ... bit 16 of it                                                          */
+#endif
   uint16_t cidx[PB_NCAP];           /* node id -> tracked index, later survivor index (0xFFFF none)             */
   uint16_t t2c[BL_TCAP];            /* tracked index -> candidate index (0xFFFF none)                           */
   alignas(16) uint32_t big[BL_BIG / 4];   /* (64-bit LDS atomics on it: must be 8-byte aligned) */
@@ -40,12 +53,12 @@ struct BlScratch {
   LC_GLOBAL uint32_t *c_minqv;      /* [PB_CCAP]                                                                 */
   LC_GLOBAL uint32_t *s_ci;         /* [PB_SCAP] candidate of survivor si                                        */
   LC_GLOBAL uint32_t *s_edges;      /* [PB_SCAP * 9] resolved edges + count                                      */
-  LC_GLOBAL uint16_t *dupo;         /* [BL_DUPCAP] occurrences that met their k-mer in the other orientation, or twice in one read */
+  LC_GLOBAL uint32_t *dupo;         /* [BL_DUPCAP] occurrences that met their k-mer in the other orientation, or twice in one read */
   LC_GLOBAL uint32_t *ord;          /* [4 * PB_CMAX] (spare) */
   LC_GLOBAL uint32_t *pq;           /* [BL_PQCAP] per-position counts: the occurrences of the candidates beyond the first LDS group (read | position << 10 | candidate << 20 | reversed << 31) */
 };
 static constexpr uint32_t BL_PQCAP = 16384u;
-static constexpr uint32_t SCRATCH_BYTES = (2u * BL_BASES + 64u + 8u * BL_TCAP + 4u * BL_TCAP + 12u * PB_CCAP + 4u * PB_SCAP + 36u * PB_SCAP + 2u * BL_DUPCAP + 16u * PB_CMAX + 4u * 16384u + 768u);
+static constexpr uint32_t SCRATCH_BYTES = (2u * BL_BASES + 64u + 8u * BL_TCAP + 4u * BL_TCAP + 12u * PB_CCAP + 4u * PB_SCAP + 36u * PB_SCAP + 4u * BL_DUPCAP + 16u * PB_CMAX + 4u * 16384u + 768u);
 static constexpr int WG = BL_WG;
 DEV void bl_scratch_carve(BlScratch *s, LC_GLOBAL uint8_t *base) {
   size_t o = 0;
@@ -58,7 +71,7 @@ DEV void bl_scratch_carve(BlScratch *s, LC_GLOBAL uint8_t *base) {
   s->c_minqv = (LC_GLOBAL uint32_t *)take(4u * PB_CCAP);
   s->s_ci = (LC_GLOBAL uint32_t *)take(4u * PB_SCAP);
   s->s_edges = (LC_GLOBAL uint32_t *)take(36u * PB_SCAP);
-  s->dupo = (LC_GLOBAL uint16_t *)take(2u * BL_DUPCAP);
+  s->dupo = (LC_GLOBAL uint32_t *)take(4u * BL_DUPCAP);
   s->ord = (LC_GLOBAL uint32_t *)take(16u * PB_CMAX);
   s->pq = (LC_GLOBAL uint32_t *)take(4u * BL_PQCAP);
 }
@@ -98,6 +111,7 @@ DEV void bl_scan32(LC_LDS uint32_t *a, int n, BL_S &S) {
   uint32_t run = 0;
   for (int i = 0; i < n; ++i) { const uint32_t x = a[i]; a[i] = run; run += x; }
   S.scan_total = run;
+  lc_emu_syncs += 2;
 #endif
 }
 
@@ -125,6 +139,13 @@ DEV unsigned long long bl_canon2(unsigned long long v, int K, unsigned long long
   *fwd = fw;
   *isF = fw < rc;
   return *isF ? fw : rc;
+}
+template <class SS> DEV uint32_t bl_idoff(SS &S, uint32_t n) {     // LDS offset of node n's first occurrence
+#if BL_OFFBITS > 16
+  return (uint32_t)S.idoff[n] | (((S.idhi[n >> 5] >> (n & 31u)) & 1u) << 16);
+#else
+  return (uint32_t)S.idoff[n];
+#endif
 }
 DEV int bl_base(const LC_LDS uint32_t *bases, uint32_t boff) { return (int)((bases[boff >> 4] >> ((boff & 15u) * 2u)) & 3u); }
 // quality-mask bits [a, b) of a read whose mask starts at word gw: all set?
@@ -497,7 +518,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
   WG_FOR(hx, nheads) {
     const uint32_t u = HL[hx];
     const lc_u4 a = pr_unpack(PT[2 * (size_t)u]), b = pr_unpack(PT[2 * (size_t)u + 1]);
-    const uint32_t mF = a.y & 0x7FFFFFFFu, mR = b.y & 0x7FFFFFFFu, cnt = mF + mR;
+    const uint32_t mF = a.y & 0x7FFFFFFFu, mR = b.y & 0x7FFFFFFFu;
     uint32_t ci; const unsigned long long kk = node_key(u, &ci);
     const uint32_t si = pos2si[u], n = sidv[si];
     const uint32_t nb = AL[u];
@@ -699,8 +720,8 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   }
   WG_LANE0 { tmpC[R] = 0; }
   bl_scan32(tmpC, R + 1, S);
-  WG_FOR(r, R + 1) { S.obase[r] = (uint16_t)tmpC[r]; }
-  WG_LANE0 { S.O = S.scan_total; S.obase[R + 1] = 0xFFFFu; }
+  WG_FOR(r, R + 1) { S.obase[r] = (bl_occ_t)tmpC[r]; }
+  WG_LANE0 { S.O = S.scan_total; S.obase[R + 1] = (bl_occ_t)~(bl_occ_t)0; }
   WG_SYNC();
   WG_FOR(r, R) {                                                 // read r holds the occurrences [obase[r], obase[r+1]): the multiples of 128 among them
     const uint32_t a = S.obase[r], b = S.obase[r + 1];
@@ -771,14 +792,14 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     uint32_t hh = (uint32_t)ck * 0x9E3779B1u ^ (((uint32_t)(ck >> 32)) ^ ((uint32_t)ck >> 15)) * 0x85EBCA77u;
     hh ^= hh >> 15; hh *= 0x2C1B3C6Du; hh ^= hh >> 12;
     uint32_t idx = hh & (BL_SLOTS - 1);
-    uint32_t fp = hh >> 16; if (fp == 0xFFFFu) fp = 0xFFFEu;
-    const uint32_t mine = (fp << 16) | boff;
+    uint32_t fp = hh >> BL_OFFBITS; if (fp == (0xFFFFFFFFu >> BL_OFFBITS)) fp -= 1u;
+    const uint32_t mine = (fp << BL_OFFBITS) | boff;
     uint32_t probes = 0;
     while (true) {
       uint32_t cur = ld2(&tab[idx]);
       if (cur == BL_EMPTY) { cur = dev_atomic_cas32(&tab[idx], BL_EMPTY, mine); if (cur == BL_EMPTY) break; }
-      if ((cur >> 16) == fp) {
-        const unsigned long long v2 = bl_kmer(S.bases, cur & 0xFFFFu, kmask);
+      if ((cur >> BL_OFFBITS) == fp) {
+        const unsigned long long v2 = bl_kmer(S.bases, cur & BL_OFFMASK, kmask);
         if (v2 == v1 || v2 == alt) {
           const bool f2 = (v2 == v1) ? isF : !isF;
           if (mine < cur) dev_atomic_min(&tab[idx], mine);
@@ -788,9 +809,9 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
           // inverted repeat, which isRepeat does not look for), means a walk comes back to the node: if that node survives
           // removeLowCov the graph has a cycle and this k is rejected (Microassembler.cc:198-206).  The occurrence is noted
           // here and looked at again once the survivors are known.
-          if (cur != mine && ((f2 != isF) || (r < nr && (cur & 0xFFFFu) - 16u * S.rdo[r] < (uint32_t)RI_TLEN(S.rinfo[r])))) {
+          if (cur != mine && ((f2 != isF) || (r < nr && (cur & BL_OFFMASK) - 16u * S.rdo[r] < (uint32_t)RI_TLEN(S.rinfo[r])))) {
             const uint32_t di = dev_atomic_add((LC_LDS uint32_t *)&S.ndup, 1u);
-            if (di < BL_DUPCAP) X.dupo[di] = (uint16_t)boff;
+            if (di < BL_DUPCAP) X.dupo[di] = boff;
           }
           break;
         }
@@ -806,13 +827,17 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   // ---- node ids in first-insertion order: rank of the slot's first-occurrence offset among the occupied slots
   {
     // bitmap over the LDS offsets of first occurrences (cidx is idle here) + its popcount prefix per PAIR of words (t2c is idle too)
-    LC_LDS uint32_t *bm = (LC_LDS uint32_t *)S.cidx;
-    LC_LDS uint32_t *pre = (LC_LDS uint32_t *)S.t2c;
     constexpr int NBW = BL_BASES / 32 + 1, NPW = (NBW + 1) / 2;
-    static_assert((size_t)NBW * 4 <= sizeof(S.cidx) && (size_t)NPW * 4 <= sizeof(S.t2c), "node-id bitmap / prefix do not fit cidx / t2c");
+    constexpr bool in_big = (size_t)NBW * 4 > sizeof(S.cidx) || (size_t)NPW * 4 > sizeof(S.t2c);      // (the larger configuration: behind the table in S.big)
+    static_assert(!in_big || (size_t)BL_SLOTS * 4 + (size_t)NBW * 4 + (size_t)NPW * 4 <= (size_t)BL_BIG, "node-id bitmap / prefix fit neither cidx / t2c nor S.big");
+    LC_LDS uint32_t *bm = in_big ? S.big + BL_SLOTS : (LC_LDS uint32_t *)S.cidx;
+    LC_LDS uint32_t *pre = in_big ? S.big + BL_SLOTS + NBW : (LC_LDS uint32_t *)S.t2c;
     WG_FOR(i, NBW) { bm[i] = 0; }
+#if BL_OFFBITS > 16
+    WG_FOR(i, PB_NCAP / 32 + 1) { S.idhi[i] = 0; }
+#endif
     WG_SYNC();
-    WG_FOR(i, BL_SLOTS) { const uint32_t e = tab[i]; if (e != BL_EMPTY) dev_atomic_or(&bm[(e & 0xFFFFu) >> 5], 1u << (e & 31u)); }
+    WG_FOR(i, BL_SLOTS) { const uint32_t e = tab[i]; if (e != BL_EMPTY) dev_atomic_or(&bm[(e & BL_OFFMASK) >> 5], 1u << (e & 31u)); }
     WG_SYNC();
     WG_FOR(i, NPW) { pre[i] = (uint32_t)dev_popc(bm[2 * i]) + (2 * i + 1 < NBW ? (uint32_t)dev_popc(bm[2 * i + 1]) : 0u); }
     bl_scan32(pre, NPW, S);
@@ -821,10 +846,13 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_FOR(i, BL_SLOTS) {
       const uint32_t e = tab[i];
       if (e != BL_EMPTY) {
-        const uint32_t off = e & 0xFFFFu, wd = off >> 5;
+        const uint32_t off = e & BL_OFFMASK, wd = off >> 5;
         const uint32_t id = pre[wd >> 1] + ((wd & 1u) ? (uint32_t)dev_popc(bm[wd - 1u]) : 0u) + (uint32_t)dev_popc(bm[wd] & ((1u << (off & 31u)) - 1u));
         tab[i] = id;                                             // slot -> node id, occurrence count in the upper half (below)
         S.idoff[id] = (uint16_t)off;
+#if BL_OFFBITS > 16
+        if (off >> 16) dev_atomic_or(&S.idhi[id >> 5], 1u << (id & 31u));
+#endif
       }
     }
     WG_SYNC();
@@ -846,7 +874,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     LC_GLOBAL unsigned long long *nhash = (LC_GLOBAL unsigned long long *)(area + PRE_OFF_NHASH);
     LC_GLOBAL uint8_t *surv = (LC_GLOBAL uint8_t *)(area + PRE_OFF_SURV);
     WG_FOR(n, N) {
-      bool f; const unsigned long long ck = bl_canon(bl_kmer(S.bases, S.idoff[n], kmask), K, kmask, &f);
+      bool f; const unsigned long long ck = bl_canon(bl_kmer(S.bases, bl_idoff(S, (uint32_t)n), kmask), K, kmask, &f);
       nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGT"[key_base(&ck, K, j)]; }, K);
       surv[n] = 0;
     }
@@ -864,7 +892,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       // with coverage 2 and is trimmed as a tip later: k is not rejected for it)
     const uint32_t nd = S.ndup < BL_DUPCAP ? S.ndup : BL_DUPCAP;
     const uint32_t cthr = (uint32_t)(avgcov / 4.0) > 4u ? (uint32_t)(avgcov / 4.0) : 4u;
-    WG_FOR(i, nd) { if ((uint32_t)S.cidx[X.occn[X.dupo[i]] & 0x1FFFu] < cthr) X.dupo[i] = (uint16_t)0xFFFFu; }
+    WG_FOR(i, nd) { if ((uint32_t)S.cidx[X.occn[X.dupo[i]] & 0x1FFFu] < cthr) X.dupo[i] = 0xFFFFFFFFu; }
   }
   {
     LC_LDS uint32_t *fl = S.big;                                 // (the table is no longer needed: occn holds node ids)
@@ -886,8 +914,8 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     LC_LDS unsigned long long *cc = (LC_LDS unsigned long long *)S.big;
     LC_LDS unsigned long long *sig = cc + T;
     LC_LDS uint32_t *mk = S.big + BL_BIG / 4 - 64;                 // marked tracked nodes (hold a flagged occurrence)
-    LC_LDS uint32_t *todo = mk - 1024;                             // flagged occurrences: read << 10 | position
-    WG_LANE0 { S.flagged = 0; if (2u * T * (1u + SW) > (uint32_t)(BL_BIG / 4 - 64 - 1024)) S.why = BLW_PAIRS; }
+    LC_LDS uint32_t *todo = mk - BL_FLAGCAP;                       // flagged occurrences: read << 10 | position
+    WG_LANE0 { S.flagged = 0; if (2u * T * (1u + SW) > (uint32_t)(BL_BIG / 4 - 64 - BL_FLAGCAP)) S.why = BLW_PAIRS; }
     if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
     WG_FOR(t, T) { cc[t] = 0; S.t2c[t] = 0; }
     WG_FOR(t, T * SW) { sig[t] = 0; }
@@ -921,13 +949,13 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       const uint32_t ti = S.cidx[e & 0x1FFFu];
       if (ti != 0xFFFFu && ((sig[ti * SW + (S.pidx[r] >> 6)] >> (S.pidx[r] & 63u)) & 1ULL)) {
         const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.flagged, 1u);
-        if (at < 1024u) todo[at] = ((uint32_t)r << 10) | (uint32_t)p;
+        if (at < BL_FLAGCAP) todo[at] = ((uint32_t)r << 10) | (uint32_t)p;
         dev_atomic_or(&mk[ti >> 5], 1u << (ti & 31u));
       }
     });
     if (C->debug_stop == 121u) { WG_LANE0 { H->why = 99; } return; }
     WG_SYNC();                                                     // (every wave's flagged occurrences are counted before lane 0 looks)
-    WG_LANE0 { if (S.flagged > 1024u) S.why = BLW_MATE; }
+    WG_LANE0 { if (S.flagged > BL_FLAGCAP) { S.why = BLW_MATE; BL_DBG("[emu] window %d: %u flagged mate occurrences (%u)\n", w, S.flagged, (uint32_t)BL_FLAGCAP); } }
     if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
     const uint32_t nflag = bl_bcast(&S.flagged);
     if (nflag) {
@@ -935,27 +963,40 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       //      this read, in push order (unsorted: SURVEY.md H3).  The occurrences of the marked nodes are listed as
       //      node << 20 | read << 10 | position and sorted, which is the order loadSequence visited them in.
       LC_LDS uint32_t *list = S.big + 2 * T;                       // (sig is done with)
-      const uint32_t lcap0 = (uint32_t)(BL_BIG / 4 - 64 - 1024) - 2u * T;
-      uint32_t lcap = 1; while (lcap * 2u <= lcap0 && lcap < 4096u) lcap *= 2u;
-      WG_LANE0 { S.g0 = 0; }
-      WG_FOR(i, lcap) { list[i] = 0xFFFFFFFFu; }
-      WG_SYNC();
-      bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
-        (void)boff;
-        if (r == nr) return;
-        const uint32_t ti = S.cidx[e & 0x1FFFu];
-        if (ti == 0xFFFFu || !((mk[ti >> 5] >> (ti & 31u)) & 1u)) return;
-        const uint32_t mt = RI_MATE(S.rinfo[r]);
-        if (mt != 1 && mt != 2) return;
-        const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.g0, 1u);
-        if (at < lcap) list[at] = (ti << 20) | ((uint32_t)r << 10) | (uint32_t)p;
-      });
-      WG_SYNC();                                                   // (the count is complete only once every wave is through: without this barrier
+      const uint32_t lcap0 = (uint32_t)(BL_BIG / 4 - 64 - BL_FLAGCAP) - 2u * T;
+      uint32_t lcap = 1; while (lcap * 2u <= lcap0 && lcap < (uint32_t)BL_BIG / 8u) lcap *= 2u;
+      if (C->debug_stop == 131u) lcap = 512u;                       // (test knob: the ranges below on ordinary windows)
+      // The list holds lcap entries; when the marked nodes have more occurrences than that, they are taken in ranges [t_lo, t_hi) of
+      // tracked indices (a node's run is complete within its range), the range halved until its occurrences fit.
+      uint32_t t_lo = 0;
+      while (t_lo < T) {
+      uint32_t t_hi = T, nl = 0;
+      while (true) {
+        WG_LANE0 { S.g0 = 0; }
+        WG_FOR(i, lcap) { list[i] = 0xFFFFFFFFu; }
+        WG_SYNC();
+        bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
+          (void)boff;
+          if (r == nr) return;
+          const uint32_t ti = S.cidx[e & 0x1FFFu];
+          if (ti == 0xFFFFu || ti < t_lo || ti >= t_hi || !((mk[ti >> 5] >> (ti & 31u)) & 1u)) return;
+          const uint32_t mt = RI_MATE(S.rinfo[r]);
+          if (mt != 1 && mt != 2) return;
+          const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.g0, 1u);
+          if (at < lcap) list[at] = (ti << 20) | ((uint32_t)r << 10) | (uint32_t)p;
+        });
+        WG_SYNC();                                                 // (the count is complete only once every wave is through: without this barrier
                                                                    //  lane 0 could pass the test on a partial count, and the sort below then ran
                                                                    //  over the flagged-occurrence list next to it -- found on the 1024-lane configuration)
-      WG_LANE0 { if (S.g0 > lcap) S.why = BLW_MATE; }
+        nl = bl_bcast(&S.g0);
+        if (nl <= lcap) break;
+        if (t_hi - t_lo <= 1u) {                                    // one node with more occurrences than the list holds
+          WG_LANE0 { S.why = BLW_MATE; BL_DBG("[emu] window %d: %u occurrences on one marked node (%u), %u tracked\n", w, S.g0, lcap, T); }
+          break;
+        }
+        t_hi = t_lo + (t_hi - t_lo) / 2u;
+      }
       if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
-      const uint32_t nl = bl_bcast(&S.g0);
       if (C->debug_stop == 123u) { WG_LANE0 { H->why = 99; } return; }
       uint32_t n2 = 1; while (n2 < nl) n2 *= 2u;
       for (uint32_t kk = 2; kk <= n2; kk <<= 1)                    // bitonic sort, ascending (the padding sorts last)
@@ -976,6 +1017,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
         const uint32_t boff = 16u * S.rdo[r] + p;
         const uint32_t e = X.occn[boff];
         const uint32_t ti = S.cidx[e & 0x1FFFu];
+        if (ti < t_lo || ti >= t_hi) continue;
         const uint32_t ri = S.rinfo[r];
         const uint32_t mi = RI_MATE(ri), nm = B.name_rank[g0 + r] & 0xFFFFu;
         uint32_t lo = 0, len = nl;                                   // start of the node's run
@@ -999,12 +1041,15 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
         while (l2 > 0) { const uint32_t h = l2 >> 1, mid = first + h; if (name_at(mid) < nm) { first = mid + 1; l2 = l2 - h - 1; } else l2 = h; }
         const bool ovl = (first != total) && !(nm < name_at(first));
         if (ovl) {                                                   // do not update coverage for overlapping mates (Graph.cc:267-271)
+          BL_DBG("[emu] window %d: overlapping mate, read %u position %u (nodes %u..%u of %u)\n", w, r, p, t_lo, t_hi, T);
           const uint32_t cls = (RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u);
           dev_atomic_add64(&cc[ti], 0ULL - (1ULL << (16 * cls)));
           X.occn[boff] = (uint16_t)(e | 0x4000u);
         }
       }
       WG_SYNC();
+      t_lo = t_hi;
+      }
     }
     if (C->debug_stop == 122u) { WG_LANE0 { H->why = 99; } return; }
     WG_FOR(t, T) { X.tcc[t] = cc[t]; X.tfl[t] = ((S.t2c[t] & 1u) ? NF_TUMOR : 0u) | ((S.t2c[t] & 2u) ? NF_NORMAL : 0u); }
@@ -1162,7 +1207,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       snode[ci] = sv ? n : LC_NIL;
       if (sv) {
         const uint32_t si = fl[ci];
-        bool f; skey[ci] = bl_canon(bl_kmer(S.bases, S.idoff[n], kmask), K, kmask, &f);
+        bool f; skey[ci] = bl_canon(bl_kmer(S.bases, bl_idoff(S, (uint32_t)n), kmask), K, kmask, &f);
         sid[si] = n; surv[n] = 1; X.s_ci[si] = (uint32_t)ci;
       }
     }
@@ -1209,7 +1254,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_SYNC();
     {   // the hint: does a node that was met twice in a read / in both orientations survive?
       const uint32_t nd = S.ndup < BL_DUPCAP ? S.ndup : BL_DUPCAP;
-      WG_FOR(i, nd) { const uint32_t o = X.dupo[i]; if (o != 0xFFFFu && S.cidx[X.occn[o] & 0x1FFFu] != 0xFFFFu) S.hint = 1; }
+      WG_FOR(i, nd) { const uint32_t o = X.dupo[i]; if (o != 0xFFFFFFFFu && S.cidx[X.occn[o] & 0x1FFFu] != 0xFFFFu) S.hint = 1; }
       WG_LANE0 { if (S.ndup > BL_DUPCAP) S.hint = 1; }
     }
     WG_SYNC();

@@ -61,6 +61,12 @@ __global__ void __launch_bounds__(bl_small::WG) __attribute__((amdgpu_waves_per_
 }
 // (the control block is set up by a kernel, not by a copy: an asynchronous copy from pageable host memory blocks the caller until the
 //  stream has caught up, and with another engine's persistent kernels on the device that is the rest of their batch)
+// ... and the same in the 1024-lane configuration, for a batch with windows beyond the 512-lane one's limits (one workgroup per CU)
+__global__ void __launch_bounds__(bl_large::WG) __attribute__((amdgpu_waves_per_eu(4, 4))) svc_kernel_large(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue,
+                                                                 uint8_t *pool, uint32_t pool_cap, int depth, SvcCtl *sv, const uint32_t *wqueue) {
+  bl_large::svc_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL uint8_t *)pre, (LC_GLOBAL uint8_t *)scratch,
+                            (LC_GLOBAL uint32_t *)queue, *(bl_large::BL_S *)&bl_large::bl_shared, (int)blockIdx.x, (LC_GLOBAL uint8_t *)pool, pool_cap, depth, (LC_GLOBAL SvcCtl *)sv, (LC_GLOBAL const uint32_t *)wqueue);
+}
 __global__ void svc_init_kernel(SvcCtl *sv, SvcCtl v) { *sv = v; }
 __global__ void svc_done_kernel(SvcCtl *sv) { __hip_atomic_store(&sv->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -191,7 +197,7 @@ struct lancet_engine {
   // build service (svc_kernel): control block + request / ready / continuation arrays in one buffer, scratch of its workgroups
   DevBuf d_svc, d_svcscratch;
   hipStream_t stream3 = nullptr; hipEvent_t ev_svc = nullptr;
-  bool svc = true, svc_running = false;      // LANCET_NO_SVC=1 (at create): every later graph of a window by the general build
+  bool svc = true, svc_running = false, svc_large = false;      // LANCET_NO_SVC=1 (at create): every later graph of a window by the general build
   int n_svc_wgs = 16; uint32_t svc_cap = 0; int svc_depth = 6;
   int svc_cus = 0, n_cus = 256;                // LANCET_SVC_CUS=n: CUs set aside for the service (CU masks on the two streams), so that its workgroups are resident
                                              // whatever the batch's kernels -- or another engine's -- occupy; 0 = no masks
@@ -560,12 +566,12 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     for (int w = 0; w < nw; ++w) {
       const uint32_t r0 = b->read_begin[w], r1 = b->read_begin[w + 1];
       bool big = r1 - r0 + 1 > e->caps.reads_cap;        // process_window's first test: more reads than a tier-1 slot holds
-      // ... or more than the larger configuration of the LDS build kernel takes (65 520 bases with every read padded to 16, 1024 reads):
+      // ... or more than the larger configuration of the LDS build kernel takes (131 040 bases with every read padded to 16, 1024 reads):
       // its graphs would all come from the general build on ONE wave (tens of ms: the tail of the launch); the several-wave kernel of the
       // re-run tier builds them in a few ms, next to everything else
       if (!big && e->prebuild && !e->no_large_build) {
         const uint64_t raw = (uint64_t)(b->seq_off[r1] - b->seq_off[r0]) + 8ull * (r1 - r0) + (b->ref_off[w + 1] - b->ref_off[w]) + 16u;    // (8: the mean padding)
-        big = raw > 65520ull || r1 - r0 > 1024u;
+        big = raw > (uint64_t)bl_large::LDS_BASES || r1 - r0 > bl_large::LDS_READS;
       }
       if (big) { e->pred.push_back((uint32_t)w); e->is_pred[w] = 1; }
     }
@@ -590,9 +596,9 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     else
     for (int w = 0; w < nw && !may_need_large; ++w) {
       const uint32_t r0 = b->read_begin[w], r1 = b->read_begin[w + 1];
-      if (r1 - r0 > 512u) { may_need_large = true; break; }
+      if (r1 - r0 > bl_small::LDS_READS) { may_need_large = true; break; }
       const uint64_t raw = (uint64_t)(b->seq_off[r1] - b->seq_off[r0]) + 15ull * (r1 - r0) + (b->ref_off[w + 1] - b->ref_off[w]) + 16u;
-      if (raw > 40960ull) may_need_large = true;
+      if (raw > (uint64_t)bl_small::LDS_BASES) may_need_large = true;
     }
     e->n_bslots_large = (e->no_large_build || !may_need_large) ? 0 : std::min(nw, cus);
     if (e->n_bslots_large) { ENS(e->d_blscratch_large, (size_t)e->n_bslots_large * bl_large::SCRATCH_BYTES); ENS(e->d_biglist, sizeof(uint32_t) * (size_t)nw); }
@@ -608,9 +614,10 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
       e->svc_cap = 2u * (uint32_t)nw + 1024u;
       const size_t off_req = 256, off_rdy = off_req + sizeof(SvcReq) * (size_t)e->svc_cap, off_cont = (off_rdy + 4u * (size_t)e->svc_cap + 63) & ~(size_t)63;
       ENS(e->d_svc, off_cont + sizeof(SvcCont) * (size_t)e->svc_cap);
-      ENS(e->d_svcscratch, (size_t)e->n_svc_wgs * bl_small::SCRATCH_BYTES);
+      e->svc_large = e->n_bslots_large > 0;             // windows above the 512-lane configuration's limits in the batch: the service runs the 1024-lane one
+      ENS(e->d_svcscratch, (size_t)e->n_svc_wgs * (e->svc_large ? bl_large::SCRATCH_BYTES : bl_small::SCRATCH_BYTES));
       memset(&e->svc_host, 0, sizeof(SvcCtl));
-      e->svc_host.cap = e->svc_cap;
+      e->svc_host.cap = e->svc_cap; e->svc_host.large = e->svc_large ? 1u : 0u;
       e->svc_host.req = (LC_GLOBAL SvcReq *)((char *)e->d_svc.p + off_req); e->svc_host.rdy = (LC_GLOBAL uint32_t *)((char *)e->d_svc.p + off_rdy);
       e->svc_host.cont = (LC_GLOBAL SvcCont *)((char *)e->d_svc.p + off_cont);
       o.svc = (LC_GLOBAL SvcCtl *)e->d_svc.p;
@@ -744,6 +751,11 @@ int lancet_engine_submit(lancet_engine *e) {
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipEventRecord(e->ev_svc, e->stream));
     HIPCHK(e, hipStreamWaitEvent(e->stream3, e->ev_svc, 0));
+    if (e->svc_large)
+      hipLaunchKernelGGL(svc_kernel_large, dim3(e->n_svc_wgs), dim3(bl_large::WG), 0, e->stream3, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
+                         (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_svcscratch.p, (uint32_t *)e->d_counters.p + 8,
+                         (uint8_t *)e->d_prepool.p, e->pool_cap, e->svc_depth, (SvcCtl *)e->d_svc.p, (const uint32_t *)e->d_counters.p + 2);
+    else
     hipLaunchKernelGGL(svc_kernel, dim3(e->n_svc_wgs), dim3(bl_small::WG), 0, e->stream3, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
                        (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_svcscratch.p, (uint32_t *)e->d_counters.p + 8,
                        (uint8_t *)e->d_prepool.p, e->pool_cap, e->svc_depth, (SvcCtl *)e->d_svc.p, (const uint32_t *)e->d_counters.p + 2);

@@ -4632,7 +4632,7 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
 
 // ---------------------------------------------------------------------------------------------------------
 // Build service (layout.h SvcCtl): the loop needs a graph at k that nobody built in LDS.  If the window is one the LDS build
-// kernel can take (its first graph came from the 512-lane configuration) the state the reference carries from one k to the
+// kernel can take (its first graph came from the configuration the service runs) the state the reference carries from one k to the
 // next (Ref_t::seq / trim of the last markRefEnds, the variants emitted so far) goes into a continuation record,
 // a request is posted and the slot is free for another window.  Returns true when the window was suspended.
 // ---------------------------------------------------------------------------------------------------------
@@ -4645,7 +4645,7 @@ DEVNI bool try_suspend(Ctx &c, int k) {
   WG_LANE0 {
     S.tmp1 = 0;
     LC_GLOBAL const PreHdr *H0 = (LC_GLOBAL const PreHdr *)(LC_CTX(c).OUT->pre + (size_t)w * PRE_STRIDE + PRE_OFF_HDR);
-    if (k != S.nosusp_k && (k & 1) && k <= 31 && !S.overflow && LC_CTX(c).OUT->pre_pool && H0->status == PB_BUILT && !H0->big) {
+    if (k != S.nosusp_k && (k & 1) && k <= 31 && !S.overflow && LC_CTX(c).OUT->pre_pool && H0->status == PB_BUILT && (!H0->big || sv->large)) {
       const uint32_t i = dev_atomic_add(&sv->req_alloc, 1u);
       if (i < sv->cap) { S.tmp1 = 1; S.svc_i = i; }
     }

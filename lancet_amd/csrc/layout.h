@@ -293,7 +293,8 @@ struct SvcCtl {
   uint32_t beat;          /* bumped by the window slots at every window / k attempt: the service's sign that somebody else runs */
   uint32_t n_gaveup;      /* service workgroups that left because nothing else made progress (kernels serialised by a profiler)  */
   uint32_t n_waiting;     /* window slots that wait for a graph: never more than there are requests out (the others leave and free their CU) */
-  uint32_t pad[2];
+  uint32_t large;         /* the service workgroups are the 1024-lane configuration: windows of any size the build kernels take may ask */
+  uint32_t pad;
   LC_GLOBAL SvcReq *req;          /* [cap] */
   LC_GLOBAL uint32_t *rdy;        /* [cap] request index + 1 */
   LC_GLOBAL SvcCont *cont;        /* [cap] */

@@ -79,8 +79,9 @@ DEV int dev_popcll(unsigned long long x) { return __popcll(x); }
 #define WG_FOR(i, n) for (int i = 0; i < (int)(n); ++i)
 #define XG_FOR(i, n) WG_FOR(i, n)
 #define XG_LANES 64
-#define WG_SYNC() ((void)0)
-#define WG_SYNC_FENCE() ((void)0)
+static thread_local unsigned long lc_emu_syncs = 0;          /* barriers a workgroup would execute (tuning aid: tests/emu LANCET_EMU_SYNCS) */
+#define WG_SYNC() ((void)++lc_emu_syncs)
+#define WG_SYNC_FENCE() ((void)++lc_emu_syncs)
 #define WG_LANE0 if (true)
 #define WG_SHARED static thread_local
 DEV uint32_t dev_atomic_min(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }

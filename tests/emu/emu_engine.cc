@@ -27,7 +27,8 @@ struct EmuResult {
 };
 
 extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batch *b, uint32_t evt_cap) {
-  EngineCaps C = lc_caps_for_batch(b, P, evt_cap, 65536);
+  EngineCaps C = getenv("LANCET_EMU_TIER1") ? lc_caps_for_batch(b, P, evt_cap, 16384, 1)      // (the engine's tier-1 work space: to see which limit a window hits there)
+                                            : lc_caps_for_batch(b, P, evt_cap, 65536);
   if (const char *ts = getenv("LANCET_TABLE_START")) C.table_start = lc_pow2_ge((uint32_t)atoi(ts));
   if (const char *st = getenv("LANCET_STOP_PHASE")) C.debug_stop = (uint32_t)atoi(st);
   const uint32_t R = b->read_begin[b->n_windows];
@@ -64,11 +65,11 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   static thread_local bl_small::BlShared BS;
   uint32_t bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t pool_cap = 0; int depth = 0;
+  static thread_local bl_large::BlShared BSL;
   O.pre = nullptr; O.pre_pool = nullptr; O.n_ahead_used = &res->n_ahead_used;
   res->n_prebuilt = 0; res->n_ahead_built = 0; res->n_ahead_used = 0; res->n_biglist = 0;
   if (!P->lr_mode && !getenv("LANCET_NO_PREBUILD") && b->n_windows > 0) {
     pre.assign((size_t)b->n_windows * PRE_STRIDE, 0xCD); blscr.assign(bl_large::SCRATCH_BYTES + 256, 0xCD);
-    static thread_local bl_large::BlShared BSL;
     memset(&BS, 0xCD, sizeof(BS)); memset(&BSL, 0xCD, sizeof(BSL));
     std::vector<uint32_t> biglist((size_t)b->n_windows + 1, 0);
     const bool large = getenv("LANCET_NO_LARGE_BUILD") == nullptr;
@@ -82,6 +83,12 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
     bl_small::build_kernel_body(P, &B, &C, pre.data(), blscr.data(), bq, BS, 0, nullptr, pool_cap ? pool.data() : nullptr, pool_cap, depth, large ? biglist.data() : nullptr, false);
     if (large) bl_large::build_kernel_body(P, &B, &C, pre.data(), blscr.data(), bq, BSL, 0, nullptr, pool_cap ? pool.data() : nullptr, pool_cap, depth, biglist.data(), true);
     res->n_biglist = bq[4];
+    if (getenv("LANCET_EMU_SYNCS")) {
+      unsigned long tot = 0; for (int i = 0; i < 16; ++i) tot += bl_emu_sync_acc[i];
+      fprintf(stderr, "[emu] build kernel: %.1f barriers per window;", (double)tot / b->n_windows);
+      for (int i = 0; i < 16; ++i) fprintf(stderr, " %d:%.1f", i, (double)bl_emu_sync_acc[i] / b->n_windows);
+      fprintf(stderr, "\n");
+    }
     O.pre = pre.data(); O.pre_pool = pool_cap ? pool.data() : nullptr;
     res->n_prebuilt = bq[1]; res->n_ahead_built = bq[3];
     res->n_cmp_done = 0;
@@ -101,10 +108,12 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
     sreq.assign(sv.cap, SvcReq{0, 0, SV_EMPTY, 0}); srdy.assign(sv.cap, 0u); scont.resize(sv.cap);
     sv.req = sreq.data(); sv.rdy = srdy.data(); sv.cont = scont.data();
     sv.alive = getenv("LANCET_SVC_DEAD") ? 0u : 1u;
+    sv.large = res->n_biglist > 0 ? 1u : 0u;                    // (engine.hip: a batch with windows beyond the 512-lane configuration runs the service in the 1024-lane one)
     O.svc = &sv;
   }
   while (window_kernel_body(P, &B, &C, &work, &O, &S, 0) != 0)
-    bl_small::svc_kernel_body(P, &B, &C, pre.data(), blscr.data(), bq, BS, 0, pool.data(), pool_cap, getenv("LANCET_SVC_DEPTH") ? atoi(getenv("LANCET_SVC_DEPTH")) : depth, &sv);
+    if (sv.large) bl_large::svc_kernel_body(P, &B, &C, pre.data(), blscr.data(), bq, BSL, 0, pool.data(), pool_cap, getenv("LANCET_SVC_DEPTH") ? atoi(getenv("LANCET_SVC_DEPTH")) : depth, &sv);
+    else bl_small::svc_kernel_body(P, &B, &C, pre.data(), blscr.data(), bq, BS, 0, pool.data(), pool_cap, getenv("LANCET_SVC_DEPTH") ? atoi(getenv("LANCET_SVC_DEPTH")) : depth, &sv);
   res->n_svc_built = sv.n_built; res->n_svc_stolen = sv.n_stolen; res->n_svc_posted = sv.req_alloc < sv.cap ? sv.req_alloc : sv.cap;
   if (getenv("LANCET_EMU_SVC")) fprintf(stderr, "[emu] svc posted %u built %u failed %u stolen %u\n", sv.req_alloc, sv.n_built, sv.n_failed, sv.n_stolen);
   res->n_variants = nv < C.var_cap ? nv : C.var_cap; res->n_blob = nb;

@@ -337,17 +337,40 @@ def test_graph_built_ahead_is_adjusted_to_the_trimmed_reference_table():
 
 def test_deep_windows_through_the_1024_lane_build_configuration(monkeypatch):
     """60x/60x windows are above the 512-lane configuration's limits (40 960 bases in LDS): the first build kernel lists them and
-    the 1024-lane configuration (65 520 bases, one workgroup per CU) builds them, graphs built ahead included.  Then 30x/30x
-    windows forced through the 1024-lane configuration (every size-dependent piece of it on inputs the other one also takes)."""
+    the 1024-lane configuration (131 040 bases under 17-bit offsets, one workgroup per CU) builds them, graphs built ahead
+    included -- all of them: windows 94-96 of this batch need the mate-overlap replay of 6417 occurrences (the 512-lane
+    configuration's list holds 4096).  Then 100x/100x windows (640 reads, 100 k bases: offsets above 65 535), and 30x/30x windows
+    forced through the 1024-lane configuration (every size-dependent piece of it on inputs the other one also takes)."""
     from lancet_amd import workload
     p = abi.default_params()
     b = workload.make_scan_batch(100, 60, 60, seed=22)
     _same_as_oracle(b, p)
-    assert emu.LAST_BIGLIST[0] == 100 and emu.LAST_PREBUILT[0] >= 80
+    assert emu.LAST_BIGLIST[0] == 100 and emu.LAST_PREBUILT[0] == 100
+    b100 = workload.make_scan_batch(24, 100, 100, seed=5, error_rate=0.001)
+    assert min(b100.seq_off[b100.read_begin[w + 1]] - b100.seq_off[b100.read_begin[w]] for w in range(24)) > 70000
+    _same_as_oracle(b100, p)
+    assert emu.LAST_BIGLIST[0] == 24 and emu.LAST_PREBUILT[0] == 24
     monkeypatch.setenv("LANCET_EMU_FORCE_LARGE", "1")
     b30 = workload.make_scan_batch(60, 30, 30, seed=4)
     _same_as_oracle(b30, p)
     assert emu.LAST_PREBUILT[0] == 60
+
+
+def test_mate_overlap_replay_in_ranges_of_nodes(monkeypatch):
+    """hasOverlappingMate's exact replay in the LDS build kernel sorts the occurrences of the marked nodes in an LDS list; when they do
+    not fit, the nodes are taken in ranges.  170-base reads at a 400 +- 40 insert: a tenth of the pairs overlap (~200 occurrences in
+    32 windows are overlapping-mate occurrences, all windows built in LDS).  With the list cut to 512 entries (LANCET_STOP_PHASE=131)
+    every window goes through several ranges: same records, stats and trace.  (The `ovl` golden, whose mates overlap almost always,
+    flags more occurrences than the build kernel keeps and runs on the general build.)"""
+    from lancet_amd import workload
+    b = workload.make_scan_batch(32, 30, 30, seed=8, read_len=170)
+    p = abi.default_params()
+    _same_as_oracle(b, p)
+    assert emu.LAST_PREBUILT[0] == 32
+    base = emu.run(b, p, evt_cap=1 << 17)
+    monkeypatch.setenv("LANCET_STOP_PHASE", "131")
+    cut = emu.run(b, p, evt_cap=1 << 17)
+    assert emu.LAST_PREBUILT[0] == 32 and cut[0] == base[0] and cut[1] == base[1] and gu.digest_trace(cut[2]) == gu.digest_trace(base[2])
 
 
 # ---- the source of the several-wave re-run tier (window_fat.hip = kernels.h with LANCET_FAT): its own code paths -- per-position

@@ -25,3 +25,9 @@ print("windows not built in LDS by reason (BLW_*: 2 size, 5 table, 6 nodes, 7 tr
 t = ph.sum(axis=1) * 1000
 nb = (hd[:, 0] & 0xFF) != 1
 print("time ms: built mean %.2f max %.2f ; not built mean %.2f max %.2f ; reads not built mean %.0f" % (t[~nb].mean(), t[~nb].max(), t[nb].mean() if nb.any() else 0, t[nb].max() if nb.any() else 0, np.diff(big.read_begin)[nb].mean() if nb.any() else 0))
+order = np.argsort(-t)[:16]
+builds = np.array([s["n_builds"] for s in st])
+print("slowest windows (ms, builds, built in LDS, reads):", [(round(float(t[w]), 1), int(builds[w]), bool(~nb[w]), int(np.diff(big.read_begin)[w])) for w in order])
+for q in (50, 90, 99, 99.9): print("slot time percentile %.1f: %.2f ms" % (q, np.percentile(t, q)))
+print("slot time by number of builds:", {int(k): (int((builds == k).sum()), round(float(t[builds == k].mean()), 2)) for k in np.unique(builds)})
+print("windows in the re-run tier", eng.rerun_count(), "ahead", eng.ahead_counts())
