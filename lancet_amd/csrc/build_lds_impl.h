@@ -5,8 +5,10 @@ namespace BL_NS {
 // An LDS offset (a base of the packed reads) has BL_OFFBITS bits; the k-mer table keeps it under a fingerprint of the remaining bits.
 #if BL_OFFBITS > 16
 typedef uint32_t bl_occ_t;          /* an occurrence index (the window may hold more than 65 535 k-mer starts) */
+typedef uint32_t bl_off_t;          /* an LDS offset kept in HBM scratch */
 #else
 typedef uint16_t bl_occ_t;
+typedef uint16_t bl_off_t;
 #endif
 static constexpr uint32_t BL_OFFMASK = (1u << BL_OFFBITS) - 1u;
 static constexpr uint32_t LDS_BASES = BL_BASES, LDS_READS = BL_RMAX;       /* this configuration's limits, for the host */
@@ -53,12 +55,12 @@ struct BlScratch {
   LC_GLOBAL uint32_t *c_minqv;      /* [PB_CCAP]                                                                 */
   LC_GLOBAL uint32_t *s_ci;         /* [PB_SCAP] candidate of survivor si                                        */
   LC_GLOBAL uint32_t *s_edges;      /* [PB_SCAP * 9] resolved edges + count                                      */
-  LC_GLOBAL uint32_t *dupo;         /* [BL_DUPCAP] occurrences that met their k-mer in the other orientation, or twice in one read */
+  LC_GLOBAL bl_off_t *dupo;         /* [BL_DUPCAP] occurrences that met their k-mer in the other orientation, or twice in one read */
   LC_GLOBAL uint32_t *ord;          /* [4 * PB_CMAX] (spare) */
   LC_GLOBAL uint32_t *pq;           /* [BL_PQCAP] per-position counts: the occurrences of the candidates beyond the first LDS group (read | position << 10 | candidate << 20 | reversed << 31) */
 };
 static constexpr uint32_t BL_PQCAP = 16384u;
-static constexpr uint32_t SCRATCH_BYTES = (2u * BL_BASES + 64u + 8u * BL_TCAP + 4u * BL_TCAP + 12u * PB_CCAP + 4u * PB_SCAP + 36u * PB_SCAP + 4u * BL_DUPCAP + 16u * PB_CMAX + 4u * 16384u + 768u);
+static constexpr uint32_t SCRATCH_BYTES = (2u * BL_BASES + 64u + 8u * BL_TCAP + 4u * BL_TCAP + 12u * PB_CCAP + 4u * PB_SCAP + 36u * PB_SCAP + (uint32_t)sizeof(bl_off_t) * BL_DUPCAP + 16u * PB_CMAX + 4u * 16384u + 768u);
 static constexpr int WG = BL_WG;
 DEV void bl_scratch_carve(BlScratch *s, LC_GLOBAL uint8_t *base) {
   size_t o = 0;
@@ -71,7 +73,7 @@ DEV void bl_scratch_carve(BlScratch *s, LC_GLOBAL uint8_t *base) {
   s->c_minqv = (LC_GLOBAL uint32_t *)take(4u * PB_CCAP);
   s->s_ci = (LC_GLOBAL uint32_t *)take(4u * PB_SCAP);
   s->s_edges = (LC_GLOBAL uint32_t *)take(36u * PB_SCAP);
-  s->dupo = (LC_GLOBAL uint32_t *)take(4u * BL_DUPCAP);
+  s->dupo = (LC_GLOBAL bl_off_t *)take(sizeof(bl_off_t) * BL_DUPCAP);
   s->ord = (LC_GLOBAL uint32_t *)take(16u * PB_CMAX);
   s->pq = (LC_GLOBAL uint32_t *)take(4u * BL_PQCAP);
 }
@@ -811,7 +813,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
           // here and looked at again once the survivors are known.
           if (cur != mine && ((f2 != isF) || (r < nr && (cur & BL_OFFMASK) - 16u * S.rdo[r] < (uint32_t)RI_TLEN(S.rinfo[r])))) {
             const uint32_t di = dev_atomic_add((LC_LDS uint32_t *)&S.ndup, 1u);
-            if (di < BL_DUPCAP) X.dupo[di] = boff;
+            if (di < BL_DUPCAP) X.dupo[di] = (bl_off_t)boff;
           }
           break;
         }
@@ -892,7 +894,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       // with coverage 2 and is trimmed as a tip later: k is not rejected for it)
     const uint32_t nd = S.ndup < BL_DUPCAP ? S.ndup : BL_DUPCAP;
     const uint32_t cthr = (uint32_t)(avgcov / 4.0) > 4u ? (uint32_t)(avgcov / 4.0) : 4u;
-    WG_FOR(i, nd) { if ((uint32_t)S.cidx[X.occn[X.dupo[i]] & 0x1FFFu] < cthr) X.dupo[i] = 0xFFFFFFFFu; }
+    WG_FOR(i, nd) { if ((uint32_t)S.cidx[X.occn[X.dupo[i]] & 0x1FFFu] < cthr) X.dupo[i] = (bl_off_t)~(bl_off_t)0; }
   }
   {
     LC_LDS uint32_t *fl = S.big;                                 // (the table is no longer needed: occn holds node ids)
@@ -1254,7 +1256,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_SYNC();
     {   // the hint: does a node that was met twice in a read / in both orientations survive?
       const uint32_t nd = S.ndup < BL_DUPCAP ? S.ndup : BL_DUPCAP;
-      WG_FOR(i, nd) { const uint32_t o = X.dupo[i]; if (o != 0xFFFFFFFFu && S.cidx[X.occn[o] & 0x1FFFu] != 0xFFFFu) S.hint = 1; }
+      WG_FOR(i, nd) { const bl_off_t o = X.dupo[i]; if (o != (bl_off_t)~(bl_off_t)0 && S.cidx[X.occn[o] & 0x1FFFu] != 0xFFFFu) S.hint = 1; }
       WG_LANE0 { if (S.ndup > BL_DUPCAP) S.hint = 1; }
     }
     WG_SYNC();

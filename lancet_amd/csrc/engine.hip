@@ -209,7 +209,7 @@ struct lancet_engine {
   // LANCET_PREP=device keeps the round-2 path (ASCII bases + qualities to the device, prep_kernel there)
   void *h_stage = nullptr; size_t h_stage_cap = 0; DevBuf d_stage;
   bool host_prep = true; int prep_threads = 0;
-  int exact_need_large = -1;       // host trim: does any window exceed the 512-lane build configuration (exact: from the trimmed lengths)?  -1 unknown
+  int exact_need_large = -1;       // host trim: windows that exceed the 512-lane build configuration (exact: from the trimmed lengths); -1 unknown
   float ms_pack = 0;
   bool dbg = false, no_fat = false, no_early_rerun = false, no_large_build = false;     // LANCET_DEBUG / LANCET_NO_FAT / ... read once, at create
   int build_slots_env = 0, ahead_depth_env = -1;
@@ -465,17 +465,19 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     h_rc[nref] = 0;
     if (e->params.lr_mode && R) { memcpy(H + o_bx, b->bx_rank, 4 * (size_t)R); memcpy(H + o_hp, b->hp, (size_t)R); }
     {   // the 512-lane build configuration's size test (build_lds_impl.h: nbw / ngw against BL_BASES), window by window on the trimmed lengths
-      std::vector<char> need((size_t)T, 0);
+      std::vector<int> need((size_t)T, 0);
       lc_parallel(T, (size_t)nw, [&](size_t lo, size_t hi, int t) {
-        for (size_t w = lo; w < hi && !need[(size_t)t]; ++w) {
+        int cnt = 0;
+        for (size_t w = lo; w < hi; ++w) {
           const uint32_t r0 = b->read_begin[w], r1 = b->read_begin[w + 1], rl = b->ref_off[w + 1] - b->ref_off[w];
           uint64_t wb = (rl + 15) / 16, wg = (rl + 31) / 32;
           for (uint32_t r = r0; r < r1; ++r) { const uint32_t tl = RI_TLEN(h_ri[r]); wb += (tl + 15) / 16; wg += (tl + 31) / 32; }
-          if (r1 - r0 > 512u || wb > BL_SMALL_BASES / 16u || wg > BL_SMALL_BASES / 32u) need[(size_t)t] = 1;
+          if (r1 - r0 > bl_small::LDS_READS || wb > bl_small::LDS_BASES / 16u || wg > bl_small::LDS_BASES / 32u) ++cnt;
         }
+        need[(size_t)t] = cnt;
       });
       e->exact_need_large = 0;
-      for (int t = 0; t < T; ++t) if (need[(size_t)t]) e->exact_need_large = 1;
+      for (int t = 0; t < T; ++t) e->exact_need_large += need[(size_t)t];
     }
     e->ms_pack = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_pack0).count();
     if (e->dbg) fprintf(stderr, "[lancet] trim + pack on %d host threads: %.1f ms, %.1f MB to the device\n", T, e->ms_pack, total / 1048576.0);
@@ -592,14 +594,15 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     // Can any window be too big for the 512-lane configuration?  Trimming only shortens reads, so the untrimmed lengths bound the
     // LDS footprint (reads padded to 16 bases + the reference); when none can, the 1024-lane kernel is not launched at all.
     bool may_need_large = false;
-    if (e->host_prep && e->exact_need_large >= 0) may_need_large = e->exact_need_large != 0;
+    int n_need_large = 0;
+    if (e->host_prep && e->exact_need_large >= 0) n_need_large = e->exact_need_large;
     else
-    for (int w = 0; w < nw && !may_need_large; ++w) {
+    for (int w = 0; w < nw; ++w) {
       const uint32_t r0 = b->read_begin[w], r1 = b->read_begin[w + 1];
-      if (r1 - r0 > bl_small::LDS_READS) { may_need_large = true; break; }
       const uint64_t raw = (uint64_t)(b->seq_off[r1] - b->seq_off[r0]) + 15ull * (r1 - r0) + (b->ref_off[w + 1] - b->ref_off[w]) + 16u;
-      if (raw > (uint64_t)bl_small::LDS_BASES) may_need_large = true;
+      if (r1 - r0 > bl_small::LDS_READS || raw > (uint64_t)bl_small::LDS_BASES) ++n_need_large;
     }
+    may_need_large = n_need_large > 0;
     e->n_bslots_large = (e->no_large_build || !may_need_large) ? 0 : std::min(nw, cus);
     if (e->n_bslots_large) { ENS(e->d_blscratch_large, (size_t)e->n_bslots_large * bl_large::SCRATCH_BYTES); ENS(e->d_biglist, sizeof(uint32_t) * (size_t)nw); }
     ENS(e->d_blphase, 16 * sizeof(unsigned long long));
@@ -614,7 +617,9 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
       e->svc_cap = 2u * (uint32_t)nw + 1024u;
       const size_t off_req = 256, off_rdy = off_req + sizeof(SvcReq) * (size_t)e->svc_cap, off_cont = (off_rdy + 4u * (size_t)e->svc_cap + 63) & ~(size_t)63;
       ENS(e->d_svc, off_cont + sizeof(SvcCont) * (size_t)e->svc_cap);
-      e->svc_large = e->n_bslots_large > 0;             // windows above the 512-lane configuration's limits in the batch: the service runs the 1024-lane one
+      // Which configuration the service runs: the 1024-lane one (a whole CU per workgroup) when a good part of the batch is beyond the
+      // 512-lane configuration's limits; else the 512-lane one, and the few deep windows build their later graphs themselves.
+      e->svc_large = e->n_bslots_large > 0 && n_need_large * 8 > nw;
       ENS(e->d_svcscratch, (size_t)e->n_svc_wgs * (e->svc_large ? bl_large::SCRATCH_BYTES : bl_small::SCRATCH_BYTES));
       memset(&e->svc_host, 0, sizeof(SvcCtl));
       e->svc_host.cap = e->svc_cap; e->svc_host.large = e->svc_large ? 1u : 0u;

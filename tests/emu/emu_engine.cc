@@ -108,7 +108,7 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
     sreq.assign(sv.cap, SvcReq{0, 0, SV_EMPTY, 0}); srdy.assign(sv.cap, 0u); scont.resize(sv.cap);
     sv.req = sreq.data(); sv.rdy = srdy.data(); sv.cont = scont.data();
     sv.alive = getenv("LANCET_SVC_DEAD") ? 0u : 1u;
-    sv.large = res->n_biglist > 0 ? 1u : 0u;                    // (engine.hip: a batch with windows beyond the 512-lane configuration runs the service in the 1024-lane one)
+    sv.large = (res->n_biglist * 8u > (uint32_t)b->n_windows || getenv("LANCET_EMU_SVC_LARGE")) ? 1u : 0u;   // (engine.hip: a batch with many windows beyond the 512-lane configuration runs the service in the 1024-lane one)
     O.svc = &sv;
   }
   while (window_kernel_body(P, &B, &C, &work, &O, &S, 0) != 0)
