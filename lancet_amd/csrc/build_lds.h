@@ -28,6 +28,12 @@
 #include "kernels.h"
 
 #define BL_EMPTY 0xFFFFFFFFu
+#ifndef BL_INS
+#define BL_INS 4                  /* occurrences a lane inserts at a time (their LDS reads overlap)                              */
+#endif
+#ifndef BL_INFLIGHT
+#define BL_INFLIGHT 4             /* occurrence words a lane has in flight in a pass over the window's occurrences (bl_for_occ) */
+#endif
 #define BL_DUPCAP 1024u
 enum { BLW_NONE = 0, BLW_NOREADS, BLW_SIZE, BLW_HASN, BLW_K, BLW_TABLE, BLW_NODES, BLW_TRACKED, BLW_CAND, BLW_QV, BLW_SURV, BLW_MATE, BLW_NAMES, BLW_PAIRS };
 

@@ -169,26 +169,22 @@ DEV bool bl_all_good(const LC_LDS uint32_t *goodm, uint32_t gw, int a, int b) {
     const int r = (int)_r; const int p = o - (int)(S).obase[r]; const uint32_t boff = 16u * (S).rdo[r] + (uint32_t)p; (void)p; (void)boff; (void)r;
 #define BL_OCC_END } }
 
-// The same walk with the occurrence's 2-byte HBM word fetched four occurrences ahead: a pass is a chain of (HBM word -> LDS
+// The same walk with the occurrence's 2-byte HBM word fetched BL_INFLIGHT occurrences ahead: a pass is a chain of (HBM word -> LDS
 // look-ups -> LDS atomics) per occurrence, and with two workgroups per CU nothing else hides the memory round trip.
 template <class F> DEV void bl_for_occ(BL_S &S, LC_GLOBAL const uint16_t *occn, F body) {
   WG_FOR(_t, BL_WG) {
     const int O_ = (int)S.O;
-    for (int o0 = _t; o0 < O_; o0 += 4 * BL_WG) {
-      int rr[4], pp[4]; uint32_t bo[4], ee[4];
-      for (int u = 0; u < 4; ++u) {
+    for (int o0 = _t; o0 < O_; o0 += BL_INFLIGHT * BL_WG) {
+      int rr[BL_INFLIGHT], pp[BL_INFLIGHT]; uint32_t bo[BL_INFLIGHT], ee[BL_INFLIGHT];
+      for (int u = 0; u < BL_INFLIGHT; ++u) {
         const int o = o0 + u * BL_WG;
         const int oc = o < O_ ? o : O_ - 1;                          // (clamped: the loads below stay unconditional, four in flight)
         uint32_t rc = S.o2r[oc >> 7];
         while ((uint32_t)oc >= S.obase[rc + 1]) ++rc;
         rr[u] = o < O_ ? (int)rc : -1; pp[u] = oc - (int)S.obase[rc]; bo[u] = 16u * S.rdo[rc] + (uint32_t)pp[u];
       }
-#ifdef BL_DBG_COND
-      for (int u = 0; u < 4; ++u) ee[u] = rr[u] >= 0 ? (uint32_t)occn[bo[u]] : 0u;
-#else
-      for (int u = 0; u < 4; ++u) ee[u] = (uint32_t)occn[bo[u]];
-#endif
-      for (int u = 0; u < 4; ++u) if (rr[u] >= 0) body(rr[u], pp[u], bo[u], ee[u]);
+      for (int u = 0; u < BL_INFLIGHT; ++u) ee[u] = (uint32_t)occn[bo[u]];
+      for (int u = 0; u < BL_INFLIGHT; ++u) if (rr[u] >= 0) body(rr[u], pp[u], bo[u], ee[u]);
     }
   }
 }
@@ -780,49 +776,71 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   LC_LDS uint32_t *tab = S.big;
   WG_FOR(i, BL_SLOTS) { tab[i] = BL_EMPTY; }
   WG_SYNC();
-  BL_OCC_BEGIN(S)
-    bool isF;
-    const unsigned long long v1 = bl_kmer(S.bases, boff, kmask);
-    unsigned long long fw1;
-    const unsigned long long ck = bl_canon2(v1, K, kmask, &isF, &fw1);
-    // An earlier occurrence v2 (as it lies in LDS: first base in the low bits) is the same node iff it is this k-mer or its
-    // reverse complement.  Read first-base-high, v2's reverse complement is ~v2 & mask (bl_canon); that equals this k-mer's
-    // forward form fw1 iff v2 == ~fw1 & mask.  So a fingerprint hit is confirmed with one k-mer cut out of LDS and two
-    // compares, without canonicalising the earlier occurrence (k is odd here: no k-mer is its own reverse complement).
-    const unsigned long long alt = (~fw1) & kmask;
-    // table hash on 32-bit words (the table is private to this pass: node ids come from first-occurrence offsets, not slots)
-    uint32_t hh = (uint32_t)ck * 0x9E3779B1u ^ (((uint32_t)(ck >> 32)) ^ ((uint32_t)ck >> 15)) * 0x85EBCA77u;
-    hh ^= hh >> 15; hh *= 0x2C1B3C6Du; hh ^= hh >> 12;
-    uint32_t idx = hh & (BL_SLOTS - 1);
-    uint32_t fp = hh >> BL_OFFBITS; if (fp == (0xFFFFFFFFu >> BL_OFFBITS)) fp -= 1u;
-    const uint32_t mine = (fp << BL_OFFBITS) | boff;
-    uint32_t probes = 0;
-    while (true) {
-      uint32_t cur = ld2(&tab[idx]);
-      if (cur == BL_EMPTY) { cur = dev_atomic_cas32(&tab[idx], BL_EMPTY, mine); if (cur == BL_EMPTY) break; }
-      if ((cur >> BL_OFFBITS) == fp) {
-        const unsigned long long v2 = bl_kmer(S.bases, cur & BL_OFFMASK, kmask);
-        if (v2 == v1 || v2 == alt) {
-          const bool f2 = (v2 == v1) ? isF : !isF;
-          if (mine < cur) dev_atomic_min(&tab[idx], mine);
-          // Scheduling hint (PreHdr::heavy).  All reads are in reference orientation and the loop over k only builds at a k
-          // above the window reference's longest repeat, so a node normally meets its k-mer once per read and always in the
-          // same orientation.  The same k-mer twice in one read (a duplication in the sample), or in both orientations (an
-          // inverted repeat, which isRepeat does not look for), means a walk comes back to the node: if that node survives
-          // removeLowCov the graph has a cycle and this k is rejected (Microassembler.cc:198-206).  The occurrence is noted
-          // here and looked at again once the survivors are known.
-          if (cur != mine && ((f2 != isF) || (r < nr && (cur & BL_OFFMASK) - 16u * S.rdo[r] < (uint32_t)RI_TLEN(S.rinfo[r])))) {
-            const uint32_t di = dev_atomic_add((LC_LDS uint32_t *)&S.ndup, 1u);
-            if (di < BL_DUPCAP) X.dupo[di] = (bl_off_t)boff;
-          }
-          break;
-        }
+  // BL_INS occurrences per lane at a time: their k-mers are cut out of LDS, hashed and their first table words read before the first
+  // probe starts (a probe is a chain of dependent LDS round trips; with two workgroups per CU little else hides them).  A table word read
+  // early can be out of date by the time its probe looks at it: an empty word is then settled by the compare-and-swap, an occupied one only
+  // ever changes to an earlier occurrence of the same k-mer.
+  WG_FOR(_t, BL_WG) {
+    const int O_ = (int)S.O;
+    for (int o0 = _t; o0 < O_; o0 += BL_INS * BL_WG) {
+      int rr[BL_INS]; uint32_t bo[BL_INS], ix[BL_INS], fpv[BL_INS], cu[BL_INS]; unsigned long long kv[BL_INS], al[BL_INS]; bool fF[BL_INS];
+      for (int u = 0; u < BL_INS; ++u) {
+        const int o = o0 + u * BL_WG;
+        const int oc = o < O_ ? o : O_ - 1;
+        uint32_t rc = S.o2r[oc >> 7];
+        while ((uint32_t)oc >= S.obase[rc + 1]) ++rc;
+        rr[u] = o < O_ ? (int)rc : -1; bo[u] = 16u * S.rdo[rc] + (uint32_t)(oc - (int)S.obase[rc]);
       }
-      idx = (idx + 1) & (BL_SLOTS - 1);
-      if (++probes > 256u) { S.why = BLW_TABLE; break; }
+      for (int u = 0; u < BL_INS; ++u) kv[u] = bl_kmer(S.bases, bo[u], kmask);
+      for (int u = 0; u < BL_INS; ++u) {
+        unsigned long long fw1;
+        const unsigned long long ck = bl_canon2(kv[u], K, kmask, &fF[u], &fw1);
+        // An earlier occurrence v2 (as it lies in LDS: first base in the low bits) is the same node iff it is this k-mer or its
+        // reverse complement.  Read first-base-high, v2's reverse complement is ~v2 & mask (bl_canon); that equals this k-mer's
+        // forward form fw1 iff v2 == ~fw1 & mask.  So a fingerprint hit is confirmed with one k-mer cut out of LDS and two
+        // compares, without canonicalising the earlier occurrence (k is odd here: no k-mer is its own reverse complement).
+        al[u] = (~fw1) & kmask;
+        // table hash on 32-bit words (the table is private to this pass: node ids come from first-occurrence offsets, not slots)
+        uint32_t hh = (uint32_t)ck * 0x9E3779B1u ^ (((uint32_t)(ck >> 32)) ^ ((uint32_t)ck >> 15)) * 0x85EBCA77u;
+        hh ^= hh >> 15; hh *= 0x2C1B3C6Du; hh ^= hh >> 12;
+        ix[u] = hh & (BL_SLOTS - 1);
+        uint32_t fp = hh >> BL_OFFBITS; if (fp == (0xFFFFFFFFu >> BL_OFFBITS)) fp -= 1u;
+        fpv[u] = fp;
+      }
+      for (int u = 0; u < BL_INS; ++u) cu[u] = ld2(&tab[ix[u]]);
+      for (int u = 0; u < BL_INS; ++u) {
+        if (rr[u] < 0) continue;
+        const int r = rr[u]; const uint32_t boff = bo[u], fp = fpv[u]; const bool isF = fF[u]; const unsigned long long v1 = kv[u], alt = al[u];
+        const uint32_t mine = (fp << BL_OFFBITS) | boff;
+        uint32_t idx = ix[u], cur = cu[u], probes = 0;
+        while (true) {
+          if (cur == BL_EMPTY) { cur = dev_atomic_cas32(&tab[idx], BL_EMPTY, mine); if (cur == BL_EMPTY) break; }
+          if ((cur >> BL_OFFBITS) == fp) {
+            const unsigned long long v2 = bl_kmer(S.bases, cur & BL_OFFMASK, kmask);
+            if (v2 == v1 || v2 == alt) {
+              const bool f2 = (v2 == v1) ? isF : !isF;
+              if (mine < cur) dev_atomic_min(&tab[idx], mine);
+              // Scheduling hint (PreHdr::heavy).  All reads are in reference orientation and the loop over k only builds at a k
+              // above the window reference's longest repeat, so a node normally meets its k-mer once per read and always in the
+              // same orientation.  The same k-mer twice in one read (a duplication in the sample), or in both orientations (an
+              // inverted repeat, which isRepeat does not look for), means a walk comes back to the node: if that node survives
+              // removeLowCov the graph has a cycle and this k is rejected (Microassembler.cc:198-206).  The occurrence is noted
+              // here and looked at again once the survivors are known.
+              if (cur != mine && ((f2 != isF) || (r < nr && (cur & BL_OFFMASK) - 16u * S.rdo[r] < (uint32_t)RI_TLEN(S.rinfo[r])))) {
+                const uint32_t di = dev_atomic_add((LC_LDS uint32_t *)&S.ndup, 1u);
+                if (di < BL_DUPCAP) X.dupo[di] = (bl_off_t)boff;
+              }
+              break;
+            }
+          }
+          idx = (idx + 1) & (BL_SLOTS - 1);
+          if (++probes > 256u) { S.why = BLW_TABLE; break; }
+          cur = ld2(&tab[idx]);
+        }
+        X.occn[boff] = (uint16_t)(idx | (isF ? 0u : 0x8000u));
+      }
     }
-    X.occn[boff] = (uint16_t)(idx | (isF ? 0u : 0x8000u));
-  BL_OCC_END
+  }
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
   BLP(S, 5);
   if (C->debug_stop == 105u) { WG_LANE0 { H->why = 99; } return; }
@@ -1513,19 +1531,28 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
 // ahead), into an area of `pool` (pool_cap areas, handed out by queue[2]); PreHdr::next links them.  A graph built ahead that
 // the window kernel does not ask for is wasted work, nothing else: results never depend on what was built ahead.
 // (queue[0] = next window, queue[1] = windows built, queue[2] = pool areas handed out, queue[3] = graphs built ahead,
-//  queue[4] = windows on `biglist`, queue[5] = next entry of it)
+//  queue[4] = windows on `biglist`, queue[5] = next entry of it, queue[7] = windows finished -- built, listed or turned away)
+// The workgroups of the build service (svc_kernel_body) work the same queue off until it is empty, before they serve their first
+// request; the kernel that the window kernel is ordered behind is this one, so its workgroups leave only when every window handed
+// out -- to either kernel -- is finished (`helpers`: queue[7], released by whoever finished the window).
 // `biglist`: the small configuration appends the windows it turns away for their size; the large one (from_list) works that list
 // off instead of the batch.
 DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *B, LC_GLOBAL const EngineCaps *C, LC_GLOBAL uint8_t *pre,
                            LC_GLOBAL uint8_t *scratch, LC_GLOBAL uint32_t *queue, BL_S &S, int slot, LC_GLOBAL unsigned long long *phase = nullptr,
-                           LC_GLOBAL uint8_t *pool = nullptr, uint32_t pool_cap = 0, int depth = 0, LC_GLOBAL uint32_t *biglist = nullptr, bool from_list = false) {
+                           LC_GLOBAL uint8_t *pool = nullptr, uint32_t pool_cap = 0, int depth = 0, LC_GLOBAL uint32_t *biglist = nullptr, bool from_list = false,
+                           bool wait_all = false) {
   LC_GLOBAL uint8_t *xbase = scratch + (size_t)slot * SCRATCH_BYTES;
   if (from_list && queue[4] == 0u) return;                       // (nothing was turned away for its size: the usual case at 30x)
   while (true) {
     WG_LANE0 { S.w = (int)dev_atomic_add(queue + (from_list ? 5 : 0), 1u); }
     int w = (int)bl_bcast(&S.w);
     if (from_list) { if ((uint32_t)w >= queue[4]) break; w = (int)biglist[w]; }
-    else if (w >= B->n_windows) break;
+    else if (w >= B->n_windows) {
+#ifndef LANCET_WAVE_EMU
+      if (wait_all) { WG_LANE0 { while (ld_acq(queue + 7) < (uint32_t)B->n_windows) dev_sleep(); } WG_SYNC(); }   // (the service's workgroups may still be at their last windows)
+#endif
+      break;
+    }
 #ifndef LANCET_WAVE_EMU
     if (threadIdx.x == 0) { for (int i = 0; i < 16; ++i) S.ph_acc[i] = 0; S.ph_cur = 0; S.t_last = wall_clock64(); }
 #endif
@@ -1557,7 +1584,8 @@ DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       if (Hw->status == PB_BUILT) dev_atomic_add(queue + 1, 1u);
       else if (!from_list && biglist && Hw->why == (uint32_t)BLW_SIZE) biglist[dev_atomic_add(queue + 4, 1u)] = (uint32_t)w;
     }
-    WG_SYNC();
+    WG_SYNC();                                                     // (every lane's stores to the hand-off area are issued ...)
+    if (!from_list) { WG_LANE0 { add_rel(queue + 7, 1u); } }       // (... and released with the count)
   }
 }
 
@@ -1572,8 +1600,12 @@ DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
 // (SvcCtl::alive == 0) and build those graphs themselves.
 DEV void svc_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *B, LC_GLOBAL const EngineCaps *C, LC_GLOBAL uint8_t *pre,
                          LC_GLOBAL uint8_t *scratch, LC_GLOBAL uint32_t *queue, BL_S &S, int slot, LC_GLOBAL uint8_t *pool, uint32_t pool_cap, int depth,
-                         LC_GLOBAL SvcCtl *sv, LC_GLOBAL const uint32_t *wqueue = nullptr) {
+                         LC_GLOBAL SvcCtl *sv, LC_GLOBAL const uint32_t *wqueue = nullptr, LC_GLOBAL uint32_t *biglist = nullptr, int help_depth = -1,
+                         LC_GLOBAL unsigned long long *phase = nullptr) {
   LC_GLOBAL uint8_t *xbase = scratch + (size_t)slot * SCRATCH_BYTES;
+  // Until the window kernel runs there is nothing to serve: the workgroup takes windows off the build kernel's queue like that kernel's own
+  // (help_depth >= 0: graphs built ahead per window there; the build kernel waits for the windows taken here, build_kernel_body `wait_all`).
+  if (help_depth >= 0) build_kernel_body(P, B, C, pre, scratch, queue, S, slot, phase, pool, pool_cap, help_depth, biglist, false, false);
 #ifndef LANCET_WAVE_EMU
   WG_LANE0 { dev_atomic_add(&sv->alive, 1u); }
   unsigned long long t_prog = wall_clock64(); uint32_t last_sum = 0xFFFFFFFFu;      // (lane 0's)

@@ -36,10 +36,10 @@ __global__ void __launch_bounds__(LANCET_WG * 2) __attribute__((amdgpu_waves_per
 
 // The first graph of every window in LDS (build_lds.h): 256 lanes per window, 2 workgroups per CU (80 KB of LDS each)
 __global__ void __launch_bounds__(bl_small::WG) __attribute__((amdgpu_waves_per_eu(BL_SMALL_EU, BL_SMALL_EU))) build_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue,
-                                                      unsigned long long *phase, uint8_t *pool, uint32_t pool_cap, int depth, uint32_t *biglist) {
+                                                      unsigned long long *phase, uint8_t *pool, uint32_t pool_cap, int depth, uint32_t *biglist, int wait_all) {
   bl_small::build_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL uint8_t *)pre, (LC_GLOBAL uint8_t *)scratch,
                     (LC_GLOBAL uint32_t *)queue, *(bl_small::BL_S *)&bl_small::bl_shared, (int)blockIdx.x, (LC_GLOBAL unsigned long long *)phase, (LC_GLOBAL uint8_t *)pool, pool_cap, depth,
-                    (LC_GLOBAL uint32_t *)biglist, false);
+                    (LC_GLOBAL uint32_t *)biglist, false, wait_all != 0);
 }
 // The same for the windows the 512-lane configuration turned away for their size (60x/60x: ~360 reads, 58 k bases): 1024 lanes,
 // one workgroup per CU (~100 KB of LDS), off the list the first kernel left.
@@ -54,10 +54,10 @@ __global__ void __launch_bounds__(bl_large::WG) __attribute__((amdgpu_waves_per_
 // graphs of later k attempts it asks for.  Launched on its own stream before the batch's kernels, leaves when svc_done_kernel
 // (enqueued behind the window kernel) has set SvcCtl::done.
 __global__ void __launch_bounds__(bl_small::WG) __attribute__((amdgpu_waves_per_eu(BL_SMALL_EU, BL_SMALL_EU))) svc_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue,
-                                                      uint8_t *pool, uint32_t pool_cap, int depth, SvcCtl *sv, const uint32_t *wqueue) {
+                                                      uint8_t *pool, uint32_t pool_cap, int depth, SvcCtl *sv, const uint32_t *wqueue, uint32_t *biglist, int help_depth, unsigned long long *phase) {
   bl_small::svc_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL uint8_t *)pre, (LC_GLOBAL uint8_t *)scratch,
                     (LC_GLOBAL uint32_t *)queue, *(bl_small::BL_S *)&bl_small::bl_shared, (int)blockIdx.x, (LC_GLOBAL uint8_t *)pool, pool_cap, depth, (LC_GLOBAL SvcCtl *)sv,
-                    (LC_GLOBAL const uint32_t *)wqueue);
+                    (LC_GLOBAL const uint32_t *)wqueue, (LC_GLOBAL uint32_t *)biglist, help_depth, (LC_GLOBAL unsigned long long *)phase);
 }
 // (the control block is set up by a kernel, not by a copy: an asynchronous copy from pageable host memory blocks the caller until the
 //  stream has caught up, and with another engine's persistent kernels on the device that is the rest of their batch)
@@ -197,8 +197,9 @@ struct lancet_engine {
   // build service (svc_kernel): control block + request / ready / continuation arrays in one buffer, scratch of its workgroups
   DevBuf d_svc, d_svcscratch;
   hipStream_t stream3 = nullptr; hipEvent_t ev_svc = nullptr;
-  bool svc = true, svc_running = false, svc_large = false;      // LANCET_NO_SVC=1 (at create): every later graph of a window by the general build
-  int n_svc_wgs = 16; uint32_t svc_cap = 0; int svc_depth = 6;
+  bool svc = true, svc_running = false, svc_large = false;
+  bool svc_help = true;                      // the service's workgroups take windows off the build kernel's queue until the window kernel runs (LANCET_SVC_HELP=0: they only wait)      // LANCET_NO_SVC=1 (at create): every later graph of a window by the general build
+  int n_svc_wgs = 24; uint32_t svc_cap = 0; int svc_depth = 6;      // (24: 412 requests of a 32768-window batch at ~0.55 ms each keep 16 busy for the whole window kernel; beyond 32 their LDS costs it more slots than the shorter waits give back)
   int svc_cus = 0, n_cus = 256;                // LANCET_SVC_CUS=n: CUs set aside for the service (CU masks on the two streams), so that its workgroups are resident
                                              // whatever the batch's kernels -- or another engine's -- occupy; 0 = no masks
   SvcCtl svc_host;
@@ -321,6 +322,7 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   e->no_large_build = getenv("LANCET_NO_LARGE_BUILD") != nullptr; e->heavy_first = getenv("LANCET_NO_HEAVY_FIRST") == nullptr;
   if (const char *s = getenv("LANCET_BUILD_SLOTS")) e->build_slots_env = std::max(1, atoi(s));
   if (const char *s = getenv("LANCET_AHEAD_DEPTH")) e->ahead_depth_env = std::max(0, std::min(16, atoi(s)));
+  if (const char *s = getenv("LANCET_SVC_HELP")) e->svc_help = atoi(s) != 0;
   if (const char *s = getenv("LANCET_SVC_WGS")) e->n_svc_wgs = std::max(0, std::min(256, atoi(s)));
   if (const char *s = getenv("LANCET_SVC_DEPTH")) e->svc_depth = std::max(0, std::min(16, atoi(s)));
   if (p->lr_mode) e->prebuild = false;                         // --linked-reads: barcode / haplotype bookkeeping lives in the general build only
@@ -690,12 +692,11 @@ static int lc_submit_body(lancet_engine *e) {
     e->fat_inflight = true;
   }
   if (e->prebuild) {
-    HIPCHK(e, hipMemsetAsync(e->d_blphase.p, 0, 16 * sizeof(unsigned long long), e->stream));
     HIPCHK(e, hipEventRecord(e->evb0, e->stream));
     hipLaunchKernelGGL(build_kernel, dim3(e->n_bslots), dim3(bl_small::WG), 0, e->stream, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
                        (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_blscratch.p, (uint32_t *)e->d_counters.p + 8,
                        (unsigned long long *)e->d_blphase.p, (uint8_t *)(e->pool_cap ? e->d_prepool.p : nullptr), e->pool_cap, e->ahead_depth,
-                       (uint32_t *)(e->n_bslots_large ? e->d_biglist.p : nullptr));
+                       (uint32_t *)(e->n_bslots_large ? e->d_biglist.p : nullptr), (e->svc_running && e->svc_help && !e->svc_large) ? 1 : 0);
     HIPCHK(e, hipGetLastError());
     if (e->dbg) { HIPCHK(e, hipStreamSynchronize(e->stream)); DBG("build_kernel done"); }
     if (e->n_bslots_large) {
@@ -747,6 +748,7 @@ int lancet_engine_submit(lancet_engine *e) {
   if (e->n_windows == 0) { e->submitted = true; return LANCET_OK; }
   HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, 128, e->stream));
   HIPCHK(e, hipMemsetAsync(e->d_stats.p, 0, sizeof(lancet_window_stats) * e->n_windows, e->stream));
+  if (e->prebuild) HIPCHK(e, hipMemsetAsync(e->d_blphase.p, 0, 16 * sizeof(unsigned long long), e->stream));      // (before the service starts: its workgroups add to it too)
   e->ms_build = 0; e->n_prebuilt = 0;
   e->fat_inflight = false; e->ms_fat = 0;
   e->svc_running = false;
@@ -763,7 +765,8 @@ int lancet_engine_submit(lancet_engine *e) {
     else
     hipLaunchKernelGGL(svc_kernel, dim3(e->n_svc_wgs), dim3(bl_small::WG), 0, e->stream3, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
                        (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_svcscratch.p, (uint32_t *)e->d_counters.p + 8,
-                       (uint8_t *)e->d_prepool.p, e->pool_cap, e->svc_depth, (SvcCtl *)e->d_svc.p, (const uint32_t *)e->d_counters.p + 2);
+                       (uint8_t *)e->d_prepool.p, e->pool_cap, e->svc_depth, (SvcCtl *)e->d_svc.p, (const uint32_t *)e->d_counters.p + 2,
+                       (uint32_t *)(e->n_bslots_large ? e->d_biglist.p : nullptr), (e->svc_help && e->prebuild) ? e->ahead_depth : -1, (unsigned long long *)e->d_blphase.p);
     HIPCHK(e, hipGetLastError());
     e->svc_running = true;
   }

@@ -62,6 +62,7 @@ template <class P> DEV auto ld2(P p) { return __hip_atomic_load(p, __ATOMIC_RELA
 // acquire load / release store at agent scope: hand-over of plain data between workgroups of different kernels (build service)
 template <class P> DEV uint32_t ld_acq(P p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 template <class P> DEV void st_rel(P p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+template <class P> DEV uint32_t add_rel(P p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 DEV void dev_sleep() { __builtin_amdgcn_s_sleep(127); }
 typedef uint4 lc_u4;
 typedef uint32_t lc_v4 __attribute__((ext_vector_type(4)));
@@ -96,6 +97,7 @@ DEV uint32_t ld2(const uint32_t *p) { return *p; }
 DEV unsigned long long ld2(const unsigned long long *p) { return *p; }
 DEV uint32_t ld_acq(const uint32_t *p) { return *p; }
 DEV void st_rel(uint32_t *p, uint32_t v) { *p = v; }
+DEV uint32_t add_rel(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 DEV void dev_sleep() {}
 struct alignas(16) lc_u4 { uint32_t x, y, z, w; };
 typedef lc_u4 lc_v4;

@@ -2,7 +2,7 @@
 # tmp_ab/new_engine.so, each through tools/quick_gpu.py on the bench workload, twice in alternation.
 cd /root/repo
 cp lancet_amd/csrc/liblancet_engine.so tmp_ab/keep.so
-for round in 1 2; do
+for round in 1; do
   for which in old new; do
     cp tmp_ab/${which}_engine.so lancet_amd/csrc/liblancet_engine.so
     echo "== $which (round $round)"
