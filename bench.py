@@ -90,18 +90,25 @@ def cpu_baseline(batch, params, variants, n1: int, nall: int):
         threads = min(threads, len(os.sched_getaffinity(0)))      # (what this process may run on)
     except (AttributeError, OSError):
         pass
+    lim = cpu_limits()
+    # a container with a CPU quota (cgroup cpu.max) gets that many CPUs' worth of time however many hardware threads it sees:
+    # the quota is what "cores" means here, and more runnable processes than about twice the quota only add throttling
+    quota = lim.get("cgroup_cpus")
+    cores = threads if not quota else max(1, min(threads, int(round(quota))))
+    procs = threads if not quota else max(1, min(threads, 2 * cores))
     phys = cpu_fanout.physical_cores()
     nall = min(nall, batch.n_windows)
-    per = max(4, nall // (threads * 6))
-    dta, kma, done = cpu_fanout.run(batch, {}, nall, threads, per)
+    per = max(4, nall // (procs * 6))
+    dta, kma, done = cpu_fanout.run(batch, {}, nall, procs, per)
     km1 = sum(s["n_kmers"] for s in ostats)
-    return {"value": round(done / dta, 2), "unit": "windows/s", "cores": threads, "physical_cores": phys, "hardware_threads": threads,
+    return {"value": round(done / dta, 2), "unit": "windows/s", "cores": cores, "processes": procs, "physical_cores": phys, "hardware_threads": threads,
             "kind": "port", "cpu_model": cpu_model(),
-            "sample": f"oracle/liblancet_oracle.so on the first {nall} windows of the same batch, {threads} worker processes (one per hardware thread; {phys} physical cores) over chunks of {per} windows, {dta:.1f} s",
+            "sample": f"oracle/liblancet_oracle.so on the first {nall} windows of the same batch, {procs} worker processes over chunks of {per} windows, {dta:.1f} s; "
+                      f"the host has {threads} hardware threads ({phys} physical cores)" + (f", this container a CPU quota of {quota:g} (cgroup cpu.max): `cores` is the quota" if quota else ""),
             "mkmers_per_s": round(kma / dta / 1e6, 3),
             "one_thread": {"value": round(n1 / dt1, 2), "mkmers_per_s": round(km1 / dt1 / 1e6, 3),
                            "sample": f"first {n1} windows, 1 thread, {dt1:.1f} s"},
-            "scaling_over_one_thread": round((done / dta) / (n1 / dt1), 1), "host_limits": cpu_limits(),
+            "scaling_over_one_thread": round((done / dta) / (n1 / dt1), 1), "host_limits": lim,
             "gpu_results_identical_on_sample": bool(same),
             "note": "the reference binary cannot travel to this box; in the authoring container it runs the golden cases at 13-23 windows/s/thread, this port at ~45 (DESIGN.md §7)"}
 

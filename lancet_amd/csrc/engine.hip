@@ -210,6 +210,7 @@ struct lancet_engine {
   // LANCET_PREP=device keeps the round-2 path (ASCII bases + qualities to the device, prep_kernel there)
   void *h_stage = nullptr; size_t h_stage_cap = 0; DevBuf d_stage;
   bool host_prep = true; int prep_threads = 0;
+  int prep_threads_auto = 1;       // hardware threads, at most 96 -- and at most twice the container's CPU quota (cgroup cpu.max): measured on a 16-CPU quota, 32 threads pack a batch in 26 ms, 16 in 39, 96 in 31
   int exact_need_large = -1;       // host trim: windows that exceed the 512-lane build configuration (exact: from the trimmed lengths); -1 unknown
   float ms_pack = 0;
   bool dbg = false, no_fat = false, no_early_rerun = false, no_large_build = false;     // LANCET_DEBUG / LANCET_NO_FAT / ... read once, at create
@@ -232,6 +233,21 @@ struct lancet_engine {
 // Copies of an engine go through ITS stream and wait for that stream only: hipMemcpy on the legacy default stream would also wait
 // for the kernels of every other engine on the device (two engines take turns on one GPU).
 static hipError_t lc_copy(lancet_engine *e, void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
+
+// The stream of the build service.  Its kernel is resident for the whole batch and must run BESIDE the batch's kernels; the runtime maps
+// streams onto a few hardware queues (four by default), and two streams that land on one queue run their kernels one after the other --
+// the service would then hold up the very kernels it waits for, until its 300 ms give-up timer.  A stream of another priority gets its
+// queue from another pool, so the service's never shares one with an ordinary stream (LANCET_SVC_PRIO=0: an ordinary stream).
+static hipError_t lc_service_stream(hipStream_t *s) {
+  const char *env = getenv("LANCET_SVC_PRIO");
+  if (!env || atoi(env) != 0) {
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo && hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();
+    *s = nullptr;
+  }
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
 
 static hipError_t lc_copy(lancet_engine *e, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
   hipError_t r = hipMemcpyAsync(dst, src, bytes, kind, e->stream);
@@ -318,6 +334,15 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (getenv("LANCET_NO_PREBUILD")) e->prebuild = false;
   if (const char *s = getenv("LANCET_PREP")) e->host_prep = strcmp(s, "device") != 0;
   if (const char *s = getenv("LANCET_PREP_THREADS")) e->prep_threads = std::max(1, atoi(s));
+  {
+    unsigned hw = std::max(1u, std::min(96u, std::thread::hardware_concurrency()));
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32] = {0}; long per = 0;
+      if (fscanf(f, "%31s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) { const long cpus = 2 * ((atol(q) + per - 1) / per); if (cpus >= 2 && (unsigned long)cpus < hw) hw = (unsigned)cpus; }
+      fclose(f);
+    }
+    e->prep_threads_auto = (int)hw;
+  }
   e->dbg = getenv("LANCET_DEBUG") != nullptr; e->no_fat = getenv("LANCET_NO_FAT") != nullptr; e->no_early_rerun = getenv("LANCET_NO_EARLY_RERUN") != nullptr;
   e->no_large_build = getenv("LANCET_NO_LARGE_BUILD") != nullptr; e->heavy_first = getenv("LANCET_NO_HEAVY_FIRST") == nullptr;
   if (const char *s = getenv("LANCET_BUILD_SLOTS")) e->build_slots_env = std::max(1, atoi(s));
@@ -327,7 +352,7 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (const char *s = getenv("LANCET_SVC_DEPTH")) e->svc_depth = std::max(0, std::min(16, atoi(s)));
   if (p->lr_mode) e->prebuild = false;                         // --linked-reads: barcode / haplotype bookkeeping lives in the general build only
   if (const char *s = getenv("LANCET_TRACE_WORDS")) e->evt_cap = (uint32_t)atoi(s);
-  e->max_slots = (e->n_cus - e->svc_cus) * 4 * LC_W_EU;
+  e->max_slots = (e->n_cus - e->svc_cus) * 4 * LC_W_EU - 4 * LC_W_EU;       // (one CU's worth short of the device: see n_bslots)
   if (e->svc_cus) e->n_svc_wgs = 2 * e->svc_cus;
   if (const char *s = getenv("LANCET_MAX_SLOTS")) e->max_slots = atoi(s);
   if (const char *s = getenv("LANCET_MEM_GB")) e->mem_budget = (size_t)atoi(s) << 30;
@@ -401,7 +426,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   db.n_windows = nw;
   if (e->host_prep) {
     // One staging buffer, same layout on both sides: window arrays, per-read words, packed bases / quality masks, reference codes.
-    const int T = e->prep_threads > 0 ? e->prep_threads : (int)std::max(1u, std::min(96u, std::thread::hardware_concurrency()));
+    const int T = e->prep_threads > 0 ? e->prep_threads : e->prep_threads_auto;
     const auto t_pack0 = std::chrono::steady_clock::now();
     std::vector<uint64_t> tb((size_t)T + 1, 0), tg((size_t)T + 1, 0);
     std::vector<char> bad((size_t)T, 0);
@@ -589,7 +614,12 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
   }
   if (e->prebuild) {
     const int cus = e->n_cus - e->svc_cus;
-    e->n_bslots = std::min(nw, cus * 2);
+    // Two 512-lane workgroups fit a CU.  The grid stays one CU's worth short of the device (the service's workgroups, which work the same
+    // queue first, counted in): the runtime carries out small copies, and copies to or from pageable memory, with copy KERNELS, and with
+    // two engines taking turns on one GPU the read-back and the upload of one batch otherwise waited until the other batch's build kernel
+    // -- which holds the registers and the LDS of every CU -- had left (38 ms per step; value_e2e 0.7 of value, now 0.95).
+    const bool svc_helps = e->svc && e->n_svc_wgs > 0 && !e->debug_stop && e->svc_help;
+    e->n_bslots = std::max(1, std::min(nw, cus * 2 - 2 - (svc_helps ? std::min(e->n_svc_wgs, cus) : 0)));
     if (e->build_slots_env) e->n_bslots = std::min(nw, e->build_slots_env);
     ENS(e->d_pre, (size_t)nw * PRE_STRIDE);
     ENS(e->d_blscratch, (size_t)e->n_bslots * bl_small::SCRATCH_BYTES);
@@ -615,7 +645,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     const bool use_svc = e->svc && e->n_svc_wgs > 0 && !e->debug_stop;
     if (use_svc) e->pool_cap += (uint32_t)std::max(64, nw / 8);
     if (use_svc) {
-      if ((!e->stream3 && hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess) || (!e->ev_svc && hipEventCreate(&e->ev_svc) != hipSuccess)) { e->err = "service stream"; return LANCET_E_HIP; }
+      if ((!e->stream3 && lc_service_stream(&e->stream3) != hipSuccess) || (!e->ev_svc && hipEventCreate(&e->ev_svc) != hipSuccess)) { e->err = "service stream"; return LANCET_E_HIP; }
       e->svc_cap = 2u * (uint32_t)nw + 1024u;
       const size_t off_req = 256, off_rdy = off_req + sizeof(SvcReq) * (size_t)e->svc_cap, off_cont = (off_rdy + 4u * (size_t)e->svc_cap + 63) & ~(size_t)63;
       ENS(e->d_svc, off_cont + sizeof(SvcCont) * (size_t)e->svc_cap);

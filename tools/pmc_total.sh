@@ -16,7 +16,7 @@ done
 python3 - <<'PY'
 import json
 try:
-    d = json.loads(open("/root/repo/gpurun_out/pmc_FETCH_SIZE.log").read().strip().splitlines()[-1])
+    d = [json.loads(l) for l in open("/root/repo/gpurun_out/pmc_FETCH_SIZE.log") if l.startswith("{")][-1]
     R = d["config"]["reads_per_gpu"]; W = d["config"]["windows_per_gpu"]
     rd = (2 * 150 + 4 + 4 + 8) * R / 1e6          # bases + qualities (150 each), offsets, four flag bytes, two word offsets per read
     wr = (10 + 5 + 1) * 4 * R / 1e6               # 10 words of bases, 5 of quality mask, the info word
