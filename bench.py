@@ -398,7 +398,7 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r3_traffic.json")) as fh:
                 for rec in json.load(fh)["measurements"]:
                     if rec["windows"] == args.windows and rec["coverage"] == args.cov and world == 1:
-                        out["roofline"]["traffic"] = int((rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024)
+                        out["roofline"]["traffic"] = int((rec["FETCH_SIZE_KB"] / rec.get("fetch_calibration", 1.0) + rec["WRITE_SIZE_KB"]) * 1024)
                         out["roofline"]["traffic_fetch_write"] = [int(rec["FETCH_SIZE_KB"] * 1024), int(rec["WRITE_SIZE_KB"] * 1024)]
                         out["roofline"]["traffic_note"] = rec["note"]
                         break
