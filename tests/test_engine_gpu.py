@@ -271,6 +271,27 @@ def test_coverage_pile_up_window_does_not_size_the_whole_batch():
     eng.close()
 
 
+def test_a_few_deep_windows_among_ordinary_ones():
+    """Three 60x/60x windows (beyond the 512-lane build configuration) among 64 ordinary ones -- a local coverage spike, the usual case in a
+    real scan: the 512-lane kernel lists them, the 1024-lane one builds them, the service stays in the 512-lane configuration (the deep
+    windows build their later graphs themselves).  Twice on one engine (the second batch's hand-off areas are the first one's), equal
+    to the oracle.  (Sending such a handful to the re-run tier instead of launching the 1024-lane kernel for them was tried: 0.4 ms less
+    kernel time per batch, but the tier's set-up copies in lancet_engine_submit wait for the other engine's kernels -- a net loss.)"""
+    from lancet_amd import workload
+    plain = workload.make_scan_batch(64, 30, 30, seed=7)
+    deep = workload.make_scan_batch(3, 60, 60, seed=23)
+    both = _concat(plain, deep)
+    p = abi.default_params()
+    ov, ost, _ = oracle.run(both, p)
+    key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
+    eng = engine.Engine(p)
+    for _ in range(2):
+        v, st = eng.process(both)
+        assert v == ov and [key(s) for s in st] == [key(s) for s in ost]
+        assert eng.prebuilt_count() + eng.rerun_count() == 67
+    eng.close()
+
+
 def test_pile_up_started_early_does_not_read_the_previous_batch_hand_off():
     """Two different batches through ONE engine; in the second a coverage pile-up sits at a window index whose hand-off area
     still holds a graph of the first batch (PB_BUILT, a k that also suits the pile-up's window).  The pile-up is launched in the
