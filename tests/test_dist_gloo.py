@@ -113,3 +113,28 @@ def test_bench_spawns_its_ranks(monkeypatch):
     seen.clear()
     bench.maybe_spawn(["--gpus", "4"], 4)
     assert not seen
+
+
+def test_strong_scaling_shards_reassemble_the_contig():
+    """`bench.py --scaling strong`: one contig dealt out in chunks, every rank's interleaved runs of windows concatenated into ITS batch
+    (workload.concat_batches); the ranks' records, mapped back through their window lists, are the one-process records."""
+    import numpy as np
+    from lancet_amd import abi, dist as ldist, workload
+    from oracle import oracle
+    full = workload.make_scan_batch(40, 20, 20, seed=3, read_len=100)
+    p = abi.default_params()
+    want, wst, _ = oracle.run(full, p)
+    got, nwin = [], 0
+    for rank in range(3):
+        mine = np.array(ldist.shard_windows(40, rank, 3, chunk=8), dtype=np.int64)
+        runs = np.split(mine, np.where(np.diff(mine) != 1)[0] + 1)
+        batch = workload.concat_batches([workload.sub_batch(full, int(r[0]), int(r[-1]) + 1) for r in runs])
+        assert batch.n_windows == len(mine)
+        nwin += batch.n_windows
+        v, st, _ = oracle.run(batch, p)
+        assert [s["final_k"] for s in st] == [wst[int(w)]["final_k"] for w in mine]
+        for r in v:
+            r["window"] = int(mine[r["window"]])
+            got.append(r)
+    assert nwin == 40
+    assert sorted(got, key=lambda r: (r["window"], r["seq"])) == want
