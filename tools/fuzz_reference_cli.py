@@ -36,6 +36,21 @@ def main():
             lo = int(rng.integers(900, 1800)); hi = lo + int(rng.integers(650, 1000))
             for rg in reads:
                 reads[rg] = [synth.SamRead(r.qname, r.flag | (0x4 if lo <= r.pos - 1 < hi else 0), r.rname, r.pos, r.mapq, r.cigar, r.seq, r.qual, r.tags) for r in reads[rg]]
+        # --rg-file (reference src/Microassembler.cc:29-48, 296-302, 611-616): every read gets RG:Z:rgA / rgB / rgC or none, the file names a
+        # random subset (also the empty one and one no read carries)
+        rg_listed = None
+        if rng.random() < 0.25:
+            for rg in reads:
+                out = []
+                for r in reads[rg]:
+                    tags = dict(r.tags); u = rng.random()
+                    if u < 0.4: tags["RG"] = "rgA"
+                    elif u < 0.7: tags["RG"] = "rgB"
+                    elif u < 0.9: tags["RG"] = "rgC"
+                    else: tags.pop("RG", None)
+                    out.append(synth.SamRead(r.qname, r.flag, r.rname, r.pos, r.mapq, r.cigar, r.seq, r.qual, tags))
+                reads[rg] = out
+            rg_listed = [g for g in ("rgA", "rgB", "rgC", "rgZ") if rng.random() < 0.5]
         opts, kw = [], {}
         def add(flag, field, val, conv=lambda v: v):
             opts.extend([flag, str(val)]); kw[field] = conv(val)
@@ -75,10 +90,16 @@ def main():
             for sample, rg in (("TUMOR", "tumor"), ("NORMAL", "normal")):
                 sam, bam = os.path.join(td, f"{rg}.sam"), os.path.join(td, f"{rg}.bam")
                 with open(sam, "w") as f:
-                    f.write("\n".join(["@HD\tVN:1.6\tSO:coordinate", f"@SQ\tSN:{data['rname']}\tLN:{L}", f"@RG\tID:{rg}\tSM:{sample}\tPL:ILLUMINA"]
+                    extra_rg = [f"@RG\tID:{x}\tSM:{sample}\tPL:ILLUMINA" for x in ("rgA", "rgB", "rgC")] if rg_listed is not None else []
+                    f.write("\n".join(["@HD\tVN:1.6\tSO:coordinate", f"@SQ\tSN:{data['rname']}\tLN:{L}", f"@RG\tID:{rg}\tSM:{sample}\tPL:ILLUMINA"] + extra_rg
                                       + [read_variety.sam_line(r) for r in reads[rg]]) + "\n")
                 mg.run([mg.TEST_VIEW, "-b", "-p", bam, sam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                 mg.run([mg.BAMTOOLS, "index", "-in", bam]); bams[rg] = bam
+            rgfile = None
+            if rg_listed is not None:
+                rgfile = os.path.join(td, "rg.txt")
+                open(rgfile, "w").write("".join(g + "\n" for g in rg_listed))
+                opts = opts + ["--rg-file", rgfile]
             r = subprocess.run([mg.REF_BIN, "--tumor", bams["tumor"], "--normal", bams["normal"], "--ref", fa, "--reg", region, "--num-threads", "1", "-v"] + opts,
                                capture_output=True, text=True, cwd=td)
             if r.returncode != 0:
@@ -86,6 +107,7 @@ def main():
             want = [f"{m.group(1)} {m.group(2)} {m.group(3)} {m.group(4)}" for m in re.finditer(r"== Processing (\d+): (\S+) numsequences: (\d+) mapped: (\d+)", r.stderr)]
             o = host.default_opts(**kw)
             H = host.NativeHost(bams["tumor"], bams["normal"], fa)
+            if rgfile: H.set_rg_file(rgfile)
             hdrs = H.tile(region, o)
             b, idx = H.batch(0, len(hdrs), o)
             nr = np.diff(b.read_begin.astype(np.int64))
