@@ -62,6 +62,9 @@ const char *lancet_host_sample(const lancet_host *h, int which);
  * no alignment), else 0.  main() turns the active-region module off when neither BAM has it (src/Lancet.cc:817-825).
  * Valid after a tile call. */
 int lancet_host_first_has_md(const lancet_host *h, int which);
+/* isRepeat (reference src/util.cc:295-315: a k-mer seen twice among the offsets [0, len - k)) on a NUL-terminated sequence: 1 or 0.
+ * The window filter of lancet_host_batch (src/Microassembler.cc:800) uses it; exported for the tests. */
+int lancet_host_debug_is_repeat(const char *seq, int k);
 
 /* Tiles "chr:start-end" (or "chr") into windows (loadRefs, reference src/Lancet.cc:189-316), puts them in processing
  * order and decodes the alignments of both BAMs the windows can select: through the .bai linear index when

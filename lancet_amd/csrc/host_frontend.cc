@@ -14,6 +14,8 @@
 #include <atomic>
 #include <cctype>
 #include <chrono>
+#include <sys/stat.h>
+#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -44,11 +46,37 @@ struct Read {
   int32_t chr;                // index into lancet_host::chroms
 };
 
+// A byte buffer that grows without initialising what it grows by: the bases / qualities / text of a scan are tens of MB per slab, a
+// std::string would zero-fill them (and first touch every page) on the one thread that resizes, before the decoding threads write
+// every byte anyway.  realloc moves large blocks by remapping.
+struct Bytes {
+  char *p = nullptr; size_t n = 0, cap = 0;
+  Bytes() {}
+  Bytes(const Bytes &) = delete; Bytes &operator=(const Bytes &) = delete;
+  Bytes(Bytes &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+  Bytes &operator=(Bytes &&o) noexcept { if (this != &o) { free(p); p = o.p; n = o.n; cap = o.cap; o.p = nullptr; o.n = o.cap = 0; } return *this; }
+  ~Bytes() { free(p); }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  void reserve(size_t want) { if (want > cap) { size_t c = cap + cap / 2; if (c < want) c = want; if (c < 4096) c = 4096; char *q = (char *)realloc(p, c); if (!q) throw std::bad_alloc(); p = q; cap = c; } }
+  void resize(size_t want) { reserve(want); n = want; }
+  void append(const char *s, size_t len) { reserve(n + len + 1); memcpy(p + n, s, len); n += len; }
+  void append(const std::string &s) { append(s.data(), s.size()); }
+  void push_back(char c) { reserve(n + 1); p[n++] = c; }
+  void clear() { n = 0; }
+  void erase_front(size_t k) { if (k >= n) { n = 0; return; } memmove(p, p + k, n - k); n -= k; }
+  char *data() { return p; }
+  const char *data() const { return p; }
+  const char *c_str() const { return p; }        // (every string in it is NUL terminated by its writer)
+  char &operator[](size_t i) { return p[i]; }
+  const char &operator[](size_t i) const { return p[i]; }
+};
+
 struct Sample {
   std::vector<Read> reads;
   std::vector<int32_t> starts;      // pos0 per read (region seek)
   std::vector<uint32_t> cigar;
-  std::string seq, qual, text;
+  Bytes seq, qual, text;
   std::string sample_name = "NA";
   std::vector<std::pair<std::string, int32_t>> refs;
   std::string path;
@@ -105,15 +133,20 @@ class BgzfReader {
     while (ubuf_.size() - upos_ < n) if (!fill(err)) return false;
     return true;
   }
+  bool have(size_t n) const { return ubuf_.size() - upos_ >= n; }     // n bytes at the cursor without reading on (a read-on moves the buffer)
   const unsigned char *cur() const { return (const unsigned char *)ubuf_.data() + upos_; }
+  const unsigned char *base() const { return (const unsigned char *)ubuf_.data(); }
+  size_t offset() const { return upos_; }
   void advance(size_t n) { upos_ += n; }
   uint64_t compressed_pos() const { return coff_; }
   uint64_t inflated_total() const { return inflated_; }
+  double fill_seconds() const { return fill_s_; }
 
  private:
   bool fill(std::string *err) {
+    struct Acc { double *t; std::chrono::steady_clock::time_point t0; ~Acc() { *t += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } acc{&fill_s_, std::chrono::steady_clock::now()};
     if (eof_) return false;
-    if (upos_ > 0) { ubuf_.erase(0, upos_); upos_ = 0; }
+    if (upos_ > 0) { ubuf_.erase_front(upos_); upos_ = 0; }
     cbuf_.resize(slab_);
     if (fseeko(f_, (off_t)coff_, SEEK_SET) != 0) { *err = "seek failed"; return false; }
     const size_t got = fread(&cbuf_[0], 1, slab_, f_);
@@ -175,7 +208,8 @@ class BgzfReader {
   static size_t slab_max() { if (const char *e = getenv("LANCET_HOST_SLAB_KB")) { const long v = atol(e); if (v >= 64) return (size_t)v << 10; } return 16u << 20; }
   FILE *f_ = nullptr;
   uint64_t coff_ = 0, inflated_ = 0;
-  std::string cbuf_, ubuf_;
+  double fill_s_ = 0;
+  Bytes cbuf_, ubuf_;
   size_t upos_ = 0, slab_ = slab_max() < (1u << 18) ? slab_max() : (1u << 18);
   bool eof_ = false;
 };
@@ -353,6 +387,15 @@ bool load_bam(const std::string &path, std::vector<Want> wants, Sample *S, std::
   BgzfReader in;
   if (!in.open(path, err)) return false;
   auto fail = [&](const std::string &m) { *err = path + ": " + (err->empty() ? m : *err); return false; };
+  {   // room for what a file of this size can hold (address space only until it is written: growing a 25 MB block later costs more than decoding it)
+    struct stat st;
+    if (stat(path.c_str(), &st) == 0 && st.st_size > 0) {
+      const size_t fs = (size_t)st.st_size;
+      try { S->seq.reserve(std::min<size_t>(3 * fs, (size_t)1 << 30)); S->qual.reserve(std::min<size_t>(3 * fs, (size_t)1 << 30)); S->text.reserve(std::min<size_t>(fs, (size_t)1 << 29));
+            S->reads.reserve(std::min<size_t>(fs / 48, (size_t)1 << 24)); S->starts.reserve(std::min<size_t>(fs / 48, (size_t)1 << 24)); S->cigar.reserve(std::min<size_t>(fs / 24, (size_t)1 << 25)); }
+      catch (const std::bad_alloc &) {}
+    }
+  }
   if (!in.need(12, err)) return fail("not a BAM file");
   if (memcmp(in.cur(), "BAM\1", 4) != 0) { err->clear(); return fail("not a BAM file"); }
   const int32_t l_text = rd_i32(in.cur() + 4);
@@ -412,6 +455,70 @@ bool load_bam(const std::string &path, std::vector<Want> wants, Sample *S, std::
   uint64_t seeks = 0;
   int32_t prev_tid = 0, prev_pos = -1; bool have_prev = false;
   bool at_end = false;
+  // Records that pass the range test are only NOTED (offset in the inflated buffer, size); they are decoded, by several threads into
+  // pieces that are then appended in order, before the buffer moves (a read-on, a seek) and at the end of a range.  Walking the chain of
+  // block sizes is all that stays serial: with the inflate on the host threads already, decoding one record after the other was 90 % of
+  // the load on a 64-thread host.
+  struct Pend { size_t off; uint32_t bs; int chr; };
+  std::vector<Pend> pend;
+  double t_decode = 0; int n_flush = 0;
+  auto flush = [&]() -> bool {
+    if (pend.empty()) return true;
+    const double tf0 = timing ? now() : 0; ++n_flush;
+    struct Acc { double *t; double t0; bool on; std::function<double()> clk; ~Acc() { if (on) *t += clk() - t0; } } acc{&t_decode, tf0, timing, now};
+    const unsigned nt = host_threads((int)(pend.size() / 2048 + 1));
+    bool ok = true;
+    if (nt <= 1) {
+      for (const Pend &q : pend) if (!decode_record(in.base() + q.off, (size_t)q.bs, q.chr, S, err)) { ok = false; break; }
+    } else {
+      std::vector<Sample> piece(nt);
+      std::vector<std::string> perr(nt);
+      std::vector<char> pok(nt, 1);
+      const unsigned char *base = in.base();
+      auto work = [&](unsigned t) {
+        const size_t lo = pend.size() * t / nt, hi = pend.size() * (t + 1) / nt;
+        Sample &P = piece[t];
+        P.reads.reserve(hi - lo); P.starts.reserve(hi - lo);
+        { size_t bytes = 0; for (size_t i = lo; i < hi; ++i) bytes += pend[i].bs;          // (a record's bases / qualities / text are each shorter than the record)
+          P.seq.reserve(bytes); P.qual.reserve(bytes); P.text.reserve(bytes / 2 + 64); P.cigar.reserve((hi - lo) * 4); }
+        for (size_t i = lo; i < hi; ++i) if (!decode_record(base + pend[i].off, (size_t)pend[i].bs, pend[i].chr, &P, &perr[t])) { pok[t] = 0; return; }
+      };
+      std::vector<std::thread> th;
+      for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+      work(0);
+      for (auto &t : th) t.join();
+      for (unsigned t = 0; t < nt && ok; ++t) if (!pok[t]) { *err = perr[t]; ok = false; }
+      // append the pieces in order: sizes first, then every piece copies itself into place and shifts its reads' offsets
+      std::vector<size_t> r0(nt + 1), c0(nt + 1), s0(nt + 1), t0(nt + 1);
+      r0[0] = S->reads.size(); c0[0] = S->cigar.size(); s0[0] = S->seq.size(); t0[0] = S->text.size();
+      for (unsigned t = 0; t < nt; ++t) { r0[t + 1] = r0[t] + piece[t].reads.size(); c0[t + 1] = c0[t] + piece[t].cigar.size(); s0[t + 1] = s0[t] + piece[t].seq.size(); t0[t + 1] = t0[t] + piece[t].text.size(); }
+      if (ok && (s0[nt] > 0xFFFFFFFFull || t0[nt] > 0xFFFFFFFFull || c0[nt] > 0xFFFFFFFFull)) { *err = "more than 4 GB of alignments in one tiling (tile fewer windows at a time)"; ok = false; }
+      if (ok) {
+        S->reads.resize(r0[nt]); S->starts.resize(r0[nt]); S->cigar.resize(c0[nt]); S->seq.resize(s0[nt]); S->qual.resize(s0[nt]); S->text.resize(t0[nt]);
+        auto place = [&](unsigned t) {
+          const Sample &P = piece[t];
+          if (!P.cigar.empty()) memcpy(&S->cigar[c0[t]], P.cigar.data(), 4 * P.cigar.size());
+          if (!P.seq.empty()) { memcpy(&S->seq[s0[t]], P.seq.data(), P.seq.size()); memcpy(&S->qual[s0[t]], P.qual.data(), P.qual.size()); }
+          if (!P.text.empty()) memcpy(&S->text[t0[t]], P.text.data(), P.text.size());
+          for (size_t i = 0; i < P.reads.size(); ++i) {
+            Read r = P.reads[i];
+            r.cig_off += (uint32_t)c0[t]; r.seq_off += (uint32_t)s0[t]; r.name_off += (uint32_t)t0[t]; r.bx_off += (uint32_t)t0[t];
+            if (r.has_md) r.md_off += (uint32_t)t0[t];
+            if (r.rg_off != 0xFFFFFFFFu) r.rg_off += (uint32_t)t0[t];
+            S->reads[r0[t] + i] = r; S->starts[r0[t] + i] = P.starts[i];
+          }
+        };
+        std::vector<std::thread> th2;
+        for (unsigned t = 1; t < nt; ++t) th2.emplace_back(place, t);
+        place(0);
+        for (auto &t : th2) t.join();
+      }
+    }
+    pend.clear();
+    return ok;
+  };
+  // an error of the walk is reported only after the records noted before it have been decoded: a damaged record earlier in the file wins
+  auto fail_after = [&](const char *m) { if (!flush()) return fail(""); err->clear(); return fail(m); };
   for (size_t ri = 0; ri < rngs.size() && !at_end; ++ri) {
     const Rng &g = rngs[ri];
     if (indexed && (size_t)g.tid < index.size()) {
@@ -419,30 +526,31 @@ bool load_bam(const std::string &path, std::vector<Want> wants, Sample *S, std::
       if (voff == 0) continue;                          // no alignment on this contig from lo onwards
       if ((voff >> 16) > in.compressed_pos()) { if (!in.seek(voff, err)) return fail(""); ++seeks; have_prev = false; }
     }
-    const size_t first = S->reads.size();
+    const size_t first = S->reads.size();              // (nothing is pending here: every range ends with a flush)
     for (;;) {
-      if (!in.need(4, err)) { if (!err->empty()) return fail(""); at_end = true; break; }
+      if (!in.have(4)) { if (!flush()) return fail(""); if (!in.need(4, err)) { if (!err->empty()) return fail(""); at_end = true; break; } }
       const int32_t bs = rd_i32(in.cur());
-      if (bs < 32) return fail("truncated alignment record");
-      if (bs > (256 << 20)) return fail("alignment record of more than 256 MB (damaged block_size?)");     // (need() would buffer the rest of the file first)
-      if (!in.need(4 + (size_t)bs, err)) return fail("truncated alignment record");
+      if (bs < 32) return fail_after("truncated alignment record");
+      if (bs > (256 << 20)) return fail_after("alignment record of more than 256 MB (damaged block_size?)");     // (need() would buffer the rest of the file first)
+      if (!in.have(4 + (size_t)bs)) { if (!flush()) return fail(""); if (!in.need(4 + (size_t)bs, err)) return fail("truncated alignment record"); }
       const unsigned char *rec = in.cur() + 4;
       const int32_t tid = rd_i32(rec), pos = rd_i32(rec + 4);
       if (tid >= 0) {
-        if (have_prev && (tid < prev_tid || (tid == prev_tid && pos < prev_pos))) { err->clear(); return fail("not coordinate sorted"); }
+        if (have_prev && (tid < prev_tid || (tid == prev_tid && pos < prev_pos))) return fail_after("not coordinate sorted");
         prev_tid = tid; prev_pos = pos; have_prev = true;
       }
       if (tid < 0 || tid > g.tid || (tid == g.tid && pos > g.hi)) { if (tid < 0) at_end = true; break; }   // left for the next range
-      if (tid == g.tid && pos >= g.lo) { if (!decode_record(rec, (size_t)bs, g.chr, S, err)) return fail(""); }
+      if (tid == g.tid && pos >= g.lo) pend.push_back(Pend{in.offset() + 4, (uint32_t)bs, g.chr});
       in.advance(4 + (size_t)bs);
     }
+    if (!flush()) return fail("");
     std::pair<size_t, size_t> &sp = S->span[(size_t)g.chr];
     if (S->reads.size() > first) { if (sp.second == sp.first) sp.first = first; sp.second = S->reads.size(); }
   }
   S->path = path;
-  if (timing) fprintf(stderr, "[lancet_host] %s: %s, %zu ranges, %llu seeks, %llu MB inflated, %zu alignments kept, %.3f s\n", path.c_str(),
+  if (timing) fprintf(stderr, "[lancet_host] %s: %s, %zu ranges, %llu seeks, %llu MB inflated, %zu alignments kept, %.3f s (read + inflate %.3f s, decode %.3f s in %d steps)\n", path.c_str(),
                       indexed ? "indexed (.bai)" : "no .bai: streamed from the start", rngs.size(), (unsigned long long)seeks,
-                      (unsigned long long)(in.inflated_total() >> 20), S->reads.size(), now() - t0);
+                      (unsigned long long)(in.inflated_total() >> 20), S->reads.size(), now() - t0, in.fill_seconds(), t_decode, n_flush);
   return true;
 }
 
@@ -661,14 +769,30 @@ unsigned host_threads(int items) {
   return nt;
 }
 
-// isRepeat (reference src/util.cc:295-315): a k-mer seen twice among offsets [0, len-K)
+// isRepeat (reference src/util.cc:295-315): a k-mer seen twice among offsets [0, len-K).  The reference sorts nothing either -- it
+// inserts every k-mer into a std::set and looks at the size; here: a rolling 64-bit hash per offset into an open-addressing table, a hit
+// confirmed on the characters (sorting the ~500 offsets of a window by 101-character compares was the largest single cost of read
+// selection: 60 of 70 us per window).
 bool is_repeat(const std::string &s, int k) {
   const int n = (int)s.size() - k;
-  if (n <= 1) return false;
-  std::vector<int> idx((size_t)n);
-  for (int i = 0; i < n; ++i) idx[(size_t)i] = i;
-  std::sort(idx.begin(), idx.end(), [&](int a, int b) { return s.compare((size_t)a, (size_t)k, s, (size_t)b, (size_t)k) < 0; });
-  for (int i = 1; i < n; ++i) if (s.compare((size_t)idx[(size_t)i - 1], (size_t)k, s, (size_t)idx[(size_t)i], (size_t)k) == 0) return true;
+  if (n <= 1 || k <= 0) return false;
+  unsigned bits = 4; while ((1u << bits) < 2u * (unsigned)n) ++bits;
+  const unsigned cap = 1u << bits;
+  static thread_local std::vector<int> tab; static thread_local std::vector<uint64_t> hs;
+  tab.assign(cap, -1); hs.resize(cap);
+  const uint64_t B = 0x100000001B3ULL;
+  uint64_t pw = 1; for (int i = 0; i + 1 < k; ++i) pw *= B;
+  uint64_t h = 0; for (int i = 0; i < k; ++i) h = h * B + (unsigned char)s[(size_t)i];
+  for (int i = 0; i < n; ++i) {
+    if (i) h = (h - (uint64_t)(unsigned char)s[(size_t)i - 1] * pw) * B + (unsigned char)s[(size_t)(i + k - 1)];
+    uint64_t x = h ^ (h >> 31); x *= 0x9E3779B97F4A7C15ULL;
+    unsigned idx = (unsigned)(x >> (64 - bits));
+    while (tab[idx] >= 0) {
+      if (hs[idx] == h && memcmp(s.data() + tab[idx], s.data() + i, (size_t)k) == 0) return true;
+      idx = (idx + 1) & (cap - 1);
+    }
+    tab[idx] = i; hs[idx] = h;
+  }
   return false;
 }
 
@@ -714,6 +838,7 @@ int lancet_host_set_rg_file(lancet_host *h, const char *path) {
   if (h->readgroups.empty()) h->readgroups.insert("null");
   return LANCET_OK;
 }
+int lancet_host_debug_is_repeat(const char *seq, int k) { return is_repeat(std::string(seq ? seq : ""), k) ? 1 : 0; }     // (tests)
 int lancet_host_first_has_md(const lancet_host *h, int which) { return h->smp[which ? 1 : 0].first_has_md; }
 const char *lancet_host_window_hdr(const lancet_host *h, int w) { return (w >= 0 && (size_t)w < h->windows.size()) ? h->windows[(size_t)w].hdr.c_str() : ""; }
 int lancet_host_window_chrom(const lancet_host *h, int w) { return (w >= 0 && (size_t)w < h->windows.size()) ? h->windows[(size_t)w].chr : -1; }

@@ -619,3 +619,33 @@ def test_lancet_gpu_finishes_and_lists_windows_that_exceeded_the_work_space(tmp_
     assert r.stdout.startswith("##fileformat=VCF")
     r = subprocess.run(args + ["--strict"], capture_output=True, text=True, env=env)
     assert r.returncode == 1 and r.stdout == "" and "--strict" in r.stderr
+
+
+def test_window_repeat_filter_equals_the_set_of_kmers():
+    """isRepeat (reference src/util.cc:295-315): a window whose k-mers at offsets [0, len - k) are not all distinct.  The native one uses a
+    rolling hash with confirmation on the characters; against a set of substrings on random windows with and without planted repeats,
+    several k, short and degenerate inputs."""
+    import ctypes as C
+    from lancet_amd import engine
+    L = engine.lib()
+    L.lancet_host_debug_is_repeat.restype = C.c_int
+    L.lancet_host_debug_is_repeat.argtypes = [C.c_char_p, C.c_int]
+    rng = np.random.default_rng(11)
+    def want(s, k):
+        n = len(s) - k
+        return n > 1 and len({s[i:i + k] for i in range(n)}) < n
+    seen = [0, 0]
+    for trial in range(600):
+        n = int(rng.choice([5, 40, 120, 600, 601, 850]))
+        s = "".join("ACGTN"[int(x)] for x in rng.choice(5, size=n, p=[0.245, 0.245, 0.245, 0.245, 0.02]))
+        k = int(rng.choice([3, 11, 31, 101, 127]))
+        if rng.random() < 0.5 and n > 2 * k + 4:            # plant a copy of a k-mer (sometimes at the very end, where the last offset does not count)
+            a = int(rng.integers(0, n - k)); b = int(rng.integers(0, n - k + 1))
+            s = s[:b] + s[a:a + k] + s[b + k:]
+        if rng.random() < 0.1:
+            s = s[0] * len(s)                               # one letter: every k-mer the same
+        w = want(s, k)
+        seen[int(w)] += 1
+        assert bool(L.lancet_host_debug_is_repeat(s.encode(), k)) == w, (trial, n, k)
+    assert seen[0] > 100 and seen[1] > 100
+    assert not L.lancet_host_debug_is_repeat(b"", 11) and not L.lancet_host_debug_is_repeat(b"ACGT", 11)
