@@ -1,0 +1,11 @@
+# The native command-line program on the pre-generated 500 kb BAM pair (build/scan500k), twice per mode, with the host side's stage times
+cd /root/repo; D=build/scan500k; REG=chr22:1000-499000; mkdir -p gpurun_out
+export LANCET_HOST_TIMING=1
+for mode in "--active-region-off" ""; do
+  for it in 1 2; do
+    ./lancet_amd/bin/lancet_gpu --tumor $D/tumor.bam --normal $D/normal.bam --ref $D/ref.fa --reg $REG $mode --date-line "Sun Sep 27 05:27:00 2026" > gpurun_out/e2e_native$mode.vcf 2> gpurun_out/e2e_native$mode.log
+    grep -h "lancet_gpu\|tumor.bam\|windows: select" gpurun_out/e2e_native$mode.log | tail -4
+  done
+done
+grep -v "^##fileDate\|^##cmdline" gpurun_out/e2e_native--active-region-off.vcf | md5sum
+grep -vc "^#" gpurun_out/e2e_native--active-region-off.vcf gpurun_out/e2e_native.vcf
