@@ -280,6 +280,9 @@ bool decode_record(const unsigned char *b, size_t bs, int chr, Sample *S, std::s
   const unsigned n_cig = rd_u16(b + 12), flag = rd_u16(b + 14);
   const int32_t l_seq = rd_i32(b + 16);
   if (l_seq < 0 || 32 + (size_t)l_name + 4 * (size_t)n_cig + (size_t)((l_seq + 1) / 2) + (size_t)l_seq > end) { *err = "alignment record with fields past its end"; return false; }
+  // (offsets into the sample's arrays are 32 bits: ~28 M reads of 150 bases per sample and tiling)
+  if ((uint64_t)S->seq.size() + (uint64_t)l_seq > 0xFFFFFFFFull || (uint64_t)S->text.size() + (uint64_t)bs > 0xFFFFFFFFull || (uint64_t)S->cigar.size() + n_cig > 0xFFFFFFFFull) {
+    *err = "more than 4 GB of alignments in one tiling (tile fewer windows at a time)"; return false; }
   Read r; memset(&r, 0, sizeof r);
   r.pos0 = pos; r.flag = (uint16_t)flag; r.mapq = (uint8_t)mapq; r.as = -1.f; r.xs = -1.f; r.chr = chr;
   size_t q = 32;
