@@ -383,7 +383,8 @@ struct Want { std::string chrom; int chr; std::vector<std::pair<int32_t, int32_t
 
 // Decodes, in file order, the alignments the tiling can select.  With a .bai next to the BAM the reader jumps to each
 // range through the linear index; without one it streams the file once and stops after the last range.
-bool load_bam(const std::string &path, std::vector<Want> wants, Sample *S, std::string *err) {
+struct BaiCache { bool tried = false, have = false; std::vector<RefIndex> index; };
+bool load_bam(const std::string &path, std::vector<Want> wants, Sample *S, std::string *err, BaiCache *bai = nullptr) {
   const bool timing = getenv("LANCET_HOST_TIMING") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
@@ -453,8 +454,10 @@ bool load_bam(const std::string &path, std::vector<Want> wants, Sample *S, std::
   }
   std::sort(rngs.begin(), rngs.end(), [](const Rng &a, const Rng &b) { return a.tid != b.tid ? a.tid < b.tid : a.lo < b.lo; });
   S->span.assign(max_chr, std::pair<size_t, size_t>(0, 0));
-  std::vector<RefIndex> index;
-  const bool indexed = load_bai(path, &index);
+  std::vector<RefIndex> own;
+  if (bai && !bai->tried) { bai->have = load_bai(path, &bai->index); bai->tried = true; }      // (lazy mode reads the index once, not once per batch)
+  const bool indexed = bai ? bai->have : load_bai(path, &own);
+  const std::vector<RefIndex> &index = bai ? bai->index : own;
   uint64_t seeks = 0;
   int32_t prev_tid = 0, prev_pos = -1; bool have_prev = false;
   bool at_end = false;
@@ -638,7 +641,13 @@ struct Fasta {
 
 struct lancet_host {
   std::string err;
-  Sample smp[2];                    // 0 normal, 1 tumor
+  Sample smp[4];                    // 0 normal, 1 tumor; 2, 3: reads an earlier window left in the graph, kept across a reload (lazy mode)
+  // Lazy mode: the tiling only builds the window table; every lancet_host_batch call loads the alignments ITS windows can select (through
+  // the .bai: a run of windows in processing order is a few stretches of the contig).  Memory is then one batch's reads instead of the whole
+  // region's -- a whole chromosome at 60x does not fit the 32-bit offsets of one load.  LANCET_HOST_LAZY=1 / 0 forces it on / off; by default
+  // it is on above 400 000 windows when both BAMs have an index.
+  bool lazy = false;
+  BaiCache bai[2];
   Fasta fa;
   std::vector<std::string> chroms;     // contigs of the tiling, in order of first appearance (chr_id of the batches)
   std::vector<const char *> chrom_ptrs;
@@ -918,6 +927,19 @@ int finish_tiling(lancet_host *h, std::map<std::string, std::vector<std::pair<in
     }
     wants.push_back(std::move(w));
   }
+  {
+    const char *e = getenv("LANCET_HOST_LAZY");
+    auto has_bai = [](const std::string &bam) {
+      std::string c[2] = {bam + ".bai", bam.size() > 4 && bam.compare(bam.size() - 4, 4, ".bam") == 0 ? bam.substr(0, bam.size() - 4) + ".bai" : std::string()};
+      for (const std::string &x : c) if (!x.empty()) { FILE *f = fopen(x.c_str(), "rb"); if (f) { fclose(f); return true; } }
+      return false;
+    };
+    const bool indexed = has_bai(h->smp[0].path) && has_bai(h->smp[1].path);
+    h->lazy = e ? (atoi(e) != 0 && indexed) : (indexed && h->windows.size() > 400000);
+    h->smp[2] = Sample(); h->smp[3] = Sample();
+    h->bai[0] = BaiCache(); h->bai[1] = BaiCache();
+    if (h->lazy) wants.clear();                      // header, sample name, MD on the first alignment: no alignments yet
+  }
   std::string errs[2]; bool ok[2] = {false, false};
   auto load = [&](int smp) {
     Sample &S = h->smp[smp];
@@ -930,6 +952,60 @@ int finish_tiling(lancet_host *h, std::map<std::string, std::vector<std::pair<in
   other.join();
   for (int smp = 0; smp < 2; ++smp) if (!ok[smp]) { h->err = errs[smp]; return LANCET_E_ARG; }
   return (int)h->windows.size();
+}
+
+}  // namespace
+
+namespace {
+
+// Lazy mode: the alignments the windows [w_begin, w_end) can select, loaded in place of the previous batch's.  Reads an earlier window left
+// in the graph (lancet_host::leak) are copied into the side store first: their indices would not survive the reload.
+int reload_for(lancet_host *h, int w_begin, int w_end) {
+  if (!h->leak.empty()) {
+    Sample keep[2];
+    for (RSel &r : h->leak) {
+      const Sample &S = h->smp[r.smp];
+      const Read &src = S.reads[r.s.idx];
+      Sample &D = keep[r.smp & 1];
+      Read d = src;
+      d.seq_off = (uint32_t)D.seq.size(); D.seq.append(S.seq.data() + src.seq_off, src.l_seq); D.qual.append(S.qual.data() + src.seq_off, src.l_seq);
+      d.cig_off = (uint32_t)D.cigar.size(); for (uint32_t c = 0; c < src.n_cig; ++c) D.cigar.push_back(S.cigar[src.cig_off + c]);
+      auto put = [&](uint32_t off) { const char *z = S.text.c_str() + off; const uint32_t o2 = (uint32_t)D.text.size(); D.text.append(z, strlen(z)); D.text.push_back('\0'); return o2; };
+      d.name_off = put(src.name_off); d.bx_off = put(src.bx_off);
+      if (src.has_md) d.md_off = put(src.md_off);
+      if (src.rg_off != 0xFFFFFFFFu) d.rg_off = put(src.rg_off);
+      r.s.idx = (uint32_t)D.reads.size(); r.smp = (uint8_t)(2 + (r.smp & 1));
+      D.reads.push_back(d); D.starts.push_back(d.pos0);
+    }
+    h->smp[2] = std::move(keep[0]); h->smp[3] = std::move(keep[1]);
+  } else { h->smp[2] = Sample(); h->smp[3] = Sample(); }
+  // the stretches of each contig these windows cover: a window selects alignments that start inside [start, end] (tile_one)
+  std::vector<Want> wants(h->chroms.size());
+  for (size_t c = 0; c < h->chroms.size(); ++c) { wants[c].chrom = h->chroms[c]; wants[c].chr = (int)c; }
+  for (int w = w_begin; w < w_end; ++w) {
+    const Window &win = h->windows[(size_t)w];
+    if (win.end >= win.start) wants[(size_t)win.chr].iv.emplace_back(win.start - 1, win.end + 1);
+  }
+  for (Want &w : wants) {
+    std::sort(w.iv.begin(), w.iv.end());
+    std::vector<std::pair<int32_t, int32_t>> m;
+    for (auto &iv : w.iv) { if (!m.empty() && iv.first <= m.back().second + 1) { if (iv.second > m.back().second) m.back().second = iv.second; } else m.push_back(iv); }
+    w.iv.swap(m);
+  }
+  wants.erase(std::remove_if(wants.begin(), wants.end(), [](const Want &w) { return w.iv.empty(); }), wants.end());
+  std::string errs[2]; bool ok[2] = {false, false};
+  auto load = [&](int smp) {
+    Sample &S = h->smp[smp];
+    const std::string path = S.path;
+    Sample fresh; fresh.path = path;
+    ok[smp] = load_bam(path, wants, &fresh, &errs[smp], &h->bai[smp]);
+    S = std::move(fresh);
+  };
+  std::thread other(load, 0);
+  load(1);
+  other.join();
+  for (int smp = 0; smp < 2; ++smp) if (!ok[smp]) { h->err = errs[smp]; return LANCET_E_ARG; }
+  return LANCET_OK;
 }
 
 }  // namespace
@@ -982,6 +1058,7 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
   const int nwin = w_end - w_begin;
   const bool timing = getenv("LANCET_HOST_TIMING") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  if (h->lazy) { const int rc = reload_for(h, w_begin, w_end); if (rc != LANCET_OK) return rc; }
   const double t0 = now();
   std::vector<std::vector<Sel>> selT((size_t)nwin), selN((size_t)nwin);
   std::vector<uint8_t> keep((size_t)nwin, 0), wmapped((size_t)nwin, 0);
@@ -1036,7 +1113,7 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
     const Window &win = h->windows[(size_t)(w_begin + i)];
     if (kept) kept[k] = w_begin + i;
     uint64_t nb = wbases[(size_t)i];
-    for (const RSel &r : pre[(size_t)k]) nb += h->smp[r.smp].reads[r.s.idx].l_seq;
+    for (const RSel &r : pre[(size_t)k]) nb += h->smp[r.smp].reads[r.s.idx].l_seq;       // (smp 2 / 3: the store of left-over reads)
     base0[(size_t)k + 1] = base0[(size_t)k] + nb;
     h->b_readbegin[(size_t)k + 1] = h->b_readbegin[(size_t)k] + (uint32_t)(pre[(size_t)k].size() + selT[(size_t)i].size() + selN[(size_t)i].size());
     h->b_refoff[(size_t)k + 1] = h->b_refoff[(size_t)k] + (uint32_t)win.seq.size();
@@ -1071,7 +1148,7 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
             memcpy(h->b_seq.p + bo, S.seq.data() + rd.seq_off, rd.l_seq); memcpy(h->b_qual.p + bo, S.qual.data() + rd.seq_off, rd.l_seq);
             bo += rd.l_seq;
             h->b_seqoff[r + 1] = (uint32_t)bo;
-            h->b_label[r] = smp ? LANCET_TMR : LANCET_NML; h->b_strand[r] = s.strand; h->b_mate[r] = s.mate; h->b_mapped[r] = s.mapped;
+            h->b_label[r] = (smp & 1) ? LANCET_TMR : LANCET_NML; h->b_strand[r] = s.strand; h->b_mate[r] = s.mate; h->b_mapped[r] = s.mapped;
             names.push_back(S.text.c_str() + rd.name_off);
             if (o->linked) { bx_of[r] = S.text.c_str() + rd.bx_off; h->b_hp[r] = (uint8_t)(rd.hp > 255 ? 255 : rd.hp); }
             ++r;

@@ -649,3 +649,57 @@ def test_window_repeat_filter_equals_the_set_of_kmers():
         assert bool(L.lancet_host_debug_is_repeat(s.encode(), k)) == w, (trial, n, k)
     assert seen[0] > 100 and seen[1] > 100
     assert not L.lancet_host_debug_is_repeat(b"", 11) and not L.lancet_host_debug_is_repeat(b"ACGT", 11)
+
+
+def test_lazy_per_batch_loading_gives_the_same_batches(tmp_path, monkeypatch, capfd):
+    """Lazy mode (LANCET_HOST_LAZY=1, needs a .bai): the tiling only builds the window table, every batch call loads the alignments its
+    windows can select.  Batches of 5 windows at a time, concatenated, equal the one batch of the eager mode -- on the two-contig BED
+    golden (bamtools-made .bai) and on the read-leak golden rewritten with an index, where reads a window leaves in the graph have to
+    survive the reload between two batches."""
+    from lancet_amd import workload
+    o = host.default_opts()
+    # bed2: BED + region on two contigs
+    paths = _bed2_paths()
+    case = __import__("json").load(open(os.path.join(G, "bed2.case.txt")))
+    bed = os.path.join(G, "bed2.bed")
+    def all_batches(paths, tile, step, o=o):
+        H = host.NativeHost(*paths)
+        hdrs = tile(H)
+        parts, kept = [], []
+        for lo in range(0, len(hdrs), step):
+            b, idx = H.batch(lo, min(len(hdrs), lo + step), o)
+            if b.n_windows:
+                parts.append(b)
+            kept += list(idx)
+        H.close()
+        return hdrs, parts, kept
+    tile_bed = lambda H: H.tile_regions([case["region"]], o, bed=bed)
+    monkeypatch.setenv("LANCET_HOST_LAZY", "0")
+    hdrs, eager, kept = all_batches(paths, tile_bed, 10 ** 6)
+    monkeypatch.setenv("LANCET_HOST_LAZY", "1")
+    monkeypatch.setenv("LANCET_HOST_TIMING", "1")
+    hdrs2, lazy, kept2 = all_batches(paths, tile_bed, 5)
+    monkeypatch.delenv("LANCET_HOST_TIMING")
+    err = capfd.readouterr().err
+    assert err.count("indexed (.bai)") >= 2 * (len(hdrs) // 5) and "0 alignments kept" in err      # (the tiling itself loaded none)
+    assert hdrs2 == hdrs and kept2 == kept and len(lazy) > 3
+    _batches_equal(eager[0], workload.concat_batches(lazy))
+    # leak_small: three windows without a mapped read leave their reads to the next one
+    lp = []
+    for smp in ("tumor", "normal"):
+        hdr, reads = bamio.read_bam(os.path.join(G, f"leak_small.{smp}.bam"))
+        out = str(tmp_path / f"leak.{smp}.bam")
+        bam_writer.write_bam(out, [("chr22", 4000)], reads, sample=smp.upper(), index=True, block=9000)
+        lp.append(out)
+    lp.append(os.path.join(G, "leak_small.fa"))
+    o2 = host.default_opts(active_region=0)
+    tile_reg = lambda H: H.tile("chr22:1000-3000", o2)
+    monkeypatch.setenv("LANCET_HOST_LAZY", "0")
+    h1, e1, k1 = all_batches(lp, tile_reg, 10 ** 6, o2)
+    counts = [int(e1[0].read_begin[i + 1] - e1[0].read_begin[i]) for i in range(e1[0].n_windows)]
+    assert 631 in counts                                     # (chr22:1850-2450 with the reads three read-less windows left behind)
+    monkeypatch.setenv("LANCET_HOST_LAZY", "1")
+    for step in (1, 2, 3):
+        h2, l2, k2 = all_batches(lp, tile_reg, step, o2)
+        assert h2 == h1 and k2 == k1
+        _batches_equal(e1[0], workload.concat_batches(l2))
