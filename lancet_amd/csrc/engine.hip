@@ -617,7 +617,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     // Two 512-lane workgroups fit a CU.  The grid stays one CU's worth short of the device (the service's workgroups, which work the same
     // queue first, counted in): the runtime carries out small copies, and copies to or from pageable memory, with copy KERNELS, and with
     // two engines taking turns on one GPU the read-back and the upload of one batch otherwise waited until the other batch's build kernel
-    // -- which holds the registers and the LDS of every CU -- had left (38 ms per step; value_e2e 0.7 of value, now 0.95).
+    // -- which holds the registers and the LDS of every CU -- had left (38 ms per step; value_e2e 0.7 of value, now 0.9).
     const bool svc_helps = e->svc && e->n_svc_wgs > 0 && !e->debug_stop && e->svc_help;
     e->n_bslots = std::max(1, std::min(nw, cus * 2 - 2 - (svc_helps ? std::min(e->n_svc_wgs, cus) : 0)));
     if (e->build_slots_env) e->n_bslots = std::min(nw, e->build_slots_env);
