@@ -152,6 +152,27 @@ const char *lancet_engine_last_error(const lancet_engine *e);
  * batch is device-resident and the caller's buffers are no longer referenced. */
 int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b);
 
+/* The same with the reads already trimmed and packed by the caller -- what lancet_engine_upload does itself, on host threads, from the
+ * ASCII arrays (Graph_t::trim, reference src/Graph.cc:355-384, then 2 bit per base and one bit per base for `quality >= MIN_QUAL_CALL`):
+ * 3 bits per base handed over instead of 16, and no second pass over the reads for a caller that assembles its batch from alignments anyway
+ * (lancet_host_batch_packed does).  `b` as for lancet_engine_upload, but seq / qual / label / strand / mate / mapped are not looked at
+ * (seq_off still gives the UNTRIMMED length of every read).  Read r owns (len + 15) / 16 words of `bases` from base_woff[r] and
+ * (len + 31) / 32 words of `good` from good_woff[r], len its untrimmed length; both offset arrays have n_reads + 1 entries, `bases` has
+ * 4 readable words past the last read's, `good` one.  Every read must have been packed by lancet_pack_read with the parameters this
+ * engine was created with (the trim and the mask depend on min_qual_trim / min_qual_call). */
+typedef struct lancet_packed_reads {
+  const uint32_t *rinfo;       /* [n_reads] trimmed length and the read's flags, as lancet_pack_read leaves them */
+  const uint32_t *base_woff;   /* [n_reads + 1] */
+  const uint32_t *good_woff;   /* [n_reads + 1] */
+  const uint32_t *bases;       /* 2 bit per base of the trimmed read, first base in the low bits */
+  const uint32_t *good;        /* 1 bit per base of the trimmed read */
+} lancet_packed_reads;
+int lancet_engine_upload_packed(lancet_engine *e, const lancet_window_batch *b, const lancet_packed_reads *p);
+/* One read, trimmed and packed: rinfo[0], (len + 15) / 16 words of bases and (len + 31) / 32 words of good are written (zero past the
+ * trimmed length).  label / strand / mate / mapped as in lancet_window_batch. */
+void lancet_pack_read(const lancet_params *P, const char *seq, const char *qual, int len, uint8_t label, uint8_t strand, uint8_t mate, uint8_t mapped,
+                      uint32_t *rinfo, uint32_t *bases, uint32_t *good);
+
 /* Runs the whole hot path (self-tuning k loop included) for every uploaded window.  Blocking. */
 int lancet_engine_run(lancet_engine *e);
 

@@ -86,6 +86,11 @@ int lancet_host_window_span(const lancet_host *h, int w, int32_t *start, int32_t
  * arrays owned by h; kept[i] = tiled index of batch window i (kept has room for w_end - w_begin entries). */
 int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o, lancet_window_batch *out,
                       int32_t *kept, int32_t *n_kept);
+/* The same batch with the reads trimmed and packed on the host threads that assemble it (lancet_pack_read's routine, with the engine's
+ * parameters `P`), for lancet_engine_upload_packed: out->seq / out->qual are NULL, `pk` receives the packed arrays (owned by the host
+ * object like the batch's, valid until the next batch call). */
+int lancet_host_batch_packed(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o, const lancet_params *P, lancet_window_batch *out,
+                             lancet_packed_reads *pk, int32_t *kept, int32_t *n_kept);
 /* barcode strings of the last batch by bx_rank (linked reads) */
 const char *const *lancet_host_bx_names(const lancet_host *h, uint32_t *n);
 

@@ -38,6 +38,12 @@ class LancetWindowBatch(C.Structure):
     ]
 
 
+class LancetPackedReads(C.Structure):
+    """include/lancet_engine.h lancet_packed_reads: the reads of a batch trimmed and packed by the caller."""
+    _fields_ = [("rinfo", C.POINTER(C.c_uint32)), ("base_woff", C.POINTER(C.c_uint32)), ("good_woff", C.POINTER(C.c_uint32)),
+                ("bases", C.POINTER(C.c_uint32)), ("good", C.POINTER(C.c_uint32))]
+
+
 class LancetVariantLR(C.Structure):
     _fields_ = [("hp", C.c_uint16 * 12), ("bx_off", C.c_uint32 * 4), ("bx_len", C.c_uint32 * 4), ("reserved", C.c_uint32 * 2)]
 

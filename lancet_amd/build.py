@@ -10,7 +10,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "liblancet_engine.so")
 SOURCES = ["engine.hip", "window_fat.hip", "host_vdb.cc", "host_frontend.cc", "host_trace.cc", "lancet_main.cc"]
 BIN = os.path.join(os.path.dirname(CSRC), "bin", "lancet_gpu")
-HEADERS = ["kernels.h", "build_lds.h", "build_lds_impl.h", "wave.h", "layout.h", "host_common.h", os.path.join("..", "..", "include", "lancet_engine.h"),
+HEADERS = ["kernels.h", "build_lds.h", "build_lds_impl.h", "wave.h", "layout.h", "host_common.h", "host_pack.h", os.path.join("..", "..", "include", "lancet_engine.h"),
            os.path.join("..", "..", "include", "lancet_host.h")]
 
 

@@ -255,38 +255,7 @@ static hipError_t lc_copy(lancet_engine *e, void *dst, const void *src, size_t b
   return hipStreamSynchronize(e->stream);
 }
 
-// Graph_t::trim (reference src/Graph.cc:355-384) + 2-bit packing + quality mask on the host: the scalar twin of prep_kernel, one read
-struct LcCodeTab { uint8_t c[256]; LcCodeTab() { for (int i = 0; i < 256; ++i) c[i] = 4; c['A'] = c['a'] = 0; c['C'] = c['c'] = 1; c['G'] = c['g'] = 2; c['T'] = c['t'] = 3; } };
-static const LcCodeTab lc_tab;
-static inline uint32_t lc_code(char b) { return lc_tab.c[(uint8_t)b]; }
-static void lc_prep_read_host(const lancet_params &P, const char *sq, const char *ql, int len, uint8_t label, uint8_t strand, uint8_t mate, uint8_t mapped,
-                              uint32_t *rinfo, uint32_t *bases, uint32_t *good) {
-  const uint8_t *tab = lc_tab.c;
-  const int qtrim = P.min_qual_trim, qcall = P.min_qual_call;
-  int fg = 0; while (fg < len && !(tab[(uint8_t)sq[fg]] < 4 && !(ql[fg] < qtrim))) ++fg;
-  int lg = len - 1; while (lg >= fg && !(tab[(uint8_t)sq[lg]] < 4 && !(ql[lg] < qtrim))) --lg;
-  bool junk = fg >= len || lg < fg;
-  if (!junk) { uint32_t any = 0; for (int p = fg; p <= lg; ++p) any |= tab[(uint8_t)sq[p]]; junk = (any & 4u) != 0; }
-  const int trim5 = junk ? 0 : fg;
-  int tlen = junk ? 0 : lg - fg + 1;
-  if (tlen > 0xFFFF) tlen = 0xFFFF;
-  *rinfo = (uint32_t)tlen | ((label == LANCET_NML ? 1u : 0u) << 16) | ((strand == LANCET_REV ? 1u : 0u) << 17) | ((uint32_t)(mate & 3) << 18) | ((mapped ? 1u : 0u) << 20);
-  const uint8_t *s = (const uint8_t *)sq + trim5; const char *q = ql + trim5;
-  const int nfull = tlen / 16;
-  for (int wv = 0; wv < nfull; ++wv) {
-    const uint8_t *x = s + wv * 16; uint32_t v = 0;
-    for (int j = 0; j < 16; ++j) v |= (uint32_t)(tab[x[j]] & 3u) << (2 * j);
-    bases[wv] = v;
-  }
-  if (tlen & 15) { uint32_t v = 0; for (int j = 0; j < (tlen & 15); ++j) v |= (uint32_t)(tab[s[nfull * 16 + j]] & 3u) << (2 * j); bases[nfull] = v; }
-  const int gfull = tlen / 32;
-  for (int wv = 0; wv < gfull; ++wv) {
-    const char *x = q + wv * 32; uint32_t v = 0;
-    for (int j = 0; j < 32; ++j) v |= (uint32_t)(x[j] >= qcall) << j;
-    good[wv] = v;
-  }
-  if (tlen & 31) { uint32_t v = 0; for (int j = 0; j < (tlen & 31); ++j) v |= (uint32_t)(q[gfull * 32 + j] >= qcall) << j; good[gfull] = v; }
-}
+#include "host_pack.h"      // lc_prep_read_host: Graph_t::trim + 2-bit packing + quality mask of one read on the host (the scalar twin of prep_kernel)
 template <class F> static void lc_parallel(int threads, size_t n, F body) {       // body(lo, hi, t) over a static split of [0, n)
   if (threads <= 1 || n < 4096) { body((size_t)0, n, 0); return; }
   std::vector<std::thread> th;
@@ -401,7 +370,23 @@ static int up(lancet_engine *e, DevBuf &b, const void *src, size_t bytes) {
 #define UP(buf, src, bytes) do { DBG(#buf); int _rc = up(e, buf, src, bytes); if (_rc) return _rc; } while (0)
 #define ENS(buf, bytes) do { if ((buf).ensure((bytes) ? (bytes) : 1)) { e->err = "hipMalloc failed"; return LANCET_E_OOM; } } while (0)
 
-int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
+static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lancet_packed_reads *pk);
+int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) { return lc_upload(e, b, nullptr); }
+// The reads arrive trimmed and packed (lancet_pack_read with THIS engine's parameters: the caller's threads did what the upload's own do
+// from the ASCII arrays); b->seq / qual / label / strand / mate / mapped are not looked at, b->seq_off still gives the untrimmed lengths.
+int lancet_engine_upload_packed(lancet_engine *e, const lancet_window_batch *b, const lancet_packed_reads *pk) {
+  if (!e || !pk || !pk->rinfo || !pk->base_woff || !pk->good_woff || !pk->bases || !pk->good) { if (e) e->err = "packed reads missing"; return LANCET_E_ARG; }
+  if (!e->host_prep) { e->err = "packed upload with LANCET_PREP=device"; return LANCET_E_STATE; }
+  return lc_upload(e, b, pk);
+}
+void lancet_pack_read(const lancet_params *P, const char *seq, const char *qual, int len, uint8_t label, uint8_t strand, uint8_t mate, uint8_t mapped,
+                      uint32_t *rinfo, uint32_t *bases, uint32_t *good) {
+  lc_prep_read_host(*P, seq, qual, len, label, strand, mate, mapped, rinfo, bases, good);
+  const uint32_t tl = RI_TLEN(*rinfo);
+  for (uint32_t wv = (tl + 15) / 16; wv < ((uint32_t)len + 15) / 16; ++wv) bases[wv] = 0;
+  for (uint32_t wv = (tl + 31) / 32; wv < ((uint32_t)len + 31) / 32; ++wv) good[wv] = 0;
+}
+static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lancet_packed_reads *pk) {
   if (!e || !b || b->n_windows < 0) return LANCET_E_ARG;
   if (e->submitted) { e->err = "upload while a batch is in flight"; return LANCET_E_STATE; }
   HIPCHK(e, hipSetDevice(e->device));
@@ -449,6 +434,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
       tb[(size_t)t + 1] += tb[(size_t)t]; tg[(size_t)t + 1] += tg[(size_t)t];
     }
     const uint64_t bo_all = tb[(size_t)T], go_all = tg[(size_t)T];
+    if (pk && ((uint64_t)pk->base_woff[R] != bo_all || (uint64_t)pk->good_woff[R] != go_all)) { e->err = "packed reads: word offsets do not match the read lengths"; return LANCET_E_ARG; }
     if (bo_all + 4 > 0xFFFFFFFFull) { e->err = "batch too large"; return LANCET_E_ARG; }
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
@@ -473,6 +459,17 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
     const lancet_params P = e->params;
     lc_parallel(T, (size_t)R, [&](size_t lo, size_t hi, int t) {
       uint64_t bo = tb[(size_t)t], go = tg[(size_t)t];
+      if (pk) {                                               // packed by the caller: copied as they are (the offsets were checked above in total, here per read)
+        for (size_t r = lo; r < hi; ++r) {
+          const uint32_t len = b->seq_off[r + 1] - b->seq_off[r];
+          if (pk->base_woff[r] != (uint32_t)bo || pk->good_woff[r] != (uint32_t)go || RI_TLEN(pk->rinfo[r]) > len) { bad[(size_t)t] = 3; return; }
+          h_bw[r] = (uint32_t)bo; h_gw[r] = (uint32_t)go; h_nm[r] = b->name_rank[r]; h_ri[r] = pk->rinfo[r];
+          bo += (len + 15) / 16; go += (len + 31) / 32;
+        }
+        const uint64_t b0 = tb[(size_t)t], g0 = tg[(size_t)t];
+        memcpy(h_ba + b0, pk->bases + b0, 4 * (size_t)(bo - b0)); memcpy(h_go + g0, pk->good + g0, 4 * (size_t)(go - g0));
+        return;
+      }
       for (size_t r = lo; r < hi; ++r) {
         const uint32_t o = b->seq_off[r], len = b->seq_off[r + 1] - o;
         h_bw[r] = (uint32_t)bo; h_gw[r] = (uint32_t)go; h_nm[r] = b->name_rank[r];
@@ -484,6 +481,7 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) {
         bo += (len + 15) / 16; go += (len + 31) / 32;
       }
     });
+    for (int t = 0; t < T; ++t) if (bad[(size_t)t] == 3) { e->err = "packed reads: word offsets / trimmed lengths do not match the read lengths"; return LANCET_E_ARG; }
     h_ri[R] = 0; h_bw[R] = (uint32_t)bo_all; h_gw[R] = (uint32_t)go_all;
     for (int i = 0; i < 4; ++i) h_ba[bo_all + (uint64_t)i] = 0;
     h_go[go_all] = 0;

@@ -15,6 +15,7 @@
 #include <cctype>
 #include <chrono>
 #include <sys/stat.h>
+#include "host_pack.h"
 #include <functional>
 #include <cmath>
 #include <cstdio>
@@ -665,7 +666,8 @@ struct lancet_host {
     ~RawBuf() { free(p); }
     void need(size_t n) { if (n > cap) { free(p); cap = n + n / 8 + 4096; p = (char *)malloc(cap); } }
     char *data() { return p; }
-  } b_seq, b_qual;
+  } b_seq, b_qual, b_pbases, b_pgood;      // ASCII bases / qualities, or (lancet_host_batch_packed) their packed form
+  std::vector<uint32_t> b_rinfo, b_bw, b_gw;
   std::vector<uint8_t> b_label, b_strand, b_mate, b_mapped, b_hp;
   std::vector<std::string> bx_names;
   std::vector<const char *> bx_ptrs;
@@ -1052,8 +1054,19 @@ int lancet_host_tile_regions(lancet_host *h, const char *bed_path, const char *c
   return finish_tiling(h, want);
 }
 
+static int host_batch_impl(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o, lancet_window_batch *out,
+                           int32_t *kept, int32_t *n_kept, const lancet_params *P, lancet_packed_reads *pk);
 int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o, lancet_window_batch *out,
-                      int32_t *kept, int32_t *n_kept) {
+                      int32_t *kept, int32_t *n_kept) { return host_batch_impl(h, w_begin, w_end, o, out, kept, n_kept, nullptr, nullptr); }
+// The same batch with the reads trimmed and packed for lancet_engine_upload_packed (host_pack.h: the engine's own routine) instead of
+// copied as ASCII: out->seq / qual are NULL, `pk` points at the packed arrays (owned by the host object like the batch's).
+int lancet_host_batch_packed(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o, const lancet_params *P, lancet_window_batch *out,
+                             lancet_packed_reads *pk, int32_t *kept, int32_t *n_kept) {
+  if (!P || !pk) { if (h) h->err = "lancet_host_batch_packed: parameters and packed-reads struct are required"; return LANCET_E_ARG; }
+  return host_batch_impl(h, w_begin, w_end, o, out, kept, n_kept, P, pk);
+}
+static int host_batch_impl(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o, lancet_window_batch *out,
+                           int32_t *kept, int32_t *n_kept, const lancet_params *P, lancet_packed_reads *pk) {
   if (!h || !o || !out || w_begin < 0 || w_end < w_begin || (size_t)w_end > h->windows.size()) { if (h) h->err = "bad window range"; return LANCET_E_ARG; }
   const int nwin = w_end - w_begin;
   const bool timing = getenv("LANCET_HOST_TIMING") != nullptr;
@@ -1062,7 +1075,7 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
   const double t0 = now();
   std::vector<std::vector<Sel>> selT((size_t)nwin), selN((size_t)nwin);
   std::vector<uint8_t> keep((size_t)nwin, 0), wmapped((size_t)nwin, 0);
-  std::vector<uint64_t> wbases((size_t)nwin, 0);
+  std::vector<uint64_t> wbases((size_t)nwin, 0), wbw((size_t)nwin, 0), wgw((size_t)nwin, 0);      // bases; 16-base / 32-base words of the packed form
   {   // per-window filters and read selection: independent windows, one chunk of windows per host thread at a time
     std::atomic<int> next(0);
     auto work = [&]() {
@@ -1076,10 +1089,10 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
         const bool okT = extract_reads(h->smp[1], win, false, *o, h->readgroups, &selT[(size_t)i]);
         const bool okN = extract_reads(h->smp[0], win, true, *o, h->readgroups, &selN[(size_t)i]);      // (both samples are read before the skip test, :833-836)
         keep[(size_t)i] = (okT && okN) ? 1 : 2;                                        // 2: skipped for coverage -> g.clear(true)
-        uint64_t nb = 0; uint8_t mp = 0;
-        for (const Sel &s : selT[(size_t)i]) { nb += h->smp[1].reads[s.idx].l_seq; mp |= s.mapped; }
-        for (const Sel &s : selN[(size_t)i]) { nb += h->smp[0].reads[s.idx].l_seq; mp |= s.mapped; }
-        wbases[(size_t)i] = nb; wmapped[(size_t)i] = mp;
+        uint64_t nb = 0, bw = 0, gw = 0; uint8_t mp = 0;
+        for (const Sel &s : selT[(size_t)i]) { const uint32_t l = h->smp[1].reads[s.idx].l_seq; nb += l; bw += (l + 15) / 16; gw += (l + 31) / 32; mp |= s.mapped; }
+        for (const Sel &s : selN[(size_t)i]) { const uint32_t l = h->smp[0].reads[s.idx].l_seq; nb += l; bw += (l + 15) / 16; gw += (l + 31) / 32; mp |= s.mapped; }
+        wbases[(size_t)i] = nb; wbw[(size_t)i] = bw; wgw[(size_t)i] = gw; wmapped[(size_t)i] = mp;
       }
     };
     unsigned nt = host_threads(nwin);
@@ -1107,22 +1120,30 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
   const int nk = (int)kw.size();
   h->b_chr.assign((size_t)nk, 0); h->b_refstart.resize((size_t)nk);
   h->b_refoff.assign((size_t)nk + 1, 0); h->b_readbegin.assign((size_t)nk + 1, 0);
-  std::vector<uint64_t> base0((size_t)nk + 1, 0);
+  std::vector<uint64_t> base0((size_t)nk + 1, 0), bw0((size_t)nk + 1, 0), gw0((size_t)nk + 1, 0);
   for (int k = 0; k < nk; ++k) {
     const int i = kw[(size_t)k];
     const Window &win = h->windows[(size_t)(w_begin + i)];
     if (kept) kept[k] = w_begin + i;
-    uint64_t nb = wbases[(size_t)i];
-    for (const RSel &r : pre[(size_t)k]) nb += h->smp[r.smp].reads[r.s.idx].l_seq;       // (smp 2 / 3: the store of left-over reads)
-    base0[(size_t)k + 1] = base0[(size_t)k] + nb;
+    uint64_t nb = wbases[(size_t)i], bw = wbw[(size_t)i], gw = wgw[(size_t)i];
+    for (const RSel &r : pre[(size_t)k]) { const uint32_t l = h->smp[r.smp].reads[r.s.idx].l_seq; nb += l; bw += (l + 15) / 16; gw += (l + 31) / 32; }   // (smp 2 / 3: the store of left-over reads)
+    base0[(size_t)k + 1] = base0[(size_t)k] + nb; bw0[(size_t)k + 1] = bw0[(size_t)k] + bw; gw0[(size_t)k + 1] = gw0[(size_t)k] + gw;
     h->b_readbegin[(size_t)k + 1] = h->b_readbegin[(size_t)k] + (uint32_t)(pre[(size_t)k].size() + selT[(size_t)i].size() + selN[(size_t)i].size());
     h->b_refoff[(size_t)k + 1] = h->b_refoff[(size_t)k] + (uint32_t)win.seq.size();
   }
   if (base0[(size_t)nk] > 0xFFFFFFFFull) { h->err = "batch holds more than 4 Gi bases: use fewer windows per batch"; return LANCET_E_ARG; }
   const size_t R = h->b_readbegin[(size_t)nk], NB = (size_t)base0[(size_t)nk];
   h->b_ref.resize(h->b_refoff[(size_t)nk]);
+  const bool packed = P != nullptr;
+  if (packed) {
+    if (bw0[(size_t)nk] + 4 > 0xFFFFFFFFull) { h->err = "batch too large"; return LANCET_E_ARG; }
+    h->b_pbases.need(4 * ((size_t)bw0[(size_t)nk] + 4)); h->b_pgood.need(4 * ((size_t)gw0[(size_t)nk] + 1));
+    if (!h->b_pbases.p || !h->b_pgood.p) { h->err = "out of memory for the batch"; return LANCET_E_ARG; }
+    h->b_rinfo.resize(R + 1); h->b_bw.resize(R + 1); h->b_gw.resize(R + 1);
+  } else {
   h->b_seq.need(NB + 1); h->b_qual.need(NB + 1);
   if (!h->b_seq.p || !h->b_qual.p) { h->err = "out of memory for the batch"; return LANCET_E_ARG; }
+  }
   h->b_seqoff.resize(R + 1); h->b_seqoff[0] = 0;
   h->b_label.resize(R); h->b_strand.resize(R); h->b_mate.resize(R); h->b_mapped.resize(R); h->b_namerank.resize(R);
   h->b_hp.resize(o->linked ? R : 0);
@@ -1140,15 +1161,24 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
         h->b_refstart[(size_t)k] = win.start; h->b_chr[(size_t)k] = win.chr;
         memcpy(&h->b_ref[h->b_refoff[(size_t)k]], win.seq.data(), win.seq.size());
         size_t r = h->b_readbegin[(size_t)k]; const size_t r0 = r; size_t bo = (size_t)base0[(size_t)k];
+        size_t pbo = (size_t)bw0[(size_t)k], pgo = (size_t)gw0[(size_t)k];
         names.clear();
         {
           auto one = [&](int smp, const Sel &s) {
             const Sample &S = h->smp[smp];
             const Read &rd = S.reads[s.idx];
-            memcpy(h->b_seq.p + bo, S.seq.data() + rd.seq_off, rd.l_seq); memcpy(h->b_qual.p + bo, S.qual.data() + rd.seq_off, rd.l_seq);
+            h->b_label[r] = (smp & 1) ? LANCET_TMR : LANCET_NML; h->b_strand[r] = s.strand; h->b_mate[r] = s.mate; h->b_mapped[r] = s.mapped;
+            if (packed) {
+              uint32_t *pb = (uint32_t *)h->b_pbases.p + pbo, *pg = (uint32_t *)h->b_pgood.p + pgo;
+              h->b_bw[r] = (uint32_t)pbo; h->b_gw[r] = (uint32_t)pgo;
+              lc_prep_read_host(*P, S.seq.data() + rd.seq_off, S.qual.data() + rd.seq_off, (int)rd.l_seq, h->b_label[r], s.strand, s.mate, s.mapped, &h->b_rinfo[r], pb, pg);
+              const uint32_t tl = h->b_rinfo[r] & 0xFFFFu, nbw = (rd.l_seq + 15) / 16, ngw = (rd.l_seq + 31) / 32;
+              for (uint32_t wv = (tl + 15) / 16; wv < nbw; ++wv) pb[wv] = 0;
+              for (uint32_t wv = (tl + 31) / 32; wv < ngw; ++wv) pg[wv] = 0;
+              pbo += nbw; pgo += ngw;
+            } else { memcpy(h->b_seq.p + bo, S.seq.data() + rd.seq_off, rd.l_seq); memcpy(h->b_qual.p + bo, S.qual.data() + rd.seq_off, rd.l_seq); }
             bo += rd.l_seq;
             h->b_seqoff[r + 1] = (uint32_t)bo;
-            h->b_label[r] = (smp & 1) ? LANCET_TMR : LANCET_NML; h->b_strand[r] = s.strand; h->b_mate[r] = s.mate; h->b_mapped[r] = s.mapped;
             names.push_back(S.text.c_str() + rd.name_off);
             if (o->linked) { bx_of[r] = S.text.c_str() + rd.bx_off; h->b_hp[r] = (uint8_t)(rd.hp > 255 ? 255 : rd.hp); }
             ++r;
@@ -1192,7 +1222,14 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
   memset(out, 0, sizeof *out);
   out->n_windows = nk;
   out->chr_id = h->b_chr.data(); out->ref_start = h->b_refstart.data(); out->ref_off = h->b_refoff.data(); out->ref_bases = h->b_ref.data();
-  out->read_begin = h->b_readbegin.data(); out->seq_off = h->b_seqoff.data(); out->seq = h->b_seq.data(); out->qual = h->b_qual.data();
+  out->read_begin = h->b_readbegin.data(); out->seq_off = h->b_seqoff.data(); out->seq = packed ? nullptr : h->b_seq.data(); out->qual = packed ? nullptr : h->b_qual.data();
+  if (packed) {
+    uint32_t *pb = (uint32_t *)h->b_pbases.p, *pg = (uint32_t *)h->b_pgood.p;
+    for (int q = 0; q < 4; ++q) pb[bw0[(size_t)nk] + (uint64_t)q] = 0;
+    pg[gw0[(size_t)nk]] = 0;
+    h->b_rinfo[R] = 0; h->b_bw[R] = (uint32_t)bw0[(size_t)nk]; h->b_gw[R] = (uint32_t)gw0[(size_t)nk];
+    pk->rinfo = h->b_rinfo.data(); pk->base_woff = h->b_bw.data(); pk->good_woff = h->b_gw.data(); pk->bases = pb; pk->good = pg;
+  }
   out->label = h->b_label.data(); out->strand = h->b_strand.data(); out->mate = h->b_mate.data(); out->mapped = h->b_mapped.data();
   out->name_rank = h->b_namerank.data();
   out->bx_rank = o->linked ? h->b_bxrank.data() : nullptr; out->hp = o->linked ? h->b_hp.data() : nullptr;

@@ -1,0 +1,39 @@
+// host_pack.h -- one read of a batch, trimmed and packed on the host: what the engine keeps of it in HBM.
+// Shared by lancet_engine_upload (engine.hip: packs the caller's ASCII arrays on host threads), lancet_pack_read (the same routine for
+// a caller that packs itself) and lancet_host_batch_packed (host_frontend.cc: packs while it assembles the batch).  Host code only.
+#pragma once
+#include <stdint.h>
+#include "../../include/lancet_engine.h"
+
+// Graph_t::trim (reference src/Graph.cc:355-384) + 2-bit packing + quality mask on the host: the scalar twin of prep_kernel, one read
+struct LcCodeTab { uint8_t c[256]; LcCodeTab() { for (int i = 0; i < 256; ++i) c[i] = 4; c['A'] = c['a'] = 0; c['C'] = c['c'] = 1; c['G'] = c['g'] = 2; c['T'] = c['t'] = 3; } };
+static const LcCodeTab lc_tab;
+static inline uint32_t lc_code(char b) { return lc_tab.c[(uint8_t)b]; }
+static inline void lc_prep_read_host(const lancet_params &P, const char *sq, const char *ql, int len, uint8_t label, uint8_t strand, uint8_t mate, uint8_t mapped,
+                              uint32_t *rinfo, uint32_t *bases, uint32_t *good) {
+  const uint8_t *tab = lc_tab.c;
+  const int qtrim = P.min_qual_trim, qcall = P.min_qual_call;
+  int fg = 0; while (fg < len && !(tab[(uint8_t)sq[fg]] < 4 && !(ql[fg] < qtrim))) ++fg;
+  int lg = len - 1; while (lg >= fg && !(tab[(uint8_t)sq[lg]] < 4 && !(ql[lg] < qtrim))) --lg;
+  bool junk = fg >= len || lg < fg;
+  if (!junk) { uint32_t any = 0; for (int p = fg; p <= lg; ++p) any |= tab[(uint8_t)sq[p]]; junk = (any & 4u) != 0; }
+  const int trim5 = junk ? 0 : fg;
+  int tlen = junk ? 0 : lg - fg + 1;
+  if (tlen > 0xFFFF) tlen = 0xFFFF;
+  *rinfo = (uint32_t)tlen | ((label == LANCET_NML ? 1u : 0u) << 16) | ((strand == LANCET_REV ? 1u : 0u) << 17) | ((uint32_t)(mate & 3) << 18) | ((mapped ? 1u : 0u) << 20);
+  const uint8_t *s = (const uint8_t *)sq + trim5; const char *q = ql + trim5;
+  const int nfull = tlen / 16;
+  for (int wv = 0; wv < nfull; ++wv) {
+    const uint8_t *x = s + wv * 16; uint32_t v = 0;
+    for (int j = 0; j < 16; ++j) v |= (uint32_t)(tab[x[j]] & 3u) << (2 * j);
+    bases[wv] = v;
+  }
+  if (tlen & 15) { uint32_t v = 0; for (int j = 0; j < (tlen & 15); ++j) v |= (uint32_t)(tab[s[nfull * 16 + j]] & 3u) << (2 * j); bases[nfull] = v; }
+  const int gfull = tlen / 32;
+  for (int wv = 0; wv < gfull; ++wv) {
+    const char *x = q + wv * 32; uint32_t v = 0;
+    for (int j = 0; j < 32; ++j) v |= (uint32_t)(x[j] >= qcall) << j;
+    good[wv] = v;
+  }
+  if (tlen & 31) { uint32_t v = 0; for (int j = 0; j < (tlen & 31); ++j) v |= (uint32_t)(q[gfull * 32 + j] >= qcall) << j; good[gfull] = v; }
+}

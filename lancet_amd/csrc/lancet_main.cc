@@ -207,17 +207,22 @@ int main(int argc, char **argv) {
     t_vdb += now() - t0;
     return true;
   };
+  // The host threads that assemble a batch also trim and pack its reads (lancet_host_batch_packed -> lancet_engine_upload_packed: 3 bits per
+  // base handed over, one pass over the reads instead of two); LANCET_GPU_ASCII=1, or trim + pack on the device (LANCET_PREP=device), keep
+  // the ASCII hand-over.
+  const bool packed = getenv("LANCET_GPU_ASCII") == nullptr && !(getenv("LANCET_PREP") && strcmp(getenv("LANCET_PREP"), "device") == 0);
   for (int c = 0; c < nchunks; ++c) {
     const int lo = c * step, hi = lo + step < nwin ? lo + step : nwin;
     Slot &sl = slots[(size_t)c % slots.size()];
-    lancet_window_batch B; int32_t nk = 0;
+    lancet_window_batch B; lancet_packed_reads PK; int32_t nk = 0;
     double t0 = now();
     if (sl.fut.valid() && !finish(sl)) return die(fail);          // its kept[] / engine must be free before they are reused
-    if (lancet_host_batch(H, lo, hi, &ho, &B, sl.kept.data(), &nk) != LANCET_OK) return die(lancet_host_last_error(H));   // (overlaps the other engines' kernels)
+    if ((packed ? lancet_host_batch_packed(H, lo, hi, &ho, &P, &B, &PK, sl.kept.data(), &nk) : lancet_host_batch(H, lo, hi, &ho, &B, sl.kept.data(), &nk)) != LANCET_OK)
+      return die(lancet_host_last_error(H));                      // (overlaps the other engines' kernels)
     t_batch += now() - t0;
     if (nk == 0) { jobs[(size_t)c].have = true; if (!flush()) return die(fail); continue; }
     t0 = now();
-    if (lancet_engine_upload(sl.e, &B) != LANCET_OK) return die(std::string("engine: ") + lancet_engine_last_error(sl.e));
+    if ((packed ? lancet_engine_upload_packed(sl.e, &B, &PK) : lancet_engine_upload(sl.e, &B)) != LANCET_OK) return die(std::string("engine: ") + lancet_engine_last_error(sl.e));
     t_engine += now() - t0;
     sl.chunk = c; sl.nk = nk; sl.base = done; done += nk; sl.bxn.clear();
     if (ho.linked) { uint32_t nbx = 0; const char *const *bxn = lancet_host_bx_names(H, &nbx); for (uint32_t i = 0; i < nbx; ++i) sl.bxn.emplace_back(bxn[i]); }

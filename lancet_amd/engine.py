@@ -99,6 +99,18 @@ class Engine:
         cb = abi.batch_to_c(batch)
         self._chk(self.L.lancet_engine_upload(self.h, C.byref(cb)))
 
+    def upload_packed(self, batch, packed) -> None:
+        """lancet_engine_upload_packed: `batch` without bases / qualities (host.NativeHost.batch(..., pack_params=...)), `packed` the dict of
+        arrays that call returned (packed with THIS engine's parameters)."""
+        self._batch = batch
+        cb = abi.batch_to_c(batch)
+        keep = {k: np.ascontiguousarray(packed[k], dtype=np.uint32) for k in ("rinfo", "base_woff", "good_woff", "bases", "good")}
+        pk = abi.LancetPackedReads(*[keep[k].ctypes.data_as(C.POINTER(C.c_uint32)) for k in ("rinfo", "base_woff", "good_woff", "bases", "good")])
+        self._packed_keep = keep
+        self.L.lancet_engine_upload_packed.restype = C.c_int
+        self.L.lancet_engine_upload_packed.argtypes = [C.c_void_p, C.POINTER(abi.LancetWindowBatch), C.POINTER(abi.LancetPackedReads)]
+        self._chk(self.L.lancet_engine_upload_packed(self.h, C.byref(cb), C.byref(pk)))
+
     def run(self) -> None:
         self._chk(self.L.lancet_engine_run(self.h))
 

@@ -48,6 +48,9 @@ def _lib():
         L.lancet_host_window_hdr.argtypes = [C.c_void_p, C.c_int]
         L.lancet_host_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(LancetHostOpts), C.POINTER(abi.LancetWindowBatch),
                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.lancet_host_batch_packed.restype = C.c_int
+        L.lancet_host_batch_packed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(LancetHostOpts), C.POINTER(abi.LancetParams), C.POINTER(abi.LancetWindowBatch),
+                                               C.POINTER(abi.LancetPackedReads), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.lancet_host_bx_names.restype = C.POINTER(C.c_char_p)
         L.lancet_host_bx_names.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         _BOUND = True
@@ -111,12 +114,18 @@ class NativeHost:
     def first_has_md(self, tumor: bool) -> bool:
         return bool(self.L.lancet_host_first_has_md(self.h, 1 if tumor else 0))
 
-    def batch(self, w_begin: int, w_end: int, opts: LancetHostOpts) -> Tuple[frontend.WindowBatch, List[int]]:
-        """Windows [w_begin, w_end) of the tiling -> (batch, tiled indices of the windows kept).  Arrays are copied out."""
+    def batch(self, w_begin: int, w_end: int, opts: LancetHostOpts, pack_params=None):
+        """Windows [w_begin, w_end) of the tiling -> (batch, tiled indices of the windows kept).  Arrays are copied out.
+        pack_params (abi.LancetParams): lancet_host_batch_packed -- the batch comes without seq / qual (empty arrays) and a third value is
+        returned, the packed reads as a dict of arrays (rinfo, base_woff, good_woff, bases, good) for Engine.upload_packed."""
         cb = abi.LancetWindowBatch()
         kept = (C.c_int32 * max(1, w_end - w_begin))()
         nk = C.c_int32()
-        rc = self.L.lancet_host_batch(self.h, w_begin, w_end, C.byref(opts), C.byref(cb), kept, C.byref(nk))
+        pk = abi.LancetPackedReads()
+        if pack_params is not None:
+            rc = self.L.lancet_host_batch_packed(self.h, w_begin, w_end, C.byref(opts), C.byref(pack_params), C.byref(cb), C.byref(pk), kept, C.byref(nk))
+        else:
+            rc = self.L.lancet_host_batch(self.h, w_begin, w_end, C.byref(opts), C.byref(cb), kept, C.byref(nk))
         if rc != 0:
             raise engine.EngineError(self.L.lancet_host_last_error(self.h).decode())
         n = cb.n_windows
@@ -142,7 +151,12 @@ class NativeHost:
         b = frontend.WindowBatch(
             n_windows=n, hdr=hdr, chrom=chrom, chr_id=arr(cb.chr_id, n, np.int32), ref_start=arr(cb.ref_start, n, np.int32),
             ref_off=ref_off, ref_bases=arr(cb.ref_bases, int(ref_off[-1]), np.uint8), read_begin=read_begin, seq_off=seq_off,
-            seq=arr(cb.seq, nb, np.uint8), qual=arr(cb.qual, nb, np.uint8), label=arr(cb.label, R, np.uint8),
+            seq=arr(cb.seq, 0 if pack_params is not None else nb, np.uint8), qual=arr(cb.qual, 0 if pack_params is not None else nb, np.uint8), label=arr(cb.label, R, np.uint8),
             strand=arr(cb.strand, R, np.uint8), mate=arr(cb.mate, R, np.uint8), mapped=arr(cb.mapped, R, np.uint8),
             name_rank=arr(cb.name_rank, R, np.uint32), **lr)
+        if pack_params is not None:
+            bw = arr(pk.base_woff, R + 1, np.uint32); gw = arr(pk.good_woff, R + 1, np.uint32)
+            packed = dict(rinfo=arr(pk.rinfo, R + 1, np.uint32), base_woff=bw, good_woff=gw,
+                          bases=arr(pk.bases, (int(bw[-1]) if R else 0) + 4, np.uint32), good=arr(pk.good, (int(gw[-1]) if R else 0) + 1, np.uint32))
+            return b, idx, packed
         return b, idx

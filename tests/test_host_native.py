@@ -703,3 +703,75 @@ def test_lazy_per_batch_loading_gives_the_same_batches(tmp_path, monkeypatch, ca
         h2, l2, k2 = all_batches(lp, tile_reg, step, o2)
         assert h2 == h1 and k2 == k1
         _batches_equal(e1[0], workload.concat_batches(l2))
+
+
+def test_packed_batch_equals_packing_the_ascii_batch():
+    """lancet_host_batch_packed (the host threads trim and pack while they assemble the batch) against lancet_pack_read -- the routine
+    lancet_engine_upload runs on the ASCII arrays -- applied read by read to the batch of lancet_host_batch: same window arrays, same trimmed
+    lengths and flags, same packed words at the same offsets; with qualities that make the trim bite (--min-base-qual / trim parameters away
+    from their defaults) and on the read-filter golden."""
+    import ctypes as C
+    from lancet_amd import abi, engine
+    L = engine.lib()
+    L.lancet_pack_read.restype = None
+    L.lancet_pack_read.argtypes = [C.POINTER(abi.LancetParams), C.c_char_p, C.c_char_p, C.c_int, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8,
+                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    for case, over in (("ar_small", {}), ("tile30", dict(min_qual_trim=33 + 25, min_qual_call=33 + 30)), ("leak_small", dict(min_qual_trim=33 + 12))):
+        paths = [os.path.join(G, f"{case}.tumor.bam"), os.path.join(G, f"{case}.normal.bam"), os.path.join(G, f"{case}.fa")]
+        if not os.path.exists(paths[0]):
+            continue
+        p = abi.default_params(**over)
+        o = host.default_opts(active_region=0)
+        H = host.NativeHost(*paths)
+        hdrs = H.tile("chr22:900-3100", o)
+        b, idx = H.batch(0, len(hdrs), o)
+        b2, idx2, pk = H.batch(0, len(hdrs), o, pack_params=p)
+        H.close()
+        assert idx2 == idx and b2.hdr == b.hdr and b2.seq.size == 0 and b2.qual.size == 0
+        for f in FIELDS:
+            if f not in ("seq", "qual"):
+                assert np.array_equal(getattr(b, f), getattr(b2, f)), f
+        R = b.n_reads
+        lens = np.diff(b.seq_off.astype(np.int64))
+        assert np.array_equal(np.diff(pk["base_woff"].astype(np.int64)), (lens + 15) // 16) and np.array_equal(np.diff(pk["good_woff"].astype(np.int64)), (lens + 31) // 32)
+        seq, qual = b.seq.tobytes(), b.qual.tobytes()
+        trimmed = 0
+        for r in range(0, R, max(1, R // 3000)):                       # (a few thousand reads per case)
+            n = int(lens[r]); so = int(b.seq_off[r])
+            ri = C.c_uint32(); wb = (C.c_uint32 * ((n + 15) // 16 + 1))(); wg = (C.c_uint32 * ((n + 31) // 32 + 1))()
+            L.lancet_pack_read(C.byref(p), seq[so:so + n], qual[so:so + n], n, int(b.label[r]), int(b.strand[r]), int(b.mate[r]), int(b.mapped[r]), C.byref(ri), wb, wg)
+            assert ri.value == int(pk["rinfo"][r]), (case, r)
+            trimmed += int((ri.value & 0xFFFF) < n)
+            a0 = int(pk["base_woff"][r]); g0 = int(pk["good_woff"][r])
+            assert list(wb)[: (n + 15) // 16] == pk["bases"][a0:a0 + (n + 15) // 16].tolist(), (case, r)
+            assert list(wg)[: (n + 31) // 32] == pk["good"][g0:g0 + (n + 31) // 32].tolist(), (case, r)
+        if over:
+            assert trimmed > 0, case
+
+
+@pytest.mark.gpu
+def test_packed_upload_gives_the_records_of_the_ascii_upload():
+    """lancet_host_batch_packed -> lancet_engine_upload_packed against lancet_host_batch -> lancet_engine_upload on the same windows (and
+    the oracle): same records and statistics, with trim parameters that bite; a packed batch whose offsets do not fit the read lengths is
+    refused."""
+    from oracle import oracle
+    from lancet_amd import abi, engine
+    for case, over in (("ar_small", {}), ("leak_small", dict(min_qual_trim=33 + 25, min_qual_call=33 + 30))):
+        paths = [os.path.join(G, f"{case}.tumor.bam"), os.path.join(G, f"{case}.normal.bam"), os.path.join(G, f"{case}.fa")]
+        p = abi.default_params(**over)
+        o = host.default_opts(active_region=0, min_qual_call=p.min_qual_call)
+        H = host.NativeHost(*paths)
+        hdrs = H.tile("chr22:900-3100", o)
+        b, idx = H.batch(0, len(hdrs), o)
+        b2, idx2, pk = H.batch(0, len(hdrs), o, pack_params=p)
+        H.close()
+        ov, ost, _ = oracle.run(b, p)
+        eng = engine.Engine(p)
+        v1, s1 = eng.process(b)
+        eng.upload_packed(b2, pk); eng.run()
+        v2, s2 = eng.results()
+        assert v1 == ov and v2 == ov and s2 == s1
+        bad = dict(pk); bad["base_woff"] = pk["base_woff"].copy(); bad["base_woff"][1:] += 1
+        with pytest.raises(engine.EngineError):
+            eng.upload_packed(b2, bad)
+        eng.close()
