@@ -775,3 +775,56 @@ def test_packed_upload_gives_the_records_of_the_ascii_upload():
         with pytest.raises(engine.EngineError):
             eng.upload_packed(b2, bad)
         eng.close()
+
+
+def test_pack_read_against_a_plain_restatement():
+    """lancet_pack_read (host_pack.h: what lancet_engine_upload does to every read, several characters per machine word) against
+    Graph_t::trim (reference src/Graph.cc:355-384) + the packing spelled out character by character: random reads with N and other
+    letters, lower case, low qualities at the ends and inside, quality bytes above 127 (negative characters), lengths around the word
+    sizes, several thresholds."""
+    import ctypes as C
+    from lancet_amd import abi, engine
+    L = engine.lib()
+    L.lancet_pack_read.restype = None
+    L.lancet_pack_read.argtypes = [C.POINTER(abi.LancetParams), C.c_char_p, C.c_char_p, C.c_int, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8,
+                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    rng = np.random.default_rng(3)
+    code = {c: i for i, c in enumerate(b"ACGT")}
+    code.update({c: i for i, c in enumerate(b"acgt")})
+    n_trim = n_junk = 0
+    for trial in range(1500):
+        n = int(rng.choice([0, 1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 150, 151, 250]))
+        qtrim, qcall = int(rng.choice([33 + 10, 33 + 2, 33 + 25])), int(rng.choice([33 + 17, 33 + 30, 34, 127]))
+        p = abi.default_params(min_qual_trim=qtrim, min_qual_call=qcall)
+        seq = bytearray(rng.choice(list(b"ACGT"), size=n).astype(np.uint8).tobytes())
+        qual = bytearray(rng.integers(33 + 20, 33 + 42, size=n, dtype=np.uint8).tobytes())
+        for i in range(n):
+            u = rng.random()
+            if u < 0.01: seq[i] = rng.choice(list(b"NRYn"))
+            elif u < 0.05: seq[i] = seq[i] | 0x20
+            if rng.random() < 0.06: qual[i] = int(rng.integers(33, 33 + 12))
+            if rng.random() < 0.01: qual[i] = int(rng.integers(128, 256))
+        k = int(rng.integers(0, 4))
+        for i in range(min(k, n)): qual[i] = 33 + 1
+        for i in range(min(int(rng.integers(0, 4)), n)): qual[n - 1 - i] = 33 + 1
+        sq = lambda b: b - 256 if b >= 128 else b                       # a C `char` on this ABI
+        good_end = lambda i: seq[i] in code and not (sq(qual[i]) < qtrim)
+        fg = 0
+        while fg < n and not good_end(fg): fg += 1
+        lg = n - 1
+        while lg >= fg and not good_end(lg): lg -= 1
+        junk = fg >= n or lg < fg or any(seq[i] not in code for i in range(fg, lg + 1))
+        tlen = 0 if junk else lg - fg + 1
+        t5 = 0 if junk else fg
+        wb = [0] * ((n + 15) // 16); wg = [0] * ((n + 31) // 32)
+        for j in range(tlen):
+            wb[j // 16] |= code[seq[t5 + j]] << (2 * (j % 16))
+            wg[j // 32] |= (1 if sq(qual[t5 + j]) >= qcall else 0) << (j % 32)
+        label, strand, mate, mapped = int(rng.choice([4, 5])), int(rng.choice([1, 2])), int(rng.integers(0, 3)), int(rng.integers(0, 2))      # TMR | NML, FWD | REV
+        ri = C.c_uint32(); ob = (C.c_uint32 * (len(wb) + 1))(); og = (C.c_uint32 * (len(wg) + 1))()
+        L.lancet_pack_read(C.byref(p), bytes(seq), bytes(qual), n, label, strand, mate, mapped, C.byref(ri), ob, og)
+        want_ri = tlen | ((1 if label == 5 else 0) << 16) | ((1 if strand == 2 else 0) << 17) | (mate << 18) | (mapped << 20)
+        assert ri.value == want_ri, (trial, n, ri.value, want_ri)
+        assert list(ob)[:len(wb)] == wb and list(og)[:len(wg)] == wg, (trial, n, tlen)
+        n_trim += int(0 < tlen < n); n_junk += int(junk and n > 0)
+    assert n_trim > 300 and n_junk > 100
