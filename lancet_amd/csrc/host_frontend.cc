@@ -82,6 +82,10 @@ struct Sample {
   std::vector<std::pair<std::string, int32_t>> refs;
   std::string path;
   int first_has_md = 1;             // MD on the first alignment of the file
+  // lancet_host_batch_packed: every alignment trimmed and packed ONCE (it is in about six windows), for the thresholds pk_qtrim / pk_qcall
+  std::vector<uint32_t> pk_tlen, pk_bw, pk_gw;        // trimmed length; first word of its bases / quality mask in pk_bases / pk_good
+  Bytes pk_bases, pk_good;
+  int pk_qtrim = -1, pk_qcall = -1; size_t pk_n = 0;
   std::vector<std::pair<size_t, size_t>> span;   // per contig of the tiling: its reads [first, last) (file order = coordinate order)
 };
 
@@ -1054,6 +1058,35 @@ int lancet_host_tile_regions(lancet_host *h, const char *bed_path, const char *c
   return finish_tiling(h, want);
 }
 
+// Trims and packs every alignment of a sample once (host_pack.h), on the host threads; a read that is not usable keeps length 0.
+static void ensure_pack_cache(Sample &S, const lancet_params &P) {
+  const size_t n = S.reads.size();
+  if (S.pk_qtrim == P.min_qual_trim && S.pk_qcall == P.min_qual_call && S.pk_n == n && S.pk_tlen.size() == n) return;
+  S.pk_tlen.assign(n, 0); S.pk_bw.assign(n + 1, 0); S.pk_gw.assign(n + 1, 0);
+  uint64_t bw = 0, gw = 0;
+  for (size_t i = 0; i < n; ++i) { S.pk_bw[i] = (uint32_t)bw; S.pk_gw[i] = (uint32_t)gw; bw += (S.reads[i].l_seq + 15) / 16; gw += (S.reads[i].l_seq + 31) / 32; }
+  S.pk_bw[n] = (uint32_t)bw; S.pk_gw[n] = (uint32_t)gw;          // (< 2^32: at most one word per 16 of the < 4 G bases)
+  S.pk_bases.resize(4 * (size_t)bw + 4); S.pk_good.resize(4 * (size_t)gw + 4);
+  uint32_t *B = (uint32_t *)S.pk_bases.data(), *G = (uint32_t *)S.pk_good.data();
+  const unsigned nt = host_threads((int)(n / 2048 + 1));
+  auto work = [&](unsigned t) {
+    for (size_t i = n * t / nt; i < n * (t + 1) / nt; ++i) {
+      const Read &r = S.reads[i];
+      uint32_t ri = 0, *pb = B + S.pk_bw[i], *pg = G + S.pk_gw[i];
+      lc_prep_read_host(P, S.seq.data() + r.seq_off, S.qual.data() + r.seq_off, (int)r.l_seq, 0, 0, 0, 0, &ri, pb, pg);
+      const uint32_t tl = ri & 0xFFFFu;
+      for (uint32_t wv = (tl + 15) / 16; wv < (r.l_seq + 15) / 16; ++wv) pb[wv] = 0;
+      for (uint32_t wv = (tl + 31) / 32; wv < (r.l_seq + 31) / 32; ++wv) pg[wv] = 0;
+      S.pk_tlen[i] = tl;
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto &t : th) t.join();
+  S.pk_qtrim = P.min_qual_trim; S.pk_qcall = P.min_qual_call; S.pk_n = n;
+}
+
 static int host_batch_impl(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o, lancet_window_batch *out,
                            int32_t *kept, int32_t *n_kept, const lancet_params *P, lancet_packed_reads *pk);
 int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o, lancet_window_batch *out,
@@ -1140,6 +1173,7 @@ static int host_batch_impl(lancet_host *h, int w_begin, int w_end, const lancet_
     h->b_pbases.need(4 * ((size_t)bw0[(size_t)nk] + 4)); h->b_pgood.need(4 * ((size_t)gw0[(size_t)nk] + 1));
     if (!h->b_pbases.p || !h->b_pgood.p) { h->err = "out of memory for the batch"; return LANCET_E_ARG; }
     h->b_rinfo.resize(R + 1); h->b_bw.resize(R + 1); h->b_gw.resize(R + 1);
+    for (int smp = 0; smp < 4; ++smp) ensure_pack_cache(h->smp[smp], *P);
   } else {
   h->b_seq.need(NB + 1); h->b_qual.need(NB + 1);
   if (!h->b_seq.p || !h->b_qual.p) { h->err = "out of memory for the batch"; return LANCET_E_ARG; }
@@ -1171,10 +1205,10 @@ static int host_batch_impl(lancet_host *h, int w_begin, int w_end, const lancet_
             if (packed) {
               uint32_t *pb = (uint32_t *)h->b_pbases.p + pbo, *pg = (uint32_t *)h->b_pgood.p + pgo;
               h->b_bw[r] = (uint32_t)pbo; h->b_gw[r] = (uint32_t)pgo;
-              lc_prep_read_host(*P, S.seq.data() + rd.seq_off, S.qual.data() + rd.seq_off, (int)rd.l_seq, h->b_label[r], s.strand, s.mate, s.mapped, &h->b_rinfo[r], pb, pg);
-              const uint32_t tl = h->b_rinfo[r] & 0xFFFFu, nbw = (rd.l_seq + 15) / 16, ngw = (rd.l_seq + 31) / 32;
-              for (uint32_t wv = (tl + 15) / 16; wv < nbw; ++wv) pb[wv] = 0;
-              for (uint32_t wv = (tl + 31) / 32; wv < ngw; ++wv) pg[wv] = 0;
+              const uint32_t nbw = (rd.l_seq + 15) / 16, ngw = (rd.l_seq + 31) / 32;      // (packed once per alignment: ensure_pack_cache)
+              memcpy(pb, (const uint32_t *)S.pk_bases.data() + S.pk_bw[s.idx], 4 * (size_t)nbw);
+              memcpy(pg, (const uint32_t *)S.pk_good.data() + S.pk_gw[s.idx], 4 * (size_t)ngw);
+              h->b_rinfo[r] = lc_rinfo_word(S.pk_tlen[s.idx], h->b_label[r], s.strand, s.mate, s.mapped);
               pbo += nbw; pgo += ngw;
             } else { memcpy(h->b_seq.p + bo, S.seq.data() + rd.seq_off, rd.l_seq); memcpy(h->b_qual.p + bo, S.qual.data() + rd.seq_off, rd.l_seq); }
             bo += rd.l_seq;

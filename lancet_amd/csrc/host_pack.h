@@ -10,6 +10,10 @@
 struct LcCodeTab { uint8_t c[256]; LcCodeTab() { for (int i = 0; i < 256; ++i) c[i] = 4; c['A'] = c['a'] = 0; c['C'] = c['c'] = 1; c['G'] = c['g'] = 2; c['T'] = c['t'] = 3; } };
 static const LcCodeTab lc_tab;
 static inline uint32_t lc_code(char b) { return lc_tab.c[(uint8_t)b]; }
+// the per-read word of the resident batch: trimmed length, sample, strand, mate number, mapped (layout.h RI_*)
+static inline uint32_t lc_rinfo_word(uint32_t tlen, uint8_t label, uint8_t strand, uint8_t mate, uint8_t mapped) {
+  return tlen | ((label == LANCET_NML ? 1u : 0u) << 16) | ((strand == LANCET_REV ? 1u : 0u) << 17) | ((uint32_t)(mate & 3) << 18) | ((mapped ? 1u : 0u) << 20);
+}
 static inline void lc_prep_read_host(const lancet_params &P, const char *sq, const char *ql, int len, uint8_t label, uint8_t strand, uint8_t mate, uint8_t mapped,
                               uint32_t *rinfo, uint32_t *bases, uint32_t *good) {
   const uint8_t *tab = lc_tab.c;
@@ -21,7 +25,7 @@ static inline void lc_prep_read_host(const lancet_params &P, const char *sq, con
   const int trim5 = junk ? 0 : fg;
   int tlen = junk ? 0 : lg - fg + 1;
   if (tlen > 0xFFFF) tlen = 0xFFFF;
-  *rinfo = (uint32_t)tlen | ((label == LANCET_NML ? 1u : 0u) << 16) | ((strand == LANCET_REV ? 1u : 0u) << 17) | ((uint32_t)(mate & 3) << 18) | ((mapped ? 1u : 0u) << 20);
+  *rinfo = lc_rinfo_word((uint32_t)tlen, label, strand, mate, mapped);
   const uint8_t *s = (const uint8_t *)sq + trim5; const char *q = ql + trim5;
   // Bases: inside the trimmed range every character is one of ACGTacgt (else the read is junk, above), and for those
   // ((c >> 1) ^ (c >> 2)) & 3 is the code 0..3; four characters of a 32-bit word are gathered into eight bits by one multiplication
