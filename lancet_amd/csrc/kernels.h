@@ -2644,67 +2644,8 @@ DEVNI void remove_low_cov(Ctx &c, int comp) {                         // referen
   print_stats(c, comp);
 }
 
-// findTandems (reference src/util.cc:574-758) on a code string (0..3); returns ans, len, motif (codes)
-DEVNI bool find_tandems(const Ctx &c, LC_GLOBAL const uint8_t *seq, int n, int pos, int *len, uint8_t *motif, int *motif_len) {
-  const unsigned MAXU = (unsigned)LC_CTX(c).P->max_unit_len, MRU = (unsigned)LC_CTX(c).P->min_report_units, MRL = (unsigned)LC_CTX(c).P->min_report_len;
-  const int delta = LC_CTX(c).P->dist_from_str;
-  bool ans = false;
-  // The scan compares bytes of the string at data-dependent places, one dependent load after the other (~10 k of them for
-  // a 600-base path), and keeps a small table indexed at run time: both live in LDS for the duration (the staging area of
-  // the per-position pass is idle in the graph phases); a string that does not fit is scanned where it lies.
-  LC_WS &S = LC_SREF(c);
-  LC_LDS uint8_t *ls = (LC_LDS uint8_t *)S.mk;
-  const bool staged = n + 8 <= 2048;
-  if (staged) {
-    LC_GLOBAL const uint32_t *src = (LC_GLOBAL const uint32_t *)seq; LC_LDS uint32_t *dst = (LC_LDS uint32_t *)ls;
-    const int nwords = (n + 3) / 4;
-#ifndef LANCET_WAVE_EMU
-#pragma unroll 8
-#endif
-    for (int w = 0; w < nwords; ++w) dst[w] = src[w];
-  }
-#define LC_SEQ(i) (staged ? (int)ls[(i)] : (int)seq[(i)])
-  int offsets_local[9][8];
-  LC_LDS int *offs_lds = (LC_LDS int *)(ls + 2048);
-  for (unsigned ml = 1; ml <= MAXU && ml <= 8; ++ml) for (unsigned ph = 0; ph < ml; ++ph) { if (staged) offs_lds[ml * 8 + ph] = (int)ph; else offsets_local[ml][ph] = (int)ph; }
-  *motif_len = 0;
-  for (unsigned i = 0; i < (unsigned)n; ++i) {
-    for (unsigned merlen = 1; merlen <= MAXU && merlen <= 8; ++merlen) {
-      int phase = (int)(i % merlen);
-      int offset = staged ? offs_lds[merlen * 8 + (unsigned)phase] : offsets_local[merlen][phase];
-      unsigned j = 0;
-      while ((j < merlen) && (i + j < (unsigned)n) && (LC_SEQ(i + j) == LC_SEQ(offset + j))) ++j;
-      if (j != merlen || (i + j + 1 == (unsigned)n)) {
-        int a = offset - 1, b = offset + (int)merlen - 1;
-        int ca = (a < 0 || a >= n) ? 255 : LC_SEQ(a), cb = (b < 0 || b >= n) ? 255 : LC_SEQ(b);    // byte before the string is 0 in libstdc++
-        if (ca != cb) {
-          if (((i - (unsigned)offset) / merlen >= MRU) && (i - (unsigned)offset >= MRL)) {
-            unsigned ml = 1;
-            while (ml < merlen) {
-              unsigned units = (i - (unsigned)offset + j) / ml;
-              int allmatch = 1;
-              for (unsigned index = 1; allmatch && (index < units); ++index)
-                for (unsigned m = 0; m < ml; ++m) if (LC_SEQ(offset + m) != LC_SEQ(offset + index * ml + m)) { allmatch = 0; break; }
-              if (!allmatch) ++ml; else break;
-            }
-            if (ml == merlen) {
-              int start = offset, end = (int)(i + j), L = (int)(i + j) - offset;
-              if ((pos >= (start - delta)) && (pos <= (end + delta))) {
-                ans = true; *len = L;
-                for (unsigned z = 0; z < merlen; ++z) if (*motif_len < 60) motif[(*motif_len)++] = (uint8_t)LC_SEQ(offset + z);
-              }
-            }
-          }
-        }
-        if (staged) offs_lds[merlen * 8 + (unsigned)phase] = (int)i; else offsets_local[merlen][phase] = (int)i;
-      }
-    }
-  }
-  return ans;
-#undef LC_SEQ
-}
-
-// The same answer from the neighbourhood of `pos` alone.  findTandems keeps, per unit length and phase, the start of the current
+// findTandems (reference src/util.cc:574-758) on a code string (0..3): answered from the neighbourhood of `pos` alone; returns ans,
+// len, motif (codes).  The reference scans the whole string and keeps, per unit length and phase, the start of the current
 // stretch of equal consecutive units, and reports a stretch when it ends (at position i, having matched j more characters) if
 // pos lies within delta of [start, i + j].  A stretch that ends at i < pos - delta - MAXU cannot reach pos, so the literal loop
 // is entered at i0 = pos - delta - MAXU with the per-(unit, phase) stretch starts found by walking back over equal units (before
@@ -2743,37 +2684,36 @@ DEVNI bool find_tandems_local(const Ctx &c, LC_GLOBAL const uint8_t *seq, int n,
     }
     offs[ml][ph] = t;
   }
+  // is [st, st + span) a whole number of copies of a unit shorter than `u`?  (the reference reports a stretch under its SMALLEST unit only)
+  auto shorter_unit = [&](int st, unsigned span, unsigned u) -> bool {
+    for (unsigned v = 1; v < u; ++v) {
+      const unsigned reps = span / v;
+      bool same = true;
+      for (unsigned q = v; same && q < reps * v; ++q) same = LC_SEQ(st + (int)q) == LC_SEQ(st + (int)(q % v));
+      if (same) return true;
+    }
+    return false;
+  };
+  auto byte_or_none = [&](int at) -> int { return (at < 0 || at >= n) ? 255 : LC_SEQ(at); };      // (the byte before a libstdc++ string is 0, never a code)
   for (unsigned i = (unsigned)i0; i < (unsigned)n; ++i) {
     bool live = false;                                           // a stretch in progress that still starts at or left of pos + delta
-    for (unsigned merlen = 1; merlen <= MU; ++merlen) {
-      const int phase = (int)(i % merlen);
-      const int offset = offs[merlen][phase];
-      unsigned j = 0;
-      while ((j < merlen) && (i + j < (unsigned)n) && (LC_SEQ(i + j) == LC_SEQ(offset + j))) ++j;
-      if (j != merlen || (i + j + 1 == (unsigned)n)) {
-        int a = offset - 1, b = offset + (int)merlen - 1;
-        int ca = (a < 0 || a >= n) ? 255 : LC_SEQ(a), cb = (b < 0 || b >= n) ? 255 : LC_SEQ(b);
-        if (ca != cb) {
-          if (((i - (unsigned)offset) / merlen >= MRU) && (i - (unsigned)offset >= MRL)) {
-            unsigned ml = 1;
-            while (ml < merlen) {
-              unsigned units = (i - (unsigned)offset + j) / ml;
-              int allmatch = 1;
-              for (unsigned index = 1; allmatch && (index < units); ++index)
-                for (unsigned m = 0; m < ml; ++m) if (LC_SEQ(offset + m) != LC_SEQ(offset + index * ml + m)) { allmatch = 0; break; }
-              if (!allmatch) ++ml; else break;
-            }
-            if (ml == merlen) {
-              int start = offset, end = (int)(i + j), L = (int)(i + j) - offset;
-              if ((pos >= (start - delta)) && (pos <= (end + delta))) {
-                ans = true; *len = L;
-                for (unsigned z = 0; z < merlen; ++z) if (*motif_len < 60) motif[(*motif_len)++] = (uint8_t)LC_SEQ(offset + z);
-              }
-            }
-          }
+    for (unsigned u = 1; u <= MU; ++u) {
+      LC_LDS int &slot = offs[u][i % u];
+      const int st = slot;
+      unsigned j = 0;                                            // characters of the unit at i that repeat the stretch's first unit
+      while (j < u && i + j < (unsigned)n && LC_SEQ(i + j) == LC_SEQ(st + (int)j)) ++j;
+      const bool ends = j != u || i + j + 1 == (unsigned)n;
+      if (!ends) continue;
+      const unsigned run = i - (unsigned)st;
+      // a stretch counts when it cannot be extended to the left by one character, is long enough, and `u` is its smallest unit
+      if (byte_or_none(st - 1) != byte_or_none(st + (int)u - 1) && run / u >= MRU && run >= MRL && !shorter_unit(st, run + j, u)) {
+        const int stop = (int)(i + j);
+        if (pos >= st - delta && pos <= stop + delta) {
+          ans = true; *len = stop - st;
+          for (unsigned z = 0; z < u; ++z) if (*motif_len < 60) motif[(*motif_len)++] = (uint8_t)LC_SEQ(st + (int)z);
         }
-        offs[merlen][phase] = (int)i;
       }
+      slot = (int)i;
     }
     for (unsigned ml = 1; ml <= MU && !live; ++ml) for (unsigned ph = 0; ph < ml; ++ph) if (offs[ml][ph] - delta <= pos) { live = true; break; }
     if (!live) break;
@@ -2822,8 +2762,7 @@ DEVNI void remove_short_links(Ctx &c, int comp) {                     // referen
       int sl = n_len(c, n);
       if (sl > (int)LC_CTX(c).C->path_cap) { OVF(c); return; }
       node_string(c, n, W.pseq);
-      find_tandems(c, W.pseq, sl, S.K - 1, &L, motif, &ml);
-      if (L == 0) { remove_node(c, n); ++links; }
+      if (!find_tandems_local(c, W.pseq, sl, S.K - 1, &L, motif, &ml)) { remove_node(c, n); ++links; }
     }
   }
   evt(c, EV_LINKS, links);
@@ -2963,8 +2902,7 @@ DEVNI void remove_short_links_wg(Ctx &c, int comp) {                  // referen
       const int sl = n_len(c, n);
       if (sl > (int)LC_CTX(c).C->path_cap) { OVF(c); break; }
       node_string(c, n, W.pseq);
-      find_tandems(c, W.pseq, sl, S.K - 1, &L, motif, &ml);
-      if (L == 0) { remove_node(c, n); ++links; }
+      if (!find_tandems_local(c, W.pseq, sl, S.K - 1, &L, motif, &ml)) { remove_node(c, n); ++links; }
     }
     evt(c, EV_LINKS, links);
     S.tmp3 = links;

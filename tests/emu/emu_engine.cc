@@ -162,7 +162,7 @@ extern "C" void lancet_emu_repeat_scan_min(const uint8_t *s, int len, int mm, in
   *outE = e; *outM = m;
 }
 
-// find_tandems: the whole-string scan and the local one (test hook; both must equal the oracle's restatement of src/util.cc:574-758)
+// find_tandems_local (test hook; must equal the oracle's restatement of src/util.cc:574-758; `local` is kept in the signature, ignored)
 extern "C" int lancet_emu_find_tandems(const uint8_t *codes, int n, int pos, int max_unit_len, int min_report_units, int min_report_len, int dist_from_str,
                                        int local, int *len, uint8_t *motif, int *motif_len) {
   lancet_params P; memset(&P, 0, sizeof(P));
@@ -170,7 +170,8 @@ extern "C" int lancet_emu_find_tandems(const uint8_t *codes, int n, int pos, int
   static WinShared S;
   Ctx c; c.P = &P; c.B = nullptr; c.C = nullptr; c.W = nullptr; c.OUT = nullptr; c.S = &S;
   *len = 0;
-  bool a = local ? find_tandems_local(c, codes, n, pos, len, motif, motif_len) : find_tandems(c, codes, n, pos, len, motif, motif_len);
+  (void)local;
+  bool a = find_tandems_local(c, codes, n, pos, len, motif, motif_len);
   return a ? 1 : 0;
 }
 

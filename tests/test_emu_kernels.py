@@ -163,10 +163,10 @@ def test_emulated_kernels_on_a_coverage_pile_up():
     assert v == ov and [s["final_k"] for s in st] == [s["final_k"] for s in ost] and len(ov) > 0
 
 
-def test_find_tandems_local_equals_whole_string_scan_and_oracle():
+def test_find_tandems_local_equals_the_oracle():
     """findTandems (reference src/util.cc:574-758) evaluated from the neighbourhood of the position only must report what the
-    whole-string scan reports: answer, length (last report wins) and the concatenated motifs, on random, STR-rich and periodic strings,
-    at every kind of position (string ends included) and under several option sets."""
+    oracle's whole-string scan reports: answer, length (last report wins) and the concatenated motifs, on random, STR-rich and periodic
+    strings, at every kind of position (string ends included) and under several option sets."""
     import ctypes
     import numpy as np
     L = emu.lib()
@@ -207,12 +207,9 @@ def test_find_tandems_local_equals_whole_string_scan_and_oracle():
         positions = sorted(set([0, 1, n - 1, n, n // 2] + [int(x) for x in rng.integers(0, n + 1, size=min(n + 1, 40))]))
         for opt in opts:
             for pos in positions:
-                full = run(s, pos, opt, 0)
                 loc = run(s, pos, opt, 1)
-                assert loc == full, (text, pos, opt, loc, full)
                 a, ln, mo = oracle.find_tandems(text, pos, *opt)
-                if opt[0] <= 4 or True:
-                    assert (a, ln if a else 0, mo[:60]) == (full[0], full[1] if full[0] else 0, full[2]), (text, pos, opt, (a, ln, mo), full)
+                assert (a, ln if a else 0, mo[:60]) == (loc[0], loc[1] if loc[0] else 0, loc[2]), (text, pos, opt, (a, ln, mo), loc)
                 checked += 1
     assert checked > 2000
 
