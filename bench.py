@@ -113,6 +113,17 @@ def cpu_baseline(batch, params, variants, n1: int, nall: int):
             "note": "the reference binary cannot travel to this box; in the authoring container it runs the golden cases at 13-23 windows/s/thread, this port at ~45 (DESIGN.md §7)"}
 
 
+def kernel_rooflines(alg_build: int, alg_window: int, per_kernel: dict) -> dict:
+    """Roofline of each kernel on its own share of the algorithmic bytes (workload.algorithmic_bytes_split)."""
+    out = {}
+    for nm, alg in (("build_kernel", alg_build), ("window_kernel", alg_window)):
+        ms = float(per_kernel.get(nm, 0.0))
+        if ms > 0:
+            out[nm] = {"algorithmic_bytes_per_launch": int(alg), "ms": round(ms, 3), "achieved": round(alg / (ms * 1e-3) / 1e9, 3),
+                       "frac": round(alg / (ms * 1e-3) / 1e9 / 8000.0, 6)}
+    return out
+
+
 def side_config(eng_cls, params, name, windows, cov_t, cov_n, steps, **kw):
     """One more BASELINE.md configuration on this GPU (smaller batch, reported beside the headline), with its own roofline:
     algorithmic bytes of the batch / HIP-event durations of its kernels."""
@@ -134,16 +145,18 @@ def side_config(eng_cls, params, name, windows, cov_t, cov_n, steps, **kw):
     per_kernel = {nm: round(float(np.mean([k[i] for k in kms])), 3) for i, nm in enumerate(names)}
     ms_all = float(sum(per_kernel.values()))
     alg = workload.algorithmic_bytes(b, stats, len(variants))
+    alg_b, alg_w = workload.algorithmic_bytes_split(b, stats, len(variants))
+    built = sum(1 for s in stats if s["n_builds"] > 0)
     out = {"name": name, "windows": windows, "steps": steps, "coverage": [cov_t, cov_n], "windows_per_s": round(windows / dt, 1),
            "mkmers_per_s": round(sum(s["n_kmers"] for s in stats) / dt / 1e6, 1), "reads_per_window": round(b.n_reads / windows, 1),
            "builds_per_window": round(sum(s["n_builds"] for s in stats) / windows, 3),
            "final_k_histogram": {int(k): int(c) for k, c in zip(ks, cnt)},
            "k_exhausted": sum(1 for s in stats if s["status"] == 2), "overflowed": sum(1 for s in stats if s["status"] < 0),
-           "windows_first_graph_in_lds": eng.prebuilt_count(), "windows_rerun_worst_case_tier": eng.rerun_count(),
+           "windows_first_graph_in_lds": eng.prebuilt_count(), "windows_that_build": built, "windows_rerun_worst_case_tier": eng.rerun_count(),
            "build_service": dict(zip(("posted", "served", "not_buildable", "taken_back"), eng.svc_counts())),
            "roofline": {"bound": "hbm", "achieved": round(alg / (ms_all * 1e-3) / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(alg / (ms_all * 1e-3) / 1e9 / 8000.0, 6), "algorithmic_bytes_per_launch": int(alg),
-                        "kernel_ms": round(ms_all, 3), "per_kernel_ms": per_kernel}}
+                        "kernel_ms": round(ms_all, 3), "per_kernel_ms": per_kernel, "per_kernel": kernel_rooflines(alg_b, alg_w, per_kernel)}}
     eng.close()
     return out
 
@@ -151,7 +164,7 @@ def side_config(eng_cls, params, name, windows, cov_t, cov_n, steps, **kw):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (default: ~5 s of timed region at ~50 ms per step)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--windows", type=int, default=32768, help="windows per GPU per step")
     ap.add_argument("--cov", type=float, default=30.0, help="coverage per sample")
@@ -303,6 +316,7 @@ def main():
     n_kmers = int(sum(s["n_kmers"] for s in stats))
     n_bad = sum(1 for s in stats if s["status"] < 0)
     alg_bytes = workload.algorithmic_bytes(batch, stats, len(variants))
+    alg_build, alg_window = workload.algorithmic_bytes_split(batch, stats, len(variants))
     if world > 1:
         t = torch.tensor([n_kmers, n_bad], dtype=torch.int64, device=comm_device)
         dist.all_reduce(t)
@@ -376,7 +390,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": None,
                          "kernel": "+".join(names), "kernel_ms": round(ms_all, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "per_kernel_ms": per_kernel,
+                         "per_kernel_ms": per_kernel, "per_kernel": kernel_rooflines(alg_build, alg_window, per_kernel),
                          "note": "one pass over the batch = the listed kernels back to back on one stream; achieved = algorithmic bytes of the batch / the sum of their HIP-event durations, measured on launches that have the GPU to themselves (profiles/: rocprofv3 of `bench.py --in-flight 1`)",
                          "pipelined": {"ms_per_step": round(1000.0 * dt / args.steps, 3), "achieved": round(alg_bytes / (dt / args.steps) / 1e9, 3), "frac": round(alg_bytes / (dt / args.steps) / 1e9 / 8000.0, 6)},
                          "peak_measured_copy": 6290.0, "frac_of_measured_copy": round(achieved / 6290.0, 6)},
@@ -395,7 +409,8 @@ def main():
         # HBM-side bytes per launch from the committed PMC passes (tools/pmc_total.sh -> profiles/r3_traffic.json):
         # rocprofv3 cannot run inside this process, so the figure is looked up for the exact workload it was taken on
         try:
-            with open(os.path.join(ROOT, "profiles", "r3_traffic.json")) as fh:
+            tj = os.path.join(ROOT, "profiles", "r4_traffic.json")
+            with open(tj if os.path.exists(tj) else os.path.join(ROOT, "profiles", "r3_traffic.json")) as fh:
                 for rec in json.load(fh)["measurements"]:
                     if rec["windows"] == args.windows and rec["coverage"] == args.cov and world == 1:
                         out["roofline"]["traffic"] = int((rec["FETCH_SIZE_KB"] / rec.get("fetch_calibration", 1.0) + rec["WRITE_SIZE_KB"]) * 1024)
@@ -413,6 +428,8 @@ def main():
                 side_config(engine.Engine, params, "config 2 at 60x/60x", 8192, 60.0, 60.0, 8),
                 side_config(engine.Engine, params, "config 4: 100x tumor / 40x normal, 30 % STR + 5 % low complexity", 4096, 100.0, 40.0, 8,
                             str_fraction=0.30, lowcomplex_fraction=0.05),
+                side_config(engine.Engine, abi.default_params(lr_mode=1), "config 5: --linked-reads (BX / HP tags on every pair), 30x/30x", 8192, 30.0, 30.0, 8,
+                            linked=True),
             ]
         print(json.dumps(out))
     if world > 1:

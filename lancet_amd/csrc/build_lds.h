@@ -35,7 +35,8 @@
 #define BL_INFLIGHT 4             /* occurrence words a lane has in flight in a pass over the window's occurrences (bl_for_occ) */
 #endif
 #define BL_DUPCAP 1024u
-enum { BLW_NONE = 0, BLW_NOREADS, BLW_SIZE, BLW_HASN, BLW_K, BLW_TABLE, BLW_NODES, BLW_TRACKED, BLW_CAND, BLW_QV, BLW_SURV, BLW_MATE, BLW_NAMES, BLW_PAIRS };
+enum { BLW_NONE = 0, BLW_NOREADS, BLW_SIZE, BLW_HASN, BLW_K, BLW_TABLE, BLW_NODES, BLW_TRACKED, BLW_CAND, BLW_QV, BLW_SURV, BLW_MATE, BLW_NAMES, BLW_PAIRS,
+       BLW_KBIG /* k > 31: the 1024-lane configuration's (keys of up to four words) */ };
 
 #ifdef LANCET_WAVE_EMU
 #define BL_DBG(...) do { if (getenv("LANCET_EMU_WHY")) fprintf(stderr, __VA_ARGS__); } while (0)
@@ -52,10 +53,13 @@ static thread_local unsigned long bl_emu_sync_acc[17], bl_emu_sync_last = 0; sta
 
 // Two size configurations of the same code:
 //   bl_small  512 lanes, 40 960 bases, 512 reads, 80 KB of LDS: two workgroups per CU -- the 30x/30x windows;
-//   bl_large 1024 lanes, 131 040 bases (17-bit offsets under a 15-bit fingerprint), 1024 reads, a 64 KB phase area (room for the
+//   bl_large 1024 lanes, 126 976 bases (17-bit offsets under a 15-bit fingerprint), 1024 reads, a 64 KB phase area (room for the
 //            mate-overlap replay of 8192 occurrences), ~158 KB of LDS: one workgroup per CU -- windows the small one turns away
 //            for their size (60x/60x: ~360 reads, 58 k bases), taken off the list the small kernel leaves.
-// Same limits on what leaves the workgroup (PB_NCAP nodes, PB_CCAP candidates, PB_SCAP survivors: layout.h).
+//            Round 4: it is also the configuration for k > 31 (k-mers of up to four 64-bit words cut out of the LDS reads, BL_KW) and
+//            for large graphs: a 16384-slot table (all of its phase area), 14 336 distinct k-mers (node -> first-occurrence offset in
+//            its HBM scratch instead of LDS, 32-bit per-occurrence words) -- windows of 100x / 40x build at k = 31..101 with 9-12 k nodes.
+// Same limits on what leaves the workgroup (PB_CCAP candidates, PB_SCAP survivors; BL_NCAP nodes within the hand-off's PreLayout::ncap).
 #ifndef BL_SMALL_WG
 #define BL_SMALL_WG 512           /* lanes of the small configuration (tuning builds: tools/variant.sh)          */
 #define BL_SMALL_EU 4             /* waves per SIMD it is compiled for: 2 workgroups per CU                      */
@@ -68,6 +72,10 @@ static thread_local unsigned long bl_emu_sync_acc[17], bl_emu_sync_last = 0; sta
 #define BL_BASES BL_SMALL_BASES   /* bases in LDS (reads padded to 16, + the reference)                       */
 #define BL_RMAX 512               /* reads per window                                                          */
 #define BL_SLOTS 8192
+#define BL_NCAP PB_NCAP           /* distinct k-mers                                                           */
+#define BL_KW 1                   /* 64-bit words of a k-mer: k <= 31                                          */
+#define BL_KMAX 31
+#define BL_WIDE 0                 /* 16-bit per-occurrence words, node -> first-occurrence offset in LDS       */
 #define BL_TCAP 2048              /* tracked nodes                                                             */
 #define BL_BIG 32768              /* bytes of the phase-dependent LDS area                                     */
 #define BL_OFFBITS 16             /* bits of an LDS base offset                                                */
@@ -82,10 +90,20 @@ static thread_local unsigned long bl_emu_sync_acc[17], bl_emu_sync_last = 0; sta
 #undef BL_OFFBITS
 #undef BL_FLAGCAP
 #undef BL_LDS_LIMIT
+#undef BL_SLOTS
+#undef BL_NCAP
+#undef BL_KW
+#undef BL_KMAX
+#undef BL_WIDE
 #define BL_NS bl_large
 #define BL_WG 1024
-#define BL_BASES 131040
+#define BL_BASES 126976
 #define BL_RMAX 1024
+#define BL_SLOTS 16384
+#define BL_NCAP PB_NCAP_WIDE
+#define BL_KW 4
+#define BL_KMAX 127
+#define BL_WIDE 1
 #define BL_BIG 65536
 #define BL_OFFBITS 17
 #define BL_FLAGCAP 2048u
@@ -96,6 +114,10 @@ static thread_local unsigned long bl_emu_sync_acc[17], bl_emu_sync_last = 0; sta
 #undef BL_BASES
 #undef BL_RMAX
 #undef BL_SLOTS
+#undef BL_NCAP
+#undef BL_KW
+#undef BL_KMAX
+#undef BL_WIDE
 #undef BL_TCAP
 #undef BL_BIG
 #undef BL_OFFBITS

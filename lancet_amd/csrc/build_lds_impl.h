@@ -11,6 +11,15 @@ typedef uint16_t bl_occ_t;
 typedef uint16_t bl_off_t;
 #endif
 static constexpr uint32_t BL_OFFMASK = (1u << BL_OFFBITS) - 1u;
+// The per-occurrence word in HBM scratch: table slot, then node id, with the orientation and the "overlapping mate" mark on top.
+#if BL_WIDE
+typedef uint32_t bl_on_t;
+static constexpr uint32_t ON_ID = 0xFFFFFu, ON_OVL = 0x40000000u, ON_ORI = 0x80000000u, ON_ORISH = 31u;
+#else
+typedef uint16_t bl_on_t;
+static constexpr uint32_t ON_ID = 0x1FFFu, ON_OVL = 0x4000u, ON_ORI = 0x8000u, ON_ORISH = 15u;
+#endif
+static_assert(BL_NCAP <= ON_ID + 1u && BL_SLOTS <= ON_ID + 1u && BL_NCAP < 65536u, "node ids / slots in a per-occurrence word");
 static constexpr uint32_t LDS_BASES = BL_BASES, LDS_READS = BL_RMAX;       /* this configuration's limits, for the host */
 static_assert(BL_BASES < (1u << BL_OFFBITS) && BL_BASES / 16 + 4 < 65536, "offsets of the packed reads");
 
@@ -24,11 +33,10 @@ struct BlShared {
   uint32_t rinfo[BL_RMAX + 4];
   uint8_t pidx[BL_RMAX + 4];        /* mate-pair signature bit of the read (0xFF none)                          */
   uint8_t prole[BL_RMAX + 4];       /* 1 = earlier mate of a pair, 2 = the later one                            */
-  uint16_t idoff[PB_NCAP];          /* node id -> LDS offset of its first occurrence (its low 16 bits)          */
-#if BL_OFFBITS > 16
-  uint32_t idhi[PB_NCAP / 32 + 1];  /* ... bit 16 of it                                                          */
+#if !BL_WIDE
+  uint16_t idoff[BL_NCAP];          /* node id -> LDS offset of its first occurrence (BL_WIDE: in the HBM scratch, BlScratch::idoff) */
 #endif
-  uint16_t cidx[PB_NCAP];           /* node id -> tracked index, later survivor index (0xFFFF none)             */
+  alignas(8) uint16_t cidx[BL_NCAP];/* node id -> tracked index, later survivor index (0xFFFF none)             */
   uint16_t t2c[BL_TCAP];            /* tracked index -> candidate index (0xFFFF none)                           */
   alignas(16) uint32_t big[BL_BIG / 4];   /* (64-bit LDS atomics on it: must be 8-byte aligned) */
   uint32_t wsum[BL_WG / 64 + 1];
@@ -47,7 +55,8 @@ struct BlShared {
 
 /* per-workgroup scratch in HBM (streamed, never shared between windows in flight) */
 struct BlScratch {
-  LC_GLOBAL uint16_t *occn;         /* [BL_BASES] slot, then node id | ori << 15, per k-mer start offset         */
+  LC_GLOBAL bl_on_t *occn;          /* [BL_BASES] slot, then node id | ON_ORI, per k-mer start offset            */
+  LC_GLOBAL uint32_t *idoff;        /* [BL_NCAP] BL_WIDE: node id -> LDS offset of its first occurrence          */
   LC_GLOBAL unsigned long long *tcc;/* [BL_TCAP] counted occurrences Tf Tr Nf Nr (4 x 16 bit)                    */
   LC_GLOBAL uint32_t *tfl;          /* [BL_TCAP] NF_TUMOR | NF_NORMAL                                            */
   LC_GLOBAL uint32_t *c_id;         /* [PB_CCAP] node of candidate ci                                            */
@@ -60,12 +69,13 @@ struct BlScratch {
   LC_GLOBAL uint32_t *pq;           /* [BL_PQCAP] per-position counts: the occurrences of the candidates beyond the first LDS group (read | position << 10 | candidate << 20 | reversed << 31) */
 };
 static constexpr uint32_t BL_PQCAP = 16384u;
-static constexpr uint32_t SCRATCH_BYTES = (2u * BL_BASES + 64u + 8u * BL_TCAP + 4u * BL_TCAP + 12u * PB_CCAP + 4u * PB_SCAP + 36u * PB_SCAP + (uint32_t)sizeof(bl_off_t) * BL_DUPCAP + 16u * PB_CMAX + 4u * 16384u + 768u);
+static constexpr uint32_t SCRATCH_BYTES = ((uint32_t)sizeof(bl_on_t) * BL_BASES + 64u + (BL_WIDE ? 4u * BL_NCAP + 64u : 64u) + 8u * BL_TCAP + 4u * BL_TCAP + 12u * PB_CCAP + 4u * PB_SCAP + 36u * PB_SCAP + (uint32_t)sizeof(bl_off_t) * BL_DUPCAP + 16u * PB_CMAX + 4u * 16384u + 768u);
 static constexpr int WG = BL_WG;
 DEV void bl_scratch_carve(BlScratch *s, LC_GLOBAL uint8_t *base) {
   size_t o = 0;
   auto take = [&](size_t bytes) { LC_GLOBAL uint8_t *p = base + o; o = (o + bytes + 63) & ~(size_t)63; return p; };
-  s->occn = (LC_GLOBAL uint16_t *)take(2u * BL_BASES + 64u);
+  s->occn = (LC_GLOBAL bl_on_t *)take(sizeof(bl_on_t) * BL_BASES + 64u);
+  s->idoff = (LC_GLOBAL uint32_t *)take(BL_WIDE ? 4u * BL_NCAP : 4u);
   s->tcc = (LC_GLOBAL unsigned long long *)take(8u * BL_TCAP);
   s->tfl = (LC_GLOBAL uint32_t *)take(4u * BL_TCAP);
   s->c_id = (LC_GLOBAL uint32_t *)take(4u * PB_CCAP);
@@ -142,12 +152,66 @@ DEV unsigned long long bl_canon2(unsigned long long v, int K, unsigned long long
   *isF = fw < rc;
   return *isF ? fw : rc;
 }
-template <class SS> DEV uint32_t bl_idoff(SS &S, uint32_t n) {     // LDS offset of node n's first occurrence
-#if BL_OFFBITS > 16
-  return (uint32_t)S.idoff[n] | (((S.idhi[n >> 5] >> (n & 31u)) & 1u) << 16);
+template <class SS, class XX> DEV uint32_t bl_idoff(SS &S, XX &X, uint32_t n) {     // LDS offset of node n's first occurrence
+#if BL_WIDE
+  (void)S; return X.idoff[n];
 #else
-  return (uint32_t)S.idoff[n];
+  (void)X; return (uint32_t)S.idoff[n];
 #endif
+}
+// ---- k-mers of more than one 64-bit word (BL_KW > 1: the 1024-lane configuration, k <= 127).  `NW` = words this k needs.
+struct BlKm { unsigned long long w[BL_KW]; };
+DEV unsigned long long bl_rev2(unsigned long long x) {             // the 32 two-bit groups of a word in reverse order
+  x = dev_brev64(x);
+  return ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+}
+// the k-mer that starts at LDS offset `boff`, as it lies there: base j at bits 2j of the word string (low word first)
+DEV void bl_kmer_x(const LC_LDS uint32_t *bases, uint32_t boff, int NW, int K, BlKm &o) {
+  const uint32_t w0 = boff >> 4, sh = (boff & 15u) * 2u;
+  const int tb = 2 * K - 64 * (NW - 1);
+  for (int i = 0; i < BL_KW; ++i) {
+    unsigned long long v = 0;
+    if (i < NW) {
+      const uint32_t w = w0 + 2u * (uint32_t)i;
+      const unsigned long long lo = (unsigned long long)bases[w] | ((unsigned long long)bases[w + 1] << 32);
+      v = sh ? ((lo >> sh) | ((unsigned long long)bases[w + 2] << (64u - sh))) : lo;
+      if (i == NW - 1 && tb < 64) v &= (1ULL << tb) - 1ULL;
+    }
+    o.w[i] = v;
+  }
+}
+// canonical form as kernels.h holds it (first base most significant, right-aligned in NW words), and `alt`: what an EARLIER occurrence
+// of the same node looks like in LDS when it lies there in the other orientation (see the insert pass)
+template <int NW> DEV void bl_canon_n(const BlKm &v, int K, BlKm &ck, BlKm &alt, bool *isF) {
+  unsigned long long R[NW + 1], fw[NW], rc[NW];
+  for (int i = 0; i < NW; ++i) R[i] = bl_rev2(v.w[NW - 1 - i]);
+  R[NW] = 0;
+  const int s = 64 * NW - 2 * K, tb = 64 - s;                       // 0 <= s < 64 ; bits of the top word in use
+  for (int i = 0; i < NW; ++i) fw[i] = s ? ((R[i] >> s) | (R[i + 1] << (64 - s))) : R[i];
+  for (int i = 0; i < NW; ++i) rc[i] = ~v.w[i];
+  if (tb < 64) rc[NW - 1] &= (1ULL << tb) - 1ULL;
+  bool less = false, decided = false;
+  for (int i = NW - 1; i >= 0; --i) if (!decided && fw[i] != rc[i]) { less = fw[i] < rc[i]; decided = true; }
+  *isF = less;
+  for (int i = 0; i < BL_KW; ++i) { ck.w[i] = i < NW ? (less ? fw[i] : rc[i]) : 0ULL; alt.w[i] = i < NW ? ~fw[i] : 0ULL; }
+  if (tb < 64) alt.w[NW - 1] &= (1ULL << tb) - 1ULL;
+}
+DEV void bl_canon_x(const BlKm &v, int NW, int K, BlKm &ck, BlKm &alt, bool *isF) {
+#if BL_KW >= 4
+  if (NW == 4) { bl_canon_n<4>(v, K, ck, alt, isF); return; }
+  if (NW == 3) { bl_canon_n<3>(v, K, ck, alt, isF); return; }
+#endif
+#if BL_KW >= 2
+  if (NW == 2) { bl_canon_n<2>(v, K, ck, alt, isF); return; }
+#endif
+  bl_canon_n<1>(v, K, ck, alt, isF);
+}
+DEV bool bl_km_eq(const BlKm &a, const BlKm &b) { bool e = true; for (int i = 0; i < BL_KW; ++i) e = e && a.w[i] == b.w[i]; return e; }
+DEV int bl_km_char(const BlKm &ck, int K, int j) {                   // j-th character of a canonical key
+  const int bit = 2 * (K - 1 - j), wd = bit >> 6;
+  unsigned long long x = ck.w[0];
+  for (int i = 1; i < BL_KW; ++i) x = wd == i ? ck.w[i] : x;
+  return (int)((x >> (bit & 63)) & 3ULL);
 }
 DEV int bl_base(const LC_LDS uint32_t *bases, uint32_t boff) { return (int)((bases[boff >> 4] >> ((boff & 15u) * 2u)) & 3u); }
 // quality-mask bits [a, b) of a read whose mask starts at word gw: all set?
@@ -171,7 +235,7 @@ DEV bool bl_all_good(const LC_LDS uint32_t *goodm, uint32_t gw, int a, int b) {
 
 // The same walk with the occurrence's 2-byte HBM word fetched BL_INFLIGHT occurrences ahead: a pass is a chain of (HBM word -> LDS
 // look-ups -> LDS atomics) per occurrence, and with two workgroups per CU nothing else hides the memory round trip.
-template <class F> DEV void bl_for_occ(BL_S &S, LC_GLOBAL const uint16_t *occn, F body) {
+template <class F> DEV void bl_for_occ(BL_S &S, LC_GLOBAL const bl_on_t *occn, F body) {
   WG_FOR(_t, BL_WG) {
     const int O_ = (int)S.O;
     for (int o0 = _t; o0 < O_; o0 += BL_INFLIGHT * BL_WG) {
@@ -213,6 +277,7 @@ template <class F> DEV void bl_for_occ(BL_S &S, LC_GLOBAL const uint16_t *occn, 
 #define BLC_MAKE(to, dir) ((uint16_t)((to) | ((dir) << 10)))
 DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const EngineCaps *C, BL_S &S, BlScratch &X, LC_GLOBAL uint8_t *area, const int K,
                              const uint32_t N, const uint32_t nsurv, const uint32_t ncand, const int reflen, const uint32_t ht_bc) {
+  LC_GLOBAL const PreLayout &PL = C->pl;
   LC_GLOBAL PreCmp *CH = (LC_GLOBAL PreCmp *)(area + PRE_OFF_CHDR);
   LC_GLOBAL const uint32_t *occ_ref = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_OCCREF);
   LC_GLOBAL const unsigned long long *nhash = (LC_GLOBAL const unsigned long long *)(area + PRE_OFF_NHASH);
@@ -275,7 +340,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
   WG_FOR(off, nrefk) {
     const uint32_t e = occ_ref[off];
     if (e & PB_GONE) continue;
-    const uint32_t u = NPOS[e & 0x1FFFu];
+    const uint32_t u = NPOS[e & ON_ID];
     const unsigned long long c4 = TCC[u];
     const uint32_t tot = (uint32_t)(c4 & 0xFFFFu) + (uint32_t)((c4 >> 16) & 0xFFFFu) + (uint32_t)((c4 >> 32) & 0xFFFFu) + (uint32_t)(c4 >> 48);
     if ((float)tot >= (float)P->cov_threshold) { dev_atomic_min((LC_LDS uint32_t *)&S.g0, (uint32_t)off); dev_atomic_max((LC_LDS uint32_t *)&S.g1, (uint32_t)off + 1u); }
@@ -285,11 +350,11 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
   WG_SYNC();
   if (why_a || g0_a == 0x7FFFFFFFu) return;
   const int so = (int)g0_a, ko = (int)g1_a - 1;
-  const uint32_t sn = occ_ref[so] & 0x1FFFu, kn = occ_ref[ko] & 0x1FFFu;
+  const uint32_t sn = occ_ref[so] & 0xFFFFFu, kn = occ_ref[ko] & 0xFFFFFu;
   WG_FOR(off, nrefk) {
     const uint32_t e = occ_ref[off];
     if (e & PB_GONE) continue;                                              // (a node that is gone is not "the same node again")
-    const uint32_t t = e & 0x1FFFu;
+    const uint32_t t = e & 0xFFFFFu;
     if ((off > so && t == sn) || (off < ko && t == kn)) S.why = 2;             // ambiguous source / sink: no anchors
   }
   if (bl_bcast(&S.why)) return;
@@ -306,7 +371,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     };
     for (int which = 0; which < 2; ++which) {
       const uint32_t oc = occ_ref[which == 0 ? so : ko];
-      const uint32_t x = NPOS[oc & 0x1FFFu], ori = oc >> 31;
+      const uint32_t x = NPOS[oc & ON_ID], ori = oc >> 31;
       const uint32_t sdir = which == 0 ? (ori ? 1u : 0u) : (ori ? 0u : 3u);     // source: FF, or FR when the k-mer is reversed ; sink: RR, or FF
       const char cut = which == 0 ? (ori ? 'F' : 'R') : (ori ? 'R' : 'F');       // the edges that start in this direction go
       for (int i = (int)NE[x] - 1; i >= 0; --i) {
@@ -468,7 +533,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
   WG_SYNC();
   if (nheads > PB_CHEADS || need > PB_CSEQ || nabs > PB_CMAX) return;
   // per node: its k-mer's figures (what compress_prepare keeps in a CmpRec)
-  auto node_key = [&](uint32_t u, uint32_t *ci_out) -> unsigned long long { const uint32_t ci = CI[u]; *ci_out = ci; return skey[ci]; };
+  auto node_key = [&](uint32_t u, uint32_t *ci_out) -> unsigned long long { const uint32_t ci = CI[u]; *ci_out = ci; return skey[(size_t)ci * PL.kw]; };      // (K <= 31 here: one word)
   const uint32_t top = ncand * (uint32_t)K;                                     // the window kernel's arena top for a graph from here
   BLPA(S, 8);
   // ---- every merged k-mer: its head, side, place in the merge order; descriptor into the head's deque, coverage into its slice
@@ -633,6 +698,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
 DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *Bp, LC_GLOBAL const EngineCaps *C, BL_S &S, LC_GLOBAL uint8_t *xbase,
                            LC_GLOBAL uint8_t *area, int w, int kmin, LC_GLOBAL const PreHdr *rep) {
   LC_GLOBAL const DevBatch &B = *Bp;
+  LC_GLOBAL const PreLayout &PL = C->pl;
   BlScratch X; bl_scratch_carve(&X, xbase);                       // (a local of this function: its pointers live in registers)
   LC_GLOBAL PreHdr *H = (LC_GLOBAL PreHdr *)(area + PRE_OFF_HDR);
   const uint32_t g0 = B.read_begin[w];
@@ -699,11 +765,15 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     }
     S.K = K;
     H->refE = S.repE; H->refM = S.repM; H->mapped = (uint32_t)S.mapped; H->have_rep = 1;          // (the window kernel does not repeat the scan)
-    if (K == 0 || K > 31 || (K & 1) == 0) S.why = BLW_K;
+    if (K == 0 || (K & 1) == 0) S.why = BLW_K;
+    else if (2 * K > 64 * (int)PL.kw) S.why = BLW_K;                     // (the batch's hand-off areas hold one-word keys)
+    else if (K > BL_KMAX) S.why = BLW_KBIG;                              // (the 1024-lane configuration takes it off the list)
   }
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
   const int K = (int)bl_bcast(&S.K);
-  const unsigned long long kmask = (1ULL << (2 * K)) - 1ULL;
+  const int NW = (2 * K + 63) / 64;                                      // 64-bit words of a k-mer
+  const unsigned long long kmask = K < 32 ? (1ULL << (2 * K)) - 1ULL : ~0ULL;   // (one-word form: K <= 31)
+  (void)kmask; (void)NW;
   const int R = nr + 1;
   BLP(S, 3);
   if (C->debug_stop == 103u) { WG_LANE0 { H->why = 99; } return; }
@@ -780,6 +850,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   // probe starts (a probe is a chain of dependent LDS round trips; with two workgroups per CU little else hides them).  A table word read
   // early can be out of date by the time its probe looks at it: an empty word is then settled by the compare-and-swap, an occupied one only
   // ever changes to an earlier occurrence of the same k-mer.
+#if BL_KW == 1
   WG_FOR(_t, BL_WG) {
     const int O_ = (int)S.O;
     for (int o0 = _t; o0 < O_; o0 += BL_INS * BL_WG) {
@@ -837,10 +908,66 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
           if (++probes > 256u) { S.why = BLW_TABLE; break; }
           cur = ld2(&tab[idx]);
         }
-        X.occn[boff] = (uint16_t)(idx | (isF ? 0u : 0x8000u));
+        X.occn[boff] = (bl_on_t)(idx | (isF ? 0u : ON_ORI));
       }
     }
   }
+#else
+  // The general form (k-mers of NW <= BL_KW words): the same probe; only offsets, table positions and fingerprints are kept per occurrence in
+  // flight -- on a fingerprint hit both k-mers are cut out of LDS again and compared word by word.
+  WG_FOR(_t, BL_WG) {
+    const int O_ = (int)S.O;
+    for (int o0 = _t; o0 < O_; o0 += BL_INS * BL_WG) {
+      int rr[BL_INS]; uint32_t bo[BL_INS], ix[BL_INS], fpv[BL_INS], cu[BL_INS]; bool fF[BL_INS];
+      for (int u = 0; u < BL_INS; ++u) {
+        const int o = o0 + u * BL_WG;
+        const int oc = o < O_ ? o : O_ - 1;
+        uint32_t rc = S.o2r[oc >> 7];
+        while ((uint32_t)oc >= S.obase[rc + 1]) ++rc;
+        rr[u] = o < O_ ? (int)rc : -1; bo[u] = 16u * S.rdo[rc] + (uint32_t)(oc - (int)S.obase[rc]);
+      }
+      for (int u = 0; u < BL_INS; ++u) {
+        BlKm v, ck, alt; bl_kmer_x(S.bases, bo[u], NW, K, v); bl_canon_x(v, NW, K, ck, alt, &fF[u]);
+        unsigned long long acc = ck.w[0];
+        for (int i = 1; i < BL_KW; ++i) if (i < NW) acc = (acc ^ (acc >> 29)) * 0x9E3779B97F4A7C15ULL + ck.w[i];
+        uint32_t hh = (uint32_t)acc * 0x9E3779B1u ^ (((uint32_t)(acc >> 32)) ^ ((uint32_t)acc >> 15)) * 0x85EBCA77u;
+        hh ^= hh >> 15; hh *= 0x2C1B3C6Du; hh ^= hh >> 12;
+        ix[u] = hh & (BL_SLOTS - 1);
+        uint32_t fp = hh >> BL_OFFBITS; if (fp == (0xFFFFFFFFu >> BL_OFFBITS)) fp -= 1u;
+        fpv[u] = fp;
+      }
+      for (int u = 0; u < BL_INS; ++u) cu[u] = ld2(&tab[ix[u]]);
+      for (int u = 0; u < BL_INS; ++u) {
+        if (rr[u] < 0) continue;
+        const int r = rr[u]; const uint32_t boff = bo[u], fp = fpv[u]; const bool isF = fF[u];
+        const uint32_t mine = (fp << BL_OFFBITS) | boff;
+        uint32_t idx = ix[u], cur = cu[u], probes = 0;
+        bool have = false; BlKm v1, alt;
+        while (true) {
+          if (cur == BL_EMPTY) { cur = dev_atomic_cas32(&tab[idx], BL_EMPTY, mine); if (cur == BL_EMPTY) break; }
+          if ((cur >> BL_OFFBITS) == fp) {
+            if (!have) { BlKm ck; bool f; bl_kmer_x(S.bases, boff, NW, K, v1); bl_canon_x(v1, NW, K, ck, alt, &f); have = true; }
+            BlKm v2; bl_kmer_x(S.bases, cur & BL_OFFMASK, NW, K, v2);
+            const bool same = bl_km_eq(v2, v1);
+            if (same || bl_km_eq(v2, alt)) {
+              const bool f2 = same ? isF : !isF;
+              if (mine < cur) dev_atomic_min(&tab[idx], mine);
+              if (cur != mine && ((f2 != isF) || (r < nr && (cur & BL_OFFMASK) - 16u * S.rdo[r] < (uint32_t)RI_TLEN(S.rinfo[r])))) {     // (the hint: see the one-word form)
+                const uint32_t di = dev_atomic_add((LC_LDS uint32_t *)&S.ndup, 1u);
+                if (di < BL_DUPCAP) X.dupo[di] = (bl_off_t)boff;
+              }
+              break;
+            }
+          }
+          idx = (idx + 1) & (BL_SLOTS - 1);
+          if (++probes > 256u) { S.why = BLW_TABLE; break; }
+          cur = ld2(&tab[idx]);
+        }
+        X.occn[boff] = (bl_on_t)(idx | (isF ? 0u : ON_ORI));
+      }
+    }
+  }
+#endif
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
   BLP(S, 5);
   if (C->debug_stop == 105u) { WG_LANE0 { H->why = 99; } return; }
@@ -848,20 +975,16 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   {
     // bitmap over the LDS offsets of first occurrences (cidx is idle here) + its popcount prefix per PAIR of words (t2c is idle too)
     constexpr int NBW = BL_BASES / 32 + 1, NPW = (NBW + 1) / 2;
-    constexpr bool in_big = (size_t)NBW * 4 > sizeof(S.cidx) || (size_t)NPW * 4 > sizeof(S.t2c);      // (the larger configuration: behind the table in S.big)
-    static_assert(!in_big || (size_t)BL_SLOTS * 4 + (size_t)NBW * 4 + (size_t)NPW * 4 <= (size_t)BL_BIG, "node-id bitmap / prefix fit neither cidx / t2c nor S.big");
-    LC_LDS uint32_t *bm = in_big ? S.big + BL_SLOTS : (LC_LDS uint32_t *)S.cidx;
-    LC_LDS uint32_t *pre = in_big ? S.big + BL_SLOTS + NBW : (LC_LDS uint32_t *)S.t2c;
+    static_assert((size_t)(NBW + NPW) * 4 <= sizeof(S.cidx), "node-id bitmap + prefix in cidx");
+    LC_LDS uint32_t *bm = (LC_LDS uint32_t *)S.cidx;
+    LC_LDS uint32_t *pre = bm + NBW;
     WG_FOR(i, NBW) { bm[i] = 0; }
-#if BL_OFFBITS > 16
-    WG_FOR(i, PB_NCAP / 32 + 1) { S.idhi[i] = 0; }
-#endif
     WG_SYNC();
     WG_FOR(i, BL_SLOTS) { const uint32_t e = tab[i]; if (e != BL_EMPTY) dev_atomic_or(&bm[(e & BL_OFFMASK) >> 5], 1u << (e & 31u)); }
     WG_SYNC();
     WG_FOR(i, NPW) { pre[i] = (uint32_t)dev_popc(bm[2 * i]) + (2 * i + 1 < NBW ? (uint32_t)dev_popc(bm[2 * i + 1]) : 0u); }
     bl_scan32(pre, NPW, S);
-    WG_LANE0 { S.N = S.scan_total; if (S.scan_total > PB_NCAP) S.why = BLW_NODES; }
+    WG_LANE0 { S.N = S.scan_total; if (S.scan_total > BL_NCAP || S.scan_total > PL.ncap) S.why = BLW_NODES; }
     if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
     WG_FOR(i, BL_SLOTS) {
       const uint32_t e = tab[i];
@@ -869,9 +992,10 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
         const uint32_t off = e & BL_OFFMASK, wd = off >> 5;
         const uint32_t id = pre[wd >> 1] + ((wd & 1u) ? (uint32_t)dev_popc(bm[wd - 1u]) : 0u) + (uint32_t)dev_popc(bm[wd] & ((1u << (off & 31u)) - 1u));
         tab[i] = id;                                             // slot -> node id, occurrence count in the upper half (below)
+#if BL_WIDE
+        X.idoff[id] = off;
+#else
         S.idoff[id] = (uint16_t)off;
-#if BL_OFFBITS > 16
-        if (off >> 16) dev_atomic_or(&S.idhi[id >> 5], 1u << (id & 31u));
 #endif
       }
     }
@@ -884,7 +1008,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
     (void)r; (void)p;
     const uint32_t old = dev_atomic_add(&tab[e & (BL_SLOTS - 1)], 1u << 16);
-    X.occn[boff] = (uint16_t)((old & 0xFFFFu) | (e & 0x8000u));
+    X.occn[boff] = (bl_on_t)((old & 0xFFFFu) | (e & ON_ORI));
   });
   WG_SYNC();
   BLP(S, 7);
@@ -894,8 +1018,13 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     LC_GLOBAL unsigned long long *nhash = (LC_GLOBAL unsigned long long *)(area + PRE_OFF_NHASH);
     LC_GLOBAL uint8_t *surv = (LC_GLOBAL uint8_t *)(area + PRE_OFF_SURV);
     WG_FOR(n, N) {
-      bool f; const unsigned long long ck = bl_canon(bl_kmer(S.bases, bl_idoff(S, (uint32_t)n), kmask), K, kmask, &f);
+#if BL_KW == 1
+      bool f; const unsigned long long ck = bl_canon(bl_kmer(S.bases, bl_idoff(S, X, (uint32_t)n), kmask), K, kmask, &f);
       nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGT"[key_base(&ck, K, j)]; }, K);
+#else
+      BlKm v, ck, alt; bool f; bl_kmer_x(S.bases, bl_idoff(S, X, (uint32_t)n), NW, K, v); bl_canon_x(v, NW, K, ck, alt, &f);
+      nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGT"[bl_km_char(ck, K, j)]; }, K);
+#endif
       surv[n] = 0;
     }
   }
@@ -912,7 +1041,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       // with coverage 2 and is trimmed as a tip later: k is not rejected for it)
     const uint32_t nd = S.ndup < BL_DUPCAP ? S.ndup : BL_DUPCAP;
     const uint32_t cthr = (uint32_t)(avgcov / 4.0) > 4u ? (uint32_t)(avgcov / 4.0) : 4u;
-    WG_FOR(i, nd) { if ((uint32_t)S.cidx[X.occn[X.dupo[i]] & 0x1FFFu] < cthr) X.dupo[i] = (bl_off_t)~(bl_off_t)0; }
+    WG_FOR(i, nd) { if ((uint32_t)S.cidx[X.occn[X.dupo[i]] & ON_ID] < cthr) X.dupo[i] = (bl_off_t)~(bl_off_t)0; }
   }
   {
     LC_LDS uint32_t *fl = S.big;                                 // (the table is no longer needed: occn holds node ids)
@@ -944,7 +1073,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
       (void)boff;
       if (r == nr) return;                                         // the reference read: no colour, never counted (Graph.cc:265)
-      const uint32_t ti = S.cidx[e & 0x1FFFu];
+      const uint32_t ti = S.cidx[e & ON_ID];
       if (ti == 0xFFFFu) return;
       const uint32_t ri = S.rinfo[r];
       const uint32_t cls = (RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u);
@@ -966,7 +1095,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     if (npairs) bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
       (void)boff;
       if (S.prole[r] != 2) return;
-      const uint32_t ti = S.cidx[e & 0x1FFFu];
+      const uint32_t ti = S.cidx[e & ON_ID];
       if (ti != 0xFFFFu && ((sig[ti * SW + (S.pidx[r] >> 6)] >> (S.pidx[r] & 63u)) & 1ULL)) {
         const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.flagged, 1u);
         if (at < BL_FLAGCAP) todo[at] = ((uint32_t)r << 10) | (uint32_t)p;
@@ -998,7 +1127,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
         bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
           (void)boff;
           if (r == nr) return;
-          const uint32_t ti = S.cidx[e & 0x1FFFu];
+          const uint32_t ti = S.cidx[e & ON_ID];
           if (ti == 0xFFFFu || ti < t_lo || ti >= t_hi || !((mk[ti >> 5] >> (ti & 31u)) & 1u)) return;
           const uint32_t mt = RI_MATE(S.rinfo[r]);
           if (mt != 1 && mt != 2) return;
@@ -1036,7 +1165,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
         const uint32_t r = todo[fi] >> 10, p = todo[fi] & 1023u;
         const uint32_t boff = 16u * S.rdo[r] + p;
         const uint32_t e = X.occn[boff];
-        const uint32_t ti = S.cidx[e & 0x1FFFu];
+        const uint32_t ti = S.cidx[e & ON_ID];
         if (ti < t_lo || ti >= t_hi) continue;
         const uint32_t ri = S.rinfo[r];
         const uint32_t mi = RI_MATE(ri), nm = B.name_rank[g0 + r] & 0xFFFFu;
@@ -1064,7 +1193,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
           BL_DBG("[emu] window %d: overlapping mate, read %u position %u (nodes %u..%u of %u)\n", w, r, p, t_lo, t_hi, T);
           const uint32_t cls = (RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u);
           dev_atomic_add64(&cc[ti], 0ULL - (1ULL << (16 * cls)));
-          X.occn[boff] = (uint16_t)(e | 0x4000u);
+          X.occn[boff] = (bl_on_t)(e | ON_OVL);
         }
       }
       WG_SYNC();
@@ -1094,7 +1223,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       fl[t] = cand;
     }
     bl_scan32(fl, (int)T + 1, S);
-    WG_LANE0 { S.ncand = S.scan_total; if (S.scan_total > PB_CCAP) S.why = BLW_CAND; else if ((size_t)S.scan_total * (size_t)K > PB_QVCAP) S.why = BLW_QV; }
+    WG_LANE0 { S.ncand = S.scan_total; if (S.scan_total > PB_CCAP) S.why = BLW_CAND; else if ((size_t)S.scan_total * (size_t)K > (size_t)PL.qvcap) S.why = BLW_QV; }
     if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
     WG_FOR(t, T) { S.t2c[t] = (fl[t + 1] != fl[t]) ? (uint16_t)fl[t] : (uint16_t)0xFFFFu; }
     WG_SYNC();
@@ -1162,19 +1291,19 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
         (void)boff;
         if (r == nr) return;
-        if (e & 0x4000u) return;                                     // an overlapping mate's occurrence: not counted
-        const uint32_t ti = S.cidx[e & 0x1FFFu];
+        if (e & ON_OVL) return;                                     // an overlapping mate's occurrence: not counted
+        const uint32_t ti = S.cidx[e & ON_ID];
         if (ti == 0xFFFFu) return;
         const uint32_t ci = S.t2c[ti];
         if (ci == 0xFFFFu) return;                                   // not a candidate
         if (ci >= c1 && c0 == 0) {                                   // a later group's: note it
           if (p > 1023 || r > 1023) { S.g1 = BL_PQCAP + 1u; return; }     // (does not fit an entry: the later groups walk everything)
           const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.g1, 1u);
-          if (at < BL_PQCAP) X.pq[at] = (uint32_t)r | ((uint32_t)p << 10) | (ci << 20) | ((e & 0x8000u) ? 0x80000000u : 0u);
+          if (at < BL_PQCAP) X.pq[at] = (uint32_t)r | ((uint32_t)p << 10) | (ci << 20) | ((e & ON_ORI) ? 0x80000000u : 0u);
           return;
         }
         if (ci < c0 || ci >= c1) return;
-        count_occ(r, p, ci, (e & 0x8000u) != 0);
+        count_occ(r, p, ci, (e & ON_ORI) != 0);
       });
       WG_SYNC();
       auto bad_of = [&](uint32_t t, int cl) -> uint32_t { return wide ? (uint32_t)((bad64[t] >> (16 * cl)) & 0xFFFFu) : ((bad32[t] >> (8 * cl)) & 0xFFu); };
@@ -1227,7 +1356,12 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       snode[ci] = sv ? n : LC_NIL;
       if (sv) {
         const uint32_t si = fl[ci];
-        bool f; skey[ci] = bl_canon(bl_kmer(S.bases, bl_idoff(S, (uint32_t)n), kmask), K, kmask, &f);
+#if BL_KW == 1
+        bool f; skey[(size_t)ci * PL.kw] = bl_canon(bl_kmer(S.bases, bl_idoff(S, X, (uint32_t)n), kmask), K, kmask, &f);
+#else
+        BlKm v, ck, alt; bool f; bl_kmer_x(S.bases, bl_idoff(S, X, (uint32_t)n), NW, K, v); bl_canon_x(v, NW, K, ck, alt, &f);
+        for (int i = 0; i < BL_KW; ++i) if (i < NW) skey[(size_t)ci * PL.kw + (uint32_t)i] = ck.w[i];
+#endif
         sid[si] = n; surv[n] = 1; X.s_ci[si] = (uint32_t)ci;
       }
     }
@@ -1242,18 +1376,18 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     LC_GLOBAL uint32_t *occ_ref = (LC_GLOBAL uint32_t *)(area + PRE_OFF_OCCREF);
     LC_GLOBAL uint16_t *refcov = (LC_GLOBAL uint16_t *)(area + PRE_OFF_REFCOV);
     LC_LDS uint32_t *inmer = S.big;                                // bitmap over node ids
-    WG_FOR(i, PB_NCAP / 32) { inmer[i] = 0; }
+    WG_FOR(i, BL_NCAP / 32) { inmer[i] = 0; }
     WG_FOR(j, reflen) { for (int q = 0; q < 4; ++q) refcov[4 * j + q] = 0; }
     WG_SYNC();
     const int nrefk = reflen - K > 0 ? reflen - K + 1 : 0;
     const uint32_t rb = 16u * S.rdo[nr];
     WG_FOR(i, reflen - K > 0 ? reflen - K : 0) {                   // i + K < seq.length()
-      const uint32_t n = X.occn[rb + (uint32_t)i] & 0x1FFFu;
+      const uint32_t n = X.occn[rb + (uint32_t)i] & ON_ID;
       dev_atomic_or(&inmer[n >> 5], 1u << (n & 31u));
     }
     WG_SYNC();
     WG_FOR(i, reflen - K > 0 ? reflen - K : 0) {                   // i + K < rawseq.length(): every one of them is in the table here
-      const uint32_t n = X.occn[rb + (uint32_t)i] & 0x1FFFu;
+      const uint32_t n = X.occn[rb + (uint32_t)i] & ON_ID;
       const uint32_t ti = S.cidx[n];
       unsigned long long c4 = 0;
       if (ti != 0xFFFFu) c4 = X.tcc[ti];
@@ -1263,10 +1397,10 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     }
     WG_LANE0 { S.refn = 0; }
     WG_SYNC();
-    WG_FOR(i, PB_NCAP / 32) { const uint32_t m = inmer[i]; if (m) dev_atomic_add((LC_LDS uint32_t *)&S.refn, (uint32_t)dev_popc(m)); }
+    WG_FOR(i, BL_NCAP / 32) { const uint32_t m = inmer[i]; if (m) dev_atomic_add((LC_LDS uint32_t *)&S.refn, (uint32_t)dev_popc(m)); }
     // survivor index per node from here on (the tracked index is in c_ti for every candidate)
     WG_SYNC();
-    LC_LDS uint32_t *inm2 = S.big + PB_NCAP / 32;                  // INMER per survivor: keep a copy of the bitmap while cidx changes meaning
+    LC_LDS uint32_t *inm2 = S.big + BL_NCAP / 32;                  // INMER per survivor: keep a copy of the bitmap while cidx changes meaning
     (void)inm2;
     WG_FOR(n, N) { S.cidx[n] = 0xFFFFu; }
     WG_SYNC();
@@ -1274,26 +1408,26 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_SYNC();
     {   // the hint: does a node that was met twice in a read / in both orientations survive?
       const uint32_t nd = S.ndup < BL_DUPCAP ? S.ndup : BL_DUPCAP;
-      WG_FOR(i, nd) { const bl_off_t o = X.dupo[i]; if (o != (bl_off_t)~(bl_off_t)0 && S.cidx[X.occn[o] & 0x1FFFu] != 0xFFFFu) S.hint = 1; }
+      WG_FOR(i, nd) { const bl_off_t o = X.dupo[i]; if (o != (bl_off_t)~(bl_off_t)0 && S.cidx[X.occn[o] & ON_ID] != 0xFFFFu) S.hint = 1; }
       WG_LANE0 { if (S.ndup > BL_DUPCAP) S.hint = 1; }
     }
     WG_SYNC();
     WG_FOR(i, nrefk) {
       const uint32_t e = X.occn[rb + (uint32_t)i];
-      const uint32_t n = e & 0x1FFFu;
-      occ_ref[i] = n | (S.cidx[n] != 0xFFFFu ? 0u : PB_GONE) | ((e & 0x8000u) ? 0x80000000u : 0u);
+      const uint32_t n = e & ON_ID;
+      occ_ref[i] = n | (S.cidx[n] != 0xFFFFu ? 0u : PB_GONE) | ((e & ON_ORI) ? 0x80000000u : 0u);
     }
   }
   BLP(S, 13);
   if (C->debug_stop == 113u) { WG_LANE0 { H->why = 99; } return; }
   // ---- trace only: edge count of every node before the filter (printStats over the whole table): distinct (side, base) slots
   if (C->evt_cap) {
-    LC_LDS uint32_t *msk = S.big + PB_NCAP / 32;                   // one byte per node, four nodes per word
-    WG_FOR(i, PB_NCAP / 4) { msk[i] = 0; }
+    LC_LDS uint32_t *msk = S.big + BL_NCAP / 32;                   // one byte per node, four nodes per word
+    WG_FOR(i, BL_NCAP / 4) { msk[i] = 0; }
     WG_LANE0 { S.edges_total = 0; }
     WG_SYNC();
     bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
-      const uint32_t n = e & 0x1FFFu, ori = e >> 15;
+      const uint32_t n = e & ON_ID, ori = (e >> ON_ORISH) & 1u;
       const int tlen = r < nr ? (int)RI_TLEN(S.rinfo[r]) : reflen;
       const int nk = tlen - K + 1;
       uint32_t m = 0;
@@ -1311,18 +1445,18 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   //      (side, extension base) slot with LDS atomicMin, groups of survivors that fit; stamp = 2 * offset of the step's u (+1 for
   //      the v side), offsets grow with (read, position) like the occurrence index of kernels.h
   {
-    LC_LDS uint32_t *inmer = S.big;                                // (kept: PB_NCAP / 32 words)
-    LC_LDS uint32_t *E = S.big + PB_NCAP / 32 + PB_NCAP / 4;       // [group][8]
-    const uint32_t gmax = (BL_BIG / 4u - PB_NCAP / 32u - PB_NCAP / 4u) / 8u;
+    LC_LDS uint32_t *inmer = S.big;                                // (kept: BL_NCAP / 32 words)
+    LC_LDS uint32_t *E = S.big + BL_NCAP / 32 + BL_NCAP / 4;       // [group][8]
+    const uint32_t gmax = (BL_BIG / 4u - BL_NCAP / 32u - BL_NCAP / 4u) / 8u;
     LC_GLOBAL NodeGr *pgr = (LC_GLOBAL NodeGr *)(area + PRE_OFF_PGR);
     for (uint32_t s0 = 0; s0 < nsurv; s0 += gmax) {
       const uint32_t s1 = s0 + gmax < nsurv ? s0 + gmax : nsurv;
       WG_FOR(i, (s1 - s0) * 8u) { E[i] = LC_NIL; }
       WG_SYNC();
       bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
-        const uint32_t si = S.cidx[e & 0x1FFFu];
+        const uint32_t si = S.cidx[e & ON_ID];
         if (si < s0 || si >= s1) return;
-        const uint32_t ori = e >> 15;
+        const uint32_t ori = (e >> ON_ORISH) & 1u;
         const int tlen = r < nr ? (int)RI_TLEN(S.rinfo[r]) : reflen;
         const int nk = tlen - K + 1;
         if (p + 1 < nk) {                                            // step p: this node is u
@@ -1347,10 +1481,10 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
         for (int i = 0; i < ne; ++i) {
           const uint32_t s = stamp[i] >> 1;
           const uint32_t a = X.occn[s], b = X.occn[s + 1];           // u and v of that step
-          const uint32_t ua = a >> 15, ub = b >> 15;
+          const uint32_t ua = (a >> ON_ORISH) & 1u, ub = (b >> ON_ORISH) & 1u;
           uint32_t to, dir;
-          if ((stamp[i] & 1u) == 0) { to = b & 0x1FFFu; dir = ua == 0 ? (ub == 0 ? 0u : 1u) : (ub == 0 ? 2u : 3u); }   // FF FR RF RR
-          else { to = a & 0x1FFFu; dir = ua == 0 ? (ub == 0 ? 3u : 1u) : (ub == 0 ? 2u : 0u); }                         // RR FR RF FF
+          if ((stamp[i] & 1u) == 0) { to = b & ON_ID; dir = ua == 0 ? (ub == 0 ? 0u : 1u) : (ub == 0 ? 2u : 3u); }   // FF FR RF RR
+          else { to = a & ON_ID; dir = ua == 0 ? (ub == 0 ? 3u : 1u) : (ub == 0 ? 2u : 0u); }                         // RR FR RF FF
           if (S.cidx[to] == 0xFFFFu) continue;                       // removeNode of a non-survivor took the edge with it
           X.s_edges[9 * (size_t)si + (uint32_t)m] = S.cidx[to];     // (neighbour by survivor index: the component search below)
           G.edges[m++] = ED_MAKE(to, dir);
@@ -1510,7 +1644,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     // ---- the window's first graph with a single component: markRefEnds and the first compress here too (bl_compress_first)
     {
       const uint32_t hbc = bl_bcast(&S.g0), hnr = bl_bcast(&S.g1), ncomp = bl_bcast(&S.nbw);
-      if (!rep && ncomp == 1u && nsurv <= PB_CMAX && nsurv + 2u <= hnr && C->debug_stop != 140u)
+      if (!rep && ncomp == 1u && nsurv <= PB_CMAX && nsurv + 2u <= hnr && K <= 31 && C->debug_stop != 140u)
         bl_compress_first(P, C, S, X, area, K, N, nsurv, ncand, reflen, hbc);
     }
   }
@@ -1541,6 +1675,7 @@ DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
                            LC_GLOBAL uint8_t *scratch, LC_GLOBAL uint32_t *queue, BL_S &S, int slot, LC_GLOBAL unsigned long long *phase = nullptr,
                            LC_GLOBAL uint8_t *pool = nullptr, uint32_t pool_cap = 0, int depth = 0, LC_GLOBAL uint32_t *biglist = nullptr, bool from_list = false,
                            bool wait_all = false) {
+  LC_GLOBAL const PreLayout &PL = C->pl;
   LC_GLOBAL uint8_t *xbase = scratch + (size_t)slot * SCRATCH_BYTES;
   if (from_list && queue[4] == 0u) return;                       // (nothing was turned away for its size: the usual case at 30x)
   while (true) {
@@ -1582,7 +1717,7 @@ DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_LANE0 {
       LC_GLOBAL const PreHdr *Hw = (LC_GLOBAL const PreHdr *)(pre + (size_t)w * PRE_STRIDE);
       if (Hw->status == PB_BUILT) dev_atomic_add(queue + 1, 1u);
-      else if (!from_list && biglist && Hw->why == (uint32_t)BLW_SIZE) biglist[dev_atomic_add(queue + 4, 1u)] = (uint32_t)w;
+      else if (!from_list && biglist && (Hw->why == (uint32_t)BLW_SIZE || Hw->why == (uint32_t)BLW_KBIG)) biglist[dev_atomic_add(queue + 4, 1u)] = (uint32_t)w;
     }
     WG_SYNC();                                                     // (every lane's stores to the hand-off area are issued ...)
     if (!from_list) { WG_LANE0 { add_rel(queue + 7, 1u); } }       // (... and released with the count)
@@ -1602,6 +1737,7 @@ DEV void svc_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBa
                          LC_GLOBAL uint8_t *scratch, LC_GLOBAL uint32_t *queue, BL_S &S, int slot, LC_GLOBAL uint8_t *pool, uint32_t pool_cap, int depth,
                          LC_GLOBAL SvcCtl *sv, LC_GLOBAL const uint32_t *wqueue = nullptr, LC_GLOBAL uint32_t *biglist = nullptr, int help_depth = -1,
                          LC_GLOBAL unsigned long long *phase = nullptr) {
+  LC_GLOBAL const PreLayout &PL = C->pl;
   LC_GLOBAL uint8_t *xbase = scratch + (size_t)slot * SCRATCH_BYTES;
   // Until the window kernel runs there is nothing to serve: the workgroup takes windows off the build kernel's queue like that kernel's own
   // (help_depth >= 0: graphs built ahead per window there; the build kernel waits for the windows taken here, build_kernel_body `wait_all`).

@@ -76,10 +76,10 @@ __global__ void svc_done_kernel(SvcCtl *sv) { __hip_atomic_store(&sv->done, 1u, 
 // Processing order of the window kernel: the windows the build kernel could not take (general build phases: slow) and those
 // with a read that repeats a k-mer (a tandem duplication: k will climb over several builds) first, so that the few long-running
 // windows do not end up as the tail of the launch.  Only the order changes; results are sorted by (window, emission) afterwards.
-__global__ void order_kernel(const uint8_t *pre, int n_windows, uint32_t *list, uint32_t *cnt) {
+__global__ void order_kernel(const uint8_t *pre, uint32_t stride, int n_windows, uint32_t *list, uint32_t *cnt) {
   const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (w >= n_windows) return;
-  const PreHdr *H = (const PreHdr *)(pre + (size_t)w * PRE_STRIDE + PRE_OFF_HDR);
+  const PreHdr *H = (const PreHdr *)(pre + (size_t)w * stride + PRE_OFF_HDR);
   const bool first = H->status != PB_BUILT ? (H->why != BLW_NOREADS) : (H->heavy != 0);
   if (first) list[atomicAdd(&cnt[0], 1u)] = (uint32_t)w;
   else list[(uint32_t)n_windows - 1u - atomicAdd(&cnt[1], 1u)] = (uint32_t)w;
@@ -215,6 +215,7 @@ struct lancet_engine {
   float ms_pack = 0;
   bool dbg = false, no_fat = false, no_early_rerun = false, no_large_build = false;     // LANCET_DEBUG / LANCET_NO_FAT / ... read once, at create
   int build_slots_env = 0, ahead_depth_env = -1;
+  int pre_wide_env = -1;           // LANCET_PRE_WIDE=0 / 1: the narrow / wide form of the hand-off areas whatever the batch looks like
   uint32_t evt_cap = 0;
   size_t mem_budget = (size_t)96 << 30;
   int max_slots = 5120;      // work-space slots = resident single-wave workgroups: 5 per SIMD (96 VGPRs, < 8 KB LDS each) x 4 SIMDs x CUs
@@ -317,6 +318,7 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (const char *s = getenv("LANCET_BUILD_SLOTS")) e->build_slots_env = std::max(1, atoi(s));
   if (const char *s = getenv("LANCET_AHEAD_DEPTH")) e->ahead_depth_env = std::max(0, std::min(16, atoi(s)));
   if (const char *s = getenv("LANCET_SVC_HELP")) e->svc_help = atoi(s) != 0;
+  if (const char *s = getenv("LANCET_PRE_WIDE")) e->pre_wide_env = atoi(s) != 0 ? 1 : 0;
   if (const char *s = getenv("LANCET_SVC_WGS")) e->n_svc_wgs = std::max(0, std::min(256, atoi(s)));
   if (const char *s = getenv("LANCET_SVC_DEPTH")) e->svc_depth = std::max(0, std::min(16, atoi(s)));
   if (p->lr_mode) e->prebuild = false;                         // --linked-reads: barcode / haplotype bookkeeping lives in the general build only
@@ -405,6 +407,12 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
   e->caps2.var_cap = e->caps.var_cap; e->caps2.blob_cap = e->caps.blob_cap; e->caps2.bx_cap = e->caps.bx_cap;
   e->caps.debug_stop = e->debug_stop;
   e->caps.table_start = e->caps2.table_start = e->table_start;
+  {   // hand-off areas of the LDS build kernel: narrow or wide (host_common.h lc_pre_layout_for_batch), one per window + the pool
+    const bool use_svc0 = e->svc && e->n_svc_wgs > 0 && !e->debug_stop;
+    const int depth0 = e->ahead_depth_env >= 0 ? e->ahead_depth_env : 6;
+    const size_t n_areas = (size_t)nw + (depth0 > 0 ? (size_t)std::max(64, nw / 4) : 0) + (use_svc0 ? (size_t)std::max(64, nw / 8) : 0);
+    e->caps.pl = e->caps2.pl = lc_pre_layout_for_batch(b, n_areas, (size_t)20 << 30, e->pre_wide_env);
+  }
   // ---- inputs
   UP(e->d_params, &e->params, sizeof(lancet_params));
   DevBatch db;
@@ -619,7 +627,7 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
     const bool svc_helps = e->svc && e->n_svc_wgs > 0 && !e->debug_stop && e->svc_help;
     e->n_bslots = std::max(1, std::min(nw, cus * 2 - 2 - (svc_helps ? std::min(e->n_svc_wgs, cus) : 0)));
     if (e->build_slots_env) e->n_bslots = std::min(nw, e->build_slots_env);
-    ENS(e->d_pre, (size_t)nw * PRE_STRIDE);
+    ENS(e->d_pre, (size_t)nw * e->caps.pl.stride);
     ENS(e->d_blscratch, (size_t)e->n_bslots * bl_small::SCRATCH_BYTES);
     // Can any window be too big for the 512-lane configuration?  Trimming only shortens reads, so the untrimmed lengths bound the
     // LDS footprint (reads padded to 16 bases + the reference); when none can, the 1024-lane kernel is not launched at all.
@@ -632,7 +640,7 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
       const uint64_t raw = (uint64_t)(b->seq_off[r1] - b->seq_off[r0]) + 15ull * (r1 - r0) + (b->ref_off[w + 1] - b->ref_off[w]) + 16u;
       if (r1 - r0 > bl_small::LDS_READS || raw > (uint64_t)bl_small::LDS_BASES) ++n_need_large;
     }
-    may_need_large = n_need_large > 0;
+    may_need_large = n_need_large > 0 || e->caps.pl.kw > 1;      // (wide hand-off areas: windows whose first k is above 31 go to the 1024-lane configuration too)
     e->n_bslots_large = (e->no_large_build || !may_need_large) ? 0 : std::min(nw, cus);
     if (e->n_bslots_large) { ENS(e->d_blscratch_large, (size_t)e->n_bslots_large * bl_large::SCRATCH_BYTES); ENS(e->d_biglist, sizeof(uint32_t) * (size_t)nw); }
     ENS(e->d_blphase, 16 * sizeof(unsigned long long));
@@ -657,7 +665,7 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
       e->svc_host.cont = (LC_GLOBAL SvcCont *)((char *)e->d_svc.p + off_cont);
       o.svc = (LC_GLOBAL SvcCtl *)e->d_svc.p;
     }
-    if (e->pool_cap) { ENS(e->d_prepool, (size_t)e->pool_cap * PRE_STRIDE); o.pre_pool = (LC_GLOBAL const uint8_t *)e->d_prepool.p; o.n_ahead_used = (LC_GLOBAL uint32_t *)e->d_counters.p + 14; }
+    if (e->pool_cap) { ENS(e->d_prepool, (size_t)e->pool_cap * e->caps.pl.stride); o.pre_pool = (LC_GLOBAL const uint8_t *)e->d_prepool.p; o.n_ahead_used = (LC_GLOBAL uint32_t *)e->d_counters.p + 14; }
   }
   UP(e->d_out, &o, sizeof(o));
   DBG("sync");
@@ -738,7 +746,7 @@ static int lc_submit_body(lancet_engine *e) {
       if (e->dbg) { HIPCHK(e, hipStreamSynchronize(e->stream)); DBG("build_kernel_large done"); }
     }
     if (e->heavy_first) {
-      hipLaunchKernelGGL(order_kernel, dim3((e->n_windows + 255) / 256), dim3(256), 0, e->stream, (const uint8_t *)e->d_pre.p, e->n_windows, (uint32_t *)e->d_order.p,
+      hipLaunchKernelGGL(order_kernel, dim3((e->n_windows + 255) / 256), dim3(256), 0, e->stream, (const uint8_t *)e->d_pre.p, e->caps.pl.stride, e->n_windows, (uint32_t *)e->d_order.p,
                          (uint32_t *)e->d_counters.p + 16);
       HIPCHK(e, hipGetLastError());
     }
@@ -1062,7 +1070,7 @@ int lancet_debug_pre_headers(lancet_engine *e, uint32_t *out) {
   if (!e || !e->uploaded || !e->d_pre.p) return LANCET_E_STATE;
   std::vector<PreHdr> h(1);
   for (int w = 0; w < e->n_windows; ++w) {
-    if (hipMemcpy(h.data(), (const uint8_t *)e->d_pre.p + (size_t)w * PRE_STRIDE + PRE_OFF_HDR, sizeof(PreHdr), hipMemcpyDeviceToHost) != hipSuccess) return LANCET_E_STATE;
+    if (hipMemcpy(h.data(), (const uint8_t *)e->d_pre.p + (size_t)w * e->caps.pl.stride + PRE_OFF_HDR, sizeof(PreHdr), hipMemcpyDeviceToHost) != hipSuccess) return LANCET_E_STATE;
     out[8 * w] = h[0].status | (h[0].why << 8); out[8 * w + 1] = h[0].K; out[8 * w + 2] = h[0].heavy; out[8 * w + 3] = h[0].N;
     out[8 * w + 4] = h[0].nsurv; out[8 * w + 5] = h[0].numcomp; out[8 * w + 6] = h[0].ncand; out[8 * w + 7] = h[0].next;
   }

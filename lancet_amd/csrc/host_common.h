@@ -14,6 +14,32 @@ static inline uint32_t lc_bucket_cap_for(uint32_t nodes) {
   return 2938680u;
 }
 
+// Layout of one hand-off area of the LDS build kernel (layout.h PreLayout): `ncap` distinct k-mers, `qvcap` (candidate, position)
+// quality rows, `kw` words per candidate key.
+static inline PreLayout lc_pre_layout(uint32_t ncap, uint32_t qvcap, uint32_t kw) {
+  PreLayout L; memset(&L, 0, sizeof(L));
+  L.ncap = ncap; L.qvcap = qvcap; L.kw = kw;
+  uint32_t o = PRE_OFF_REFCOV + 8u * LC_MAXW;
+  auto take = [&](uint32_t bytes, uint32_t align) { o = (o + align - 1u) & ~(align - 1u); const uint32_t at = o; o += bytes; return at; };
+  L.nhash = take(8u * ncap, 64u); L.surv = take(ncap, 64u);
+  L.snode = take(4u * PB_CCAP, 64u); L.skey = take(8u * kw * PB_CCAP, 64u); L.sid = take(4u * PB_SCAP, 64u);
+  L.pgr = take(128u * PB_SCAP, 128u); L.order = take(4u * PB_SCAP, 64u); L.qv = take(8u * qvcap, 64u);
+  L.chdr = take(64u, 64u); L.clive = take(4u * (PB_CMAX + 2u), 64u); L.cseq = take(4u * PB_CSEQ, 64u);
+  L.stride = (o + 255u) & ~255u;
+  return L;
+}
+// Which form a batch gets: the wide one (PB_NCAP_WIDE k-mers, keys of 4 words, PB_QVCAP_WIDE rows: windows of 100x / 40x build at
+// k = 31..101 with 9-12 k distinct k-mers) when its windows are deep (more than 400 reads on average: 60x / 60x windows, ~360 reads, all fit the narrow form) and `n_areas` of them stay
+// within `budget` bytes; else the narrow one.  LANCET_PRE_WIDE=0 / 1 forces either (read by the caller, passed as `force`).
+static inline PreLayout lc_pre_layout_for_batch(const lancet_window_batch *b, size_t n_areas, size_t budget, int force = -1) {
+  const PreLayout narrow = lc_pre_layout(PB_NCAP, PB_QVCAP, 1u), wide = lc_pre_layout(PB_NCAP_WIDE, PB_QVCAP_WIDE, LC_NWMAX);
+  if (force == 0 || b->n_windows <= 0) return narrow;
+  if (force == 1) return wide;
+  const uint32_t R = b->read_begin[b->n_windows];
+  const bool deep = R / (uint32_t)b->n_windows > 400u;
+  return (deep && n_areas * (size_t)wide.stride <= budget) ? wide : narrow;
+}
+
 // Work-space caps for a batch: the largest window decides.
 // tier 1 = the common case (small tables: cheap to clear, cache/TLB friendly); tier 2 = worst case for the window
 // shapes in the batch, used to re-run the windows that overflowed tier 1.
@@ -68,6 +94,7 @@ static inline EngineCaps lc_caps_for_batch(const lancet_window_batch *b, const l
   c.blob_cap = (uint32_t)b->n_windows * 4096u + (4u << 20);
   c.lr_mode = p->lr_mode ? 1u : 0u;
   c.bx_cap = c.lr_mode ? (uint32_t)b->n_windows * 8192u + (1u << 20) : 0u;
+  c.pl = lc_pre_layout(PB_NCAP, PB_QVCAP, 1u);      // (the engine replaces it per upload: lc_pre_layout_for_batch)
   return c;
 }
 

@@ -89,7 +89,8 @@ struct WinShared {
   int cmp_done;                                  // the graph came with markRefEnds and the first compress done (build_lds_impl.h bl_compress_first)
   uint32_t cmp_dead, cmp_edges0, cmp_nsurv;      // ... its cleanDead count, the survivors' edge total before markRefEnds (trace), the survivors
   int seq_lazy;                                  // graph from the LDS build kernel: the k-mer nodes' descriptors are not written yet (seq_materialize)
-  unsigned long long lz_area;                    // ... its hand-off area (candidate keys)
+  unsigned long long lz_area;                    // ... its hand-off area
+  unsigned long long lz_skey; uint32_t lz_kw;    // ... the candidate keys there, words per key
   int mr_src, mr_snk, mr_ambs, mr_ambk;          // mark_ref_scan: first / last qualifying reference offset, ambiguity flags
   int QS, LR;                                    // counters per (survivor, position): 4, or 10 with --linked-reads ; lr_mode
   unsigned long long t_last, phase_acc[16];
@@ -282,6 +283,12 @@ DEV bool key_less(const unsigned long long *a, const unsigned long long *b, int 
   for (int w = NW - 1; w >= 0; --w) { if (a[w] != b[w]) return a[w] < b[w]; }
   return false;
 }
+// j-th character of candidate ci's key in a hand-off area of the LDS build kernel (layout.h PRE_OFF_SKEY: `kw` words per candidate)
+DEV int pre_key_base(LC_GLOBAL const unsigned long long *skey, uint32_t kw, uint32_t ci, int K, int j) {
+  const int bit = 2 * (K - 1 - j);
+  return (int)((skey[(size_t)ci * kw + (uint32_t)(bit >> 6)] >> (bit & 63)) & 3ULL);
+}
+#define LC_PL(c) (LC_CTX(c).C->pl)
 
 // ---------------------------------------------------------------------------------------------------------
 // K0: reference repeat scan.  isRepeat / isAlmostRepeat (reference src/util.cc:295-360) for every k at once:
@@ -2150,24 +2157,23 @@ DEV bool l0_tandem(const GrLine0 &g, uint32_t self) {
 }
 // descriptor i of candidate ci's k-mer while the descriptors are not materialised (load_prebuilt)
 DEV uint32_t seq_desc_lazy(const LC_WS &S, uint32_t node, uint32_t ci, int K, int i) {
-  LC_GLOBAL const unsigned long long *skey = (LC_GLOBAL const unsigned long long *)((LC_GLOBAL const uint8_t *)(uintptr_t)S.lz_area + PRE_OFF_SKEY);
-  const unsigned long long kk = skey[ci];
-  return SD_MAKE(node, i, key_base(&kk, K, i));
+  return SD_MAKE(node, i, pre_key_base((LC_GLOBAL const unsigned long long *)(uintptr_t)S.lz_skey, S.lz_kw, ci, K, i));
 }
 // all lanes: write every survivor's descriptors (what load_prebuilt used to do), for the routes that read W.seq of k-mer nodes directly
 DEVNI void seq_materialize_all(Ctx &c) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   if (!wg_bcast(&S.seq_lazy)) return;
+  LC_GLOBAL const PreLayout &PL = LC_PL(c);
   LC_GLOBAL const uint8_t *area = (LC_GLOBAL const uint8_t *)(uintptr_t)S.lz_area;
   LC_GLOBAL const PreHdr *H = (LC_GLOBAL const PreHdr *)(area + PRE_OFF_HDR);
   LC_GLOBAL const uint32_t *snode = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_SNODE);
   LC_GLOBAL const unsigned long long *skey = (LC_GLOBAL const unsigned long long *)(area + PRE_OFF_SKEY);
   const int K = wg_uniform(S.K);
-  const uint32_t ncand = H->ncand;
+  const uint32_t ncand = H->ncand, kw = PL.kw;
   WG_FOR(t, ncand * (uint32_t)K) {
     const uint32_t ci = (uint32_t)t / (uint32_t)K; const int i = (int)((uint32_t)t % (uint32_t)K);
     const uint32_t n = snode[ci];
-    if (n != LC_NIL) { const unsigned long long kk = skey[ci]; W.seq[t] = SD_MAKE(n, i, key_base(&kk, K, i)); }
+    if (n != LC_NIL) W.seq[t] = SD_MAKE(n, i, pre_key_base(skey, kw, ci, K, i));
   }
   WG_LANE0 { S.seq_lazy = 0; }
   WG_SYNC();
@@ -2196,9 +2202,7 @@ DEVNI void compress_prepare(Ctx &c, int comp) {
     const GrLine0 BF = gr_line0(&gr[bF]), BR = gr_line0(&gr[bR]);
     uint32_t d0, dK;
     if (lazy && seq_lo == nqv * (uint32_t)K) {                  // (a k-mer node of a graph from the LDS build kernel: its descriptors follow from its key)
-      LC_GLOBAL const unsigned long long *skey = (LC_GLOBAL const unsigned long long *)((LC_GLOBAL const uint8_t *)(uintptr_t)S.lz_area + PRE_OFF_SKEY);
-      const unsigned long long kk = skey[nqv];
-      d0 = SD_MAKE(n, 0, key_base(&kk, K, 0)); dK = SD_MAKE(n, K - 1, key_base(&kk, K, K - 1));
+      d0 = seq_desc_lazy(S, n, nqv, K, 0); dK = seq_desc_lazy(S, n, nqv, K, K - 1);
     } else { d0 = seq[seq_lo]; dK = seq[seq_lo + (uint32_t)(K - 1)]; }
     LC_GLOBAL const uint16_t *q0p = qv + ((size_t)nqv * K + 0) * QS, *qKp = qv + ((size_t)nqv * K + (size_t)(K - 1)) * QS;
     const int tq0 = (int)q0p[0] + (int)q0p[1] + (int)q0p[2] + (int)q0p[3], tqK = (int)qKp[0] + (int)qKp[1] + (int)qKp[2] + (int)qKp[3];
@@ -4421,6 +4425,7 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   LC_GLOBAL const uint8_t *pre = LC_CTX(c).OUT->pre;
   if (!pre) return false;
+  LC_GLOBAL const PreLayout &PL = LC_PL(c);
   LC_GLOBAL const uint8_t *area = pre + (size_t)S.w * PRE_STRIDE;
   LC_GLOBAL const PreHdr *H = (LC_GLOBAL const PreHdr *)(area + PRE_OFF_HDR);
   // the window's first graph, or one the build kernel built ahead for a later k of this loop (PreHdr::next)
@@ -4502,8 +4507,7 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
       // a k-mer node that stayed on its own: its K descriptors (the merged ones are in the heads' deques, the heads' own k-mers too)
       const uint32_t nqv = r[7].x, slo = r[5].z, shi = r[5].w;
       if (!sp && nqv != LC_NIL && slo == nqv * (uint32_t)K && shi == slo + (uint32_t)K) {
-        const unsigned long long kk = skey[nqv];
-        for (int t = 0; t < K; ++t) W.seq[slo + (uint32_t)t] = SD_MAKE(id, t, key_base(&kk, K, t));
+        for (int t = 0; t < K; ++t) W.seq[slo + (uint32_t)t] = SD_MAKE(id, t, pre_key_base(skey, PL.kw, nqv, K, t));
       }
     }
     { const uint32_t base = ncand * (uint32_t)K; WG_FOR(i, seqn) { W.seq[base + (uint32_t)i] = cseq[i]; } }
@@ -4525,7 +4529,7 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
   // into a unitig by the first compress, which needs only the first and the last descriptor of a node -- both follow from its
   // key.  compress_prepare / compress_rank derive what they need (seq_desc_lazy) and write out the K descriptors of the few
   // nodes that stay on their own; any other route into the graph phases calls seq_materialize_all first.
-  WG_LANE0 { S.seq_lazy = 1; S.lz_area = (unsigned long long)(uintptr_t)area; }
+  WG_LANE0 { S.seq_lazy = 1; S.lz_area = (unsigned long long)(uintptr_t)area; S.lz_skey = (unsigned long long)(uintptr_t)skey; S.lz_kw = PL.kw; }
   (void)snode; (void)skey;
   }
   WG_FOR(i, (N + 3) / 4) { ((LC_GLOBAL uint32_t *)W.survb)[i] = ((LC_GLOBAL const uint32_t *)surv)[i]; }
@@ -4580,10 +4584,11 @@ DEVNI bool try_suspend(Ctx &c, int k) {
   LC_GLOBAL SvcCtl *sv = LC_CTX(c).OUT->svc;
   if (!sv) return false;
   const int w = wg_uniform(S.w);
+  LC_GLOBAL const PreLayout &PL = LC_PL(c);
   WG_LANE0 {
     S.tmp1 = 0;
     LC_GLOBAL const PreHdr *H0 = (LC_GLOBAL const PreHdr *)(LC_CTX(c).OUT->pre + (size_t)w * PRE_STRIDE + PRE_OFF_HDR);
-    if (k != S.nosusp_k && (k & 1) && k <= 31 && !S.overflow && LC_CTX(c).OUT->pre_pool && H0->status == PB_BUILT && (!H0->big || sv->large)) {
+    if (k != S.nosusp_k && (k & 1) && (k <= 31 || (sv->large && 2 * k <= 64 * (int)PL.kw)) && !S.overflow && LC_CTX(c).OUT->pre_pool && H0->status == PB_BUILT && (!H0->big || sv->large)) {
       const uint32_t i = dev_atomic_add(&sv->req_alloc, 1u);
       if (i < sv->cap) { S.tmp1 = 1; S.svc_i = i; }
     }
@@ -4613,6 +4618,7 @@ DEVNI bool try_suspend(Ctx &c, int k) {
 // ---------------------------------------------------------------------------------------------------------
 DEV void process_window(Ctx &c, int w, int rq = -1) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W; LC_GLOBAL const DevBatch &B = *LC_CTX(c).B;
+  LC_GLOBAL const PreLayout &PL = LC_PL(c);
   WG_LANE0 {
     S.items_ready = 0;
     S.w = w; S.overflow = 0; S.evt_len = 0; S.emit_seq = 0; S.n_kmers = 0; S.max_nodes = 0; S.n_builds = 0; S.N_last = 0; S.final_k = 0;

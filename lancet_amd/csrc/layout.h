@@ -69,6 +69,11 @@
 #define CS_ST(c) (((c) >> 27) & 3u)   /* 0 counted, 1 candidate (needs the mate-overlap replay), 2 suppressed */
 #define CS_MAKE(r, p, ori, st) ((uint32_t)(r) | ((uint32_t)(p) << 16) | ((uint32_t)(ori) << 26) | ((uint32_t)(st) << 27))
 
+struct PreLayout {
+  uint32_t ncap, qvcap, kw;
+  uint32_t nhash, surv, snode, skey, sid, pgr, order, qv, chdr, clive, cseq;
+  uint32_t stride, pad;
+};
 struct EngineCaps {
   uint32_t reads_cap;    /* reads per window (incl. the reference pseudo-read)            */
   uint32_t occ_cap;      /* k-mer occurrences per (window, k)                              */
@@ -89,6 +94,7 @@ struct EngineCaps {
   uint32_t table_start;  /* testing only: first table size of every build (power of two; 0 = estimated)       */
   uint32_t lr_mode;      /* --linked-reads: 10 instead of 4 counters per (survivor, position), barcode outputs */
   uint32_t bx_cap;       /* barcode ids (u32) of the variants' barcode sets, whole batch (lr_mode)   */
+  struct PreLayout pl;   /* hand-off areas of the LDS build kernel (below)                           */
 };
 
 /* device-resident batch (after upload + prep) */
@@ -152,10 +158,12 @@ struct CmpRec {
  * first removeLowCov, their per-position quality counts, the reference pseudo-read's node per offset and the reference
  * coverage.  A window the LDS limits do not hold (or that needs the mate-overlap replay, N handling, even k, k > 31) is marked
  * PB_NOT_BUILT and takes the general path (build phases of kernels.h in HBM). */
-#define PB_NCAP 5632          /* distinct k-mers per window (LDS table of 8192 slots)                          */
+#define PB_NCAP 5632          /* distinct k-mers per window of the narrow hand-off (512-lane build: LDS table of 8192 slots) */
+#define PB_NCAP_WIDE 14336    /* ... of the wide one (1024-lane build: 16384 slots)                             */
 #define PB_CCAP 2048          /* candidates: nodes not decided by their occurrence count alone                 */
 #define PB_SCAP 2048          /* survivors of the first removeLowCov                                          */
-#define PB_QVCAP 32768        /* (candidate, k-mer position) entries of per-position quality counts            */
+#define PB_QVCAP 32768        /* (candidate, k-mer position) entries of per-position quality counts, narrow hand-off */
+#define PB_QVCAP_WIDE 196608  /* ... wide (2048 candidates at k = 96)                                           */
 #define PB_GONE 0x40000000u   /* occ_ref: the node of this reference k-mer did not survive the first removeLowCov (its id is still in the low bits) */
 #define PB_NOT_BUILT 0u
 #define PB_BUILT 1u
@@ -176,17 +184,27 @@ struct PreHdr {
   uint32_t big;               /* built by the 1024-lane configuration (the build service runs the 512-lane one)   */
   uint32_t pad[9];
 };
+/* The area's layout is fixed per engine upload, not per build: the front (header, reference arrays) is the same everywhere, the
+ * arrays behind it are sized by three numbers the host picks for the batch (host_common.h lc_pre_layout) -- `ncap` distinct k-mers
+ * a hand-off may hold, `qvcap` (candidate, position) quality rows, `kw` 64-bit words per candidate key (1: k <= 31; 4: k <= 127).
+ * A batch of deep windows (100x / 40x: 9-12 k distinct k-mers at k = 31..101) gets the wide form, the bulk of a 30x scan the narrow
+ * one (660 KB per window instead of 1.7 MB).  Kernel code reads the offsets through `PL` (= EngineCaps::pl). */
 #define PRE_OFF_HDR 0u
 #define PRE_OFF_OCCREF 128u                                   /* u32[LC_MAXW]   node | ori << 31 per reference offset   */
 #define PRE_OFF_REFCOV (PRE_OFF_OCCREF + 4u * LC_MAXW)        /* u16[LC_MAXW*4]                                         */
-#define PRE_OFF_NHASH (PRE_OFF_REFCOV + 8u * LC_MAXW)         /* u64[PB_NCAP]   std::hash of every node, by node id     */
-#define PRE_OFF_SURV (PRE_OFF_NHASH + 8u * PB_NCAP)           /* u8[PB_NCAP]    1 = survivor                            */
-#define PRE_OFF_SNODE (PRE_OFF_SURV + PB_NCAP)                /* u32[PB_CCAP]   node of candidate ci (LC_NIL: not a survivor) */
-#define PRE_OFF_SKEY (PRE_OFF_SNODE + 4u * PB_CCAP)           /* u64[PB_CCAP]   its canonical k-mer                     */
-#define PRE_OFF_SID (PRE_OFF_SKEY + 8u * PB_CCAP)             /* u32[PB_SCAP]   node of survivor si                     */
-#define PRE_OFF_PGR (PRE_OFF_SID + 4u * PB_SCAP)              /* NodeGr[PB_SCAP] records of the survivors, dense        */
-#define PRE_OFF_ORDER (PRE_OFF_PGR + 128u * PB_SCAP)          /* u32[PB_SCAP]   the survivors in libstdc++ table order  */
-#define PRE_OFF_QV (PRE_OFF_ORDER + 4u * PB_SCAP)             /* u16[PB_QVCAP*4] rows of K positions per candidate      */
+#define PRE_OFF_VAR (PRE_OFF_REFCOV + 8u * LC_MAXW)           /* what follows is laid out by lc_pre_layout:             */
+#define PRE_OFF_NHASH (PL.nhash)                              /* u64[ncap]      std::hash of every node, by node id     */
+#define PRE_OFF_SURV (PL.surv)                                /* u8[ncap]       1 = survivor                            */
+#define PRE_OFF_SNODE (PL.snode)                              /* u32[PB_CCAP]   node of candidate ci (LC_NIL: not a survivor) */
+#define PRE_OFF_SKEY (PL.skey)                                /* u64[PB_CCAP * kw] its canonical k-mer, `kw` words each (right-aligned, low word first) */
+#define PRE_OFF_SID (PL.sid)                                  /* u32[PB_SCAP]   node of survivor si                     */
+#define PRE_OFF_PGR (PL.pgr)                                  /* NodeGr[PB_SCAP] records of the survivors, dense        */
+#define PRE_OFF_ORDER (PL.order)                              /* u32[PB_SCAP]   the survivors in libstdc++ table order  */
+#define PRE_OFF_QV (PL.qv)                                    /* u16[qvcap*4]   rows of K positions per candidate       */
+#define PRE_OFF_CHDR (PL.chdr)                                /* PreCmp                                                 */
+#define PRE_OFF_CLIVE (PL.clive)                              /* u32[PB_CMAX + 2]  record index (survivor index, or nsurv + k for special k) per table position */
+#define PRE_OFF_CSEQ (PL.cseq)                                /* u32[PB_CSEQ]                                           */
+#define PRE_STRIDE (PL.stride)
 /* ---- first compress done by the build kernel (build_lds_impl.h bl_compress_first): single-component first graphs ----
  * markRefEnds + the first Graph_t::compress of the component in LDS; the window kernel then loads the ~20 unitigs instead of ~600
  * k-mer nodes and starts at hasCycle.  PreCmp::done == 0: nothing here, the window kernel does both itself. */
@@ -205,10 +223,6 @@ struct PreCmp {
   unsigned long long spec_hash[2];   /* std::hash of "source1" / "sink1"                                               */
   uint32_t pad[4];
 };
-#define PRE_OFF_CHDR ((PRE_OFF_QV + 8u * PB_QVCAP + 63u) & ~63u)
-#define PRE_OFF_CLIVE (PRE_OFF_CHDR + 64u)                    /* u32[PB_CMAX + 2]  record index (survivor index, or nsurv + k for special k) per table position */
-#define PRE_OFF_CSEQ ((PRE_OFF_CLIVE + 4u * (PB_CMAX + 2u) + 63u) & ~63u)   /* u32[PB_CSEQ]                                  */
-#define PRE_STRIDE ((PRE_OFF_CSEQ + 4u * PB_CSEQ + 255u) & ~255u)
 
 /* One slot of work space.  All pointers are device pointers into one big allocation. */
 struct Work {

@@ -21,17 +21,26 @@ for _i, _c in enumerate(b"ACGT"):
 
 
 def _simulate(haps, probs, coverage: float, span: Tuple[int, int], rng, read_len: int, ins_mean: float, ins_sd: float,
-              err: float):
+              err: float, linked: bool = False):
     """Returns dict of arrays for all reads of one sample: seq[R,L] (ASCII), qual[R,L] (+33), pos0[R], end0[R],
-    frag[R], mate[R] (1|2), strand[R]."""
+    frag[R], mate[R] (1|2), strand[R]; linked: also bx[R] (barcode code of the fragment, -1: no BX tag) and hp[R] (0|1|2), drawn as
+    synth.simulate_sample draws them (a pool of n_frag / 3 barcodes, 10 % of the fragments without one; HP 0 for 30 %, else the haplotype
+    with 3 % phasing errors; 5 % of the reads without the tag)."""
     lo, hi = span
     n_frag = int(coverage * (hi - lo) / (2.0 * read_len))
     hsel = rng.choice(len(haps), size=n_frag, p=probs)
     ins = np.maximum(read_len, np.rint(rng.normal(ins_mean, ins_sd, size=n_frag)).astype(np.int64))
     s_ref = rng.integers(lo, np.maximum(lo + 1, hi - ins))
     first_fwd = rng.integers(0, 2, size=n_frag).astype(bool)
-    out = {k: [] for k in ("seq", "qual", "pos0", "end0", "frag", "mate", "strand")}
+    out = {k: [] for k in ("seq", "qual", "pos0", "end0", "frag", "mate", "strand") + (("bx", "hp") if linked else ())}
     ar = np.arange(read_len)
+    if linked:
+        rng_lr = np.random.default_rng(int(rng.integers(0, 2 ** 31)))
+        f_code = rng_lr.integers(0, max(4, n_frag // 3), size=n_frag).astype(np.int64)
+        f_code[rng_lr.random(n_frag) < 0.1] = -1
+        f_hp = np.where(rng_lr.random(n_frag) < 0.3, 0, np.where(hsel == 0, 1, 2)).astype(np.uint8)
+        flip = rng_lr.random(n_frag) < 0.03
+        f_hp = np.where(flip, np.where(f_hp == 0, 1, 3 - f_hp), f_hp).astype(np.uint8)
     for h, (hb, hp) in enumerate(haps):
         idx = np.nonzero(hsel == h)[0]
         if idx.size == 0:
@@ -62,6 +71,10 @@ def _simulate(haps, probs, coverage: float, span: Tuple[int, int], rng, read_len
             is_first = (which == 0) == first_fwd[idx[good]]
             out["mate"].append(np.where(is_first, 1, 2).astype(np.uint8))
             out["strand"].append(np.full(n, REV if which == 1 else FWD, dtype=np.uint8))
+            if linked:
+                fr = idx[good]
+                out["bx"].append(f_code[fr])
+                out["hp"].append(np.where(rng_lr.random(n) < 0.05, 0, f_hp[fr]).astype(np.uint8))
     res = {k: np.concatenate(v) for k, v in out.items()}
     order = np.lexsort((res["mate"], res["frag"], res["pos0"]))     # coordinate order, ties by name
     return {k: v[order] for k, v in res.items()}
@@ -70,7 +83,7 @@ def _simulate(haps, probs, coverage: float, span: Tuple[int, int], rng, read_len
 def make_scan_batch(n_windows: int, cov_t: float = 30.0, cov_n: float = 30.0, seed: int = 22, read_len: int = 150,
                     window: int = 600, stride: int = 100, error_rate: float = 0.005, somatic_every: int = 2000,
                     germline_every: int = 1000, chrom: str = "chr22", str_fraction: float = 0.0,
-                    lowcomplex_fraction: float = 0.0) -> WindowBatch:
+                    lowcomplex_fraction: float = 0.0, linked: bool = False) -> WindowBatch:
     margin = 1000
     region_len = window + stride * (n_windows - 1)
     ref_len = region_len + 2 * margin
@@ -83,8 +96,8 @@ def make_scan_batch(n_windows: int, cov_t: float = 30.0, cov_n: float = 30.0, se
     rng_t = np.random.default_rng(seed + 101)
     rng_n = np.random.default_rng(seed + 202)
     span = (margin - 400, margin + region_len + 400)
-    T = _simulate([h0, h1, h2], [0.5, 0.25, 0.25], cov_t, span, rng_t, read_len, 400.0, 40.0, error_rate)
-    N = _simulate([h0, h1], [0.5, 0.5], cov_n, span, rng_n, read_len, 400.0, 40.0, error_rate)
+    T = _simulate([h0, h1, h2], [0.5, 0.25, 0.25], cov_t, span, rng_t, read_len, 400.0, 40.0, error_rate, linked)
+    N = _simulate([h0, h1], [0.5, 0.5], cov_n, span, rng_n, read_len, 400.0, 40.0, error_rate, linked)
     ref_b = np.frombuffer(ref.encode(), dtype=np.uint8)
     starts = margin + 1 + stride * np.arange(n_windows, dtype=np.int64)          # Ref_t::refstart (1-based)
     sel_idx: List[np.ndarray] = []
@@ -107,10 +120,21 @@ def make_scan_batch(n_windows: int, cov_t: float = 30.0, cov_n: float = 30.0, se
         sel_idx.append(parts[1][1]); sel_lab.append(np.full(nn, NML, dtype=np.uint8))
         read_begin[w + 1] = read_begin[w] + nt + nn
     labels = np.concatenate(sel_lab)
-    seqs, quals, strand, mate = [], [], [], []
+    seqs, quals, strand, mate, bxs, hps = [], [], [], [], [], []
     for i, k in enumerate(sel_idx):
         S = T if (i % 2 == 0) else N
         seqs.append(S["seq"][k]); quals.append(S["qual"][k]); strand.append(S["strand"][k]); mate.append(S["mate"][k])
+        if linked:
+            c = S["bx"][k]
+            bxs.append(np.where(c >= 0, 2 * c + (i % 2), -1)); hps.append(S["hp"][k])      # (the two samples' barcodes: disjoint names)
+    lr = {}
+    if linked:
+        code = np.concatenate(bxs) if bxs else np.zeros(0, dtype=np.int64)
+        uniq, inv = np.unique(code[code >= 0], return_inverse=True)                          # names "B%012d-1": string order = numeric order
+        rank = np.full(code.shape, 0xFFFFFFFF, dtype=np.uint32)
+        rank[code >= 0] = inv.astype(np.uint32)
+        lr = dict(bx_rank=rank, hp=np.concatenate(hps).astype(np.uint8) if hps else np.zeros(0, dtype=np.uint8),
+                  bx_names=[f"B{int(u):012d}-1" for u in uniq])
     seq = np.concatenate(seqs).reshape(-1)
     qual = np.concatenate(quals).reshape(-1)
     R = int(read_begin[-1])
@@ -122,7 +146,7 @@ def make_scan_batch(n_windows: int, cov_t: float = 30.0, cov_n: float = 30.0, se
         ref_bases=np.concatenate(refs).copy(), read_begin=read_begin,
         seq_off=(read_len * np.arange(R + 1, dtype=np.uint64)).astype(np.uint32), seq=np.ascontiguousarray(seq),
         qual=np.ascontiguousarray(qual), label=labels, strand=np.concatenate(strand), mate=np.concatenate(mate),
-        mapped=np.ones(R, dtype=np.uint8), name_rank=np.concatenate(ranks) if ranks else np.zeros(0, dtype=np.uint32))
+        mapped=np.ones(R, dtype=np.uint8), name_rank=np.concatenate(ranks) if ranks else np.zeros(0, dtype=np.uint32), **lr)
 
 
 def sub_batch(b: WindowBatch, w0: int, w1: int) -> WindowBatch:
@@ -158,6 +182,22 @@ def concat_batches(parts) -> WindowBatch:
         chr_id=cat("chr_id"), ref_start=cat("ref_start"), ref_off=offs("ref_off", None), ref_bases=cat("ref_bases"),
         read_begin=offs("read_begin", None), seq_off=offs("seq_off", None), seq=cat("seq"), qual=cat("qual"), label=cat("label"),
         strand=cat("strand"), mate=cat("mate"), mapped=cat("mapped"), name_rank=cat("name_rank"))
+
+
+def algorithmic_bytes_split(b: WindowBatch, stats, n_variants: int):
+    """The same bytes by the kernel whose work they are: (graph construction -- reads, reference, 16 B per k-mer occurrence: the LDS build
+    kernel; graph passes, paths, alignment, records -- 40 B per node, 128 B per variant: the window kernel).  Their sum is algorithmic_bytes."""
+    build = win = 0
+    lens = np.diff(b.seq_off.astype(np.int64))
+    per_read = (lens + 3) // 4 + lens
+    csum = np.concatenate([[0], np.cumsum(per_read)])
+    for w in range(b.n_windows):
+        st = stats[w]
+        W = int(b.ref_off[w + 1] - b.ref_off[w])
+        reads_b = int(csum[int(b.read_begin[w + 1])] - csum[int(b.read_begin[w])])
+        build += st["n_builds"] * (reads_b + (W + 3) // 4 + W // 8) + 16 * st["n_kmers"]
+        win += st["n_builds"] * 40 * st["max_nodes"]
+    return int(build), int(win + 128 * n_variants)
 
 
 def algorithmic_bytes(b: WindowBatch, stats, n_variants: int) -> int:

@@ -29,6 +29,7 @@ struct EmuResult {
 extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batch *b, uint32_t evt_cap) {
   EngineCaps C = getenv("LANCET_EMU_TIER1") ? lc_caps_for_batch(b, P, evt_cap, 16384, 1)      // (the engine's tier-1 work space: to see which limit a window hits there)
                                             : lc_caps_for_batch(b, P, evt_cap, 65536);
+  C.pl = lc_pre_layout_for_batch(b, 1, (size_t)1 << 40, getenv("LANCET_PRE_WIDE") ? atoi(getenv("LANCET_PRE_WIDE")) : -1);      // (engine.hip lc_upload)
   if (const char *ts = getenv("LANCET_TABLE_START")) C.table_start = lc_pow2_ge((uint32_t)atoi(ts));
   if (const char *st = getenv("LANCET_STOP_PHASE")) C.debug_stop = (uint32_t)atoi(st);
   const uint32_t R = b->read_begin[b->n_windows];
@@ -69,15 +70,15 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   O.pre = nullptr; O.pre_pool = nullptr; O.n_ahead_used = &res->n_ahead_used;
   res->n_prebuilt = 0; res->n_ahead_built = 0; res->n_ahead_used = 0; res->n_biglist = 0;
   if (!P->lr_mode && !getenv("LANCET_NO_PREBUILD") && b->n_windows > 0) {
-    pre.assign((size_t)b->n_windows * PRE_STRIDE, 0xCD); blscr.assign(bl_large::SCRATCH_BYTES + 256, 0xCD);
+    pre.assign((size_t)b->n_windows * C.pl.stride, 0xCD); blscr.assign(bl_large::SCRATCH_BYTES + 256, 0xCD);
     memset(&BS, 0xCD, sizeof(BS)); memset(&BSL, 0xCD, sizeof(BSL));
     std::vector<uint32_t> biglist((size_t)b->n_windows + 1, 0);
     const bool large = getenv("LANCET_NO_LARGE_BUILD") == nullptr;
     depth = getenv("LANCET_AHEAD_DEPTH") ? atoi(getenv("LANCET_AHEAD_DEPTH")) : 6;
     pool_cap = (uint32_t)(b->n_windows / 4 + (depth > 0 ? 8 : 0) + (getenv("LANCET_NO_SVC") ? 0 : (b->n_windows < 128 ? 4 * b->n_windows + 24 : 536)));
-    if (pool_cap) pool.assign((size_t)pool_cap * PRE_STRIDE, 0xCD);
+    if (pool_cap) pool.assign((size_t)pool_cap * C.pl.stride, 0xCD);
     if (getenv("LANCET_EMU_FORCE_LARGE")) {                     // (test hook: every window through the 1024-lane configuration)
-      for (int w = 0; w < b->n_windows; ++w) { biglist[(size_t)w] = (uint32_t)w; PreHdr *H = (PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); H->status = PB_NOT_BUILT; H->why = 0; H->have_rep = 0; H->heavy = 0; H->next = 0; }
+      for (int w = 0; w < b->n_windows; ++w) { biglist[(size_t)w] = (uint32_t)w; PreHdr *H = (PreHdr *)(pre.data() + (size_t)w * C.pl.stride); H->status = PB_NOT_BUILT; H->why = 0; H->have_rep = 0; H->heavy = 0; H->next = 0; }
       bq[4] = (uint32_t)b->n_windows;
     } else
     bl_small::build_kernel_body(P, &B, &C, pre.data(), blscr.data(), bq, BS, 0, nullptr, pool_cap ? pool.data() : nullptr, pool_cap, depth, large ? biglist.data() : nullptr, false);
@@ -92,11 +93,11 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
     O.pre = pre.data(); O.pre_pool = pool_cap ? pool.data() : nullptr;
     res->n_prebuilt = bq[1]; res->n_ahead_built = bq[3];
     res->n_cmp_done = 0;
-    for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); const PreCmp *CH = (const PreCmp *)(pre.data() + (size_t)w * PRE_STRIDE + PRE_OFF_CHDR); if (H->status == PB_BUILT && CH->done == 1u) ++res->n_cmp_done; }
+    for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * C.pl.stride); const PreCmp *CH = (const PreCmp *)(pre.data() + (size_t)w * C.pl.stride + C.pl.chdr); if (H->status == PB_BUILT && CH->done == 1u) ++res->n_cmp_done; }
     if (getenv("LANCET_EMU_CMP")) fprintf(stderr, "[emu] first compress done by the build kernel: %u of %u built windows\n", res->n_cmp_done, bq[1]);
-    if (getenv("LANCET_EMU_HEAVY")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); if (H->status == PB_BUILT && H->heavy) fprintf(stderr, "[emu] heavy %d K %d\n", w, H->K); }
-    if (getenv("LANCET_EMU_HDR")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); fprintf(stderr, "[emu] hdr %d status %u K %d refE %d refM %d heavy %u next %u\n", w, H->status, H->K, H->refE, H->refM, H->heavy, H->next); }
-    if (getenv("LANCET_EMU_WHY")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * PRE_STRIDE); if (H->status != PB_BUILT) fprintf(stderr, "[emu] window %d not prebuilt: why %u\n", w, H->why); }
+    if (getenv("LANCET_EMU_HEAVY")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * C.pl.stride); if (H->status == PB_BUILT && H->heavy) fprintf(stderr, "[emu] heavy %d K %d\n", w, H->K); }
+    if (getenv("LANCET_EMU_HDR")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * C.pl.stride); fprintf(stderr, "[emu] hdr %d status %u K %d refE %d refM %d heavy %u next %u\n", w, H->status, H->K, H->refE, H->refM, H->heavy, H->next); }
+    if (getenv("LANCET_EMU_WHY")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * C.pl.stride); if (H->status != PB_BUILT) fprintf(stderr, "[emu] window %d not prebuilt: why %u\n", w, H->why); }
   }
   static thread_local WinShared S;
   memset(&S, 0xCD, sizeof(S));

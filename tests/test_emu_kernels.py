@@ -353,6 +353,29 @@ def test_deep_windows_through_the_1024_lane_build_configuration(monkeypatch):
     assert emu.LAST_PREBUILT[0] == 60
 
 
+def test_deep_str_windows_build_in_lds_at_k_above_31(monkeypatch):
+    """BASELINE config 4 (100x tumor / 40x normal over STR-rich sequence): the windows that find a k build at k = 33..101 with 8-12 k
+    distinct k-mers.  The 1024-lane configuration cuts k-mers of up to four 64-bit words out of the LDS reads (CanonicalMer_t::set,
+    reference src/Mer.hh:57-71, on multi-word keys), holds 14 336 nodes under a 16 384-slot table and hands candidate keys over in
+    `kw` words (wide hand-off areas): every window that builds is built there, records / stats / trace equal the oracle's.  With the
+    narrow areas forced (one-word keys) the same windows take the general build: same results."""
+    from lancet_amd import workload
+    p = abi.default_params()
+    seen = set()
+    for seed, n in ((22, 60), (202, 64)):
+        b = workload.make_scan_batch(n, 100.0, 40.0, seed=seed, str_fraction=0.30, lowcomplex_fraction=0.05)
+        st = _same_as_oracle(b, p)
+        builds = sum(1 for s in st if s["n_builds"] > 0)
+        assert builds >= 20 and emu.LAST_PREBUILT[0] == builds, (builds, emu.LAST_PREBUILT)
+        seen |= {(2 * s["final_k"] + 63) // 64 for s in st if s["status"] == 0}
+        assert max(s["max_nodes"] for s in st) > 8192
+    assert seen >= {2, 3, 4}, seen                                # two-, three- and four-word k-mers all occurred
+    monkeypatch.setenv("LANCET_PRE_WIDE", "0")
+    b = workload.make_scan_batch(24, 100.0, 40.0, seed=22, str_fraction=0.30, lowcomplex_fraction=0.05)
+    _same_as_oracle(workload.sub_batch(b, 12, 24), p)
+    assert emu.LAST_PREBUILT[0] == 0
+
+
 def test_mate_overlap_replay_in_ranges_of_nodes(monkeypatch):
     """hasOverlappingMate's exact replay in the LDS build kernel sorts the occurrences of the marked nodes in an LDS list; when they do
     not fit, the nodes are taken in ranges.  170-base reads at a 400 +- 40 insert: a tenth of the pairs overlap (~200 occurrences in

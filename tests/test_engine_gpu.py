@@ -88,6 +88,24 @@ def test_deep_windows_through_the_1024_lane_build_configuration():
         assert (built == 0) if off else (built == 160), built        # (all: the 1024-lane configuration's replay list holds the 6417 occurrences of windows 94-96)
 
 
+def test_deep_str_windows_build_in_lds_at_k_above_31():
+    """BASELINE config 4 on the device: 100x / 40x windows over STR-rich sequence build at k = 33..101 with 8-12 k distinct k-mers -- in
+    LDS, by the 1024-lane configuration (multi-word k-mers, 16 384-slot table, wide hand-off areas); equal to the oracle, twice."""
+    from lancet_amd import workload
+    batch = workload.make_scan_batch(192, 100.0, 40.0, seed=22, str_fraction=0.30, lowcomplex_fraction=0.05)
+    p = abi.default_params()
+    ov, ostats, _ = oracle.run(batch, p)
+    key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
+    builds = sum(1 for s in ostats if s["n_builds"] > 0)
+    assert builds > 60 and max(s["final_k"] for s in ostats) > 95
+    eng = engine.Engine(p, device=0)
+    for _ in range(2):
+        variants, stats = eng.process(batch)
+        assert variants == ov and [key(s) for s in stats] == [key(s) for s in ostats]
+        assert eng.prebuilt_count() >= (9 * builds) // 10 and eng.rerun_count() == 0, (eng.prebuilt_count(), builds, eng.rerun_count())
+    eng.close()
+
+
 def test_very_deep_windows_use_17_bit_offsets_in_lds():
     """100x/100x windows at a low error rate: ~640 reads, ~100 k bases with every read padded to 16 -- LDS offsets above 65 535 in the
     1024-lane build configuration (15-bit fingerprint over a 17-bit offset in the k-mer table); all built in LDS, equal to the oracle."""
