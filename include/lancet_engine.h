@@ -250,6 +250,16 @@ int  lancet_vdb_add(lancet_vdb *db, const lancet_variant *v, uint32_t n, const c
 int  lancet_vdb_add_lr(lancet_vdb *db, const lancet_variant *v, const lancet_variant_lr *lr, uint32_t n, const char *blob,
                        const uint32_t *bx_blob, const char *const *bx_names, uint32_t n_bx,
                        const char *const *chr_names, int32_t n_chr);
+/* Keys where the records are made, inserts where the VariantDB lives (a multi-GPU run: every rank keys its own records, rank 0 merges):
+ * lancet_vdb_keys writes the 32 raw sha256 bytes addVar keys its map with (reference src/VariantDB.cc:36-40, Variant_t::getSignature
+ * src/Variant.cc:339-344) per record; lancet_vdb_add_keyed is lancet_vdb_add / lancet_vdb_add_lr (lr, bx_blob, bx_names may be null)
+ * with those keys given.  Keys that do not belong to the records are the caller's error (not checked). */
+int  lancet_vdb_keys(const lancet_variant *v, uint32_t n, const char *blob, const char *const *chr_names, int32_t n_chr, uint8_t *keys);
+/* keep[i] = 1 for the records of a keyed stream that can change a VariantDB (per key: the first, and the first that reaches the key's
+ * largest total coverage; reference src/VariantDB.cc:45-88); a rank drops the others before its records travel to the merging rank. */
+int  lancet_vdb_reduce(const lancet_variant *v, const uint8_t *keys, uint32_t n, uint8_t *keep);
+int  lancet_vdb_add_keyed(lancet_vdb *db, const lancet_variant *v, const lancet_variant_lr *lr, const uint8_t *keys, uint32_t n, const char *blob,
+                          const uint32_t *bx_blob, const char *const *bx_names, uint32_t n_bx, const char *const *chr_names, int32_t n_chr);
 uint32_t lancet_vdb_size(const lancet_vdb *db);
 /* Writes the VCF (header + sorted body) into a malloc'd string the caller frees with lancet_free.
  * date_line: text after "##fileDate=" (ctime() format incl. trailing newline), may be NULL -> omitted. */

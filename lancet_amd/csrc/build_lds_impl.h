@@ -844,13 +844,15 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   if (C->debug_stop == 104u) { WG_LANE0 { H->why = 99; } return; }
   // ---- pass 1: every k-mer into the table (first occurrence kept), slot per occurrence to HBM
   LC_LDS uint32_t *tab = S.big;
-  WG_FOR(i, BL_SLOTS) { tab[i] = BL_EMPTY; }
+  // (a batch with narrow hand-off areas holds at most PB_NCAP nodes per window: 8192 slots do, as in the 512-lane configuration)
+  const uint32_t nslots = (PL.ncap > PB_NCAP || BL_SLOTS < 8192u) ? (uint32_t)BL_SLOTS : 8192u;
+  WG_FOR(i, nslots) { tab[i] = BL_EMPTY; }
   WG_SYNC();
   // BL_INS occurrences per lane at a time: their k-mers are cut out of LDS, hashed and their first table words read before the first
   // probe starts (a probe is a chain of dependent LDS round trips; with two workgroups per CU little else hides them).  A table word read
   // early can be out of date by the time its probe looks at it: an empty word is then settled by the compare-and-swap, an occupied one only
   // ever changes to an earlier occurrence of the same k-mer.
-#if BL_KW == 1
+  if (BL_KW == 1 || NW == 1) {       // one-word k-mers (k <= 31): the form below; else the general one behind it
   WG_FOR(_t, BL_WG) {
     const int O_ = (int)S.O;
     for (int o0 = _t; o0 < O_; o0 += BL_INS * BL_WG) {
@@ -874,7 +876,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
         // table hash on 32-bit words (the table is private to this pass: node ids come from first-occurrence offsets, not slots)
         uint32_t hh = (uint32_t)ck * 0x9E3779B1u ^ (((uint32_t)(ck >> 32)) ^ ((uint32_t)ck >> 15)) * 0x85EBCA77u;
         hh ^= hh >> 15; hh *= 0x2C1B3C6Du; hh ^= hh >> 12;
-        ix[u] = hh & (BL_SLOTS - 1);
+        ix[u] = hh & (nslots - 1);
         uint32_t fp = hh >> BL_OFFBITS; if (fp == (0xFFFFFFFFu >> BL_OFFBITS)) fp -= 1u;
         fpv[u] = fp;
       }
@@ -904,7 +906,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
               break;
             }
           }
-          idx = (idx + 1) & (BL_SLOTS - 1);
+          idx = (idx + 1) & (nslots - 1);
           if (++probes > 256u) { S.why = BLW_TABLE; break; }
           cur = ld2(&tab[idx]);
         }
@@ -912,7 +914,9 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       }
     }
   }
-#else
+  }
+#if BL_KW > 1
+  else {
   // The general form (k-mers of NW <= BL_KW words): the same probe; only offsets, table positions and fingerprints are kept per occurrence in
   // flight -- on a fingerprint hit both k-mers are cut out of LDS again and compared word by word.
   WG_FOR(_t, BL_WG) {
@@ -932,7 +936,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
         for (int i = 1; i < BL_KW; ++i) if (i < NW) acc = (acc ^ (acc >> 29)) * 0x9E3779B97F4A7C15ULL + ck.w[i];
         uint32_t hh = (uint32_t)acc * 0x9E3779B1u ^ (((uint32_t)(acc >> 32)) ^ ((uint32_t)acc >> 15)) * 0x85EBCA77u;
         hh ^= hh >> 15; hh *= 0x2C1B3C6Du; hh ^= hh >> 12;
-        ix[u] = hh & (BL_SLOTS - 1);
+        ix[u] = hh & (nslots - 1);
         uint32_t fp = hh >> BL_OFFBITS; if (fp == (0xFFFFFFFFu >> BL_OFFBITS)) fp -= 1u;
         fpv[u] = fp;
       }
@@ -959,13 +963,14 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
               break;
             }
           }
-          idx = (idx + 1) & (BL_SLOTS - 1);
+          idx = (idx + 1) & (nslots - 1);
           if (++probes > 256u) { S.why = BLW_TABLE; break; }
           cur = ld2(&tab[idx]);
         }
         X.occn[boff] = (bl_on_t)(idx | (isF ? 0u : ON_ORI));
       }
     }
+  }
   }
 #endif
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
@@ -980,13 +985,13 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     LC_LDS uint32_t *pre = bm + NBW;
     WG_FOR(i, NBW) { bm[i] = 0; }
     WG_SYNC();
-    WG_FOR(i, BL_SLOTS) { const uint32_t e = tab[i]; if (e != BL_EMPTY) dev_atomic_or(&bm[(e & BL_OFFMASK) >> 5], 1u << (e & 31u)); }
+    WG_FOR(i, nslots) { const uint32_t e = tab[i]; if (e != BL_EMPTY) dev_atomic_or(&bm[(e & BL_OFFMASK) >> 5], 1u << (e & 31u)); }
     WG_SYNC();
     WG_FOR(i, NPW) { pre[i] = (uint32_t)dev_popc(bm[2 * i]) + (2 * i + 1 < NBW ? (uint32_t)dev_popc(bm[2 * i + 1]) : 0u); }
     bl_scan32(pre, NPW, S);
     WG_LANE0 { S.N = S.scan_total; if (S.scan_total > BL_NCAP || S.scan_total > PL.ncap) S.why = BLW_NODES; }
     if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
-    WG_FOR(i, BL_SLOTS) {
+    WG_FOR(i, nslots) {
       const uint32_t e = tab[i];
       if (e != BL_EMPTY) {
         const uint32_t off = e & BL_OFFMASK, wd = off >> 5;
@@ -1007,7 +1012,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   // ---- pass 2: slot -> node id per occurrence (HBM, streamed), occurrences per node
   bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
     (void)r; (void)p;
-    const uint32_t old = dev_atomic_add(&tab[e & (BL_SLOTS - 1)], 1u << 16);
+    const uint32_t old = dev_atomic_add(&tab[e & (nslots - 1)], 1u << 16);
     X.occn[boff] = (bl_on_t)((old & 0xFFFFu) | (e & ON_ORI));
   });
   WG_SYNC();
@@ -1018,13 +1023,14 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     LC_GLOBAL unsigned long long *nhash = (LC_GLOBAL unsigned long long *)(area + PRE_OFF_NHASH);
     LC_GLOBAL uint8_t *surv = (LC_GLOBAL uint8_t *)(area + PRE_OFF_SURV);
     WG_FOR(n, N) {
-#if BL_KW == 1
-      bool f; const unsigned long long ck = bl_canon(bl_kmer(S.bases, bl_idoff(S, X, (uint32_t)n), kmask), K, kmask, &f);
-      nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGT"[key_base(&ck, K, j)]; }, K);
-#else
+#if BL_KW > 1
+      if (NW > 1) {
       BlKm v, ck, alt; bool f; bl_kmer_x(S.bases, bl_idoff(S, X, (uint32_t)n), NW, K, v); bl_canon_x(v, NW, K, ck, alt, &f);
       nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGT"[bl_km_char(ck, K, j)]; }, K);
+      } else
 #endif
+      { bool f; const unsigned long long ck = bl_canon(bl_kmer(S.bases, bl_idoff(S, X, (uint32_t)n), kmask), K, kmask, &f);
+        nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGT"[key_base(&ck, K, j)]; }, K); }
       surv[n] = 0;
     }
   }
@@ -1035,7 +1041,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   int tmin = 1;
   while ((tmin <= P->low_cov_threshold) || ((double)tmin <= (P->min_cov_ratio * avgcov))) ++tmin;
   const uint32_t tthr = tmin < 2 ? (uint32_t)tmin : 2u;
-  WG_FOR(i, BL_SLOTS) { const uint32_t e = tab[i]; if (e != BL_EMPTY) S.cidx[e & 0xFFFFu] = (uint16_t)(e >> 16); }     // count by node id
+  WG_FOR(i, nslots) { const uint32_t e = tab[i]; if (e != BL_EMPTY) S.cidx[e & 0xFFFFu] = (uint16_t)(e >> 16); }     // count by node id
   WG_SYNC();
   {   // the hint's occurrences: only nodes with real coverage matter (a hairpin in one erroneous read survives removeLowCov
       // with coverage 2 and is trimmed as a tip later: k is not rejected for it)
@@ -1356,12 +1362,13 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       snode[ci] = sv ? n : LC_NIL;
       if (sv) {
         const uint32_t si = fl[ci];
-#if BL_KW == 1
-        bool f; skey[(size_t)ci * PL.kw] = bl_canon(bl_kmer(S.bases, bl_idoff(S, X, (uint32_t)n), kmask), K, kmask, &f);
-#else
+#if BL_KW > 1
+        if (NW > 1) {
         BlKm v, ck, alt; bool f; bl_kmer_x(S.bases, bl_idoff(S, X, (uint32_t)n), NW, K, v); bl_canon_x(v, NW, K, ck, alt, &f);
         for (int i = 0; i < BL_KW; ++i) if (i < NW) skey[(size_t)ci * PL.kw + (uint32_t)i] = ck.w[i];
+        } else
 #endif
+        { bool f; skey[(size_t)ci * PL.kw] = bl_canon(bl_kmer(S.bases, bl_idoff(S, X, (uint32_t)n), kmask), K, kmask, &f); }
         sid[si] = n; surv[n] = 1; X.s_ci[si] = (uint32_t)ci;
       }
     }

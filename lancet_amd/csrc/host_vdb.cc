@@ -20,6 +20,7 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #if defined(__x86_64__) || defined(__i386__)
@@ -142,7 +143,9 @@ bool Sha256::use_ni() {
 struct Dig {
   uint8_t b[32];
   bool operator<(const Dig &o) const { return memcmp(b, o.b, 32) < 0; }
+  bool operator==(const Dig &o) const { return memcmp(b, o.b, 32) == 0; }
 };
+struct DigHash { size_t operator()(const Dig &d) const { uint64_t x; memcpy(&x, d.b + 8, 8); return (size_t)x; } };   // (a digest is its own hash; byte 0 picks the shard)
 void sha256_bin(const char *p, size_t n, Dig &d) { Sha256 c; c.init(); c.update((const uint8_t *)p, n); c.digest(d.b); }
 
 // ---- FET_t
@@ -305,15 +308,18 @@ struct byPos {   // reference src/VariantDB.hh:37-54 (pairs by value there; same
 
 }  // namespace
 
-// The reference keeps one std::map.  Here it is cut into 16 by the first hex digit of the key (the top four bits of the
-// digest), so walking shard 0..15 in turn IS the single map's iteration order, and a batch of records replayed on rank 0
-// is hashed by all host threads and inserted one shard per thread.  Each shard sees its records in arrival order:
-// addVar's "larger total coverage replaces, first wins ties" is decided per key, and a key lives in exactly one shard.
+// The reference keeps one std::map, of which only two things are observable: addVar's per-key rule and the iteration order at the
+// end (it feeds printToVCF's unstable sort).  Here the table is cut into 16 by the first hex digit of the key (the top four bits of
+// the digest) and each shard is a HASH table (round 4: rank 0 replays 180 k records per 8-GPU step, and a red-black tree of
+// 32-byte keys cost it ~0.15 us per record); lancet_vdb_vcf sorts every shard's entries by key -- shard 0..15 in turn is then the
+// single map's iteration order.  A batch of records is inserted one shard per thread; each shard sees its records in arrival
+// order: addVar's "larger total coverage replaces, first wins ties" is decided per key, and a key lives in exactly one shard.
 static const int VDB_SHARDS = 16;
 struct lancet_vdb {
   lancet_filters fs;
   bool lr = false;             // VariantDB_t::LR_MODE
-  std::map<Dig, Variant> db[VDB_SHARDS];
+  struct alignas(128) Shard : std::unordered_map<Dig, Variant, DigHash> {};      // (a shard per cache line pair: neighbouring shards are filled by different threads)
+  Shard db[VDB_SHARDS];
   size_t size() const { size_t n = 0; for (int s = 0; s < VDB_SHARDS; ++s) n += db[s].size(); return n; }
 };
 static int vdb_threads() {
@@ -336,8 +342,24 @@ lancet_vdb *lancet_vdb_create(const lancet_filters *f) { lancet_vdb *d = new lan
 void lancet_vdb_destroy(lancet_vdb *db) { delete db; }
 uint32_t lancet_vdb_size(const lancet_vdb *db) { return db ? (uint32_t)db->size() : 0; }
 
+// keys of n records (step 1 of addVar: Variant_t's normalisation, getSignature, sha256), threads [0, T)
+static void vdb_keys(const lancet_variant *v, uint32_t n, const char *blob, const char *const *chr_names, Dig *key, int T) {
+  auto body = [&](int t) {
+    std::string ref, alt, sig; int pos; char type; unsigned short len;
+    for (uint32_t i = (uint32_t)((uint64_t)n * t / T), hi = (uint32_t)((uint64_t)n * (t + 1) / T); i < hi; ++i) {
+      Variant::normalise(v[i], blob, ref, alt, pos, type, len);
+      Variant::signature_into(sig, chr_names[v[i].chr_id], pos, type, len, ref, alt);
+      sha256_bin(sig.data(), sig.size(), key[i]);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back(body, t);
+  body(0);
+  for (auto &x : th) x.join();
+}
+
 static int vdb_add(lancet_vdb *db, const lancet_variant *v, const lancet_variant_lr *lr, uint32_t n, const char *blob, const uint32_t *bx_blob,
-                   const char *const *bx_names, uint32_t n_bx, const char *const *chr_names, int32_t n_chr) {
+                   const char *const *bx_names, uint32_t n_bx, const char *const *chr_names, int32_t n_chr, const uint8_t *prekeys = nullptr) {
   if (!db || (n && (!v || !blob))) return LANCET_E_ARG;
   if (lr) db->lr = true;
   for (uint32_t i = 0; i < n; ++i) if (v[i].chr_id < 0 || v[i].chr_id >= n_chr) return LANCET_E_ARG;
@@ -352,24 +374,31 @@ static int vdb_add(lancet_vdb *db, const lancet_variant *v, const lancet_variant
   static const bool timing = getenv("LANCET_VDB_TIMING") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto t0 = now();
-  std::vector<Dig> key(n);
-  run([&](int t) {
-    std::string ref, alt, sig; int pos; char type; unsigned short len;
-    for (uint32_t i = (uint32_t)((uint64_t)n * t / T), hi = (uint32_t)((uint64_t)n * (t + 1) / T); i < hi; ++i) {
-      Variant::normalise(v[i], blob, ref, alt, pos, type, len);
-      Variant::signature_into(sig, chr_names[v[i].chr_id], pos, type, len, ref, alt);
-      sha256_bin(sig.data(), sig.size(), key[i]);
-    }
-  });
+  std::vector<Dig> own;
+  const Dig *key = (const Dig *)prekeys;                          // (the records came with their keys: lancet_vdb_keys on the rank that made them)
+  if (!key) { own.resize(n); vdb_keys(v, n, blob, chr_names, own.data(), T); key = own.data(); }
   auto t1 = now();
-  // 2. addVar (src/VariantDB.cc:28-91), shard s on thread s mod T, records in arrival order
+  // 2. addVar (src/VariantDB.cc:28-91), shard s on thread s mod T, records in arrival order.  Large batches: the records' indices are
+  //    dealt out by shard first (a counting sort, arrival order kept), so that a thread walks its own records only.
+  std::vector<uint32_t> by_shard; uint32_t sh_at[VDB_SHARDS + 1] = {0};
+  if (T > 1) {
+    uint32_t cnt[VDB_SHARDS] = {0};
+    for (uint32_t i = 0; i < n; ++i) ++cnt[key[i].b[0] >> 4];
+    for (int q = 0; q < VDB_SHARDS; ++q) sh_at[q + 1] = sh_at[q] + cnt[q];
+    by_shard.resize(n);
+    uint32_t fill[VDB_SHARDS]; memcpy(fill, sh_at, sizeof(fill));
+    for (uint32_t i = 0; i < n; ++i) by_shard[fill[key[i].b[0] >> 4]++] = i;
+    for (int q = 0; q < VDB_SHARDS; ++q) db->db[q].reserve(db->db[q].size() + cnt[q] / 3 + 16);      // (a variant is met by ~4 overlapping windows)
+  }
+  auto t1b = now();
   run([&](int t) {
-    for (uint32_t i = 0; i < n; ++i) {
-      int sh = key[i].b[0] >> 4;
-      if (sh % T != t) continue;
+    for (int shq = T > 1 ? t : 0; shq < (T > 1 ? VDB_SHARDS : 1); shq += T)
+    for (uint32_t j = T > 1 ? sh_at[shq] : 0, je = T > 1 ? sh_at[shq + 1] : n; j < je; ++j) {
+      const uint32_t i = T > 1 ? by_shard[j] : j;
+      const int sh = key[i].b[0] >> 4;
       auto &m = db->db[sh];
-      auto it = m.lower_bound(key[i]);
-      if (it != m.end() && !(key[i] < it->first)) {
+      auto it = m.find(key[i]);
+      if (it != m.end()) {
         if (it->second.tot() < Variant::tot_of(v[i])) {          // keep the entry with the larger total coverage; first wins ties
           Variant &o = it->second;
           o.kmer = v[i].kmer;
@@ -385,12 +414,13 @@ static int vdb_add(lancet_vdb *db, const lancet_variant *v, const lancet_variant
           }
         }
       } else {
-        auto ins = m.emplace_hint(it, std::piecewise_construct, std::forward_as_tuple(key[i]), std::forward_as_tuple(chr_names[v[i].chr_id], v[i], blob));
+        auto ins = m.emplace(std::piecewise_construct, std::forward_as_tuple(key[i]), std::forward_as_tuple(chr_names[v[i].chr_id], v[i], blob)).first;
         if (lr) ins->second.set_lr(lr[i], bx_blob, bx_names, n_bx);
       }
     }
   });
-  if (timing) fprintf(stderr, "lancet_vdb_add: %u records, %d threads: keys %.2f ms, insert %.2f ms\n", n, T, std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(now() - t1).count());
+  if (timing) fprintf(stderr, "  (dealing the records out by shard: %.2f ms)\n", std::chrono::duration<double, std::milli>(t1b - t1).count());
+  if (timing) fprintf(stderr, "lancet_vdb_add: %u records%s, %d threads: keys %.2f ms, insert %.2f ms\n", n, prekeys ? " (keyed)" : "", T, std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(now() - t1).count());
   return LANCET_OK;
 }
 int lancet_vdb_add(lancet_vdb *db, const lancet_variant *v, uint32_t n, const char *blob, const char *const *chr_names, int32_t n_chr) {
@@ -402,6 +432,45 @@ int lancet_vdb_add_lr(lancet_vdb *db, const lancet_variant *v, const lancet_vari
   if (!db) return LANCET_E_ARG;
   db->lr = true;
   return vdb_add(db, v, lr, n, blob, bx_blob, bx_names, n_bx, chr_names, n_chr);
+}
+
+/* The 32-byte key of every record as VariantDB_t::addVar computes it (reference src/VariantDB.cc:36-40: sha256 of getSignature() of the
+ * normalised Variant_t), 32 raw digest bytes per record (the hex string's order is their memcmp order).  Computed where the records are
+ * made -- every rank of a multi-GPU run -- so that the rank that owns the VariantDB only inserts (lancet_vdb_add_keyed). */
+int lancet_vdb_keys(const lancet_variant *v, uint32_t n, const char *blob, const char *const *chr_names, int32_t n_chr, uint8_t *keys) {
+  if (n && (!v || !blob || !keys || !chr_names)) return LANCET_E_ARG;
+  for (uint32_t i = 0; i < n; ++i) if (v[i].chr_id < 0 || v[i].chr_id >= n_chr) return LANCET_E_ARG;
+  vdb_keys(v, n, blob, chr_names, (Dig *)keys, n >= 32768 ? vdb_threads() : 1);
+  return LANCET_OK;
+}
+/* Which of n keyed records (in the order they would be added) can change a VariantDB at all: per key, addVar keeps the strings of the
+ * FIRST record and the k-mer size / coverages (/ haplotype counts / barcode sets) of the first record that reaches the key's largest
+ * total coverage (src/VariantDB.cc:45-88: a strictly larger total replaces, the first wins ties) -- every other record of the key is a
+ * no-op whatever comes before or after it, in this stream or in another rank's.  keep[i] = 1 for those one or two records per key.
+ * A rank applies this to its own records before they travel: a variant is met by ~4.5 overlapping windows, so ~2.5x fewer records
+ * reach the rank that merges, and the merged database is the same (the argument holds for any split of the windows over the ranks
+ * that keeps each rank's records in their global order). */
+int lancet_vdb_reduce(const lancet_variant *v, const uint8_t *keys, uint32_t n, uint8_t *keep) {
+  if (n && (!v || !keys || !keep)) return LANCET_E_ARG;
+  struct Ent { uint32_t first, best; int best_tot; };
+  std::unordered_map<Dig, Ent, DigHash> m;
+  m.reserve(n / 3 + 16);
+  const Dig *key = (const Dig *)keys;
+  for (uint32_t i = 0; i < n; ++i) {
+    keep[i] = 0;
+    const int tot = Variant::tot_of(v[i]);
+    auto it = m.find(key[i]);
+    if (it == m.end()) m.emplace(key[i], Ent{i, i, tot});
+    else if (it->second.best_tot < tot) { it->second.best = i; it->second.best_tot = tot; }
+  }
+  for (auto &kv : m) { keep[kv.second.first] = 1; keep[kv.second.best] = 1; }
+  return LANCET_OK;
+}
+int lancet_vdb_add_keyed(lancet_vdb *db, const lancet_variant *v, const lancet_variant_lr *lr, const uint8_t *keys, uint32_t n, const char *blob,
+                         const uint32_t *bx_blob, const char *const *bx_names, uint32_t n_bx, const char *const *chr_names, int32_t n_chr) {
+  if (!db || (n && !keys)) return LANCET_E_ARG;
+  if (lr) db->lr = true;
+  return vdb_add(db, v, lr, n, blob, bx_blob, bx_names, n_bx, chr_names, n_chr, keys);
 }
 
 char *lancet_vdb_vcf(lancet_vdb *db, const char *version, const char *cmdline, const char *reference, const char *date_line,
@@ -455,7 +524,11 @@ char *lancet_vdb_vcf(lancet_vdb *db, const char *version, const char *cmdline, c
   // order of equal positions depends on that starting order: shard 0..15 in turn reproduces it.
   std::vector<const std::pair<const Dig, Variant> *> vec;
   vec.reserve(db->size());
-  for (int s = 0; s < VDB_SHARDS; ++s) for (auto &kv : db->db[s]) vec.push_back(&kv);
+  for (int s = 0; s < VDB_SHARDS; ++s) {                       // (a shard's entries in key order = that stretch of the reference's map)
+    const size_t at = vec.size();
+    for (auto &kv : db->db[s]) vec.push_back(&kv);
+    std::sort(vec.begin() + (ptrdiff_t)at, vec.end(), [](const std::pair<const Dig, Variant> *a, const std::pair<const Dig, Variant> *b) { return a->first < b->first; });
+  }
   std::sort(vec.begin(), vec.end(), byPos());
   std::string out = hdr.str();
   for (auto *kv : vec) out += kv->second.vcf(fs);

@@ -8,7 +8,9 @@ A payload carries everything `Variant_t`'s constructor gets (reference src/Graph
 `lancet_variant` records, their string blob and -- with --linked-reads -- the `lancet_variant_lr` records, the barcode ids
 of their four barcode sets and the names of the barcodes used (ids are ranks inside ONE batch, so they travel as names).
 Rank 0 replays the union in (global window index, emission order): `addVar` keeps the first record on ties
-(src/VariantDB.cc:51), so the VCF must not depend on how the windows were dealt out."""
+(src/VariantDB.cc:51), so the VCF must not depend on how the windows were dealt out.
+Every rank also sends the 32-byte addVar key of each of its records (lancet_vdb_keys: Variant_t's normalisation, getSignature and
+sha256, src/VariantDB.cc:36-40), so that rank 0 -- the serial part of an N-rank step -- only inserts (lancet_vdb_add_keyed)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -31,32 +33,47 @@ def shard_windows(n_windows: int, rank: int, world: int, chunk: int = 4096) -> L
 
 
 def pack_records(vptr, n: int, blob: bytes, lrptr=None, bx_blob=None, bx_names: Optional[Sequence[str]] = None, *,
-                 chr_names: Sequence[str], window_index: Optional[np.ndarray] = None) -> bytes:
+                 chr_names: Sequence[str], window_index: Optional[np.ndarray] = None, with_keys: bool = True, reduce: bool = True) -> bytes:
     """One rank's records as bytes.  chr_names[chr_id] = the contig names of the rank's batch (required: records carry ids);
-    window_index[w] = global index of the rank's window w (default: identity)."""
+    window_index[w] = global index of the rank's window w (default: identity); with_keys: the records' addVar keys travel along;
+    reduce (with keys): only the records that can change the VariantDB travel (lancet_vdb_reduce: per key the first record and the
+    first of the largest total coverage) -- the rank's records must be in (window, emission) order, as the engine returns them."""
     if not chr_names:
         raise ValueError("pack_records: chr_names is required")
+    keys = b""; keep = None
+    if with_keys and n:
+        from . import engine
+        k = engine.record_keys(vptr, n, blob, chr_names)
+        if reduce:
+            keep = engine.records_that_matter(vptr, k, n)
+            k = np.ascontiguousarray(k[keep])
+        keys = k.tobytes()
     recs = np.frombuffer(C.string_at(vptr, n * _VDT.itemsize), dtype=_VDT).copy() if n else np.zeros(0, dtype=_VDT)
+    n_all = n
+    if keep is not None:
+        recs = np.ascontiguousarray(recs[keep]); n = len(recs)
     if window_index is not None and n:
         recs["window"] = np.asarray(window_index, dtype=np.int64)[recs["window"]]
     lr = b""; ids = np.zeros(0, dtype=np.uint32); names = b""
     has_lr = lrptr is not None and bool(lrptr)
     if has_lr:
-        l = np.frombuffer(C.string_at(lrptr, n * _LDT.itemsize), dtype=_LDT).copy() if n else np.zeros(0, dtype=_LDT)
-        nbx = int((l["bx_off"] + l["bx_len"]).max()) if n else 0
+        l = np.frombuffer(C.string_at(lrptr, n_all * _LDT.itemsize), dtype=_LDT).copy() if n_all else np.zeros(0, dtype=_LDT)
+        nbx = int((l["bx_off"] + l["bx_len"]).max()) if n_all else 0
         raw = np.ctypeslib.as_array(bx_blob, shape=(nbx,)).astype(np.uint32) if nbx else np.zeros(0, dtype=np.uint32)
         used, inv = np.unique(raw, return_inverse=True)                       # only the barcodes that occur travel
         ids = inv.astype(np.uint32)
         names = "\0".join(bx_names[int(u)] for u in used).encode()
+        if keep is not None:
+            l = np.ascontiguousarray(l[keep])
         lr = l.tobytes()
     chrs = "\0".join(chr_names).encode()
-    hdr = np.array([n, len(blob), 1 if has_lr else 0, len(ids), len(names), len(chrs), 0, 0], dtype=np.uint64)
-    return hdr.tobytes() + recs.tobytes() + blob + lr + ids.tobytes() + names + chrs
+    hdr = np.array([n, len(blob), 1 if has_lr else 0, len(ids), len(names), len(chrs), len(keys), 0], dtype=np.uint64)
+    return hdr.tobytes() + recs.tobytes() + blob + lr + ids.tobytes() + names + chrs + keys
 
 
 def unpack_records(buf: bytes, copy: bool = True) -> dict:
     """copy=False returns read-only views into `buf` for the record arrays (merge_into_vdb copies them once, into place)."""
-    n, bl, has_lr, nbx, nl, cl, _, _ = (int(x) for x in np.frombuffer(buf[:8 * _HDR], dtype=np.uint64))
+    n, bl, has_lr, nbx, nl, cl, kl, _ = (int(x) for x in np.frombuffer(buf[:8 * _HDR], dtype=np.uint64))
     o = 8 * _HDR
     own = (lambda a: a.copy()) if copy else (lambda a: a)
     recs = own(np.frombuffer(buf, dtype=_VDT, count=n, offset=o)); o += n * _VDT.itemsize
@@ -66,8 +83,9 @@ def unpack_records(buf: bytes, copy: bool = True) -> dict:
         lr = own(np.frombuffer(buf, dtype=_LDT, count=n, offset=o)); o += n * _LDT.itemsize
         ids = own(np.frombuffer(buf, dtype=np.uint32, count=nbx, offset=o)); o += 4 * nbx
         names = buf[o:o + nl].decode().split("\0") if nl else []; o += nl
-    chrs = buf[o:o + cl].decode().split("\0") if cl else []
-    return dict(n=n, recs=recs, blob=blob, lr=lr, bx_ids=ids, bx_names=names, chr_names=chrs)
+    chrs = buf[o:o + cl].decode().split("\0") if cl else []; o += cl
+    keys = own(np.frombuffer(buf, dtype=np.uint8, count=kl, offset=o).reshape(-1, 32)) if kl else None
+    return dict(n=n, recs=recs, blob=blob, lr=lr, bx_ids=ids, bx_names=names, chr_names=chrs, keys=keys)
 
 
 def gather_bytes(payload: bytes, device: torch.device, dst: int = 0) -> List[bytes]:
@@ -110,11 +128,15 @@ def merge_into_vdb(parts: Sequence[bytes], db) -> int:
     if lr_mode and not all(p["lr"] is not None for p in ps):
         raise ValueError("merge_into_vdb: some ranks sent linked-read records and some did not (one run is either --linked-reads or not)")
     total = sum(p["n"] for p in ps)
+    keyed = all(p["keys"] is not None for p in ps)
+    keys = np.empty((total, 32), dtype=np.uint8) if keyed else None
     recs = np.empty(total, dtype=_VDT)                        # every part is copied once, straight into its place
     lr = np.empty(total, dtype=_LDT) if lr_mode else None
     for p in ps:
         r = recs[o:o + p["n"]]
         r[:] = p["recs"]
+        if keyed:
+            keys[o:o + p["n"]] = p["keys"]
         cmap = np.zeros(max(1, len(p["chr_names"])), dtype=np.int32)
         for i, c in enumerate(p["chr_names"]):
             if c not in chr_names:
@@ -141,6 +163,8 @@ def merge_into_vdb(parts: Sequence[bytes], db) -> int:
     if total > 1 and not bool(np.all((w[1:] > w[:-1]) | ((w[1:] == w[:-1]) & (q[1:] >= q[:-1])))):
         order = np.lexsort((q, w))
         recs = np.ascontiguousarray(recs[order])
+        if keyed:
+            keys = np.ascontiguousarray(keys[order])
         if lr_mode:
             lr = np.ascontiguousarray(lr[order])
     blob = b"".join(blobs) + b"\0"
@@ -152,8 +176,14 @@ def merge_into_vdb(parts: Sequence[bytes], db) -> int:
         sorted_names = sorted(bx_names)
         ids = rank_of[np.concatenate(ids_all)].astype(np.uint32) if id_base else np.zeros(1, dtype=np.uint32)
         ids = np.ascontiguousarray(ids)
-        db.add_raw_lr(vptr, lr.ctypes.data_as(C.POINTER(abi.LancetVariantLR)), len(recs), blob,
-                      ids.ctypes.data_as(C.POINTER(C.c_uint32)), sorted_names, chr_names)
+        if keyed:
+            db.add_raw_keyed(vptr, lr.ctypes.data_as(C.POINTER(abi.LancetVariantLR)), keys, len(recs), blob,
+                             ids.ctypes.data_as(C.POINTER(C.c_uint32)), sorted_names, chr_names)
+        else:
+            db.add_raw_lr(vptr, lr.ctypes.data_as(C.POINTER(abi.LancetVariantLR)), len(recs), blob,
+                          ids.ctypes.data_as(C.POINTER(C.c_uint32)), sorted_names, chr_names)
+    elif keyed:
+        db.add_raw_keyed(vptr, None, keys, len(recs), blob, None, None, chr_names)
     else:
         db.add_raw(vptr, len(recs), blob, chr_names)
     return len(recs)

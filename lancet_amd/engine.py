@@ -66,6 +66,10 @@ def lib():
         L.lancet_vdb_add.argtypes = [C.c_void_p, C.POINTER(abi.LancetVariant), C.c_uint32, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32]
         L.lancet_vdb_add_lr.argtypes = [C.c_void_p, C.POINTER(abi.LancetVariant), C.POINTER(abi.LancetVariantLR), C.c_uint32, C.c_char_p,
                                         C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_int32]
+        L.lancet_vdb_keys.argtypes = [C.POINTER(abi.LancetVariant), C.c_uint32, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.c_void_p]
+        L.lancet_vdb_add_keyed.argtypes = [C.c_void_p, C.POINTER(abi.LancetVariant), C.POINTER(abi.LancetVariantLR), C.c_void_p, C.c_uint32, C.c_char_p,
+                                           C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_int32]
+        L.lancet_vdb_reduce.argtypes = [C.POINTER(abi.LancetVariant), C.c_void_p, C.c_uint32, C.c_void_p]
         L.lancet_vdb_size.restype = C.c_uint32
         L.lancet_vdb_size.argtypes = [C.c_void_p]
         L.lancet_vdb_vcf.restype = C.c_void_p
@@ -257,6 +261,27 @@ class Engine:
             pass
 
 
+def record_keys(vptr, n: int, blob: bytes, chr_names: Sequence[str]):
+    """lancet_vdb_keys: the 32-byte addVar key (sha256 of Variant_t::getSignature) of each of n records -> uint8[n, 32]."""
+    import numpy as np
+    keys = np.zeros((max(1, n), 32), dtype=np.uint8)
+    names = abi.c_string_array(list(chr_names))
+    rc = lib().lancet_vdb_keys(vptr, n, blob, names, len(chr_names), keys.ctypes.data)
+    if rc != 0:
+        raise EngineError(f"lancet_vdb_keys: {ERRORS.get(rc, rc)}")
+    return keys[:n]
+
+
+def records_that_matter(vptr, keys, n: int):
+    """lancet_vdb_reduce: bool[n], the records of a keyed stream (in adding order) that can change a VariantDB."""
+    import numpy as np
+    keep = np.zeros(max(1, n), dtype=np.uint8)
+    rc = lib().lancet_vdb_reduce(vptr, keys.ctypes.data, n, keep.ctypes.data)
+    if rc != 0:
+        raise EngineError(f"lancet_vdb_reduce: {ERRORS.get(rc, rc)}")
+    return keep[:n].astype(bool)
+
+
 class VariantDB:
     """reference src/VariantDB.cc: addVar + printToVCF (host)."""
 
@@ -276,6 +301,16 @@ class VariantDB:
         rc = self.L.lancet_vdb_add_lr(self.h, vptr, lrptr, n, blob, bx_blob, bxn, len(bx_names), names, len(chr_names))
         if rc != 0:
             raise EngineError(f"lancet_vdb_add_lr: {ERRORS.get(rc, rc)}")
+
+    def add_raw_keyed(self, vptr, lrptr, keys, n: int, blob: bytes, bx_blob, bx_names: Optional[Sequence[str]], chr_names: Sequence[str]) -> None:
+        """The records with their addVar keys (record_keys, computed where the records were made): rank 0 of a multi-GPU run only inserts.
+        keys: numpy uint8 array of 32 * n bytes; lrptr / bx_blob / bx_names None without --linked-reads."""
+        names = abi.c_string_array(list(chr_names))
+        bxn = abi.c_string_array(list(bx_names)) if bx_names is not None else None
+        rc = self.L.lancet_vdb_add_keyed(self.h, vptr, lrptr, keys.ctypes.data, n, blob, bx_blob, bxn, len(bx_names) if bx_names is not None else 0,
+                                         names, len(chr_names))
+        if rc != 0:
+            raise EngineError(f"lancet_vdb_add_keyed: {ERRORS.get(rc, rc)}")
 
     def add_records(self, records: List[dict], chr_names: Sequence[str], bx_names: Optional[Sequence[str]] = None) -> None:
         """records: dicts as produced by abi.variants_to_py (any source); with bx_names: linked-read records

@@ -131,3 +131,63 @@ def test_large_batch_replay_equals_small_batches(mode):
             got.add((f[0], int(f[1]), f[3], f[4], int(k), tuple(cov)))
         exp = set((c, p, ra[0], ra[1], k, tuple(cov)) for (c, p, ra, k, cov) in want.values())
         assert got == exp
+
+
+@pytest.mark.parametrize("mode", ["plain", "lr"])
+def test_keys_made_by_the_senders_and_reduced_streams_give_the_same_database(mode):
+    """Rank 0 of an N-rank step only inserts: the records arrive with their addVar keys (lancet_vdb_keys on the rank that made them) and
+    without the records that cannot change the database (lancet_vdb_reduce: per key the first record and the first of the largest total
+    coverage).  70 000 records with many repeated keys, ties and replacements, dealt out over 8 ranks in chunks of windows (so that a
+    key's records lie on several ranks, out of order at rank 0): the VCF bytes equal those of one plain lancet_vdb_add, with and
+    without the reduction; the keys equal hashlib's sha256 of the reference's signature string."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    from lancet_amd import abi, dist as ldist, engine
+    n = 70000
+    recs, blob, lr, ids, bxn = make_records(n, mode == "lr")
+    chrs = ["chr1", "chr10", "chr2"]
+    vp = lambda a: a.ctypes.data_as(C.POINTER(abi.LancetVariant))
+    lp = lambda a: a.ctypes.data_as(C.POINTER(abi.LancetVariantLR))
+    base = engine.VariantDB()
+    if lr is not None:
+        base.add_raw_lr(vp(recs), lp(lr), n, blob, ids.ctypes.data_as(C.POINTER(C.c_uint32)), bxn, chrs)
+    else:
+        base.add_raw(vp(recs), n, blob, chrs)
+    want = base.vcf(date_line="##fileDate=x\n")
+    keys = engine.record_keys(vp(recs), n, blob, chrs)
+    for i in (0, 1, 777, n - 1):                                   # the key IS sha256(getSignature())
+        r = recs[i]
+        ref = blob[r["ref_off"]:r["ref_off"] + r["ref_len"]].decode(); alt = blob[r["alt_off"]:r["alt_off"] + r["alt_len"]].decode()
+        code = chr(r["code"]); pos = int(r["pos"]); typ = "?"; ln = 0
+        if code == "^": typ = "I"; ref = ""; ln = len(alt)
+        if code == "v": typ = "D"; alt = ""; ln = len(ref)
+        if code == "x": typ = "S"; pos += 1
+        if code == "c":
+            typ = "C"; ref = ref.replace("-", ""); alt = alt.replace("-", ""); ln = abs(len(ref) - len(alt)) or len(alt)
+        if typ != "S":
+            ref = chr(r["prev_bp_alt"]) + ref; alt = chr(r["prev_bp_alt"]) + alt
+        else:
+            ln = 1
+        assert bytes(keys[i]) == hashlib.sha256(("%s:%d:%s:%d:%s:%s" % (chrs[r["chr_id"]], pos, typ, ln, ref, alt)).encode()).digest()
+    keep = engine.records_that_matter(vp(recs), keys, n)
+    assert 0 < keep.sum() < n - 5000                               # (repeated keys: ties and smaller totals drop out)
+    world = 8
+    for reduce in (False, True):
+        parts = []
+        for rank in range(world):
+            mine = np.array(ldist.shard_windows(int(recs["window"].max()) + 1, rank, world, chunk=5), dtype=np.int64)
+            sel = np.isin(recs["window"], mine)
+            sub = np.ascontiguousarray(recs[sel])
+            local = np.searchsorted(mine, sub["window"])           # the rank's own window numbering
+            sub["window"] = local
+            kw = {}
+            if lr is not None:
+                sl = np.ascontiguousarray(lr[sel])
+                parts.append(ldist.pack_records(vp(sub), len(sub), blob, lp(sl), ids.ctypes.data_as(C.POINTER(C.c_uint32)), bxn,
+                                                chr_names=chrs, window_index=mine, reduce=reduce))
+            else:
+                parts.append(ldist.pack_records(vp(sub), len(sub), blob, chr_names=chrs, window_index=mine, reduce=reduce))
+        db = engine.VariantDB()
+        added = ldist.merge_into_vdb(parts, db)
+        assert (added < n - 3000) if reduce else (added == n)
+        assert db.vcf(date_line="##fileDate=x\n") == want, reduce
