@@ -159,13 +159,17 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b);
  * (seq_off still gives the UNTRIMMED length of every read).  Read r owns (len + 15) / 16 words of `bases` from base_woff[r] and
  * (len + 31) / 32 words of `good` from good_woff[r], len its untrimmed length; both offset arrays have n_reads + 1 entries, `bases` has
  * 4 readable words past the last read's, `good` one.  Every read must have been packed by lancet_pack_read with the parameters this
- * engine was created with (the trim and the mask depend on min_qual_trim / min_qual_call). */
+ * engine was created with: the trim and the mask depend on min_qual_trim / min_qual_call, which the producer records in the struct
+ * (lancet_host_batch_packed does; a caller of lancet_pack_read copies them from the lancet_params it packed with) -- an engine created
+ * with other thresholds refuses the batch (LANCET_E_ARG) instead of building graphs from reads trimmed for another run. */
 typedef struct lancet_packed_reads {
   const uint32_t *rinfo;       /* [n_reads] trimmed length and the read's flags, as lancet_pack_read leaves them */
   const uint32_t *base_woff;   /* [n_reads + 1] */
   const uint32_t *good_woff;   /* [n_reads + 1] */
   const uint32_t *bases;       /* 2 bit per base of the trimmed read, first base in the low bits */
   const uint32_t *good;        /* 1 bit per base of the trimmed read */
+  int32_t min_qual_trim;       /* the thresholds the reads were trimmed / masked with (lancet_params of the packing side) */
+  int32_t min_qual_call;
 } lancet_packed_reads;
 int lancet_engine_upload_packed(lancet_engine *e, const lancet_window_batch *b, const lancet_packed_reads *p);
 /* One read, trimmed and packed: rinfo[0], (len + 15) / 16 words of bases and (len + 31) / 32 words of good are written (zero past the

@@ -708,7 +708,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   WG_LANE0 { S.hint = 0; S.ndup = 0; S.w = w; S.why = BLW_NONE; S.R = nr + 1; S.reflen = reflen; S.hasN = 0; S.mapped = 0; S.flagged = 0; S.npairs = 0; S.edges_total = 0; S.refn = 0;
              H->status = PB_NOT_BUILT; H->why = 0; H->have_rep = 0; H->heavy = 0; H->next = 0;
              ((LC_GLOBAL PreCmp *)(area + PRE_OFF_CHDR))->done = 0;
-             if (nr > BL_RMAX || reflen > LC_MAXW || reflen < 1) S.why = BLW_SIZE; }
+             if (nr > BL_RMAX || reflen > (int)PL.maxw || reflen < 1) S.why = BLW_SIZE; }
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
   // ---- mapped reads, N in the window reference, per-read geometry
   LC_LDS uint32_t *tmpA = S.big, *tmpB = S.big + (BL_RMAX + 8), *tmpC = S.big + 2 * (BL_RMAX + 8);

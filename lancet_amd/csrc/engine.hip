@@ -379,6 +379,11 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) { retur
 int lancet_engine_upload_packed(lancet_engine *e, const lancet_window_batch *b, const lancet_packed_reads *pk) {
   if (!e || !pk || !pk->rinfo || !pk->base_woff || !pk->good_woff || !pk->bases || !pk->good) { if (e) e->err = "packed reads missing"; return LANCET_E_ARG; }
   if (!e->host_prep) { e->err = "packed upload with LANCET_PREP=device"; return LANCET_E_STATE; }
+  if (pk->min_qual_trim != e->params.min_qual_trim || pk->min_qual_call != e->params.min_qual_call) {
+    e->err = "packed reads were trimmed / masked with other thresholds (min_qual_trim " + std::to_string(pk->min_qual_trim) + ", min_qual_call " + std::to_string(pk->min_qual_call) +
+             ") than this engine's (" + std::to_string(e->params.min_qual_trim) + ", " + std::to_string(e->params.min_qual_call) + ")";
+    return LANCET_E_ARG;
+  }
   return lc_upload(e, b, pk);
 }
 void lancet_pack_read(const lancet_params *P, const char *seq, const char *qual, int len, uint8_t label, uint8_t strand, uint8_t mate, uint8_t mapped,
@@ -1004,6 +1009,7 @@ int lancet_debug_align_mode(lancet_engine *e, const char *S, const char *T, char
   EngineCaps caps; memset(&caps, 0, sizeof(caps));
   caps.reads_cap = 4; caps.occ_cap = 64; caps.node_cap = 16; caps.table_cap = 32; caps.bucket_cap = 32; caps.special_cap = 4; caps.surv_cap = 4;
   caps.seq_cap = 64; caps.queue_cap = 4; caps.path_cap = (uint32_t)m + 8; caps.max_k = 16; caps.qv_cap = 64;
+  caps.max_w = std::max<uint32_t>(LC_MAXW_DEFAULT, ((uint32_t)n + 63u) & ~63u);
   size_t bytes = lc_work_carve(nullptr, nullptr, caps);
   DevBuf mem, dcaps, dwork, ds, dt, dl;
   std::vector<uint8_t> sc(n), tc(m);
@@ -1025,7 +1031,7 @@ int lancet_debug_align_mode(lancet_engine *e, const char *S, const char *T, char
   if (L == -2) rc = LANCET_E_STATE;
   else if (L < 0 || L + 1 > cap) rc = LANCET_E_UNSUPPORTED;
   else {
-    const int acap = LC_MAXW + (int)caps.path_cap + 2;
+    const int acap = (int)caps.max_w + (int)caps.path_cap + 2;
     HIPCHK(e, lc_copy(e, S_aln, w.aln, L, hipMemcpyDeviceToHost));
     HIPCHK(e, lc_copy(e, T_aln, w.aln + acap, L, hipMemcpyDeviceToHost));
     S_aln[L] = 0; T_aln[L] = 0;

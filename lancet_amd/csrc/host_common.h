@@ -16,11 +16,12 @@ static inline uint32_t lc_bucket_cap_for(uint32_t nodes) {
 
 // Layout of one hand-off area of the LDS build kernel (layout.h PreLayout): `ncap` distinct k-mers, `qvcap` (candidate, position)
 // quality rows, `kw` words per candidate key.
-static inline PreLayout lc_pre_layout(uint32_t ncap, uint32_t qvcap, uint32_t kw) {
+static inline PreLayout lc_pre_layout(uint32_t ncap, uint32_t qvcap, uint32_t kw, uint32_t maxw = LC_MAXW_DEFAULT) {
   PreLayout L; memset(&L, 0, sizeof(L));
-  L.ncap = ncap; L.qvcap = qvcap; L.kw = kw;
-  uint32_t o = PRE_OFF_REFCOV + 8u * LC_MAXW;
+  L.ncap = ncap; L.qvcap = qvcap; L.kw = kw; L.maxw = maxw;
+  uint32_t o = PRE_OFF_OCCREF + 4u * maxw;
   auto take = [&](uint32_t bytes, uint32_t align) { o = (o + align - 1u) & ~(align - 1u); const uint32_t at = o; o += bytes; return at; };
+  L.refcov = take(8u * maxw, 64u);
   L.nhash = take(8u * ncap, 64u); L.surv = take(ncap, 64u);
   L.snode = take(4u * PB_CCAP, 64u); L.skey = take(8u * kw * PB_CCAP, 64u); L.sid = take(4u * PB_SCAP, 64u);
   L.pgr = take(128u * PB_SCAP, 128u); L.order = take(4u * PB_SCAP, 64u); L.qv = take(8u * qvcap, 64u);
@@ -31,8 +32,15 @@ static inline PreLayout lc_pre_layout(uint32_t ncap, uint32_t qvcap, uint32_t kw
 // Which form a batch gets: the wide one (PB_NCAP_WIDE k-mers, keys of 4 words, PB_QVCAP_WIDE rows: windows of 100x / 40x build at
 // k = 31..101 with 9-12 k distinct k-mers) when its windows are deep (more than 400 reads on average: 60x / 60x windows, ~360 reads, all fit the narrow form) and `n_areas` of them stay
 // within `budget` bytes; else the narrow one.  LANCET_PRE_WIDE=0 / 1 forces either (read by the caller, passed as `force`).
+static inline uint32_t lc_max_w_for_batch(const lancet_window_batch *b) {      // EngineCaps::max_w
+  uint32_t m = LC_MAXW_DEFAULT;
+  for (int w = 0; w < b->n_windows; ++w) { const uint32_t l = b->ref_off[w + 1] - b->ref_off[w]; if (l > m && l <= LC_MAXW) m = l; }
+  m = (m + 63u) & ~63u;
+  return m > LC_MAXW ? (uint32_t)LC_MAXW : m;
+}
 static inline PreLayout lc_pre_layout_for_batch(const lancet_window_batch *b, size_t n_areas, size_t budget, int force = -1) {
-  const PreLayout narrow = lc_pre_layout(PB_NCAP, PB_QVCAP, 1u), wide = lc_pre_layout(PB_NCAP_WIDE, PB_QVCAP_WIDE, LC_NWMAX);
+  const uint32_t mw = lc_max_w_for_batch(b);
+  const PreLayout narrow = lc_pre_layout(PB_NCAP, PB_QVCAP, 1u, mw), wide = lc_pre_layout(PB_NCAP_WIDE, PB_QVCAP_WIDE, LC_NWMAX, mw);
   if (force == 0 || b->n_windows <= 0) return narrow;
   if (force == 1) return wide;
   const uint32_t R = b->read_begin[b->n_windows];
@@ -85,7 +93,8 @@ static inline EngineCaps lc_caps_for_batch(const lancet_window_batch *b, const l
     { uint64_t q = 4ull * (uint64_t)(p->dfs_limit > 0 ? p->dfs_limit : 1000000) + 4096; if (q < 65536) q = 65536; if (q > (4ull << 20)) q = 4ull << 20; c.queue_cap = (uint32_t)q; }
   }
   c.seq_cap = 3 * c.qv_cap + 65536;
-  c.path_cap = LC_MAXW + (uint32_t)p->max_indel_len + 256;
+  c.max_w = lc_max_w_for_batch(b);              // (a window above LC_MAXW is reported LANCET_W_OVERFLOW on its own)
+  c.path_cap = c.max_w + (uint32_t)p->max_indel_len + 256;
   c.evt_cap = evt_cap;
   // Records of the whole batch.  A scan emits ~0.7 per window; permissive settings (--low-cov 0 on noisy reads) reach several
   // hundred per window (fuzz case 7122: 355), and a small batch has no other windows to average that out: 64 per window and
@@ -94,7 +103,7 @@ static inline EngineCaps lc_caps_for_batch(const lancet_window_batch *b, const l
   c.blob_cap = (uint32_t)b->n_windows * 4096u + (4u << 20);
   c.lr_mode = p->lr_mode ? 1u : 0u;
   c.bx_cap = c.lr_mode ? (uint32_t)b->n_windows * 8192u + (1u << 20) : 0u;
-  c.pl = lc_pre_layout(PB_NCAP, PB_QVCAP, 1u);      // (the engine replaces it per upload: lc_pre_layout_for_batch)
+  c.pl = lc_pre_layout(PB_NCAP, PB_QVCAP, 1u, c.max_w);      // (the engine replaces it per upload: lc_pre_layout_for_batch)
   return c;
 }
 
@@ -112,13 +121,14 @@ struct LcCarver {
 static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   LcCarver k{base, 0};
   const size_t nodes = (size_t)c.node_cap + c.special_cap;
+  const size_t MW = c.max_w ? c.max_w : LC_MAXW_DEFAULT;
   Work t; memset(&t, 0, sizeof(t));
   t.occ_base = k.take<uint32_t>(c.reads_cap + 1);
   t.rd = k.take<uint32_t>(4 * (size_t)c.reads_cap);
   t.cand = k.take<uint8_t>(c.reads_cap);
   t.mate_of = k.take<uint32_t>(c.reads_cap);
-  t.items = k.take<uint32_t>(2 * ((size_t)c.reads_cap + LC_MAXW / LC_SEG + 2));
-  t.chunk = k.take<uint32_t>(2 * (((size_t)c.reads_cap + LC_MAXW / LC_SEG + 2) / 64 + 2));
+  t.items = k.take<uint32_t>(2 * ((size_t)c.reads_cap + MW / LC_SEG + 2));
+  t.chunk = k.take<uint32_t>(2 * (((size_t)c.reads_cap + MW / LC_SEG + 2) / 64 + 2));
   t.occ = k.take<uint32_t>(c.occ_cap);
   t.slots = k.take<uint32_t>(4 * (size_t)c.table_cap);
   t.todo = k.take<uint32_t>(c.table_cap);
@@ -136,7 +146,7 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.qv = k.take<uint16_t>((size_t)c.qv_cap * (c.lr_mode ? 10 : 4));
   t.qv_own = t.qv;
   t.khp = k.take<uint16_t>(c.lr_mode ? nodes * 6 : 1);
-  t.refhp = k.take<uint16_t>(c.lr_mode ? LC_MAXW * 6 : 1);
+  t.refhp = k.take<uint16_t>(c.lr_mode ? MW * 6 : 1);
   t.bxbuf = k.take<uint32_t>(c.lr_mode ? c.reads_cap : 1);
   t.seq = k.take<uint32_t>(c.seq_cap);
   t.ht_next = k.take<uint32_t>(nodes);
@@ -145,14 +155,14 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.ht_start = k.take<uint32_t>(c.bucket_cap);
   t.order = k.take<uint32_t>(nodes + 1);
   t.scratch = k.take<uint32_t>(2 * nodes > c.occ_cap ? 2 * nodes : c.occ_cap);
-  t.refcov = k.take<uint16_t>(LC_MAXW * 4);
+  t.refcov = k.take<uint16_t>(MW * 4);
   t.queue = k.take<BfsEntry>(c.queue_cap);
   t.pnodes = k.take<uint32_t>(nodes); t.pedges = k.take<uint32_t>(nodes);
   t.pdesc = k.take<uint32_t>(c.path_cap);
   t.pseq = k.take<uint8_t>(c.path_cap);
-  t.tb = k.take<uint8_t>((size_t)(LC_MAXW + c.path_cap + 4) * (LC_MAXW + 2));   /* anti-diagonal-major: (n+m+1) diagonals of n+1 cells */
-  t.dp = k.take<int32_t>(7 * (LC_MAXW + 2));
-  t.aln = k.take<uint8_t>(2 * (size_t)(LC_MAXW + c.path_cap + 2));
+  t.tb = k.take<uint8_t>((size_t)(MW + c.path_cap + 4) * (MW + 2));   /* anti-diagonal-major: (n+m+1) diagonals of n+1 cells */
+  t.dp = k.take<int32_t>(7 * (MW + 2));
+  t.aln = k.take<uint8_t>(2 * (size_t)(MW + c.path_cap + 2));
   t.evt = k.take<uint32_t>(c.evt_cap + 8);
   t.survb = k.take<uint8_t>(nodes + 1);
   if (w) *w = t;

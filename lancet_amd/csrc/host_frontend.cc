@@ -1263,6 +1263,7 @@ static int host_batch_impl(lancet_host *h, int w_begin, int w_end, const lancet_
     pg[gw0[(size_t)nk]] = 0;
     h->b_rinfo[R] = 0; h->b_bw[R] = (uint32_t)bw0[(size_t)nk]; h->b_gw[R] = (uint32_t)gw0[(size_t)nk];
     pk->rinfo = h->b_rinfo.data(); pk->base_woff = h->b_bw.data(); pk->good_woff = h->b_gw.data(); pk->bases = pb; pk->good = pg;
+    pk->min_qual_trim = P->min_qual_trim; pk->min_qual_call = P->min_qual_call;
   }
   out->label = h->b_label.data(); out->strand = h->b_strand.data(); out->mate = h->b_mate.data(); out->mapped = h->b_mapped.data();
   out->name_rank = h->b_namerank.data();

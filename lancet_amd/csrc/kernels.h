@@ -3264,7 +3264,7 @@ DEVNI int path_string(Ctx &c, int n) {
 DEVNI int path_string_wg(Ctx &c, int n) {
   LC_GLOBAL Work &W = *LC_CTX(c).W; LC_WS &S = LC_SREF(c);
   const int K = S.K;
-  const int dcap = 7 * (LC_MAXW + 2);
+  const int dcap = 7 * ((int)LC_CTX(c).C->max_w + 2);
   if (2 * (n + 1) > dcap || n < 2) { WG_LANE0 { S.ps_len = path_string(c, n); } return wg_bcast(&S.ps_len); }
   LC_GLOBAL uint32_t *off = (LC_GLOBAL uint32_t *)W.dp, *pdir = off + (n + 1);
   WG_LANE0 { S.ps_first = 0x7FFFFFFF; off[n] = 0; }
@@ -3327,7 +3327,7 @@ DEV bool status_cnt_T(const Ctx &c, uint32_t n) {                   // Node_t::i
 // ---------------------------------------------------------------------------------------------------------
 DEV void align_fill_arrays(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const uint8_t *Tx, int m) {
   LC_GLOBAL Work &W = *LC_CTX(c).W;
-  const int A = LC_MAXW + 2;
+  const int A = (int)LC_CTX(c).C->max_w + 2;
   int32_t *Mb[3] = {W.dp, W.dp + A, W.dp + 2 * A};
   int32_t *Xb[2] = {W.dp + 3 * A, W.dp + 4 * A};
   int32_t *Yb[2] = {W.dp + 5 * A, W.dp + 6 * A};
@@ -3361,10 +3361,11 @@ DEV void align_fill_arrays(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL
   }
 }
 #ifndef LANCET_WAVE_EMU
-// GPU form: systolic over the wave.  Lane l owns rows l+1, l+65, ... (<= 10 rows for a 640-base window); cell (i,j)
+// GPU form: systolic over the wave.  Lane l owns rows l+1, l+65, ... (GMAX of them: 10 for a window of up to 640 bases); cell (i,j)
 // is computed at step t = i + j, so everything a cell needs was produced one or two steps earlier by the lane above
 // (wave shuffles) or by the lane itself.  The score diagonals never touch memory; only the traceback bytes do.
-DEVNI void align_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const uint8_t *Tx, int m) {
+template <int GMAX>
+DEVNI void align_fill_g(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const uint8_t *Tx, int m) {
   static_assert(LANCET_WG == 64, "one wave per window");
   LC_GLOBAL Work &W = *LC_CTX(c).W;
   if (threadIdx.x == 0) LC_SREF(c).al_band = 0;
@@ -3372,7 +3373,6 @@ DEVNI void align_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL cons
   if (lane < 64) {                                                   // (helper waves of the fat form only wait at the barrier below)
   for (int j = lane; j < m + 1; j += 64) W.tb[LC_TB(0, j, n)] = (uint8_t)((j == 0 ? 3 : 2) | (0 << 2) | (2 << 4));           // M[0][j] '^' ; Y[0][j] '*'
   for (int i = lane + 1; i < n + 1; i += 64) W.tb[LC_TB(i, 0, n)] = (uint8_t)(1 | (2 << 2) | (0 << 4));     // M[i][0] '<' ; X[i][0] '*'
-  constexpr int GMAX = (LC_MAXW + 63) / 64;
   const int G = (n + 63) / 64;
   // per row: M, X (packed 16+16 in A) and Y, M(i-1,j-1) (packed in B); all scores fit 16 bits (|score| < 4*1280)
   int A[GMAX], Bv[GMAX], sg[GMAX];
@@ -3420,6 +3420,13 @@ DEVNI void align_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL cons
   }
   WG_SYNC();
 }
+DEV void align_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const uint8_t *Tx, int m) {
+  if (n <= LC_MAXW_DEFAULT) { align_fill_g<(LC_MAXW_DEFAULT + 63) / 64>(c, Sx, n, Tx, m); return; }     // ten rows per lane, in registers
+  // A longer window (--window-size above 640) whose band could not be certified: the diagonals in the slot's work space instead of
+  // 16 rows per lane in registers (which cost the whole kernel a wave per SIMD: 136 VGPRs).  Rare twice over, and exact all the same.
+  WG_LANE0 { LC_SREF(c).al_band = 0; }
+  align_fill_arrays(c, Sx, n, Tx, m);
+}
 #else
 DEV void align_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const uint8_t *Tx, int m) { LC_SREF(c).al_band = 0; align_fill_arrays(c, Sx, n, Tx, m); }
 #endif
@@ -3453,7 +3460,7 @@ DEVNI bool align_fill_band(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL
   const int w = (127 - (d < 0 ? -d : d)) / 2;
   if (w < 8 || n < 1 || m < 1) return false;
   const int lo = (d < 0 ? d : 0) - w, hi = lo + 127;
-  if ((size_t)(n + m + 2) * 64 > (size_t)(LC_MAXW + LC_CTX(c).C->path_cap + 4) * (LC_MAXW + 2)) return false;
+  if ((size_t)(n + m + 2) * 64 > (size_t)(LC_CTX(c).C->max_w + LC_CTX(c).C->path_cap + 4) * (LC_CTX(c).C->max_w + 2)) return false;
   WG_LANE0 { S.al_band = 1; S.al_lo = lo; S.al_score = LC_BNEG; }
 #ifndef LANCET_WAVE_EMU
   {
@@ -3569,7 +3576,7 @@ DEVNI bool align_fill_band(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL
 // notes -- the walk itself then has no loads but the traceback bytes, eight cells of a diagonal at a time.
 DEVNI int align_traceback(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOBAL const uint8_t *Tx, int m) {
   LC_GLOBAL Work &W = *LC_CTX(c).W;
-  const int cap = LC_MAXW + (int)LC_CTX(c).C->path_cap + 2;
+  const int cap = (int)LC_CTX(c).C->max_w + (int)LC_CTX(c).C->path_cap + 2;
   LC_GLOBAL uint32_t *cols = W.scratch;
   (void)Sx; (void)Tx;
   int i = n, j = m, L = 0;
@@ -3623,7 +3630,7 @@ DEVNI int align_traceback_wg(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOB
   (void)Sx; (void)Tx;
   if (threadIdx.x < 64) {
     const int lane = (int)threadIdx.x;
-    const int cap = LC_MAXW + (int)LC_CTX(c).C->path_cap + 2;
+    const int cap = (int)LC_CTX(c).C->max_w + (int)LC_CTX(c).C->path_cap + 2;
     LC_GLOBAL uint32_t *cols = W.scratch;
     LC_GLOBAL const uint8_t *tbp = W.tb;
     const int band = S.al_band, blo = S.al_lo;
@@ -3674,7 +3681,7 @@ DEVNI int align_traceback_wg(Ctx &c, LC_GLOBAL const uint8_t *Sx, int n, LC_GLOB
 // all lanes: the aligned strings from the noted columns (noted from the end of the alignment backwards)
 DEVNI void align_traceback_fill(Ctx &c, LC_GLOBAL const uint8_t *Sx, LC_GLOBAL const uint8_t *Tx, int L) {
   LC_GLOBAL Work &W = *LC_CTX(c).W;
-  const int cap = LC_MAXW + (int)LC_CTX(c).C->path_cap + 2;
+  const int cap = (int)LC_CTX(c).C->max_w + (int)LC_CTX(c).C->path_cap + 2;
   LC_GLOBAL uint8_t *ra = W.aln, *pa = W.aln + cap;
   LC_GLOBAL const uint32_t *cols = W.scratch;
   WG_FOR(x, L) {
@@ -3866,7 +3873,7 @@ DEVNI void emit_variant(Ctx &c, const TS &t, const uint16_t cov[8], int strLen, 
 //   scratch[0..L) = pos_in_ref, scratch[L+1..2L+1) = pathpos - (column consumes a path base), scratch[2L+2..] = column list
 DEVNI void walk_prepare(Ctx &c, int L) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
-  const int cap = LC_MAXW + (int)LC_CTX(c).C->path_cap + 2;
+  const int cap = (int)LC_CTX(c).C->max_w + (int)LC_CTX(c).C->path_cap + 2;
   LC_GLOBAL const uint8_t *ra = W.aln, *pa = W.aln + cap;
   LC_GLOBAL uint32_t *E1 = W.scratch, *E2 = W.scratch + (L + 1), *F = W.scratch + 2 * (L + 1), *cols = W.scratch + 3 * (L + 1);
   WG_LANE0 { S.wk[0] = S.wk[1] = S.wk[2] = S.wk[3] = 0; E1[L] = 0; E2[L] = 0; F[L] = 0; }
@@ -3888,7 +3895,7 @@ DEVNI void walk_prepare(Ctx &c, int L) {
 DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int K = S.K;
-  const int cap = LC_MAXW + (int)LC_CTX(c).C->path_cap + 2;
+  const int cap = (int)LC_CTX(c).C->max_w + (int)LC_CTX(c).C->path_cap + 2;
   LC_GLOBAL const uint8_t *ra = W.aln, *pa = W.aln + cap;
   const int refstart = LC_CTX(c).B->ref_start[S.w];
   TS *ts = (TS *)(void *)W.tb;                 // the traceback matrix is dead by now: reuse it for the transcripts
@@ -4059,7 +4066,7 @@ DEV void walk_gather(Ctx &c, volatile LC_LDS uint32_t *rec, int pathpos, int P, 
 DEVNI void process_path_walk_wg(Ctx &c, int np, int plen, int L, int complete) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int K = wg_uniform(S.K);
-  const int cap = LC_MAXW + (int)LC_CTX(c).C->path_cap + 2;
+  const int cap = (int)LC_CTX(c).C->max_w + (int)LC_CTX(c).C->path_cap + 2;
   LC_GLOBAL const uint8_t *ra = W.aln, *pa = W.aln + cap;
   const int refstart = LC_CTX(c).B->ref_start[S.w];
   const int trim5 = wg_uniform(S.trim5);
@@ -4366,13 +4373,13 @@ DEVNI void count_ref_path(Ctx &c) {
         const int hd = (n == m) ? wg_uniform(S.ps_hd) : -1;
         const bool need_align = (hd == -1 || hd > 5);
         if (!need_align) {
-          const int cap = LC_MAXW + (int)LC_CTX(c).C->path_cap + 2;
+          const int cap = (int)LC_CTX(c).C->max_w + (int)LC_CTX(c).C->path_cap + 2;
           WG_FOR(i, n) { W.aln[i] = "ACGTN"[rs[i]]; W.aln[cap + i] = "ACGT"[W.pseq[i]]; }
         }
         WG_LANE0 {
           S.part[5] = (uint32_t)m; S.part[6] = need_align ? 1u : 0u;
           if (!need_align) S.part[7] = (uint32_t)n;
-          if (n > LC_MAXW || n < 1 || m < 1) OVF(c);
+          if (n > (int)LC_CTX(c).C->max_w || n < 1 || m < 1) OVF(c);
           if (S.overflow) S.part[3] = 1;
         }
       }
@@ -4629,7 +4636,7 @@ DEV void process_window(Ctx &c, int w, int rq = -1) {
     S.R = nr + 1;                                   // + the reference pseudo-read, appended last (Graph.cc:535-540)
     S.seq_t5 = 0; S.seq_len = S.reflen; S.trim5 = 0; S.trim3 = 0;
     S.tmp0 = 0;
-    if ((uint32_t)S.R > LC_CTX(c).C->reads_cap || S.R > 0xFFFF || S.reflen > LC_MAXW || S.reflen < 1) S.overflow = 1;   // csr / item words keep the read in 16 bits
+    if ((uint32_t)S.R > LC_CTX(c).C->reads_cap || S.R > 0xFFFF || S.reflen > (int)LC_CTX(c).C->max_w || S.reflen < 1) S.overflow = 1;   // csr / item words keep the read in 16 bits
     S.hasN = 0;
     S.nosusp_k = -1;
     if (rq >= 0) {                                  // what the window carried when it was suspended

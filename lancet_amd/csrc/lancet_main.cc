@@ -39,7 +39,7 @@ int die(const std::string &m) { fprintf(stderr, "lancet_gpu: %s\n", m.c_str()); 
 void usage() {
   fputs("Usage: lancet_gpu --tumor T.bam --normal N.bam --ref ref.fa (--reg chr:start-end | --bed regions.bed) [options] > out.vcf\n"
         "The reference's options with the reference's defaults (lancet --help), except:\n"
-        "   --window-size, -w  <int>   : at most 640 bp (the engine's per-window tables; the reference default is 600)\n"
+        "   --window-size, -w  <int>   : at most 1024 bp (the engine's per-window tables; the reference default is 600)\n"
         "   --max-k, -K        <int>   : at most 127; --min-k at least 3; --max-unit-length at most 8\n"
         "   --num-threads, -X  <int>   : accepted and ignored (windows are batched on the GPU)\n"
         "   --kmer-recovery, --print-graph, --node-str-len, --more-verbose, --print-config-file: not offered\n"

@@ -23,7 +23,9 @@
 #define LC_EMAX 12            /* edges per node (8 possible k-mer extensions + source/sink + slack)       */
 #define LC_NIL 0xFFFFFFFFu
 #define LC_BB 0xFFFFFFFEu     /* libstdc++ _M_before_begin sentinel in the bucket array                   */
-#define LC_MAXW 640           /* window length cap (reference WINDOW_SIZE = 600)                          */
+#define LC_MAXW 1024          /* hard cap of a window's length (k-mer positions of the reference pseudo-read are 10 bits; registers of the
+                                 full-matrix alignment); the work space is laid out for EngineCaps::max_w, the longest window of the batch */
+#define LC_MAXW_DEFAULT 640   /* ... which is at least this (reference WINDOW_SIZE = 600): the layouts of ordinary batches do not depend on the batch */
 #define LC_RS_WORDS 96        /* 64-bit words of the LDS copy of a string in repeat_scan (16 bases each) */
 #define LC_STAGE 192          /* occurrences staged in LDS per round of the per-position quality counts     */
 #define LC_PACK 8             /* candidates handled together in that pass                                   */
@@ -70,9 +72,9 @@
 #define CS_MAKE(r, p, ori, st) ((uint32_t)(r) | ((uint32_t)(p) << 16) | ((uint32_t)(ori) << 26) | ((uint32_t)(st) << 27))
 
 struct PreLayout {
-  uint32_t ncap, qvcap, kw;
-  uint32_t nhash, surv, snode, skey, sid, pgr, order, qv, chdr, clive, cseq;
-  uint32_t stride, pad;
+  uint32_t ncap, qvcap, kw, maxw;
+  uint32_t refcov, nhash, surv, snode, skey, sid, pgr, order, qv, chdr, clive, cseq;
+  uint32_t stride;
 };
 struct EngineCaps {
   uint32_t reads_cap;    /* reads per window (incl. the reference pseudo-read)            */
@@ -94,6 +96,7 @@ struct EngineCaps {
   uint32_t table_start;  /* testing only: first table size of every build (power of two; 0 = estimated)       */
   uint32_t lr_mode;      /* --linked-reads: 10 instead of 4 counters per (survivor, position), barcode outputs */
   uint32_t bx_cap;       /* barcode ids (u32) of the variants' barcode sets, whole batch (lr_mode)   */
+  uint32_t max_w;        /* longest window reference of the batch, rounded up (>= LC_MAXW_DEFAULT, <= LC_MAXW): sizes the alignment / coverage arrays */
   struct PreLayout pl;   /* hand-off areas of the LDS build kernel (below)                           */
 };
 
@@ -190,9 +193,8 @@ struct PreHdr {
  * A batch of deep windows (100x / 40x: 9-12 k distinct k-mers at k = 31..101) gets the wide form, the bulk of a 30x scan the narrow
  * one (660 KB per window instead of 1.7 MB).  Kernel code reads the offsets through `PL` (= EngineCaps::pl). */
 #define PRE_OFF_HDR 0u
-#define PRE_OFF_OCCREF 128u                                   /* u32[LC_MAXW]   node | ori << 31 per reference offset   */
-#define PRE_OFF_REFCOV (PRE_OFF_OCCREF + 4u * LC_MAXW)        /* u16[LC_MAXW*4]                                         */
-#define PRE_OFF_VAR (PRE_OFF_REFCOV + 8u * LC_MAXW)           /* what follows is laid out by lc_pre_layout:             */
+#define PRE_OFF_OCCREF 128u                                   /* u32[maxw]      node | ori << 31 per reference offset   */
+#define PRE_OFF_REFCOV (PL.refcov)                            /* u16[maxw*4]                                            */
 #define PRE_OFF_NHASH (PL.nhash)                              /* u64[ncap]      std::hash of every node, by node id     */
 #define PRE_OFF_SURV (PL.surv)                                /* u8[ncap]       1 = survivor                            */
 #define PRE_OFF_SNODE (PL.snode)                              /* u32[PB_CCAP]   node of candidate ci (LC_NIL: not a survivor) */
@@ -231,8 +233,8 @@ struct Work {
   LC_GLOBAL uint32_t *rd;           /* [reads_cap*4] per read: info word, packed-base offset, quality-mask offset, first occurrence (one 16-byte load) */
   LC_GLOBAL uint8_t *cand;          /* [reads_cap]   read has an earlier opposite mate of the same name  */
   LC_GLOBAL uint32_t *mate_of;      /* [reads_cap]   index of that earlier mate (when unique)            */
-  LC_GLOBAL uint32_t *items;        /* [2*(reads_cap + LC_MAXW/LC_SEG + 2)] work items of the per-occurrence passes */
-  LC_GLOBAL uint32_t *chunk;        /* [2*((reads_cap + LC_MAXW/LC_SEG + 2)/64 + 2)] sweep origin/length per group of items */
+  LC_GLOBAL uint32_t *items;        /* [2*(reads_cap + max_w/LC_SEG + 2)] work items of the per-occurrence passes */
+  LC_GLOBAL uint32_t *chunk;        /* [2*((reads_cap + max_w/LC_SEG + 2)/64 + 2)] sweep origin/length per group of items */
   LC_GLOBAL uint32_t *occ;          /* [occ_cap]     slot (then node) | ori<<31                           */
   LC_GLOBAL uint32_t *slots;        /* [4*table_cap] k-mer table, 16 bytes per slot: tag (u64), first occurrence, node id */
   LC_GLOBAL uint32_t *mv;           /* [4*occ_cap] mate-name vectors of the nodes with flagged occurrences (read << 16 | name rank) */
@@ -253,7 +255,7 @@ struct Work {
   LC_GLOBAL uint16_t *qv;           /* [qv_cap * QS] per-position min-quality counts Tf Tr Nf Nr (QS = 4), in lr_mode followed by
                              hp0/hp1/hp2_minqv of the tumor and of the normal (QS = 10)        */
   LC_GLOBAL uint16_t *khp;          /* [nodes*6] lr_mode: last-written hp0 hp1 hp2 of the k-mer, tumor then normal */
-  LC_GLOBAL uint16_t *refhp;        /* [LC_MAXW*6] lr_mode: the same per rawseq position (Ref_t coverage)  */
+  LC_GLOBAL uint16_t *refhp;        /* [max_w*6] lr_mode: the same per rawseq position (Ref_t coverage)  */
   LC_GLOBAL uint32_t *bxbuf;        /* [reads_cap] lr_mode: sorted distinct barcodes of the set being collected */
   LC_GLOBAL uint32_t *seq;          /* [seq_cap] descriptor arena                                        */
   /* ---- libstdc++ node-table order ---- */
@@ -264,16 +266,16 @@ struct Work {
   LC_GLOBAL uint32_t *order;        /* [nodes] iteration order of the live table                         */
   LC_GLOBAL uint32_t *scratch;      /* [nodes*2] stacks / queues of the graph passes                     */
   /* ---- reference coverage ---- */
-  LC_GLOBAL uint16_t *refcov;       /* [LC_MAXW*4] Tf Tr Nf Nr per rawseq position                       */
+  LC_GLOBAL uint16_t *refcov;       /* [max_w*4] Tf Tr Nf Nr per rawseq position                       */
   /* ---- paths ---- */
   LC_GLOBAL BfsEntry *queue;        /* [queue_cap]                                                       */
   LC_GLOBAL uint32_t *pnodes;       /* [nodes] nodes of the current path                                 */
   LC_GLOBAL uint32_t *pedges;       /* [nodes] edge refs of the current path                             */
   LC_GLOBAL uint32_t *pdesc;        /* [path_cap] descriptor per path base                               */
   LC_GLOBAL uint8_t *pseq;          /* [path_cap] path string (codes 0..3)                               */
-  LC_GLOBAL uint8_t *tb;            /* [(LC_MAXW+2)*(path_cap+2)] traceback bits                         */
-  LC_GLOBAL int32_t *dp;            /* [7*(LC_MAXW+2)] alignment diagonals                               */
-  LC_GLOBAL uint8_t *aln;           /* [2*(LC_MAXW+path_cap+2)] aligned strings (ASCII)                  */
+  LC_GLOBAL uint8_t *tb;            /* [(max_w+2)*(path_cap+2)] traceback bits                         */
+  LC_GLOBAL int32_t *dp;            /* [7*(max_w+2)] alignment diagonals                               */
+  LC_GLOBAL uint8_t *aln;           /* [2*(max_w+path_cap+2)] aligned strings (ASCII)                  */
   LC_GLOBAL uint32_t *evt;          /* [evt_cap] trace events                                            */
   LC_GLOBAL uint8_t *survb;         /* [nodes] prebuilt window: survivor flag per node (stands in for the stale node records) */
 };

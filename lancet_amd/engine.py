@@ -110,6 +110,8 @@ class Engine:
         cb = abi.batch_to_c(batch)
         keep = {k: np.ascontiguousarray(packed[k], dtype=np.uint32) for k in ("rinfo", "base_woff", "good_woff", "bases", "good")}
         pk = abi.LancetPackedReads(*[keep[k].ctypes.data_as(C.POINTER(C.c_uint32)) for k in ("rinfo", "base_woff", "good_woff", "bases", "good")])
+        # (the thresholds the producer packed with: host.NativeHost.batch records them; a dict without them claims this engine's own)
+        pk.min_qual_trim = int(packed.get("min_qual_trim", self.params.min_qual_trim)); pk.min_qual_call = int(packed.get("min_qual_call", self.params.min_qual_call))
         self._packed_keep = keep
         self.L.lancet_engine_upload_packed.restype = C.c_int
         self.L.lancet_engine_upload_packed.argtypes = [C.c_void_p, C.POINTER(abi.LancetWindowBatch), C.POINTER(abi.LancetPackedReads)]

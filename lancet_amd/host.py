@@ -157,6 +157,7 @@ class NativeHost:
         if pack_params is not None:
             bw = arr(pk.base_woff, R + 1, np.uint32); gw = arr(pk.good_woff, R + 1, np.uint32)
             packed = dict(rinfo=arr(pk.rinfo, R + 1, np.uint32), base_woff=bw, good_woff=gw,
-                          bases=arr(pk.bases, (int(bw[-1]) if R else 0) + 4, np.uint32), good=arr(pk.good, (int(gw[-1]) if R else 0) + 1, np.uint32))
+                          bases=arr(pk.bases, (int(bw[-1]) if R else 0) + 4, np.uint32), good=arr(pk.good, (int(gw[-1]) if R else 0) + 1, np.uint32),
+                          min_qual_trim=int(pk.min_qual_trim), min_qual_call=int(pk.min_qual_call))
             return b, idx, packed
         return b, idx

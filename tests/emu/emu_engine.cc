@@ -183,6 +183,7 @@ extern "C" int lancet_emu_align(const char *Sa, const char *Ta, char *S_aln, cha
   EngineCaps caps; memset(&caps, 0, sizeof(caps));
   caps.reads_cap = 4; caps.occ_cap = 64; caps.node_cap = 16; caps.table_cap = 32; caps.bucket_cap = 32; caps.special_cap = 4; caps.surv_cap = 4;
   caps.seq_cap = 64; caps.queue_cap = 4; caps.path_cap = (uint32_t)m + 8; caps.max_k = 16; caps.qv_cap = 64;
+  caps.max_w = LC_MAXW_DEFAULT > (((uint32_t)n + 63u) & ~63u) ? LC_MAXW_DEFAULT : (((uint32_t)n + 63u) & ~63u);
   size_t bytes = lc_work_carve(nullptr, nullptr, caps);
   std::vector<char> mem(bytes + 256, 0);
   Work w; lc_work_carve(&w, mem.data(), caps);
@@ -196,7 +197,7 @@ extern "C" int lancet_emu_align(const char *Sa, const char *Ta, char *S_aln, cha
   int L = align_traceback(c, sc.data(), n, tc.data(), m);
   if (S.overflow || L + 1 > cap) return -1;
   align_traceback_fill(c, sc.data(), tc.data(), L);
-  const int acap = LC_MAXW + (int)caps.path_cap + 2;
+  const int acap = (int)caps.max_w + (int)caps.path_cap + 2;
   memcpy(S_aln, w.aln, L); memcpy(T_aln, w.aln + acap, L); S_aln[L] = 0; T_aln[L] = 0;
   return L;
 }

@@ -376,6 +376,18 @@ def test_deep_str_windows_build_in_lds_at_k_above_31(monkeypatch):
     assert emu.LAST_PREBUILT[0] == 0
 
 
+def test_windows_of_1000_bases_among_ordinary_ones():
+    """`--window-size 1000` (the reference takes any -w: src/Lancet.cc:662,732): the work space and the hand-off areas are laid out for
+    the longest window of the batch (EngineCaps::max_w, up to LC_MAXW = 1024), the full-matrix alignment keeps 16 rows per lane for
+    them.  Windows of 600, 1000 and 1024 bases in one batch: records, stats and trace equal the oracle's, all built in LDS."""
+    from lancet_amd import workload
+    p = abi.default_params()
+    big = workload.concat_batches([workload.make_scan_batch(10, 30, 30, seed=7), workload.make_scan_batch(12, 30, 30, seed=8, window=1000),
+                                   workload.make_scan_batch(4, 30, 30, seed=9, window=1024)])
+    st = _same_as_oracle(big, p)
+    assert all(s["status"] >= 0 for s in st) and emu.LAST_PREBUILT[0] == big.n_windows
+
+
 def test_mate_overlap_replay_in_ranges_of_nodes(monkeypatch):
     """hasOverlappingMate's exact replay in the LDS build kernel sorts the occurrences of the marked nodes in an LDS list; when they do
     not fit, the nodes are taken in ranges.  170-base reads at a 400 +- 40 insert: a tenth of the pairs overlap (~200 occurrences in

@@ -391,16 +391,45 @@ def test_host_and_device_trim_and_pack_agree(monkeypatch):
         assert out[0][0] == ov
 
 
+def test_window_size_1000_inside_ordinary_batches():
+    """`--window-size 1000` (reference src/Lancet.cc:662,732: any -w): windows of 600, 1000 and 1024 (= LC_MAXW) bases in one batch --
+    work space and hand-off areas laid out for the longest, the full-matrix alignment forced for every path on a second engine
+    (LANCET_NO_BAND is not a knob: the band certifies itself or not; the device alignment test covers 1024-base strings) -- equal
+    to the oracle in records, stats and trace."""
+    from lancet_amd import workload
+    p = abi.default_params()
+    big = workload.concat_batches([workload.make_scan_batch(40, 30, 30, seed=7), workload.make_scan_batch(48, 30, 30, seed=8, window=1000),
+                                   workload.make_scan_batch(16, 30, 30, seed=9, window=1024)])
+    ov, ostats, otr = oracle.run(big, p, verbose=True)
+    key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
+    eng = engine.Engine(p, device=0, trace_words=1 << 17)
+    for _ in range(2):
+        variants, stats = eng.process(big)
+        assert variants == ov and [key(s) for s in stats] == [key(s) for s in ostats]
+        assert gu.digest_trace(eng.trace_text()) == gu.digest_trace(otr)
+    assert all(s["status"] >= 0 for s in stats) and len(ov) > 20
+    eng.close()
+    # the device alignment on strings of the longest window (full matrix: 16 rows per lane; band; band with fall-back)
+    import random
+    rnd = random.Random(5)
+    S = "".join(rnd.choice("ACGT") for _ in range(1024))
+    T = S[:300] + "ACGTTGCA" + S[300:700] + S[720:]
+    eng = engine.Engine(p, device=0)
+    for mode in (0, 1):
+        assert eng.debug_align(S, T, mode=mode) == oracle.align(S, T)
+    eng.close()
+
+
 def test_a_window_beyond_the_engine_limits_fails_alone():
-    """One window of 700 bp (LC_MAXW is 640) and one with 70 000 reads (read ids are 16 bit) inside an ordinary batch: they are reported
+    """One window of 1100 bp (LC_MAXW is 1024) and one with 70 000 reads (read ids are 16 bit) inside an ordinary batch: they are reported
     LANCET_W_OVERFLOW on their own; the batch is not refused and every other window equals the oracle."""
     from lancet_amd import frontend, workload
     p = abi.default_params()
     b = workload.make_scan_batch(24, 20, 20, seed=9, read_len=100)
-    # window 5: 100 more reference bases
+    # window 5: 500 more reference bases
     ref = bytearray(b.ref_bases.tobytes()); cut = int(b.ref_off[6])
-    ref[cut:cut] = (b"ACGT" * 25)
-    ref_off = b.ref_off.astype(np.int64).copy(); ref_off[6:] += 100
+    ref[cut:cut] = (b"ACGTA" * 100)
+    ref_off = b.ref_off.astype(np.int64).copy(); ref_off[6:] += 500
     # window 11: its reads 400 times over (70 k reads, names ranked densely)
     r0, r1 = int(b.read_begin[11]), int(b.read_begin[12]); n = r1 - r0; times = 70000 // n + 1
     lens = np.diff(b.seq_off.astype(np.int64))

@@ -753,7 +753,7 @@ def test_packed_batch_equals_packing_the_ascii_batch():
 def test_packed_upload_gives_the_records_of_the_ascii_upload():
     """lancet_host_batch_packed -> lancet_engine_upload_packed against lancet_host_batch -> lancet_engine_upload on the same windows (and
     the oracle): same records and statistics, with trim parameters that bite; a packed batch whose offsets do not fit the read lengths is
-    refused."""
+    refused, and so is one packed with other quality thresholds than the engine's."""
     from oracle import oracle
     from lancet_amd import abi, engine
     for case, over in (("ar_small", {}), ("leak_small", dict(min_qual_trim=33 + 25, min_qual_call=33 + 30))):
@@ -775,6 +775,11 @@ def test_packed_upload_gives_the_records_of_the_ascii_upload():
         with pytest.raises(engine.EngineError):
             eng.upload_packed(b2, bad)
         eng.close()
+        # reads packed for other thresholds are refused, not assembled (the trim and the quality mask depend on them)
+        other = engine.Engine(abi.default_params(min_qual_trim=p.min_qual_trim + 3))
+        with pytest.raises(engine.EngineError):
+            other.upload_packed(b2, pk)
+        other.close()
 
 
 def test_pack_read_against_a_plain_restatement():

@@ -21,14 +21,16 @@ def replicate(batch, times):
 
 case = sys.argv[1] if len(sys.argv) > 1 else "tile30"
 times = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-if case in ("bench", "bench60"):                      # the bench.py workload (bench60: at 60x/60x), `times` windows
+if case in ("bench", "bench60", "bench4", "bench5"):   # the bench.py workload (bench60: at 60x/60x; bench4: config 4; bench5: linked reads), `times` windows
     from lancet_amd import workload
     cov = 60 if case == "bench60" else 30
-    big, mk, xk = workload.make_scan_batch(times, cov, cov, seed=22), 11, 101
+    if case == "bench4": big, mk, xk = workload.make_scan_batch(times, 100.0, 40.0, seed=22, str_fraction=0.30, lowcomplex_fraction=0.05), 11, 101
+    elif case == "bench5": big, mk, xk = workload.make_scan_batch(times, 30.0, 30.0, seed=22, linked=True), 11, 101
+    else: big, mk, xk = workload.make_scan_batch(times, cov, cov, seed=22), 11, 101
 else:
     meta, batch, kept, (mk, xk) = gu.case_batch(case)
     big = replicate(batch, times)
-p = abi.default_params(min_k=mk, max_k=xk)
+p = abi.default_params(min_k=mk, max_k=xk, lr_mode=1) if case == "bench5" else abi.default_params(min_k=mk, max_k=xk)
 eng = engine.Engine(p)
 t = time.time(); eng.upload(big); print("upload s", time.time() - t, "windows", big.n_windows, "slots/bytes", eng.geometry())
 for it in range(3):
