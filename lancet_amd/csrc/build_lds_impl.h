@@ -206,13 +206,35 @@ DEV void bl_canon_x(const BlKm &v, int NW, int K, BlKm &ck, BlKm &alt, bool *isF
 #endif
   bl_canon_n<1>(v, K, ck, alt, isF);
 }
-DEV bool bl_km_eq(const BlKm &a, const BlKm &b) { bool e = true; for (int i = 0; i < BL_KW; ++i) e = e && a.w[i] == b.w[i]; return e; }
-DEV int bl_km_char(const BlKm &ck, int K, int j) {                   // j-th character of a canonical key
-  const int bit = 2 * (K - 1 - j), wd = bit >> 6;
-  unsigned long long x = ck.w[0];
-  for (int i = 1; i < BL_KW; ++i) x = wd == i ? ck.w[i] : x;
-  return (int)((x >> (bit & 63)) & 3ULL);
+// libstdc++ std::hash of the canonical k-mer's string (kernels.h std_hash_bytes), characters taken off the top of the key eight at a
+// time: the key is shifted to the top of its NW words once and then moves left by 16 bits per block -- constant register indices
+// only (a character picked by a run-time word index put the key in scratch memory: one dependent load per character).
+DEV int bl_acgt(int code) { return (int)((0x54474341u >> (8 * code)) & 0xFFu); }      // 'A' 'C' 'G' 'T' without a look-up in constant memory
+DEV unsigned long long bl_std_hash_km(const BlKm &ck, int NW, int K) {
+  unsigned long long w[BL_KW];
+  {   // left-align: shift the NW-word value left by 64 * NW - 2 * K bits (< 64), then move it to the top of the BL_KW words
+    const int s = 64 * NW - 2 * K;
+    unsigned long long t[BL_KW];
+    for (int i = 0; i < BL_KW; ++i) t[i] = i < NW ? ((ck.w[i] << s) | ((i > 0 && s) ? (ck.w[i - 1] >> (64 - s)) : 0ULL)) : 0ULL;
+    for (int i = 0; i < BL_KW; ++i) { unsigned long long x = 0; for (int j = 0; j < BL_KW; ++j) if (j + (BL_KW - NW) == i) x = t[j]; w[i] = x; }
+  }
+  const unsigned long long mul = (0xc6a4a793ULL << 32) + 0x5bd1e995ULL;
+  unsigned long long hash = 0xc70f6907ULL ^ ((unsigned long long)K * mul);
+  auto take = [&](int nch) -> unsigned long long {                    // the next nch (<= 8) characters as a little-endian block of bytes
+    const uint32_t top = (uint32_t)(w[BL_KW - 1] >> 48);
+    unsigned long long d = 0;
+    for (int j = 0; j < 8; ++j) if (j < nch) d |= (unsigned long long)bl_acgt((int)((top >> (14 - 2 * j)) & 3u)) << (8 * j);
+    for (int i = BL_KW - 1; i > 0; --i) w[i] = (w[i] << 16) | (w[i - 1] >> 48);
+    w[0] <<= 16;
+    return d;
+  };
+  const int nblk = K & ~7;
+  for (int i = 0; i < nblk; i += 8) { unsigned long long d = take(8); d *= mul; d ^= d >> 47; d *= mul; hash ^= d; hash *= mul; }
+  if (K & 7) { const unsigned long long d = take(K & 7); hash ^= d; hash *= mul; }
+  hash ^= hash >> 47; hash *= mul; hash ^= hash >> 47;
+  return hash;
 }
+DEV bool bl_km_eq(const BlKm &a, const BlKm &b) { bool e = true; for (int i = 0; i < BL_KW; ++i) e = e && a.w[i] == b.w[i]; return e; }
 DEV int bl_base(const LC_LDS uint32_t *bases, uint32_t boff) { return (int)((bases[boff >> 4] >> ((boff & 15u) * 2u)) & 3u); }
 // quality-mask bits [a, b) of a read whose mask starts at word gw: all set?
 DEV bool bl_all_good(const LC_LDS uint32_t *goodm, uint32_t gw, int a, int b) {
@@ -275,8 +297,11 @@ template <class F> DEV void bl_for_occ(BL_S &S, LC_GLOBAL const bl_on_t *occn, F
 #define BLC_TO(e) ((uint32_t)(e) & 0x3FFu)
 #define BLC_DIR(e) (((uint32_t)(e) >> 10) & 3u)
 #define BLC_MAKE(to, dir) ((uint16_t)((to) | ((dir) << 10)))
-DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const EngineCaps *C, BL_S &S, BlScratch &X, LC_GLOBAL uint8_t *area, const int K,
-                             const uint32_t N, const uint32_t nsurv, const uint32_t ncand, const int reflen, const uint32_t ht_bc) {
+DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const EngineCaps *C, BL_S &S, BlScratch &X, LC_GLOBAL uint8_t *area, const int K_,
+                             const uint32_t N_, const uint32_t nsurv_, const uint32_t ncand_, const int reflen_, const uint32_t ht_bc_) {
+  P = lc_sgpr(P); C = lc_sgpr(C); area = lc_sgpr(area);                        // (uniform arguments: scalar registers, wave.h lc_sgpr)
+  const uint32_t N = lc_sgpr(N_), nsurv = lc_sgpr(nsurv_), ncand = lc_sgpr(ncand_), ht_bc = lc_sgpr(ht_bc_); const int reflen = lc_sgpr(reflen_);
+  const int K = lc_sgpr(K_);
   LC_GLOBAL const PreLayout &PL = C->pl;
   LC_GLOBAL PreCmp *CH = (LC_GLOBAL PreCmp *)(area + PRE_OFF_CHDR);
   LC_GLOBAL const uint32_t *occ_ref = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_OCCREF);
@@ -697,6 +722,8 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
 // rep: the window's isRepeat / isAlmostRepeat operands when an earlier call scanned the reference already, else null.
 DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *Bp, LC_GLOBAL const EngineCaps *C, BL_S &S, LC_GLOBAL uint8_t *xbase,
                            LC_GLOBAL uint8_t *area, int w, int kmin, LC_GLOBAL const PreHdr *rep) {
+  P = lc_sgpr(P); Bp = lc_sgpr(Bp); C = lc_sgpr(C); xbase = lc_sgpr(xbase); area = lc_sgpr(area); rep = lc_sgpr(rep);      // (uniform arguments: scalar registers, wave.h lc_sgpr)
+  w = lc_sgpr(w); kmin = lc_sgpr(kmin);
   LC_GLOBAL const DevBatch &B = *Bp;
   LC_GLOBAL const PreLayout &PL = C->pl;
   BlScratch X; bl_scratch_carve(&X, xbase);                       // (a local of this function: its pointers live in registers)
@@ -1022,17 +1049,18 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   {
     LC_GLOBAL unsigned long long *nhash = (LC_GLOBAL unsigned long long *)(area + PRE_OFF_NHASH);
     LC_GLOBAL uint8_t *surv = (LC_GLOBAL uint8_t *)(area + PRE_OFF_SURV);
-    WG_FOR(n, N) {
+    WG_FULL_BEGIN(n, act, N)                                     // (every lane hashes: wave.h WG_FULL_BEGIN)
+      unsigned long long h;
 #if BL_KW > 1
       if (NW > 1) {
-      BlKm v, ck, alt; bool f; bl_kmer_x(S.bases, bl_idoff(S, X, (uint32_t)n), NW, K, v); bl_canon_x(v, NW, K, ck, alt, &f);
-      nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGT"[bl_km_char(ck, K, j)]; }, K);
+        BlKm v, ck, alt; bool f; bl_kmer_x(S.bases, bl_idoff(S, X, (uint32_t)n), NW, K, v); bl_canon_x(v, NW, K, ck, alt, &f);
+        h = bl_std_hash_km(ck, NW, K);
       } else
 #endif
       { bool f; const unsigned long long ck = bl_canon(bl_kmer(S.bases, bl_idoff(S, X, (uint32_t)n), kmask), K, kmask, &f);
-        nhash[n] = std_hash_bytes([&](int j) -> int { return (int)"ACGT"[key_base(&ck, K, j)]; }, K); }
-      surv[n] = 0;
-    }
+        h = std_hash_bytes([&](int j) -> int { return bl_acgt((int)((ck >> (2 * (K - 1 - j))) & 3ULL)); }, K); }
+      if (act) { nhash[n] = h; surv[n] = 0; }
+    WG_FULL_END
   }
   // ---- tracked nodes: those whose occurrence count leaves the first removeLowCov test open, and every node with a read AND
   //      a reference occurrence (their counts feed Ref_t::computeCoverage).  A node with one occurrence is decided: its

@@ -213,6 +213,7 @@ struct lancet_engine {
   int prep_threads_auto = 1;       // hardware threads, at most 96 -- and at most twice the container's CPU quota (cgroup cpu.max): measured on a 16-CPU quota, 32 threads pack a batch in 26 ms, 16 in 39, 96 in 31
   int exact_need_large = -1;       // host trim: windows that exceed the 512-lane build configuration (exact: from the trimmed lengths); -1 unknown
   float ms_pack = 0;
+  bool up_timing = false;          // LANCET_UPLOAD_TIMING=1: where lancet_engine_upload spends its time (allocations, packing, the copy), on stderr
   bool dbg = false, no_fat = false, no_early_rerun = false, no_large_build = false;     // LANCET_DEBUG / LANCET_NO_FAT / ... read once, at create
   int build_slots_env = 0, ahead_depth_env = -1;
   int pre_wide_env = -1;           // LANCET_PRE_WIDE=0 / 1: the narrow / wide form of the hand-off areas whatever the batch looks like
@@ -313,6 +314,7 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
     }
     e->prep_threads_auto = (int)hw;
   }
+  e->up_timing = getenv("LANCET_UPLOAD_TIMING") != nullptr;
   e->dbg = getenv("LANCET_DEBUG") != nullptr; e->no_fat = getenv("LANCET_NO_FAT") != nullptr; e->no_early_rerun = getenv("LANCET_NO_EARLY_RERUN") != nullptr;
   e->no_large_build = getenv("LANCET_NO_LARGE_BUILD") != nullptr; e->heavy_first = getenv("LANCET_NO_HEAVY_FIRST") == nullptr;
   if (const char *s = getenv("LANCET_BUILD_SLOTS")) e->build_slots_env = std::max(1, atoi(s));
@@ -398,6 +400,15 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
   if (e->submitted) { e->err = "upload while a batch is in flight"; return LANCET_E_STATE; }
   HIPCHK(e, hipSetDevice(e->device));
   e->uploaded = false; e->ran = false;
+  auto t_up0 = std::chrono::steady_clock::now();
+  auto tick = [&](const char *what, size_t bytes = 0) {
+    if (!e->up_timing) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[lancet upload] %-34s %8.1f ms", what, std::chrono::duration<double, std::milli>(t - t_up0).count());
+    if (bytes) fprintf(stderr, "  (%.2f GB)", bytes / 1073741824.0);
+    fprintf(stderr, "\n");
+    t_up0 = t;
+  };
   const int nw = b->n_windows;
   if (e->params.lr_mode && nw > 0 && b->read_begin[nw] > 0 && (!b->bx_rank || !b->hp)) { e->err = "lr_mode needs bx_rank and hp"; return LANCET_E_ARG; }
   const uint32_t R = nw ? b->read_begin[nw] : 0;
@@ -567,6 +578,7 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
   db.good_woff = (LC_GLOBAL const uint32_t *)e->d_gw.p; db.bases = (LC_GLOBAL const uint32_t *)e->d_bases.p; db.good = (LC_GLOBAL const uint32_t *)e->d_good.p;
   db.bx_rank = e->params.lr_mode ? (LC_GLOBAL const uint32_t *)e->d_bx.p : nullptr; db.hp = e->params.lr_mode ? (LC_GLOBAL const uint8_t *)e->d_hp.p : nullptr;
   }
+  tick("inputs (pack + stage + copy)");
   UP(e->d_batch, &db, sizeof(db));
   UP(e->d_caps, &e->caps, sizeof(e->caps));
   UP(e->d_caps2, &e->caps2, sizeof(e->caps2));
@@ -582,6 +594,7 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
     slots = slots * 3 / 4;
   }
   e->n_slots = slots;
+  tick("work space of the window kernel", (size_t)slots * slot_bytes);
   std::vector<Work> works(slots);
   for (int s = 0; s < slots; ++s) lc_work_carve(&works[s], (char *)e->d_workmem.p + (size_t)s * slot_bytes, e->caps);
   UP(e->d_works, works.data(), sizeof(Work) * slots);
@@ -632,7 +645,9 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
     const bool svc_helps = e->svc && e->n_svc_wgs > 0 && !e->debug_stop && e->svc_help;
     e->n_bslots = std::max(1, std::min(nw, cus * 2 - 2 - (svc_helps ? std::min(e->n_svc_wgs, cus) : 0)));
     if (e->build_slots_env) e->n_bslots = std::min(nw, e->build_slots_env);
+    tick("outputs");
     ENS(e->d_pre, (size_t)nw * e->caps.pl.stride);
+    tick("hand-off areas", (size_t)nw * e->caps.pl.stride);
     ENS(e->d_blscratch, (size_t)e->n_bslots * bl_small::SCRATCH_BYTES);
     // Can any window be too big for the 512-lane configuration?  Trimming only shortens reads, so the untrimmed lengths bound the
     // LDS footprint (reads padded to 16 bases + the reference); when none can, the 1024-lane kernel is not launched at all.
@@ -670,11 +685,12 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
       e->svc_host.cont = (LC_GLOBAL SvcCont *)((char *)e->d_svc.p + off_cont);
       o.svc = (LC_GLOBAL SvcCtl *)e->d_svc.p;
     }
-    if (e->pool_cap) { ENS(e->d_prepool, (size_t)e->pool_cap * e->caps.pl.stride); o.pre_pool = (LC_GLOBAL const uint8_t *)e->d_prepool.p; o.n_ahead_used = (LC_GLOBAL uint32_t *)e->d_counters.p + 14; }
+    if (e->pool_cap) { ENS(e->d_prepool, (size_t)e->pool_cap * e->caps.pl.stride); tick("pool of hand-off areas", (size_t)e->pool_cap * e->caps.pl.stride); o.pre_pool = (LC_GLOBAL const uint8_t *)e->d_prepool.p; o.n_ahead_used = (LC_GLOBAL uint32_t *)e->d_counters.p + 14; }
   }
   UP(e->d_out, &o, sizeof(o));
   DBG("sync");
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  tick("rest + stream sync");
   DBG("uploaded");
   e->uploaded = true;
   return LANCET_OK;

@@ -66,8 +66,8 @@ struct WinShared {
   int wk_stop, wk_nts, wk_last, wk_code, wk_tend, wk_tref;   // process_path_walk_wg: lane 0's state between the chunks of columns
   // (8 KB of LDS per workgroup = 20 single-wave workgroups per CU, the fifth wave per SIMD: two pairs of buffers that are
   //  never live together share their space)
-  union {
-    uint32_t mk[LC_QSTAGE][4];                   // staged quality masks of up to LC_QSTAGE occurrences
+  union alignas(16) {
+    uint32_t mk[LC_QSTAGE][4];                   // staged quality masks of up to LC_QSTAGE occurrences (read back as 16-byte vectors)
     unsigned long long rs[LC_RS_WORDS];          // repeat_scan (window start): the string at 4 bits per base
     uint8_t lbytes[LC_QSTAGE * 16];              // alignment: the two strings (band fill) ; transcript walk: the transcripts (LC_TS_LDS of them)
   };

@@ -32,6 +32,11 @@ DEV int wg_thin_lane() { const int t = (int)threadIdx.x; return t < 64 ? t : 0x3
 #define XG_FOR(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += (int)blockDim.x)
 #define XG_LANES LC_FAT_LANES
 #endif
+// A data-parallel loop whose body EVERY lane runs: a lane past the end works on the last item again and `act` is false for it (the body
+// guards its stores with it).  For loops with a heavy body: no EXEC-masked region around it, so whatever the register allocator moves
+// inside the body is moved in every lane (see lc_sgpr below for what happened otherwise).
+#define WG_FULL_BEGIN(i, act, n) for (int _b = 0; _b < (int)(n); _b += (int)blockDim.x) { const bool act = _b + (int)threadIdx.x < (int)(n); const int i = act ? _b + (int)threadIdx.x : (int)(n) - 1;
+#define WG_FULL_END }
 // Agent-scope fence before the barrier: the phases communicate through HBM with a mix of atomics (performed
 // at L2) and plain loads (which may hit the CU's vector L1), so the L1 has to be invalidated at phase boundaries.
 #define WG_SYNC() __syncthreads()
@@ -64,6 +69,18 @@ template <class P> DEV uint32_t ld_acq(P p) { return __hip_atomic_load(p, __ATOM
 template <class P> DEV void st_rel(P p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 template <class P> DEV uint32_t add_rel(P p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 DEV void dev_sleep() { __builtin_amdgcn_s_sleep(127); }
+// A pointer / integer that is the same in every lane, moved to scalar registers.  Arguments of a non-inlined device function arrive in
+// VGPRs whatever they hold; a value the compiler knows to be uniform needs no VGPR live range -- and cannot be hit by the live-range
+// split ROCm 7.2's register allocator was seen to place in front of an EXEC restore (round 4: the copy of the EngineCaps pointer sat
+// BEFORE `s_or_b64 exec` of the join block of a loop that waves without work skip, so those waves went on with a stale register and
+// faulted on the next load through it; tools/check_exec_copies.py looks for that shape in the compiled kernels).
+DEV uint32_t lc_sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+DEV int lc_sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T> DEV T *lc_sgpr(T *p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned long long r = (unsigned long long)lc_sgpr((uint32_t)v) | ((unsigned long long)lc_sgpr((uint32_t)(v >> 32)) << 32);
+  return (T *)r;
+}
 typedef uint4 lc_u4;
 typedef uint32_t lc_v4 __attribute__((ext_vector_type(4)));
 // 16-byte load / store through a global pointer (HIP's uint4 has no copy from an address-space reference)
@@ -78,6 +95,8 @@ DEV int dev_popcll(unsigned long long x) { return __popcll(x); }
 #define DEV static inline
 #define DEVNI static
 #define WG_FOR(i, n) for (int i = 0; i < (int)(n); ++i)
+#define WG_FULL_BEGIN(i, act, n) for (int i = 0; i < (int)(n); ++i) { const bool act = true;
+#define WG_FULL_END }
 #define XG_FOR(i, n) WG_FOR(i, n)
 #define XG_LANES 64
 static thread_local unsigned long lc_emu_syncs = 0;          /* barriers a workgroup would execute (tuning aid: tests/emu LANCET_EMU_SYNCS) */
@@ -99,6 +118,7 @@ DEV uint32_t ld_acq(const uint32_t *p) { return *p; }
 DEV void st_rel(uint32_t *p, uint32_t v) { *p = v; }
 DEV uint32_t add_rel(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 DEV void dev_sleep() {}
+template <class T> DEV T lc_sgpr(T v) { return v; }
 struct alignas(16) lc_u4 { uint32_t x, y, z, w; };
 typedef lc_u4 lc_v4;
 DEV lc_u4 ldg4(const uint32_t *p) { return *(const lc_u4 *)p; }

@@ -102,3 +102,12 @@ def test_native_trace_formatter_matches_the_python_one(lib, name):
         got.append(ctypes.string_at(ptr).decode())
         lib.lancet_free(ptr)
     assert "".join(got) == text
+
+
+def test_no_register_copies_in_front_of_an_exec_restore():
+    """A miscompile of ROCm 7.2's backend met in round 4 (tools/check_exec_copies.py): live-range copies of the register allocator placed
+    at the top of a join block BEFORE `s_or_b64 exec` -- waves that skipped the region went on with a stale register (a memory fault in
+    the 1024-lane build kernel on windows with fewer nodes than lanes).  The compiled kernels of every .hip are scanned for that shape."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_exec_copies.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
