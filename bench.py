@@ -168,6 +168,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--windows", type=int, default=32768, help="windows per GPU per step")
     ap.add_argument("--cov", type=float, default=30.0, help="coverage per sample")
+    ap.add_argument("--cov-normal", type=float, default=None, help="coverage of the normal sample when it differs from --cov (config 4: --cov 100 --cov-normal 40)")
+    ap.add_argument("--str-fraction", type=float, default=0.0, help="share of the synthetic reference that is short tandem repeats (config 4: 0.30)")
+    ap.add_argument("--lowcomplex-fraction", type=float, default=0.0, help="share that is low-complexity sequence (config 4: 0.05)")
+    ap.add_argument("--linked", action="store_true", help="BX / HP tags on every pair and --linked-reads in the engine (config 5)")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="windows timed on one thread of the CPU oracle (0 = skip the CPU legs)")
     ap.add_argument("--cpu-sample-all", type=int, default=16384, help="windows timed on all host cores")
     ap.add_argument("--no-configs", action="store_true", help="skip the side configurations (60x/60x, 100x/40x STR)")
@@ -204,23 +208,25 @@ def main():
     torch.cuda.set_device(device)
     comm_device = torch.device("cpu") if one_gpu else device
 
+    cov_n = args.cov if args.cov_normal is None else args.cov_normal
+    wl_kw = dict(str_fraction=args.str_fraction, lowcomplex_fraction=args.lowcomplex_fraction, linked=args.linked)
     rccl_ranks = dist.get_world_size() if world > 1 else 1     # what the process group reports, not what was asked for
     strong = args.scaling == "strong" and world > 1
     if strong:
         # one contig, its windows dealt out in chunks of 1024 (dist.shard_windows): every rank holds interleaved runs of windows, so the
         # records reach rank 0 out of window order and the replay has to restore it
         chrom = "chr22"
-        full = workload.make_scan_batch(args.windows, args.cov, args.cov, seed=22, chrom=chrom)
+        full = workload.make_scan_batch(args.windows, args.cov, cov_n, seed=22, chrom=chrom, **wl_kw)
         mine = np.array(ldist.shard_windows(args.windows, rank, world, chunk=1024), dtype=np.int64)
         runs = np.split(mine, np.where(np.diff(mine) != 1)[0] + 1) if len(mine) else []
         batch = workload.concat_batches([workload.sub_batch(full, int(r[0]), int(r[-1]) + 1) for r in runs])
         windex = mine
     else:
         chrom = f"chr{22 + rank}" if rank else "chr22"           # one synthetic contig per rank
-        batch = workload.make_scan_batch(args.windows, args.cov, args.cov, seed=22 + 1000 * rank, chrom=chrom)
+        batch = workload.make_scan_batch(args.windows, args.cov, cov_n, seed=22 + 1000 * rank, chrom=chrom, **wl_kw)
         windex = rank * args.windows + np.arange(args.windows, dtype=np.int64)
     n_local = batch.n_windows
-    params = abi.default_params()
+    params = abi.default_params(lr_mode=1) if args.linked else abi.default_params()
     # `--in-flight 2` (default): two engines on the GPU, each with the batch resident, submitted in turn -- the kernels of step
     # i+1 are queued while step i drains, so the tail of a batch (a few windows that need several k attempts) overlaps the bulk of
     # the next one, as in a scan that streams batch after batch.  Every step is completed (results on the host) inside the timed region.
@@ -379,8 +385,10 @@ def main():
             "value_e2e": round(n_local / e2e_s, 2),
             "value_e2e_note": f"PCIe-inclusive, per GPU: host buffers -> upload + trim/pack ({up_ms:.0f} ms per batch) + kernels, {nfl} batch(es) in flight; never `value`",
             "config": {"workload": f"chr22-scan proxy: {args.windows} windows/GPU x 600 bp, stride 100, "
-                                   f"{args.cov:g}x tumor / {args.cov:g}x normal, 2x150 bp, k=11..101, active-region-off",
-                       "windows_per_gpu": args.windows, "coverage": [args.cov, args.cov], "reads_per_gpu": int(batch.n_reads),
+                                   f"{args.cov:g}x tumor / {cov_n:g}x normal, 2x150 bp, k=11..101, active-region-off"
+                                   + (f", {100 * args.str_fraction:g} % STR / {100 * args.lowcomplex_fraction:g} % low complexity" if args.str_fraction or args.lowcomplex_fraction else "")
+                                   + (", --linked-reads (BX / HP tags)" if args.linked else ""),
+                       "windows_per_gpu": args.windows, "coverage": [args.cov, cov_n], "reads_per_gpu": int(batch.n_reads),
                        "records_rank0_contig": len(variants), "records_sha256_rank0_contig": h.hexdigest()[:16],
                        "slots_in_flight": n_slots, "batches_in_flight": nfl, "upload_first_ms": round(upload_first_ms, 1), "upload_ms": round(up_ms, 1),
                        "windows_first_graph_in_lds": eng.prebuilt_count(), "graphs_built_ahead": eng.ahead_counts()[0], "graphs_taken_from_pool": eng.ahead_counts()[1],
@@ -412,7 +420,8 @@ def main():
             tj = os.path.join(ROOT, "profiles", "r4_traffic.json")
             with open(tj if os.path.exists(tj) else os.path.join(ROOT, "profiles", "r3_traffic.json")) as fh:
                 for rec in json.load(fh)["measurements"]:
-                    if rec["windows"] == args.windows and rec["coverage"] == args.cov and world == 1:
+                    if rec["windows"] == args.windows and rec["coverage"] == args.cov and rec.get("coverage_normal", rec["coverage"]) == cov_n \
+                            and rec.get("str_fraction", 0.0) == args.str_fraction and bool(rec.get("linked", False)) == bool(args.linked) and world == 1:
                         out["roofline"]["traffic"] = int((rec["FETCH_SIZE_KB"] / rec.get("fetch_calibration", 1.0) + rec["WRITE_SIZE_KB"]) * 1024)
                         out["roofline"]["traffic_fetch_write"] = [int(rec["FETCH_SIZE_KB"] * 1024), int(rec["WRITE_SIZE_KB"] * 1024)]
                         out["roofline"]["traffic_note"] = rec["note"]

@@ -537,12 +537,19 @@ DEV void wg_scan(LC_GLOBAL uint32_t *a, int n, LC_WS &S, volatile LC_LDS uint32_
     const int l = (int)threadIdx.x;
     int lo = l * chunk, hi = lo + chunk; if (hi > n) hi = n;
     uint32_t s = 0;
-    for (int i = lo; i < hi; ++i) s += ld2(&a[i]);
+    int i4 = lo;                                                      // (four loads in flight per trip: a lane's chunk is a serial walk otherwise)
+    for (; i4 + 4 <= hi; i4 += 4) { const uint32_t x0 = ld2(&a[i4]), x1 = ld2(&a[i4 + 1]), x2 = ld2(&a[i4 + 2]), x3 = ld2(&a[i4 + 3]); s += x0 + x1 + x2 + x3; }
+    for (int i = i4; i < hi; ++i) s += ld2(&a[i]);
     uint32_t inc = s;
     for (int d = 1; d < LANCET_WG; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, d, LANCET_WG); if (l >= d) inc += t; }
     const uint32_t total = (uint32_t)__shfl((int)inc, LANCET_WG - 1, LANCET_WG);
     uint32_t run = inc - s;
-    for (int i = lo; i < hi; ++i) { const uint32_t t = ld2(&a[i]); a[i] = run; run += t; }
+    i4 = lo;
+    for (; i4 + 4 <= hi; i4 += 4) {
+      const uint32_t x0 = ld2(&a[i4]), x1 = ld2(&a[i4 + 1]), x2 = ld2(&a[i4 + 2]), x3 = ld2(&a[i4 + 3]);
+      a[i4] = run; a[i4 + 1] = run + x0; a[i4 + 2] = run + x0 + x1; a[i4 + 3] = run + x0 + x1 + x2; run += x0 + x1 + x2 + x3;
+    }
+    for (int i = i4; i < hi; ++i) { const uint32_t t = ld2(&a[i]); a[i] = run; run += t; }
     if (l == 0) part[LANCET_WG] = total;
   }
   WG_SYNC();
@@ -1052,18 +1059,29 @@ DEVNI void lr_node_replay(Ctx &c, uint32_t lo, uint32_t hi, uint32_t *out) {
     W.csr[j] = v;
   }
   unsigned long long bxc = 0, covw = 0, hpcT = 0, hpcN = 0, hpwT = 0, hpwN = 0;      // 16-bit fields
+  // hasBX is "did an earlier occurrence of this node carry the same barcode in the same sample": one word per occurrence (barcode << 1 |
+  // sample; no barcode / the reference read: never equal to anything) written once into the node's stretch of W.mv (idle by now, indexed
+  // like the csr), so that the quadratic search is one load per step instead of three dependent ones (round 4: 56 % of a linked-read
+  // window's time was spent here).
+  LC_GLOBAL uint32_t *bxk = W.mv;
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint32_t r = CS_READ(W.csr[i]);
+    uint32_t key = 0xFFFFFFFEu;
+    if (r != refr) { const uint32_t bx = B.bx_rank[g0 + r]; key = bx == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((bx << 1) | RI_NML(B.rinfo[g0 + r])); }
+    bxk[i] = key;
+  }
   auto lr_event = [&](uint32_t i) {
     const uint32_t e = W.csr[i], g = g0 + CS_READ(e);
     const uint32_t ri = B.rinfo[g];
     const uint32_t s = RI_NML(ri), d = RI_REV(ri), bx = B.bx_rank[g];
     uint32_t h = B.hp[g]; if (h > 2) h = 2;
     bool seen = false;
-    if (bx != 0xFFFFFFFFu)
-      for (uint32_t j = lo; j < i; ++j) {
-        const uint32_t rj = CS_READ(W.csr[j]);
-        if (rj == refr) continue;
-        if (RI_NML(B.rinfo[g0 + rj]) == s && B.bx_rank[g0 + rj] == bx) { seen = true; break; }
-      }
+    if (bx != 0xFFFFFFFFu) {
+      const uint32_t key = (bx << 1) | s;
+      uint32_t j = lo;
+      for (; j + 4 <= i && !seen; j += 4) { const uint32_t k0 = bxk[j], k1 = bxk[j + 1], k2 = bxk[j + 2], k3 = bxk[j + 3]; seen = k0 == key || k1 == key || k2 == key || k3 == key; }
+      for (; j < i && !seen; ++j) seen = bxk[j] == key;
+    }
     if (!seen) {
       if (bx != 0xFFFFFFFFu) bxc += 1ULL << (16 * (2 * s + d));
       if (s) hpcN += 1ULL << (16 * h); else hpcT += 1ULL << (16 * h);
@@ -1951,23 +1969,49 @@ DEVNI void order_stage(Ctx &c, LC_GLOBAL const uint32_t *Q, LC_GLOBAL uint32_t *
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   LC_GLOBAL uint32_t *bkt = W.scratch, *tmp = W.scratch + LC_CTX(c).C->node_cap;
   LC_GLOBAL uint32_t *first = W.ht_bucket, *cnt = W.ht_cnt, *start = W.ht_start, *out = W.ht_next;
+  LC_GLOBAL const unsigned long long *nhash = W.nhash;
+  // Every pass below is a chain of dependent global round trips per element (index -> hash -> bucket words); LC_ILP elements per lane are
+  // in flight per trip (round 4: a table of 10 k nodes -- 100x / 40x windows at k = 31..101 -- spent 8 ms here on one wave).
+  // (an element past the end is clamped for the loads and skipped for the stores)
   WG_FOR(b, (int)B) { cnt[b] = 0; first[b] = LC_NIL; }
   WG_SYNC();
-  WG_FOR(i, n) {
-    uint32_t b = ht_mod(W.nhash[Q[i]], B);
-    bkt[i] = b;
-    dev_atomic_add(&cnt[b], 1u);
-    dev_atomic_min(&first[b], (uint32_t)i);
+  WG_FOR_ILP(i0, n) {
+    uint32_t q[LC_ILP]; unsigned long long h[LC_ILP];
+    for (int u = 0; u < LC_ILP; ++u) { const int i = i0 + u * LC_ILP_STRIDE; q[u] = Q[i < n ? i : n - 1]; }
+    for (int u = 0; u < LC_ILP; ++u) h[u] = nhash[q[u]];
+    for (int u = 0; u < LC_ILP; ++u) {
+      const int i = i0 + u * LC_ILP_STRIDE;
+      if (i >= n) continue;
+      const uint32_t b = ht_mod(h[u], B);
+      bkt[i] = b;
+      dev_atomic_add(&cnt[b], 1u);
+      dev_atomic_min(&first[b], (uint32_t)i);
+    }
   }
   WG_SYNC();
-  WG_FOR(i, n) { uint32_t b = bkt[i]; tmp[n - 1 - i] = (ld2(&first[b]) == (uint32_t)i) ? ld2(&cnt[b]) : 0u; }
+  WG_FOR_ILP(i0, n) {
+    uint32_t b[LC_ILP], f[LC_ILP], m[LC_ILP];
+    for (int u = 0; u < LC_ILP; ++u) { const int i = i0 + u * LC_ILP_STRIDE; b[u] = bkt[i < n ? i : n - 1]; }
+    for (int u = 0; u < LC_ILP; ++u) { f[u] = ld2(&first[b[u]]); m[u] = ld2(&cnt[b[u]]); }
+    for (int u = 0; u < LC_ILP; ++u) { const int i = i0 + u * LC_ILP_STRIDE; if (i < n) tmp[n - 1 - i] = (f[u] == (uint32_t)i) ? m[u] : 0u; }
+  }
   WG_SYNC();
   wg_scan(tmp, n, S);                                   // elements in front of the run that starts with position i
-  WG_FOR(i, n) { uint32_t b = bkt[i]; if (ld2(&first[b]) == (uint32_t)i) start[b] = tmp[n - 1 - i]; }
+  WG_FOR_ILP(i0, n) {
+    uint32_t b[LC_ILP], f[LC_ILP], t[LC_ILP];
+    for (int u = 0; u < LC_ILP; ++u) { const int i = i0 + u * LC_ILP_STRIDE; const int ic = i < n ? i : n - 1; b[u] = bkt[ic]; t[u] = tmp[n - 1 - ic]; }
+    for (int u = 0; u < LC_ILP; ++u) f[u] = ld2(&first[b[u]]);
+    for (int u = 0; u < LC_ILP; ++u) { const int i = i0 + u * LC_ILP_STRIDE; if (i < n && f[u] == (uint32_t)i) start[b[u]] = t[u]; }
+  }
   WG_SYNC();
   WG_FOR(b, (int)B) { first[b] = 0; }                   // from here: fill cursor of the run
   WG_SYNC();
-  WG_FOR(i, n) { uint32_t b = bkt[i]; uint32_t at = start[b] + dev_atomic_add(&first[b], 1u); out[at] = (uint32_t)i; }
+  WG_FOR_ILP(i0, n) {
+    uint32_t b[LC_ILP], s0[LC_ILP];
+    for (int u = 0; u < LC_ILP; ++u) { const int i = i0 + u * LC_ILP_STRIDE; b[u] = bkt[i < n ? i : n - 1]; }
+    for (int u = 0; u < LC_ILP; ++u) s0[u] = start[b[u]];
+    for (int u = 0; u < LC_ILP; ++u) { const int i = i0 + u * LC_ILP_STRIDE; if (i < n) { const uint32_t at = s0[u] + dev_atomic_add(&first[b[u]], 1u); out[at] = (uint32_t)i; } }
+  }
   WG_SYNC();
   WG_FOR(b, (int)B) {
     uint32_t m = ld2(&cnt[b]);
@@ -1977,7 +2021,12 @@ DEVNI void order_stage(Ctx &c, LC_GLOBAL const uint32_t *Q, LC_GLOBAL uint32_t *
     }
   }
   WG_SYNC();
-  WG_FOR(j, n) { Qn[j] = Q[out[j]]; }
+  WG_FOR_ILP(j0, n) {
+    uint32_t o[LC_ILP], v[LC_ILP];
+    for (int u = 0; u < LC_ILP; ++u) { const int j = j0 + u * LC_ILP_STRIDE; o[u] = out[j < n ? j : n - 1]; }
+    for (int u = 0; u < LC_ILP; ++u) v[u] = Q[o[u]];
+    for (int u = 0; u < LC_ILP; ++u) { const int j = j0 + u * LC_ILP_STRIDE; if (j < n) Qn[j] = v[u]; }
+  }
   WG_SYNC();
 }
 

@@ -37,6 +37,17 @@ DEV int wg_thin_lane() { const int t = (int)threadIdx.x; return t < 64 ? t : 0x3
 // inside the body is moved in every lane (see lc_sgpr below for what happened otherwise).
 #define WG_FULL_BEGIN(i, act, n) for (int _b = 0; _b < (int)(n); _b += (int)blockDim.x) { const bool act = _b + (int)threadIdx.x < (int)(n); const int i = act ? _b + (int)threadIdx.x : (int)(n) - 1;
 #define WG_FULL_END }
+// A data-parallel loop that hands every lane LC_ILP independent items per trip (item u of a trip is i0 + u * LC_ILP_STRIDE, valid while
+// < n): for loops that are a chain of dependent global round trips per item -- the loads of the items of one trip are issued together.
+//   WG_FOR_ILP(i0, n) { idx[u] = i0 + u * LC_ILP_STRIDE ... }
+#define LC_ILP 4
+#ifndef LANCET_FAT
+#define LC_ILP_STRIDE ((int)blockDim.x)
+#define WG_FOR_ILP(i0, n) for (int i0 = (int)threadIdx.x; i0 < (int)(n); i0 += LC_ILP * (int)blockDim.x)
+#else
+#define LC_ILP_STRIDE 64
+#define WG_FOR_ILP(i0, n) for (int i0 = wg_thin_lane(); i0 < (int)(n); i0 += LC_ILP * 64)
+#endif
 // Agent-scope fence before the barrier: the phases communicate through HBM with a mix of atomics (performed
 // at L2) and plain loads (which may hit the CU's vector L1), so the L1 has to be invalidated at phase boundaries.
 #define WG_SYNC() __syncthreads()
@@ -95,6 +106,9 @@ DEV int dev_popcll(unsigned long long x) { return __popcll(x); }
 #define DEV static inline
 #define DEVNI static
 #define WG_FOR(i, n) for (int i = 0; i < (int)(n); ++i)
+#define LC_ILP 4
+#define LC_ILP_STRIDE 1
+#define WG_FOR_ILP(i0, n) for (int i0 = 0; i0 < (int)(n); i0 += LC_ILP)
 #define WG_FULL_BEGIN(i, act, n) for (int i = 0; i < (int)(n); ++i) { const bool act = true;
 #define WG_FULL_END }
 #define XG_FOR(i, n) WG_FOR(i, n)
