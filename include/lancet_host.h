@@ -86,7 +86,12 @@ int lancet_host_window_span(const lancet_host *h, int w, int32_t *start, int32_t
  * arrays owned by h; kept[i] = tiled index of batch window i (kept has room for w_end - w_begin entries). */
 int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o, lancet_window_batch *out,
                       int32_t *kept, int32_t *n_kept);
-/* The same batch with the reads trimmed and packed on the host threads that assemble it (lancet_pack_read's routine, with the engine's
+/* Loading: a tiling normally decodes every alignment its windows can select before the first batch.  Above 400 000 windows (or with
+ * LANCET_HOST_LAZY=1; =0 switches it off) and when BOTH BAMs have a .bai that parses, the tiling only builds the window table and every
+ * lancet_host_batch[_packed] call loads what ITS windows can select through the index (same batches; a run of neighbouring windows per
+ * call is what this is made for -- far-apart ranges cost a seek each).  When that mode is wanted but an index is missing or unreadable a
+ * notice goes to stderr and the tiling loads everything at once.
+ * The same batch with the reads trimmed and packed on the host threads that assemble it (lancet_pack_read's routine, with the engine's
  * parameters `P`), for lancet_engine_upload_packed: out->seq / out->qual are NULL, `pk` receives the packed arrays (owned by the host
  * object like the batch's, valid until the next batch call). */
 int lancet_host_batch_packed(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o, const lancet_params *P, lancet_window_batch *out,

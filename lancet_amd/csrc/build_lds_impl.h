@@ -1798,7 +1798,7 @@ DEV void svc_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBa
           const uint32_t sum = ld2(queue) + ld2(&sv->beat) + ld2(&sv->req_alloc) + (wqueue ? ld2(wqueue) : 0u);
           const unsigned long long now = wall_clock64();
           if (sum != last_sum) { last_sum = sum; t_prog = now; }
-          else if (now - t_prog > 30000000ull) { dev_atomic_add(&sv->n_gaveup, 1u); st = 0xFFFFFFFFu; break; }      // 300 ms at 100 MHz
+          else if (now - t_prog > 30000000ull) { dev_atomic_add(&sv->n_gaveup, 1u); st_rel(&sv->nosvc, 1u); st = 0xFFFFFFFFu; break; }      // 300 ms at 100 MHz (the ticket it holds is never served: no window posts a request from here on)
         }
         dev_sleep();
 #endif

@@ -160,6 +160,9 @@ struct lancet_engine {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_done = nullptr;     // recorded by every submit behind the batch's kernels (ev1 is re-recorded by the re-run tier in lancet_engine_wait): what lancet_engine_submit_after waits for
+  hipEvent_t wait_ev = nullptr;     // lancet_engine_submit_after: the event this submit's kernels wait for (set around the call only)
+  int slots2_pred = 0;              // re-run tier of the windows started early: laid out by submit before it waits for `wait_ev`
   std::string err;
   // device buffers
   DevBuf d_params, d_batch, d_caps, d_out, d_works;
@@ -301,7 +304,8 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
     }
   }
   if ((!e->stream && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) || hipEventCreate(&e->ev0) != hipSuccess ||
-      hipEventCreate(&e->ev1) != hipSuccess || hipEventCreate(&e->evb0) != hipSuccess || hipEventCreate(&e->evb1) != hipSuccess) { delete e; return LANCET_E_HIP; }
+      hipEventCreate(&e->ev1) != hipSuccess || hipEventCreate(&e->evb0) != hipSuccess || hipEventCreate(&e->evb1) != hipSuccess ||
+      hipEventCreate(&e->ev_done) != hipSuccess) { delete e; return LANCET_E_HIP; }
   if (getenv("LANCET_NO_PREBUILD")) e->prebuild = false;
   if (const char *s = getenv("LANCET_PREP")) e->host_prep = strcmp(s, "device") != 0;
   if (const char *s = getenv("LANCET_PREP_THREADS")) e->prep_threads = std::max(1, atoi(s));
@@ -350,6 +354,7 @@ void lancet_engine_destroy(lancet_engine *e) {
   if (e->evb1) (void)hipEventDestroy(e->evb1);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->ev_done) (void)hipEventDestroy(e->ev_done);
   if (e->evf0) (void)hipEventDestroy(e->evf0);
   if (e->evf1) (void)hipEventDestroy(e->evf1);
   if (e->ev_ready) (void)hipEventDestroy(e->ev_ready);
@@ -737,9 +742,8 @@ static int lc_launch_rerun_kernel(lancet_engine *e, int slots2, hipStream_t st) 
 // Everything after the launch of the build service goes through lc_submit_body: whatever it returns, svc_done_kernel is enqueued
 // behind it, so that the service's workgroups never outlive a submit that failed half way.
 static int lc_submit_body(lancet_engine *e) {
-  if (!e->pred.empty()) {          // the pile-ups start now, next to everything else
-    int slots2 = lc_prepare_rerun(e, e->pred, 4, true);
-    if (slots2 < 0) return slots2;
+  if (!e->pred.empty()) {          // the pile-ups start now, next to everything else (their work space was laid out by lancet_engine_submit)
+    const int slots2 = e->slots2_pred;
     HIPCHK(e, hipEventRecord(e->ev_ready, e->stream));            // counters and statistics are cleared
     HIPCHK(e, hipStreamWaitEvent(e->stream2, e->ev_ready, 0));
     HIPCHK(e, hipEventRecord(e->evf0, e->stream2));
@@ -786,13 +790,14 @@ static int lc_submit_body(lancet_engine *e) {
 // kernels are persistent and sized for the whole device (LDS of every CU); side by side with the other batch's they only slow each other
 // down (measured: 61-68 ms per step overlapped, 57 one batch at a time, 54-55 back to back like this).  What the second engine buys is
 // that upload, launch and read-back of one batch run while the other's kernels do.
+// `prev` must have been submitted (its lancet_engine_submit[_after] has returned) by the time of this call -- its done-event is recorded
+// by then; a caller that submits from several threads orders them itself (lancet_main.cc submits on one thread and waits on others).
 int lancet_engine_submit_after(lancet_engine *e, lancet_engine *prev) {
   if (!e) return LANCET_E_ARG;
-  if (prev && prev != e && prev->device == e->device) {          // (an event never recorded, or long since reached, does not hold anything up)
-    HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipStreamWaitEvent(e->stream, prev->ev1, 0));
-  }
-  return lancet_engine_submit(e);
+  e->wait_ev = (prev && prev != e && prev->device == e->device) ? prev->ev_done : nullptr;      // (an event never recorded, or long since reached, does not hold anything up)
+  const int rc = lancet_engine_submit(e);
+  e->wait_ev = nullptr;
+  return rc;
 }
 
 int lancet_engine_submit(lancet_engine *e) {
@@ -803,6 +808,11 @@ int lancet_engine_submit(lancet_engine *e) {
   e->ran = false;
   e->variants.clear(); e->blob.clear(); e->stats.clear(); e->evt_len.clear(); e->evt.clear(); e->variants_lr.clear(); e->bx_blob.clear();
   if (e->n_windows == 0) { e->submitted = true; return LANCET_OK; }
+  // The copies that lay out the early re-run tier synchronise this engine's stream: they go first, so that the host thread is not held
+  // until the other engine's kernels are through (the wait below is only enqueued, on the device).
+  e->slots2_pred = 0;
+  if (!e->pred.empty()) { e->slots2_pred = lc_prepare_rerun(e, e->pred, 4, true); if (e->slots2_pred < 0) return e->slots2_pred; }
+  if (e->wait_ev) HIPCHK(e, hipStreamWaitEvent(e->stream, e->wait_ev, 0));
   HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, 128, e->stream));
   HIPCHK(e, hipMemsetAsync(e->d_stats.p, 0, sizeof(lancet_window_stats) * e->n_windows, e->stream));
   if (e->prebuild) HIPCHK(e, hipMemsetAsync(e->d_blphase.p, 0, 16 * sizeof(unsigned long long), e->stream));      // (before the service starts: its workgroups add to it too)
@@ -840,6 +850,7 @@ int lancet_engine_submit(lancet_engine *e) {
     }
   }
   if (rc) { (void)hipStreamSynchronize(e->stream); if (e->stream2) (void)hipStreamSynchronize(e->stream2); e->fat_inflight = false; return rc; }
+  HIPCHK(e, hipEventRecord(e->ev_done, e->stream));             // the batch's kernels (build, window, the service's leave signal) are behind this
   e->submitted = true;
   return LANCET_OK;
 }

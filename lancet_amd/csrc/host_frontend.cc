@@ -940,10 +940,19 @@ int finish_tiling(lancet_host *h, std::map<std::string, std::vector<std::pair<in
       for (const std::string &x : c) if (!x.empty()) { FILE *f = fopen(x.c_str(), "rb"); if (f) { fclose(f); return true; } }
       return false;
     };
-    const bool indexed = has_bai(h->smp[0].path) && has_bai(h->smp[1].path);
-    h->lazy = e ? (atoi(e) != 0 && indexed) : (indexed && h->windows.size() > 400000);
+    bool indexed = has_bai(h->smp[0].path) && has_bai(h->smp[1].path);
+    const bool want_lazy = e ? atoi(e) != 0 : h->windows.size() > 400000;      // (lancet_host.h: above 400 000 windows a tiling loads batch by batch)
     h->smp[2] = Sample(); h->smp[3] = Sample();
     h->bai[0] = BaiCache(); h->bai[1] = BaiCache();
+    if (want_lazy && indexed) {
+      // lazy only with both indexes PARSED (a file that merely exists would make every batch stream its BAM from the start)
+      for (int smp = 0; smp < 2; ++smp) { h->bai[smp].have = load_bai(h->smp[smp].path, &h->bai[smp].index); h->bai[smp].tried = true; }
+      indexed = h->bai[0].have && h->bai[1].have;
+    }
+    h->lazy = want_lazy && indexed;
+    if (want_lazy && !h->lazy)
+      fprintf(stderr, "[lancet_host] batch-by-batch loading %s but not possible: both BAMs need a readable .bai (%s); the whole tiling's alignments are loaded at once\n",
+              e ? "asked for (LANCET_HOST_LAZY)" : "wanted for this many windows", has_bai(h->smp[0].path) && has_bai(h->smp[1].path) ? "an index could not be parsed" : "an index is missing");
     if (h->lazy) wants.clear();                      // header, sample name, MD on the first alignment: no alignments yet
   }
   std::string errs[2]; bool ok[2] = {false, false};

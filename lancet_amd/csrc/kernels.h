@@ -4644,7 +4644,7 @@ DEVNI bool try_suspend(Ctx &c, int k) {
   WG_LANE0 {
     S.tmp1 = 0;
     LC_GLOBAL const PreHdr *H0 = (LC_GLOBAL const PreHdr *)(LC_CTX(c).OUT->pre + (size_t)w * PRE_STRIDE + PRE_OFF_HDR);
-    if (k != S.nosusp_k && (k & 1) && (k <= 31 || (sv->large && 2 * k <= 64 * (int)PL.kw)) && !S.overflow && LC_CTX(c).OUT->pre_pool && H0->status == PB_BUILT && (!H0->big || sv->large)) {
+    if (k != S.nosusp_k && (k & 1) && !ld2(&sv->nosvc) && (k <= 31 || (sv->large && 2 * k <= 64 * (int)PL.kw)) && !S.overflow && LC_CTX(c).OUT->pre_pool && H0->status == PB_BUILT && (!H0->big || sv->large)) {
       const uint32_t i = dev_atomic_add(&sv->req_alloc, 1u);
       if (i < sv->cap) { S.tmp1 = 1; S.svc_i = i; }
     }

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <ctime>
 #include <future>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -151,6 +152,7 @@ int main(int argc, char **argv) {
   std::vector<Slot> slots(engs.size());
   for (size_t k = 0; k < engs.size(); ++k) { slots[k].e = engs[k]; slots[k].kept.resize((size_t)step); }
   long done = 0;
+  std::map<int, lancet_engine *> last_on_dev;      // device -> the engine submitted last on it
   int next_add = 0;
   std::string fail;
   std::vector<std::string> overflowed;
@@ -227,9 +229,16 @@ int main(int argc, char **argv) {
     sl.chunk = c; sl.nk = nk; sl.base = done; done += nk; sl.bxn.clear();
     if (ho.linked) { uint32_t nbx = 0; const char *const *bxn = lancet_host_bx_names(H, &nbx); for (uint32_t i = 0; i < nbx; ++i) sl.bxn.emplace_back(bxn[i]); }
     lancet_engine *e = sl.e;
-    // (the engine that took the chunk before this one: on the same GPU the two batches' kernels run back to back, not side by side)
-    lancet_engine *prev = (c > 0 && slots.size() > 1) ? slots[(size_t)(c - 1) % slots.size()].e : nullptr;
-    sl.fut = std::async(std::launch::async, [e, prev]() { const int rc = lancet_engine_submit_after(e, prev); return rc ? rc : lancet_engine_wait(e); });
+    // The launch happens HERE, on the one thread that submits (a few hundred microseconds: everything is asynchronous), behind the kernels
+    // of the last engine submitted on the same GPU -- the two batches' kernels run back to back, not side by side; its done-event is
+    // recorded by then because its own submit has returned.  Only the wait (re-run tier, read-back) goes to another thread.
+    const int dev = devs.size() > 1 ? devs[(size_t)c % slots.size() % devs.size()] : devs[0];
+    lancet_engine *prev = last_on_dev.count(dev) ? last_on_dev[dev] : nullptr;
+    t0 = now();
+    if (lancet_engine_submit_after(e, prev) != LANCET_OK) return die(std::string("engine: ") + lancet_engine_last_error(e));
+    t_engine += now() - t0;
+    last_on_dev[dev] = e;
+    sl.fut = std::async(std::launch::async, [e]() { return lancet_engine_wait(e); });
     if (!flush()) return die(fail);
   }
   for (Slot &sl : slots) if (sl.fut.valid() && !finish(sl)) return die(fail);

@@ -310,7 +310,7 @@ struct SvcCtl {
   uint32_t n_gaveup;      /* service workgroups that left because nothing else made progress (kernels serialised by a profiler)  */
   uint32_t n_waiting;     /* window slots that wait for a graph: never more than there are requests out (the others leave and free their CU) */
   uint32_t large;         /* the service workgroups are the 1024-lane configuration: windows of any size the build kernels take may ask */
-  uint32_t pad;
+  uint32_t nosvc;         /* a service workgroup gave up waiting (kernels serialised by a profiler): windows stop suspending and build their later graphs themselves */
   LC_GLOBAL SvcReq *req;          /* [cap] */
   LC_GLOBAL uint32_t *rdy;        /* [cap] request index + 1 */
   LC_GLOBAL SvcCont *cont;        /* [cap] */
