@@ -10,6 +10,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <memory>
 #include <cerrno>
 #include <atomic>
 #include <cctype>
@@ -86,6 +87,7 @@ struct Sample {
   std::vector<uint32_t> pk_tlen, pk_bw, pk_gw;        // trimmed length; first word of its bases / quality mask in pk_bases / pk_good
   Bytes pk_bases, pk_good;
   int pk_qtrim = -1, pk_qcall = -1; size_t pk_n = 0;
+  std::unique_ptr<std::atomic<uint8_t>[]> pk_state;   // per alignment: 0 not packed yet, 1 a thread is packing it, 2 packed (pack_read_once)
   std::vector<std::pair<size_t, size_t>> span;   // per contig of the tiling: its reads [first, last) (file order = coordinate order)
 };
 
@@ -1068,32 +1070,37 @@ int lancet_host_tile_regions(lancet_host *h, const char *bed_path, const char *c
 }
 
 // Trims and packs every alignment of a sample once (host_pack.h), on the host threads; a read that is not usable keeps length 0.
+// The packed form of a load's alignments: laid out here (word offsets, room for every alignment), filled by pack_read_once when a window
+// first SELECTS an alignment -- duplicates, low-MAPQ reads and reads no window takes are never trimmed or packed, and their pages of the
+// two arrays are never touched (round 4; it used to pack the whole load on the first packed batch).
 static void ensure_pack_cache(Sample &S, const lancet_params &P) {
   const size_t n = S.reads.size();
-  if (S.pk_qtrim == P.min_qual_trim && S.pk_qcall == P.min_qual_call && S.pk_n == n && S.pk_tlen.size() == n) return;
+  if (S.pk_qtrim == P.min_qual_trim && S.pk_qcall == P.min_qual_call && S.pk_n == n && S.pk_tlen.size() == n && S.pk_state) return;
   S.pk_tlen.assign(n, 0); S.pk_bw.assign(n + 1, 0); S.pk_gw.assign(n + 1, 0);
   uint64_t bw = 0, gw = 0;
   for (size_t i = 0; i < n; ++i) { S.pk_bw[i] = (uint32_t)bw; S.pk_gw[i] = (uint32_t)gw; bw += (S.reads[i].l_seq + 15) / 16; gw += (S.reads[i].l_seq + 31) / 32; }
   S.pk_bw[n] = (uint32_t)bw; S.pk_gw[n] = (uint32_t)gw;          // (< 2^32: at most one word per 16 of the < 4 G bases)
   S.pk_bases.resize(4 * (size_t)bw + 4); S.pk_good.resize(4 * (size_t)gw + 4);
-  uint32_t *B = (uint32_t *)S.pk_bases.data(), *G = (uint32_t *)S.pk_good.data();
-  const unsigned nt = host_threads((int)(n / 2048 + 1));
-  auto work = [&](unsigned t) {
-    for (size_t i = n * t / nt; i < n * (t + 1) / nt; ++i) {
-      const Read &r = S.reads[i];
-      uint32_t ri = 0, *pb = B + S.pk_bw[i], *pg = G + S.pk_gw[i];
-      lc_prep_read_host(P, S.seq.data() + r.seq_off, S.qual.data() + r.seq_off, (int)r.l_seq, 0, 0, 0, 0, &ri, pb, pg);
-      const uint32_t tl = ri & 0xFFFFu;
-      for (uint32_t wv = (tl + 15) / 16; wv < (r.l_seq + 15) / 16; ++wv) pb[wv] = 0;
-      for (uint32_t wv = (tl + 31) / 32; wv < (r.l_seq + 31) / 32; ++wv) pg[wv] = 0;
-      S.pk_tlen[i] = tl;
-    }
-  };
-  std::vector<std::thread> th;
-  for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
-  work(0);
-  for (auto &t : th) t.join();
+  S.pk_state.reset(new std::atomic<uint8_t>[n + 1]);
+  for (size_t i = 0; i <= n; ++i) S.pk_state[i].store(0, std::memory_order_relaxed);
   S.pk_qtrim = P.min_qual_trim; S.pk_qcall = P.min_qual_call; S.pk_n = n;
+}
+// Trim + pack alignment i of the load, once: the first thread to ask does it, a thread that asks meanwhile waits for it (the batch is
+// assembled by several threads, and an alignment is in about six windows).
+static inline void pack_read_once(Sample &S, const lancet_params &P, size_t i) {
+  std::atomic<uint8_t> &st = S.pk_state[i];
+  if (st.load(std::memory_order_acquire) == 2) return;
+  uint8_t expect = 0;
+  if (st.compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) {
+    const Read &r = S.reads[i];
+    uint32_t ri = 0, *pb = (uint32_t *)S.pk_bases.data() + S.pk_bw[i], *pg = (uint32_t *)S.pk_good.data() + S.pk_gw[i];
+    lc_prep_read_host(P, S.seq.data() + r.seq_off, S.qual.data() + r.seq_off, (int)r.l_seq, 0, 0, 0, 0, &ri, pb, pg);
+    const uint32_t tl = ri & 0xFFFFu;
+    for (uint32_t wv = (tl + 15) / 16; wv < (r.l_seq + 15) / 16; ++wv) pb[wv] = 0;
+    for (uint32_t wv = (tl + 31) / 32; wv < (r.l_seq + 31) / 32; ++wv) pg[wv] = 0;
+    S.pk_tlen[i] = tl;
+    st.store(2, std::memory_order_release);
+  } else while (st.load(std::memory_order_acquire) != 2) std::this_thread::yield();
 }
 
 static int host_batch_impl(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o, lancet_window_batch *out,
@@ -1208,13 +1215,14 @@ static int host_batch_impl(lancet_host *h, int w_begin, int w_end, const lancet_
         names.clear();
         {
           auto one = [&](int smp, const Sel &s) {
-            const Sample &S = h->smp[smp];
+            Sample &S = h->smp[smp];
             const Read &rd = S.reads[s.idx];
             h->b_label[r] = (smp & 1) ? LANCET_TMR : LANCET_NML; h->b_strand[r] = s.strand; h->b_mate[r] = s.mate; h->b_mapped[r] = s.mapped;
             if (packed) {
               uint32_t *pb = (uint32_t *)h->b_pbases.p + pbo, *pg = (uint32_t *)h->b_pgood.p + pgo;
               h->b_bw[r] = (uint32_t)pbo; h->b_gw[r] = (uint32_t)pgo;
-              const uint32_t nbw = (rd.l_seq + 15) / 16, ngw = (rd.l_seq + 31) / 32;      // (packed once per alignment: ensure_pack_cache)
+              const uint32_t nbw = (rd.l_seq + 15) / 16, ngw = (rd.l_seq + 31) / 32;
+              pack_read_once(S, *P, s.idx);                                             // (packed once per alignment, when a window first takes it)
               memcpy(pb, (const uint32_t *)S.pk_bases.data() + S.pk_bw[s.idx], 4 * (size_t)nbw);
               memcpy(pg, (const uint32_t *)S.pk_good.data() + S.pk_gw[s.idx], 4 * (size_t)ngw);
               h->b_rinfo[r] = lc_rinfo_word(S.pk_tlen[s.idx], h->b_label[r], s.strand, s.mate, s.mapped);
