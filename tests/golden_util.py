@@ -66,6 +66,11 @@ def case_params(meta):
     return int(opt["--padding"]), int(opt["--min-k"]), int(opt["--max-k"])
 
 
+def case_window(meta) -> int:
+    """--window-size of the case (reference default 600, src/Lancet.cc:662)."""
+    return int(_flag_values(meta).get("--window-size", 600))
+
+
 def params(meta, **over):
     """lancet_params of the case: reference defaults, the case's graph / STR / quality flags, lr_mode."""
     from lancet_amd import abi
@@ -93,7 +98,7 @@ def case_active_region(meta) -> bool:
 def case_batch(name: str):
     meta, ref, rname, reads = load_case(name)
     padding, min_k, max_k = case_params(meta)
-    windows = frontend.tile_region(ref, rname, meta["region"], padding=padding)
+    windows = frontend.tile_region(ref, rname, meta["region"], padding=padding, window_size=case_window(meta))
     batch, kept = frontend.batch_from_sam(windows, reads["tumor"], reads["normal"], max_k=max_k, linked=case_lr(meta),
                                           active_region=case_active_region(meta))
     return meta, batch, kept, (min_k, max_k)

@@ -103,6 +103,10 @@ CASES = {
                     somatic_every=600, germline_every=500, read_len=100), "chr22:1000-6500", []),
     "dups": (dict(ref_len=8000, cov_t=40, cov_n=40, ref_seed=5, tumor_seed=15, normal_seed=25, dup_prob=1.0,
                   somatic_every=600, germline_every=500, read_len=100), "chr22:1000-6500", []),
+    # --window-size above the default (the reference takes any -w: src/Lancet.cc:662,732): 1000-base windows every 100 bases -- the
+    # engine lays its work space out for the batch's longest window (round 4: up to LC_MAXW = 1024)
+    "w1000": (dict(ref_len=9000, cov_t=30, cov_n=30, ref_seed=61, tumor_seed=161, normal_seed=261, somatic_every=700, germline_every=500),
+              "chr22:1500-6500", ["--window-size", "1000"]),
 }
 
 
