@@ -223,7 +223,7 @@ struct lancet_engine {
   uint32_t evt_cap = 0;
   size_t mem_budget = (size_t)96 << 30;
   int max_slots = 5120;      // work-space slots = resident single-wave workgroups: 5 per SIMD (96 VGPRs, < 8 KB LDS each) x 4 SIMDs x CUs
-  uint32_t max_nodes_limit = 65536;
+  uint32_t max_nodes_limit = 65536; bool max_nodes_env = false;
   // host results
   std::vector<lancet_variant> variants;
   std::vector<char> blob;
@@ -333,7 +333,7 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (e->svc_cus) e->n_svc_wgs = 2 * e->svc_cus;
   if (const char *s = getenv("LANCET_MAX_SLOTS")) e->max_slots = atoi(s);
   if (const char *s = getenv("LANCET_MEM_GB")) e->mem_budget = (size_t)atoi(s) << 30;
-  if (const char *s = getenv("LANCET_MAX_NODES")) e->max_nodes_limit = (uint32_t)atoi(s);
+  if (const char *s = getenv("LANCET_MAX_NODES")) { e->max_nodes_limit = (uint32_t)atoi(s); e->max_nodes_env = true; }
   if (const char *s = getenv("LANCET_NODE_CAP1")) e->node_cap1 = (uint32_t)atoi(s);
   if (const char *s = getenv("LANCET_STOP_PHASE")) e->debug_stop = (uint32_t)atoi(s);
   if (const char *s = getenv("LANCET_TABLE_START")) e->table_start = lc_pow2_ge((uint32_t)atoi(s));
@@ -421,10 +421,16 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
   const uint32_t nref = nw ? b->ref_off[nw] : 0;
   e->n_windows = nw; e->n_reads = (int)R;
   if (nw == 0) { e->uploaded = true; return LANCET_OK; }
-  // (a window longer than LC_MAXW, or with more than 65 535 reads, does not fail the batch: process_window reports it LANCET_W_OVERFLOW
-  //  on its own and every other window is assembled)
+  // (a window longer than LC_MAXW does not fail the batch: process_window reports it LANCET_W_OVERFLOW on its own and every other
+  //  window is assembled.  A window of more than 65 535 reads -- the reference takes up to MAX_AVG_COV = 10 000x per sample,
+  //  src/Microassembler.cc:491-496 -- overflows the one-wave kernel's 16-bit read ids and runs in the re-run tier, whose csr words and
+  //  mate-name records keep the read in 32 bits (layout.h cs_t); its node tables are then sized for up to 2^20 distinct k-mers
+  //  instead of 65 536, unless LANCET_MAX_NODES says otherwise.)
   e->caps = lc_caps_for_batch(b, &e->params, e->evt_cap, e->node_cap1, 1);
-  e->caps2 = lc_caps_for_batch(b, &e->params, e->evt_cap, e->max_nodes_limit, 2);
+  uint32_t nodes2 = e->max_nodes_limit;
+  if (!e->max_nodes_env) for (int w = 0; w < nw; ++w) if (b->read_begin[w + 1] - b->read_begin[w] >= 0xFFFFu) { nodes2 = std::max(nodes2, 1u << 20); break; }
+  e->caps2 = lc_caps_for_batch(b, &e->params, e->evt_cap, nodes2, 2);
+  e->caps2.wide_ids = e->no_fat ? 0u : 1u;                     // (LANCET_NO_FAT: the one-wave kernel re-runs, with its 16-bit limit)
   e->caps2.var_cap = e->caps.var_cap; e->caps2.blob_cap = e->caps.blob_cap; e->caps2.bx_cap = e->caps.bx_cap;
   e->caps.debug_stop = e->debug_stop;
   e->caps.table_start = e->caps2.table_start = e->table_start;
@@ -448,17 +454,17 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
       uint64_t bo = 0, go = 0; char bd = 0;
       for (size_t r = lo; r < hi; ++r) {
         const uint32_t len = b->seq_off[r + 1] - b->seq_off[r]; bo += (len + 15) / 16; go += (len + 31) / 32;
-        if (b->name_rank[r] > 0xFFFFu) {              // fine in a window of more than 65 535 reads (reported as an overflow of that window), else not a dense rank
+        if (b->name_rank[r] > 0xFFFFu) {              // fine in a window of more than 65 535 reads (the re-run tier's), if it is a dense rank
           const uint32_t *ub = std::upper_bound(b->read_begin, b->read_begin + nw + 1, (uint32_t)r);
           const size_t w = (size_t)(ub - b->read_begin) - 1;
-          if (b->read_begin[w + 1] - b->read_begin[w] <= 0xFFFFu) bd = 1;
+          if (b->name_rank[r] >= b->read_begin[w + 1] - b->read_begin[w]) bd = 1;
         }
         if (e->params.lr_mode && b->hp[r] > 2) bd = 2;
       }
       tb[(size_t)t + 1] = bo; tg[(size_t)t + 1] = go; bad[(size_t)t] = bd;
     });
     for (int t = 0; t < T; ++t) {
-      if (bad[(size_t)t] == 1) { e->err = "name_rank must be the dense per-window rank (< 65536)"; return LANCET_E_ARG; }
+      if (bad[(size_t)t] == 1) { e->err = "name_rank must be the dense per-window rank (< the window's reads)"; return LANCET_E_ARG; }
       if (bad[(size_t)t] == 2) { e->err = "hp must be 0, 1 or 2"; return LANCET_E_ARG; }      // Node_t::addHP indexes a 3-array (src/Node.cc:54-57)
       tb[(size_t)t + 1] += tb[(size_t)t]; tg[(size_t)t + 1] += tg[(size_t)t];
     }
@@ -546,7 +552,7 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
   for (uint32_t r = 0; r < R; ++r) if (b->name_rank[r] > 0xFFFFu) {
     const uint32_t *ub = std::upper_bound(b->read_begin, b->read_begin + nw + 1, r);
     const size_t w = (size_t)(ub - b->read_begin) - 1;
-    if (b->read_begin[w + 1] - b->read_begin[w] <= 0xFFFFu) { e->err = "name_rank must be the dense per-window rank (< 65536)"; return LANCET_E_ARG; }
+    if (b->name_rank[r] >= b->read_begin[w + 1] - b->read_begin[w]) { e->err = "name_rank must be the dense per-window rank (< the window's reads)"; return LANCET_E_ARG; }
   }
   if (e->params.lr_mode) for (uint32_t r = 0; r < R; ++r) if (b->hp[r] > 2) { e->err = "hp must be 0, 1 or 2"; return LANCET_E_ARG; }   // Node_t::addHP indexes a 3-array (src/Node.cc:54-57)
   UP(e->d_chr, b->chr_id, sizeof(int32_t) * nw);

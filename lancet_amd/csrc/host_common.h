@@ -132,14 +132,14 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.occ = k.take<uint32_t>(c.occ_cap);
   t.slots = k.take<uint32_t>(4 * (size_t)c.table_cap);
   t.todo = k.take<uint32_t>(c.table_cap);
-  t.mv = k.take<uint32_t>(4 * (size_t)c.occ_cap);
+  t.mv = k.take<uint32_t>((c.wide_ids ? 8 : 4) * (size_t)c.occ_cap);
   t.slot_key = k.take<unsigned long long>((size_t)c.table_cap * LC_NWMAX);
   t.bitmap = k.take<uint32_t>((c.occ_cap + c.special_cap) / 32 + 4);   /* also the visited set of the component search (node ids) */
   t.bitpre = k.take<uint32_t>(c.occ_cap / 32 + 2);
-  t.csr = k.take<uint32_t>(c.occ_cap);
+  t.csr = k.take<uint32_t>((c.wide_ids ? 2 : 1) * (size_t)c.occ_cap);
   t.nkey = k.take<unsigned long long>(nodes * LC_NWMAX);
   t.nhash = k.take<unsigned long long>(nodes);
-  t.nfill = k.take<uint32_t>(nodes + 1);
+  t.nfill = k.take<uint32_t>((c.wide_ids ? 2 : 1) * (nodes + 1));
   t.gr = k.take<NodeGr>(nodes + 1);          /* + the stand-in record of reference k-mers whose node is gone (prebuilt windows) */
   t.cmp = k.take<CmpRec>(nodes);
   t.nocc = k.take<uint32_t>(nodes + 1);

@@ -187,14 +187,19 @@ template <class P> DEV int wg_bcast(P p) {
 }
 template <class P> DEV uint32_t wg_bcastu(P p) { return (uint32_t)wg_bcast(p); }
 
-DEV void evt(Ctx &c, uint32_t code, uint32_t a = 0, uint32_t b = 0, uint32_t d = 0, uint32_t e = 0, uint32_t f = 0,
-             uint32_t g = 0, uint32_t h = 0) {
-  if (!LC_CTX(c).C->evt_cap) return;
+// (the record is written out of line: inlined at its ~60 call sites the eight operands were what the window kernel spilled -- 142 VGPRs,
+//  all on paths that run with tracing on only)
+DEVNI void evt_write(Ctx &c, uint32_t code, uint32_t a, uint32_t b, uint32_t d, uint32_t e, uint32_t f, uint32_t g, uint32_t h) {
   LC_WS &S = LC_SREF(c);
   if (S.evt_len + 8 > LC_CTX(c).C->evt_cap) return;
   uint32_t *p = LC_CTX(c).W->evt + S.evt_len;
   p[0] = code; p[1] = a; p[2] = b; p[3] = d; p[4] = e; p[5] = f; p[6] = g; p[7] = h;
   S.evt_len += 8;
+}
+DEV void evt(Ctx &c, uint32_t code, uint32_t a = 0, uint32_t b = 0, uint32_t d = 0, uint32_t e = 0, uint32_t f = 0,
+             uint32_t g = 0, uint32_t h = 0) {
+  if (!LC_CTX(c).C->evt_cap) return;
+  evt_write(c, code, a, b, d, e, f, g, h);
 }
 DEV void evt_bytes(Ctx &c, const uint8_t *s, uint32_t n) {   // raw bytes appended after an event, padded to 8 words
   if (!LC_CTX(c).C->evt_cap) return;
@@ -834,7 +839,7 @@ DEV bool nk_is_forward(const uint8_t *ref, int p, int K) {                      
 #define SL_NODE(W, i) ((W).slots[4 * (size_t)(i) + 3])
 
 // ---- work items of the per-occurrence passes: one per read, the (long) reference pseudo-read cut into segments of
-// LC_SEG k-mer starts so that no lane trails the wave.  items[2i] = read | first k-mer start << 16,
+// LC_SEG k-mer starts so that no lane trails the wave.  items[2i] = read | first k-mer start << IT_RBITS,
 // items[2i+1] = sweep offset | number of k-mer starts << 16.  chunk[2c], chunk[2c+1] = sweep origin / length of the
 // c-th group of LANCET_WG items.  The sweep offset lines the lanes of a group up on the same genome position
 // (reads arrive in coordinate order per sample, so rank * (W - len) / n is a fair estimate of a read's start): at a
@@ -852,7 +857,7 @@ DEVNI void build_items(Ctx &c) {
     }
     for (int b0 = 0; b0 < S.reflen; b0 += LC_SEG) {
       int len = S.reflen - b0 < LC_SEG ? S.reflen - b0 : LC_SEG;
-      W.items[2 * n] = (uint32_t)nr | ((uint32_t)b0 << 16); W.items[2 * n + 1] = ((uint32_t)len << 16); ++n;
+      W.items[2 * n] = (uint32_t)nr | ((uint32_t)b0 << IT_RBITS); W.items[2 * n + 1] = ((uint32_t)len << 16); ++n;
     }
     S.nitems = n;
     for (int cb = 0; cb < n; cb += LANCET_WG) {
@@ -867,7 +872,7 @@ DEVNI void build_items(Ctx &c) {
     const int _tlo = (int)(W).chunk[2 * (_cb / LANCET_WG)], _span = (int)(W).chunk[2 * (_cb / LANCET_WG) + 1]; \
     WG_FOR(_j, (_ni - _cb < LANCET_WG ? _ni - _cb : LANCET_WG)) { \
       const uint32_t _i0 = (W).items[2 * (_cb + _j)], _i1 = (W).items[2 * (_cb + _j) + 1]; \
-      const int r = (int)(_i0 & 0xFFFFu), _b0 = (int)(_i0 >> 16), _e = (int)(_i1 & 0xFFFFu) - _tlo; \
+      const int r = (int)(_i0 & ((1u << IT_RBITS) - 1u)), _b0 = (int)(_i0 >> IT_RBITS), _e = (int)(_i1 & 0xFFFFu) - _tlo; \
       uint32_t rinfo, bw, gw; int tlen; bool isref; \
       read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref); \
       const int nk = tlen - (S).K > 0 ? tlen - (S).K + 1 : 0;   /* a read of exactly K bases has no k-mer: loadSequence needs len > K (Graph.cc:121-124), and occ_base[] allots it no occurrence */ \
@@ -1048,15 +1053,17 @@ DEV bool step_all_good(const Ctx &c, bool isref, uint32_t gw, int s, int tlen, i
 //   out[0..3] = cov_distr fwd/rev of tumor, normal (barcode counts) ; out[4..6] / out[7..9] = hp0 hp1 hp2 tumor / normal
 //   csr bits 29..31 of a counted occurrence = "hpX had grown" (feeds hpX_minqv in the per-position pass)
 #define LC_PK(x, i) ((uint32_t)(((x) >> (16 * (i))) & 0xFFFFULL))
+#define W_CSR(W) ((LC_GLOBAL cs_t *)(W).csr)       /* layout.h cs_t: 32-bit words, 64-bit in the re-run tier */
 DEVNI void lr_node_replay(Ctx &c, uint32_t lo, uint32_t hi, uint32_t *out) {
   LC_GLOBAL Work &W = *LC_CTX(c).W; LC_GLOBAL const DevBatch &B = *LC_CTX(c).B; LC_WS &S = LC_SREF(c);
   const uint32_t g0 = B.read_begin[S.w];
   const uint32_t refr = (uint32_t)(S.R - 1);
+  LC_GLOBAL cs_t *csr = W_CSR(W);
   for (uint32_t i = lo + 1; i < hi; ++i) {                      // order of the visits
-    const uint32_t v = W.csr[i], kv = (CS_READ(v) << 10) | CS_POS(v);
+    const cs_t v = csr[i]; const cs_key_t kv = CS_KEY(v);
     uint32_t j = i;
-    while (j > lo) { const uint32_t u = W.csr[j - 1]; if (((CS_READ(u) << 10) | CS_POS(u)) <= kv) break; W.csr[j] = u; --j; }
-    W.csr[j] = v;
+    while (j > lo) { const cs_t u = csr[j - 1]; if (CS_KEY(u) <= kv) break; csr[j] = u; --j; }
+    csr[j] = v;
   }
   unsigned long long bxc = 0, covw = 0, hpcT = 0, hpcN = 0, hpwT = 0, hpwN = 0;      // 16-bit fields
   // hasBX is "did an earlier occurrence of this node carry the same barcode in the same sample": one word per occurrence (barcode << 1 |
@@ -1065,13 +1072,13 @@ DEVNI void lr_node_replay(Ctx &c, uint32_t lo, uint32_t hi, uint32_t *out) {
   // window's time was spent here).
   LC_GLOBAL uint32_t *bxk = W.mv;
   for (uint32_t i = lo; i < hi; ++i) {
-    const uint32_t r = CS_READ(W.csr[i]);
+    const uint32_t r = CS_READ(csr[i]);
     uint32_t key = 0xFFFFFFFEu;
     if (r != refr) { const uint32_t bx = B.bx_rank[g0 + r]; key = bx == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((bx << 1) | RI_NML(B.rinfo[g0 + r])); }
     bxk[i] = key;
   }
   auto lr_event = [&](uint32_t i) {
-    const uint32_t e = W.csr[i], g = g0 + CS_READ(e);
+    const cs_t e = csr[i]; const uint32_t g = g0 + CS_READ(e);
     const uint32_t ri = B.rinfo[g];
     const uint32_t s = RI_NML(ri), d = RI_REV(ri), bx = B.bx_rank[g];
     uint32_t h = B.hp[g]; if (h > 2) h = 2;
@@ -1088,7 +1095,7 @@ DEVNI void lr_node_replay(Ctx &c, uint32_t lo, uint32_t hi, uint32_t *out) {
     }
   };
   auto cov_event = [&](uint32_t i) {
-    const uint32_t e = W.csr[i];
+    const cs_t e = csr[i];
     if (CS_ST(e) != 0) return;
     const uint32_t ri = B.rinfo[g0 + CS_READ(e)];
     const uint32_t s = RI_NML(ri), d = RI_REV(ri);
@@ -1098,13 +1105,13 @@ DEVNI void lr_node_replay(Ctx &c, uint32_t lo, uint32_t hi, uint32_t *out) {
     const int f = (int)(2 * s + d);
     covw = (covw & ~(0xFFFFULL << (16 * f))) | ((unsigned long long)LC_PK(bxc, f) << (16 * f));
     if (s) hpwN = cur; else hpwT = cur;
-    W.csr[i] = e | (grow << 29);
+    csr[i] = e | (cs_t)(grow << 29);
   };
   for (uint32_t i = lo; i < hi; ++i) {
-    const uint32_t e = W.csr[i];
+    const cs_t e = csr[i];
     if (CS_READ(e) == refr) continue;                            // BX "null", label REF: no effect (Graph.cc:243-262)
     bool pair = false;
-    if (CS_POS(e) == 0 && i + 1 < hi) { const uint32_t e2 = W.csr[i + 1]; pair = CS_READ(e2) == CS_READ(e) && CS_POS(e2) == 1; }
+    if (CS_POS(e) == 0 && i + 1 < hi) { const cs_t e2 = csr[i + 1]; pair = CS_READ(e2) == CS_READ(e) && CS_POS(e2) == 1; }
     lr_event(i);
     if (pair) lr_event(i + 1);
     cov_event(i);
@@ -1411,7 +1418,7 @@ DEVNI void build_csr(Ctx &c) {
           const int o = o0 + u * XG_LANES;
           if (o < O) {
             const uint32_t st = rr[u] == refr ? 2u : ((oc[u] & 0x40000000u) ? 1u : 0u);     // the reference read never counts (Graph.cc:265)
-            W.csr[at[u] + rk[u]] = CS_MAKE(rr[u], pp[u], oc[u] >> 31, st);
+            W_CSR(W)[at[u] + rk[u]] = CS_MAKE(rr[u], pp[u], oc[u] >> 31, st);
           }
         }
       }
@@ -1444,44 +1451,54 @@ DEVNI void build_csr(Ctx &c) {
       XG_FOR(li, nmarked) {
         const uint32_t n = W.pnodes[li];
         const uint32_t lo = W.nocc[n], hi = W.nocc[n + 1], len = hi - lo;
+        LC_GLOBAL cs_t *csr = W_CSR(W);
         for (uint32_t i = lo + 1; i < hi; ++i) {                 // visiting order (the run is nearly sorted already)
-          const uint32_t v = W.csr[i], kv = (CS_READ(v) << 10) | CS_POS(v);
+          const cs_t v = csr[i]; const cs_key_t kv = CS_KEY(v);
           uint32_t j = i;
-          while (j > lo) { const uint32_t u = W.csr[j - 1]; if (((CS_READ(u) << 10) | CS_POS(u)) <= kv) break; W.csr[j] = u; --j; }
-          W.csr[j] = v;
+          while (j > lo) { const cs_t u = csr[j - 1]; if (CS_KEY(u) <= kv) break; csr[j] = u; --j; }
+          csr[j] = v;
         }
         uint32_t n1 = 0, n2 = 0;
-        LC_GLOBAL uint32_t *v1 = W.mv + 4 * (size_t)lo, *v2 = v1 + 2 * (size_t)len;
+        LC_GLOBAL mv_t *v1 = (LC_GLOBAL mv_t *)W.mv + 4 * (size_t)lo, *v2 = v1 + 2 * (size_t)len;      // (mv_t: layout.h; each occurrence pushes at most twice)
         for (uint32_t i = lo; i < hi; ++i) {
-          const uint32_t e = W.csr[i], er = CS_READ(e);
+          const cs_t e = csr[i]; const uint32_t er = CS_READ(e);
           if ((int)er == S.R - 1) continue;
           const uint32_t ri = LC_CTX(c).B->rinfo[g0 + er], mt = RI_MATE(ri);
           if (mt != 1 && mt != 2) continue;
           const int ep = (int)CS_POS(e), etl = (int)RI_TLEN(ri);
-          const uint32_t rec = (er << 16) | (LC_CTX(c).B->name_rank[g0 + er] & 0xFFFFu);      // ranks < number of reads < 2^16
+          const mv_t rec = MV_REC(er, LC_CTX(c).B->name_rank[g0 + er]);                      // (ranks < number of reads)
           const uint32_t pushes = (ep >= 1 ? 1u : 0u) + (ep <= etl - K - 1 ? 1u : 0u);   // as v of step p-1, as u of step p
           for (uint32_t q = 0; q < pushes; ++q) { if (mt == 1) v1[n1++] = rec; else v2[n2++] = rec; }
         }
+#if LC_WIDE_IDS
+        W.nfill[2 * (size_t)n] = n1; W.nfill[2 * (size_t)n + 1] = n2;
+#else
         W.nfill[n] = n1 | (n2 << 16);
+#endif
       }
       WG_SYNC();
       XG_FOR(ti, ntodo) {
         const uint32_t r = W.todo[ti] >> 10, p = W.todo[ti] & 1023u;
-        const uint32_t mi = RI_MATE(LC_CTX(c).B->rinfo[g0 + r]), nm = LC_CTX(c).B->name_rank[g0 + r] & 0xFFFFu;
+        const uint32_t mi = RI_MATE(LC_CTX(c).B->rinfo[g0 + r]), nm = MV_NAME(MV_REC(0u, LC_CTX(c).B->name_rank[g0 + r]));
         const uint32_t X = W.occ[W.occ_base[r] + p] & 0x3FFFFFFFu;
         const uint32_t lo = W.nocc[X], len = W.nocc[X + 1] - lo;
-        LC_GLOBAL const uint32_t *vec = W.mv + 4 * (size_t)lo + (mi == 1 ? 2 * (size_t)len : 0);   // the OTHER mate's pushes
+        LC_GLOBAL const mv_t *vec = (LC_GLOBAL const mv_t *)W.mv + 4 * (size_t)lo + (mi == 1 ? 2 * (size_t)len : 0);   // the OTHER mate's pushes
+#if LC_WIDE_IDS
+        const uint32_t nv = mi == 1 ? W.nfill[2 * (size_t)X + 1] : W.nfill[2 * (size_t)X];
+#else
         const uint32_t nv = mi == 1 ? (W.nfill[X] >> 16) : (W.nfill[X] & 0xFFFFu);
+#endif
         uint32_t total = 0;                                       // pushes of reads before r
-        { uint32_t f = 0, l = nv; while (l > 0) { const uint32_t h = l >> 1; if ((vec[f + h] >> 16) < r) { f += h + 1; l -= h + 1; } else l = h; } total = f; }
+        { uint32_t f = 0, l = nv; while (l > 0) { const uint32_t h = l >> 1; if (MV_READ(vec[f + h]) < r) { f += h + 1; l -= h + 1; } else l = h; } total = f; }
         uint32_t first = 0, l2 = total;                           // std::lower_bound over the names, as pushed
-        while (l2 > 0) { const uint32_t h = l2 >> 1, mid = first + h; if ((vec[mid] & 0xFFFFu) < nm) { first = mid + 1; l2 = l2 - h - 1; } else l2 = h; }
-        const bool ovl = (first != total) && !(nm < (vec[first] & 0xFFFFu));
+        while (l2 > 0) { const uint32_t h = l2 >> 1, mid = first + h; if (MV_NAME(vec[mid]) < nm) { first = mid + 1; l2 = l2 - h - 1; } else l2 = h; }
+        const bool ovl = (first != total) && !(nm < MV_NAME(vec[first]));
         uint32_t f = lo, l = len;                                 // the occurrence's own entry in the sorted run
-        const uint32_t key = (r << 10) | p;
-        while (l > 0) { const uint32_t h = l >> 1; const uint32_t u = W.csr[f + h]; if (((CS_READ(u) << 10) | CS_POS(u)) < key) { f += h + 1; l -= h + 1; } else l = h; }
-        const uint32_t e = W.csr[f];
-        W.csr[f] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), ovl ? 2u : 0u);
+        const cs_key_t key = CS_KEY_OF(r, p);
+        LC_GLOBAL cs_t *csr = W_CSR(W);
+        while (l > 0) { const uint32_t h = l >> 1; const cs_t u = csr[f + h]; if (CS_KEY(u) < key) { f += h + 1; l -= h + 1; } else l = h; }
+        const cs_t e = csr[f];
+        csr[f] = CS_MAKE(CS_READ(e), CS_POS(e), CS_ORI(e), ovl ? 2u : 0u);
       }
     }
     WG_LANE0 { S.seq_top = 0; S.qv_top = 0; }
@@ -1503,7 +1520,7 @@ DEVNI void gather_edges_even(Ctx &c, uint32_t n, uint32_t lo, uint32_t hi) {
   uint32_t ef[20];
   for (int j = 0; j < 20; ++j) ef[j] = LC_NIL;
   for (uint32_t q = lo; q < hi; ++q) {
-    const uint32_t e = W.csr[q];
+    const cs_t e = W_CSR(W)[q];
     const int r = (int)CS_READ(e), p = (int)CS_POS(e);
     const uint32_t ori = CS_ORI(e);
     const bool isref = r == Rref;
@@ -1585,7 +1602,7 @@ DEVNI void build_gather(Ctx &c) {
 #pragma unroll 4
 #endif
     for (uint32_t q = lo; q < hi; ++q) {
-      const uint32_t e = W.csr[q];
+      const cs_t e = W_CSR(W)[q];
       const int r = (int)CS_READ(e), p = (int)CS_POS(e);
       const uint32_t ori = CS_ORI(e), st = CS_ST(e);
       // (read_geom without its volatile LDS reads, so that the loads of the unrolled iterations can be issued together)
@@ -1709,7 +1726,7 @@ DEVNI void build_qcounts(Ctx &c) {
         float gcov[4] = {0.f, 0.f, 0.f, 0.f}; uint32_t gfl = 0;
         const bool gfetch = r0 == 0 && ln < gN;                  // lane k: candidate k's record for the tail of this group
         if (gfetch) { LC_GLOBAL const NodeGr &G = W.gr[S.g_n[ln]]; gcov[0] = G.cov[0]; gcov[1] = G.cov[1]; gcov[2] = G.cov[2]; gcov[3] = G.cov[3]; gfl = G.flags; }
-        uint32_t e[U], m[U][4], meta[U]; bool act[U];
+        cs_t e[U]; uint32_t m[U][4], meta[U]; bool act[U];
         const uint32_t *gd[U]; uint32_t ri[U];
         for (int u = 0; u < U; ++u) {
           const int j = ln + u * LC_QLANES;
@@ -1719,7 +1736,7 @@ DEVNI void build_qcounts(Ctx &c) {
             uint32_t src;
             if (big) src = S.g_lo[0] + r0 + (uint32_t)j;
             else { int k = 0; while (k + 1 < gN && (uint32_t)j >= S.g_es[k + 1]) ++k; src = S.g_lo[k] + ((uint32_t)j - S.g_es[k]); }
-            e[u] = W.csr[src];
+            e[u] = W_CSR(W)[src];
           }
         }
         for (int u = 0; u < U; ++u) {
@@ -1735,7 +1752,7 @@ DEVNI void build_qcounts(Ctx &c) {
             #define LC_TAKE(t) ((32 * (t) < K) ? ((gd[u][wv + (t)] >> sh) | ((sh && 32 * (t) + 32 - sh < K) ? (gd[u][wv + (t) + 1] << (32 - sh)) : 0u)) : 0u)
             m[u][0] = LC_TAKE(0); m[u][1] = LC_TAKE(1); m[u][2] = LC_TAKE(2); m[u][3] = LC_TAKE(3);
             #undef LC_TAKE
-            meta[u] = 1u | (((RI_NML(ri[u]) ? 2u : 0u) + (RI_REV(ri[u]) ? 1u : 0u)) << 1) | (CS_ORI(e[u]) << 3) | ((e[u] >> 29) << 4);
+            meta[u] = 1u | (((RI_NML(ri[u]) ? 2u : 0u) + (RI_REV(ri[u]) ? 1u : 0u)) << 1) | (CS_ORI(e[u]) << 3) | (((uint32_t)e[u] >> 29) << 4);
           }
         }
         for (int u = 0; u < U; ++u) {
@@ -3820,7 +3837,7 @@ DEV void bx_add_node(Ctx &c, uint32_t X, uint32_t nml, uint32_t *n) {
   const uint32_t g0 = B.read_begin[S.w], refr = (uint32_t)(S.R - 1);
   LC_GLOBAL uint32_t *buf = W.bxbuf;
   for (uint32_t i = W.nocc[X]; i < W.nocc[X + 1]; ++i) {
-    const uint32_t r = CS_READ(W.csr[i]);
+    const uint32_t r = CS_READ(W_CSR(W)[i]);
     if (r == refr) continue;
     if (RI_NML(B.rinfo[g0 + r]) != nml) continue;
     const uint32_t bx = B.bx_rank[g0 + r];
@@ -4685,7 +4702,8 @@ DEV void process_window(Ctx &c, int w, int rq = -1) {
     S.R = nr + 1;                                   // + the reference pseudo-read, appended last (Graph.cc:535-540)
     S.seq_t5 = 0; S.seq_len = S.reflen; S.trim5 = 0; S.trim3 = 0;
     S.tmp0 = 0;
-    if ((uint32_t)S.R > LC_CTX(c).C->reads_cap || S.R > 0xFFFF || S.reflen > (int)LC_CTX(c).C->max_w || S.reflen < 1) S.overflow = 1;   // csr / item words keep the read in 16 bits
+    if ((uint32_t)S.R > LC_CTX(c).C->reads_cap || (uint32_t)S.R > LC_READS_MAX || S.reflen > (int)LC_CTX(c).C->max_w || S.reflen < 1) S.overflow = 1;   // csr / item words keep the read in 16 bits (in 32 / 21 in the re-run tier: layout.h cs_t)
+    if (LC_WIDE_IDS && !LC_CTX(c).C->wide_ids) S.overflow = 1;                                  // (a work space laid out for the 32-bit words)
     S.hasN = 0;
     S.nosusp_k = -1;
     if (rq >= 0) {                                  // what the window carried when it was suspended

@@ -64,12 +64,40 @@
 #define SD_KMER(d) ((d) >> 9)
 #define SD_MAKE(kmer, off, base) (((uint32_t)(kmer) << 9) | ((uint32_t)(off) << 2) | (uint32_t)(base))
 
-/* csr entry: read [15:0], k-mer position in read [25:16], ori R [26], state [28:27]                      */
+/* csr entry (cs_t): read [15:0], k-mer position in read [25:16], ori R [26], state [28:27], lr_mode "hpX had grown" [31:29].
+ * The re-run tier (window_fat.hip, LANCET_FAT) keeps the read in the upper half of a 64-bit word instead: windows of more than
+ * 65 535 reads (the reference assembles up to MAX_AVG_COV = 10 000x per sample, src/Microassembler.cc:491-496) run there.   */
+#define CS_POS(c) (((uint32_t)(c) >> 16) & 0x3FFu)
+#define CS_ORI(c) (((uint32_t)(c) >> 26) & 1u)
+#define CS_ST(c) (((uint32_t)(c) >> 27) & 3u)   /* 0 counted, 1 candidate (needs the mate-overlap replay), 2 suppressed */
+#ifdef LANCET_FAT
+#define LC_WIDE_IDS 1
+typedef unsigned long long cs_t;
+typedef unsigned long long cs_key_t;
+#define CS_READ(c) ((uint32_t)((c) >> 32))
+#define CS_MAKE(r, p, ori, st) (((cs_t)(uint32_t)(r) << 32) | (cs_t)(((uint32_t)(p) << 16) | ((uint32_t)(ori) << 26) | ((uint32_t)(st) << 27)))
+#define CS_KEY_OF(r, p) (((cs_key_t)(uint32_t)(r) << 10) | (cs_key_t)(uint32_t)(p))
+#define MV_REC(r, name) (((unsigned long long)(uint32_t)(r) << 32) | (unsigned long long)(uint32_t)(name))
+#define MV_READ(x) ((uint32_t)((x) >> 32))
+#define MV_NAME(x) ((uint32_t)(x))
+typedef unsigned long long mv_t;
+#define IT_RBITS 21           /* items[]: read [20:0], first k-mer start [31:21]                                              */
+#define LC_READS_MAX 0x1FFFFFu
+#else
+#define LC_WIDE_IDS 0
+typedef uint32_t cs_t;
+typedef uint32_t cs_key_t;
 #define CS_READ(c) ((c) & 0xFFFFu)
-#define CS_POS(c) (((c) >> 16) & 0x3FFu)
-#define CS_ORI(c) (((c) >> 26) & 1u)
-#define CS_ST(c) (((c) >> 27) & 3u)   /* 0 counted, 1 candidate (needs the mate-overlap replay), 2 suppressed */
 #define CS_MAKE(r, p, ori, st) ((uint32_t)(r) | ((uint32_t)(p) << 16) | ((uint32_t)(ori) << 26) | ((uint32_t)(st) << 27))
+#define CS_KEY_OF(r, p) (((uint32_t)(r) << 10) | (uint32_t)(p))
+#define MV_REC(r, name) (((uint32_t)(r) << 16) | ((uint32_t)(name) & 0xFFFFu))
+#define MV_READ(x) ((x) >> 16)
+#define MV_NAME(x) ((x) & 0xFFFFu)
+typedef uint32_t mv_t;
+#define IT_RBITS 16           /* items[]: read [15:0], first k-mer start [31:16]                                              */
+#define LC_READS_MAX 0xFFFFu
+#endif
+#define CS_KEY(c) CS_KEY_OF(CS_READ(c), CS_POS(c))
 
 struct PreLayout {
   uint32_t ncap, qvcap, kw, maxw;
@@ -96,6 +124,7 @@ struct EngineCaps {
   uint32_t table_start;  /* testing only: first table size of every build (power of two; 0 = estimated)       */
   uint32_t lr_mode;      /* --linked-reads: 10 instead of 4 counters per (survivor, position), barcode outputs */
   uint32_t bx_cap;       /* barcode ids (u32) of the variants' barcode sets, whole batch (lr_mode)   */
+  uint32_t wide_ids;     /* work space laid out for the re-run tier's 64-bit csr words / mate-name records (read ids above 16 bits) */
   uint32_t max_w;        /* longest window reference of the batch, rounded up (>= LC_MAXW_DEFAULT, <= LC_MAXW): sizes the alignment / coverage arrays */
   struct PreLayout pl;   /* hand-off areas of the LDS build kernel (below)                           */
 };
@@ -237,16 +266,16 @@ struct Work {
   LC_GLOBAL uint32_t *chunk;        /* [2*((reads_cap + max_w/LC_SEG + 2)/64 + 2)] sweep origin/length per group of items */
   LC_GLOBAL uint32_t *occ;          /* [occ_cap]     slot (then node) | ori<<31                           */
   LC_GLOBAL uint32_t *slots;        /* [4*table_cap] k-mer table, 16 bytes per slot: tag (u64), first occurrence, node id */
-  LC_GLOBAL uint32_t *mv;           /* [4*occ_cap] mate-name vectors of the nodes with flagged occurrences (read << 16 | name rank) */
+  LC_GLOBAL uint32_t *mv;           /* [4*occ_cap] mate-name vectors of the nodes with flagged occurrences (read << 16 | name rank); wide_ids: [8*occ_cap], 64-bit records */
   LC_GLOBAL uint32_t *todo;         /* [table_cap] occurrences flagged by the mate-overlap prefilter (read << 10 | position)  */
   LC_GLOBAL unsigned long long *slot_key; /* [table_cap * LC_NWMAX]                                    */
   LC_GLOBAL uint32_t *bitmap;       /* [occ_cap/32 + 2]                                                  */
   LC_GLOBAL uint32_t *bitpre;       /* [occ_cap/32 + 2]                                                  */
-  LC_GLOBAL uint32_t *csr;          /* [occ_cap]                                                         */
+  LC_GLOBAL uint32_t *csr;          /* [occ_cap] cs_t words (wide_ids: [2*occ_cap], 64-bit words)          */
   /* ---- nodes: index < node_cap are k-mers in first-insertion order; then special nodes ---- */
   LC_GLOBAL unsigned long long *nkey;     /* [nodes * LC_NWMAX] right-aligned 2-bit canonical k-mer     */
   LC_GLOBAL unsigned long long *nhash;    /* [nodes] libstdc++ std::hash<std::string> of the node id     */
-  LC_GLOBAL uint32_t *nfill;        /* [nodes+1] csr fill cursors                                        */
+  LC_GLOBAL uint32_t *nfill;        /* [nodes+1] csr fill cursors (wide_ids: [2*(nodes+1)])               */
   LC_GLOBAL NodeGr *gr;             /* [nodes]                                                           */
   LC_GLOBAL CmpRec *cmp;            /* [nodes] compress_prepare records                                   */
   LC_GLOBAL uint32_t *nocc;         /* [nodes+1] csr offsets                                             */

@@ -30,6 +30,7 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   EngineCaps C = getenv("LANCET_EMU_TIER1") ? lc_caps_for_batch(b, P, evt_cap, 16384, 1)      // (the engine's tier-1 work space: to see which limit a window hits there)
                                             : lc_caps_for_batch(b, P, evt_cap, 65536);
   C.pl = lc_pre_layout_for_batch(b, 1, (size_t)1 << 40, getenv("LANCET_PRE_WIDE") ? atoi(getenv("LANCET_PRE_WIDE")) : -1);      // (engine.hip lc_upload)
+  C.wide_ids = LC_WIDE_IDS;                        // (libemu_fat.so: the re-run tier's 64-bit csr words, as engine.hip lays its tier 2 out)
   if (const char *ts = getenv("LANCET_TABLE_START")) C.table_start = lc_pow2_ge((uint32_t)atoi(ts));
   if (const char *st = getenv("LANCET_STOP_PHASE")) C.debug_stop = (uint32_t)atoi(st);
   const uint32_t R = b->read_begin[b->n_windows];

@@ -443,6 +443,23 @@ def test_fat_source_on_coverage_pile_ups(fat_emu):
         assert v == ov and [_KEY(s) for s in st] == [_KEY(s) for s in ost]
 
 
+@pytest.mark.parametrize("linked", [False, True])
+def test_fat_source_on_a_window_of_more_than_65535_reads(linked, fat_emu):
+    """~95 000 reads of 50 bases in one window (3100x / 3100x; the reference goes up to MAX_AVG_COV = 10 000x per sample): the re-run
+    tier's csr words, mate-name records and work items keep the read in 32 / 21 bits (layout.h cs_t) -- the one-wave source refuses it."""
+    from lancet_amd import workload
+    big = workload.make_scan_batch(1, 3100, 3100, seed=8, read_len=50, error_rate=0.0005, linked=linked)
+    assert int(big.read_begin[1]) > 90000
+    p = abi.default_params(); p.lr_mode = 1 if linked else 0
+    ov, ost, _ = oracle.run(big, p)
+    v, st, _ = fat_emu.run(big, p)
+    assert v == ov and [_KEY(s) for s in st] == [_KEY(s) for s in ost] and len(ov) > 0
+    if not linked:
+        emu.FAT[0] = False
+        _, st1, _ = emu.run(big, p)
+        assert st1[0]["status"] < 0
+
+
 @pytest.mark.parametrize("seed", [0, 1])
 def test_fat_source_on_random_linked_read_windows(seed, fat_emu):
     test_emulated_kernels_match_oracle_on_random_linked_read_windows(seed)

@@ -420,9 +420,48 @@ def test_window_size_1000_inside_ordinary_batches():
     eng.close()
 
 
+_KEY = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
+
+
+def test_windows_of_more_than_65535_reads():
+    """The reference assembles up to MAX_AVG_COV = 10 000x per sample (src/Microassembler.cc:491-496): ~96 000 reads of 150 bases in a 600-base
+    window at 11 500x / 11 500x (13 M k-mer occurrences; pairs with overlapping mates by the hundred, so the mate-name vectors of the
+    overlap replay hold read ids above 16 bits), and ~95 000 reads of 50 bases, among ordinary windows -- they run in the re-run tier
+    next to the rest of the batch and equal the oracle; twice on one engine."""
+    from lancet_amd import workload
+    plain = workload.make_scan_batch(24, 30, 30, seed=7)
+    big150 = workload.make_scan_batch(1, 11500, 11500, seed=5, read_len=150, error_rate=0.0005)
+    big50 = workload.make_scan_batch(1, 3100, 3100, seed=8, read_len=50, error_rate=0.0005)
+    # (reads of different lengths in one batch: seq_off is per read)
+    both = _concat(_concat(plain, big150), big50)
+    assert int(both.read_begin[25] - both.read_begin[24]) > 90000 and int(both.read_begin[26] - both.read_begin[25]) > 90000
+    p = abi.default_params()
+    ov, ost, _ = oracle.run(both, p)
+    eng = engine.Engine(p)
+    for _ in range(2):
+        v, st = eng.process(both)
+        assert v == ov and [_KEY(s) for s in st] == [_KEY(s) for s in ost]
+        assert eng.rerun_count() == 2
+    eng.close()
+
+
+def test_linked_read_window_of_more_than_65535_reads():
+    """--linked-reads on a window of ~95 000 reads: the barcode replay and getBXsetAt walk csr runs whose read ids need 17 bits."""
+    from lancet_amd import workload
+    big = workload.make_scan_batch(1, 3100, 3100, seed=8, read_len=50, error_rate=0.0005, linked=True)
+    assert int(big.read_begin[1]) > 90000
+    p = abi.default_params(); p.lr_mode = 1
+    ov, ost, _ = oracle.run(big, p)
+    eng = engine.Engine(p)
+    v, st = eng.process(big)
+    assert v == ov and [_KEY(s) for s in st] == [_KEY(s) for s in ost] and len(ov) > 0
+    eng.close()
+
+
 def test_a_window_beyond_the_engine_limits_fails_alone():
-    """One window of 1100 bp (LC_MAXW is 1024) and one with 70 000 reads (read ids are 16 bit) inside an ordinary batch: they are reported
-    LANCET_W_OVERFLOW on their own; the batch is not refused and every other window equals the oracle."""
+    """One window of 1100 bp (LC_MAXW is 1024) inside an ordinary batch is reported LANCET_W_OVERFLOW on its own: the batch is not refused and
+    every other window equals the oracle -- among them one with 70 000 reads, which overflows the one-wave kernel's 16-bit read ids and
+    is assembled by the re-run tier (64-bit csr words and mate-name records there: layout.h cs_t)."""
     from lancet_amd import frontend, workload
     p = abi.default_params()
     b = workload.make_scan_batch(24, 20, 20, seed=9, read_len=100)
@@ -447,9 +486,11 @@ def test_a_window_beyond_the_engine_limits_fails_alone():
                                label=rep(b.label), strand=rep(b.strand), mate=rep(b.mate), mapped=rep(b.mapped), name_rank=name)
     eng = engine.Engine(p)
     v, st = eng.process(big)
-    assert st[5]["status"] < 0 and st[11]["status"] < 0
-    ov, ost, _ = oracle.run(b, p)
-    keep = [w for w in range(b.n_windows) if w not in (5, 11)]
+    assert st[5]["status"] < 0
+    ov, ost, _ = oracle.run(big, p)
+    keep = [w for w in range(b.n_windows) if w != 5]
     assert all(st[w]["status"] >= 0 for w in keep)
     assert [x for x in v if x["window"] in keep] == [x for x in ov if x["window"] in keep]
+    assert [_KEY(st[w]) for w in keep] == [_KEY(ost[w]) for w in keep]
+    assert int(big.read_begin[12] - big.read_begin[11]) > 65535 and st[11]["n_kmers"] == ost[11]["n_kmers"] > 5_000_000
     eng.close()
