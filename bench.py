@@ -437,7 +437,7 @@ def main():
                 side_config(engine.Engine, params, "config 2 at 60x/60x", 8192, 60.0, 60.0, 8),
                 side_config(engine.Engine, params, "config 4: 100x tumor / 40x normal, 30 % STR + 5 % low complexity", 4096, 100.0, 40.0, 8,
                             str_fraction=0.30, lowcomplex_fraction=0.05),
-                side_config(engine.Engine, abi.default_params(lr_mode=1), "config 5: --linked-reads (BX / HP tags on every pair), 30x/30x", 8192, 30.0, 30.0, 8,
+                side_config(engine.Engine, abi.default_params(lr_mode=1), "config 5: --linked-reads (BX / HP tags on every pair), 30x/30x", 16384, 30.0, 30.0, 6,
                             linked=True),
             ]
         print(json.dumps(out))

@@ -1121,6 +1121,149 @@ DEVNI void lr_node_replay(Ctx &c, uint32_t lo, uint32_t hi, uint32_t *out) {
   for (int j = 0; j < 3; ++j) { out[4 + j] = LC_PK(hpwT, j); out[7 + j] = LC_PK(hpwN, j); }
 }
 
+// The same replay by the whole wave, for the nodes of LR_COOP_MIN..LR_COOP_MAX occurrences, several nodes at a time (round 4: with one lane
+// per node the replay was 44 % of a linked-read window -- a chain of dependent loads per occurrence and a search over the node's
+// earlier occurrences for every one of them, 72 nodes per lane; one node at a time by the wave was no better: ~14 us of exposed
+// round trips per node).  A batch = consecutive nodes of perm[0..n_many) whose eligible runs fit LR_COOP_MAX staged occurrences; lane j
+// takes the j-th staged occurrence, everything a lane needs from the others goes through LDS, all loops stay inside the node's segment:
+//   1. the run is sorted into visiting order by rank (keys (read, position) are distinct),
+//   2. per occurrence: hasBX key (barcode << 1 | sample), class bits; "counted" = not the reference read, not an overlapping mate,
+//   3. seen_j = an earlier occurrence of the node carries the same key (Node_t::hasBX); an occurrence that is not seen ADDS (barcode
+//      count of its (sample, strand), haplotype count of its sample),
+//   4. a counted occurrence j takes the counts over the occurrences up to E(j), E(j) = j + 1 for the first of a (position 0,
+//      position 1) pair of one read -- both LR events of loadSequence's offset 0 precede the coverage events -- else j (counts fit
+//      8 bits here); the last counted occurrence of a (sample, strand) / of a sample leaves the node's values,
+//   5. "grown" bits against the previous counted occurrence of the same sample.
+// Same results as lr_node_replay: the ten values, the csr run sorted, grown bits in csr bits 29..31.
+#define LR_COOP_MIN 6u
+#define LR_COOP_MAX 192u
+#define LR_COOP_SEGS 32u
+static_assert(LR_COOP_MAX <= LC_QSTAGE && LR_COOP_MAX < 256u && LR_COOP_SEGS * LR_COOP_MIN >= LR_COOP_MAX, "staging area ; 8-bit counts ; segments of a full batch");
+DEVNI void lr_replay_batches(Ctx &c, uint32_t n_list) {
+  LC_GLOBAL Work &W = *LC_CTX(c).W; LC_GLOBAL const DevBatch &B = *LC_CTX(c).B; LC_WS &S = LC_SREF(c);
+  const uint32_t g0 = B.read_begin[S.w], refr = (uint32_t)(S.R - 1);
+  LC_GLOBAL cs_t *csr = W_CSR(W);
+  LC_GLOBAL const uint32_t *list = W.scratch;                      // (node, csr start | occurrences << 24) of the nodes build_gather left for the wave
+  LC_LDS cs_t *raw = (LC_LDS cs_t *)S.mmeta;                       // [LR_COOP_MAX] the runs as stored ; afterwards out[seg][16] bytes: the ten values
+  LC_LDS uint8_t *outv = (LC_LDS uint8_t *)S.mmeta;
+  LC_LDS cs_t *ev = (LC_LDS cs_t *)S.lbytes;                       // [MAX] in visiting order
+  LC_LDS uint32_t *key = (LC_LDS uint32_t *)(ev + LR_COOP_MAX);    // [MAX] hasBX key
+  LC_LDS uint32_t *cur = key + LR_COOP_MAX;                        // [MAX] counted: the haplotype counts of its sample at its coverage event (3 x 8 bit) | previous counted one << 24
+  LC_LDS uint8_t *meta = (LC_LDS uint8_t *)(cur + LR_COOP_MAX);    // [MAX] 1 adds | 2 barcode present | class f << 2 | haplotype << 4 | 64 counted | 128 first of a pair
+  LC_LDS uint8_t *segof = meta + LR_COOP_MAX;                      // [MAX] segment of a staged occurrence
+  LC_LDS uint32_t *seg = (LC_LDS uint32_t *)(segof + LR_COOP_MAX); // [SEGS][3] node, csr start, first staged slot | occurrences << 16
+  LC_LDS uint32_t *cand_n = (LC_LDS uint32_t *)S.part2;            // the next 64 entries of the list
+  LC_LDS uint32_t *cand_lm = (LC_LDS uint32_t *)S.part;
+  static_assert(sizeof(cs_t) * LR_COOP_MAX <= sizeof(uint32_t) * LC_QSTAGE && 16u * LR_COOP_SEGS <= sizeof(uint32_t) * LC_QSTAGE &&
+                (sizeof(cs_t) + 8u + 2u) * LR_COOP_MAX + 12u * LR_COOP_SEGS <= 16u * LC_QSTAGE, "LDS arrays of the replay");
+  uint32_t li = 0, lbase = 0, lend = 0;                            // next entry ; the entries in LDS are [lbase, lend)
+  while (li < n_list) {
+    if (li >= lend || (lend < n_list && li + 16u > lend)) {        // refill (also when fewer than 16 are left: a batch rarely takes more)
+      WG_FOR(t, 64) { if (li + (uint32_t)t < n_list) { cand_n[t] = list[2 * (size_t)(li + (uint32_t)t)]; cand_lm[t] = list[2 * (size_t)(li + (uint32_t)t) + 1]; } }
+      lbase = li; lend = li + 64u < n_list ? li + 64u : n_list;
+      WG_SYNC();
+    }
+    WG_LANE0 {                                                     // the batch: entries li .. li + S.tmp2 - 1 = S.tmp3 segments, S.tmp1 staged occurrences
+      uint32_t tot = 0, ns = 0, t = li - lbase;
+      for (; lbase + t < lend; ++t) {
+        const uint32_t mm = cand_lm[t] >> 24;
+        if (tot + mm > LR_COOP_MAX || ns == LR_COOP_SEGS) break;
+        seg[3 * ns] = cand_n[t]; seg[3 * ns + 1] = cand_lm[t] & 0xFFFFFFu; seg[3 * ns + 2] = tot | (mm << 16);
+        ++ns; tot += mm;
+      }
+      S.tmp1 = (int)tot; S.tmp2 = (int)(lbase + t - li); S.tmp3 = (int)ns;
+    }
+    const uint32_t tot = (uint32_t)wg_bcast(&S.tmp1), adv = (uint32_t)wg_bcast(&S.tmp2), ns = (uint32_t)wg_bcast(&S.tmp3);
+    WG_FOR(t, ns) { const uint32_t b0 = seg[3 * t + 2] & 0xFFFFu, mm = seg[3 * t + 2] >> 16; for (uint32_t q = 0; q < mm; ++q) segof[b0 + q] = (uint8_t)t; }
+    WG_SYNC_LDS();
+    WG_FOR(j, tot) { const uint32_t sg = segof[j]; raw[j] = csr[seg[3 * sg + 1] + ((uint32_t)j - (seg[3 * sg + 2] & 0xFFFFu))]; }
+    WG_SYNC_LDS();
+    WG_FOR(j, tot) {
+      const uint32_t sg = segof[j], b0 = seg[3 * sg + 2] & 0xFFFFu, e0 = b0 + (seg[3 * sg + 2] >> 16);
+      const cs_t v = raw[j]; const cs_key_t kv = CS_KEY(v);
+      const uint32_t r = CS_READ(v);                               // (the three loads are in flight during the loop below)
+      uint32_t k = 0xFFFFFFFEu, mt = 0;
+      if (r != refr) {
+        const uint32_t g = g0 + r, ri = B.rinfo[g], sm = RI_NML(ri), d = RI_REV(ri), bx = B.bx_rank[g];
+        uint32_t h = B.hp[g]; if (h > 2) h = 2;
+        k = bx == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((bx << 1) | sm);
+        mt = (bx != 0xFFFFFFFFu ? 2u : 0u) | ((2u * sm + d) << 2) | (h << 4) | (CS_ST(v) == 0 ? 64u : 0u);
+      }
+      uint32_t rank = 0;
+#ifndef LANCET_WAVE_EMU
+#pragma unroll 4
+#endif
+      for (uint32_t i = b0; i < e0; ++i) rank += CS_KEY(raw[i]) < kv ? 1u : 0u;
+      ev[b0 + rank] = v; key[b0 + rank] = k; meta[b0 + rank] = (uint8_t)mt;
+    }
+    WG_SYNC_LDS();
+    WG_FOR(t, LR_COOP_SEGS * 4u) { ((LC_LDS uint32_t *)outv)[t] = 0; }          // (raw[] is done with)
+    WG_FOR(j, tot) {
+      const uint32_t b0 = seg[3 * (uint32_t)segof[j] + 2] & 0xFFFFu, e0 = b0 + (seg[3 * (uint32_t)segof[j] + 2] >> 16);
+      const uint32_t k = key[j];
+      uint32_t same = 0;
+#ifndef LANCET_WAVE_EMU
+#pragma unroll 4
+#endif
+      for (uint32_t i = b0; i < (uint32_t)j; ++i) same |= key[i] == k ? 1u : 0u;
+      uint32_t mt = meta[j];
+      if (k != 0xFFFFFFFEu && (k == 0xFFFFFFFFu || !same)) mt |= 1u;           // (the reference read: no LR event at all ; no barcode: hasBX is never true)
+      if (k != 0xFFFFFFFEu) { const cs_t e = ev[j]; if (CS_POS(e) == 0 && (uint32_t)j + 1 < e0) { const cs_t e2 = ev[j + 1]; if (CS_READ(e2) == CS_READ(e) && CS_POS(e2) == 1) mt |= 128u; } }
+      meta[j] = (uint8_t)mt;
+    }
+    WG_SYNC_LDS();
+    WG_FOR(j, tot) {
+      const uint32_t mt = meta[j];
+      if (mt & 64u) {
+        const uint32_t sg = segof[j], b0 = seg[3 * sg + 2] & 0xFFFFu, e0 = b0 + (seg[3 * sg + 2] >> 16);
+        const uint32_t f = (mt >> 2) & 3u, sm = f >> 1, E = (uint32_t)j + ((mt & 128u) ? 1u : 0u);
+        uint32_t bxc = 0, hpc = 0;                                 // barcode counts per (sample, strand), 4 x 8 bit ; haplotype counts of THIS sample, 3 x 8 bit
+        uint32_t later_f = 0, later_s = 0, prev = 0xFFFFFFFFu;
+#ifndef LANCET_WAVE_EMU
+#pragma unroll 4
+#endif
+        for (uint32_t i = b0; i < e0; ++i) {
+          const uint32_t x = meta[i];
+          const bool cnt_s = (x & 64u) && ((x >> 3) & 1u) == sm;   // a counted occurrence of this sample
+          if (i <= E && (x & 1u)) {
+            if (x & 2u) bxc += 1u << (8u * ((x >> 2) & 3u));
+            if (((x >> 3) & 1u) == sm) hpc += 1u << (8u * ((x >> 4) & 3u));
+          }
+          if (cnt_s && i < (uint32_t)j) prev = i;
+          if (cnt_s && i > (uint32_t)j) { later_s = 1; if (((x >> 2) & 3u) == f) later_f = 1; }
+        }
+        cur[j] = hpc | (prev == 0xFFFFFFFFu ? 0xFF000000u : ((prev - b0) << 24));
+        if (!later_f) outv[16 * sg + f] = (uint8_t)((bxc >> (8u * f)) & 0xFFu);
+        if (!later_s) for (uint32_t q = 0; q < 3; ++q) outv[16 * sg + 4 + 3 * sm + q] = (uint8_t)((hpc >> (8u * q)) & 0xFFu);
+      }
+    }
+    WG_SYNC_LDS();
+    WG_FOR(j, tot) {
+      const uint32_t mt = meta[j], sg = segof[j], b0 = seg[3 * sg + 2] & 0xFFFFu;
+      cs_t e = ev[j];
+      if (mt & 64u) {
+        const uint32_t now = cur[j], pv = now >> 24;
+        const uint32_t old = pv == 0xFFu ? 0u : cur[b0 + pv];
+        uint32_t grow = 0;
+        for (uint32_t q = 0; q < 3; ++q) if (((old >> (8u * q)) & 0xFFu) < ((now >> (8u * q)) & 0xFFu)) grow |= 1u << q;
+        e |= (cs_t)(grow << 29);
+      }
+      csr[seg[3 * sg + 1] + ((uint32_t)j - b0)] = e;
+    }
+    WG_FOR(t, ns) {
+      const uint32_t n = seg[3 * t];
+      LC_GLOBAL NodeGr &G = W.gr[n];
+      uint32_t sum = 0;
+      for (int q = 0; q < 4; ++q) { const uint32_t v = outv[16 * t + q]; G.kc[q] = (uint16_t)v; sum += v; }
+      for (int q = 0; q < 6; ++q) W.khp[6 * (size_t)n + q] = (uint16_t)outv[16 * t + 4 + q];
+      G.mincov = (int)sum;
+    }
+    WG_SYNC_LDS();
+    li += adv;
+  }
+  WG_SYNC();
+}
+
 // buildgraph is cut into separately compiled pieces (DEVNI): one register allocation per phase instead of one for the
 // whole window program, which kept values of later phases alive (and spilled) across the hot loops of earlier ones.
 DEVNI void build_tables(Ctx &c) {
@@ -1586,7 +1729,9 @@ DEVNI void build_gather(Ctx &c) {
       perm[ia ? a : (ib ? ta + b : ta + tb + ((uint32_t)n - a - b))] = (uint32_t)n;
     }
     WG_SYNC();
+    WG_LANE0 { S.tmp2 = 0; }                                      // linked reads: nodes listed for lr_replay_batches
   }
+  SUBPHASE(c, 5, 11);
   XG_FOR(pi, S.N) {
     const int n = (int)W.ht_next[pi];
     uint32_t ef0 = LC_NIL, ef1 = LC_NIL, ef2 = LC_NIL, ef3 = LC_NIL, ef4 = LC_NIL, ef5 = LC_NIL, ef6 = LC_NIL, ef7 = LC_NIL, ef8 = LC_NIL, ef9 = LC_NIL;
@@ -1659,10 +1804,15 @@ DEVNI void build_gather(Ctx &c) {
     kc[0] = (uint16_t)c0; kc[1] = (uint16_t)c1; kc[2] = (uint16_t)c2; kc[3] = (uint16_t)c3;
     G.cov[0] = (float)c0; G.cov[1] = (float)c1; G.cov[2] = (float)c2; G.cov[3] = (float)c3;
     if (S.LR) {        // cov_distr holds barcode counts instead of read counts; the float coverages stay read counts
-      uint32_t lrv[10];
-      lr_node_replay(c, lo, hi, lrv);
-      for (int q = 0; q < 4; ++q) kc[q] = (uint16_t)lrv[q];
-      for (int q = 0; q < 6; ++q) W.khp[6 * (size_t)n + q] = (uint16_t)lrv[4 + q];
+      if (hi - lo >= LR_COOP_MIN && hi - lo <= LR_COOP_MAX && lo < (1u << 24)) {     // by the whole wave, below: listed
+        const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.tmp2, 1u);
+        W.scratch[2 * (size_t)at] = (uint32_t)n; W.scratch[2 * (size_t)at + 1] = lo | ((hi - lo) << 24);
+      } else {
+        uint32_t lrv[10];
+        lr_node_replay(c, lo, hi, lrv);
+        for (int q = 0; q < 4; ++q) kc[q] = (uint16_t)lrv[q];
+        for (int q = 0; q < 6; ++q) W.khp[6 * (size_t)n + q] = (uint16_t)lrv[4 + q];
+      }
     }
     G.mincov = (int)(uint16_t)kc[0] + (int)(uint16_t)kc[1] + (int)(uint16_t)kc[2] + (int)(uint16_t)kc[3];
     G.mincovqv = 0;
@@ -1670,6 +1820,9 @@ DEVNI void build_gather(Ctx &c) {
   }
   WG_LANE0 { W.order[S.N] = 0; }
   WG_SYNC();
+  SUBPHASE(c, 5, 12);
+  if (S.LR) lr_replay_batches(c, (uint32_t)wg_bcast(&S.tmp2));     // (the nodes listed above)
+  SUBPHASE(c, 5, 13);
   wg_scan(W.order, (int)S.N + 1, S);
   // the candidates with their csr range next to them (compact arrays for the group formation of the per-position pass)
   XG_FOR(n, S.N) { if (W.order[n + 1] != W.order[n]) { const uint32_t at = W.order[n]; W.pnodes[at] = (uint32_t)n; W.pedges[at] = W.nocc[n]; W.ht_bucket[at] = W.nocc[n + 1] - W.nocc[n]; } }

@@ -54,6 +54,9 @@ DEV int wg_thin_lane() { const int t = (int)threadIdx.x; return t < 64 ? t : 0x3
 // Used at the phase boundaries of the table build, where atomics (executed at L2) are followed by plain loads of the
 // same words (which may hit the vector L1): agent-scope fence = L1 invalidate.
 #define WG_SYNC_FENCE() do { __threadfence(); __syncthreads(); } while (0)
+// Barrier between phases that hand data over through LDS only: waits for the LDS operations, not for the global stores in flight (a
+// __syncthreads() waits for their acknowledgement too -- a round trip to HBM per barrier in a latency-bound loop).
+#define WG_SYNC_LDS() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
 // lane-0 predicate, opaque to the optimiser (two consecutive lane-0 sections must not be merged or threaded)
 DEV bool wg_is_lane0() { uint32_t t = threadIdx.x; asm volatile("" : "+v"(t)); return t == 0; }
 DEV void wg_sync_fn() { __syncthreads(); }
@@ -116,6 +119,7 @@ DEV int dev_popcll(unsigned long long x) { return __popcll(x); }
 static thread_local unsigned long lc_emu_syncs = 0;          /* barriers a workgroup would execute (tuning aid: tests/emu LANCET_EMU_SYNCS) */
 #define WG_SYNC() ((void)++lc_emu_syncs)
 #define WG_SYNC_FENCE() ((void)++lc_emu_syncs)
+#define WG_SYNC_LDS() ((void)++lc_emu_syncs)
 #define WG_LANE0 if (true)
 #define WG_SHARED static thread_local
 DEV uint32_t dev_atomic_min(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
