@@ -4,7 +4,8 @@ tools/make_golden.py): for each seed a random configuration (coverages, error ra
 complexity content, variant density, duplications, k range, linked reads) goes through the reference and through the
 oracle and the emulated kernels; VCF and -v digest must agree.  A case that does not is kept under /tmp for a golden.
 
-    python tools/fuzz_reference.py [first_seed] [n]"""
+    python tools/fuzz_reference.py [first_seed] [n]          (LANCET_FUZZ_LINKED=1: linked reads in every case;
+                                                              LANCET_FUZZ_FAT=1: the re-run tier's source in the emulator)"""
 import os
 import sys
 import tempfile
@@ -21,7 +22,7 @@ from oracle import oracle, vcf_oracle  # noqa: E402
 
 def random_case(seed):
     rng = np.random.default_rng(seed)
-    linked = rng.random() < 0.25
+    linked = rng.random() < 0.25 or bool(os.environ.get("LANCET_FUZZ_LINKED"))     # (LANCET_FUZZ_LINKED=1: every case with --linked-reads)
     kw = dict(ref_len=int(rng.integers(3200, 5200)), cov_t=float(rng.choice([18, 30, 45, 70, 110])), cov_n=float(rng.choice([15, 28, 40, 60])),
               ref_seed=1000 + seed, tumor_seed=2000 + seed, normal_seed=3000 + seed, error_rate=float(rng.choice([0.0, 0.003, 0.008, 0.015])),
               read_len=int(rng.choice([76, 100, 125, 150])), insert_mean=float(rng.choice([190, 260, 330, 420])), insert_sd=float(rng.choice([20, 40, 60])),
@@ -72,6 +73,8 @@ def random_case(seed):
 
 
 def main():
+    if os.environ.get("LANCET_FUZZ_FAT"):
+        os.environ["LANCET_NO_PREBUILD"] = "1"; emu.FAT[0] = True
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     mg.check_reference_is_unmodified()
