@@ -1741,6 +1741,7 @@ DEVNI void build_gather(Ctx &c) {
       ef6 = (_s == 6 && _v < ef6) ? _v : ef6; ef7 = (_s == 7 && _v < ef7) ? _v : ef7; ef8 = (_s == 8 && _v < ef8) ? _v : ef8; \
       ef9 = (_s == 9 && _v < ef9) ? _v : ef9; } while (0)
     uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, fl = 0;
+    bool onref = false;                                            // a k-mer of the reference pseudo-read (Ref_t's tables ask for its counts)
     const uint32_t lo = W.nocc[n], hi = W.nocc[n + 1];
     const int Rref = S.R - 1, reflen_ = S.reflen;
 #ifndef LANCET_WAVE_EMU
@@ -1752,6 +1753,7 @@ DEVNI void build_gather(Ctx &c) {
       const uint32_t ori = CS_ORI(e), st = CS_ST(e);
       // (read_geom without its volatile LDS reads, so that the loads of the unrolled iterations can be issued together)
       const bool isref = r == Rref;
+      onref = onref || isref;
       const lc_u4 rdv = *(const lc_u4 *)(W.rd + 4 * (size_t)r);                 // rinfo, packed-base offset, quality-mask offset, first occurrence
       const uint32_t rinfo = rdv.x, bw = rdv.y, gw = rdv.z;
       const int tlen = isref ? reflen_ : (int)RI_TLEN(rinfo);
@@ -1803,7 +1805,9 @@ DEVNI void build_gather(Ctx &c) {
     uint16_t *kc = G.kc;                     // counts per strand/sample as the cov_t fields hold them (unsigned short)
     kc[0] = (uint16_t)c0; kc[1] = (uint16_t)c1; kc[2] = (uint16_t)c2; kc[3] = (uint16_t)c3;
     G.cov[0] = (float)c0; G.cov[1] = (float)c1; G.cov[2] = (float)c2; G.cov[3] = (float)c3;
-    if (S.LR) {        // cov_distr holds barcode counts instead of read counts; the float coverages stay read counts
+    if (S.LR && low && !onref) {       // removed by the first removeLowCov and not a reference k-mer: nobody reads its barcode / haplotype counts
+      for (int q = 0; q < 6; ++q) W.khp[6 * (size_t)n + q] = 0;
+    } else if (S.LR) {        // cov_distr holds barcode counts instead of read counts; the float coverages stay read counts
       if (hi - lo >= LR_COOP_MIN && hi - lo <= LR_COOP_MAX && lo < (1u << 24)) {     // by the whole wave, below: listed
         const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.tmp2, 1u);
         W.scratch[2 * (size_t)at] = (uint32_t)n; W.scratch[2 * (size_t)at + 1] = lo | ((hi - lo) << 24);

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /root/repo/$O/kt
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/kt -- python /root/repo/bench.py --steps 20 --cpu-sample 0 --no-configs --in-flight 1 > /root/repo/$O/kt.log 2>&1
 cat /root/repo/$O/kt/*/*kernel_stats.csv | head -14 > /root/repo/$O/kernel_trace_stats.csv; head -8 /root/repo/$O/kernel_trace_stats.csv
-for cfg in "headline|" "60x|--windows 8192 --cov 60" "config4|--windows 4096 --cov 100 --cov-normal 40 --str-fraction 0.3 --lowcomplex-fraction 0.05" "config5|--windows 8192 --linked"; do
+for cfg in "headline|" "60x|--windows 8192 --cov 60" "config4|--windows 4096 --cov 100 --cov-normal 40 --str-fraction 0.3 --lowcomplex-fraction 0.05" "config5|--windows 16384 --linked"; do
   name=${cfg%%|*}; args=${cfg#*|}
   echo "== PMC passes: $name ($args)" | tee -a /root/repo/$O/pmc.txt
   PMC_TIMEOUT=240 BENCH_ARGS="$args" bash /root/repo/tools/pmc_total.sh 2>&1 | tee -a /root/repo/$O/pmc.txt
