@@ -1144,18 +1144,20 @@ DEVNI void lr_replay_batches(Ctx &c, uint32_t n_list) {
   const uint32_t g0 = B.read_begin[S.w], refr = (uint32_t)(S.R - 1);
   LC_GLOBAL cs_t *csr = W_CSR(W);
   LC_GLOBAL const uint32_t *list = W.scratch;                      // (node, csr start | occurrences << 24) of the nodes build_gather left for the wave
-  LC_LDS cs_t *raw = (LC_LDS cs_t *)S.mmeta;                       // [LR_COOP_MAX] the runs as stored ; afterwards out[seg][16] bytes: the ten values
-  LC_LDS uint8_t *outv = (LC_LDS uint8_t *)S.mmeta;
+  LC_LDS cs_t *raw = (LC_LDS cs_t *)S.mmeta;                       // [LR_COOP_MAX] the runs as stored ; afterwards win[seg][6]: what the last counted occurrence
+  LC_LDS uint32_t *win = (LC_LDS uint32_t *)S.mmeta;               //   of a (sample, strand) [0..3] / of a sample [4..5] leaves: (its place + 1) << 24 | value(s), by atomic max
   LC_LDS cs_t *ev = (LC_LDS cs_t *)S.lbytes;                       // [MAX] in visiting order
   LC_LDS uint32_t *key = (LC_LDS uint32_t *)(ev + LR_COOP_MAX);    // [MAX] hasBX key
   LC_LDS uint32_t *cur = key + LR_COOP_MAX;                        // [MAX] counted: the haplotype counts of its sample at its coverage event (3 x 8 bit) | previous counted one << 24
   LC_LDS uint8_t *meta = (LC_LDS uint8_t *)(cur + LR_COOP_MAX);    // [MAX] 1 adds | 2 barcode present | class f << 2 | haplotype << 4 | 64 counted | 128 first of a pair
   LC_LDS uint8_t *segof = meta + LR_COOP_MAX;                      // [MAX] segment of a staged occurrence
-  LC_LDS uint32_t *seg = (LC_LDS uint32_t *)(segof + LR_COOP_MAX); // [SEGS][3] node, csr start, first staged slot | occurrences << 16
+  LC_LDS uint32_t *seg = (LC_LDS uint32_t *)(segof + LR_COOP_MAX); // [SEGS][3] node, csr start, first staged slot | occurrences << 16 | run not in visiting order << 31
   LC_LDS uint32_t *cand_n = (LC_LDS uint32_t *)S.part2;            // the next 64 entries of the list
   LC_LDS uint32_t *cand_lm = (LC_LDS uint32_t *)S.part;
-  static_assert(sizeof(cs_t) * LR_COOP_MAX <= sizeof(uint32_t) * LC_QSTAGE && 16u * LR_COOP_SEGS <= sizeof(uint32_t) * LC_QSTAGE &&
+  static_assert(sizeof(cs_t) * LR_COOP_MAX <= sizeof(uint32_t) * LC_QSTAGE && 24u * LR_COOP_SEGS <= sizeof(uint32_t) * LC_QSTAGE &&
                 (sizeof(cs_t) + 8u + 2u) * LR_COOP_MAX + 12u * LR_COOP_SEGS <= 16u * LC_QSTAGE, "LDS arrays of the replay");
+#define LR_SEG_B0(sg) (seg[3 * (sg) + 2] & 0xFFFFu)
+#define LR_SEG_M(sg) ((seg[3 * (sg) + 2] >> 16) & 0x7FFFu)
   uint32_t li = 0, lbase = 0, lend = 0;                            // next entry ; the entries in LDS are [lbase, lend)
   while (li < n_list) {
     if (li >= lend || (lend < n_list && li + 16u > lend)) {        // refill (also when fewer than 16 are left: a batch rarely takes more)
@@ -1174,12 +1176,21 @@ DEVNI void lr_replay_batches(Ctx &c, uint32_t n_list) {
       S.tmp1 = (int)tot; S.tmp2 = (int)(lbase + t - li); S.tmp3 = (int)ns;
     }
     const uint32_t tot = (uint32_t)wg_bcast(&S.tmp1), adv = (uint32_t)wg_bcast(&S.tmp2), ns = (uint32_t)wg_bcast(&S.tmp3);
-    WG_FOR(t, ns) { const uint32_t b0 = seg[3 * t + 2] & 0xFFFFu, mm = seg[3 * t + 2] >> 16; for (uint32_t q = 0; q < mm; ++q) segof[b0 + q] = (uint8_t)t; }
+    WG_FOR(t, ns) { const uint32_t b0 = LR_SEG_B0(t), mm = LR_SEG_M(t); for (uint32_t q = 0; q < mm; ++q) segof[b0 + q] = (uint8_t)t; }
     WG_SYNC_LDS();
-    WG_FOR(j, tot) { const uint32_t sg = segof[j]; raw[j] = csr[seg[3 * sg + 1] + ((uint32_t)j - (seg[3 * sg + 2] & 0xFFFFu))]; }
+    WG_FOR(j, tot) {                                               // the runs as stored; a run that is not in visiting order yet is marked (arrival order: nearly always sorted)
+      const uint32_t sg = segof[j], b0 = LR_SEG_B0(sg);
+      LC_GLOBAL const cs_t *src = csr + seg[3 * sg + 1] + ((uint32_t)j - b0);
+      cs_t v = src[0];
+      if ((uint32_t)j > b0) { const cs_t vp = src[-1]; if (CS_KEY(vp) > CS_KEY(v)) dev_atomic_or(&seg[3 * sg + 2], 0x80000000u); }
+      if (LC_CTX(c).C->debug_stop == 141u) {                       // (test knob: every run arrives backwards -- the emulated lanes fill them in visiting order)
+        v = csr[seg[3 * sg + 1] + (LR_SEG_M(sg) - 1u - ((uint32_t)j - b0))]; dev_atomic_or(&seg[3 * sg + 2], 0x80000000u);
+      }
+      raw[j] = v;
+    }
     WG_SYNC_LDS();
     WG_FOR(j, tot) {
-      const uint32_t sg = segof[j], b0 = seg[3 * sg + 2] & 0xFFFFu, e0 = b0 + (seg[3 * sg + 2] >> 16);
+      const uint32_t sg = segof[j], b0 = LR_SEG_B0(sg), e0 = b0 + LR_SEG_M(sg);
       const cs_t v = raw[j]; const cs_key_t kv = CS_KEY(v);
       const uint32_t r = CS_READ(v);                               // (the three loads are in flight during the loop below)
       uint32_t k = 0xFFFFFFFEu, mt = 0;
@@ -1189,17 +1200,20 @@ DEVNI void lr_replay_batches(Ctx &c, uint32_t n_list) {
         k = bx == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((bx << 1) | sm);
         mt = (bx != 0xFFFFFFFFu ? 2u : 0u) | ((2u * sm + d) << 2) | (h << 4) | (CS_ST(v) == 0 ? 64u : 0u);
       }
-      uint32_t rank = 0;
+      uint32_t rank = (uint32_t)j - b0;
+      if (seg[3 * sg + 2] >> 31) {
+        rank = 0;
 #ifndef LANCET_WAVE_EMU
 #pragma unroll 4
 #endif
-      for (uint32_t i = b0; i < e0; ++i) rank += CS_KEY(raw[i]) < kv ? 1u : 0u;
+        for (uint32_t i = b0; i < e0; ++i) rank += CS_KEY(raw[i]) < kv ? 1u : 0u;
+      }
       ev[b0 + rank] = v; key[b0 + rank] = k; meta[b0 + rank] = (uint8_t)mt;
     }
     WG_SYNC_LDS();
-    WG_FOR(t, LR_COOP_SEGS * 4u) { ((LC_LDS uint32_t *)outv)[t] = 0; }          // (raw[] is done with)
+    WG_FOR(t, LR_COOP_SEGS * 6u) { win[t] = 0; }                   // (raw[] is done with)
     WG_FOR(j, tot) {
-      const uint32_t b0 = seg[3 * (uint32_t)segof[j] + 2] & 0xFFFFu, e0 = b0 + (seg[3 * (uint32_t)segof[j] + 2] >> 16);
+      const uint32_t sg = segof[j], b0 = LR_SEG_B0(sg), e0 = b0 + LR_SEG_M(sg);
       const uint32_t k = key[j];
       uint32_t same = 0;
 #ifndef LANCET_WAVE_EMU
@@ -1215,31 +1229,29 @@ DEVNI void lr_replay_batches(Ctx &c, uint32_t n_list) {
     WG_FOR(j, tot) {
       const uint32_t mt = meta[j];
       if (mt & 64u) {
-        const uint32_t sg = segof[j], b0 = seg[3 * sg + 2] & 0xFFFFu, e0 = b0 + (seg[3 * sg + 2] >> 16);
+        const uint32_t sg = segof[j], b0 = LR_SEG_B0(sg);
         const uint32_t f = (mt >> 2) & 3u, sm = f >> 1, E = (uint32_t)j + ((mt & 128u) ? 1u : 0u);
-        uint32_t bxc = 0, hpc = 0;                                 // barcode counts per (sample, strand), 4 x 8 bit ; haplotype counts of THIS sample, 3 x 8 bit
-        uint32_t later_f = 0, later_s = 0, prev = 0xFFFFFFFFu;
+        // what is added up to E: barcodes of THIS (sample, strand), haplotypes of THIS sample (3 x 8 bit) ; the counted occurrence of the sample before this one
+        uint32_t bxc = 0, hpc = 0, prev = 0xFFu;
+        const uint32_t want_b = 3u | (f << 2), want_s = 1u | (sm << 3), cnt_s = 64u | (sm << 3);
 #ifndef LANCET_WAVE_EMU
 #pragma unroll 4
 #endif
-        for (uint32_t i = b0; i < e0; ++i) {
+        for (uint32_t i = b0; i <= E; ++i) {
           const uint32_t x = meta[i];
-          const bool cnt_s = (x & 64u) && ((x >> 3) & 1u) == sm;   // a counted occurrence of this sample
-          if (i <= E && (x & 1u)) {
-            if (x & 2u) bxc += 1u << (8u * ((x >> 2) & 3u));
-            if (((x >> 3) & 1u) == sm) hpc += 1u << (8u * ((x >> 4) & 3u));
-          }
-          if (cnt_s && i < (uint32_t)j) prev = i;
-          if (cnt_s && i > (uint32_t)j) { later_s = 1; if (((x >> 2) & 3u) == f) later_f = 1; }
+          bxc += (x & 15u) == want_b ? 1u : 0u;
+          hpc += (x & 9u) == want_s ? (1u << (8u * ((x >> 4) & 3u))) : 0u;
+          prev = ((x & 72u) == cnt_s && i < (uint32_t)j) ? i - b0 : prev;
         }
-        cur[j] = hpc | (prev == 0xFFFFFFFFu ? 0xFF000000u : ((prev - b0) << 24));
-        if (!later_f) outv[16 * sg + f] = (uint8_t)((bxc >> (8u * f)) & 0xFFu);
-        if (!later_s) for (uint32_t q = 0; q < 3; ++q) outv[16 * sg + 4 + 3 * sm + q] = (uint8_t)((hpc >> (8u * q)) & 0xFFu);
+        cur[j] = hpc | (prev << 24);
+        const uint32_t place = ((uint32_t)j - b0 + 1u) << 24;      // the last one wins
+        dev_atomic_max(&win[6 * sg + f], place | bxc);
+        dev_atomic_max(&win[6 * sg + 4 + sm], place | hpc);
       }
     }
     WG_SYNC_LDS();
     WG_FOR(j, tot) {
-      const uint32_t mt = meta[j], sg = segof[j], b0 = seg[3 * sg + 2] & 0xFFFFu;
+      const uint32_t mt = meta[j], sg = segof[j], b0 = LR_SEG_B0(sg);
       cs_t e = ev[j];
       if (mt & 64u) {
         const uint32_t now = cur[j], pv = now >> 24;
@@ -1254,13 +1266,15 @@ DEVNI void lr_replay_batches(Ctx &c, uint32_t n_list) {
       const uint32_t n = seg[3 * t];
       LC_GLOBAL NodeGr &G = W.gr[n];
       uint32_t sum = 0;
-      for (int q = 0; q < 4; ++q) { const uint32_t v = outv[16 * t + q]; G.kc[q] = (uint16_t)v; sum += v; }
-      for (int q = 0; q < 6; ++q) W.khp[6 * (size_t)n + q] = (uint16_t)outv[16 * t + 4 + q];
+      for (int q = 0; q < 4; ++q) { const uint32_t v = win[6 * t + q] & 0xFFu; G.kc[q] = (uint16_t)v; sum += v; }
+      for (int sm = 0; sm < 2; ++sm) for (int q = 0; q < 3; ++q) W.khp[6 * (size_t)n + 3 * sm + q] = (uint16_t)((win[6 * t + 4 + sm] >> (8 * q)) & 0xFFu);
       G.mincov = (int)sum;
     }
     WG_SYNC_LDS();
     li += adv;
   }
+#undef LR_SEG_B0
+#undef LR_SEG_M
   WG_SYNC();
 }
 
@@ -1824,7 +1838,6 @@ DEVNI void build_gather(Ctx &c) {
   }
   WG_LANE0 { W.order[S.N] = 0; }
   WG_SYNC();
-  SUBPHASE(c, 5, 12);
   if (S.LR) lr_replay_batches(c, (uint32_t)wg_bcast(&S.tmp2));     // (the nodes listed above)
   SUBPHASE(c, 5, 13);
   wg_scan(W.order, (int)S.N + 1, S);

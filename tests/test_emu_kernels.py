@@ -443,6 +443,20 @@ def test_fat_source_on_coverage_pile_ups(fat_emu):
         assert v == ov and [_KEY(s) for s in st] == [_KEY(s) for s in ost]
 
 
+def test_linked_read_replay_by_the_wave_sorts_runs_that_arrive_out_of_order(monkeypatch):
+    """lr_replay_batches takes a node's csr run as the csr pass left it -- in ARRIVAL order of the lanes' atomics, which on the device is
+    not always the visiting order; the emulated lanes run one after the other and always deliver sorted runs.  With LANCET_STOP_PHASE=141
+    every staged run is read backwards and must come out sorted by rank: same records, same trace."""
+    meta, batch, kept, _ = gu.case_batch("lr30")
+    p = gu.params(meta)
+    monkeypatch.setenv("LANCET_NO_PREBUILD", "1")
+    base = emu.run(batch, p, evt_cap=1 << 17)
+    monkeypatch.setenv("LANCET_STOP_PHASE", "141")
+    back = emu.run(batch, p, evt_cap=1 << 17)
+    assert back[0] == base[0] and [_KEY(s) for s in back[1]] == [_KEY(s) for s in base[1]] and gu.digest_trace(back[2]) == gu.digest_trace(base[2])
+    assert gu.digest_trace(base[2]) == gu.golden_trace("lr30") and len(base[0]) > 0
+
+
 @pytest.mark.parametrize("linked", [False, True])
 def test_fat_source_on_a_window_of_more_than_65535_reads(linked, fat_emu):
     """~95 000 reads of 50 bases in one window (3100x / 3100x; the reference goes up to MAX_AVG_COV = 10 000x per sample): the re-run
