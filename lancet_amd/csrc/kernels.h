@@ -1135,10 +1135,10 @@ DEVNI void lr_node_replay(Ctx &c, uint32_t lo, uint32_t hi, uint32_t *out) {
 //      8 bits here); the last counted occurrence of a (sample, strand) / of a sample leaves the node's values,
 //   5. "grown" bits against the previous counted occurrence of the same sample.
 // Same results as lr_node_replay: the ten values, the csr run sorted, grown bits in csr bits 29..31.
-#define LR_COOP_MIN 6u
+#define LR_COOP_MIN 3u
 #define LR_COOP_MAX 192u
 #define LR_COOP_SEGS 32u
-static_assert(LR_COOP_MAX <= LC_QSTAGE && LR_COOP_MAX < 256u && LR_COOP_SEGS * LR_COOP_MIN >= LR_COOP_MAX, "staging area ; 8-bit counts ; segments of a full batch");
+static_assert(LR_COOP_MAX <= LC_QSTAGE && LR_COOP_MAX < 256u, "staging area ; 8-bit counts");
 DEVNI void lr_replay_batches(Ctx &c, uint32_t n_list) {
   LC_GLOBAL Work &W = *LC_CTX(c).W; LC_GLOBAL const DevBatch &B = *LC_CTX(c).B; LC_WS &S = LC_SREF(c);
   const uint32_t g0 = B.read_begin[S.w], refr = (uint32_t)(S.R - 1);
@@ -1838,6 +1838,7 @@ DEVNI void build_gather(Ctx &c) {
   }
   WG_LANE0 { W.order[S.N] = 0; }
   WG_SYNC();
+  SUBPHASE(c, 5, 12);
   if (S.LR) lr_replay_batches(c, (uint32_t)wg_bcast(&S.tmp2));     // (the nodes listed above)
   SUBPHASE(c, 5, 13);
   wg_scan(W.order, (int)S.N + 1, S);
