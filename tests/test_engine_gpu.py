@@ -1,6 +1,8 @@
 """Parity tests proper: the HIP engine, called through the C-ABI, against (a) the oracle on the same inputs,
 (b) the committed reference goldens (VCF + `-v` stage trace).  Bit-exact: everything is integer/index work
 except four float coverages per node, which must round exactly like the reference (no tolerance)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -18,8 +20,13 @@ def _names(batch):
     return [id2chr[i] for i in range(len(id2chr))]
 
 
+# tools/fat_check.sh runs this suite with a 64-entry tier-1 node table (LANCET_NODE_CAP1=64: practically every window is assembled by the
+# several-wave kernel of the re-run tier): the records are compared as always, the counts of what tier 1 itself served are not
+TIER1 = "LANCET_NODE_CAP1" not in os.environ
+
 # every reference-made golden, including `bushy` (--low-cov 0: one path search of 600 k partial paths, 12 s for its 17 windows on
 # an MI355X, all through the worst-case tier) and `evenk` (--min-k 12: k-mers that are their own reverse complement)
+
 GPU_CASES = list(gu.CASES)
 
 
@@ -102,7 +109,7 @@ def test_deep_str_windows_build_in_lds_at_k_above_31():
     for _ in range(2):
         variants, stats = eng.process(batch)
         assert variants == ov and [key(s) for s in stats] == [key(s) for s in ostats]
-        assert eng.prebuilt_count() >= (9 * builds) // 10 and eng.rerun_count() == 0, (eng.prebuilt_count(), builds, eng.rerun_count())
+        assert not TIER1 or (eng.prebuilt_count() >= (9 * builds) // 10 and eng.rerun_count() == 0), (eng.prebuilt_count(), builds, eng.rerun_count())
     eng.close()
 
 
@@ -118,7 +125,7 @@ def test_very_deep_windows_use_17_bit_offsets_in_lds():
     for _ in range(2):
         variants, stats = eng.process(batch)
         assert variants == ov and [key(s) for s in stats] == [key(s) for s in ostats]
-        assert eng.prebuilt_count() == 96 and eng.rerun_count() == 0      # (windows 80-83: a mate-overlap replay of 14 k occurrences, in two ranges of nodes)
+        assert not TIER1 or (eng.prebuilt_count() == 96 and eng.rerun_count() == 0)      # (windows 80-83: a mate-overlap replay of 14 k occurrences, in two ranges of nodes)
     eng.close()
 
 
@@ -306,7 +313,7 @@ def test_a_few_deep_windows_among_ordinary_ones():
     for _ in range(2):
         v, st = eng.process(both)
         assert v == ov and [key(s) for s in st] == [key(s) for s in ost]
-        assert eng.prebuilt_count() + eng.rerun_count() == 67
+        assert not TIER1 or eng.prebuilt_count() + eng.rerun_count() == 67
     eng.close()
 
 
@@ -328,7 +335,7 @@ def test_pile_up_started_early_does_not_read_the_previous_batch_hand_off():
         v, st = eng.process(first)
         assert v == o1 and [s["final_k"] for s in st] == [s["final_k"] for s in s1], rnd
         v, st = eng.process(second)
-        assert eng.rerun_count() == 2 and all(s["status"] >= 0 for s in st)
+        assert (not TIER1 or eng.rerun_count() == 2) and all(s["status"] >= 0 for s in st)
         assert v == o2 and [(s["final_k"], s["n_builds"]) for s in st] == [(s["final_k"], s["n_builds"]) for s in s2], rnd
     eng.close()
 
@@ -354,9 +361,10 @@ def test_build_service_is_scheduling_only(monkeypatch):
         eng.close()
         for k_ in env:
             monkeypatch.delenv(k_)
-    assert served[0][0] >= 1 and served[0][1] + served[0][3] == served[0][0] and served[3] == (0, 0, 0, 0), served
-    extra = sum(s["n_builds"] - 1 for s in ost)
-    assert served[2][0] == extra, (served, extra)
+    if TIER1:
+        assert served[0][0] >= 1 and served[0][1] + served[0][3] == served[0][0] and served[3] == (0, 0, 0, 0), served
+        extra = sum(s["n_builds"] - 1 for s in ost)
+        assert served[2][0] == extra, (served, extra)
 
 
 def test_host_and_device_trim_and_pack_agree(monkeypatch):
@@ -441,7 +449,7 @@ def test_windows_of_more_than_65535_reads():
     for _ in range(2):
         v, st = eng.process(both)
         assert v == ov and [_KEY(s) for s in st] == [_KEY(s) for s in ost]
-        assert eng.rerun_count() == 2
+        assert not TIER1 or eng.rerun_count() == 2
     eng.close()
 
 
