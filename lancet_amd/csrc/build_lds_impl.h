@@ -102,7 +102,7 @@ DEV unsigned long long dev_atomic_or64(unsigned long long *p, unsigned long long
 #define bl_bcast(p) wg_bcastu(p)
 
 // exclusive prefix sum of an LDS array in place, whole workgroup; the total lands in S.scan_total
-DEV void bl_scan32(LC_LDS uint32_t *a, int n, BL_S &S) {
+template <class T> DEV void bl_scan_t(LC_LDS T *a, int n, BL_S &S) {
   WG_SYNC();
 #ifndef LANCET_WAVE_EMU
   const int t = (int)threadIdx.x, chunk = (n + BL_WG - 1) / BL_WG;
@@ -116,15 +116,31 @@ DEV void bl_scan32(LC_LDS uint32_t *a, int n, BL_S &S) {
   uint32_t woff = 0;
   for (int i = 0; i < (t >> 6); ++i) woff += S.wsum[i];
   uint32_t run = woff + inc - s;
-  for (int i = lo; i < hi; ++i) { const uint32_t x = a[i]; a[i] = run; run += x; }
+  for (int i = lo; i < hi; ++i) { const uint32_t x = a[i]; a[i] = (T)run; run += x; }
   if (t == BL_WG - 1) S.scan_total = run;
   __syncthreads();
 #else
   uint32_t run = 0;
-  for (int i = 0; i < n; ++i) { const uint32_t x = a[i]; a[i] = run; run += x; }
+  for (int i = 0; i < n; ++i) { const uint32_t x = a[i]; a[i] = (T)run; run += x; }
   S.scan_total = run;
   lc_emu_syncs += 2;
 #endif
+}
+DEV void bl_scan32(LC_LDS uint32_t *a, int n, BL_S &S) { bl_scan_t<uint32_t>(a, n, S); }
+// 16-bit halves of LDS words under 32-bit atomics (the table order of large tables: twice the elements in the same LDS)
+DEV void bl_min16(LC_LDS uint16_t *a, uint32_t i, uint32_t v) {
+  LC_LDS uint32_t *w = (LC_LDS uint32_t *)a + (i >> 1); const uint32_t sh = (i & 1u) * 16u;
+  uint32_t old = *(volatile LC_LDS uint32_t *)w;
+  while (((old >> sh) & 0xFFFFu) > v) {
+    const uint32_t want = (old & ~(0xFFFFu << sh)) | (v << sh);
+    const uint32_t got = dev_atomic_cas32(w, old, want);
+    if (got == old) break;
+    old = got;
+  }
+}
+DEV uint32_t bl_add16(LC_LDS uint16_t *a, uint32_t i, uint32_t inc) {        // returns the half before the addition (no carry: the callers' sums stay below 65 536)
+  LC_LDS uint32_t *w = (LC_LDS uint32_t *)a + (i >> 1); const uint32_t sh = (i & 1u) * 16u;
+  return (dev_atomic_add(w, inc << sh) >> sh) & 0xFFFFu;
 }
 
 // the k-mer that starts at LDS offset `boff`: base j at bits 2j (k <= 31)
@@ -1546,9 +1562,11 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   BLP(S, 15);
   // ---- libstdc++ iteration order of the node table after the N inserts (kernels.h first_lowcov / order_stage),
   //      reduced to the survivors (cleanDead), and markConnectedComponents over them -- all in LDS: the reads are done with, the
-  //      whole arena from S.bases to the end of S.big is laid out anew.  Tables of more than 4096 nodes leave this to the window kernel.
+  //      whole arena from S.bases to the end of S.big is laid out anew.  Tables of more than 4096 nodes: the 1024-lane configuration, whose
+  //      arena holds the arrays for its BL_NCAP nodes once the bucket minima and the run counters are 16-bit halves (below); else the window kernel.
   WG_LANE0 { H->have_order = 0; }
-  if (N <= 4096u && nsurv > 0) {
+  const bool wide_tab = BL_WIDE != 0 && N > 4096u;
+  if ((N <= 4096u || (wide_tab && N <= BL_NCAP)) && nsurv > 0) {
     LC_LDS uint8_t *arena = (LC_LDS uint8_t *)&S.bases[0];
     LC_LDS uint32_t *first = (LC_LDS uint32_t *)arena;                       // [5120] smallest position of a bucket's elements
     LC_LDS uint32_t *tmp = first + 5120;                                     // [4104] run sizes -> run starts -> fill cursors
@@ -1557,6 +1575,23 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     LC_LDS uint32_t *nx = (LC_LDS uint32_t *)(nh + 32), *bk = nx + 32;           // [32] list links, [64] buckets of the sequential prefix
     LC_LDS uint16_t *pos2si = (LC_LDS uint16_t *)(bk + 64);                      // [PB_SCAP] survivor index of the node at a position
     static_assert(5120 * 4 + 4104 * 4 + 4 * 4096 * 2 + 32 * 8 + 32 * 4 + 64 * 4 + PB_SCAP * 2 <= offsetof(BlShared, big) + BL_BIG, "order arena");
+    // what the steps after the stages use, wherever the layout puts it: the scan array (N + 1 words; then the components' parent / touch words),
+    // node -> position among the survivors, the neighbour lists, the component numbers
+    LC_LDS uint32_t *tmpP = tmp, *numP = first; LC_LDS uint16_t *nposP = (LC_LDS uint16_t *)first, *adjP = Qa;
+#if BL_WIDE
+    LC_LDS uint16_t *first16 = (LC_LDS uint16_t *)arena, *tmp16 = first16 + 20768, *bktw = nullptr;       // [20 753 + 1] bucket minima ; [BL_NCAP + 2] run counters
+    static_assert(BL_NCAP <= 14336 && BL_NCAP < 16384, "positions / run sizes in 16 bits, bucket counts up to 20 753");
+    if (wide_tab) {
+      Qa = tmp16 + 14352; Qb = Qa + 14336; bktw = Qb + 14336;
+      nh = (LC_LDS unsigned long long *)(bktw + 14336); nx = (LC_LDS uint32_t *)(nh + 32); bk = nx + 32; pos2si = (LC_LDS uint16_t *)(bk + 64);
+      tmpP = (LC_LDS uint32_t *)arena;                                       // [14 337] over first16 / tmp16 (57 348 of their 70 240 bytes) ...
+      numP = tmpP + 14352;                                                   // ... [PB_SCAP + 1] behind it
+      nposP = bktw;                                                          // [N] (the buckets are done with)
+      adjP = (LC_LDS uint16_t *)(tmpP + 4104);                               // [8 * PB_SCAP] behind parent / touch, inside the scan array (read out by then)
+    }
+    static_assert(2 * (20768 + 14352 + 3 * 14336) + 32 * 8 + 32 * 4 + 64 * 4 + PB_SCAP * 2 <= offsetof(BlShared, big) + BL_BIG && 4 * (14352 + PB_SCAP + 1) <= 2 * (20768 + 14352) &&
+                  4 * 4104 + 2 * 8 * PB_SCAP <= 4 * 14337, "order arena of the large tables");
+#endif
     LC_GLOBAL const unsigned long long *nhash = (LC_GLOBAL const unsigned long long *)(area + PRE_OFF_NHASH);
     const uint32_t SEQ = 13u;
     const uint32_t n0 = N < SEQ ? N : SEQ;
@@ -1595,7 +1630,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     }
     LC_LDS uint16_t *Q = Qa, *Qn = Qb;
     uint32_t nprev = SEQ, B = SEQ;
-    if (N > SEQ) while (true) {
+    if (N > SEQ && !wide_tab) while (true) {
       B = ht_next_prime(2u * B);
       const uint32_t n = N < B ? N : B;
       WG_FOR(j, n - nprev) { Q[nprev + (uint32_t)j] = (uint16_t)(nprev + (uint32_t)j); }
@@ -1621,23 +1656,53 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       if (N <= B) break;
       nprev = B;
     }
+#if BL_WIDE
+    // the same stages for a table of up to BL_NCAP nodes (bucket counts up to 20 753): first / run counters as 16-bit halves of LDS words
+    // (positions and run sizes stay below 16 384), the sorted positions written straight into the other order array and converted in place
+    if (N > SEQ && wide_tab) while (true) {
+      B = ht_next_prime(2u * B);
+      const uint32_t n = N < B ? N : B;
+      WG_FOR(j, n - nprev) { Q[nprev + (uint32_t)j] = (uint16_t)(nprev + (uint32_t)j); }
+      WG_FOR(b, (B + 2u) / 2u) { ((LC_LDS uint32_t *)first16)[b] = 0xFFFFFFFFu; }
+      WG_FOR(i, (n + 3u) / 2u) { ((LC_LDS uint32_t *)tmp16)[i] = 0; }
+      WG_SYNC();
+      WG_FOR(i, n) { const uint32_t b = ht_mod(nhash[Q[i]], B); bktw[i] = (uint16_t)b; bl_min16(first16, b, (uint32_t)i); }
+      WG_SYNC();
+      WG_FOR(i, n) { (void)bl_add16(tmp16, n - 1u - (uint32_t)first16[bktw[i]], 1u); }     // elements per run, runs indexed by their first position, latest first
+      bl_scan_t<uint16_t>(tmp16, (int)n, S);
+      WG_FOR(i, n) { const uint32_t at = bl_add16(tmp16, n - 1u - (uint32_t)first16[bktw[i]], 1u); Qn[at] = (uint16_t)i; }
+      WG_SYNC();
+      WG_FOR(x, n) {                                                          // inside a run: latest first
+        if (x > 0 && bktw[Qn[x - 1]] == bktw[Qn[x]]) continue;
+        const uint32_t b = bktw[Qn[x]];
+        uint32_t e = (uint32_t)x + 1; while (e < n && bktw[Qn[e]] == b) ++e;
+        for (uint32_t i = (uint32_t)x + 1; i < e; ++i) { const uint16_t v = Qn[i]; uint32_t j = i; while (j > (uint32_t)x && Qn[j - 1] < v) { Qn[j] = Qn[j - 1]; --j; } Qn[j] = v; }
+      }
+      WG_SYNC();
+      WG_FOR(j, n) { Qn[j] = Q[Qn[j]]; }                                     // (positions -> nodes: every lane its own entries)
+      WG_SYNC();
+      { LC_LDS uint16_t *t = Q; Q = Qn; Qn = t; }
+      if (N <= B) break;
+      nprev = B;
+    }
+#endif
     if (N > SEQ) { WG_LANE0 { S.g0 = B; S.g1 = B; } }
     // ---- cleanDead: the survivors in that order; position of every survivor
     LC_GLOBAL const uint8_t *surv = (LC_GLOBAL const uint8_t *)(area + PRE_OFF_SURV);
     LC_GLOBAL uint32_t *order_s = (LC_GLOBAL uint32_t *)(area + PRE_OFF_ORDER);
     LC_GLOBAL const uint32_t *sidv = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_SID);
-    WG_FOR(j, N + 1) { tmp[j] = (j < (int)N && surv[Q[j]]) ? 1u : 0u; }
-    bl_scan32(tmp, (int)N + 1, S);
-    WG_FOR(j, N) { if (tmp[j + 1] != tmp[j]) { order_s[tmp[j]] = Q[j]; first[Q[j]] = tmp[j]; } }    // first[]: node -> position among the survivors (N <= 4096 < 5120)
+    WG_FOR(j, N + 1) { tmpP[j] = (j < (int)N && surv[Q[j]]) ? 1u : 0u; }
+    bl_scan32(tmpP, (int)N + 1, S);
+    WG_FOR(j, N) { if (tmpP[j + 1] != tmpP[j]) { order_s[tmpP[j]] = Q[j]; nposP[Q[j]] = (uint16_t)tmpP[j]; } }    // nposP[]: node -> position among the survivors
     WG_SYNC();
     // ---- markConnectedComponents (Graph.cc:2252-2336): min-label hooking + pointer jumping over the survivors' positions; the label of a
     //      component is the position of its first node in table order, which is also what numbers the components
-    LC_LDS uint32_t *parent = tmp;                                           // [nsurv]
-    LC_LDS uint32_t *touch = tmp + 2052;                                     // [nsurv] bit 0: component holds a reference k-mer ; later: component number
-    LC_LDS uint16_t *adj = Qa;                                               // [nsurv * 8] neighbours as positions (Qa .. out: 32 KB)
+    LC_LDS uint32_t *parent = tmpP;                                          // [nsurv]
+    LC_LDS uint32_t *touch = tmpP + 2052;                                    // [nsurv] bit 0: component holds a reference k-mer ; later: component number
+    LC_LDS uint16_t *adj = adjP;                                             // [nsurv * 8] neighbours as positions (small tables: Qa .. out, 32 KB)
     WG_FOR(si, nsurv) {
-      const uint32_t ppos = first[sidv[si]];
-      for (int e = 0; e < 8; ++e) { const uint32_t t = X.s_edges[9 * (size_t)si + (uint32_t)e]; adj[8 * ppos + (uint32_t)e] = t == 0xFFFFu ? (uint16_t)ppos : (uint16_t)first[sidv[t]]; }
+      const uint32_t ppos = nposP[sidv[si]];
+      for (int e = 0; e < 8; ++e) { const uint32_t t = X.s_edges[9 * (size_t)si + (uint32_t)e]; adj[8 * ppos + (uint32_t)e] = t == 0xFFFFu ? (uint16_t)ppos : nposP[sidv[t]]; }
       parent[ppos] = ppos; touch[ppos] = X.s_edges[9 * (size_t)si + 8]; pos2si[ppos] = (uint16_t)si;
     }
     WG_SYNC();
@@ -1666,7 +1731,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     }
     WG_FOR(u, nsurv) { if (touch[u] & 1u) dev_atomic_or(&touch[parent[u]], 2u); }
     WG_SYNC();
-    LC_LDS uint32_t *num = first;                                            // (positions are no longer looked up by node)
+    LC_LDS uint32_t *num = numP;                                             // (small tables: over nposP -- positions are no longer looked up by node)
     WG_FOR(u, nsurv + 1) { num[u] = (u < (int)nsurv && parent[u] == (uint32_t)u) ? 1u : 0u; }
     bl_scan32(num, (int)nsurv + 1, S);
     WG_LANE0 { S.nbw = S.scan_total; S.ngw = 0; }                            // (nbw / ngw are free by now: components, components on the reference)
@@ -1679,7 +1744,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     // ---- the window's first graph with a single component: markRefEnds and the first compress here too (bl_compress_first)
     {
       const uint32_t hbc = bl_bcast(&S.g0), hnr = bl_bcast(&S.g1), ncomp = bl_bcast(&S.nbw);
-      if (!rep && ncomp == 1u && nsurv <= PB_CMAX && nsurv + 2u <= hnr && K <= 31 && C->debug_stop != 140u)
+      if (!rep && ncomp == 1u && nsurv <= PB_CMAX && nsurv + 2u <= hnr && K <= 31 && !wide_tab && C->debug_stop != 140u)
         bl_compress_first(P, C, S, X, area, K, N, nsurv, ncand, reflen, hbc);
     }
   }
