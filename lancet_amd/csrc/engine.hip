@@ -1104,13 +1104,13 @@ int lancet_engine_build_phase_times(lancet_engine *e, const unsigned long long *
 // windows of the last run whose first graph came from the LDS build kernel
 int lancet_engine_prebuilt_count(lancet_engine *e) { return e ? e->n_prebuilt : -1; }
 
-// test/tuning hook: the hand-off headers of the last run (status, K, heavy, N, nsurv, numcomp, ncand, next per window)
+// test/tuning hook: the hand-off headers of the last run (status | why << 8 | table order and components came along << 16, K, heavy, N, nsurv, numcomp, ncand, next per window)
 int lancet_debug_pre_headers(lancet_engine *e, uint32_t *out) {
   if (!e || !e->uploaded || !e->d_pre.p) return LANCET_E_STATE;
   std::vector<PreHdr> h(1);
   for (int w = 0; w < e->n_windows; ++w) {
     if (hipMemcpy(h.data(), (const uint8_t *)e->d_pre.p + (size_t)w * e->caps.pl.stride + PRE_OFF_HDR, sizeof(PreHdr), hipMemcpyDeviceToHost) != hipSuccess) return LANCET_E_STATE;
-    out[8 * w] = h[0].status | (h[0].why << 8); out[8 * w + 1] = h[0].K; out[8 * w + 2] = h[0].heavy; out[8 * w + 3] = h[0].N;
+    out[8 * w] = h[0].status | (h[0].why << 8) | (h[0].have_order == 1u ? 1u << 16 : 0u); out[8 * w + 1] = h[0].K; out[8 * w + 2] = h[0].heavy; out[8 * w + 3] = h[0].N;
     out[8 * w + 4] = h[0].nsurv; out[8 * w + 5] = h[0].numcomp; out[8 * w + 6] = h[0].ncand; out[8 * w + 7] = h[0].next;
   }
   return LANCET_OK;

@@ -195,6 +195,17 @@ class Engine:
     def prebuilt_count(self) -> int:
         return int(self.L.lancet_engine_prebuilt_count(self.h))
 
+    def pre_headers(self):
+        """test hook: per window of the last run (built in LDS, K, nodes, table order + components came along) from the hand-off headers"""
+        import numpy as np
+        nw = self._batch.n_windows
+        out = np.zeros(8 * max(1, nw), dtype=np.uint32)
+        self.L.lancet_debug_pre_headers.argtypes = [C.c_void_p, C.c_void_p]
+        if self.L.lancet_debug_pre_headers(self.h, out.ctypes.data) != 0:
+            return []
+        o = out.reshape(-1, 8)[:nw]
+        return [dict(built=int(r[0] & 0xFF) == 1, K=int(r[1]), nodes=int(r[3]), order=bool(r[0] >> 16 & 1)) for r in o]
+
     def ahead_counts(self):
         """(graphs the build kernel built ahead at a later k, how many the window kernel took)"""
         b, u = C.c_int32(), C.c_int32()

@@ -97,7 +97,8 @@ def test_deep_windows_through_the_1024_lane_build_configuration():
 
 def test_deep_str_windows_build_in_lds_at_k_above_31():
     """BASELINE config 4 on the device: 100x / 40x windows over STR-rich sequence build at k = 33..101 with 8-12 k distinct k-mers -- in
-    LDS, by the 1024-lane configuration (multi-word k-mers, 16 384-slot table, wide hand-off areas); equal to the oracle, twice."""
+    LDS, by the 1024-lane configuration (multi-word k-mers, 16 384-slot table, wide hand-off areas), the libstdc++ table order of those
+    tables (bucket counts 10 273 and 20 753) included; equal to the oracle, twice."""
     from lancet_amd import workload
     batch = workload.make_scan_batch(192, 100.0, 40.0, seed=22, str_fraction=0.30, lowcomplex_fraction=0.05)
     p = abi.default_params()
@@ -110,6 +111,9 @@ def test_deep_str_windows_build_in_lds_at_k_above_31():
         variants, stats = eng.process(batch)
         assert variants == ov and [key(s) for s in stats] == [key(s) for s in ostats]
         assert not TIER1 or (eng.prebuilt_count() >= (9 * builds) // 10 and eng.rerun_count() == 0), (eng.prebuilt_count(), builds, eng.rerun_count())
+        if TIER1:     # the table order, cleanDead and the components of these 8-12 k-node tables came from the build kernel too (16-bit bucket minima)
+            hd = [h for h in eng.pre_headers() if h["built"]]
+            assert len(hd) >= (9 * builds) // 10 and all(h["order"] for h in hd) and max(h["nodes"] for h in hd) > 10273 and min(h["nodes"] for h in hd) > 4096
     eng.close()
 
 
