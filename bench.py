@@ -124,9 +124,12 @@ def kernel_rooflines(alg_build: int, alg_window: int, per_kernel: dict) -> dict:
     return out
 
 
-def side_config(eng_cls, params, name, windows, cov_t, cov_n, steps, **kw):
+def side_config(eng_cls, params, name, windows, cov_t, cov_n, steps, streaming=False, **kw):
     """One more BASELINE.md configuration on this GPU (smaller batch, reported beside the headline), with its own roofline:
-    algorithmic bytes of the batch / HIP-event durations of its kernels."""
+    algorithmic bytes of the batch / HIP-event durations of its kernels.  `windows_per_s` is one batch at a time on the GPU (submit, wait,
+    submit ...).  streaming=True adds `windows_per_s_streaming`: two engines with the batch resident, submitted in turn and NOT chained -- the
+    next batch's window kernel fills the slots the last multi-build windows of this one leave idle, as in a scan that streams batch after
+    batch (for a configuration that runs the window kernel alone: next to a build kernel the overlap costs more than it hides, bench --chain)."""
     import numpy as np
     from lancet_amd import workload
     b = workload.make_scan_batch(windows, cov_t, cov_n, seed=22, **kw)
@@ -157,6 +160,28 @@ def side_config(eng_cls, params, name, windows, cov_t, cov_n, steps, **kw):
            "roofline": {"bound": "hbm", "achieved": round(alg / (ms_all * 1e-3) / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(alg / (ms_all * 1e-3) / 1e9 / 8000.0, 6), "algorithmic_bytes_per_launch": int(alg),
                         "kernel_ms": round(ms_all, 3), "per_kernel_ms": per_kernel, "per_kernel": kernel_rooflines(alg_b, alg_w, per_kernel)}}
+    if streaming:
+        e2 = eng_cls(params, device=0)
+        e2.upload(b)
+        pair = [eng, e2]
+        pend = []
+        for i in range(2):                      # (warm-up: both engines once)
+            pair[i].submit(); pend.append(pair[i])
+        while pend:
+            pend.pop(0).wait()
+        t = time.perf_counter()
+        for i in range(2 * steps):
+            e = pair[i % 2]
+            e.submit(); pend.append(e)
+            if len(pend) >= 2:
+                pend.pop(0).wait()
+        while pend:
+            pend.pop(0).wait()
+        out["windows_per_s_streaming"] = round(windows * 2 * steps / (time.perf_counter() - t), 1)
+        out["streaming_note"] = "two engines with the batch resident, submitted in turn, not chained; results read back every step"
+        v2, _ = e2.results()
+        out["streaming_results_identical"] = bool(v2 == variants)
+        e2.close()
     eng.close()
     return out
 
@@ -438,7 +463,7 @@ def main():
                 side_config(engine.Engine, params, "config 4: 100x tumor / 40x normal, 30 % STR + 5 % low complexity", 4096, 100.0, 40.0, 8,
                             str_fraction=0.30, lowcomplex_fraction=0.05),
                 side_config(engine.Engine, abi.default_params(lr_mode=1), "config 5: --linked-reads (BX / HP tags on every pair), 30x/30x", 16384, 30.0, 30.0, 6,
-                            linked=True),
+                            streaming=True, linked=True),
             ]
         print(json.dumps(out))
     if world > 1:
