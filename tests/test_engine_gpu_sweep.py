@@ -14,7 +14,14 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
+# LANCET_SWEEP_OFFSET=<n>: other draws than the committed 48 (n is added to every seed); LANCET_SWEEP_LINKED=1: every draw with BX / HP tags
+# and --linked-reads.  For a longer run on the GPU box beside the suite (tools/fat_check.sh style), not set by the tests themselves.
+OFFSET = int(os.environ.get("LANCET_SWEEP_OFFSET", "0"))
+LINKED = bool(os.environ.get("LANCET_SWEEP_LINKED"))
+
+
 def draw(seed):
+    seed += OFFSET
     rng = np.random.default_rng(90000 + seed)
     pick = lambda xs: xs[int(rng.integers(0, len(xs)))]
     over = {}
@@ -52,6 +59,8 @@ def draw(seed):
               read_len=int(pick([76, 100, 125, 150, 250])), error_rate=float(pick([0.0, 0.003, 0.005, 0.008, 0.015])),
               str_fraction=float(pick([0.0, 0.0, 0.1, 0.3])), lowcomplex_fraction=float(pick([0.0, 0.0, 0.05])),
               somatic_every=int(pick([400, 1000, 2000])), germline_every=int(pick([300, 1000])))
+    if LINKED:
+        over["lr_mode"] = 1; wl["linked"] = True
     return over, wl
 
 
@@ -72,7 +81,7 @@ def oracle_parallel(batch, p, per=16):
 def test_random_options_and_workloads_match_the_oracle(seed):
     over, wl = draw(seed)
     p = abi.default_params(**over)
-    batch = workload.make_scan_batch(384, seed=700 + seed, **wl)
+    batch = workload.make_scan_batch(384, seed=700 + seed + OFFSET, **wl)
     eng = engine.Engine(p, device=0)
     variants, stats = eng.process(batch)
     ov, ostats = oracle_parallel(batch, p)
@@ -94,7 +103,7 @@ def test_random_draws_through_the_rerun_tier(seed, monkeypatch):
     monkeypatch.setenv("LANCET_NODE_CAP1", "64")
     over, wl = draw(seed)
     p = abi.default_params(**over)
-    batch = workload.make_scan_batch(256, seed=700 + seed, **wl)
+    batch = workload.make_scan_batch(256, seed=700 + seed + OFFSET, **wl)
     eng = engine.Engine(p, device=0)
     variants, stats = eng.process(batch)
     assert eng.rerun_count() > 0
