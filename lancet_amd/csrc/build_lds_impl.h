@@ -757,7 +757,8 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   LC_LDS uint32_t *tmpA = S.big, *tmpB = S.big + (BL_RMAX + 8), *tmpC = S.big + 2 * (BL_RMAX + 8);
   WG_FOR(r, nr + 1) {
     uint32_t ri = 0; int tlen = reflen;
-    if (r < nr) { ri = B.rinfo[g0 + (uint32_t)r]; tlen = (int)RI_TLEN(ri); if (RI_MAPPED(ri)) dev_atomic_add((LC_LDS uint32_t *)&S.mapped, 1u); }
+    if (r < nr) { ri = B.rinfo[g0 + (uint32_t)r]; tlen = (int)RI_TLEN(ri); if (RI_MAPPED(ri)) dev_atomic_add((LC_LDS uint32_t *)&S.mapped, 1u);
+                  if (tlen > 1023) S.flagged = 1; }                         // (k-mer positions are 10 bits here: such a window is the general build's)
     S.rinfo[r] = ri;
     tmpA[r] = (uint32_t)((tlen + 15) / 16); tmpB[r] = (uint32_t)((tlen + 31) / 32);
   }
@@ -771,7 +772,8 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     S.nbw = nbw; S.ngw = ngw;
     if (S.mapped <= 0) S.why = BLW_NOREADS;                    // the window kernel reports LANCET_W_NO_READS itself
     else if (S.hasN) S.why = BLW_HASN;
-    else if (nbw > BL_BASES / 16 || ngw > BL_BASES / 32) S.why = BLW_SIZE;
+    else if (nbw > BL_BASES / 16 || ngw > BL_BASES / 32 || S.flagged) S.why = BLW_SIZE;
+    S.flagged = 0;
   }
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
   WG_FOR(r, nr + 2) { S.rdo[r] = (uint16_t)tmpA[r]; S.gwo[r] = (uint16_t)tmpB[r]; }

@@ -1292,6 +1292,7 @@ DEVNI void build_tables(Ctx &c) {
     read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref);
     W.rd[4 * r] = rinfo; W.rd[4 * r + 1] = bw; W.rd[4 * r + 2] = gw;
     W.occ_base[r] = tlen - K > 0 ? (uint32_t)(tlen - K + 1) : 0u;
+    if (tlen - K + 1 > 1024) OVF(c);                             // k-mer positions are 10 bits in the occurrence words (layout.h CS_POS): reads of up to 1023 + k bases
     if (tlen > 0 && !isref) dev_atomic_add((LC_LDS uint32_t *)&S.tmp1, (uint32_t)tlen);          // totalreadbp_m (Graph.cc:121-124)
     if (tlen - K > 0) dev_atomic_add((LC_LDS uint32_t *)&S.tmp2, (uint32_t)(tlen - K));
   }

@@ -457,6 +457,37 @@ def test_linked_read_replay_by_the_wave_sorts_runs_that_arrive_out_of_order(monk
     assert gu.digest_trace(base[2]) == gu.golden_trace("lr30") and len(base[0]) > 0
 
 
+def test_a_read_longer_than_the_position_field_fails_its_window_alone():
+    """k-mer positions are 10 bits in the occurrence words of both build paths: a window that holds a read of 1100 + bases is reported
+    LANCET_W_OVERFLOW (never assembled with wrapped positions), the windows beside it equal the oracle."""
+    import numpy as np
+    from lancet_amd import frontend, workload
+    b = workload.make_scan_batch(3, 20, 20, seed=4, read_len=100)
+    rng = np.random.default_rng(1)
+    L = 1150
+    r1 = int(b.read_begin[2])                                    # the new read becomes the last one of window 1
+    s1 = int(b.seq_off[r1])
+    ins = lambda a, v: np.concatenate([a[:r1], np.array([v], dtype=a.dtype), a[r1:]])
+    seq = np.concatenate([b.seq[:s1], np.frombuffer(bytes(rng.choice(list(b"ACGT"), L).astype(np.uint8)), dtype=np.uint8), b.seq[s1:]])
+    qual = np.concatenate([b.qual[:s1], np.full(L, ord("I"), dtype=np.uint8), b.qual[s1:]])
+    lens = np.diff(b.seq_off.astype(np.int64)); lens = np.concatenate([lens[:r1], [L], lens[r1:]])
+    read_begin = b.read_begin.astype(np.int64).copy(); read_begin[2:] += 1
+    big = frontend.WindowBatch(n_windows=3, hdr=b.hdr, chrom=b.chrom, chr_id=b.chr_id, ref_start=b.ref_start, ref_off=b.ref_off, ref_bases=b.ref_bases,
+                               read_begin=read_begin.astype(np.uint32), seq_off=np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32), seq=seq, qual=qual,
+                               label=ins(b.label, b.label[0]), strand=ins(b.strand, b.strand[0]), mate=ins(b.mate, 0), mapped=ins(b.mapped, 1),
+                               name_rank=ins(b.name_rank, int(b.read_begin[2] - b.read_begin[1])))
+    p = abi.default_params()
+    ov, ost, _ = oracle.run(b, p)
+    for fat in (False, True):
+        emu.FAT[0] = fat
+        try:
+            v, st, _ = emu.run(big, p)
+        finally:
+            emu.FAT[0] = False
+        assert st[1]["status"] < 0 and st[0]["status"] >= 0 and st[2]["status"] >= 0
+        assert [x for x in v if x["window"] != 1] == [x for x in ov if x["window"] != 1]
+
+
 @pytest.mark.parametrize("linked", [False, True])
 def test_fat_source_on_a_window_of_more_than_65535_reads(linked, fat_emu):
     """~95 000 reads of 50 bases in one window (3100x / 3100x; the reference goes up to MAX_AVG_COV = 10 000x per sample): the re-run
