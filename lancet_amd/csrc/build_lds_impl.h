@@ -1058,9 +1058,11 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
     (void)r; (void)p;
     const uint32_t old = dev_atomic_add(&tab[e & (nslots - 1)], 1u << 16);
+    if (BL_BASES > 65535u && (old >> 16) >= 0xFFFEu) S.why = BLW_SIZE;       // (a k-mer with 65 535 occurrences -- reads that are one long repeat, by the hundred -- would wrap the 16-bit counts: the general build's)
     X.occn[boff] = (bl_on_t)((old & 0xFFFFu) | (e & ON_ORI));
   });
   WG_SYNC();
+  if (BL_BASES > 65535u) { if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; } }
   BLP(S, 7);
   if (C->debug_stop == 107u) { WG_LANE0 { H->why = 99; } return; }
   // ---- std::hash of every node's k-mer (libstdc++ table order), survivor bytes cleared

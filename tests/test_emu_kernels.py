@@ -488,6 +488,33 @@ def test_a_read_longer_than_the_position_field_fails_its_window_alone():
         assert [x for x in v if x["window"] != 1] == [x for x in ov if x["window"] != 1]
 
 
+def test_a_kmer_with_more_occurrences_than_a_16_bit_count_is_never_counted_modulo():
+    """800 reads of 150 A's piled on one window: the k-mer A^k occurs ~110 000 times, more than the 16-bit occurrence counts of the 1024-lane
+    build kernel (which must turn the window away instead of counting modulo 65 536) and more than the reference's own unsigned short
+    per-position counters (the general build reports the window LANCET_W_OVERFLOW).  Either way: reported, or equal to the oracle."""
+    import numpy as np
+    from lancet_amd import frontend, workload
+    b = workload.make_scan_batch(3, 10, 10, seed=4, read_len=100)
+    L, M = 150, 800
+    r1 = int(b.read_begin[2]); s1 = int(b.seq_off[r1])
+    insn = lambda a, v: np.concatenate([a[:r1], np.full(M, v, dtype=a.dtype), a[r1:]])
+    seq = np.concatenate([b.seq[:s1], np.full(L * M, ord("A"), dtype=np.uint8), b.seq[s1:]])
+    qual = np.concatenate([b.qual[:s1], np.full(L * M, ord("I"), dtype=np.uint8), b.qual[s1:]])
+    lens = np.diff(b.seq_off.astype(np.int64)); lens = np.concatenate([lens[:r1], np.full(M, L), lens[r1:]])
+    read_begin = b.read_begin.astype(np.int64).copy(); read_begin[2:] += M
+    n1 = int(b.read_begin[2] - b.read_begin[1])
+    name = np.concatenate([b.name_rank[:r1], (n1 + np.arange(M)).astype(np.uint32), b.name_rank[r1:]])
+    big = frontend.WindowBatch(n_windows=3, hdr=b.hdr, chrom=b.chrom, chr_id=b.chr_id, ref_start=b.ref_start, ref_off=b.ref_off, ref_bases=b.ref_bases,
+                               read_begin=read_begin.astype(np.uint32), seq_off=np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32), seq=seq, qual=qual,
+                               label=insn(b.label, b.label[0]), strand=insn(b.strand, 0), mate=insn(b.mate, 0), mapped=insn(b.mapped, 1), name_rank=name)
+    p = abi.default_params()
+    ov, ost, _ = oracle.run(big, p)
+    v, st, _ = emu.run(big, p)
+    assert emu.LAST_PREBUILT[0] == 2                              # (windows 0 and 2: the build kernel; window 1 turned away)
+    assert st[1]["status"] < 0 or [x for x in v if x["window"] == 1] == [x for x in ov if x["window"] == 1]
+    assert [x for x in v if x["window"] != 1] == [x for x in ov if x["window"] != 1] and st[0]["status"] >= 0 and st[2]["status"] >= 0
+
+
 @pytest.mark.parametrize("linked", [False, True])
 def test_fat_source_on_a_window_of_more_than_65535_reads(linked, fat_emu):
     """~95 000 reads of 50 bases in one window (3100x / 3100x; the reference goes up to MAX_AVG_COV = 10 000x per sample): the re-run
