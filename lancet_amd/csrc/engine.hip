@@ -334,6 +334,8 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (const char *s = getenv("LANCET_MAX_SLOTS")) e->max_slots = atoi(s);
   if (const char *s = getenv("LANCET_MEM_GB")) e->mem_budget = (size_t)atoi(s) << 30;
   if (const char *s = getenv("LANCET_MAX_NODES")) { e->max_nodes_limit = (uint32_t)atoi(s); e->max_nodes_env = true; }
+  if (e->max_nodes_limit > (1u << 22)) e->max_nodes_limit = 1u << 22;        // (sequence descriptors keep the k-mer node in 23 bits: layout.h SD_KMER)
+  if (e->max_nodes_limit < 1024u) e->max_nodes_limit = 1024u;
   if (const char *s = getenv("LANCET_NODE_CAP1")) e->node_cap1 = (uint32_t)atoi(s);
   if (const char *s = getenv("LANCET_STOP_PHASE")) e->debug_stop = (uint32_t)atoi(s);
   if (const char *s = getenv("LANCET_TABLE_START")) e->table_start = lc_pow2_ge((uint32_t)atoi(s));
