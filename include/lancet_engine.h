@@ -69,7 +69,8 @@ typedef struct lancet_window_batch {
   const uint32_t *seq_off;     /* [n_reads+1] offsets into seq / qual                                  */
   const char     *seq;         /* ReadInfo_t::seq_m                                                    */
   const char     *qual;        /* ReadInfo_t::qv_m                                                     */
-  const uint8_t  *label;       /* [n_reads] LANCET_TMR | LANCET_NML   (ReadInfo_t::label_m)            */
+  const uint8_t  *label;       /* [n_reads] LANCET_TMR | LANCET_NML   (ReadInfo_t::label_m); label / strand / mate with
+                                   any other value are refused at upload (LANCET_E_ARG)                  */
   const uint8_t  *strand;      /* [n_reads] LANCET_FWD | LANCET_REV   (ReadInfo_t::strand)             */
   const uint8_t  *mate;        /* [n_reads] 0 | 1 | 2                 (ReadInfo_t::mate_order_m)       */
   const uint8_t  *mapped;      /* [n_reads] 1 = CODE_MAPPED, 0 = CODE_BASTARD (ReadInfo_t::code_m)     */

@@ -462,12 +462,14 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
           if (b->name_rank[r] >= b->read_begin[w + 1] - b->read_begin[w]) bd = 1;
         }
         if (e->params.lr_mode && b->hp[r] > 2) bd = 2;
+        if (!pk && ((b->label[r] != LANCET_TMR && b->label[r] != LANCET_NML) || (b->strand[r] != LANCET_FWD && b->strand[r] != LANCET_REV) || b->mate[r] > 2)) bd = 3;
       }
       tb[(size_t)t + 1] = bo; tg[(size_t)t + 1] = go; bad[(size_t)t] = bd;
     });
     for (int t = 0; t < T; ++t) {
       if (bad[(size_t)t] == 1) { e->err = "name_rank must be the dense per-window rank (< the window's reads)"; return LANCET_E_ARG; }
       if (bad[(size_t)t] == 2) { e->err = "hp must be 0, 1 or 2"; return LANCET_E_ARG; }      // Node_t::addHP indexes a 3-array (src/Node.cc:54-57)
+      if (bad[(size_t)t] == 3) { e->err = "label must be LANCET_TMR / LANCET_NML, strand LANCET_FWD / LANCET_REV, mate 0, 1 or 2"; return LANCET_E_ARG; }
       tb[(size_t)t + 1] += tb[(size_t)t]; tg[(size_t)t + 1] += tg[(size_t)t];
     }
     const uint64_t bo_all = tb[(size_t)T], go_all = tg[(size_t)T];
@@ -557,6 +559,8 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
     if (b->name_rank[r] >= b->read_begin[w + 1] - b->read_begin[w]) { e->err = "name_rank must be the dense per-window rank (< the window's reads)"; return LANCET_E_ARG; }
   }
   if (e->params.lr_mode) for (uint32_t r = 0; r < R; ++r) if (b->hp[r] > 2) { e->err = "hp must be 0, 1 or 2"; return LANCET_E_ARG; }   // Node_t::addHP indexes a 3-array (src/Node.cc:54-57)
+  if (!pk) for (uint32_t r = 0; r < R; ++r) if ((b->label[r] != LANCET_TMR && b->label[r] != LANCET_NML) || (b->strand[r] != LANCET_FWD && b->strand[r] != LANCET_REV) || b->mate[r] > 2) {
+    e->err = "label must be LANCET_TMR / LANCET_NML, strand LANCET_FWD / LANCET_REV, mate 0, 1 or 2"; return LANCET_E_ARG; }
   UP(e->d_chr, b->chr_id, sizeof(int32_t) * nw);
   UP(e->d_refstart, b->ref_start, sizeof(int32_t) * nw);
   UP(e->d_refoff, b->ref_off, sizeof(uint32_t) * (nw + 1));

@@ -470,6 +470,25 @@ def test_linked_read_window_of_more_than_65535_reads():
     eng.close()
 
 
+def test_upload_refuses_labels_the_reference_does_not_have():
+    """label / strand / mate outside the reference's values (src/Ref.hh:36-37, src/ReadInfo.hh:30-31) would be read as 'not normal' / 'not
+    reverse' by the kernels and as neither sample by anything that tests for equality: refused at upload, LANCET_E_ARG."""
+    import copy
+    from lancet_amd import workload
+    b = workload.make_scan_batch(4, 20, 20, seed=4, read_len=100)
+    eng = engine.Engine(abi.default_params())
+    for field, bad in (("label", 0), ("strand", 0), ("mate", 3)):
+        bb = copy.copy(b)
+        a = getattr(b, field).copy(); a[5] = bad
+        setattr(bb, field, a)
+        with pytest.raises(engine.EngineError, match="label must be"):
+            eng.upload(bb)
+    v, st = eng.process(b)                                        # (the engine is usable after a refused upload)
+    ov, ost, _ = oracle.run(b, abi.default_params())
+    assert v == ov
+    eng.close()
+
+
 def test_a_window_beyond_the_engine_limits_fails_alone():
     """One window of 1100 bp (LC_MAXW is 1024) inside an ordinary batch is reported LANCET_W_OVERFLOW on its own: the batch is not refused and
     every other window equals the oracle -- among them one with 70 000 reads, which overflows the one-wave kernel's 16-bit read ids and
