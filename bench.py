@@ -265,20 +265,51 @@ def main():
         e2.upload(batch)
     n_slots, slot_bytes = eng.geometry()
     last = {}
-    tm = {"gather": 0.0, "replay": 0.0, "steps": 0}
+    tm = {"gather": 0.0, "replay": 0.0, "pack": 0.0, "host": 0.0, "steps": 0}
+
+    # N ranks: what happens to a finished step's records -- keys + per-key reduction (pack_records), the sizes all_gather and the payload
+    # send / recv (gather_bytes), on rank 0 the replay -- runs on a communication thread of its own, so that the thread that submits the
+    # kernels only waits for them (step i's gather overlaps step i + 1's kernels; the C side and the collectives release the GIL).  The
+    # communication thread is the only one that issues collectives while steps run, in step order on every rank.  An engine's result
+    # buffers are valid until its next submit: `busy[engine]` is set when its records have been packed.
+    comm_q = queue.Queue()
+    busy = {}
+
+    def comm_worker():
+        torch.cuda.set_device(device)            # (the current device is per thread)
+        while True:
+            item = comm_q.get()
+            try:
+                if item is None:
+                    return
+                e, packed = item
+                try:
+                    vp, n, blob, _ = e.raw_results()
+                    tg = time.perf_counter()
+                    payload = ldist.pack_records(vp, n, blob, chr_names=[chrom], window_index=windex)
+                    tm["pack"] += time.perf_counter() - tg
+                finally:
+                    packed.set()                 # (the engine may be submitted again)
+                tg = time.perf_counter()
+                parts = ldist.gather_bytes(payload, comm_device)
+                tm["gather"] += time.perf_counter() - tg; tm["steps"] += 1
+                if rank == 0:
+                    merge_q.put(parts)
+            except BaseException as ex:          # surfaced by run_steps
+                last["error"] = ex
+            finally:
+                comm_q.task_done()
 
     def complete(e):
         e.wait()
         if world > 1:
-            vp, n, blob, _ = e.raw_results()
-            tg = time.perf_counter()
-            parts = ldist.gather_bytes(ldist.pack_records(vp, n, blob, chr_names=[chrom], window_index=windex), comm_device)
-            tm["gather"] += time.perf_counter() - tg; tm["steps"] += 1
-            if rank == 0:
-                merge_q.put(parts)
+            th = time.perf_counter()
+            busy[id(e)] = threading.Event()
+            comm_q.put((e, busy[id(e)]))
+            tm["host"] += time.perf_counter() - th
 
-    # rank 0 replays the gathered records on a second host thread (the C side releases the GIL), so that the replay of step i
-    # overlaps the gather of step i+1; run_steps() returns only when every step it submitted has been replayed.
+    # rank 0 replays the gathered records on a further host thread, so that the replay of step i overlaps the gather of step i+1;
+    # run_steps() returns only when every step it submitted has been gathered and replayed.
     merge_q = queue.Queue()
 
     def merger():
@@ -297,11 +328,14 @@ def main():
             finally:
                 merge_q.task_done()
 
-    if world > 1 and rank == 0:
-        threading.Thread(target=merger, daemon=True).start()
+    if world > 1:
+        threading.Thread(target=comm_worker, daemon=True).start()
+        if rank == 0:
+            threading.Thread(target=merger, daemon=True).start()
 
     def run_steps(k):
         _run_steps(k)
+        comm_q.join()
         merge_q.join()
         if "error" in last:
             raise last["error"]
@@ -310,6 +344,11 @@ def main():
         pend = []
         for i in range(k):
             e = engs[i % nfl]
+            ev = busy.pop(id(e), None)
+            if ev is not None:
+                th = time.perf_counter()
+                ev.wait()                        # (its previous step's records are still being packed)
+                tm["host"] += time.perf_counter() - th
             e.submit(after=pend[-1] if pend and args.chain else None)
             pend.append(e)
             if len(pend) >= nfl:
@@ -321,7 +360,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    tm["gather"] = tm["replay"] = 0.0; tm["steps"] = 0
+    tm["gather"] = tm["replay"] = tm["pack"] = tm["host"] = 0.0; tm["steps"] = 0
     t0 = time.perf_counter()
     run_steps(args.steps)
     if world > 1:
@@ -436,6 +475,8 @@ def main():
             out["comm_backend"] = dist.get_backend()
             out["gather_ms_per_step_by_rank"] = gather_ms      # sizes all_gather + payload send / recv, as each rank saw it
             out["replay_ms_per_step_rank0"] = round(1000.0 * tm["replay"] / max(1, args.steps), 3)
+            out["pack_ms_per_step_rank0"] = round(1000.0 * tm["pack"] / max(1, args.steps), 3)           # keys + per-key reduction, communication thread
+            out["submit_thread_comm_ms_per_step_rank0"] = round(1000.0 * tm["host"] / max(1, args.steps), 3)   # what the submitting thread spends on the gather (hand-over + waits)
             out["windows_per_rank"] = n_local
             if one_gpu:
                 out["config"]["comm"] = "LANCET_BENCH_ONE_GPU=1: all ranks on device 0, gather over gloo -- a check of the N-rank path, not a measurement"

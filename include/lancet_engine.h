@@ -168,6 +168,10 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b);
  * (lancet_host_batch_packed does; a caller of lancet_pack_read copies them from the lancet_params it packed with) -- an engine created
  * with other thresholds refuses the batch (LANCET_E_ARG) instead of building graphs from reads trimmed for another run. */
 typedef struct lancet_packed_reads {
+  uint32_t struct_size;        /* sizeof(lancet_packed_reads) as the CALLER's header has it: the first field, so that a caller built against
+                                  another layout of this struct is refused (LANCET_E_ARG) instead of being read past its end.  The producers
+                                  in this library (lancet_host_batch_packed) fill it in */
+  uint32_t reserved;           /* 0 */
   const uint32_t *rinfo;       /* [n_reads] trimmed length and the read's flags, as lancet_pack_read leaves them */
   const uint32_t *base_woff;   /* [n_reads + 1] */
   const uint32_t *good_woff;   /* [n_reads + 1] */

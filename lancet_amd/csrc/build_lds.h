@@ -35,6 +35,22 @@
 #define BL_INFLIGHT 4             /* occurrence words a lane has in flight in a pass over the window's occurrences (bl_for_occ) */
 #endif
 #define BL_DUPCAP 1024u
+#ifndef LANCET_WAVE_EMU
+#define BL_UNROLL _Pragma("unroll")
+#else
+#define BL_UNROLL
+#endif
+// The tail of a window's build (table order, components, first compress: ~165 workgroup barriers with little work between them) at a raised
+// wave priority: its waves mostly wait, and what they issue between two barriers is on the critical path of the window, while the other
+// workgroup of the CU is, most of the time, in an occurrence pass that is bound by VALU throughput and fills whatever slots are left.
+#ifndef BL_TAIL_PRIO
+#define BL_TAIL_PRIO 0
+#endif
+#if !defined(LANCET_WAVE_EMU)
+#define BL_TAIL_PRIO_SET(p) do { if (BL_TAIL_PRIO) __builtin_amdgcn_s_setprio(p); } while (0)
+#else
+#define BL_TAIL_PRIO_SET(p) ((void)0)
+#endif
 enum { BLW_NONE = 0, BLW_NOREADS, BLW_SIZE, BLW_HASN, BLW_K, BLW_TABLE, BLW_NODES, BLW_TRACKED, BLW_CAND, BLW_QV, BLW_SURV, BLW_MATE, BLW_NAMES, BLW_PAIRS,
        BLW_KBIG /* k > 31: the 1024-lane configuration's (keys of up to four words) */ };
 

@@ -28,8 +28,8 @@ struct BlShared {
   uint32_t goodm[BL_BASES / 32 + 4];
   uint16_t rdo[BL_RMAX + 4];        /* first 16-base word of read r                                             */
   uint16_t gwo[BL_RMAX + 4];        /* first quality-mask word of read r                                        */
-  bl_occ_t obase[BL_RMAX + 4];      /* first occurrence index of read r; [R] = O                                */
-  uint16_t o2r[BL_BASES / 128 + 2]; /* read that holds occurrence 128 * j                                       */
+  bl_occ_t cbase[BL_RMAX + 4];      /* first chunk (eight k-mer starts, bl_chunk) of read r; [R] = all chunks   */
+  uint16_t c2r[BL_BASES / 128 + 2]; /* read that holds chunk 16 * j                                             */
   uint32_t rinfo[BL_RMAX + 4];
   uint8_t pidx[BL_RMAX + 4];        /* mate-pair signature bit of the read (0xFF none)                          */
   uint8_t prole[BL_RMAX + 4];       /* 1 = earlier mate of a pair, 2 = the later one                            */
@@ -69,7 +69,7 @@ struct BlScratch {
   LC_GLOBAL uint32_t *pq;           /* [BL_PQCAP] per-position counts: the occurrences of the candidates beyond the first LDS group (read | position << 10 | candidate << 20 | reversed << 31) */
 };
 static constexpr uint32_t BL_PQCAP = 16384u;
-static constexpr uint32_t SCRATCH_BYTES = ((uint32_t)sizeof(bl_on_t) * BL_BASES + 64u + (BL_WIDE ? 4u * BL_NCAP + 64u : 64u) + 8u * BL_TCAP + 4u * BL_TCAP + 12u * PB_CCAP + 4u * PB_SCAP + 36u * PB_SCAP + (uint32_t)sizeof(bl_off_t) * BL_DUPCAP + 16u * PB_CMAX + 4u * 16384u + 768u);
+static constexpr uint32_t SCRATCH_BYTES = (((uint32_t)sizeof(bl_on_t) * BL_BASES + 64u + (BL_WIDE ? 4u * BL_NCAP + 64u : 64u) + 8u * BL_TCAP + 4u * BL_TCAP + 12u * PB_CCAP + 4u * PB_SCAP + 36u * PB_SCAP + (uint32_t)sizeof(bl_off_t) * BL_DUPCAP + 16u * PB_CMAX + 4u * 16384u + 768u) + 255u) & ~255u;   /* (a multiple of 256: the strips' 16-byte loads stay aligned in every slot) */
 static constexpr int WG = BL_WG;
 DEV void bl_scratch_carve(BlScratch *s, LC_GLOBAL uint8_t *base) {
   size_t o = 0;
@@ -147,7 +147,7 @@ DEV uint32_t bl_add16(LC_LDS uint16_t *a, uint32_t i, uint32_t inc) {        // 
 DEV unsigned long long bl_kmer(const LC_LDS uint32_t *bases, uint32_t boff, unsigned long long kmask) {
   const uint32_t w = boff >> 4, sh = (boff & 15u) * 2u;
   const unsigned long long lo = (unsigned long long)bases[w] | ((unsigned long long)bases[w + 1] << 32);
-  const unsigned long long v = sh ? ((lo >> sh) | ((unsigned long long)bases[w + 2] << (64u - sh))) : lo;
+  const unsigned long long v = (lo >> sh) | (((unsigned long long)bases[w + 2] << 1) << (63u - sh));     // (no branch on sh == 0: three reads always, in flight together)
   return v & kmask;
 }
 // canonical form as kernels.h holds it (first base most significant; CanonicalMer_t::set, reference src/Mer.hh:57-71: tie -> R)
@@ -265,30 +265,91 @@ DEV bool bl_all_good(const LC_LDS uint32_t *goodm, uint32_t gw, int a, int b) {
   return true;
 }
 
-// every occurrence o of the window: read r, k-mer start p in the read, LDS offset boff of the k-mer (lane-strided)
-#define BL_OCC_BEGIN(S) WG_FOR(_t, BL_WG) { const int _O = (int)(S).O; \
-  for (int o = _t; o < _O; o += BL_WG) { uint32_t _r = (S).o2r[o >> 7]; while ((uint32_t)o >= (S).obase[_r + 1]) ++_r; \
-    const int r = (int)_r; const int p = o - (int)(S).obase[r]; const uint32_t boff = 16u * (S).rdo[r] + (uint32_t)p; (void)p; (void)boff; (void)r;
-#define BL_OCC_END } }
-
-// The same walk with the occurrence's 2-byte HBM word fetched BL_INFLIGHT occurrences ahead: a pass is a chain of (HBM word -> LDS
-// look-ups -> LDS atomics) per occurrence, and with two workgroups per CU nothing else hides the memory round trip.
-template <class F> DEV void bl_for_occ(BL_S &S, LC_GLOBAL const bl_on_t *occn, F body) {
+// 64 bits of a read's quality mask (first word gw) from bit s on (bits past the read's last base belong to whatever follows: the callers
+// only look at bits inside the read)
+DEV unsigned long long bl_good64(const LC_LDS uint32_t *goodm, uint32_t gw, int s) {
+  const uint32_t w = gw + ((uint32_t)s >> 5), sh = (uint32_t)s & 31u;
+  const unsigned long long lo = (unsigned long long)goodm[w] | ((unsigned long long)goodm[w + 1] << 32);
+  return sh ? ((lo >> sh) | ((unsigned long long)goodm[w + 2] << (64u - sh))) : lo;
+}
+// ---- The walk over the window's k-mer occurrences, eight at a time.
+// A "chunk" is eight consecutive k-mer starts: the bases [8c, 8c + 8) of the LDS copy of the reads.  A read starts on a 16-base word, so
+// a chunk lies inside ONE read: the read (w2r + rdo), its trimmed length and the number of its k-mers are looked up once per eight
+// occurrences instead of once per occurrence, the chunk's per-occurrence words in HBM scratch are one 16-byte load (BL_WIDE: two), and the
+// bases / quality bits of all eight k-mers come out of the same three LDS words.  (Until round 5 every lane took single occurrences,
+// lane-strided over a dense occurrence index: ~25 of the ~110-150 VALU instructions per occurrence and pass were that look-up -- and the
+// occurrence passes are VALU-bound, profiles/r5_sq_counters.txt.)  Chunks past a read's last k-mer are skipped; no pass depends on the
+// order the occurrences are visited in (first occurrences and edge stamps by atomicMin on offsets, counts by atomic adds, lists sorted).
+struct BlChunk {
+  int r, p0, nv;                    /* read, k-mer start of the chunk's first occurrence in it, occurrences in the chunk (1..8) */
+  uint32_t boff0;                   /* LDS offset (base index) of that first occurrence = index of its per-occurrence word       */
+  int tlen;                         /* the read's trimmed length (the window reference: its length)                              */
+};
+// chunk q of the window (chunks are numbered densely: read r owns ceil(k-mers / 8) of them from cbase[r] on)
+DEV void bl_chunk(BL_S &S, int q, int nr, int reflen, int K, BlChunk &ch) {
+  uint32_t r = S.c2r[(uint32_t)q >> 4];
+  while ((uint32_t)q >= (uint32_t)S.cbase[r + 1]) ++r;
+  const int tlen = (int)r < nr ? (int)RI_TLEN(S.rinfo[r]) : reflen;
+  const int p0 = 8 * (q - (int)S.cbase[r]);
+  ch.r = (int)r; ch.p0 = p0; ch.tlen = tlen; ch.boff0 = 16u * (uint32_t)S.rdo[r] + (uint32_t)p0;
+  const int left = tlen - K + 1 - p0;                                 // (>= 1: the read has a k-mer start in this chunk)
+  ch.nv = left < 8 ? left : 8;
+}
+// the eight per-occurrence words of a chunk (HBM scratch), as loaded
+#if BL_WIDE
+struct BlOccW { lc_u4 a, b; };
+DEV BlOccW bl_occw_load(LC_GLOBAL const bl_on_t *occn, uint32_t boff0) { BlOccW w; w.a = ldg4((LC_GLOBAL const uint32_t *)(occn + boff0)); w.b = ldg4((LC_GLOBAL const uint32_t *)(occn + boff0 + 4u)); return w; }
+DEV void bl_occw_store(LC_GLOBAL bl_on_t *occn, uint32_t boff0, const BlOccW &w) { stg4((LC_GLOBAL uint32_t *)(occn + boff0), w.a); stg4((LC_GLOBAL uint32_t *)(occn + boff0 + 4u), w.b); }
+DEV uint32_t bl_occw_get(const BlOccW &w, int j) {
+  const uint32_t lo = (j & 2) ? ((j & 1) ? w.a.w : w.a.z) : ((j & 1) ? w.a.y : w.a.x), hi = (j & 2) ? ((j & 1) ? w.b.w : w.b.z) : ((j & 1) ? w.b.y : w.b.x);
+  return (j & 4) ? hi : lo;
+}
+DEV void bl_occw_set(BlOccW &w, int j, uint32_t v) {
+  if (j == 0) w.a.x = v; else if (j == 1) w.a.y = v; else if (j == 2) w.a.z = v; else if (j == 3) w.a.w = v;
+  else if (j == 4) w.b.x = v; else if (j == 5) w.b.y = v; else if (j == 6) w.b.z = v; else w.b.w = v;
+}
+#else
+struct BlOccW { lc_u4 a; };
+DEV BlOccW bl_occw_load(LC_GLOBAL const bl_on_t *occn, uint32_t boff0) { BlOccW w; w.a = ldg4((LC_GLOBAL const uint32_t *)(occn + boff0)); return w; }
+DEV void bl_occw_store(LC_GLOBAL bl_on_t *occn, uint32_t boff0, const BlOccW &w) { stg4((LC_GLOBAL uint32_t *)(occn + boff0), w.a); }
+DEV uint32_t bl_occw_get(const BlOccW &w, int j) {
+  const uint32_t x = (j & 4) ? ((j & 2) ? w.a.w : w.a.z) : ((j & 2) ? w.a.y : w.a.x);
+  return (j & 1) ? (x >> 16) : (x & 0xFFFFu);
+}
+DEV void bl_occw_set(BlOccW &w, int j, uint32_t v) {                 // (v < 65 536)
+  const uint32_t sh = (uint32_t)(j & 1) * 16u, m = ~(0xFFFFu << sh), x = v << sh;
+  if ((j >> 1) == 0) w.a.x = (w.a.x & m) | x; else if ((j >> 1) == 1) w.a.y = (w.a.y & m) | x; else if ((j >> 1) == 2) w.a.z = (w.a.z & m) | x; else w.a.w = (w.a.w & m) | x;
+}
+#endif
+// every chunk of the window that holds k-mer starts: body(chunk, its eight per-occurrence words).  The words of the lane's NEXT chunk are
+// loaded before this one is worked off (unconditionally, index clamped: a conditional load would wait for every earlier store).
+template <class F> DEV void bl_for_chunk(BL_S &S, LC_GLOBAL const bl_on_t *occn, F body) {
+  const int nr = S.R - 1, NC = (int)S.cbase[nr + 1], reflen = S.reflen, K = S.K;
   WG_FOR(_t, BL_WG) {
-    const int O_ = (int)S.O;
-    for (int o0 = _t; o0 < O_; o0 += BL_INFLIGHT * BL_WG) {
-      int rr[BL_INFLIGHT], pp[BL_INFLIGHT]; uint32_t bo[BL_INFLIGHT], ee[BL_INFLIGHT];
-      for (int u = 0; u < BL_INFLIGHT; ++u) {
-        const int o = o0 + u * BL_WG;
-        const int oc = o < O_ ? o : O_ - 1;                          // (clamped: the loads below stay unconditional, four in flight)
-        uint32_t rc = S.o2r[oc >> 7];
-        while ((uint32_t)oc >= S.obase[rc + 1]) ++rc;
-        rr[u] = o < O_ ? (int)rc : -1; pp[u] = oc - (int)S.obase[rc]; bo[u] = 16u * S.rdo[rc] + (uint32_t)pp[u];
+    if (_t < NC) {
+      BlChunk ch; bl_chunk(S, _t, nr, reflen, K, ch);
+      BlOccW cur = bl_occw_load(occn, ch.boff0);
+      for (int q = _t; q < NC; q += BL_WG) {
+        BlChunk nx = ch;
+        if (q + BL_WG < NC) bl_chunk(S, q + BL_WG, nr, reflen, K, nx);        // (LDS look-ups only; the load below stays unconditional)
+        const BlOccW nxt = bl_occw_load(occn, nx.boff0);
+        body(ch, cur);
+        cur = nxt; ch = nx;
       }
-      for (int u = 0; u < BL_INFLIGHT; ++u) ee[u] = (uint32_t)occn[bo[u]];
-      for (int u = 0; u < BL_INFLIGHT; ++u) if (rr[u] >= 0) body(rr[u], pp[u], bo[u], ee[u]);
     }
   }
+}
+// the same walk, one call of `body(r, p, boff, word)` per occurrence
+template <class F> DEV void bl_for_occ(BL_S &S, LC_GLOBAL const bl_on_t *occn, F body) {
+  bl_for_chunk(S, occn, [&](const BlChunk &ch, const BlOccW &w) {
+    for (int j = 0; j < ch.nv; ++j) body(ch.r, ch.p0 + j, ch.boff0 + (uint32_t)j, bl_occw_get(w, j));
+  });
+}
+// the chunk's bases as a bit string: base i of the chunk (i = 0 .. 8 + K - 2 <= 37 for k <= 31) at bits 2i of (lo, hi)
+DEV void bl_chunk_bases(const LC_LDS uint32_t *bases, int c, unsigned long long &lo, unsigned long long &hi) {
+  const uint32_t wd = (uint32_t)c >> 1;
+  lo = (unsigned long long)bases[wd] | ((unsigned long long)bases[wd + 1] << 32); hi = (unsigned long long)bases[wd + 2];
+  if (c & 1) { lo = (lo >> 16) | (hi << 48); hi >>= 16; }
 }
 
 
@@ -765,9 +826,10 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   WG_FOR(i, reflen) { if (refc[i] > 3) S.hasN = 1; }
   WG_LANE0 { tmpA[nr + 1] = 0; tmpB[nr + 1] = 0; }
   bl_scan32(tmpA, nr + 2, S);
-  const uint32_t nbw = bl_bcast(&S.scan_total);
+  const uint32_t nbw = lc_sgpr((uint32_t)S.scan_total);                           // (a scan ends in a barrier, and the next one overwrites the total only behind two of its own)
   bl_scan32(tmpB, nr + 2, S);
-  const uint32_t ngw = bl_bcast(&S.scan_total);
+  const uint32_t ngw = lc_sgpr((uint32_t)S.scan_total);
+  WG_SYNC();
   WG_LANE0 {
     S.nbw = nbw; S.ngw = ngw;
     if (S.mapped <= 0) S.why = BLW_NOREADS;                    // the window kernel reports LANCET_W_NO_READS itself
@@ -814,8 +876,10 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     else if (2 * K > 64 * (int)PL.kw) S.why = BLW_K;                     // (the batch's hand-off areas hold one-word keys)
     else if (K > BL_KMAX) S.why = BLW_KBIG;                              // (the 1024-lane configuration takes it off the list)
   }
-  if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
-  const int K = (int)bl_bcast(&S.K);
+  WG_SYNC();
+  const int why_k = lc_sgpr((int)S.why); const int K = lc_sgpr((int)S.K);                    // (both words between one pair of barriers)
+  WG_SYNC();
+  if (why_k) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
   const int NW = (2 * K + 63) / 64;                                      // 64-bit words of a k-mer
   const unsigned long long kmask = K < 32 ? (1ULL << (2 * K)) - 1ULL : ~0ULL;   // (one-word form: K <= 31)
   (void)kmask; (void)NW;
@@ -832,13 +896,16 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     if (tlen - K > 0) dev_atomic_add((LC_LDS uint32_t *)&S.n_kmers, (uint32_t)(tlen - K));
   }
   WG_LANE0 { tmpC[R] = 0; }
+  // (one scan for two prefix sums: k-mer starts in the low 17 bits -- at most BL_BASES < 2^17 of them -- and chunks of eight above)
+  WG_FOR(r, R) { tmpC[r] |= ((tmpC[r] + 7u) >> 3) << 17; }
   bl_scan32(tmpC, R + 1, S);
-  WG_FOR(r, R + 1) { S.obase[r] = (bl_occ_t)tmpC[r]; }
-  WG_LANE0 { S.O = S.scan_total; S.obase[R + 1] = (bl_occ_t)~(bl_occ_t)0; }
+  WG_LANE0 { S.O = S.scan_total & 0x1FFFFu; }                  // (all chunks of the window: cbase[R], below)
+  WG_FOR(r, R + 1) { S.cbase[r] = (bl_occ_t)(tmpC[r] >> 17); }
+  WG_LANE0 { S.cbase[R + 1] = (bl_occ_t)~(bl_occ_t)0; }
   WG_SYNC();
-  WG_FOR(r, R) {                                                 // read r holds the occurrences [obase[r], obase[r+1]): the multiples of 128 among them
-    const uint32_t a = S.obase[r], b = S.obase[r + 1];
-    for (uint32_t j = (a + 127u) >> 7; (j << 7) < b; ++j) S.o2r[j] = (uint16_t)r;
+  WG_FOR(r, R) {                                                 // read r holds the chunks [cbase[r], cbase[r+1]): the multiples of 16 among them
+    const uint32_t a = S.cbase[r], b = S.cbase[r + 1];
+    for (uint32_t j = (a + 15u) >> 4; (j << 4) < b; ++j) S.c2r[j] = (uint16_t)r;
   }
   WG_SYNC();
   // ---- mate pairs: a read with exactly one earlier read of the same name and the opposite mate number is the later mate of
@@ -893,69 +960,80 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   const uint32_t nslots = (PL.ncap > PB_NCAP || BL_SLOTS < 8192u) ? (uint32_t)BL_SLOTS : 8192u;
   WG_FOR(i, nslots) { tab[i] = BL_EMPTY; }
   WG_SYNC();
-  // BL_INS occurrences per lane at a time: their k-mers are cut out of LDS, hashed and their first table words read before the first
-  // probe starts (a probe is a chain of dependent LDS round trips; with two workgroups per CU little else hides them).  A table word read
-  // early can be out of date by the time its probe looks at it: an empty word is then settled by the compare-and-swap, an occupied one only
-  // ever changes to an earlier occurrence of the same k-mer.
+  // A lane takes a chunk of eight consecutive k-mer starts (bl_chunk) in two batches of BL_INS = 4: the batch's k-mers are shifted out of the
+  // chunk's three LDS words, hashed and their first table words read before the first probe starts (a probe is a chain of dependent LDS
+  // round trips).  A table word read early can be out of date by the time its probe looks at it: an empty word is then settled by the
+  // compare-and-swap, an occupied one only ever changes to an earlier occurrence of the same k-mer.
+  // (Measured and dropped in round 5: the four probes of a batch in lock step -- one loop that advances all four, their LDS reads in flight
+  // together -- 2.62 against 2.36 workgroup-seconds per 32 768 windows: the loop runs until the slowest of 4 x 64 probes is through.)
+  static_assert(BL_INS == 4, "two batches of four per chunk");
+  const int NC = (int)S.cbase[R];                                 // (written before the last barrier)
   if (BL_KW == 1 || NW == 1) {       // one-word k-mers (k <= 31): the form below; else the general one behind it
   WG_FOR(_t, BL_WG) {
-    const int O_ = (int)S.O;
-    for (int o0 = _t; o0 < O_; o0 += BL_INS * BL_WG) {
-      int rr[BL_INS]; uint32_t bo[BL_INS], ix[BL_INS], fpv[BL_INS], cu[BL_INS]; unsigned long long kv[BL_INS], al[BL_INS]; bool fF[BL_INS];
-      for (int u = 0; u < BL_INS; ++u) {
-        const int o = o0 + u * BL_WG;
-        const int oc = o < O_ ? o : O_ - 1;
-        uint32_t rc = S.o2r[oc >> 7];
-        while ((uint32_t)oc >= S.obase[rc + 1]) ++rc;
-        rr[u] = o < O_ ? (int)rc : -1; bo[u] = 16u * S.rdo[rc] + (uint32_t)(oc - (int)S.obase[rc]);
-      }
-      for (int u = 0; u < BL_INS; ++u) kv[u] = bl_kmer(S.bases, bo[u], kmask);
-      for (int u = 0; u < BL_INS; ++u) {
-        unsigned long long fw1;
-        const unsigned long long ck = bl_canon2(kv[u], K, kmask, &fF[u], &fw1);
-        // An earlier occurrence v2 (as it lies in LDS: first base in the low bits) is the same node iff it is this k-mer or its
-        // reverse complement.  Read first-base-high, v2's reverse complement is ~v2 & mask (bl_canon); that equals this k-mer's
-        // forward form fw1 iff v2 == ~fw1 & mask.  So a fingerprint hit is confirmed with one k-mer cut out of LDS and two
-        // compares, without canonicalising the earlier occurrence (k is odd here: no k-mer is its own reverse complement).
-        al[u] = (~fw1) & kmask;
-        // table hash on 32-bit words (the table is private to this pass: node ids come from first-occurrence offsets, not slots)
-        uint32_t hh = (uint32_t)ck * 0x9E3779B1u ^ (((uint32_t)(ck >> 32)) ^ ((uint32_t)ck >> 15)) * 0x85EBCA77u;
-        hh ^= hh >> 15; hh *= 0x2C1B3C6Du; hh ^= hh >> 12;
-        ix[u] = hh & (nslots - 1);
-        uint32_t fp = hh >> BL_OFFBITS; if (fp == (0xFFFFFFFFu >> BL_OFFBITS)) fp -= 1u;
-        fpv[u] = fp;
-      }
-      for (int u = 0; u < BL_INS; ++u) cu[u] = ld2(&tab[ix[u]]);
-      for (int u = 0; u < BL_INS; ++u) {
-        if (rr[u] < 0) continue;
-        const int r = rr[u]; const uint32_t boff = bo[u], fp = fpv[u]; const bool isF = fF[u]; const unsigned long long v1 = kv[u], alt = al[u];
-        const uint32_t mine = (fp << BL_OFFBITS) | boff;
-        uint32_t idx = ix[u], cur = cu[u], probes = 0;
-        while (true) {
-          if (cur == BL_EMPTY) { cur = dev_atomic_cas32(&tab[idx], BL_EMPTY, mine); if (cur == BL_EMPTY) break; }
-          if ((cur >> BL_OFFBITS) == fp) {
-            const unsigned long long v2 = bl_kmer(S.bases, cur & BL_OFFMASK, kmask);
-            if (v2 == v1 || v2 == alt) {
-              const bool f2 = (v2 == v1) ? isF : !isF;
-              if (mine < cur) dev_atomic_min(&tab[idx], mine);
-              // Scheduling hint (PreHdr::heavy).  All reads are in reference orientation and the loop over k only builds at a k
-              // above the window reference's longest repeat, so a node normally meets its k-mer once per read and always in the
-              // same orientation.  The same k-mer twice in one read (a duplication in the sample), or in both orientations (an
-              // inverted repeat, which isRepeat does not look for), means a walk comes back to the node: if that node survives
-              // removeLowCov the graph has a cycle and this k is rejected (Microassembler.cc:198-206).  The occurrence is noted
-              // here and looked at again once the survivors are known.
-              if (cur != mine && ((f2 != isF) || (r < nr && (cur & BL_OFFMASK) - 16u * S.rdo[r] < (uint32_t)RI_TLEN(S.rinfo[r])))) {
-                const uint32_t di = dev_atomic_add((LC_LDS uint32_t *)&S.ndup, 1u);
-                if (di < BL_DUPCAP) X.dupo[di] = (bl_off_t)boff;
-              }
-              break;
-            }
-          }
-          idx = (idx + 1) & (nslots - 1);
-          if (++probes > 256u) { S.why = BLW_TABLE; break; }
-          cur = ld2(&tab[idx]);
+    for (int q = _t; q < NC; q += BL_WG) {
+      BlChunk ch; bl_chunk(S, q, nr, reflen, K, ch);
+      const int r = ch.r; const uint32_t rb = ch.boff0 - (uint32_t)ch.p0;          // LDS offset of the read's first base
+      unsigned long long lo, hi; bl_chunk_bases(S.bases, (int)(ch.boff0 >> 3), lo, hi);
+      for (int hb = 0; hb < 2; ++hb) {
+        if (4 * hb >= ch.nv) break;
+        uint32_t ix[BL_INS], fpv[BL_INS], cu[BL_INS], sw[BL_INS]; unsigned long long kv[BL_INS], al[BL_INS]; bool fF[BL_INS];
+        BL_UNROLL for (int u = 0; u < BL_INS; ++u) kv[u] = (u ? ((lo >> (2 * u)) | (hi << (64 - 2 * u))) : lo) & kmask;
+        lo = (lo >> 8) | (hi << 56); hi >>= 8;                        // (the next batch starts four bases on)
+        BL_UNROLL for (int u = 0; u < BL_INS; ++u) {
+          unsigned long long fw1;
+          const unsigned long long ck = bl_canon2(kv[u], K, kmask, &fF[u], &fw1);
+          // An earlier occurrence v2 (as it lies in LDS: first base in the low bits) is the same node iff it is this k-mer or its
+          // reverse complement.  Read first-base-high, v2's reverse complement is ~v2 & mask (bl_canon); that equals this k-mer's
+          // forward form fw1 iff v2 == ~fw1 & mask.  So a fingerprint hit is confirmed with one k-mer cut out of LDS and two
+          // compares, without canonicalising the earlier occurrence (k is odd here: no k-mer is its own reverse complement).
+          al[u] = (~fw1) & kmask;
+          // table hash on 32-bit words (the table is private to this pass: node ids come from first-occurrence offsets, not slots)
+          uint32_t hh = (uint32_t)ck * 0x9E3779B1u ^ (((uint32_t)(ck >> 32)) ^ ((uint32_t)ck >> 15)) * 0x85EBCA77u;
+          hh ^= hh >> 15; hh *= 0x2C1B3C6Du; hh ^= hh >> 12;
+          ix[u] = hh & (nslots - 1);
+          uint32_t fp = hh >> BL_OFFBITS; if (fp == (0xFFFFFFFFu >> BL_OFFBITS)) fp -= 1u;
+          fpv[u] = fp;
         }
-        X.occn[boff] = (bl_on_t)(idx | (isF ? 0u : ON_ORI));
+        BL_UNROLL for (int u = 0; u < BL_INS; ++u) cu[u] = ld2(&tab[ix[u]]);
+        BL_UNROLL for (int u = 0; u < BL_INS; ++u) {
+          sw[u] = 0;
+          if (4 * hb + u < ch.nv) {
+            const uint32_t boff = ch.boff0 + (uint32_t)(4 * hb + u), fp = fpv[u]; const bool isF = fF[u]; const unsigned long long v1 = kv[u], alt = al[u];
+            const uint32_t mine = (fp << BL_OFFBITS) | boff;
+            uint32_t idx = ix[u], cur = cu[u], probes = 0;
+            while (true) {
+              if (cur == BL_EMPTY) { cur = dev_atomic_cas32(&tab[idx], BL_EMPTY, mine); if (cur == BL_EMPTY) break; }
+              if ((cur >> BL_OFFBITS) == fp) {
+                const unsigned long long v2 = bl_kmer(S.bases, cur & BL_OFFMASK, kmask);
+                if (v2 == v1 || v2 == alt) {
+                  const bool f2 = (v2 == v1) ? isF : !isF;
+                  if (mine < cur) dev_atomic_min(&tab[idx], mine);
+                  // Scheduling hint (PreHdr::heavy).  All reads are in reference orientation and the loop over k only builds at a k
+                  // above the window reference's longest repeat, so a node normally meets its k-mer once per read and always in the
+                  // same orientation.  The same k-mer twice in one read (a duplication in the sample), or in both orientations (an
+                  // inverted repeat, which isRepeat does not look for), means a walk comes back to the node: if that node survives
+                  // removeLowCov the graph has a cycle and this k is rejected (Microassembler.cc:198-206).  The occurrence is noted
+                  // here and looked at again once the survivors are known.
+                  if (cur != mine && ((f2 != isF) || (r < nr && (cur & BL_OFFMASK) - rb < (uint32_t)ch.tlen))) {
+                    const uint32_t di = dev_atomic_add((LC_LDS uint32_t *)&S.ndup, 1u);
+                    if (di < BL_DUPCAP) X.dupo[di] = (bl_off_t)boff;
+                  }
+                  break;
+                }
+              }
+              idx = (idx + 1) & (nslots - 1);
+              if (++probes > 256u) { S.why = BLW_TABLE; break; }
+              cur = ld2(&tab[idx]);
+            }
+            sw[u] = idx | (isF ? 0u : ON_ORI);
+          }
+        }
+        // the batch's four words (table slot | orientation) in one store; a word past the read's last k-mer is 0
+#if BL_WIDE
+        { lc_u4 qv4; qv4.x = sw[0]; qv4.y = sw[1]; qv4.z = sw[2]; qv4.w = sw[3]; stg4((LC_GLOBAL uint32_t *)(X.occn + ch.boff0 + 4u * (uint32_t)hb), qv4); }
+#else
+        stg2((LC_GLOBAL uint32_t *)(X.occn + ch.boff0 + 4u * (uint32_t)hb), sw[0] | (sw[1] << 16), sw[2] | (sw[3] << 16));
+#endif
       }
     }
   }
@@ -965,54 +1043,59 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   // The general form (k-mers of NW <= BL_KW words): the same probe; only offsets, table positions and fingerprints are kept per occurrence in
   // flight -- on a fingerprint hit both k-mers are cut out of LDS again and compared word by word.
   WG_FOR(_t, BL_WG) {
-    const int O_ = (int)S.O;
-    for (int o0 = _t; o0 < O_; o0 += BL_INS * BL_WG) {
-      int rr[BL_INS]; uint32_t bo[BL_INS], ix[BL_INS], fpv[BL_INS], cu[BL_INS]; bool fF[BL_INS];
-      for (int u = 0; u < BL_INS; ++u) {
-        const int o = o0 + u * BL_WG;
-        const int oc = o < O_ ? o : O_ - 1;
-        uint32_t rc = S.o2r[oc >> 7];
-        while ((uint32_t)oc >= S.obase[rc + 1]) ++rc;
-        rr[u] = o < O_ ? (int)rc : -1; bo[u] = 16u * S.rdo[rc] + (uint32_t)(oc - (int)S.obase[rc]);
-      }
-      for (int u = 0; u < BL_INS; ++u) {
-        BlKm v, ck, alt; bl_kmer_x(S.bases, bo[u], NW, K, v); bl_canon_x(v, NW, K, ck, alt, &fF[u]);
-        unsigned long long acc = ck.w[0];
-        for (int i = 1; i < BL_KW; ++i) if (i < NW) acc = (acc ^ (acc >> 29)) * 0x9E3779B97F4A7C15ULL + ck.w[i];
-        uint32_t hh = (uint32_t)acc * 0x9E3779B1u ^ (((uint32_t)(acc >> 32)) ^ ((uint32_t)acc >> 15)) * 0x85EBCA77u;
-        hh ^= hh >> 15; hh *= 0x2C1B3C6Du; hh ^= hh >> 12;
-        ix[u] = hh & (nslots - 1);
-        uint32_t fp = hh >> BL_OFFBITS; if (fp == (0xFFFFFFFFu >> BL_OFFBITS)) fp -= 1u;
-        fpv[u] = fp;
-      }
-      for (int u = 0; u < BL_INS; ++u) cu[u] = ld2(&tab[ix[u]]);
-      for (int u = 0; u < BL_INS; ++u) {
-        if (rr[u] < 0) continue;
-        const int r = rr[u]; const uint32_t boff = bo[u], fp = fpv[u]; const bool isF = fF[u];
-        const uint32_t mine = (fp << BL_OFFBITS) | boff;
-        uint32_t idx = ix[u], cur = cu[u], probes = 0;
-        bool have = false; BlKm v1, alt;
-        while (true) {
-          if (cur == BL_EMPTY) { cur = dev_atomic_cas32(&tab[idx], BL_EMPTY, mine); if (cur == BL_EMPTY) break; }
-          if ((cur >> BL_OFFBITS) == fp) {
-            if (!have) { BlKm ck; bool f; bl_kmer_x(S.bases, boff, NW, K, v1); bl_canon_x(v1, NW, K, ck, alt, &f); have = true; }
-            BlKm v2; bl_kmer_x(S.bases, cur & BL_OFFMASK, NW, K, v2);
-            const bool same = bl_km_eq(v2, v1);
-            if (same || bl_km_eq(v2, alt)) {
-              const bool f2 = same ? isF : !isF;
-              if (mine < cur) dev_atomic_min(&tab[idx], mine);
-              if (cur != mine && ((f2 != isF) || (r < nr && (cur & BL_OFFMASK) - 16u * S.rdo[r] < (uint32_t)RI_TLEN(S.rinfo[r])))) {     // (the hint: see the one-word form)
-                const uint32_t di = dev_atomic_add((LC_LDS uint32_t *)&S.ndup, 1u);
-                if (di < BL_DUPCAP) X.dupo[di] = (bl_off_t)boff;
-              }
-              break;
-            }
-          }
-          idx = (idx + 1) & (nslots - 1);
-          if (++probes > 256u) { S.why = BLW_TABLE; break; }
-          cur = ld2(&tab[idx]);
+    for (int q = _t; q < NC; q += BL_WG) {
+      BlChunk ch; bl_chunk(S, q, nr, reflen, K, ch);
+      const int r = ch.r; const uint32_t rb = ch.boff0 - (uint32_t)ch.p0;
+      for (int hb = 0; hb < 2; ++hb) {
+        if (4 * hb >= ch.nv) break;
+        uint32_t ix[BL_INS], fpv[BL_INS], cu[BL_INS], sw[BL_INS]; bool fF[BL_INS];
+        for (int u = 0; u < BL_INS; ++u) {
+          const int jj = 4 * hb + u < ch.nv ? 4 * hb + u : ch.nv - 1;      // (clamped: a k-mer past the read's end is not cut out)
+          BlKm v, ck, alt; bl_kmer_x(S.bases, ch.boff0 + (uint32_t)jj, NW, K, v); bl_canon_x(v, NW, K, ck, alt, &fF[u]);
+          unsigned long long acc = ck.w[0];
+          for (int i = 1; i < BL_KW; ++i) if (i < NW) acc = (acc ^ (acc >> 29)) * 0x9E3779B97F4A7C15ULL + ck.w[i];
+          uint32_t hh = (uint32_t)acc * 0x9E3779B1u ^ (((uint32_t)(acc >> 32)) ^ ((uint32_t)acc >> 15)) * 0x85EBCA77u;
+          hh ^= hh >> 15; hh *= 0x2C1B3C6Du; hh ^= hh >> 12;
+          ix[u] = hh & (nslots - 1);
+          uint32_t fp = hh >> BL_OFFBITS; if (fp == (0xFFFFFFFFu >> BL_OFFBITS)) fp -= 1u;
+          fpv[u] = fp;
         }
-        X.occn[boff] = (bl_on_t)(idx | (isF ? 0u : ON_ORI));
+        for (int u = 0; u < BL_INS; ++u) cu[u] = ld2(&tab[ix[u]]);
+        for (int u = 0; u < BL_INS; ++u) {
+          sw[u] = 0;
+          if (4 * hb + u < ch.nv) {
+          const uint32_t boff = ch.boff0 + (uint32_t)(4 * hb + u), fp = fpv[u]; const bool isF = fF[u];
+          const uint32_t mine = (fp << BL_OFFBITS) | boff;
+          uint32_t idx = ix[u], cur = cu[u], probes = 0;
+          bool have = false; BlKm v1, alt;
+          while (true) {
+            if (cur == BL_EMPTY) { cur = dev_atomic_cas32(&tab[idx], BL_EMPTY, mine); if (cur == BL_EMPTY) break; }
+            if ((cur >> BL_OFFBITS) == fp) {
+              if (!have) { BlKm ck; bool f; bl_kmer_x(S.bases, boff, NW, K, v1); bl_canon_x(v1, NW, K, ck, alt, &f); have = true; }
+              BlKm v2; bl_kmer_x(S.bases, cur & BL_OFFMASK, NW, K, v2);
+              const bool same = bl_km_eq(v2, v1);
+              if (same || bl_km_eq(v2, alt)) {
+                const bool f2 = same ? isF : !isF;
+                if (mine < cur) dev_atomic_min(&tab[idx], mine);
+                if (cur != mine && ((f2 != isF) || (r < nr && (cur & BL_OFFMASK) - rb < (uint32_t)ch.tlen))) {     // (the hint: see the one-word form)
+                  const uint32_t di = dev_atomic_add((LC_LDS uint32_t *)&S.ndup, 1u);
+                  if (di < BL_DUPCAP) X.dupo[di] = (bl_off_t)boff;
+                }
+                break;
+              }
+            }
+            idx = (idx + 1) & (nslots - 1);
+            if (++probes > 256u) { S.why = BLW_TABLE; break; }
+            cur = ld2(&tab[idx]);
+          }
+          sw[u] = idx | (isF ? 0u : ON_ORI);
+          }
+        }
+#if BL_WIDE
+        { lc_u4 q; q.x = sw[0]; q.y = sw[1]; q.z = sw[2]; q.w = sw[3]; stg4((LC_GLOBAL uint32_t *)(X.occn + ch.boff0 + 4u * (uint32_t)hb), q); }
+#else
+        stg2((LC_GLOBAL uint32_t *)(X.occn + ch.boff0 + 4u * (uint32_t)hb), sw[0] | (sw[1] << 16), sw[2] | (sw[3] << 16));
+#endif
       }
     }
   }
@@ -1055,11 +1138,20 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   BLP(S, 6);
   if (C->debug_stop == 106u) { WG_LANE0 { H->why = 99; } return; }
   // ---- pass 2: slot -> node id per occurrence (HBM, streamed), occurrences per node
-  bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
-    (void)r; (void)p;
-    const uint32_t old = dev_atomic_add(&tab[e & (nslots - 1)], 1u << 16);
-    if (BL_BASES > 65535u && (old >> 16) >= 0xFFFEu) S.why = BLW_SIZE;       // (a k-mer with 65 535 occurrences -- reads that are one long repeat, by the hundred -- would wrap the 16-bit counts: the general build's)
-    X.occn[boff] = (bl_on_t)((old & 0xFFFFu) | (e & ON_ORI));
+  // (the eight atomics of a chunk are issued together -- a word past the read's last k-mer adds 0 to slot 0 -- and waited for once)
+  bl_for_chunk(S, X.occn, [&](const BlChunk &ch, const BlOccW &w) {
+    uint32_t old[8];
+    BL_UNROLL for (int j = 0; j < 8; ++j) {
+      const bool act = j < ch.nv;
+      const uint32_t e = bl_occw_get(w, j);
+      old[j] = dev_atomic_add(&tab[act ? (e & (nslots - 1)) : 0u], act ? (1u << 16) : 0u);
+    }
+    BlOccW o = {};
+    BL_UNROLL for (int j = 0; j < 8; ++j) {
+      if (BL_BASES > 65535u && j < ch.nv && (old[j] >> 16) >= 0xFFFEu) S.why = BLW_SIZE;       // (a k-mer with 65 535 occurrences -- reads that are one long repeat, by the hundred -- would wrap the 16-bit counts: the general build's)
+      bl_occw_set(o, j, j < ch.nv ? ((old[j] & 0xFFFFu) | (bl_occw_get(w, j) & ON_ORI)) : 0u);
+    }
+    bl_occw_store(X.occn, ch.boff0, o);
   });
   WG_SYNC();
   if (BL_BASES > 65535u) { if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; } }
@@ -1124,43 +1216,65 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_FOR(t, T * SW) { sig[t] = 0; }
     WG_FOR(i, 64) { mk[i] = 0; }
     WG_SYNC();
-    bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
-      (void)boff;
+    bl_for_chunk(S, X.occn, [&](const BlChunk &ch, const BlOccW &w) {
+      const int r = ch.r;
       if (r == nr) return;                                         // the reference read: no colour, never counted (Graph.cc:265)
-      const uint32_t ti = S.cidx[e & ON_ID];
-      if (ti == 0xFFFFu) return;
       const uint32_t ri = S.rinfo[r];
-      const uint32_t cls = (RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u);
-      dev_atomic_add64(&cc[ti], 1ULL << (16 * cls));
-      if (RI_NML(ri)) { if (!(S.t2c[ti] & 2u)) dev_atomic_or((LC_LDS uint32_t *)&S.t2c[ti & ~1u], (ti & 1u) ? (2u << 16) : 2u); }
-      else if (!(S.t2c[ti] & 1u)) {
-        const int tlen = (int)RI_TLEN(ri);
-        const uint32_t gw = S.gwo[r];
-        // the step's u and v both pass MIN_QUAL_CALL at every base: bases s..s+K of the read, for step s = p or p - 1
-        const bool ok = (p < tlen - K && bl_all_good(S.goodm, gw, p, p + K + 1)) || (p - 1 >= 0 && p - 1 < tlen - K && bl_all_good(S.goodm, gw, p - 1, p + K));
-        if (ok) dev_atomic_or((LC_LDS uint32_t *)&S.t2c[ti & ~1u], (ti & 1u) ? (1u << 16) : 1u);
+      const bool nml = RI_NML(ri) != 0;
+      const unsigned long long inc = 1ULL << (16u * ((nml ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u)));
+      const int tlen = ch.tlen;
+      const bool early = S.prole[r] == 1; const uint32_t px = S.pidx[r];
+      // tumor reads: "the step's u and v both pass MIN_QUAL_CALL at every base" needs the bases s..s+K of the read, for step s = p or p - 1:
+      // the mask bits from position p0 - 1 on (bit 0 = position p0 - 1; p0 = 0: bit 0 is not a base), 1 + 8 + K <= 40 of them for k <= 31
+      const bool fastq = !nml && K <= 31;
+      const unsigned long long gq = fastq ? (ch.p0 > 0 ? bl_good64(S.goodm, S.gwo[r], ch.p0 - 1) : (bl_good64(S.goodm, S.gwo[r], 0) << 1)) : 0ULL;
+      const unsigned long long need = K <= 31 ? (1ULL << (K + 1)) - 1ULL : 0ULL;
+      // eight look-ups in flight, then the atomics: a wave spends most of its time waiting for LDS round trips (profiles/r5_sq_counters.txt),
+      // and one occurrence after the other is two dependent round trips each (node -> tracked index -> colour flags)
+      uint32_t ti[8], t2[8];
+      BL_UNROLL for (int j = 0; j < 8; ++j) ti[j] = S.cidx[bl_occw_get(w, j) & ON_ID];       // (a word past the read's last k-mer is 0: node 0)
+      BL_UNROLL for (int j = 0; j < 8; ++j) { if (j >= ch.nv) ti[j] = 0xFFFFu; t2[j] = S.t2c[ti[j] != 0xFFFFu ? ti[j] : 0u]; }
+      BL_UNROLL for (int j = 0; j < 8; ++j) {
+        if (ti[j] == 0xFFFFu) continue;
+        const int p = ch.p0 + j;
+        dev_atomic_add64(&cc[ti[j]], inc);
+        if (nml) { if (!(t2[j] & 2u)) dev_atomic_or((LC_LDS uint32_t *)&S.t2c[ti[j] & ~1u], (ti[j] & 1u) ? (2u << 16) : 2u); }
+        else if (!(t2[j] & 1u)) {
+          bool ok;
+          if (fastq) ok = (p < tlen - K && ((gq >> (j + 1)) & need) == need) || (p - 1 >= 0 && p - 1 < tlen - K && ((gq >> j) & need) == need);
+          else { const uint32_t gw = S.gwo[r];
+                 ok = (p < tlen - K && bl_all_good(S.goodm, gw, p, p + K + 1)) || (p - 1 >= 0 && p - 1 < tlen - K && bl_all_good(S.goodm, gw, p - 1, p + K)); }
+          if (ok) dev_atomic_or((LC_LDS uint32_t *)&S.t2c[ti[j] & ~1u], (ti[j] & 1u) ? (1u << 16) : 1u);
+        }
+        if (early) dev_atomic_or64(&sig[ti[j] * SW + (px >> 6)], 1ULL << (px & 63u));
       }
-      if (S.prole[r] == 1) dev_atomic_or64(&sig[ti * SW + (S.pidx[r] >> 6)], 1ULL << (S.pidx[r] & 63u));
     });
     WG_SYNC();
     if (C->debug_stop == 120u) { WG_LANE0 { H->why = 99; } return; }
     // the later mates: an occurrence on a node that also holds one of the earlier mate can be an "overlapping mate"
     // (Node_t::hasOverlappingMate, src/Node.cc:638-661: a hit needs the name to BE in the other mate's vector); these are replayed
-    if (npairs) bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
-      (void)boff;
-      if (S.prole[r] != 2) return;
-      const uint32_t ti = S.cidx[e & ON_ID];
-      if (ti != 0xFFFFu && ((sig[ti * SW + (S.pidx[r] >> 6)] >> (S.pidx[r] & 63u)) & 1ULL)) {
-        const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.flagged, 1u);
-        if (at < BL_FLAGCAP) todo[at] = ((uint32_t)r << 10) | (uint32_t)p;
-        dev_atomic_or(&mk[ti >> 5], 1u << (ti & 31u));
+    if (npairs) bl_for_chunk(S, X.occn, [&](const BlChunk &ch, const BlOccW &w) {
+      const int r = ch.r;
+      if (S.prole[r] != 2) return;                                 // (only the later mate of a pair can meet its earlier mate's pushes)
+      const uint32_t px = S.pidx[r];
+      uint32_t ti[8]; unsigned long long sg[8];
+      BL_UNROLL for (int j = 0; j < 8; ++j) ti[j] = S.cidx[bl_occw_get(w, j) & ON_ID];
+      BL_UNROLL for (int j = 0; j < 8; ++j) { if (j >= ch.nv) ti[j] = 0xFFFFu; sg[j] = sig[(ti[j] != 0xFFFFu ? ti[j] : 0u) * SW + (px >> 6)]; }
+      BL_UNROLL for (int j = 0; j < 8; ++j) {
+        if (ti[j] != 0xFFFFu && ((sg[j] >> (px & 63u)) & 1ULL)) {
+          const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.flagged, 1u);
+          if (at < BL_FLAGCAP) todo[at] = ((uint32_t)r << 10) | (uint32_t)(ch.p0 + j);
+          dev_atomic_or(&mk[ti[j] >> 5], 1u << (ti[j] & 31u));
+        }
       }
     });
     if (C->debug_stop == 121u) { WG_LANE0 { H->why = 99; } return; }
     WG_SYNC();                                                     // (every wave's flagged occurrences are counted before lane 0 looks)
     WG_LANE0 { if (S.flagged > BL_FLAGCAP) { S.why = BLW_MATE; BL_DBG("[emu] window %d: %u flagged mate occurrences (%u)\n", w, S.flagged, (uint32_t)BL_FLAGCAP); } }
-    if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
-    const uint32_t nflag = bl_bcast(&S.flagged);
+    WG_SYNC();
+    const int why_f = lc_sgpr((int)S.why); const uint32_t nflag = lc_sgpr((uint32_t)S.flagged);
+    WG_SYNC();
+    if (why_f) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
     if (nflag) {
       // ---- exact replay (kernels.h build_csr): std::binary_search over the names the OTHER mate number pushed on the node before
       //      this read, in push order (unsorted: SURVEY.md H3).  The occurrences of the marked nodes are listed as
@@ -1342,22 +1456,45 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
           if (ci >= c0 && ci < c1) count_occ((int)(v & 0x3FFu), (int)((v >> 10) & 0x3FFu), ci, (v >> 31) != 0);
         }
       } else
-      bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
-        (void)boff;
+      bl_for_chunk(S, X.occn, [&](const BlChunk &ch, const BlOccW &w) {
+        const int r = ch.r;
         if (r == nr) return;
-        if (e & ON_OVL) return;                                     // an overlapping mate's occurrence: not counted
-        const uint32_t ti = S.cidx[e & ON_ID];
-        if (ti == 0xFFFFu) return;
-        const uint32_t ci = S.t2c[ti];
-        if (ci == 0xFFFFu) return;                                   // not a candidate
-        if (ci >= c1 && c0 == 0) {                                   // a later group's: note it
-          if (p > 1023 || r > 1023) { S.g1 = BL_PQCAP + 1u; return; }     // (does not fit an entry: the later groups walk everything)
-          const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.g1, 1u);
-          if (at < BL_PQCAP) X.pq[at] = (uint32_t)r | ((uint32_t)p << 10) | (ci << 20) | ((e & ON_ORI) ? 0x80000000u : 0u);
-          return;
+        const uint32_t ri = S.rinfo[r];
+        const uint32_t cls = (RI_NML(ri) ? 2u : 0u) + (RI_REV(ri) ? 1u : 0u);
+        // the bases of the chunk's k-mers below MIN_QUAL_CALL: bit i = read position p0 + i (8 + K - 1 <= 38 of them for k <= 31)
+        const bool fastq = K <= 31;
+        const unsigned long long bq = fastq ? ~bl_good64(S.goodm, S.gwo[r], ch.p0) : 0ULL;
+        const uint32_t km = fastq ? (uint32_t)((1ULL << K) - 1ULL) : 0u;
+        // eight look-ups in flight (node -> tracked index, then -> candidate); an occurrence none of whose bases is below the threshold has
+        // nothing to count and is not looked up at all (k = 13 at 7 % low-quality bases: 4 of 10)
+        uint32_t ti[8], ci[8], mm[8];
+        BL_UNROLL for (int j = 0; j < 8; ++j) {
+          const uint32_t e = bl_occw_get(w, j);
+          mm[j] = fastq ? ((uint32_t)(bq >> j) & km) : 1u;             // bit i: base i of this k-mer (as the read has it) is below the threshold
+          if (j >= ch.nv || (e & ON_OVL)) mm[j] = 0;                   // (an overlapping mate's occurrence: not counted)
+          ti[j] = S.cidx[e & ON_ID];
         }
-        if (ci < c0 || ci >= c1) return;
-        count_occ(r, p, ci, (e & ON_ORI) != 0);
+        BL_UNROLL for (int j = 0; j < 8; ++j) { if (!mm[j]) ti[j] = 0xFFFFu; ci[j] = S.t2c[ti[j] != 0xFFFFu ? ti[j] : 0u]; }
+        BL_UNROLL for (int j = 0; j < 8; ++j) {
+          if (ti[j] == 0xFFFFu || ci[j] == 0xFFFFu) continue;         // not tracked / not a candidate
+          const int p = ch.p0 + j; const uint32_t e = bl_occw_get(w, j);
+          if (ci[j] >= c1 && c0 == 0) {                                // a later group's: note it
+            if (p > 1023 || r > 1023) { S.g1 = BL_PQCAP + 1u; continue; }     // (does not fit an entry: the later groups walk everything)
+            const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.g1, 1u);
+            if (at < BL_PQCAP) X.pq[at] = (uint32_t)r | ((uint32_t)p << 10) | (ci[j] << 20) | ((e & ON_ORI) ? 0x80000000u : 0u);
+            continue;
+          }
+          if (ci[j] < c0 || ci[j] >= c1) continue;
+          if (!fastq) { count_occ(r, p, ci[j], (e & ON_ORI) != 0); continue; }
+          uint32_t m = mm[j];
+          const uint32_t base = (ci[j] - c0) * (uint32_t)K; const bool rev = (e & ON_ORI) != 0;
+          while (m) {
+            const int jb = (int)__builtin_ctz(m); m &= m - 1u;
+            const uint32_t i = (uint32_t)(rev ? K - 1 - jb : jb);
+            if (wide) dev_atomic_add64(&bad64[base + i], 1ULL << (16 * cls));
+            else dev_atomic_add(&bad32[base + i], 1u << (8 * cls));
+          }
+        }
       });
       WG_SYNC();
       auto bad_of = [&](uint32_t t, int cl) -> uint32_t { return wide ? (uint32_t)((bad64[t] >> (16 * cl)) & 0xFFFFu) : ((bad32[t] >> (8 * cl)) & 0xFFu); };
@@ -1508,21 +1645,31 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       const uint32_t s1 = s0 + gmax < nsurv ? s0 + gmax : nsurv;
       WG_FOR(i, (s1 - s0) * 8u) { E[i] = LC_NIL; }
       WG_SYNC();
-      bl_for_occ(S, X.occn, [&](int r, int p, uint32_t boff, uint32_t e) {
-        const uint32_t si = S.cidx[e & ON_ID];
-        if (si < s0 || si >= s1) return;
-        const uint32_t ori = (e >> ON_ORISH) & 1u;
-        const int tlen = r < nr ? (int)RI_TLEN(S.rinfo[r]) : reflen;
-        const int nk = tlen - K + 1;
-        if (p + 1 < nk) {                                            // step p: this node is u
-          const int b = bl_base(S.bases, boff + (uint32_t)K);
-          const uint32_t sl = (ori == 0 ? 0u : 4u) + (uint32_t)(ori == 0 ? b : 3 - b);
-          dev_atomic_min(&E[(si - s0) * 8u + sl], 2u * boff);
-        }
-        if (p > 0) {                                                 // step p-1: this node is v
-          const int b = bl_base(S.bases, boff - 1u);
-          const uint32_t sl = (ori == 0 ? 4u : 0u) + (uint32_t)(ori == 0 ? b : 3 - b);
-          dev_atomic_min(&E[(si - s0) * 8u + sl], 2u * (boff - 1u) + 1u);
+      bl_for_chunk(S, X.occn, [&](const BlChunk &ch, const BlOccW &w) {
+        const int nk = ch.tlen - K + 1;
+        // the extension bases out of the chunk's own words (k <= 31): base i of the chunk at bits 2i of (lo, hi); the base in front of the
+        // chunk's first k-mer is read on its own
+        const bool fastb = K <= 31;
+        unsigned long long lo = 0, hi = 0;
+        if (fastb) bl_chunk_bases(S.bases, (int)(ch.boff0 >> 3), lo, hi);
+        uint32_t sv[8];
+        BL_UNROLL for (int j = 0; j < 8; ++j) sv[j] = S.cidx[bl_occw_get(w, j) & ON_ID];
+        BL_UNROLL for (int j = 0; j < 8; ++j) {
+          const uint32_t si = sv[j];
+          if (j >= ch.nv || si < s0 || si >= s1) continue;
+          const int p = ch.p0 + j; const uint32_t boff = ch.boff0 + (uint32_t)j;
+          const uint32_t ori = (bl_occw_get(w, j) >> ON_ORISH) & 1u;
+          if (p + 1 < nk) {                                            // step p: this node is u
+            const int i = j + K;
+            const int b = fastb ? (int)((i < 32 ? (lo >> (2 * i)) : (hi >> (2 * i - 64))) & 3ULL) : bl_base(S.bases, boff + (uint32_t)K);
+            const uint32_t sl = (ori == 0 ? 0u : 4u) + (uint32_t)(ori == 0 ? b : 3 - b);
+            dev_atomic_min(&E[(si - s0) * 8u + sl], 2u * boff);
+          }
+          if (p > 0) {                                                 // step p-1: this node is v
+            const int b = (fastb && j > 0) ? (int)((lo >> (2 * (j - 1))) & 3ULL) : bl_base(S.bases, boff - 1u);
+            const uint32_t sl = (ori == 0 ? 4u : 0u) + (uint32_t)(ori == 0 ? b : 3 - b);
+            dev_atomic_min(&E[(si - s0) * 8u + sl], 2u * (boff - 1u) + 1u);
+          }
         }
       });
       WG_SYNC();
@@ -1564,6 +1711,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     }
   }
   BLP(S, 15);
+  BL_TAIL_PRIO_SET(BL_TAIL_PRIO);
   // ---- libstdc++ iteration order of the node table after the N inserts (kernels.h first_lowcov / order_stage),
   //      reduced to the survivors (cleanDead), and markConnectedComponents over them -- all in LDS: the reads are done with, the
   //      whole arena from S.bases to the end of S.big is laid out anew.  Tables of more than 4096 nodes: the 1024-lane configuration, whose
@@ -1634,31 +1782,47 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     }
     LC_LDS uint16_t *Q = Qa, *Qn = Qb;
     uint32_t nprev = SEQ, B = SEQ;
-    if (N > SEQ && !wide_tab) while (true) {
-      B = ht_next_prime(2u * B);
-      const uint32_t n = N < B ? N : B;
-      WG_FOR(j, n - nprev) { Q[nprev + (uint32_t)j] = (uint16_t)(nprev + (uint32_t)j); }
-      WG_FOR(b, B) { first[b] = LC_NIL; }
-      WG_FOR(i, n + 1) { tmp[i] = 0; }
-      WG_SYNC();
-      WG_FOR(i, n) { const uint32_t b = ht_mod(nhash[Q[i]], B); bkt[i] = (uint16_t)b; dev_atomic_min(&first[b], (uint32_t)i); }
-      WG_SYNC();
-      WG_FOR(i, n) { dev_atomic_add(&tmp[n - 1 - first[bkt[i]]], 1u); }      // elements per run, runs indexed by their first position, latest first
-      bl_scan32(tmp, (int)n, S);
-      WG_FOR(i, n) { const uint32_t at = dev_atomic_add(&tmp[n - 1 - first[bkt[i]]], 1u); out[at] = (uint16_t)i; }
-      WG_SYNC();
-      WG_FOR(x, n) {                                                          // inside a run: latest first
-        if (x > 0 && bkt[out[x - 1]] == bkt[out[x]]) continue;
-        const uint32_t b = bkt[out[x]];
-        uint32_t e = (uint32_t)x + 1; while (e < n && bkt[out[e]] == b) ++e;
-        for (uint32_t i = (uint32_t)x + 1; i < e; ++i) { const uint16_t v = out[i]; uint32_t j = i; while (j > (uint32_t)x && out[j - 1] < v) { out[j] = out[j - 1]; --j; } out[j] = v; }
+    // Six barriers per growth stage (eight until round 5 -- these stages are barriers with little work between them, ~100 of a window's ~300):
+    // the bucket minima carry a stamp that falls from stage to stage above the position, so that a stage's atomicMin overrides what the
+    // stages before left and `first` is cleared once, not per stage; the stage's last pass -- the lane at the head of a run orders the run
+    // and moves its nodes into the other order array -- also clears the run counters and appends the next stage's new nodes.
+    if (N > SEQ && !wide_tab) {
+      {
+        const uint32_t B1 = ht_next_prime(2u * SEQ), n1 = N < B1 ? N : B1;
+        WG_FOR(b, 5120) { first[b] = LC_NIL; }
+        WG_FOR(i, n1 + 1) { tmp[i] = 0; }
+        WG_FOR(j, n1 - SEQ) { Q[SEQ + (uint32_t)j] = (uint16_t)(SEQ + (uint32_t)j); }
+        WG_SYNC();
       }
-      WG_SYNC();
-      WG_FOR(j, n) { Qn[j] = Q[out[j]]; }
-      WG_SYNC();
-      { LC_LDS uint16_t *t = Q; Q = Qn; Qn = t; }
-      if (N <= B) break;
-      nprev = B;
+      uint32_t stamp = 0xFFFEu;
+      while (true) {
+        B = ht_next_prime(2u * B);
+        const uint32_t n = N < B ? N : B;
+        const uint32_t st = stamp << 16; --stamp;
+        WG_FOR(i, n) { const uint32_t b = ht_mod(nhash[Q[i]], B); bkt[i] = (uint16_t)b; dev_atomic_min(&first[b], st | (uint32_t)i); }
+        WG_SYNC();
+        WG_FOR(i, n) { dev_atomic_add(&tmp[n - 1 - (first[bkt[i]] & 0xFFFFu)], 1u); }      // elements per run, runs indexed by their first position, latest first
+        bl_scan32(tmp, (int)n, S);
+        WG_FOR(i, n) { const uint32_t at = dev_atomic_add(&tmp[n - 1 - (first[bkt[i]] & 0xFFFFu)], 1u); out[at] = (uint16_t)i; }
+        WG_SYNC();
+        const bool last = N <= B;
+        const uint32_t Bn = ht_next_prime(2u * B), nn = N < Bn ? N : Bn;
+        WG_FOR(x, n) {                                                          // inside a run: latest first; then the run's nodes into the other array
+          if (x > 0 && bkt[out[x - 1]] == bkt[out[x]]) continue;
+          const uint32_t b = bkt[out[x]];
+          uint32_t e = (uint32_t)x + 1; while (e < n && bkt[out[e]] == b) ++e;
+          for (uint32_t i = (uint32_t)x + 1; i < e; ++i) { const uint16_t v = out[i]; uint32_t j = i; while (j > (uint32_t)x && out[j - 1] < v) { out[j] = out[j - 1]; --j; } out[j] = v; }
+          for (uint32_t i = (uint32_t)x; i < e; ++i) Qn[i] = Q[out[i]];
+        }
+        if (!last) {
+          WG_FOR(i, nn + 1) { tmp[i] = 0; }
+          WG_FOR(j, nn - n) { Qn[n + (uint32_t)j] = (uint16_t)(n + (uint32_t)j); }
+        }
+        WG_SYNC();
+        { LC_LDS uint16_t *t = Q; Q = Qn; Qn = t; }
+        if (last) break;
+        nprev = B;
+      }
     }
 #if BL_WIDE
     // the same stages for a table of up to BL_NCAP nodes (bucket counts up to 20 753): first / run counters as 16-bit halves of LDS words
@@ -1701,6 +1865,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_SYNC();
     // ---- markConnectedComponents (Graph.cc:2252-2336): min-label hooking + pointer jumping over the survivors' positions; the label of a
     //      component is the position of its first node in table order, which is also what numbers the components
+    BLPA(S, 14);                                                             // (profiling builds: the components apart from the table order)
     LC_LDS uint32_t *parent = tmpP;                                          // [nsurv]
     LC_LDS uint32_t *touch = tmpP + 2052;                                    // [nsurv] bit 0: component holds a reference k-mer ; later: component number
     LC_LDS uint16_t *adj = adjP;                                             // [nsurv * 8] neighbours as positions (small tables: Qa .. out, 32 KB)
@@ -1712,26 +1877,26 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_SYNC();
     // (a round = one hooking pass + three pointer-jumping passes, one barrier each, then ONE look at the change flag: testing
     //  for convergence after every pass cost two more barriers of the 512-lane workgroup per pass, and these passes do little
-    //  else than wait at barriers.  A round that changed nothing leaves every parent a root with no smaller neighbour label.)
-    WG_LANE0 { S.flagged = 0; }
-    WG_SYNC();
-    while (true) {
+    //  else than wait at barriers.  A round that changed nothing leaves every parent a root with no smaller neighbour label.
+    //  Two change flags taken in turn -- S.flagged / S.ndup, both idle here -- so that a round is its four barriers and nothing else: the
+    //  flag of the round after is cleared by lane 0 in this round's last pass, and every lane looks at this round's flag behind the last barrier.)
+    WG_LANE0 { S.flagged = 0; S.ndup = 0; }
+    for (int round = 0; ; ++round) {
+      LC_LDS uint32_t *flag = (round & 1) ? (LC_LDS uint32_t *)&S.ndup : (LC_LDS uint32_t *)&S.flagged;
+      LC_LDS uint32_t *other = (round & 1) ? (LC_LDS uint32_t *)&S.flagged : (LC_LDS uint32_t *)&S.ndup;
       WG_FOR(u, nsurv) {
         const uint32_t pu = ld2(&parent[u]);
         uint32_t m = pu;
         for (int e = 0; e < 8; ++e) { const uint32_t pv = ld2(&parent[adj[8 * (uint32_t)u + (uint32_t)e]]); if (pv < m) m = pv; }
-        if (m < pu) { dev_atomic_min(&parent[pu], m); dev_atomic_min(&parent[u], m); S.flagged = 1; }
+        if (m < pu) { dev_atomic_min(&parent[pu], m); dev_atomic_min(&parent[u], m); *flag = 1; }
       }
       WG_SYNC();
       for (int jp = 0; jp < 3; ++jp) {
-        WG_FOR(u, nsurv) { const uint32_t pu = ld2(&parent[u]), gp = ld2(&parent[pu]); if (gp != pu) { dev_atomic_min(&parent[u], gp); S.flagged = 1; } }
+        WG_FOR(u, nsurv) { const uint32_t pu = ld2(&parent[u]), gp = ld2(&parent[pu]); if (gp != pu) { dev_atomic_min(&parent[u], gp); *flag = 1; } }
+        if (jp == 2) { WG_FOR(z, 1) { *other = 0; } }
         WG_SYNC();
       }
-      const uint32_t changed = S.flagged;                                   // (every lane reads it, then a barrier, then lane 0 clears it)
-      WG_SYNC();
-      if (!changed) break;
-      WG_LANE0 { S.flagged = 0; }
-      WG_SYNC();
+      if (!*(volatile LC_LDS uint32_t *)flag) break;
     }
     WG_FOR(u, nsurv) { if (touch[u] & 1u) dev_atomic_or(&touch[parent[u]], 2u); }
     WG_SYNC();
@@ -1745,13 +1910,17 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_FOR(u, nsurv) { pgr2[pos2si[u]].comp = (int)(num[parent[u]] + 1u); }   // numbered by the position of the component's first node
     WG_LANE0 { H->have_order = 1; H->ht_bc = S.g0; H->ht_next_resize = S.g1; H->numcomp = S.nbw; H->refcomp = S.ngw; }
     WG_SYNC();
+    BLPA(S, 15);
     // ---- the window's first graph with a single component: markRefEnds and the first compress here too (bl_compress_first)
     {
-      const uint32_t hbc = bl_bcast(&S.g0), hnr = bl_bcast(&S.g1), ncomp = bl_bcast(&S.nbw);
+      WG_SYNC();
+      const uint32_t hbc = lc_sgpr((uint32_t)S.g0), hnr = lc_sgpr((uint32_t)S.g1), ncomp = lc_sgpr((uint32_t)S.nbw);
+      WG_SYNC();
       if (!rep && ncomp == 1u && nsurv <= PB_CMAX && nsurv + 2u <= hnr && K <= 31 && !wide_tab && C->debug_stop != 140u)
         bl_compress_first(P, C, S, X, area, K, N, nsurv, ncand, reflen, hbc);
     }
   }
+  BL_TAIL_PRIO_SET(0);
   WG_LANE0 {
     H->K = K; H->refE = S.repE; H->refM = S.repM; H->N = S.N; H->O = S.O; H->totalreadbp = S.totalreadbp; H->n_kmers = S.n_kmers;
     H->ncand = S.ncand; H->nsurv = S.nsurv; H->edges_total = S.edges_total; H->refn = S.refn; H->why = 0; H->heavy = S.hint;

@@ -386,6 +386,10 @@ int lancet_engine_upload(lancet_engine *e, const lancet_window_batch *b) { retur
 // The reads arrive trimmed and packed (lancet_pack_read with THIS engine's parameters: the caller's threads did what the upload's own do
 // from the ASCII arrays); b->seq / qual / label / strand / mate / mapped are not looked at, b->seq_off still gives the untrimmed lengths.
 int lancet_engine_upload_packed(lancet_engine *e, const lancet_window_batch *b, const lancet_packed_reads *pk) {
+  if (e && pk && pk->struct_size != (uint32_t)sizeof(lancet_packed_reads)) {
+    e->err = "lancet_packed_reads: struct_size " + std::to_string(pk->struct_size) + " is not this library's " + std::to_string(sizeof(lancet_packed_reads)) + " (caller built against another header)";
+    return LANCET_E_ARG;
+  }
   if (!e || !pk || !pk->rinfo || !pk->base_woff || !pk->good_woff || !pk->bases || !pk->good) { if (e) e->err = "packed reads missing"; return LANCET_E_ARG; }
   if (!e->host_prep) { e->err = "packed upload with LANCET_PREP=device"; return LANCET_E_STATE; }
   if (pk->min_qual_trim != e->params.min_qual_trim || pk->min_qual_call != e->params.min_qual_call) {

@@ -1279,6 +1279,7 @@ static int host_batch_impl(lancet_host *h, int w_begin, int w_end, const lancet_
     for (int q = 0; q < 4; ++q) pb[bw0[(size_t)nk] + (uint64_t)q] = 0;
     pg[gw0[(size_t)nk]] = 0;
     h->b_rinfo[R] = 0; h->b_bw[R] = (uint32_t)bw0[(size_t)nk]; h->b_gw[R] = (uint32_t)gw0[(size_t)nk];
+    pk->struct_size = (uint32_t)sizeof(lancet_packed_reads); pk->reserved = 0;
     pk->rinfo = h->b_rinfo.data(); pk->base_woff = h->b_bw.data(); pk->good_woff = h->b_gw.data(); pk->bases = pb; pk->good = pg;
     pk->min_qual_trim = P->min_qual_trim; pk->min_qual_call = P->min_qual_call;
   }

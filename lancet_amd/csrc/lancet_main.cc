@@ -217,6 +217,7 @@ int main(int argc, char **argv) {
     const int lo = c * step, hi = lo + step < nwin ? lo + step : nwin;
     Slot &sl = slots[(size_t)c % slots.size()];
     lancet_window_batch B; lancet_packed_reads PK; int32_t nk = 0;
+    memset(&PK, 0, sizeof(PK));
     double t0 = now();
     if (sl.fut.valid() && !finish(sl)) return die(fail);          // its kept[] / engine must be free before they are reused
     if ((packed ? lancet_host_batch_packed(H, lo, hi, &ho, &P, &B, &PK, sl.kept.data(), &nk) : lancet_host_batch(H, lo, hi, &ho, &B, sl.kept.data(), &nk)) != LANCET_OK)

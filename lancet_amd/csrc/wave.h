@@ -100,6 +100,8 @@ typedef uint32_t lc_v4 __attribute__((ext_vector_type(4)));
 // 16-byte load / store through a global pointer (HIP's uint4 has no copy from an address-space reference)
 DEV lc_u4 ldg4(LC_GLOBAL const uint32_t *p) { const lc_v4 t = *(LC_GLOBAL const lc_v4 *)p; lc_u4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w; return r; }
 DEV void stg4(LC_GLOBAL uint32_t *p, const lc_u4 v) { lc_v4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(LC_GLOBAL lc_v4 *)p = t; }
+typedef uint32_t lc_v2 __attribute__((ext_vector_type(2)));
+DEV void stg2(LC_GLOBAL uint32_t *p, uint32_t a, uint32_t b) { lc_v2 t; t.x = a; t.y = b; *(LC_GLOBAL lc_v2 *)p = t; }      // 8-byte store (8-byte aligned)
 DEV int dev_popc(uint32_t x) { return __popc(x); }
 DEV unsigned long long dev_brev64(unsigned long long x) { return __brevll(x); }
 DEV int dev_popcll(unsigned long long x) { return __popcll(x); }
@@ -139,8 +141,9 @@ DEV void dev_sleep() {}
 template <class T> DEV T lc_sgpr(T v) { return v; }
 struct alignas(16) lc_u4 { uint32_t x, y, z, w; };
 typedef lc_u4 lc_v4;
-DEV lc_u4 ldg4(const uint32_t *p) { return *(const lc_u4 *)p; }
-DEV void stg4(uint32_t *p, const lc_u4 v) { *(lc_u4 *)p = v; }
+DEV lc_u4 ldg4(const uint32_t *p) { lc_u4 v; memcpy(&v, p, 16); return v; }
+DEV void stg4(uint32_t *p, const lc_u4 v) { memcpy(p, &v, 16); }
+DEV void stg2(uint32_t *p, uint32_t a, uint32_t b) { memcpy(p, &a, 4); memcpy(p + 1, &b, 4); }
 DEV int dev_popc(uint32_t x) { return __builtin_popcount(x); }
 DEV unsigned long long dev_brev64(unsigned long long x) {
   x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);

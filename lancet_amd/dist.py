@@ -32,6 +32,22 @@ def shard_windows(n_windows: int, rank: int, world: int, chunk: int = 4096) -> L
     return [i for i in range(n_windows) if (i // chunk) % world == rank]
 
 
+def records_in_replay_order(recs: np.ndarray, window_index: Optional[np.ndarray]) -> bool:
+    """The per-key reduction (lancet_vdb_reduce) keeps, per key, the FIRST record and the first of the largest total coverage -- "first"
+    in the order rank 0 will replay them (global window, emission).  It may only run on a rank whose records are already in that order:
+    (window, seq_in_window) non-decreasing in the array, and the local -> global window map strictly increasing.  Otherwise the caller
+    sends every record (rank 0 sorts; reference src/VariantDB.cc:28-91 then sees what one process would have seen)."""
+    if len(recs) > 1:
+        w, q = recs["window"], recs["seq_in_window"]
+        if not bool(np.all((w[1:] > w[:-1]) | ((w[1:] == w[:-1]) & (q[1:] >= q[:-1])))):
+            return False
+    if window_index is not None:
+        wi = np.asarray(window_index, dtype=np.int64)
+        if len(wi) > 1 and not bool(np.all(wi[1:] > wi[:-1])):
+            return False
+    return True
+
+
 def pack_records(vptr, n: int, blob: bytes, lrptr=None, bx_blob=None, bx_names: Optional[Sequence[str]] = None, *,
                  chr_names: Sequence[str], window_index: Optional[np.ndarray] = None, with_keys: bool = True, reduce: bool = True) -> bytes:
     """One rank's records as bytes.  chr_names[chr_id] = the contig names of the rank's batch (required: records carry ids);
@@ -41,14 +57,14 @@ def pack_records(vptr, n: int, blob: bytes, lrptr=None, bx_blob=None, bx_names: 
     if not chr_names:
         raise ValueError("pack_records: chr_names is required")
     keys = b""; keep = None
+    recs = np.frombuffer(C.string_at(vptr, n * _VDT.itemsize), dtype=_VDT).copy() if n else np.zeros(0, dtype=_VDT)
     if with_keys and n:
         from . import engine
         k = engine.record_keys(vptr, n, blob, chr_names)
-        if reduce:
+        if reduce and records_in_replay_order(recs, window_index):
             keep = engine.records_that_matter(vptr, k, n)
             k = np.ascontiguousarray(k[keep])
         keys = k.tobytes()
-    recs = np.frombuffer(C.string_at(vptr, n * _VDT.itemsize), dtype=_VDT).copy() if n else np.zeros(0, dtype=_VDT)
     n_all = n
     if keep is not None:
         recs = np.ascontiguousarray(recs[keep]); n = len(recs)
@@ -100,16 +116,16 @@ def gather_bytes(payload: bytes, device: torch.device, dst: int = 0) -> List[byt
         if len(payload):
             dist.send(torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device), dst=dst)
         return []
-    bufs = [None] * world
-    reqs = []
+    # one receive buffer for all ranks, every irecv posted before any wait, ONE device -> host copy at the end
+    offs = [0] * (world + 1)
     for r in range(world):
-        if r == dst or sizes[r] == 0:
-            continue
-        bufs[r] = torch.empty(sizes[r], dtype=torch.uint8, device=device)
-        reqs.append(dist.irecv(bufs[r], src=r))
+        offs[r + 1] = offs[r] + (0 if r == dst else sizes[r])
+    buf = torch.empty(max(1, offs[world]), dtype=torch.uint8, device=device)
+    reqs = [dist.irecv(buf[offs[r]:offs[r + 1]], src=r) for r in range(world) if r != dst and sizes[r]]
     for q in reqs:
         q.wait()
-    return [payload if r == dst else (bytes(bufs[r].cpu().numpy().tobytes()) if bufs[r] is not None else b"") for r in range(world)]
+    host = buf.cpu().numpy() if offs[world] else np.zeros(0, dtype=np.uint8)
+    return [payload if r == dst else host[offs[r]:offs[r + 1]].tobytes() for r in range(world)]
 
 
 def merge_into_vdb(parts: Sequence[bytes], db) -> int:

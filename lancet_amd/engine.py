@@ -109,9 +109,13 @@ class Engine:
         self._batch = batch
         cb = abi.batch_to_c(batch)
         keep = {k: np.ascontiguousarray(packed[k], dtype=np.uint32) for k in ("rinfo", "base_woff", "good_woff", "bases", "good")}
-        pk = abi.LancetPackedReads(*[keep[k].ctypes.data_as(C.POINTER(C.c_uint32)) for k in ("rinfo", "base_woff", "good_woff", "bases", "good")])
-        # (the thresholds the producer packed with: host.NativeHost.batch records them; a dict without them claims this engine's own)
-        pk.min_qual_trim = int(packed.get("min_qual_trim", self.params.min_qual_trim)); pk.min_qual_call = int(packed.get("min_qual_call", self.params.min_qual_call))
+        pk = abi.LancetPackedReads(C.sizeof(abi.LancetPackedReads), 0, *[keep[k].ctypes.data_as(C.POINTER(C.c_uint32)) for k in ("rinfo", "base_woff", "good_woff", "bases", "good")])
+        # the thresholds the producer packed with (host.NativeHost.batch records them): required -- a dict without them would claim this
+        # engine's own and walk past the C side's check against reads packed with other thresholds
+        for k in ("min_qual_trim", "min_qual_call"):
+            if k not in packed:
+                raise EngineError(f"upload_packed: the packed dict has no '{k}' (the thresholds the reads were trimmed / masked with)")
+        pk.min_qual_trim = int(packed["min_qual_trim"]); pk.min_qual_call = int(packed["min_qual_call"])
         self._packed_keep = keep
         self.L.lancet_engine_upload_packed.restype = C.c_int
         self.L.lancet_engine_upload_packed.argtypes = [C.c_void_p, C.POINTER(abi.LancetWindowBatch), C.POINTER(abi.LancetPackedReads)]

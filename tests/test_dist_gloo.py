@@ -62,11 +62,18 @@ def _worker(rank, world, port, case, q):
             r["window"] = li
             recs.append(r)
     arr, blob, lra, bxb = records_to_c(recs, lr)
+    import time
+    t0 = time.perf_counter()
     payload = ldist.pack_records(arr, len(recs), blob, lra, bxb, batch.bx_names, chr_names=["chr22"], window_index=mine)
+    t1 = time.perf_counter()
     parts = ldist.gather_bytes(payload, torch.device("cpu"))
+    t2 = time.perf_counter()
     if rank == 0:
         db = engine.VariantDB()
         n = ldist.merge_into_vdb(parts, db)
+        # (a printed figure, pytest -s: what a step's gather costs the thread that runs it -- in bench.py a communication thread, not the one that submits kernels)
+        print(f"[gloo x{world}] {case}: {len(recs)} records on rank 0, pack_records {1e3 * (t1 - t0):.2f} ms, gather_bytes {1e3 * (t2 - t1):.2f} ms, "
+              f"merge_into_vdb {1e3 * (time.perf_counter() - t2):.2f} ms", file=sys.stderr)
         q.put((n, db.vcf()))
     else:
         assert parts == []
@@ -104,6 +111,22 @@ def test_eight_rank_gather_with_keys_made_on_the_sending_ranks(case):
     n, vcf = _run_ranks(8, case)
     assert n > 0
     assert vcf == gu.golden_vcf(case)
+
+
+def test_unordered_records_are_sent_whole():
+    """pack_records' per-key reduction keeps "the first" record of a key -- first in the order rank 0 replays them.  A rank whose records are
+    not in (window, emission) order, or whose local -> global window map is not increasing, must send every record."""
+    import numpy as np
+    from lancet_amd import dist as ldist
+    dt = np.dtype(ldist.abi.LancetVariant)
+    recs = np.zeros(4, dtype=dt)
+    recs["window"] = [0, 0, 1, 2]; recs["seq_in_window"] = [0, 1, 0, 0]
+    assert ldist.records_in_replay_order(recs, None) and ldist.records_in_replay_order(recs, np.array([5, 9, 12]))
+    assert not ldist.records_in_replay_order(recs, np.array([5, 4, 12]))            # the window map goes backwards
+    recs["window"] = [0, 1, 0, 2]
+    assert not ldist.records_in_replay_order(recs, None)                              # the records do
+    recs["window"] = [0, 0, 1, 2]; recs["seq_in_window"] = [1, 0, 0, 0]
+    assert not ldist.records_in_replay_order(recs, None)
 
 
 def test_shard_windows_partitions_everything():

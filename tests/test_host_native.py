@@ -774,6 +774,19 @@ def test_packed_upload_gives_the_records_of_the_ascii_upload():
         bad = dict(pk); bad["base_woff"] = pk["base_woff"].copy(); bad["base_woff"][1:] += 1
         with pytest.raises(engine.EngineError):
             eng.upload_packed(b2, bad)
+        # a producer that does not say which thresholds it packed with is refused (the check below could not see a mismatch otherwise) ...
+        with pytest.raises(engine.EngineError, match="min_qual_trim"):
+            eng.upload_packed(b2, {k: v for k, v in pk.items() if k != "min_qual_trim"})
+        # ... and so is a caller built against another layout of lancet_packed_reads (its size travels in the struct's first field)
+        import ctypes as C
+        keep = {k: np.ascontiguousarray(pk[k], dtype=np.uint32) for k in ("rinfo", "base_woff", "good_woff", "bases", "good")}
+        old = abi.LancetPackedReads(40, 0, *[keep[k].ctypes.data_as(C.POINTER(C.c_uint32)) for k in ("rinfo", "base_woff", "good_woff", "bases", "good")])
+        old.min_qual_trim, old.min_qual_call = int(pk["min_qual_trim"]), int(pk["min_qual_call"])
+        cb = abi.batch_to_c(b2)
+        eng.L.lancet_engine_upload_packed.restype = C.c_int
+        eng.L.lancet_engine_upload_packed.argtypes = [C.c_void_p, C.POINTER(abi.LancetWindowBatch), C.POINTER(abi.LancetPackedReads)]
+        assert eng.L.lancet_engine_upload_packed(eng.h, C.byref(cb), C.byref(old)) == -1       # LANCET_E_ARG
+        assert b"struct_size" in eng.L.lancet_engine_last_error(eng.h)
         eng.close()
         # reads packed for other thresholds are refused, not assembled (the trim and the quality mask depend on them)
         other = engine.Engine(abi.default_params(min_qual_trim=p.min_qual_trim + 3))
