@@ -155,7 +155,8 @@ def side_config(eng_cls, params, name, windows, cov_t, cov_n, steps, streaming=F
            "builds_per_window": round(sum(s["n_builds"] for s in stats) / windows, 3),
            "final_k_histogram": {int(k): int(c) for k, c in zip(ks, cnt)},
            "k_exhausted": sum(1 for s in stats if s["status"] == 2), "overflowed": sum(1 for s in stats if s["status"] < 0),
-           "windows_first_graph_in_lds": eng.prebuilt_count(), "windows_that_build": built, "windows_rerun_worst_case_tier": eng.rerun_count(),
+           "windows_first_graph_in_lds": eng.prebuilt_count(), "windows_that_build": built, "building_windows_per_s": round(built / dt, 1),
+           "windows_rerun_worst_case_tier": eng.rerun_count(),
            "build_service": dict(zip(("posted", "served", "not_buildable", "taken_back"), eng.svc_counts())),
            "roofline": {"bound": "hbm", "achieved": round(alg / (ms_all * 1e-3) / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(alg / (ms_all * 1e-3) / 1e9 / 8000.0, 6), "algorithmic_bytes_per_launch": int(alg),
@@ -186,6 +187,37 @@ def side_config(eng_cls, params, name, windows, cov_t, cov_n, steps, streaming=F
     return out
 
 
+def bam_e2e(d: str, region: str):
+    """BAM -> VCF with the native command-line program (lancet_amd/bin/lancet_gpu: BGZF inflate, alignment decode, tiling, read selection,
+    trim + pack, upload, kernels, VariantDB, VCF) on a pre-generated synthetic tumor / normal pair, when one is there (tools/make_scan_bams.py;
+    build/ is not part of the repository's history).  A whole process per run -- start-up, device initialisation and the work-space allocation
+    included -- twice, the second run reported; windows / wall seconds.  The 5 Mb contig of BASELINE.md config 2: profiles/r5_e2e_5mb.txt."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "lancet_amd", "bin", "lancet_gpu")
+    need = [os.path.join(d, f) for f in ("tumor.bam", "normal.bam", "ref.fa")]
+    if not os.path.exists(exe) or not all(os.path.exists(f) for f in need):
+        return None
+    res = None
+    for _ in range(2):
+        try:
+            r = subprocess.run([exe, "--tumor", need[0], "--normal", need[1], "--ref", need[2], "--reg", region, "--active-region-off"],
+                               capture_output=True, text=True, timeout=120, env=dict(os.environ, LANCET_HOST_TIMING="1"))
+        except (OSError, subprocess.TimeoutExpired):
+            return None
+        m = re.search(r"\[lancet_gpu\] (\d+) windows tiled, (\d+) assembled.*?(\d+) variants", r.stderr)
+        w = re.search(r"\[lancet_gpu\] wall ([0-9.]+) s: input decode \+ tiling ([0-9.]+), window filters \+ batches ([0-9.]+), engine \(upload \+ kernels \+ results\) ([0-9.]+) \(kernels ([0-9.]+)\), VariantDB ([0-9.]+)", r.stderr)
+        if r.returncode not in (0, 3) or not m or not w:
+            return None
+        wall = float(w.group(1))
+        res = {"value": round(int(m.group(2)) / wall, 1), "unit": "windows/s", "windows": int(m.group(2)), "variants": int(m.group(3)), "wall_s": wall,
+               "decode_tiling_s": float(w.group(2)), "filters_batches_s": float(w.group(3)), "engine_s": float(w.group(4)), "kernels_s": float(w.group(5)),
+               "vcf_records": sum(1 for l in r.stdout.splitlines() if l and not l.startswith("#")),
+               "what": f"lancet_gpu --tumor/--normal/--ref --reg {region} --active-region-off on {os.path.relpath(d, ROOT)} (500 kb, 30x/30x, 2x150 bp), second of two runs, "
+                       "a whole process: start-up, device initialisation and allocation included"}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,6 +231,7 @@ def main():
     ap.add_argument("--linked", action="store_true", help="BX / HP tags on every pair and --linked-reads in the engine (config 5)")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="windows timed on one thread of the CPU oracle (0 = skip the CPU legs)")
     ap.add_argument("--cpu-sample-all", type=int, default=16384, help="windows timed on all host cores")
+    ap.add_argument("--no-bam", action="store_true", help="skip the BAM -> VCF run of the native program (value_bam_e2e)")
     ap.add_argument("--no-configs", action="store_true", help="skip the side configurations (60x/60x, 100x/40x STR)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight per GPU (engines submitted in turn); 1 = every step alone on the GPU")
     ap.add_argument("--chain", type=int, default=1, help="1: a batch's kernels start when those of the batch before it (other engine) are through -- back to back, no host gap; 0: as soon as submitted")
@@ -480,17 +513,27 @@ def main():
             out["windows_per_rank"] = n_local
             if one_gpu:
                 out["config"]["comm"] = "LANCET_BENCH_ONE_GPU=1: all ranks on device 0, gather over gloo -- a check of the N-rank path, not a measurement"
-        # HBM-side bytes per launch from the committed PMC passes (tools/pmc_total.sh -> profiles/r3_traffic.json):
-        # rocprofv3 cannot run inside this process, so the figure is looked up for the exact workload it was taken on
+        # HBM-side bytes per launch from the committed PMC passes (tools/pmc_total.sh -> profiles/r5_traffic.json): rocprofv3 cannot run
+        # inside this process, so the figure is looked up for the exact workload it was taken on -- and only when it was taken on THESE
+        # kernels (sha1 over lancet_amd/csrc/*.h, *.hip, recorded with the passes): a record of other kernels is not quoted.
         try:
-            tj = os.path.join(ROOT, "profiles", "r4_traffic.json")
-            with open(tj if os.path.exists(tj) else os.path.join(ROOT, "profiles", "r3_traffic.json")) as fh:
+            fp = workload.kernel_fingerprint()
+            for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json"):
+                tj = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(tj):
+                    break
+            with open(tj) as fh:
                 for rec in json.load(fh)["measurements"]:
                     if rec["windows"] == args.windows and rec["coverage"] == args.cov and rec.get("coverage_normal", rec["coverage"]) == cov_n \
                             and rec.get("str_fraction", 0.0) == args.str_fraction and bool(rec.get("linked", False)) == bool(args.linked) and world == 1:
+                        if rec.get("kernel_fingerprint") != fp:
+                            out["roofline"]["traffic_note"] = (f"profiles/{name} holds PMC passes for this workload, but taken on other kernels (fingerprint "
+                                                               f"{rec.get('kernel_fingerprint')}, these are {fp}): not quoted; re-run tools/profile_round5.sh")
+                            break
                         out["roofline"]["traffic"] = int((rec["FETCH_SIZE_KB"] / rec.get("fetch_calibration", 1.0) + rec["WRITE_SIZE_KB"]) * 1024)
                         out["roofline"]["traffic_fetch_write"] = [int(rec["FETCH_SIZE_KB"] * 1024), int(rec["WRITE_SIZE_KB"] * 1024)]
                         out["roofline"]["traffic_note"] = rec["note"]
+                        out["roofline"]["traffic_kernel_fingerprint"] = fp
                         break
         except (OSError, KeyError, ValueError):
             pass
@@ -498,6 +541,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(batch, params, variants, args.cpu_sample, args.cpu_sample_all)
         for e2 in engs:
             e2.close()
+        if world == 1 and not args.no_bam:
+            bam = bam_e2e(os.path.join(ROOT, "build", "scan500k"), "chr22:1000-499000")
+            if bam:
+                out["value_bam_e2e"] = bam.pop("value")       # BAM -> VCF by the native program, a whole process: never `value`
+                out["value_bam_e2e_detail"] = bam
         if world == 1 and not args.no_configs:
             out["configs"] = [
                 side_config(engine.Engine, params, "config 2 at 60x/60x", 8192, 60.0, 60.0, 8),

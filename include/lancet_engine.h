@@ -120,7 +120,7 @@ typedef struct lancet_window_stats {
   int32_t  n_variants;
   uint64_t n_kmers;       /* sum over builds of the loadSequence trip count         */
   uint32_t max_nodes;     /* largest node table over the builds                                       */
-  uint32_t reserved;
+  uint32_t sum_nodes;     /* sum over the builds of their node tables' sizes (40 B per node of every build) */
 } lancet_window_stats;
 
 #define LANCET_W_OK            0   /* processed (possibly with no variants)                          */

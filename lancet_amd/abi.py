@@ -61,7 +61,7 @@ class LancetVariant(C.Structure):
 
 class LancetWindowStats(C.Structure):
     _fields_ = [("status", C.c_int32), ("final_k", C.c_int32), ("n_builds", C.c_int32), ("n_variants", C.c_int32),
-                ("n_kmers", C.c_uint64), ("max_nodes", C.c_uint32), ("reserved", C.c_uint32)]
+                ("n_kmers", C.c_uint64), ("max_nodes", C.c_uint32), ("sum_nodes", C.c_uint32)]
 
 
 class LancetFilters(C.Structure):

@@ -174,7 +174,8 @@ struct lancet_engine {
   EngineCaps caps2;     // tier 2 (re-run of overflowed windows)
   DevBuf d_caps2, d_works2, d_workmem2, d_out2, d_winlist, d_skip;
   int n_slots2 = 0;
-  uint32_t node_cap1 = 16384;   // tier-1 node limit per window (tables are sized per build, so a generous limit costs memory only)
+  uint32_t node_cap1 = 16384;   // tier-1 node limit per window when LANCET_NODE_CAP1 sets it (else from the batch, lc_upload)
+  bool node_cap1_env = false;
   uint32_t debug_stop = 0;   // LANCET_STOP_PHASE (profiling only)
   uint32_t table_start = 0;  // LANCET_TABLE_START (testing only: exercises the table-doubling path)
   int n_windows = 0, n_reads = 0, n_slots = 0;
@@ -336,7 +337,7 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (const char *s = getenv("LANCET_MAX_NODES")) { e->max_nodes_limit = (uint32_t)atoi(s); e->max_nodes_env = true; }
   if (e->max_nodes_limit > (1u << 22)) e->max_nodes_limit = 1u << 22;        // (sequence descriptors keep the k-mer node in 23 bits: layout.h SD_KMER)
   if (e->max_nodes_limit < 1024u) e->max_nodes_limit = 1024u;
-  if (const char *s = getenv("LANCET_NODE_CAP1")) e->node_cap1 = (uint32_t)atoi(s);
+  if (const char *s = getenv("LANCET_NODE_CAP1")) { e->node_cap1 = (uint32_t)atoi(s); e->node_cap1_env = true; }
   if (const char *s = getenv("LANCET_STOP_PHASE")) e->debug_stop = (uint32_t)atoi(s);
   if (const char *s = getenv("LANCET_TABLE_START")) e->table_start = lc_pow2_ge((uint32_t)atoi(s));
   *out = e;
@@ -432,7 +433,15 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
   //  src/Microassembler.cc:491-496 -- overflows the one-wave kernel's 16-bit read ids and runs in the re-run tier, whose csr words and
   //  mate-name records keep the read in 32 bits (layout.h cs_t); its node tables are then sized for up to 2^20 distinct k-mers
   //  instead of 65 536, unless LANCET_MAX_NODES says otherwise.)
-  e->caps = lc_caps_for_batch(b, &e->params, e->evt_cap, e->node_cap1, 1);
+  // Tier-1 node limit: from the batch unless LANCET_NODE_CAP1 says otherwise -- a quarter of the mean window's bases as distinct k-mers
+  // (30x/30x: ~2.1 k nodes of 27 k bases), a power of two between 8192 and 16384 (16384 for every batch until round 5: the node-sized
+  // arrays are a third of a slot), and never below what a hand-off area of the LDS build kernel may hold (set further down).
+  uint32_t node_cap1 = e->node_cap1;
+  if (!e->node_cap1_env && nw > 0) {
+    const uint64_t mean_bases = ((uint64_t)b->seq_off[b->read_begin[nw]] + b->ref_off[nw]) / (uint64_t)nw;
+    node_cap1 = mean_bases / 4 <= 8192 ? 8192u : 16384u;
+  }
+  e->caps = lc_caps_for_batch(b, &e->params, e->evt_cap, node_cap1, 1);
   uint32_t nodes2 = e->max_nodes_limit;
   if (!e->max_nodes_env) for (int w = 0; w < nw; ++w) if (b->read_begin[w + 1] - b->read_begin[w] >= 0xFFFFu) { nodes2 = std::max(nodes2, 1u << 20); break; }
   e->caps2 = lc_caps_for_batch(b, &e->params, e->evt_cap, nodes2, 2);
@@ -445,6 +454,12 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
     const int depth0 = e->ahead_depth_env >= 0 ? e->ahead_depth_env : 6;
     const size_t n_areas = (size_t)nw + (depth0 > 0 ? (size_t)std::max(64, nw / 4) : 0) + (use_svc0 ? (size_t)std::max(64, nw / 8) : 0);
     e->caps.pl = e->caps2.pl = lc_pre_layout_for_batch(b, n_areas, (size_t)20 << 30, e->pre_wide_env);
+    if (!e->node_cap1_env && e->caps.pl.ncap + 64u > node_cap1) {          // (wide hand-off areas: 14 336 nodes may arrive from the build kernel)
+      const PreLayout pl = e->caps.pl;
+      e->caps = lc_caps_for_batch(b, &e->params, e->evt_cap, 16384u, 1);
+      e->caps.debug_stop = e->debug_stop; e->caps.table_start = e->table_start; e->caps.pl = pl;
+      e->caps2.var_cap = e->caps.var_cap; e->caps2.blob_cap = e->caps.blob_cap; e->caps2.bx_cap = e->caps.bx_cap;
+    }
   }
   // ---- inputs
   UP(e->d_params, &e->params, sizeof(lancet_params));
@@ -639,7 +654,8 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
   if (!e->debug_stop && !e->no_fat && !e->no_early_rerun) {
     for (int w = 0; w < nw; ++w) {
       const uint32_t r0 = b->read_begin[w], r1 = b->read_begin[w + 1];
-      bool big = r1 - r0 + 1 > e->caps.reads_cap;        // process_window's first test: more reads than a tier-1 slot holds
+      bool big = r1 - r0 + 1 > e->caps.reads_cap ||      // process_window's first tests: more reads, or more bases, than a tier-1 slot holds
+                 (uint64_t)(b->seq_off[r1] - b->seq_off[r0]) + (b->ref_off[w + 1] - b->ref_off[w]) + 64u > (uint64_t)e->caps.occ_cap;
       // ... or more than the larger configuration of the LDS build kernel takes (131 040 bases with every read padded to 16, 1024 reads):
       // its graphs would all come from the general build on ONE wave (tens of ms: the tail of the launch); the several-wave kernel of the
       // re-run tier builds them in a few ms, next to everything else

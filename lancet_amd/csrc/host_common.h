@@ -66,7 +66,9 @@ static inline EngineCaps lc_caps_for_batch(const lancet_window_batch *b, const l
     // out for windows up to 4x the mean (they overflow at once and run in tier 2, whose limits are the true maxima)
     const uint32_t R = b->read_begin[b->n_windows];
     const uint64_t mean_reads = R / (uint32_t)b->n_windows, mean_bases = ((uint64_t)b->seq_off[R] + b->ref_off[b->n_windows]) / (uint64_t)b->n_windows;
-    const uint64_t lim_reads = 4 * mean_reads + 256, lim_bases = 4 * mean_bases + 32768;
+    // (round 5: bases 2x the mean + 16 Ki instead of 4x + 32 Ki -- the occurrence-sized arrays are a third of a slot, and what lies between
+    //  is a handful of windows per scan that run in the re-run tier like the pile-ups above them)
+    const uint64_t lim_reads = 4 * mean_reads + 256, lim_bases = 2 * mean_bases + 16384;
     if (max_reads > lim_reads) max_reads = (uint32_t)lim_reads;
     if (max_bases > lim_bases) max_bases = lim_bases;
   }

@@ -50,7 +50,7 @@ struct WinShared {
   int emit_seq;
   uint32_t evt_len;
   unsigned long long n_kmers;
-  uint32_t max_nodes;
+  uint32_t max_nodes, sum_nodes;
   int n_builds, final_k, status;
   int tmp0, tmp1, tmp2, tmp3, hasN;
   int rs_bad;                          // repeat_scan_min: the 2-bit staging met a code above 3
@@ -1347,7 +1347,7 @@ DEVNI void build_tables(Ctx &c) {
   XG_FOR(i, nwords) { W.bitpre[i] = (uint32_t)dev_popc(ld2(&W.bitmap[i])); }
   WG_SYNC();
   wg_scan(W.bitpre, nwords, S);
-  WG_LANE0 { S.N = S.part[LANCET_WG]; S.N_last = (uint32_t)S.N; if (S.N > C.node_cap) OVF(c); if (S.N > S.max_nodes) S.max_nodes = S.N; S.nspecial = 0; }
+  WG_LANE0 { S.N = S.part[LANCET_WG]; S.N_last = (uint32_t)S.N; if (S.N > C.node_cap) OVF(c); if (S.N > S.max_nodes) S.max_nodes = S.N; S.sum_nodes += (uint32_t)S.N; S.nspecial = 0; }
   if (wg_bcast(&S.overflow)) return;
   XG_FOR(l, XG_LANES) {
     const int T = (int)(S.tmask + 1), NW = S.NW; const bool hasN = S.hasN != 0;
@@ -1876,7 +1876,9 @@ DEVNI void build_qcounts(Ctx &c) {
       for (uint32_t k = 0; k < LC_PACK && ci + k < ncand; ++k) {
         const uint32_t q = ci - cqb + k;
         const uint32_t n = S.cq_n[q], lo = S.cq_lo[q], cnt = S.cq_cnt[q];
-        if (cnt > 0xFFFFu) OVF(c);                                // the per-position counters are 16 bits wide
+        // (a candidate with more than 65 535 occurrences: the reference's per-position counters are unsigned short and wrap -- src/Ref.hh:43-52,
+        //  ++ in Node_t::updateCovDistr -- and so do these: its rounds below add into 16-bit fields, round by round; until round 5 such a
+        //  window was reported LANCET_W_OVERFLOW)
         if (gN > 0 && tot + cnt > LC_QSTAGE) break;
         S.g_n[gN] = n; S.g_lo[gN] = lo; S.g_cnt[gN] = cnt; S.g_es[gN] = tot; S.g_min[gN] = 0x7FFFFFFFu;
         ++gN; tot += cnt;
@@ -2002,9 +2004,12 @@ DEVNI void build_qcounts(Ctx &c) {
         const int k = big ? 0 : t / K, i = big ? t : t - k * K;
         const int es = big ? 0 : (int)S.g_es[k], ee = big ? cnt : es + (int)S.g_cnt[k];
         const uint32_t *mm = (const uint32_t *)S.mmeta;
-        unsigned long long a = 0;                                      // four 16-bit counters: class c at bits 16c
+        unsigned long long a = 0;                                      // four 16-bit counters: class c at bits 16c -- of THIS round (at most LC_QSTAGE entries: no field
+                                                                       // carries into its neighbour); what the rounds before counted is added below, modulo 65 536 as the
+                                                                       // reference's unsigned short counters count
         uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0;       // lr_mode: hp0/1/2_minqv tumor, normal
-        if (!first) a = (unsigned long long)S.acc[i][0] | ((unsigned long long)S.acc[i][1] << 16) | ((unsigned long long)S.acc[i][2] << 32) | ((unsigned long long)S.acc[i][3] << 48);
+        uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+        if (!first) { p0 = S.acc[i][0]; p1 = S.acc[i][1]; p2 = S.acc[i][2]; p3 = S.acc[i][3]; }
         if (!first && LR) { h0 = S.acc[i][4]; h1 = S.acc[i][5]; h2 = S.acc[i][6]; h3 = S.acc[i][7]; h4 = S.acc[i][8]; h5 = S.acc[i][9]; }
         // bit of k-mer position i in an entry: position i of a forward occurrence, K-1-i of a reverse one
         const int iR = K - 1 - i;
@@ -2033,7 +2038,8 @@ DEVNI void build_qcounts(Ctx &c) {
         } else {
           for (int j = es; j < ee; ++j) add_entry(mk4[j], mm[j]);
         }
-        const uint32_t a0 = (uint32_t)(a & 0xFFFFu), a1 = (uint32_t)((a >> 16) & 0xFFFFu), a2 = (uint32_t)((a >> 32) & 0xFFFFu), a3 = (uint32_t)(a >> 48);
+        const uint32_t a0 = (p0 + (uint32_t)(a & 0xFFFFu)) & 0xFFFFu, a1 = (p1 + (uint32_t)((a >> 16) & 0xFFFFu)) & 0xFFFFu,
+                       a2 = (p2 + (uint32_t)((a >> 32) & 0xFFFFu)) & 0xFFFFu, a3 = (p3 + (uint32_t)(a >> 48)) & 0xFFFFu;
         if (!last) {
           S.acc[i][0] = (uint16_t)a0; S.acc[i][1] = (uint16_t)a1; S.acc[i][2] = (uint16_t)a2; S.acc[i][3] = (uint16_t)a3;
           if (LR) { S.acc[i][4] = (uint16_t)h0; S.acc[i][5] = (uint16_t)h1; S.acc[i][6] = (uint16_t)h2; S.acc[i][7] = (uint16_t)h3; S.acc[i][8] = (uint16_t)h4; S.acc[i][9] = (uint16_t)h5; }
@@ -4687,6 +4693,7 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
     if (S.n_builds > 0 && LC_CTX(c).OUT->n_ahead_used) dev_atomic_add(LC_CTX(c).OUT->n_ahead_used, 1u);
     S.N = N; S.N_last = N; S.O = H->O; S.totalreadbp = (int)H->totalreadbp; S.n_kmers += (unsigned long long)H->n_kmers; ++S.n_builds;
     if (N > S.max_nodes) S.max_nodes = N;
+    S.sum_nodes += N;
     S.nspecial = 0; S.qv_top = ncand; S.seq_top = ncand * (uint32_t)K; S.tmask = 0; S.tfull = 0; S.prebuilt = 1;
     S.pre_edges = H->edges_total; S.pre_refn = H->refn;
     W.occ_base[S.R - 1] = 0;                                     // the reference pseudo-read's occurrences are the only ones the graph phases visit
@@ -4846,7 +4853,7 @@ DEVNI bool try_suspend(Ctx &c, int k) {
   WG_LANE0 {
     LC_GLOBAL SvcCont &ct = sv->cont[i];
     ct.k = k; ct.seq_t5 = S.seq_t5; ct.seq_len = S.seq_len; ct.trim5 = S.trim5; ct.trim3 = S.trim3; ct.emit_seq = S.emit_seq;
-    ct.n_builds = S.n_builds; ct.final_k = S.final_k; ct.max_nodes = S.max_nodes; ct.evt_len = S.evt_len; ct.N_last = S.N_last; ct.pad = 0;
+    ct.n_builds = S.n_builds; ct.final_k = S.final_k; ct.max_nodes = S.max_nodes; ct.evt_len = S.evt_len; ct.N_last = S.N_last; ct.sum_nodes = S.sum_nodes;
     ct.n_kmers = S.n_kmers;
     sv->req[i].w = (uint32_t)w; sv->req[i].k = k;
     if (LC_CTX(c).OUT->phase) for (int q = 0; q < 16; ++q) LC_CTX(c).OUT->phase[(size_t)w * 16 + q] = S.phase_acc[q];
@@ -4866,7 +4873,7 @@ DEV void process_window(Ctx &c, int w, int rq = -1) {
   LC_GLOBAL const PreLayout &PL = LC_PL(c);
   WG_LANE0 {
     S.items_ready = 0;
-    S.w = w; S.overflow = 0; S.evt_len = 0; S.emit_seq = 0; S.n_kmers = 0; S.max_nodes = 0; S.n_builds = 0; S.N_last = 0; S.final_k = 0;
+    S.w = w; S.overflow = 0; S.evt_len = 0; S.emit_seq = 0; S.n_kmers = 0; S.max_nodes = 0; S.sum_nodes = 0; S.n_builds = 0; S.N_last = 0; S.final_k = 0;
     S.status = LANCET_W_OK;
     S.LR = LC_CTX(c).C->lr_mode ? 1 : 0; S.QS = S.LR ? 10 : 4;
     S.reflen = (int)(B.ref_off[w + 1] - B.ref_off[w]);
@@ -4881,7 +4888,7 @@ DEV void process_window(Ctx &c, int w, int rq = -1) {
     if (rq >= 0) {                                  // what the window carried when it was suspended
       LC_GLOBAL const SvcCont &ct = LC_CTX(c).OUT->svc->cont[rq];
       S.seq_t5 = ct.seq_t5; S.seq_len = ct.seq_len; S.trim5 = ct.trim5; S.trim3 = ct.trim3; S.emit_seq = ct.emit_seq;
-      S.n_builds = ct.n_builds; S.final_k = ct.final_k; S.max_nodes = ct.max_nodes; S.evt_len = ct.evt_len; S.N_last = ct.N_last;
+      S.n_builds = ct.n_builds; S.final_k = ct.final_k; S.max_nodes = ct.max_nodes; S.sum_nodes = ct.sum_nodes; S.evt_len = ct.evt_len; S.N_last = ct.N_last;
       S.n_kmers = ct.n_kmers; S.nosusp_k = ct.k;
     }
   }
@@ -5153,7 +5160,7 @@ DEV int window_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_LANE0 {
       lancet_window_stats &st = OUT->stats[w];
       st.status = S->status; st.final_k = S->final_k; st.n_builds = S->n_builds; st.n_variants = S->emit_seq;
-      st.n_kmers = S->n_kmers; st.max_nodes = S->max_nodes; st.reserved = 0;
+      st.n_kmers = S->n_kmers; st.max_nodes = S->max_nodes; st.sum_nodes = S->sum_nodes;
       if (OUT->phase) for (int i = 0; i < 16; ++i) OUT->phase[(size_t)w * 16 + i] = S->phase_acc[i];
       if (C->evt_cap) { OUT->evt_len[w] = S->evt_len; for (uint32_t i = 0; i < S->evt_len; ++i) OUT->evt_out[(size_t)w * C->evt_cap + i] = LC_CTX(c).W->evt[i]; }
     }

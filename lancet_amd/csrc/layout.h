@@ -323,7 +323,7 @@ struct Work {
 struct SvcReq { uint32_t w; int32_t k; uint32_t state; uint32_t pad; };
 struct SvcCont {          /* WinShared fields that live across the k attempts of a window */
   int32_t k, seq_t5, seq_len, trim5, trim3, emit_seq, n_builds, final_k;
-  uint32_t max_nodes, evt_len, N_last, pad;
+  uint32_t max_nodes, evt_len, N_last, sum_nodes;
   unsigned long long n_kmers;
 };
 struct SvcCtl {

@@ -165,7 +165,7 @@ class Engine:
             abi.variants_lr_to_py(variants, lp, bp)
         nw = self._batch.n_windows
         stats = [dict(status=sp[i].status, final_k=sp[i].final_k, n_builds=sp[i].n_builds, n_variants=sp[i].n_variants,
-                      n_kmers=sp[i].n_kmers, max_nodes=sp[i].max_nodes) for i in range(nw)]
+                      n_kmers=sp[i].n_kmers, max_nodes=sp[i].max_nodes, sum_nodes=sp[i].sum_nodes) for i in range(nw)]
         return variants, stats
 
     def timing_ms(self):

@@ -196,7 +196,7 @@ def algorithmic_bytes_split(b: WindowBatch, stats, n_variants: int):
         W = int(b.ref_off[w + 1] - b.ref_off[w])
         reads_b = int(csum[int(b.read_begin[w + 1])] - csum[int(b.read_begin[w])])
         build += st["n_builds"] * (reads_b + (W + 3) // 4 + W // 8) + 16 * st["n_kmers"]
-        win += st["n_builds"] * 40 * st["max_nodes"]
+        win += 40 * st.get("sum_nodes", st["n_builds"] * st["max_nodes"])      # (every build its own node table)
     return int(build), int(win + 128 * n_variants)
 
 
@@ -211,5 +211,19 @@ def algorithmic_bytes(b: WindowBatch, stats, n_variants: int) -> int:
         st = stats[w]
         W = int(b.ref_off[w + 1] - b.ref_off[w])
         reads_b = int(csum[int(b.read_begin[w + 1])] - csum[int(b.read_begin[w])])
-        total += st["n_builds"] * (reads_b + (W + 3) // 4 + W // 8 + 40 * st["max_nodes"]) + 16 * st["n_kmers"]
+        total += st["n_builds"] * (reads_b + (W + 3) // 4 + W // 8) + 40 * st.get("sum_nodes", st["n_builds"] * st["max_nodes"]) + 16 * st["n_kmers"]
     return int(total + 128 * n_variants)
+
+
+def kernel_fingerprint() -> str:
+    """sha1 over the device sources (lancet_amd/csrc/*.h, *.hip): what a measurement that was not taken by this very process (the PMC
+    traffic passes, profiles/*_traffic.json) must have been taken on for bench.py to quote it."""
+    import hashlib
+    import os
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]

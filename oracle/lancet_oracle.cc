@@ -561,7 +561,7 @@ struct Graph {
   std::vector<ReadInfo> reads;
   std::vector<OutVariant> *out = nullptr;
   int cur_window = 0, cur_chr = 0, emit_seq = 0;
-  uint64_t n_kmers = 0; uint32_t max_nodes = 0; int n_builds = 0;
+  uint64_t n_kmers = 0; uint32_t max_nodes = 0, sum_nodes = 0; int n_builds = 0;
   std::unordered_map<std::string, std::set<uint32_t>> bxT, bxN;                       // Graph_t::bx_table_tmr / _nml
 
   void setK(int k) { K = k; MAX_LINK_LEN = (int)floor((double)K / 2.0); }              // Graph.hh:143
@@ -701,6 +701,7 @@ struct Graph {
     }
     for (auto &kv : nodes) kv.second->computeMinCov();
     if (nodes.size() > max_nodes) max_nodes = nodes.size();
+    sum_nodes += (uint32_t)nodes.size();
     ref->computeCoverage(LANCET_TMR);
     ref->computeCoverage(LANCET_NML);
   }
@@ -1307,7 +1308,7 @@ void *lancet_oracle_run(const lancet_params *P, const lancet_window_batch *b, co
     ref.refend = ref.refstart + (int)ref.rawseq.length();
     ref.hdr = hdrs ? hdrs[w] : (ref.chr + ":" + std::to_string(ref.refstart) + "-" + std::to_string(ref.refend));
     g.cur_window = w; g.cur_chr = b->chr_id[w]; g.emit_seq = 0;
-    g.n_kmers = 0; g.max_nodes = 0; g.n_builds = 0;
+    g.n_kmers = 0; g.max_nodes = 0; g.sum_nodes = 0; g.n_builds = 0;
     for (uint32_t r = b->read_begin[w]; r < b->read_begin[w + 1]; ++r) {             // Graph_t::addAlignment, Graph.cc:487-501
       ReadInfo ri;
       ri.label = b->label[r];
@@ -1323,7 +1324,7 @@ void *lancet_oracle_run(const lancet_params *P, const lancet_window_batch *b, co
     size_t before = out.size();
     processGraph(g, &ref, graphCnt, &st);
     st.n_variants = (int)(out.size() - before);
-    st.n_kmers = g.n_kmers; st.max_nodes = g.max_nodes; st.n_builds = g.n_builds;
+    st.n_kmers = g.n_kmers; st.max_nodes = g.max_nodes; st.sum_nodes = g.sum_nodes; st.n_builds = g.n_builds;
   }
   for (auto &v : out) {
     lancet_variant lv; memset(&lv, 0, sizeof(lv));

@@ -76,7 +76,7 @@ def run(batch, params=None, verbose: bool = False):
             abi.variants_lr_to_py(variants, L.lancet_oracle_variants_lr(h), L.lancet_oracle_bx_blob(h))
         sp = L.lancet_oracle_stats(h)
         stats = [dict(status=sp[i].status, final_k=sp[i].final_k, n_builds=sp[i].n_builds, n_variants=sp[i].n_variants,
-                      n_kmers=sp[i].n_kmers, max_nodes=sp[i].max_nodes) for i in range(batch.n_windows)]
+                      n_kmers=sp[i].n_kmers, max_nodes=sp[i].max_nodes, sum_nodes=sp[i].sum_nodes) for i in range(batch.n_windows)]
         trace = L.lancet_oracle_trace(h).decode()
     finally:
         L.lancet_oracle_free(h)

@@ -1,20 +1,24 @@
-# Round-4 profile set on the GPU box (profiles/README.md): the default bench line, rocprofv3 --kernel-trace --stats of the same workload with
+# Round-5 profile set on the GPU box (profiles/README.md): the default bench line, rocprofv3 --kernel-trace --stats of the same workload with
 # one batch at a time on the GPU (what roofline.kernel_ms is measured on), the PMC traffic passes (FETCH_SIZE / WRITE_SIZE, separate passes)
-# for the headline workload AND the three side configurations, kernel resources, the end-to-end scan.
-TAG=${1:-r4_final}
+# for the headline workload AND the three side configurations, kernel resources, the end-to-end scans (500 kb, and the 5 Mb contig when its
+# BAMs are there), the SQ counter passes of the build kernel.
+TAG=${1:-r5_final}
 cd /root/repo; O=gpurun_out/$TAG; mkdir -p $O
-timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.json | cut -c1-200
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.json | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
 rm -rf /root/repo/$O/kt
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/kt -- python /root/repo/bench.py --steps 20 --cpu-sample 0 --no-configs --in-flight 1 > /root/repo/$O/kt.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/kt -- python /root/repo/bench.py --steps 20 --cpu-sample 0 --no-configs --no-bam --in-flight 1 > /root/repo/$O/kt.log 2>&1
 cat /root/repo/$O/kt/*/*kernel_stats.csv | head -14 > /root/repo/$O/kernel_trace_stats.csv; head -8 /root/repo/$O/kernel_trace_stats.csv
 for cfg in "headline|" "60x|--windows 8192 --cov 60" "config4|--windows 4096 --cov 100 --cov-normal 40 --str-fraction 0.3 --lowcomplex-fraction 0.05" "config5|--windows 16384 --linked"; do
   name=${cfg%%|*}; args=${cfg#*|}
   echo "== PMC passes: $name ($args)" | tee -a /root/repo/$O/pmc.txt
-  PMC_TIMEOUT=240 BENCH_ARGS="$args" bash /root/repo/tools/pmc_total.sh 2>&1 | tee -a /root/repo/$O/pmc.txt
+  PMC_TIMEOUT=240 BENCH_ARGS="--no-bam $args" bash /root/repo/tools/pmc_total.sh 2>&1 | tee -a /root/repo/$O/pmc.txt
   grep -h "^{" /root/repo/gpurun_out/pmc_FETCH_SIZE.log | tail -1 > /root/repo/$O/pmc_bench_$name.json
 done
 cd /root/repo
 bash tools/kernel_resources.sh > $O/kernel_resources.txt 2>&1
 LANCET_UPLOAD_TIMING=1 bash tools/e2e_quick.sh > $O/e2e.txt 2>&1; grep -h "lancet upload" gpurun_out/e2e_native*.log | tail -24 >> $O/e2e.txt
+bash tools/e2e_5mb.sh > $O/e2e_5mb.txt 2>&1
+timeout 200 python tools/quick_gpu.py bench 32768 > $O/phases_headline.txt 2>&1
+python tools/traffic_json.py $O $TAG --keep profiles/r4_traffic.json > $O/traffic.json
 rm -rf $O/kt gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE

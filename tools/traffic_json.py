@@ -47,7 +47,10 @@ def main():
         W = line["config"]["windows_per_gpu"]; cov = line["config"]["coverage"]
         alg = line["roofline"]["algorithmic_bytes_per_launch"]
         traffic = (fetch / fcal + write) * 1024 * 1024
-        rec = {"round": tag, "config": name, "windows": W, "coverage": cov[0]}
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from lancet_amd import workload
+        rec = {"round": tag, "config": name, "windows": W, "coverage": cov[0], "kernel_fingerprint": workload.kernel_fingerprint(),
+               "kernel_ms_of_the_pass": line["roofline"].get("per_kernel_ms")}
         if cov[1] != cov[0]:
             rec["coverage_normal"] = cov[1]
         m = re.search(r"--str-fraction (\S+)", b["args"])
@@ -63,7 +66,7 @@ def main():
     old = []
     if keep and os.path.exists(keep):
         old = [r for r in json.load(open(keep))["measurements"] if r.get("round") != tag]
-    print(json.dumps({"how": "tools/profile_round4.sh + tools/traffic_json.py on MI355X (see each record's note); the records of earlier rounds follow for comparison",
+    print(json.dumps({"how": "tools/profile_round5.sh + tools/traffic_json.py on MI355X (see each record's note); the records of earlier rounds follow for comparison",
                       "measurements": out + old}, indent=1))
 
 
