@@ -127,6 +127,32 @@ template <class T> DEV void bl_scan_t(LC_LDS T *a, int n, BL_S &S) {
 #endif
 }
 DEV void bl_scan32(LC_LDS uint32_t *a, int n, BL_S &S) { bl_scan_t<uint32_t>(a, n, S); }
+// the same scan over run sizes, which also sets bit `start` of `heads` for every run that is not empty (the table-order stages: a run's
+// first position, known here for free, is what the pass after the fill would otherwise work out through four dependent look-ups)
+DEV void bl_scan32_heads(LC_LDS uint32_t *a, int n, BL_S &S, LC_LDS uint32_t *heads) {
+  WG_SYNC();
+#ifndef LANCET_WAVE_EMU
+  const int t = (int)threadIdx.x, chunk = (n + BL_WG - 1) / BL_WG;
+  int lo = t * chunk, hi = lo + chunk; if (lo > n) lo = n; if (hi > n) hi = n;
+  uint32_t s = 0;
+  for (int i = lo; i < hi; ++i) s += a[i];
+  uint32_t inc = s; const int lane = t & 63;
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += x; }
+  if (lane == 63) S.wsum[t >> 6] = inc;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int i = 0; i < (t >> 6); ++i) woff += S.wsum[i];
+  uint32_t run = woff + inc - s;
+  for (int i = lo; i < hi; ++i) { const uint32_t x = a[i]; a[i] = run; if (x) dev_atomic_or(&heads[run >> 5], 1u << (run & 31u)); run += x; }
+  if (t == BL_WG - 1) S.scan_total = run;
+  __syncthreads();
+#else
+  uint32_t run = 0;
+  for (int i = 0; i < n; ++i) { const uint32_t x = a[i]; a[i] = run; if (x) heads[run >> 5] |= 1u << (run & 31u); run += x; }
+  S.scan_total = run;
+  lc_emu_syncs += 2;
+#endif
+}
 // 16-bit halves of LDS words under 32-bit atomics (the table order of large tables: twice the elements in the same LDS)
 DEV void bl_min16(LC_LDS uint16_t *a, uint32_t i, uint32_t v) {
   LC_LDS uint32_t *w = (LC_LDS uint32_t *)a + (i >> 1); const uint32_t sh = (i & 1u) * 16u;
@@ -265,6 +291,20 @@ DEV bool bl_all_good(const LC_LDS uint32_t *goodm, uint32_t gw, int a, int b) {
   return true;
 }
 
+// a growth stage of the table order, first pass: bucket of every element under B buckets, smallest position per bucket (stamped: see the stages);
+// U = elements per lane (n <= U * BL_WG <= 4096), all of a lane's look-ups in flight together
+template <int U> DEV void bl_stage_buckets(const LC_LDS uint16_t *Q, LC_GLOBAL const unsigned long long *nhash, uint32_t n, uint32_t B, uint32_t st,
+                                           LC_LDS uint16_t *bkt, LC_LDS uint32_t *first) {
+  WG_FOR(_t, BL_WG) {
+    uint32_t qi[U]; unsigned long long hv[U];
+    BL_UNROLL for (int u = 0; u < U; ++u) { const uint32_t i = (uint32_t)_t + (uint32_t)u * BL_WG; qi[u] = Q[i < n ? i : 0u]; }
+    BL_UNROLL for (int u = 0; u < U; ++u) hv[u] = nhash[qi[u]];
+    BL_UNROLL for (int u = 0; u < U; ++u) {
+      const uint32_t i = (uint32_t)_t + (uint32_t)u * BL_WG;
+      if (i < n) { const uint32_t b = ht_mod(hv[u], B); bkt[i] = (uint16_t)b; dev_atomic_min(&first[b], st | i); }
+    }
+  }
+}
 // 64 bits of a read's quality mask (first word gw) from bit s on (bits past the read's last base belong to whatever follows: the callers
 // only look at bits inside the read)
 DEV unsigned long long bl_good64(const LC_LDS uint32_t *goodm, uint32_t gw, int s) {
@@ -370,6 +410,13 @@ DEV void bl_chunk_bases(const LC_LDS uint32_t *bases, int c, unsigned long long 
 #define BLPA(S, id) BLP(S, id)
 #else
 #define BLPA(S, id) ((void)0)
+#endif
+// -DLANCET_PROF_ORDER: the steps of a growth stage of the table order in the phase slots 1..6 (1 buckets + minima, 2 run sizes, 3 scan, 4 fill,
+// 5 run order + move, 6 the rest of the tail up to the components), the components in 7, what follows in 15
+#ifdef LANCET_PROF_ORDER
+#define BLPO(S, id) BLP(S, id)
+#else
+#define BLPO(S, id) ((void)0)
 #endif
 #define BLC_TO(e) ((uint32_t)(e) & 0x3FFu)
 #define BLC_DIR(e) (((uint32_t)(e) >> 10) & 3u)
@@ -1014,31 +1061,33 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
           if (4 * hb + u < ch.nv) {
             const uint32_t boff = ch.boff0 + (uint32_t)(4 * hb + u), fp = fpv[u]; const bool isF = fF[u]; const unsigned long long v1 = kv[u], alt = al[u];
             const uint32_t mine = (fp << BL_OFFBITS) | boff;
-            uint32_t idx = ix[u], cur = cu[u], probes = 0;
+            // (the loop only finds the slot; what a hit has to do is done behind it -- every exit out of a loop body costs the compiled
+            //  loop a set of EXEC-mask bookkeeping per trip)
+            uint32_t idx = ix[u], cur = cu[u], probes = 0; bool hit = false; unsigned long long v2 = 0;
             while (true) {
               if (cur == BL_EMPTY) { cur = dev_atomic_cas32(&tab[idx], BL_EMPTY, mine); if (cur == BL_EMPTY) break; }
               if ((cur >> BL_OFFBITS) == fp) {
-                const unsigned long long v2 = bl_kmer(S.bases, cur & BL_OFFMASK, kmask);
-                if (v2 == v1 || v2 == alt) {
-                  const bool f2 = (v2 == v1) ? isF : !isF;
-                  if (mine < cur) dev_atomic_min(&tab[idx], mine);
-                  // Scheduling hint (PreHdr::heavy).  All reads are in reference orientation and the loop over k only builds at a k
-                  // above the window reference's longest repeat, so a node normally meets its k-mer once per read and always in the
-                  // same orientation.  The same k-mer twice in one read (a duplication in the sample), or in both orientations (an
-                  // inverted repeat, which isRepeat does not look for), means a walk comes back to the node: if that node survives
-                  // removeLowCov the graph has a cycle and this k is rejected (Microassembler.cc:198-206).  The occurrence is noted
-                  // here and looked at again once the survivors are known.
-                  if (cur != mine && ((f2 != isF) || (r < nr && (cur & BL_OFFMASK) - rb < (uint32_t)ch.tlen))) {
-                    const uint32_t di = dev_atomic_add((LC_LDS uint32_t *)&S.ndup, 1u);
-                    if (di < BL_DUPCAP) X.dupo[di] = (bl_off_t)boff;
-                  }
-                  break;
-                }
+                v2 = bl_kmer(S.bases, cur & BL_OFFMASK, kmask);
+                if (v2 == v1 || v2 == alt) { hit = true; break; }
               }
               idx = (idx + 1) & (nslots - 1);
-              if (++probes > 256u) { S.why = BLW_TABLE; break; }
+              if (++probes > 256u) break;
               cur = ld2(&tab[idx]);
             }
+            if (hit) {
+              const bool f2 = (v2 == v1) ? isF : !isF;
+              if (mine < cur) dev_atomic_min(&tab[idx], mine);
+              // Scheduling hint (PreHdr::heavy).  All reads are in reference orientation and the loop over k only builds at a k
+              // above the window reference's longest repeat, so a node normally meets its k-mer once per read and always in the
+              // same orientation.  The same k-mer twice in one read (a duplication in the sample), or in both orientations (an
+              // inverted repeat, which isRepeat does not look for), means a walk comes back to the node: if that node survives
+              // removeLowCov the graph has a cycle and this k is rejected (Microassembler.cc:198-206).  The occurrence is noted
+              // here and looked at again once the survivors are known.
+              if (cur != mine && ((f2 != isF) || (r < nr && (cur & BL_OFFMASK) - rb < (uint32_t)ch.tlen))) {
+                const uint32_t di = dev_atomic_add((LC_LDS uint32_t *)&S.ndup, 1u);
+                if (di < BL_DUPCAP) X.dupo[di] = (bl_off_t)boff;
+              }
+            } else if (probes > 256u) S.why = BLW_TABLE;
             sw[u] = idx | (isF ? 0u : ON_ORI);
           }
         }
@@ -1740,7 +1789,8 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     LC_LDS unsigned long long *nh = (LC_LDS unsigned long long *)(out + 4096);   // [32] hashes of the first inserts
     LC_LDS uint32_t *nx = (LC_LDS uint32_t *)(nh + 32), *bk = nx + 32;           // [32] list links, [64] buckets of the sequential prefix
     LC_LDS uint16_t *pos2si = (LC_LDS uint16_t *)(bk + 64);                      // [PB_SCAP] survivor index of the node at a position
-    static_assert(5120 * 4 + 4104 * 4 + 4 * 4096 * 2 + 32 * 8 + 32 * 4 + 64 * 4 + PB_SCAP * 2 <= offsetof(BlShared, big) + BL_BIG, "order arena");
+    LC_LDS uint32_t *heads = (LC_LDS uint32_t *)(pos2si + PB_SCAP);              // [128] bit x: position x is the first of a run (growth stages)
+    static_assert(5120 * 4 + 4104 * 4 + 4 * 4096 * 2 + 32 * 8 + 32 * 4 + 64 * 4 + PB_SCAP * 2 + 128 * 4 <= offsetof(BlShared, big) + BL_BIG, "order arena");
     // what the steps after the stages use, wherever the layout puts it: the scan array (N + 1 words; then the components' parent / touch words),
     // node -> position among the survivors, the neighbour lists, the component numbers
     LC_LDS uint32_t *tmpP = tmp, *numP = first; LC_LDS uint16_t *nposP = (LC_LDS uint16_t *)first, *adjP = Qa;
@@ -1804,6 +1854,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       {
         const uint32_t B1 = ht_next_prime(2u * SEQ), n1 = N < B1 ? N : B1;
         WG_FOR(b, 5120) { first[b] = LC_NIL; }
+        WG_FOR(i, 128) { heads[i] = 0; }
         WG_FOR(i, n1 + 1) { tmp[i] = 0; }
         WG_FOR(j, n1 - SEQ) { Q[SEQ + (uint32_t)j] = (uint16_t)(SEQ + (uint32_t)j); }
         WG_SYNC();
@@ -1813,18 +1864,29 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
         B = ht_next_prime(2u * B);
         const uint32_t n = N < B ? N : B;
         const uint32_t st = stamp << 16; --stamp;
-        WG_FOR(i, n) { const uint32_t b = ht_mod(nhash[Q[i]], B); bkt[i] = (uint16_t)b; dev_atomic_min(&first[b], st | (uint32_t)i); }
+        BLPO(S, 1);
+        WG_FOR(i, 128) { heads[i] = 0; }                                        // (set by this stage's scan, read in its last pass: two barriers from here)
+        // (a lane's elements together: position -> node -> hash is an LDS and a global round trip, one after the other per element otherwise)
+        if (n <= 2u * BL_WG) bl_stage_buckets<2>(Q, nhash, n, B, st, bkt, first);
+        else if (n <= 4u * BL_WG) bl_stage_buckets<4>(Q, nhash, n, B, st, bkt, first);
+        else bl_stage_buckets<8>(Q, nhash, n, B, st, bkt, first);
         WG_SYNC();
+        BLPO(S, 2);
         WG_FOR(i, n) { dev_atomic_add(&tmp[n - 1 - (first[bkt[i]] & 0xFFFFu)], 1u); }      // elements per run, runs indexed by their first position, latest first
-        bl_scan32(tmp, (int)n, S);
+        BLPO(S, 3);
+        bl_scan32_heads(tmp, (int)n, S, heads);
+        BLPO(S, 4);
         WG_FOR(i, n) { const uint32_t at = dev_atomic_add(&tmp[n - 1 - (first[bkt[i]] & 0xFFFFu)], 1u); out[at] = (uint16_t)i; }
         WG_SYNC();
+        BLPO(S, 5);
         const bool last = N <= B;
         const uint32_t Bn = ht_next_prime(2u * B), nn = N < Bn ? N : Bn;
         WG_FOR(x, n) {                                                          // inside a run: latest first; then the run's nodes into the other array
-          if (x > 0 && bkt[out[x - 1]] == bkt[out[x]]) continue;
-          const uint32_t b = bkt[out[x]];
-          uint32_t e = (uint32_t)x + 1; while (e < n && bkt[out[e]] == b) ++e;
+          const uint32_t hw = heads[(uint32_t)x >> 5];
+          if (!((hw >> ((uint32_t)x & 31u)) & 1u)) continue;                     // (not the first position of a run)
+          uint32_t e = n;                                                       // the next run's first position
+          { uint32_t wd = (uint32_t)x >> 5, m = ((uint32_t)x & 31u) == 31u ? 0u : (hw >> (((uint32_t)x & 31u) + 1u)) << (((uint32_t)x & 31u) + 1u);
+            while (true) { if (m) { const uint32_t c = 32u * wd + (uint32_t)__builtin_ctz(m); if (c < e) e = c; break; } if (32u * (++wd) >= n) break; m = heads[wd]; } }
           for (uint32_t i = (uint32_t)x + 1; i < e; ++i) { const uint16_t v = out[i]; uint32_t j = i; while (j > (uint32_t)x && out[j - 1] < v) { out[j] = out[j - 1]; --j; } out[j] = v; }
           for (uint32_t i = (uint32_t)x; i < e; ++i) Qn[i] = Q[out[i]];
         }
@@ -1833,6 +1895,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
           WG_FOR(j, nn - n) { Qn[n + (uint32_t)j] = (uint16_t)(n + (uint32_t)j); }
         }
         WG_SYNC();
+        BLPO(S, 6);
         { LC_LDS uint16_t *t = Q; Q = Qn; Qn = t; }
         if (last) break;
         nprev = B;
@@ -1880,6 +1943,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     // ---- markConnectedComponents (Graph.cc:2252-2336): min-label hooking + pointer jumping over the survivors' positions; the label of a
     //      component is the position of its first node in table order, which is also what numbers the components
     BLPA(S, 14);                                                             // (profiling builds: the components apart from the table order)
+    BLPO(S, 7);
     LC_LDS uint32_t *parent = tmpP;                                          // [nsurv]
     LC_LDS uint32_t *touch = tmpP + 2052;                                    // [nsurv] bit 0: component holds a reference k-mer ; later: component number
     LC_LDS uint16_t *adj = adjP;                                             // [nsurv * 8] neighbours as positions (small tables: Qa .. out, 32 KB)
@@ -1924,7 +1988,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_FOR(u, nsurv) { pgr2[pos2si[u]].comp = (int)(num[parent[u]] + 1u); }   // numbered by the position of the component's first node
     WG_LANE0 { H->have_order = 1; H->ht_bc = S.g0; H->ht_next_resize = S.g1; H->numcomp = S.nbw; H->refcomp = S.ngw; }
     WG_SYNC();
-    BLPA(S, 15);
+    BLPA(S, 15); BLPO(S, 15);
     // ---- the window's first graph with a single component: markRefEnds and the first compress here too (bl_compress_first)
     {
       WG_SYNC();

@@ -61,7 +61,7 @@ struct WinShared {
   uint32_t part[LANCET_WG + 1];
   uint32_t part2[LANCET_WG + 1];                 // second scan scratch (part[0..7] carry the path loop's state)
   int wk[4];                                     // walk_prepare: match / snp / ins / del columns
-  int ps_first, ps_len, ps_hd;                   // path_string_wg: first real node, length ; Hamming distance to the reference
+  int ps_first, ps_len, ps_hd, ps_tl;                 // path_string_wg: first real node, length ; Hamming distance to the reference
   int wk_n;                                      // walk_prepare: number of non-match columns
   int wk_stop, wk_nts, wk_last, wk_code, wk_tend, wk_tref;   // process_path_walk_wg: lane 0's state between the chunks of columns
   // (8 KB of LDS per workgroup = 20 single-wave workgroups per CU, the fifth wave per SIMD: two pairs of buffers that are
@@ -375,9 +375,13 @@ DEVNI void repeat_scan(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL cons
 // B = bits per base in the staged copy: 4 (any code, 16 positions per 64-bit word) or 2 (codes 0..3 only, 32 positions per word:
 // half the words to walk).  The 2-bit form is used whenever the string holds no N; `bad2` (LDS) is raised by the staging pass
 // of the 2-bit form when it meets a code above 3, and the caller then runs the 4-bit form.
+// [ra, rb): when given (the repeat test of a PATH, repeats_in_graph_paths), only windows that overlap these positions -- in either copy of
+// the string -- are looked at: every shift walks the mask words of the positions [ra, rb) and of [ra - d, rb - d) instead of the whole
+// string.  Reporting a window outside the range as well is harmless (it is a near-repeat of the string all the same); E is not exact then.
 template <int B>
 DEV void repeat_scan_min_t(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL const uint8_t *s, int len, int mm, int rmin,
-                           volatile LC_LDS int *outE, volatile LC_LDS int *outM, const LC_LDS uint32_t *packed2, volatile LC_LDS int *bad2) {
+                           volatile LC_LDS int *outE, volatile LC_LDS int *outM, const LC_LDS uint32_t *packed2, volatile LC_LDS int *bad2,
+                           int ra = 0, int rb = 0x7FFFFFFF) {
   constexpr int PW = 64 / B, SH = B == 4 ? 4 : 5, LB = B == 4 ? 2 : 1;
   constexpr unsigned long long M1 = B == 4 ? 0x1111111111111111ULL : 0x5555555555555555ULL;
   const int nwords = len / PW + 3;
@@ -478,9 +482,21 @@ DEV void repeat_scan_min_t(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL 
       else run_end(a, b);
       ++nc;
     };
-    int run = 0;                                                   // matches ending just before the current word
     const int nw = (lenM + PW - 1) >> SH;
-    for (int w = 0; w < nw; ++w) {
+    // the words to walk: all of them, or (a range was given) those of [ra, rb) and of [ra - d, rb - d), the lower stretch first
+    int wlo[2] = {0, 0}, whi[2] = {0, nw};
+    if (ra > 0 || rb < lenM) {
+      const int a0 = ra > 0 ? ra : 0, a1 = rb < lenM ? rb : lenM, b0 = ra - d > 0 ? ra - d : 0, b1 = rb - d < lenM ? rb - d : lenM;
+      wlo[1] = a0 >> SH; whi[1] = a1 > a0 ? (a1 + PW - 1) >> SH : wlo[1];
+      wlo[0] = b0 >> SH; whi[0] = b1 > b0 ? (b1 + PW - 1) >> SH : wlo[0];
+      if (whi[0] >= wlo[1]) { if (wlo[0] < wlo[1]) wlo[1] = wlo[0]; if (whi[0] > whi[1]) whi[1] = whi[0]; whi[0] = wlo[0]; }      // (they touch: one stretch)
+      if (whi[1] > nw) whi[1] = nw;
+      if (whi[0] > nw) whi[0] = nw;
+    }
+    for (int part = 0; part < 2; ++part) {
+    int run = 0;                                                   // matches ending just before the current word (a run that began before the
+                                                                   // stretch counts from the stretch's start: the windows looked for lie inside it)
+    for (int w = wlo[part]; w < whi[part]; ++w) {
       const unsigned long long ne = NE(w);
       const int p0 = w << SH;
       if (ne == 0) { run += PW; continue; }
@@ -505,7 +521,8 @@ DEV void repeat_scan_min_t(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL 
       }
       run = PW - 1 - ql;
     }
-    if (run >= rmin) note(lenM - run, lenM);                       // (a last word without a mismatch: lenM a multiple of PW)
+    if (run >= rmin) { const int e = (whi[part] << SH) < lenM ? (whi[part] << SH) : lenM; note(e - run, e); }   // (a stretch that ends inside a run; the whole string: lenM a multiple of PW)
+    }
     for (int j = 0; j < 6; ++j) {
       if (j < nc) { const uint32_t v = j == 0 ? c0 : j == 1 ? c1 : j == 2 ? c2 : j == 3 ? c3 : j == 4 ? c4 : c5; run_end((int)(v >> 16), (int)(v & 0xFFFFu)); }
     }
@@ -516,19 +533,20 @@ DEV void repeat_scan_min_t(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL 
 }
 // `bits2`: LDS word the 2-bit form may use as its "met an N" flag; null: 4-bit form at once (a string known to hold N)
 DEVNI void repeat_scan_min(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL const uint8_t *s, int len, int mm, int lminE, int lminM,
-                           volatile LC_LDS int *outE, volatile LC_LDS int *outM, const LC_LDS uint32_t *packed2 = nullptr, volatile LC_LDS int *bits2 = nullptr) {
+                           volatile LC_LDS int *outE, volatile LC_LDS int *outM, const LC_LDS uint32_t *packed2 = nullptr, volatile LC_LDS int *bits2 = nullptr,
+                           int ra = 0, int rb = 0x7FFFFFFF) {
   int rmin = lminE;
   { const int rm = (lminM - mm + mm) / (mm + 1); if (rm < rmin) rmin = rm; }       // ceil((lminM - mm) / (mm + 1))
   if (mm > 7 || mm < 0 || len + 48 > 16 * LC_RS_WORDS || rmin < 3) { repeat_scan(rsbuf, s, len, mm, outE, outM); return; }
   WG_LANE0 { *outE = 0; *outM = 0; if (bits2) *bits2 = 0; }
   WG_SYNC();
   if (bits2) {
-    repeat_scan_min_t<2>(rsbuf, s, len, mm, rmin, outE, outM, packed2, bits2);
+    repeat_scan_min_t<2>(rsbuf, s, len, mm, rmin, outE, outM, packed2, bits2, ra, rb);
     if (!wg_bcast(bits2)) return;
     WG_LANE0 { *outE = 0; *outM = 0; }
     WG_SYNC();
   }
-  repeat_scan_min_t<4>(rsbuf, s, len, mm, rmin, outE, outM, packed2, nullptr);
+  repeat_scan_min_t<4>(rsbuf, s, len, mm, rmin, outE, outM, packed2, nullptr, ra, rb);
 }
 
 // exclusive prefix sum of a[0..n) in place; returns total in part[LANCET_WG] (default: S.part)
@@ -4545,13 +4563,32 @@ DEVNI bool repeats_in_graph_paths(Ctx &c) {
       // isAlmostRepeat(path->str(), K, MAX_MISMATCH): only M >= K + 1 is asked.  A path that spells the reference between the anchors
       // needs no scan: its longest near-repeat cannot exceed that of the whole window reference, which passed this very test for
       // this k before the graph was built (Microassembler.cc:124-131; the test is only made when reflen > k).
+      // Round 5: a path that DIFFERS from the reference between the anchors needs only the windows that overlap what differs.  With the
+      // common prefix and suffix taken off, the path is ref[0, a) + something + ref[b', end): a window of k + 1 positions that lies inside
+      // the prefix or the suffix, compared with another such window, is a pair of windows of the window reference at two DIFFERENT places
+      // (the one in the suffix maps to a position >= b' >= a, past the one in the prefix) -- which the reference passed; so a new
+      // near-repeat has a window of its pair overlapping [a, b).  The scan walks, per shift, only the mask words around it.
       const int pl = wg_bcast(&S.tmp3);
       LC_GLOBAL const uint8_t *rs = LC_CTX(c).B->ref_codes + LC_CTX(c).B->ref_off[S.w] + S.seq_t5;
-      WG_LANE0 { S.ps_hd = (pl == S.seq_len && S.reflen - S.K > 0) ? 0 : 1; }
+      const int rl = wg_uniform(S.seq_len), ml = pl < rl ? pl : rl;
+      const bool tested = S.reflen - S.K > 0;                       // (the window reference went through this test for this k)
+      WG_LANE0 { S.ps_hd = 0x7FFFFFFF; S.ps_tl = 0x7FFFFFFF; }
       WG_SYNC();
-      if (pl == S.seq_len) { WG_FOR(i, pl) { if (rs[i] != W.pseq[i]) S.ps_hd = 1; } }
-      if (wg_bcast(&S.ps_hd)) repeat_scan_min(S.rs, W.pseq, pl, LC_CTX(c).P->max_mismatch, 0x7FFF, wg_uniform(S.K) + 1, &S.repE, &S.repM, nullptr, &S.rs_bad);
-      else { WG_LANE0 { S.repE = 0; S.repM = 0; } }
+      if (tested) {
+        WG_FOR(i, ml) {
+          if (rs[i] != W.pseq[i]) dev_atomic_min((LC_LDS uint32_t *)&S.ps_hd, (uint32_t)i);
+          if (rs[rl - 1 - i] != W.pseq[pl - 1 - i]) dev_atomic_min((LC_LDS uint32_t *)&S.ps_tl, (uint32_t)i);
+        }
+      }
+      const int hd = wg_bcast(&S.ps_hd), tl = wg_bcast(&S.ps_tl);
+      if (tested && pl == rl && hd == 0x7FFFFFFF) { WG_LANE0 { S.repE = 0; S.repM = 0; } }          // the reference itself
+      else if (!tested) repeat_scan_min(S.rs, W.pseq, pl, LC_CTX(c).P->max_mismatch, 0x7FFF, wg_uniform(S.K) + 1, &S.repE, &S.repM, nullptr, &S.rs_bad);
+      else {
+        const int a = hd < ml ? hd : ml;                              // common prefix
+        int sf = tl < ml ? tl : ml; if (a + sf > ml) sf = ml - a;     // common suffix, not overlapping the prefix in either string
+        const int b = pl - sf, K1 = wg_uniform(S.K) + 1;
+        repeat_scan_min(S.rs, W.pseq, pl, LC_CTX(c).P->max_mismatch, 0x7FFF, K1, &S.repE, &S.repM, nullptr, &S.rs_bad, a - K1, b + K1);
+      }
     }
     SUBPHASE(c, 3, 5);
     WG_LANE0 {

@@ -257,7 +257,7 @@ int main(int argc, char **argv) {
   lancet_free(vcf);
   lancet_vdb_destroy(db); lancet_host_close(H); for (lancet_engine *e : engs) lancet_engine_destroy(e);
   if (!overflowed.empty()) {
-    fprintf(stderr, "lancet_gpu: %zu window(s) exceeded the engine's work space (tier-2 limits, DESIGN.md section 4) and contributed NO variants:\n", overflowed.size());
+    fprintf(stderr, "lancet_gpu: %zu window(s) exceeded the engine's work space (tier-2 limits, DESIGN.md section 9) and contributed NO variants:\n", overflowed.size());
     for (const std::string &w : overflowed) fprintf(stderr, "lancet_gpu:   %s\n", w.c_str());
     return 3;
   }

@@ -164,6 +164,14 @@ extern "C" void lancet_emu_repeat_scan_min(const uint8_t *s, int len, int mm, in
   *outE = e; *outM = m;
 }
 
+// the path form of the scan (kernels.h repeats_in_graph_paths): only the windows that overlap the positions [ra, rb) in either copy
+extern "C" void lancet_emu_repeat_scan_range(const uint8_t *s, int len, int mm, int lminM, int ra, int rb, int *outM) {
+  static WinShared S;
+  volatile int e = 0, m = 0, bad = 0;
+  repeat_scan_min(S.rs, s, len, mm, 0x7FFF, lminM, &e, &m, nullptr, &bad, ra, rb);
+  *outM = m;
+}
+
 // find_tandems_local (test hook; must equal the oracle's restatement of src/util.cc:574-758; `local` is kept in the signature, ignored)
 extern "C" int lancet_emu_find_tandems(const uint8_t *codes, int n, int pos, int max_unit_len, int min_report_units, int min_report_len, int dist_from_str,
                                        int local, int *len, uint8_t *motif, int *motif_len) {

@@ -54,6 +54,70 @@ def test_repeat_scan_bitparallel_matches_bytewise():
             assert out[0] == out[1], (len(s), mm, out)
 
 
+def test_repeat_scan_of_a_path_looks_only_around_what_differs_from_the_reference():
+    """kernels.h repeats_in_graph_paths (round 5): isAlmostRepeat of a path that differs from the reference between the anchors is decided
+    from the windows that overlap the difference (common prefix and suffix taken off), because the window reference passed the same test
+    for this k.  On references that pass it, random edits -- substitutions, insertions (random sequence, copies of what is next to them:
+    tandem duplications, copies from elsewhere: dispersed repeats), deletions, several edits far apart -- must be decided exactly like
+    the full byte-wise scan decides them (reference src/util.cc:317-360)."""
+    import ctypes
+    import numpy as np
+    L = emu.lib()
+    f = L.lancet_emu_repeat_scan
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    f.restype = None
+    g = L.lancet_emu_repeat_scan_range
+    g.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    g.restype = None
+    rng = np.random.default_rng(55)
+
+    def full_m(s, mm):
+        e, m = ctypes.c_int(-1), ctypes.c_int(-1)
+        f(s.ctypes.data, len(s), mm, 0, ctypes.byref(e), ctypes.byref(m))
+        return m.value
+
+    n_true = n_cases = 0
+    for trial in range(400):
+        n = int(rng.choice([120, 300, 599, 640]))
+        K = int(rng.choice([11, 13, 15, 21, 31, 45]))
+        mm = int(rng.choice([0, 1, 2, 2, 3]))
+        R = rng.integers(0, 4, size=n).astype(np.uint8)
+        if rng.random() < 0.3:                                       # low-complexity stretches: references near the limit
+            a = int(rng.integers(0, n - 40)); R[a:a + 40] = np.tile(rng.integers(0, 4, size=int(rng.integers(1, 5))).astype(np.uint8), 40)[:40]
+        if n - K <= 0 or full_m(R, mm) >= K + 1:
+            continue                                                 # (the loop over k never builds at such a k)
+        P = R.copy()
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(1, len(P) - 1)); kind = rng.random()
+            if kind < 0.3:
+                P[pos] = (P[pos] + 1 + rng.integers(0, 3)) % 4
+            elif kind < 0.5:
+                ln = int(rng.integers(1, 40)); P = np.concatenate([P[:pos], rng.integers(0, 4, size=ln).astype(np.uint8), P[pos:]])
+            elif kind < 0.7:                                         # tandem duplication
+                ln = int(rng.integers(1, min(60, pos) + 1)); P = np.concatenate([P[:pos], P[pos - ln:pos], P[pos:]])
+            elif kind < 0.8:                                         # a copy from elsewhere
+                ln = int(rng.integers(8, 50)); src = int(rng.integers(0, max(1, len(P) - ln))); P = np.concatenate([P[:pos], P[src:src + ln], P[pos:]])
+            else:
+                ln = int(rng.integers(1, min(40, len(P) - pos - 1) + 1)); P = np.concatenate([P[:pos], P[pos + ln:]])
+        P = np.ascontiguousarray(P)
+        if len(P) - K <= 0:
+            continue
+        ml = min(len(P), len(R))
+        neq = np.nonzero(P[:ml] != R[:ml])[0]; a = int(neq[0]) if len(neq) else ml
+        neq = np.nonzero(P[::-1][:ml] != R[::-1][:ml])[0]; sf = int(neq[0]) if len(neq) else ml
+        if len(P) == len(R) and a == ml:
+            continue
+        if a + sf > ml:
+            sf = ml - a
+        b = len(P) - sf
+        want = full_m(P, mm) >= K + 1
+        m = ctypes.c_int(-1)
+        g(P.ctypes.data, len(P), mm, K + 1, a - (K + 1), b + (K + 1), ctypes.byref(m))
+        assert (m.value >= K + 1) == want, (trial, n, K, mm, a, b, len(P), m.value, full_m(P, mm))
+        n_cases += 1; n_true += int(want)
+    assert n_cases > 200 and n_true > 20, (n_cases, n_true)
+
+
 def test_repeat_scan_long_matches_only_decides_like_the_full_scan():
     """repeat_scan_min looks only at match runs long enough to matter for `E >= k` (k >= lminE) and `M >= k + 1` (k + 1 >= lminM):
     every such decision must equal the byte-wise restatement's (reference src/util.cc:295-360)."""

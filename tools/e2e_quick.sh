@@ -8,7 +8,7 @@ for mode in "--active-region-off" ""; do
   done
 done
 # the same run four times with 5 s between the processes: the seconds of hipMalloc some of the runs above pay are the driver wiping the VRAM
-# the process BEFORE released (tools/malloc_probe.hip) -- a process that starts on an idle device pays none
+# the process BEFORE released (DESIGN_HISTORY.md 7a, tools/malloc_probe.hip) -- a process that starts on an idle device pays none
 echo "== --active-region-off, 5 s after the previous process, four times"
 for it in 1 2 3 4; do
   sleep 5
