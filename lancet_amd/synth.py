@@ -211,7 +211,7 @@ def _cigar_md(ref_b: np.ndarray, seq: np.ndarray, rpos: np.ndarray):
 def simulate_sample(ref: str, rname: str, haps: List[Tuple[np.ndarray, np.ndarray]], hap_probs: List[float],
                     coverage: float, seed: int, prefix: str, rg: str, read_len: int = 150,
                     insert_mean: float = 400.0, insert_sd: float = 40.0, error_rate: float = 0.005,
-                    region: Tuple[int, int] | None = None, linked: bool = False) -> List[Tuple[SamRead, SamRead]]:
+                    region: Tuple[int, int] | None = None, linked: bool = False, monotone_starts: bool = False) -> List[Tuple[SamRead, SamRead]]:
     """Simulates fragments; returns list of (read1, read2) with read1.pos <= read2.pos not guaranteed.
     linked=True adds 10x-style tags from a separate random stream (the reads themselves do not change): BX:Z barcode
     shared by a few fragments (some fragments have none), HP:i haplotype 0 (unassigned) / 1 / 2."""
@@ -224,13 +224,18 @@ def simulate_sample(ref: str, rname: str, haps: List[Tuple[np.ndarray, np.ndarra
     qual_levels = np.array([37, 30, 25, 12], dtype=np.uint8)
     qual_p = np.array([0.70, 0.15, 0.08, 0.07])
     pairs = []
+    # monotone_starts (tools/make_scan_bams.py with worker processes): the fragment start is looked up in the haplotype's reference
+    # coordinates with the inserted bases (-1) filled forward, so that the binary search is over a sorted array.  Without it (the generator
+    # of every fixture and of the bench workload: unchanged) a long insertion makes the search land on the same haplotype position for many
+    # starts -- a handful of windows per megabase then hold thousands of reads (the "pile-ups" of the earlier rounds' scans).
+    hsearch = [np.maximum.accumulate(hp_) for _, hp_ in haps] if monotone_starts else None
     for f in range(n_frag):
         h = int(rng.choice(len(haps), p=hap_probs))
         hb, hp = haps[h]
         ins = max(read_len, int(round(rng.normal(insert_mean, insert_sd))))
         # fragment start in haplotype coordinates, chosen through a reference coordinate inside region
         s_ref = int(rng.integers(lo, max(lo + 1, hi - ins)))
-        s = int(np.searchsorted(hp, s_ref))  # hp is non-decreasing except -1 runs; good enough
+        s = int(np.searchsorted(hsearch[h] if monotone_starts else hp, np.int32(s_ref)))  # hp is non-decreasing except -1 runs; good enough (int32 like hp: a Python int makes numpy convert the whole array per call)
         while s < len(hp) and hp[s] < 0:
             s += 1
         e = s + ins

@@ -4,8 +4,10 @@
 
 procs > 1: the contig is dealt out in stretches to worker processes (same reference, same planted variants; every stretch its own read
 seed; a fragment starts inside its stretch and may end in the next one, so the coverage has no seams), which simulate AND encode their
-reads; the parent sorts the records by (position, name, flag) and writes the BAM + .bai.  procs = 1 is the generator of the earlier rounds
-(build/scan500k was made with it)."""
+reads; the parent sorts the records by (position, name, flag) and writes the BAM + .bai.  Fragment starts are looked up in a sorted copy of
+the haplotype's coordinates (synth.simulate_sample monotone_starts): uniform coverage.  procs = 1 is the generator of the earlier rounds
+(build/scan500k was made with it): its binary search over coordinates with inserted bases piles thousands of fragments onto a few loci per
+megabase -- the coverage pile-ups of the earlier rounds' scans, kept there as they are a useful stress."""
 import multiprocessing as mp
 import os, struct, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,7 +39,7 @@ def _stretch(job):
     g = _G
     haps, probs, cov, seed, prefix, rg = (g["haps_t"], [0.5, 0.25, 0.25], g["cov_t"], 101, "T", "tumor") if which == "T" else (g["haps_n"], [0.5, 0.5], g["cov_n"], 202, "N", "normal")
     pairs = synth.simulate_sample(g["ref"], g["rname"], haps, probs, cov, seed + 1000 * i, f"{prefix}{i:02d}x", rg, read_len=150, error_rate=0.005,
-                                  region=(lo, min(hi + 400, len(g["ref"]))), insert_mean=400.0, insert_sd=40.0)
+                                  region=(lo, min(hi + 400, len(g["ref"]))), insert_mean=400.0, insert_sd=40.0, monotone_starts=True)
     keys, blob = [], bytearray()
     for a, b in pairs:
         for r in (a, b):

@@ -18,7 +18,7 @@ done
 cd /root/repo
 bash tools/kernel_resources.sh > $O/kernel_resources.txt 2>&1
 LANCET_UPLOAD_TIMING=1 bash tools/e2e_quick.sh > $O/e2e.txt 2>&1; grep -h "lancet upload" gpurun_out/e2e_native*.log | tail -24 >> $O/e2e.txt
-bash tools/e2e_5mb.sh > $O/e2e_5mb.txt 2>&1
+# (tools/e2e_5mb.sh is run on its own: it makes its 5 Mb BAM pairs on the box first -> profiles/r5_e2e_5mb.txt)
 timeout 200 python tools/quick_gpu.py bench 32768 > $O/phases_headline.txt 2>&1
 python tools/traffic_json.py $O $TAG --keep profiles/r4_traffic.json > $O/traffic.json
 rm -rf $O/kt gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
