@@ -306,16 +306,16 @@ def main():
     last = {}
     tm = {"gather": 0.0, "replay": 0.0, "pack": 0.0, "host": 0.0, "steps": 0}
 
-    # N ranks: what happens to a finished step's records -- keys + per-key reduction (pack_records), the sizes all_gather and the payload
-    # send / recv (gather_bytes), on rank 0 the replay -- runs on a communication thread of its own, so that the thread that submits the
-    # kernels only waits for them (step i's gather overlaps step i + 1's kernels; the C side and the collectives release the GIL).  The
-    # communication thread is the only one that issues collectives while steps run, in step order on every rank.  An engine's result
+    # N ranks: what happens to a finished step's records -- keys + per-key reduction (pack_records), then the sizes all_gather and the payload
+    # send / recv (gather_bytes), on rank 0 then the replay -- runs on threads of its own, a stage each, so that the thread that submits the
+    # kernels only waits for them (step i's gather overlaps step i + 1's kernels; the C side and the collectives release the GIL) and a
+    # slow gather (rank 0 waits for the slowest rank) does not hold up the packing of the next step's records.  An engine's result
     # buffers are valid until its next submit: `busy[engine]` is set when its records have been packed.
     comm_q = queue.Queue()
+    gather_q = queue.Queue()
     busy = {}
 
-    def comm_worker():
-        torch.cuda.set_device(device)            # (the current device is per thread)
+    def comm_worker():                           # stage 1: the finished engine's records -> one payload (keys, per-key reduction)
         while True:
             item = comm_q.get()
             try:
@@ -329,15 +329,29 @@ def main():
                     tm["pack"] += time.perf_counter() - tg
                 finally:
                     packed.set()                 # (the engine may be submitted again)
+                gather_q.put(payload)
+            except BaseException as ex:          # surfaced by run_steps
+                last["error"] = ex
+                gather_q.put(b"")                # (the other ranks wait in the collective: take part with nothing)
+            finally:
+                comm_q.task_done()
+
+    def gather_worker():                         # stage 2: the only thread that issues collectives while steps run, in step order on every rank
+        torch.cuda.set_device(device)            # (the current device is per thread)
+        while True:
+            payload = gather_q.get()
+            try:
+                if payload is None:
+                    return
                 tg = time.perf_counter()
                 parts = ldist.gather_bytes(payload, comm_device)
                 tm["gather"] += time.perf_counter() - tg; tm["steps"] += 1
                 if rank == 0:
                     merge_q.put(parts)
-            except BaseException as ex:          # surfaced by run_steps
+            except BaseException as ex:
                 last["error"] = ex
             finally:
-                comm_q.task_done()
+                gather_q.task_done()
 
     def complete(e):
         e.wait()
@@ -369,12 +383,14 @@ def main():
 
     if world > 1:
         threading.Thread(target=comm_worker, daemon=True).start()
+        threading.Thread(target=gather_worker, daemon=True).start()
         if rank == 0:
             threading.Thread(target=merger, daemon=True).start()
 
     def run_steps(k):
         _run_steps(k)
         comm_q.join()
+        gather_q.join()
         merge_q.join()
         if "error" in last:
             raise last["error"]

@@ -179,6 +179,14 @@ typedef struct lancet_packed_reads {
   const uint32_t *good;        /* 1 bit per base of the trimmed read */
   int32_t min_qual_trim;       /* the thresholds the reads were trimmed / masked with (lancet_params of the packing side) */
   int32_t min_qual_call;
+  /* Reads stored once (round 5).  Windows every 100 bases of 600 put an alignment into ~6 windows (reference src/Microassembler.cc:436-655
+   * fetches it for each of them).  read_index != NULL: the five arrays above describe n_distinct DISTINCT reads (offsets: n_distinct + 1
+   * entries) and read_index[r], r < read_begin[n_windows], says which of them read r of the batch is -- the words of an alignment are packed,
+   * staged and copied to the device once per batch instead of once per window that holds it.  label / strand / mate / mapped are the
+   * alignment's (in rinfo); only the name rank is per window (lancet_window_batch::name_rank).  NULL: one entry per read of the batch. */
+  const uint32_t *read_index;
+  uint32_t n_distinct;
+  uint32_t reserved2;          /* 0 */
 } lancet_packed_reads;
 int lancet_engine_upload_packed(lancet_engine *e, const lancet_window_batch *b, const lancet_packed_reads *p);
 /* One read, trimmed and packed: rinfo[0], (len + 15) / 16 words of bases and (len + 31) / 32 words of good are written (zero past the

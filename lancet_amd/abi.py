@@ -42,7 +42,8 @@ class LancetPackedReads(C.Structure):
     """include/lancet_engine.h lancet_packed_reads: the reads of a batch trimmed and packed by the caller."""
     _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32),
                 ("rinfo", C.POINTER(C.c_uint32)), ("base_woff", C.POINTER(C.c_uint32)), ("good_woff", C.POINTER(C.c_uint32)),
-                ("bases", C.POINTER(C.c_uint32)), ("good", C.POINTER(C.c_uint32)), ("min_qual_trim", C.c_int32), ("min_qual_call", C.c_int32)]
+                ("bases", C.POINTER(C.c_uint32)), ("good", C.POINTER(C.c_uint32)), ("min_qual_trim", C.c_int32), ("min_qual_call", C.c_int32),
+                ("read_index", C.POINTER(C.c_uint32)), ("n_distinct", C.c_uint32), ("reserved2", C.c_uint32)]
 
 
 class LancetVariantLR(C.Structure):

@@ -391,6 +391,7 @@ int lancet_engine_upload_packed(lancet_engine *e, const lancet_window_batch *b, 
     e->err = "lancet_packed_reads: struct_size " + std::to_string(pk->struct_size) + " is not this library's " + std::to_string(sizeof(lancet_packed_reads)) + " (caller built against another header)";
     return LANCET_E_ARG;
   }
+  if (e && pk && pk->read_index && pk->n_distinct == 0 && b && b->n_windows > 0 && b->read_begin[b->n_windows] > 0) { e->err = "packed reads: read_index without distinct reads"; return LANCET_E_ARG; }
   if (!e || !pk || !pk->rinfo || !pk->base_woff || !pk->good_woff || !pk->bases || !pk->good) { if (e) e->err = "packed reads missing"; return LANCET_E_ARG; }
   if (!e->host_prep) { e->err = "packed upload with LANCET_PREP=device"; return LANCET_E_STATE; }
   if (pk->min_qual_trim != e->params.min_qual_trim || pk->min_qual_call != e->params.min_qual_call) {
@@ -491,8 +492,11 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
       if (bad[(size_t)t] == 3) { e->err = "label must be LANCET_TMR / LANCET_NML, strand LANCET_FWD / LANCET_REV, mate 0, 1 or 2"; return LANCET_E_ARG; }
       tb[(size_t)t + 1] += tb[(size_t)t]; tg[(size_t)t + 1] += tg[(size_t)t];
     }
-    const uint64_t bo_all = tb[(size_t)T], go_all = tg[(size_t)T];
-    if (pk && ((uint64_t)pk->base_woff[R] != bo_all || (uint64_t)pk->good_woff[R] != go_all)) { e->err = "packed reads: word offsets do not match the read lengths"; return LANCET_E_ARG; }
+    // packed reads stored ONCE per batch (pk->read_index: a read of a window -> one of pk->n_distinct reads; an alignment lies in ~6 of the
+    // overlapping windows): the per-read words of the device batch point into the one copy, whose words are staged and copied once
+    const bool shared = pk && pk->read_index;
+    const uint64_t bo_all = shared ? (uint64_t)pk->base_woff[pk->n_distinct] : tb[(size_t)T], go_all = shared ? (uint64_t)pk->good_woff[pk->n_distinct] : tg[(size_t)T];
+    if (pk && !shared && ((uint64_t)pk->base_woff[R] != bo_all || (uint64_t)pk->good_woff[R] != go_all)) { e->err = "packed reads: word offsets do not match the read lengths"; return LANCET_E_ARG; }
     if (bo_all + 4 > 0xFFFFFFFFull) { e->err = "batch too large"; return LANCET_E_ARG; }
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
@@ -517,6 +521,15 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
     const lancet_params P = e->params;
     lc_parallel(T, (size_t)R, [&](size_t lo, size_t hi, int t) {
       uint64_t bo = tb[(size_t)t], go = tg[(size_t)t];
+      if (shared) {                                           // every read of a window names its distinct read; the distinct reads' words are copied below
+        const uint32_t nd = pk->n_distinct;
+        for (size_t r = lo; r < hi; ++r) {
+          const uint32_t len = b->seq_off[r + 1] - b->seq_off[r], u = pk->read_index[r];
+          if (u >= nd || pk->base_woff[u + 1] - pk->base_woff[u] != (len + 15) / 16 || pk->good_woff[u + 1] - pk->good_woff[u] != (len + 31) / 32 || RI_TLEN(pk->rinfo[u]) > len) { bad[(size_t)t] = 3; return; }
+          h_bw[r] = pk->base_woff[u]; h_gw[r] = pk->good_woff[u]; h_nm[r] = b->name_rank[r]; h_ri[r] = pk->rinfo[u];
+        }
+        return;
+      }
       if (pk) {                                               // packed by the caller: copied as they are (the offsets were checked above in total, here per read)
         for (size_t r = lo; r < hi; ++r) {
           const uint32_t len = b->seq_off[r + 1] - b->seq_off[r];
@@ -539,7 +552,11 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
         bo += (len + 15) / 16; go += (len + 31) / 32;
       }
     });
-    for (int t = 0; t < T; ++t) if (bad[(size_t)t] == 3) { e->err = "packed reads: word offsets / trimmed lengths do not match the read lengths"; return LANCET_E_ARG; }
+    for (int t = 0; t < T; ++t) if (bad[(size_t)t] == 3) { e->err = "packed reads: word offsets / trimmed lengths / read indices do not match the read lengths"; return LANCET_E_ARG; }
+    if (shared) {                                             // the one copy of the words
+      lc_parallel(T, (size_t)bo_all, [&](size_t lo, size_t hi, int) { memcpy(h_ba + lo, pk->bases + lo, 4 * (hi - lo)); });
+      lc_parallel(T, (size_t)go_all, [&](size_t lo, size_t hi, int) { memcpy(h_go + lo, pk->good + lo, 4 * (hi - lo)); });
+    }
     h_ri[R] = 0; h_bw[R] = (uint32_t)bo_all; h_gw[R] = (uint32_t)go_all;
     for (int i = 0; i < 4; ++i) h_ba[bo_all + (uint64_t)i] = 0;
     h_go[go_all] = 0;

@@ -88,6 +88,7 @@ struct Sample {
   Bytes pk_bases, pk_good;
   int pk_qtrim = -1, pk_qcall = -1; size_t pk_n = 0;
   std::unique_ptr<std::atomic<uint8_t>[]> pk_state;   // per alignment: 0 not packed yet, 1 a thread is packing it, 2 packed (pack_read_once)
+  std::vector<uint32_t> uidx;                          // lancet_host_batch_packed, reads stored once: per alignment its place among the batch's distinct reads of this sample (0xFFFFFFFF: in no window of the batch)
   std::vector<std::pair<size_t, size_t>> span;   // per contig of the tiling: its reads [first, last) (file order = coordinate order)
 };
 
@@ -673,7 +674,7 @@ struct lancet_host {
     void need(size_t n) { if (n > cap) { free(p); cap = n + n / 8 + 4096; p = (char *)malloc(cap); } }
     char *data() { return p; }
   } b_seq, b_qual, b_pbases, b_pgood;      // ASCII bases / qualities, or (lancet_host_batch_packed) their packed form
-  std::vector<uint32_t> b_rinfo, b_bw, b_gw;
+  std::vector<uint32_t> b_rinfo, b_bw, b_gw, b_ridx;   // (b_ridx: reads stored once -- which distinct read each read of a window is; the three others then describe the distinct reads)
   std::vector<uint8_t> b_label, b_strand, b_mate, b_mapped, b_hp;
   std::vector<std::string> bx_names;
   std::vector<const char *> bx_ptrs;
@@ -1184,12 +1185,84 @@ static int host_batch_impl(lancet_host *h, int w_begin, int w_end, const lancet_
   const size_t R = h->b_readbegin[(size_t)nk], NB = (size_t)base0[(size_t)nk];
   h->b_ref.resize(h->b_refoff[(size_t)nk]);
   const bool packed = P != nullptr;
+  // Reads stored once (LANCET_HOST_SHARED=0: one copy per window, as until round 5): windows every 100 bases of 600 put an alignment into ~6
+  // of them.  The batch's DISTINCT alignments are numbered (per sample in file order: tumor, normal, then the two stores of left-over reads),
+  // trimmed + packed on first use as before, and their words go into the batch once; a read of a window is an index into them.
+  const bool shared = packed && !(getenv("LANCET_HOST_SHARED") && atoi(getenv("LANCET_HOST_SHARED")) == 0);
+  uint32_t ubase[4] = {0, 0, 0, 0}; size_t U = 0; uint64_t ubw_all = 0, ugw_all = 0;
+  std::vector<std::pair<uint8_t, uint32_t>> ulist;                  // distinct read u -> (sample, alignment)
   if (packed) {
+    for (int smp = 0; smp < 4; ++smp) ensure_pack_cache(h->smp[smp], *P);
+    if (shared) {
+      for (int smp = 0; smp < 4; ++smp) h->smp[smp].uidx.assign(h->smp[smp].reads.size(), 0xFFFFFFFFu);
+      {   // which alignments the batch's windows hold (the same word from several threads: relaxed stores)
+        std::atomic<int> next(0);
+        auto mark = [&]() {
+          for (;;) {
+            const int k = next.fetch_add(1);
+            if (k >= nk) break;
+            const int i = kw[(size_t)k];
+            for (const RSel &rs : pre[(size_t)k]) __atomic_store_n(&h->smp[rs.smp].uidx[rs.s.idx], 0u, __ATOMIC_RELAXED);
+            for (const Sel &s2 : selT[(size_t)i]) __atomic_store_n(&h->smp[1].uidx[s2.idx], 0u, __ATOMIC_RELAXED);
+            for (const Sel &s2 : selN[(size_t)i]) __atomic_store_n(&h->smp[0].uidx[s2.idx], 0u, __ATOMIC_RELAXED);
+          }
+        };
+        unsigned nt = host_threads(nk);
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(mark);
+        mark();
+        for (auto &t : th) t.join();
+      }
+      const int order[4] = {1, 0, 2, 3};
+      for (int q = 0; q < 4; ++q) {
+        Sample &S = h->smp[order[q]];
+        ubase[order[q]] = (uint32_t)U;
+        uint32_t c = 0;
+        for (size_t i = 0; i < S.uidx.size(); ++i) if (S.uidx[i] != 0xFFFFFFFFu) { S.uidx[i] = c++; ulist.emplace_back((uint8_t)order[q], (uint32_t)i); }
+        U += c;
+      }
+      h->b_rinfo.resize(U + 1); h->b_bw.resize(U + 1); h->b_gw.resize(U + 1); h->b_ridx.resize(R);
+      for (size_t u = 0; u < U; ++u) {
+        const uint32_t l = h->smp[ulist[u].first].reads[ulist[u].second].l_seq;
+        h->b_bw[u] = (uint32_t)ubw_all; h->b_gw[u] = (uint32_t)ugw_all;
+        ubw_all += (l + 15) / 16; ugw_all += (l + 31) / 32;
+      }
+      if (ubw_all + 4 > 0xFFFFFFFFull) { h->err = "batch too large"; return LANCET_E_ARG; }
+      h->b_bw[U] = (uint32_t)ubw_all; h->b_gw[U] = (uint32_t)ugw_all; h->b_rinfo[U] = 0;
+      h->b_pbases.need(4 * ((size_t)ubw_all + 4)); h->b_pgood.need(4 * ((size_t)ugw_all + 1));
+      if (!h->b_pbases.p || !h->b_pgood.p) { h->err = "out of memory for the batch"; return LANCET_E_ARG; }
+      {   // the distinct reads: trimmed + packed when first met (pack_read_once), their words into the batch, once
+        std::atomic<size_t> next(0);
+        auto packu = [&]() {
+          for (;;) {
+            const size_t u0 = next.fetch_add(256);
+            if (u0 >= U) break;
+            const size_t u1 = u0 + 256 < U ? u0 + 256 : U;
+            for (size_t u = u0; u < u1; ++u) {
+              const int smp = ulist[u].first; const uint32_t idx = ulist[u].second;
+              Sample &S = h->smp[smp];
+              const Read &rd = S.reads[idx];
+              pack_read_once(S, *P, idx);
+              memcpy((uint32_t *)h->b_pbases.p + h->b_bw[u], (const uint32_t *)S.pk_bases.data() + S.pk_bw[idx], 4 * (size_t)((rd.l_seq + 15) / 16));
+              memcpy((uint32_t *)h->b_pgood.p + h->b_gw[u], (const uint32_t *)S.pk_good.data() + S.pk_gw[idx], 4 * (size_t)((rd.l_seq + 31) / 32));
+              const uint8_t mate = (rd.flag & 0x40) ? 1 : ((rd.flag & 0x80) ? 2 : 0);
+              h->b_rinfo[u] = lc_rinfo_word(S.pk_tlen[idx], (smp & 1) ? LANCET_TMR : LANCET_NML, (rd.flag & 0x10) ? LANCET_REV : LANCET_FWD,
+                                            ((rd.flag & 0x40) && (rd.flag & 0x80)) ? 2 : mate, (uint8_t)((rd.flag & 0x4) ? 0 : 1));      // (as extract_reads derives them: the alignment's own, whatever the window)
+            }
+          }
+        };
+        unsigned nt = host_threads((int)std::min<size_t>(U / 256 + 1, 1u << 20));
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(packu);
+        packu();
+        for (auto &t : th) t.join();
+      }
+    } else {
     if (bw0[(size_t)nk] + 4 > 0xFFFFFFFFull) { h->err = "batch too large"; return LANCET_E_ARG; }
     h->b_pbases.need(4 * ((size_t)bw0[(size_t)nk] + 4)); h->b_pgood.need(4 * ((size_t)gw0[(size_t)nk] + 1));
     if (!h->b_pbases.p || !h->b_pgood.p) { h->err = "out of memory for the batch"; return LANCET_E_ARG; }
     h->b_rinfo.resize(R + 1); h->b_bw.resize(R + 1); h->b_gw.resize(R + 1);
-    for (int smp = 0; smp < 4; ++smp) ensure_pack_cache(h->smp[smp], *P);
+    }
   } else {
   h->b_seq.need(NB + 1); h->b_qual.need(NB + 1);
   if (!h->b_seq.p || !h->b_qual.p) { h->err = "out of memory for the batch"; return LANCET_E_ARG; }
@@ -1218,7 +1291,8 @@ static int host_batch_impl(lancet_host *h, int w_begin, int w_end, const lancet_
             Sample &S = h->smp[smp];
             const Read &rd = S.reads[s.idx];
             h->b_label[r] = (smp & 1) ? LANCET_TMR : LANCET_NML; h->b_strand[r] = s.strand; h->b_mate[r] = s.mate; h->b_mapped[r] = s.mapped;
-            if (packed) {
+            if (shared) h->b_ridx[r] = ubase[smp] + S.uidx[s.idx];
+            else if (packed) {
               uint32_t *pb = (uint32_t *)h->b_pbases.p + pbo, *pg = (uint32_t *)h->b_pgood.p + pgo;
               h->b_bw[r] = (uint32_t)pbo; h->b_gw[r] = (uint32_t)pgo;
               const uint32_t nbw = (rd.l_seq + 15) / 16, ngw = (rd.l_seq + 31) / 32;
@@ -1276,9 +1350,16 @@ static int host_batch_impl(lancet_host *h, int w_begin, int w_end, const lancet_
   out->read_begin = h->b_readbegin.data(); out->seq_off = h->b_seqoff.data(); out->seq = packed ? nullptr : h->b_seq.data(); out->qual = packed ? nullptr : h->b_qual.data();
   if (packed) {
     uint32_t *pb = (uint32_t *)h->b_pbases.p, *pg = (uint32_t *)h->b_pgood.p;
+    memset(pk, 0, sizeof *pk);
+    if (shared) {
+      for (int q = 0; q < 4; ++q) pb[ubw_all + (uint64_t)q] = 0;
+      pg[ugw_all] = 0;
+      pk->read_index = h->b_ridx.data(); pk->n_distinct = (uint32_t)U;
+    } else {
     for (int q = 0; q < 4; ++q) pb[bw0[(size_t)nk] + (uint64_t)q] = 0;
     pg[gw0[(size_t)nk]] = 0;
     h->b_rinfo[R] = 0; h->b_bw[R] = (uint32_t)bw0[(size_t)nk]; h->b_gw[R] = (uint32_t)gw0[(size_t)nk];
+    }
     pk->struct_size = (uint32_t)sizeof(lancet_packed_reads); pk->reserved = 0;
     pk->rinfo = h->b_rinfo.data(); pk->base_woff = h->b_bw.data(); pk->good_woff = h->b_gw.data(); pk->bases = pb; pk->good = pg;
     pk->min_qual_trim = P->min_qual_trim; pk->min_qual_call = P->min_qual_call;

@@ -116,6 +116,9 @@ class Engine:
             if k not in packed:
                 raise EngineError(f"upload_packed: the packed dict has no '{k}' (the thresholds the reads were trimmed / masked with)")
         pk.min_qual_trim = int(packed["min_qual_trim"]); pk.min_qual_call = int(packed["min_qual_call"])
+        if packed.get("read_index") is not None:              # the reads stored once per batch (include/lancet_engine.h)
+            keep["read_index"] = np.ascontiguousarray(packed["read_index"], dtype=np.uint32)
+            pk.read_index = keep["read_index"].ctypes.data_as(C.POINTER(C.c_uint32)); pk.n_distinct = int(packed["n_distinct"])
         self._packed_keep = keep
         self.L.lancet_engine_upload_packed.restype = C.c_int
         self.L.lancet_engine_upload_packed.argtypes = [C.c_void_p, C.POINTER(abi.LancetWindowBatch), C.POINTER(abi.LancetPackedReads)]

@@ -155,9 +155,13 @@ class NativeHost:
             strand=arr(cb.strand, R, np.uint8), mate=arr(cb.mate, R, np.uint8), mapped=arr(cb.mapped, R, np.uint8),
             name_rank=arr(cb.name_rank, R, np.uint32), **lr)
         if pack_params is not None:
-            bw = arr(pk.base_woff, R + 1, np.uint32); gw = arr(pk.good_woff, R + 1, np.uint32)
-            packed = dict(rinfo=arr(pk.rinfo, R + 1, np.uint32), base_woff=bw, good_woff=gw,
-                          bases=arr(pk.bases, (int(bw[-1]) if R else 0) + 4, np.uint32), good=arr(pk.good, (int(gw[-1]) if R else 0) + 1, np.uint32),
+            shared = bool(pk.read_index)                      # the reads stored once: the arrays describe pk.n_distinct distinct reads
+            U = int(pk.n_distinct) if shared else R
+            bw = arr(pk.base_woff, U + 1, np.uint32); gw = arr(pk.good_woff, U + 1, np.uint32)
+            packed = dict(rinfo=arr(pk.rinfo, U + 1, np.uint32), base_woff=bw, good_woff=gw,
+                          bases=arr(pk.bases, (int(bw[-1]) if U else 0) + 4, np.uint32), good=arr(pk.good, (int(gw[-1]) if U else 0) + 1, np.uint32),
                           min_qual_trim=int(pk.min_qual_trim), min_qual_call=int(pk.min_qual_call))
+            if shared:
+                packed["read_index"] = arr(pk.read_index, R, np.uint32); packed["n_distinct"] = U
             return b, idx, packed
         return b, idx

@@ -216,14 +216,14 @@ def algorithmic_bytes(b: WindowBatch, stats, n_variants: int) -> int:
 
 
 def kernel_fingerprint() -> str:
-    """sha1 over the device sources (lancet_amd/csrc/*.h, *.hip): what a measurement that was not taken by this very process (the PMC
-    traffic passes, profiles/*_traffic.json) must have been taken on for bench.py to quote it."""
+    """sha1 over the kernels' sources (the device headers of lancet_amd/csrc: kernels.h, build_lds.h, build_lds_impl.h, wave.h, layout.h):
+    what a measurement that was not taken by this very process (the PMC traffic passes, profiles/*_traffic.json) must have been taken on
+    for bench.py to quote it."""
     import hashlib
     import os
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
     h = hashlib.sha1()
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".hip")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in ("build_lds.h", "build_lds_impl.h", "kernels.h", "layout.h", "wave.h"):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

@@ -42,7 +42,7 @@ def test_struct_layouts_match_header(lib):
     assert ctypes.sizeof(abi.LancetParams) == 72
     assert ctypes.sizeof(abi.LancetVariant) == 64
     assert ctypes.sizeof(abi.LancetWindowStats) == 32
-    assert ctypes.sizeof(abi.LancetPackedReads) == 56 and abi.LancetPackedReads.struct_size.offset == 0      # (the size travels in the first field)
+    assert ctypes.sizeof(abi.LancetPackedReads) == 72 and abi.LancetPackedReads.struct_size.offset == 0      # (the size travels in the first field)
     p = abi.LancetParams()
     lib.lancet_params_default(ctypes.byref(p))
     d = abi.default_params()

@@ -705,11 +705,13 @@ def test_lazy_per_batch_loading_gives_the_same_batches(tmp_path, monkeypatch, ca
         _batches_equal(e1[0], workload.concat_batches(l2))
 
 
-def test_packed_batch_equals_packing_the_ascii_batch():
+@pytest.mark.parametrize("shared_form", [True, False])
+def test_packed_batch_equals_packing_the_ascii_batch(shared_form, monkeypatch):
     """lancet_host_batch_packed (the host threads trim and pack while they assemble the batch) against lancet_pack_read -- the routine
     lancet_engine_upload runs on the ASCII arrays -- applied read by read to the batch of lancet_host_batch: same window arrays, same trimmed
     lengths and flags, same packed words at the same offsets; with qualities that make the trim bite (--min-base-qual / trim parameters away
     from their defaults) and on the read-filter golden."""
+    monkeypatch.setenv("LANCET_HOST_SHARED", "1" if shared_form else "0")
     import ctypes as C
     from lancet_amd import abi, engine
     L = engine.lib()
@@ -733,16 +735,24 @@ def test_packed_batch_equals_packing_the_ascii_batch():
                 assert np.array_equal(getattr(b, f), getattr(b2, f)), f
         R = b.n_reads
         lens = np.diff(b.seq_off.astype(np.int64))
-        assert np.array_equal(np.diff(pk["base_woff"].astype(np.int64)), (lens + 15) // 16) and np.array_equal(np.diff(pk["good_woff"].astype(np.int64)), (lens + 31) // 32)
+        # round 5: the reads are stored once per batch -- `read_index` says which distinct read a read of a window is (an alignment lies in
+        # several of the overlapping windows); LANCET_HOST_SHARED=0 (second pass of this test) keeps one copy per window
+        ridx = pk["read_index"].astype(np.int64) if "read_index" in pk else np.arange(R)
+        if shared_form:
+            assert "read_index" in pk and pk["n_distinct"] < R and len(pk["rinfo"]) == pk["n_distinct"] + 1, case
+        else:
+            assert "read_index" not in pk
+        assert np.array_equal(np.diff(pk["base_woff"].astype(np.int64))[ridx], (lens + 15) // 16) and np.array_equal(np.diff(pk["good_woff"].astype(np.int64))[ridx], (lens + 31) // 32)
         seq, qual = b.seq.tobytes(), b.qual.tobytes()
         trimmed = 0
         for r in range(0, R, max(1, R // 3000)):                       # (a few thousand reads per case)
             n = int(lens[r]); so = int(b.seq_off[r])
             ri = C.c_uint32(); wb = (C.c_uint32 * ((n + 15) // 16 + 1))(); wg = (C.c_uint32 * ((n + 31) // 32 + 1))()
             L.lancet_pack_read(C.byref(p), seq[so:so + n], qual[so:so + n], n, int(b.label[r]), int(b.strand[r]), int(b.mate[r]), int(b.mapped[r]), C.byref(ri), wb, wg)
-            assert ri.value == int(pk["rinfo"][r]), (case, r)
+            u = int(ridx[r])
+            assert ri.value == int(pk["rinfo"][u]), (case, r)
             trimmed += int((ri.value & 0xFFFF) < n)
-            a0 = int(pk["base_woff"][r]); g0 = int(pk["good_woff"][r])
+            a0 = int(pk["base_woff"][u]); g0 = int(pk["good_woff"][u])
             assert list(wb)[: (n + 15) // 16] == pk["bases"][a0:a0 + (n + 15) // 16].tolist(), (case, r)
             assert list(wg)[: (n + 31) // 32] == pk["good"][g0:g0 + (n + 31) // 32].tolist(), (case, r)
         if over:

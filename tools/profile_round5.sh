@@ -20,5 +20,8 @@ bash tools/kernel_resources.sh > $O/kernel_resources.txt 2>&1
 LANCET_UPLOAD_TIMING=1 bash tools/e2e_quick.sh > $O/e2e.txt 2>&1; grep -h "lancet upload" gpurun_out/e2e_native*.log | tail -24 >> $O/e2e.txt
 # (tools/e2e_5mb.sh is run on its own: it makes its 5 Mb BAM pairs on the box first -> profiles/r5_e2e_5mb.txt)
 timeout 200 python tools/quick_gpu.py bench 32768 > $O/phases_headline.txt 2>&1
+for c in bench60 bench4 bench5; do timeout 200 python tools/quick_gpu.py $c 8192 > $O/phases_$c.txt 2>&1; done
+# the N-rank path end to end on the one-GPU box (both ranks on device 0, gather over gloo): a check of the communication thread, not a measurement
+LANCET_BENCH_ONE_GPU=1 timeout 300 python bench.py --gpus 2 --steps 10 --windows 8192 --cpu-sample 0 --no-configs --no-bam > $O/bench_2rank_onegpu.json 2> $O/bench_2rank_onegpu.err; tail -n 1 $O/bench_2rank_onegpu.json | cut -c1-200
 python tools/traffic_json.py $O $TAG --keep profiles/r4_traffic.json > $O/traffic.json
 rm -rf $O/kt gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
