@@ -70,21 +70,47 @@ __global__ void __launch_bounds__(bl_large::WG) __attribute__((amdgpu_waves_per_
 __global__ void svc_init_kernel(SvcCtl *sv, SvcCtl v) { *sv = v; }
 __global__ void svc_done_kernel(SvcCtl *sv) { __hip_atomic_store(&sv->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Processing order of the window kernel: longest expected first.  A slot takes the next window of the list when it is through with
+// one, so the launch ends one window's time after the list runs dry: what is taken last has to be short, and what may run long has to be
+// under way early.  What the build kernel left in the hand-off area says how long a window will take (tools/window_cost.py,
+// profiles/r5_window_order.txt; eighths of a millisecond of a slot at 30x-60x):
+//   not built (general build phases in the window kernel)      very long              first
+//   a read repeats a k-mer (`heavy`: k will climb, 2+ builds)   2.1 ms, up to 6
+//   first compress not done here (several components)           1.3 ms .. 2.9 ms by the number of survivors
+//   first compress done: nodes left in the table                3 .. 5: 0.35 ms (no bubble: nothing to align), 8: 1.1 ms, 11: 1.7 ms, 16: 2.6 ms
+//   no reads / no k                                             0.1 ms                 last
+// Only the order changes; results are sorted by (window, emission) afterwards.
+#define ORD_CLASSES 32
+#define LC_COUNTER_BYTES 512            /* u32: 0..3 results, 2 the window kernel's queue head, 8..15 the build kernels', 32..63 windows per class, 64..95 places given out per class */
+__device__ uint32_t order_class(const uint8_t *area, uint32_t chdr) {
+  const PreHdr *H = (const PreHdr *)(area + PRE_OFF_HDR);
+  if (H->status != PB_BUILT) return (H->why == BLW_NOREADS || H->why == BLW_K) ? 0u : 31u;
+  if (H->heavy) return 26u;
+  const PreCmp *Cm = (const PreCmp *)(area + chdr);
+  if (Cm->done) { const uint32_t m = Cm->m_live; return m <= 5u ? 3u : std::min(23u, (3u * m) / 2u - 3u); }
+  const uint32_t ns = H->nsurv;
+  return ns <= 520u ? 10u : std::min(23u, (ns - 400u) / 12u);
+}
+__global__ void order_class_kernel(const uint8_t *pre, uint32_t stride, uint32_t chdr, int n_windows, uint8_t *cls, uint32_t *cnt, int two) {
+  const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (w >= n_windows) return;
+  uint32_t c = order_class(pre + (size_t)w * stride, chdr);
+  if (two && c) c = c >= 26u ? 31u : 1u;          // (LANCET_ORDER=two: what will run long first, the rest as they come -- the order of round 4)
+  cls[w] = (uint8_t)c;
+  atomicAdd(&cnt[c], 1u);
+}
+__global__ void order_place_kernel(int n_windows, const uint8_t *cls, const uint32_t *cnt, uint32_t *cur, uint32_t *list) {
+  const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (w >= n_windows) return;
+  const uint32_t c = cls[w];
+  uint32_t base = 0;
+  for (uint32_t q = ORD_CLASSES - 1u; q > c; --q) base += cnt[q];
+  list[base + atomicAdd(&cur[c], 1u)] = (uint32_t)w;
+}
+
 // Graph_t::trim (reference src/Graph.cc:355-384) + 2-bit packing + quality mask, one wave per read: the lanes look at consecutive
 // bases (a wave instruction reads 64 consecutive bytes), first / last base that is DNA with quality >= MIN_QUAL_TRIM by wave
 // reduction, junk test (a non-ACGT base inside the kept part) by ballot, then one output word per lane.
-// Processing order of the window kernel: the windows the build kernel could not take (general build phases: slow) and those
-// with a read that repeats a k-mer (a tandem duplication: k will climb over several builds) first, so that the few long-running
-// windows do not end up as the tail of the launch.  Only the order changes; results are sorted by (window, emission) afterwards.
-__global__ void order_kernel(const uint8_t *pre, uint32_t stride, int n_windows, uint32_t *list, uint32_t *cnt) {
-  const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (w >= n_windows) return;
-  const PreHdr *H = (const PreHdr *)(pre + (size_t)w * stride + PRE_OFF_HDR);
-  const bool first = H->status != PB_BUILT ? (H->why != BLW_NOREADS) : (H->heavy != 0);
-  if (first) list[atomicAdd(&cnt[0], 1u)] = (uint32_t)w;
-  else list[(uint32_t)n_windows - 1u - atomicAdd(&cnt[1], 1u)] = (uint32_t)w;
-}
-
 __global__ void __launch_bounds__(256) prep_kernel(const lancet_params *P, int n_reads, const char *seq, const char *qual, const uint32_t *seq_off,
                             const uint8_t *label, const uint8_t *strand, const uint8_t *mate, const uint8_t *mapped,
                             uint32_t *rinfo, uint32_t *bases, const uint32_t *bw, uint32_t *good, const uint32_t *gw) {
@@ -194,6 +220,7 @@ struct lancet_engine {
   uint32_t pool_cap = 0; int ahead_depth = 6;      // graphs built ahead for windows whose k will climb (build_lds.h, build_kernel_body)
   int n_ahead_built = 0, n_ahead_used = 0;
   bool heavy_first = true;    // LANCET_NO_HEAVY_FIRST=1: windows in batch order
+  int order_mode = 0;         // LANCET_ORDER=two: two classes only (see order_class)
   unsigned long long blphase[16] = {0};
   int n_bslots = 0, n_prebuilt = 0;
   bool prebuild = true;       // LANCET_NO_PREBUILD=1: every window through the general build phases (comparison / debugging)
@@ -322,6 +349,7 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   e->up_timing = getenv("LANCET_UPLOAD_TIMING") != nullptr;
   e->dbg = getenv("LANCET_DEBUG") != nullptr; e->no_fat = getenv("LANCET_NO_FAT") != nullptr; e->no_early_rerun = getenv("LANCET_NO_EARLY_RERUN") != nullptr;
   e->no_large_build = getenv("LANCET_NO_LARGE_BUILD") != nullptr; e->heavy_first = getenv("LANCET_NO_HEAVY_FIRST") == nullptr;
+  if (const char *s = getenv("LANCET_ORDER")) e->order_mode = strcmp(s, "two") == 0 ? 1 : 0;
   if (const char *s = getenv("LANCET_BUILD_SLOTS")) e->build_slots_env = std::max(1, atoi(s));
   if (const char *s = getenv("LANCET_AHEAD_DEPTH")) e->ahead_depth_env = std::max(0, std::min(16, atoi(s)));
   if (const char *s = getenv("LANCET_SVC_HELP")) e->svc_help = atoi(s) != 0;
@@ -655,7 +683,7 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
   ENS(e->d_variants, sizeof(lancet_variant) * e->caps.var_cap);
   ENS(e->d_blob, e->caps.blob_cap);
   if (e->caps.lr_mode) { ENS(e->d_varlr, sizeof(lancet_variant_lr) * e->caps.var_cap); ENS(e->d_bxblob, sizeof(uint32_t) * e->caps.bx_cap); }
-  ENS(e->d_counters, 128);
+  ENS(e->d_counters, LC_COUNTER_BYTES);
   ENS(e->d_stats, sizeof(lancet_window_stats) * nw);
   ENS(e->d_evtlen, sizeof(uint32_t) * nw);
   ENS(e->d_phase, sizeof(unsigned long long) * 16 * nw);
@@ -718,7 +746,7 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
     e->n_bslots_large = (e->no_large_build || !may_need_large) ? 0 : std::min(nw, cus);
     if (e->n_bslots_large) { ENS(e->d_blscratch_large, (size_t)e->n_bslots_large * bl_large::SCRATCH_BYTES); ENS(e->d_biglist, sizeof(uint32_t) * (size_t)nw); }
     ENS(e->d_blphase, 16 * sizeof(unsigned long long));
-    if (e->heavy_first) { ENS(e->d_order, sizeof(uint32_t) * (size_t)nw); o.win_list = (LC_GLOBAL const uint32_t *)e->d_order.p; o.n_list = (uint32_t)nw; }
+    if (e->heavy_first) { ENS(e->d_order, (sizeof(uint32_t) + 1u) * (size_t)nw); o.win_list = (LC_GLOBAL const uint32_t *)e->d_order.p; o.n_list = (uint32_t)nw; }
     o.pre = (LC_GLOBAL const uint8_t *)e->d_pre.p;
     e->ahead_depth = e->ahead_depth_env >= 0 ? e->ahead_depth_env : 6;
     e->pool_cap = e->ahead_depth > 0 ? (uint32_t)std::max(64, nw / 4) : 0u;
@@ -820,8 +848,10 @@ static int lc_submit_body(lancet_engine *e) {
       if (e->dbg) { HIPCHK(e, hipStreamSynchronize(e->stream)); DBG("build_kernel_large done"); }
     }
     if (e->heavy_first) {
-      hipLaunchKernelGGL(order_kernel, dim3((e->n_windows + 255) / 256), dim3(256), 0, e->stream, (const uint8_t *)e->d_pre.p, e->caps.pl.stride, e->n_windows, (uint32_t *)e->d_order.p,
-                         (uint32_t *)e->d_counters.p + 16);
+      uint8_t *cls = (uint8_t *)e->d_order.p + sizeof(uint32_t) * (size_t)e->n_windows;
+      uint32_t *cnt = (uint32_t *)e->d_counters.p + 32;
+      hipLaunchKernelGGL(order_class_kernel, dim3((e->n_windows + 255) / 256), dim3(256), 0, e->stream, (const uint8_t *)e->d_pre.p, e->caps.pl.stride, e->caps.pl.chdr, e->n_windows, cls, cnt, e->order_mode);
+      hipLaunchKernelGGL(order_place_kernel, dim3((e->n_windows + 255) / 256), dim3(256), 0, e->stream, e->n_windows, (const uint8_t *)cls, (const uint32_t *)cnt, cnt + ORD_CLASSES, (uint32_t *)e->d_order.p);
       HIPCHK(e, hipGetLastError());
     }
     HIPCHK(e, hipEventRecord(e->evb1, e->stream));
@@ -862,7 +892,7 @@ int lancet_engine_submit(lancet_engine *e) {
   e->slots2_pred = 0;
   if (!e->pred.empty()) { e->slots2_pred = lc_prepare_rerun(e, e->pred, 4, true); if (e->slots2_pred < 0) return e->slots2_pred; }
   if (e->wait_ev) HIPCHK(e, hipStreamWaitEvent(e->stream, e->wait_ev, 0));
-  HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, 128, e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, LC_COUNTER_BYTES, e->stream));
   HIPCHK(e, hipMemsetAsync(e->d_stats.p, 0, sizeof(lancet_window_stats) * e->n_windows, e->stream));
   if (e->prebuild) HIPCHK(e, hipMemsetAsync(e->d_blphase.p, 0, 16 * sizeof(unsigned long long), e->stream));      // (before the service starts: its workgroups add to it too)
   e->ms_build = 0; e->n_prebuilt = 0;
@@ -1155,6 +1185,17 @@ int lancet_debug_pre_headers(lancet_engine *e, uint32_t *out) {
     if (hipMemcpy(h.data(), (const uint8_t *)e->d_pre.p + (size_t)w * e->caps.pl.stride + PRE_OFF_HDR, sizeof(PreHdr), hipMemcpyDeviceToHost) != hipSuccess) return LANCET_E_STATE;
     out[8 * w] = h[0].status | (h[0].why << 8) | (h[0].have_order == 1u ? 1u << 16 : 0u); out[8 * w + 1] = h[0].K; out[8 * w + 2] = h[0].heavy; out[8 * w + 3] = h[0].N;
     out[8 * w + 4] = h[0].nsurv; out[8 * w + 5] = h[0].numcomp; out[8 * w + 6] = h[0].ncand; out[8 * w + 7] = h[0].next;
+  }
+  return LANCET_OK;
+}
+
+// test / tuning hook: per window of the last run, what the build kernel's first compress left (done, nodes in the table, k-mer nodes merged away, words of sequence)
+int lancet_debug_pre_cmp(lancet_engine *e, uint32_t *out) {
+  if (!e || !e->uploaded || !e->d_pre.p) return LANCET_E_STATE;
+  PreCmp h;
+  for (int w = 0; w < e->n_windows; ++w) {
+    if (hipMemcpy(&h, (const uint8_t *)e->d_pre.p + (size_t)w * e->caps.pl.stride + e->caps.pl.chdr, sizeof(PreCmp), hipMemcpyDeviceToHost) != hipSuccess) return LANCET_E_STATE;
+    out[4 * w] = h.done; out[4 * w + 1] = h.m_live; out[4 * w + 2] = h.dead; out[4 * w + 3] = h.seqn;
   }
   return LANCET_OK;
 }

@@ -4893,6 +4893,9 @@ DEVNI bool try_suspend(Ctx &c, int k) {
     ct.n_builds = S.n_builds; ct.final_k = S.final_k; ct.max_nodes = S.max_nodes; ct.evt_len = S.evt_len; ct.N_last = S.N_last; ct.sum_nodes = S.sum_nodes;
     ct.n_kmers = S.n_kmers;
     sv->req[i].w = (uint32_t)w; sv->req[i].k = k;
+#ifdef LANCET_PROF_TIMELINE
+    S.phase_acc[4] = wall_clock64();                          // (when it was put aside)
+#endif
     if (LC_CTX(c).OUT->phase) for (int q = 0; q < 16; ++q) LC_CTX(c).OUT->phase[(size_t)w * 16 + q] = S.phase_acc[q];
     S.status = LANCET_W_SUSPENDED;
   }
@@ -5189,11 +5192,17 @@ DEV int window_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     if (threadIdx.x == 0) {
       for (int i = 0; i < 16; ++i) S->phase_acc[i] = (rq >= 0 && OUT->phase) ? OUT->phase[(size_t)w * 16 + i] : 0ull;
       S->phase_cur = 0; S->t_last = wall_clock64();
+#ifdef LANCET_PROF_TIMELINE   /* profiling builds only (tools/timeline.py): when the window was taken, resumed and finished, in the slots of the general build's phases */
+      if (rq < 0) { S->phase_acc[2] = S->t_last; S->phase_acc[4] = 0; S->phase_acc[5] = 0; S->phase_acc[6] = 0; S->phase_acc[7] = (unsigned long long)slot; } else { S->phase_acc[5] = S->t_last; S->phase_acc[6] += 1; }
+#endif
     }
 #endif
     process_window(c, w, rq);
     if (wg_bcast(&S->status) == LANCET_W_SUSPENDED) continue;
     PHASE(c, 0);
+#ifdef LANCET_PROF_TIMELINE
+    WG_LANE0 { S->phase_acc[3] = wall_clock64(); }
+#endif
     WG_LANE0 {
       lancet_window_stats &st = OUT->stats[w];
       st.status = S->status; st.final_k = S->final_k; st.n_builds = S->n_builds; st.n_variants = S->emit_seq;

@@ -33,8 +33,8 @@ def test_library_carries_every_gfx950_kernel(lib):
     """The device code of both translation units is in the shipped library: the LDS build kernel in its two sizes, the
     window kernel on one wave and on several (the re-run tier), ordering and read preparation."""
     blob = open(build.LIB, "rb").read()
-    for k in (b"build_kernel", b"build_kernel_large", b"svc_kernel", b"svc_kernel_large", b"order_kernel", b"prep_kernel", b"window_kernel", b"window_kernel_fat"):
-        assert re.search(rb"_Z\d+" + k + rb"P", blob), k
+    for k in (b"build_kernel", b"build_kernel_large", b"svc_kernel", b"svc_kernel_large", b"order_class_kernel", b"order_place_kernel", b"prep_kernel", b"window_kernel", b"window_kernel_fat"):
+        assert re.search(rb"_Z\d+" + k + rb"[Pi]", blob), k
     assert b"gfx950" in blob
 
 

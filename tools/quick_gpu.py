@@ -72,3 +72,25 @@ if os.environ.get("QUICK_SLOW"):
         print(f"  multi phase {i:2d} {n:36s} {ml[i]:9.3f} s  {100 * ml[i] / ml.sum():5.1f} %")
     import collections
     print("builds histogram:", sorted(collections.Counter(s_["n_builds"] for s_ in st).items()))
+if os.environ.get("QUICK_TIMELINE"):      # (engine built with -DLANCET_PROF_TIMELINE: tools/variant.sh) the window kernel's launch over time
+    ph = eng.phase_times()
+    start, end, susp, res, nres, slot = ph[:, 2], ph[:, 3], ph[:, 4], ph[:, 5], ph[:, 6] * 1e8, (ph[:, 7] * 1e8).astype(int)
+    t0 = start.min(); span = end.max() - t0
+    ms = lambda x: round(1000 * float(x - t0), 2)
+    print(f"timeline: span {1000 * span:.2f} ms; the last window was taken at {ms(start.max())} ms; ends: p50 {ms(_np.percentile(end, 50))} p90 {ms(_np.percentile(end, 90))} p99 {ms(_np.percentile(end, 99))} p99.9 {ms(_np.percentile(end, 99.9))}")
+    parked = (nres > 0)
+    print(f"  put aside for the build service: {int(parked.sum())} windows, {int(nres.sum())} times; last hand-over {ms(susp[parked].max()) if parked.any() else 0} ms, last resume {ms(res[parked].max()) if parked.any() else 0} ms; mean wait of the last round {1000 * float((res[parked] - susp[parked]).mean()) if parked.any() else 0:.2f} ms")
+    nslot = int(slot.max()) + 1
+    last = _np.zeros(nslot); busy = _np.zeros(nslot)
+    _np.maximum.at(last, slot, end - t0)
+    print(f"  slots seen {len(set(slot.tolist()))}; a slot's last window ends at: mean {1000 * last[last > 0].mean():.2f} ms p10 {1000 * _np.percentile(last[last > 0], 10):.2f} p50 {1000 * _np.percentile(last[last > 0], 50):.2f} p90 {1000 * _np.percentile(last[last > 0], 90):.2f}")
+    edges = _np.arange(0, span + 5e-4, 5e-4)
+    act = [int(((start - t0 < b + 5e-4) & (end - t0 > b)).sum()) for b in edges]
+    print("  windows between taken and finished, per 0.5 ms:", act)
+    fin = [int(((end - t0 >= b) & (end - t0 < b + 5e-4)).sum()) for b in edges]
+    print("  windows finished per 0.5 ms:", fin)
+    tk = [int(((start - t0 >= b) & (start - t0 < b + 5e-4)).sum()) for b in edges]
+    print("  windows taken per 0.5 ms:", tk)
+    lastw = _np.argsort(-end)[:20]
+    print("  the last to finish (taken, put aside, resumed, finished ms; times resumed; builds; k; busy ms):")
+    for i in lastw: print("   ", ms(start[i]), ms(susp[i]) if nres[i] else "-", ms(res[i]) if nres[i] else "-", ms(end[i]), int(nres[i]), st[i]["n_builds"], st[i]["final_k"], round(1000 * float(ptw[i] - ph[i, 2:8].sum()), 2))
