@@ -353,8 +353,11 @@ def main():
             finally:
                 gather_q.task_done()
 
+    done_at = []                                 # host clock at every completion of the timed steps (config.step_ms: where a slow run lost its time)
+
     def complete(e):
         e.wait()
+        done_at.append(time.perf_counter())
         if world > 1:
             th = time.perf_counter()
             busy[id(e)] = threading.Event()
@@ -416,6 +419,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     tm["gather"] = tm["replay"] = tm["pack"] = tm["host"] = 0.0; tm["steps"] = 0
+    del done_at[:]
     t0 = time.perf_counter()
     run_steps(args.steps)
     if world > 1:
@@ -430,6 +434,13 @@ def main():
         gl = [torch.zeros(1, dtype=torch.float64, device=comm_device) for _ in range(world)]
         dist.all_gather(gl, g)
         gather_ms = [round(float(x.item()), 3) for x in gl]
+    step_ms = [1e3 * (b - a) for a, b in zip([t0] + done_at[:-1], done_at)][:args.steps]
+    q = max(1, len(step_ms) // 5)
+    step_summary = {"median": round(float(np.median(step_ms)), 2), "max": round(max(step_ms), 2), "slowest_step": int(np.argmax(step_ms)),
+                    "mean_first_fifth": round(float(np.mean(step_ms[:q])), 2), "mean_last_fifth": round(float(np.mean(step_ms[-q:])), 2),
+                    "over_1.25x_median": int(sum(1 for x in step_ms if x > 1.25 * np.median(step_ms)))} if step_ms else None
+    if os.environ.get("LANCET_BENCH_STEPS"):
+        print("[bench] step ms:", [round(x, 1) for x in step_ms], file=sys.stderr)
     # kernel durations for the roofline: launches that have the GPU to themselves (with two batches in flight the HIP events of a
     # kernel also cover the time it shares the device with the other batch's kernels)
     kernel_ms = []
@@ -509,7 +520,7 @@ def main():
                                    + (", --linked-reads (BX / HP tags)" if args.linked else ""),
                        "windows_per_gpu": args.windows, "coverage": [args.cov, cov_n], "reads_per_gpu": int(batch.n_reads),
                        "records_rank0_contig": len(variants), "records_sha256_rank0_contig": h.hexdigest()[:16],
-                       "slots_in_flight": n_slots, "batches_in_flight": nfl, "upload_first_ms": round(upload_first_ms, 1), "upload_ms": round(up_ms, 1),
+                       "slots_in_flight": n_slots, "batches_in_flight": nfl, "step_ms": step_summary, "upload_first_ms": round(upload_first_ms, 1), "upload_ms": round(up_ms, 1),
                        "windows_first_graph_in_lds": eng.prebuilt_count(), "graphs_built_ahead": eng.ahead_counts()[0], "graphs_taken_from_pool": eng.ahead_counts()[1],
                        "build_service": dict(zip(("posted", "served", "not_buildable", "taken_back"), eng.svc_counts())),
                        "windows_rerun_worst_case_tier": eng.rerun_count(), "workspace_MB_per_slot": round(slot_bytes / 2 ** 20, 1),

@@ -128,8 +128,8 @@ typedef struct lancet_window_stats {
 #define LANCET_W_K_EXHAUSTED   2   /* every k up to max_k was rejected                                */
 #define LANCET_W_OVERFLOW     -1   /* a device work-space limit was hit; results for this window are
                                       NOT valid (reported loudly, never silently wrong).  Limits per window: a
-                                      reference of at most 1024 bases, reads of at most 1023 + k bases, per-position
-                                      counts below 65 536 (the reference's unsigned short counters), 2^21 reads
+                                      reference of at most 1024 bases, reads of at most 1023 + k bases (per-position
+                                      counts wrap at 65 536 as the reference's unsigned short counters do), 2^21 reads
                                       (more than 65 535 reads: assembled by the re-run tier), 2^20 distinct k-mers
                                       unless LANCET_MAX_NODES says otherwise                            */
 
