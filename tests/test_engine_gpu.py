@@ -346,15 +346,16 @@ def test_pile_up_started_early_does_not_read_the_previous_batch_hand_off():
 
 def test_build_service_is_scheduling_only(monkeypatch):
     """Cycle-prone windows (tandem duplications: k climbs) with the build service on, with more service workgroups, with nothing
-    built ahead (every later graph on request), and with the service off: identical records and per-window statistics, equal
-    to the oracle's; the service did serve requests."""
+    built ahead (every later graph on request), with the service off, and with the windows taken in another order (engine.hip
+    order_class): identical records and per-window statistics, equal to the oracle's; the service did serve requests."""
     from lancet_amd import workload
     p = abi.default_params()
     b = workload.make_scan_batch(600, 30, 30, seed=11)
     ov, ost, _ = oracle.run(b, p)
     key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
     served = []
-    for env in ({}, {"LANCET_SVC_WGS": "64"}, {"LANCET_AHEAD_DEPTH": "0", "LANCET_SVC_DEPTH": "0"}, {"LANCET_NO_SVC": "1"}):
+    # (the last two: the order the window kernel takes the windows in -- two classes as in round 4, batch order -- instead of longest expected first)
+    for env in ({}, {"LANCET_SVC_WGS": "64"}, {"LANCET_AHEAD_DEPTH": "0", "LANCET_SVC_DEPTH": "0"}, {"LANCET_NO_SVC": "1"}, {"LANCET_ORDER": "two"}, {"LANCET_NO_HEAVY_FIRST": "1"}):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         eng = engine.Engine(p)
