@@ -11,6 +11,11 @@ N ranks): rank r assembles its own synthetic contig (weak scaling); inside the t
 rank are sent to rank 0 over RCCL (sizes by all_gather, payloads point to point) and rank 0 replays them in window order
 into a VariantDB.
 
+Order of a run: upload (outside the timed region), `--settle` untimed steps (default 200: a device fresh from boot was seen to run its
+first seconds of steps 7 % slower than ever after, with the kernels' own durations unchanged), `--warmup` untimed steps, barrier +
+synchronize, EXACTLY `--steps` timed steps, barrier + synchronize; then, untimed, the kernel durations on launches that have the GPU to
+themselves (roofline), the PCIe-inclusive loop, the CPU baseline, the native BAM -> VCF run and the side configurations.
+
 Prints ONE JSON line on rank 0."""
 import argparse
 import hashlib
@@ -239,6 +244,8 @@ def main():
     ap.add_argument("--cpu-sample-all", type=int, default=16384, help="windows timed on all host cores")
     ap.add_argument("--no-bam", action="store_true", help="skip the BAM -> VCF run of the native program (value_bam_e2e)")
     ap.add_argument("--no-configs", action="store_true", help="skip the side configurations (60x/60x, 100x/40x STR)")
+    ap.add_argument("--settle", type=int, default=int(os.environ.get("LANCET_BENCH_SETTLE_STEPS", "200")),
+                    help="untimed steps before the warmup (a device fresh from boot runs the first seconds 7 %% slower; 0 = none)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight per GPU (engines submitted in turn); 1 = every step alone on the GPU")
     ap.add_argument("--chain", type=int, default=1, help="1: a batch's kernels start when those of the batch before it (other engine) are through -- back to back, no host gap; 0: as soon as submitted")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
@@ -414,6 +421,19 @@ def main():
         while pend:
             complete(pend.pop(0))
 
+    # Settling (untimed, before the warmup steps that were asked for): in three of eight runs that were the first GPU process on a fresh
+    # box every step of the timed loop took 3.1 ms longer than in the next process on the same box, with the kernels' own durations
+    # unchanged (profiles/README.md, round 5) -- a device that has not been under load yet.  A fixed number of steps (the same on every
+    # rank: no collective decides it), reported in config.settle.
+    settle = {"steps": 0}
+    if args.settle > 0:
+        chunk = max(1, min(25, args.settle))
+        ms = []
+        while settle["steps"] < args.settle:
+            n = min(chunk, args.settle - settle["steps"])
+            tc = time.perf_counter(); run_steps(n); ms.append(1e3 * (time.perf_counter() - tc) / n)
+            settle["steps"] += n
+        settle.update({"ms_per_step_first_chunk": round(ms[0], 2), "ms_per_step_last_chunk": round(ms[-1], 2), "ms_per_step_min_chunk": round(min(ms), 2)})
     run_steps(args.warmup)
     if world > 1:
         dist.barrier()
@@ -520,7 +540,7 @@ def main():
                                    + (", --linked-reads (BX / HP tags)" if args.linked else ""),
                        "windows_per_gpu": args.windows, "coverage": [args.cov, cov_n], "reads_per_gpu": int(batch.n_reads),
                        "records_rank0_contig": len(variants), "records_sha256_rank0_contig": h.hexdigest()[:16],
-                       "slots_in_flight": n_slots, "batches_in_flight": nfl, "step_ms": step_summary, "upload_first_ms": round(upload_first_ms, 1), "upload_ms": round(up_ms, 1),
+                       "slots_in_flight": n_slots, "batches_in_flight": nfl, "step_ms": step_summary, "settle": settle, "upload_first_ms": round(upload_first_ms, 1), "upload_ms": round(up_ms, 1),
                        "windows_first_graph_in_lds": eng.prebuilt_count(), "graphs_built_ahead": eng.ahead_counts()[0], "graphs_taken_from_pool": eng.ahead_counts()[1],
                        "build_service": dict(zip(("posted", "served", "not_buildable", "taken_back"), eng.svc_counts())),
                        "windows_rerun_worst_case_tier": eng.rerun_count(), "workspace_MB_per_slot": round(slot_bytes / 2 ** 20, 1),

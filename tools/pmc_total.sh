@@ -8,7 +8,7 @@
 cd /root/repo; mkdir -p gpurun_out; cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   d=/root/repo/gpurun_out/pmc_$c; rm -rf $d
-  LANCET_SVC_HELP=0 LANCET_PREP=device timeout ${PMC_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- python /root/repo/bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-configs --in-flight 1 $BENCH_ARGS > $d.log 2>&1 || echo "pass $c: rc $?"
+  LANCET_SVC_HELP=0 LANCET_PREP=device timeout ${PMC_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- python /root/repo/bench.py --steps 1 --warmup 0 --settle 0 --cpu-sample 0 --no-configs --in-flight 1 $BENCH_ARGS > $d.log 2>&1 || echo "pass $c: rc $?"
   for k in "build_kernel(" "build_kernel_large(" "window_kernel(" "svc_kernel(" "prep_kernel("; do
     grep -F "$k" $d/*/*counter_collection.csv | awk -F, -v k=$k -v c=$c '{n=NF; v[NR]=$(n-2); t[NR]=($(n)-$(n-1))/1e6} END {if (NR) { s=0; for (i=1;i<=NR;i++) s+=v[i]; printf "%s %s mean %.1f MB over %d launches (last %.1f MB, %.1f ms)\n", k, c, s/NR/1024, NR, v[NR]/1024, t[NR]} }'
   done

@@ -7,7 +7,7 @@ cd /root/repo; O=gpurun_out/$TAG; mkdir -p $O
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.json | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
 rm -rf /root/repo/$O/kt
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/kt -- python /root/repo/bench.py --steps 20 --cpu-sample 0 --no-configs --no-bam --in-flight 1 > /root/repo/$O/kt.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/kt -- python /root/repo/bench.py --steps 20 --settle 0 --cpu-sample 0 --no-configs --no-bam --in-flight 1 > /root/repo/$O/kt.log 2>&1
 cat /root/repo/$O/kt/*/*kernel_stats.csv | head -14 > /root/repo/$O/kernel_trace_stats.csv; head -8 /root/repo/$O/kernel_trace_stats.csv
 for cfg in "headline|" "60x|--windows 8192 --cov 60" "config4|--windows 4096 --cov 100 --cov-normal 40 --str-fraction 0.3 --lowcomplex-fraction 0.05" "config5|--windows 16384 --linked"; do
   name=${cfg%%|*}; args=${cfg#*|}
@@ -22,6 +22,6 @@ LANCET_UPLOAD_TIMING=1 bash tools/e2e_quick.sh > $O/e2e.txt 2>&1; grep -h "lance
 timeout 200 python tools/quick_gpu.py bench 32768 > $O/phases_headline.txt 2>&1
 for c in bench60 bench4 bench5; do timeout 200 python tools/quick_gpu.py $c 8192 > $O/phases_$c.txt 2>&1; done
 # the N-rank path end to end on the one-GPU box (both ranks on device 0, gather over gloo): a check of the communication thread, not a measurement
-LANCET_BENCH_ONE_GPU=1 timeout 300 python bench.py --gpus 2 --steps 10 --windows 8192 --cpu-sample 0 --no-configs --no-bam > $O/bench_2rank_onegpu.json 2> $O/bench_2rank_onegpu.err; tail -n 1 $O/bench_2rank_onegpu.json | cut -c1-200
+LANCET_BENCH_ONE_GPU=1 timeout 300 python bench.py --gpus 2 --steps 10 --settle 0 --windows 8192 --cpu-sample 0 --no-configs --no-bam > $O/bench_2rank_onegpu.json 2> $O/bench_2rank_onegpu.err; tail -n 1 $O/bench_2rank_onegpu.json | cut -c1-200
 python tools/traffic_json.py $O $TAG --keep profiles/r4_traffic.json > $O/traffic.json
 rm -rf $O/kt gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
