@@ -11,7 +11,7 @@ N ranks): rank r assembles its own synthetic contig (weak scaling); inside the t
 rank are sent to rank 0 over RCCL (sizes by all_gather, payloads point to point) and rank 0 replays them in window order
 into a VariantDB.
 
-Order of a run: upload (outside the timed region), `--settle` untimed steps (default 200: a device fresh from boot was seen to run its
+Order of a run: upload (outside the timed region), `--settle` untimed steps (default 300: a device fresh from boot was seen to run its
 first seconds of steps 7 % slower than ever after, with the kernels' own durations unchanged), `--warmup` untimed steps, barrier +
 synchronize, EXACTLY `--steps` timed steps, barrier + synchronize; then, untimed, the kernel durations on launches that have the GPU to
 themselves (roofline), the PCIe-inclusive loop, the CPU baseline, the native BAM -> VCF run and the side configurations.
@@ -244,7 +244,7 @@ def main():
     ap.add_argument("--cpu-sample-all", type=int, default=16384, help="windows timed on all host cores")
     ap.add_argument("--no-bam", action="store_true", help="skip the BAM -> VCF run of the native program (value_bam_e2e)")
     ap.add_argument("--no-configs", action="store_true", help="skip the side configurations (60x/60x, 100x/40x STR)")
-    ap.add_argument("--settle", type=int, default=int(os.environ.get("LANCET_BENCH_SETTLE_STEPS", "200")),
+    ap.add_argument("--settle", type=int, default=int(os.environ.get("LANCET_BENCH_SETTLE_STEPS", "300")),
                     help="untimed steps before the warmup (a device fresh from boot runs the first seconds 7 %% slower; 0 = none)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight per GPU (engines submitted in turn); 1 = every step alone on the GPU")
     ap.add_argument("--chain", type=int, default=1, help="1: a batch's kernels start when those of the batch before it (other engine) are through -- back to back, no host gap; 0: as soon as submitted")
