@@ -362,9 +362,12 @@ def main():
 
     done_at = []                                 # host clock at every completion of the timed steps (config.step_ms: where a slow run lost its time)
 
+    kern_in_loop = []                            # the kernels' HIP-event durations of every timed step, as they ran in the pipeline (config.step_ms)
+
     def complete(e):
         e.wait()
         done_at.append(time.perf_counter())
+        kern_in_loop.append(e.kernel_times())
         if world > 1:
             th = time.perf_counter()
             busy[id(e)] = threading.Event()
@@ -440,6 +443,7 @@ def main():
     torch.cuda.synchronize()
     tm["gather"] = tm["replay"] = tm["pack"] = tm["host"] = 0.0; tm["steps"] = 0
     del done_at[:]
+    del kern_in_loop[:]
     t0 = time.perf_counter()
     run_steps(args.steps)
     if world > 1:
@@ -459,6 +463,10 @@ def main():
     step_summary = {"median": round(float(np.median(step_ms)), 2), "max": round(max(step_ms), 2), "slowest_step": int(np.argmax(step_ms)),
                     "mean_first_fifth": round(float(np.mean(step_ms[:q])), 2), "mean_last_fifth": round(float(np.mean(step_ms[-q:])), 2),
                     "over_1.25x_median": int(sum(1 for x in step_ms if x > 1.25 * np.median(step_ms)))} if step_ms else None
+    if step_summary is not None and kern_in_loop:
+        kl = [k for k in kern_in_loop[:args.steps] if k]
+        if kl:      # (with two batches in flight these include the time a kernel shares the device with the other batch's copies; the roofline uses launches that are alone)
+            step_summary["kernel_ms_in_the_pipeline"] = [round(float(np.mean([k[i] for k in kl])), 3) for i in range(len(kl[0]))]
     if os.environ.get("LANCET_BENCH_STEPS"):
         print("[bench] step ms:", [round(x, 1) for x in step_ms], file=sys.stderr)
     # kernel durations for the roofline: launches that have the GPU to themselves (with two batches in flight the HIP events of a
