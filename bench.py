@@ -104,7 +104,10 @@ def cpu_baseline(batch, params, variants, n1: int, nall: int):
     phys = cpu_fanout.physical_cores()
     nall = min(nall, batch.n_windows)
     per = max(4, nall // (procs * 6))
-    dta, kma, done = cpu_fanout.run(batch, {}, nall, procs, per)
+    dta, kma, done, orecs = cpu_fanout.run(batch, {}, nall, procs, per, want_records=True)
+    # every record the fan-out produced against the engine's, field by field, in (window, emission) order: the full sample, not its head
+    erecs = [v for v in variants if v["window"] < nall]
+    same_all = orecs == erecs
     km1 = sum(s["n_kmers"] for s in ostats)
     return {"value": round(done / dta, 2), "unit": "windows/s", "cores": cores, "processes": procs, "physical_cores": phys, "hardware_threads": threads,
             "kind": "port", "cpu_model": cpu_model(),
@@ -114,7 +117,8 @@ def cpu_baseline(batch, params, variants, n1: int, nall: int):
             "one_thread": {"value": round(n1 / dt1, 2), "mkmers_per_s": round(km1 / dt1 / 1e6, 3),
                            "sample": f"first {n1} windows, 1 thread, {dt1:.1f} s"},
             "scaling_over_one_thread": round((done / dta) / (n1 / dt1), 1), "host_limits": lim,
-            "gpu_results_identical_on_sample": bool(same),
+            "gpu_results_identical_on_sample": bool(same and same_all),
+            "windows_compared": int(nall), "records_compared": len(erecs), "one_thread_windows_compared": int(n1),
             "note": "the reference binary cannot travel to this box; in the authoring container it runs the golden cases at 13-23 windows/s/thread, this port at ~45 (DESIGN.md §7)"}
 
 

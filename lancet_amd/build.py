@@ -21,16 +21,20 @@ def needs_build() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+def device_flags() -> list:
+    """Compile flags of the two .hip files (part of workload.kernel_fingerprint).  HIPCC_EXTRA: -D knobs of tuning builds."""
+    return (["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+            + os.environ.get("HIPCC_EXTRA", "").split())
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -ffp-contract=off: float coverage averaging must round like the reference's SSE code (SURVEY.md H4)
     steps = [
-        [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
-         "-c", "engine.hip", "-o", "engine.o"],
-        [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
-         "-c", "window_fat.hip", "-o", "window_fat.o"],
+        [hipcc] + device_flags() + ["-c", "engine.hip", "-o", "engine.o"],
+        [hipcc] + device_flags() + ["-c", "window_fat.hip", "-o", "window_fat.o"],
         [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-c", "host_vdb.cc", "-o", "host_vdb.o"],
         [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-pthread", "-c", "host_frontend.cc", "-o", "host_frontend.o"],
         [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-c", "host_trace.cc", "-o", "host_trace.o"],

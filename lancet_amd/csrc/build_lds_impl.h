@@ -1867,6 +1867,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
         BLPO(S, 1);
         WG_FOR(i, 128) { heads[i] = 0; }                                        // (set by this stage's scan, read in its last pass: two barriers from here)
         // (a lane's elements together: position -> node -> hash is an LDS and a global round trip, one after the other per element otherwise)
+        static_assert(8 * BL_WG >= 4096, "bl_stage_buckets<8> covers a growth stage of up to 4096 elements");
         if (n <= 2u * BL_WG) bl_stage_buckets<2>(Q, nhash, n, B, st, bkt, first);
         else if (n <= 4u * BL_WG) bl_stage_buckets<4>(Q, nhash, n, B, st, bkt, first);
         else bl_stage_buckets<8>(Q, nhash, n, B, st, bkt, first);
@@ -1952,13 +1953,13 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       for (int e = 0; e < 8; ++e) { const uint32_t t = X.s_edges[9 * (size_t)si + (uint32_t)e]; adj[8 * ppos + (uint32_t)e] = t == 0xFFFFu ? (uint16_t)ppos : nposP[sidv[t]]; }
       parent[ppos] = ppos; touch[ppos] = X.s_edges[9 * (size_t)si + 8]; pos2si[ppos] = (uint16_t)si;
     }
+    WG_LANE0 { S.flagged = 0; S.ndup = 0; }                                  // (the rounds' two change flags, cleared in front of the barrier every wave passes before its first hooking pass)
     WG_SYNC();
     // (a round = one hooking pass + three pointer-jumping passes, one barrier each, then ONE look at the change flag: testing
     //  for convergence after every pass cost two more barriers of the 512-lane workgroup per pass, and these passes do little
     //  else than wait at barriers.  A round that changed nothing leaves every parent a root with no smaller neighbour label.
     //  Two change flags taken in turn -- S.flagged / S.ndup, both idle here -- so that a round is its four barriers and nothing else: the
     //  flag of the round after is cleared by lane 0 in this round's last pass, and every lane looks at this round's flag behind the last barrier.)
-    WG_LANE0 { S.flagged = 0; S.ndup = 0; }
     for (int round = 0; ; ++round) {
       LC_LDS uint32_t *flag = (round & 1) ? (LC_LDS uint32_t *)&S.ndup : (LC_LDS uint32_t *)&S.flagged;
       LC_LDS uint32_t *other = (round & 1) ? (LC_LDS uint32_t *)&S.flagged : (LC_LDS uint32_t *)&S.ndup;

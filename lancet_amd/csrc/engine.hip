@@ -435,7 +435,6 @@ int lancet_engine_upload_packed(lancet_engine *e, const lancet_window_batch *b, 
     e->err = "lancet_packed_reads: struct_size " + std::to_string(pk->struct_size) + " is not this library's " + std::to_string(sizeof(lancet_packed_reads)) + " (caller built against another header)";
     return LANCET_E_ARG;
   }
-  if (e && pk && pk->read_index && pk->n_distinct == 0 && b && b->n_windows > 0 && b->read_begin[b->n_windows] > 0) { e->err = "packed reads: read_index without distinct reads"; return LANCET_E_ARG; }
   if (!e || !pk || !pk->rinfo || !pk->base_woff || !pk->good_woff || !pk->bases || !pk->good) { if (e) e->err = "packed reads missing"; return LANCET_E_ARG; }
   if (!e->host_prep) { e->err = "packed upload with LANCET_PREP=device"; return LANCET_E_STATE; }
   if (pk->min_qual_trim != e->params.min_qual_trim || pk->min_qual_call != e->params.min_qual_call) {
@@ -539,6 +538,7 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
     // packed reads stored ONCE per batch (pk->read_index: a read of a window -> one of pk->n_distinct reads; an alignment lies in ~6 of the
     // overlapping windows): the per-read words of the device batch point into the one copy, whose words are staged and copied once
     const bool shared = pk && pk->read_index;
+    if (shared && pk->n_distinct == 0 && R > 0) { e->err = "packed reads: read_index without distinct reads"; return LANCET_E_ARG; }
     const uint64_t bo_all = shared ? (uint64_t)pk->base_woff[pk->n_distinct] : tb[(size_t)T], go_all = shared ? (uint64_t)pk->good_woff[pk->n_distinct] : tg[(size_t)T];
     if (pk && !shared && ((uint64_t)pk->base_woff[R] != bo_all || (uint64_t)pk->good_woff[R] != go_all)) { e->err = "packed reads: word offsets do not match the read lengths"; return LANCET_E_ARG; }
     if (bo_all + 4 > 0xFFFFFFFFull) { e->err = "batch too large"; return LANCET_E_ARG; }
@@ -569,7 +569,8 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
         const uint32_t nd = pk->n_distinct;
         for (size_t r = lo; r < hi; ++r) {
           const uint32_t len = b->seq_off[r + 1] - b->seq_off[r], u = pk->read_index[r];
-          if (u >= nd || pk->base_woff[u + 1] - pk->base_woff[u] != (len + 15) / 16 || pk->good_woff[u + 1] - pk->good_woff[u] != (len + 31) / 32 || RI_TLEN(pk->rinfo[u]) > len) { bad[(size_t)t] = 3; return; }
+          if (u >= nd || pk->base_woff[u + 1] < pk->base_woff[u] || pk->good_woff[u + 1] < pk->good_woff[u] || (uint64_t)pk->base_woff[u + 1] > bo_all || (uint64_t)pk->good_woff[u + 1] > go_all ||
+              pk->base_woff[u + 1] - pk->base_woff[u] != (len + 15) / 16 || pk->good_woff[u + 1] - pk->good_woff[u] != (len + 31) / 32 || RI_TLEN(pk->rinfo[u]) > len) { bad[(size_t)t] = 3; return; }
           h_bw[r] = pk->base_woff[u]; h_gw[r] = pk->good_woff[u]; h_nm[r] = b->name_rank[r]; h_ri[r] = pk->rinfo[u];
         }
         return;

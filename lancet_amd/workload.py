@@ -216,14 +216,17 @@ def algorithmic_bytes(b: WindowBatch, stats, n_variants: int) -> int:
 
 
 def kernel_fingerprint() -> str:
-    """sha1 over the kernels' sources (the device headers of lancet_amd/csrc: kernels.h, build_lds.h, build_lds_impl.h, wave.h, layout.h):
-    what a measurement that was not taken by this very process (the PMC traffic passes, profiles/*_traffic.json) must have been taken on
-    for bench.py to quote it."""
+    """sha1 over everything that decides what the device code is: the device headers of lancet_amd/csrc (kernels.h, build_lds.h,
+    build_lds_impl.h, wave.h, layout.h), the two .hip files (launch bounds, waves per SIMD, the order kernels) and the compile commands of
+    lancet_amd/build.py (tuning builds pass -D knobs through HIPCC_EXTRA, which is part of them).  A measurement that was not taken by this
+    very process (the PMC traffic passes, profiles/*_traffic.json) must have been taken on the same fingerprint for bench.py to quote it."""
     import hashlib
     import os
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
     h = hashlib.sha1()
-    for f in ("build_lds.h", "build_lds_impl.h", "kernels.h", "layout.h", "wave.h"):
+    for f in ("build_lds.h", "build_lds_impl.h", "kernels.h", "layout.h", "wave.h", "engine.hip", "window_fat.hip"):
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
+    from . import build as _b
+    h.update(" ".join(_b.device_flags()).encode())
     return h.hexdigest()[:16]

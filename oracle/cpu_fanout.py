@@ -55,16 +55,27 @@ def _worker(d: str, idx: int, n: int) -> None:
         return
     t = time.perf_counter()
     km = nw = 0
+    recs = []
     for j, (a, b) in enumerate(meta["ranges"]):
         if j % n == idx:
-            _, st, _ = oracle.run(workload.sub_batch(batch, a, b), p)
+            ov, st, _ = oracle.run(workload.sub_batch(batch, a, b), p)
             km += sum(s["n_kmers"] for s in st)
             nw += b - a
+            recs.append((a, ov))
     print("done", km, nw, time.perf_counter() - t, flush=True)
+    # (outside the timed region) the records of this worker's chunks, window numbers of the whole sample: the caller compares them with the engine's
+    out = []
+    for a, ov in recs:
+        for v in ov:
+            v = dict(v); v["window"] = int(v["window"]) + a
+            out.append(v)
+    pickle.dump(out, open(os.path.join(d, "records_%d.pkl" % idx), "wb"))
+    print("saved", flush=True)
 
 
-def run(batch, params_kw: dict, n_windows: int, workers: int, chunk: int, timeout_s: float = 300.0):
-    """Oracle over windows [0, n_windows) of `batch` on `workers` processes.  Returns (seconds, k-mers, windows done)."""
+def run(batch, params_kw: dict, n_windows: int, workers: int, chunk: int, timeout_s: float = 300.0, want_records: bool = False):
+    """Oracle over windows [0, n_windows) of `batch` on `workers` processes.  Returns (seconds, k-mers, windows done), and with
+    want_records the oracle's variant records of all those windows in (window, emission) order as a fourth item."""
     sys.path.insert(0, _ROOT)
     from lancet_amd import workload
     sample = workload.sub_batch(batch, 0, n_windows)
@@ -96,7 +107,15 @@ def run(batch, params_kw: dict, n_windows: int, workers: int, chunk: int, timeou
                 raise RuntimeError("cpu_fanout: a worker failed")
             km += int(f[1]); nw += int(f[2])
         dt = time.perf_counter() - t
-        return dt, km, nw
+        if not want_records:
+            return dt, km, nw
+        records = []
+        for i, p in enumerate(procs):
+            if p.stdout.readline().strip() != "saved":
+                raise RuntimeError("cpu_fanout: a worker did not save its records")
+            records.extend(pickle.load(open(os.path.join(d, "records_%d.pkl" % i), "rb")))
+        records.sort(key=lambda v: v["window"])                   # (stable: emission order inside a window is kept)
+        return dt, km, nw, records
     finally:
         for p in procs:
             try:
