@@ -4,6 +4,7 @@ reference-made fixtures by test_cli.py / test_frontend*.py): identical batches a
 import io
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -14,6 +15,7 @@ import golden_util as gu
 from lancet_amd import bamio, build, frontend, host, synth
 
 G = gu.GOLDEN
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIELDS = ("chr_id", "ref_start", "ref_off", "ref_bases", "read_begin", "seq_off", "seq", "qual", "label", "strand", "mate", "mapped", "name_rank")
 
 
@@ -856,3 +858,20 @@ def test_pack_read_against_a_plain_restatement():
         assert list(ob)[:len(wb)] == wb and list(og)[:len(wg)] == wg, (trial, n, tlen)
         n_trim += int(0 < tlen < n); n_junk += int(junk and n > 0)
     assert n_trim > 300 and n_junk > 100
+
+
+@pytest.mark.gpu
+def test_scan_of_a_synthetic_contig_equals_the_oracle_window_by_window_and_in_the_vcf(tmp_path):
+    """tools/e2e_parity.py on a 100 kb tumor / normal pair made here (981 windows; the 5 Mb contig of BASELINE config 2 goes through
+    the same script on the box: profiles/r6_e2e_parity_5mb.json): `lancet_gpu`'s VCF, the engine's records of the native host side's
+    batches and the oracle's records of the same batches (+ oracle/vcf_oracle.py) must agree record by record and byte by byte."""
+    import json
+    d = str(tmp_path / "scan100k")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_scan_bams.py"), d, "100000", "30", "30", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_parity.py"), d, "chr22:1000-99000", "--batch-windows", "400", "--active-region-off"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["records_identical"] and out["vcf_oracle_equals_lancet_gpu"] and out["vcf_engine_records_native_vdb_equals_lancet_gpu"] and out["vcf_header_lines_identical"]
+    assert out["windows_assembled"] > 900 and out["vcf_lines"] > 0 and out["records_compared"] >= out["vcf_lines"]
