@@ -8,10 +8,10 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "liblancet_engine.so")
-SOURCES = ["engine.hip", "window_fat.hip", "host_vdb.cc", "host_frontend.cc", "host_trace.cc", "lancet_main.cc"]
+SOURCES = ["engine.hip", "window_fat.hip", "host_vdb.cc", "host_frontend.cc", "host_trace.cc", "host_gather.cc", "lancet_main.cc"]
 BIN = os.path.join(os.path.dirname(CSRC), "bin", "lancet_gpu")
 HEADERS = ["kernels.h", "build_lds.h", "build_lds_impl.h", "wave.h", "layout.h", "host_common.h", "host_pack.h", os.path.join("..", "..", "include", "lancet_engine.h"),
-           os.path.join("..", "..", "include", "lancet_host.h")]
+           os.path.join("..", "..", "include", "lancet_host.h"), os.path.join("..", "..", "include", "lancet_gather.h")]
 
 
 def needs_build() -> bool:
@@ -38,7 +38,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-c", "host_vdb.cc", "-o", "host_vdb.o"],
         [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-pthread", "-c", "host_frontend.cc", "-o", "host_frontend.o"],
         [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-c", "host_trace.cc", "-o", "host_trace.o"],
-        [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "engine.o", "window_fat.o", "host_vdb.o", "host_frontend.o", "host_trace.o", "-lz", "-lpthread", "-o", LIB],
+        # the multi-process record gather: HIP runtime API + RCCL's header only (librccl is loaded on first use, not linked)
+        [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-pthread", "-I/opt/rocm/include", "-c", "host_gather.cc", "-o", "host_gather.o"],
+        [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "engine.o", "window_fat.o", "host_vdb.o", "host_frontend.o", "host_trace.o", "host_gather.o", "-lz", "-lpthread", "-ldl", "-o", LIB],
         # the reference's command line on the native host side; finds the library next to itself
         [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-pthread", "lancet_main.cc", "-o", BIN, "-L.", "-llancet_engine",
          "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath-link,/opt/rocm/lib"],

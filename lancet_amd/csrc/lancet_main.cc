@@ -8,9 +8,19 @@
 // go to the engines in turn while the host prepares the next one; records reach the VariantDB in window order whatever
 // the number of engines), --strict (no VCF at all when a window exceeded the engine's work space; by default the run
 // finishes, the windows are listed on stderr and the exit code is 3).
+// --ranks N: N processes, one per GPU (rank r on --devices[r mod #devices], default device r): the batches of --batch-windows windows are
+// dealt out to the ranks in turn, every rank keys and reduces its records (lancet_records_pack) and they are gathered to rank 0 over RCCL
+// (lancet_comm_gather: sizes by one all-gather, payloads by send / recv to rank 0 only) and replayed into the VariantDB in window order
+// (lancet_records_merge) -- what the reference does with its per-thread databases at the end of main() (reference src/Lancet.cc:940-959).
+// Without --rank the program starts the N ranks itself (children of this process, --rank r --rendezvous <path> appended) and waits for
+// them; a job launcher may start the ranks itself with --rank / --rendezvous.  The VCF (rank 0's stdout) does not depend on N.
 // Not offered: --kmer-recovery, --print-graph; --num-threads is accepted and ignored (windows are
 // batched on the GPU); -v prints the reference's per-window stage trace to stderr.
 #include "../../include/lancet_host.h"
+#include "../../include/lancet_gather.h"
+
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cstdio>
@@ -34,7 +44,7 @@ const Opt OPTS[] = {
   {"min-coverage-normal", 'z', 1}, {"max-coverage-normal", 'j', 1}, {"min-phred-fisher", 's', 1},
   {"min-phred-fisher-str", 'E', 1}, {"min-strand-bias", 'f', 1}, {"max-unit-length", 'U', 1}, {"min-report-unit", 'N', 1},
   {"min-report-len", 'Y', 1}, {"dist-from-str", 'D', 1}, {"linked-reads", 'J', 0}, {"primary-alignment-only", 'I', 0},
-  {"XA-tag-filter", 'O', 0}, {"active-region-off", 'W', 0}, {"verbose", 'v', 0}, {"device", 0, 1}, {"devices", 0, 1}, {"batch-windows", 0, 1}, {"date-line", 0, 1}, {"strict", 0, 0}, {"help", 'h', 0},
+  {"XA-tag-filter", 'O', 0}, {"active-region-off", 'W', 0}, {"verbose", 'v', 0}, {"device", 0, 1}, {"devices", 0, 1}, {"batch-windows", 0, 1}, {"date-line", 0, 1}, {"strict", 0, 0}, {"ranks", 0, 1}, {"rank", 0, 1}, {"rendezvous", 0, 1}, {"help", 'h', 0},
 };
 int die(const std::string &m) { fprintf(stderr, "lancet_gpu: %s\n", m.c_str()); return 1; }
 void usage() {
@@ -50,6 +60,9 @@ void usage() {
         "   --batch-windows <n>               : windows per engine batch [32768]\n"
         "   --strict                          : write no VCF when a window exceeded the engine's work space (default: finish,\n"
         "                                       list those windows on stderr, exit code 3)\n"
+        "   --ranks <n>                       : n processes, one per GPU; records gathered to rank 0 over RCCL, same VCF for every n\n"
+        "   --rank <r> --rendezvous <path>    : this process is rank r of --ranks (a launcher starts the ranks; without --rank the\n"
+        "                                       program starts them itself)\n"
         "BAM input: <bam>.bai / <stem>.bai is used when present (one seek per tiled stretch); otherwise the BAM is streamed once.\n"
         "There is no CPU path: a gfx950 device is required.\n", stderr);
 }
@@ -59,7 +72,8 @@ int main(int argc, char **argv) {
   std::string tumor, normal, ref, reg, bed, qrange = "!", date_line, devices, rg_file;
   int min_k = 11, max_k = 101, trim_lowqual = 10, min_base_qual = 17, tip_len = 11, cov_thr = 5, low_cov = 1, dfs_limit = 1000000;
   int max_indel_len = 500, max_mismatch = 2, max_unit_length = 4, min_report_unit = 3, min_report_len = 7, dist_from_str = 1;
-  int device = 0, batch_windows = 32768, verbose = 0, strict = 0;
+  int device = 0, batch_windows = 32768, verbose = 0, strict = 0, ranks = 0, rank = -1;
+  std::string rendezvous;
   double cov_ratio = 0.01;
   lancet_host_opts ho; lancet_host_opts_default(&ho);
   lancet_filters flt; lancet_filters_default(&flt);
@@ -90,9 +104,37 @@ int main(int argc, char **argv) {
     else if (L == "linked-reads") ho.linked = 1; else if (L == "primary-alignment-only") ho.primary_alignment_only = 1; else if (L == "XA-tag-filter") ho.xa_filter = 1;
     else if (L == "active-region-off") ho.active_region = 0; else if (L == "verbose") verbose = 1; else if (L == "device") device = atoi(v); else if (L == "devices") devices = v; else if (L == "batch-windows") batch_windows = atoi(v);
     else if (L == "date-line") date_line = v; else if (L == "bed") bed = v; else if (L == "rg-file") rg_file = v; else if (L == "strict") strict = 1;
+    else if (L == "ranks") ranks = atoi(v); else if (L == "rank") rank = atoi(v); else if (L == "rendezvous") rendezvous = v;
     else if (L == "help") { usage(); return 0; }
   }
   if (tumor.empty() || normal.empty() || ref.empty() || (reg.empty() && bed.empty())) { usage(); return die("--tumor, --normal, --ref and a region (--reg) or BED file (--bed) are required"); }
+  if (ranks < 0 || (ranks == 0 && rank >= 0) || (ranks > 0 && rank >= ranks)) return die("--ranks must be >= 1 and --rank one of 0 .. ranks-1");
+  if (ranks > 0 && rank < 0) {
+    // the launcher: rank r = this program again with --rank r --rendezvous <path>; rank 0 writes the VCF to the stdout they all inherit
+    if (rendezvous.empty()) {
+      const char *shm = access("/dev/shm", W_OK) == 0 ? "/dev/shm" : "/tmp";
+      rendezvous = std::string(shm) + "/lancet_gpu_" + std::to_string((long)getpid()) + ".id";
+    }
+    unlink(rendezvous.c_str());
+    std::vector<pid_t> kids;
+    for (int r = 0; r < ranks; ++r) {
+      const pid_t pid = fork();
+      if (pid < 0) return die("fork failed");
+      if (pid == 0) {
+        std::vector<std::string> av(argv, argv + argc);
+        av.push_back("--rank"); av.push_back(std::to_string(r)); av.push_back("--rendezvous"); av.push_back(rendezvous);
+        std::vector<char *> cv; for (std::string &x : av) cv.push_back(&x[0]); cv.push_back(nullptr);
+        execv("/proc/self/exe", cv.data());
+        _exit(127);
+      }
+      kids.push_back(pid);
+    }
+    int worst = 0;
+    for (pid_t k : kids) { int st = 0; if (waitpid(k, &st, 0) < 0) worst = worst ? worst : 1; else { const int c = WIFEXITED(st) ? WEXITSTATUS(st) : 1; if (c && (!worst || c == 1)) worst = c; } }
+    unlink(rendezvous.c_str());
+    return worst;
+  }
+  if (ranks > 0 && rendezvous.empty()) return die("--rank needs --rendezvous <path> (the same path for every rank)");
   const int qoff = qrange.empty() ? 33 : (unsigned char)qrange[0];
   lancet_params P; lancet_params_default(&P);
   P.min_k = min_k; P.max_k = max_k; P.max_tip_len = tip_len; P.cov_threshold = cov_thr; P.low_cov_threshold = low_cov; P.dfs_limit = dfs_limit;
@@ -109,9 +151,18 @@ int main(int argc, char **argv) {
   // upload of a batch with the kernels of the previous one).  Batches go to the engines in turn; there is no CPU path:
   // without a GPU engine creation fails.
   std::vector<int> devs;
-  if (devices.empty()) devs.push_back(device);
+  if (devices.empty()) devs.push_back(ranks > 0 ? rank : device);
   else { size_t p0 = 0; while (p0 <= devices.size()) { size_t q = devices.find(',', p0); if (q == std::string::npos) q = devices.size(); if (q > p0) devs.push_back(atoi(devices.substr(p0, q - p0).c_str())); p0 = q + 1; } }
   if (devs.empty()) return die("--devices is empty");
+  if (ranks > 0) { const int d = devs[(size_t)rank % devs.size()]; devs.assign(1, d); }     // one GPU per rank
+  // the communicator first: a rank that cannot join must not leave the others waiting at the gather
+  lancet_comm *comm = nullptr;
+  if (ranks > 0) {
+    char cerr[512] = "";
+    comm = lancet_comm_create(rank, ranks, devs[0], rendezvous.c_str(), 300.0, cerr, sizeof cerr);
+    if (!comm) return die(std::string("rank ") + std::to_string(rank) + ": cannot join the communicator: " + cerr);
+    if (ranks > 1 && !getenv("LANCET_HOST_LAZY")) setenv("LANCET_HOST_LAZY", "1", 0);     // a rank loads what ITS batches select (needs both .bai; else a notice and everything is loaded)
+  }
   std::vector<lancet_engine *> engs;
   for (int d : devs) {
     lancet_engine *e = nullptr;
@@ -144,9 +195,11 @@ int main(int argc, char **argv) {
   // of its kernels overlap with batch i (what `--devices 0,0` asks for explicitly; bench.py --in-flight 2 measures it)
   if (devices.empty() && nchunks > 1 && engs.size() == 1) {
     lancet_engine *e2 = nullptr;
-    if (lancet_engine_create(&P, device, &e2) == LANCET_OK) { if (verbose) lancet_engine_set_trace(e2, 1u << 17); engs.push_back(e2); }
+    if (lancet_engine_create(&P, devs[0], &e2) == LANCET_OK) { if (verbose) lancet_engine_set_trace(e2, 1u << 17); engs.push_back(e2); }
   }
-  struct Job { bool have = false; std::string trace; std::vector<lancet_variant> v; std::string blob; std::vector<lancet_variant_lr> lr; std::vector<uint32_t> bx; std::vector<std::string> bxn; };
+  struct Job { bool have = false; std::string trace; std::vector<lancet_variant> v; std::string blob; std::vector<lancet_variant_lr> lr; std::vector<uint32_t> bx; std::vector<std::string> bxn;
+               std::vector<int64_t> widx; /* --ranks: tiled (= global) number of the batch's window w */ };
+  std::vector<std::vector<uint8_t>> parts;      // --ranks: this rank's batches, packed (lancet_records_pack), in batch order
   struct Slot { lancet_engine *e = nullptr; std::future<int> fut; int chunk = -1; int nk = 0; long base = 0; std::vector<int32_t> kept; std::vector<std::string> bxn; };
   std::vector<Job> jobs((size_t)nchunks);
   std::vector<Slot> slots(engs.size());
@@ -172,6 +225,7 @@ int main(int argc, char **argv) {
     }
     Job &j = jobs[(size_t)sl.chunk];
     j.v.assign(v, v + nv); j.blob.assign(blob, blen);
+    if (comm) j.widx.assign(sl.kept.begin(), sl.kept.begin() + sl.nk);
     if (ho.linked) {
       const lancet_variant_lr *lr; const uint32_t *bxb; uint32_t bxl;
       if (lancet_engine_results_lr(sl.e, &lr, &bxb, &bxl) != LANCET_OK) { fail = std::string("engine: ") + lancet_engine_last_error(sl.e); return false; }
@@ -196,6 +250,15 @@ int main(int argc, char **argv) {
       Job &j = jobs[(size_t)next_add];
       if (!j.trace.empty()) fputs(j.trace.c_str(), stderr);
       int arc = LANCET_OK;
+      if (comm) {                                    // the records travel: keyed, reduced, window numbers of the whole tiling
+        if (!j.v.empty()) {
+          std::vector<const char *> names; for (auto &n : j.bxn) names.push_back(n.c_str());
+          uint8_t *pb = nullptr; size_t pl = 0;
+          arc = lancet_records_pack(j.v.data(), (uint32_t)j.v.size(), j.blob.data(), (uint32_t)j.blob.size(), ho.linked ? j.lr.data() : nullptr, ho.linked ? j.bx.data() : nullptr,
+                                    ho.linked ? names.data() : nullptr, (uint32_t)names.size(), chr_names, n_chr, j.widx.data(), (uint32_t)j.widx.size(), 1, &pb, &pl);
+          if (arc == LANCET_OK) { parts.emplace_back(pb, pb + pl); lancet_free(pb); }
+        }
+      } else
       if (!j.v.empty()) {
         if (ho.linked) {
           std::vector<const char *> names; for (auto &n : j.bxn) names.push_back(n.c_str());
@@ -215,7 +278,8 @@ int main(int argc, char **argv) {
   const bool packed = getenv("LANCET_GPU_ASCII") == nullptr && !(getenv("LANCET_PREP") && strcmp(getenv("LANCET_PREP"), "device") == 0);
   for (int c = 0; c < nchunks; ++c) {
     const int lo = c * step, hi = lo + step < nwin ? lo + step : nwin;
-    Slot &sl = slots[(size_t)c % slots.size()];
+    if (comm && c % ranks != rank) { jobs[(size_t)c].have = true; if (!flush()) return die(fail); continue; }      // another rank's batch
+    Slot &sl = slots[(size_t)(comm ? c / ranks : c) % slots.size()];
     lancet_window_batch B; lancet_packed_reads PK; int32_t nk = 0;
     memset(&PK, 0, sizeof(PK));
     double t0 = now();
@@ -233,7 +297,7 @@ int main(int argc, char **argv) {
     // The launch happens HERE, on the one thread that submits (a few hundred microseconds: everything is asynchronous), behind the kernels
     // of the last engine submitted on the same GPU -- the two batches' kernels run back to back, not side by side; its done-event is
     // recorded by then because its own submit has returned.  Only the wait (re-run tier, read-back) goes to another thread.
-    const int dev = devs.size() > 1 ? devs[(size_t)c % slots.size() % devs.size()] : devs[0];
+    const int dev = devs.size() > 1 ? devs[(size_t)(comm ? c / ranks : c) % slots.size() % devs.size()] : devs[0];
     lancet_engine *prev = last_on_dev.count(dev) ? last_on_dev[dev] : nullptr;
     t0 = now();
     if (lancet_engine_submit_after(e, prev) != LANCET_OK) return die(std::string("engine: ") + lancet_engine_last_error(e));
@@ -244,8 +308,49 @@ int main(int argc, char **argv) {
   }
   for (Slot &sl : slots) if (sl.fut.valid() && !finish(sl)) return die(fail);
   if (!flush()) return die(fail);
+  double t_gather = 0;
+  if (comm) {
+    // one payload per rank: u64 number of parts, their lengths, the parts; rank 0 replays every rank's parts into the database
+    const double tg0 = now();
+    std::vector<uint8_t> payload(8 * (1 + parts.size()));
+    { uint64_t x = parts.size(); memcpy(payload.data(), &x, 8); for (size_t i = 0; i < parts.size(); ++i) { x = parts[i].size(); memcpy(payload.data() + 8 * (1 + i), &x, 8); } }
+    for (auto &pt : parts) payload.insert(payload.end(), pt.begin(), pt.end());
+    uint8_t *all = nullptr; std::vector<size_t> lens((size_t)ranks, 0);
+    if (lancet_comm_gather(comm, payload.data(), payload.size(), &all, lens.data()) != LANCET_OK) return die(std::string("rank ") + std::to_string(rank) + ": gather: " + lancet_comm_last_error(comm));
+    uint32_t added = 0;
+    if (rank == 0) {
+      std::vector<const uint8_t *> pp; std::vector<size_t> pl;
+      size_t o = 0;
+      for (int r = 0; r < ranks; ++r) {
+        const uint8_t *b = all + o; const size_t len = lens[(size_t)r]; o += len;
+        if (len < 8) return die("gather: a rank sent a damaged payload");
+        uint64_t np = 0; memcpy(&np, b, 8);
+        if (8 * (1 + np) > len) return die("gather: a rank sent a damaged payload");
+        size_t q = 8 * (1 + (size_t)np);
+        for (uint64_t i = 0; i < np; ++i) { uint64_t x; memcpy(&x, b + 8 * (1 + i), 8); if (q + x > len) return die("gather: a rank sent a damaged payload"); pp.push_back(b + q); pl.push_back((size_t)x); q += (size_t)x; }
+      }
+      if (lancet_records_merge(db, pp.data(), pl.data(), (int)pp.size(), &added) != LANCET_OK) return die("VariantDB rejected the gathered records");
+    }
+    t_gather = now() - tg0;
+    fprintf(stderr, "[lancet_gpu] rank %d of %d on GPU %d (%s): %ld windows assembled, %zu batches, %zu bytes to rank 0%s\n", rank, ranks, devs[0], lancet_comm_transport(comm), done, parts.size(),
+            payload.size(), rank == 0 ? (std::string("; ") + std::to_string(added) + " records replayed").c_str() : "");
+    if (all) lancet_free(all);
+    lancet_comm_destroy(comm);
+  }
+  if (ranks > 0 && rank != 0) {
+    lancet_vdb_destroy(db); lancet_host_close(H); for (lancet_engine *e : engs) lancet_engine_destroy(e);
+    if (!overflowed.empty()) {
+      fprintf(stderr, "lancet_gpu: rank %d: %zu window(s) exceeded the engine's work space and contributed NO variants:\n", rank, overflowed.size());
+      for (const std::string &w : overflowed) fprintf(stderr, "lancet_gpu:   %s\n", w.c_str());
+      return 3;
+    }
+    return 0;
+  }
   std::string cmdline = "lancet";
-  for (int i = 1; i < argc; ++i) { if (strcmp(argv[i], "--date-line") == 0) { ++i; continue; } cmdline += " "; cmdline += argv[i]; }
+  for (int i = 1; i < argc; ++i) {
+    if (strcmp(argv[i], "--date-line") == 0 || strcmp(argv[i], "--rank") == 0 || strcmp(argv[i], "--rendezvous") == 0) { ++i; continue; }     // (what names the run / the process, not the job)
+    cmdline += " "; cmdline += argv[i];
+  }
   if (date_line.empty()) { time_t t = time(nullptr); date_line = ctime(&t); }
   else if (date_line.back() != '\n') date_line += "\n";
   char *vcf = lancet_vdb_vcf(db, nullptr, cmdline.c_str(), ref.c_str(), date_line.c_str(), lancet_host_sample(H, 0), lancet_host_sample(H, 1));
@@ -253,7 +358,7 @@ int main(int argc, char **argv) {
   fputs(vcf, stdout);
   fprintf(stderr, "[lancet_gpu] %d windows tiled, %ld assembled on %zu engine(s), first GPU %d, %u variants\n", nwin, done, engs.size(), devs[0], lancet_vdb_size(db));
   if (timing) fprintf(stderr, "[lancet_gpu] wall %.3f s: input decode + tiling %.3f, window filters + batches %.3f, engine (upload + kernels + results) %.3f (kernels %.3f), VariantDB %.3f\n",
-                      now() - t_start, t_tile, t_batch, t_engine, t_kernel / 1000.0, t_vdb);
+                      now() - t_start, t_tile, t_batch, t_engine, t_kernel / 1000.0, t_vdb + t_gather);
   lancet_free(vcf);
   lancet_vdb_destroy(db); lancet_host_close(H); for (lancet_engine *e : engs) lancet_engine_destroy(e);
   if (!overflowed.empty()) {

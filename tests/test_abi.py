@@ -21,7 +21,7 @@ def lib():
 
 
 def test_library_exports_every_declared_symbol(lib):
-    hdr = open(os.path.join(ROOT, "include", "lancet_engine.h")).read() + open(os.path.join(ROOT, "include", "lancet_host.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "lancet_engine.h")).read() + open(os.path.join(ROOT, "include", "lancet_host.h")).read() + open(os.path.join(ROOT, "include", "lancet_gather.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = set(re.findall(r"\b(lancet_[a-z_]+)\s*\(", hdr))
     assert len(names) >= 25 and "lancet_host_batch" in names

@@ -875,3 +875,30 @@ def test_scan_of_a_synthetic_contig_equals_the_oracle_window_by_window_and_in_th
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["records_identical"] and out["vcf_oracle_equals_lancet_gpu"] and out["vcf_engine_records_native_vdb_equals_lancet_gpu"] and out["vcf_header_lines_identical"]
     assert out["windows_assembled"] > 900 and out["vcf_lines"] > 0 and out["records_compared"] >= out["vcf_lines"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,region,extra,files", [
+    ("ar_small", "chr22:900-3000", ["--ranks", "1", "--batch-windows", "4"], False),                       # RCCL itself: one rank, the whole pack -> gather -> merge route
+    ("lr_small", "chr22:800-2700", ["--linked-reads", "--ranks", "1", "--batch-windows", "5"], False),
+    ("ar_small", "chr22:900-3000", ["--ranks", "2", "--devices", "0,0", "--batch-windows", "3"], True),   # two processes on the one GPU: payloads over the test transport
+    ("lr_small", "chr22:800-2700", ["--linked-reads", "--ranks", "3", "--devices", "0,0,0", "--batch-windows", "2"], True)])
+def test_lancet_gpu_ranks_gather_the_records_to_rank_0_and_write_the_reference_vcf(case, region, extra, files):
+    """`lancet_gpu --ranks N`: N processes (one engine each) take the batches in turn, pack + key + reduce their records
+    (lancet_records_pack), gather them to rank 0 (lancet_comm_gather: RCCL; two ranks cannot share a GPU under RCCL, so the N > 1 cases
+    on this one-GPU box carry the payloads through the test transport) and rank 0 replays them in window order (lancet_records_merge):
+    the reference's single-process VCF byte for byte, ##cmdline without the launcher's --rank / --rendezvous."""
+    env = dict(os.environ)
+    if files:
+        env["LANCET_COMM_TEST_FILES"] = "1"
+    else:
+        env.pop("LANCET_COMM_TEST_FILES", None)
+    r = subprocess.run([build.BIN, "--tumor", os.path.join(G, f"{case}.tumor.bam"), "--normal", os.path.join(G, f"{case}.normal.bam"),
+                        "--ref", os.path.join(G, f"{case}.fa"), "--reg", region, "--date-line", "Sun Sep 27 05:27:00 2026"] + extra,
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert _body(r.stdout) == gu.golden_vcf(case)
+    assert "--rendezvous" not in r.stdout and "--rank " not in r.stdout and "--ranks" in r.stdout
+    n = int(extra[extra.index("--ranks") + 1])
+    assert sum(1 for l in r.stderr.splitlines() if l.startswith("[lancet_gpu] rank ")) == n
+    assert ("(files)" in r.stderr) == files and ("(rccl)" in r.stderr) == (not files)
