@@ -280,7 +280,17 @@ int comm_open_rccl(lancet_comm *c, double timeout_s) {
     if (!read_file_when_there(c->path, b, now_s() + timeout_s) || b.size() != sizeof id) return fail(c, "rank 0's id did not appear at " + c->path, LANCET_E_STATE);
     memcpy(&id, b.data(), sizeof id);
   }
-  NCHK(c, c->p_init(&c->comm, c->world, id, c->rank));
+  {
+    // RCCL prints a version banner on STDOUT when a communicator comes up -- the stream rank 0 writes the VCF to.  For the time of the call
+    // file descriptor 1 points at stderr.
+    fflush(stdout);
+    const int saved = dup(1);
+    if (saved >= 0) dup2(2, 1);
+    const ncclResult_t r = c->p_init(&c->comm, c->world, id, c->rank);
+    fflush(nullptr);
+    if (saved >= 0) { dup2(saved, 1); close(saved); }
+    if (r != ncclSuccess) return fail(c, std::string("ncclCommInitRank: ") + c->p_errstr(r) + " (NCCL_DEBUG=WARN says why; two ranks on one GPU are refused)");
+  }
   HCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HCHK(c, hipMalloc((void **)&c->d_sizes, 8 * ((size_t)c->world + 1)));
   return LANCET_OK;

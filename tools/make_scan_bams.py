@@ -1,6 +1,10 @@
 """Synthetic tumor/normal BAM + FASTA for end-to-end runs of the command-line programs (test-side BAM writer).
 
-    python tools/make_scan_bams.py OUTDIR [ref_len=500000] [cov_t=30] [cov_n=30] [procs=1]
+    python tools/make_scan_bams.py OUTDIR [ref_len=500000] [cov_t=30] [cov_n=30] [procs=1] [contigs=1]
+
+contigs > 1 (with procs > 1): that many contigs of ref_len bases each (chr1 .. chr22, chrX, chrY; every contig its own reference, variants and
+read seeds), one BAM pair + .bai over all of them, a multi-contig FASTA + .fai and OUTDIR/regions.bed (the whole genome minus 1 kb at the
+contig ends): the one-GPU proxy of BASELINE config 3.
 
 procs > 1: the contig is dealt out in stretches to worker processes (same reference, same planted variants; every stretch its own read
 seed; a fragment starts inside its stretch and may end in the next one, so the coverage has no seams), which simulate AND encode their
@@ -38,12 +42,14 @@ def _stretch(job):
     which, i, lo, hi = job
     g = _G
     haps, probs, cov, seed, prefix, rg = (g["haps_t"], [0.5, 0.25, 0.25], g["cov_t"], 101, "T", "tumor") if which == "T" else (g["haps_n"], [0.5, 0.5], g["cov_n"], 202, "N", "normal")
-    pairs = synth.simulate_sample(g["ref"], g["rname"], haps, probs, cov, seed + 1000 * i, f"{prefix}{i:02d}x", rg, read_len=150, error_rate=0.005,
+    tid = g.get("tid", 0)
+    tag = f"{prefix}{i:02d}x" if not g.get("multi") else f"{prefix}{tid:02d}_{i:02d}x"
+    pairs = synth.simulate_sample(g["ref"], g["rname"], haps, probs, cov, seed + 1000 * i + 100003 * tid, tag, rg, read_len=150, error_rate=0.005,
                                   region=(lo, min(hi + 400, len(g["ref"]))), insert_mean=400.0, insert_sd=40.0, monotone_starts=True)
     keys, blob = [], bytearray()
     for a, b in pairs:
         for r in (a, b):
-            rec, rl = _encode(r, 0)
+            rec, rl = _encode(r, tid)
             keys.append((r.pos, r.qname, r.flag, rl, len(blob), len(rec)))
             blob += rec
     return which, i, keys, bytes(blob)
@@ -55,13 +61,14 @@ def _write(path, refs, sample, rg, parts, block=60000):
     for n, l in refs:
         body += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
     items = []
-    for pi, (keys, blob) in enumerate(parts):
-        items += [(k[0], k[1], k[2], pi, k[3], k[4], k[5]) for k in keys]
+    for pi, part in enumerate(parts):                               # (keys, blob) of contig 0, or (tid, keys, blob)
+        tid, keys = (0, part[0]) if len(part) == 2 else (part[0], part[1])
+        items += [(tid, k[0], k[1], k[2], pi, k[3], k[4], k[5]) for k in keys]
     items.sort()
     spans = []
-    for pos, _, _, pi, rl, off, ln in items:
-        spans.append((0, pos - 1, pos - 1 + rl, len(body), len(body) + 4 + ln))
-        body += struct.pack("<i", ln) + parts[pi][1][off:off + ln]
+    for tid, pos, _, _, pi, rl, off, ln in items:
+        spans.append((tid, pos - 1, pos - 1 + rl, len(body), len(body) + 4 + ln))
+        body += struct.pack("<i", ln) + parts[pi][-1][off:off + ln]
     coff = []
     with open(path, "wb") as fh:
         for i in range(0, len(body), block):
@@ -71,8 +78,9 @@ def _write(path, refs, sample, rg, parts, block=60000):
         fh.write(bam_writer._bgzf_block(b""))
     voff = lambda u: (coff[u // block] << 16) | (u % block)
     out = bytearray(b"BAI\1" + struct.pack("<i", len(refs)))
-    bins, lin = {}, {}
+    per = [({}, {}) for _ in refs]
     for (tid, beg, end, u0, u1) in spans:
+        bins, lin = per[tid]
         b = bam_writer._reg2bin(beg, end)
         ch = bins.setdefault(b, [])
         if ch and ch[-1][1] == voff(u0):
@@ -81,17 +89,18 @@ def _write(path, refs, sample, rg, parts, block=60000):
             ch.append([voff(u0), voff(u1)])
         for w in range(beg >> 14, ((end - 1) >> 14) + 1):
             lin[w] = min(lin.get(w, voff(u0)), voff(u0))
-    out += struct.pack("<i", len(bins))
-    for b in sorted(bins):
-        out += struct.pack("<Ii", b, len(bins[b]))
-        for c0, c1 in bins[b]:
-            out += struct.pack("<QQ", c0, c1)
-    n = max(lin) + 1
-    out += struct.pack("<i", n)
-    prev = 0
-    for w in range(n):
-        prev = lin.get(w, prev)
-        out += struct.pack("<Q", prev)
+    for bins, lin in per:
+        out += struct.pack("<i", len(bins))
+        for b in sorted(bins):
+            out += struct.pack("<Ii", b, len(bins[b]))
+            for c0, c1 in bins[b]:
+                out += struct.pack("<QQ", c0, c1)
+        n = (max(lin) + 1) if lin else 0
+        out += struct.pack("<i", n)
+        prev = 0
+        for w in range(n):
+            prev = lin.get(w, prev)
+            out += struct.pack("<Q", prev)
     with open(path + ".bai", "wb") as fh:
         fh.write(bytes(out))
     return len(items)
@@ -113,6 +122,40 @@ def main():
         bam_writer.write_bam(os.path.join(out, "normal.bam"), refs, synth.pairs_to_sorted_reads(data["normal"]), sample="NORMAL", index=True)
         synth.write_fasta(os.path.join(out, "ref.fa"), data["rname"], data["ref"])
         print(f"{out}: {ref_len} bp, {cov_t}x/{cov_n}x, {time.time() - t:.1f} s; region {data['rname']}:1000-{ref_len - 1000}")
+        return
+    contigs = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+    if contigs > 1:
+        names = ([f"chr{i}" for i in range(1, 23)] + ["chrX", "chrY"])[:contigs]
+        refs, allp, seqs = [], {"T": [], "N": []}, []
+        for tid, name in enumerate(names):
+            ref = synth.random_reference(ref_len, 22 + tid, 0.0, 0.0)
+            variants = synth.plant_variants(ref, 23 + tid, 2000, 1000, dup_prob=0.0)
+            germ = [v for v in variants if not v.somatic]
+            h0, h1, h2 = synth.build_haplotype(ref, []), synth.build_haplotype(ref, germ), synth.build_haplotype(ref, variants)
+            _G.update(ref=ref, rname=name, haps_t=[h0, h1, h2], haps_n=[h0, h1], cov_t=cov_t, cov_n=cov_n, tid=tid, multi=True)
+            nst = max(procs, (ref_len + 249999) // 250000)
+            bounds = [ref_len * i // nst for i in range(nst + 1)]
+            jobs = [(w, i, bounds[i], bounds[i + 1]) for w in ("T", "N") for i in range(nst)]
+            with mp.get_context("fork").Pool(procs) as pool:
+                res = pool.map(_stretch, jobs, chunksize=1)
+            for w in ("T", "N"):
+                allp[w] += [(tid, k, b) for ww, i, k, b in sorted((r for r in res if r[0] == w), key=lambda r: r[1])]
+            refs.append((name, ref_len)); seqs.append(ref)
+            print(f"{name}: simulated, {time.time() - t:.0f} s", flush=True)
+        for w, fname, sample in (("T", "tumor.bam", "TUMOR"), ("N", "normal.bam", "NORMAL")):
+            n = _write(os.path.join(out, fname), refs, sample, "tumor" if w == "T" else "normal", allp[w])
+            print(f"{fname}: {n} alignments, {time.time() - t:.0f} s")
+        width, off = 60, 0
+        with open(os.path.join(out, "ref.fa"), "w") as f, open(os.path.join(out, "ref.fa.fai"), "w") as fi, open(os.path.join(out, "regions.bed"), "w") as fb:
+            for (name, ln), seq in zip(refs, seqs):
+                hdr = f">{name}\n"
+                f.write(hdr); off += len(hdr)
+                fi.write(f"{name}\t{ln}\t{off}\t{width}\t{width + 1}\n")
+                for i in range(0, ln, width):
+                    f.write(seq[i:i + width] + "\n")
+                off += ln + (ln + width - 1) // width
+                fb.write(f"{name}\t1000\t{ln - 1000}\n")
+        print(f"{out}: {contigs} contigs x {ref_len} bp, {cov_t}x/{cov_n}x, {procs} processes, {time.time() - t:.1f} s; --bed {out}/regions.bed")
         return
     ref = synth.random_reference(ref_len, 22, 0.0, 0.0)
     variants = synth.plant_variants(ref, 23, 2000, 1000, dup_prob=0.0)
