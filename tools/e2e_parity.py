@@ -32,7 +32,7 @@ def _body(text: str) -> str:
 
 def main() -> int:
     ap = argparse.ArgumentParser()
-    ap.add_argument("dir"); ap.add_argument("region")
+    ap.add_argument("dir"); ap.add_argument("region", help="chr:start-end, or a BED file (name ends in .bed): --bed")
     ap.add_argument("--batch-windows", type=int, default=8192)
     ap.add_argument("--active-region-off", action="store_true")
     ap.add_argument("--procs", type=int, default=0)
@@ -57,7 +57,8 @@ def main() -> int:
     out = {"inputs": a.dir, "region": a.region, "batch_windows": a.batch_windows, "active_region": not a.active_region_off, "oracle_processes": procs}
     # ---- route 1: the program
     t0 = time.time()
-    cmd = [build.BIN, "--tumor", T, "--normal", N, "--ref", F, "--reg", a.region, "--batch-windows", str(a.batch_windows)]
+    bed = a.region.endswith(".bed")
+    cmd = [build.BIN, "--tumor", T, "--normal", N, "--ref", F, "--bed" if bed else "--reg", a.region, "--batch-windows", str(a.batch_windows)]
     if a.active_region_off:
         cmd.append("--active-region-off")
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -71,7 +72,7 @@ def main() -> int:
     p = abi.default_params()
     o = host.default_opts(active_region=0 if a.active_region_off else 1)
     nh = host.NativeHost(T, N, F)
-    hdrs = nh.tile(a.region, o)
+    hdrs = nh.tile_regions([], o, bed=a.region) if bed else nh.tile(a.region, o)
     if not (nh.first_has_md(True) or nh.first_has_md(False)):
         o.active_region = 0                                          # (main() turns the module off: reference src/Lancet.cc:817-825)
     nwin = len(hdrs) if not a.max_windows else min(len(hdrs), a.max_windows)
