@@ -196,28 +196,39 @@ def side_config(eng_cls, params, name, windows, cov_t, cov_n, steps, streaming=F
     return out
 
 
-def bam_e2e(d: str, region: str):
+def bam_e2e(d: str, region_args, gen_args, what: str, extra=("--devices", "0,0", "--batch-windows", "8192")):
     """BAM -> VCF with the native command-line program (lancet_amd/bin/lancet_gpu: BGZF inflate, alignment decode, tiling, read selection,
-    trim + pack, upload, kernels, VariantDB, VCF) on a pre-generated synthetic tumor / normal pair, when one is there (tools/make_scan_bams.py;
-    build/ is not part of the repository's history).  A whole process per run -- start-up, device initialisation and the work-space allocation
-    included -- twice, the second run reported; windows / wall seconds.  The 5 Mb contig of BASELINE.md config 2: profiles/r5_e2e_5mb.txt."""
+    trim + pack, upload, kernels, VariantDB, VCF) on a synthetic tumor / normal pair made by tools/make_scan_bams.py -- made here when it
+    is not there yet (build/ is not part of the repository's history; always 14 worker processes: the stretches, and so the reads, depend on
+    that number).  A whole process per run -- start-up, device initialisation and the work-space allocation included -- three times, the
+    fastest reported; windows / wall seconds."""
+    import hashlib
     import re
     import subprocess
     exe = os.path.join(ROOT, "lancet_amd", "bin", "lancet_gpu")
     need = [os.path.join(d, f) for f in ("tumor.bam", "normal.bam", "ref.fa")]
+    made_s = None
+    if os.path.exists(exe) and not all(os.path.exists(f) for f in need):
+        t = time.perf_counter()
+        try:
+            subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_scan_bams.py"), d] + [str(x) for x in gen_args], capture_output=True, text=True, timeout=600)
+        except (OSError, subprocess.TimeoutExpired):
+            return None
+        made_s = round(time.perf_counter() - t, 1)
     if not os.path.exists(exe) or not all(os.path.exists(f) for f in need):
         return None
-    res = None; walls = []
+    res = None; walls = []; md5s = set()
     for _ in range(3):
         try:
-            r = subprocess.run([exe, "--tumor", need[0], "--normal", need[1], "--ref", need[2], "--reg", region, "--active-region-off"],
-                               capture_output=True, text=True, timeout=120, env=dict(os.environ, LANCET_HOST_TIMING="1"))
+            r = subprocess.run([exe, "--tumor", need[0], "--normal", need[1], "--ref", need[2]] + [a.replace("{d}", d) for a in region_args] + ["--active-region-off"] + list(extra),
+                               capture_output=True, text=True, timeout=300, env=dict(os.environ, LANCET_HOST_TIMING="1"))
         except (OSError, subprocess.TimeoutExpired):
             return None
         m = re.search(r"\[lancet_gpu\] (\d+) windows tiled, (\d+) assembled.*?(\d+) variants", r.stderr)
         w = re.search(r"\[lancet_gpu\] wall ([0-9.]+) s: input decode \+ tiling ([0-9.]+), window filters \+ batches ([0-9.]+), engine \(upload \+ kernels \+ results\) ([0-9.]+) \(kernels ([0-9.]+)\), VariantDB ([0-9.]+)", r.stderr)
         if r.returncode not in (0, 3) or not m or not w:
             return None
+        md5s.add(hashlib.md5("".join(l + "\n" for l in r.stdout.splitlines() if not l.startswith(("##fileDate", "##cmdline", "##reference"))).encode()).hexdigest())
         wall = float(w.group(1))
         walls.append(wall)
         if res is not None and wall >= res["wall_s"]:
@@ -225,11 +236,14 @@ def bam_e2e(d: str, region: str):
         res = {"value": round(int(m.group(2)) / wall, 1), "unit": "windows/s", "windows": int(m.group(2)), "variants": int(m.group(3)), "wall_s": wall,
                "decode_tiling_s": float(w.group(2)), "filters_batches_s": float(w.group(3)), "engine_s": float(w.group(4)), "kernels_s": float(w.group(5)),
                "vcf_records": sum(1 for l in r.stdout.splitlines() if l and not l.startswith("#")),
-               "what": f"lancet_gpu --tumor/--normal/--ref --reg {region} --active-region-off on {os.path.relpath(d, ROOT)} (500 kb, 30x/30x, 2x150 bp), the fastest of three runs, "
+               "what": f"lancet_gpu --tumor/--normal/--ref {' '.join(region_args)} --active-region-off {' '.join(extra)} on {os.path.relpath(d, ROOT)} ({what}), the fastest of three runs, "
                        "a whole process: start-up, device initialisation and allocation included (a run that follows a process which just released tens of GB "
-                       "of device memory may wait seconds in hipMalloc for the driver to wipe it: DESIGN_HISTORY.md 7a)"}
+                       "of device memory may wait in hipMalloc for the driver to wipe it: DESIGN_HISTORY.md 7a)"}
     if res:
         res["wall_s_all_runs"] = walls
+        res["vcf_md5"] = sorted(md5s)[0] if len(md5s) == 1 else sorted(md5s)          # (one value: the three runs wrote the same VCF)
+        if made_s is not None:
+            res["inputs_made_s"] = made_s
     return res
 
 
@@ -607,12 +621,21 @@ def main():
         for e2 in engs:
             e2.close()
         if world == 1 and not args.no_bam:
-            bam = bam_e2e(os.path.join(ROOT, "build", "scan500k"), "chr22:1000-499000")
+            # BASELINE config 2's 5 Mb contig (49 981 windows; every record and the VCF of this very input against the oracle:
+            # tools/e2e_parity.py, profiles/r6_e2e_parity_5mb.json)
+            bam = bam_e2e(os.path.join(ROOT, "build", "scan5m"), ["--reg", "chr22:1000-4999000"], [5000000, 30, 30, 14], "5 Mb contig, 30x/30x, 2x150 bp")
             if bam:
                 out["value_bam_e2e"] = bam.pop("value")       # BAM -> VCF by the native program, a whole process: never `value`
                 out["value_bam_e2e_detail"] = bam
+            # BASELINE config 3 as a one-GPU proxy: 24 contigs through --bed, the N-process route (lancet_gpu --ranks 1: pack, RCCL gather, merge on rank 0)
+            c3 = bam_e2e(os.path.join(ROOT, "build", "scan24x100k"), ["--bed", "{d}/regions.bed"], [100000, 30, 30, 14, 24], "24 contigs x 100 kb, 30x/30x, 2x150 bp",
+                         extra=("--ranks", "1", "--batch-windows", "8192"))
+            if c3:
+                c3["name"] = "config 3 proxy on one GPU: 24 contigs, --bed, lancet_gpu --ranks 1 (records packed, gathered over RCCL, replayed on rank 0); the 24 x 1 Mb run, engines / ranks / oracle parity: profiles/r6_config3_proxy.txt"
+                c3["windows_per_s"] = c3.pop("value")
+                out["config3_proxy"] = c3
         if world == 1 and not args.no_configs:
-            out["configs"] = [
+            out["configs"] = ([out.pop("config3_proxy")] if "config3_proxy" in out else []) + [
                 side_config(engine.Engine, params, "config 2 at 60x/60x", 8192, 60.0, 60.0, 8),
                 side_config(engine.Engine, params, "config 4: 100x tumor / 40x normal, 30 % STR + 5 % low complexity", 4096, 100.0, 40.0, 8,
                             str_fraction=0.30, lowcomplex_fraction=0.05),

@@ -25,6 +25,7 @@
 #include <map>
 #include <set>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <unordered_set>
@@ -88,6 +89,7 @@ struct Sample {
   Bytes pk_bases, pk_good;
   int pk_qtrim = -1, pk_qcall = -1; size_t pk_n = 0;
   std::unique_ptr<std::atomic<uint8_t>[]> pk_state;   // per alignment: 0 not packed yet, 1 a thread is packing it, 2 packed (pack_read_once)
+  size_t u_lo = 1, u_hi = 0;                           // [u_lo, u_hi]: the entries of uidx the last batch wrote (all others are 0xFFFFFFFF)
   std::vector<uint32_t> uidx;                          // lancet_host_batch_packed, reads stored once: per alignment its place among the batch's distinct reads of this sample (0xFFFFFFFF: in no window of the batch)
   std::vector<std::pair<size_t, size_t>> span;   // per contig of the tiling: its reads [first, last) (file order = coordinate order)
 };
@@ -1194,17 +1196,32 @@ static int host_batch_impl(lancet_host *h, int w_begin, int w_end, const lancet_
   if (packed) {
     for (int smp = 0; smp < 4; ++smp) ensure_pack_cache(h->smp[smp], *P);
     if (shared) {
-      for (int smp = 0; smp < 4; ++smp) h->smp[smp].uidx.assign(h->smp[smp].reads.size(), 0xFFFFFFFFu);
+      // (only the index range the batch's windows touch is visited: a scan over every loaded alignment per batch was O(total reads) per
+      //  batch, single-threaded -- millions of alignments per sample in a scan that is loaded at once)
+      for (int smp = 0; smp < 4; ++smp) {
+        Sample &S = h->smp[smp];
+        if (S.uidx.size() != S.reads.size()) { S.uidx.assign(S.reads.size(), 0xFFFFFFFFu); S.u_lo = 1; S.u_hi = 0; }
+        for (size_t i = S.u_lo; i <= S.u_hi && i < S.uidx.size(); ++i) S.uidx[i] = 0xFFFFFFFFu;      // what the batch before wrote
+        S.u_lo = 1; S.u_hi = 0;
+      }
       {   // which alignments the batch's windows hold (the same word from several threads: relaxed stores)
         std::atomic<int> next(0);
+        std::mutex mm;
         auto mark = [&]() {
+          size_t lo[4] = {SIZE_MAX, SIZE_MAX, SIZE_MAX, SIZE_MAX}, hi[4] = {0, 0, 0, 0}; bool any[4] = {false, false, false, false};
+          auto touch = [&](int smp, size_t idx) { __atomic_store_n(&h->smp[smp].uidx[idx], 0u, __ATOMIC_RELAXED); if (idx < lo[smp]) lo[smp] = idx; if (idx > hi[smp]) hi[smp] = idx; any[smp] = true; };
           for (;;) {
             const int k = next.fetch_add(1);
             if (k >= nk) break;
             const int i = kw[(size_t)k];
-            for (const RSel &rs : pre[(size_t)k]) __atomic_store_n(&h->smp[rs.smp].uidx[rs.s.idx], 0u, __ATOMIC_RELAXED);
-            for (const Sel &s2 : selT[(size_t)i]) __atomic_store_n(&h->smp[1].uidx[s2.idx], 0u, __ATOMIC_RELAXED);
-            for (const Sel &s2 : selN[(size_t)i]) __atomic_store_n(&h->smp[0].uidx[s2.idx], 0u, __ATOMIC_RELAXED);
+            for (const RSel &rs : pre[(size_t)k]) touch(rs.smp, rs.s.idx);
+            for (const Sel &s2 : selT[(size_t)i]) touch(1, s2.idx);
+            for (const Sel &s2 : selN[(size_t)i]) touch(0, s2.idx);
+          }
+          std::lock_guard<std::mutex> g(mm);
+          for (int smp = 0; smp < 4; ++smp) if (any[smp]) {
+            Sample &S = h->smp[smp];
+            if (S.u_lo > S.u_hi) { S.u_lo = lo[smp]; S.u_hi = hi[smp]; } else { if (lo[smp] < S.u_lo) S.u_lo = lo[smp]; if (hi[smp] > S.u_hi) S.u_hi = hi[smp]; }
           }
         };
         unsigned nt = host_threads(nk);
@@ -1218,7 +1235,7 @@ static int host_batch_impl(lancet_host *h, int w_begin, int w_end, const lancet_
         Sample &S = h->smp[order[q]];
         ubase[order[q]] = (uint32_t)U;
         uint32_t c = 0;
-        for (size_t i = 0; i < S.uidx.size(); ++i) if (S.uidx[i] != 0xFFFFFFFFu) { S.uidx[i] = c++; ulist.emplace_back((uint8_t)order[q], (uint32_t)i); }
+        for (size_t i = S.u_lo; i <= S.u_hi && i < S.uidx.size(); ++i) if (S.uidx[i] != 0xFFFFFFFFu) { S.uidx[i] = c++; ulist.emplace_back((uint8_t)order[q], (uint32_t)i); }
         U += c;
       }
       h->b_rinfo.resize(U + 1); h->b_bw.resize(U + 1); h->b_gw.resize(U + 1); h->b_ridx.resize(R);
