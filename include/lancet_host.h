@@ -96,6 +96,11 @@ int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_
  * object like the batch's, valid until the next batch call). */
 int lancet_host_batch_packed(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o, const lancet_params *P, lancet_window_batch *out,
                              lancet_packed_reads *pk, int32_t *kept, int32_t *n_kept);
+/* Batch calls need not follow each other: a call that does not start where the previous one ended works out again what the windows before
+ * it left in the graph (the reference's read leak across windows, src/Microassembler.cc:83) -- an N-process run deals the window table out.
+ * lancet_host_load_range: lazy mode only (else a no-op) -- loads, once, what the windows [w_begin, w_end) can select, so that the batch calls
+ * inside that range do not load again (the range a rank owns). */
+int lancet_host_load_range(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o);
 /* barcode strings of the last batch by bx_rank (linked reads) */
 const char *const *lancet_host_bx_names(const lancet_host *h, uint32_t *n);
 

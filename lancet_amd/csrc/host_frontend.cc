@@ -664,6 +664,8 @@ struct lancet_host {
   std::vector<Window> windows;      // processing order
   std::vector<RSel> leak;           // reads of a window without a mapped read: the reference's processGraph returns before g.clear()
                                     // (src/Microassembler.cc:83), so they are still in the graph when the next window is loaded
+  int next_w = 0;                   // where the last batch call ended: a call that starts elsewhere works `leak` out again (prime_leak)
+  int loaded_lo = 0, loaded_hi = 0; // lazy mode: the windows whose alignments are loaded (lancet_host_load_range); a batch inside them does not reload
   // last batch
   std::vector<int32_t> b_chr, b_refstart;
   std::vector<uint32_t> b_refoff, b_readbegin, b_seqoff, b_namerank, b_bxrank;
@@ -1042,7 +1044,7 @@ int lancet_host_tile(lancet_host *h, const char *region, const lancet_host_opts 
 // padded twice.  Lines starting with '#' are skipped; columns are tab separated.
 int lancet_host_tile_regions(lancet_host *h, const char *bed_path, const char *const *regions, int n_regions, const lancet_host_opts *o) {
   if (!h || !o) return LANCET_E_ARG;
-  h->windows.clear(); h->leak.clear(); h->chroms.clear();
+  h->windows.clear(); h->leak.clear(); h->chroms.clear(); h->next_w = 0; h->loaded_lo = h->loaded_hi = 0;
   std::map<std::string, std::vector<std::pair<int32_t, int32_t>>> want;
   if (bed_path && *bed_path) {
     std::string bed;
@@ -1106,8 +1108,55 @@ static inline void pack_read_once(Sample &S, const lancet_params &P, size_t i) {
   } else while (st.load(std::memory_order_acquire) != 2) std::this_thread::yield();
 }
 
+// What the windows before w_begin left in the graph, for a batch call that does not continue the previous one (an N-process run deals the
+// batches out: lancet_main.cc --ranks).  `leak` is sequential state of the reference's window loop: a window that passes the filters
+// but has no mapped read returns from processGraph before g.clear() (src/Microassembler.cc:83), so its reads are still there when the next
+// window is loaded; a window with a mapped read, or one skipped for coverage (g.clear(true), :836), ends the run; a window the filters
+// turn away (:799-820) does not touch the graph.  So the leak entering w_begin is the reads of the trailing run of such windows: walk
+// backwards until one ends it -- nearly always the very first step.
+static int prime_leak(lancet_host *h, int w_begin, const lancet_host_opts *o) {
+  h->leak.clear();
+  for (int w = w_begin - 1; w >= 0; --w) {
+    const Window &win = h->windows[(size_t)w];
+    if (win.seq.empty() || is_repeat(win.seq, o->max_k)) continue;
+    if (h->lazy) {                                    // this window's alignments (what was collected so far moves to the side store)
+      const int rc = reload_for(h, w, w + 1); if (rc != LANCET_OK) return rc;
+      h->loaded_lo = w; h->loaded_hi = w + 1;
+    }
+    if (o->active_region && !(is_active_region(h->smp[1], win, false, *o, h->readgroups) || is_active_region(h->smp[0], win, true, *o, h->readgroups))) continue;
+    std::vector<Sel> sT, sN;
+    const bool okT = extract_reads(h->smp[1], win, false, *o, h->readgroups, &sT);
+    const bool okN = extract_reads(h->smp[0], win, true, *o, h->readgroups, &sN);
+    if (!(okT && okN)) break;                         // skipped for coverage: the graph was cleared
+    uint8_t mp = 0;
+    for (const Sel &x : sT) mp |= x.mapped;
+    for (const Sel &x : sN) mp |= x.mapped;
+    if (mp) break;                                    // processed: cleared
+    std::vector<RSel> mine;                           // this window's reads come BEFORE what the later windows of the run added
+    for (const Sel &x : sT) mine.push_back(RSel{1, x});
+    for (const Sel &x : sN) mine.push_back(RSel{0, x});
+    mine.insert(mine.end(), h->leak.begin(), h->leak.end());
+    h->leak.swap(mine);
+  }
+  return LANCET_OK;
+}
+
 static int host_batch_impl(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o, lancet_window_batch *out,
                            int32_t *kept, int32_t *n_kept, const lancet_params *P, lancet_packed_reads *pk);
+// Lazy mode: loads, once, the alignments the windows [w_begin, w_end) can select; batch calls inside that range then load nothing.  (A rank
+// of an N-process run owns one contiguous range of the window table; in the table's order -- header strings -- a batch of windows is
+// scattered over its contig, so loading batch by batch touches the same stretches again and again.)  Without lazy mode: nothing to do.
+int lancet_host_load_range(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o) {
+  if (!h || !o || w_begin < 0 || w_end < w_begin || (size_t)w_end > h->windows.size()) { if (h) h->err = "bad window range"; return LANCET_E_ARG; }
+  if (!h->lazy || w_end == w_begin) return LANCET_OK;
+  // what the windows before the range left in the graph first (it loads single windows), then the range: reload_for moves those reads to the
+  // side store, and the batch call that starts at w_begin continues from here
+  if (w_begin != h->next_w) { const int rc = prime_leak(h, w_begin, o); if (rc != LANCET_OK) return rc; }
+  const int rc = reload_for(h, w_begin, w_end);
+  if (rc != LANCET_OK) return rc;
+  h->loaded_lo = w_begin; h->loaded_hi = w_end; h->next_w = w_begin;
+  return LANCET_OK;
+}
 int lancet_host_batch(lancet_host *h, int w_begin, int w_end, const lancet_host_opts *o, lancet_window_batch *out,
                       int32_t *kept, int32_t *n_kept) { return host_batch_impl(h, w_begin, w_end, o, out, kept, n_kept, nullptr, nullptr); }
 // The same batch with the reads trimmed and packed for lancet_engine_upload_packed (host_pack.h: the engine's own routine) instead of
@@ -1123,7 +1172,12 @@ static int host_batch_impl(lancet_host *h, int w_begin, int w_end, const lancet_
   const int nwin = w_end - w_begin;
   const bool timing = getenv("LANCET_HOST_TIMING") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  if (h->lazy) { const int rc = reload_for(h, w_begin, w_end); if (rc != LANCET_OK) return rc; }
+  if (w_begin != h->next_w) { const int rc = prime_leak(h, w_begin, o); if (rc != LANCET_OK) return rc; }      // (not the continuation of the call before)
+  if (h->lazy && !(w_begin >= h->loaded_lo && w_end <= h->loaded_hi)) {
+    const int rc = reload_for(h, w_begin, w_end); if (rc != LANCET_OK) return rc;
+    h->loaded_lo = w_begin; h->loaded_hi = w_end;
+  }
+  h->next_w = w_end;
   const double t0 = now();
   std::vector<std::vector<Sel>> selT((size_t)nwin), selN((size_t)nwin);
   std::vector<uint8_t> keep((size_t)nwin, 0), wmapped((size_t)nwin, 0);

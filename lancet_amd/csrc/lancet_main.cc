@@ -9,7 +9,7 @@
 // the number of engines), --strict (no VCF at all when a window exceeded the engine's work space; by default the run
 // finishes, the windows are listed on stderr and the exit code is 3).
 // --ranks N: N processes, one per GPU (rank r on --devices[r mod #devices], default device r): the batches of --batch-windows windows are
-// dealt out to the ranks in turn, every rank keys and reduces its records (lancet_records_pack) and they are gathered to rank 0 over RCCL
+// dealt out to the ranks in contiguous runs, every rank keys and reduces its records (lancet_records_pack) and they are gathered to rank 0 over RCCL
 // (lancet_comm_gather: sizes by one all-gather, payloads by send / recv to rank 0 only) and replayed into the VariantDB in window order
 // (lancet_records_merge) -- what the reference does with its per-thread databases at the end of main() (reference src/Lancet.cc:940-959).
 // Without --rank the program starts the N ranks itself (children of this process, --rank r --rendezvous <path> appended) and waits for
@@ -161,7 +161,7 @@ int main(int argc, char **argv) {
     char cerr[512] = "";
     comm = lancet_comm_create(rank, ranks, devs[0], rendezvous.c_str(), 300.0, cerr, sizeof cerr);
     if (!comm) return die(std::string("rank ") + std::to_string(rank) + ": cannot join the communicator: " + cerr);
-    if (ranks > 1 && !getenv("LANCET_HOST_LAZY")) setenv("LANCET_HOST_LAZY", "1", 0);     // a rank loads what ITS batches select (needs both .bai; else a notice and everything is loaded)
+    if (ranks > 1 && !getenv("LANCET_HOST_LAZY")) setenv("LANCET_HOST_LAZY", "1", 0);     // a rank loads what ITS windows select, once (lancet_host_load_range; needs both .bai, else a notice and everything is loaded)
   }
   std::vector<lancet_engine *> engs;
   for (int d : devs) {
@@ -276,10 +276,14 @@ int main(int argc, char **argv) {
   // base handed over, one pass over the reads instead of two); LANCET_GPU_ASCII=1, or trim + pack on the device (LANCET_PREP=device), keep
   // the ASCII hand-over.
   const bool packed = getenv("LANCET_GPU_ASCII") == nullptr && !(getenv("LANCET_PREP") && strcmp(getenv("LANCET_PREP"), "device") == 0);
+  // --ranks: rank r owns one contiguous run of batches -- in the table's order (header strings) that is a run of contigs, whose alignments
+  // the rank loads once; the records then reach rank 0 in window order, rank by rank
+  const int c_lo = comm ? (int)((long)nchunks * rank / ranks) : 0, c_hi = comm ? (int)((long)nchunks * (rank + 1) / ranks) : nchunks;
+  if (comm && c_hi > c_lo && lancet_host_load_range(H, c_lo * step, c_hi * step < nwin ? c_hi * step : nwin, &ho) != LANCET_OK) return die(lancet_host_last_error(H));
   for (int c = 0; c < nchunks; ++c) {
     const int lo = c * step, hi = lo + step < nwin ? lo + step : nwin;
-    if (comm && c % ranks != rank) { jobs[(size_t)c].have = true; if (!flush()) return die(fail); continue; }      // another rank's batch
-    Slot &sl = slots[(size_t)(comm ? c / ranks : c) % slots.size()];
+    if (comm && (c < c_lo || c >= c_hi)) { jobs[(size_t)c].have = true; if (!flush()) return die(fail); continue; }      // another rank's batch
+    Slot &sl = slots[(size_t)c % slots.size()];
     lancet_window_batch B; lancet_packed_reads PK; int32_t nk = 0;
     memset(&PK, 0, sizeof(PK));
     double t0 = now();
@@ -297,7 +301,7 @@ int main(int argc, char **argv) {
     // The launch happens HERE, on the one thread that submits (a few hundred microseconds: everything is asynchronous), behind the kernels
     // of the last engine submitted on the same GPU -- the two batches' kernels run back to back, not side by side; its done-event is
     // recorded by then because its own submit has returned.  Only the wait (re-run tier, read-back) goes to another thread.
-    const int dev = devs.size() > 1 ? devs[(size_t)(comm ? c / ranks : c) % slots.size() % devs.size()] : devs[0];
+    const int dev = devs.size() > 1 ? devs[(size_t)c % slots.size() % devs.size()] : devs[0];
     lancet_engine *prev = last_on_dev.count(dev) ? last_on_dev[dev] : nullptr;
     t0 = now();
     if (lancet_engine_submit_after(e, prev) != LANCET_OK) return die(std::string("engine: ") + lancet_engine_last_error(e));

@@ -387,6 +387,59 @@ def test_reads_of_a_window_without_mapped_reads_stay_in_the_graph_as_in_the_refe
     H.close()
 
 
+def test_batch_calls_in_any_order_carry_the_read_leak_of_the_windows_before_them(tmp_path, monkeypatch):
+    """An N-process run deals the window table out (lancet_gpu --ranks): a batch call that does not start where the previous one ended
+    has to work out again what the windows before it left in the graph (lancet_host.h; reference src/Microassembler.cc:83).  On the
+    leak fixture -- windows 6, 7, 8 hold no mapped read, window 9 inherits their reads: 631 in all -- every window asked for on its own, last
+    window first, equals that window of the sequential scan; so do runs of three windows starting inside the leaking run, with and without
+    the per-call loading of lazy mode (an indexed copy of the fixture), and with lancet_host_load_range in front."""
+    from lancet_amd import bamio
+    fa = os.path.join(G, "leak_small.fa")
+    o = host.default_opts(active_region=0)
+
+    def baseline(paths):
+        H = host.NativeHost(*paths)
+        n = len(H.tile("chr22:1000-3000", o))
+        seq = [H.batch(w, w + 1, o)[0] for w in range(n)]
+        H.close()
+        assert int(np.diff(seq[8].read_begin)[0]) == 631 and [b.n_windows for b in seq[5:8]] == [1, 1, 1]
+        return n, seq
+
+    def same(a, b):
+        assert a.n_windows == b.n_windows
+        for f in FIELDS:
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+
+    def check(paths, n, seq):
+        H2 = host.NativeHost(*paths)
+        assert len(H2.tile("chr22:1000-3000", o)) == n
+        for w in reversed(range(n)):
+            same(H2.batch(w, w + 1, o)[0], seq[w])
+        for lo in (6, 7, 8, 5):                                   # runs that start inside / just before the leaking run
+            b3 = H2.batch(lo, min(n, lo + 3), o)[0]
+            assert [int(x) for x in np.diff(b3.read_begin)] == [int(np.diff(seq[w].read_begin)[0]) for w in range(lo, min(n, lo + 3)) if seq[w].n_windows]
+        H2.L.lancet_host_load_range.argtypes = [host.C.c_void_p, host.C.c_int, host.C.c_int, host.C.POINTER(host.LancetHostOpts)]
+        assert H2.L.lancet_host_load_range(H2.h, 7, n, host.C.byref(o)) == 0
+        for w in range(7, n):
+            same(H2.batch(w, w + 1, o)[0], seq[w])
+        H2.close()
+
+    paths = [os.path.join(G, "leak_small.tumor.bam"), os.path.join(G, "leak_small.normal.bam"), fa]
+    n, seq = baseline(paths)
+    check(paths, n, seq)
+    # lazy mode needs indexes: copies of the fixture written with the test-side BAM writer (+ .bai)
+    lp = []
+    for nm, sample in (("tumor", "TUMOR"), ("normal", "NORMAL")):
+        hdr, reads = bamio.read_bam(os.path.join(G, f"leak_small.{nm}.bam"))
+        out = str(tmp_path / (nm + ".bam"))
+        bam_writer.write_bam(out, hdr["refs"], reads, sample=sample, index=True)
+        lp.append(out)
+    monkeypatch.setenv("LANCET_HOST_LAZY", "0")
+    n2, seq2 = baseline(lp + [fa])
+    monkeypatch.setenv("LANCET_HOST_LAZY", "1")
+    check(lp + [fa], n2, seq2)
+
+
 @pytest.mark.gpu
 def test_lancet_gpu_reproduces_the_reference_s_read_leak():
     r = subprocess.run([build.BIN, "--tumor", os.path.join(G, "leak_small.tumor.bam"), "--normal", os.path.join(G, "leak_small.normal.bam"),
@@ -882,7 +935,10 @@ def test_scan_of_a_synthetic_contig_equals_the_oracle_window_by_window_and_in_th
     ("ar_small", "chr22:900-3000", ["--ranks", "1", "--batch-windows", "4"], False),                       # RCCL itself: one rank, the whole pack -> gather -> merge route
     ("lr_small", "chr22:800-2700", ["--linked-reads", "--ranks", "1", "--batch-windows", "5"], False),
     ("ar_small", "chr22:900-3000", ["--ranks", "2", "--devices", "0,0", "--batch-windows", "3"], True),   # two processes on the one GPU: payloads over the test transport
-    ("lr_small", "chr22:800-2700", ["--linked-reads", "--ranks", "3", "--devices", "0,0,0", "--batch-windows", "2"], True)])
+    ("lr_small", "chr22:800-2700", ["--linked-reads", "--ranks", "3", "--devices", "0,0,0", "--batch-windows", "2"], True),
+    # the reference's read leak across windows (windows 6-8 without a mapped read, window 9 inherits their reads): rank boundaries inside that run
+    ("leak_small", "chr22:1000-3000", ["--active-region-off", "--ranks", "2", "--devices", "0,0", "--batch-windows", "1"], True),
+    ("leak_small", "chr22:1000-3000", ["--active-region-off", "--ranks", "3", "--devices", "0,0,0", "--batch-windows", "1"], True)])
 def test_lancet_gpu_ranks_gather_the_records_to_rank_0_and_write_the_reference_vcf(case, region, extra, files):
     """`lancet_gpu --ranks N`: N processes (one engine each) take the batches in turn, pack + key + reduce their records
     (lancet_records_pack), gather them to rank 0 (lancet_comm_gather: RCCL; two ranks cannot share a GPU under RCCL, so the N > 1 cases
