@@ -57,7 +57,8 @@ void usage() {
         "Additional options:\n"
         "   --device <n> | --devices a,b,...  : GPU(s) to use; an entry may repeat (two engines on one GPU overlap the upload of a\n"
         "                                       batch with the kernels of the previous one)\n"
-        "   --batch-windows <n>               : windows per engine batch [32768]\n"
+        "   --batch-windows <n>               : windows per engine batch [8192: a scan waits for the host side, and smaller batches keep two engines\n"
+        "                                       on the GPU busy while the next batch is assembled; 32768 is what the kernels alone like best]\n"
         "   --strict                          : write no VCF when a window exceeded the engine's work space (default: finish,\n"
         "                                       list those windows on stderr, exit code 3)\n"
         "   --ranks <n>                       : n processes, one per GPU; records gathered to rank 0 over RCCL, same VCF for every n\n"
@@ -72,7 +73,7 @@ int main(int argc, char **argv) {
   std::string tumor, normal, ref, reg, bed, qrange = "!", date_line, devices, rg_file;
   int min_k = 11, max_k = 101, trim_lowqual = 10, min_base_qual = 17, tip_len = 11, cov_thr = 5, low_cov = 1, dfs_limit = 1000000;
   int max_indel_len = 500, max_mismatch = 2, max_unit_length = 4, min_report_unit = 3, min_report_len = 7, dist_from_str = 1;
-  int device = 0, batch_windows = 32768, verbose = 0, strict = 0, ranks = 0, rank = -1;
+  int device = 0, batch_windows = 8192, verbose = 0, strict = 0, ranks = 0, rank = -1;
   std::string rendezvous;
   double cov_ratio = 0.01;
   lancet_host_opts ho; lancet_host_opts_default(&ho);
