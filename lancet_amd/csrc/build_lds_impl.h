@@ -871,7 +871,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   const int reflen = (int)(B.ref_off[w + 1] - B.ref_off[w]);
   LC_GLOBAL const uint8_t *refc = B.ref_codes + B.ref_off[w];
   WG_LANE0 { S.hint = 0; S.ndup = 0; S.w = w; S.why = BLW_NONE; S.R = nr + 1; S.reflen = reflen; S.hasN = 0; S.mapped = 0; S.flagged = 0; S.npairs = 0; S.edges_total = 0; S.refn = 0;
-             H->status = PB_NOT_BUILT; H->why = 0; H->have_rep = 0; H->heavy = 0; H->next = 0;
+             H->status = PB_NOT_BUILT; H->why = 0; H->have_rep = 0; H->heavy = 0; H->next = 0; H->lr = 0; H->lr_total = 0;
              ((LC_GLOBAL PreCmp *)(area + PRE_OFF_CHDR))->done = 0;
              if (nr > BL_RMAX || reflen > (int)PL.maxw || reflen < 1) S.why = BLW_SIZE; }
   if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
@@ -1462,6 +1462,44 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     WG_SYNC();
   }
   const uint32_t ncand = bl_bcast(&S.ncand);
+  // ---- --linked-reads: the occurrences of the tracked nodes leave the workgroup as well, as csr runs by node id (layout.h PRE_OFF_LRNOCC /
+  //      PRE_OFF_LRCSR; entries = the window kernel's cs_t words: read, position, orientation, state 2 = not counted -- the reference pseudo-read,
+  //      an overlapping mate).  Barcode and haplotype bookkeeping (Node_t::addBX / addHP / hasBX, reference src/Graph.cc:239-263,
+  //      src/Node.cc:30-118) is a replay over a node's occurrences in visiting order: the window kernel does it (kernels.h load_prebuilt_lr)
+  //      over these runs instead of building the whole window in HBM to get at them.  What this kernel computes does not depend on barcodes:
+  //      the four per-position counters, the first removeLowCov (on mincovQV of those), edges, table order, components.  A node with
+  //      one occurrence is not tracked and has no run: it is removed and no reference k-mer with a read on it (those are tracked).
+  if (P->lr_mode) {
+    LC_GLOBAL uint32_t *lrnocc = (LC_GLOBAL uint32_t *)(area + PRE_OFF_LRNOCC);
+    LC_GLOBAL uint32_t *lrcsr = (LC_GLOBAL uint32_t *)(area + PRE_OFF_LRCSR);
+    LC_LDS uint32_t *cur = S.big;                                  // [N + 1] occurrences per node -> run starts -> fill cursors
+    static_assert(4u * (BL_NCAP + 2u) <= (uint32_t)BL_BIG, "run starts of every node in the phase area");
+    WG_FOR(n, N + 1) { cur[n] = 0; }
+    WG_SYNC();
+    bl_for_chunk(S, X.occn, [&](const BlChunk &ch, const BlOccW &w) {
+      uint32_t nd[8];
+      BL_UNROLL for (int j = 0; j < 8; ++j) nd[j] = bl_occw_get(w, j) & ON_ID;
+      BL_UNROLL for (int j = 0; j < 8; ++j) { if (j < ch.nv && S.cidx[nd[j]] != 0xFFFFu) dev_atomic_add(&cur[nd[j]], 1u); }
+    });
+    bl_scan32(cur, (int)N + 1, S);
+    WG_LANE0 { if (PL.lrcap == 0u || S.scan_total > PL.lrcap) S.why = BLW_SIZE; }
+    if (bl_bcast(&S.why)) { WG_LANE0 { H->why = (uint32_t)S.why; } return; }
+    WG_FOR(n, N + 1) { lrnocc[n] = cur[n]; }
+    WG_SYNC();
+    bl_for_chunk(S, X.occn, [&](const BlChunk &ch, const BlOccW &w) {
+      const uint32_t st_r = ch.r == nr ? 2u : 0u;                   // (the reference pseudo-read never counts: Graph.cc:265)
+      uint32_t ev[8], at[8]; bool tk[8];
+      BL_UNROLL for (int j = 0; j < 8; ++j) { ev[j] = bl_occw_get(w, j); tk[j] = j < ch.nv && S.cidx[ev[j] & ON_ID] != 0xFFFFu; }
+      BL_UNROLL for (int j = 0; j < 8; ++j) at[j] = tk[j] ? dev_atomic_add(&cur[ev[j] & ON_ID], 1u) : 0u;
+      BL_UNROLL for (int j = 0; j < 8; ++j) {
+        if (!tk[j]) continue;
+        const uint32_t st = st_r ? st_r : ((ev[j] & ON_OVL) ? 2u : 0u);
+        lrcsr[at[j]] = (uint32_t)ch.r | ((uint32_t)(ch.p0 + j) << 16) | (((ev[j] >> ON_ORISH) & 1u) << 26) | (st << 27);
+      }
+    });
+    WG_SYNC();
+    WG_LANE0 { H->lr = 1u; H->lr_total = S.scan_total; }
+  }
   BLP(S, 10);
   if (C->debug_stop == 110u) { WG_LANE0 { H->why = 99; } return; }
   // ---- per-position quality counts of the candidates (Node_t::updateCovDistr minqv_fwd / minqv_rev, src/Node.cc:470-497) as
@@ -1995,7 +2033,8 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       WG_SYNC();
       const uint32_t hbc = lc_sgpr((uint32_t)S.g0), hnr = lc_sgpr((uint32_t)S.g1), ncomp = lc_sgpr((uint32_t)S.nbw);
       WG_SYNC();
-      if (!rep && ncomp == 1u && nsurv <= PB_CMAX && nsurv + 2u <= hnr && K <= 31 && !wide_tab && C->debug_stop != 140u)
+      // (--linked-reads: a node's counts are barcode counts the window kernel has yet to replay -- no compress here)
+      if (!rep && ncomp == 1u && nsurv <= PB_CMAX && nsurv + 2u <= hnr && K <= 31 && !wide_tab && C->debug_stop != 140u && !P->lr_mode)
         bl_compress_first(P, C, S, X, area, K, N, nsurv, ncand, reflen, hbc);
     }
   }

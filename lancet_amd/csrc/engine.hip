@@ -372,7 +372,10 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (const char *s = getenv("LANCET_PRE_WIDE")) e->pre_wide_env = atoi(s) != 0 ? 1 : 0;
   if (const char *s = getenv("LANCET_SVC_WGS")) e->n_svc_wgs = std::max(0, std::min(256, atoi(s)));
   if (const char *s = getenv("LANCET_SVC_DEPTH")) e->svc_depth = std::max(0, std::min(16, atoi(s)));
-  if (p->lr_mode) e->prebuild = false;                         // --linked-reads: barcode / haplotype bookkeeping lives in the general build only
+  // --linked-reads: the build kernel builds the window's first graph and hands the tracked nodes' occurrences over; the window kernel replays
+  // barcodes and haplotypes over them (kernels.h load_prebuilt_lr).  No graphs built ahead and no build service in this mode: a later k of a
+  // window is the general build's.  LANCET_LR_PREBUILD=0: the general build for every window (the route until round 5).
+  if (p->lr_mode) { if (const char *s = getenv("LANCET_LR_PREBUILD")) { if (atoi(s) == 0) e->prebuild = false; } e->ahead_depth_env = 0; }
   if (const char *s = getenv("LANCET_TRACE_WORDS")) e->evt_cap = (uint32_t)atoi(s);
   e->max_slots = (e->n_cus - e->svc_cus) * 4 * LC_W_EU - 4 * LC_W_EU;       // (one CU's worth short of the device: see n_bslots)
   if (e->svc_cus) e->n_svc_wgs = 2 * e->svc_cus;
@@ -497,7 +500,7 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
     const bool use_svc0 = e->svc && e->n_svc_wgs > 0 && !e->debug_stop;
     const int depth0 = e->ahead_depth_env >= 0 ? e->ahead_depth_env : 6;
     const size_t n_areas = (size_t)nw + (depth0 > 0 ? (size_t)std::max(64, nw / 4) : 0) + (use_svc0 ? (size_t)std::max(64, nw / 8) : 0);
-    e->caps.pl = e->caps2.pl = lc_pre_layout_for_batch(b, n_areas, (size_t)20 << 30, e->pre_wide_env);
+    e->caps.pl = e->caps2.pl = lc_pre_layout_for_batch(b, n_areas, (size_t)20 << 30, e->pre_wide_env, e->params.lr_mode != 0);
     if (!e->node_cap1_env && e->caps.pl.ncap + 64u > node_cap1) {          // (wide hand-off areas: 14 336 nodes may arrive from the build kernel)
       const PreLayout pl = e->caps.pl;
       e->caps = lc_caps_for_batch(b, &e->params, e->evt_cap, 16384u, 1);

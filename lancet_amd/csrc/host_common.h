@@ -16,7 +16,7 @@ static inline uint32_t lc_bucket_cap_for(uint32_t nodes) {
 
 // Layout of one hand-off area of the LDS build kernel (layout.h PreLayout): `ncap` distinct k-mers, `qvcap` (candidate, position)
 // quality rows, `kw` words per candidate key.
-static inline PreLayout lc_pre_layout(uint32_t ncap, uint32_t qvcap, uint32_t kw, uint32_t maxw = LC_MAXW_DEFAULT) {
+static inline PreLayout lc_pre_layout(uint32_t ncap, uint32_t qvcap, uint32_t kw, uint32_t maxw = LC_MAXW_DEFAULT, uint32_t lrcap = 0) {
   PreLayout L; memset(&L, 0, sizeof(L));
   L.ncap = ncap; L.qvcap = qvcap; L.kw = kw; L.maxw = maxw;
   uint32_t o = PRE_OFF_OCCREF + 4u * maxw;
@@ -26,6 +26,7 @@ static inline PreLayout lc_pre_layout(uint32_t ncap, uint32_t qvcap, uint32_t kw
   L.snode = take(4u * PB_CCAP, 64u); L.skey = take(8u * kw * PB_CCAP, 64u); L.sid = take(4u * PB_SCAP, 64u);
   L.pgr = take(128u * PB_SCAP, 128u); L.order = take(4u * PB_SCAP, 64u); L.qv = take(8u * qvcap, 64u);
   L.chdr = take(64u, 64u); L.clive = take(4u * (PB_CMAX + 2u), 64u); L.cseq = take(4u * PB_CSEQ, 64u);
+  if (lrcap) { L.lrnocc = take(4u * (ncap + 2u), 64u); L.lrcsr = take(4u * lrcap, 64u); L.lrcap = lrcap; }      // --linked-reads
   L.stride = (o + 255u) & ~255u;
   return L;
 }
@@ -38,9 +39,9 @@ static inline uint32_t lc_max_w_for_batch(const lancet_window_batch *b) {      /
   m = (m + 63u) & ~63u;
   return m > LC_MAXW ? (uint32_t)LC_MAXW : m;
 }
-static inline PreLayout lc_pre_layout_for_batch(const lancet_window_batch *b, size_t n_areas, size_t budget, int force = -1) {
+static inline PreLayout lc_pre_layout_for_batch(const lancet_window_batch *b, size_t n_areas, size_t budget, int force = -1, bool lr = false) {
   const uint32_t mw = lc_max_w_for_batch(b);
-  const PreLayout narrow = lc_pre_layout(PB_NCAP, PB_QVCAP, 1u, mw), wide = lc_pre_layout(PB_NCAP_WIDE, PB_QVCAP_WIDE, LC_NWMAX, mw);
+  const PreLayout narrow = lc_pre_layout(PB_NCAP, PB_QVCAP, 1u, mw, lr ? PB_LRCAP : 0u), wide = lc_pre_layout(PB_NCAP_WIDE, PB_QVCAP_WIDE, LC_NWMAX, mw, lr ? PB_LRCAP_WIDE : 0u);
   if (force == 0 || b->n_windows <= 0) return narrow;
   if (force == 1) return wide;
   const uint32_t R = b->read_begin[b->n_windows];
@@ -150,6 +151,7 @@ static inline size_t lc_work_carve(Work *w, char *base, const EngineCaps &c) {
   t.khp = k.take<uint16_t>(c.lr_mode ? nodes * 6 : 1);
   t.refhp = k.take<uint16_t>(c.lr_mode ? MW * 6 : 1);
   t.bxbuf = k.take<uint32_t>(c.lr_mode ? c.reads_cap : 1);
+  t.lr_refnode = k.take<uint32_t>(c.lr_mode ? MW : 1);
   t.seq = k.take<uint32_t>(c.seq_cap);
   t.ht_next = k.take<uint32_t>(nodes);
   t.ht_bucket = k.take<uint32_t>(c.bucket_cap);

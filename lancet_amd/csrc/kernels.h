@@ -78,8 +78,9 @@ struct WinShared {
 #endif
   uint32_t g_n[LC_PACK], g_lo[LC_PACK], g_cnt[LC_PACK], g_es[LC_PACK], g_min[LC_PACK], g_N;   // the candidates of the current group
   uint32_t g_fl[LC_PACK]; float g_tt[LC_PACK], g_tn[LC_PACK];      // their flags and tumor / normal coverage (fetched while the occurrences are staged)
+  uint32_t g_row[LC_PACK];                                         // build_qcounts in rows-only mode: the quality row of each candidate of the group
   union {
-    struct { uint32_t cq_n[64], cq_lo[64], cq_cnt[64]; };          // the next 64 candidates (node, csr start, occurrences), fetched together
+    struct { uint32_t cq_n[64], cq_lo[64], cq_cnt[64], cq_row[64]; };   // the next 64 candidates (node, csr start, occurrences; rows-only mode: the row to write), fetched together
     uint16_t acc[128][10];                       // a candidate with more occurrences than the staging area, between its rounds: per k-mer
                                                  // position running counts Tf Tr Nf Nr (+ lr_mode: T hp0-2, N hp0-2 minqv); the candidate list is re-fetched after it
   };
@@ -1865,10 +1866,14 @@ DEVNI void build_gather(Ctx &c) {
   XG_FOR(n, S.N) { if (W.order[n + 1] != W.order[n]) { const uint32_t at = W.order[n]; W.pnodes[at] = (uint32_t)n; W.pedges[at] = W.nocc[n]; W.ht_bucket[at] = W.nocc[n + 1] - W.nocc[n]; } }
   WG_SYNC();
 }
-DEVNI void build_qcounts(Ctx &c) {
+// rows_n > 0 ("rows only", kernels.h load_prebuilt_lr): the list holds rows_n nodes whose fate is known -- the survivors of a graph the LDS
+// build kernel made, in --linked-reads mode -- and W.ht_start[x] names the quality row of entry x; only the rows are written (all ten
+// counters), no predicate, no record, no descriptor.
+DEVNI void build_qcounts(Ctx &c, uint32_t rows_n = 0) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W; LC_GLOBAL const EngineCaps &C = *LC_CTX(c).C;
   const int K = S.K;
   (void)C; (void)K; (void)W;
+  const bool rows = rows_n != 0;
   const double avgcov = ((double)S.totalreadbp) / ((double)S.reflen);
   // ---- undecided nodes: number of counted reads whose base passes MIN_QUAL_CALL, per k-mer position and strand/sample
   //      (Node_t::updateCovDistr minqv_fwd/minqv_rev, reference src/Node.cc:470-497).  Up to LC_PACK consecutive
@@ -1876,7 +1881,7 @@ DEVNI void build_qcounts(Ctx &c) {
   //      in rounds): the dependent chain occurrence -> read info -> quality words is paid once per group.
   //      Step 1, lane = occurrence (two per lane, loads issued together): K quality bits + class of the occurrence -> LDS.
   //      Step 2, lane = (candidate, k-mer position): count over the candidate's staged occurrences out of LDS.
-  const uint32_t ncand = wg_bcastu(&S.part[LANCET_WG]);
+  const uint32_t ncand = rows ? rows_n : wg_bcastu(&S.part[LANCET_WG]);
   const int QS = S.QS; const bool LR = S.LR != 0;
   uint32_t ci = 0, cqb = 0;
   bool cq_valid = false;
@@ -1884,7 +1889,7 @@ DEVNI void build_qcounts(Ctx &c) {
     if (!cq_valid || ci + LC_PACK > cqb + 64) {  // candidate list a line at a time into LDS: group formation is a lane-0 chain
       WG_FOR(t, 64) {
         const uint32_t x = ci + (uint32_t)t;
-        if (x < ncand) { S.cq_n[t] = W.pnodes[x]; S.cq_lo[t] = W.pedges[x]; S.cq_cnt[t] = W.ht_bucket[x]; }
+        if (x < ncand) { S.cq_n[t] = W.pnodes[x]; S.cq_lo[t] = W.pedges[x]; S.cq_cnt[t] = W.ht_bucket[x]; S.cq_row[t] = rows ? W.ht_start[x] : 0u; }
       }
       WG_SYNC();
       cqb = ci; cq_valid = true;
@@ -1899,11 +1904,13 @@ DEVNI void build_qcounts(Ctx &c) {
         //  window was reported LANCET_W_OVERFLOW)
         if (gN > 0 && tot + cnt > LC_QSTAGE) break;
         S.g_n[gN] = n; S.g_lo[gN] = lo; S.g_cnt[gN] = cnt; S.g_es[gN] = tot; S.g_min[gN] = 0x7FFFFFFFu;
+        S.g_row[gN] = rows ? S.cq_row[q] : S.qv_top + gN;
+        if (rows && ((size_t)S.cq_row[q] + 1u) * (size_t)K > (size_t)LC_CTX(c).C->qv_cap) OVF(c);
         ++gN; tot += cnt;
         if (tot >= LC_QSTAGE) break;
       }
       S.g_N = gN;
-      if (S.qv_top + gN > LC_CTX(c).C->surv_cap || ((size_t)S.qv_top + gN) * (size_t)K > (size_t)LC_CTX(c).C->qv_cap) OVF(c);
+      if (!rows && (S.qv_top + gN > LC_CTX(c).C->surv_cap || ((size_t)S.qv_top + gN) * (size_t)K > (size_t)LC_CTX(c).C->qv_cap)) OVF(c);
     }
     if (wg_bcast(&S.overflow)) return;
     const int gN = wg_uniform((int)S.g_N);
@@ -2007,7 +2014,7 @@ DEVNI void build_qcounts(Ctx &c) {
           XG_FOR(t, T) {
             const int k = big ? 0 : t / K, i = big ? t : t - k * K;
             const uint32_t a0 = S.pacc[10 * t], a1 = S.pacc[10 * t + 1], a2 = S.pacc[10 * t + 2], a3 = S.pacc[10 * t + 3];
-            LC_GLOBAL uint16_t *qq = W.qv + (size_t)(qi0 + (uint32_t)k) * K * QS;
+            LC_GLOBAL uint16_t *qq = W.qv + (size_t)S.g_row[k] * K * QS;
             qq[QS * i] = (uint16_t)a0; qq[QS * i + 1] = (uint16_t)a1; qq[QS * i + 2] = (uint16_t)a2; qq[QS * i + 3] = (uint16_t)a3;
             if (LR) { uint16_t *qh = qq + QS * i + 4; for (int q = 0; q < 6; ++q) qh[q] = (uint16_t)S.pacc[10 * t + 4 + q]; }
             const int sq = (int)(uint16_t)a0 + (int)(uint16_t)a1 + (int)(uint16_t)a2 + (int)(uint16_t)a3;
@@ -2062,7 +2069,7 @@ DEVNI void build_qcounts(Ctx &c) {
           S.acc[i][0] = (uint16_t)a0; S.acc[i][1] = (uint16_t)a1; S.acc[i][2] = (uint16_t)a2; S.acc[i][3] = (uint16_t)a3;
           if (LR) { S.acc[i][4] = (uint16_t)h0; S.acc[i][5] = (uint16_t)h1; S.acc[i][6] = (uint16_t)h2; S.acc[i][7] = (uint16_t)h3; S.acc[i][8] = (uint16_t)h4; S.acc[i][9] = (uint16_t)h5; }
         } else {
-          LC_GLOBAL uint16_t *qq = W.qv + (size_t)(qi0 + (uint32_t)k) * K * QS;
+          LC_GLOBAL uint16_t *qq = W.qv + (size_t)S.g_row[k] * K * QS;
           qq[QS * i] = (uint16_t)a0; qq[QS * i + 1] = (uint16_t)a1; qq[QS * i + 2] = (uint16_t)a2; qq[QS * i + 3] = (uint16_t)a3;
           if (LR) { uint16_t *qh = qq + QS * i + 4; qh[0] = (uint16_t)h0; qh[1] = (uint16_t)h1; qh[2] = (uint16_t)h2; qh[3] = (uint16_t)h3; qh[4] = (uint16_t)h4; qh[5] = (uint16_t)h5; }
           const int sq = (int)(uint16_t)a0 + (int)(uint16_t)a1 + (int)(uint16_t)a2 + (int)(uint16_t)a3;
@@ -2071,6 +2078,7 @@ DEVNI void build_qcounts(Ctx &c) {
       }
       WG_SYNC();
     }
+    if (rows) { ci += (uint32_t)gN; if (big) cq_valid = false; continue; }
     // ---- the first removeLowCov predicate per candidate; survivors keep their counts (slot qi0 + k; a non-survivor
     //      leaves its slot unused) and start their sequence-descriptor deque
     WG_FOR(t, gN * K) {
@@ -2107,7 +2115,7 @@ DEVNI void build_qcounts(Ctx &c) {
     ci += (uint32_t)gN;
     if (big) cq_valid = false;                   // its running counts lived where the candidate list does
   }
-  WG_LANE0 { S.seq_top = S.qv_top * (uint32_t)K; }
+  if (!rows) WG_LANE0 { S.seq_top = S.qv_top * (uint32_t)K; }
   WG_SYNC();
 }
 DEVNI void build_refcov(Ctx &c) {
@@ -4088,8 +4096,11 @@ DEVNI void emit_variant_lr(Ctx &c, uint32_t vi, const TS &t, const uint16_t hp12
     if (q < 2) {                           // k-mers of Ref_t::seq at [ref_pos-1, ref_end_pos-1] that are in the reference's mer table
       for (int i = (int)t.ref_pos - 1; i <= (int)t.ref_end_pos - 1; ++i) {
         if (i < 0 || i + K > S.seq_len) continue;            // shorter substr: not a key of the table
-        const uint32_t X = W.occ[ro + (uint32_t)(S.seq_t5 + i)] & 0x3FFFFFFFu;
-        if (W.gr[X].flags & NF_INMER) bx_add_node(c, X, nml, &n);
+        // (a graph from the LDS build kernel: W.occ names a stand-in for a k-mer whose node did not survive, but Ref_t's barcode table
+        //  holds the reads of every k-mer of its mer table -- the node and the membership bit come from lr_refnode, load_prebuilt_lr)
+        const uint32_t rv = S.prebuilt ? W.lr_refnode[S.seq_t5 + i] : 0u;
+        const uint32_t X = S.prebuilt ? (rv & 0x3FFFFFFFu) : (W.occ[ro + (uint32_t)(S.seq_t5 + i)] & 0x3FFFFFFFu);
+        if (S.prebuilt ? (rv >> 31) != 0u : (W.gr[X].flags & NF_INMER) != 0u) bx_add_node(c, X, nml, &n);
       }
     } else {                               // k-mers of the path string at [start_pos-2, end_pos-1]
       for (int i = (int)t.start_pos - 2; i <= (int)t.end_pos - 1; ++i) {
@@ -4704,6 +4715,120 @@ DEVNI void count_ref_path(Ctx &c) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// --linked-reads, a graph from the LDS build kernel.  What a node carries in this mode beyond the ordinary counts -- barcode counts per
+// strand and sample in place of read counts (cov_distr), haplotype counts, the per-position hpX_minqv counters, Ref_t's coverage
+// tables from the barcode counts, the barcode sets of a variant -- is the result of a replay over the node's occurrences in visiting order
+// (Node_t::hasBX / addBX / addHP, reference src/Graph.cc:239-317, src/Node.cc:30-118, 502-520; src/Ref.cc:75-170).  The build kernel
+// handed the occurrences of every tracked node over as csr runs (layout.h PRE_OFF_LRNOCC / PRE_OFF_LRCSR); load_prebuilt has loaded
+// the graph.  Here, for the survivors and for the nodes of reference k-mers:
+//   1. per-read words, the runs (copied: the replay sorts them and sets the "grown" bits),
+//   2. the node of every reference offset with its mer-table bit (emit_variant_lr: Ref_t::getBXsetAt asks nodes that did not survive too),
+//   3. the replay (lr_node_replay / lr_replay_batches, as build_gather runs them) -> kc[], mincov, khp[],
+//   4. the survivors' quality rows with all ten counters (build_qcounts, rows only) -- W.qv is the slot's own array, stride 10,
+//   5. Ref_t::computeCoverage from the barcode counts (build_refcov's rule; the window's first graph: every k-mer of rawseq but the last is in the table),
+//   6. the open-addressing table of the survivors' k-mers for Graph_t::getBXsetAt (kmer_lookup; every k-mer of a path string is a live node).
+// ---------------------------------------------------------------------------------------------------------
+DEVNI void load_prebuilt_lr(Ctx &c, LC_GLOBAL const uint8_t *area) {
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  LC_GLOBAL const PreLayout &PL = LC_PL(c);
+  LC_GLOBAL const PreHdr *H = (LC_GLOBAL const PreHdr *)(area + PRE_OFF_HDR);
+  const uint32_t N = H->N, ncand = H->ncand, nsurv = H->nsurv, total = H->lr_total;
+  const int K = S.K, NW = S.NW, reflen = S.reflen;
+  LC_GLOBAL const uint32_t *lrnocc = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_LRNOCC), *lrcsr = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_LRCSR);
+  LC_GLOBAL const uint32_t *occ_ref = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_OCCREF);
+  LC_GLOBAL const uint32_t *snode = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_SNODE), *sid = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_SID);
+  LC_GLOBAL const unsigned long long *skey = (LC_GLOBAL const unsigned long long *)(area + PRE_OFF_SKEY);
+  LC_GLOBAL const uint8_t *surv = (LC_GLOBAL const uint8_t *)(area + PRE_OFF_SURV);
+  const int nrefk = reflen - K > 0 ? reflen - K + 1 : 0;
+  // ---- 1
+  WG_LANE0 { W.qv = W.qv_own; }
+  WG_FOR(r, S.R) {
+    uint32_t rinfo, bw, gw; int tlen; bool isref;
+    read_geom(c, r, &rinfo, &bw, &gw, &tlen, &isref);
+    W.rd[4 * r] = rinfo; W.rd[4 * r + 1] = bw; W.rd[4 * r + 2] = gw; W.rd[4 * r + 3] = 0;
+  }
+  WG_FOR(n, N + 1) { W.nocc[n] = lrnocc[n]; }
+  WG_FOR(i, total) { const uint32_t v = lrcsr[i]; W_CSR(W)[i] = CS_MAKE(v & 0xFFFFu, (v >> 16) & 0x3FFu, (v >> 26) & 1u, (v >> 27) & 3u); }
+  // ---- 2
+  WG_FOR(i, (N + 31u) / 32u) { W.bitmap[i] = 0; W.bitpre[i] = 0; }
+  WG_SYNC();
+  WG_FOR(i, nrefk) {
+    const uint32_t n = occ_ref[i] & 0x3FFFFFFFu & ~PB_GONE;
+    dev_atomic_or(&W.bitmap[n >> 5], 1u << (n & 31u));
+    if (i < reflen - K) dev_atomic_or(&W.bitpre[n >> 5], 1u << (n & 31u));              // i + K < rawseq.length(): in Ref_t::mertable (src/Ref.cc:40-64)
+  }
+  WG_LANE0 { S.tmp2 = 0; }
+  WG_SYNC();
+  WG_FOR(i, nrefk) {
+    const uint32_t n = occ_ref[i] & 0x3FFFFFFFu & ~PB_GONE;
+    W.lr_refnode[i] = n | (((ld2(&W.bitpre[n >> 5]) >> (n & 31u)) & 1u) << 31);
+  }
+  // ---- 3
+  WG_FOR(n, N) {
+    const bool onr = ((ld2(&W.bitmap[(uint32_t)n >> 5]) >> ((uint32_t)n & 31u)) & 1u) != 0;
+    if (!surv[n] && !onr) continue;
+    const uint32_t lo = lrnocc[n], hi = lrnocc[n + 1];
+    if (hi - lo >= LR_COOP_MIN && hi - lo <= LR_COOP_MAX && lo < (1u << 24)) {        // by the whole wave, below: listed
+      const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.tmp2, 1u);
+      W.scratch[2 * (size_t)at] = (uint32_t)n; W.scratch[2 * (size_t)at + 1] = lo | ((hi - lo) << 24);
+    } else {
+      uint32_t lrv[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (hi > lo) lr_node_replay(c, lo, hi, lrv);                                      // (no run: the reference pseudo-read is the node's only occurrence)
+      LC_GLOBAL NodeGr &G = W.gr[n];
+      for (int q = 0; q < 4; ++q) G.kc[q] = (uint16_t)lrv[q];
+      for (int q = 0; q < 6; ++q) W.khp[6 * (size_t)n + q] = (uint16_t)lrv[4 + q];
+      G.mincov = (int)(uint16_t)lrv[0] + (int)(uint16_t)lrv[1] + (int)(uint16_t)lrv[2] + (int)(uint16_t)lrv[3];
+    }
+  }
+  WG_SYNC();
+  lr_replay_batches(c, (uint32_t)wg_bcast(&S.tmp2));
+  // ---- 4
+  WG_FOR(si, nsurv) {
+    const uint32_t n = sid[si];
+    W.pnodes[si] = n; W.pedges[si] = lrnocc[n]; W.ht_bucket[si] = lrnocc[n + 1] - lrnocc[n]; W.ht_start[si] = W.gr[n].nqv;
+  }
+  WG_SYNC();
+  if (nsurv) build_qcounts(c, nsurv);
+  if (wg_bcast(&S.overflow)) return;
+  // ---- 5
+  WG_FOR(j, reflen) { for (int q = 0; q < 4; ++q) W.refcov[4 * j + q] = 0; for (int q = 0; q < 6; ++q) W.refhp[6 * j + q] = 0; }
+  WG_SYNC();
+  WG_FOR(i, reflen - K > 0 ? reflen - K : 0) {
+    const uint32_t X = W.lr_refnode[i] & 0x3FFFFFFFu;
+    uint16_t v[4], h[6];
+    for (int q = 0; q < 4; ++q) v[q] = W.gr[X].kc[q];
+    for (int q = 0; q < 6; ++q) h[q] = W.khp[6 * (size_t)X + q];
+    if (i == 0) { for (int j = 0; j < K; ++j) { for (int q = 0; q < 4; ++q) W.refcov[4 * j + q] = v[q]; for (int q = 0; q < 6; ++q) W.refhp[6 * j + q] = h[q]; } }
+    else { for (int q = 0; q < 4; ++q) W.refcov[4 * (i + K - 1) + q] = v[q]; for (int q = 0; q < 6; ++q) W.refhp[6 * (i + K - 1) + q] = h[q]; }
+  }
+  // ---- 6
+  WG_LANE0 { uint32_t tcap = 1024; while (tcap < 2u * nsurv + 2u && tcap < LC_CTX(c).C->table_cap) tcap <<= 1; S.tmask = tcap - 1u; S.tfull = 0; }
+  const uint32_t mask = wg_bcastu(&S.tmask);
+  WG_FOR(i, mask + 1u) { lc_u4 z; z.x = 0; z.y = 0; z.z = LC_NIL; z.w = 0; *(lc_u4 *)(W.slots + 4 * (size_t)i) = z; }
+  WG_SYNC_FENCE();
+  WG_FOR(ci, ncand) {
+    const uint32_t n = snode[ci];
+    if (n == LC_NIL) continue;
+    unsigned long long ck[LC_NWMAX];
+    for (int w = 0; w < LC_NWMAX; ++w) ck[w] = w < NW ? skey[(size_t)ci * PL.kw + (uint32_t)w] : 0ULL;
+    unsigned long long h = 0; uint32_t idx;
+    if (NW == 1 && K <= 31) { h = ck[0] + 1ULL; idx = (uint32_t)mix64(h) & mask; }      // (kmer_lookup's hashing)
+    else {
+      for (int w = 0; w < NW; ++w) h = mix64(h ^ (ck[w] + 0x9e3779b97f4a7c15ULL * (unsigned long long)(w + 1)));
+      h &= ~(1ULL << 63);
+      if (h == 0) h = 1;
+      idx = (uint32_t)h & mask;
+    }
+    for (uint32_t probes = 0; probes <= mask; ++probes) {
+      const unsigned long long old = dev_atomic_cas64(&SL_TAG(W, idx), 0ULL, h);
+      if (old == 0ULL) { SL_NODE(W, idx) = n; if (!(NW == 1 && K <= 31)) for (int w = 0; w < NW; ++w) W.slot_key[(size_t)idx * LC_NWMAX + w] = ck[w]; break; }
+      idx = (idx + 1) & mask;                                      // (an equal 64-bit tag of another long k-mer: the next slot, as the look-up probes on)
+    }
+  }
+  WG_SYNC_FENCE();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // The window's first graph as the LDS build kernel left it (build_lds.h, layout.h PreHdr ...): the slot's arrays are
 // brought to the state build_graph() leaves them in, as far as the graph phases read them -- std::hash of every node,
 // survivor flags, the survivors' records / per-position counts / sequence descriptors, the reference pseudo-read's
@@ -4722,7 +4847,9 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
     H = (LC_GLOBAL const PreHdr *)(area + PRE_OFF_HDR);
   }
   WG_LANE0 { S.tmp1 = (H->status == PB_BUILT && H->K == k && H->N <= LC_CTX(c).C->node_cap && (size_t)H->ncand * (size_t)k <= (size_t)LC_CTX(c).C->qv_cap &&
-                       H->ncand <= LC_CTX(c).C->surv_cap && (size_t)H->ncand * (size_t)k <= (size_t)LC_CTX(c).C->seq_cap) ? 1 : 0; }
+                       H->ncand <= LC_CTX(c).C->surv_cap && (size_t)H->ncand * (size_t)k <= (size_t)LC_CTX(c).C->seq_cap) ? 1 : 0;
+             // --linked-reads: only with the tracked nodes' occurrences handed over, only the window's first graph (Ref_t::seq untrimmed), and room for the runs
+             if (S.LR && !(H->lr == 1u && H->have_order == 1u && S.seq_t5 == 0 && S.seq_len == S.reflen && H->lr_total <= LC_CTX(c).C->occ_cap)) S.tmp1 = 0; }
   if (!wg_bcast(&S.tmp1)) return false;
   const uint32_t N = H->N, ncand = H->ncand, nsurv = H->nsurv;
   const int K = k;
@@ -4858,6 +4985,7 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
     }
   }
   WG_SYNC();
+  if (wg_uniform(S.LR)) load_prebuilt_lr(c, area);
   return true;
 }
 

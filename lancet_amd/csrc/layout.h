@@ -102,6 +102,7 @@ typedef uint32_t mv_t;
 struct PreLayout {
   uint32_t ncap, qvcap, kw, maxw;
   uint32_t refcov, nhash, surv, snode, skey, sid, pgr, order, qv, chdr, clive, cseq;
+  uint32_t lrnocc, lrcsr, lrcap;   /* --linked-reads only (else 0): csr offsets by node id, the csr entries of the tracked nodes, room for them */
   uint32_t stride;
 };
 struct EngineCaps {
@@ -196,6 +197,8 @@ struct CmpRec {
 #define PB_SCAP 2048          /* survivors of the first removeLowCov                                          */
 #define PB_QVCAP 32768        /* (candidate, k-mer position) entries of per-position quality counts, narrow hand-off */
 #define PB_QVCAP_WIDE 196608  /* ... wide (2048 candidates at k = 96)                                           */
+#define PB_LRCAP 40960u       /* --linked-reads: csr entries a narrow hand-off holds (= the 512-lane build's bases in LDS) */
+#define PB_LRCAP_WIDE 126976u /* ... a wide one (the 1024-lane build's)                                           */
 #define PB_GONE 0x40000000u   /* occ_ref: the node of this reference k-mer did not survive the first removeLowCov (its id is still in the low bits) */
 #define PB_NOT_BUILT 0u
 #define PB_BUILT 1u
@@ -214,7 +217,10 @@ struct PreHdr {
   uint32_t next;              /* 1 + index of the pool area that holds this window's graph at the next k of its loop (built ahead
                                  because `heavy` says this k will be rejected, or on request of the window kernel), 0: none */
   uint32_t big;               /* built by the 1024-lane configuration (the build service runs the 512-lane one)   */
-  uint32_t pad[9];
+  uint32_t lr;                /* --linked-reads: the occurrences of the tracked nodes came along (PRE_OFF_LRNOCC / PRE_OFF_LRCSR): the window kernel replays
+                                 barcodes and haplotypes over them (kernels.h load_prebuilt_lr) instead of building the window in HBM    */
+  uint32_t lr_total;          /* ... csr entries                                                                    */
+  uint32_t pad[7];
 };
 /* The area's layout is fixed per engine upload, not per build: the front (header, reference arrays) is the same everywhere, the
  * arrays behind it are sized by three numbers the host picks for the batch (host_common.h lc_pre_layout) -- `ncap` distinct k-mers
@@ -235,6 +241,8 @@ struct PreHdr {
 #define PRE_OFF_CHDR (PL.chdr)                                /* PreCmp                                                 */
 #define PRE_OFF_CLIVE (PL.clive)                              /* u32[PB_CMAX + 2]  record index (survivor index, or nsurv + k for special k) per table position */
 #define PRE_OFF_CSEQ (PL.cseq)                                /* u32[PB_CSEQ]                                           */
+#define PRE_OFF_LRNOCC (PL.lrnocc)                            /* u32[ncap + 2]  --linked-reads: csr run of node n = [lrnocc[n], lrnocc[n+1]) (empty for a node with one occurrence) */
+#define PRE_OFF_LRCSR (PL.lrcsr)                              /* u32[lrcap]     ... the runs: cs_t words (read, position, orientation, state), unsorted inside a run */
 #define PRE_STRIDE (PL.stride)
 /* ---- first compress done by the build kernel (build_lds_impl.h bl_compress_first): single-component first graphs ----
  * markRefEnds + the first Graph_t::compress of the component in LDS; the window kernel then loads the ~20 unitigs instead of ~600
@@ -286,6 +294,8 @@ struct Work {
   LC_GLOBAL uint16_t *khp;          /* [nodes*6] lr_mode: last-written hp0 hp1 hp2 of the k-mer, tumor then normal */
   LC_GLOBAL uint16_t *refhp;        /* [max_w*6] lr_mode: the same per rawseq position (Ref_t coverage)  */
   LC_GLOBAL uint32_t *bxbuf;        /* [reads_cap] lr_mode: sorted distinct barcodes of the set being collected */
+  LC_GLOBAL uint32_t *lr_refnode;   /* [max_w] lr_mode, graph from the LDS build kernel: node of the reference k-mer at an offset (also when it did not survive),
+                                       bit 31 = the k-mer is in Ref_t::mertable (kernels.h load_prebuilt_lr, emit_variant_lr)          */
   LC_GLOBAL uint32_t *seq;          /* [seq_cap] descriptor arena                                        */
   /* ---- libstdc++ node-table order ---- */
   LC_GLOBAL uint32_t *ht_next;      /* [nodes]                                                           */

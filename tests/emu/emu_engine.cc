@@ -29,7 +29,7 @@ struct EmuResult {
 extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batch *b, uint32_t evt_cap) {
   EngineCaps C = getenv("LANCET_EMU_TIER1") ? lc_caps_for_batch(b, P, evt_cap, 16384, 1)      // (the engine's tier-1 work space: to see which limit a window hits there)
                                             : lc_caps_for_batch(b, P, evt_cap, 65536);
-  C.pl = lc_pre_layout_for_batch(b, 1, (size_t)1 << 40, getenv("LANCET_PRE_WIDE") ? atoi(getenv("LANCET_PRE_WIDE")) : -1);      // (engine.hip lc_upload)
+  C.pl = lc_pre_layout_for_batch(b, 1, (size_t)1 << 40, getenv("LANCET_PRE_WIDE") ? atoi(getenv("LANCET_PRE_WIDE")) : -1, P->lr_mode != 0);      // (engine.hip lc_upload)
   C.wide_ids = LC_WIDE_IDS;                        // (libemu_fat.so: the re-run tier's 64-bit csr words, as engine.hip lays its tier 2 out)
   if (const char *ts = getenv("LANCET_TABLE_START")) C.table_start = lc_pow2_ge((uint32_t)atoi(ts));
   if (const char *st = getenv("LANCET_STOP_PHASE")) C.debug_stop = (uint32_t)atoi(st);
@@ -70,12 +70,14 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   static thread_local bl_large::BlShared BSL;
   O.pre = nullptr; O.pre_pool = nullptr; O.n_ahead_used = &res->n_ahead_used;
   res->n_prebuilt = 0; res->n_ahead_built = 0; res->n_ahead_used = 0; res->n_biglist = 0;
-  if (!P->lr_mode && !getenv("LANCET_NO_PREBUILD") && b->n_windows > 0) {
+  const bool lr_pre = !(getenv("LANCET_LR_PREBUILD") && atoi(getenv("LANCET_LR_PREBUILD")) == 0);      // (engine.hip: --linked-reads windows through the build kernel unless switched off)
+  if ((!P->lr_mode || lr_pre) && !getenv("LANCET_NO_PREBUILD") && b->n_windows > 0) {
     pre.assign((size_t)b->n_windows * C.pl.stride, 0xCD); blscr.assign(bl_large::SCRATCH_BYTES + 256, 0xCD);
     memset(&BS, 0xCD, sizeof(BS)); memset(&BSL, 0xCD, sizeof(BSL));
     std::vector<uint32_t> biglist((size_t)b->n_windows + 1, 0);
     const bool large = getenv("LANCET_NO_LARGE_BUILD") == nullptr;
     depth = getenv("LANCET_AHEAD_DEPTH") ? atoi(getenv("LANCET_AHEAD_DEPTH")) : 6;
+    if (P->lr_mode) depth = 0;                                   // (engine.hip: no graphs built ahead, no service in --linked-reads mode)
     pool_cap = (uint32_t)(b->n_windows / 4 + (depth > 0 ? 8 : 0) + (getenv("LANCET_NO_SVC") ? 0 : (b->n_windows < 128 ? 4 * b->n_windows + 24 : 536)));
     if (pool_cap) pool.assign((size_t)pool_cap * C.pl.stride, 0xCD);
     if (getenv("LANCET_EMU_FORCE_LARGE")) {                     // (test hook: every window through the 1024-lane configuration)
@@ -105,7 +107,7 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   // ---- the build service (engine.hip svc_kernel): LANCET_NO_SVC=1 off, LANCET_SVC_DEAD=1 nobody serves (the slots take their requests back)
   SvcCtl sv; memset(&sv, 0, sizeof(sv));
   std::vector<SvcReq> sreq; std::vector<uint32_t> srdy; std::vector<SvcCont> scont;
-  if (O.pre && O.pre_pool && !getenv("LANCET_NO_SVC")) {
+  if (O.pre && O.pre_pool && !getenv("LANCET_NO_SVC") && !P->lr_mode) {
     sv.cap = (uint32_t)b->n_windows * 4u + 16u;
     sreq.assign(sv.cap, SvcReq{0, 0, SV_EMPTY, 0}); srdy.assign(sv.cap, 0u); scont.resize(sv.cap);
     sv.req = sreq.data(); sv.rdy = srdy.data(); sv.cont = scont.data();

@@ -203,6 +203,35 @@ def test_emulated_kernels_match_oracle_on_random_linked_read_windows(seed):
     assert gu.digest_trace(tr) == gu.digest_trace(otr)
 
 
+@pytest.mark.parametrize("route", ["small", "large", "fat"])
+def test_linked_read_windows_through_the_lds_build_and_the_replay_over_its_runs(route, monkeypatch):
+    """--linked-reads windows whose first graph comes from the LDS build kernel (build_lds_impl.h: the tracked nodes' occurrences are handed
+    over as csr runs; kernels.h load_prebuilt_lr replays barcodes / haplotypes over them, recounts the ten per-position counters of the
+    survivors, recomputes Ref_t's tables from the barcode counts and builds the table getBXsetAt looks k-mers up in) -- the windows of
+    bench.py's config 5, both build configurations and the re-run tier's source: records (haplotype counts, barcode sets), stats and the
+    whole stage trace equal the oracle's, and equal the general build of every window (LANCET_LR_PREBUILD=0, the route until round 5)."""
+    from lancet_amd import workload
+    b = workload.make_scan_batch(10, 30, 30, seed=5 if route != "large" else 6, linked=True, somatic_every=700, germline_every=400)
+    p = abi.default_params(lr_mode=1)
+    if route == "large":
+        monkeypatch.setenv("LANCET_EMU_FORCE_LARGE", "1")
+    emu.FAT[0] = route == "fat"
+    try:
+        v, st, tr = emu.run(b, p, evt_cap=1 << 18)
+        built = emu.LAST_PREBUILT[0]
+        ov, ost, otr = oracle.run(b, p, verbose=True)
+        assert built == b.n_windows and len(ov) > 3 and v == ov
+        assert any(any(len(x) for x in r["bx"]) for r in ov) and any(any(r["hp"]) for r in ov)
+        key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
+        assert [key(s) for s in st] == [key(s) for s in ost]
+        assert gu.digest_trace(tr) == gu.digest_trace(otr)
+        monkeypatch.setenv("LANCET_LR_PREBUILD", "0")
+        v2, st2, tr2 = emu.run(b, p, evt_cap=1 << 18)
+        assert emu.LAST_PREBUILT[0] == 0 and v2 == ov and gu.digest_trace(tr2) == gu.digest_trace(otr)
+    finally:
+        emu.FAT[0] = False
+
+
 @pytest.mark.parametrize("name", ["dups", "nref"])
 def test_table_doubling_path_gives_the_same_graphs(name, monkeypatch):
     """Each build sizes its k-mer table from an estimate and doubles it when it fills up; started at 64 slots, every
