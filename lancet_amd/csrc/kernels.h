@@ -4740,6 +4740,7 @@ DEVNI void load_prebuilt_lr(Ctx &c, LC_GLOBAL const uint8_t *area) {
   LC_GLOBAL const unsigned long long *skey = (LC_GLOBAL const unsigned long long *)(area + PRE_OFF_SKEY);
   LC_GLOBAL const uint8_t *surv = (LC_GLOBAL const uint8_t *)(area + PRE_OFF_SURV);
   const int nrefk = reflen - K > 0 ? reflen - K + 1 : 0;
+  PHASE(c, 2);
   // ---- 1
   WG_LANE0 { W.qv = W.qv_own; }
   WG_FOR(r, S.R) {
@@ -4763,6 +4764,7 @@ DEVNI void load_prebuilt_lr(Ctx &c, LC_GLOBAL const uint8_t *area) {
     const uint32_t n = occ_ref[i] & 0x3FFFFFFFu & ~PB_GONE;
     W.lr_refnode[i] = n | (((ld2(&W.bitpre[n >> 5]) >> (n & 31u)) & 1u) << 31);
   }
+  PHASE(c, 4);
   // ---- 3
   WG_FOR(n, N) {
     const bool onr = ((ld2(&W.bitmap[(uint32_t)n >> 5]) >> ((uint32_t)n & 31u)) & 1u) != 0;
@@ -4781,7 +4783,9 @@ DEVNI void load_prebuilt_lr(Ctx &c, LC_GLOBAL const uint8_t *area) {
     }
   }
   WG_SYNC();
+  PHASE(c, 5);
   lr_replay_batches(c, (uint32_t)wg_bcast(&S.tmp2));
+  PHASE(c, 6);
   // ---- 4
   WG_FOR(si, nsurv) {
     const uint32_t n = sid[si];
@@ -4790,6 +4794,7 @@ DEVNI void load_prebuilt_lr(Ctx &c, LC_GLOBAL const uint8_t *area) {
   WG_SYNC();
   if (nsurv) build_qcounts(c, nsurv);
   if (wg_bcast(&S.overflow)) return;
+  PHASE(c, 3);
   // ---- 5
   WG_FOR(j, reflen) { for (int q = 0; q < 4; ++q) W.refcov[4 * j + q] = 0; for (int q = 0; q < 6; ++q) W.refhp[6 * j + q] = 0; }
   WG_SYNC();
