@@ -219,6 +219,7 @@ def bam_e2e(d: str, region_args, gen_args, what: str, extra=("--devices", "0,0",
         return None
     res = None; walls = []; md5s = set()
     for _ in range(3):
+        time.sleep(5)          # (a process that allocates tens of GB right after another one released as much waits seconds in hipMalloc for the driver's wipe)
         try:
             r = subprocess.run([exe, "--tumor", need[0], "--normal", need[1], "--ref", need[2]] + [a.replace("{d}", d) for a in region_args] + ["--active-region-off"] + list(extra),
                                capture_output=True, text=True, timeout=300, env=dict(os.environ, LANCET_HOST_TIMING="1"))

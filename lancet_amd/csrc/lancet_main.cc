@@ -156,13 +156,17 @@ int main(int argc, char **argv) {
   else { size_t p0 = 0; while (p0 <= devices.size()) { size_t q = devices.find(',', p0); if (q == std::string::npos) q = devices.size(); if (q > p0) devs.push_back(atoi(devices.substr(p0, q - p0).c_str())); p0 = q + 1; } }
   if (devs.empty()) return die("--devices is empty");
   if (ranks > 0) { const int d = devs[(size_t)rank % devs.size()]; devs.assign(1, d); }     // one GPU per rank
-  // the communicator first: a rank that cannot join must not leave the others waiting at the gather
+  // The communicator comes up on a thread of its own while this one decodes, tiles and assembles (loading librccl and ncclCommInitRank take
+  // about a second and a half, and nothing needs the communicator before the gather at the end); a rank that cannot join reports it there --
+  // the others then fail in ncclCommInitRank or time out at the rendezvous.
+  const bool ranked = ranks > 0;
   lancet_comm *comm = nullptr;
-  if (ranks > 0) {
-    char cerr[512] = "";
-    comm = lancet_comm_create(rank, ranks, devs[0], rendezvous.c_str(), 300.0, cerr, sizeof cerr);
-    if (!comm) return die(std::string("rank ") + std::to_string(rank) + ": cannot join the communicator: " + cerr);
+  char cerr[512] = "";
+  std::future<lancet_comm *> comm_fut;
+  if (ranked) {
     if (ranks > 1 && !getenv("LANCET_HOST_LAZY")) setenv("LANCET_HOST_LAZY", "1", 0);     // a rank loads what ITS windows select, once (lancet_host_load_range; needs both .bai, else a notice and everything is loaded)
+    const int cdev = devs[0];                                                                // (the environment is settled before the thread starts: it reads it)
+    comm_fut = std::async(std::launch::async, [=, &cerr]() { return lancet_comm_create(rank, ranks, cdev, rendezvous.c_str(), 300.0, cerr, sizeof cerr); });
   }
   std::vector<lancet_engine *> engs;
   for (int d : devs) {
@@ -226,7 +230,7 @@ int main(int argc, char **argv) {
     }
     Job &j = jobs[(size_t)sl.chunk];
     j.v.assign(v, v + nv); j.blob.assign(blob, blen);
-    if (comm) j.widx.assign(sl.kept.begin(), sl.kept.begin() + sl.nk);
+    if (ranked) j.widx.assign(sl.kept.begin(), sl.kept.begin() + sl.nk);
     if (ho.linked) {
       const lancet_variant_lr *lr; const uint32_t *bxb; uint32_t bxl;
       if (lancet_engine_results_lr(sl.e, &lr, &bxb, &bxl) != LANCET_OK) { fail = std::string("engine: ") + lancet_engine_last_error(sl.e); return false; }
@@ -251,7 +255,7 @@ int main(int argc, char **argv) {
       Job &j = jobs[(size_t)next_add];
       if (!j.trace.empty()) fputs(j.trace.c_str(), stderr);
       int arc = LANCET_OK;
-      if (comm) {                                    // the records travel: keyed, reduced, window numbers of the whole tiling
+      if (ranked) {                                  // the records travel: keyed, reduced, window numbers of the whole tiling
         if (!j.v.empty()) {
           std::vector<const char *> names; for (auto &n : j.bxn) names.push_back(n.c_str());
           uint8_t *pb = nullptr; size_t pl = 0;
@@ -279,11 +283,11 @@ int main(int argc, char **argv) {
   const bool packed = getenv("LANCET_GPU_ASCII") == nullptr && !(getenv("LANCET_PREP") && strcmp(getenv("LANCET_PREP"), "device") == 0);
   // --ranks: rank r owns one contiguous run of batches -- in the table's order (header strings) that is a run of contigs, whose alignments
   // the rank loads once; the records then reach rank 0 in window order, rank by rank
-  const int c_lo = comm ? (int)((long)nchunks * rank / ranks) : 0, c_hi = comm ? (int)((long)nchunks * (rank + 1) / ranks) : nchunks;
-  if (comm && c_hi > c_lo && lancet_host_load_range(H, c_lo * step, c_hi * step < nwin ? c_hi * step : nwin, &ho) != LANCET_OK) return die(lancet_host_last_error(H));
+  const int c_lo = ranked ? (int)((long)nchunks * rank / ranks) : 0, c_hi = ranked ? (int)((long)nchunks * (rank + 1) / ranks) : nchunks;
+  if (ranked && c_hi > c_lo && lancet_host_load_range(H, c_lo * step, c_hi * step < nwin ? c_hi * step : nwin, &ho) != LANCET_OK) return die(lancet_host_last_error(H));
   for (int c = 0; c < nchunks; ++c) {
     const int lo = c * step, hi = lo + step < nwin ? lo + step : nwin;
-    if (comm && (c < c_lo || c >= c_hi)) { jobs[(size_t)c].have = true; if (!flush()) return die(fail); continue; }      // another rank's batch
+    if (ranked && (c < c_lo || c >= c_hi)) { jobs[(size_t)c].have = true; if (!flush()) return die(fail); continue; }      // another rank's batch
     Slot &sl = slots[(size_t)c % slots.size()];
     lancet_window_batch B; lancet_packed_reads PK; int32_t nk = 0;
     memset(&PK, 0, sizeof(PK));
@@ -314,7 +318,9 @@ int main(int argc, char **argv) {
   for (Slot &sl : slots) if (sl.fut.valid() && !finish(sl)) return die(fail);
   if (!flush()) return die(fail);
   double t_gather = 0;
-  if (comm) {
+  if (ranked) {
+    comm = comm_fut.get();
+    if (!comm) return die(std::string("rank ") + std::to_string(rank) + ": cannot join the communicator: " + cerr);
     // one payload per rank: u64 number of parts, their lengths, the parts; rank 0 replays every rank's parts into the database
     const double tg0 = now();
     std::vector<uint8_t> payload(8 * (1 + parts.size()));
