@@ -628,12 +628,17 @@ def main():
             if bam:
                 out["value_bam_e2e"] = bam.pop("value")       # BAM -> VCF by the native program, a whole process: never `value`
                 out["value_bam_e2e_detail"] = bam
-            # BASELINE config 3 as a one-GPU proxy: 24 contigs through --bed, the N-process route (lancet_gpu --ranks 1: pack, RCCL gather, merge on rank 0)
-            c3 = bam_e2e(os.path.join(ROOT, "build", "scan24x100k"), ["--bed", "{d}/regions.bed"], [100000, 30, 30, 14, 24], "24 contigs x 100 kb, 30x/30x, 2x150 bp",
-                         extra=("--ranks", "1", "--batch-windows", "8192"))
+            # BASELINE config 3 as a one-GPU proxy: 24 contigs through --bed -- two engines on the GPU, and the N-process route with one rank
+            # (lancet_gpu --ranks 1: pack, RCCL gather, merge on rank 0; bringing the communicator up is a second and a half of every such run)
+            d3 = os.path.join(ROOT, "build", "scan24x100k")
+            c3 = bam_e2e(d3, ["--bed", "{d}/regions.bed"], [100000, 30, 30, 14, 24], "24 contigs x 100 kb, 30x/30x, 2x150 bp")
             if c3:
-                c3["name"] = "config 3 proxy on one GPU: 24 contigs, --bed, lancet_gpu --ranks 1 (records packed, gathered over RCCL, replayed on rank 0); the 24 x 1 Mb run, engines / ranks / oracle parity: profiles/r6_config3_proxy.txt"
+                c3["name"] = "config 3 proxy on one GPU: 24 contigs (23 544 windows), lancet_gpu --bed; the 24 x 1 Mb run (239 664 windows; engines / batch sizes / ranks / every record against the oracle): profiles/r6_config3_proxy.txt"
                 c3["windows_per_s"] = c3.pop("value")
+                r1 = bam_e2e(d3, ["--bed", "{d}/regions.bed"], [100000, 30, 30, 14, 24], "24 contigs x 100 kb", extra=("--ranks", "1", "--batch-windows", "8192"))
+                if r1:
+                    c3["n_process_route_one_rank"] = {"windows_per_s": r1["value"], "wall_s_all_runs": r1["wall_s_all_runs"], "vcf_md5_equal": r1["vcf_md5"] == c3["vcf_md5"],
+                                                      "what": "the same input through lancet_gpu --ranks 1: records packed (keys + reduction), gathered over RCCL, replayed on rank 0"}
                 out["config3_proxy"] = c3
         if world == 1 and not args.no_configs:
             out["configs"] = ([out.pop("config3_proxy")] if "config3_proxy" in out else []) + [
