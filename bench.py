@@ -593,12 +593,12 @@ def main():
             out["windows_per_rank"] = n_local
             if one_gpu:
                 out["config"]["comm"] = "LANCET_BENCH_ONE_GPU=1: all ranks on device 0, gather over gloo -- a check of the N-rank path, not a measurement"
-        # HBM-side bytes per launch from the committed PMC passes (tools/pmc_total.sh -> profiles/r5_traffic.json): rocprofv3 cannot run
+        # HBM-side bytes per launch from the committed PMC passes (tools/pmc_total.sh -> profiles/r6_traffic.json): rocprofv3 cannot run
         # inside this process, so the figure is looked up for the exact workload it was taken on -- and only when it was taken on THESE
         # kernels (sha1 over lancet_amd/csrc/*.h, *.hip, recorded with the passes): a record of other kernels is not quoted.
         try:
             fp = workload.kernel_fingerprint()
-            for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json"):
+            for name in ("r6_traffic.json", "r5_traffic.json", "r4_traffic.json", "r3_traffic.json"):
                 tj = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tj):
                     break
@@ -608,7 +608,7 @@ def main():
                             and rec.get("str_fraction", 0.0) == args.str_fraction and bool(rec.get("linked", False)) == bool(args.linked) and world == 1:
                         if rec.get("kernel_fingerprint") != fp:
                             out["roofline"]["traffic_note"] = (f"profiles/{name} holds PMC passes for this workload, but taken on other kernels (fingerprint "
-                                                               f"{rec.get('kernel_fingerprint')}, these are {fp}): not quoted; re-run tools/profile_round5.sh")
+                                                               f"{rec.get('kernel_fingerprint')}, these are {fp}): not quoted; re-run tools/profile_round6.sh")
                             break
                         out["roofline"]["traffic"] = int((rec["FETCH_SIZE_KB"] / rec.get("fetch_calibration", 1.0) + rec["WRITE_SIZE_KB"]) * 1024)
                         out["roofline"]["traffic_fetch_write"] = [int(rec["FETCH_SIZE_KB"] * 1024), int(rec["WRITE_SIZE_KB"] * 1024)]
