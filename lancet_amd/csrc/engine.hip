@@ -330,7 +330,7 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   lancet_engine *e = new lancet_engine();
   e->params = *p; e->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete e; return LANCET_E_HIP; }
-  if (getenv("LANCET_NO_SVC") || p->lr_mode || getenv("LANCET_NO_PREBUILD")) e->svc = false;
+  if (getenv("LANCET_NO_SVC") || getenv("LANCET_NO_PREBUILD") || (p->lr_mode && getenv("LANCET_LR_PREBUILD") && atoi(getenv("LANCET_LR_PREBUILD")) == 0)) e->svc = false;
   if (const char *s = getenv("LANCET_SVC_CUS")) e->svc_cus = std::max(0, std::min(64, atoi(s)));
   { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->n_cus = cus; }
   if (!e->svc || e->svc_cus * 4 > e->n_cus) e->svc_cus = 0;
@@ -372,10 +372,10 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   if (const char *s = getenv("LANCET_PRE_WIDE")) e->pre_wide_env = atoi(s) != 0 ? 1 : 0;
   if (const char *s = getenv("LANCET_SVC_WGS")) e->n_svc_wgs = std::max(0, std::min(256, atoi(s)));
   if (const char *s = getenv("LANCET_SVC_DEPTH")) e->svc_depth = std::max(0, std::min(16, atoi(s)));
-  // --linked-reads: the build kernel builds the window's first graph and hands the tracked nodes' occurrences over; the window kernel replays
-  // barcodes and haplotypes over them (kernels.h load_prebuilt_lr).  No graphs built ahead and no build service in this mode: a later k of a
-  // window is the general build's.  LANCET_LR_PREBUILD=0: the general build for every window (the route until round 5).
-  if (p->lr_mode) { if (const char *s = getenv("LANCET_LR_PREBUILD")) { if (atoi(s) == 0) e->prebuild = false; } e->ahead_depth_env = 0; }
+  // --linked-reads: the build kernel builds a window's graphs as for any other batch (graphs ahead, the build service) and hands the tracked
+  // nodes' occurrences over with each; the window kernel replays barcodes and haplotypes over them (kernels.h load_prebuilt_lr).
+  // LANCET_LR_PREBUILD=0: the general build for every window (the route until round 5).
+  if (p->lr_mode) { if (const char *s = getenv("LANCET_LR_PREBUILD")) { if (atoi(s) == 0) e->prebuild = false; } }
   if (const char *s = getenv("LANCET_TRACE_WORDS")) e->evt_cap = (uint32_t)atoi(s);
   e->max_slots = (e->n_cus - e->svc_cus) * 4 * LC_W_EU - 4 * LC_W_EU;       // (one CU's worth short of the device: see n_bslots)
   if (e->svc_cus) e->n_svc_wgs = 2 * e->svc_cus;

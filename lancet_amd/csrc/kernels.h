@@ -4725,7 +4725,7 @@ DEVNI void count_ref_path(Ctx &c) {
 //   2. the node of every reference offset with its mer-table bit (emit_variant_lr: Ref_t::getBXsetAt asks nodes that did not survive too),
 //   3. the replay (lr_node_replay / lr_replay_batches, as build_gather runs them) -> kc[], mincov, khp[],
 //   4. the survivors' quality rows with all ten counters (build_qcounts, rows only) -- W.qv is the slot's own array, stride 10,
-//   5. Ref_t::computeCoverage from the barcode counts (build_refcov's rule; the window's first graph: every k-mer of rawseq but the last is in the table),
+//   5. Ref_t::computeCoverage from the barcode counts (build_refcov's rule, over Ref_t::seq as the k attempts before this one left it),
 //   6. the open-addressing table of the survivors' k-mers for Graph_t::getBXsetAt (kmer_lookup; every k-mer of a path string is a live node).
 // ---------------------------------------------------------------------------------------------------------
 DEVNI void load_prebuilt_lr(Ctx &c, LC_GLOBAL const uint8_t *area) {
@@ -4740,6 +4740,7 @@ DEVNI void load_prebuilt_lr(Ctx &c, LC_GLOBAL const uint8_t *area) {
   LC_GLOBAL const unsigned long long *skey = (LC_GLOBAL const unsigned long long *)(area + PRE_OFF_SKEY);
   LC_GLOBAL const uint8_t *surv = (LC_GLOBAL const uint8_t *)(area + PRE_OFF_SURV);
   const int nrefk = reflen - K > 0 ? reflen - K + 1 : 0;
+  const int t5 = wg_bcast(&S.seq_t5), L = wg_bcast(&S.seq_len);
   PHASE(c, 2);
   // ---- 1
   WG_LANE0 { W.qv = W.qv_own; }
@@ -4756,7 +4757,9 @@ DEVNI void load_prebuilt_lr(Ctx &c, LC_GLOBAL const uint8_t *area) {
   WG_FOR(i, nrefk) {
     const uint32_t n = occ_ref[i] & 0x3FFFFFFFu & ~PB_GONE;
     dev_atomic_or(&W.bitmap[n >> 5], 1u << (n & 31u));
-    if (i < reflen - K) dev_atomic_or(&W.bitpre[n >> 5], 1u << (n & 31u));              // i + K < rawseq.length(): in Ref_t::mertable (src/Ref.cc:40-64)
+    // Ref_t::mertable (indexMers, src/Ref.cc:40-64): the k-mers at i + K < seq.length() of Ref_t::seq -- all of rawseq for the window's first
+    // graph; what an earlier, rejected k of this window trimmed it to (markRefEnds) for a graph built ahead or by the service
+    if (i >= t5 && i - t5 < L - K) dev_atomic_or(&W.bitpre[n >> 5], 1u << (n & 31u));
   }
   WG_LANE0 { S.tmp2 = 0; }
   WG_SYNC();
@@ -4799,10 +4802,12 @@ DEVNI void load_prebuilt_lr(Ctx &c, LC_GLOBAL const uint8_t *area) {
   WG_FOR(j, reflen) { for (int q = 0; q < 4; ++q) W.refcov[4 * j + q] = 0; for (int q = 0; q < 6; ++q) W.refhp[6 * j + q] = 0; }
   WG_SYNC();
   WG_FOR(i, reflen - K > 0 ? reflen - K : 0) {
-    const uint32_t X = W.lr_refnode[i] & 0x3FFFFFFFu;
-    uint16_t v[4], h[6];
-    for (int q = 0; q < 4; ++q) v[q] = W.gr[X].kc[q];
-    for (int q = 0; q < 6; ++q) h[q] = W.khp[6 * (size_t)X + q];
+    const uint32_t rv = W.lr_refnode[i], X = rv & 0x3FFFFFFFu;
+    uint16_t v[4] = {0, 0, 0, 0}, h[6] = {0, 0, 0, 0, 0, 0};
+    if (rv >> 31) {                                                  // (computeCoverage reads 0 for a k-mer that is not in the table)
+      for (int q = 0; q < 4; ++q) v[q] = W.gr[X].kc[q];
+      for (int q = 0; q < 6; ++q) h[q] = W.khp[6 * (size_t)X + q];
+    }
     if (i == 0) { for (int j = 0; j < K; ++j) { for (int q = 0; q < 4; ++q) W.refcov[4 * j + q] = v[q]; for (int q = 0; q < 6; ++q) W.refhp[6 * j + q] = h[q]; } }
     else { for (int q = 0; q < 4; ++q) W.refcov[4 * (i + K - 1) + q] = v[q]; for (int q = 0; q < 6; ++q) W.refhp[6 * (i + K - 1) + q] = h[q]; }
   }
@@ -4853,8 +4858,8 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
   }
   WG_LANE0 { S.tmp1 = (H->status == PB_BUILT && H->K == k && H->N <= LC_CTX(c).C->node_cap && (size_t)H->ncand * (size_t)k <= (size_t)LC_CTX(c).C->qv_cap &&
                        H->ncand <= LC_CTX(c).C->surv_cap && (size_t)H->ncand * (size_t)k <= (size_t)LC_CTX(c).C->seq_cap) ? 1 : 0;
-             // --linked-reads: only with the tracked nodes' occurrences handed over, only the window's first graph (Ref_t::seq untrimmed), and room for the runs
-             if (S.LR && !(H->lr == 1u && H->have_order == 1u && S.seq_t5 == 0 && S.seq_len == S.reflen && H->lr_total <= LC_CTX(c).C->occ_cap)) S.tmp1 = 0; }
+             // --linked-reads: only with the tracked nodes' occurrences handed over, and room for the runs
+             if (S.LR && !(H->lr == 1u && H->have_order == 1u && H->lr_total <= LC_CTX(c).C->occ_cap)) S.tmp1 = 0; }
   if (!wg_bcast(&S.tmp1)) return false;
   const uint32_t N = H->N, ncand = H->ncand, nsurv = H->nsurv;
   const int K = k;

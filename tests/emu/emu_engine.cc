@@ -77,7 +77,6 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
     std::vector<uint32_t> biglist((size_t)b->n_windows + 1, 0);
     const bool large = getenv("LANCET_NO_LARGE_BUILD") == nullptr;
     depth = getenv("LANCET_AHEAD_DEPTH") ? atoi(getenv("LANCET_AHEAD_DEPTH")) : 6;
-    if (P->lr_mode) depth = 0;                                   // (engine.hip: no graphs built ahead, no service in --linked-reads mode)
     pool_cap = (uint32_t)(b->n_windows / 4 + (depth > 0 ? 8 : 0) + (getenv("LANCET_NO_SVC") ? 0 : (b->n_windows < 128 ? 4 * b->n_windows + 24 : 536)));
     if (pool_cap) pool.assign((size_t)pool_cap * C.pl.stride, 0xCD);
     if (getenv("LANCET_EMU_FORCE_LARGE")) {                     // (test hook: every window through the 1024-lane configuration)
@@ -107,7 +106,7 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
   // ---- the build service (engine.hip svc_kernel): LANCET_NO_SVC=1 off, LANCET_SVC_DEAD=1 nobody serves (the slots take their requests back)
   SvcCtl sv; memset(&sv, 0, sizeof(sv));
   std::vector<SvcReq> sreq; std::vector<uint32_t> srdy; std::vector<SvcCont> scont;
-  if (O.pre && O.pre_pool && !getenv("LANCET_NO_SVC") && !P->lr_mode) {
+  if (O.pre && O.pre_pool && !getenv("LANCET_NO_SVC")) {
     sv.cap = (uint32_t)b->n_windows * 4u + 16u;
     sreq.assign(sv.cap, SvcReq{0, 0, SV_EMPTY, 0}); srdy.assign(sv.cap, 0u); scont.resize(sv.cap);
     sv.req = sreq.data(); sv.rdy = srdy.data(); sv.cont = scont.data();

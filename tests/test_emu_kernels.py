@@ -232,6 +232,27 @@ def test_linked_read_windows_through_the_lds_build_and_the_replay_over_its_runs(
         emu.FAT[0] = False
 
 
+@pytest.mark.parametrize("seed", [0, 2])
+def test_linked_read_windows_that_climb_through_many_k_take_graphs_built_ahead_and_by_the_service(seed):
+    """--linked-reads with tandem duplications everywhere: windows that reject a dozen k.  Their later graphs come from the build kernel too
+    (built ahead, or by the build service on request) -- with Ref_t::seq trimmed by the k attempts before, which load_prebuilt_lr's mer-table
+    bits and coverage tables have to follow -- and everything still equals the oracle: records, stats, the whole trace."""
+    from lancet_amd import frontend, synth
+    data = synth.make_tumor_normal(ref_len=4200, cov_t=34, cov_n=28, ref_seed=70 + seed, tumor_seed=170 + seed, normal_seed=270 + seed, linked=True,
+                                   dup_prob=1.0, str_fraction=0.05, somatic_every=350, germline_every=260, read_len=100, insert_mean=330.0, insert_sd=30.0)
+    windows = frontend.tile_region(data["ref"], data["rname"], "chr22:500-3600")
+    batch, kept = frontend.batch_from_sam(windows, synth.pairs_to_sorted_reads(data["tumor"]), synth.pairs_to_sorted_reads(data["normal"]), linked=True)
+    p = abi.default_params(lr_mode=1)
+    v, st, tr = emu.run(batch, p, evt_cap=1 << 18)
+    taken, served = emu.LAST_AHEAD[1], emu.LAST_SVC[1]
+    ov, ost, otr = oracle.run(batch, p, verbose=True)
+    assert emu.LAST_PREBUILT[0] >= 10 and taken >= 40 and served >= 40 and max(s["n_builds"] for s in ost) >= 9
+    assert len(ov) > 0 and v == ov
+    key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
+    assert [key(s) for s in st] == [key(s) for s in ost]
+    assert gu.digest_trace(tr) == gu.digest_trace(otr)
+
+
 @pytest.mark.parametrize("name", ["dups", "nref"])
 def test_table_doubling_path_gives_the_same_graphs(name, monkeypatch):
     """Each build sizes its k-mer table from an estimate and doubles it when it fills up; started at 64 slots, every
