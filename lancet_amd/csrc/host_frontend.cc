@@ -8,6 +8,7 @@
 
 #include <sys/types.h>
 #include <zlib.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <memory>
@@ -120,6 +121,24 @@ inline uint64_t rd_u64(const unsigned char *p) { uint64_t v; memcpy(&v, p, 8); r
 // BGZF (SAM spec 4.1): a series of gzip members, each with the BC extra subfield holding the block size.  The file is
 // read in slabs of whole blocks from a compressed offset onwards; the blocks of a slab are independent deflate streams
 // and are inflated on the host threads.  Memory in flight is one slab, whatever the size of the file.
+// libdeflate (when the loader finds libdeflate.so.0; no header needed for three entry points) inflates a BGZF block two to three times faster
+// than zlib's inflate -- and inflating is what the input decoding waits for.  Raw deflate streams of known output size; zlib otherwise.
+struct LibDeflate {
+  void *(*alloc)() = nullptr;
+  int (*inflate)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;      // 0 = LIBDEFLATE_SUCCESS
+  void (*release)(void *) = nullptr;
+  LibDeflate() {
+    if (const char *e = getenv("LANCET_HOST_ZLIB")) { if (atoi(e) != 0) return; }         // (LANCET_HOST_ZLIB=1: zlib, for comparison)
+    void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+    inflate = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+    release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+    if (!alloc || !inflate || !release) { alloc = nullptr; inflate = nullptr; release = nullptr; }
+  }
+};
+static const LibDeflate &libdeflate() { static const LibDeflate L; return L; }
+
 class BgzfReader {
  public:
   ~BgzfReader() { if (f_) fclose(f_); }
@@ -189,12 +208,19 @@ class BgzfReader {
     ubuf_.resize(base + total);
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0);
+    const LibDeflate &LD = libdeflate();
     auto work = [&]() {
+      void *dec = LD.alloc ? LD.alloc() : nullptr;
       for (;;) {
         const size_t i = next.fetch_add(1);
         if (i >= blks.size()) break;
         const Blk &b = blks[i];
         if (b.isize == 0) continue;
+        if (dec) {
+          size_t got_out = 0;
+          if (LD.inflate(dec, raw + b.cdata, b.clen, &ubuf_[base + b.opos], b.isize, &got_out) != 0 || got_out != b.isize) bad = 1;
+          continue;
+        }
         z_stream zs; memset(&zs, 0, sizeof zs);
         if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; continue; }
         zs.next_in = (Bytef *)raw + b.cdata; zs.avail_in = (uInt)b.clen;
@@ -203,6 +229,7 @@ class BgzfReader {
         if (rc != Z_STREAM_END || zs.total_out != b.isize) bad = 1;
         inflateEnd(&zs);
       }
+      if (dec) LD.release(dec);
     };
     const unsigned nt = host_threads((int)(blks.size() / 8 + 1));
     std::vector<std::thread> th;
