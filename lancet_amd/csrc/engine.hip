@@ -204,6 +204,8 @@ struct lancet_engine {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_done = nullptr;     // recorded by every submit behind the batch's kernels (ev1 is re-recorded by the re-run tier in lancet_engine_wait): what lancet_engine_submit_after waits for
   hipEvent_t wait_ev = nullptr;     // lancet_engine_submit_after: the event this submit's kernels wait for (set around the call only)
+  hipEvent_t ev_a_done = nullptr;   // recorded behind the build kernels (and the ordering kernels) of a submit: LANCET_STAGGER=1 lets the next engine's kernels start there
+  bool stagger = false;
   int slots2_pred = 0;              // re-run tier of the windows started early: laid out by submit before it waits for `wait_ev`
   std::string err;
   // device buffers
@@ -349,7 +351,8 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
   }
   if ((!e->stream && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) || hipEventCreate(&e->ev0) != hipSuccess ||
       hipEventCreate(&e->ev1) != hipSuccess || hipEventCreate(&e->evb0) != hipSuccess || hipEventCreate(&e->evb1) != hipSuccess ||
-      hipEventCreate(&e->ev_done) != hipSuccess) { delete e; return LANCET_E_HIP; }
+      hipEventCreate(&e->ev_done) != hipSuccess || hipEventCreate(&e->ev_a_done) != hipSuccess) { delete e; return LANCET_E_HIP; }
+  e->stagger = getenv("LANCET_STAGGER") && atoi(getenv("LANCET_STAGGER")) != 0;
   if (getenv("LANCET_NO_PREBUILD")) e->prebuild = false;
   if (const char *s = getenv("LANCET_PREP")) e->host_prep = strcmp(s, "device") != 0;
   if (const char *s = getenv("LANCET_PREP_THREADS")) e->prep_threads = std::max(1, atoi(s));
@@ -405,6 +408,7 @@ void lancet_engine_destroy(lancet_engine *e) {
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->ev_done) (void)hipEventDestroy(e->ev_done);
+  if (e->ev_a_done) (void)hipEventDestroy(e->ev_a_done);
   if (e->evf0) (void)hipEventDestroy(e->evf0);
   if (e->evf1) (void)hipEventDestroy(e->evf1);
   if (e->ev_ready) (void)hipEventDestroy(e->ev_ready);
@@ -876,6 +880,7 @@ static int lc_submit_body(lancet_engine *e) {
     }
     HIPCHK(e, hipEventRecord(e->evb1, e->stream));
   }
+  HIPCHK(e, hipEventRecord(e->ev_a_done, e->stream));
   HIPCHK(e, hipEventRecord(e->ev0, e->stream));
   hipLaunchKernelGGL(window_kernel, dim3(e->n_slots), dim3(LANCET_WG), 0, e->stream, (const lancet_params *)e->d_params.p,
                      (const DevBatch *)e->d_batch.p, (const EngineCaps *)e->d_caps.p, (Work *)e->d_works.p, (DevOut *)e->d_out.p);
@@ -893,7 +898,7 @@ static int lc_submit_body(lancet_engine *e) {
 // by then; a caller that submits from several threads orders them itself (lancet_main.cc submits on one thread and waits on others).
 int lancet_engine_submit_after(lancet_engine *e, lancet_engine *prev) {
   if (!e) return LANCET_E_ARG;
-  e->wait_ev = (prev && prev != e && prev->device == e->device) ? prev->ev_done : nullptr;      // (an event never recorded, or long since reached, does not hold anything up)
+  e->wait_ev = (prev && prev != e && prev->device == e->device) ? (e->stagger ? prev->ev_a_done : prev->ev_done) : nullptr;      // (an event never recorded, or long since reached, does not hold anything up)
   const int rc = lancet_engine_submit(e);
   e->wait_ev = nullptr;
   return rc;
