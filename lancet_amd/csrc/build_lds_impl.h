@@ -855,137 +855,6 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
   WG_SYNC();
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// --linked-reads: the replay of loadSequence's barcode / haplotype bookkeeping (Node_t::hasBX / addBX / addHP, reference
-// src/Graph.cc:239-317, src/Node.cc:30-118; kernels.h lr_node_replay is the lane-serial statement of it, lr_replay_batches the window
-// kernel's form) over the csr runs this workgroup has just written -- with 512 lanes and the runs staged in LDS instead of one wave per
-// window over HBM (4 ms of slot time per window there: 40 % of a linked-read window).  Batches of consecutive nodes whose runs fit the
-// staging area; one lane per staged occurrence; everything a lane needs from the others is in LDS.  Nothing is put into visiting order
-// (read, then position): every rule is stated on the occurrences' (read, position) keys instead --
-//   an occurrence ADDS when it is not the reference pseudo-read's and no occurrence of the node with a smaller key carries the same
-//     (barcode, sample) (no barcode: hasBX is never true) -- to the barcode count of its (sample, strand) if it has a barcode, to the haplotype
-//     count of its sample;
-//   a COUNTED occurrence (state 0) takes the counts over the occurrences up to its own key -- and over its (same read, position 1) partner
-//     when it is at position 0: both LR events of loadSequence's first step precede the coverage events;
-//   the node's values are those of the counted occurrence with the largest key per (sample, strand) / per sample; the "grown" bits of a
-//     counted occurrence compare its haplotype counts with those of the counted occurrence of the same sample before it.
-// Out: lrval[10 n ..] for every node with a run of 1..255 occurrences ([10 n] stays 0xFFFF otherwise: the window kernel replays that node),
-// the grown bits ORed into the runs.  Returns false when the phase area leaves too little room (nothing written: PreHdr::lr stays 1).
-// ---------------------------------------------------------------------------------------------------------
-DEVNI bool bl_lr_replay(BL_S &S, LC_GLOBAL const DevBatch *Bp, uint32_t g0_, int nr_, uint32_t N_, LC_GLOBAL uint32_t *lrcsr, LC_GLOBAL uint16_t *lrval) {
-  Bp = lc_sgpr(Bp); lrcsr = lc_sgpr(lrcsr); lrval = lc_sgpr(lrval);
-  const uint32_t g0 = lc_sgpr(g0_), N = lc_sgpr(N_); const int nr = lc_sgpr(nr_);
-  LC_LDS uint32_t *cur = S.big;                                    // [N + 1] run END of node n (the fill pass left its cursors there)
-  const uint32_t w_bx = (N + 3u) & ~1u, w_hp = w_bx + (uint32_t)nr + 1u, w_ev = w_hp + ((uint32_t)nr + 7u) / 4u;
-  if (w_ev + 17u * 128u > (uint32_t)BL_BIG / 4u) return false;
-  uint32_t CAP = ((((uint32_t)BL_BIG / 4u - w_ev) * 4u) / 17u) & ~63u;
-  if (CAP > 8192u) CAP = 8192u;
-  if (CAP < 512u) return false;
-  LC_LDS uint32_t *bxl = S.big + w_bx;
-  LC_LDS uint8_t *hpl = (LC_LDS uint8_t *)(S.big + w_hp);
-  LC_LDS uint32_t *ev = S.big + w_ev, *key = ev + CAP, *cu = key + CAP;
-  LC_LDS uint16_t *ss = (LC_LDS uint16_t *)(cu + CAP), *se = ss + CAP;
-  LC_LDS uint8_t *meta = (LC_LDS uint8_t *)(se + CAP);
-  WG_FOR(r, nr) { bxl[r] = Bp->bx_rank[g0 + (uint32_t)r]; uint32_t h = Bp->hp[g0 + (uint32_t)r]; hpl[r] = (uint8_t)(h > 2u ? 2u : h); }
-  WG_FOR(n, N + 1) { lrval[10 * (size_t)n] = (uint16_t)0xFFFFu; }
-  WG_SYNC();
-#define BLR_VK(v) ((((v) & 0xFFFFu) << 10) | (((v) >> 16) & 0x3FFu))       /* visiting order: read, then position */
-  uint32_t n0 = 0;
-  while (n0 < N) {
-    WG_LANE0 {                                                       // [n0, n1): as many nodes as fit the staging area (at least one)
-      const uint32_t b0 = n0 ? cur[n0 - 1u] : 0u;
-      uint32_t lo = n0, hi = N;
-      while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if (cur[mid - 1u] - b0 <= CAP) lo = mid; else hi = mid - 1u; }
-      S.g0 = lo > n0 ? lo : n0 + 1u;
-    }
-    const uint32_t n1 = bl_bcast(&S.g0);
-    const uint32_t b0 = n0 ? cur[n0 - 1u] : 0u, tot = cur[n1 - 1u] - b0;
-    if (tot == 0u || tot > CAP) { n0 = n1; continue; }              // (no tracked node among them / one node with more occurrences than the area holds: the window kernel's)
-    WG_FOR(t, tot) {
-      const uint32_t v = lrcsr[b0 + (uint32_t)t];
-      uint32_t lo = n0, hi = n1 - 1u;                               // the node: the first whose run ends behind t
-      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cur[mid] > b0 + (uint32_t)t) hi = mid; else lo = mid + 1u; }
-      const uint32_t s0 = (lo ? cur[lo - 1u] : 0u) - b0, e0 = cur[lo] - b0;
-      ss[t] = (uint16_t)s0; se[t] = (uint16_t)e0;
-      const uint32_t r = v & 0xFFFFu;
-      uint32_t k = 0xFFFFFFFEu, mt = 0;
-      if ((int)r != nr && e0 - s0 <= 255u) {
-        const uint32_t ri = S.rinfo[r], sm = RI_NML(ri), d = RI_REV(ri), bx = bxl[r], h = hpl[r];
-        k = bx == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((bx << 1) | sm);
-        mt = (bx != 0xFFFFFFFFu ? 2u : 0u) | ((2u * sm + d) << 2) | (h << 4) | (((v >> 27) & 3u) == 0u ? 64u : 0u);
-      }
-      ev[t] = v; key[t] = k; meta[t] = (uint8_t)mt;
-    }
-    WG_SYNC();
-    WG_FOR(t, tot) {                                                 // adds ; first of a (position 0, position 1) pair of one read
-      const uint32_t k = key[t];
-      if (k == 0xFFFFFFFEu) continue;
-      const uint32_t s0 = ss[t], e0 = se[t], v = ev[t], vk = BLR_VK(v);
-      const bool p0 = ((v >> 16) & 0x3FFu) == 0u;
-      uint32_t same = 0, pair = 0;
-      for (uint32_t i = s0; i < e0; ++i) {
-        const uint32_t vi = ev[i];
-        same |= (key[i] == k && BLR_VK(vi) < vk) ? 1u : 0u;
-        pair |= (p0 && (vi & 0xFFFFu) == (v & 0xFFFFu) && ((vi >> 16) & 0x3FFu) == 1u && key[i] != 0xFFFFFFFEu) ? 1u : 0u;
-      }
-      uint32_t mt = meta[t];
-      if (k == 0xFFFFFFFFu || !same) mt |= 1u;
-      if (pair) mt |= 128u;
-      meta[t] = (uint8_t)mt;
-    }
-    WG_SYNC();
-    WG_FOR(t, tot) {                                                 // a counted occurrence: the counts at its coverage event
-      const uint32_t mt = meta[t];
-      if (!(mt & 64u)) continue;
-      const uint32_t s0 = ss[t], e0 = se[t], v = ev[t], vk = BLR_VK(v), rd = v & 0xFFFFu;
-      const uint32_t f = (mt >> 2) & 3u, sm = f >> 1, want_b = 3u | (f << 2), want_s = 1u | (sm << 3);
-      const bool first = (mt & 128u) != 0;
-      uint32_t bxc = 0, hpc = 0;
-      for (uint32_t i = s0; i < e0; ++i) {
-        const uint32_t vi = ev[i], x = meta[i];
-        const bool incl = BLR_VK(vi) <= vk || (first && (vi & 0xFFFFu) == rd && ((vi >> 16) & 0x3FFu) == 1u);
-        if (incl) { bxc += (x & 15u) == want_b ? 1u : 0u; hpc += (x & 9u) == want_s ? (1u << (8u * ((x >> 4) & 3u))) : 0u; }
-      }
-      cu[t] = (hpc & 0xFFFFFFu) | (bxc << 24);
-    }
-    WG_SYNC();
-    WG_FOR(t, tot) {                                                 // grown bits against the counted occurrence of the same sample before it; back to the run
-      const uint32_t mt = meta[t];
-      if (!(mt & 64u)) continue;
-      const uint32_t s0 = ss[t], e0 = se[t], v = ev[t], vk = BLR_VK(v), cnt_s = 64u | (mt & 8u);
-      uint32_t pk = 0, old = 0; bool have = false;
-      for (uint32_t i = s0; i < e0; ++i) {
-        if ((meta[i] & 72u) != cnt_s) continue;
-        const uint32_t vki = BLR_VK(ev[i]);
-        if (vki < vk && (!have || vki > pk)) { have = true; pk = vki; old = cu[i]; }
-      }
-      const uint32_t now = cu[t];
-      uint32_t grow = 0;
-      for (uint32_t q = 0; q < 3u; ++q) if (((old >> (8u * q)) & 0xFFu) < ((now >> (8u * q)) & 0xFFu)) grow |= 1u << q;
-      if (grow) lrcsr[b0 + (uint32_t)t] = v | (grow << 29);
-    }
-    WG_FOR(x, (n1 - n0) * 6u) {                                      // the node's values: what its last counted occurrence per (sample, strand) / per sample leaves
-      const uint32_t n = n0 + (uint32_t)x / 6u, q = (uint32_t)x % 6u;
-      const uint32_t s0 = (n ? cur[n - 1u] : 0u) - b0, e0 = cur[n] - b0;
-      if (e0 == s0 || e0 - s0 > 255u) continue;
-      uint32_t bk = 0, val = 0; bool have = false;
-      for (uint32_t i = s0; i < e0; ++i) {
-        const uint32_t xm = meta[i];
-        if (!(xm & 64u)) continue;
-        if (q < 4u ? ((xm >> 2) & 3u) != q : ((xm >> 3) & 1u) != q - 4u) continue;
-        const uint32_t vki = BLR_VK(ev[i]);
-        if (!have || vki > bk) { have = true; bk = vki; val = cu[i]; }
-      }
-      if (q < 4u) lrval[10 * (size_t)n + q] = (uint16_t)(have ? (val >> 24) : 0u);
-      else for (uint32_t h = 0; h < 3u; ++h) lrval[10 * (size_t)n + 4u + 3u * (q - 4u) + h] = (uint16_t)(have ? ((val >> (8u * h)) & 0xFFu) : 0u);
-    }
-    WG_SYNC();
-    n0 = n1;
-  }
-#undef BLR_VK
-  return true;
-}
-
 // One window.  Returns with the hand-off area of the window written (PB_BUILT) or marked PB_NOT_BUILT.
 // kmin: the loop over k starts there (min_k for the window's first graph; the k after a rejected one for a graph built ahead).
 // rep: the window's isRepeat / isAlmostRepeat operands when an earlier call scanned the reference already, else null.
@@ -1630,7 +1499,6 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     });
     WG_SYNC();
     WG_LANE0 { H->lr = 1u; H->lr_total = S.scan_total; }
-    if (C->debug_stop != 150u && bl_lr_replay(S, Bp, g0, nr, N, lrcsr, (LC_GLOBAL uint16_t *)(area + PRE_OFF_LRVAL))) { WG_LANE0 { H->lr = 2u; } }      // (150: test knob -- the window kernel replays every node)
   }
   BLP(S, 10);
   if (C->debug_stop == 110u) { WG_LANE0 { H->why = 99; } return; }

@@ -4741,8 +4741,6 @@ DEVNI void load_prebuilt_lr(Ctx &c, LC_GLOBAL const uint8_t *area) {
   LC_GLOBAL const uint8_t *surv = (LC_GLOBAL const uint8_t *)(area + PRE_OFF_SURV);
   const int nrefk = reflen - K > 0 ? reflen - K + 1 : 0;
   const int t5 = wg_bcast(&S.seq_t5), L = wg_bcast(&S.seq_len);
-  const bool in_a = H->lr == 2u;
-  LC_GLOBAL const uint16_t *lrval = (LC_GLOBAL const uint16_t *)(area + PRE_OFF_LRVAL);
   PHASE(c, 2);
   // ---- 1
   WG_LANE0 { W.qv = W.qv_own; }
@@ -4752,7 +4750,7 @@ DEVNI void load_prebuilt_lr(Ctx &c, LC_GLOBAL const uint8_t *area) {
     W.rd[4 * r] = rinfo; W.rd[4 * r + 1] = bw; W.rd[4 * r + 2] = gw; W.rd[4 * r + 3] = 0;
   }
   WG_FOR(n, N + 1) { W.nocc[n] = lrnocc[n]; }
-  WG_FOR(i, total) { const uint32_t v = lrcsr[i]; W_CSR(W)[i] = CS_MAKE(v & 0xFFFFu, (v >> 16) & 0x3FFu, (v >> 26) & 1u, (v >> 27) & 3u) | (cs_t)(v & 0xE0000000u); }      // (bits 29..31: the grown bits, where the build kernel ran the replay)
+  WG_FOR(i, total) { const uint32_t v = lrcsr[i]; W_CSR(W)[i] = CS_MAKE(v & 0xFFFFu, (v >> 16) & 0x3FFu, (v >> 26) & 1u, (v >> 27) & 3u); }
   // ---- 2
   WG_FOR(i, (N + 31u) / 32u) { W.bitmap[i] = 0; W.bitpre[i] = 0; }
   WG_SYNC();
@@ -4774,14 +4772,6 @@ DEVNI void load_prebuilt_lr(Ctx &c, LC_GLOBAL const uint8_t *area) {
   WG_FOR(n, N) {
     const bool onr = ((ld2(&W.bitmap[(uint32_t)n >> 5]) >> ((uint32_t)n & 31u)) & 1u) != 0;
     if (!surv[n] && !onr) continue;
-    if (in_a && lrval[10 * (size_t)n] != 0xFFFFu) {                 // the build kernel replayed this node (build_lds_impl.h bl_lr_replay): its grown bits are in the run
-      LC_GLOBAL NodeGr &G = W.gr[n];
-      uint32_t sum = 0;
-      for (int q = 0; q < 4; ++q) { const uint16_t v = lrval[10 * (size_t)n + q]; G.kc[q] = v; sum += v; }
-      for (int q = 0; q < 6; ++q) W.khp[6 * (size_t)n + q] = lrval[10 * (size_t)n + 4 + q];
-      G.mincov = (int)sum;
-      continue;
-    }
     const uint32_t lo = lrnocc[n], hi = lrnocc[n + 1];
     if (hi - lo >= LR_COOP_MIN && hi - lo <= LR_COOP_MAX && lo < (1u << 24)) {        // by the whole wave, below: listed
       const uint32_t at = dev_atomic_add((LC_LDS uint32_t *)&S.tmp2, 1u);
@@ -4869,7 +4859,7 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
   WG_LANE0 { S.tmp1 = (H->status == PB_BUILT && H->K == k && H->N <= LC_CTX(c).C->node_cap && (size_t)H->ncand * (size_t)k <= (size_t)LC_CTX(c).C->qv_cap &&
                        H->ncand <= LC_CTX(c).C->surv_cap && (size_t)H->ncand * (size_t)k <= (size_t)LC_CTX(c).C->seq_cap) ? 1 : 0;
              // --linked-reads: only with the tracked nodes' occurrences handed over, and room for the runs
-             if (S.LR && !((H->lr == 1u || H->lr == 2u) && H->have_order == 1u && H->lr_total <= LC_CTX(c).C->occ_cap)) S.tmp1 = 0; }
+             if (S.LR && !(H->lr == 1u && H->have_order == 1u && H->lr_total <= LC_CTX(c).C->occ_cap)) S.tmp1 = 0; }
   if (!wg_bcast(&S.tmp1)) return false;
   const uint32_t N = H->N, ncand = H->ncand, nsurv = H->nsurv;
   const int K = k;

@@ -103,7 +103,6 @@ struct PreLayout {
   uint32_t ncap, qvcap, kw, maxw;
   uint32_t refcov, nhash, surv, snode, skey, sid, pgr, order, qv, chdr, clive, cseq;
   uint32_t lrnocc, lrcsr, lrcap;   /* --linked-reads only (else 0): csr offsets by node id, the csr entries of the tracked nodes, room for them */
-  uint32_t lrval;                  /* ... the replay's ten values per node, where the build kernel ran it (PreHdr::lr == 2)                        */
   uint32_t stride;
 };
 struct EngineCaps {
@@ -218,7 +217,7 @@ struct PreHdr {
   uint32_t next;              /* 1 + index of the pool area that holds this window's graph at the next k of its loop (built ahead
                                  because `heavy` says this k will be rejected, or on request of the window kernel), 0: none */
   uint32_t big;               /* built by the 1024-lane configuration (the build service runs the 512-lane one)   */
-  uint32_t lr;                /* (1, or 2: with the replay done by the build kernel -- PRE_OFF_LRVAL, grown bits in the runs) --linked-reads: the occurrences of the tracked nodes came along (PRE_OFF_LRNOCC / PRE_OFF_LRCSR): the window kernel replays
+  uint32_t lr;                /* --linked-reads: the occurrences of the tracked nodes came along (PRE_OFF_LRNOCC / PRE_OFF_LRCSR): the window kernel replays
                                  barcodes and haplotypes over them (kernels.h load_prebuilt_lr) instead of building the window in HBM    */
   uint32_t lr_total;          /* ... csr entries                                                                    */
   uint32_t pad[7];
@@ -243,7 +242,6 @@ struct PreHdr {
 #define PRE_OFF_CLIVE (PL.clive)                              /* u32[PB_CMAX + 2]  record index (survivor index, or nsurv + k for special k) per table position */
 #define PRE_OFF_CSEQ (PL.cseq)                                /* u32[PB_CSEQ]                                           */
 #define PRE_OFF_LRNOCC (PL.lrnocc)                            /* u32[ncap + 2]  --linked-reads: csr run of node n = [lrnocc[n], lrnocc[n+1]) (empty for a node with one occurrence) */
-#define PRE_OFF_LRVAL (PL.lrval)                              /* u16[(ncap + 1) * 10] ... PreHdr::lr == 2: barcode counts Tf Tr Nf Nr, hp0-2 tumor, hp0-2 normal of node n; [10 n] == 0xFFFF: not replayed here */
 #define PRE_OFF_LRCSR (PL.lrcsr)                              /* u32[lrcap]     ... the runs: cs_t words (read, position, orientation, state), unsorted inside a run */
 #define PRE_STRIDE (PL.stride)
 /* ---- first compress done by the build kernel (build_lds_impl.h bl_compress_first): single-component first graphs ----

@@ -98,7 +98,7 @@ extern "C" void *lancet_emu_run(const lancet_params *P, const lancet_window_batc
     for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * C.pl.stride); const PreCmp *CH = (const PreCmp *)(pre.data() + (size_t)w * C.pl.stride + C.pl.chdr); if (H->status == PB_BUILT && CH->done == 1u) ++res->n_cmp_done; }
     if (getenv("LANCET_EMU_CMP")) fprintf(stderr, "[emu] first compress done by the build kernel: %u of %u built windows\n", res->n_cmp_done, bq[1]);
     if (getenv("LANCET_EMU_HEAVY")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * C.pl.stride); if (H->status == PB_BUILT && H->heavy) fprintf(stderr, "[emu] heavy %d K %d\n", w, H->K); }
-    if (getenv("LANCET_EMU_HDR")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * C.pl.stride); fprintf(stderr, "[emu] hdr %d status %u K %d N %u order %u refE %d refM %d heavy %u next %u lr %u\n", w, H->status, H->K, H->N, H->have_order, H->refE, H->refM, H->heavy, H->next, H->lr); }
+    if (getenv("LANCET_EMU_HDR")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * C.pl.stride); fprintf(stderr, "[emu] hdr %d status %u K %d N %u order %u refE %d refM %d heavy %u next %u\n", w, H->status, H->K, H->N, H->have_order, H->refE, H->refM, H->heavy, H->next); }
     if (getenv("LANCET_EMU_WHY")) for (int w = 0; w < b->n_windows; ++w) { const PreHdr *H = (const PreHdr *)(pre.data() + (size_t)w * C.pl.stride); if (H->status != PB_BUILT) fprintf(stderr, "[emu] window %d not prebuilt: why %u\n", w, H->why); }
   }
   static thread_local WinShared S;

@@ -207,8 +207,7 @@ def test_emulated_kernels_match_oracle_on_random_linked_read_windows(seed):
 def test_linked_read_windows_through_the_lds_build_and_the_replay_over_its_runs(route, monkeypatch):
     """--linked-reads windows whose first graph comes from the LDS build kernel (build_lds_impl.h: the tracked nodes' occurrences are handed
     over as csr runs; kernels.h load_prebuilt_lr replays barcodes / haplotypes over them, recounts the ten per-position counters of the
-    survivors, recomputes Ref_t's tables from the barcode counts and builds the table getBXsetAt looks k-mers up in; the replay itself in the build
-    kernel, build_lds_impl.h bl_lr_replay, or -- switched off there -- by the window kernel) -- the windows of
+    survivors, recomputes Ref_t's tables from the barcode counts and builds the table getBXsetAt looks k-mers up in) -- the windows of
     bench.py's config 5, both build configurations and the re-run tier's source: records (haplotype counts, barcode sets), stats and the
     whole stage trace equal the oracle's, and equal the general build of every window (LANCET_LR_PREBUILD=0, the route until round 5)."""
     from lancet_amd import workload
@@ -226,11 +225,6 @@ def test_linked_read_windows_through_the_lds_build_and_the_replay_over_its_runs(
         key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
         assert [key(s) for s in st] == [key(s) for s in ost]
         assert gu.digest_trace(tr) == gu.digest_trace(otr)
-        # the replay itself runs in the build kernel (bl_lr_replay); with it switched off there the window kernel replays every node over the runs
-        monkeypatch.setenv("LANCET_STOP_PHASE", "150")
-        v3, st3, tr3 = emu.run(b, p, evt_cap=1 << 18)
-        assert emu.LAST_PREBUILT[0] == b.n_windows and v3 == ov and gu.digest_trace(tr3) == gu.digest_trace(otr)
-        monkeypatch.delenv("LANCET_STOP_PHASE")
         monkeypatch.setenv("LANCET_LR_PREBUILD", "0")
         v2, st2, tr2 = emu.run(b, p, evt_cap=1 << 18)
         assert emu.LAST_PREBUILT[0] == 0 and v2 == ov and gu.digest_trace(tr2) == gu.digest_trace(otr)
