@@ -19,9 +19,11 @@
 #include "../../include/lancet_host.h"
 #include "../../include/lancet_gather.h"
 
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -130,8 +132,19 @@ int main(int argc, char **argv) {
       }
       kids.push_back(pid);
     }
-    int worst = 0;
-    for (pid_t k : kids) { int st = 0; if (waitpid(k, &st, 0) < 0) worst = worst ? worst : 1; else { const int c = WIFEXITED(st) ? WEXITSTATUS(st) : 1; if (c && (!worst || c == 1)) worst = c; } }
+    // a rank that fails (exit code other than 0 / 3: bad input, no device, a communicator that does not come up) takes the others with it --
+    // they would wait for it at the rendezvous or in the gather
+    int worst = 0; size_t left = kids.size();
+    while (left > 0) {
+      int st = 0;
+      const pid_t k = waitpid(-1, &st, 0);
+      if (k < 0) { worst = worst ? worst : 1; break; }
+      if (std::find(kids.begin(), kids.end(), k) == kids.end()) continue;
+      --left;
+      const int c = WIFEXITED(st) ? WEXITSTATUS(st) : 1;
+      if (c && (!worst || c == 1 || worst == 3)) worst = c;
+      if (c != 0 && c != 3) for (pid_t o : kids) if (o != k) kill(o, SIGTERM);
+    }
     unlink(rendezvous.c_str());
     return worst;
   }
