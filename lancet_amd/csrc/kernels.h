@@ -4319,7 +4319,8 @@ DEVNI void process_path_walk(Ctx &c, int np, int plen, int L, int complete) {
 // binary search over the path's node ends (they grow along the path).
 //   record (10 words): alt N fwd|rev, N qf|qr, alt T fwd|rev, T qf|qr, ref N fwd|rev, ref T fwd|rev, column / position j, P, pos_in_ref,
 //                      flags (1 spanner within tumor, 2 no spanner, 4 P outside the path) | column code << 8
-DEV void walk_gather(Ctx &c, volatile LC_LDS uint32_t *rec, int pathpos, int P, uint32_t refpos, int plen, int np, LC_GLOBAL const uint32_t *pend, uint32_t w6, uint32_t w8, uint32_t code) {
+// (lr: words 10..18 of the record take the haplotype counts of the position too -- path hp0-2 and hp0-2_minqv, normal then tumor; reference hp0-2)
+DEV void walk_gather(Ctx &c, volatile LC_LDS uint32_t *rec, int pathpos, int P, uint32_t refpos, int plen, int np, LC_GLOBAL const uint32_t *pend, uint32_t w6, uint32_t w8, uint32_t code, bool lr = false) {
   LC_GLOBAL Work &W = *LC_CTX(c).W;
   uint32_t fl = 0;
   // first node whose end reaches pathpos (special nodes carry the running position: never the answer unless nothing else is)
@@ -4334,7 +4335,22 @@ DEV void walk_gather(Ctx &c, volatile LC_LDS uint32_t *rec, int pathpos, int P, 
   rec[2] = (uint32_t)ct4[0] | ((uint32_t)ct4[1] << 16); rec[3] = (uint32_t)ct4[2] | ((uint32_t)ct4[3] << 16);
   rec[4] = (uint32_t)rn2[0] | ((uint32_t)rn2[1] << 16); rec[5] = (uint32_t)rt2[0] | ((uint32_t)rt2[1] << 16);
   rec[6] = w6; rec[7] = (uint32_t)P; rec[8] = w8; rec[9] = fl | (code << 8);
+  if (lr) {
+    HPc ha, hr;
+    for (int j = 0; j < 3; ++j) { ha.nh[j] = ha.th[j] = ha.nq[j] = ha.tq[j] = 0; }
+    if (!(P < 0 || P >= plen)) path_hp_at(c, P, ha);
+    ref_hp_at(c, refpos, hr);
+    rec[10] = (uint32_t)ha.nh[0] | ((uint32_t)ha.nh[1] << 16); rec[11] = (uint32_t)ha.nh[2] | ((uint32_t)ha.nq[0] << 16); rec[12] = (uint32_t)ha.nq[1] | ((uint32_t)ha.nq[2] << 16);
+    rec[13] = (uint32_t)ha.th[0] | ((uint32_t)ha.th[1] << 16); rec[14] = (uint32_t)ha.th[2] | ((uint32_t)ha.tq[0] << 16); rec[15] = (uint32_t)ha.tq[1] | ((uint32_t)ha.tq[2] << 16);
+    rec[16] = (uint32_t)hr.nh[0] | ((uint32_t)hr.nh[1] << 16); rec[17] = (uint32_t)hr.nh[2] | ((uint32_t)hr.th[0] << 16); rec[18] = (uint32_t)hr.th[1] | ((uint32_t)hr.th[2] << 16);
+  }
   (void)W;
+}
+DEV void walk_unpack_hp(volatile LC_LDS uint32_t *rc, HPc &ha, HPc &hr) {
+  ha.nh[0] = (uint16_t)rc[10]; ha.nh[1] = (uint16_t)(rc[10] >> 16); ha.nh[2] = (uint16_t)rc[11]; ha.nq[0] = (uint16_t)(rc[11] >> 16); ha.nq[1] = (uint16_t)rc[12]; ha.nq[2] = (uint16_t)(rc[12] >> 16);
+  ha.th[0] = (uint16_t)rc[13]; ha.th[1] = (uint16_t)(rc[13] >> 16); ha.th[2] = (uint16_t)rc[14]; ha.tq[0] = (uint16_t)(rc[14] >> 16); ha.tq[1] = (uint16_t)rc[15]; ha.tq[2] = (uint16_t)(rc[15] >> 16);
+  hr.nh[0] = (uint16_t)rc[16]; hr.nh[1] = (uint16_t)(rc[16] >> 16); hr.nh[2] = (uint16_t)rc[17]; hr.th[0] = (uint16_t)(rc[17] >> 16); hr.th[1] = (uint16_t)rc[18]; hr.th[2] = (uint16_t)(rc[18] >> 16);
+  for (int j = 0; j < 3; ++j) { hr.nq[j] = hr.tq[j] = 0; }
 }
 DEVNI void process_path_walk_wg(Ctx &c, int np, int plen, int L, int complete) {
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
@@ -4351,7 +4367,9 @@ DEVNI void process_path_walk_wg(Ctx &c, int np, int plen, int L, int complete) {
 #endif
   constexpr int LC_TS_LDS = (int)(sizeof(S.lbytes) / sizeof(TS));
   volatile LC_LDS uint32_t *recs = (volatile LC_LDS uint32_t *)&S.acc[0][0];
-  static_assert(sizeof(S.acc) >= 64 * 10 * sizeof(uint32_t), "64 column records");
+  static_assert(sizeof(S.acc) >= 64 * 10 * sizeof(uint32_t) && sizeof(S.acc) >= 32 * 19 * sizeof(uint32_t), "64 column records of 10 words, or 32 of 19 (--linked-reads: + the haplotype counts)");
+  const bool LR = wg_uniform(S.LR) != 0;
+  const int RS = LR ? 19 : 10, CW = LR ? 32 : 64;                  // words per record ; columns per round
   LC_GLOBAL const uint32_t *E1 = W.scratch, *E2 = W.scratch + (L + 1), *cols = W.scratch + 3 * (L + 1);
   // ---- the path's nodes: end position (Path_t::pathcontig's cur + span) | special << 31, isStatusCnt('T')  (W.cmp is idle after the first compress)
   LC_GLOBAL uint32_t *pend = (LC_GLOBAL uint32_t *)W.cmp;
@@ -4378,24 +4396,24 @@ DEVNI void process_path_walk_wg(Ctx &c, int np, int plen, int L, int complete) {
   const int ncols = wg_bcast(&S.wk_n);
   // ---- the non-match columns
   SUBPHASE(c, 4, 4);
-  for (int c0 = 0; c0 < ncols; c0 += 64) {
+  for (int c0 = 0; c0 < ncols; c0 += CW) {
     WG_FOR(l, LANCET_WG) {
       const int ci = c0 + l;
-      if (ci < ncols) {
+      if (l < CW && ci < ncols) {
         const int i = (int)cols[ci];
         const uint8_t r = ra[i], p = pa[i];
         const uint32_t code = r == '-' ? (uint32_t)'^' : (p == '-' ? (uint32_t)'v' : (uint32_t)'x');
         const uint32_t pos_in_ref = E1[i];
         const int pathpos = (int)(E2[i] + (p != '-' ? 1u : 0u));
-        walk_gather(c, recs + 10 * l, pathpos, pathpos - 1, pos_in_ref + (uint32_t)trim5, plen, np, pend, (uint32_t)i, pos_in_ref, code);
+        walk_gather(c, recs + RS * l, pathpos, pathpos - 1, pos_in_ref + (uint32_t)trim5, plen, np, pend, (uint32_t)i, pos_in_ref, code, LR);
       }
     }
     WG_SYNC();
     WG_LANE0 {
-      const int cnt = ncols - c0 < 64 ? ncols - c0 : 64;
+      const int cnt = ncols - c0 < CW ? ncols - c0 : CW;
       int nts = S.wk_nts, last_col = S.wk_last; char code = (char)S.wk_code, prev_code;
       for (int l = 0; l < cnt && !S.wk_stop; ++l) {
-        volatile LC_LDS uint32_t *rc = recs + 10 * l;
+        volatile LC_LDS uint32_t *rc = recs + RS * l;
         const int i = (int)rc[6], P = (int)rc[7]; const uint32_t pos_in_ref = rc[8], fl = rc[9] & 0xFFu;
         prev_code = (last_col == i - 1) ? code : '=';
         last_col = i; code = (char)(rc[9] >> 8);
@@ -4406,14 +4424,16 @@ DEVNI void process_path_walk_wg(Ctx &c, int np, int plen, int L, int complete) {
         uint16_t ct4[4] = {(uint16_t)rc[2], (uint16_t)(rc[2] >> 16), (uint16_t)rc[3], (uint16_t)(rc[3] >> 16)};
         uint16_t rn2[2] = {(uint16_t)rc[4], (uint16_t)(rc[4] >> 16)}, rt2[2] = {(uint16_t)rc[5], (uint16_t)(rc[5] >> 16)};
         const unsigned rrpos = pos_in_ref + (unsigned)refstart + (unsigned)trim5;
+        HPc ha, hr;
+        if (LR) walk_unpack_hp(rc, ha, hr); else { for (int j = 0; j < 3; ++j) { ha.nh[j] = ha.th[j] = ha.nq[j] = ha.tq[j] = 0; hr.nh[j] = hr.th[j] = hr.nq[j] = hr.tq[j] = 0; } }
         if (nts > 0 && prev_code != '=') {
           auto &t = ts[nts - 1];
           if (within_tumor) t.somatic = true;
           const int reflen_before = t.col1 - t.col0 + 1;
           t.col1 = i; t.end_pos = (uint32_t)P; t.ref_end_pos = pos_in_ref;
-          if (code == '^' && t.code == code && t.pos == rrpos) { ts_add_alt(t, cn4, ct4); }
-          else if (code == 'v' && t.code == code && (t.pos + (unsigned)(reflen_before + 1)) == rrpos) { ts_add_ref(t, rn2, rt2); }
-          else if (code == 'x' || t.code != code) { t.code = 'c'; ts_add_alt(t, cn4, ct4); ts_add_ref(t, rn2, rt2); }
+          if (code == '^' && t.code == code && t.pos == rrpos) { ts_add_alt(t, cn4, ct4); if (LR) ts_hp_add_alt(t, ha); }
+          else if (code == 'v' && t.code == code && (t.pos + (unsigned)(reflen_before + 1)) == rrpos) { ts_add_ref(t, rn2, rt2); if (LR) ts_hp_add_ref(t, hr); }
+          else if (code == 'x' || t.code != code) { t.code = 'c'; ts_add_alt(t, cn4, ct4); ts_add_ref(t, rn2, rt2); if (LR) { ts_hp_add_alt(t, ha); ts_hp_add_ref(t, hr); } }
         } else {
           int pr = i - 1, pq = i - 1;
           while (pr >= 0 && ra[pr] != 'A' && ra[pr] != 'C' && ra[pr] != 'G' && ra[pr] != 'T') --pr;
@@ -4426,8 +4446,7 @@ DEVNI void process_path_walk_wg(Ctx &c, int np, int plen, int L, int complete) {
           t.col0 = i; t.col1 = i; t.somatic = within_tumor; t.prev_bp_ref = (char)ra[pr]; t.prev_bp_alt = (char)pa[pq];
           for (int q = 0; q < 4; ++q) { acc_init(t.aN[q], cn4[q]); acc_init(t.aT[q], ct4[q]); }
           for (int q = 0; q < 2; ++q) { acc_init(t.rN[q], rn2[q]); acc_init(t.rT[q], rt2[q]); }
-          HPc z; for (int j = 0; j < 3; ++j) { z.nh[j] = z.th[j] = z.nq[j] = z.tq[j] = 0; }
-          ts_hp_init(t, z, z);
+          ts_hp_init(t, ha, hr);                                          // (zeros without --linked-reads)
         }
       }
       S.wk_nts = nts; S.wk_last = last_col; S.wk_code = (int)code;
@@ -4444,31 +4463,35 @@ DEVNI void process_path_walk_wg(Ctx &c, int np, int plen, int L, int complete) {
     WG_LANE0 { const auto &t = ts[ti]; S.wk_code = (int)t.code; S.wk_tend = (int)t.end_pos; S.wk_tref = (int)t.ref_end_pos; S.wk_stop = 0; }
     if ((char)wg_bcast(&S.wk_code) != 'x') {
       const int tend = wg_bcast(&S.wk_tend), tref = wg_bcast(&S.wk_tref);
-      for (int j0 = 0; j0 <= K; j0 += 64) {
+      for (int j0 = 0; j0 <= K; j0 += CW) {
         WG_FOR(l, LANCET_WG) {
           const int j = j0 + l;
-          if (j <= K) {
+          if (l < CW && j <= K) {
             const unsigned idx1 = (unsigned)tend + (unsigned)j;
             // (idx1 >= plen: the path contributes nothing at this position, the reference still does)
             // contig_at(idx1) and coverage[idx1]: the node search is made for idx1 itself here (not idx1 + 1 as in the column walk)
-            walk_gather(c, recs + 10 * l, (int)idx1, idx1 < (unsigned)plen ? (int)idx1 : -1, (uint32_t)tref + (uint32_t)trim5 + (uint32_t)j, plen, np, pend, (uint32_t)j, idx1 < (unsigned)plen ? 1u : 0u, 0u);
+            walk_gather(c, recs + RS * l, (int)idx1, idx1 < (unsigned)plen ? (int)idx1 : -1, (uint32_t)tref + (uint32_t)trim5 + (uint32_t)j, plen, np, pend, (uint32_t)j, idx1 < (unsigned)plen ? 1u : 0u, 0u, LR);
           }
         }
         WG_SYNC();
         WG_LANE0 {
           auto &t = ts[ti];
-          const int cnt = K + 1 - j0 < 64 ? K + 1 - j0 : 64;
+          const int cnt = K + 1 - j0 < CW ? K + 1 - j0 : CW;
           for (int l = 0; l < cnt; ++l) {
-            volatile LC_LDS uint32_t *rc = recs + 10 * l;
+            volatile LC_LDS uint32_t *rc = recs + RS * l;
+            HPc ha, hr;
+            if (LR) walk_unpack_hp(rc, ha, hr);
             if (rc[8]) {                                                   // idx1 < plen
               if (rc[9] & 2u) { S.wk_stop = 1; break; }                    // contig_at == NIL: the reference leaves the loop over j
               if (rc[9] & 1u) t.somatic = true;
               uint16_t cn4[4] = {(uint16_t)rc[0], (uint16_t)(rc[0] >> 16), (uint16_t)rc[1], (uint16_t)(rc[1] >> 16)};
               uint16_t ct4[4] = {(uint16_t)rc[2], (uint16_t)(rc[2] >> 16), (uint16_t)rc[3], (uint16_t)(rc[3] >> 16)};
               ts_add_alt(t, cn4, ct4);
+              if (LR) ts_hp_add_alt(t, ha);
             }
             uint16_t rn2[2] = {(uint16_t)rc[4], (uint16_t)(rc[4] >> 16)}, rt2[2] = {(uint16_t)rc[5], (uint16_t)(rc[5] >> 16)};
             ts_add_ref(t, rn2, rt2);
+            if (LR) ts_hp_add_ref(t, hr);
           }
         }
         if (wg_bcast(&S.wk_stop)) break;
@@ -4484,7 +4507,19 @@ DEVNI void process_path_walk_wg(Ctx &c, int np, int plen, int L, int complete) {
       uint16_t ACTF = x ? t.aT[2].mn : t.aT[0].mn, ACTR = x ? t.aT[3].mn : t.aT[1].mn;
       if (t.somatic) { RCNF = acc_mean(t.rN[0]); RCNR = acc_mean(t.rN[1]); RCTF = acc_mean(t.rT[0]); RCTR = acc_mean(t.rT[1]); ACNF = 0; ACNR = 0; }
       uint16_t cov[8] = {RCNF, RCNR, RCTF, RCTR, ACNF, ACNR, ACTF, ACTR};
-      uint16_t hp12[12]; for (int q = 0; q < 12; ++q) hp12[q] = 0;
+      uint16_t hp12[12]; for (int q = 0; q < 12; ++q) hp12[q] = 0;       // HPRN HPRT HPAN HPAT as {hp1, hp2, hp0} (Graph.cc:1091-1128, 1166-1169; process_path_walk has the same lines)
+      if (LR) {
+        const uint32_t nref = t.rN[0].n;
+        auto mean = [&](uint16_t sum) -> uint16_t { return nref > 0 ? (uint16_t)((float)sum / (float)nref) : (uint16_t)0; };
+        uint16_t RN[3], RT[3], AN[3], AT[3];
+        for (int j = 0; j < 3; ++j) {
+          RN[j] = t.hrmnN[j]; RT[j] = t.hrmnT[j];
+          AN[j] = x ? t.haqN[j] : t.hamnN[j]; AT[j] = x ? t.haqT[j] : t.hamnT[j];
+          if (t.somatic) { RT[j] = mean(t.hrsumT[j]); RN[j] = mean(t.hrsumN[j]); AN[j] = 0; }
+        }
+        const uint16_t v[12] = {RN[1], RN[2], RN[0], RT[1], RT[2], RT[0], AN[1], AN[2], AN[0], AT[1], AT[2], AT[0]};
+        for (int q = 0; q < 12; ++q) hp12[q] = v[q];
+      }
       if (LC_CTX(c).C->evt_cap) {
         evt(c, EV_TS, t.pos, (uint32_t)(t.col1 - t.col0 + 1), ((uint32_t)RCNF << 16) | RCNR, ((uint32_t)RCTF << 16) | RCTR,
             ((uint32_t)ACNF << 16) | ACNR, ((uint32_t)ACTF << 16) | ACTR, ((uint32_t)(uint8_t)t.prev_bp_ref << 8) | (uint8_t)t.prev_bp_alt);
@@ -4695,7 +4730,7 @@ DEVNI void count_ref_path(Ctx &c) {
 #else
       const bool old_walk = false;
 #endif
-      if (wg_uniform(S.LR) || old_walk) {
+      if (old_walk) {
         WG_LANE0 { if (!S.overflow) process_path_walk(c, (int)S.part[4], (int)S.part[5], (int)S.part[7], (int)S.part[1]); }
       } else if (!wg_bcast(&S.overflow)) {
         process_path_walk_wg(c, (int)wg_bcastu(&S.part[4]), (int)wg_bcastu(&S.part[5]), (int)wg_bcastu(&S.part[7]), (int)wg_bcastu(&S.part[1]));
