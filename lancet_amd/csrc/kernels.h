@@ -4730,7 +4730,11 @@ DEVNI void count_ref_path(Ctx &c) {
 #else
       const bool old_walk = false;
 #endif
+#ifdef LANCET_LR_WALK_LANE0                /* (tuning builds: --linked-reads windows on the one-lane walk, as until round 6) */
+      if (old_walk || wg_uniform(S.LR)) {
+#else
       if (old_walk) {
+#endif
         WG_LANE0 { if (!S.overflow) process_path_walk(c, (int)S.part[4], (int)S.part[5], (int)S.part[7], (int)S.part[1]); }
       } else if (!wg_bcast(&S.overflow)) {
         process_path_walk_wg(c, (int)wg_bcastu(&S.part[4]), (int)wg_bcastu(&S.part[5]), (int)wg_bcastu(&S.part[7]), (int)wg_bcastu(&S.part[1]));
