@@ -532,6 +532,261 @@ DEV void repeat_scan_min_t(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL 
   }
   WG_SYNC();
 }
+// The same scan for a string without N (codes 0..3), on two BIT PLANES of the string (bit j of word w of plane q = bit q of the code of
+// base 64 w + j): a lane's shift then walks 64 positions per 64-bit word -- mismatch mask = (P0 ^ P0 >> d) | (P1 ^ P1 >> d), one bit per
+// position, no gaps to skip in ctz / clz -- instead of 32 (the 2-bit form this replaces) or 16, and a long run is sized without loops:
+// the mm + 1 mismatches on either side of it are the top / bottom bits of the 64 positions left / right of the run, cut out of the mask
+// words once (the walk back / forward over the words is kept for the run whose neighbourhood holds fewer: a match run of 60).
+// MM: max_mismatch at compile time (0..3: the lists of mismatches stay in registers), or -1: any mm <= 7.
+// The staging pass raises *bad2 when it meets a code above 3 (string taken from bytes); the caller then runs the 4-bit form.
+DEV uint32_t rs_even16(uint32_t v) {                               // the 16 even bits of v, packed
+  v &= 0x55555555u; v = (v | (v >> 1)) & 0x33333333u; v = (v | (v >> 2)) & 0x0F0F0F0Fu; v = (v | (v >> 4)) & 0x00FF00FFu; v = (v | (v >> 8)) & 0x0000FFFFu;
+  return v;
+}
+DEV int rs_ctz64(unsigned long long x) { return __builtin_ctzll(x); }
+DEV int rs_top64(unsigned long long x) { return 63 - __builtin_clzll(x); }
+#if defined(LANCET_PROF_SCAN) && !defined(LANCET_WAVE_EMU)      /* profiling builds only: when the staging pass and the shift loop of the last scan ended (lane 0) */
+static __shared__ unsigned long long lc_scan_t[4];
+#define RS_PROF(i) do { if (threadIdx.x == 0) lc_scan_t[i] = wall_clock64(); } while (0)
+#else
+#define RS_PROF(i) ((void)0)
+#endif
+template <int MM>
+DEV void repeat_scan_planes(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL const uint8_t *s, int len, int mm_, int rmin, int lf,
+                            volatile LC_LDS int *outE, volatile LC_LDS int *outM, const LC_LDS uint32_t *packed2, volatile LC_LDS int *bad2,
+                            int ra = 0, int rb = 0x7FFFFFFF) {
+  const int mm = MM >= 0 ? MM : mm_;
+  const int nwords = len / 64 + 3;
+  const bool al4 = (((size_t)s) & 3u) == 0;
+  volatile LC_LDS unsigned long long *pl0 = rsbuf, *pl1 = rsbuf + nwords;
+  RS_PROF(0);
+  WG_FOR(w, nwords) {
+    unsigned long long v0 = 0, v1 = 0;
+    if (packed2) {
+      const int nw32 = (len + 15) >> 4;
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t x = 4 * w + t < nw32 ? packed2[4 * w + t] : 0u;
+        v0 |= (unsigned long long)rs_even16(x) << (16 * t); v1 |= (unsigned long long)rs_even16(x >> 1) << (16 * t);
+      }
+    } else if (al4 && 64 * w + 64 <= len) {                        // sixteen aligned 4-byte loads, issued together
+      LC_GLOBAL const uint32_t *q = (LC_GLOBAL const uint32_t *)(s + 64 * w);
+      uint32_t aa[16]; for (int t = 0; t < 16; ++t) aa[t] = q[t];
+      uint32_t any = 0;
+      for (int t = 0; t < 16; ++t) {
+        any |= aa[t];
+        v0 |= (unsigned long long)((((aa[t] & 0x01010101u) * 0x00204081u) >> 21) & 0xFu) << (4 * t);
+        v1 |= (unsigned long long)(((((aa[t] >> 1) & 0x01010101u) * 0x00204081u) >> 21) & 0xFu) << (4 * t);
+      }
+      if (any & 0xFCFCFCFCu) *bad2 = 1;
+    } else {
+      for (int j = 0; j < 64; ++j) { const int idx = 64 * w + j; if (idx < len) { const uint32_t cde = s[idx]; if (cde > 3u) *bad2 = 1; v0 |= (unsigned long long)(cde & 1u) << j; v1 |= (unsigned long long)((cde >> 1) & 1u) << j; } }
+    }
+    if (len - 64 * w < 64) { const unsigned long long m = len - 64 * w > 0 ? (1ULL << (len - 64 * w)) - 1ULL : 0ULL; v0 &= m; v1 &= m; }
+    pl0[w] = v0; pl1[w] = v1;
+  }
+  WG_SYNC();
+  if (!packed2 && wg_bcast(bad2)) return;                           // a code above 3: the caller runs the 4-bit form
+  RS_PROF(1);
+  const LC_LDS unsigned long long *P0 = (const LC_LDS unsigned long long *)pl0, *P1 = (const LC_LDS unsigned long long *)pl1;
+  const int nsh = len > 1 ? len - 1 : 0;
+  WG_FOR(it, nsh) {
+    const int d = it + 1;
+    const int lenE = len - 1 - d, lenM = len - d;
+    const int dw = d >> 6, sb = d & 63;
+    // mismatch mask of word w of this shift: bit j set <=> position 64 w + j mismatches (positions >= lenM read as mismatches)
+    auto NE = [&](int w) -> unsigned long long {
+      const int p0 = w << 6;
+      if (p0 >= lenM) return ~0ULL;
+      const int wb = w + dw;
+      const unsigned long long b0 = sb ? ((P0[wb] >> sb) | (P0[wb + 1] << (64 - sb))) : P0[wb];
+      const unsigned long long b1 = sb ? ((P1[wb] >> sb) | (P1[wb + 1] << (64 - sb))) : P1[wb];
+      unsigned long long ne = (P0[w] ^ b0) | (P1[w] ^ b1);
+      if (lenM - p0 < 64) ne |= ~0ULL << (lenM - p0);
+      return ne;
+    };
+    // the mask of the 64 positions [pos, pos + 64), pos >= -64: bit i = position pos + i (positions below 0: clear)
+    auto ctx = [&](int pos) -> unsigned long long {
+      const int w = pos >> 6, sh = pos & 63;
+      const unsigned long long lo = w < 0 ? 0ULL : NE(w);
+      if (!sh) return lo;
+      return (lo >> sh) | (NE(w + 1) << (64 - sh));
+    };
+    auto prev_mis = [&](int pos) -> int {                        // largest mismatch position < pos, or -1
+      int w = (pos - 1) >> 6;
+      if (pos <= 0) return -1;
+      unsigned long long m = NE(w);
+      const int hi = pos - (w << 6);                             // positions [0, hi) of the word
+      if (hi < 64) m &= (1ULL << hi) - 1ULL;
+      while (true) {
+        if (m) return (w << 6) + rs_top64(m);
+        if (--w < 0) return -1;
+        m = NE(w);
+      }
+    };
+    auto next_mis = [&](int pos) -> int {                        // smallest mismatch position > pos, or lenM
+      int w = (pos + 1) >> 6;
+      if (pos + 1 >= lenM) return lenM;
+      unsigned long long m = NE(w);
+      const int lo = pos + 1 - (w << 6);
+      if (lo > 0) m &= ~((1ULL << lo) - 1ULL);
+      while (true) {
+        if (m) { const int q = (w << 6) + rs_ctz64(m); return q < lenM ? q : lenM; }
+        if ((++w << 6) >= lenM) return lenM;
+        m = NE(w);
+      }
+    };
+    int bestE = 0, bestM = 0;
+    auto run_end = [&](int a, int b) {                             // match run [a, b) (MM >= 0: a == b, the start of a window the filter let through)
+      constexpr int NP = MM >= 0 ? MM + 1 : 8;
+      int pv[NP];                                                  // pv[i]: the (i+1)-th mismatch left of a (-1: none)
+      {
+        unsigned long long Lm = ctx(a - 64);
+        const bool at_start = a - 64 <= 0;
+        int q = a; bool inctx = true;
+        for (int i = 0; i < NP; ++i) {
+          if (i <= mm) {
+            if (q >= 0) {
+              if (inctx) {
+                if (Lm) { const int hb = rs_top64(Lm); Lm &= ~(1ULL << hb); q = a - 64 + hb; }
+                else if (at_start) q = -1;
+                else { inctx = false; q = prev_mis(a - 64); }
+              } else q = prev_mis(q);
+            }
+            pv[i] = q;
+          } else pv[i] = -1;
+        }
+      }
+      {
+        unsigned long long Rm = ctx(b);
+        const bool at_end = b + 64 >= lenM;
+        int q = b - 1; bool inctx = true;
+        for (int j = 0; j < NP; ++j) {
+          if (j <= mm) {
+            if (q < lenM) {
+              if (inctx) {
+                if (Rm) { const int lb = rs_ctz64(Rm); Rm &= Rm - 1ULL; q = b + lb; if (q > lenM) q = lenM; }
+                else if (at_end) q = lenM;
+                else { inctx = false; q = next_mis(b + 63); }
+              } else q = next_mis(q);
+            } else q = lenM;
+            if (j == 0) { const int e = (q < lenE ? q : lenE) - (pv[0] + 1); if (e > bestE) bestE = e; }      // the match run between the nearest mismatches either side
+            int left = -1;                                         // pv[mm - j]
+            for (int i = 0; i < NP; ++i) if (i + j == mm) left = pv[i];
+            const int L = q - left - 1; if (L > bestM) bestM = L;
+          }
+        }
+      }
+    };
+    // The walk only NOTES the long runs (a << 16 | b, up to six per shift in registers); they are sized afterwards, all lanes of
+    // the wave together -- sizing a run where it is found would serialise the wave on the lane that found it.
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0; int nc = 0;
+    auto note = [&](int a, int b) {
+      const uint32_t v = ((uint32_t)a << 16) | (uint32_t)b;
+      if (nc == 0) c0 = v; else if (nc == 1) c1 = v; else if (nc == 2) c2 = v; else if (nc == 3) c3 = v; else if (nc == 4) c4 = v; else if (nc == 5) c5 = v;
+      else run_end(a, b);
+      ++nc;
+    };
+    if (MM >= 0) {
+      // ---- The filter walk.  What counts is a window of >= lminM positions with <= mm mismatches or a match run of >= lminE: both hold a
+      // window of lf = min(lminE, lminM, 32) positions with <= mm mismatches.  The number of mismatches among the lf positions from p on is
+      // counted for 64 - lf + 1 values of p at a time, bit-sliced: T[k] bit p = "at least k + 1 mismatches in the window at p", windows of
+      // 1, 2, 4 ... positions doubled and put together along the bits of lf.  A start p that passes is looked at only if position p - 1
+      // mismatches (or p is the first start of the stretch): every maximal window begins behind a mismatch, and inside a long repeat
+      // (mismatches are rare there) the starts would otherwise be counted by the hundred.  On random sequence one shift in fifteen has such
+      // a start (lf = 11, mm = 2); the run walk below met two or three runs of four matches in every shift and sized each of them.
+      constexpr int NL = MM >= 0 ? MM + 1 : 1;
+      constexpr int TOP = MM >= 0 ? MM : 0;
+      const int SV = 64 - lf + 1;                                    // starts per chunk
+      int slo[2] = {0, 0}, shi[2] = {0, lenM};
+      if (ra > 0 || rb < lenM) {                                     // starts whose window of lf positions overlaps [ra, rb) in either copy, the lower stretch first
+        const int a0 = ra - lf + 1 > 0 ? ra - lf + 1 : 0, a1 = rb < lenM ? rb : lenM, b0 = ra - d - lf + 1 > 0 ? ra - d - lf + 1 : 0, b1 = rb - d < lenM ? rb - d : lenM;
+        slo[1] = a0; shi[1] = a1 > a0 ? a1 : a0; slo[0] = b0; shi[0] = b1 > b0 ? b1 : b0;
+        if (shi[0] >= slo[1]) { if (slo[0] < slo[1]) slo[1] = slo[0]; if (shi[0] > shi[1]) shi[1] = shi[0]; shi[0] = slo[0]; }      // (they touch: one stretch)
+      }
+      for (int part = 0; part < 2; ++part) {
+        unsigned long long prevbit = 1ULL;                           // does position base - 1 mismatch?  (the first start of a stretch is always looked at)
+        for (int base = slo[part]; base < shi[part]; base += SV) {
+          unsigned long long x;
+          {
+            const int wa = base >> 6, sa = base & 63, pb = base + d, wb = pb >> 6, sb2 = pb & 63;
+            const unsigned long long a0l = P0[wa], a0h = P0[wa + 1], a1l = P1[wa], a1h = P1[wa + 1], b0l = P0[wb], b0h = P0[wb + 1], b1l = P1[wb], b1h = P1[wb + 1];
+            const unsigned long long a0 = sa ? ((a0l >> sa) | (a0h << (64 - sa))) : a0l, a1 = sa ? ((a1l >> sa) | (a1h << (64 - sa))) : a1l;
+            const unsigned long long b0 = sb2 ? ((b0l >> sb2) | (b0h << (64 - sb2))) : b0l, b1 = sb2 ? ((b1l >> sb2) | (b1h << (64 - sb2))) : b1l;
+            x = (a0 ^ b0) | (a1 ^ b1);
+            if (lenM - base < 64) x |= ~0ULL << (lenM - base);
+          }
+          unsigned long long Pw[NL], Ac[NL];
+          auto combine = [&](unsigned long long (&R)[NL], const unsigned long long (&A)[NL], const unsigned long long (&B)[NL], int sh) {
+            unsigned long long Bs[NL], O[NL];
+            for (int k = 0; k < NL; ++k) Bs[k] = B[k] >> sh;
+            for (int k = 0; k < NL; ++k) { unsigned long long r = A[k] | Bs[k]; for (int i = 0; i < k; ++i) r |= A[i] & Bs[k - 1 - i]; O[k] = r; }
+            for (int k = 0; k < NL; ++k) R[k] = O[k];
+          };
+          for (int k = 0; k < NL; ++k) Pw[k] = 0;
+          Pw[0] = x;
+          bool have = false; int alen = 0;
+          for (int bit = 1; ; bit <<= 1) {
+            if (lf & bit) { if (!have) { for (int k = 0; k < NL; ++k) Ac[k] = Pw[k]; have = true; alen = bit; } else { combine(Ac, Ac, Pw, alen); alen += bit; } }
+            if ((bit << 1) > lf) break;
+            combine(Pw, Pw, Pw, bit);
+          }
+          const int left = shi[part] - base, nv = left < SV ? left : SV;
+          unsigned long long cand = ~Ac[TOP] & ((x << 1) | prevbit) & (nv >= 64 ? ~0ULL : ((1ULL << nv) - 1ULL));
+          prevbit = (x >> (SV - 1)) & 1ULL;
+          while (cand) { const int p = base + rs_ctz64(cand); cand &= cand - 1ULL; note(p, p); }
+        }
+      }
+    }
+    const int nw = MM >= 0 ? 0 : (lenM + 63) >> 6;
+    // the words to walk: all of them, or (a range was given) those of [ra, rb) and of [ra - d, rb - d), the lower stretch first
+    int wlo[2] = {0, 0}, whi[2] = {0, nw};
+    if (MM < 0 && (ra > 0 || rb < lenM)) {
+      const int a0 = ra > 0 ? ra : 0, a1 = rb < lenM ? rb : lenM, b0 = ra - d > 0 ? ra - d : 0, b1 = rb - d < lenM ? rb - d : lenM;
+      wlo[1] = a0 >> 6; whi[1] = a1 > a0 ? (a1 + 63) >> 6 : wlo[1];
+      wlo[0] = b0 >> 6; whi[0] = b1 > b0 ? (b1 + 63) >> 6 : wlo[0];
+      if (whi[0] >= wlo[1]) { if (wlo[0] < wlo[1]) wlo[1] = wlo[0]; if (whi[0] > whi[1]) whi[1] = whi[0]; whi[0] = wlo[0]; }      // (they touch: one stretch)
+      if (whi[1] > nw) whi[1] = nw;
+      if (whi[0] > nw) whi[0] = nw;
+    }
+    int s1 = 1; while (2 * s1 <= rmin) s1 *= 2;                     // (the in-word test for a run of rmin matches: doubling, then the rest)
+    for (int part = 0; part < 2; ++part) {
+      int run = 0;                                                 // matches ending just before the current word (a run that began before the
+                                                                   // stretch counts from the stretch's start: the windows looked for lie inside it)
+      for (int w = wlo[part]; w < whi[part]; ++w) {
+        const unsigned long long ne = NE(w);
+        const int p0 = w << 6;
+        if (ne == 0) { run += 64; continue; }
+        const int q1 = rs_ctz64(ne), ql = rs_top64(ne);
+        if (run + q1 >= rmin) note(p0 - run, p0 + q1);
+        if (rmin <= 62 && ql - q1 > rmin) {                        // a run of >= rmin matches between two mismatches of this word?
+          unsigned long long t = ~ne;
+          for (int h = 1; h < s1; h *= 2) t &= t >> h;
+          if (s1 < rmin) t &= t >> (rmin - s1);
+          t &= ~((2ULL << q1) - 1ULL);                             // starts after the first mismatch ...
+          t &= (1ULL << ql) - 1ULL;                                // ... and before the last one
+          // every set bit of t starts rmin matching positions; the lowest one of a group is where a long run begins, the next
+          // mismatch above it is where it ends: one trip per LONG run
+          while (t) {
+            const int sbit = rs_ctz64(t);                                  // run [sbit, e)
+            const int e = sbit + rs_ctz64(ne >> sbit);                     // (the word's last mismatch is above sbit: not zero)
+            note(p0 + sbit, p0 + e);
+            t = e >= 64 ? 0ULL : (t & ~((1ULL << e) - 1ULL));
+          }
+        }
+        run = 63 - ql;
+      }
+      if (MM < 0 && run >= rmin) { const int e = (whi[part] << 6) < lenM ? (whi[part] << 6) : lenM; note(e - run, e); }   // (a stretch that ends inside a run)
+    }
+    for (int j = 0; j < 6; ++j) {
+      if (j < nc) { const uint32_t v = j == 0 ? c0 : j == 1 ? c1 : j == 2 ? c2 : j == 3 ? c3 : j == 4 ? c4 : c5; run_end((int)(v >> 16), (int)(v & 0xFFFFu)); }
+    }
+    if (bestE > 0) dev_atomic_max((LC_LDS uint32_t *)outE, (uint32_t)bestE);
+    if (bestM > 0) dev_atomic_max((LC_LDS uint32_t *)outM, (uint32_t)bestM);
+  }
+  RS_PROF(2);
+  WG_SYNC();
+  RS_PROF(3);
+}
 // `bits2`: LDS word the 2-bit form may use as its "met an N" flag; null: 4-bit form at once (a string known to hold N)
 DEVNI void repeat_scan_min(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL const uint8_t *s, int len, int mm, int lminE, int lminM,
                            volatile LC_LDS int *outE, volatile LC_LDS int *outM, const LC_LDS uint32_t *packed2 = nullptr, volatile LC_LDS int *bits2 = nullptr,
@@ -542,7 +797,11 @@ DEVNI void repeat_scan_min(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL 
   WG_LANE0 { *outE = 0; *outM = 0; if (bits2) *bits2 = 0; }
   WG_SYNC();
   if (bits2) {
-    repeat_scan_min_t<2>(rsbuf, s, len, mm, rmin, outE, outM, packed2, bits2, ra, rb);
+    int lf = lminE < lminM ? lminE : lminM; if (lf > 32) lf = 32;
+    if (mm == 2 && lf >= 4) repeat_scan_planes<2>(rsbuf, s, len, mm, rmin, lf, outE, outM, packed2, bits2, ra, rb);      // (MAX_MISMATCH's default: the filter walk)
+    else if (mm == 1 && lf >= 4) repeat_scan_planes<1>(rsbuf, s, len, mm, rmin, lf, outE, outM, packed2, bits2, ra, rb);
+    else if (mm == 0 && lf >= 4) repeat_scan_planes<0>(rsbuf, s, len, mm, rmin, lf, outE, outM, packed2, bits2, ra, rb);
+    else repeat_scan_planes<-1>(rsbuf, s, len, mm, rmin, lf, outE, outM, packed2, bits2, ra, rb);
     if (!wg_bcast(bits2)) return;
     WG_LANE0 { *outE = 0; *outM = 0; }
     WG_SYNC();

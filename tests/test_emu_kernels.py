@@ -162,6 +162,45 @@ def test_repeat_scan_long_matches_only_decides_like_the_full_scan():
                     assert max(m.value, k0) == max(m0.value, k0), (len(s), mm, k0, form, m.value, m0.value)
 
 
+def test_repeat_scan_planes_on_planted_near_repeats():
+    """The bit-plane form of repeat_scan_min (round 6: 64 positions per word, a long run sized from the 64 positions either side of it):
+    planted copies with 0..4 substitutions at random places -- runs longer than a word, mismatches on word boundaries, copies that end at
+    the last base -- and low-complexity stretches, against the byte-wise restatement (reference src/util.cc:295-360)."""
+    import ctypes
+    import numpy as np
+    L = emu.lib()
+    f = L.lancet_emu_repeat_scan
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    f.restype = None
+    g = L.lancet_emu_repeat_scan_min
+    g.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    g.restype = None
+    rng = np.random.default_rng(606)
+    for trial in range(160):
+        n = int(rng.choice([70, 128, 129, 191, 192, 257, 600, 640, 1000, 1400]))
+        s = rng.integers(0, 4, size=n).astype(np.uint8)
+        for _ in range(int(rng.integers(1, 4))):
+            ln = int(rng.integers(8, min(200, n // 2)))
+            src = int(rng.integers(0, n - ln)); dst = int(rng.integers(0, n - ln))
+            if rng.random() < 0.3:
+                dst = n - ln                                          # up to the last base
+            seg = s[src:src + ln].copy()
+            for _ in range(int(rng.integers(0, 5))):
+                seg[int(rng.integers(0, ln))] ^= int(rng.integers(1, 4))
+            s[dst:dst + ln] = seg
+        if rng.random() < 0.3:
+            a = int(rng.integers(0, n - 60)); s[a:a + 60] = np.tile(rng.integers(0, 4, size=int(rng.integers(1, 4))).astype(np.uint8), 60)[:60]
+        for mm in (0, 1, 2, 3, 5):
+            e0, m0 = ctypes.c_int(-1), ctypes.c_int(-1)
+            f(s.ctypes.data, n, mm, 0, ctypes.byref(e0), ctypes.byref(m0))
+            for k0 in (5, 11, 13, 31):
+                for form in ((1, 2) if n <= 640 else (1,)):
+                    e, m = ctypes.c_int(-1), ctypes.c_int(-1)
+                    g(s.ctypes.data, n, mm, k0, k0 + 1, ctypes.byref(e), ctypes.byref(m), form)
+                    assert max(e.value, k0 - 1) == max(e0.value, k0 - 1), (trial, n, mm, k0, form, e.value, e0.value)
+                    assert max(m.value, k0) == max(m0.value, k0), (trial, n, mm, k0, form, m.value, m0.value)
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
 def test_emulated_kernels_match_oracle_on_random_cycle_prone_windows(seed):
     """Not reference goldens but oracle-pinned stress: tandem duplications, STR-rich reference, dense variants -- many
