@@ -105,6 +105,7 @@ struct WinShared {
   int nosusp_k;                                  // build service: the k this window was resumed for (no second request for it)
   uint32_t svc_i;                                // ... the request just posted
   int act, act_arg;                              // what the slot does next (window_kernel_body)
+  int gc_ok;                                     // graph_cache_wg: the live nodes' edge lists are in LDS (the staging area)
 };
 
 // The one WinShared of the workgroup.  Functions reach it by name rather than through the pointer in Ctx: a pointer
@@ -3694,6 +3695,120 @@ DEVNI bool has_cycle(Ctx &c, bool colored = false) {                            
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The cleaned graph in LDS (round 6).  After the first compress a component is a dozen unitigs, and hasCycle and the path search walk it
+// on one lane: every step a chain of dependent loads from the node records in HBM (flags, degree, an edge word, the neighbour's flags
+// and colour ...), ~35 us per call for a graph that fits a few cache lines.  graph_cache_wg (all lanes) copies what those walks read --
+// per table position: node id, degree, the edges as (position of the neighbour, direction, "used by an earlier path" flag), string
+// length, the special-node bit -- into the staging area of the per-position pass (idle in the graph phases) with an id -> position
+// table beside it; has_cycle_cached / bfs_cached are has_cycle / bfs on that copy: the same visits in the same order.  A table of more
+// than GC_MAX live nodes (or an edge to a node that is not in the table) takes the HBM walk as before.  The copy is made right before
+// each walk: the passes in between rewrite edge lists, and the repeat scan of a path uses the same LDS.
+// ---------------------------------------------------------------------------------------------------------
+#define GC_MAX 48
+#define GC_HASH 128
+#define GC_OFF_ID 0
+#define GC_OFF_HASH (GC_OFF_ID + 4 * GC_MAX)
+#define GC_OFF_E (GC_OFF_HASH + 4 * GC_HASH)
+#define GC_OFF_LEN (GC_OFF_E + 2 * 12 * GC_MAX)
+#define GC_OFF_NE (GC_OFF_LEN + 2 * GC_MAX)
+#define GC_OFF_FL (GC_OFF_NE + GC_MAX)
+#define GC_OFF_COL (GC_OFF_FL + GC_MAX)
+#define GC_OFF_ST (GC_OFF_COL + GC_MAX)
+#define GC_BYTES (GC_OFF_ST + 3 * (GC_MAX + 2))
+#define GC_TPOS(e) ((uint32_t)(e) & 63u)
+#define GC_DIR(e) (((uint32_t)(e) >> 6) & 3u)
+#define GC_FLAG(e) (((uint32_t)(e) >> 8) & 1u)
+DEV uint32_t gc_lookup(const volatile LC_LDS uint32_t *ids, const volatile LC_LDS uint32_t *hash, uint32_t id) {   // position of node id in the table order, or LC_NIL
+  uint32_t h = (id * 0x9E3779B1u) >> 25;
+  for (int t = 0; t < GC_HASH; ++t) {
+    const uint32_t v = hash[h];
+    if (v == 0u) return LC_NIL;
+    if (ids[v - 1u] == id) return v - 1u;
+    h = (h + 1u) & (GC_HASH - 1u);
+  }
+  return LC_NIL;
+}
+DEVNI bool graph_cache_wg(Ctx &c) {
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  static_assert(GC_BYTES <= (int)sizeof(S.lbytes) && GC_MAX <= 64 && (GC_HASH & (GC_HASH - 1)) == 0 && GC_HASH >= 2 * GC_MAX, "graph cache in the staging area");
+  const int M = (int)wg_bcastu(&S.M);
+  if (M > GC_MAX || M < 1) return false;
+  volatile LC_LDS uint8_t *base = &S.lbytes[0];
+  volatile LC_LDS uint32_t *ids = (volatile LC_LDS uint32_t *)(base + GC_OFF_ID), *hash = (volatile LC_LDS uint32_t *)(base + GC_OFF_HASH);
+  volatile LC_LDS uint16_t *ge = (volatile LC_LDS uint16_t *)(base + GC_OFF_E), *glen = (volatile LC_LDS uint16_t *)(base + GC_OFF_LEN);
+  volatile LC_LDS uint8_t *gne = base + GC_OFF_NE, *gfl = base + GC_OFF_FL;
+  WG_FOR(i, GC_HASH) { hash[i] = 0u; }
+  WG_LANE0 { S.gc_ok = 1; }
+  WG_FOR(i, M) {
+    const uint32_t id = W.order[i];
+    ids[i] = id;
+    uint32_t h = (id * 0x9E3779B1u) >> 25;
+    while (dev_atomic_cas32((LC_LDS uint32_t *)&hash[h], 0u, (uint32_t)i + 1u) != 0u) h = (h + 1u) & (GC_HASH - 1u);
+  }
+  WG_SYNC();
+  WG_FOR(i, M) {
+    const uint32_t id = ids[i];
+    LC_GLOBAL const NodeGr *g = &W.gr[id];
+    const GrLine0 G = gr_line0(g);
+    const lc_u4 h1 = ldg4((LC_GLOBAL const uint32_t *)g + 20);          // mincov mincovqv seq_lo seq_hi
+    const bool sp = (G.flags & NF_SPECIAL) != 0;
+    const uint32_t len = sp ? 0u : h1.w - h1.z;
+    bool ok = G.necnt <= 12u && len <= 0xFFFFu;
+#define LC_X(j, e) do { if ((uint32_t)(j) < G.necnt) { const uint32_t tp = gc_lookup(ids, hash, ED_TO(e)); if (tp == LC_NIL) ok = false; \
+                        ge[12 * i + (j)] = (uint16_t)((tp & 63u) | (ED_DIR(e) << 6) | (ED_FLAG(e) << 8)); } } while (0)
+    LC_L0_EACH(G, LC_X);
+#undef LC_X
+    gne[i] = (uint8_t)G.necnt; gfl[i] = sp ? 1 : 0; glen[i] = (uint16_t)len;
+    if (!ok) S.gc_ok = 0;
+  }
+  return wg_bcast(&S.gc_ok) != 0;
+}
+// has_cycle on the copy (lane 0): colours and the stack of (position, next edge, direction) in LDS too
+DEVNI bool has_cycle_cached(Ctx &c) {
+  LC_WS &S = LC_SREF(c);
+  if (S.source == LC_NIL || S.sink == LC_NIL) return false;
+  volatile LC_LDS uint8_t *base = &S.lbytes[0];
+  const volatile LC_LDS uint32_t *ids = (const volatile LC_LDS uint32_t *)(base + GC_OFF_ID), *hash = (const volatile LC_LDS uint32_t *)(base + GC_OFF_HASH);
+  const volatile LC_LDS uint16_t *ge = (const volatile LC_LDS uint16_t *)(base + GC_OFF_E);
+  const volatile LC_LDS uint8_t *gne = base + GC_OFF_NE, *gfl = base + GC_OFF_FL;
+  volatile LC_LDS uint8_t *col = base + GC_OFF_COL, *st = base + GC_OFF_ST;
+  const int M = (int)S.M;
+  for (int i = 0; i < M; ++i) col[i] = gfl[i] ? 0 : 1;
+  const uint32_t src = gc_lookup(ids, hash, S.source);
+  if (src == LC_NIL) return false;                                  // (the source is in the table whenever it exists)
+  bool ans = false;
+  for (int pass = 0; pass < 2 && !ans; ++pass) {
+    int sp = 0;
+    st[0] = (uint8_t)src; st[1] = 0; st[2] = (uint8_t)(pass == 0 ? 'F' : 'R'); sp = 1;
+    col[src] = 2;
+    while (sp && !ans) {
+      volatile LC_LDS uint8_t *fr = st + 3 * (sp - 1);
+      const uint32_t node = fr[0]; const char dir = (char)fr[2];
+      bool descended = false;
+      uint32_t ei = fr[1]; const uint32_t ne = gne[node];
+      while (ei < ne) {
+        const uint32_t e = ge[12 * node + ei]; ++ei;
+        if (!is_dir(GC_DIR(e), dir)) continue;
+        const uint32_t other = GC_TPOS(e);
+        if (gfl[other]) continue;
+        const uint32_t oc = col[other];
+        if (oc == 2) { ans = true; break; }
+        if (oc == 1) {
+          col[other] = 2;
+          fr[1] = (uint8_t)ei;
+          volatile LC_LDS uint8_t *nf = st + 3 * sp; nf[0] = (uint8_t)other; nf[1] = 0; nf[2] = (uint8_t)dir_dest(GC_DIR(e)); ++sp;
+          descended = true; break;
+        }
+      }
+      if (ans) break;
+      if (!descended) { col[node] = 3; --sp; }
+    }
+  }
+  if (ans) evt(c, EV_CYCLE, S.K);
+  return ans;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // path enumeration: Graph_t::bfs (reference src/Graph.cc:1299-1425), a FIFO over whole paths.  Paths are
 // queue entries with parent links; the winner is the first-dequeued path with the most unflagged edges.
 // Returns queue index of the best path or LC_NIL.
@@ -3737,6 +3852,57 @@ DEVNI uint32_t bfs(Ctx &c) {
         ne.len = cur.len + n_strlen(c, other) - S.K + 1;
         uint32_t ef = ED_FLAG(e);
         ne.bits = (uint8_t)(((cur.bits & 1) & ef) | (Q[idx].bits & 2));
+        ne.score = (uint16_t)(cur.score + (ef == 0 ? 1 : 0));
+        Q[qt++] = ne;
+      }
+    }
+  }
+  if (complete == 0) best = LC_NIL;
+  return best;
+}
+// bfs on the copy graph_cache_wg made (lane 0): the queue stays where it is, what an expansion reads of the graph comes out of LDS
+DEVNI uint32_t bfs_cached(Ctx &c) {
+  LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
+  LC_GLOBAL BfsEntry *Q = W.queue;
+  const uint32_t cap = LC_CTX(c).C->queue_cap;
+  volatile LC_LDS uint8_t *base = &S.lbytes[0];
+  const volatile LC_LDS uint32_t *ids = (const volatile LC_LDS uint32_t *)(base + GC_OFF_ID), *hash = (const volatile LC_LDS uint32_t *)(base + GC_OFF_HASH);
+  const volatile LC_LDS uint16_t *ge = (const volatile LC_LDS uint16_t *)(base + GC_OFF_E), *glen = (const volatile LC_LDS uint16_t *)(base + GC_OFF_LEN);
+  const volatile LC_LDS uint8_t *gne = base + GC_OFF_NE;
+  const int reflen = S.seq_len, K = S.K;
+  const int max_indel = LC_CTX(c).P->max_indel_len, dfs_limit = LC_CTX(c).P->dfs_limit;
+  const uint32_t sink = S.sink;
+  uint32_t qh = 0, qt = 0;
+  const bool tracing = LC_CTX(c).C->evt_cap != 0;
+  S.bfs_dfs = 0;
+  Q[qt].parent = LC_NIL; Q[qt].node = S.source; Q[qt].edge = LC_NIL; Q[qt].len = K; Q[qt].score = 0; Q[qt].dir = 'F'; Q[qt].bits = 1; ++qt;
+  uint32_t best = LC_NIL; int complete = 0; int visit = 0; uint32_t best_score = 0;
+  while (qh < qt) {
+    ++visit;
+    if (dfs_limit && visit > dfs_limit) { evt(c, EV_DFSLIMIT); S.bfs_dfs = 1; break; }
+    const uint32_t idx = qh++;
+    const BfsEntry cur = Q[idx];
+    if (cur.node == sink && (cur.bits & 1) == 0) {
+      ++complete;
+      if (best == LC_NIL || cur.score > best_score) { best = idx; best_score = cur.score; }
+    } else if (cur.len > reflen + max_indel) {
+    } else {
+      const uint32_t pos = gc_lookup(ids, hash, cur.node);
+      if (pos == LC_NIL) { OVF(c); return LC_NIL; }                   // (cannot happen: every queue entry's node came out of the table)
+      const int cnt = (int)gne[pos];
+      uint8_t bits2 = cur.bits & 2;
+      for (int i = 0; i < cnt; ++i) {
+        const uint32_t e = ge[12 * pos + (uint32_t)i];
+        if (!is_dir(GC_DIR(e), (char)cur.dir)) continue;
+        const uint32_t tp = GC_TPOS(e), other = ids[tp];
+        // Path_t::hasCycle: only ever printed (see bfs)
+        if (tracing && !bits2 && path_has_node(c, idx, other)) { bits2 = 2; Q[idx].bits |= 2; }
+        if (qt >= cap) { OVF(c); return LC_NIL; }
+        BfsEntry ne;
+        ne.parent = idx; ne.node = other; ne.edge = (cur.node << 4) | (uint32_t)i; ne.dir = (uint8_t)dir_dest(GC_DIR(e));
+        ne.len = cur.len + (int)glen[tp] - K + 1;
+        const uint32_t ef = GC_FLAG(e);
+        ne.bits = (uint8_t)(((cur.bits & 1) & ef) | bits2);
         ne.score = (uint16_t)(cur.score + (ef == 0 ? 1 : 0));
         Q[qt++] = ne;
       }
@@ -4854,8 +5020,9 @@ DEVNI bool repeats_in_graph_paths(Ctx &c) {
   }
   while (wg_bcast(&S.tmp0) == 0) {
     SUBPHASE(c, 3, 2);
+    const bool gcached = graph_cache_wg(c);                           // (again for every path: the path before flagged its edges, and the scan below uses the same LDS)
     WG_LANE0 {
-      uint32_t best = bfs(c);
+      uint32_t best = gcached ? bfs_cached(c) : bfs(c);
       if (best == LC_NIL || S.overflow) { S.tmp0 = 1; S.pc_end_dfs = S.bfs_dfs; }
       else { S.tmp2 = path_unpack(c, best); S.pc_bits = (W.queue[best].bits & 2) ? 1 : 0; S.pc_dfs = S.bfs_dfs; }
     }
@@ -5517,12 +5684,13 @@ DEV void process_window(Ctx &c, int w, int rq = -1) {
       }
       SUBPHASE(c, 1, 15);
       if (wg_bcast(&S.tmp2)) compact_absorbed_wg(c);
+      PHASE(c, 9);
+      SUBPHASE(c, 2, 4);
+      const bool gcached = graph_cache_wg(c);                         // (all lanes: the component's edge lists into LDS for the walk below)
       WG_LANE0 {
         const uint32_t dead = (uint32_t)S.tmp1;
-        PHASE(c, 9);
-        SUBPHASE(c, 2, 4);
         S.tmp0 = 0;
-        if (!S.overflow && has_cycle(c)) S.tmp0 = 1;
+        if (!S.overflow && (gcached ? has_cycle_cached(c) : has_cycle(c))) S.tmp0 = 1;
         if (!S.tmp0 && !S.overflow) {
           evt(c, EV_COMPRESS); evt(c, EV_CLEANDEAD, dead);
           print_stats(c, comp);
@@ -5537,7 +5705,7 @@ DEV void process_window(Ctx &c, int w, int rq = -1) {
         SUBPHASE(c, 2, 7);
         if (!wg_bcast(&S.overflow)) remove_short_links_wg(c, comp);
         SUBPHASE(c, 2, 4);
-        WG_LANE0 { if (!S.overflow && has_cycle(c)) S.tmp0 = 1; }
+        { const bool gc2 = graph_cache_wg(c); WG_LANE0 { if (!S.overflow && (gc2 ? has_cycle_cached(c) : has_cycle(c))) S.tmp0 = 1; } }
         SUBPHASE(c, 2, 9);
       }
       if (wg_bcast(&S.overflow)) break;
