@@ -106,6 +106,7 @@ struct WinShared {
   uint32_t svc_i;                                // ... the request just posted
   int act, act_arg;                              // what the slot does next (window_kernel_body)
   int gc_ok;                                     // graph_cache_wg: the live nodes' edge lists are in LDS (the staging area)
+  uint32_t cn_mn, cn_mq;                         // compress_node_wv: minima over the descriptors a merge appends
 };
 
 // The one WinShared of the workgroup.  Functions reach it by name rather than through the pointer in Ctx: a pointer
@@ -3379,9 +3380,132 @@ DEVNI void clean_dead_flags_wg(Ctx &c, bool quiet) {
   WG_LANE0 { S.M = (uint32_t)live; S.ht_elt -= (uint32_t)(M - live); if (!quiet) evt(c, EV_CLEANDEAD, (uint32_t)(M - live)); }
   WG_SYNC();
 }
+// Graph_t::compressNode (reference src/Graph.cc:2486-2706) by the whole wave (round 6; the single-wave window kernel only).  The merges of
+// the passes that follow the first compress join unitigs of a hundred k-mers and more: compress_node copies the absorbed node's
+// descriptors one by one and looks up the coverage minima behind each -- a load, a store and three dependent loads per descriptor on
+// one lane, ~100 us of the ~120 us removeTips took per window.  Here every lane runs the node-level logic on the same values (uniform
+// loads of the two records; only lane 0 stores), and the loops over descriptors -- the copy, the minima, the move of a deque that has
+// no room left -- are shared out over the lanes.  Same merges in the same order, same float operations per merge.
+DEV int l0_buddy_idx(const GrLine0 &g, uint32_t self, char dir) {      // get_buddy on the registers: index of the one edge in direction dir, or -1
+  if (g.flags & NF_SPECIAL) return -1;
+  int ret = -1, cnt = 0; uint32_t ew = 0;
+#define LC_X(i, e) do { if ((uint32_t)(i) < g.necnt && is_dir(ED_DIR(e), dir)) { if (cnt == 0) { ret = (i); ew = (e); } ++cnt; } } while (0)
+  LC_L0_EACH(g, LC_X);
+#undef LC_X
+  if (cnt != 1 || ED_TO(ew) == self) return -1;
+  return ret;
+}
+DEV uint32_t l0_edge(const GrLine0 &g, int idx) {
+  uint32_t r = 0;
+#define LC_X(i, e) do { if ((i) == idx) r = (e); } while (0)
+  LC_L0_EACH(g, LC_X);
+#undef LC_X
+  return r;
+}
+#ifndef LANCET_FAT
+DEVNI void compress_node_wv(Ctx &c, uint32_t node, char dir) {
+  LC_GLOBAL Work &W = *LC_CTX(c).W; LC_WS &S = LC_SREF(c);
+  const int K = wg_uniform(S.K);
+#ifndef LANCET_WAVE_EMU
+  const bool l0 = wg_is_lane0();
+#else
+  const bool l0 = true;
+#endif
+  while (!wg_uniform(S.overflow)) {
+    LC_GLOBAL NodeGr *gn = &W.gr[node];
+    const GrLine0 G = gr_line0(gn);
+    const int uid = wg_uniform(l0_buddy_idx(G, node, dir));
+    if (uid == -1) return;
+    if (wg_uniform((int)l0_tandem(G, node))) return;
+    const uint32_t ew = (uint32_t)wg_uniform((int)l0_edge(G, uid));
+    const uint32_t edir = ED_DIR(ew);
+    const char bdir = (edir == 0 || edir == 2) ? 'R' : 'F';
+    const uint32_t buddy = ED_TO(ew);
+    LC_GLOBAL NodeGr *gb = &W.gr[buddy];
+    const GrLine0 B = gr_line0(gb);
+    if (wg_uniform((int)l0_tandem(B, buddy))) return;
+    const int buid = wg_uniform(l0_buddy_idx(B, buddy, bdir));
+    if (buid == -1) return;
+    const bool brev = dir_dest(edir) == 'R';
+    // second halves of the two records: cov[4] | mincov mincovqv seq_lo seq_hi | seq_clo seq_chi nkm nkmT
+    const lc_u4 nc4 = ldg4((LC_GLOBAL const uint32_t *)gn + 16), nm4 = ldg4((LC_GLOBAL const uint32_t *)gn + 20), ns4 = ldg4((LC_GLOBAL const uint32_t *)gn + 24);
+    const lc_u4 bc4 = ldg4((LC_GLOBAL const uint32_t *)gb + 16), bm4 = ldg4((LC_GLOBAL const uint32_t *)gb + 20), bs4 = ldg4((LC_GLOBAL const uint32_t *)gb + 24);
+    uint32_t lo = (uint32_t)wg_uniform((int)nm4.z), hi = (uint32_t)wg_uniform((int)nm4.w), clo = (uint32_t)wg_uniform((int)ns4.x), chi = (uint32_t)wg_uniform((int)ns4.y);
+    const uint32_t blo = (uint32_t)wg_uniform((int)bm4.z), bhi = (uint32_t)wg_uniform((int)bm4.w);
+    const int alen = (int)(hi - lo), blen = (int)(bhi - blo);
+    const uint32_t tail = (uint32_t)(blen - (K - 1));
+    // seq_reserve: room for `tail` more descriptors behind (dir F) / in front (dir R); else the deque moves to the top of the arena
+    {
+      const uint32_t front = dir == 'F' ? 0u : tail, back = dir == 'F' ? tail : 0u;
+      if (!(lo - clo >= front && chi - hi >= back)) {
+        const uint32_t len = hi - lo, cap = 2 * (len + front + back) + 16;
+        const uint32_t top = (uint32_t)wg_uniform((int)S.seq_top);
+        if (top + cap > LC_CTX(c).C->seq_cap) { if (l0) OVF(c); return; }
+        const uint32_t nlo = top + (cap - len - front - back) / 2 + front;
+        WG_FOR(i, len) { W.seq[nlo + (uint32_t)i] = W.seq[lo + (uint32_t)i]; }
+        if (l0) { S.seq_top = top + cap; gn->seq_clo = top; gn->seq_chi = top + cap; }
+        clo = top; chi = top + cap; lo = nlo; hi = nlo + len;
+      }
+    }
+    // merged = astr + bstr[K-1:]  (dir F: append ; dir R: prepend the reverse complement), and Node_t::computeMinCov over what is appended
+    if (l0) { S.cn_mn = nm4.x; S.cn_mq = nm4.y; }
+    {
+      uint32_t mn = 0x7FFFFFFFu, mq = 0x7FFFFFFFu;
+      WG_FOR(t, tail) {
+        uint32_t d = brev ? W.seq[bhi - 1 - ((uint32_t)(K - 1) + (uint32_t)t)] : W.seq[blo + (uint32_t)(K - 1) + (uint32_t)t];
+        if (brev) d ^= 3u;
+        if (dir == 'F') W.seq[hi + (uint32_t)t] = d; else { d ^= 3u; W.seq[lo - 1 - (uint32_t)t] = d; }
+        int tt, tq; desc_tot(c, d, &tt, &tq);
+        if ((uint32_t)tt < mn) mn = (uint32_t)tt;
+        if ((uint32_t)tq < mq) mq = (uint32_t)tq;
+      }
+      WG_FOR(l, LANCET_WG) { if (mn != 0x7FFFFFFFu) { dev_atomic_min((LC_LDS uint32_t *)&S.cn_mn, mn); dev_atomic_min((LC_LDS uint32_t *)&S.cn_mq, mq); mn = 0x7FFFFFFFu; } }
+    }
+    const uint32_t nmn = (uint32_t)wg_uniform((int)S.cn_mn), nmq = (uint32_t)wg_uniform((int)S.cn_mq);
+    const int amer = alen - K + 1, bmer = blen - K + 1;
+    if (l0) {
+      if (dir == 'F') gn->seq_hi = hi + tail; else gn->seq_lo = lo - tail;
+      if (dir == 'F') { if (lo != nm4.z) gn->seq_lo = lo; } else { if (hi != nm4.w) gn->seq_hi = hi; }      // (the deque moved)
+      gn->mincov = (int)nmn; gn->mincovqv = (int)nmq;
+      gn->nkm = ns4.z + bs4.z; gn->nkmT = ns4.w + bs4.w;
+      const float ncv[4] = {__builtin_bit_cast(float, nc4.x), __builtin_bit_cast(float, nc4.y), __builtin_bit_cast(float, nc4.z), __builtin_bit_cast(float, nc4.w)};
+      const float bcv[4] = {__builtin_bit_cast(float, bc4.x), __builtin_bit_cast(float, bc4.y), __builtin_bit_cast(float, bc4.z), __builtin_bit_cast(float, bc4.w)};
+      for (int q = 0; q < 4; ++q) gn->cov[q] = ((ncv[q] * amer) + (bcv[q] * bmer)) / (amer + bmer);      // Graph.cc:2632-2636
+      gb->flags = B.flags | NF_DEAD;
+      gn->flags = G.flags | (B.flags & (NF_TUMOR | NF_NORMAL));
+      erase_edge_at(c, node, uid);
+      const int bcnt = (int)B.necnt;
+      for (int i = 0; i < bcnt; ++i) {
+        if (i == buid) continue;
+        const uint32_t be = l0_edge(B, i);
+        uint32_t ndir = ED_DIR(be);
+        if (edir == 1 || edir == 2) ndir = flipme(ndir);
+        const uint32_t other = ED_TO(be);
+        const int cnt = (int)gn->necnt;
+        if (cnt >= LC_EMAX) { OVF(c); break; }
+        if (other == buddy) { gn->edges[cnt] = ED_MAKE(node, ndir) | (be & (1u << 30)); gn->necnt = cnt + 1; }
+        else {
+          gn->edges[cnt] = ED_MAKE(other, ndir) | (be & (1u << 30)); gn->necnt = cnt + 1;
+          update_edge(c, other, buddy, fliplink(ED_DIR(be)), node, fliplink(ndir));
+        }
+      }
+    }
+  }
+}
+#endif
 DEVNI void compress_wg(Ctx &c, int comp) {                            // Graph_t::compress, reference src/Graph.cc:2712-2732
   LC_WS &S = LC_SREF(c); LC_GLOBAL Work &W = *LC_CTX(c).W;
   const int nc = pass_candidates_wg(c, comp, GP_MERGE);
+#ifndef LANCET_FAT
+  WG_LANE0 { S.tmp2 = 0; evt(c, EV_COMPRESS); }
+  for (int j = 0; j < nc && !wg_uniform(S.overflow); ++j) {          // (every lane runs the merges: compress_node_wv)
+    const uint32_t n = (uint32_t)wg_uniform((int)W.pedges[j]);
+    if (wg_uniform((int)W.gr[n].flags) & NF_DEAD) continue;
+    compress_node_wv(c, n, 'F');
+    compress_node_wv(c, n, 'R');
+  }
+  WG_SYNC();
+#else
   WG_LANE0 {
     S.tmp2 = 0;
     evt(c, EV_COMPRESS);
@@ -3392,6 +3516,7 @@ DEVNI void compress_wg(Ctx &c, int comp) {                            // Graph_t
       compress_node(c, n, 'R');
     }
   }
+#endif
   clean_dead_flags_wg(c, false);
 }
 DEVNI void remove_low_cov_wg(Ctx &c, int comp) {                      // reference src/Graph.cc:2790-2827 (docompression=true)
