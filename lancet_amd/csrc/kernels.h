@@ -3187,7 +3187,8 @@ DEVNI void remove_low_cov(Ctx &c, int comp) {                         // referen
 // i0 every unit is a whole one and the end-of-string rule of the reference cannot fire), and left as soon as every stretch in
 // progress starts right of pos + delta.  ~200 character comparisons instead of ~10 000 for a 600-base path; same order of the
 // reports (the reference appends every reported motif and keeps the last length).
-DEVNI bool find_tandems_local(const Ctx &c, LC_GLOBAL const uint8_t *seq, int n, int pos, int *len, uint8_t *motif, int *motif_len) {
+DEVNI bool find_tandems_local(const Ctx &c, LC_GLOBAL const uint8_t *seq, int n, int pos, int *len, uint8_t *motif, int *motif_len,
+                               const volatile LC_LDS uint8_t *stg = nullptr, int stg_lo = 0, int stg_hi = 0) {      // stg: seq[stg_lo .. stg_hi) in LDS (the caller's copy; every character is read a dozen times)
   const unsigned MAXU = (unsigned)LC_CTX(c).P->max_unit_len, MRU = (unsigned)LC_CTX(c).P->min_report_units, MRL = (unsigned)LC_CTX(c).P->min_report_len;
   const int delta = LC_CTX(c).P->dist_from_str;
   bool ans = false;
@@ -3195,7 +3196,7 @@ DEVNI bool find_tandems_local(const Ctx &c, LC_GLOBAL const uint8_t *seq, int n,
   const unsigned MU = MAXU < 8 ? MAXU : 8;
   int i0 = pos - delta - (int)MU; if (i0 < 0) i0 = 0;
   if (i0 > n) i0 = n;
-#define LC_SEQ(i) ((int)seq[(i)])
+#define LC_SEQ(i) (((int)(i) >= stg_lo && (int)(i) < stg_hi) ? (int)stg[(int)(i) - stg_lo] : (int)seq[(i)])
   // (the stretch starts are indexed at run time: in LDS -- the staging area of the per-position pass is idle in the graph phases -- an
   //  indexed local array would live in scratch memory)
 #ifndef LANCET_WAVE_EMU
@@ -4086,6 +4087,48 @@ DEVNI int path_string_wg(Ctx &c, int n) {
   const int K = S.K;
   const int dcap = 7 * ((int)LC_CTX(c).C->max_w + 2);
   if (2 * (n + 1) > dcap || n < 2) { WG_LANE0 { S.ps_len = path_string(c, n); } return wg_bcast(&S.ps_len); }
+  if (n <= 64) {
+    // (round 6) a path of up to 64 nodes -- all but the odd one: what the per-base loop looks up per node (offset in the string, deque bounds,
+    // direction) is staged in LDS (the staging area of the per-position pass, idle here) by one lane per node; a base then costs a binary search
+    // in LDS and ONE load from the descriptor arena instead of the ~8 dependent loads from HBM of the form below.  Same string, same descriptors.
+    volatile LC_LDS uint8_t *lb = &S.lbytes[0];
+    volatile LC_LDS uint32_t *loff = (volatile LC_LDS uint32_t *)lb, *llen = loff + 66, *lslo = llen + 64, *lshi = lslo + 64;
+    volatile LC_LDS uint8_t *ldir = (volatile LC_LDS uint8_t *)(lshi + 64);
+    static_assert(4 * (66 + 3 * 64) + 64 <= (int)sizeof(S.lbytes), "path nodes staged in LDS");
+    WG_LANE0 { S.ps_first = 0x7FFFFFFF; }
+    WG_FOR(i, n) {
+      const uint32_t nd = W.pnodes[i];
+      const uint32_t pe = W.pedges[i == 0 ? 1 : i];
+      LC_GLOBAL const uint32_t *g = (LC_GLOBAL const uint32_t *)&W.gr[nd];
+      const uint32_t fl = g[0]; const lc_u4 h1 = ldg4(g + 20);         // mincov mincovqv seq_lo seq_hi
+      const uint32_t e = W.gr[pe >> 4].edges[pe & 15u];
+      const bool sp = (fl & NF_SPECIAL) != 0;
+      if (!sp) dev_atomic_min((LC_LDS uint32_t *)&S.ps_first, (uint32_t)i);
+      ldir[i] = (uint8_t)(i == 0 ? dir_start(ED_DIR(e)) : dir_dest(ED_DIR(e)));
+      lslo[i] = h1.z; lshi[i] = h1.w; llen[i] = sp ? 0xFFFFFFFFu : h1.w - h1.z;
+    }
+    WG_SYNC();
+    const int f = wg_uniform(S.ps_first);
+    WG_FOR(i, n + 1) {
+      uint32_t sum = 0;
+      for (int j = 0; j < i; ++j) { const uint32_t L = llen[j]; if (L != 0xFFFFFFFFu) sum += (j == f ? L : L - (uint32_t)(K - 1)); }
+      loff[i] = sum;
+    }
+    WG_SYNC();
+    const int plen = (int)wg_uniform((int)loff[n]);
+    if (plen > (int)LC_CTX(c).C->path_cap) { WG_LANE0 { OVF(c); } return 0; }
+    WG_FOR(x, plen) {
+      int lo = 0, hi = n - 1;                                    // last node whose offset is <= x and that contributes
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)loff[mid] <= x) lo = mid; else hi = mid - 1; }
+      while (lo > 0 && loff[lo + 1] == loff[lo]) --lo;           // (special nodes and empty contributions share an offset)
+      const uint32_t slo = lslo[lo], shi = lshi[lo];
+      const uint32_t j = (uint32_t)(x - (int)loff[lo]) + (lo == f ? 0u : (uint32_t)(K - 1));
+      const uint32_t d = (ldir[lo] == (uint8_t)'R') ? (W.seq[shi - 1 - j] ^ 3u) : W.seq[slo + j];
+      W.pdesc[x] = d; W.pseq[x] = (uint8_t)SD_BASE(d);
+    }
+    WG_SYNC();
+    return plen;
+  }
   LC_GLOBAL uint32_t *off = (LC_GLOBAL uint32_t *)W.dp, *pdir = off + (n + 1);
   WG_LANE0 { S.ps_first = 0x7FFFFFFF; off[n] = 0; }
   WG_FOR(i, n) {
@@ -5048,6 +5091,15 @@ DEVNI void process_path_walk_wg(Ctx &c, int np, int plen, int L, int complete) {
       }
     }
     SUBPHASE(c, 4, 6);
+    // (round 6) the path string around the transcript in LDS for findTandems: lane 0 compares every character there a dozen times, one load
+    // from HBM each until now -- 2.4 of the walk's 5.8 slot-seconds per 32768 windows.  The column records (S.acc) are read out by now.
+    volatile LC_LDS uint8_t *stg = (volatile LC_LDS uint8_t *)&S.acc[0][0];
+    int stg_lo = (int)ts[ti].start_pos - 1024; if (stg_lo < 0) stg_lo = 0;
+    stg_lo = wg_uniform(stg_lo);
+    const int stg_hi = stg_lo + 2048 < plen ? stg_lo + 2048 : plen;
+    static_assert(sizeof(S.acc) >= 2048, "path string staged for findTandems");
+    WG_FOR(i, stg_hi - stg_lo) { stg[i] = W.pseq[stg_lo + i]; }
+    WG_SYNC();
     WG_LANE0 {
       auto &t = ts[ti];
       const bool x = t.code == 'x';
@@ -5079,7 +5131,7 @@ DEVNI void process_path_walk_wg(Ctx &c, int np, int plen, int L, int complete) {
       }
       if (ACNF > 0 || ACNR > 0 || ACTF > 0 || ACTR > 0) {
         int LEN = 0, ml = 0; uint8_t motif[64];
-        bool ans = find_tandems_local(c, W.pseq, plen, (int)t.start_pos, &LEN, motif, &ml);
+        bool ans = find_tandems_local(c, W.pseq, plen, (int)t.start_pos, &LEN, motif, &ml, stg, stg_lo, stg_hi);
         TS tc; tc.pos = t.pos; tc.ref_pos = t.ref_pos; tc.start_pos = t.start_pos; tc.end_pos = t.end_pos; tc.ref_end_pos = t.ref_end_pos; tc.col0 = t.col0; tc.col1 = t.col1;
         tc.code = t.code; tc.prev_bp_ref = t.prev_bp_ref; tc.prev_bp_alt = t.prev_bp_alt; tc.somatic = t.somatic;      // (what emit_variant reads; short reads: no haplotype fields)
         emit_variant(c, tc, cov, LEN, motif, ml, ans, ra, pa, hp12, plen);
