@@ -248,7 +248,7 @@ struct lancet_engine {
   hipStream_t stream3 = nullptr; hipEvent_t ev_svc = nullptr;
   bool svc = true, svc_running = false, svc_large = false;
   bool svc_help = true;                      // the service's workgroups take windows off the build kernel's queue until the window kernel runs (LANCET_SVC_HELP=0: they only wait)      // LANCET_NO_SVC=1 (at create): every later graph of a window by the general build
-  int n_svc_wgs = 24; uint32_t svc_cap = 0; int svc_depth = 6;      // (24: 412 requests of a 32768-window batch at ~0.55 ms each keep 16 busy for the whole window kernel; beyond 32 their LDS costs it more slots than the shorter waits give back)
+  int n_svc_wgs = 32; uint32_t svc_cap = 0; int svc_depth = 6;      // (round 6: 32 -- with the window kernel's slot time down by an eighth its last millisecond is windows waiting for the service: 11.9 -> 11.6 ms; beyond 32 their LDS costs it more slots than the shorter waits give back: 36 -> 12.0, 48 -> 13.3 ms)
   int svc_cus = 0, n_cus = 256;                // LANCET_SVC_CUS=n: CUs set aside for the service (CU masks on the two streams), so that its workgroups are resident
                                              // whatever the batch's kernels -- or another engine's -- occupy; 0 = no masks
   SvcCtl svc_host;
