@@ -3080,6 +3080,13 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
   // ---- the float averaging of the merges (Graph.cc:2632-2636), in merge order: the one strictly sequential piece -- a clean window is
   //      ONE chain of ~590 merges, four IEEE divisions each.  The four coverages are independent recurrences: one lane per (head,
   //      coverage) instead of one per head, the next four operands already on their way.
+  // Round 6: the division by the integer t + 2 as in the build kernel's copy of this loop (build_lds_impl.h bl_compress_first, where the proof is):
+  // (float)((double)numerator * RCP[t]) with RCP[t] = 1.0 / (double)(t + 2) IS the correctly rounded float quotient -- five dependent
+  // instructions per merge instead of the IEEE division's twelve.  The table is made by all lanes in the (idle) scratch array.
+  LC_GLOBAL double *RCP = (LC_GLOBAL double *)W.scratch;
+  static_assert(sizeof(double) == 8, "reciprocal table");
+  WG_FOR(t, nabs) { RCP[t] = 1.0 / (double)((uint32_t)t + 2u); }
+  WG_SYNC();
   WG_FOR(x, 4 * nheads) {
     const uint32_t i = hl[(uint32_t)x >> 2], q = (uint32_t)x & 3u;
     const uint32_t cnt = hs[i + 1] - hs[i];
@@ -3087,17 +3094,21 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
     LC_GLOBAL NodeGr &G = W.gr[W.order[i]];
     float nc = G.cov[q];
     LC_GLOBAL const uint32_t *sl = ord + 4 * (size_t)hs[i] + q;
-#define LC_MERGE_STEP(cv, t) do { if ((t) < cnt) { const int amer = (int)(t) + 1, bmer = 1;   /* Graph.cc:2632-2636, same expression, same order */ \
-      nc = ((nc * amer) + (__builtin_bit_cast(float, (cv)) * bmer)) / (amer + bmer); } } while (0)
-#define LC_MERGE_LOAD(u, t0) sl[4 * (size_t)((t0) + (u) < cnt ? (t0) + (u) : cnt - 1)]
-    uint32_t n0 = LC_MERGE_LOAD(0u, 0u), n1 = LC_MERGE_LOAD(1u, 0u), n2 = LC_MERGE_LOAD(2u, 0u), n3 = LC_MERGE_LOAD(3u, 0u);
+#define LC_MERGE_STEP(cv, rv, t) do { if ((t) < cnt) { const int amer = (int)(t) + 1, bmer = 1;   /* Graph.cc:2632-2636: same numerator, same order; the division as above */ \
+      const float num = (nc * amer) + (__builtin_bit_cast(float, (cv)) * bmer); nc = (float)((double)num * (rv)); } } while (0)
+#define LC_MERGE_IDX(u, t0) ((size_t)((t0) + (u) < cnt ? (t0) + (u) : cnt - 1))
+    uint32_t n0 = sl[4 * LC_MERGE_IDX(0u, 0u)], n1 = sl[4 * LC_MERGE_IDX(1u, 0u)], n2 = sl[4 * LC_MERGE_IDX(2u, 0u)], n3 = sl[4 * LC_MERGE_IDX(3u, 0u)];
+    double r0 = RCP[LC_MERGE_IDX(0u, 0u)], r1 = RCP[LC_MERGE_IDX(1u, 0u)], r2 = RCP[LC_MERGE_IDX(2u, 0u)], r3 = RCP[LC_MERGE_IDX(3u, 0u)];
     for (uint32_t t0 = 0; t0 < cnt; t0 += 4) {
-      const uint32_t c0 = n0, c1 = n1, c2 = n2, c3 = n3;
-      if (t0 + 4 < cnt) { n0 = LC_MERGE_LOAD(0u, t0 + 4); n1 = LC_MERGE_LOAD(1u, t0 + 4); n2 = LC_MERGE_LOAD(2u, t0 + 4); n3 = LC_MERGE_LOAD(3u, t0 + 4); }
-      LC_MERGE_STEP(c0, t0); LC_MERGE_STEP(c1, t0 + 1); LC_MERGE_STEP(c2, t0 + 2); LC_MERGE_STEP(c3, t0 + 3);
+      const uint32_t c0 = n0, c1 = n1, c2 = n2, c3 = n3; const double d0 = r0, d1 = r1, d2 = r2, d3 = r3;
+      if (t0 + 4 < cnt) {
+        n0 = sl[4 * LC_MERGE_IDX(0u, t0 + 4)]; n1 = sl[4 * LC_MERGE_IDX(1u, t0 + 4)]; n2 = sl[4 * LC_MERGE_IDX(2u, t0 + 4)]; n3 = sl[4 * LC_MERGE_IDX(3u, t0 + 4)];
+        r0 = RCP[LC_MERGE_IDX(0u, t0 + 4)]; r1 = RCP[LC_MERGE_IDX(1u, t0 + 4)]; r2 = RCP[LC_MERGE_IDX(2u, t0 + 4)]; r3 = RCP[LC_MERGE_IDX(3u, t0 + 4)];
+      }
+      LC_MERGE_STEP(c0, d0, t0); LC_MERGE_STEP(c1, d1, t0 + 1); LC_MERGE_STEP(c2, d2, t0 + 2); LC_MERGE_STEP(c3, d3, t0 + 3);
     }
 #undef LC_MERGE_STEP
-#undef LC_MERGE_LOAD
+#undef LC_MERGE_IDX
     G.cov[q] = nc;
   }
   WG_SYNC();
