@@ -858,8 +858,13 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
 // One window.  Returns with the hand-off area of the window written (PB_BUILT) or marked PB_NOT_BUILT.
 // kmin: the loop over k starts there (min_k for the window's first graph; the k after a rejected one for a graph built ahead).
 // rep: the window's isRepeat / isAlmostRepeat operands when an earlier call scanned the reference already, else null.
+// cmp_later: a graph at a later k of the window's loop (rep != null) gets markRefEnds and the first compress here too -- the build service's
+//            graphs: a window that was put aside for one is on the critical path of the launch when it comes back, and the service has the
+//            time; graphs built ahead by the build kernel itself leave that to the window kernel (a workgroup-second there is worth six
+//            slot-seconds here).  Neither step depends on what an earlier k left of Ref_t::seq (they scan every offset of rawseq for live
+//            nodes: kernels.h mark_ref_scan); what does -- the mer-table flags, the reference coverage -- load_prebuilt sets right.
 DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *Bp, LC_GLOBAL const EngineCaps *C, BL_S &S, LC_GLOBAL uint8_t *xbase,
-                           LC_GLOBAL uint8_t *area, int w, int kmin, LC_GLOBAL const PreHdr *rep) {
+                           LC_GLOBAL uint8_t *area, int w, int kmin, LC_GLOBAL const PreHdr *rep, bool cmp_later = false) {
   P = lc_sgpr(P); Bp = lc_sgpr(Bp); C = lc_sgpr(C); xbase = lc_sgpr(xbase); area = lc_sgpr(area); rep = lc_sgpr(rep);      // (uniform arguments: scalar registers, wave.h lc_sgpr)
   w = lc_sgpr(w); kmin = lc_sgpr(kmin);
   LC_GLOBAL const DevBatch &B = *Bp;
@@ -2038,7 +2043,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       const uint32_t hbc = lc_sgpr((uint32_t)S.g0), hnr = lc_sgpr((uint32_t)S.g1), ncomp = lc_sgpr((uint32_t)S.nbw);
       WG_SYNC();
       // (--linked-reads: a node's counts are barcode counts the window kernel has yet to replay -- no compress here)
-      if (!rep && ncomp == 1u && nsurv <= PB_CMAX && nsurv + 2u <= hnr && K <= 31 && !wide_tab && C->debug_stop != 140u && !P->lr_mode)
+      if ((!rep || cmp_later) && ncomp == 1u && nsurv <= PB_CMAX && nsurv + 2u <= hnr && K <= 31 && !wide_tab && C->debug_stop != 140u && !P->lr_mode)
         bl_compress_first(P, C, S, X, area, K, N, nsurv, ncand, reflen, hbc);
     }
   }
@@ -2186,7 +2191,7 @@ DEV void svc_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBa
         const uint32_t a = bl_bcast(&S.scan_total);
         if (a == 0xFFFFFFFFu) break;
         LC_GLOBAL uint8_t *nx = pool + (size_t)a * PRE_STRIDE;
-        bl_build_window(P, B, C, S, xbase, nx, w, lvl == 0 ? k : cur->K + 2, H0);
+        bl_build_window(P, B, C, S, xbase, nx, w, lvl == 0 ? k : cur->K + 2, H0, true);
         WG_SYNC();
         if (((LC_GLOBAL PreHdr *)nx)->status != PB_BUILT) break;
         WG_LANE0 { cur->next = a + 1u; dev_atomic_add(queue + 3, 1u); }

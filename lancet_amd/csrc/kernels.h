@@ -5544,7 +5544,10 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
   LC_GLOBAL const PreCmp *CH = (LC_GLOBAL const PreCmp *)(area + PRE_OFF_CHDR);
   WG_LANE0 { S.tmp1 = (S.seq_t5 != 0 || S.seq_len != S.reflen) ? 1 : 0; }       // Ref_t::seq trimmed by an earlier k of this window (see below)
   const bool trimmed_before = wg_bcast(&S.tmp1) != 0;
-  const bool cdone = pre_order && !trimmed_before && CH->done == 1u && LC_CTX(c).C->special_cap >= 2u && CH->m_live <= LC_CTX(c).C->node_cap &&
+  const int t5_before = wg_uniform(S.seq_t5), len_before = wg_uniform(S.seq_len);     // (Ref_t::seq as the k attempts before this one left it: markRefEnds of THIS graph, when it came along, sets S.seq_* anew below)
+  // (round 6: also when an earlier k has trimmed Ref_t::seq -- the build service's graphs: neither markRefEnds nor the compress looks at
+  //  Ref_t::seq, and what does is set right below, `trimmed_before`)
+  const bool cdone = pre_order && CH->done == 1u && LC_CTX(c).C->special_cap >= 2u && CH->m_live <= LC_CTX(c).C->node_cap &&
                      (size_t)ncand * (size_t)K + CH->seqn <= (size_t)LC_CTX(c).C->seq_cap;
   WG_LANE0 { S.cmp_done = cdone ? 1 : 0; }
   if (cdone) {
@@ -5624,7 +5627,7 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
   // are not in the table, their nodes are not reference nodes (unless another k-mer inside is the same node) and
   // computeCoverage (src/Ref.cc:173-250) reads 0 for them.  Same rule as build_refcov, applied to what came along.
   if (trimmed_before) {
-    const int t5 = wg_bcast(&S.seq_t5), L = wg_bcast(&S.seq_len);
+    const int t5 = t5_before, L = len_before;
     WG_FOR(i, (N + 31u) / 32u) { W.bitmap[i] = 0; }
     WG_SYNC();
     WG_FOR(i, L - K > 0 ? L - K : 0) {
@@ -5632,10 +5635,15 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
       if (p < nrefk) { const uint32_t n = occ_ref[p] & 0x3FFFFFFFu; dev_atomic_or(&W.bitmap[n >> 5], 1u << (n & 31u)); }
     }
     WG_SYNC();                                                     // (the bitmap is read past the L1 below: ld2)
+    WG_LANE0 { S.tmp1 = 0; }
     WG_FOR(si, nsurv) {
       const uint32_t n = sid[si]; const uint32_t f = W.gr[n].flags;
-      W.gr[n].flags = ((ld2(&W.bitmap[n >> 5]) >> (n & 31u)) & 1u) ? (f | NF_INMER) : (f & ~(uint32_t)NF_INMER);
+      const bool in = ((ld2(&W.bitmap[n >> 5]) >> (n & 31u)) & 1u) != 0;
+      W.gr[n].flags = in ? (f | NF_INMER) : (f & ~(uint32_t)NF_INMER);
+      if (in) S.tmp1 = 1;
     }
+    WG_SYNC();
+    WG_LANE0 { if (S.cmp_done) S.refcomp = S.tmp1 ? 1 : 0; }          // (the one component holds a reference k-mer of the trimmed seq or not: markConnectedComponents' count)
     WG_FOR(i, S.reflen - K > 0 ? S.reflen - K : 0) {
       const uint32_t n = occ_ref[i] & 0x3FFFFFFFu;
       if (!((ld2(&W.bitmap[n >> 5]) >> (n & 31u)) & 1u)) {

@@ -80,6 +80,11 @@ if os.environ.get("QUICK_TIMELINE"):      # (engine built with -DLANCET_PROF_TIM
     print(f"timeline: span {1000 * span:.2f} ms; the last window was taken at {ms(start.max())} ms; ends: p50 {ms(_np.percentile(end, 50))} p90 {ms(_np.percentile(end, 90))} p99 {ms(_np.percentile(end, 99))} p99.9 {ms(_np.percentile(end, 99.9))}")
     parked = (nres > 0)
     print(f"  put aside for the build service: {int(parked.sum())} windows, {int(nres.sum())} times; last hand-over {ms(susp[parked].max()) if parked.any() else 0} ms, last resume {ms(res[parked].max()) if parked.any() else 0} ms; mean wait of the last round {1000 * float((res[parked] - susp[parked]).mean()) if parked.any() else 0:.2f} ms")
+    if parked.any():                            # the waits (last round of each window) by the millisecond in which the window was put aside
+        w_ = res[parked] - susp[parked]; at = susp[parked] - t0
+        for b in range(int(1000 * span) + 1):
+            m = (at >= b * 1e-3) & (at < (b + 1) * 1e-3)
+            if m.any(): print(f"    put aside in ms {b:2d}: {int(m.sum()):4d} windows, wait mean {1000 * float(w_[m].mean()):.2f} max {1000 * float(w_[m].max()):.2f} ms")
     nslot = int(slot.max()) + 1
     last = _np.zeros(nslot); busy = _np.zeros(nslot)
     _np.maximum.at(last, slot, end - t0)
