@@ -235,7 +235,9 @@ int lancet_engine_ahead_counts(lancet_engine *e, int32_t *built, int32_t *used);
  * resumes.  out = requests posted, served, not buildable in LDS, taken back by the window kernel (general build).  Scheduling
  * only: results never depend on who built a graph. */
 int lancet_engine_svc_counts(lancet_engine *e, uint32_t out[4]);
-/* Profiling aid: wall-clock ticks (10 ns) the LDS build kernel's workgroups spent per phase in the last run (16 values). */
+/* Profiling aid: wall-clock ticks (10 ns) the LDS build kernel's workgroups spent per phase in the last run (16 values).
+ * Accounted only in an engine made with LANCET_PHASE_TIMES set in the environment (zeros otherwise; the same holds for
+ * lancet_engine_phase_times): the accounting costs both kernels a clock read per phase and the build kernel contended atomics per window. */
 int lancet_engine_build_phase_times(lancet_engine *e, const unsigned long long **ticks);
 
 /* ---- the reference's -v stage trace (reference src/Microassembler.cc:87-246, Graph.cc verbose blocks) ----

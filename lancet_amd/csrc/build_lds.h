@@ -60,7 +60,7 @@ enum { BLW_NONE = 0, BLW_NOREADS, BLW_SIZE, BLW_HASN, BLW_K, BLW_TABLE, BLW_NODE
 #define BL_DBG(...) ((void)0)
 #endif
 #ifndef LANCET_WAVE_EMU
-#define BLP(S, id) do { if (threadIdx.x == 0) { const unsigned long long _t = wall_clock64(); (S).ph_acc[(S).ph_cur] += _t - (S).t_last; (S).t_last = _t; (S).ph_cur = (id); } } while (0)
+#define BLP(S, id) do { if (threadIdx.x == 0 && (S).ph_cur >= 0) { const unsigned long long _t = wall_clock64();      /* (ph_cur < 0: nobody asked for phase times, LANCET_PHASE_TIMES) */ (S).ph_acc[(S).ph_cur] += _t - (S).t_last; (S).t_last = _t; (S).ph_cur = (id); } } while (0)
 #else
 static thread_local unsigned long bl_emu_sync_acc[17], bl_emu_sync_last = 0; static thread_local int bl_emu_sync_cur = 16;   /* barriers per phase (tuning aid) */
 #define BLP(S, id) do { bl_emu_sync_acc[bl_emu_sync_cur] += lc_emu_syncs - bl_emu_sync_last; bl_emu_sync_last = lc_emu_syncs; bl_emu_sync_cur = (id); } while (0)

@@ -2089,7 +2089,7 @@ DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       break;
     }
 #ifndef LANCET_WAVE_EMU
-    if (threadIdx.x == 0) { for (int i = 0; i < 16; ++i) S.ph_acc[i] = 0; S.ph_cur = 0; S.t_last = wall_clock64(); }
+    if (threadIdx.x == 0) { if (phase) { for (int i = 0; i < 16; ++i) S.ph_acc[i] = 0; S.ph_cur = 0; S.t_last = wall_clock64(); } else S.ph_cur = -1; }
 #endif
     bl_build_window(P, B, C, S, xbase, pre + (size_t)w * PRE_STRIDE, w, P->min_k, nullptr);
     {
@@ -2120,7 +2120,10 @@ DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       else if (!from_list && biglist && (Hw->why == (uint32_t)BLW_SIZE || Hw->why == (uint32_t)BLW_KBIG)) biglist[dev_atomic_add(queue + 4, 1u)] = (uint32_t)w;
     }
     WG_SYNC();                                                     // (every lane's stores to the hand-off area are issued ...)
-    if (!from_list) { WG_LANE0 { add_rel(queue + 7, 1u); } }       // (... and released with the count)
+    // (... and released with the count -- by the service's workgroups: their kernel stays resident, nothing else makes what they wrote visible
+    //  to the window kernel; the build kernel's own stores are written back when it ends, and an agent-scope release per window is an L2
+    //  write-back per window)
+    if (!from_list) { WG_LANE0 { if (wait_all) dev_atomic_add(queue + 7, 1u); else add_rel(queue + 7, 1u); } }
   }
 }
 
@@ -2176,7 +2179,7 @@ DEV void svc_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBa
     if (st != SV_CLAIMED) continue;                                 // a window slot took it back
     const int w = (int)sv->req[t].w, k = sv->req[t].k;
 #ifndef LANCET_WAVE_EMU
-    if (threadIdx.x == 0) { for (int i = 0; i < 16; ++i) S.ph_acc[i] = 0; S.ph_cur = 0; S.t_last = wall_clock64(); }
+    if (threadIdx.x == 0) { if (phase) { for (int i = 0; i < 16; ++i) S.ph_acc[i] = 0; S.ph_cur = 0; S.t_last = wall_clock64(); } else S.ph_cur = -1; }
 #endif
     LC_GLOBAL PreHdr *H0 = (LC_GLOBAL PreHdr *)(pre + (size_t)w * PRE_STRIDE), *cur = H0;
     for (int hop = 0; hop < 64 && cur->next != 0u; ++hop) cur = (LC_GLOBAL PreHdr *)(pool + (size_t)(cur->next - 1u) * PRE_STRIDE);

@@ -262,6 +262,7 @@ struct lancet_engine {
   int prep_threads_auto = 1;       // hardware threads, at most 96 -- and at most twice the container's CPU quota (cgroup cpu.max): measured on a 16-CPU quota, 32 threads pack a batch in 26 ms, 16 in 39, 96 in 31
   int exact_need_large = -1;       // host trim: windows that exceed the 512-lane build configuration (exact: from the trimmed lengths); -1 unknown
   float ms_pack = 0;
+  bool phase_times = false;        // LANCET_PHASE_TIMES=1: lancet_engine_phase_times / _build_phase_times return ticks (else zeros)
   bool up_timing = false;          // LANCET_UPLOAD_TIMING=1: where lancet_engine_upload spends its time (allocations, packing, the copy), on stderr
   bool dbg = false, no_fat = false, no_early_rerun = false, no_large_build = false;     // LANCET_DEBUG / LANCET_NO_FAT / ... read once, at create
   int build_slots_env = 0, ahead_depth_env = -1;
@@ -366,6 +367,7 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
     e->prep_threads_auto = (int)hw;
   }
   e->up_timing = getenv("LANCET_UPLOAD_TIMING") != nullptr;
+  e->phase_times = getenv("LANCET_PHASE_TIMES") != nullptr && atoi(getenv("LANCET_PHASE_TIMES")) != 0;      // per-phase tick accounting of both kernels (tools/quick_gpu.py ...): clock reads per phase and contended atomics per window otherwise
   e->dbg = getenv("LANCET_DEBUG") != nullptr; e->no_fat = getenv("LANCET_NO_FAT") != nullptr; e->no_early_rerun = getenv("LANCET_NO_EARLY_RERUN") != nullptr;
   e->no_large_build = getenv("LANCET_NO_LARGE_BUILD") != nullptr; e->heavy_first = getenv("LANCET_NO_HEAVY_FIRST") == nullptr;
   if (const char *s = getenv("LANCET_ORDER")) e->order_mode = strcmp(s, "two") == 0 ? 1 : 0;
@@ -716,7 +718,7 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
   o.variants = (LC_GLOBAL lancet_variant *)e->d_variants.p; o.blob = (LC_GLOBAL char *)e->d_blob.p;
   o.n_variants = (LC_GLOBAL uint32_t *)e->d_counters.p; o.n_blob = (LC_GLOBAL uint32_t *)e->d_counters.p + 1; o.queue_head = (LC_GLOBAL uint32_t *)e->d_counters.p + 2;
   o.n_bx = (LC_GLOBAL uint32_t *)e->d_counters.p + 3; o.variants_lr = (LC_GLOBAL lancet_variant_lr *)e->d_varlr.p; o.bx_blob = (LC_GLOBAL uint32_t *)e->d_bxblob.p;
-  o.stats = (LC_GLOBAL lancet_window_stats *)e->d_stats.p; o.evt_len = (LC_GLOBAL uint32_t *)e->d_evtlen.p; o.evt_out = (LC_GLOBAL uint32_t *)e->d_evt.p; o.phase = (LC_GLOBAL unsigned long long *)e->d_phase.p; o.win_list = nullptr; o.n_list = 0;
+  o.stats = (LC_GLOBAL lancet_window_stats *)e->d_stats.p; o.evt_len = (LC_GLOBAL uint32_t *)e->d_evtlen.p; o.evt_out = (LC_GLOBAL uint32_t *)e->d_evt.p; o.phase = e->phase_times ? (LC_GLOBAL unsigned long long *)e->d_phase.p : nullptr; o.win_list = nullptr; o.n_list = 0;
   o.pre = nullptr; o.pre_pool = nullptr; o.n_ahead_used = nullptr; o.skip = nullptr; o.svc = nullptr;
   e->svc_cap = 0;
   e->pred.clear(); e->is_pred.assign(nw, 0);
@@ -857,7 +859,7 @@ static int lc_submit_body(lancet_engine *e) {
     HIPCHK(e, hipEventRecord(e->evb0, e->stream));
     hipLaunchKernelGGL(build_kernel, dim3(e->n_bslots), dim3(bl_small::WG), 0, e->stream, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
                        (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_blscratch.p, (uint32_t *)e->d_counters.p + 8,
-                       (unsigned long long *)e->d_blphase.p, (uint8_t *)(e->pool_cap ? e->d_prepool.p : nullptr), e->pool_cap, e->ahead_depth,
+                       (unsigned long long *)(e->phase_times ? e->d_blphase.p : nullptr), (uint8_t *)(e->pool_cap ? e->d_prepool.p : nullptr), e->pool_cap, e->ahead_depth,
                        (uint32_t *)(e->n_bslots_large ? e->d_biglist.p : nullptr), (e->svc_running && e->svc_help && !e->svc_large) ? 1 : 0);
     HIPCHK(e, hipGetLastError());
     if (e->dbg) { HIPCHK(e, hipStreamSynchronize(e->stream)); DBG("build_kernel done"); }
@@ -867,7 +869,7 @@ static int lc_submit_body(lancet_engine *e) {
       const int glarge = e->n_biglist < 0 ? e->n_bslots_large : std::max(8, std::min(e->n_bslots_large, e->n_biglist));
       hipLaunchKernelGGL(build_kernel_large, dim3(glarge), dim3(bl_large::WG), 0, e->stream, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
                          (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_blscratch_large.p, (uint32_t *)e->d_counters.p + 8,
-                         (unsigned long long *)e->d_blphase.p, (uint8_t *)(e->pool_cap ? e->d_prepool.p : nullptr), e->pool_cap, e->ahead_depth, (uint32_t *)e->d_biglist.p);
+                         (unsigned long long *)(e->phase_times ? e->d_blphase.p : nullptr), (uint8_t *)(e->pool_cap ? e->d_prepool.p : nullptr), e->pool_cap, e->ahead_depth, (uint32_t *)e->d_biglist.p);
       HIPCHK(e, hipGetLastError());
       if (e->dbg) { HIPCHK(e, hipStreamSynchronize(e->stream)); DBG("build_kernel_large done"); }
     }
@@ -937,7 +939,7 @@ int lancet_engine_submit(lancet_engine *e) {
     hipLaunchKernelGGL(svc_kernel, dim3(e->n_svc_wgs), dim3(bl_small::WG), 0, e->stream3, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
                        (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_svcscratch.p, (uint32_t *)e->d_counters.p + 8,
                        (uint8_t *)e->d_prepool.p, e->pool_cap, e->svc_depth, (SvcCtl *)e->d_svc.p, (const uint32_t *)e->d_counters.p + 2,
-                       (uint32_t *)(e->n_bslots_large ? e->d_biglist.p : nullptr), (e->svc_help && e->prebuild) ? e->ahead_depth : -1, (unsigned long long *)e->d_blphase.p);
+                       (uint32_t *)(e->n_bslots_large ? e->d_biglist.p : nullptr), (e->svc_help && e->prebuild) ? e->ahead_depth : -1, (unsigned long long *)(e->phase_times ? e->d_blphase.p : nullptr));
     HIPCHK(e, hipGetLastError());
     e->svc_running = true;
   }
@@ -984,7 +986,7 @@ int lancet_engine_wait(lancet_engine *e) {
     uint32_t bq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(e, lc_copy(e, bq, (uint32_t *)e->d_counters.p + 8, sizeof(bq), hipMemcpyDeviceToHost));
     e->n_prebuilt = (int)bq[1]; e->n_ahead_built = (int)bq[3]; e->n_ahead_used = (int)bq[6]; e->n_biglist = (int)bq[4];
-    HIPCHK(e, lc_copy(e, e->blphase, e->d_blphase.p, sizeof(e->blphase), hipMemcpyDeviceToHost));
+    if (e->phase_times) HIPCHK(e, lc_copy(e, e->blphase, e->d_blphase.p, sizeof(e->blphase), hipMemcpyDeviceToHost)); else memset(e->blphase, 0, sizeof(e->blphase));
   }
   if (e->ms_fat > e->ms_window + e->ms_build) e->ms_window = e->ms_fat - e->ms_build;    // both started together: the window kernels' time is the longer of the two
   e->ms_all = e->ms_window + e->ms_build;
@@ -1178,7 +1180,7 @@ int lancet_engine_phase_times(lancet_engine *e, const unsigned long long **ticks
     if (e->submitted) { e->err = "phase times while a batch is in flight"; return LANCET_E_STATE; }
     HIPCHK(e, hipSetDevice(e->device));
     e->phase.resize((size_t)e->n_windows * 16);
-    HIPCHK(e, lc_copy(e, e->phase.data(), e->d_phase.p, sizeof(unsigned long long) * e->phase.size(), hipMemcpyDeviceToHost));
+    if (e->phase_times) HIPCHK(e, lc_copy(e, e->phase.data(), e->d_phase.p, sizeof(unsigned long long) * e->phase.size(), hipMemcpyDeviceToHost));      // (else zeros: LANCET_PHASE_TIMES was not set when the engine was made)
   }
   *ticks = e->phase.data();
   return LANCET_OK;

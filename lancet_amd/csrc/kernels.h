@@ -152,7 +152,7 @@ static __shared__ Ctx lc_ctx;
 
 // per-phase wall-clock accounting (lane 0; 100 MHz constant counter), read back through lancet_engine_phase_times
 #ifndef LANCET_WAVE_EMU
-#define PHASE(c, id) do { if (threadIdx.x == 0) { unsigned long long _t = wall_clock64(); (c).S->phase_acc[(c).S->phase_cur] += _t - (c).S->t_last; (c).S->t_last = _t; (c).S->phase_cur = (id); } } while (0)
+#define PHASE(c, id) do { if (threadIdx.x == 0 && (c).S->phase_cur >= 0) { unsigned long long _t = wall_clock64(); (c).S->phase_acc[(c).S->phase_cur] += _t - (c).S->t_last; (c).S->t_last = _t; (c).S->phase_cur = (id); } } while (0)
 #else
 #define PHASE(c, id) ((void)0)
 #endif
@@ -5989,8 +5989,9 @@ DEV int window_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       if (OUT->skip && OUT->skip[w]) continue;      // a coverage pile-up the host sent straight to the re-run tier (engine.hip)
     } else { rq = arg; w = (int)sv->req[rq].w; }
 #ifndef LANCET_WAVE_EMU
-    if (threadIdx.x == 0) {
-      for (int i = 0; i < 16; ++i) S->phase_acc[i] = (rq >= 0 && OUT->phase) ? OUT->phase[(size_t)w * 16 + i] : 0ull;
+    if (threadIdx.x == 0 && !OUT->phase) S->phase_cur = -1;            // (nobody asked for phase times: PHASE does nothing)
+    if (threadIdx.x == 0 && OUT->phase) {
+      for (int i = 0; i < 16; ++i) S->phase_acc[i] = rq >= 0 ? OUT->phase[(size_t)w * 16 + i] : 0ull;
       S->phase_cur = 0; S->t_last = wall_clock64();
 #ifdef LANCET_PROF_TIMELINE   /* profiling builds only (tools/timeline.py): when the window was taken, resumed and finished, in the slots of the general build's phases */
       if (rq < 0) { S->phase_acc[2] = S->t_last; S->phase_acc[4] = 0; S->phase_acc[5] = 0; S->phase_acc[6] = 0; S->phase_acc[7] = (unsigned long long)slot; } else { S->phase_acc[5] = S->t_last; S->phase_acc[6] += 1; }

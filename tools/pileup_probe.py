@@ -1,4 +1,5 @@
 """Phase breakdown of the coverage pile-up windows of the 500 kb scan BAMs (build/scan500k, tools/make_scan_bams.py)."""
+import os as _os; _os.environ.setdefault("LANCET_PHASE_TIMES", "1")      # (the engine accounts per-phase ticks only on request)
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

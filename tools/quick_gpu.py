@@ -1,4 +1,5 @@
 """Quick GPU sanity/timing: replicate a golden case N times into one batch and time the engine."""
+import os as _os; _os.environ.setdefault("LANCET_PHASE_TIMES", "1")      # (the engine accounts per-phase ticks only on request)
 import sys, time, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,4 +1,5 @@
 """Per-window slot time of the window kernel against what the build kernel knows about the window (tuning aid for order_kernel)."""
+import os as _os; _os.environ.setdefault("LANCET_PHASE_TIMES", "1")      # (the engine accounts per-phase ticks only on request)
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

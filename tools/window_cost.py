@@ -2,6 +2,7 @@
 order is made (order_class, engine.hip).  Writes gpurun_out/window_cost_<case>.npz: per window the busy time, the phase split, the
 statistics and the hand-off header's numbers.
     python tools/window_cost.py [bench|bench60|bench4] [windows]"""
+import os as _os; _os.environ.setdefault("LANCET_PHASE_TIMES", "1")      # (the engine accounts per-phase ticks only on request)
 import ctypes as C
 import os
 import sys
