@@ -779,38 +779,16 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     G.seq_clo = top + nb; G.seq_lo = top + nb; G.seq_hi = top + nb + (uint32_t)K + cnt; G.seq_chi = G.seq_hi;
   }
   BLPA(S, 11);
-  // ---- the float averaging of the merges (Graph.cc:2632-2636) in merge order: one lane per (head, coverage).  This is the one strictly
-  //      sequential piece of the build -- a clean window is ONE chain of ~500 merges -- and it was 6.5 % of the kernel: a float division is
-  //      ~12 dependent instructions.  The divisor of merge t is the integer t + 2, so the quotient is taken as
-  //          (float)((double)numerator * RCP[t]),   RCP[t] = 1.0 / (double)(t + 2)   (a table in LDS, made by all lanes beforehand),
-  //      which IS the correctly rounded float quotient: the double product is off by less than 2^-52 relative (two roundings of 2^-53),
-  //      while the exact quotient of two 24-bit floats is either a float or more than 2^-49 relative away from every midpoint between two
-  //      floats (|A * 2^24 - M * B| >= 1 for an odd M: B < 2^24 cannot divide it out) -- so rounding the product to float rounds as the
-  //      quotient does.  (No overflow / subnormals here: coverages below 65 536, divisors below 4096.)  The numerator is computed in float
-  //      exactly as the reference does: (nc * amer) + (bc * bmer), bmer = 1.
-  LC_LDS double *RCP = (LC_LDS double *)LNK;                                   // (the links are done with; 8 * (PB_CMAX + 2) bytes)
-  WG_SYNC();
-  WG_FOR(t, nabs) { RCP[t] = 1.0 / (double)((uint32_t)t + 2u); }
-  WG_SYNC();
-  WG_FOR(x, 4 * nheads) {
-    const uint32_t hx = (uint32_t)x >> 2, q = (uint32_t)x & 3u;
-    const uint32_t u = HL[hx];
-    const uint32_t cnt = HS[u + 1] - HS[u];
-    float nc = (float)(uint32_t)((TCC[u] >> (16 * q)) & 0xFFFFu);
-    LC_LDS const unsigned long long *sl = ORD + HS[u];
-    // (the operands of the next four merges are on their way while these four are worked off)
-    auto opnd = [&](uint32_t t) -> float { return (float)(uint32_t)((sl[t < cnt ? t : cnt - 1] >> (16 * q)) & 0xFFFFu); };
-    auto rcp = [&](uint32_t t) -> double { return RCP[t < cnt ? t : cnt - 1]; };
-    float n0 = opnd(0), n1 = opnd(1), n2 = opnd(2), n3 = opnd(3);
-    double r0 = rcp(0), r1 = rcp(1), r2 = rcp(2), r3 = rcp(3);
-    for (uint32_t t0 = 0; t0 < cnt; t0 += 4) {
-      const float c0 = n0, c1 = n1, c2 = n2, c3 = n3; const double d0 = r0, d1 = r1, d2 = r2, d3 = r3;
-      if (t0 + 4 < cnt) { n0 = opnd(t0 + 4); n1 = opnd(t0 + 5); n2 = opnd(t0 + 6); n3 = opnd(t0 + 7); r0 = rcp(t0 + 4); r1 = rcp(t0 + 5); r2 = rcp(t0 + 6); r3 = rcp(t0 + 7); }
-#define BLC_STEP(cv, rv, t) do { if ((t) < cnt) { const int amer = (int)(t) + 1, bmer = 1; const float num = (nc * amer) + ((cv) * bmer); nc = (float)((double)num * (rv)); } } while (0)   /* Graph.cc:2632-2636: same numerator, same order; the division as above */
-      BLC_STEP(c0, d0, t0); BLC_STEP(c1, d1, t0 + 1); BLC_STEP(c2, d2, t0 + 2); BLC_STEP(c3, d3, t0 + 3);
-#undef BLC_STEP
-    }
-    pgr[pos2si[u]].cov[q] = nc;
+  // ---- the float averaging of the merges (Graph.cc:2632-2636) in merge order is the one strictly sequential piece of the build -- a clean
+  //      window is ONE chain of ~500 merges, a chain of dependent float operations on four lanes while 508 wait: it was 0.8 of this kernel's
+  //      14.5 workgroup-seconds per batch.  Round 6: it is left to the window kernel (load_prebuilt), where the same 25 us per window are
+  //      one wave's of sixteen per CU.  What it needs leaves here: the merged k-mers' counts in merge order (CORD) and, per unitig head, its
+  //      record, its slice of that list and the number of merges (CHL); the head's record keeps cov[] = its own k-mer's counts until then.
+  {
+    LC_GLOBAL unsigned long long *cord = (LC_GLOBAL unsigned long long *)(area + PRE_OFF_CORD);
+    LC_GLOBAL uint32_t *chl = (LC_GLOBAL uint32_t *)(area + PRE_OFF_CHL);
+    WG_FOR(t, nabs) { cord[t] = ORD[t]; }
+    WG_FOR(hx, nheads) { const uint32_t u = HL[hx]; chl[3 * hx] = (uint32_t)pos2si[u]; chl[3 * hx + 1] = HS[u]; chl[3 * hx + 2] = HS[u + 1] - HS[u]; }
   }
   BLPA(S, 12);
   // ---- every live node: edges into a merged k-mer go to its head (frame flipped with it); the records' edge lists; dead flags
@@ -848,7 +826,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     WG_FOR(u, Pn) { if (AL[u]) clive[keep[final_index((uint32_t)u)]] = (uint32_t)u < nsurv ? (uint32_t)pos2si[u] : (0x80000000u | ((uint32_t)u - nsurv)); }
   }
   WG_LANE0 {
-    CH->m_live = Pn - nabs; CH->dead = nabs; CH->seqn = need; CH->src_off = so; CH->snk_off = ko; CH->edges0 = edges0; CH->pad0 = 0;
+    CH->m_live = Pn - nabs; CH->dead = nabs; CH->seqn = need; CH->src_off = so; CH->snk_off = ko; CH->edges0 = edges0; CH->cov_heads = nheads;
     CH->spec_hash[0] = hsrc; CH->spec_hash[1] = hsnk;
     CH->done = 1;
   }

@@ -26,6 +26,7 @@ static inline PreLayout lc_pre_layout(uint32_t ncap, uint32_t qvcap, uint32_t kw
   L.snode = take(4u * PB_CCAP, 64u); L.skey = take(8u * kw * PB_CCAP, 64u); L.sid = take(4u * PB_SCAP, 64u);
   L.pgr = take(128u * PB_SCAP, 128u); L.order = take(4u * PB_SCAP, 64u); L.qv = take(8u * qvcap, 64u);
   L.chdr = take(64u, 64u); L.clive = take(4u * (PB_CMAX + 2u), 64u); L.cseq = take(4u * PB_CSEQ, 64u);
+  L.cord = take(8u * PB_CMAX, 64u); L.chl = take(12u * PB_CHEADS, 64u);
   if (lrcap) { L.lrnocc = take(4u * (ncap + 2u), 64u); L.lrcsr = take(4u * lrcap, 64u); L.lrcap = lrcap; }      // --linked-reads
   L.stride = (o + 255u) & ~255u;
   return L;

@@ -3080,9 +3080,12 @@ DEVNI bool compress_rank(Ctx &c, int comp) {
   // ---- the float averaging of the merges (Graph.cc:2632-2636), in merge order: the one strictly sequential piece -- a clean window is
   //      ONE chain of ~590 merges, four IEEE divisions each.  The four coverages are independent recurrences: one lane per (head,
   //      coverage) instead of one per head, the next four operands already on their way.
-  // Round 6: the division by the integer t + 2 as in the build kernel's copy of this loop (build_lds_impl.h bl_compress_first, where the proof is):
-  // (float)((double)numerator * RCP[t]) with RCP[t] = 1.0 / (double)(t + 2) IS the correctly rounded float quotient -- five dependent
-  // instructions per merge instead of the IEEE division's twelve.  The table is made by all lanes in the (idle) scratch array.
+  // Round 6: the division by the integer t + 2 as (float)((double)numerator * RCP[t]), RCP[t] = 1.0 / (double)(t + 2): that IS the correctly
+  // rounded float quotient -- the double product is off by less than 2^-52 relative (two roundings of 2^-53), while the exact quotient of two
+  // 24-bit floats is either a float or more than 2^-49 relative away from every midpoint between two floats (|A * 2^24 - M * B| >= 1 for an
+  // odd M: B < 2^24 cannot divide it out), so rounding the product to float rounds as the quotient does (no overflow / subnormals: coverages
+  // below 65 536, divisors below 4097).  Five dependent instructions per merge instead of the IEEE division's twelve.  The table is made by
+  // all lanes in the (idle) scratch array.
   LC_GLOBAL double *RCP = (LC_GLOBAL double *)W.scratch;
   static_assert(sizeof(double) == 8, "reciprocal table");
   WG_FOR(t, nabs) { RCP[t] = 1.0 / (double)((uint32_t)t + 2u); }
@@ -5594,6 +5597,48 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
     }
     { const uint32_t base = ncand * (uint32_t)K; WG_FOR(i, seqn) { W.seq[base + (uint32_t)i] = cseq[i]; } }
     WG_LANE0 { S.seq_lazy = 0; }
+    // ---- the coverage of the unitig heads: the float averaging of the merges (reference src/Graph.cc:2632-2636) in merge order, which the
+    //      build kernel leaves to this wave (round 6: there it held a 512-lane workgroup for 25 us per window on four lanes).  One lane per
+    //      (head, coverage): nc starts as the head's own k-mer's count and takes the merged k-mers' counts one by one,
+    //          nc = ((nc * amer) + (bc * bmer)) / (amer + bmer),  amer = t + 1, bmer = 1   (the reference's expression, IEEE float division).
+    //      The operands come in chunks of LC_COV_CHUNK through LDS (the staging area, idle here): straight from HBM every fourth merge
+    //      waited a round trip -- 80 us per window instead of 25.  A head whose slice spans chunks keeps its value in its record in between.
+    const uint32_t nch = CH->cov_heads;
+    if (nch) {
+      LC_GLOBAL const unsigned long long *cord = (LC_GLOBAL const unsigned long long *)(area + PRE_OFF_CORD);
+      LC_GLOBAL const uint32_t *chl = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_CHL);
+      constexpr uint32_t LC_COV_CHUNK = 256u;
+      static_assert(8u * LC_COV_CHUNK <= sizeof(S.lbytes), "merge operands staged in LDS");
+      volatile LC_LDS unsigned long long *ops = (volatile LC_LDS unsigned long long *)&S.lbytes[0];
+      const uint32_t nabs = CH->dead;
+      WG_SYNC();                                                    // (the heads' records are in place: their cov[] is rewritten below)
+      for (uint32_t c0 = 0; c0 < nabs; c0 += LC_COV_CHUNK) {
+        const uint32_t c1 = c0 + LC_COV_CHUNK < nabs ? c0 + LC_COV_CHUNK : nabs;
+        WG_FOR(i, c1 - c0) { ops[i] = cord[c0 + (uint32_t)i]; }
+        WG_SYNC();
+        WG_FOR(x, 4 * nch) {
+          const uint32_t hx = (uint32_t)x >> 2, q = (uint32_t)x & 3u;
+          const uint32_t st = chl[3 * hx + 1], cnt = chl[3 * hx + 2];
+          const uint32_t lo = st > c0 ? st : c0, hi = st + cnt < c1 ? st + cnt : c1;
+          if (lo >= hi) continue;                                   // (nothing of this head's slice in the chunk)
+          LC_GLOBAL NodeGr &G = W.gr[sid[chl[3 * hx]]];
+          float nc = lo == st ? (float)(uint32_t)G.kc[q] : G.cov[q];
+#ifndef LANCET_WAVE_EMU
+          __builtin_amdgcn_s_setprio(3);                            // (a chain of dependent operations: every issue slot it can get)
+#endif
+          for (uint32_t g = lo; g < hi; ++g) {
+            const int amer = (int)(g - st) + 1, bmer = 1;
+            const float bc = (float)(uint32_t)((ops[g - c0] >> (16 * q)) & 0xFFFFu);
+            nc = ((nc * amer) + (bc * bmer)) / (amer + bmer);
+          }
+#ifndef LANCET_WAVE_EMU
+          __builtin_amdgcn_s_setprio(0);
+#endif
+          G.cov[q] = nc;
+        }
+        WG_SYNC();
+      }
+    }
   } else {
   if (pre_order) {                                               // only the survivors' hashes are looked at again (unordered_map::insert of the special nodes)
     LC_GLOBAL const uint32_t *ord = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_ORDER);

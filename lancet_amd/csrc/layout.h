@@ -101,7 +101,7 @@ typedef uint32_t mv_t;
 
 struct PreLayout {
   uint32_t ncap, qvcap, kw, maxw;
-  uint32_t refcov, nhash, surv, snode, skey, sid, pgr, order, qv, chdr, clive, cseq;
+  uint32_t refcov, nhash, surv, snode, skey, sid, pgr, order, qv, chdr, clive, cseq, cord, chl;
   uint32_t lrnocc, lrcsr, lrcap;   /* --linked-reads only (else 0): csr offsets by node id, the csr entries of the tracked nodes, room for them */
   uint32_t stride;
 };
@@ -241,6 +241,8 @@ struct PreHdr {
 #define PRE_OFF_CHDR (PL.chdr)                                /* PreCmp                                                 */
 #define PRE_OFF_CLIVE (PL.clive)                              /* u32[PB_CMAX + 2]  record index (survivor index, or nsurv + k for special k) per table position */
 #define PRE_OFF_CSEQ (PL.cseq)                                /* u32[PB_CSEQ]                                           */
+#define PRE_OFF_CORD (PL.cord)                                /* u64[PB_CMAX]   the merged k-mers' counted occurrences (4 x 16 bit) in merge order: operands of the coverage recurrence */
+#define PRE_OFF_CHL (PL.chl)                                  /* u32[3 * PB_CHEADS]  per unitig head: survivor index, first entry of its slice of CORD, merges */
 #define PRE_OFF_LRNOCC (PL.lrnocc)                            /* u32[ncap + 2]  --linked-reads: csr run of node n = [lrnocc[n], lrnocc[n+1]) (empty for a node with one occurrence) */
 #define PRE_OFF_LRCSR (PL.lrcsr)                              /* u32[lrcap]     ... the runs: cs_t words (read, position, orientation, state), unsorted inside a run */
 #define PRE_STRIDE (PL.stride)
@@ -258,7 +260,7 @@ struct PreCmp {
   uint32_t seqn;              /* words used in CSEQ: the window kernel's arena top moves by this                       */
   int32_t src_off, snk_off;   /* markRefEnds: offsets of the source / sink k-mer in the window reference              */
   uint32_t edges0;            /* trace only: edges of the survivors before markRefEnds                                 */
-  uint32_t pad0;
+  uint32_t cov_heads;         /* unitig heads whose coverage (the float recurrence over the merges) is left to the window kernel: entries of CHL */
   unsigned long long spec_hash[2];   /* std::hash of "source1" / "sink1"                                               */
   uint32_t pad[4];
 };
