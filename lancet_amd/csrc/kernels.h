@@ -5626,10 +5626,11 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
 #ifndef LANCET_WAVE_EMU
           __builtin_amdgcn_s_setprio(3);                            // (a chain of dependent operations: every issue slot it can get)
 #endif
+          float famer = (float)((int)(lo - st) + 1);                // (amer and amer + bmer as floats: small integers, exactly what the conversions give)
           for (uint32_t g = lo; g < hi; ++g) {
-            const int amer = (int)(g - st) + 1, bmer = 1;
             const float bc = (float)(uint32_t)((ops[g - c0] >> (16 * q)) & 0xFFFFu);
-            nc = ((nc * amer) + (bc * bmer)) / (amer + bmer);
+            nc = ((nc * famer) + bc) / (famer + 1.0f);
+            famer += 1.0f;
           }
 #ifndef LANCET_WAVE_EMU
           __builtin_amdgcn_s_setprio(0);
