@@ -808,6 +808,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
       uint32_t to = BLC_TO(ew), dir = BLC_DIR(ew);
       if (FL[to] & 16u) { dir ^= (INFO[to] >> 1) & 1u; to = HEADOF[to]; }
       G.edges[e] = ED_MAKE(to < nsurv ? sidv[pos2si[to]] : PB_SPECIAL + (to - nsurv), dir);
+      if (head) NEWE[13 * (size_t)hx + 1 + (size_t)e] = BLC_MAKE(to, dir); else E[8 * (uint32_t)u + (uint32_t)e] = BLC_MAKE(to, dir);      // (the final list by position too: the cycle check below)
     }
     for (int e = cnt; e < LC_EMAX; ++e) G.edges[e] = 0;
     G.necnt = (uint32_t)cnt;
@@ -815,6 +816,51 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
   BLPA(S, 13);
   // ---- cleanDead: the table order without the merged k-mers, the two special nodes in their places
   WG_SYNC();
+  // ---- the scheduling hint made exact (round 6).  S.hint says "a surviving node was met twice in one read / in both orientations: this k
+  //      will very likely be rejected for a cycle" and makes the workgroup build the next k at once; a third of the graphs built ahead that
+  //      way were never asked for (3032 built, 2037 taken per 32 768 windows: 0.4 workgroup-seconds).  The graph the window kernel's first
+  //      hasCycle will walk (reference src/Graph.cc:593-681: the DFS from the source in either direction) lies here, compressed, in LDS:
+  //      lane 0 walks it when the hint is set and takes the hint back when there is no cycle.  Scheduling only -- a graph that is then
+  //      missing (a cycle that only appears after removeTips, a near-repeat in a path) is built by the service on request, as for any
+  //      window without a hint; results never depend on what was built ahead.
+  WG_LANE0 {
+    if (S.hint) {
+      LC_LDS uint8_t *col = INFO;                                                 // (INFO is done with) 0 special / absorbed, 1 unvisited, 2 on the stack, 3 done
+      LC_LDS uint16_t *stk = (LC_LDS uint16_t *)LNK;                              // (the links are done with) frames of (position, next edge, direction)
+      static_assert(8 * (PB_CMAX + 2) >= 6 * (PB_CMAX + 3), "DFS stack in the link array");
+      for (uint32_t u = 0; u < Pn; ++u) col[u] = (FL[u] & (12u | 16u)) ? 0 : 1;
+      bool cyc = false;
+      for (int pass = 0; pass < 2 && !cyc; ++pass) {
+        uint32_t sp = 1; stk[0] = (uint16_t)SRC; stk[1] = 0; stk[2] = (uint16_t)(pass == 0 ? 'F' : 'R');
+        col[SRC] = 2;
+        while (sp && !cyc) {
+          LC_LDS uint16_t *fr = stk + 3 * (sp - 1);
+          const uint32_t node = fr[0]; const char dir = (char)fr[2];
+          const bool hd = HS[node + 1] != HS[node];
+          const uint32_t hxn = hd ? (uint32_t)HX[node] : 0u;
+          const uint32_t ne = hd ? (uint32_t)NEWE[13 * (size_t)hxn] : (uint32_t)NE[node];
+          bool descended = false;
+          uint32_t ei = fr[1];
+          while (ei < ne) {
+            const uint32_t e = hd ? NEWE[13 * (size_t)hxn + 1 + ei] : E[8 * node + ei]; ++ei;
+            if (!is_dir(BLC_DIR(e), dir)) continue;
+            const uint32_t other = BLC_TO(e);
+            if (FL[other] & 12u) continue;
+            const uint32_t oc = col[other];
+            if (oc == 2) { cyc = true; break; }
+            if (oc == 1) {
+              col[other] = 2; fr[1] = (uint16_t)ei;
+              LC_LDS uint16_t *nf = stk + 3 * sp; nf[0] = (uint16_t)other; nf[1] = 0; nf[2] = (uint16_t)dir_dest(BLC_DIR(e)); ++sp;
+              descended = true; break;
+            }
+          }
+          if (cyc) break;
+          if (!descended) { col[node] = 3; --sp; }
+        }
+      }
+      if (!cyc) S.hint = 0;
+    }
+  }
   WG_FOR(u, Pn + 1) { AL[u] = ((uint32_t)u < Pn && !(FL[u] & 16u)) ? 1u : 0u; }   // (AL is done with: keep flags by FINAL index)
   WG_SYNC();
   {
