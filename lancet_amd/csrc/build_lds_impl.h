@@ -2127,7 +2127,7 @@ DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
         const uint32_t a = bl_bcast(&S.scan_total);
         if (a == 0xFFFFFFFFu) break;
         LC_GLOBAL uint8_t *nx = pool + (size_t)a * PRE_STRIDE;
-        bl_build_window(P, B, C, S, xbase, nx, w, cur->K + 2, H0);
+        bl_build_window(P, B, C, S, xbase, nx, w, cur->K + 2, H0, true);
         WG_SYNC();
         WG_LANE0 { if (((LC_GLOBAL PreHdr *)nx)->status == PB_BUILT) { cur->next = a + 1u; dev_atomic_add(queue + 3, 1u); } }
         if (((LC_GLOBAL PreHdr *)nx)->status != PB_BUILT) break;

@@ -106,6 +106,9 @@ def test_random_draws_through_the_rerun_tier(seed, monkeypatch):
     batch = workload.make_scan_batch(256, seed=700 + seed + OFFSET, **wl)
     eng = engine.Engine(p, device=0)
     variants, stats = eng.process(batch)
+    if eng.rerun_count() == 0 and all(s["n_builds"] == 0 for s in stats):
+        eng.close()
+        pytest.skip("this draw builds no graph (every k of every window is turned down by the reference repeat test): nothing can overflow tier 1")
     assert eng.rerun_count() > 0
     ov, ostats = oracle_parallel(batch, p)
     key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
