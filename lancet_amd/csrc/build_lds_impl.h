@@ -975,10 +975,6 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
   (void)kmask; (void)NW;
   const int R = nr + 1;
   BLP(S, 3);
-#if defined(LANCET_PROF_SCAN) && !defined(LANCET_WAVE_EMU)      /* the scan's shift loop in slot 13, lane 0's own walk in 9, the wait for the other waves in 11 */
-  if (threadIdx.x == 0 && !rep) { const unsigned long long a = lc_scan_t[1] - lc_scan_t[0], b = lc_scan_t[2] - lc_scan_t[1], c3 = lc_scan_t[3] - lc_scan_t[2];
-    S.ph_acc[2] -= a + b + c3; S.ph_acc[13] += a; S.ph_acc[9] += b; S.ph_acc[11] += c3; }
-#endif
   if (C->debug_stop == 103u) { WG_LANE0 { H->why = 99; } return; }
   // ---- occurrence index space (read r owns its k-mers p = 0..tlen-K; a read of exactly K bases has none, Graph.cc:142-143)
   WG_LANE0 { S.totalreadbp = 0; S.n_kmers = 0; }

@@ -539,20 +539,16 @@ DEV void repeat_scan_min_t(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL 
 // position, no gaps to skip in ctz / clz -- instead of 32 (the 2-bit form this replaces) or 16, and a long run is sized without loops:
 // the mm + 1 mismatches on either side of it are the top / bottom bits of the 64 positions left / right of the run, cut out of the mask
 // words once (the walk back / forward over the words is kept for the run whose neighbourhood holds fewer: a match run of 60).
-// MM: max_mismatch at compile time (0..3: the lists of mismatches stay in registers), or -1: any mm <= 7.
-// The staging pass raises *bad2 when it meets a code above 3 (string taken from bytes); the caller then runs the 4-bit form.
+// MM: max_mismatch at compile time (0..2: the filter walk described inside, the lists of mismatches in registers), or -1: any mm <= 7, the
+// walk over match runs of rmin positions (what repeat_scan_min_t does 16 positions per word) on the planes.
+// The staging pass raises *bad2 when it meets a code above 3 (string taken from bytes); the caller then runs the 4-bit form
+// (repeat_scan_min_t<4>; its B == 2 branches are no longer instantiated).
 DEV uint32_t rs_even16(uint32_t v) {                               // the 16 even bits of v, packed
   v &= 0x55555555u; v = (v | (v >> 1)) & 0x33333333u; v = (v | (v >> 2)) & 0x0F0F0F0Fu; v = (v | (v >> 4)) & 0x00FF00FFu; v = (v | (v >> 8)) & 0x0000FFFFu;
   return v;
 }
 DEV int rs_ctz64(unsigned long long x) { return __builtin_ctzll(x); }
 DEV int rs_top64(unsigned long long x) { return 63 - __builtin_clzll(x); }
-#if defined(LANCET_PROF_SCAN) && !defined(LANCET_WAVE_EMU)      /* profiling builds only: when the staging pass and the shift loop of the last scan ended (lane 0) */
-static __shared__ unsigned long long lc_scan_t[4];
-#define RS_PROF(i) do { if (threadIdx.x == 0) lc_scan_t[i] = wall_clock64(); } while (0)
-#else
-#define RS_PROF(i) ((void)0)
-#endif
 template <int MM>
 DEV void repeat_scan_planes(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL const uint8_t *s, int len, int mm_, int rmin, int lf,
                             volatile LC_LDS int *outE, volatile LC_LDS int *outM, const LC_LDS uint32_t *packed2, volatile LC_LDS int *bad2,
@@ -561,7 +557,6 @@ DEV void repeat_scan_planes(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL
   const int nwords = len / 64 + 3;
   const bool al4 = (((size_t)s) & 3u) == 0;
   volatile LC_LDS unsigned long long *pl0 = rsbuf, *pl1 = rsbuf + nwords;
-  RS_PROF(0);
   WG_FOR(w, nwords) {
     unsigned long long v0 = 0, v1 = 0;
     if (packed2) {
@@ -588,7 +583,6 @@ DEV void repeat_scan_planes(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL
   }
   WG_SYNC();
   if (!packed2 && wg_bcast(bad2)) return;                           // a code above 3: the caller runs the 4-bit form
-  RS_PROF(1);
   const LC_LDS unsigned long long *P0 = (const LC_LDS unsigned long long *)pl0, *P1 = (const LC_LDS unsigned long long *)pl1;
   const int nsh = len > 1 ? len - 1 : 0;
   WG_FOR(it, nsh) {
@@ -785,9 +779,7 @@ DEV void repeat_scan_planes(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL
     if (bestE > 0) dev_atomic_max((LC_LDS uint32_t *)outE, (uint32_t)bestE);
     if (bestM > 0) dev_atomic_max((LC_LDS uint32_t *)outM, (uint32_t)bestM);
   }
-  RS_PROF(2);
   WG_SYNC();
-  RS_PROF(3);
 }
 // `bits2`: LDS word the 2-bit form may use as its "met an N" flag; null: 4-bit form at once (a string known to hold N)
 DEVNI void repeat_scan_min(volatile LC_LDS unsigned long long *rsbuf, LC_GLOBAL const uint8_t *s, int len, int mm, int lminE, int lminM,
