@@ -422,10 +422,10 @@ DEV void bl_chunk_bases(const LC_LDS uint32_t *bases, int c, unsigned long long 
 #define BLC_DIR(e) (((uint32_t)(e) >> 10) & 3u)
 #define BLC_MAKE(to, dir) ((uint16_t)((to) | ((dir) << 10)))
 DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const EngineCaps *C, BL_S &S, BlScratch &X, LC_GLOBAL uint8_t *area, const int K_,
-                             const uint32_t N_, const uint32_t nsurv_, const uint32_t ncand_, const int reflen_, const uint32_t ht_bc_) {
+                             const uint32_t N_, const uint32_t nsurv_, const uint32_t ncand_, const int reflen_, const uint32_t ht_bc_, const uint32_t refmask_) {
   P = lc_sgpr(P); C = lc_sgpr(C); area = lc_sgpr(area);                        // (uniform arguments: scalar registers, wave.h lc_sgpr)
   const uint32_t N = lc_sgpr(N_), nsurv = lc_sgpr(nsurv_), ncand = lc_sgpr(ncand_), ht_bc = lc_sgpr(ht_bc_); const int reflen = lc_sgpr(reflen_);
-  const int K = lc_sgpr(K_);
+  const int K = lc_sgpr(K_); const uint32_t refmask = lc_sgpr(refmask_);
   LC_GLOBAL const PreLayout &PL = C->pl;
   LC_GLOBAL PreCmp *CH = (LC_GLOBAL PreCmp *)(area + PRE_OFF_CHDR);
   LC_GLOBAL const uint32_t *occ_ref = (LC_GLOBAL const uint32_t *)(area + PRE_OFF_OCCREF);
@@ -462,7 +462,10 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
   static_assert(13376 >= (PB_CMAX + 2) * 16 && 14272 - 13376 >= PB_CMAX + 2 && 16896 - 15168 >= 2 * PB_CMAX && 23616 - 16896 >= 8 * (PB_CMAX + 2) &&
                 36992 - 23616 >= 16 * (PB_CMAX + 2) && 40384 - 36992 >= 4 * (PB_CMAX + 3) && 45504 - 43776 >= 2 * (PB_CMAX + 2) && 48128 - 46400 >= 2 * (PB_CMAX + 2) &&
                 52736 - 48640 >= 16 * PB_CHEADS && 59392 - 52736 >= 26 * PB_CHEADS && 59392 + 2 * 4096 <= 70304, "compress arena");
-  WG_LANE0 { CH->done = 0; S.why = 0; S.flagged = 0; S.g0 = 0x7FFFFFFFu; S.g1 = 0; S.ndup = 0; }
+  // Round 6: a graph of several components comes here too -- for its component 1 (the component of the table's first node: with a second,
+  // small component beside the one that holds the window that is the large one 99 times in 100).  The window kernel works the components
+  // off in turn, component 1 first; the others stay as they are (FL bit 32: not in component 1 -- no anchor, no mergeable link).
+  WG_LANE0 { CH->done = 0; S.why = 0; S.flagged = 0; S.g0 = 0x7FFFFFFFu; S.g1 = 0; S.ndup = 0; S.wsum[0] = 0; S.wsum[1] = 0; }      // (wsum: the scans' partial sums, idle until the first scan below)
   BLPA(S, 1);
   WG_FOR(n, N) { NPOS[n] = (uint16_t)0xFFFFu; }
   WG_SYNC();
@@ -479,10 +482,13 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
       ne = G.necnt; fl = G.flags & 3u;
       if (ne > 8u) { S.why = 1; ne = 8; }
       for (uint32_t e = 0; e < ne; ++e) E[8 * (uint32_t)u + e] = BLC_MAKE((uint32_t)SI2POS[X.s_edges[9 * (size_t)si + e]], ED_DIR(G.edges[e]));
-      dev_atomic_add((LC_LDS uint32_t *)&S.ndup, ne);                         // (trace: edges before markRefEnds)
+      dev_atomic_add((LC_LDS uint32_t *)&S.wsum[0], ne);                      // (trace: edges before markRefEnds, all survivors ...)
+      if (G.comp == 1) { dev_atomic_add((LC_LDS uint32_t *)&S.ndup, ne); dev_atomic_add((LC_LDS uint32_t *)&S.wsum[1], 1u); }      // (... component 1's, its survivors)
+      else fl |= 32u;
     } else fl = (uint32_t)u == SRC ? 4u : 8u;
     NE[u] = (uint8_t)ne; FL[u] = (uint8_t)fl;
   }
+  WG_SYNC();                                                                // (the scans read FL bit 32 of other lanes' positions)
   BLPA(S, 2);
   // ---- markRefEnds' two scans (kernels.h mark_ref_scan): first / last reference offset whose node survives with getTotCov() >= COV_THRESHOLD
   const int nrefk = reflen - K > 0 ? reflen - K + 1 : 0;
@@ -492,10 +498,10 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     const uint32_t u = NPOS[e & ON_ID];
     const unsigned long long c4 = TCC[u];
     const uint32_t tot = (uint32_t)(c4 & 0xFFFFu) + (uint32_t)((c4 >> 16) & 0xFFFFu) + (uint32_t)((c4 >> 32) & 0xFFFFu) + (uint32_t)(c4 >> 48);
-    if ((float)tot >= (float)P->cov_threshold) { dev_atomic_min((LC_LDS uint32_t *)&S.g0, (uint32_t)off); dev_atomic_max((LC_LDS uint32_t *)&S.g1, (uint32_t)off + 1u); }
+    if ((float)tot >= (float)P->cov_threshold && !(FL[u] & 32u)) { dev_atomic_min((LC_LDS uint32_t *)&S.g0, (uint32_t)off); dev_atomic_max((LC_LDS uint32_t *)&S.g1, (uint32_t)off + 1u); }      // (kernels.h mark_ref_scan: ... and is in the component)
   }
   WG_SYNC();
-  const uint32_t why_a = S.why, g0_a = S.g0, g1_a = S.g1, edges0 = S.ndup;     // (one pair of barriers for the four words; S.ndup serves as a flag further down)
+  const uint32_t why_a = S.why, g0_a = S.g0, g1_a = S.g1, edges0 = S.ndup, edges_all = S.wsum[0], n_c1 = S.wsum[1];     // (one pair of barriers for the six words; S.ndup serves as a flag further down)
   WG_SYNC();
   if (why_a || g0_a == 0x7FFFFFFFu) return;
   const int so = (int)g0_a, ko = (int)g1_a - 1;
@@ -580,7 +586,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
   auto tandem = [&](uint32_t u) -> bool { const int cnt = (int)NE[u]; for (int i = 0; i < cnt; ++i) if (BLC_TO(E[8 * u + i]) == u) return true; return false; };
   WG_FOR(u, Pn) {
     uint32_t l0 = 0, l1 = 0;
-    if (!(FL[u] & 12u) && !tandem((uint32_t)u)) {
+    if (!(FL[u] & (12u | 32u)) && !tandem((uint32_t)u)) {
       for (int sd = 0; sd < 2; ++sd) {
         const int uid = buddy((uint32_t)u, sd == 0 ? 'F' : 'R');
         if (uid < 0) continue;
@@ -872,7 +878,7 @@ DEVNI void bl_compress_first(LC_GLOBAL const lancet_params *P, LC_GLOBAL const E
     WG_FOR(u, Pn) { if (AL[u]) clive[keep[final_index((uint32_t)u)]] = (uint32_t)u < nsurv ? (uint32_t)pos2si[u] : (0x80000000u | ((uint32_t)u - nsurv)); }
   }
   WG_LANE0 {
-    CH->m_live = Pn - nabs; CH->dead = nabs; CH->seqn = need; CH->src_off = so; CH->snk_off = ko; CH->edges0 = edges0; CH->cov_heads = nheads;
+    CH->m_live = Pn - nabs; CH->dead = nabs; CH->seqn = need; CH->src_off = so; CH->snk_off = ko; CH->edges0 = edges0; CH->cov_heads = nheads; CH->edges_all = edges_all; CH->n_c1 = n_c1; CH->refmask = refmask; CH->pad1 = 0;
     CH->spec_hash[0] = hsrc; CH->spec_hash[1] = hsnk;
     CH->done = 1;
   }
@@ -2049,9 +2055,9 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     LC_LDS uint32_t *num = numP;                                             // (small tables: over nposP -- positions are no longer looked up by node)
     WG_FOR(u, nsurv + 1) { num[u] = (u < (int)nsurv && parent[u] == (uint32_t)u) ? 1u : 0u; }
     bl_scan32(num, (int)nsurv + 1, S);
-    WG_LANE0 { S.nbw = S.scan_total; S.ngw = 0; }                            // (nbw / ngw are free by now: components, components on the reference)
+    WG_LANE0 { S.nbw = S.scan_total; S.ngw = 0; S.flagged = 0; }             // (nbw / ngw are free by now: components, components on the reference; flagged: which of the first 32 those are)
     WG_SYNC();
-    WG_FOR(u, nsurv) { if (parent[u] == (uint32_t)u && (touch[u] & 2u)) dev_atomic_add((LC_LDS uint32_t *)&S.ngw, 1u); }
+    WG_FOR(u, nsurv) { if (parent[u] == (uint32_t)u && (touch[u] & 2u)) { dev_atomic_add((LC_LDS uint32_t *)&S.ngw, 1u); if (num[u] < 32u) dev_atomic_or((LC_LDS uint32_t *)&S.flagged, 1u << num[u]); } }
     LC_GLOBAL NodeGr *pgr2 = (LC_GLOBAL NodeGr *)(area + PRE_OFF_PGR);
     WG_FOR(u, nsurv) { pgr2[pos2si[u]].comp = (int)(num[parent[u]] + 1u); }   // numbered by the position of the component's first node
     WG_LANE0 { H->have_order = 1; H->ht_bc = S.g0; H->ht_next_resize = S.g1; H->numcomp = S.nbw; H->refcomp = S.ngw; }
@@ -2060,11 +2066,13 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     // ---- the window's first graph with a single component: markRefEnds and the first compress here too (bl_compress_first)
     {
       WG_SYNC();
-      const uint32_t hbc = lc_sgpr((uint32_t)S.g0), hnr = lc_sgpr((uint32_t)S.g1), ncomp = lc_sgpr((uint32_t)S.nbw);
+      const uint32_t hbc = lc_sgpr((uint32_t)S.g0), hnr = lc_sgpr((uint32_t)S.g1), ncomp = lc_sgpr((uint32_t)S.nbw), refmask = lc_sgpr((uint32_t)S.flagged);
       WG_SYNC();
       // (--linked-reads: a node's counts are barcode counts the window kernel has yet to replay -- no compress here)
-      if ((!rep || cmp_later) && ncomp == 1u && nsurv <= PB_CMAX && nsurv + 2u <= hnr && K <= 31 && !wide_tab && C->debug_stop != 140u && !P->lr_mode)
-        bl_compress_first(P, C, S, X, area, K, N, nsurv, ncand, reflen, hbc);
+      // (round 6: several components too -- for component 1; only for a window's first graph: load_prebuilt's fix-up after an earlier k's trim
+      //  knows one component)
+      if ((!rep || cmp_later) && (ncomp == 1u || (!rep && ncomp <= 32u)) && nsurv <= PB_CMAX && nsurv + 2u <= hnr && K <= 31 && !wide_tab && C->debug_stop != 140u && !P->lr_mode)
+        bl_compress_first(P, C, S, X, area, K, N, nsurv, ncand, reflen, hbc, refmask);
     }
   }
   BL_TAIL_PRIO_SET(0);

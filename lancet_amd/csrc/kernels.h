@@ -88,7 +88,8 @@ struct WinShared {
   int cmp_ok;                                    // compress_prepare: the component qualifies for compress_fast
   uint32_t cmp_nh;                               // compress_rank: heads found
   int cmp_done;                                  // the graph came with markRefEnds and the first compress done (build_lds_impl.h bl_compress_first)
-  uint32_t cmp_dead, cmp_edges0, cmp_nsurv;      // ... its cleanDead count, the survivors' edge total before markRefEnds (trace), the survivors
+  uint32_t cmp_dead, cmp_edges0, cmp_nsurv;      // ... its cleanDead count, component 1's edge total before markRefEnds (trace), the survivors
+  uint32_t cmp_edges_all, cmp_n1, cmp_refmask;   // ... all survivors' edge total, the survivors in component 1, which components hold a reference k-mer (round 6: graphs of several components)
   int seq_lazy;                                  // graph from the LDS build kernel: the k-mer nodes' descriptors are not written yet (seq_materialize)
   unsigned long long lz_area;                    // ... its hand-off area
   unsigned long long lz_skey; uint32_t lz_kw;    // ... the candidate keys there, words per key
@@ -5553,7 +5554,7 @@ DEVNI bool load_prebuilt(Ctx &c, int k) {
       const int so = CH->src_off, ko = CH->snk_off;
       S.M = mlive; S.ht_elt = mlive; S.nspecial = 2; S.source = ncap; S.sink = ncap + 1u;
       S.seq_t5 = so; S.seq_len = ko - so + K; S.trim5 = so & 0xFFFF; S.trim3 = (S.reflen - ko - K) & 0xFFFF;
-      S.seq_top = ncand * (uint32_t)K + seqn; S.cmp_dead = CH->dead; S.cmp_edges0 = CH->edges0; S.cmp_nsurv = nsurv;
+      S.seq_top = ncand * (uint32_t)K + seqn; S.cmp_dead = CH->dead; S.cmp_edges0 = CH->edges0; S.cmp_nsurv = nsurv; S.cmp_edges_all = CH->edges_all; S.cmp_n1 = CH->n_c1; S.cmp_refmask = CH->refmask;
     }
     // what the descriptors of merged k-mers still point at: the k-mer's counts and its quality-count row (first and last 16 bytes of a record)
     WG_FOR(si, nsurv) {
@@ -5855,9 +5856,10 @@ DEV void process_window(Ctx &c, int w, int rq = -1) {
       WG_LANE0 {
         if (LC_CTX(c).C->evt_cap) {
           evt(c, EV_CLEANDEAD, S.N - S.cmp_nsurv);
-          evt(c, EV_STATS, 0, S.cmp_nsurv, S.cmp_edges0, S.cmp_nsurv * (uint32_t)S.K);
+          evt(c, EV_STATS, 0, S.cmp_nsurv, S.cmp_edges_all, S.cmp_nsurv * (uint32_t)S.K);
           evt(c, EV_CC, S.cmp_nsurv);
-          if (S.refcomp) evt(c, EV_CCID, 1u);
+          if (S.numcomp == 1) { if (S.refcomp) evt(c, EV_CCID, 1u); }                     // (refcomp: after an earlier k's trim it is load_prebuilt's, not the mask's)
+          else for (int q = 1; q <= S.numcomp && q <= 32; ++q) if ((S.cmp_refmask >> (q - 1)) & 1u) evt(c, EV_CCID, (uint32_t)q);
           evt(c, EV_CCEND, (uint32_t)S.numcomp, (uint32_t)S.refcomp);
         }
       }
@@ -5887,10 +5889,10 @@ DEV void process_window(Ctx &c, int w, int rq = -1) {
     STOP_SET(c, 8);
     if (wg_bcast(&S.overflow)) break;
     for (int comp = 1; comp <= numcomp; ++comp) {
-      if (cdone) {
+      if (cdone && comp == 1) {                                       // (the build kernel's markRefEnds + compress are component 1's; the others go the whole way here)
         WG_LANE0 {
           if (LC_CTX(c).C->evt_cap) {
-            evt(c, EV_STATS, 1u, S.cmp_nsurv, S.cmp_edges0, S.cmp_nsurv * (uint32_t)S.K);
+            evt(c, EV_STATS, 1u, S.cmp_nsurv, S.cmp_edges0, S.cmp_n1 * (uint32_t)S.K);
             evt(c, EV_TRIM, (uint32_t)S.seq_t5, (uint32_t)(S.reflen - (S.seq_t5 + S.seq_len)), (uint32_t)S.seq_len);
           }
           S.tmp1 = (int)S.cmp_dead; S.tmp2 = 0;
@@ -5906,7 +5908,7 @@ DEV void process_window(Ctx &c, int w, int rq = -1) {
       PHASE(c, 15);
       compress_prepare(c, comp);
       }
-      const bool ranked = cdone || (wg_bcast(&S.cmp_ok) && compress_rank(c, comp));     // (whole wave; false: a ring or an irregular link, nothing touched)
+      const bool ranked = (cdone && comp == 1) || (wg_bcast(&S.cmp_ok) && compress_rank(c, comp));     // (whole wave; false: a ring or an irregular link, nothing touched)
       if (!ranked) seq_materialize_all(c);
       if (!ranked) WG_LANE0 {
         // The reference runs hasCycle on the k-mer graph and compresses only if there is none.  Unitig compaction merges

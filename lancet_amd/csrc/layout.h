@@ -262,7 +262,10 @@ struct PreCmp {
   uint32_t edges0;            /* trace only: edges of the survivors before markRefEnds                                 */
   uint32_t cov_heads;         /* unitig heads whose coverage (the float recurrence over the merges) is left to the window kernel: entries of CHL */
   unsigned long long spec_hash[2];   /* std::hash of "source1" / "sink1"                                               */
-  uint32_t pad[4];
+  uint32_t edges_all;         /* trace only: edges of ALL survivors before markRefEnds (edges0: those of component 1)         */
+  uint32_t n_c1;              /* survivors in component 1 -- the component markRefEnds and the compress were done for          */
+  uint32_t refmask;           /* bit q - 1: component q holds a reference k-mer (graphs of up to 32 components come along)     */
+  uint32_t pad1;
 };
 
 /* One slot of work space.  All pointers are device pointers into one big allocation. */
