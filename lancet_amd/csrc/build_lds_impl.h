@@ -2099,6 +2099,9 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
 // out -- to either kernel -- is finished (`helpers`: queue[7], released by whoever finished the window).
 // `biglist`: the small configuration appends the windows it turns away for their size; the large one (from_list) works that list
 // off instead of the batch.
+#ifndef BL_END_G
+#define BL_END_G 512
+#endif
 DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *B, LC_GLOBAL const EngineCaps *C, LC_GLOBAL uint8_t *pre,
                            LC_GLOBAL uint8_t *scratch, LC_GLOBAL uint32_t *queue, BL_S &S, int slot, LC_GLOBAL unsigned long long *phase = nullptr,
                            LC_GLOBAL uint8_t *pool = nullptr, uint32_t pool_cap = 0, int depth = 0, LC_GLOBAL uint32_t *biglist = nullptr, bool from_list = false,
@@ -2122,7 +2125,11 @@ DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     bl_build_window(P, B, C, S, xbase, pre + (size_t)w * PRE_STRIDE, w, P->min_k, nullptr);
     {
       LC_GLOBAL PreHdr *H0 = (LC_GLOBAL PreHdr *)(pre + (size_t)w * PRE_STRIDE), *cur = H0;
-      for (int lvl = 0; pool && lvl < depth; ++lvl) {
+      // (the end of the queue: a chain of graphs built ahead for one of the last windows taken is what the whole launch then waits for -- every other
+      //  workgroup has left.  The last BL_END_G windows of the batch get no graph ahead, the BL_END_G before them one, ...: what they lack the build
+      //  service builds at the START of the window kernel's launch, where it has nothing else to do -- these windows are taken first there, PreHdr::heavy)
+      const int dmax = from_list ? depth : (B->n_windows - 1 - w) / BL_END_G;
+      for (int lvl = 0; pool && lvl < depth && lvl < dmax; ++lvl) {
         WG_SYNC();
         WG_LANE0 {
           S.scan_total = 0xFFFFFFFFu;

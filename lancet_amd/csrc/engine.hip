@@ -87,7 +87,9 @@ __device__ uint32_t order_class(const uint8_t *area, uint32_t chdr) {
   if (H->status != PB_BUILT) return (H->why == BLW_NOREADS || H->why == BLW_K) ? 0u : 31u;
   if (H->heavy) return 26u;
   const PreCmp *Cm = (const PreCmp *)(area + chdr);
-  if (Cm->done) { const uint32_t m = Cm->m_live; return m <= 5u ? 3u : std::min(23u, (3u * m) / 2u - 3u); }
+  if (Cm->done) {
+    const uint32_t m = Cm->m_live;
+    return m <= 5u ? 3u : std::min(23u, (3u * m) / 2u - 3u); }
   const uint32_t ns = H->nsurv;
   return ns <= 520u ? 10u : std::min(23u, (ns - 400u) / 12u);
 }
