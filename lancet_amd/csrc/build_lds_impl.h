@@ -2028,6 +2028,7 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     }
     WG_LANE0 { S.flagged = 0; S.ndup = 0; }                                  // (the rounds' two change flags, cleared in front of the barrier every wave passes before its first hooking pass)
     WG_SYNC();
+#ifdef BL_CC_ROUNDS
     // (a round = one hooking pass + three pointer-jumping passes, one barrier each, then ONE look at the change flag: testing
     //  for convergence after every pass cost two more barriers of the 512-lane workgroup per pass, and these passes do little
     //  else than wait at barriers.  A round that changed nothing leaves every parent a root with no smaller neighbour label.
@@ -2050,6 +2051,38 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
       }
       if (!*(volatile LC_LDS uint32_t *)flag) break;
     }
+#else
+    // (round 6: a lock-free union-find over the positions instead of rounds of hooking and pointer jumping -- 7 to 10 rounds of four passes
+    //  and four barriers each on a graph that is mostly long chains in hash order.  A link always goes from the larger root to the smaller
+    //  (compare-and-swap on a node that is still its own parent), finds halve the paths they walk (atomic min: a parent only ever moves towards
+    //  the root), so the forest stays acyclic under any interleaving and the one root a component is left with is its smallest position -- the same
+    //  labels the rounds converged to.  Two passes, two barriers.)
+    auto uf_find = [&](uint32_t x) -> uint32_t {
+      while (true) {
+        const uint32_t p = ld2(&parent[x]);
+        if (p == x) return x;
+        const uint32_t gp = ld2(&parent[p]);
+        if (gp == p) return p;
+        dev_atomic_min(&parent[x], gp);
+        x = gp;
+      }
+    };
+    WG_FOR(u, nsurv) {
+      for (int e = 0; e < 8; ++e) {
+        uint32_t a = (uint32_t)u, b = adj[8 * (uint32_t)u + (uint32_t)e];
+        if (b == a) continue;
+        while (true) {
+          a = uf_find(a); b = uf_find(b);
+          if (a == b) break;
+          const uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
+          if (dev_atomic_cas32(&parent[hi], hi, lo) == hi) break;
+        }
+      }
+    }
+    WG_SYNC();
+    WG_FOR(u, nsurv) { const uint32_t r = uf_find((uint32_t)u); dev_atomic_min(&parent[u], r); }
+    WG_SYNC();
+#endif
     WG_FOR(u, nsurv) { if (touch[u] & 1u) dev_atomic_or(&touch[parent[u]], 2u); }
     WG_SYNC();
     LC_LDS uint32_t *num = numP;                                             // (small tables: over nposP -- positions are no longer looked up by node)
