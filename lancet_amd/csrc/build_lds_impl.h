@@ -2138,9 +2138,10 @@ DEVNI void bl_build_window(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
 DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const DevBatch *B, LC_GLOBAL const EngineCaps *C, LC_GLOBAL uint8_t *pre,
                            LC_GLOBAL uint8_t *scratch, LC_GLOBAL uint32_t *queue, BL_S &S, int slot, LC_GLOBAL unsigned long long *phase = nullptr,
                            LC_GLOBAL uint8_t *pool = nullptr, uint32_t pool_cap = 0, int depth = 0, LC_GLOBAL uint32_t *biglist = nullptr, bool from_list = false,
-                           bool wait_all = false) {
+                           bool wait_all = false, int cycle = 0) {
   LC_GLOBAL const PreLayout &PL = C->pl;
   LC_GLOBAL uint8_t *xbase = scratch + (size_t)slot * SCRATCH_BYTES;
+  int done_here = 0;
   if (from_list && queue[4] == 0u) return;                       // (nothing was turned away for its size: the usual case at 30x)
   while (true) {
     WG_LANE0 { S.w = (int)dev_atomic_add(queue + (from_list ? 5 : 0), 1u); }
@@ -2192,6 +2193,7 @@ DEV void build_kernel_body(LC_GLOBAL const lancet_params *P, LC_GLOBAL const Dev
     //  to the window kernel; the build kernel's own stores are written back when it ends, and an agent-scope release per window is an L2
     //  write-back per window)
     if (!from_list) { WG_LANE0 { if (wait_all) dev_atomic_add(queue + 7, 1u); else add_rel(queue + 7, 1u); } }
+    if (cycle > 0 && ++done_here >= cycle) break;                  // (LANCET_BUILD_CYCLE: the grid holds a workgroup for every `cycle` windows)
   }
 }
 

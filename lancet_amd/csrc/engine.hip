@@ -36,10 +36,35 @@ __global__ void __launch_bounds__(LANCET_WG * 2) __attribute__((amdgpu_waves_per
 
 // The first graph of every window in LDS (build_lds.h): 256 lanes per window, 2 workgroups per CU (80 KB of LDS each)
 __global__ void __launch_bounds__(bl_small::WG) __attribute__((amdgpu_waves_per_eu(BL_SMALL_EU, BL_SMALL_EU))) build_kernel(const lancet_params *P, const DevBatch *B, const EngineCaps *C, uint8_t *pre, uint8_t *scratch, uint32_t *queue,
-                                                      unsigned long long *phase, uint8_t *pool, uint32_t pool_cap, int depth, uint32_t *biglist, int wait_all) {
+                                                      unsigned long long *phase, uint8_t *pool, uint32_t pool_cap, int depth, uint32_t *biglist, int wait_all, int cycle, uint32_t *slotmap, int nslots, int first_gen) {
+  int slot = (int)blockIdx.x;
+  bl_small::BL_S &S = *(bl_small::BL_S *)&bl_small::bl_shared;
+  const int slots_on = cycle;                                      // (scratch slots by the bitmap for every workgroup of such a launch)
+  if ((int)blockIdx.x >= first_gen) cycle = 0;                     // (the workgroups behind the first generation stay)
+  if (slots_on > 0) {            // (LANCET_BUILD_CYCLE: a workgroup leaves after `cycle` windows and the grid is that much larger; scratch slots by a bitmap)
+    if (threadIdx.x == 0) {
+      int got = -1;
+      while (got < 0) {
+        for (int i = 0; i < (nslots + 31) / 32 && got < 0; ++i) {
+          uint32_t m = __hip_atomic_load(&slotmap[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          while (~m) {
+            const int b = __builtin_ctz(~m);
+            if (i * 32 + b >= nslots) break;
+            const uint32_t old = atomicOr(&slotmap[i], 1u << b);
+            if (!(old & (1u << b))) { got = i * 32 + b; break; }
+            m = old | (1u << b);
+          }
+        }
+        if (got < 0) __builtin_amdgcn_s_sleep(127);
+      }
+      S.w = got;
+    }
+    __syncthreads(); slot = S.w; __syncthreads();
+  }
   bl_small::build_kernel_body((LC_GLOBAL const lancet_params *)P, (LC_GLOBAL const DevBatch *)B, (LC_GLOBAL const EngineCaps *)C, (LC_GLOBAL uint8_t *)pre, (LC_GLOBAL uint8_t *)scratch,
-                    (LC_GLOBAL uint32_t *)queue, *(bl_small::BL_S *)&bl_small::bl_shared, (int)blockIdx.x, (LC_GLOBAL unsigned long long *)phase, (LC_GLOBAL uint8_t *)pool, pool_cap, depth,
-                    (LC_GLOBAL uint32_t *)biglist, false, wait_all != 0);
+                    (LC_GLOBAL uint32_t *)queue, S, slot, (LC_GLOBAL unsigned long long *)phase, (LC_GLOBAL uint8_t *)pool, pool_cap, depth,
+                    (LC_GLOBAL uint32_t *)biglist, false, wait_all != 0, cycle);
+  if (slots_on > 0) { __syncthreads(); if (threadIdx.x == 0) atomicAnd(&slotmap[slot >> 5], ~(1u << (slot & 31))); }
 }
 // The same for the windows the 512-lane configuration turned away for their size (60x/60x: ~360 reads, 58 k bases): 1024 lanes,
 // one workgroup per CU (~100 KB of LDS), off the list the first kernel left.
@@ -68,6 +93,22 @@ __global__ void __launch_bounds__(bl_large::WG) __attribute__((amdgpu_waves_per_
                             (LC_GLOBAL uint32_t *)queue, *(bl_large::BL_S *)&bl_large::bl_shared, (int)blockIdx.x, (LC_GLOBAL uint8_t *)pool, pool_cap, depth, (LC_GLOBAL SvcCtl *)sv, (LC_GLOBAL const uint32_t *)wqueue);
 }
 __global__ void svc_init_kernel(SvcCtl *sv, SvcCtl v) { *sv = v; }
+// Gate of lancet_engine_submit_after (LANCET_GATE): one wave, no LDS, at the head of this engine's stream.  It leaves when the OTHER engine's window
+// kernel has taken the last window off its list (`head` >= n) -- from then on that kernel's slots leave their CUs one after the other while a few dozen
+// windows that wait for the build service keep the launch alive for another ~2 ms: this engine's build kernel is dispatched onto the CUs as they empty.
+// It must not become launchable earlier: whatever of it is resident when the window kernel is dispatched takes that kernel's slots away for the whole
+// launch (LANCET_STAGGER, profiles/r6_stagger_rejected.txt).  No progress of the head for 2 ms (a profiler that serialises kernels, a launch that failed): leave.
+__global__ void gate_kernel(const uint32_t *head, uint32_t n) {
+  if (threadIdx.x != 0) return;
+  unsigned long long t_prog = wall_clock64(); uint32_t last = 0xFFFFFFFFu;
+  while (true) {
+    const uint32_t h = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (h >= n) break;
+    const unsigned long long now = wall_clock64();
+    if (h != last) { last = h; t_prog = now; } else if (now - t_prog > 200000ull) break;       // 2 ms at 100 MHz
+    __builtin_amdgcn_s_sleep(127);
+  }
+}
 __global__ void svc_done_kernel(SvcCtl *sv) { __hip_atomic_store(&sv->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Processing order of the window kernel: longest expected first.  A slot takes the next window of the list when it is through with
@@ -208,6 +249,10 @@ struct lancet_engine {
   hipEvent_t wait_ev = nullptr;     // lancet_engine_submit_after: the event this submit's kernels wait for (set around the call only)
   hipEvent_t ev_a_done = nullptr;   // recorded behind the build kernels (and the ordering kernels) of a submit: LANCET_STAGGER=1 lets the next engine's kernels start there
   bool stagger = false;
+  hipEvent_t gate_prev_done = nullptr;
+  bool gate = false; const uint32_t *gate_head = nullptr; uint32_t gate_n = 0;      // LANCET_GATE: gate_kernel above (set around a submit_after only)
+  int build_cycle = 3;            // windows a first-generation build workgroup takes before it leaves, in a launch behind the gate (LANCET_BUILD_CYCLE; 0: persistent as ever)
+  bool cycle_now = false;         // this submit's build kernel is such a launch
   int slots2_pred = 0;              // re-run tier of the windows started early: laid out by submit before it waits for `wait_ev`
   std::string err;
   // device buffers
@@ -356,6 +401,8 @@ int lancet_engine_create(const lancet_params *p, int device, lancet_engine **out
       hipEventCreate(&e->ev1) != hipSuccess || hipEventCreate(&e->evb0) != hipSuccess || hipEventCreate(&e->evb1) != hipSuccess ||
       hipEventCreate(&e->ev_done) != hipSuccess || hipEventCreate(&e->ev_a_done) != hipSuccess) { delete e; return LANCET_E_HIP; }
   e->stagger = getenv("LANCET_STAGGER") && atoi(getenv("LANCET_STAGGER")) != 0;
+  e->gate = !(getenv("LANCET_GATE") && atoi(getenv("LANCET_GATE")) == 0) && !e->stagger;       // (on unless LANCET_GATE=0)
+  if (const char *s = getenv("LANCET_BUILD_CYCLE")) e->build_cycle = std::max(0, atoi(s));
   if (getenv("LANCET_NO_PREBUILD")) e->prebuild = false;
   if (const char *s = getenv("LANCET_PREP")) e->host_prep = strcmp(s, "device") != 0;
   if (const char *s = getenv("LANCET_PREP_THREADS")) e->prep_threads = std::max(1, atoi(s));
@@ -758,7 +805,7 @@ static int lc_upload(lancet_engine *e, const lancet_window_batch *b, const lance
     tick("outputs");
     ENS(e->d_pre, (size_t)nw * e->caps.pl.stride);
     tick("hand-off areas", (size_t)nw * e->caps.pl.stride);
-    ENS(e->d_blscratch, (size_t)e->n_bslots * bl_small::SCRATCH_BYTES);
+    ENS(e->d_blscratch, (size_t)((e->build_cycle && e->gate) ? std::max(e->n_bslots, 2 * e->n_cus) : e->n_bslots) * bl_small::SCRATCH_BYTES);
     // Can any window be too big for the 512-lane configuration?  Trimming only shortens reads, so the untrimmed lengths bound the
     // LDS footprint (reads padded to 16 bases + the reference); when none can, the 1024-lane kernel is not launched at all.
     bool may_need_large = false;
@@ -859,10 +906,15 @@ static int lc_submit_body(lancet_engine *e) {
   }
   if (e->prebuild) {
     HIPCHK(e, hipEventRecord(e->evb0, e->stream));
-    hipLaunchKernelGGL(build_kernel, dim3(e->n_bslots), dim3(bl_small::WG), 0, e->stream, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
+    // (behind the gate the first workgroups of this launch land on CUs the other batch's window kernel is still leaving: wherever its slots left their 80 KB, for as long
+    //  as they stay -- so they stay for `build_cycle` windows only, and a second generation, dispatched as they leave, is the persistent one; profiles/r6h_gate.txt)
+    const int cyc = e->cycle_now ? e->build_cycle : 0;
+    const int bl_nslots = std::max(e->n_bslots, 2 * e->n_cus), bl_grid = cyc ? 2 * e->n_bslots : e->n_bslots;
+    hipLaunchKernelGGL(build_kernel, dim3(bl_grid), dim3(bl_small::WG), 0, e->stream, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
                        (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_blscratch.p, (uint32_t *)e->d_counters.p + 8,
                        (unsigned long long *)(e->phase_times ? e->d_blphase.p : nullptr), (uint8_t *)(e->pool_cap ? e->d_prepool.p : nullptr), e->pool_cap, e->ahead_depth,
-                       (uint32_t *)(e->n_bslots_large ? e->d_biglist.p : nullptr), (e->svc_running && e->svc_help && !e->svc_large) ? 1 : 0);
+                       (uint32_t *)(e->n_bslots_large ? e->d_biglist.p : nullptr), (e->svc_running && e->svc_help && !e->svc_large) ? 1 : 0,
+                       cyc, (uint32_t *)e->d_counters.p + 96, bl_nslots, e->n_bslots);
     HIPCHK(e, hipGetLastError());
     if (e->dbg) { HIPCHK(e, hipStreamSynchronize(e->stream)); DBG("build_kernel done"); }
     if (e->n_bslots_large) {
@@ -902,9 +954,13 @@ static int lc_submit_body(lancet_engine *e) {
 // by then; a caller that submits from several threads orders them itself (lancet_main.cc submits on one thread and waits on others).
 int lancet_engine_submit_after(lancet_engine *e, lancet_engine *prev) {
   if (!e) return LANCET_E_ARG;
-  e->wait_ev = (prev && prev != e && prev->device == e->device) ? (e->stagger ? prev->ev_a_done : prev->ev_done) : nullptr;      // (an event never recorded, or long since reached, does not hold anything up)
+  const bool gate_ok = e->gate && prev && !prev->params.lr_mode && !e->params.lr_mode;
+  e->wait_ev = (prev && prev != e && prev->device == e->device) ? ((e->stagger || gate_ok) ? prev->ev_a_done : prev->ev_done) : nullptr;      // (an event never recorded, or long since reached, does not hold anything up)
+  // (not with --linked-reads: there the window kernel's launch is three times the build kernel's and ends on many busy slots, not on a few waiting windows --
+  //  the next batch's build workgroups trickle in between them for milliseconds: config 5 232 k instead of 243 k windows/s, profiles/r6h_gate.txt)
+  if (e->wait_ev && e->gate && prev->submitted && prev->n_windows > 0 && !prev->params.lr_mode && !e->params.lr_mode) { e->gate_head = (const uint32_t *)prev->d_counters.p + 2; e->gate_n = (uint32_t)std::max(1, prev->n_windows - prev->n_windows / 4); e->gate_prev_done = prev->ev_done; }
   const int rc = lancet_engine_submit(e);
-  e->wait_ev = nullptr;
+  e->wait_ev = nullptr; e->gate_head = nullptr; e->gate_prev_done = nullptr;
   return rc;
 }
 
@@ -921,6 +977,8 @@ int lancet_engine_submit(lancet_engine *e) {
   e->slots2_pred = 0;
   if (!e->pred.empty()) { e->slots2_pred = lc_prepare_rerun(e, e->pred, 4, true); if (e->slots2_pred < 0) return e->slots2_pred; }
   if (e->wait_ev) HIPCHK(e, hipStreamWaitEvent(e->stream, e->wait_ev, 0));
+  e->cycle_now = e->wait_ev && e->gate_head && e->build_cycle > 0;
+  if (e->wait_ev && e->gate_head) { hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, e->stream, e->gate_head, e->gate_n); HIPCHK(e, hipGetLastError()); }
   HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, LC_COUNTER_BYTES, e->stream));
   HIPCHK(e, hipMemsetAsync(e->d_stats.p, 0, sizeof(lancet_window_stats) * e->n_windows, e->stream));
   if (e->prebuild) HIPCHK(e, hipMemsetAsync(e->d_blphase.p, 0, 16 * sizeof(unsigned long long), e->stream));      // (before the service starts: its workgroups add to it too)
@@ -933,6 +991,7 @@ int lancet_engine_submit(lancet_engine *e) {
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipEventRecord(e->ev_svc, e->stream));
     HIPCHK(e, hipStreamWaitEvent(e->stream3, e->ev_svc, 0));
+    if (e->gate_prev_done) HIPCHK(e, hipStreamWaitEvent(e->stream3, e->gate_prev_done, 0));      // (the service's workgroups stay for two kernels: not into a CU half full of the other batch's slots)
     if (e->svc_large)
       hipLaunchKernelGGL(svc_kernel_large, dim3(e->n_svc_wgs), dim3(bl_large::WG), 0, e->stream3, (const lancet_params *)e->d_params.p, (const DevBatch *)e->d_batch.p,
                          (const EngineCaps *)e->d_caps.p, (uint8_t *)e->d_pre.p, (uint8_t *)e->d_svcscratch.p, (uint32_t *)e->d_counters.p + 8,
