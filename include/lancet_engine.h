@@ -207,7 +207,10 @@ int lancet_engine_submit(lancet_engine *e);
 int lancet_engine_wait(lancet_engine *e);
 /* submit for the second of two engines that take turns on one device: e's kernels start when `prev`'s kernels are through (a batch's
  * kernels are sized for the whole device; side by side with another batch's they only slow each other down), while the host side of
- * the two batches -- upload, launch, read-back -- overlaps the other's kernels.  prev == NULL: lancet_engine_submit. */
+ * the two batches -- upload, launch, read-back -- overlaps the other's kernels.  prev == NULL: lancet_engine_submit.
+ * "Through" is, unless LANCET_GATE=0 is in the environment of the process that made the engines (and never in lr_mode): prev's window
+ * kernel has taken the last quarter of its windows in hand -- e's build kernel is dispatched onto the CUs as that launch leaves them
+ * (profiles/r6h_gate.txt).  Results do not depend on it. */
 int lancet_engine_submit_after(lancet_engine *e, lancet_engine *prev);
 
 /* Results of the last run: variants ordered by (window, seq_in_window) so that the caller can replay
