@@ -372,6 +372,45 @@ def test_build_service_is_scheduling_only(monkeypatch):
         assert served[2][0] == extra, (served, extra)
 
 
+def test_two_engines_taking_turns_is_scheduling_only(monkeypatch):
+    """Two engines on one GPU, submitted in turn (lancet_engine_submit_after): the second batch's build kernel starts under the end of
+    the first batch's window kernel (engine.hip gate_kernel; its first generation of build workgroups leaves after a few windows, scratch
+    slots by a bitmap).  Six batches -- enough windows to fill every window slot, a small one, an empty one -- through the pair with the gate
+    on (default) and off: the records and statistics of one engine taking the batches one by one, which equal the oracle's on the first."""
+    from lancet_amd import workload
+    p = abi.default_params()
+    batches = [workload.make_scan_batch(n, 30, 30, seed=sd) for n, sd in ((6000, 31), (5000, 32), (300, 33), (6000, 34), (4500, 35))]
+    batches.insert(3, workload.sub_batch(batches[2], 0, 0))
+    key = lambda s: (s["status"], s["final_k"], s["n_builds"], s["n_variants"], s["n_kmers"], s["max_nodes"])
+    one = engine.Engine(p)
+    want = []
+    for b in batches:
+        v, st = one.process(b)
+        want.append((v, [key(s) for s in st]))
+    one.close()
+    ov, ost, _ = oracle.run(batches[2], p)
+    assert want[2] == (ov, [key(s) for s in ost])
+    for env in ({}, {"LANCET_GATE": "0"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        pair = [engine.Engine(p), engine.Engine(p)]
+        for rep in range(2):
+            got = [None] * len(batches)
+            pair[0].upload(batches[0]); pair[0].submit()
+            for i in range(1, len(batches) + 1):
+                cur, prev = pair[i & 1], pair[(i - 1) & 1]
+                if i < len(batches):
+                    cur.upload(batches[i]); cur.submit(after=prev)
+                prev.wait()
+                v, st = prev.results()
+                got[i - 1] = (v, [key(s) for s in st])
+            assert got == want, (env, rep, [a == b for a, b in zip(got, want)])
+        for e_ in pair:
+            e_.close()
+        for k_ in env:
+            monkeypatch.delenv(k_)
+
+
 def test_host_and_device_trim_and_pack_agree(monkeypatch):
     """Graph_t::trim + packing runs on host threads at upload (pinned staging, one DMA); LANCET_PREP=device keeps the device kernel
     (prep_kernel).  Same records either way, on reads with low-quality ends, N bases and junk reads (golden `filters`-like
